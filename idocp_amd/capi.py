@@ -1,0 +1,151 @@
+"""ctypes mirror of include/idocp_hip.h.
+
+This is the binding a Python caller of the drop-in library uses; the tests and
+bench.py go through it so that every GPU parity test exercises the C ABI.  It
+holds no arithmetic: structures, prototypes and thin argument marshalling only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_JOINTS, MAX_NV, MAX_NQ, MAX_CONTACTS = 16, 24, 25, 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libidocp_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("nu", C.c_int),
+        ("has_floating_base", C.c_int),
+        ("parent", C.c_int * MAX_JOINTS), ("jtype", C.c_int * MAX_JOINTS),
+        ("idx_q", C.c_int * MAX_JOINTS), ("idx_v", C.c_int * MAX_JOINTS),
+        ("axis", (C.c_double * 3) * MAX_JOINTS),
+        ("plc_R", (C.c_double * 9) * MAX_JOINTS), ("plc_p", (C.c_double * 3) * MAX_JOINTS),
+        ("mass", C.c_double * MAX_JOINTS), ("com", (C.c_double * 3) * MAX_JOINTS),
+        ("inertia", (C.c_double * 9) * MAX_JOINTS),
+        ("gravity", C.c_double * 3),
+        ("q_min", C.c_double * MAX_NV), ("q_max", C.c_double * MAX_NV),
+        ("v_max", C.c_double * MAX_NV), ("u_max", C.c_double * MAX_NV),
+        ("ncontacts", C.c_int),
+        ("contact_frame_id", C.c_int * MAX_CONTACTS), ("contact_joint", C.c_int * MAX_CONTACTS),
+        ("contact_R", (C.c_double * 9) * MAX_CONTACTS), ("contact_p", (C.c_double * 3) * MAX_CONTACTS),
+        ("total_mass", C.c_double),
+    ]
+
+
+class Cost(C.Structure):
+    _fields_ = [
+        ("q_ref", C.c_double * MAX_NQ), ("v_ref", C.c_double * MAX_NV), ("u_ref", C.c_double * MAX_NV),
+        ("q_weight", C.c_double * MAX_NV), ("v_weight", C.c_double * MAX_NV),
+        ("a_weight", C.c_double * MAX_NV), ("u_weight", C.c_double * MAX_NV),
+        ("qf_weight", C.c_double * MAX_NV), ("vf_weight", C.c_double * MAX_NV),
+    ]
+
+    def set(self, name, values):
+        arr = getattr(self, name)
+        values = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        for i, x in enumerate(values):
+            arr[i] = float(x)
+        return self
+
+
+class Constraints(C.Structure):
+    _fields_ = [
+        ("joint_position_limits", C.c_int), ("joint_velocity_limits", C.c_int),
+        ("joint_torque_limits", C.c_int),
+        ("barrier", C.c_double), ("fraction_to_boundary_rate", C.c_double),
+    ]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _proto(lib):
+    vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
+    P = C.POINTER
+    lib.idocp_model_from_urdf.argtypes = [cs, P(ci), ci, P(Model)]
+    lib.idocp_model_from_urdf.restype = ci
+    lib.idocp_model_frame_id.argtypes = [cs, cs]
+    lib.idocp_model_frame_id.restype = ci
+    lib.idocp_cost_init.argtypes = [P(Cost)]
+    lib.idocp_cost_init.restype = None
+    lib.idocp_constraints_init.argtypes = [P(Constraints)]
+    lib.idocp_constraints_init.restype = None
+    lib.idocp_last_error.restype = cs
+    lib.idocp_version.restype = cs
+    lib.idocp_unocp_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
+    lib.idocp_unocp_create.restype = ci
+    lib.idocp_unocp_destroy.argtypes = [vp]
+    lib.idocp_unocp_destroy.restype = None
+    for name, args in [
+        ("idocp_unocp_set_solution", [vp, cs, c_double_p]),
+        ("idocp_unocp_set_solution_batch", [vp, cs, c_double_p]),
+        ("idocp_unocp_init_constraints", [vp]),
+        ("idocp_unocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
+        ("idocp_unocp_update_solution_device", [vp, cd, vp, vp]),
+        ("idocp_unocp_synchronize", [vp]),
+        ("idocp_device_alloc", [P(vp), C.c_ulonglong]),
+        ("idocp_device_free", [vp]),
+        ("idocp_device_upload", [vp, vp, C.c_ulonglong]),
+        ("idocp_device_count", [P(ci)]),
+        ("idocp_unocp_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
+        ("idocp_unocp_kkt_error", [vp, c_double_p]),
+        ("idocp_unocp_get_solution", [vp, cs, ci, c_double_p]),
+        ("idocp_unocp_get_direction", [vp, cs, ci, c_double_p]),
+        ("idocp_unocp_get_step_sizes", [vp, c_double_p, c_double_p]),
+        ("idocp_unocp_get_riccati", [vp, ci, c_double_p, c_double_p, c_double_p, c_double_p]),
+        ("idocp_unocp_get_constraint_data", [vp, ci, c_double_p, c_double_p]),
+        ("idocp_unocp_dimc", [vp]),
+        ("idocp_unocp_launch_linearize", [vp, cd, vp, vp]),
+        ("idocp_unocp_launch_riccati", [vp, vp, vp]),
+        ("idocp_unocp_launch_expand", [vp]),
+        ("idocp_unocp_launch_integrate", [vp]),
+        ("idocp_rnea_derivatives", [P(Model), ci, c_double_p, c_double_p, c_double_p, c_double_p,
+                                    c_double_p, c_double_p, c_double_p, ci]),
+    ]:
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = ci
+    lib.idocp_unocp_stream.argtypes = [vp]
+    lib.idocp_unocp_stream.restype = vp
+
+
+def lib():
+    """Load libidocp_hip.so (the HIP extension).  Fails loudly when it is missing:
+    there is no CPU fallback for the product path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                "HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _proto(_lib)
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def last_error():
+    return lib().idocp_last_error().decode()
+
+
+def check(rc, what="idocp call"):
+    if rc != 0:
+        raise RuntimeError("%s failed with status %d: %s" % (what, rc, last_error()))
+
+
+def model_from_urdf(path, contact_frames=()):
+    m = Model()
+    cf = (C.c_int * max(1, len(contact_frames)))(*contact_frames)
+    check(lib().idocp_model_from_urdf(path.encode(), cf, len(contact_frames), C.byref(m)), "idocp_model_from_urdf")
+    return m

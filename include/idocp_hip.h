@@ -1,0 +1,215 @@
+/*
+ * idocp_hip.h -- C ABI of the MI355X-native KKT-condensation + Riccati hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI:
+ * its boundary is the C++ classes idocp::Robot (include/idocp/robot/robot.hpp:26),
+ * idocp::UnOCPSolver (include/idocp/unocp/unocp_solver.hpp:25-188) and
+ * idocp::OCPSolver (include/idocp/ocp/ocp_solver.hpp).  The C++ facade in
+ * include/idocp/ *.hpp keeps those class names / method names and forwards every
+ * call to the functions declared here; each entry point cites the reference
+ * method it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types
+ *   - every function returns an int status: 0 ok, <0 bad argument / runtime
+ *     failure (IDOCP_E_*), >0 numerical failure (1 + index of the failing stage)
+ *   - caller-owned host buffers, library-owned device buffers; one HIP stream
+ *     per handle; a handle is thread-compatible (one caller at a time)
+ *   - all arithmetic is IEEE FP64; matrices crossing the ABI are column-major
+ *     (the reference's Eigen default)
+ *   - "batch" = number of independent OCP instances solved side by side by one
+ *     handle (the data-parallel axis of the throughput metric).  batch == 1
+ *     reproduces one reference solver object.
+ */
+#ifndef IDOCP_HIP_H_
+#define IDOCP_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDOCP_MAX_JOINTS 16
+#define IDOCP_MAX_NV 24
+#define IDOCP_MAX_NQ 25
+#define IDOCP_MAX_CONTACTS 4
+
+#define IDOCP_OK 0
+#define IDOCP_E_ARG (-1)      /* invalid argument (reference: throw + std::exit) */
+#define IDOCP_E_IO (-2)       /* URDF could not be read / parsed                   */
+#define IDOCP_E_DEVICE (-3)   /* HIP runtime error, no GPU, or extension missing   */
+#define IDOCP_E_UNSUPPORTED (-4)
+
+#define IDOCP_JOINT_REVOLUTE 0
+#define IDOCP_JOINT_FREEFLYER 1
+
+/*
+ * Flat rigid-body model: what pinocchio::Model holds for the reference
+ * (src/robot/robot.cpp:8-85).  Joint i (0-based) is pinocchio joint i+1; the
+ * universe is parent -1.  Spatial vectors are (linear, angular) like
+ * pinocchio::Motion / Force.  Rotations are row-major 3x3.
+ */
+typedef struct idocp_model {
+  int njoints;
+  int nq, nv, nu;              /* nu = nv - dim_passive                           */
+  int has_floating_base;       /* joint 0 is a free-flyer (q: xyz + quat xyzw)    */
+  int parent[IDOCP_MAX_JOINTS];
+  int jtype[IDOCP_MAX_JOINTS];
+  int idx_q[IDOCP_MAX_JOINTS];
+  int idx_v[IDOCP_MAX_JOINTS];
+  double axis[IDOCP_MAX_JOINTS][3];   /* revolute axis in the joint frame          */
+  double plc_R[IDOCP_MAX_JOINTS][9];  /* joint placement in the parent joint frame */
+  double plc_p[IDOCP_MAX_JOINTS][3];  /*   x_parent = R x_joint + p                */
+  double mass[IDOCP_MAX_JOINTS];      /* body inertia (fixed children merged):     */
+  double com[IDOCP_MAX_JOINTS][3];    /*   centre of mass in the joint frame       */
+  double inertia[IDOCP_MAX_JOINTS][9];/*   rotational inertia about the com        */
+  double gravity[3];                  /* (0, 0, -9.81)                             */
+  double q_min[IDOCP_MAX_NV];         /* limits of the nu actuated joints          */
+  double q_max[IDOCP_MAX_NV];         /* (reference: Robot::initializeJointLimits, */
+  double v_max[IDOCP_MAX_NV];         /*  include/idocp/robot/robot.hxx:699-709)   */
+  double u_max[IDOCP_MAX_NV];
+  int ncontacts;                      /* point contacts (robot.cpp:66-70)          */
+  int contact_frame_id[IDOCP_MAX_CONTACTS]; /* pinocchio frame index               */
+  int contact_joint[IDOCP_MAX_CONTACTS];    /* parent joint of the contact frame   */
+  double contact_R[IDOCP_MAX_CONTACTS][9];  /* frame placement in that joint frame */
+  double contact_p[IDOCP_MAX_CONTACTS][3];
+  double total_mass;
+} idocp_model_t;
+
+/*
+ * ConfigurationSpaceCost (src/cost/configuration_space_cost.cpp:241-397), the
+ * cost of configs C1/C2.  Unset weights are zero like the reference's ctor.
+ */
+typedef struct idocp_cost {
+  double q_ref[IDOCP_MAX_NQ];
+  double v_ref[IDOCP_MAX_NV];
+  double u_ref[IDOCP_MAX_NV];
+  double q_weight[IDOCP_MAX_NV];
+  double v_weight[IDOCP_MAX_NV];
+  double a_weight[IDOCP_MAX_NV];
+  double u_weight[IDOCP_MAX_NV];
+  double qf_weight[IDOCP_MAX_NV];
+  double vf_weight[IDOCP_MAX_NV];
+} idocp_cost_t;
+
+/*
+ * Inequality constraints handled by the primal-dual interior point method
+ * (include/idocp/constraints/pdipm.hxx:13-87).  The six joint-limit components
+ * are what JointConstraintsFactory::create() pushes
+ * (src/utils/joint_constraints_factory.cpp:21-38), in the reference's order:
+ * position lower/upper, velocity lower/upper, torque lower/upper.
+ */
+typedef struct idocp_constraints {
+  int joint_position_limits;   /* 0/1 */
+  int joint_velocity_limits;   /* 0/1 */
+  int joint_torque_limits;     /* 0/1 */
+  double barrier;                     /* default 1.0e-04 */
+  double fraction_to_boundary_rate;   /* default 0.995   */
+} idocp_constraints_t;
+
+/* ---- Robot ------------------------------------------------------------ */
+
+/* Replaces Robot::Robot(path_to_urdf[, contact_frames]) (src/robot/robot.cpp:8-85):
+ * reads the URDF and fills *out.  contact_frames are pinocchio frame indices
+ * (may be NULL when ncontacts == 0). */
+int idocp_model_from_urdf(const char* path_to_urdf, const int* contact_frames,
+                          int ncontacts, idocp_model_t* out);
+
+/* Frame name -> pinocchio-compatible frame index (robot.cpp printRobotModel
+ * enumerates the same table); returns -1 if absent. */
+int idocp_model_frame_id(const char* path_to_urdf, const char* frame_name);
+
+void idocp_cost_init(idocp_cost_t* cost);                 /* all zero          */
+void idocp_constraints_init(idocp_constraints_t* c);      /* reference defaults */
+
+/* ---- UnOCPSolver (fixed-base, no contacts) ----------------------------- */
+
+typedef struct idocp_unocp idocp_unocp_t;
+
+/* UnOCPSolver::UnOCPSolver(robot, cost, constraints, T, N, nthreads)
+ * (src/unocp/unocp_solver.cpp:11-48).  nthreads has no meaning on the GPU; it
+ * is replaced by `batch` independent instances and a device ordinal. */
+int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost,
+                       const idocp_constraints_t* constraints, double T, int N,
+                       int batch, int device, idocp_unocp_t** out);
+void idocp_unocp_destroy(idocp_unocp_t* h);
+
+/* UnOCPSolver::setSolution(name, value) (unocp_solver.cpp:157-181): name in
+ * {"q","v","a","u"}; value[dim] is written to every stage of every instance,
+ * then the constraints are re-initialised. */
+int idocp_unocp_set_solution(idocp_unocp_t* h, const char* name,
+                             const double* value);
+/* Same, one value per instance: values[batch][dim]. */
+int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name,
+                                   const double* values);
+/* UnOCPSolver::initConstraints() (unocp_solver.cpp:59-70). */
+int idocp_unocp_init_constraints(idocp_unocp_t* h);
+
+/* UnOCPSolver::updateSolution(t, q, v, line_search) (unocp_solver.cpp:73-134).
+ * q[batch][nq], v[batch][nv] are host pointers.  line_search must be 0 (the
+ * reference default; the filter line search is out of scope). */
+int idocp_unocp_update_solution(idocp_unocp_t* h, double t, const double* q,
+                                const double* v, int line_search);
+/* Same with q, v already resident in device memory (HBM); asynchronous on the
+ * handle's stream -- call idocp_unocp_synchronize() before reading results. */
+int idocp_unocp_update_solution_device(idocp_unocp_t* h, double t,
+                                       const double* d_q, const double* d_v);
+int idocp_unocp_synchronize(idocp_unocp_t* h);
+/* Native stream handle (hipStream_t) so callers can record HIP events on it. */
+void* idocp_unocp_stream(idocp_unocp_t* h);
+/* Device allocation helpers for callers without a HIP binding (bench/tests). */
+int idocp_device_alloc(void** d_ptr, unsigned long long nbytes);
+int idocp_device_free(void* d_ptr);
+int idocp_device_upload(void* d_dst, const void* h_src, unsigned long long nbytes);
+int idocp_device_count(int* count);
+
+/* UnOCPSolver::computeKKTResidual(t, q, v) + KKTError() (unocp_solver.cpp:
+ * 184-225): kkt_error[batch]. */
+int idocp_unocp_compute_kkt_residual(idocp_unocp_t* h, double t, const double* q,
+                                     const double* v);
+int idocp_unocp_kkt_error(idocp_unocp_t* h, double* kkt_error);
+
+/* UnOCPSolver::getSolution(name) (unocp_solver.cpp:240-309): name in
+ * {"q","v","a","u","lmd","gmm","beta"}; out[(N+1)][dim] for one instance
+ * (a, u, beta: N stages). */
+int idocp_unocp_get_solution(idocp_unocp_t* h, const char* name, int instance,
+                             double* out);
+/* Newton direction of the last updateSolution (parity tests): name in
+ * {"dq","dv","da","du","dlmd","dgmm","dbeta"}; same shapes. */
+int idocp_unocp_get_direction(idocp_unocp_t* h, const char* name, int instance,
+                              double* out);
+/* Step sizes of the last updateSolution: primal[batch], dual[batch]. */
+int idocp_unocp_get_step_sizes(idocp_unocp_t* h, double* primal, double* dual);
+/* Riccati factorization of one instance: P[N+1][2nv*2nv] (col-major, blocks
+ * [Pqq Pqv; Pvq Pvv]), s[N+1][2nv], K[N][nv*2nv] (col-major), k[N][nv]. Any
+ * pointer may be NULL.  (split_riccati_factorization.hpp:15-134,
+ * lqr_state_feedback_policy.hpp:11-28) */
+int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s,
+                            double* K, double* k);
+/* Slack / dual variables of the IPM, [N][dimc] for one instance. */
+int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance,
+                                    double* slack, double* dual);
+int idocp_unocp_dimc(const idocp_unocp_t* h);
+
+/* Kernel-level entry points used by the parity tests and the roofline
+ * measurement (one launch each, on the handle's stream). */
+int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q,
+                                 const double* d_v);
+int idocp_unocp_launch_riccati(idocp_unocp_t* h, const double* d_q,
+                               const double* d_v);
+int idocp_unocp_launch_expand(idocp_unocp_t* h);
+int idocp_unocp_launch_integrate(idocp_unocp_t* h);
+/* Inverse dynamics + its derivatives for `n` independent samples on the device
+ * (Robot::RNEA / RNEADerivatives, include/idocp/robot/robot.hxx:444-500).
+ * q[n][nq], v[n][nv], a[n][nv] host; tau[n][nv]; dq/dv/da[n][nv*nv] col-major. */
+int idocp_rnea_derivatives(const idocp_model_t* model, int n, const double* q,
+                           const double* v, const double* a, double* tau,
+                           double* dtau_dq, double* dtau_dv, double* dtau_da,
+                           int device);
+
+const char* idocp_last_error(void);
+const char* idocp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDOCP_HIP_H_ */

@@ -1,0 +1,459 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md and unocp.hpp).
+#include "unocp.hpp"
+
+#include <chrono>
+#include <stdexcept>
+#include <string>
+
+namespace oracle {
+
+// ------------------------------------------------------------ constraints ----
+Constraints::Constraints(const Robot& robot, const idocp_constraints_t& c)
+    : barrier(c.barrier), fraction_to_boundary_rate(c.fraction_to_boundary_rate) {
+  const idocp_model_t& m = robot.model();
+  const int nu = m.nu;
+  auto vec = [&](const double* p, double sgn) { Mat v(nu); for (int i = 0; i < nu; ++i) v[i] = sgn * p[i]; return v; };
+  // Constraints::push_back sorts components into position / velocity /
+  // acceleration level lists (constraints.hxx:24-36); JointConstraintsFactory
+  // pushes lower before upper (joint_constraints_factory.cpp:21-38).
+  if (c.joint_position_limits) {
+    components.push_back({JointLimit::Q, -1, vec(m.q_min, 1.0)});
+    components.push_back({JointLimit::Q, +1, vec(m.q_max, 1.0)});
+  }
+  if (c.joint_velocity_limits) {
+    components.push_back({JointLimit::V, -1, vec(m.v_max, -1.0)});
+    components.push_back({JointLimit::V, +1, vec(m.v_max, 1.0)});
+  }
+  if (c.joint_torque_limits) {
+    components.push_back({JointLimit::U, -1, vec(m.u_max, -1.0)});
+    components.push_back({JointLimit::U, +1, vec(m.u_max, 1.0)});
+  }
+}
+
+int Constraints::dimc_total() const {
+  int n = 0; for (auto& c : components) n += c.lim.size(); return n;
+}
+
+static const Mat& varOf(const JointLimit& jl, const SplitSolution& s) {
+  return jl.var == JointLimit::Q ? s.q : (jl.var == JointLimit::V ? s.v : s.u);
+}
+static const Mat& dvarOf(const JointLimit& jl, const SplitDirection& d) {
+  return jl.var == JointLimit::Q ? d.dq : (jl.var == JointLimit::V ? d.dv : d.du);
+}
+
+// pdipm::ComputeDuality + the component's computePrimalAndDualResidual
+// (pdipm.hxx:26-31; e.g. joint_torques_upper_limit.cpp:82-86)
+static void computePrimalAndDualResidual(const Constraints& cs, const JointLimit& jl,
+                                         ConstraintComponentData& data, const SplitSolution& s) {
+  const Mat& x = varOf(jl, s);
+  const int n = jl.lim.size(), off = x.size() - n;      // .tail(dimc_)
+  for (int i = 0; i < n; ++i) {
+    data.residual[i] = jl.sign * (x[off + i] - jl.lim[i]) + data.slack[i];
+    data.duality[i] = data.slack[i] * data.dual[i] - cs.barrier;
+  }
+}
+
+// ------------------------------------------------------------- SplitUnOCP ----
+SplitUnOCP::SplitUnOCP(int nv_)
+    : nv(nv_), ID(nv_), dID_dq(nv_, nv_), dID_dv(nv_, nv_), dID_da(nv_, nv_), lu_condensed(nv_),
+      Qqq(nv_, nv_), Qvv_diag(nv_), Qaa_diag(nv_), Quu_diag(nv_),
+      Fq(nv_), Fv(nv_), lq(nv_), lv(nv_), la(nv_), lu(nv_) {}
+
+UnOCPSolver::UnOCPSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& cons,
+                         double T, int N)
+    : robot(model), cost(cost_), constraints(robot, cons),
+      s(N + 1, SplitSolution(robot)), d(N + 1, SplitDirection(robot)),
+      ocp(N, SplitUnOCP(model.nv)),
+      unkkt_matrix(N, SplitUnKKTMatrix(model.nv)), unkkt_residual(N, SplitUnKKTResidual(model.nv)),
+      terminal_Qqq(model.nv, model.nv), terminal_Qvv(model.nv, model.nv), terminal_lq(model.nv), terminal_lv(model.nv),
+      riccati(N + 1, SplitRiccatiFactorization(model.nv)),
+      K(N, Mat(model.nv, 2 * model.nv)), k(N, Mat(model.nv)),
+      N_(N), T_(T), dt_(T / N) {
+  if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
+  if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
+  if (robot.hasFloatingBase() || robot.maxPointContacts() > 0)
+    throw std::logic_error("robot has floating base or contacts: use OCPSolver");   // split_unocp.hxx:27-33
+  initConstraints();
+}
+
+void UnOCPSolver::setSolution(const std::string& name, const Mat& value) {
+  for (auto& e : s) {
+    if (name == "q") e.q = value;
+    else if (name == "v") e.v = value;
+    else if (name == "a") e.a = value;
+    else if (name == "u") e.u = value;
+    else throw std::invalid_argument("invalid arugment: name must be q, v, a, or u!");
+  }
+  initConstraints();
+}
+
+// SplitUnOCP::initConstraints (split_unocp.hxx:61-66) -> createConstraintsData
+// + setSlackAndDual -> pdipm::SetSlackAndDualPositive (pdipm.hxx:13-23)
+void UnOCPSolver::initConstraints() {
+  for (int i = 0; i < N_; ++i) {
+    ConstraintsData& cd = ocp[i].cdata;
+    cd.time_stage = i;
+    cd.data.clear();
+    for (const JointLimit& jl : constraints.components) {
+      ConstraintComponentData data(jl.lim.size());
+      if (constraints.valid(jl, i)) {
+        const Mat& x = varOf(jl, s[i]);
+        const int n = jl.lim.size(), off = x.size() - n;
+        for (int r = 0; r < n; ++r) {
+          data.slack[r] = -jl.sign * (x[off + r] - jl.lim[r]);
+          while (data.slack[r] < constraints.barrier) data.slack[r] += constraints.barrier;
+          data.dual[r] = constraints.barrier / data.slack[r];
+        }
+      }
+      cd.data.push_back(data);
+    }
+  }
+}
+
+// ConfigurationSpaceCost::computeStageCostDerivatives (configuration_space_cost.cpp:292-310)
+static void stageCostDerivatives(const idocp_cost_t& c, double dt, const SplitSolution& s, SplitUnOCP& o) {
+  const int nv = o.nv;
+  for (int i = 0; i < nv; ++i) {
+    o.lq[i] += dt * c.q_weight[i] * (s.q[i] - c.q_ref[i]);
+    o.lv[i] += dt * c.v_weight[i] * (s.v[i] - c.v_ref[i]);
+    o.la[i] += dt * c.a_weight[i] * s.a[i];
+    o.lu[i] += dt * c.u_weight[i] * (s.u[i] - c.u_ref[i]);
+  }
+}
+
+static Mat& residualOf(const JointLimit& jl, SplitUnOCP& o) {
+  return jl.var == JointLimit::Q ? o.lq : (jl.var == JointLimit::V ? o.lv : o.lu);
+}
+static Mat& hessianDiagOf(const JointLimit& jl, SplitUnOCP& o, Mat& qqdiag) {
+  return jl.var == JointLimit::Q ? qqdiag : (jl.var == JointLimit::V ? o.Qvv_diag : o.Quu_diag);
+}
+
+// stateequation::linearizeForwardEuler, fixed base (state_equation.hxx:12-37,210-221)
+static void linearizeForwardEuler(double dt, const SplitSolution& s, const SplitSolution& sn, SplitUnOCP& o) {
+  const int nv = o.nv;
+  for (int i = 0; i < nv; ++i) {
+    o.Fq[i] = s.q[i] - sn.q[i] + dt * s.v[i];
+    o.Fv[i] = s.v[i] + dt * s.a[i] - sn.v[i];
+    o.lq[i] += sn.lmd[i] - s.lmd[i];
+    o.lv[i] += dt * sn.lmd[i] + sn.gmm[i] - s.gmm[i];
+    o.la[i] += dt * sn.gmm[i];
+  }
+}
+
+// SplitUnOCP::computeKKTResidual up to (and including) the dynamics
+// (split_unocp.hxx:141-161); with_hessian=false.  linearizeOCP shares it.
+void UnOCPSolver::computeStageResidual(int i, double /*t*/) {
+  SplitUnOCP& o = ocp[i];
+  const SplitSolution& si = s[i];
+  o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero(); o.Fq.setZero(); o.Fv.setZero();
+  stageCostDerivatives(cost, dt_, si, o);
+  // Constraints::computePrimalAndDualResidual + augmentDualResidual
+  for (size_t c = 0; c < constraints.components.size(); ++c) {
+    const JointLimit& jl = constraints.components[c];
+    if (!constraints.valid(jl, i)) continue;
+    ConstraintComponentData& data = o.cdata.data[c];
+    computePrimalAndDualResidual(constraints, jl, data, si);
+    Mat& l = residualOf(jl, o);
+    const int n = jl.lim.size(), off = l.size() - n;
+    for (int r = 0; r < n; ++r) l[off + r] += jl.sign * dt_ * data.dual[r];
+  }
+  linearizeForwardEuler(dt_, si, s[i + 1], o);
+  // UnconstrainedDynamics::linearizeUnconstrainedDynamics (unconstrained_dynamics.hxx:55-65)
+  robot.RNEA(si.q, si.v, si.a, o.ID);
+  o.ID -= si.u;
+  robot.RNEADerivatives(si.q, si.v, si.a, o.dID_dq, o.dID_dv, o.dID_da);
+  o.lq += dt_ * (o.dID_dq.t() * si.beta);
+  o.lv += dt_ * (o.dID_dv.t() * si.beta);
+  o.la += dt_ * (o.dID_da.t() * si.beta);
+  o.lu -= dt_ * si.beta;
+}
+
+// SplitUnOCP::linearizeOCP (split_unocp.hxx:69-99)
+void UnOCPSolver::linearizeStage(int i, double t, const Mat& /*q_prev*/) {
+  SplitUnOCP& o = ocp[i];
+  const SplitSolution& si = s[i];
+  const int nv = o.nv;
+  o.Qqq.setZero(); o.Qvv_diag.setZero(); o.Qaa_diag.setZero(); o.Quu_diag.setZero();
+  o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero();
+  stageCostDerivatives(cost, dt_, si, o);
+  for (size_t c = 0; c < constraints.components.size(); ++c) {          // augmentDualResidual
+    const JointLimit& jl = constraints.components[c];
+    if (!constraints.valid(jl, i)) continue;
+    const ConstraintComponentData& data = o.cdata.data[c];
+    Mat& l = residualOf(jl, o);
+    const int n = jl.lim.size(), off = l.size() - n;
+    for (int r = 0; r < n; ++r) l[off + r] += jl.sign * dt_ * data.dual[r];
+  }
+  linearizeForwardEuler(dt_, si, s[i + 1], o);
+  robot.RNEA(si.q, si.v, si.a, o.ID);
+  o.ID -= si.u;
+  robot.RNEADerivatives(si.q, si.v, si.a, o.dID_dq, o.dID_dv, o.dID_da);
+  o.lq += dt_ * (o.dID_dq.t() * si.beta);
+  o.lv += dt_ * (o.dID_dv.t() * si.beta);
+  o.la += dt_ * (o.dID_da.t() * si.beta);
+  o.lu -= dt_ * si.beta;
+  // ConfigurationSpaceCost::computeStageCostHessian (configuration_space_cost.cpp:351-365)
+  Mat Qqq_diag(nv);
+  for (int r = 0; r < nv; ++r) {
+    Qqq_diag[r] += dt_ * cost.q_weight[r];
+    o.Qvv_diag[r] += dt_ * cost.v_weight[r];
+    o.Qaa_diag[r] += dt_ * cost.a_weight[r];
+    o.Quu_diag[r] += dt_ * cost.u_weight[r];
+  }
+  // Constraints::condenseSlackAndDual (e.g. joint_torques_upper_limit.cpp:62-73)
+  for (size_t c = 0; c < constraints.components.size(); ++c) {
+    const JointLimit& jl = constraints.components[c];
+    if (!constraints.valid(jl, i)) continue;
+    ConstraintComponentData& data = o.cdata.data[c];
+    Mat& l = residualOf(jl, o);
+    Mat& H = hessianDiagOf(jl, o, Qqq_diag);
+    const int n = jl.lim.size(), off = l.size() - n;
+    for (int r = 0; r < n; ++r) H[off + r] += dt_ * data.dual[r] / data.slack[r];
+    computePrimalAndDualResidual(constraints, jl, data, si);
+    for (int r = 0; r < n; ++r)
+      l[off + r] += jl.sign * dt_ * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
+  }
+  for (int r = 0; r < nv; ++r) o.Qqq(r, r) = Qqq_diag[r];
+  // UnconstrainedDynamics::condenseUnconstrainedDynamics (unconstrained_dynamics.hxx:68-94)
+  SplitUnKKTMatrix& Q = unkkt_matrix[i];
+  SplitUnKKTResidual& R = unkkt_residual[i];
+  for (int r = 0; r < nv; ++r) o.lu_condensed[r] = o.lu[r] + o.Quu_diag[r] * o.ID[r];
+  R.lq = o.lq + o.dID_dq.t() * o.lu_condensed;
+  R.lv = o.lv + o.dID_dv.t() * o.lu_condensed;
+  R.la = o.la + o.dID_da.t() * o.lu_condensed;
+  R.Fq = o.Fq; R.Fv = o.Fv;
+  Mat Quu_dq = o.dID_dq, Quu_dv = o.dID_dv, Quu_da = o.dID_da;
+  for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) {
+    Quu_dq(r, c) *= o.Quu_diag[r]; Quu_dv(r, c) *= o.Quu_diag[r]; Quu_da(r, c) *= o.Quu_diag[r];
+  }
+  // block order (a, q, v): Qaa=(0,0) Qaq=(0,1) Qav=(0,2) Qqq=(1,1) Qqv=(1,2) Qvv=(2,2)
+  Q.Q.setZero();
+  Q.set(1, 1, o.dID_dq.t() * Quu_dq);
+  Q.set(1, 2, o.dID_dq.t() * Quu_dv);
+  Q.set(2, 2, o.dID_dv.t() * Quu_dv);
+  Q.set(0, 1, o.dID_da.t() * Quu_dq);
+  Q.set(0, 2, o.dID_da.t() * Quu_dv);
+  Q.set(0, 0, o.dID_da.t() * Quu_da);
+  Q.add(1, 1, o.Qqq);
+  for (int r = 0; r < nv; ++r) { Q.Q(2 * nv + r, 2 * nv + r) += o.Qvv_diag[r]; Q.Q(r, r) += o.Qaa_diag[r]; }
+  (void)t;
+}
+
+// TerminalOCP::linearizeOCP (terminal_ocp.hxx:50-66), fixed base
+void UnOCPSolver::linearizeTerminal(double /*t*/) {
+  const SplitSolution& sN = s[N_];
+  const int nv = robot.dimv();
+  terminal_lq.setZero(); terminal_lv.setZero();
+  for (int i = 0; i < nv; ++i) {            // computeTerminalCostDerivatives (configuration_space_cost.cpp:313-329)
+    terminal_lq[i] += cost.qf_weight[i] * (sN.q[i] - cost.q_ref[i]);
+    terminal_lv[i] += cost.vf_weight[i] * (sN.v[i] - cost.v_ref[i]);
+  }
+  terminal_lq -= sN.lmd;                    // linearizeForwardEulerTerminal (state_equation.hxx:66-83)
+  terminal_lv -= sN.gmm;
+  terminal_Qqq.setZero(); terminal_Qvv.setZero();
+  for (int i = 0; i < nv; ++i) { terminal_Qqq(i, i) += cost.qf_weight[i]; terminal_Qvv(i, i) += cost.vf_weight[i]; }
+}
+
+void UnOCPSolver::linearizeOCP(double t, const Mat& q) {
+  for (int i = 0; i <= N_; ++i) {
+    if (i == 0) linearizeStage(0, t, q);
+    else if (i < N_) linearizeStage(i, t + i * dt_, s[i - 1].q);
+    else linearizeTerminal(t + T_);
+  }
+}
+
+// UnRiccatiRecursion::backwardRiccatiRecursionTerminal + backwardRiccatiRecursion
+// (unriccati_recursion.cpp:39-58)
+void UnOCPSolver::backwardRiccatiRecursion() {
+  const int nv = robot.dimv();
+  riccati[N_].Pqq = terminal_Qqq;
+  riccati[N_].Pvv = terminal_Qvv;
+  riccati[N_].sq = -terminal_lq;
+  riccati[N_].sv = -terminal_lv;
+  const double dt = dt_;
+  for (int i = N_ - 1; i >= 0; --i) {
+    const SplitRiccatiFactorization& rn = riccati[i + 1];
+    SplitUnKKTMatrix& Q = unkkt_matrix[i];
+    SplitUnKKTResidual& R = unkkt_residual[i];
+    // BackwardUnRiccatiRecursionFactorizer::factorizeKKTMatrix
+    // (backward_unriccati_recursion_factorizer.hxx:29-54)
+    Q.add(1, 1, rn.Pqq);
+    Q.add(1, 2, rn.Pqq, dt);
+    Q.add(1, 2, rn.Pqv);
+    Q.set(2, 1, Q.blk(1, 2).t());
+    Q.add(2, 2, rn.Pqq, dt * dt);
+    Q.add(2, 2, rn.Pqv, dt);
+    Q.add(2, 2, rn.Pqv.t(), dt);
+    Q.add(2, 2, rn.Pvv);
+    Q.add(0, 1, rn.Pqv.t(), dt);               // Qaq^T += dt Pqv
+    Q.add(0, 2, rn.Pqv.t(), dt * dt);          // Qav^T += dt^2 Pqv
+    Q.add(0, 2, rn.Pvv.t(), dt);               // Qav^T += dt Pvv
+    Q.add(0, 0, rn.Pvv, dt * dt);
+    R.la += dt * (rn.Pqv.t() * R.Fq);
+    R.la += dt * (rn.Pvv * R.Fv);
+    R.la -= dt * rn.sv;
+    // SplitUnRiccatiFactorizer::backwardRiccatiRecursion (split_unriccati_factorizer.hxx:30-46)
+    LLT llt;
+    if (!llt.compute(Q.blk(0, 0))) throw std::runtime_error("Riccati: Qaa not positive definite at stage " + std::to_string(i));
+    Mat Qax = Q.Q.block(0, nv, nv, 2 * nv);
+    K[i] = -llt.solve(Qax);
+    k[i] = -llt.solve(R.la);
+    // factorizeRiccatiFactorization (backward_unriccati_recursion_factorizer.hxx:57-89)
+    SplitRiccatiFactorization& r = riccati[i];
+    r.Pqq = Q.blk(1, 1); r.Pqv = Q.blk(1, 2); r.Pvv = Q.blk(2, 2);
+    Mat GK = Q.blk(0, 0) * K[i];
+    Mat Kq = K[i].block(0, 0, nv, nv), Kv = K[i].block(0, nv, nv, nv);
+    Mat GKq = GK.block(0, 0, nv, nv), GKv = GK.block(0, nv, nv, nv);
+    r.Pqq -= Kq.t() * GKq;
+    r.Pqv -= Kq.t() * GKv;
+    r.Pvv -= Kv.t() * GKv;
+    r.Pvq = r.Pqv.t();
+    r.Pqq = 0.5 * (r.Pqq + r.Pqq.t());
+    r.Pvv = 0.5 * (r.Pvv + r.Pvv.t());
+    r.sq = rn.sq;
+    r.sq -= rn.Pqq * R.Fq;
+    r.sq -= rn.Pqv * R.Fv;
+    r.sv = rn.sv;
+    r.sv += dt * r.sq;
+    r.sv -= rn.Pqv.t() * R.Fq;
+    r.sv -= rn.Pvv * R.Fv;
+    r.sq -= R.lq;
+    r.sv -= R.lv;
+    r.sq -= Q.blk(0, 1).t() * k[i];
+    r.sv -= Q.blk(0, 2).t() * k[i];
+  }
+}
+
+// d[0] initial state (unocp_solver.cpp:100-101) + UnRiccatiRecursion::forwardRiccatiRecursion
+// (unriccati_recursion.cpp:60-65; split_unriccati_factorizer.hxx:49-57)
+void UnOCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
+  const int nv = robot.dimv();
+  d[0].dq = q - s[0].q;
+  d[0].dv = v - s[0].v;
+  for (int i = 0; i < N_; ++i) {
+    Mat dx(2 * nv); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
+    d[i].da = K[i] * dx + k[i];
+    d[i + 1].dq = unkkt_residual[i].Fq + d[i].dq;
+    d[i + 1].dv = unkkt_residual[i].Fv + d[i].dv;
+    d[i + 1].dq += dt_ * d[i].dv;
+    d[i + 1].dv += dt_ * d[i].da;
+  }
+}
+
+// pdipm::FractionToBoundary (pdipm.hxx:52-73)
+static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {
+  double m = 1;
+  for (int i = 0; i < vec.size(); ++i) {
+    const double f = -rate * (vec[i] / dvec[i]);
+    if (f > 0 && f < 1 && f < m) m = f;
+  }
+  return m;
+}
+
+// second parallel loop of UnOCPSolver::updateSolution (unocp_solver.cpp:103-115)
+void UnOCPSolver::computeDirection() {
+  double pmin = 1, dmin = 1;
+  for (int i = 0; i <= N_; ++i) {
+    const SplitRiccatiFactorization& r = riccati[i];
+    // SplitUnRiccatiFactorizer::computeCostateDirection (split_unriccati_factorizer.hxx:60-68)
+    d[i].dlmd = r.Pqq * d[i].dq;
+    d[i].dlmd += r.Pqv * d[i].dv;
+    d[i].dlmd -= r.sq;
+    d[i].dgmm = r.Pqv.t() * d[i].dq;
+    d[i].dgmm += r.Pvv * d[i].dv;
+    d[i].dgmm -= r.sv;
+    if (i < N_) {
+      SplitUnOCP& o = ocp[i];
+      // UnconstrainedDynamics::computeCondensedDirection (unconstrained_dynamics.hxx:97-106)
+      d[i].du = o.ID;
+      d[i].du += o.dID_dq * d[i].dq;
+      d[i].du += o.dID_dv * d[i].dv;
+      d[i].du += o.dID_da * d[i].da;
+      for (int r2 = 0; r2 < o.nv; ++r2) d[i].dbeta[r2] = (o.lu[r2] + o.Quu_diag[r2] * d[i].du[r2]) / dt_;
+      // Constraints::computeSlackAndDualDirection + step sizes
+      for (size_t c = 0; c < constraints.components.size(); ++c) {
+        const JointLimit& jl = constraints.components[c];
+        if (!constraints.valid(jl, i)) continue;
+        ConstraintComponentData& data = o.cdata.data[c];
+        const Mat& dx = dvarOf(jl, d[i]);
+        const int n = jl.lim.size(), off = dx.size() - n;
+        for (int r2 = 0; r2 < n; ++r2) {
+          data.dslack[r2] = -jl.sign * dx[off + r2] - data.residual[r2];
+          data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];   // pdipm.hxx:76-81
+        }
+        const double ps = fractionToBoundary(constraints.fraction_to_boundary_rate, data.slack, data.dslack);
+        const double ds = fractionToBoundary(constraints.fraction_to_boundary_rate, data.dual, data.ddual);
+        if (ps < pmin) pmin = ps;
+        if (ds < dmin) dmin = ds;
+      }
+    }
+  }
+  primal_step_size = pmin; dual_step_size = dmin;
+}
+
+// third parallel loop (unocp_solver.cpp:121-133): updatePrimal / updateDual
+void UnOCPSolver::integrate() {
+  const double ap = primal_step_size, ad = dual_step_size;
+  for (int i = 0; i <= N_; ++i) {
+    s[i].lmd += ap * d[i].dlmd;
+    s[i].gmm += ap * d[i].dgmm;
+    s[i].q += ap * d[i].dq;
+    s[i].v += ap * d[i].dv;
+    if (i < N_) {
+      s[i].a += ap * d[i].da;
+      s[i].u += ap * d[i].du;
+      s[i].beta += ap * d[i].dbeta;
+      for (size_t c = 0; c < constraints.components.size(); ++c) {
+        if (!constraints.valid(constraints.components[c], i)) continue;
+        ConstraintComponentData& data = ocp[i].cdata.data[c];
+        data.slack += ap * data.dslack;
+        data.dual += ad * data.ddual;
+      }
+    }
+  }
+}
+
+void UnOCPSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+  linearizeOCP(t, q);
+  auto t0 = std::chrono::steady_clock::now();
+  backwardRiccatiRecursion();
+  forwardRiccatiRecursion(q, v);
+  riccati_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  computeDirection();
+  integrate();
+}
+
+void UnOCPSolver::computeKKTResidual(double t, const Mat& /*q*/, const Mat& /*v*/) {
+  for (int i = 0; i < N_; ++i) computeStageResidual(i, t + i * dt_);
+  // TerminalOCP::computeKKTResidual (terminal_ocp.hxx:118-131)
+  const SplitSolution& sN = s[N_];
+  terminal_lq.setZero(); terminal_lv.setZero();
+  for (int i = 0; i < robot.dimv(); ++i) {
+    terminal_lq[i] += cost.qf_weight[i] * (sN.q[i] - cost.q_ref[i]);
+    terminal_lv[i] += cost.vf_weight[i] * (sN.v[i] - cost.v_ref[i]);
+  }
+  terminal_lq -= sN.lmd;
+  terminal_lv -= sN.gmm;
+}
+
+// UnOCPSolver::KKTError (unocp_solver.cpp:190-202) / squaredNormKKTResidual (split_unocp.hxx:164-174)
+double UnOCPSolver::KKTError() {
+  double sum = 0;
+  for (int i = 0; i < N_; ++i) {
+    const SplitUnOCP& o = ocp[i];
+    double e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
+    e += o.Fq.squaredNorm() + o.Fv.squaredNorm();
+    e += dt_ * dt_ * o.ID.squaredNorm();
+    double c = 0;
+    for (size_t j = 0; j < constraints.components.size(); ++j) {
+      if (!constraints.valid(constraints.components[j], i)) continue;
+      c += o.cdata.data[j].residual.squaredNorm() + o.cdata.data[j].duality.squaredNorm();
+    }
+    e += dt_ * dt_ * c;
+    sum += e;
+  }
+  sum += terminal_lq.squaredNorm() + terminal_lv.squaredNorm();
+  return std::sqrt(sum);
+}
+
+}  // namespace oracle

@@ -1,0 +1,141 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the fixed-base ("unconstrained") half of the idocp hot
+// path: SplitUnOCP / TerminalOCP / UnconstrainedDynamics / UnRiccatiRecursion /
+// UnOCPSolver.  Each function cites the reference lines it follows; the order
+// of operations is the reference's.
+#ifndef ORACLE_UNOCP_HPP_
+#define ORACLE_UNOCP_HPP_
+
+#include <memory>
+#include <vector>
+
+#include "idocp_hip.h"
+#include "mat.hpp"
+#include "rbd.hpp"
+
+namespace oracle {
+
+// include/idocp/ocp/split_solution.hxx:10-31 (fixed-base fields)
+struct SplitSolution {
+  Mat lmd, gmm, q, v, a, u, beta;
+  explicit SplitSolution(const Robot& r)
+      : lmd(r.dimv()), gmm(r.dimv()), q(r.dimq()), v(r.dimv()), a(r.dimv()), u(r.dimu()), beta(r.dimv()) {}
+};
+
+// include/idocp/ocp/split_direction.hxx:8-23 (fixed-base fields)
+struct SplitDirection {
+  Mat dlmd, dgmm, dq, dv, da, du, dbeta;
+  explicit SplitDirection(const Robot& r)
+      : dlmd(r.dimv()), dgmm(r.dimv()), dq(r.dimv()), dv(r.dimv()), da(r.dimv()), du(r.dimu()), dbeta(r.dimv()) {}
+};
+
+// include/idocp/constraints/constraint_component_data.hpp
+struct ConstraintComponentData {
+  Mat slack, dual, residual, duality, dslack, ddual;
+  explicit ConstraintComponentData(int dimc = 0)
+      : slack(dimc), dual(dimc), residual(dimc), duality(dimc), dslack(dimc), ddual(dimc) {}
+};
+
+// One joint-limit component (src/constraints/joint_*_limit.cpp); the six
+// reference classes differ only in the variable, the bound and a sign.
+struct JointLimit {
+  enum Var { Q = 0, V = 1, U = 2 };
+  Var var;
+  int sign;            // -1 lower limit, +1 upper limit
+  Mat lim;             // bound (xmin for lower, xmax for upper)
+  int level() const { return var == Q ? 0 : (var == V ? 1 : 2); }  // position / velocity / acceleration
+};
+
+// include/idocp/constraints/constraints.hxx + constraints_data.hpp:18-42
+struct Constraints {
+  std::vector<JointLimit> components;   // stored level by level like the reference
+  double barrier = 1.0e-04, fraction_to_boundary_rate = 0.995;
+  Constraints(const Robot& robot, const idocp_constraints_t& c);
+  int dimc_total() const;
+  bool valid(const JointLimit& jl, int time_stage) const {
+    // ConstraintsData(time_stage): stage 0 -> acceleration level only,
+    // stage 1 -> velocity + acceleration, >= 2 -> all
+    if (time_stage >= 2) return true;
+    if (time_stage == 1) return jl.level() >= 1;
+    return jl.level() >= 2;
+  }
+};
+
+struct ConstraintsData {
+  int time_stage = 0;
+  std::vector<ConstraintComponentData> data;   // one per component (invalid ones keep dimc 0 semantics)
+};
+
+// include/idocp/unocp/split_unkkt_matrix.hxx:31-147 -- Q ordered (a, q, v)
+struct SplitUnKKTMatrix {
+  int nv; Mat Q;
+  explicit SplitUnKKTMatrix(int nv_) : nv(nv_), Q(3 * nv_, 3 * nv_) {}
+  Mat blk(int bi, int bj) const { return Q.block(bi * nv, bj * nv, nv, nv); }
+  void set(int bi, int bj, const Mat& m) { Q.setBlock(bi * nv, bj * nv, m); }
+  void add(int bi, int bj, const Mat& m, double al = 1.0) { Q.addBlock(bi * nv, bj * nv, m, al); }
+};
+// include/idocp/unocp/split_unkkt_residual.hxx:29-103 -- (Fq, Fv, la, lq, lv)
+struct SplitUnKKTResidual {
+  Mat Fq, Fv, la, lq, lv;
+  explicit SplitUnKKTResidual(int nv) : Fq(nv), Fv(nv), la(nv), lq(nv), lv(nv) {}
+};
+
+// include/idocp/ocp/split_riccati_factorization.hpp:15-134
+struct SplitRiccatiFactorization {
+  Mat Pqq, Pqv, Pvq, Pvv, sq, sv;
+  explicit SplitRiccatiFactorization(int nv) : Pqq(nv, nv), Pqv(nv, nv), Pvq(nv, nv), Pvv(nv, nv), sq(nv), sv(nv) {}
+};
+
+// SplitUnOCP (include/idocp/unocp/split_unocp.hxx) with its private
+// kkt_matrix_/kkt_residual_, UnconstrainedDynamics and constraints data.
+struct SplitUnOCP {
+  int nv;
+  ConstraintsData cdata;
+  Mat ID, dID_dq, dID_dv, dID_da, lu_condensed;     // UnconstrainedDynamics members
+  Mat Qqq, Qvv_diag, Qaa_diag, Quu_diag;            // used parts of kkt_matrix_
+  Mat Fq, Fv, lq, lv, la, lu;                       // kkt_residual_
+  explicit SplitUnOCP(int nv_);
+};
+
+class UnOCPSolver {
+ public:
+  UnOCPSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints,
+              double T, int N);
+  void setSolution(const std::string& name, const Mat& value);   // unocp_solver.cpp:157-181
+  void initConstraints();                                        // unocp_solver.cpp:59-70
+  void updateSolution(double t, const Mat& q, const Mat& v);      // unocp_solver.cpp:73-134
+  void computeKKTResidual(double t, const Mat& q, const Mat& v);  // unocp_solver.cpp:205-225
+  double KKTError();                                              // unocp_solver.cpp:190-202
+
+  // hot-path pieces, exposed so kernel-level parity tests can stop in between
+  void linearizeOCP(double t, const Mat& q);                      // K1
+  void backwardRiccatiRecursion();                                // S1
+  void forwardRiccatiRecursion(const Mat& q, const Mat& v);       // S2
+  void computeDirection();                                        // K2 (+ step sizes)
+  void integrate();                                               // K3
+
+  int N() const { return N_; }
+  Robot robot;
+  idocp_cost_t cost;
+  Constraints constraints;
+  std::vector<SplitSolution> s;
+  std::vector<SplitDirection> d;
+  std::vector<SplitUnOCP> ocp;               // stages 0..N-1
+  std::vector<SplitUnKKTMatrix> unkkt_matrix;
+  std::vector<SplitUnKKTResidual> unkkt_residual;
+  Mat terminal_Qqq, terminal_Qvv, terminal_lq, terminal_lv;
+  std::vector<SplitRiccatiFactorization> riccati;
+  std::vector<Mat> K, k;                      // LQRStateFeedbackPolicy per stage
+  double primal_step_size = 1, dual_step_size = 1;
+  double riccati_seconds = 0;                 // accumulated wall time of S1+S2
+
+ private:
+  int N_; double T_, dt_;
+  void linearizeStage(int i, double t, const Mat& q_prev);
+  void linearizeTerminal(double t);
+  void computeStageResidual(int i, double t);
+};
+
+}  // namespace oracle
+#endif  // ORACLE_UNOCP_HPP_
