@@ -1,0 +1,467 @@
+// C-ABI implementation of the UnOCPSolver path (include/idocp_hip.h).
+//
+// Host side of the boundary: owns the device buffers and the HIP stream of a
+// handle, converts the flat model/cost/constraint structs into the device
+// parameter blocks and sequences the kernels exactly like
+// UnOCPSolver::updateSolution does (src/unocp/unocp_solver.cpp:73-134):
+//   linearize (K1) -> backward/forward Riccati (S1,S2) -> expand + step sizes
+//   (K2) -> integrate (K3).
+// There is NO CPU fallback: without a GPU every entry point that needs the
+// device returns IDOCP_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_util.hpp"
+#include "idocp_hip.h"
+#include "unocp_launch.hpp"
+
+using namespace idocp_dev;
+using idocp_host::set_last_error;
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      return IDOCP_E_DEVICE;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+namespace {
+
+void toDevModel(const idocp_model_t& m, DevModel& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.njoints = m.njoints; d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.has_floating_base = m.has_floating_base;
+  for (int i = 0; i < m.njoints; ++i) {
+    d.parent[i] = m.parent[i]; d.jtype[i] = m.jtype[i]; d.idx_q[i] = m.idx_q[i]; d.idx_v[i] = m.idx_v[i];
+    std::memcpy(d.axis[i], m.axis[i], sizeof(double) * 3);
+    std::memcpy(d.R[i], m.plc_R[i], sizeof(double) * 9);
+    std::memcpy(d.p[i], m.plc_p[i], sizeof(double) * 3);
+    d.mass[i] = m.mass[i];
+    const double* c = m.com[i];
+    const double* I = m.inertia[i];
+    const double ms = m.mass[i];
+    for (int k = 0; k < 3; ++k) d.mc[i][k] = ms * c[k];
+    // Io = Ic + m (c.c 1 - c c^T)   (inertia about the joint-frame origin)
+    const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    d.Io[i][0] = I[0] + ms * (cc - c[0] * c[0]);
+    d.Io[i][1] = I[1] - ms * c[0] * c[1];
+    d.Io[i][2] = I[2] - ms * c[0] * c[2];
+    d.Io[i][3] = I[4] + ms * (cc - c[1] * c[1]);
+    d.Io[i][4] = I[5] - ms * c[1] * c[2];
+    d.Io[i][5] = I[8] + ms * (cc - c[2] * c[2]);
+  }
+  std::memcpy(d.gravity, m.gravity, sizeof(double) * 3);
+}
+
+// The UnOCP kernels are compiled for a serial chain of NV revolute joints.
+bool isRevoluteChain(const idocp_model_t& m, int nv) {
+  if (m.njoints != nv || m.nv != nv || m.nq != nv || m.has_floating_base || m.ncontacts != 0) return false;
+  for (int i = 0; i < nv; ++i)
+    if (m.parent[i] != i - 1 || m.jtype[i] != IDOCP_JOINT_REVOLUTE || m.idx_v[i] != i) return false;
+  return true;
+}
+
+}  // namespace
+
+struct idocp_unocp {
+  idocp_model_t model;
+  idocp_cost_t cost;
+  idocp_constraints_t cons;
+  int N, batch, device, nv;
+  double T;
+  hipStream_t stream = nullptr;
+  UnBuffers B{};
+  std::vector<void*> allocs;
+  double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr;   // staging for host-pointer entry points
+  bool has_direction = false;
+};
+
+namespace {
+
+using L7 = UnLayout<7>;
+
+int allocBuf(idocp_unocp* h, double** p, size_t n) {
+  HIP_TRY(hipMalloc((void**)p, n * sizeof(double)));
+  h->allocs.push_back(*p);
+  HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(double), h->stream));
+  return IDOCP_OK;
+}
+
+struct FieldRef { int offset, dim, nstages_extra; };   // nstages = N + nstages_extra
+
+bool solField(const std::string& n, int nv, FieldRef& f) {
+  if (n == "lmd") f = {L7::S_LMD, nv, 1};
+  else if (n == "gmm") f = {L7::S_GMM, nv, 1};
+  else if (n == "q") f = {L7::S_Q, nv, 1};
+  else if (n == "v") f = {L7::S_V, nv, 1};
+  else if (n == "a") f = {L7::S_A, nv, 0};
+  else if (n == "u") f = {L7::S_U, nv, 0};
+  else if (n == "beta") f = {L7::S_BETA, nv, 0};
+  else return false;
+  return true;
+}
+
+int setDevice(const idocp_unocp* h) {
+  HIP_TRY(hipSetDevice(h->device));
+  return IDOCP_OK;
+}
+
+int copyRecords(idocp_unocp* h, const double* d_base, size_t rec_stride, size_t nrec, int offset, int dim, double* out) {
+  // strided device -> host copy of one field of consecutive records
+  HIP_TRY(hipMemcpy2DAsync(out, dim * sizeof(double), d_base + offset, rec_stride * sizeof(double), dim * sizeof(double),
+                           nrec, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idocp_device_count(int* count) {
+  if (!count) return IDOCP_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return IDOCP_OK;
+}
+
+int idocp_device_alloc(void** d_ptr, unsigned long long nbytes) {
+  if (!d_ptr) return IDOCP_E_ARG;
+  HIP_TRY(hipMalloc(d_ptr, nbytes));
+  return IDOCP_OK;
+}
+int idocp_device_free(void* d_ptr) { HIP_TRY(hipFree(d_ptr)); return IDOCP_OK; }
+int idocp_device_upload(void* d_dst, const void* h_src, unsigned long long nbytes) {
+  HIP_TRY(hipMemcpy(d_dst, h_src, nbytes, hipMemcpyHostToDevice));
+  return IDOCP_OK;
+}
+
+int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
+                       double T, int N, int batch, int device, idocp_unocp_t** out) {
+  if (!model || !cost || !constraints || !out) { set_last_error("idocp_unocp_create: null argument"); return IDOCP_E_ARG; }
+  // argument checks of UnOCPSolver::UnOCPSolver (unocp_solver.cpp:33-47) and SplitUnOCP (split_unocp.hxx:26-33)
+  if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }
+  if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
+  if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
+  if (model->has_floating_base) { set_last_error("robot has floating base: robot should have no constraints!"); return IDOCP_E_ARG; }
+  if (model->ncontacts > 0) { set_last_error("robot can have contacts: robot should have no constraints!"); return IDOCP_E_ARG; }
+  if (!isRevoluteChain(*model, 7)) {
+    set_last_error("idocp_unocp_create: this build carries UnOCP kernels for a 7-dof revolute chain (iiwa14) only");
+    return IDOCP_E_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: the idocp HIP path has no CPU fallback");
+    return IDOCP_E_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { set_last_error("invalid device ordinal"); return IDOCP_E_ARG; }
+  idocp_unocp* h = new idocp_unocp();
+  h->model = *model; h->cost = *cost; h->cons = *constraints;
+  h->N = N; h->batch = batch; h->device = device; h->T = T; h->nv = model->nv;
+  int rc = IDOCP_OK;
+  auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+    set_last_error("hipSetDevice/hipStreamCreate failed");
+    return fail(IDOCP_E_DEVICE);
+  }
+  const size_t nrec1 = (size_t)batch * (N + 1), nrec0 = (size_t)batch * N;
+  UnBuffers& B = h->B;
+  double* tmp;
+  if ((rc = allocBuf(h, &B.sol, nrec1 * L7::SOL))) return fail(rc);
+  if ((rc = allocBuf(h, &B.dir, nrec1 * L7::SOL))) return fail(rc);
+  if ((rc = allocBuf(h, &B.slack, nrec0 * L7::CON))) return fail(rc);
+  if ((rc = allocBuf(h, &B.dual, nrec0 * L7::CON))) return fail(rc);
+  if ((rc = allocBuf(h, &B.kkt, nrec0 * L7::KKT))) return fail(rc);
+  if ((rc = allocBuf(h, &B.dyn, nrec0 * L7::DYN))) return fail(rc);
+  if ((rc = allocBuf(h, &B.ric, nrec1 * L7::RIC))) return fail(rc);
+  if ((rc = allocBuf(h, &B.gain, nrec0 * L7::GAIN))) return fail(rc);
+  if ((rc = allocBuf(h, &B.step_stage, nrec0 * 2))) return fail(rc);
+  if ((rc = allocBuf(h, &B.step, (size_t)batch * 2))) return fail(rc);
+  if ((rc = allocBuf(h, &B.err_stage, nrec1))) return fail(rc);
+  if ((rc = allocBuf(h, &B.err, (size_t)batch))) return fail(rc);
+  if ((rc = allocBuf(h, &h->d_q0, (size_t)batch * model->nq))) return fail(rc);
+  if ((rc = allocBuf(h, &h->d_v0, (size_t)batch * model->nv))) return fail(rc);
+  if ((rc = allocBuf(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
+  if ((rc = allocBuf(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
+  B.status = reinterpret_cast<int*>(tmp);
+  DevModel dm; toDevModel(*model, dm);
+  UnProblem up; std::memset(&up, 0, sizeof(up));
+  up.N = N; up.batch = batch; up.T = T; up.dt = T / N;
+  for (int i = 0; i < model->nv; ++i) {
+    up.q_ref[i] = cost->q_ref[i]; up.v_ref[i] = cost->v_ref[i]; up.u_ref[i] = cost->u_ref[i];
+    up.q_weight[i] = cost->q_weight[i]; up.v_weight[i] = cost->v_weight[i]; up.a_weight[i] = cost->a_weight[i];
+    up.u_weight[i] = cost->u_weight[i]; up.qf_weight[i] = cost->qf_weight[i]; up.vf_weight[i] = cost->vf_weight[i];
+    up.q_min[i] = model->q_min[i]; up.q_max[i] = model->q_max[i]; up.v_max[i] = model->v_max[i]; up.u_max[i] = model->u_max[i];
+  }
+  up.use_q_limits = constraints->joint_position_limits; up.use_v_limits = constraints->joint_velocity_limits;
+  up.use_u_limits = constraints->joint_torque_limits;
+  up.barrier = constraints->barrier; up.fraction_rate = constraints->fraction_to_boundary_rate;
+  void *d_model = nullptr, *d_prob = nullptr;
+  if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&d_prob, sizeof(UnProblem)) != hipSuccess) {
+    set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
+  }
+  h->allocs.push_back(d_model); h->allocs.push_back(d_prob);
+  if (hipMemcpyAsync(d_model, &dm, sizeof(dm), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(d_prob, &up, sizeof(up), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess) {
+    set_last_error("hipMemcpy failed"); return fail(IDOCP_E_DEVICE);
+  }
+  B.model = static_cast<const DevModel*>(d_model);
+  B.prob = static_cast<const UnProblem*>(d_prob);
+  // the reference constructor ends with initConstraints() (unocp_solver.cpp:47)
+  UnLaunch<7>::initConstraints(B, batch, N, h->stream);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("initConstraints launch failed"); return fail(IDOCP_E_DEVICE); }
+  *out = h;
+  return IDOCP_OK;
+}
+
+void idocp_unocp_destroy(idocp_unocp_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int setSolutionImpl(idocp_unocp_t* h, const char* name, const double* values, int per_instance) {
+  if (!h || !name || !values) return IDOCP_E_ARG;
+  FieldRef f;
+  const std::string n(name);
+  if (!(n == "q" || n == "v" || n == "a" || n == "u") || !solField(n, h->nv, f)) {
+    set_last_error("invalid arugment: name must be q, v, a, or u!");
+    return IDOCP_E_ARG;
+  }
+  int rc = setDevice(h); if (rc) return rc;
+  const size_t cnt = (size_t)(per_instance ? h->batch : 1) * f.dim;
+  HIP_TRY(hipMemcpyAsync(h->d_tmp, values, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  fillField(h->B.sol, L7::SOL, f.offset, f.dim, h->N + 1, h->batch, h->d_tmp, per_instance, h->stream);
+  UnLaunch<7>::initConstraints(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_unocp_set_solution(idocp_unocp_t* h, const char* name, const double* value) { return setSolutionImpl(h, name, value, 0); }
+int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name, const double* values) { return setSolutionImpl(h, name, values, 1); }
+
+int idocp_unocp_init_constraints(idocp_unocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::initConstraints(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+int idocp_unocp_update_solution_device(idocp_unocp_t* h, double t, const double* d_q, const double* d_v) {
+  if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  (void)t;   // ConfigurationSpaceCost is time-invariant
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  UnLaunch<7>::linearize(h->B, h->batch, h->N, h->stream);
+  UnLaunch<7>::riccati(h->B, h->batch, h->N, d_q, d_v, h->stream);
+  UnLaunch<7>::expand(h->B, h->batch, h->N, h->stream);
+  UnLaunch<7>::integrate(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  h->has_direction = true;
+  return IDOCP_OK;
+}
+
+static int statusOf(idocp_unocp_t* h) {
+  std::vector<int> st(h->batch);
+  HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->batch; ++b)
+    if (st[b] != 0) { set_last_error("Riccati: Qaa not positive definite (instance " + std::to_string(b) + ")"); return st[b]; }
+  return IDOCP_OK;
+}
+
+int idocp_unocp_synchronize(idocp_unocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+void* idocp_unocp_stream(idocp_unocp_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int idocp_unocp_update_solution(idocp_unocp_t* h, double t, const double* q, const double* v, int line_search) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * h->model.nq, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * h->model.nv, hipMemcpyHostToDevice, h->stream));
+  rc = idocp_unocp_update_solution_device(h, t, h->d_q0, h->d_v0);
+  if (rc) return rc;
+  return statusOf(h);
+}
+
+int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q, const double* d_v) {
+  if (!h) return IDOCP_E_ARG;
+  (void)t; (void)d_q; (void)d_v;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::linearize(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+int idocp_unocp_launch_riccati(idocp_unocp_t* h, const double* d_q, const double* d_v) {
+  if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::riccati(h->B, h->batch, h->N, d_q, d_v, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+int idocp_unocp_launch_expand(idocp_unocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::expand(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+int idocp_unocp_launch_integrate(idocp_unocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::integrate(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+
+int idocp_unocp_compute_kkt_residual(idocp_unocp_t* h, double t, const double* q, const double* v) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  (void)t;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::residual(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_unocp_kkt_error(idocp_unocp_t* h, double* kkt_error) {
+  if (!h || !kkt_error) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(kkt_error, h->B.err, sizeof(double) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+static int getRecords(idocp_unocp_t* h, const double* base, const char* name, int instance, double* out, bool direction) {
+  if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  std::string n(name);
+  if (direction) { if (n.size() < 2 || n[0] != 'd') return IDOCP_E_ARG; n = n.substr(1); }
+  FieldRef f;
+  if (!solField(n, h->nv, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  int rc = setDevice(h); if (rc) return rc;
+  const size_t nst = h->N + f.nstages_extra;
+  return copyRecords(h, base + (size_t)instance * (h->N + 1) * L7::SOL, L7::SOL, nst, f.offset, f.dim, out);
+}
+int idocp_unocp_get_solution(idocp_unocp_t* h, const char* name, int instance, double* out) {
+  return getRecords(h, h ? h->B.sol : nullptr, name, instance, out, false);
+}
+int idocp_unocp_get_direction(idocp_unocp_t* h, const char* name, int instance, double* out) {
+  return getRecords(h, h ? h->B.dir : nullptr, name, instance, out, true);
+}
+
+int idocp_unocp_get_step_sizes(idocp_unocp_t* h, double* primal, double* dual) {
+  if (!h || !primal || !dual) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  std::vector<double> st((size_t)h->batch * 2);
+  HIP_TRY(hipMemcpyAsync(st.data(), h->B.step, sizeof(double) * st.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->batch; ++b) { primal[b] = st[2 * b]; dual[b] = st[2 * b + 1]; }
+  return IDOCP_OK;
+}
+
+int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s, double* K, double* k) {
+  if (!h || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  const int nv = h->nv, nx = 2 * nv, N = h->N;
+  std::vector<double> ric((size_t)(N + 1) * L7::RIC), gain((size_t)N * L7::GAIN);
+  HIP_TRY(hipMemcpyAsync(ric.data(), h->B.ric + (size_t)instance * (N + 1) * L7::RIC, ric.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(gain.data(), h->B.gain + (size_t)instance * N * L7::GAIN, gain.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i <= N; ++i) {
+    const double* r = &ric[(size_t)i * L7::RIC];
+    if (P) {
+      double* Pm = P + (size_t)i * nx * nx;
+      for (int c = 0; c < nv; ++c) for (int rr = 0; rr < nv; ++rr) {
+        Pm[c * nx + rr] = r[L7::R_PQQ + c * nv + rr];              // Pqq
+        Pm[(nv + c) * nx + rr] = r[L7::R_PQV + c * nv + rr];       // Pqv
+        Pm[c * nx + nv + rr] = r[L7::R_PQV + rr * nv + c];         // Pvq = Pqv^T
+        Pm[(nv + c) * nx + nv + rr] = r[L7::R_PVV + c * nv + rr];  // Pvv
+      }
+    }
+    if (s) { std::memcpy(s + (size_t)i * nx, r + L7::R_SQ, sizeof(double) * nv); std::memcpy(s + (size_t)i * nx + nv, r + L7::R_SV, sizeof(double) * nv); }
+    if (i < N) {
+      const double* g = &gain[(size_t)i * L7::GAIN];
+      if (K) std::memcpy(K + (size_t)i * nv * nx, g + L7::G_K, sizeof(double) * nv * nx);
+      if (k) std::memcpy(k + (size_t)i * nv, g + L7::G_k, sizeof(double) * nv);
+    }
+  }
+  return IDOCP_OK;
+}
+
+int idocp_unocp_dimc(const idocp_unocp_t* h) {
+  if (!h) return 0;
+  return h->nv * 2 * ((h->cons.joint_position_limits ? 1 : 0) + (h->cons.joint_velocity_limits ? 1 : 0) + (h->cons.joint_torque_limits ? 1 : 0));
+}
+
+// [N][dimc] with the enabled components in the reference's order; rows that are
+// not valid at a stage (constraints_data.hpp:18-42) read 0.
+int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance, double* slack, double* dual) {
+  if (!h || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  const int nv = h->nv, N = h->N, dimc = idocp_unocp_dimc(h);
+  std::vector<double> sl((size_t)N * L7::CON), du((size_t)N * L7::CON);
+  HIP_TRY(hipMemcpyAsync(sl.data(), h->B.slack + (size_t)instance * N * L7::CON, sl.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * N * L7::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int use[3] = {h->cons.joint_position_limits, h->cons.joint_velocity_limits, h->cons.joint_torque_limits};
+  for (int i = 0; i < N; ++i) {
+    int off = 0;
+    for (int c = 0; c < 6; ++c) {
+      if (!use[c / 2]) continue;
+      const bool valid = (c < 2) ? i >= 2 : ((c < 4) ? i >= 1 : true);
+      for (int r = 0; r < nv; ++r) {
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * L7::CON + c * nv + r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * L7::CON + c * nv + r] : 0.0;
+      }
+      off += nv;
+    }
+  }
+  return IDOCP_OK;
+}
+
+int idocp_rnea_derivatives(const idocp_model_t* model, int n, const double* q, const double* v, const double* a,
+                           double* tau, double* dtau_dq, double* dtau_dv, double* dtau_da, int device) {
+  if (!model || n <= 0 || !q || !v || !a || !tau || !dtau_dq || !dtau_dv || !dtau_da) return IDOCP_E_ARG;
+  if (!isRevoluteChain(*model, 7)) { set_last_error("idocp_rnea_derivatives: 7-dof revolute chain only in this build"); return IDOCP_E_UNSUPPORTED; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_last_error("no HIP device available"); return IDOCP_E_DEVICE; }
+  HIP_TRY(hipSetDevice(device));
+  const int nv = model->nv;
+  DevModel dm; toDevModel(*model, dm);
+  DevModel* d_m; double *d_q, *d_v, *d_a, *d_tau, *d_dq, *d_dv, *d_da;
+  HIP_TRY(hipMalloc((void**)&d_m, sizeof(dm)));
+  HIP_TRY(hipMalloc((void**)&d_q, sizeof(double) * n * nv)); HIP_TRY(hipMalloc((void**)&d_v, sizeof(double) * n * nv));
+  HIP_TRY(hipMalloc((void**)&d_a, sizeof(double) * n * nv)); HIP_TRY(hipMalloc((void**)&d_tau, sizeof(double) * n * nv));
+  HIP_TRY(hipMalloc((void**)&d_dq, sizeof(double) * n * nv * nv)); HIP_TRY(hipMalloc((void**)&d_dv, sizeof(double) * n * nv * nv));
+  HIP_TRY(hipMalloc((void**)&d_da, sizeof(double) * n * nv * nv));
+  HIP_TRY(hipMemcpy(d_m, &dm, sizeof(dm), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * n * nv, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_v, v, sizeof(double) * n * nv, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_a, a, sizeof(double) * n * nv, hipMemcpyHostToDevice));
+  UnLaunch<7>::rneaDerivatives(d_m, n, d_q, d_v, d_a, d_tau, d_dq, d_dv, d_da, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(tau, d_tau, sizeof(double) * n * nv, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dtau_dq, d_dq, sizeof(double) * n * nv * nv, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dtau_dv, d_dv, sizeof(double) * n * nv * nv, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dtau_da, d_da, sizeof(double) * n * nv * nv, hipMemcpyDeviceToHost));
+  (void)hipFree(d_m); (void)hipFree(d_q); (void)hipFree(d_v); (void)hipFree(d_a); (void)hipFree(d_tau);
+  (void)hipFree(d_dq); (void)hipFree(d_dv); (void)hipFree(d_da);
+  return IDOCP_OK;
+}
+
+}  // extern "C"

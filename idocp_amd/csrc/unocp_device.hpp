@@ -1,0 +1,78 @@
+// Device data layout + kernel parameter block of the fixed-base (UnOCP) path.
+//
+// HBM layout.  Every per-stage quantity of every OCP
+// instance lives in ONE horizon-batched array of fixed-stride records,
+//     record(b, i) = base + (b * (N+1) + i) * STRIDE        (FP64)
+// with STRIDE rounded up to 16 doubles (128 B = one L2 line) so that the lane
+// group that owns a stage reads/writes its record with whole-line, coalesced
+// accesses.  Matrices inside a record are column-major like the reference's
+// Eigen blocks.
+#ifndef IDOCP_UNOCP_DEVICE_HPP_
+#define IDOCP_UNOCP_DEVICE_HPP_
+
+#include "dev_rbd.hpp"
+
+namespace idocp_dev {
+
+__host__ __device__ constexpr int roundUp16(int n) { return (n + 15) / 16 * 16; }
+
+template <int NV>
+struct UnLayout {
+  // solution record  (SplitSolution, include/idocp/ocp/split_solution.hxx:10-31)
+  static constexpr int S_LMD = 0, S_GMM = NV, S_Q = 2 * NV, S_V = 3 * NV, S_A = 4 * NV, S_U = 5 * NV, S_BETA = 6 * NV;
+  static constexpr int SOL = roundUp16(7 * NV);
+  // direction record (SplitDirection, split_direction.hxx:8-23): same field order with d-prefix
+  // IPM rows: [q_lower, q_upper, v_lower, v_upper, u_lower, u_upper] x NV
+  static constexpr int NC = 6 * NV;
+  static constexpr int CON = roundUp16(NC);
+  // condensed stage KKT (SplitUnKKTMatrix / SplitUnKKTResidual, split_unkkt_matrix.hxx:31-147,
+  // split_unkkt_residual.hxx:29-103); only the blocks the Riccati step reads
+  static constexpr int K_QAA = 0, K_QAQ = NV * NV, K_QAV = 2 * NV * NV, K_QQQ = 3 * NV * NV, K_QQV = 4 * NV * NV,
+                       K_QVV = 5 * NV * NV, K_FQ = 6 * NV * NV, K_FV = K_FQ + NV, K_LA = K_FV + NV, K_LQ = K_LA + NV,
+                       K_LV = K_LQ + NV;
+  static constexpr int KKT = roundUp16(6 * NV * NV + 5 * NV);
+  // inverse-dynamics cache needed by the expansion (UnconstrainedDynamics members,
+  // unconstrained_dynamics.hpp): dID/dq, dID/dv, dID/da, ID, lu, diag(Quu)
+  static constexpr int D_DQ = 0, D_DV = NV * NV, D_DA = 2 * NV * NV, D_ID = 3 * NV * NV, D_LU = D_ID + NV, D_QUU = D_LU + NV;
+  static constexpr int DYN = roundUp16(3 * NV * NV + 3 * NV);
+  // Riccati factorization (SplitRiccatiFactorization, split_riccati_factorization.hpp:15-134)
+  static constexpr int R_PQQ = 0, R_PQV = NV * NV, R_PVV = 2 * NV * NV, R_SQ = 3 * NV * NV, R_SV = R_SQ + NV;
+  static constexpr int RIC = roundUp16(3 * NV * NV + 2 * NV);
+  // LQR policy (lqr_state_feedback_policy.hpp:11-28): K (NV x 2NV col-major), k
+  static constexpr int G_K = 0, G_k = 2 * NV * NV;
+  static constexpr int GAIN = roundUp16(2 * NV * NV + NV);
+};
+
+// Problem constants (cost, limits, IPM parameters), uniform across the grid.
+struct UnProblem {
+  int N, batch;
+  double T, dt;
+  double q_ref[IDOCP_MAX_NV], v_ref[IDOCP_MAX_NV], u_ref[IDOCP_MAX_NV];
+  double q_weight[IDOCP_MAX_NV], v_weight[IDOCP_MAX_NV], a_weight[IDOCP_MAX_NV], u_weight[IDOCP_MAX_NV];
+  double qf_weight[IDOCP_MAX_NV], vf_weight[IDOCP_MAX_NV];
+  double q_min[IDOCP_MAX_NV], q_max[IDOCP_MAX_NV], v_max[IDOCP_MAX_NV], u_max[IDOCP_MAX_NV];
+  int use_q_limits, use_v_limits, use_u_limits;
+  double barrier, fraction_rate;
+};
+
+// All device pointers of one handle.
+struct UnBuffers {
+  const DevModel* model;
+  const UnProblem* prob;
+  double* sol;       // [batch][N+1][SOL]
+  double* dir;       // [batch][N+1][SOL]
+  double* slack;     // [batch][N][CON]
+  double* dual;      // [batch][N][CON]
+  double* kkt;       // [batch][N][KKT]
+  double* dyn;       // [batch][N][DYN]
+  double* ric;       // [batch][N+1][RIC]
+  double* gain;      // [batch][N][GAIN]
+  double* step_stage;  // [batch][N][2]  (primal, dual) fraction-to-boundary per stage
+  double* step;        // [batch][2]
+  double* err_stage;   // [batch][N+1]   squared KKT residual per stage
+  double* err;         // [batch]
+  int* status;         // [batch]  0 ok, 1+stage on a failed Cholesky
+};
+
+}  // namespace idocp_dev
+#endif  // IDOCP_UNOCP_DEVICE_HPP_

@@ -1,0 +1,778 @@
+// HIP kernels of the fixed-base (UnOCPSolver) hot path for gfx950 / MI355X.
+//
+// Kernel inventory (SURVEY.md section 2.3 numbering; reference loops they replace):
+//   K1  un_linearize_kernel<NV,0>  SplitUnOCP::linearizeOCP for every stage       (src/unocp/unocp_solver.cpp:78-94)
+//   S1  un_riccati_backward_kernel UnRiccatiRecursion::backwardRiccatiRecursion   (src/unocp/unriccati_recursion.cpp:39-58)
+//   S2  un_riccati_forward_kernel  ... ::forwardRiccatiRecursion                  (src/unocp/unriccati_recursion.cpp:60-65)
+//   K2  un_expand_kernel           costate/condensed/slack-dual directions + steps (src/unocp/unocp_solver.cpp:103-115)
+//   K3  un_integrate_kernel        updatePrimal / updateDual                      (src/unocp/unocp_solver.cpp:121-133)
+//   K4  un_linearize_kernel<NV,1>  computeKKTResidual + squaredNormKKTResidual     (src/unocp/unocp_solver.cpp:184-225)
+//
+// Work decomposition: wavefronts are 64 lanes wide but the
+// per-stage blocks are 7x7, so a wavefront is split into LANE GROUPS that each
+// own one stage (K1: 3*NV lanes = one tangent seed per lane; K2/K3: 8 lanes = one
+// row per lane) or one OCP instance (S1/S2: 8 lanes = one block column per lane).
+// Workgroups are a single wavefront, so the barriers below are wave-local.
+#include <hip/hip_runtime.h>
+
+#include "unocp_launch.hpp"
+
+namespace idocp_dev {
+
+#define WAVE_SYNC() __syncthreads()
+
+// One inequality row of the primal-dual interior point method
+// (include/idocp/constraints/pdipm.hxx:13-87; row formulas e.g.
+// src/constraints/joint_torques_upper_limit.cpp:48-87).  sgn = -1 lower, +1 upper:
+//   g(x) = sgn (x - lim) <= 0,  residual = g + slack,  duality = slack dual - barrier
+struct IpmRow {
+  double residual, duality;
+};
+__device__ __forceinline__ IpmRow ipmResidual(double sgn, double x, double lim, double slack, double dual, double barrier) {
+  IpmRow r;
+  r.residual = sgn * (x - lim) + slack;
+  r.duality = slack * dual - barrier;
+  return r;
+}
+
+// pdipm::FractionToBoundary for one row (pdipm.hxx:52-73)
+__device__ __forceinline__ double fractionToBoundary(double rate, double x, double dx, double cur) {
+  const double f = -rate * (x / dx);
+  return (f > 0.0 && f < 1.0 && f < cur) ? f : cur;
+}
+
+// Limit of IPM row `comp` (0..5 = q_lo,q_hi,v_lo,v_hi,u_lo,u_hi), joint k, and its sign.
+__device__ __forceinline__ double limitOf(const UnProblem* __restrict__ P, int comp, int k) {
+  switch (comp) {
+    case 0: return P->q_min[k];
+    case 1: return P->q_max[k];
+    case 2: return -P->v_max[k];
+    case 3: return P->v_max[k];
+    case 4: return -P->u_max[k];
+    default: return P->u_max[k];
+  }
+}
+// ConstraintsData(time_stage) level gating (constraints_data.hpp:18-42) + enabled components
+__device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int comp, int stage) {
+  if (comp < 2) return P->use_q_limits && stage >= 2;
+  if (comp < 4) return P->use_v_limits && stage >= 1;
+  return P->use_u_limits != 0;
+}
+
+// --------------------------------------------------------------------- K1 ----
+// MODE 0: linearize + condense -> kkt, dyn records.  MODE 1: KKT residual ->
+// err_stage.  Lane (kind, k) of a stage group differentiates ID w.r.t. q_k
+// (kind 0), v_k (kind 1) or a_k (kind 2).
+template <int NV, int MODE>
+__global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int LPS = 3 * NV;        // lanes per stage
+  constexpr int SPW = 64 / LPS;      // stages per wavefront
+  __shared__ double s_dID[SPW][3][NV * NV];
+  __shared__ double s_err[SPW][LPS];
+  __shared__ double s_cs[SPW][NV][2];
+  __shared__ double s_tau[SPW][NV];
+  __shared__ double s_dummy[NV];
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const int g0 = lane / LPS;
+  const int g = g0 < SPW ? g0 : SPW - 1;
+  const int seed = lane - g0 * LPS;
+  const int kind = (g0 < SPW) ? seed / NV : 0;
+  const int k = (g0 < SPW) ? seed - kind * NV : 0;
+  const long total = (long)P->batch * N;
+  long unit = (long)blockIdx.x * SPW + g;
+  const bool active = (g0 < SPW) && (unit < total);
+  if (unit >= total) unit = total - 1;
+  const long b = unit / N;
+  const int i = (int)(unit - b * N);
+  const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
+  const double* __restrict__ sn = s + L::SOL;
+  const double* __restrict__ slack = B.slack + unit * L::CON;
+  const double* __restrict__ dual = B.dual + unit * L::CON;
+
+  // ---- inverse dynamics with one tangent per lane (registers only) ----
+  // cos/sin of the joint angles are shared by the stage group through LDS
+  if (g0 < SPW && seed < NV) {
+    double sj, cj;
+    sincos(s[L::S_Q + seed], &sj, &cj);
+    s_cs[g][seed][0] = cj; s_cs[g][seed][1] = sj;
+  }
+  WAVE_SYNC();
+  // each lane writes its column d tau / d seed straight into the LDS copy of
+  // dID/d(q|v|a); the seed-0 lane also writes the nominal tau
+  rneaChain<NV>(B.model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, (g0 < SPW) && seed == 0, &s_tau[g][0],
+                (g0 < SPW) ? &s_dID[g][kind][k * NV] : &s_dummy[0]);
+  WAVE_SYNC();
+  double tau_d[NV], ID[NV];
+#pragma unroll
+  for (int r = 0; r < NV; ++r) { tau_d[r] = s_dID[g][kind][k * NV + r]; ID[r] = s_tau[g][r] - s[L::S_U + r]; }
+
+  // ---- torque-level rows: needed by every lane (lu_condensed couples all rows) ----
+  // UnconstrainedDynamics::linearize/condense (unconstrained_dynamics.hxx:55-94)
+  double lu_c[NV], quu[NV], lu_mine = 0.0;
+  double e_con = 0.0;   // MODE 1: squared IPM residuals owned by this lane
+#pragma unroll
+  for (int r = 0; r < NV; ++r) {
+    const double u = s[L::S_U + r];
+    double lu = dt * P->u_weight[r] * (u - P->u_ref[r]) - dt * s[L::S_BETA + r];
+    double h = dt * P->u_weight[r];
+    if (P->use_u_limits) {
+#pragma unroll
+      for (int c = 4; c < 6; ++c) {
+        const double sgn = (c == 4) ? -1.0 : 1.0;
+        const double sl = slack[c * NV + r], du = dual[c * NV + r];
+        const IpmRow row = ipmResidual(sgn, u, limitOf(P, c, r), sl, du, P->barrier);
+        lu += sgn * dt * du;
+        if (MODE == 0) {
+          lu += sgn * dt * (du * row.residual - row.duality) / sl;
+          h += dt * du / sl;
+        } else if (kind == 2 && k == r) {
+          e_con += row.residual * row.residual + row.duality * row.duality;
+        }
+      }
+    }
+    quu[r] = h;
+    lu_c[r] = lu + h * ID[r];
+    if (r == k) lu_mine = lu;
+  }
+
+  // ---- this lane's own gradient element: lq[k] / lv[k] / la[k] ----
+  // cost (configuration_space_cost.cpp:292-310), dual residual, state equation
+  // (state_equation.hxx:12-37), inverse-dynamics multiplier (unconstrained_dynamics.hxx:55-65)
+  double l, h, F = 0.0;
+  {
+    const double qk = s[L::S_Q + k], vk = s[L::S_V + k], ak = s[L::S_A + k];
+    const double lmd = s[L::S_LMD + k], gmm = s[L::S_GMM + k];
+    const double lmdn = sn[L::S_LMD + k], gmmn = sn[L::S_GMM + k];
+    double x, w, ref;
+    if (kind == 0) {
+      x = qk; w = P->q_weight[k]; ref = P->q_ref[k];
+      l = lmdn - lmd;
+      F = qk - sn[L::S_Q + k] + dt * vk;
+    } else if (kind == 1) {
+      x = vk; w = P->v_weight[k]; ref = P->v_ref[k];
+      l = dt * lmdn + gmmn - gmm;
+      F = vk + dt * ak - sn[L::S_V + k];
+    } else {
+      x = ak; w = P->a_weight[k]; ref = 0.0;
+      l = dt * gmmn;
+    }
+    l += dt * w * (x - ref);
+    h = dt * w;
+    if (kind < 2) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = 2 * kind + cc;
+        if (rowValid(P, c, i)) {
+          const double sgn = (cc == 0) ? -1.0 : 1.0;
+          const double sl = slack[c * NV + k], du = dual[c * NV + k];
+          const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, k), sl, du, P->barrier);
+          l += sgn * dt * du;
+          if (MODE == 0) {
+            l += sgn * dt * (du * row.residual - row.duality) / sl;
+            h += dt * du / sl;
+          } else {
+            e_con += row.residual * row.residual + row.duality * row.duality;
+          }
+        }
+      }
+    }
+    double dotb = 0.0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) dotb += tau_d[r] * s[L::S_BETA + r];
+    l += dt * dotb;
+  }
+
+  if (MODE == 1) {
+    // SplitUnOCP::squaredNormKKTResidual (split_unocp.hxx:164-174)
+    double e = l * l + dt * dt * e_con;
+    if (kind == 0) e += F * F + dt * dt * ID[k] * ID[k];
+    if (kind == 1) e += F * F + lu_mine * lu_mine;
+    if (g0 < SPW) s_err[g][seed] = active ? e : 0.0;
+    WAVE_SYNC();
+    if (active && seed == 0) {
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < LPS; ++j) sum += s_err[g][j];
+      B.err_stage[b * (N + 1) + i] = sum;
+    }
+    return;
+  }
+
+  // ---- condensation: l += dID^T lu_c ; Q = dID^T diag(Quu) dID + diag ----
+  double dotc = 0.0;
+#pragma unroll
+  for (int r = 0; r < NV; ++r) dotc += tau_d[r] * lu_c[r];
+  const double l_c = l + dotc;
+
+  double* __restrict__ kk = B.kkt + unit * L::KKT;
+  double* __restrict__ dy = B.dyn + unit * L::DYN;
+  double dcol[NV];
+#pragma unroll
+  for (int r = 0; r < NV; ++r) dcol[r] = quu[r] * tau_d[r];
+  // block (kind1, kind2): Q_{kind1,kind2}[:, k2] for this lane's (kind2, k2) = (kind, k)
+#pragma unroll 1
+  for (int k1kind = 0; k1kind < 3; ++k1kind) {
+    // destination offset inside the kkt record, -1 if the block is not needed
+    int dst;
+    if (k1kind == 0) dst = (kind == 0) ? L::K_QQQ : ((kind == 1) ? L::K_QQV : -1);
+    else if (k1kind == 1) dst = (kind == 1) ? L::K_QVV : -1;
+    else dst = (kind == 0) ? L::K_QAQ : ((kind == 1) ? L::K_QAV : L::K_QAA);
+    const double* __restrict__ A = &s_dID[g][k1kind][0];
+#pragma unroll
+    for (int k1 = 0; k1 < NV; ++k1) {
+      double acc = (k1kind == kind && k1 == k) ? h : 0.0;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) acc += A[k1 * NV + r] * dcol[r];
+      if (active && dst >= 0) kk[dst + k * NV + k1] = acc;
+    }
+  }
+  if (active) {
+    if (kind == 0) { kk[L::K_LQ + k] = l_c; kk[L::K_FQ + k] = F; dy[L::D_ID + k] = ID[k]; }
+    else if (kind == 1) { kk[L::K_LV + k] = l_c; kk[L::K_FV + k] = F; dy[L::D_LU + k] = lu_mine; }
+    else { kk[L::K_LA + k] = l_c; dy[L::D_QUU + k] = quu[k]; }
+#pragma unroll
+    for (int r = 0; r < NV; ++r) dy[kind * NV * NV + k * NV + r] = tau_d[r];
+  }
+}
+
+// --------------------------------------------------------------------- S1 ----
+// Backward Riccati sweep.  8 lanes per OCP instance, lane c owns column c of
+// every NV x NV block (registers); whole blocks that other lanes need (rows of
+// P, Qaa for the Cholesky, K for K^T G K) go through the group's LDS slab.
+template <int NV>
+__global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  static_assert(NV <= 8, "one block column per lane of an 8-lane group");
+  constexpr int NN = NV * NV;
+  __shared__ double sh[8][6 * NN + 8];
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const int g = lane >> 3;
+  const int c0 = lane & 7;
+  const int c = c0 < NV ? c0 : NV - 1;
+  long inst = (long)blockIdx.x * 8 + g;
+  const bool active = (inst < P->batch) && (c0 < NV);
+  if (inst >= P->batch) inst = P->batch - 1;
+  double* pqq = sh[g];
+  double* pqv = pqq + NN;
+  double* pvv = pqv + NN;
+  double* sQaa = pvv + NN;
+  double* sKq = sQaa + NN;
+  double* sKv = sKq + NN;
+  double* sla = sKv + NN;
+
+  // terminal stage: UnRiccatiRecursion::backwardRiccatiRecursionTerminal
+  // (unriccati_recursion.cpp:39-47) on TerminalOCP::linearizeOCP (terminal_ocp.hxx:50-66)
+  double Pqq[NV], Pqv[NV], Pvv[NV], sq, sv;
+  {
+    const double* __restrict__ sN = B.sol + (inst * (N + 1) + N) * L::SOL;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      Pqq[r] = (r == c) ? P->qf_weight[c] : 0.0;
+      Pqv[r] = 0.0;
+      Pvv[r] = (r == c) ? P->vf_weight[c] : 0.0;
+    }
+    sq = -(P->qf_weight[c] * (sN[L::S_Q + c] - P->q_ref[c]) - sN[L::S_LMD + c]);
+    sv = -(P->vf_weight[c] * (sN[L::S_V + c] - P->v_ref[c]) - sN[L::S_GMM + c]);
+    double* __restrict__ rr = B.ric + (inst * (N + 1) + N) * L::RIC;
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        rr[L::R_PQQ + c * NV + r] = Pqq[r]; rr[L::R_PQV + c * NV + r] = Pqv[r]; rr[L::R_PVV + c * NV + r] = Pvv[r];
+        pqq[c * NV + r] = Pqq[r]; pqv[c * NV + r] = Pqv[r]; pvv[c * NV + r] = Pvv[r];
+      }
+      rr[L::R_SQ + c] = sq; rr[L::R_SV + c] = sv;
+    }
+  }
+  WAVE_SYNC();
+
+  for (int i = N - 1; i >= 0; --i) {
+    const double* __restrict__ kk = B.kkt + (inst * N + i) * L::KKT;
+    double Qaa[NV], Qaq[NV], Qav[NV], Qqq[NV], Qqv[NV], Qvv[NV], Fq[NV], Fv[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      Qaa[r] = kk[L::K_QAA + c * NV + r]; Qaq[r] = kk[L::K_QAQ + c * NV + r]; Qav[r] = kk[L::K_QAV + c * NV + r];
+      Qqq[r] = kk[L::K_QQQ + c * NV + r]; Qqv[r] = kk[L::K_QQV + c * NV + r]; Qvv[r] = kk[L::K_QVV + c * NV + r];
+      Fq[r] = kk[L::K_FQ + r]; Fv[r] = kk[L::K_FV + r];
+    }
+    double la = kk[L::K_LA + c];
+    const double lq = kk[L::K_LQ + c], lv = kk[L::K_LV + c];
+
+    // BackwardUnRiccatiRecursionFactorizer::factorizeKKTMatrix
+    // (backward_unriccati_recursion_factorizer.hxx:29-54), column c of each block
+    double PqqFq = 0.0, PqvFv = 0.0, PqvtFq = 0.0, PvvFv = 0.0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const double PqqRow = pqq[r * NV + c];   // Pqq(c, r)
+      const double PqvRow = pqv[r * NV + c];   // Pqv(c, r) = Pqv^T(r, c)
+      const double PvvRow = pvv[r * NV + c];   // Pvv(c, r) = Pvv^T(r, c)
+      Qqq[r] += Pqq[r];
+      Qqv[r] += dt * Pqq[r] + Pqv[r];
+      Qvv[r] += dt * dt * Pqq[r] + dt * Pqv[r] + dt * PqvRow + Pvv[r];
+      Qaq[r] += dt * PqvRow;
+      Qav[r] += dt * dt * PqvRow + dt * PvvRow;
+      Qaa[r] += dt * dt * Pvv[r];
+      PqqFq += PqqRow * Fq[r];
+      PqvFv += PqvRow * Fv[r];
+      PqvtFq += Pqv[r] * Fq[r];
+      PvvFv += PvvRow * Fv[r];
+    }
+    la += dt * PqvtFq + dt * PvvFv - dt * sv;
+    // factorizeRiccatiFactorization, vector part that needs P_{i+1}
+    // (backward_unriccati_recursion_factorizer.hxx:78-86; note sv += dt*sq before lq is subtracted)
+    double sq_new = sq - PqqFq - PqvFv;
+    double sv_new = sv + dt * sq_new - PqvtFq - PvvFv;
+    sq_new -= lq;
+    sv_new -= lv;
+
+    WAVE_SYNC();          // all lanes finished reading rows of P_{i+1}
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) sQaa[c * NV + r] = Qaa[r];
+      sla[c] = la;
+    }
+    WAVE_SYNC();
+
+    // SplitUnRiccatiFactorizer::backwardRiccatiRecursion (split_unriccati_factorizer.hxx:30-46):
+    // Eigen::LLT(Qaa) done redundantly by every lane, then each lane solves its own columns.
+    double Lm[NV][NV];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      double d = sQaa[j * NV + j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) d -= Lm[j][m] * Lm[j][m];
+      ok = ok && (d > 0.0);
+      const double ljj = sqrt(d);
+      const double inv = 1.0 / ljj;
+      Lm[j][j] = ljj;
+#pragma unroll
+      for (int r = j + 1; r < NV; ++r) {
+        double t = sQaa[j * NV + r];
+#pragma unroll
+        for (int m = 0; m < j; ++m) t -= Lm[r][m] * Lm[j][m];
+        Lm[r][j] = t * inv;
+      }
+    }
+    if (!ok && active && c == 0 && B.status[inst] == 0) B.status[inst] = 1 + i;
+    double Kq[NV], Kv[NV], kv[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) { Kq[r] = -Qaq[r]; Kv[r] = -Qav[r]; kv[r] = -sla[r]; }
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {           // forward substitution  L y = b
+#pragma unroll
+      for (int m = 0; m < r; ++m) { Kq[r] -= Lm[r][m] * Kq[m]; Kv[r] -= Lm[r][m] * Kv[m]; kv[r] -= Lm[r][m] * kv[m]; }
+      const double inv = 1.0 / Lm[r][r];
+      Kq[r] *= inv; Kv[r] *= inv; kv[r] *= inv;
+    }
+#pragma unroll
+    for (int r = NV - 1; r >= 0; --r) {      // backward substitution  L^T x = y
+#pragma unroll
+      for (int m = r + 1; m < NV; ++m) { Kq[r] -= Lm[m][r] * Kq[m]; Kv[r] -= Lm[m][r] * Kv[m]; kv[r] -= Lm[m][r] * kv[m]; }
+      const double inv = 1.0 / Lm[r][r];
+      Kq[r] *= inv; Kv[r] *= inv; kv[r] *= inv;
+    }
+    // GK = Qaa K (backward_unriccati_recursion_factorizer.hxx:68)
+    double GKq[NV], GKv[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) { GKq[r] = 0.0; GKv[r] = 0.0; }
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const double a = sQaa[m * NV + r];
+        GKq[r] += a * Kq[m];
+        GKv[r] += a * Kv[m];
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) { sKq[c * NV + r] = Kq[r]; sKv[c * NV + r] = Kv[r]; }
+    }
+    WAVE_SYNC();
+    // P = F - K^T G K  (:69-74), column c
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      double a = 0.0, b2 = 0.0, d2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const double kq = sKq[j * NV + r], kvv = sKv[j * NV + r];
+        a += kq * GKq[r];
+        b2 += kq * GKv[r];
+        d2 += kvv * GKv[r];
+      }
+      Pqq[j] = Qqq[j] - a;
+      Pqv[j] = Qqv[j] - b2;
+      Pvv[j] = Qvv[j] - d2;
+    }
+    double qaqk = 0.0, qavk = 0.0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) { qaqk += Qaq[r] * kv[r]; qavk += Qav[r] * kv[r]; }
+    sq = sq_new - qaqk;                      // (:87-88)
+    sv = sv_new - qavk;
+    // preserve the symmetry of Pqq, Pvv (:76-77): needs the transposes
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) { pqq[c * NV + r] = Pqq[r]; pqv[c * NV + r] = Pqv[r]; pvv[c * NV + r] = Pvv[r]; }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      Pqq[r] = 0.5 * (Pqq[r] + pqq[r * NV + c]);
+      Pvv[r] = 0.5 * (Pvv[r] + pvv[r * NV + c]);
+    }
+    WAVE_SYNC();
+    double* __restrict__ rr = B.ric + (inst * (N + 1) + i) * L::RIC;
+    double* __restrict__ gg = B.gain + (inst * N + i) * L::GAIN;
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        pqq[c * NV + r] = Pqq[r]; pvv[c * NV + r] = Pvv[r];
+        rr[L::R_PQQ + c * NV + r] = Pqq[r]; rr[L::R_PQV + c * NV + r] = Pqv[r]; rr[L::R_PVV + c * NV + r] = Pvv[r];
+        gg[L::G_K + c * NV + r] = Kq[r]; gg[L::G_K + NN + c * NV + r] = Kv[r];
+      }
+      rr[L::R_SQ + c] = sq; rr[L::R_SV + c] = sv;
+      gg[L::G_k + c] = kv[c];
+    }
+    WAVE_SYNC();
+  }
+}
+
+// --------------------------------------------------------------------- S2 ----
+// Forward Riccati sweep: 8 lanes per instance, lane r owns row r.
+// d[0] (unocp_solver.cpp:100-101) then split_unriccati_factorizer.hxx:49-57.
+template <int NV>
+__global__ __launch_bounds__(64) void un_riccati_forward_kernel(UnBuffers B, const double* __restrict__ q0,
+                                                               const double* __restrict__ v0) {
+  using L = UnLayout<NV>;
+  constexpr int NN = NV * NV;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const int g = lane >> 3;
+  const int r0 = lane & 7;
+  const int r = r0 < NV ? r0 : NV - 1;
+  long inst = (long)blockIdx.x * 8 + g;
+  const bool active = (inst < P->batch) && (r0 < NV);
+  if (inst >= P->batch) inst = P->batch - 1;
+  const double* __restrict__ s0 = B.sol + inst * (N + 1) * L::SOL;
+  double dq = q0[inst * NV + r] - s0[L::S_Q + r];
+  double dv = v0[inst * NV + r] - s0[L::S_V + r];
+  for (int i = 0; i < N; ++i) {
+    const double* __restrict__ gg = B.gain + (inst * N + i) * L::GAIN;
+    const double* __restrict__ kk = B.kkt + (inst * N + i) * L::KKT;
+    double da = gg[L::G_k + r];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const double dqc = __shfl(dq, (g << 3) + c);
+      const double dvc = __shfl(dv, (g << 3) + c);
+      da += gg[L::G_K + c * NV + r] * dqc + gg[L::G_K + NN + c * NV + r] * dvc;
+    }
+    double* __restrict__ dd = B.dir + (inst * (N + 1) + i) * L::SOL;
+    if (active) { dd[L::S_Q + r] = dq; dd[L::S_V + r] = dv; dd[L::S_A + r] = da; }
+    const double dqn = kk[L::K_FQ + r] + dq + dt * dv;
+    const double dvn = kk[L::K_FV + r] + dv + dt * da;
+    dq = dqn; dv = dvn;
+  }
+  double* __restrict__ dd = B.dir + (inst * (N + 1) + N) * L::SOL;
+  if (active) { dd[L::S_Q + r] = dq; dd[L::S_V + r] = dv; }
+}
+
+// --------------------------------------------------------------------- K2 ----
+// Direction expansion for every stage incl. the terminal one: 8 lanes per stage,
+// lane r owns row r.  Costate direction (split_unriccati_factorizer.hxx:60-68),
+// condensed direction (unconstrained_dynamics.hxx:97-106), slack/dual directions
+// (joint_*_limit.cpp computeSlackAndDualDirection; pdipm.hxx:76-81) and the
+// fraction-to-boundary step sizes of the stage (pdipm.hxx:52-73).
+template <int NV>
+__global__ __launch_bounds__(64) void un_expand_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const int g = lane >> 3;
+  const int r0 = lane & 7;
+  const int r = r0 < NV ? r0 : NV - 1;
+  const long total = (long)P->batch * (N + 1);
+  long unit = (long)blockIdx.x * 8 + g;
+  const bool active = (unit < total) && (r0 < NV);
+  if (unit >= total) unit = total - 1;
+  const long b = unit / (N + 1);
+  const int i = (int)(unit - b * (N + 1));
+  double* __restrict__ dd = B.dir + unit * L::SOL;
+  const double* __restrict__ rr = B.ric + unit * L::RIC;
+  double dq[NV], dv[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) { dq[c] = dd[L::S_Q + c]; dv[c] = dd[L::S_V + c]; }
+  double dlmd = -rr[L::R_SQ + r], dgmm = -rr[L::R_SV + r];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    dlmd += rr[L::R_PQQ + c * NV + r] * dq[c] + rr[L::R_PQV + c * NV + r] * dv[c];
+    dgmm += rr[L::R_PQV + r * NV + c] * dq[c] + rr[L::R_PVV + c * NV + r] * dv[c];
+  }
+  if (active) { dd[L::S_LMD + r] = dlmd; dd[L::S_GMM + r] = dgmm; }
+  if (i == N) return;          // uniform within the 8-lane group; other groups continue
+
+  const long su = b * N + i;
+  const double* __restrict__ dy = B.dyn + su * L::DYN;
+  const double* __restrict__ s = B.sol + unit * L::SOL;
+  double du = dy[L::D_ID + r];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    du += dy[L::D_DQ + c * NV + r] * dq[c] + dy[L::D_DV + c * NV + r] * dv[c] + dy[L::D_DA + c * NV + r] * dd[L::S_A + c];
+  }
+  const double dbeta = (dy[L::D_LU + r] + dy[L::D_QUU + r] * du) / dt;
+  if (active) { dd[L::S_U + r] = du; dd[L::S_BETA + r] = dbeta; }
+
+  const double* __restrict__ slack = B.slack + su * L::CON;
+  const double* __restrict__ dual = B.dual + su * L::CON;
+  double ps = 1.0, ds = 1.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    if (!rowValid(P, c, i)) continue;
+    const double sgn = (c & 1) ? 1.0 : -1.0;
+    const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
+    const double dx = (c < 2) ? dq[r] : ((c < 4) ? dv[r] : du);
+    const double sl = slack[c * NV + r], dl = dual[c * NV + r];
+    const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
+    const double dslack = -sgn * dx - row.residual;
+    const double ddual = -(dl * dslack + row.duality) / sl;
+    ps = fractionToBoundary(P->fraction_rate, sl, dslack, ps);
+    ds = fractionToBoundary(P->fraction_rate, dl, ddual, ds);
+  }
+  if (!active) { ps = 1.0; ds = 1.0; }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
+    ps = fmin(ps, __shfl_xor(ps, off));
+    ds = fmin(ds, __shfl_xor(ds, off));
+  }
+  if (active && r0 == 0) { B.step_stage[su * 2] = ps; B.step_stage[su * 2 + 1] = ds; }
+}
+
+// min over the stages of one instance (unocp_solver.cpp:114-115): one wavefront per instance
+__global__ __launch_bounds__(64) void un_reduce_steps_kernel(UnBuffers B) {
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long b = blockIdx.x;
+  double ps = 1.0, ds = 1.0;
+  for (int i = threadIdx.x; i < N; i += 64) {
+    ps = fmin(ps, B.step_stage[(b * N + i) * 2]);
+    ds = fmin(ds, B.step_stage[(b * N + i) * 2 + 1]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    ps = fmin(ps, __shfl_xor(ps, off));
+    ds = fmin(ds, __shfl_xor(ds, off));
+  }
+  if (threadIdx.x == 0) { B.step[b * 2] = ps; B.step[b * 2 + 1] = ds; }
+}
+
+// --------------------------------------------------------------------- K3 ----
+// updatePrimal / updateDual (split_unocp.hxx:123-138; split_solution.hxx:215-240;
+// terminal_ocp.hxx:100-110).  dslack / ddual are recomputed from the pre-update
+// state instead of being round-tripped through HBM.
+template <int NV>
+__global__ __launch_bounds__(64) void un_integrate_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x;
+  const int g = lane >> 3;
+  const int r0 = lane & 7;
+  const int r = r0 < NV ? r0 : NV - 1;
+  const long total = (long)P->batch * (N + 1);
+  long unit = (long)blockIdx.x * 8 + g;
+  const bool active = (unit < total) && (r0 < NV);
+  if (unit >= total) unit = total - 1;
+  const long b = unit / (N + 1);
+  const int i = (int)(unit - b * (N + 1));
+  const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
+  double* __restrict__ s = B.sol + unit * L::SOL;
+  const double* __restrict__ dd = B.dir + unit * L::SOL;
+  const double q = s[L::S_Q + r], v = s[L::S_V + r], u = s[L::S_U + r];
+  const double dq = dd[L::S_Q + r], dv = dd[L::S_V + r], du = dd[L::S_U + r];
+  if (active) {
+    s[L::S_LMD + r] += ap * dd[L::S_LMD + r];
+    s[L::S_GMM + r] += ap * dd[L::S_GMM + r];
+    s[L::S_Q + r] = q + ap * dq;
+    s[L::S_V + r] = v + ap * dv;
+  }
+  if (i == N) return;
+  if (active) {
+    s[L::S_A + r] += ap * dd[L::S_A + r];
+    s[L::S_U + r] = u + ap * du;
+    s[L::S_BETA + r] += ap * dd[L::S_BETA + r];
+  }
+  const long su = b * N + i;
+  double* __restrict__ slack = B.slack + su * L::CON;
+  double* __restrict__ dual = B.dual + su * L::CON;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    if (!rowValid(P, c, i)) continue;
+    const double sgn = (c & 1) ? 1.0 : -1.0;
+    const double x = (c < 2) ? q : ((c < 4) ? v : u);
+    const double dx = (c < 2) ? dq : ((c < 4) ? dv : du);
+    const double sl = slack[c * NV + r], dl = dual[c * NV + r];
+    const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
+    const double dslack = -sgn * dx - row.residual;
+    const double ddual = -(dl * dslack + row.duality) / sl;
+    if (active) { slack[c * NV + r] = sl + ap * dslack; dual[c * NV + r] = dl + ad * ddual; }
+  }
+}
+
+// SplitUnOCP::initConstraints -> pdipm::SetSlackAndDualPositive (split_unocp.hxx:61-66; pdipm.hxx:13-23)
+template <int NV>
+__global__ __launch_bounds__(64) void un_init_constraints_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x;
+  const int g = lane >> 3;
+  const int r = lane & 7;
+  const long total = (long)P->batch * N;
+  const long su = (long)blockIdx.x * 8 + g;
+  if (su >= total || r >= NV) return;
+  const long b = su / N;
+  const int i = (int)(su - b * N);
+  const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
+  for (int c = 0; c < 6; ++c) {
+    double sl = 1.0, dl = 0.0;
+    if (rowValid(P, c, i)) {
+      const double sgn = (c & 1) ? 1.0 : -1.0;
+      const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
+      sl = -sgn * (x - limitOf(P, c, r));
+      while (sl < P->barrier) sl += P->barrier;
+      dl = P->barrier / sl;
+    }
+    B.slack[su * L::CON + c * NV + r] = sl;
+    B.dual[su * L::CON + c * NV + r] = dl;
+  }
+}
+
+// KKTError(): sum the stage errors + the terminal stage's lx (unocp_solver.cpp:190-202;
+// terminal_ocp.hxx:118-144).  One wavefront per instance.
+template <int NV>
+__global__ __launch_bounds__(64) void un_kkt_error_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long b = blockIdx.x;
+  double e = 0.0;
+  for (int i = threadIdx.x; i < N; i += 64) e += B.err_stage[b * (N + 1) + i];
+  if (threadIdx.x < NV) {
+    const int r = threadIdx.x;
+    const double* __restrict__ sN = B.sol + (b * (N + 1) + N) * L::SOL;
+    const double lq = P->qf_weight[r] * (sN[L::S_Q + r] - P->q_ref[r]) - sN[L::S_LMD + r];
+    const double lv = P->vf_weight[r] * (sN[L::S_V + r] - P->v_ref[r]) - sN[L::S_GMM + r];
+    e += lq * lq + lv * lv;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
+  if (threadIdx.x == 0) B.err[b] = sqrt(e);
+}
+
+// setSolution(name, value): write one field of every stage record (unocp_solver.cpp:157-181).
+// per_instance = 0: value[dim] broadcast; 1: value[batch][dim].
+__global__ void un_fill_field_kernel(double* __restrict__ sol, int stride, int offset, int dim, long nrec_per_inst,
+                                     long batch, const double* __restrict__ value, int per_instance) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = batch * nrec_per_inst * dim;
+  if (idx >= total) return;
+  const int e = (int)(idx % dim);
+  const long rec = idx / dim;
+  const long b = rec / nrec_per_inst;
+  sol[rec * stride + offset + e] = value[(per_instance ? b * dim : 0) + e];
+}
+
+// Stand-alone inverse dynamics + derivatives for n samples (parity tests of the
+// rigid-body layer): same lane mapping as K1.
+template <int NV>
+__global__ __launch_bounds__(64) void rnea_derivatives_kernel(const DevModel* __restrict__ model, int n,
+                                                             const double* __restrict__ q, const double* __restrict__ v,
+                                                             const double* __restrict__ a, double* __restrict__ tau,
+                                                             double* __restrict__ dq, double* __restrict__ dv,
+                                                             double* __restrict__ da) {
+  constexpr int LPS = 3 * NV, SPW = 64 / LPS;
+  const int lane = threadIdx.x;
+  const int g = lane / LPS;
+  const int seed = lane - g * LPS;
+  const int kind = seed / NV, k = seed - kind * NV;
+  const long smp = (long)blockIdx.x * SPW + g;
+  __shared__ double s_cs[SPW][NV][2];
+  const bool on = (g < SPW) && (smp < n);
+  const long sm = on ? smp : 0;
+  const int gg = g < SPW ? g : SPW - 1;
+  if (on && seed < NV) {
+    double sj, cj;
+    sincos(q[sm * NV + seed], &sj, &cj);
+    s_cs[gg][seed][0] = cj; s_cs[gg][seed][1] = sj;
+  }
+  WAVE_SYNC();
+  if (!on) return;
+  double* out = (kind == 0) ? dq : ((kind == 1) ? dv : da);
+  rneaChain<NV>(model, &s_cs[gg][0][0], v + sm * NV, a + sm * NV, kind, k, seed == 0, tau + sm * NV,
+                out + sm * NV * NV + k * NV);
+}
+
+// ------------------------------------------------------------ launchers ----
+template <int NV>
+void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t st) {
+    constexpr int SPW = 64 / (3 * NV);
+    const long units = batch * N;
+    hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+  }
+template <int NV>
+void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t st) {
+    constexpr int SPW = 64 / (3 * NV);
+    const long units = batch * N;
+    hipLaunchKernelGGL((un_linearize_kernel<NV, 1>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+    hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
+  }
+template <int NV>
+void UnLaunch<NV>::riccati(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
+    const unsigned blocks = (unsigned)((batch + 7) / 8);
+    hipLaunchKernelGGL((un_riccati_backward_kernel<NV>), dim3(blocks), dim3(64), 0, st, B);
+    hipLaunchKernelGGL((un_riccati_forward_kernel<NV>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
+  }
+template <int NV>
+void UnLaunch<NV>::expand(const UnBuffers& B, long batch, int N, hipStream_t st) {
+    const long units = batch * (N + 1);
+    hipLaunchKernelGGL((un_expand_kernel<NV>), dim3((unsigned)((units + 7) / 8)), dim3(64), 0, st, B);
+    hipLaunchKernelGGL(un_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+  }
+template <int NV>
+void UnLaunch<NV>::integrate(const UnBuffers& B, long batch, int N, hipStream_t st) {
+    const long units = batch * (N + 1);
+    hipLaunchKernelGGL((un_integrate_kernel<NV>), dim3((unsigned)((units + 7) / 8)), dim3(64), 0, st, B);
+  }
+template <int NV>
+void UnLaunch<NV>::initConstraints(const UnBuffers& B, long batch, int N, hipStream_t st) {
+    const long units = batch * N;
+    hipLaunchKernelGGL((un_init_constraints_kernel<NV>), dim3((unsigned)((units + 7) / 8)), dim3(64), 0, st, B);
+  }
+template <int NV>
+void UnLaunch<NV>::rneaDerivatives(const DevModel* m, int n, const double* q, const double* v, const double* a, double* tau,
+                              double* dq, double* dv, double* da, hipStream_t st) {
+    constexpr int SPW = 64 / (3 * NV);
+    hipLaunchKernelGGL((rnea_derivatives_kernel<NV>), dim3((unsigned)((n + SPW - 1) / SPW)), dim3(64), 0, st, m, n, q, v, a,
+                       tau, dq, dv, da);
+  }
+
+template struct UnLaunch<7>;
+
+void fillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,
+               int per_instance, hipStream_t st) {
+  const long total = batch * nrec_per_inst * dim;
+  hipLaunchKernelGGL(un_fill_field_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sol, stride, offset, dim,
+                     nrec_per_inst, batch, value, per_instance);
+}
+
+}  // namespace idocp_dev

@@ -1,0 +1,224 @@
+"""Shared test plumbing: oracle loader (ctypes), workload definitions, thin
+wrappers over the product C ABI.  The oracle is the CHECKER only."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+from idocp_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+IIWA_URDF = os.path.join(GOLDEN, "urdf", "iiwa14.urdf")
+ANYMAL_URDF = os.path.join(GOLDEN, "urdf", "anymal.urdf")
+ANYMAL_CONTACT_FRAMES = (14, 24, 34, 44)
+dp = capi.c_double_p
+
+_oracle = None
+
+
+def oracle():
+    """liboracle.so; (re)built with make if missing or stale."""
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
+        if r.returncode != 0 and not os.path.exists(path):
+            raise RuntimeError("cannot build the oracle:\n" + r.stderr)
+        lib = C.CDLL(path)
+        vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
+        PM = C.POINTER(capi.Model)
+        lib.oracle_rnea.argtypes = [PM, dp, dp, dp, dp, ci, dp]
+        lib.oracle_rnea_derivatives.argtypes = [PM, dp, dp, dp, dp, ci, dp, dp, dp]
+        lib.oracle_unocp_create.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]
+        lib.oracle_unocp_create.restype = vp
+        lib.oracle_unocp_destroy.argtypes = [vp]
+        lib.oracle_unocp_set_solution.argtypes = [vp, cs, dp]
+        lib.oracle_unocp_init_constraints.argtypes = [vp]
+        lib.oracle_unocp_update_solution.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unocp_stage.argtypes = [vp, ci, cd, dp, dp]
+        lib.oracle_unocp_compute_kkt_residual.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unocp_kkt_error.argtypes = [vp]
+        lib.oracle_unocp_kkt_error.restype = cd
+        lib.oracle_unocp_get_solution.argtypes = [vp, cs, dp]
+        lib.oracle_unocp_get_direction.argtypes = [vp, cs, dp]
+        lib.oracle_unocp_get_step_sizes.argtypes = [vp, dp, dp]
+        lib.oracle_unocp_get_riccati.argtypes = [vp, dp, dp, dp, dp]
+        lib.oracle_unocp_dimc.argtypes = [vp]
+        lib.oracle_unocp_get_constraint_data.argtypes = [vp, dp, dp]
+        lib.oracle_unocp_get_unkkt.argtypes = [vp, dp, dp]
+        lib.oracle_unocp_bench.argtypes = [vp, cd, dp, dp, ci, dp]
+        lib.oracle_unocp_bench.restype = cd
+        _oracle = lib
+    return _oracle
+
+
+def arr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+def load_golden(robot):
+    with open(os.path.join(GOLDEN, "rbd_%s.json" % robot)) as f:
+        return json.load(f)
+
+
+def iiwa14_model():
+    return capi.model_from_urdf(IIWA_URDF)
+
+
+def unocp_problem(model):
+    """Workload of examples/iiwa14/unocp_benchmark.cpp:20-43."""
+    nv = model.nv
+    cost = capi.Cost()
+    cost.set("q_ref", np.full(nv, -5.0)).set("v_ref", np.full(nv, -9.0))
+    cost.set("q_weight", np.full(nv, 10.0)).set("qf_weight", np.full(nv, 10.0))
+    cost.set("v_weight", np.full(nv, 0.1)).set("vf_weight", np.full(nv, 0.1))
+    cost.set("a_weight", np.full(nv, 0.01)).set("u_weight", np.zeros(nv))
+    cons = capi.Constraints()
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    for i in range(model.nu):           # robot.setJointEffortLimit(Constant(200))
+        model.u_max[i] = 200.0
+    return cost, cons
+
+
+SOL_FIELDS = ("q", "v", "a", "u", "lmd", "gmm", "beta")
+DIR_FIELDS = tuple("d" + f for f in SOL_FIELDS)
+
+
+def stages_of(name, N):
+    return N if name in ("a", "u", "beta", "da", "du", "dbeta") else N + 1
+
+
+class OracleUnOCP:
+    def __init__(self, model, cost, cons, T, N):
+        self.lib = oracle()
+        self.N, self.nv = N, model.nv
+        self.h = self.lib.oracle_unocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_unocp_destroy(self.h)
+            self.h = None
+
+    def set_solution(self, name, value):
+        assert self.lib.oracle_unocp_set_solution(self.h, name.encode(), P(arr(value))) == 0
+
+    def update(self, t, q, v):
+        return self.lib.oracle_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+
+    def stage(self, what, t, q, v):
+        return self.lib.oracle_unocp_stage(self.h, what, t, P(arr(q)), P(arr(v)))
+
+    def kkt_error(self, t, q, v):
+        self.lib.oracle_unocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v)))
+        return self.lib.oracle_unocp_kkt_error(self.h)
+
+    def solution(self, name):
+        out = np.zeros((self.N + 1, self.nv))
+        assert self.lib.oracle_unocp_get_solution(self.h, name.encode(), P(out)) == 0
+        return out[:stages_of(name, self.N)]
+
+    def direction(self, name):
+        out = np.zeros((self.N + 1, self.nv))
+        assert self.lib.oracle_unocp_get_direction(self.h, name.encode(), P(out)) == 0
+        return out[:stages_of(name, self.N)]
+
+    def step_sizes(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.oracle_unocp_get_step_sizes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def riccati(self):
+        nv, N = self.nv, self.N
+        Pm, s = np.zeros((N + 1, 2 * nv, 2 * nv)), np.zeros((N + 1, 2 * nv))
+        K, k = np.zeros((N, 2 * nv, nv)), np.zeros((N, nv))
+        self.lib.oracle_unocp_get_riccati(self.h, P(Pm), P(s), P(K), P(k))
+        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k      # col-major -> [row, col]
+
+    def constraint_data(self):
+        dimc = self.lib.oracle_unocp_dimc(self.h)
+        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
+        self.lib.oracle_unocp_get_constraint_data(self.h, P(sl), P(du))
+        return sl, du
+
+    def unkkt(self):
+        nv, N = self.nv, self.N
+        Q, r = np.zeros((N, 3 * nv, 3 * nv)), np.zeros((N, 5 * nv))
+        self.lib.oracle_unocp_get_unkkt(self.h, P(Q), P(r))
+        return Q.transpose(0, 2, 1), r
+
+
+class HipUnOCP:
+    """Product path through the C ABI (idocp_unocp_*)."""
+
+    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
+        self.lib = capi.lib()
+        self.N, self.nv, self.batch = N, model.nv, batch
+        h = C.c_void_p()
+        capi.check(self.lib.idocp_unocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
+                   "idocp_unocp_create")
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.idocp_unocp_destroy(self.h)
+            self.h = None
+
+    def set_solution(self, name, value):
+        capi.check(self.lib.idocp_unocp_set_solution(self.h, name.encode(), P(arr(value))), "set_solution")
+
+    def set_solution_batch(self, name, values):
+        capi.check(self.lib.idocp_unocp_set_solution_batch(self.h, name.encode(), P(arr(values))), "set_solution_batch")
+
+    def update(self, t, q, v):
+        q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
+        v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
+        return self.lib.idocp_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)), 0)
+
+    def kkt_error(self, t, q, v):
+        q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
+        v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
+        capi.check(self.lib.idocp_unocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v))), "compute_kkt_residual")
+        out = np.zeros(self.batch)
+        capi.check(self.lib.idocp_unocp_kkt_error(self.h, P(out)), "kkt_error")
+        return out
+
+    def solution(self, name, instance=0):
+        out = np.zeros((self.N + 1, self.nv))
+        capi.check(self.lib.idocp_unocp_get_solution(self.h, name.encode(), instance, P(out)), "get_solution")
+        return out[:stages_of(name, self.N)]
+
+    def direction(self, name, instance=0):
+        out = np.zeros((self.N + 1, self.nv))
+        capi.check(self.lib.idocp_unocp_get_direction(self.h, name.encode(), instance, P(out)), "get_direction")
+        return out[:stages_of(name, self.N)]
+
+    def step_sizes(self):
+        a, b = np.zeros(self.batch), np.zeros(self.batch)
+        capi.check(self.lib.idocp_unocp_get_step_sizes(self.h, P(a), P(b)), "get_step_sizes")
+        return a, b
+
+    def riccati(self, instance=0):
+        nv, N = self.nv, self.N
+        Pm, s = np.zeros((N + 1, 2 * nv, 2 * nv)), np.zeros((N + 1, 2 * nv))
+        K, k = np.zeros((N, 2 * nv, nv)), np.zeros((N, nv))
+        capi.check(self.lib.idocp_unocp_get_riccati(self.h, instance, P(Pm), P(s), P(K), P(k)), "get_riccati")
+        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
+
+    def constraint_data(self, instance=0):
+        dimc = self.lib.idocp_unocp_dimc(self.h)
+        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
+        capi.check(self.lib.idocp_unocp_get_constraint_data(self.h, instance, P(sl), P(du)), "get_constraint_data")
+        return sl, du
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))

@@ -1,0 +1,58 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/idocp_hip.h declares; argument errors follow the documented codes.  No
+compute call is made here."""
+import ctypes as C
+import os
+import re
+
+from idocp_amd import capi
+from helpers import ROOT, iiwa14_model, unocp_problem
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "idocp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(idocp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = capi.lib()
+    names = declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_and_defaults():
+    lib = capi.lib()
+    assert b"gfx950" in lib.idocp_version()
+    c = capi.Constraints()
+    lib.idocp_constraints_init(C.byref(c))
+    assert c.barrier == 1.0e-04 and c.fraction_to_boundary_rate == 0.995
+
+
+def test_create_argument_errors():
+    # UnOCPSolver's constructor checks (src/unocp/unocp_solver.cpp:33-47) surface as IDOCP_E_ARG
+    lib = capi.lib()
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    h = C.c_void_p()
+    assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), -1.0, 20, 1, 0, C.byref(h)) == -1
+    assert b"T must be positive" in lib.idocp_last_error()
+    assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 0, 1, 0, C.byref(h)) == -1
+    assert b"N must be positive" in lib.idocp_last_error()
+    assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 0, 0, C.byref(h)) == -1
+
+
+def test_no_cpu_fallback_without_gpu():
+    # On a box without a GPU creating a solver must fail loudly (IDOCP_E_DEVICE), never fall back.
+    lib = capi.lib()
+    n = C.c_int()
+    lib.idocp_device_count(C.byref(n))
+    if n.value > 0:
+        return
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    h = C.c_void_p()
+    assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 1, 0, C.byref(h)) == -3
+    assert b"no CPU fallback" in lib.idocp_last_error()
