@@ -108,6 +108,7 @@ def _proto(lib):
         ("idocp_unocp_launch_riccati", [vp, vp, vp]),
         ("idocp_unocp_launch_expand", [vp]),
         ("idocp_unocp_launch_integrate", [vp]),
+        ("idocp_unocp_launch_kernel", [vp, ci, vp, vp]),
         ("idocp_rnea_derivatives", [P(Model), ci, c_double_p, c_double_p, c_double_p, c_double_p,
                                     c_double_p, c_double_p, c_double_p, ci]),
     ]:

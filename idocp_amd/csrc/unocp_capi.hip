@@ -329,6 +329,14 @@ int idocp_unocp_launch_integrate(idocp_unocp_t* h) {
   return IDOCP_OK;
 }
 
+int idocp_unocp_launch_kernel(idocp_unocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
+  if (!h || kernel_id < 0 || kernel_id > 5 || !d_q || !d_v) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::single(kernel_id, h->B, h->batch, h->N, d_q, d_v, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+
 int idocp_unocp_compute_kkt_residual(idocp_unocp_t* h, double t, const double* q, const double* v) {
   if (!h || !q || !v) return IDOCP_E_ARG;
   (void)t;

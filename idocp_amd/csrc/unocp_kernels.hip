@@ -766,6 +766,22 @@ void UnLaunch<NV>::rneaDerivatives(const DevModel* m, int n, const double* q, co
                        tau, dq, dv, da);
   }
 
+template <int NV>
+void UnLaunch<NV>::single(int kernel_id, const UnBuffers& B, long batch, int N, const double* q0, const double* v0,
+                          hipStream_t st) {
+  constexpr int SPW = 64 / (3 * NV);
+  const unsigned inst_blocks = (unsigned)((batch + 7) / 8);
+  const unsigned stage_blocks = (unsigned)((batch * (N + 1) + 7) / 8);
+  switch (kernel_id) {
+    case 0: hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B); break;
+    case 1: hipLaunchKernelGGL((un_riccati_backward_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
+    case 2: hipLaunchKernelGGL((un_riccati_forward_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B, q0, v0); break;
+    case 3: hipLaunchKernelGGL((un_expand_kernel<NV>), dim3(stage_blocks), dim3(64), 0, st, B); break;
+    case 4: hipLaunchKernelGGL(un_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B); break;
+    default: hipLaunchKernelGGL((un_integrate_kernel<NV>), dim3(stage_blocks), dim3(64), 0, st, B); break;
+  }
+}
+
 template struct UnLaunch<7>;
 
 void fillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,

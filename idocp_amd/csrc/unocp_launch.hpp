@@ -13,6 +13,7 @@ struct UnLaunch {
   static void linearize(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void residual(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void riccati(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);
+  static void single(int kernel_id, const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);
   static void expand(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void integrate(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void initConstraints(const UnBuffers& B, long batch, int N, hipStream_t st);

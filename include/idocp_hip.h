@@ -198,6 +198,11 @@ int idocp_unocp_launch_riccati(idocp_unocp_t* h, const double* d_q,
                                const double* d_v);
 int idocp_unocp_launch_expand(idocp_unocp_t* h);
 int idocp_unocp_launch_integrate(idocp_unocp_t* h);
+/* One single kernel launch, for per-kernel timing: kernel_id 0 = K1 linearize,
+ * 1 = S1 backward Riccati, 2 = S2 forward Riccati, 3 = K2 expand, 4 = step-size
+ * reduction, 5 = K3 integrate. */
+int idocp_unocp_launch_kernel(idocp_unocp_t* h, int kernel_id, const double* d_q,
+                              const double* d_v);
 /* Inverse dynamics + its derivatives for `n` independent samples on the device
  * (Robot::RNEA / RNEADerivatives, include/idocp/robot/robot.hxx:444-500).
  * q[n][nq], v[n][nv], a[n][nv] host; tau[n][nv]; dq/dv/da[n][nv*nv] col-major. */
