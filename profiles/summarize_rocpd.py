@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 rocpd SQLite database (--kernel-trace --stats, optionally
+--pmc) into the small text summary that is committed under profiles/.
+
+usage: summarize_rocpd.py <results.db> [more.db ...] > profiles/rNN_<what>.txt
+"""
+import sqlite3
+import sys
+
+
+def main():
+    for path in sys.argv[1:]:
+        db = sqlite3.connect(path)
+        cur = db.cursor()
+        print("# %s" % path)
+        print("%-62s %7s %12s %12s %12s %12s %6s %6s %6s" %
+              ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "vgpr", "agpr", "lds"))
+        rows = cur.execute(
+            "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+            "max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name order by sum(duration) desc")
+        for name, n, tot, avg, mn, mx, vg, ag, lds in rows:
+            print("%-62s %7d %12.3f %12.2f %12.2f %12.2f %6s %6s %6s" %
+                  (name[:62], n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, vg, ag, lds))
+        try:
+            rows = list(cur.execute(
+                "select k.name, p.name, count(*), avg(e.value), sum(e.value) "
+                "from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                "join kernels k on k.id = e.event_id group by k.name, p.name"))
+        except sqlite3.Error:
+            rows = []
+        if rows:
+            print("\n%-62s %-22s %7s %16s" % ("kernel", "counter", "samples", "avg_per_dispatch"))
+            for kname, cname, n, avg, tot in rows:
+                print("%-62s %-22s %7d %16.1f" % (kname[:62], cname, n, avg))
+        print()
+
+
+if __name__ == "__main__":
+    main()
