@@ -1,0 +1,75 @@
+// idocp::Constraints + the six joint-limit components -- facade.
+// (include/idocp/constraints/constraints.hxx; src/constraints/joint_*_limit.cpp)
+// The limits themselves come from the Robot (qmin_/qmax_/vmax_/umax_ are read
+// from it by the reference constructors too); a component only switches its
+// limit family on and carries the IPM parameters.
+#ifndef IDOCP_CONSTRAINTS_HPP_
+#define IDOCP_CONSTRAINTS_HPP_
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+
+#include "idocp/robot/robot.hpp"
+#include "idocp_hip.h"
+
+namespace idocp {
+
+class ConstraintComponentBase {
+ public:
+  enum Family { Position, Velocity, Torque };
+  ConstraintComponentBase(Family f, bool upper, double barrier, double rate)
+      : family(f), upper(upper), barrier(barrier), fraction_to_boundary_rate(rate) {}
+  virtual ~ConstraintComponentBase() {}
+  Family family;
+  bool upper;
+  double barrier, fraction_to_boundary_rate;
+};
+
+#define IDOCP_LIMIT_CLASS(NAME, FAMILY, UPPER)                                                        \
+  class NAME final : public ConstraintComponentBase {                                                 \
+   public:                                                                                            \
+    explicit NAME(const Robot&, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)   \
+        : ConstraintComponentBase(FAMILY, UPPER, barrier, fraction_to_boundary_rate) {}               \
+  }
+IDOCP_LIMIT_CLASS(JointPositionLowerLimit, Position, false);
+IDOCP_LIMIT_CLASS(JointPositionUpperLimit, Position, true);
+IDOCP_LIMIT_CLASS(JointVelocityLowerLimit, Velocity, false);
+IDOCP_LIMIT_CLASS(JointVelocityUpperLimit, Velocity, true);
+IDOCP_LIMIT_CLASS(JointTorquesLowerLimit, Torque, false);
+IDOCP_LIMIT_CLASS(JointTorquesUpperLimit, Torque, true);
+#undef IDOCP_LIMIT_CLASS
+
+class Constraints {
+ public:
+  Constraints() : lo_{0, 0, 0}, hi_{0, 0, 0} {
+    idocp_constraints_init(&c_);
+    c_.joint_position_limits = c_.joint_velocity_limits = c_.joint_torque_limits = 0;
+  }
+  void push_back(const std::shared_ptr<ConstraintComponentBase>& c) {
+    (c->upper ? hi_ : lo_)[c->family] = 1;
+    c_.barrier = c->barrier;
+    c_.fraction_to_boundary_rate = c->fraction_to_boundary_rate;
+  }
+  // The kernels treat a limit family as a lower+upper pair (what
+  // JointConstraintsFactory::create() builds); a lone lower or upper limit is rejected.
+  idocp_constraints_t native() const {
+    idocp_constraints_t c = c_;
+    int* flag[3] = {&c.joint_position_limits, &c.joint_velocity_limits, &c.joint_torque_limits};
+    for (int f = 0; f < 3; ++f) {
+      if (lo_[f] != hi_[f]) {
+        std::cerr << "unsupported constraints: joint limits must come in lower/upper pairs on the HIP path" << '\n';
+        std::exit(EXIT_FAILURE);
+      }
+      *flag[f] = lo_[f];
+    }
+    return c;
+  }
+
+ private:
+  idocp_constraints_t c_;
+  int lo_[3], hi_[3];
+};
+
+}  // namespace idocp
+#endif  // IDOCP_CONSTRAINTS_HPP_

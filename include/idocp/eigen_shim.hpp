@@ -1,0 +1,69 @@
+// Minimal Eigen stand-in for the facade when Eigen3 is not installed.
+//
+// The reference's public API passes Eigen::VectorXd / Eigen::MatrixXd
+// (e.g. UnOCPSolver::updateSolution, include/idocp/unocp/unocp_solver.hpp:84).
+// If <Eigen/Core> is available it is used unchanged; otherwise this header
+// provides the tiny subset of the two types that the drivers touch: size(),
+// data(), operator[] / operator(), Zero(), Constant(), setZero(), resize().
+#ifndef IDOCP_EIGEN_SHIM_HPP_
+#define IDOCP_EIGEN_SHIM_HPP_
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define IDOCP_HAVE_EIGEN 1
+#endif
+#endif
+
+#ifndef IDOCP_HAVE_EIGEN
+#include <cassert>
+#include <ostream>
+#include <vector>
+
+namespace Eigen {
+
+class VectorXd {
+ public:
+  VectorXd() {}
+  explicit VectorXd(int n) : d_(n, 0.0) {}
+  static VectorXd Zero(int n) { return VectorXd(n); }
+  static VectorXd Constant(int n, double v) { VectorXd x(n); for (auto& e : x.d_) e = v; return x; }
+  int size() const { return (int)d_.size(); }
+  void resize(int n) { d_.assign(n, 0.0); }
+  void setZero() { for (auto& e : d_) e = 0.0; }
+  double* data() { return d_.data(); }
+  const double* data() const { return d_.data(); }
+  double& operator[](int i) { assert(i >= 0 && i < size()); return d_[i]; }
+  double operator[](int i) const { assert(i >= 0 && i < size()); return d_[i]; }
+  double& operator()(int i) { return (*this)[i]; }
+  double operator()(int i) const { return (*this)[i]; }
+  double& coeffRef(int i) { return (*this)[i]; }
+  double coeff(int i) const { return (*this)[i]; }
+  VectorXd operator-(const VectorXd& o) const { assert(size() == o.size()); VectorXd r(size()); for (int i = 0; i < size(); ++i) r[i] = d_[i] - o.d_[i]; return r; }
+  VectorXd operator+(const VectorXd& o) const { assert(size() == o.size()); VectorXd r(size()); for (int i = 0; i < size(); ++i) r[i] = d_[i] + o.d_[i]; return r; }
+ private:
+  std::vector<double> d_;
+};
+inline std::ostream& operator<<(std::ostream& os, const VectorXd& v) { for (int i = 0; i < v.size(); ++i) os << (i ? " " : "") << v[i]; return os; }
+
+class MatrixXd {   // column-major
+ public:
+  MatrixXd() : r_(0), c_(0) {}
+  MatrixXd(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
+  static MatrixXd Zero(int r, int c) { return MatrixXd(r, c); }
+  int rows() const { return r_; }
+  int cols() const { return c_; }
+  void resize(int r, int c) { r_ = r; c_ = c; d_.assign((size_t)r * c, 0.0); }
+  void setZero() { for (auto& e : d_) e = 0.0; }
+  double* data() { return d_.data(); }
+  const double* data() const { return d_.data(); }
+  double& operator()(int i, int j) { assert(i >= 0 && i < r_ && j >= 0 && j < c_); return d_[(size_t)j * r_ + i]; }
+  double operator()(int i, int j) const { assert(i >= 0 && i < r_ && j >= 0 && j < c_); return d_[(size_t)j * r_ + i]; }
+ private:
+  int r_, c_;
+  std::vector<double> d_;
+};
+
+}  // namespace Eigen
+#endif  // !IDOCP_HAVE_EIGEN
+#endif  // IDOCP_EIGEN_SHIM_HPP_

@@ -1,0 +1,69 @@
+// idocp::Robot -- facade over the C ABI (include/idocp_hip.h).
+// Mirrors the part of the reference class the drivers of the hot path use
+// (include/idocp/robot/robot.hpp:26; src/robot/robot.cpp:8-85,113-170).
+#ifndef IDOCP_ROBOT_HPP_
+#define IDOCP_ROBOT_HPP_
+
+#include <cstdlib>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "idocp/eigen_shim.hpp"
+#include "idocp_hip.h"
+
+namespace idocp {
+
+class Robot {
+ public:
+  // Robot(path_to_urdf) / Robot(path_to_urdf, contact_frames): errors follow the
+  // reference convention -- message on stderr, std::exit(EXIT_FAILURE).
+  explicit Robot(const std::string& path_to_urdf, const std::vector<int>& contact_frames = {}) {
+    const int rc = idocp_model_from_urdf(path_to_urdf.c_str(), contact_frames.empty() ? nullptr : contact_frames.data(),
+                                         (int)contact_frames.size(), &model_);
+    if (rc != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+  }
+  Robot() : model_() {}
+
+  int dimq() const { return model_.nq; }
+  int dimv() const { return model_.nv; }
+  int dimu() const { return model_.nu; }
+  int dim_passive() const { return model_.has_floating_base ? 6 : 0; }
+  int max_dimf() const { return 3 * model_.ncontacts; }
+  bool hasFloatingBase() const { return model_.has_floating_base != 0; }
+  int maxPointContacts() const { return model_.ncontacts; }
+  double totalWeight() const { return -model_.total_mass * model_.gravity[2]; }
+
+  Eigen::VectorXd jointEffortLimit() const { return get(model_.u_max); }
+  Eigen::VectorXd jointVelocityLimit() const { return get(model_.v_max); }
+  Eigen::VectorXd lowerJointPositionLimit() const { return get(model_.q_min); }
+  Eigen::VectorXd upperJointPositionLimit() const { return get(model_.q_max); }
+  void setJointEffortLimit(const Eigen::VectorXd& v) { set(model_.u_max, v, "invalid size of joint_effort_limit"); }
+  void setJointVelocityLimit(const Eigen::VectorXd& v) { set(model_.v_max, v, "invalid size of joint_velocity_limit"); }
+  void setLowerJointPositionLimit(const Eigen::VectorXd& v) { set(model_.q_min, v, "invalid size of lower_joint_position_limit"); }
+  void setUpperJointPositionLimit(const Eigen::VectorXd& v) { set(model_.q_max, v, "invalid size of upper_joint_position_limit"); }
+
+  const idocp_model_t& model() const { return model_; }
+
+ private:
+  idocp_model_t model_;
+  Eigen::VectorXd get(const double* p) const {
+    Eigen::VectorXd v(model_.nu);
+    for (int i = 0; i < model_.nu; ++i) v[i] = p[i];
+    return v;
+  }
+  void set(double* p, const Eigen::VectorXd& v, const char* msg) {
+    if (v.size() != model_.nu) {   // robot.cpp:113-170: throw -> catch -> exit
+      std::cerr << msg << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    for (int i = 0; i < model_.nu; ++i) p[i] = v[i];
+  }
+};
+
+}  // namespace idocp
+#endif  // IDOCP_ROBOT_HPP_

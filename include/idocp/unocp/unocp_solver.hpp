@@ -1,0 +1,114 @@
+// idocp::UnOCPSolver -- drop-in facade over the HIP path.
+//
+// Same constructor signature and methods as the reference class
+// (include/idocp/unocp/unocp_solver.hpp:25-188; src/unocp/unocp_solver.cpp).
+// Every method forwards to the C ABI (include/idocp_hip.h); the arithmetic runs
+// in the HIP kernels.  `nthreads` is accepted for source compatibility and
+// ignored (the GPU replaces the OpenMP team).  Argument errors: message on
+// stderr + std::exit(EXIT_FAILURE), like the reference.
+#ifndef IDOCP_UNOCP_SOLVER_HPP_
+#define IDOCP_UNOCP_SOLVER_HPP_
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "idocp/constraints/constraints.hpp"
+#include "idocp/cost/cost_function.hpp"
+#include "idocp/eigen_shim.hpp"
+#include "idocp/robot/robot.hpp"
+#include "idocp_hip.h"
+
+namespace idocp {
+
+// fixed-base subset of include/idocp/ocp/split_solution.hxx:10-31
+struct SplitSolution {
+  Eigen::VectorXd lmd, gmm, q, v, a, u, beta;
+};
+
+class UnOCPSolver {
+ public:
+  UnOCPSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
+              const double T, const int N, const int nthreads = 1, const int device = 0)
+      : robot_(robot), N_(N), h_(nullptr) {
+    (void)nthreads;
+    const idocp_cost_t c = cost->native();
+    const idocp_constraints_t k = constraints->native();
+    check(idocp_unocp_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    cache_.resize(N + 1);
+  }
+  ~UnOCPSolver() { idocp_unocp_destroy(h_); }
+  UnOCPSolver(const UnOCPSolver&) = delete;
+  UnOCPSolver& operator=(const UnOCPSolver&) = delete;
+
+  void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
+
+  void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    check(idocp_unocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
+  }
+
+  const SplitSolution& getSolution(const int stage) {
+    SplitSolution& s = cache_.at(stage);
+    const char* names[7] = {"lmd", "gmm", "q", "v", "a", "u", "beta"};
+    Eigen::VectorXd* dst[7] = {&s.lmd, &s.gmm, &s.q, &s.v, &s.a, &s.u, &s.beta};
+    for (int f = 0; f < 7; ++f) {
+      const bool terminal_only = (f < 4);
+      if (stage == N_ && !terminal_only) { dst[f]->resize(robot_.dimv()); continue; }
+      const std::vector<Eigen::VectorXd> all = getSolution(names[f]);
+      *dst[f] = all[stage];
+    }
+    return s;
+  }
+
+  std::vector<Eigen::VectorXd> getSolution(const std::string& name) const {
+    const int dim = robot_.dimv();
+    const bool per_stage = (name == "a" || name == "u" || name == "beta");
+    const int n = per_stage ? N_ : N_ + 1;
+    std::vector<double> buf((size_t)(N_ + 1) * dim);
+    check(idocp_unocp_get_solution(h_, name.c_str(), 0, buf.data()));
+    std::vector<Eigen::VectorXd> out(n, Eigen::VectorXd(dim));
+    for (int i = 0; i < n; ++i) for (int j = 0; j < dim; ++j) out[i][j] = buf[(size_t)i * dim + j];
+    return out;
+  }
+
+  // The reference leaves this unimplemented for the Un path (unocp_solver.cpp:144-154);
+  // here it returns the acceleration gains Kq, Kv of the LQR policy da = K dx + k.
+  void getStateFeedbackGain(const int time_stage, Eigen::MatrixXd& Kq, Eigen::MatrixXd& Kv) const {
+    const int nv = robot_.dimv();
+    std::vector<double> K((size_t)N_ * nv * 2 * nv);
+    check(idocp_unocp_get_riccati(h_, 0, nullptr, nullptr, K.data(), nullptr));
+    Kq.resize(nv, nv); Kv.resize(nv, nv);
+    const double* Ki = &K[(size_t)time_stage * nv * 2 * nv];
+    for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) { Kq(r, c) = Ki[c * nv + r]; Kv(r, c) = Ki[(nv + c) * nv + r]; }
+  }
+
+  void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_unocp_set_solution(h_, name.c_str(), value.data())); }
+  void clearLineSearchFilter() {}
+
+  double KKTError() {
+    double e = 0;
+    check(idocp_unocp_kkt_error(h_, &e));
+    return e;
+  }
+  void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    check(idocp_unocp_compute_kkt_residual(h_, t, q.data(), v.data()));
+  }
+  idocp_unocp_t* handle() { return h_; }
+
+ private:
+  Robot robot_;
+  int N_;
+  idocp_unocp_t* h_;
+  std::vector<SplitSolution> cache_;
+  static void check(int rc) {
+    if (rc != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+  }
+};
+
+}  // namespace idocp
+#endif  // IDOCP_UNOCP_SOLVER_HPP_
