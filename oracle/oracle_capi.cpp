@@ -46,6 +46,59 @@ int oracle_rnea_derivatives(const idocp_model_t* m, const double* q, const doubl
   return 0;
 }
 
+// Contact-path rigid-body routines for golden tests.  All outputs col-major.
+// C[3nc], dCdq/dCdv/dCda[3nc x nv], frames: p[nc][3], R[nc][9], v[nc][6], a[nc][6],
+// vdq/adq/adv/ada [nc][6 x nv], MJtJinv[(nv+3nc)^2]
+int oracle_contact_kinematics(const idocp_model_t* m, const double* q, const double* v, const double* a,
+                              const double* contact_points, double time_step, double* C, double* dCdq, double* dCdv,
+                              double* dCda, double* fp, double* fR, double* fv, double* fa, double* vdq, double* adq,
+                              double* adv, double* ada, double* MJtJinv) {
+  Robot r(*m);
+  const int nv = m->nv, nc = m->ncontacts;
+  Mat Q = toVec(q, m->nq), V = toVec(v, nv), A = toVec(a, nv);
+  r.updateKinematics(Q, V, A);
+  std::vector<bool> act(nc, true); std::vector<Mat> cp;
+  for (int c = 0; c < nc; ++c) cp.push_back(toVec(contact_points + 3 * c, 3));
+  Mat Cm, Dq, Dv, Da;
+  r.computeBaumgarteResidual(act, time_step, cp, Cm);
+  r.computeBaumgarteDerivatives(act, time_step, Dq, Dv, Da);
+  std::memcpy(C, Cm.d.data(), sizeof(double) * 3 * nc);
+  std::memcpy(dCdq, Dq.d.data(), sizeof(double) * 3 * nc * nv);
+  std::memcpy(dCdv, Dv.d.data(), sizeof(double) * 3 * nc * nv);
+  std::memcpy(dCda, Da.d.data(), sizeof(double) * 3 * nc * nv);
+  for (int c = 0; c < nc; ++c) {
+    r.contactFrame(c, fp + 3 * c, fR + 9 * c, fv + 6 * c, fa + 6 * c);
+    Mat a1, a2, a3, a4;
+    r.frameDerivatives(c, a1, a2, a3, a4);
+    const size_t n = (size_t)6 * nv;
+    std::memcpy(vdq + c * n, a1.d.data(), sizeof(double) * n); std::memcpy(adq + c * n, a2.d.data(), sizeof(double) * n);
+    std::memcpy(adv + c * n, a3.d.data(), sizeof(double) * n); std::memcpy(ada + c * n, a4.d.data(), sizeof(double) * n);
+  }
+  if (MJtJinv) {
+    Mat dq, dv, Mm, out;
+    r.RNEADerivatives(Q, V, A, dq, dv, Mm);
+    Robot::computeMJtJinv(Mm, Da, out);
+    std::memcpy(MJtJinv, out.d.data(), sizeof(double) * out.size());
+  }
+  return 0;
+}
+
+// Lie operations: q_int = q (+) dv ; diff = q1 (-) q ; J0 = d diff / d q (ARG0), J1 = d diff / d q1 (ARG1)
+int oracle_lie_ops(const idocp_model_t* m, const double* q, const double* q1, const double* dv, double* q_int,
+                   double* diff, double* J0, double* J1) {
+  Robot r(*m);
+  Mat Q = toVec(q, m->nq), Q1 = toVec(q1, m->nq), DV = toVec(dv, m->nv), out, d, j0, j1;
+  r.integrateConfiguration(Q, DV, 1.0, out);
+  r.subtractConfiguration(Q1, Q, d);
+  r.dSubtractdConfigurationMinus(Q1, Q, j0);
+  r.dSubtractdConfigurationPlus(Q1, Q, j1);
+  std::memcpy(q_int, out.d.data(), sizeof(double) * m->nq);
+  std::memcpy(diff, d.d.data(), sizeof(double) * m->nv);
+  std::memcpy(J0, j0.d.data(), sizeof(double) * m->nv * m->nv);
+  std::memcpy(J1, j1.d.data(), sizeof(double) * m->nv * m->nv);
+  return 0;
+}
+
 // ---- UnOCPSolver ---------------------------------------------------------
 void* oracle_unocp_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k,
                           double T, int N) {

@@ -272,3 +272,349 @@ void Robot::RNEADerivatives(const Mat& q, const Mat& v, const Mat& a, Mat& dq, M
 }
 
 }  // namespace oracle
+
+// ======================================================================= contact
+namespace oracle {
+
+static void actInvMotion(const double* R, const double* p, const double* m, double* out) {
+  // SE3::actInv on a motion: lin = R^T (v - p x w), ang = R^T w
+  double pxw[3]; cross3(p, m + 3, pxw);
+  double t[3] = {m[0] - pxw[0], m[1] - pxw[1], m[2] - pxw[2]};
+  for (int i = 0; i < 3; ++i) {
+    out[i] = R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2];
+    out[3 + i] = R[i] * m[3] + R[3 + i] * m[4] + R[6 + i] * m[5];
+  }
+}
+
+void Robot::updateKinematics(const Mat& q, const Mat& v, const Mat& a) {
+  const int n = m_.njoints, nv = m_.nv;
+  if ((int)kMi_.size() != n) { kMi_.resize(n); kS_ = Mat(6, nv); kv_.assign(n, Mat(6)); ka_.assign(n, Mat(6)); }
+  for (int i = 0; i < n; ++i) {
+    const int pa = m_.parent[i];
+    SE3 li; jointPlacement(i, q, li);
+    if (pa >= 0) {
+      matmul3(kMi_[pa].R, li.R, kMi_[i].R);
+      double t[3]; matvec3(kMi_[pa].R, li.p, t);
+      for (int k = 0; k < 3; ++k) kMi_[i].p[k] = kMi_[pa].p[k] + t[k];
+    } else {
+      kMi_[i] = li;
+    }
+    const double* R = kMi_[i].R; const double* p = kMi_[i].p;
+    const int iv = m_.idx_v[i];
+    const int ndof = m_.jtype[i] == IDOCP_JOINT_FREEFLYER ? 6 : 1;
+    if (ndof == 1) {
+      double w[3], l[3]; matvec3(R, m_.axis[i], w); cross3(p, w, l);
+      for (int k = 0; k < 3; ++k) { kS_(k, iv) = l[k]; kS_(3 + k, iv) = w[k]; }
+    } else {
+      for (int c = 0; c < 3; ++c) {
+        double e[3] = {0, 0, 0}; e[c] = 1; double Re[3], l[3];
+        matvec3(R, e, Re); cross3(p, Re, l);
+        for (int k = 0; k < 3; ++k) {
+          kS_(k, iv + c) = Re[k]; kS_(3 + k, iv + c) = 0;
+          kS_(k, iv + 3 + c) = l[k]; kS_(3 + k, iv + 3 + c) = Re[k];
+        }
+      }
+    }
+    double vJ[6] = {0, 0, 0, 0, 0, 0}, aJ[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < ndof; ++c) for (int k = 0; k < 6; ++k) {
+      vJ[k] += kS_(k, iv + c) * v[iv + c]; aJ[k] += kS_(k, iv + c) * a[iv + c];
+    }
+    for (int k = 0; k < 6; ++k) kv_[i][k] = (pa >= 0 ? kv_[pa][k] : 0.0) + vJ[k];
+    double vxvJ[6]; crossMM(kv_[i].d.data(), vJ, vxvJ);
+    for (int k = 0; k < 6; ++k) ka_[i][k] = (pa >= 0 ? ka_[pa][k] : 0.0) + aJ[k] + vxvJ[k];
+  }
+}
+
+static void framePlacement(const idocp_model_t& m, const std::vector<SE3>& kMi, int c, double* R, double* p) {
+  const int j = m.contact_joint[c];
+  matmul3(kMi[j].R, m.contact_R[c], R);
+  double t[3]; matvec3(kMi[j].R, m.contact_p[c], t);
+  for (int k = 0; k < 3; ++k) p[k] = kMi[j].p[k] + t[k];
+}
+
+void Robot::contactFrame(int c, double* p_world, double* R_world, double* v_local, double* a_local) const {
+  double R[9], p[3];
+  framePlacement(m_, kMi_, c, R, p);
+  const int j = m_.contact_joint[c];
+  if (p_world) std::memcpy(p_world, p, sizeof(p));
+  if (R_world) std::memcpy(R_world, R, sizeof(R));
+  if (v_local) actInvMotion(R, p, kv_[j].d.data(), v_local);
+  if (a_local) actInvMotion(R, p, ka_[j].d.data(), a_local);
+}
+
+// Derivatives of the frame's LOCAL spatial velocity / acceleration.  With
+// V-, A- the world-frame velocity / acceleration of the parent of column j's
+// joint, S_j the world-frame column, ov_i/oa_i those of the frame's joint:
+//   dv/dq_j = fXo (V- x S_j)
+//   da/dq_j = fXo (A- x S_j + (V- x S_j) x (ov_i - V-))
+//   da/dv_j = fXo (ov_J(j) x S_j + V- x S_j - ov_i x S_j)
+//   da/da_j = fXo S_j                       (= LOCAL frame Jacobian)
+// for j in the support of the frame, 0 otherwise (Carpentier & Mansard 2018,
+// as implemented by pinocchio::getFrame{Velocity,Acceleration}Derivatives).
+void Robot::frameDerivatives(int c, Mat& vdq, Mat& adq, Mat& adv, Mat& ada) const {
+  const int nv = m_.nv, ji = m_.contact_joint[c];
+  vdq = Mat(6, nv); adq = Mat(6, nv); adv = Mat(6, nv); ada = Mat(6, nv);
+  double R[9], p[3];
+  framePlacement(m_, kMi_, c, R, p);
+  const double zero[6] = {0, 0, 0, 0, 0, 0};
+  for (int col = 0; col < nv; ++col) {
+    const int jc = dof_joint_[col];
+    if (!in_subtree_[jc][ji]) continue;
+    const int pa = m_.parent[jc];
+    const double* Vm = pa >= 0 ? kv_[pa].d.data() : zero;
+    const double* Am = pa >= 0 ? ka_[pa].d.data() : zero;
+    const double* Sj = &kS_.d[6 * col];
+    const double* ovi = kv_[ji].d.data();
+    double VxS[6], AxS[6], d[6], t[6], JxS[6], ixS[6], w[6];
+    crossMM(Vm, Sj, VxS); crossMM(Am, Sj, AxS);
+    for (int k = 0; k < 6; ++k) d[k] = ovi[k] - Vm[k];
+    crossMM(VxS, d, t);
+    crossMM(kv_[jc].d.data(), Sj, JxS); crossMM(ovi, Sj, ixS);
+    actInvMotion(R, p, VxS, &vdq.d[6 * col]);
+    for (int k = 0; k < 6; ++k) w[k] = AxS[k] + t[k];
+    actInvMotion(R, p, w, &adq.d[6 * col]);
+    for (int k = 0; k < 6; ++k) w[k] = JxS[k] + VxS[k] - ixS[k];
+    actInvMotion(R, p, w, &adv.d[6 * col]);
+    actInvMotion(R, p, Sj, &ada.d[6 * col]);
+  }
+}
+
+void Robot::computeBaumgarteResidual(const std::vector<bool>& active, double time_step,
+                                     const std::vector<Mat>& contact_points, Mat& C) const {
+  int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
+  C = Mat(3 * na);
+  const double wv = 2 / time_step, wp = 1 / (time_step * time_step);
+  int row = 0;
+  for (int c = 0; c < m_.ncontacts; ++c) {
+    if (!active[c]) continue;
+    double p[3], v[6], a[6], wxv[3];
+    contactFrame(c, p, nullptr, v, a);
+    cross3(v + 3, v, wxv);                       // classical acceleration = a_lin + w x v_lin
+    for (int k = 0; k < 3; ++k)
+      C[row + k] = (a[k] + wxv[k]) + wv * v[k] + wp * (p[k] - contact_points[c][k]);
+    row += 3;
+  }
+}
+
+void Robot::computeBaumgarteDerivatives(const std::vector<bool>& active, double time_step, Mat& dCdq, Mat& dCdv,
+                                        Mat& dCda) const {
+  const int nv = m_.nv;
+  int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
+  dCdq = Mat(3 * na, nv); dCdv = Mat(3 * na, nv); dCda = Mat(3 * na, nv);
+  const double wv = 2 / time_step, wp = 1 / (time_step * time_step);
+  int row = 0;
+  for (int c = 0; c < m_.ncontacts; ++c) {
+    if (!active[c]) continue;
+    Mat vdq, adq, adv, J;
+    frameDerivatives(c, vdq, adq, adv, J);
+    double R[9], v[6], Sl[9], Sw[9];
+    contactFrame(c, nullptr, R, v, nullptr);
+    skew(v, Sl); skew(v + 3, Sw);
+    // point_contact.hxx:117-143, term by term (note the reference ADDS v_linear_skew * d(omega))
+    for (int col = 0; col < nv; ++col) {
+      for (int r = 0; r < 3; ++r) {
+        double dq = adq(r, col), dv = adv(r, col);
+        for (int k = 0; k < 3; ++k) {
+          dq += Sw[3 * r + k] * vdq(k, col) + Sl[3 * r + k] * vdq(3 + k, col);
+          dv += Sw[3 * r + k] * J(k, col) + Sl[3 * r + k] * J(3 + k, col);
+        }
+        dq += wv * vdq(r, col);
+        dv += wv * J(r, col);
+        double RJ = 0; for (int k = 0; k < 3; ++k) RJ += R[3 * r + k] * J(k, col);
+        dq += wp * RJ;
+        dCdq(row + r, col) = dq; dCdv(row + r, col) = dv; dCda(row + r, col) = J(r, col);
+      }
+    }
+    row += 3;
+  }
+}
+
+void Robot::computeMJtJinv(const Mat& M, const Mat& J, Mat& out) {
+  // robot.hxx:576-615.  pinocchio's sparse U D U^T factorisation of M is replaced
+  // by a dense Cholesky (same solution); the block algebra follows the reference.
+  const int nv = M.r, nf = J.r;
+  LLT lltM; lltM.compute(M);
+  Mat Minv = lltM.solve(Mat::Identity(nv));
+  out = Mat(nv + nf, nv + nf);
+  if (nf == 0) { out.setBlock(0, 0, Minv); return; }
+  Mat JMinvJt = J * Minv * J.t();
+  LLT llt; llt.compute(JMinvJt);
+  Mat bottomRight = llt.solve(-1.0 * Mat::Identity(nf));          // -(J Minv Jt)^-1
+  Mat bottomLeft = J * Minv;
+  Mat topRight = bottomLeft.t() * (-bottomRight);
+  Mat topLeft = Minv - topRight * bottomLeft;
+  out.setBlock(0, 0, topLeft); out.setBlock(0, nv, topRight);
+  out.setBlock(nv, 0, topRight.t()); out.setBlock(nv, nv, bottomRight);
+}
+
+// ------------------------------------------------------------- Lie group ----
+static void exp3(const double* w, double* R) {
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  double a, b;                      // R = I + a K + b K^2
+  if (t < 1e-8) { a = 1 - t2 / 6; b = 0.5 - t2 / 24; } else { a = std::sin(t) / t; b = (1 - std::cos(t)) / t2; }
+  double K[9]; skew(w, K);
+  double K2[9]; matmul3(K, K, K2);
+  for (int i = 0; i < 9; ++i) R[i] = a * K[i] + b * K2[i];
+  R[0] += 1; R[4] += 1; R[8] += 1;
+}
+static void log3(const double* R, double* w, double* theta) {
+  double c = (R[0] + R[4] + R[8] - 1) / 2; c = c > 1 ? 1 : (c < -1 ? -1 : c);
+  const double t = std::acos(c);
+  const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const double s = t < 1e-8 ? 0.5 + t * t / 12 : t / (2 * std::sin(t));
+  for (int k = 0; k < 3; ++k) w[k] = s * ax[k];
+  *theta = t;
+}
+static void Vmat(const double* w, double* V) {   // exp6: t = V(w) v
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  double b, c;
+  if (t < 1e-8) { b = 0.5 - t2 / 24; c = 1.0 / 6 - t2 / 120; } else { b = (1 - std::cos(t)) / t2; c = (t - std::sin(t)) / (t2 * t); }
+  double K[9]; skew(w, K);
+  double K2[9]; matmul3(K, K, K2);
+  for (int i = 0; i < 9; ++i) V[i] = b * K[i] + c * K2[i];
+  V[0] += 1; V[4] += 1; V[8] += 1;
+}
+static void VmatInv(const double* w, double* Vi) {   // log6: v = V(w)^-1 t
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  double beta;
+  if (t < 1e-4) beta = 1.0 / 12 + t2 / 720; else beta = 1 / t2 - std::sin(t) / (2 * t * (1 - std::cos(t)));
+  double K[9]; skew(w, K);
+  double K2[9]; matmul3(K, K, K2);
+  for (int i = 0; i < 9; ++i) Vi[i] = -0.5 * K[i] + beta * K2[i];
+  Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
+}
+static void RtoQuat(const double* R, double* q) {   // xyzw
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { const double s = std::sqrt(tr + 1) * 2; q[3] = s / 4; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const double s = std::sqrt(1 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = s / 4; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { const double s = std::sqrt(1 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = s / 4; q[2] = (R[5] + R[7]) / s; }
+  else { const double s = std::sqrt(1 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = s / 4; }
+}
+
+// pinocchio::integrate (SpecialEuclideanOperation<3>: q (+) v = q * exp6(v))
+void Robot::integrateConfiguration(const Mat& q, const Mat& v, double length, Mat& q_out) const {
+  Mat out = q;
+  for (int i = 0; i < m_.njoints; ++i) {
+    const int iq = m_.idx_q[i], iv = m_.idx_v[i];
+    if (m_.jtype[i] == IDOCP_JOINT_REVOLUTE) { out[iq] = q[iq] + length * v[iv]; continue; }
+    double R[9], w[3], vl[3], V[9], E[9], t[3], Rt[3], Rn[9], qt[4];
+    quatToR(&q.d[iq + 3], R);
+    for (int k = 0; k < 3; ++k) { vl[k] = length * v[iv + k]; w[k] = length * v[iv + 3 + k]; }
+    Vmat(w, V); matvec3(V, vl, t); matvec3(R, t, Rt);
+    exp3(w, E); matmul3(R, E, Rn); RtoQuat(Rn, qt);
+    // keep the quaternion on the same hemisphere as the input
+    double dotq = 0; for (int k = 0; k < 4; ++k) dotq += qt[k] * q[iq + 3 + k];
+    const double sgn = dotq < 0 ? -1.0 : 1.0;
+    double nrm = 0; for (int k = 0; k < 4; ++k) nrm += qt[k] * qt[k];
+    nrm = std::sqrt(nrm);
+    for (int k = 0; k < 3; ++k) out[iq + k] = q[iq + k] + Rt[k];
+    for (int k = 0; k < 4; ++k) out[iq + 3 + k] = sgn * qt[k] / nrm;
+  }
+  q_out = out;
+}
+
+// M = M_minus^-1 M_plus of the free-flyer (R, p)
+static void relativePlacement(const double* qm, const double* qp, double* R, double* p) {
+  double Rm[9], Rp[9], Rmt[9], d[3];
+  quatToR(qm + 3, Rm); quatToR(qp + 3, Rp);
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rmt[3 * r + s] = Rm[3 * s + r];
+  matmul3(Rmt, Rp, R);
+  for (int k = 0; k < 3; ++k) d[k] = qp[k] - qm[k];
+  matvec3(Rmt, d, p);
+}
+
+// pinocchio::difference(q_minus, q_plus) = log6(q_minus^-1 q_plus)
+void Robot::subtractConfiguration(const Mat& q_plus, const Mat& q_minus, Mat& diff) const {
+  diff = Mat(m_.nv);
+  for (int i = 0; i < m_.njoints; ++i) {
+    const int iq = m_.idx_q[i], iv = m_.idx_v[i];
+    if (m_.jtype[i] == IDOCP_JOINT_REVOLUTE) { diff[iv] = q_plus[iq] - q_minus[iq]; continue; }
+    double R[9], p[3], w[3], th, Vi[9], vl[3];
+    relativePlacement(&q_minus.d[iq], &q_plus.d[iq], R, p);
+    log3(R, w, &th); VmatInv(w, Vi); matvec3(Vi, p, vl);
+    for (int k = 0; k < 3; ++k) { diff[iv + k] = vl[k]; diff[iv + 3 + k] = w[k]; }
+  }
+}
+
+// Jlog6 of pinocchio's explog.hpp: derivative of log6(M exp6(d)) w.r.t. d.
+static void Jlog6(const double* R, const double* p, Mat& J) {
+  double w[3], t;
+  log3(R, w, &t);
+  const double t2 = t * t;
+  double alpha, diag;
+  if (t < 1e-4) { alpha = 1.0 / 12 + t2 / 720; diag = 0.5 * (2 - t2 / 6); }
+  else { const double st = std::sin(t), ct = std::cos(t), st_1mct = st / (1 - ct); alpha = 1 / t2 - st_1mct / (2 * t); diag = 0.5 * t * st_1mct; }
+  double A[9];
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) A[3 * r + s] = alpha * w[r] * w[s];
+  A[0] += diag; A[4] += diag; A[8] += diag;
+  double Kw[9]; skew(w, Kw);
+  for (int k = 0; k < 9; ++k) A[k] += 0.5 * Kw[k];
+  double beta, bdot;
+  if (t < 1e-4) { beta = 1.0 / 12 + t2 / 720; bdot = 1.0 / 360; }
+  else {
+    const double tinv = 1 / t, t2inv = tinv * tinv, st = std::sin(t), ct = std::cos(t), inv22ct = 1 / (2 * (1 - ct));
+    beta = t2inv - st * tinv * inv22ct;
+    bdot = -2 * t2inv * t2inv + (1 + st * tinv) * t2inv * inv22ct;
+  }
+  const double wTp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  double v3[3];
+  for (int k = 0; k < 3; ++k) v3[k] = (bdot * wTp) * w[k] - (t2 * bdot + 2 * beta) * p[k];
+  double Cm[9];
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Cm[3 * r + s] = v3[r] * w[s] + beta * w[r] * p[s];
+  Cm[0] += wTp * beta; Cm[4] += wTp * beta; Cm[8] += wTp * beta;
+  double Kp[9]; skew(p, Kp);
+  for (int k = 0; k < 9; ++k) Cm[k] += 0.5 * Kp[k];
+  double B[9]; matmul3(Cm, A, B);
+  J = Mat(6, 6);
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) { J(r, s) = A[3 * r + s]; J(3 + r, 3 + s) = A[3 * r + s]; J(r, 3 + s) = B[3 * r + s]; }
+}
+
+// pinocchio::dDifference(q_minus, q_plus, ARG1)
+void Robot::dSubtractdConfigurationPlus(const Mat& q_plus, const Mat& q_minus, Mat& J) const {
+  J = Mat::Identity(m_.nv);
+  for (int i = 0; i < m_.njoints; ++i) {
+    if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
+    double R[9], p[3]; Mat J6;
+    relativePlacement(&q_minus.d[m_.idx_q[i]], &q_plus.d[m_.idx_q[i]], R, p);
+    Jlog6(R, p, J6);
+    J.setBlock(m_.idx_v[i], m_.idx_v[i], J6);
+  }
+}
+
+// pinocchio::dDifference(q_minus, q_plus, ARG0) = -Jlog6(M) Ad(M^-1),  M = q_minus^-1 q_plus
+void Robot::dSubtractdConfigurationMinus(const Mat& q_plus, const Mat& q_minus, Mat& J) const {
+  J = -1.0 * Mat::Identity(m_.nv);
+  for (int i = 0; i < m_.njoints; ++i) {
+    if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
+    double R[9], p[3]; Mat J6;
+    relativePlacement(&q_minus.d[m_.idx_q[i]], &q_plus.d[m_.idx_q[i]], R, p);
+    Jlog6(R, p, J6);
+    // action matrix of M^-1 = (R^T, -R^T p): [[R^T, [-R^T p]x R^T],[0, R^T]]
+    double Rt[9], mp[3], K[9], KRt[9];
+    for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
+    matvec3(Rt, p, mp); for (int k = 0; k < 3; ++k) mp[k] = -mp[k];
+    skew(mp, K); matmul3(K, Rt, KRt);
+    Mat Ad(6, 6);
+    for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) { Ad(r, s) = Rt[3 * r + s]; Ad(3 + r, 3 + s) = Rt[3 * r + s]; Ad(r, 3 + s) = KRt[3 * r + s]; }
+    J.setBlock(m_.idx_v[i], m_.idx_v[i], -1.0 * (J6 * Ad));
+  }
+}
+
+// Robot::dSubtractdConfigurationInverse (robot.hxx:151-163): block-triangular 6x6 inverse
+void Robot::dSubtractdConfigurationInverse(const Mat& J, Mat& Jinv) {
+  auto inv3 = [](const Mat& A) {
+    Mat I(3, 3);
+    const double det = A(0, 0) * (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(1, 2) * A(2, 0)) +
+                       A(0, 2) * (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0));
+    I(0, 0) = (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) / det; I(0, 1) = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) / det; I(0, 2) = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) / det;
+    I(1, 0) = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) / det; I(1, 1) = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) / det; I(1, 2) = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) / det;
+    I(2, 0) = (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0)) / det; I(2, 1) = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) / det; I(2, 2) = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) / det;
+    return I;
+  };
+  Jinv = Mat(6, 6);
+  Mat TLi = inv3(J.block(0, 0, 3, 3)), BRi = inv3(J.block(3, 3, 3, 3));
+  Jinv.setBlock(0, 0, TLi); Jinv.setBlock(3, 3, BRi);
+  Jinv.setBlock(0, 3, -1.0 * (TLi * (J.block(0, 3, 3, 3) * BRi)));
+}
+
+}  // namespace oracle

@@ -318,6 +318,224 @@ def generate(name, urdf, contact_frames, nsamples, seed):
     return M
 
 
+
+
+# ===================================================================== contact
+# Frame kinematics + Baumgarte constraint + Lie-group operations of the floating
+# base, for the contact path.  Exact pieces come
+# from the complex step; the Baumgarte derivative is then ASSEMBLED with the
+# reference's own formula (include/idocp/robot/point_contact.hxx:91-144).
+def frame_kinematics(M, q, v, a, dq_seed=None):
+    """Per contact frame: world position p, world rotation R, LOCAL spatial
+    velocity (lin, ang) and LOCAL spatial acceleration (no gravity)."""
+    n = M["njoints"]
+    cplx = dq_seed is not None or np.iscomplexobj(v) or np.iscomplexobj(a)
+    dt = complex if cplx else float
+    Rw, pw, vl, vw, al, aw = ([None] * n for _ in range(6))
+    for i in range(n):
+        R, p = joint_transform(M, i, q, dq_seed)
+        pa = M["parent"][i]
+        iv = M["idx_v"][i]
+        if pa < 0:
+            Rw[i], pw[i] = R, p
+            pvl, pvw, pal, paw = (np.zeros(3, dt) for _ in range(4))
+        else:
+            Rw[i], pw[i] = Rw[pa] @ R, pw[pa] + Rw[pa] @ p
+            pvl, pvw, pal, paw = vl[pa], vw[pa], al[pa], aw[pa]
+        w_ = R.T @ pvw
+        v_ = R.T @ (pvl + np.cross(pvw, p))
+        aw_ = R.T @ paw
+        al_ = R.T @ (pal + np.cross(paw, p))
+        if M["jtype"][i] == 0:
+            ax = M["axis"][i]
+            vJl, vJw = np.zeros(3, dt), ax * v[iv]
+            aJl, aJw = np.zeros(3, dt), ax * a[iv]
+        else:
+            vJl, vJw = np.array(v[iv:iv + 3], dt), np.array(v[iv + 3:iv + 6], dt)
+            aJl, aJw = np.array(a[iv:iv + 3], dt), np.array(a[iv + 3:iv + 6], dt)
+        vl[i], vw[i] = v_ + vJl, w_ + vJw
+        al[i] = al_ + aJl + np.cross(vw[i], vJl) + np.cross(vl[i], vJw)
+        aw[i] = aw_ + aJw + np.cross(vw[i], vJw)
+    out = []
+    for (fid, jid, Rc, pc) in M["contacts"]:
+        Rf = Rw[jid] @ Rc
+        pf = pw[jid] + Rw[jid] @ pc
+        # motion transform joint frame -> contact frame
+        fw = Rc.T @ vw[jid]
+        fv = Rc.T @ (vl[jid] + np.cross(vw[jid], pc))
+        faw = Rc.T @ aw[jid]
+        fal = Rc.T @ (al[jid] + np.cross(aw[jid], pc))
+        out.append(dict(p=pf, R=Rf, v=np.concatenate([fv, fw]), a=np.concatenate([fal, faw])))
+    return out
+
+
+def frame_derivatives(M, q, v, a):
+    """frame_v_partial_dq, a_partial_dq, a_partial_dv, a_partial_da (6 x nv, LOCAL)
+    and d p_world / dq (3 x nv) per contact, by complex step."""
+    h, nv, nc = 1e-30, M["nv"], len(M["contacts"])
+    vdq, adq, adv, ada = (np.zeros((nc, 6, nv)) for _ in range(4))
+    pdq = np.zeros((nc, 3, nv))
+    for k in range(nv):
+        e = np.zeros(nv, complex)
+        e[k] = 1j * h
+        fq = frame_kinematics(M, q, v, a, dq_seed=e)
+        fv = frame_kinematics(M, q, v + e, a)
+        fa = frame_kinematics(M, q, v, a + e)
+        for c in range(nc):
+            vdq[c, :, k] = fq[c]["v"].imag / h
+            adq[c, :, k] = fq[c]["a"].imag / h
+            pdq[c, :, k] = fq[c]["p"].imag / h
+            adv[c, :, k] = fv[c]["a"].imag / h
+            ada[c, :, k] = fa[c]["a"].imag / h
+    return vdq, adq, adv, ada, pdq
+
+
+def baumgarte(M, q, v, a, contact_points, time_step):
+    """Residual and derivatives exactly as PointContact computes them
+    (point_contact.hxx:67-87, 91-144)."""
+    fk = frame_kinematics(M, q, v, a)
+    vdq, adq, adv, ada, pdq = frame_derivatives(M, q, v, a)
+    nc, nv = len(fk), M["nv"]
+    C = np.zeros(3 * nc)
+    dCdq, dCdv, dCda = (np.zeros((3 * nc, nv)) for _ in range(3))
+    wv, wp = 2.0 / time_step, 1.0 / (time_step * time_step)
+    for c in range(nc):
+        vl, vw = fk[c]["v"][:3].real, fk[c]["v"][3:].real
+        acl = fk[c]["a"][:3].real + np.cross(vw, vl)            # classical acceleration, LOCAL
+        C[3 * c:3 * c + 3] = acl + wv * vl + wp * (fk[c]["p"].real - contact_points[c])
+        J = ada[c]                                              # LOCAL frame Jacobian
+        dq = adq[c, :3] + skew(vw) @ vdq[c, :3] + skew(vl) @ vdq[c, 3:]
+        dv = adv[c, :3] + skew(vw) @ J[:3] + skew(vl) @ J[3:]
+        dq = dq + wv * vdq[c, :3]
+        dv = dv + wv * ada[c, :3]
+        dq = dq + wp * (fk[c]["R"].real @ J[:3])
+        dCdq[3 * c:3 * c + 3], dCdv[3 * c:3 * c + 3], dCda[3 * c:3 * c + 3] = dq, dv, ada[c, :3]
+    return C, dCdq, dCdv, dCda, fk, (vdq, adq, adv, ada, pdq)
+
+
+# ---- SE(3) x R^n Lie operations (pinocchio::integrate / difference / dDifference)
+def exp3(w):
+    t = np.linalg.norm(w)
+    K = skew(w)
+    if t < 1e-10:
+        return np.eye(3) + K + 0.5 * K @ K
+    return np.eye(3) + np.sin(t) / t * K + (1 - np.cos(t)) / (t * t) * K @ K
+
+
+def log3(R):
+    c = min(1.0, max(-1.0, (np.trace(R) - 1) / 2))
+    t = np.arccos(c)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if t < 1e-10:
+        return 0.5 * w
+    return t / (2 * np.sin(t)) * w
+
+
+def Vmat(w):
+    t = np.linalg.norm(w)
+    K = skew(w)
+    if t < 1e-10:
+        return np.eye(3) + 0.5 * K + K @ K / 6
+    return np.eye(3) + (1 - np.cos(t)) / (t * t) * K + (t - np.sin(t)) / (t ** 3) * K @ K
+
+
+def R_to_quat(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = np.sqrt(max(0.0, 1 + R[0, 0] - R[1, 1] - R[2, 2])) / 2
+    y = np.sqrt(max(0.0, 1 - R[0, 0] + R[1, 1] - R[2, 2])) / 2
+    z = np.sqrt(max(0.0, 1 - R[0, 0] - R[1, 1] + R[2, 2])) / 2
+    x, y, z = np.copysign(x, R[2, 1] - R[1, 2]), np.copysign(y, R[0, 2] - R[2, 0]), np.copysign(z, R[1, 0] - R[0, 1])
+    return np.array([x, y, z, w])
+
+
+def integrate(M, q, dv):
+    """q (+) dv with the free-flyer convention of pinocchio (SE3 exponential)."""
+    out = np.array(q, float)
+    for i in range(M["njoints"]):
+        iq, iv = M["idx_q"][i], M["idx_v"][i]
+        if M["jtype"][i] == 0:
+            out[iq] = q[iq] + dv[iv]
+        else:
+            R = quat_to_R(*q[iq + 3:iq + 7])
+            vl, w = dv[iv:iv + 3], dv[iv + 3:iv + 6]
+            out[iq:iq + 3] = q[iq:iq + 3] + R @ (Vmat(w) @ vl)
+            out[iq + 3:iq + 7] = R_to_quat(R @ exp3(w))
+    return out
+
+
+def difference(M, q0, q1):
+    """q1 (-) q0 = log(q0^{-1} q1)  (tangent at q0)."""
+    out = np.zeros(M["nv"])
+    for i in range(M["njoints"]):
+        iq, iv = M["idx_q"][i], M["idx_v"][i]
+        if M["jtype"][i] == 0:
+            out[iv] = q1[iq] - q0[iq]
+        else:
+            R0, R1 = quat_to_R(*q0[iq + 3:iq + 7]), quat_to_R(*q1[iq + 3:iq + 7])
+            R = R0.T @ R1
+            p = R0.T @ (q1[iq:iq + 3] - q0[iq:iq + 3])
+            w = log3(R)
+            out[iv:iv + 3] = np.linalg.solve(Vmat(w), p)
+            out[iv + 3:iv + 6] = w
+    return out
+
+
+def ddifference(M, q0, q1, arg):
+    """Jacobian of difference(q0, q1) w.r.t. a tangent perturbation of q0 (arg=0)
+    or q1 (arg=1), by Richardson-extrapolated central differences."""
+    nv = M["nv"]
+    J = np.zeros((nv, nv))
+
+    def f(e):
+        return difference(M, integrate(M, q0, e), q1) if arg == 0 else difference(M, q0, integrate(M, q1, e))
+
+    for k in range(nv):
+        e = np.zeros(nv)
+        d = []
+        for hh in (1e-3, 5e-4):
+            e[k] = hh
+            fp = f(e)
+            e[k] = -hh
+            fm = f(e)
+            d.append((fp - fm) / (2 * hh))
+        J[:, k] = (4 * d[1] - d[0]) / 3
+    return J
+
+
+def generate_contact(name, urdf, contact_frames, nsamples, seed):
+    M = load_model(urdf, contact_frames)
+    rng = np.random.default_rng(seed)
+    time_step = 0.05
+    samples = []
+    for s in range(nsamples):
+        q = random_q(M, rng)
+        v = rng.uniform(-1, 1, M["nv"])
+        a = rng.uniform(-1, 1, M["nv"])
+        cp = rng.uniform(-0.5, 0.5, (len(contact_frames), 3))
+        C, dCdq, dCdv, dCda, fk, (vdq, adq, adv, ada, pdq) = baumgarte(M, q, v, a, cp, time_step)
+        _, _, Mm = rnea_derivatives(M, q, v, a)
+        KKT = np.block([[Mm, dCda.T], [dCda, np.zeros((dCda.shape[0],) * 2)]])
+        q1 = integrate(M, q, rng.uniform(-0.6, 0.6, M["nv"]))
+        dvv = rng.uniform(-0.5, 0.5, M["nv"])
+        rec = dict(q=q.tolist(), v=v.tolist(), a=a.tolist(), contact_points=cp.tolist(), time_step=time_step,
+                   frame_p=[f["p"].real.tolist() for f in fk], frame_R=[f["R"].real.reshape(-1).tolist() for f in fk],
+                   frame_v=[f["v"].real.tolist() for f in fk], frame_a=[f["a"].real.tolist() for f in fk],
+                   v_partial_dq=vdq.tolist(), a_partial_dq=adq.tolist(), a_partial_dv=adv.tolist(),
+                   a_partial_da=ada.tolist(), p_partial_dq=pdq.tolist(),
+                   C=C.tolist(), dCdq=dCdq.tolist(), dCdv=dCdv.tolist(), dCda=dCda.tolist(),
+                   MJtJinv=np.linalg.inv(KKT).tolist(),
+                   q1=q1.tolist(), dv=dvv.tolist(), q_plus_dv=integrate(M, q, dvv).tolist(),
+                   q1_minus_q=difference(M, q, q1).tolist(),
+                   dDiff_arg0=ddifference(M, q, q1, 0).tolist(), dDiff_arg1=ddifference(M, q, q1, 1).tolist())
+        samples.append(rec)
+    out = dict(robot=name, samples=samples,
+               note="generated by tests/golden/gen_golden_rbd.py generate_contact (complex step / Richardson differences)")
+    with open(os.path.join(HERE, "contact_%s.json" % name), "w") as f:
+        json.dump(out, f)
+    print("contact", name, "samples", nsamples)
+
+
 if __name__ == "__main__":
     generate("iiwa14", os.path.join(HERE, "urdf", "iiwa14.urdf"), (), 6, 20240)
     generate("anymal", os.path.join(HERE, "urdf", "anymal.urdf"), (14, 24, 34, 44), 6, 20250)
+    generate_contact("anymal", os.path.join(HERE, "urdf", "anymal.urdf"), (14, 24, 34, 44), 4, 20251)

@@ -32,6 +32,8 @@ def oracle():
         PM = C.POINTER(capi.Model)
         lib.oracle_rnea.argtypes = [PM, dp, dp, dp, dp, ci, dp]
         lib.oracle_rnea_derivatives.argtypes = [PM, dp, dp, dp, dp, ci, dp, dp, dp]
+        lib.oracle_contact_kinematics.argtypes = [PM, dp, dp, dp, dp, cd] + [dp] * 13
+        lib.oracle_lie_ops.argtypes = [PM] + [dp] * 7
         lib.oracle_unocp_create.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]
         lib.oracle_unocp_create.restype = vp
         lib.oracle_unocp_destroy.argtypes = [vp]

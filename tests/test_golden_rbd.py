@@ -85,3 +85,68 @@ def test_oracle_rnea_and_derivatives_match_golden(robot, urdf, frames):
             assert rel_err(tau, s["tau_impulse"]) < 1e-13
             assert rel_err(dq.T, s["dimp_dq"]) < 1e-12
             assert rel_err(da.T, s["dimp_ddv"]) < 1e-12
+
+
+def test_oracle_contact_kinematics_baumgarte_mjtjinv_match_golden():
+    """Frame kinematics and their derivatives (pinocchio getFrame*Derivatives, LOCAL),
+    the Baumgarte residual/derivatives as PointContact assembles them, and MJtJinv."""
+    import json
+    import os
+    from helpers import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "contact_anymal.json")))
+    m = capi.model_from_urdf(ANYMAL_URDF, ANYMAL_CONTACT_FRAMES)
+    nv, nc = m.nv, m.ncontacts
+    ol = oracle()
+    for s in g["samples"]:
+        q, v, a, cp = arr(s["q"]), arr(s["v"]), arr(s["a"]), arr(s["contact_points"])
+        C = np.zeros(3 * nc)
+        dq, dv, da = (np.zeros((nv, 3 * nc)) for _ in range(3))          # col-major (3nc x nv)
+        fp, fR, fv, fa = np.zeros((nc, 3)), np.zeros((nc, 9)), np.zeros((nc, 6)), np.zeros((nc, 6))
+        vdq, adq, adv, ada = (np.zeros((nc, nv, 6)) for _ in range(4))    # col-major (6 x nv) per contact
+        K = np.zeros((nv + 3 * nc, nv + 3 * nc))
+        ol.oracle_contact_kinematics(C_byref(m), P(q), P(v), P(a), P(cp), C_double(s["time_step"]), P(C), P(dq), P(dv), P(da),
+                                     P(fp), P(fR), P(fv), P(fa), P(vdq), P(adq), P(adv), P(ada), P(K))
+        assert rel_err(fp, s["frame_p"]) < 1e-13 and rel_err(fR, s["frame_R"]) < 1e-13
+        assert rel_err(fv, s["frame_v"]) < 1e-12 and rel_err(fa, s["frame_a"]) < 1e-12
+        assert rel_err(vdq.transpose(0, 2, 1), s["v_partial_dq"]) < 1e-12
+        assert rel_err(adq.transpose(0, 2, 1), s["a_partial_dq"]) < 1e-12
+        assert rel_err(adv.transpose(0, 2, 1), s["a_partial_dv"]) < 1e-12
+        assert rel_err(ada.transpose(0, 2, 1), s["a_partial_da"]) < 1e-12
+        assert rel_err(C, s["C"]) < 1e-12
+        assert rel_err(dq.T, s["dCdq"]) < 1e-12 and rel_err(dv.T, s["dCdv"]) < 1e-12 and rel_err(da.T, s["dCda"]) < 1e-12
+        # MJtJinv: golden = dense inverse of [M J^T; J 0]; also the identity test/robot/robot_test.cpp:535-567 asserts
+        assert rel_err(K.T, s["MJtJinv"]) < 1e-9
+        Mm = np.linalg.inv(np.array(s["MJtJinv"]))
+        assert np.abs(K.T @ Mm - np.eye(nv + 3 * nc)).max() < 1e-9
+
+
+def test_oracle_lie_group_operations_match_golden():
+    """integrate / difference / dDifference (ARG0, ARG1) of SE(3) x R^12 (robot.hxx:23-163)."""
+    import json
+    import os
+    from helpers import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "contact_anymal.json")))
+    m = capi.model_from_urdf(ANYMAL_URDF, ANYMAL_CONTACT_FRAMES)
+    nv = m.nv
+    ol = oracle()
+    for s in g["samples"]:
+        q, q1, dv = arr(s["q"]), arr(s["q1"]), arr(s["dv"])
+        qi, diff, J0, J1 = np.zeros(m.nq), np.zeros(nv), np.zeros((nv, nv)), np.zeros((nv, nv))
+        ol.oracle_lie_ops(C_byref(m), P(q), P(q1), P(dv), P(qi), P(diff), P(J0), P(J1))
+        gq = arr(s["q_plus_dv"])
+        if np.dot(gq[3:7], qi[3:7]) < 0:
+            gq[3:7] *= -1                      # quaternion double cover
+        assert rel_err(qi, gq) < 1e-12
+        assert rel_err(diff, s["q1_minus_q"]) < 1e-12
+        # golden Jacobians are Richardson-extrapolated differences (~1e-9 accurate)
+        assert rel_err(J0.T, s["dDiff_arg0"]) < 1e-7 and rel_err(J1.T, s["dDiff_arg1"]) < 1e-7
+        # block-triangular structure the reference's 6x6 inverse relies on (robot.hxx:151-163)
+        assert np.abs(J1.T[3:6, 0:3]).max() < 1e-14 and np.abs(J0.T[3:6, 0:3]).max() < 1e-14
+
+
+def C_byref(x):
+    return C.byref(x)
+
+
+def C_double(x):
+    return C.c_double(x)
