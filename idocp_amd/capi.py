@@ -43,6 +43,11 @@ class Cost(C.Structure):
         ("q_weight", C.c_double * MAX_NV), ("v_weight", C.c_double * MAX_NV),
         ("a_weight", C.c_double * MAX_NV), ("u_weight", C.c_double * MAX_NV),
         ("qf_weight", C.c_double * MAX_NV), ("vf_weight", C.c_double * MAX_NV),
+        ("f_weight", (C.c_double * 3) * MAX_CONTACTS), ("f_ref", (C.c_double * 3) * MAX_CONTACTS),
+        ("use_trotting_ref", C.c_int),
+        ("t_start", C.c_double), ("t_period", C.c_double), ("step_length", C.c_double),
+        ("front_swing_knee", C.c_double), ("hip_swing_knee", C.c_double),
+        ("front_stance_knee", C.c_double), ("hip_stance_knee", C.c_double),
     ]
 
     def set(self, name, values):
@@ -57,6 +62,7 @@ class Constraints(C.Structure):
     _fields_ = [
         ("joint_position_limits", C.c_int), ("joint_velocity_limits", C.c_int),
         ("joint_torque_limits", C.c_int),
+        ("linearized_friction_cone", C.c_int), ("mu", C.c_double),
         ("barrier", C.c_double), ("fraction_to_boundary_rate", C.c_double),
     ]
 

@@ -369,5 +369,6 @@ extern "C" void idocp_cost_init(idocp_cost_t* cost) { if (cost) std::memset(cost
 extern "C" void idocp_constraints_init(idocp_constraints_t* c) {
   if (!c) return;
   c->joint_position_limits = 1; c->joint_velocity_limits = 1; c->joint_torque_limits = 1;
+  c->linearized_friction_cone = 0; c->mu = 0.7;
   c->barrier = 1.0e-04; c->fraction_to_boundary_rate = 0.995;
 }

@@ -45,6 +45,7 @@ class Constraints {
   Constraints() : lo_{0, 0, 0}, hi_{0, 0, 0} {
     idocp_constraints_init(&c_);
     c_.joint_position_limits = c_.joint_velocity_limits = c_.joint_torque_limits = 0;
+    c_.linearized_friction_cone = 0;
   }
   void push_back(const std::shared_ptr<ConstraintComponentBase>& c) {
     (c->upper ? hi_ : lo_)[c->family] = 1;

@@ -89,6 +89,15 @@ typedef struct idocp_cost {
   double u_weight[IDOCP_MAX_NV];
   double qf_weight[IDOCP_MAX_NV];
   double vf_weight[IDOCP_MAX_NV];
+  /* ContactForceCost (src/cost/contact_force_cost.cpp:153-194): per contact */
+  double f_weight[IDOCP_MAX_CONTACTS][3];
+  double f_ref[IDOCP_MAX_CONTACTS][3];
+  /* TrottingConfigurationSpaceCost (include/idocp/cost/trotting_configuration_space_cost.hpp:
+   * 126-164): when use_trotting_ref != 0, q_ref holds q_standing and the reference
+   * of stage time t is generated on the host; v_ref[0] = step_length / t_period. */
+  int use_trotting_ref;
+  double t_start, t_period, step_length;
+  double front_swing_knee, hip_swing_knee, front_stance_knee, hip_stance_knee;
 } idocp_cost_t;
 
 /*
@@ -102,6 +111,8 @@ typedef struct idocp_constraints {
   int joint_position_limits;   /* 0/1 */
   int joint_velocity_limits;   /* 0/1 */
   int joint_torque_limits;     /* 0/1 */
+  int linearized_friction_cone;/* 0/1: LinearizedFrictionCone (src/constraints/linearized_friction_cone.cpp) */
+  double mu;                          /* friction coefficient                     */
   double barrier;                     /* default 1.0e-04 */
   double fraction_to_boundary_rate;   /* default 0.995   */
 } idocp_constraints_t;

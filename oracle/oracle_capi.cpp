@@ -242,3 +242,168 @@ double oracle_unocp_bench(void* h, double t, const double* q, const double* v, i
 }
 
 }  // extern "C"
+
+// ---- OCPSolver (contact path, uniform contact status) ------------------------
+#include "ocp.hpp"
+extern "C" {
+
+void* oracle_ocp_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
+  try { return new OCPSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
+}
+void oracle_ocp_destroy(void* h) { delete static_cast<OCPSolver*>(h); }
+int oracle_ocp_set_contact_status(void* h, const int* active, const double* points) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  std::vector<int> a(active, active + s->robot.maxPointContacts());
+  s->setContactStatusUniformly(a, points);
+  return 0;
+}
+int oracle_ocp_set_solution(void* h, const char* name, const double* value) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const std::string n(name);
+  const int dim = n == "q" ? s->robot.dimq() : (n == "u" ? s->robot.dimu() : (n == "f" ? 3 : s->robot.dimv()));
+  try { s->setSolution(n, toVec(value, dim)); } catch (...) { return -1; }
+  return 0;
+}
+int oracle_ocp_init_constraints(void* h, double t) { static_cast<OCPSolver*>(h)->initConstraints(t); return 0; }
+int oracle_ocp_update_solution(void* h, double t, const double* q, const double* v) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); } catch (...) { return 1; }
+  return 0;
+}
+// 0 linearize, 1 Riccati backward+forward, 2 direction, 3 integrate
+int oracle_ocp_stage(void* h, int what, double t, const double* q, const double* v) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  Mat Q = toVec(q, s->robot.dimq()), V = toVec(v, s->robot.dimv());
+  try {
+    if (what == 0) s->linearizeOCP(t, Q);
+    else if (what == 1) { s->backwardRiccatiRecursion(); s->forwardRiccatiRecursion(Q, V); }
+    else if (what == 2) s->computeDirection();
+    else if (what == 3) s->integrateSolution();
+    else return -1;
+  } catch (...) { return 1; }
+  return 0;
+}
+int oracle_ocp_compute_kkt_residual(void* h, double t, const double* q, const double* v) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+  return 0;
+}
+double oracle_ocp_kkt_error(void* h) { return static_cast<OCPSolver*>(h)->KKTError(); }
+
+// field of every stage, padded to `stride` doubles per stage: out[(N+1)][stride].
+// solution names: q v a u f lmd gmm beta mu nu_passive ; direction names: dq dv da df du dlmd dgmm dbeta dmu dnu_passive
+// f / mu / df / dmu are reported per contact slot ([nc][3], inactive slots 0 for directions).
+int oracle_ocp_get(void* h, const char* name, int stride, double* out) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const std::string n(name);
+  const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
+  for (int i = 0; i <= s->N(); ++i) {
+    double* o = out + (size_t)i * stride;
+    const SplitSolutionC& x = s->s[i];
+    const SplitDirectionC& d = s->d[i];
+    auto put = [&](const Mat& m) { for (int k = 0; k < m.size() && k < stride; ++k) o[k] = m[k]; };
+    auto putSlots = [&](const Mat& stack, int off) {   // stacked active rows -> contact slots
+      int st = 0;
+      for (int c = 0; c < nc; ++c) if (s->contact_status.active[c]) { for (int k = 0; k < 3; ++k) o[3 * c + k] = stack[off + st + k]; st += 3; }
+    };
+    if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a); else if (n == "u") put(x.u);
+    else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
+    else if (n == "nu_passive") put(x.nu_passive);
+    else if (n == "f") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.f[c][k]; }
+    else if (n == "mu") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.mu[c][k]; }
+    else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv); else if (n == "du") put(d.du);
+    else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm); else if (n == "dnu_passive") put(d.dnu_passive);
+    else if (n == "da") { if (i < s->N()) put(d.daf.segment(0, nv)); }
+    else if (n == "dbeta") { if (i < s->N()) put(d.dbetamu.segment(0, nv)); }
+    else if (n == "df") { if (i < s->N()) putSlots(d.daf, nv); }
+    else if (n == "dmu") { if (i < s->N()) putSlots(d.dbetamu, nv); }
+    else return -1;
+  }
+  return 0;
+}
+int oracle_ocp_get_step_sizes(void* h, double* primal, double* dual) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  *primal = s->primal_step_size; *dual = s->dual_step_size; return 0;
+}
+// P[N+1][2nv*2nv] col-major, s[N+1][2nv], K[N][nu*2nv] col-major (nu x 2nv), k[N][nu]
+int oracle_ocp_get_riccati(void* h, double* P, double* sv, double* K, double* k) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const int nv = s->robot.dimv(), nx = 2 * nv, nu = s->robot.dimu();
+  for (int i = 0; i <= s->N(); ++i) {
+    const RiccatiC& r = s->riccati[i];
+    if (P) {
+      Mat Pm(nx, nx);
+      Pm.setBlock(0, 0, r.Pqq); Pm.setBlock(0, nv, r.Pqv); Pm.setBlock(nv, 0, r.Pqv.t()); Pm.setBlock(nv, nv, r.Pvv);
+      std::memcpy(P + (size_t)i * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
+    }
+    if (sv) { std::memcpy(sv + (size_t)i * nx, r.sq.d.data(), sizeof(double) * nv); std::memcpy(sv + (size_t)i * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
+    if (i < s->N()) {
+      if (K) std::memcpy(K + (size_t)i * nu * nx, s->K[i].d.data(), sizeof(double) * nu * nx);
+      if (k) std::memcpy(k + (size_t)i * nu, s->k[i].d.data(), sizeof(double) * nu);
+    }
+  }
+  return 0;
+}
+int oracle_ocp_dimc(void* h) { return static_cast<OCPSolver*>(h)->dimc(); }
+// slack / dual [N][dimc]: enabled components in order; rows invalid at a stage read 0
+int oracle_ocp_get_constraint_data(void* h, double* slack, double* dual) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const int dimc = s->dimc();
+  const idocp_constraints_t& c = s->cons;
+  const int en[7] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits,
+                     c.joint_torque_limits, c.joint_torque_limits, c.linearized_friction_cone};
+  for (int i = 0; i < s->N(); ++i) {
+    int off = 0;
+    for (int comp = 0; comp < 7; ++comp) {
+      if (!en[comp]) continue;
+      const IpmData& data = s->ipm[i][comp];
+      const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
+      for (int r = 0; r < data.slack.size(); ++r) {
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? data.slack[r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? data.dual[r] : 0.0;
+      }
+      off += data.slack.size();
+    }
+  }
+  return 0;
+}
+// condensed stage LQR data after linearize (before the Riccati sweep modifies it), col-major:
+// Qxx[2nv x 2nv], Qxu[2nv x nu], Quu[nu x nu], A[2nv x 2nv] = [Fqq Fqv; Fvq Fvv], B[2nv x nu] = [0; Fvu],
+// lx[2nv], lu[nu], Fx[2nv]
+int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Quu, double* A, double* B, double* lx,
+                             double* lu, double* Fx) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const int nv = s->robot.dimv(), nu = s->robot.dimu(), nx = 2 * nv;
+  const SplitKKTMatrixC& M = s->kkt_matrix[i];
+  const SplitKKTResidualC& R = s->kkt_residual[i];
+  std::memcpy(Qxx, M.Qxx.d.data(), sizeof(double) * nx * nx);
+  Mat qxu = M.Qxu_full.block(0, 6, nx, nu), quu = M.Quu_full.block(6, 6, nu, nu);
+  std::memcpy(Qxu, qxu.d.data(), sizeof(double) * nx * nu);
+  std::memcpy(Quu, quu.d.data(), sizeof(double) * nu * nu);
+  Mat Am(nx, nx), Bm(nx, nu);
+  // implicit parts: Fqq = I, Fqv = dt I outside the leading 6x6 blocks
+  // (backward_riccati_recursion_factorizer.hxx:66-71, 96-100)
+  Mat Fqq = Mat::Identity(nv);
+  Fqq.setBlock(0, 0, M.Fqq6);
+  Mat Fqv_full = s->stepDt() * Mat::Identity(nv);
+  Fqv_full.setBlock(0, 0, M.Fqv6);
+  Am.setBlock(0, 0, Fqq); Am.setBlock(0, nv, Fqv_full); Am.setBlock(nv, 0, M.Fvq); Am.setBlock(nv, nv, M.Fvv);
+  Bm.setBlock(nv, 0, M.Fvu);
+  std::memcpy(A, Am.d.data(), sizeof(double) * nx * nx);
+  std::memcpy(B, Bm.d.data(), sizeof(double) * nx * nu);
+  for (int r = 0; r < nv; ++r) { lx[r] = R.lq[r]; lx[nv + r] = R.lv[r]; Fx[r] = R.Fq[r]; Fx[nv + r] = R.Fv[r]; }
+  std::memcpy(lu, R.lu.d.data(), sizeof(double) * nu);
+  return 0;
+}
+double oracle_ocp_bench(void* h, double t, const double* q, const double* v, int iters, double* riccati_seconds) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  Mat Q = toVec(q, s->robot.dimq()), V = toVec(v, s->robot.dimv());
+  s->riccati_seconds = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) s->updateSolution(t, Q, V);
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (riccati_seconds) *riccati_seconds = s->riccati_seconds;
+  return el;
+}
+
+}  // extern "C"

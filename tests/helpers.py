@@ -224,3 +224,153 @@ class HipUnOCP:
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+# ------------------------------------------------------------------ contact path
+def anymal_model():
+    return capi.model_from_urdf(ANYMAL_URDF, ANYMAL_CONTACT_FRAMES)
+
+
+ANYMAL_Q_STANDING = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])
+
+
+def anymal_problem(model, trotting_ref=True):
+    """Cost / constraints of examples/anymal/anymal_trotting.cpp:33-107:
+    TrottingConfigurationSpaceCost + ContactForceCost, 6 joint limits + LinearizedFrictionCone(mu=0.7)."""
+    nv = model.nv
+    cost = capi.Cost()
+    cost.set("q_ref", ANYMAL_Q_STANDING)
+    cost.set("q_weight", np.full(nv, 10.0)).set("qf_weight", np.full(nv, 10.0))
+    vw = np.concatenate([np.ones(6), np.full(12, 0.1)])
+    aw = np.concatenate([np.full(6, 0.1), np.full(12, 0.01)])
+    cost.set("v_weight", vw).set("vf_weight", vw).set("a_weight", aw)
+    w = -model.total_mass * model.gravity[2]
+    for c in range(4):
+        for k in range(3):
+            cost.f_weight[c][k] = 0.001
+            cost.f_ref[c][k] = 0.0
+        cost.f_ref[c][2] = 0.25 * w                      # ContactForceCost::set_f_ref(robot)
+    if trotting_ref:
+        cost.use_trotting_ref = 1
+        cost.t_start, cost.t_period, cost.step_length = 0.5, 0.5, 0.15
+        cost.front_swing_knee, cost.hip_swing_knee = 1.7, 1.7
+        cost.front_stance_knee, cost.hip_stance_knee = 0.0, 0.0
+    cons = capi.Constraints()
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    cons.linearized_friction_cone = 1
+    cons.mu = 0.7
+    return cost, cons
+
+
+def _setup_oracle_ocp(lib):
+    if getattr(lib, "_ocp_ready", False):
+        return
+    vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
+    PM = C.POINTER(capi.Model)
+    lib.oracle_ocp_create.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]
+    lib.oracle_ocp_create.restype = vp
+    lib.oracle_ocp_destroy.argtypes = [vp]
+    lib.oracle_ocp_set_contact_status.argtypes = [vp, C.POINTER(ci), dp]
+    lib.oracle_ocp_set_solution.argtypes = [vp, cs, dp]
+    lib.oracle_ocp_init_constraints.argtypes = [vp, cd]
+    lib.oracle_ocp_update_solution.argtypes = [vp, cd, dp, dp]
+    lib.oracle_ocp_stage.argtypes = [vp, ci, cd, dp, dp]
+    lib.oracle_ocp_compute_kkt_residual.argtypes = [vp, cd, dp, dp]
+    lib.oracle_ocp_kkt_error.argtypes = [vp]
+    lib.oracle_ocp_kkt_error.restype = cd
+    lib.oracle_ocp_get.argtypes = [vp, cs, ci, dp]
+    lib.oracle_ocp_get_step_sizes.argtypes = [vp, dp, dp]
+    lib.oracle_ocp_get_riccati.argtypes = [vp, dp, dp, dp, dp]
+    lib.oracle_ocp_dimc.argtypes = [vp]
+    lib.oracle_ocp_get_constraint_data.argtypes = [vp, dp, dp]
+    lib.oracle_ocp_get_lqr_stage.argtypes = [vp, ci] + [dp] * 8
+    lib.oracle_ocp_bench.argtypes = [vp, cd, dp, dp, ci, dp]
+    lib.oracle_ocp_bench.restype = cd
+    lib._ocp_ready = True
+
+
+OCP_SOL_FIELDS = {"q": 19, "v": 18, "a": 18, "u": 12, "f": 12, "lmd": 18, "gmm": 18, "beta": 18, "mu": 12, "nu_passive": 6}
+OCP_DIR_FIELDS = {"dq": 18, "dv": 18, "da": 18, "du": 12, "df": 12, "dlmd": 18, "dgmm": 18, "dbeta": 18, "dmu": 12,
+                  "dnu_passive": 6}
+OCP_STAGE_ONLY = ("a", "u", "f", "beta", "mu", "nu_passive", "da", "du", "df", "dbeta", "dmu", "dnu_passive")
+
+
+class OracleOCP:
+    def __init__(self, model, cost, cons, T, N):
+        self.lib = oracle()
+        _setup_oracle_ocp(self.lib)
+        self.N, self.nv, self.nu, self.nq = N, model.nv, model.nu, model.nq
+        self.h = self.lib.oracle_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_ocp_destroy(self.h)
+            self.h = None
+
+    def set_contact_status(self, active, points):
+        a = (C.c_int * 4)(*[int(x) for x in active])
+        assert self.lib.oracle_ocp_set_contact_status(self.h, a, P(arr(points))) == 0
+
+    def set_solution(self, name, value):
+        assert self.lib.oracle_ocp_set_solution(self.h, name.encode(), P(arr(value))) == 0
+
+    def init_constraints(self, t=0.0):
+        self.lib.oracle_ocp_init_constraints(self.h, t)
+
+    def update(self, t, q, v):
+        return self.lib.oracle_ocp_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+
+    def stage(self, what, t, q, v):
+        return self.lib.oracle_ocp_stage(self.h, what, t, P(arr(q)), P(arr(v)))
+
+    def kkt_error(self, t, q, v):
+        self.lib.oracle_ocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v)))
+        return self.lib.oracle_ocp_kkt_error(self.h)
+
+    def get(self, name):
+        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS[name]
+        out = np.zeros((self.N + 1, dim))
+        assert self.lib.oracle_ocp_get(self.h, name.encode(), dim, P(out)) == 0
+        return out[:self.N] if name in OCP_STAGE_ONLY else out
+
+    def step_sizes(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.oracle_ocp_get_step_sizes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def riccati(self):
+        nv, nu, N = self.nv, self.nu, self.N
+        Pm, s = np.zeros((N + 1, 2 * nv, 2 * nv)), np.zeros((N + 1, 2 * nv))
+        K, k = np.zeros((N, 2 * nv, nu)), np.zeros((N, nu))
+        self.lib.oracle_ocp_get_riccati(self.h, P(Pm), P(s), P(K), P(k))
+        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
+
+    def constraint_data(self):
+        dimc = self.lib.oracle_ocp_dimc(self.h)
+        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
+        self.lib.oracle_ocp_get_constraint_data(self.h, P(sl), P(du))
+        return sl, du
+
+    def lqr_stage(self, i):
+        nv, nu = self.nv, self.nu
+        nx = 2 * nv
+        Qxx, Qxu, Quu, A, B = np.zeros((nx, nx)), np.zeros((nu, nx)), np.zeros((nu, nu)), np.zeros((nx, nx)), np.zeros((nu, nx))
+        lx, lu, Fx = np.zeros(nx), np.zeros(nu), np.zeros(nx)
+        self.lib.oracle_ocp_get_lqr_stage(self.h, i, P(Qxx), P(Qxu), P(Quu), P(A), P(B), P(lx), P(lu), P(Fx))
+        return Qxx.T, Qxu.T, Quu.T, A.T, B.T, lx, lu, Fx
+
+
+def anymal_contact_points(model):
+    """World positions of the four feet at q_standing (robot.getContactPoints after
+    updateFrameKinematics(q_standing), examples/anymal/anymal_trotting.cpp:141-143)."""
+    lib = oracle()
+    nv, nc = model.nv, model.ncontacts
+    q, z = arr(ANYMAL_Q_STANDING), np.zeros(nv)
+    fp = np.zeros((nc, 3))
+    tmp = [np.zeros(n) for n in (3 * nc, 3 * nc * nv, 3 * nc * nv, 3 * nc * nv)]
+    fR, fv, fa = np.zeros((nc, 9)), np.zeros((nc, 6)), np.zeros((nc, 6))
+    d4 = [np.zeros(nc * 6 * nv) for _ in range(4)]
+    lib.oracle_contact_kinematics(C.byref(model), P(q), P(z), P(z), P(np.zeros((nc, 3))), C.c_double(0.05), P(tmp[0]), P(tmp[1]),
+                                  P(tmp[2]), P(tmp[3]), P(fp), P(fR), P(fv), P(fa), P(d4[0]), P(d4[1]), P(d4[2]), P(d4[3]), None)
+    return fp
