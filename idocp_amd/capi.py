@@ -123,6 +123,35 @@ def _proto(lib):
         f.restype = ci
     lib.idocp_unocp_stream.argtypes = [vp]
     lib.idocp_unocp_stream.restype = vp
+    lib.idocp_ocp_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
+    lib.idocp_ocp_create.restype = ci
+    lib.idocp_ocp_destroy.argtypes = [vp]
+    lib.idocp_ocp_destroy.restype = None
+    lib.idocp_ocp_stream.argtypes = [vp]
+    lib.idocp_ocp_stream.restype = vp
+    for name, args in [
+        ("idocp_ocp_set_contact_status_uniformly", [vp, P(ci), c_double_p]),
+        ("idocp_ocp_set_solution", [vp, cs, c_double_p]),
+        ("idocp_ocp_set_solution_batch", [vp, cs, c_double_p]),
+        ("idocp_ocp_init_constraints", [vp, cd]),
+        ("idocp_ocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
+        ("idocp_ocp_update_solution_device", [vp, cd, vp, vp]),
+        ("idocp_ocp_synchronize", [vp]),
+        ("idocp_ocp_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
+        ("idocp_ocp_kkt_error", [vp, c_double_p]),
+        ("idocp_ocp_get_solution", [vp, cs, ci, c_double_p]),
+        ("idocp_ocp_get_direction", [vp, cs, ci, c_double_p]),
+        ("idocp_ocp_get_step_sizes", [vp, c_double_p, c_double_p]),
+        ("idocp_ocp_get_riccati", [vp, ci, c_double_p, c_double_p, c_double_p, c_double_p]),
+        ("idocp_ocp_get_state_feedback_gain", [vp, ci, ci, c_double_p, c_double_p]),
+        ("idocp_ocp_dimc", [vp]),
+        ("idocp_ocp_get_constraint_data", [vp, ci, c_double_p, c_double_p]),
+        ("idocp_ocp_get_lqr_stage", [vp, ci, ci] + [c_double_p] * 8),
+        ("idocp_ocp_launch_kernel", [vp, ci, vp, vp]),
+    ]:
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = ci
 
 
 def lib():

@@ -1,0 +1,518 @@
+// C-ABI implementation of the OCPSolver path (include/idocp_hip.h).
+//
+// Sequences the contact-path kernels like OCPSolver::updateSolution
+// (src/ocp/ocp_solver.cpp:67-92): [host: per-stage reference q_ref(t_i)] ->
+// tangent RNEA (K5a) -> condensation (K5b) -> backward / forward Riccati (S3, S4)
+// -> expand primal + step sizes (K6) -> expand dual + integrate (K7).
+// The hybrid discretisation (OCPDiscretizer) is host-side index logic; this
+// build accepts only event-free horizons, so the schedule is the plain grid.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_util.hpp"
+#include "idocp_hip.h"
+#include "ocp_launch.hpp"
+
+using namespace idocp_dev;
+using idocp_host::set_last_error;
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      return IDOCP_E_DEVICE;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+namespace {
+
+using DQ = LeggedDims<4, 3>;
+using LQ = OcpLayout<DQ>;
+
+void toDevModelOcp(const idocp_model_t& m, DevModel& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.njoints = m.njoints; d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.has_floating_base = m.has_floating_base;
+  for (int i = 0; i < m.njoints; ++i) {
+    d.parent[i] = m.parent[i]; d.jtype[i] = m.jtype[i]; d.idx_q[i] = m.idx_q[i]; d.idx_v[i] = m.idx_v[i];
+    std::memcpy(d.axis[i], m.axis[i], sizeof(double) * 3);
+    std::memcpy(d.R[i], m.plc_R[i], sizeof(double) * 9);
+    std::memcpy(d.p[i], m.plc_p[i], sizeof(double) * 3);
+    d.mass[i] = m.mass[i];
+    const double* c = m.com[i];
+    const double* I = m.inertia[i];
+    const double ms = m.mass[i];
+    for (int k = 0; k < 3; ++k) d.mc[i][k] = ms * c[k];
+    const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    d.Io[i][0] = I[0] + ms * (cc - c[0] * c[0]); d.Io[i][1] = I[1] - ms * c[0] * c[1]; d.Io[i][2] = I[2] - ms * c[0] * c[2];
+    d.Io[i][3] = I[4] + ms * (cc - c[1] * c[1]); d.Io[i][4] = I[5] - ms * c[1] * c[2]; d.Io[i][5] = I[8] + ms * (cc - c[2] * c[2]);
+  }
+  std::memcpy(d.gravity, m.gravity, sizeof(double) * 3);
+}
+
+// free-flyer (identity placement) + 4 chains of 3 revolute joints, contact c on the tip joint of leg c
+bool isQuadruped(const idocp_model_t& m) {
+  if (!m.has_floating_base || m.njoints != DQ::NJ || m.nv != DQ::NV || m.nq != DQ::NQ || m.ncontacts != DQ::NC) return false;
+  if (m.jtype[0] != IDOCP_JOINT_FREEFLYER || m.parent[0] != -1) return false;
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int k = 0; k < 9; ++k) if (std::fabs(m.plc_R[0][k] - I3[k]) > 1e-14) return false;
+  for (int k = 0; k < 3; ++k) if (std::fabs(m.plc_p[0][k]) > 1e-14) return false;
+  for (int leg = 0; leg < DQ::NL; ++leg)
+    for (int j = 0; j < DQ::LJ; ++j) {
+      const int ji = 1 + leg * DQ::LJ + j;
+      if (m.jtype[ji] != IDOCP_JOINT_REVOLUTE || m.parent[ji] != (j == 0 ? 0 : ji - 1) || m.idx_v[ji] != 6 + leg * DQ::LJ + j) return false;
+    }
+  for (int c = 0; c < DQ::NC; ++c) if (m.contact_joint[c] != DQ::LJ * (c + 1)) return false;
+  return true;
+}
+
+}  // namespace
+
+struct idocp_ocp {
+  idocp_model_t model;
+  idocp_cost_t cost;
+  idocp_constraints_t cons;
+  int N, batch, device;
+  double T;
+  hipStream_t stream = nullptr;
+  OcpBuffers B{};
+  OcpProblem prob;
+  std::vector<void*> allocs;
+  double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr, *d_qref = nullptr;
+  void* d_prob = nullptr;
+  double qref_time = NAN;
+  bool contact_status_set = false;
+};
+
+namespace {
+
+int allocBufO(idocp_ocp* h, double** p, size_t n) {
+  HIP_TRY(hipMalloc((void**)p, n * sizeof(double)));
+  h->allocs.push_back(*p);
+  HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(double), h->stream));
+  return IDOCP_OK;
+}
+int setDev(const idocp_ocp* h) { HIP_TRY(hipSetDevice(h->device)); return IDOCP_OK; }
+
+// (Trotting)ConfigurationSpaceCost reference of stage time t
+// (include/idocp/cost/trotting_configuration_space_cost.hpp:126-164)
+void qRefAt(const idocp_cost_t& c, int nq, double t, double* q_ref) {
+  for (int i = 0; i < nq; ++i) q_ref[i] = c.q_ref[i];
+  if (!c.use_trotting_ref || !(t > c.t_start)) return;
+  const double tau = t - c.t_start;
+  const int steps = (int)std::floor(tau / c.t_period);
+  const double rate = (tau - steps * c.t_period) / c.t_period;
+  const double sin2 = std::sin(M_PI_2 * rate);
+  q_ref[0] += (steps + rate) * c.step_length;
+  if (steps % 2 == 0) {
+    q_ref[9] -= sin2 * c.front_swing_knee;  q_ref[12] -= sin2 * c.hip_stance_knee;
+    q_ref[15] += sin2 * c.front_stance_knee; q_ref[18] += sin2 * c.hip_swing_knee;
+  } else {
+    q_ref[9] += sin2 * c.front_stance_knee; q_ref[12] += sin2 * c.hip_swing_knee;
+    q_ref[15] -= sin2 * c.front_swing_knee; q_ref[18] -= sin2 * c.hip_stance_knee;
+  }
+}
+
+int uploadQRef(idocp_ocp* h, double t) {
+  if (h->qref_time == t) return IDOCP_OK;
+  const int N = h->N, nq = h->model.nq;
+  std::vector<double> tab((size_t)(N + 1) * nq);
+  const double dt = h->T / N;
+  for (int i = 0; i <= N; ++i) qRefAt(h->cost, nq, i < N ? t + i * dt : t + h->T, &tab[(size_t)i * nq]);   // ocp_discretizer t(i)
+  HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
+  h->qref_time = t;
+  return IDOCP_OK;
+}
+
+int uploadProblem(idocp_ocp* h) {
+  HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+struct Field { int offset, dim, extra; };
+bool solFieldO(const std::string& n, Field& f) {
+  if (n == "lmd") f = {LQ::S_LMD, DQ::NV, 1};
+  else if (n == "gmm") f = {LQ::S_GMM, DQ::NV, 1};
+  else if (n == "q") f = {LQ::S_Q, DQ::NQ, 1};
+  else if (n == "v") f = {LQ::S_V, DQ::NV, 1};
+  else if (n == "a") f = {LQ::S_A, DQ::NV, 0};
+  else if (n == "u") f = {LQ::S_U, DQ::NU, 0};
+  else if (n == "beta") f = {LQ::S_BETA, DQ::NV, 0};
+  else if (n == "f") f = {LQ::S_F, DQ::NF, 0};
+  else if (n == "mu") f = {LQ::S_MU, DQ::NF, 0};
+  else if (n == "nu_passive") f = {LQ::S_NUP, 6, 0};
+  else return false;
+  return true;
+}
+bool dirFieldO(const std::string& n, Field& f) {
+  if (n == "dlmd") f = {LQ::D_LMD, DQ::NV, 1};
+  else if (n == "dgmm") f = {LQ::D_GMM, DQ::NV, 1};
+  else if (n == "dq") f = {LQ::D_Q, DQ::NV, 1};
+  else if (n == "dv") f = {LQ::D_V, DQ::NV, 1};
+  else if (n == "da") f = {LQ::D_A, DQ::NV, 0};
+  else if (n == "du") f = {LQ::D_U, DQ::NU, 0};
+  else if (n == "dbeta") f = {LQ::D_BETA, DQ::NV, 0};
+  else if (n == "df") f = {LQ::D_F, DQ::NF, 0};
+  else if (n == "dmu") f = {LQ::D_MU, DQ::NF, 0};
+  else if (n == "dnu_passive") f = {LQ::D_NUP, 6, 0};
+  else return false;
+  return true;
+}
+
+int copyField(idocp_ocp* h, const double* base, size_t stride, size_t nrec, const Field& f, double* out) {
+  HIP_TRY(hipMemcpy2DAsync(out, f.dim * sizeof(double), base + f.offset, stride * sizeof(double), f.dim * sizeof(double), nrec,
+                           hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                     int N, int batch, int device, idocp_ocp_t** out) {
+  if (!model || !cost || !constraints || !out) { set_last_error("idocp_ocp_create: null argument"); return IDOCP_E_ARG; }
+  if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }       // ocp_solver.cpp:27-44
+  if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
+  if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
+  if (!isQuadruped(*model)) {
+    set_last_error("idocp_ocp_create: this build carries OCP kernels for a floating-base quadruped (4 legs x 3 joints, 4 point contacts) only");
+    return IDOCP_E_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: the idocp HIP path has no CPU fallback");
+    return IDOCP_E_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { set_last_error("invalid device ordinal"); return IDOCP_E_ARG; }
+  idocp_ocp* h = new idocp_ocp();
+  h->model = *model; h->cost = *cost; h->cons = *constraints; h->N = N; h->batch = batch; h->device = device; h->T = T;
+  auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_last_error("hipStreamCreate failed"); return fail(IDOCP_E_DEVICE); }
+  const size_t n1 = (size_t)batch * (N + 1), n0 = (size_t)batch * N;
+  OcpBuffers& B = h->B;
+  int rc;
+  double* tmp;
+  if ((rc = allocBufO(h, &B.sol, n1 * LQ::SOL))) return fail(rc);
+  if ((rc = allocBufO(h, &B.dir, n1 * LQ::DIR))) return fail(rc);
+  if ((rc = allocBufO(h, &B.slack, n0 * LQ::CON))) return fail(rc);
+  if ((rc = allocBufO(h, &B.dual, n0 * LQ::CON))) return fail(rc);
+  if ((rc = allocBufO(h, &B.lin, n0 * LQ::LIN))) return fail(rc);
+  if ((rc = allocBufO(h, &B.kkt, n1 * LQ::KKT))) return fail(rc);
+  if ((rc = allocBufO(h, &B.exp, n1 * LQ::EXP))) return fail(rc);
+  if ((rc = allocBufO(h, &B.ric, n1 * LQ::RIC))) return fail(rc);
+  if ((rc = allocBufO(h, &B.gain, n0 * LQ::GAIN))) return fail(rc);
+  if ((rc = allocBufO(h, &B.step_stage, n0 * 2))) return fail(rc);
+  if ((rc = allocBufO(h, &B.step, (size_t)batch * 2))) return fail(rc);
+  if ((rc = allocBufO(h, &B.err_stage, n1))) return fail(rc);
+  if ((rc = allocBufO(h, &B.err, (size_t)batch))) return fail(rc);
+  if ((rc = allocBufO(h, &h->d_q0, (size_t)batch * DQ::NQ))) return fail(rc);
+  if ((rc = allocBufO(h, &h->d_v0, (size_t)batch * DQ::NV))) return fail(rc);
+  if ((rc = allocBufO(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
+  if ((rc = allocBufO(h, &h->d_qref, (size_t)(N + 1) * DQ::NQ))) return fail(rc);
+  if ((rc = allocBufO(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
+  B.status = reinterpret_cast<int*>(tmp);
+  B.q_ref = h->d_qref;
+  DevModel dm; toDevModelOcp(*model, dm);
+  OcpProblem& p = h->prob;
+  std::memset(&p, 0, sizeof(p));
+  p.N = N; p.batch = batch; p.T = T; p.dt = T / N;
+  p.baumgarte_time_step = T / N;                           // hybrid_container.hpp:186-188
+  for (int i = 0; i < DQ::NV; ++i) {
+    p.v_ref[i] = cost->v_ref[i]; p.q_weight[i] = cost->q_weight[i]; p.v_weight[i] = cost->v_weight[i]; p.a_weight[i] = cost->a_weight[i];
+    p.qf_weight[i] = cost->qf_weight[i]; p.vf_weight[i] = cost->vf_weight[i];
+  }
+  if (cost->use_trotting_ref) p.v_ref[0] = cost->step_length / cost->t_period;     // trotting_configuration_space_cost.cpp:81-83
+  for (int i = 0; i < DQ::NU; ++i) {
+    p.u_ref[i] = cost->u_ref[i]; p.u_weight[i] = cost->u_weight[i];
+    p.q_min[i] = model->q_min[i]; p.q_max[i] = model->q_max[i]; p.v_max[i] = model->v_max[i]; p.u_max[i] = model->u_max[i];
+  }
+  for (int c = 0; c < DQ::NC; ++c) {
+    for (int k = 0; k < 3; ++k) { p.f_weight[c][k] = cost->f_weight[c][k]; p.f_ref[c][k] = cost->f_ref[c][k]; p.contact_p[c][k] = model->contact_p[c][k]; }
+    std::memcpy(p.contact_R[c], model->contact_R[c], sizeof(double) * 9);
+    p.active[c] = 0; p.row_of[c] = -1;
+  }
+  p.use_q_limits = constraints->joint_position_limits; p.use_v_limits = constraints->joint_velocity_limits;
+  p.use_u_limits = constraints->joint_torque_limits; p.use_friction_cone = constraints->linearized_friction_cone;
+  p.mu = constraints->mu; p.barrier = constraints->barrier; p.fraction_rate = constraints->fraction_to_boundary_rate;
+  void* d_model = nullptr;
+  if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&h->d_prob, sizeof(OcpProblem)) != hipSuccess) {
+    set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
+  }
+  h->allocs.push_back(d_model); h->allocs.push_back(h->d_prob);
+  if (hipMemcpyAsync(d_model, &dm, sizeof(dm), hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_last_error("hipMemcpy failed"); return fail(IDOCP_E_DEVICE); }
+  B.model = static_cast<const DevModel*>(d_model);
+  B.prob = static_cast<const OcpProblem*>(h->d_prob);
+  if ((rc = uploadProblem(h))) return fail(rc);
+  // identity quaternion in every q so that an unset solution is a valid configuration
+  {
+    std::vector<double> q(DQ::NQ, 0.0); q[6] = 1.0;
+    if (hipMemcpyAsync(h->d_tmp, q.data(), sizeof(double) * DQ::NQ, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+    ocpFillField(B.sol, LQ::SOL, LQ::S_Q, DQ::NQ, N + 1, batch, h->d_tmp, 0, 1, h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  }
+  *out = h;
+  return IDOCP_OK;
+}
+
+void idocp_ocp_destroy(idocp_ocp_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int idocp_ocp_set_contact_status_uniformly(idocp_ocp_t* h, const int* active, const double* contact_points) {
+  if (!h || !active || !contact_points) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  int row = 0;
+  for (int c = 0; c < DQ::NC; ++c) {
+    h->prob.active[c] = active[c] ? 1 : 0;
+    h->prob.row_of[c] = active[c] ? row : -1;
+    if (active[c]) row += 3;
+    for (int k = 0; k < 3; ++k) h->prob.contact_point[c][k] = contact_points[3 * c + k];
+  }
+  h->prob.dimf = row;
+  h->contact_status_set = true;
+  return uploadProblem(h);
+}
+
+static int setSolutionO(idocp_ocp_t* h, const char* name, const double* values, int per_instance) {
+  if (!h || !name || !values) return IDOCP_E_ARG;
+  const std::string n(name);
+  Field f;
+  if (!(n == "q" || n == "v" || n == "a" || n == "f" || n == "u") || !solFieldO(n, f)) {
+    set_last_error("invalid arugment: name must be q, v, a, f, or u!");
+    return IDOCP_E_ARG;
+  }
+  int rc = setDev(h); if (rc) return rc;
+  const int dim = (n == "f") ? 3 : f.dim, repeat = (n == "f") ? DQ::NC : 1;
+  const size_t cnt = (size_t)(per_instance ? h->batch : 1) * dim;
+  HIP_TRY(hipMemcpyAsync(h->d_tmp, values, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  ocpFillField(h->B.sol, LQ::SOL, f.offset, dim, h->N + 1, h->batch, h->d_tmp, per_instance, repeat, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value) { return setSolutionO(h, name, value, 0); }
+int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double* values) { return setSolutionO(h, name, values, 1); }
+
+int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
+  if (!h) return IDOCP_E_ARG;
+  (void)t;
+  int rc = setDev(h); if (rc) return rc;
+  OcpLaunch<DQ>::initConstraints(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
+  if (!h || kernel_id < 0 || kernel_id > 6 || !d_q || !d_v) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if (h->qref_time != h->qref_time && (rc = uploadQRef(h, 0.0))) return rc;      // first use: reference of t = 0
+  switch (kernel_id) {
+    case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream); break;
+    case 1: OcpLaunch<DQ>::condense(h->B, h->batch, h->N, d_q, h->stream); break;
+    case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, h->N, h->stream); break;
+    case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, h->N, d_q, d_v, h->stream); break;
+    default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, h->N, h->stream); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+
+int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q, const double* d_v) {
+  if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  if (!h->contact_status_set) { set_last_error("idocp_ocp_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = uploadQRef(h, t))) return rc;
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream);
+  OcpLaunch<DQ>::condense(h->B, h->batch, h->N, d_q, h->stream);
+  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, h->N, h->stream);
+  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, h->N, d_q, d_v, h->stream);
+  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, h->N, h->stream);
+  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+
+int idocp_ocp_synchronize(idocp_ocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+void* idocp_ocp_stream(idocp_ocp_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v, int line_search) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
+  if ((rc = idocp_ocp_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  std::vector<int> st(h->batch);
+  HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->batch; ++b)
+    if (st[b] != 0) { set_last_error("Cholesky failed (M, J M^-1 J^T or Quu not positive definite), instance " + std::to_string(b)); return st[b]; }
+  return IDOCP_OK;
+}
+
+int idocp_ocp_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, const double* v) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = uploadQRef(h, t))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
+  OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream);
+  OcpLaunch<DQ>::residual(h->B, h->batch, h->N, h->d_q0, h->stream);
+  ocpKktErrorReduce(h->B, h->batch, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_ocp_kkt_error(idocp_ocp_t* h, double* kkt_error) {
+  if (!h || !kkt_error) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(kkt_error, h->B.err, sizeof(double) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, double* out) {
+  if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  Field f;
+  if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  return copyField(h, h->B.sol + (size_t)instance * (h->N + 1) * LQ::SOL, LQ::SOL, h->N + f.extra, f, out);
+}
+int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out) {
+  if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  Field f;
+  if (!dirFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  return copyField(h, h->B.dir + (size_t)instance * (h->N + 1) * LQ::DIR, LQ::DIR, h->N + f.extra, f, out);
+}
+
+int idocp_ocp_get_step_sizes(idocp_ocp_t* h, double* primal, double* dual) {
+  if (!h || !primal || !dual) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  std::vector<double> st((size_t)h->batch * 2);
+  HIP_TRY(hipMemcpyAsync(st.data(), h->B.step, sizeof(double) * st.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->batch; ++b) { primal[b] = st[2 * b]; dual[b] = st[2 * b + 1]; }
+  return IDOCP_OK;
+}
+
+int idocp_ocp_get_riccati(idocp_ocp_t* h, int instance, double* P, double* s, double* K, double* k) {
+  if (!h || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  const int nv = DQ::NV, nx = DQ::NX, nu = DQ::NU, N = h->N;
+  std::vector<double> ric((size_t)(N + 1) * LQ::RIC), gain((size_t)N * LQ::GAIN);
+  HIP_TRY(hipMemcpyAsync(ric.data(), h->B.ric + (size_t)instance * (N + 1) * LQ::RIC, ric.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(gain.data(), h->B.gain + (size_t)instance * N * LQ::GAIN, gain.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i <= N; ++i) {
+    const double* r = &ric[(size_t)i * LQ::RIC];
+    if (P) {
+      double* Pm = P + (size_t)i * nx * nx;
+      for (int c = 0; c < nv; ++c) for (int rr = 0; rr < nv; ++rr) {
+        Pm[c * nx + rr] = r[LQ::R_PQQ + c * nv + rr];
+        Pm[(nv + c) * nx + rr] = r[LQ::R_PQV + c * nv + rr];
+        Pm[c * nx + nv + rr] = r[LQ::R_PQV + rr * nv + c];
+        Pm[(nv + c) * nx + nv + rr] = r[LQ::R_PVV + c * nv + rr];
+      }
+    }
+    if (s) { std::memcpy(s + (size_t)i * nx, r + LQ::R_SQ, sizeof(double) * nv); std::memcpy(s + (size_t)i * nx + nv, r + LQ::R_SV, sizeof(double) * nv); }
+    if (i < N) {
+      const double* g = &gain[(size_t)i * LQ::GAIN];
+      if (K) std::memcpy(K + (size_t)i * nu * nx, g + LQ::G_K, sizeof(double) * nu * nx);
+      if (k) std::memcpy(k + (size_t)i * nu, g + LQ::G_k, sizeof(double) * nu);
+    }
+  }
+  return IDOCP_OK;
+}
+
+int idocp_ocp_get_state_feedback_gain(idocp_ocp_t* h, int instance, int stage, double* Kq, double* Kv) {
+  if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->N || !Kq || !Kv) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  std::vector<double> g(LQ::GAIN);
+  HIP_TRY(hipMemcpyAsync(g.data(), h->B.gain + ((size_t)instance * h->N + stage) * LQ::GAIN, g.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memcpy(Kq, &g[LQ::G_K], sizeof(double) * DQ::NU * DQ::NV);                      // K.leftCols(nv)
+  std::memcpy(Kv, &g[LQ::G_K + DQ::NU * DQ::NV], sizeof(double) * DQ::NU * DQ::NV);   // K.rightCols(nv)
+  return IDOCP_OK;
+}
+
+int idocp_ocp_dimc(const idocp_ocp_t* h) {
+  if (!h) return 0;
+  const idocp_constraints_t& c = h->cons;
+  return 2 * DQ::NU * ((c.joint_position_limits ? 1 : 0) + (c.joint_velocity_limits ? 1 : 0) + (c.joint_torque_limits ? 1 : 0)) +
+         (c.linearized_friction_cone ? 5 * DQ::NC : 0);
+}
+
+int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual) {
+  if (!h || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  const int N = h->N, dimc = idocp_ocp_dimc(h);
+  std::vector<double> sl((size_t)N * LQ::CON), du((size_t)N * LQ::CON);
+  HIP_TRY(hipMemcpyAsync(sl.data(), h->B.slack + (size_t)instance * N * LQ::CON, sl.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * N * LQ::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const idocp_constraints_t& c = h->cons;
+  const int use[4] = {c.joint_position_limits, c.joint_velocity_limits, c.joint_torque_limits, c.linearized_friction_cone};
+  for (int i = 0; i < N; ++i) {
+    int off = 0;
+    for (int comp = 0; comp < 7; ++comp) {
+      if (!use[comp < 6 ? comp / 2 : 3]) continue;
+      const int n = comp < 6 ? DQ::NU : 5 * DQ::NC, base = comp < 6 ? comp * DQ::NU : LQ::C_FRIC;
+      const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
+      for (int r = 0; r < n; ++r) {
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * LQ::CON + base + r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * LQ::CON + base + r] : 0.0;
+      }
+      off += n;
+    }
+  }
+  return IDOCP_OK;
+}
+
+int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu, double* Quu, double* A, double* Bm,
+                            double* lx, double* lu, double* Fx) {
+  if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->N) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  const int nv = DQ::NV, nx = DQ::NX, nu = DQ::NU;
+  std::vector<double> k(LQ::KKT);
+  HIP_TRY(hipMemcpyAsync(k.data(), h->B.kkt + ((size_t)instance * (h->N + 1) + stage) * LQ::KKT, k.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memcpy(Qxx, &k[LQ::K_QXX], sizeof(double) * nx * nx);
+  std::memcpy(Qxu, &k[LQ::K_QXU], sizeof(double) * nx * nu);
+  std::memcpy(Quu, &k[LQ::K_QUU], sizeof(double) * nu * nu);
+  std::memset(A, 0, sizeof(double) * nx * nx);
+  std::memset(Bm, 0, sizeof(double) * nx * nu);
+  const double dt = h->T / h->N;
+  for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) {
+    double fqq = (r == c) ? 1.0 : 0.0, fqv = (r == c) ? dt : 0.0;
+    if (r < 6 && c < 6) { fqq = k[LQ::K_FQQ + r + 6 * c]; fqv = k[LQ::K_FQV + r + 6 * c]; }
+    else if (r < 6 || c < 6) { fqq = 0.0; fqv = 0.0; }
+    A[r + nx * c] = fqq; A[r + nx * (nv + c)] = fqv;
+    A[(nv + r) + nx * c] = k[LQ::K_FVQ + r + nv * c]; A[(nv + r) + nx * (nv + c)] = k[LQ::K_FVV + r + nv * c];
+  }
+  for (int j = 0; j < nu; ++j) for (int r = 0; r < nv; ++r) Bm[(nv + r) + nx * j] = k[LQ::K_FVU + r + nv * j];
+  std::memcpy(lx, &k[LQ::K_LX], sizeof(double) * nx);
+  std::memcpy(lu, &k[LQ::K_LU], sizeof(double) * nu);
+  std::memcpy(Fx, &k[LQ::K_FX], sizeof(double) * nx);
+  return IDOCP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// K5b -- per-stage KKT assembly and contact-dynamics condensation (and, with
+// RESIDUAL = true, K8: the stage's squared KKT residual).
+//
+// Replaces SplitOCP::linearizeOCP after the rigid-body part (include/idocp/ocp/split_ocp.hxx:58-91):
+//   cost derivatives / Hessian      (src/cost/configuration_space_cost.cpp:292-365,
+//                                    trotting_configuration_space_cost.cpp:269-343, contact_force_cost.cpp:153-194)
+//   IPM terms                       (src/constraints/joint_*_limit.cpp, linearized_friction_cone.cpp:107-152)
+//   state equation, floating base   (include/idocp/ocp/state_equation.hxx:12-63)
+//   multipliers of ID and C         (include/idocp/ocp/contact_dynamics.hxx:48-81)
+//   ContactDynamics::condenseContactDynamics incl. Robot::computeMJtJinv
+//                                   (contact_dynamics.hxx:105-158; include/idocp/robot/robot.hxx:576-615)
+// and TerminalOCP::linearizeOCP (include/idocp/ocp/terminal_ocp.hxx:50-66) for the last stage.
+//
+// One 256-thread workgroup per stage; every block of the stage lives in LDS
+// (~72 kB, two workgroups per CU).  Reads the lin record of K5a, writes the kkt
+// record (LQR stage for the Riccati sweep) and the exp record (expansion cache).
+#include <hip/hip_runtime.h>
+
+#include "dev_dense.hpp"
+#include "dev_lie.hpp"
+#include "ocp_device.hpp"
+#include "ocp_launch.hpp"
+
+namespace idocp_dev {
+
+__device__ __forceinline__ double ocpLimit(const OcpProblem* __restrict__ P, int comp, int r) {
+  switch (comp) {
+    case 0: return P->q_min[r];
+    case 1: return P->q_max[r];
+    case 2: return -P->v_max[r];
+    case 3: return P->v_max[r];
+    case 4: return -P->u_max[r];
+    default: return P->u_max[r];
+  }
+}
+__device__ __forceinline__ bool ocpRowValid(const OcpProblem* __restrict__ P, int comp, int stage) {
+  if (comp < 2) return P->use_q_limits && stage >= 2;
+  if (comp < 4) return P->use_v_limits && stage >= 1;
+  if (comp < 6) return P->use_u_limits != 0;
+  return P->use_friction_cone != 0;
+}
+// LinearizedFrictionCone: g(f) = Jc f (linearized_friction_cone.cpp:25-29, .hpp:72-84)
+__device__ __forceinline__ double frictionJacEntry(double mu, int r, int x) {
+  const double m2 = mu * 0.70710678118654752440;
+  if (x == 2) return r == 0 ? -1.0 : -m2;
+  if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
+  return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
+}
+
+template <typename D>
+struct CondenseSmem {
+  using L = OcpLayout<D>;
+  static constexpr int NV = D::NV, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU;
+  static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV, IDC = JM + NF * NV, MJ = IDC + 32,
+                       MJD = MJ + NVF * NVF, QAFQV = MJD + NVF * NX, QAFU = QAFQV + NVF * NX, QXX = QAFU + NVF * NV,
+                       QXU = QXX + NX * NX, QUU = QXU + NX * NV, MINV = QUU + NV * NV, BL = MINV + NV * NV, SM = BL + NF * NV,
+                       BR = SM + NF * NF, QFF = BR + NF * NF, VEC = QFF + NF * NF;
+  // vectors
+  static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
+                       LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV, JQ = BM + 32, FQQ = JQ + 36, FQQP = FQQ + 36,
+                       FQQI = FQQP + 36, FQQPI = FQQI + 36, FQV = FQQPI + 36, QDIFF = FQV + 36, FQ6 = QDIFF + 8, ERR = FQ6 + 8,
+                       TOTAL = ERR + 256;
+};
+
+template <typename D, bool RESIDUAL>
+__global__ __launch_bounds__(256) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
+  using L = OcpLayout<D>;
+  using S = CondenseSmem<D>;
+  constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_ok;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int tid = threadIdx.x, nt = 256;
+  const long unit = blockIdx.x;                   // over batch * (N + 1)
+  const long b = unit / (N + 1);
+  const int i = (int)(unit - b * (N + 1));
+  const bool terminal = (i == N);
+  const int dimf = P->dimf, dimvf = NV + dimf;
+  const double* __restrict__ s = B.sol + unit * L::SOL;
+  const double* __restrict__ sn = s + L::SOL;       // only dereferenced for i < N
+  const double* __restrict__ q = s + L::S_Q;
+  const double* __restrict__ qref = B.q_ref + (long)i * NQ;
+  const double* __restrict__ q_prev = (i == 0) ? (q0 + b * NQ) : (s - L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
+  const long su = b * N + i;                       // stage index without terminal records
+  double* kk = B.kkt + unit * L::KKT;
+  double* ee = B.exp + unit * L::EXP;
+
+  // ---- A. load the lin record, clear the accumulators ----
+  if (!terminal) {
+    const double* __restrict__ lin = B.lin + su * L::LIN;
+    for (int e = tid; e < NVF * NX + NV * NV + NF * NV; e += nt) sm[S::DIDC + e] = lin[e];       // DIDC, MM, JM are contiguous in both
+    if (tid < NVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
+  }
+  for (int e = tid; e < NX * NX + NX * NV + NV * NV; e += nt) sm[S::QXX + e] = 0.0;              // QXX, QXU, QUU contiguous
+  for (int e = tid; e < NF * NF; e += nt) sm[S::QFF + e] = 0.0;
+  if (tid == 0) s_ok = 1;
+  // ---- B. Lie-group terms of the floating base (one lane per task) ----
+  if (tid == 0) {              // cost: qdiff = q (-) q_ref, Jq = d qdiff / dq   (ARG1)
+    double R[9], p[3];
+    lieRelative(qref, q, R, p);
+    lieLog6(R, p, &sm[S::QDIFF]);
+    lieJlog6(R, p, &sm[S::JQ]);
+  } else if (tid == 64 && !terminal) {   // state equation: s.q (-) q_next
+    double R[9], p[3], J0[36];
+    lieRelative(sn + L::S_Q, q, R, p);
+    lieLog6(R, p, &sm[S::FQ6]);
+    lieJlog6(R, p, &sm[S::FQQ]);                         // dSubtractdConfigurationPlus(s.q, q_next)
+    lieDDiffArg0(R, p, &sm[S::FQQ], J0);                 // dSubtractdConfigurationMinus(s.q, q_next)
+    lieBlockInverse(J0, &sm[S::FQQI]);                   // Fqq_inv
+  } else if (tid == 128) {      // previous stage's equation: q_prev (-) s.q
+    double R[9], p[3], J1[36];
+    lieRelative(q, q_prev, R, p);
+    lieJlog6(R, p, J1);
+    lieDDiffArg0(R, p, J1, &sm[S::FQQP]);                // dSubtractdConfigurationMinus(q_prev, s.q)
+    lieBlockInverse(&sm[S::FQQP], &sm[S::FQQPI]);        // Fqq_prev_inv
+  }
+  __syncthreads();
+
+  const double v_ref0 = P->v_ref[0];
+  if (terminal) {
+    // ---- TerminalOCP::linearizeOCP ----
+    if (tid < NV) {
+      const int r = tid;
+      double lq, lv;
+      if (r < 6) {
+        lq = 0.0;
+        for (int m2 = 0; m2 < 6; ++m2) lq += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::QDIFF + m2];
+        double t1 = 0.0;
+        for (int m2 = 0; m2 < 6; ++m2) t1 += sm[S::FQQP + m2 + 6 * r] * s[L::S_LMD + m2];
+        lq += t1;
+      } else {
+        lq = P->qf_weight[r] * (q[r + 1] - qref[r + 1]) - s[L::S_LMD + r];
+      }
+      lv = P->vf_weight[r] * (s[L::S_V + r] - (r == 0 ? v_ref0 : P->v_ref[r])) - s[L::S_GMM + r];
+      if (RESIDUAL) { sm[S::ERR + tid] = lq * lq + lv * lv; }
+      else { kk[L::K_LX + r] = lq; kk[L::K_LX + NV + r] = lv; }
+    } else if (RESIDUAL) {
+      sm[S::ERR + tid] = 0.0;
+    }
+    if (RESIDUAL) {
+      __syncthreads();
+      if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[unit] = e; }
+      return;
+    }
+    for (int e = tid; e < 36; e += nt) {
+      const int c = e / 6, r = e - 6 * c;
+      double acc = 0.0;
+      for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c];
+      sm[S::QXX + r + NX * c] = acc;
+      ee[L::E_FQQPI + e] = sm[S::FQQPI + e];
+    }
+    __syncthreads();
+    if (tid < NV) {
+      if (tid >= 6) sm[S::QXX + tid + NX * tid] = P->qf_weight[tid];
+      sm[S::QXX + (NV + tid) + NX * (NV + tid)] = P->vf_weight[tid];
+    }
+    __syncthreads();
+    for (int e = tid; e < NX * NX; e += nt) kk[L::K_QXX + e] = sm[S::QXX + e];
+    return;
+  }
+
+  // ---- C. gradients, residuals, diagonal Hessian terms ----
+  const double* __restrict__ slack = B.slack + su * L::CON;
+  const double* __restrict__ dual = B.dual + su * L::CON;
+  // bm = [beta ; mu_stack]
+  if (tid < NV) sm[S::BM + tid] = s[L::S_BETA + tid];
+  if (tid < NC && P->active[tid]) for (int x = 0; x < 3; ++x) sm[S::BM + NV + P->row_of[tid] + x] = s[L::S_MU + 3 * tid + x];
+  __syncthreads();
+  double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below)
+  if (tid < NV) {
+    const int r = tid;
+    const double vr = s[L::S_V + r], ar = s[L::S_A + r];
+    const double lmd = s[L::S_LMD + r], gmm = s[L::S_GMM + r], lmdn = sn[L::S_LMD + r], gmmn = sn[L::S_GMM + r];
+    double lq, lv, la, hq = 0.0, hv, ha;
+    // cost + state equation
+    if (r < 6) {
+      lq = 0.0;
+      for (int m2 = 0; m2 < 6; ++m2) lq += sm[S::JQ + m2 + 6 * r] * P->q_weight[m2] * sm[S::QDIFF + m2];
+      lq *= dt;
+      double t1 = 0.0;
+      for (int m2 = 0; m2 < 6; ++m2) t1 += sm[S::FQQ + m2 + 6 * r] * sn[L::S_LMD + m2] + sm[S::FQQP + m2 + 6 * r] * s[L::S_LMD + m2];
+      lq += t1;
+      sm[S::FQ + r] = sm[S::FQ6 + r] + dt * vr;
+    } else {
+      lq = dt * P->q_weight[r] * (q[r + 1] - qref[r + 1]) + lmdn - lmd;
+      hq = dt * P->q_weight[r];
+      sm[S::FQ + r] = q[r + 1] - sn[L::S_Q + r + 1] + dt * vr;
+    }
+    lv = dt * P->v_weight[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r])) + dt * lmdn + gmmn - gmm;
+    la = dt * P->a_weight[r] * ar + dt * gmmn;
+    hv = dt * P->v_weight[r];
+    ha = dt * P->a_weight[r];
+    sm[S::FV + r] = vr + dt * ar - sn[L::S_V + r];
+    // joint position / velocity limits act on the actuated joints (tail(dimu))
+    if (r >= 6) {
+      const int j = r - 6;
+      for (int c = 0; c < 4; ++c) {
+        if (!ocpRowValid(P, c, i)) continue;
+        const double sgn = (c & 1) ? 1.0 : -1.0;
+        const double x = (c < 2) ? q[r + 1] : vr;
+        const double sl = slack[c * NU + j], du = dual[c * NU + j];
+        const double res = sgn * (x - ocpLimit(P, c, j)) + sl, duality = sl * du - P->barrier;
+        double g = sgn * dt * du, h = 0.0;
+        if (RESIDUAL) err_ipm += res * res + duality * duality;
+        else { g += sgn * dt * (du * res - duality) / sl; h = dt * du / sl; }
+        if (c < 2) { lq += g; hq += h; } else { lv += g; hv += h; }
+      }
+    }
+    // multipliers of [ID; C]:  l += dt [dID;dC]^T [beta; mu]
+    double dq = 0.0, dv = 0.0, da = 0.0;
+    for (int row = 0; row < dimvf; ++row) {
+      const double bmr = sm[S::BM + row];
+      dq += sm[S::DIDC + row + NVF * r] * bmr;
+      dv += sm[S::DIDC + row + NVF * (NV + r)] * bmr;
+    }
+    for (int row = 0; row < NV; ++row) da += sm[S::MM + row + NV * r] * sm[S::BM + row];
+    for (int row = 0; row < dimf; ++row) da += sm[S::JM + row + NF * r] * sm[S::BM + NV + row];
+    lq += dt * dq; lv += dt * dv; la += dt * da;
+    sm[S::LQ + r] = lq; sm[S::LV + r] = lv; sm[S::LA + r] = la; sm[S::QAA + r] = ha;
+    if (!RESIDUAL) {
+      if (r >= 6) sm[S::QXX + r + NX * r] = hq;
+      sm[S::QXX + (NV + r) + NX * (NV + r)] = hv;
+    } else {
+      const double idr = sm[S::IDC + r];
+      err_local += lq * lq + lv * lv + la * la + sm[S::FQ + r] * sm[S::FQ + r] + sm[S::FV + r] * sm[S::FV + r] + dt * dt * idr * idr;
+    }
+  } else if (tid >= 64 && tid < 64 + NU) {
+    // torque rows: lu, Quu diagonal
+    const int j = tid - 64;
+    const double u = s[L::S_U + j];
+    double lu = dt * P->u_weight[j] * (u - P->u_ref[j]) - dt * s[L::S_BETA + 6 + j];
+    double h = dt * P->u_weight[j];
+    for (int c = 4; c < 6; ++c) {
+      if (!ocpRowValid(P, c, i)) continue;
+      const double sgn = (c & 1) ? 1.0 : -1.0;
+      const double sl = slack[c * NU + j], du = dual[c * NU + j];
+      const double res = sgn * (u - ocpLimit(P, c, j)) + sl, duality = sl * du - P->barrier;
+      lu += sgn * dt * du;
+      if (RESIDUAL) err_ipm += res * res + duality * duality;
+      else { lu += sgn * dt * (du * res - duality) / sl; h += dt * du / sl; }
+    }
+    sm[S::LU + j] = lu;
+    if (!RESIDUAL) sm[S::QUU + (6 + j) + NV * (6 + j)] = h;
+    else err_local += lu * lu;
+  } else if (tid >= 128 && tid < 128 + 6) {
+    // passive (floating-base) rows: lu_passive = dt nu_passive - dt beta.head(6)
+    const int r = tid - 128;
+    const double lup = dt * s[L::S_NUP + r] - dt * s[L::S_BETA + r];
+    sm[S::LUP + r] = lup;
+    if (RESIDUAL) err_local += lup * lup;
+  } else if (tid >= 192 && tid < 192 + NC) {
+    // contact-force rows: ContactForceCost + LinearizedFrictionCone + (- dt J beta)
+    const int c = tid - 192;
+    if (P->active[c]) {
+      const int row = P->row_of[c];
+      double lf[3], f[3];
+      for (int x = 0; x < 3; ++x) {
+        f[x] = s[L::S_F + 3 * c + x];
+        lf[x] = dt * P->f_weight[c][x] * (f[x] - P->f_ref[c][x]);
+        if (!RESIDUAL) sm[S::QFF + (row + x) + NF * (row + x)] = dt * P->f_weight[c][x];
+      }
+      if (ocpRowValid(P, 6, i)) {
+        double dd[5];
+        for (int r = 0; r < 5; ++r) {
+          const int idx = L::C_FRIC + 5 * c + r;
+          const double sl = slack[idx], du = dual[idx];
+          double g = 0.0;
+          for (int x = 0; x < 3; ++x) g += frictionJacEntry(P->mu, r, x) * f[x];
+          const double res = g + sl, duality = sl * du - P->barrier;
+          double coef = du;
+          if (RESIDUAL) err_ipm += res * res + duality * duality;
+          else coef += (du * res - duality) / sl;
+          dd[r] = du / sl;
+          for (int x = 0; x < 3; ++x) lf[x] += dt * frictionJacEntry(P->mu, r, x) * coef;
+        }
+        if (!RESIDUAL) {
+          for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) {
+            double acc = 0.0;
+            for (int r = 0; r < 5; ++r) acc += frictionJacEntry(P->mu, r, x) * dd[r] * frictionJacEntry(P->mu, r, y);
+            sm[S::QFF + (row + x) + NF * (row + y)] += dt * acc;
+          }
+        }
+      }
+      for (int x = 0; x < 3; ++x) {
+        double jb = 0.0;
+        for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + NF * col] * s[L::S_BETA + col];
+        lf[x] -= dt * jb;
+        sm[S::LF + row + x] = lf[x];
+        if (RESIDUAL) { const double cr = sm[S::IDC + NV + row + x]; err_local += lf[x] * lf[x] + dt * dt * cr * cr; }
+      }
+    }
+  }
+  if (RESIDUAL) {
+    // SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264)
+    sm[S::ERR + tid] = err_local + dt * dt * err_ipm;
+    __syncthreads();
+    if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[unit] = e; }
+    return;
+  }
+  __syncthreads();
+  // cost Hessian of the base block: dt Jq^T W Jq  (6 x 6)
+  if (tid < 36) {
+    const int c = tid / 6, r = tid - 6 * c;
+    double acc = 0.0;
+    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * P->q_weight[m2] * sm[S::JQ + m2 + 6 * c];
+    sm[S::QXX + r + NX * c] = dt * acc;
+  }
+  // ---- D. condenseForwardEuler (state_equation.hxx:40-63) ----
+  if (tid >= 64 && tid < 64 + 36) {
+    const int e = tid - 64, c = e / 6, r = e - 6 * c;
+    double acc = 0.0;
+    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQQ + m2 + 6 * c];
+    kk[L::K_FQQ + e] = -acc;                       // Fqq = -Fqq_inv * Fqq
+    kk[L::K_FQV + e] = -dt * sm[S::FQQI + e];      // Fqv = -dt Fqq_inv
+    ee[L::E_FQQPI + e] = sm[S::FQQPI + e];
+  }
+  if (tid >= 128 && tid < 128 + 6) {
+    const int r = tid - 128;
+    double acc = 0.0;
+    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQ + m2];
+    sm[S::FQ6 + r] = -acc;
+  }
+  __syncthreads();
+  if (tid < 6) sm[S::FQ + tid] = sm[S::FQ6 + tid];
+
+  // ---- E. Robot::computeMJtJinv ----
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int c = e / NV, r = e - c * NV;
+    sm[S::MJ + r + NVF * c] = sm[S::MM + e];       // Cholesky workspace: top-left of MJ
+    sm[S::MINV + e] = (r == c) ? 1.0 : 0.0;
+  }
+  choleskyInPlace(&sm[S::MJ], NVF, NV, tid, nt, &s_ok);
+  choleskySolve(&sm[S::MJ], NVF, NV, &sm[S::MINV], NV, NV, tid, nt);
+  __syncthreads();
+  if (dimf > 0) {
+    mm(colMajor(&sm[S::BL], NF), colMajor(&sm[S::JM], NF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
+    __syncthreads();
+    mm(colMajor(&sm[S::SM], NF), colMajor(&sm[S::BL], NF), transposed(colMajor(&sm[S::JM], NF)), dimf, dimf, NV, 1.0, false, tid, nt);
+    for (int e = tid; e < NF * NF; e += nt) { const int c = e / NF, r = e - c * NF; sm[S::BR + e] = (r == c) ? -1.0 : 0.0; }
+    __syncthreads();
+    choleskyInPlace(&sm[S::SM], NF, dimf, tid, nt, &s_ok);
+    choleskySolve(&sm[S::SM], NF, dimf, &sm[S::BR], NF, dimf, tid, nt);                  // BR = -(J Minv J^T)^-1
+    __syncthreads();
+    // TR = BL^T (-BR)  -> MJ top-right ; BL^T of it -> bottom-left ; BR -> bottom-right
+    mm(sub(colMajor(&sm[S::MJ], NVF), 0, NV), transposed(colMajor(&sm[S::BL], NF)), colMajor(&sm[S::BR], NF), NV, dimf, dimf, -1.0, false, tid, nt);
+    __syncthreads();
+    for (int e = tid; e < dimf * NV; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * c] = sm[S::MJ + c + NVF * (NV + r)]; }
+    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * (NV + c)] = sm[S::BR + r + NF * c]; }
+    __syncthreads();
+  }
+  // TL = Minv - TR BL
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int c = e / NV, r = e - c * NV;
+    double acc = sm[S::MINV + e];
+    for (int p = 0; p < dimf; ++p) acc -= sm[S::MJ + r + NVF * (NV + p)] * sm[S::BL + p + NF * c];
+    sm[S::QAFU + e] = acc;                          // staged (MJ top-left still holds the Cholesky factor)
+  }
+  __syncthreads();
+  for (int e = tid; e < NV * NV; e += nt) { const int c = e / NV, r = e - c * NV; sm[S::MJ + r + NVF * c] = sm[S::QAFU + e]; }
+  __syncthreads();
+
+  // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
+  mm(colMajor(&sm[S::MJD], NVF), colMajor(&sm[S::MJ], NVF), colMajor(&sm[S::DIDC], NVF), dimvf, NX, dimvf, 1.0, false, tid, nt);
+  mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], NVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
+  __syncthreads();
+  for (int e = tid; e < dimvf * NX; e += nt) {
+    const int c = e / dimvf, r = e - c * dimvf;
+    double val;
+    if (r < NV) val = -sm[S::QAA + r] * sm[S::MJD + r + NVF * c];
+    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + NF * p] * sm[S::MJD + (NV + p) + NVF * c]; val = -acc; }
+    sm[S::QAFQV + r + NVF * c] = val;
+  }
+  for (int e = tid; e < dimvf * NV; e += nt) {
+    const int c = e / dimvf, r = e - c * dimvf;
+    double val;
+    if (r < NV) val = sm[S::QAA + r] * sm[S::MJ + r + NVF * c];
+    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + NF * p] * sm[S::MJ + (NV + p) + NVF * c]; val = acc; }
+    sm[S::QAFU + r + NVF * c] = val;
+  }
+  if (tid < dimvf) {
+    const int r = tid;
+    double val;
+    if (r < NV) val = sm[S::LA + r] - sm[S::QAA + r] * sm[S::MJIDC + r];
+    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + NF * p] * sm[S::MJIDC + NV + p]; val = -sm[S::LF + r - NV] - acc; }
+    sm[S::LAF + r] = val;
+  }
+  __syncthreads();
+  // ---- H. condensed Hessian / gradients / dynamics (contact_dynamics.hxx:129-157) ----
+  mm(colMajor(&sm[S::QXX], NX), transposed(colMajor(&sm[S::MJD], NVF)), colMajor(&sm[S::QAFQV], NVF), NX, NX, dimvf, -1.0, true, tid, nt);
+  mm(colMajor(&sm[S::QXU], NX), transposed(colMajor(&sm[S::MJD], NVF)), colMajor(&sm[S::QAFU], NVF), NX, NV, dimvf, -1.0, true, tid, nt);
+  mm(colMajor(&sm[S::QUU], NV), colMajor(&sm[S::MJ], NVF), colMajor(&sm[S::QAFU], NVF), NV, NV, dimvf, 1.0, true, tid, nt);
+  if (tid < NX) {                                   // lx -= MJD^T laf
+    double acc = 0.0;
+    for (int p = 0; p < dimvf; ++p) acc += sm[S::MJD + p + NVF * tid] * sm[S::LAF + p];
+    if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;
+  } else if (tid >= 64 && tid < 64 + NV) {          // [lu_passive; lu] += MJ.topRows(NV) laf ; Fv -= dt MJIDC
+    const int r = tid - 64;
+    double acc = 0.0;
+    for (int p = 0; p < dimvf; ++p) acc += sm[S::MJ + r + NVF * p] * sm[S::LAF + p];
+    if (r < 6) sm[S::LUP + r] += acc; else sm[S::LU + r - 6] += acc;
+    sm[S::FV + r] -= dt * sm[S::MJIDC + r];
+  }
+  __syncthreads();
+
+  // ---- I. write the kkt and exp records ----
+  for (int e = tid; e < NX * NX; e += nt) kk[L::K_QXX + e] = sm[S::QXX + e];
+  for (int e = tid; e < NX * NU; e += nt) { const int c = e / NX, r = e - c * NX; kk[L::K_QXU + e] = sm[S::QXU + r + NX * (6 + c)]; }
+  for (int e = tid; e < NU * NU; e += nt) { const int c = e / NU, r = e - c * NU; kk[L::K_QUU + e] = sm[S::QUU + (6 + r) + NV * (6 + c)]; }
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int c = e / NV, r = e - c * NV;
+    kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + NVF * c];
+    kk[L::K_FVV + e] = -dt * sm[S::MJD + r + NVF * (NV + c)] + (r == c ? 1.0 : 0.0);
+  }
+  for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = dt * sm[S::MJ + r + NVF * (6 + c)]; }
+  if (tid < NV) {
+    kk[L::K_LX + tid] = sm[S::LQ + tid]; kk[L::K_LX + NV + tid] = sm[S::LV + tid];
+    kk[L::K_FX + tid] = sm[S::FQ + tid]; kk[L::K_FX + NV + tid] = sm[S::FV + tid];
+  }
+  if (tid < NU) kk[L::K_LU + tid] = sm[S::LU + tid];
+  for (int e = tid; e < NVF * NVF; e += nt) ee[L::E_MJ + e] = sm[S::MJ + e];
+  for (int e = tid; e < NVF * NX; e += nt) { ee[L::E_MJD + e] = sm[S::MJD + e]; ee[L::E_QAFQV + e] = sm[S::QAFQV + e]; }
+  for (int e = tid; e < NVF * NU; e += nt) ee[L::E_QAFU + e] = sm[S::QAFU + NVF * 6 + e];          // columns 6.. of Qafu_full
+  if (tid < NVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
+  if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
+  for (int e = tid; e < 6 * NU; e += nt) { const int c = e / 6, r = e - 6 * c; ee[L::E_QUUP + e] = sm[S::QUU + r + NV * (6 + c)]; }
+  for (int e = tid; e < NX * 6; e += nt) ee[L::E_QXUP + e] = sm[S::QXU + e];                       // columns 0..5 of Qxu_full
+  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + i;
+}
+
+template <typename D>
+static void launchCondense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st, bool residual) {
+  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  const unsigned blocks = (unsigned)(batch * (N + 1));
+  if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true>), dim3(blocks), dim3(256), smem, st, B, q0);
+  else hipLaunchKernelGGL((ocp_condense_kernel<D, false>), dim3(blocks), dim3(256), smem, st, B, q0);
+}
+
+template <typename D>
+void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st) {
+  launchCondense<D>(B, batch, N, q0, st, false);
+}
+template <typename D>
+void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st) {
+  launchCondense<D>(B, batch, N, q0, st, true);
+}
+
+template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);
+
+}  // namespace idocp_dev

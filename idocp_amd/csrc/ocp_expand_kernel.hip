@@ -1,0 +1,364 @@
+// K6 / K7 and small helpers of the contact path.
+//
+// K6  ocp_expand_primal_kernel   RiccatiRecursionSolver::computeDirection (src/ocp/riccati_recursion_solver.cpp:165-251):
+//       costate direction (split_riccati_factorizer.hxx:131-139), ContactDynamics::computeCondensedPrimalDirection
+//       (contact_dynamics.hxx:161-168), slack/dual directions and fraction-to-boundary step sizes
+//       (joint_*_limit.cpp, linearized_friction_cone.cpp:155-182, pdipm.hxx:52-81)
+// K7  ocp_expand_dual_integrate_kernel   OCPLinearizer::integrateSolution (src/ocp/ocp_linearizer.cpp:140-221):
+//       ContactDynamics::computeCondensedDualDirection (contact_dynamics.hxx:171-190), costate correction
+//       (state_equation.hxx:96-108), SplitSolution::integrate (split_solution.hxx:215-240), slack/dual update
+// One wavefront per stage.
+#include <hip/hip_runtime.h>
+
+#include "dev_lie.hpp"
+#include "ocp_device.hpp"
+#include "ocp_launch.hpp"
+
+namespace idocp_dev {
+
+__device__ __forceinline__ double ocpLimit2(const OcpProblem* __restrict__ P, int comp, int r) {
+  switch (comp) {
+    case 0: return P->q_min[r];
+    case 1: return P->q_max[r];
+    case 2: return -P->v_max[r];
+    case 3: return P->v_max[r];
+    case 4: return -P->u_max[r];
+    default: return P->u_max[r];
+  }
+}
+__device__ __forceinline__ bool ocpRowValid2(const OcpProblem* __restrict__ P, int comp, int stage) {
+  if (comp < 2) return P->use_q_limits && stage >= 2;
+  if (comp < 4) return P->use_v_limits && stage >= 1;
+  if (comp < 6) return P->use_u_limits != 0;
+  return P->use_friction_cone != 0;
+}
+__device__ __forceinline__ double frictionJacEntry2(double mu, int r, int x) {
+  const double m2 = mu * 0.70710678118654752440;
+  if (x == 2) return r == 0 ? -1.0 : -m2;
+  if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
+  return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
+}
+__device__ __forceinline__ double f2b(double rate, double x, double dx, double cur) {
+  const double f = -rate * (x / dx);
+  return (f > 0.0 && f < 1.0 && f < cur) ? f : cur;
+}
+
+// One IPM row (joint limit or friction cone) of stage i: value of the
+// constrained function g(x) and its directional derivative dg.
+template <typename D>
+__device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, int i, int row, const double* __restrict__ s,
+                                       const double* dq, const double* dv, const double* du, const double* df_slot, double* g,
+                                       double* dg) {
+  using L = OcpLayout<D>;
+  constexpr int NU = D::NU;
+  if (row < L::C_FRIC) {
+    const int c = row / NU, j = row - c * NU;
+    if (!ocpRowValid2(P, c, i)) return false;
+    const double sgn = (c & 1) ? 1.0 : -1.0;
+    const double x = (c < 2) ? s[L::S_Q + 7 + j] : ((c < 4) ? s[L::S_V + 6 + j] : s[L::S_U + j]);
+    const double dx = (c < 2) ? dq[6 + j] : ((c < 4) ? dv[6 + j] : du[j]);
+    *g = sgn * (x - ocpLimit2(P, c, j));
+    *dg = sgn * dx;
+    return true;
+  }
+  const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
+  if (!ocpRowValid2(P, 6, i) || !P->active[c]) return false;
+  double gg = 0.0, dd = 0.0;
+  for (int x = 0; x < 3; ++x) { const double j = frictionJacEntry2(P->mu, r, x); gg += j * s[L::S_F + 3 * c + x]; dd += j * df_slot[3 * c + x]; }
+  *g = gg; *dg = dd;
+  return true;
+}
+
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
+  __shared__ double dx[NX], du[NU], dfs[NF];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const long b = unit / (N + 1);
+  const int i = (int)(unit - b * (N + 1));
+  double* __restrict__ dd = B.dir + unit * L::DIR;
+  const double* __restrict__ rr = B.ric + unit * L::RIC;
+  if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
+  if (lane < NU && i < N) du[lane] = dd[L::D_U + lane];
+  if (lane < NF) dfs[lane] = 0.0;
+  __syncthreads();
+  if (lane < NV) {
+    const int r = lane;
+    double dl = -rr[L::R_SQ + r], dg = -rr[L::R_SV + r];
+    for (int c = 0; c < NV; ++c) {
+      dl += rr[L::R_PQQ + r + NV * c] * dx[c] + rr[L::R_PQV + r + NV * c] * dx[NV + c];
+      dg += rr[L::R_PQV + c + NV * r] * dx[c] + rr[L::R_PVV + r + NV * c] * dx[NV + c];
+    }
+    dd[L::D_LMD + r] = dl; dd[L::D_GMM + r] = dg;
+  }
+  if (i == N) return;
+  const long su = b * N + i;
+  const double* __restrict__ ee = B.exp + unit * L::EXP;
+  const double* __restrict__ s = B.sol + unit * L::SOL;
+  const int dimf = P->dimf, dimvf = NV + dimf;
+  if (lane < dimvf) {
+    const int r = lane;
+    double acc = -ee[L::E_MJIDC + r];
+    for (int c = 0; c < NX; ++c) acc -= ee[L::E_MJD + r + NVF * c] * dx[c];
+    for (int j = 0; j < NU; ++j) acc += ee[L::E_MJ + r + NVF * (6 + j)] * du[j];
+    if (r < NV) dd[L::D_A + r] = acc;
+    else {
+      // d.df() *= -1; packed active row -> contact slot
+      const int pr = r - NV;
+      for (int c = 0; c < NC; ++c) if (P->active[c] && pr >= P->row_of[c] && pr < P->row_of[c] + 3) {
+        const int slot = 3 * c + (pr - P->row_of[c]);
+        dfs[slot] = -acc; dd[L::D_F + slot] = -acc;
+      }
+    }
+  }
+  __syncthreads();
+  const double* __restrict__ slack = B.slack + su * L::CON;
+  const double* __restrict__ dual = B.dual + su * L::CON;
+  double ps = 1.0, ds = 1.0;
+  for (int row = lane; row < L::NCON; row += 64) {
+    double g, dg;
+    if (!ipmRow<D>(P, i, row, s, dx, dx + NV, du, dfs, &g, &dg)) continue;
+    const double sl = slack[row], dl = dual[row];
+    const double res = g + sl, duality = sl * dl - P->barrier;
+    const double dslack = -dg - res;
+    const double ddual = -(dl * dslack + duality) / sl;
+    ps = f2b(P->fraction_rate, sl, dslack, ps);
+    ds = f2b(P->fraction_rate, dl, ddual, ds);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { ps = fmin(ps, __shfl_xor(ps, off)); ds = fmin(ds, __shfl_xor(ds, off)); }
+  if (lane == 0) { B.step_stage[su * 2] = ps; B.step_stage[su * 2 + 1] = ds; }
+}
+
+__global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long b = blockIdx.x;
+  double ps = 1.0, ds = 1.0;
+  for (int i = threadIdx.x; i < N; i += 64) { ps = fmin(ps, B.step_stage[(b * N + i) * 2]); ds = fmin(ds, B.step_stage[(b * N + i) * 2 + 1]); }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { ps = fmin(ps, __shfl_xor(ps, off)); ds = fmin(ds, __shfl_xor(ds, off)); }
+  if (threadIdx.x == 0) { B.step[b * 2] = ps; B.step[b * 2 + 1] = ds; }
+}
+
+__global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B) {
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long b = blockIdx.x;
+  double e = 0.0;
+  for (int i = threadIdx.x; i <= N; i += 64) e += B.err_stage[b * (N + 1) + i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
+  if (threadIdx.x == 0) B.err[b] = sqrt(e);
+}
+
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
+  __shared__ double dx[NX], du[NU], dfs[NF], laf[NVF + 2], dbm[NVF + 2], dlh[6];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const long b = unit / (N + 1);
+  const int i = (int)(unit - b * (N + 1));
+  const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
+  double* __restrict__ dd = B.dir + unit * L::DIR;
+  double* __restrict__ s = B.sol + unit * L::SOL;
+  const double* __restrict__ ee = B.exp + unit * L::EXP;
+  const int dimf = P->dimf, dimvf = NV + dimf;
+  if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
+  if (lane < 6) dlh[lane] = dd[L::D_LMD + lane];
+  if (i < N) {
+    if (lane < NU) du[lane] = dd[L::D_U + lane];
+    if (lane < NF) dfs[lane] = dd[L::D_F + lane];
+  }
+  __syncthreads();
+  if (i < N) {
+    const double* __restrict__ dgn = dd + L::DIR + L::D_GMM;          // d[i+1].dgmm
+    // ---- ContactDynamics::computeCondensedDualDirection ----
+    if (lane < dimvf) {
+      const int r = lane;
+      double acc = ee[L::E_LAF + r];
+      for (int c = 0; c < NX; ++c) acc += ee[L::E_QAFQV + r + NVF * c] * dx[c];
+      for (int j = 0; j < NU; ++j) acc += ee[L::E_QAFU + r + NVF * j] * du[j];
+      if (r < NV) acc += dt * dgn[r];
+      laf[r] = acc;
+    }
+    if (lane >= 32 && lane < 38) {
+      const int r = lane - 32;
+      double acc = ee[L::E_LUP + r];
+      for (int j = 0; j < NU; ++j) acc += ee[L::E_QUUP + r + 6 * j] * du[j];
+      for (int c = 0; c < NX; ++c) acc += ee[L::E_QXUP + c + NX * r] * dx[c];
+      for (int c = 0; c < NV; ++c) acc += dt * ee[L::E_MJ + r + NVF * c] * dgn[c];
+      dd[L::D_NUP + r] = -acc / dt;
+    }
+    __syncthreads();
+    if (lane < dimvf) {
+      const int r = lane;
+      double acc = 0.0;
+      for (int p = 0; p < dimvf; ++p) acc += ee[L::E_MJ + r + NVF * p] * laf[p];
+      dbm[r] = -acc / dt;
+      if (r < NV) dd[L::D_BETA + r] = dbm[r];
+      else {
+        const int pr = r - NV;
+        for (int c = 0; c < NC; ++c) if (P->active[c] && pr >= P->row_of[c] && pr < P->row_of[c] + 3) dd[L::D_MU + 3 * c + (pr - P->row_of[c])] = dbm[r];
+      }
+    }
+  }
+  // ---- correctCostateDirectionForwardEuler: dlmd.head(6) = -Fqq_prev_inv^T dlmd.head(6) ----
+  double dl_corr = 0.0;
+  if (lane < 6) {
+    double acc = 0.0;
+    for (int m = 0; m < 6; ++m) acc += ee[L::E_FQQPI + m + 6 * lane] * dlh[m];
+    dl_corr = -acc;
+    dd[L::D_LMD + lane] = dl_corr;
+  }
+  __syncthreads();
+  // ---- IPM slack / dual update (needs the pre-update primal variables) ----
+  if (i < N) {
+    const long su = b * N + i;
+    double* __restrict__ slack = B.slack + su * L::CON;
+    double* __restrict__ dual = B.dual + su * L::CON;
+    for (int row = lane; row < L::NCON; row += 64) {
+      double g, dg;
+      const bool valid = ipmRow<D>(P, i, row, s, dx, dx + NV, du, dfs, &g, &dg);
+      const double sl = slack[row], dl = dual[row];
+      double dslack, ddual;
+      if (valid) {
+        const double res = g + sl, duality = sl * dl - P->barrier;
+        dslack = -dg - res;
+        ddual = -(dl * dslack + duality) / sl;
+      } else if (row >= L::C_FRIC && ocpRowValid2(P, 6, i)) {
+        dslack = 1.0; ddual = 1.0;       // rows of inactive contacts (linearized_friction_cone.cpp:162-163)
+      } else {
+        continue;
+      }
+      slack[row] = sl + ap * dslack;
+      dual[row] = dl + ad * ddual;
+    }
+  }
+  __syncthreads();
+  // ---- SplitSolution::integrate ----
+  if (lane < NV) {
+    const int r = lane;
+    s[L::S_LMD + r] += ap * (r < 6 ? dl_corr : dd[L::D_LMD + r]);
+    s[L::S_GMM + r] += ap * dd[L::D_GMM + r];
+    s[L::S_V + r] += ap * dx[NV + r];
+    if (r >= 6) s[L::S_Q + r + 1] += ap * dx[r];
+    if (i < N) {
+      s[L::S_A + r] += ap * dd[L::D_A + r];
+      s[L::S_BETA + r] += ap * dbm[r];
+    }
+  }
+  if (lane == 32) {
+    double qn[7];
+    lieIntegrateBase(s + L::S_Q, dx, ap, qn);
+    for (int k = 0; k < 7; ++k) s[L::S_Q + k] = qn[k];
+  }
+  if (i < N) {
+    if (lane >= 40 && lane < 40 + NU) s[L::S_U + lane - 40] += ap * du[lane - 40];
+    if (lane >= 52 && lane < 58) s[L::S_NUP + lane - 52] += ap * dd[L::D_NUP + lane - 52];
+    if (lane < NF) {
+      const int c = lane / 3;
+      if (P->active[c]) { s[L::S_F + lane] += ap * dfs[lane]; s[L::S_MU + lane] += ap * dd[L::D_MU + lane]; }
+    }
+  }
+}
+
+// SplitOCP::initConstraints -> setSlackAndDual -> pdipm::SetSlackAndDualPositive (split_ocp.hxx:50-55; pdipm.hxx:13-23)
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NU = D::NU;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long su = blockIdx.x;
+  const long b = su / N;
+  const int i = (int)(su - b * N);
+  const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
+  for (int row = threadIdx.x; row < L::NCON; row += 64) {
+    double sl = 1.0, dl = 0.0;
+    bool valid;
+    double g = 0.0;
+    if (row < L::C_FRIC) {
+      const int c = row / NU, j = row - c * NU;
+      valid = ocpRowValid2(P, c, i);
+      if (valid) {
+        const double sgn = (c & 1) ? 1.0 : -1.0;
+        const double x = (c < 2) ? s[L::S_Q + 7 + j] : ((c < 4) ? s[L::S_V + 6 + j] : s[L::S_U + j]);
+        g = sgn * (x - ocpLimit2(P, c, j));
+      }
+    } else {
+      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
+      const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
+      valid = ocpRowValid2(P, 6, i);
+      if (valid) for (int x = 0; x < 3; ++x) g += frictionJacEntry2(P->mu, r, x) * s[L::S_F + 3 * c + x];
+    }
+    if (valid) {
+      sl = -g;
+      while (sl < P->barrier) sl += P->barrier;
+      dl = P->barrier / sl;
+    }
+    B.slack[su * L::CON + row] = sl;
+    B.dual[su * L::CON + row] = dl;
+  }
+}
+
+// setSolution: write `repeat` copies of value[dim] into one field of every stage record
+__global__ void ocp_fill_field_kernel(double* __restrict__ sol, int stride, int offset, int dim, long nrec_per_inst, long batch,
+                                      const double* __restrict__ value, int per_instance, int repeat) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long width = (long)dim * repeat;
+  const long total = batch * nrec_per_inst * width;
+  if (idx >= total) return;
+  const int e = (int)(idx % width);
+  const long rec = idx / width;
+  const long b = rec / nrec_per_inst;
+  sol[rec * stride + offset + e] = value[(per_instance ? b * dim : 0) + (e % dim)];
+}
+
+template <typename D>
+void OcpLaunch<D>::expandPrimal(const OcpBuffers& B, long batch, int N, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+  hipLaunchKernelGGL(ocp_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+}
+template <typename D>
+void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int N, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+}
+template <typename D>
+void OcpLaunch<D>::initConstraints(const OcpBuffers& B, long batch, int N, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_init_constraints_kernel<D>), dim3((unsigned)(batch * N)), dim3(64), 0, st, B);
+}
+
+template <typename D>
+void OcpLaunch<D>::single(int kernel_id, const OcpBuffers& B, long batch, int N, hipStream_t st) {
+  if (kernel_id == 4) hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+  else if (kernel_id == 5) hipLaunchKernelGGL(ocp_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+  else hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+}
+
+void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st) {
+  hipLaunchKernelGGL(ocp_kkt_error_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+}
+
+void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,
+                  int per_instance, int repeat, hipStream_t st) {
+  const long total = batch * nrec_per_inst * dim * repeat;
+  hipLaunchKernelGGL(ocp_fill_field_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sol, stride, offset, dim,
+                     nrec_per_inst, batch, value, per_instance, repeat);
+}
+
+template void OcpLaunch<LeggedDims<4, 3>>::expandPrimal(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::expandDualIntegrate(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::initConstraints(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::single(int, const OcpBuffers&, long, int, hipStream_t);
+
+}  // namespace idocp_dev

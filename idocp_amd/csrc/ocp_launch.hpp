@@ -1,0 +1,29 @@
+// Host-visible launch wrappers of the contact-path kernels.
+#ifndef IDOCP_OCP_LAUNCH_HPP_
+#define IDOCP_OCP_LAUNCH_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include "ocp_device.hpp"
+
+namespace idocp_dev {
+
+template <typename D>
+struct OcpLaunch {
+  static void rnea(const OcpBuffers& B, long batch, int N, hipStream_t st);          // K5a
+  static void condense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st);   // K5b (+ terminal)
+  static void residual(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st);   // K8
+  static void riccatiBackward(const OcpBuffers& B, long batch, int N, hipStream_t st);               // S3
+  static void riccatiForward(const OcpBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);  // S4
+  static void expandPrimal(const OcpBuffers& B, long batch, int N, hipStream_t st);   // K6 (+ step-size reduction)
+  static void expandDualIntegrate(const OcpBuffers& B, long batch, int N, hipStream_t st);   // K7
+  static void initConstraints(const OcpBuffers& B, long batch, int N, hipStream_t st);
+  static void single(int kernel_id, const OcpBuffers& B, long batch, int N, hipStream_t st);   // ids 4, 5, 6
+};
+
+void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st);
+void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,
+                  int per_instance, int repeat, hipStream_t st);
+
+}  // namespace idocp_dev
+#endif  // IDOCP_OCP_LAUNCH_HPP_

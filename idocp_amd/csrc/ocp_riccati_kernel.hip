@@ -1,0 +1,304 @@
+// S3 / S4 -- backward and forward Riccati sweeps of the contact path.
+//
+// Replaces RiccatiRecursionSolver::backwardRiccatiRecursion / computeInitialStateDirection /
+// forwardRiccatiRecursion for a horizon without discrete events (src/ocp/riccati_recursion_solver.cpp:48-162)
+// and the per-stage factorizers they call:
+//   BackwardRiccatiRecursionFactorizer::factorizeKKTMatrix / factorizeRiccatiFactorization
+//                              (include/idocp/ocp/backward_riccati_recursion_factorizer.hxx:44-161)
+//   SplitRiccatiFactorizer::backwardRiccatiRecursion / forwardRiccatiRecursion
+//                              (include/idocp/ocp/split_riccati_factorizer.hxx:36-52, 103-128)
+// The dynamics are x+ = A x + B u + Fx with A = [Fqq Fqv; Fvq Fvv], B = [0; Fvu]; only the leading
+// 6x6 blocks of Fqq / Fqv differ from I / dt I (floating base) and are the only ones stored.
+//
+// S3: one 256-thread workgroup per OCP instance walks the horizon backwards with
+// P_{i+1} and the stage's LQR blocks resident in LDS (~52 kB -> three instances per CU).
+#include <hip/hip_runtime.h>
+
+#include "dev_dense.hpp"
+#include "dev_lie.hpp"
+#include "ocp_device.hpp"
+#include "ocp_launch.hpp"
+
+namespace idocp_dev {
+
+template <typename D>
+struct RiccatiSmem {
+  static constexpr int NV = D::NV, NX = D::NX, NU = D::NU;
+  static constexpr int PQQ = 0, PQV = PQQ + NV * NV, PVV = PQV + NV * NV, SQ = PVV + NV * NV, SV = SQ + NV,
+                       STAGE = SV + NV + 4,                                  // copy of the kkt record
+                       ATPQQ = STAGE + OcpLayout<D>::KKT, ATPQV = ATPQQ + NV * NV, ATPVQ = ATPQV + NV * NV, ATPVV = ATPVQ + NV * NV,
+                       BTPQ = ATPVV + NV * NV, BTPV = BTPQ + NU * NV, KM = BTPV + NU * NV, GK = KM + NU * NX, KV = GK + NU * NX,
+                       GW = KV + 16, SQN = GW + NU * NU, SVN = SQN + NV, TOTAL = SVN + NV + 4;
+};
+
+template <typename D>
+__global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  using S = RiccatiSmem<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_ok;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int tid = threadIdx.x, nt = 256;
+  const long b = blockIdx.x;
+  double* Pqq = &sm[S::PQQ];
+  double* Pqv = &sm[S::PQV];
+  double* Pvv = &sm[S::PVV];
+  double* st = &sm[S::STAGE];
+  if (tid == 0) s_ok = 1;
+  // terminal stage (riccati_recursion_solver.cpp:53-56)
+  {
+    const double* __restrict__ kk = B.kkt + (b * (N + 1) + N) * L::KKT;
+    double* __restrict__ rr = B.ric + (b * (N + 1) + N) * L::RIC;
+    for (int e = tid; e < NN; e += nt) {
+      const int c = e / NV, r = e - c * NV;
+      const double pqq = kk[L::K_QXX + r + NX * c], pvv = kk[L::K_QXX + (NV + r) + NX * (NV + c)];
+      Pqq[e] = pqq; Pqv[e] = 0.0; Pvv[e] = pvv;
+      rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = 0.0; rr[L::R_PVV + e] = pvv;
+    }
+    if (tid < NV) {
+      const double sq = -kk[L::K_LX + tid], sv = -kk[L::K_LX + NV + tid];
+      sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
+      rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
+    }
+  }
+  __syncthreads();
+  for (int i = N - 1; i >= 0; --i) {
+    const double* __restrict__ kk = B.kkt + (b * (N + 1) + i) * L::KKT;
+    for (int e = tid; e < L::KKT; e += nt) st[e] = kk[e];
+    __syncthreads();
+    double* Qxx = st + L::K_QXX;
+    double* Qxu = st + L::K_QXU;
+    double* Quu = st + L::K_QUU;
+    const double* Fqq6 = st + L::K_FQQ;
+    const double* Fqv6 = st + L::K_FQV;
+    const double* Fvq = st + L::K_FVQ;
+    const double* Fvv = st + L::K_FVV;
+    const double* Fvu = st + L::K_FVU;
+    const double* lx = st + L::K_LX;
+    double* lu = st + L::K_LU;
+    const double* Fx = st + L::K_FX;
+    // ---- A^T P blocks and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
+    for (int e = tid; e < NN; e += nt) {
+      const int c = e / NV, r = e - c * NV;
+      double aqq, aqv, avq, avv;
+      if (r < 6) {
+        aqq = aqv = avq = avv = 0.0;
+        for (int m = 0; m < 6; ++m) {
+          const double fq = Fqq6[m + 6 * r], fv = Fqv6[m + 6 * r], pq = Pqq[m + NV * c], pv = Pqv[m + NV * c];
+          aqq += fq * pq; aqv += fq * pv; avq += fv * pq; avv += fv * pv;
+        }
+      } else {
+        aqq = Pqq[e]; aqv = Pqv[e]; avq = dt * Pqq[e]; avv = dt * Pqv[e];
+      }
+      for (int m = 0; m < NV; ++m) {
+        const double fvq = Fvq[m + NV * r], fvv = Fvv[m + NV * r], pvq = Pqv[c + NV * m], pvv = Pvv[m + NV * c];
+        aqq += fvq * pvq; aqv += fvq * pvv; avq += fvv * pvq; avv += fvv * pvv;
+      }
+      sm[S::ATPQQ + e] = aqq; sm[S::ATPQV + e] = aqv; sm[S::ATPVQ + e] = avq; sm[S::ATPVV + e] = avv;
+    }
+    for (int e = tid; e < NU * NV; e += nt) {
+      const int c = e / NU, j = e - c * NU;
+      double bq = 0.0, bv = 0.0;
+      for (int m = 0; m < NV; ++m) { const double f = Fvu[m + NV * j]; bq += f * Pqv[c + NV * m]; bv += f * Pvv[m + NV * c]; }
+      sm[S::BTPQ + e] = bq; sm[S::BTPV + e] = bv;
+    }
+    __syncthreads();
+    const double* AtPqq = &sm[S::ATPQQ];
+    const double* AtPqv = &sm[S::ATPQV];
+    const double* AtPvq = &sm[S::ATPVQ];
+    const double* AtPvv = &sm[S::ATPVV];
+    const double* BtPq = &sm[S::BTPQ];
+    const double* BtPv = &sm[S::BTPV];
+    // ---- F, H, G and the vector term (:79-113) ----
+    for (int e = tid; e < NN; e += nt) {
+      const int c = e / NV, r = e - c * NV;
+      double qqq, qqv, qvv;
+      if (c < 6) {
+        qqq = qqv = qvv = 0.0;
+        for (int m = 0; m < 6; ++m) {
+          qqq += AtPqq[r + NV * m] * Fqq6[m + 6 * c];
+          qqv += AtPqq[r + NV * m] * Fqv6[m + 6 * c];
+          qvv += AtPvq[r + NV * m] * Fqv6[m + 6 * c];
+        }
+      } else {
+        qqq = AtPqq[e]; qqv = dt * AtPqq[e]; qvv = dt * AtPvq[e];
+      }
+      for (int m = 0; m < NV; ++m) {
+        qqq += AtPqv[r + NV * m] * Fvq[m + NV * c];
+        qqv += AtPqv[r + NV * m] * Fvv[m + NV * c];
+        qvv += AtPvv[r + NV * m] * Fvv[m + NV * c];
+      }
+      Qxx[r + NX * c] += qqq;
+      Qxx[r + NX * (NV + c)] += qqv;
+      Qxx[(NV + r) + NX * (NV + c)] += qvv;
+    }
+    for (int e = tid; e < NV * NU; e += nt) {
+      const int j = e / NV, r = e - j * NV;
+      double hq = 0.0, hv = 0.0;
+      for (int m = 0; m < NV; ++m) { const double f = Fvu[m + NV * j]; hq += AtPqv[r + NV * m] * f; hv += AtPvv[r + NV * m] * f; }
+      Qxu[r + NX * j] += hq;
+      Qxu[(NV + r) + NX * j] += hv;
+    }
+    for (int e = tid; e < NU * NU; e += nt) {
+      const int l = e / NU, j = e - l * NU;
+      double g = 0.0;
+      for (int m = 0; m < NV; ++m) g += BtPv[j + NU * m] * Fvu[m + NV * l];
+      Quu[e] += g;
+    }
+    if (tid < NU) {
+      const int j = tid;
+      double acc = 0.0;
+      for (int c = 0; c < NV; ++c) acc += BtPq[j + NU * c] * Fx[c] + BtPv[j + NU * c] * Fx[NV + c];
+      for (int m = 0; m < NV; ++m) acc -= Fvu[m + NV * j] * sm[S::SV + m];
+      lu[j] += acc;
+    }
+    __syncthreads();
+    // Qvq = Qqv^T (:94) -- only read through Qqv below, kept for completeness of the record
+    // ---- LLT(Quu), K = -Quu^-1 Qxu^T, k = -Quu^-1 lu (split_riccati_factorizer.hxx:43-46) ----
+    for (int e = tid; e < NU * NU; e += nt) sm[S::GW + e] = Quu[e];
+    choleskyInPlace(&sm[S::GW], NU, NU, tid, nt, &s_ok);
+    for (int e = tid; e < NU * NX; e += nt) { const int c = e / NU, j = e - c * NU; sm[S::KM + e] = -Qxu[c + NX * j]; }
+    if (tid < NU) sm[S::KV + tid] = -lu[tid];
+    __syncthreads();
+    choleskySolve(&sm[S::GW], NU, NU, &sm[S::KM], NU, NX, tid, nt);
+    if (tid == nt - 1) choleskySolve(&sm[S::GW], NU, NU, &sm[S::KV], NU, 1, 0, 1);
+    __syncthreads();
+    // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
+    mm(colMajor(&sm[S::GK], NU), colMajor(Quu, NU), colMajor(&sm[S::KM], NU), NU, NX, NU, 1.0, false, tid, nt);
+    // s recursion (:141-160) needs P_{i+1}, s_{i+1}: do it before P is overwritten
+    if (tid < NV) {
+      const int r = tid;
+      double sq, sv;
+      if (r < 6) {
+        sq = sv = 0.0;
+        for (int m = 0; m < 6; ++m) { sq += Fqq6[m + 6 * r] * sm[S::SQ + m]; sv += Fqv6[m + 6 * r] * sm[S::SQ + m]; }
+      } else {
+        sq = sm[S::SQ + r]; sv = dt * sm[S::SQ + r];
+      }
+      for (int m = 0; m < NV; ++m) { sq += Fvq[m + NV * r] * sm[S::SV + m]; sv += Fvv[m + NV * r] * sm[S::SV + m]; }
+      for (int c = 0; c < NV; ++c) {
+        sq -= AtPqq[r + NV * c] * Fx[c] + AtPqv[r + NV * c] * Fx[NV + c];
+        sv -= AtPvq[r + NV * c] * Fx[c] + AtPvv[r + NV * c] * Fx[NV + c];
+      }
+      sq -= lx[r]; sv -= lx[NV + r];
+      for (int j = 0; j < NU; ++j) { sq -= Qxu[r + NX * j] * sm[S::KV + j]; sv -= Qxu[(NV + r) + NX * j] * sm[S::KV + j]; }
+      sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
+    }
+    __syncthreads();
+    // P = F - K^T G K (:122-131)
+    for (int e = tid; e < NN; e += nt) {
+      const int c = e / NV, r = e - c * NV;
+      double a = 0.0, b2 = 0.0, d2 = 0.0;
+      for (int j = 0; j < NU; ++j) {
+        const double kq = sm[S::KM + j + NU * r], kv = sm[S::KM + j + NU * (NV + r)];
+        a += kq * sm[S::GK + j + NU * c];
+        b2 += kq * sm[S::GK + j + NU * (NV + c)];
+        d2 += kv * sm[S::GK + j + NU * (NV + c)];
+      }
+      Pqq[e] = Qxx[r + NX * c] - a;
+      Pqv[e] = Qxx[r + NX * (NV + c)] - b2;
+      Pvv[e] = Qxx[(NV + r) + NX * (NV + c)] - d2;
+    }
+    __syncthreads();
+    // preserve the symmetry (:133-135) -- symmetrised values staged in the A^T P scratch
+    for (int e = tid; e < NN; e += nt) {
+      const int c = e / NV, r = e - c * NV;
+      sm[S::ATPQQ + e] = 0.5 * (Pqq[e] + Pqq[c + NV * r]);
+      sm[S::ATPVV + e] = 0.5 * (Pvv[e] + Pvv[c + NV * r]);
+    }
+    __syncthreads();
+    double* __restrict__ rr = B.ric + (b * (N + 1) + i) * L::RIC;
+    double* __restrict__ gg = B.gain + (b * N + i) * L::GAIN;
+    for (int e = tid; e < NN; e += nt) {
+      Pqq[e] = sm[S::ATPQQ + e]; Pvv[e] = sm[S::ATPVV + e];
+      rr[L::R_PQQ + e] = Pqq[e]; rr[L::R_PQV + e] = Pqv[e]; rr[L::R_PVV + e] = Pvv[e];
+    }
+    if (tid < NV) {
+      sm[S::SQ + tid] = sm[S::SQN + tid]; sm[S::SV + tid] = sm[S::SVN + tid];
+      rr[L::R_SQ + tid] = sm[S::SQN + tid]; rr[L::R_SV + tid] = sm[S::SVN + tid];
+    }
+    for (int e = tid; e < NU * NX; e += nt) gg[L::G_K + e] = sm[S::KM + e];
+    if (tid < NU) gg[L::G_k + tid] = sm[S::KV + tid];
+    __syncthreads();
+  }
+  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1;
+}
+
+// S4: forward sweep, one wavefront per instance.
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, const double* __restrict__ q0,
+                                                                const double* __restrict__ v0) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NU = D::NU;
+  __shared__ double dx[NX], du[NU], dxn[NX];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  const double* __restrict__ s0 = B.sol + b * (N + 1) * L::SOL;
+  // RiccatiRecursionSolver::computeInitialStateDirection (riccati_recursion_solver.cpp:110-126)
+  if (lane == 0) {
+    double R[9], p[3], d6[6];
+    lieRelative(s0 + L::S_Q, q0 + b * NQ, R, p);         // q (-) s[0].q
+    lieLog6(R, p, d6);
+    const double* __restrict__ Fi = B.exp + b * (N + 1) * L::EXP + L::E_FQQPI;
+    for (int r = 0; r < 6; ++r) { double acc = 0.0; for (int m = 0; m < 6; ++m) acc += Fi[r + 6 * m] * d6[m]; dx[r] = -acc; }
+  }
+  if (lane >= 6 && lane < NV) dx[lane] = q0[b * NQ + lane + 1] - s0[L::S_Q + lane + 1];
+  if (lane < NV) dx[NV + lane] = v0[b * NV + lane] - s0[L::S_V + lane];
+  __syncthreads();
+  for (int i = 0; i < N; ++i) {
+    const double* __restrict__ gg = B.gain + (b * N + i) * L::GAIN;
+    const double* __restrict__ kk = B.kkt + (b * (N + 1) + i) * L::KKT;
+    double* __restrict__ dd = B.dir + (b * (N + 1) + i) * L::DIR;
+    if (lane < NU) {
+      double acc = gg[L::G_k + lane];
+      for (int c = 0; c < NX; ++c) acc += gg[L::G_K + lane + NU * c] * dx[c];
+      du[lane] = acc;
+      dd[L::D_U + lane] = acc;
+    }
+    if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
+    __syncthreads();
+    if (lane < NV) {
+      const int r = lane;
+      double dq = kk[L::K_FX + r], dv = kk[L::K_FX + NV + r];
+      if (r < 6) {
+        for (int m = 0; m < 6; ++m) dq += kk[L::K_FQQ + r + 6 * m] * dx[m] + kk[L::K_FQV + r + 6 * m] * dx[NV + m];
+      } else {
+        dq += dx[r] + dt * dx[NV + r];
+      }
+      for (int c = 0; c < NV; ++c) dv += kk[L::K_FVQ + r + NV * c] * dx[c] + kk[L::K_FVV + r + NV * c] * dx[NV + c];
+      for (int j = 0; j < NU; ++j) dv += kk[L::K_FVU + r + NV * j] * du[j];
+      dxn[r] = dq; dxn[NV + r] = dv;
+    }
+    __syncthreads();
+    if (lane < NX) dx[lane] = dxn[lane];
+    __syncthreads();
+  }
+  double* __restrict__ dd = B.dir + (b * (N + 1) + N) * L::DIR;
+  if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
+}
+
+template <typename D>
+void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int N, hipStream_t st) {
+  const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((ocp_riccati_backward_kernel<D>), dim3((unsigned)batch), dim3(256), smem, st, B);
+}
+template <typename D>
+void OcpLaunch<D>::riccatiForward(const OcpBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_riccati_forward_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0);
+}
+
+template void OcpLaunch<LeggedDims<4, 3>>::riccatiBackward(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::riccatiForward(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
+
+}  // namespace idocp_dev

@@ -222,6 +222,67 @@ int idocp_rnea_derivatives(const idocp_model_t* model, int n, const double* q,
                            double* dtau_dq, double* dtau_dv, double* dtau_da,
                            int device);
 
+/* ---- OCPSolver (floating base + point contacts) --------------------------- */
+
+typedef struct idocp_ocp idocp_ocp_t;
+
+/* OCPSolver::OCPSolver(robot, cost, constraints, T, N, max_num_impulse, nthreads)
+ * (src/ocp/ocp_solver.cpp:9-47).  This build carries the kernels for a quadruped
+ * (free-flyer + 4 legs x 3 revolute joints, one point contact per foot) and a
+ * contact sequence WITHOUT discrete events (setContactStatusUniformly only);
+ * impulse / lift stages are rejected with IDOCP_E_UNSUPPORTED. */
+int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost,
+                     const idocp_constraints_t* constraints, double T, int N,
+                     int batch, int device, idocp_ocp_t** out);
+void idocp_ocp_destroy(idocp_ocp_t* h);
+/* OCPSolver::setContactStatusUniformly (ocp_solver.cpp:169-171): active[ncontacts]
+ * flags and the world contact points contact_points[ncontacts][3]
+ * (ContactStatus::setContactPoints). */
+int idocp_ocp_set_contact_status_uniformly(idocp_ocp_t* h, const int* active,
+                                           const double* contact_points);
+/* OCPSolver::setSolution (ocp_solver.cpp:95-165): name in {"q","v","a","f","u"};
+ * "f" takes one 3-vector written to every contact.  Does not re-initialise the
+ * constraints (like the reference). */
+int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value);
+int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double* values);
+/* OCPSolver::initConstraints(t) (ocp_solver.cpp:60-64). */
+int idocp_ocp_init_constraints(idocp_ocp_t* h, double t);
+/* OCPSolver::updateSolution (ocp_solver.cpp:67-92). q[batch][nq], v[batch][nv]. */
+int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q,
+                              const double* v, int line_search);
+int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
+                                     const double* d_v);
+int idocp_ocp_synchronize(idocp_ocp_t* h);
+void* idocp_ocp_stream(idocp_ocp_t* h);
+/* OCPSolver::computeKKTResidual + KKTError (ocp_solver.cpp:202-213). */
+int idocp_ocp_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q,
+                                   const double* v);
+int idocp_ocp_kkt_error(idocp_ocp_t* h, double* kkt_error);
+/* OCPSolver::getSolution(name): q v a u f lmd gmm beta mu nu_passive; out[(N+1)][dim]
+ * (f, mu: [ncontacts*3] per stage; stage-only fields fill N rows). */
+int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, double* out);
+/* Newton direction: dq dv da du df dlmd dgmm dbeta dmu dnu_passive. */
+int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out);
+int idocp_ocp_get_step_sizes(idocp_ocp_t* h, double* primal, double* dual);
+/* P[N+1][2nv*2nv], s[N+1][2nv], K[N][nu*2nv] (nu x 2nv col-major), k[N][nu]. */
+int idocp_ocp_get_riccati(idocp_ocp_t* h, int instance, double* P, double* s, double* K,
+                          double* k);
+/* OCPSolver::getStateFeedbackGain (ocp_solver.cpp:101-111): Kq, Kv (nu x nv col-major). */
+int idocp_ocp_get_state_feedback_gain(idocp_ocp_t* h, int instance, int stage, double* Kq,
+                                      double* Kv);
+int idocp_ocp_dimc(const idocp_ocp_t* h);
+int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual);
+/* Condensed LQR data of one stage after the linearisation kernels (parity tests):
+ * Qxx[2nv*2nv], Qxu[2nv*nu], Quu[nu*nu], A[2nv*2nv], B[2nv*nu], lx[2nv], lu[nu], Fx[2nv]. */
+int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu,
+                            double* Quu, double* A, double* B, double* lx, double* lu,
+                            double* Fx);
+/* One kernel launch: 0 = tangent RNEA, 1 = condense, 2 = backward Riccati,
+ * 3 = forward Riccati, 4 = expand primal, 5 = step-size reduction,
+ * 6 = expand dual + integrate. */
+int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q,
+                            const double* d_v);
+
 const char* idocp_last_error(void);
 const char* idocp_version(void);
 

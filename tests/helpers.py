@@ -374,3 +374,83 @@ def anymal_contact_points(model):
     lib.oracle_contact_kinematics(C.byref(model), P(q), P(z), P(z), P(np.zeros((nc, 3))), C.c_double(0.05), P(tmp[0]), P(tmp[1]),
                                   P(tmp[2]), P(tmp[3]), P(fp), P(fR), P(fv), P(fa), P(d4[0]), P(d4[1]), P(d4[2]), P(d4[3]), None)
     return fp
+
+
+class HipOCP:
+    """Contact path through the C ABI (idocp_ocp_*)."""
+
+    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
+        self.lib = capi.lib()
+        self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
+        h = C.c_void_p()
+        capi.check(self.lib.idocp_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
+                   "idocp_ocp_create")
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.idocp_ocp_destroy(self.h)
+            self.h = None
+
+    def set_contact_status(self, active, points):
+        a = (C.c_int * 4)(*[int(x) for x in active])
+        capi.check(self.lib.idocp_ocp_set_contact_status_uniformly(self.h, a, P(arr(points))), "set_contact_status")
+
+    def set_solution(self, name, value):
+        capi.check(self.lib.idocp_ocp_set_solution(self.h, name.encode(), P(arr(value))), "set_solution")
+
+    def set_solution_batch(self, name, values):
+        capi.check(self.lib.idocp_ocp_set_solution_batch(self.h, name.encode(), P(arr(values))), "set_solution_batch")
+
+    def init_constraints(self, t=0.0):
+        capi.check(self.lib.idocp_ocp_init_constraints(self.h, t), "init_constraints")
+
+    def _bc(self, x, dim):
+        x = arr(x)
+        return arr(np.broadcast_to(x, (self.batch, dim))) if x.ndim == 1 else x
+
+    def update(self, t, q, v):
+        return self.lib.idocp_ocp_update_solution(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv)), 0)
+
+    def kkt_error(self, t, q, v):
+        capi.check(self.lib.idocp_ocp_compute_kkt_residual(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv))),
+                   "compute_kkt_residual")
+        out = np.zeros(self.batch)
+        capi.check(self.lib.idocp_ocp_kkt_error(self.h, P(out)), "kkt_error")
+        return out
+
+    def get(self, name, instance=0):
+        if name in OCP_SOL_FIELDS:
+            dim, fn = OCP_SOL_FIELDS[name], self.lib.idocp_ocp_get_solution
+        else:
+            dim, fn = OCP_DIR_FIELDS[name], self.lib.idocp_ocp_get_direction
+        out = np.zeros((self.N + 1, dim))
+        capi.check(fn(self.h, name.encode(), instance, P(out)), "get " + name)
+        return out[:self.N] if name in OCP_STAGE_ONLY else out
+
+    def step_sizes(self):
+        a, b = np.zeros(self.batch), np.zeros(self.batch)
+        capi.check(self.lib.idocp_ocp_get_step_sizes(self.h, P(a), P(b)), "get_step_sizes")
+        return a, b
+
+    def riccati(self, instance=0):
+        nv, nu, N = self.nv, self.nu, self.N
+        Pm, s = np.zeros((N + 1, 2 * nv, 2 * nv)), np.zeros((N + 1, 2 * nv))
+        K, k = np.zeros((N, 2 * nv, nu)), np.zeros((N, nu))
+        capi.check(self.lib.idocp_ocp_get_riccati(self.h, instance, P(Pm), P(s), P(K), P(k)), "get_riccati")
+        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
+
+    def constraint_data(self, instance=0):
+        dimc = self.lib.idocp_ocp_dimc(self.h)
+        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
+        capi.check(self.lib.idocp_ocp_get_constraint_data(self.h, instance, P(sl), P(du)), "get_constraint_data")
+        return sl, du
+
+    def lqr_stage(self, i, instance=0):
+        nv, nu = self.nv, self.nu
+        nx = 2 * nv
+        Qxx, Qxu, Quu, A, B = np.zeros((nx, nx)), np.zeros((nu, nx)), np.zeros((nu, nu)), np.zeros((nx, nx)), np.zeros((nu, nx))
+        lx, lu, Fx = np.zeros(nx), np.zeros(nu), np.zeros(nx)
+        capi.check(self.lib.idocp_ocp_get_lqr_stage(self.h, instance, i, P(Qxx), P(Qxu), P(Quu), P(A), P(B), P(lx), P(lu), P(Fx)),
+                   "get_lqr_stage")
+        return Qxx.T, Qxu.T, Quu.T, A.T, B.T, lx, lu, Fx

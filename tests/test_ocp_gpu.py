@@ -1,0 +1,172 @@
+"""GPU parity tests of the OCPSolver hot path (ANYmal, uniform 4-contact horizon)
+through the C ABI.  Bar: Newton direction within 1e-10 (FP64) of the CPU
+restatement (BASELINE.json north_star), as max-abs error / max(1, max|ref|)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from idocp_amd import capi
+from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, P, anymal_contact_points,
+                     anymal_model, anymal_problem, arr, rel_err)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def make_pair(N, T, batch=1, trotting_ref=True, perturb=0.02, seed=3, active=(1, 1, 1, 1)):
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=trotting_ref)
+    o = OracleOCP(m, cost, cons, T, N)
+    g = HipOCP(m, cost, cons, T, N, batch=batch)
+    pts = anymal_contact_points(m)
+    q = ANYMAL_Q_STANDING.copy()
+    v = np.zeros(m.nv)
+    f0 = [0, 0, 0.25 * (-m.total_mass * m.gravity[2])]
+    for s in (o, g):
+        s.set_contact_status(active, pts)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", f0)
+        s.init_constraints(0.0)
+    rng = np.random.default_rng(seed)
+    q[7:] += perturb * rng.uniform(-1, 1, 12)
+    q[0:2] += perturb * rng.uniform(-1, 1, 2)
+    return m, o, g, q, v
+
+
+def test_lqr_stage_parity_after_linearisation_kernels():
+    # kernel-level: K5a + K5b against SplitOCP::linearizeOCP of the oracle
+    m, o, g, q, v = make_pair(6, 0.3)
+    assert o.update(0.2, q, v) == 0 and g.update(0.2, q, v) == 0       # move off the initial guess
+    assert o.stage(0, 0.2, q, v) == 0
+    d_q, d_v = C.c_void_p(), C.c_void_p()
+    lib = capi.lib()
+    capi.check(lib.idocp_device_alloc(C.byref(d_q), q.nbytes))
+    capi.check(lib.idocp_device_alloc(C.byref(d_v), v.nbytes))
+    capi.check(lib.idocp_device_upload(d_q, arr(q).ctypes.data, q.nbytes))
+    capi.check(lib.idocp_device_upload(d_v, arr(v).ctypes.data, v.nbytes))
+    # solution states must agree before comparing the linearisation
+    for f in OCP_SOL_FIELDS:
+        assert rel_err(g.get(f), o.get(f)) < TOL, f
+    capi.check(lib.idocp_ocp_launch_kernel(g.h, 0, d_q, d_v))
+    capi.check(lib.idocp_ocp_launch_kernel(g.h, 1, d_q, d_v))
+    capi.check(lib.idocp_ocp_synchronize(g.h))
+    names = ("Qxx", "Qxu", "Quu", "A", "B", "lx", "lu", "Fx")
+    for i in range(o.N):
+        for name, a, b in zip(names, g.lqr_stage(i), o.lqr_stage(i)):
+            if name == "Qxx":       # the lower-left block (Qvq) is only filled by the Riccati sweep
+                a, b = np.triu(a), np.triu(b)
+            assert rel_err(a, b) < TOL, (i, name)
+
+
+@pytest.mark.parametrize("N,T,t", [(20, 1.0, 0.0), (100, 5.0, 0.0), (9, 0.45, 0.37)])
+def test_first_iteration_direction_parity(N, T, t):
+    m, o, g, q, v = make_pair(N, T)
+    assert o.update(t, q, v) == 0
+    assert g.update(t, q, v) == 0
+    for f in OCP_DIR_FIELDS:
+        assert rel_err(g.get(f), o.get(f)) < TOL, f
+    ao, bo = o.step_sizes()
+    ag, bg = g.step_sizes()
+    assert abs(ag[0] - ao) < 1e-10 and abs(bg[0] - bo) < 1e-10
+    for f in OCP_SOL_FIELDS:
+        assert rel_err(g.get(f), o.get(f)) < TOL, f
+    Po, so, Ko, ko = o.riccati()
+    Pg, sg, Kg, kg = g.riccati()
+    assert rel_err(Pg, Po) < TOL and rel_err(sg, so) < TOL and rel_err(Kg, Ko) < TOL and rel_err(kg, ko) < TOL
+    sl_o, du_o = o.constraint_data()
+    sl_g, du_g = g.constraint_data()
+    assert rel_err(sl_g, sl_o) < TOL and rel_err(du_g, du_o) < TOL
+
+
+def test_multi_iteration_parity_and_convergence():
+    m, o, g, q, v = make_pair(20, 0.5, trotting_ref=False)
+    e_o = [o.kkt_error(0.0, q, v)]
+    e_g = [g.kkt_error(0.0, q, v)[0]]
+    assert abs(e_g[0] - e_o[0]) < 1e-9 * max(1.0, e_o[0])
+    for it in range(30):
+        assert o.update(0.0, q, v) == 0
+        assert g.update(0.0, q, v) == 0
+        e_o.append(o.kkt_error(0.0, q, v))
+        e_g.append(g.kkt_error(0.0, q, v)[0])
+        if it < 4:
+            for f in OCP_DIR_FIELDS:
+                assert rel_err(g.get(f), o.get(f)) < 1e-8, (it, f)
+            assert abs(e_g[-1] - e_o[-1]) < 1e-8 * max(1.0, e_o[-1])
+    assert e_g[-1] < 1e-4 * e_g[0] and e_o[-1] < 1e-4 * e_o[0]
+    for f in ("q", "v", "a", "u", "f"):
+        assert rel_err(g.get(f), o.get(f)) < 1e-6, f
+
+
+def test_batch_instances_and_ragged_sizes():
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    pts = anymal_contact_points(m)
+    N, T = 12, 0.6
+    f0 = [0, 0, 0.25 * (-m.total_mass * m.gravity[2])]
+    rng = np.random.default_rng(20250)
+    for batch in (1, 5):
+        g = HipOCP(m, cost, cons, T, N, batch=batch)
+        g.set_contact_status([1, 1, 1, 1], pts)
+        q0 = np.tile(ANYMAL_Q_STANDING, (batch, 1))
+        q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (batch, 12))
+        q0[:, 0:2] += 0.02 * rng.uniform(-1, 1, (batch, 2))
+        v0 = np.zeros((batch, m.nv))
+        g.set_solution_batch("q", q0)
+        g.set_solution("v", v0[0])
+        g.set_solution("f", f0)
+        g.init_constraints(0.0)
+        assert g.update(0.1, q0, v0) == 0
+        for b in range(batch):
+            o = OracleOCP(m, cost, cons, T, N)
+            o.set_contact_status([1, 1, 1, 1], pts)
+            o.set_solution("q", q0[b])
+            o.set_solution("v", v0[b])
+            o.set_solution("f", f0)
+            o.init_constraints(0.0)
+            assert o.update(0.1, q0[b], v0[b]) == 0
+            for f in OCP_DIR_FIELDS:
+                assert rel_err(g.get(f, b), o.get(f)) < TOL, (batch, b, f)
+
+
+def test_state_feedback_gain_and_unsupported_inputs():
+    m, o, g, q, v = make_pair(8, 0.4)
+    o.update(0.0, q, v)
+    g.update(0.0, q, v)
+    _, _, Ko, _ = o.riccati()
+    Kq, Kv = np.zeros((m.nv, m.nu)), np.zeros((m.nv, m.nu))
+    capi.check(g.lib.idocp_ocp_get_state_feedback_gain(g.h, 0, 3, P(Kq), P(Kv)))
+    assert rel_err(Kq.T, Ko[3][:, :m.nv]) < TOL and rel_err(Kv.T, Ko[3][:, m.nv:]) < TOL
+    assert g.lib.idocp_ocp_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 1) == -4      # line search: unsupported
+
+
+def test_full_size_properties_c3():
+    # BASELINE config C3 size (ANYmal, N=100, 4 contacts) with a batch: size-independent properties
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    pts = anymal_contact_points(m)
+    N, T, batch = 100, 5.0, 64
+    g = HipOCP(m, cost, cons, T, N, batch=batch)
+    g.set_contact_status([1, 1, 1, 1], pts)
+    rng = np.random.default_rng(20250)
+    q0 = np.tile(ANYMAL_Q_STANDING, (batch, 1))
+    q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (batch, 12))
+    q0[1] = q0[0]
+    v0 = np.zeros((batch, m.nv))
+    g.set_solution_batch("q", q0)
+    g.set_solution("v", v0[0])
+    g.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    g.init_constraints(0.0)
+    e0 = g.kkt_error(0.0, q0, v0)
+    for _ in range(40):
+        assert g.update(0.0, q0, v0) == 0
+    e1 = g.kkt_error(0.0, q0, v0)
+    assert np.isfinite(e1).all() and (e1 < 1e-2 * e0).all(), (e0.max(), e1.max())
+    assert np.array_equal(g.get("q", 0), g.get("q", 1))              # identical instances, identical results
+    qs = g.get("q", 5)
+    assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12   # quaternions stay normalised
+    Pm, s, K, k = g.riccati(5)
+    assert np.abs(Pm - Pm.transpose(0, 2, 1)).max() < 1e-8 * np.abs(Pm).max()
+    sl, du = g.constraint_data(5)
+    assert (sl[2:] > 0).all() and (du[2:] > 0).all()
