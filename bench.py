@@ -31,8 +31,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE_IIWA = 5544            # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 5
-KERNELS = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
+A_STAGE = {"iiwa14": 5544, "anymal": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 5
+KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
+KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
+               "ocp_reduce_steps", "ocp_expand_dual_integrate"]
 
 
 class Hip:
@@ -62,22 +64,34 @@ class Hip:
         return ms.value
 
 
-def cpu_baseline(model, cost, cons, T, N, q, v, target_seconds=12.0):
+def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=12.0):
     """CPU restatement (oracle, kind "port") timed on this host with the
     reference's CPUTime protocol, single thread, on a bounded sample."""
-    from helpers import OracleUnOCP, P, arr, oracle
-    o = OracleUnOCP(model, cost, cons, T, N)
-    o.set_solution("q", q)
-    o.set_solution("v", v)
+    from helpers import OracleOCP, OracleUnOCP, P, arr, oracle
     lib = oracle()
     ric = C.c_double()
-    for _ in range(50):                       # converge first (examples/iiwa14/unocp_benchmark.cpp:50-52)
+    if workload == "iiwa14":
+        o = OracleUnOCP(model, cost, cons, T, N)
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        bench = lib.oracle_unocp_bench
+        nconv = 50
+    else:
+        o = OracleOCP(model, cost, cons, T, N)
+        o.set_contact_status([1, 1, 1, 1], pts)
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+        o.init_constraints(0.0)
+        bench = lib.oracle_ocp_bench
+        nconv = 10
+    for _ in range(nconv):                    # converge first (examples/*/…_benchmark.cpp call Convergence before CPUTime)
         o.update(0.0, q, v)
-    t_probe = lib.oracle_unocp_bench(o.h, 0.0, P(arr(q)), P(arr(v)), 20, C.byref(ric))
-    iters = int(max(20, min(20000, target_seconds / max(t_probe / 20, 1e-9))))
-    el = lib.oracle_unocp_bench(o.h, 0.0, P(arr(q)), P(arr(v)), iters, C.byref(ric))
+    t_probe = bench(o.h, 0.0, P(arr(q)), P(arr(v)), 5, C.byref(ric))
+    iters = int(max(5, min(20000, target_seconds / max(t_probe / 5, 1e-9))))
+    el = bench(o.h, 0.0, P(arr(q)), P(arr(v)), iters, C.byref(ric))
     return {"value": iters / el, "unit": "SQP iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d updateSolution calls of one iiwa14 N=%d instance, single thread (oracle/, -O3)" % (iters, N),
+            "sample": "%d updateSolution calls of one %s N=%d instance, single thread (oracle/, -O3)" % (iters, workload, N),
             "ms_per_update": 1e3 * el / iters, "ms_per_riccati_sweep": 1e3 * ric.value / iters}
 
 
@@ -86,7 +100,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16384, help="independent OCP instances per GPU")
+    ap.add_argument("--workload", choices=["anymal", "iiwa14"], default="anymal")
+    ap.add_argument("--batch", type=int, default=0, help="independent OCP instances per GPU (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -102,40 +117,74 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from idocp_amd import capi
-    from helpers import HipUnOCP, iiwa14_model, unocp_problem
+    from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,
+                         unocp_problem)
     lib = capi.lib()                       # fails loudly if the HIP extension is missing
     hip = Hip()
     hip.rt.hipSetDevice(local_rank)
 
-    # workload: BASELINE.json configs[1] -- iiwa14 UnOCPSolver, N=100, T=5 (dt=0.05), FP64,
-    # batch of instances with perturbed initial states
-    N, T, B = args.horizon, 0.05 * args.horizon, args.batch
-    model = iiwa14_model()
-    cost, cons = unocp_problem(model)
-    nv = model.nv
+    N = args.horizon
+    T = 0.05 * N
     rng = np.random.default_rng(20240 + rank)
-    q0 = np.ascontiguousarray(2.0 + 0.1 * rng.uniform(-1, 1, (B, nv)))
-    v0 = np.zeros((B, nv))
-    solver = HipUnOCP(model, cost, cons, T, N, batch=B, device=local_rank)
-    solver.set_solution_batch("q", q0)
-    solver.set_solution("v", v0[0])
+    pts = None
+    if args.workload == "anymal":
+        # BASELINE.json configs[2] / metric config: ANYmal OCPSolver, N=100, T=5 (dt=0.05), 4 point contacts active on
+        # every stage (the uniform-contact variant of SURVEY 8d C3: trotting cost + linearized friction cone), FP64
+        B = args.batch or 1024
+        model = anymal_model()
+        cost, cons = anymal_problem(model, trotting_ref=True)
+        pts = anymal_contact_points(model)
+        nq, nv = model.nq, model.nv
+        q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
+        q0[:, 0:2] += 0.02 * rng.uniform(-1, 1, (B, 2))
+        q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
+        q0 = np.ascontiguousarray(q0)
+        v0 = np.zeros((B, nv))
+        solver = HipOCP(model, cost, cons, T, N, batch=B, device=local_rank)
+        solver.set_contact_status([1, 1, 1, 1], pts)
+        solver.set_solution_batch("q", q0)
+        solver.set_solution("v", v0[0])
+        solver.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+        solver.init_constraints(0.0)
+        KERNELS = KERNELS_OCP
+        launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
+        units = {0: B * N, 1: B * (N + 1), 2: B * N, 3: B * N, 4: B * (N + 1), 5: B * N, 6: B * (N + 1)}
+        riccati_ids = (2, 3)
+        desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, 4 point contacts active on every stage (BASELINE.json configs[2], "
+                "uniform-contact variant), trotting cost + joint limits + linearized friction cone; " % (N, T))
+        assert solver.update(0.0, q0, v0) == 0            # one full update through the host entry (uploads the stage references)
+    else:
+        # BASELINE.json configs[1]: iiwa14 UnOCPSolver, N=100, T=5, FP64
+        B = args.batch or 16384
+        model = iiwa14_model()
+        cost, cons = unocp_problem(model)
+        nq, nv = model.nq, model.nv
+        q0 = np.ascontiguousarray(2.0 + 0.1 * rng.uniform(-1, 1, (B, nv)))
+        v0 = np.zeros((B, nv))
+        solver = HipUnOCP(model, cost, cons, T, N, batch=B, device=local_rank)
+        solver.set_solution_batch("q", q0)
+        solver.set_solution("v", v0[0])
+        KERNELS = KERNELS_UN
+        launch, sync_fn, stream = lib.idocp_unocp_launch_kernel, lib.idocp_unocp_synchronize, lib.idocp_unocp_stream(solver.h)
+        units = {0: B * N, 1: B * N, 2: B * N, 3: B * (N + 1), 4: B * N, 5: B * (N + 1)}
+        riccati_ids = (1, 2)
+        desc = "iiwa14 UnOCPSolver N=%d T=%.2f FP64 (BASELINE.json configs[1]); " % (N, T)
     d_q, d_v = C.c_void_p(), C.c_void_p()
     capi.check(lib.idocp_device_alloc(C.byref(d_q), q0.nbytes))
     capi.check(lib.idocp_device_alloc(C.byref(d_v), v0.nbytes))
     capi.check(lib.idocp_device_upload(d_q, q0.ctypes.data, q0.nbytes))
     capi.check(lib.idocp_device_upload(d_v, v0.ctypes.data, v0.nbytes))
-    stream = lib.idocp_unocp_stream(solver.h)
 
     def step(events=None):
         for kid in range(len(KERNELS)):
             if events is not None:
                 hip.record(events[kid], stream)
-            capi.check(lib.idocp_unocp_launch_kernel(solver.h, kid, d_q, d_v), KERNELS[kid])
+            capi.check(launch(solver.h, kid, d_q, d_v), KERNELS[kid])
         if events is not None:
             hip.record(events[len(KERNELS)], stream)
 
     def sync():
-        capi.check(lib.idocp_unocp_synchronize(solver.h))
+        capi.check(sync_fn(solver.h))
         hip.rt.hipDeviceSynchronize()
         if dist is not None:
             import torch
@@ -168,15 +217,15 @@ def main():
             kms[kid] += hip.elapsed_ms(ev[k][kid], ev[k][kid + 1])
     kms /= args.steps
     dom = int(np.argmax(kms))
-    units = {0: B * N, 1: B * N, 2: B * N, 3: B * (N + 1), 4: B * N, 5: B * (N + 1)}
-    alg_bytes = A_STAGE_IIWA * units[dom]
+    a_stage = A_STAGE[args.workload]
+    alg_bytes = a_stage * units[dom]
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("batch") == B and rec.get("horizon") == N:
+            if rec.get("batch") == B and rec.get("horizon") == N and rec.get("workload", "iiwa14") == args.workload:
                 traffic = rec.get("hbm_bytes_per_launch", {}).get(KERNELS[dom])
         except Exception:
             traffic = None
@@ -192,19 +241,18 @@ def main():
             "metric": "SQP iterations/sec (whole node)", "value": total_iters / el, "unit": "SQP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "iiwa14 UnOCPSolver N=%d T=%.2f FP64 (BASELINE.json configs[1]); "
-                                   "batch=%d independent OCP instances per GPU, replicas across GPUs" % (N, T, B),
+            "config": {"workload": desc + "batch=%d independent OCP instances per GPU, replicas across GPUs" % B,
                        "horizon": N, "batch_per_gpu": B, "parallelism": "replicas x%d" % world,
-                       "ms_per_riccati_sweep": float(kms[1] + kms[2]),
+                       "ms_per_riccati_sweep": float(sum(kms[i] for i in riccati_ids)),
                        "kernel_ms": {KERNELS[i]: float(kms[i]) for i in range(len(KERNELS))},
                        "max_kkt_error_after": float(np.max(kkt))},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kms[dom]),
-                         "whole_step_frac": A_STAGE_IIWA * B * (N + 1) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "whole_step_frac": a_stage * B * (N + 1) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, cost, cons, T, N, q0[0], v0[0])
+            out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
