@@ -64,6 +64,36 @@ __device__ __forceinline__ void choleskyInPlace(double* A, int ld, int n, int ti
   __syncthreads();
 }
 
+// In-place inverse of an SPD n x n column-major block by Gauss-Jordan
+// elimination without pivoting (stable for SPD: every pivot is a positive Schur
+// complement).  n steps of fully parallel O(n^2) work and two barriers each --
+// no triangular solves with only n busy threads, which is what makes it the
+// better fit for a 256-thread workgroup than Cholesky + substitution.
+__device__ __forceinline__ void spdInverseInPlace(double* A, int ld, int n, int tid, int nthreads, int* ok) {
+  for (int k = 0; k < n; ++k) {
+    __syncthreads();
+    const double p = A[k + k * ld];
+    if (tid == 0 && !(p > 0.0)) *ok = 0;
+    const double ip = 1.0 / p;
+    double upd[4];                         // n*n <= 4 * nthreads for every block on this path
+    int cnt = 0;
+    for (int e = tid; e < n * n; e += nthreads, ++cnt) {
+      const int j = e / n, i = e - j * n;
+      const double aik = A[i + k * ld], akj = A[k + j * ld], aij = A[i + j * ld];
+      double v;
+      if (i == k && j == k) v = ip;
+      else if (i == k) v = akj * ip;
+      else if (j == k) v = -aik * ip;
+      else v = aij - aik * akj * ip;
+      upd[cnt & 3] = v;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int e = tid; e < n * n; e += nthreads, ++cnt) { const int j = e / n, i = e - j * n; A[i + j * ld] = upd[cnt & 3]; }
+  }
+  __syncthreads();
+}
+
 // Solve L L^T X = Bm for nrhs columns, one thread per right-hand side (in place).
 __device__ __forceinline__ void choleskySolve(const double* Lm, int ld, int n, double* X, int ldx, int nrhs, int tid, int nthreads) {
   for (int c = tid; c < nrhs; c += nthreads) {

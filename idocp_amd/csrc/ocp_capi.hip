@@ -205,6 +205,7 @@ int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const
   if ((rc = allocBufO(h, &B.slack, n0 * LQ::CON))) return fail(rc);
   if ((rc = allocBufO(h, &B.dual, n0 * LQ::CON))) return fail(rc);
   if ((rc = allocBufO(h, &B.lin, n0 * LQ::LIN))) return fail(rc);
+  if ((rc = allocBufO(h, &B.lie, n1 * LQ::LIE))) return fail(rc);
   if ((rc = allocBufO(h, &B.kkt, n1 * LQ::KKT))) return fail(rc);
   if ((rc = allocBufO(h, &B.exp, n1 * LQ::EXP))) return fail(rc);
   if ((rc = allocBufO(h, &B.ric, n1 * LQ::RIC))) return fail(rc);

@@ -63,7 +63,7 @@ struct CondenseSmem {
 };
 
 template <typename D, bool RESIDUAL>
-__global__ __launch_bounds__(256) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
+__global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
   using L = OcpLayout<D>;
   using S = CondenseSmem<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
@@ -96,25 +96,14 @@ __global__ __launch_bounds__(256) void ocp_condense_kernel(OcpBuffers B, const d
   for (int e = tid; e < NX * NX + NX * NV + NV * NV; e += nt) sm[S::QXX + e] = 0.0;              // QXX, QXU, QUU contiguous
   for (int e = tid; e < NF * NF; e += nt) sm[S::QFF + e] = 0.0;
   if (tid == 0) s_ok = 1;
-  // ---- B. Lie-group terms of the floating base (one lane per task) ----
-  if (tid == 0) {              // cost: qdiff = q (-) q_ref, Jq = d qdiff / dq   (ARG1)
-    double R[9], p[3];
-    lieRelative(qref, q, R, p);
-    lieLog6(R, p, &sm[S::QDIFF]);
-    lieJlog6(R, p, &sm[S::JQ]);
-  } else if (tid == 64 && !terminal) {   // state equation: s.q (-) q_next
-    double R[9], p[3], J0[36];
-    lieRelative(sn + L::S_Q, q, R, p);
-    lieLog6(R, p, &sm[S::FQ6]);
-    lieJlog6(R, p, &sm[S::FQQ]);                         // dSubtractdConfigurationPlus(s.q, q_next)
-    lieDDiffArg0(R, p, &sm[S::FQQ], J0);                 // dSubtractdConfigurationMinus(s.q, q_next)
-    lieBlockInverse(J0, &sm[S::FQQI]);                   // Fqq_inv
-  } else if (tid == 128) {      // previous stage's equation: q_prev (-) s.q
-    double R[9], p[3], J1[36];
-    lieRelative(q, q_prev, R, p);
-    lieJlog6(R, p, J1);
-    lieDDiffArg0(R, p, J1, &sm[S::FQQP]);                // dSubtractdConfigurationMinus(q_prev, s.q)
-    lieBlockInverse(&sm[S::FQQP], &sm[S::FQQPI]);        // Fqq_prev_inv
+  // ---- B. Lie-group terms of the floating base (from ocp_lie_kernel) ----
+  {
+    const double* __restrict__ zz = B.lie + unit * L::LIE;
+    if (tid < 36) {
+      sm[S::JQ + tid] = zz[L::Z_JQ + tid]; sm[S::FQQ + tid] = zz[L::Z_FQQ + tid]; sm[S::FQQI + tid] = zz[L::Z_FQQI + tid];
+      sm[S::FQQP + tid] = zz[L::Z_FQQP + tid]; sm[S::FQQPI + tid] = zz[L::Z_FQQPI + tid];
+    }
+    if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = zz[L::Z_QDIFF + tid - 64]; sm[S::FQ6 + tid - 64] = zz[L::Z_FQ6 + tid - 64]; }
   }
   __syncthreads();
 
@@ -325,29 +314,21 @@ __global__ __launch_bounds__(256) void ocp_condense_kernel(OcpBuffers B, const d
   __syncthreads();
   if (tid < 6) sm[S::FQ + tid] = sm[S::FQ6 + tid];
 
-  // ---- E. Robot::computeMJtJinv ----
-  for (int e = tid; e < NV * NV; e += nt) {
-    const int c = e / NV, r = e - c * NV;
-    sm[S::MJ + r + NVF * c] = sm[S::MM + e];       // Cholesky workspace: top-left of MJ
-    sm[S::MINV + e] = (r == c) ? 1.0 : 0.0;
-  }
-  choleskyInPlace(&sm[S::MJ], NVF, NV, tid, nt, &s_ok);
-  choleskySolve(&sm[S::MJ], NVF, NV, &sm[S::MINV], NV, NV, tid, nt);
-  __syncthreads();
+  // ---- E. Robot::computeMJtJinv (robot.hxx:576-615) ----
+  // M^-1 and (J M^-1 J^T)^-1 by in-place Gauss-Jordan on the SPD blocks (the reference uses
+  // pinocchio's sparse Cholesky + Eigen::LLT; same inverses up to rounding)
+  for (int e = tid; e < NV * NV; e += nt) sm[S::MINV + e] = sm[S::MM + e];
+  spdInverseInPlace(&sm[S::MINV], NV, NV, tid, nt, &s_ok);
   if (dimf > 0) {
     mm(colMajor(&sm[S::BL], NF), colMajor(&sm[S::JM], NF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
     __syncthreads();
     mm(colMajor(&sm[S::SM], NF), colMajor(&sm[S::BL], NF), transposed(colMajor(&sm[S::JM], NF)), dimf, dimf, NV, 1.0, false, tid, nt);
-    for (int e = tid; e < NF * NF; e += nt) { const int c = e / NF, r = e - c * NF; sm[S::BR + e] = (r == c) ? -1.0 : 0.0; }
-    __syncthreads();
-    choleskyInPlace(&sm[S::SM], NF, dimf, tid, nt, &s_ok);
-    choleskySolve(&sm[S::SM], NF, dimf, &sm[S::BR], NF, dimf, tid, nt);                  // BR = -(J Minv J^T)^-1
-    __syncthreads();
-    // TR = BL^T (-BR)  -> MJ top-right ; BL^T of it -> bottom-left ; BR -> bottom-right
-    mm(sub(colMajor(&sm[S::MJ], NVF), 0, NV), transposed(colMajor(&sm[S::BL], NF)), colMajor(&sm[S::BR], NF), NV, dimf, dimf, -1.0, false, tid, nt);
+    spdInverseInPlace(&sm[S::SM], NF, dimf, tid, nt, &s_ok);            // SM = (J Minv J^T)^-1 ;  BR = -SM
+    // TR = BL^T SM -> MJ top-right ; its transpose -> bottom-left ; -SM -> bottom-right
+    mm(sub(colMajor(&sm[S::MJ], NVF), 0, NV), transposed(colMajor(&sm[S::BL], NF)), colMajor(&sm[S::SM], NF), NV, dimf, dimf, 1.0, false, tid, nt);
     __syncthreads();
     for (int e = tid; e < dimf * NV; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * c] = sm[S::MJ + c + NVF * (NV + r)]; }
-    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * (NV + c)] = sm[S::BR + r + NF * c]; }
+    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * (NV + c)] = -sm[S::SM + r + NF * c]; }
     __syncthreads();
   }
   // TL = Minv - TR BL
@@ -355,10 +336,8 @@ __global__ __launch_bounds__(256) void ocp_condense_kernel(OcpBuffers B, const d
     const int c = e / NV, r = e - c * NV;
     double acc = sm[S::MINV + e];
     for (int p = 0; p < dimf; ++p) acc -= sm[S::MJ + r + NVF * (NV + p)] * sm[S::BL + p + NF * c];
-    sm[S::QAFU + e] = acc;                          // staged (MJ top-left still holds the Cholesky factor)
+    sm[S::MJ + r + NVF * c] = acc;
   }
-  __syncthreads();
-  for (int e = tid; e < NV * NV; e += nt) { const int c = e / NV, r = e - c * NV; sm[S::MJ + r + NVF * c] = sm[S::QAFU + e]; }
   __syncthreads();
 
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
@@ -429,6 +408,54 @@ __global__ __launch_bounds__(256) void ocp_condense_kernel(OcpBuffers B, const d
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + i;
 }
 
+// Lie-group terms of the floating base for every stage (state_equation.hxx:12-63, cost Jacobian
+// of q (-) q_ref): blockIdx.y selects the task so that a wavefront never diverges between tasks.
+//   task 0: qdiff = q (-) q_ref and Jq = dSubtractdConfigurationPlus(q, q_ref)
+//   task 1: Fq.head(6) = (q (-) q_next).head(6), Fqq = dSubtractdConfigurationPlus(q, q_next),
+//           Fqq_inv = inverse of dSubtractdConfigurationMinus(q, q_next)
+//   task 2: Fqq_prev = dSubtractdConfigurationMinus(q_prev, q), Fqq_prev_inv
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double* __restrict__ q0) {
+  using L = OcpLayout<D>;
+  constexpr int NQ = D::NQ;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long unit = (long)blockIdx.x * 64 + threadIdx.x;
+  if (unit >= (long)P->batch * (N + 1)) return;
+  const long b = unit / (N + 1);
+  const int i = (int)(unit - b * (N + 1));
+  const int task = blockIdx.y;
+  const double* __restrict__ s = B.sol + unit * L::SOL;
+  const double* __restrict__ q = s + L::S_Q;
+  double* __restrict__ zz = B.lie + unit * L::LIE;
+  double R[9], p[3], Ja[36], Jb[36], d6[6];
+  if (task == 0) {
+    lieRelative(B.q_ref + (long)i * NQ, q, R, p);
+    lieLog6(R, p, d6);
+    lieJlog6(R, p, Ja);
+    for (int k = 0; k < 36; ++k) zz[L::Z_JQ + k] = Ja[k];
+    for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
+  } else if (task == 1) {
+    if (i == N) return;
+    lieRelative(s + L::SOL + L::S_Q, q, R, p);
+    lieLog6(R, p, d6);
+    lieJlog6(R, p, Ja);
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
+    for (int k = 0; k < 6; ++k) zz[L::Z_FQ6 + k] = d6[k];
+    lieDDiffArg0(R, p, Ja, Jb);
+    lieBlockInverse(Jb, Ja);
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQI + k] = Ja[k];
+  } else {
+    const double* __restrict__ q_prev = (i == 0) ? (q0 + b * NQ) : (s - L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
+    lieRelative(q, q_prev, R, p);
+    lieJlog6(R, p, Ja);
+    lieDDiffArg0(R, p, Ja, Jb);
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQP + k] = Jb[k];
+    lieBlockInverse(Jb, Ja);
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQPI + k] = Ja[k];
+  }
+}
+
 template <typename D>
 static void launchCondense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st, bool residual) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
@@ -439,6 +466,7 @@ static void launchCondense(const OcpBuffers& B, long batch, int N, const double*
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * (N + 1));
+  hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true>), dim3(blocks), dim3(256), smem, st, B, q0);
   else hipLaunchKernelGGL((ocp_condense_kernel<D, false>), dim3(blocks), dim3(256), smem, st, B, q0);
 }

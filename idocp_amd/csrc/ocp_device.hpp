@@ -51,6 +51,9 @@ struct OcpLayout {
   static constexpr int EXP = roundUp16(E_FQQPI + 36);
   static constexpr int R_PQQ = 0, R_PQV = NV * NV, R_PVV = 2 * NV * NV, R_SQ = 3 * NV * NV, R_SV = R_SQ + NV;
   static constexpr int RIC = roundUp16(R_SV + NV);
+  // Lie-group terms of the floating base, produced by the small pre-kernel (6x6 blocks column-major)
+  static constexpr int Z_JQ = 0, Z_QDIFF = 36, Z_FQQ = 44, Z_FQ6 = 80, Z_FQQI = 88, Z_FQQP = 124, Z_FQQPI = 160;
+  static constexpr int LIE = roundUp16(196);
   static constexpr int G_K = 0, G_k = NU * NX;
   static constexpr int GAIN = roundUp16(G_k + NU);
 };
@@ -81,6 +84,7 @@ struct OcpBuffers {
   double* slack;         // [batch][N][CON]
   double* dual;          // [batch][N][CON]
   double* lin;           // [batch][N][LIN]
+  double* lie;           // [batch][N+1][LIE]
   double* kkt;           // [batch][N+1][KKT]   (terminal record holds Qxx and lx only)
   double* exp;           // [batch][N+1][EXP]   (terminal record holds Fqq_prev_inv only)
   double* ric;           // [batch][N+1][RIC]
