@@ -148,6 +148,7 @@ def _proto(lib):
         ("idocp_ocp_get_constraint_data", [vp, ci, c_double_p, c_double_p]),
         ("idocp_ocp_get_lqr_stage", [vp, ci, ci] + [c_double_p] * 8),
         ("idocp_ocp_launch_kernel", [vp, ci, vp, vp]),
+        ("idocp_ocp_get_profile", [vp, C.POINTER(C.c_longlong), ci]),
     ]:
         f = getattr(lib, name)
         f.argtypes = args

@@ -22,13 +22,35 @@ __device__ __forceinline__ MatView colMajor(double* p, int ld) { return MatView{
 __device__ __forceinline__ MatView transposed(MatView a) { return MatView{a.p, a.cs, a.rs}; }
 __device__ __forceinline__ MatView sub(MatView a, int i0, int j0) { return MatView{a.p + i0 * a.rs + j0 * a.cs, a.rs, a.cs}; }
 
-// C (m x n) = beta * C + alpha * A (m x k) * B (k x n); beta in {0, 1}
+// C (m x n) = beta * C + alpha * A (m x k) * B (k x n); beta in {0, 1}.
+// The inner product is unrolled by 6 (or 3) with independent accumulators so that
+// several LDS reads are in flight per lane: with a rolled loop every FMA waits for
+// two dependent ds_read latencies and the kernel is latency-bound.  Every inner
+// dimension on this path (12, 18, 18 + 3 n_contacts, 36) is a multiple of 3.
+template <int U>
+__device__ __forceinline__ double dotStrided(const double* a, int as, const double* b, int bs, int k) {
+  double acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = 0.0;
+  for (int p = 0; p < k; p += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] += a[(p + u) * as] * b[(p + u) * bs];
+  }
+  double r = acc[0];
+#pragma unroll
+  for (int u = 1; u < U; ++u) r += acc[u];
+  return r;
+}
+__device__ __forceinline__ double dotAny(const double* a, int as, const double* b, int bs, int k) {
+  if (k % 6 == 0) return dotStrided<6>(a, as, b, bs, k);
+  if (k % 3 == 0) return dotStrided<3>(a, as, b, bs, k);
+  return dotStrided<1>(a, as, b, bs, k);
+}
 __device__ __forceinline__ void mm(MatView C, MatView A, MatView Bm, int m, int n, int k, double alpha, bool accumulate,
                                    int tid, int nthreads) {
   for (int e = tid; e < m * n; e += nthreads) {
     const int j = e / m, i = e - j * m;
-    double acc = 0.0;
-    for (int p = 0; p < k; ++p) acc += A(i, p) * Bm(p, j);
+    const double acc = dotAny(A.p + i * A.rs, A.cs, Bm.p + j * Bm.cs, Bm.rs, k);
     if (accumulate) C(i, j) += alpha * acc; else C(i, j) = alpha * acc;
   }
 }
@@ -37,8 +59,7 @@ __device__ __forceinline__ void mm(MatView C, MatView A, MatView Bm, int m, int 
 __device__ __forceinline__ void mv(double* y, MatView A, const double* x, int m, int k, double alpha, bool accumulate, int tid,
                                    int nthreads) {
   for (int i = tid; i < m; i += nthreads) {
-    double acc = 0.0;
-    for (int p = 0; p < k; ++p) acc += A(i, p) * x[p];
+    const double acc = dotAny(A.p + i * A.rs, A.cs, x, 1, k);
     if (accumulate) y[i] += alpha * acc; else y[i] = alpha * acc;
   }
 }
@@ -64,34 +85,73 @@ __device__ __forceinline__ void choleskyInPlace(double* A, int ld, int n, int ti
   __syncthreads();
 }
 
-// In-place inverse of an SPD n x n column-major block by Gauss-Jordan
-// elimination without pivoting (stable for SPD: every pivot is a positive Schur
-// complement).  n steps of fully parallel O(n^2) work and two barriers each --
-// no triangular solves with only n busy threads, which is what makes it the
-// better fit for a 256-thread workgroup than Cholesky + substitution.
-__device__ __forceinline__ void spdInverseInPlace(double* A, int ld, int n, int tid, int nthreads, int* ok) {
+// Inverse of an SPD n x n column-major block by Gauss-Jordan elimination without
+// pivoting (stable for SPD: every pivot is a positive Schur complement).  n steps
+// of fully parallel O(n^2) work with ONE barrier each: the sweep ping-pongs
+// between A and the scratch block W (same ld), and every thread keeps the (i, j)
+// of its (at most two) elements in registers, so a step is three LDS reads, one
+// reciprocal and one LDS write per element.  The inverse ends up in A.
+// Requires n * n <= 2 * nthreads.
+__device__ __forceinline__ void spdInverse(double* A, double* W, int ld, int n, int tid, int nthreads, int* ok) {
+  const int e0 = tid, e1 = tid + nthreads;
+  const bool has0 = e0 < n * n, has1 = e1 < n * n;
+  const int j0 = has0 ? e0 / n : 0, i0 = has0 ? e0 - j0 * n : 0;
+  const int j1 = has1 ? e1 / n : 0, i1 = has1 ? e1 - j1 * n : 0;
+  double* src = A;
+  double* dst = W;
+  __syncthreads();
   for (int k = 0; k < n; ++k) {
-    __syncthreads();
-    const double p = A[k + k * ld];
+    const double p = src[k + k * ld];
     if (tid == 0 && !(p > 0.0)) *ok = 0;
     const double ip = 1.0 / p;
-    double upd[4];                         // n*n <= 4 * nthreads for every block on this path
-    int cnt = 0;
-    for (int e = tid; e < n * n; e += nthreads, ++cnt) {
-      const int j = e / n, i = e - j * n;
-      const double aik = A[i + k * ld], akj = A[k + j * ld], aij = A[i + j * ld];
-      double v;
-      if (i == k && j == k) v = ip;
-      else if (i == k) v = akj * ip;
-      else if (j == k) v = -aik * ip;
-      else v = aij - aik * akj * ip;
-      upd[cnt & 3] = v;
+    if (has0) {
+      const double aik = src[i0 + k * ld], akj = src[k + j0 * ld], aij = src[i0 + j0 * ld];
+      dst[i0 + j0 * ld] = (i0 == k) ? ((j0 == k) ? ip : akj * ip) : ((j0 == k) ? -aik * ip : aij - aik * akj * ip);
+    }
+    if (has1) {
+      const double aik = src[i1 + k * ld], akj = src[k + j1 * ld], aij = src[i1 + j1 * ld];
+      dst[i1 + j1 * ld] = (i1 == k) ? ((j1 == k) ? ip : akj * ip) : ((j1 == k) ? -aik * ip : aij - aik * akj * ip);
     }
     __syncthreads();
-    cnt = 0;
-    for (int e = tid; e < n * n; e += nthreads, ++cnt) { const int j = e / n, i = e - j * n; A[i + j * ld] = upd[cnt & 3]; }
+    double* t = src; src = dst; dst = t;
   }
-  __syncthreads();
+  if (src != A) {            // odd n: the result sits in W
+    if (has0) A[i0 + j0 * ld] = src[i0 + j0 * ld];
+    if (has1) A[i1 + j1 * ld] = src[i1 + j1 * ld];
+    __syncthreads();
+  }
+}
+
+// C (m x n) (+)= alpha * X^T Y with X (k x m, ldx) and Y (k x n, ldy) column-major,
+// i.e. both operands contiguous along the contraction index: 2 x 2 register blocks,
+// 16-byte LDS reads (two k's per read): 0.5 LDS instruction per FMA instead of 2.
+// m, n even; column starts 16-byte aligned (ldx, ldy even, even base offsets).
+__device__ __forceinline__ void mmTN22(double* C, int ldc, const double* X, int ldx, const double* Y, int ldy, int m, int n, int k,
+                                       double alpha, bool accumulate, int tid, int nthreads) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int mb = m >> 1, nb = n >> 1, k2 = k >> 1;
+  for (int e = tid; e < mb * nb; e += nthreads) {
+    const int jb = e / mb, ib = e - jb * mb;
+    const double* x0 = X + (2 * ib) * ldx;
+    const double* x1 = x0 + ldx;
+    const double* y0 = Y + (2 * jb) * ldy;
+    const double* y1 = y0 + ldy;
+    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+#pragma unroll 3
+    for (int p = 0; p < k2; ++p) {
+      const d2 a0 = *reinterpret_cast<const d2*>(x0 + 2 * p), a1 = *reinterpret_cast<const d2*>(x1 + 2 * p);
+      const d2 b0 = *reinterpret_cast<const d2*>(y0 + 2 * p), b1 = *reinterpret_cast<const d2*>(y1 + 2 * p);
+      c00 += a0.x * b0.x + a0.y * b0.y; c01 += a0.x * b1.x + a0.y * b1.y;
+      c10 += a1.x * b0.x + a1.y * b0.y; c11 += a1.x * b1.x + a1.y * b1.y;
+    }
+    if (k & 1) {
+      const int p = k - 1;
+      c00 += x0[p] * y0[p]; c01 += x0[p] * y1[p]; c10 += x1[p] * y0[p]; c11 += x1[p] * y1[p];
+    }
+    double* c = C + 2 * ib + (2 * jb) * ldc;
+    if (accumulate) { c[0] += alpha * c00; c[1] += alpha * c10; c[ldc] += alpha * c01; c[ldc + 1] += alpha * c11; }
+    else { c[0] = alpha * c00; c[1] = alpha * c10; c[ldc] = alpha * c01; c[ldc + 1] = alpha * c11; }
+  }
 }
 
 // Solve L L^T X = Bm for nrhs columns, one thread per right-hand side (in place).

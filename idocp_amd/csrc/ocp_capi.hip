@@ -220,6 +220,8 @@ int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const
   if ((rc = allocBufO(h, &h->d_qref, (size_t)(N + 1) * DQ::NQ))) return fail(rc);
   if ((rc = allocBufO(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
   B.status = reinterpret_cast<int*>(tmp);
+  if ((rc = allocBufO(h, &tmp, 64))) return fail(rc);
+  B.prof = reinterpret_cast<long long*>(tmp);
   B.q_ref = h->d_qref;
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
@@ -485,6 +487,13 @@ int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, d
       off += n;
     }
   }
+  return IDOCP_OK;
+}
+
+int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n) {
+  if (!h || !out || n <= 0 || n > 64) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipMemcpy(out, h->B.prof, sizeof(long long) * n, hipMemcpyDeviceToHost));
   return IDOCP_OK;
 }
 

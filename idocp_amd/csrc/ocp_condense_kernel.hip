@@ -59,7 +59,8 @@ struct CondenseSmem {
   static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
                        LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV, JQ = BM + 32, FQQ = JQ + 36, FQQP = FQQ + 36,
                        FQQI = FQQP + 36, FQQPI = FQQI + 36, FQV = FQQPI + 36, QDIFF = FQV + 36, FQ6 = QDIFF + 8, ERR = FQ6 + 8,
-                       TOTAL = ERR + 256;
+                       SOLS = ERR + 256, SOLN = SOLS + OcpLayout<D>::SOL, SLK = SOLN + OcpLayout<D>::SOL, DUL = SLK + OcpLayout<D>::CON,
+                       TOTAL = DUL + OcpLayout<D>::CON;
 };
 
 template <typename D, bool RESIDUAL>
@@ -78,12 +79,16 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   const int i = (int)(unit - b * (N + 1));
   const bool terminal = (i == N);
   const int dimf = P->dimf, dimvf = NV + dimf;
-  const double* __restrict__ s = B.sol + unit * L::SOL;
-  const double* __restrict__ sn = s + L::SOL;       // only dereferenced for i < N
-  const double* __restrict__ q = s + L::S_Q;
+  const double* __restrict__ s_g = B.sol + unit * L::SOL;
+  const double* s = &sm[S::SOLS];                   // LDS copies of this stage's and the next stage's solution records
+  const double* sn = &sm[S::SOLN];                  // (only valid for i < N)
+  const double* q = s + L::S_Q;
   const double* __restrict__ qref = B.q_ref + (long)i * NQ;
-  const double* __restrict__ q_prev = (i == 0) ? (q0 + b * NQ) : (s - L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
+  const double* __restrict__ q_prev = (i == 0) ? (q0 + b * NQ) : (s_g - L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
   const long su = b * N + i;                       // stage index without terminal records
+  const bool stamp = (!RESIDUAL) && tid == 0 && unit == 7 && B.prof != nullptr;
+#define STAMP(k) do { if (stamp) B.prof[k] = wall_clock64(); } while (0)
+  STAMP(0);
   double* kk = B.kkt + unit * L::KKT;
   double* ee = B.exp + unit * L::EXP;
 
@@ -93,9 +98,12 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     for (int e = tid; e < NVF * NX + NV * NV + NF * NV; e += nt) sm[S::DIDC + e] = lin[e];       // DIDC, MM, JM are contiguous in both
     if (tid < NVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
   }
+  for (int e = tid; e < (terminal ? L::SOL : 2 * L::SOL); e += nt) sm[S::SOLS + e] = s_g[e];     // this and the next record
+  if (!terminal) for (int e = tid; e < L::CON; e += nt) { sm[S::SLK + e] = B.slack[su * L::CON + e]; sm[S::DUL + e] = B.dual[su * L::CON + e]; }
   for (int e = tid; e < NX * NX + NX * NV + NV * NV; e += nt) sm[S::QXX + e] = 0.0;              // QXX, QXU, QUU contiguous
   for (int e = tid; e < NF * NF; e += nt) sm[S::QFF + e] = 0.0;
   if (tid == 0) s_ok = 1;
+  STAMP(1);
   // ---- B. Lie-group terms of the floating base (from ocp_lie_kernel) ----
   {
     const double* __restrict__ zz = B.lie + unit * L::LIE;
@@ -150,9 +158,10 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     return;
   }
 
+  STAMP(2);
   // ---- C. gradients, residuals, diagonal Hessian terms ----
-  const double* __restrict__ slack = B.slack + su * L::CON;
-  const double* __restrict__ dual = B.dual + su * L::CON;
+  const double* slack = &sm[S::SLK];
+  const double* dual = &sm[S::DUL];
   // bm = [beta ; mu_stack]
   if (tid < NV) sm[S::BM + tid] = s[L::S_BETA + tid];
   if (tid < NC && P->active[tid]) for (int x = 0; x < 3; ++x) sm[S::BM + NV + P->row_of[tid] + x] = s[L::S_MU + 3 * tid + x];
@@ -198,14 +207,9 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
       }
     }
     // multipliers of [ID; C]:  l += dt [dID;dC]^T [beta; mu]
-    double dq = 0.0, dv = 0.0, da = 0.0;
-    for (int row = 0; row < dimvf; ++row) {
-      const double bmr = sm[S::BM + row];
-      dq += sm[S::DIDC + row + NVF * r] * bmr;
-      dv += sm[S::DIDC + row + NVF * (NV + r)] * bmr;
-    }
-    for (int row = 0; row < NV; ++row) da += sm[S::MM + row + NV * r] * sm[S::BM + row];
-    for (int row = 0; row < dimf; ++row) da += sm[S::JM + row + NF * r] * sm[S::BM + NV + row];
+    const double dq = dotAny(&sm[S::DIDC + NVF * r], 1, &sm[S::BM], 1, dimvf);
+    const double dv = dotAny(&sm[S::DIDC + NVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
+    const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + NF * r], 1, &sm[S::BM + NV], 1, dimf);
     lq += dt * dq; lv += dt * dv; la += dt * da;
     sm[S::LQ + r] = lq; sm[S::LV + r] = lv; sm[S::LA + r] = la; sm[S::QAA + r] = ha;
     if (!RESIDUAL) {
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     return;
   }
   __syncthreads();
+  STAMP(3);
   // cost Hessian of the base block: dt Jq^T W Jq  (6 x 6)
   if (tid < 36) {
     const int c = tid / 6, r = tid - 6 * c;
@@ -314,16 +319,18 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   __syncthreads();
   if (tid < 6) sm[S::FQ + tid] = sm[S::FQ6 + tid];
 
+  STAMP(4);
   // ---- E. Robot::computeMJtJinv (robot.hxx:576-615) ----
   // M^-1 and (J M^-1 J^T)^-1 by in-place Gauss-Jordan on the SPD blocks (the reference uses
   // pinocchio's sparse Cholesky + Eigen::LLT; same inverses up to rounding)
   for (int e = tid; e < NV * NV; e += nt) sm[S::MINV + e] = sm[S::MM + e];
-  spdInverseInPlace(&sm[S::MINV], NV, NV, tid, nt, &s_ok);
+  spdInverse(&sm[S::MINV], &sm[S::QAFU], NV, NV, tid, nt, &s_ok);
+  STAMP(5);
   if (dimf > 0) {
     mm(colMajor(&sm[S::BL], NF), colMajor(&sm[S::JM], NF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
     __syncthreads();
     mm(colMajor(&sm[S::SM], NF), colMajor(&sm[S::BL], NF), transposed(colMajor(&sm[S::JM], NF)), dimf, dimf, NV, 1.0, false, tid, nt);
-    spdInverseInPlace(&sm[S::SM], NF, dimf, tid, nt, &s_ok);            // SM = (J Minv J^T)^-1 ;  BR = -SM
+    spdInverse(&sm[S::SM], &sm[S::BR], NF, dimf, tid, nt, &s_ok);        // SM = (J Minv J^T)^-1 ;  BR = -SM
     // TR = BL^T SM -> MJ top-right ; its transpose -> bottom-left ; -SM -> bottom-right
     mm(sub(colMajor(&sm[S::MJ], NVF), 0, NV), transposed(colMajor(&sm[S::BL], NF)), colMajor(&sm[S::SM], NF), NV, dimf, dimf, 1.0, false, tid, nt);
     __syncthreads();
@@ -331,31 +338,32 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * (NV + c)] = -sm[S::SM + r + NF * c]; }
     __syncthreads();
   }
+  STAMP(6);
   // TL = Minv - TR BL
   for (int e = tid; e < NV * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;
-    double acc = sm[S::MINV + e];
-    for (int p = 0; p < dimf; ++p) acc -= sm[S::MJ + r + NVF * (NV + p)] * sm[S::BL + p + NF * c];
-    sm[S::MJ + r + NVF * c] = acc;
+    sm[S::MJ + r + NVF * c] = sm[S::MINV + e] - dotAny(&sm[S::MJ + r + NVF * NV], NVF, &sm[S::BL + NF * c], 1, dimf);
   }
   __syncthreads();
 
+  STAMP(7);
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
-  mm(colMajor(&sm[S::MJD], NVF), colMajor(&sm[S::MJ], NVF), colMajor(&sm[S::DIDC], NVF), dimvf, NX, dimvf, 1.0, false, tid, nt);
+  if ((dimvf & 1) == 0) mmTN22(&sm[S::MJD], NVF, &sm[S::MJ], NVF, &sm[S::DIDC], NVF, dimvf, NX, dimvf, 1.0, false, tid, nt);   // MJ symmetric
+  else mm(colMajor(&sm[S::MJD], NVF), colMajor(&sm[S::MJ], NVF), colMajor(&sm[S::DIDC], NVF), dimvf, NX, dimvf, 1.0, false, tid, nt);
   mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], NVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
   __syncthreads();
   for (int e = tid; e < dimvf * NX; e += nt) {
     const int c = e / dimvf, r = e - c * dimvf;
     double val;
     if (r < NV) val = -sm[S::QAA + r] * sm[S::MJD + r + NVF * c];
-    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + NF * p] * sm[S::MJD + (NV + p) + NVF * c]; val = -acc; }
+    else val = -dotAny(&sm[S::QFF + (r - NV)], NF, &sm[S::MJD + NV + NVF * c], 1, dimf);
     sm[S::QAFQV + r + NVF * c] = val;
   }
   for (int e = tid; e < dimvf * NV; e += nt) {
     const int c = e / dimvf, r = e - c * dimvf;
     double val;
     if (r < NV) val = sm[S::QAA + r] * sm[S::MJ + r + NVF * c];
-    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + NF * p] * sm[S::MJ + (NV + p) + NVF * c]; val = acc; }
+    else val = dotAny(&sm[S::QFF + (r - NV)], NF, &sm[S::MJ + NV + NVF * c], 1, dimf);
     sm[S::QAFU + r + NVF * c] = val;
   }
   if (tid < dimvf) {
@@ -366,23 +374,23 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::LAF + r] = val;
   }
   __syncthreads();
+  STAMP(8);
   // ---- H. condensed Hessian / gradients / dynamics (contact_dynamics.hxx:129-157) ----
-  mm(colMajor(&sm[S::QXX], NX), transposed(colMajor(&sm[S::MJD], NVF)), colMajor(&sm[S::QAFQV], NVF), NX, NX, dimvf, -1.0, true, tid, nt);
-  mm(colMajor(&sm[S::QXU], NX), transposed(colMajor(&sm[S::MJD], NVF)), colMajor(&sm[S::QAFU], NVF), NX, NV, dimvf, -1.0, true, tid, nt);
-  mm(colMajor(&sm[S::QUU], NV), colMajor(&sm[S::MJ], NVF), colMajor(&sm[S::QAFU], NVF), NV, NV, dimvf, 1.0, true, tid, nt);
+  mmTN22(&sm[S::QXX], NX, &sm[S::MJD], NVF, &sm[S::QAFQV], NVF, NX, NX, dimvf, -1.0, true, tid, nt);
+  mmTN22(&sm[S::QXU], NX, &sm[S::MJD], NVF, &sm[S::QAFU], NVF, NX, NV, dimvf, -1.0, true, tid, nt);
+  mmTN22(&sm[S::QUU], NV, &sm[S::MJ], NVF, &sm[S::QAFU], NVF, NV, NV, dimvf, 1.0, true, tid, nt);      // MJ symmetric
   if (tid < NX) {                                   // lx -= MJD^T laf
-    double acc = 0.0;
-    for (int p = 0; p < dimvf; ++p) acc += sm[S::MJD + p + NVF * tid] * sm[S::LAF + p];
+    const double acc = dotAny(&sm[S::MJD + NVF * tid], 1, &sm[S::LAF], 1, dimvf);
     if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;
   } else if (tid >= 64 && tid < 64 + NV) {          // [lu_passive; lu] += MJ.topRows(NV) laf ; Fv -= dt MJIDC
     const int r = tid - 64;
-    double acc = 0.0;
-    for (int p = 0; p < dimvf; ++p) acc += sm[S::MJ + r + NVF * p] * sm[S::LAF + p];
+    const double acc = dotAny(&sm[S::MJ + r], NVF, &sm[S::LAF], 1, dimvf);
     if (r < 6) sm[S::LUP + r] += acc; else sm[S::LU + r - 6] += acc;
     sm[S::FV + r] -= dt * sm[S::MJIDC + r];
   }
   __syncthreads();
 
+  STAMP(9);
   // ---- I. write the kkt and exp records ----
   for (int e = tid; e < NX * NX; e += nt) kk[L::K_QXX + e] = sm[S::QXX + e];
   for (int e = tid; e < NX * NU; e += nt) { const int c = e / NX, r = e - c * NX; kk[L::K_QXU + e] = sm[S::QXU + r + NX * (6 + c)]; }
@@ -405,7 +413,9 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
   for (int e = tid; e < 6 * NU; e += nt) { const int c = e / 6, r = e - 6 * c; ee[L::E_QUUP + e] = sm[S::QUU + r + NV * (6 + c)]; }
   for (int e = tid; e < NX * 6; e += nt) ee[L::E_QXUP + e] = sm[S::QXU + e];                       // columns 0..5 of Qxu_full
+  STAMP(10);
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + i;
+#undef STAMP
 }
 
 // Lie-group terms of the floating base for every stage (state_equation.hxx:12-63, cost Jacobian

@@ -94,6 +94,7 @@ struct OcpBuffers {
   double* err_stage;     // [batch][N+1]
   double* err;           // [batch]
   int* status;           // [batch]
+  long long* prof;       // [64] diagnostic: wall-clock stamps of one workgroup of the condensation kernel
 };
 
 }  // namespace idocp_dev

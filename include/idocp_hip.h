@@ -277,6 +277,9 @@ int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, d
 int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu,
                             double* Quu, double* A, double* B, double* lx, double* lu,
                             double* Fx);
+/* Diagnostic: wall-clock stamps (100 MHz ticks) taken at the phase boundaries of one
+ * workgroup of the condensation kernel during the last launch; n <= 64. */
+int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n);
 /* One kernel launch: 0 = tangent RNEA, 1 = condense, 2 = backward Riccati,
  * 3 = forward Riccati, 4 = expand primal, 5 = step-size reduction,
  * 6 = expand dual + integrate. */
