@@ -122,6 +122,42 @@ __device__ __forceinline__ void spdInverse(double* A, double* W, int ld, int n, 
   }
 }
 
+// Same elimination executed by ONE wavefront (lanes 0..63) with no workgroup
+// barrier: LDS operations of a single wavefront are processed in program order,
+// so a step only needs a compiler-level fence between the writes of step k and
+// the reads of step k+1.  Each step costs one LDS round trip + one reciprocal
+// (~300 cycles) instead of a 4-wave barrier round (~900 cycles).  n * n <= 64 * ME.
+template <int ME>
+__device__ __forceinline__ void spdInverseWave(double* A, double* W, int ld, int n, int lane, int* ok) {
+  int ii[ME], jj[ME];
+#pragma unroll
+  for (int t = 0; t < ME; ++t) { const int e = lane + 64 * t; const int j = e / n; jj[t] = j; ii[t] = e - j * n; }
+  double* src = A;
+  double* dst = W;
+  for (int k = 0; k < n; ++k) {
+    const double p = src[k + k * ld];
+    if (lane == 0 && !(p > 0.0)) *ok = 0;
+    const double ip = 1.0 / p;
+#pragma unroll
+    for (int t = 0; t < ME; ++t) {
+      if (lane + 64 * t < n * n) {
+        const int i = ii[t], j = jj[t];
+        const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
+        dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double* tmp = src; src = dst; dst = tmp;
+  }
+  if (src != A) {
+#pragma unroll
+    for (int t = 0; t < ME; ++t) if (lane + 64 * t < n * n) A[ii[t] + jj[t] * ld] = src[ii[t] + jj[t] * ld];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // C (m x n) (+)= alpha * X^T Y with X (k x m, ldx) and Y (k x n, ldy) column-major,
 // i.e. both operands contiguous along the contraction index: 2 x 2 register blocks,
 // 16-byte LDS reads (two k's per read): 0.5 LDS instruction per FMA instead of 2.
@@ -151,6 +187,35 @@ __device__ __forceinline__ void mmTN22(double* C, int ldc, const double* X, int 
     double* c = C + 2 * ib + (2 * jb) * ldc;
     if (accumulate) { c[0] += alpha * c00; c[1] += alpha * c10; c[ldc] += alpha * c01; c[ldc + 1] += alpha * c11; }
     else { c[0] = alpha * c00; c[1] = alpha * c10; c[ldc] = alpha * c01; c[ldc + 1] = alpha * c11; }
+  }
+}
+
+// Same product with a caller-supplied epilogue: store(r, c, dot) is invoked once per
+// output element, so results can go straight to global memory (no LDS accumulator).
+template <typename Store>
+__device__ __forceinline__ void mmTN22Epi(const double* X, int ldx, const double* Y, int ldy, int m, int n, int k, int tid, int nthreads,
+                                          Store store) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int mb = m >> 1, nb = n >> 1, k2 = k >> 1;
+  for (int e = tid; e < mb * nb; e += nthreads) {
+    const int jb = e / mb, ib = e - jb * mb;
+    const double* x0 = X + (2 * ib) * ldx;
+    const double* x1 = x0 + ldx;
+    const double* y0 = Y + (2 * jb) * ldy;
+    const double* y1 = y0 + ldy;
+    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+#pragma unroll 3
+    for (int p = 0; p < k2; ++p) {
+      const d2 a0 = *reinterpret_cast<const d2*>(x0 + 2 * p), a1 = *reinterpret_cast<const d2*>(x1 + 2 * p);
+      const d2 b0 = *reinterpret_cast<const d2*>(y0 + 2 * p), b1 = *reinterpret_cast<const d2*>(y1 + 2 * p);
+      c00 += a0.x * b0.x + a0.y * b0.y; c01 += a0.x * b1.x + a0.y * b1.y;
+      c10 += a1.x * b0.x + a1.y * b0.y; c11 += a1.x * b1.x + a1.y * b1.y;
+    }
+    if (k & 1) {
+      const int p = k - 1;
+      c00 += x0[p] * y0[p]; c01 += x0[p] * y1[p]; c10 += x1[p] * y0[p]; c11 += x1[p] * y1[p];
+    }
+    store(2 * ib, 2 * jb, c00); store(2 * ib + 1, 2 * jb, c10); store(2 * ib, 2 * jb + 1, c01); store(2 * ib + 1, 2 * jb + 1, c11);
   }
 }
 

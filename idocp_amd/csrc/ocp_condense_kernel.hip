@@ -12,7 +12,7 @@
 // and TerminalOCP::linearizeOCP (include/idocp/ocp/terminal_ocp.hxx:50-66) for the last stage.
 //
 // One 256-thread workgroup per stage; every block of the stage lives in LDS
-// (~72 kB, two workgroups per CU).  Reads the lin record of K5a, writes the kkt
+// (~38 kB after aliasing, four workgroups per CU).  Reads the lin record of K5a, writes the kkt
 // record (LQR stage for the Riccati sweep) and the exp record (expansion cache).
 #include <hip/hip_runtime.h>
 
@@ -51,20 +51,31 @@ template <typename D>
 struct CondenseSmem {
   using L = OcpLayout<D>;
   static constexpr int NV = D::NV, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU;
+  // matrices.  Aliases (lifetimes in the kernel body):
+  //   MINV  = MM            the mass matrix is inverted in place (scratch: MJ, not yet written)
+  //   QAFQV = DIDC          dIDCdqv is dead once MJD = MJtJinv * dIDCdqv is formed
+  //   QAFU  = MM .. JM      M^-1 and J are dead once MJtJinv is assembled
+  //   BL, SM, BR  share the block that holds the solution / slack / dual copies during phase C
+  //   ERR   = MJ            (RESIDUAL variant only, which never forms MJtJinv)
+  // The condensed Hessian blocks are never staged in LDS: phase H writes them to the kkt record.
   static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV, IDC = JM + NF * NV, MJ = IDC + 32,
-                       MJD = MJ + NVF * NVF, QAFQV = MJD + NVF * NX, QAFU = QAFQV + NVF * NX, QXX = QAFU + NVF * NV,
-                       QXU = QXX + NX * NX, QUU = QXU + NX * NV, MINV = QUU + NV * NV, BL = MINV + NV * NV, SM = BL + NF * NV,
-                       BR = SM + NF * NF, QFF = BR + NF * NF, VEC = QFF + NF * NF;
+                       MJD = MJ + NVF * NVF, QFF = MJD + NVF * NX, TMP = QFF + NF * NF,
+                       MINV = MM, QAFQV = DIDC, QAFU = MM, ERR = MJ;
+  static constexpr int SOLS = TMP, SOLN = SOLS + L::SOL, SLK = SOLN + L::SOL, DUL = SLK + L::CON, TMP_EARLY = DUL + L::CON - TMP;
+  static constexpr int BL = TMP, SM = BL + NF * NV, BR = SM + NF * NF, TMP_LATE = BR + NF * NF - TMP;
+  static constexpr int VEC = TMP + (TMP_EARLY > TMP_LATE ? TMP_EARLY : TMP_LATE);
+  static_assert(NVF * NV <= NV * NV + NF * NV, "Qafu_full must fit in the M / J blocks");
+  static_assert(256 <= NVF * NVF, "ERR aliases MJ");
   // vectors
   static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
                        LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV, JQ = BM + 32, FQQ = JQ + 36, FQQP = FQQ + 36,
-                       FQQI = FQQP + 36, FQQPI = FQQI + 36, FQV = FQQPI + 36, QDIFF = FQV + 36, FQ6 = QDIFF + 8, ERR = FQ6 + 8,
-                       SOLS = ERR + 256, SOLN = SOLS + OcpLayout<D>::SOL, SLK = SOLN + OcpLayout<D>::SOL, DUL = SLK + OcpLayout<D>::CON,
-                       TOTAL = DUL + OcpLayout<D>::CON;
+                       FQQI = FQQP + 36, FQQPI = FQQI + 36, FQV = FQQPI + 36, QDIFF = FQV + 36, FQ6 = QDIFF + 8,
+                       HQD = FQ6 + 8, HVD = HQD + NV, HUD = HVD + NV, QB6 = HUD + NU,       // diagonal / base-block Hessian terms before condensing
+                       TOTAL = QB6 + 36 + 2;
 };
 
 template <typename D, bool RESIDUAL>
-__global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
+__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
   using L = OcpLayout<D>;
   using S = CondenseSmem<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
@@ -100,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   }
   for (int e = tid; e < (terminal ? L::SOL : 2 * L::SOL); e += nt) sm[S::SOLS + e] = s_g[e];     // this and the next record
   if (!terminal) for (int e = tid; e < L::CON; e += nt) { sm[S::SLK + e] = B.slack[su * L::CON + e]; sm[S::DUL + e] = B.dual[su * L::CON + e]; }
-  for (int e = tid; e < NX * NX + NX * NV + NV * NV; e += nt) sm[S::QXX + e] = 0.0;              // QXX, QXU, QUU contiguous
   for (int e = tid; e < NF * NF; e += nt) sm[S::QFF + e] = 0.0;
   if (tid == 0) s_ok = 1;
   STAMP(1);
@@ -141,20 +151,14 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
       if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[unit] = e; }
       return;
     }
-    for (int e = tid; e < 36; e += nt) {
-      const int c = e / 6, r = e - 6 * c;
-      double acc = 0.0;
-      for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c];
-      sm[S::QXX + r + NX * c] = acc;
-      ee[L::E_FQQPI + e] = sm[S::FQQPI + e];
+    for (int e = tid; e < NX * NX; e += nt) {
+      const int c = e / NX, r = e - NX * c;
+      double val = 0.0;
+      if (r < 6 && c < 6) { for (int m2 = 0; m2 < 6; ++m2) val += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c]; }
+      else if (r == c) val = (r < NV) ? P->qf_weight[r] : P->vf_weight[r - NV];
+      kk[L::K_QXX + e] = val;
     }
-    __syncthreads();
-    if (tid < NV) {
-      if (tid >= 6) sm[S::QXX + tid + NX * tid] = P->qf_weight[tid];
-      sm[S::QXX + (NV + tid) + NX * (NV + tid)] = P->vf_weight[tid];
-    }
-    __syncthreads();
-    for (int e = tid; e < NX * NX; e += nt) kk[L::K_QXX + e] = sm[S::QXX + e];
+    if (tid < 36) ee[L::E_FQQPI + tid] = sm[S::FQQPI + tid];
     return;
   }
 
@@ -213,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     lq += dt * dq; lv += dt * dv; la += dt * da;
     sm[S::LQ + r] = lq; sm[S::LV + r] = lv; sm[S::LA + r] = la; sm[S::QAA + r] = ha;
     if (!RESIDUAL) {
-      if (r >= 6) sm[S::QXX + r + NX * r] = hq;
-      sm[S::QXX + (NV + r) + NX * (NV + r)] = hv;
+      sm[S::HQD + r] = hq;
+      sm[S::HVD + r] = hv;
     } else {
       const double idr = sm[S::IDC + r];
       err_local += lq * lq + lv * lv + la * la + sm[S::FQ + r] * sm[S::FQ + r] + sm[S::FV + r] * sm[S::FV + r] + dt * dt * idr * idr;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
       else { lu += sgn * dt * (du * res - duality) / sl; h += dt * du / sl; }
     }
     sm[S::LU + j] = lu;
-    if (!RESIDUAL) sm[S::QUU + (6 + j) + NV * (6 + j)] = h;
+    if (!RESIDUAL) sm[S::HUD + j] = h;
     else err_local += lu * lu;
   } else if (tid >= 128 && tid < 128 + 6) {
     // passive (floating-base) rows: lu_passive = dt nu_passive - dt beta.head(6)
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
     const int c = tid / 6, r = tid - 6 * c;
     double acc = 0.0;
     for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * P->q_weight[m2] * sm[S::JQ + m2 + 6 * c];
-    sm[S::QXX + r + NX * c] = dt * acc;
+    sm[S::QB6 + tid] = dt * acc;
   }
   // ---- D. condenseForwardEuler (state_equation.hxx:40-63) ----
   if (tid >= 64 && tid < 64 + 36) {
@@ -323,14 +327,14 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   // ---- E. Robot::computeMJtJinv (robot.hxx:576-615) ----
   // M^-1 and (J M^-1 J^T)^-1 by in-place Gauss-Jordan on the SPD blocks (the reference uses
   // pinocchio's sparse Cholesky + Eigen::LLT; same inverses up to rounding)
-  for (int e = tid; e < NV * NV; e += nt) sm[S::MINV + e] = sm[S::MM + e];
-  spdInverse(&sm[S::MINV], &sm[S::QAFU], NV, NV, tid, nt, &s_ok);
+  spdInverse(&sm[S::MINV], &sm[S::MJ], NV, NV, tid, nt, &s_ok);          // in place (MINV aliases MM); MJ is free scratch here
   STAMP(5);
   if (dimf > 0) {
     mm(colMajor(&sm[S::BL], NF), colMajor(&sm[S::JM], NF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
     __syncthreads();
     mm(colMajor(&sm[S::SM], NF), colMajor(&sm[S::BL], NF), transposed(colMajor(&sm[S::JM], NF)), dimf, dimf, NV, 1.0, false, tid, nt);
-    spdInverse(&sm[S::SM], &sm[S::BR], NF, dimf, tid, nt, &s_ok);        // SM = (J Minv J^T)^-1 ;  BR = -SM
+    __syncthreads();
+    spdInverse(&sm[S::SM], &sm[S::BR], NF, dimf, tid, nt, &s_ok);      // SM = (J Minv J^T)^-1
     // TR = BL^T SM -> MJ top-right ; its transpose -> bottom-left ; -SM -> bottom-right
     mm(sub(colMajor(&sm[S::MJ], NVF), 0, NV), transposed(colMajor(&sm[S::BL], NF)), colMajor(&sm[S::SM], NF), NV, dimf, dimf, 1.0, false, tid, nt);
     __syncthreads();
@@ -376,9 +380,22 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   __syncthreads();
   STAMP(8);
   // ---- H. condensed Hessian / gradients / dynamics (contact_dynamics.hxx:129-157) ----
-  mmTN22(&sm[S::QXX], NX, &sm[S::MJD], NVF, &sm[S::QAFQV], NVF, NX, NX, dimvf, -1.0, true, tid, nt);
-  mmTN22(&sm[S::QXU], NX, &sm[S::MJD], NVF, &sm[S::QAFU], NVF, NX, NV, dimvf, -1.0, true, tid, nt);
-  mmTN22(&sm[S::QUU], NV, &sm[S::MJ], NVF, &sm[S::QAFU], NVF, NV, NV, dimvf, 1.0, true, tid, nt);      // MJ symmetric
+  // Qxx = (cost + IPM terms) - MJD^T Qafqv ; Qxu_full = -MJD^T Qafu_full ; Quu_full = diag + MJ.topRows^T Qafu_full.
+  // The products go straight to the kkt / exp records.
+  mmTN22Epi(&sm[S::MJD], NVF, &sm[S::QAFQV], NVF, NX, NX, dimvf, tid, nt, [&](int r, int c, double v) {
+    double base = 0.0;
+    if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
+    else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
+    kk[L::K_QXX + r + NX * c] = base - v;
+  });
+  mmTN22Epi(&sm[S::MJD], NVF, &sm[S::QAFU], NVF, NX, NV, dimvf, tid, nt, [&](int r, int c, double v) {
+    if (c < 6) ee[L::E_QXUP + r + NX * c] = -v;            // passive columns of Qxu_full
+    else kk[L::K_QXU + r + NX * (c - 6)] = -v;
+  });
+  mmTN22Epi(&sm[S::MJ], NVF, &sm[S::QAFU + NVF * 6], NVF, NV, NU, dimvf, tid, nt, [&](int r, int c, double v) {      // MJ symmetric
+    if (r < 6) ee[L::E_QUUP + r + 6 * c] = v;              // Quu_passive_topRight
+    else kk[L::K_QUU + (r - 6) + NU * c] = v + ((r - 6 == c) ? sm[S::HUD + c] : 0.0);
+  });
   if (tid < NX) {                                   // lx -= MJD^T laf
     const double acc = dotAny(&sm[S::MJD + NVF * tid], 1, &sm[S::LAF], 1, dimvf);
     if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;
@@ -392,9 +409,6 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
 
   STAMP(9);
   // ---- I. write the kkt and exp records ----
-  for (int e = tid; e < NX * NX; e += nt) kk[L::K_QXX + e] = sm[S::QXX + e];
-  for (int e = tid; e < NX * NU; e += nt) { const int c = e / NX, r = e - c * NX; kk[L::K_QXU + e] = sm[S::QXU + r + NX * (6 + c)]; }
-  for (int e = tid; e < NU * NU; e += nt) { const int c = e / NU, r = e - c * NU; kk[L::K_QUU + e] = sm[S::QUU + (6 + r) + NV * (6 + c)]; }
   for (int e = tid; e < NV * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;
     kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + NVF * c];
@@ -411,8 +425,6 @@ __global__ __launch_bounds__(256, 2) void ocp_condense_kernel(OcpBuffers B, cons
   for (int e = tid; e < NVF * NU; e += nt) ee[L::E_QAFU + e] = sm[S::QAFU + NVF * 6 + e];          // columns 6.. of Qafu_full
   if (tid < NVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
-  for (int e = tid; e < 6 * NU; e += nt) { const int c = e / 6, r = e - 6 * c; ee[L::E_QUUP + e] = sm[S::QUU + r + NV * (6 + c)]; }
-  for (int e = tid; e < NX * 6; e += nt) ee[L::E_QXUP + e] = sm[S::QXU + e];                       // columns 0..5 of Qxu_full
   STAMP(10);
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + i;
 #undef STAMP

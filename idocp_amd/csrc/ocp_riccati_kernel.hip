@@ -13,6 +13,7 @@
 // S3: one 256-thread workgroup per OCP instance walks the horizon backwards with
 // P_{i+1} and the stage's LQR blocks resident in LDS (~52 kB -> three instances per CU).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
@@ -25,14 +26,18 @@ template <typename D>
 struct RiccatiSmem {
   static constexpr int NV = D::NV, NX = D::NX, NU = D::NU;
   static constexpr int PQQ = 0, PQV = PQQ + NV * NV, PVV = PQV + NV * NV, SQ = PVV + NV * NV, SV = SQ + NV,
-                       STAGE = SV + NV + 4,                                  // copy of the kkt record
-                       ATPQQ = STAGE + OcpLayout<D>::KKT, ATPQV = ATPQQ + NV * NV, ATPVQ = ATPQV + NV * NV, ATPVV = ATPVQ + NV * NV,
-                       BTPQ = ATPVV + NV * NV, BTPV = BTPQ + NU * NV, KM = BTPV + NU * NV, GK = KM + NU * NX, KV = GK + NU * NX,
+                       STAGE = SV + NV + 4,                                  // copy of the kkt record without Qxx
+                       STAGE_LEN = OcpLayout<D>::KKT - OcpLayout<D>::K_QXU,
+                       ATPQQ = STAGE + STAGE_LEN, ATPQV = ATPQQ + NV * NV, ATPVQ = ATPQV + NV * NV, ATPVV = ATPVQ + NV * NV,
+                       BTPQ = ATPVV + NV * NV, BTPV = BTPQ + NU * NV, KM = BTPV + NU * NV,
+                       GK = BTPQ,                                            // Quu K reuses the B^T P scratch
+                       KV = KM + NU * NX,
                        GW = KV + 16, SQN = GW + NU * NU, SVN = SQN + NV, TOTAL = SVN + NV + 4;
+  static_assert(2 * NU * NV == NU * NX, "GK aliases B^T P");
 };
 
-template <typename D>
-__global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B) {
+template <typename D, int NT>
+__global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = RiccatiSmem<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV;
@@ -41,12 +46,14 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
   const OcpProblem* __restrict__ P = B.prob;
   const int N = P->N;
   const double dt = P->dt;
-  const int tid = threadIdx.x, nt = 256;
+  const int tid = threadIdx.x;
+  constexpr int nt = NT;
   const long b = blockIdx.x;
   double* Pqq = &sm[S::PQQ];
   double* Pqv = &sm[S::PQV];
   double* Pvv = &sm[S::PVV];
-  double* st = &sm[S::STAGE];
+  double* st = &sm[S::STAGE];     // st[k - K_QXU] holds kkt[k] for k >= K_QXU
+  constexpr int KO = L::K_QXU, SL = S::STAGE_LEN;
   if (tid == 0) s_ok = 1;
   // terminal stage (riccati_recursion_solver.cpp:53-56)
   {
@@ -64,22 +71,49 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
       rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }
   }
+  {
+    const double* __restrict__ kk = B.kkt + (b * (N + 1) + N - 1) * L::KKT;
+    for (int e = tid; e < SL; e += nt) st[e] = kk[KO + e];
+  }
   __syncthreads();
   for (int i = N - 1; i >= 0; --i) {
-    const double* __restrict__ kk = B.kkt + (b * (N + 1) + i) * L::KKT;
-    for (int e = tid; e < L::KKT; e += nt) st[e] = kk[e];
-    __syncthreads();
-    double* Qxx = st + L::K_QXX;
-    double* Qxu = st + L::K_QXU;
-    double* Quu = st + L::K_QUU;
-    const double* Fqq6 = st + L::K_FQQ;
-    const double* Fqv6 = st + L::K_FQV;
-    const double* Fvq = st + L::K_FVQ;
-    const double* Fvv = st + L::K_FVV;
-    const double* Fvu = st + L::K_FVU;
-    const double* lx = st + L::K_LX;
-    double* lu = st + L::K_LU;
-    const double* Fx = st + L::K_FX;
+    const bool stamp = tid == 0 && b == 7 && i == N / 2 && B.prof != nullptr;
+#define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
+    RSTAMP(0);
+    // software pipeline: the record of stage i was staged into LDS at the end of the previous
+    // iteration; issue the global loads of stage i-1 now and park them in registers
+    constexpr int PF = (SL + NT - 1) / NT, QF = (NN + NT - 1) / NT;
+    double pre[PF], qxx[3][QF];
+    {
+      // Qxx of THIS stage is consumed once per element in the F phase: straight to registers
+      const double* __restrict__ kc = B.kkt + (b * (N + 1) + i) * L::KKT;
+#pragma unroll
+      for (int t = 0; t < QF; ++t) {
+        const int e = tid + NT * t;
+        if (e < NN) {
+          const int c = e / NV, r = e - c * NV;
+          qxx[0][t] = kc[L::K_QXX + r + NX * c];
+          qxx[1][t] = kc[L::K_QXX + r + NX * (NV + c)];
+          qxx[2][t] = kc[L::K_QXX + (NV + r) + NX * (NV + c)];
+        }
+      }
+    }
+    if (i > 0) {
+      const double* __restrict__ kn = B.kkt + (b * (N + 1) + i - 1) * L::KKT + KO;
+#pragma unroll
+      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; pre[t] = (e < SL) ? kn[e] : 0.0; }
+    }
+    double* Qxu = st + (L::K_QXU - KO);
+    double* Quu = st + (L::K_QUU - KO);
+    const double* Fqq6 = st + (L::K_FQQ - KO);
+    const double* Fqv6 = st + (L::K_FQV - KO);
+    const double* Fvq = st + (L::K_FVQ - KO);
+    const double* Fvv = st + (L::K_FVV - KO);
+    const double* Fvu = st + (L::K_FVU - KO);
+    const double* lx = st + (L::K_LX - KO);
+    double* lu = st + (L::K_LU - KO);
+    const double* Fx = st + (L::K_FX - KO);
+    RSTAMP(1);
     // ---- A^T P blocks and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
@@ -112,8 +146,12 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
     const double* AtPvv = &sm[S::ATPVV];
     const double* BtPq = &sm[S::BTPQ];
     const double* BtPv = &sm[S::BTPV];
-    // ---- F, H, G and the vector term (:79-113) ----
-    for (int e = tid; e < NN; e += nt) {
+    RSTAMP(2);
+    // ---- F, H, G and the vector term (:79-113); F overwrites P_{i+1}, which is dead from here ----
+#pragma unroll
+    for (int t = 0; t < QF; ++t) {
+      const int e = tid + NT * t;
+      if (e >= NN) break;
       const int c = e / NV, r = e - c * NV;
       double qqq, qqv, qvv;
       if (c < 6) {
@@ -131,9 +169,9 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
         qqv += AtPqv[r + NV * m] * Fvv[m + NV * c];
         qvv += AtPvv[r + NV * m] * Fvv[m + NV * c];
       }
-      Qxx[r + NX * c] += qqq;
-      Qxx[r + NX * (NV + c)] += qqv;
-      Qxx[(NV + r) + NX * (NV + c)] += qvv;
+      Pqq[e] = qxx[0][t] + qqq;
+      Pqv[e] = qxx[1][t] + qqv;
+      Pvv[e] = qxx[2][t] + qvv;
     }
     for (int e = tid; e < NV * NU; e += nt) {
       const int j = e / NV, r = e - j * NV;
@@ -156,16 +194,31 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
       lu[j] += acc;
     }
     __syncthreads();
+    RSTAMP(3);
     // Qvq = Qqv^T (:94) -- only read through Qqv below, kept for completeness of the record
     // ---- LLT(Quu), K = -Quu^-1 Qxu^T, k = -Quu^-1 lu (split_riccati_factorizer.hxx:43-46) ----
+    // (the reference factorises with Eigen::LLT; here Quu^-1 is formed by Gauss-Jordan on one
+    // wavefront and applied with two small products -- same K, k up to rounding)
     for (int e = tid; e < NU * NU; e += nt) sm[S::GW + e] = Quu[e];
-    choleskyInPlace(&sm[S::GW], NU, NU, tid, nt, &s_ok);
-    for (int e = tid; e < NU * NX; e += nt) { const int c = e / NU, j = e - c * NU; sm[S::KM + e] = -Qxu[c + NX * j]; }
-    if (tid < NU) sm[S::KV + tid] = -lu[tid];
     __syncthreads();
-    choleskySolve(&sm[S::GW], NU, NU, &sm[S::KM], NU, NX, tid, nt);
-    if (tid == nt - 1) choleskySolve(&sm[S::GW], NU, NU, &sm[S::KV], NU, 1, 0, 1);
+    if (tid < 64) spdInverseWave<3>(&sm[S::GW], &sm[S::GK], NU, NU, tid, &s_ok);
     __syncthreads();
+    for (int e = tid; e < NU * NX; e += nt) {
+      const int c = e / NU, j = e - c * NU;
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
+      sm[S::KM + e] = -acc;
+    }
+    if (tid >= NT - NU) {
+      const int j = tid - (NT - NU);
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
+      sm[S::KV + j] = -acc;
+    }
+    __syncthreads();
+    RSTAMP(4);
     // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
     mm(colMajor(&sm[S::GK], NU), colMajor(Quu, NU), colMajor(&sm[S::KM], NU), NU, NX, NU, 1.0, false, tid, nt);
     // s recursion (:141-160) needs P_{i+1}, s_{i+1}: do it before P is overwritten
@@ -188,6 +241,7 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
       sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
     }
     __syncthreads();
+    RSTAMP(5);
     // P = F - K^T G K (:122-131)
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
@@ -198,11 +252,12 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
         b2 += kq * sm[S::GK + j + NU * (NV + c)];
         d2 += kv * sm[S::GK + j + NU * (NV + c)];
       }
-      Pqq[e] = Qxx[r + NX * c] - a;
-      Pqv[e] = Qxx[r + NX * (NV + c)] - b2;
-      Pvv[e] = Qxx[(NV + r) + NX * (NV + c)] - d2;
+      Pqq[e] -= a;
+      Pqv[e] -= b2;
+      Pvv[e] -= d2;
     }
     __syncthreads();
+    RSTAMP(6);
     // preserve the symmetry (:133-135) -- symmetrised values staged in the A^T P scratch
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
@@ -210,6 +265,7 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
       sm[S::ATPVV + e] = 0.5 * (Pvv[e] + Pvv[c + NV * r]);
     }
     __syncthreads();
+    RSTAMP(7);
     double* __restrict__ rr = B.ric + (b * (N + 1) + i) * L::RIC;
     double* __restrict__ gg = B.gain + (b * N + i) * L::GAIN;
     for (int e = tid; e < NN; e += nt) {
@@ -223,6 +279,13 @@ __global__ __launch_bounds__(256) void ocp_riccati_backward_kernel(OcpBuffers B)
     for (int e = tid; e < NU * NX; e += nt) gg[L::G_K + e] = sm[S::KM + e];
     if (tid < NU) gg[L::G_k + tid] = sm[S::KV + tid];
     __syncthreads();
+    if (i > 0) {
+#pragma unroll
+      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; if (e < SL) st[e] = pre[t]; }
+    }
+    __syncthreads();
+    RSTAMP(8);
+#undef RSTAMP
   }
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1;
 }
@@ -288,10 +351,21 @@ void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int N, hipSt
   const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
-  hipLaunchKernelGGL((ocp_riccati_backward_kernel<D>), dim3((unsigned)batch), dim3(256), smem, st, B);
+  // Throughput mode (many instances): two wavefronts per instance, four instances per CU (39.8 kB
+  // of LDS each) -- measured best at batch 1024 (2.48 ms vs 3.22 ms with one and 2.96 ms with four
+  // wavefronts).  Latency mode (few instances): four wavefronts per instance.
+  // IDOCP_RICCATI_NT={64,128,256} overrides the choice (tuning aid).
+  static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
+  if (nt_env == 128) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128>), dim3((unsigned)batch), dim3(128), smem, st, B);
+  else if (nt_env == 256) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256>), dim3((unsigned)batch), dim3(256), smem, st, B);
+  else if (nt_env == 64) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 64>), dim3((unsigned)batch), dim3(64), smem, st, B);
+  else if (batch >= 512) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128>), dim3((unsigned)batch), dim3(128), smem, st, B);
+  else hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256>), dim3((unsigned)batch), dim3(256), smem, st, B);
 }
 template <typename D>
 void OcpLaunch<D>::riccatiForward(const OcpBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
