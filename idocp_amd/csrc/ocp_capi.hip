@@ -324,7 +324,7 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
   if (h->qref_time != h->qref_time && (rc = uploadQRef(h, 0.0))) return rc;      // first use: reference of t = 0
   switch (kernel_id) {
     case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream); break;
-    case 1: OcpLaunch<DQ>::condense(h->B, h->batch, h->N, d_q, h->stream); break;
+    case 1: OcpLaunch<DQ>::condense(h->B, h->batch, h->N, h->prob.dimf, d_q, h->stream); break;
     case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, h->N, h->stream); break;
     case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, h->N, d_q, d_v, h->stream); break;
     default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, h->N, h->stream); break;
@@ -340,7 +340,7 @@ int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q
   if ((rc = uploadQRef(h, t))) return rc;
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
   OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream);
-  OcpLaunch<DQ>::condense(h->B, h->batch, h->N, d_q, h->stream);
+  OcpLaunch<DQ>::condense(h->B, h->batch, h->N, h->prob.dimf, d_q, h->stream);
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, h->N, h->stream);
   OcpLaunch<DQ>::riccatiForward(h->B, h->batch, h->N, d_q, d_v, h->stream);
   OcpLaunch<DQ>::expandPrimal(h->B, h->batch, h->N, h->stream);

@@ -74,7 +74,7 @@ struct CondenseSmem {
                        TOTAL = QB6 + 36 + 2;
 };
 
-template <typename D, bool RESIDUAL>
+template <typename D, bool RESIDUAL, int DIMF>
 __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
   using L = OcpLayout<D>;
   using S = CondenseSmem<D>;
@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const long b = unit / (N + 1);
   const int i = (int)(unit - b * (N + 1));
   const bool terminal = (i == N);
-  const int dimf = P->dimf, dimvf = NV + dimf;
+  // DIMF >= 0: the number of active contact rows is a compile-time constant (every loop bound and
+  // index division below folds); DIMF < 0: read it from the problem record.
+  const int dimf = (DIMF >= 0) ? DIMF : P->dimf, dimvf = NV + dimf;
   const double* __restrict__ s_g = B.sol + unit * L::SOL;
   const double* s = &sm[S::SOLS];                   // LDS copies of this stage's and the next stage's solution records
   const double* sn = &sm[S::SOLN];                  // (only valid for i < N)
@@ -479,30 +481,32 @@ __global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double*
 }
 
 template <typename D>
-static void launchCondense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st, bool residual) {
+static void launchCondense(const OcpBuffers& B, long batch, int N, int dimf, const double* q0, hipStream_t st, bool residual) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * (N + 1));
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
-  if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true>), dim3(blocks), dim3(256), smem, st, B, q0);
-  else hipLaunchKernelGGL((ocp_condense_kernel<D, false>), dim3(blocks), dim3(256), smem, st, B, q0);
+  if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
+  else if (dimf == D::NF) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0);      // all feet in contact
+  else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
 }
 
 template <typename D>
-void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st) {
-  launchCondense<D>(B, batch, N, q0, st, false);
+void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int N, int dimf, const double* q0, hipStream_t st) {
+  launchCondense<D>(B, batch, N, dimf, q0, st, false);
 }
 template <typename D>
 void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st) {
-  launchCondense<D>(B, batch, N, q0, st, true);
+  launchCondense<D>(B, batch, N, -1, q0, st, true);
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);
 
 }  // namespace idocp_dev

@@ -11,7 +11,7 @@ namespace idocp_dev {
 template <typename D>
 struct OcpLaunch {
   static void rnea(const OcpBuffers& B, long batch, int N, hipStream_t st);          // K5a
-  static void condense(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st);   // K5b (+ terminal)
+  static void condense(const OcpBuffers& B, long batch, int N, int dimf, const double* q0, hipStream_t st);   // K5b (+ terminal)
   static void residual(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st);   // K8
   static void riccatiBackward(const OcpBuffers& B, long batch, int N, hipStream_t st);               // S3
   static void riccatiForward(const OcpBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);  // S4
