@@ -221,12 +221,16 @@ def main():
     alg_bytes = a_stage * units[dom]
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
+    # HBM bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and
+    # WRITE_SIZE in separate passes, gfx950 correction applied) by profiles/run_profiles.sh; only quoted
+    # when the committed record was taken on this very workload / batch / horizon.
+    import glob
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
         try:
             rec = json.load(open(pmc))
             if rec.get("batch") == B and rec.get("horizon") == N and rec.get("workload", "iiwa14") == args.workload:
                 traffic = rec.get("hbm_bytes_per_launch", {}).get(KERNELS[dom])
+                break
         except Exception:
             traffic = None
 

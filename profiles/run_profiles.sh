@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on a GPU box (run through gpurun from the repo root):
+#   profiles/run_profiles.sh <round> <workload>         e.g.  profiles/run_profiles.sh 01 anymal
+# Pass 1: --kernel-trace --stats of the default bench command.
+# Pass 2/3: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (no other trace domains).
+# Raw databases stay under gpurun_out/ (scratch); the text / json summaries are copied to profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+rnd=$1; wl=$2
+out=$R/gpurun_out/prof_r$rnd
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out -o ${wl}_trace -- python3 $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $out/${wl}_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out -o ${wl}_fetch -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $out/${wl}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out -o ${wl}_write -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $out/${wl}_write.log 2>&1
+cd $R
+line=$(grep '^{"metric"' $out/${wl}_trace.log | tail -1)
+batch=$(echo "$line" | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['config']['batch_per_gpu'])")
+hor=$(echo "$line" | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['config']['horizon'])")
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline"; echo "# bench line: $line"; python3 profiles/summarize_rocpd.py $out/${wl}_trace_results.db; } > $out/r${rnd}_${wl}_kernel_trace.txt
+python3 profiles/summarize_rocpd.py $out/${wl}_fetch_results.db $out/${wl}_write_results.db > $out/r${rnd}_${wl}_pmc_hbm.txt
+python3 profiles/make_traffic_json.py $out/${wl}_fetch_results.db $out/${wl}_write_results.db $wl $batch $hor $rnd > $out/r${rnd}_pmc_traffic_${wl}.json
+echo "$line"
