@@ -95,6 +95,50 @@ def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_secon
             "ms_per_update": 1e3 * el / iters, "ms_per_riccati_sweep": 1e3 * ric.value / iters}
 
 
+def init_distributed(backend, local_rank):
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    backend "nccl" is RCCL on ROCm; the CPU test of this scaffolding uses "gloo"."""
+    import torch
+    import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
+def run_timed(step, sync, steps, warmup, dist, device, events=None):
+    """The timing protocol of the contract: `warmup` untimed steps, then EXACTLY `steps` steps
+    bracketed by barrier + synchronize on both sides; returns the MAX elapsed seconds over ranks.
+    The replicas exchange nothing else (the Riccati path does not shard)."""
+    for _ in range(warmup):
+        step(None)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(events[k] if events is not None else None)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    return el
+
+
+def whole_job_value(world, batch_per_rank, steps, elapsed):
+    """SQP iterations per second summed over all ranks (weak scaling: every rank owns `batch_per_rank`
+    independent OCP instances)."""
+    return world * batch_per_rank * steps / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,10 +155,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = init_distributed("nccl", local_rank)
 
     from idocp_amd import capi
     from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,
@@ -190,25 +231,8 @@ def main():
             import torch
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
     ev = [[hip.event() for _ in range(len(KERNELS) + 1)] for _ in range(args.steps)]
-    if dist is not None:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
-    sync()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
+    el = run_timed(step, sync, args.steps, args.warmup, dist, "cuda", ev)
 
     # per-kernel average durations from the events of the timed region
     kms = np.zeros(len(KERNELS))
@@ -239,10 +263,9 @@ def main():
     assert np.isfinite(kkt).all(), "non-finite KKT error after the timed region"
 
     if rank == 0:
-        total_iters = world * B * args.steps
         ms_step = 1e3 * el / args.steps
         out = {
-            "metric": "SQP iterations/sec (whole node)", "value": total_iters / el, "unit": "SQP iterations/s",
+            "metric": "SQP iterations/sec (whole node)", "value": whole_job_value(world, B, args.steps, el), "unit": "SQP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + "batch=%d independent OCP instances per GPU, replicas across GPUs" % B,

@@ -81,6 +81,12 @@ def _proto(lib):
     lib.idocp_model_from_urdf.restype = ci
     lib.idocp_model_frame_id.argtypes = [cs, cs]
     lib.idocp_model_frame_id.restype = ci
+    lib.idocp_abi_check.argtypes = [C.c_ulong, C.c_ulong, C.c_ulong]
+    lib.idocp_abi_check.restype = ci
+    if lib.idocp_abi_check(C.sizeof(Model), C.sizeof(Cost), C.sizeof(Constraints)) != 0:
+        raise LibraryMissing("idocp_amd/capi.py structs do not match libidocp_hip.so (rebuild: python idocp_amd/build.py)")
+    lib.idocp_model_contact_positions.argtypes = [P(Model), vp, vp]
+    lib.idocp_model_contact_positions.restype = ci
     lib.idocp_cost_init.argtypes = [P(Cost)]
     lib.idocp_cost_init.restype = None
     lib.idocp_constraints_init.argtypes = [P(Constraints)]

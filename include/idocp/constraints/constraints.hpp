@@ -17,13 +17,14 @@ namespace idocp {
 
 class ConstraintComponentBase {
  public:
-  enum Family { Position, Velocity, Torque };
+  enum Family { Position, Velocity, Torque, LinearFrictionCone };
   ConstraintComponentBase(Family f, bool upper, double barrier, double rate)
       : family(f), upper(upper), barrier(barrier), fraction_to_boundary_rate(rate) {}
   virtual ~ConstraintComponentBase() {}
   Family family;
   bool upper;
   double barrier, fraction_to_boundary_rate;
+  double mu = 0.0;
 };
 
 #define IDOCP_LIMIT_CLASS(NAME, FAMILY, UPPER)                                                        \
@@ -40,6 +41,28 @@ IDOCP_LIMIT_CLASS(JointTorquesLowerLimit, Torque, false);
 IDOCP_LIMIT_CLASS(JointTorquesUpperLimit, Torque, true);
 #undef IDOCP_LIMIT_CLASS
 
+// LinearizedFrictionCone (include/idocp/constraints/linearized_friction_cone.hpp:17-120,
+// src/constraints/linearized_friction_cone.cpp): five rows per active contact, evaluated in K5b.
+class LinearizedFrictionCone final : public ConstraintComponentBase {
+ public:
+  LinearizedFrictionCone(const Robot&, const double mu, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(LinearFrictionCone, false, barrier, fraction_to_boundary_rate) { setFrictionCoefficient(mu); }
+  void setFrictionCoefficient(const double mu_in) {
+    if (mu_in <= 0) {      // linearized_friction_cone.cpp:20-31
+      std::cerr << "invalid argment: mu must be positive" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    mu = mu_in;
+  }
+};
+// Impulse twin: accepted so that the reference's drivers compile; it only acts on impulse stages,
+// which the HIP path does not carry yet.
+class LinearizedImpulseFrictionCone final : public ConstraintComponentBase {
+ public:
+  LinearizedImpulseFrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(LinearFrictionCone, true, barrier, fraction_to_boundary_rate) { mu = mu_in; }
+};
+
 class Constraints {
  public:
   Constraints() : lo_{0, 0, 0}, hi_{0, 0, 0} {
@@ -48,6 +71,10 @@ class Constraints {
     c_.linearized_friction_cone = 0;
   }
   void push_back(const std::shared_ptr<ConstraintComponentBase>& c) {
+    if (c->family == ConstraintComponentBase::LinearFrictionCone) {
+      if (!c->upper) { c_.linearized_friction_cone = 1; c_.mu = c->mu; }     // upper = impulse twin (no-op)
+      return;
+    }
     (c->upper ? hi_ : lo_)[c->family] = 1;
     c_.barrier = c->barrier;
     c_.fraction_to_boundary_rate = c->fraction_to_boundary_rate;

@@ -2,10 +2,13 @@
 //
 // The reference's cost is an open plug-in system (CostFunctionComponentBase with
 // virtual dispatch, include/idocp/cost/cost_function.hxx).  The HIP path
-// evaluates the cost inside the stage kernel, so only the components it carries
-// natively can be pushed: ConfigurationSpaceCost
-// (src/cost/configuration_space_cost.cpp:241-397).  Anything else is rejected
-// at push_back -- there is no silent CPU fallback.
+// evaluates the cost inside the stage kernels, so only the components it carries
+// natively can be pushed: one configuration-space cost (ConfigurationSpaceCost,
+// src/cost/configuration_space_cost.cpp:241-397, or TrottingConfigurationSpaceCost,
+// src/cost/trotting_configuration_space_cost.cpp) and one ContactForceCost
+// (src/cost/contact_force_cost.cpp:153-194).  Anything else -- or a second
+// component of the same kind -- is rejected at push_back: there is no silent
+// CPU fallback.
 #ifndef IDOCP_COST_FUNCTION_HPP_
 #define IDOCP_COST_FUNCTION_HPP_
 
@@ -22,7 +25,10 @@ namespace idocp {
 class CostFunctionComponentBase {
  public:
   virtual ~CostFunctionComponentBase() {}
-  // adds this component's parameters to the flat cost block; false = cannot be represented
+  enum Kind { ConfigurationSpace = 0, ContactForce = 1 };
+  virtual Kind kind() const { return ConfigurationSpace; }
+  // writes this component's parameters into its fields of the flat cost block;
+  // false = cannot be represented
   virtual bool exportTo(idocp_cost_t& cost) const = 0;
 };
 
@@ -40,7 +46,12 @@ class ConfigurationSpaceCost final : public CostFunctionComponentBase {
   void set_u_weight(const Eigen::VectorXd& v) { put(c_.u_weight, v, dimu_, "u_weight"); }
   void set_qf_weight(const Eigen::VectorXd& v) { put(c_.qf_weight, v, dimv_, "qf_weight"); }
   void set_vf_weight(const Eigen::VectorXd& v) { put(c_.vf_weight, v, dimv_, "vf_weight"); }
-  bool exportTo(idocp_cost_t& cost) const override { cost = c_; return true; }
+  bool exportTo(idocp_cost_t& cost) const override {
+    idocp_cost_t keep = cost;                       // contact-force fields belong to another component
+    cost = c_;
+    for (int i = 0; i < IDOCP_MAX_CONTACTS; ++i) for (int k = 0; k < 3; ++k) { cost.f_weight[i][k] = keep.f_weight[i][k]; cost.f_ref[i][k] = keep.f_ref[i][k]; }
+    return true;
+  }
 
  private:
   int dimq_, dimv_, dimu_;
@@ -56,18 +67,19 @@ class ConfigurationSpaceCost final : public CostFunctionComponentBase {
 
 class CostFunction {
  public:
-  CostFunction() : n_(0) { idocp_cost_init(&c_); }
+  CostFunction() : have_{false, false} { idocp_cost_init(&c_); }
   void push_back(const std::shared_ptr<CostFunctionComponentBase>& c) {
-    if (n_ > 0 || !c->exportTo(c_)) {
-      std::cerr << "unsupported cost: the HIP path carries exactly one ConfigurationSpaceCost component" << '\n';
+    const int k = (int)c->kind();
+    if (have_[k] || !c->exportTo(c_)) {
+      std::cerr << "unsupported cost: the HIP path carries one configuration-space cost and one ContactForceCost" << '\n';
       std::exit(EXIT_FAILURE);
     }
-    ++n_;
+    have_[k] = true;
   }
   const idocp_cost_t& native() const { return c_; }
 
  private:
-  int n_;
+  bool have_[2];
   idocp_cost_t c_;
 };
 

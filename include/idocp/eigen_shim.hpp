@@ -22,6 +22,18 @@
 
 namespace Eigen {
 
+// `v << a, b, c;` of Eigen's CommaInitializer, for the examples' reference vectors
+template <typename V>
+class CommaInit {
+ public:
+  CommaInit(V& v, double first) : v_(v), i_(0) { put(first); }
+  CommaInit& operator,(double x) { put(x); return *this; }
+ private:
+  V& v_;
+  int i_;
+  void put(double x) { assert(i_ < v_.size()); v_[i_++] = x; }
+};
+
 class VectorXd {
  public:
   VectorXd() {}
@@ -39,12 +51,32 @@ class VectorXd {
   double operator()(int i) const { return (*this)[i]; }
   double& coeffRef(int i) { return (*this)[i]; }
   double coeff(int i) const { return (*this)[i]; }
+  CommaInit<VectorXd> operator<<(double first) { return CommaInit<VectorXd>(*this, first); }
   VectorXd operator-(const VectorXd& o) const { assert(size() == o.size()); VectorXd r(size()); for (int i = 0; i < size(); ++i) r[i] = d_[i] - o.d_[i]; return r; }
   VectorXd operator+(const VectorXd& o) const { assert(size() == o.size()); VectorXd r(size()); for (int i = 0; i < size(); ++i) r[i] = d_[i] + o.d_[i]; return r; }
  private:
   std::vector<double> d_;
 };
 inline std::ostream& operator<<(std::ostream& os, const VectorXd& v) { for (int i = 0; i < v.size(); ++i) os << (i ? " " : "") << v[i]; return os; }
+
+class Vector3d {
+ public:
+  Vector3d() : d_{0.0, 0.0, 0.0} {}
+  Vector3d(double x, double y, double z) : d_{x, y, z} {}
+  static Vector3d Zero() { return Vector3d(); }
+  int size() const { return 3; }
+  double* data() { return d_; }
+  const double* data() const { return d_; }
+  double& operator[](int i) { assert(i >= 0 && i < 3); return d_[i]; }
+  double operator[](int i) const { assert(i >= 0 && i < 3); return d_[i]; }
+  double& operator()(int i) { return (*this)[i]; }
+  double operator()(int i) const { return (*this)[i]; }
+  double& coeffRef(int i) { return (*this)[i]; }
+  double coeff(int i) const { return (*this)[i]; }
+  CommaInit<Vector3d> operator<<(double first) { return CommaInit<Vector3d>(*this, first); }
+ private:
+  double d_[3];
+};
 
 class MatrixXd {   // column-major
  public:

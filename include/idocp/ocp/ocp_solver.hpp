@@ -1,0 +1,144 @@
+// idocp::OCPSolver -- drop-in facade over the HIP contact path.
+//
+// Same constructor signature and methods as the reference class
+// (include/idocp/ocp/ocp_solver.hpp:32-232; src/ocp/ocp_solver.cpp).  Every
+// method forwards to the C ABI (include/idocp_hip.h); the arithmetic runs in
+// the HIP kernels K5a/K5b/S3/S4/K6/K7/K8.  `nthreads` is accepted for source
+// compatibility and ignored (the GPU replaces the OpenMP team).  Argument
+// errors: message on stderr + std::exit(EXIT_FAILURE), like the reference.
+//
+// Carried in this round: a horizon with one contact status on every stage
+// (setContactStatusUniformly).  Contact sequences with discrete events
+// (pushBackContactStatus: impulse / lift stages) are rejected loudly.
+#ifndef IDOCP_OCP_SOLVER_HPP_
+#define IDOCP_OCP_SOLVER_HPP_
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "idocp/constraints/constraints.hpp"
+#include "idocp/cost/cost_function.hpp"
+#include "idocp/eigen_shim.hpp"
+#include "idocp/robot/contact_status.hpp"
+#include "idocp/robot/robot.hpp"
+#include "idocp_hip.h"
+
+namespace idocp {
+
+// include/idocp/ocp/split_solution.hxx:10-31 (f, mu: one 3-vector per contact, stacked)
+struct SplitSolutionOCP {
+  Eigen::VectorXd lmd, gmm, q, v, a, u, beta, f_stack, mu_stack, nu_passive;
+};
+
+class OCPSolver {
+ public:
+  OCPSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
+            const double T, const int N, const int max_num_impulse = 0, const int nthreads = 1, const int device = 0)
+      : robot_(robot), N_(N), h_(nullptr) {
+    (void)nthreads;
+    if (max_num_impulse < 0) {      // ocp_solver.cpp:34-36
+      std::cerr << "invalid value: max_num_impulse must be non-negative!" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    const idocp_cost_t c = cost->native();
+    const idocp_constraints_t k = constraints->native();
+    check(idocp_ocp_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    cache_.resize(N + 1);
+  }
+  ~OCPSolver() { idocp_ocp_destroy(h_); }
+  OCPSolver(const OCPSolver&) = delete;
+  OCPSolver& operator=(const OCPSolver&) = delete;
+
+  void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
+
+  void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    check(idocp_ocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
+  }
+
+  std::vector<Eigen::VectorXd> getSolution(const std::string& name) const {
+    const int dim = dimOf(name);
+    const bool per_stage = !(name == "q" || name == "v" || name == "lmd" || name == "gmm");
+    const int n = per_stage ? N_ : N_ + 1;
+    std::vector<double> buf((size_t)(N_ + 1) * dim);
+    check(idocp_ocp_get_solution(h_, name.c_str(), 0, buf.data()));
+    std::vector<Eigen::VectorXd> out(n, Eigen::VectorXd(dim));
+    for (int i = 0; i < n; ++i) for (int j = 0; j < dim; ++j) out[i][j] = buf[(size_t)i * dim + j];
+    return out;
+  }
+
+  const SplitSolutionOCP& getSolution(const int stage) {
+    SplitSolutionOCP& s = cache_.at(stage);
+    const char* names[10] = {"lmd", "gmm", "q", "v", "a", "u", "beta", "f", "mu", "nu_passive"};
+    Eigen::VectorXd* dst[10] = {&s.lmd, &s.gmm, &s.q, &s.v, &s.a, &s.u, &s.beta, &s.f_stack, &s.mu_stack, &s.nu_passive};
+    for (int f = 0; f < 10; ++f) {
+      if (stage == N_ && f >= 4) { dst[f]->resize(dimOf(names[f])); continue; }
+      *dst[f] = getSolution(names[f])[stage];
+    }
+    return s;
+  }
+
+  // OCPSolver::getStateFeedbackGain (ocp_solver.cpp:103-113): du = Kq dq + Kv dv
+  void getStateFeedbackGain(const int time_stage, Eigen::MatrixXd& Kq, Eigen::MatrixXd& Kv) const {
+    const int nv = robot_.dimv(), nu = robot_.dimu();
+    Kq.resize(nu, nv); Kv.resize(nu, nv);
+    check(idocp_ocp_get_state_feedback_gain(h_, 0, time_stage, Kq.data(), Kv.data()));
+  }
+
+  void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_ocp_set_solution(h_, name.c_str(), value.data())); }
+  void setSolution(const std::string& name, const Eigen::Vector3d& value) { check(idocp_ocp_set_solution(h_, name.c_str(), value.data())); }
+
+  void setContactStatusUniformly(const ContactStatus& contact_status) {
+    const int nc = contact_status.maxPointContacts();
+    std::vector<int> active(nc);
+    std::vector<double> pts(3 * (size_t)nc);
+    for (int c = 0; c < nc; ++c) {
+      active[c] = contact_status.isContactActive(c) ? 1 : 0;
+      for (int k = 0; k < 3; ++k) pts[3 * c + k] = contact_status.contactPoint(c)[k];
+    }
+    check(idocp_ocp_set_contact_status_uniformly(h_, active.data(), pts.data()));
+  }
+  void pushBackContactStatus(const ContactStatus&, const double) { unsupported("pushBackContactStatus"); }
+  void setContactPoints(const int, const std::vector<Eigen::Vector3d>&) { unsupported("setContactPoints(contact_phase, ...)"); }
+  void popBackContactStatus() { unsupported("popBackContactStatus"); }
+  void popFrontContactStatus() { unsupported("popFrontContactStatus"); }
+  void clearLineSearchFilter() {}
+
+  double KKTError() {
+    double e = 0;
+    check(idocp_ocp_kkt_error(h_, &e));
+    return e;
+  }
+  void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    check(idocp_ocp_compute_kkt_residual(h_, t, q.data(), v.data()));
+  }
+  idocp_ocp_t* handle() { return h_; }
+
+ private:
+  Robot robot_;
+  int N_;
+  idocp_ocp_t* h_;
+  std::vector<SplitSolutionOCP> cache_;
+  int dimOf(const std::string& name) const {
+    if (name == "q") return robot_.dimq();
+    if (name == "u") return robot_.dimu();
+    if (name == "f" || name == "mu") return robot_.max_dimf();
+    if (name == "nu_passive") return robot_.dim_passive();
+    return robot_.dimv();
+  }
+  static void check(int rc) {
+    if (rc != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+  }
+  static void unsupported(const char* what) {
+    std::cerr << "unsupported: OCPSolver::" << what << " (discrete events) is not carried by the HIP path yet" << '\n';
+    std::exit(EXIT_FAILURE);
+  }
+};
+
+}  // namespace idocp
+#endif  // IDOCP_OCP_SOLVER_HPP_

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "idocp/eigen_shim.hpp"
+#include "idocp/robot/contact_status.hpp"
 #include "idocp_hip.h"
 
 namespace idocp {
@@ -20,6 +21,10 @@ class Robot {
   // Robot(path_to_urdf) / Robot(path_to_urdf, contact_frames): errors follow the
   // reference convention -- message on stderr, std::exit(EXIT_FAILURE).
   explicit Robot(const std::string& path_to_urdf, const std::vector<int>& contact_frames = {}) {
+    if (idocp_abi_check(sizeof(idocp_model_t), sizeof(idocp_cost_t), sizeof(idocp_constraints_t)) != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
     const int rc = idocp_model_from_urdf(path_to_urdf.c_str(), contact_frames.empty() ? nullptr : contact_frames.data(),
                                          (int)contact_frames.size(), &model_);
     if (rc != IDOCP_OK) {
@@ -47,10 +52,36 @@ class Robot {
   void setLowerJointPositionLimit(const Eigen::VectorXd& v) { set(model_.q_min, v, "invalid size of lower_joint_position_limit"); }
   void setUpperJointPositionLimit(const Eigen::VectorXd& v) { set(model_.q_max, v, "invalid size of upper_joint_position_limit"); }
 
+  // Robot::createContactStatus / updateFrameKinematics / setContactPoints / getContactPoints
+  // (include/idocp/robot/robot.hxx:85-91, 262-283, 661-683).  Host arithmetic; see
+  // idocp_model_contact_positions in idocp_hip.h.
+  ContactStatus createContactStatus() const { return ContactStatus(model_.ncontacts); }
+  void updateFrameKinematics(const Eigen::VectorXd& q) {
+    if (q.size() != model_.nq) {
+      std::cerr << "invalid size: q.size() must be " << model_.nq << "!" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    points_.assign(3 * (size_t)model_.ncontacts, 0.0);
+    if (idocp_model_contact_positions(&model_, q.data(), points_.data()) != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+  }
+  void getContactPoints(std::vector<Eigen::Vector3d>& contact_points) const {
+    contact_points.resize(model_.ncontacts);
+    for (int c = 0; c < model_.ncontacts; ++c) for (int k = 0; k < 3; ++k) contact_points[c][k] = points_.at(3 * c + k);
+  }
+  void setContactPoints(ContactStatus& contact_status) const {
+    std::vector<Eigen::Vector3d> pts;
+    getContactPoints(pts);
+    contact_status.setContactPoints(pts);
+  }
+
   const idocp_model_t& model() const { return model_; }
 
  private:
   idocp_model_t model_;
+  std::vector<double> points_;     // contact-frame positions of the last updateFrameKinematics(q)
   Eigen::VectorXd get(const double* p) const {
     Eigen::VectorXd v(model_.nu);
     for (int i = 0; i < model_.nu; ++i) v[i] = p[i];

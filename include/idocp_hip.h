@@ -129,6 +129,18 @@ int idocp_model_from_urdf(const char* path_to_urdf, const int* contact_frames,
  * enumerates the same table); returns -1 if absent. */
 int idocp_model_frame_id(const char* path_to_urdf, const char* frame_name);
 
+/* World positions points[ncontacts][3] of the contact frames at configuration q:
+ * Robot::updateFrameKinematics(q) + Robot::setContactPoints / getContactPoints
+ * (include/idocp/robot/robot.hxx:85-91, 262-283).  Host arithmetic (problem
+ * set-up before the contact sequence is built, examples/anymal/ocp_benchmark.cpp:
+ * 104-106), not part of the hot path. */
+int idocp_model_contact_positions(const idocp_model_t* model, const double* q, double* points);
+
+/* Guards against a driver compiled against an older header than the loaded library:
+ * pass sizeof(idocp_model_t), sizeof(idocp_cost_t), sizeof(idocp_constraints_t);
+ * returns IDOCP_E_ARG on a mismatch.  The C++ facade calls it from idocp::Robot. */
+int idocp_abi_check(unsigned long model_size, unsigned long cost_size, unsigned long constraints_size);
+
 void idocp_cost_init(idocp_cost_t* cost);                 /* all zero          */
 void idocp_constraints_init(idocp_constraints_t* c);      /* reference defaults */
 

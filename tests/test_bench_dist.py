@@ -1,0 +1,69 @@
+"""Multi-process scaffolding of bench.py on CPU (gloo, world size 2).
+
+The Riccati path does not shard: N ranks run N independent replicas and the only
+collectives are the barriers around the timed region and the MAX-reduction of the elapsed time.
+This test runs exactly that code (`bench.init_distributed`, `bench.run_timed`,
+`bench.whole_job_value`) with a stand-in step function, one process per rank.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, %r)
+import bench
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist = bench.init_distributed("gloo", 0)
+calls = {"step": 0, "sync": 0}
+def step(events):
+    calls["step"] += 1
+    time.sleep(0.01 * (1 + 2 * rank))        # rank 1 is three times slower
+def sync():
+    calls["sync"] += 1
+el = bench.run_timed(step, sync, steps=5, warmup=2, dist=dist, device="cpu")
+val = bench.whole_job_value(world, 8, 5, el)
+print(json.dumps({"rank": rank, "elapsed": el, "value": val, "steps": calls["step"], "syncs": calls["sync"]}), flush=True)
+dist.destroy_process_group()
+""" % ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_replica_timing_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1]))
+    # every rank ran warmup + steps, and reports the SAME (max over ranks) elapsed time
+    assert all(o["steps"] == 7 for o in outs)
+    assert abs(outs[0]["elapsed"] - outs[1]["elapsed"]) < 1e-12
+    assert outs[0]["elapsed"] >= 5 * 0.03 * 0.9          # bounded below by the slow rank
+    # whole-job value = instances of all ranks / max time
+    assert abs(outs[0]["value"] - 2 * 8 * 5 / outs[0]["elapsed"]) < 1e-9
+
+
+def test_whole_job_value_weak_scaling():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.whole_job_value(1, 1024, 10, 0.5) == 1024 * 10 / 0.5
+    assert bench.whole_job_value(8, 1024, 10, 0.5) == 8 * bench.whole_job_value(1, 1024, 10, 0.5)

@@ -56,3 +56,35 @@ def test_no_cpu_fallback_without_gpu():
     h = C.c_void_p()
     assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 1, 0, C.byref(h)) == -3
     assert b"no CPU fallback" in lib.idocp_last_error()
+
+
+def test_contact_positions_host_fk_matches_oracle():
+    """idocp_model_contact_positions is host arithmetic (problem set-up), so it can be checked
+    without a GPU: feet of ANYmal at q_standing and at a random configuration vs the oracle's
+    frame kinematics (Robot::updateFrameKinematics + getContactPoints, robot.hxx:85-91, 262-283)."""
+    import ctypes as C
+    import numpy as np
+    from helpers import ANYMAL_Q_STANDING, P, anymal_model, arr, oracle
+    from idocp_amd import capi
+    lib = capi.lib()
+    model = anymal_model()
+    olib = oracle()
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        q = arr(ANYMAL_Q_STANDING).copy()
+        if trial > 0:
+            q[0:3] += rng.uniform(-0.3, 0.3, 3)
+            quat = rng.normal(size=4)
+            q[3:7] = quat / np.linalg.norm(quat)
+            q[7:] += rng.uniform(-0.5, 0.5, 12)
+        pts = np.zeros((model.ncontacts, 3))
+        assert lib.idocp_model_contact_positions(C.byref(model), P(q), P(pts)) == 0
+        nv, nc = model.nv, model.ncontacts
+        z = np.zeros(nv)
+        fp = np.zeros((nc, 3))
+        tmp = [np.zeros(n) for n in (3 * nc, 3 * nc * nv, 3 * nc * nv, 3 * nc * nv)]
+        fR, fv, fa = np.zeros((nc, 9)), np.zeros((nc, 6)), np.zeros((nc, 6))
+        d4 = [np.zeros(nc * 6 * nv) for _ in range(4)]
+        olib.oracle_contact_kinematics(C.byref(model), P(q), P(z), P(z), P(np.zeros((nc, 3))), C.c_double(0.05), P(tmp[0]), P(tmp[1]),
+                                       P(tmp[2]), P(tmp[3]), P(fp), P(fR), P(fv), P(fa), P(d4[0]), P(d4[1]), P(d4[2]), P(d4[3]), None)
+        assert np.abs(pts - fp).max() < 1e-13

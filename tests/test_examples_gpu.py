@@ -1,0 +1,75 @@
+"""The C++ facade (include/idocp/**) end to end on the GPU: build the example drivers with g++,
+run them, and compare the KKT errors they print (ocpbenchmarker::Convergence,
+include/idocp/utils/ocp_benchmarker.hxx:36-52) with the oracle driven on the same problem."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ANYMAL_Q_STANDING, ANYMAL_URDF, IIWA_URDF, OracleOCP, anymal_contact_points, anymal_model
+from idocp_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def build_examples():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "all"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def kkt_errors(stdout):
+    init = float(re.search(r"Initial KKT error = ([-+0-9.eE]+|nan|inf)", stdout).group(1))
+    its = [float(x) for x in re.findall(r"KKT error after iteration \d+ = ([-+0-9.eE]+|nan|inf)", stdout)]
+    return init, its
+
+
+def test_anymal_ocp_benchmark_example_matches_oracle():
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "anymal_ocp_benchmark"), ANYMAL_URDF, "20"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 10 and "CPU time per update" in r.stdout
+    # the same problem through the oracle (examples/anymal/ocp_benchmark.cpp:31-114 as data)
+    model = anymal_model()
+    nv = model.nv
+    cost = capi.Cost()
+    cost.set("q_ref", ANYMAL_Q_STANDING)
+    cost.set("q_weight", np.full(nv, 10.0)).set("qf_weight", np.full(nv, 10.0))
+    cost.set("v_weight", np.ones(nv)).set("vf_weight", np.ones(nv)).set("a_weight", np.full(nv, 0.01))
+    for c in range(4):
+        for k in range(3):
+            cost.f_weight[c][k] = 0.001
+            cost.f_ref[c][k] = 0.0
+        cost.f_ref[c][2] = 70.0
+    cons = capi.Constraints()
+    import ctypes as C
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    cons.linearized_friction_cone = 1
+    cons.mu = 0.7
+    o = OracleOCP(model, cost, cons, 0.5, 20)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
+    o.set_contact_status([1, 1, 1, 1], anymal_contact_points(model))
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    o.init_constraints(0.0)
+    ref_init = o.kkt_error(0.0, q, v)
+    assert abs(init - ref_init) <= 1e-5 * max(1.0, ref_init)          # printed with 6 significant digits
+    for k in range(10):
+        o.update(0.0, q, v)
+        ref = o.kkt_error(0.0, q, v)
+        assert abs(its[k] - ref) <= 2e-5 * max(1.0, ref), (k, its[k], ref)
+    assert its[-1] < init
+
+
+def test_iiwa14_unocp_benchmark_example_matches_oracle():
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "iiwa14_unocp_benchmark"), IIWA_URDF, "20"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) >= 10 and its[-1] < init
