@@ -48,6 +48,8 @@ class Cost(C.Structure):
         ("t_start", C.c_double), ("t_period", C.c_double), ("step_length", C.c_double),
         ("front_swing_knee", C.c_double), ("hip_swing_knee", C.c_double),
         ("front_stance_knee", C.c_double), ("hip_stance_knee", C.c_double),
+        ("qi_weight", C.c_double * MAX_NV), ("vi_weight", C.c_double * MAX_NV), ("dvi_weight", C.c_double * MAX_NV),
+        ("fi_weight", (C.c_double * 3) * MAX_CONTACTS), ("fi_ref", (C.c_double * 3) * MAX_CONTACTS),
     ]
 
     def set(self, name, values):
@@ -64,6 +66,7 @@ class Constraints(C.Structure):
         ("joint_torque_limits", C.c_int),
         ("linearized_friction_cone", C.c_int), ("mu", C.c_double),
         ("barrier", C.c_double), ("fraction_to_boundary_rate", C.c_double),
+        ("linearized_impulse_friction_cone", C.c_int),
     ]
 
 

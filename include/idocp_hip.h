@@ -98,6 +98,14 @@ typedef struct idocp_cost {
   int use_trotting_ref;
   double t_start, t_period, step_length;
   double front_swing_knee, hip_swing_knee, front_stance_knee, hip_stance_knee;
+  /* Impulse-stage terms (computeImpulseCostDerivatives / Hessian of the same components,
+   * src/cost/trotting_configuration_space_cost.cpp:308-376, contact_force_cost.cpp:167-211):
+   * weights on q, v, dv and on the impulse forces.  Only used by horizons with impulse events. */
+  double qi_weight[IDOCP_MAX_NV];
+  double vi_weight[IDOCP_MAX_NV];
+  double dvi_weight[IDOCP_MAX_NV];
+  double fi_weight[IDOCP_MAX_CONTACTS][3];
+  double fi_ref[IDOCP_MAX_CONTACTS][3];
 } idocp_cost_t;
 
 /*
@@ -115,6 +123,8 @@ typedef struct idocp_constraints {
   double mu;                          /* friction coefficient                     */
   double barrier;                     /* default 1.0e-04 */
   double fraction_to_boundary_rate;   /* default 0.995   */
+  int linearized_impulse_friction_cone; /* 0/1: LinearizedImpulseFrictionCone on impulse stages
+                                         * (src/constraints/linearized_impulse_friction_cone.cpp), same mu */
 } idocp_constraints_t;
 
 /* ---- Robot ------------------------------------------------------------ */

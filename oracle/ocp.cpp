@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <stdexcept>
 
 namespace oracle {
@@ -11,7 +12,7 @@ static const int kP = 6;   // kDimFloatingBase
 
 SplitSolutionC::SplitSolutionC(const Robot& r)
     : lmd(r.dimv()), gmm(r.dimv()), q(r.dimq()), v(r.dimv()), a(r.dimv()), u(r.dimu()), beta(r.dimv()), nu_passive(6),
-      f(r.maxPointContacts(), Mat(3)), mu(r.maxPointContacts(), Mat(3)) {
+      xi(3 * r.maxPointContacts()), f(r.maxPointContacts(), Mat(3)), mu(r.maxPointContacts(), Mat(3)) {
   if (r.hasFloatingBase()) q[6] = 1.0;
 }
 Mat SplitSolutionC::f_stack(const ContactStatus& cs) const {
@@ -25,31 +26,101 @@ Mat SplitSolutionC::mu_stack(const ContactStatus& cs) const {
   return o;
 }
 SplitDirectionC::SplitDirectionC(const Robot& r)
-    : dlmd(r.dimv()), dgmm(r.dimv()), du(r.dimu()), dq(r.dimv()), dv(r.dimv()), daf(r.dimv()), dbetamu(r.dimv()), dnu_passive(6) {}
+    : dlmd(r.dimv()), dgmm(r.dimv()), du(r.dimu()), dq(r.dimv()), dv(r.dimv()), daf(r.dimv()), dbetamu(r.dimv()), dnu_passive(6),
+      dxi(0) {}
 SplitKKTMatrixC::SplitKKTMatrixC(int nv_, int nu_)
     : nv(nv_), nu(nu_), Qxx(2 * nv_, 2 * nv_), Qxu_full(2 * nv_, nv_), Quu_full(nv_, nv_), Qaa_diag(nv_), Qff(0, 0),
       Fqq6(6, 6), Fqv6(6, 6), Fvq(nv_, nv_), Fvv(nv_, nv_), Fvu(nv_, nu_), Fqq_prev6(6, 6), Fqq_inv(6, 6), Fqq_prev_inv(6, 6) {}
-SplitKKTResidualC::SplitKKTResidualC(int nv, int nu) : Fq(nv), Fv(nv), lq(nv), lv(nv), la(nv), lf(0), lu(nu), lu_passive(6), Fq_prev(6) {}
+SplitKKTResidualC::SplitKKTResidualC(int nv, int nu)
+    : Fq(nv), Fv(nv), lq(nv), lv(nv), la(nv), lf(0), lu(nu), lu_passive(6), Fq_prev(6), P(0) {}
 
-OCPSolver::OCPSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N)
-    : robot(model), cost(cost_), cons(constraints), s(N + 1, SplitSolutionC(robot)), d(N + 1, SplitDirectionC(robot)),
-      kkt_matrix(N + 1, SplitKKTMatrixC(model.nv, model.nu)), kkt_residual(N + 1, SplitKKTResidualC(model.nv, model.nu)),
-      cd(N), ipm(N), riccati(N + 1, RiccatiC(model.nv)), K(N, Mat(model.nu, 2 * model.nv)), k(N, Mat(model.nu)),
-      N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), T_(T), dt_(T / N) {
-  if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
-  if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
-  if (!robot.hasFloatingBase()) throw std::logic_error("OCPSolver oracle: floating-base robots only");
-  contact_status.active.assign(nc_, false);
-  contact_status.points.assign(nc_, Mat(3));
+int ContactSequenceC::eventOfImpulse(int k) const {
+  for (int e = 0, n = 0; e < numEvents(); ++e) if (is_impulse[e]) { if (n == k) return e; ++n; }
+  return -1;
+}
+int ContactSequenceC::eventOfLift(int k) const {
+  for (int e = 0, n = 0; e < numEvents(); ++e) if (!is_impulse[e]) { if (n == k) return e; ++n; }
+  return -1;
 }
 
-void OCPSolver::setContactStatusUniformly(const std::vector<int>& active, const double* pts) {
-  for (int c = 0; c < nc_; ++c) {
-    contact_status.active[c] = active[c] != 0;
-    for (int k2 = 0; k2 < 3; ++k2) contact_status.points[c][k2] = pts[3 * c + k2];
+OCPSolver::OCPSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N,
+                     int max_num_impulse)
+    : robot(model), cost(cost_), cons(constraints), N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts),
+      max_events_(max_num_impulse), T_(T), dt_(T / N) {
+  if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
+  if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
+  if (max_num_impulse < 0) throw std::out_of_range("invalid value: max_num_impulse must be non-negative!");
+  if (!robot.hasFloatingBase()) throw std::logic_error("OCPSolver oracle: floating-base robots only");
+  const int ns = nslots();
+  s.assign(ns, SplitSolutionC(robot));
+  d.assign(ns, SplitDirectionC(robot));
+  kkt_matrix.assign(ns, SplitKKTMatrixC(model.nv, model.nu));
+  kkt_residual.assign(ns, SplitKKTResidualC(model.nv, model.nu));
+  cd.resize(ns); sw.resize(ns); ipm.resize(ns);
+  riccati.assign(ns, RiccatiC(model.nv));
+  K.assign(ns, Mat(model.nu, 2 * model.nv)); k.assign(ns, Mat(model.nu));
+  ContactStatus cs0;
+  cs0.active.assign(nc_, false);
+  cs0.points.assign(nc_, Mat(3));
+  seq.phases.assign(1, cs0);                       // ContactSequence ctor: default (no contact) status
+  discretize(0.0);
+}
+
+int OCPSolver::slotOf(int kind, int index) const {
+  switch (kind) {
+    case NodeC::Impulse: return N_ideal_ + 1 + index;
+    case NodeC::Aux: return N_ideal_ + 1 + max_events_ + index;
+    case NodeC::Lift: return N_ideal_ + 1 + 2 * max_events_ + index;
+    default: return index;
   }
 }
 
+// ContactSequence::setContactStatusUniformly (contact_sequence.hxx:47-51)
+void OCPSolver::setContactStatusUniformly(const std::vector<int>& active, const double* pts) {
+  ContactStatus cs;
+  cs.active.assign(nc_, false); cs.points.assign(nc_, Mat(3));
+  for (int c = 0; c < nc_; ++c) {
+    cs.active[c] = active[c] != 0;
+    for (int k2 = 0; k2 < 3; ++k2) cs.points[c][k2] = pts[3 * c + k2];
+  }
+  seq.phases.assign(1, cs);
+  seq.event_time.clear(); seq.is_impulse.clear(); seq.impulse_status.clear();
+  discretized_ = false;
+}
+
+// ContactSequence::push_back (contact_sequence.hxx:52-104) + DiscreteEvent::setDiscreteEvent (discrete_event.hxx:57-84)
+void OCPSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, double switching_time) {
+  if (seq.numEvents() + 1 > max_events_) throw std::runtime_error("Number of discrete events exceeds predefined max_num_events!");
+  if (seq.numEvents() > 0 && switching_time <= seq.event_time.back()) throw std::runtime_error("event_time must be larger than the last event time!");
+  const ContactStatus& pre = seq.phases.back();
+  ContactStatus post, imp;
+  post.active.assign(nc_, false); post.points.assign(nc_, Mat(3));
+  imp.active.assign(nc_, false); imp.points.assign(nc_, Mat(3));
+  bool exist_impulse = false, exist_lift = false;
+  for (int c = 0; c < nc_; ++c) {
+    post.active[c] = active[c] != 0;
+    for (int k2 = 0; k2 < 3; ++k2) { post.points[c][k2] = pts[3 * c + k2]; imp.points[c][k2] = pts[3 * c + k2]; }
+    if (pre.active[c]) { if (!post.active[c]) exist_lift = true; }
+    else if (post.active[c]) { imp.active[c] = true; exist_impulse = true; }
+  }
+  if (!exist_impulse && !exist_lift) throw std::runtime_error("discrete_event.existDiscreteEvent() must be true!");
+  seq.phases.push_back(post);
+  seq.event_time.push_back(switching_time);
+  seq.is_impulse.push_back(exist_impulse);
+  seq.impulse_status.push_back(imp);
+  discretized_ = false;
+}
+
+// ContactSequence::setContactPoints (contact_sequence.hxx:252-268)
+void OCPSolver::setContactPoints(int phase, const double* pts) {
+  if (phase >= (int)seq.phases.size()) throw std::runtime_error("contact_phase must be smaller than numContactPhases()!");
+  for (int c = 0; c < nc_; ++c) for (int k2 = 0; k2 < 3; ++k2) {
+    seq.phases[phase].points[c][k2] = pts[3 * c + k2];
+    if (phase > 0 && seq.is_impulse[phase - 1]) seq.impulse_status[phase - 1].points[c][k2] = pts[3 * c + k2];
+  }
+}
+
+// OCPSolver::setSolution (ocp_solver.cpp:95-165): every stage, including the event stages ("a" sets dv on impulse stages)
 void OCPSolver::setSolution(const std::string& name, const Mat& value) {
   for (auto& e : s) {
     if (name == "q") e.q = value;
@@ -61,21 +132,102 @@ void OCPSolver::setSolution(const std::string& name, const Mat& value) {
   }
 }
 
+// ------------------------------------------------------------ discretiser ----
+// OCPDiscretizer::discretizeOCP (ocp_discretizer.hxx:65-374), transcribed step by step.
+void OCPSolver::discretize(double t) {
+  const double min_dt = std::sqrt(std::numeric_limits<double>::epsilon());    // ocp_discretizer.hpp:108-109
+  const double dt_ideal = T_ / N_ideal_, max_dt = dt_ideal - min_dt;
+  const int Ni = seq.numImpulse(), Nl = seq.numLift();
+  std::vector<int> tsbi(Ni + 1, -1), tsbl(Nl + 1, -1);
+  std::vector<double> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
+  // countDiscreteEvents (:271-288)
+  for (int kx = 0; kx < Ni; ++kx) { t_imp[kx] = seq.event_time[seq.eventOfImpulse(kx)]; tsbi[kx] = (int)std::floor((t_imp[kx] - t) / dt_ideal); }
+  for (int kx = 0; kx < Nl; ++kx) { t_lift[kx] = seq.event_time[seq.eventOfLift(kx)]; tsbl[kx] = (int)std::floor((t_lift[kx] - t) / dt_ideal); }
+  // countTimeSteps (:291-345)
+  std::vector<double> dts(N_ideal_ + 1, dt_ideal), ts(N_ideal_ + 1, 0.0);
+  int ii = 0, li = 0, on_grid = 0;
+  for (int i = 0; i < N_ideal_; ++i) {
+    const int stage = i - on_grid;
+    if (ii < Ni && i == tsbi[ii]) {
+      dts[stage] = t_imp[ii] - i * dt_ideal - t;
+      if (dts[stage] <= min_dt) { tsbi[ii] = stage - 1; dt_aux[ii] = dt_ideal; ts[stage] = t + (i - 1) * dt_ideal; ++on_grid; ++ii; }
+      else if (dts[stage] >= max_dt) { tsbi[ii] = i + 1; ts[stage] = t + i * dt_ideal; }
+      else { tsbi[ii] = stage; dt_aux[ii] = dt_ideal - dts[stage]; ts[stage] = t + i * dt_ideal; ++ii; }
+    } else if (li < Nl && i == tsbl[li]) {
+      dts[stage] = t_lift[li] - i * dt_ideal - t;
+      if (dts[stage] <= min_dt) { tsbl[li] = stage - 1; dt_lift[li] = dt_ideal; ts[stage] = t + (i - 1) * dt_ideal; ++on_grid; ++li; }
+      else if (dts[stage] >= max_dt) { tsbl[li] = i + 1; ts[stage] = t + i * dt_ideal; }
+      else { tsbl[li] = stage; dt_lift[li] = dt_ideal - dts[stage]; ts[stage] = t + i * dt_ideal; ++li; }
+    } else {
+      dts[stage] = dt_ideal; ts[stage] = t + i * dt_ideal;
+    }
+  }
+  N_ = N_ideal_ - on_grid;
+  ts[N_] = t + T_;
+  // countTimeStages (:348-391) and countContactPhase (:394-404)
+  std::vector<int> imp_after(N_ + 1, -1), lift_after(N_ + 1, -1), phase(N_ + 1, 0);
+  ii = 0; li = 0;
+  int num_events = 0;
+  for (int i = 0; i < N_; ++i) {
+    if (ii < Ni && i == tsbi[ii]) imp_after[i] = ii++;
+    if (li < Nl && i == tsbl[li]) lift_after[i] = li++;
+    phase[i] = num_events;
+    if (imp_after[i] >= 0 || lift_after[i] >= 0) ++num_events;
+  }
+  phase[N_] = num_events;
+  for (int i = 0; i < N_; ++i) if (imp_after[i] >= 0 && lift_after[i] >= 0) throw std::runtime_error("OCPDiscretizer: not well defined");
+  // the chain
+  chain.clear();
+  auto node = [&](int kind, int index, double tt, double dtt, int ph, int level) {
+    NodeC nd; nd.kind = kind; nd.index = index; nd.slot = slotOf(kind, index); nd.t = tt; nd.dt = dtt; nd.phase = ph; nd.level = level;
+    chain.push_back(nd);
+  };
+  for (int i = 0; i < N_; ++i) {
+    node(NodeC::Stage, i, ts[i], dts[i], phase[i], i);
+    // switching constraint two steps ahead of an impulse (ocp_linearizer.hxx:152-163)
+    if (imp_after[i] < 0 && lift_after[i] < 0 && i + 1 < N_ && imp_after[i + 1] >= 0) {
+      chain.back().sw_event = seq.eventOfImpulse(imp_after[i + 1]);
+      chain.back().sw_dt_next = dts[i + 1];
+    }
+    if (imp_after[i] >= 0) {
+      const int kx = imp_after[i];
+      node(NodeC::Impulse, kx, t_imp[kx], 0.0, seq.eventOfImpulse(kx), -1);
+      node(NodeC::Aux, kx, t_imp[kx], dt_aux[kx], phase[i + 1], 0);
+    } else if (lift_after[i] >= 0) {
+      const int kx = lift_after[i];
+      node(NodeC::Lift, kx, t_lift[kx], dt_lift[kx], phase[i + 1], 0);
+      if (i + 1 < N_ && imp_after[i + 1] >= 0) {            // (:205-217)
+        chain.back().sw_event = seq.eventOfImpulse(imp_after[i + 1]);
+        chain.back().sw_dt_next = dts[i + 1];
+      }
+    }
+  }
+  node(NodeC::Terminal, N_, ts[N_], 0.0, phase[N_], N_);
+  discretized_ = true;
+}
+
+const ContactStatus& OCPSolver::nodeContacts(int p) const {
+  const NodeC& nd = chain[p];
+  return nd.kind == NodeC::Impulse ? seq.impulse_status[nd.phase] : seq.phases[nd.phase];
+}
+
 // ------------------------------------------------------------ constraints ----
-bool OCPSolver::componentEnabled(int c) const {
+bool OCPSolver::componentEnabled(int c, bool impulse) const {
+  if (impulse) return c == 6 && cons.linearized_impulse_friction_cone != 0;
   if (c < 2) return cons.joint_position_limits != 0;
   if (c < 4) return cons.joint_velocity_limits != 0;
   if (c < 6) return cons.joint_torque_limits != 0;
   return cons.linearized_friction_cone != 0;
 }
-bool OCPSolver::componentValid(int c, int stage) const {     // constraints_data.hpp:18-42
-  if (!componentEnabled(c)) return false;
-  if (c < 2) return stage >= 2;
-  if (c < 4) return stage >= 1;
+bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraints_data.hpp:18-42
+  if (nd.kind == NodeC::Impulse) return componentEnabled(c, true);
+  if (!componentEnabled(c, false)) return false;
+  if (c < 2) return nd.level >= 2;
+  if (c < 4) return nd.level >= 1;
   return true;
 }
 int OCPSolver::componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
-int OCPSolver::dimc() const { int n = 0; for (int c = 0; c < 7; ++c) if (componentEnabled(c)) n += componentDim(c); return n; }
+int OCPSolver::dimc() const { int n = 0; for (int c = 0; c < 7; ++c) if (componentEnabled(c, false)) n += componentDim(c); return n; }
 
 static double limitOf(const idocp_model_t& m, int c, int k2) {
   switch (c) {
@@ -104,30 +256,38 @@ static void frictionJac(double mu, double J[5][3]) {        // linearized_fricti
   for (int r = 0; r < 5; ++r) for (int c = 0; c < 3; ++c) J[r][c] = Jc[r][c];
 }
 
-// OCPLinearizer::initConstraints (ocp_linearizer.cpp:40-70) -> SplitOCP::initConstraints
-void OCPSolver::initConstraints(double /*t*/) {
-  for (int i = 0; i < N_; ++i) {
-    ipm[i].clear();
-    for (int c = 0; c < 7; ++c) {
-      IpmData data(componentDim(c));
-      if (componentValid(c, i)) {
-        if (c < 6) {
-          const double sgn = (c & 1) ? 1.0 : -1.0;
-          for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
-        } else {
-          for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
-            double res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
-            for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
-          }
-        }
-        for (int r = 0; r < data.slack.size(); ++r) {
-          while (data.slack[r] < cons.barrier) data.slack[r] += cons.barrier;
-          data.dual[r] = cons.barrier / data.slack[r];
+
+// SplitOCP::initConstraints / ImpulseSplitOCP::initConstraints (split_ocp.hxx:50-55, impulse_split_ocp.hxx:33-37)
+void OCPSolver::initNodeConstraints(const NodeC& nd) {
+  const SplitSolutionC& sp = s[nd.slot];
+  ipm[nd.slot].clear();
+  for (int c = 0; c < 7; ++c) {
+    IpmData data(componentDim(c));
+    if (componentValid(c, nd)) {
+      if (c < 6) {
+        const double sgn = (c & 1) ? 1.0 : -1.0;
+        for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(sp, c, r, nv_, nu_) - limitOf(robot.model(), c, r));
+      } else {
+        for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
+          double res[5]; frictionConeResidual(cons.mu, sp.f[cc], res);
+          for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
         }
       }
-      ipm[i].push_back(data);
+      for (int r = 0; r < data.slack.size(); ++r) {
+        while (data.slack[r] < cons.barrier) data.slack[r] += cons.barrier;
+        data.dual[r] = cons.barrier / data.slack[r];
+      }
     }
+    ipm[nd.slot].push_back(data);
   }
+}
+
+// OCPSolver::initConstraints (ocp_solver.cpp:60-64) -> OCPLinearizer::initConstraints (ocp_linearizer.cpp:40-70)
+void OCPSolver::initConstraints(double t) {
+  discretize(t);
+  // every slot gets constraint data (the reference initialises all N_ideal stages and every event stage in use)
+  for (int i = 0; i <= N_ideal_; ++i) { NodeC nd; nd.kind = i < N_ideal_ ? NodeC::Stage : NodeC::Terminal; nd.slot = i; nd.index = i; nd.level = i; initNodeConstraints(nd); }
+  for (const NodeC& nd : chain) if (nd.kind == NodeC::Impulse || nd.kind == NodeC::Aux || nd.kind == NodeC::Lift) initNodeConstraints(nd);
 }
 
 // ------------------------------------------------------------------ cost ----
@@ -149,49 +309,64 @@ void OCPSolver::qRef(double t, Mat& q_ref) const {
   }
 }
 
+
 // ---------------------------------------------------------------- stages ----
-// SplitOCP::linearizeOCP (split_ocp.hxx:58-91) / computeKKTResidual (:189-214)
-void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual_only) {
-  const SplitSolutionC& si = s[i];
-  const SplitSolutionC& sn = s[i + 1];
-  SplitKKTMatrixC& M = kkt_matrix[i];
-  SplitKKTResidualC& R = kkt_residual[i];
-  ContactDynamicsDataC& D = cd[i];
-  const ContactStatus& cs = contact_status;
+// SplitOCP::linearizeOCP (split_ocp.hxx:58-134) / computeKKTResidual (:189-248) for Stage / Aux / Lift nodes, and
+// ImpulseSplitOCP::linearizeOCP / computeKKTResidual (impulse_split_ocp.hxx:40-66, 107-124) for Impulse nodes.
+// The two are the same computation with (dt_dyn, dt_q) = (dt, dt) vs (1, 0), "a" playing the role of dv, no torque
+// variables on the impulse stage, and the contact VELOCITY constraint instead of the Baumgarte constraint.
+void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
+  const NodeC& nd = chain[p];
+  const bool impulse = nd.kind == NodeC::Impulse;
+  const SplitSolutionC& si = s[nd.slot];
+  const SplitSolutionC& sn = s[chain[p + 1].slot];
+  SplitKKTMatrixC& M = kkt_matrix[nd.slot];
+  SplitKKTResidualC& R = kkt_residual[nd.slot];
+  ContactDynamicsDataC& D = cd[nd.slot];
+  const ContactStatus& cs = nodeContacts(p);
   const int nv = nv_, nu = nu_, dimf = cs.dimf();
-  const double dt = dt_;
-  robot.updateKinematics(si.q, si.v, si.a);
+  const double dt = impulse ? 1.0 : nd.dt;          // scaling of cost / constraints / dynamics multipliers
+  const double dtq = impulse ? 0.0 : nd.dt;         // q+ = q (+) dtq v
+  const double t = nd.t;
+  if (impulse) robot.updateKinematics(si.q, si.v + si.a, Mat(nv));     // impulse_split_ocp.hxx:47
+  else robot.updateKinematics(si.q, si.v, si.a);
   if (!residual_only) {
     M.Qxx.setZero(); M.Qxu_full.setZero(); M.Quu_full.setZero(); M.Qaa_diag.setZero(); M.Qff = Mat(dimf, dimf);
     M.Fvq.setZero(); M.Fvv.setZero(); M.Fvu.setZero();
   }
   R.Fq.setZero(); R.Fv.setZero(); R.lq.setZero(); R.lv.setZero(); R.la.setZero(); R.lf = Mat(dimf); R.lu.setZero(); R.lu_passive.setZero();
+  R.P = Mat(0);
+  const double* wq = impulse ? cost.qi_weight : cost.q_weight;
+  const double* wv = impulse ? cost.vi_weight : cost.v_weight;
+  const double* wa = impulse ? cost.dvi_weight : cost.a_weight;
+  const double (*wf)[3] = impulse ? cost.fi_weight : cost.f_weight;
+  const double (*rf)[3] = impulse ? cost.fi_ref : cost.f_ref;
   // ---- cost: (Trotting)ConfigurationSpaceCost + ContactForceCost
-  // (configuration_space_cost.cpp:292-310, trotting_configuration_space_cost.cpp:269-286, contact_force_cost.cpp:153-165)
+  // (configuration_space_cost.cpp:292-310, trotting_configuration_space_cost.cpp:269-327, contact_force_cost.cpp:153-179)
   Mat q_ref, qdiff, Jq;
   qRef(t, q_ref);
   robot.subtractConfiguration(si.q, q_ref, qdiff);
   robot.dSubtractdConfigurationPlus(si.q, q_ref, Jq);
-  Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.q_weight[r] * qdiff[r];
+  Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = wq[r] * qdiff[r];
   R.lq += dt * (Jq.t() * Wq);
   const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
   for (int r = 0; r < nv; ++r) {
-    R.lv[r] += dt * cost.v_weight[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
-    R.la[r] += dt * cost.a_weight[r] * si.a[r];
+    R.lv[r] += dt * wv[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+    R.la[r] += dt * wa[r] * si.a[r];
   }
-  for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
+  if (!impulse) for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
   {
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
-      for (int r = 0; r < 3; ++r) R.lf[st + r] += dt * cost.f_weight[c][r] * (si.f[c][r] - cost.f_ref[c][r]);
+      for (int r = 0; r < 3; ++r) R.lf[st + r] += dt * wf[c][r] * (si.f[c][r] - rf[c][r]);
       st += 3;
     }
   }
   // ---- constraints: [computePrimalAndDualResidual] + augmentDualResidual
   double Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int c = 0; c < 7; ++c) {
-    if (!componentValid(c, i)) continue;
-    IpmData& data = ipm[i][c];
+    if (!componentValid(c, nd)) continue;
+    IpmData& data = ipm[nd.slot][c];
     if (c < 6) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
       Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
@@ -219,9 +394,10 @@ void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual
       }
     }
   }
-  // ---- state equation: linearizeForwardEuler (state_equation.hxx:12-37, 210-221)
+  // ---- state equation: linearizeForwardEuler (state_equation.hxx:12-37, 210-221) /
+  //      linearizeImpulseForwardEuler (impulse_state_equation.hxx:10-34, 119-128)
   Mat diff; robot.subtractConfiguration(si.q, sn.q, diff);
-  for (int r = 0; r < nv; ++r) { R.Fq[r] = diff[r] + dt * si.v[r]; R.Fv[r] = si.v[r] + dt * si.a[r] - sn.v[r]; }
+  for (int r = 0; r < nv; ++r) { R.Fq[r] = diff[r] + dtq * si.v[r]; R.Fv[r] = si.v[r] + dt * si.a[r] - sn.v[r]; }
   Mat Fqq, Fqq_prev;
   robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq);
   robot.dSubtractdConfigurationMinus(q_prev, si.q, Fqq_prev);
@@ -231,10 +407,10 @@ void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual
     Mat t1 = M.Fqq6.t() * sn.lmd.segment(0, 6) + M.Fqq_prev6.t() * si.lmd.segment(0, 6);
     for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
     for (int r = 6; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
-    for (int r = 0; r < nv; ++r) { R.lv[r] += dt * sn.lmd[r] + sn.gmm[r] - si.gmm[r]; R.la[r] += dt * sn.gmm[r]; }
+    for (int r = 0; r < nv; ++r) { R.lv[r] += dtq * sn.lmd[r] + sn.gmm[r] - si.gmm[r]; R.la[r] += dt * sn.gmm[r]; }
   }
   if (!residual_only) {
-    // condenseForwardEuler (state_equation.hxx:40-63)
+    // condenseForwardEuler (state_equation.hxx:40-63) / condenseImpulseForwardEuler (impulse_state_equation.hxx:36-57)
     Robot::dSubtractdConfigurationInverse(M.Fqq_prev6, M.Fqq_prev_inv);
     Mat Fm; robot.dSubtractdConfigurationMinus(si.q, sn.q, Fm);
     M.Fqq_prev6 = Fm.block(0, 0, 6, 6);
@@ -242,19 +418,28 @@ void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual
     M.Fqq_prev6 = M.Fqq6;
     R.Fq_prev = R.Fq.segment(0, 6);
     M.Fqq6 = -1.0 * (M.Fqq_inv * M.Fqq_prev6);
-    M.Fqv6 = (-dt) * M.Fqq_inv;
+    M.Fqv6 = (-dtq) * M.Fqq_inv;
     R.Fq.setSegment(0, -1.0 * (M.Fqq_inv * R.Fq_prev));
   }
-  // ---- ContactDynamics::linearizeContactDynamics (contact_dynamics.hxx:48-102)
+  // ---- ContactDynamics::linearizeContactDynamics (contact_dynamics.hxx:48-102) /
+  //      ImpulseDynamicsForwardEuler::linearizeImpulseDynamics (impulse_dynamics_forward_euler.hxx:18-58)
   robot.setContactForces(cs.active, si.f);
-  Mat ID_full;
-  robot.RNEA(si.q, si.v, si.a, ID_full);
-  for (int r = 0; r < nu; ++r) ID_full[kP + r] -= si.u[r];
-  Mat dIDdq, dIDdv;
-  robot.RNEADerivatives(si.q, si.v, si.a, dIDdq, dIDdv, D.dIDda);
-  Mat C, dCdq, dCdv;
-  robot.computeBaumgarteResidual(cs.active, dt_, cs.points, C);      // baumgarte_time_step = T/N (hybrid_container.hpp:186-188)
-  robot.computeBaumgarteDerivatives(cs.active, dt_, dCdq, dCdv, D.dCda);
+  Mat ID_full, dIDdq, dIDdv, C, dCdq, dCdv;
+  if (impulse) {
+    const Mat zero(nv);
+    robot.RNEA(si.q, zero, si.a, ID_full, false);                       // RNEAImpulse (robot.hxx:505-517)
+    robot.RNEADerivatives(si.q, zero, si.a, dIDdq, dIDdv, D.dIDda, false);
+    dIDdv = Mat(nv, nv);                                               // dImD/dv = 0 (never formed by the reference)
+    robot.computeImpulseVelocityResidual(cs.active, C);
+    robot.computeImpulseVelocityDerivatives(cs.active, dCdq, dCdv);
+    D.dCda = dCdv;                                                     // dC/ddv = dC/dv (:36-41)
+  } else {
+    robot.RNEA(si.q, si.v, si.a, ID_full);
+    for (int r = 0; r < nu; ++r) ID_full[kP + r] -= si.u[r];
+    robot.RNEADerivatives(si.q, si.v, si.a, dIDdq, dIDdv, D.dIDda);
+    robot.computeBaumgarteResidual(cs.active, dt_, cs.points, C);      // baumgarte_time_step = T/N (hybrid_container.hpp:186-188)
+    robot.computeBaumgarteDerivatives(cs.active, dt_, dCdq, dCdv, D.dCda);
+  }
   D.IDC = Mat(nv + dimf); D.IDC.setSegment(0, ID_full); D.IDC.setSegment(nv, C);
   D.dIDCdqv = Mat(nv + dimf, 2 * nv);
   D.dIDCdqv.setBlock(0, 0, dIDdq); D.dIDCdqv.setBlock(0, nv, dIDdv);
@@ -264,27 +449,54 @@ void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual
   R.la += dt * (D.dIDda.t() * si.beta);
   const Mat mu_stack = si.mu_stack(cs);
   if (dimf > 0) R.lf -= dt * (D.dCda * si.beta);
-  for (int r = 0; r < 6; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
-  for (int r = 0; r < nu; ++r) R.lu[r] -= dt * si.beta[kP + r];
+  if (!impulse) {
+    for (int r = 0; r < 6; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
+    for (int r = 0; r < nu; ++r) R.lu[r] -= dt * si.beta[kP + r];
+  }
   if (dimf > 0) {
     R.lq += dt * (dCdq.t() * mu_stack);
     R.lv += dt * (dCdv.t() * mu_stack);
     R.la += dt * (D.dCda.t() * mu_stack);
   }
+  // ---- ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:27-66)
+  SwitchingC& W = sw[nd.slot];
+  if (nd.sw_event >= 0) {
+    const ContactStatus& is = seq.impulse_status[nd.sw_event];
+    const int dimi = is.dimf();
+    const double dt1 = nd.dt, dt2 = nd.sw_dt_next;
+    Mat dq_ = (dt1 + dt2) * si.v + (dt1 * dt2) * si.a, q_;
+    robot.integrateConfiguration(si.q, dq_, 1.0, q_);
+    robot.updateKinematics(q_, Mat(nv), Mat(nv));
+    robot.computeContactResidual(is.active, is.points, R.P);
+    Mat Pq, dint_dq, dint_dv;
+    robot.computeContactDerivative(is.active, Pq);
+    robot.dIntegratedConfiguration(si.q, dq_, dint_dq);
+    robot.dIntegratedVelocity(si.q, dq_, dint_dv);
+    Mat Phiq = Pq * dint_dq, PqJ = Pq * dint_dv;
+    W.Phix = Mat(dimi, 2 * nv);
+    W.Phix.setBlock(0, 0, Phiq); W.Phix.setBlock(0, nv, (dt1 + dt2) * PqJ);
+    W.Phia = (dt1 * dt2) * PqJ;
+    const Mat xi = si.xi.segment(0, dimi);
+    R.lq += Phiq.t() * xi;
+    R.lv += W.Phix.block(0, nv, dimi, nv).t() * xi;
+    R.la += W.Phia.t() * xi;
+  } else {
+    W = SwitchingC();
+  }
   if (residual_only) return;
-  // ---- cost Hessian (configuration_space_cost.cpp:351-365; contact_force_cost.cpp:182-194)
+  // ---- cost Hessian (configuration_space_cost.cpp:351-365; contact_force_cost.cpp:182-211)
   {
-    Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.q_weight[r];
+    Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= wq[r];
     M.Qxx.addBlock(0, 0, Jq.t() * WJ, dt);
-    for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += dt * cost.v_weight[r]; M.Qaa_diag[r] += dt * cost.a_weight[r]; }
-    for (int r = 0; r < nu; ++r) M.Quu_full(kP + r, kP + r) += dt * cost.u_weight[r];
+    for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += dt * wv[r]; M.Qaa_diag[r] += dt * wa[r]; }
+    if (!impulse) for (int r = 0; r < nu; ++r) M.Quu_full(kP + r, kP + r) += dt * cost.u_weight[r];
     int st = 0;
-    for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += dt * cost.f_weight[c][r]; st += 3; }
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += dt * wf[c][r]; st += 3; }
   }
   // ---- Constraints::condenseSlackAndDual
   for (int c = 0; c < 7; ++c) {
-    if (!componentValid(c, i)) continue;
-    IpmData& data = ipm[i][c];
+    if (!componentValid(c, nd)) continue;
+    IpmData& data = ipm[nd.slot][c];
     if (c < 6) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
       Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
@@ -299,7 +511,7 @@ void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual
         l[off + r] += sgn * dt * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
       }
     } else {
-      // linearized_friction_cone.cpp:125-152, 184-202
+      // linearized_friction_cone.cpp:125-152, 184-202 ; linearized_impulse_friction_cone.cpp (same with dt = 1)
       data.residual.setZero(); data.duality.setZero();
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
@@ -320,48 +532,56 @@ void OCPSolver::linearizeStage(int i, double t, const Mat& q_prev, bool residual
       }
     }
   }
-  // ---- ContactDynamics::condenseContactDynamics (contact_dynamics.hxx:105-158)
+  // ---- ContactDynamics::condenseContactDynamics (contact_dynamics.hxx:105-158) /
+  //      ImpulseDynamicsForwardEuler::condenseImpulseDynamics (impulse_dynamics_forward_euler.hxx:59-105)
   Robot::computeMJtJinv(D.dIDda, D.dCda, D.MJtJinv);
   D.MJtJinv_dIDCdqv = D.MJtJinv * D.dIDCdqv;
   D.MJtJinv_IDC = D.MJtJinv * D.IDC;
   D.Qafqv = Mat(nv + dimf, 2 * nv);
   D.Qafu_full = Mat(nv + dimf, nv);
   for (int c = 0; c < 2 * nv; ++c) for (int r = 0; r < nv; ++r) D.Qafqv(r, c) = -M.Qaa_diag[r] * D.MJtJinv_dIDCdqv(r, c);
-  for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) D.Qafu_full(r, c) = M.Qaa_diag[r] * D.MJtJinv(r, c);
+  if (!impulse) for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) D.Qafu_full(r, c) = M.Qaa_diag[r] * D.MJtJinv(r, c);
   if (dimf > 0) {
     D.Qafqv.setBlock(nv, 0, -1.0 * (M.Qff * D.MJtJinv_dIDCdqv.block(nv, 0, dimf, 2 * nv)));
-    D.Qafu_full.setBlock(nv, 0, M.Qff * D.MJtJinv.block(nv, 0, dimf, nv));
+    if (!impulse) D.Qafu_full.setBlock(nv, 0, M.Qff * D.MJtJinv.block(nv, 0, dimf, nv));
   }
   D.laf = Mat(nv + dimf);
   for (int r = 0; r < nv; ++r) D.laf[r] = R.la[r] - M.Qaa_diag[r] * D.MJtJinv_IDC[r];
   if (dimf > 0) D.laf.setSegment(nv, -1.0 * R.lf - M.Qff * D.MJtJinv_IDC.segment(nv, dimf));
   M.Qxx -= D.MJtJinv_dIDCdqv.t() * D.Qafqv;
-  M.Qxu_full -= D.MJtJinv_dIDCdqv.t() * D.Qafu_full;
   {
     Mat lx = D.MJtJinv_dIDCdqv.t() * D.laf;
     for (int r = 0; r < nv; ++r) { R.lq[r] -= lx[r]; R.lv[r] -= lx[nv + r]; }
   }
-  M.Quu_full += D.MJtJinv.block(0, 0, nv, nv + dimf) * D.Qafu_full;
-  {
+  if (!impulse) {
+    M.Qxu_full -= D.MJtJinv_dIDCdqv.t() * D.Qafu_full;
+    M.Quu_full += D.MJtJinv.block(0, 0, nv, nv + dimf) * D.Qafu_full;
     Mat t1 = D.MJtJinv.block(0, 0, nv, nv + dimf) * D.laf;
     for (int r = 0; r < 6; ++r) R.lu_passive[r] += t1[r];
     for (int r = 0; r < nu; ++r) R.lu[r] += t1[kP + r];
+    M.Fvu = dt * D.MJtJinv.block(0, kP, nv, nu);
   }
   M.Fvq = (-dt) * D.MJtJinv_dIDCdqv.block(0, 0, nv, nv);
   M.Fvv = (-dt) * D.MJtJinv_dIDCdqv.block(0, nv, nv, nv) + Mat::Identity(nv);
-  M.Fvu = dt * D.MJtJinv.block(0, kP, nv, nu);
   for (int r = 0; r < nv; ++r) R.Fv[r] -= dt * D.MJtJinv_IDC[r];
+  // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199)
+  if (nd.sw_event >= 0) {
+    W.Phix -= W.Phia * D.MJtJinv_dIDCdqv.block(0, 0, nv, 2 * nv);
+    W.Phiu = W.Phia * D.MJtJinv.block(0, kP, nv, nu);
+    R.P -= W.Phia * D.MJtJinv_IDC.segment(0, nv);
+  }
 }
 
 // TerminalOCP::linearizeOCP / computeKKTResidual (terminal_ocp.hxx:50-66, 118-131)
-void OCPSolver::linearizeTerminal(double t, const Mat& q_prev, bool residual_only) {
-  const SplitSolutionC& sN = s[N_];
-  SplitKKTMatrixC& M = kkt_matrix[N_];
-  SplitKKTResidualC& R = kkt_residual[N_];
+void OCPSolver::linearizeTerminal(int p, const Mat& q_prev, bool residual_only) {
+  const NodeC& nd = chain[p];
+  const SplitSolutionC& sN = s[nd.slot];
+  SplitKKTMatrixC& M = kkt_matrix[nd.slot];
+  SplitKKTResidualC& R = kkt_residual[nd.slot];
   const int nv = nv_;
   R.lq.setZero(); R.lv.setZero();
   Mat q_ref, qdiff, Jq;
-  qRef(t, q_ref);
+  qRef(nd.t, q_ref);
   robot.subtractConfiguration(sN.q, q_ref, qdiff);
   robot.dSubtractdConfigurationPlus(sN.q, q_ref, Jq);
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.qf_weight[r] * qdiff[r];
@@ -383,133 +603,207 @@ void OCPSolver::linearizeTerminal(double t, const Mat& q_prev, bool residual_onl
   for (int r = 0; r < nv; ++r) M.Qxx(nv + r, nv + r) += cost.vf_weight[r];
 }
 
+// OCPLinearizer::runParallel (ocp_linearizer.hxx:113-228); q_prev (:231-248) is the chain predecessor's q
 void OCPSolver::linearizeOCP(double t, const Mat& q) {
-  for (int i = 0; i <= N_; ++i) {
-    const Mat& q_prev = (i == 0) ? q : s[i - 1].q;                      // ocp_linearizer.hxx:231-248
-    if (i < N_) linearizeStage(i, t + i * dt_, q_prev, false);
-    else linearizeTerminal(t + T_, q_prev, false);
+  discretize(t);
+  for (int p = 0; p < M(); ++p) {
+    const Mat& q_prev = (p == 0) ? q : s[chain[p - 1].slot].q;
+    if (p < M() - 1) linearizeNode(p, q_prev, false);
+    else linearizeTerminal(p, q_prev, false);
   }
 }
 
 void OCPSolver::computeKKTResidual(double t, const Mat& q, const Mat& /*v*/) {
-  for (int i = 0; i <= N_; ++i) {
-    const Mat& q_prev = (i == 0) ? q : s[i - 1].q;
-    if (i < N_) linearizeStage(i, t + i * dt_, q_prev, true);
-    else linearizeTerminal(t + T_, q_prev, true);
+  discretize(t);
+  for (int p = 0; p < M(); ++p) {
+    const Mat& q_prev = (p == 0) ? q : s[chain[p - 1].slot].q;
+    if (p < M() - 1) linearizeNode(p, q_prev, true);
+    else linearizeTerminal(p, q_prev, true);
   }
 }
 
-// OCPLinearizer::KKTError (ocp_linearizer.cpp:98-137); SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267)
+// OCPLinearizer::KKTError (ocp_linearizer.cpp:98-137); SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267);
+// ImpulseSplitOCP::squaredNormKKTResidual (impulse_split_ocp.hxx:127-137)
 double OCPSolver::KKTError() {
   double sum = 0;
-  for (int i = 0; i < N_; ++i) {
-    const SplitKKTResidualC& R = kkt_residual[i];
+  for (int p = 0; p < M() - 1; ++p) {
+    const NodeC& nd = chain[p];
+    const SplitKKTResidualC& R = kkt_residual[nd.slot];
+    const double dt = nd.kind == NodeC::Impulse ? 1.0 : nd.dt;
     double e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
-               R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt_ * dt_ * cd[i].IDC.squaredNorm();
+               R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt * dt * cd[nd.slot].IDC.squaredNorm();
     double c2 = 0;
-    for (int c = 0; c < 7; ++c) if (componentValid(c, i)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
-    sum += e + dt_ * dt_ * c2;
+    for (int c = 0; c < 7; ++c) if (componentValid(c, nd)) c2 += ipm[nd.slot][c].residual.squaredNorm() + ipm[nd.slot][c].duality.squaredNorm();
+    sum += e + dt * dt * c2 + R.P.squaredNorm();
   }
-  sum += kkt_residual[N_].lq.squaredNorm() + kkt_residual[N_].lv.squaredNorm();
+  const SplitKKTResidualC& RN = kkt_residual[chain.back().slot];
+  sum += RN.lq.squaredNorm() + RN.lv.squaredNorm();
   return std::sqrt(sum);
 }
 
 // ---------------------------------------------------------------- Riccati ----
-// RiccatiRecursionSolver::backwardRiccatiRecursion without events (riccati_recursion_solver.cpp:48-107)
+// RiccatiRecursionSolver::backwardRiccatiRecursion (riccati_recursion_solver.cpp:48-107): a walk down the chain.
+// Stage / Aux / Lift: SplitRiccatiFactorizer::backwardRiccatiRecursion (split_riccati_factorizer.hxx:24-101), with the
+// Schur-complement variant on stages that carry a switching constraint.  Impulse:
+// ImpulseSplitRiccatiFactorizer::backwardRiccatiRecursion (impulse_backward_riccati_recursion_factorizer.hxx:30-107) --
+// the same recursion with Fqv = 0 and no control.
 void OCPSolver::backwardRiccatiRecursion() {
   const int nv = nv_, nu = nu_, nj = nv - 6;
-  const double dt = dt_;
-  riccati[N_].Pqq = kkt_matrix[N_].Qxx.block(0, 0, nv, nv);
-  riccati[N_].Pvv = kkt_matrix[N_].Qxx.block(nv, nv, nv, nv);
-  riccati[N_].Pqv = Mat(nv, nv);
-  riccati[N_].sq = -kkt_residual[N_].lq;
-  riccati[N_].sv = -kkt_residual[N_].lv;
-  for (int i = N_ - 1; i >= 0; --i) {
-    const RiccatiC& rn = riccati[i + 1];
-    SplitKKTMatrixC& M = kkt_matrix[i];
-    SplitKKTResidualC& R = kkt_residual[i];
+  {
+    const int sl = chain.back().slot;
+    riccati[sl].Pqq = kkt_matrix[sl].Qxx.block(0, 0, nv, nv);
+    riccati[sl].Pvv = kkt_matrix[sl].Qxx.block(nv, nv, nv, nv);
+    riccati[sl].Pqv = Mat(nv, nv);
+    riccati[sl].sq = -kkt_residual[sl].lq;
+    riccati[sl].sv = -kkt_residual[sl].lv;
+  }
+  for (int p = M() - 2; p >= 0; --p) {
+    const NodeC& nd = chain[p];
+    const bool impulse = nd.kind == NodeC::Impulse;
+    const double dt = impulse ? 0.0 : nd.dt;
+    const int sl = nd.slot;
+    const RiccatiC& rn = riccati[chain[p + 1].slot];
+    SplitKKTMatrixC& Mx = kkt_matrix[sl];
+    SplitKKTResidualC& R = kkt_residual[sl];
     // BackwardRiccatiRecursionFactorizer::factorizeKKTMatrix (backward_riccati_recursion_factorizer.hxx:44-114)
     Mat AtPqq(nv, nv), AtPqv(nv, nv), AtPvq(nv, nv), AtPvv(nv, nv);
-    AtPqq.setBlock(0, 0, M.Fqq6.t() * rn.Pqq.block(0, 0, 6, nv)); AtPqq.setBlock(6, 0, rn.Pqq.block(6, 0, nj, nv));
-    AtPqv.setBlock(0, 0, M.Fqq6.t() * rn.Pqv.block(0, 0, 6, nv)); AtPqv.setBlock(6, 0, rn.Pqv.block(6, 0, nj, nv));
-    AtPvq.setBlock(0, 0, M.Fqv6.t() * rn.Pqq.block(0, 0, 6, nv)); AtPvq.setBlock(6, 0, dt * rn.Pqq.block(6, 0, nj, nv));
-    AtPvv.setBlock(0, 0, M.Fqv6.t() * rn.Pqv.block(0, 0, 6, nv)); AtPvv.setBlock(6, 0, dt * rn.Pqv.block(6, 0, nj, nv));
-    AtPqq += M.Fvq.t() * rn.Pqv.t();
-    AtPqv += M.Fvq.t() * rn.Pvv;
-    AtPvq += M.Fvv.t() * rn.Pqv.t();
-    AtPvv += M.Fvv.t() * rn.Pvv;
-    Mat BtPq = M.Fvu.t() * rn.Pqv.t();
-    Mat BtPv = M.Fvu.t() * rn.Pvv;
-    Mat Qqq = M.Qxx.block(0, 0, nv, nv), Qqv = M.Qxx.block(0, nv, nv, nv), Qvv = M.Qxx.block(nv, nv, nv, nv);
-    Qqq.addBlock(0, 0, AtPqq.block(0, 0, nv, 6) * M.Fqq6); Qqq.addBlock(0, 6, AtPqq.block(0, 6, nv, nj));
-    Qqv.addBlock(0, 0, AtPqq.block(0, 0, nv, 6) * M.Fqv6); Qqv.addBlock(0, 6, AtPqq.block(0, 6, nv, nj), dt);
-    Qvv.addBlock(0, 0, AtPvq.block(0, 0, nv, 6) * M.Fqv6); Qvv.addBlock(0, 6, AtPvq.block(0, 6, nv, nj), dt);
-    Qqq += AtPqv * M.Fvq;
-    Qqv += AtPqv * M.Fvv;
-    Qvv += AtPvv * M.Fvv;
-    M.Qxx.setBlock(0, 0, Qqq); M.Qxx.setBlock(0, nv, Qqv); M.Qxx.setBlock(nv, nv, Qvv); M.Qxx.setBlock(nv, 0, Qqv.t());
-    Mat Qqu = M.Qxu_full.block(0, kP, nv, nu), Qvu = M.Qxu_full.block(nv, kP, nv, nu);
-    Qqu += AtPqv * M.Fvu;
-    Qvu += AtPvv * M.Fvu;
-    M.Qxu_full.setBlock(0, kP, Qqu); M.Qxu_full.setBlock(nv, kP, Qvu);
-    Mat Quu = M.Quu_full.block(kP, kP, nu, nu);
-    Quu += BtPv * M.Fvu;
-    M.Quu_full.setBlock(kP, kP, Quu);
-    R.lu += BtPq * R.Fq;
-    R.lu += BtPv * R.Fv;
-    R.lu -= M.Fvu.t() * rn.sv;
-    // SplitRiccatiFactorizer::backwardRiccatiRecursion (split_riccati_factorizer.hxx:36-52)
-    LLT llt;
-    if (!llt.compute(Quu)) throw std::runtime_error("Riccati: Quu not positive definite at stage " + std::to_string(i));
-    Mat Qxu(2 * nv, nu); Qxu.setBlock(0, 0, Qqu); Qxu.setBlock(nv, 0, Qvu);
-    K[i] = -llt.solve(Qxu.t());
-    k[i] = -llt.solve(R.lu);
-    // factorizeRiccatiFactorization (backward_riccati_recursion_factorizer.hxx:117-161)
-    RiccatiC& r = riccati[i];
-    r.Pqq = Qqq; r.Pqv = Qqv; r.Pvv = Qvv;
-    Mat GK = Quu * K[i];
-    Mat Kq = K[i].block(0, 0, nu, nv), Kv = K[i].block(0, nv, nu, nv);
-    r.Pqq -= Kq.t() * GK.block(0, 0, nu, nv);
-    r.Pqv -= Kq.t() * GK.block(0, nv, nu, nv);
-    r.Pvv -= Kv.t() * GK.block(0, nv, nu, nv);
+    AtPqq.setBlock(0, 0, Mx.Fqq6.t() * rn.Pqq.block(0, 0, 6, nv)); AtPqq.setBlock(6, 0, rn.Pqq.block(6, 0, nj, nv));
+    AtPqv.setBlock(0, 0, Mx.Fqq6.t() * rn.Pqv.block(0, 0, 6, nv)); AtPqv.setBlock(6, 0, rn.Pqv.block(6, 0, nj, nv));
+    if (!impulse) {
+      AtPvq.setBlock(0, 0, Mx.Fqv6.t() * rn.Pqq.block(0, 0, 6, nv)); AtPvq.setBlock(6, 0, dt * rn.Pqq.block(6, 0, nj, nv));
+      AtPvv.setBlock(0, 0, Mx.Fqv6.t() * rn.Pqv.block(0, 0, 6, nv)); AtPvv.setBlock(6, 0, dt * rn.Pqv.block(6, 0, nj, nv));
+    }
+    AtPqq += Mx.Fvq.t() * rn.Pqv.t();
+    AtPqv += Mx.Fvq.t() * rn.Pvv;
+    AtPvq += Mx.Fvv.t() * rn.Pqv.t();
+    AtPvv += Mx.Fvv.t() * rn.Pvv;
+    Mat Qqq = Mx.Qxx.block(0, 0, nv, nv), Qqv = Mx.Qxx.block(0, nv, nv, nv), Qvv = Mx.Qxx.block(nv, nv, nv, nv);
+    Qqq.addBlock(0, 0, AtPqq.block(0, 0, nv, 6) * Mx.Fqq6); Qqq.addBlock(0, 6, AtPqq.block(0, 6, nv, nj));
+    if (!impulse) {
+      Qqv.addBlock(0, 0, AtPqq.block(0, 0, nv, 6) * Mx.Fqv6); Qqv.addBlock(0, 6, AtPqq.block(0, 6, nv, nj), dt);
+      Qvv.addBlock(0, 0, AtPvq.block(0, 0, nv, 6) * Mx.Fqv6); Qvv.addBlock(0, 6, AtPvq.block(0, 6, nv, nj), dt);
+    }
+    Qqq += AtPqv * Mx.Fvq;
+    Qqv += AtPqv * Mx.Fvv;
+    Qvv += AtPvv * Mx.Fvv;
+    Mx.Qxx.setBlock(0, 0, Qqq); Mx.Qxx.setBlock(0, nv, Qqv); Mx.Qxx.setBlock(nv, nv, Qvv); Mx.Qxx.setBlock(nv, 0, Qqv.t());
+    RiccatiC& r = riccati[sl];
+    Mat Qqu(nv, nu), Qvu(nv, nu);
+    if (impulse) {
+      K[sl].setZero(); k[sl].setZero();
+      r.Pqq = Qqq; r.Pqv = Qqv; r.Pvv = Qvv;
+    } else {
+      Mat BtPq = Mx.Fvu.t() * rn.Pqv.t();
+      Mat BtPv = Mx.Fvu.t() * rn.Pvv;
+      Qqu = Mx.Qxu_full.block(0, kP, nv, nu); Qvu = Mx.Qxu_full.block(nv, kP, nv, nu);
+      Qqu += AtPqv * Mx.Fvu;
+      Qvu += AtPvv * Mx.Fvu;
+      Mx.Qxu_full.setBlock(0, kP, Qqu); Mx.Qxu_full.setBlock(nv, kP, Qvu);
+      Mat Quu = Mx.Quu_full.block(kP, kP, nu, nu);
+      Quu += BtPv * Mx.Fvu;
+      Mx.Quu_full.setBlock(kP, kP, Quu);
+      R.lu += BtPq * R.Fq;
+      R.lu += BtPv * R.Fv;
+      R.lu -= Mx.Fvu.t() * rn.sv;
+      LLT llt;
+      if (!llt.compute(Quu)) throw std::runtime_error("Riccati: Quu not positive definite at chain position " + std::to_string(p));
+      Mat Qxu(2 * nv, nu); Qxu.setBlock(0, 0, Qqu); Qxu.setBlock(nv, 0, Qvu);
+      SwitchingC& W = sw[sl];
+      Mat DtM, KtDtM;
+      if (nd.sw_event < 0) {
+        // split_riccati_factorizer.hxx:24-41
+        K[sl] = -llt.solve(Qxu.t());
+        k[sl] = -llt.solve(R.lu);
+      } else {
+        // Schur complement w.r.t. the switching constraint (:43-101)
+        Mat Ginv = llt.solve(Mat::Identity(nu));
+        Mat DGinv = llt.solve(W.Phiu.t()).t();
+        Mat S = DGinv * W.Phiu.t();
+        LLT llt_s;
+        if (!llt_s.compute(S)) throw std::runtime_error("Riccati: switching-constraint Schur complement not positive definite");
+        Mat SinvDGinv = llt_s.solve(DGinv);
+        Ginv -= SinvDGinv.t() * DGinv;
+        K[sl] = -1.0 * (Ginv * Qxu.t());
+        K[sl] -= SinvDGinv.t() * W.Phix;
+        k[sl] = -1.0 * (Ginv * R.lu);
+        k[sl] -= SinvDGinv.t() * R.P;
+        W.M = llt_s.solve(W.Phix);
+        W.M -= SinvDGinv * Qxu.t();
+        W.m = llt_s.solve(R.P);
+        W.m -= SinvDGinv * R.lu;
+        DtM = W.Phiu.t() * W.M;
+        KtDtM = K[sl].t() * DtM;
+      }
+      // factorizeRiccatiFactorization (backward_riccati_recursion_factorizer.hxx:117-161)
+      r.Pqq = Qqq; r.Pqv = Qqv; r.Pvv = Qvv;
+      Mat GK = Quu * K[sl];
+      Mat Kq = K[sl].block(0, 0, nu, nv), Kv = K[sl].block(0, nv, nu, nv);
+      r.Pqq -= Kq.t() * GK.block(0, 0, nu, nv);
+      r.Pqv -= Kq.t() * GK.block(0, nv, nu, nv);
+      r.Pvv -= Kv.t() * GK.block(0, nv, nu, nv);
+    }
     r.Pqq = 0.5 * (r.Pqq + r.Pqq.t());
     r.Pvv = 0.5 * (r.Pvv + r.Pvv.t());
     r.sq = Mat(nv); r.sv = Mat(nv);
-    r.sq.setSegment(0, M.Fqq6.t() * rn.sq.segment(0, 6)); r.sq.setSegment(6, rn.sq.segment(6, nj));
-    r.sv.setSegment(0, M.Fqv6.t() * rn.sq.segment(0, 6)); r.sv.setSegment(6, dt * rn.sq.segment(6, nj));
-    r.sq += M.Fvq.t() * rn.sv;
-    r.sv += M.Fvv.t() * rn.sv;
+    r.sq.setSegment(0, Mx.Fqq6.t() * rn.sq.segment(0, 6)); r.sq.setSegment(6, rn.sq.segment(6, nj));
+    if (!impulse) { r.sv.setSegment(0, Mx.Fqv6.t() * rn.sq.segment(0, 6)); r.sv.setSegment(6, dt * rn.sq.segment(6, nj)); }
+    r.sq += Mx.Fvq.t() * rn.sv;
+    r.sv += Mx.Fvv.t() * rn.sv;
     r.sq -= AtPqq * R.Fq;
     r.sq -= AtPqv * R.Fv;
     r.sv -= AtPvq * R.Fq;
     r.sv -= AtPvv * R.Fv;
     r.sq -= R.lq;
     r.sv -= R.lv;
-    r.sq -= Qqu * k[i];
-    r.sv -= Qvu * k[i];
+    if (!impulse) {
+      r.sq -= Qqu * k[sl];
+      r.sv -= Qvu * k[sl];
+      if (nd.sw_event >= 0) {
+        // split_riccati_factorizer.hxx:88-100
+        SwitchingC& W = sw[sl];
+        Mat DtM = W.Phiu.t() * W.M;
+        Mat KtDtM = K[sl].t() * DtM;
+        r.Pqq -= KtDtM.block(0, 0, nv, nv);
+        r.Pqq -= KtDtM.block(0, 0, nv, nv).t();
+        r.Pqv -= KtDtM.block(0, nv, nv, nv);
+        r.Pqv -= KtDtM.block(nv, 0, nv, nv).t();
+        r.Pvv -= KtDtM.block(nv, nv, nv, nv);
+        r.Pvv -= KtDtM.block(nv, nv, nv, nv).t();
+        r.sq -= W.Phix.block(0, 0, W.Phix.r, nv).t() * W.m;
+        r.sv -= W.Phix.block(0, nv, W.Phix.r, nv).t() * W.m;
+      }
+    }
   }
 }
 
 // computeInitialStateDirection + forwardRiccatiRecursion (riccati_recursion_solver.cpp:110-162;
-// split_riccati_factorizer.hxx:103-128)
+// split_riccati_factorizer.hxx:103-128; impulse_split_riccati_factorizer.hxx:27-44)
 void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
   const int nv = nv_, nj = nv - 6;
-  robot.subtractConfiguration(q, s[0].q, d[0].dq);
-  d[0].dq.setSegment(0, -1.0 * (kkt_matrix[0].Fqq_prev_inv * d[0].dq.segment(0, 6)));
-  d[0].dv = v - s[0].v;
-  for (int i = 0; i < N_; ++i) {
-    const SplitKKTMatrixC& M = kkt_matrix[i];
-    const SplitKKTResidualC& R = kkt_residual[i];
-    Mat dx(2 * nv); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
-    d[i].du = K[i] * dx + k[i];
+  {
+    const int s0 = chain[0].slot;
+    robot.subtractConfiguration(q, s[s0].q, d[s0].dq);
+    d[s0].dq.setSegment(0, -1.0 * (kkt_matrix[s0].Fqq_prev_inv * d[s0].dq.segment(0, 6)));
+    d[s0].dv = v - s[s0].v;
+  }
+  for (int p = 0; p < M() - 1; ++p) {
+    const NodeC& nd = chain[p];
+    const int sl = nd.slot, sn = chain[p + 1].slot;
+    const bool impulse = nd.kind == NodeC::Impulse;
+    const double dt = impulse ? 0.0 : nd.dt;
+    const SplitKKTMatrixC& Mx = kkt_matrix[sl];
+    const SplitKKTResidualC& R = kkt_residual[sl];
+    Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
+    if (impulse) d[sl].du.setZero(); else d[sl].du = K[sl] * dx + k[sl];
     Mat dqn = R.Fq, dvn = R.Fv;
-    Mat h = M.Fqq6 * d[i].dq.segment(0, 6) + M.Fqv6 * d[i].dv.segment(0, 6);
+    Mat h = Mx.Fqq6 * d[sl].dq.segment(0, 6);
+    if (!impulse) h += Mx.Fqv6 * d[sl].dv.segment(0, 6);
     for (int r = 0; r < 6; ++r) dqn[r] += h[r];
-    for (int r = 0; r < nj; ++r) dqn[6 + r] += d[i].dq[6 + r] + dt_ * d[i].dv[6 + r];
-    dvn += M.Fvq * d[i].dq;
-    dvn += M.Fvv * d[i].dv;
-    dvn += M.Fvu * d[i].du;
-    d[i + 1].dq = dqn; d[i + 1].dv = dvn;
+    for (int r = 0; r < nj; ++r) dqn[6 + r] += d[sl].dq[6 + r] + dt * d[sl].dv[6 + r];
+    dvn += Mx.Fvq * d[sl].dq;
+    dvn += Mx.Fvv * d[sl].dv;
+    if (!impulse) dvn += Mx.Fvu * d[sl].du;
+    d[sn].dq = dqn; d[sn].dv = dvn;
   }
 }
 
@@ -522,42 +816,50 @@ static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {
   return m;
 }
 
+
 // RiccatiRecursionSolver::computeDirection (riccati_recursion_solver.cpp:165-251)
 void OCPSolver::computeDirection() {
   const int nv = nv_, nu = nu_;
   double pmin = 1, dmin = 1;
   double Jc[5][3]; frictionJac(cons.mu, Jc);
-  for (int i = 0; i <= N_; ++i) {
-    const RiccatiC& r = riccati[i];
-    d[i].dlmd = r.Pqq * d[i].dq + r.Pqv * d[i].dv - r.sq;
-    d[i].dgmm = r.Pqv.t() * d[i].dq + r.Pvv * d[i].dv - r.sv;
-    if (i == N_) continue;
-    const ContactDynamicsDataC& D = cd[i];
-    const int dimf = contact_status.dimf();
-    // ContactDynamics::computeCondensedPrimalDirection (contact_dynamics.hxx:161-168)
-    Mat dx(2 * nv); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
-    d[i].daf = -1.0 * (D.MJtJinv_dIDCdqv * dx);
-    d[i].daf += D.MJtJinv.block(0, kP, nv + dimf, nu) * d[i].du;
-    d[i].daf -= D.MJtJinv_IDC;
-    for (int r2 = 0; r2 < dimf; ++r2) d[i].daf[nv + r2] *= -1;
+  for (int p = 0; p < M(); ++p) {
+    const NodeC& nd = chain[p];
+    const int sl = nd.slot;
+    const RiccatiC& r = riccati[sl];
+    d[sl].dlmd = r.Pqq * d[sl].dq + r.Pqv * d[sl].dv - r.sq;
+    d[sl].dgmm = r.Pqv.t() * d[sl].dq + r.Pvv * d[sl].dv - r.sv;
+    if (nd.kind == NodeC::Terminal) continue;
+    const bool impulse = nd.kind == NodeC::Impulse;
+    const ContactDynamicsDataC& D = cd[sl];
+    const ContactStatus& cs = nodeContacts(p);
+    const int dimf = cs.dimf();
+    // ContactDynamics::computeCondensedPrimalDirection (contact_dynamics.hxx:161-168) /
+    // ImpulseDynamicsForwardEuler::expansionPrimal (impulse_dynamics_forward_euler.hxx:119-125)
+    Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
+    d[sl].daf = -1.0 * (D.MJtJinv_dIDCdqv * dx);
+    if (!impulse) d[sl].daf += D.MJtJinv.block(0, kP, nv + dimf, nu) * d[sl].du;
+    d[sl].daf -= D.MJtJinv_IDC;
+    for (int r2 = 0; r2 < dimf; ++r2) d[sl].daf[nv + r2] *= -1;
+    // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145)
+    if (nd.sw_event >= 0) d[sl].dxi = sw[sl].M * dx + sw[sl].m; else d[sl].dxi = Mat(0);
     // Constraints::computeSlackAndDualDirection + step sizes
     for (int c = 0; c < 7; ++c) {
-      if (!componentValid(c, i)) continue;
-      IpmData& data = ipm[i][c];
+      if (!componentValid(c, nd)) continue;
+      IpmData& data = ipm[sl][c];
       if (c < 6) {
         const double sgn = (c & 1) ? 1.0 : -1.0;
         for (int r2 = 0; r2 < nu; ++r2) {
-          const double dxr = c < 2 ? d[i].dq[kP + r2] : (c < 4 ? d[i].dv[kP + r2] : d[i].du[r2]);
+          const double dxr = c < 2 ? d[sl].dq[kP + r2] : (c < 4 ? d[sl].dv[kP + r2] : d[sl].du[r2]);
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
       } else {
         for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }   // linearized_friction_cone.cpp:162-163
         int st = 0;
-        for (int cc = 0; cc < nc_; ++cc) if (contact_status.active[cc]) {
+        for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           for (int r2 = 0; r2 < 5; ++r2) {
             const int idx = 5 * cc + r2;
-            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[i].daf[nv + st + x];
+            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[sl].daf[nv + st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
           }
@@ -574,48 +876,62 @@ void OCPSolver::computeDirection() {
 // OCPLinearizer::integrateSolution (ocp_linearizer.cpp:140-221)
 void OCPSolver::integrateSolution() {
   const int nv = nv_, nu = nu_;
-  const double ap = primal_step_size, ad = dual_step_size, dt = dt_;
-  for (int i = 0; i <= N_; ++i) {
-    SplitKKTMatrixC& M = kkt_matrix[i];
-    if (i < N_) {
-      ContactDynamicsDataC& D = cd[i];
-      SplitKKTResidualC& R = kkt_residual[i];
-      const int dimf = contact_status.dimf();
-      Mat dx(2 * nv); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
-      const Mat& dgmm = d[i + 1].dgmm;
-      // ContactDynamics::computeCondensedDualDirection (contact_dynamics.hxx:171-190)
-      d[i].dnu_passive = R.lu_passive;
-      d[i].dnu_passive += M.Quu_full.block(0, kP, 6, nu) * d[i].du;
-      d[i].dnu_passive += M.Qxu_full.block(0, 0, 2 * nv, 6).t() * dx;
-      d[i].dnu_passive += dt * (D.MJtJinv.block(0, 0, 6, nv) * dgmm);
-      d[i].dnu_passive = (-1.0 / dt) * d[i].dnu_passive;
+  const double ap = primal_step_size, ad = dual_step_size;
+  for (int p = 0; p < M(); ++p) {
+    const NodeC& nd = chain[p];
+    const int sl = nd.slot;
+    SplitKKTMatrixC& Mx = kkt_matrix[sl];
+    const bool terminal = nd.kind == NodeC::Terminal, impulse = nd.kind == NodeC::Impulse;
+    const ContactStatus& cs = nodeContacts(p);
+    if (!terminal) {
+      ContactDynamicsDataC& D = cd[sl];
+      SplitKKTResidualC& R = kkt_residual[sl];
+      const double dt = impulse ? 1.0 : nd.dt;
+      const int dimf = cs.dimf();
+      Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
+      const Mat& dgmm = d[chain[p + 1].slot].dgmm;
+      // ContactDynamics::computeCondensedDualDirection (contact_dynamics.hxx:171-190) /
+      // ImpulseDynamicsForwardEuler::expansionDual (impulse_dynamics_forward_euler.hxx:127-137)
+      if (!impulse) {
+        d[sl].dnu_passive = R.lu_passive;
+        d[sl].dnu_passive += Mx.Quu_full.block(0, kP, 6, nu) * d[sl].du;
+        d[sl].dnu_passive += Mx.Qxu_full.block(0, 0, 2 * nv, 6).t() * dx;
+        d[sl].dnu_passive += dt * (D.MJtJinv.block(0, 0, 6, nv) * dgmm);
+        d[sl].dnu_passive = (-1.0 / dt) * d[sl].dnu_passive;
+      } else {
+        d[sl].dnu_passive.setZero();
+      }
       D.laf += D.Qafqv * dx;
-      D.laf += D.Qafu_full.block(0, kP, nv + dimf, nu) * d[i].du;
+      if (!impulse) D.laf += D.Qafu_full.block(0, kP, nv + dimf, nu) * d[sl].du;
       for (int r = 0; r < nv; ++r) D.laf[r] += dt * dgmm[r];
-      d[i].dbetamu = (-1.0 / dt) * (D.MJtJinv * D.laf);
+      d[sl].dbetamu = (-1.0 / dt) * (D.MJtJinv * D.laf);
     }
     // stateequation::correctCostateDirectionForwardEuler (state_equation.hxx:96-108)
-    d[i].dlmd.setSegment(0, -1.0 * (M.Fqq_prev_inv.t() * d[i].dlmd.segment(0, 6)));
-    // SplitOCP::updatePrimal / TerminalOCP::updatePrimal -> SplitSolution::integrate (split_solution.hxx:215-240)
-    SplitSolutionC& si = s[i];
-    si.lmd += ap * d[i].dlmd;
-    si.gmm += ap * d[i].dgmm;
-    Mat qn; robot.integrateConfiguration(si.q, d[i].dq, ap, qn); si.q = qn;
-    si.v += ap * d[i].dv;
-    if (i == N_) continue;
-    si.a += ap * d[i].daf.segment(0, nv);
-    si.u += ap * d[i].du;
-    si.beta += ap * d[i].dbetamu.segment(0, nv);
-    si.nu_passive += ap * d[i].dnu_passive;
+    d[sl].dlmd.setSegment(0, -1.0 * (Mx.Fqq_prev_inv.t() * d[sl].dlmd.segment(0, 6)));
+    // SplitOCP / ImpulseSplitOCP / TerminalOCP::updatePrimal -> (Impulse)SplitSolution::integrate
+    // (split_solution.hxx:215-240, impulse_split_solution.hxx:188-203)
+    SplitSolutionC& si = s[sl];
+    si.lmd += ap * d[sl].dlmd;
+    si.gmm += ap * d[sl].dgmm;
+    Mat qn; robot.integrateConfiguration(si.q, d[sl].dq, ap, qn); si.q = qn;
+    si.v += ap * d[sl].dv;
+    if (terminal) continue;
+    si.a += ap * d[sl].daf.segment(0, nv);
+    si.beta += ap * d[sl].dbetamu.segment(0, nv);
+    if (!impulse) {
+      si.u += ap * d[sl].du;
+      si.nu_passive += ap * d[sl].dnu_passive;
+    }
     int st = 0;
-    for (int c = 0; c < nc_; ++c) if (contact_status.active[c]) {
-      for (int r = 0; r < 3; ++r) { si.f[c][r] += ap * d[i].daf[nv + st + r]; si.mu[c][r] += ap * d[i].dbetamu[nv + st + r]; }
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
+      for (int r = 0; r < 3; ++r) { si.f[c][r] += ap * d[sl].daf[nv + st + r]; si.mu[c][r] += ap * d[sl].dbetamu[nv + st + r]; }
       st += 3;
     }
+    if (nd.sw_event >= 0) for (int r = 0; r < d[sl].dxi.size(); ++r) si.xi[r] += ap * d[sl].dxi[r];
     for (int c = 0; c < 7; ++c) {
-      if (!componentValid(c, i)) continue;
-      ipm[i][c].slack += ap * ipm[i][c].dslack;
-      ipm[i][c].dual += ad * ipm[i][c].ddual;
+      if (!componentValid(c, nd)) continue;
+      ipm[sl][c].slack += ap * ipm[sl][c].dslack;
+      ipm[sl][c].dual += ad * ipm[sl][c].ddual;
     }
   }
 }

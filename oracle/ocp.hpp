@@ -1,11 +1,20 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
-// CPU restatement of the contact-capable half of the idocp hot path for a
-// horizon WITHOUT discrete events (uniform contact status): SplitOCP /
-// TerminalOCP / ContactDynamics / state equation with floating base /
-// SplitRiccatiFactorizer / RiccatiRecursionSolver / OCPLinearizer / OCPSolver.
-// Impulse, aux and lift stages and the switching constraint are not restated
-// yet.  Every function cites the reference lines it follows.
+// CPU restatement of the contact-capable half of the idocp hot path, including
+// horizons with discrete events: SplitOCP / ImpulseSplitOCP / TerminalOCP,
+// ContactDynamics / ImpulseDynamicsForwardEuler, the state equations with a
+// floating base, ForwardSwitchingConstraint, the (constrained) Riccati
+// factorizers, RiccatiRecursionSolver, OCPLinearizer, ContactSequence,
+// OCPDiscretizer and OCPSolver.  Every function cites the reference lines it follows.
+//
+// Storage: like the reference (hybrid_container.hpp:60-168) every stage owns a fixed
+// SLOT -- grid stage i -> i, impulse k -> N+1+k, aux k -> N+1+E+k, lift k -> N+1+2E+k
+// (E = max number of events) -- so nothing moves when the discretisation changes.
+// The discretiser produces the CHAIN: the slots in time order
+//   stage, [impulse, aux | lift], stage, ..., terminal.
+// Every neighbour relation of the reference (q_prev, s_next, d_next, riccati_next;
+// ocp_linearizer.hxx:113-248, riccati_recursion_solver.cpp:48-162) is the chain
+// predecessor / successor.  The HIP path uses the same slots and the same chain.
 #ifndef ORACLE_OCP_HPP_
 #define ORACLE_OCP_HPP_
 
@@ -18,7 +27,7 @@
 
 namespace oracle {
 
-// include/idocp/robot/contact_status.hxx
+// include/idocp/robot/contact_status.hxx, impulse_status.hxx: a set of active point contacts + their world points
 struct ContactStatus {
   std::vector<bool> active;
   std::vector<Mat> points;       // world contact points
@@ -26,9 +35,35 @@ struct ContactStatus {
   bool hasActiveContacts() const { return dimf() > 0; }
 };
 
-// include/idocp/ocp/split_solution.hxx:10-31
+// include/idocp/hybrid/contact_sequence.hxx:56-333
+struct ContactSequenceC {
+  std::vector<ContactStatus> phases;           // contact_statuses_
+  std::vector<double> event_time;              // one per discrete event
+  std::vector<bool> is_impulse;                // DiscreteEvent::existImpulse (discrete_event.hxx:57-84)
+  std::vector<ContactStatus> impulse_status;   // per EVENT (only meaningful where is_impulse)
+  int numEvents() const { return (int)event_time.size(); }
+  int numImpulse() const { int n = 0; for (bool b : is_impulse) n += b ? 1 : 0; return n; }
+  int numLift() const { return numEvents() - numImpulse(); }
+  int eventOfImpulse(int k) const;             // event index of the k-th impulse
+  int eventOfLift(int k) const;
+};
+
+// One stage of the chain.
+struct NodeC {
+  enum Kind { Stage = 0, Impulse = 1, Aux = 2, Lift = 3, Terminal = 4 };
+  int kind = Stage;
+  int slot = 0;           // storage slot of this stage
+  int index = 0;          // grid stage (Stage / Terminal), impulse index (Impulse / Aux), lift index (Lift)
+  double t = 0, dt = 0;   // dt = 0 for Impulse / Terminal
+  int phase = 0;          // contact phase (Stage / Aux / Lift); for Impulse: the event index
+  int level = 0;          // time step handed to Constraints::createConstraintsData: grid stage, 0 (aux, lift), -1 (impulse)
+  int sw_event = -1;      // event index of the impulse whose switching constraint sits on this stage (or -1)
+  double sw_dt_next = 0;  // dt of the stage between this one and the impulse
+};
+
+// include/idocp/ocp/split_solution.hxx:10-31, impulse/impulse_split_solution.hxx (a = dv on impulse stages)
 struct SplitSolutionC {
-  Mat lmd, gmm, q, v, a, u, beta, nu_passive;
+  Mat lmd, gmm, q, v, a, u, beta, nu_passive, xi;
   std::vector<Mat> f, mu;        // per contact (3)
   explicit SplitSolutionC(const Robot& r);
   Mat f_stack(const ContactStatus& cs) const;
@@ -37,7 +72,7 @@ struct SplitSolutionC {
 
 // include/idocp/ocp/split_direction.hxx:8-23
 struct SplitDirectionC {
-  Mat dlmd, dgmm, du, dq, dv, daf, dbetamu, dnu_passive;
+  Mat dlmd, dgmm, du, dq, dv, daf, dbetamu, dnu_passive, dxi;
   explicit SplitDirectionC(const Robot& r);
 };
 
@@ -47,7 +82,7 @@ struct IpmData {                  // ConstraintComponentData
 };
 
 // SplitKKTMatrix / SplitKKTResidual (include/idocp/ocp/split_kkt_matrix.hxx:11-30,75-497;
-// split_kkt_residual.hxx:10-26) with the blocks kept as separate matrices.
+// split_kkt_residual.hxx:10-26; impulse twins) with the blocks kept as separate matrices.
 struct SplitKKTMatrixC {
   int nv, nu;
   Mat Qxx, Qxu_full, Quu_full;    // (2nv x 2nv), (2nv x nv), (nv x nv); u_full = [passive(6) ; u]
@@ -58,13 +93,20 @@ struct SplitKKTMatrixC {
   SplitKKTMatrixC(int nv_, int nu_);
 };
 struct SplitKKTResidualC {
-  Mat Fq, Fv, lq, lv, la, lf, lu, lu_passive, Fq_prev;
+  Mat Fq, Fv, lq, lv, la, lf, lu, lu_passive, Fq_prev, P;
   explicit SplitKKTResidualC(int nv, int nu);
 };
 
-// ContactDynamicsData (include/idocp/ocp/contact_dynamics_data.hxx)
+// ContactDynamicsData / ImpulseDynamicsForwardEulerData (include/idocp/ocp/contact_dynamics_data.hxx)
 struct ContactDynamicsDataC {
   Mat dIDda, dCda, dIDCdqv, MJtJinv, MJtJinv_dIDCdqv, Qafqv, Qafu_full, IDC, MJtJinv_IDC, laf;
+};
+
+// SplitStateConstraintJacobian + SplitConstrainedRiccatiFactorization
+// (split_state_constraint_jacobian.hxx, split_constrained_riccati_factorization.hxx)
+struct SwitchingC {
+  Mat Phix, Phia, Phiu;          // dimi x 2nv, dimi x nv, dimi x nu
+  Mat M, m;                      // dxi = M dx + m
 };
 
 struct RiccatiC {
@@ -74,33 +116,45 @@ struct RiccatiC {
 
 class OCPSolver {
  public:
-  OCPSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N);
-  void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points /*[nc][3]*/);
+  OCPSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N,
+            int max_num_impulse = 0);
+  void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points /*[nc][3]*/);   // ocp_solver.cpp:169-171
+  void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, double switching_time);   // :174-177
+  void setContactPoints(int contact_phase, const double* contact_points);                                     // :180-184
   void setSolution(const std::string& name, const Mat& value);      // ocp_solver.cpp:95-165
   void initConstraints(double t);                                   // ocp_solver.cpp:60-64
   void updateSolution(double t, const Mat& q, const Mat& v);         // ocp_solver.cpp:67-92
   void computeKKTResidual(double t, const Mat& q, const Mat& v);     // ocp_solver.cpp:202-207
   double KKTError();                                                 // ocp_linearizer.cpp:98-137
 
+  void discretize(double t);                                         // OCPDiscretizer::discretizeOCP (ocp_discretizer.hxx:65-374)
   void linearizeOCP(double t, const Mat& q);                         // K5
   void backwardRiccatiRecursion();                                   // S3
   void forwardRiccatiRecursion(const Mat& q, const Mat& v);          // S4 (+ initial state direction)
   void computeDirection();                                           // K6
   void integrateSolution();                                          // K7
 
-  int N() const { return N_; }
+  int N() const { return N_; }                 // grid stages after discretisation (N_ideal minus events on the grid)
+  int M() const { return (int)chain.size(); }  // chain length = N + 1 + 2 N_impulse + N_lift
   double stepDt() const { return dt_; }
   int dimc() const;
+  const ContactStatus& nodeContacts(int p) const;     // contact (or impulse) status a node is linearised with
   Robot robot;
   idocp_cost_t cost;
   idocp_constraints_t cons;
-  ContactStatus contact_status;
+  ContactSequenceC seq;
+  std::vector<NodeC> chain;
+  int slotOf(int kind, int index) const;
+  int posOfSlot(int slot) const { for (int p = 0; p < (int)chain.size(); ++p) if (chain[p].slot == slot) return p; return -1; }
+  int nslots() const { return N_ideal_ + 1 + 3 * max_events_; }
+  // all per-stage arrays are indexed by SLOT; chain[p].slot maps a chain position to it
   std::vector<SplitSolutionC> s;
   std::vector<SplitDirectionC> d;
   std::vector<SplitKKTMatrixC> kkt_matrix;
   std::vector<SplitKKTResidualC> kkt_residual;
   std::vector<ContactDynamicsDataC> cd;
-  std::vector<std::vector<IpmData>> ipm;    // [stage][component]
+  std::vector<SwitchingC> sw;
+  std::vector<std::vector<IpmData>> ipm;    // [node][component]
   std::vector<RiccatiC> riccati;
   std::vector<Mat> K, k;
   double primal_step_size = 1, dual_step_size = 1;
@@ -108,14 +162,16 @@ class OCPSolver {
   void qRef(double t, Mat& q_ref) const;                              // trotting_configuration_space_cost.hpp:126-164
 
  private:
-  int N_, nv_, nu_, nc_;
+  int N_ideal_, N_, nv_, nu_, nc_, max_events_;
   double T_, dt_;
-  // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone
-  bool componentEnabled(int c) const;
-  bool componentValid(int c, int stage) const;
+  bool discretized_ = false;
+  // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone (impulse cone on impulse stages)
+  bool componentEnabled(int c, bool impulse) const;
+  bool componentValid(int c, const NodeC& nd) const;
   int componentDim(int c) const;
-  void linearizeStage(int i, double t, const Mat& q_prev, bool residual_only);
-  void linearizeTerminal(double t, const Mat& q_prev, bool residual_only);
+  void initNodeConstraints(const NodeC& nd);
+  void linearizeNode(int p, const Mat& q_prev, bool residual_only);
+  void linearizeTerminal(int p, const Mat& q_prev, bool residual_only);
 };
 
 }  // namespace oracle

@@ -250,6 +250,38 @@ extern "C" {
 void* oracle_ocp_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
   try { return new OCPSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
 }
+// OCPSolver(robot, cost, constraints, T, N, max_num_impulse, nthreads) (ocp_solver.cpp:10-47)
+void* oracle_ocp_create_hybrid(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N,
+                               int max_num_impulse) {
+  try { return new OCPSolver(*m, *c, *k, T, N, max_num_impulse); } catch (...) { return nullptr; }
+}
+// OCPSolver::pushBackContactStatus / setContactPoints (ocp_solver.cpp:174-184)
+int oracle_ocp_push_back_contact_status(void* h, const int* active, const double* points, double switching_time) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  std::vector<int> a(active, active + s->robot.maxPointContacts());
+  try { s->pushBackContactStatus(a, points, switching_time); } catch (...) { return -1; }
+  return 0;
+}
+int oracle_ocp_set_contact_points(void* h, int phase, const double* points) {
+  try { static_cast<OCPSolver*>(h)->setContactPoints(phase, points); } catch (...) { return -1; }
+  return 0;
+}
+// the chain produced by the last discretisation: returns its length M; arrays (may be NULL) of length M
+int oracle_ocp_chain(void* h, double t, int* kind, int* index, int* slot, double* tt, double* dt, int* sw_event, int* dimf) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  s->discretize(t);
+  for (int p = 0; p < s->M(); ++p) {
+    const NodeC& nd = s->chain[p];
+    if (kind) kind[p] = nd.kind;
+    if (index) index[p] = nd.index;
+    if (slot) slot[p] = nd.slot;
+    if (tt) tt[p] = nd.t;
+    if (dt) dt[p] = nd.dt;
+    if (sw_event) sw_event[p] = nd.sw_event;
+    if (dimf) dimf[p] = nd.kind == NodeC::Terminal ? 0 : s->nodeContacts(p).dimf();
+  }
+  return s->M();
+}
 void oracle_ocp_destroy(void* h) { delete static_cast<OCPSolver*>(h); }
 int oracle_ocp_set_contact_status(void* h, const int* active, const double* points) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
@@ -293,31 +325,68 @@ double oracle_ocp_kkt_error(void* h) { return static_cast<OCPSolver*>(h)->KKTErr
 // field of every stage, padded to `stride` doubles per stage: out[(N+1)][stride].
 // solution names: q v a u f lmd gmm beta mu nu_passive ; direction names: dq dv da df du dlmd dgmm dbeta dmu dnu_passive
 // f / mu / df / dmu are reported per contact slot ([nc][3], inactive slots 0 for directions).
+static int ocpGetOne(OCPSolver* s, const std::string& n, int p, int stride, double* o) {
+  const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
+  const NodeC& nd = s->chain[p];
+  const bool terminal = nd.kind == NodeC::Terminal;
+  const SplitSolutionC& x = s->s[nd.slot];
+  const SplitDirectionC& d = s->d[nd.slot];
+  auto put = [&](const Mat& m) { for (int k = 0; k < m.size() && k < stride; ++k) o[k] = m[k]; };
+  auto putSlots = [&](const Mat& stack, int off) {   // stacked active rows -> contact slots
+    const ContactStatus& cs = s->nodeContacts(p);
+    int st = 0;
+    for (int c = 0; c < nc; ++c) if (cs.active[c]) { for (int k = 0; k < 3; ++k) o[3 * c + k] = stack[off + st + k]; st += 3; }
+  };
+  if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a); else if (n == "u") put(x.u);
+  else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
+  else if (n == "nu_passive") put(x.nu_passive);
+  else if (n == "xi") put(x.xi);
+  else if (n == "f") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.f[c][k]; }
+  else if (n == "mu") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.mu[c][k]; }
+  else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv); else if (n == "du") put(d.du);
+  else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm); else if (n == "dnu_passive") put(d.dnu_passive);
+  else if (n == "dxi") put(d.dxi);
+  else if (n == "da") { if (!terminal) put(d.daf.segment(0, nv)); }
+  else if (n == "dbeta") { if (!terminal) put(d.dbetamu.segment(0, nv)); }
+  else if (n == "df") { if (!terminal) putSlots(d.daf, nv); }
+  else if (n == "dmu") { if (!terminal) putSlots(d.dbetamu, nv); }
+  else return -1;
+  return 0;
+}
 int oracle_ocp_get(void* h, const char* name, int stride, double* out) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   const std::string n(name);
-  const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
   for (int i = 0; i <= s->N(); ++i) {
-    double* o = out + (size_t)i * stride;
-    const SplitSolutionC& x = s->s[i];
-    const SplitDirectionC& d = s->d[i];
-    auto put = [&](const Mat& m) { for (int k = 0; k < m.size() && k < stride; ++k) o[k] = m[k]; };
-    auto putSlots = [&](const Mat& stack, int off) {   // stacked active rows -> contact slots
-      int st = 0;
-      for (int c = 0; c < nc; ++c) if (s->contact_status.active[c]) { for (int k = 0; k < 3; ++k) o[3 * c + k] = stack[off + st + k]; st += 3; }
-    };
-    if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a); else if (n == "u") put(x.u);
-    else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
-    else if (n == "nu_passive") put(x.nu_passive);
-    else if (n == "f") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.f[c][k]; }
-    else if (n == "mu") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.mu[c][k]; }
-    else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv); else if (n == "du") put(d.du);
-    else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm); else if (n == "dnu_passive") put(d.dnu_passive);
-    else if (n == "da") { if (i < s->N()) put(d.daf.segment(0, nv)); }
-    else if (n == "dbeta") { if (i < s->N()) put(d.dbetamu.segment(0, nv)); }
-    else if (n == "df") { if (i < s->N()) putSlots(d.daf, nv); }
-    else if (n == "dmu") { if (i < s->N()) putSlots(d.dbetamu, nv); }
-    else return -1;
+    const int p = s->posOfSlot(i);
+    if (p < 0) return -1;
+    if (ocpGetOne(s, n, p, stride, out + (size_t)i * stride) != 0) return -1;
+  }
+  return 0;
+}
+// the same fields for every stage of the chain, in chain order: out[M][stride]
+int oracle_ocp_get_chain(void* h, const char* name, int stride, double* out) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const std::string n(name);
+  for (int p = 0; p < s->M(); ++p) if (ocpGetOne(s, n, p, stride, out + (size_t)p * stride) != 0) return -1;
+  return 0;
+}
+// Riccati factorisation along the chain: P[M][2nv*2nv], s[M][2nv], K[M-1][nu*2nv], k[M-1][nu]
+int oracle_ocp_get_riccati_chain(void* h, double* P, double* sv, double* K, double* k) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const int nv = s->robot.dimv(), nx = 2 * nv, nu = s->robot.dimu();
+  for (int p = 0; p < s->M(); ++p) {
+    const int sl = s->chain[p].slot;
+    const RiccatiC& r = s->riccati[sl];
+    if (P) {
+      Mat Pm(nx, nx);
+      Pm.setBlock(0, 0, r.Pqq); Pm.setBlock(0, nv, r.Pqv); Pm.setBlock(nv, 0, r.Pqv.t()); Pm.setBlock(nv, nv, r.Pvv);
+      std::memcpy(P + (size_t)p * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
+    }
+    if (sv) { std::memcpy(sv + (size_t)p * nx, r.sq.d.data(), sizeof(double) * nv); std::memcpy(sv + (size_t)p * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
+    if (p < s->M() - 1) {
+      if (K) std::memcpy(K + (size_t)p * nu * nx, s->K[sl].d.data(), sizeof(double) * nu * nx);
+      if (k) std::memcpy(k + (size_t)p * nu, s->k[sl].d.data(), sizeof(double) * nu);
+    }
   }
   return 0;
 }
@@ -385,7 +454,9 @@ int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Q
   // (backward_riccati_recursion_factorizer.hxx:66-71, 96-100)
   Mat Fqq = Mat::Identity(nv);
   Fqq.setBlock(0, 0, M.Fqq6);
-  Mat Fqv_full = s->stepDt() * Mat::Identity(nv);
+  const int pos = s->posOfSlot(i);
+  const double dt_node = (pos >= 0 && s->chain[pos].kind != NodeC::Impulse) ? s->chain[pos].dt : 0.0;
+  Mat Fqv_full = dt_node * Mat::Identity(nv);
   Fqv_full.setBlock(0, 0, M.Fqv6);
   Am.setBlock(0, 0, Fqq); Am.setBlock(0, nv, Fqv_full); Am.setBlock(nv, 0, M.Fvq); Am.setBlock(nv, nv, M.Fvv);
   Bm.setBlock(nv, 0, M.Fvu);

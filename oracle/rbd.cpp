@@ -429,6 +429,63 @@ void Robot::computeBaumgarteDerivatives(const std::vector<bool>& active, double 
   }
 }
 
+void Robot::computeImpulseVelocityResidual(const std::vector<bool>& active, Mat& C) const {
+  int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
+  C = Mat(3 * na);
+  int row = 0;
+  for (int c = 0; c < m_.ncontacts; ++c) {
+    if (!active[c]) continue;
+    double v[6];
+    contactFrame(c, nullptr, nullptr, v, nullptr);
+    for (int k = 0; k < 3; ++k) C[row + k] = v[k];
+    row += 3;
+  }
+}
+
+void Robot::computeImpulseVelocityDerivatives(const std::vector<bool>& active, Mat& dCdq, Mat& dCdv) const {
+  const int nv = m_.nv;
+  int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
+  dCdq = Mat(3 * na, nv); dCdv = Mat(3 * na, nv);
+  int row = 0;
+  for (int c = 0; c < m_.ncontacts; ++c) {
+    if (!active[c]) continue;
+    Mat vdq, adq, adv, J;
+    frameDerivatives(c, vdq, adq, adv, J);
+    for (int col = 0; col < nv; ++col) for (int r = 0; r < 3; ++r) { dCdq(row + r, col) = vdq(r, col); dCdv(row + r, col) = J(r, col); }
+    row += 3;
+  }
+}
+
+void Robot::computeContactResidual(const std::vector<bool>& active, const std::vector<Mat>& contact_points, Mat& P) const {
+  int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
+  P = Mat(3 * na);
+  int row = 0;
+  for (int c = 0; c < m_.ncontacts; ++c) {
+    if (!active[c]) continue;
+    double p[3];
+    contactFrame(c, p, nullptr, nullptr, nullptr);
+    for (int k = 0; k < 3; ++k) P[row + k] = p[k] - contact_points[c][k];
+    row += 3;
+  }
+}
+
+void Robot::computeContactDerivative(const std::vector<bool>& active, Mat& Pq) const {
+  const int nv = m_.nv;
+  int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
+  Pq = Mat(3 * na, nv);
+  int row = 0;
+  for (int c = 0; c < m_.ncontacts; ++c) {
+    if (!active[c]) continue;
+    Mat vdq, adq, adv, J;
+    frameDerivatives(c, vdq, adq, adv, J);
+    double R[9];
+    contactFrame(c, nullptr, R, nullptr, nullptr);
+    for (int col = 0; col < nv; ++col)
+      for (int r = 0; r < 3; ++r) { double acc = 0; for (int k = 0; k < 3; ++k) acc += R[3 * r + k] * J(k, col); Pq(row + r, col) = acc; }
+    row += 3;
+  }
+}
+
 void Robot::computeMJtJinv(const Mat& M, const Mat& J, Mat& out) {
   // robot.hxx:576-615.  pinocchio's sparse U D U^T factorisation of M is replaced
   // by a dense Cholesky (same solution); the block algebra follows the reference.
@@ -597,6 +654,42 @@ void Robot::dSubtractdConfigurationMinus(const Mat& q_plus, const Mat& q_minus, 
     Mat Ad(6, 6);
     for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) { Ad(r, s) = Rt[3 * r + s]; Ad(3 + r, 3 + s) = Rt[3 * r + s]; Ad(r, 3 + s) = KRt[3 * r + s]; }
     J.setBlock(m_.idx_v[i], m_.idx_v[i], -1.0 * (J6 * Ad));
+  }
+}
+
+// exp6(v) of the free-flyer tangent v = (lin, ang): (R, p) = (exp3(w), V(w) lin)
+static void exp6(const double* v6, double* R, double* p) {
+  double V[9];
+  exp3(v6 + 3, R); Vmat(v6 + 3, V); matvec3(V, v6, p);
+}
+
+// pinocchio::dIntegrate(q, v, ARG0): SpecialEuclideanOperation<3>::dIntegrate_dq_impl = exp6(v).toActionMatrixInverse()
+void Robot::dIntegratedConfiguration(const Mat& /*q*/, const Mat& v, Mat& J) const {
+  J = Mat::Identity(m_.nv);
+  for (int i = 0; i < m_.njoints; ++i) {
+    if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
+    double R[9], p[3], Rt[9], mp[3], K[9], KRt[9];
+    exp6(&v.d[m_.idx_v[i]], R, p);
+    for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
+    matvec3(Rt, p, mp); for (int k = 0; k < 3; ++k) mp[k] = -mp[k];
+    skew(mp, K); matmul3(K, Rt, KRt);
+    Mat Ad(6, 6);
+    for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) { Ad(r, s) = Rt[3 * r + s]; Ad(3 + r, 3 + s) = Rt[3 * r + s]; Ad(r, 3 + s) = KRt[3 * r + s]; }
+    J.setBlock(m_.idx_v[i], m_.idx_v[i], Ad);
+  }
+}
+
+// pinocchio::dIntegrate(q, v, ARG1): dIntegrate_dv_impl = Jexp6(v) = Jlog6(exp6(v))^-1
+void Robot::dIntegratedVelocity(const Mat& /*q*/, const Mat& v, Mat& J) const {
+  J = Mat::Identity(m_.nv);
+  for (int i = 0; i < m_.njoints; ++i) {
+    if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
+    double R[9], p[3];
+    exp6(&v.d[m_.idx_v[i]], R, p);
+    Mat Jl, Je;
+    Jlog6(R, p, Jl);
+    dSubtractdConfigurationInverse(Jl, Je);       // Jlog6 is block upper-triangular [A B; 0 A]
+    J.setBlock(m_.idx_v[i], m_.idx_v[i], Je);
   }
 }
 

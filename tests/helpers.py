@@ -255,11 +255,38 @@ def anymal_problem(model, trotting_ref=True):
         cost.t_start, cost.t_period, cost.step_length = 0.5, 0.5, 0.15
         cost.front_swing_knee, cost.hip_swing_knee = 1.7, 1.7
         cost.front_stance_knee, cost.hip_stance_knee = 0.0, 0.0
+    # impulse-stage weights of the same example (:74-82, :93): qi = q, vi = v, dvi = a, fi = f weights
+    cost.set("qi_weight", np.full(nv, 10.0)).set("vi_weight", vw).set("dvi_weight", aw)
+    for c in range(4):
+        for k in range(3):
+            cost.fi_weight[c][k] = 0.001
+            cost.fi_ref[c][k] = 0.0
     cons = capi.Constraints()
     capi.lib().idocp_constraints_init(C.byref(cons))
     cons.linearized_friction_cone = 1
+    cons.linearized_impulse_friction_cone = 1
     cons.mu = 0.7
     return cost, cons
+
+
+def trotting_sequence(solver, model, num_impulse_phases, t_start=0.5, t_period=0.5, step_length=0.15):
+    """Contact sequence of examples/anymal/anymal_trotting.cpp:141-177, transcribed as data: all feet ->
+    {LH, RF} at t_start -> {LF, RH} at t_start + t_period -> ... (feet advance by step_length)."""
+    pts = anymal_contact_points(model).copy()
+    solver.set_contact_status([1, 1, 1, 1], pts)
+    solver.push_back_contact_status([0, 1, 1, 0], pts, t_start)
+    pts[0, 0] += 0.5 * step_length
+    pts[3, 0] += 0.5 * step_length
+    solver.push_back_contact_status([1, 0, 0, 1], pts, t_start + t_period)
+    for i in range(2, num_impulse_phases + 1):
+        if i % 2 == 0:
+            pts[1, 0] += step_length
+            pts[2, 0] += step_length
+            solver.push_back_contact_status([0, 1, 1, 0], pts, t_start + i * t_period)
+        else:
+            pts[0, 0] += step_length
+            pts[3, 0] += step_length
+            solver.push_back_contact_status([1, 0, 0, 1], pts, t_start + i * t_period)
 
 
 def _setup_oracle_ocp(lib):
@@ -286,6 +313,14 @@ def _setup_oracle_ocp(lib):
     lib.oracle_ocp_get_lqr_stage.argtypes = [vp, ci] + [dp] * 8
     lib.oracle_ocp_bench.argtypes = [vp, cd, dp, dp, ci, dp]
     lib.oracle_ocp_bench.restype = cd
+    lib.oracle_ocp_create_hybrid.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci, ci]
+    lib.oracle_ocp_create_hybrid.restype = vp
+    lib.oracle_ocp_push_back_contact_status.argtypes = [vp, C.POINTER(ci), dp, cd]
+    lib.oracle_ocp_set_contact_points.argtypes = [vp, ci, dp]
+    ip = C.POINTER(ci)
+    lib.oracle_ocp_chain.argtypes = [vp, cd, ip, ip, ip, dp, dp, ip, ip]
+    lib.oracle_ocp_get_chain.argtypes = [vp, cs, ci, dp]
+    lib.oracle_ocp_get_riccati_chain.argtypes = [vp, dp, dp, dp, dp]
     lib._ocp_ready = True
 
 
@@ -295,13 +330,52 @@ OCP_DIR_FIELDS = {"dq": 18, "dv": 18, "da": 18, "du": 12, "df": 12, "dlmd": 18, 
 OCP_STAGE_ONLY = ("a", "u", "f", "beta", "mu", "nu_passive", "da", "du", "df", "dbeta", "dmu", "dnu_passive")
 
 
+OCP_CHAIN_EXTRA = {"xi": 12, "dxi": 12}
+NODE_KINDS = ("stage", "impulse", "aux", "lift", "terminal")
+
+
 class OracleOCP:
-    def __init__(self, model, cost, cons, T, N):
+    def __init__(self, model, cost, cons, T, N, max_num_impulse=0):
         self.lib = oracle()
         _setup_oracle_ocp(self.lib)
         self.N, self.nv, self.nu, self.nq = N, model.nv, model.nu, model.nq
-        self.h = self.lib.oracle_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
+        self.max_events = max_num_impulse
+        if max_num_impulse > 0:
+            self.h = self.lib.oracle_ocp_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse)
+        else:
+            self.h = self.lib.oracle_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
         assert self.h
+
+    # ---- contact sequences with discrete events (OCPSolver::pushBackContactStatus, ocp_solver.cpp:174-184)
+    def push_back_contact_status(self, active, points, switching_time):
+        a = (C.c_int * 4)(*[int(x) for x in active])
+        assert self.lib.oracle_ocp_push_back_contact_status(self.h, a, P(arr(points)), switching_time) == 0
+
+    def set_contact_points(self, phase, points):
+        assert self.lib.oracle_ocp_set_contact_points(self.h, phase, P(arr(points))) == 0
+
+    def chain(self, t):
+        """Stages in time order after OCPDiscretizer::discretizeOCP(t): list of dicts."""
+        cap = self.N + 1 + 3 * max(self.max_events, 1)
+        IA = lambda: (C.c_int * cap)()
+        kind, index, slot, sw, dimf = IA(), IA(), IA(), IA(), IA()
+        tt, dt = np.zeros(cap), np.zeros(cap)
+        M = self.lib.oracle_ocp_chain(self.h, t, kind, index, slot, P(tt), P(dt), sw, dimf)
+        return [dict(kind=NODE_KINDS[kind[p]], index=index[p], slot=slot[p], t=tt[p], dt=dt[p], sw_event=sw[p], dimf=dimf[p])
+                for p in range(M)]
+
+    def get_chain(self, name, M):
+        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or OCP_CHAIN_EXTRA[name]
+        out = np.zeros((M, dim))
+        assert self.lib.oracle_ocp_get_chain(self.h, name.encode(), dim, P(out)) == 0
+        return out
+
+    def riccati_chain(self, M):
+        nv, nu = self.nv, self.nu
+        Pm, s = np.zeros((M, 2 * nv, 2 * nv)), np.zeros((M, 2 * nv))
+        K, k = np.zeros((M - 1, 2 * nv, nu)), np.zeros((M - 1, nu))
+        self.lib.oracle_ocp_get_riccati_chain(self.h, P(Pm), P(s), P(K), P(k))
+        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
 
     def __del__(self):
         if getattr(self, "h", None):
