@@ -83,6 +83,57 @@ int oracle_contact_kinematics(const idocp_model_t* m, const double* q, const dou
   return 0;
 }
 
+// ForwardSwitchingConstraint terms for all contacts (forward_switching_constraint.hxx:27-66), col-major:
+// P[3nc] = foot positions at q (+) ((dt1+dt2) v + dt1 dt2 a) minus points; Phiq, Phiv, Phia [3nc x nv]
+int oracle_switching_terms(const idocp_model_t* m, const double* q, const double* v, const double* a, double dt1, double dt2,
+                           const double* points, double* Pout, double* Phiq, double* Phiv, double* Phia) {
+  Robot r(*m);
+  const int nv = m->nv, nc = m->ncontacts;
+  Mat Q = toVec(q, m->nq), V = toVec(v, nv), A = toVec(a, nv);
+  Mat dq = (dt1 + dt2) * V + (dt1 * dt2) * A, q2;
+  r.integrateConfiguration(Q, dq, 1.0, q2);
+  r.updateKinematics(q2, Mat(nv), Mat(nv));
+  std::vector<bool> act(nc, true); std::vector<Mat> cp;
+  for (int c = 0; c < nc; ++c) cp.push_back(toVec(points + 3 * c, 3));
+  Mat Pm, Pq, Jq, Jv;
+  r.computeContactResidual(act, cp, Pm);
+  r.computeContactDerivative(act, Pq);
+  r.dIntegratedConfiguration(Q, dq, Jq);
+  r.dIntegratedVelocity(Q, dq, Jv);
+  Mat a1 = Pq * Jq, a2 = (dt1 + dt2) * (Pq * Jv), a3 = (dt1 * dt2) * (Pq * Jv);
+  std::memcpy(Pout, Pm.d.data(), sizeof(double) * 3 * nc);
+  std::memcpy(Phiq, a1.d.data(), sizeof(double) * 3 * nc * nv);
+  std::memcpy(Phiv, a2.d.data(), sizeof(double) * 3 * nc * nv);
+  std::memcpy(Phia, a3.d.data(), sizeof(double) * 3 * nc * nv);
+  return 0;
+}
+
+// Impulse-stage rigid-body terms (impulse_dynamics_forward_euler.hxx:40-58), col-major, all contacts active:
+// ImD[nv] = rnea(q, 0, dv) without gravity with the impulse forces f[nc][3]; dImDdq, dImDddv [nv x nv];
+// C[3nc] = LOCAL linear velocity of the feet at (q, v + dv); dCdq, dCdv [3nc x nv]
+int oracle_impulse_terms(const idocp_model_t* m, const double* q, const double* v, const double* dv, const double* f, double* ImD,
+                         double* dImDdq, double* dImDddv, double* C, double* dCdq, double* dCdv) {
+  Robot r(*m);
+  const int nv = m->nv, nc = m->ncontacts;
+  Mat Q = toVec(q, m->nq), V = toVec(v, nv), DV = toVec(dv, nv), zero(nv);
+  std::vector<bool> act(nc, true); std::vector<Mat> fs;
+  for (int c = 0; c < nc; ++c) fs.push_back(toVec(f + 3 * c, 3));
+  r.updateKinematics(Q, V + DV, zero);
+  r.setContactForces(act, fs);
+  Mat tau, dq, dvv, da, Cm, Cq, Cv;
+  r.RNEA(Q, zero, DV, tau, false);
+  r.RNEADerivatives(Q, zero, DV, dq, dvv, da, false);
+  r.computeImpulseVelocityResidual(act, Cm);
+  r.computeImpulseVelocityDerivatives(act, Cq, Cv);
+  std::memcpy(ImD, tau.d.data(), sizeof(double) * nv);
+  std::memcpy(dImDdq, dq.d.data(), sizeof(double) * nv * nv);
+  std::memcpy(dImDddv, da.d.data(), sizeof(double) * nv * nv);
+  std::memcpy(C, Cm.d.data(), sizeof(double) * 3 * nc);
+  std::memcpy(dCdq, Cq.d.data(), sizeof(double) * 3 * nc * nv);
+  std::memcpy(dCdv, Cv.d.data(), sizeof(double) * 3 * nc * nv);
+  return 0;
+}
+
 // Lie operations: q_int = q (+) dv ; diff = q1 (-) q ; J0 = d diff / d q (ARG0), J1 = d diff / d q1 (ARG1)
 int oracle_lie_ops(const idocp_model_t* m, const double* q, const double* q1, const double* dv, double* q_int,
                    double* diff, double* J0, double* J1) {

@@ -1,0 +1,159 @@
+"""CPU checks of the hybrid (discrete-event) half of the oracle: the discretiser's chain, the
+rigid-body terms of the impulse stage and of the switching constraint against finite differences on
+the configuration manifold, and convergence of the full hybrid SQP iteration on the reference's
+trotting problem (examples/anymal/anymal_trotting.cpp, transcribed as data in helpers.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import (ANYMAL_Q_STANDING, OracleOCP, P, anymal_contact_points, anymal_model, anymal_problem, arr, oracle,
+                     trotting_sequence)
+
+
+def integrate(model, q, dv):
+    lib = oracle()
+    out, d, j0, j1 = np.zeros(model.nq), np.zeros(model.nv), np.zeros(model.nv ** 2), np.zeros(model.nv ** 2)
+    lib.oracle_lie_ops(C.byref(model), P(arr(q)), P(arr(q)), P(arr(dv)), P(out), P(d), P(j0), P(j1))
+    return out
+
+
+def random_state(model, seed):
+    rng = np.random.default_rng(seed)
+    q = ANYMAL_Q_STANDING.copy()
+    q[0:3] += rng.uniform(-0.2, 0.2, 3)
+    quat = np.array([0, 0, 0, 1.0]) + 0.3 * rng.normal(size=4)
+    q[3:7] = quat / np.linalg.norm(quat)
+    q[7:] += rng.uniform(-0.4, 0.4, 12)
+    return q, rng.uniform(-1, 1, model.nv), rng.uniform(-1, 1, model.nv), rng
+
+
+def test_switching_constraint_jacobians_match_finite_differences():
+    # forward_switching_constraint.hxx:27-66: Phiq = Pq dIntegrate_dq, Phiv = (dt1+dt2) Pq dIntegrate_dv, Phia = dt1 dt2 Pq dIntegrate_dv
+    m = anymal_model()
+    lib = oracle()
+    nv, nc = m.nv, m.ncontacts
+    q, v, a, rng = random_state(m, 5)
+    pts = rng.uniform(-0.5, 0.5, (nc, 3))
+    dt1, dt2 = 0.05, 0.031
+
+    def terms(q_, v_, a_):
+        Pm, Pq, Pv, Pa = np.zeros(3 * nc), np.zeros((nv, 3 * nc)), np.zeros((nv, 3 * nc)), np.zeros((nv, 3 * nc))
+        lib.oracle_switching_terms(C.byref(m), P(arr(q_)), P(arr(v_)), P(arr(a_)), C.c_double(dt1), C.c_double(dt2), P(arr(pts)),
+                                   P(Pm), P(Pq), P(Pv), P(Pa))
+        return Pm, Pq.T, Pv.T, Pa.T
+
+    P0, Phiq, Phiv, Phia = terms(q, v, a)
+    eps = 1e-6
+    for k in range(nv):
+        e = np.zeros(nv)
+        e[k] = eps
+        fd_q = (terms(integrate(m, q, e), v, a)[0] - terms(integrate(m, q, -e), v, a)[0]) / (2 * eps)
+        fd_v = (terms(q, v + e, a)[0] - terms(q, v - e, a)[0]) / (2 * eps)
+        fd_a = (terms(q, v, a + e)[0] - terms(q, v, a - e)[0]) / (2 * eps)
+        assert np.abs(fd_q - Phiq[:, k]).max() < 1e-7
+        assert np.abs(fd_v - Phiv[:, k]).max() < 1e-7
+        assert np.abs(fd_a - Phia[:, k]).max() < 1e-7
+
+
+def test_impulse_stage_terms_match_finite_differences():
+    # impulse_dynamics_forward_euler.hxx:40-58: ImD(q, dv, f), C = v_foot(q, v + dv) and their partials
+    m = anymal_model()
+    lib = oracle()
+    nv, nc = m.nv, m.ncontacts
+    q, v, dv, rng = random_state(m, 9)
+    f = rng.uniform(-20, 20, (nc, 3))
+
+    def terms(q_, v_, dv_):
+        ImD, dq, ddv = np.zeros(nv), np.zeros((nv, nv)), np.zeros((nv, nv))
+        Cm, Cq, Cv = np.zeros(3 * nc), np.zeros((nv, 3 * nc)), np.zeros((nv, 3 * nc))
+        lib.oracle_impulse_terms(C.byref(m), P(arr(q_)), P(arr(v_)), P(arr(dv_)), P(arr(f)), P(ImD), P(dq), P(ddv), P(Cm), P(Cq), P(Cv))
+        return ImD, dq.T, ddv.T, Cm, Cq.T, Cv.T
+
+    ImD, dImDdq, dImDddv, Cm, dCdq, dCdv = terms(q, v, dv)
+    eps = 1e-6
+    for k in range(nv):
+        e = np.zeros(nv)
+        e[k] = eps
+        tp, tm = terms(integrate(m, q, e), v, dv), terms(integrate(m, q, -e), v, dv)
+        assert np.abs((tp[0] - tm[0]) / (2 * eps) - dImDdq[:, k]).max() < 2e-6
+        assert np.abs((tp[3] - tm[3]) / (2 * eps) - dCdq[:, k]).max() < 1e-7
+        tp, tm = terms(q, v, dv + e), terms(q, v, dv - e)
+        assert np.abs((tp[0] - tm[0]) / (2 * eps) - dImDddv[:, k]).max() < 2e-6
+        assert np.abs((tp[3] - tm[3]) / (2 * eps) - dCdv[:, k]).max() < 1e-7       # dC/ddv = dC/dv
+        tp, tm = terms(q, v + e, dv), terms(q, v - e, dv)
+        assert np.abs(tp[0] - tm[0]).max() == 0.0                                # the impulse dynamics do not depend on v
+        assert np.abs((tp[3] - tm[3]) / (2 * eps) - dCdv[:, k]).max() < 1e-7
+
+
+def make_trotting(N=30, T=1.55, nimp=2):
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+    trotting_sequence(o, m, nimp)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    o.init_constraints(0.0)
+    return m, o, q, v
+
+
+def test_discretiser_chain_of_the_trotting_example():
+    # OCPDiscretizer (ocp_discretizer.hxx:65-374): lift at 0.5 s, impulses (with simultaneous lift) at 1.0 s and 1.5 s
+    m, o, q, v = make_trotting()
+    ch = o.chain(0.0)
+    dt = 1.55 / 30
+    assert len(ch) == 30 + 1 + 2 * 2 + 1
+    kinds = "".join(c["kind"][0] for c in ch)
+    assert kinds == "s" * 10 + "l" + "s" * 10 + "ia" + "s" * 10 + "ia" + "t"
+    lift = ch[10]
+    assert abs(ch[9]["dt"] - (0.5 - 9 * dt)) < 1e-12 and abs(lift["dt"] - (dt - ch[9]["dt"])) < 1e-12 and abs(lift["t"] - 0.5) < 1e-12
+    imp = [p for p, c in enumerate(ch) if c["kind"] == "impulse"]
+    for p, t_imp, event in zip(imp, (1.0, 1.5), (1, 2)):
+        assert abs(ch[p]["t"] - t_imp) < 1e-12 and ch[p]["dt"] == 0.0
+        assert abs(ch[p - 1]["dt"] + ch[p + 1]["dt"] - dt) < 1e-12                 # dt + dt_aux = dt_ideal
+        assert ch[p - 2]["sw_event"] == event                                      # switching constraint two stages ahead
+        assert ch[p]["dimf"] == 6
+    assert sum(1 for c in ch if c["sw_event"] >= 0) == 2
+    assert [c["dimf"] for c in ch[:10]] == [12] * 10 and all(c["dimf"] == 6 for c in ch[10:-1])
+    # total time of the chain equals the horizon length
+    assert abs(sum(c["dt"] for c in ch) - 1.55) < 1e-12
+    # moving the initial time moves the events across the grid but keeps the chain well defined
+    ch2 = o.chain(0.23)
+    assert len(ch2) == len(ch) and abs(sum(c["dt"] for c in ch2) - 1.55) < 1e-12
+    assert [c["kind"] for c in ch2].index("lift") == 6 and ch2[5]["dt"] < dt
+
+
+def test_hybrid_sqp_converges_on_the_trotting_example():
+    m, o, q, v = make_trotting()
+    e0 = o.kkt_error(0.0, q, v)
+    errs = []
+    for it in range(25):                                       # ocpbenchmarker::Convergence(ocp_solver, t, q, v, 25, false)
+        assert o.update(0.0, q, v) == 0
+        errs.append(o.kkt_error(0.0, q, v))
+    assert errs[0] < e0 and errs[-1] < 1e-9 and np.isfinite(errs).all()
+    # the converged trajectory satisfies the switching constraints: the swing feet land on the contact points
+    ch = o.chain(0.0)
+    M = len(ch)
+    xi = o.get_chain("xi", M)
+    assert all(np.abs(xi[p]).max() > 0 for p, c in enumerate(ch) if c["sw_event"] >= 0)
+    qs = o.get_chain("q", M)
+    lib = oracle()
+    for p, c in enumerate(ch):
+        if c["kind"] != "impulse":
+            continue
+        nv, nc = m.nv, m.ncontacts
+        z = np.zeros(nv)
+        fp = np.zeros((nc, 3))
+        tmp = [np.zeros(n) for n in (3 * nc, 3 * nc * nv, 3 * nc * nv, 3 * nc * nv)]
+        fR, fv, fa = np.zeros((nc, 9)), np.zeros((nc, 6)), np.zeros((nc, 6))
+        d4 = [np.zeros(nc * 6 * nv) for _ in range(4)]
+        lib.oracle_contact_kinematics(C.byref(m), P(arr(qs[p])), P(z), P(z), P(np.zeros((nc, 3))), C.c_double(0.05), P(tmp[0]), P(tmp[1]),
+                                      P(tmp[2]), P(tmp[3]), P(fp), P(fR), P(fv), P(fa), P(d4[0]), P(d4[1]), P(d4[2]), P(d4[3]), None)
+        pts = anymal_contact_points(m)
+        landed = (0, 3)                                          # LF, RH touch down at every impulse of this gait
+        for cidx in landed:
+            # on the ground up to the O(dt^2) gap between exp(a) exp(b) and exp(a + b) on SE(3): the constraint is
+            # imposed on the two-step prediction q (+) ((dt1+dt2) v + dt1 dt2 a), not on the impulse stage's own q
+            assert abs(fp[cidx, 2] - pts[cidx, 2]) < 1e-3
