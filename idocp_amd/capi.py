@@ -134,6 +134,24 @@ def _proto(lib):
     lib.idocp_unocp_stream.restype = vp
     lib.idocp_ocp_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
     lib.idocp_ocp_create.restype = ci
+    lib.idocp_ocp_create_hybrid.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, P(vp)]
+    lib.idocp_ocp_create_hybrid.restype = ci
+    lib.idocp_ocp_push_back_contact_status.argtypes = [vp, P(ci), vp, cd]
+    lib.idocp_ocp_push_back_contact_status.restype = ci
+    lib.idocp_ocp_set_contact_points.argtypes = [vp, ci, vp]
+    lib.idocp_ocp_set_contact_points.restype = ci
+    lib.idocp_ocp_pop_back_contact_status.argtypes = [vp]
+    lib.idocp_ocp_pop_back_contact_status.restype = ci
+    lib.idocp_ocp_pop_front_contact_status.argtypes = [vp]
+    lib.idocp_ocp_pop_front_contact_status.restype = ci
+    lib.idocp_ocp_get_chain.argtypes = [vp, cd, ci, P(ci), P(ci), P(ci), vp, P(ci), P(ci)]
+    lib.idocp_ocp_get_chain.restype = ci
+    lib.idocp_ocp_get_solution_chain.argtypes = [vp, cs, ci, vp]
+    lib.idocp_ocp_get_solution_chain.restype = ci
+    lib.idocp_ocp_get_direction_chain.argtypes = [vp, cs, ci, vp]
+    lib.idocp_ocp_get_direction_chain.restype = ci
+    lib.idocp_ocp_get_riccati_chain.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.idocp_ocp_get_riccati_chain.restype = ci
     lib.idocp_ocp_destroy.argtypes = [vp]
     lib.idocp_ocp_destroy.restype = None
     lib.idocp_ocp_stream.argtypes = [vp]

@@ -150,5 +150,31 @@ __device__ __forceinline__ void lieIntegrateBase(const double* q, const double* 
   for (int k = 0; k < 4; ++k) qout[3 + k] = sgn * qt[k];
 }
 
+// exp6 of a free-flyer tangent v = (lin, ang): (R, p) = (exp3(w), V(w) lin)   (pinocchio::exp6)
+__device__ __forceinline__ void lieExp6(const double* vin, double* R, double* p) {
+  const double* w = vin + 3;
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = sqrt(t2);
+  double a, b, c;
+  if (t < 1e-8) { a = 1 - t2 / 6; b = 0.5 - t2 / 24; c = 1.0 / 6 - t2 / 120; }
+  else { a = sin(t) / t; b = (1 - cos(t)) / t2; c = (t - sin(t)) / (t2 * t); }
+  double K[9], K2[9], V[9];
+  lieSkew(w, K); lieMatmul3(K, K, K2);
+  for (int i = 0; i < 9; ++i) { V[i] = b * K[i] + c * K2[i]; R[i] = a * K[i] + b * K2[i]; }
+  V[0] += 1; V[4] += 1; V[8] += 1; R[0] += 1; R[4] += 1; R[8] += 1;
+  lieMatvec3(V, vin, p);
+}
+
+// pinocchio::dIntegrate(q, v, ARG0) for the free-flyer: action matrix of exp6(v)^-1 (6x6 column-major)
+__device__ __forceinline__ void lieDIntegrateArg0(const double* R, const double* p, double* A) {
+  double Rt[9], mp[3], K[9], KRt[9];
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
+  lieMatvec3(Rt, p, mp);
+  for (int k = 0; k < 3; ++k) mp[k] = -mp[k];
+  lieSkew(mp, K); lieMatmul3(K, Rt, KRt);
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) {
+    A[r + 6 * s] = Rt[3 * r + s]; A[(3 + r) + 6 * (3 + s)] = Rt[3 * r + s]; A[r + 6 * (3 + s)] = KRt[3 * r + s]; A[(3 + r) + 6 * s] = 0.0;
+  }
+}
+
 }  // namespace idocp_dev
 #endif  // IDOCP_DEV_LIE_HPP_

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -72,11 +73,18 @@ bool isQuadruped(const idocp_model_t& m) {
 
 }  // namespace
 
+// idocp::ContactStatus / ImpulseStatus on the host (include/idocp/robot/contact_status.hxx)
+struct HostStatus {
+  int active[IDOCP_MAX_CONTACTS] = {0, 0, 0, 0};
+  double points[IDOCP_MAX_CONTACTS][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  int dimf() const { int n = 0; for (int c = 0; c < DQ::NC; ++c) n += active[c] ? 3 : 0; return n; }
+};
+
 struct idocp_ocp {
   idocp_model_t model;
   idocp_cost_t cost;
   idocp_constraints_t cons;
-  int N, batch, device;
+  int N, E, NS, batch, device;         // N = grid intervals (N_ideal), E = max number of discrete events, NS = slots per instance
   double T;
   hipStream_t stream = nullptr;
   OcpBuffers B{};
@@ -84,8 +92,22 @@ struct idocp_ocp {
   std::vector<void*> allocs;
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr, *d_qref = nullptr;
   void* d_prob = nullptr;
-  double qref_time = NAN;
+  OcpNode* d_nodes = nullptr;
   bool contact_status_set = false;
+  // ContactSequence (include/idocp/hybrid/contact_sequence.hxx:56-333)
+  std::vector<HostStatus> phases;
+  std::vector<double> event_time;
+  std::vector<char> is_impulse;
+  std::vector<HostStatus> impulse_status;          // per event
+  // chain of the last discretisation (OCPDiscretizer, ocp_discretizer.hxx:65-374)
+  std::vector<OcpNode> chain;
+  std::vector<int> chain_index;
+  std::vector<double> chain_t;
+  int Ngrid = 0;                      // grid stages after discretisation
+  double disc_time = NAN;
+  bool seq_dirty = true, has_switch = false;
+  int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
+  int M() const { return (int)chain.size(); }
 };
 
 namespace {
@@ -117,21 +139,128 @@ void qRefAt(const idocp_cost_t& c, int nq, double t, double* q_ref) {
   }
 }
 
-int uploadQRef(idocp_ocp* h, double t) {
-  if (h->qref_time == t) return IDOCP_OK;
-  const int N = h->N, nq = h->model.nq;
-  std::vector<double> tab((size_t)(N + 1) * nq);
-  const double dt = h->T / N;
-  for (int i = 0; i <= N; ++i) qRefAt(h->cost, nq, i < N ? t + i * dt : t + h->T, &tab[(size_t)i * nq]);   // ocp_discretizer t(i)
-  HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
-  h->qref_time = t;
-  return IDOCP_OK;
+int slotOf(const idocp_ocp* h, int kind, int index) {
+  switch (kind) {
+    case 1: return h->N + 1 + index;
+    case 2: return h->N + 1 + h->E + index;
+    case 3: return h->N + 1 + 2 * h->E + index;
+    default: return index;
+  }
 }
 
-int uploadProblem(idocp_ocp* h) {
+void fillStatus(OcpNode& nd, const HostStatus& st) {
+  int row = 0;
+  for (int c = 0; c < DQ::NC; ++c) {
+    nd.active[c] = st.active[c] ? 1 : 0;
+    nd.row_of[c] = st.active[c] ? row : -1;
+    if (st.active[c]) row += 3;
+    for (int k = 0; k < 3; ++k) nd.contact_point[c][k] = st.points[c][k];
+  }
+  nd.dimf = row;
+}
+
+// OCPDiscretizer::discretizeOCP(contact_sequence, t) (ocp_discretizer.hxx:65-374): event times -> time stages, time
+// steps of the stages around an event, contact phase of every stage -- and from those the chain of stages in time
+// order.  Host-side index logic, re-run only when the initial time or the contact sequence changes.
+int discretize(idocp_ocp* h, double t) {
+  if (!h->seq_dirty && h->disc_time == t) return IDOCP_OK;
+  const int N_ideal = h->N;
+  const double min_dt = std::sqrt(std::numeric_limits<double>::epsilon());       // ocp_discretizer.hpp:108-109
+  const double dt_ideal = h->T / N_ideal, max_dt = dt_ideal - min_dt;
+  std::vector<int> ev_imp, ev_lift;
+  for (int e = 0; e < (int)h->event_time.size(); ++e) (h->is_impulse[e] ? ev_imp : ev_lift).push_back(e);
+  const int Ni = (int)ev_imp.size(), Nl = (int)ev_lift.size();
+  std::vector<int> tsbi(Ni + 1, -1), tsbl(Nl + 1, -1);
+  std::vector<double> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
+  for (int k = 0; k < Ni; ++k) { t_imp[k] = h->event_time[ev_imp[k]]; tsbi[k] = (int)std::floor((t_imp[k] - t) / dt_ideal); }    // countDiscreteEvents
+  for (int k = 0; k < Nl; ++k) { t_lift[k] = h->event_time[ev_lift[k]]; tsbl[k] = (int)std::floor((t_lift[k] - t) / dt_ideal); }
+  std::vector<double> dts(N_ideal + 1, dt_ideal), ts(N_ideal + 1, 0.0);
+  int ii = 0, li = 0, on_grid = 0;
+  for (int i = 0; i < N_ideal; ++i) {                                                                                           // countTimeSteps
+    const int stage = i - on_grid;
+    if (ii < Ni && i == tsbi[ii]) {
+      dts[stage] = t_imp[ii] - i * dt_ideal - t;
+      if (dts[stage] <= min_dt) { tsbi[ii] = stage - 1; dt_aux[ii] = dt_ideal; ts[stage] = t + (i - 1) * dt_ideal; ++on_grid; ++ii; }
+      else if (dts[stage] >= max_dt) { tsbi[ii] = i + 1; ts[stage] = t + i * dt_ideal; }
+      else { tsbi[ii] = stage; dt_aux[ii] = dt_ideal - dts[stage]; ts[stage] = t + i * dt_ideal; ++ii; }
+    } else if (li < Nl && i == tsbl[li]) {
+      dts[stage] = t_lift[li] - i * dt_ideal - t;
+      if (dts[stage] <= min_dt) { tsbl[li] = stage - 1; dt_lift[li] = dt_ideal; ts[stage] = t + (i - 1) * dt_ideal; ++on_grid; ++li; }
+      else if (dts[stage] >= max_dt) { tsbl[li] = i + 1; ts[stage] = t + i * dt_ideal; }
+      else { tsbl[li] = stage; dt_lift[li] = dt_ideal - dts[stage]; ts[stage] = t + i * dt_ideal; ++li; }
+    } else {
+      dts[stage] = dt_ideal; ts[stage] = t + i * dt_ideal;
+    }
+  }
+  const int Ng = N_ideal - on_grid;
+  ts[Ng] = t + h->T;
+  std::vector<int> imp_after(Ng + 1, -1), lift_after(Ng + 1, -1), phase(Ng + 1, 0);                                             // countTimeStages / countContactPhase
+  ii = 0; li = 0;
+  int num_events = 0;
+  for (int i = 0; i < Ng; ++i) {
+    if (ii < Ni && i == tsbi[ii]) imp_after[i] = ii++;
+    if (li < Nl && i == tsbl[li]) lift_after[i] = li++;
+    phase[i] = num_events;
+    if (imp_after[i] >= 0 && lift_after[i] >= 0) { set_last_error("OCPDiscretizer: an impulse and a lift fall into the same time stage"); return IDOCP_E_ARG; }
+    if (imp_after[i] >= 0 || lift_after[i] >= 0) ++num_events;
+  }
+  phase[Ng] = num_events;
+  if (num_events > (int)h->phases.size() - 1) { set_last_error("OCPDiscretizer: inconsistent contact sequence"); return IDOCP_E_ARG; }
+  h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
+  auto node = [&](int kind, int index, double tt, double dtt, const HostStatus& st, int level) {
+    OcpNode nd;
+    std::memset(&nd, 0, sizeof(nd));
+    nd.kind = kind; nd.slot = slotOf(h, kind, index); nd.level = level;
+    nd.has_u = (kind == 1) ? 0 : 1;
+    nd.dt = (kind == 1) ? 1.0 : dtt;
+    nd.dtq = (kind == 1) ? 0.0 : dtt;
+    fillStatus(nd, st);
+    h->chain.push_back(nd); h->chain_index.push_back(index); h->chain_t.push_back(tt);
+  };
+  auto addSwitch = [&](OcpNode& nd, int impulse_index, double dt_next) {              // ocp_linearizer.hxx:152-163, 205-217
+    const HostStatus& is = h->impulse_status[ev_imp[impulse_index]];
+    int row = 0;
+    for (int c = 0; c < DQ::NC; ++c) {
+      nd.sw_active[c] = is.active[c] ? 1 : 0;
+      nd.sw_row[c] = is.active[c] ? row : -1;
+      if (is.active[c]) row += 3;
+      for (int k = 0; k < 3; ++k) nd.sw_point[c][k] = is.points[c][k];
+    }
+    nd.sw_dimi = row;
+    nd.sw_dt1 = nd.dtq; nd.sw_dt2 = dt_next;
+  };
+  h->has_switch = false;
+  for (int i = 0; i < Ng; ++i) {
+    node(0, i, ts[i], dts[i], h->phases[phase[i]], i);
+    if (imp_after[i] < 0 && lift_after[i] < 0 && i + 1 < Ng && imp_after[i + 1] >= 0) { addSwitch(h->chain.back(), imp_after[i + 1], dts[i + 1]); h->has_switch = true; }
+    if (imp_after[i] >= 0) {
+      const int k = imp_after[i];
+      node(1, k, t_imp[k], 0.0, h->impulse_status[ev_imp[k]], -1);
+      node(2, k, t_imp[k], dt_aux[k], h->phases[phase[i + 1]], 0);
+    } else if (lift_after[i] >= 0) {
+      const int k = lift_after[i];
+      node(3, k, t_lift[k], dt_lift[k], h->phases[phase[i + 1]], 0);
+      if (i + 1 < Ng && imp_after[i + 1] >= 0) { addSwitch(h->chain.back(), imp_after[i + 1], dts[i + 1]); h->has_switch = true; }
+    }
+  }
+  node(4, Ng, ts[Ng], 0.0, h->phases[phase[Ng]], Ng);
+  const int M = h->M();
+  for (int p = 0; p < M; ++p) {
+    h->chain[p].prev = p > 0 ? h->chain[p - 1].slot : -1;
+    h->chain[p].next = p + 1 < M ? h->chain[p + 1].slot : -1;
+  }
+  h->Ngrid = Ng;
+  h->uniform_dimf = -1;
+  if (h->event_time.empty()) h->uniform_dimf = h->chain[0].dimf;
+  // upload: chain, per-stage cost references, problem header
+  std::vector<double> tab((size_t)M * DQ::NQ);
+  for (int p = 0; p < M; ++p) qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]);
+  h->prob.M = M; h->prob.NS = h->NS;
+  HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
+  h->disc_time = t; h->seq_dirty = false;
   return IDOCP_OK;
 }
 
@@ -147,6 +276,7 @@ bool solFieldO(const std::string& n, Field& f) {
   else if (n == "f") f = {LQ::S_F, DQ::NF, 0};
   else if (n == "mu") f = {LQ::S_MU, DQ::NF, 0};
   else if (n == "nu_passive") f = {LQ::S_NUP, 6, 0};
+  else if (n == "xi") f = {LQ::S_XI, DQ::NF, 0};
   else return false;
   return true;
 }
@@ -161,6 +291,7 @@ bool dirFieldO(const std::string& n, Field& f) {
   else if (n == "df") f = {LQ::D_F, DQ::NF, 0};
   else if (n == "dmu") f = {LQ::D_MU, DQ::NF, 0};
   else if (n == "dnu_passive") f = {LQ::D_NUP, 6, 0};
+  else if (n == "dxi") f = {LQ::D_XI, DQ::NF, 0};
   else return false;
   return true;
 }
@@ -176,11 +307,12 @@ int copyField(idocp_ocp* h, const double* base, size_t stride, size_t nrec, cons
 
 extern "C" {
 
-int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
-                     int N, int batch, int device, idocp_ocp_t** out) {
+int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                            int N, int max_num_impulse, int batch, int device, idocp_ocp_t** out) {
   if (!model || !cost || !constraints || !out) { set_last_error("idocp_ocp_create: null argument"); return IDOCP_E_ARG; }
   if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }       // ocp_solver.cpp:27-44
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
+  if (max_num_impulse < 0) { set_last_error("invalid value: max_num_impulse must be non-negative!"); return IDOCP_E_ARG; }
   if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
   if (!isQuadruped(*model)) {
     set_last_error("idocp_ocp_create: this build carries OCP kernels for a floating-base quadruped (4 legs x 3 joints, 4 point contacts) only");
@@ -193,44 +325,50 @@ int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const
   }
   if (device < 0 || device >= ndev) { set_last_error("invalid device ordinal"); return IDOCP_E_ARG; }
   idocp_ocp* h = new idocp_ocp();
-  h->model = *model; h->cost = *cost; h->cons = *constraints; h->N = N; h->batch = batch; h->device = device; h->T = T;
+  h->model = *model; h->cost = *cost; h->cons = *constraints; h->N = N; h->E = max_num_impulse; h->batch = batch; h->device = device; h->T = T;
+  h->NS = N + 1 + 3 * max_num_impulse;
   auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_last_error("hipStreamCreate failed"); return fail(IDOCP_E_DEVICE); }
-  const size_t n1 = (size_t)batch * (N + 1), n0 = (size_t)batch * N;
+  const size_t ns = (size_t)batch * h->NS;
   OcpBuffers& B = h->B;
   int rc;
   double* tmp;
-  if ((rc = allocBufO(h, &B.sol, n1 * LQ::SOL))) return fail(rc);
-  if ((rc = allocBufO(h, &B.dir, n1 * LQ::DIR))) return fail(rc);
-  if ((rc = allocBufO(h, &B.slack, n0 * LQ::CON))) return fail(rc);
-  if ((rc = allocBufO(h, &B.dual, n0 * LQ::CON))) return fail(rc);
-  if ((rc = allocBufO(h, &B.lin, n0 * LQ::LIN))) return fail(rc);
-  if ((rc = allocBufO(h, &B.lie, n1 * LQ::LIE))) return fail(rc);
-  if ((rc = allocBufO(h, &B.kkt, n1 * LQ::KKT))) return fail(rc);
-  if ((rc = allocBufO(h, &B.exp, n1 * LQ::EXP))) return fail(rc);
-  if ((rc = allocBufO(h, &B.ric, n1 * LQ::RIC))) return fail(rc);
-  if ((rc = allocBufO(h, &B.gain, n0 * LQ::GAIN))) return fail(rc);
-  if ((rc = allocBufO(h, &B.step_stage, n0 * 2))) return fail(rc);
+  if ((rc = allocBufO(h, &B.sol, ns * LQ::SOL))) return fail(rc);
+  if ((rc = allocBufO(h, &B.dir, ns * LQ::DIR))) return fail(rc);
+  if ((rc = allocBufO(h, &B.slack, ns * LQ::CON))) return fail(rc);
+  if ((rc = allocBufO(h, &B.dual, ns * LQ::CON))) return fail(rc);
+  if ((rc = allocBufO(h, &B.lin, ns * LQ::LIN))) return fail(rc);
+  if ((rc = allocBufO(h, &B.lie, ns * LQ::LIE))) return fail(rc);
+  if ((rc = allocBufO(h, &B.kkt, ns * LQ::KKT))) return fail(rc);
+  if ((rc = allocBufO(h, &B.exp, ns * LQ::EXP))) return fail(rc);
+  if ((rc = allocBufO(h, &B.ric, ns * LQ::RIC))) return fail(rc);
+  if ((rc = allocBufO(h, &B.gain, ns * LQ::GAIN))) return fail(rc);
+  if ((rc = allocBufO(h, &B.swc, max_num_impulse > 0 ? ns * LQ::SWC : 16))) return fail(rc);
+  if ((rc = allocBufO(h, &B.step_stage, ns * 2))) return fail(rc);
   if ((rc = allocBufO(h, &B.step, (size_t)batch * 2))) return fail(rc);
-  if ((rc = allocBufO(h, &B.err_stage, n1))) return fail(rc);
+  if ((rc = allocBufO(h, &B.err_stage, ns))) return fail(rc);
   if ((rc = allocBufO(h, &B.err, (size_t)batch))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_q0, (size_t)batch * DQ::NQ))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_v0, (size_t)batch * DQ::NV))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
-  if ((rc = allocBufO(h, &h->d_qref, (size_t)(N + 1) * DQ::NQ))) return fail(rc);
+  if ((rc = allocBufO(h, &h->d_qref, (size_t)h->NS * DQ::NQ))) return fail(rc);
   if ((rc = allocBufO(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
   B.status = reinterpret_cast<int*>(tmp);
   if ((rc = allocBufO(h, &tmp, 64))) return fail(rc);
   B.prof = reinterpret_cast<long long*>(tmp);
+  if ((rc = allocBufO(h, &tmp, ((size_t)h->NS * sizeof(OcpNode) + 7) / 8))) return fail(rc);
+  h->d_nodes = reinterpret_cast<OcpNode*>(tmp);
+  B.nodes = h->d_nodes;
   B.q_ref = h->d_qref;
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
   std::memset(&p, 0, sizeof(p));
-  p.N = N; p.batch = batch; p.T = T; p.dt = T / N;
+  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS;
   p.baumgarte_time_step = T / N;                           // hybrid_container.hpp:186-188
   for (int i = 0; i < DQ::NV; ++i) {
     p.v_ref[i] = cost->v_ref[i]; p.q_weight[i] = cost->q_weight[i]; p.v_weight[i] = cost->v_weight[i]; p.a_weight[i] = cost->a_weight[i];
     p.qf_weight[i] = cost->qf_weight[i]; p.vf_weight[i] = cost->vf_weight[i];
+    p.qi_weight[i] = cost->qi_weight[i]; p.vi_weight[i] = cost->vi_weight[i]; p.dvi_weight[i] = cost->dvi_weight[i];
   }
   if (cost->use_trotting_ref) p.v_ref[0] = cost->step_length / cost->t_period;     // trotting_configuration_space_cost.cpp:81-83
   for (int i = 0; i < DQ::NU; ++i) {
@@ -238,12 +376,16 @@ int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const
     p.q_min[i] = model->q_min[i]; p.q_max[i] = model->q_max[i]; p.v_max[i] = model->v_max[i]; p.u_max[i] = model->u_max[i];
   }
   for (int c = 0; c < DQ::NC; ++c) {
-    for (int k = 0; k < 3; ++k) { p.f_weight[c][k] = cost->f_weight[c][k]; p.f_ref[c][k] = cost->f_ref[c][k]; p.contact_p[c][k] = model->contact_p[c][k]; }
+    for (int k = 0; k < 3; ++k) {
+      p.f_weight[c][k] = cost->f_weight[c][k]; p.f_ref[c][k] = cost->f_ref[c][k];
+      p.fi_weight[c][k] = cost->fi_weight[c][k]; p.fi_ref[c][k] = cost->fi_ref[c][k];
+      p.contact_p[c][k] = model->contact_p[c][k];
+    }
     std::memcpy(p.contact_R[c], model->contact_R[c], sizeof(double) * 9);
-    p.active[c] = 0; p.row_of[c] = -1;
   }
   p.use_q_limits = constraints->joint_position_limits; p.use_v_limits = constraints->joint_velocity_limits;
   p.use_u_limits = constraints->joint_torque_limits; p.use_friction_cone = constraints->linearized_friction_cone;
+  p.use_impulse_friction_cone = constraints->linearized_impulse_friction_cone;
   p.mu = constraints->mu; p.barrier = constraints->barrier; p.fraction_rate = constraints->fraction_to_boundary_rate;
   void* d_model = nullptr;
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&h->d_prob, sizeof(OcpProblem)) != hipSuccess) {
@@ -253,16 +395,22 @@ int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const
   if (hipMemcpyAsync(d_model, &dm, sizeof(dm), hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_last_error("hipMemcpy failed"); return fail(IDOCP_E_DEVICE); }
   B.model = static_cast<const DevModel*>(d_model);
   B.prob = static_cast<const OcpProblem*>(h->d_prob);
-  if ((rc = uploadProblem(h))) return fail(rc);
+  h->phases.assign(1, HostStatus());                      // ContactSequence ctor: default (no contact) status
+  if ((rc = discretize(h, 0.0))) return fail(rc);
   // identity quaternion in every q so that an unset solution is a valid configuration
   {
     std::vector<double> q(DQ::NQ, 0.0); q[6] = 1.0;
     if (hipMemcpyAsync(h->d_tmp, q.data(), sizeof(double) * DQ::NQ, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
-    ocpFillField(B.sol, LQ::SOL, LQ::S_Q, DQ::NQ, N + 1, batch, h->d_tmp, 0, 1, h->stream);
+    ocpFillField(B.sol, LQ::SOL, LQ::S_Q, DQ::NQ, h->NS, batch, h->d_tmp, 0, 1, h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
   }
   *out = h;
   return IDOCP_OK;
+}
+
+int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                     int N, int batch, int device, idocp_ocp_t** out) {
+  return idocp_ocp_create_hybrid(model, cost, constraints, T, N, 0, batch, device, out);
 }
 
 void idocp_ocp_destroy(idocp_ocp_t* h) {
@@ -274,19 +422,107 @@ void idocp_ocp_destroy(idocp_ocp_t* h) {
   delete h;
 }
 
+static HostStatus makeStatus(const int* active, const double* contact_points) {
+  HostStatus st;
+  for (int c = 0; c < DQ::NC; ++c) {
+    st.active[c] = active[c] ? 1 : 0;
+    for (int k = 0; k < 3; ++k) st.points[c][k] = contact_points[3 * c + k];
+  }
+  return st;
+}
+
 int idocp_ocp_set_contact_status_uniformly(idocp_ocp_t* h, const int* active, const double* contact_points) {
   if (!h || !active || !contact_points) return IDOCP_E_ARG;
-  int rc = setDev(h); if (rc) return rc;
-  int row = 0;
-  for (int c = 0; c < DQ::NC; ++c) {
-    h->prob.active[c] = active[c] ? 1 : 0;
-    h->prob.row_of[c] = active[c] ? row : -1;
-    if (active[c]) row += 3;
-    for (int k = 0; k < 3; ++k) h->prob.contact_point[c][k] = contact_points[3 * c + k];
-  }
-  h->prob.dimf = row;
+  h->phases.assign(1, makeStatus(active, contact_points));            // contact_sequence.hxx:47-51
+  h->event_time.clear(); h->is_impulse.clear(); h->impulse_status.clear();
   h->contact_status_set = true;
-  return uploadProblem(h);
+  h->seq_dirty = true;
+  return IDOCP_OK;
+}
+
+int idocp_ocp_push_back_contact_status(idocp_ocp_t* h, const int* active, const double* contact_points, double switching_time) {
+  if (!h || !active || !contact_points) return IDOCP_E_ARG;
+  if (!h->contact_status_set) { set_last_error("Call setContactStatusUniformly() before calling push_back()!"); return IDOCP_E_ARG; }
+  if ((int)h->event_time.size() + 1 > h->E) {
+    set_last_error("Number of discrete events=" + std::to_string(h->event_time.size() + 1) + " exceeds predefined max_num_events=" + std::to_string(h->E) + "!");
+    return IDOCP_E_ARG;
+  }
+  if (!h->event_time.empty() && switching_time <= h->event_time.back()) {
+    set_last_error("event_time=" + std::to_string(switching_time) + " must be larger than the last event time=" + std::to_string(h->event_time.back()) + "!");
+    return IDOCP_E_ARG;
+  }
+  // DiscreteEvent::setDiscreteEvent (discrete_event.hxx:57-84)
+  const HostStatus& pre = h->phases.back();
+  const HostStatus post = makeStatus(active, contact_points);
+  HostStatus imp = post;
+  bool exist_impulse = false, exist_lift = false;
+  for (int c = 0; c < DQ::NC; ++c) {
+    imp.active[c] = 0;
+    if (pre.active[c]) { if (!post.active[c]) exist_lift = true; }
+    else if (post.active[c]) { imp.active[c] = 1; exist_impulse = true; }
+  }
+  if (!exist_impulse && !exist_lift) { set_last_error("discrete_event.existDiscreteEvent() must be true!"); return IDOCP_E_ARG; }
+  h->phases.push_back(post);
+  h->event_time.push_back(switching_time);
+  h->is_impulse.push_back(exist_impulse ? 1 : 0);
+  h->impulse_status.push_back(imp);
+  h->seq_dirty = true;
+  return IDOCP_OK;
+}
+
+int idocp_ocp_set_contact_points(idocp_ocp_t* h, int contact_phase, const double* contact_points) {
+  if (!h || !contact_points) return IDOCP_E_ARG;
+  if (contact_phase < 0 || contact_phase >= (int)h->phases.size()) {
+    set_last_error("contact_phase=" + std::to_string(contact_phase) + " must be smaller than numContactPhases()" + std::to_string(h->phases.size()) + "!");
+    return IDOCP_E_ARG;
+  }
+  for (int c = 0; c < DQ::NC; ++c) for (int k = 0; k < 3; ++k) {
+    h->phases[contact_phase].points[c][k] = contact_points[3 * c + k];
+    if (contact_phase > 0 && h->is_impulse[contact_phase - 1]) h->impulse_status[contact_phase - 1].points[c][k] = contact_points[3 * c + k];
+  }
+  h->seq_dirty = true;
+  return IDOCP_OK;
+}
+
+int idocp_ocp_pop_back_contact_status(idocp_ocp_t* h) {              // contact_sequence.hxx:105-125
+  if (!h) return IDOCP_E_ARG;
+  if (!h->event_time.empty()) {
+    h->event_time.pop_back(); h->is_impulse.pop_back(); h->impulse_status.pop_back(); h->phases.pop_back();
+  } else {
+    h->phases.assign(1, HostStatus());
+  }
+  h->seq_dirty = true;
+  return IDOCP_OK;
+}
+
+int idocp_ocp_pop_front_contact_status(idocp_ocp_t* h) {             // contact_sequence.hxx:126-146
+  if (!h) return IDOCP_E_ARG;
+  if (!h->event_time.empty()) {
+    h->event_time.erase(h->event_time.begin()); h->is_impulse.erase(h->is_impulse.begin());
+    h->impulse_status.erase(h->impulse_status.begin()); h->phases.erase(h->phases.begin());
+  } else {
+    h->phases.assign(1, HostStatus());
+  }
+  h->seq_dirty = true;
+  return IDOCP_OK;
+}
+
+int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot, double* dt, int* dimf, int* sw_dimi) {
+  if (!h) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  const int M = h->M();
+  if (capacity < M) { set_last_error("idocp_ocp_get_chain: capacity too small"); return IDOCP_E_ARG; }
+  for (int p = 0; p < M; ++p) {
+    const OcpNode& nd = h->chain[p];
+    if (kind) kind[p] = nd.kind;
+    if (index) index[p] = h->chain_index[p];
+    if (slot) slot[p] = nd.slot;
+    if (dt) dt[p] = nd.dtq;
+    if (dimf) dimf[p] = nd.kind == 4 ? 0 : nd.dimf;
+    if (sw_dimi) sw_dimi[p] = nd.sw_dimi;
+  }
+  return M;
 }
 
 static int setSolutionO(idocp_ocp_t* h, const char* name, const double* values, int per_instance) {
@@ -301,7 +537,8 @@ static int setSolutionO(idocp_ocp_t* h, const char* name, const double* values, 
   const int dim = (n == "f") ? 3 : f.dim, repeat = (n == "f") ? DQ::NC : 1;
   const size_t cnt = (size_t)(per_instance ? h->batch : 1) * dim;
   HIP_TRY(hipMemcpyAsync(h->d_tmp, values, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  ocpFillField(h->B.sol, LQ::SOL, f.offset, dim, h->N + 1, h->batch, h->d_tmp, per_instance, repeat, h->stream);
+  // every stage incl. the event stages (ocp_solver.cpp:95-165; "a" sets dv on impulse stages)
+  ocpFillField(h->B.sol, LQ::SOL, f.offset, dim, h->NS, h->batch, h->d_tmp, per_instance, repeat, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
 }
@@ -310,9 +547,9 @@ int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double*
 
 int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
   if (!h) return IDOCP_E_ARG;
-  (void)t;
   int rc = setDev(h); if (rc) return rc;
-  OcpLaunch<DQ>::initConstraints(h->B, h->batch, h->N, h->stream);
+  if ((rc = discretize(h, t))) return rc;                 // ocp_solver.cpp:60-64
+  OcpLaunch<DQ>::initConstraints(h->B, h->batch, h->M(), h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
@@ -321,13 +558,17 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
 int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
   if (!h || kernel_id < 0 || kernel_id > 6 || !d_q || !d_v) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
-  if (h->qref_time != h->qref_time && (rc = uploadQRef(h, 0.0))) return rc;      // first use: reference of t = 0
+  if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
+  const int M = h->M();
   switch (kernel_id) {
-    case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream); break;
-    case 1: OcpLaunch<DQ>::condense(h->B, h->batch, h->N, h->prob.dimf, d_q, h->stream); break;
-    case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, h->N, h->stream); break;
-    case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, h->N, d_q, d_v, h->stream); break;
-    default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, h->N, h->stream); break;
+    case 0:
+      OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->stream);
+      if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
+      break;
+    case 1: OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream); break;
+    case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream); break;
+    case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
+    default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;
   }
   HIP_TRY(hipGetLastError());
   return IDOCP_OK;
@@ -337,14 +578,16 @@ int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q
   if (!h || !d_q || !d_v) return IDOCP_E_ARG;
   if (!h->contact_status_set) { set_last_error("idocp_ocp_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
-  if ((rc = uploadQRef(h, t))) return rc;
+  if ((rc = discretize(h, t))) return rc;                 // ocp_.discretize(contact_sequence_, t) (ocp_solver.cpp:72)
+  const int M = h->M();
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream);
-  OcpLaunch<DQ>::condense(h->B, h->batch, h->N, h->prob.dimf, d_q, h->stream);
-  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, h->N, h->stream);
-  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, h->N, d_q, d_v, h->stream);
-  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, h->N, h->stream);
-  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, h->N, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
+  OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream);
+  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream);
+  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
   HIP_TRY(hipGetLastError());
   return IDOCP_OK;
 }
@@ -368,17 +611,19 @@ int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q, const d
   HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int b = 0; b < h->batch; ++b)
-    if (st[b] != 0) { set_last_error("Cholesky failed (M, J M^-1 J^T or Quu not positive definite), instance " + std::to_string(b)); return st[b]; }
+    if (st[b] != 0) { set_last_error("factorisation failed (M, J M^-1 J^T, Quu or the switching-constraint Schur complement not positive definite), instance " + std::to_string(b)); return st[b]; }
   return IDOCP_OK;
 }
 
 int idocp_ocp_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, const double* v) {
   if (!h || !q || !v) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
-  if ((rc = uploadQRef(h, t))) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  const int M = h->M();
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, h->N, h->stream);
-  OcpLaunch<DQ>::residual(h->B, h->batch, h->N, h->d_q0, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
+  OcpLaunch<DQ>::residual(h->B, h->batch, M, h->d_q0, h->stream);
   ocpKktErrorReduce(h->B, h->batch, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -392,19 +637,44 @@ int idocp_ocp_kkt_error(idocp_ocp_t* h, double* kkt_error) {
   return IDOCP_OK;
 }
 
+// grid stages 0..N live in slots 0..N, so the stage-wise getters are plain strided copies
 int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;
   if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
-  return copyField(h, h->B.sol + (size_t)instance * (h->N + 1) * LQ::SOL, LQ::SOL, h->N + f.extra, f, out);
+  return copyField(h, h->B.sol + (size_t)instance * h->NS * LQ::SOL, LQ::SOL, h->Ngrid + f.extra, f, out);
 }
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;
   if (!dirFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
-  return copyField(h, h->B.dir + (size_t)instance * (h->N + 1) * LQ::DIR, LQ::DIR, h->N + f.extra, f, out);
+  return copyField(h, h->B.dir + (size_t)instance * h->NS * LQ::DIR, LQ::DIR, h->Ngrid + f.extra, f, out);
+}
+
+// the same fields for every stage of the chain, in chain order: out[M][dim] (rows of stages that do not carry the
+// field, e.g. "u" on an impulse stage, hold whatever the slot holds)
+static int getChainField(idocp_ocp_t* h, const double* base, size_t stride, const Field& f, int instance, double* out) {
+  int rc = setDev(h); if (rc) return rc;
+  const int M = h->M();
+  std::vector<double> all((size_t)h->NS * stride);
+  HIP_TRY(hipMemcpyAsync(all.data(), base + (size_t)instance * h->NS * stride, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int p = 0; p < M; ++p) std::memcpy(out + (size_t)p * f.dim, &all[(size_t)h->chain[p].slot * stride + f.offset], sizeof(double) * f.dim);
+  return IDOCP_OK;
+}
+int idocp_ocp_get_solution_chain(idocp_ocp_t* h, const char* name, int instance, double* out) {
+  if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  Field f;
+  if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  return getChainField(h, h->B.sol, LQ::SOL, f, instance, out);
+}
+int idocp_ocp_get_direction_chain(idocp_ocp_t* h, const char* name, int instance, double* out) {
+  if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  Field f;
+  if (!dirFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  return getChainField(h, h->B.dir, LQ::DIR, f, instance, out);
 }
 
 int idocp_ocp_get_step_sizes(idocp_ocp_t* h, double* primal, double* dual) {
@@ -417,16 +687,19 @@ int idocp_ocp_get_step_sizes(idocp_ocp_t* h, double* primal, double* dual) {
   return IDOCP_OK;
 }
 
-int idocp_ocp_get_riccati(idocp_ocp_t* h, int instance, double* P, double* s, double* K, double* k) {
+// chain != 0: one entry per stage of the chain (P, s: M entries; K, k: M - 1); chain == 0: grid stages 0..N
+static int getRiccati(idocp_ocp_t* h, int instance, int chain, double* P, double* s, double* K, double* k) {
   if (!h || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
-  const int nv = DQ::NV, nx = DQ::NX, nu = DQ::NU, N = h->N;
-  std::vector<double> ric((size_t)(N + 1) * LQ::RIC), gain((size_t)N * LQ::GAIN);
-  HIP_TRY(hipMemcpyAsync(ric.data(), h->B.ric + (size_t)instance * (N + 1) * LQ::RIC, ric.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(gain.data(), h->B.gain + (size_t)instance * N * LQ::GAIN, gain.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const int nv = DQ::NV, nx = DQ::NX, nu = DQ::NU;
+  const int n = chain ? h->M() : h->Ngrid + 1;
+  std::vector<double> ric((size_t)h->NS * LQ::RIC), gain((size_t)h->NS * LQ::GAIN);
+  HIP_TRY(hipMemcpyAsync(ric.data(), h->B.ric + (size_t)instance * h->NS * LQ::RIC, ric.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(gain.data(), h->B.gain + (size_t)instance * h->NS * LQ::GAIN, gain.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  for (int i = 0; i <= N; ++i) {
-    const double* r = &ric[(size_t)i * LQ::RIC];
+  for (int i = 0; i < n; ++i) {
+    const int slot = chain ? h->chain[i].slot : i;
+    const double* r = &ric[(size_t)slot * LQ::RIC];
     if (P) {
       double* Pm = P + (size_t)i * nx * nx;
       for (int c = 0; c < nv; ++c) for (int rr = 0; rr < nv; ++rr) {
@@ -437,20 +710,22 @@ int idocp_ocp_get_riccati(idocp_ocp_t* h, int instance, double* P, double* s, do
       }
     }
     if (s) { std::memcpy(s + (size_t)i * nx, r + LQ::R_SQ, sizeof(double) * nv); std::memcpy(s + (size_t)i * nx + nv, r + LQ::R_SV, sizeof(double) * nv); }
-    if (i < N) {
-      const double* g = &gain[(size_t)i * LQ::GAIN];
+    if (i < n - 1) {
+      const double* g = &gain[(size_t)slot * LQ::GAIN];
       if (K) std::memcpy(K + (size_t)i * nu * nx, g + LQ::G_K, sizeof(double) * nu * nx);
       if (k) std::memcpy(k + (size_t)i * nu, g + LQ::G_k, sizeof(double) * nu);
     }
   }
   return IDOCP_OK;
 }
+int idocp_ocp_get_riccati(idocp_ocp_t* h, int instance, double* P, double* s, double* K, double* k) { return getRiccati(h, instance, 0, P, s, K, k); }
+int idocp_ocp_get_riccati_chain(idocp_ocp_t* h, int instance, double* P, double* s, double* K, double* k) { return getRiccati(h, instance, 1, P, s, K, k); }
 
 int idocp_ocp_get_state_feedback_gain(idocp_ocp_t* h, int instance, int stage, double* Kq, double* Kv) {
-  if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->N || !Kq || !Kv) return IDOCP_E_ARG;
+  if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->Ngrid || !Kq || !Kv) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   std::vector<double> g(LQ::GAIN);
-  HIP_TRY(hipMemcpyAsync(g.data(), h->B.gain + ((size_t)instance * h->N + stage) * LQ::GAIN, g.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(g.data(), h->B.gain + ((size_t)instance * h->NS + stage) * LQ::GAIN, g.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memcpy(Kq, &g[LQ::G_K], sizeof(double) * DQ::NU * DQ::NV);                      // K.leftCols(nv)
   std::memcpy(Kv, &g[LQ::G_K + DQ::NU * DQ::NV], sizeof(double) * DQ::NU * DQ::NV);   // K.rightCols(nv)
@@ -467,10 +742,10 @@ int idocp_ocp_dimc(const idocp_ocp_t* h) {
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual) {
   if (!h || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
-  const int N = h->N, dimc = idocp_ocp_dimc(h);
+  const int N = h->Ngrid, dimc = idocp_ocp_dimc(h);
   std::vector<double> sl((size_t)N * LQ::CON), du((size_t)N * LQ::CON);
-  HIP_TRY(hipMemcpyAsync(sl.data(), h->B.slack + (size_t)instance * N * LQ::CON, sl.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * N * LQ::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(sl.data(), h->B.slack + (size_t)instance * h->NS * LQ::CON, sl.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * h->NS * LQ::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const idocp_constraints_t& c = h->cons;
   const int use[4] = {c.joint_position_limits, c.joint_velocity_limits, c.joint_torque_limits, c.linearized_friction_cone};
@@ -499,18 +774,19 @@ int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n) {
 
 int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu, double* Quu, double* A, double* Bm,
                             double* lx, double* lu, double* Fx) {
-  if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->N) return IDOCP_E_ARG;
+  if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->Ngrid) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   const int nv = DQ::NV, nx = DQ::NX, nu = DQ::NU;
   std::vector<double> k(LQ::KKT);
-  HIP_TRY(hipMemcpyAsync(k.data(), h->B.kkt + ((size_t)instance * (h->N + 1) + stage) * LQ::KKT, k.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(k.data(), h->B.kkt + ((size_t)instance * h->NS + stage) * LQ::KKT, k.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memcpy(Qxx, &k[LQ::K_QXX], sizeof(double) * nx * nx);
   std::memcpy(Qxu, &k[LQ::K_QXU], sizeof(double) * nx * nu);
   std::memcpy(Quu, &k[LQ::K_QUU], sizeof(double) * nu * nu);
   std::memset(A, 0, sizeof(double) * nx * nx);
   std::memset(Bm, 0, sizeof(double) * nx * nu);
-  const double dt = h->T / h->N;
+  double dt = h->T / h->N;
+  for (const OcpNode& nd : h->chain) if (nd.slot == stage) dt = nd.dtq;
   for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) {
     double fqq = (r == c) ? 1.0 : 0.0, fqv = (r == c) ? dt : 0.0;
     if (r < 6 && c < 6) { fqq = k[LQ::K_FQQ + r + 6 * c]; fqv = k[LQ::K_FQV + r + 6 * c]; }

@@ -33,9 +33,12 @@ __device__ __forceinline__ double ocpLimit(const OcpProblem* __restrict__ P, int
     default: return P->u_max[r];
   }
 }
-__device__ __forceinline__ bool ocpRowValid(const OcpProblem* __restrict__ P, int comp, int stage) {
-  if (comp < 2) return P->use_q_limits && stage >= 2;
-  if (comp < 4) return P->use_v_limits && stage >= 1;
+// which IPM rows exist on a stage (constraints_data.hpp:18-42): `level` is the time step the constraint data was created
+// with (grid stage; 0 on aux / lift stages); impulse stages only carry the impulse friction cone
+__device__ __forceinline__ bool ocpRowValid(const OcpProblem* __restrict__ P, int comp, int level, bool impulse) {
+  if (impulse) return comp == 6 && P->use_impulse_friction_cone != 0;
+  if (comp < 2) return P->use_q_limits && level >= 2;
+  if (comp < 4) return P->use_v_limits && level >= 1;
   if (comp < 6) return P->use_u_limits != 0;
   return P->use_friction_cone != 0;
 }
@@ -82,28 +85,37 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
-  const double dt = P->dt;
+  const int M = P->M;
   const int tid = threadIdx.x, nt = 256;
-  const long unit = blockIdx.x;                   // over batch * (N + 1)
-  const long b = unit / (N + 1);
-  const int i = (int)(unit - b * (N + 1));
-  const bool terminal = (i == N);
+  const long unit = blockIdx.x;                   // over batch * M: one stage of the chain per workgroup
+  const long b = unit / M;
+  const int pos = (int)(unit - b * M);
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const bool terminal = (pos == M - 1);
+  const bool impulse = nd->kind == 1;
+  const int i = nd->level;                          // constraint gating level
+  const double dt = nd->dt;                         // scaling of cost / constraints / dynamics multipliers (1 on impulse stages)
+  const double dtq = nd->dtq;                       // q+ = q (+) dtq v (0 on impulse stages)
   // DIMF >= 0: the number of active contact rows is a compile-time constant (every loop bound and
-  // index division below folds); DIMF < 0: read it from the problem record.
-  const int dimf = (DIMF >= 0) ? DIMF : P->dimf, dimvf = NV + dimf;
-  const double* __restrict__ s_g = B.sol + unit * L::SOL;
+  // index division below folds); DIMF < 0: read it from the stage's node.
+  const int dimf = (DIMF >= 0) ? DIMF : nd->dimf, dimvf = NV + dimf;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ s_g = B.sol + rec * L::SOL;
+  const double* __restrict__ sn_g = B.sol + (b * P->NS + (terminal ? nd->slot : nd->next)) * L::SOL;
   const double* s = &sm[S::SOLS];                   // LDS copies of this stage's and the next stage's solution records
-  const double* sn = &sm[S::SOLN];                  // (only valid for i < N)
+  const double* sn = &sm[S::SOLN];                  // (only valid for non-terminal stages)
   const double* q = s + L::S_Q;
-  const double* __restrict__ qref = B.q_ref + (long)i * NQ;
-  const double* __restrict__ q_prev = (i == 0) ? (q0 + b * NQ) : (s_g - L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
-  const long su = b * N + i;                       // stage index without terminal records
+  const double* __restrict__ qref = B.q_ref + (long)pos * NQ;
+  const long su = rec;
   const bool stamp = (!RESIDUAL) && tid == 0 && unit == 7 && B.prof != nullptr;
 #define STAMP(k) do { if (stamp) B.prof[k] = wall_clock64(); } while (0)
   STAMP(0);
-  double* kk = B.kkt + unit * L::KKT;
-  double* ee = B.exp + unit * L::EXP;
+  double* kk = B.kkt + rec * L::KKT;
+  double* ee = B.exp + rec * L::EXP;
+  // cost weights of this stage: the impulse stage has its own (trotting_configuration_space_cost.cpp:308-376)
+  const double* __restrict__ w_q = impulse ? P->qi_weight : P->q_weight;
+  const double* __restrict__ w_v = impulse ? P->vi_weight : P->v_weight;
+  const double* __restrict__ w_a = impulse ? P->dvi_weight : P->a_weight;
 
   // ---- A. load the lin record, clear the accumulators ----
   if (!terminal) {
@@ -111,14 +123,14 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     for (int e = tid; e < NVF * NX + NV * NV + NF * NV; e += nt) sm[S::DIDC + e] = lin[e];       // DIDC, MM, JM are contiguous in both
     if (tid < NVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
   }
-  for (int e = tid; e < (terminal ? L::SOL : 2 * L::SOL); e += nt) sm[S::SOLS + e] = s_g[e];     // this and the next record
+  for (int e = tid; e < L::SOL; e += nt) { sm[S::SOLS + e] = s_g[e]; if (!terminal) sm[S::SOLN + e] = sn_g[e]; }     // this and the next stage of the chain
   if (!terminal) for (int e = tid; e < L::CON; e += nt) { sm[S::SLK + e] = B.slack[su * L::CON + e]; sm[S::DUL + e] = B.dual[su * L::CON + e]; }
   for (int e = tid; e < NF * NF; e += nt) sm[S::QFF + e] = 0.0;
   if (tid == 0) s_ok = 1;
   STAMP(1);
   // ---- B. Lie-group terms of the floating base (from ocp_lie_kernel) ----
   {
-    const double* __restrict__ zz = B.lie + unit * L::LIE;
+    const double* __restrict__ zz = B.lie + rec * L::LIE;
     if (tid < 36) {
       sm[S::JQ + tid] = zz[L::Z_JQ + tid]; sm[S::FQQ + tid] = zz[L::Z_FQQ + tid]; sm[S::FQQI + tid] = zz[L::Z_FQQI + tid];
       sm[S::FQQP + tid] = zz[L::Z_FQQP + tid]; sm[S::FQQPI + tid] = zz[L::Z_FQQPI + tid];
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
     if (RESIDUAL) {
       __syncthreads();
-      if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[unit] = e; }
+      if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[rec] = e; }
       return;
     }
     for (int e = tid; e < NX * NX; e += nt) {
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* dual = &sm[S::DUL];
   // bm = [beta ; mu_stack]
   if (tid < NV) sm[S::BM + tid] = s[L::S_BETA + tid];
-  if (tid < NC && P->active[tid]) for (int x = 0; x < 3; ++x) sm[S::BM + NV + P->row_of[tid] + x] = s[L::S_MU + 3 * tid + x];
+  if (tid < NC && nd->active[tid]) for (int x = 0; x < 3; ++x) sm[S::BM + NV + nd->row_of[tid] + x] = s[L::S_MU + 3 * tid + x];
   __syncthreads();
   double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below)
   if (tid < NV) {
@@ -181,27 +193,27 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     // cost + state equation
     if (r < 6) {
       lq = 0.0;
-      for (int m2 = 0; m2 < 6; ++m2) lq += sm[S::JQ + m2 + 6 * r] * P->q_weight[m2] * sm[S::QDIFF + m2];
+      for (int m2 = 0; m2 < 6; ++m2) lq += sm[S::JQ + m2 + 6 * r] * w_q[m2] * sm[S::QDIFF + m2];
       lq *= dt;
       double t1 = 0.0;
       for (int m2 = 0; m2 < 6; ++m2) t1 += sm[S::FQQ + m2 + 6 * r] * sn[L::S_LMD + m2] + sm[S::FQQP + m2 + 6 * r] * s[L::S_LMD + m2];
       lq += t1;
-      sm[S::FQ + r] = sm[S::FQ6 + r] + dt * vr;
+      sm[S::FQ + r] = sm[S::FQ6 + r] + dtq * vr;
     } else {
-      lq = dt * P->q_weight[r] * (q[r + 1] - qref[r + 1]) + lmdn - lmd;
-      hq = dt * P->q_weight[r];
-      sm[S::FQ + r] = q[r + 1] - sn[L::S_Q + r + 1] + dt * vr;
+      lq = dt * w_q[r] * (q[r + 1] - qref[r + 1]) + lmdn - lmd;
+      hq = dt * w_q[r];
+      sm[S::FQ + r] = q[r + 1] - sn[L::S_Q + r + 1] + dtq * vr;
     }
-    lv = dt * P->v_weight[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r])) + dt * lmdn + gmmn - gmm;
-    la = dt * P->a_weight[r] * ar + dt * gmmn;
-    hv = dt * P->v_weight[r];
-    ha = dt * P->a_weight[r];
+    lv = dt * w_v[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r])) + dtq * lmdn + gmmn - gmm;
+    la = dt * w_a[r] * ar + dt * gmmn;
+    hv = dt * w_v[r];
+    ha = dt * w_a[r];
     sm[S::FV + r] = vr + dt * ar - sn[L::S_V + r];
     // joint position / velocity limits act on the actuated joints (tail(dimu))
     if (r >= 6) {
       const int j = r - 6;
       for (int c = 0; c < 4; ++c) {
-        if (!ocpRowValid(P, c, i)) continue;
+        if (!ocpRowValid(P, c, i, impulse)) continue;
         const double sgn = (c & 1) ? 1.0 : -1.0;
         const double x = (c < 2) ? q[r + 1] : vr;
         const double sl = slack[c * NU + j], du = dual[c * NU + j];
@@ -217,6 +229,14 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const double dv = dotAny(&sm[S::DIDC + NVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
     const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + NF * r], 1, &sm[S::BM + NV], 1, dimf);
     lq += dt * dq; lv += dt * dv; la += dt * da;
+    // ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:49-51): + Phi^T xi
+    if (nd->sw_dimi > 0) {
+      const double* __restrict__ W = B.swc + rec * L::SWC;
+      for (int j = 0; j < nd->sw_dimi; ++j) {
+        const double xi = s[L::S_XI + j];
+        lq += W[L::W_PHIX + j + NF * r] * xi; lv += W[L::W_PHIX + j + NF * (NV + r)] * xi; la += W[L::W_PHIA + j + NF * r] * xi;
+      }
+    }
     sm[S::LQ + r] = lq; sm[S::LV + r] = lv; sm[S::LA + r] = la; sm[S::QAA + r] = ha;
     if (!RESIDUAL) {
       sm[S::HQD + r] = hq;
@@ -226,13 +246,15 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       err_local += lq * lq + lv * lv + la * la + sm[S::FQ + r] * sm[S::FQ + r] + sm[S::FV + r] * sm[S::FV + r] + dt * dt * idr * idr;
     }
   } else if (tid >= 64 && tid < 64 + NU) {
-    // torque rows: lu, Quu diagonal
+    // torque rows: lu, Quu diagonal.  An impulse stage has no torques: lu = 0 and a unit Quu make the
+    // Riccati step below return K = 0, k = 0 and P = F, i.e. ImpulseSplitRiccatiFactorizer's recursion.
     const int j = tid - 64;
     const double u = s[L::S_U + j];
     double lu = dt * P->u_weight[j] * (u - P->u_ref[j]) - dt * s[L::S_BETA + 6 + j];
     double h = dt * P->u_weight[j];
+    if (impulse) { lu = 0.0; h = 1.0; }
     for (int c = 4; c < 6; ++c) {
-      if (!ocpRowValid(P, c, i)) continue;
+      if (!ocpRowValid(P, c, i, impulse)) continue;
       const double sgn = (c & 1) ? 1.0 : -1.0;
       const double sl = slack[c * NU + j], du = dual[c * NU + j];
       const double res = sgn * (u - ocpLimit(P, c, j)) + sl, duality = sl * du - P->barrier;
@@ -246,21 +268,22 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   } else if (tid >= 128 && tid < 128 + 6) {
     // passive (floating-base) rows: lu_passive = dt nu_passive - dt beta.head(6)
     const int r = tid - 128;
-    const double lup = dt * s[L::S_NUP + r] - dt * s[L::S_BETA + r];
+    const double lup = impulse ? 0.0 : dt * s[L::S_NUP + r] - dt * s[L::S_BETA + r];
     sm[S::LUP + r] = lup;
     if (RESIDUAL) err_local += lup * lup;
   } else if (tid >= 192 && tid < 192 + NC) {
     // contact-force rows: ContactForceCost + LinearizedFrictionCone + (- dt J beta)
     const int c = tid - 192;
-    if (P->active[c]) {
-      const int row = P->row_of[c];
+    if (nd->active[c]) {
+      const int row = nd->row_of[c];
       double lf[3], f[3];
       for (int x = 0; x < 3; ++x) {
         f[x] = s[L::S_F + 3 * c + x];
-        lf[x] = dt * P->f_weight[c][x] * (f[x] - P->f_ref[c][x]);
-        if (!RESIDUAL) sm[S::QFF + (row + x) + NF * (row + x)] = dt * P->f_weight[c][x];
+        const double wf = impulse ? P->fi_weight[c][x] : P->f_weight[c][x], rf = impulse ? P->fi_ref[c][x] : P->f_ref[c][x];
+        lf[x] = dt * wf * (f[x] - rf);
+        if (!RESIDUAL) sm[S::QFF + (row + x) + NF * (row + x)] = dt * wf;
       }
-      if (ocpRowValid(P, 6, i)) {
+      if (ocpRowValid(P, 6, i, impulse)) {
         double dd[5];
         for (int r = 0; r < 5; ++r) {
           const int idx = L::C_FRIC + 5 * c + r;
@@ -293,9 +316,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   if (RESIDUAL) {
     // SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264)
+    if (nd->sw_dimi > 0 && tid >= 200 && tid < 200 + nd->sw_dimi) {
+      const double pr = B.swc[rec * L::SWC + L::W_P + tid - 200];
+      err_local += pr * pr;
+    }
     sm[S::ERR + tid] = err_local + dt * dt * err_ipm;
     __syncthreads();
-    if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[unit] = e; }
+    if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[rec] = e; }
     return;
   }
   __syncthreads();
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   if (tid < 36) {
     const int c = tid / 6, r = tid - 6 * c;
     double acc = 0.0;
-    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * P->q_weight[m2] * sm[S::JQ + m2 + 6 * c];
+    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * w_q[m2] * sm[S::JQ + m2 + 6 * c];
     sm[S::QB6 + tid] = dt * acc;
   }
   // ---- D. condenseForwardEuler (state_equation.hxx:40-63) ----
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     double acc = 0.0;
     for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQQ + m2 + 6 * c];
     kk[L::K_FQQ + e] = -acc;                       // Fqq = -Fqq_inv * Fqq
-    kk[L::K_FQV + e] = -dt * sm[S::FQQI + e];      // Fqv = -dt Fqq_inv
+    kk[L::K_FQV + e] = -dtq * sm[S::FQQI + e];     // Fqv = -dt Fqq_inv (0 on impulse stages)
     ee[L::E_FQQPI + e] = sm[S::FQQPI + e];
   }
   if (tid >= 128 && tid < 128 + 6) {
@@ -352,6 +379,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   __syncthreads();
 
+  const double hu = nd->has_u ? 1.0 : 0.0;          // impulse stages have no torque variables: Qafu = 0, Fvu = 0
   STAMP(7);
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
   if ((dimvf & 1) == 0) mmTN22(&sm[S::MJD], NVF, &sm[S::MJ], NVF, &sm[S::DIDC], NVF, dimvf, NX, dimvf, 1.0, false, tid, nt);   // MJ symmetric
@@ -370,7 +398,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     double val;
     if (r < NV) val = sm[S::QAA + r] * sm[S::MJ + r + NVF * c];
     else val = dotAny(&sm[S::QFF + (r - NV)], NF, &sm[S::MJ + NV + NVF * c], 1, dimf);
-    sm[S::QAFU + r + NVF * c] = val;
+    sm[S::QAFU + r + NVF * c] = hu * val;
   }
   if (tid < dimvf) {
     const int r = tid;
@@ -403,7 +431,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;
   } else if (tid >= 64 && tid < 64 + NV) {          // [lu_passive; lu] += MJ.topRows(NV) laf ; Fv -= dt MJIDC
     const int r = tid - 64;
-    const double acc = dotAny(&sm[S::MJ + r], NVF, &sm[S::LAF], 1, dimvf);
+    const double acc = hu * dotAny(&sm[S::MJ + r], NVF, &sm[S::LAF], 1, dimvf);
     if (r < 6) sm[S::LUP + r] += acc; else sm[S::LU + r - 6] += acc;
     sm[S::FV + r] -= dt * sm[S::MJIDC + r];
   }
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + NVF * c];
     kk[L::K_FVV + e] = -dt * sm[S::MJD + r + NVF * (NV + c)] + (r == c ? 1.0 : 0.0);
   }
-  for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = dt * sm[S::MJ + r + NVF * (6 + c)]; }
+  for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = hu * dt * sm[S::MJ + r + NVF * (6 + c)]; }
   if (tid < NV) {
     kk[L::K_LX + tid] = sm[S::LQ + tid]; kk[L::K_LX + NV + tid] = sm[S::LV + tid];
     kk[L::K_FX + tid] = sm[S::FQ + tid]; kk[L::K_FX + NV + tid] = sm[S::FV + tid];
@@ -427,8 +455,30 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   for (int e = tid; e < NVF * NU; e += nt) ee[L::E_QAFU + e] = sm[S::QAFU + NVF * 6 + e];          // columns 6.. of Qafu_full
   if (tid < NVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
+  // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199) ----
+  if (nd->sw_dimi > 0) {
+    const int dimi = nd->sw_dimi;
+    double* __restrict__ W = B.swc + rec * L::SWC;
+    for (int e = tid; e < dimi * NX; e += nt) {           // Phix -= Phia MJtJinv_dIDCdqv.topRows(nv)
+      const int c = e / dimi, j = e - c * dimi;
+      double acc = 0.0;
+      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + j + NF * m2] * sm[S::MJD + m2 + NVF * c];
+      W[L::W_PHIX + j + NF * c] -= acc;
+    }
+    for (int e = tid; e < dimi * NU; e += nt) {           // Phiu = Phia MJtJinv.block(0, 6, nv, nu)
+      const int c = e / dimi, j = e - c * dimi;
+      double acc = 0.0;
+      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + j + NF * m2] * sm[S::MJ + m2 + NVF * (6 + c)];
+      W[L::W_PHIU + j + NF * c] = acc;
+    }
+    if (tid < dimi) {                                     // P -= Phia MJtJinv_IDC.head(nv)
+      double acc = 0.0;
+      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + tid + NF * m2] * sm[S::MJIDC + m2];
+      W[L::W_P + tid] -= acc;
+    }
+  }
   STAMP(10);
-  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + i;
+  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + pos;
 #undef STAMP
 }
 
@@ -443,25 +493,27 @@ __global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double*
   using L = OcpLayout<D>;
   constexpr int NQ = D::NQ;
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
+  const int M = P->M;
   const long unit = (long)blockIdx.x * 64 + threadIdx.x;
-  if (unit >= (long)P->batch * (N + 1)) return;
-  const long b = unit / (N + 1);
-  const int i = (int)(unit - b * (N + 1));
+  if (unit >= (long)P->batch * M) return;
+  const long b = unit / M;
+  const int pos = (int)(unit - b * M);
+  const OcpNode* __restrict__ nd = B.nodes + pos;
   const int task = blockIdx.y;
-  const double* __restrict__ s = B.sol + unit * L::SOL;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
-  double* __restrict__ zz = B.lie + unit * L::LIE;
+  double* __restrict__ zz = B.lie + rec * L::LIE;
   double R[9], p[3], Ja[36], Jb[36], d6[6];
   if (task == 0) {
-    lieRelative(B.q_ref + (long)i * NQ, q, R, p);
+    lieRelative(B.q_ref + (long)pos * NQ, q, R, p);
     lieLog6(R, p, d6);
     lieJlog6(R, p, Ja);
     for (int k = 0; k < 36; ++k) zz[L::Z_JQ + k] = Ja[k];
     for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
   } else if (task == 1) {
-    if (i == N) return;
-    lieRelative(s + L::SOL + L::S_Q, q, R, p);
+    if (pos == M - 1) return;
+    lieRelative(B.sol + (b * P->NS + nd->next) * L::SOL + L::S_Q, q, R, p);
     lieLog6(R, p, d6);
     lieJlog6(R, p, Ja);
     for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
@@ -470,7 +522,7 @@ __global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double*
     lieBlockInverse(Jb, Ja);
     for (int k = 0; k < 36; ++k) zz[L::Z_FQQI + k] = Ja[k];
   } else {
-    const double* __restrict__ q_prev = (i == 0) ? (q0 + b * NQ) : (s - L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
+    const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * NQ) : (B.sol + (b * P->NS + nd->prev) * L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
     lieRelative(q, q_prev, R, p);
     lieJlog6(R, p, Ja);
     lieDDiffArg0(R, p, Ja, Jb);
@@ -480,8 +532,10 @@ __global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double*
   }
 }
 
+// M = chain length; dimf >= 0: every non-terminal stage of the chain is a regular stage with `dimf` active contact rows
+// (enables the compile-time instantiation), -1: mixed chain.
 template <typename D>
-static void launchCondense(const OcpBuffers& B, long batch, int N, int dimf, const double* q0, hipStream_t st, bool residual) {
+static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st, bool residual) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
@@ -490,7 +544,7 @@ static void launchCondense(const OcpBuffers& B, long batch, int N, int dimf, con
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
-  const unsigned blocks = (unsigned)(batch * (N + 1));
+  const unsigned blocks = (unsigned)(batch * M);
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
   else if (dimf == D::NF) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0);      // all feet in contact
@@ -498,12 +552,12 @@ static void launchCondense(const OcpBuffers& B, long batch, int N, int dimf, con
 }
 
 template <typename D>
-void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int N, int dimf, const double* q0, hipStream_t st) {
-  launchCondense<D>(B, batch, N, dimf, q0, st, false);
+void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st) {
+  launchCondense<D>(B, batch, M, dimf, q0, st, false);
 }
 template <typename D>
-void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st) {
-  launchCondense<D>(B, batch, N, -1, q0, st, true);
+void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st) {
+  launchCondense<D>(B, batch, M, -1, q0, st, true);
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);

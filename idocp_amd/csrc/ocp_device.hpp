@@ -24,14 +24,14 @@ struct LeggedDims {
 template <typename D>
 struct OcpLayout {
   static constexpr int NV = D::NV, NQ = D::NQ, NU = D::NU, NF = D::NF, NX = D::NX, NVF = D::NVF, NC = D::NC;
-  // solution (split_solution.hxx:10-31): lmd gmm q v a u beta f mu nu_passive
+  // solution (split_solution.hxx:10-31): lmd gmm q v a u beta f mu nu_passive xi  (a = dv on impulse stages)
   static constexpr int S_LMD = 0, S_GMM = NV, S_Q = 2 * NV, S_V = S_Q + NQ, S_A = S_V + NV, S_U = S_A + NV, S_BETA = S_U + NU,
-                       S_F = S_BETA + NV, S_MU = S_F + NF, S_NUP = S_MU + NF;
-  static constexpr int SOL = roundUp16(S_NUP + 6);
+                       S_F = S_BETA + NV, S_MU = S_F + NF, S_NUP = S_MU + NF, S_XI = S_NUP + 6;
+  static constexpr int SOL = roundUp16(S_XI + NF);
   // direction (split_direction.hxx:8-23)
   static constexpr int D_LMD = 0, D_GMM = NV, D_Q = 2 * NV, D_V = 3 * NV, D_A = 4 * NV, D_U = 5 * NV, D_BETA = D_U + NU,
-                       D_F = D_BETA + NV, D_MU = D_F + NF, D_NUP = D_MU + NF;
-  static constexpr int DIR = roundUp16(D_NUP + 6);
+                       D_F = D_BETA + NV, D_MU = D_F + NF, D_NUP = D_MU + NF, D_XI = D_NUP + 6;
+  static constexpr int DIR = roundUp16(D_XI + NF);
   // IPM rows: 6 joint-limit components x NU, then 5 friction-cone rows per contact
   static constexpr int C_FRIC = 6 * NU, NCON = 6 * NU + 5 * NC;
   static constexpr int CON = roundUp16(NCON);
@@ -56,21 +56,44 @@ struct OcpLayout {
   static constexpr int LIE = roundUp16(196);
   static constexpr int G_K = 0, G_k = NU * NX;
   static constexpr int GAIN = roundUp16(G_k + NU);
+  // switching-constraint record of a stage two steps ahead of an impulse (SplitStateConstraintJacobian +
+  // SplitConstrainedRiccatiFactorization): P (NF), Phix (NF x NX, ld NF), Phia (NF x NV), Phiu (NF x NU),
+  // then the multiplier policy dxi = M dx + m written by the Riccati sweep: M (NF x NX), m (NF)
+  static constexpr int W_P = 0, W_PHIX = NF, W_PHIA = W_PHIX + NF * NX, W_PHIU = W_PHIA + NF * NV, W_M = W_PHIU + NF * NU,
+                       W_m = W_M + NF * NX;
+  static constexpr int SWC = roundUp16(W_m + NF);
+};
+
+// One stage of the CHAIN (time order): stage, [impulse, aux | lift], stage, ..., terminal.  Every stage owns a fixed
+// storage SLOT (grid stage i -> i, impulse k -> N+1+k, aux k -> N+1+E+k, lift k -> N+1+2E+k, like the separate arrays
+// of the reference's hybrid_container.hpp:60-168); the chain is rebuilt by the host-side discretiser
+// (OCPDiscretizer, ocp_discretizer.hxx:65-374) and says who the neighbours are.
+struct OcpNode {
+  int slot, next, prev;     // prev = -1: the predecessor is the initial state
+  int kind;                 // 0 stage, 1 impulse, 2 aux, 3 lift, 4 terminal
+  int level;                // time step for the constraint gating (constraints_data.hpp:18-42): stage index, 0 aux / lift
+  int has_u;                // 0 on impulse stages (no torque variables)
+  int dimf, active[IDOCP_MAX_CONTACTS], row_of[IDOCP_MAX_CONTACTS];   // contact (or impulse) status of this stage
+  double dt;                // scaling of cost / constraint / dynamics multipliers: the time step, 1 on impulse stages
+  double dtq;               // q+ = q (+) dtq v: the time step, 0 on impulse stages
+  double contact_point[IDOCP_MAX_CONTACTS][3];
+  int sw_dimi, sw_active[IDOCP_MAX_CONTACTS], sw_row[IDOCP_MAX_CONTACTS];     // switching constraint carried by this stage
+  double sw_dt1, sw_dt2, sw_point[IDOCP_MAX_CONTACTS][3];
 };
 
 struct OcpProblem {
-  int N, batch;
-  double T, dt;
+  int N, batch;            // N = grid intervals (N_ideal)
+  int M, NS;               // chain length of the current discretisation; storage slots per instance
+  double T, dt;            // dt = T / N: Baumgarte time step and the time step of the regular stages
   double v_ref[IDOCP_MAX_NV], u_ref[IDOCP_MAX_NV];
   double q_weight[IDOCP_MAX_NV], v_weight[IDOCP_MAX_NV], a_weight[IDOCP_MAX_NV], u_weight[IDOCP_MAX_NV];
   double qf_weight[IDOCP_MAX_NV], vf_weight[IDOCP_MAX_NV];
   double f_weight[IDOCP_MAX_CONTACTS][3], f_ref[IDOCP_MAX_CONTACTS][3];
   double q_min[IDOCP_MAX_NV], q_max[IDOCP_MAX_NV], v_max[IDOCP_MAX_NV], u_max[IDOCP_MAX_NV];
-  int use_q_limits, use_v_limits, use_u_limits, use_friction_cone;
+  double qi_weight[IDOCP_MAX_NV], vi_weight[IDOCP_MAX_NV], dvi_weight[IDOCP_MAX_NV];         // impulse stages
+  double fi_weight[IDOCP_MAX_CONTACTS][3], fi_ref[IDOCP_MAX_CONTACTS][3];
+  int use_q_limits, use_v_limits, use_u_limits, use_friction_cone, use_impulse_friction_cone;
   double mu, barrier, fraction_rate;
-  // contact status of the horizon (uniform): active flags, packed row of each contact (-1 inactive), dimf
-  int active[IDOCP_MAX_CONTACTS], row_of[IDOCP_MAX_CONTACTS], dimf;
-  double contact_point[IDOCP_MAX_CONTACTS][3];     // world
   double contact_R[IDOCP_MAX_CONTACTS][9], contact_p[IDOCP_MAX_CONTACTS][3];   // frame placement in the tip joint
   double baumgarte_time_step;
 };
@@ -78,20 +101,23 @@ struct OcpProblem {
 struct OcpBuffers {
   const DevModel* model;
   const OcpProblem* prob;
-  const double* q_ref;   // [N+1][NQ] reference configuration of every stage (time-varying cost)
-  double* sol;           // [batch][N+1][SOL]
-  double* dir;           // [batch][N+1][DIR]
-  double* slack;         // [batch][N][CON]
-  double* dual;          // [batch][N][CON]
-  double* lin;           // [batch][N][LIN]
-  double* lie;           // [batch][N+1][LIE]
-  double* kkt;           // [batch][N+1][KKT]   (terminal record holds Qxx and lx only)
-  double* exp;           // [batch][N+1][EXP]   (terminal record holds Fqq_prev_inv only)
-  double* ric;           // [batch][N+1][RIC]
-  double* gain;          // [batch][N][GAIN]
-  double* step_stage;    // [batch][N][2]
+  const OcpNode* nodes;  // [M] the chain
+  const double* q_ref;   // [M][NQ] reference configuration of every stage of the chain (time-varying cost)
+  // per-stage arrays, indexed [instance][slot] (NS slots per instance)
+  double* sol;           // [batch][NS][SOL]
+  double* dir;           // [batch][NS][DIR]
+  double* slack;         // [batch][NS][CON]
+  double* dual;          // [batch][NS][CON]
+  double* lin;           // [batch][NS][LIN]
+  double* lie;           // [batch][NS][LIE]
+  double* kkt;           // [batch][NS][KKT]   (terminal record holds Qxx and lx only)
+  double* exp;           // [batch][NS][EXP]   (terminal record holds Fqq_prev_inv only)
+  double* ric;           // [batch][NS][RIC]
+  double* gain;          // [batch][NS][GAIN]
+  double* swc;           // [batch][NS][SWC]   (only stages that carry a switching constraint)
+  double* step_stage;    // [batch][NS][2]
   double* step;          // [batch][2]
-  double* err_stage;     // [batch][N+1]
+  double* err_stage;     // [batch][NS]
   double* err;           // [batch]
   int* status;           // [batch]
   long long* prof;       // [64] diagnostic: wall-clock stamps of one workgroup of the condensation kernel

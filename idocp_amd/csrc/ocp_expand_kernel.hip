@@ -26,9 +26,11 @@ __device__ __forceinline__ double ocpLimit2(const OcpProblem* __restrict__ P, in
     default: return P->u_max[r];
   }
 }
-__device__ __forceinline__ bool ocpRowValid2(const OcpProblem* __restrict__ P, int comp, int stage) {
-  if (comp < 2) return P->use_q_limits && stage >= 2;
-  if (comp < 4) return P->use_v_limits && stage >= 1;
+// which IPM rows exist on a stage (constraints_data.hpp:18-42); see ocpRowValid in ocp_condense_kernel.hip
+__device__ __forceinline__ bool ocpRowValid2(const OcpProblem* __restrict__ P, int comp, int level, bool impulse) {
+  if (impulse) return comp == 6 && P->use_impulse_friction_cone != 0;
+  if (comp < 2) return P->use_q_limits && level >= 2;
+  if (comp < 4) return P->use_v_limits && level >= 1;
   if (comp < 6) return P->use_u_limits != 0;
   return P->use_friction_cone != 0;
 }
@@ -46,14 +48,14 @@ __device__ __forceinline__ double f2b(double rate, double x, double dx, double c
 // One IPM row (joint limit or friction cone) of stage i: value of the
 // constrained function g(x) and its directional derivative dg.
 template <typename D>
-__device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, int i, int row, const double* __restrict__ s,
+__device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd, int row, const double* __restrict__ s,
                                        const double* dq, const double* dv, const double* du, const double* df_slot, double* g,
                                        double* dg) {
   using L = OcpLayout<D>;
   constexpr int NU = D::NU;
   if (row < L::C_FRIC) {
     const int c = row / NU, j = row - c * NU;
-    if (!ocpRowValid2(P, c, i)) return false;
+    if (!ocpRowValid2(P, c, nd->level, nd->kind == 1)) return false;
     const double sgn = (c & 1) ? 1.0 : -1.0;
     const double x = (c < 2) ? s[L::S_Q + 7 + j] : ((c < 4) ? s[L::S_V + 6 + j] : s[L::S_U + j]);
     const double dx = (c < 2) ? dq[6 + j] : ((c < 4) ? dv[6 + j] : du[j]);
@@ -62,7 +64,7 @@ __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, int i, 
     return true;
   }
   const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
-  if (!ocpRowValid2(P, 6, i) || !P->active[c]) return false;
+  if (!ocpRowValid2(P, 6, nd->level, nd->kind == 1) || !nd->active[c]) return false;
   double gg = 0.0, dd = 0.0;
   for (int x = 0; x < 3; ++x) { const double j = frictionJacEntry2(P->mu, r, x); gg += j * s[L::S_F + 3 * c + x]; dd += j * df_slot[3 * c + x]; }
   *g = gg; *dg = dd;
@@ -75,15 +77,18 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
   __shared__ double dx[NX], du[NU], dfs[NF];
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
+  const int M = P->M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
-  const long b = unit / (N + 1);
-  const int i = (int)(unit - b * (N + 1));
-  double* __restrict__ dd = B.dir + unit * L::DIR;
-  const double* __restrict__ rr = B.ric + unit * L::RIC;
+  const long b = unit / M;
+  const int pos = (int)(unit - b * M);
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const bool terminal = (pos == M - 1);
+  const long rec = b * P->NS + nd->slot;
+  double* __restrict__ dd = B.dir + rec * L::DIR;
+  const double* __restrict__ rr = B.ric + rec * L::RIC;
   if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
-  if (lane < NU && i < N) du[lane] = dd[L::D_U + lane];
+  if (lane < NU && !terminal) du[lane] = dd[L::D_U + lane];
   if (lane < NF) dfs[lane] = 0.0;
   __syncthreads();
   if (lane < NV) {
@@ -95,11 +100,19 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     }
     dd[L::D_LMD + r] = dl; dd[L::D_GMM + r] = dg;
   }
-  if (i == N) return;
-  const long su = b * N + i;
-  const double* __restrict__ ee = B.exp + unit * L::EXP;
-  const double* __restrict__ s = B.sol + unit * L::SOL;
-  const int dimf = P->dimf, dimvf = NV + dimf;
+  if (terminal) return;
+  const long su = rec;
+  const double* __restrict__ ee = B.exp + rec * L::EXP;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  const int dimf = nd->dimf, dimvf = NV + dimf;
+  // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145): dxi = M dx + m
+  if (nd->sw_dimi > 0 && lane >= 32 && lane < 32 + nd->sw_dimi) {
+    const int l = lane - 32;
+    const double* __restrict__ W = B.swc + rec * L::SWC;
+    double acc = W[L::W_m + l];
+    for (int c = 0; c < NX; ++c) acc += W[L::W_M + l + NF * c] * dx[c];
+    dd[L::D_XI + l] = acc;
+  }
   if (lane < dimvf) {
     const int r = lane;
     double acc = -ee[L::E_MJIDC + r];
@@ -109,8 +122,8 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     else {
       // d.df() *= -1; packed active row -> contact slot
       const int pr = r - NV;
-      for (int c = 0; c < NC; ++c) if (P->active[c] && pr >= P->row_of[c] && pr < P->row_of[c] + 3) {
-        const int slot = 3 * c + (pr - P->row_of[c]);
+      for (int c = 0; c < NC; ++c) if (nd->active[c] && pr >= nd->row_of[c] && pr < nd->row_of[c] + 3) {
+        const int slot = 3 * c + (pr - nd->row_of[c]);
         dfs[slot] = -acc; dd[L::D_F + slot] = -acc;
       }
     }
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   double ps = 1.0, ds = 1.0;
   for (int row = lane; row < L::NCON; row += 64) {
     double g, dg;
-    if (!ipmRow<D>(P, i, row, s, dx, dx + NV, du, dfs, &g, &dg)) continue;
+    if (!ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) continue;
     const double sl = slack[row], dl = dual[row];
     const double res = g + sl, duality = sl * dl - P->barrier;
     const double dslack = -dg - res;
@@ -136,10 +149,13 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
 
 __global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
+  const int M = P->M;
   const long b = blockIdx.x;
   double ps = 1.0, ds = 1.0;
-  for (int i = threadIdx.x; i < N; i += 64) { ps = fmin(ps, B.step_stage[(b * N + i) * 2]); ds = fmin(ds, B.step_stage[(b * N + i) * 2 + 1]); }
+  for (int i = threadIdx.x; i < M - 1; i += 64) {
+    const long rec = b * P->NS + B.nodes[i].slot;
+    ps = fmin(ps, B.step_stage[rec * 2]); ds = fmin(ds, B.step_stage[rec * 2 + 1]);
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { ps = fmin(ps, __shfl_xor(ps, off)); ds = fmin(ds, __shfl_xor(ds, off)); }
   if (threadIdx.x == 0) { B.step[b * 2] = ps; B.step[b * 2 + 1] = ds; }
@@ -147,10 +163,10 @@ __global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
 
 __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B) {
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
+  const int M = P->M;
   const long b = blockIdx.x;
   double e = 0.0;
-  for (int i = threadIdx.x; i <= N; i += 64) e += B.err_stage[b * (N + 1) + i];
+  for (int i = threadIdx.x; i < M; i += 64) e += B.err_stage[b * P->NS + B.nodes[i].slot];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
   if (threadIdx.x == 0) B.err[b] = sqrt(e);
@@ -162,26 +178,29 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
   __shared__ double dx[NX], du[NU], dfs[NF], laf[NVF + 2], dbm[NVF + 2], dlh[6];
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
-  const double dt = P->dt;
+  const int M = P->M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
-  const long b = unit / (N + 1);
-  const int i = (int)(unit - b * (N + 1));
+  const long b = unit / M;
+  const int pos = (int)(unit - b * M);
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const bool stage = (pos < M - 1);                 // not the terminal stage
+  const double dt = nd->dt;                         // 1 on impulse stages
+  const long rec = b * P->NS + nd->slot;
   const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
-  double* __restrict__ dd = B.dir + unit * L::DIR;
-  double* __restrict__ s = B.sol + unit * L::SOL;
-  const double* __restrict__ ee = B.exp + unit * L::EXP;
-  const int dimf = P->dimf, dimvf = NV + dimf;
+  double* __restrict__ dd = B.dir + rec * L::DIR;
+  double* __restrict__ s = B.sol + rec * L::SOL;
+  const double* __restrict__ ee = B.exp + rec * L::EXP;
+  const int dimf = nd->dimf, dimvf = NV + dimf;
   if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
   if (lane < 6) dlh[lane] = dd[L::D_LMD + lane];
-  if (i < N) {
+  if (stage) {
     if (lane < NU) du[lane] = dd[L::D_U + lane];
     if (lane < NF) dfs[lane] = dd[L::D_F + lane];
   }
   __syncthreads();
-  if (i < N) {
-    const double* __restrict__ dgn = dd + L::DIR + L::D_GMM;          // d[i+1].dgmm
+  if (stage) {
+    const double* __restrict__ dgn = B.dir + (b * P->NS + nd->next) * L::DIR + L::D_GMM;          // dgmm of the next stage of the chain
     // ---- ContactDynamics::computeCondensedDualDirection ----
     if (lane < dimvf) {
       const int r = lane;
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       for (int j = 0; j < NU; ++j) acc += ee[L::E_QUUP + r + 6 * j] * du[j];
       for (int c = 0; c < NX; ++c) acc += ee[L::E_QXUP + c + NX * r] * dx[c];
       for (int c = 0; c < NV; ++c) acc += dt * ee[L::E_MJ + r + NVF * c] * dgn[c];
-      dd[L::D_NUP + r] = -acc / dt;
+      dd[L::D_NUP + r] = nd->has_u ? -acc / dt : 0.0;
     }
     __syncthreads();
     if (lane < dimvf) {
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       if (r < NV) dd[L::D_BETA + r] = dbm[r];
       else {
         const int pr = r - NV;
-        for (int c = 0; c < NC; ++c) if (P->active[c] && pr >= P->row_of[c] && pr < P->row_of[c] + 3) dd[L::D_MU + 3 * c + (pr - P->row_of[c])] = dbm[r];
+        for (int c = 0; c < NC; ++c) if (nd->active[c] && pr >= nd->row_of[c] && pr < nd->row_of[c] + 3) dd[L::D_MU + 3 * c + (pr - nd->row_of[c])] = dbm[r];
       }
     }
   }
@@ -222,20 +241,20 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   }
   __syncthreads();
   // ---- IPM slack / dual update (needs the pre-update primal variables) ----
-  if (i < N) {
-    const long su = b * N + i;
+  if (stage) {
+    const long su = rec;
     double* __restrict__ slack = B.slack + su * L::CON;
     double* __restrict__ dual = B.dual + su * L::CON;
     for (int row = lane; row < L::NCON; row += 64) {
       double g, dg;
-      const bool valid = ipmRow<D>(P, i, row, s, dx, dx + NV, du, dfs, &g, &dg);
+      const bool valid = ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg);
       const double sl = slack[row], dl = dual[row];
       double dslack, ddual;
       if (valid) {
         const double res = g + sl, duality = sl * dl - P->barrier;
         dslack = -dg - res;
         ddual = -(dl * dslack + duality) / sl;
-      } else if (row >= L::C_FRIC && ocpRowValid2(P, 6, i)) {
+      } else if (row >= L::C_FRIC && ocpRowValid2(P, 6, nd->level, nd->kind == 1)) {
         dslack = 1.0; ddual = 1.0;       // rows of inactive contacts (linearized_friction_cone.cpp:162-163)
       } else {
         continue;
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
     s[L::S_GMM + r] += ap * dd[L::D_GMM + r];
     s[L::S_V + r] += ap * dx[NV + r];
     if (r >= 6) s[L::S_Q + r + 1] += ap * dx[r];
-    if (i < N) {
+    if (stage) {
       s[L::S_A + r] += ap * dd[L::D_A + r];
       s[L::S_BETA + r] += ap * dbm[r];
     }
@@ -262,12 +281,15 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
     lieIntegrateBase(s + L::S_Q, dx, ap, qn);
     for (int k = 0; k < 7; ++k) s[L::S_Q + k] = qn[k];
   }
-  if (i < N) {
-    if (lane >= 40 && lane < 40 + NU) s[L::S_U + lane - 40] += ap * du[lane - 40];
-    if (lane >= 52 && lane < 58) s[L::S_NUP + lane - 52] += ap * dd[L::D_NUP + lane - 52];
+  if (stage) {
+    if (nd->has_u) {
+      if (lane >= 40 && lane < 40 + NU) s[L::S_U + lane - 40] += ap * du[lane - 40];
+      if (lane >= 52 && lane < 58) s[L::S_NUP + lane - 52] += ap * dd[L::D_NUP + lane - 52];
+    }
     if (lane < NF) {
       const int c = lane / 3;
-      if (P->active[c]) { s[L::S_F + lane] += ap * dfs[lane]; s[L::S_MU + lane] += ap * dd[L::D_MU + lane]; }
+      if (nd->active[c]) { s[L::S_F + lane] += ap * dfs[lane]; s[L::S_MU + lane] += ap * dd[L::D_MU + lane]; }
+      if (lane < nd->sw_dimi) s[L::S_XI + lane] += ap * dd[L::D_XI + lane];       // split_solution.hxx:235-238
     }
   }
 }
@@ -278,18 +300,22 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
   using L = OcpLayout<D>;
   constexpr int NU = D::NU;
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
-  const long su = blockIdx.x;
-  const long b = su / N;
-  const int i = (int)(su - b * N);
-  const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
+  const int M = P->M;
+  const long unit = blockIdx.x;                     // over batch * (M - 1): the non-terminal stages of the chain
+  const long b = unit / (M - 1);
+  const int pos = (int)(unit - b * (M - 1));
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const int i = nd->level;
+  const bool impulse = nd->kind == 1;
+  const long su = b * P->NS + nd->slot;
+  const double* __restrict__ s = B.sol + su * L::SOL;
   for (int row = threadIdx.x; row < L::NCON; row += 64) {
     double sl = 1.0, dl = 0.0;
     bool valid;
     double g = 0.0;
     if (row < L::C_FRIC) {
       const int c = row / NU, j = row - c * NU;
-      valid = ocpRowValid2(P, c, i);
+      valid = ocpRowValid2(P, c, i, impulse);
       if (valid) {
         const double sgn = (c & 1) ? 1.0 : -1.0;
         const double x = (c < 2) ? s[L::S_Q + 7 + j] : ((c < 4) ? s[L::S_V + 6 + j] : s[L::S_U + j]);
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
     } else {
       // all contacts, active or not (linearized_friction_cone.cpp:96-104)
       const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
-      valid = ocpRowValid2(P, 6, i);
+      valid = ocpRowValid2(P, 6, i, impulse);
       if (valid) for (int x = 0; x < 3; ++x) g += frictionJacEntry2(P->mu, r, x) * s[L::S_F + 3 * c + x];
     }
     if (valid) {
@@ -325,24 +351,24 @@ __global__ void ocp_fill_field_kernel(double* __restrict__ sol, int stride, int 
 }
 
 template <typename D>
-void OcpLaunch<D>::expandPrimal(const OcpBuffers& B, long batch, int N, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+void OcpLaunch<D>::expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
   hipLaunchKernelGGL(ocp_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
 }
 template <typename D>
-void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int N, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
 }
 template <typename D>
-void OcpLaunch<D>::initConstraints(const OcpBuffers& B, long batch, int N, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_init_constraints_kernel<D>), dim3((unsigned)(batch * N)), dim3(64), 0, st, B);
+void OcpLaunch<D>::initConstraints(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_init_constraints_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
 }
 
 template <typename D>
-void OcpLaunch<D>::single(int kernel_id, const OcpBuffers& B, long batch, int N, hipStream_t st) {
-  if (kernel_id == 4) hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+void OcpLaunch<D>::single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  if (kernel_id == 4) hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
   else if (kernel_id == 5) hipLaunchKernelGGL(ocp_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
-  else hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * (N + 1))), dim3(64), 0, st, B);
+  else hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
 }
 
 void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st) {

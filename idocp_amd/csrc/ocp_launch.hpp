@@ -10,15 +10,17 @@ namespace idocp_dev {
 
 template <typename D>
 struct OcpLaunch {
-  static void rnea(const OcpBuffers& B, long batch, int N, hipStream_t st);          // K5a
-  static void condense(const OcpBuffers& B, long batch, int N, int dimf, const double* q0, hipStream_t st);   // K5b (+ terminal)
-  static void residual(const OcpBuffers& B, long batch, int N, const double* q0, hipStream_t st);   // K8
-  static void riccatiBackward(const OcpBuffers& B, long batch, int N, hipStream_t st);               // S3
-  static void riccatiForward(const OcpBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);  // S4
-  static void expandPrimal(const OcpBuffers& B, long batch, int N, hipStream_t st);   // K6 (+ step-size reduction)
-  static void expandDualIntegrate(const OcpBuffers& B, long batch, int N, hipStream_t st);   // K7
-  static void initConstraints(const OcpBuffers& B, long batch, int N, hipStream_t st);
-  static void single(int kernel_id, const OcpBuffers& B, long batch, int N, hipStream_t st);   // ids 4, 5, 6
+  // M = length of the chain (stages in time order incl. event stages and the terminal stage)
+  static void rnea(const OcpBuffers& B, long batch, int M, hipStream_t st);          // K5a (M - 1 stages)
+  static void switching(const OcpBuffers& B, long batch, int M, hipStream_t st);     // K5s: switching-constraint terms (all stages; no-op where absent)
+  static void condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st);   // K5b (+ terminal); dimf = -1: mixed chain
+  static void residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st);   // K8
+  static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
+  static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
+  static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
+  static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7
+  static void initConstraints(const OcpBuffers& B, long batch, int M, hipStream_t st);
+  static void single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st);   // ids 4, 5, 6
 };
 
 void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st);

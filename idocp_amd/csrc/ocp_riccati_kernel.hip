@@ -34,21 +34,27 @@ struct RiccatiSmem {
                        KV = KM + NU * NX,
                        GW = KV + 16, SQN = GW + NU * NU, SVN = SQN + NV, TOTAL = SVN + NV + 4;
   static_assert(2 * NU * NV == NU * NX, "GK aliases B^T P");
+  // extra blocks of the HYBRID instantiation (stages that carry a switching constraint: Schur-complement step of
+  // SplitRiccatiFactorizer::backwardRiccatiRecursion, split_riccati_factorizer.hxx:43-101)
+  static constexpr int NF = D::NF;
+  static constexpr int PHIX = TOTAL, PHIU = PHIX + NF * NX, DG = PHIU + NF * NU, SS = DG + NF * NU, SDG = SS + NF * NF,
+                       MMX = SDG + NF * NU, DTM = MMX + NF * NX, PV = DTM + NU * NX, MV = PV + NF, TOTAL_HYBRID = MV + NF + 4;
 };
 
-template <typename D, int NT>
+template <typename D, int NT, bool HYBRID>
 __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = RiccatiSmem<D>;
-  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV, NF = D::NF;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
-  const double dt = P->dt;
+  const int M = P->M;
+  const OcpNode* __restrict__ nodes = B.nodes;
   const int tid = threadIdx.x;
   constexpr int nt = NT;
   const long b = blockIdx.x;
+  const long base = b * P->NS;                    // first record of this instance
   double* Pqq = &sm[S::PQQ];
   double* Pqv = &sm[S::PQV];
   double* Pvv = &sm[S::PVV];
@@ -57,8 +63,8 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
   if (tid == 0) s_ok = 1;
   // terminal stage (riccati_recursion_solver.cpp:53-56)
   {
-    const double* __restrict__ kk = B.kkt + (b * (N + 1) + N) * L::KKT;
-    double* __restrict__ rr = B.ric + (b * (N + 1) + N) * L::RIC;
+    const double* __restrict__ kk = B.kkt + (base + nodes[M - 1].slot) * L::KKT;
+    double* __restrict__ rr = B.ric + (base + nodes[M - 1].slot) * L::RIC;
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
       const double pqq = kk[L::K_QXX + r + NX * c], pvv = kk[L::K_QXX + (NV + r) + NX * (NV + c)];
@@ -72,12 +78,18 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     }
   }
   {
-    const double* __restrict__ kk = B.kkt + (b * (N + 1) + N - 1) * L::KKT;
+    const double* __restrict__ kk = B.kkt + (base + nodes[M - 2].slot) * L::KKT;
     for (int e = tid; e < SL; e += nt) st[e] = kk[KO + e];
   }
   __syncthreads();
-  for (int i = N - 1; i >= 0; --i) {
-    const bool stamp = tid == 0 && b == 7 && i == N / 2 && B.prof != nullptr;
+  // walk the chain backwards (riccati_recursion_solver.cpp:48-107): impulse stages are ordinary steps with
+  // Fqv = 0 (dtq = 0), Fvu = 0, Qxu = 0, Quu = I written by K5b, which makes K = 0, k = 0 and P = F
+  for (int i = M - 2; i >= 0; --i) {
+    const OcpNode* __restrict__ nd = nodes + i;
+    const double dt = nd->dtq;
+    const long rec = base + nd->slot;
+    const int dimi = HYBRID ? nd->sw_dimi : 0;
+    const bool stamp = tid == 0 && b == 7 && i == M / 2 && B.prof != nullptr;
 #define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
     RSTAMP(0);
     // software pipeline: the record of stage i was staged into LDS at the end of the previous
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     double pre[PF], qxx[3][QF];
     {
       // Qxx of THIS stage is consumed once per element in the F phase: straight to registers
-      const double* __restrict__ kc = B.kkt + (b * (N + 1) + i) * L::KKT;
+      const double* __restrict__ kc = B.kkt + rec * L::KKT;
 #pragma unroll
       for (int t = 0; t < QF; ++t) {
         const int e = tid + NT * t;
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       }
     }
     if (i > 0) {
-      const double* __restrict__ kn = B.kkt + (b * (N + 1) + i - 1) * L::KKT + KO;
+      const double* __restrict__ kn = B.kkt + (base + nodes[i - 1].slot) * L::KKT + KO;
 #pragma unroll
       for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; pre[t] = (e < SL) ? kn[e] : 0.0; }
     }
@@ -203,11 +215,50 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     __syncthreads();
     if (tid < 64) spdInverseWave<3>(&sm[S::GW], &sm[S::GK], NU, NU, tid, &s_ok);
     __syncthreads();
+    if (HYBRID && dimi > 0) {
+      // ---- Schur complement w.r.t. the switching constraint Phix dx + Phiu du + P = 0 (split_riccati_factorizer.hxx:56-70) ----
+      const double* __restrict__ W = B.swc + rec * L::SWC;
+      for (int e = tid; e < dimi * NX; e += nt) { const int c = e / dimi, j = e - c * dimi; sm[S::PHIX + j + NF * c] = W[L::W_PHIX + j + NF * c]; }
+      for (int e = tid; e < dimi * NU; e += nt) { const int c = e / dimi, j = e - c * dimi; sm[S::PHIU + j + NF * c] = W[L::W_PHIU + j + NF * c]; }
+      if (tid < dimi) sm[S::PV + tid] = W[L::W_P + tid];
+      __syncthreads();
+      for (int e = tid; e < dimi * NU; e += nt) {                // DGinv = Phiu Ginv
+        const int c = e / dimi, j = e - c * dimi;
+        double acc = 0.0;
+        for (int m = 0; m < NU; ++m) acc += sm[S::PHIU + j + NF * m] * sm[S::GW + m + NU * c];
+        sm[S::DG + j + NF * c] = acc;
+      }
+      __syncthreads();
+      for (int e = tid; e < dimi * dimi; e += nt) {              // S = DGinv Phiu^T
+        const int c = e / dimi, j = e - c * dimi;
+        double acc = 0.0;
+        for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * sm[S::PHIU + c + NF * m];
+        sm[S::SS + j + NF * c] = acc;
+      }
+      __syncthreads();
+      if (tid < 64) spdInverseWave<3>(&sm[S::SS], &sm[S::SDG], NF, dimi, tid, &s_ok);      // S^-1 (LLT in the reference)
+      __syncthreads();
+      for (int e = tid; e < dimi * NU; e += nt) {                // SinvDGinv
+        const int c = e / dimi, j = e - c * dimi;
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += sm[S::SS + j + NF * l] * sm[S::DG + l + NF * c];
+        sm[S::SDG + j + NF * c] = acc;
+      }
+      __syncthreads();
+      for (int e = tid; e < NU * NU; e += nt) {                  // Ginv -= SinvDGinv^T DGinv
+        const int c = e / NU, r = e - c * NU;
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * r] * sm[S::DG + l + NF * c];
+        sm[S::GW + e] -= acc;
+      }
+      __syncthreads();
+    }
     for (int e = tid; e < NU * NX; e += nt) {
       const int c = e / NU, j = e - c * NU;
       double acc = 0.0;
 #pragma unroll
       for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
+      if (HYBRID && dimi > 0) for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * sm[S::PHIX + l + NF * c];     // K -= SinvDGinv^T Phix
       sm[S::KM + e] = -acc;
     }
     if (tid >= NT - NU) {
@@ -215,9 +266,38 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       double acc = 0.0;
 #pragma unroll
       for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
+      if (HYBRID && dimi > 0) for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * sm[S::PV + l];              // k -= SinvDGinv^T P
       sm[S::KV + j] = -acc;
     }
+    if (HYBRID && dimi > 0) {
+      // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu
+      double* __restrict__ W = B.swc + rec * L::SWC;
+      for (int e = tid; e < dimi * NX; e += nt) {
+        const int c = e / dimi, l = e - c * dimi;
+        double acc = 0.0;
+        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * sm[S::PHIX + j + NF * c];
+        for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
+        sm[S::MMX + l + NF * c] = acc;
+        W[L::W_M + l + NF * c] = acc;
+      }
+      if (tid < dimi) {
+        const int l = tid;
+        double acc = 0.0;
+        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * sm[S::PV + j];
+        for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * lu[m];
+        sm[S::MV + l] = acc;
+        W[L::W_m + l] = acc;
+      }
+    }
     __syncthreads();
+    if (HYBRID && dimi > 0) {
+      for (int e = tid; e < NU * NX; e += nt) {                  // DtM = Phiu^T M (:88)
+        const int c = e / NU, m = e - c * NU;
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += sm[S::PHIU + l + NF * m] * sm[S::MMX + l + NF * c];
+        sm[S::DTM + m + NU * c] = acc;
+      }
+    }
     RSTAMP(4);
     // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
     mm(colMajor(&sm[S::GK], NU), colMajor(Quu, NU), colMajor(&sm[S::KM], NU), NU, NX, NU, 1.0, false, tid, nt);
@@ -266,15 +346,31 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     }
     __syncthreads();
     RSTAMP(7);
-    double* __restrict__ rr = B.ric + (b * (N + 1) + i) * L::RIC;
-    double* __restrict__ gg = B.gain + (b * N + i) * L::GAIN;
+    double* __restrict__ rr = B.ric + rec * L::RIC;
+    double* __restrict__ gg = B.gain + rec * L::GAIN;
     for (int e = tid; e < NN; e += nt) {
-      Pqq[e] = sm[S::ATPQQ + e]; Pvv[e] = sm[S::ATPVV + e];
-      rr[L::R_PQQ + e] = Pqq[e]; rr[L::R_PQV + e] = Pqv[e]; rr[L::R_PVV + e] = Pvv[e];
+      double pqq = sm[S::ATPQQ + e], pqv = Pqv[e], pvv = sm[S::ATPVV + e];
+      if (HYBRID && dimi > 0) {
+        // P -= K^T D^T M + (K^T D^T M)^T, block by block (split_riccati_factorizer.hxx:88-97)
+        const int c = e / NV, r = e - c * NV;
+        double aqq = 0.0, aqv = 0.0, avv = 0.0;
+        for (int j = 0; j < NU; ++j) {
+          const double kqr = sm[S::KM + j + NU * r], kqc = sm[S::KM + j + NU * c], kvr = sm[S::KM + j + NU * (NV + r)], kvc = sm[S::KM + j + NU * (NV + c)];
+          const double dqr = sm[S::DTM + j + NU * r], dqc = sm[S::DTM + j + NU * c], dvr = sm[S::DTM + j + NU * (NV + r)], dvc = sm[S::DTM + j + NU * (NV + c)];
+          aqq += kqr * dqc + kqc * dqr;
+          aqv += kqr * dvc + kvc * dqr;
+          avv += kvr * dvc + kvc * dvr;
+        }
+        pqq -= aqq; pqv -= aqv; pvv -= avv;
+      }
+      Pqq[e] = pqq; Pqv[e] = pqv; Pvv[e] = pvv;
+      rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
     }
     if (tid < NV) {
-      sm[S::SQ + tid] = sm[S::SQN + tid]; sm[S::SV + tid] = sm[S::SVN + tid];
-      rr[L::R_SQ + tid] = sm[S::SQN + tid]; rr[L::R_SV + tid] = sm[S::SVN + tid];
+      double sq = sm[S::SQN + tid], sv = sm[S::SVN + tid];
+      if (HYBRID && dimi > 0) for (int l = 0; l < dimi; ++l) { sq -= sm[S::PHIX + l + NF * tid] * sm[S::MV + l]; sv -= sm[S::PHIX + l + NF * (NV + tid)] * sm[S::MV + l]; }     // (:98-99)
+      sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
+      rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }
     for (int e = tid; e < NU * NX; e += nt) gg[L::G_K + e] = sm[S::KM + e];
     if (tid < NU) gg[L::G_k + tid] = sm[S::KV + tid];
@@ -298,26 +394,29 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NU = D::NU;
   __shared__ double dx[NX], du[NU], dxn[NX];
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
-  const double dt = P->dt;
+  const int M = P->M;
+  const OcpNode* __restrict__ nodes = B.nodes;
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
-  const double* __restrict__ s0 = B.sol + b * (N + 1) * L::SOL;
+  const long base = b * P->NS;
+  const double* __restrict__ s0 = B.sol + (base + nodes[0].slot) * L::SOL;
   // RiccatiRecursionSolver::computeInitialStateDirection (riccati_recursion_solver.cpp:110-126)
   if (lane == 0) {
     double R[9], p[3], d6[6];
     lieRelative(s0 + L::S_Q, q0 + b * NQ, R, p);         // q (-) s[0].q
     lieLog6(R, p, d6);
-    const double* __restrict__ Fi = B.exp + b * (N + 1) * L::EXP + L::E_FQQPI;
+    const double* __restrict__ Fi = B.exp + (base + nodes[0].slot) * L::EXP + L::E_FQQPI;
     for (int r = 0; r < 6; ++r) { double acc = 0.0; for (int m = 0; m < 6; ++m) acc += Fi[r + 6 * m] * d6[m]; dx[r] = -acc; }
   }
   if (lane >= 6 && lane < NV) dx[lane] = q0[b * NQ + lane + 1] - s0[L::S_Q + lane + 1];
   if (lane < NV) dx[NV + lane] = v0[b * NV + lane] - s0[L::S_V + lane];
   __syncthreads();
-  for (int i = 0; i < N; ++i) {
-    const double* __restrict__ gg = B.gain + (b * N + i) * L::GAIN;
-    const double* __restrict__ kk = B.kkt + (b * (N + 1) + i) * L::KKT;
-    double* __restrict__ dd = B.dir + (b * (N + 1) + i) * L::DIR;
+  for (int i = 0; i < M - 1; ++i) {                 // forwardRiccatiRecursion along the chain (riccati_recursion_solver.cpp:129-162)
+    const long rec = base + nodes[i].slot;
+    const double dt = nodes[i].dtq;
+    const double* __restrict__ gg = B.gain + rec * L::GAIN;
+    const double* __restrict__ kk = B.kkt + rec * L::KKT;
+    double* __restrict__ dd = B.dir + rec * L::DIR;
     if (lane < NU) {
       double acc = gg[L::G_k + lane];
       for (int c = 0; c < NX; ++c) acc += gg[L::G_K + lane + NU * c] * dx[c];
@@ -342,37 +441,45 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
     if (lane < NX) dx[lane] = dxn[lane];
     __syncthreads();
   }
-  double* __restrict__ dd = B.dir + (b * (N + 1) + N) * L::DIR;
+  double* __restrict__ dd = B.dir + (base + nodes[M - 1].slot) * L::DIR;
   if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
 }
 
 template <typename D>
-void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int N, hipStream_t st) {
-  const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double);
+void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st) {
+  (void)M;
+  const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double), smem_h = RiccatiSmem<D>::TOTAL_HYBRID * sizeof(double);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     configured = true;
+  }
+  // A chain with switching constraints takes the HYBRID instantiation (55 kB of LDS: two instances per CU).
+  if (hybrid) {
+    hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, true>), dim3((unsigned)batch), dim3(128), smem_h, st, B);
+    return;
   }
   // Throughput mode (many instances): two wavefronts per instance, four instances per CU (39.8 kB
   // of LDS each) -- measured best at batch 1024 (2.48 ms vs 3.22 ms with one and 2.96 ms with four
   // wavefronts).  Latency mode (few instances): four wavefronts per instance.
   // IDOCP_RICCATI_NT={64,128,256} overrides the choice (tuning aid).
   static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
-  if (nt_env == 128) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128>), dim3((unsigned)batch), dim3(128), smem, st, B);
-  else if (nt_env == 256) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256>), dim3((unsigned)batch), dim3(256), smem, st, B);
-  else if (nt_env == 64) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 64>), dim3((unsigned)batch), dim3(64), smem, st, B);
-  else if (batch >= 512) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128>), dim3((unsigned)batch), dim3(128), smem, st, B);
-  else hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256>), dim3((unsigned)batch), dim3(256), smem, st, B);
+  if (nt_env == 128) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, false>), dim3((unsigned)batch), dim3(128), smem, st, B);
+  else if (nt_env == 256) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256, false>), dim3((unsigned)batch), dim3(256), smem, st, B);
+  else if (nt_env == 64) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 64, false>), dim3((unsigned)batch), dim3(64), smem, st, B);
+  else if (batch >= 512) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, false>), dim3((unsigned)batch), dim3(128), smem, st, B);
+  else hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256, false>), dim3((unsigned)batch), dim3(256), smem, st, B);
 }
 template <typename D>
-void OcpLaunch<D>::riccatiForward(const OcpBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
+void OcpLaunch<D>::riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st) {
+  (void)M;
   hipLaunchKernelGGL((ocp_riccati_forward_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0);
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::riccatiBackward(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::riccatiBackward(const OcpBuffers&, long, int, bool, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::riccatiForward(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 
 }  // namespace idocp_dev

@@ -17,6 +17,12 @@
 // skew(v_lin) * d(omega); an exact derivative would subtract it) so that the
 // Newton direction matches the reference, not just the mathematics.
 // Output: lin record = [dID;dC]/d(q,v), dID/da (= M), dC/da (= J), [ID; C].
+//
+// Impulse stages (ImpulseDynamicsForwardEuler::linearizeImpulseDynamics,
+// include/idocp/impulse/impulse_dynamics_forward_euler.hxx:18-58; robot.hxx:283-320, 505-541) run the same
+// sweep twice: pass 0 with (v, a, g) = (0, dv, 0) gives ImD = rnea_impulse(q, dv), dImD/dq and dImD/ddv;
+// pass 1 with the velocity v + dv gives the contact-velocity constraint C = v_foot and dC/dq, dC/dv
+// (= dC/ddv = J, emitted by the v- AND the a-seed lanes).
 #include <hip/hip_runtime.h>
 
 #include "ocp_device.hpp"
@@ -40,20 +46,22 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
   __shared__ double s_out[3 * NV][NVF];   // column of each seed lane: rows [dID (NV) ; dC (NF)]
   __shared__ double s_idc[NVF];           // nominal [ID ; C]
   __shared__ double s_cs[D::NU][2];       // cos / sin of the leg joint angles
+  __shared__ double s_v[NV], s_a[NV];     // velocity / acceleration inputs of the current pass
   const DevModel* __restrict__ m = B.model;
   const OcpProblem* __restrict__ P = B.prob;
-  const int N = P->N;
+  const int M = P->M;
   const int lane = threadIdx.x;
   const bool seeded = lane < 3 * NV;
   const int kind = seeded ? lane / NV : 3;
   const int k = seeded ? lane - kind * NV : -1;
-  const long unit = blockIdx.x;                       // one stage per wavefront
-  const long b = unit / N;
-  const int i = (int)(unit - b * N);
-  const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
+  const long unit = blockIdx.x;                       // one non-terminal stage of the chain per wavefront
+  const long b = unit / (M - 1);
+  const int pos = (int)(unit - b * (M - 1));
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const bool impulse = nd->kind == 1;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
-  const double* __restrict__ vv = s + L::S_V;
-  const double* __restrict__ aa = s + L::S_A;
   if (lane < D::NU) {
     double sj, cj;
     sincos(q[7 + lane], &sj, &cj);
@@ -62,159 +70,185 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
   // zero the C rows of inactive contacts / unused rows
   for (int r = lane; r < 3 * NV * NVF; r += 64) (&s_out[0][0])[r] = 0.0;
   if (lane < NVF) s_idc[lane] = 0.0;
-  __syncthreads();
   double* __restrict__ col = seeded ? &s_out[lane][0] : &s_out[0][0];
-  const double gz = m->gravity[2];
+  const double gz = impulse ? 0.0 : m->gravity[2];
   const double wv = 2.0 / P->baumgarte_time_step, wp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
-
-  // ---- base (free-flyer): placement, velocity, acceleration (with the gravity field) ----
   double Rn[9];
   quatToRot(q + 3, Rn);
   // tangent of q (+) e_k on the manifold: dp = R e_lin, dR = R skew(e_ang)   (local-frame perturbation)
   const double el[3] = {(kind == 0 && k == 0) ? 1.0 : 0.0, (kind == 0 && k == 1) ? 1.0 : 0.0, (kind == 0 && k == 2) ? 1.0 : 0.0};
   const double ea[3] = {(kind == 0 && k == 3) ? 1.0 : 0.0, (kind == 0 && k == 4) ? 1.0 : 0.0, (kind == 0 && k == 5) ? 1.0 : 0.0};
-  Mat3<T> Rb;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    Rb.m[3 * r + 0] = T(Rn[3 * r + 0], Rn[3 * r + 1] * ea[2] - Rn[3 * r + 2] * ea[1]);
-    Rb.m[3 * r + 1] = T(Rn[3 * r + 1], Rn[3 * r + 2] * ea[0] - Rn[3 * r + 0] * ea[2]);
-    Rb.m[3 * r + 2] = T(Rn[3 * r + 2], Rn[3 * r + 0] * ea[1] - Rn[3 * r + 1] * ea[0]);
-  }
-  const Vec3<T> pb = mk<T>(T(q[0], Rn[0] * el[0] + Rn[1] * el[1] + Rn[2] * el[2]), T(q[1], Rn[3] * el[0] + Rn[4] * el[1] + Rn[5] * el[2]),
-                           T(q[2], Rn[6] * el[0] + Rn[7] * el[1] + Rn[8] * el[2]));
-  auto seedV = [&](int idx) { return T(vv[idx], (kind == 1 && k == idx) ? 1.0 : 0.0); };
-  auto seedA = [&](int idx) { return T(aa[idx], (kind == 2 && k == idx) ? 1.0 : 0.0); };
-  const Vec3<T> vb = mk<T>(seedV(0), seedV(1), seedV(2)), wb = mk<T>(seedV(3), seedV(4), seedV(5));
-  // a_gf = a_joint + R^T (0, 0, -g_z)  (base acceleration in the gravity field; v x vJ = 0 for the root)
-  const Vec3<T> ab = mk<T>(seedA(0) - gz * Rb.m[6], seedA(1) - gz * Rb.m[7], seedA(2) - gz * Rb.m[8]);
-  const Vec3<T> alb = mk<T>(seedA(3), seedA(4), seedA(5));
-  Vec3<T> Fbl, Fbn;
-  {
-    Vec3<T> hl, hn, f, n;
-    inertiaMul<T>(m, 0, vb, wb, hl, hn);
-    inertiaMul<T>(m, 0, ab, alb, f, n);
-    Fbl = f + cross(wb, hl);
-    Fbn = n + cross(wb, hn) + cross(vb, hl);
-  }
 
-  // ---- legs ----
+  const int npass = impulse ? 2 : 1;
 #pragma unroll 1
-  for (int leg = 0; leg < NL; ++leg) {
-    Vec3<T> v = vb, w = wb, bl = ab, bw = alb;      // motion of the parent body, in its frame
-    Mat3<T> Rw = Rb;                                // world pose of the current frame
-    Vec3<T> pw = pb;
-#pragma unroll 1
-    for (int j = 0; j < LJ; ++j) {
-      const int ji = 1 + leg * LJ + j, dof = 6 + leg * LJ + j, ci = leg * LJ + j;
-      const bool mine = (k == dof);
-      const T cqi(s_cs[ci][0], (mine && kind == 0) ? -s_cs[ci][1] : 0.0);
-      const T sqi(s_cs[ci][1], (mine && kind == 0) ? s_cs[ci][0] : 0.0);
-      const T qdi(vv[dof], (mine && kind == 1) ? 1.0 : 0.0);
-      const T qddi(aa[dof], (mine && kind == 2) ? 1.0 : 0.0);
-      Mat3<T> R;
-      revoluteRotation<T>(m->R[ji], m->axis[ji], cqi, sqi, R);
-      const double* p = m->p[ji];
-      const double* u = m->axis[ji];
-      pw = pw + mul(Rw, mk<T>(T(p[0]), T(p[1]), T(p[2])));
-      {
-        Mat3<T> Rn2;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) Rn2.m[3 * r + c] = Rw.m[3 * r] * R.m[c] + Rw.m[3 * r + 1] * R.m[3 + c] + Rw.m[3 * r + 2] * R.m[6 + c];
-        Rw = Rn2;
-      }
-      const Vec3<T> wc = mulT(R, w);
-      const Vec3<T> vc = mulT(R, v + crossVC<T>(w, p));
-      const Vec3<T> bwc = mulT(R, bw);
-      const Vec3<T> blc = mulT(R, bl + crossVC<T>(bw, p));
-      const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
-      w = wc + vJ;
-      v = vc;
-      bw = bwc + mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) + cross(w, vJ);
-      bl = blc + cross(v, vJ);
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool do_dyn = (pass == 0), do_con = (!impulse) || (pass == 1);
+    // velocity seeds: the v lanes; in the kinematic pass of an impulse stage also the a lanes (dC/ddv = dC/dv)
+    const bool vseed = (kind == 1) || (impulse && pass == 1 && kind == 2);
+    const bool aseed = (kind == 2) && !(impulse && pass == 1);
+    __syncthreads();
+    if (lane < NV) {
+      const double vin = s[L::S_V + lane], ain = s[L::S_A + lane];
+      s_v[lane] = impulse ? (pass == 0 ? 0.0 : vin + ain) : vin;
+      s_a[lane] = impulse ? (pass == 0 ? ain : 0.0) : ain;
     }
-    // ---- contact frame at the foot (tip joint of this leg) ----
-    Vec3<T> fel = mk<T>(T(0.0), T(0.0), T(0.0)), fen = fel;     // contact force as a spatial force on the tip joint
-    if (P->active[leg]) {
-      const double* Rc = P->contact_R[leg];
-      const double* pc = P->contact_p[leg];
-      const int row = NV + P->row_of[leg];
-      // frame spatial velocity / acceleration (acceleration WITHOUT gravity: a = a_gf + R_w^T g)
-      const Vec3<T> al_ng = mk<T>(bl.x + gz * Rw.m[6], bl.y + gz * Rw.m[7], bl.z + gz * Rw.m[8]);
-      const Vec3<T> vj = v + crossVC<T>(w, pc);
-      const Vec3<T> aj = al_ng + crossVC<T>(bw, pc);
-      auto rotT = [&](Vec3<T> x) {
-        return mk<T>(Rc[0] * x.x + Rc[3] * x.y + Rc[6] * x.z, Rc[1] * x.x + Rc[4] * x.y + Rc[7] * x.z, Rc[2] * x.x + Rc[5] * x.y + Rc[8] * x.z);
-      };
-      const Vec3<T> fv = rotT(vj), fw = rotT(w), fa = rotT(aj);
-      const Vec3<T> pf = pw + mul(Rw, mk<T>(T(pc[0]), T(pc[1]), T(pc[2])));
-      // nominal residual (point_contact.hxx:67-87)
-      const double cx = fa.x.v + (fw.y.v * fv.z.v - fw.z.v * fv.y.v) + wv * fv.x.v + wp * (pf.x.v - P->contact_point[leg][0]);
-      const double cy = fa.y.v + (fw.z.v * fv.x.v - fw.x.v * fv.z.v) + wv * fv.y.v + wp * (pf.y.v - P->contact_point[leg][1]);
-      const double cz = fa.z.v + (fw.x.v * fv.y.v - fw.y.v * fv.x.v) + wv * fv.z.v + wp * (pf.z.v - P->contact_point[leg][2]);
-      // derivative column (point_contact.hxx:117-143): da_lin + skew(w) dv_lin + skew(v_lin) dw + (2/D) dv_lin + (1/D^2) dp_world
-      const double dx = fa.x.d + (fw.y.v * fv.z.d - fw.z.v * fv.y.d) + (fv.y.v * fw.z.d - fv.z.v * fw.y.d) + wv * fv.x.d + wp * pf.x.d;
-      const double dy = fa.y.d + (fw.z.v * fv.x.d - fw.x.v * fv.z.d) + (fv.z.v * fw.x.d - fv.x.v * fw.z.d) + wv * fv.y.d + wp * pf.y.d;
-      const double dz = fa.z.d + (fw.x.v * fv.y.d - fw.y.v * fv.x.d) + (fv.x.v * fw.y.d - fv.y.v * fw.x.d) + wv * fv.z.d + wp * pf.z.d;
-      if (seeded) { col[row] = dx; col[row + 1] = dy; col[row + 2] = dz; }
-      if (lane == 0) { s_idc[row] = cx; s_idc[row + 1] = cy; s_idc[row + 2] = cz; }
-      // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
-      const double* f = s + L::S_F + 3 * leg;
-      const double fx = Rc[0] * f[0] + Rc[1] * f[1] + Rc[2] * f[2], fy = Rc[3] * f[0] + Rc[4] * f[1] + Rc[5] * f[2],
-                   fz = Rc[6] * f[0] + Rc[7] * f[1] + Rc[8] * f[2];
-      fel = mk<T>(T(fx), T(fy), T(fz));
-      fen = mk<T>(T(pc[1] * fz - pc[2] * fy), T(pc[2] * fx - pc[0] * fz), T(pc[0] * fy - pc[1] * fx));
+    __syncthreads();
+    // ---- base (free-flyer): placement, velocity, acceleration (with the gravity field) ----
+    Mat3<T> Rb;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Rb.m[3 * r + 0] = T(Rn[3 * r + 0], Rn[3 * r + 1] * ea[2] - Rn[3 * r + 2] * ea[1]);
+      Rb.m[3 * r + 1] = T(Rn[3 * r + 1], Rn[3 * r + 2] * ea[0] - Rn[3 * r + 0] * ea[2]);
+      Rb.m[3 * r + 2] = T(Rn[3 * r + 2], Rn[3 * r + 0] * ea[1] - Rn[3 * r + 1] * ea[0]);
     }
-    // ---- inward sweep: accumulate forces, emit tau, undo the kinematic steps ----
-    Vec3<T> Fl = mk<T>(T(0.0), T(0.0), T(0.0)) - fel, Fn = mk<T>(T(0.0), T(0.0), T(0.0)) - fen;
-#pragma unroll 1
-    for (int j = LJ - 1; j >= 0; --j) {
-      const int ji = 1 + leg * LJ + j, dof = 6 + leg * LJ + j, ci = leg * LJ + j;
-      const double* u = m->axis[ji];
+    const Vec3<T> pb = mk<T>(T(q[0], Rn[0] * el[0] + Rn[1] * el[1] + Rn[2] * el[2]), T(q[1], Rn[3] * el[0] + Rn[4] * el[1] + Rn[5] * el[2]),
+                             T(q[2], Rn[6] * el[0] + Rn[7] * el[1] + Rn[8] * el[2]));
+    auto seedV = [&](int idx) { return T(s_v[idx], (vseed && k == idx) ? 1.0 : 0.0); };
+    auto seedA = [&](int idx) { return T(s_a[idx], (aseed && k == idx) ? 1.0 : 0.0); };
+    const Vec3<T> vb = mk<T>(seedV(0), seedV(1), seedV(2)), wb = mk<T>(seedV(3), seedV(4), seedV(5));
+    // a_gf = a_joint + R^T (0, 0, -g_z)  (base acceleration in the gravity field; v x vJ = 0 for the root)
+    const Vec3<T> ab = mk<T>(seedA(0) - gz * Rb.m[6], seedA(1) - gz * Rb.m[7], seedA(2) - gz * Rb.m[8]);
+    const Vec3<T> alb = mk<T>(seedA(3), seedA(4), seedA(5));
+    Vec3<T> Fbl, Fbn;
+    {
       Vec3<T> hl, hn, f, n;
-      inertiaMul<T>(m, ji, v, w, hl, hn);
-      inertiaMul<T>(m, ji, bl, bw, f, n);
-      Fl = Fl + f + cross(w, hl);
-      Fn = Fn + n + cross(w, hn) + cross(v, hl);
-      const T ti = u[0] * Fn.x + u[1] * Fn.y + u[2] * Fn.z;
-      if (seeded) col[dof] = ti.d;
-      if (lane == 0) s_idc[dof] = ti.v;
-      const bool mine = (k == dof);
-      const T cqi(s_cs[ci][0], (mine && kind == 0) ? -s_cs[ci][1] : 0.0);
-      const T sqi(s_cs[ci][1], (mine && kind == 0) ? s_cs[ci][0] : 0.0);
-      Mat3<T> R;
-      revoluteRotation<T>(m->R[ji], m->axis[ji], cqi, sqi, R);
-      const double* p = m->p[ji];
-      const Vec3<T> Rf = mul(R, Fl);
-      Fn = mul(R, Fn) + crossC<T>(p, Rf);
-      Fl = Rf;
-      if (j > 0) {
-        const T qdi(vv[dof], (mine && kind == 1) ? 1.0 : 0.0);
-        const T qddi(aa[dof], (mine && kind == 2) ? 1.0 : 0.0);
+      inertiaMul<T>(m, 0, vb, wb, hl, hn);
+      inertiaMul<T>(m, 0, ab, alb, f, n);
+      Fbl = f + cross(wb, hl);
+      Fbn = n + cross(wb, hn) + cross(vb, hl);
+    }
+
+    // ---- legs ----
+#pragma unroll 1
+    for (int leg = 0; leg < NL; ++leg) {
+      Vec3<T> v = vb, w = wb, bl = ab, bw = alb;      // motion of the parent body, in its frame
+      Mat3<T> Rw = Rb;                                // world pose of the current frame
+      Vec3<T> pw = pb;
+#pragma unroll 1
+      for (int j = 0; j < LJ; ++j) {
+        const int ji = 1 + leg * LJ + j, dof = 6 + leg * LJ + j, ci = leg * LJ + j;
+        const bool mine = (k == dof);
+        const T cqi(s_cs[ci][0], (mine && kind == 0) ? -s_cs[ci][1] : 0.0);
+        const T sqi(s_cs[ci][1], (mine && kind == 0) ? s_cs[ci][0] : 0.0);
+        const T qdi(s_v[dof], (mine && vseed) ? 1.0 : 0.0);
+        const T qddi(s_a[dof], (mine && aseed) ? 1.0 : 0.0);
+        Mat3<T> R;
+        revoluteRotation<T>(m->R[ji], m->axis[ji], cqi, sqi, R);
+        const double* p = m->p[ji];
+        const double* u = m->axis[ji];
+        pw = pw + mul(Rw, mk<T>(T(p[0]), T(p[1]), T(p[2])));
+        {
+          Mat3<T> Rn2;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rn2.m[3 * r + c] = Rw.m[3 * r] * R.m[c] + Rw.m[3 * r + 1] * R.m[3 + c] + Rw.m[3 * r + 2] * R.m[6 + c];
+          Rw = Rn2;
+        }
+        const Vec3<T> wc = mulT(R, w);
+        const Vec3<T> vc = mulT(R, v + crossVC<T>(w, p));
+        const Vec3<T> bwc = mulT(R, bw);
+        const Vec3<T> blc = mulT(R, bl + crossVC<T>(bw, p));
         const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
-        const Vec3<T> bwc = bw - mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) - cross(w, vJ);
-        const Vec3<T> blc = bl - cross(v, vJ);
-        const Vec3<T> wc = w - vJ;
-        w = mul(R, wc);
-        v = mul(R, v) - crossVC<T>(w, p);
-        bw = mul(R, bwc);
-        bl = mul(R, blc) - crossVC<T>(bw, p);
+        w = wc + vJ;
+        v = vc;
+        bw = bwc + mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) + cross(w, vJ);
+        bl = blc + cross(v, vJ);
+      }
+      // ---- contact frame at the foot (tip joint of this leg) ----
+      Vec3<T> fel = mk<T>(T(0.0), T(0.0), T(0.0)), fen = fel;     // contact force as a spatial force on the tip joint
+      if (nd->active[leg]) {
+        const double* Rc = P->contact_R[leg];
+        const double* pc = P->contact_p[leg];
+        const int row = NV + nd->row_of[leg];
+        if (do_con) {
+          // frame spatial velocity / acceleration (acceleration WITHOUT gravity: a = a_gf + R_w^T g)
+          const Vec3<T> al_ng = mk<T>(bl.x + gz * Rw.m[6], bl.y + gz * Rw.m[7], bl.z + gz * Rw.m[8]);
+          const Vec3<T> vj = v + crossVC<T>(w, pc);
+          const Vec3<T> aj = al_ng + crossVC<T>(bw, pc);
+          auto rotT = [&](Vec3<T> x) {
+            return mk<T>(Rc[0] * x.x + Rc[3] * x.y + Rc[6] * x.z, Rc[1] * x.x + Rc[4] * x.y + Rc[7] * x.z, Rc[2] * x.x + Rc[5] * x.y + Rc[8] * x.z);
+          };
+          const Vec3<T> fv = rotT(vj), fw = rotT(w), fa = rotT(aj);
+          const Vec3<T> pf = pw + mul(Rw, mk<T>(T(pc[0]), T(pc[1]), T(pc[2])));
+          double cx, cy, cz, dx, dy, dz;
+          if (impulse) {
+            // contact-velocity constraint (point_contact.hxx:145-175): LOCAL linear velocity of the frame
+            cx = fv.x.v; cy = fv.y.v; cz = fv.z.v;
+            dx = fv.x.d; dy = fv.y.d; dz = fv.z.d;
+          } else {
+            // nominal residual (point_contact.hxx:67-87)
+            cx = fa.x.v + (fw.y.v * fv.z.v - fw.z.v * fv.y.v) + wv * fv.x.v + wp * (pf.x.v - nd->contact_point[leg][0]);
+            cy = fa.y.v + (fw.z.v * fv.x.v - fw.x.v * fv.z.v) + wv * fv.y.v + wp * (pf.y.v - nd->contact_point[leg][1]);
+            cz = fa.z.v + (fw.x.v * fv.y.v - fw.y.v * fv.x.v) + wv * fv.z.v + wp * (pf.z.v - nd->contact_point[leg][2]);
+            // derivative column (point_contact.hxx:117-143): da_lin + skew(w) dv_lin + skew(v_lin) dw + (2/D) dv_lin + (1/D^2) dp_world
+            dx = fa.x.d + (fw.y.v * fv.z.d - fw.z.v * fv.y.d) + (fv.y.v * fw.z.d - fv.z.v * fw.y.d) + wv * fv.x.d + wp * pf.x.d;
+            dy = fa.y.d + (fw.z.v * fv.x.d - fw.x.v * fv.z.d) + (fv.z.v * fw.x.d - fv.x.v * fw.z.d) + wv * fv.y.d + wp * pf.y.d;
+            dz = fa.z.d + (fw.x.v * fv.y.d - fw.y.v * fv.x.d) + (fv.x.v * fw.y.d - fv.y.v * fw.x.d) + wv * fv.z.d + wp * pf.z.d;
+          }
+          if (seeded) { col[row] = dx; col[row + 1] = dy; col[row + 2] = dz; }
+          if (lane == 0) { s_idc[row] = cx; s_idc[row + 1] = cy; s_idc[row + 2] = cz; }
+        }
+        // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
+        const double* f = s + L::S_F + 3 * leg;
+        const double fx = Rc[0] * f[0] + Rc[1] * f[1] + Rc[2] * f[2], fy = Rc[3] * f[0] + Rc[4] * f[1] + Rc[5] * f[2],
+                     fz = Rc[6] * f[0] + Rc[7] * f[1] + Rc[8] * f[2];
+        fel = mk<T>(T(fx), T(fy), T(fz));
+        fen = mk<T>(T(pc[1] * fz - pc[2] * fy), T(pc[2] * fx - pc[0] * fz), T(pc[0] * fy - pc[1] * fx));
+      }
+      if (!do_dyn) continue;                          // kinematic pass of an impulse stage: no forces
+      // ---- inward sweep: accumulate forces, emit tau, undo the kinematic steps ----
+      Vec3<T> Fl = mk<T>(T(0.0), T(0.0), T(0.0)) - fel, Fn = mk<T>(T(0.0), T(0.0), T(0.0)) - fen;
+#pragma unroll 1
+      for (int j = LJ - 1; j >= 0; --j) {
+        const int ji = 1 + leg * LJ + j, dof = 6 + leg * LJ + j, ci = leg * LJ + j;
+        const double* u = m->axis[ji];
+        Vec3<T> hl, hn, f, n;
+        inertiaMul<T>(m, ji, v, w, hl, hn);
+        inertiaMul<T>(m, ji, bl, bw, f, n);
+        Fl = Fl + f + cross(w, hl);
+        Fn = Fn + n + cross(w, hn) + cross(v, hl);
+        const T ti = u[0] * Fn.x + u[1] * Fn.y + u[2] * Fn.z;
+        if (seeded) col[dof] = ti.d;
+        if (lane == 0) s_idc[dof] = ti.v;
+        const bool mine = (k == dof);
+        const T cqi(s_cs[ci][0], (mine && kind == 0) ? -s_cs[ci][1] : 0.0);
+        const T sqi(s_cs[ci][1], (mine && kind == 0) ? s_cs[ci][0] : 0.0);
+        Mat3<T> R;
+        revoluteRotation<T>(m->R[ji], m->axis[ji], cqi, sqi, R);
+        const double* p = m->p[ji];
+        const Vec3<T> Rf = mul(R, Fl);
+        Fn = mul(R, Fn) + crossC<T>(p, Rf);
+        Fl = Rf;
+        if (j > 0) {
+          const T qdi(s_v[dof], (mine && vseed) ? 1.0 : 0.0);
+          const T qddi(s_a[dof], (mine && aseed) ? 1.0 : 0.0);
+          const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
+          const Vec3<T> bwc = bw - mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) - cross(w, vJ);
+          const Vec3<T> blc = bl - cross(v, vJ);
+          const Vec3<T> wc = w - vJ;
+          w = mul(R, wc);
+          v = mul(R, v) - crossVC<T>(w, p);
+          bw = mul(R, bwc);
+          bl = mul(R, blc) - crossVC<T>(bw, p);
+        }
+      }
+      Fbl = Fbl + Fl;
+      Fbn = Fbn + Fn;
+    }
+    if (do_dyn) {
+      // base rows: tau[0:6] = total spatial force on the base (S = identity)
+      if (seeded) {
+        col[0] = Fbl.x.d; col[1] = Fbl.y.d; col[2] = Fbl.z.d; col[3] = Fbn.x.d; col[4] = Fbn.y.d; col[5] = Fbn.z.d;
+      }
+      if (lane == 0) {
+        s_idc[0] = Fbl.x.v; s_idc[1] = Fbl.y.v; s_idc[2] = Fbl.z.v; s_idc[3] = Fbn.x.v; s_idc[4] = Fbn.y.v; s_idc[5] = Fbn.z.v;
       }
     }
-    Fbl = Fbl + Fl;
-    Fbn = Fbn + Fn;
-  }
-  // base rows: tau[0:6] = total spatial force on the base (S = identity)
-  if (seeded) {
-    col[0] = Fbl.x.d; col[1] = Fbl.y.d; col[2] = Fbl.z.d; col[3] = Fbn.x.d; col[4] = Fbn.y.d; col[5] = Fbn.z.d;
-  }
-  if (lane == 0) {
-    s_idc[0] = Fbl.x.v; s_idc[1] = Fbl.y.v; s_idc[2] = Fbl.z.v; s_idc[3] = Fbn.x.v; s_idc[4] = Fbn.y.v; s_idc[5] = Fbn.z.v;
   }
   __syncthreads();
   // ---- coalesced write of the lin record ----
-  double* __restrict__ lin = B.lin + unit * L::LIN;
+  double* __restrict__ lin = B.lin + rec * L::LIN;
   for (int e = lane; e < NVF * NX; e += 64) lin[L::L_DIDC + e] = (&s_out[0][0])[e];          // q and v seeds: 2 NV columns of NVF
   for (int e = lane; e < NV * NV; e += 64) {                                                 // a seeds, rows 0..NV-1 = M
     const int c = e / NV, r = e - c * NV;
@@ -224,13 +258,13 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
     const int c = e / NF, r = e - c * NF;
     lin[L::L_J + e] = s_out[2 * NV + c][NV + r];
   }
-  // ID - u on the actuated rows (contact_dynamics.hxx:88)
-  if (lane < NVF) lin[L::L_IDC + lane] = s_idc[lane] - ((lane >= 6 && lane < NV) ? s[L::S_U + lane - 6] : 0.0);
+  // ID - u on the actuated rows (contact_dynamics.hxx:88); the impulse stage has no torques
+  if (lane < NVF) lin[L::L_IDC + lane] = s_idc[lane] - ((nd->has_u && lane >= 6 && lane < NV) ? s[L::S_U + lane - 6] : 0.0);
 }
 
 template <typename D>
-void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int N, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_rnea_kernel<D>), dim3((unsigned)(batch * N)), dim3(64), 0, st, B);
+void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_rnea_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::rnea(const OcpBuffers&, long, int, hipStream_t);

@@ -252,16 +252,40 @@ typedef struct idocp_ocp idocp_ocp_t;
  * (src/ocp/ocp_solver.cpp:9-47).  This build carries the kernels for a quadruped
  * (free-flyer + 4 legs x 3 revolute joints, one point contact per foot) and a
  * contact sequence WITHOUT discrete events (setContactStatusUniformly only);
- * impulse / lift stages are rejected with IDOCP_E_UNSUPPORTED. */
+ * created this way it holds event-free horizons only (max_num_impulse = 0). */
 int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost,
                      const idocp_constraints_t* constraints, double T, int N,
                      int batch, int device, idocp_ocp_t** out);
+/* OCPSolver(robot, cost, constraints, T, N, max_num_impulse, nthreads) (ocp_solver.cpp:10-47):
+ * reserves stages for up to max_num_impulse discrete events (impulse + aux stage or a
+ * lift stage each) so that contact sequences can be pushed. */
+int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost,
+                            const idocp_constraints_t* constraints, double T, int N,
+                            int max_num_impulse, int batch, int device, idocp_ocp_t** out);
 void idocp_ocp_destroy(idocp_ocp_t* h);
 /* OCPSolver::setContactStatusUniformly (ocp_solver.cpp:169-171): active[ncontacts]
  * flags and the world contact points contact_points[ncontacts][3]
  * (ContactStatus::setContactPoints). */
 int idocp_ocp_set_contact_status_uniformly(idocp_ocp_t* h, const int* active,
                                            const double* contact_points);
+/* OCPSolver::pushBackContactStatus / setContactPoints / popBackContactStatus /
+ * popFrontContactStatus (ocp_solver.cpp:174-197) -> ContactSequence (include/idocp/hybrid/
+ * contact_sequence.hxx:52-268) and DiscreteEvent (discrete_event.hxx:57-84): a status
+ * that activates a contact is an impulse event (impulse + aux stage and a switching
+ * constraint two stages ahead), one that only deactivates contacts is a lift event. */
+int idocp_ocp_push_back_contact_status(idocp_ocp_t* h, const int* active,
+                                       const double* contact_points, double switching_time);
+int idocp_ocp_set_contact_points(idocp_ocp_t* h, int contact_phase, const double* contact_points);
+int idocp_ocp_pop_back_contact_status(idocp_ocp_t* h);
+int idocp_ocp_pop_front_contact_status(idocp_ocp_t* h);
+/* The stages in time order after OCPDiscretizer::discretizeOCP(contact_sequence, t)
+ * (include/idocp/hybrid/ocp_discretizer.hxx:65-374).  Returns the chain length
+ * M = N + 1 + 2 N_impulse + N_lift (or a negative error code); arrays of `capacity`
+ * entries, any may be NULL: kind (0 stage, 1 impulse, 2 aux, 3 lift, 4 terminal), index
+ * (grid stage / impulse index / lift index), storage slot, time step, dimf, rows of the
+ * switching constraint carried by the stage. */
+int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot,
+                        double* dt, int* dimf, int* sw_dimi);
 /* OCPSolver::setSolution (ocp_solver.cpp:95-165): name in {"q","v","a","f","u"};
  * "f" takes one 3-vector written to every contact.  Does not re-initialise the
  * constraints (like the reference). */
@@ -285,10 +309,18 @@ int idocp_ocp_kkt_error(idocp_ocp_t* h, double* kkt_error);
 int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, double* out);
 /* Newton direction: dq dv da du df dlmd dgmm dbeta dmu dnu_passive. */
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out);
+/* The same fields for every stage of the chain (incl. impulse / aux / lift stages), in
+ * chain order: out[M][dim].  Extra names: "xi" / "dxi" (multiplier of the switching
+ * constraint, max_dimf entries).  On impulse stages "a" / "da" hold dv / ddv. */
+int idocp_ocp_get_solution_chain(idocp_ocp_t* h, const char* name, int instance, double* out);
+int idocp_ocp_get_direction_chain(idocp_ocp_t* h, const char* name, int instance, double* out);
 int idocp_ocp_get_step_sizes(idocp_ocp_t* h, double* primal, double* dual);
 /* P[N+1][2nv*2nv], s[N+1][2nv], K[N][nu*2nv] (nu x 2nv col-major), k[N][nu]. */
 int idocp_ocp_get_riccati(idocp_ocp_t* h, int instance, double* P, double* s, double* K,
                           double* k);
+/* Chain order: P[M][..], s[M][..], K[M-1][..], k[M-1][..]. */
+int idocp_ocp_get_riccati_chain(idocp_ocp_t* h, int instance, double* P, double* s, double* K,
+                                double* k);
 /* OCPSolver::getStateFeedbackGain (ocp_solver.cpp:101-111): Kq, Kv (nu x nv col-major). */
 int idocp_ocp_get_state_feedback_gain(idocp_ocp_t* h, int instance, int stage, double* Kq,
                                       double* Kv);

@@ -453,13 +453,49 @@ def anymal_contact_points(model):
 class HipOCP:
     """Contact path through the C ABI (idocp_ocp_*)."""
 
-    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
+    def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
         self.lib = capi.lib()
         self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
+        self.max_events = max_num_impulse
         h = C.c_void_p()
-        capi.check(self.lib.idocp_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
-                   "idocp_ocp_create")
+        if max_num_impulse > 0:
+            capi.check(self.lib.idocp_ocp_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse, batch,
+                                                        device, C.byref(h)), "idocp_ocp_create_hybrid")
+        else:
+            capi.check(self.lib.idocp_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
+                       "idocp_ocp_create")
         self.h = h
+
+    # ---- contact sequences with discrete events
+    def push_back_contact_status(self, active, points, switching_time):
+        a = (C.c_int * 4)(*[int(x) for x in active])
+        capi.check(self.lib.idocp_ocp_push_back_contact_status(self.h, a, P(arr(points)), switching_time), "push_back_contact_status")
+
+    def set_contact_points(self, phase, points):
+        capi.check(self.lib.idocp_ocp_set_contact_points(self.h, phase, P(arr(points))), "set_contact_points")
+
+    def chain(self, t):
+        cap = self.N + 1 + 3 * max(self.max_events, 1)
+        IA = lambda: (C.c_int * cap)()
+        kind, index, slot, dimf, sw = IA(), IA(), IA(), IA(), IA()
+        dt = np.zeros(cap)
+        M = self.lib.idocp_ocp_get_chain(self.h, t, cap, kind, index, slot, P(dt), dimf, sw)
+        assert M > 0, capi.lib().idocp_last_error()
+        return [dict(kind=NODE_KINDS[kind[p]], index=index[p], slot=slot[p], dt=dt[p], dimf=dimf[p], sw_dimi=sw[p]) for p in range(M)]
+
+    def get_chain(self, name, M, instance=0):
+        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or OCP_CHAIN_EXTRA[name]
+        out = np.zeros((M, dim))
+        fn = self.lib.idocp_ocp_get_solution_chain if (name in OCP_SOL_FIELDS or name == "xi") else self.lib.idocp_ocp_get_direction_chain
+        capi.check(fn(self.h, name.encode(), instance, P(out)), "get_chain")
+        return out
+
+    def riccati_chain(self, M, instance=0):
+        nv, nu = self.nv, self.nu
+        Pm, s = np.zeros((M, 2 * nv, 2 * nv)), np.zeros((M, 2 * nv))
+        K, k = np.zeros((M - 1, 2 * nv, nu)), np.zeros((M - 1, nu))
+        capi.check(self.lib.idocp_ocp_get_riccati_chain(self.h, instance, P(Pm), P(s), P(K), P(k)), "get_riccati_chain")
+        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
 
     def __del__(self):
         if getattr(self, "h", None):
