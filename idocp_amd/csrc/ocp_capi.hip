@@ -105,7 +105,7 @@ struct idocp_ocp {
   std::vector<double> chain_t;
   int Ngrid = 0;                      // grid stages after discretisation
   double disc_time = NAN;
-  bool seq_dirty = true, has_switch = false;
+  bool seq_dirty = true, has_switch = false, has_impulse = false;
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
   int M() const { return (int)chain.size(); }
 };
@@ -230,6 +230,7 @@ int discretize(idocp_ocp* h, double t) {
     nd.sw_dt1 = nd.dtq; nd.sw_dt2 = dt_next;
   };
   h->has_switch = false;
+  h->has_impulse = Ni > 0;
   for (int i = 0; i < Ng; ++i) {
     node(0, i, ts[i], dts[i], h->phases[phase[i]], i);
     if (imp_after[i] < 0 && lift_after[i] < 0 && i + 1 < Ng && imp_after[i + 1] >= 0) { addSwitch(h->chain.back(), imp_after[i + 1], dts[i + 1]); h->has_switch = true; }
@@ -562,7 +563,7 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
   const int M = h->M();
   switch (kernel_id) {
     case 0:
-      OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->stream);
+      OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->has_impulse, h->stream);
       if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
       break;
     case 1: OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream); break;
@@ -581,7 +582,7 @@ int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q
   if ((rc = discretize(h, t))) return rc;                 // ocp_.discretize(contact_sequence_, t) (ocp_solver.cpp:72)
   const int M = h->M();
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->has_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream);
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
@@ -621,7 +622,7 @@ int idocp_ocp_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, co
   if ((rc = discretize(h, t))) return rc;
   const int M = h->M();
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->has_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::residual(h->B, h->batch, M, h->d_q0, h->stream);
   ocpKktErrorReduce(h->B, h->batch, h->stream);

@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
-  const bool impulse = nd->kind == 1;
+  // DIMF >= 0 is only launched on event-free chains (launchCondense): no impulse stages, no switching constraints
+  constexpr bool PLAIN = (DIMF >= 0);
+  const bool impulse = PLAIN ? false : (nd->kind == 1);
+  const int sw_dimi = PLAIN ? 0 : nd->sw_dimi;
   const int i = nd->level;                          // constraint gating level
   const double dt = nd->dt;                         // scaling of cost / constraints / dynamics multipliers (1 on impulse stages)
   const double dtq = nd->dtq;                       // q+ = q (+) dtq v (0 on impulse stages)
@@ -230,9 +233,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + NF * r], 1, &sm[S::BM + NV], 1, dimf);
     lq += dt * dq; lv += dt * dv; la += dt * da;
     // ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:49-51): + Phi^T xi
-    if (nd->sw_dimi > 0) {
+    if (sw_dimi > 0) {
       const double* __restrict__ W = B.swc + rec * L::SWC;
-      for (int j = 0; j < nd->sw_dimi; ++j) {
+      for (int j = 0; j < sw_dimi; ++j) {
         const double xi = s[L::S_XI + j];
         lq += W[L::W_PHIX + j + NF * r] * xi; lv += W[L::W_PHIX + j + NF * (NV + r)] * xi; la += W[L::W_PHIA + j + NF * r] * xi;
       }
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   if (RESIDUAL) {
     // SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264)
-    if (nd->sw_dimi > 0 && tid >= 200 && tid < 200 + nd->sw_dimi) {
+    if (sw_dimi > 0 && tid >= 200 && tid < 200 + sw_dimi) {
       const double pr = B.swc[rec * L::SWC + L::W_P + tid - 200];
       err_local += pr * pr;
     }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   __syncthreads();
 
-  const double hu = nd->has_u ? 1.0 : 0.0;          // impulse stages have no torque variables: Qafu = 0, Fvu = 0
+  const double hu = (PLAIN || nd->has_u) ? 1.0 : 0.0;          // impulse stages have no torque variables: Qafu = 0, Fvu = 0
   STAMP(7);
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
   if ((dimvf & 1) == 0) mmTN22(&sm[S::MJD], NVF, &sm[S::MJ], NVF, &sm[S::DIDC], NVF, dimvf, NX, dimvf, 1.0, false, tid, nt);   // MJ symmetric
@@ -456,8 +459,8 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   if (tid < NVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
   // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199) ----
-  if (nd->sw_dimi > 0) {
-    const int dimi = nd->sw_dimi;
+  if (sw_dimi > 0) {
+    const int dimi = sw_dimi;
     double* __restrict__ W = B.swc + rec * L::SWC;
     for (int e = tid; e < dimi * NX; e += nt) {           // Phix -= Phia MJtJinv_dIDCdqv.topRows(nv)
       const int c = e / dimi, j = e - c * dimi;

@@ -38,7 +38,8 @@ __device__ __forceinline__ void quatToRot(const double* __restrict__ qt, double*
   R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
-template <typename D>
+// HYBRID = false: the chain holds regular stages only (no impulse stage): one pass, inputs straight from the record.
+template <typename D, bool HYBRID>
 __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NL = D::NL, LJ = D::LJ, NF = D::NF, NVF = D::NVF, NX = D::NX;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
   const long b = unit / (M - 1);
   const int pos = (int)(unit - b * (M - 1));
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  const bool impulse = nd->kind == 1;
+  const bool impulse = HYBRID ? (nd->kind == 1) : false;
   const long rec = b * P->NS + nd->slot;
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
@@ -263,10 +264,11 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
 }
 
 template <typename D>
-void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_rnea_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
+void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st) {
+  if (hybrid) hipLaunchKernelGGL((ocp_rnea_kernel<D, true>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
+  else hipLaunchKernelGGL((ocp_rnea_kernel<D, false>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::rnea(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::rnea(const OcpBuffers&, long, int, bool, hipStream_t);
 
 }  // namespace idocp_dev
