@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE = {"iiwa14": 5544, "anymal": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 5
+A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
 KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
                "ocp_reduce_steps", "ocp_expand_dual_integrate"]
@@ -64,13 +64,22 @@ class Hip:
         return ms.value
 
 
-def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=12.0):
+def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=12.0, nimp=0):
     """CPU restatement (oracle, kind "port") timed on this host with the
     reference's CPUTime protocol, single thread, on a bounded sample."""
-    from helpers import OracleOCP, OracleUnOCP, P, arr, oracle
+    from helpers import OracleOCP, OracleUnOCP, P, arr, oracle, trotting_sequence
     lib = oracle()
     ric = C.c_double()
-    if workload == "iiwa14":
+    if workload == "anymal_trotting":
+        o = OracleOCP(model, cost, cons, T, N, max_num_impulse=nimp + 1)
+        trotting_sequence(o, model, nimp)
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+        o.init_constraints(0.0)
+        bench = lib.oracle_ocp_bench
+        nconv = 10
+    elif workload == "iiwa14":
         o = OracleUnOCP(model, cost, cons, T, N)
         o.set_solution("q", q)
         o.set_solution("v", v)
@@ -144,7 +153,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["anymal", "iiwa14"], default="anymal")
+    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "iiwa14"], default="anymal_trotting",
+                    help="anymal_trotting = BASELINE.json configs[2] (trotting contact sequence); anymal = its uniform 4-contact variant "
+                         "(SURVEY 8d roofline case); iiwa14 = configs[1]")
     ap.add_argument("--batch", type=int, default=0, help="independent OCP instances per GPU (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,7 +170,7 @@ def main():
 
     from idocp_amd import capi
     from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,
-                         unocp_problem)
+                         trotting_sequence, unocp_problem)
     lib = capi.lib()                       # fails loudly if the HIP extension is missing
     hip = Hip()
     hip.rt.hipSetDevice(local_rank)
@@ -168,7 +179,33 @@ def main():
     T = 0.05 * N
     rng = np.random.default_rng(20240 + rank)
     pts = None
-    if args.workload == "anymal":
+    nimp = 0
+    if args.workload == "anymal_trotting":
+        # ANYmal OCPSolver, N=100, T=5.05, trotting schedule of examples/anymal/anymal_trotting.cpp:144-177 with
+        # 9 impulse phases (1 lift + 9 impulse events: 120 stages in the chain), switching constraints, impulse stages
+        nimp = 9
+        T = 0.5 + nimp * 0.5 + 0.05
+        B = args.batch or 1024
+        model = anymal_model()
+        cost, cons = anymal_problem(model, trotting_ref=True)
+        nq, nv = model.nq, model.nv
+        q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
+        v0 = np.zeros((B, nv))
+        solver = HipOCP(model, cost, cons, T, N, batch=B, device=local_rank, max_num_impulse=nimp + 1)
+        trotting_sequence(solver, model, nimp)
+        solver.set_solution("q", q0[0])
+        solver.set_solution("v", v0[0])
+        solver.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+        solver.init_constraints(0.0)
+        Mc = len(solver.chain(0.0))
+        KERNELS = KERNELS_OCP
+        launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
+        units = {0: B * (Mc - 1), 1: B * Mc, 2: B * (Mc - 1), 3: B * (Mc - 1), 4: B * Mc, 5: B * (Mc - 1), 6: B * Mc}
+        riccati_ids = (2, 3)
+        desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, trotting contact sequence (1 lift + %d impulse events, %d stages incl. impulse / "
+                "aux / lift stages, switching constraints; BASELINE.json configs[2]); " % (N, T, nimp, Mc))
+        assert solver.update(0.0, q0, v0) == 0
+    elif args.workload == "anymal":
         # BASELINE.json configs[2] / metric config: ANYmal OCPSolver, N=100, T=5 (dt=0.05), 4 point contacts active on
         # every stage (the uniform-contact variant of SURVEY 8d C3: trotting cost + linearized friction cone), FP64
         B = args.batch or 1024
@@ -279,7 +316,7 @@ def main():
                          "whole_step_frac": a_stage * B * (N + 1) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts)
+            out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts, nimp=nimp)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -55,8 +55,8 @@ class LinearizedFrictionCone final : public ConstraintComponentBase {
     mu = mu_in;
   }
 };
-// Impulse twin: accepted so that the reference's drivers compile; it only acts on impulse stages,
-// which the HIP path does not carry yet.
+// Impulse twin (src/constraints/linearized_impulse_friction_cone.cpp): the same cone on the impulse forces of an
+// impulse stage (no time-step scaling).
 class LinearizedImpulseFrictionCone final : public ConstraintComponentBase {
  public:
   LinearizedImpulseFrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
@@ -72,7 +72,8 @@ class Constraints {
   }
   void push_back(const std::shared_ptr<ConstraintComponentBase>& c) {
     if (c->family == ConstraintComponentBase::LinearFrictionCone) {
-      if (!c->upper) { c_.linearized_friction_cone = 1; c_.mu = c->mu; }     // upper = impulse twin (no-op)
+      if (!c->upper) c_.linearized_friction_cone = 1; else c_.linearized_impulse_friction_cone = 1;     // upper = impulse twin
+      c_.mu = c->mu;
       return;
     }
     (c->upper ? hi_ : lo_)[c->family] = 1;

@@ -20,12 +20,14 @@ class ContactForceCost final : public CostFunctionComponentBase {
     for (int i = 0; i < n_; ++i) { c_.f_ref[i][0] = 0.0; c_.f_ref[i][1] = 0.0; c_.f_ref[i][2] = robot.totalWeight() / n_; }
   }
   void set_f_weight(const std::vector<Eigen::Vector3d>& f_weight) { put(c_.f_weight, f_weight, "f_weight"); }
-  // impulse-force terms: accepted so that the reference's drivers compile; they only act on
-  // impulse stages, which the HIP path does not carry yet (idocp_ocp_create rejects them).
-  void set_fi_ref(const std::vector<Eigen::Vector3d>&) {}
-  void set_fi_weight(const std::vector<Eigen::Vector3d>&) {}
+  // impulse-force terms (contact_force_cost.cpp:167-211): act on the impulse stages
+  void set_fi_ref(const std::vector<Eigen::Vector3d>& fi_ref) { put(c_.fi_ref, fi_ref, "fi_ref"); }
+  void set_fi_weight(const std::vector<Eigen::Vector3d>& fi_weight) { put(c_.fi_weight, fi_weight, "fi_weight"); }
   bool exportTo(idocp_cost_t& cost) const override {
-    for (int i = 0; i < n_; ++i) for (int k = 0; k < 3; ++k) { cost.f_weight[i][k] = c_.f_weight[i][k]; cost.f_ref[i][k] = c_.f_ref[i][k]; }
+    for (int i = 0; i < n_; ++i) for (int k = 0; k < 3; ++k) {
+      cost.f_weight[i][k] = c_.f_weight[i][k]; cost.f_ref[i][k] = c_.f_ref[i][k];
+      cost.fi_weight[i][k] = c_.fi_weight[i][k]; cost.fi_ref[i][k] = c_.fi_ref[i][k];
+    }
     return true;
   }
 

@@ -40,14 +40,17 @@ class TrottingConfigurationSpaceCost final : public CostFunctionComponentBase {
   void set_a_weight(const Eigen::VectorXd& v) { put(c_.a_weight, v, dimv_, "a_weight"); }
   void set_qf_weight(const Eigen::VectorXd& v) { put(c_.qf_weight, v, dimv_, "qf_weight"); }
   void set_vf_weight(const Eigen::VectorXd& v) { put(c_.vf_weight, v, dimv_, "vf_weight"); }
-  // impulse-stage weights: accepted for source compatibility (see ContactForceCost::set_fi_weight)
-  void set_qi_weight(const Eigen::VectorXd&) {}
-  void set_vi_weight(const Eigen::VectorXd&) {}
-  void set_dvi_weight(const Eigen::VectorXd&) {}
+  // impulse-stage weights (computeImpulseCostDerivatives / Hessian, trotting_configuration_space_cost.cpp:308-376)
+  void set_qi_weight(const Eigen::VectorXd& v) { put(c_.qi_weight, v, dimv_, "qi_weight"); }
+  void set_vi_weight(const Eigen::VectorXd& v) { put(c_.vi_weight, v, dimv_, "vi_weight"); }
+  void set_dvi_weight(const Eigen::VectorXd& v) { put(c_.dvi_weight, v, dimv_, "dvi_weight"); }
   bool exportTo(idocp_cost_t& cost) const override {
     idocp_cost_t keep = cost;
     cost = c_;
-    for (int i = 0; i < IDOCP_MAX_CONTACTS; ++i) for (int k = 0; k < 3; ++k) { cost.f_weight[i][k] = keep.f_weight[i][k]; cost.f_ref[i][k] = keep.f_ref[i][k]; }
+    for (int i = 0; i < IDOCP_MAX_CONTACTS; ++i) for (int k = 0; k < 3; ++k) {
+      cost.f_weight[i][k] = keep.f_weight[i][k]; cost.f_ref[i][k] = keep.f_ref[i][k];
+      cost.fi_weight[i][k] = keep.fi_weight[i][k]; cost.fi_ref[i][k] = keep.fi_ref[i][k];
+    }
     return true;
   }
 

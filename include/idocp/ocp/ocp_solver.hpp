@@ -7,9 +7,9 @@
 // compatibility and ignored (the GPU replaces the OpenMP team).  Argument
 // errors: message on stderr + std::exit(EXIT_FAILURE), like the reference.
 //
-// Carried in this round: a horizon with one contact status on every stage
-// (setContactStatusUniformly).  Contact sequences with discrete events
-// (pushBackContactStatus: impulse / lift stages) are rejected loudly.
+// Contact sequences with discrete events (pushBackContactStatus: lift stages,
+// impulse + aux stages, switching constraints) run on the same kernels; the
+// event stages are reachable through getSolution("...", "impulse" | "aux" | "lift").
 #ifndef IDOCP_OCP_SOLVER_HPP_
 #define IDOCP_OCP_SOLVER_HPP_
 
@@ -45,7 +45,7 @@ class OCPSolver {
     }
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
-    check(idocp_ocp_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    check(idocp_ocp_create_hybrid(&robot.model(), &c, &k, T, N, max_num_impulse, 1, device, &h_));
     cache_.resize(N + 1);
   }
   ~OCPSolver() { idocp_ocp_destroy(h_); }
@@ -91,19 +91,25 @@ class OCPSolver {
   void setSolution(const std::string& name, const Eigen::Vector3d& value) { check(idocp_ocp_set_solution(h_, name.c_str(), value.data())); }
 
   void setContactStatusUniformly(const ContactStatus& contact_status) {
-    const int nc = contact_status.maxPointContacts();
-    std::vector<int> active(nc);
-    std::vector<double> pts(3 * (size_t)nc);
-    for (int c = 0; c < nc; ++c) {
-      active[c] = contact_status.isContactActive(c) ? 1 : 0;
-      for (int k = 0; k < 3; ++k) pts[3 * c + k] = contact_status.contactPoint(c)[k];
-    }
+    std::vector<int> active;
+    std::vector<double> pts;
+    flatten(contact_status, active, pts);
     check(idocp_ocp_set_contact_status_uniformly(h_, active.data(), pts.data()));
   }
-  void pushBackContactStatus(const ContactStatus&, const double) { unsupported("pushBackContactStatus"); }
-  void setContactPoints(const int, const std::vector<Eigen::Vector3d>&) { unsupported("setContactPoints(contact_phase, ...)"); }
-  void popBackContactStatus() { unsupported("popBackContactStatus"); }
-  void popFrontContactStatus() { unsupported("popFrontContactStatus"); }
+  // ocp_solver.cpp:174-197
+  void pushBackContactStatus(const ContactStatus& contact_status, const double switching_time) {
+    std::vector<int> active;
+    std::vector<double> pts;
+    flatten(contact_status, active, pts);
+    check(idocp_ocp_push_back_contact_status(h_, active.data(), pts.data(), switching_time));
+  }
+  void setContactPoints(const int contact_phase, const std::vector<Eigen::Vector3d>& contact_points) {
+    std::vector<double> pts(3 * contact_points.size());
+    for (size_t c = 0; c < contact_points.size(); ++c) for (int k = 0; k < 3; ++k) pts[3 * c + k] = contact_points[c][k];
+    check(idocp_ocp_set_contact_points(h_, contact_phase, pts.data()));
+  }
+  void popBackContactStatus() { check(idocp_ocp_pop_back_contact_status(h_)); }
+  void popFrontContactStatus() { check(idocp_ocp_pop_front_contact_status(h_)); }
   void clearLineSearchFilter() {}
 
   double KKTError() {
@@ -134,9 +140,13 @@ class OCPSolver {
       std::exit(EXIT_FAILURE);
     }
   }
-  static void unsupported(const char* what) {
-    std::cerr << "unsupported: OCPSolver::" << what << " (discrete events) is not carried by the HIP path yet" << '\n';
-    std::exit(EXIT_FAILURE);
+  static void flatten(const ContactStatus& cs, std::vector<int>& active, std::vector<double>& pts) {
+    const int nc = cs.maxPointContacts();
+    active.resize(nc); pts.resize(3 * (size_t)nc);
+    for (int c = 0; c < nc; ++c) {
+      active[c] = cs.isContactActive(c) ? 1 : 0;
+      for (int k = 0; k < 3; ++k) pts[3 * c + k] = cs.contactPoint(c)[k];
+    }
   }
 };
 

@@ -73,3 +73,30 @@ def test_iiwa14_unocp_benchmark_example_matches_oracle():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     init, its = kkt_errors(r.stdout)
     assert len(its) >= 10 and its[-1] < init
+
+
+def test_anymal_trotting_example_matches_oracle():
+    """examples/anymal_trotting.cpp = the reference's examples/anymal/anymal_trotting.cpp driver (contact sequence with a
+    lift and two impulse events) through the facade: its printed KKT errors follow the oracle's hybrid SQP iteration."""
+    from helpers import anymal_problem, trotting_sequence
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "anymal_trotting"), ANYMAL_URDF], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 25
+    model = anymal_model()
+    cost, cons = anymal_problem(model, trotting_ref=True)
+    o = OracleOCP(model, cost, cons, 1.55, 30, max_num_impulse=3)
+    trotting_sequence(o, model, 2)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(model.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    o.init_constraints(0.0)
+    ref_init = o.kkt_error(0.0, q, v)
+    assert abs(init - ref_init) <= 1e-5 * max(1.0, ref_init)          # printed with 6 significant digits
+    for k in range(25):
+        o.update(0.0, q, v)
+        ref = o.kkt_error(0.0, q, v)
+        assert abs(its[k] - ref) <= 2e-5 * max(1.0, ref) + 1e-9, (k, its[k], ref)
+    assert its[-1] < 1e-8
