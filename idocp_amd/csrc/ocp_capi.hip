@@ -364,7 +364,7 @@ int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
   std::memset(&p, 0, sizeof(p));
-  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS;
+  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS; p.E = max_num_impulse;
   p.baumgarte_time_step = T / N;                           // hybrid_container.hpp:186-188
   for (int i = 0; i < DQ::NV; ++i) {
     p.v_ref[i] = cost->v_ref[i]; p.q_weight[i] = cost->q_weight[i]; p.v_weight[i] = cost->v_weight[i]; p.a_weight[i] = cost->a_weight[i];
@@ -550,7 +550,7 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
   if (!h) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   if ((rc = discretize(h, t))) return rc;                 // ocp_solver.cpp:60-64
-  OcpLaunch<DQ>::initConstraints(h->B, h->batch, h->M(), h->stream);
+  OcpLaunch<DQ>::initConstraints(h->B, h->batch, h->NS, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;

@@ -83,7 +83,7 @@ struct OcpNode {
 
 struct OcpProblem {
   int N, batch;            // N = grid intervals (N_ideal)
-  int M, NS;               // chain length of the current discretisation; storage slots per instance
+  int M, NS, E;            // chain length of the current discretisation; storage slots per instance; max events
   double T, dt;            // dt = T / N: Baumgarte time step and the time step of the regular stages
   double v_ref[IDOCP_MAX_NV], u_ref[IDOCP_MAX_NV];
   double q_weight[IDOCP_MAX_NV], v_weight[IDOCP_MAX_NV], a_weight[IDOCP_MAX_NV], u_weight[IDOCP_MAX_NV];

@@ -299,15 +299,15 @@ template <typename D>
 __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NU = D::NU;
+  // Every SLOT is initialised, whether or not the current chain uses it (OCPLinearizer::initConstraints,
+  // ocp_linearizer.cpp:40-70, covers all N grid stages and the event stages): a later re-discretisation may bring a
+  // slot into the chain.  Kind and gating level follow from the slot index alone.
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
-  const long unit = blockIdx.x;                     // over batch * (M - 1): the non-terminal stages of the chain
-  const long b = unit / (M - 1);
-  const int pos = (int)(unit - b * (M - 1));
-  const OcpNode* __restrict__ nd = B.nodes + pos;
-  const int i = nd->level;
-  const bool impulse = nd->kind == 1;
-  const long su = b * P->NS + nd->slot;
+  const int NS = P->NS, N = P->N, E = P->E;
+  const long su = blockIdx.x;                       // over batch * NS
+  const int slot = (int)(su % NS);
+  const bool impulse = (slot > N && slot <= N + E);
+  const int i = (slot <= N) ? slot : (impulse ? -1 : 0);      // grid stage index; 0 on aux / lift stages
   const double* __restrict__ s = B.sol + su * L::SOL;
   for (int row = threadIdx.x; row < L::NCON; row += 64) {
     double sl = 1.0, dl = 0.0;
@@ -360,8 +360,8 @@ void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, h
   hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
 }
 template <typename D>
-void OcpLaunch<D>::initConstraints(const OcpBuffers& B, long batch, int M, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_init_constraints_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
+void OcpLaunch<D>::initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_init_constraints_kernel<D>), dim3((unsigned)(batch * NS)), dim3(64), 0, st, B);
 }
 
 template <typename D>

@@ -19,7 +19,7 @@ struct OcpLaunch {
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
   static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
   static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7
-  static void initConstraints(const OcpBuffers& B, long batch, int M, hipStream_t st);
+  static void initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st);     // every slot
   static void single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st);   // ids 4, 5, 6
 };
 

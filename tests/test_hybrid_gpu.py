@@ -89,3 +89,23 @@ def test_hybrid_convergence_and_kkt_error_parity():
         assert abs(e_g[0] - e_o) <= tol * max(1.0, e_o) + 1e-10, (it, e_g[0], e_o)
     assert e_g[0] < 1e-8
     compare_chain(o, g, M, ["q", "v", "a", "u", "f"], 1e-6, "converged solution")
+
+
+def test_moving_horizon_rediscretisation_parity():
+    """MPC use: the initial time advances, the events slide across the grid and the chain changes shape while the
+    stage records stay in their slots (OCPSolver::updateSolution re-discretises on every call, ocp_solver.cpp:72-73).
+    GPU and oracle must follow the same path through several re-discretisations."""
+    m, o, g, q, v = make_pair(31, 1.55, 2)
+    kinds_seen = set()
+    for it, t in enumerate([0.0, 0.0, 0.013, 0.027, 0.05, 0.05, 0.081, 0.11]):
+        assert o.update(t, q, v) == 0 and g.update(t, q, v) == 0
+        co, cg = o.chain(t), g.chain(t)
+        assert [(a["kind"], a["slot"]) for a in co] == [(b["kind"], b["slot"]) for b in cg]
+        kinds_seen.add("".join(c["kind"][0] for c in co))
+        M = len(co)
+        tol = 1e-10 if it == 0 else 1e-6
+        for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu"):
+            assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < tol, (it, t, f)
+        e_o, e_g = o.kkt_error(t, q, v), g.kkt_error(t, q, v)
+        assert abs(e_g[0] - e_o) <= 1e-6 * max(1.0, e_o)
+    assert len(kinds_seen) >= 2          # the chain did change shape along the way
