@@ -105,7 +105,9 @@ struct idocp_ocp {
   std::vector<double> chain_t;
   int Ngrid = 0;                      // grid stages after discretisation
   double disc_time = NAN;
-  bool seq_dirty = true, has_switch = false, has_impulse = false;
+  bool seq_dirty = true, has_switch = false;
+  int n_impulse = 0;
+  int* d_impulse_pos = nullptr;
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
   int M() const { return (int)chain.size(); }
 };
@@ -230,7 +232,6 @@ int discretize(idocp_ocp* h, double t) {
     nd.sw_dt1 = nd.dtq; nd.sw_dt2 = dt_next;
   };
   h->has_switch = false;
-  h->has_impulse = Ni > 0;
   for (int i = 0; i < Ng; ++i) {
     node(0, i, ts[i], dts[i], h->phases[phase[i]], i);
     if (imp_after[i] < 0 && lift_after[i] < 0 && i + 1 < Ng && imp_after[i + 1] >= 0) { addSwitch(h->chain.back(), imp_after[i + 1], dts[i + 1]); h->has_switch = true; }
@@ -259,6 +260,10 @@ int discretize(idocp_ocp* h, double t) {
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
+  std::vector<int> ipos;
+  for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
+  h->n_impulse = (int)ipos.size();
+  if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
   h->disc_time = t; h->seq_dirty = false;
@@ -360,6 +365,9 @@ int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost
   if ((rc = allocBufO(h, &tmp, ((size_t)h->NS * sizeof(OcpNode) + 7) / 8))) return fail(rc);
   h->d_nodes = reinterpret_cast<OcpNode*>(tmp);
   B.nodes = h->d_nodes;
+  if ((rc = allocBufO(h, &tmp, ((size_t)(max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
+  h->d_impulse_pos = reinterpret_cast<int*>(tmp);
+  B.impulse_pos = h->d_impulse_pos;
   B.q_ref = h->d_qref;
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
@@ -563,7 +571,7 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
   const int M = h->M();
   switch (kernel_id) {
     case 0:
-      OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->has_impulse, h->stream);
+      OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
       if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
       break;
     case 1: OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream); break;
@@ -582,7 +590,7 @@ int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q
   if ((rc = discretize(h, t))) return rc;                 // ocp_.discretize(contact_sequence_, t) (ocp_solver.cpp:72)
   const int M = h->M();
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->has_impulse, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream);
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
@@ -622,7 +630,7 @@ int idocp_ocp_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, co
   if ((rc = discretize(h, t))) return rc;
   const int M = h->M();
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->has_impulse, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::residual(h->B, h->batch, M, h->d_q0, h->stream);
   ocpKktErrorReduce(h->B, h->batch, h->stream);

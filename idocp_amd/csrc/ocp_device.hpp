@@ -102,6 +102,7 @@ struct OcpBuffers {
   const DevModel* model;
   const OcpProblem* prob;
   const OcpNode* nodes;  // [M] the chain
+  const int* impulse_pos; // chain positions of the impulse stages
   const double* q_ref;   // [M][NQ] reference configuration of every stage of the chain (time-varying cost)
   // per-stage arrays, indexed [instance][slot] (NS slots per instance)
   double* sol;           // [batch][NS][SOL]

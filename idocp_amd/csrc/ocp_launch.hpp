@@ -11,7 +11,7 @@ namespace idocp_dev {
 template <typename D>
 struct OcpLaunch {
   // M = length of the chain (stages in time order incl. event stages and the terminal stage)
-  static void rnea(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);          // K5a (M - 1 stages); hybrid: chain with impulse stages
+  static void rnea(const OcpBuffers& B, long batch, int M, int n_impulse, hipStream_t st);      // K5a (M - 1 stages; the n_impulse impulse stages in a launch of their own)
   static void switching(const OcpBuffers& B, long batch, int M, hipStream_t st);     // K5s: switching-constraint terms (all stages; no-op where absent)
   static void condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st);   // K5b (+ terminal); dimf = -1: mixed chain
   static void residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st);   // K8

@@ -36,9 +36,15 @@ struct RiccatiSmem {
   static_assert(2 * NU * NV == NU * NX, "GK aliases B^T P");
   // extra blocks of the HYBRID instantiation (stages that carry a switching constraint: Schur-complement step of
   // SplitRiccatiFactorizer::backwardRiccatiRecursion, split_riccati_factorizer.hxx:43-101)
+  // They alias blocks that are dead at that point, so the HYBRID instantiation needs no extra LDS:
+  //   A^T P (dead once F, H, G and the k-independent part of the s recursion are done; only ATPQQ / ATPVV are reused
+  //   later, as symmetrisation scratch):  DG, SS -> ATPQQ ;  DtM (lives until the write-back) -> ATPQV..ATPVQ ;
+  //   SDG, m, Phix^T m -> ATPVV (consumed before the symmetrisation)
+  //   B^T P / GK: M (dead once DtM is formed, before GK = Quu K is written)
+  // Phix, Phiu, P are read from the swc record (L2) where needed.
   static constexpr int NF = D::NF;
-  static constexpr int PHIX = TOTAL, PHIU = PHIX + NF * NX, DG = PHIU + NF * NU, SS = DG + NF * NU, SDG = SS + NF * NF,
-                       MMX = SDG + NF * NU, DTM = MMX + NF * NX, PV = DTM + NU * NX, MV = PV + NF, TOTAL_HYBRID = MV + NF + 4;
+  static constexpr int DG = ATPQQ, SS = DG + NF * NU, DTM = ATPQV, SDG = ATPVV, MV = SDG + NF * NU, SCORR = MV + NF, MMX = BTPQ;
+  static_assert(2 * NF * NU <= NV * NV && NU * NX <= 2 * NV * NV && NF * NU + NF + NX <= NV * NV && NF * NX <= 2 * NU * NV, "hybrid aliases");
 };
 
 template <typename D, int NT, bool HYBRID>
@@ -206,6 +212,25 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       lu[j] += acc;
     }
     __syncthreads();
+    // s recursion (:141-160), part that does not depend on k; needs P_{i+1}, s_{i+1} and A^T P, all still intact here
+    if (tid < NV) {
+      const int r = tid;
+      double sq, sv;
+      if (r < 6) {
+        sq = sv = 0.0;
+        for (int m = 0; m < 6; ++m) { sq += Fqq6[m + 6 * r] * sm[S::SQ + m]; sv += Fqv6[m + 6 * r] * sm[S::SQ + m]; }
+      } else {
+        sq = sm[S::SQ + r]; sv = dt * sm[S::SQ + r];
+      }
+      for (int m = 0; m < NV; ++m) { sq += Fvq[m + NV * r] * sm[S::SV + m]; sv += Fvv[m + NV * r] * sm[S::SV + m]; }
+      for (int c = 0; c < NV; ++c) {
+        sq -= AtPqq[r + NV * c] * Fx[c] + AtPqv[r + NV * c] * Fx[NV + c];
+        sv -= AtPvq[r + NV * c] * Fx[c] + AtPvv[r + NV * c] * Fx[NV + c];
+      }
+      sq -= lx[r]; sv -= lx[NV + r];
+      sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
+    }
+    __syncthreads();
     RSTAMP(3);
     // Qvq = Qqv^T (:94) -- only read through Qqv below, kept for completeness of the record
     // ---- LLT(Quu), K = -Quu^-1 Qxu^T, k = -Quu^-1 lu (split_riccati_factorizer.hxx:43-46) ----
@@ -218,21 +243,18 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     if (HYBRID && dimi > 0) {
       // ---- Schur complement w.r.t. the switching constraint Phix dx + Phiu du + P = 0 (split_riccati_factorizer.hxx:56-70) ----
       const double* __restrict__ W = B.swc + rec * L::SWC;
-      for (int e = tid; e < dimi * NX; e += nt) { const int c = e / dimi, j = e - c * dimi; sm[S::PHIX + j + NF * c] = W[L::W_PHIX + j + NF * c]; }
-      for (int e = tid; e < dimi * NU; e += nt) { const int c = e / dimi, j = e - c * dimi; sm[S::PHIU + j + NF * c] = W[L::W_PHIU + j + NF * c]; }
-      if (tid < dimi) sm[S::PV + tid] = W[L::W_P + tid];
-      __syncthreads();
+      const double* __restrict__ Phiu = W + L::W_PHIU;
       for (int e = tid; e < dimi * NU; e += nt) {                // DGinv = Phiu Ginv
         const int c = e / dimi, j = e - c * dimi;
         double acc = 0.0;
-        for (int m = 0; m < NU; ++m) acc += sm[S::PHIU + j + NF * m] * sm[S::GW + m + NU * c];
+        for (int m = 0; m < NU; ++m) acc += Phiu[j + NF * m] * sm[S::GW + m + NU * c];
         sm[S::DG + j + NF * c] = acc;
       }
       __syncthreads();
       for (int e = tid; e < dimi * dimi; e += nt) {              // S = DGinv Phiu^T
         const int c = e / dimi, j = e - c * dimi;
         double acc = 0.0;
-        for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * sm[S::PHIU + c + NF * m];
+        for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * Phiu[c + NF * m];
         sm[S::SS + j + NF * c] = acc;
       }
       __syncthreads();
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       double acc = 0.0;
 #pragma unroll
       for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
-      if (HYBRID && dimi > 0) for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * sm[S::PHIX + l + NF * c];     // K -= SinvDGinv^T Phix
+      if (HYBRID && dimi > 0) { const double* __restrict__ Phix = B.swc + rec * L::SWC + L::W_PHIX; for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Phix[l + NF * c]; }     // K -= SinvDGinv^T Phix
       sm[S::KM + e] = -acc;
     }
     if (tid >= NT - NU) {
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       double acc = 0.0;
 #pragma unroll
       for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
-      if (HYBRID && dimi > 0) for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * sm[S::PV + l];              // k -= SinvDGinv^T P
+      if (HYBRID && dimi > 0) { const double* __restrict__ Pv = B.swc + rec * L::SWC + L::W_P; for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Pv[l]; }              // k -= SinvDGinv^T P
       sm[S::KV + j] = -acc;
     }
     if (HYBRID && dimi > 0) {
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       for (int e = tid; e < dimi * NX; e += nt) {
         const int c = e / dimi, l = e - c * dimi;
         double acc = 0.0;
-        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * sm[S::PHIX + j + NF * c];
+        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * W[L::W_PHIX + j + NF * c];
         for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
         sm[S::MMX + l + NF * c] = acc;
         W[L::W_M + l + NF * c] = acc;
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
       if (tid < dimi) {
         const int l = tid;
         double acc = 0.0;
-        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * sm[S::PV + j];
+        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * W[L::W_P + j];
         for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * lu[m];
         sm[S::MV + l] = acc;
         W[L::W_m + l] = acc;
@@ -291,32 +313,27 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     }
     __syncthreads();
     if (HYBRID && dimi > 0) {
+      const double* __restrict__ W = B.swc + rec * L::SWC;
       for (int e = tid; e < NU * NX; e += nt) {                  // DtM = Phiu^T M (:88)
         const int c = e / NU, m = e - c * NU;
         double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += sm[S::PHIU + l + NF * m] * sm[S::MMX + l + NF * c];
+        for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIU + l + NF * m] * sm[S::MMX + l + NF * c];
         sm[S::DTM + m + NU * c] = acc;
       }
+      if (tid < NX) {                                            // Phix^T m (:98-99), consumed at the write-back
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIX + l + NF * tid] * sm[S::MV + l];
+        sm[S::SCORR + tid] = acc;
+      }
+      __syncthreads();                                           // M (aliasing GK) is dead from here
     }
     RSTAMP(4);
     // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
     mm(colMajor(&sm[S::GK], NU), colMajor(Quu, NU), colMajor(&sm[S::KM], NU), NU, NX, NU, 1.0, false, tid, nt);
-    // s recursion (:141-160) needs P_{i+1}, s_{i+1}: do it before P is overwritten
+    // s recursion, part 2: - Qxu k
     if (tid < NV) {
       const int r = tid;
-      double sq, sv;
-      if (r < 6) {
-        sq = sv = 0.0;
-        for (int m = 0; m < 6; ++m) { sq += Fqq6[m + 6 * r] * sm[S::SQ + m]; sv += Fqv6[m + 6 * r] * sm[S::SQ + m]; }
-      } else {
-        sq = sm[S::SQ + r]; sv = dt * sm[S::SQ + r];
-      }
-      for (int m = 0; m < NV; ++m) { sq += Fvq[m + NV * r] * sm[S::SV + m]; sv += Fvv[m + NV * r] * sm[S::SV + m]; }
-      for (int c = 0; c < NV; ++c) {
-        sq -= AtPqq[r + NV * c] * Fx[c] + AtPqv[r + NV * c] * Fx[NV + c];
-        sv -= AtPvq[r + NV * c] * Fx[c] + AtPvv[r + NV * c] * Fx[NV + c];
-      }
-      sq -= lx[r]; sv -= lx[NV + r];
+      double sq = sm[S::SQN + r], sv = sm[S::SVN + r];
       for (int j = 0; j < NU; ++j) { sq -= Qxu[r + NX * j] * sm[S::KV + j]; sv -= Qxu[(NV + r) + NX * j] * sm[S::KV + j]; }
       sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
     }
@@ -338,6 +355,9 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     }
     __syncthreads();
     RSTAMP(6);
+    double sc_q = 0.0, sc_v = 0.0;                    // Phix^T m of this thread's row, read before ATPVV becomes scratch
+    if (HYBRID && dimi > 0 && tid < NV) { sc_q = sm[S::SCORR + tid]; sc_v = sm[S::SCORR + NV + tid]; }
+    __syncthreads();
     // preserve the symmetry (:133-135) -- symmetrised values staged in the A^T P scratch
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     }
     if (tid < NV) {
       double sq = sm[S::SQN + tid], sv = sm[S::SVN + tid];
-      if (HYBRID && dimi > 0) for (int l = 0; l < dimi; ++l) { sq -= sm[S::PHIX + l + NF * tid] * sm[S::MV + l]; sv -= sm[S::PHIX + l + NF * (NV + tid)] * sm[S::MV + l]; }     // (:98-99)
+      if (HYBRID && dimi > 0) { sq -= sc_q; sv -= sc_v; }     // (:98-99)
       sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
       rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }
@@ -448,7 +468,7 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
 template <typename D>
 void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st) {
   (void)M;
-  const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double), smem_h = RiccatiSmem<D>::TOTAL_HYBRID * sizeof(double);
+  const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double), smem_h = smem;      // the Schur blocks alias dead ones
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -457,7 +477,7 @@ void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool 
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     configured = true;
   }
-  // A chain with switching constraints takes the HYBRID instantiation (55 kB of LDS: two instances per CU).
+  // A chain with switching constraints takes the HYBRID instantiation (same LDS footprint).
   if (hybrid) {
     hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, true>), dim3((unsigned)batch), dim3(128), smem_h, st, B);
     return;

@@ -38,9 +38,11 @@ __device__ __forceinline__ void quatToRot(const double* __restrict__ qt, double*
   R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
-// HYBRID = false: the chain holds regular stages only (no impulse stage): one pass, inputs straight from the record.
-template <typename D, bool HYBRID>
-__global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
+// IMPULSE = false: regular (stage / aux / lift) stages, one pass; launched over every non-terminal stage of the chain,
+// impulse stages return at once.  IMPULSE = true: the impulse stages only (two passes), launched over the list
+// B.impulse_pos of their chain positions.
+template <typename D, bool IMPULSE>
+__global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NL = D::NL, LJ = D::LJ, NF = D::NF, NVF = D::NVF, NX = D::NX;
   typedef Dual T;
@@ -56,10 +58,12 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
   const int kind = seeded ? lane / NV : 3;
   const int k = seeded ? lane - kind * NV : -1;
   const long unit = blockIdx.x;                       // one non-terminal stage of the chain per wavefront
-  const long b = unit / (M - 1);
-  const int pos = (int)(unit - b * (M - 1));
+  const int per = IMPULSE ? nlist : (M - 1);
+  const long b = unit / per;
+  const int pos = IMPULSE ? B.impulse_pos[(int)(unit - b * per)] : (int)(unit - b * per);
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  const bool impulse = HYBRID ? (nd->kind == 1) : false;
+  constexpr bool impulse = IMPULSE;
+  if (!IMPULSE && nd->kind == 1) return;
   const long rec = b * P->NS + nd->slot;
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
@@ -264,11 +268,11 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B) {
 }
 
 template <typename D>
-void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st) {
-  if (hybrid) hipLaunchKernelGGL((ocp_rnea_kernel<D, true>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
-  else hipLaunchKernelGGL((ocp_rnea_kernel<D, false>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
+void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, int n_impulse, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_rnea_kernel<D, false>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B, 0);
+  if (n_impulse > 0) hipLaunchKernelGGL((ocp_rnea_kernel<D, true>), dim3((unsigned)(batch * n_impulse)), dim3(64), 0, st, B, n_impulse);
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::rnea(const OcpBuffers&, long, int, bool, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::rnea(const OcpBuffers&, long, int, int, hipStream_t);
 
 }  // namespace idocp_dev
