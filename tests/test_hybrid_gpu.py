@@ -109,3 +109,40 @@ def test_moving_horizon_rediscretisation_parity():
         e_o, e_g = o.kkt_error(t, q, v), g.kkt_error(t, q, v)
         assert abs(e_g[0] - e_o) <= 1e-6 * max(1.0, e_o)
     assert len(kinds_seen) >= 2          # the chain did change shape along the way
+
+
+def test_flight_phase_sequence_parity():
+    """A running-style contact sequence with a FLIGHT phase (no active contact: dimf = 0 stages, two lift events in a row,
+    then two impulse events), the pattern of examples/anymal/anymal_running.cpp:148-215.  First iterations only: the point
+    is that every stage kind / contact dimension combination takes the same path on the GPU and in the oracle."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    N, T, E = 24, 1.0, 5
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+    g = HipOCP(m, cost, cons, T, N, max_num_impulse=E)
+    from helpers import anymal_contact_points
+    pts = anymal_contact_points(m).copy()
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in (o, g):
+        s.set_contact_status([1, 1, 1, 1], pts)
+        s.push_back_contact_status([0, 1, 0, 1], pts, 0.21)          # front feet lift
+        s.push_back_contact_status([0, 0, 0, 0], pts, 0.33)          # flight
+        p2 = pts.copy()
+        p2[:, 0] += 0.05
+        s.push_back_contact_status([1, 0, 1, 0], p2, 0.47)           # front feet touch down (impulse)
+        s.push_back_contact_status([1, 1, 1, 1], p2, 0.61)           # hind feet touch down (impulse)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    co, cg = o.chain(0.0), g.chain(0.0)
+    assert [(a["kind"], a["slot"], a["dimf"]) for a in co] == [(b["kind"], b["slot"], b["dimf"]) for b in cg]
+    assert any(c["dimf"] == 0 and c["kind"] == "stage" for c in co) and sum(1 for c in co if c["kind"] == "impulse") == 2
+    M = len(co)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, f
+    for it in range(3):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    for f in ("q", "v", "a", "u", "f"):
+        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-6, f
