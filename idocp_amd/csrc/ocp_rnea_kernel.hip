@@ -41,22 +41,29 @@ __device__ __forceinline__ void quatToRot(const double* __restrict__ qt, double*
 // IMPULSE = false: regular (stage / aux / lift) stages, one pass; launched over every non-terminal stage of the chain,
 // impulse stages return at once.  IMPULSE = true: the impulse stages only (two passes), launched over the list
 // B.impulse_pos of their chain positions.
+//
+// Work decomposition.  A tangent seed on a joint of leg L only perturbs leg L and (through the transmitted force) the base
+// rows; a seed on a base coordinate perturbs everything.  So the unit of work is an ITEM = (seed, leg): 18 base seeds x NL
+// legs + 9 joint seeds of each leg = 27 NL items (108 for a quadruped), each ONE leg sweep with one tangent -- half the
+// 54 seeds x 4 legs of the dense scheme.  A wavefront takes the items of a stage in ceil(27 NL / 64) rounds; the base rows
+// of a base seed are summed from its NL items (and the base's own inertial term) in a fixed order afterwards.
 template <typename D, bool IMPULSE>
 __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NL = D::NL, LJ = D::LJ, NF = D::NF, NVF = D::NVF, NX = D::NX;
+  constexpr int IPL = 18 + 3 * LJ, NITEMS = NL * IPL, ROUNDS = (NITEMS + 63) / 64;      // items per leg, items, rounds
   typedef Dual T;
-  __shared__ double s_out[3 * NV][NVF];   // column of each seed lane: rows [dID (NV) ; dC (NF)]
+  __shared__ double s_out[3 * NV][NVF];   // column of each seed: rows [dID (NV) ; dC (NF)]
   __shared__ double s_idc[NVF];           // nominal [ID ; C]
   __shared__ double s_cs[D::NU][2];       // cos / sin of the leg joint angles
   __shared__ double s_v[NV], s_a[NV];     // velocity / acceleration inputs of the current pass
+  __shared__ double s_bt[NITEMS][6];      // tangent of the force each item's leg transmits to the base
+  __shared__ double s_bown[18][6];        // tangent of the base's own inertial force, per base seed
+  __shared__ double s_bn[NL + 1][6];      // nominal base force: own, then per leg
   const DevModel* __restrict__ m = B.model;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const int lane = threadIdx.x;
-  const bool seeded = lane < 3 * NV;
-  const int kind = seeded ? lane / NV : 3;
-  const int k = seeded ? lane - kind * NV : -1;
   const long unit = blockIdx.x;                       // one non-terminal stage of the chain per wavefront
   const int per = IMPULSE ? nlist : (M - 1);
   const long b = unit / per;
@@ -72,25 +79,18 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
     sincos(q[7 + lane], &sj, &cj);
     s_cs[lane][0] = cj; s_cs[lane][1] = sj;
   }
-  // zero the C rows of inactive contacts / unused rows
+  // zero the C rows of inactive contacts / rows a seed does not reach
   for (int r = lane; r < 3 * NV * NVF; r += 64) (&s_out[0][0])[r] = 0.0;
   if (lane < NVF) s_idc[lane] = 0.0;
-  double* __restrict__ col = seeded ? &s_out[lane][0] : &s_out[0][0];
   const double gz = impulse ? 0.0 : m->gravity[2];
   const double wv = 2.0 / P->baumgarte_time_step, wp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
   double Rn[9];
   quatToRot(q + 3, Rn);
-  // tangent of q (+) e_k on the manifold: dp = R e_lin, dR = R skew(e_ang)   (local-frame perturbation)
-  const double el[3] = {(kind == 0 && k == 0) ? 1.0 : 0.0, (kind == 0 && k == 1) ? 1.0 : 0.0, (kind == 0 && k == 2) ? 1.0 : 0.0};
-  const double ea[3] = {(kind == 0 && k == 3) ? 1.0 : 0.0, (kind == 0 && k == 4) ? 1.0 : 0.0, (kind == 0 && k == 5) ? 1.0 : 0.0};
 
   const int npass = impulse ? 2 : 1;
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     const bool do_dyn = (pass == 0), do_con = (!impulse) || (pass == 1);
-    // velocity seeds: the v lanes; in the kinematic pass of an impulse stage also the a lanes (dC/ddv = dC/dv)
-    const bool vseed = (kind == 1) || (impulse && pass == 1 && kind == 2);
-    const bool aseed = (kind == 2) && !(impulse && pass == 1);
     __syncthreads();
     if (lane < NV) {
       const double vin = s[L::S_V + lane], ain = s[L::S_A + lane];
@@ -98,37 +98,49 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
       s_a[lane] = impulse ? (pass == 0 ? ain : 0.0) : ain;
     }
     __syncthreads();
-    // ---- base (free-flyer): placement, velocity, acceleration (with the gravity field) ----
-    Mat3<T> Rb;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      Rb.m[3 * r + 0] = T(Rn[3 * r + 0], Rn[3 * r + 1] * ea[2] - Rn[3 * r + 2] * ea[1]);
-      Rb.m[3 * r + 1] = T(Rn[3 * r + 1], Rn[3 * r + 2] * ea[0] - Rn[3 * r + 0] * ea[2]);
-      Rb.m[3 * r + 2] = T(Rn[3 * r + 2], Rn[3 * r + 0] * ea[1] - Rn[3 * r + 1] * ea[0]);
-    }
-    const Vec3<T> pb = mk<T>(T(q[0], Rn[0] * el[0] + Rn[1] * el[1] + Rn[2] * el[2]), T(q[1], Rn[3] * el[0] + Rn[4] * el[1] + Rn[5] * el[2]),
-                             T(q[2], Rn[6] * el[0] + Rn[7] * el[1] + Rn[8] * el[2]));
-    auto seedV = [&](int idx) { return T(s_v[idx], (vseed && k == idx) ? 1.0 : 0.0); };
-    auto seedA = [&](int idx) { return T(s_a[idx], (aseed && k == idx) ? 1.0 : 0.0); };
-    const Vec3<T> vb = mk<T>(seedV(0), seedV(1), seedV(2)), wb = mk<T>(seedV(3), seedV(4), seedV(5));
-    // a_gf = a_joint + R^T (0, 0, -g_z)  (base acceleration in the gravity field; v x vJ = 0 for the root)
-    const Vec3<T> ab = mk<T>(seedA(0) - gz * Rb.m[6], seedA(1) - gz * Rb.m[7], seedA(2) - gz * Rb.m[8]);
-    const Vec3<T> alb = mk<T>(seedA(3), seedA(4), seedA(5));
-    Vec3<T> Fbl, Fbn;
-    {
-      Vec3<T> hl, hn, f, n;
-      inertiaMul<T>(m, 0, vb, wb, hl, hn);
-      inertiaMul<T>(m, 0, ab, alb, f, n);
-      Fbl = f + cross(wb, hl);
-      Fbn = n + cross(wb, hn) + cross(vb, hl);
-    }
-
-    // ---- legs ----
 #pragma unroll 1
-    for (int leg = 0; leg < NL; ++leg) {
-      Vec3<T> v = vb, w = wb, bl = ab, bw = alb;      // motion of the parent body, in its frame
-      Mat3<T> Rw = Rb;                                // world pose of the current frame
-      Vec3<T> pw = pb;
+    for (int round = 0; round < ROUNDS; ++round) {
+      const int item = round * 64 + lane;
+      if (item >= NITEMS) continue;
+      const int leg = item / IPL, j0 = item - leg * IPL;
+      const bool base_seed = j0 < 18;
+      const int kind = base_seed ? j0 / 6 : (j0 - 18) / LJ;                           // 0: q, 1: v, 2: a
+      const int k = base_seed ? j0 - 6 * kind : 6 + leg * LJ + (j0 - 18 - LJ * kind);   // velocity index of the seed
+      double* __restrict__ col = &s_out[kind * NV + k][0];
+      // velocity seeds: the v seeds; in the kinematic pass of an impulse stage also the a seeds (dC/ddv = dC/dv)
+      const bool vseed = (kind == 1) || (impulse && pass == 1 && kind == 2);
+      const bool aseed = (kind == 2) && !(impulse && pass == 1);
+      // ---- base (free-flyer): placement, velocity, acceleration (with the gravity field) ----
+      // tangent of q (+) e_k on the manifold: dp = R e_lin, dR = R skew(e_ang)   (local-frame perturbation)
+      const double el[3] = {(kind == 0 && k == 0) ? 1.0 : 0.0, (kind == 0 && k == 1) ? 1.0 : 0.0, (kind == 0 && k == 2) ? 1.0 : 0.0};
+      const double ea[3] = {(kind == 0 && k == 3) ? 1.0 : 0.0, (kind == 0 && k == 4) ? 1.0 : 0.0, (kind == 0 && k == 5) ? 1.0 : 0.0};
+      Mat3<T> Rw;                                       // world pose of the current frame (starts at the base)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Rw.m[3 * r + 0] = T(Rn[3 * r + 0], Rn[3 * r + 1] * ea[2] - Rn[3 * r + 2] * ea[1]);
+        Rw.m[3 * r + 1] = T(Rn[3 * r + 1], Rn[3 * r + 2] * ea[0] - Rn[3 * r + 0] * ea[2]);
+        Rw.m[3 * r + 2] = T(Rn[3 * r + 2], Rn[3 * r + 0] * ea[1] - Rn[3 * r + 1] * ea[0]);
+      }
+      Vec3<T> pw = mk<T>(T(q[0], Rn[0] * el[0] + Rn[1] * el[1] + Rn[2] * el[2]), T(q[1], Rn[3] * el[0] + Rn[4] * el[1] + Rn[5] * el[2]),
+                         T(q[2], Rn[6] * el[0] + Rn[7] * el[1] + Rn[8] * el[2]));
+      auto seedV = [&](int idx) { return T(s_v[idx], (vseed && k == idx) ? 1.0 : 0.0); };
+      auto seedA = [&](int idx) { return T(s_a[idx], (aseed && k == idx) ? 1.0 : 0.0); };
+      Vec3<T> v = mk<T>(seedV(0), seedV(1), seedV(2)), w = mk<T>(seedV(3), seedV(4), seedV(5));
+      // a_gf = a_joint + R^T (0, 0, -g_z)  (base acceleration in the gravity field; v x vJ = 0 for the root)
+      Vec3<T> bl = mk<T>(seedA(0) - gz * Rw.m[6], seedA(1) - gz * Rw.m[7], seedA(2) - gz * Rw.m[8]);
+      Vec3<T> bw = mk<T>(seedA(3), seedA(4), seedA(5));
+      if (do_dyn && leg == 0 && base_seed) {
+        // the base's own inertial force: once per base seed (and once for the nominal value)
+        Vec3<T> hl, hn, f, n;
+        inertiaMul<T>(m, 0, v, w, hl, hn);
+        inertiaMul<T>(m, 0, bl, bw, f, n);
+        const Vec3<T> Fbl = f + cross(w, hl);
+        const Vec3<T> Fbn = n + cross(w, hn) + cross(v, hl);
+        double* o = &s_bown[j0][0];
+        o[0] = Fbl.x.d; o[1] = Fbl.y.d; o[2] = Fbl.z.d; o[3] = Fbn.x.d; o[4] = Fbn.y.d; o[5] = Fbn.z.d;
+        if (j0 == 0) { double* on = &s_bn[0][0]; on[0] = Fbl.x.v; on[1] = Fbl.y.v; on[2] = Fbl.z.v; on[3] = Fbn.x.v; on[4] = Fbn.y.v; on[5] = Fbn.z.v; }
+      }
+      // ---- the leg of this item ----
 #pragma unroll 1
       for (int j = 0; j < LJ; ++j) {
         const int ji = 1 + leg * LJ + j, dof = 6 + leg * LJ + j, ci = leg * LJ + j;
@@ -191,8 +203,8 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
             dy = fa.y.d + (fw.z.v * fv.x.d - fw.x.v * fv.z.d) + (fv.z.v * fw.x.d - fv.x.v * fw.z.d) + wv * fv.y.d + wp * pf.y.d;
             dz = fa.z.d + (fw.x.v * fv.y.d - fw.y.v * fv.x.d) + (fv.x.v * fw.y.d - fv.y.v * fw.x.d) + wv * fv.z.d + wp * pf.z.d;
           }
-          if (seeded) { col[row] = dx; col[row + 1] = dy; col[row + 2] = dz; }
-          if (lane == 0) { s_idc[row] = cx; s_idc[row + 1] = cy; s_idc[row + 2] = cz; }
+          col[row] = dx; col[row + 1] = dy; col[row + 2] = dz;
+          if (j0 == 0) { s_idc[row] = cx; s_idc[row + 1] = cy; s_idc[row + 2] = cz; }
         }
         // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
         const double* f = s + L::S_F + 3 * leg;
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
         Fl = Fl + f + cross(w, hl);
         Fn = Fn + n + cross(w, hn) + cross(v, hl);
         const T ti = u[0] * Fn.x + u[1] * Fn.y + u[2] * Fn.z;
-        if (seeded) col[dof] = ti.d;
-        if (lane == 0) s_idc[dof] = ti.v;
+        col[dof] = ti.d;
+        if (j0 == 0) s_idc[dof] = ti.v;
         const bool mine = (k == dof);
         const T cqi(s_cs[ci][0], (mine && kind == 0) ? -s_cs[ci][1] : 0.0);
         const T sqi(s_cs[ci][1], (mine && kind == 0) ? s_cs[ci][0] : 0.0);
@@ -238,16 +250,31 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
           bl = mul(R, blc) - crossVC<T>(bw, p);
         }
       }
-      Fbl = Fbl + Fl;
-      Fbn = Fbn + Fn;
+      {
+        double* o = &s_bt[item][0];
+        o[0] = Fl.x.d; o[1] = Fl.y.d; o[2] = Fl.z.d; o[3] = Fn.x.d; o[4] = Fn.y.d; o[5] = Fn.z.d;
+        if (j0 == 0) { double* on = &s_bn[1 + leg][0]; on[0] = Fl.x.v; on[1] = Fl.y.v; on[2] = Fl.z.v; on[3] = Fn.x.v; on[4] = Fn.y.v; on[5] = Fn.z.v; }
+      }
     }
     if (do_dyn) {
-      // base rows: tau[0:6] = total spatial force on the base (S = identity)
-      if (seeded) {
-        col[0] = Fbl.x.d; col[1] = Fbl.y.d; col[2] = Fbl.z.d; col[3] = Fbn.x.d; col[4] = Fbn.y.d; col[5] = Fbn.z.d;
+      __syncthreads();
+      // base rows: tau[0:6] = total spatial force on the base (S = identity): own term + legs, in leg order
+      for (int e = lane; e < 3 * NV * 6; e += 64) {
+        const int c = e / 6, r = e - 6 * c, kind = c / NV, k = c - kind * NV;
+        double acc;
+        if (k < 6) {
+          acc = s_bown[kind * 6 + k][r];
+          for (int leg = 0; leg < NL; ++leg) acc += s_bt[leg * IPL + kind * 6 + k][r];
+        } else {
+          const int leg = (k - 6) / LJ;
+          acc = s_bt[leg * IPL + 18 + LJ * kind + (k - 6 - leg * LJ)][r];
+        }
+        s_out[c][r] = acc;
       }
-      if (lane == 0) {
-        s_idc[0] = Fbl.x.v; s_idc[1] = Fbl.y.v; s_idc[2] = Fbl.z.v; s_idc[3] = Fbn.x.v; s_idc[4] = Fbn.y.v; s_idc[5] = Fbn.z.v;
+      if (lane < 6) {
+        double acc = s_bn[0][lane];
+        for (int leg = 0; leg < NL; ++leg) acc += s_bn[1 + leg][lane];
+        s_idc[lane] = acc;
       }
     }
   }
