@@ -946,4 +946,519 @@ void OCPSolver::updateSolution(double t, const Mat& q, const Mat& v) {
   integrateSolution();
 }
 
+// =============================================================================================== ParNMPC ====
+ParNMPCSolver::ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N)
+    : robot(model), cost(cost_), cons(constraints), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), T_(T), dt_(T / N) {
+  if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
+  if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
+  if (!robot.hasFloatingBase()) throw std::logic_error("ParNMPCSolver oracle: floating-base robots only");
+  s.assign(N, SplitSolutionC(robot)); s_new = s;
+  d.assign(N, SplitDirectionC(robot));
+  kkt_matrix.assign(N, SplitKKTMatrixC(model.nv, model.nu));
+  kkt_residual.assign(N, SplitKKTResidualC(model.nv, model.nu));
+  cd.resize(N); ipm.resize(N);
+  const int nx = 2 * nv_;
+  KKT_mat_inv.assign(N, Mat(2 * nx + nu_, 2 * nx + nu_));
+  aux_mat.assign(N, Mat(nx, nx));
+  x_res.assign(N, Mat(nx));
+  contact_status.active.assign(nc_, false);
+  contact_status.points.assign(nc_, Mat(3));
+}
+
+void ParNMPCSolver::setContactStatusUniformly(const std::vector<int>& active, const double* pts) {
+  for (int c = 0; c < nc_; ++c) {
+    contact_status.active[c] = active[c] != 0;
+    for (int k2 = 0; k2 < 3; ++k2) contact_status.points[c][k2] = pts[3 * c + k2];
+  }
+}
+
+void ParNMPCSolver::setSolution(const std::string& name, const Mat& value) {
+  for (auto& e : s) {
+    if (name == "q") e.q = value;
+    else if (name == "v") e.v = value;
+    else if (name == "a") e.a = value;
+    else if (name == "u") e.u = value;
+    else if (name == "f") { for (auto& f : e.f) f = value; }
+    else throw std::invalid_argument("invalid arugment: name must be q, v, a, f, or u!");
+  }
+}
+
+bool ParNMPCSolver::componentValid(int c, int level) const {     // constraints_data.hpp:18-42
+  if (c < 2) return cons.joint_position_limits != 0 && level >= 2;
+  if (c < 4) return cons.joint_velocity_limits != 0 && level >= 1;
+  if (c < 6) return cons.joint_torque_limits != 0;
+  return cons.linearized_friction_cone != 0;
+}
+
+void ParNMPCSolver::qRef(double t, Mat& q_ref) const {
+  OCPSolver tmp_unused_guard(robot.model(), cost, cons, 1.0, 1);     // reuse the reference generator of the OCP oracle
+  tmp_unused_guard.qRef(t, q_ref);
+}
+
+// BackwardCorrectionSolver::initAuxMat (backward_correction_solver.cpp:54-92): every aux_mat = terminal cost Hessian at s[N-1]
+void ParNMPCSolver::initBackwardCorrection(double t) {
+  const int nv = nv_;
+  Mat q_ref, Jq;
+  qRef(t + N_ * dt_, q_ref);
+  robot.dSubtractdConfigurationPlus(s[N_ - 1].q, q_ref, Jq);
+  Mat Qxx(2 * nv, 2 * nv);
+  Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.qf_weight[r];
+  Qxx.addBlock(0, 0, Jq.t() * WJ);
+  for (int r = 0; r < nv; ++r) Qxx(nv + r, nv + r) += cost.vf_weight[r];
+  for (auto& a : aux_mat) a = Qxx;
+}
+
+// ParNMPCLinearizer::initConstraints (parnmpc_linearizer.cpp:43-75): stage i with time step i + 1
+void ParNMPCSolver::initConstraints(double /*t*/) {
+  for (int i = 0; i < N_; ++i) {
+    ipm[i].clear();
+    for (int c = 0; c < 7; ++c) {
+      IpmData data(componentDim(c));
+      if (componentValid(c, i + 1)) {
+        if (c < 6) {
+          const double sgn = (c & 1) ? 1.0 : -1.0;
+          for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
+        } else {
+          for (int cc = 0; cc < nc_; ++cc) {
+            double res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
+            for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
+          }
+        }
+        for (int r = 0; r < data.slack.size(); ++r) {
+          while (data.slack[r] < cons.barrier) data.slack[r] += cons.barrier;
+          data.dual[r] = cons.barrier / data.slack[r];
+        }
+      }
+      ipm[i].push_back(data);
+    }
+  }
+}
+
+// SplitParNMPC::linearizeOCP (split_parnmpc.hxx:50-84) / TerminalParNMPC::linearizeOCP (terminal_parnmpc.hxx:50-82)
+// and the computeKKTResidual twins.
+void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  const bool terminal = (i == N_ - 1);
+  const SplitSolutionC& si = s[i];
+  SplitKKTMatrixC& M = kkt_matrix[i];
+  SplitKKTResidualC& R = kkt_residual[i];
+  ContactDynamicsDataC& D = cd[i];
+  const ContactStatus& cs = contact_status;
+  const int nv = nv_, nu = nu_, dimf = cs.dimf(), level = i + 1;
+  const double dt = dt_;
+  robot.updateKinematics(si.q, si.v, si.a);
+  if (!residual_only) {
+    M.Qxx.setZero(); M.Qxu_full.setZero(); M.Quu_full.setZero(); M.Qaa_diag.setZero(); M.Qff = Mat(dimf, dimf);
+    M.Fvq.setZero(); M.Fvv.setZero(); M.Fvu.setZero();
+  }
+  R.Fq.setZero(); R.Fv.setZero(); R.lq.setZero(); R.lv.setZero(); R.la.setZero(); R.lf = Mat(dimf); R.lu.setZero(); R.lu_passive.setZero();
+  // ---- cost (stage + terminal on the last stage)
+  Mat q_ref, qdiff, Jq;
+  qRef(t, q_ref);
+  robot.subtractConfiguration(si.q, q_ref, qdiff);
+  robot.dSubtractdConfigurationPlus(si.q, q_ref, Jq);
+  Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.q_weight[r] * qdiff[r];
+  R.lq += dt * (Jq.t() * Wq);
+  const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  for (int r = 0; r < nv; ++r) {
+    R.lv[r] += dt * cost.v_weight[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+    R.la[r] += dt * cost.a_weight[r] * si.a[r];
+  }
+  for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
+  {
+    int st = 0;
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
+      for (int r = 0; r < 3; ++r) R.lf[st + r] += dt * cost.f_weight[c][r] * (si.f[c][r] - cost.f_ref[c][r]);
+      st += 3;
+    }
+  }
+  if (terminal) {
+    Mat Wf(nv); for (int r = 0; r < nv; ++r) Wf[r] = cost.qf_weight[r] * qdiff[r];
+    R.lq += Jq.t() * Wf;
+    for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+  }
+  // ---- constraints
+  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  for (int c = 0; c < 7; ++c) {
+    if (!componentValid(c, level)) continue;
+    IpmData& data = ipm[i][c];
+    if (c < 6) {
+      const double sgn = (c & 1) ? 1.0 : -1.0;
+      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
+      const int off = l.size() - nu;
+      for (int r = 0; r < nu; ++r) {
+        if (residual_only) {
+          data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), c, r)) + data.slack[r];
+          data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
+        }
+        l[off + r] += sgn * dt * data.dual[r];
+      }
+    } else {
+      if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
+      int st = 0;
+      for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+        if (residual_only) {
+          double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+          for (int r = 0; r < 5; ++r) {
+            data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
+            data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
+          }
+        }
+        for (int x = 0; x < 3; ++x) for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * data.dual[5 * cc + r];
+        st += 3;
+      }
+    }
+  }
+  // ---- state equation: linearizeBackwardEuler[Terminal] (state_equation.hxx:96-147, 222-233)
+  Mat diff; robot.subtractConfiguration(q_prev, si.q, diff);
+  for (int r = 0; r < nv; ++r) { R.Fq[r] = diff[r] + dt * si.v[r]; R.Fv[r] = v_prev[r] - si.v[r] + dt * si.a[r]; }
+  Mat Fqq; robot.dSubtractdConfigurationMinus(q_prev, si.q, Fqq);
+  M.Fqq6 = Fqq.block(0, 0, 6, 6);
+  {
+    Mat t1 = M.Fqq6.t() * si.lmd.segment(0, 6);
+    if (!terminal) {
+      const SplitSolutionC& sn = s[i + 1];
+      Mat Fqq_next; robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq_next);
+      M.Fqq_prev6 = Fqq_next.block(0, 0, 6, 6);
+      t1 += M.Fqq_prev6.t() * sn.lmd.segment(0, 6);
+      for (int r = 6; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
+      for (int r = 0; r < nv; ++r) R.lv[r] += dt * si.lmd[r] - si.gmm[r] + sn.gmm[r];
+    } else {
+      for (int r = 6; r < nv; ++r) R.lq[r] -= si.lmd[r];
+      for (int r = 0; r < nv; ++r) R.lv[r] += dt * si.lmd[r] - si.gmm[r];
+    }
+    for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
+    for (int r = 0; r < nv; ++r) R.la[r] += dt * si.gmm[r];
+  }
+  if (!residual_only) {
+    // condenseBackwardEuler (state_equation.hxx:149-170)
+    Mat Fp; robot.dSubtractdConfigurationPlus(q_prev, si.q, Fp);
+    Robot::dSubtractdConfigurationInverse(Fp.block(0, 0, 6, 6), M.Fqq_inv);
+    M.Fqq_prev6 = M.Fqq6;
+    R.Fq_prev = R.Fq.segment(0, 6);
+    M.Fqq6 = M.Fqq_inv * M.Fqq_prev6;
+    M.Fqv6 = dt * M.Fqq_inv;
+    R.Fq.setSegment(0, M.Fqq_inv * R.Fq_prev);
+  }
+  // ---- ContactDynamics::linearizeContactDynamics
+  robot.setContactForces(cs.active, si.f);
+  Mat ID_full, dIDdq, dIDdv, C, dCdq, dCdv;
+  robot.RNEA(si.q, si.v, si.a, ID_full);
+  for (int r = 0; r < nu; ++r) ID_full[kP + r] -= si.u[r];
+  robot.RNEADerivatives(si.q, si.v, si.a, dIDdq, dIDdv, D.dIDda);
+  robot.computeBaumgarteResidual(cs.active, dt_, cs.points, C);
+  robot.computeBaumgarteDerivatives(cs.active, dt_, dCdq, dCdv, D.dCda);
+  D.IDC = Mat(nv + dimf); D.IDC.setSegment(0, ID_full); D.IDC.setSegment(nv, C);
+  D.dIDCdqv = Mat(nv + dimf, 2 * nv);
+  D.dIDCdqv.setBlock(0, 0, dIDdq); D.dIDCdqv.setBlock(0, nv, dIDdv);
+  D.dIDCdqv.setBlock(nv, 0, dCdq); D.dIDCdqv.setBlock(nv, nv, dCdv);
+  R.lq += dt * (dIDdq.t() * si.beta);
+  R.lv += dt * (dIDdv.t() * si.beta);
+  R.la += dt * (D.dIDda.t() * si.beta);
+  const Mat mu_stack = si.mu_stack(cs);
+  if (dimf > 0) R.lf -= dt * (D.dCda * si.beta);
+  for (int r = 0; r < 6; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
+  for (int r = 0; r < nu; ++r) R.lu[r] -= dt * si.beta[kP + r];
+  if (dimf > 0) {
+    R.lq += dt * (dCdq.t() * mu_stack);
+    R.lv += dt * (dCdv.t() * mu_stack);
+    R.la += dt * (D.dCda.t() * mu_stack);
+  }
+  if (residual_only) return;
+  // ---- cost Hessian
+  {
+    Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.q_weight[r];
+    M.Qxx.addBlock(0, 0, Jq.t() * WJ, dt);
+    for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += dt * cost.v_weight[r]; M.Qaa_diag[r] += dt * cost.a_weight[r]; }
+    for (int r = 0; r < nu; ++r) M.Quu_full(kP + r, kP + r) += dt * cost.u_weight[r];
+    int st = 0;
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += dt * cost.f_weight[c][r]; st += 3; }
+    if (terminal) {
+      Mat WJf = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJf(r, c) *= cost.qf_weight[r];
+      M.Qxx.addBlock(0, 0, Jq.t() * WJf);
+      for (int r = 0; r < nv; ++r) M.Qxx(nv + r, nv + r) += cost.vf_weight[r];
+    }
+  }
+  // ---- Constraints::condenseSlackAndDual
+  for (int c = 0; c < 7; ++c) {
+    if (!componentValid(c, level)) continue;
+    IpmData& data = ipm[i][c];
+    if (c < 6) {
+      const double sgn = (c & 1) ? 1.0 : -1.0;
+      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
+      const int off = l.size() - nu;
+      for (int r = 0; r < nu; ++r) {
+        const double h = dt * data.dual[r] / data.slack[r];
+        if (c < 2) M.Qxx(kP + r, kP + r) += h;
+        else if (c < 4) M.Qxx(nv + kP + r, nv + kP + r) += h;
+        else M.Quu_full(kP + r, kP + r) += h;
+        data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), c, r)) + data.slack[r];
+        data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
+        l[off + r] += sgn * dt * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
+      }
+    } else {
+      data.residual.setZero(); data.duality.setZero();
+      int st = 0;
+      for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        double rr[5], dd[5];
+        for (int r = 0; r < 5; ++r) {
+          const int idx = 5 * cc + r;
+          data.residual[idx] = res[r] + data.slack[idx];
+          data.duality[idx] = data.slack[idx] * data.dual[idx] - cons.barrier;
+          rr[r] = (data.dual[idx] * data.residual[idx] - data.duality[idx]) / data.slack[idx];
+          dd[r] = data.dual[idx] / data.slack[idx];
+        }
+        for (int x = 0; x < 3; ++x) {
+          for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
+          for (int y = 0; y < 3; ++y) { double acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
+        }
+        st += 3;
+      }
+    }
+  }
+  // ---- ContactDynamics::condenseContactDynamics(..., is_forward_euler = false) (contact_dynamics.hxx:105-158)
+  Robot::computeMJtJinv(D.dIDda, D.dCda, D.MJtJinv);
+  D.MJtJinv_dIDCdqv = D.MJtJinv * D.dIDCdqv;
+  D.MJtJinv_IDC = D.MJtJinv * D.IDC;
+  D.Qafqv = Mat(nv + dimf, 2 * nv);
+  D.Qafu_full = Mat(nv + dimf, nv);
+  for (int c = 0; c < 2 * nv; ++c) for (int r = 0; r < nv; ++r) D.Qafqv(r, c) = -M.Qaa_diag[r] * D.MJtJinv_dIDCdqv(r, c);
+  for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) D.Qafu_full(r, c) = M.Qaa_diag[r] * D.MJtJinv(r, c);
+  if (dimf > 0) {
+    D.Qafqv.setBlock(nv, 0, -1.0 * (M.Qff * D.MJtJinv_dIDCdqv.block(nv, 0, dimf, 2 * nv)));
+    D.Qafu_full.setBlock(nv, 0, M.Qff * D.MJtJinv.block(nv, 0, dimf, nv));
+  }
+  D.laf = Mat(nv + dimf);
+  for (int r = 0; r < nv; ++r) D.laf[r] = R.la[r] - M.Qaa_diag[r] * D.MJtJinv_IDC[r];
+  if (dimf > 0) D.laf.setSegment(nv, -1.0 * R.lf - M.Qff * D.MJtJinv_IDC.segment(nv, dimf));
+  M.Qxx -= D.MJtJinv_dIDCdqv.t() * D.Qafqv;
+  M.Qxu_full -= D.MJtJinv_dIDCdqv.t() * D.Qafu_full;
+  {
+    Mat lx = D.MJtJinv_dIDCdqv.t() * D.laf;
+    for (int r = 0; r < nv; ++r) { R.lq[r] -= lx[r]; R.lv[r] -= lx[nv + r]; }
+  }
+  M.Quu_full += D.MJtJinv.block(0, 0, nv, nv + dimf) * D.Qafu_full;
+  {
+    Mat t1 = D.MJtJinv.block(0, 0, nv, nv + dimf) * D.laf;
+    for (int r = 0; r < 6; ++r) R.lu_passive[r] += t1[r];
+    for (int r = 0; r < nu; ++r) R.lu[r] += t1[kP + r];
+  }
+  M.Fvq = (-dt) * D.MJtJinv_dIDCdqv.block(0, 0, nv, nv);
+  M.Fvv = (-dt) * D.MJtJinv_dIDCdqv.block(0, nv, nv, nv) - Mat::Identity(nv);
+  M.Fvu = dt * D.MJtJinv.block(0, kP, nv, nu);
+  for (int r = 0; r < nv; ++r) R.Fv[r] -= dt * D.MJtJinv_IDC[r];
+}
+
+// BackwardCorrectionSolver::coarseUpdate (backward_correction_solver.cpp:95-250) -> SplitBackwardCorrection::coarseUpdate
+// (split_backward_correction.hxx:30-72) -> SplitKKTMatrixInverter::invert (split_kkt_matrix_inverter.hxx:44-80)
+void ParNMPCSolver::coarseUpdate(double t, const Mat& q, const Mat& v) {
+  const int nv = nv_, nu = nu_, nx = 2 * nv, nQ = nu + nx, nK = nx + nQ;
+  for (int i = 0; i < N_; ++i) {
+    const Mat& q_prev = i == 0 ? q : s[i - 1].q;
+    const Mat& v_prev = i == 0 ? v : s[i - 1].v;
+    linearizeStage(i, t + (i + 1) * dt_, q_prev, v_prev, false);
+    SplitKKTMatrixC& M = kkt_matrix[i];
+    const SplitKKTResidualC& R = kkt_residual[i];
+    if (i < N_ - 1) M.Qxx += aux_mat[i + 1];
+    M.Qxx.setBlock(nv, 0, M.Qxx.block(0, nv, nv, nv).t());            // Qvq = Qqv^T
+    // Qss = [Quu Qux; Qxu Qxx] in the order (u, q, v); F = [0 Fqq Fqv; Fvu Fvq Fvv]
+    Mat Q(nQ, nQ), F(nx, nQ);
+    Mat Qxu = M.Qxu_full.block(0, kP, nx, nu);
+    Q.setBlock(0, 0, M.Quu_full.block(kP, kP, nu, nu)); Q.setBlock(0, nu, Qxu.t()); Q.setBlock(nu, 0, Qxu); Q.setBlock(nu, nu, M.Qxx);
+    Mat Fqq = -1.0 * Mat::Identity(nv), Fqv = dt_ * Mat::Identity(nv);
+    Fqq.setBlock(0, 0, M.Fqq6); Fqv.setBlock(0, 0, M.Fqv6);
+    for (int r = 0; r < 6; ++r) for (int c = 6; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; Fqv(r, c) = 0; Fqv(c, r) = 0; }
+    F.setBlock(0, nu, Fqq); F.setBlock(0, nu + nv, Fqv);
+    F.setBlock(nv, 0, M.Fvu); F.setBlock(nv, nu, M.Fvq); F.setBlock(nv, nu + nv, M.Fvv);
+    LLT lltQ;
+    if (!lltQ.compute(Q)) throw std::runtime_error("ParNMPC: Qss not positive definite at stage " + std::to_string(i));
+    Mat Qinv = lltQ.solve(Mat::Identity(nQ));
+    Mat FQinv = F * Qinv;
+    Mat S = F * FQinv.t();
+    LLT lltS;
+    if (!lltS.compute(S)) throw std::runtime_error("ParNMPC: F Qss^-1 F^T not positive definite at stage " + std::to_string(i));
+    Mat TL = -1.0 * lltS.solve(Mat::Identity(nx));
+    Mat TR = -1.0 * (TL * FQinv);
+    Mat BR = Qinv - TR.t() * (S * TR);
+    Mat& Ki = KKT_mat_inv[i];
+    Ki = Mat(nK, nK);
+    Ki.setBlock(0, 0, TL); Ki.setBlock(0, nx, TR); Ki.setBlock(nx, 0, TR.t()); Ki.setBlock(nx, nx, BR);
+    Mat res(nK);
+    res.setSegment(0, R.Fq); res.setSegment(nv, R.Fv); res.setSegment(nx, R.lu); res.setSegment(nx + nu, R.lq); res.setSegment(nx + nu + nv, R.lv);
+    Mat dir = Ki * res;
+    SplitSolutionC& sn = s_new[i];
+    sn = s[i];
+    sn.lmd = s[i].lmd - dir.segment(0, nv);
+    sn.gmm = s[i].gmm - dir.segment(nv, nv);
+    sn.u = s[i].u - dir.segment(nx, nu);
+    Mat qn; robot.integrateConfiguration(s[i].q, dir.segment(nx + nu, nv), -1.0, qn); sn.q = qn;
+    sn.v = s[i].v - dir.segment(nx + nu + nv, nv);
+  }
+}
+
+// backward_correction_solver.cpp:253-287; split_backward_correction.hxx:84-95
+void ParNMPCSolver::backwardCorrectionSerial() {
+  const int nv = nv_, nx = 2 * nv, nK = 2 * nx + nu_;
+  for (int i = N_ - 2; i >= 0; --i) {
+    x_res[i].setSegment(0, s_new[i + 1].lmd - s[i + 1].lmd);
+    x_res[i].setSegment(nv, s_new[i + 1].gmm - s[i + 1].gmm);
+    Mat dx = KKT_mat_inv[i].block(0, nK - nx, nx, nx) * x_res[i];
+    s_new[i].lmd -= dx.segment(0, nv);
+    s_new[i].gmm -= dx.segment(nv, nv);
+  }
+}
+// :288-318; split_backward_correction.hxx:96-108
+void ParNMPCSolver::backwardCorrectionParallel() {
+  const int nv = nv_, nu = nu_, nx = 2 * nv, nK = 2 * nx + nu;
+  for (int i = 0; i < N_ - 1; ++i) {
+    Mat dz = KKT_mat_inv[i].block(nx, nK - nx, nK - nx, nx) * x_res[i];       // (du, dq, dv)
+    s_new[i].u -= dz.segment(0, nu);
+    Mat qn; robot.integrateConfiguration(s_new[i].q, dz.segment(nu, nv), -1.0, qn); s_new[i].q = qn;
+    s_new[i].v -= dz.segment(nu + nv, nv);
+  }
+}
+// :319-352; split_backward_correction.hxx:109-120
+void ParNMPCSolver::forwardCorrectionSerial() {
+  const int nv = nv_, nx = 2 * nv, nK = 2 * nx + nu_;
+  for (int i = 1; i < N_; ++i) {
+    Mat dq; robot.subtractConfiguration(s_new[i - 1].q, s[i - 1].q, dq);
+    x_res[i].setSegment(0, dq);
+    x_res[i].setSegment(nv, s_new[i - 1].v - s[i - 1].v);
+    Mat dx = KKT_mat_inv[i].block(nK - nx, 0, nx, nx) * x_res[i];
+    Mat qn; robot.integrateConfiguration(s_new[i].q, dx.segment(0, nv), -1.0, qn); s_new[i].q = qn;
+    s_new[i].v -= dx.segment(nv, nv);
+  }
+}
+// :353-470; split_backward_correction.hxx:121-155; SplitParNMPC::computeCondensed{Primal,Dual}Direction
+void ParNMPCSolver::forwardCorrectionParallel() {
+  const int nv = nv_, nu = nu_, nx = 2 * nv, nK = 2 * nx + nu;
+  double pmin = 1, dmin = 1;
+  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  const ContactStatus& cs = contact_status;
+  const int dimf = cs.dimf();
+  for (int i = 0; i < N_; ++i) {
+    if (i > 0) {
+      Mat dh = KKT_mat_inv[i].block(0, 0, nK - nx, nx) * x_res[i];             // (dlmd, dgmm, du)
+      s_new[i].lmd -= dh.segment(0, nv);
+      s_new[i].gmm -= dh.segment(nv, nv);
+      s_new[i].u -= dh.segment(nx, nu);
+    }
+    aux_mat[i] = -1.0 * KKT_mat_inv[i].block(0, 0, nx, nx);
+    // computeDirection
+    d[i].dlmd = s_new[i].lmd - s[i].lmd;
+    d[i].dgmm = s_new[i].gmm - s[i].gmm;
+    d[i].du = s_new[i].u - s[i].u;
+    robot.subtractConfiguration(s_new[i].q, s[i].q, d[i].dq);
+    d[i].dv = s_new[i].v - s[i].v;
+    // primal expansion
+    const ContactDynamicsDataC& D = cd[i];
+    Mat dx(nx); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
+    d[i].daf = -1.0 * (D.MJtJinv_dIDCdqv * dx);
+    d[i].daf += D.MJtJinv.block(0, kP, nv + dimf, nu) * d[i].du;
+    d[i].daf -= D.MJtJinv_IDC;
+    for (int r2 = 0; r2 < dimf; ++r2) d[i].daf[nv + r2] *= -1;
+    for (int c = 0; c < 7; ++c) {
+      if (!componentValid(c, i + 1)) continue;
+      IpmData& data = ipm[i][c];
+      if (c < 6) {
+        const double sgn = (c & 1) ? 1.0 : -1.0;
+        for (int r2 = 0; r2 < nu; ++r2) {
+          const double dxr = c < 2 ? d[i].dq[kP + r2] : (c < 4 ? d[i].dv[kP + r2] : d[i].du[r2]);
+          data.dslack[r2] = -sgn * dxr - data.residual[r2];
+          data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
+        }
+      } else {
+        for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
+        int st = 0;
+        for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+          for (int r2 = 0; r2 < 5; ++r2) {
+            const int idx = 5 * cc + r2;
+            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[i].daf[nv + st + x];
+            data.dslack[idx] = -Jdf - data.residual[idx];
+            data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
+          }
+          st += 3;
+        }
+      }
+      pmin = std::min(pmin, fractionToBoundary(cons.fraction_to_boundary_rate, data.slack, data.dslack));
+      dmin = std::min(dmin, fractionToBoundary(cons.fraction_to_boundary_rate, data.dual, data.ddual));
+    }
+    // dual expansion (contact_dynamics.hxx:171-190) with the stage's OWN dgmm, then the costate correction
+    // (state_equation.hxx:172-181)
+    SplitKKTMatrixC& M = kkt_matrix[i];
+    SplitKKTResidualC& R = kkt_residual[i];
+    ContactDynamicsDataC& Dm = cd[i];
+    d[i].dnu_passive = R.lu_passive;
+    d[i].dnu_passive += M.Quu_full.block(0, kP, 6, nu) * d[i].du;
+    d[i].dnu_passive += M.Qxu_full.block(0, 0, nx, 6).t() * dx;
+    d[i].dnu_passive += dt_ * (Dm.MJtJinv.block(0, 0, 6, nv) * d[i].dgmm);
+    d[i].dnu_passive = (-1.0 / dt_) * d[i].dnu_passive;
+    Dm.laf += Dm.Qafqv * dx;
+    Dm.laf += Dm.Qafu_full.block(0, kP, nv + dimf, nu) * d[i].du;
+    for (int r = 0; r < nv; ++r) Dm.laf[r] += dt_ * d[i].dgmm[r];
+    d[i].dbetamu = (-1.0 / dt_) * (Dm.MJtJinv * Dm.laf);
+    d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, 6));
+  }
+  primal_step_size = pmin; dual_step_size = dmin;
+}
+
+// ParNMPCLinearizer::integrateSolution (parnmpc_linearizer.cpp:248-300)
+void ParNMPCSolver::integrateSolution() {
+  const int nv = nv_;
+  const double ap = primal_step_size, ad = dual_step_size;
+  for (int i = 0; i < N_; ++i) {
+    SplitSolutionC& si = s[i];
+    si.lmd += ap * d[i].dlmd;
+    si.gmm += ap * d[i].dgmm;
+    Mat qn; robot.integrateConfiguration(si.q, d[i].dq, ap, qn); si.q = qn;
+    si.v += ap * d[i].dv;
+    si.a += ap * d[i].daf.segment(0, nv);
+    si.u += ap * d[i].du;
+    si.beta += ap * d[i].dbetamu.segment(0, nv);
+    si.nu_passive += ap * d[i].dnu_passive;
+    int st = 0;
+    for (int c = 0; c < nc_; ++c) if (contact_status.active[c]) {
+      for (int r = 0; r < 3; ++r) { si.f[c][r] += ap * d[i].daf[nv + st + r]; si.mu[c][r] += ap * d[i].dbetamu[nv + st + r]; }
+      st += 3;
+    }
+    for (int c = 0; c < 7; ++c) {
+      if (!componentValid(c, i + 1)) continue;
+      ipm[i][c].slack += ap * ipm[i][c].dslack;
+      ipm[i][c].dual += ad * ipm[i][c].ddual;
+    }
+  }
+}
+
+void ParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+  coarseUpdate(t, q, v);
+  auto t0 = std::chrono::steady_clock::now();
+  backwardCorrectionSerial();
+  serial_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  backwardCorrectionParallel();
+  t0 = std::chrono::steady_clock::now();
+  forwardCorrectionSerial();
+  serial_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  forwardCorrectionParallel();
+  integrateSolution();
+}
+
+void ParNMPCSolver::computeKKTResidual(double t, const Mat& q, const Mat& v) {
+  for (int i = 0; i < N_; ++i) linearizeStage(i, t + (i + 1) * dt_, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
+}
+
+// ParNMPCLinearizer::KKTError (parnmpc_linearizer.cpp:203-247); SplitParNMPC::squaredNormKKTResidual (split_parnmpc.hxx:250-266):
+// note that the constraint residuals are NOT weighted by dt^2 here, unlike SplitOCP
+double ParNMPCSolver::KKTError() {
+  double sum = 0;
+  for (int i = 0; i < N_; ++i) {
+    const SplitKKTResidualC& R = kkt_residual[i];
+    double e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
+               R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt_ * dt_ * cd[i].IDC.squaredNorm();
+    double c2 = 0;
+    for (int c = 0; c < 7; ++c) if (componentValid(c, i + 1)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
+    sum += e + c2;
+  }
+  return std::sqrt(sum);
+}
+
 }  // namespace oracle

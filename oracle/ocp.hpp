@@ -174,5 +174,51 @@ class OCPSolver {
   void linearizeTerminal(int p, const Mat& q_prev, bool residual_only);
 };
 
+// ParNMPCSolver for horizons WITHOUT discrete events (src/ocp/parnmpc_solver.cpp:66-103): backward-Euler stages
+// (SplitParNMPC / TerminalParNMPC, include/idocp/ocp/split_parnmpc.hxx, terminal_parnmpc.hxx), per-stage KKT inverse
+// (SplitKKTMatrixInverter, split_kkt_matrix_inverter.hxx:44-80), coarse update and the four correction sweeps of
+// BackwardCorrectionSolver (src/ocp/backward_correction_solver.cpp:62-490, split_backward_correction.hxx:30-155).
+// Stage i (0 <= i < N) lives at time t + (i + 1) dt; the state before stage 0 is the measured (q, v).
+class ParNMPCSolver {
+ public:
+  ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N);
+  void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points);
+  void setSolution(const std::string& name, const Mat& value);
+  void initBackwardCorrection(double t);                              // parnmpc_solver.cpp:66-70
+  void initConstraints(double t);                                     // parnmpc_linearizer.cpp:43-75
+  void updateSolution(double t, const Mat& q, const Mat& v);           // parnmpc_solver.cpp:73-103
+  void computeKKTResidual(double t, const Mat& q, const Mat& v);
+  double KKTError();                                                   // parnmpc_linearizer.cpp:203-247
+  // the phases of updateSolution, separately callable
+  void coarseUpdate(double t, const Mat& q, const Mat& v);
+  void backwardCorrectionSerial();
+  void backwardCorrectionParallel();
+  void forwardCorrectionSerial();
+  void forwardCorrectionParallel();
+  void integrateSolution();
+  int N() const { return N_; }
+  Robot robot;
+  idocp_cost_t cost;
+  idocp_constraints_t cons;
+  ContactStatus contact_status;
+  std::vector<SplitSolutionC> s, s_new;
+  std::vector<SplitDirectionC> d;
+  std::vector<SplitKKTMatrixC> kkt_matrix;
+  std::vector<SplitKKTResidualC> kkt_residual;
+  std::vector<ContactDynamicsDataC> cd;
+  std::vector<std::vector<IpmData>> ipm;
+  std::vector<Mat> KKT_mat_inv, aux_mat, x_res;      // (2nx+nu)^2, nx^2, nx per stage
+  double primal_step_size = 1, dual_step_size = 1;
+  double serial_seconds = 0;
+
+ private:
+  int N_, nv_, nu_, nc_;
+  double T_, dt_;
+  bool componentValid(int c, int level) const;
+  int componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
+  void qRef(double t, Mat& q_ref) const;
+  void linearizeStage(int i, double t, const Mat& q_prev, const Mat& v_prev, bool residual_only);
+};
+
 }  // namespace oracle
 #endif  // ORACLE_OCP_HPP_

@@ -528,4 +528,62 @@ double oracle_ocp_bench(void* h, double t, const double* q, const double* v, int
   return el;
 }
 
+// ---- ParNMPCSolver (event-free horizons) -------------------------------------------------
+void* oracle_parnmpc_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
+  try { return new ParNMPCSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
+}
+void oracle_parnmpc_destroy(void* h) { delete static_cast<ParNMPCSolver*>(h); }
+int oracle_parnmpc_set_contact_status(void* h, const int* active, const double* points) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  std::vector<int> a(active, active + s->robot.maxPointContacts());
+  s->setContactStatusUniformly(a, points);
+  return 0;
+}
+int oracle_parnmpc_set_solution(void* h, const char* name, const double* value) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  const std::string n(name);
+  const int dim = n == "q" ? s->robot.dimq() : (n == "u" ? s->robot.dimu() : (n == "f" ? 3 : s->robot.dimv()));
+  try { s->setSolution(n, toVec(value, dim)); } catch (...) { return -1; }
+  return 0;
+}
+int oracle_parnmpc_init(void* h, double t) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  s->initBackwardCorrection(t);
+  s->initConstraints(t);
+  return 0;
+}
+int oracle_parnmpc_update_solution(void* h, double t, const double* q, const double* v) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); } catch (...) { return 1; }
+  return 0;
+}
+double oracle_parnmpc_kkt_error(void* h, double t, const double* q, const double* v) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+  return s->KKTError();
+}
+// solution / direction field of every stage: out[N][stride]
+int oracle_parnmpc_get(void* h, const char* name, int stride, double* out) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  const std::string n(name);
+  const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
+  for (int i = 0; i < s->N(); ++i) {
+    double* o = out + (size_t)i * stride;
+    const SplitSolutionC& x = s->s[i];
+    const SplitDirectionC& d = s->d[i];
+    auto put = [&](const Mat& m) { for (int k = 0; k < m.size() && k < stride; ++k) o[k] = m[k]; };
+    if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a); else if (n == "u") put(x.u);
+    else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
+    else if (n == "f") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.f[c][k]; }
+    else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv); else if (n == "du") put(d.du);
+    else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm);
+    else if (n == "da") put(d.daf.segment(0, nv));
+    else return -1;
+  }
+  return 0;
+}
+int oracle_parnmpc_get_step_sizes(void* h, double* primal, double* dual) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  *primal = s->primal_step_size; *dual = s->dual_step_size; return 0;
+}
 }  // extern "C"

@@ -435,6 +435,62 @@ class OracleOCP:
         return Qxx.T, Qxu.T, Quu.T, A.T, B.T, lx, lu, Fx
 
 
+class OracleParNMPC:
+    """ParNMPCSolver of the oracle (event-free horizons): examples/anymal/parnmpc_benchmark.cpp call order."""
+
+    def __init__(self, model, cost, cons, T, N):
+        self.lib = lib = oracle()
+        vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
+        if not getattr(lib, "_parnmpc_ready", False):
+            lib.oracle_parnmpc_create.argtypes = [C.POINTER(capi.Model), C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]
+            lib.oracle_parnmpc_create.restype = vp
+            lib.oracle_parnmpc_destroy.argtypes = [vp]
+            lib.oracle_parnmpc_set_contact_status.argtypes = [vp, C.POINTER(ci), dp]
+            lib.oracle_parnmpc_set_solution.argtypes = [vp, cs, dp]
+            lib.oracle_parnmpc_init.argtypes = [vp, cd]
+            lib.oracle_parnmpc_update_solution.argtypes = [vp, cd, dp, dp]
+            lib.oracle_parnmpc_kkt_error.argtypes = [vp, cd, dp, dp]
+            lib.oracle_parnmpc_kkt_error.restype = cd
+            lib.oracle_parnmpc_get.argtypes = [vp, cs, ci, dp]
+            lib.oracle_parnmpc_get_step_sizes.argtypes = [vp, dp, dp]
+            lib._parnmpc_ready = True
+        self.N, self.nv = N, model.nv
+        self.h = lib.oracle_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_parnmpc_destroy(self.h)
+            self.h = None
+
+    def set_contact_status(self, active, points):
+        a = (C.c_int * 4)(*[int(x) for x in active])
+        assert self.lib.oracle_parnmpc_set_contact_status(self.h, a, P(arr(points))) == 0
+
+    def set_solution(self, name, value):
+        assert self.lib.oracle_parnmpc_set_solution(self.h, name.encode(), P(arr(value))) == 0
+
+    def init(self, t=0.0):                      # initBackwardCorrection(t) + initConstraints(t)
+        self.lib.oracle_parnmpc_init(self.h, t)
+
+    def update(self, t, q, v):
+        return self.lib.oracle_parnmpc_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+
+    def kkt_error(self, t, q, v):
+        return self.lib.oracle_parnmpc_kkt_error(self.h, t, P(arr(q)), P(arr(v)))
+
+    def get(self, name):
+        dim = {"q": 19, "u": 12, "f": 12, "du": 12}.get(name, self.nv)
+        out = np.zeros((self.N, dim))
+        assert self.lib.oracle_parnmpc_get(self.h, name.encode(), dim, P(out)) == 0
+        return out
+
+    def step_sizes(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.oracle_parnmpc_get_step_sizes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+
 def anymal_contact_points(model):
     """World positions of the four feet at q_standing (robot.getContactPoints after
     updateFrameKinematics(q_standing), examples/anymal/anymal_trotting.cpp:141-143)."""
