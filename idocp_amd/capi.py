@@ -134,6 +134,18 @@ def _proto(lib):
     lib.idocp_unocp_stream.restype = vp
     lib.idocp_ocp_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
     lib.idocp_ocp_create.restype = ci
+    lib.idocp_parnmpc_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
+    lib.idocp_parnmpc_create.restype = ci
+    lib.idocp_parnmpc_init_backward_correction.argtypes = [vp, cd]
+    lib.idocp_parnmpc_init_backward_correction.restype = ci
+    lib.idocp_parnmpc_update_solution.argtypes = [vp, cd, vp, vp, ci]
+    lib.idocp_parnmpc_update_solution.restype = ci
+    lib.idocp_parnmpc_update_solution_device.argtypes = [vp, cd, vp, vp]
+    lib.idocp_parnmpc_update_solution_device.restype = ci
+    lib.idocp_parnmpc_launch_phase.argtypes = [vp, ci, vp, vp]
+    lib.idocp_parnmpc_launch_phase.restype = ci
+    lib.idocp_parnmpc_compute_kkt_residual.argtypes = [vp, cd, vp, vp]
+    lib.idocp_parnmpc_compute_kkt_residual.restype = ci
     lib.idocp_ocp_create_hybrid.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, P(vp)]
     lib.idocp_ocp_create_hybrid.restype = ci
     lib.idocp_ocp_push_back_contact_status.argtypes = [vp, P(ci), vp, cd]

@@ -94,6 +94,7 @@ struct idocp_ocp {
   void* d_prob = nullptr;
   OcpNode* d_nodes = nullptr;
   bool contact_status_set = false;
+  bool parnmpc = false;               // backward-Euler stages + backward correction instead of the Riccati sweep
   // ContactSequence (include/idocp/hybrid/contact_sequence.hxx:56-333)
   std::vector<HostStatus> phases;
   std::vector<double> event_time;
@@ -164,8 +165,11 @@ void fillStatus(OcpNode& nd, const HostStatus& st) {
 // OCPDiscretizer::discretizeOCP(contact_sequence, t) (ocp_discretizer.hxx:65-374): event times -> time stages, time
 // steps of the stages around an event, contact phase of every stage -- and from those the chain of stages in time
 // order.  Host-side index logic, re-run only when the initial time or the contact sequence changes.
+int discretizeParNMPC(idocp_ocp* h, double t);
+
 int discretize(idocp_ocp* h, double t) {
   if (!h->seq_dirty && h->disc_time == t) return IDOCP_OK;
+  if (h->parnmpc) return discretizeParNMPC(h, t);
   const int N_ideal = h->N;
   const double min_dt = std::sqrt(std::numeric_limits<double>::epsilon());       // ocp_discretizer.hpp:108-109
   const double dt_ideal = h->T / N_ideal, max_dt = dt_ideal - min_dt;
@@ -270,6 +274,37 @@ int discretize(idocp_ocp* h, double t) {
   return IDOCP_OK;
 }
 
+// ParNMPCDiscretizer for a horizon without events (include/idocp/hybrid/parnmpc_discretizer.hxx): N backward-Euler stages,
+// stage i at time t + (i + 1) dt with constraint level i + 1 (parnmpc_linearizer.cpp:43-58), followed by a placeholder so
+// that the per-stage kernels see the usual "M - 1 stages + one more" chain.
+int discretizeParNMPC(idocp_ocp* h, double t) {
+  if (!h->event_time.empty()) { set_last_error("ParNMPC: contact sequences with discrete events are not carried yet"); return IDOCP_E_UNSUPPORTED; }
+  const int N = h->N;
+  const double dt = h->T / N;
+  h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
+  for (int i = 0; i <= N; ++i) {
+    OcpNode nd;
+    std::memset(&nd, 0, sizeof(nd));
+    nd.kind = i < N ? 0 : 4; nd.slot = i; nd.level = i + 1; nd.has_u = 1; nd.dt = dt; nd.dtq = dt;
+    nd.prev = i - 1; nd.next = i < N ? i + 1 : -1;
+    fillStatus(nd, h->phases[0]);
+    h->chain.push_back(nd); h->chain_index.push_back(i); h->chain_t.push_back(t + (i + 1) * dt);
+  }
+  h->chain_t[N] = t + N * dt;
+  h->Ngrid = N - 1;                  // getters: stages 0 .. N-1
+  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0;
+  const int M = N + 1;
+  std::vector<double> tab((size_t)M * DQ::NQ);
+  for (int p = 0; p < M; ++p) qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]);
+  h->prob.M = M; h->prob.NS = h->NS;
+  HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->disc_time = t; h->seq_dirty = false;
+  return IDOCP_OK;
+}
+
 struct Field { int offset, dim, extra; };
 bool solFieldO(const std::string& n, Field& f) {
   if (n == "lmd") f = {LQ::S_LMD, DQ::NV, 1};
@@ -313,8 +348,8 @@ int copyField(idocp_ocp* h, const double* base, size_t stride, size_t nrec, cons
 
 extern "C" {
 
-int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
-                            int N, int max_num_impulse, int batch, int device, idocp_ocp_t** out) {
+static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                         int N, int max_num_impulse, int batch, int device, bool parnmpc, idocp_ocp_t** out) {
   if (!model || !cost || !constraints || !out) { set_last_error("idocp_ocp_create: null argument"); return IDOCP_E_ARG; }
   if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }       // ocp_solver.cpp:27-44
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
@@ -350,6 +385,13 @@ int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost
   if ((rc = allocBufO(h, &B.ric, ns * LQ::RIC))) return fail(rc);
   if ((rc = allocBufO(h, &B.gain, ns * LQ::GAIN))) return fail(rc);
   if ((rc = allocBufO(h, &B.swc, max_num_impulse > 0 ? ns * LQ::SWC : 16))) return fail(rc);
+  h->parnmpc = parnmpc;
+  if (parnmpc) {
+    if ((rc = allocBufO(h, &B.snew, ns * LQ::SNEW))) return fail(rc);
+    if ((rc = allocBufO(h, &B.kinv, ns * LQ::KINV))) return fail(rc);
+    if ((rc = allocBufO(h, &B.aux, ns * LQ::AUX))) return fail(rc);
+    if ((rc = allocBufO(h, &B.xres, ns * LQ::XRES))) return fail(rc);
+  }
   if ((rc = allocBufO(h, &B.step_stage, ns * 2))) return fail(rc);
   if ((rc = allocBufO(h, &B.step, (size_t)batch * 2))) return fail(rc);
   if ((rc = allocBufO(h, &B.err_stage, ns))) return fail(rc);
@@ -372,7 +414,7 @@ int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
   std::memset(&p, 0, sizeof(p));
-  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS; p.E = max_num_impulse;
+  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS; p.E = max_num_impulse; p.backward_euler = parnmpc ? 1 : 0;
   p.baumgarte_time_step = T / N;                           // hybrid_container.hpp:186-188
   for (int i = 0; i < DQ::NV; ++i) {
     p.v_ref[i] = cost->v_ref[i]; p.q_weight[i] = cost->q_weight[i]; p.v_weight[i] = cost->v_weight[i]; p.a_weight[i] = cost->a_weight[i];
@@ -417,9 +459,13 @@ int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost
   return IDOCP_OK;
 }
 
+int idocp_ocp_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                            int N, int max_num_impulse, int batch, int device, idocp_ocp_t** out) {
+  return createOcpImpl(model, cost, constraints, T, N, max_num_impulse, batch, device, false, out);
+}
 int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
                      int N, int batch, int device, idocp_ocp_t** out) {
-  return idocp_ocp_create_hybrid(model, cost, constraints, T, N, 0, batch, device, out);
+  return createOcpImpl(model, cost, constraints, T, N, 0, batch, device, false, out);
 }
 
 void idocp_ocp_destroy(idocp_ocp_t* h) {
@@ -652,14 +698,14 @@ int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, doubl
   Field f;
   if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
-  return copyField(h, h->B.sol + (size_t)instance * h->NS * LQ::SOL, LQ::SOL, h->Ngrid + f.extra, f, out);
+  return copyField(h, h->B.sol + (size_t)instance * h->NS * LQ::SOL, LQ::SOL, h->parnmpc ? h->N : h->Ngrid + f.extra, f, out);
 }
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;
   if (!dirFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
-  return copyField(h, h->B.dir + (size_t)instance * h->NS * LQ::DIR, LQ::DIR, h->Ngrid + f.extra, f, out);
+  return copyField(h, h->B.dir + (size_t)instance * h->NS * LQ::DIR, LQ::DIR, h->parnmpc ? h->N : h->Ngrid + f.extra, f, out);
 }
 
 // the same fields for every stage of the chain, in chain order: out[M][dim] (rows of stages that do not carry the
@@ -807,6 +853,88 @@ int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx
   std::memcpy(lx, &k[LQ::K_LX], sizeof(double) * nx);
   std::memcpy(lu, &k[LQ::K_LU], sizeof(double) * nu);
   std::memcpy(Fx, &k[LQ::K_FX], sizeof(double) * nx);
+  return IDOCP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- ParNMPC ----
+// idocp::ParNMPCSolver (src/ocp/parnmpc_solver.cpp) for horizons without discrete events.  The handle is an idocp_ocp with
+// backward-Euler stages; solution / direction getters, setters and the KKT error go through the idocp_ocp_* entry points
+// with stage index 0 .. N-1 (there is no separate terminal stage: stage N-1 carries the terminal cost).
+int idocp_parnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                         int N, int batch, int device, idocp_ocp_t** out) {
+  return createOcpImpl(model, cost, constraints, T, N, 0, batch, device, true, out);
+}
+
+// ParNMPCSolver::initBackwardCorrection (parnmpc_solver.cpp:66-70)
+int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t) {
+  if (!h || !h->parnmpc) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  OcpLaunch<DQ>::parnmpcPhase(4, h->B, h->batch, h->M(), h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+// phases of ParNMPCSolver::updateSolution (parnmpc_solver.cpp:73-103), separately launchable (bench, tests):
+// 0 K5a tangent RNEA, 1 K9a backward-Euler condensation, 2 K9b KKT inverse + coarse update, 3 S5 backward serial,
+// 4 K10a backward parallel, 5 S6 forward serial, 6 K10b forward parallel + direction, 7 K6 expansion + step sizes,
+// 8 step-size reduction, 9 K7 dual expansion + integration
+int idocp_parnmpc_launch_phase(idocp_ocp_t* h, int phase, const double* d_q, const double* d_v) {
+  if (!h || !h->parnmpc || phase < 0 || phase > 9 || !d_q || !d_v) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
+  const int M = h->M();
+  switch (phase) {
+    case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream); break;
+    case 1: OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, d_q, d_v, false, h->stream); break;
+    case 2: OcpLaunch<DQ>::parnmpcInverse(h->B, h->batch, M, h->stream); break;
+    case 3: case 4: case 5: case 6: OcpLaunch<DQ>::parnmpcPhase(phase - 3, h->B, h->batch, M, h->stream); break;
+    case 7: OcpLaunch<DQ>::single(4, h->B, h->batch, M, h->stream); break;
+    case 8: OcpLaunch<DQ>::single(5, h->B, h->batch, M, h->stream); break;
+    default: OcpLaunch<DQ>::single(6, h->B, h->batch, M, h->stream); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+
+int idocp_parnmpc_update_solution_device(idocp_ocp_t* h, double t, const double* d_q, const double* d_v) {
+  if (!h || !h->parnmpc || !d_q || !d_v) return IDOCP_E_ARG;
+  if (!h->contact_status_set) { set_last_error("idocp_parnmpc_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  for (int phase = 0; phase <= 9; ++phase) if ((rc = idocp_parnmpc_launch_phase(h, phase, d_q, d_v))) return rc;
+  return IDOCP_OK;
+}
+
+int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v, int line_search) {
+  if (!h || !h->parnmpc || !q || !v) return IDOCP_E_ARG;
+  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
+  if ((rc = idocp_parnmpc_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  std::vector<int> st(h->batch);
+  HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->batch; ++b)
+    if (st[b] != 0) { set_last_error("factorisation failed (a stage matrix is not positive definite), instance " + std::to_string(b)); return st[b]; }
+  return IDOCP_OK;
+}
+
+int idocp_parnmpc_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, const double* v) {
+  if (!h || !h->parnmpc || !q || !v) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  const int M = h->M();
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream);
+  OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, h->d_q0, h->d_v0, true, h->stream);
+  ocpKktErrorReduce(h->B, h->batch, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
 }
 

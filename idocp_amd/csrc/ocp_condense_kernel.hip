@@ -77,8 +77,14 @@ struct CondenseSmem {
                        TOTAL = QB6 + 36 + 2;
 };
 
-template <typename D, bool RESIDUAL, int DIMF>
-__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0) {
+// BWD = true: the backward-Euler stage of ParNMPC (SplitParNMPC / TerminalParNMPC::linearizeOCP,
+// include/idocp/ocp/split_parnmpc.hxx:50-84, terminal_parnmpc.hxx:50-82; state_equation.hxx:96-170;
+// ContactDynamics::condenseContactDynamics(..., is_forward_euler = false)).  The lie record then holds, in the same
+// places: FQQ = dSubtract_dPlus(q, q_next), FQQP = dSubtract_dMinus(q_prev, q), FQQI = dSubtract_dPlus(q_prev, q)^-1,
+// FQ6 = (q_prev (-) q).head(6) (parnmpc_lie_kernel).  The chain ends with an unused placeholder stage; the last real
+// stage (position M - 2) carries the terminal cost.
+template <typename D, bool RESIDUAL, int DIMF, bool BWD = false>
+__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr) {
   using L = OcpLayout<D>;
   using S = CondenseSmem<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
@@ -92,6 +98,8 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
+  if (BWD && terminal) return;                      // placeholder stage
+  const bool last = BWD && (pos == M - 2);          // ParNMPC: the stage that carries the terminal cost
   // DIMF >= 0 is only launched on event-free chains (launchCondense): no impulse stages, no switching constraints
   constexpr bool PLAIN = (DIMF >= 0);
   const bool impulse = PLAIN ? false : (nd->kind == 1);
@@ -193,6 +201,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const double vr = s[L::S_V + r], ar = s[L::S_A + r];
     const double lmd = s[L::S_LMD + r], gmm = s[L::S_GMM + r], lmdn = sn[L::S_LMD + r], gmmn = sn[L::S_GMM + r];
     double lq, lv, la, hq = 0.0, hv, ha;
+    // backward Euler: the predecessor's state (the measured state in front of the first stage)
+    const double* __restrict__ sp_g = (BWD && nd->prev >= 0) ? B.sol + (b * P->NS + nd->prev) * L::SOL : nullptr;
+    const double qpr = !BWD ? 0.0 : (sp_g ? sp_g[L::S_Q + r + 1] : q0[b * NQ + r + 1]);
+    const double vpr = !BWD ? 0.0 : (sp_g ? sp_g[L::S_V + r] : v0[b * NV + r]);
     // cost + state equation
     if (r < 6) {
       lq = 0.0;
@@ -205,13 +217,26 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     } else {
       lq = dt * w_q[r] * (q[r + 1] - qref[r + 1]) + lmdn - lmd;
       hq = dt * w_q[r];
-      sm[S::FQ + r] = q[r + 1] - sn[L::S_Q + r + 1] + dtq * vr;
+      sm[S::FQ + r] = BWD ? (qpr - q[r + 1] + dtq * vr) : (q[r + 1] - sn[L::S_Q + r + 1] + dtq * vr);
     }
-    lv = dt * w_v[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r])) + dtq * lmdn + gmmn - gmm;
-    la = dt * w_a[r] * ar + dt * gmmn;
+    lv = dt * w_v[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r])) + (BWD ? dtq * lmd : dtq * lmdn) + gmmn - gmm;
+    la = dt * w_a[r] * ar + dt * (BWD ? gmm : gmmn);
     hv = dt * w_v[r];
     ha = dt * w_a[r];
-    sm[S::FV + r] = vr + dt * ar - sn[L::S_V + r];
+    sm[S::FV + r] = BWD ? (vpr - vr + dt * ar) : (vr + dt * ar - sn[L::S_V + r]);
+    if (last) {
+      // TerminalParNMPC: + terminal cost (computeTerminalCostDerivatives / Hessian) on the last stage
+      if (r < 6) {
+        double tq = 0.0;
+        for (int m2 = 0; m2 < 6; ++m2) tq += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::QDIFF + m2];
+        lq += tq;
+      } else {
+        lq += P->qf_weight[r] * (q[r + 1] - qref[r + 1]);
+        hq += P->qf_weight[r];
+      }
+      lv += P->vf_weight[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r]));
+      hv += P->vf_weight[r];
+    }
     // joint position / velocity limits act on the actuated joints (tail(dimu))
     if (r >= 6) {
       const int j = r - 6;
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       const double pr = B.swc[rec * L::SWC + L::W_P + tid - 200];
       err_local += pr * pr;
     }
-    sm[S::ERR + tid] = err_local + dt * dt * err_ipm;
+    sm[S::ERR + tid] = err_local + (BWD ? 1.0 : dt * dt) * err_ipm;      // split_parnmpc.hxx:263 does not weight by dt^2
     __syncthreads();
     if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[rec] = e; }
     return;
@@ -335,22 +360,24 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const int c = tid / 6, r = tid - 6 * c;
     double acc = 0.0;
     for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * w_q[m2] * sm[S::JQ + m2 + 6 * c];
-    sm[S::QB6 + tid] = dt * acc;
+    double accf = 0.0;
+    if (last) for (int m2 = 0; m2 < 6; ++m2) accf += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c];
+    sm[S::QB6 + tid] = dt * acc + accf;
   }
   // ---- D. condenseForwardEuler (state_equation.hxx:40-63) ----
   if (tid >= 64 && tid < 64 + 36) {
     const int e = tid - 64, c = e / 6, r = e - 6 * c;
     double acc = 0.0;
-    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQQ + m2 + 6 * c];
-    kk[L::K_FQQ + e] = -acc;                       // Fqq = -Fqq_inv * Fqq
-    kk[L::K_FQV + e] = -dtq * sm[S::FQQI + e];     // Fqv = -dt Fqq_inv (0 on impulse stages)
-    ee[L::E_FQQPI + e] = sm[S::FQQPI + e];
+    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[(BWD ? S::FQQP : S::FQQ) + m2 + 6 * c];
+    kk[L::K_FQQ + e] = BWD ? acc : -acc;                              // Fqq = -Fqq_inv * Fqq  (backward Euler: + Fqq_inv * Fqq)
+    kk[L::K_FQV + e] = (BWD ? dtq : -dtq) * sm[S::FQQI + e];          // Fqv = -dt Fqq_inv (0 on impulse stages; backward: + dt Fqq_inv)
+    ee[L::E_FQQPI + e] = sm[(BWD ? S::FQQI : S::FQQPI) + e];          // what the costate correction needs
   }
   if (tid >= 128 && tid < 128 + 6) {
     const int r = tid - 128;
     double acc = 0.0;
     for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQ + m2];
-    sm[S::FQ6 + r] = -acc;
+    sm[S::FQ6 + r] = BWD ? acc : -acc;
   }
   __syncthreads();
   if (tid < 6) sm[S::FQ + tid] = sm[S::FQ6 + tid];
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   for (int e = tid; e < NV * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;
     kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + NVF * c];
-    kk[L::K_FVV + e] = -dt * sm[S::MJD + r + NVF * (NV + c)] + (r == c ? 1.0 : 0.0);
+    kk[L::K_FVV + e] = -dt * sm[S::MJD + r + NVF * (NV + c)] + (r == c ? (BWD ? -1.0 : 1.0) : 0.0);
   }
   for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = hu * dt * sm[S::MJ + r + NVF * (6 + c)]; }
   if (tid < NV) {
@@ -535,6 +562,51 @@ __global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double*
   }
 }
 
+// Lie-group terms of the backward-Euler stage (state_equation.hxx:96-170): same record, same places as ocp_lie_kernel
+//   task 0: qdiff = q (-) q_ref and Jq
+//   task 1: FQQ = dSubtractdConfigurationPlus(q, q_next)                      (coupling with the next stage's lmd)
+//   task 2: FQ6 = (q_prev (-) q).head(6), FQQP = dSubtractdConfigurationMinus(q_prev, q),
+//           FQQI = dSubtractdConfigurationPlus(q_prev, q)^-1
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_lie_kernel(OcpBuffers B, const double* __restrict__ q0) {
+  using L = OcpLayout<D>;
+  constexpr int NQ = D::NQ;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const long unit = (long)blockIdx.x * 64 + threadIdx.x;
+  if (unit >= (long)P->batch * (M - 1)) return;
+  const long b = unit / (M - 1);
+  const int pos = (int)(unit - b * (M - 1));
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const int task = blockIdx.y;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  const double* __restrict__ q = s + L::S_Q;
+  double* __restrict__ zz = B.lie + rec * L::LIE;
+  double R[9], p[3], Ja[36], Jb[36], d6[6];
+  if (task == 0) {
+    lieRelative(B.q_ref + (long)pos * NQ, q, R, p);
+    lieLog6(R, p, d6);
+    lieJlog6(R, p, Ja);
+    for (int k = 0; k < 36; ++k) zz[L::Z_JQ + k] = Ja[k];
+    for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
+  } else if (task == 1) {
+    lieRelative(B.sol + (b * P->NS + nd->next) * L::SOL + L::S_Q, q, R, p);      // q (-) q_next; ARG of q: Jlog6
+    lieJlog6(R, p, Ja);
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
+  } else {
+    const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * NQ) : (B.sol + (b * P->NS + nd->prev) * L::SOL + L::S_Q);
+    lieRelative(q, q_prev, R, p);                                                 // q_prev (-) q
+    lieLog6(R, p, d6);
+    for (int k = 0; k < 6; ++k) zz[L::Z_FQ6 + k] = d6[k];
+    lieJlog6(R, p, Ja);                                                           // d/d q_prev  (dSubtract_dPlus)
+    lieDDiffArg0(R, p, Ja, Jb);                                                   // d/d q       (dSubtract_dMinus)
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQP + k] = Jb[k];
+    lieBlockInverse(Ja, Jb);
+    for (int k = 0; k < 36; ++k) zz[L::Z_FQQI + k] = Jb[k];
+  }
+}
+
 // M = chain length; dimf >= 0: every non-terminal stage of the chain is a regular stage with `dimf` active contact rows
 // (enables the compile-time instantiation), -1: mixed chain.
 template <typename D>
@@ -562,8 +634,25 @@ template <typename D>
 void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st) {
   launchCondense<D>(B, batch, M, -1, q0, st, true);
 }
+// ParNMPC: backward-Euler stages 0..M-2 (the chain's last entry is a placeholder)
+template <typename D>
+void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, bool residual,
+                                         hipStream_t st) {
+  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  const unsigned stages = (unsigned)(batch * (M - 1));
+  hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, B, q0);
+  if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0);
+  else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0);
+}
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::condenseBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, bool, hipStream_t);
 
 }  // namespace idocp_dev

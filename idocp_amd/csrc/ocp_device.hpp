@@ -62,6 +62,17 @@ struct OcpLayout {
   static constexpr int W_P = 0, W_PHIX = NF, W_PHIA = W_PHIX + NF * NX, W_PHIU = W_PHIA + NF * NV, W_M = W_PHIU + NF * NU,
                        W_m = W_M + NF * NX;
   static constexpr int SWC = roundUp16(W_m + NF);
+  // ---- ParNMPC (backward correction) ----
+  // coarse / corrected iterate of a stage (SplitBackwardCorrection's s_new): lmd gmm u q v
+  static constexpr int N_LMD = 0, N_GMM = NV, N_U = 2 * NV, N_Q = N_U + NU, N_V = N_Q + NQ;
+  static constexpr int SNEW = roundUp16(N_V + NV);
+  // the columns of the stage's KKT-matrix inverse the correction sweeps need (split_backward_correction.hxx:84-140),
+  // column-major with leading dimension NK = 2 NX + NU (rows: lmd gmm | u q v):
+  //   C0 = KKT_inv[:, 0 : NX]  (auxMat, forward corrections),  C1 = KKT_inv[:, NK - NX : NK]  (backward corrections)
+  static constexpr int NK = 2 * NX + NU, I_C0 = 0, I_C1 = NK * NX;
+  static constexpr int KINV = roundUp16(2 * NK * NX);
+  static constexpr int AUX = roundUp16(NX * NX);
+  static constexpr int XRES = roundUp16(NX);
 };
 
 // One stage of the CHAIN (time order): stage, [impulse, aux | lift], stage, ..., terminal.  Every stage owns a fixed
@@ -84,6 +95,7 @@ struct OcpNode {
 struct OcpProblem {
   int N, batch;            // N = grid intervals (N_ideal)
   int M, NS, E;            // chain length of the current discretisation; storage slots per instance; max events
+  int backward_euler;      // 1: ParNMPC stages (stage i lives at t + (i+1) dt, constraint level i + 1, own dgmm in the dual expansion)
   double T, dt;            // dt = T / N: Baumgarte time step and the time step of the regular stages
   double v_ref[IDOCP_MAX_NV], u_ref[IDOCP_MAX_NV];
   double q_weight[IDOCP_MAX_NV], v_weight[IDOCP_MAX_NV], a_weight[IDOCP_MAX_NV], u_weight[IDOCP_MAX_NV];
@@ -116,6 +128,11 @@ struct OcpBuffers {
   double* ric;           // [batch][NS][RIC]
   double* gain;          // [batch][NS][GAIN]
   double* swc;           // [batch][NS][SWC]   (only stages that carry a switching constraint)
+  // ParNMPC only
+  double* snew;          // [batch][NS][SNEW]
+  double* kinv;          // [batch][NS][KINV]
+  double* aux;           // [batch][NS][AUX]   aux_mat of every stage (BackwardCorrectionSolver::aux_mat_)
+  double* xres;          // [batch][NS][XRES]
   double* step_stage;    // [batch][NS][2]
   double* step;          // [batch][2]
   double* err_stage;     // [batch][NS]

@@ -87,11 +87,12 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   const long rec = b * P->NS + nd->slot;
   double* __restrict__ dd = B.dir + rec * L::DIR;
   const double* __restrict__ rr = B.ric + rec * L::RIC;
+  if (P->backward_euler && terminal) return;        // ParNMPC: placeholder stage
   if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
   if (lane < NU && !terminal) du[lane] = dd[L::D_U + lane];
   if (lane < NF) dfs[lane] = 0.0;
   __syncthreads();
-  if (lane < NV) {
+  if (lane < NV && !P->backward_euler) {            // ParNMPC: dlmd, dgmm come from the backward correction (K10b)
     const int r = lane;
     double dl = -rr[L::R_SQ + r], dg = -rr[L::R_SV + r];
     for (int c = 0; c < NV; ++c) {
@@ -185,6 +186,8 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool stage = (pos < M - 1);                 // not the terminal stage
+  const bool bwd = P->backward_euler != 0;          // ParNMPC: own dgmm, + Fqq_inv^T in the costate correction
+  if (bwd && !stage) return;
   const double dt = nd->dt;                         // 1 on impulse stages
   const long rec = b * P->NS + nd->slot;
   const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   }
   __syncthreads();
   if (stage) {
-    const double* __restrict__ dgn = B.dir + (b * P->NS + nd->next) * L::DIR + L::D_GMM;          // dgmm of the next stage of the chain
+    const double* __restrict__ dgn = B.dir + (b * P->NS + (bwd ? nd->slot : nd->next)) * L::DIR + L::D_GMM;   // dgmm of the next stage of the chain (backward Euler: of this stage)
     // ---- ContactDynamics::computeCondensedDualDirection ----
     if (lane < dimvf) {
       const int r = lane;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   if (lane < 6) {
     double acc = 0.0;
     for (int m = 0; m < 6; ++m) acc += ee[L::E_FQQPI + m + 6 * lane] * dlh[m];
-    dl_corr = -acc;
+    dl_corr = bwd ? acc : -acc;                     // state_equation.hxx:96-108 / 172-181
     dd[L::D_LMD + lane] = dl_corr;
   }
   __syncthreads();
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
   const long su = blockIdx.x;                       // over batch * NS
   const int slot = (int)(su % NS);
   const bool impulse = (slot > N && slot <= N + E);
-  const int i = (slot <= N) ? slot : (impulse ? -1 : 0);      // grid stage index; 0 on aux / lift stages
+  const int i = (slot <= N) ? slot + (P->backward_euler ? 1 : 0) : (impulse ? -1 : 0);      // grid stage index (ParNMPC: + 1); 0 on aux / lift stages
   const double* __restrict__ s = B.sol + su * L::SOL;
   for (int row = threadIdx.x; row < L::NCON; row += 64) {
     double sl = 1.0, dl = 0.0;

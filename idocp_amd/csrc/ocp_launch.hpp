@@ -15,8 +15,12 @@ struct OcpLaunch {
   static void switching(const OcpBuffers& B, long batch, int M, hipStream_t st);     // K5s: switching-constraint terms (all stages; no-op where absent)
   static void condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st);   // K5b (+ terminal); dimf = -1: mixed chain
   static void residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st);   // K8
+  static void condenseBackwardEuler(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, bool residual,
+                                    hipStream_t st);                                          // K9a: ParNMPC stage (K5b with backward Euler)
   static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
+  static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9b
+  static void parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, hipStream_t st);   // 0 S5, 1 K10a, 2 S6, 3 K10b, 4 init aux_mat
   static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
   static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7
   static void initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st);     // every slot

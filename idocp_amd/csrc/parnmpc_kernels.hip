@@ -1,0 +1,404 @@
+// ParNMPC: per-stage KKT inverse, coarse update and the correction sweeps.
+//
+// Replaces, for horizons without discrete events,
+//   SplitKKTMatrixInverter::invert            (include/idocp/ocp/split_kkt_matrix_inverter.hxx:44-80)
+//   SplitBackwardCorrection::coarseUpdate ... forwardCorrectionParallel, computeDirection
+//                                             (include/idocp/ocp/split_backward_correction.hxx:30-155)
+//   BackwardCorrectionSolver                  (src/ocp/backward_correction_solver.cpp:54-490)
+// The stage linearisation itself is K5a + K5b<BWD> (ocp_rnea_kernel.hip, ocp_condense_kernel.hip).
+//
+// K9b  parnmpc_kkt_inverse_kernel   one 256-thread workgroup per stage: Qss^-1 (48 x 48) and (F Qss^-1 F^T)^-1 (36 x 36) by
+//                                   Gauss-Jordan in LDS, the two column blocks of the KKT inverse the sweeps need, the coarse
+//                                   direction and the coarse iterate s_new
+// S5   parnmpc_backward_serial      one wavefront per instance walks the stages backwards (lmd, gmm corrections)
+// K10a parnmpc_backward_parallel    one wavefront per stage (u, q, v corrections)
+// S6   parnmpc_forward_serial       one wavefront per instance walks forwards (q, v corrections)
+// K10b parnmpc_forward_parallel     one wavefront per stage (lmd, gmm, u corrections), aux_mat, Newton direction s_new - s
+#include <hip/hip_runtime.h>
+
+#include "dev_dense.hpp"
+#include "dev_lie.hpp"
+#include "ocp_device.hpp"
+#include "ocp_launch.hpp"
+
+namespace idocp_dev {
+
+// In-place inverse of an SPD matrix by Gauss-Jordan, any size: ping-pong between A and W (same ld), one barrier per
+// pivot, elements dealt round-robin.  The inverse ends up in A.
+__device__ __forceinline__ void spdInverseAny(double* A, double* W, int ld, int n, int tid, int nthreads, int* ok) {
+  double* src = A;
+  double* dst = W;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const double p = src[k + k * ld];
+    if (tid == 0 && !(p > 0.0)) *ok = 0;
+    const double ip = 1.0 / p;
+    for (int e = tid; e < n * n; e += nthreads) {
+      const int j = e / n, i = e - j * n;
+      const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
+      dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
+    }
+    __syncthreads();
+    double* t = src; src = dst; dst = t;
+  }
+  if (src != A) {
+    for (int e = tid; e < n * n; e += nthreads) { const int j = e / n, i = e - j * n; A[i + j * ld] = src[i + j * ld]; }
+    __syncthreads();
+  }
+}
+
+template <typename D>
+struct KktInvSmem {
+  static constexpr int NX = D::NX, NU = D::NU, NQ_ = NU + NX;       // NQ_ = dim of (u, q, v)
+  // Q / Q^-1 ; scratch of its inversion, then FQ = F Q^-1 ; F, then scratch of S's inversion ; S / S^-1 ; TR = S^-1 FQ
+  static constexpr int Q = 0, W1 = Q + NQ_ * NQ_, F = W1 + NQ_ * NQ_, S = F + NX * NQ_, TR = S + NX * NX,
+                       R1 = TR + NX * NQ_, R2 = R1 + NX, T1 = R2 + NQ_, DIR = T1 + NQ_, TOTAL = DIR + NX + NQ_ + 4;
+  static constexpr int FQ = W1, W2 = F;
+  static_assert(NX * NX <= NX * NQ_, "S scratch fits in F");
+};
+
+template <typename D>
+__global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  using S = KktInvSmem<D>;
+  constexpr int NV = D::NV, NQc = D::NQ, NX = D::NX, NU = D::NU, NQ = S::NQ_, NK = L::NK;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_ok;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int tid = threadIdx.x, nt = 256;
+  const long unit = blockIdx.x;
+  const long b = unit / (M - 1);
+  const int pos = (int)(unit - b * (M - 1));
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const bool last = (pos == M - 2);
+  const double dt = nd->dt;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ kk = B.kkt + rec * L::KKT;
+  const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
+  if (tid == 0) s_ok = 1;
+  // ---- Qss in the order (u, q, v) (SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next, Qvq = Qqv^T, Qux = Qxu^T) ----
+  for (int e = tid; e < NQ * NQ; e += nt) {
+    const int c = e / NQ, r = e - c * NQ;
+    double v;
+    if (r < NU && c < NU) v = kk[L::K_QUU + r + NU * c];
+    else if (r < NU) v = kk[L::K_QXU + (c - NU) + NX * r];
+    else if (c < NU) v = kk[L::K_QXU + (r - NU) + NX * c];
+    else {
+      int rr = r - NU, cc = c - NU;
+      const double a = last ? 0.0 : aux[rr + NX * cc];
+      if (rr >= NV && cc < NV) { const int t = rr; rr = cc; cc = t; }      // lower-left block: transpose of the upper-right one
+      v = kk[L::K_QXX + rr + NX * cc] + a;
+    }
+    sm[S::Q + e] = v;
+  }
+  // ---- F = [0 Fqq Fqv; Fvu Fvq Fvv] (NX x NQ): backward Euler has Fqq = -I, Fqv = dt I outside the base blocks ----
+  for (int e = tid; e < NX * NQ; e += nt) {
+    const int c = e / NX, r = e - c * NX;
+    double v = 0.0;
+    if (r < NV) {
+      if (c >= NU && c < NU + NV) { const int cq = c - NU; v = (r < 6 && cq < 6) ? kk[L::K_FQQ + r + 6 * cq] : ((r >= 6 && r == cq) ? -1.0 : 0.0); }
+      else if (c >= NU + NV) { const int cv = c - NU - NV; v = (r < 6 && cv < 6) ? kk[L::K_FQV + r + 6 * cv] : ((r >= 6 && r == cv) ? dt : 0.0); }
+    } else {
+      const int rv = r - NV;
+      if (c < NU) v = kk[L::K_FVU + rv + NV * c];
+      else if (c < NU + NV) v = kk[L::K_FVQ + rv + NV * (c - NU)];
+      else v = kk[L::K_FVV + rv + NV * (c - NU - NV)];
+    }
+    sm[S::F + e] = v;
+  }
+  // residual (split_kkt_residual.hxx): r1 = [Fq; Fv], r2 = [lu; lq; lv]
+  if (tid < NX) sm[S::R1 + tid] = kk[L::K_FX + tid];
+  if (tid >= 64 && tid < 64 + NU) sm[S::R2 + tid - 64] = kk[L::K_LU + tid - 64];
+  if (tid >= 128 && tid < 128 + NX) sm[S::R2 + NU + tid - 128] = kk[L::K_LX + tid - 128];
+  // ---- Q^-1 (llt_Q_.solve(I), split_kkt_matrix_inverter.hxx:55-58) ----
+  spdInverseAny(&sm[S::Q], &sm[S::W1], NQ, NQ, tid, nt, &s_ok);
+  // FQ = F Q^-1 (multiplyF, :60), S = F FQ^T (:61)
+  for (int e = tid; e < NX * NQ; e += nt) {
+    const int c = e / NX, r = e - c * NX;
+    double acc = 0.0;
+    for (int m = 0; m < NQ; ++m) acc += sm[S::F + r + NX * m] * sm[S::Q + m + NQ * c];
+    sm[S::FQ + e] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < NX * NX; e += nt) {
+    const int c = e / NX, r = e - c * NX;
+    double acc = 0.0;
+    for (int m = 0; m < NQ; ++m) acc += sm[S::F + r + NX * m] * sm[S::FQ + c + NX * m];
+    sm[S::S + e] = acc;
+  }
+  __syncthreads();
+  spdInverseAny(&sm[S::S], &sm[S::W2], NX, NX, tid, nt, &s_ok);          // S^-1 (:62-66); F is dead, its block is the scratch
+  // TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69)
+  for (int e = tid; e < NX * NQ; e += nt) {
+    const int c = e / NX, r = e - c * NX;
+    double acc = 0.0;
+    for (int m = 0; m < NX; ++m) acc += sm[S::S + r + NX * m] * sm[S::FQ + m + NX * c];
+    sm[S::TR + e] = acc;
+  }
+  // t1 = r1 - FQ r2
+  if (tid < NX) {
+    double acc = sm[S::R1 + tid];
+    for (int m = 0; m < NQ; ++m) acc -= sm[S::FQ + tid + NX * m] * sm[S::R2 + m];
+    sm[S::T1 + tid] = acc;
+  }
+  __syncthreads();
+  // ---- the column blocks of the inverse: C0 = [TL; TR^T] with TL = -S^-1 ; C1 = [TR[:, NU:]; BR[:, NU:]],
+  //      BR = Q^-1 - TR^T FQ (:70-78) ----
+  double* __restrict__ ki = B.kinv + rec * L::KINV;
+  for (int e = tid; e < NK * NX; e += nt) {
+    const int c = e / NK, r = e - c * NK;
+    double c0, c1;
+    if (r < NX) {
+      c0 = -sm[S::S + r + NX * c];
+      c1 = sm[S::TR + r + NX * (NU + c)];
+    } else {
+      const int rq = r - NX;
+      c0 = sm[S::TR + c + NX * rq];
+      double acc = sm[S::Q + rq + NQ * (NU + c)];
+      for (int m = 0; m < NX; ++m) acc -= sm[S::TR + m + NX * rq] * sm[S::FQ + m + NX * (NU + c)];
+      c1 = acc;
+    }
+    ki[L::I_C0 + e] = c0;
+    ki[L::I_C1 + e] = c1;
+  }
+  // ---- coarse direction = KKT_inv * [r1; r2]: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - FQ r2) ----
+  if (tid < NX) {
+    double acc = 0.0;
+    for (int m = 0; m < NX; ++m) acc -= sm[S::S + tid + NX * m] * sm[S::R1 + m];
+    for (int m = 0; m < NQ; ++m) acc += sm[S::TR + tid + NX * m] * sm[S::R2 + m];
+    sm[S::DIR + tid] = acc;
+  } else if (tid >= 64 && tid < 64 + NQ) {
+    const int r = tid - 64;
+    double acc = 0.0;
+    for (int m = 0; m < NQ; ++m) acc += sm[S::Q + r + NQ * m] * sm[S::R2 + m];
+    for (int m = 0; m < NX; ++m) acc += sm[S::TR + m + NX * r] * sm[S::T1 + m];
+    sm[S::DIR + NX + r] = acc;
+  }
+  __syncthreads();
+  // ---- s_new = s - direction (split_backward_correction.hxx:49-58) ----
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  double* __restrict__ sn = B.snew + rec * L::SNEW;
+  const double* dir = &sm[S::DIR];          // dlmd dgmm | du dq dv
+  if (tid < NV) {
+    sn[L::N_LMD + tid] = s[L::S_LMD + tid] - dir[tid];
+    sn[L::N_GMM + tid] = s[L::S_GMM + tid] - dir[NV + tid];
+    sn[L::N_V + tid] = s[L::S_V + tid] - dir[NX + NU + NV + tid];
+    if (tid >= 6) sn[L::N_Q + tid + 1] = s[L::S_Q + tid + 1] - dir[NX + NU + tid];
+  }
+  if (tid >= 64 && tid < 64 + NU) sn[L::N_U + tid - 64] = s[L::S_U + tid - 64] - dir[NX + tid - 64];
+  if (tid == 128) {
+    double qn[7];
+    lieIntegrateBase(s + L::S_Q, dir + NX + NU, -1.0, qn);
+    for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
+  }
+  (void)NQc;
+  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1000 + pos;
+}
+
+// y[0:rows] = A[r0 : r0 + rows, 0 : NX] x  for a column block A (ld NK) in global memory; one lane per row
+template <int NX, int NK>
+__device__ __forceinline__ double blockRowDot(const double* __restrict__ A, int row, const double* x) {
+  double acc = 0.0;
+  for (int m = 0; m < NX; ++m) acc += A[row + NK * m] * x[m];
+  return acc;
+}
+
+// S5: BackwardCorrectionSolver::backwardCorrectionSerial (backward_correction_solver.cpp:253-287)
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
+  __shared__ double x[NX];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int lane = threadIdx.x;
+  const long base = (long)blockIdx.x * P->NS;
+  for (int i = M - 3; i >= 0; --i) {
+    const long rec = base + B.nodes[i].slot, recn = base + B.nodes[i + 1].slot;
+    if (lane < NX) {
+      const int off = lane < NV ? 0 : 1;      // lmd then gmm: contiguous in both records
+      (void)off;
+      x[lane] = B.snew[recn * L::SNEW + L::N_LMD + lane] - B.sol[recn * L::SOL + L::S_LMD + lane];
+      B.xres[rec * L::XRES + lane] = x[lane];
+    }
+    __syncthreads();
+    if (lane < NX) {
+      const double dx = blockRowDot<NX, NK>(B.kinv + rec * L::KINV + L::I_C1, lane, x);
+      B.snew[rec * L::SNEW + L::N_LMD + lane] -= dx;
+    }
+    __syncthreads();
+  }
+}
+
+// K10a: backwardCorrectionParallel (:288-318; split_backward_correction.hxx:96-108): stages 0 .. N-2
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK;
+  __shared__ double x[NX], dz[NX + NU];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const long b = unit / (M - 2);
+  const int pos = (int)(unit - b * (M - 2));
+  const long rec = b * P->NS + B.nodes[pos].slot;
+  if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
+  __syncthreads();
+  if (lane < NU + NX) dz[lane] = blockRowDot<NX, NK>(B.kinv + rec * L::KINV + L::I_C1, NX + lane, x);     // (du, dq, dv)
+  __syncthreads();
+  double* __restrict__ sn = B.snew + rec * L::SNEW;
+  if (lane < NU) sn[L::N_U + lane] -= dz[lane];
+  if (lane < NV) {
+    sn[L::N_V + lane] -= dz[NU + NV + lane];
+    if (lane >= 6) sn[L::N_Q + lane + 1] -= dz[NU + lane];
+  }
+  if (lane == 32) {
+    double qn[7];
+    lieIntegrateBase(sn + L::N_Q, dz + NU, -1.0, qn);
+    for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
+  }
+}
+
+// S6: forwardCorrectionSerial (:319-352; split_backward_correction.hxx:109-120)
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
+  __shared__ double x[NX], dx[NX];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int lane = threadIdx.x;
+  const long base = (long)blockIdx.x * P->NS;
+  for (int i = 1; i <= M - 2; ++i) {
+    const long rec = base + B.nodes[i].slot, recp = base + B.nodes[i - 1].slot;
+    const double* __restrict__ snp = B.snew + recp * L::SNEW;
+    const double* __restrict__ sp = B.sol + recp * L::SOL;
+    if (lane == 0) {
+      double R[9], p[3], d6[6];
+      lieRelative(sp + L::S_Q, snp + L::N_Q, R, p);          // s_new_prev.q (-) s_prev.q
+      lieLog6(R, p, d6);
+      for (int k = 0; k < 6; ++k) x[k] = d6[k];
+    }
+    if (lane >= 6 && lane < NV) x[lane] = snp[L::N_Q + lane + 1] - sp[L::S_Q + lane + 1];
+    if (lane < NV) x[NV + lane] = snp[L::N_V + lane] - sp[L::S_V + lane];
+    __syncthreads();
+    if (lane < NX) {
+      B.xres[rec * L::XRES + lane] = x[lane];
+      dx[lane] = blockRowDot<NX, NK>(B.kinv + rec * L::KINV + L::I_C0, NK - NX + lane, x);
+    }
+    __syncthreads();
+    double* __restrict__ sn = B.snew + rec * L::SNEW;
+    if (lane < NV) {
+      sn[L::N_V + lane] -= dx[NV + lane];
+      if (lane >= 6) sn[L::N_Q + lane + 1] -= dx[lane];
+    }
+    if (lane == 32) {
+      double qn[7];
+      lieIntegrateBase(sn + L::N_Q, dx, -1.0, qn);
+      for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
+    }
+    __syncthreads();
+  }
+}
+
+// K10b: forwardCorrectionParallel (:353-470; split_backward_correction.hxx:121-155): lmd / gmm / u corrections (stages > 0),
+// aux_mat = - KKT_inv.topLeftCorner(nx, nx), and the Newton direction d = s_new - s written into the dir record
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK;
+  __shared__ double x[NX], dh[NX + NU];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const long b = unit / (M - 1);
+  const int pos = (int)(unit - b * (M - 1));
+  const long rec = b * P->NS + B.nodes[pos].slot;
+  const double* __restrict__ ki = B.kinv + rec * L::KINV;
+  double* __restrict__ sn = B.snew + rec * L::SNEW;
+  if (pos > 0) {
+    if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
+    __syncthreads();
+    if (lane < NX + NU) dh[lane] = blockRowDot<NX, NK>(ki + L::I_C0, lane, x);        // (dlmd, dgmm, du)
+    __syncthreads();
+    if (lane < NX) sn[L::N_LMD + lane] -= dh[lane];
+    if (lane < NU) sn[L::N_U + lane] -= dh[NX + lane];
+  }
+  double* __restrict__ aux = B.aux + rec * L::AUX;
+  for (int e = lane; e < NX * NX; e += 64) { const int c = e / NX, r = e - c * NX; aux[e] = -ki[L::I_C0 + r + NK * c]; }
+  __syncthreads();
+  // computeDirection (split_backward_correction.hxx:141-154)
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  double* __restrict__ dd = B.dir + rec * L::DIR;
+  if (lane < NV) {
+    dd[L::D_LMD + lane] = sn[L::N_LMD + lane] - s[L::S_LMD + lane];
+    dd[L::D_GMM + lane] = sn[L::N_GMM + lane] - s[L::S_GMM + lane];
+    dd[L::D_V + lane] = sn[L::N_V + lane] - s[L::S_V + lane];
+    if (lane >= 6) dd[L::D_Q + lane] = sn[L::N_Q + lane + 1] - s[L::S_Q + lane + 1];
+  }
+  if (lane < NU) dd[L::D_U + lane] = sn[L::N_U + lane] - s[L::S_U + lane];
+  if (lane == 32) {
+    double R[9], p[3], d6[6];
+    lieRelative(s + L::S_Q, sn + L::N_Q, R, p);            // s_new.q (-) s.q
+    lieLog6(R, p, d6);
+    for (int k = 0; k < 6; ++k) dd[L::D_Q + k] = d6[k];
+  }
+}
+
+// BackwardCorrectionSolver::initAuxMat (:54-92): every aux_mat = the terminal cost Hessian at the last stage
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_init_aux_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NQ = D::NQ;
+  __shared__ double Jq[36];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  const long base = b * P->NS;
+  if (lane == 0) {
+    double R[9], p[3];
+    lieRelative(B.q_ref + (long)(M - 2) * NQ, B.sol + (base + B.nodes[M - 2].slot) * L::SOL + L::S_Q, R, p);
+    lieJlog6(R, p, Jq);
+  }
+  __syncthreads();
+  for (int pos = 0; pos < M - 1; ++pos) {
+    double* __restrict__ aux = B.aux + (base + B.nodes[pos].slot) * L::AUX;
+    for (int e = lane; e < NX * NX; e += 64) {
+      const int c = e / NX, r = e - c * NX;
+      double v = 0.0;
+      if (r < 6 && c < 6) { for (int m = 0; m < 6; ++m) v += Jq[m + 6 * r] * P->qf_weight[m] * Jq[m + 6 * c]; }
+      else if (r == c) v = r < NV ? P->qf_weight[r] : P->vf_weight[r - NV];
+      aux[e] = v;
+    }
+  }
+}
+
+template <typename D>
+void OcpLaunch<D>::parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  const size_t smem = KktInvSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)parnmpc_kkt_inverse_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((parnmpc_kkt_inverse_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(256), smem, st, B);
+}
+template <typename D>
+void OcpLaunch<D>::parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  switch (phase) {
+    case 0: hipLaunchKernelGGL((parnmpc_backward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
+    case 1: if (M > 2) hipLaunchKernelGGL((parnmpc_backward_parallel_kernel<D>), dim3((unsigned)(batch * (M - 2))), dim3(64), 0, st, B); break;
+    case 2: hipLaunchKernelGGL((parnmpc_forward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
+    case 3: hipLaunchKernelGGL((parnmpc_forward_parallel_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B); break;
+    default: hipLaunchKernelGGL((parnmpc_init_aux_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
+  }
+}
+
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcInverse(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcPhase(int, const OcpBuffers&, long, int, hipStream_t);
+
+}  // namespace idocp_dev

@@ -334,6 +334,32 @@ int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx
 /* Diagnostic: wall-clock stamps (100 MHz ticks) taken at the phase boundaries of one
  * workgroup of the condensation kernel during the last launch; n <= 64. */
 int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n);
+/* ---- ParNMPCSolver (src/ocp/parnmpc_solver.cpp), horizons without discrete events -------------
+ * Backward-Euler stages + backward correction (stage-parallel Newton) instead of the Riccati
+ * sweep.  The handle is an idocp_ocp_t: contact status, setSolution, initConstraints, KKTError,
+ * getters and step sizes go through the idocp_ocp_* entry points above with N stages 0..N-1
+ * (stage i lives at t + (i+1) T/N; stage N-1 carries the terminal cost). */
+int idocp_parnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost,
+                         const idocp_constraints_t* constraints, double T, int N, int batch,
+                         int device, idocp_ocp_t** out);
+/* ParNMPCSolver::initBackwardCorrection (parnmpc_solver.cpp:66-70): aux_mat of every stage
+ * = terminal cost Hessian. */
+int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t);
+/* ParNMPCSolver::updateSolution (parnmpc_solver.cpp:73-103): coarseUpdate,
+ * backwardCorrectionSerial / Parallel, forwardCorrectionSerial / Parallel, step sizes,
+ * integrateSolution.  q[batch][nq], v[batch][nv]. */
+int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v,
+                                  int line_search);
+int idocp_parnmpc_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
+                                         const double* d_v);
+/* One phase of updateSolution (bench / tests): 0 tangent RNEA, 1 backward-Euler condensation,
+ * 2 KKT inverse + coarse update, 3 backward serial, 4 backward parallel, 5 forward serial,
+ * 6 forward parallel + direction, 7 expansion + step sizes, 8 step-size reduction,
+ * 9 dual expansion + integration. */
+int idocp_parnmpc_launch_phase(idocp_ocp_t* h, int phase, const double* d_q, const double* d_v);
+/* ParNMPCSolver::computeKKTResidual (parnmpc_solver.cpp:200-206); read with idocp_ocp_kkt_error. */
+int idocp_parnmpc_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, const double* v);
+
 /* One kernel launch: 0 = tangent RNEA, 1 = condense, 2 = backward Riccati,
  * 3 = forward Riccati, 4 = expand primal, 5 = step-size reduction,
  * 6 = expand dual + integrate. */

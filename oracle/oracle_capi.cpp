@@ -575,9 +575,17 @@ int oracle_parnmpc_get(void* h, const char* name, int stride, double* out) {
     if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a); else if (n == "u") put(x.u);
     else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
     else if (n == "f") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.f[c][k]; }
+    else if (n == "mu") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = x.mu[c][k]; }
+    else if (n == "nu_passive") put(x.nu_passive);
     else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv); else if (n == "du") put(d.du);
-    else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm);
+    else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm); else if (n == "dnu_passive") put(d.dnu_passive);
     else if (n == "da") put(d.daf.segment(0, nv));
+    else if (n == "dbeta") put(d.dbetamu.segment(0, nv));
+    else if (n == "df" || n == "dmu") {
+      const Mat& st = n == "df" ? d.daf : d.dbetamu;
+      int k0 = 0;
+      for (int c = 0; c < nc; ++c) if (s->contact_status.active[c]) { for (int k = 0; k < 3; ++k) o[3 * c + k] = st[nv + k0 + k]; k0 += 3; }
+    }
     else return -1;
   }
   return 0;

@@ -480,7 +480,7 @@ class OracleParNMPC:
         return self.lib.oracle_parnmpc_kkt_error(self.h, t, P(arr(q)), P(arr(v)))
 
     def get(self, name):
-        dim = {"q": 19, "u": 12, "f": 12, "du": 12}.get(name, self.nv)
+        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS[name]
         out = np.zeros((self.N, dim))
         assert self.lib.oracle_parnmpc_get(self.h, name.encode(), dim, P(out)) == 0
         return out
@@ -620,3 +620,39 @@ class HipOCP:
         capi.check(self.lib.idocp_ocp_get_lqr_stage(self.h, instance, i, P(Qxx), P(Qxu), P(Quu), P(A), P(B), P(lx), P(lu), P(Fx)),
                    "get_lqr_stage")
         return Qxx.T, Qxu.T, Quu.T, A.T, B.T, lx, lu, Fx
+
+
+class HipParNMPC(HipOCP):
+    """ParNMPCSolver through the C ABI (idocp_parnmpc_* + the shared idocp_ocp_* entry points)."""
+
+    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
+        self.lib = capi.lib()
+        self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
+        self.max_events = 0
+        h = C.c_void_p()
+        capi.check(self.lib.idocp_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
+                   "idocp_parnmpc_create")
+        self.h = h
+
+    def init(self, t=0.0):
+        capi.check(self.lib.idocp_parnmpc_init_backward_correction(self.h, t), "init_backward_correction")
+        self.init_constraints(t)
+
+    def update(self, t, q, v):
+        return self.lib.idocp_parnmpc_update_solution(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv)), 0)
+
+    def kkt_error(self, t, q, v):
+        capi.check(self.lib.idocp_parnmpc_compute_kkt_residual(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv))),
+                   "compute_kkt_residual")
+        out = np.zeros(self.batch)
+        capi.check(self.lib.idocp_ocp_kkt_error(self.h, P(out)), "kkt_error")
+        return out
+
+    def get(self, name, instance=0):
+        if name in OCP_SOL_FIELDS:
+            dim, fn = OCP_SOL_FIELDS[name], self.lib.idocp_ocp_get_solution
+        else:
+            dim, fn = OCP_DIR_FIELDS[name], self.lib.idocp_ocp_get_direction
+        out = np.zeros((self.N, dim))
+        capi.check(fn(self.h, name.encode(), instance, P(out)), "get " + name)
+        return out
