@@ -1,0 +1,98 @@
+"""Horizon-sharded ParNMPC: one process per shard of the horizon, halo exchange between neighbours.
+
+ParNMPC (src/ocp/parnmpc_solver.cpp:73-103) is stage-parallel except for two thin serial sweeps (the backward correction
+of (lmd, gmm) and the forward correction of (q, v)), so the stages [r N/G, (r+1) N/G) of one horizon can live on rank r
+(BASELINE.json configs[3]: N = 256 over 2 / 4 / 8 GPUs).  Per iteration a rank exchanges with its neighbours only
+
+  state_last   (q, v)            of its last stage   -> right   (the "previous state" of the neighbour's first stage)
+  costate_first(lmd, gmm, q)     of its first stage  -> left    (coupling terms of the neighbour's last stage)
+  aux_first    aux_mat           of its first stage  -> left    (added to the neighbour's last Qxx)
+  bwd_first    corrected lmd,gmm of its first stage  -> left    (pipeline of the backward serial sweep)
+  fwd_last     corrected q, v    of its last stage   -> right   (pipeline of the forward serial sweep)
+
+plus an all-reduce(min) of the two step sizes and an all-reduce(sum) of the squared KKT error.  The collectives are
+torch.distributed point-to-point sends over RCCL (xGMI) on the GPUs; the same driver runs on gloo with the CPU oracle
+as the shard backend (tests/test_parnmpc_dist.py), which is how the protocol is tested without GPUs.
+
+A shard backend provides:
+  batch, halo_size(kind), export(kind) -> tensor[batch, size], import_(kind, tensor), phase(name, t),
+  local_steps() -> tensor[batch, 2], set_steps(tensor), err2(t) -> tensor[batch]
+"""
+STATE_LAST, COSTATE_FIRST, AUX_FIRST, BWD_FIRST, FWD_LAST, AUX_ALL = 0, 1, 2, 3, 4, 5
+
+
+class ShardedParNMPC:
+    def __init__(self, shard, dist, rank, world):
+        self.s, self.dist, self.rank, self.world = shard, dist, rank, world
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+
+    # ---- point-to-point helpers (a send and a receive with different peers may be in flight together)
+    def _sendrecv(self, send_kind, send_to, recv_kind, recv_from):
+        import torch
+        reqs = []
+        rbuf = None
+        if send_to is not None:
+            reqs.append(self.dist.isend(self.s.export(send_kind).contiguous(), dst=send_to))
+        if recv_from is not None:
+            like = self.s.export(recv_kind)
+            rbuf = torch.empty_like(like)
+            reqs.append(self.dist.irecv(rbuf, src=recv_from))
+        for r in reqs:
+            r.wait()
+        return rbuf
+
+    def init_backward_correction(self, t):
+        """ParNMPCSolver::initBackwardCorrection: aux_mat = terminal cost Hessian at the LAST stage of the horizon, so the
+        last rank computes it and everybody takes its value."""
+        import torch
+        self.s.phase("init_aux", t)
+        buf = self.s.export(AUX_ALL).contiguous()
+        self.dist.broadcast(buf, src=self.world - 1)
+        self.s.import_(AUX_ALL, buf)
+
+    def exchange_boundary(self):
+        got = self._sendrecv(STATE_LAST, self.right, STATE_LAST, self.left)
+        if got is not None:
+            self.s.import_(STATE_LAST, got)
+        got = self._sendrecv(COSTATE_FIRST, self.left, COSTATE_FIRST, self.right)
+        if got is not None:
+            self.s.import_(COSTATE_FIRST, got)
+        got = self._sendrecv(AUX_FIRST, self.left, AUX_FIRST, self.right)
+        if got is not None:
+            self.s.import_(AUX_FIRST, got)
+
+    def update(self, t):
+        import torch
+        self.exchange_boundary()
+        self.s.phase("linearize", t)
+        # backward serial sweep: right to left
+        if self.right is not None:
+            buf = torch.empty_like(self.s.export(BWD_FIRST))
+            self.dist.recv(buf, src=self.right)
+            self.s.import_(BWD_FIRST, buf)
+        self.s.phase("bwd_serial", t)
+        if self.left is not None:
+            self.dist.send(self.s.export(BWD_FIRST).contiguous(), dst=self.left)
+        self.s.phase("bwd_parallel", t)
+        # forward serial sweep: left to right
+        if self.left is not None:
+            buf = torch.empty_like(self.s.export(FWD_LAST))
+            self.dist.recv(buf, src=self.left)
+            self.s.import_(FWD_LAST, buf)
+        self.s.phase("fwd_serial", t)
+        if self.right is not None:
+            self.dist.send(self.s.export(FWD_LAST).contiguous(), dst=self.right)
+        self.s.phase("fwd_parallel", t)
+        steps = self.s.local_steps().contiguous()
+        if self.world > 1:
+            self.dist.all_reduce(steps, op=self.dist.ReduceOp.MIN)
+        self.s.set_steps(steps)
+        self.s.phase("integrate", t)
+
+    def kkt_error(self, t):
+        self.exchange_boundary()
+        e2 = self.s.err2(t).contiguous()
+        if self.world > 1:
+            self.dist.all_reduce(e2, op=self.dist.ReduceOp.SUM)
+        return e2.sqrt()

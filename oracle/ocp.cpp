@@ -948,7 +948,8 @@ void OCPSolver::updateSolution(double t, const Mat& q, const Mat& v) {
 
 // =============================================================================================== ParNMPC ====
 ParNMPCSolver::ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N)
-    : robot(model), cost(cost_), cons(constraints), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), T_(T), dt_(T / N) {
+    : robot(model), cost(cost_), cons(constraints), next_s(robot), next_snew(robot), prev_s(robot), prev_snew(robot),
+      N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), T_(T), dt_(T / N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (!robot.hasFloatingBase()) throw std::logic_error("ParNMPCSolver oracle: floating-base robots only");
@@ -963,6 +964,36 @@ ParNMPCSolver::ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cos
   x_res.assign(N, Mat(nx));
   contact_status.active.assign(nc_, false);
   contact_status.points.assign(nc_, Mat(3));
+  next_aux = Mat(nx, nx);
+}
+
+int ParNMPCSolver::haloSize(int kind) const {
+  const int nq = robot.dimq(), nv = nv_, nx = 2 * nv;
+  switch (kind) { case 0: case 4: return nq + nv; case 1: return 2 * nv + nq; case 2: return nx * nx; case 3: return 2 * nv; default: return nx * nx; }
+}
+void ParNMPCSolver::exportHalo(int kind, double* out) const {
+  const int nq = robot.dimq(), nv = nv_;
+  auto put = [&](const Mat& m, int off) { for (int k = 0; k < m.size(); ++k) out[off + k] = m[k]; };
+  switch (kind) {
+    case 0: put(s[N_ - 1].q, 0); put(s[N_ - 1].v, nq); break;
+    case 1: put(s[0].lmd, 0); put(s[0].gmm, nv); put(s[0].q, 2 * nv); break;
+    case 2: put(aux_mat[0], 0); break;
+    case 3: put(s_new[0].lmd, 0); put(s_new[0].gmm, nv); break;
+    case 4: put(s_new[N_ - 1].q, 0); put(s_new[N_ - 1].v, nq); break;
+    default: put(aux_mat[0], 0); break;
+  }
+}
+void ParNMPCSolver::importHalo(int kind, const double* in) {
+  const int nq = robot.dimq(), nv = nv_;
+  auto get = [&](Mat& m, int off) { for (int k = 0; k < m.size(); ++k) m[k] = in[off + k]; };
+  switch (kind) {
+    case 0: get(prev_s.q, 0); get(prev_s.v, nq); break;                 // also handed to coarseUpdate as (q, v)
+    case 1: get(next_s.lmd, 0); get(next_s.gmm, nv); get(next_s.q, 2 * nv); break;
+    case 2: get(next_aux, 0); break;
+    case 3: get(next_snew.lmd, 0); get(next_snew.gmm, nv); break;
+    case 4: get(prev_snew.q, 0); get(prev_snew.v, nq); break;
+    default: for (auto& a : aux_mat) get(a, 0); get(next_aux, 0); break;
+  }
 }
 
 void ParNMPCSolver::setContactStatusUniformly(const std::vector<int>& active, const double* pts) {
@@ -999,7 +1030,7 @@ void ParNMPCSolver::qRef(double t, Mat& q_ref) const {
 void ParNMPCSolver::initBackwardCorrection(double t) {
   const int nv = nv_;
   Mat q_ref, Jq;
-  qRef(t + N_ * dt_, q_ref);
+  qRef(t + (stage_offset + N_) * dt_, q_ref);
   robot.dSubtractdConfigurationPlus(s[N_ - 1].q, q_ref, Jq);
   Mat Qxx(2 * nv, 2 * nv);
   Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.qf_weight[r];
@@ -1014,7 +1045,7 @@ void ParNMPCSolver::initConstraints(double /*t*/) {
     ipm[i].clear();
     for (int c = 0; c < 7; ++c) {
       IpmData data(componentDim(c));
-      if (componentValid(c, i + 1)) {
+      if (componentValid(c, stage_offset + i + 1)) {
         if (c < 6) {
           const double sgn = (c & 1) ? 1.0 : -1.0;
           for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
@@ -1037,13 +1068,13 @@ void ParNMPCSolver::initConstraints(double /*t*/) {
 // SplitParNMPC::linearizeOCP (split_parnmpc.hxx:50-84) / TerminalParNMPC::linearizeOCP (terminal_parnmpc.hxx:50-82)
 // and the computeKKTResidual twins.
 void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
-  const bool terminal = (i == N_ - 1);
+  const bool terminal = has_terminal && (i == N_ - 1);
   const SplitSolutionC& si = s[i];
   SplitKKTMatrixC& M = kkt_matrix[i];
   SplitKKTResidualC& R = kkt_residual[i];
   ContactDynamicsDataC& D = cd[i];
   const ContactStatus& cs = contact_status;
-  const int nv = nv_, nu = nu_, dimf = cs.dimf(), level = i + 1;
+  const int nv = nv_, nu = nu_, dimf = cs.dimf(), level = stage_offset + i + 1;
   const double dt = dt_;
   robot.updateKinematics(si.q, si.v, si.a);
   if (!residual_only) {
@@ -1116,7 +1147,7 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   {
     Mat t1 = M.Fqq6.t() * si.lmd.segment(0, 6);
     if (!terminal) {
-      const SplitSolutionC& sn = s[i + 1];
+      const SplitSolutionC& sn = (i == N_ - 1) ? next_s : s[i + 1];
       Mat Fqq_next; robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq_next);
       M.Fqq_prev6 = Fqq_next.block(0, 0, 6, 6);
       t1 += M.Fqq_prev6.t() * sn.lmd.segment(0, 6);
@@ -1256,10 +1287,11 @@ void ParNMPCSolver::coarseUpdate(double t, const Mat& q, const Mat& v) {
   for (int i = 0; i < N_; ++i) {
     const Mat& q_prev = i == 0 ? q : s[i - 1].q;
     const Mat& v_prev = i == 0 ? v : s[i - 1].v;
-    linearizeStage(i, t + (i + 1) * dt_, q_prev, v_prev, false);
+    linearizeStage(i, t + (stage_offset + i + 1) * dt_, q_prev, v_prev, false);
     SplitKKTMatrixC& M = kkt_matrix[i];
     const SplitKKTResidualC& R = kkt_residual[i];
     if (i < N_ - 1) M.Qxx += aux_mat[i + 1];
+    else if (!has_terminal) M.Qxx += next_aux;
     M.Qxx.setBlock(nv, 0, M.Qxx.block(0, nv, nv, nv).t());            // Qvq = Qqv^T
     // Qss = [Quu Qux; Qxu Qxx] in the order (u, q, v); F = [0 Fqq Fqv; Fvu Fvq Fvv]
     Mat Q(nQ, nQ), F(nx, nQ);
@@ -1299,9 +1331,11 @@ void ParNMPCSolver::coarseUpdate(double t, const Mat& q, const Mat& v) {
 // backward_correction_solver.cpp:253-287; split_backward_correction.hxx:84-95
 void ParNMPCSolver::backwardCorrectionSerial() {
   const int nv = nv_, nx = 2 * nv, nK = 2 * nx + nu_;
-  for (int i = N_ - 2; i >= 0; --i) {
-    x_res[i].setSegment(0, s_new[i + 1].lmd - s[i + 1].lmd);
-    x_res[i].setSegment(nv, s_new[i + 1].gmm - s[i + 1].gmm);
+  for (int i = has_terminal ? N_ - 2 : N_ - 1; i >= 0; --i) {
+    const SplitSolutionC& sn_next = (i == N_ - 1) ? next_snew : s_new[i + 1];
+    const SplitSolutionC& s_next = (i == N_ - 1) ? next_s : s[i + 1];
+    x_res[i].setSegment(0, sn_next.lmd - s_next.lmd);
+    x_res[i].setSegment(nv, sn_next.gmm - s_next.gmm);
     Mat dx = KKT_mat_inv[i].block(0, nK - nx, nx, nx) * x_res[i];
     s_new[i].lmd -= dx.segment(0, nv);
     s_new[i].gmm -= dx.segment(nv, nv);
@@ -1310,7 +1344,7 @@ void ParNMPCSolver::backwardCorrectionSerial() {
 // :288-318; split_backward_correction.hxx:96-108
 void ParNMPCSolver::backwardCorrectionParallel() {
   const int nv = nv_, nu = nu_, nx = 2 * nv, nK = 2 * nx + nu;
-  for (int i = 0; i < N_ - 1; ++i) {
+  for (int i = 0; i < (has_terminal ? N_ - 1 : N_); ++i) {
     Mat dz = KKT_mat_inv[i].block(nx, nK - nx, nK - nx, nx) * x_res[i];       // (du, dq, dv)
     s_new[i].u -= dz.segment(0, nu);
     Mat qn; robot.integrateConfiguration(s_new[i].q, dz.segment(nu, nv), -1.0, qn); s_new[i].q = qn;
@@ -1320,10 +1354,12 @@ void ParNMPCSolver::backwardCorrectionParallel() {
 // :319-352; split_backward_correction.hxx:109-120
 void ParNMPCSolver::forwardCorrectionSerial() {
   const int nv = nv_, nx = 2 * nv, nK = 2 * nx + nu_;
-  for (int i = 1; i < N_; ++i) {
-    Mat dq; robot.subtractConfiguration(s_new[i - 1].q, s[i - 1].q, dq);
+  for (int i = has_prev ? 0 : 1; i < N_; ++i) {
+    const SplitSolutionC& snp = (i == 0) ? prev_snew : s_new[i - 1];
+    const SplitSolutionC& sp = (i == 0) ? prev_s : s[i - 1];
+    Mat dq; robot.subtractConfiguration(snp.q, sp.q, dq);
     x_res[i].setSegment(0, dq);
-    x_res[i].setSegment(nv, s_new[i - 1].v - s[i - 1].v);
+    x_res[i].setSegment(nv, snp.v - sp.v);
     Mat dx = KKT_mat_inv[i].block(nK - nx, 0, nx, nx) * x_res[i];
     Mat qn; robot.integrateConfiguration(s_new[i].q, dx.segment(0, nv), -1.0, qn); s_new[i].q = qn;
     s_new[i].v -= dx.segment(nv, nv);
@@ -1337,7 +1373,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
   const ContactStatus& cs = contact_status;
   const int dimf = cs.dimf();
   for (int i = 0; i < N_; ++i) {
-    if (i > 0) {
+    if (i > 0 || has_prev) {
       Mat dh = KKT_mat_inv[i].block(0, 0, nK - nx, nx) * x_res[i];             // (dlmd, dgmm, du)
       s_new[i].lmd -= dh.segment(0, nv);
       s_new[i].gmm -= dh.segment(nv, nv);
@@ -1358,7 +1394,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
     d[i].daf -= D.MJtJinv_IDC;
     for (int r2 = 0; r2 < dimf; ++r2) d[i].daf[nv + r2] *= -1;
     for (int c = 0; c < 7; ++c) {
-      if (!componentValid(c, i + 1)) continue;
+      if (!componentValid(c, stage_offset + i + 1)) continue;
       IpmData& data = ipm[i][c];
       if (c < 6) {
         const double sgn = (c & 1) ? 1.0 : -1.0;
@@ -1422,7 +1458,7 @@ void ParNMPCSolver::integrateSolution() {
       st += 3;
     }
     for (int c = 0; c < 7; ++c) {
-      if (!componentValid(c, i + 1)) continue;
+      if (!componentValid(c, stage_offset + i + 1)) continue;
       ipm[i][c].slack += ap * ipm[i][c].dslack;
       ipm[i][c].dual += ad * ipm[i][c].ddual;
     }
@@ -1443,22 +1479,23 @@ void ParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v) {
 }
 
 void ParNMPCSolver::computeKKTResidual(double t, const Mat& q, const Mat& v) {
-  for (int i = 0; i < N_; ++i) linearizeStage(i, t + (i + 1) * dt_, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
+  for (int i = 0; i < N_; ++i) linearizeStage(i, t + (stage_offset + i + 1) * dt_, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
 }
 
 // ParNMPCLinearizer::KKTError (parnmpc_linearizer.cpp:203-247); SplitParNMPC::squaredNormKKTResidual (split_parnmpc.hxx:250-266):
 // note that the constraint residuals are NOT weighted by dt^2 here, unlike SplitOCP
-double ParNMPCSolver::KKTError() {
+double ParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
+double ParNMPCSolver::KKTErrorSquared() {
   double sum = 0;
   for (int i = 0; i < N_; ++i) {
     const SplitKKTResidualC& R = kkt_residual[i];
     double e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
                R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt_ * dt_ * cd[i].IDC.squaredNorm();
     double c2 = 0;
-    for (int c = 0; c < 7; ++c) if (componentValid(c, i + 1)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
+    for (int c = 0; c < 7; ++c) if (componentValid(c, stage_offset + i + 1)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
     sum += e + c2;
   }
-  return std::sqrt(sum);
+  return sum;
 }
 
 }  // namespace oracle

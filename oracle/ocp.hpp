@@ -210,6 +210,22 @@ class ParNMPCSolver {
   std::vector<Mat> KKT_mat_inv, aux_mat, x_res;      // (2nx+nu)^2, nx^2, nx per stage
   double primal_step_size = 1, dual_step_size = 1;
   double serial_seconds = 0;
+  // ---- horizon sharding (stages of one horizon spread over several processes) ----
+  // This object then owns the stages [stage_offset, stage_offset + N) of a longer horizon.  What it needs from its
+  // neighbours arrives through importHalo: the state in front of its first stage (has_prev), the first stage of the
+  // right neighbour (lmd, gmm, q for the coupling terms; aux_mat; corrected lmd, gmm for the backward sweep) and the
+  // corrected state of the left neighbour's last stage for the forward sweep.
+  int stage_offset = 0;
+  bool has_terminal = true, has_prev = false;
+  SplitSolutionC next_s, next_snew, prev_s, prev_snew;
+  Mat next_aux;
+  // kinds: 0 state_last (q, v of the last stage -> right), 1 costate_first (lmd, gmm, q of the first stage -> left),
+  //        2 aux_first (-> left), 3 bwd_first (s_new.lmd, s_new.gmm of the first stage -> left),
+  //        4 fwd_last (s_new.q, s_new.v of the last stage -> right), 5 aux_all (aux_mat of every stage, init only)
+  int haloSize(int kind) const;
+  void exportHalo(int kind, double* out) const;
+  void importHalo(int kind, const double* in);
+  double KKTErrorSquared();
 
  private:
   int N_, nv_, nu_, nc_;

@@ -594,4 +594,40 @@ int oracle_parnmpc_get_step_sizes(void* h, double* primal, double* dual) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
   *primal = s->primal_step_size; *dual = s->dual_step_size; return 0;
 }
+// ---- horizon sharding of the ParNMPC oracle (see ParNMPCSolver in ocp.hpp) ----
+int oracle_parnmpc_set_shard(void* h, int stage_offset, int has_terminal, int has_prev) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  s->stage_offset = stage_offset; s->has_terminal = has_terminal != 0; s->has_prev = has_prev != 0;
+  return 0;
+}
+// 0 linearize + coarse update, 1 backward serial, 2 backward parallel, 3 forward serial, 4 forward parallel (+ directions,
+// local step sizes), 5 integrate
+int oracle_parnmpc_phase(void* h, int phase, double t, const double* q, const double* v) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  try {
+    switch (phase) {
+      case 0: s->coarseUpdate(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); break;
+      case 1: s->backwardCorrectionSerial(); break;
+      case 2: s->backwardCorrectionParallel(); break;
+      case 3: s->forwardCorrectionSerial(); break;
+      case 4: s->forwardCorrectionParallel(); break;
+      default: s->integrateSolution(); break;
+    }
+  } catch (...) { return 1; }
+  return 0;
+}
+int oracle_parnmpc_init_constraints_only(void* h, double t) { static_cast<ParNMPCSolver*>(h)->initConstraints(t); return 0; }
+int oracle_parnmpc_init_aux_only(void* h, double t) { static_cast<ParNMPCSolver*>(h)->initBackwardCorrection(t); return 0; }
+int oracle_parnmpc_halo_size(void* h, int kind) { return static_cast<ParNMPCSolver*>(h)->haloSize(kind); }
+int oracle_parnmpc_export(void* h, int kind, double* out) { static_cast<ParNMPCSolver*>(h)->exportHalo(kind, out); return 0; }
+int oracle_parnmpc_import(void* h, int kind, const double* in) { static_cast<ParNMPCSolver*>(h)->importHalo(kind, in); return 0; }
+int oracle_parnmpc_set_step_sizes(void* h, double primal, double dual) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  s->primal_step_size = primal; s->dual_step_size = dual; return 0;
+}
+double oracle_parnmpc_kkt_error_squared(void* h, double t, const double* q, const double* v) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+  return s->KKTErrorSquared();
+}
 }  // extern "C"

@@ -1,0 +1,86 @@
+"""Horizon-sharded ParNMPC on CPU: two gloo processes, each owning half of the stages, drive the halo protocol of
+idocp_amd/parnmpc_dist.py with the oracle as the shard backend; the result must equal the single-process oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from helpers import ANYMAL_Q_STANDING, OracleParNMPCShard, anymal_contact_points, anymal_model, anymal_problem
+from idocp_amd.parnmpc_dist import ShardedParNMPC
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+N, T, iters = 20, 0.5, 6
+m = anymal_model()
+cost, cons = anymal_problem(m, trotting_ref=False)
+q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+qq = q.copy(); qq[7:] += 0.05
+shard = OracleParNMPCShard(m, cost, cons, T, N, rank, world, qq, v)
+shard.o.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+shard.o.set_solution("q", q); shard.o.set_solution("v", v)
+shard.o.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+drv = ShardedParNMPC(shard, dist, rank, world)
+drv.init_backward_correction(0.0)
+shard.o.lib.oracle_parnmpc_init_constraints_only(shard.o.h, 0.0)
+errs = []
+for it in range(iters):
+    drv.update(0.0)
+    errs.append(float(drv.kkt_error(0.0)[0]))
+out = {"rank": rank, "errs": errs, "q": shard.o.get("q").tolist(), "u": shard.o.get("u").tolist(), "lmd": shard.o.get("lmd").tolist()}
+print("RESULT" + json.dumps(out), flush=True)
+dist.destroy_process_group()
+""" % (ROOT, ROOT)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_shards_equal_the_single_process_oracle(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import ANYMAL_Q_STANDING, OracleParNMPC, anymal_contact_points, anymal_model, anymal_problem
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT")][-1][6:]))
+    outs.sort(key=lambda o: o["rank"])
+    # single-process reference
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    o = OracleParNMPC(m, cost, cons, 0.5, 20)
+    o.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    o.init(0.0)
+    qq = q.copy()
+    qq[7:] += 0.05
+    errs = []
+    for it in range(6):
+        assert o.update(0.0, qq, v) == 0
+        errs.append(o.kkt_error(0.0, qq, v))
+    assert np.allclose(outs[0]["errs"], errs, rtol=1e-9, atol=1e-12) and np.allclose(outs[1]["errs"], errs, rtol=1e-9, atol=1e-12)
+    for f in ("q", "u", "lmd"):
+        both = np.concatenate([np.array(outs[0][f]), np.array(outs[1][f])])
+        assert np.abs(both - o.get(f)).max() < 1e-9, f
