@@ -165,7 +165,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("IDOCP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL scaffolding on one GPU
         dist = init_distributed("nccl", local_rank)
 
     from idocp_amd import capi

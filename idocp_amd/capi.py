@@ -146,6 +146,24 @@ def _proto(lib):
     lib.idocp_parnmpc_launch_phase.restype = ci
     lib.idocp_parnmpc_compute_kkt_residual.argtypes = [vp, cd, vp, vp]
     lib.idocp_parnmpc_compute_kkt_residual.restype = ci
+    lib.idocp_parnmpc_create_shard.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, ci, ci, P(vp)]
+    lib.idocp_parnmpc_create_shard.restype = ci
+    lib.idocp_parnmpc_halo_size.argtypes = [ci]
+    lib.idocp_parnmpc_halo_size.restype = ci
+    lib.idocp_parnmpc_export_halo.argtypes = [vp, ci, vp]
+    lib.idocp_parnmpc_export_halo.restype = ci
+    lib.idocp_parnmpc_import_halo.argtypes = [vp, ci, vp]
+    lib.idocp_parnmpc_import_halo.restype = ci
+    lib.idocp_parnmpc_prev_state.argtypes = [vp, P(vp), P(vp)]
+    lib.idocp_parnmpc_prev_state.restype = ci
+    lib.idocp_parnmpc_step_sizes_device.argtypes = [vp, P(vp)]
+    lib.idocp_parnmpc_step_sizes_device.restype = ci
+    lib.idocp_parnmpc_discretize.argtypes = [vp, cd]
+    lib.idocp_parnmpc_discretize.restype = ci
+    lib.idocp_parnmpc_kkt_error_squared_device.argtypes = [vp, cd, vp]
+    lib.idocp_parnmpc_kkt_error_squared_device.restype = ci
+    lib.idocp_device_copy.argtypes = [vp, vp, C.c_ulong]
+    lib.idocp_device_copy.restype = ci
     lib.idocp_ocp_create_hybrid.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, P(vp)]
     lib.idocp_ocp_create_hybrid.restype = ci
     lib.idocp_ocp_push_back_contact_status.argtypes = [vp, P(ci), vp, cd]

@@ -95,6 +95,8 @@ struct idocp_ocp {
   OcpNode* d_nodes = nullptr;
   bool contact_status_set = false;
   bool parnmpc = false;               // backward-Euler stages + backward correction instead of the Riccati sweep
+  int stage_offset = 0;               // ParNMPC horizon sharding: global index of the first stage of this shard
+  bool has_terminal = true, has_prev = false;
   // ContactSequence (include/idocp/hybrid/contact_sequence.hxx:56-333)
   std::vector<HostStatus> phases;
   std::vector<double> event_time;
@@ -285,12 +287,13 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   for (int i = 0; i <= N; ++i) {
     OcpNode nd;
     std::memset(&nd, 0, sizeof(nd));
-    nd.kind = i < N ? 0 : 4; nd.slot = i; nd.level = i + 1; nd.has_u = 1; nd.dt = dt; nd.dtq = dt;
+    nd.kind = i < N ? 0 : 4; nd.slot = i; nd.level = h->stage_offset + i + 1; nd.has_u = 1; nd.dt = dt; nd.dtq = dt;
     nd.prev = i - 1; nd.next = i < N ? i + 1 : -1;
     fillStatus(nd, h->phases[0]);
-    h->chain.push_back(nd); h->chain_index.push_back(i); h->chain_t.push_back(t + (i + 1) * dt);
+    h->chain.push_back(nd); h->chain_index.push_back(i); h->chain_t.push_back(t + (h->stage_offset + i + 1) * dt);
   }
-  h->chain_t[N] = t + N * dt;
+  h->chain_t[N] = t + (h->stage_offset + N) * dt;
+  h->prob.has_terminal = h->has_terminal ? 1 : 0; h->prob.has_prev = h->has_prev ? 1 : 0; h->prob.stage_offset = h->stage_offset;
   h->Ngrid = N - 1;                  // getters: stages 0 .. N-1
   h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0;
   const int M = N + 1;
@@ -391,6 +394,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
     if ((rc = allocBufO(h, &B.kinv, ns * LQ::KINV))) return fail(rc);
     if ((rc = allocBufO(h, &B.aux, ns * LQ::AUX))) return fail(rc);
     if ((rc = allocBufO(h, &B.xres, ns * LQ::XRES))) return fail(rc);
+    if ((rc = allocBufO(h, &B.fwd_prev, (size_t)batch * (DQ::NQ + DQ::NV)))) return fail(rc);
   }
   if ((rc = allocBufO(h, &B.step_stage, ns * 2))) return fail(rc);
   if ((rc = allocBufO(h, &B.step, (size_t)batch * 2))) return fail(rc);
@@ -414,7 +418,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
   std::memset(&p, 0, sizeof(p));
-  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS; p.E = max_num_impulse; p.backward_euler = parnmpc ? 1 : 0;
+  p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS; p.E = max_num_impulse; p.backward_euler = parnmpc ? 1 : 0; p.has_terminal = 1; p.has_prev = 0;
   p.baumgarte_time_step = T / N;                           // hybrid_container.hpp:186-188
   for (int i = 0; i < DQ::NV; ++i) {
     p.v_ref[i] = cost->v_ref[i]; p.q_weight[i] = cost->q_weight[i]; p.v_weight[i] = cost->v_weight[i]; p.a_weight[i] = cost->a_weight[i];
@@ -870,7 +874,7 @@ int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t) {
   if (!h || !h->parnmpc) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   if ((rc = discretize(h, t))) return rc;
-  OcpLaunch<DQ>::parnmpcPhase(4, h->B, h->batch, h->M(), h->stream);
+  OcpLaunch<DQ>::parnmpcPhase(4, h->B, h->batch, h->M(), h->has_terminal, h->d_q0, h->d_v0, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
@@ -889,7 +893,7 @@ int idocp_parnmpc_launch_phase(idocp_ocp_t* h, int phase, const double* d_q, con
     case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream); break;
     case 1: OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, d_q, d_v, false, h->stream); break;
     case 2: OcpLaunch<DQ>::parnmpcInverse(h->B, h->batch, M, h->stream); break;
-    case 3: case 4: case 5: case 6: OcpLaunch<DQ>::parnmpcPhase(phase - 3, h->B, h->batch, M, h->stream); break;
+    case 3: case 4: case 5: case 6: OcpLaunch<DQ>::parnmpcPhase(phase - 3, h->B, h->batch, M, h->has_terminal, d_q, d_v, h->stream); break;
     case 7: OcpLaunch<DQ>::single(4, h->B, h->batch, M, h->stream); break;
     case 8: OcpLaunch<DQ>::single(5, h->B, h->batch, M, h->stream); break;
     default: OcpLaunch<DQ>::single(6, h->B, h->batch, M, h->stream); break;
@@ -935,6 +939,92 @@ int idocp_parnmpc_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q
   ocpKktErrorReduce(h->B, h->batch, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+// ---- horizon sharding (idocp_amd/parnmpc_dist.py; SURVEY.md 8e, BASELINE.json configs[3]) ----
+// One handle per shard: the stages [stage_offset, stage_offset + N) of a longer horizon (T = N * dt of the shard).
+int idocp_parnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                               int N, int stage_offset, int has_terminal, int has_prev, int batch, int device, idocp_ocp_t** out) {
+  if (stage_offset < 0) { set_last_error("invalid value: stage_offset must be non-negative!"); return IDOCP_E_ARG; }
+  int rc = createOcpImpl(model, cost, constraints, T, N, 0, batch, device, true, out);
+  if (rc) return rc;
+  (*out)->stage_offset = stage_offset; (*out)->has_terminal = has_terminal != 0; (*out)->has_prev = has_prev != 0;
+  (*out)->seq_dirty = true;
+  return IDOCP_OK;
+}
+// doubles per instance of a halo: 0 state_last, 1 costate_first, 2 aux_first, 3 bwd_first, 4 fwd_last, 5 aux_all
+int idocp_parnmpc_halo_size(int kind) {
+  switch (kind) {
+    case 0: case 4: return DQ::NQ + DQ::NV;
+    case 1: return 2 * DQ::NV + DQ::NQ;
+    case 3: return 2 * DQ::NV;
+    case 2: case 5: return DQ::NX * DQ::NX;
+    default: return -1;
+  }
+}
+// d_buf[batch][halo_size(kind)] in device memory.  Importing kind 0 sets the state in front of the first stage (what the
+// *_device entry points otherwise take as d_q, d_v): use idocp_parnmpc_prev_state to get those pointers.
+int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf) {
+  if (!h || !h->parnmpc || !d_buf || idocp_parnmpc_halo_size(kind) < 0) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
+  OcpLaunch<DQ>::parnmpcHalo(h->B, h->batch, kind, false, d_buf, h->d_q0, h->d_v0, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf) {
+  if (!h || !h->parnmpc || !d_buf || idocp_parnmpc_halo_size(kind) < 0) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
+  OcpLaunch<DQ>::parnmpcHalo(h->B, h->batch, kind, true, const_cast<double*>(d_buf), h->d_q0, h->d_v0, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+// device pointers of the state in front of the first stage, q[batch][nq], v[batch][nv] (rank 0 uploads the measured state
+// there; the other shards receive it through import_halo(0))
+int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v) {
+  if (!h || !h->parnmpc || !d_q || !d_v) return IDOCP_E_ARG;
+  *d_q = h->d_q0; *d_v = h->d_v0;
+  return IDOCP_OK;
+}
+// step sizes [batch][2] (primal, dual) in device memory: read after phase 8, overwrite with the global minimum before phase 9
+int idocp_parnmpc_step_sizes_device(idocp_ocp_t* h, double** d_steps) {
+  if (!h || !d_steps) return IDOCP_E_ARG;
+  *d_steps = h->B.step;
+  return IDOCP_OK;
+}
+// discretise at time t (uploads the stage references) without running anything: call before the first phase of an iteration
+int idocp_parnmpc_discretize(idocp_ocp_t* h, double t) {
+  if (!h || !h->parnmpc) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  return discretize(h, t);
+}
+
+// KKT residual with the state in front of the first stage already in device memory (sharded horizons); the squared
+// error of the shard's stages is then d_err2[batch]
+int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_err2) {
+  if (!h || !h->parnmpc || !d_err2) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  const int M = h->M();
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream);
+  OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, h->d_q0, h->d_v0, true, h->stream);
+  ocpKktErrorReduce(h->B, h->batch, h->stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> e(h->batch);
+  HIP_TRY(hipMemcpyAsync(e.data(), h->B.err, sizeof(double) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (double& x : e) x *= x;
+  HIP_TRY(hipMemcpy(d_err2, e.data(), sizeof(double) * h->batch, hipMemcpyHostToDevice));
+  return IDOCP_OK;
+}
+int idocp_device_copy(void* d_dst, const void* d_src, unsigned long nbytes) {
+  if (!d_dst || !d_src) return IDOCP_E_ARG;
+  HIP_TRY(hipMemcpy(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice));
   return IDOCP_OK;
 }
 

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
   if (BWD && terminal) return;                      // placeholder stage
-  const bool last = BWD && (pos == M - 2);          // ParNMPC: the stage that carries the terminal cost
+  const bool last = BWD && P->has_terminal && (pos == M - 2);   // ParNMPC: the stage that carries the terminal cost
   // DIMF >= 0 is only launched on event-free chains (launchCondense): no impulse stages, no switching constraints
   constexpr bool PLAIN = (DIMF >= 0);
   const bool impulse = PLAIN ? false : (nd->kind == 1);

@@ -95,6 +95,8 @@ struct OcpNode {
 struct OcpProblem {
   int N, batch;            // N = grid intervals (N_ideal)
   int M, NS, E;            // chain length of the current discretisation; storage slots per instance; max events
+  int stage_offset;             // ParNMPC horizon sharding: global index of this shard's first stage
+  int has_terminal, has_prev;   // ParNMPC horizon sharding: this shard ends with the terminal stage / has a left neighbour
   int backward_euler;      // 1: ParNMPC stages (stage i lives at t + (i+1) dt, constraint level i + 1, own dgmm in the dual expansion)
   double T, dt;            // dt = T / N: Baumgarte time step and the time step of the regular stages
   double v_ref[IDOCP_MAX_NV], u_ref[IDOCP_MAX_NV];
@@ -133,6 +135,7 @@ struct OcpBuffers {
   double* kinv;          // [batch][NS][KINV]
   double* aux;           // [batch][NS][AUX]   aux_mat of every stage (BackwardCorrectionSolver::aux_mat_)
   double* xres;          // [batch][NS][XRES]
+  double* fwd_prev;      // [batch][NQ + NV]   corrected (q, v) of the left neighbour's last stage (sharded horizon)
   double* step_stage;    // [batch][NS][2]
   double* step;          // [batch][2]
   double* err_stage;     // [batch][NS]

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
   const long su = blockIdx.x;                       // over batch * NS
   const int slot = (int)(su % NS);
   const bool impulse = (slot > N && slot <= N + E);
-  const int i = (slot <= N) ? slot + (P->backward_euler ? 1 : 0) : (impulse ? -1 : 0);      // grid stage index (ParNMPC: + 1); 0 on aux / lift stages
+  const int i = (slot <= N) ? slot + (P->backward_euler ? 1 + P->stage_offset : 0) : (impulse ? -1 : 0);      // grid stage index (ParNMPC: + 1); 0 on aux / lift stages
   const double* __restrict__ s = B.sol + su * L::SOL;
   for (int row = threadIdx.x; row < L::NCON; row += 64) {
     double sl = 1.0, dl = 0.0;

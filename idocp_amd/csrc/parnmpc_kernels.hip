@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   const long b = unit / (M - 1);
   const int pos = (int)(unit - b * (M - 1));
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  const bool last = (pos == M - 2);
+  const bool last = P->has_terminal && (pos == M - 2);
   const double dt = nd->dt;
   const long rec = b * P->NS + nd->slot;
   const double* __restrict__ kk = B.kkt + rec * L::KKT;
@@ -214,7 +214,9 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
   const int M = P->M;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * P->NS;
-  for (int i = M - 3; i >= 0; --i) {
+  // a shard that does not end the horizon also corrects its last stage, against the imported first stage of its
+  // right neighbour (held in the placeholder records)
+  for (int i = P->has_terminal ? M - 3 : M - 2; i >= 0; --i) {
     const long rec = base + B.nodes[i].slot, recn = base + B.nodes[i + 1].slot;
     if (lane < NX) {
       const int off = lane < NV ? 0 : 1;      // lmd then gmm: contiguous in both records
@@ -241,8 +243,9 @@ __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffer
   const int M = P->M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
-  const long b = unit / (M - 2);
-  const int pos = (int)(unit - b * (M - 2));
+  const int per = P->has_terminal ? M - 2 : M - 1;
+  const long b = unit / per;
+  const int pos = (int)(unit - b * per);
   const long rec = b * P->NS + B.nodes[pos].slot;
   if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
   __syncthreads();
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffer
 
 // S6: forwardCorrectionSerial (:319-352; split_backward_correction.hxx:109-120)
 template <typename D>
-__global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
   __shared__ double x[NX], dx[NX];
@@ -271,18 +274,28 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
   const int M = P->M;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * P->NS;
-  for (int i = 1; i <= M - 2; ++i) {
-    const long rec = base + B.nodes[i].slot, recp = base + B.nodes[i - 1].slot;
-    const double* __restrict__ snp = B.snew + recp * L::SNEW;
-    const double* __restrict__ sp = B.sol + recp * L::SOL;
+  constexpr int NQ = D::NQ;
+  const long b = blockIdx.x;
+  // a shard with a left neighbour also corrects its first stage: previous state = the imported (q, v) of the
+  // neighbour's last stage (q0, v0), its corrected value = fwd_prev
+  for (int i = P->has_prev ? 0 : 1; i <= M - 2; ++i) {
+    const long rec = base + B.nodes[i].slot;
+    const double *spq, *spv, *snq, *snv;
+    if (i == 0) {
+      spq = q0 + b * NQ; spv = v0 + b * NV; snq = B.fwd_prev + b * (NQ + NV); snv = snq + NQ;
+    } else {
+      const long recp = base + B.nodes[i - 1].slot;
+      spq = B.sol + recp * L::SOL + L::S_Q; spv = B.sol + recp * L::SOL + L::S_V;
+      snq = B.snew + recp * L::SNEW + L::N_Q; snv = B.snew + recp * L::SNEW + L::N_V;
+    }
     if (lane == 0) {
       double R[9], p[3], d6[6];
-      lieRelative(sp + L::S_Q, snp + L::N_Q, R, p);          // s_new_prev.q (-) s_prev.q
+      lieRelative(spq, snq, R, p);          // s_new_prev.q (-) s_prev.q
       lieLog6(R, p, d6);
       for (int k = 0; k < 6; ++k) x[k] = d6[k];
     }
-    if (lane >= 6 && lane < NV) x[lane] = snp[L::N_Q + lane + 1] - sp[L::S_Q + lane + 1];
-    if (lane < NV) x[NV + lane] = snp[L::N_V + lane] - sp[L::S_V + lane];
+    if (lane >= 6 && lane < NV) x[lane] = snq[lane + 1] - spq[lane + 1];
+    if (lane < NV) x[NV + lane] = snv[lane] - spv[lane];
     __syncthreads();
     if (lane < NX) {
       B.xres[rec * L::XRES + lane] = x[lane];
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers
   const long rec = b * P->NS + B.nodes[pos].slot;
   const double* __restrict__ ki = B.kinv + rec * L::KINV;
   double* __restrict__ sn = B.snew + rec * L::SNEW;
-  if (pos > 0) {
+  if (pos > 0 || P->has_prev) {
     if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
     __syncthreads();
     if (lane < NX + NU) dh[lane] = blockRowDot<NX, NK>(ki + L::I_C0, lane, x);        // (dlmd, dgmm, du)
@@ -377,6 +390,51 @@ __global__ __launch_bounds__(64) void parnmpc_init_aux_kernel(OcpBuffers B) {
   }
 }
 
+// Pack / unpack the halo of a shard (idocp_amd/parnmpc_dist.py): buf[batch][size]
+//   0 state_last  : export (q, v) of the last stage            | import -> q0, v0 (the state in front of the first stage)
+//   1 costate_first: export (lmd, gmm, q) of the first stage   | import -> placeholder sol record
+//   2 aux_first   : export aux_mat of the first stage          | import -> placeholder aux record
+//   3 bwd_first   : export corrected (lmd, gmm) of stage 0     | import -> placeholder snew record
+//   4 fwd_last    : export corrected (q, v) of the last stage  | import -> fwd_prev
+//   5 aux_all     : export aux_mat of stage 0                  | import -> every aux record (initBackwardCorrection)
+template <typename D>
+__global__ void parnmpc_halo_kernel(OcpBuffers B, int kind, int do_import, double* __restrict__ buf, double* __restrict__ q0,
+                                    double* __restrict__ v0) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const long b = blockIdx.x;
+  const long base = b * P->NS;
+  const long first = base + B.nodes[0].slot, lastr = base + B.nodes[M - 2].slot, ph = base + B.nodes[M - 1].slot;
+  const int size = (kind == 0 || kind == 4) ? NQ + NV : (kind == 1 ? 2 * NV + NQ : (kind == 3 ? 2 * NV : NX * NX));
+  double* __restrict__ x = buf + b * size;
+  for (int e = threadIdx.x; e < size; e += blockDim.x) {
+    if (kind == 0) {
+      if (do_import) { if (e < NQ) q0[b * NQ + e] = x[e]; else v0[b * NV + e - NQ] = x[e]; }
+      else x[e] = e < NQ ? B.sol[lastr * L::SOL + L::S_Q + e] : B.sol[lastr * L::SOL + L::S_V + e - NQ];
+    } else if (kind == 1) {
+      const int off = e < 2 * NV ? L::S_LMD + e : L::S_Q + e - 2 * NV;
+      if (do_import) B.sol[ph * L::SOL + off] = x[e]; else x[e] = B.sol[first * L::SOL + off];
+    } else if (kind == 2) {
+      if (do_import) B.aux[ph * L::AUX + e] = x[e]; else x[e] = B.aux[first * L::AUX + e];
+    } else if (kind == 3) {
+      if (do_import) B.snew[ph * L::SNEW + L::N_LMD + e] = x[e]; else x[e] = B.snew[first * L::SNEW + L::N_LMD + e];
+    } else if (kind == 4) {
+      if (do_import) B.fwd_prev[b * (NQ + NV) + e] = x[e];
+      else x[e] = e < NQ ? B.snew[lastr * L::SNEW + L::N_Q + e] : B.snew[lastr * L::SNEW + L::N_V + e - NQ];
+    } else {
+      if (do_import) { for (int pos = 0; pos < M; ++pos) B.aux[(base + B.nodes[pos].slot) * L::AUX + e] = x[e]; }
+      else x[e] = B.aux[first * L::AUX + e];
+    }
+  }
+}
+
+template <typename D>
+void OcpLaunch<D>::parnmpcHalo(const OcpBuffers& B, long batch, int kind, bool do_import, double* buf, double* q0, double* v0, hipStream_t st) {
+  hipLaunchKernelGGL((parnmpc_halo_kernel<D>), dim3((unsigned)batch), dim3(128), 0, st, B, kind, do_import ? 1 : 0, buf, q0, v0);
+}
+
 template <typename D>
 void OcpLaunch<D>::parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st) {
   const size_t smem = KktInvSmem<D>::TOTAL * sizeof(double);
@@ -388,17 +446,20 @@ void OcpLaunch<D>::parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStr
   hipLaunchKernelGGL((parnmpc_kkt_inverse_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(256), smem, st, B);
 }
 template <typename D>
-void OcpLaunch<D>::parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, hipStream_t st) {
+void OcpLaunch<D>::parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, bool has_terminal, const double* q0, const double* v0,
+                                hipStream_t st) {
+  const int nbp = has_terminal ? M - 2 : M - 1;      // stages of the backward parallel correction
   switch (phase) {
     case 0: hipLaunchKernelGGL((parnmpc_backward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
-    case 1: if (M > 2) hipLaunchKernelGGL((parnmpc_backward_parallel_kernel<D>), dim3((unsigned)(batch * (M - 2))), dim3(64), 0, st, B); break;
-    case 2: hipLaunchKernelGGL((parnmpc_forward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
+    case 1: if (nbp > 0) hipLaunchKernelGGL((parnmpc_backward_parallel_kernel<D>), dim3((unsigned)(batch * nbp)), dim3(64), 0, st, B); break;
+    case 2: hipLaunchKernelGGL((parnmpc_forward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0); break;
     case 3: hipLaunchKernelGGL((parnmpc_forward_parallel_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B); break;
     default: hipLaunchKernelGGL((parnmpc_init_aux_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
   }
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::parnmpcInverse(const OcpBuffers&, long, int, hipStream_t);
-template void OcpLaunch<LeggedDims<4, 3>>::parnmpcPhase(int, const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcHalo(const OcpBuffers&, long, int, bool, double*, double*, double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcPhase(int, const OcpBuffers&, long, int, bool, const double*, const double*, hipStream_t);
 
 }  // namespace idocp_dev

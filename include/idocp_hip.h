@@ -359,6 +359,30 @@ int idocp_parnmpc_update_solution_device(idocp_ocp_t* h, double t, const double*
 int idocp_parnmpc_launch_phase(idocp_ocp_t* h, int phase, const double* d_q, const double* d_v);
 /* ParNMPCSolver::computeKKTResidual (parnmpc_solver.cpp:200-206); read with idocp_ocp_kkt_error. */
 int idocp_parnmpc_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q, const double* v);
+/* Horizon sharding (BASELINE.json configs[3]; protocol in idocp_amd/parnmpc_dist.py): one handle per
+ * process holds the stages [stage_offset, stage_offset + N) of a longer horizon (T = N * dt of the
+ * shard).  Halos are packed into / unpacked from caller-owned DEVICE buffers d_buf[batch][size] that
+ * the caller moves between ranks (RCCL send / recv); kinds: 0 state_last (q, v -> right),
+ * 1 costate_first (lmd, gmm, q -> left), 2 aux_first (-> left), 3 bwd_first (corrected lmd, gmm ->
+ * left), 4 fwd_last (corrected q, v -> right), 5 aux_all (initBackwardCorrection broadcast). */
+int idocp_parnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* cost,
+                               const idocp_constraints_t* constraints, double T, int N,
+                               int stage_offset, int has_terminal, int has_prev, int batch,
+                               int device, idocp_ocp_t** out);
+int idocp_parnmpc_halo_size(int kind);
+int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf);
+int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf);
+/* Device pointers of the state in front of the first stage (q[batch][nq], v[batch][nv]) and of
+ * the step sizes ([batch][2]: primal, dual) -- the latter is all-reduced (min) between phases 8 and 9. */
+int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v);
+int idocp_parnmpc_step_sizes_device(idocp_ocp_t* h, double** d_steps);
+/* Discretise at time t (stage references, constraint levels) before launching phases by hand. */
+int idocp_parnmpc_discretize(idocp_ocp_t* h, double t);
+/* Squared KKT error of this shard's stages, d_err2[batch] in device memory (summed over the ranks by
+ * the caller); the state in front of the first stage is the one held on the device. */
+int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_err2);
+/* Device-to-device copy (moving halos between the library's buffers and the caller's). */
+int idocp_device_copy(void* d_dst, const void* d_src, unsigned long nbytes);
 
 /* One kernel launch: 0 = tangent RNEA, 1 = condense, 2 = backward Riccati,
  * 3 = forward Riccati, 4 = expand primal, 5 = step-size reduction,

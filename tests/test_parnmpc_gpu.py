@@ -58,3 +58,70 @@ def test_convergence_and_batch():
     assert e_g[0] < 1e-8
     for f in ("q", "v", "a", "u", "f"):
         assert rel_err(g.get(f, 2), o.get(f)) < 1e-6, f
+
+
+def test_two_shards_on_one_gpu_equal_the_whole_horizon():
+    """Horizon sharding (BASELINE.json configs[3]) without a second GPU: two shard handles of 10 stages each on this GPU,
+    the halo protocol of idocp_amd/parnmpc_dist.py executed by hand in its pipeline order, against one handle of 20."""
+    import torch
+    from helpers import P, arr
+    from idocp_amd import capi
+    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    m, o, g, q, v = make_pair(20, 0.5)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    shards = [HipParNMPCShard(m, cost, cons, 0.5, 20, r, 2, 1, 0) for r in range(2)]
+    lib = capi.lib()
+    import ctypes as C
+    for sh in shards:
+        a = (C.c_int * 4)(1, 1, 1, 1)
+        capi.check(lib.idocp_ocp_set_contact_status_uniformly(sh.h, a, P(arr(pts))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"q", P(arr(ANYMAL_Q_STANDING))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"v", P(np.zeros(m.nv))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"f", P(arr([0, 0, 0.25 * (-m.total_mass * m.gravity[2])]))))
+    s0, s1 = shards
+    s0.set_initial_state(q[None, :], v[None, :])
+    s1.phase("init_aux", 0.0)
+    s0.phase("init_aux", 0.0)
+    s0.import_(5, s1.export(5))
+    for sh in shards:
+        capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
+
+    def boundary():
+        s1.import_(0, s0.export(0))
+        s0.import_(1, s1.export(1))
+        s0.import_(2, s1.export(2))
+
+    def get(sh, name, dim):
+        out = np.zeros((10, dim))
+        fn = lib.idocp_ocp_get_solution
+        capi.check(fn(sh.h, name.encode(), 0, P(out)))
+        return out
+
+    for it in range(4):
+        assert g.update(0.0, q, v) == 0
+        boundary()
+        for sh in shards:
+            sh.phase("linearize", 0.0)
+        s1.phase("bwd_serial", 0.0)
+        s0.import_(3, s1.export(3))
+        s0.phase("bwd_serial", 0.0)
+        for sh in shards:
+            sh.phase("bwd_parallel", 0.0)
+        s0.phase("fwd_serial", 0.0)
+        s1.import_(4, s0.export(4))
+        s1.phase("fwd_serial", 0.0)
+        for sh in shards:
+            sh.phase("fwd_parallel", 0.0)
+        steps = torch.minimum(s0.local_steps(), s1.local_steps())
+        ag, bg = g.step_sizes()
+        assert abs(float(steps[0, 0]) - ag[0]) < 1e-12 and abs(float(steps[0, 1]) - bg[0]) < 1e-12
+        for sh in shards:
+            sh.set_steps(steps)
+            sh.phase("integrate", 0.0)
+        for name, dim in (("q", 19), ("v", 18), ("u", 12), ("lmd", 18), ("a", 18)):
+            both = np.concatenate([get(s0, name, dim), get(s1, name, dim)])
+            assert rel_err(both, g.get(name)) < 1e-9, (it, name)
+    boundary()
+    e2 = float(s0.err2(0.0)[0] + s1.err2(0.0)[0])
+    assert abs(np.sqrt(e2) - g.kkt_error(0.0, q, v)[0]) < 1e-9 * max(1.0, np.sqrt(e2))
