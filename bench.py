@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
+A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032, "anymal_parnmpc": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
 KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
                "ocp_reduce_steps", "ocp_expand_dual_integrate"]
@@ -148,14 +148,120 @@ def whole_job_value(world, batch_per_rank, steps, elapsed):
     return world * batch_per_rank * steps / elapsed
 
 
+def run_parnmpc(args, rank, local_rank, world, dist):
+    """BASELINE.json configs[3]: ANYmal ParNMPCSolver, N = 256 (T = 12.8, dt = 0.05), 4 point contacts on every stage, the
+    stages of every instance sharded over the ranks (idocp_amd/parnmpc_dist.py): halo exchange with the neighbours over
+    RCCL, all-reduce of step sizes.  Strong scaling: the batch of instances is the same whatever the number of GPUs."""
+    import torch
+    from idocp_amd import capi
+    from idocp_amd.parnmpc_dist import HipParNMPCShard, ShardedParNMPC
+    from helpers import ANYMAL_Q_STANDING, OracleParNMPC, P, anymal_contact_points, anymal_model, anymal_problem, arr
+    torch.cuda.set_device(local_rank)
+    torch.cuda.init()                      # torch's HIP runtime first (see tests/conftest.py)
+    lib = capi.lib()
+    N = args.horizon if args.horizon != 100 else 256
+    T = 0.05 * N
+    B = args.batch or 256
+    if N % world:
+        raise SystemExit("--horizon must be divisible by the number of GPUs")
+    model = anymal_model()
+    cost, cons = anymal_problem(model, trotting_ref=True)
+    pts = anymal_contact_points(model)
+    rng = np.random.default_rng(20250)
+    q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
+    q0[:, 0:2] += 0.02 * rng.uniform(-1, 1, (B, 2))
+    q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
+    v0 = np.zeros((B, model.nv))
+    shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
+    a = (C.c_int * 4)(1, 1, 1, 1)
+    capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, a, P(arr(pts))))
+    capi.check(lib.idocp_ocp_set_solution(shard.h, b"q", P(arr(ANYMAL_Q_STANDING))))
+    capi.check(lib.idocp_ocp_set_solution(shard.h, b"v", P(np.zeros(model.nv))))
+    capi.check(lib.idocp_ocp_set_solution(shard.h, b"f", P(arr([0, 0, 0.25 * (-model.total_mass * model.gravity[2])]))))
+    if rank == 0:
+        shard.set_initial_state(q0, v0)
+    drv = ShardedParNMPC(shard, dist if world > 1 else _NoDist(), rank, world)
+    drv.init_backward_correction(0.0)
+    capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
+    phase_ms = {}
+    orig_phase = shard.phase
+
+    def timed_phase(name, t):
+        t0 = time.perf_counter()
+        orig_phase(name, t)
+        phase_ms[name] = phase_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+    shard.phase = timed_phase
+
+    def step(_events):
+        drv.update(0.0)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    el = run_timed(step, sync, args.steps, args.warmup, dist, "cuda")
+    nrun = args.steps + args.warmup
+    kms = {k: v / nrun for k, v in phase_ms.items() if k != "init_aux"}
+    kkt = drv.kkt_error(0.0)
+    assert bool(torch.isfinite(kkt).all()), "non-finite KKT error after the timed region"
+    if rank == 0:
+        ms_step = 1e3 * el / args.steps
+        dom = max(kms, key=kms.get)
+        stages = B * (N // world)
+        alg_bytes = A_STAGE["anymal_parnmpc"] * stages
+        achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "SQP iterations/sec (whole node)", "value": B * args.steps / el, "unit": "SQP iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "ANYmal ParNMPCSolver N=%d T=%.2f FP64, 4 point contacts on every stage (BASELINE.json configs[3]); "
+                                   "batch=%d OCP instances, the %d stages of every instance sharded over %d GPU(s) with halo exchange"
+                                   % (N, T, B, N, world),
+                       "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
+                       "phase_ms": kms, "max_kkt_error_after": float(kkt.max())},
+            "roofline": {"bound": "hbm", "kernel": "parnmpc_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": kms[dom],
+                         "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
+        }
+        if not args.no_cpu_baseline:
+            o = OracleParNMPC(model, cost, cons, T, N)
+            o.set_contact_status([1, 1, 1, 1], pts)
+            o.set_solution("q", ANYMAL_Q_STANDING)
+            o.set_solution("v", np.zeros(model.nv))
+            o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+            o.init(0.0)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 12.0:
+                o.update(0.0, q0[0], v0[0])
+                n += 1
+            elc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n / elc, "unit": "SQP iterations/s", "cores": 1, "kind": "port",
+                                   "sample": "%d updateSolution calls of one ParNMPC N=%d instance, single thread (oracle/, -O3)" % (n, N),
+                                   "ms_per_update": 1e3 * elc / n}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+class _NoDist:
+    """world = 1: the driver never communicates"""
+    class ReduceOp:
+        MIN = SUM = None
+
+    def broadcast(self, *a, **k):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "iiwa14"], default="anymal_trotting",
+    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_parnmpc", "iiwa14"], default="anymal_trotting",
                     help="anymal_trotting = BASELINE.json configs[2] (trotting contact sequence); anymal = its uniform 4-contact variant "
-                         "(SURVEY 8d roofline case); iiwa14 = configs[1]")
+                         "(SURVEY 8d roofline case); iiwa14 = configs[1]; anymal_parnmpc = configs[3] (ParNMPC, N=256, the horizon "
+                         "sharded over the ranks, strong scaling)")
     ap.add_argument("--batch", type=int, default=0, help="independent OCP instances per GPU (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,6 +273,9 @@ def main():
     dist = None
     if world > 1 or os.environ.get("IDOCP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL scaffolding on one GPU
         dist = init_distributed("nccl", local_rank)
+
+    if args.workload == "anymal_parnmpc":
+        return run_parnmpc(args, rank, local_rank, world, dist)
 
     from idocp_amd import capi
     from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,

@@ -1,0 +1,100 @@
+// idocp::ParNMPCSolver -- drop-in facade over the HIP ParNMPC path.
+//
+// Same constructor signature and methods as the reference class
+// (include/idocp/ocp/parnmpc_solver.hpp; src/ocp/parnmpc_solver.cpp).  Every method forwards to
+// the C ABI (include/idocp_hip.h: idocp_parnmpc_* and the shared idocp_ocp_* entry points); the
+// arithmetic runs in the HIP kernels K5a / K5b<BWD> / K9b / S5 / K10a / S6 / K10b / K6 / K7.
+// Carried: horizons with one contact status (setContactStatusUniformly); contact sequences
+// with discrete events are rejected loudly on this solver (they run on idocp::OCPSolver).
+#ifndef IDOCP_PARNMPC_SOLVER_HPP_
+#define IDOCP_PARNMPC_SOLVER_HPP_
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "idocp/constraints/constraints.hpp"
+#include "idocp/cost/cost_function.hpp"
+#include "idocp/eigen_shim.hpp"
+#include "idocp/robot/contact_status.hpp"
+#include "idocp/robot/robot.hpp"
+#include "idocp_hip.h"
+
+namespace idocp {
+
+class ParNMPCSolver {
+ public:
+  ParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
+                const double T, const int N, const int max_num_impulse = 0, const int nthreads = 1, const int device = 0)
+      : robot_(robot), N_(N), h_(nullptr) {
+    (void)nthreads; (void)max_num_impulse;
+    const idocp_cost_t c = cost->native();
+    const idocp_constraints_t k = constraints->native();
+    check(idocp_parnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+  }
+  ~ParNMPCSolver() { idocp_ocp_destroy(h_); }
+  ParNMPCSolver(const ParNMPCSolver&) = delete;
+  ParNMPCSolver& operator=(const ParNMPCSolver&) = delete;
+
+  void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
+  void initBackwardCorrection(const double t) { check(idocp_parnmpc_init_backward_correction(h_, t)); }
+
+  void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    check(idocp_parnmpc_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
+  }
+
+  // stages 0 .. N-1 (stage i lives at t + (i + 1) T / N)
+  std::vector<Eigen::VectorXd> getSolution(const std::string& name) const {
+    const int dim = name == "q" ? robot_.dimq() : (name == "u" ? robot_.dimu() : ((name == "f" || name == "mu") ? robot_.max_dimf() : robot_.dimv()));
+    std::vector<double> buf((size_t)N_ * dim);
+    check(idocp_ocp_get_solution(h_, name.c_str(), 0, buf.data()));
+    std::vector<Eigen::VectorXd> out(N_, Eigen::VectorXd(dim));
+    for (int i = 0; i < N_; ++i) for (int j = 0; j < dim; ++j) out[i][j] = buf[(size_t)i * dim + j];
+    return out;
+  }
+
+  void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_ocp_set_solution(h_, name.c_str(), value.data())); }
+  void setSolution(const std::string& name, const Eigen::Vector3d& value) { check(idocp_ocp_set_solution(h_, name.c_str(), value.data())); }
+
+  void setContactStatusUniformly(const ContactStatus& contact_status) {
+    const int nc = contact_status.maxPointContacts();
+    std::vector<int> active(nc);
+    std::vector<double> pts(3 * (size_t)nc);
+    for (int c = 0; c < nc; ++c) {
+      active[c] = contact_status.isContactActive(c) ? 1 : 0;
+      for (int k = 0; k < 3; ++k) pts[3 * c + k] = contact_status.contactPoint(c)[k];
+    }
+    check(idocp_ocp_set_contact_status_uniformly(h_, active.data(), pts.data()));
+  }
+  void pushBackContactStatus(const ContactStatus&, const double) {
+    std::cerr << "unsupported: ParNMPCSolver with discrete events is not carried by the HIP path (use OCPSolver)" << '\n';
+    std::exit(EXIT_FAILURE);
+  }
+  void clearLineSearchFilter() {}
+
+  double KKTError() {
+    double e = 0;
+    check(idocp_ocp_kkt_error(h_, &e));
+    return e;
+  }
+  void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    check(idocp_parnmpc_compute_kkt_residual(h_, t, q.data(), v.data()));
+  }
+  idocp_ocp_t* handle() { return h_; }
+
+ private:
+  Robot robot_;
+  int N_;
+  idocp_ocp_t* h_;
+  static void check(int rc) {
+    if (rc != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+  }
+};
+
+}  // namespace idocp
+#endif  // IDOCP_PARNMPC_SOLVER_HPP_

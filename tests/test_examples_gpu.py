@@ -100,3 +100,42 @@ def test_anymal_trotting_example_matches_oracle():
         ref = o.kkt_error(0.0, q, v)
         assert abs(its[k] - ref) <= 2e-5 * max(1.0, ref) + 1e-9, (k, its[k], ref)
     assert its[-1] < 1e-8
+
+
+def test_anymal_parnmpc_benchmark_example_matches_oracle():
+    from helpers import OracleParNMPC
+    import ctypes as C
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "anymal_parnmpc_benchmark"), ANYMAL_URDF, "20"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 20
+    model = anymal_model()
+    nv = model.nv
+    cost = capi.Cost()
+    cost.set("q_ref", ANYMAL_Q_STANDING)
+    cost.set("q_weight", np.full(nv, 10.0)).set("qf_weight", np.full(nv, 10.0))
+    cost.set("v_weight", np.ones(nv)).set("vf_weight", np.ones(nv)).set("a_weight", np.full(nv, 0.01))
+    for c in range(4):
+        for k in range(3):
+            cost.f_weight[c][k] = 0.001
+            cost.f_ref[c][k] = 0.0
+        cost.f_ref[c][2] = 70.0
+    cons = capi.Constraints()
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    cons.linearized_friction_cone = 1
+    cons.mu = 0.7
+    o = OracleParNMPC(model, cost, cons, 0.5, 20)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
+    o.set_contact_status([1, 1, 1, 1], anymal_contact_points(model))
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    o.init(0.0)
+    ref_init = o.kkt_error(0.0, q, v)
+    assert abs(init - ref_init) <= 1e-5 * max(1.0, ref_init)
+    for k in range(20):
+        o.update(0.0, q, v)
+        ref = o.kkt_error(0.0, q, v)
+        assert abs(its[k] - ref) <= 2e-5 * max(1.0, ref) + 1e-9, (k, its[k], ref)
