@@ -23,9 +23,18 @@
 
 namespace idocp_dev {
 
-// In-place inverse of an SPD matrix by Gauss-Jordan, any size: ping-pong between A and W (same ld), one barrier per
-// pivot, elements dealt round-robin.  The inverse ends up in A.
+// In-place inverse of an SPD matrix by Gauss-Jordan, any size up to ME * nthreads elements: ping-pong between A and W
+// (same ld), one barrier per pivot; every thread keeps the (i, j) of its elements in registers so that a pivot step is
+// three LDS reads, one multiply-add and one LDS write per element.  The inverse ends up in A.
+template <int ME>
 __device__ __forceinline__ void spdInverseAny(double* A, double* W, int ld, int n, int tid, int nthreads, int* ok) {
+  int ei[ME], ej[ME];
+#pragma unroll
+  for (int t = 0; t < ME; ++t) {
+    const int e = tid + nthreads * t;
+    ej[t] = e < n * n ? e / n : -1;
+    ei[t] = e < n * n ? e - ej[t] * n : 0;
+  }
   double* src = A;
   double* dst = W;
   __syncthreads();
@@ -33,16 +42,20 @@ __device__ __forceinline__ void spdInverseAny(double* A, double* W, int ld, int 
     const double p = src[k + k * ld];
     if (tid == 0 && !(p > 0.0)) *ok = 0;
     const double ip = 1.0 / p;
-    for (int e = tid; e < n * n; e += nthreads) {
-      const int j = e / n, i = e - j * n;
-      const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
-      dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
+#pragma unroll
+    for (int t = 0; t < ME; ++t) {
+      const int i = ei[t], j = ej[t];
+      if (j >= 0) {
+        const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
+        dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
+      }
     }
     __syncthreads();
-    double* t = src; src = dst; dst = t;
+    double* t2 = src; src = dst; dst = t2;
   }
   if (src != A) {
-    for (int e = tid; e < n * n; e += nthreads) { const int j = e / n, i = e - j * n; A[i + j * ld] = src[i + j * ld]; }
+#pragma unroll
+    for (int t = 0; t < ME; ++t) if (ej[t] >= 0) A[ei[t] + ej[t] * ld] = src[ei[t] + ej[t] * ld];
     __syncthreads();
   }
 }
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   if (tid >= 64 && tid < 64 + NU) sm[S::R2 + tid - 64] = kk[L::K_LU + tid - 64];
   if (tid >= 128 && tid < 128 + NX) sm[S::R2 + NU + tid - 128] = kk[L::K_LX + tid - 128];
   // ---- Q^-1 (llt_Q_.solve(I), split_kkt_matrix_inverter.hxx:55-58) ----
-  spdInverseAny(&sm[S::Q], &sm[S::W1], NQ, NQ, tid, nt, &s_ok);
+  spdInverseAny<(NQ * NQ + 255) / 256>(&sm[S::Q], &sm[S::W1], NQ, NQ, tid, nt, &s_ok);
   // FQ = F Q^-1 (multiplyF, :60), S = F FQ^T (:61)
   for (int e = tid; e < NX * NQ; e += nt) {
     const int c = e / NX, r = e - c * NX;
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
     sm[S::S + e] = acc;
   }
   __syncthreads();
-  spdInverseAny(&sm[S::S], &sm[S::W2], NX, NX, tid, nt, &s_ok);          // S^-1 (:62-66); F is dead, its block is the scratch
+  spdInverseAny<(NX * NX + 255) / 256>(&sm[S::S], &sm[S::W2], NX, NX, tid, nt, &s_ok);          // S^-1 (:62-66); F is dead, its block is the scratch
   // TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69)
   for (int e = tid; e < NX * NQ; e += nt) {
     const int c = e / NX, r = e - c * NX;
