@@ -45,6 +45,7 @@ class Hip:
         self.rt.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.rt.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
         self.rt.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.rt.hipEventDestroy.argtypes = [C.c_void_p]
         self.rt.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         self.rt.hipDeviceSynchronize.argtypes = []
         self.rt.hipSetDevice.argtypes = [C.c_int]
@@ -185,10 +186,33 @@ def run_parnmpc(args, rank, local_rank, world, dist):
     capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
     phase_ms = {}
     orig_phase = shard.phase
+    # HIP events on the handle's own stream around every kernel launch of the iteration (rocprofv3 names)
+    hip = Hip()
+    stream = lib.idocp_ocp_stream(shard.h)
+    PH_KERNEL = {0: "ocp_rnea", 1: "ocp_condense_residual", 2: "parnmpc_kkt_inverse", 3: "parnmpc_backward_serial",
+                 4: "parnmpc_backward_parallel", 5: "parnmpc_forward_serial", 6: "parnmpc_forward_parallel", 7: "ocp_expand_primal",
+                 8: "ocp_reduce_steps", 9: "ocp_expand_dual_integrate"}
+    kernel_ms, kernel_n = {}, {}
 
     def timed_phase(name, t):
         t0 = time.perf_counter()
-        orig_phase(name, t)
+        if name == "init_aux":
+            orig_phase(name, t)
+        else:
+            if name == "linearize":
+                capi.check(lib.idocp_parnmpc_discretize(shard.h, t), "discretize")
+            phs = shard.PHASES[name]
+            ev = [hip.event() for _ in range(len(phs) + 1)]
+            for k, ph in enumerate(phs):
+                hip.record(ev[k], stream)
+                capi.check(lib.idocp_parnmpc_launch_phase(shard.h, ph, shard.d_q, shard.d_v), "phase %d" % ph)
+            hip.record(ev[len(phs)], stream)
+            capi.check(lib.idocp_ocp_synchronize(shard.h))
+            for k, ph in enumerate(phs):
+                kernel_ms[PH_KERNEL[ph]] = kernel_ms.get(PH_KERNEL[ph], 0.0) + hip.elapsed_ms(ev[k], ev[k + 1])
+                kernel_n[PH_KERNEL[ph]] = kernel_n.get(PH_KERNEL[ph], 0) + 1
+            for e in ev:
+                hip.rt.hipEventDestroy(e)
         phase_ms[name] = phase_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
     shard.phase = timed_phase
 
@@ -205,10 +229,21 @@ def run_parnmpc(args, rank, local_rank, world, dist):
     assert bool(torch.isfinite(kkt).all()), "non-finite KKT error after the timed region"
     if rank == 0:
         ms_step = 1e3 * el / args.steps
-        dom = max(kms, key=kms.get)
+        ker = {k: v / kernel_n[k] for k, v in kernel_ms.items()}
+        dom = max(ker, key=ker.get)
         stages = B * (N // world)
         alg_bytes = A_STAGE["anymal_parnmpc"] * stages
-        achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
+        achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
+        traffic = None
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_anymal_parnmpc.json")), reverse=True):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("batch") == B and rec.get("horizon") == N and world == 1:
+                    traffic = rec.get("hbm_bytes_per_launch", {}).get(dom)
+                    break
+            except Exception:
+                traffic = None
         out = {
             "metric": "SQP iterations/sec (whole node)", "value": B * args.steps / el, "unit": "SQP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -217,10 +252,10 @@ def run_parnmpc(args, rank, local_rank, world, dist):
                                    "batch=%d OCP instances, the %d stages of every instance sharded over %d GPU(s) with halo exchange"
                                    % (N, T, B, N, world),
                        "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
-                       "phase_ms": kms, "max_kkt_error_after": float(kkt.max())},
-            "roofline": {"bound": "hbm", "kernel": "parnmpc_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": kms[dom],
+                       "phase_ms": kms, "kernel_ms": ker, "max_kkt_error_after": float(kkt.max())},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": ker[dom],
                          "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
         }
         if not args.no_cpu_baseline:

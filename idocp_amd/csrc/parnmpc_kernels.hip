@@ -8,8 +8,8 @@
 // The stage linearisation itself is K5a + K5b<BWD> (ocp_rnea_kernel.hip, ocp_condense_kernel.hip).
 //
 // K9b  parnmpc_kkt_inverse_kernel   one 256-thread workgroup per stage: Qss^-1 (48 x 48) and (F Qss^-1 F^T)^-1 (36 x 36) by
-//                                   Gauss-Jordan in LDS, the two column blocks of the KKT inverse the sweeps need, the coarse
-//                                   direction and the coarse iterate s_new
+//                                   Gauss-Jordan on 3 x 3 register tiles, the two column blocks of the KKT inverse the sweeps
+//                                   need, the coarse direction and the coarse iterate s_new
 // S5   parnmpc_backward_serial      one wavefront per instance walks the stages backwards (lmd, gmm corrections)
 // K10a parnmpc_backward_parallel    one wavefront per stage (u, q, v corrections)
 // S6   parnmpc_forward_serial       one wavefront per instance walks forwards (q, v corrections)
@@ -23,51 +23,86 @@
 
 namespace idocp_dev {
 
-// In-place inverse of an SPD matrix by Gauss-Jordan, any size up to ME * nthreads elements: ping-pong between A and W
-// (same ld), one barrier per pivot; every thread keeps the (i, j) of its elements in registers so that a pivot step is
-// three LDS reads, one multiply-add and one LDS write per element.  The inverse ends up in A.
-template <int ME>
-__device__ __forceinline__ void spdInverseAny(double* A, double* W, int ld, int n, int tid, int nthreads, int* ok) {
-  int ei[ME], ej[ME];
+// ---- 3 x 3 register tiles ----
+// K9b keeps every matrix it factorises or multiplies as 3 x 3 tiles in registers, thread (bi, bj) owning rows 3 bi .. 3 bi + 2 and
+// columns 3 bj .. 3 bj + 2: an inner-product step is 6 LDS reads for 9 multiply-adds, a Gauss-Jordan pivot step shares only the
+// pivot row and column through LDS.
+
+// acc += A(3 bi + r, m) B(m, 3 bj + c), m = 0 .. K - 1 in ascending order; a(r, m), b(m, c) fetch the operands
+template <int K, typename FA, typename FB>
+__device__ __forceinline__ void tileMM(double (&acc)[3][3], FA a, FB b) {
+#pragma unroll 4
+  for (int m = 0; m < K; ++m) {
+    double av[3], bv[3];
 #pragma unroll
-  for (int t = 0; t < ME; ++t) {
-    const int e = tid + nthreads * t;
-    ej[t] = e < n * n ? e / n : -1;
-    ei[t] = e < n * n ? e - ej[t] * n : 0;
+    for (int r = 0; r < 3; ++r) av[r] = a(r, m);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bv[c] = b(m, c);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] += av[r] * bv[c];
   }
-  double* src = A;
-  double* dst = W;
-  __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    const double p = src[k + k * ld];
-    if (tid == 0 && !(p > 0.0)) *ok = 0;
-    const double ip = 1.0 / p;
+}
+
+// Inverse of an SPD N x N matrix held as 3 x 3 tiles by the threads with active = true (N / 3 x N / 3 of them), by Gauss-Jordan
+// without pivoting.  Per pivot k the owners of column k and of row k publish them in pv (two ping-pong buffers of 2 N + 1
+// doubles, the last one the reciprocal of the pivot), one barrier, and every thread updates its tile.  Every thread of the
+// workgroup must call this (barriers).
+template <int N>
+__device__ __forceinline__ void gaussJordanTiles(double (&a)[3][3], const bool active, const int bi, const int bj, double* pv, int* ok) {
+  constexpr int NB = N / 3, PV = 2 * N + 2;
+  static_assert(N % 3 == 0, "tile size");
+  for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
-    for (int t = 0; t < ME; ++t) {
-      const int i = ei[t], j = ej[t];
-      if (j >= 0) {
-        const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
-        dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
+    for (int kr = 0; kr < 3; ++kr) {
+      const int k = 3 * kb + kr;
+      double* col = pv + ((k & 1) ? PV : 0);
+      double* row = col + N;
+      if (active && bj == kb) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) col[3 * bi + r] = a[r][kr];
+        if (bi == kb) {
+          const double p = a[kr][kr];
+          if (!(p > 0.0)) *ok = 0;
+          row[N] = 1.0 / p;
+        }
+      }
+      if (active && bi == kb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[3 * bj + c] = a[kr][c];
+      }
+      __syncthreads();
+      if (active) {
+        const double ip = row[N];
+        double ci[3], rj[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ci[r] = col[3 * bi + r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rj[c] = row[3 * bj + c];
+        const bool rowk = bi == kb, colk = bj == kb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const bool ik = (r == kr) && rowk, jk = (c == kr) && colk;
+            a[r][c] = ik ? (jk ? ip : rj[c] * ip) : (jk ? -ci[r] * ip : a[r][c] - ci[r] * rj[c] * ip);
+          }
       }
     }
-    __syncthreads();
-    double* t2 = src; src = dst; dst = t2;
-  }
-  if (src != A) {
-#pragma unroll
-    for (int t = 0; t < ME; ++t) if (ej[t] >= 0) A[ei[t] + ej[t] * ld] = src[ei[t] + ej[t] * ld];
-    __syncthreads();
   }
 }
 
 template <typename D>
 struct KktInvSmem {
   static constexpr int NX = D::NX, NU = D::NU, NQ_ = NU + NX;       // NQ_ = dim of (u, q, v)
-  // Q / Q^-1 ; scratch of its inversion, then FQ = F Q^-1 ; F, then scratch of S's inversion ; S / S^-1 ; TR = S^-1 FQ
-  static constexpr int Q = 0, W1 = Q + NQ_ * NQ_, F = W1 + NQ_ * NQ_, S = F + NX * NQ_, TR = S + NX * NX,
-                       R1 = TR + NX * NQ_, R2 = R1 + NX, T1 = R2 + NQ_, DIR = T1 + NQ_, TOTAL = DIR + NX + NQ_ + 4;
-  static constexpr int FQ = W1, W2 = F;
-  static_assert(NX * NX <= NX * NQ_, "S scratch fits in F");
+  // Q^-1 (later BR in its columns NU..) ; F, then S^-1 ; FQ = F Q^-1 ; TR = S^-1 FQ ; pivot rows / columns ; vectors
+  static constexpr int Q = 0, F = Q + NQ_ * NQ_, FQ = F + NX * NQ_, TR = FQ + NX * NQ_, PV = TR + NX * NQ_,
+                       R1 = PV + 2 * (2 * NQ_ + 2), R2 = R1 + NX, T1 = R2 + NQ_, DIR = T1 + NQ_, TOTAL = DIR + NX + NQ_ + 4;
+  static constexpr int SI = F;
+  static_assert(NX * NX <= NX * NQ_, "S^-1 fits in F");
+  static_assert(NX % 3 == 0 && NQ_ % 3 == 0 && NU % 3 == 0, "3 x 3 tiles");
+  static_assert((NQ_ / 3) * (NQ_ / 3) <= 256, "one tile per thread");
 };
 
 template <typename D>
@@ -75,6 +110,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   using L = OcpLayout<D>;
   using S = KktInvSmem<D>;
   constexpr int NV = D::NV, NQc = D::NQ, NX = D::NX, NU = D::NU, NQ = S::NQ_, NK = L::NK;
+  constexpr int TQ = NQ / 3, TX = NX / 3;        // tiles per side of Q (16) and of S (12)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
@@ -90,21 +126,30 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   const double* __restrict__ kk = B.kkt + rec * L::KKT;
   const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
   if (tid == 0) s_ok = 1;
-  // ---- Qss in the order (u, q, v) (SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next, Qvq = Qqv^T, Qux = Qxu^T) ----
-  for (int e = tid; e < NQ * NQ; e += nt) {
-    const int c = e / NQ, r = e - c * NQ;
-    double v;
-    if (r < NU && c < NU) v = kk[L::K_QUU + r + NU * c];
-    else if (r < NU) v = kk[L::K_QXU + (c - NU) + NX * r];
-    else if (c < NU) v = kk[L::K_QXU + (r - NU) + NX * c];
-    else {
-      int rr = r - NU, cc = c - NU;
-      const double a = last ? 0.0 : aux[rr + NX * cc];
-      if (rr >= NV && cc < NV) { const int t = rr; rr = cc; cc = t; }      // lower-left block: transpose of the upper-right one
-      v = kk[L::K_QXX + rr + NX * cc] + a;
+  // ---- Qss in the order (u, q, v) (SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next, Qvq = Qqv^T, Qux = Qxu^T):
+  //      straight into the register tiles ----
+  double a[3][3];
+  const int qi = tid % TQ, qj = tid / TQ;
+  const bool q_on = tid < TQ * TQ;
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) {
+      const int r = 3 * qi + tr, c = 3 * qj + tc;
+      double v = 0.0;
+      if (q_on) {
+        if (r < NU && c < NU) v = kk[L::K_QUU + r + NU * c];
+        else if (r < NU) v = kk[L::K_QXU + (c - NU) + NX * r];
+        else if (c < NU) v = kk[L::K_QXU + (r - NU) + NX * c];
+        else {
+          int rr = r - NU, cc = c - NU;
+          const double ax = last ? 0.0 : aux[rr + NX * cc];
+          if (rr >= NV && cc < NV) { const int t = rr; rr = cc; cc = t; }      // lower-left block: transpose of the upper-right one
+          v = kk[L::K_QXX + rr + NX * cc] + ax;
+        }
+      }
+      a[tr][tc] = v;
     }
-    sm[S::Q + e] = v;
-  }
   // ---- F = [0 Fqq Fqv; Fvu Fvq Fvv] (NX x NQ): backward Euler has Fqq = -I, Fqv = dt I outside the base blocks ----
   for (int e = tid; e < NX * NQ; e += nt) {
     const int c = e / NX, r = e - c * NX;
@@ -124,61 +169,66 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   if (tid < NX) sm[S::R1 + tid] = kk[L::K_FX + tid];
   if (tid >= 64 && tid < 64 + NU) sm[S::R2 + tid - 64] = kk[L::K_LU + tid - 64];
   if (tid >= 128 && tid < 128 + NX) sm[S::R2 + NU + tid - 128] = kk[L::K_LX + tid - 128];
+  __syncthreads();                                   // s_ok
   // ---- Q^-1 (llt_Q_.solve(I), split_kkt_matrix_inverter.hxx:55-58) ----
-  spdInverseAny<(NQ * NQ + 255) / 256>(&sm[S::Q], &sm[S::W1], NQ, NQ, tid, nt, &s_ok);
-  // FQ = F Q^-1 (multiplyF, :60), S = F FQ^T (:61)
-  for (int e = tid; e < NX * NQ; e += nt) {
-    const int c = e / NX, r = e - c * NX;
-    double acc = 0.0;
-    for (int m = 0; m < NQ; ++m) acc += sm[S::F + r + NX * m] * sm[S::Q + m + NQ * c];
-    sm[S::FQ + e] = acc;
+  gaussJordanTiles<NQ>(a, q_on, qi, qj, &sm[S::PV], &s_ok);
+  if (q_on) {
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) sm[S::Q + 3 * qi + tr + NQ * (3 * qj + tc)] = a[tr][tc];
   }
   __syncthreads();
-  for (int e = tid; e < NX * NX; e += nt) {
-    const int c = e / NX, r = e - c * NX;
-    double acc = 0.0;
-    for (int m = 0; m < NQ; ++m) acc += sm[S::F + r + NX * m] * sm[S::FQ + c + NX * m];
-    sm[S::S + e] = acc;
+  // ---- FQ = F Q^-1 (multiplyF, :60): TX x TQ tiles ----
+  const int fi = tid % TX, fj = tid / TX;            // tile of an NX x NQ matrix
+  const bool f_on = tid < TX * TQ;
+  if (f_on) {
+    double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    tileMM<NQ>(acc, [&](int r, int m) { return sm[S::F + 3 * fi + r + NX * m]; },
+               [&](int m, int c) { return sm[S::Q + m + NQ * (3 * fj + c)]; });
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) sm[S::FQ + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
   }
   __syncthreads();
-  spdInverseAny<(NX * NX + 255) / 256>(&sm[S::S], &sm[S::W2], NX, NX, tid, nt, &s_ok);          // S^-1 (:62-66); F is dead, its block is the scratch
-  // TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69)
-  for (int e = tid; e < NX * NQ; e += nt) {
-    const int c = e / NX, r = e - c * NX;
-    double acc = 0.0;
-    for (int m = 0; m < NX; ++m) acc += sm[S::S + r + NX * m] * sm[S::FQ + m + NX * c];
-    sm[S::TR + e] = acc;
-  }
-  // t1 = r1 - FQ r2
-  if (tid < NX) {
-    double acc = sm[S::R1 + tid];
-    for (int m = 0; m < NQ; ++m) acc -= sm[S::FQ + tid + NX * m] * sm[S::R2 + m];
-    sm[S::T1 + tid] = acc;
+  // ---- S = F FQ^T (:61) into register tiles, S^-1 (:62-66) ----
+  const bool s_on = tid < TX * TX;                   // (fi, fj) is then a tile of an NX x NX matrix as well
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) a[tr][tc] = 0.0;
+  if (s_on)
+    tileMM<NQ>(a, [&](int r, int m) { return sm[S::F + 3 * fi + r + NX * m]; },
+               [&](int m, int c) { return sm[S::FQ + 3 * fj + c + NX * m]; });
+  gaussJordanTiles<NX>(a, s_on, fi, fj, &sm[S::PV], &s_ok);      // its first barrier also ends the reads of F
+  if (s_on) {
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) sm[S::SI + 3 * fi + tr + NX * (3 * fj + tc)] = a[tr][tc];
   }
   __syncthreads();
-  // ---- the column blocks of the inverse: C0 = [TL; TR^T] with TL = -S^-1 ; C1 = [TR[:, NU:]; BR[:, NU:]],
-  //      BR = Q^-1 - TR^T FQ (:70-78) ----
-  double* __restrict__ ki = B.kinv + rec * L::KINV;
-  for (int e = tid; e < NK * NX; e += nt) {
-    const int c = e / NK, r = e - c * NK;
-    double c0, c1;
-    if (r < NX) {
-      c0 = -sm[S::S + r + NX * c];
-      c1 = sm[S::TR + r + NX * (NU + c)];
-    } else {
-      const int rq = r - NX;
-      c0 = sm[S::TR + c + NX * rq];
-      double acc = sm[S::Q + rq + NQ * (NU + c)];
-      for (int m = 0; m < NX; ++m) acc -= sm[S::TR + m + NX * rq] * sm[S::FQ + m + NX * (NU + c)];
-      c1 = acc;
-    }
-    ki[L::I_C0 + e] = c0;
-    ki[L::I_C1 + e] = c1;
+  // ---- TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69) ; t1 = r1 - FQ r2 ----
+  if (f_on) {
+    double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    tileMM<NX>(acc, [&](int r, int m) { return sm[S::SI + 3 * fi + r + NX * m]; },
+               [&](int m, int c) { return sm[S::FQ + m + NX * (3 * fj + c)]; });
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) sm[S::TR + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
+  } else if (tid >= 256 - NX) {
+    const int r = tid - (256 - NX);
+    double acc = sm[S::R1 + r];
+    for (int m = 0; m < NQ; ++m) acc -= sm[S::FQ + r + NX * m] * sm[S::R2 + m];
+    sm[S::T1 + r] = acc;
   }
+  __syncthreads();
   // ---- coarse direction = KKT_inv * [r1; r2]: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - FQ r2) ----
   if (tid < NX) {
     double acc = 0.0;
-    for (int m = 0; m < NX; ++m) acc -= sm[S::S + tid + NX * m] * sm[S::R1 + m];
+    for (int m = 0; m < NX; ++m) acc -= sm[S::SI + tid + NX * m] * sm[S::R1 + m];
     for (int m = 0; m < NQ; ++m) acc += sm[S::TR + tid + NX * m] * sm[S::R2 + m];
     sm[S::DIR + tid] = acc;
   } else if (tid >= 64 && tid < 64 + NQ) {
@@ -189,6 +239,39 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
     sm[S::DIR + NX + r] = acc;
   }
   __syncthreads();
+  // ---- BR[:, NU:] = Q^-1[:, NU:] - TR^T FQ[:, NU:] (:70-78), in place: TQ x TX tiles ----
+  {
+    const int bi2 = tid % TQ, bj2 = tid / TQ;
+    if (tid < TQ * TX) {
+      double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+      tileMM<NX>(acc, [&](int r, int m) { return sm[S::TR + m + NX * (3 * bi2 + r)]; },
+                 [&](int m, int c) { return sm[S::FQ + m + NX * (NU + 3 * bj2 + c)]; });
+#pragma unroll
+      for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 3; ++tc) {
+          double* q = &sm[S::Q + 3 * bi2 + tr + NQ * (NU + 3 * bj2 + tc)];
+          *q = *q - acc[tr][tc];
+        }
+    }
+  }
+  __syncthreads();
+  // ---- the column blocks of the inverse: C0 = [TL; TR^T] with TL = -S^-1 ; C1 = [TR[:, NU:]; BR[:, NU:]] ----
+  double* __restrict__ ki = B.kinv + rec * L::KINV;
+  for (int e = tid; e < NK * NX; e += nt) {
+    const int c = e / NK, r = e - c * NK;
+    double c0, c1;
+    if (r < NX) {
+      c0 = -sm[S::SI + r + NX * c];
+      c1 = sm[S::TR + r + NX * (NU + c)];
+    } else {
+      const int rq = r - NX;
+      c0 = sm[S::TR + c + NX * rq];
+      c1 = sm[S::Q + rq + NQ * (NU + c)];
+    }
+    ki[L::I_C0 + e] = c0;
+    ki[L::I_C1 + e] = c1;
+  }
   // ---- s_new = s - direction (split_backward_correction.hxx:49-58) ----
   const double* __restrict__ s = B.sol + rec * L::SOL;
   double* __restrict__ sn = B.snew + rec * L::SNEW;
