@@ -96,13 +96,15 @@ __device__ __forceinline__ void gaussJordanTiles(double (&a)[3][3], const bool a
 template <typename D>
 struct KktInvSmem {
   static constexpr int NX = D::NX, NU = D::NU, NQ_ = NU + NX;       // NQ_ = dim of (u, q, v)
-  // Q^-1 (later BR in its columns NU..) ; F, then S^-1 ; FQ = F Q^-1 ; TR = S^-1 FQ ; pivot rows / columns ; vectors
-  static constexpr int Q = 0, F = Q + NQ_ * NQ_, FQ = F + NX * NQ_, TR = FQ + NX * NQ_, PV = TR + NX * NQ_,
-                       R1 = PV + 2 * (2 * NQ_ + 2), R2 = R1 + NX, T1 = R2 + NQ_, DIR = T1 + NQ_, TOTAL = DIR + NX + NQ_ + 4;
-  static constexpr int SI = F;
-  static_assert(NX * NX <= NX * NQ_, "S^-1 fits in F");
+  // Two matrix regions reused by lifetime (36 kB in all, four workgroups per CU):
+  //   A : Q^-1 (NQ x NQ) -> FQ = F Q^-1 (NX x NQ) -> BR[:, NU:] (NQ x NX)
+  //   B : F (NX x NQ)    -> S^-1 (NX x NX)        -> TR = S^-1 FQ (NX x NQ)
+  // then the pivot rows / columns of the Gauss-Jordan steps and the vectors.
+  static constexpr int A = 0, B = A + NQ_ * NQ_, PV = B + NX * NQ_,
+                       R1 = PV + 2 * (2 * NQ_ + 2), R2 = R1 + NX, T1 = R2 + NQ_, W = T1 + NQ_, DIR = W + NQ_, TOTAL = DIR + NX + NQ_ + 4;
   static_assert(NX % 3 == 0 && NQ_ % 3 == 0 && NU % 3 == 0, "3 x 3 tiles");
   static_assert((NQ_ / 3) * (NQ_ / 3) <= 256, "one tile per thread");
+  static_assert((NQ_ / 3) * (NX / 3) + NQ_ <= 256 && (NQ_ / 3) * (NX / 3) + NX <= 256, "side jobs next to the NX x NQ tiles");
 };
 
 template <typename D>
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   using L = OcpLayout<D>;
   using S = KktInvSmem<D>;
   constexpr int NV = D::NV, NQc = D::NQ, NX = D::NX, NU = D::NU, NQ = S::NQ_, NK = L::NK;
-  constexpr int TQ = NQ / 3, TX = NX / 3;        // tiles per side of Q (16) and of S (12)
+  constexpr int TQ = NQ / 3, TX = NX / 3, TU = NU / 3;        // tiles per side of Q (16), of S (12), of the u block (4)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
@@ -125,10 +127,11 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   const long rec = b * P->NS + nd->slot;
   const double* __restrict__ kk = B.kkt + rec * L::KKT;
   const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
+  double* __restrict__ ki = B.kinv + rec * L::KINV;
   if (tid == 0) s_ok = 1;
   // ---- Qss in the order (u, q, v) (SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next, Qvq = Qqv^T, Qux = Qxu^T):
   //      straight into the register tiles ----
-  double a[3][3];
+  double qinv[3][3];
   const int qi = tid % TQ, qj = tid / TQ;
   const bool q_on = tid < TQ * TQ;
 #pragma unroll
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
           v = kk[L::K_QXX + rr + NX * cc] + ax;
         }
       }
-      a[tr][tc] = v;
+      qinv[tr][tc] = v;
     }
   // ---- F = [0 Fqq Fqv; Fvu Fvq Fvv] (NX x NQ): backward Euler has Fqq = -I, Fqv = dt I outside the base blocks ----
   for (int e = tid; e < NX * NQ; e += nt) {
@@ -163,114 +166,126 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
       else if (c < NU + NV) v = kk[L::K_FVQ + rv + NV * (c - NU)];
       else v = kk[L::K_FVV + rv + NV * (c - NU - NV)];
     }
-    sm[S::F + e] = v;
+    sm[S::B + e] = v;
   }
   // residual (split_kkt_residual.hxx): r1 = [Fq; Fv], r2 = [lu; lq; lv]
   if (tid < NX) sm[S::R1 + tid] = kk[L::K_FX + tid];
   if (tid >= 64 && tid < 64 + NU) sm[S::R2 + tid - 64] = kk[L::K_LU + tid - 64];
   if (tid >= 128 && tid < 128 + NX) sm[S::R2 + NU + tid - 128] = kk[L::K_LX + tid - 128];
   __syncthreads();                                   // s_ok
-  // ---- Q^-1 (llt_Q_.solve(I), split_kkt_matrix_inverter.hxx:55-58) ----
-  gaussJordanTiles<NQ>(a, q_on, qi, qj, &sm[S::PV], &s_ok);
+  // ---- Q^-1 (llt_Q_.solve(I), split_kkt_matrix_inverter.hxx:55-58); the tiles stay in registers for BR ----
+  gaussJordanTiles<NQ>(qinv, q_on, qi, qj, &sm[S::PV], &s_ok);
   if (q_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-      for (int tc = 0; tc < 3; ++tc) sm[S::Q + 3 * qi + tr + NQ * (3 * qj + tc)] = a[tr][tc];
+      for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * qi + tr + NQ * (3 * qj + tc)] = qinv[tr][tc];
   }
   __syncthreads();
-  // ---- FQ = F Q^-1 (multiplyF, :60): TX x TQ tiles ----
+  // ---- FQ = F Q^-1 (multiplyF, :60): TX x TQ tiles ; w = Q^-1 r2 ----
   const int fi = tid % TX, fj = tid / TX;            // tile of an NX x NQ matrix
   const bool f_on = tid < TX * TQ;
+  double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   if (f_on) {
-    double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    tileMM<NQ>(acc, [&](int r, int m) { return sm[S::F + 3 * fi + r + NX * m]; },
-               [&](int m, int c) { return sm[S::Q + m + NQ * (3 * fj + c)]; });
+    tileMM<NQ>(acc, [&](int r, int m) { return sm[S::B + 3 * fi + r + NX * m]; },
+               [&](int m, int c) { return sm[S::A + m + NQ * (3 * fj + c)]; });
+  } else if (tid < TX * TQ + NQ) {
+    const int r = tid - TX * TQ;
+    double w = 0.0;
+    for (int m = 0; m < NQ; ++m) w += sm[S::A + r + NQ * m] * sm[S::R2 + m];
+    sm[S::W + r] = w;
+  }
+  __syncthreads();                                   // Q^-1 is dead in LDS: FQ takes its place
+  if (f_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-      for (int tc = 0; tc < 3; ++tc) sm[S::FQ + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
+      for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
   }
   __syncthreads();
   // ---- S = F FQ^T (:61) into register tiles, S^-1 (:62-66) ----
   const bool s_on = tid < TX * TX;                   // (fi, fj) is then a tile of an NX x NX matrix as well
-#pragma unroll
-  for (int tr = 0; tr < 3; ++tr)
-#pragma unroll
-    for (int tc = 0; tc < 3; ++tc) a[tr][tc] = 0.0;
+  double sinv[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   if (s_on)
-    tileMM<NQ>(a, [&](int r, int m) { return sm[S::F + 3 * fi + r + NX * m]; },
-               [&](int m, int c) { return sm[S::FQ + 3 * fj + c + NX * m]; });
-  gaussJordanTiles<NX>(a, s_on, fi, fj, &sm[S::PV], &s_ok);      // its first barrier also ends the reads of F
+    tileMM<NQ>(sinv, [&](int r, int m) { return sm[S::B + 3 * fi + r + NX * m]; },
+               [&](int m, int c) { return sm[S::A + 3 * fj + c + NX * m]; });
+  gaussJordanTiles<NX>(sinv, s_on, fi, fj, &sm[S::PV], &s_ok);      // its first barrier also ends the reads of F
   if (s_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-      for (int tc = 0; tc < 3; ++tc) sm[S::SI + 3 * fi + tr + NX * (3 * fj + tc)] = a[tr][tc];
+      for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * fi + tr + NX * (3 * fj + tc)] = sinv[tr][tc];
   }
   __syncthreads();
-  // ---- TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69) ; t1 = r1 - FQ r2 ----
+  // ---- TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69) ; t1 = r1 - FQ r2 ; what else reads S^-1: TL = -S^-1 (the top
+  //      of C0) and the first half of the top of the coarse direction, -S^-1 r1 ----
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) acc[tr][tc] = 0.0;
   if (f_on) {
-    double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    tileMM<NX>(acc, [&](int r, int m) { return sm[S::SI + 3 * fi + r + NX * m]; },
-               [&](int m, int c) { return sm[S::FQ + m + NX * (3 * fj + c)]; });
+    tileMM<NX>(acc, [&](int r, int m) { return sm[S::B + 3 * fi + r + NX * m]; },
+               [&](int m, int c) { return sm[S::A + m + NX * (3 * fj + c)]; });
+  } else if (tid < TX * TQ + NX) {
+    const int r = tid - TX * TQ;
+    double t = sm[S::R1 + r];
+    for (int m = 0; m < NQ; ++m) t -= sm[S::A + r + NX * m] * sm[S::R2 + m];
+    sm[S::T1 + r] = t;
+    double d = 0.0;
+    for (int m = 0; m < NX; ++m) d -= sm[S::B + r + NX * m] * sm[S::R1 + m];
+    sm[S::DIR + r] = d;
+  }
+  for (int e = tid; e < NX * NX; e += nt) {
+    const int c = e / NX, r = e - c * NX;
+    ki[L::I_C0 + r + NK * c] = -sm[S::B + e];
+  }
+  __syncthreads();                                   // S^-1 is dead: TR takes its place
+  if (f_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-      for (int tc = 0; tc < 3; ++tc) sm[S::TR + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
-  } else if (tid >= 256 - NX) {
-    const int r = tid - (256 - NX);
-    double acc = sm[S::R1 + r];
-    for (int m = 0; m < NQ; ++m) acc -= sm[S::FQ + r + NX * m] * sm[S::R2 + m];
-    sm[S::T1 + r] = acc;
+      for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
   }
   __syncthreads();
-  // ---- coarse direction = KKT_inv * [r1; r2]: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - FQ r2) ----
-  if (tid < NX) {
-    double acc = 0.0;
-    for (int m = 0; m < NX; ++m) acc -= sm[S::SI + tid + NX * m] * sm[S::R1 + m];
-    for (int m = 0; m < NQ; ++m) acc += sm[S::TR + tid + NX * m] * sm[S::R2 + m];
-    sm[S::DIR + tid] = acc;
-  } else if (tid >= 64 && tid < 64 + NQ) {
-    const int r = tid - 64;
-    double acc = 0.0;
-    for (int m = 0; m < NQ; ++m) acc += sm[S::Q + r + NQ * m] * sm[S::R2 + m];
-    for (int m = 0; m < NX; ++m) acc += sm[S::TR + m + NX * r] * sm[S::T1 + m];
-    sm[S::DIR + NX + r] = acc;
-  }
-  __syncthreads();
-  // ---- BR[:, NU:] = Q^-1[:, NU:] - TR^T FQ[:, NU:] (:70-78), in place: TQ x TX tiles ----
-  {
-    const int bi2 = tid % TQ, bj2 = tid / TQ;
-    if (tid < TQ * TX) {
-      double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-      tileMM<NX>(acc, [&](int r, int m) { return sm[S::TR + m + NX * (3 * bi2 + r)]; },
-                 [&](int m, int c) { return sm[S::FQ + m + NX * (NU + 3 * bj2 + c)]; });
+  // ---- BR[:, NU:] = Q^-1[:, NU:] - TR^T FQ[:, NU:] (:70-78) by the threads that hold those tiles of Q^-1 ;
+  //      coarse direction = KKT_inv * [r1; r2]: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - FQ r2) ----
+  const bool b_on = q_on && qj >= TU;
+  if (b_on) {
 #pragma unroll
-      for (int tr = 0; tr < 3; ++tr)
+    for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-        for (int tc = 0; tc < 3; ++tc) {
-          double* q = &sm[S::Q + 3 * bi2 + tr + NQ * (NU + 3 * bj2 + tc)];
-          *q = *q - acc[tr][tc];
-        }
-    }
+      for (int tc = 0; tc < 3; ++tc) acc[tr][tc] = 0.0;
+    tileMM<NX>(acc, [&](int r, int m) { return sm[S::B + m + NX * (3 * qi + r)]; },
+               [&](int m, int c) { return sm[S::A + m + NX * (3 * qj + c)]; });
+  } else if (tid < NX) {
+    double d = sm[S::DIR + tid];
+    for (int m = 0; m < NQ; ++m) d += sm[S::B + tid + NX * m] * sm[S::R2 + m];
+    sm[S::DIR + tid] = d;
+  }
+  if (tid >= 256 - NQ) {                             // after its tile: the bottom of the direction
+    const int r = tid - (256 - NQ);
+    double d = sm[S::W + r];
+    for (int m = 0; m < NX; ++m) d += sm[S::B + m + NX * r] * sm[S::T1 + m];
+    sm[S::DIR + NX + r] = d;
+  }
+  __syncthreads();                                   // FQ is dead: BR[:, NU:] takes its place (NQ x NX)
+  if (b_on) {
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * qi + tr + NQ * (3 * (qj - TU) + tc)] = qinv[tr][tc] - acc[tr][tc];
   }
   __syncthreads();
-  // ---- the column blocks of the inverse: C0 = [TL; TR^T] with TL = -S^-1 ; C1 = [TR[:, NU:]; BR[:, NU:]] ----
-  double* __restrict__ ki = B.kinv + rec * L::KINV;
+  // ---- the column blocks of the inverse: C0 = [TL; TR^T] with TL = -S^-1 (above) ; C1 = [TR[:, NU:]; BR[:, NU:]] ----
   for (int e = tid; e < NK * NX; e += nt) {
     const int c = e / NK, r = e - c * NK;
-    double c0, c1;
     if (r < NX) {
-      c0 = -sm[S::SI + r + NX * c];
-      c1 = sm[S::TR + r + NX * (NU + c)];
+      ki[L::I_C1 + e] = sm[S::B + r + NX * (NU + c)];
     } else {
       const int rq = r - NX;
-      c0 = sm[S::TR + c + NX * rq];
-      c1 = sm[S::Q + rq + NQ * (NU + c)];
+      ki[L::I_C0 + e] = sm[S::B + c + NX * rq];
+      ki[L::I_C1 + e] = sm[S::A + rq + NQ * c];
     }
-    ki[L::I_C0 + e] = c0;
-    ki[L::I_C1 + e] = c1;
   }
   // ---- s_new = s - direction (split_backward_correction.hxx:49-58) ----
   const double* __restrict__ s = B.sol + rec * L::SOL;
