@@ -380,48 +380,69 @@ template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
-  __shared__ double x[NX], dx[NX];
+  constexpr int NQ = D::NQ, NS_ = NQ + NV;
+  // cur = the corrected (q, v) of the stage before; sp / sn = s and the coarse s_new (q, v) of the stages i - 1 / i
+  __shared__ double x[NX], dx[NX], cur[NS_], spL[NS_], snL[NS_];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const int lane = threadIdx.x;
   const long base = (long)blockIdx.x * P->NS;
-  constexpr int NQ = D::NQ;
   const long b = blockIdx.x;
   // a shard with a left neighbour also corrects its first stage: previous state = the imported (q, v) of the
   // neighbour's last stage (q0, v0), its corrected value = fwd_prev
-  for (int i = P->has_prev ? 0 : 1; i <= M - 2; ++i) {
+  const int i0 = P->has_prev ? 0 : 1;
+  {
+    const double *cq, *cv;
+    if (i0 == 0) { cq = B.fwd_prev + b * NS_; cv = cq + NQ; }
+    else { const long recp = base + B.nodes[0].slot; cq = B.snew + recp * L::SNEW + L::N_Q; cv = B.snew + recp * L::SNEW + L::N_V; }
+    if (lane < NQ) cur[lane] = cq[lane];
+    if (lane < NV) cur[NQ + lane] = cv[lane];
+  }
+  for (int i = i0; i <= M - 2; ++i) {
     const long rec = base + B.nodes[i].slot;
-    const double *spq, *spv, *snq, *snv;
-    if (i == 0) {
-      spq = q0 + b * NQ; spv = v0 + b * NV; snq = B.fwd_prev + b * (NQ + NV); snv = snq + NQ;
-    } else {
-      const long recp = base + B.nodes[i - 1].slot;
-      spq = B.sol + recp * L::SOL + L::S_Q; spv = B.sol + recp * L::SOL + L::S_V;
-      snq = B.snew + recp * L::SNEW + L::N_Q; snv = B.snew + recp * L::SNEW + L::N_V;
+    const double *spq, *spv;
+    if (i == 0) { spq = q0 + b * NQ; spv = v0 + b * NV; }
+    else { const long recp = base + B.nodes[i - 1].slot; spq = B.sol + recp * L::SOL + L::S_Q; spv = B.sol + recp * L::SOL + L::S_V; }
+    double* __restrict__ sn = B.snew + rec * L::SNEW;
+    // every load of the stage is issued here, ahead of the SE(3) log that only needs cur and s_prev: the rows of the
+    // KKT-inverse block arrive while lane 0 works
+    const double sp_q = lane < NQ ? spq[lane] : 0.0, sp_v = lane < NV ? spv[lane] : 0.0;
+    const double sn_q = lane < NQ ? sn[L::N_Q + lane] : 0.0, sn_v = lane < NV ? sn[L::N_V + lane] : 0.0;
+    double arow[NX];
+    {
+      const double* __restrict__ A = B.kinv + rec * L::KINV + L::I_C0 + (NK - NX) + (lane < NX ? lane : 0);
+#pragma unroll
+      for (int m = 0; m < NX; ++m) arow[m] = A[NK * m];
     }
+    if (lane < NQ) { spL[lane] = sp_q; snL[lane] = sn_q; }
+    if (lane < NV) { spL[NQ + lane] = sp_v; snL[NQ + lane] = sn_v; }
+    __syncthreads();
     if (lane == 0) {
       double R[9], p[3], d6[6];
-      lieRelative(spq, snq, R, p);          // s_new_prev.q (-) s_prev.q
+      lieRelative(spL, cur, R, p);          // s_new_prev.q (-) s_prev.q
       lieLog6(R, p, d6);
       for (int k = 0; k < 6; ++k) x[k] = d6[k];
     }
-    if (lane >= 6 && lane < NV) x[lane] = snq[lane + 1] - spq[lane + 1];
-    if (lane < NV) x[NV + lane] = snv[lane] - spv[lane];
+    if (lane >= 6 && lane < NV) x[lane] = cur[lane + 1] - spL[lane + 1];
+    if (lane < NV) x[NV + lane] = cur[NQ + lane] - spL[NQ + lane];
     __syncthreads();
     if (lane < NX) {
       B.xres[rec * L::XRES + lane] = x[lane];
-      dx[lane] = blockRowDot<NX, NK>(B.kinv + rec * L::KINV + L::I_C0, NK - NX + lane, x);
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NX; ++m) acc += arow[m] * x[m];
+      dx[lane] = acc;
     }
     __syncthreads();
-    double* __restrict__ sn = B.snew + rec * L::SNEW;
     if (lane < NV) {
-      sn[L::N_V + lane] -= dx[NV + lane];
-      if (lane >= 6) sn[L::N_Q + lane + 1] -= dx[lane];
+      const double nv = snL[NQ + lane] - dx[NV + lane];
+      sn[L::N_V + lane] = nv; cur[NQ + lane] = nv;
+      if (lane >= 6) { const double nq = snL[lane + 1] - dx[lane]; sn[L::N_Q + lane + 1] = nq; cur[lane + 1] = nq; }
     }
     if (lane == 32) {
       double qn[7];
-      lieIntegrateBase(sn + L::N_Q, dx, -1.0, qn);
-      for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
+      lieIntegrateBase(snL, dx, -1.0, qn);
+      for (int k = 0; k < 7; ++k) { sn[L::N_Q + k] = qn[k]; cur[k] = qn[k]; }
     }
     __syncthreads();
   }
