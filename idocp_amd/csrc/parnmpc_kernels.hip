@@ -320,27 +320,54 @@ template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
-  __shared__ double x[NX];
+  __shared__ double x[2][NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, ln = lane < NX ? lane : 0;
   const long base = (long)blockIdx.x * P->NS;
   // a shard that does not end the horizon also corrects its last stage, against the imported first stage of its
   // right neighbour (held in the placeholder records)
-  for (int i = P->has_terminal ? M - 3 : M - 2; i >= 0; --i) {
-    const long rec = base + B.nodes[i].slot, recn = base + B.nodes[i + 1].slot;
-    if (lane < NX) {
-      const int off = lane < NV ? 0 : 1;      // lmd then gmm: contiguous in both records
-      (void)off;
-      x[lane] = B.snew[recn * L::SNEW + L::N_LMD + lane] - B.sol[recn * L::SOL + L::S_LMD + lane];
-      B.xres[rec * L::XRES + lane] = x[lane];
+  const int i_first = P->has_terminal ? M - 3 : M - 2;
+  if (i_first < 0) return;
+  // Lane r carries the corrected (lmd, gmm)[r] of the stage after in a register; the rows of the next stage's block
+  // of the KKT inverse and its s / s_new entries are fetched while the current stage is multiplied.
+  auto loadRows = [&](int i, double (&row)[NX]) {
+    const double* __restrict__ A = B.kinv + (base + B.nodes[i].slot) * L::KINV + L::I_C1 + ln;
+#pragma unroll
+    for (int m = 0; m < NX; ++m) row[m] = A[NK * m];
+  };
+  double rowa[NX], rowb[NX];
+  double cur, s_next, s_i, sn_i;
+  {
+    const long recn = base + B.nodes[i_first + 1].slot, rec = base + B.nodes[i_first].slot;
+    cur = B.snew[recn * L::SNEW + L::N_LMD + ln];          // lmd then gmm: contiguous in both records
+    s_next = B.sol[recn * L::SOL + L::S_LMD + ln];
+    s_i = B.sol[rec * L::SOL + L::S_LMD + ln];
+    sn_i = B.snew[rec * L::SNEW + L::N_LMD + ln];
+    loadRows(i_first, rowa);
+  }
+  auto stage = [&](int i, const double (&row)[NX], double (&row_next)[NX], double* xb) {
+    const long rec = base + B.nodes[i].slot;
+    const double xl = cur - s_next;
+    if (lane < NX) { xb[lane] = xl; B.xres[rec * L::XRES + lane] = xl; }
+    const double s_here = s_i, sn_here = sn_i;
+    if (i > 0) {
+      const long recp = base + B.nodes[i - 1].slot;
+      s_i = B.sol[recp * L::SOL + L::S_LMD + ln];
+      sn_i = B.snew[recp * L::SNEW + L::N_LMD + ln];
+      loadRows(i - 1, row_next);
     }
     __syncthreads();
-    if (lane < NX) {
-      const double dx = blockRowDot<NX, NK>(B.kinv + rec * L::KINV + L::I_C1, lane, x);
-      B.snew[rec * L::SNEW + L::N_LMD + lane] -= dx;
-    }
-    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < NX; ++m) acc += row[m] * xb[m];
+    cur = sn_here - acc;
+    s_next = s_here;
+    if (lane < NX) B.snew[rec * L::SNEW + L::N_LMD + lane] = cur;
+  };
+  for (int i = i_first; i >= 0; i -= 2) {
+    stage(i, rowa, rowb, x[0]);
+    if (i >= 1) stage(i - 1, rowb, rowa, x[1]);
   }
 }
 
