@@ -48,7 +48,7 @@ struct RiccatiSmem {
 };
 
 template <typename D, int NT, bool HYBRID>
-__global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = RiccatiSmem<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV, NF = D::NF;
@@ -100,19 +100,34 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     RSTAMP(0);
     // software pipeline: the record of stage i was staged into LDS at the end of the previous
     // iteration; issue the global loads of stage i-1 now and park them in registers
-    constexpr int PF = (SL + NT - 1) / NT, QF = (NN + NT - 1) / NT;
-    double pre[PF], qxx[3][QF];
+    constexpr int PF = (SL + NT - 1) / NT;
+    // Phases 1 and 2 below work on 3 x 3 register tiles, one JOB per thread and round (a job = one tile position of
+    // one or two output blocks that share an operand):
+    //   phase 1 (96 jobs):  0..35 (A^T P)qq|qv   36..71 (A^T P)vq|vv   72..95 (B^T P)q|v
+    //   phase 2 (112 jobs): 0..35 F_qq|F_qv      36..71 F_vv           72..95 H_q|H_v     96..111 G
+    constexpr int T6 = NV / 3, T4 = NU / 3, J1 = 2 * T6 * T6 + T4 * T6, J2A = T6 * T6, J2B = 2 * T6 * T6, J2C = J2B + T6 * T4,
+                  J2D = J2C + T4 * T4, JPT = (J2D + NT - 1) / NT;
+    static_assert(NV % 3 == 0 && NU % 3 == 0 && NV >= 6, "3 x 3 tiles aligned with the 6 x 6 base block");
+    double pre[PF], qxx[JPT][2][3][3];
     {
-      // Qxx of THIS stage is consumed once per element in the F phase: straight to registers
+      // Qxx of THIS stage is consumed once per element in the F phase: straight to the registers of the job that adds it
       const double* __restrict__ kc = B.kkt + rec * L::KKT;
 #pragma unroll
-      for (int t = 0; t < QF; ++t) {
-        const int e = tid + NT * t;
-        if (e < NN) {
-          const int c = e / NV, r = e - c * NV;
-          qxx[0][t] = kc[L::K_QXX + r + NX * c];
-          qxx[1][t] = kc[L::K_QXX + r + NX * (NV + c)];
-          qxx[2][t] = kc[L::K_QXX + (NV + r) + NX * (NV + c)];
+      for (int jj = 0; jj < JPT; ++jj) {
+        const int job = tid + NT * jj;
+        if (job < J2B) {
+          const int t = job < J2A ? job : job - J2A, r0 = 3 * (t % T6), c0 = 3 * (t / T6);
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              if (job < J2A) {
+                qxx[jj][0][a][c] = kc[L::K_QXX + (r0 + a) + NX * (c0 + c)];
+                qxx[jj][1][a][c] = kc[L::K_QXX + (r0 + a) + NX * (NV + c0 + c)];
+              } else {
+                qxx[jj][0][a][c] = kc[L::K_QXX + (NV + r0 + a) + NX * (NV + c0 + c)];
+              }
+            }
         }
       }
     }
@@ -133,29 +148,62 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     const double* Fx = st + (L::K_FX - KO);
     RSTAMP(1);
     // ---- A^T P blocks and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
-    for (int e = tid; e < NN; e += nt) {
-      const int c = e / NV, r = e - c * NV;
-      double aqq, aqv, avq, avv;
-      if (r < 6) {
-        aqq = aqv = avq = avv = 0.0;
+    for (int job = tid; job < J1; job += nt) {
+      // out1 = X^T Pvq (+ base1), out2 = X^T Pvv (+ base2) on one tile: X = Fvq (qq|qv), Fvv (vq|vv) or Fvu (B^T P)
+      const bool bt = job >= 2 * T6 * T6, vhalf = !bt && job >= T6 * T6;
+      const int t = bt ? job - 2 * T6 * T6 : (vhalf ? job - T6 * T6 : job);
+      const int nr = bt ? T4 : T6, r0 = 3 * (t % nr), c0 = 3 * (t / nr);
+      const double* X = (bt ? Fvu : (vhalf ? Fvv : Fvq)) + NV * r0;
+      double a1[3][3], a2[3][3];
+      if (bt) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a1[a][c] = a2[a][c] = 0.0;
+      } else if (r0 < 6) {
+        const double* F6 = (vhalf ? Fqv6 : Fqq6) + 6 * r0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a1[a][c] = a2[a][c] = 0.0;
+#pragma unroll
         for (int m = 0; m < 6; ++m) {
-          const double fq = Fqq6[m + 6 * r], fv = Fqv6[m + 6 * r], pq = Pqq[m + NV * c], pv = Pqv[m + NV * c];
-          aqq += fq * pq; aqv += fq * pv; avq += fv * pq; avv += fv * pv;
+          double f[3], pq[3], pv[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { f[a] = F6[m + 6 * a]; pq[a] = Pqq[m + NV * (c0 + a)]; pv[a] = Pqv[m + NV * (c0 + a)]; }
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a1[a][c] += f[a] * pq[c]; a2[a][c] += f[a] * pv[c]; }
         }
       } else {
-        aqq = Pqq[e]; aqv = Pqv[e]; avq = dt * Pqq[e]; avv = dt * Pqv[e];
+        const double sc = vhalf ? dt : 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int e = (r0 + a) + NV * (c0 + c);
+            a1[a][c] = vhalf ? sc * Pqq[e] : Pqq[e];
+            a2[a][c] = vhalf ? sc * Pqv[e] : Pqv[e];
+          }
       }
+#pragma unroll 3
       for (int m = 0; m < NV; ++m) {
-        const double fvq = Fvq[m + NV * r], fvv = Fvv[m + NV * r], pvq = Pqv[c + NV * m], pvv = Pvv[m + NV * c];
-        aqq += fvq * pvq; aqv += fvq * pvv; avq += fvv * pvq; avv += fvv * pvv;
+        double f[3], pvq[3], pvv[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { f[a] = X[m + NV * a]; pvq[a] = Pqv[(c0 + a) + NV * m]; pvv[a] = Pvv[m + NV * (c0 + a)]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { a1[a][c] += f[a] * pvq[c]; a2[a][c] += f[a] * pvv[c]; }
       }
-      sm[S::ATPQQ + e] = aqq; sm[S::ATPQV + e] = aqv; sm[S::ATPVQ + e] = avq; sm[S::ATPVV + e] = avv;
-    }
-    for (int e = tid; e < NU * NV; e += nt) {
-      const int c = e / NU, j = e - c * NU;
-      double bq = 0.0, bv = 0.0;
-      for (int m = 0; m < NV; ++m) { const double f = Fvu[m + NV * j]; bq += f * Pqv[c + NV * m]; bv += f * Pvv[m + NV * c]; }
-      sm[S::BTPQ + e] = bq; sm[S::BTPV + e] = bv;
+      double* o1 = bt ? &sm[S::BTPQ] : (vhalf ? &sm[S::ATPVQ] : &sm[S::ATPQQ]);
+      double* o2 = bt ? &sm[S::BTPV] : (vhalf ? &sm[S::ATPVV] : &sm[S::ATPQV]);
+      const int ldo = bt ? NU : NV;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o1[(r0 + a) + ldo * (c0 + c)] = a1[a][c]; o2[(r0 + a) + ldo * (c0 + c)] = a2[a][c]; }
     }
     __syncthreads();
     const double* AtPqq = &sm[S::ATPQQ];
@@ -167,68 +215,99 @@ __global__ __launch_bounds__(NT) void ocp_riccati_backward_kernel(OcpBuffers B) 
     RSTAMP(2);
     // ---- F, H, G and the vector term (:79-113); F overwrites P_{i+1}, which is dead from here ----
 #pragma unroll
-    for (int t = 0; t < QF; ++t) {
-      const int e = tid + NT * t;
-      if (e >= NN) break;
-      const int c = e / NV, r = e - c * NV;
-      double qqq, qqv, qvv;
-      if (c < 6) {
-        qqq = qqv = qvv = 0.0;
-        for (int m = 0; m < 6; ++m) {
-          qqq += AtPqq[r + NV * m] * Fqq6[m + 6 * c];
-          qqv += AtPqq[r + NV * m] * Fqv6[m + 6 * c];
-          qvv += AtPvq[r + NV * m] * Fqv6[m + 6 * c];
+    for (int jj = 0; jj < JPT; ++jj) {
+      const int job = tid + NT * jj;
+      // Every tile job runs the same instruction stream (no divergence inside a wavefront):
+      //   out1 = base1 + X1 Y1, out2 = base2 + X2 Y2 with per-job operand pointers
+      //   F_qq | F_qv : X1 = X2 = (A^T P)qv, Y1 = Fvq, Y2 = Fvv ;  F_vv : X2 = (A^T P)vv, Y2 = Fvv (out1 unused)
+      //   H_q | H_v   : X1 = (A^T P)qv, X2 = (A^T P)vv, Y1 = Y2 = Fvu ;  G : X1 = (B^T P)v, Y1 = Fvu (out2 unused)
+      if (job < J2D) {
+        int type, t, nr;
+        if (job < J2A) { type = 0; t = job; nr = T6; }
+        else if (job < J2B) { type = 1; t = job - J2A; nr = T6; }
+        else if (job < J2C) { type = 2; t = job - J2B; nr = T6; }
+        else { type = 3; t = job - J2C; nr = T4; }
+        const int r0 = 3 * (t % nr), c0 = 3 * (t / nr);
+        const double* X1 = (type == 3 ? BtPv : AtPqv) + r0;
+        const double* X2 = (type == 0 ? AtPqv : AtPvv) + (type == 3 ? 0 : r0);
+        const int ldx1 = type == 3 ? NU : NV;
+        const double* Y1 = (type == 0 || type == 1 ? Fvq : Fvu) + NV * c0;
+        const double* Y2 = (type == 0 || type == 1 ? Fvv : Fvu) + NV * c0;
+        double a1[3][3], a2[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a1[a][c] = a2[a][c] = 0.0;
+        if (type <= 1) {
+          const double* Ab = (type == 1 ? AtPvq : AtPqq) + r0;          // multiplies the 6 x 6 / identity part of A
+          if (c0 < 6) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+              double x[3], fq[3], fv[3];
+#pragma unroll
+              for (int a = 0; a < 3; ++a) { x[a] = Ab[a + NV * m]; fq[a] = Fqq6[m + 6 * (c0 + a)]; fv[a] = Fqv6[m + 6 * (c0 + a)]; }
+#pragma unroll
+              for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { a1[a][c] += x[a] * fq[c]; a2[a][c] += x[a] * fv[c]; }
+            }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { const double x = Ab[a + NV * (c0 + c)]; a1[a][c] = x; a2[a][c] = dt * x; }
+          }
         }
-      } else {
-        qqq = AtPqq[e]; qqv = dt * AtPqq[e]; qvv = dt * AtPvq[e];
+#pragma unroll 3
+        for (int m = 0; m < NV; ++m) {
+          double x1[3], x2[3], y1[3], y2[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { x1[a] = X1[a + ldx1 * m]; x2[a] = X2[a + NV * m]; y1[a] = Y1[m + NV * a]; y2[a] = Y2[m + NV * a]; }
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a1[a][c] += x1[a] * y1[c]; a2[a][c] += x2[a] * y2[c]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int e = (r0 + a) + NV * (c0 + c);
+            if (type == 0) { Pqq[e] = qxx[jj][0][a][c] + a1[a][c]; Pqv[e] = qxx[jj][1][a][c] + a2[a][c]; }
+            else if (type == 1) Pvv[e] = qxx[jj][0][a][c] + a2[a][c];
+            else if (type == 2) { Qxu[(r0 + a) + NX * (c0 + c)] += a1[a][c]; Qxu[(NV + r0 + a) + NX * (c0 + c)] += a2[a][c]; }
+            else Quu[(r0 + a) + NU * (c0 + c)] += a1[a][c];
+          }
       }
-      for (int m = 0; m < NV; ++m) {
-        qqq += AtPqv[r + NV * m] * Fvq[m + NV * c];
-        qqv += AtPqv[r + NV * m] * Fvv[m + NV * c];
-        qvv += AtPvv[r + NV * m] * Fvv[m + NV * c];
-      }
-      Pqq[e] = qxx[0][t] + qqq;
-      Pqv[e] = qxx[1][t] + qqv;
-      Pvv[e] = qxx[2][t] + qvv;
     }
-    for (int e = tid; e < NV * NU; e += nt) {
-      const int j = e / NV, r = e - j * NV;
-      double hq = 0.0, hv = 0.0;
-      for (int m = 0; m < NV; ++m) { const double f = Fvu[m + NV * j]; hq += AtPqv[r + NV * m] * f; hv += AtPvv[r + NV * m] * f; }
-      Qxu[r + NX * j] += hq;
-      Qxu[(NV + r) + NX * j] += hv;
-    }
-    for (int e = tid; e < NU * NU; e += nt) {
-      const int l = e / NU, j = e - l * NU;
-      double g = 0.0;
-      for (int m = 0; m < NV; ++m) g += BtPv[j + NU * m] * Fvu[m + NV * l];
-      Quu[e] += g;
-    }
-    if (tid < NU) {
-      const int j = tid;
+    // The two vector terms run behind the tile jobs of different wavefronts (NT >= 128): lu on the last NU threads,
+    // the k-independent part of the s recursion (:141-160) on the first 2 NV.  Neither reads anything the tile jobs write
+    // (P_{i+1} is only read through A^T P here).
+    if (tid >= NT - NU) {
+      const int j = tid - (NT - NU);
       double acc = 0.0;
       for (int c = 0; c < NV; ++c) acc += BtPq[j + NU * c] * Fx[c] + BtPv[j + NU * c] * Fx[NV + c];
       for (int m = 0; m < NV; ++m) acc -= Fvu[m + NV * j] * sm[S::SV + m];
       lu[j] += acc;
     }
-    __syncthreads();
-    // s recursion (:141-160), part that does not depend on k; needs P_{i+1}, s_{i+1} and A^T P, all still intact here
-    if (tid < NV) {
-      const int r = tid;
-      double sq, sv;
+    if (tid < 2 * NV) {
+      const bool isv = tid >= NV;
+      const int r = isv ? tid - NV : tid;
+      const double* F6 = isv ? Fqv6 : Fqq6;
+      const double* Fm = isv ? Fvv : Fvq;
+      const double* A1 = isv ? AtPvq : AtPqq;
+      const double* A2 = isv ? AtPvv : AtPqv;
+      double acc;
       if (r < 6) {
-        sq = sv = 0.0;
-        for (int m = 0; m < 6; ++m) { sq += Fqq6[m + 6 * r] * sm[S::SQ + m]; sv += Fqv6[m + 6 * r] * sm[S::SQ + m]; }
+        acc = 0.0;
+        for (int m = 0; m < 6; ++m) acc += F6[m + 6 * r] * sm[S::SQ + m];
       } else {
-        sq = sm[S::SQ + r]; sv = dt * sm[S::SQ + r];
+        acc = isv ? dt * sm[S::SQ + r] : sm[S::SQ + r];
       }
-      for (int m = 0; m < NV; ++m) { sq += Fvq[m + NV * r] * sm[S::SV + m]; sv += Fvv[m + NV * r] * sm[S::SV + m]; }
-      for (int c = 0; c < NV; ++c) {
-        sq -= AtPqq[r + NV * c] * Fx[c] + AtPqv[r + NV * c] * Fx[NV + c];
-        sv -= AtPvq[r + NV * c] * Fx[c] + AtPvv[r + NV * c] * Fx[NV + c];
-      }
-      sq -= lx[r]; sv -= lx[NV + r];
-      sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
+      for (int m = 0; m < NV; ++m) acc += Fm[m + NV * r] * sm[S::SV + m];
+      for (int c = 0; c < NV; ++c) acc -= A1[r + NV * c] * Fx[c] + A2[r + NV * c] * Fx[NV + c];
+      acc -= lx[isv ? NV + r : r];
+      sm[(isv ? S::SVN : S::SQN) + r] = acc;
     }
     __syncthreads();
     RSTAMP(3);
