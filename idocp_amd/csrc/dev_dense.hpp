@@ -158,6 +158,54 @@ __device__ __forceinline__ void spdInverseWave(double* A, double* W, int ld, int
   }
 }
 
+// The same elimination with the matrix in REGISTERS of one wavefront: lane r keeps row r (n <= N <= 64 rows, N columns),
+// the pivot row travels through v_readlane (scalar registers), nothing touches LDS between the load and the store, so a
+// step is the reciprocal of the pivot plus N independent multiply-adds per lane.  Same update formula, same results as
+// spdInverse.  In place on the column-major block A (ld); every lane of the wavefront must call it.
+__device__ __forceinline__ double readLaneF64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// 1 / p for a positive, normal p: hardware estimate + two Newton steps (the error of the estimate, 2^-26 or so, is squared
+// twice; the result is within an ulp of the IEEE quotient) -- a third of the dependent instructions of the division
+// sequence, which sits on the critical path of every pivot step.
+__device__ __forceinline__ double recipNewton(double p) {
+  double x = __builtin_amdgcn_rcp(p);
+  double e = __builtin_fma(-p, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-p, x, 1.0);
+  return __builtin_fma(x, e, x);
+}
+template <int N>
+__device__ __forceinline__ void spdInverseRows(double* A, int ld, int n, int lane, int* ok) {
+  double a[N];
+  const bool on = lane < n;
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (on && j < n) ? A[lane + ld * j] : 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {
+      double prow[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) prow[j] = readLaneF64(a[j], k);
+      const double p = prow[k];
+      if (lane == 0 && !(p > 0.0)) *ok = 0;
+      const double ip = recipNewton(p);
+      const double aik = a[k];
+      const bool isk = lane == k;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (j == k) continue;
+        const double akj = prow[j];
+        a[j] = isk ? akj * ip : a[j] - aik * akj * ip;
+      }
+      a[k] = isk ? ip : -aik * ip;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) if (on && j < n) A[lane + ld * j] = a[j];
+}
+
 // C (m x n) (+)= alpha * X^T Y with X (k x m, ldx) and Y (k x n, ldy) column-major,
 // i.e. both operands contiguous along the contraction index: 2 x 2 register blocks,
 // 16-byte LDS reads (two k's per read): 0.5 LDS instruction per FMA instead of 2.

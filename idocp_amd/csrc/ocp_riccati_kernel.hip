@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
             a2[a][c] = vhalf ? sc * Pqv[e] : Pqv[e];
           }
       }
-#pragma unroll 3
+#pragma unroll 6
       for (int m = 0; m < NV; ++m) {
         double f[3], pvq[3], pvv[3];
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
               for (int c = 0; c < 3; ++c) { const double x = Ab[a + NV * (c0 + c)]; a1[a][c] = x; a2[a][c] = dt * x; }
           }
         }
-#pragma unroll 3
+#pragma unroll 6
         for (int m = 0; m < NV; ++m) {
           double x1[3], x2[3], y1[3], y2[3];
 #pragma unroll
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     // The two vector terms run behind the tile jobs of different wavefronts (NT >= 128): lu on the last NU threads,
     // the k-independent part of the s recursion (:141-160) on the first 2 NV.  Neither reads anything the tile jobs write
     // (P_{i+1} is only read through A^T P here).
+    RSTAMP(11);
     if (tid >= NT - NU) {
       const int j = tid - (NT - NU);
       double acc = 0.0;
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
       acc -= lx[isv ? NV + r : r];
       sm[(isv ? S::SVN : S::SQN) + r] = acc;
     }
+    RSTAMP(12);
     __syncthreads();
     RSTAMP(3);
     // Qvq = Qqv^T (:94) -- only read through Qqv below, kept for completeness of the record
@@ -317,8 +319,10 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     // wavefront and applied with two small products -- same K, k up to rounding)
     for (int e = tid; e < NU * NU; e += nt) sm[S::GW + e] = Quu[e];
     __syncthreads();
-    if (tid < 64) spdInverseWave<3>(&sm[S::GW], &sm[S::GK], NU, NU, tid, &s_ok);
+    RSTAMP(9);
+    if (tid < 64) spdInverseRows<NU>(&sm[S::GW], NU, NU, tid, &s_ok);
     __syncthreads();
+    RSTAMP(10);
     if (HYBRID && dimi > 0) {
       // ---- Schur complement w.r.t. the switching constraint Phix dx + Phiu du + P = 0 (split_riccati_factorizer.hxx:56-70) ----
       const double* __restrict__ W = B.swc + rec * L::SWC;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
         sm[S::SS + j + NF * c] = acc;
       }
       __syncthreads();
-      if (tid < 64) spdInverseWave<3>(&sm[S::SS], &sm[S::SDG], NF, dimi, tid, &s_ok);      // S^-1 (LLT in the reference)
+      if (tid < 64) spdInverseRows<NF>(&sm[S::SS], NF, dimi, tid, &s_ok);      // S^-1 (LLT in the reference)
       __syncthreads();
       for (int e = tid; e < dimi * NU; e += nt) {                // SinvDGinv
         const int c = e / dimi, j = e - c * dimi;
