@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032, "anymal_parnmpc": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
+A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
 KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
                "ocp_reduce_steps", "ocp_expand_dual_integrate"]
@@ -68,10 +68,19 @@ class Hip:
 def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=12.0, nimp=0):
     """CPU restatement (oracle, kind "port") timed on this host with the
     reference's CPUTime protocol, single thread, on a bounded sample."""
-    from helpers import OracleOCP, OracleUnOCP, P, arr, oracle, trotting_sequence
+    from helpers import OracleOCP, OracleUnOCP, P, arr, oracle, running_sequence, trotting_sequence
     lib = oracle()
     ric = C.c_double()
-    if workload == "anymal_trotting":
+    if workload == "anymal_running":
+        o = OracleOCP(model, cost, cons, T, N, max_num_impulse=nimp)
+        running_sequence(o, model, 10)
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+        o.init_constraints(0.0)
+        bench = lib.oracle_ocp_bench
+        nconv = 10
+    elif workload == "anymal_trotting":
         o = OracleOCP(model, cost, cons, T, N, max_num_impulse=nimp + 1)
         trotting_sequence(o, model, nimp)
         o.set_solution("q", q)
@@ -293,7 +302,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_parnmpc", "iiwa14"], default="anymal_trotting",
+    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "iiwa14"], default="anymal_trotting",
                     help="anymal_trotting = BASELINE.json configs[2] (trotting contact sequence); anymal = its uniform 4-contact variant "
                          "(SURVEY 8d roofline case); iiwa14 = configs[1]; anymal_parnmpc = configs[3] (ParNMPC, N=256, the horizon "
                          "sharded over the ranks, strong scaling)")
@@ -348,6 +357,33 @@ def main():
         riccati_ids = (2, 3)
         desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, trotting contact sequence (1 lift + %d impulse events, %d stages incl. impulse / "
                 "aux / lift stages, switching constraints; BASELINE.json configs[2]); " % (N, T, nimp, Mc))
+        assert solver.update(0.0, q0, v0) == 0
+    elif args.workload == "anymal_running":
+        # BASELINE.json configs[4] in FP64: ANYmal OCPSolver on the running gait of examples/anymal/anymal_running.cpp:29-231
+        # (40 discrete events: 26 touch-downs, 14 lift-offs, flight phases without any contact), N = 200, T = 7
+        from helpers import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
+        N = args.horizon if args.horizon != 100 else 200
+        T = 7.0
+        nimp = 26
+        B = args.batch or 512
+        model = anymal_model()
+        cost, cons = running_problem(model, 10)
+        nq, nv = model.nq, model.nv
+        q0 = np.tile(ANYMAL_Q_RUNNING_START, (B, 1))
+        v0 = np.zeros((B, nv))
+        solver = HipOCP(model, cost, cons, T, N, batch=B, device=local_rank, max_num_impulse=nimp)
+        running_sequence(solver, model, 10)
+        solver.set_solution("q", q0[0])
+        solver.set_solution("v", v0[0])
+        solver.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+        solver.init_constraints(0.0)
+        Mc = len(solver.chain(0.0))
+        KERNELS = KERNELS_OCP
+        launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
+        units = {0: B * (Mc - 1), 1: B * Mc, 2: B * (Mc - 1), 3: B * (Mc - 1), 4: B * Mc, 5: B * (Mc - 1), 6: B * Mc}
+        riccati_ids = (2, 3)
+        desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, running contact sequence of examples/anymal/anymal_running.cpp (26 impulse + 14 lift "
+                "events, flight phases, %d stages in the chain; BASELINE.json configs[4] in FP64); " % (N, T, Mc))
         assert solver.update(0.0, q0, v0) == 0
     elif args.workload == "anymal":
         # BASELINE.json configs[2] / metric config: ANYmal OCPSolver, N=100, T=5 (dt=0.05), 4 point contacts active on

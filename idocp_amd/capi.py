@@ -50,6 +50,7 @@ class Cost(C.Structure):
         ("front_stance_knee", C.c_double), ("hip_stance_knee", C.c_double),
         ("qi_weight", C.c_double * MAX_NV), ("vi_weight", C.c_double * MAX_NV), ("dvi_weight", C.c_double * MAX_NV),
         ("fi_weight", (C.c_double * 3) * MAX_CONTACTS), ("fi_ref", (C.c_double * 3) * MAX_CONTACTS),
+        ("use_time_varying_ref", C.c_int), ("tv_t_begin", C.c_double), ("tv_t_end", C.c_double),
     ]
 
     def set(self, name, values):

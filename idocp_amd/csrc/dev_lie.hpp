@@ -1,4 +1,4 @@
-// SE(3) Lie-group pieces of the floating base, device side (single-lane scalar
+// SE(3) Lie-group pieces of the floating base (host + device; on the device single-lane scalar
 // code; executed by one lane per task inside the condensation / integration
 // kernels).  Same closed forms as pinocchio's explog.hpp (log3, Jlog3, Jlog6,
 // exp6), which the reference reaches through pinocchio::difference /
@@ -10,26 +10,26 @@
 
 namespace idocp_dev {
 
-__device__ __forceinline__ void lieQuatToR(const double* qt, double* R) {
+__host__ __device__ __forceinline__ void lieQuatToR(const double* qt, double* R) {
   const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
   R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
-__device__ __forceinline__ void lieMatmul3(const double* A, const double* Bm, double* C) {
+__host__ __device__ __forceinline__ void lieMatmul3(const double* A, const double* Bm, double* C) {
   double T[9];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * i] * Bm[j] + A[3 * i + 1] * Bm[3 + j] + A[3 * i + 2] * Bm[6 + j];
   for (int i = 0; i < 9; ++i) C[i] = T[i];
 }
-__device__ __forceinline__ void lieMatvec3(const double* R, const double* x, double* y) {
+__host__ __device__ __forceinline__ void lieMatvec3(const double* R, const double* x, double* y) {
   const double a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2], b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2],
                c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
   y[0] = a; y[1] = b; y[2] = c;
 }
-__device__ __forceinline__ void lieSkew(const double* v, double* S) {
+__host__ __device__ __forceinline__ void lieSkew(const double* v, double* S) {
   S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
 }
-__device__ __forceinline__ void lieLog3(const double* R, double* w, double* theta) {
+__host__ __device__ __forceinline__ void lieLog3(const double* R, double* w, double* theta) {
   double c = (R[0] + R[4] + R[8] - 1) / 2; c = c > 1 ? 1 : (c < -1 ? -1 : c);
   const double t = acos(c);
   const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
@@ -38,7 +38,7 @@ __device__ __forceinline__ void lieLog3(const double* R, double* w, double* thet
   *theta = t;
 }
 // M = M_minus^-1 M_plus of two free-flyer configurations (xyz + quat xyzw)
-__device__ __forceinline__ void lieRelative(const double* qm, const double* qp, double* R, double* p) {
+__host__ __device__ __forceinline__ void lieRelative(const double* qm, const double* qp, double* R, double* p) {
   double Rm[9], Rp[9], Rmt[9], d[3];
   lieQuatToR(qm + 3, Rm); lieQuatToR(qp + 3, Rp);
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rmt[3 * r + s] = Rm[3 * s + r];
@@ -47,7 +47,7 @@ __device__ __forceinline__ void lieRelative(const double* qm, const double* qp, 
   lieMatvec3(Rmt, d, p);
 }
 // log6(M) = (V(w)^-1 p, w)
-__device__ __forceinline__ void lieLog6(const double* R, const double* p, double* out) {
+__host__ __device__ __forceinline__ void lieLog6(const double* R, const double* p, double* out) {
   double w[3], t;
   lieLog3(R, w, &t);
   const double t2 = t * t;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void lieLog6(const double* R, const double* p, double
   out[3] = w[0]; out[4] = w[1]; out[5] = w[2];
 }
 // Jlog6(M): 6x6, written column-major with leading dimension 6
-__device__ __forceinline__ void lieJlog6(const double* R, const double* p, double* J) {
+__host__ __device__ __forceinline__ void lieJlog6(const double* R, const double* p, double* J) {
   double w[3], t;
   lieLog3(R, w, &t);
   const double t2 = t * t;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void lieJlog6(const double* R, const double* p, doubl
   }
 }
 // dDifference ARG0 = -Jlog6(M) Ad(M^-1); J1 = Jlog6(M) given (col-major 6x6) -> J0 (col-major 6x6)
-__device__ __forceinline__ void lieDDiffArg0(const double* R, const double* p, const double* J1, double* J0) {
+__host__ __device__ __forceinline__ void lieDDiffArg0(const double* R, const double* p, const double* J1, double* J0) {
   double Rt[9], mp[3], K[9], KRt[9], Ad[36];
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
   lieMatvec3(Rt, p, mp);
@@ -107,7 +107,7 @@ __device__ __forceinline__ void lieDDiffArg0(const double* R, const double* p, c
   }
 }
 // Robot::dSubtractdConfigurationInverse (robot.hxx:151-163): inverse of [[A, B],[0, D]] (col-major 6x6 in / out)
-__device__ __forceinline__ void lieBlockInverse(const double* J, double* Ji) {
+__host__ __device__ __forceinline__ void lieBlockInverse(const double* J, double* Ji) {
   auto inv3 = [](const double* A /*col-major ld 6*/, double* I /*row-major 3x3*/) {
     const double a00 = A[0], a01 = A[6], a02 = A[12], a10 = A[1], a11 = A[7], a12 = A[13], a20 = A[2], a21 = A[8], a22 = A[14];
     const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
@@ -123,7 +123,7 @@ __device__ __forceinline__ void lieBlockInverse(const double* J, double* Ji) {
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) { Ji[r + 6 * s] = TL[3 * r + s]; Ji[3 + r + 6 * (3 + s)] = BR[3 * r + s]; Ji[r + 6 * (3 + s)] = -T2[3 * r + s]; }
 }
 // q (+) length * v for the free-flyer part (pinocchio::integrate): p' = p + R V(w) v_lin ; quat' = quat(R exp3(w))
-__device__ __forceinline__ void lieIntegrateBase(const double* q, const double* vin, double length, double* qout) {
+__host__ __device__ __forceinline__ void lieIntegrateBase(const double* q, const double* vin, double length, double* qout) {
   double R[9], w[3], vl[3];
   lieQuatToR(q + 3, R);
   for (int k = 0; k < 3; ++k) { vl[k] = length * vin[k]; w[k] = length * vin[3 + k]; }
@@ -151,7 +151,7 @@ __device__ __forceinline__ void lieIntegrateBase(const double* q, const double* 
 }
 
 // exp6 of a free-flyer tangent v = (lin, ang): (R, p) = (exp3(w), V(w) lin)   (pinocchio::exp6)
-__device__ __forceinline__ void lieExp6(const double* vin, double* R, double* p) {
+__host__ __device__ __forceinline__ void lieExp6(const double* vin, double* R, double* p) {
   const double* w = vin + 3;
   const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = sqrt(t2);
   double a, b, c;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void lieExp6(const double* vin, double* R, double* p)
 }
 
 // pinocchio::dIntegrate(q, v, ARG0) for the free-flyer: action matrix of exp6(v)^-1 (6x6 column-major)
-__device__ __forceinline__ void lieDIntegrateArg0(const double* R, const double* p, double* A) {
+__host__ __device__ __forceinline__ void lieDIntegrateArg0(const double* R, const double* p, double* A) {
   double Rt[9], mp[3], K[9], KRt[9];
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
   lieMatvec3(Rt, p, mp);

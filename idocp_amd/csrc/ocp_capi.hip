@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "dev_lie.hpp"
 #include "host_util.hpp"
 #include "idocp_hip.h"
 #include "ocp_launch.hpp"
@@ -129,6 +130,18 @@ int setDev(const idocp_ocp* h) { HIP_TRY(hipSetDevice(h->device)); return IDOCP_
 // (include/idocp/cost/trotting_configuration_space_cost.hpp:126-164)
 void qRefAt(const idocp_cost_t& c, int nq, double t, double* q_ref) {
   for (int i = 0; i < nq; ++i) q_ref[i] = c.q_ref[i];
+  if (c.use_time_varying_ref) {
+    // TimeVaryingConfigurationSpaceCost::set_q_ref (time_varying_configuration_space_cost.hpp:98-109):
+    // q_begin (+) tau v_ref with tau = t - t_begin clamped to the window (q_end = q_begin (+) (t_end - t_begin) v_ref)
+    const double tau = t <= c.tv_t_begin ? 0.0 : ((t < c.tv_t_end ? t : c.tv_t_end) - c.tv_t_begin);
+    if (tau > 0.0) {
+      double v6[6] = {c.v_ref[0], c.v_ref[1], c.v_ref[2], c.v_ref[3], c.v_ref[4], c.v_ref[5]}, qb[7];
+      idocp_dev::lieIntegrateBase(c.q_ref, v6, tau, qb);
+      for (int i = 0; i < 7; ++i) q_ref[i] = qb[i];
+      for (int i = 7; i < nq; ++i) q_ref[i] = c.q_ref[i] + tau * c.v_ref[i - 1];
+    }
+    return;
+  }
   if (!c.use_trotting_ref || !(t > c.t_start)) return;
   const double tau = t - c.t_start;
   const int steps = (int)std::floor(tau / c.t_period);
@@ -142,6 +155,12 @@ void qRefAt(const idocp_cost_t& c, int nq, double t, double* q_ref) {
     q_ref[9] += sin2 * c.front_stance_knee; q_ref[12] += sin2 * c.hip_swing_knee;
     q_ref[15] -= sin2 * c.front_swing_knee; q_ref[18] -= sin2 * c.hip_stance_knee;
   }
+}
+
+// TimeVaryingConfigurationSpaceCost::v_ref(t) (time_varying_configuration_space_cost.hpp:111-118): zero outside the window
+double vRefOnAt(const idocp_cost_t& c, double t) {
+  if (!c.use_time_varying_ref) return 1.0;
+  return (t > c.tv_t_begin && t < c.tv_t_end) ? 1.0 : 0.0;
 }
 
 int slotOf(const idocp_ocp* h, int kind, int index) {
@@ -262,7 +281,7 @@ int discretize(idocp_ocp* h, double t) {
   if (h->event_time.empty()) h->uniform_dimf = h->chain[0].dimf;
   // upload: chain, per-stage cost references, problem header
   std::vector<double> tab((size_t)M * DQ::NQ);
-  for (int p = 0; p < M; ++p) qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]);
+  for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
@@ -298,7 +317,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0;
   const int M = N + 1;
   std::vector<double> tab((size_t)M * DQ::NQ);
-  for (int p = 0; p < M; ++p) qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]);
+  for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
@@ -502,8 +521,10 @@ int idocp_ocp_set_contact_status_uniformly(idocp_ocp_t* h, const int* active, co
 int idocp_ocp_push_back_contact_status(idocp_ocp_t* h, const int* active, const double* contact_points, double switching_time) {
   if (!h || !active || !contact_points) return IDOCP_E_ARG;
   if (!h->contact_status_set) { set_last_error("Call setContactStatusUniformly() before calling push_back()!"); return IDOCP_E_ARG; }
-  if ((int)h->event_time.size() + 1 > h->E) {
-    set_last_error("Number of discrete events=" + std::to_string(h->event_time.size() + 1) + " exceeds predefined max_num_events=" + std::to_string(h->E) + "!");
+  // the sequence holds up to N events (ocp_solver.cpp:16: contact_sequence_(robot, N)); the event stages live in
+  // max_num_impulse impulse / aux / lift slots each (hybrid_container.hpp:39-96), checked below
+  if ((int)h->event_time.size() + 1 > h->N) {
+    set_last_error("Number of discrete events=" + std::to_string(h->event_time.size() + 1) + " exceeds predefined max_num_events=" + std::to_string(h->N) + "!");
     return IDOCP_E_ARG;
   }
   if (!h->event_time.empty() && switching_time <= h->event_time.back()) {
@@ -521,6 +542,14 @@ int idocp_ocp_push_back_contact_status(idocp_ocp_t* h, const int* active, const 
     else if (post.active[c]) { imp.active[c] = 1; exist_impulse = true; }
   }
   if (!exist_impulse && !exist_lift) { set_last_error("discrete_event.existDiscreteEvent() must be true!"); return IDOCP_E_ARG; }
+  {
+    int n_same = 0;
+    for (int e : h->is_impulse) n_same += ((e != 0) == exist_impulse) ? 1 : 0;
+    if (n_same + 1 > h->E) {
+      set_last_error(std::string("Number of ") + (exist_impulse ? "impulse" : "lift") + " events=" + std::to_string(n_same + 1) + " exceeds max_num_impulse=" + std::to_string(h->E) + "!");
+      return IDOCP_E_ARG;
+    }
+  }
   h->phases.push_back(post);
   h->event_time.push_back(switching_time);
   h->is_impulse.push_back(exist_impulse ? 1 : 0);

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   __syncthreads();
 
-  const double v_ref0 = P->v_ref[0];
+  const double vref_on = nd->vref_on;          // TimeVaryingConfigurationSpaceCost::v_ref(t): zero outside the window
+  const double v_ref0 = vref_on * P->v_ref[0];
   if (terminal) {
     // ---- TerminalOCP::linearizeOCP ----
     if (tid < NV) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       } else {
         lq = P->qf_weight[r] * (q[r + 1] - qref[r + 1]) - s[L::S_LMD + r];
       }
-      lv = P->vf_weight[r] * (s[L::S_V + r] - (r == 0 ? v_ref0 : P->v_ref[r])) - s[L::S_GMM + r];
+      lv = P->vf_weight[r] * (s[L::S_V + r] - (r == 0 ? v_ref0 : vref_on * P->v_ref[r])) - s[L::S_GMM + r];
       if (RESIDUAL) { sm[S::ERR + tid] = lq * lq + lv * lv; }
       else { kk[L::K_LX + r] = lq; kk[L::K_LX + NV + r] = lv; }
     } else if (RESIDUAL) {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       hq = dt * w_q[r];
       sm[S::FQ + r] = BWD ? (qpr - q[r + 1] + dtq * vr) : (q[r + 1] - sn[L::S_Q + r + 1] + dtq * vr);
     }
-    lv = dt * w_v[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r])) + (BWD ? dtq * lmd : dtq * lmdn) + gmmn - gmm;
+    lv = dt * w_v[r] * (vr - (r == 0 ? v_ref0 : vref_on * P->v_ref[r])) + (BWD ? dtq * lmd : dtq * lmdn) + gmmn - gmm;
     la = dt * w_a[r] * ar + dt * (BWD ? gmm : gmmn);
     hv = dt * w_v[r];
     ha = dt * w_a[r];
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         lq += P->qf_weight[r] * (q[r + 1] - qref[r + 1]);
         hq += P->qf_weight[r];
       }
-      lv += P->vf_weight[r] * (vr - (r == 0 ? v_ref0 : P->v_ref[r]));
+      lv += P->vf_weight[r] * (vr - (r == 0 ? v_ref0 : vref_on * P->v_ref[r]));
       hv += P->vf_weight[r];
     }
     // joint position / velocity limits act on the actuated joints (tail(dimu))

@@ -87,6 +87,7 @@ struct OcpNode {
   int dimf, active[IDOCP_MAX_CONTACTS], row_of[IDOCP_MAX_CONTACTS];   // contact (or impulse) status of this stage
   double dt;                // scaling of cost / constraint / dynamics multipliers: the time step, 1 on impulse stages
   double dtq;               // q+ = q (+) dtq v: the time step, 0 on impulse stages
+  double vref_on;           // 1, or 0 where a time-varying cost switches its velocity reference off (stage time outside its window)
   double contact_point[IDOCP_MAX_CONTACTS][3];
   int sw_dimi, sw_active[IDOCP_MAX_CONTACTS], sw_row[IDOCP_MAX_CONTACTS];     // switching constraint carried by this stage
   double sw_dt1, sw_dt2, sw_point[IDOCP_MAX_CONTACTS][3];

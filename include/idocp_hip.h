@@ -106,6 +106,13 @@ typedef struct idocp_cost {
   double dvi_weight[IDOCP_MAX_NV];
   double fi_weight[IDOCP_MAX_CONTACTS][3];
   double fi_ref[IDOCP_MAX_CONTACTS][3];
+  /* TimeVaryingConfigurationSpaceCost (include/idocp/cost/time_varying_configuration_space_cost.hpp:98-118,
+   * src/cost/time_varying_configuration_space_cost.cpp:58-85): when use_time_varying_ref != 0, q_ref holds q_begin,
+   * v_ref the constant reference velocity; the reference of stage time t is q_begin for t <= tv_t_begin,
+   * q_begin (+) (t - tv_t_begin) v_ref inside (tv_t_begin, tv_t_end) and q_begin (+) (tv_t_end - tv_t_begin) v_ref after;
+   * the velocity reference is v_ref inside the window and zero outside. */
+  int use_time_varying_ref;
+  double tv_t_begin, tv_t_end;
 } idocp_cost_t;
 
 /*

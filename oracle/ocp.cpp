@@ -90,7 +90,9 @@ void OCPSolver::setContactStatusUniformly(const std::vector<int>& active, const 
 
 // ContactSequence::push_back (contact_sequence.hxx:52-104) + DiscreteEvent::setDiscreteEvent (discrete_event.hxx:57-84)
 void OCPSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, double switching_time) {
-  if (seq.numEvents() + 1 > max_events_) throw std::runtime_error("Number of discrete events exceeds predefined max_num_events!");
+  // the sequence itself holds up to N events (ocp_solver.cpp:16: contact_sequence_(robot, N)); the event stages live in
+  // containers of max_num_impulse impulse / aux / lift entries each (hybrid_container.hpp:39-96), checked below
+  if (seq.numEvents() + 1 > N_ideal_) throw std::runtime_error("Number of discrete events exceeds predefined max_num_events!");
   if (seq.numEvents() > 0 && switching_time <= seq.event_time.back()) throw std::runtime_error("event_time must be larger than the last event time!");
   const ContactStatus& pre = seq.phases.back();
   ContactStatus post, imp;
@@ -104,6 +106,7 @@ void OCPSolver::pushBackContactStatus(const std::vector<int>& active, const doub
     else if (post.active[c]) { imp.active[c] = true; exist_impulse = true; }
   }
   if (!exist_impulse && !exist_lift) throw std::runtime_error("discrete_event.existDiscreteEvent() must be true!");
+  if ((exist_impulse ? seq.numImpulse() : seq.numLift()) + 1 > max_events_) throw std::runtime_error("more impulse / lift events than max_num_impulse!");
   seq.phases.push_back(post);
   seq.event_time.push_back(switching_time);
   seq.is_impulse.push_back(exist_impulse);
@@ -291,9 +294,24 @@ void OCPSolver::initConstraints(double t) {
 }
 
 // ------------------------------------------------------------------ cost ----
+// TimeVaryingConfigurationSpaceCost::v_ref(t) (include/idocp/cost/time_varying_configuration_space_cost.hpp:111-118)
+static double vRefScale(const idocp_cost_t& cost, double t) {
+  if (!cost.use_time_varying_ref) return 1.0;
+  return (t > cost.tv_t_begin && t < cost.tv_t_end) ? 1.0 : 0.0;
+}
+
 void OCPSolver::qRef(double t, Mat& q_ref) const {
   q_ref = Mat(robot.dimq());
   for (int i = 0; i < robot.dimq(); ++i) q_ref[i] = cost.q_ref[i];
+  if (cost.use_time_varying_ref) {      // set_q_ref (time_varying_configuration_space_cost.hpp:98-109)
+    const double tau = t <= cost.tv_t_begin ? 0.0 : ((t < cost.tv_t_end ? t : cost.tv_t_end) - cost.tv_t_begin);
+    if (tau > 0.0) {
+      Mat qb = q_ref, v(robot.dimv());
+      for (int i = 0; i < robot.dimv(); ++i) v[i] = cost.v_ref[i];
+      robot.integrateConfiguration(qb, v, tau, q_ref);
+    }
+    return;
+  }
   if (!cost.use_trotting_ref || !(t > cost.t_start)) return;
   const double tau = t - cost.t_start;
   const int steps = (int)std::floor(tau / cost.t_period);
@@ -350,8 +368,9 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = wq[r] * qdiff[r];
   R.lq += dt * (Jq.t() * Wq);
   const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const double vs = vRefScale(cost, t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) {
-    R.lv[r] += dt * wv[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+    R.lv[r] += dt * wv[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
     R.la[r] += dt * wa[r] * si.a[r];
   }
   if (!impulse) for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
@@ -587,7 +606,8 @@ void OCPSolver::linearizeTerminal(int p, const Mat& q_prev, bool residual_only) 
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.qf_weight[r] * qdiff[r];
   R.lq += Jq.t() * Wq;
   const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
-  for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (sN.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+  const double vs = vRefScale(cost, nd.t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
+  for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (sN.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   // linearizeForwardEulerTerminal (state_equation.hxx:66-83)
   Mat Fqq_prev; robot.dSubtractdConfigurationMinus(q_prev, sN.q, Fqq_prev);
   M.Fqq_prev6 = Fqq_prev.block(0, 0, 6, 6);
@@ -1090,8 +1110,9 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.q_weight[r] * qdiff[r];
   R.lq += dt * (Jq.t() * Wq);
   const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const double vs = vRefScale(cost, t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) {
-    R.lv[r] += dt * cost.v_weight[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+    R.lv[r] += dt * cost.v_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
     R.la[r] += dt * cost.a_weight[r] * si.a[r];
   }
   for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
@@ -1105,7 +1126,7 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   if (terminal) {
     Mat Wf(nv); for (int r = 0; r < nv; ++r) Wf[r] = cost.qf_weight[r] * qdiff[r];
     R.lq += Jq.t() * Wf;
-    for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (si.v[r] - (r == 0 ? v_ref0 : cost.v_ref[r]));
+    for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   }
   // ---- constraints
   double Jc[5][3]; frictionJac(cons.mu, Jc);

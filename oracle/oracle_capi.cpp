@@ -372,6 +372,13 @@ int oracle_ocp_compute_kkt_residual(void* h, double t, const double* q, const do
   return 0;
 }
 double oracle_ocp_kkt_error(void* h) { return static_cast<OCPSolver*>(h)->KKTError(); }
+// reference configuration of the configuration-space cost at time t (q_ref[nq])
+void oracle_ocp_q_ref(void* h, double t, double* q_ref) {
+  OCPSolver* o = static_cast<OCPSolver*>(h);
+  Mat q;
+  o->qRef(t, q);
+  for (int i = 0; i < o->robot.dimq(); ++i) q_ref[i] = q[i];
+}
 
 // field of every stage, padded to `stride` doubles per stage: out[(N+1)][stride].
 // solution names: q v a u f lmd gmm beta mu nu_passive ; direction names: dq dv da df du dlmd dgmm dbeta dmu dnu_passive

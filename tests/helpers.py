@@ -289,6 +289,90 @@ def trotting_sequence(solver, model, num_impulse_phases, t_start=0.5, t_period=0
             solver.push_back_contact_status([1, 0, 0, 1], pts, t_start + i * t_period)
 
 
+ANYMAL_Q_RUNNING_START = ANYMAL_Q_STANDING.copy()
+ANYMAL_Q_RUNNING_START[0] = -3.0
+
+
+def running_problem(model, steps=10):
+    """Cost / constraints of examples/anymal/anymal_running.cpp:34-128 (BASELINE.json configs[4]):
+    TimeVaryingConfigurationSpaceCost (reference moving with stride / t_period inside the running window) +
+    ContactForceCost(f_ref = (0, 0, 70)), six joint limits, linearized (impulse) friction cones with mu = 0.8."""
+    nv = model.nv
+    stride, t_start = 0.4, 1.0
+    t_period = 0.135 + 0.05 + 0.165
+    cost = capi.Cost()
+    cost.set("q_ref", ANYMAL_Q_RUNNING_START)
+    qw = np.concatenate([np.ones(3), np.full(15, 10.0)])
+    vw = np.concatenate([np.full(3, 0.01), np.full(15, 0.1)])
+    aw = np.full(nv, 0.01)
+    cost.set("q_weight", qw).set("qf_weight", qw).set("qi_weight", qw)
+    cost.set("v_weight", vw).set("vf_weight", vw).set("vi_weight", vw)
+    cost.set("a_weight", aw).set("dvi_weight", aw)
+    v_ref = np.zeros(nv)
+    v_ref[0] = stride / t_period
+    cost.set("v_ref", v_ref)
+    cost.use_time_varying_ref = 1
+    cost.tv_t_begin, cost.tv_t_end = t_start, t_start + (0.5 + steps) * t_period
+    for c in range(4):
+        for k, wk in enumerate((1e-1, 1e-1, 1e-7)):
+            cost.f_weight[c][k] = wk
+            cost.fi_weight[c][k] = wk
+            cost.f_ref[c][k] = 0.0
+            cost.fi_ref[c][k] = 0.0
+        cost.f_ref[c][2] = 70.0
+    cons = capi.Constraints()
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    cons.linearized_friction_cone = 1
+    cons.linearized_impulse_friction_cone = 1
+    cons.mu = 0.8
+    return cost, cons
+
+
+def running_sequence(solver, model, steps=10):
+    """Contact sequence of examples/anymal/anymal_running.cpp:137-215, transcribed as data: all feet -> hind feet {LH, RH}
+    -> flight -> front feet {LF, RF} -> hind feet -> ... -> all feet; 3 steps + 2 * (steps + 2) + ... = 6 + 3 steps + 4
+    discrete events.  Returns the number of events pushed."""
+    stride, hip, t_start = 0.4, 0.2, 1.0
+    t_fs, t_fhs, t_hs = 0.135, 0.05, 0.165
+    t_period = t_fs + t_fhs + t_hs
+    pts = anymal_contact_points(model, ANYMAL_Q_RUNNING_START).copy()
+    ALL, HIND, FRONT, NONE = [1, 1, 1, 1], [0, 1, 0, 1], [1, 0, 1, 0], [0, 0, 0, 0]
+    n = [0]
+
+    def push(status, t):
+        solver.push_back_contact_status(status, pts, t)
+        n[0] += 1
+    solver.set_contact_status(ALL, pts)
+    i_fs, i_fhs, i_hs = 0.125, 0.05, 0.125
+    t_initial = i_fs + i_fhs + i_hs
+    i_fs2, i_fhs2, i_hs2 = 0.135, 0.055, 0.15
+    t_initial2 = i_fs2 + i_fhs2 + i_hs2
+    push(HIND, t_start)
+    push(NONE, t_start + i_fs)
+    pts[[0, 2], 0] += 0.25 * stride
+    pts[[1, 3], 0] += 0.25 * stride + 0.5 * hip
+    push(FRONT, t_start + i_fs + i_fhs)
+    push(HIND, t_start + t_initial)
+    push(NONE, t_start + t_initial + i_fs2)
+    pts[[0, 2], 0] += 0.5 * stride
+    pts[[1, 3], 0] += 0.5 * stride + 0.5 * hip
+    push(FRONT, t_start + t_initial + i_fs2 + i_fhs2)
+    t_end_init = t_start + t_initial + t_initial2
+    for i in range(steps):
+        push(HIND, t_end_init + i * t_period)
+        push(NONE, t_end_init + i * t_period + t_fs)
+        pts[:, 0] += stride
+        push(FRONT, t_end_init + i * t_period + t_fs + t_fhs)
+    push(HIND, t_end_init + steps * t_period)
+    e_fs, e_fhs, e_hs = 0.15, 0.05, 0.15
+    push(NONE, t_end_init + steps * t_period + e_fs)
+    pts[[0, 2], 0] += 0.5 * stride
+    pts[[1, 3], 0] += 0.5 * stride - hip
+    push(FRONT, t_end_init + steps * t_period + e_fs + e_fhs)
+    push(ALL, t_end_init + steps * t_period + e_fs + e_fhs + e_hs)
+    return n[0]
+
+
 def _setup_oracle_ocp(lib):
     if getattr(lib, "_ocp_ready", False):
         return
@@ -305,6 +389,7 @@ def _setup_oracle_ocp(lib):
     lib.oracle_ocp_compute_kkt_residual.argtypes = [vp, cd, dp, dp]
     lib.oracle_ocp_kkt_error.argtypes = [vp]
     lib.oracle_ocp_kkt_error.restype = cd
+    lib.oracle_ocp_q_ref.argtypes = [vp, cd, dp]
     lib.oracle_ocp_get.argtypes = [vp, cs, ci, dp]
     lib.oracle_ocp_get_step_sizes.argtypes = [vp, dp, dp]
     lib.oracle_ocp_get_riccati.argtypes = [vp, dp, dp, dp, dp]
@@ -501,12 +586,12 @@ class OracleParNMPC:
         return a.value, b.value
 
 
-def anymal_contact_points(model):
+def anymal_contact_points(model, q_at=None):
     """World positions of the four feet at q_standing (robot.getContactPoints after
     updateFrameKinematics(q_standing), examples/anymal/anymal_trotting.cpp:141-143)."""
     lib = oracle()
     nv, nc = model.nv, model.ncontacts
-    q, z = arr(ANYMAL_Q_STANDING), np.zeros(nv)
+    q, z = arr(ANYMAL_Q_STANDING if q_at is None else q_at), np.zeros(nv)
     fp = np.zeros((nc, 3))
     tmp = [np.zeros(n) for n in (3 * nc, 3 * nc * nv, 3 * nc * nv, 3 * nc * nv)]
     fR, fv, fa = np.zeros((nc, 9)), np.zeros((nc, 6)), np.zeros((nc, 6))

@@ -102,6 +102,33 @@ def test_anymal_trotting_example_matches_oracle():
     assert its[-1] < 1e-8
 
 
+def test_anymal_running_example_matches_oracle():
+    """examples/anymal_running.cpp = the reference's examples/anymal/anymal_running.cpp driver (TimeVaryingConfigurationSpaceCost,
+    40 discrete events with flight phases, N = 240, T = 7) through the facade, 20 SQP iterations."""
+    from helpers import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "anymal_running"), ANYMAL_URDF, "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 20
+    model = anymal_model()
+    cost, cons = running_problem(model, 10)
+    o = OracleOCP(model, cost, cons, 7.0, 240, max_num_impulse=26)
+    assert running_sequence(o, model, 10) == 40
+    q, v = ANYMAL_Q_RUNNING_START.copy(), np.zeros(model.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    o.init_constraints(0.0)
+    ref_init = o.kkt_error(0.0, q, v)
+    assert abs(init - ref_init) <= 1e-5 * max(1.0, ref_init)          # printed with 6 significant digits
+    for k in range(20):
+        o.update(0.0, q, v)
+        ref = o.kkt_error(0.0, q, v)
+        assert abs(its[k] - ref) <= 5e-5 * max(1.0, ref), (k, its[k], ref)
+    assert its[-1] < 0.05 * init
+
+
 def test_anymal_parnmpc_benchmark_example_matches_oracle():
     from helpers import OracleParNMPC
     import ctypes as C

@@ -146,3 +146,37 @@ def test_flight_phase_sequence_parity():
         assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
     for f in ("q", "v", "a", "u", "f"):
         assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-6, f
+
+
+def test_running_example_parity():
+    """BASELINE.json configs[4]'s problem: examples/anymal/anymal_running.cpp (TimeVaryingConfigurationSpaceCost, 40 discrete
+    events -- 26 touch-downs, 14 lift-offs --, flight phases, N = 240, T = 7) on the GPU against the oracle: same chain, the
+    first Newton direction to 1e-10 (1e-9 where a stage of a few milliseconds sits in front of an impulse), the same KKT
+    error along the first iterations."""
+    from helpers import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
+    m = anymal_model()
+    steps = 10
+    cost, cons = running_problem(m, steps)
+    N, T, E = 240, 7.0, (steps + 3) * 2
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+    g = HipOCP(m, cost, cons, T, N, batch=2, max_num_impulse=E)
+    q, v = ANYMAL_Q_RUNNING_START.copy(), np.zeros(m.nv)
+    for s in (o, g):
+        assert running_sequence(s, m, steps) == 40
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    co, cg = o.chain(0.0), g.chain(0.0)
+    assert [(a["kind"], a["slot"], a["dimf"]) for a in co] == [(b["kind"], b["slot"], b["dimf"]) for b in cg]
+    assert max(abs(a["dt"] - b["dt"]) for a, b in zip(co, cg)) < 1e-15
+    M = len(co)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) <= 1e-9 * e_o and abs(e_g[1] - e_o) <= 1e-9 * e_o
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, f
+    for it in range(12):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) <= 1e-5 * e_o, (e_g, e_o)

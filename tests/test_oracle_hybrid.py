@@ -157,3 +157,51 @@ def test_hybrid_sqp_converges_on_the_trotting_example():
             # on the ground up to the O(dt^2) gap between exp(a) exp(b) and exp(a + b) on SE(3): the constraint is
             # imposed on the two-step prediction q (+) ((dt1+dt2) v + dt1 dt2 a), not on the impulse stage's own q
             assert abs(fp[cidx, 2] - pts[cidx, 2]) < 1e-3
+
+
+def make_running(N=240, T=7.0, steps=10):
+    from helpers import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
+    m = anymal_model()
+    cost, cons = running_problem(m, steps)
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=(steps + 3) * 2)
+    nev = running_sequence(o, m, steps)
+    q, v = ANYMAL_Q_RUNNING_START.copy(), np.zeros(m.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    o.init_constraints(0.0)
+    return m, o, q, v, nev
+
+
+def test_running_example_chain_and_time_varying_reference():
+    # examples/anymal/anymal_running.cpp:29-231: 40 discrete events (hind feet -> flight -> front feet per stride), the
+    # touch-downs are impulses, the lift-offs lifts; TimeVaryingConfigurationSpaceCost moves the reference inside its window
+    m, o, q, v, nev = make_running()
+    assert nev == 6 + 3 * 10 + 4
+    ch = o.chain(0.0)
+    n_imp = sum(1 for c in ch if c["kind"] == "impulse")
+    n_lift = sum(1 for c in ch if c["kind"] == "lift")
+    assert n_imp + n_lift == nev and n_imp == 26          # every stride: hind feet land, front feet land
+    assert abs(sum(c["dt"] for c in ch) - 7.0) < 1e-9
+    assert any(c["dimf"] == 0 and c["kind"] == "stage" for c in ch)          # flight phases
+    assert {c["dimf"] for c in ch if c["kind"] == "impulse"} == {6}          # two feet touch down at a time
+    assert ch[0]["dimf"] == 12 and ch[-2]["dimf"] == 12 and ch[-1]["kind"] == "terminal"
+    # the reference configuration: rests at x = -3 before the window, moves with stride / t_period inside, rests after
+    from helpers import ANYMAL_Q_RUNNING_START
+    lib = oracle()
+    qr = np.zeros(m.nq)
+    t_period, t_start = 0.35, 1.0
+    for t, x in ((0.5, -3.0), (1.0, -3.0), (1.0 + 0.7, -3.0 + 0.7 * 0.4 / t_period), (6.9, -3.0 + 10.5 * 0.4)):
+        lib.oracle_ocp_q_ref(o.h, C.c_double(t), P(qr))
+        assert abs(qr[0] - x) < 1e-12 and np.abs(qr[1:] - ANYMAL_Q_RUNNING_START[1:]).max() < 1e-14, (t, qr[0], x)
+
+
+def test_running_example_converges():
+    # ocpbenchmarker::Convergence(ocp_solver, t, q, v, 350, false) in the reference's driver; the decrease is linear once the
+    # gait is found (fixed barrier 1e-4, fraction-to-boundary 0.995), 60 iterations are enough to see it
+    m, o, q, v, _ = make_running()
+    e = [o.kkt_error(0.0, q, v)]
+    for it in range(60):
+        assert o.update(0.0, q, v) == 0
+        e.append(o.kkt_error(0.0, q, v))
+    assert np.isfinite(e).all() and e[30] < 1.0 and e[60] < 0.5 * e[45] < 0.25 * e[30], e[::15]
