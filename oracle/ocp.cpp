@@ -967,24 +967,39 @@ void OCPSolver::updateSolution(double t, const Mat& q, const Mat& v) {
 }
 
 // =============================================================================================== ParNMPC ====
-ParNMPCSolver::ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N)
+ParNMPCSolver::ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N,
+                             int max_num_impulse)
     : robot(model), cost(cost_), cons(constraints), next_s(robot), next_snew(robot), prev_s(robot), prev_snew(robot),
-      N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), T_(T), dt_(T / N) {
+      N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), max_events_(max_num_impulse), T_(T), dt_(T / N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
+  if (max_num_impulse < 0) throw std::out_of_range("invalid value: max_num_impulse must be non-negative!");
   if (!robot.hasFloatingBase()) throw std::logic_error("ParNMPCSolver oracle: floating-base robots only");
-  s.assign(N, SplitSolutionC(robot)); s_new = s;
-  d.assign(N, SplitDirectionC(robot));
-  kkt_matrix.assign(N, SplitKKTMatrixC(model.nv, model.nu));
-  kkt_residual.assign(N, SplitKKTResidualC(model.nv, model.nu));
-  cd.resize(N); ipm.resize(N);
+  const int ns = nslots();
+  s.assign(ns, SplitSolutionC(robot)); s_new = s;
+  d.assign(ns, SplitDirectionC(robot));
+  kkt_matrix.assign(ns, SplitKKTMatrixC(model.nv, model.nu));
+  kkt_residual.assign(ns, SplitKKTResidualC(model.nv, model.nu));
+  cd.resize(ns); ipm.resize(ns);
   const int nx = 2 * nv_;
-  KKT_mat_inv.assign(N, Mat(2 * nx + nu_, 2 * nx + nu_));
-  aux_mat.assign(N, Mat(nx, nx));
-  x_res.assign(N, Mat(nx));
+  KKT_mat_inv.assign(ns, Mat(2 * nx + nu_, 2 * nx + nu_));
+  aux_mat.assign(ns, Mat(nx, nx));
+  x_res.assign(ns, Mat(nx));
+  sw_Pq.resize(ns);
+  imp.resize(ns);
   contact_status.active.assign(nc_, false);
   contact_status.points.assign(nc_, Mat(3));
+  seq.phases.assign(1, contact_status);
   next_aux = Mat(nx, nx);
+}
+
+int ParNMPCSolver::slotOf(int kind, int index) const {
+  switch (kind) {
+    case NodeC::Impulse: return N_ideal_ + index;
+    case NodeC::Aux: return N_ideal_ + max_events_ + index;
+    case NodeC::Lift: return N_ideal_ + 2 * max_events_ + index;
+    default: return index;
+  }
 }
 
 int ParNMPCSolver::haloSize(int kind) const {
@@ -1021,8 +1036,36 @@ void ParNMPCSolver::setContactStatusUniformly(const std::vector<int>& active, co
     contact_status.active[c] = active[c] != 0;
     for (int k2 = 0; k2 < 3; ++k2) contact_status.points[c][k2] = pts[3 * c + k2];
   }
+  seq.phases.assign(1, contact_status);
+  seq.event_time.clear(); seq.is_impulse.clear(); seq.impulse_status.clear();
+  discretized_ = false;
 }
 
+// ContactSequence::push_back (contact_sequence.hxx:63-117); capacities as in OCPSolver (see OCPSolver::pushBackContactStatus)
+void ParNMPCSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, double switching_time) {
+  if (seq.numEvents() + 1 > N_ideal_) throw std::runtime_error("Number of discrete events exceeds predefined max_num_events!");
+  if (seq.numEvents() > 0 && switching_time <= seq.event_time.back()) throw std::runtime_error("event_time must be larger than the last event time!");
+  const ContactStatus& pre = seq.phases.back();
+  ContactStatus post, im;
+  post.active.assign(nc_, false); post.points.assign(nc_, Mat(3));
+  im.active.assign(nc_, false); im.points.assign(nc_, Mat(3));
+  bool exist_impulse = false, exist_lift = false;
+  for (int c = 0; c < nc_; ++c) {
+    post.active[c] = active[c] != 0;
+    for (int k2 = 0; k2 < 3; ++k2) { post.points[c][k2] = pts[3 * c + k2]; im.points[c][k2] = pts[3 * c + k2]; }
+    if (pre.active[c]) { if (!post.active[c]) exist_lift = true; }
+    else if (post.active[c]) { im.active[c] = true; exist_impulse = true; }
+  }
+  if (!exist_impulse && !exist_lift) throw std::runtime_error("discrete_event.existDiscreteEvent() must be true!");
+  if ((exist_impulse ? seq.numImpulse() : seq.numLift()) + 1 > max_events_) throw std::runtime_error("more impulse / lift events than max_num_impulse!");
+  seq.phases.push_back(post);
+  seq.event_time.push_back(switching_time);
+  seq.is_impulse.push_back(exist_impulse);
+  seq.impulse_status.push_back(im);
+  discretized_ = false;
+}
+
+// parnmpc_solver.cpp:106-160: every stage, including the event stages ("a" sets dv on impulse stages)
 void ParNMPCSolver::setSolution(const std::string& name, const Mat& value) {
   for (auto& e : s) {
     if (name == "q") e.q = value;
@@ -1034,9 +1077,91 @@ void ParNMPCSolver::setSolution(const std::string& name, const Mat& value) {
   }
 }
 
-bool ParNMPCSolver::componentValid(int c, int level) const {     // constraints_data.hpp:18-42
-  if (c < 2) return cons.joint_position_limits != 0 && level >= 2;
-  if (c < 4) return cons.joint_velocity_limits != 0 && level >= 1;
+// ParNMPCDiscretizer::discretizeOCP (parnmpc_discretizer.hxx:65-72): countDiscreteEvents (:246-262), countTimeSteps
+// (:265-324), countTimeStages (:327-361), countContactPhase (:364-373)
+void ParNMPCSolver::discretize(double t) {
+  if (discretized_ && disc_t_ == t) return;
+  chain.clear();
+  const int Ne = seq.numEvents();
+  if (Ne == 0) {
+    N_ = N_ideal_;
+    for (int i = 0; i < N_; ++i) {
+      PNode nd;
+      nd.kind = (has_terminal && i == N_ - 1) ? NodeC::Terminal : NodeC::Stage;
+      nd.slot = i; nd.index = i; nd.t = t + (stage_offset + i + 1) * dt_; nd.dt = dt_; nd.phase = 0; nd.level = stage_offset + i + 1;
+      chain.push_back(nd);
+    }
+    discretized_ = true; disc_t_ = t;
+    return;
+  }
+  if (stage_offset != 0 || !has_terminal || has_prev) throw std::logic_error("ParNMPC oracle: horizon sharding only without discrete events");
+  const int Nid = N_ideal_, Ni = seq.numImpulse(), Nl = seq.numLift();
+  const double dt_ideal = dt_, min_dt = std::sqrt(std::numeric_limits<double>::epsilon()), max_dt = dt_ideal - min_dt;
+  std::vector<int> tsai(Ni + 1, -1), tsal(Nl + 1, -1);      // time stage AFTER the impulse / lift
+  std::vector<double> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
+  for (int k = 0; k < Ni; ++k) { t_imp[k] = seq.event_time[seq.eventOfImpulse(k)]; tsai[k] = (int)std::floor((t_imp[k] - t) / dt_ideal); }
+  for (int k = 0; k < Nl; ++k) { t_lift[k] = seq.event_time[seq.eventOfLift(k)]; tsal[k] = (int)std::floor((t_lift[k] - t) / dt_ideal); }
+  std::vector<double> dts(Nid + 1, dt_ideal), ts(Nid + 1, 0.0);
+  int ii = 0, li = 0, on_grid = 0;
+  for (int i = 0; i < Nid; ++i) {
+    const int stage = i - on_grid;
+    if (ii < Ni && i == tsai[ii]) {
+      dts[stage] = (i + 1) * dt_ideal + t - t_imp[ii];
+      if (dts[stage] <= min_dt) { tsai[ii] = i + 1; ts[stage] = t + (i + 1) * dt_ideal; }
+      else if (dts[stage] >= max_dt) { tsai[ii] = stage - 1; dt_aux[ii] = dt_ideal; ts[stage] = t + i * dt_ideal; ++on_grid; ++ii; }
+      else { tsai[ii] = stage; dt_aux[ii] = dt_ideal - dts[stage]; ts[stage] = t + (i + 1) * dt_ideal; ++ii; }
+    } else if (li < Nl && i == tsal[li]) {
+      dts[stage] = (i + 1) * dt_ideal + t - t_lift[li];
+      if (dts[stage] <= min_dt) { tsal[li] = i + 1; ts[stage] = t + (i + 1) * dt_ideal; }
+      else if (dts[stage] >= max_dt) { tsal[li] = stage - 1; dt_lift[li] = dt_ideal; ts[stage] = t + i * dt_ideal; ++on_grid; ++li; }
+      else { tsal[li] = stage; dt_lift[li] = dt_ideal - dts[stage]; ts[stage] = t + (i + 1) * dt_ideal; ++li; }
+    } else {
+      dts[stage] = dt_ideal; ts[stage] = t + (i + 1) * dt_ideal;
+    }
+  }
+  N_ = Nid - on_grid;
+  ts[N_ - 1] = t + T_;
+  std::vector<int> imp_before(N_, -1), lift_before(N_, -1), phase(N_, 0);
+  ii = 0; li = 0;
+  int num_events = 0;
+  for (int i = 0; i < N_; ++i) {
+    if (ii < Ni && i == tsai[ii]) imp_before[i] = ii++;
+    if (li < Nl && i == tsal[li]) lift_before[i] = li++;
+    if (imp_before[i] >= 0 && lift_before[i] >= 0) throw std::runtime_error("ParNMPCDiscretizer: an impulse and a lift fall into the same time stage");
+    if (imp_before[i] >= 0 || lift_before[i] >= 0) ++num_events;
+    phase[i] = num_events;
+  }
+  if (ii != Ni || li != Nl) throw std::runtime_error("ParNMPCDiscretizer: a discrete event lies outside the horizon");
+  for (int i = 0; i + 1 < N_; ++i) if (imp_before[i] >= 0 && imp_before[i + 1] >= 0) throw std::runtime_error("ParNMPCDiscretizer: impulses in consecutive time stages");
+  if (imp_before[0] >= 0 || lift_before[0] >= 0) throw std::logic_error("ParNMPC oracle: a discrete event in front of the first time stage is not carried");
+  for (int i = 0; i < N_; ++i) {
+    const int phase_before = i > 0 ? phase[i - 1] : 0;
+    if (imp_before[i] >= 0) {
+      const int k = imp_before[i];
+      PNode a; a.kind = NodeC::Aux; a.index = k; a.slot = slotOf(NodeC::Aux, k); a.t = t_imp[k]; a.dt = dt_aux[k]; a.phase = phase_before; a.level = 0;
+      a.event = seq.eventOfImpulse(k);
+      chain.push_back(a);
+      PNode m; m.kind = NodeC::Impulse; m.index = k; m.slot = slotOf(NodeC::Impulse, k); m.t = t_imp[k]; m.dt = 0.0; m.phase = phase_before; m.level = -1;
+      m.event = seq.eventOfImpulse(k);
+      chain.push_back(m);
+    } else if (lift_before[i] >= 0) {
+      const int k = lift_before[i];
+      PNode l; l.kind = NodeC::Lift; l.index = k; l.slot = slotOf(NodeC::Lift, k); l.t = t_lift[k]; l.dt = dt_lift[k]; l.phase = phase_before; l.level = 0;
+      chain.push_back(l);
+    }
+    PNode nd;
+    nd.kind = (i == N_ - 1) ? NodeC::Terminal : NodeC::Stage;
+    nd.slot = i; nd.index = i; nd.t = ts[i]; nd.dt = dts[i]; nd.phase = phase[i];
+    nd.level = (i == N_ - 1) ? N_ideal_ : i + 1;        // parnmpc_linearizer.cpp:43-58: terminal.initConstraints(robot, N_ideal, ...)
+    chain.push_back(nd);
+  }
+  discretized_ = true; disc_t_ = t;
+}
+
+bool ParNMPCSolver::componentValid(int c, const PNode& nd) const {     // constraints_data.hpp:18-42
+  if (nd.kind == NodeC::Impulse) return c == 6 && cons.linearized_impulse_friction_cone != 0;
+  if (c < 2) return cons.joint_position_limits != 0 && nd.level >= 2;
+  if (c < 4) return cons.joint_velocity_limits != 0 && nd.level >= 1;
   if (c < 6) return cons.joint_torque_limits != 0;
   return cons.linearized_friction_cone != 0;
 }
@@ -1046,11 +1171,17 @@ void ParNMPCSolver::qRef(double t, Mat& q_ref) const {
   tmp_unused_guard.qRef(t, q_ref);
 }
 
+const SplitSolutionC* ParNMPCSolver::nextSolution(int p) const {
+  if (p + 1 < (int)chain.size()) return &s[chain[p + 1].slot];
+  return has_terminal ? nullptr : &next_s;
+}
+
 // BackwardCorrectionSolver::initAuxMat (backward_correction_solver.cpp:54-92): every aux_mat = terminal cost Hessian at s[N-1]
 void ParNMPCSolver::initBackwardCorrection(double t) {
+  discretize(t);
   const int nv = nv_;
   Mat q_ref, Jq;
-  qRef(t + (stage_offset + N_) * dt_, q_ref);
+  qRef(seq.numEvents() == 0 ? t + (stage_offset + N_) * dt_ : chain.back().t, q_ref);
   robot.dSubtractdConfigurationPlus(s[N_ - 1].q, q_ref, Jq);
   Mat Qxx(2 * nv, 2 * nv);
   Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.qf_weight[r];
@@ -1059,49 +1190,70 @@ void ParNMPCSolver::initBackwardCorrection(double t) {
   for (auto& a : aux_mat) a = Qxx;
 }
 
-// ParNMPCLinearizer::initConstraints (parnmpc_linearizer.cpp:43-75): stage i with time step i + 1
-void ParNMPCSolver::initConstraints(double /*t*/) {
-  for (int i = 0; i < N_; ++i) {
-    ipm[i].clear();
-    for (int c = 0; c < 7; ++c) {
-      IpmData data(componentDim(c));
-      if (componentValid(c, stage_offset + i + 1)) {
-        if (c < 6) {
-          const double sgn = (c & 1) ? 1.0 : -1.0;
-          for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
-        } else {
-          for (int cc = 0; cc < nc_; ++cc) {
-            double res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
-            for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
-          }
-        }
-        for (int r = 0; r < data.slack.size(); ++r) {
-          while (data.slack[r] < cons.barrier) data.slack[r] += cons.barrier;
-          data.dual[r] = cons.barrier / data.slack[r];
+// SplitParNMPC::initConstraints / ImpulseSplitParNMPC::initConstraints: slack = -g(s) pushed above the barrier, dual = barrier / slack
+void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
+  const int i = nd.slot;
+  const ContactStatus& cs = nodeContacts(nd);
+  ipm[i].clear();
+  for (int c = 0; c < 7; ++c) {
+    IpmData data(componentDim(c));
+    if (componentValid(c, nd)) {
+      if (c < 6) {
+        const double sgn = (c & 1) ? 1.0 : -1.0;
+        for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
+      } else {
+        for (int cc = 0; cc < nc_; ++cc) {
+          if (seq.numEvents() > 0 && !cs.active[cc]) { for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = cons.barrier; continue; }
+          double res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
+          for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
         }
       }
-      ipm[i].push_back(data);
+      for (int r = 0; r < data.slack.size(); ++r) {
+        while (data.slack[r] < cons.barrier) data.slack[r] += cons.barrier;
+        data.dual[r] = cons.barrier / data.slack[r];
+      }
     }
+    ipm[i].push_back(data);
   }
 }
 
-// SplitParNMPC::linearizeOCP (split_parnmpc.hxx:50-84) / TerminalParNMPC::linearizeOCP (terminal_parnmpc.hxx:50-82)
-// and the computeKKTResidual twins.
-void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
-  const bool terminal = has_terminal && (i == N_ - 1);
+// ParNMPCLinearizer::initConstraints (parnmpc_linearizer.cpp:43-75): stage i with time step i + 1, aux / lift with 0
+void ParNMPCSolver::initConstraints(double t) {
+  discretize(t);
+  if (seq.numEvents() == 0) {
+    for (const PNode& nd : chain) initNodeConstraints(nd);
+    return;
+  }
+  // every grid slot (the reference initialises all N_ideal stages), then the event stages in use
+  for (int i = 0; i < N_ideal_; ++i) {
+    PNode nd; nd.kind = i < N_ideal_ - 1 ? NodeC::Stage : NodeC::Terminal; nd.slot = i; nd.index = i; nd.level = i + 1; nd.phase = 0;
+    for (const PNode& c : chain) if ((c.kind == NodeC::Stage || c.kind == NodeC::Terminal) && c.slot == i) nd.phase = c.phase;
+    initNodeConstraints(nd);
+  }
+  for (const PNode& nd : chain) if (nd.kind == NodeC::Impulse || nd.kind == NodeC::Aux || nd.kind == NodeC::Lift) initNodeConstraints(nd);
+}
+
+// SplitParNMPC::linearizeOCP (split_parnmpc.hxx:50-84; with the switching constraint of an aux stage :86-124) /
+// TerminalParNMPC::linearizeOCP (terminal_parnmpc.hxx:50-82) and the computeKKTResidual twins.
+void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  const PNode& nd = chain[p];
+  if (nd.kind == NodeC::Impulse) { linearizeImpulse(p, q_prev, v_prev, residual_only); return; }
+  const int i = nd.slot;
+  const bool terminal = nd.kind == NodeC::Terminal;
   const SplitSolutionC& si = s[i];
   SplitKKTMatrixC& M = kkt_matrix[i];
   SplitKKTResidualC& R = kkt_residual[i];
   ContactDynamicsDataC& D = cd[i];
-  const ContactStatus& cs = contact_status;
-  const int nv = nv_, nu = nu_, dimf = cs.dimf(), level = stage_offset + i + 1;
-  const double dt = dt_;
+  const ContactStatus& cs = nodeContacts(nd);
+  const int nv = nv_, nu = nu_, dimf = cs.dimf();
+  const double dt = nd.dt, t = nd.t;
   robot.updateKinematics(si.q, si.v, si.a);
   if (!residual_only) {
     M.Qxx.setZero(); M.Qxu_full.setZero(); M.Quu_full.setZero(); M.Qaa_diag.setZero(); M.Qff = Mat(dimf, dimf);
     M.Fvq.setZero(); M.Fvv.setZero(); M.Fvu.setZero();
   }
   R.Fq.setZero(); R.Fv.setZero(); R.lq.setZero(); R.lv.setZero(); R.la.setZero(); R.lf = Mat(dimf); R.lu.setZero(); R.lu_passive.setZero();
+  R.P = Mat(0);
   // ---- cost (stage + terminal on the last stage)
   Mat q_ref, qdiff, Jq;
   qRef(t, q_ref);
@@ -1131,7 +1283,7 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   // ---- constraints
   double Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int c = 0; c < 7; ++c) {
-    if (!componentValid(c, level)) continue;
+    if (!componentValid(c, nd)) continue;
     IpmData& data = ipm[i][c];
     if (c < 6) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
@@ -1168,7 +1320,7 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   {
     Mat t1 = M.Fqq6.t() * si.lmd.segment(0, 6);
     if (!terminal) {
-      const SplitSolutionC& sn = (i == N_ - 1) ? next_s : s[i + 1];
+      const SplitSolutionC& sn = *nextSolution(p);
       Mat Fqq_next; robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq_next);
       M.Fqq_prev6 = Fqq_next.block(0, 0, 6, 6);
       t1 += M.Fqq_prev6.t() * sn.lmd.segment(0, 6);
@@ -1215,6 +1367,15 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
     R.lv += dt * (dCdv.t() * mu_stack);
     R.la += dt * (D.dCda.t() * mu_stack);
   }
+  // ---- switchingconstraint::linearizeSwitchingConstraint (switching_constraint.hxx:8-21) on the aux stage: the feet that
+  //      touch down at the impulse are already on their contact points
+  if (nd.kind == NodeC::Aux) {
+    const ContactStatus& is = seq.impulse_status[nd.event];
+    const int dimi = is.dimf();
+    robot.computeContactResidual(is.active, is.points, R.P);
+    robot.computeContactDerivative(is.active, sw_Pq[i]);
+    R.lq += sw_Pq[i].t() * si.xi.segment(0, dimi);
+  }
   if (residual_only) return;
   // ---- cost Hessian
   {
@@ -1232,7 +1393,7 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   }
   // ---- Constraints::condenseSlackAndDual
   for (int c = 0; c < 7; ++c) {
-    if (!componentValid(c, level)) continue;
+    if (!componentValid(c, nd)) continue;
     IpmData& data = ipm[i][c];
     if (c < 6) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
@@ -1301,60 +1462,250 @@ void ParNMPCSolver::linearizeStage(int i, double t, const Mat& q_prev, const Mat
   for (int r = 0; r < nv; ++r) R.Fv[r] -= dt * D.MJtJinv_IDC[r];
 }
 
+// ImpulseSplitParNMPC::linearizeOCP / computeKKTResidual (impulse_split_parnmpc.hxx:33-60, 96-113):
+// impulse cost + impulse friction cone, linearizeImpulseBackwardEuler / condenseImpulseBackwardEuler
+// (impulse_state_equation.hxx:59-111), ImpulseDynamicsBackwardEuler::linearizeImpulseDynamics / condenseImpulseDynamics
+// (impulse_dynamics_backward_euler.hxx:20-97).  Stored in the regular containers: a = dv, R.la = ldv, R.P = V,
+// M.Qff, M.Qxx; the impulse-only blocks in imp[slot].
+void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  const PNode& nd = chain[p];
+  const int i = nd.slot;
+  const SplitSolutionC& si = s[i];
+  SplitKKTMatrixC& M = kkt_matrix[i];
+  SplitKKTResidualC& R = kkt_residual[i];
+  ImpulseDataC& I = imp[i];
+  const ContactStatus& is = seq.impulse_status[nd.event];
+  const int nv = nv_, dimf = is.dimf();
+  robot.updateKinematics(si.q, si.v, Mat(nv));
+  R.Fq.setZero(); R.Fv.setZero(); R.lq.setZero(); R.lv.setZero(); R.la.setZero(); R.lf = Mat(dimf); R.lu.setZero(); R.lu_passive.setZero();
+  if (!residual_only) { M.Qxx.setZero(); M.Qff = Mat(dimf, dimf); I.Qdvdv = Mat(nv); I.Qqf = Mat(nv, dimf); }
+  // ---- impulse cost (computeImpulseCostDerivatives of the cost components: no dt)
+  Mat q_ref, qdiff, Jq;
+  qRef(nd.t, q_ref);
+  robot.subtractConfiguration(si.q, q_ref, qdiff);
+  robot.dSubtractdConfigurationPlus(si.q, q_ref, Jq);
+  Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.qi_weight[r] * qdiff[r];
+  R.lq += Jq.t() * Wq;
+  const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const double vs = vRefScale(cost, nd.t);
+  for (int r = 0; r < nv; ++r) {
+    R.lv[r] += cost.vi_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
+    R.la[r] += cost.dvi_weight[r] * si.a[r];
+  }
+  {
+    int st = 0;
+    for (int c = 0; c < nc_; ++c) if (is.active[c]) {
+      for (int r = 0; r < 3; ++r) R.lf[st + r] += cost.fi_weight[c][r] * (si.f[c][r] - cost.fi_ref[c][r]);
+      st += 3;
+    }
+  }
+  // ---- impulse friction cone: augmentDualResidual
+  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  const bool cone = componentValid(6, nd);
+  if (cone) {
+    IpmData& data = ipm[i][6];
+    if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
+    int st = 0;
+    for (int cc = 0; cc < nc_; ++cc) if (is.active[cc]) {
+      if (residual_only) {
+        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        for (int r = 0; r < 5; ++r) {
+          data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
+          data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
+        }
+      }
+      for (int x = 0; x < 3; ++x) for (int r = 0; r < 5; ++r) R.lf[st + x] += Jc[r][x] * data.dual[5 * cc + r];
+      st += 3;
+    }
+  }
+  // ---- linearizeImpulseBackwardEuler (impulse_state_equation.hxx:59-85)
+  const SplitSolutionC& sn = *nextSolution(p);
+  Mat diff; robot.subtractConfiguration(q_prev, si.q, diff);
+  for (int r = 0; r < nv; ++r) { R.Fq[r] = diff[r]; R.Fv[r] = v_prev[r] - si.v[r] + si.a[r]; }
+  Mat Fqq; robot.dSubtractdConfigurationMinus(q_prev, si.q, Fqq);
+  M.Fqq6 = Fqq.block(0, 0, 6, 6);
+  {
+    Mat Fqq_next; robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq_next);
+    M.Fqq_prev6 = Fqq_next.block(0, 0, 6, 6);
+    Mat t1 = M.Fqq_prev6.t() * sn.lmd.segment(0, 6);
+    t1 += M.Fqq6.t() * si.lmd.segment(0, 6);
+    for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
+    for (int r = 6; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
+    for (int r = 0; r < nv; ++r) { R.lv[r] += -si.gmm[r] + sn.gmm[r]; R.la[r] += si.gmm[r]; }
+  }
+  if (!residual_only) {
+    // condenseImpulseBackwardEuler (:86-111)
+    Mat Fp; robot.dSubtractdConfigurationPlus(q_prev, si.q, Fp);
+    Robot::dSubtractdConfigurationInverse(Fp.block(0, 0, 6, 6), M.Fqq_inv);
+    M.Fqq_prev6 = M.Fqq6;
+    R.Fq_prev = R.Fq.segment(0, 6);
+    M.Fqq6 = M.Fqq_inv * M.Fqq_prev6;
+    R.Fq.setSegment(0, M.Fqq_inv * R.Fq_prev);
+  }
+  // ---- ImpulseDynamicsBackwardEuler::linearizeImpulseDynamics (:20-58)
+  robot.setContactForces(is.active, si.f);
+  {
+    const Mat zero(nv);
+    Mat dIDdv_unused;
+    robot.RNEA(si.q, zero, si.a, I.ImD, false);                               // RNEAImpulse (robot.hxx:505-517)
+    robot.RNEADerivatives(si.q, zero, si.a, I.dImDdq, dIDdv_unused, I.dImDddv, false);
+  }
+  robot.computeImpulseVelocityResidual(is.active, R.P);
+  robot.computeImpulseVelocityDerivatives(is.active, I.Vq, I.Vv);
+  const Mat mu_stack = si.mu_stack(is);
+  R.lq += I.dImDdq.t() * si.beta;
+  R.la += I.dImDddv.t() * si.beta;
+  if (dimf > 0) {
+    R.lf -= I.Vv * si.beta;
+    R.lq += I.Vq.t() * mu_stack;
+    R.lv += I.Vv.t() * mu_stack;
+  }
+  if (residual_only) return;
+  // ---- impulse cost Hessian
+  {
+    Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.qi_weight[r];
+    M.Qxx.addBlock(0, 0, Jq.t() * WJ);
+    for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += cost.vi_weight[r]; I.Qdvdv[r] += cost.dvi_weight[r]; }
+    int st = 0;
+    for (int c = 0; c < nc_; ++c) if (is.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += cost.fi_weight[c][r]; st += 3; }
+  }
+  // ---- condenseSlackAndDual of the impulse friction cone
+  if (cone) {
+    IpmData& data = ipm[i][6];
+    data.residual.setZero(); data.duality.setZero();
+    int st = 0;
+    for (int cc = 0; cc < nc_; ++cc) if (is.active[cc]) {
+      double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+      double rr[5], dd[5];
+      for (int r = 0; r < 5; ++r) {
+        const int idx = 5 * cc + r;
+        data.residual[idx] = res[r] + data.slack[idx];
+        data.duality[idx] = data.slack[idx] * data.dual[idx] - cons.barrier;
+        rr[r] = (data.dual[idx] * data.residual[idx] - data.duality[idx]) / data.slack[idx];
+        dd[r] = data.dual[idx] / data.slack[idx];
+      }
+      for (int x = 0; x < 3; ++x) {
+        for (int r = 0; r < 5; ++r) R.lf[st + x] += Jc[r][x] * rr[r];
+        for (int y = 0; y < 3; ++y) { double acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += acc; }
+      }
+      st += 3;
+    }
+  }
+  // ---- condenseImpulseDynamics (:59-97)
+  {
+    LLT lltM;
+    if (!lltM.compute(I.dImDddv)) throw std::runtime_error("ParNMPC: mass matrix not positive definite on an impulse stage");
+    I.Minv = lltM.solve(Mat::Identity(nv));                                   // Robot::computeMinv
+  }
+  I.Fvq = -1.0 * (I.Minv * I.dImDdq);
+  I.Fvf = I.Minv * I.Vv.t();
+  I.Minv_ImD = I.Minv * I.ImD;
+  I.Qdvq = I.Fvq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) I.Qdvq(r, c) *= I.Qdvdv[r];
+  I.Qdvf = I.Fvf; for (int c = 0; c < dimf; ++c) for (int r = 0; r < nv; ++r) I.Qdvf(r, c) *= I.Qdvdv[r];
+  I.ldv = R.la;
+  for (int r = 0; r < nv; ++r) I.ldv[r] -= I.Qdvdv[r] * I.Minv_ImD[r];
+  M.Qxx.addBlock(0, 0, I.Fvq.t() * I.Qdvq);
+  I.Qqf += I.Fvq.t() * I.Qdvf;
+  M.Qff += I.Fvf.t() * I.Qdvf;
+  R.lq += I.Fvq.t() * I.ldv;
+  R.lf += I.Fvf.t() * I.ldv;
+  for (int r = 0; r < nv; ++r) R.Fv[r] -= I.Minv_ImD[r];
+}
+
 // BackwardCorrectionSolver::coarseUpdate (backward_correction_solver.cpp:95-250) -> SplitBackwardCorrection::coarseUpdate
-// (split_backward_correction.hxx:30-72) -> SplitKKTMatrixInverter::invert (split_kkt_matrix_inverter.hxx:44-80)
+// (split_backward_correction.hxx:30-72) / ImpulseSplitBackwardCorrection::coarseUpdate (impulse_split_backward_correction.hxx:30-56)
+// -> SplitKKTMatrixInverter::invert (split_kkt_matrix_inverter.hxx:44-80; with Pq :110-166) /
+// ImpulseSplitKKTMatrixInverter::invert (impulse_split_kkt_matrix_inverter.hxx:34-80).  One code path: the stage's KKT matrix is
+//   [ 0  J ; J^T  Q ]  with  J = [F ; C] (C = Pq rows of an aux stage / V rows of an impulse stage) and Q over (w, q, v),
+// w = u (regular, aux, lift, terminal) or f (impulse).
 void ParNMPCSolver::coarseUpdate(double t, const Mat& q, const Mat& v) {
-  const int nv = nv_, nu = nu_, nx = 2 * nv, nQ = nu + nx, nK = nx + nQ;
-  for (int i = 0; i < N_; ++i) {
-    const Mat& q_prev = i == 0 ? q : s[i - 1].q;
-    const Mat& v_prev = i == 0 ? v : s[i - 1].v;
-    linearizeStage(i, t + (stage_offset + i + 1) * dt_, q_prev, v_prev, false);
+  discretize(t);
+  const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
+  for (int p = 0; p < Mc; ++p) {
+    const PNode& nd = chain[p];
+    const int i = nd.slot;
+    const Mat& q_prev = p == 0 ? q : s[chain[p - 1].slot].q;
+    const Mat& v_prev = p == 0 ? v : s[chain[p - 1].slot].v;
+    linearizeNode(p, q_prev, v_prev, false);
     SplitKKTMatrixC& M = kkt_matrix[i];
     const SplitKKTResidualC& R = kkt_residual[i];
-    if (i < N_ - 1) M.Qxx += aux_mat[i + 1];
+    if (p + 1 < Mc) M.Qxx += aux_mat[chain[p + 1].slot];
     else if (!has_terminal) M.Qxx += next_aux;
-    M.Qxx.setBlock(nv, 0, M.Qxx.block(0, nv, nv, nv).t());            // Qvq = Qqv^T
-    // Qss = [Quu Qux; Qxu Qxx] in the order (u, q, v); F = [0 Fqq Fqv; Fvu Fvq Fvv]
-    Mat Q(nQ, nQ), F(nx, nQ);
-    Mat Qxu = M.Qxu_full.block(0, kP, nx, nu);
-    Q.setBlock(0, 0, M.Quu_full.block(kP, kP, nu, nu)); Q.setBlock(0, nu, Qxu.t()); Q.setBlock(nu, 0, Qxu); Q.setBlock(nu, nu, M.Qxx);
-    Mat Fqq = -1.0 * Mat::Identity(nv), Fqv = dt_ * Mat::Identity(nv);
-    Fqq.setBlock(0, 0, M.Fqq6); Fqv.setBlock(0, 0, M.Fqv6);
-    for (int r = 0; r < 6; ++r) for (int c = 6; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; Fqv(r, c) = 0; Fqv(c, r) = 0; }
-    F.setBlock(0, nu, Fqq); F.setBlock(0, nu + nv, Fqv);
-    F.setBlock(nv, 0, M.Fvu); F.setBlock(nv, nu, M.Fvq); F.setBlock(nv, nu + nv, M.Fvv);
+    const bool impulse = nd.kind == NodeC::Impulse, aux = nd.kind == NodeC::Aux;
+    const int ni = (impulse || aux) ? seq.impulse_status[nd.event].dimf() : 0;
+    const int nw = impulse ? ni : nu, nQ = nw + nx, nr = nx + ni, nK = nr + nQ;
+    Mat Q(nQ, nQ), J(nr, nQ);
+    Mat res(nK);
+    if (!impulse) {
+      M.Qxx.setBlock(nv, 0, M.Qxx.block(0, nv, nv, nv).t());            // Qvq = Qqv^T
+      // Qss = [Quu Qux; Qxu Qxx] in the order (u, q, v); F = [0 Fqq Fqv; Fvu Fvq Fvv]
+      Mat Qxu = M.Qxu_full.block(0, kP, nx, nu);
+      Q.setBlock(0, 0, M.Quu_full.block(kP, kP, nu, nu)); Q.setBlock(0, nu, Qxu.t()); Q.setBlock(nu, 0, Qxu); Q.setBlock(nu, nu, M.Qxx);
+      Mat Fqq = -1.0 * Mat::Identity(nv), Fqv = nd.dt * Mat::Identity(nv);
+      Fqq.setBlock(0, 0, M.Fqq6); Fqv.setBlock(0, 0, M.Fqv6);
+      for (int r = 0; r < 6; ++r) for (int c = 6; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; Fqv(r, c) = 0; Fqv(c, r) = 0; }
+      J.setBlock(0, nu, Fqq); J.setBlock(0, nu + nv, Fqv);
+      J.setBlock(nv, 0, M.Fvu); J.setBlock(nv, nu, M.Fvq); J.setBlock(nv, nu + nv, M.Fvv);
+      if (aux) J.setBlock(nx, nu, sw_Pq[i]);
+      res.setSegment(0, R.Fq); res.setSegment(nv, R.Fv);
+      if (aux) res.setSegment(nx, R.P);
+      res.setSegment(nr, R.lu); res.setSegment(nr + nu, R.lq); res.setSegment(nr + nu + nv, R.lv);
+    } else {
+      // ImpulseSplitKKTMatrix (impulse_split_kkt_matrix.hxx:53-307): Qss over (f, q, v); Jac = [0 Fqq 0; Fvf Fvq -I; 0 Vq Vv]
+      const ImpulseDataC& I = imp[i];
+      M.Qxx.setBlock(nv, 0, M.Qxx.block(0, nv, nv, nv).t());
+      Q.setBlock(0, 0, M.Qff); Q.setBlock(0, ni, I.Qqf.t()); Q.setBlock(ni, 0, I.Qqf); Q.setBlock(ni, ni, M.Qxx);
+      Mat Fqq = -1.0 * Mat::Identity(nv);
+      Fqq.setBlock(0, 0, M.Fqq6);
+      for (int r = 0; r < 6; ++r) for (int c = 6; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; }
+      J.setBlock(0, ni, Fqq);
+      J.setBlock(nv, 0, I.Fvf); J.setBlock(nv, ni, I.Fvq); J.setBlock(nv, ni + nv, -1.0 * Mat::Identity(nv));
+      J.setBlock(nx, ni, I.Vq); J.setBlock(nx, ni + nv, I.Vv);
+      res.setSegment(0, R.Fq); res.setSegment(nv, R.Fv); res.setSegment(nx, R.P);
+      res.setSegment(nr, R.lf); res.setSegment(nr + ni, R.lq); res.setSegment(nr + ni + nv, R.lv);
+    }
     LLT lltQ;
-    if (!lltQ.compute(Q)) throw std::runtime_error("ParNMPC: Qss not positive definite at stage " + std::to_string(i));
+    if (!lltQ.compute(Q)) throw std::runtime_error("ParNMPC: Qss not positive definite at chain position " + std::to_string(p));
     Mat Qinv = lltQ.solve(Mat::Identity(nQ));
-    Mat FQinv = F * Qinv;
-    Mat S = F * FQinv.t();
+    Mat JQinv = J * Qinv;
+    Mat S = J * JQinv.t();
     LLT lltS;
-    if (!lltS.compute(S)) throw std::runtime_error("ParNMPC: F Qss^-1 F^T not positive definite at stage " + std::to_string(i));
-    Mat TL = -1.0 * lltS.solve(Mat::Identity(nx));
-    Mat TR = -1.0 * (TL * FQinv);
+    if (!lltS.compute(S)) throw std::runtime_error("ParNMPC: J Qss^-1 J^T not positive definite at chain position " + std::to_string(p));
+    Mat TL = -1.0 * lltS.solve(Mat::Identity(nr));
+    Mat TR = -1.0 * (TL * JQinv);
     Mat BR = Qinv - TR.t() * (S * TR);
     Mat& Ki = KKT_mat_inv[i];
     Ki = Mat(nK, nK);
-    Ki.setBlock(0, 0, TL); Ki.setBlock(0, nx, TR); Ki.setBlock(nx, 0, TR.t()); Ki.setBlock(nx, nx, BR);
-    Mat res(nK);
-    res.setSegment(0, R.Fq); res.setSegment(nv, R.Fv); res.setSegment(nx, R.lu); res.setSegment(nx + nu, R.lq); res.setSegment(nx + nu + nv, R.lv);
+    Ki.setBlock(0, 0, TL); Ki.setBlock(0, nr, TR); Ki.setBlock(nr, 0, TR.t()); Ki.setBlock(nr, nr, BR);
     Mat dir = Ki * res;
     SplitSolutionC& sn = s_new[i];
     sn = s[i];
     sn.lmd = s[i].lmd - dir.segment(0, nv);
     sn.gmm = s[i].gmm - dir.segment(nv, nv);
-    sn.u = s[i].u - dir.segment(nx, nu);
-    Mat qn; robot.integrateConfiguration(s[i].q, dir.segment(nx + nu, nv), -1.0, qn); sn.q = qn;
-    sn.v = s[i].v - dir.segment(nx + nu + nv, nv);
+    if (aux) for (int k2 = 0; k2 < ni; ++k2) sn.xi[k2] = s[i].xi[k2] - dir[nx + k2];
+    if (impulse) {
+      const ContactStatus& is = seq.impulse_status[nd.event];
+      int st = 0;
+      for (int c = 0; c < nc_; ++c) if (is.active[c]) {
+        for (int k2 = 0; k2 < 3; ++k2) { sn.mu[c][k2] = s[i].mu[c][k2] - dir[nx + st + k2]; sn.f[c][k2] = s[i].f[c][k2] - dir[nr + st + k2]; }
+        st += 3;
+      }
+    } else {
+      sn.u = s[i].u - dir.segment(nr, nu);
+    }
+    Mat qn; robot.integrateConfiguration(s[i].q, dir.segment(nr + nw, nv), -1.0, qn); sn.q = qn;
+    sn.v = s[i].v - dir.segment(nr + nw + nv, nv);
   }
 }
 
 // backward_correction_solver.cpp:253-287; split_backward_correction.hxx:84-95
 void ParNMPCSolver::backwardCorrectionSerial() {
-  const int nv = nv_, nx = 2 * nv, nK = 2 * nx + nu_;
-  for (int i = has_terminal ? N_ - 2 : N_ - 1; i >= 0; --i) {
-    const SplitSolutionC& sn_next = (i == N_ - 1) ? next_snew : s_new[i + 1];
-    const SplitSolutionC& s_next = (i == N_ - 1) ? next_s : s[i + 1];
+  const int nv = nv_, nx = 2 * nv, Mc = (int)chain.size();
+  for (int p = has_terminal ? Mc - 2 : Mc - 1; p >= 0; --p) {
+    const int i = chain[p].slot;
+    const SplitSolutionC& sn_next = (p == Mc - 1) ? next_snew : s_new[chain[p + 1].slot];
+    const SplitSolutionC& s_next = (p == Mc - 1) ? next_s : s[chain[p + 1].slot];
+    const int nK = KKT_mat_inv[i].r;
     x_res[i].setSegment(0, sn_next.lmd - s_next.lmd);
     x_res[i].setSegment(nv, sn_next.gmm - s_next.gmm);
     Mat dx = KKT_mat_inv[i].block(0, nK - nx, nx, nx) * x_res[i];
@@ -1362,22 +1713,40 @@ void ParNMPCSolver::backwardCorrectionSerial() {
     s_new[i].gmm -= dx.segment(nv, nv);
   }
 }
-// :288-318; split_backward_correction.hxx:96-108
+// :288-318; split_backward_correction.hxx:96-108; impulse_split_backward_correction.hxx:70-79
 void ParNMPCSolver::backwardCorrectionParallel() {
-  const int nv = nv_, nu = nu_, nx = 2 * nv, nK = 2 * nx + nu;
-  for (int i = 0; i < (has_terminal ? N_ - 1 : N_); ++i) {
-    Mat dz = KKT_mat_inv[i].block(nx, nK - nx, nK - nx, nx) * x_res[i];       // (du, dq, dv)
-    s_new[i].u -= dz.segment(0, nu);
-    Mat qn; robot.integrateConfiguration(s_new[i].q, dz.segment(nu, nv), -1.0, qn); s_new[i].q = qn;
-    s_new[i].v -= dz.segment(nu + nv, nv);
+  const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
+  for (int p = 0; p < (has_terminal ? Mc - 1 : Mc); ++p) {
+    const PNode& nd = chain[p];
+    const int i = nd.slot;
+    const int nK = KKT_mat_inv[i].r;
+    const bool impulse = nd.kind == NodeC::Impulse, aux = nd.kind == NodeC::Aux;
+    const int ni = (impulse || aux) ? seq.impulse_status[nd.event].dimf() : 0;
+    const int nw = impulse ? ni : nu;
+    Mat dz = KKT_mat_inv[i].block(nx, nK - nx, nK - nx, nx) * x_res[i];       // (dxi | dmu, du | df, dq, dv)
+    if (aux) for (int k2 = 0; k2 < ni; ++k2) s_new[i].xi[k2] -= dz[k2];
+    if (impulse) {
+      const ContactStatus& is = seq.impulse_status[nd.event];
+      int st = 0;
+      for (int c = 0; c < nc_; ++c) if (is.active[c]) {
+        for (int k2 = 0; k2 < 3; ++k2) { s_new[i].mu[c][k2] -= dz[st + k2]; s_new[i].f[c][k2] -= dz[ni + st + k2]; }
+        st += 3;
+      }
+    } else {
+      s_new[i].u -= dz.segment(ni, nu);
+    }
+    Mat qn; robot.integrateConfiguration(s_new[i].q, dz.segment(ni + nw, nv), -1.0, qn); s_new[i].q = qn;
+    s_new[i].v -= dz.segment(ni + nw + nv, nv);
   }
 }
 // :319-352; split_backward_correction.hxx:109-120
 void ParNMPCSolver::forwardCorrectionSerial() {
-  const int nv = nv_, nx = 2 * nv, nK = 2 * nx + nu_;
-  for (int i = has_prev ? 0 : 1; i < N_; ++i) {
-    const SplitSolutionC& snp = (i == 0) ? prev_snew : s_new[i - 1];
-    const SplitSolutionC& sp = (i == 0) ? prev_s : s[i - 1];
+  const int nv = nv_, nx = 2 * nv, Mc = (int)chain.size();
+  for (int p = has_prev ? 0 : 1; p < Mc; ++p) {
+    const int i = chain[p].slot;
+    const SplitSolutionC& snp = (p == 0) ? prev_snew : s_new[chain[p - 1].slot];
+    const SplitSolutionC& sp = (p == 0) ? prev_s : s[chain[p - 1].slot];
+    const int nK = KKT_mat_inv[i].r;
     Mat dq; robot.subtractConfiguration(snp.q, sp.q, dq);
     x_res[i].setSegment(0, dq);
     x_res[i].setSegment(nv, snp.v - sp.v);
@@ -1386,36 +1755,93 @@ void ParNMPCSolver::forwardCorrectionSerial() {
     s_new[i].v -= dx.segment(nv, nv);
   }
 }
-// :353-470; split_backward_correction.hxx:121-155; SplitParNMPC::computeCondensed{Primal,Dual}Direction
+// :353-470; split_backward_correction.hxx:121-155; impulse_split_backward_correction.hxx:93-125;
+// SplitParNMPC / ImpulseSplitParNMPC::computeCondensed{Primal,Dual}Direction
 void ParNMPCSolver::forwardCorrectionParallel() {
-  const int nv = nv_, nu = nu_, nx = 2 * nv, nK = 2 * nx + nu;
+  const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
   double pmin = 1, dmin = 1;
   double Jc[5][3]; frictionJac(cons.mu, Jc);
-  const ContactStatus& cs = contact_status;
-  const int dimf = cs.dimf();
-  for (int i = 0; i < N_; ++i) {
-    if (i > 0 || has_prev) {
-      Mat dh = KKT_mat_inv[i].block(0, 0, nK - nx, nx) * x_res[i];             // (dlmd, dgmm, du)
+  for (int p = 0; p < Mc; ++p) {
+    const PNode& nd = chain[p];
+    const int i = nd.slot;
+    const int nK = KKT_mat_inv[i].r;
+    const bool impulse = nd.kind == NodeC::Impulse, aux = nd.kind == NodeC::Aux;
+    const int ni = (impulse || aux) ? seq.impulse_status[nd.event].dimf() : 0;
+    const ContactStatus& cs = nodeContacts(nd);
+    const int dimf = cs.dimf();
+    const double dt = nd.dt;
+    if (p > 0 || has_prev) {
+      Mat dh = KKT_mat_inv[i].block(0, 0, nK - nx, nx) * x_res[i];             // (dlmd, dgmm, dxi | dmu, du | df)
       s_new[i].lmd -= dh.segment(0, nv);
       s_new[i].gmm -= dh.segment(nv, nv);
-      s_new[i].u -= dh.segment(nx, nu);
+      if (aux) for (int k2 = 0; k2 < ni; ++k2) s_new[i].xi[k2] -= dh[nx + k2];
+      if (impulse) {
+        int st = 0;
+        for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
+          for (int k2 = 0; k2 < 3; ++k2) { s_new[i].mu[c][k2] -= dh[nx + st + k2]; s_new[i].f[c][k2] -= dh[nx + ni + st + k2]; }
+          st += 3;
+        }
+      } else {
+        s_new[i].u -= dh.segment(nx + ni, nu);
+      }
     }
     aux_mat[i] = -1.0 * KKT_mat_inv[i].block(0, 0, nx, nx);
     // computeDirection
     d[i].dlmd = s_new[i].lmd - s[i].lmd;
     d[i].dgmm = s_new[i].gmm - s[i].gmm;
-    d[i].du = s_new[i].u - s[i].u;
     robot.subtractConfiguration(s_new[i].q, s[i].q, d[i].dq);
     d[i].dv = s_new[i].v - s[i].v;
+    Mat dx(nx); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
+    SplitKKTMatrixC& M = kkt_matrix[i];
+    SplitKKTResidualC& R = kkt_residual[i];
+    if (impulse) {
+      ImpulseDataC& I = imp[i];
+      Mat df(dimf), dmu(dimf);
+      int st = 0;
+      for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
+        for (int k2 = 0; k2 < 3; ++k2) { df[st + k2] = s_new[i].f[c][k2] - s[i].f[c][k2]; dmu[st + k2] = s_new[i].mu[c][k2] - s[i].mu[c][k2]; }
+        st += 3;
+      }
+      // ImpulseDynamicsBackwardEuler::computeCondensedPrimalDirection (:98-104)
+      Mat ddv = -1.0 * I.Minv_ImD;
+      ddv += I.Fvq * d[i].dq;
+      if (dimf > 0) ddv += I.Fvf * df;
+      d[i].daf = Mat(nv + dimf); d[i].daf.setSegment(0, ddv); d[i].daf.setSegment(nv, df);
+      if (componentValid(6, nd)) {
+        IpmData& data = ipm[i][6];
+        for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
+        st = 0;
+        for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+          for (int r2 = 0; r2 < 5; ++r2) {
+            const int idx = 5 * cc + r2;
+            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * df[st + x];
+            data.dslack[idx] = -Jdf - data.residual[idx];
+            data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
+          }
+          st += 3;
+        }
+        pmin = std::min(pmin, fractionToBoundary(cons.fraction_to_boundary_rate, data.slack, data.dslack));
+        dmin = std::min(dmin, fractionToBoundary(cons.fraction_to_boundary_rate, data.dual, data.ddual));
+      }
+      // computeCondensedDualDirection (:105-111), then the costate correction (state_equation.hxx:172-181)
+      I.ldv += I.Qdvq * d[i].dq;
+      if (dimf > 0) I.ldv += I.Qdvf * df;
+      I.ldv += d[i].dgmm;
+      Mat dbeta = -1.0 * (I.Minv * I.ldv);
+      d[i].dbetamu = Mat(nv + dimf); d[i].dbetamu.setSegment(0, dbeta); d[i].dbetamu.setSegment(nv, dmu);
+      d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, 6));
+      continue;
+    }
+    d[i].du = s_new[i].u - s[i].u;
+    if (aux) { d[i].dxi = Mat(ni); for (int k2 = 0; k2 < ni; ++k2) d[i].dxi[k2] = s_new[i].xi[k2] - s[i].xi[k2]; }
     // primal expansion
     const ContactDynamicsDataC& D = cd[i];
-    Mat dx(nx); dx.setSegment(0, d[i].dq); dx.setSegment(nv, d[i].dv);
     d[i].daf = -1.0 * (D.MJtJinv_dIDCdqv * dx);
     d[i].daf += D.MJtJinv.block(0, kP, nv + dimf, nu) * d[i].du;
     d[i].daf -= D.MJtJinv_IDC;
     for (int r2 = 0; r2 < dimf; ++r2) d[i].daf[nv + r2] *= -1;
     for (int c = 0; c < 7; ++c) {
-      if (!componentValid(c, stage_offset + i + 1)) continue;
+      if (!componentValid(c, nd)) continue;
       IpmData& data = ipm[i][c];
       if (c < 6) {
         const double sgn = (c & 1) ? 1.0 : -1.0;
@@ -1442,44 +1868,47 @@ void ParNMPCSolver::forwardCorrectionParallel() {
     }
     // dual expansion (contact_dynamics.hxx:171-190) with the stage's OWN dgmm, then the costate correction
     // (state_equation.hxx:172-181)
-    SplitKKTMatrixC& M = kkt_matrix[i];
-    SplitKKTResidualC& R = kkt_residual[i];
     ContactDynamicsDataC& Dm = cd[i];
     d[i].dnu_passive = R.lu_passive;
     d[i].dnu_passive += M.Quu_full.block(0, kP, 6, nu) * d[i].du;
     d[i].dnu_passive += M.Qxu_full.block(0, 0, nx, 6).t() * dx;
-    d[i].dnu_passive += dt_ * (Dm.MJtJinv.block(0, 0, 6, nv) * d[i].dgmm);
-    d[i].dnu_passive = (-1.0 / dt_) * d[i].dnu_passive;
+    d[i].dnu_passive += dt * (Dm.MJtJinv.block(0, 0, 6, nv) * d[i].dgmm);
+    d[i].dnu_passive = (-1.0 / dt) * d[i].dnu_passive;
     Dm.laf += Dm.Qafqv * dx;
     Dm.laf += Dm.Qafu_full.block(0, kP, nv + dimf, nu) * d[i].du;
-    for (int r = 0; r < nv; ++r) Dm.laf[r] += dt_ * d[i].dgmm[r];
-    d[i].dbetamu = (-1.0 / dt_) * (Dm.MJtJinv * Dm.laf);
+    for (int r = 0; r < nv; ++r) Dm.laf[r] += dt * d[i].dgmm[r];
+    d[i].dbetamu = (-1.0 / dt) * (Dm.MJtJinv * Dm.laf);
     d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, 6));
   }
   primal_step_size = pmin; dual_step_size = dmin;
 }
 
-// ParNMPCLinearizer::integrateSolution (parnmpc_linearizer.cpp:248-300)
+// ParNMPCLinearizer::integrateSolution (parnmpc_linearizer.cpp:248-300); SplitSolution::integrate / ImpulseSplitSolution::integrate
 void ParNMPCSolver::integrateSolution() {
   const int nv = nv_;
   const double ap = primal_step_size, ad = dual_step_size;
-  for (int i = 0; i < N_; ++i) {
+  for (const PNode& nd : chain) {
+    const int i = nd.slot;
+    const ContactStatus& cs = nodeContacts(nd);
     SplitSolutionC& si = s[i];
     si.lmd += ap * d[i].dlmd;
     si.gmm += ap * d[i].dgmm;
     Mat qn; robot.integrateConfiguration(si.q, d[i].dq, ap, qn); si.q = qn;
     si.v += ap * d[i].dv;
     si.a += ap * d[i].daf.segment(0, nv);
-    si.u += ap * d[i].du;
     si.beta += ap * d[i].dbetamu.segment(0, nv);
-    si.nu_passive += ap * d[i].dnu_passive;
+    if (nd.kind != NodeC::Impulse) {
+      si.u += ap * d[i].du;
+      si.nu_passive += ap * d[i].dnu_passive;
+    }
+    if (nd.kind == NodeC::Aux) for (int k2 = 0; k2 < d[i].dxi.size(); ++k2) si.xi[k2] += ap * d[i].dxi[k2];
     int st = 0;
-    for (int c = 0; c < nc_; ++c) if (contact_status.active[c]) {
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
       for (int r = 0; r < 3; ++r) { si.f[c][r] += ap * d[i].daf[nv + st + r]; si.mu[c][r] += ap * d[i].dbetamu[nv + st + r]; }
       st += 3;
     }
     for (int c = 0; c < 7; ++c) {
-      if (!componentValid(c, stage_offset + i + 1)) continue;
+      if (!componentValid(c, nd)) continue;
       ipm[i][c].slack += ap * ipm[i][c].dslack;
       ipm[i][c].dual += ad * ipm[i][c].ddual;
     }
@@ -1500,20 +1929,31 @@ void ParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v) {
 }
 
 void ParNMPCSolver::computeKKTResidual(double t, const Mat& q, const Mat& v) {
-  for (int i = 0; i < N_; ++i) linearizeStage(i, t + (stage_offset + i + 1) * dt_, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
+  discretize(t);
+  for (int p = 0; p < (int)chain.size(); ++p)
+    linearizeNode(p, p == 0 ? q : s[chain[p - 1].slot].q, p == 0 ? v : s[chain[p - 1].slot].v, true);
 }
 
-// ParNMPCLinearizer::KKTError (parnmpc_linearizer.cpp:203-247); SplitParNMPC::squaredNormKKTResidual (split_parnmpc.hxx:250-266):
-// note that the constraint residuals are NOT weighted by dt^2 here, unlike SplitOCP
+// ParNMPCLinearizer::KKTError (parnmpc_linearizer.cpp:203-247); SplitParNMPC::squaredNormKKTResidual (split_parnmpc.hxx:250-266;
+// the switching-constraint residual of an aux stage included), ImpulseSplitParNMPC::squaredNormKKTResidual
+// (impulse_split_parnmpc.hxx:114-124): note that the constraint residuals are NOT weighted by dt^2 here, unlike SplitOCP
 double ParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
 double ParNMPCSolver::KKTErrorSquared() {
   double sum = 0;
-  for (int i = 0; i < N_; ++i) {
+  for (const PNode& nd : chain) {
+    const int i = nd.slot;
     const SplitKKTResidualC& R = kkt_residual[i];
-    double e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
-               R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt_ * dt_ * cd[i].IDC.squaredNorm();
+    double e;
+    if (nd.kind == NodeC::Impulse) {
+      e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() +
+          imp[i].ImD.squaredNorm() + R.P.squaredNorm();
+    } else {
+      e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
+          R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + nd.dt * nd.dt * cd[i].IDC.squaredNorm();
+      if (nd.kind == NodeC::Aux) e += R.P.squaredNorm();
+    }
     double c2 = 0;
-    for (int c = 0; c < 7; ++c) if (componentValid(c, stage_offset + i + 1)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
+    for (int c = 0; c < 7; ++c) if (componentValid(c, nd)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
     sum += e + c2;
   }
   return sum;

@@ -174,15 +174,28 @@ class OCPSolver {
   void linearizeTerminal(int p, const Mat& q_prev, bool residual_only);
 };
 
-// ParNMPCSolver for horizons WITHOUT discrete events (src/ocp/parnmpc_solver.cpp:66-103): backward-Euler stages
-// (SplitParNMPC / TerminalParNMPC, include/idocp/ocp/split_parnmpc.hxx, terminal_parnmpc.hxx), per-stage KKT inverse
-// (SplitKKTMatrixInverter, split_kkt_matrix_inverter.hxx:44-80), coarse update and the four correction sweeps of
-// BackwardCorrectionSolver (src/ocp/backward_correction_solver.cpp:62-490, split_backward_correction.hxx:30-155).
+// ParNMPCSolver (src/ocp/parnmpc_solver.cpp:66-103): backward-Euler stages (SplitParNMPC / TerminalParNMPC,
+// include/idocp/ocp/split_parnmpc.hxx, terminal_parnmpc.hxx), per-stage KKT inverse (SplitKKTMatrixInverter,
+// split_kkt_matrix_inverter.hxx:44-166), coarse update and the four correction sweeps of BackwardCorrectionSolver
+// (src/ocp/backward_correction_solver.cpp:62-490, split_backward_correction.hxx:30-155).
 // Stage i (0 <= i < N) lives at time t + (i + 1) dt; the state before stage 0 is the measured (q, v).
+//
+// Horizons with discrete events (ParNMPCDiscretizer, include/idocp/hybrid/parnmpc_discretizer.hxx:65-397): the event
+// stages sit IN FRONT of the grid stage that follows the event,
+//   ..., stage i-1, [aux k, impulse k | lift k], stage i, ...
+// aux / lift are ordinary backward-Euler stages with their own time step (the aux stage also carries the switching
+// constraint P(q) = 0 of the impulse, switching_constraint.hxx:8-21, as rows Pq of its KKT matrix); the impulse stage is
+// ImpulseSplitParNMPC (impulse_split_parnmpc.hxx:33-60) with ImpulseDynamicsBackwardEuler (impulse_dynamics_backward_euler
+// .hxx:20-128) and its own KKT matrix in the variables (lmd, gmm, mu | f, q, v) (impulse_split_kkt_matrix_inverter.hxx:34-120,
+// impulse_split_backward_correction.hxx:30-127).  As in the OCP oracle every neighbour relation of the reference is the
+// chain predecessor / successor, and every stage owns a fixed slot: grid stage i -> i, impulse k -> N + k,
+// aux k -> N + E + k, lift k -> N + 2E + k.
 class ParNMPCSolver {
  public:
-  ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N);
+  ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N,
+                int max_num_impulse = 0);
   void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points);
+  void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, double switching_time);
   void setSolution(const std::string& name, const Mat& value);
   void initBackwardCorrection(double t);                              // parnmpc_solver.cpp:66-70
   void initConstraints(double t);                                     // parnmpc_linearizer.cpp:43-75
@@ -196,21 +209,42 @@ class ParNMPCSolver {
   void forwardCorrectionSerial();
   void forwardCorrectionParallel();
   void integrateSolution();
-  int N() const { return N_; }
+  int N() const { return N_; }                 // grid stages of the current discretisation
+  int M() const { return (int)chain.size(); }  // chain length = N + 2 N_impulse + N_lift
+  struct PNode {
+    int kind = NodeC::Stage;   // Stage, Impulse, Aux, Lift, Terminal (= the last grid stage, which carries the terminal cost)
+    int slot = 0, index = 0;   // index: grid stage / impulse index / lift index
+    double t = 0, dt = 0;
+    int phase = 0;             // contact phase (Stage / Aux / Lift / Terminal)
+    int level = 0;             // time step of Constraints::createConstraintsData: i + 1 (stage i), 0 (aux, lift), -1 (impulse)
+    int event = -1;            // Aux / Impulse: event index of the impulse
+  };
+  void discretize(double t);                                           // ParNMPCDiscretizer::discretizeOCP
+  std::vector<PNode> chain;
+  ContactSequenceC seq;
+  const ContactStatus& nodeContacts(const PNode& nd) const { return nd.kind == NodeC::Impulse ? seq.impulse_status[nd.event] : seq.phases[nd.phase]; }
+  int slotOf(int kind, int index) const;
+  int nslots() const { return N_ideal_ + 3 * max_events_; }
   Robot robot;
   idocp_cost_t cost;
   idocp_constraints_t cons;
-  ContactStatus contact_status;
+  ContactStatus contact_status;      // the first contact phase (the only one of an event-free horizon)
+  // all per-stage arrays are indexed by SLOT
   std::vector<SplitSolutionC> s, s_new;
   std::vector<SplitDirectionC> d;
   std::vector<SplitKKTMatrixC> kkt_matrix;
   std::vector<SplitKKTResidualC> kkt_residual;
   std::vector<ContactDynamicsDataC> cd;
   std::vector<std::vector<IpmData>> ipm;
-  std::vector<Mat> KKT_mat_inv, aux_mat, x_res;      // (2nx+nu)^2, nx^2, nx per stage
+  std::vector<Mat> KKT_mat_inv, aux_mat, x_res;      // dimKKT^2, nx^2, nx per stage
+  std::vector<Mat> sw_Pq;                            // aux stages: Pq (dimi x nv); the residual P sits in kkt_residual.P
+  // ImpulseDynamicsBackwardEulerData + the impulse blocks of ImpulseSplitKKTMatrix (per impulse slot)
+  struct ImpulseDataC { Mat ImD, dImDdq, dImDddv, Minv, Minv_ImD, Qdvq, Qdvf, ldv, Fvq, Fvf, Vq, Vv, Qqf, Qdvdv; };
+  std::vector<ImpulseDataC> imp;
   double primal_step_size = 1, dual_step_size = 1;
   double serial_seconds = 0;
-  // ---- horizon sharding (stages of one horizon spread over several processes) ----
+  // ---- horizon sharding (stages of one horizon spread over several processes; event-free
+  // horizons only) ----
   // This object then owns the stages [stage_offset, stage_offset + N) of a longer horizon.  What it needs from its
   // neighbours arrives through importHalo: the state in front of its first stage (has_prev), the first stage of the
   // right neighbour (lmd, gmm, q for the coupling terms; aux_mat; corrected lmd, gmm for the backward sweep) and the
@@ -228,12 +262,17 @@ class ParNMPCSolver {
   double KKTErrorSquared();
 
  private:
-  int N_, nv_, nu_, nc_;
+  int N_ideal_, N_, nv_, nu_, nc_, max_events_;
   double T_, dt_;
-  bool componentValid(int c, int level) const;
+  double disc_t_ = 0;
+  bool discretized_ = false;
+  bool componentValid(int c, const PNode& nd) const;
   int componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
   void qRef(double t, Mat& q_ref) const;
-  void linearizeStage(int i, double t, const Mat& q_prev, const Mat& v_prev, bool residual_only);
+  void initNodeConstraints(const PNode& nd);
+  void linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only);
+  void linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only);
+  const SplitSolutionC* nextSolution(int p) const;       // s of the chain successor (next_s behind the last stage of a shard)
 };
 
 }  // namespace oracle

@@ -15,7 +15,9 @@ using namespace oracle;
 
 static Mat toVec(const double* p, int n) { Mat v(n); std::memcpy(v.d.data(), p, sizeof(double) * n); return v; }
 
+static std::string g_oracle_error;
 extern "C" {
+const char* oracle_last_error(void) { return g_oracle_error.c_str(); }
 
 int oracle_rnea(const idocp_model_t* m, const double* q, const double* v, const double* a,
                 const double* fext_local /* [ncontacts][3] or NULL */, int gravity, double* tau) {
@@ -539,6 +541,62 @@ double oracle_ocp_bench(void* h, double t, const double* q, const double* v, int
 void* oracle_parnmpc_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
   try { return new ParNMPCSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
 }
+void* oracle_parnmpc_create_hybrid(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N,
+                                   int max_num_impulse) {
+  try { return new ParNMPCSolver(*m, *c, *k, T, N, max_num_impulse); } catch (...) { return nullptr; }
+}
+int oracle_parnmpc_push_back_contact_status(void* h, const int* active, const double* points, double switching_time) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  std::vector<int> a(active, active + s->robot.maxPointContacts());
+  try { s->pushBackContactStatus(a, points, switching_time); } catch (...) { return -1; }
+  return 0;
+}
+// the chain of the discretisation at time t (ParNMPCDiscretizer): returns its length; arrays of `capacity` entries
+int oracle_parnmpc_chain(void* h, double t, int capacity, int* kind, int* index, int* slot, double* tt, double* dt, int* dimf, int* level) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  try { s->discretize(t); } catch (...) { return -1; }
+  const int M = s->M();
+  for (int p = 0; p < M && p < capacity; ++p) {
+    const ParNMPCSolver::PNode& nd = s->chain[p];
+    kind[p] = nd.kind; index[p] = nd.index; slot[p] = nd.slot; tt[p] = nd.t; dt[p] = nd.dt; dimf[p] = s->nodeContacts(nd).dimf(); level[p] = nd.level;
+  }
+  return M;
+}
+// solution / direction field along the chain: out[M][stride]  (a = dv, da = ddv on impulse stages)
+int oracle_parnmpc_get_chain(void* h, const char* name, int stride, double* out) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  const std::string n(name);
+  const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
+  for (int p = 0; p < s->M(); ++p) {
+    const ParNMPCSolver::PNode& nd = s->chain[p];
+    double* o = out + (size_t)p * stride;
+    for (int k = 0; k < stride; ++k) o[k] = 0.0;
+    const SplitSolutionC& x = s->s[nd.slot];
+    const SplitDirectionC& d = s->d[nd.slot];
+    const ContactStatus& cs = s->nodeContacts(nd);
+    auto put = [&](const Mat& m) { for (int k = 0; k < m.size() && k < stride; ++k) o[k] = m[k]; };
+    if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a);
+    else if (n == "u") { if (nd.kind != NodeC::Impulse) put(x.u); }
+    else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
+    else if (n == "xi") { if (nd.kind == NodeC::Aux) put(x.xi); }
+    else if (n == "f" || n == "mu") { for (int c = 0; c < nc; ++c) if (cs.active[c]) for (int k = 0; k < 3; ++k) o[3 * c + k] = (n == "f" ? x.f : x.mu)[c][k]; }
+    else if (n == "nu_passive") { if (nd.kind != NodeC::Impulse) put(x.nu_passive); }
+    else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv);
+    else if (n == "du") { if (nd.kind != NodeC::Impulse) put(d.du); }
+    else if (n == "dlmd") put(d.dlmd); else if (n == "dgmm") put(d.dgmm);
+    else if (n == "dnu_passive") { if (nd.kind != NodeC::Impulse) put(d.dnu_passive); }
+    else if (n == "dxi") { if (nd.kind == NodeC::Aux) put(d.dxi); }
+    else if (n == "da") put(d.daf.segment(0, nv));
+    else if (n == "dbeta") put(d.dbetamu.segment(0, nv));
+    else if (n == "df" || n == "dmu") {
+      const Mat& st = n == "df" ? d.daf : d.dbetamu;
+      int k0 = 0;
+      for (int c = 0; c < nc; ++c) if (cs.active[c]) { for (int k = 0; k < 3; ++k) o[3 * c + k] = st[nv + k0 + k]; k0 += 3; }
+    }
+    else return -1;
+  }
+  return 0;
+}
 void oracle_parnmpc_destroy(void* h) { delete static_cast<ParNMPCSolver*>(h); }
 int oracle_parnmpc_set_contact_status(void* h, const int* active, const double* points) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
@@ -561,7 +619,8 @@ int oracle_parnmpc_init(void* h, double t) {
 }
 int oracle_parnmpc_update_solution(void* h, double t, const double* q, const double* v) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
-  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); } catch (...) { return 1; }
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); }
+  catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
   return 0;
 }
 double oracle_parnmpc_kkt_error(void* h, double t, const double* q, const double* v) {
@@ -620,7 +679,7 @@ int oracle_parnmpc_phase(void* h, int phase, double t, const double* q, const do
       case 4: s->forwardCorrectionParallel(); break;
       default: s->integrateSolution(); break;
     }
-  } catch (...) { return 1; }
+  } catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
   return 0;
 }
 int oracle_parnmpc_init_constraints_only(void* h, double t) { static_cast<ParNMPCSolver*>(h)->initConstraints(t); return 0; }

@@ -521,9 +521,11 @@ class OracleOCP:
 
 
 class OracleParNMPC:
-    """ParNMPCSolver of the oracle (event-free horizons): examples/anymal/parnmpc_benchmark.cpp call order."""
+    """ParNMPCSolver of the oracle: examples/anymal/parnmpc_benchmark.cpp call order; with max_num_impulse > 0 also horizons
+    with discrete events (examples/anymal/anymal_trotting_parnmpc.cpp)."""
+    KINDS = ("stage", "impulse", "aux", "lift", "terminal")
 
-    def __init__(self, model, cost, cons, T, N):
+    def __init__(self, model, cost, cons, T, N, max_num_impulse=0):
         self.lib = lib = oracle()
         vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
         if not getattr(lib, "_parnmpc_ready", False):
@@ -549,8 +551,17 @@ class OracleParNMPC:
             lib.oracle_parnmpc_init_constraints_only.argtypes = [vp, cd]
             lib.oracle_parnmpc_init_aux_only.argtypes = [vp, cd]
             lib._parnmpc_ready = True
-        self.N, self.nv = N, model.nv
-        self.h = lib.oracle_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
+            lib.oracle_parnmpc_create_hybrid.argtypes = [C.POINTER(capi.Model), C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci, ci]
+            lib.oracle_parnmpc_create_hybrid.restype = vp
+            lib.oracle_parnmpc_push_back_contact_status.argtypes = [vp, C.POINTER(ci), dp, cd]
+            ip = C.POINTER(ci)
+            lib.oracle_parnmpc_chain.argtypes = [vp, cd, ci, ip, ip, ip, dp, dp, ip, ip]
+            lib.oracle_parnmpc_get_chain.argtypes = [vp, cs, ci, dp]
+        self.N, self.nv, self.max_num_impulse = N, model.nv, max_num_impulse
+        if max_num_impulse > 0:
+            self.h = lib.oracle_parnmpc_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse)
+        else:
+            self.h = lib.oracle_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
         assert self.h
 
     def __del__(self):
@@ -564,6 +575,25 @@ class OracleParNMPC:
 
     def set_solution(self, name, value):
         assert self.lib.oracle_parnmpc_set_solution(self.h, name.encode(), P(arr(value))) == 0
+
+    def push_back_contact_status(self, active, points, switching_time):
+        a = (C.c_int * 4)(*[int(x) for x in active])
+        assert self.lib.oracle_parnmpc_push_back_contact_status(self.h, a, P(arr(points)), switching_time) == 0
+
+    def chain(self, t=0.0):
+        cap = self.N + 3 * self.max_num_impulse + 1
+        I = lambda: (C.c_int * cap)()
+        kind, index, slot, dimf, level = I(), I(), I(), I(), I()
+        tt, dt = np.zeros(cap), np.zeros(cap)
+        M = self.lib.oracle_parnmpc_chain(self.h, t, cap, kind, index, slot, P(tt), P(dt), dimf, level)
+        assert M >= 0, "the oracle rejected the discretisation"
+        return [dict(kind=self.KINDS[kind[p]], index=index[p], slot=slot[p], t=tt[p], dt=dt[p], dimf=dimf[p], level=level[p]) for p in range(M)]
+
+    def get_chain(self, name, M):
+        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or {"xi": 12, "dxi": 12}[name]
+        out = np.zeros((M, dim))
+        assert self.lib.oracle_parnmpc_get_chain(self.h, name.encode(), dim, P(out)) == 0
+        return out
 
     def init(self, t=0.0):                      # initBackwardCorrection(t) + initConstraints(t)
         self.lib.oracle_parnmpc_init(self.h, t)

@@ -37,3 +37,59 @@ def test_parnmpc_converges_to_a_kkt_point():
         assert np.abs(prev_q[7:] - Q[i, 7:] + dt * V[i, 6:]).max() < 1e-9
         assert np.abs(prev_v - V[i] + dt * A[i]).max() < 1e-9
         prev_q, prev_v = Q[i], V[i]
+
+
+# ---- horizons with discrete events (ParNMPCDiscretizer, aux / impulse / lift stages of the backward-Euler formulation) ----
+def make_hybrid(N=20, T=1.0, t_lift=0.52, t_touch=0.83):
+    """All feet -> {LH, RF} at t_lift -> all feet again at t_touch: one lift and one impulse event off the grid."""
+    import ctypes as C
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    p = OracleParNMPC(m, cost, cons, T, N, max_num_impulse=3)
+    pts = anymal_contact_points(m).copy()
+    p.set_contact_status([1, 1, 1, 1], pts)
+    p.push_back_contact_status([0, 1, 1, 0], pts, t_lift)
+    p.push_back_contact_status([1, 1, 1, 1], pts, t_touch)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    p.set_solution("q", q)
+    p.set_solution("v", v)
+    p.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    p.init(0.0)
+    return m, p, q, v
+
+
+def test_hybrid_chain():
+    # parnmpc_discretizer.hxx:246-373: the event stages sit in front of the grid stage that follows the event; the stage
+    # after the event keeps the rest of the interval
+    m, p, q, v = make_hybrid()
+    ch = p.chain(0.0)
+    dt = 1.0 / 20
+    assert "".join(c["kind"][0] for c in ch) == "s" * 10 + "l" + "s" * 6 + "ai" + "s" * 3 + "t"
+    lift, aux, imp = ch[10], ch[17], ch[18]
+    assert abs(lift["t"] - 0.52) < 1e-12 and abs(lift["dt"] - 0.02) < 1e-12 and abs(ch[11]["dt"] - 0.03) < 1e-12
+    assert abs(aux["t"] - 0.83) < 1e-12 and abs(aux["dt"] - 0.03) < 1e-12 and imp["dt"] == 0.0 and abs(ch[19]["dt"] - 0.02) < 1e-12
+    assert lift["dimf"] == 12 and ch[11]["dimf"] == 6 and aux["dimf"] == 6 and imp["dimf"] == 6 and ch[19]["dimf"] == 12
+    assert [c["level"] for c in (lift, aux, imp)] == [0, 0, -1] and ch[0]["level"] == 1 and ch[-1]["level"] == 20
+    assert abs(sum(c["dt"] for c in ch) - 1.0) < 1e-12
+
+
+def test_hybrid_direction_is_a_newton_direction():
+    """With a fixed step size alpha the KKT error of a Newton-type iteration falls by (1 - alpha) per iteration once the
+    lagged coupling terms (aux_mat) have caught up: the aux stage with its switching constraint, the impulse stage with its
+    own KKT matrix, the lift stage and all the chain neighbour relations have to be consistent for that.  (Full steps from
+    this cold start diverge -- ParNMPC has no globalisation; the reference's driver runs 200 iterations.)"""
+    m, p, q, v = make_hybrid()
+    lib = p.lib
+    alpha = 0.1
+    e = [p.kkt_error(0.0, q, v)]
+    from helpers import P, arr
+    for it in range(60):
+        for ph in range(5):
+            assert lib.oracle_parnmpc_phase(p.h, ph, 0.0, P(arr(q)), P(arr(v))) == 0
+        a, b = p.step_sizes()
+        lib.oracle_parnmpc_set_step_sizes(p.h, min(a, alpha), min(b, alpha))
+        assert lib.oracle_parnmpc_phase(p.h, 5, 0.0, P(arr(q)), P(arr(v))) == 0
+        e.append(p.kkt_error(0.0, q, v))
+    rate = [e[k + 1] / e[k] for k in range(30, 60)]
+    assert max(abs(r - (1 - alpha)) for r in rate) < 5e-3, rate
+    assert e[-1] < 0.01 * e[0]
