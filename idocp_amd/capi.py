@@ -137,6 +137,8 @@ def _proto(lib):
     lib.idocp_ocp_create.restype = ci
     lib.idocp_parnmpc_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
     lib.idocp_parnmpc_create.restype = ci
+    lib.idocp_parnmpc_create_hybrid.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, P(vp)]
+    lib.idocp_parnmpc_create_hybrid.restype = ci
     lib.idocp_parnmpc_init_backward_correction.argtypes = [vp, cd]
     lib.idocp_parnmpc_init_backward_correction.restype = ci
     lib.idocp_parnmpc_update_solution.argtypes = [vp, cd, vp, vp, ci]

@@ -295,11 +295,128 @@ int discretize(idocp_ocp* h, double t) {
   return IDOCP_OK;
 }
 
+// ParNMPCDiscretizer::discretizeOCP with discrete events (parnmpc_discretizer.hxx:65-72: countDiscreteEvents :246-262,
+// countTimeSteps :265-324, countTimeStages :327-361, countContactPhase :364-373).  The event stages sit IN FRONT of the grid
+// stage that follows the event:  ..., stage i-1, [aux k, impulse k | lift k], stage i, ...; the aux stage carries the
+// switching constraint of its impulse (sw_* fields of the node, with sw_dt1 = sw_dt2 = 0: the constraint acts on the aux
+// stage's own configuration).
+int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
+  if (h->stage_offset != 0 || !h->has_terminal || h->has_prev) { set_last_error("ParNMPC: horizon shards carry event-free horizons only"); return IDOCP_E_UNSUPPORTED; }
+  const int Nid = h->N;
+  const double dt_ideal = h->T / Nid, min_dt = std::sqrt(std::numeric_limits<double>::epsilon()), max_dt = dt_ideal - min_dt;
+  std::vector<int> ev_imp, ev_lift;
+  for (int e = 0; e < (int)h->event_time.size(); ++e) (h->is_impulse[e] ? ev_imp : ev_lift).push_back(e);
+  const int Ni = (int)ev_imp.size(), Nl = (int)ev_lift.size();
+  std::vector<int> tsai(Ni + 1, -1), tsal(Nl + 1, -1);        // time stage AFTER the impulse / lift
+  std::vector<double> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
+  for (int k = 0; k < Ni; ++k) { t_imp[k] = h->event_time[ev_imp[k]]; tsai[k] = (int)std::floor((t_imp[k] - t) / dt_ideal); }
+  for (int k = 0; k < Nl; ++k) { t_lift[k] = h->event_time[ev_lift[k]]; tsal[k] = (int)std::floor((t_lift[k] - t) / dt_ideal); }
+  std::vector<double> dts(Nid + 1, dt_ideal), ts(Nid + 1, 0.0);
+  int ii = 0, li = 0, on_grid = 0;
+  for (int i = 0; i < Nid; ++i) {
+    const int stage = i - on_grid;
+    if (ii < Ni && i == tsai[ii]) {
+      dts[stage] = (i + 1) * dt_ideal + t - t_imp[ii];
+      if (dts[stage] <= min_dt) { tsai[ii] = i + 1; ts[stage] = t + (i + 1) * dt_ideal; }
+      else if (dts[stage] >= max_dt) { tsai[ii] = stage - 1; dt_aux[ii] = dt_ideal; ts[stage] = t + i * dt_ideal; ++on_grid; ++ii; }
+      else { tsai[ii] = stage; dt_aux[ii] = dt_ideal - dts[stage]; ts[stage] = t + (i + 1) * dt_ideal; ++ii; }
+    } else if (li < Nl && i == tsal[li]) {
+      dts[stage] = (i + 1) * dt_ideal + t - t_lift[li];
+      if (dts[stage] <= min_dt) { tsal[li] = i + 1; ts[stage] = t + (i + 1) * dt_ideal; }
+      else if (dts[stage] >= max_dt) { tsal[li] = stage - 1; dt_lift[li] = dt_ideal; ts[stage] = t + i * dt_ideal; ++on_grid; ++li; }
+      else { tsal[li] = stage; dt_lift[li] = dt_ideal - dts[stage]; ts[stage] = t + (i + 1) * dt_ideal; ++li; }
+    } else {
+      dts[stage] = dt_ideal; ts[stage] = t + (i + 1) * dt_ideal;
+    }
+  }
+  const int Ng = Nid - on_grid;
+  ts[Ng - 1] = t + h->T;
+  std::vector<int> imp_before(Ng, -1), lift_before(Ng, -1), phase(Ng, 0);
+  ii = 0; li = 0;
+  int num_events = 0;
+  for (int i = 0; i < Ng; ++i) {
+    if (ii < Ni && i == tsai[ii]) imp_before[i] = ii++;
+    if (li < Nl && i == tsal[li]) lift_before[i] = li++;
+    if (imp_before[i] >= 0 && lift_before[i] >= 0) { set_last_error("ParNMPCDiscretizer: an impulse and a lift fall into the same time stage"); return IDOCP_E_ARG; }
+    if (imp_before[i] >= 0 || lift_before[i] >= 0) ++num_events;
+    phase[i] = num_events;
+  }
+  if (ii != Ni || li != Nl) { set_last_error("ParNMPCDiscretizer: a discrete event lies outside the horizon"); return IDOCP_E_ARG; }
+  for (int i = 0; i + 1 < Ng; ++i)
+    if (imp_before[i] >= 0 && imp_before[i + 1] >= 0) { set_last_error("ParNMPCDiscretizer: impulses in consecutive time stages"); return IDOCP_E_ARG; }
+  if (imp_before[0] >= 0 || lift_before[0] >= 0) { set_last_error("ParNMPC: a discrete event in front of the first time stage is not carried"); return IDOCP_E_UNSUPPORTED; }
+  h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
+  auto node = [&](int kind, int index, double tt, double dtt, const HostStatus& st, int level) {
+    OcpNode nd;
+    std::memset(&nd, 0, sizeof(nd));
+    nd.kind = kind; nd.slot = slotOf(h, kind, index); nd.level = level;
+    nd.has_u = (kind == 1) ? 0 : 1;
+    nd.dt = (kind == 1) ? 1.0 : dtt;
+    nd.dtq = (kind == 1) ? 0.0 : dtt;
+    fillStatus(nd, st);
+    h->chain.push_back(nd); h->chain_index.push_back(index); h->chain_t.push_back(tt);
+  };
+  h->has_switch = false;
+  for (int i = 0; i < Ng; ++i) {
+    const int phase_before = i > 0 ? phase[i - 1] : 0;
+    if (imp_before[i] >= 0) {
+      const int k = imp_before[i];
+      const HostStatus& is = h->impulse_status[ev_imp[k]];
+      node(2, k, t_imp[k], dt_aux[k], h->phases[phase_before], 0);
+      {
+        OcpNode& nd = h->chain.back();                              // switchingconstraint::linearizeSwitchingConstraint on the aux stage
+        int row = 0;
+        for (int c = 0; c < DQ::NC; ++c) {
+          nd.sw_active[c] = is.active[c] ? 1 : 0;
+          nd.sw_row[c] = is.active[c] ? row : -1;
+          if (is.active[c]) row += 3;
+          for (int k2 = 0; k2 < 3; ++k2) nd.sw_point[c][k2] = is.points[c][k2];
+        }
+        nd.sw_dimi = row; nd.sw_dt1 = 0.0; nd.sw_dt2 = 0.0;
+        h->has_switch = true;
+      }
+      node(1, k, t_imp[k], 0.0, is, -1);
+    } else if (lift_before[i] >= 0) {
+      const int k = lift_before[i];
+      node(3, k, t_lift[k], dt_lift[k], h->phases[phase_before], 0);
+    }
+    node(0, i, ts[i], dts[i], h->phases[phase[i]], (i == Ng - 1) ? Nid : i + 1);      // parnmpc_linearizer.cpp:43-58
+  }
+  {
+    OcpNode nd;                                                     // placeholder behind the last stage (see below)
+    std::memset(&nd, 0, sizeof(nd));
+    nd.kind = 4; nd.slot = Nid; nd.level = Nid; nd.has_u = 1; nd.dt = dt_ideal; nd.dtq = dt_ideal;
+    fillStatus(nd, h->phases[phase[Ng - 1]]);
+    h->chain.push_back(nd); h->chain_index.push_back(Ng); h->chain_t.push_back(t + h->T);
+  }
+  const int M = h->M();
+  for (int p = 0; p < M; ++p) {
+    h->chain[p].prev = p > 0 ? h->chain[p - 1].slot : -1;
+    h->chain[p].next = p + 1 < M ? h->chain[p + 1].slot : -1;
+  }
+  h->prob.has_terminal = 1; h->prob.has_prev = 0; h->prob.stage_offset = 0;
+  h->Ngrid = Ng - 1;
+  h->uniform_dimf = -1;
+  std::vector<double> tab((size_t)M * DQ::NQ);
+  for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
+  h->prob.M = M; h->prob.NS = h->NS;
+  HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
+  std::vector<int> ipos;
+  for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
+  h->n_impulse = (int)ipos.size();
+  if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->disc_time = t; h->seq_dirty = false;
+  return IDOCP_OK;
+}
+
 // ParNMPCDiscretizer for a horizon without events (include/idocp/hybrid/parnmpc_discretizer.hxx): N backward-Euler stages,
 // stage i at time t + (i + 1) dt with constraint level i + 1 (parnmpc_linearizer.cpp:43-58), followed by a placeholder so
 // that the per-stage kernels see the usual "M - 1 stages + one more" chain.
 int discretizeParNMPC(idocp_ocp* h, double t) {
-  if (!h->event_time.empty()) { set_last_error("ParNMPC: contact sequences with discrete events are not carried yet"); return IDOCP_E_UNSUPPORTED; }
+  if (!h->event_time.empty()) return discretizeParNMPCHybrid(h, t);
   const int N = h->N;
   const double dt = h->T / N;
   h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
@@ -896,6 +1013,11 @@ int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx
 int idocp_parnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
                          int N, int batch, int device, idocp_ocp_t** out) {
   return createOcpImpl(model, cost, constraints, T, N, 0, batch, device, true, out);
+}
+
+int idocp_parnmpc_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                                int N, int max_num_impulse, int batch, int device, idocp_ocp_t** out) {
+  return createOcpImpl(model, cost, constraints, T, N, max_num_impulse, batch, device, true, out);
 }
 
 // ParNMPCSolver::initBackwardCorrection (parnmpc_solver.cpp:66-70)

@@ -349,6 +349,13 @@ int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n);
 int idocp_parnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost,
                          const idocp_constraints_t* constraints, double T, int N, int batch,
                          int device, idocp_ocp_t** out);
+/* ParNMPCSolver(robot, cost, constraints, T, N, max_num_impulse, nthreads) (include/idocp/ocp/parnmpc_solver.hpp) for horizons
+ * with discrete events: idocp_ocp_push_back_contact_status / set_contact_points / pop_* act on the handle as for OCPSolver;
+ * the chain of stages (idocp_ocp_get_chain) follows ParNMPCDiscretizer (aux / impulse / lift stages in FRONT of the grid stage
+ * that follows the event). */
+int idocp_parnmpc_create_hybrid(const idocp_model_t* model, const idocp_cost_t* cost,
+                                const idocp_constraints_t* constraints, double T, int N, int max_num_impulse,
+                                int batch, int device, idocp_ocp_t** out);
 /* ParNMPCSolver::initBackwardCorrection (parnmpc_solver.cpp:66-70): aux_mat of every stage
  * = terminal cost Hessian. */
 int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t);

@@ -750,13 +750,17 @@ class HipOCP:
 class HipParNMPC(HipOCP):
     """ParNMPCSolver through the C ABI (idocp_parnmpc_* + the shared idocp_ocp_* entry points)."""
 
-    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
+    def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
         self.lib = capi.lib()
         self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
-        self.max_events = 0
+        self.max_events = max_num_impulse
         h = C.c_void_p()
-        capi.check(self.lib.idocp_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
-                   "idocp_parnmpc_create")
+        if max_num_impulse > 0:
+            capi.check(self.lib.idocp_parnmpc_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse, batch, device,
+                                                            C.byref(h)), "idocp_parnmpc_create_hybrid")
+        else:
+            capi.check(self.lib.idocp_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
+                       "idocp_parnmpc_create")
         self.h = h
 
     def init(self, t=0.0):
