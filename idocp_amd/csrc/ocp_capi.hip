@@ -112,6 +112,8 @@ struct idocp_ocp {
   bool seq_dirty = true, has_switch = false;
   int n_impulse = 0;
   int* d_impulse_pos = nullptr;
+  int* d_general_pos = nullptr;     // ParNMPC: chain positions of the aux (switching rows) / impulse stages
+  int n_general = 0;
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
   int M() const { return (int)chain.size(); }
 };
@@ -406,6 +408,10 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
   h->n_impulse = (int)ipos.size();
   if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> gpos;
+  for (int p = 0; p < M; ++p) if (parnmpcShape<LQ>(h->chain[p]).general) gpos.push_back(p);
+  h->n_general = (int)gpos.size();
+  if (!gpos.empty()) HIP_TRY(hipMemcpyAsync(h->d_general_pos, gpos.data(), sizeof(int) * gpos.size(), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->disc_time = t; h->seq_dirty = false;
@@ -431,7 +437,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   h->chain_t[N] = t + (h->stage_offset + N) * dt;
   h->prob.has_terminal = h->has_terminal ? 1 : 0; h->prob.has_prev = h->has_prev ? 1 : 0; h->prob.stage_offset = h->stage_offset;
   h->Ngrid = N - 1;                  // getters: stages 0 .. N-1
-  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0;
+  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0; h->n_general = 0;
   const int M = N + 1;
   std::vector<double> tab((size_t)M * DQ::NQ);
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
@@ -550,6 +556,9 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &tmp, ((size_t)(max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
   h->d_impulse_pos = reinterpret_cast<int*>(tmp);
   B.impulse_pos = h->d_impulse_pos;
+  if ((rc = allocBufO(h, &tmp, ((size_t)(2 * max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
+  h->d_general_pos = reinterpret_cast<int*>(tmp);
+  B.general_pos = h->d_general_pos;
   B.q_ref = h->d_qref;
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
@@ -1041,9 +1050,16 @@ int idocp_parnmpc_launch_phase(idocp_ocp_t* h, int phase, const double* d_q, con
   if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
   const int M = h->M();
   switch (phase) {
-    case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream); break;
-    case 1: OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, d_q, d_v, false, h->stream); break;
-    case 2: OcpLaunch<DQ>::parnmpcInverse(h->B, h->batch, M, h->stream); break;
+    case 0: OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream); break;
+    case 1:
+      if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);          // P, Pq of the aux stages
+      OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, d_q, d_v, false, h->stream);
+      OcpLaunch<DQ>::parnmpcImpulseCondense(h->B, h->batch, h->n_impulse, false, d_q, d_v, h->stream);
+      break;
+    case 2:
+      OcpLaunch<DQ>::parnmpcInverse(h->B, h->batch, M, h->stream);
+      OcpLaunch<DQ>::parnmpcEventInverse(h->B, h->batch, h->n_general, h->stream);
+      break;
     case 3: case 4: case 5: case 6: OcpLaunch<DQ>::parnmpcPhase(phase - 3, h->B, h->batch, M, h->has_terminal, d_q, d_v, h->stream); break;
     case 7: OcpLaunch<DQ>::single(4, h->B, h->batch, M, h->stream); break;
     case 8: OcpLaunch<DQ>::single(5, h->B, h->batch, M, h->stream); break;
@@ -1085,8 +1101,10 @@ int idocp_parnmpc_compute_kkt_residual(idocp_ocp_t* h, double t, const double* q
   const int M = h->M();
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, h->d_q0, h->d_v0, true, h->stream);
+  OcpLaunch<DQ>::parnmpcImpulseCondense(h->B, h->batch, h->n_impulse, true, h->d_q0, h->d_v0, h->stream);
   ocpKktErrorReduce(h->B, h->batch, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1162,8 +1180,10 @@ int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_e
   int rc = setDev(h); if (rc) return rc;
   if ((rc = discretize(h, t))) return rc;
   const int M = h->M();
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, 0, h->stream);
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, h->d_q0, h->d_v0, true, h->stream);
+  OcpLaunch<DQ>::parnmpcImpulseCondense(h->B, h->batch, h->n_impulse, true, h->d_q0, h->d_v0, h->stream);
   ocpKktErrorReduce(h->B, h->batch, h->stream);
   HIP_TRY(hipGetLastError());
   std::vector<double> e(h->batch);

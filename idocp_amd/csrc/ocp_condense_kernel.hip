@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // DIMF >= 0 is only launched on event-free chains (launchCondense): no impulse stages, no switching constraints
   constexpr bool PLAIN = (DIMF >= 0);
   const bool impulse = PLAIN ? false : (nd->kind == 1);
+  if (BWD && impulse) return;                       // ParNMPC: the backward-Euler impulse stage is K9i (parnmpc_event_kernels.hip)
   const int sw_dimi = PLAIN ? 0 : nd->sw_dimi;
   const int i = nd->level;                          // constraint gating level
   const double dt = nd->dt;                         // scaling of cost / constraints / dynamics multipliers (1 on impulse stages)

@@ -64,13 +64,17 @@ struct OcpLayout {
   static constexpr int SWC = roundUp16(W_m + NF);
   // ---- ParNMPC (backward correction) ----
   // coarse / corrected iterate of a stage (SplitBackwardCorrection's s_new): lmd gmm u q v
-  static constexpr int N_LMD = 0, N_GMM = NV, N_U = 2 * NV, N_Q = N_U + NU, N_V = N_Q + NQ;
-  static constexpr int SNEW = roundUp16(N_V + NV);
+  // (event stages: N_U holds f on an impulse stage; N_XI the switching multiplier xi of an aux stage / mu of an impulse stage)
+  static constexpr int N_LMD = 0, N_GMM = NV, N_U = 2 * NV, N_Q = N_U + NU, N_V = N_Q + NQ, N_XI = N_V + NV;
+  static constexpr int SNEW = roundUp16(N_XI + NF);
   // the columns of the stage's KKT-matrix inverse the correction sweeps need (split_backward_correction.hxx:84-140),
   // column-major with leading dimension NK = 2 NX + NU (rows: lmd gmm | u q v):
   //   C0 = KKT_inv[:, 0 : NX]  (auxMat, forward corrections),  C1 = KKT_inv[:, NK - NX : NK]  (backward corrections)
   static constexpr int NK = 2 * NX + NU, I_C0 = 0, I_C1 = NK * NX;
-  static constexpr int KINV = roundUp16(2 * NK * NX);
+  // event stages (aux with the switching-constraint rows, impulse): rows  lmd gmm | xi or mu (ni) | u or f (nw) | q v,
+  // nK = 2 NX + ni + nw <= NKG; same two column blocks with leading dimension NKG, C1 at I_C1G
+  static constexpr int NKG = 2 * NX + NU + NF, I_C1G = NKG * NX;
+  static constexpr int KINV = roundUp16(2 * NKG * NX);
   static constexpr int AUX = roundUp16(NX * NX);
   static constexpr int XRES = roundUp16(NX);
 };
@@ -92,6 +96,25 @@ struct OcpNode {
   int sw_dimi, sw_active[IDOCP_MAX_CONTACTS], sw_row[IDOCP_MAX_CONTACTS];     // switching constraint carried by this stage
   double sw_dt1, sw_dt2, sw_point[IDOCP_MAX_CONTACTS][3];
 };
+
+// ParNMPC: shape of a stage's KKT matrix (SplitBackwardCorrection / ImpulseSplitBackwardCorrection::dimKKT_)
+struct ParnmpcShape {
+  bool general, impulse;   // general = impulse stage, or aux stage with switching-constraint rows
+  int ni, nw, nk, ld, c1;  // extra constraint rows, size of the u / f block, dimKKT, leading dimension and offset of C1 in the kinv record
+};
+template <typename L>
+__host__ __device__ inline ParnmpcShape parnmpcShape(const OcpNode& nd) {
+  ParnmpcShape s;
+  s.impulse = nd.kind == 1;
+  const bool aux = nd.kind == 2 && nd.sw_dimi > 0;
+  s.general = s.impulse || aux;
+  s.ni = s.impulse ? nd.dimf : (aux ? nd.sw_dimi : 0);
+  s.nw = s.impulse ? nd.dimf : L::NU;
+  s.nk = 2 * L::NX + s.ni + s.nw;
+  s.ld = s.general ? L::NKG : L::NK;
+  s.c1 = s.general ? L::I_C1G : L::I_C1;
+  return s;
+}
 
 struct OcpProblem {
   int N, batch;            // N = grid intervals (N_ideal)
@@ -118,6 +141,7 @@ struct OcpBuffers {
   const OcpProblem* prob;
   const OcpNode* nodes;  // [M] the chain
   const int* impulse_pos; // chain positions of the impulse stages
+  const int* general_pos; // ParNMPC: chain positions of the stages with a general KKT shape (aux with switching rows, impulse)
   const double* q_ref;   // [M][NQ] reference configuration of every stage of the chain (time-varying cost)
   // per-stage arrays, indexed [instance][slot] (NS slots per instance)
   double* sol;           // [batch][NS][SOL]

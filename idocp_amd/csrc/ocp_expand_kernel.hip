@@ -107,14 +107,31 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const int dimf = nd->dimf, dimvf = NV + dimf;
   // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145): dxi = M dx + m
-  if (nd->sw_dimi > 0 && lane >= 32 && lane < 32 + nd->sw_dimi) {
+  const bool bimp = P->backward_euler && nd->kind == 1;      // ParNMPC impulse stage: df, dmu come from the backward correction
+  if (bimp) {
+    // ImpulseDynamicsBackwardEuler::computeCondensedPrimalDirection (impulse_dynamics_backward_euler.hxx:98-104):
+    // ddv = - Minv ImD + Fvq dq + Fvf df   (K9i left Fvq / Fvf in the kkt record, du holds df in packed rows)
+    const double* __restrict__ kk = B.kkt + rec * L::KKT;
+    if (lane < NF) dfs[lane] = dd[L::D_F + lane];
+    if (lane < NV) {
+      double acc = -ee[L::E_MJIDC + lane];
+      double t1 = 0.0;
+      for (int c = 0; c < NV; ++c) t1 += kk[L::K_FVQ + lane + NV * c] * dx[c];
+      acc += t1;
+      double t2 = 0.0;
+      for (int j = 0; j < dimf; ++j) t2 += kk[L::K_FVU + lane + NV * j] * du[j];
+      acc += t2;
+      dd[L::D_A + lane] = acc;
+    }
+  }
+  if (!P->backward_euler && nd->sw_dimi > 0 && lane >= 32 && lane < 32 + nd->sw_dimi) {
     const int l = lane - 32;
     const double* __restrict__ W = B.swc + rec * L::SWC;
     double acc = W[L::W_m + l];
     for (int c = 0; c < NX; ++c) acc += W[L::W_M + l + NF * c] * dx[c];
     dd[L::D_XI + l] = acc;
   }
-  if (lane < dimvf) {
+  if (!bimp && lane < dimvf) {
     const int r = lane;
     double acc = -ee[L::E_MJIDC + r];
     for (int c = 0; c < NX; ++c) acc -= ee[L::E_MJD + r + NVF * c] * dx[c];
@@ -194,7 +211,8 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   double* __restrict__ dd = B.dir + rec * L::DIR;
   double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ ee = B.exp + rec * L::EXP;
-  const int dimf = nd->dimf, dimvf = NV + dimf;
+  const bool bimp = bwd && nd->kind == 1;           // ParNMPC impulse stage (K9i filled the exp record): only the dv rows, dmu from K10b
+  const int dimf = nd->dimf, dimvf = bimp ? NV : NV + dimf;
   if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
   if (lane < 6) dlh[lane] = dd[L::D_LMD + lane];
   if (stage) {

@@ -20,6 +20,9 @@ struct OcpLaunch {
   static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
   static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9b
+  static void parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n_impulse, bool residual, const double* q0, const double* v0,
+                                     hipStream_t st);                                               // K9i: impulse stages of a ParNMPC chain
+  static void parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st); // K9g: aux (switching rows) and impulse stages
   static void parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, bool has_terminal, const double* q0, const double* v0,
                            hipStream_t st);                                                       // 0 S5, 1 K10a, 2 S6, 3 K10b, 4 init aux_mat
   static void parnmpcHalo(const OcpBuffers& B, long batch, int kind, bool do_import, double* buf, double* q0, double* v0, hipStream_t st);

@@ -94,7 +94,9 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
     __syncthreads();
     if (lane < NV) {
       const double vin = s[L::S_V + lane], ain = s[L::S_A + lane];
-      s_v[lane] = impulse ? (pass == 0 ? 0.0 : vin + ain) : vin;
+      // kinematic pass of an impulse stage: post-impact velocity = v + dv (forward Euler, impulse_split_ocp.hxx:47) or v itself
+      // (backward Euler: v IS the post-impact velocity, impulse_split_parnmpc.hxx:43)
+      s_v[lane] = impulse ? (pass == 0 ? 0.0 : (P->backward_euler ? vin : vin + ain)) : vin;
       s_a[lane] = impulse ? (pass == 0 ? ain : 0.0) : ain;
     }
     __syncthreads();

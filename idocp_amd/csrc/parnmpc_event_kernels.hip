@@ -1,0 +1,490 @@
+// ParNMPC: the event stages of a horizon with discrete events (ParNMPCDiscretizer chain, see ocp_capi.hip).
+//
+//   lift stage      an ordinary backward-Euler stage with its own time step: K5a / K5b<BWD> / K9b as they are
+//   aux stage       ordinary stage + the switching constraint P(q) = 0 of the impulse that follows (switching_constraint.hxx:
+//                   8-21): K5s produces P, Pq; K5b<BWD> adds Pq^T xi; its KKT matrix has dimi more constraint rows
+//                   (SplitKKTMatrixInverter::invert with Pq, split_kkt_matrix_inverter.hxx:110-166)  -> K9g below
+//   impulse stage   ImpulseSplitParNMPC::linearizeOCP (impulse_split_parnmpc.hxx:33-60): impulse cost + impulse friction cone,
+//                   linearizeImpulseBackwardEuler / condenseImpulseBackwardEuler (impulse_state_equation.hxx:59-111),
+//                   ImpulseDynamicsBackwardEuler::linearizeImpulseDynamics / condenseImpulseDynamics
+//                   (impulse_dynamics_backward_euler.hxx:20-97)                                  -> K9i below
+//                   and its KKT matrix in (lmd, gmm, mu | f, q, v) (ImpulseSplitKKTMatrixInverter::invert,
+//                   impulse_split_kkt_matrix_inverter.hxx:34-80)                                  -> K9g below
+//
+// K9i writes the impulse stage into the SAME records as a regular stage, re-using their blocks
+//   kkt:  K_QXX = Qxx, K_QXU = [Qqf; 0] (NX x ni), K_QUU = Qff (ni x ni), K_FQQ = Fqq6, K_FVQ = Fvq, K_FVV = -I,
+//         K_FVU = Fvf (NV x ni), K_LX = (lq, lv), K_LU = lf, K_FX = (Fq, Fv)
+//   swc:  W_P = V (contact-velocity residual), W_PHIX = [Vq Vv]
+//   exp:  what K6 / K7 need for computeCondensed{Primal,Dual}Direction of the impulse stage
+// so that K9g treats aux and impulse stages alike:  J = [F ; C], C = the W_PHIX rows on the (q, v) columns,
+// Q over (w, q, v) with w = u (aux) or f (impulse).  These stages are few (two per touch-down), the kernels are written
+// for clarity, not for speed.
+#include <hip/hip_runtime.h>
+
+#include "dev_dense.hpp"
+#include "dev_lie.hpp"
+#include "ocp_device.hpp"
+#include "ocp_launch.hpp"
+
+namespace idocp_dev {
+
+namespace {
+
+// LinearizedImpulseFrictionCone: same cone as LinearizedFrictionCone (linearized_friction_cone.cpp:25-29)
+__device__ __forceinline__ double coneJac(double mu, int r, int x) {
+  const double m2 = mu * 0.70710678118654752440;
+  if (x == 2) return r == 0 ? -1.0 : -m2;
+  if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
+  return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
+}
+
+// inverse of an SPD n x n block (n <= 48) by Gauss-Jordan, ping-pong between A and W (both ld), 256 threads
+__device__ __forceinline__ void spdInverseBlock(double* A, double* W, int ld, int n, int tid, int* ok) {
+  double* src = A;
+  double* dst = W;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const double p = src[k + k * ld];
+    if (tid == 0 && !(p > 0.0)) *ok = 0;
+    const double ip = 1.0 / p;
+    for (int e = tid; e < n * n; e += 256) {
+      const int j = e / n, i = e - j * n;
+      const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
+      dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
+    }
+    __syncthreads();
+    double* t = src; src = dst; dst = t;
+  }
+  if (src != A) {
+    for (int e = tid; e < n * n; e += 256) { const int j = e / n, i = e - j * n; A[i + j * ld] = src[i + j * ld]; }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- K9i ----
+template <typename D, bool RESIDUAL>
+__global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
+  __shared__ double Mi[NV * NV], Fvq[NV * NV], Fvf[NV * NF], Vq[NF * NV], Vv[NF * NV], dIq[NV * NV];
+  __shared__ double lq[NV], lv[NV], ldv[NV], lf[NF], Fq[NV], Fv[NV], ImD[NV], Vr[NF], MiI[NV], qdd[NV], mu_p[NF], f_p[NF], err[256];
+  __shared__ double Qff[NF * NF], Jq6[36], Fqq6[36], FqqI[36], FqqP[36], Fq6[6];
+  __shared__ int s_ok;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int tid = threadIdx.x;
+  const int n_imp = gridDim.y;
+  (void)n_imp;
+  const long b = blockIdx.x;
+  const int pos = B.impulse_pos[blockIdx.y];
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const int ni = nd->dimf;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  const double* __restrict__ sn = B.sol + (b * P->NS + nd->next) * L::SOL;
+  const double* __restrict__ sp = nd->prev >= 0 ? B.sol + (b * P->NS + nd->prev) * L::SOL : nullptr;
+  const double* __restrict__ lin = B.lin + rec * L::LIN;
+  const double* __restrict__ zz = B.lie + rec * L::LIE;
+  const double* __restrict__ qref = B.q_ref + (long)pos * NQ;
+  const double* __restrict__ slack = B.slack + rec * L::CON;
+  const double* __restrict__ dual = B.dual + rec * L::CON;
+  const bool cone = P->use_impulse_friction_cone != 0;
+  const double vref_on = nd->vref_on;
+  if (tid == 0) s_ok = 1;
+  // ---- load: dImD/dq, M, Vq, Vv, ImD, V (lin record of the impulse pass of K5a), the Lie-group blocks ----
+  for (int e = tid; e < NV * NV; e += 256) { const int c = e / NV, r = e - c * NV; dIq[e] = lin[L::L_DIDC + r + NVF * c]; Mi[e] = lin[L::L_M + e]; }
+  for (int e = tid; e < ni * NV; e += 256) {
+    const int c = e / ni, j = e - c * ni;
+    Vq[j + NF * c] = lin[L::L_DIDC + (NV + j) + NVF * c];
+    Vv[j + NF * c] = lin[L::L_DIDC + (NV + j) + NVF * (NV + c)];
+  }
+  if (tid < NV) ImD[tid] = lin[L::L_IDC + tid];
+  if (tid < ni) Vr[tid] = lin[L::L_IDC + NV + tid];
+  if (tid < 36) { Jq6[tid] = zz[L::Z_JQ + tid]; FqqP[tid] = zz[L::Z_FQQP + tid]; FqqI[tid] = zz[L::Z_FQQI + tid]; Fqq6[tid] = zz[L::Z_FQQ + tid]; }
+  if (tid < 6) { Fq6[tid] = zz[L::Z_FQ6 + tid]; qdd[tid] = zz[L::Z_QDIFF + tid]; }
+  if (tid < NC && nd->active[tid]) for (int x = 0; x < 3; ++x) { mu_p[nd->row_of[tid] + x] = s[L::S_MU + 3 * tid + x]; f_p[nd->row_of[tid] + x] = s[L::S_F + 3 * tid + x]; }
+  for (int e = tid; e < NF * NF; e += 256) Qff[e] = 0.0;
+  __syncthreads();
+  // ---- impulse cost, state equation, multipliers of the impulse dynamics and of the velocity constraint: gradients ----
+  if (tid < NV) {
+    const int r = tid;
+    const double q_r = s[L::S_Q + (r < 6 ? r : r + 1)];
+    (void)q_r;
+    const double vr = s[L::S_V + r], dvr = s[L::S_A + r];
+    const double lmd = s[L::S_LMD + r], gmm = s[L::S_GMM + r], lmdn = sn[L::S_LMD + r], gmmn = sn[L::S_GMM + r];
+    const double vpr = sp ? sp[L::S_V + r] : v0[b * NV + r];
+    double a_q, a_v, a_dv;
+    if (r < 6) {
+      a_q = 0.0;
+      for (int m2 = 0; m2 < 6; ++m2) a_q += Jq6[m2 + 6 * r] * P->qi_weight[m2] * qdd[m2];
+      double t1 = 0.0;
+      for (int m2 = 0; m2 < 6; ++m2) t1 += Fqq6[m2 + 6 * r] * sn[L::S_LMD + m2] + FqqP[m2 + 6 * r] * s[L::S_LMD + m2];
+      a_q += t1;
+      Fq[r] = Fq6[r];
+    } else {
+      const double qpr = sp ? sp[L::S_Q + r + 1] : q0[b * NQ + r + 1];
+      a_q = P->qi_weight[r] * (s[L::S_Q + r + 1] - qref[r + 1]) + lmdn - lmd;
+      Fq[r] = qpr - s[L::S_Q + r + 1];
+    }
+    a_v = P->vi_weight[r] * (vr - vref_on * P->v_ref[r]) - gmm + gmmn;
+    a_dv = P->dvi_weight[r] * dvr + gmm;
+    Fv[r] = vpr - vr + dvr;
+    // + dImD/dq^T beta, + M^T beta, + Vq^T mu, + Vv^T mu
+    double dq = 0.0, dm = 0.0;
+    for (int m = 0; m < NV; ++m) { dq += dIq[m + NV * r] * s[L::S_BETA + m]; dm += Mi[m + NV * r] * s[L::S_BETA + m]; }
+    a_q += dq; a_dv += dm;
+    double vq = 0.0, vv = 0.0;
+    for (int j = 0; j < ni; ++j) { vq += Vq[j + NF * r] * mu_p[j]; vv += Vv[j + NF * r] * mu_p[j]; }
+    a_q += vq; a_v += vv;
+    lq[r] = a_q; lv[r] = a_v; ldv[r] = a_dv;
+  }
+  // lf of the contacts that touch down: impulse force cost + cone + (- Vv beta)
+  double e_ipm = 0.0;
+  if (tid >= 64 && tid < 64 + NC && nd->active[tid - 64]) {
+    const int c = tid - 64, row = nd->row_of[c];
+    double rr[5], ddv[5];
+    for (int r = 0; r < 5; ++r) {
+      const int idx = L::C_FRIC + 5 * c + r;
+      double g = 0.0;
+      for (int x = 0; x < 3; ++x) g += coneJac(P->mu, r, x) * s[L::S_F + 3 * c + x];
+      const double sl = slack[idx], du = dual[idx];
+      const double res = g + sl, duality = sl * du - P->barrier;
+      if (RESIDUAL) { rr[r] = du; ddv[r] = 0.0; e_ipm += res * res + duality * duality; }
+      else { rr[r] = du + (du * res - duality) / sl; ddv[r] = du / sl; }
+    }
+    for (int x = 0; x < 3; ++x) {
+      double a = P->fi_weight[c][x] * (s[L::S_F + 3 * c + x] - P->fi_ref[c][x]);
+      if (cone) for (int r = 0; r < 5; ++r) a += coneJac(P->mu, r, x) * rr[r];
+      double vb = 0.0;
+      for (int m = 0; m < NV; ++m) vb += Vv[(row + x) + NF * m] * s[L::S_BETA + m];
+      lf[row + x] = a - vb;
+      if (!RESIDUAL) {
+        for (int y = 0; y < 3; ++y) {
+          double h = (x == y) ? P->fi_weight[c][x] : 0.0;
+          if (cone) for (int r = 0; r < 5; ++r) h += coneJac(P->mu, r, x) * ddv[r] * coneJac(P->mu, r, y);
+          Qff[(row + x) + NF * (row + y)] = h;
+        }
+      }
+    }
+    if (!cone) e_ipm = 0.0;
+  }
+  __syncthreads();
+  if (RESIDUAL) {
+    // ImpulseSplitParNMPC::squaredNormKKTResidual (impulse_split_parnmpc.hxx:114-124)
+    double e = e_ipm;
+    if (tid < NV) e += lq[tid] * lq[tid] + lv[tid] * lv[tid] + ldv[tid] * ldv[tid] + Fq[tid] * Fq[tid] + Fv[tid] * Fv[tid] + ImD[tid] * ImD[tid];
+    if (tid < ni) e += lf[tid] * lf[tid] + Vr[tid] * Vr[tid];
+    err[tid] = e;
+    __syncthreads();
+    if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.err_stage[rec] = acc; }
+    return;
+  }
+  double* __restrict__ kk = B.kkt + rec * L::KKT;
+  double* __restrict__ ee = B.exp + rec * L::EXP;
+  double* __restrict__ W = B.swc + rec * L::SWC;
+  // ---- condenseImpulseBackwardEuler: Fqq = Fqq_inv Fqq(q_prev, q), Fq.head(6) = Fqq_inv Fq.head(6) ----
+  if (tid < 36) {
+    const int c = tid / 6, r = tid - 6 * c;
+    double acc = 0.0;
+    for (int m = 0; m < 6; ++m) acc += FqqI[r + 6 * m] * FqqP[m + 6 * c];
+    kk[L::K_FQQ + tid] = acc;
+    kk[L::K_FQV + tid] = 0.0;
+    ee[L::E_FQQPI + tid] = FqqI[tid];
+  } else if (tid >= 64 && tid < 70) {
+    const int r = tid - 64;
+    double acc = 0.0;
+    for (int m = 0; m < 6; ++m) acc += FqqI[r + 6 * m] * Fq6[m];
+    Fq[r] = acc;
+  }
+  // ---- Minv (Robot::computeMinv), Fvq = -Minv dImD/dq, Fvf = Minv Vv^T, Minv ImD ----
+  __syncthreads();
+  if (tid < 64) spdInverseRows<NV>(Mi, NV, NV, tid, &s_ok);
+  __syncthreads();
+  for (int e = tid; e < NV * NV; e += 256) {
+    const int c = e / NV, r = e - c * NV;
+    double acc = 0.0;
+    for (int m = 0; m < NV; ++m) acc += Mi[r + NV * m] * dIq[m + NV * c];
+    Fvq[e] = -acc;
+  }
+  for (int e = tid; e < NV * ni; e += 256) {
+    const int j = e / NV, r = e - j * NV;
+    double acc = 0.0;
+    for (int m = 0; m < NV; ++m) acc += Mi[r + NV * m] * Vv[j + NF * m];
+    Fvf[r + NV * j] = acc;
+  }
+  if (tid >= 192 && tid < 192 + NV) {
+    const int r = tid - 192;
+    double acc = 0.0;
+    for (int m = 0; m < NV; ++m) acc += Mi[r + NV * m] * ImD[m];
+    MiI[r] = acc;
+  }
+  __syncthreads();
+  if (tid < NV) ldv[tid] -= P->dvi_weight[tid] * MiI[tid];            // data.ldv = ldv - Qdvdv Minv ImD
+  __syncthreads();
+  // ---- condensed blocks (Qdvq = Qdvdv Fvq, Qdvf = Qdvdv Fvf) ----
+  // Qxx = [Qqq 0; 0 Qvv]
+  for (int e = tid; e < NX * NX; e += 256) {
+    const int c = e / NX, r = e - c * NX;
+    double v = 0.0;
+    if (r < NV && c < NV) {
+      if (r < 6 && c < 6) { for (int m2 = 0; m2 < 6; ++m2) v += Jq6[m2 + 6 * r] * P->qi_weight[m2] * Jq6[m2 + 6 * c]; }
+      else if (r == c) v = P->qi_weight[r];
+      double acc = 0.0;
+      for (int m = 0; m < NV; ++m) acc += Fvq[m + NV * r] * (P->dvi_weight[m] * Fvq[m + NV * c]);
+      v += acc;
+    } else if (r == c) {
+      v = P->vi_weight[r - NV];
+    }
+    kk[L::K_QXX + e] = v;
+  }
+  // Qxf = [Qqf; 0] in the place of Qxu, Qff in the place of Quu, Fvf in the place of Fvu
+  for (int e = tid; e < NX * NU; e += 256) {
+    const int j = e / NX, r = e - j * NX;
+    double v = 0.0;
+    if (r < NV && j < ni) for (int m = 0; m < NV; ++m) v += Fvq[m + NV * r] * (P->dvi_weight[m] * Fvf[m + NV * j]);
+    kk[L::K_QXU + e] = v;
+  }
+  for (int e = tid; e < NU * NU; e += 256) {
+    const int c = e / NU, r = e - c * NU;
+    double v = 0.0;
+    if (r < ni && c < ni) {
+      v = Qff[r + NF * c];
+      double acc = 0.0;
+      for (int m = 0; m < NV; ++m) acc += Fvf[m + NV * r] * (P->dvi_weight[m] * Fvf[m + NV * c]);
+      v += acc;
+    } else if (r == c) v = 1.0;
+    kk[L::K_QUU + e] = v;
+  }
+  for (int e = tid; e < NV * NV; e += 256) {
+    const int c = e / NV, r = e - c * NV;
+    kk[L::K_FVQ + e] = Fvq[e];
+    kk[L::K_FVV + e] = (r == c) ? -1.0 : 0.0;
+    ee[L::E_MJ + r + NVF * c] = Mi[e];
+    ee[L::E_QAFQV + r + NVF * c] = P->dvi_weight[r] * Fvq[e];
+    ee[L::E_QAFQV + r + NVF * (NV + c)] = 0.0;
+  }
+  for (int e = tid; e < NV * NU; e += 256) {
+    const int j = e / NV, r = e - j * NV;
+    kk[L::K_FVU + e] = j < ni ? Fvf[e] : 0.0;
+    ee[L::E_QAFU + r + NVF * j] = j < ni ? P->dvi_weight[r] * Fvf[e] : 0.0;
+  }
+  // gradients, residuals
+  if (tid < NV) {
+    const int r = tid;
+    double aq = 0.0;
+    for (int m = 0; m < NV; ++m) aq += Fvq[m + NV * r] * ldv[m];
+    kk[L::K_LX + r] = lq[r] + aq;
+    kk[L::K_LX + NV + r] = lv[r];
+    kk[L::K_FX + r] = Fq[r];
+    kk[L::K_FX + NV + r] = Fv[r] - MiI[r];
+    ee[L::E_MJIDC + r] = MiI[r];
+    ee[L::E_LAF + r] = ldv[r];
+  }
+  if (tid >= 64 && tid < 64 + NU) {
+    const int j = tid - 64;
+    double v = 0.0;
+    if (j < ni) { v = lf[j]; double af = 0.0; for (int m = 0; m < NV; ++m) af += Fvf[m + NV * j] * ldv[m]; v += af; }
+    kk[L::K_LU + j] = v;
+  }
+  // the contact-velocity constraint rows
+  if (tid >= 128 && tid < 128 + NF) W[L::W_P + tid - 128] = (tid - 128 < ni) ? Vr[tid - 128] : 0.0;
+  for (int e = tid; e < NF * NX; e += 256) {
+    const int c = e / NF, j = e - c * NF;
+    W[L::W_PHIX + e] = j < ni ? (c < NV ? Vq[j + NF * c] : Vv[j + NF * (c - NV)]) : 0.0;
+  }
+  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 2000 + pos;
+}
+
+// ---------------------------------------------------------------------------------------------------- K9g ----
+// KKT inverse + coarse update of an aux stage (switching rows) or an impulse stage: dense, run-time sizes
+//   nr = NX + ni constraint rows, nQ = nw + NX variables, nK = nr + nQ.
+template <typename D>
+__global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NC = D::NC, LD = NX + NF;      // LD = 48: leading dimension of every LDS block
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_ok;
+  double* Q = sm;                       // Q^-1
+  double* J = Q + LD * LD;              // J (nr x nQ)
+  double* JQ = J + LD * LD;             // J Q^-1
+  double* Sm = JQ + LD * LD;            // S, S^-1
+  double* TR = Sm + LD * LD;            // S^-1 J Q^-1
+  double* Wk = TR + LD * LD;            // scratch
+  double* r1 = Wk + LD * LD;            // constraint residuals (nr)
+  double* r2 = r1 + LD;                 // gradients (nQ)
+  double* t1 = r2 + LD;
+  double* dir = t1 + LD;                // 2 LD
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x;
+  const int pos = B.general_pos[blockIdx.y];
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const ParnmpcShape sh = parnmpcShape<L>(*nd);
+  const int ni = sh.ni, nw = sh.nw, nr = NX + ni, nQ = nw + NX, nK = sh.nk;
+  const bool impulse = sh.impulse;
+  const bool last = P->has_terminal && (pos == M - 2);
+  const double dt = nd->dt;
+  const long rec = b * P->NS + nd->slot;
+  const double* __restrict__ kk = B.kkt + rec * L::KKT;
+  const double* __restrict__ W = B.swc + rec * L::SWC;
+  const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
+  double* __restrict__ ki = B.kinv + rec * L::KINV;
+  if (tid == 0) s_ok = 1;
+  // ---- Q over (w, q, v): [Qww Qwx; Qxw Qxx + aux_mat_next] ----
+  for (int e = tid; e < LD * LD; e += 256) { Q[e] = 0.0; J[e] = 0.0; }
+  __syncthreads();
+  for (int e = tid; e < nQ * nQ; e += 256) {
+    const int c = e / nQ, r = e - c * nQ;
+    double v;
+    if (r < nw && c < nw) v = kk[L::K_QUU + r + NU * c];
+    else if (r < nw) v = kk[L::K_QXU + (c - nw) + NX * r];
+    else if (c < nw) v = kk[L::K_QXU + (r - nw) + NX * c];
+    else {
+      int rr = r - nw, cc = c - nw;
+      const double ax = last ? 0.0 : aux[rr + NX * cc];
+      if (rr >= NV && cc < NV) { const int t = rr; rr = cc; cc = t; }      // Qvq = Qqv^T
+      v = kk[L::K_QXX + rr + NX * cc] + ax;
+    }
+    Q[r + LD * c] = v;
+  }
+  // ---- J = [0 Fqq Fqv; Fvw Fvq Fvv; 0 Cq Cv] ----
+  for (int e = tid; e < nr * nQ; e += 256) {
+    const int c = e / nr, r = e - c * nr;
+    double v = 0.0;
+    if (r < NV) {
+      if (c >= nw && c < nw + NV) { const int cq = c - nw; v = (r < 6 && cq < 6) ? kk[L::K_FQQ + r + 6 * cq] : ((r >= 6 && r == cq) ? -1.0 : 0.0); }
+      else if (c >= nw + NV && !impulse) { const int cv = c - nw - NV; v = (r < 6 && cv < 6) ? kk[L::K_FQV + r + 6 * cv] : ((r >= 6 && r == cv) ? dt : 0.0); }
+    } else if (r < NX) {
+      const int rv = r - NV;
+      if (c < nw) v = kk[L::K_FVU + rv + NV * c];
+      else if (c < nw + NV) v = kk[L::K_FVQ + rv + NV * (c - nw)];
+      else v = kk[L::K_FVV + rv + NV * (c - nw - NV)];
+    } else if (c >= nw) {
+      v = W[L::W_PHIX + (r - NX) + NF * (c - nw)];
+    }
+    J[r + LD * c] = v;
+  }
+  if (tid < nr) r1[tid] = tid < NX ? kk[L::K_FX + tid] : W[L::W_P + tid - NX];
+  if (tid >= 64 && tid < 64 + nQ) { const int r = tid - 64; r2[r] = r < nw ? kk[L::K_LU + r] : kk[L::K_LX + r - nw]; }
+  __syncthreads();
+  // ---- Q^-1, JQ = J Q^-1, S = J JQ^T, S^-1, TR = S^-1 JQ ----
+  spdInverseBlock(Q, Wk, LD, nQ, tid, &s_ok);
+  for (int e = tid; e < nr * nQ; e += 256) {
+    const int c = e / nr, r = e - c * nr;
+    double acc = 0.0;
+    for (int m = 0; m < nQ; ++m) acc += J[r + LD * m] * Q[m + LD * c];
+    JQ[r + LD * c] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < nr * nr; e += 256) {
+    const int c = e / nr, r = e - c * nr;
+    double acc = 0.0;
+    for (int m = 0; m < nQ; ++m) acc += J[r + LD * m] * JQ[c + LD * m];
+    Sm[r + LD * c] = acc;
+  }
+  __syncthreads();
+  spdInverseBlock(Sm, Wk, LD, nr, tid, &s_ok);
+  for (int e = tid; e < nr * nQ; e += 256) {
+    const int c = e / nr, r = e - c * nr;
+    double acc = 0.0;
+    for (int m = 0; m < nr; ++m) acc += Sm[r + LD * m] * JQ[m + LD * c];
+    TR[r + LD * c] = acc;
+  }
+  if (tid >= 256 - LD && tid - (256 - LD) < nr) {
+    const int r = tid - (256 - LD);
+    double acc = r1[r];
+    for (int m = 0; m < nQ; ++m) acc -= JQ[r + LD * m] * r2[m];
+    t1[r] = acc;
+  }
+  __syncthreads();
+  // ---- coarse direction: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - JQ r2) ----
+  if (tid < nr) {
+    double acc = 0.0;
+    for (int m = 0; m < nr; ++m) acc -= Sm[tid + LD * m] * r1[m];
+    for (int m = 0; m < nQ; ++m) acc += TR[tid + LD * m] * r2[m];
+    dir[tid] = acc;
+  } else if (tid >= 64 && tid < 64 + nQ) {
+    const int r = tid - 64;
+    double acc = 0.0;
+    for (int m = 0; m < nQ; ++m) acc += Q[r + LD * m] * r2[m];
+    for (int m = 0; m < nr; ++m) acc += TR[m + LD * r] * t1[m];
+    dir[LD + r] = acc;
+  }
+  // ---- BR[:, nQ - NX :] = Q^-1[:, nQ - NX :] - TR^T JQ[:, nQ - NX :]  -> Wk (nQ x NX) ----
+  for (int e = tid; e < nQ * NX; e += 256) {
+    const int c = e / nQ, r = e - c * nQ;
+    double acc = Q[r + LD * (nw + c)];
+    for (int m = 0; m < nr; ++m) acc -= TR[m + LD * r] * JQ[m + LD * (nw + c)];
+    Wk[r + LD * c] = acc;
+  }
+  __syncthreads();
+  // ---- column blocks of the inverse, leading dimension NKG: C0 = KKT_inv[:, 0:NX], C1 = KKT_inv[:, nK-NX:nK] ----
+  for (int e = tid; e < nK * NX; e += 256) {
+    const int c = e / nK, r = e - c * nK;
+    double c0, c1;
+    if (r < nr) {
+      c0 = -Sm[r + LD * c];
+      c1 = TR[r + LD * (nw + c)];
+    } else {
+      const int rq = r - nr;
+      c0 = TR[c + LD * rq];
+      c1 = Wk[rq + LD * c];
+    }
+    ki[L::I_C0 + r + L::NKG * c] = c0;
+    ki[L::I_C1G + r + L::NKG * c] = c1;
+  }
+  // ---- s_new = s - direction (split_backward_correction.hxx:49-63, impulse_split_backward_correction.hxx:43-55) ----
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  double* __restrict__ sn = B.snew + rec * L::SNEW;
+  const double* dw = dir + LD;              // (dw, dq, dv)
+  if (tid < NV) {
+    sn[L::N_LMD + tid] = s[L::S_LMD + tid] - dir[tid];
+    sn[L::N_GMM + tid] = s[L::S_GMM + tid] - dir[NV + tid];
+    sn[L::N_V + tid] = s[L::S_V + tid] - dw[nw + NV + tid];
+    if (tid >= 6) sn[L::N_Q + tid + 1] = s[L::S_Q + tid + 1] - dw[nw + tid];
+  }
+  if (!impulse) {
+    if (tid >= 64 && tid < 64 + NU) sn[L::N_U + tid - 64] = s[L::S_U + tid - 64] - dw[tid - 64];
+    if (tid >= 96 && tid < 96 + ni) sn[L::N_XI + tid - 96] = s[L::S_XI + tid - 96] - dir[NX + tid - 96];
+  } else if (tid >= 64 && tid < 64 + NC && nd->active[tid - 64]) {
+    const int c = tid - 64, row = nd->row_of[c];
+    for (int k = 0; k < 3; ++k) {
+      sn[L::N_U + row + k] = s[L::S_F + 3 * c + k] - dw[row + k];             // f, packed rows
+      sn[L::N_XI + row + k] = s[L::S_MU + 3 * c + k] - dir[NX + row + k];     // mu, packed rows
+    }
+  }
+  if (tid == 128) {
+    double qn[7];
+    lieIntegrateBase(s + L::S_Q, dw + nw, -1.0, qn);
+    for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
+  }
+  if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1000 + pos;
+}
+
+template <typename D>
+void OcpLaunch<D>::parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n_impulse, bool residual, const double* q0, const double* v0,
+                                          hipStream_t st) {
+  if (n_impulse <= 0) return;
+  if (residual) hipLaunchKernelGGL((parnmpc_impulse_condense_kernel<D, true>), dim3((unsigned)batch, (unsigned)n_impulse), dim3(256), 0, st, B, q0, v0);
+  else hipLaunchKernelGGL((parnmpc_impulse_condense_kernel<D, false>), dim3((unsigned)batch, (unsigned)n_impulse), dim3(256), 0, st, B, q0, v0);
+}
+
+template <typename D>
+void OcpLaunch<D>::parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st) {
+  if (n_general <= 0) return;
+  constexpr int LD = D::NX + D::NF;
+  const size_t smem = (6 * LD * LD + 5 * LD + 8) * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)parnmpc_kkt_inverse_general_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((parnmpc_kkt_inverse_general_kernel<D>), dim3((unsigned)batch, (unsigned)n_general), dim3(256), smem, st, B);
+}
+
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcImpulseCondense(const OcpBuffers&, long, int, bool, const double*, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcEventInverse(const OcpBuffers&, long, int, hipStream_t);
+
+}  // namespace idocp_dev

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   const long b = unit / (M - 1);
   const int pos = (int)(unit - b * (M - 1));
   const OcpNode* __restrict__ nd = B.nodes + pos;
+  if (parnmpcShape<L>(*nd).general) return;        // aux stages with switching rows and impulse stages: parnmpc_event_kernels.hip
   const bool last = P->has_terminal && (pos == M - 2);
   const double dt = nd->dt;
   const long rec = b * P->NS + nd->slot;
@@ -308,10 +309,10 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
 }
 
 // y[0:rows] = A[r0 : r0 + rows, 0 : NX] x  for a column block A (ld NK) in global memory; one lane per row
-template <int NX, int NK>
-__device__ __forceinline__ double blockRowDot(const double* __restrict__ A, int row, const double* x) {
+template <int NX>
+__device__ __forceinline__ double blockRowDot(const double* __restrict__ A, int ld, int row, const double* x) {
   double acc = 0.0;
-  for (int m = 0; m < NX; ++m) acc += A[row + NK * m] * x[m];
+  for (int m = 0; m < NX; ++m) acc += A[row + ld * m] * x[m];
   return acc;
 }
 
@@ -332,9 +333,11 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
   // Lane r carries the corrected (lmd, gmm)[r] of the stage after in a register; the rows of the next stage's block
   // of the KKT inverse and its s / s_new entries are fetched while the current stage is multiplied.
   auto loadRows = [&](int i, double (&row)[NX]) {
-    const double* __restrict__ A = B.kinv + (base + B.nodes[i].slot) * L::KINV + L::I_C1 + ln;
+    const ParnmpcShape sh = parnmpcShape<L>(B.nodes[i]);
+    const double* __restrict__ A = B.kinv + (base + B.nodes[i].slot) * L::KINV + sh.c1 + ln;
+    const int ld = sh.ld;
 #pragma unroll
-    for (int m = 0; m < NX; ++m) row[m] = A[NK * m];
+    for (int m = 0; m < NX; ++m) row[m] = A[ld * m];
   };
   double rowa[NX], rowb[NX];
   double cur, s_next, s_i, sn_i;
@@ -376,7 +379,7 @@ template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK;
-  __shared__ double x[NX], dz[NX + NU];
+  __shared__ double x[NX], dz[L::NKG - NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const int lane = threadIdx.x;
@@ -385,19 +388,22 @@ __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffer
   const long b = unit / per;
   const int pos = (int)(unit - b * per);
   const long rec = b * P->NS + B.nodes[pos].slot;
+  const ParnmpcShape sh = parnmpcShape<L>(B.nodes[pos]);
+  const int ni = sh.ni, nw = sh.nw;
   if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
   __syncthreads();
-  if (lane < NU + NX) dz[lane] = blockRowDot<NX, NK>(B.kinv + rec * L::KINV + L::I_C1, NX + lane, x);     // (du, dq, dv)
+  if (lane < sh.nk - NX) dz[lane] = blockRowDot<NX>(B.kinv + rec * L::KINV + sh.c1, sh.ld, NX + lane, x);     // (dxi | dmu, du | df, dq, dv)
   __syncthreads();
   double* __restrict__ sn = B.snew + rec * L::SNEW;
-  if (lane < NU) sn[L::N_U + lane] -= dz[lane];
+  if (lane < ni) sn[L::N_XI + lane] -= dz[lane];
+  if (lane < nw) sn[L::N_U + lane] -= dz[ni + lane];
   if (lane < NV) {
-    sn[L::N_V + lane] -= dz[NU + NV + lane];
-    if (lane >= 6) sn[L::N_Q + lane + 1] -= dz[NU + lane];
+    sn[L::N_V + lane] -= dz[ni + nw + NV + lane];
+    if (lane >= 6) sn[L::N_Q + lane + 1] -= dz[ni + nw + lane];
   }
   if (lane == 32) {
     double qn[7];
-    lieIntegrateBase(sn + L::N_Q, dz + NU, -1.0, qn);
+    lieIntegrateBase(sn + L::N_Q, dz + ni + nw, -1.0, qn);
     for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
   }
 }
@@ -437,9 +443,11 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
     const double sn_q = lane < NQ ? sn[L::N_Q + lane] : 0.0, sn_v = lane < NV ? sn[L::N_V + lane] : 0.0;
     double arow[NX];
     {
-      const double* __restrict__ A = B.kinv + rec * L::KINV + L::I_C0 + (NK - NX) + (lane < NX ? lane : 0);
+      const ParnmpcShape sh = parnmpcShape<L>(B.nodes[i]);
+      const double* __restrict__ A = B.kinv + rec * L::KINV + L::I_C0 + (sh.nk - NX) + (lane < NX ? lane : 0);
+      const int ld = sh.ld;
 #pragma unroll
-      for (int m = 0; m < NX; ++m) arow[m] = A[NK * m];
+      for (int m = 0; m < NX; ++m) arow[m] = A[ld * m];
     }
     if (lane < NQ) { spL[lane] = sp_q; snL[lane] = sn_q; }
     if (lane < NV) { spL[NQ + lane] = sp_v; snL[NQ + lane] = sn_v; }
@@ -481,7 +489,7 @@ template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK;
-  __shared__ double x[NX], dh[NX + NU];
+  __shared__ double x[NX], dh[L::NKG - NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const int lane = threadIdx.x;
@@ -489,18 +497,21 @@ __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers
   const long b = unit / (M - 1);
   const int pos = (int)(unit - b * (M - 1));
   const long rec = b * P->NS + B.nodes[pos].slot;
+  const ParnmpcShape sh = parnmpcShape<L>(B.nodes[pos]);
+  const int ni = sh.ni, nw = sh.nw, ld = sh.ld;
   const double* __restrict__ ki = B.kinv + rec * L::KINV;
   double* __restrict__ sn = B.snew + rec * L::SNEW;
   if (pos > 0 || P->has_prev) {
     if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
     __syncthreads();
-    if (lane < NX + NU) dh[lane] = blockRowDot<NX, NK>(ki + L::I_C0, lane, x);        // (dlmd, dgmm, du)
+    if (lane < sh.nk - NX) dh[lane] = blockRowDot<NX>(ki + L::I_C0, ld, lane, x);        // (dlmd, dgmm, dxi | dmu, du | df)
     __syncthreads();
     if (lane < NX) sn[L::N_LMD + lane] -= dh[lane];
-    if (lane < NU) sn[L::N_U + lane] -= dh[NX + lane];
+    if (lane < ni) sn[L::N_XI + lane] -= dh[NX + lane];
+    if (lane < nw) sn[L::N_U + lane] -= dh[NX + ni + lane];
   }
   double* __restrict__ aux = B.aux + rec * L::AUX;
-  for (int e = lane; e < NX * NX; e += 64) { const int c = e / NX, r = e - c * NX; aux[e] = -ki[L::I_C0 + r + NK * c]; }
+  for (int e = lane; e < NX * NX; e += 64) { const int c = e / NX, r = e - c * NX; aux[e] = -ki[L::I_C0 + r + ld * c]; }
   __syncthreads();
   // computeDirection (split_backward_correction.hxx:141-154)
   const double* __restrict__ s = B.sol + rec * L::SOL;
@@ -511,7 +522,20 @@ __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers
     dd[L::D_V + lane] = sn[L::N_V + lane] - s[L::S_V + lane];
     if (lane >= 6) dd[L::D_Q + lane] = sn[L::N_Q + lane + 1] - s[L::S_Q + lane + 1];
   }
-  if (lane < NU) dd[L::D_U + lane] = sn[L::N_U + lane] - s[L::S_U + lane];
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  if (!sh.impulse) {
+    if (lane < NU) dd[L::D_U + lane] = sn[L::N_U + lane] - s[L::S_U + lane];
+    if (lane < ni) dd[L::D_XI + lane] = sn[L::N_XI + lane] - s[L::S_XI + lane];             // aux stage: dxi (:147-150)
+  } else if (lane < D::NC && nd->active[lane]) {
+    // impulse stage (impulse_split_backward_correction.hxx:113-125): dmu, df, packed rows -> contact slots
+    const int row = nd->row_of[lane];
+    for (int k = 0; k < 3; ++k) {
+      const double df = sn[L::N_U + row + k] - s[L::S_F + 3 * lane + k];
+      dd[L::D_F + 3 * lane + k] = df;
+      dd[L::D_U + row + k] = df;                       // packed rows: what K6 / K7 multiply with Fvf / Qdvf
+      dd[L::D_MU + 3 * lane + k] = sn[L::N_XI + row + k] - s[L::S_MU + 3 * lane + k];
+    }
+  }
   if (lane == 32) {
     double R[9], p[3], d6[6];
     lieRelative(s + L::S_Q, sn + L::N_Q, R, p);            // s_new.q (-) s.q

@@ -579,7 +579,7 @@ int oracle_parnmpc_get_chain(void* h, const char* name, int stride, double* out)
     else if (n == "u") { if (nd.kind != NodeC::Impulse) put(x.u); }
     else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);
     else if (n == "xi") { if (nd.kind == NodeC::Aux) put(x.xi); }
-    else if (n == "f" || n == "mu") { for (int c = 0; c < nc; ++c) if (cs.active[c]) for (int k = 0; k < 3; ++k) o[3 * c + k] = (n == "f" ? x.f : x.mu)[c][k]; }
+    else if (n == "f" || n == "mu") { for (int c = 0; c < nc; ++c) for (int k = 0; k < 3; ++k) o[3 * c + k] = (n == "f" ? x.f : x.mu)[c][k]; }      // every contact slot (inactive ones keep their initial guess)
     else if (n == "nu_passive") { if (nd.kind != NodeC::Impulse) put(x.nu_passive); }
     else if (n == "dq") put(d.dq); else if (n == "dv") put(d.dv);
     else if (n == "du") { if (nd.kind != NodeC::Impulse) put(d.du); }
