@@ -3,9 +3,9 @@
 // Same constructor signature and methods as the reference class
 // (include/idocp/ocp/parnmpc_solver.hpp; src/ocp/parnmpc_solver.cpp).  Every method forwards to
 // the C ABI (include/idocp_hip.h: idocp_parnmpc_* and the shared idocp_ocp_* entry points); the
-// arithmetic runs in the HIP kernels K5a / K5b<BWD> / K9b / S5 / K10a / S6 / K10b / K6 / K7.
-// Carried: horizons with one contact status (setContactStatusUniformly); contact sequences
-// with discrete events are rejected loudly on this solver (they run on idocp::OCPSolver).
+// arithmetic runs in the HIP kernels K5a / K5b<BWD> / K9b / S5 / K10a / S6 / K10b / K6 / K7 and, for
+// contact sequences with discrete events (pushBackContactStatus; max_num_impulse > 0), K5s / K9i / K9g
+// for the aux and impulse stages of the ParNMPCDiscretizer chain.
 #ifndef IDOCP_PARNMPC_SOLVER_HPP_
 #define IDOCP_PARNMPC_SOLVER_HPP_
 
@@ -29,10 +29,11 @@ class ParNMPCSolver {
   ParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
                 const double T, const int N, const int max_num_impulse = 0, const int nthreads = 1, const int device = 0)
       : robot_(robot), N_(N), h_(nullptr) {
-    (void)nthreads; (void)max_num_impulse;
+    (void)nthreads;
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
-    check(idocp_parnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    if (max_num_impulse > 0) check(idocp_parnmpc_create_hybrid(&robot.model(), &c, &k, T, N, max_num_impulse, 1, device, &h_));
+    else check(idocp_parnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
   }
   ~ParNMPCSolver() { idocp_ocp_destroy(h_); }
   ParNMPCSolver(const ParNMPCSolver&) = delete;
@@ -68,10 +69,24 @@ class ParNMPCSolver {
     }
     check(idocp_ocp_set_contact_status_uniformly(h_, active.data(), pts.data()));
   }
-  void pushBackContactStatus(const ContactStatus&, const double) {
-    std::cerr << "unsupported: ParNMPCSolver with discrete events is not carried by the HIP path (use OCPSolver)" << '\n';
-    std::exit(EXIT_FAILURE);
+  // parnmpc_solver.cpp:179-206
+  void pushBackContactStatus(const ContactStatus& contact_status, const double switching_time) {
+    const int nc = contact_status.maxPointContacts();
+    std::vector<int> active(nc);
+    std::vector<double> pts(3 * (size_t)nc);
+    for (int c = 0; c < nc; ++c) {
+      active[c] = contact_status.isContactActive(c) ? 1 : 0;
+      for (int k = 0; k < 3; ++k) pts[3 * c + k] = contact_status.contactPoint(c)[k];
+    }
+    check(idocp_ocp_push_back_contact_status(h_, active.data(), pts.data(), switching_time));
   }
+  void setContactPoints(const int contact_phase, const std::vector<Eigen::Vector3d>& contact_points) {
+    std::vector<double> pts(3 * contact_points.size());
+    for (size_t c = 0; c < contact_points.size(); ++c) for (int k = 0; k < 3; ++k) pts[3 * c + k] = contact_points[c][k];
+    check(idocp_ocp_set_contact_points(h_, contact_phase, pts.data()));
+  }
+  void popBackContactStatus() { check(idocp_ocp_pop_back_contact_status(h_)); }
+  void popFrontContactStatus() { check(idocp_ocp_pop_front_contact_status(h_)); }
   void clearLineSearchFilter() {}
 
   double KKTError() {

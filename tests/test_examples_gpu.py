@@ -166,3 +166,39 @@ def test_anymal_parnmpc_benchmark_example_matches_oracle():
         o.update(0.0, q, v)
         ref = o.kkt_error(0.0, q, v)
         assert abs(its[k] - ref) <= 2e-5 * max(1.0, ref) + 1e-9, (k, its[k], ref)
+
+
+def test_anymal_trotting_parnmpc_example_matches_oracle():
+    """examples/anymal_trotting_parnmpc.cpp = the reference's examples/anymal/anymal_trotting_parnmpc.cpp driver (lift + impulse
+    events on a ParNMPC horizon) through the facade.  Full ParNMPC steps from this cold start do not contract (the reference runs
+    200 iterations without a line search), so only the first iterations are compared, before the two trajectories of the same
+    unstable iteration part."""
+    from helpers import OracleParNMPC, anymal_problem
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "anymal_trotting_parnmpc"), ANYMAL_URDF, "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 3
+    model = anymal_model()
+    cost, cons = anymal_problem(model, trotting_ref=True)
+    cons.linearized_friction_cone = 0
+    cons.linearized_impulse_friction_cone = 0
+    o = OracleParNMPC(model, cost, cons, 1.55, 60, max_num_impulse=3)
+    pts = anymal_contact_points(model).copy()
+    o.set_contact_status([1, 1, 1, 1], pts)
+    o.push_back_contact_status([0, 1, 1, 0], pts, 0.5)
+    pts[0, 0] += 0.075
+    pts[3, 0] += 0.075
+    o.push_back_contact_status([1, 0, 0, 1], pts, 1.0)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(model.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    o.init(0.0)
+    ref_init = o.kkt_error(0.0, q, v)
+    assert abs(init - ref_init) <= 1e-5 * max(1.0, ref_init)
+    assert o.update(0.0, q, v) == 0
+    ref = o.kkt_error(0.0, q, v)
+    assert abs(its[0] - ref) <= 1e-4 * max(1.0, ref), (its[0], ref)
+    assert np.isfinite(its).all()
