@@ -491,8 +491,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   if (tid < NU) kk[L::K_LU + tid] = sm[S::LU + tid];
   for (int e = tid; e < NVF * NVF; e += nt) ee[L::E_MJ + e] = sm[S::MJ + e];
-  for (int e = tid; e < NVF * NX; e += nt) { ee[L::E_MJD + e] = sm[S::MJD + e]; ee[L::E_QAFQV + e] = sm[S::QAFQV + e]; }
-  for (int e = tid; e < NVF * NU; e += nt) ee[L::E_QAFU + e] = sm[S::QAFU + NVF * 6 + e];          // columns 6.. of Qafu_full
+  for (int e = tid; e < NVF * NX; e += nt) ee[L::E_MJD + e] = sm[S::MJD + e];
+  if (tid < NV) ee[L::E_QAA + tid] = sm[S::QAA + tid];
+  for (int e = tid; e < NF * NF; e += nt) ee[L::E_QFF + e] = sm[S::QFF + e];
   if (tid < NVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
   // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199) ----

@@ -133,9 +133,10 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   }
   if (!bimp && lane < dimvf) {
     const int r = lane;
-    double acc = -ee[L::E_MJIDC + r];
-    for (int c = 0; c < NX; ++c) acc -= ee[L::E_MJD + r + NVF * c] * dx[c];
-    for (int j = 0; j < NU; ++j) acc += ee[L::E_MJ + r + NVF * (6 + j)] * du[j];
+    double acc = -ee[L::E_MJIDC + r], tt = 0.0, ww = 0.0;
+    for (int c = 0; c < NX; ++c) { const double mjd = ee[L::E_MJD + r + NVF * c]; acc -= mjd * dx[c]; tt += mjd * dx[c]; }
+    for (int j = 0; j < NU; ++j) { const double mj = ee[L::E_MJ + r + NVF * (6 + j)]; acc += mj * du[j]; ww += mj * du[j]; }
+    dd[L::D_T + r] = tt; dd[L::D_W + r] = ww;        // for the dual expansion (K7)
     if (r < NV) dd[L::D_A + r] = acc;
     else {
       // d.df() *= -1; packed active row -> contact slot
@@ -226,8 +227,21 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
     if (lane < dimvf) {
       const int r = lane;
       double acc = ee[L::E_LAF + r];
-      for (int c = 0; c < NX; ++c) acc += ee[L::E_QAFQV + r + NVF * c] * dx[c];
-      for (int j = 0; j < NU; ++j) acc += ee[L::E_QAFU + r + NVF * j] * du[j];
+      if (bimp) {
+        // ImpulseDynamicsBackwardEuler::computeCondensedDualDirection (impulse_dynamics_backward_euler.hxx:105-111):
+        // ldv += Qdvdv (Fvq dq + Fvf df) + dgmm, with Fvq dq + Fvf df = ddv + Minv ImD
+        acc += ee[L::E_QAA + r] * (dd[L::D_A + r] + ee[L::E_MJIDC + r]);
+      } else if (r < NV) {
+        // Qafqv dx + Qafu du with Qafqv = -diag(Qaa) MJD, Qafu = diag(Qaa) MJ[:, u] (contact_dynamics.hxx:112-123)
+        const double qaa = ee[L::E_QAA + r];
+        acc += -qaa * dd[L::D_T + r];
+        acc += (nd->has_u ? qaa : 0.0) * dd[L::D_W + r];
+      } else {
+        double a1 = 0.0, a2 = 0.0;
+        for (int p = 0; p < dimf; ++p) { const double qff = ee[L::E_QFF + (r - NV) + NF * p]; a1 += qff * dd[L::D_T + NV + p]; a2 += qff * dd[L::D_W + NV + p]; }
+        acc += -a1;
+        acc += nd->has_u ? a2 : 0.0;
+      }
       if (r < NV) acc += dt * dgn[r];
       laf[r] = acc;
     }

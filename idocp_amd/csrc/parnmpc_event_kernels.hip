@@ -261,13 +261,10 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     kk[L::K_FVQ + e] = Fvq[e];
     kk[L::K_FVV + e] = (r == c) ? -1.0 : 0.0;
     ee[L::E_MJ + r + NVF * c] = Mi[e];
-    ee[L::E_QAFQV + r + NVF * c] = P->dvi_weight[r] * Fvq[e];
-    ee[L::E_QAFQV + r + NVF * (NV + c)] = 0.0;
   }
   for (int e = tid; e < NV * NU; e += 256) {
     const int j = e / NV, r = e - j * NV;
     kk[L::K_FVU + e] = j < ni ? Fvf[e] : 0.0;
-    ee[L::E_QAFU + r + NVF * j] = j < ni ? P->dvi_weight[r] * Fvf[e] : 0.0;
   }
   // gradients, residuals
   if (tid < NV) {
@@ -280,6 +277,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     kk[L::K_FX + NV + r] = Fv[r] - MiI[r];
     ee[L::E_MJIDC + r] = MiI[r];
     ee[L::E_LAF + r] = ldv[r];
+    ee[L::E_QAA + r] = P->dvi_weight[r];             // Qdvdv
   }
   if (tid >= 64 && tid < 64 + NU) {
     const int j = tid - 64;
