@@ -1,0 +1,89 @@
+"""Error behaviour of the C ABI on a live handle: where the reference throws and exits (std::out_of_range /
+std::invalid_argument / std::runtime_error followed by std::exit(EXIT_FAILURE), e.g. src/ocp/ocp_solver.cpp:20-57, 95-165,
+include/idocp/hybrid/contact_sequence.hxx:63-117) the library returns IDOCP_E_ARG and leaves the reference's message in
+idocp_last_error(); nothing is silently accepted, nothing falls back to a CPU path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import ANYMAL_Q_STANDING, HipOCP, HipParNMPC, P, anymal_contact_points, anymal_model, anymal_problem, arr
+from idocp_amd import capi
+
+pytestmark = pytest.mark.gpu
+E_ARG, E_UNSUPPORTED = -1, -4
+
+
+def test_contact_sequence_errors():
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    lib = capi.lib()
+    g = HipOCP(m, cost, cons, 1.0, 20, max_num_impulse=2)
+    pts = anymal_contact_points(m)
+    a = lambda s: (C.c_int * 4)(*s)
+    # push_back before setContactStatusUniformly
+    assert lib.idocp_ocp_push_back_contact_status(g.h, a([0, 1, 1, 0]), P(arr(pts)), 0.3) == E_ARG
+    assert "setContactStatusUniformly" in capi.last_error()
+    g.set_contact_status([1, 1, 1, 1], pts)
+    # a status equal to the last one is no discrete event
+    assert lib.idocp_ocp_push_back_contact_status(g.h, a([1, 1, 1, 1]), P(arr(pts)), 0.3) == E_ARG
+    assert "existDiscreteEvent" in capi.last_error()
+    g.push_back_contact_status([0, 1, 1, 0], pts, 0.3)
+    # event times must increase
+    assert lib.idocp_ocp_push_back_contact_status(g.h, a([1, 1, 1, 1]), P(arr(pts)), 0.3) == E_ARG
+    assert "must be larger than the last event time" in capi.last_error()
+    g.push_back_contact_status([1, 1, 1, 1], pts, 0.5)          # impulse 1
+    g.push_back_contact_status([0, 1, 1, 0], pts, 0.6)          # lift 2
+    g.push_back_contact_status([1, 1, 1, 1], pts, 0.7)          # impulse 2
+    # a third lift does not fit max_num_impulse = 2
+    assert lib.idocp_ocp_push_back_contact_status(g.h, a([0, 1, 1, 0]), P(arr(pts)), 0.8) == E_ARG
+    assert "max_num_impulse" in capi.last_error()
+    # contact phase out of range
+    assert lib.idocp_ocp_set_contact_points(g.h, 9, P(arr(pts))) == E_ARG
+    # two events inside one interval of the grid are rejected by the discretiser when the horizon is used
+    g2 = HipOCP(m, cost, cons, 1.0, 20, max_num_impulse=2)
+    g2.set_contact_status([1, 1, 1, 1], pts)
+    g2.push_back_contact_status([0, 1, 1, 0], pts, 0.31)
+    g2.push_back_contact_status([1, 1, 1, 1], pts, 0.33)
+    assert lib.idocp_ocp_init_constraints(g2.h, 0.0) == E_ARG
+    assert "same time stage" in capi.last_error()
+
+
+def test_solver_argument_errors():
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    lib = capi.lib()
+    h = C.c_void_p()
+    for T, N, nimp, batch in ((0.0, 20, 0, 1), (1.0, 0, 0, 1), (1.0, 20, -1, 1), (1.0, 20, 0, 0)):
+        assert lib.idocp_ocp_create_hybrid(C.byref(m), C.byref(cost), C.byref(cons), T, N, nimp, batch, 0, C.byref(h)) == E_ARG
+    g = HipOCP(m, cost, cons, 1.0, 20)
+    assert lib.idocp_ocp_set_solution(g.h, b"w", P(np.zeros(19))) == E_ARG
+    assert "name must be q, v, a, f, or u" in capi.last_error()
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    # updateSolution before a contact status was given; line search is not carried
+    assert lib.idocp_ocp_update_solution(g.h, 0.0, P(q), P(v), 0) == E_ARG
+    g.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+    assert lib.idocp_ocp_update_solution(g.h, 0.0, P(q), P(v), 1) == E_UNSUPPORTED
+    assert "line_search" in capi.last_error()
+    # getters: unknown field, instance out of range
+    out = np.zeros((21, 19))
+    assert lib.idocp_ocp_get_solution(g.h, b"nope", 0, P(out)) == E_ARG
+    assert lib.idocp_ocp_get_solution(g.h, b"q", 5, P(out)) == E_ARG
+
+
+def test_parnmpc_unsupported_cases_fail_loudly():
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    lib = capi.lib()
+    pts = anymal_contact_points(m)
+    # discrete events on a handle created without room for them
+    g = HipParNMPC(m, cost, cons, 1.0, 20)
+    g.set_contact_status([1, 1, 1, 1], pts)
+    a = (C.c_int * 4)(0, 1, 1, 0)
+    assert lib.idocp_ocp_push_back_contact_status(g.h, a, P(arr(pts)), 0.52) == E_ARG
+    # an event inside the first interval of a ParNMPC horizon
+    g2 = HipParNMPC(m, cost, cons, 1.0, 20, max_num_impulse=2)
+    g2.set_contact_status([1, 1, 1, 1], pts)
+    g2.push_back_contact_status([0, 1, 1, 0], pts, 0.02)
+    assert lib.idocp_parnmpc_init_backward_correction(g2.h, 0.0) == E_UNSUPPORTED
+    assert "first time stage" in capi.last_error()
