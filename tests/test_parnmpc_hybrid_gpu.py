@@ -54,7 +54,10 @@ def compare(o, g, M, fields, tol, what):
 # 1e-10 on the lift-only chain; 1e-9 where an aux / impulse pair sits in the chain: the two KKT matrices with the extra
 # constraint rows (Pq, [Vq Vv]) are inverted by Gauss-Jordan here and by two LLTs in the oracle, and the stages around the
 # event are a few milliseconds long (multipliers of order 1e3)
-@pytest.mark.parametrize("events,tol", [(LIFT, 1e-10), (LIFT_TOUCH, 1e-9)], ids=["lift", "lift+impulse"])
+ON_GRID = [([0, 1, 1, 0], 0.5), ([1, 1, 1, 1], 0.8)]          # both events on grid points of N = 20, T = 1 (parnmpc_discretizer.hxx:281-289)
+
+
+@pytest.mark.parametrize("events,tol", [(LIFT, 1e-10), (LIFT_TOUCH, 1e-9), (ON_GRID, 1e-9)], ids=["lift", "lift+impulse", "on-grid"])
 def test_first_iteration_direction_parity_along_the_chain(events, tol):
     m, o, g, q, v = make_pair(20, 1.0, events)
     M = check_chain(o, g)
