@@ -31,7 +31,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
+A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
+           "anymal_parnmpc_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
 KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
                "ocp_reduce_steps", "ocp_expand_dual_integrate"]
@@ -169,6 +170,7 @@ def run_parnmpc(args, rank, local_rank, world, dist):
     torch.cuda.set_device(local_rank)
     torch.cuda.init()                      # torch's HIP runtime first (see tests/conftest.py)
     lib = capi.lib()
+    trot = args.workload == "anymal_parnmpc_trotting"
     N = args.horizon if args.horizon != 100 else 256
     T = 0.05 * N
     B = args.batch or 256
@@ -182,15 +184,38 @@ def run_parnmpc(args, rank, local_rank, world, dist):
     q0[:, 0:2] += 0.02 * rng.uniform(-1, 1, (B, 2))
     q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
     v0 = np.zeros((B, model.nv))
-    shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
-    a = (C.c_int * 4)(1, 1, 1, 1)
-    capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, a, P(arr(pts))))
+    n_events = 0
+    if trot:
+        # the "trotting variant" of configs[3]: the contact sequence of examples/anymal/anymal_trotting.cpp over the whole horizon
+        # (a lift-off, then a touch-down + lift-off every 0.5 s: one lift stage and an aux / impulse pair per touch-down in the
+        # chain), events a quarter of a time step off the grid.  One GPU.  The ITERATE IS FROZEN at the initial guess (the step
+        # sizes are set to 0 after every direction has been computed): ParNMPC has no globalisation, and from a standing cold
+        # start its iteration does not contract on this problem -- in the CPU restatement exactly as here (it does converge, to
+        # 1e-12, on shorter horizons with the footholds in place: tests/test_oracle_parnmpc.py, tests/test_parnmpc_hybrid_gpu.py).
+        # Every kernel of the iteration runs on the full chain; the integration adds 0 * direction.
+        if world != 1:
+            raise SystemExit("anymal_parnmpc_trotting runs on one GPU (chains with discrete events are not sharded)")
+        n_events = int((T - 0.5125) / 0.5) + 1
+        shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank, max_num_impulse=n_events)
+
+        class _Seq:
+            def set_contact_status(self, active, points):
+                capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points))))
+
+            def push_back_contact_status(self, active, points, t_ev):
+                capi.check(lib.idocp_ocp_push_back_contact_status(shard.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points)), t_ev))
+        from helpers import trotting_sequence
+        trotting_sequence(_Seq(), model, n_events - 1, t_start=0.5125)
+    else:
+        shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
+        a = (C.c_int * 4)(1, 1, 1, 1)
+        capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, a, P(arr(pts))))
     capi.check(lib.idocp_ocp_set_solution(shard.h, b"q", P(arr(ANYMAL_Q_STANDING))))
     capi.check(lib.idocp_ocp_set_solution(shard.h, b"v", P(np.zeros(model.nv))))
     capi.check(lib.idocp_ocp_set_solution(shard.h, b"f", P(arr([0, 0, 0.25 * (-model.total_mass * model.gravity[2])]))))
     if rank == 0:
         shard.set_initial_state(q0, v0)
-    drv = ShardedParNMPC(shard, dist if world > 1 else _NoDist(), rank, world)
+    drv = ShardedParNMPC(shard, dist if world > 1 else _NoDist(), rank, world, max_step=0.0 if trot else None)
     drv.init_backward_correction(0.0)
     capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
     phase_ms = {}
@@ -240,12 +265,12 @@ def run_parnmpc(args, rank, local_rank, world, dist):
         ms_step = 1e3 * el / args.steps
         ker = {k: v / kernel_n[k] for k, v in kernel_ms.items()}
         dom = max(ker, key=ker.get)
-        stages = B * (N // world)
+        stages = B * ((N // world) + (2 * (n_events - 1) + 1 if trot else 0))
         alg_bytes = A_STAGE["anymal_parnmpc"] * stages
         achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
         traffic = None
         import glob
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_anymal_parnmpc.json")), reverse=True):
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("horizon") == N and world == 1:
@@ -257,9 +282,10 @@ def run_parnmpc(args, rank, local_rank, world, dist):
             "metric": "SQP iterations/sec (whole node)", "value": B * args.steps / el, "unit": "SQP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ANYmal ParNMPCSolver N=%d T=%.2f FP64, 4 point contacts on every stage (BASELINE.json configs[3]); "
-                                   "batch=%d OCP instances, the %d stages of every instance sharded over %d GPU(s) with halo exchange"
-                                   % (N, T, B, N, world),
+            "config": {"workload": ("ANYmal ParNMPCSolver N=%d T=%.2f FP64, %s (BASELINE.json configs[3]); "
+                                    "batch=%d OCP instances, the %d stages of every instance sharded over %d GPU(s) with halo exchange"
+                                    % (N, T, ("trotting contact sequence (1 lift + %d impulse events in the chain), iterate frozen at the initial guess" % (n_events - 1)) if trot
+                                       else "4 point contacts on every stage", B, N, world)),
                        "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
                        "phase_ms": kms, "kernel_ms": ker, "max_kkt_error_after": float(kkt.max())},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -267,7 +293,7 @@ def run_parnmpc(args, rank, local_rank, world, dist):
                          "avg_launch_ms": ker[dom],
                          "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not trot:
             o = OracleParNMPC(model, cost, cons, T, N)
             o.set_contact_status([1, 1, 1, 1], pts)
             o.set_solution("q", ANYMAL_Q_STANDING)
@@ -302,7 +328,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "iiwa14"], default="anymal_trotting",
+    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "anymal_parnmpc_trotting", "iiwa14"], default="anymal_trotting",
                     help="anymal_trotting = BASELINE.json configs[2] (trotting contact sequence); anymal = its uniform 4-contact variant "
                          "(SURVEY 8d roofline case); iiwa14 = configs[1]; anymal_parnmpc = configs[3] (ParNMPC, N=256, the horizon "
                          "sharded over the ranks, strong scaling)")
@@ -318,7 +344,7 @@ def main():
     if world > 1 or os.environ.get("IDOCP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL scaffolding on one GPU
         dist = init_distributed("nccl", local_rank)
 
-    if args.workload == "anymal_parnmpc":
+    if args.workload in ("anymal_parnmpc", "anymal_parnmpc_trotting"):
         return run_parnmpc(args, rank, local_rank, world, dist)
 
     from idocp_amd import capi

@@ -267,6 +267,76 @@ __device__ __forceinline__ void mmTN22Epi(const double* X, int ldx, const double
   }
 }
 
+// ---- 3 x 3 register tiles ----
+// K9b / K9g keep every matrix it factorises or multiplies as 3 x 3 tiles in registers, thread (bi, bj) owning rows 3 bi .. 3 bi + 2 and
+// columns 3 bj .. 3 bj + 2: an inner-product step is 6 LDS reads for 9 multiply-adds, a Gauss-Jordan pivot step shares only the
+// pivot row and column through LDS.
+
+// acc += A(3 bi + r, m) B(m, 3 bj + c), m = 0 .. K - 1 in ascending order; a(r, m), b(m, c) fetch the operands
+template <int K, typename FA, typename FB>
+__device__ __forceinline__ void tileMM(double (&acc)[3][3], FA a, FB b) {
+#pragma unroll 4
+  for (int m = 0; m < K; ++m) {
+    double av[3], bv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) av[r] = a(r, m);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bv[c] = b(m, c);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] += av[r] * bv[c];
+  }
+}
+
+// Inverse of an SPD N x N matrix held as 3 x 3 tiles by the threads with active = true (N / 3 x N / 3 of them), by Gauss-Jordan
+// without pivoting.  Per pivot k the owners of column k and of row k publish them in pv (two ping-pong buffers of 2 N + 1
+// doubles, the last one the reciprocal of the pivot), one barrier, and every thread updates its tile.  Every thread of the
+// workgroup must call this (barriers).
+template <int N>
+__device__ __forceinline__ void gaussJordanTiles(double (&a)[3][3], const bool active, const int bi, const int bj, double* pv, int* ok) {
+  constexpr int NB = N / 3, PV = 2 * N + 2;
+  static_assert(N % 3 == 0, "tile size");
+  for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+    for (int kr = 0; kr < 3; ++kr) {
+      const int k = 3 * kb + kr;
+      double* col = pv + ((k & 1) ? PV : 0);
+      double* row = col + N;
+      if (active && bj == kb) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) col[3 * bi + r] = a[r][kr];
+        if (bi == kb) {
+          const double p = a[kr][kr];
+          if (!(p > 0.0)) *ok = 0;
+          row[N] = 1.0 / p;
+        }
+      }
+      if (active && bi == kb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[3 * bj + c] = a[kr][c];
+      }
+      __syncthreads();
+      if (active) {
+        const double ip = row[N];
+        double ci[3], rj[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ci[r] = col[3 * bi + r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rj[c] = row[3 * bj + c];
+        const bool rowk = bi == kb, colk = bj == kb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const bool ik = (r == kr) && rowk, jk = (c == kr) && colk;
+            a[r][c] = ik ? (jk ? ip : rj[c] * ip) : (jk ? -ci[r] * ip : a[r][c] - ci[r] * rj[c] * ip);
+          }
+      }
+    }
+  }
+}
+
 // Solve L L^T X = Bm for nrhs columns, one thread per right-hand side (in place).
 __device__ __forceinline__ void choleskySolve(const double* Lm, int ld, int n, double* X, int ldx, int nrhs, int tid, int nthreads) {
   for (int c = tid; c < nrhs; c += nthreads) {

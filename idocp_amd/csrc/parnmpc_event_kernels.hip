@@ -17,8 +17,7 @@
 //   swc:  W_P = V (contact-velocity residual), W_PHIX = [Vq Vv]
 //   exp:  what K6 / K7 need for computeCondensed{Primal,Dual}Direction of the impulse stage
 // so that K9g treats aux and impulse stages alike:  J = [F ; C], C = the W_PHIX rows on the (q, v) columns,
-// Q over (w, q, v) with w = u (aux) or f (impulse).  These stages are few (two per touch-down), the kernels are written
-// for clarity, not for speed.
+// Q over (w, q, v) with w = u (aux) or f (impulse).
 #include <hip/hip_runtime.h>
 
 #include "dev_dense.hpp"
@@ -36,29 +35,6 @@ __device__ __forceinline__ double coneJac(double mu, int r, int x) {
   if (x == 2) return r == 0 ? -1.0 : -m2;
   if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
   return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
-}
-
-// inverse of an SPD n x n block (n <= 48) by Gauss-Jordan, ping-pong between A and W (both ld), 256 threads
-__device__ __forceinline__ void spdInverseBlock(double* A, double* W, int ld, int n, int tid, int* ok) {
-  double* src = A;
-  double* dst = W;
-  __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    const double p = src[k + k * ld];
-    if (tid == 0 && !(p > 0.0)) *ok = 0;
-    const double ip = 1.0 / p;
-    for (int e = tid; e < n * n; e += 256) {
-      const int j = e / n, i = e - j * n;
-      const double aik = src[i + k * ld], akj = src[k + j * ld], aij = src[i + j * ld];
-      dst[i + j * ld] = (i == k) ? ((j == k) ? ip : akj * ip) : ((j == k) ? -aik * ip : aij - aik * akj * ip);
-    }
-    __syncthreads();
-    double* t = src; src = dst; dst = t;
-  }
-  if (src != A) {
-    for (int e = tid; e < n * n; e += 256) { const int j = e / n, i = e - j * n; A[i + j * ld] = src[i + j * ld]; }
-    __syncthreads();
-  }
 }
 
 }  // namespace
@@ -295,153 +271,199 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
 }
 
 // ---------------------------------------------------------------------------------------------------- K9g ----
-// KKT inverse + coarse update of an aux stage (switching rows) or an impulse stage: dense, run-time sizes
-//   nr = NX + ni constraint rows, nQ = nw + NX variables, nK = nr + nQ.
+// KKT inverse + coarse update of an aux stage (switching rows) or an impulse stage, on the 3 x 3 register tiles of K9b.
+// The stage's matrices are PADDED to fixed sizes so that every loop bound is a compile-time constant:
+//   variables  (w, q, v) with w = u or f padded to NU entries (identity on the padding)      -> Q is NQ x NQ, NQ = NU + NX = 48
+//   constraints [F (NX rows); C (ni rows); zero rows up to NR = NX + NF = 48]; S = J Q^-1 J^T gets 1 on the padded diagonal
+// Padded rows / columns of the inverse are never written out; the kinv record holds the true layout
+//   lmd gmm | xi or mu (ni) | u or f (nw) | q v     with leading dimension NKG.
+template <typename D>
+struct KktInvEventSmem {
+  static constexpr int NX = D::NX, NU = D::NU, NF = D::NF, NQ_ = NU + NX, NR = NX + NF;
+  static_assert(NQ_ == NR && NR % 3 == 0 && (NR / 3) * (NR / 3) <= 256, "square 48 x 48 tiles, one per thread");
+  //   A : Q^-1 -> JQ = J Q^-1 -> BR[:, NU:] (NQ x NX) ;  B : J -> S^-1 -> TR = S^-1 JQ
+  static constexpr int A = 0, B = A + NQ_ * NQ_, PV = B + NR * NQ_,
+                       R1 = PV + 2 * (2 * NQ_ + 2), R2 = R1 + NR, T1 = R2 + NQ_, W = T1 + NR, DIR = W + NQ_, TOTAL = DIR + NR + NQ_ + 4;
+};
+
 template <typename D>
 __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
-  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NC = D::NC, LD = NX + NF;      // LD = 48: leading dimension of every LDS block
+  using S = KktInvEventSmem<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NC = D::NC, NQ = S::NQ_, NR = S::NR;
+  constexpr int TQ = NQ / 3;                       // 16 tiles per side of every matrix
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
-  double* Q = sm;                       // Q^-1
-  double* J = Q + LD * LD;              // J (nr x nQ)
-  double* JQ = J + LD * LD;             // J Q^-1
-  double* Sm = JQ + LD * LD;            // S, S^-1
-  double* TR = Sm + LD * LD;            // S^-1 J Q^-1
-  double* Wk = TR + LD * LD;            // scratch
-  double* r1 = Wk + LD * LD;            // constraint residuals (nr)
-  double* r2 = r1 + LD;                 // gradients (nQ)
-  double* t1 = r2 + LD;
-  double* dir = t1 + LD;                // 2 LD
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nt = 256;
   const long b = blockIdx.x;
   const int pos = B.general_pos[blockIdx.y];
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const ParnmpcShape sh = parnmpcShape<L>(*nd);
-  const int ni = sh.ni, nw = sh.nw, nr = NX + ni, nQ = nw + NX, nK = sh.nk;
+  const int ni = sh.ni, nw = sh.nw, nr = NX + ni, nK = sh.nk;
   const bool impulse = sh.impulse;
   const bool last = P->has_terminal && (pos == M - 2);
   const double dt = nd->dt;
   const long rec = b * P->NS + nd->slot;
   const double* __restrict__ kk = B.kkt + rec * L::KKT;
-  const double* __restrict__ W = B.swc + rec * L::SWC;
+  const double* __restrict__ Wc = B.swc + rec * L::SWC;
   const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
   double* __restrict__ ki = B.kinv + rec * L::KINV;
   if (tid == 0) s_ok = 1;
-  // ---- Q over (w, q, v): [Qww Qwx; Qxw Qxx + aux_mat_next] ----
-  for (int e = tid; e < LD * LD; e += 256) { Q[e] = 0.0; J[e] = 0.0; }
-  __syncthreads();
-  for (int e = tid; e < nQ * nQ; e += 256) {
-    const int c = e / nQ, r = e - c * nQ;
-    double v;
-    if (r < nw && c < nw) v = kk[L::K_QUU + r + NU * c];
-    else if (r < nw) v = kk[L::K_QXU + (c - nw) + NX * r];
-    else if (c < nw) v = kk[L::K_QXU + (r - nw) + NX * c];
-    else {
-      int rr = r - nw, cc = c - nw;
-      const double ax = last ? 0.0 : aux[rr + NX * cc];
-      if (rr >= NV && cc < NV) { const int t = rr; rr = cc; cc = t; }      // Qvq = Qqv^T
-      v = kk[L::K_QXX + rr + NX * cc] + ax;
+  // ---- Q over (w, q, v), padded, straight into the register tiles ----
+  double qinv[3][3];
+  const int ti = tid % TQ, tj = tid / TQ;          // tile (ti, tj) of a 48 x 48 matrix
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) {
+      const int r = 3 * ti + tr, c = 3 * tj + tc;
+      double v;
+      if (r < NU && c < NU) v = (r < nw && c < nw) ? kk[L::K_QUU + r + NU * c] : (r == c ? 1.0 : 0.0);
+      else if (r < NU) v = r < nw ? kk[L::K_QXU + (c - NU) + NX * r] : 0.0;
+      else if (c < NU) v = c < nw ? kk[L::K_QXU + (r - NU) + NX * c] : 0.0;
+      else {
+        int rr = r - NU, cc = c - NU;
+        const double ax = last ? 0.0 : aux[rr + NX * cc];
+        if (rr >= NV && cc < NV) { const int t = rr; rr = cc; cc = t; }      // Qvq = Qqv^T
+        v = kk[L::K_QXX + rr + NX * cc] + ax;
+      }
+      qinv[tr][tc] = v;
     }
-    Q[r + LD * c] = v;
-  }
-  // ---- J = [0 Fqq Fqv; Fvw Fvq Fvv; 0 Cq Cv] ----
-  for (int e = tid; e < nr * nQ; e += 256) {
-    const int c = e / nr, r = e - c * nr;
+  // ---- J = [0 Fqq Fqv; Fvw Fvq Fvv; 0 Cq Cv; 0] (NR x NQ) -> region B ----
+  for (int e = tid; e < NR * NQ; e += nt) {
+    const int c = e / NR, r = e - c * NR;
     double v = 0.0;
     if (r < NV) {
-      if (c >= nw && c < nw + NV) { const int cq = c - nw; v = (r < 6 && cq < 6) ? kk[L::K_FQQ + r + 6 * cq] : ((r >= 6 && r == cq) ? -1.0 : 0.0); }
-      else if (c >= nw + NV && !impulse) { const int cv = c - nw - NV; v = (r < 6 && cv < 6) ? kk[L::K_FQV + r + 6 * cv] : ((r >= 6 && r == cv) ? dt : 0.0); }
+      if (c >= NU && c < NU + NV) { const int cq = c - NU; v = (r < 6 && cq < 6) ? kk[L::K_FQQ + r + 6 * cq] : ((r >= 6 && r == cq) ? -1.0 : 0.0); }
+      else if (c >= NU + NV && !impulse) { const int cv = c - NU - NV; v = (r < 6 && cv < 6) ? kk[L::K_FQV + r + 6 * cv] : ((r >= 6 && r == cv) ? dt : 0.0); }
     } else if (r < NX) {
       const int rv = r - NV;
-      if (c < nw) v = kk[L::K_FVU + rv + NV * c];
-      else if (c < nw + NV) v = kk[L::K_FVQ + rv + NV * (c - nw)];
-      else v = kk[L::K_FVV + rv + NV * (c - nw - NV)];
-    } else if (c >= nw) {
-      v = W[L::W_PHIX + (r - NX) + NF * (c - nw)];
+      if (c < NU) v = c < nw ? kk[L::K_FVU + rv + NV * c] : 0.0;
+      else if (c < NU + NV) v = kk[L::K_FVQ + rv + NV * (c - NU)];
+      else v = kk[L::K_FVV + rv + NV * (c - NU - NV)];
+    } else if (r < nr && c >= NU) {
+      v = Wc[L::W_PHIX + (r - NX) + NF * (c - NU)];
     }
-    J[r + LD * c] = v;
+    sm[S::B + e] = v;
   }
-  if (tid < nr) r1[tid] = tid < NX ? kk[L::K_FX + tid] : W[L::W_P + tid - NX];
-  if (tid >= 64 && tid < 64 + nQ) { const int r = tid - 64; r2[r] = r < nw ? kk[L::K_LU + r] : kk[L::K_LX + r - nw]; }
+  if (tid < NR) sm[S::R1 + tid] = tid < NX ? kk[L::K_FX + tid] : (tid < nr ? Wc[L::W_P + tid - NX] : 0.0);
+  if (tid >= 64 && tid < 64 + NQ) { const int r = tid - 64; sm[S::R2 + r] = r < NU ? (r < nw ? kk[L::K_LU + r] : 0.0) : kk[L::K_LX + r - NU]; }
   __syncthreads();
-  // ---- Q^-1, JQ = J Q^-1, S = J JQ^T, S^-1, TR = S^-1 JQ ----
-  spdInverseBlock(Q, Wk, LD, nQ, tid, &s_ok);
-  for (int e = tid; e < nr * nQ; e += 256) {
+  // ---- Q^-1 ----
+  gaussJordanTiles<NQ>(qinv, true, ti, tj, &sm[S::PV], &s_ok);
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * ti + tr + NQ * (3 * tj + tc)] = qinv[tr][tc];
+  __syncthreads();
+  // ---- JQ = J Q^-1 (all 256 tiles), then w = Q^-1 r2 ----
+  double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  tileMM<NQ>(acc, [&](int r, int m) { return sm[S::B + 3 * ti + r + NR * m]; },
+             [&](int m, int c) { return sm[S::A + m + NQ * (3 * tj + c)]; });
+  if (tid < NQ) {
+    double w = 0.0;
+    for (int m = 0; m < NQ; ++m) w += sm[S::A + tid + NQ * m] * sm[S::R2 + m];
+    sm[S::W + tid] = w;
+  }
+  __syncthreads();                                   // Q^-1 is dead in LDS: JQ takes its place
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * ti + tr + NR * (3 * tj + tc)] = acc[tr][tc];
+  __syncthreads();
+  // ---- S = J JQ^T (+ 1 on the padded diagonal) into register tiles, S^-1 ----
+  double sinv[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  tileMM<NQ>(sinv, [&](int r, int m) { return sm[S::B + 3 * ti + r + NR * m]; },
+             [&](int m, int c) { return sm[S::A + 3 * tj + c + NR * m]; });
+  if (ti == tj) {
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) if (3 * ti + t3 >= nr) sinv[t3][t3] = 1.0;
+  }
+  gaussJordanTiles<NR>(sinv, true, ti, tj, &sm[S::PV], &s_ok);      // its first barrier also ends the reads of J
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * ti + tr + NR * (3 * tj + tc)] = sinv[tr][tc];
+  __syncthreads();
+  // ---- TR = S^-1 JQ ; t1 = r1 - JQ r2 ; what else reads S^-1: TL = -S^-1[:, 0:NX] and -S^-1 r1 ----
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) acc[tr][tc] = 0.0;
+  tileMM<NR>(acc, [&](int r, int m) { return sm[S::B + 3 * ti + r + NR * m]; },
+             [&](int m, int c) { return sm[S::A + m + NR * (3 * tj + c)]; });
+  if (tid < NR) {
+    const int r = tid;
+    double t = sm[S::R1 + r];
+    for (int m = 0; m < NQ; ++m) t -= sm[S::A + r + NR * m] * sm[S::R2 + m];
+    sm[S::T1 + r] = t;
+    double d = 0.0;
+    for (int m = 0; m < NR; ++m) d -= sm[S::B + r + NR * m] * sm[S::R1 + m];
+    sm[S::DIR + r] = d;
+  }
+  for (int e = tid; e < nr * NX; e += nt) {
     const int c = e / nr, r = e - c * nr;
-    double acc = 0.0;
-    for (int m = 0; m < nQ; ++m) acc += J[r + LD * m] * Q[m + LD * c];
-    JQ[r + LD * c] = acc;
+    ki[L::I_C0 + r + L::NKG * c] = -sm[S::B + r + NR * c];
+  }
+  __syncthreads();                                   // S^-1 is dead: TR takes its place
+#pragma unroll
+  for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * ti + tr + NR * (3 * tj + tc)] = acc[tr][tc];
+  __syncthreads();
+  // ---- BR[:, NU:] = Q^-1[:, NU:] - TR^T JQ[:, NU:] by the threads that hold those tiles of Q^-1 ; coarse direction ----
+  const bool b_on = tj >= NU / 3;
+  if (b_on) {
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) acc[tr][tc] = 0.0;
+    tileMM<NR>(acc, [&](int r, int m) { return sm[S::B + m + NR * (3 * ti + r)]; },
+               [&](int m, int c) { return sm[S::A + m + NR * (3 * tj + c)]; });
+  } else if (tid < NR) {
+    double d = sm[S::DIR + tid];
+    for (int m = 0; m < NQ; ++m) d += sm[S::B + tid + NR * m] * sm[S::R2 + m];
+    sm[S::DIR + tid] = d;
+  }
+  if (tid >= 256 - NQ) {
+    const int r = tid - (256 - NQ);
+    double d = sm[S::W + r];
+    for (int m = 0; m < NR; ++m) d += sm[S::B + m + NR * r] * sm[S::T1 + m];
+    sm[S::DIR + NR + r] = d;
+  }
+  __syncthreads();                                   // JQ is dead: BR[:, NU:] takes its place (NQ x NX)
+  if (b_on) {
+#pragma unroll
+    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * ti + tr + NQ * (3 * (tj - NU / 3) + tc)] = qinv[tr][tc] - acc[tr][tc];
   }
   __syncthreads();
-  for (int e = tid; e < nr * nr; e += 256) {
-    const int c = e / nr, r = e - c * nr;
-    double acc = 0.0;
-    for (int m = 0; m < nQ; ++m) acc += J[r + LD * m] * JQ[c + LD * m];
-    Sm[r + LD * c] = acc;
-  }
-  __syncthreads();
-  spdInverseBlock(Sm, Wk, LD, nr, tid, &s_ok);
-  for (int e = tid; e < nr * nQ; e += 256) {
-    const int c = e / nr, r = e - c * nr;
-    double acc = 0.0;
-    for (int m = 0; m < nr; ++m) acc += Sm[r + LD * m] * JQ[m + LD * c];
-    TR[r + LD * c] = acc;
-  }
-  if (tid >= 256 - LD && tid - (256 - LD) < nr) {
-    const int r = tid - (256 - LD);
-    double acc = r1[r];
-    for (int m = 0; m < nQ; ++m) acc -= JQ[r + LD * m] * r2[m];
-    t1[r] = acc;
-  }
-  __syncthreads();
-  // ---- coarse direction: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - JQ r2) ----
-  if (tid < nr) {
-    double acc = 0.0;
-    for (int m = 0; m < nr; ++m) acc -= Sm[tid + LD * m] * r1[m];
-    for (int m = 0; m < nQ; ++m) acc += TR[tid + LD * m] * r2[m];
-    dir[tid] = acc;
-  } else if (tid >= 64 && tid < 64 + nQ) {
-    const int r = tid - 64;
-    double acc = 0.0;
-    for (int m = 0; m < nQ; ++m) acc += Q[r + LD * m] * r2[m];
-    for (int m = 0; m < nr; ++m) acc += TR[m + LD * r] * t1[m];
-    dir[LD + r] = acc;
-  }
-  // ---- BR[:, nQ - NX :] = Q^-1[:, nQ - NX :] - TR^T JQ[:, nQ - NX :]  -> Wk (nQ x NX) ----
-  for (int e = tid; e < nQ * NX; e += 256) {
-    const int c = e / nQ, r = e - c * nQ;
-    double acc = Q[r + LD * (nw + c)];
-    for (int m = 0; m < nr; ++m) acc -= TR[m + LD * r] * JQ[m + LD * (nw + c)];
-    Wk[r + LD * c] = acc;
-  }
-  __syncthreads();
-  // ---- column blocks of the inverse, leading dimension NKG: C0 = KKT_inv[:, 0:NX], C1 = KKT_inv[:, nK-NX:nK] ----
-  for (int e = tid; e < nK * NX; e += 256) {
+  // ---- column blocks of the inverse in the true row layout: C0 = KKT_inv[:, 0:NX] (top part written above),
+  //      C1 = KKT_inv[:, nK-NX : nK] ----
+  for (int e = tid; e < nK * NX; e += nt) {
     const int c = e / nK, r = e - c * nK;
-    double c0, c1;
     if (r < nr) {
-      c0 = -Sm[r + LD * c];
-      c1 = TR[r + LD * (nw + c)];
+      ki[L::I_C1G + r + L::NKG * c] = sm[S::B + r + NR * (NU + c)];
     } else {
-      const int rq = r - nr;
-      c0 = TR[c + LD * rq];
-      c1 = Wk[rq + LD * c];
+      const int rt = r - nr;                                   // true variable row: w (nw), then q, v
+      const int rq = rt < nw ? rt : NU + (rt - nw);            // padded variable row
+      ki[L::I_C0 + r + L::NKG * c] = sm[S::B + c + NR * rq];
+      ki[L::I_C1G + r + L::NKG * c] = sm[S::A + rq + NQ * c];
     }
-    ki[L::I_C0 + r + L::NKG * c] = c0;
-    ki[L::I_C1G + r + L::NKG * c] = c1;
   }
   // ---- s_new = s - direction (split_backward_correction.hxx:49-63, impulse_split_backward_correction.hxx:43-55) ----
   const double* __restrict__ s = B.sol + rec * L::SOL;
   double* __restrict__ sn = B.snew + rec * L::SNEW;
-  const double* dw = dir + LD;              // (dw, dq, dv)
+  const double* dir = &sm[S::DIR];          // padded: [lmd gmm | extra (NF) ] | [w (NU) | dq dv]
+  const double* dw = dir + NR;
   if (tid < NV) {
     sn[L::N_LMD + tid] = s[L::S_LMD + tid] - dir[tid];
     sn[L::N_GMM + tid] = s[L::S_GMM + tid] - dir[NV + tid];
-    sn[L::N_V + tid] = s[L::S_V + tid] - dw[nw + NV + tid];
-    if (tid >= 6) sn[L::N_Q + tid + 1] = s[L::S_Q + tid + 1] - dw[nw + tid];
+    sn[L::N_V + tid] = s[L::S_V + tid] - dw[NU + NV + tid];
+    if (tid >= 6) sn[L::N_Q + tid + 1] = s[L::S_Q + tid + 1] - dw[NU + tid];
   }
   if (!impulse) {
     if (tid >= 64 && tid < 64 + NU) sn[L::N_U + tid - 64] = s[L::S_U + tid - 64] - dw[tid - 64];
@@ -455,7 +477,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
   }
   if (tid == 128) {
     double qn[7];
-    lieIntegrateBase(s + L::S_Q, dw + nw, -1.0, qn);
+    lieIntegrateBase(s + L::S_Q, dw + NU, -1.0, qn);
     for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
   }
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1000 + pos;
@@ -472,8 +494,7 @@ void OcpLaunch<D>::parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n
 template <typename D>
 void OcpLaunch<D>::parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st) {
   if (n_general <= 0) return;
-  constexpr int LD = D::NX + D::NF;
-  const size_t smem = (6 * LD * LD + 5 * LD + 8) * sizeof(double);
+  const size_t smem = KktInvEventSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)parnmpc_kkt_inverse_general_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

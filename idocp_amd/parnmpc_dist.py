@@ -22,8 +22,8 @@ STATE_LAST, COSTATE_FIRST, AUX_FIRST, BWD_FIRST, FWD_LAST, AUX_ALL = 0, 1, 2, 3,
 
 
 class ShardedParNMPC:
-    def __init__(self, shard, dist, rank, world):
-        self.s, self.dist, self.rank, self.world = shard, dist, rank, world
+    def __init__(self, shard, dist, rank, world, max_step=None):
+        self.s, self.dist, self.rank, self.world, self.max_step = shard, dist, rank, world, max_step
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
 
@@ -87,6 +87,8 @@ class ShardedParNMPC:
         steps = self.s.local_steps().contiguous()
         if self.world > 1:
             self.dist.all_reduce(steps, op=self.dist.ReduceOp.MIN)
+        if self.max_step is not None:               # damped iteration (ParNMPC itself has no globalisation)
+            steps = steps.clamp(max=self.max_step)
         self.s.set_steps(steps)
         self.s.phase("integrate", t)
 
@@ -104,7 +106,7 @@ class HipParNMPCShard:
     PHASES = {"linearize": (0, 1, 2), "bwd_serial": (3,), "bwd_parallel": (4,), "fwd_serial": (5,), "fwd_parallel": (6, 7, 8),
               "integrate": (9,)}
 
-    def __init__(self, model, cost, cons, T, N, rank, world, batch, device):
+    def __init__(self, model, cost, cons, T, N, rank, world, batch, device, max_num_impulse=0):
         import ctypes as C
         import torch
         from idocp_amd import capi
@@ -114,9 +116,15 @@ class HipParNMPCShard:
         self.Nl, self.batch, self.rank, self.world = N // world, batch, rank, world
         self.dev = torch.device("cuda", device)
         h = C.c_void_p()
-        capi.check(self.lib.idocp_parnmpc_create_shard(C.byref(model), C.byref(cost), C.byref(cons), T / world, self.Nl, rank * self.Nl,
-                                                       1 if rank == world - 1 else 0, 1 if rank > 0 else 0, batch, device, C.byref(h)),
-                   "idocp_parnmpc_create_shard")
+        if max_num_impulse > 0:
+            # a horizon with discrete events lives on one GPU (the chain of event stages is not sharded yet)
+            assert world == 1, "horizons with discrete events are not sharded"
+            capi.check(self.lib.idocp_parnmpc_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse, batch, device,
+                                                            C.byref(h)), "idocp_parnmpc_create_hybrid")
+        else:
+            capi.check(self.lib.idocp_parnmpc_create_shard(C.byref(model), C.byref(cost), C.byref(cons), T / world, self.Nl, rank * self.Nl,
+                                                           1 if rank == world - 1 else 0, 1 if rank > 0 else 0, batch, device, C.byref(h)),
+                       "idocp_parnmpc_create_shard")
         self.h = h
         dq, dv, ds = C.c_void_p(), C.c_void_p(), C.c_void_p()
         capi.check(self.lib.idocp_parnmpc_prev_state(self.h, C.byref(dq), C.byref(dv)))

@@ -106,3 +106,24 @@ def test_reference_trotting_example_chain_and_first_iteration():
     a, b = g.step_sizes()
     ao, bo = o.step_sizes()
     assert abs(a[0] - ao) < 1e-6 and abs(b[0] - bo) < 1e-6 and abs(a[2] - ao) < 1e-6
+
+
+SWAP_IN_PLACE = [([0, 1, 1, 0], 0.52), ([1, 0, 0, 1], 0.83)]        # {LH, RF} -> {LF, RH} at once: lift-off and touch-down in one impulse event
+
+
+@pytest.mark.parametrize("events", [LIFT_TOUCH, SWAP_IN_PLACE], ids=["touch-down", "swap"])
+def test_converges_like_the_oracle(events):
+    """Undamped ParNMPC iterations on a chain with a lift, an aux and an impulse stage: the GPU path walks the same transient
+    (KKT error up to a few hundred) and reaches the same KKT point as the oracle.  (Longer chains converge too -- the oracle test
+    runs five events -- but through transients of 1e4 and more that no longer let two FP64 implementations be compared
+    iteration by iteration.)"""
+    m, o, g, q, v = make_pair(20, 1.0, events, batch=2)
+    M = check_chain(o, g)
+    for it in range(36):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        if it in (2, 5, 9):
+            e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+            assert np.abs(e_g - e_o).max() <= 1e-4 * e_o, (it, e_o, e_g)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert e_o < 1e-9 and e_g.max() < 1e-9, (e_o, e_g)
+    compare(o, g, M, ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "xi"), 1e-8, "converged solution")
