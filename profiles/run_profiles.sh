@@ -3,7 +3,8 @@
 #   profiles/run_profiles.sh <round> <workload>         e.g.  profiles/run_profiles.sh 01 anymal
 # Pass 1: --kernel-trace --stats of the default bench command.
 # Pass 2/3: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (no other trace domains).
-# Raw databases stay under gpurun_out/ (scratch); the text / json summaries are copied to profiles/.
+# The raw rocpd databases are summarised on the box and removed; the text / json summaries come back under gpurun_out/ and are
+# copied to profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 rnd=$1; wl=$2
@@ -20,4 +21,5 @@ hor=$(echo "$line" | python3 -c "import sys,json; print(json.loads(sys.stdin.rea
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline"; echo "# bench line: $line"; python3 profiles/summarize_rocpd.py $out/${wl}_trace_results.db; } > $out/r${rnd}_${wl}_kernel_trace.txt
 python3 profiles/summarize_rocpd.py $out/${wl}_fetch_results.db $out/${wl}_write_results.db > $out/r${rnd}_${wl}_pmc_hbm.txt
 python3 profiles/make_traffic_json.py $out/${wl}_fetch_results.db $out/${wl}_write_results.db $wl $batch $hor $rnd > $out/r${rnd}_pmc_traffic_${wl}.json
+rm -f $out/${wl}_trace_results.db $out/${wl}_fetch_results.db $out/${wl}_write_results.db      # the summaries above are what is kept (gpurun_out/ is capped at 64 MiB)
 echo "$line"
