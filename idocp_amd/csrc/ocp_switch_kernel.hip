@@ -24,7 +24,7 @@ namespace idocp_dev {
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
-  constexpr int NV = D::NV, NQ = D::NQ, NL = D::NL, LJ = D::LJ, NF = D::NF, NX = D::NX, NU = D::NU;
+  constexpr int NV = D::NV, NQ = D::NQ, NL = D::NL, LJ = D::LJ, NF = D::NF, NU = D::NU;
   typedef Dual T;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;

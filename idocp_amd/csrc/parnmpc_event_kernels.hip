@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     ee[L::E_MJ + r + NVF * c] = Mi[e];
   }
   for (int e = tid; e < NV * NU; e += 256) {
-    const int j = e / NV, r = e - j * NV;
+    const int j = e / NV;
     kk[L::K_FVU + e] = j < ni ? Fvf[e] : 0.0;
   }
   // gradients, residuals

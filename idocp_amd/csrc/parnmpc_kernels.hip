@@ -250,7 +250,7 @@ __device__ __forceinline__ double blockRowDot(const double* __restrict__ A, int 
 template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
-  constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
+  constexpr int NX = D::NX;
   __shared__ double x[2][NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
 template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
-  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK;
+  constexpr int NV = D::NV, NX = D::NX;
   __shared__ double x[NX], dz[L::NKG - NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffer
 template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
   using L = OcpLayout<D>;
-  constexpr int NV = D::NV, NX = D::NX, NK = L::NK;
+  constexpr int NV = D::NV, NX = D::NX;
   constexpr int NQ = D::NQ, NS_ = NQ + NV;
   // cur = the corrected (q, v) of the stage before; sp / sn = s and the coarse s_new (q, v) of the stages i - 1 / i
   __shared__ double x[NX], dx[NX], cur[NS_], spL[NS_], snL[NS_];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
 template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
-  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU;
   __shared__ double x[NX], dh[L::NKG - NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;

@@ -737,7 +737,7 @@ void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t s
     hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
   }
 template <int NV>
-void UnLaunch<NV>::riccati(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
+void UnLaunch<NV>::riccati(const UnBuffers& B, long batch, int /*N*/, const double* q0, const double* v0, hipStream_t st) {
     const unsigned blocks = (unsigned)((batch + 7) / 8);
     hipLaunchKernelGGL((un_riccati_backward_kernel<NV>), dim3(blocks), dim3(64), 0, st, B);
     hipLaunchKernelGGL((un_riccati_forward_kernel<NV>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
