@@ -346,7 +346,9 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   if (ii != Ni || li != Nl) { set_last_error("ParNMPCDiscretizer: a discrete event lies outside the horizon"); return IDOCP_E_ARG; }
   for (int i = 0; i + 1 < Ng; ++i)
     if (imp_before[i] >= 0 && imp_before[i + 1] >= 0) { set_last_error("ParNMPCDiscretizer: impulses in consecutive time stages"); return IDOCP_E_ARG; }
-  if (imp_before[0] >= 0 || lift_before[0] >= 0) { set_last_error("ParNMPC: a discrete event in front of the first time stage is not carried"); return IDOCP_E_UNSUPPORTED; }
+  // a lift in front of the first time stage is an ordinary first element of the chain; an impulse there is not carried (the
+  // reference linearises that aux stage without the switching constraint but inverts with it, backward_correction_solver.cpp:214-231)
+  if (imp_before[0] >= 0) { set_last_error("ParNMPC: an impulse in front of the first time stage is not carried"); return IDOCP_E_UNSUPPORTED; }
   h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
   auto node = [&](int kind, int index, double tt, double dtt, const HostStatus& st, int level) {
     OcpNode nd;

@@ -1133,7 +1133,10 @@ void ParNMPCSolver::discretize(double t) {
   }
   if (ii != Ni || li != Nl) throw std::runtime_error("ParNMPCDiscretizer: a discrete event lies outside the horizon");
   for (int i = 0; i + 1 < N_; ++i) if (imp_before[i] >= 0 && imp_before[i + 1] >= 0) throw std::runtime_error("ParNMPCDiscretizer: impulses in consecutive time stages");
-  if (imp_before[0] >= 0 || lift_before[0] >= 0) throw std::logic_error("ParNMPC oracle: a discrete event in front of the first time stage is not carried");
+  // A lift in front of the first time stage is an ordinary first element of the chain (its predecessor is the measured state,
+  // backward_correction_solver.cpp:232-246).  An impulse there is not carried: the reference linearises that aux stage without
+  // the switching constraint but inverts its KKT matrix with it (:214-231).
+  if (imp_before[0] >= 0) throw std::logic_error("ParNMPC oracle: an impulse in front of the first time stage is not carried");
   for (int i = 0; i < N_; ++i) {
     const int phase_before = i > 0 ? phase[i - 1] : 0;
     if (imp_before[i] >= 0) {

@@ -55,9 +55,11 @@ def compare(o, g, M, fields, tol, what):
 # constraint rows (Pq, [Vq Vv]) are inverted by Gauss-Jordan here and by two LLTs in the oracle, and the stages around the
 # event are a few milliseconds long (multipliers of order 1e3)
 ON_GRID = [([0, 1, 1, 0], 0.5), ([1, 1, 1, 1], 0.8)]          # both events on grid points of N = 20, T = 1 (parnmpc_discretizer.hxx:281-289)
+LIFT_FIRST = [([0, 1, 1, 0], 0.02), ([1, 1, 1, 1], 0.43)]      # the lift inside the first interval: the chain starts with the lift stage
 
 
-@pytest.mark.parametrize("events,tol", [(LIFT, 1e-10), (LIFT_TOUCH, 1e-9), (ON_GRID, 1e-9)], ids=["lift", "lift+impulse", "on-grid"])
+@pytest.mark.parametrize("events,tol", [(LIFT, 1e-10), (LIFT_TOUCH, 1e-9), (ON_GRID, 1e-9), (LIFT_FIRST, 1e-9)],
+                         ids=["lift", "lift+impulse", "on-grid", "lift-first"])
 def test_first_iteration_direction_parity_along_the_chain(events, tol):
     m, o, g, q, v = make_pair(20, 1.0, events)
     M = check_chain(o, g)
