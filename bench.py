@@ -191,7 +191,7 @@ def run_parnmpc(args, rank, local_rank, world, dist):
         # chain), events a quarter of a time step off the grid.  One GPU.  The ITERATE IS FROZEN at the initial guess (the step
         # sizes are set to 0 after every direction has been computed): ParNMPC has no globalisation, and from a standing cold
         # start its iteration does not contract on this problem -- in the CPU restatement exactly as here (it does converge, to
-        # 1e-12, on shorter horizons with the footholds in place: tests/test_oracle_parnmpc.py, tests/test_parnmpc_hybrid_gpu.py).
+        # 1e-12, on short horizons with the footholds in place: tests/test_oracle_parnmpc.py, tests/test_parnmpc_hybrid_gpu.py).
         # Every kernel of the iteration runs on the full chain; the integration adds 0 * direction.
         if world != 1:
             raise SystemExit("anymal_parnmpc_trotting runs on one GPU (chains with discrete events are not sharded)")

@@ -309,7 +309,7 @@ __device__ __forceinline__ void gaussJordanTiles(double (&a)[3][3], const bool a
         if (bi == kb) {
           const double p = a[kr][kr];
           if (!(p > 0.0)) *ok = 0;
-          row[N] = recipNewton(p);
+          row[N] = 1.0 / p;
         }
       }
       if (active && bi == kb) {

@@ -618,17 +618,13 @@ class OracleParNMPC:
 
 def anymal_contact_points(model, q_at=None):
     """World positions of the four feet at q_standing (robot.getContactPoints after
-    updateFrameKinematics(q_standing), examples/anymal/anymal_trotting.cpp:141-143)."""
-    lib = oracle()
-    nv, nc = model.nv, model.ncontacts
-    q, z = arr(ANYMAL_Q_STANDING if q_at is None else q_at), np.zeros(nv)
-    fp = np.zeros((nc, 3))
-    tmp = [np.zeros(n) for n in (3 * nc, 3 * nc * nv, 3 * nc * nv, 3 * nc * nv)]
-    fR, fv, fa = np.zeros((nc, 9)), np.zeros((nc, 6)), np.zeros((nc, 6))
-    d4 = [np.zeros(nc * 6 * nv) for _ in range(4)]
-    lib.oracle_contact_kinematics(C.byref(model), P(q), P(z), P(z), P(np.zeros((nc, 3))), C.c_double(0.05), P(tmp[0]), P(tmp[1]),
-                                  P(tmp[2]), P(tmp[3]), P(fp), P(fR), P(fv), P(fa), P(d4[0]), P(d4[1]), P(d4[2]), P(d4[3]), None)
-    return fp
+    updateFrameKinematics(q_standing), examples/anymal/anymal_trotting.cpp:141-143): problem set-up, done by the PRODUCT's host
+    kinematics (idocp_model_contact_positions) so that neither bench.py nor the GPU tests route their inputs through the
+    oracle; tests/test_capi_symbols.py checks that entry against the oracle's frame kinematics."""
+    q = arr(ANYMAL_Q_STANDING if q_at is None else q_at)
+    pts = np.zeros((model.ncontacts, 3))
+    capi.check(capi.lib().idocp_model_contact_positions(C.byref(model), P(q), P(pts)), "idocp_model_contact_positions")
+    return pts
 
 
 class HipOCP:

@@ -37,8 +37,10 @@ def test_first_iteration_direction_parity(N, T):
     assert abs(e_g[0] - e_o) <= 1e-10 * max(1.0, e_o)
     assert o.update(0.0, q, v) == 0
     assert g.update(0.0, q, v) == 0
+    # 1e-10 on the N = 20 horizon (measured 1e-12); on N = 64 the two serial correction sweeps pass 64 stages' worth of 84 x 84
+    # KKT inverses (Gauss-Jordan here, two LLTs in the oracle): 1e-10 .. 2e-10 depending on the last bits of the inputs
     for f in OCP_DIR_FIELDS:
-        assert rel_err(g.get(f), o.get(f)) < TOL, f
+        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 5e-10), f
     ao, bo = o.step_sizes()
     ag, bg = g.step_sizes()
     assert abs(ag[0] - ao) < 1e-10 and abs(bg[0] - bo) < 1e-10

@@ -116,9 +116,8 @@ SWAP_IN_PLACE = [([0, 1, 1, 0], 0.52), ([1, 0, 0, 1], 0.83)]        # {LH, RF} -
 @pytest.mark.parametrize("events", [LIFT_TOUCH, SWAP_IN_PLACE], ids=["touch-down", "swap"])
 def test_converges_like_the_oracle(events):
     """Undamped ParNMPC iterations on a chain with a lift, an aux and an impulse stage: the GPU path walks the same transient
-    (KKT error up to a few hundred) and reaches the same KKT point as the oracle.  (Longer chains converge too -- the oracle test
-    runs five events -- but through transients of 1e4 and more that no longer let two FP64 implementations be compared
-    iteration by iteration.)"""
+    (KKT error up to a few hundred) and reaches the same KKT point as the oracle.  (Longer chains pass through transients of
+    1e4 and more that no longer let two FP64 implementations be compared iteration by iteration.)"""
     m, o, g, q, v = make_pair(20, 1.0, events, batch=2)
     M = check_chain(o, g)
     for it in range(36):
