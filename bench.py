@@ -188,13 +188,12 @@ def run_parnmpc(args, rank, local_rank, world, dist):
     if trot:
         # the "trotting variant" of configs[3]: the contact sequence of examples/anymal/anymal_trotting.cpp over the whole horizon
         # (a lift-off, then a touch-down + lift-off every 0.5 s: one lift stage and an aux / impulse pair per touch-down in the
-        # chain), events a quarter of a time step off the grid.  One GPU.  The ITERATE IS FROZEN at the initial guess (the step
+        # chain), events a quarter of a time step off the grid; sharded like the event-free horizon (every rank keeps its slice of
+        # the chain, idocp_parnmpc_create_hybrid_shard).  The ITERATE IS FROZEN at the initial guess (the step
         # sizes are set to 0 after every direction has been computed): ParNMPC has no globalisation, and from a standing cold
         # start its iteration does not contract on this problem -- in the CPU restatement exactly as here (it does converge, to
         # 1e-12, on short horizons with the footholds in place: tests/test_oracle_parnmpc.py, tests/test_parnmpc_hybrid_gpu.py).
         # Every kernel of the iteration runs on the full chain; the integration adds 0 * direction.
-        if world != 1:
-            raise SystemExit("anymal_parnmpc_trotting runs on one GPU (chains with discrete events are not sharded)")
         n_events = int((T - 0.5125) / 0.5) + 1
         shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank, max_num_impulse=n_events)
 

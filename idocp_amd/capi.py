@@ -151,6 +151,8 @@ def _proto(lib):
     lib.idocp_parnmpc_compute_kkt_residual.restype = ci
     lib.idocp_parnmpc_create_shard.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, ci, ci, P(vp)]
     lib.idocp_parnmpc_create_shard.restype = ci
+    lib.idocp_parnmpc_create_hybrid_shard.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, ci, ci, P(vp)]
+    lib.idocp_parnmpc_create_hybrid_shard.restype = ci
     lib.idocp_parnmpc_halo_size.argtypes = [ci]
     lib.idocp_parnmpc_halo_size.restype = ci
     lib.idocp_parnmpc_export_halo.argtypes = [vp, ci, vp]

@@ -114,6 +114,7 @@ struct idocp_ocp {
   int* d_impulse_pos = nullptr;
   int* d_general_pos = nullptr;     // ParNMPC: chain positions of the aux (switching rows) / impulse stages
   int n_general = 0;
+  int slice_begin = 0, slice_end = -1;   // ParNMPC with events: this handle keeps the grid stages [slice_begin, slice_end) of the chain (-1: all)
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
   int M() const { return (int)chain.size(); }
 };
@@ -303,7 +304,7 @@ int discretize(idocp_ocp* h, double t) {
 // switching constraint of its impulse (sw_* fields of the node, with sw_dt1 = sw_dt2 = 0: the constraint acts on the aux
 // stage's own configuration).
 int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
-  if (h->stage_offset != 0 || !h->has_terminal || h->has_prev) { set_last_error("ParNMPC: horizon shards carry event-free horizons only"); return IDOCP_E_UNSUPPORTED; }
+  if (h->stage_offset != 0) { set_last_error("ParNMPC: a horizon with discrete events is sharded by idocp_parnmpc_create_hybrid_shard"); return IDOCP_E_UNSUPPORTED; }
   const int Nid = h->N;
   const double dt_ideal = h->T / Nid, min_dt = std::sqrt(std::numeric_limits<double>::epsilon()), max_dt = dt_ideal - min_dt;
   std::vector<int> ev_imp, ev_lift;
@@ -386,19 +387,50 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
     }
     node(0, i, ts[i], dts[i], h->phases[phase[i]], (i == Ng - 1) ? Nid : i + 1);      // parnmpc_linearizer.cpp:43-58
   }
-  {
+  bool is_last_shard = true, is_first_shard = true;
+  if (h->slice_end >= 0) {
+    // A shard of the chain (idocp_parnmpc_create_hybrid_shard): the grid stages [slice_begin, slice_end) and the event stages in
+    // front of each of them; slots and constraint levels stay the global ones.  The placeholder behind the slice is the slot of
+    // the right neighbour's first stage, where the imported halos (lmd, gmm, q, aux_mat, corrected lmd, gmm) land.
+    const int lo = h->slice_begin, hi = std::min(h->slice_end, Ng);
+    std::vector<OcpNode> nodes;
+    std::vector<int> idx;
+    std::vector<double> tt;
+    int next_slot = -1;
+    for (size_t p = 0; p < h->chain.size(); ++p) {
+      size_t g = p;
+      while (h->chain[g].kind != 0) ++g;                            // event stages precede their grid stage
+      const int owner = h->chain_index[g];
+      if (owner >= lo && owner < hi) { nodes.push_back(h->chain[p]); idx.push_back(h->chain_index[p]); tt.push_back(h->chain_t[p]); }
+      else if (owner >= hi && next_slot < 0) next_slot = h->chain[p].slot;
+    }
+    if (nodes.empty()) { set_last_error("ParNMPC: empty shard of the chain"); return IDOCP_E_ARG; }
+    h->chain.swap(nodes); h->chain_index.swap(idx); h->chain_t.swap(tt);
+    is_first_shard = lo == 0; is_last_shard = hi >= Ng;
+    if (!is_last_shard) {
+      OcpNode nd;
+      std::memset(&nd, 0, sizeof(nd));
+      nd.kind = 4; nd.slot = next_slot; nd.level = Nid; nd.has_u = 1; nd.dt = dt_ideal; nd.dtq = dt_ideal;
+      fillStatus(nd, h->phases[0]);
+      h->chain.push_back(nd); h->chain_index.push_back(hi); h->chain_t.push_back(t + h->T);
+    }
+    h->has_switch = false;
+    for (const OcpNode& nd : h->chain) if (nd.sw_dimi > 0) h->has_switch = true;
+  }
+  if (is_last_shard) {
     OcpNode nd;                                                     // placeholder behind the last stage (see below)
     std::memset(&nd, 0, sizeof(nd));
     nd.kind = 4; nd.slot = Nid; nd.level = Nid; nd.has_u = 1; nd.dt = dt_ideal; nd.dtq = dt_ideal;
     fillStatus(nd, h->phases[phase[Ng - 1]]);
     h->chain.push_back(nd); h->chain_index.push_back(Ng); h->chain_t.push_back(t + h->T);
   }
+  h->has_terminal = is_last_shard; h->has_prev = !is_first_shard;
   const int M = h->M();
   for (int p = 0; p < M; ++p) {
     h->chain[p].prev = p > 0 ? h->chain[p - 1].slot : -1;
     h->chain[p].next = p + 1 < M ? h->chain[p + 1].slot : -1;
   }
-  h->prob.has_terminal = 1; h->prob.has_prev = 0; h->prob.stage_offset = 0;
+  h->prob.has_terminal = h->has_terminal ? 1 : 0; h->prob.has_prev = h->has_prev ? 1 : 0; h->prob.stage_offset = 0;
   h->Ngrid = Ng - 1;
   h->uniform_dimf = -1;
   std::vector<double> tab((size_t)M * DQ::NQ);
@@ -1121,6 +1153,19 @@ int idocp_parnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* c
   int rc = createOcpImpl(model, cost, constraints, T, N, 0, batch, device, true, out);
   if (rc) return rc;
   (*out)->stage_offset = stage_offset; (*out)->has_terminal = has_terminal != 0; (*out)->has_prev = has_prev != 0;
+  (*out)->seq_dirty = true;
+  return IDOCP_OK;
+}
+// A shard of a horizon WITH discrete events: the handle discretises the whole horizon (T, N, the contact sequence pushed on
+// every rank alike) and keeps the grid stages [stage_begin, stage_end) of the chain together with the event stages in front
+// of each of them; the halos are those of an event-free shard (they only carry q, v, lmd, gmm and aux_mat).
+int idocp_parnmpc_create_hybrid_shard(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
+                                      int N, int max_num_impulse, int stage_begin, int stage_end, int batch, int device, idocp_ocp_t** out) {
+  if (stage_begin < 0 || stage_end <= stage_begin || stage_end > N) { set_last_error("invalid value: 0 <= stage_begin < stage_end <= N must hold!"); return IDOCP_E_ARG; }
+  int rc = createOcpImpl(model, cost, constraints, T, N, max_num_impulse, batch, device, true, out);
+  if (rc) return rc;
+  (*out)->slice_begin = stage_begin; (*out)->slice_end = stage_end;
+  (*out)->has_terminal = stage_end == N; (*out)->has_prev = stage_begin > 0;
   (*out)->seq_dirty = true;
   return IDOCP_OK;
 }

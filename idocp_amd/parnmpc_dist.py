@@ -117,10 +117,10 @@ class HipParNMPCShard:
         self.dev = torch.device("cuda", device)
         h = C.c_void_p()
         if max_num_impulse > 0:
-            # a horizon with discrete events lives on one GPU (the chain of event stages is not sharded yet)
-            assert world == 1, "horizons with discrete events are not sharded"
-            capi.check(self.lib.idocp_parnmpc_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse, batch, device,
-                                                            C.byref(h)), "idocp_parnmpc_create_hybrid")
+            # a horizon with discrete events: every rank holds the whole contact sequence and keeps its slice of the chain
+            capi.check(self.lib.idocp_parnmpc_create_hybrid_shard(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse,
+                                                                  rank * self.Nl, (rank + 1) * self.Nl, batch, device, C.byref(h)),
+                       "idocp_parnmpc_create_hybrid_shard")
         else:
             capi.check(self.lib.idocp_parnmpc_create_shard(C.byref(model), C.byref(cost), C.byref(cons), T / world, self.Nl, rank * self.Nl,
                                                            1 if rank == world - 1 else 0, 1 if rank > 0 else 0, batch, device, C.byref(h)),

@@ -383,6 +383,12 @@ int idocp_parnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* c
                                const idocp_constraints_t* constraints, double T, int N,
                                int stage_offset, int has_terminal, int has_prev, int batch,
                                int device, idocp_ocp_t** out);
+/* The same for a horizon WITH discrete events: every rank creates its handle with the whole horizon (T, N, max_num_impulse) and
+ * pushes the whole contact sequence; the handle keeps the grid stages [stage_begin, stage_end) of the ParNMPCDiscretizer chain
+ * and the event stages in front of each of them.  Halos as above. */
+int idocp_parnmpc_create_hybrid_shard(const idocp_model_t* model, const idocp_cost_t* cost,
+                                      const idocp_constraints_t* constraints, double T, int N, int max_num_impulse,
+                                      int stage_begin, int stage_end, int batch, int device, idocp_ocp_t** out);
 int idocp_parnmpc_halo_size(int kind);
 int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf);
 int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf);

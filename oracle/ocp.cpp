@@ -1009,13 +1009,15 @@ int ParNMPCSolver::haloSize(int kind) const {
 void ParNMPCSolver::exportHalo(int kind, double* out) const {
   const int nq = robot.dimq(), nv = nv_;
   auto put = [&](const Mat& m, int off) { for (int k = 0; k < m.size(); ++k) out[off + k] = m[k]; };
+  // first / last stage of this shard's chain (slots 0 and N - 1 of an event-free shard)
+  const int first = chain.empty() ? 0 : chain.front().slot, last = chain.empty() ? N_ - 1 : chain.back().slot;
   switch (kind) {
-    case 0: put(s[N_ - 1].q, 0); put(s[N_ - 1].v, nq); break;
-    case 1: put(s[0].lmd, 0); put(s[0].gmm, nv); put(s[0].q, 2 * nv); break;
-    case 2: put(aux_mat[0], 0); break;
-    case 3: put(s_new[0].lmd, 0); put(s_new[0].gmm, nv); break;
-    case 4: put(s_new[N_ - 1].q, 0); put(s_new[N_ - 1].v, nq); break;
-    default: put(aux_mat[0], 0); break;
+    case 0: put(s[last].q, 0); put(s[last].v, nq); break;
+    case 1: put(s[first].lmd, 0); put(s[first].gmm, nv); put(s[first].q, 2 * nv); break;
+    case 2: put(aux_mat[first], 0); break;
+    case 3: put(s_new[first].lmd, 0); put(s_new[first].gmm, nv); break;
+    case 4: put(s_new[last].q, 0); put(s_new[last].v, nq); break;
+    default: put(aux_mat[first], 0); break;
   }
 }
 void ParNMPCSolver::importHalo(int kind, const double* in) {
@@ -1094,7 +1096,7 @@ void ParNMPCSolver::discretize(double t) {
     discretized_ = true; disc_t_ = t;
     return;
   }
-  if (stage_offset != 0 || !has_terminal || has_prev) throw std::logic_error("ParNMPC oracle: horizon sharding only without discrete events");
+  if (stage_offset != 0) throw std::logic_error("ParNMPC oracle: a horizon with discrete events is sharded by setChainSlice");
   const int Nid = N_ideal_, Ni = seq.numImpulse(), Nl = seq.numLift();
   const double dt_ideal = dt_, min_dt = std::sqrt(std::numeric_limits<double>::epsilon()), max_dt = dt_ideal - min_dt;
   std::vector<int> tsai(Ni + 1, -1), tsal(Nl + 1, -1);      // time stage AFTER the impulse / lift
@@ -1157,6 +1159,22 @@ void ParNMPCSolver::discretize(double t) {
     nd.slot = i; nd.index = i; nd.t = ts[i]; nd.dt = dts[i]; nd.phase = phase[i];
     nd.level = (i == N_ - 1) ? N_ideal_ : i + 1;        // parnmpc_linearizer.cpp:43-58: terminal.initConstraints(robot, N_ideal, ...)
     chain.push_back(nd);
+  }
+  if (slice_end >= 0) {
+    // a shard of the chain: the grid stages [slice_begin, slice_end) and the event stages in front of each of them
+    const int lo = slice_begin, hi = std::min(slice_end, N_);
+    std::vector<PNode> mine;
+    int owner = 0;                                   // grid stage the current node belongs to
+    for (size_t p = 0; p < chain.size(); ++p) {
+      // event stages precede their grid stage: look ahead for it
+      size_t g = p;
+      while (chain[g].kind != NodeC::Stage && chain[g].kind != NodeC::Terminal) ++g;
+      owner = chain[g].index;
+      if (owner >= lo && owner < hi) mine.push_back(chain[p]);
+    }
+    chain.swap(mine);
+    has_prev = lo > 0;
+    has_terminal = hi >= N_;
   }
   discretized_ = true; disc_t_ = t;
 }

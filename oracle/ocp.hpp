@@ -251,6 +251,11 @@ class ParNMPCSolver {
   // corrected state of the left neighbour's last stage for the forward sweep.
   int stage_offset = 0;
   bool has_terminal = true, has_prev = false;
+  // Horizons WITH discrete events are sharded by a slice of the chain instead: this object discretises the whole horizon and
+  // keeps the grid stages [slice_begin, slice_end) together with the event stages in front of each of them (slots and
+  // constraint levels stay the global ones); has_prev / has_terminal follow from the slice.  slice_end < 0: the whole chain.
+  int slice_begin = 0, slice_end = -1;
+  void setChainSlice(int stage_begin, int stage_end) { slice_begin = stage_begin; slice_end = stage_end; discretized_ = false; }
   SplitSolutionC next_s, next_snew, prev_s, prev_snew;
   Mat next_aux;
   // kinds: 0 state_last (q, v of the last stage -> right), 1 costate_first (lmd, gmm, q of the first stage -> left),

@@ -666,6 +666,12 @@ int oracle_parnmpc_set_shard(void* h, int stage_offset, int has_terminal, int ha
   s->stage_offset = stage_offset; s->has_terminal = has_terminal != 0; s->has_prev = has_prev != 0;
   return 0;
 }
+// a horizon WITH discrete events: this object keeps the grid stages [stage_begin, stage_end) of the whole horizon and the event
+// stages in front of them
+int oracle_parnmpc_set_chain_slice(void* h, int stage_begin, int stage_end) {
+  static_cast<ParNMPCSolver*>(h)->setChainSlice(stage_begin, stage_end);
+  return 0;
+}
 // 0 linearize + coarse update, 1 backward serial, 2 backward parallel, 3 forward serial, 4 forward parallel (+ directions,
 // local step sizes), 5 integrate
 int oracle_parnmpc_phase(void* h, int phase, double t, const double* q, const double* v) {

@@ -787,11 +787,17 @@ class OracleParNMPCShard:
     """Shard backend of idocp_amd.parnmpc_dist.ShardedParNMPC on top of the oracle (one instance, CPU tensors)."""
     PHASES = {"linearize": 0, "bwd_serial": 1, "bwd_parallel": 2, "fwd_serial": 3, "fwd_parallel": 4, "integrate": 5}
 
-    def __init__(self, model, cost, cons, T, N, rank, world, q0, v0):
+    def __init__(self, model, cost, cons, T, N, rank, world, q0, v0, max_num_impulse=0):
         assert N % world == 0
         self.Nl = N // world
-        self.o = OracleParNMPC(model, cost, cons, T / world, self.Nl)
-        self.o.lib.oracle_parnmpc_set_shard(self.o.h, rank * self.Nl, 1 if rank == world - 1 else 0, 1 if rank > 0 else 0)
+        if max_num_impulse > 0:
+            # a horizon with discrete events: every shard discretises the whole horizon and keeps its slice of the chain
+            self.o = OracleParNMPC(model, cost, cons, T, N, max_num_impulse=max_num_impulse)
+            self.o.lib.oracle_parnmpc_set_chain_slice.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            self.o.lib.oracle_parnmpc_set_chain_slice(self.o.h, rank * self.Nl, (rank + 1) * self.Nl)
+        else:
+            self.o = OracleParNMPC(model, cost, cons, T / world, self.Nl)
+            self.o.lib.oracle_parnmpc_set_shard(self.o.h, rank * self.Nl, 1 if rank == world - 1 else 0, 1 if rank > 0 else 0)
         self.batch = 1
         self.q_prev, self.v_prev = arr(q0).copy(), arr(v0).copy()      # rank 0: the measured state; else the imported halo
         self.nq = model.nq

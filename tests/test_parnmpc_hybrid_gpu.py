@@ -128,3 +128,84 @@ def test_converges_like_the_oracle(events):
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
     assert e_o < 1e-9 and e_g.max() < 1e-9, (e_o, e_g)
     compare(o, g, M, ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "xi"), 1e-8, "converged solution")
+
+
+def test_two_shards_of_a_chain_with_events_on_one_gpu_equal_the_whole_chain():
+    """Horizon sharding of a chain with discrete events (idocp_parnmpc_create_hybrid_shard) without a second GPU: two shard
+    handles on this GPU -- the lift stage in the first, the aux / impulse pair in the second --, the halo protocol of
+    idocp_amd/parnmpc_dist.py executed by hand in its pipeline order, against one handle that holds the whole chain."""
+    import ctypes as C
+    import torch
+    from helpers import P, arr
+    from idocp_amd import capi
+    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    events = [([0, 1, 1, 0], 0.27), ([1, 1, 1, 1], 0.83)]
+    m, o, g, q, v = make_pair(20, 1.0, events)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    lib = capi.lib()
+    shards = [HipParNMPCShard(m, cost, cons, 1.0, 20, r, 2, 1, 0, max_num_impulse=3) for r in range(2)]
+    for sh in shards:
+        capi.check(lib.idocp_ocp_set_contact_status_uniformly(sh.h, (C.c_int * 4)(1, 1, 1, 1), P(arr(pts))))
+        for status, t_ev in events:
+            capi.check(lib.idocp_ocp_push_back_contact_status(sh.h, (C.c_int * 4)(*status), P(arr(pts)), t_ev))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"q", P(arr(ANYMAL_Q_STANDING))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"v", P(np.zeros(m.nv))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"f", P(arr([0, 0, 0.25 * (-m.total_mass * m.gravity[2])]))))
+    s0, s1 = shards
+    s0.set_initial_state(q[None, :], v[None, :])
+    s1.phase("init_aux", 0.0)
+    s0.phase("init_aux", 0.0)
+    s0.import_(5, s1.export(5))
+    for sh in shards:
+        capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
+
+    def boundary():
+        s1.import_(0, s0.export(0))
+        s0.import_(1, s1.export(1))
+        s0.import_(2, s1.export(2))
+
+    def chain_of(sh):
+        cap = 64
+        kind, slot = (C.c_int * cap)(), (C.c_int * cap)()
+        M = lib.idocp_ocp_get_chain(sh.h, 0.0, cap, kind, None, slot, None, None, None)
+        return [(kind[p], slot[p]) for p in range(M)]
+
+    c0, c1, cw = chain_of(s0), chain_of(s1), chain_of(g)
+    # the two slices (without their placeholders) are the whole chain
+    assert c0[:-1] + c1[:-1] == cw[:-1] and 3 in [k for k, _ in c0] and 1 in [k for k, _ in c1] and 2 in [k for k, _ in c1]
+
+    def get(sh, name, dim, n):
+        out = np.zeros((n, dim))
+        capi.check(lib.idocp_ocp_get_solution_chain(sh.h, name.encode(), 0, P(out)))
+        return out
+
+    M = len(cw)
+    for it in range(4):
+        assert g.update(0.0, q, v) == 0
+        boundary()
+        for sh in shards:
+            sh.phase("linearize", 0.0)
+        s1.phase("bwd_serial", 0.0)
+        s0.import_(3, s1.export(3))
+        s0.phase("bwd_serial", 0.0)
+        for sh in shards:
+            sh.phase("bwd_parallel", 0.0)
+        s0.phase("fwd_serial", 0.0)
+        s1.import_(4, s0.export(4))
+        s1.phase("fwd_serial", 0.0)
+        for sh in shards:
+            sh.phase("fwd_parallel", 0.0)
+        steps = torch.minimum(s0.local_steps(), s1.local_steps())
+        ag, bg = g.step_sizes()
+        assert abs(float(steps[0, 0]) - ag[0]) < 1e-10 and abs(float(steps[0, 1]) - bg[0]) < 1e-10
+        for sh in shards:
+            sh.set_steps(steps)
+            sh.phase("integrate", 0.0)
+        for name, dim in (("q", 19), ("v", 18), ("lmd", 18), ("a", 18), ("f", 12)):
+            both = np.concatenate([get(s0, name, dim, len(c0))[:-1], get(s1, name, dim, len(c1))[:-1]])
+            whole = get(g, name, dim, M)[:-1]
+            assert rel_err(both, whole) < 1e-9, (it, name)
+    boundary()
+    e2 = float(s0.err2(0.0)[0] + s1.err2(0.0)[0])
+    assert abs(np.sqrt(e2) - g.kkt_error(0.0, q, v)[0]) < 1e-9 * max(1.0, np.sqrt(e2))
