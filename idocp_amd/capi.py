@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libidocp_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
 
 
 class Model(C.Structure):
@@ -120,6 +121,7 @@ def _proto(lib):
         ("idocp_unocp_get_riccati", [vp, ci, c_double_p, c_double_p, c_double_p, c_double_p]),
         ("idocp_unocp_get_constraint_data", [vp, ci, c_double_p, c_double_p]),
         ("idocp_unocp_dimc", [vp]),
+        ("idocp_unocp_is_current_solution_feasible", [vp, c_int_p, c_int_p]),
         ("idocp_unocp_launch_linearize", [vp, cd, vp, vp]),
         ("idocp_unocp_launch_riccati", [vp, vp, vp]),
         ("idocp_unocp_launch_expand", [vp]),
@@ -207,6 +209,7 @@ def _proto(lib):
         ("idocp_ocp_get_riccati", [vp, ci, c_double_p, c_double_p, c_double_p, c_double_p]),
         ("idocp_ocp_get_state_feedback_gain", [vp, ci, ci, c_double_p, c_double_p]),
         ("idocp_ocp_dimc", [vp]),
+        ("idocp_ocp_is_current_solution_feasible", [vp, c_int_p, c_int_p]),
         ("idocp_ocp_get_constraint_data", [vp, ci, c_double_p, c_double_p]),
         ("idocp_ocp_get_lqr_stage", [vp, ci, ci] + [c_double_p] * 8),
         ("idocp_ocp_launch_kernel", [vp, ci, vp, vp]),

@@ -980,6 +980,54 @@ int idocp_ocp_get_state_feedback_gain(idocp_ocp_t* h, int instance, int stage, d
   return IDOCP_OK;
 }
 
+// OCPSolver::isCurrentSolutionFeasible (ocp_solver.cpp:216-248) / ParNMPCSolver (parnmpc_solver.cpp:231-273): the primal
+// iterate against the inequality constraints, stage by stage along the chain.  A host-side check on the downloaded solution
+// records (a few kB per instance): joint limits with the time-step gating of constraints_data.hpp:18-42, the linearised
+// (impulse) friction cone on the active contacts.  feasible[b] = 1 / 0; where[b] = chain position of the first offending
+// stage in the reference's order (stages, impulses, aux, lifts), -1 if none.
+int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* where) {
+  if (!h || !feasible) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
+  const int M = h->M(), nu = DQ::NU;
+  const OcpProblem& P = h->prob;
+  std::vector<double> sol((size_t)h->batch * h->NS * LQ::SOL);
+  HIP_TRY(hipMemcpyAsync(sol.data(), h->B.sol, sol.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const double m2 = P.mu * 0.70710678118654752440;
+  auto stageOk = [&](const OcpNode& nd, const double* s) {
+    if (nd.kind == 1) {                                               // linearized_impulse_friction_cone.cpp:82-94
+      if (!P.use_impulse_friction_cone) return true;
+    } else {
+      if (P.use_q_limits && nd.level >= 2)                            // joint_position_{lower,upper}_limit.cpp:38-47
+        for (int r = 0; r < nu; ++r) { const double q = s[LQ::S_Q + DQ::NQ - nu + r]; if (q < P.q_min[r] || q > P.q_max[r]) return false; }
+      if (P.use_v_limits && nd.level >= 1)
+        for (int r = 0; r < nu; ++r) { const double v = s[LQ::S_V + DQ::NV - nu + r]; if (v < -P.v_max[r] || v > P.v_max[r]) return false; }
+      if (P.use_u_limits && nd.has_u)
+        for (int r = 0; r < nu; ++r) { const double u = s[LQ::S_U + r]; if (u < -P.u_max[r] || u > P.u_max[r]) return false; }
+      if (!P.use_friction_cone) return true;
+    }
+    for (int c = 0; c < DQ::NC; ++c) {                                // linearized_friction_cone.cpp:87-99
+      if (!nd.active[c]) continue;
+      const double fx = s[LQ::S_F + 3 * c], fy = s[LQ::S_F + 3 * c + 1], fz = s[LQ::S_F + 3 * c + 2];
+      if (-fz > 0 || fx - m2 * fz > 0 || -fx - m2 * fz > 0 || fy - m2 * fz > 0 || -fy - m2 * fz > 0) return false;
+    }
+    return true;
+  };
+  for (int b = 0; b < h->batch; ++b) {
+    int bad = -1;
+    for (int kind = 0; kind < 4 && bad < 0; ++kind)
+      for (int p = 0; p < M && bad < 0; ++p) {
+        const OcpNode& nd = h->chain[p];
+        if (nd.kind != kind) continue;
+        if (!stageOk(nd, &sol[((size_t)b * h->NS + nd.slot) * LQ::SOL])) bad = p;
+      }
+    feasible[b] = bad < 0 ? 1 : 0;
+    if (where) where[b] = bad;
+  }
+  return IDOCP_OK;
+}
+
 int idocp_ocp_dimc(const idocp_ocp_t* h) {
   if (!h) return 0;
   const idocp_constraints_t& c = h->cons;

@@ -410,6 +410,32 @@ int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s
   return IDOCP_OK;
 }
 
+// UnOCPSolver::isCurrentSolutionFeasible (unocp_solver.cpp:228-237): joint limits of stages 0..N-1 with the time-step
+// gating of constraints_data.hpp:18-42, checked on the host from the downloaded solution records.
+int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, int* where) {
+  if (!h || !feasible) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  const int nv = h->nv, N = h->N;
+  std::vector<double> sol((size_t)h->batch * (N + 1) * L7::SOL);
+  HIP_TRY(hipMemcpyAsync(sol.data(), h->B.sol, sol.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const idocp_model_t& m = h->model;
+  for (int b = 0; b < h->batch; ++b) {
+    int bad = -1;
+    for (int i = 0; i < N && bad < 0; ++i) {
+      const double* s = &sol[((size_t)b * (N + 1) + i) * L7::SOL];
+      for (int r = 0; r < nv && bad < 0; ++r) {
+        if (h->cons.joint_position_limits && i >= 2 && (s[L7::S_Q + r] < m.q_min[r] || s[L7::S_Q + r] > m.q_max[r])) bad = i;
+        if (h->cons.joint_velocity_limits && i >= 1 && (s[L7::S_V + r] < -m.v_max[r] || s[L7::S_V + r] > m.v_max[r])) bad = i;
+        if (h->cons.joint_torque_limits && (s[L7::S_U + r] < -m.u_max[r] || s[L7::S_U + r] > m.u_max[r])) bad = i;
+      }
+    }
+    feasible[b] = bad < 0 ? 1 : 0;
+    if (where) where[b] = bad;
+  }
+  return IDOCP_OK;
+}
+
 int idocp_unocp_dimc(const idocp_unocp_t* h) {
   if (!h) return 0;
   return h->nv * 2 * ((h->cons.joint_position_limits ? 1 : 0) + (h->cons.joint_velocity_limits ? 1 : 0) + (h->cons.joint_torque_limits ? 1 : 0));

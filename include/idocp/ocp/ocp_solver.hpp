@@ -80,6 +80,14 @@ class OCPSolver {
     return s;
   }
 
+  // OCPSolver::isCurrentSolutionFeasible (ocp_solver.cpp:216-248)
+  bool isCurrentSolutionFeasible() {
+    int ok = 0, where = -1;
+    check(idocp_ocp_is_current_solution_feasible(h_, &ok, &where));
+    if (!ok) std::cout << "INFEASIBLE at stage " << where << " of the discretised horizon" << std::endl;
+    return ok != 0;
+  }
+
   // OCPSolver::getStateFeedbackGain (ocp_solver.cpp:103-113): du = Kq dq + Kv dv
   void getStateFeedbackGain(const int time_stage, Eigen::MatrixXd& Kq, Eigen::MatrixXd& Kv) const {
     const int nv = robot_.dimv(), nu = robot_.dimu();

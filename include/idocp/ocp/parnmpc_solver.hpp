@@ -89,6 +89,14 @@ class ParNMPCSolver {
   void popFrontContactStatus() { check(idocp_ocp_pop_front_contact_status(h_)); }
   void clearLineSearchFilter() {}
 
+  // ParNMPCSolver::isCurrentSolutionFeasible (parnmpc_solver.cpp:231-273)
+  bool isCurrentSolutionFeasible() {
+    int ok = 0, where = -1;
+    check(idocp_ocp_is_current_solution_feasible(h_, &ok, &where));
+    if (!ok) std::cout << "INFEASIBLE at stage " << where << " of the discretised horizon" << std::endl;
+    return ok != 0;
+  }
+
   double KKTError() {
     double e = 0;
     check(idocp_ocp_kkt_error(h_, &e));

@@ -87,6 +87,14 @@ class UnOCPSolver {
   void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_unocp_set_solution(h_, name.c_str(), value.data())); }
   void clearLineSearchFilter() {}
 
+  // UnOCPSolver::isCurrentSolutionFeasible (unocp_solver.cpp:228-237)
+  bool isCurrentSolutionFeasible() {
+    int ok = 0, where = -1;
+    check(idocp_unocp_is_current_solution_feasible(h_, &ok, &where));
+    if (!ok) std::cout << "INFEASIBLE at time stage " << where << std::endl;
+    return ok != 0;
+  }
+
   double KKTError() {
     double e = 0;
     check(idocp_unocp_kkt_error(h_, &e));

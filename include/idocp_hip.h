@@ -229,6 +229,11 @@ int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s
 int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance,
                                     double* slack, double* dual);
 int idocp_unocp_dimc(const idocp_unocp_t* h);
+/* UnOCPSolver::isCurrentSolutionFeasible (unocp_solver.cpp:228-237): feasible[batch]
+ * = 1 if the primal iterate satisfies the joint limits on every stage (with the
+ * time-step gating of constraints_data.hpp:18-42), else 0; where[batch] (may be
+ * NULL) = first offending stage or -1. */
+int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, int* where);
 
 /* Kernel-level entry points used by the parity tests and the roofline
  * measurement (one launch each, on the handle's stream). */
@@ -332,6 +337,12 @@ int idocp_ocp_get_riccati_chain(idocp_ocp_t* h, int instance, double* P, double*
 int idocp_ocp_get_state_feedback_gain(idocp_ocp_t* h, int instance, int stage, double* Kq,
                                       double* Kv);
 int idocp_ocp_dimc(const idocp_ocp_t* h);
+/* OCPSolver::isCurrentSolutionFeasible (ocp_solver.cpp:216-248) and
+ * ParNMPCSolver::isCurrentSolutionFeasible (parnmpc_solver.cpp:231-273): feasible[batch]
+ * = 1 if the primal iterate satisfies the joint limits and the linearised (impulse)
+ * friction cones on every stage of the current chain; where[batch] (may be NULL) =
+ * chain position of the first offending stage (stages, then impulses, aux, lifts) or -1. */
+int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* where);
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual);
 /* Condensed LQR data of one stage after the linearisation kernels (parity tests):
  * Qxx[2nv*2nv], Qxu[2nv*nu], Quu[nu*nu], A[2nv*2nv], B[2nv*nu], lx[2nv], lu[nu], Fx[2nv]. */

@@ -644,6 +644,31 @@ void OCPSolver::computeKKTResidual(double t, const Mat& q, const Mat& /*v*/) {
 
 // OCPLinearizer::KKTError (ocp_linearizer.cpp:98-137); SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267);
 // ImpulseSplitOCP::squaredNormKKTResidual (impulse_split_ocp.hxx:127-137)
+// OCPSolver::isCurrentSolutionFeasible (ocp_solver.cpp:216-248) with the component tests of joint_*_limit.cpp:36-47 and
+// linearized_(impulse_)friction_cone.cpp:82-99, in the reference's order (stages; the terminal stage carries no constraints, impulses, aux, lifts)
+int OCPSolver::isCurrentSolutionFeasible() const {
+  for (int kind = NodeC::Stage; kind <= NodeC::Lift; ++kind)
+    for (int p = 0; p < (int)chain.size(); ++p) {
+      const auto& nd = chain[p];
+      if (!(nd.kind == kind)) continue;
+      const SplitSolutionC& si = s[nd.slot];
+      for (int c = 0; c < 6; ++c) {
+        if (!componentValid(c, nd)) continue;
+        for (int r = 0; r < nu_; ++r) {
+          const double x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
+          if ((c & 1) ? x > lim : x < lim) return p;
+        }
+      }
+      if (!componentValid(6, nd)) continue;
+      const ContactStatus& cs = nodeContacts(p);
+      for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        for (int r = 0; r < 5; ++r) if (res[r] > 0) return p;
+      }
+    }
+  return -1;
+}
+
 double OCPSolver::KKTError() {
   double sum = 0;
   for (int p = 0; p < M() - 1; ++p) {
@@ -1958,6 +1983,31 @@ void ParNMPCSolver::computeKKTResidual(double t, const Mat& q, const Mat& v) {
 // ParNMPCLinearizer::KKTError (parnmpc_linearizer.cpp:203-247); SplitParNMPC::squaredNormKKTResidual (split_parnmpc.hxx:250-266;
 // the switching-constraint residual of an aux stage included), ImpulseSplitParNMPC::squaredNormKKTResidual
 // (impulse_split_parnmpc.hxx:114-124): note that the constraint residuals are NOT weighted by dt^2 here, unlike SplitOCP
+// ParNMPCSolver::isCurrentSolutionFeasible (parnmpc_solver.cpp:231-273) with the component tests of joint_*_limit.cpp:36-47 and
+// linearized_(impulse_)friction_cone.cpp:82-99, in the reference's order (stages incl. the terminal one, impulses, aux, lifts)
+int ParNMPCSolver::isCurrentSolutionFeasible() const {
+  for (int kind = NodeC::Stage; kind <= NodeC::Lift; ++kind)
+    for (int p = 0; p < (int)chain.size(); ++p) {
+      const auto& nd = chain[p];
+      if (!(nd.kind == kind || (kind == NodeC::Stage && nd.kind == NodeC::Terminal))) continue;
+      const SplitSolutionC& si = s[nd.slot];
+      for (int c = 0; c < 6; ++c) {
+        if (!componentValid(c, nd)) continue;
+        for (int r = 0; r < nu_; ++r) {
+          const double x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
+          if ((c & 1) ? x > lim : x < lim) return p;
+        }
+      }
+      if (!componentValid(6, nd)) continue;
+      const ContactStatus& cs = nodeContacts(nd);
+      for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        for (int r = 0; r < 5; ++r) if (res[r] > 0) return p;
+      }
+    }
+  return -1;
+}
+
 double ParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
 double ParNMPCSolver::KKTErrorSquared() {
   double sum = 0;

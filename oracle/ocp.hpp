@@ -126,6 +126,7 @@ class OCPSolver {
   void updateSolution(double t, const Mat& q, const Mat& v);         // ocp_solver.cpp:67-92
   void computeKKTResidual(double t, const Mat& q, const Mat& v);     // ocp_solver.cpp:202-207
   double KKTError();                                                 // ocp_linearizer.cpp:98-137
+  int isCurrentSolutionFeasible() const;                             // ocp_solver.cpp:216-248: first offending chain position or -1
 
   void discretize(double t);                                         // OCPDiscretizer::discretizeOCP (ocp_discretizer.hxx:65-374)
   void linearizeOCP(double t, const Mat& q);                         // K5
@@ -202,6 +203,7 @@ class ParNMPCSolver {
   void updateSolution(double t, const Mat& q, const Mat& v);           // parnmpc_solver.cpp:73-103
   void computeKKTResidual(double t, const Mat& q, const Mat& v);
   double KKTError();                                                   // parnmpc_linearizer.cpp:203-247
+  int isCurrentSolutionFeasible() const;                               // parnmpc_solver.cpp:231-273: first offending chain position or -1
   // the phases of updateSolution, separately callable
   void coarseUpdate(double t, const Mat& q, const Mat& v);
   void backwardCorrectionSerial();

@@ -190,6 +190,7 @@ int oracle_unocp_compute_kkt_residual(void* h, double t, const double* q, const 
   s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
   return 0;
 }
+int oracle_unocp_is_current_solution_feasible(void* h) { return static_cast<UnOCPSolver*>(h)->isCurrentSolutionFeasible(); }
 double oracle_unocp_kkt_error(void* h) { return static_cast<UnOCPSolver*>(h)->KKTError(); }
 
 static const Mat* solField(const SplitSolution& s, const std::string& n) {
@@ -373,6 +374,7 @@ int oracle_ocp_compute_kkt_residual(void* h, double t, const double* q, const do
   s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
   return 0;
 }
+int oracle_ocp_is_current_solution_feasible(void* h) { return static_cast<OCPSolver*>(h)->isCurrentSolutionFeasible(); }
 double oracle_ocp_kkt_error(void* h) { return static_cast<OCPSolver*>(h)->KKTError(); }
 // reference configuration of the configuration-space cost at time t (q_ref[nq])
 void oracle_ocp_q_ref(void* h, double t, double* q_ref) {
@@ -623,6 +625,7 @@ int oracle_parnmpc_update_solution(void* h, double t, const double* q, const dou
   catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
   return 0;
 }
+int oracle_parnmpc_is_current_solution_feasible(void* h) { return static_cast<ParNMPCSolver*>(h)->isCurrentSolutionFeasible(); }
 double oracle_parnmpc_kkt_error(void* h, double t, const double* q, const double* v) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
   s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));

@@ -437,6 +437,20 @@ void UnOCPSolver::computeKKTResidual(double t, const Mat& /*q*/, const Mat& /*v*
 }
 
 // UnOCPSolver::KKTError (unocp_solver.cpp:190-202) / squaredNormKKTResidual (split_unocp.hxx:164-174)
+// UnOCPSolver::isCurrentSolutionFeasible (unocp_solver.cpp:228-237) with the component tests of
+// joint_{position,velocity,torques}_{lower,upper}_limit.cpp:36-47
+int UnOCPSolver::isCurrentSolutionFeasible() const {
+  for (int i = 0; i < N_; ++i)
+    for (const JointLimit& jl : constraints.components) {
+      if (!constraints.valid(jl, i)) continue;
+      const Mat& x = varOf(jl, s[i]);
+      const int n = jl.lim.size(), off = x.size() - n;
+      for (int r = 0; r < n; ++r)
+        if (jl.sign < 0 ? x[off + r] < jl.lim[r] : x[off + r] > jl.lim[r]) return i;
+    }
+  return -1;
+}
+
 double UnOCPSolver::KKTError() {
   double sum = 0;
   for (int i = 0; i < N_; ++i) {

@@ -107,6 +107,7 @@ class UnOCPSolver {
   void updateSolution(double t, const Mat& q, const Mat& v);      // unocp_solver.cpp:73-134
   void computeKKTResidual(double t, const Mat& q, const Mat& v);  // unocp_solver.cpp:205-225
   double KKTError();                                              // unocp_solver.cpp:190-202
+  int isCurrentSolutionFeasible() const;                          // unocp_solver.cpp:228-237: first offending stage or -1
 
   // hot-path pieces, exposed so kernel-level parity tests can stop in between
   void linearizeOCP(double t, const Mat& q);                      // K1

@@ -44,6 +44,7 @@ def oracle():
         lib.oracle_unocp_compute_kkt_residual.argtypes = [vp, cd, dp, dp]
         lib.oracle_unocp_kkt_error.argtypes = [vp]
         lib.oracle_unocp_kkt_error.restype = cd
+        lib.oracle_unocp_is_current_solution_feasible.argtypes = [vp]
         lib.oracle_unocp_get_solution.argtypes = [vp, cs, dp]
         lib.oracle_unocp_get_direction.argtypes = [vp, cs, dp]
         lib.oracle_unocp_get_step_sizes.argtypes = [vp, dp, dp]
@@ -118,6 +119,10 @@ class OracleUnOCP:
     def stage(self, what, t, q, v):
         return self.lib.oracle_unocp_stage(self.h, what, t, P(arr(q)), P(arr(v)))
 
+    def infeasible_stage(self):
+        """first stage violating an inequality constraint, -1 if the iterate is feasible"""
+        return self.lib.oracle_unocp_is_current_solution_feasible(self.h)
+
     def kkt_error(self, t, q, v):
         self.lib.oracle_unocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v)))
         return self.lib.oracle_unocp_kkt_error(self.h)
@@ -183,6 +188,13 @@ class HipUnOCP:
         q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
         v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
         return self.lib.idocp_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)), 0)
+
+    def infeasible_stage(self):
+        ok, where = np.zeros(self.batch, dtype=np.int32), np.zeros(self.batch, dtype=np.int32)
+        capi.check(self.lib.idocp_unocp_is_current_solution_feasible(self.h, ok.ctypes.data_as(capi.c_int_p),
+                                                                     where.ctypes.data_as(capi.c_int_p)), "is_feasible")
+        assert np.all((where < 0) == (ok == 1))
+        return where
 
     def kkt_error(self, t, q, v):
         q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
@@ -389,6 +401,7 @@ def _setup_oracle_ocp(lib):
     lib.oracle_ocp_compute_kkt_residual.argtypes = [vp, cd, dp, dp]
     lib.oracle_ocp_kkt_error.argtypes = [vp]
     lib.oracle_ocp_kkt_error.restype = cd
+    lib.oracle_ocp_is_current_solution_feasible.argtypes = [vp]
     lib.oracle_ocp_q_ref.argtypes = [vp, cd, dp]
     lib.oracle_ocp_get.argtypes = [vp, cs, ci, dp]
     lib.oracle_ocp_get_step_sizes.argtypes = [vp, dp, dp]
@@ -483,6 +496,10 @@ class OracleOCP:
     def stage(self, what, t, q, v):
         return self.lib.oracle_ocp_stage(self.h, what, t, P(arr(q)), P(arr(v)))
 
+    def infeasible_stage(self):
+        """chain position of the first stage violating an inequality constraint, -1 if the iterate is feasible"""
+        return self.lib.oracle_ocp_is_current_solution_feasible(self.h)
+
     def kkt_error(self, t, q, v):
         self.lib.oracle_ocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v)))
         return self.lib.oracle_ocp_kkt_error(self.h)
@@ -538,6 +555,7 @@ class OracleParNMPC:
             lib.oracle_parnmpc_update_solution.argtypes = [vp, cd, dp, dp]
             lib.oracle_parnmpc_kkt_error.argtypes = [vp, cd, dp, dp]
             lib.oracle_parnmpc_kkt_error.restype = cd
+            lib.oracle_parnmpc_is_current_solution_feasible.argtypes = [vp]
             lib.oracle_parnmpc_get.argtypes = [vp, cs, ci, dp]
             lib.oracle_parnmpc_get_step_sizes.argtypes = [vp, dp, dp]
             lib.oracle_parnmpc_set_shard.argtypes = [vp, ci, ci, ci]
@@ -600,6 +618,9 @@ class OracleParNMPC:
 
     def update(self, t, q, v):
         return self.lib.oracle_parnmpc_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+
+    def infeasible_stage(self):
+        return self.lib.oracle_parnmpc_is_current_solution_feasible(self.h)
 
     def kkt_error(self, t, q, v):
         return self.lib.oracle_parnmpc_kkt_error(self.h, t, P(arr(q)), P(arr(v)))
@@ -698,6 +719,13 @@ class HipOCP:
 
     def update(self, t, q, v):
         return self.lib.idocp_ocp_update_solution(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv)), 0)
+
+    def infeasible_stage(self):
+        ok, where = np.zeros(self.batch, dtype=np.int32), np.zeros(self.batch, dtype=np.int32)
+        capi.check(self.lib.idocp_ocp_is_current_solution_feasible(self.h, ok.ctypes.data_as(capi.c_int_p),
+                                                                   where.ctypes.data_as(capi.c_int_p)), "is_feasible")
+        assert np.all((where < 0) == (ok == 1))
+        return where
 
     def kkt_error(self, t, q, v):
         capi.check(self.lib.idocp_ocp_compute_kkt_residual(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv))),
