@@ -113,6 +113,8 @@ struct idocp_ocp {
   int n_impulse = 0;
   int* d_impulse_pos = nullptr;
   int* d_general_pos = nullptr;     // ParNMPC: chain positions of the aux (switching rows) / impulse stages
+  int* d_cond_pos = nullptr;        // chain positions by stage class of K5b (all feet | half of them | the rest)
+  int cond_n[3] = {0, 0, 0};
   int n_general = 0;
   int slice_begin = 0, slice_end = -1;   // ParNMPC with events: this handle keeps the grid stages [slice_begin, slice_end) of the chain (-1: all)
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
@@ -292,6 +294,16 @@ int discretize(idocp_ocp* h, double t) {
   for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
   h->n_impulse = (int)ipos.size();
   if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
+  // stage classes of K5b (OcpLaunch::condenseMixed)
+  std::vector<int> cls[3];
+  for (int p = 0; p < M; ++p) {
+    const OcpNode& nd = h->chain[p];
+    const bool plain = (nd.kind == 0 || nd.kind == 2 || nd.kind == 3) && nd.sw_dimi == 0;
+    cls[plain && nd.dimf == DQ::NF ? 0 : (plain && nd.dimf == DQ::NF / 2 ? 1 : 2)].push_back(p);
+  }
+  std::vector<int> cpos;
+  for (int c = 0; c < 3; ++c) { h->cond_n[c] = (int)cls[c].size(); cpos.insert(cpos.end(), cls[c].begin(), cls[c].end()); }
+  HIP_TRY(hipMemcpyAsync(h->d_cond_pos, cpos.data(), sizeof(int) * cpos.size(), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
   h->disc_time = t; h->seq_dirty = false;
@@ -593,6 +605,9 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &tmp, ((size_t)(2 * max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
   h->d_general_pos = reinterpret_cast<int*>(tmp);
   B.general_pos = h->d_general_pos;
+  if ((rc = allocBufO(h, &tmp, ((size_t)h->NS * sizeof(int) + 7) / 8))) return fail(rc);
+  h->d_cond_pos = reinterpret_cast<int*>(tmp);
+  B.cond_pos = h->d_cond_pos;
   B.q_ref = h->d_qref;
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
@@ -803,6 +818,12 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
   return IDOCP_OK;
 }
 
+// K5b: one launch on an event-free chain with all feet in contact, else one launch per stage class
+static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q) {
+  if (h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] == 0) OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream);
+  else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream);
+}
+
 int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
   if (!h || kernel_id < 0 || kernel_id > 6 || !d_q || !d_v) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
@@ -813,7 +834,7 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
       OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
       if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
       break;
-    case 1: OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream); break;
+    case 1: launchCondenseO(h, M, d_q); break;
     case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream); break;
     case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
     default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;
@@ -831,7 +852,7 @@ int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
   OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
-  OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream);
+  launchCondenseO(h, M, d_q);
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
   OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream);
   OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);

@@ -84,7 +84,8 @@ struct CondenseSmem {
 // FQ6 = (q_prev (-) q).head(6) (parnmpc_lie_kernel).  The chain ends with an unused placeholder stage; the last real
 // stage (position M - 2) carries the terminal cost.
 template <typename D, bool RESIDUAL, int DIMF, bool BWD = false>
-__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr) {
+__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
+                                                              const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
   using S = CondenseSmem<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
@@ -94,13 +95,15 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const int M = P->M;
   const int tid = threadIdx.x, nt = 256;
   const long unit = blockIdx.x;                   // over batch * M: one stage of the chain per workgroup
-  const long b = unit / M;
-  const int pos = (int)(unit - b * M);
+  const int per = plist ? nlist : M;              // (or over batch * nlist: the chain positions of one stage class, launchCondenseMixed)
+  const long b = unit / per;
+  const int pos = plist ? plist[unit - b * per] : (int)(unit - b * per);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
   if (BWD && terminal) return;                      // placeholder stage
   const bool last = BWD && P->has_terminal && (pos == M - 2);   // ParNMPC: the stage that carries the terminal cost
-  // DIMF >= 0 is only launched on event-free chains (launchCondense): no impulse stages, no switching constraints
+  // DIMF >= 0 is only launched on stages without an impulse or a switching constraint (launchCondense: event-free chains;
+  // launchCondenseMixed: those stages of a chain with events, grouped by their number of contact rows)
   constexpr bool PLAIN = (DIMF >= 0);
   const bool impulse = PLAIN ? false : (nd->kind == 1);
   if (BWD && impulse) return;                       // ParNMPC: the backward-Euler impulse stage is K9i (parnmpc_event_kernels.hip)
@@ -641,6 +644,28 @@ template <typename D>
 void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st) {
   launchCondense<D>(B, batch, M, dimf, q0, st, false);
 }
+// Chains with discrete events: the stages are grouped on the host by what the kernel can fold at compile time --
+// class 0: all feet in contact, class 1: half of them (trot, pace, bound), both without impulse / switching constraint;
+// class 2: everything else (impulse stages, stages carrying a switching constraint, other contact counts, the terminal
+// stage) on the general instantiation.  B.cond_pos holds the chain positions class by class, n[c] their counts.
+template <typename D>
+void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[3], const double* q0, hipStream_t st) {
+  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  const unsigned blocks = (unsigned)(batch * M);
+  const double* none = nullptr;
+  hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
+  // the largest class first; the launches are independent (every stage writes its own records)
+  if (n[1] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0], n[1]);
+  if (n[0] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]);
+  if (n[2] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]);
+}
 template <typename D>
 void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st) {
   launchCondense<D>(B, batch, M, -1, q0, st, true);
@@ -663,6 +688,7 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::condenseBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, bool, hipStream_t);
 

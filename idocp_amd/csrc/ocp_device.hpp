@@ -145,6 +145,7 @@ struct OcpBuffers {
   const OcpNode* nodes;  // [M] the chain
   const int* impulse_pos; // chain positions of the impulse stages
   const int* general_pos; // ParNMPC: chain positions of the stages with a general KKT shape (aux with switching rows, impulse)
+  const int* cond_pos;    // chain positions grouped by stage class of K5b (OcpLaunch::condenseMixed)
   const double* q_ref;   // [M][NQ] reference configuration of every stage of the chain (time-varying cost)
   // per-stage arrays, indexed [instance][slot] (NS slots per instance)
   double* sol;           // [batch][NS][SOL]
