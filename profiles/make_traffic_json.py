@@ -30,12 +30,11 @@ def per_launch(path, counter):
             key += "_residual"
         elif key.startswith("un_linearize") and re.search(r",\s*1>", name):
             key += "_residual"
-        # several template variants of one kernel (e.g. compile-time contact dimension) share a key
-        cur = out.get(key)
-        val = 1024.0 * total / launches
-        if cur is None or launches > cur[0]:
-            out[key] = (launches, val)
-    return {k: v[1] for k, v in out.items()}
+        # the template variants of one kernel that run side by side in every step (K5b per stage class, K5a regular + impulse
+        # launch) share a key: bytes of all of them per step = sum of their totals / launches of the most frequent one
+        cur = out.get(key, (0, 0.0))
+        out[key] = (max(cur[0], launches), cur[1] + 1024.0 * total)
+    return {k: v[1] / v[0] for k, v in out.items()}
 
 
 def main():

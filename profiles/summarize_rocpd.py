@@ -8,6 +8,13 @@ import sqlite3
 import sys
 
 
+def short(name):
+    """kernel name without the boilerplate, so that the template arguments that tell the variants apart stay visible"""
+    for a, b in (("void ", ""), ("idocp_dev::", ""), ("LeggedDims<4, 3>", "D"), ("_kernel", ""), ("OcpBuffers", "B"), ("double const*", "cd*")):
+        name = name.replace(a, b)
+    return name[:62]
+
+
 def main():
     for path in sys.argv[1:]:
         db = sqlite3.connect(path)
@@ -20,7 +27,7 @@ def main():
             "max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name order by sum(duration) desc")
         for name, n, tot, avg, mn, mx, vg, ag, lds in rows:
             print("%-62s %7d %12.3f %12.2f %12.2f %12.2f %6s %6s %6s" %
-                  (name[:62], n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, vg, ag, lds))
+                  (short(name), n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, vg, ag, lds))
         try:
             rows = list(cur.execute(
                 "select k.name, p.name, count(*), avg(e.value), sum(e.value) "
@@ -31,7 +38,7 @@ def main():
         if rows:
             print("\n%-62s %-22s %7s %16s" % ("kernel", "counter", "samples", "avg_per_dispatch"))
             for kname, cname, n, avg, tot in rows:
-                print("%-62s %-22s %7d %16.1f" % (kname[:62], cname, n, avg))
+                print("%-62s %-22s %7d %16.1f" % (kshort(name), cname, n, avg))
         print()
 
 
