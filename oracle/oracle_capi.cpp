@@ -245,6 +245,92 @@ int oracle_unocp_get_riccati(void* h, double* P, double* sv, double* K, double* 
   }
   return 0;
 }
+// ---- UnParNMPCSolver -----------------------------------------------------
+void* oracle_unparnmpc_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
+  try { return new UnParNMPCSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
+}
+void oracle_unparnmpc_destroy(void* h) { delete static_cast<UnParNMPCSolver*>(h); }
+int oracle_unparnmpc_set_solution(void* h, const char* name, const double* value) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const std::string n(name);
+  try { s->setSolution(n, toVec(value, n == "q" ? s->robot.dimq() : s->robot.dimv())); } catch (...) { return -1; }
+  return 0;
+}
+int oracle_unparnmpc_init(void* h, double t) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  s->initConstraints(); s->initBackwardCorrection(t); return 0;
+}
+int oracle_unparnmpc_update_solution(void* h, double t, const double* q, const double* v) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); } catch (...) { return 1; }
+  return 0;
+}
+// staged execution: 0 coarse update, 1 backward serial, 2 backward parallel, 3 forward serial, 4 forward parallel
+// (+ direction and step sizes), 5 integrate
+int oracle_unparnmpc_stage(void* h, int what, double t, const double* q, const double* v) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  try {
+    if (what == 0) s->coarseUpdate(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+    else if (what == 1) s->backwardCorrectionSerial();
+    else if (what == 2) s->backwardCorrectionParallel();
+    else if (what == 3) s->forwardCorrectionSerial();
+    else if (what == 4) s->forwardCorrectionParallel();
+    else if (what == 5) s->integrate();
+    else return -1;
+  } catch (...) { return 1; }
+  return 0;
+}
+double oracle_unparnmpc_kkt_error(void* h, double t, const double* q, const double* v) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+  return s->KKTError();
+}
+int oracle_unparnmpc_is_current_solution_feasible(void* h) { return static_cast<UnParNMPCSolver*>(h)->isCurrentSolutionFeasible(); }
+// out[N][dim]; names: the solution fields, "d" + field for the direction, "new_" + field for the coarse / corrected iterate
+int oracle_unparnmpc_get(void* h, const char* name, double* out) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const std::string n(name);
+  for (int i = 0; i < s->N(); ++i) {
+    const Mat* f = n.rfind("new_", 0) == 0 ? solField(s->s_new[i], n.substr(4)) : (n[0] == 'd' ? dirField(s->d[i], n) : solField(s->s[i], n));
+    if (!f) return -1;
+    std::memcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
+  }
+  return 0;
+}
+int oracle_unparnmpc_get_step_sizes(void* h, double* primal, double* dual) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  *primal = s->primal_step_size; *dual = s->dual_step_size; return 0;
+}
+// per stage: KKT inverse [N][5nv*5nv] (col-major), aux matrix [N][2nv*2nv]
+int oracle_unparnmpc_get_matrices(void* h, double* kkt_inv, double* aux) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const int nv = s->robot.dimv(), nk = 5 * nv, nx = 2 * nv;
+  for (int i = 0; i < s->N(); ++i) {
+    if (kkt_inv) std::memcpy(kkt_inv + (size_t)i * nk * nk, s->kkt_inv[i].d.data(), sizeof(double) * nk * nk);
+    if (aux) std::memcpy(aux + (size_t)i * nx * nx, s->aux_mat[i].d.data(), sizeof(double) * nx * nx);
+  }
+  return 0;
+}
+// slack / dual [N][dimc]; rows of components that are not valid at a stage are 0
+int oracle_unparnmpc_get_constraint_data(void* h, double* slack, double* dual) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const int dimc = s->constraints.dimc_total();
+  for (int i = 0; i < s->N(); ++i) {
+    int off = 0;
+    for (size_t c = 0; c < s->constraints.components.size(); ++c) {
+      const ConstraintComponentData& data = s->ocp[i].cdata.data[c];
+      const int n = s->constraints.components[c].lim.size();
+      const bool valid = s->constraints.valid(s->constraints.components[c], i + 1);
+      for (int r = 0; r < n; ++r) {
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? data.slack[r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? data.dual[r] : 0.0;
+      }
+      off += n;
+    }
+  }
+  return 0;
+}
+
 int oracle_unocp_dimc(void* h) { return static_cast<UnOCPSolver*>(h)->constraints.dimc_total(); }
 // slack/dual [N][dimc]; rows of components that are not valid at a stage are 0
 int oracle_unocp_get_constraint_data(void* h, double* slack, double* dual) {

@@ -470,4 +470,328 @@ double UnOCPSolver::KKTError() {
   return std::sqrt(sum);
 }
 
+
+// ======================================================================= UnParNMPC ====
+UnParNMPCSolver::UnParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& cons, double T, int N)
+    : robot(model), cost(cost_), constraints(robot, cons),
+      s(N, SplitSolution(robot)), s_new(N, SplitSolution(robot)), d(N, SplitDirection(robot)), ocp(N, SplitUnOCP(model.nv)),
+      unkkt_matrix(N, SplitUnKKTMatrix(model.nv)), unkkt_residual(N, SplitUnKKTResidual(model.nv)),
+      aux_mat(N, Mat(2 * model.nv, 2 * model.nv)), kkt_inv(N, Mat(5 * model.nv, 5 * model.nv)), x_res(N, Mat(2 * model.nv)),
+      N_(N), T_(T), dt_(T / N) {
+  if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
+  if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
+  if (robot.hasFloatingBase() || robot.maxPointContacts() > 0)
+    throw std::logic_error("robot has floating base or contacts: use ParNMPCSolver");   // split_unparnmpc.hxx:27-33
+  initConstraints();
+}
+
+void UnParNMPCSolver::setSolution(const std::string& name, const Mat& value) {
+  for (auto& e : s) {
+    if (name == "q") e.q = value;
+    else if (name == "v") e.v = value;
+    else if (name == "a") e.a = value;
+    else if (name == "u") e.u = value;
+    else throw std::invalid_argument("invalid arugment: name must be q, v, a, or u!");
+  }
+  initConstraints();
+}
+
+// stage i is created with time step i + 1 (unparnmpc_solver.cpp:55-66): only stage 0 lacks the position-level rows
+void UnParNMPCSolver::initConstraints() {
+  for (int i = 0; i < N_; ++i) {
+    ConstraintsData& cd = ocp[i].cdata;
+    cd.time_stage = i + 1;
+    cd.data.clear();
+    for (const JointLimit& jl : constraints.components) {
+      ConstraintComponentData data(jl.lim.size());
+      if (constraints.valid(jl, i + 1)) {
+        const Mat& x = varOf(jl, s[i]);
+        const int n = jl.lim.size(), off = x.size() - n;
+        for (int r = 0; r < n; ++r) {
+          data.slack[r] = -jl.sign * (x[off + r] - jl.lim[r]);
+          while (data.slack[r] < constraints.barrier) data.slack[r] += constraints.barrier;
+          data.dual[r] = constraints.barrier / data.slack[r];
+        }
+      }
+      cd.data.push_back(data);
+    }
+  }
+}
+
+// UnBackwardCorrection::initAuxMat: the terminal cost Hessian (configuration_space_cost.cpp:368-380) on every stage
+void UnParNMPCSolver::initBackwardCorrection(double /*t*/) {
+  const int nv = robot.dimv();
+  for (int i = 0; i < N_; ++i) {
+    aux_mat[i].setZero();
+    for (int r = 0; r < nv; ++r) { aux_mat[i](r, r) = cost.qf_weight[r]; aux_mat[i](nv + r, nv + r) = cost.vf_weight[r]; }
+  }
+}
+
+// SplitUnParNMPC::linearizeOCP / computeKKTResidual (split_unparnmpc.hxx:69-102, 142-163) and the terminal twins
+// (terminal_unparnmpc.hxx:69-102, 147-168): stage i < N - 1 couples to s[i + 1] through the costate, the last stage
+// carries the terminal cost instead.
+void UnParNMPCSolver::linearizeStage(int i, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  SplitUnOCP& o = ocp[i];
+  const SplitSolution& si = s[i];
+  const bool terminal = (i == N_ - 1);
+  const int nv = o.nv, level = i + 1;
+  if (!residual_only) { o.Qqq.setZero(); o.Qvv_diag.setZero(); o.Qaa_diag.setZero(); o.Quu_diag.setZero(); }
+  o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero();
+  stageCostDerivatives(cost, dt_, si, o);
+  if (terminal)                                        // computeTerminalCostDerivatives (configuration_space_cost.cpp:313-329)
+    for (int r = 0; r < nv; ++r) {
+      o.lq[r] += cost.qf_weight[r] * (si.q[r] - cost.q_ref[r]);
+      o.lv[r] += cost.vf_weight[r] * (si.v[r] - cost.v_ref[r]);
+    }
+  for (size_t c = 0; c < constraints.components.size(); ++c) {          // [computePrimalAndDualResidual +] augmentDualResidual
+    const JointLimit& jl = constraints.components[c];
+    if (!constraints.valid(jl, level)) continue;
+    ConstraintComponentData& data = o.cdata.data[c];
+    if (residual_only) computePrimalAndDualResidual(constraints, jl, data, si);
+    Mat& l = residualOf(jl, o);
+    const int n = jl.lim.size(), off = l.size() - n;
+    for (int r = 0; r < n; ++r) l[off + r] += jl.sign * dt_ * data.dual[r];
+  }
+  // stateequation::linearizeBackwardEuler / ...Terminal, fixed base (state_equation.hxx:111-167)
+  for (int r = 0; r < nv; ++r) {
+    o.Fq[r] = q_prev[r] - si.q[r] + dt_ * si.v[r];
+    o.Fv[r] = v_prev[r] - si.v[r] + dt_ * si.a[r];
+    if (terminal) { o.lq[r] -= si.lmd[r]; o.lv[r] += dt_ * si.lmd[r] - si.gmm[r]; }
+    else { o.lq[r] += s[i + 1].lmd[r] - si.lmd[r]; o.lv[r] += dt_ * si.lmd[r] - si.gmm[r] + s[i + 1].gmm[r]; }
+    o.la[r] += dt_ * si.gmm[r];
+  }
+  // UnconstrainedDynamics::linearizeUnconstrainedDynamics (unconstrained_dynamics.hxx:55-65)
+  robot.RNEA(si.q, si.v, si.a, o.ID);
+  o.ID -= si.u;
+  robot.RNEADerivatives(si.q, si.v, si.a, o.dID_dq, o.dID_dv, o.dID_da);
+  o.lq += dt_ * (o.dID_dq.t() * si.beta);
+  o.lv += dt_ * (o.dID_dv.t() * si.beta);
+  o.la += dt_ * (o.dID_da.t() * si.beta);
+  o.lu -= dt_ * si.beta;
+  if (residual_only) return;
+  // computeStageCostHessian [+ computeTerminalCostHessian] (configuration_space_cost.cpp:351-380)
+  Mat Qqq_diag(nv);
+  for (int r = 0; r < nv; ++r) {
+    Qqq_diag[r] += dt_ * cost.q_weight[r] + (terminal ? cost.qf_weight[r] : 0.0);
+    o.Qvv_diag[r] += dt_ * cost.v_weight[r] + (terminal ? cost.vf_weight[r] : 0.0);
+    o.Qaa_diag[r] += dt_ * cost.a_weight[r];
+    o.Quu_diag[r] += dt_ * cost.u_weight[r];
+  }
+  for (size_t c = 0; c < constraints.components.size(); ++c) {          // condenseSlackAndDual
+    const JointLimit& jl = constraints.components[c];
+    if (!constraints.valid(jl, level)) continue;
+    ConstraintComponentData& data = o.cdata.data[c];
+    Mat& l = residualOf(jl, o);
+    Mat& H = hessianDiagOf(jl, o, Qqq_diag);
+    const int n = jl.lim.size(), off = l.size() - n;
+    for (int r = 0; r < n; ++r) H[off + r] += dt_ * data.dual[r] / data.slack[r];
+    computePrimalAndDualResidual(constraints, jl, data, si);
+    for (int r = 0; r < n; ++r) l[off + r] += jl.sign * dt_ * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
+  }
+  for (int r = 0; r < nv; ++r) o.Qqq(r, r) = Qqq_diag[r];
+  // condenseUnconstrainedDynamics (unconstrained_dynamics.hxx:68-94)
+  SplitUnKKTMatrix& Q = unkkt_matrix[i];
+  SplitUnKKTResidual& R = unkkt_residual[i];
+  for (int r = 0; r < nv; ++r) o.lu_condensed[r] = o.lu[r] + o.Quu_diag[r] * o.ID[r];
+  R.lq = o.lq + o.dID_dq.t() * o.lu_condensed;
+  R.lv = o.lv + o.dID_dv.t() * o.lu_condensed;
+  R.la = o.la + o.dID_da.t() * o.lu_condensed;
+  R.Fq = o.Fq; R.Fv = o.Fv;
+  Mat Quu_dq = o.dID_dq, Quu_dv = o.dID_dv, Quu_da = o.dID_da;
+  for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) {
+    Quu_dq(r, c) *= o.Quu_diag[r]; Quu_dv(r, c) *= o.Quu_diag[r]; Quu_da(r, c) *= o.Quu_diag[r];
+  }
+  Q.Q.setZero();
+  Q.set(1, 1, o.dID_dq.t() * Quu_dq);
+  Q.set(1, 2, o.dID_dq.t() * Quu_dv);
+  Q.set(2, 2, o.dID_dv.t() * Quu_dv);
+  Q.set(0, 1, o.dID_da.t() * Quu_dq);
+  Q.set(0, 2, o.dID_da.t() * Quu_dv);
+  Q.set(0, 0, o.dID_da.t() * Quu_da);
+  Q.add(1, 1, o.Qqq);
+  for (int r = 0; r < nv; ++r) { Q.Q(2 * nv + r, 2 * nv + r) += o.Qvv_diag[r]; Q.Q(r, r) += o.Qaa_diag[r]; }
+}
+
+// UnBackwardCorrection::coarseUpdate (unbackward_correction.cpp:67-97) with SplitUnBackwardCorrection::coarseUpdate
+// (split_unbackward_correction.hxx:38-64) and SplitUnKKTMatrixInverter::invert (split_unkkt_matrix_inverter.hxx:37-80)
+void UnParNMPCSolver::coarseUpdate(double /*t*/, const Mat& q, const Mat& v) {
+  const int nv = robot.dimv(), nx = 2 * nv, nq3 = 3 * nv, nk = 5 * nv;
+  for (int i = 0; i < N_; ++i) {
+    linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, false);
+    Mat& Q = unkkt_matrix[i].Q;
+    if (i < N_ - 1) Q.addBlock(nv, nv, aux_mat[i + 1]);                         // Qxx += aux_mat_next
+    for (int c = 0; c < nq3; ++c) for (int r = c + 1; r < nq3; ++r) Q(r, c) = Q(c, r);     // Qvq = Qqv^T, Qxa = Qax^T
+    Mat& Ki = kkt_inv[i];
+    Ki.setZero();
+    LLT lltQ;
+    if (!lltQ.compute(Q)) throw std::runtime_error("UnParNMPC: Q not positive definite at stage " + std::to_string(i));
+    const Mat Qinv = lltQ.solve(Mat::Identity(nq3));
+    // F = [0 -I dt I; dt I 0 -I] in the (a, q, v) ordering
+    Mat FQinv(nx, nq3);
+    for (int c = 0; c < nq3; ++c) for (int r = 0; r < nv; ++r) {
+      FQinv(r, c) = -Qinv(nv + r, c) + dt_ * Qinv(2 * nv + r, c);
+      FQinv(nv + r, c) = dt_ * Qinv(r, c) - Qinv(2 * nv + r, c);
+    }
+    Mat S(nx, nx);
+    for (int r = 0; r < nx; ++r) for (int c = 0; c < nv; ++c) {
+      S(r, c) = -FQinv(r, nv + c) + dt_ * FQinv(r, 2 * nv + c);
+      S(r, nv + c) = dt_ * FQinv(r, c) - FQinv(r, 2 * nv + c);
+    }
+    LLT lltS;
+    if (!lltS.compute(S)) throw std::runtime_error("UnParNMPC: S not positive definite at stage " + std::to_string(i));
+    const Mat TL = -1.0 * lltS.solve(Mat::Identity(nx));
+    const Mat TR = -1.0 * (TL * FQinv);
+    Ki.setBlock(0, 0, TL);
+    Ki.setBlock(0, nx, TR);
+    Ki.setBlock(nx, 0, TR.t());
+    Ki.setBlock(nx, nx, Qinv - TR.t() * (S * TR));
+    // d = KKT_inv * residual ; s_new = s - d
+    const SplitUnKKTResidual& R = unkkt_residual[i];
+    Mat res(nk);
+    res.setSegment(0, R.Fq); res.setSegment(nv, R.Fv); res.setSegment(2 * nv, R.la); res.setSegment(3 * nv, R.lq); res.setSegment(4 * nv, R.lv);
+    const Mat dd = Ki * res;
+    d[i].dlmd = dd.segment(0, nv); d[i].dgmm = dd.segment(nv, nv); d[i].da = dd.segment(2 * nv, nv);
+    d[i].dq = dd.segment(3 * nv, nv); d[i].dv = dd.segment(4 * nv, nv);
+    s_new[i] = s[i];
+    s_new[i].lmd -= d[i].dlmd; s_new[i].gmm -= d[i].dgmm; s_new[i].a -= d[i].da; s_new[i].q -= d[i].dq; s_new[i].v -= d[i].dv;
+  }
+}
+
+// split_unbackward_correction.hxx:72-81
+void UnParNMPCSolver::backwardCorrectionSerial() {
+  const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
+  for (int i = N_ - 2; i >= 0; --i) {
+    x_res[i].setSegment(0, s_new[i + 1].lmd - s[i + 1].lmd);
+    x_res[i].setSegment(nv, s_new[i + 1].gmm - s[i + 1].gmm);
+    const Mat dx = kkt_inv[i].block(0, nk - nx, nx, nx) * x_res[i];
+    s_new[i].lmd -= dx.segment(0, nv);
+    s_new[i].gmm -= dx.segment(nv, nv);
+  }
+}
+
+// split_unbackward_correction.hxx:84-92
+void UnParNMPCSolver::backwardCorrectionParallel() {
+  const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
+  for (int i = N_ - 2; i >= 0; --i) {
+    const Mat dd = kkt_inv[i].block(nx, nk - nx, nk - nx, nx) * x_res[i];
+    s_new[i].a -= dd.segment(0, nv);
+    s_new[i].q -= dd.segment(nv, nv);
+    s_new[i].v -= dd.segment(2 * nv, nv);
+  }
+}
+
+// split_unbackward_correction.hxx:95-104
+void UnParNMPCSolver::forwardCorrectionSerial() {
+  const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
+  for (int i = 1; i < N_; ++i) {
+    x_res[i].setSegment(0, s_new[i - 1].q - s[i - 1].q);
+    x_res[i].setSegment(nv, s_new[i - 1].v - s[i - 1].v);
+    const Mat dx = kkt_inv[i].block(nk - nx, 0, nx, nx) * x_res[i];
+    s_new[i].q -= dx.segment(0, nv);
+    s_new[i].v -= dx.segment(nv, nv);
+  }
+}
+
+// last parallel loop of UnBackwardCorrection::backwardCorrection (unbackward_correction.cpp:114-131):
+// forwardCorrectionParallel + aux_mat, computeDirection (split_unbackward_correction.hxx:107-123), the condensed
+// direction (unconstrained_dynamics.hxx:97-106), slack / dual directions and the step sizes
+void UnParNMPCSolver::forwardCorrectionParallel() {
+  const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
+  double pmin = 1, dmin = 1;
+  for (int i = 0; i < N_; ++i) {
+    if (i > 0) {
+      const Mat dd = kkt_inv[i].block(0, 0, nk - nx, nx) * x_res[i];
+      s_new[i].lmd -= dd.segment(0, nv);
+      s_new[i].gmm -= dd.segment(nv, nv);
+      s_new[i].a -= dd.segment(2 * nv, nv);
+      aux_mat[i] = -1.0 * kkt_inv[i].block(0, 0, nx, nx);
+    }
+    d[i].dlmd = s_new[i].lmd - s[i].lmd;
+    d[i].dgmm = s_new[i].gmm - s[i].gmm;
+    d[i].da = s_new[i].a - s[i].a;
+    d[i].dq = s_new[i].q - s[i].q;
+    d[i].dv = s_new[i].v - s[i].v;
+    SplitUnOCP& o = ocp[i];
+    d[i].du = o.ID;
+    d[i].du += o.dID_dq * d[i].dq;
+    d[i].du += o.dID_dv * d[i].dv;
+    d[i].du += o.dID_da * d[i].da;
+    for (int r2 = 0; r2 < nv; ++r2) d[i].dbeta[r2] = (o.lu[r2] + o.Quu_diag[r2] * d[i].du[r2]) / dt_;
+    for (size_t c = 0; c < constraints.components.size(); ++c) {
+      const JointLimit& jl = constraints.components[c];
+      if (!constraints.valid(jl, i + 1)) continue;
+      ConstraintComponentData& data = o.cdata.data[c];
+      const Mat& dx = dvarOf(jl, d[i]);
+      const int n = jl.lim.size(), off = dx.size() - n;
+      for (int r2 = 0; r2 < n; ++r2) {
+        data.dslack[r2] = -jl.sign * dx[off + r2] - data.residual[r2];
+        data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
+      }
+      const double ps = fractionToBoundary(constraints.fraction_to_boundary_rate, data.slack, data.dslack);
+      const double ds = fractionToBoundary(constraints.fraction_to_boundary_rate, data.dual, data.ddual);
+      if (ps < pmin) pmin = ps;
+      if (ds < dmin) dmin = ds;
+    }
+  }
+  primal_step_size = pmin; dual_step_size = dmin;
+}
+
+// updatePrimal / updateDual of every stage (unparnmpc_solver.cpp:88-102; split_solution.hxx:215-240)
+void UnParNMPCSolver::integrate() {
+  const double ap = primal_step_size, ad = dual_step_size;
+  for (int i = 0; i < N_; ++i) {
+    s[i].lmd += ap * d[i].dlmd; s[i].gmm += ap * d[i].dgmm; s[i].q += ap * d[i].dq; s[i].v += ap * d[i].dv;
+    s[i].a += ap * d[i].da; s[i].u += ap * d[i].du; s[i].beta += ap * d[i].dbeta;
+    for (size_t c = 0; c < constraints.components.size(); ++c) {
+      if (!constraints.valid(constraints.components[c], i + 1)) continue;
+      ConstraintComponentData& data = ocp[i].cdata.data[c];
+      data.slack += ap * data.dslack;
+      data.dual += ad * data.ddual;
+    }
+  }
+}
+
+void UnParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+  coarseUpdate(t, q, v);
+  backwardCorrectionSerial();
+  backwardCorrectionParallel();
+  forwardCorrectionSerial();
+  forwardCorrectionParallel();
+  integrate();
+}
+
+void UnParNMPCSolver::computeKKTResidual(double /*t*/, const Mat& q, const Mat& v) {
+  for (int i = 0; i < N_; ++i) linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
+}
+
+// squaredNormKKTResidual of every stage (split_unparnmpc.hxx:166-176, terminal_unparnmpc.hxx:171-181)
+double UnParNMPCSolver::KKTError() {
+  double sum = 0;
+  for (int i = 0; i < N_; ++i) {
+    const SplitUnOCP& o = ocp[i];
+    double e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
+    e += o.Fq.squaredNorm() + o.Fv.squaredNorm();
+    e += dt_ * dt_ * o.ID.squaredNorm();
+    double c = 0;
+    for (size_t j = 0; j < constraints.components.size(); ++j) {
+      if (!constraints.valid(constraints.components[j], i + 1)) continue;
+      c += o.cdata.data[j].residual.squaredNorm() + o.cdata.data[j].duality.squaredNorm();
+    }
+    sum += e + dt_ * dt_ * c;
+  }
+  return std::sqrt(sum);
+}
+
+int UnParNMPCSolver::isCurrentSolutionFeasible() const {
+  for (int i = 0; i < N_; ++i)
+    for (const JointLimit& jl : constraints.components) {
+      if (!constraints.valid(jl, i + 1)) continue;
+      const Mat& x = varOf(jl, s[i]);
+      const int n = jl.lim.size(), off = x.size() - n;
+      for (int r = 0; r < n; ++r)
+        if (jl.sign < 0 ? x[off + r] < jl.lim[r] : x[off + r] > jl.lim[r]) return i;
+    }
+  return -1;
+}
+
 }  // namespace oracle

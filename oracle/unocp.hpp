@@ -138,5 +138,47 @@ class UnOCPSolver {
   void computeStageResidual(int i, double t);
 };
 
+
+// UnParNMPCSolver (src/unocp/unparnmpc_solver.cpp:55-243): backward-Euler stages (SplitUnParNMPC / TerminalUnParNMPC,
+// include/idocp/unocp/split_unparnmpc.hxx:60-110, terminal_unparnmpc.hxx:60-113), the per-stage KKT inverse
+// (split_unkkt_matrix_inverter.hxx:37-80) and the coarse update + four correction sweeps of UnBackwardCorrection
+// (src/unocp/unbackward_correction.cpp:55-132, split_unbackward_correction.hxx:38-123).  Stage i (0 <= i < N) lives at
+// time t + (i + 1) dt and is created with constraint time step i + 1; the state before stage 0 is the measured (q, v).
+// KKT ordering (lmd, gmm, a, q, v): rows [Fq, Fv, la, lq, lv].
+class UnParNMPCSolver {
+ public:
+  UnParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N);
+  void setSolution(const std::string& name, const Mat& value);    // unparnmpc_solver.cpp:121-146
+  void initConstraints();                                         // unparnmpc_solver.cpp:55-66
+  void initBackwardCorrection(double t);                          // unbackward_correction.cpp:55-64
+  void updateSolution(double t, const Mat& q, const Mat& v);       // unparnmpc_solver.cpp:74-103
+  void computeKKTResidual(double t, const Mat& q, const Mat& v);   // unparnmpc_solver.cpp:169-187
+  double KKTError();                                               // unparnmpc_solver.cpp:154-166
+  int isCurrentSolutionFeasible() const;                           // unparnmpc_solver.cpp:190-209
+  // the phases of updateSolution, separately callable
+  void coarseUpdate(double t, const Mat& q, const Mat& v);         // unbackward_correction.cpp:67-97
+  void backwardCorrectionSerial();                                 // :104-106
+  void backwardCorrectionParallel();                               // :107-110
+  void forwardCorrectionSerial();                                  // :111-113
+  void forwardCorrectionParallel();                                // :114-131 (+ direction, condensed direction, step sizes)
+  void integrate();                                                // unparnmpc_solver.cpp:88-102
+
+  int N() const { return N_; }
+  Robot robot;
+  idocp_cost_t cost;
+  Constraints constraints;
+  std::vector<SplitSolution> s, s_new;        // N stages
+  std::vector<SplitDirection> d;
+  std::vector<SplitUnOCP> ocp;                // per-stage private data of SplitUnParNMPC (same members as SplitUnOCP)
+  std::vector<SplitUnKKTMatrix> unkkt_matrix;
+  std::vector<SplitUnKKTResidual> unkkt_residual;
+  std::vector<Mat> aux_mat, kkt_inv, x_res;   // 2nv x 2nv, 5nv x 5nv, 2nv
+  double primal_step_size = 1, dual_step_size = 1;
+
+ private:
+  int N_; double T_, dt_;
+  void linearizeStage(int i, const Mat& q_prev, const Mat& v_prev, bool residual_only);
+};
+
 }  // namespace oracle
 #endif  // ORACLE_UNOCP_HPP_

@@ -54,6 +54,20 @@ def oracle():
         lib.oracle_unocp_get_unkkt.argtypes = [vp, dp, dp]
         lib.oracle_unocp_bench.argtypes = [vp, cd, dp, dp, ci, dp]
         lib.oracle_unocp_bench.restype = cd
+        lib.oracle_unparnmpc_create.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]
+        lib.oracle_unparnmpc_create.restype = vp
+        lib.oracle_unparnmpc_destroy.argtypes = [vp]
+        lib.oracle_unparnmpc_set_solution.argtypes = [vp, cs, dp]
+        lib.oracle_unparnmpc_init.argtypes = [vp, cd]
+        lib.oracle_unparnmpc_update_solution.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unparnmpc_stage.argtypes = [vp, ci, cd, dp, dp]
+        lib.oracle_unparnmpc_kkt_error.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unparnmpc_kkt_error.restype = cd
+        lib.oracle_unparnmpc_is_current_solution_feasible.argtypes = [vp]
+        lib.oracle_unparnmpc_get.argtypes = [vp, cs, dp]
+        lib.oracle_unparnmpc_get_step_sizes.argtypes = [vp, dp, dp]
+        lib.oracle_unparnmpc_get_matrices.argtypes = [vp, dp, dp]
+        lib.oracle_unparnmpc_get_constraint_data.argtypes = [vp, dp, dp]
         _oracle = lib
     return _oracle
 
@@ -160,6 +174,61 @@ class OracleUnOCP:
         Q, r = np.zeros((N, 3 * nv, 3 * nv)), np.zeros((N, 5 * nv))
         self.lib.oracle_unocp_get_unkkt(self.h, P(Q), P(r))
         return Q.transpose(0, 2, 1), r
+
+
+class OracleUnParNMPC:
+    """oracle::UnParNMPCSolver: N backward-Euler stages, every field is [N][nv]"""
+
+    def __init__(self, model, cost, cons, T, N):
+        self.lib = oracle()
+        self.N, self.nv = N, model.nv
+        self.h = self.lib.oracle_unparnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_unparnmpc_destroy(self.h)
+            self.h = None
+
+    def set_solution(self, name, value):
+        assert self.lib.oracle_unparnmpc_set_solution(self.h, name.encode(), P(arr(value))) == 0
+
+    def init(self, t=0.0):
+        self.lib.oracle_unparnmpc_init(self.h, t)
+
+    def update(self, t, q, v):
+        return self.lib.oracle_unparnmpc_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+
+    def stage(self, what, t, q, v):
+        return self.lib.oracle_unparnmpc_stage(self.h, what, t, P(arr(q)), P(arr(v)))
+
+    def kkt_error(self, t, q, v):
+        return self.lib.oracle_unparnmpc_kkt_error(self.h, t, P(arr(q)), P(arr(v)))
+
+    def infeasible_stage(self):
+        return self.lib.oracle_unparnmpc_is_current_solution_feasible(self.h)
+
+    def get(self, name):
+        out = np.zeros((self.N, self.nv))
+        assert self.lib.oracle_unparnmpc_get(self.h, name.encode(), P(out)) == 0, name
+        return out
+
+    def step_sizes(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.oracle_unparnmpc_get_step_sizes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def matrices(self):
+        nv, N = self.nv, self.N
+        K, A = np.zeros((N, 5 * nv, 5 * nv)), np.zeros((N, 2 * nv, 2 * nv))
+        self.lib.oracle_unparnmpc_get_matrices(self.h, P(K), P(A))
+        return K.transpose(0, 2, 1), A.transpose(0, 2, 1)           # col-major -> [row, col]
+
+    def constraint_data(self):
+        dimc = 6 * self.nv
+        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
+        self.lib.oracle_unparnmpc_get_constraint_data(self.h, P(sl), P(du))
+        return sl, du
 
 
 class HipUnOCP:
