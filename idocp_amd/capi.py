@@ -100,6 +100,8 @@ def _proto(lib):
     lib.idocp_version.restype = cs
     lib.idocp_unocp_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
     lib.idocp_unocp_create.restype = ci
+    lib.idocp_unparnmpc_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
+    lib.idocp_unparnmpc_create.restype = ci
     lib.idocp_unocp_destroy.argtypes = [vp]
     lib.idocp_unocp_destroy.restype = None
     for name, args in [
@@ -123,6 +125,12 @@ def _proto(lib):
         ("idocp_unocp_dimc", [vp]),
         ("idocp_unocp_is_current_solution_feasible", [vp, c_int_p, c_int_p]),
         ("idocp_unocp_launch_linearize", [vp, cd, vp, vp]),
+        ("idocp_unparnmpc_init_backward_correction", [vp, cd]),
+        ("idocp_unparnmpc_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
+        ("idocp_unparnmpc_update_solution_device", [vp, cd, vp, vp]),
+        ("idocp_unparnmpc_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
+        ("idocp_unparnmpc_launch_phase", [vp, ci, vp, vp]),
+        ("idocp_unparnmpc_get_new_solution", [vp, cs, ci, c_double_p]),
         ("idocp_unocp_launch_riccati", [vp, vp, vp]),
         ("idocp_unocp_launch_expand", [vp]),
         ("idocp_unocp_launch_integrate", [vp]),

@@ -78,6 +78,7 @@ struct idocp_unocp {
   std::vector<void*> allocs;
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr;   // staging for host-pointer entry points
   bool has_direction = false;
+  int bwd = 0;                  // 1: UnParNMPC handle (backward-Euler stages, idocp_unparnmpc_*)
 };
 
 namespace {
@@ -141,8 +142,8 @@ int idocp_device_upload(void* d_dst, const void* h_src, unsigned long long nbyte
   return IDOCP_OK;
 }
 
-int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
-                       double T, int N, int batch, int device, idocp_unocp_t** out) {
+static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
+                      double T, int N, int batch, int device, int bwd, idocp_unocp_t** out) {
   if (!model || !cost || !constraints || !out) { set_last_error("idocp_unocp_create: null argument"); return IDOCP_E_ARG; }
   // argument checks of UnOCPSolver::UnOCPSolver (unocp_solver.cpp:33-47) and SplitUnOCP (split_unocp.hxx:26-33)
   if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }
@@ -162,7 +163,7 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, con
   if (device < 0 || device >= ndev) { set_last_error("invalid device ordinal"); return IDOCP_E_ARG; }
   idocp_unocp* h = new idocp_unocp();
   h->model = *model; h->cost = *cost; h->cons = *constraints;
-  h->N = N; h->batch = batch; h->device = device; h->T = T; h->nv = model->nv;
+  h->N = N; h->batch = batch; h->device = device; h->T = T; h->nv = model->nv; h->bwd = bwd;
   int rc = IDOCP_OK;
   auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -189,6 +190,12 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, con
   if ((rc = allocBuf(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
   if ((rc = allocBuf(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
   B.status = reinterpret_cast<int*>(tmp);
+  if (bwd) {
+    if ((rc = allocBuf(h, &B.kinv, nrec0 * L7::KINV))) return fail(rc);
+    if ((rc = allocBuf(h, &B.snew, nrec1 * L7::SOL))) return fail(rc);
+    if ((rc = allocBuf(h, &B.aux, nrec1 * L7::AUX))) return fail(rc);
+    if ((rc = allocBuf(h, &B.xres, nrec1 * L7::XRES))) return fail(rc);
+  }
   DevModel dm; toDevModel(*model, dm);
   UnProblem up; std::memset(&up, 0, sizeof(up));
   up.N = N; up.batch = batch; up.T = T; up.dt = T / N;
@@ -201,6 +208,7 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, con
   up.use_q_limits = constraints->joint_position_limits; up.use_v_limits = constraints->joint_velocity_limits;
   up.use_u_limits = constraints->joint_torque_limits;
   up.barrier = constraints->barrier; up.fraction_rate = constraints->fraction_to_boundary_rate;
+  up.backward_euler = bwd;
   void *d_model = nullptr, *d_prob = nullptr;
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&d_prob, sizeof(UnProblem)) != hipSuccess) {
     set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
@@ -215,9 +223,20 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, con
   B.prob = static_cast<const UnProblem*>(d_prob);
   // the reference constructor ends with initConstraints() (unocp_solver.cpp:47)
   UnLaunch<7>::initConstraints(B, batch, N, h->stream);
+  if (bwd) UnLaunch<7>::parnmpcInitAux(B, batch, N, h->stream);
   if (hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("initConstraints launch failed"); return fail(IDOCP_E_DEVICE); }
   *out = h;
   return IDOCP_OK;
+}
+
+int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
+                       double T, int N, int batch, int device, idocp_unocp_t** out) {
+  return createImpl(model, cost, constraints, T, N, batch, device, 0, out);
+}
+// UnParNMPCSolver::UnParNMPCSolver (src/unocp/unparnmpc_solver.cpp:11-44): same arguments and checks
+int idocp_unparnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
+                           double T, int N, int batch, int device, idocp_unocp_t** out) {
+  return createImpl(model, cost, constraints, T, N, batch, device, 1, out);
 }
 
 void idocp_unocp_destroy(idocp_unocp_t* h) {
@@ -256,8 +275,16 @@ int idocp_unocp_init_constraints(idocp_unocp_t* h) {
   return IDOCP_OK;
 }
 
+static int wrongKind(const idocp_unocp_t* h, int want_bwd) {
+  if (h->bwd == want_bwd) return 0;
+  set_last_error(want_bwd ? "this handle is an UnOCPSolver (idocp_unocp_create): use idocp_unocp_*"
+                          : "this handle is an UnParNMPCSolver (idocp_unparnmpc_create): use idocp_unparnmpc_*");
+  return IDOCP_E_ARG;
+}
+
 int idocp_unocp_update_solution_device(idocp_unocp_t* h, double t, const double* d_q, const double* d_v) {
   if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   (void)t;   // ConfigurationSpaceCost is time-invariant
   int rc = setDevice(h); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
@@ -302,6 +329,7 @@ int idocp_unocp_update_solution(idocp_unocp_t* h, double t, const double* q, con
 int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q, const double* d_v) {
   if (!h) return IDOCP_E_ARG;
   (void)t; (void)d_q; (void)d_v;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   UnLaunch<7>::linearize(h->B, h->batch, h->N, h->stream);
   HIP_TRY(hipGetLastError());
@@ -309,6 +337,7 @@ int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q, 
 }
 int idocp_unocp_launch_riccati(idocp_unocp_t* h, const double* d_q, const double* d_v) {
   if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   UnLaunch<7>::riccati(h->B, h->batch, h->N, d_q, d_v, h->stream);
   HIP_TRY(hipGetLastError());
@@ -316,6 +345,7 @@ int idocp_unocp_launch_riccati(idocp_unocp_t* h, const double* d_q, const double
 }
 int idocp_unocp_launch_expand(idocp_unocp_t* h) {
   if (!h) return IDOCP_E_ARG;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   UnLaunch<7>::expand(h->B, h->batch, h->N, h->stream);
   HIP_TRY(hipGetLastError());
@@ -323,6 +353,7 @@ int idocp_unocp_launch_expand(idocp_unocp_t* h) {
 }
 int idocp_unocp_launch_integrate(idocp_unocp_t* h) {
   if (!h) return IDOCP_E_ARG;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   UnLaunch<7>::integrate(h->B, h->batch, h->N, h->stream);
   HIP_TRY(hipGetLastError());
@@ -331,6 +362,7 @@ int idocp_unocp_launch_integrate(idocp_unocp_t* h) {
 
 int idocp_unocp_launch_kernel(idocp_unocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
   if (!h || kernel_id < 0 || kernel_id > 5 || !d_q || !d_v) return IDOCP_E_ARG;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   UnLaunch<7>::single(kernel_id, h->B, h->batch, h->N, d_q, d_v, h->stream);
   HIP_TRY(hipGetLastError());
@@ -339,6 +371,7 @@ int idocp_unocp_launch_kernel(idocp_unocp_t* h, int kernel_id, const double* d_q
 
 int idocp_unocp_compute_kkt_residual(idocp_unocp_t* h, double t, const double* q, const double* v) {
   if (!h || !q || !v) return IDOCP_E_ARG;
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   (void)t;
   int rc = setDevice(h); if (rc) return rc;
   UnLaunch<7>::residual(h->B, h->batch, h->N, h->stream);
@@ -350,6 +383,64 @@ int idocp_unocp_kkt_error(idocp_unocp_t* h, double* kkt_error) {
   if (!h || !kkt_error) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(kkt_error, h->B.err, sizeof(double) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+// ---- UnParNMPCSolver (src/unocp/unparnmpc_solver.cpp) on an idocp_unparnmpc_create handle ----
+int idocp_unparnmpc_init_backward_correction(idocp_unocp_t* h, double t) {          // unparnmpc_solver.cpp:69-71
+  if (!h) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  (void)t;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::parnmpcInitAux(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_launch_phase(idocp_unocp_t* h, int phase, const double* d_q, const double* d_v) {
+  if (!h || phase < 0 || phase > 6 || !d_q || !d_v) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::parnmpcPhase(phase, h->B, h->batch, h->N, d_q, d_v, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_update_solution_device(idocp_unocp_t* h, double t, const double* d_q, const double* d_v) {
+  if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  (void)t;
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  for (int phase = 0; phase <= 6; ++phase) UnLaunch<7>::parnmpcPhase(phase, h->B, h->batch, h->N, d_q, d_v, h->stream);
+  HIP_TRY(hipGetLastError());
+  h->has_direction = true;
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_update_solution(idocp_unocp_t* h, double t, const double* q, const double* v, int line_search) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * h->model.nq, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * h->model.nv, hipMemcpyHostToDevice, h->stream));
+  if ((rc = idocp_unparnmpc_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  std::vector<int> st(h->batch);
+  HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->batch; ++b)
+    if (st[b] != 0) { set_last_error("UnParNMPC: stage KKT matrix not invertible (Q or F Q^-1 F^T not positive definite), instance " + std::to_string(b)); return st[b]; }
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_compute_kkt_residual(idocp_unocp_t* h, double t, const double* q, const double* v) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  (void)t;
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * h->model.nq, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * h->model.nv, hipMemcpyHostToDevice, h->stream));
+  UnLaunch<7>::parnmpcResidual(h->B, h->batch, h->N, h->d_q0, h->d_v0, h->stream);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
 }
@@ -369,6 +460,10 @@ int idocp_unocp_get_solution(idocp_unocp_t* h, const char* name, int instance, d
 }
 int idocp_unocp_get_direction(idocp_unocp_t* h, const char* name, int instance, double* out) {
   return getRecords(h, h ? h->B.dir : nullptr, name, instance, out, true);
+}
+int idocp_unparnmpc_get_new_solution(idocp_unocp_t* h, const char* name, int instance, double* out) {
+  if (!h || wrongKind(h, 1)) return IDOCP_E_ARG;
+  return getRecords(h, h->B.snew, name, instance, out, false);
 }
 
 int idocp_unocp_get_step_sizes(idocp_unocp_t* h, double* primal, double* dual) {
@@ -425,8 +520,8 @@ int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, in
     for (int i = 0; i < N && bad < 0; ++i) {
       const double* s = &sol[((size_t)b * (N + 1) + i) * L7::SOL];
       for (int r = 0; r < nv && bad < 0; ++r) {
-        if (h->cons.joint_position_limits && i >= 2 && (s[L7::S_Q + r] < m.q_min[r] || s[L7::S_Q + r] > m.q_max[r])) bad = i;
-        if (h->cons.joint_velocity_limits && i >= 1 && (s[L7::S_V + r] < -m.v_max[r] || s[L7::S_V + r] > m.v_max[r])) bad = i;
+        if (h->cons.joint_position_limits && i + h->bwd >= 2 && (s[L7::S_Q + r] < m.q_min[r] || s[L7::S_Q + r] > m.q_max[r])) bad = i;
+        if (h->cons.joint_velocity_limits && i + h->bwd >= 1 && (s[L7::S_V + r] < -m.v_max[r] || s[L7::S_V + r] > m.v_max[r])) bad = i;
         if (h->cons.joint_torque_limits && (s[L7::S_U + r] < -m.u_max[r] || s[L7::S_U + r] > m.u_max[r])) bad = i;
       }
     }
@@ -456,7 +551,7 @@ int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance, double* slac
     int off = 0;
     for (int c = 0; c < 6; ++c) {
       if (!use[c / 2]) continue;
-      const bool valid = (c < 2) ? i >= 2 : ((c < 4) ? i >= 1 : true);
+      const bool valid = (c < 2) ? i + h->bwd >= 2 : ((c < 4) ? i + h->bwd >= 1 : true);
       for (int r = 0; r < nv; ++r) {
         if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * L7::CON + c * nv + r] : 0.0;
         if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * L7::CON + c * nv + r] : 0.0;

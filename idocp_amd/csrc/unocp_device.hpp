@@ -41,6 +41,14 @@ struct UnLayout {
   // LQR policy (lqr_state_feedback_policy.hpp:11-28): K (NV x 2NV col-major), k
   static constexpr int G_K = 0, G_k = 2 * NV * NV;
   static constexpr int GAIN = roundUp16(2 * NV * NV + NV);
+  // UnParNMPC: the blocks of the per-stage KKT inverse the correction sweeps read (KKT ordering lmd, gmm | a, q, v;
+  // split_unbackward_correction.hxx:72-104): TL = -S^-1 (NX x NX), TR = S^-1 F Q^-1 (NX x 3NV), BRC = the (q, v) columns
+  // of the bottom-right block (3NV x NX); all column-major
+  static constexpr int NX = 2 * NV, NQ3 = 3 * NV;
+  static constexpr int I_TL = 0, I_TR = NX * NX, I_BRC = I_TR + NX * NQ3;
+  static constexpr int KINV = roundUp16(I_BRC + NQ3 * NX);
+  static constexpr int AUX = roundUp16(NX * NX);            // aux_mat of a stage (unbackward_correction.hpp)
+  static constexpr int XRES = roundUp16(2 * NX);            // x_res of the backward [0, NX) and of the forward [NX, 2NX) sweep
 };
 
 // Problem constants (cost, limits, IPM parameters), uniform across the grid.
@@ -53,6 +61,7 @@ struct UnProblem {
   double q_min[IDOCP_MAX_NV], q_max[IDOCP_MAX_NV], v_max[IDOCP_MAX_NV], u_max[IDOCP_MAX_NV];
   int use_q_limits, use_v_limits, use_u_limits;
   double barrier, fraction_rate;
+  int backward_euler;     // UnParNMPC: stage i sits at t + (i + 1) dt, constraint time step i + 1, the last stage is terminal
 };
 
 // All device pointers of one handle.
@@ -72,6 +81,11 @@ struct UnBuffers {
   double* err_stage;   // [batch][N+1]   squared KKT residual per stage
   double* err;         // [batch]
   int* status;         // [batch]  0 ok, 1+stage on a failed Cholesky
+  // UnParNMPC only (null otherwise)
+  double* kinv;        // [batch][N][KINV]
+  double* snew;        // [batch][N+1][SOL]  coarse / corrected iterate s_new (lmd, gmm, q, v, a)
+  double* aux;         // [batch][N+1][AUX]
+  double* xres;        // [batch][N+1][XRES]
 };
 
 }  // namespace idocp_dev

@@ -15,6 +15,7 @@
 // Workgroups are a single wavefront, so the barriers below are wave-local.
 #include <hip/hip_runtime.h>
 
+#include "dev_dense.hpp"
 #include "unocp_launch.hpp"
 
 namespace idocp_dev {
@@ -54,6 +55,7 @@ __device__ __forceinline__ double limitOf(const UnProblem* __restrict__ P, int c
 }
 // ConstraintsData(time_stage) level gating (constraints_data.hpp:18-42) + enabled components
 __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int comp, int stage) {
+  stage += P->backward_euler;          // UnParNMPC creates stage i with time step i + 1 (unparnmpc_solver.cpp:55-66)
   if (comp < 2) return P->use_q_limits && stage >= 2;
   if (comp < 4) return P->use_v_limits && stage >= 1;
   return P->use_u_limits != 0;
@@ -63,8 +65,12 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
 // MODE 0: linearize + condense -> kkt, dyn records.  MODE 1: KKT residual ->
 // err_stage.  Lane (kind, k) of a stage group differentiates ID w.r.t. q_k
 // (kind 0), v_k (kind 1) or a_k (kind 2).
-template <int NV, int MODE>
-__global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B) {
+// BWD: the backward-Euler stage of UnParNMPC (SplitUnParNMPC / TerminalUnParNMPC::linearizeOCP, split_unparnmpc.hxx:69-102,
+// terminal_unparnmpc.hxx:69-102; stateequation::linearizeBackwardEuler[Terminal], state_equation.hxx:111-167): the state
+// equation couples to the PREVIOUS stage (the measured state q0, v0 for stage 0), the last stage carries the terminal cost.
+template <int NV, int MODE, bool BWD = false>
+__global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
+                                                          const double* __restrict__ v0 = nullptr) {
   using L = UnLayout<NV>;
   constexpr int LPS = 3 * NV;        // lanes per stage
   constexpr int SPW = 64 / LPS;      // stages per wavefront
@@ -148,20 +154,36 @@ __global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B) {
     const double lmd = s[L::S_LMD + k], gmm = s[L::S_GMM + k];
     const double lmdn = sn[L::S_LMD + k], gmmn = sn[L::S_GMM + k];
     double x, w, ref;
+    const bool term = BWD && (i == N - 1);
     if (kind == 0) {
       x = qk; w = P->q_weight[k]; ref = P->q_ref[k];
-      l = lmdn - lmd;
-      F = qk - sn[L::S_Q + k] + dt * vk;
+      if (BWD) {
+        l = (term ? 0.0 : lmdn) - lmd;
+        F = (i > 0 ? (s - L::SOL)[L::S_Q + k] : q0[b * NV + k]) - qk + dt * vk;
+      } else {
+        l = lmdn - lmd;
+        F = qk - sn[L::S_Q + k] + dt * vk;
+      }
     } else if (kind == 1) {
       x = vk; w = P->v_weight[k]; ref = P->v_ref[k];
-      l = dt * lmdn + gmmn - gmm;
-      F = vk + dt * ak - sn[L::S_V + k];
+      if (BWD) {
+        l = dt * lmd - gmm + (term ? 0.0 : gmmn);
+        F = (i > 0 ? (s - L::SOL)[L::S_V + k] : v0[b * NV + k]) - vk + dt * ak;
+      } else {
+        l = dt * lmdn + gmmn - gmm;
+        F = vk + dt * ak - sn[L::S_V + k];
+      }
     } else {
       x = ak; w = P->a_weight[k]; ref = 0.0;
-      l = dt * gmmn;
+      l = BWD ? dt * gmm : dt * gmmn;
     }
     l += dt * w * (x - ref);
     h = dt * w;
+    if (term && kind < 2) {          // computeTerminalCostDerivatives / Hessian (configuration_space_cost.cpp:313-329, 368-380)
+      const double wf = (kind == 0) ? P->qf_weight[k] : P->vf_weight[k];
+      l += wf * (x - ref);
+      h += wf;
+    }
     if (kind < 2) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
@@ -667,7 +689,7 @@ __global__ __launch_bounds__(64) void un_kkt_error_kernel(UnBuffers B) {
   const long b = blockIdx.x;
   double e = 0.0;
   for (int i = threadIdx.x; i < N; i += 64) e += B.err_stage[b * (N + 1) + i];
-  if (threadIdx.x < NV) {
+  if (threadIdx.x < NV && !P->backward_euler) {     // UnParNMPC: the last STAGE carries the terminal cost
     const int r = threadIdx.x;
     const double* __restrict__ sN = B.sol + (b * (N + 1) + N) * L::SOL;
     const double lq = P->qf_weight[r] * (sN[L::S_Q + r] - P->q_ref[r]) - sN[L::S_LMD + r];
@@ -720,6 +742,322 @@ __global__ __launch_bounds__(64) void rnea_derivatives_kernel(const DevModel* __
   double* out = (kind == 0) ? dq : ((kind == 1) ? dv : da);
   rneaChain<NV>(model, &s_cs[gg][0][0], v + sm * NV, a + sm * NV, kind, k, seed == 0, tau + sm * NV,
                 out + sm * NV * NV + k * NV);
+}
+
+
+// ================================================================ UnParNMPC ====
+// UnParNMPCSolver::updateSolution (src/unocp/unparnmpc_solver.cpp:74-103) = UnBackwardCorrection::coarseUpdate +
+// backwardCorrection (src/unocp/unbackward_correction.cpp:67-132):
+//   K1b  un_linearize_kernel<NV, 0, true>       SplitUnParNMPC / TerminalUnParNMPC::linearizeOCP          (per stage)
+//   K9u  unparnmpc_coarse_update_kernel         SplitUnKKTMatrixInverter::invert + coarseUpdate            (per stage)
+//   S5u  unparnmpc_backward_serial_kernel       backwardCorrectionSerial, stages N-2 .. 0                  (per instance)
+//   K10u unparnmpc_backward_parallel_kernel     backwardCorrectionParallel                                 (per stage)
+//   S6u  unparnmpc_forward_serial_kernel        forwardCorrectionSerial, stages 1 .. N-1                   (per instance)
+//   K11u unparnmpc_expand_kernel                forwardCorrectionParallel + aux_mat + computeDirection +
+//                                               computeCondensedDirection + slack / dual directions + steps (per stage)
+//   K3   un_integrate_kernel                    updatePrimal / updateDual
+// Stage i of instance b uses record b * (N + 1) + i of the (N + 1)-record arrays (record N stays unused and zero).
+
+// K9u: one wavefront per stage.  KKT matrix [[0 F]; [F^T Q]] in the ordering (lmd, gmm | a, q, v) with
+// F = [0 -I dt I; dt I 0 -I] (split_unkkt_matrix_inverter.hxx:37-80):
+//   Q^-1, FQ = F Q^-1, S = FQ F^T, TL = -S^-1, TR = S^-1 FQ, BR = Q^-1 - FQ^T TR;
+// d = K^-1 [Fq Fv la lq lv], s_new = s - d (split_unbackward_correction.hxx:50-64).  Both inverses run in the registers
+// of the wavefront (spdInverseRows), the products go through LDS.
+template <int NV>
+__global__ __launch_bounds__(64) void unparnmpc_coarse_update_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int NX = L::NX, NQ = L::NQ3, NK = 5 * NV;
+  __shared__ double sQ[NQ * NQ], sFQ[NX * NQ], sS[NX * NX], sTR[NX * NQ], sres[NK], st1[NX], sd[NK];
+  __shared__ int s_ok;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const long b = unit / N;
+  const int i = (int)(unit - b * N);
+  const long rec = b * (N + 1) + i;
+  const double* __restrict__ kk = B.kkt + unit * L::KKT;
+  const double* __restrict__ aux = B.aux + (rec + 1) * L::AUX;       // aux_mat of the NEXT stage (none behind the last one)
+  if (lane == 0) s_ok = 1;
+  // Q in the ordering (a, q, v) from the six upper blocks K1b stores, + aux_mat_next on the (q, v) block
+  for (int e = lane; e < NQ * NQ; e += 64) {
+    const int c = e / NQ, r = e - c * NQ;
+    const int bi = r / NV, ri = r - bi * NV, bj = c / NV, cj = c - bj * NV;
+    const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
+    const int rr = bi <= bj ? ri : cj, cc = bi <= bj ? cj : ri;
+    const int off = lo == 0 ? (hi == 0 ? L::K_QAA : (hi == 1 ? L::K_QAQ : L::K_QAV)) : (lo == 1 ? (hi == 1 ? L::K_QQQ : L::K_QQV) : L::K_QVV);
+    double val = kk[off + cc * NV + rr];
+    if (lo == hi && ri > cj) val = kk[off + ri * NV + cj];           // diagonal blocks: read the upper triangle only
+    if (i < N - 1 && bi >= 1 && bj >= 1) val += aux[(c - NV) * NX + (r - NV)];
+    sQ[e] = val;
+  }
+  if (lane < NK) sres[lane] = kk[L::K_FQ + lane];                     // [Fq Fv la lq lv] are contiguous in the kkt record
+  __syncthreads();
+  spdInverseRows<NQ>(sQ, NQ, NQ, lane, &s_ok);
+  __syncthreads();
+  for (int e = lane; e < NX * NQ; e += 64) {
+    const int c = e / NX, r = e - c * NX;
+    sFQ[e] = r < NV ? -sQ[(NV + r) + NQ * c] + dt * sQ[(2 * NV + r) + NQ * c] : dt * sQ[(r - NV) + NQ * c] - sQ[(NV + r) + NQ * c];
+  }
+  __syncthreads();
+  for (int e = lane; e < NX * NX; e += 64) {
+    const int c = e / NX, r = e - c * NX;
+    sS[e] = c < NV ? -sFQ[r + NX * (NV + c)] + dt * sFQ[r + NX * (2 * NV + c)] : dt * sFQ[r + NX * (c - NV)] - sFQ[r + NX * (NV + c)];
+  }
+  __syncthreads();
+  spdInverseRows<NX>(sS, NX, NX, lane, &s_ok);
+  __syncthreads();
+  for (int e = lane; e < NX * NQ; e += 64) {                          // TR = S^-1 FQ
+    const int c = e / NX, r = e - c * NX;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) acc += sS[r + NX * k] * sFQ[k + NX * c];
+    sTR[e] = acc;
+  }
+  __syncthreads();
+  double* __restrict__ ki = B.kinv + unit * L::KINV;
+  for (int e = lane; e < NX * NX; e += 64) ki[L::I_TL + e] = -sS[e];
+  for (int e = lane; e < NX * NQ; e += 64) ki[L::I_TR + e] = sTR[e];
+  for (int e = lane; e < NQ * NX; e += 64) {                          // the (q, v) columns of BR = Q^-1 - FQ^T TR
+    const int c = e / NQ, r = e - c * NQ;
+    double acc = sQ[r + NQ * (NV + c)];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) acc -= sFQ[k + NX * r] * sTR[k + NX * (NV + c)];
+    ki[L::I_BRC + e] = acc;
+  }
+  // d = K^-1 res:  t1 = TR l,  d_top = -S^-1 Fx + t1,  d_bot = TR^T Fx + Q^-1 l - FQ^T t1
+  if (lane < NX) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) acc += sTR[lane + NX * c] * sres[NX + c];
+    st1[lane] = acc;
+  }
+  __syncthreads();
+  if (lane < NX) {
+    double acc = st1[lane];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) acc -= sS[lane + NX * k] * sres[k];
+    sd[lane] = acc;
+  } else if (lane < NX + NQ) {
+    const int r = lane - NX;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) acc += sTR[k + NX * r] * sres[k] - sFQ[k + NX * r] * st1[k];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) acc += sQ[r + NQ * c] * sres[NX + c];
+    sd[lane] = acc;
+  }
+  __syncthreads();
+  // s_new = s - d in the fields (lmd, gmm | a, q, v)
+  if (lane < NK) {
+    const int f = lane < NX ? L::S_LMD + lane : (lane < NX + NV ? L::S_A + (lane - NX) : L::S_Q + (lane - NX - NV));
+    B.snew[rec * L::SOL + f] = B.sol[rec * L::SOL + f] - sd[lane];
+  }
+  if (lane == 0 && !s_ok) atomicMax(&B.status[b], 1 + i);
+}
+
+// S5u: 16 lanes per instance, lane r < NX owns row r of the costate pair (lmd, gmm).  Stage i:
+//   x_res = s_new[i+1].(lmd, gmm) - s[i+1].(lmd, gmm);  s_new[i].(lmd, gmm) -= K^-1(0.., 3nv..) x_res   (TR's (q, v) columns)
+// (split_unbackward_correction.hxx:72-81).  The loads of stage i - 1 are issued before the dependent chain of stage i.
+template <int NV>
+__global__ __launch_bounds__(64) void unparnmpc_backward_serial_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int NX = L::NX;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x, g = lane >> 4, r0 = lane & 15, r = r0 < NX ? r0 : NX - 1;
+  long b = (long)blockIdx.x * 4 + g;
+  const bool active = b < P->batch && r0 < NX;
+  if (b >= P->batch) b = P->batch - 1;
+  const int base = lane & ~15;
+  const double* __restrict__ sol = B.sol + b * (N + 1) * L::SOL;
+  double* __restrict__ snew = B.snew + b * (N + 1) * L::SOL;
+  double* __restrict__ xres = B.xres + b * (N + 1) * L::XRES;
+  const double* __restrict__ kinv = B.kinv + b * N * L::KINV;
+  if (N < 2) return;
+  double cur = snew[(N - 1) * L::SOL + r];                // (lmd, gmm) are the first NX entries of a record
+  double m[NX], mn[NX];
+  double s_next = sol[(N - 1) * L::SOL + r], own = snew[(N - 2) * L::SOL + r];
+#pragma unroll
+  for (int c = 0; c < NX; ++c) m[c] = kinv[(long)(N - 2) * L::KINV + L::I_TR + (NV + c) * NX + r];
+  for (int i = N - 2; i >= 0; --i) {
+    double s_next_n = 0.0, own_n = 0.0;
+    if (i > 0) {
+      s_next_n = sol[i * L::SOL + r]; own_n = snew[(i - 1) * L::SOL + r];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) mn[c] = kinv[(long)(i - 1) * L::KINV + L::I_TR + (NV + c) * NX + r];
+    }
+    const double x = cur - s_next;
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) acc += m[c] * __shfl(x, base + c);
+    cur = own - acc;
+    if (active) { xres[i * L::XRES + r] = x; snew[i * L::SOL + r] = cur; }
+    s_next = s_next_n; own = own_n;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) m[c] = mn[c];
+  }
+}
+
+// K10u: s_new[i].(a, q, v) -= K^-1(2nv.., 3nv..) x_res for i <= N - 2 (split_unbackward_correction.hxx:84-92): 32 lanes per
+// stage, lane r < 3 NV owns one row.
+template <int NV>
+__global__ __launch_bounds__(64) void unparnmpc_backward_parallel_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int NX = L::NX, NQ = L::NQ3;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x, g = lane >> 5, r = lane & 31;
+  const long total = (long)P->batch * (N - 1);
+  const long unit = (long)blockIdx.x * 2 + g;
+  if (unit >= total || r >= NQ) return;
+  const long b = unit / (N - 1);
+  const int i = (int)(unit - b * (N - 1));
+  const long rec = b * (N + 1) + i;
+  const double* __restrict__ x = B.xres + rec * L::XRES;
+  const double* __restrict__ m = B.kinv + (b * N + i) * L::KINV + L::I_BRC;
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < NX; ++c) acc += m[r + NQ * c] * x[c];
+  const int f = r < NV ? L::S_A + r : L::S_Q + (r - NV);
+  B.snew[rec * L::SOL + f] -= acc;
+}
+
+// S6u: 16 lanes per instance, lane r < NX owns row r of the state (q, v).  Stage i >= 1:
+//   x_res = s_new[i-1].(q, v) - s[i-1].(q, v);  s_new[i].(q, v) -= K^-1(3nv.., 0..) x_res   (= TR(:, q v)^T)
+// (split_unbackward_correction.hxx:95-104)
+template <int NV>
+__global__ __launch_bounds__(64) void unparnmpc_forward_serial_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int NX = L::NX;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x, g = lane >> 4, r0 = lane & 15, r = r0 < NX ? r0 : NX - 1;
+  long b = (long)blockIdx.x * 4 + g;
+  const bool active = b < P->batch && r0 < NX;
+  if (b >= P->batch) b = P->batch - 1;
+  const int base = lane & ~15;
+  const double* __restrict__ sol = B.sol + b * (N + 1) * L::SOL;
+  double* __restrict__ snew = B.snew + b * (N + 1) * L::SOL;
+  double* __restrict__ xres = B.xres + b * (N + 1) * L::XRES;
+  const double* __restrict__ kinv = B.kinv + b * N * L::KINV;
+  if (N < 2) return;
+  double cur = snew[L::S_Q + r];                           // (q, v) are contiguous in a record
+  double m[NX], mn[NX];
+  double s_prev = sol[L::S_Q + r], own = snew[L::SOL + L::S_Q + r];
+#pragma unroll
+  for (int c = 0; c < NX; ++c) m[c] = kinv[(long)L::KINV + L::I_TR + (NV + r) * NX + c];
+  for (int i = 1; i < N; ++i) {
+    double s_prev_n = 0.0, own_n = 0.0;
+    if (i + 1 < N) {
+      s_prev_n = sol[i * L::SOL + L::S_Q + r]; own_n = snew[(i + 1) * L::SOL + L::S_Q + r];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) mn[c] = kinv[(long)(i + 1) * L::KINV + L::I_TR + (NV + r) * NX + c];
+    }
+    const double x = cur - s_prev;
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) acc += m[c] * __shfl(x, base + c);
+    cur = own - acc;
+    if (active) { xres[i * L::XRES + NX + r] = x; snew[i * L::SOL + L::S_Q + r] = cur; }
+    s_prev = s_prev_n; own = own_n;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) m[c] = mn[c];
+  }
+}
+
+// K11u: the last parallel loop of UnBackwardCorrection::backwardCorrection (unbackward_correction.cpp:114-131), 8 lanes per
+// stage, lane r owns row r: forwardCorrectionParallel (i > 0: (lmd, gmm, a) -= K^-1(0.., 0..) x_res; aux_mat = S^-1),
+// computeDirection d = s_new - s, the condensed direction (unconstrained_dynamics.hxx:97-106), the slack / dual directions
+// and the fraction-to-boundary step sizes of the stage.
+template <int NV>
+__global__ __launch_bounds__(64) void unparnmpc_expand_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int NX = L::NX;
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x, g = lane >> 3, r0 = lane & 7, r = r0 < NV ? r0 : NV - 1;
+  const long total = (long)P->batch * N;
+  long su = (long)blockIdx.x * 8 + g;
+  const bool active = (su < total) && (r0 < NV);
+  if (su >= total) su = total - 1;
+  const long b = su / N;
+  const int i = (int)(su - b * N);
+  const long rec = b * (N + 1) + i;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  double* __restrict__ sn = B.snew + rec * L::SOL;
+  double* __restrict__ dd = B.dir + rec * L::SOL;
+  const double* __restrict__ ki = B.kinv + su * L::KINV;
+  double n_lmd = sn[L::S_LMD + r], n_gmm = sn[L::S_GMM + r], n_a = sn[L::S_A + r];
+  if (i > 0) {
+    const double* __restrict__ x = B.xres + rec * L::XRES + NX;
+    double c_lmd = 0.0, c_gmm = 0.0, c_a = 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      const double xc = x[c];
+      c_lmd += ki[L::I_TL + r + NX * c] * xc;
+      c_gmm += ki[L::I_TL + NV + r + NX * c] * xc;
+      c_a += ki[L::I_TR + c + NX * r] * xc;                 // K^-1(2nv + r, c) = TR(c, r)
+    }
+    n_lmd -= c_lmd; n_gmm -= c_gmm; n_a -= c_a;
+    if (active) { sn[L::S_LMD + r] = n_lmd; sn[L::S_GMM + r] = n_gmm; sn[L::S_A + r] = n_a; }
+    double* __restrict__ aux = B.aux + rec * L::AUX;        // aux_mat[i] = -K^-1.topLeft = S^-1
+    if (su < total) for (int e = r0; e < NX * NX; e += 8) aux[e] = -ki[L::I_TL + e];
+  }
+  double dq[NV], dv[NV], da[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) { dq[c] = sn[L::S_Q + c] - s[L::S_Q + c]; dv[c] = sn[L::S_V + c] - s[L::S_V + c]; }
+  const double da_r = n_a - s[L::S_A + r];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) da[c] = __shfl(da_r, (lane & ~7) + c);
+  const double* __restrict__ dy = B.dyn + su * L::DYN;
+  double du = dy[L::D_ID + r];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) du += dy[L::D_DQ + c * NV + r] * dq[c] + dy[L::D_DV + c * NV + r] * dv[c] + dy[L::D_DA + c * NV + r] * da[c];
+  const double dbeta = (dy[L::D_LU + r] + dy[L::D_QUU + r] * du) / dt;
+  if (active) {
+    dd[L::S_LMD + r] = n_lmd - s[L::S_LMD + r]; dd[L::S_GMM + r] = n_gmm - s[L::S_GMM + r];
+    dd[L::S_Q + r] = dq[r]; dd[L::S_V + r] = dv[r]; dd[L::S_A + r] = da_r; dd[L::S_U + r] = du; dd[L::S_BETA + r] = dbeta;
+  }
+  const double* __restrict__ slack = B.slack + su * L::CON;
+  const double* __restrict__ dual = B.dual + su * L::CON;
+  double ps = 1.0, ds = 1.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    if (!rowValid(P, c, i)) continue;
+    const double sgn = (c & 1) ? 1.0 : -1.0;
+    const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
+    const double dx = (c < 2) ? dq[r] : ((c < 4) ? dv[r] : du);
+    const double sl = slack[c * NV + r], dl = dual[c * NV + r];
+    const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
+    const double dslack = -sgn * dx - row.residual;
+    const double ddual = -(dl * dslack + row.duality) / sl;
+    ps = fractionToBoundary(P->fraction_rate, sl, dslack, ps);
+    ds = fractionToBoundary(P->fraction_rate, dl, ddual, ds);
+  }
+  if (!active) { ps = 1.0; ds = 1.0; }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
+    ps = fmin(ps, __shfl_xor(ps, off));
+    ds = fmin(ds, __shfl_xor(ds, off));
+  }
+  if (active && r0 == 0) { B.step_stage[su * 2] = ps; B.step_stage[su * 2 + 1] = ds; }
+}
+
+// UnBackwardCorrection::initAuxMat (unbackward_correction.cpp:55-64): the terminal cost Hessian on every stage
+template <int NV>
+__global__ void unparnmpc_init_aux_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  constexpr int NX = L::NX;
+  const UnProblem* __restrict__ P = B.prob;
+  const long total = (long)P->batch * (P->N + 1) * NX * NX;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long rec = idx / (NX * NX);
+  const int e = (int)(idx - rec * NX * NX), c = e / NX, r = e - c * NX;
+  B.aux[rec * L::AUX + e] = (r == c) ? (r < NV ? P->qf_weight[r] : P->vf_weight[r - NV]) : 0.0;
 }
 
 // ------------------------------------------------------------ launchers ----
@@ -780,6 +1118,37 @@ void UnLaunch<NV>::single(int kernel_id, const UnBuffers& B, long batch, int N, 
     case 4: hipLaunchKernelGGL(un_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B); break;
     default: hipLaunchKernelGGL((un_integrate_kernel<NV>), dim3(stage_blocks), dim3(64), 0, st, B); break;
   }
+}
+
+// UnParNMPC: phase 0 linearize, 1 coarse update, 2 backward serial, 3 backward parallel, 4 forward serial,
+// 5 forward parallel + direction + step sizes, 6 integrate
+template <int NV>
+void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
+  constexpr int SPW = 64 / (3 * NV);
+  const unsigned inst_blocks = (unsigned)((batch + 3) / 4);
+  switch (phase) {
+    case 0: hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0); break;
+    case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)(batch * N)), dim3(64), 0, st, B); break;
+    case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
+    case 3: if (N > 1) hipLaunchKernelGGL((unparnmpc_backward_parallel_kernel<NV>), dim3((unsigned)((batch * (N - 1) + 1) / 2)), dim3(64), 0, st, B); break;
+    case 4: hipLaunchKernelGGL((unparnmpc_forward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
+    case 5:
+      hipLaunchKernelGGL((unparnmpc_expand_kernel<NV>), dim3((unsigned)((batch * N + 7) / 8)), dim3(64), 0, st, B);
+      hipLaunchKernelGGL(un_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+      break;
+    default: hipLaunchKernelGGL((un_integrate_kernel<NV>), dim3((unsigned)((batch * (N + 1) + 7) / 8)), dim3(64), 0, st, B); break;
+  }
+}
+template <int NV>
+void UnLaunch<NV>::parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
+  constexpr int SPW = 64 / (3 * NV);
+  hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+  hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
+}
+template <int NV>
+void UnLaunch<NV>::parnmpcInitAux(const UnBuffers& B, long batch, int N, hipStream_t st) {
+  const long total = batch * (N + 1) * 4 * NV * NV;
+  hipLaunchKernelGGL((unparnmpc_init_aux_kernel<NV>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B);
 }
 
 template struct UnLaunch<7>;

@@ -17,6 +17,10 @@ struct UnLaunch {
   static void expand(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void integrate(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void initConstraints(const UnBuffers& B, long batch, int N, hipStream_t st);
+  // UnParNMPC (backward-Euler stages + backward correction)
+  static void parnmpcPhase(int phase, const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);
+  static void parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);
+  static void parnmpcInitAux(const UnBuffers& B, long batch, int N, hipStream_t st);
   static void rneaDerivatives(const DevModel* m, int n, const double* q, const double* v, const double* a, double* tau,
                               double* dq, double* dv, double* da, hipStream_t st);
 };

@@ -235,6 +235,34 @@ int idocp_unocp_dimc(const idocp_unocp_t* h);
  * NULL) = first offending stage or -1. */
 int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, int* where);
 
+/* ---- UnParNMPCSolver (include/idocp/unocp/unparnmpc_solver.hpp:31-189, src/unocp/unparnmpc_solver.cpp) ----
+ * The stage-parallel solver of the fixed-base problem: N backward-Euler stages (stage i at t + (i+1) dt, created with
+ * constraint time step i + 1, the last one terminal), per-stage KKT inverse, coarse update and the four correction
+ * sweeps of UnBackwardCorrection (src/unocp/unbackward_correction.cpp:55-132).  The handle type is shared with
+ * UnOCPSolver: idocp_unocp_set_solution[_batch], _init_constraints, _get_solution, _get_direction, _get_step_sizes,
+ * _kkt_error, _get_constraint_data, _is_current_solution_feasible, _synchronize, _stream and _destroy work on it (the
+ * stage-wise getters return the N stages in their first N rows); the entry points below replace the rest. */
+int idocp_unparnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost,
+                           const idocp_constraints_t* constraints, double T, int N, int batch,
+                           int device, idocp_unocp_t** out);
+/* UnParNMPCSolver::initBackwardCorrection (unparnmpc_solver.cpp:69-71) */
+int idocp_unparnmpc_init_backward_correction(idocp_unocp_t* h, double t);
+/* UnParNMPCSolver::updateSolution (unparnmpc_solver.cpp:74-103); q, v: [batch][nv] on the host */
+int idocp_unparnmpc_update_solution(idocp_unocp_t* h, double t, const double* q, const double* v,
+                                    int line_search);
+/* the same with device-resident (q, v), asynchronous on the handle's stream */
+int idocp_unparnmpc_update_solution_device(idocp_unocp_t* h, double t, const double* d_q,
+                                           const double* d_v);
+/* UnParNMPCSolver::computeKKTResidual (unparnmpc_solver.cpp:169-187); read it with idocp_unocp_kkt_error */
+int idocp_unparnmpc_compute_kkt_residual(idocp_unocp_t* h, double t, const double* q,
+                                         const double* v);
+/* One phase of updateSolution (parity tests, roofline measurement): 0 linearize, 1 KKT inverse + coarse update,
+ * 2 backward serial, 3 backward parallel, 4 forward serial, 5 forward parallel + direction + step sizes, 6 integrate. */
+int idocp_unparnmpc_launch_phase(idocp_unocp_t* h, int phase, const double* d_q, const double* d_v);
+/* The coarse / corrected iterate s_new of the backward correction (fields lmd, gmm, a, q, v), like
+ * idocp_unocp_get_solution. */
+int idocp_unparnmpc_get_new_solution(idocp_unocp_t* h, const char* name, int instance, double* out);
+
 /* Kernel-level entry points used by the parity tests and the roofline
  * measurement (one launch each, on the handle's stream). */
 int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q,

@@ -302,6 +302,57 @@ class HipUnOCP:
         return sl, du
 
 
+class HipUnParNMPC(HipUnOCP):
+    """Product path of UnParNMPCSolver through the C ABI (idocp_unparnmpc_* on the shared handle type); fields are [N][nv]."""
+
+    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
+        self.lib = capi.lib()
+        self.N, self.nv, self.batch = N, model.nv, batch
+        h = C.c_void_p()
+        capi.check(self.lib.idocp_unparnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
+                   "idocp_unparnmpc_create")
+        self.h = h
+        self._dq = self._dv = None
+
+    def init(self, t=0.0):
+        capi.check(self.lib.idocp_unocp_init_constraints(self.h), "init_constraints")
+        capi.check(self.lib.idocp_unparnmpc_init_backward_correction(self.h, t), "init_backward_correction")
+
+    def _bc(self, x):
+        return arr(np.broadcast_to(arr(x), (self.batch, self.nv)) if np.ndim(x) == 1 else x)
+
+    def update(self, t, q, v):
+        return self.lib.idocp_unparnmpc_update_solution(self.h, t, P(self._bc(q)), P(self._bc(v)), 0)
+
+    def phase(self, phase, q, v):
+        """one phase of updateSolution (0 linearize ... 6 integrate) with (q, v) uploaded once"""
+        if self._dq is None:
+            self._dq, self._dv = C.c_void_p(), C.c_void_p()
+            capi.check(self.lib.idocp_device_alloc(C.byref(self._dq), 8 * self.batch * self.nv), "alloc")
+            capi.check(self.lib.idocp_device_alloc(C.byref(self._dv), 8 * self.batch * self.nv), "alloc")
+        qq, vv = self._bc(q), self._bc(v)
+        capi.check(self.lib.idocp_device_upload(self._dq, qq.ctypes.data, qq.nbytes), "upload")
+        capi.check(self.lib.idocp_device_upload(self._dv, vv.ctypes.data, vv.nbytes), "upload")
+        capi.check(self.lib.idocp_unparnmpc_launch_phase(self.h, phase, self._dq, self._dv), "launch_phase")
+        capi.check(self.lib.idocp_unocp_synchronize(self.h), "synchronize")
+
+    def kkt_error(self, t, q, v):
+        capi.check(self.lib.idocp_unparnmpc_compute_kkt_residual(self.h, t, P(self._bc(q)), P(self._bc(v))), "compute_kkt_residual")
+        out = np.zeros(self.batch)
+        capi.check(self.lib.idocp_unocp_kkt_error(self.h, P(out)), "kkt_error")
+        return out
+
+    def get(self, name, instance=0):
+        out = np.zeros((self.N + 1, self.nv))
+        if name.startswith("new_"):
+            capi.check(self.lib.idocp_unparnmpc_get_new_solution(self.h, name[4:].encode(), instance, P(out)), "get_new_solution")
+        elif name[0] == "d":
+            capi.check(self.lib.idocp_unocp_get_direction(self.h, name.encode(), instance, P(out)), "get_direction")
+        else:
+            capi.check(self.lib.idocp_unocp_get_solution(self.h, name.encode(), instance, P(out)), "get_solution")
+        return out[:self.N]
+
+
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))

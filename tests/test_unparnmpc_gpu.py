@@ -1,0 +1,107 @@
+"""GPU parity of UnParNMPCSolver (iiwa14) against the oracle, through the C ABI: phase by phase on the first iteration,
+then iterate by iterate.  Bar: 1e-10 on the Newton direction (FP64)."""
+import numpy as np
+import pytest
+
+from helpers import HipUnParNMPC, OracleUnParNMPC, iiwa14_model, rel_err, unocp_problem
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+SOL = ("q", "v", "a", "u", "lmd", "gmm", "beta")
+DIR = tuple("d" + f for f in SOL)
+NEW = tuple("new_" + f for f in ("lmd", "gmm", "a", "q", "v"))
+
+
+def make_pair(N, T, batch=1, q0=2.0):
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    o, g = OracleUnParNMPC(m, cost, cons, T, N), HipUnParNMPC(m, cost, cons, T, N, batch=batch)
+    q, v = np.full(m.nv, q0), np.zeros(m.nv)
+    for s in (o, g):
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.init(0.0)
+    return m, o, g, q, v
+
+
+def compare(o, g, fields, tol, what):
+    for f in fields:
+        e = rel_err(g.get(f), o.get(f))
+        assert e < tol, (what, f, e)
+
+
+@pytest.mark.parametrize("N,T", [(20, 1.0), (3, 0.3), (64, 2.0)])
+def test_phase_by_phase_parity_of_the_first_iteration(N, T):
+    m, o, g, q, v = make_pair(N, T)
+    # oracle stage 0 = linearize + KKT inverse + coarse update = GPU phases 0, 1
+    assert o.stage(0, 0.0, q, v) == 0
+    g.phase(0, q, v)
+    g.phase(1, q, v)
+    compare(o, g, NEW, TOL, "coarse update")
+    for k, name in ((1, "backward serial"), (2, "backward parallel"), (3, "forward serial")):
+        assert o.stage(k, 0.0, q, v) == 0
+        g.phase(k + 1, q, v)
+        compare(o, g, NEW, TOL, name)
+    assert o.stage(4, 0.0, q, v) == 0
+    g.phase(5, q, v)
+    compare(o, g, NEW, TOL, "forward parallel")
+    compare(o, g, DIR, TOL, "direction")
+    ao, bo = o.step_sizes()
+    ag, bg = g.step_sizes()
+    assert abs(ag[0] - ao) < 1e-9 and abs(bg[0] - bo) < 1e-9
+    assert o.stage(5, 0.0, q, v) == 0
+    g.phase(6, q, v)
+    compare(o, g, SOL, TOL, "integrated solution")
+    so, do = o.constraint_data()
+    sg, dg = g.constraint_data()
+    assert rel_err(sg, so) < TOL and rel_err(dg, do) < TOL
+
+
+def test_multi_iteration_parity_and_convergence():
+    # ocpbenchmarker::Convergence protocol of examples/iiwa14/unparnmpc_benchmark.cpp (N = 20, T = 1, 100 iterations)
+    m, o, g, q, v = make_pair(20, 1.0, batch=2)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) < 1e-9 * max(1.0, e_o) and e_g[0] == e_g[1]
+    for it in range(100):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        if it < 3:                                   # iterate-by-iterate parity while rounding has not yet been amplified
+            compare(o, g, DIR, 1e-9 if it else TOL, "iteration %d" % it)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert e_o < 1e-6 and e_g[0] < 1e-6 and e_g[1] < 1e-6
+    compare(o, g, ("q", "v", "a", "u"), 1e-6, "converged solution")
+    assert o.infeasible_stage() == -1 and list(g.infeasible_stage()) == [-1, -1]
+
+
+def test_batch_instances_are_independent():
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    rng = np.random.default_rng(3)
+    B, N = 5, 12
+    q0 = 1.0 + 0.5 * rng.uniform(-1, 1, (B, m.nv))
+    v0 = 0.2 * rng.uniform(-1, 1, (B, m.nv))
+    g = HipUnParNMPC(m, cost, cons, 0.6, N, batch=B)
+    g.set_solution_batch("q", q0)
+    g.set_solution_batch("v", v0)
+    g.init(0.0)
+    assert g.update(0.0, q0, v0) == 0
+    for b in (0, 3, 4):
+        o = OracleUnParNMPC(m, cost, cons, 0.6, N)
+        o.set_solution("q", q0[b])
+        o.set_solution("v", v0[b])
+        o.init(0.0)
+        assert o.update(0.0, q0[b], v0[b]) == 0
+        for f in DIR:
+            assert rel_err(g.get(f, b), o.get(f)) < TOL, (b, f)
+
+
+def test_handle_kinds_are_not_interchangeable_and_line_search_is_rejected():
+    from helpers import HipUnOCP, P, arr
+    E_ARG, E_UNSUPPORTED = -1, -4
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    g, u = HipUnParNMPC(m, cost, cons, 1.0, 4), HipUnOCP(m, cost, cons, 1.0, 4)
+    q, v = np.full(m.nv, 1.0), np.zeros(m.nv)
+    assert g.lib.idocp_unocp_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 0) == E_ARG
+    assert b"UnParNMPCSolver" in g.lib.idocp_last_error()
+    assert u.lib.idocp_unparnmpc_update_solution(u.h, 0.0, P(arr(q)), P(arr(v)), 0) == E_ARG
+    assert g.lib.idocp_unparnmpc_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 1) == E_UNSUPPORTED
