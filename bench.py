@@ -31,9 +31,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE = {"iiwa14": 5544, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
+A_STAGE = {"iiwa14": 5544, "iiwa14_unparnmpc": 5656, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
            "anymal_parnmpc_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
+KERNELS_UNP = ["un_linearize", "unparnmpc_coarse_update", "unparnmpc_backward_serial", "unparnmpc_backward_parallel",
+               "unparnmpc_forward_serial", "unparnmpc_expand", "un_integrate"]
 KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
                "ocp_reduce_steps", "ocp_expand_dual_integrate"]
 
@@ -69,7 +71,7 @@ class Hip:
 def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=12.0, nimp=0):
     """CPU restatement (oracle, kind "port") timed on this host with the
     reference's CPUTime protocol, single thread, on a bounded sample."""
-    from helpers import OracleOCP, OracleUnOCP, P, arr, oracle, running_sequence, trotting_sequence
+    from helpers import OracleOCP, OracleUnOCP, OracleUnParNMPC, P, arr, oracle, running_sequence, trotting_sequence
     lib = oracle()
     ric = C.c_double()
     if workload == "anymal_running":
@@ -96,6 +98,13 @@ def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_secon
         o.set_solution("v", v)
         bench = lib.oracle_unocp_bench
         nconv = 50
+    elif workload == "iiwa14_unparnmpc":
+        o = OracleUnParNMPC(model, cost, cons, T, N)
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        o.init(0.0)
+        bench = lib.oracle_unparnmpc_bench
+        nconv = 100
     else:
         o = OracleOCP(model, cost, cons, T, N)
         o.set_contact_status([1, 1, 1, 1], pts)
@@ -327,7 +336,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "anymal_parnmpc_trotting", "iiwa14"], default="anymal_trotting",
+    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "anymal_parnmpc_trotting", "iiwa14", "iiwa14_unparnmpc"], default="anymal_trotting",
                     help="anymal_trotting = BASELINE.json configs[2] (trotting contact sequence); anymal = its uniform 4-contact variant "
                          "(SURVEY 8d roofline case); iiwa14 = configs[1]; anymal_parnmpc = configs[3] (ParNMPC, N=256, the horizon "
                          "sharded over the ranks, strong scaling)")
@@ -347,7 +356,7 @@ def main():
         return run_parnmpc(args, rank, local_rank, world, dist)
 
     from idocp_amd import capi
-    from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,
+    from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, HipUnParNMPC, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,
                          trotting_sequence, unocp_problem)
     lib = capi.lib()                       # fails loudly if the HIP extension is missing
     hip = Hip()
@@ -436,6 +445,25 @@ def main():
         desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, 4 point contacts active on every stage (BASELINE.json configs[2], "
                 "uniform-contact variant), trotting cost + joint limits + linearized friction cone; " % (N, T))
         assert solver.update(0.0, q0, v0) == 0            # one full update through the host entry (uploads the stage references)
+    elif args.workload == "iiwa14_unparnmpc":
+        # iiwa14 UnParNMPCSolver (examples/iiwa14/unparnmpc_benchmark.cpp at the horizon of configs[1]), FP64
+        B = args.batch or 8192
+        model = iiwa14_model()
+        cost, cons = unocp_problem(model)
+        nq, nv = model.nq, model.nv
+        q0 = np.ascontiguousarray(2.0 + 0.1 * rng.uniform(-1, 1, (B, nv)))
+        v0 = np.zeros((B, nv))
+        q0 = np.ascontiguousarray(1.0 + 0.1 * rng.uniform(-1, 1, (B, nv)))     # inside the joint limits: the stage-wise method needs a feasible start
+        solver = HipUnParNMPC(model, cost, cons, T, N, batch=B, device=local_rank)
+        solver.set_solution_batch("q", q0)
+        solver.set_solution("v", v0[0])
+        solver.init(0.0)
+        KERNELS = KERNELS_UNP
+        launch, sync_fn, stream = lib.idocp_unparnmpc_launch_phase, lib.idocp_unocp_synchronize, lib.idocp_unocp_stream(solver.h)
+        units = {0: B * N, 1: B * N, 2: B * (N - 1), 3: B * (N - 1), 4: B * (N - 1), 5: B * N, 6: B * N}
+        riccati_ids = (2, 4)
+        desc = "iiwa14 UnParNMPCSolver N=%d T=%.2f FP64 (SURVEY 8f row 2; backward correction sweeps in place of the Riccati sweeps); " % (N, T)
+        assert solver.update(0.0, q0, v0) == 0
     else:
         # BASELINE.json configs[1]: iiwa14 UnOCPSolver, N=100, T=5, FP64
         B = args.batch or 16384

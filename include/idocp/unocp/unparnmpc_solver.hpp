@@ -1,0 +1,104 @@
+// idocp::UnParNMPCSolver -- drop-in facade over the HIP path.
+//
+// Same constructor signature and methods as the reference class
+// (include/idocp/unocp/unparnmpc_solver.hpp:31-189; src/unocp/unparnmpc_solver.cpp).
+// Every method forwards to the C ABI (include/idocp_hip.h, idocp_unparnmpc_* and the
+// shared idocp_unocp_* accessors); the arithmetic runs in the HIP kernels.  `nthreads`
+// is accepted for source compatibility and ignored.  Argument errors: message on
+// stderr + std::exit(EXIT_FAILURE), like the reference.
+#ifndef IDOCP_UNPARNMPC_SOLVER_HPP_
+#define IDOCP_UNPARNMPC_SOLVER_HPP_
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "idocp/constraints/constraints.hpp"
+#include "idocp/cost/cost_function.hpp"
+#include "idocp/eigen_shim.hpp"
+#include "idocp/robot/robot.hpp"
+#include "idocp/unocp/unocp_solver.hpp"      // SplitSolution
+#include "idocp_hip.h"
+
+namespace idocp {
+
+class UnParNMPCSolver {
+ public:
+  UnParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
+                  const double T, const int N, const int nthreads = 1, const int device = 0)
+      : robot_(robot), N_(N), h_(nullptr) {
+    (void)nthreads;
+    const idocp_cost_t c = cost->native();
+    const idocp_constraints_t k = constraints->native();
+    check(idocp_unparnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    cache_.resize(N);
+  }
+  ~UnParNMPCSolver() { idocp_unocp_destroy(h_); }
+  UnParNMPCSolver(const UnParNMPCSolver&) = delete;
+  UnParNMPCSolver& operator=(const UnParNMPCSolver&) = delete;
+
+  void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
+  void initBackwardCorrection(const double t) { check(idocp_unparnmpc_init_backward_correction(h_, t)); }
+
+  void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    check(idocp_unparnmpc_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
+  }
+
+  // stage in [0, N): the N backward-Euler stages (stage i lives at t + (i + 1) dt)
+  const SplitSolution& getSolution(const int stage) {
+    SplitSolution& s = cache_.at(stage);
+    const char* names[7] = {"lmd", "gmm", "q", "v", "a", "u", "beta"};
+    Eigen::VectorXd* dst[7] = {&s.lmd, &s.gmm, &s.q, &s.v, &s.a, &s.u, &s.beta};
+    for (int f = 0; f < 7; ++f) *dst[f] = getSolution(names[f])[stage];
+    return s;
+  }
+
+  std::vector<Eigen::VectorXd> getSolution(const std::string& name) const {
+    const int dim = robot_.dimv();
+    std::vector<double> buf((size_t)(N_ + 1) * dim);
+    check(idocp_unocp_get_solution(h_, name.c_str(), 0, buf.data()));
+    std::vector<Eigen::VectorXd> out(N_, Eigen::VectorXd(dim));
+    for (int i = 0; i < N_; ++i) for (int j = 0; j < dim; ++j) out[i][j] = buf[(size_t)i * dim + j];
+    return out;
+  }
+
+  // left unimplemented by the reference as well (unparnmpc_solver.cpp:107-118)
+  void getStateFeedbackGain(const int, Eigen::MatrixXd&, Eigen::MatrixXd&) const {}
+
+  void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_unocp_set_solution(h_, name.c_str(), value.data())); }
+  void clearLineSearchFilter() {}
+
+  bool isCurrentSolutionFeasible() {
+    int ok = 0, where = -1;
+    check(idocp_unocp_is_current_solution_feasible(h_, &ok, &where));
+    if (!ok) std::cout << "INFEASIBLE at time stage " << where << std::endl;
+    return ok != 0;
+  }
+
+  double KKTError() {
+    double e = 0;
+    check(idocp_unocp_kkt_error(h_, &e));
+    return e;
+  }
+  void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    check(idocp_unparnmpc_compute_kkt_residual(h_, t, q.data(), v.data()));
+  }
+  idocp_unocp_t* handle() { return h_; }
+
+ private:
+  Robot robot_;
+  int N_;
+  idocp_unocp_t* h_;
+  std::vector<SplitSolution> cache_;
+  static void check(int rc) {
+    if (rc != IDOCP_OK) {
+      std::cerr << idocp_last_error() << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+  }
+};
+
+}  // namespace idocp
+#endif  // IDOCP_UNPARNMPC_SOLVER_HPP_

@@ -285,6 +285,15 @@ double oracle_unparnmpc_kkt_error(void* h, double t, const double* q, const doub
   s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
   return s->KKTError();
 }
+// `iters` updateSolution calls at fixed (t, q, v); returns total seconds (the sweeps are not timed separately)
+double oracle_unparnmpc_bench(void* h, double t, const double* q, const double* v, int iters, double* sweep_seconds) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  Mat Q = toVec(q, s->robot.dimq()), V = toVec(v, s->robot.dimv());
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) s->updateSolution(t, Q, V);
+  if (sweep_seconds) *sweep_seconds = 0.0;
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 int oracle_unparnmpc_is_current_solution_feasible(void* h) { return static_cast<UnParNMPCSolver*>(h)->isCurrentSolutionFeasible(); }
 // out[N][dim]; names: the solution fields, "d" + field for the direction, "new_" + field for the coarse / corrected iterate
 int oracle_unparnmpc_get(void* h, const char* name, double* out) {

@@ -28,7 +28,7 @@ def per_launch(path, counter):
         key = m.group(1)
         if "condense" in key and re.search(r",\s*true", name):
             key += "_residual"
-        elif key.startswith("un_linearize") and re.search(r",\s*1>", name):
+        elif key.startswith("un_linearize") and re.search(r"_kernel<\d+,\s*1\b", name):
             key += "_residual"
         # the template variants of one kernel that run side by side in every step (K5b per stage class, K5a regular + impulse
         # launch) share a key: bytes of all of them per step = sum of their totals / launches of the most frequent one

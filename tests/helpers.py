@@ -68,6 +68,8 @@ def oracle():
         lib.oracle_unparnmpc_get_step_sizes.argtypes = [vp, dp, dp]
         lib.oracle_unparnmpc_get_matrices.argtypes = [vp, dp, dp]
         lib.oracle_unparnmpc_get_constraint_data.argtypes = [vp, dp, dp]
+        lib.oracle_unparnmpc_bench.argtypes = [vp, cd, dp, dp, ci, dp]
+        lib.oracle_unparnmpc_bench.restype = cd
         _oracle = lib
     return _oracle
 

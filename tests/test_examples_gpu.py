@@ -75,6 +75,31 @@ def test_iiwa14_unocp_benchmark_example_matches_oracle():
     assert len(its) >= 10 and its[-1] < init
 
 
+def test_iiwa14_unparnmpc_benchmark_example_matches_oracle():
+    """examples/iiwa14_unparnmpc_benchmark.cpp = the reference's examples/iiwa14/unparnmpc_benchmark.cpp through the facade
+    (idocp::UnParNMPCSolver): the printed KKT errors follow the oracle's iteration and reach its floor."""
+    from helpers import OracleUnParNMPC, iiwa14_model, unocp_problem
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "iiwa14_unparnmpc_benchmark"), IIWA_URDF], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 100 and "feasible: yes" in r.stdout
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    o = OracleUnParNMPC(m, cost, cons, 1.0, 20)
+    q, v = np.full(m.nv, 2.0), np.zeros(m.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.init(0.0)
+    assert abs(init - o.kkt_error(0.0, q, v)) < 1e-5 * init          # printed with 6 significant digits
+    for k in range(3):
+        assert o.update(0.0, q, v) == 0
+        e = o.kkt_error(0.0, q, v)
+        assert abs(its[k] - e) < 1e-5 * e, (k, its[k], e)
+    assert its[-1] < 1e-6
+
+
 def test_anymal_trotting_example_matches_oracle():
     """examples/anymal_trotting.cpp = the reference's examples/anymal/anymal_trotting.cpp driver (contact sequence with a
     lift and two impulse events) through the facade: its printed KKT errors follow the oracle's hybrid SQP iteration."""
