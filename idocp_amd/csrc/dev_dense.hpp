@@ -206,6 +206,42 @@ __device__ __forceinline__ void spdInverseRows(double* A, int ld, int n, int lan
   for (int j = 0; j < N; ++j) if (on && j < n) A[lane + ld * j] = a[j];
 }
 
+// The same register-resident elimination for G independent n = N matrices at once: lanes [g N, (g + 1) N) of the wavefront
+// hold the rows of matrix g (column-major, leading dimension N, `gstride` doubles apart), the pivot rows travel through
+// ds_bpermute (__shfl) instead of v_readlane, so one pass of N dependent pivot steps serves all G matrices.  G N <= 64;
+// every lane of the wavefront must call it; ok[g] is cleared when matrix g is not positive definite.
+template <int N, int G>
+__device__ __forceinline__ void spdInverseRowsGrouped(double* A, int gstride, int lane, int* ok) {
+  static_assert(N * G <= 64, "the groups must fit in one wavefront");
+  const int g0 = lane / N;
+  const bool on = g0 < G;
+  const int g = on ? g0 : 0, r = on ? lane - g0 * N : 0, src0 = g * N;
+  double* Ag = A + g * gstride;
+  double a[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = Ag[r + N * j];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double prow[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) prow[j] = __shfl(a[j], src0 + k);
+    const double p = prow[k];
+    if (on && r == k && !(p > 0.0)) ok[g] = 0;
+    const double ip = recipNewton(p);
+    const double aik = a[k];
+    const bool isk = r == k;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (j == k) continue;
+      const double akj = prow[j];
+      a[j] = isk ? akj * ip : a[j] - aik * akj * ip;
+    }
+    a[k] = isk ? ip : -aik * ip;
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) if (on) Ag[r + N * j] = a[j];
+}
+
 // C (m x n) (+)= alpha * X^T Y with X (k x m, ldx) and Y (k x n, ldy) column-major,
 // i.e. both operands contiguous along the contraction index: 2 x 2 register blocks,
 // 16-byte LDS reads (two k's per read): 0.5 LDS instruction per FMA instead of 2.

@@ -758,28 +758,34 @@ __global__ __launch_bounds__(64) void rnea_derivatives_kernel(const DevModel* __
 //   K3   un_integrate_kernel                    updatePrimal / updateDual
 // Stage i of instance b uses record b * (N + 1) + i of the (N + 1)-record arrays (record N stays unused and zero).
 
-// K9u: one wavefront per stage.  KKT matrix [[0 F]; [F^T Q]] in the ordering (lmd, gmm | a, q, v) with
-// F = [0 -I dt I; dt I 0 -I] (split_unkkt_matrix_inverter.hxx:37-80):
+// K9u: one wavefront per stage, three stages per workgroup.  KKT matrix [[0 F]; [F^T Q]] in the ordering
+// (lmd, gmm | a, q, v) with F = [0 -I dt I; dt I 0 -I] (split_unkkt_matrix_inverter.hxx:37-80):
 //   Q^-1, FQ = F Q^-1, S = FQ F^T, TL = -S^-1, TR = S^-1 FQ, BR = Q^-1 - FQ^T TR;
-// d = K^-1 [Fq Fv la lq lv], s_new = s - d (split_unbackward_correction.hxx:50-64).  Both inverses run in the registers
-// of the wavefront (spdInverseRows), the products go through LDS.
+// d = K^-1 [Fq Fv la lq lv], s_new = s - d (split_unbackward_correction.hxx:50-64).  The two inverses are chains of
+// dependent pivot steps that use 21 (14) lanes each: wavefront 0 runs them for the three stages of the workgroup at once in
+// its registers (spdInverseRowsGrouped), everything else is done by each wavefront for its own stage through LDS.
 template <int NV>
-__global__ __launch_bounds__(64) void unparnmpc_coarse_update_kernel(UnBuffers B) {
+__global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers B) {
   using L = UnLayout<NV>;
-  constexpr int NX = L::NX, NQ = L::NQ3, NK = 5 * NV;
-  __shared__ double sQ[NQ * NQ], sFQ[NX * NQ], sS[NX * NX], sTR[NX * NQ], sres[NK], st1[NX], sd[NK];
-  __shared__ int s_ok;
+  constexpr int NX = L::NX, NQ = L::NQ3, NK = 5 * NV, SPB = 3;
+  __shared__ double sQa[SPB][NQ * NQ], sFQa[SPB][NX * NQ], sSa[SPB][NX * NX], sTRa[SPB][NX * NQ], sresa[SPB][NK], st1a[SPB][NX], sda[SPB][NK];
+  __shared__ int s_ok[SPB];
   const UnProblem* __restrict__ P = B.prob;
   const int N = P->N;
   const double dt = P->dt;
-  const int lane = threadIdx.x;
-  const long unit = blockIdx.x;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long total = (long)P->batch * N;
+  long unit = (long)blockIdx.x * SPB + w;
+  const bool valid = unit < total;
+  if (!valid) unit = total - 1;
+  double* sQ = sQa[w]; double* sFQ = sFQa[w]; double* sS = sSa[w]; double* sTR = sTRa[w];
+  double* sres = sresa[w]; double* st1 = st1a[w]; double* sd = sda[w];
   const long b = unit / N;
   const int i = (int)(unit - b * N);
   const long rec = b * (N + 1) + i;
   const double* __restrict__ kk = B.kkt + unit * L::KKT;
   const double* __restrict__ aux = B.aux + (rec + 1) * L::AUX;       // aux_mat of the NEXT stage (none behind the last one)
-  if (lane == 0) s_ok = 1;
+  if (lane == 0) s_ok[w] = 1;
   // Q in the ordering (a, q, v) from the six upper blocks K1b stores, + aux_mat_next on the (q, v) block
   for (int e = lane; e < NQ * NQ; e += 64) {
     const int c = e / NQ, r = e - c * NQ;
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(64) void unparnmpc_coarse_update_kernel(UnBuffers B
   }
   if (lane < NK) sres[lane] = kk[L::K_FQ + lane];                     // [Fq Fv la lq lv] are contiguous in the kkt record
   __syncthreads();
-  spdInverseRows<NQ>(sQ, NQ, NQ, lane, &s_ok);
+  if (w == 0) spdInverseRowsGrouped<NQ, SPB>(&sQa[0][0], NQ * NQ, lane, s_ok);
   __syncthreads();
   for (int e = lane; e < NX * NQ; e += 64) {
     const int c = e / NX, r = e - c * NX;
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(64) void unparnmpc_coarse_update_kernel(UnBuffers B
     sS[e] = c < NV ? -sFQ[r + NX * (NV + c)] + dt * sFQ[r + NX * (2 * NV + c)] : dt * sFQ[r + NX * (c - NV)] - sFQ[r + NX * (NV + c)];
   }
   __syncthreads();
-  spdInverseRows<NX>(sS, NX, NX, lane, &s_ok);
+  if (w == 0) spdInverseRowsGrouped<NX, SPB>(&sSa[0][0], NX * NX, lane, s_ok);
   __syncthreads();
   for (int e = lane; e < NX * NQ; e += 64) {                          // TR = S^-1 FQ
     const int c = e / NX, r = e - c * NX;
@@ -817,14 +823,16 @@ __global__ __launch_bounds__(64) void unparnmpc_coarse_update_kernel(UnBuffers B
   }
   __syncthreads();
   double* __restrict__ ki = B.kinv + unit * L::KINV;
-  for (int e = lane; e < NX * NX; e += 64) ki[L::I_TL + e] = -sS[e];
-  for (int e = lane; e < NX * NQ; e += 64) ki[L::I_TR + e] = sTR[e];
+  if (valid) {
+    for (int e = lane; e < NX * NX; e += 64) ki[L::I_TL + e] = -sS[e];
+    for (int e = lane; e < NX * NQ; e += 64) ki[L::I_TR + e] = sTR[e];
+  }
   for (int e = lane; e < NQ * NX; e += 64) {                          // the (q, v) columns of BR = Q^-1 - FQ^T TR
     const int c = e / NQ, r = e - c * NQ;
     double acc = sQ[r + NQ * (NV + c)];
 #pragma unroll
     for (int k = 0; k < NX; ++k) acc -= sFQ[k + NX * r] * sTR[k + NX * (NV + c)];
-    ki[L::I_BRC + e] = acc;
+    if (valid) ki[L::I_BRC + e] = acc;
   }
   // d = K^-1 res:  t1 = TR l,  d_top = -S^-1 Fx + t1,  d_bot = TR^T Fx + Q^-1 l - FQ^T t1
   if (lane < NX) {
@@ -850,11 +858,11 @@ __global__ __launch_bounds__(64) void unparnmpc_coarse_update_kernel(UnBuffers B
   }
   __syncthreads();
   // s_new = s - d in the fields (lmd, gmm | a, q, v)
-  if (lane < NK) {
+  if (valid && lane < NK) {
     const int f = lane < NX ? L::S_LMD + lane : (lane < NX + NV ? L::S_A + (lane - NX) : L::S_Q + (lane - NX - NV));
     B.snew[rec * L::SOL + f] = B.sol[rec * L::SOL + f] - sd[lane];
   }
-  if (lane == 0 && !s_ok) atomicMax(&B.status[b], 1 + i);
+  if (valid && lane == 0 && !s_ok[w]) atomicMax(&B.status[b], 1 + i);
 }
 
 // S5u: 16 lanes per instance, lane r < NX owns row r of the costate pair (lmd, gmm).  Stage i:
@@ -1128,7 +1136,7 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
   const unsigned inst_blocks = (unsigned)((batch + 3) / 4);
   switch (phase) {
     case 0: hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0); break;
-    case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)(batch * N)), dim3(64), 0, st, B); break;
+    case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + 2) / 3)), dim3(192), 0, st, B); break;
     case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
     case 3: if (N > 1) hipLaunchKernelGGL((unparnmpc_backward_parallel_kernel<NV>), dim3((unsigned)((batch * (N - 1) + 1) / 2)), dim3(64), 0, st, B); break;
     case 4: hipLaunchKernelGGL((unparnmpc_forward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
