@@ -42,6 +42,11 @@ int main(int argc, char** argv) {
   parnmpc_solver.initBackwardCorrection(t);
   idocp::ocpbenchmarker::Convergence(parnmpc_solver, t, q, v, 100, false);
   idocp::ocpbenchmarker::CPUTime(parnmpc_solver, t, q, v, 1000, false);
+  if (argc > 2) {                      // solution I/O of the reference (unparnmpc_solver.cpp:286-327)
+    parnmpc_solver.saveSolution(std::string(argv[2]) + "_q.txt", "q");
+    parnmpc_solver.saveSolution(std::string(argv[2]) + "_u.txt", "u");
+    parnmpc_solver.printSolution("v");
+  }
   std::cout << "feasible: " << (parnmpc_solver.isCurrentSolutionFeasible() ? "yes" : "no")
             << ", q at the last stage: " << parnmpc_solver.getSolution(N - 1).q << std::endl;
   return 0;

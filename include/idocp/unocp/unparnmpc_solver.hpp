@@ -10,6 +10,7 @@
 #define IDOCP_UNPARNMPC_SOLVER_HPP_
 
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -75,6 +76,38 @@ class UnParNMPCSolver {
     check(idocp_unocp_is_current_solution_feasible(h_, &ok, &where));
     if (!ok) std::cout << "INFEASIBLE at time stage " << where << std::endl;
     return ok != 0;
+  }
+
+  // UnParNMPCSolver::printSolution / saveSolution (unparnmpc_solver.cpp:243-327): the stage-wise solution on stdout / as a text file, one stage per
+  // line.  "end-effector" needs frame kinematics of arbitrary frames, which the HIP path does not carry.
+  void printSolution(const std::string& name = "all", const std::vector<int> frames = {}) const {
+    (void)frames;
+    if (name == "end-effector") { std::cerr << "printSolution(\"end-effector\") is not supported by the HIP path" << std::endl; return; }
+    const char* fields[4] = {"q", "v", "a", "u"};
+    if (name == "all") {
+      std::vector<std::vector<Eigen::VectorXd>> all;
+      for (const char* f : fields) all.push_back(getSolution(f));
+      for (size_t i = 0; i < all[0].size(); ++i)
+        for (int f = 0; f < 4; ++f)
+          if (i < all[f].size()) std::cout << fields[f] << "[" << i << "] = " << all[f][i] << std::endl;
+      return;
+    }
+    for (const char* f : fields) {
+      if (name != f) continue;
+      const std::vector<Eigen::VectorXd> sol = getSolution(f);
+      for (size_t i = 0; i < sol.size(); ++i) std::cout << f << "[" << i << "] = " << sol[i] << std::endl;
+    }
+  }
+  void saveSolution(const std::string& path_to_file, const std::string& name) const {
+    std::ofstream file(path_to_file);
+    if (name == "q" || name == "v" || name == "a" || name == "u") {
+      const std::vector<Eigen::VectorXd> sol = getSolution(name);
+      for (const Eigen::VectorXd& x : sol) {
+        for (int j = 0; j < (int)x.size(); ++j) file << x[j] << " ";
+        file << "\n";
+      }
+    }
+    file.close();
   }
 
   double KKTError() {

@@ -80,7 +80,9 @@ def test_iiwa14_unparnmpc_benchmark_example_matches_oracle():
     (idocp::UnParNMPCSolver): the printed KKT errors follow the oracle's iteration and reach its floor."""
     from helpers import OracleUnParNMPC, iiwa14_model, unocp_problem
     build_examples()
-    r = subprocess.run([os.path.join(ROOT, "examples", "iiwa14_unparnmpc_benchmark"), IIWA_URDF], capture_output=True, text=True,
+    out = os.path.join(ROOT, "gpurun_out", "unparnmpc_solution")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    r = subprocess.run([os.path.join(ROOT, "examples", "iiwa14_unparnmpc_benchmark"), IIWA_URDF, out], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     init, its = kkt_errors(r.stdout)
@@ -98,6 +100,13 @@ def test_iiwa14_unparnmpc_benchmark_example_matches_oracle():
         e = o.kkt_error(0.0, q, v)
         assert abs(its[k] - e) < 1e-5 * e, (k, its[k], e)
     assert its[-1] < 1e-6
+    # saveSolution / printSolution (unparnmpc_solver.cpp:243-327): N lines of dimq / dimu numbers, the converged trajectory
+    for _ in range(97):
+        assert o.update(0.0, q, v) == 0
+    Q, U = np.loadtxt(out + "_q.txt"), np.loadtxt(out + "_u.txt")
+    assert Q.shape == (20, m.nv) and U.shape == (20, m.nv)
+    assert np.abs(Q - o.get("q")).max() < 1e-4 and np.abs(U - o.get("u")).max() < 1e-2      # 6 significant digits in the file
+    assert "v[19] = " in r.stdout
 
 
 def test_anymal_trotting_example_matches_oracle():
