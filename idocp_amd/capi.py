@@ -125,6 +125,8 @@ def _proto(lib):
         ("idocp_unocp_dimc", [vp]),
         ("idocp_unocp_is_current_solution_feasible", [vp, c_int_p, c_int_p]),
         ("idocp_unocp_launch_linearize", [vp, cd, vp, vp]),
+        ("idocp_unocp_clear_line_search_filter", [vp]),
+        ("idocp_unocp_line_search_eval", [vp, c_double_p, c_double_p, c_double_p]),
         ("idocp_unparnmpc_init_backward_correction", [vp, cd]),
         ("idocp_unparnmpc_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
         ("idocp_unparnmpc_update_solution_device", [vp, cd, vp, vp]),

@@ -12,6 +12,7 @@
 
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "host_util.hpp"
@@ -79,6 +80,8 @@ struct idocp_unocp {
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr;   // staging for host-pointer entry points
   bool has_direction = false;
   int bwd = 0;                  // 1: UnParNMPC handle (backward-Euler stages, idocp_unparnmpc_*)
+  // filter line search (LineSearchFilter, src/line_search/line_search_filter.cpp): one filter per instance
+  std::vector<std::vector<std::pair<double, double>>> filters;
 };
 
 namespace {
@@ -190,6 +193,10 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   if ((rc = allocBuf(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
   if ((rc = allocBuf(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
   B.status = reinterpret_cast<int*>(tmp);
+  if ((rc = allocBuf(h, &B.ls_alpha, (size_t)batch))) return fail(rc);
+  if ((rc = allocBuf(h, &B.ls_stage, nrec1 * 2))) return fail(rc);
+  if ((rc = allocBuf(h, &B.ls_out, (size_t)batch * 2))) return fail(rc);
+  h->filters.assign(batch, {});
   if (bwd) {
     if ((rc = allocBuf(h, &B.kinv, nrec0 * L7::KINV))) return fail(rc);
     if ((rc = allocBuf(h, &B.snew, nrec1 * L7::SOL))) return fail(rc);
@@ -275,6 +282,58 @@ int idocp_unocp_init_constraints(idocp_unocp_t* h) {
   return IDOCP_OK;
 }
 
+// UnLineSearch::computeStepSize (include/idocp/line_search/unline_search.hpp:62-92) for every instance of the batch: the
+// trial iterates are evaluated on the device (un_line_search_kernel), the filter logic (line_search_filter.cpp:33-63,
+// defaults line_search_filter.hpp:16-17, line_search.hpp:25-26) runs here.  On return B.step holds the accepted primal
+// step of every instance.  d_q, d_v: the measured state of the update (device).
+static int lineSearchEval(idocp_unocp_t* h, const std::vector<double>& alpha, const double* d_q, const double* d_v, std::vector<double>& out) {
+  HIP_TRY(hipMemcpyAsync(h->B.ls_alpha, alpha.data(), sizeof(double) * h->batch, hipMemcpyHostToDevice, h->stream));
+  UnLaunch<7>::lineSearchEval(h->B, h->batch, h->N, h->bwd != 0, d_q, d_v, h->stream);
+  HIP_TRY(hipGetLastError());
+  out.resize((size_t)h->batch * 2);
+  HIP_TRY(hipMemcpyAsync(out.data(), h->B.ls_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+static int runLineSearch(idocp_unocp_t* h, const double* d_q, const double* d_v) {
+  const double cost_rate = 0.005, con_rate = 0.005, reduction = 0.75, min_step = 0.05;
+  const int B = h->batch;
+  auto accepted = [](const std::vector<std::pair<double, double>>& f, double c, double v) {
+    for (const auto& p : f) if (c >= p.first && v >= p.second) return false;
+    return true;
+  };
+  auto augment = [&](std::vector<std::pair<double, double>>& f, double c, double v) {
+    for (auto it = f.begin(); it != f.end();) { if (c <= it->first && v <= it->second) it = f.erase(it); else ++it; }
+    f.push_back({c - cost_rate * v, (1 - con_rate) * v});
+  };
+  std::vector<double> step((size_t)B * 2), alpha(B, 0.0), cv;
+  int rc;
+  bool any_empty = false;
+  for (int b = 0; b < B; ++b) any_empty = any_empty || h->filters[b].empty();
+  if (any_empty) {                                  // "if filter is empty, augment the current solution to the filter"
+    if ((rc = lineSearchEval(h, alpha, d_q, d_v, cv))) return rc;
+    for (int b = 0; b < B; ++b) if (h->filters[b].empty()) augment(h->filters[b], cv[2 * b], cv[2 * b + 1]);
+  }
+  HIP_TRY(hipMemcpyAsync(step.data(), h->B.step, sizeof(double) * step.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<char> done(B, 0);
+  int open = 0;
+  for (int b = 0; b < B; ++b) { alpha[b] = step[2 * b]; if (!(alpha[b] > min_step)) done[b] = 1; else ++open; }
+  while (open > 0) {
+    if ((rc = lineSearchEval(h, alpha, d_q, d_v, cv))) return rc;
+    for (int b = 0; b < B; ++b) {
+      if (done[b]) continue;
+      if (accepted(h->filters[b], cv[2 * b], cv[2 * b + 1])) { augment(h->filters[b], cv[2 * b], cv[2 * b + 1]); done[b] = 1; --open; continue; }
+      alpha[b] *= reduction;
+      if (!(alpha[b] > min_step)) { done[b] = 1; --open; }
+    }
+  }
+  for (int b = 0; b < B; ++b) step[2 * b] = alpha[b] > min_step ? alpha[b] : min_step;
+  HIP_TRY(hipMemcpyAsync(h->B.step, step.data(), sizeof(double) * step.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));         // `step` is a stack temporary
+  return IDOCP_OK;
+}
+
 static int wrongKind(const idocp_unocp_t* h, int want_bwd) {
   if (h->bwd == want_bwd) return 0;
   set_last_error(want_bwd ? "this handle is an UnOCPSolver (idocp_unocp_create): use idocp_unocp_*"
@@ -317,13 +376,45 @@ void* idocp_unocp_stream(idocp_unocp_t* h) { return h ? (void*)h->stream : nullp
 
 int idocp_unocp_update_solution(idocp_unocp_t* h, double t, const double* q, const double* v, int line_search) {
   if (!h || !q || !v) return IDOCP_E_ARG;
-  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  if (wrongKind(h, 0)) return IDOCP_E_ARG;
   int rc = setDevice(h); if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * h->model.nq, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * h->model.nv, hipMemcpyHostToDevice, h->stream));
-  rc = idocp_unocp_update_solution_device(h, t, h->d_q0, h->d_v0);
-  if (rc) return rc;
-  return statusOf(h);
+  if (!line_search) {
+    rc = idocp_unocp_update_solution_device(h, t, h->d_q0, h->d_v0);
+    if (rc) return rc;
+    return statusOf(h);
+  }
+  // unocp_solver.cpp:116-120: the filter line search sits between the direction and the update
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  UnLaunch<7>::linearize(h->B, h->batch, h->N, h->stream);
+  UnLaunch<7>::riccati(h->B, h->batch, h->N, h->d_q0, h->d_v0, h->stream);
+  UnLaunch<7>::expand(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  if ((rc = statusOf(h))) return rc;
+  if ((rc = runLineSearch(h, h->d_q0, h->d_v0))) return rc;
+  UnLaunch<7>::integrate(h->B, h->batch, h->N, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->has_direction = true;
+  return IDOCP_OK;
+}
+
+// UnOCPSolver / UnParNMPCSolver::clearLineSearchFilter (unocp_solver.cpp:185-187)
+int idocp_unocp_clear_line_search_filter(idocp_unocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  for (auto& f : h->filters) f.clear();
+  return IDOCP_OK;
+}
+// (total cost, total constraint violation) of s + alpha[b] d for every instance (UnLineSearch::computeCostAndViolation;
+// alpha = 0: the iterate itself), with the measured state of the last host-pointer update / residual call
+int idocp_unocp_line_search_eval(idocp_unocp_t* h, const double* alpha, double* cost, double* violation) {
+  if (!h || !alpha || !cost || !violation) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  std::vector<double> a(alpha, alpha + h->batch), cv;
+  if ((rc = lineSearchEval(h, a, h->d_q0, h->d_v0, cv))) return rc;
+  for (int b = 0; b < h->batch; ++b) { cost[b] = cv[2 * b]; violation[b] = cv[2 * b + 1]; }
+  return IDOCP_OK;
 }
 
 int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q, const double* d_v) {
@@ -420,11 +511,20 @@ int idocp_unparnmpc_update_solution_device(idocp_unocp_t* h, double t, const dou
 int idocp_unparnmpc_update_solution(idocp_unocp_t* h, double t, const double* q, const double* v, int line_search) {
   if (!h || !q || !v) return IDOCP_E_ARG;
   if (wrongKind(h, 1)) return IDOCP_E_ARG;
-  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
   int rc = setDevice(h); if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * h->model.nq, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * h->model.nv, hipMemcpyHostToDevice, h->stream));
-  if ((rc = idocp_unparnmpc_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  if (!line_search) {
+    if ((rc = idocp_unparnmpc_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  } else {                                           // unparnmpc_solver.cpp:81-86
+    HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+    for (int phase = 0; phase <= 5; ++phase) UnLaunch<7>::parnmpcPhase(phase, h->B, h->batch, h->N, h->d_q0, h->d_v0, h->stream);
+    HIP_TRY(hipGetLastError());
+    if ((rc = runLineSearch(h, h->d_q0, h->d_v0))) return rc;
+    UnLaunch<7>::parnmpcPhase(6, h->B, h->batch, h->N, h->d_q0, h->d_v0, h->stream);
+    HIP_TRY(hipGetLastError());
+    h->has_direction = true;
+  }
   std::vector<int> st(h->batch);
   HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

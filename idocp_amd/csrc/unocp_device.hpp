@@ -81,6 +81,10 @@ struct UnBuffers {
   double* err_stage;   // [batch][N+1]   squared KKT residual per stage
   double* err;         // [batch]
   int* status;         // [batch]  0 ok, 1+stage on a failed Cholesky
+  // filter line search (UnLineSearch): trial step per instance, (cost, violation) per stage and per instance
+  double* ls_alpha;    // [batch]
+  double* ls_stage;    // [batch][N+1][2]
+  double* ls_out;      // [batch][2]
   // UnParNMPC only (null otherwise)
   double* kinv;        // [batch][N][KINV]
   double* snew;        // [batch][N+1][SOL]  coarse / corrected iterate s_new (lmd, gmm, q, v, a)

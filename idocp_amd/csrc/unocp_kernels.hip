@@ -1068,6 +1068,121 @@ __global__ void unparnmpc_init_aux_kernel(UnBuffers B) {
   B.aux[rec * L::AUX + e] = (r == c) ? (r < NV ? P->qf_weight[r] : P->vf_weight[r - NV]) : 0.0;
 }
 
+
+// ============================================================= line search ====
+// UnLineSearch::computeCostAndViolation (src/line_search/unline_search.cpp:55-121) at the trial iterate s + alpha d
+// (computeTrySolution, unline_search.hpp:125-133; alpha = ls_alpha[instance], 0 = the iterate itself): per stage
+//   cost      = stage cost (configuration_space_cost.cpp:241-256) + dt * barrier(slack + alpha dslack) (pdipm.hxx:84-87)
+//               [+ terminal cost: of stage N for UnOCP, of the last stage for UnParNMPC]
+//   violation = |state-equation residual|_1 + dt |ID - u|_1 + dt |g(x_try) + slack|_1
+// (split_unocp.hxx:177-217, split_unparnmpc.hxx:179-227).  Same lane mapping as K1 (the inverse dynamics of the trial point
+// needs the chain recursion; its tangent outputs are discarded); lane (kind, k) adds the terms of q_k / v_k / (a_k, u_k).
+template <int NV, bool BWD>
+__global__ __launch_bounds__(64) void un_line_search_kernel(UnBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
+  using L = UnLayout<NV>;
+  constexpr int LPS = 3 * NV;
+  constexpr int SPW = 64 / LPS;
+  __shared__ double s_x[SPW][4][NV];          // trial q, v, a, u
+  __shared__ double s_cs[SPW][NV][2];
+  __shared__ double s_tau[SPW][NV];
+  __shared__ double s_dcol[SPW][LPS][NV];     // discarded tangent columns
+  __shared__ double s_sum[SPW][LPS][2];
+  __shared__ double s_dummy[NV];
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const double dt = P->dt;
+  const int lane = threadIdx.x;
+  const int g0 = lane / LPS;
+  const int g = g0 < SPW ? g0 : SPW - 1;
+  const int seed = lane - g0 * LPS;
+  const int kind = (g0 < SPW) ? seed / NV : 0;
+  const int k = (g0 < SPW) ? seed - kind * NV : 0;
+  const long total = (long)P->batch * N;
+  long unit = (long)blockIdx.x * SPW + g;
+  const bool active = (g0 < SPW) && (unit < total);
+  if (unit >= total) unit = total - 1;
+  const long b = unit / N;
+  const int i = (int)(unit - b * N);
+  const long rec = b * (N + 1) + i;
+  const double al = B.ls_alpha[b];
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  const double* __restrict__ dd = B.dir + rec * L::SOL;
+  const double* __restrict__ slack = B.slack + unit * L::CON;
+  if (g0 < SPW && seed < NV) {
+    const double qt = s[L::S_Q + seed] + al * dd[L::S_Q + seed];
+    s_x[g][0][seed] = qt;
+    s_x[g][1][seed] = s[L::S_V + seed] + al * dd[L::S_V + seed];
+    s_x[g][2][seed] = s[L::S_A + seed] + al * dd[L::S_A + seed];
+    s_x[g][3][seed] = s[L::S_U + seed] + al * dd[L::S_U + seed];
+    double sj, cj;
+    sincos(qt, &sj, &cj);
+    s_cs[g][seed][0] = cj; s_cs[g][seed][1] = sj;
+  }
+  WAVE_SYNC();
+  rneaChain<NV>(B.model, &s_cs[g][0][0], &s_x[g][1][0], &s_x[g][2][0], kind, k, (g0 < SPW) && seed == 0, &s_tau[g][0],
+                (g0 < SPW) ? &s_dcol[g][seed][0] : &s_dummy[0]);
+  WAVE_SYNC();
+  double cost = 0.0, viol = 0.0;
+  const double qt = s_x[g][0][k], vt = s_x[g][1][k], at = s_x[g][2][k], ut = s_x[g][3][k];
+  const bool term = BWD ? (i == N - 1) : false;
+  // the neighbour of the state equation at ITS trial point (the measured state is fixed)
+  double qo, vo;
+  if (BWD) {
+    if (i > 0) { qo = (s - L::SOL)[L::S_Q + k] + al * (dd - L::SOL)[L::S_Q + k]; vo = (s - L::SOL)[L::S_V + k] + al * (dd - L::SOL)[L::S_V + k]; }
+    else { qo = q0[b * NV + k]; vo = v0[b * NV + k]; }
+  } else {
+    qo = (s + L::SOL)[L::S_Q + k] + al * (dd + L::SOL)[L::S_Q + k]; vo = (s + L::SOL)[L::S_V + k] + al * (dd + L::SOL)[L::S_V + k];
+  }
+  double x_cur, x_try, dx;
+  if (kind == 0) {
+    x_cur = s[L::S_Q + k]; x_try = qt; dx = dd[L::S_Q + k];
+    cost += 0.5 * dt * P->q_weight[k] * (qt - P->q_ref[k]) * (qt - P->q_ref[k]);
+    if (term) cost += 0.5 * P->qf_weight[k] * (qt - P->q_ref[k]) * (qt - P->q_ref[k]);
+    if (!BWD && i == N - 1) cost += 0.5 * P->qf_weight[k] * (qo - P->q_ref[k]) * (qo - P->q_ref[k]);     // TerminalOCP::terminalCost of stage N
+    viol += fabs(BWD ? qo - qt + dt * vt : qt - qo + dt * vt);
+  } else if (kind == 1) {
+    x_cur = s[L::S_V + k]; x_try = vt; dx = dd[L::S_V + k];
+    cost += 0.5 * dt * P->v_weight[k] * (vt - P->v_ref[k]) * (vt - P->v_ref[k]);
+    if (term) cost += 0.5 * P->vf_weight[k] * (vt - P->v_ref[k]) * (vt - P->v_ref[k]);
+    if (!BWD && i == N - 1) cost += 0.5 * P->vf_weight[k] * (vo - P->v_ref[k]) * (vo - P->v_ref[k]);
+    viol += fabs(BWD ? vo - vt + dt * at : vt + dt * at - vo);
+    viol += dt * fabs(s_tau[g][k] - ut);
+  } else {
+    x_cur = s[L::S_U + k]; x_try = ut; dx = dd[L::S_U + k];
+    cost += 0.5 * dt * (P->a_weight[k] * at * at + P->u_weight[k] * (ut - P->u_ref[k]) * (ut - P->u_ref[k]));
+  }
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = 2 * kind + cc;
+    if (!rowValid(P, c, i)) continue;
+    const double sgn = (cc == 0) ? -1.0 : 1.0;
+    const double lim = limitOf(P, c, k), sl = slack[c * NV + k];
+    const double dslack = -sgn * dx - (sgn * (x_cur - lim) + sl);
+    cost -= dt * P->barrier * log(sl + al * dslack);
+    viol += dt * fabs(sgn * (x_try - lim) + sl);
+  }
+  if (g0 < SPW) { s_sum[g][seed][0] = active ? cost : 0.0; s_sum[g][seed][1] = active ? viol : 0.0; }
+  WAVE_SYNC();
+  if (active && seed == 0) {
+    double c0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) { c0 += s_sum[g][j][0]; v1 += s_sum[g][j][1]; }
+    B.ls_stage[rec * 2] = c0; B.ls_stage[rec * 2 + 1] = v1;
+  }
+}
+
+// totalCosts / totalViolations (unline_search.hpp:143-149): one wavefront per instance
+__global__ __launch_bounds__(64) void un_line_search_reduce_kernel(UnBuffers B) {
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const long b = blockIdx.x;
+  double c = 0.0, v = 0.0;
+  for (int i = threadIdx.x; i < N; i += 64) { c += B.ls_stage[(b * (N + 1) + i) * 2]; v += B.ls_stage[(b * (N + 1) + i) * 2 + 1]; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { c += __shfl_xor(c, off); v += __shfl_xor(v, off); }
+  if (threadIdx.x == 0) { B.ls_out[b * 2] = c; B.ls_out[b * 2 + 1] = v; }
+}
+
 // ------------------------------------------------------------ launchers ----
 template <int NV>
 void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t st) {
@@ -1157,6 +1272,15 @@ template <int NV>
 void UnLaunch<NV>::parnmpcInitAux(const UnBuffers& B, long batch, int N, hipStream_t st) {
   const long total = batch * (N + 1) * 4 * NV * NV;
   hipLaunchKernelGGL((unparnmpc_init_aux_kernel<NV>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B);
+}
+
+template <int NV>
+void UnLaunch<NV>::lineSearchEval(const UnBuffers& B, long batch, int N, bool bwd, const double* q0, const double* v0, hipStream_t st) {
+  constexpr int SPW = 64 / (3 * NV);
+  const unsigned blocks = (unsigned)((batch * N + SPW - 1) / SPW);
+  if (bwd) hipLaunchKernelGGL((un_line_search_kernel<NV, true>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
+  else hipLaunchKernelGGL((un_line_search_kernel<NV, false>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
+  hipLaunchKernelGGL(un_line_search_reduce_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
 }
 
 template struct UnLaunch<7>;

@@ -21,6 +21,8 @@ struct UnLaunch {
   static void parnmpcPhase(int phase, const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);
   static void parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st);
   static void parnmpcInitAux(const UnBuffers& B, long batch, int N, hipStream_t st);
+  // UnLineSearch::computeCostAndViolation at the trial steps B.ls_alpha -> B.ls_out
+  static void lineSearchEval(const UnBuffers& B, long batch, int N, bool bwd, const double* q0, const double* v0, hipStream_t st);
   static void rneaDerivatives(const DevModel* m, int n, const double* q, const double* v, const double* a, double* tau,
                               double* dq, double* dv, double* da, hipStream_t st);
 };

@@ -86,7 +86,7 @@ class UnOCPSolver {
   }
 
   void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_unocp_set_solution(h_, name.c_str(), value.data())); }
-  void clearLineSearchFilter() {}
+  void clearLineSearchFilter() { check(idocp_unocp_clear_line_search_filter(h_)); }
 
   // UnOCPSolver::isCurrentSolutionFeasible (unocp_solver.cpp:228-237)
   bool isCurrentSolutionFeasible() {

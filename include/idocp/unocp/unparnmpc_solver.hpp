@@ -69,7 +69,7 @@ class UnParNMPCSolver {
   void getStateFeedbackGain(const int, Eigen::MatrixXd&, Eigen::MatrixXd&) const {}
 
   void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_unocp_set_solution(h_, name.c_str(), value.data())); }
-  void clearLineSearchFilter() {}
+  void clearLineSearchFilter() { check(idocp_unocp_clear_line_search_filter(h_)); }
 
   bool isCurrentSolutionFeasible() {
     int ok = 0, where = -1;

@@ -235,6 +235,16 @@ int idocp_unocp_dimc(const idocp_unocp_t* h);
  * NULL) = first offending stage or -1. */
 int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, int* where);
 
+/* Filter line search of the two fixed-base solvers (UnLineSearch, include/idocp/line_search/unline_search.hpp:62-92;
+ * LineSearchFilter, src/line_search/line_search_filter.cpp): idocp_unocp_update_solution / idocp_unparnmpc_update_solution
+ * with line_search != 0 evaluate the trial iterates on the device and keep one filter per instance.
+ * UnOCPSolver / UnParNMPCSolver::clearLineSearchFilter: */
+int idocp_unocp_clear_line_search_filter(idocp_unocp_t* h);
+/* UnLineSearch::computeCostAndViolation of s + alpha[b] d for every instance (alpha = 0: the iterate itself), with the
+ * measured state of the last host-pointer update / residual call: cost[batch], violation[batch]. */
+int idocp_unocp_line_search_eval(idocp_unocp_t* h, const double* alpha, double* cost,
+                                 double* violation);
+
 /* ---- UnParNMPCSolver (include/idocp/unocp/unparnmpc_solver.hpp:31-189, src/unocp/unparnmpc_solver.cpp) ----
  * The stage-parallel solver of the fixed-base problem: N backward-Euler stages (stage i at t + (i+1) dt, created with
  * constraint time step i + 1, the last one terminal), per-stage KKT inverse, coarse update and the four correction

@@ -172,6 +172,17 @@ int oracle_unocp_update_solution(void* h, double t, const double* q, const doubl
   try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); } catch (...) { return 1; }
   return 0;
 }
+// updateSolution(t, q, v, line_search = true) and the pieces of UnLineSearch
+int oracle_unocp_update_solution_ls(void* h, double t, const double* q, const double* v) {
+  UnOCPSolver* s = static_cast<UnOCPSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()), true); } catch (...) { return 1; }
+  return 0;
+}
+void oracle_unocp_clear_line_search_filter(void* h) { static_cast<UnOCPSolver*>(h)->line_search.filter.clear(); }
+int oracle_unocp_cost_and_violation(void* h, double alpha, double* out) {
+  const auto cv = static_cast<UnOCPSolver*>(h)->costAndViolation(alpha);
+  out[0] = cv.first; out[1] = cv.second; return 0;
+}
 // staged execution (kernel-level parity): 0 linearize, 1 backward+forward Riccati, 2 direction, 3 integrate
 int oracle_unocp_stage(void* h, int what, double t, const double* q, const double* v) {
   UnOCPSolver* s = static_cast<UnOCPSolver*>(h);
@@ -264,6 +275,17 @@ int oracle_unparnmpc_update_solution(void* h, double t, const double* q, const d
   UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
   try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); } catch (...) { return 1; }
   return 0;
+}
+int oracle_unparnmpc_update_solution_ls(void* h, double t, const double* q, const double* v) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()), true); } catch (...) { return 1; }
+  return 0;
+}
+void oracle_unparnmpc_clear_line_search_filter(void* h) { static_cast<UnParNMPCSolver*>(h)->line_search.filter.clear(); }
+int oracle_unparnmpc_cost_and_violation(void* h, double alpha, const double* q, const double* v, double* out) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const auto cv = s->costAndViolation(alpha, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+  out[0] = cv.first; out[1] = cv.second; return 0;
 }
 // staged execution: 0 coarse update, 1 backward serial, 2 backward parallel, 3 forward serial, 4 forward parallel
 // (+ direction and step sizes), 5 integrate

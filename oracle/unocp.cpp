@@ -2,6 +2,7 @@
 #include "unocp.hpp"
 
 #include <chrono>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 
@@ -350,6 +351,49 @@ static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {
   return m;
 }
 
+// Pieces of SplitUnOCP / SplitUnParNMPC::stageCost and constraintViolation (split_unocp.hxx:177-217,
+// split_unparnmpc.hxx:179-227) at the trial point s + alpha d of one stage: the configuration-space cost
+// (configuration_space_cost.cpp:241-256), the barrier on slack + alpha dslack (pdipm.hxx:84-87), dt |ID|_1 and
+// dt |g(x_try) + slack|_1 with the CURRENT slack.
+struct TrialPoint { Mat q, v, a, u; };
+static TrialPoint trialPoint(const SplitSolution& s, const SplitDirection& d, double alpha) {
+  return {s.q + alpha * d.dq, s.v + alpha * d.dv, s.a + alpha * d.da, s.u + alpha * d.du};
+}
+static double trialStageCost(const idocp_cost_t& c, const Constraints& cs, const ConstraintsData& cd, int level, double dt,
+                             const TrialPoint& x, double alpha, bool terminal_cost) {
+  const int nv = x.v.size();
+  double l = 0, lf = 0;
+  for (int r = 0; r < nv; ++r) {
+    l += c.q_weight[r] * (x.q[r] - c.q_ref[r]) * (x.q[r] - c.q_ref[r]) + c.v_weight[r] * (x.v[r] - c.v_ref[r]) * (x.v[r] - c.v_ref[r]) +
+         c.a_weight[r] * x.a[r] * x.a[r] + c.u_weight[r] * (x.u[r] - c.u_ref[r]) * (x.u[r] - c.u_ref[r]);
+    lf += c.qf_weight[r] * (x.q[r] - c.q_ref[r]) * (x.q[r] - c.q_ref[r]) + c.vf_weight[r] * (x.v[r] - c.v_ref[r]) * (x.v[r] - c.v_ref[r]);
+  }
+  double cost = 0.5 * dt * l + (terminal_cost ? 0.5 * lf : 0.0);
+  for (size_t j = 0; j < cs.components.size(); ++j) {
+    if (!cs.valid(cs.components[j], level)) continue;
+    const ConstraintComponentData& data = cd.data[j];
+    double sum = 0;
+    for (int r = 0; r < data.slack.size(); ++r) sum += std::log(data.slack[r] + alpha * data.dslack[r]);
+    cost += dt * (-cs.barrier * sum);
+  }
+  return cost;
+}
+static double trialConstraintViolation(Robot& robot, const Constraints& cs, const ConstraintsData& cd, int level, double dt,
+                                       const TrialPoint& x) {
+  Mat ID(x.v.size());
+  robot.RNEA(x.q, x.v, x.a, ID);
+  double viol = 0;
+  for (int r = 0; r < ID.size(); ++r) viol += dt * std::fabs(ID[r] - x.u[r]);
+  for (size_t j = 0; j < cs.components.size(); ++j) {
+    const JointLimit& jl = cs.components[j];
+    if (!cs.valid(jl, level)) continue;
+    const Mat& var = jl.var == JointLimit::Q ? x.q : (jl.var == JointLimit::V ? x.v : x.u);
+    const int n = jl.lim.size(), off = var.size() - n;
+    for (int r = 0; r < n; ++r) viol += dt * std::fabs(jl.sign * (var[off + r] - jl.lim[r]) + cd.data[j].slack[r]);
+  }
+  return viol;
+}
+
 // second parallel loop of UnOCPSolver::updateSolution (unocp_solver.cpp:103-115)
 void UnOCPSolver::computeDirection() {
   double pmin = 1, dmin = 1;
@@ -413,13 +457,34 @@ void UnOCPSolver::integrate() {
   }
 }
 
-void UnOCPSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+// UnLineSearch::computeCostAndViolation(UnOCP&, ...) (unline_search.cpp:55-82): forward-Euler residual against the trial
+// point of the next stage, terminal cost of stage N
+std::pair<double, double> UnOCPSolver::costAndViolation(double alpha) const {
+  Robot rb = robot;
+  double cost_sum = 0, viol = 0;
+  for (int i = 0; i < N_; ++i) {
+    const TrialPoint x = trialPoint(s[i], d[i], alpha);
+    const Mat qn = s[i + 1].q + alpha * d[i + 1].dq, vn = s[i + 1].v + alpha * d[i + 1].dv;
+    cost_sum += trialStageCost(cost, constraints, ocp[i].cdata, i, dt_, x, alpha, false);
+    for (int r = 0; r < rb.dimv(); ++r) viol += std::fabs(x.q[r] - qn[r] + dt_ * x.v[r]) + std::fabs(x.v[r] + dt_ * x.a[r] - vn[r]);
+    viol += trialConstraintViolation(rb, constraints, ocp[i].cdata, i, dt_, x);
+  }
+  const Mat qN = s[N_].q + alpha * d[N_].dq, vN = s[N_].v + alpha * d[N_].dv;
+  double lf = 0;
+  for (int r = 0; r < rb.dimv(); ++r)
+    lf += cost.qf_weight[r] * (qN[r] - cost.q_ref[r]) * (qN[r] - cost.q_ref[r]) + cost.vf_weight[r] * (vN[r] - cost.v_ref[r]) * (vN[r] - cost.v_ref[r]);
+  return {cost_sum + 0.5 * lf, viol};
+}
+
+void UnOCPSolver::updateSolution(double t, const Mat& q, const Mat& v, bool use_line_search) {
   linearizeOCP(t, q);
   auto t0 = std::chrono::steady_clock::now();
   backwardRiccatiRecursion();
   forwardRiccatiRecursion(q, v);
   riccati_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   computeDirection();
+  if (use_line_search)            // unocp_solver.cpp:116-120
+    primal_step_size = line_search.computeStepSize([&](double a) { return costAndViolation(a); }, primal_step_size);
   integrate();
 }
 
@@ -751,12 +816,29 @@ void UnParNMPCSolver::integrate() {
   }
 }
 
-void UnParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+// UnLineSearch::computeCostAndViolation(UnParNMPC&, ...) (unline_search.cpp:85-121): backward-Euler residual against the
+// trial point of the previous stage (the measured state for stage 0), terminal cost on the last stage
+std::pair<double, double> UnParNMPCSolver::costAndViolation(double alpha, const Mat& q, const Mat& v) const {
+  Robot rb = robot;
+  double cost_sum = 0, viol = 0;
+  for (int i = 0; i < N_; ++i) {
+    const TrialPoint x = trialPoint(s[i], d[i], alpha);
+    const Mat qp = i == 0 ? q : s[i - 1].q + alpha * d[i - 1].dq, vp = i == 0 ? v : s[i - 1].v + alpha * d[i - 1].dv;
+    cost_sum += trialStageCost(cost, constraints, ocp[i].cdata, i + 1, dt_, x, alpha, i == N_ - 1);
+    for (int r = 0; r < rb.dimv(); ++r) viol += std::fabs(qp[r] - x.q[r] + dt_ * x.v[r]) + std::fabs(vp[r] - x.v[r] + dt_ * x.a[r]);
+    viol += trialConstraintViolation(rb, constraints, ocp[i].cdata, i + 1, dt_, x);
+  }
+  return {cost_sum, viol};
+}
+
+void UnParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v, bool use_line_search) {
   coarseUpdate(t, q, v);
   backwardCorrectionSerial();
   backwardCorrectionParallel();
   forwardCorrectionSerial();
   forwardCorrectionParallel();
+  if (use_line_search)            // unparnmpc_solver.cpp:81-86
+    primal_step_size = line_search.computeStepSize([&](double a) { return costAndViolation(a, q, v); }, primal_step_size);
   integrate();
 }
 

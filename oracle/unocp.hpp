@@ -8,6 +8,7 @@
 #define ORACLE_UNOCP_HPP_
 
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "idocp_hip.h"
@@ -87,6 +88,37 @@ struct SplitRiccatiFactorization {
   explicit SplitRiccatiFactorization(int nv) : Pqq(nv, nv), Pqv(nv, nv), Pvq(nv, nv), Pvv(nv, nv), sq(nv), sv(nv) {}
 };
 
+// LineSearchFilter (src/line_search/line_search_filter.cpp:33-63) with the defaults of line_search_filter.hpp:16-17 and the
+// step-size schedule of UnLineSearch::computeStepSize (include/idocp/line_search/unline_search.hpp:62-92, defaults
+// line_search.hpp:25-26)
+struct LineSearchFilterC {
+  std::vector<std::pair<double, double>> filter;
+  double cost_reduction_rate = 0.005, constraints_reduction_rate = 0.005;
+  double step_size_reduction_rate = 0.75, min_step_size = 0.05;
+  bool isAccepted(double cost, double violation) const {
+    for (const auto& p : filter) if (cost >= p.first && violation >= p.second) return false;
+    return true;
+  }
+  void augment(double cost, double violation) {
+    for (auto it = filter.begin(); it != filter.end();) {
+      if (cost <= it->first && violation <= it->second) it = filter.erase(it); else ++it;
+    }
+    filter.push_back({cost - cost_reduction_rate * violation, (1 - constraints_reduction_rate) * violation});
+  }
+  // eval(alpha) -> (total cost, total violation) of the trial iterate s + alpha d (alpha = 0: the iterate itself)
+  template <typename Eval>
+  double computeStepSize(Eval eval, double max_primal_step_size) {
+    if (filter.empty()) { const auto cv = eval(0.0); augment(cv.first, cv.second); }
+    double a = max_primal_step_size;
+    while (a > min_step_size) {
+      const auto cv = eval(a);
+      if (isAccepted(cv.first, cv.second)) { augment(cv.first, cv.second); break; }
+      a *= step_size_reduction_rate;
+    }
+    return a > min_step_size ? a : min_step_size;
+  }
+};
+
 // SplitUnOCP (include/idocp/unocp/split_unocp.hxx) with its private
 // kkt_matrix_/kkt_residual_, UnconstrainedDynamics and constraints data.
 struct SplitUnOCP {
@@ -104,7 +136,9 @@ class UnOCPSolver {
               double T, int N);
   void setSolution(const std::string& name, const Mat& value);   // unocp_solver.cpp:157-181
   void initConstraints();                                        // unocp_solver.cpp:59-70
-  void updateSolution(double t, const Mat& q, const Mat& v);      // unocp_solver.cpp:73-134
+  void updateSolution(double t, const Mat& q, const Mat& v, bool line_search = false);      // unocp_solver.cpp:73-134
+  std::pair<double, double> costAndViolation(double alpha) const;  // UnLineSearch::computeCostAndViolation (unline_search.cpp:55-82)
+  LineSearchFilterC line_search;                                   // clearLineSearchFilter = line_search.filter.clear()
   void computeKKTResidual(double t, const Mat& q, const Mat& v);  // unocp_solver.cpp:205-225
   double KKTError();                                              // unocp_solver.cpp:190-202
   int isCurrentSolutionFeasible() const;                          // unocp_solver.cpp:228-237: first offending stage or -1
@@ -151,7 +185,9 @@ class UnParNMPCSolver {
   void setSolution(const std::string& name, const Mat& value);    // unparnmpc_solver.cpp:121-146
   void initConstraints();                                         // unparnmpc_solver.cpp:55-66
   void initBackwardCorrection(double t);                          // unbackward_correction.cpp:55-64
-  void updateSolution(double t, const Mat& q, const Mat& v);       // unparnmpc_solver.cpp:74-103
+  void updateSolution(double t, const Mat& q, const Mat& v, bool line_search = false);       // unparnmpc_solver.cpp:74-103
+  std::pair<double, double> costAndViolation(double alpha, const Mat& q, const Mat& v) const;   // unline_search.cpp:85-121
+  LineSearchFilterC line_search;
   void computeKKTResidual(double t, const Mat& q, const Mat& v);   // unparnmpc_solver.cpp:169-187
   double KKTError();                                               // unparnmpc_solver.cpp:154-166
   int isCurrentSolutionFeasible() const;                           // unparnmpc_solver.cpp:190-209

@@ -70,6 +70,12 @@ def oracle():
         lib.oracle_unparnmpc_get_constraint_data.argtypes = [vp, dp, dp]
         lib.oracle_unparnmpc_bench.argtypes = [vp, cd, dp, dp, ci, dp]
         lib.oracle_unparnmpc_bench.restype = cd
+        lib.oracle_unocp_update_solution_ls.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unocp_clear_line_search_filter.argtypes = [vp]
+        lib.oracle_unocp_cost_and_violation.argtypes = [vp, cd, dp]
+        lib.oracle_unparnmpc_update_solution_ls.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unparnmpc_clear_line_search_filter.argtypes = [vp]
+        lib.oracle_unparnmpc_cost_and_violation.argtypes = [vp, cd, dp, dp, dp]
         _oracle = lib
     return _oracle
 
@@ -129,8 +135,17 @@ class OracleUnOCP:
     def set_solution(self, name, value):
         assert self.lib.oracle_unocp_set_solution(self.h, name.encode(), P(arr(value))) == 0
 
-    def update(self, t, q, v):
-        return self.lib.oracle_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+    def update(self, t, q, v, line_search=False):
+        f = self.lib.oracle_unocp_update_solution_ls if line_search else self.lib.oracle_unocp_update_solution
+        return f(self.h, t, P(arr(q)), P(arr(v)))
+
+    def clear_line_search_filter(self):
+        self.lib.oracle_unocp_clear_line_search_filter(self.h)
+
+    def cost_and_violation(self, alpha):
+        out = np.zeros(2)
+        self.lib.oracle_unocp_cost_and_violation(self.h, alpha, P(out))
+        return out
 
     def stage(self, what, t, q, v):
         return self.lib.oracle_unocp_stage(self.h, what, t, P(arr(q)), P(arr(v)))
@@ -198,8 +213,17 @@ class OracleUnParNMPC:
     def init(self, t=0.0):
         self.lib.oracle_unparnmpc_init(self.h, t)
 
-    def update(self, t, q, v):
-        return self.lib.oracle_unparnmpc_update_solution(self.h, t, P(arr(q)), P(arr(v)))
+    def update(self, t, q, v, line_search=False):
+        f = self.lib.oracle_unparnmpc_update_solution_ls if line_search else self.lib.oracle_unparnmpc_update_solution
+        return f(self.h, t, P(arr(q)), P(arr(v)))
+
+    def clear_line_search_filter(self):
+        self.lib.oracle_unparnmpc_clear_line_search_filter(self.h)
+
+    def cost_and_violation(self, alpha, q, v):
+        out = np.zeros(2)
+        self.lib.oracle_unparnmpc_cost_and_violation(self.h, alpha, P(arr(q)), P(arr(v)), P(out))
+        return out
 
     def stage(self, what, t, q, v):
         return self.lib.oracle_unparnmpc_stage(self.h, what, t, P(arr(q)), P(arr(v)))
@@ -255,10 +279,33 @@ class HipUnOCP:
     def set_solution_batch(self, name, values):
         capi.check(self.lib.idocp_unocp_set_solution_batch(self.h, name.encode(), P(arr(values))), "set_solution_batch")
 
-    def update(self, t, q, v):
+    def update(self, t, q, v, line_search=False):
         q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
         v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
-        return self.lib.idocp_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)), 0)
+        return self.lib.idocp_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)), 1 if line_search else 0)
+
+    def launch(self, kernel_id, q, v):
+        """one kernel of updateSolution (0 linearize, 1 / 2 Riccati backward / forward, 3 expand, 4 reduce steps, 5 integrate)"""
+        if getattr(self, "_dq", None) is None:
+            self._dq, self._dv = C.c_void_p(), C.c_void_p()
+            capi.check(self.lib.idocp_device_alloc(C.byref(self._dq), 8 * self.batch * self.nv), "alloc")
+            capi.check(self.lib.idocp_device_alloc(C.byref(self._dv), 8 * self.batch * self.nv), "alloc")
+        qq = arr(np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q)
+        vv = arr(np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v)
+        capi.check(self.lib.idocp_device_upload(self._dq, qq.ctypes.data, qq.nbytes), "upload")
+        capi.check(self.lib.idocp_device_upload(self._dv, vv.ctypes.data, vv.nbytes), "upload")
+        capi.check(self.lib.idocp_unocp_launch_kernel(self.h, kernel_id, self._dq, self._dv), "launch_kernel")
+        capi.check(self.lib.idocp_unocp_synchronize(self.h), "synchronize")
+
+    def clear_line_search_filter(self):
+        capi.check(self.lib.idocp_unocp_clear_line_search_filter(self.h), "clear_line_search_filter")
+
+    def cost_and_violation(self, alpha):
+        """UnLineSearch::computeCostAndViolation at s + alpha d (scalar or per instance) -> (cost[batch], violation[batch])"""
+        a = arr(np.broadcast_to(arr(alpha), (self.batch,)))
+        c, v = np.zeros(self.batch), np.zeros(self.batch)
+        capi.check(self.lib.idocp_unocp_line_search_eval(self.h, P(a), P(c), P(v)), "line_search_eval")
+        return c, v
 
     def infeasible_stage(self):
         ok, where = np.zeros(self.batch, dtype=np.int32), np.zeros(self.batch, dtype=np.int32)
@@ -323,8 +370,8 @@ class HipUnParNMPC(HipUnOCP):
     def _bc(self, x):
         return arr(np.broadcast_to(arr(x), (self.batch, self.nv)) if np.ndim(x) == 1 else x)
 
-    def update(self, t, q, v):
-        return self.lib.idocp_unparnmpc_update_solution(self.h, t, P(self._bc(q)), P(self._bc(v)), 0)
+    def update(self, t, q, v, line_search=False):
+        return self.lib.idocp_unparnmpc_update_solution(self.h, t, P(self._bc(q)), P(self._bc(v)), 1 if line_search else 0)
 
     def phase(self, phase, q, v):
         """one phase of updateSolution (0 linearize ... 6 integrate) with (q, v) uploaded once"""

@@ -74,3 +74,26 @@ def test_gating_and_step_sizes():
     assert o.update(0.0, q, v) == 0
     ap, ad = o.step_sizes()
     assert 0 < ap <= 1 and 0 < ad <= 1
+
+
+def test_filter_line_search_step_rule():
+    # UnLineSearch::computeStepSize (unline_search.hpp:62-92): the accepted step is the fraction-to-boundary step times a
+    # power of 0.75, or the floor 0.05 -- also when the fraction-to-boundary step itself is below the floor, which can push
+    # a slack through zero (the barrier cost is NaN from then on and the filter accepts everything: reference behaviour)
+    from helpers import OracleUnOCP
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    q, v = np.full(m.nv, 1.0), np.zeros(m.nv)
+    for make_solver in (lambda: OracleUnOCP(m, cost, cons, 1.0, 20), lambda: OracleUnParNMPC(m, cost, cons, 1.0, 20)):
+        o = make_solver()
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        if hasattr(o, "init"):
+            o.init(0.0)
+        c0 = o.cost_and_violation(0.0, q, v) if isinstance(o, OracleUnParNMPC) else o.cost_and_violation(0.0)
+        assert np.isfinite(c0).all() and c0[0] > 0 and c0[1] > 0
+        for it in range(6):
+            assert o.update(0.0, q, v, line_search=True) == 0
+            assert 0.05 <= o.step_sizes()[0] <= 1.0
+        o.clear_line_search_filter()
+        assert o.update(0.0, q, v, line_search=True) == 0

@@ -180,7 +180,35 @@ def test_full_size_properties_c2():
         assert (sl[2:] > 0).all() and (du[2:] > 0).all()
 
 
-def test_line_search_is_rejected():
-    m, o, g, q, v = make_pair(20, 1.0)
-    rc = g.lib.idocp_unocp_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 1)
-    assert rc == -4
+def test_filter_line_search_parity():
+    # UnLineSearch (include/idocp/line_search/unline_search.hpp:62-92): the trial-iterate cost / violation and the accepted
+    # step of every iteration against the oracle
+    m, o, g, q, v = make_pair(20, 1.0, batch=2)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    # the state the line search sees: direction and step sizes computed, iterate not yet updated
+    for what in (0, 1, 2):
+        assert o.stage(what, 0.0, q, v) == 0
+    for kid in (0, 1, 2, 3, 4):
+        g.launch(kid, q, v)
+    amax = o.step_sizes()[0]
+    for alpha in (0.0, 0.5 * amax, amax):
+        co, vo = o.cost_and_violation(alpha)
+        cg, vg = g.cost_and_violation(alpha)
+        assert abs(cg[0] - co) < 1e-10 * max(1.0, abs(co)) and abs(vg[0] - vo) < 1e-10 * max(1.0, vo), (alpha, cg, co, vg, vo)
+        assert cg[0] == cg[1] and vg[0] == vg[1]
+    assert o.stage(3, 0.0, q, v) == 0
+    g.launch(5, q, v)
+    for it in range(8):
+        assert o.update(0.0, q, v, line_search=True) == 0 and g.update(0.0, q, v, line_search=True) == 0
+        ao, _ = o.step_sizes()
+        ag, _ = g.step_sizes()
+        assert abs(ag[0] - ao) < 1e-9 and ag[0] == ag[1], (it, ag, ao)
+        for f in ("q", "v", "a", "u"):
+            assert rel_err(g.solution(f), o.solution(f)) < 1e-8, (it, f)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) < 1e-7 * max(1.0, e_o)
+    # clearLineSearchFilter: the next call starts from an empty filter again on both sides
+    o.clear_line_search_filter()
+    g.clear_line_search_filter()
+    assert o.update(0.0, q, v, line_search=True) == 0 and g.update(0.0, q, v, line_search=True) == 0
+    assert abs(g.step_sizes()[0][0] - o.step_sizes()[0]) < 1e-9

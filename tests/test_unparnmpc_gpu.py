@@ -94,9 +94,9 @@ def test_batch_instances_are_independent():
             assert rel_err(g.get(f, b), o.get(f)) < TOL, (b, f)
 
 
-def test_handle_kinds_are_not_interchangeable_and_line_search_is_rejected():
+def test_handle_kinds_are_not_interchangeable():
     from helpers import HipUnOCP, P, arr
-    E_ARG, E_UNSUPPORTED = -1, -4
+    E_ARG = -1
     m = iiwa14_model()
     cost, cons = unocp_problem(m)
     g, u = HipUnParNMPC(m, cost, cons, 1.0, 4), HipUnOCP(m, cost, cons, 1.0, 4)
@@ -104,4 +104,28 @@ def test_handle_kinds_are_not_interchangeable_and_line_search_is_rejected():
     assert g.lib.idocp_unocp_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 0) == E_ARG
     assert b"UnParNMPCSolver" in g.lib.idocp_last_error()
     assert u.lib.idocp_unparnmpc_update_solution(u.h, 0.0, P(arr(q)), P(arr(v)), 0) == E_ARG
-    assert g.lib.idocp_unparnmpc_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 1) == E_UNSUPPORTED
+
+
+def test_filter_line_search_parity():
+    # UnLineSearch on the backward-Euler stages (src/line_search/unline_search.cpp:85-121)
+    m, o, g, q, v = make_pair(20, 1.0, batch=2, q0=1.0)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    g.kkt_error(0.0, q, v)                                                   # leaves the measured state on the device
+    # the state the line search sees: direction and step sizes computed, iterate not yet updated
+    for k in range(5):
+        assert o.stage(k, 0.0, q, v) == 0
+    for ph in range(6):
+        g.phase(ph, q, v)
+    amax = o.step_sizes()[0]
+    for alpha in (0.0, 0.5 * amax, amax):
+        co, vo = o.cost_and_violation(alpha, q, v)
+        cg, vg = g.cost_and_violation(alpha)
+        assert abs(cg[0] - co) < 1e-10 * max(1.0, abs(co)) and abs(vg[0] - vo) < 1e-10 * max(1.0, vo), (alpha, cg, co, vg, vo)
+    assert o.stage(5, 0.0, q, v) == 0
+    g.phase(6, q, v)
+    for it in range(8):
+        assert o.update(0.0, q, v, line_search=True) == 0 and g.update(0.0, q, v, line_search=True) == 0
+        ao, _ = o.step_sizes()
+        ag, _ = g.step_sizes()
+        assert abs(ag[0] - ao) < 1e-9 and ag[0] == ag[1], (it, ag, ao)
+        compare(o, g, ("q", "v", "a", "u"), 1e-8, "line search iteration %d" % it)
