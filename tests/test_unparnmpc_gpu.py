@@ -30,7 +30,7 @@ def compare(o, g, fields, tol, what):
         assert e < tol, (what, f, e)
 
 
-@pytest.mark.parametrize("N,T", [(20, 1.0), (3, 0.3), (64, 2.0)])
+@pytest.mark.parametrize("N,T", [(20, 1.0), (3, 0.3), (64, 2.0), (1, 0.05), (2, 0.1)])
 def test_phase_by_phase_parity_of_the_first_iteration(N, T):
     m, o, g, q, v = make_pair(N, T)
     # oracle stage 0 = linearize + KKT inverse + coarse update = GPU phases 0, 1
@@ -129,3 +129,30 @@ def test_filter_line_search_parity():
         ag, _ = g.step_sizes()
         assert abs(ag[0] - ao) < 1e-9 and ag[0] == ag[1], (it, ag, ao)
         compare(o, g, ("q", "v", "a", "u"), 1e-8, "line search iteration %d" % it)
+
+
+@pytest.mark.parametrize("batch", [1, 4, 7])
+def test_ragged_batch_sizes(batch):
+    # the per-stage kernels pack 3 (K1, K9u), 8 (K11u, K3) or 2 (K10u) stages and the sweeps 4 instances per wavefront:
+    # batch * N not a multiple of any of them
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    N = 5
+    rng = np.random.default_rng(batch)
+    q0 = 1.0 + 0.3 * rng.uniform(-1, 1, (batch, m.nv))
+    v0 = 0.1 * rng.uniform(-1, 1, (batch, m.nv))
+    g = HipUnParNMPC(m, cost, cons, 0.25, N, batch=batch)
+    g.set_solution_batch("q", q0)
+    g.set_solution_batch("v", v0)
+    g.init(0.0)
+    for _ in range(2):
+        assert g.update(0.0, q0, v0) == 0
+    b = batch - 1
+    o = OracleUnParNMPC(m, cost, cons, 0.25, N)
+    o.set_solution("q", q0[b])
+    o.set_solution("v", v0[b])
+    o.init(0.0)
+    for _ in range(2):
+        assert o.update(0.0, q0[b], v0[b]) == 0
+    for f in DIR:
+        assert rel_err(g.get(f, b), o.get(f)) < 1e-9, f
