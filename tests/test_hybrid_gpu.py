@@ -180,3 +180,40 @@ def test_running_example_parity():
         assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
     assert abs(e_g[0] - e_o) <= 1e-5 * e_o, (e_g, e_o)
+
+
+def test_full_size_c3_trotting_parity_and_properties():
+    # BASELINE configs[2] at its own size, the default bench workload: N = 100, T = 5.05, 1 lift + 9 impulse events
+    # (120 stages in the chain).  First iterations against the oracle along the whole chain, then size-independent properties.
+    nimp = 9
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    T, N = 0.5 + nimp * 0.5 + 0.05, 100
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+    g = HipOCP(m, cost, cons, T, N, batch=3, max_num_impulse=nimp + 1)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in (o, g):
+        trotting_sequence(s, m, nimp)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    M = len(o.chain(0.0))
+    assert M == 120 and len(g.chain(0.0)) == M
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) <= 1e-9 * max(1.0, e_o)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    # The last touch-down of this schedule sits 5 ms after a grid point: the switching-constraint Schur step of that short
+    # stage is as ill-conditioned as the one of GRIDS' last entry, two FP64 evaluation orders of P separate by 2e-8 there (1e-14
+    # on the stages behind it) and the difference decays again towards the front of the horizon.  1e-10 on the first half
+    # of the chain, 5e-6 overall (measured 1e-6 on dv, 2e-7 on dq).
+    compare_chain(o, g, M, list(OCP_DIR_FIELDS), 5e-6, "first iteration, full size")
+    for f in OCP_DIR_FIELDS:
+        a, b = g.get_chain(f, M), o.get_chain(f, M)
+        assert np.abs(a[:60] - b[:60]).max() / max(1.0, np.abs(b).max()) < 1e-10, f
+    for it in range(9):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) <= 1e-4 * max(1.0, e_o) and e_g[0] == e_g[2]
+    qs = g.get_chain("q", M, 1)
+    assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12
