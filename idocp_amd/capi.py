@@ -102,6 +102,8 @@ def _proto(lib):
     lib.idocp_unocp_create.restype = ci
     lib.idocp_unparnmpc_create.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, P(vp)]
     lib.idocp_unparnmpc_create.restype = ci
+    lib.idocp_unparnmpc_create_shard.argtypes = [P(Model), P(Cost), P(Constraints), cd, ci, ci, ci, ci, ci, P(vp)]
+    lib.idocp_unparnmpc_create_shard.restype = ci
     lib.idocp_unocp_destroy.argtypes = [vp]
     lib.idocp_unocp_destroy.restype = None
     for name, args in [
@@ -133,6 +135,12 @@ def _proto(lib):
         ("idocp_unparnmpc_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
         ("idocp_unparnmpc_launch_phase", [vp, ci, vp, vp]),
         ("idocp_unparnmpc_get_new_solution", [vp, cs, ci, c_double_p]),
+        ("idocp_unparnmpc_halo_size", [ci]),
+        ("idocp_unparnmpc_export_halo", [vp, ci, vp]),
+        ("idocp_unparnmpc_import_halo", [vp, ci, vp]),
+        ("idocp_unparnmpc_prev_state", [vp, P(vp), P(vp)]),
+        ("idocp_unparnmpc_step_sizes_device", [vp, P(vp)]),
+        ("idocp_unparnmpc_kkt_error_squared_device", [vp, cd, vp]),
         ("idocp_unocp_launch_riccati", [vp, vp, vp]),
         ("idocp_unocp_launch_expand", [vp]),
         ("idocp_unocp_launch_integrate", [vp]),

@@ -80,6 +80,8 @@ struct idocp_unocp {
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr;   // staging for host-pointer entry points
   bool has_direction = false;
   int bwd = 0;                  // 1: UnParNMPC handle (backward-Euler stages, idocp_unparnmpc_*)
+  int level_offset = 0;         // constraint time step of local stage i = i + level_offset
+  int shard = 0;                // 1: a horizon shard of UnParNMPC (idocp_unparnmpc_create_shard)
   // filter line search (LineSearchFilter, src/line_search/line_search_filter.cpp): one filter per instance
   std::vector<std::vector<std::pair<double, double>>> filters;
 };
@@ -145,8 +147,11 @@ int idocp_device_upload(void* d_dst, const void* h_src, unsigned long long nbyte
   return IDOCP_OK;
 }
 
+// bwd: 0 UnOCP, 1 UnParNMPC.  N, dt: the stages this handle holds and their time step; stage_offset / has_terminal / has_prev
+// describe a horizon shard of UnParNMPC (0 / 1 / 0 for a whole horizon).
 static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
-                      double T, int N, int batch, int device, int bwd, idocp_unocp_t** out) {
+                      double T, int N, int batch, int device, int bwd, idocp_unocp_t** out, double dt = 0.0, int stage_offset = 0,
+                      int has_terminal = 1, int has_prev = 0) {
   if (!model || !cost || !constraints || !out) { set_last_error("idocp_unocp_create: null argument"); return IDOCP_E_ARG; }
   // argument checks of UnOCPSolver::UnOCPSolver (unocp_solver.cpp:33-47) and SplitUnOCP (split_unocp.hxx:26-33)
   if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }
@@ -167,6 +172,7 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   idocp_unocp* h = new idocp_unocp();
   h->model = *model; h->cost = *cost; h->cons = *constraints;
   h->N = N; h->batch = batch; h->device = device; h->T = T; h->nv = model->nv; h->bwd = bwd;
+  h->level_offset = bwd ? 1 + stage_offset : 0; h->shard = (stage_offset != 0 || !has_terminal || has_prev) ? 1 : 0;
   int rc = IDOCP_OK;
   auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -202,10 +208,12 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     if ((rc = allocBuf(h, &B.snew, nrec1 * L7::SOL))) return fail(rc);
     if ((rc = allocBuf(h, &B.aux, nrec1 * L7::AUX))) return fail(rc);
     if ((rc = allocBuf(h, &B.xres, nrec1 * L7::XRES))) return fail(rc);
+    if ((rc = allocBuf(h, &B.xprev, (size_t)batch * L7::NX))) return fail(rc);
   }
   DevModel dm; toDevModel(*model, dm);
   UnProblem up; std::memset(&up, 0, sizeof(up));
-  up.N = N; up.batch = batch; up.T = T; up.dt = T / N;
+  up.N = N; up.batch = batch; up.T = T; up.dt = dt > 0.0 ? dt : T / N;
+  up.stage_offset = stage_offset; up.has_terminal = has_terminal; up.has_prev = has_prev;
   for (int i = 0; i < model->nv; ++i) {
     up.q_ref[i] = cost->q_ref[i]; up.v_ref[i] = cost->v_ref[i]; up.u_ref[i] = cost->u_ref[i];
     up.q_weight[i] = cost->q_weight[i]; up.v_weight[i] = cost->v_weight[i]; up.a_weight[i] = cost->a_weight[i];
@@ -244,6 +252,85 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, con
 int idocp_unparnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
                            double T, int N, int batch, int device, idocp_unocp_t** out) {
   return createImpl(model, cost, constraints, T, N, batch, device, 1, out);
+}
+
+static int wrongKind(const idocp_unocp_t* h, int want_bwd);
+
+// One shard of the horizon of UnParNMPCSolver: the stages [stage_begin, stage_end) of N (include/idocp_hip.h)
+int idocp_unparnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
+                                 double T, int N, int stage_begin, int stage_end, int batch, int device, idocp_unocp_t** out) {
+  if (N <= 0 || stage_begin < 0 || stage_end > N || stage_begin >= stage_end) { set_last_error("idocp_unparnmpc_create_shard: invalid stage range"); return IDOCP_E_ARG; }
+  if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }
+  return createImpl(model, cost, constraints, T, stage_end - stage_begin, batch, device, 1, out, T / N, stage_begin, stage_end == N ? 1 : 0,
+                    stage_begin > 0 ? 1 : 0);
+}
+// halo kinds as in idocp_parnmpc_halo_size: 0 state_last (q, v), 1 costate_first (lmd, gmm), 2 aux_first, 3 bwd_first (corrected
+// lmd, gmm), 4 fwd_last (corrected q, v)
+int idocp_unparnmpc_halo_size(int kind) {
+  switch (kind) {
+    case 0: case 1: case 3: case 4: return L7::NX;
+    case 2: return L7::NX * L7::NX;
+    default: return 0;
+  }
+}
+int idocp_unparnmpc_export_halo(idocp_unocp_t* h, int kind, double* d_buf) {
+  if (!h || !d_buf || kind < 0 || kind > 4) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  const long rs = (long)(h->N + 1) * L7::SOL, last = (long)(h->N - 1) * L7::SOL;
+  const int nx = L7::NX;
+  switch (kind) {
+    case 0: stridedCopy(d_buf, nx, 0, h->B.sol, rs, last + L7::S_Q, nx, h->batch, h->stream); break;
+    case 1: stridedCopy(d_buf, nx, 0, h->B.sol, rs, L7::S_LMD, nx, h->batch, h->stream); break;
+    case 2: stridedCopy(d_buf, nx * nx, 0, h->B.aux, (long)(h->N + 1) * L7::AUX, 0, nx * nx, h->batch, h->stream); break;
+    case 3: stridedCopy(d_buf, nx, 0, h->B.snew, rs, L7::S_LMD, nx, h->batch, h->stream); break;
+    default: stridedCopy(d_buf, nx, 0, h->B.snew, rs, last + L7::S_Q, nx, h->batch, h->stream); break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_import_halo(idocp_unocp_t* h, int kind, const double* d_buf) {
+  if (!h || !d_buf || kind < 0 || kind > 4) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  const long rs = (long)(h->N + 1) * L7::SOL, next = (long)h->N * L7::SOL;
+  const int nx = L7::NX, nv = h->nv;
+  switch (kind) {
+    case 0:   // the left neighbour's last state becomes this shard's "measured" state
+      stridedCopy(h->d_q0, nv, 0, d_buf, nx, 0, nv, h->batch, h->stream);
+      stridedCopy(h->d_v0, nv, 0, d_buf, nx, nv, nv, h->batch, h->stream);
+      break;
+    case 1: stridedCopy(h->B.sol, rs, next + L7::S_LMD, d_buf, nx, 0, nx, h->batch, h->stream); break;
+    case 2: stridedCopy(h->B.aux, (long)(h->N + 1) * L7::AUX, (long)h->N * L7::AUX, d_buf, nx * nx, 0, nx * nx, h->batch, h->stream); break;
+    case 3: stridedCopy(h->B.snew, rs, next + L7::S_LMD, d_buf, nx, 0, nx, h->batch, h->stream); break;
+    default: stridedCopy(h->B.xprev, nx, 0, d_buf, nx, 0, nx, h->batch, h->stream); break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_prev_state(idocp_unocp_t* h, double** d_q, double** d_v) {
+  if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  *d_q = h->d_q0; *d_v = h->d_v0;
+  return IDOCP_OK;
+}
+int idocp_unparnmpc_step_sizes_device(idocp_unocp_t* h, double** d_steps) {
+  if (!h || !d_steps) return IDOCP_E_ARG;
+  *d_steps = h->B.step;
+  return IDOCP_OK;
+}
+// squared KKT error of the local stages with the resident previous state (d_q0, d_v0): d_err2[batch] on the device
+int idocp_unparnmpc_kkt_error_squared_device(idocp_unocp_t* h, double t, double* d_err2) {
+  if (!h || !d_err2) return IDOCP_E_ARG;
+  if (wrongKind(h, 1)) return IDOCP_E_ARG;
+  (void)t;
+  int rc = setDevice(h); if (rc) return rc;
+  UnLaunch<7>::parnmpcResidual(h->B, h->batch, h->N, h->d_q0, h->d_v0, h->stream);
+  squareInto(d_err2, h->B.err, h->batch, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
 }
 
 void idocp_unocp_destroy(idocp_unocp_t* h) {
@@ -296,6 +383,7 @@ static int lineSearchEval(idocp_unocp_t* h, const std::vector<double>& alpha, co
   return IDOCP_OK;
 }
 static int runLineSearch(idocp_unocp_t* h, const double* d_q, const double* d_v) {
+  if (h->shard) { set_last_error("line_search=true is not supported on a horizon shard"); return IDOCP_E_UNSUPPORTED; }
   const double cost_rate = 0.005, con_rate = 0.005, reduction = 0.75, min_step = 0.05;
   const int B = h->batch;
   auto accepted = [](const std::vector<std::pair<double, double>>& f, double c, double v) {
@@ -620,8 +708,8 @@ int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, in
     for (int i = 0; i < N && bad < 0; ++i) {
       const double* s = &sol[((size_t)b * (N + 1) + i) * L7::SOL];
       for (int r = 0; r < nv && bad < 0; ++r) {
-        if (h->cons.joint_position_limits && i + h->bwd >= 2 && (s[L7::S_Q + r] < m.q_min[r] || s[L7::S_Q + r] > m.q_max[r])) bad = i;
-        if (h->cons.joint_velocity_limits && i + h->bwd >= 1 && (s[L7::S_V + r] < -m.v_max[r] || s[L7::S_V + r] > m.v_max[r])) bad = i;
+        if (h->cons.joint_position_limits && i + h->level_offset >= 2 && (s[L7::S_Q + r] < m.q_min[r] || s[L7::S_Q + r] > m.q_max[r])) bad = i;
+        if (h->cons.joint_velocity_limits && i + h->level_offset >= 1 && (s[L7::S_V + r] < -m.v_max[r] || s[L7::S_V + r] > m.v_max[r])) bad = i;
         if (h->cons.joint_torque_limits && (s[L7::S_U + r] < -m.u_max[r] || s[L7::S_U + r] > m.u_max[r])) bad = i;
       }
     }
@@ -651,7 +739,7 @@ int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance, double* slac
     int off = 0;
     for (int c = 0; c < 6; ++c) {
       if (!use[c / 2]) continue;
-      const bool valid = (c < 2) ? i + h->bwd >= 2 : ((c < 4) ? i + h->bwd >= 1 : true);
+      const bool valid = (c < 2) ? i + h->level_offset >= 2 : ((c < 4) ? i + h->level_offset >= 1 : true);
       for (int r = 0; r < nv; ++r) {
         if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * L7::CON + c * nv + r] : 0.0;
         if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * L7::CON + c * nv + r] : 0.0;

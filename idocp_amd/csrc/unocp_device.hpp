@@ -62,6 +62,10 @@ struct UnProblem {
   int use_q_limits, use_v_limits, use_u_limits;
   double barrier, fraction_rate;
   int backward_euler;     // UnParNMPC: stage i sits at t + (i + 1) dt, constraint time step i + 1, the last stage is terminal
+  // UnParNMPC horizon shard (idocp_unparnmpc_create_shard): local stage i is stage stage_offset + i of the horizon;
+  // has_terminal: the shard ends with the terminal stage (else record N holds the right neighbour's first stage: lmd, gmm,
+  // aux, corrected lmd, gmm); has_prev: (q0, v0) is the left neighbour's last stage and B.xprev its corrected (q, v)
+  int stage_offset, has_terminal, has_prev;
 };
 
 // All device pointers of one handle.
@@ -90,6 +94,7 @@ struct UnBuffers {
   double* snew;        // [batch][N+1][SOL]  coarse / corrected iterate s_new (lmd, gmm, q, v, a)
   double* aux;         // [batch][N+1][AUX]
   double* xres;        // [batch][N+1][XRES]
+  double* xprev;       // [batch][2 NV]  shard with has_prev: corrected (q, v) of the left neighbour's last stage
 };
 
 }  // namespace idocp_dev

@@ -55,7 +55,7 @@ __device__ __forceinline__ double limitOf(const UnProblem* __restrict__ P, int c
 }
 // ConstraintsData(time_stage) level gating (constraints_data.hpp:18-42) + enabled components
 __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int comp, int stage) {
-  stage += P->backward_euler;          // UnParNMPC creates stage i with time step i + 1 (unparnmpc_solver.cpp:55-66)
+  if (P->backward_euler) stage += 1 + P->stage_offset;     // UnParNMPC creates stage i with time step i + 1 (unparnmpc_solver.cpp:55-66)
   if (comp < 2) return P->use_q_limits && stage >= 2;
   if (comp < 4) return P->use_v_limits && stage >= 1;
   return P->use_u_limits != 0;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const dou
     const double lmd = s[L::S_LMD + k], gmm = s[L::S_GMM + k];
     const double lmdn = sn[L::S_LMD + k], gmmn = sn[L::S_GMM + k];
     double x, w, ref;
-    const bool term = BWD && (i == N - 1);
+    const bool term = BWD && P->has_terminal && (i == N - 1);
     if (kind == 0) {
       x = qk; w = P->q_weight[k]; ref = P->q_ref[k];
       if (BWD) {
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
     const int off = lo == 0 ? (hi == 0 ? L::K_QAA : (hi == 1 ? L::K_QAQ : L::K_QAV)) : (lo == 1 ? (hi == 1 ? L::K_QQQ : L::K_QQV) : L::K_QVV);
     double val = kk[off + cc * NV + rr];
     if (lo == hi && ri > cj) val = kk[off + ri * NV + cj];           // diagonal blocks: read the upper triangle only
-    if (i < N - 1 && bi >= 1 && bj >= 1) val += aux[(c - NV) * NX + (r - NV)];
+    if ((i < N - 1 || !P->has_terminal) && bi >= 1 && bj >= 1) val += aux[(c - NV) * NX + (r - NV)];
     sQ[e] = val;
   }
   if (lane < NK) sres[lane] = kk[L::K_FQ + lane];                     // [Fq Fv la lq lv] are contiguous in the kkt record
@@ -883,13 +883,16 @@ __global__ __launch_bounds__(64) void unparnmpc_backward_serial_kernel(UnBuffers
   double* __restrict__ snew = B.snew + b * (N + 1) * L::SOL;
   double* __restrict__ xres = B.xres + b * (N + 1) * L::XRES;
   const double* __restrict__ kinv = B.kinv + b * N * L::KINV;
-  if (N < 2) return;
-  double cur = snew[(N - 1) * L::SOL + r];                // (lmd, gmm) are the first NX entries of a record
+  // the sweep starts behind the terminal stage; on a shard that ends earlier it starts from the right neighbour's first
+  // stage, whose (lmd, gmm) and corrected (lmd, gmm) sit in record N
+  const int i_first = P->has_terminal ? N - 2 : N - 1;
+  if (i_first < 0) return;
+  double cur = snew[(i_first + 1) * L::SOL + r];           // (lmd, gmm) are the first NX entries of a record
   double m[NX], mn[NX];
-  double s_next = sol[(N - 1) * L::SOL + r], own = snew[(N - 2) * L::SOL + r];
+  double s_next = sol[(i_first + 1) * L::SOL + r], own = snew[i_first * L::SOL + r];
 #pragma unroll
-  for (int c = 0; c < NX; ++c) m[c] = kinv[(long)(N - 2) * L::KINV + L::I_TR + (NV + c) * NX + r];
-  for (int i = N - 2; i >= 0; --i) {
+  for (int c = 0; c < NX; ++c) m[c] = kinv[(long)i_first * L::KINV + L::I_TR + (NV + c) * NX + r];
+  for (int i = i_first; i >= 0; --i) {
     double s_next_n = 0.0, own_n = 0.0;
     if (i > 0) {
       s_next_n = sol[i * L::SOL + r]; own_n = snew[(i - 1) * L::SOL + r];
@@ -917,11 +920,12 @@ __global__ __launch_bounds__(64) void unparnmpc_backward_parallel_kernel(UnBuffe
   const UnProblem* __restrict__ P = B.prob;
   const int N = P->N;
   const int lane = threadIdx.x, g = lane >> 5, r = lane & 31;
-  const long total = (long)P->batch * (N - 1);
+  const int nc = P->has_terminal ? N - 1 : N;             // stages that have a successor
+  const long total = (long)P->batch * nc;
   const long unit = (long)blockIdx.x * 2 + g;
   if (unit >= total || r >= NQ) return;
-  const long b = unit / (N - 1);
-  const int i = (int)(unit - b * (N - 1));
+  const long b = unit / nc;
+  const int i = (int)(unit - b * nc);
   const long rec = b * (N + 1) + i;
   const double* __restrict__ x = B.xres + rec * L::XRES;
   const double* __restrict__ m = B.kinv + (b * N + i) * L::KINV + L::I_BRC;
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(64) void unparnmpc_backward_parallel_kernel(UnBuffe
 //   x_res = s_new[i-1].(q, v) - s[i-1].(q, v);  s_new[i].(q, v) -= K^-1(3nv.., 0..) x_res   (= TR(:, q v)^T)
 // (split_unbackward_correction.hxx:95-104)
 template <int NV>
-__global__ __launch_bounds__(64) void unparnmpc_forward_serial_kernel(UnBuffers B) {
+__global__ __launch_bounds__(64) void unparnmpc_forward_serial_kernel(UnBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
   using L = UnLayout<NV>;
   constexpr int NX = L::NX;
   const UnProblem* __restrict__ P = B.prob;
@@ -950,13 +954,18 @@ __global__ __launch_bounds__(64) void unparnmpc_forward_serial_kernel(UnBuffers 
   double* __restrict__ snew = B.snew + b * (N + 1) * L::SOL;
   double* __restrict__ xres = B.xres + b * (N + 1) * L::XRES;
   const double* __restrict__ kinv = B.kinv + b * N * L::KINV;
-  if (N < 2) return;
-  double cur = snew[L::S_Q + r];                           // (q, v) are contiguous in a record
+  // the sweep starts at stage 1; on a shard with a left neighbour it starts at stage 0 from that neighbour's last stage
+  // (its state is the shard's "measured" state q0 / v0, its corrected state B.xprev)
+  const int i_first = P->has_prev ? 0 : 1;
+  if (i_first >= N) return;
+  double cur, s_prev;
+  if (P->has_prev) { cur = B.xprev[b * NX + r]; s_prev = r < NV ? q0[b * NV + r] : v0[b * NV + r - NV]; }
+  else { cur = snew[L::S_Q + r]; s_prev = sol[L::S_Q + r]; }           // (q, v) are contiguous in a record
   double m[NX], mn[NX];
-  double s_prev = sol[L::S_Q + r], own = snew[L::SOL + L::S_Q + r];
+  double own = snew[i_first * L::SOL + L::S_Q + r];
 #pragma unroll
-  for (int c = 0; c < NX; ++c) m[c] = kinv[(long)L::KINV + L::I_TR + (NV + r) * NX + c];
-  for (int i = 1; i < N; ++i) {
+  for (int c = 0; c < NX; ++c) m[c] = kinv[(long)i_first * L::KINV + L::I_TR + (NV + r) * NX + c];
+  for (int i = i_first; i < N; ++i) {
     double s_prev_n = 0.0, own_n = 0.0;
     if (i + 1 < N) {
       s_prev_n = sol[i * L::SOL + L::S_Q + r]; own_n = snew[(i + 1) * L::SOL + L::S_Q + r];
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(64) void unparnmpc_expand_kernel(UnBuffers B) {
   double* __restrict__ dd = B.dir + rec * L::SOL;
   const double* __restrict__ ki = B.kinv + su * L::KINV;
   double n_lmd = sn[L::S_LMD + r], n_gmm = sn[L::S_GMM + r], n_a = sn[L::S_A + r];
-  if (i > 0) {
+  if (i > 0 || P->has_prev) {
     const double* __restrict__ x = B.xres + rec * L::XRES + NX;
     double c_lmd = 0.0, c_gmm = 0.0, c_a = 0.0;
 #pragma unroll
@@ -1124,7 +1133,7 @@ __global__ __launch_bounds__(64) void un_line_search_kernel(UnBuffers B, const d
   WAVE_SYNC();
   double cost = 0.0, viol = 0.0;
   const double qt = s_x[g][0][k], vt = s_x[g][1][k], at = s_x[g][2][k], ut = s_x[g][3][k];
-  const bool term = BWD ? (i == N - 1) : false;
+  const bool term = BWD ? (P->has_terminal && i == N - 1) : false;
   // the neighbour of the state equation at ITS trial point (the measured state is fixed)
   double qo, vo;
   if (BWD) {
@@ -1181,6 +1190,21 @@ __global__ __launch_bounds__(64) void un_line_search_reduce_kernel(UnBuffers B) 
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { c += __shfl_xor(c, off); v += __shfl_xor(v, off); }
   if (threadIdx.x == 0) { B.ls_out[b * 2] = c; B.ls_out[b * 2 + 1] = v; }
+}
+
+// Halo exchange of a horizon shard: dst[b][dst_off + e] = src[b][src_off + e], e < n, with per-instance strides
+__global__ void un_strided_copy_kernel(double* __restrict__ dst, long dst_stride, long dst_off, const double* __restrict__ src,
+                                       long src_stride, long src_off, int n, long batch) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= batch * n) return;
+  const long b = idx / n;
+  const int e = (int)(idx - b * n);
+  dst[b * dst_stride + dst_off + e] = src[b * src_stride + src_off + e];
+}
+// squared KKT error of the local stages (summed over the ranks by the caller)
+__global__ void un_square_kernel(double* __restrict__ out, const double* __restrict__ err, long batch) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < batch) out[b] = err[b] * err[b];
 }
 
 // ------------------------------------------------------------ launchers ----
@@ -1253,8 +1277,8 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
     case 0: hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0); break;
     case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + 2) / 3)), dim3(192), 0, st, B); break;
     case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
-    case 3: if (N > 1) hipLaunchKernelGGL((unparnmpc_backward_parallel_kernel<NV>), dim3((unsigned)((batch * (N - 1) + 1) / 2)), dim3(64), 0, st, B); break;
-    case 4: hipLaunchKernelGGL((unparnmpc_forward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
+    case 3: hipLaunchKernelGGL((unparnmpc_backward_parallel_kernel<NV>), dim3((unsigned)((batch * N + 1) / 2)), dim3(64), 0, st, B); break;
+    case 4: hipLaunchKernelGGL((unparnmpc_forward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B, q0, v0); break;
     case 5:
       hipLaunchKernelGGL((unparnmpc_expand_kernel<NV>), dim3((unsigned)((batch * N + 7) / 8)), dim3(64), 0, st, B);
       hipLaunchKernelGGL(un_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
@@ -1281,6 +1305,14 @@ void UnLaunch<NV>::lineSearchEval(const UnBuffers& B, long batch, int N, bool bw
   if (bwd) hipLaunchKernelGGL((un_line_search_kernel<NV, true>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
   else hipLaunchKernelGGL((un_line_search_kernel<NV, false>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
   hipLaunchKernelGGL(un_line_search_reduce_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+}
+
+void stridedCopy(double* dst, long dst_stride, long dst_off, const double* src, long src_stride, long src_off, int n, long batch, hipStream_t st) {
+  hipLaunchKernelGGL(un_strided_copy_kernel, dim3((unsigned)((batch * n + 255) / 256)), dim3(256), 0, st, dst, dst_stride, dst_off, src, src_stride,
+                     src_off, n, batch);
+}
+void squareInto(double* out, const double* err, long batch, hipStream_t st) {
+  hipLaunchKernelGGL(un_square_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, out, err, batch);
 }
 
 template struct UnLaunch<7>;

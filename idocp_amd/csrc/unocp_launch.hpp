@@ -27,6 +27,8 @@ struct UnLaunch {
                               double* dq, double* dv, double* da, hipStream_t st);
 };
 
+void stridedCopy(double* dst, long dst_stride, long dst_off, const double* src, long src_stride, long src_off, int n, long batch, hipStream_t st);
+void squareInto(double* out, const double* err, long batch, hipStream_t st);
 void fillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,
                int per_instance, hipStream_t st);
 

@@ -180,3 +180,80 @@ class HipParNMPCShard:
         buf = self.torch.empty((self.batch,), dtype=self.torch.float64, device=self.dev)
         self.capi.check(self.lib.idocp_parnmpc_kkt_error_squared_device(self.h, t, buf.data_ptr()), "kkt_error_squared")
         return buf
+
+
+class HipUnParNMPCShard:
+    """Shard backend of the fixed-base UnParNMPCSolver on the HIP path (idocp_unparnmpc_create_shard): the same protocol
+    through ShardedParNMPC.  aux_mat is initialised locally on every rank (the terminal cost Hessian of the fixed-base cost is
+    constant), so the AUX_ALL broadcast carries nothing."""
+    PHASES = {"linearize": (0, 1), "bwd_serial": (2,), "bwd_parallel": (3,), "fwd_serial": (4,), "fwd_parallel": (5,), "integrate": (6,)}
+
+    def __init__(self, model, cost, cons, T, N, rank, world, batch, device):
+        import ctypes as C
+        import torch
+        from idocp_amd import capi
+        assert N % world == 0, "the horizon must divide evenly among the ranks"
+        self.C, self.torch, self.capi = C, torch, capi
+        self.lib = capi.lib()
+        self.Nl, self.batch, self.rank, self.world = N // world, batch, rank, world
+        self.dev = torch.device("cuda", device)
+        h = C.c_void_p()
+        capi.check(self.lib.idocp_unparnmpc_create_shard(C.byref(model), C.byref(cost), C.byref(cons), T, N, rank * self.Nl,
+                                                         (rank + 1) * self.Nl, batch, device, C.byref(h)), "idocp_unparnmpc_create_shard")
+        self.h = h
+        dq, dv, ds = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(self.lib.idocp_unparnmpc_prev_state(self.h, C.byref(dq), C.byref(dv)))
+        capi.check(self.lib.idocp_unparnmpc_step_sizes_device(self.h, C.byref(ds)))
+        self.d_q, self.d_v, self.d_steps = dq, dv, ds
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.idocp_unocp_destroy(self.h)
+            self.h = None
+
+    def set_initial_state(self, q, v):
+        """rank 0: the measured state q[batch][nv], v[batch][nv] (host arrays)"""
+        import numpy as np
+        q, v = np.ascontiguousarray(q, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+        self.capi.check(self.lib.idocp_device_upload(self.d_q, q.ctypes.data, q.nbytes))
+        self.capi.check(self.lib.idocp_device_upload(self.d_v, v.ctypes.data, v.nbytes))
+
+    def halo_size(self, kind):
+        return 1 if kind == AUX_ALL else self.lib.idocp_unparnmpc_halo_size(kind)
+
+    def export(self, kind):
+        buf = self.torch.zeros((self.batch, self.halo_size(kind)), dtype=self.torch.float64, device=self.dev)
+        if kind != AUX_ALL:
+            self.capi.check(self.lib.idocp_unparnmpc_export_halo(self.h, kind, buf.data_ptr()), "export_halo")
+        return buf
+
+    def import_(self, kind, tensor):
+        if kind == AUX_ALL:
+            return
+        tensor = tensor.contiguous()
+        self.torch.cuda.synchronize(self.dev)
+        self.capi.check(self.lib.idocp_unparnmpc_import_halo(self.h, kind, tensor.data_ptr()), "import_halo")
+
+    def phase(self, name, t):
+        if name == "init_aux":
+            self.capi.check(self.lib.idocp_unocp_init_constraints(self.h), "init_constraints")
+            self.capi.check(self.lib.idocp_unparnmpc_init_backward_correction(self.h, t), "init_backward_correction")
+            return
+        for ph in self.PHASES[name]:
+            self.capi.check(self.lib.idocp_unparnmpc_launch_phase(self.h, ph, self.d_q, self.d_v), "phase %d" % ph)
+        self.capi.check(self.lib.idocp_unocp_synchronize(self.h))
+
+    def local_steps(self):
+        buf = self.torch.empty((self.batch, 2), dtype=self.torch.float64, device=self.dev)
+        self.capi.check(self.lib.idocp_device_copy(buf.data_ptr(), self.d_steps, buf.numel() * 8))
+        return buf
+
+    def set_steps(self, tensor):
+        tensor = tensor.contiguous()
+        self.torch.cuda.synchronize(self.dev)
+        self.capi.check(self.lib.idocp_device_copy(self.d_steps, tensor.data_ptr(), tensor.numel() * 8))
+
+    def err2(self, t):
+        buf = self.torch.empty((self.batch,), dtype=self.torch.float64, device=self.dev)
+        self.capi.check(self.lib.idocp_unparnmpc_kkt_error_squared_device(self.h, t, buf.data_ptr()), "kkt_error_squared")
+        return buf

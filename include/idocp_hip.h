@@ -273,6 +273,24 @@ int idocp_unparnmpc_launch_phase(idocp_unocp_t* h, int phase, const double* d_q,
  * idocp_unocp_get_solution. */
 int idocp_unparnmpc_get_new_solution(idocp_unocp_t* h, const char* name, int instance, double* out);
 
+/* Horizon sharding of UnParNMPCSolver (the fixed-base twin of idocp_parnmpc_create_shard; protocol and halo kinds as in
+ * idocp_amd/parnmpc_dist.py): the handle holds the stages [stage_begin, stage_end) of a horizon of N stages over T.
+ * Halo kinds: 0 state_last (q, v of the last stage -> the right neighbour's previous state), 1 costate_first (lmd, gmm of the
+ * first stage -> left), 2 aux_first (aux_mat of the first stage -> left), 3 bwd_first (corrected lmd, gmm of the first stage
+ * -> left, pipeline of the backward serial sweep), 4 fwd_last (corrected q, v of the last stage -> right, pipeline of the
+ * forward serial sweep).  Buffers are device pointers, [batch][idocp_unparnmpc_halo_size(kind)]. */
+int idocp_unparnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* cost,
+                                 const idocp_constraints_t* constraints, double T, int N, int stage_begin,
+                                 int stage_end, int batch, int device, idocp_unocp_t** out);
+int idocp_unparnmpc_halo_size(int kind);
+int idocp_unparnmpc_export_halo(idocp_unocp_t* h, int kind, double* d_buf);
+int idocp_unparnmpc_import_halo(idocp_unocp_t* h, int kind, const double* d_buf);
+/* device buffers of the previous state (rank 0: the measured state) and of the (primal, dual) step sizes [batch][2] */
+int idocp_unparnmpc_prev_state(idocp_unocp_t* h, double** d_q, double** d_v);
+int idocp_unparnmpc_step_sizes_device(idocp_unocp_t* h, double** d_steps);
+/* squared KKT error of the local stages, d_err2[batch] on the device (to be summed over the ranks) */
+int idocp_unparnmpc_kkt_error_squared_device(idocp_unocp_t* h, double t, double* d_err2);
+
 /* Kernel-level entry points used by the parity tests and the roofline
  * measurement (one launch each, on the handle's stream). */
 int idocp_unocp_launch_linearize(idocp_unocp_t* h, double t, const double* d_q,

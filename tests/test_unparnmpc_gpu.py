@@ -156,3 +156,60 @@ def test_ragged_batch_sizes(batch):
         assert o.update(0.0, q0[b], v0[b]) == 0
     for f in DIR:
         assert rel_err(g.get(f, b), o.get(f)) < 1e-9, f
+
+
+def test_two_shards_on_one_gpu_equal_the_whole_horizon():
+    """Horizon sharding of the fixed-base solver without a second GPU: two shard handles of 10 stages each on this GPU, the
+    halo protocol of idocp_amd/parnmpc_dist.py executed by hand in its pipeline order, against one handle of 20."""
+    import torch
+    from helpers import P, arr
+    from idocp_amd import capi
+    from idocp_amd.parnmpc_dist import HipUnParNMPCShard
+    m, o, g, q, v = make_pair(20, 1.0, q0=1.0)
+    cost, cons = unocp_problem(m)
+    lib = capi.lib()
+    shards = [HipUnParNMPCShard(m, cost, cons, 1.0, 20, r, 2, 1, 0) for r in range(2)]
+    for sh in shards:
+        capi.check(lib.idocp_unocp_set_solution(sh.h, b"q", P(arr(q))))
+        capi.check(lib.idocp_unocp_set_solution(sh.h, b"v", P(arr(v))))
+        sh.phase("init_aux", 0.0)
+    s0, s1 = shards
+    s0.set_initial_state(q[None, :], v[None, :])
+
+    def boundary():
+        s1.import_(0, s0.export(0))
+        s0.import_(1, s1.export(1))
+        s0.import_(2, s1.export(2))
+
+    def get(sh, name):
+        out = np.zeros((11, m.nv))
+        capi.check(lib.idocp_unocp_get_solution(sh.h, name.encode(), 0, P(out)))
+        return out[:10]
+
+    for it in range(5):
+        assert g.update(0.0, q, v) == 0
+        boundary()
+        for sh in shards:
+            sh.phase("linearize", 0.0)
+        s1.phase("bwd_serial", 0.0)
+        s0.import_(3, s1.export(3))
+        s0.phase("bwd_serial", 0.0)
+        for sh in shards:
+            sh.phase("bwd_parallel", 0.0)
+        s0.phase("fwd_serial", 0.0)
+        s1.import_(4, s0.export(4))
+        s1.phase("fwd_serial", 0.0)
+        for sh in shards:
+            sh.phase("fwd_parallel", 0.0)
+        steps = torch.minimum(s0.local_steps(), s1.local_steps())
+        ag, bg = g.step_sizes()
+        assert abs(float(steps[0, 0]) - ag[0]) < 1e-12 and abs(float(steps[0, 1]) - bg[0]) < 1e-12
+        for sh in shards:
+            sh.set_steps(steps)
+            sh.phase("integrate", 0.0)
+        for name in SOL:
+            both = np.concatenate([get(s0, name), get(s1, name)])
+            assert rel_err(both, g.get(name)) < 1e-12, (it, name)
+    boundary()
+    e2 = s0.err2(0.0) + s1.err2(0.0)
+    assert abs(float(e2[0].sqrt()) - g.kkt_error(0.0, q, v)[0]) < 1e-9 * max(1.0, float(e2[0].sqrt()))
