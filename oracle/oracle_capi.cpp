@@ -307,6 +307,45 @@ double oracle_unparnmpc_kkt_error(void* h, double t, const double* q, const doub
   s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
   return s->KKTError();
 }
+// horizon shard of UnParNMPC (test twin of idocp_unparnmpc_create_shard + the halo entry points; kinds as in include/idocp_hip.h)
+int oracle_unparnmpc_set_slice(void* h, int lo, int hi) { static_cast<UnParNMPCSolver*>(h)->setSlice(lo, hi); return 0; }
+int oracle_unparnmpc_export(void* h, int kind, double* out) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const int nv = s->robot.dimv(), lo = s->lo(), hi = s->hi();
+  auto put2 = [&](const Mat& a, const Mat& b) { std::memcpy(out, a.d.data(), sizeof(double) * nv); std::memcpy(out + nv, b.d.data(), sizeof(double) * nv); };
+  switch (kind) {
+    case 0: put2(s->s[hi - 1].q, s->s[hi - 1].v); break;
+    case 1: put2(s->s[lo].lmd, s->s[lo].gmm); break;
+    case 2: std::memcpy(out, s->aux_mat[lo].d.data(), sizeof(double) * 4 * nv * nv); break;
+    case 3: put2(s->s_new[lo].lmd, s->s_new[lo].gmm); break;
+    case 4: put2(s->s_new[hi - 1].q, s->s_new[hi - 1].v); break;
+    default: return -1;
+  }
+  return 0;
+}
+int oracle_unparnmpc_import(void* h, int kind, const double* in) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  const int nv = s->robot.dimv(), lo = s->lo(), hi = s->hi();
+  auto get2 = [&](Mat& a, Mat& b) { a = toVec(in, nv); b = toVec(in + nv, nv); };
+  switch (kind) {
+    case 0: get2(s->s[lo - 1].q, s->s[lo - 1].v); break;
+    case 1: get2(s->s[hi].lmd, s->s[hi].gmm); break;
+    case 2: std::memcpy(s->aux_mat[hi].d.data(), in, sizeof(double) * 4 * nv * nv); break;
+    case 3: get2(s->s_new[hi].lmd, s->s_new[hi].gmm); break;
+    case 4: get2(s->s_new[lo - 1].q, s->s_new[lo - 1].v); break;
+    default: return -1;
+  }
+  return 0;
+}
+void oracle_unparnmpc_set_step_sizes(void* h, double primal, double dual) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  s->primal_step_size = primal; s->dual_step_size = dual;
+}
+double oracle_unparnmpc_kkt_error_squared(void* h, double t, const double* q, const double* v) {
+  UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
+  s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));
+  return s->KKTErrorSquared();
+}
 // `iters` updateSolution calls at fixed (t, q, v); returns total seconds (the sweeps are not timed separately)
 double oracle_unparnmpc_bench(void* h, double t, const double* q, const double* v, int iters, double* sweep_seconds) {
   UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);

@@ -1,6 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md and unocp.hpp).
 #include "unocp.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <stdexcept>
@@ -542,7 +543,7 @@ UnParNMPCSolver::UnParNMPCSolver(const idocp_model_t& model, const idocp_cost_t&
       s(N, SplitSolution(robot)), s_new(N, SplitSolution(robot)), d(N, SplitDirection(robot)), ocp(N, SplitUnOCP(model.nv)),
       unkkt_matrix(N, SplitUnKKTMatrix(model.nv)), unkkt_residual(N, SplitUnKKTResidual(model.nv)),
       aux_mat(N, Mat(2 * model.nv, 2 * model.nv)), kkt_inv(N, Mat(5 * model.nv, 5 * model.nv)), x_res(N, Mat(2 * model.nv)),
-      N_(N), T_(T), dt_(T / N) {
+      N_(N), T_(T), dt_(T / N), lo_(0), hi_(N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (robot.hasFloatingBase() || robot.maxPointContacts() > 0)
@@ -681,7 +682,7 @@ void UnParNMPCSolver::linearizeStage(int i, const Mat& q_prev, const Mat& v_prev
 // (split_unbackward_correction.hxx:38-64) and SplitUnKKTMatrixInverter::invert (split_unkkt_matrix_inverter.hxx:37-80)
 void UnParNMPCSolver::coarseUpdate(double /*t*/, const Mat& q, const Mat& v) {
   const int nv = robot.dimv(), nx = 2 * nv, nq3 = 3 * nv, nk = 5 * nv;
-  for (int i = 0; i < N_; ++i) {
+  for (int i = lo_; i < hi_; ++i) {
     linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, false);
     Mat& Q = unkkt_matrix[i].Q;
     if (i < N_ - 1) Q.addBlock(nv, nv, aux_mat[i + 1]);                         // Qxx += aux_mat_next
@@ -725,7 +726,7 @@ void UnParNMPCSolver::coarseUpdate(double /*t*/, const Mat& q, const Mat& v) {
 // split_unbackward_correction.hxx:72-81
 void UnParNMPCSolver::backwardCorrectionSerial() {
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
-  for (int i = N_ - 2; i >= 0; --i) {
+  for (int i = std::min(hi_ - 1, N_ - 2); i >= lo_; --i) {
     x_res[i].setSegment(0, s_new[i + 1].lmd - s[i + 1].lmd);
     x_res[i].setSegment(nv, s_new[i + 1].gmm - s[i + 1].gmm);
     const Mat dx = kkt_inv[i].block(0, nk - nx, nx, nx) * x_res[i];
@@ -737,7 +738,7 @@ void UnParNMPCSolver::backwardCorrectionSerial() {
 // split_unbackward_correction.hxx:84-92
 void UnParNMPCSolver::backwardCorrectionParallel() {
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
-  for (int i = N_ - 2; i >= 0; --i) {
+  for (int i = std::min(hi_ - 1, N_ - 2); i >= lo_; --i) {
     const Mat dd = kkt_inv[i].block(nx, nk - nx, nk - nx, nx) * x_res[i];
     s_new[i].a -= dd.segment(0, nv);
     s_new[i].q -= dd.segment(nv, nv);
@@ -748,7 +749,7 @@ void UnParNMPCSolver::backwardCorrectionParallel() {
 // split_unbackward_correction.hxx:95-104
 void UnParNMPCSolver::forwardCorrectionSerial() {
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
-  for (int i = 1; i < N_; ++i) {
+  for (int i = std::max(lo_, 1); i < hi_; ++i) {
     x_res[i].setSegment(0, s_new[i - 1].q - s[i - 1].q);
     x_res[i].setSegment(nv, s_new[i - 1].v - s[i - 1].v);
     const Mat dx = kkt_inv[i].block(nk - nx, 0, nx, nx) * x_res[i];
@@ -763,7 +764,7 @@ void UnParNMPCSolver::forwardCorrectionSerial() {
 void UnParNMPCSolver::forwardCorrectionParallel() {
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
   double pmin = 1, dmin = 1;
-  for (int i = 0; i < N_; ++i) {
+  for (int i = lo_; i < hi_; ++i) {
     if (i > 0) {
       const Mat dd = kkt_inv[i].block(0, 0, nk - nx, nx) * x_res[i];
       s_new[i].lmd -= dd.segment(0, nv);
@@ -804,7 +805,7 @@ void UnParNMPCSolver::forwardCorrectionParallel() {
 // updatePrimal / updateDual of every stage (unparnmpc_solver.cpp:88-102; split_solution.hxx:215-240)
 void UnParNMPCSolver::integrate() {
   const double ap = primal_step_size, ad = dual_step_size;
-  for (int i = 0; i < N_; ++i) {
+  for (int i = lo_; i < hi_; ++i) {
     s[i].lmd += ap * d[i].dlmd; s[i].gmm += ap * d[i].dgmm; s[i].q += ap * d[i].dq; s[i].v += ap * d[i].dv;
     s[i].a += ap * d[i].da; s[i].u += ap * d[i].du; s[i].beta += ap * d[i].dbeta;
     for (size_t c = 0; c < constraints.components.size(); ++c) {
@@ -843,13 +844,14 @@ void UnParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v, bool 
 }
 
 void UnParNMPCSolver::computeKKTResidual(double /*t*/, const Mat& q, const Mat& v) {
-  for (int i = 0; i < N_; ++i) linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
+  for (int i = lo_; i < hi_; ++i) linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
 }
 
 // squaredNormKKTResidual of every stage (split_unparnmpc.hxx:166-176, terminal_unparnmpc.hxx:171-181)
-double UnParNMPCSolver::KKTError() {
+double UnParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
+double UnParNMPCSolver::KKTErrorSquared() {
   double sum = 0;
-  for (int i = 0; i < N_; ++i) {
+  for (int i = lo_; i < hi_; ++i) {
     const SplitUnOCP& o = ocp[i];
     double e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
     e += o.Fq.squaredNorm() + o.Fv.squaredNorm();
@@ -861,7 +863,7 @@ double UnParNMPCSolver::KKTError() {
     }
     sum += e + dt_ * dt_ * c;
   }
-  return std::sqrt(sum);
+  return sum;
 }
 
 int UnParNMPCSolver::isCurrentSolutionFeasible() const {

@@ -191,6 +191,12 @@ class UnParNMPCSolver {
   void computeKKTResidual(double t, const Mat& q, const Mat& v);   // unparnmpc_solver.cpp:169-187
   double KKTError();                                               // unparnmpc_solver.cpp:154-166
   int isCurrentSolutionFeasible() const;                           // unparnmpc_solver.cpp:190-209
+  // horizon shard (test twin of idocp_unparnmpc_create_shard): every loop runs over the stages [lo, hi) only; the
+  // neighbours' stages lo - 1 and hi are filled by the halo imports (oracle_unparnmpc_import)
+  void setSlice(int lo, int hi) { lo_ = lo; hi_ = hi; }
+  int lo() const { return lo_; }
+  int hi() const { return hi_; }
+  double KKTErrorSquared();
   // the phases of updateSolution, separately callable
   void coarseUpdate(double t, const Mat& q, const Mat& v);         // unbackward_correction.cpp:67-97
   void backwardCorrectionSerial();                                 // :104-106
@@ -213,6 +219,7 @@ class UnParNMPCSolver {
 
  private:
   int N_; double T_, dt_;
+  int lo_ = 0, hi_ = 0;
   void linearizeStage(int i, const Mat& q_prev, const Mat& v_prev, bool residual_only);
 };
 

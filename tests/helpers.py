@@ -70,6 +70,12 @@ def oracle():
         lib.oracle_unparnmpc_get_constraint_data.argtypes = [vp, dp, dp]
         lib.oracle_unparnmpc_bench.argtypes = [vp, cd, dp, dp, ci, dp]
         lib.oracle_unparnmpc_bench.restype = cd
+        lib.oracle_unparnmpc_set_slice.argtypes = [vp, ci, ci]
+        lib.oracle_unparnmpc_export.argtypes = [vp, ci, dp]
+        lib.oracle_unparnmpc_import.argtypes = [vp, ci, dp]
+        lib.oracle_unparnmpc_set_step_sizes.argtypes = [vp, cd, cd]
+        lib.oracle_unparnmpc_kkt_error_squared.argtypes = [vp, cd, dp, dp]
+        lib.oracle_unparnmpc_kkt_error_squared.restype = cd
         lib.oracle_unocp_update_solution_ls.argtypes = [vp, cd, dp, dp]
         lib.oracle_unocp_clear_line_search_filter.argtypes = [vp]
         lib.oracle_unocp_cost_and_violation.argtypes = [vp, cd, dp]
@@ -1031,3 +1037,51 @@ class OracleParNMPCShard:
     def err2(self, t):
         import torch
         return torch.tensor([self.o.lib.oracle_parnmpc_kkt_error_squared(self.o.h, t, P(self.q_prev), P(self.v_prev))], dtype=torch.float64)
+
+
+class OracleUnParNMPCShard:
+    """Shard backend of idocp_amd.parnmpc_dist.ShardedParNMPC on top of the fixed-base oracle (one instance, CPU tensors):
+    every rank holds a whole-horizon oracle and works on its slice of the stages; the halos fill the neighbours' stages."""
+    PHASES = {"linearize": 0, "bwd_serial": 1, "bwd_parallel": 2, "fwd_serial": 3, "fwd_parallel": 4, "integrate": 5}
+
+    def __init__(self, model, cost, cons, T, N, rank, world, q0, v0):
+        assert N % world == 0
+        self.Nl, self.rank = N // world, rank
+        self.o = OracleUnParNMPC(model, cost, cons, T, N)
+        self.o.lib.oracle_unparnmpc_set_slice(self.o.h, rank * self.Nl, (rank + 1) * self.Nl)
+        self.batch, self.nv = 1, model.nv
+        self.q0, self.v0 = arr(q0).copy(), arr(v0).copy()          # the measured state (used by rank 0 only)
+
+    def halo_size(self, kind):
+        return {0: 2 * self.nv, 1: 2 * self.nv, 2: 4 * self.nv * self.nv, 3: 2 * self.nv, 4: 2 * self.nv, 5: 1}[kind]
+
+    def export(self, kind):
+        import torch
+        out = np.zeros(self.halo_size(kind))
+        if kind != 5:
+            assert self.o.lib.oracle_unparnmpc_export(self.o.h, kind, P(out)) == 0
+        return torch.from_numpy(out).reshape(1, -1)
+
+    def import_(self, kind, tensor):
+        if kind == 5:
+            return
+        a = np.ascontiguousarray(tensor.numpy().reshape(-1))
+        assert self.o.lib.oracle_unparnmpc_import(self.o.h, kind, P(a)) == 0
+
+    def phase(self, name, t):
+        if name == "init_aux":
+            self.o.init(t)
+            return
+        assert self.o.stage(self.PHASES[name], t, self.q0, self.v0) == 0
+
+    def local_steps(self):
+        import torch
+        a, b = self.o.step_sizes()
+        return torch.tensor([[a, b]], dtype=torch.float64)
+
+    def set_steps(self, tensor):
+        self.o.lib.oracle_unparnmpc_set_step_sizes(self.o.h, float(tensor[0, 0]), float(tensor[0, 1]))
+
+    def err2(self, t):
+        import torch
+        return torch.tensor([self.o.lib.oracle_unparnmpc_kkt_error_squared(self.o.h, t, P(self.q0), P(self.v0))], dtype=torch.float64)

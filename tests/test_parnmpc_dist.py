@@ -165,3 +165,64 @@ def test_two_shards_of_a_chain_with_events_equal_the_single_process_oracle(tmp_p
         both = np.concatenate([np.array(outs[0][f]), np.array(outs[1][f])])
         ref = o.get_chain(f, M)
         assert np.abs(both - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), f
+
+
+WORKER_UN = r"""
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from helpers import OracleUnParNMPCShard, iiwa14_model, unocp_problem
+from idocp_amd.parnmpc_dist import ShardedParNMPC
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+N, T, iters = 20, 1.0, 8
+m = iiwa14_model()
+cost, cons = unocp_problem(m)
+q, v = np.full(m.nv, 1.0), np.zeros(m.nv)
+shard = OracleUnParNMPCShard(m, cost, cons, T, N, rank, world, q, v)
+shard.o.set_solution("q", q); shard.o.set_solution("v", v)
+drv = ShardedParNMPC(shard, dist, rank, world)
+drv.init_backward_correction(0.0)
+errs = []
+for it in range(iters):
+    drv.update(0.0)
+    errs.append(float(drv.kkt_error(0.0)[0]))
+lo, hi = rank * (N // world), (rank + 1) * (N // world)
+out = {"rank": rank, "errs": errs, "q": shard.o.get("q")[lo:hi].tolist(), "u": shard.o.get("u")[lo:hi].tolist(), "lmd": shard.o.get("lmd")[lo:hi].tolist()}
+print("RESULT" + json.dumps(out), flush=True)
+dist.destroy_process_group()
+""" % (ROOT, ROOT)
+
+
+def test_two_fixed_base_shards_equal_the_single_process_oracle(tmp_path):
+    """UnParNMPCSolver: the same driver and protocol with the fixed-base oracle as the shard backend, two gloo processes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import OracleUnParNMPC, iiwa14_model, unocp_problem
+    script = tmp_path / "worker_un.py"
+    script.write_text(WORKER_UN)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT")][-1][6:]))
+    outs.sort(key=lambda o: o["rank"])
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    o = OracleUnParNMPC(m, cost, cons, 1.0, 20)
+    q, v = np.full(m.nv, 1.0), np.zeros(m.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.init(0.0)
+    errs = []
+    for it in range(8):
+        assert o.update(0.0, q, v) == 0
+        errs.append(o.kkt_error(0.0, q, v))
+    assert np.allclose(outs[0]["errs"], errs, rtol=1e-9, atol=1e-12) and np.allclose(outs[1]["errs"], errs, rtol=1e-9, atol=1e-12)
+    for f in ("q", "u", "lmd"):
+        both = np.concatenate([np.array(outs[0][f]), np.array(outs[1][f])])
+        assert np.abs(both - o.get(f)).max() < 1e-9, f
