@@ -87,3 +87,37 @@ def test_parnmpc_unsupported_cases_fail_loudly():
     g2.push_back_contact_status([1, 1, 1, 1], pts, 0.02)
     assert lib.idocp_parnmpc_init_backward_correction(g2.h, 0.0) == E_UNSUPPORTED
     assert "first time stage" in capi.last_error()
+
+
+def test_fixed_base_solver_argument_errors():
+    """UnOCPSolver / UnParNMPCSolver constructor checks (unocp_solver.cpp:33-47, unparnmpc_solver.cpp:11-44), the shard range,
+    and the entry points that belong to the other solver kind."""
+    import ctypes as C
+    from helpers import HipUnOCP, HipUnParNMPC, iiwa14_model, unocp_problem
+    from idocp_amd import capi
+    lib = capi.lib()
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    h = C.c_void_p()
+    for fn in (lib.idocp_unocp_create, lib.idocp_unparnmpc_create):
+        assert fn(C.byref(m), C.byref(cost), C.byref(cons), -1.0, 10, 1, 0, C.byref(h)) == E_ARG
+        assert b"T must be positive" in lib.idocp_last_error()
+        assert fn(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 0, 1, 0, C.byref(h)) == E_ARG
+        assert b"N must be positive" in lib.idocp_last_error()
+    am = anymal_model()
+    assert lib.idocp_unparnmpc_create(C.byref(am), C.byref(cost), C.byref(cons), 1.0, 10, 1, 0, C.byref(h)) == E_ARG     # floating base
+    for lo, hi in ((-1, 5), (5, 5), (8, 11)):
+        assert lib.idocp_unparnmpc_create_shard(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 10, lo, hi, 1, 0, C.byref(h)) == E_ARG
+    g, u = HipUnParNMPC(m, cost, cons, 1.0, 4), HipUnOCP(m, cost, cons, 1.0, 4)
+    d = C.c_void_p()
+    capi.check(lib.idocp_device_alloc(C.byref(d), 8 * 64))
+    assert lib.idocp_unparnmpc_export_halo(u.h, 0, d) == E_ARG and lib.idocp_unparnmpc_export_halo(g.h, 7, d) == E_ARG
+    assert lib.idocp_unparnmpc_init_backward_correction(u.h, 0.0) == E_ARG
+    assert lib.idocp_unocp_launch_kernel(g.h, 0, d, d) == E_ARG
+    assert lib.idocp_unparnmpc_launch_phase(g.h, 9, d, d) == E_ARG
+    # a horizon shard has no line search
+    sh = C.c_void_p()
+    capi.check(lib.idocp_unparnmpc_create_shard(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 10, 0, 5, 1, 0, C.byref(sh)))
+    q, v = np.full(m.nv, 1.0), np.zeros(m.nv)
+    assert lib.idocp_unparnmpc_update_solution(sh, 0.0, P(arr(q)), P(arr(v)), 1) == E_UNSUPPORTED
+    lib.idocp_unocp_destroy(sh)
