@@ -185,8 +185,8 @@ int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name,
 int idocp_unocp_init_constraints(idocp_unocp_t* h);
 
 /* UnOCPSolver::updateSolution(t, q, v, line_search) (unocp_solver.cpp:73-134).
- * q[batch][nq], v[batch][nv] are host pointers.  line_search must be 0 (the
- * reference default; the filter line search is out of scope). */
+ * q[batch][nq], v[batch][nv] are host pointers.  line_search != 0: filter line
+ * search (unocp_solver.cpp:116-120), one filter per instance, see below. */
 int idocp_unocp_update_solution(idocp_unocp_t* h, double t, const double* q,
                                 const double* v, int line_search);
 /* Same with q, v already resident in device memory (HBM); asynchronous on the
@@ -361,7 +361,8 @@ int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value
 int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double* values);
 /* OCPSolver::initConstraints(t) (ocp_solver.cpp:60-64). */
 int idocp_ocp_init_constraints(idocp_ocp_t* h, double t);
-/* OCPSolver::updateSolution (ocp_solver.cpp:67-92). q[batch][nq], v[batch][nv]. */
+/* OCPSolver::updateSolution (ocp_solver.cpp:67-92). q[batch][nq], v[batch][nv].  line_search must be 0: the filter line
+ * search of the floating-base solvers (src/line_search/line_search.cpp) is not carried; IDOCP_E_UNSUPPORTED otherwise. */
 int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q,
                               const double* v, int line_search);
 int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
@@ -428,7 +429,7 @@ int idocp_parnmpc_create_hybrid(const idocp_model_t* model, const idocp_cost_t* 
 int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t);
 /* ParNMPCSolver::updateSolution (parnmpc_solver.cpp:73-103): coarseUpdate,
  * backwardCorrectionSerial / Parallel, forwardCorrectionSerial / Parallel, step sizes,
- * integrateSolution.  q[batch][nq], v[batch][nv]. */
+ * integrateSolution.  q[batch][nq], v[batch][nv]; line_search must be 0 (see idocp_ocp_update_solution). */
 int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v,
                                   int line_search);
 int idocp_parnmpc_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
