@@ -1,122 +1,42 @@
-// ANYmal trotting through the drop-in facade: the driver of the reference's examples/anymal/anymal_trotting.cpp:25-193
-// (TrottingConfigurationSpaceCost + ContactForceCost, six joint limits, linearized (impulse) friction cones, contact
-// sequence all feet -> {LH, RF} -> {LF, RH} -> ..., N = 30, T = 1.55, two impulse phases, 25 SQP iterations).
-//
-//   usage: anymal_trotting <path/to/anymal.urdf>
-#include <iostream>
-#include <memory>
-#include <string>
-
-#include "idocp/constraints/constraints.hpp"
-#include "idocp/cost/contact_force_cost.hpp"
-#include "idocp/cost/cost_function.hpp"
+// ANYmal trotting on the HIP path, through idocp::OCPSolver.
+// Workload: the one of the reference's examples/anymal/anymal_trotting.cpp (trotting reference cost + contact-force cost,
+// joint limits, friction cones with mu = 0.7 on stages and impulses; all feet -> {LH, RF} -> {LF, RH} -> ..., steps of
+// 0.15 m every 0.5 s from t = 0.5; N = 30, T = 1.55, two touch-down phases, 25 iterations).
+//   usage: anymal_trotting <anymal.urdf>
+#include "common.hpp"
 #include "idocp/cost/trotting_configuration_space_cost.hpp"
 #include "idocp/ocp/ocp_solver.hpp"
-#include "idocp/robot/robot.hpp"
-#include "idocp/utils/ocp_benchmarker.hpp"
 
 int main(int argc, char** argv) {
-  if (argc < 2) {
-    std::cerr << "usage: " << argv[0] << " <anymal.urdf>" << std::endl;
-    return 2;
-  }
-  std::vector<int> contact_frames = {14, 24, 34, 44};   // LF, LH, RF, RH
-  idocp::Robot robot(argv[1], contact_frames);
+  idocp::Robot robot(ex::needUrdf(argc, argv), ex::anymalFeet());
+  const double step = 0.15, t0 = 0.5, period = 0.5;
+  const int touch_downs = 2, horizon = 30;
+  const ex::Vec stand = ex::anymalStanding();
 
-  const double step_length = 0.15;
-  const double t_start = 0.5;
-  const double t_period = 0.5;
-
+  auto gait_cost = std::make_shared<idocp::TrottingConfigurationSpaceCost>(robot);
+  idocp::TrottingSwingAngles swing;
+  swing.front_swing_knee = swing.hip_swing_knee = 1.7;
+  gait_cost->set_ref(t0, period, stand, step, swing);
+  ex::attachWeights(*gait_cost, ex::filled(18, 10), ex::runs({{6, 1}, {12, 0.1}}), ex::runs({{6, 0.1}, {12, 0.01}}), true);
   auto cost = std::make_shared<idocp::CostFunction>();
-  Eigen::VectorXd q_standing(robot.dimq());
-  q_standing << 0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0;
-  Eigen::VectorXd q_weight = Eigen::VectorXd::Constant(robot.dimv(), 10);
-  Eigen::VectorXd v_weight(robot.dimv());
-  v_weight << 1, 1, 1, 1, 1, 1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1;
-  Eigen::VectorXd a_weight(robot.dimv());
-  a_weight << 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01;
-  idocp::TrottingSwingAngles swing_angles;
-  swing_angles.front_swing_knee = 1.7;
-  swing_angles.hip_swing_knee = 1.7;
-  auto config_cost = std::make_shared<idocp::TrottingConfigurationSpaceCost>(robot);
-  config_cost->set_ref(t_start, t_period, q_standing, step_length, swing_angles);
-  config_cost->set_q_weight(q_weight);
-  config_cost->set_qf_weight(q_weight);
-  config_cost->set_qi_weight(q_weight);
-  config_cost->set_v_weight(v_weight);
-  config_cost->set_vf_weight(v_weight);
-  config_cost->set_vi_weight(v_weight);
-  config_cost->set_a_weight(a_weight);
-  config_cost->set_dvi_weight(a_weight);
-  cost->push_back(config_cost);
-  auto contact_cost = std::make_shared<idocp::ContactForceCost>(robot);
-  std::vector<Eigen::Vector3d> f_weight(contact_frames.size(), Eigen::Vector3d(0.001, 0.001, 0.001));
-  contact_cost->set_f_weight(f_weight);
-  contact_cost->set_fi_weight(f_weight);
-  contact_cost->set_f_ref(robot);
-  cost->push_back(contact_cost);
+  cost->push_back(gait_cost);
+  cost->push_back(ex::forceCost(robot, ex::V3(0.001, 0.001, 0.001), true, nullptr));
 
-  auto constraints = std::make_shared<idocp::Constraints>();
-  constraints->push_back(std::make_shared<idocp::JointPositionLowerLimit>(robot));
-  constraints->push_back(std::make_shared<idocp::JointPositionUpperLimit>(robot));
-  constraints->push_back(std::make_shared<idocp::JointVelocityLowerLimit>(robot));
-  constraints->push_back(std::make_shared<idocp::JointVelocityUpperLimit>(robot));
-  constraints->push_back(std::make_shared<idocp::JointTorquesLowerLimit>(robot));
-  constraints->push_back(std::make_shared<idocp::JointTorquesUpperLimit>(robot));
-  const double mu = 0.7;
-  constraints->push_back(std::make_shared<idocp::LinearizedFrictionCone>(robot, mu));
-  constraints->push_back(std::make_shared<idocp::LinearizedImpulseFrictionCone>(robot, mu));
+  idocp::OCPSolver solver(robot, cost, ex::jointLimits(robot, 0.7, true), t0 + touch_downs * period + 0.05, horizon, touch_downs + 1, 4);
 
-  const double T = 1.55;   // t_start + max_num_impulse_phase * t_period + 0.05
-  const int N = 30;
-  const int max_num_impulse_phase = 2;
-  const int nthreads = 4;
-  const double t = 0;
-  idocp::OCPSolver ocp_solver(robot, cost, constraints, T, N, max_num_impulse_phase + 1, nthreads);
-
-  robot.updateFrameKinematics(q_standing);
-  std::vector<Eigen::Vector3d> contact_points(robot.maxPointContacts(), Eigen::Vector3d::Zero());
-  robot.getContactPoints(contact_points);
-  auto contact_status_initial = robot.createContactStatus();
-  contact_status_initial.activateContacts({0, 1, 2, 3});
-  contact_status_initial.setContactPoints(contact_points);
-  ocp_solver.setContactStatusUniformly(contact_status_initial);
-
-  auto contact_status_even = robot.createContactStatus();
-  contact_status_even.activateContacts({1, 2});
-  contact_status_even.setContactPoints(contact_points);
-  ocp_solver.pushBackContactStatus(contact_status_even, t_start);
-
-  auto contact_status_odd = robot.createContactStatus();
-  contact_points[0].coeffRef(0) += 0.5 * step_length;
-  contact_points[3].coeffRef(0) += 0.5 * step_length;
-  contact_status_odd.activateContacts({0, 3});
-  contact_status_odd.setContactPoints(contact_points);
-  ocp_solver.pushBackContactStatus(contact_status_odd, t_start + t_period);
-
-  for (int i = 2; i <= max_num_impulse_phase; ++i) {
-    if (i % 2 == 0) {
-      contact_points[1].coeffRef(0) += step_length;
-      contact_points[2].coeffRef(0) += step_length;
-      contact_status_even.setContactPoints(contact_points);
-      ocp_solver.pushBackContactStatus(contact_status_even, t_start + i * t_period);
-    } else {
-      contact_points[0].coeffRef(0) += step_length;
-      contact_points[3].coeffRef(0) += step_length;
-      contact_status_odd.setContactPoints(contact_points);
-      ocp_solver.pushBackContactStatus(contact_status_odd, t_start + i * t_period);
-    }
+  // diagonal pairs alternate; the first swing covers half a step
+  ex::Schedule gait(ex::footholds(robot, stand));
+  gait.add({0, 1, 2, 3}, 0.0);
+  gait.add({1, 2}, t0);
+  for (int k = 1; k <= touch_downs; ++k) {
+    const bool lf_rh_land = (k % 2 == 1);
+    if (lf_rh_land) { gait.advance({0, 3}, k == 1 ? 0.5 * step : step); gait.add({0, 3}, t0 + k * period); }
+    else { gait.advance({1, 2}, step); gait.add({1, 2}, t0 + k * period); }
   }
+  gait.install(solver, robot);
 
-  Eigen::VectorXd q = q_standing;
-  Eigen::VectorXd v = Eigen::VectorXd::Zero(robot.dimv());
-  ocp_solver.setSolution("q", q);
-  ocp_solver.setSolution("v", v);
-  Eigen::Vector3d f_init(0, 0, 0.25 * robot.totalWeight());
-  ocp_solver.setSolution("f", f_init);
-  ocp_solver.initConstraints(t);
-
-  const bool line_search = false;
-  idocp::ocpbenchmarker::Convergence(ocp_solver, t, q, v, 25, line_search);
+  ex::restingGuess(solver, robot, stand);
+  solver.initConstraints(0.0);
+  idocp::ocpbenchmarker::Convergence(solver, 0.0, stand, ex::Vec::Zero(robot.dimv()), 25, false);
   return 0;
 }

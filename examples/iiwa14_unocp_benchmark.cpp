@@ -1,46 +1,31 @@
-// Driver for the drop-in facade: the workload of the reference's
-// examples/iiwa14/unocp_benchmark.cpp (same public API calls), running on the
-// HIP path.  Build: make -C examples.   Usage: ./iiwa14_unocp_benchmark <urdf>
-#include <iostream>
-#include <memory>
-#include <string>
-
+// iiwa14 reaching, idocp::UnOCPSolver on the HIP path: convergence and time per update.
+// Workload: the one of the reference's examples/iiwa14/unocp_benchmark.cpp (configuration-space cost pulling every joint
+// towards -5 rad at -9 rad/s, joint limits with 200 Nm torque limits; N = 20, T = 1, start at 2 rad on every joint).
+//   usage: iiwa14_unocp_benchmark [iiwa14.urdf]
+#include "common.hpp"
 #include "idocp/cost/configuration_space_cost.hpp"
-#include "idocp/cost/cost_function.hpp"
-#include "idocp/robot/robot.hpp"
 #include "idocp/unocp/unocp_solver.hpp"
 #include "idocp/utils/joint_constraints_factory.hpp"
-#include "idocp/utils/ocp_benchmarker.hpp"
 
 int main(int argc, char** argv) {
-  const std::string path_to_urdf = argc > 1 ? argv[1] : "tests/golden/urdf/iiwa14.urdf";
-  idocp::Robot robot(path_to_urdf);
-  robot.setJointEffortLimit(Eigen::VectorXd::Constant(robot.dimu(), 200));
+  idocp::Robot robot(argc > 1 ? argv[1] : "tests/golden/urdf/iiwa14.urdf");
+  const int n = robot.dimv();
+  robot.setJointEffortLimit(ex::filled(robot.dimu(), 200));
+  auto reach = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
+  reach->set_q_ref(ex::filled(n, -5));
+  reach->set_v_ref(ex::filled(n, -9));
+  ex::attachWeights(*reach, ex::filled(n, 10), ex::filled(n, 0.1), ex::filled(n, 0.01), false);
+  reach->set_u_weight(ex::filled(n, 0.0));
   auto cost = std::make_shared<idocp::CostFunction>();
-  auto config_cost = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
-  config_cost->set_q_ref(Eigen::VectorXd::Constant(robot.dimv(), -5));
-  config_cost->set_v_ref(Eigen::VectorXd::Constant(robot.dimv(), -9));
-  config_cost->set_q_weight(Eigen::VectorXd::Constant(robot.dimv(), 10));
-  config_cost->set_qf_weight(Eigen::VectorXd::Constant(robot.dimv(), 10));
-  config_cost->set_v_weight(Eigen::VectorXd::Constant(robot.dimv(), 0.1));
-  config_cost->set_vf_weight(Eigen::VectorXd::Constant(robot.dimv(), 0.1));
-  config_cost->set_a_weight(Eigen::VectorXd::Constant(robot.dimv(), 0.01));
-  config_cost->set_u_weight(Eigen::VectorXd::Constant(robot.dimv(), 0.0));
-  cost->push_back(config_cost);
-  idocp::JointConstraintsFactory constraints_factory(robot);
-  auto constraints = constraints_factory.create();
+  cost->push_back(reach);
 
-  const double T = 1;
-  const int N = 20;
-  const int nthreads = 4;
-  const double t = 0;
-  const Eigen::VectorXd q = Eigen::VectorXd::Constant(robot.dimq(), 2);
-  const Eigen::VectorXd v = Eigen::VectorXd::Zero(robot.dimv());
-  idocp::UnOCPSolver ocp_solver(robot, cost, constraints, T, N, nthreads);
-  ocp_solver.setSolution("q", q);
-  ocp_solver.setSolution("v", v);
-  idocp::ocpbenchmarker::Convergence(ocp_solver, t, q, v, 50, false);
-  idocp::ocpbenchmarker::CPUTime(ocp_solver, t, q, v, 1000, false);
-  std::cout << "q at the terminal stage: " << ocp_solver.getSolution(N).q << std::endl;
+  const int horizon = 20;
+  idocp::UnOCPSolver solver(robot, cost, idocp::JointConstraintsFactory(robot).create(), 1.0, horizon, 4);
+  const ex::Vec q = ex::filled(robot.dimq(), 2), v = ex::Vec::Zero(n);
+  solver.setSolution("q", q);
+  solver.setSolution("v", v);
+  idocp::ocpbenchmarker::Convergence(solver, 0.0, q, v, 50, false);
+  idocp::ocpbenchmarker::CPUTime(solver, 0.0, q, v, 1000, false);
+  std::cout << "q at the terminal stage: " << solver.getSolution(horizon).q << std::endl;
   return 0;
 }
