@@ -50,10 +50,13 @@ __device__ __forceinline__ double frictionJacEntry(double mu, int r, int x) {
   return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
 }
 
-template <typename D>
+// SFP: number of contact rows the LDS blocks are laid out for (= leading dimension of J, Qff, BL, SM; NV + SFP for the
+// (a, f)-sized blocks).  D::NF in general; the instantiations with a compile-time contact count use that count, which
+// takes the footprint from 38.7 kB (12 rows) to 30.9 kB (6 rows): a fifth workgroup per CU.
+template <typename D, int SFP = D::NF>
 struct CondenseSmem {
   using L = OcpLayout<D>;
-  static constexpr int NV = D::NV, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU;
+  static constexpr int NV = D::NV, NX = D::NX, NF = SFP, NVF = D::NV + SFP, NU = D::NU;
   // matrices.  Aliases (lifetimes in the kernel body):
   //   MINV  = MM            the mass matrix is inverted in place (scratch: MJ, not yet written)
   //   QAFQV = DIDC          dIDCdqv is dead once MJD = MJtJinv * dIDCdqv is formed
@@ -84,11 +87,12 @@ struct CondenseSmem {
 // FQ6 = (q_prev (-) q).head(6) (parnmpc_lie_kernel).  The chain ends with an unused placeholder stage; the last real
 // stage (position M - 2) carries the terminal cost.
 template <typename D, bool RESIDUAL, int DIMF, bool BWD = false>
-__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
+__global__ __launch_bounds__(256, (DIMF > 0 && DIMF < D::NF) ? 5 : 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
-  using S = CondenseSmem<D>;
+  using S = CondenseSmem<D, (DIMF > 0) ? DIMF : D::NF>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
+  constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>); NF / NVF: the HBM records'
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
@@ -135,12 +139,18 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // ---- A. load the lin record, clear the accumulators ----
   if (!terminal) {
     const double* __restrict__ lin = B.lin + su * L::LIN;
-    for (int e = tid; e < NVF * NX + NV * NV + NF * NV; e += nt) sm[S::DIDC + e] = lin[e];       // DIDC, MM, JM are contiguous in both
-    if (tid < NVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
+    if (SF == NF) {
+      for (int e = tid; e < NVF * NX + NV * NV + NF * NV; e += nt) sm[S::DIDC + e] = lin[e];     // DIDC, MM, JM are contiguous in both
+    } else {                                                                                     // narrower LDS blocks: column by column
+      for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; sm[S::DIDC + e] = lin[L::L_DIDC + r + NVF * c]; }
+      for (int e = tid; e < NV * NV; e += nt) sm[S::MM + e] = lin[L::L_M + e];
+      for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
+    }
+    if (tid < SVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
   }
   for (int e = tid; e < L::SOL; e += nt) { sm[S::SOLS + e] = s_g[e]; if (!terminal) sm[S::SOLN + e] = sn_g[e]; }     // this and the next stage of the chain
   if (!terminal) for (int e = tid; e < L::CON; e += nt) { sm[S::SLK + e] = B.slack[su * L::CON + e]; sm[S::DUL + e] = B.dual[su * L::CON + e]; }
-  for (int e = tid; e < NF * NF; e += nt) sm[S::QFF + e] = 0.0;
+  for (int e = tid; e < SF * SF; e += nt) sm[S::QFF + e] = 0.0;
   if (tid == 0) s_ok = 1;
   STAMP(1);
   // ---- B. Lie-group terms of the floating base (from ocp_lie_kernel) ----
@@ -258,9 +268,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       }
     }
     // multipliers of [ID; C]:  l += dt [dID;dC]^T [beta; mu]
-    const double dq = dotAny(&sm[S::DIDC + NVF * r], 1, &sm[S::BM], 1, dimvf);
-    const double dv = dotAny(&sm[S::DIDC + NVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
-    const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + NF * r], 1, &sm[S::BM + NV], 1, dimf);
+    const double dq = dotAny(&sm[S::DIDC + SVF * r], 1, &sm[S::BM], 1, dimvf);
+    const double dv = dotAny(&sm[S::DIDC + SVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
+    const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + SF * r], 1, &sm[S::BM + NV], 1, dimf);
     lq += dt * dq; lv += dt * dv; la += dt * da;
     // ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:49-51): + Phi^T xi
     if (sw_dimi > 0) {
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         f[x] = s[L::S_F + 3 * c + x];
         const double wf = impulse ? P->fi_weight[c][x] : P->f_weight[c][x], rf = impulse ? P->fi_ref[c][x] : P->f_ref[c][x];
         lf[x] = dt * wf * (f[x] - rf);
-        if (!RESIDUAL) sm[S::QFF + (row + x) + NF * (row + x)] = dt * wf;
+        if (!RESIDUAL) sm[S::QFF + (row + x) + SF * (row + x)] = dt * wf;
       }
       if (ocpRowValid(P, 6, i, impulse)) {
         double dd[5];
@@ -334,13 +344,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
           for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) {
             double acc = 0.0;
             for (int r = 0; r < 5; ++r) acc += frictionJacEntry(P->mu, r, x) * dd[r] * frictionJacEntry(P->mu, r, y);
-            sm[S::QFF + (row + x) + NF * (row + y)] += dt * acc;
+            sm[S::QFF + (row + x) + SF * (row + y)] += dt * acc;
           }
         }
       }
       for (int x = 0; x < 3; ++x) {
         double jb = 0.0;
-        for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + NF * col] * s[L::S_BETA + col];
+        for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + SF * col] * s[L::S_BETA + col];
         lf[x] -= dt * jb;
         sm[S::LF + row + x] = lf[x];
         if (RESIDUAL) { const double cr = sm[S::IDC + NV + row + x]; err_local += lf[x] * lf[x] + dt * dt * cr * cr; }
@@ -401,53 +411,53 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   STAMP(5);
   if (dimf > 0) {
-    mm(colMajor(&sm[S::BL], NF), colMajor(&sm[S::JM], NF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
+    mm(colMajor(&sm[S::BL], SF), colMajor(&sm[S::JM], SF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
     __syncthreads();
-    mm(colMajor(&sm[S::SM], NF), colMajor(&sm[S::BL], NF), transposed(colMajor(&sm[S::JM], NF)), dimf, dimf, NV, 1.0, false, tid, nt);
+    mm(colMajor(&sm[S::SM], SF), colMajor(&sm[S::BL], SF), transposed(colMajor(&sm[S::JM], SF)), dimf, dimf, NV, 1.0, false, tid, nt);
     __syncthreads();
-    if (tid < 64) spdInverseRows<NF>(&sm[S::SM], NF, dimf, tid, &s_ok);      // SM = (J Minv J^T)^-1
+    if (tid < 64) spdInverseRows<SF>(&sm[S::SM], SF, dimf, tid, &s_ok);      // SM = (J Minv J^T)^-1
     __syncthreads();
     // TR = BL^T SM -> MJ top-right ; its transpose -> bottom-left ; -SM -> bottom-right
-    mm(sub(colMajor(&sm[S::MJ], NVF), 0, NV), transposed(colMajor(&sm[S::BL], NF)), colMajor(&sm[S::SM], NF), NV, dimf, dimf, 1.0, false, tid, nt);
+    mm(sub(colMajor(&sm[S::MJ], SVF), 0, NV), transposed(colMajor(&sm[S::BL], SF)), colMajor(&sm[S::SM], SF), NV, dimf, dimf, 1.0, false, tid, nt);
     __syncthreads();
-    for (int e = tid; e < dimf * NV; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * c] = sm[S::MJ + c + NVF * (NV + r)]; }
-    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + NVF * (NV + c)] = -sm[S::SM + r + NF * c]; }
+    for (int e = tid; e < dimf * NV; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * c] = sm[S::MJ + c + SVF * (NV + r)]; }
+    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
     __syncthreads();
   }
   STAMP(6);
   // TL = Minv - TR BL
   for (int e = tid; e < NV * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;
-    sm[S::MJ + r + NVF * c] = sm[S::MINV + e] - dotAny(&sm[S::MJ + r + NVF * NV], NVF, &sm[S::BL + NF * c], 1, dimf);
+    sm[S::MJ + r + SVF * c] = sm[S::MINV + e] - dotAny(&sm[S::MJ + r + SVF * NV], SVF, &sm[S::BL + SF * c], 1, dimf);
   }
   __syncthreads();
 
   const double hu = (PLAIN || nd->has_u) ? 1.0 : 0.0;          // impulse stages have no torque variables: Qafu = 0, Fvu = 0
   STAMP(7);
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
-  if ((dimvf & 1) == 0) mmTN22(&sm[S::MJD], NVF, &sm[S::MJ], NVF, &sm[S::DIDC], NVF, dimvf, NX, dimvf, 1.0, false, tid, nt);   // MJ symmetric
-  else mm(colMajor(&sm[S::MJD], NVF), colMajor(&sm[S::MJ], NVF), colMajor(&sm[S::DIDC], NVF), dimvf, NX, dimvf, 1.0, false, tid, nt);
-  mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], NVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
+  if ((dimvf & 1) == 0) mmTN22(&sm[S::MJD], SVF, &sm[S::MJ], SVF, &sm[S::DIDC], SVF, dimvf, NX, dimvf, 1.0, false, tid, nt);   // MJ symmetric
+  else mm(colMajor(&sm[S::MJD], SVF), colMajor(&sm[S::MJ], SVF), colMajor(&sm[S::DIDC], SVF), dimvf, NX, dimvf, 1.0, false, tid, nt);
+  mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], SVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
   __syncthreads();
   for (int e = tid; e < dimvf * NX; e += nt) {
     const int c = e / dimvf, r = e - c * dimvf;
     double val;
-    if (r < NV) val = -sm[S::QAA + r] * sm[S::MJD + r + NVF * c];
-    else val = -dotAny(&sm[S::QFF + (r - NV)], NF, &sm[S::MJD + NV + NVF * c], 1, dimf);
-    sm[S::QAFQV + r + NVF * c] = val;
+    if (r < NV) val = -sm[S::QAA + r] * sm[S::MJD + r + SVF * c];
+    else val = -dotAny(&sm[S::QFF + (r - NV)], SF, &sm[S::MJD + NV + SVF * c], 1, dimf);
+    sm[S::QAFQV + r + SVF * c] = val;
   }
   for (int e = tid; e < dimvf * NV; e += nt) {
     const int c = e / dimvf, r = e - c * dimvf;
     double val;
-    if (r < NV) val = sm[S::QAA + r] * sm[S::MJ + r + NVF * c];
-    else val = dotAny(&sm[S::QFF + (r - NV)], NF, &sm[S::MJ + NV + NVF * c], 1, dimf);
-    sm[S::QAFU + r + NVF * c] = hu * val;
+    if (r < NV) val = sm[S::QAA + r] * sm[S::MJ + r + SVF * c];
+    else val = dotAny(&sm[S::QFF + (r - NV)], SF, &sm[S::MJ + NV + SVF * c], 1, dimf);
+    sm[S::QAFU + r + SVF * c] = hu * val;
   }
   if (tid < dimvf) {
     const int r = tid;
     double val;
     if (r < NV) val = sm[S::LA + r] - sm[S::QAA + r] * sm[S::MJIDC + r];
-    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + NF * p] * sm[S::MJIDC + NV + p]; val = -sm[S::LF + r - NV] - acc; }
+    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + SF * p] * sm[S::MJIDC + NV + p]; val = -sm[S::LF + r - NV] - acc; }
     sm[S::LAF + r] = val;
   }
   __syncthreads();
@@ -455,26 +465,26 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // ---- H. condensed Hessian / gradients / dynamics (contact_dynamics.hxx:129-157) ----
   // Qxx = (cost + IPM terms) - MJD^T Qafqv ; Qxu_full = -MJD^T Qafu_full ; Quu_full = diag + MJ.topRows^T Qafu_full.
   // The products go straight to the kkt / exp records.
-  mmTN22Epi(&sm[S::MJD], NVF, &sm[S::QAFQV], NVF, NX, NX, dimvf, tid, nt, [&](int r, int c, double v) {
+  mmTN22Epi(&sm[S::MJD], SVF, &sm[S::QAFQV], SVF, NX, NX, dimvf, tid, nt, [&](int r, int c, double v) {
     double base = 0.0;
     if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
     else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
     kk[L::K_QXX + r + NX * c] = base - v;
   });
-  mmTN22Epi(&sm[S::MJD], NVF, &sm[S::QAFU], NVF, NX, NV, dimvf, tid, nt, [&](int r, int c, double v) {
+  mmTN22Epi(&sm[S::MJD], SVF, &sm[S::QAFU], SVF, NX, NV, dimvf, tid, nt, [&](int r, int c, double v) {
     if (c < 6) ee[L::E_QXUP + r + NX * c] = -v;            // passive columns of Qxu_full
     else kk[L::K_QXU + r + NX * (c - 6)] = -v;
   });
-  mmTN22Epi(&sm[S::MJ], NVF, &sm[S::QAFU + NVF * 6], NVF, NV, NU, dimvf, tid, nt, [&](int r, int c, double v) {      // MJ symmetric
+  mmTN22Epi(&sm[S::MJ], SVF, &sm[S::QAFU + SVF * 6], SVF, NV, NU, dimvf, tid, nt, [&](int r, int c, double v) {      // MJ symmetric
     if (r < 6) ee[L::E_QUUP + r + 6 * c] = v;              // Quu_passive_topRight
     else kk[L::K_QUU + (r - 6) + NU * c] = v + ((r - 6 == c) ? sm[S::HUD + c] : 0.0);
   });
   if (tid < NX) {                                   // lx -= MJD^T laf
-    const double acc = dotAny(&sm[S::MJD + NVF * tid], 1, &sm[S::LAF], 1, dimvf);
+    const double acc = dotAny(&sm[S::MJD + SVF * tid], 1, &sm[S::LAF], 1, dimvf);
     if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;
   } else if (tid >= 64 && tid < 64 + NV) {          // [lu_passive; lu] += MJ.topRows(NV) laf ; Fv -= dt MJIDC
     const int r = tid - 64;
-    const double acc = hu * dotAny(&sm[S::MJ + r], NVF, &sm[S::LAF], 1, dimvf);
+    const double acc = hu * dotAny(&sm[S::MJ + r], SVF, &sm[S::LAF], 1, dimvf);
     if (r < 6) sm[S::LUP + r] += acc; else sm[S::LU + r - 6] += acc;
     sm[S::FV + r] -= dt * sm[S::MJIDC + r];
   }
@@ -484,20 +494,25 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // ---- I. write the kkt and exp records ----
   for (int e = tid; e < NV * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;
-    kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + NVF * c];
-    kk[L::K_FVV + e] = -dt * sm[S::MJD + r + NVF * (NV + c)] + (r == c ? (BWD ? -1.0 : 1.0) : 0.0);
+    kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + SVF * c];
+    kk[L::K_FVV + e] = -dt * sm[S::MJD + r + SVF * (NV + c)] + (r == c ? (BWD ? -1.0 : 1.0) : 0.0);
   }
-  for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = hu * dt * sm[S::MJ + r + NVF * (6 + c)]; }
+  for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = hu * dt * sm[S::MJ + r + SVF * (6 + c)]; }
   if (tid < NV) {
     kk[L::K_LX + tid] = sm[S::LQ + tid]; kk[L::K_LX + NV + tid] = sm[S::LV + tid];
     kk[L::K_FX + tid] = sm[S::FQ + tid]; kk[L::K_FX + NV + tid] = sm[S::FV + tid];
   }
   if (tid < NU) kk[L::K_LU + tid] = sm[S::LU + tid];
-  for (int e = tid; e < NVF * NVF; e += nt) ee[L::E_MJ + e] = sm[S::MJ + e];
-  for (int e = tid; e < NVF * NX; e += nt) ee[L::E_MJD + e] = sm[S::MJD + e];
+  if (SF == NF) {
+    for (int e = tid; e < NVF * NVF; e += nt) ee[L::E_MJ + e] = sm[S::MJ + e];
+    for (int e = tid; e < NVF * NX; e += nt) ee[L::E_MJD + e] = sm[S::MJD + e];
+  } else {
+    for (int e = tid; e < SVF * SVF; e += nt) { const int c = e / SVF, r = e - c * SVF; ee[L::E_MJ + r + NVF * c] = sm[S::MJ + e]; }
+    for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; ee[L::E_MJD + r + NVF * c] = sm[S::MJD + e]; }
+  }
   if (tid < NV) ee[L::E_QAA + tid] = sm[S::QAA + tid];
-  for (int e = tid; e < NF * NF; e += nt) ee[L::E_QFF + e] = sm[S::QFF + e];
-  if (tid < NVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
+  for (int e = tid; e < SF * SF; e += nt) { const int c = e / SF, r = e - c * SF; ee[L::E_QFF + r + NF * c] = sm[S::QFF + e]; }
+  if (tid < SVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
   // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199) ----
   if (sw_dimi > 0) {
@@ -506,13 +521,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     for (int e = tid; e < dimi * NX; e += nt) {           // Phix -= Phia MJtJinv_dIDCdqv.topRows(nv)
       const int c = e / dimi, j = e - c * dimi;
       double acc = 0.0;
-      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + j + NF * m2] * sm[S::MJD + m2 + NVF * c];
+      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + j + NF * m2] * sm[S::MJD + m2 + SVF * c];
       W[L::W_PHIX + j + NF * c] -= acc;
     }
     for (int e = tid; e < dimi * NU; e += nt) {           // Phiu = Phia MJtJinv.block(0, 6, nv, nu)
       const int c = e / dimi, j = e - c * dimi;
       double acc = 0.0;
-      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + j + NF * m2] * sm[S::MJ + m2 + NVF * (6 + c)];
+      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + j + NF * m2] * sm[S::MJ + m2 + SVF * (6 + c)];
       W[L::W_PHIU + j + NF * c] = acc;
     }
     if (tid < dimi) {                                     // P -= Phia MJtJinv_IDC.head(nv)
@@ -650,19 +665,19 @@ void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, co
 // stage) on the general instantiation.  B.cond_pos holds the chain positions class by class, n[c] their counts.
 template <typename D>
 void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[3], const double* q0, hipStream_t st) {
-  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
+  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double), smem_half = CondenseSmem<D, D::NF / 2>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
   // the largest class first; the launches are independent (every stage writes its own records)
-  if (n[1] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0], n[1]);
+  if (n[1] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]);
   if (n[0] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]);
   if (n[2] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]);
 }
