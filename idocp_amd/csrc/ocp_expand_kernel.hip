@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B) {
 }
 
 template <typename D>
-__global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
   __shared__ double dx[NX], du[NU], dfs[NF], laf[NVF + 2], dbm[NVF + 2], dlh[6];
