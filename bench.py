@@ -322,6 +322,41 @@ def run_parnmpc(args, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with
+    torch.distributed.run and hand back their exit code.  Called BEFORE this process imports torch or makes any
+    HIP call -- a process that has initialised the GPU must never be replaced or forked into ranks.  The ranks
+    inherit stdout, so rank 0's JSON line is this command's output."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd).returncode
+
+
+def run_stub(args, rank, world, dist):
+    """Test scaffolding (IDOCP_BENCH_STUB=1, tests/test_bench_dist.py): the launcher, the rendezvous, the timing protocol
+    and the JSON line of the replicas path with a stand-in step that needs no GPU (backend from IDOCP_BENCH_BACKEND)."""
+    B = args.batch or 8
+    a = np.ones((64, 64))
+
+    def step(_events):
+        np.dot(a, a)
+        time.sleep(0.002 * (1 + rank))
+
+    el = run_timed(step, lambda: None, args.steps, args.warmup, dist, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": whole_job_value(world, B, args.steps, el), "unit": "SQP iterations/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "scaling": "weak",
+                          "config": {"workload": "stub (no GPU)", "batch_per_gpu": B}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 class _NoDist:
     """world = 1: the driver never communicates"""
     class ReduceOp:
@@ -345,12 +380,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N`: this process has not touched the GPU (numpy / ctypes only so far); it becomes the launcher
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    backend = os.environ.get("IDOCP_BENCH_BACKEND", "nccl")
     dist = None
     if world > 1 or os.environ.get("IDOCP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL scaffolding on one GPU
-        dist = init_distributed("nccl", local_rank)
+        dist = init_distributed(backend, local_rank)
+    if os.environ.get("IDOCP_BENCH_STUB"):
+        return run_stub(args, rank, world, dist)
 
     if args.workload in ("anymal_parnmpc", "anymal_parnmpc_trotting"):
         return run_parnmpc(args, rank, local_rank, world, dist)

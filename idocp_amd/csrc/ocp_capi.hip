@@ -546,6 +546,12 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
   if (max_num_impulse < 0) { set_last_error("invalid value: max_num_impulse must be non-negative!"); return IDOCP_E_ARG; }
   if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
+  // ConstraintComponentBase::setBarrier / setFractionToBoundaryRate (constraint_component_base.hxx:10-24) assert these; a
+  // non-positive barrier would make the slack initialisation (pdipm.hxx:13-24) loop forever on the device
+  if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }
+  if (!(constraints->fraction_to_boundary_rate > 0 && constraints->fraction_to_boundary_rate <= 1)) {
+    set_last_error("invalid value: fraction_to_boundary_rate must be in (0, 1]!"); return IDOCP_E_ARG;
+  }
   if (!isQuadruped(*model)) {
     set_last_error("idocp_ocp_create: this build carries OCP kernels for a floating-base quadruped (4 legs x 3 joints, 4 point contacts) only");
     return IDOCP_E_UNSUPPORTED;

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
     }
     if (valid) {
       sl = -g;
-      while (sl < P->barrier) sl += P->barrier;
+      for (int it = 0; it < (1 << 26) && sl < P->barrier; ++it) sl += P->barrier;      // pdipm.hxx:17-20, bounded
       dl = P->barrier / sl;
     }
     B.slack[su * L::CON + row] = sl;

@@ -157,6 +157,10 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   if (!(T > 0)) { set_last_error("invalid value: T must be positive!"); return IDOCP_E_ARG; }
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
   if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
+  if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }      // constraint_component_base.hxx:10-24
+  if (!(constraints->fraction_to_boundary_rate > 0 && constraints->fraction_to_boundary_rate <= 1)) {
+    set_last_error("invalid value: fraction_to_boundary_rate must be in (0, 1]!"); return IDOCP_E_ARG;
+  }
   if (model->has_floating_base) { set_last_error("robot has floating base: robot should have no constraints!"); return IDOCP_E_ARG; }
   if (model->ncontacts > 0) { set_last_error("robot can have contacts: robot should have no constraints!"); return IDOCP_E_ARG; }
   if (!isRevoluteChain(*model, 7)) {

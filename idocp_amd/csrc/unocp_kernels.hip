@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64) void un_init_constraints_kernel(UnBuffers B) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
       const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
       sl = -sgn * (x - limitOf(P, c, r));
-      while (sl < P->barrier) sl += P->barrier;
+      for (int it = 0; it < (1 << 26) && sl < P->barrier; ++it) sl += P->barrier;      // pdipm.hxx:17-20, bounded
       dl = P->barrier / sl;
     }
     B.slack[su * L::CON + c * NV + r] = sl;

@@ -67,3 +67,26 @@ def test_whole_job_value_weak_scaling():
     import bench
     assert bench.whole_job_value(1, 1024, 10, 0.5) == 1024 * 10 / 0.5
     assert bench.whole_job_value(8, 1024, 10, 0.5) == 8 * bench.whole_job_value(1, 1024, 10, 0.5)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` (no launcher, no RANK in the environment) must start two ranks itself, rendezvous,
+    and print ONE JSON line with n_gpus == 2 (gloo + a stand-in step: no GPU here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IDOCP_BENCH_STUB="1", IDOCP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
+    assert out["ms_per_step"] >= 4.0 * 0.9            # bounded below by the slower rank (2 x 2 ms)
+    assert abs(out["value"] - 2 * 8 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_rejects_mismatched_world():
+    """Started under a launcher with a world size that contradicts --gpus: fail loudly instead of printing n_gpus of the flag."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", IDOCP_BENCH_STUB="1", IDOCP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

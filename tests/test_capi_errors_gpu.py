@@ -121,3 +121,27 @@ def test_fixed_base_solver_argument_errors():
     q, v = np.full(m.nv, 1.0), np.zeros(m.nv)
     assert lib.idocp_unparnmpc_update_solution(sh, 0.0, P(arr(q)), P(arr(v)), 1) == E_UNSUPPORTED
     lib.idocp_unocp_destroy(sh)
+
+
+def test_interior_point_parameters_are_validated():
+    """A zeroed idocp_constraints_t (barrier = 0) or a rate outside (0, 1] is rejected at create
+    (ConstraintComponentBase::setBarrier / setFractionToBoundaryRate assert the same, constraint_component_base.hxx:10-24):
+    on the device `while (slack < barrier) slack += barrier` (pdipm.hxx:17-20) would never end."""
+    import copy
+    from helpers import iiwa14_model, unocp_problem
+    lib = capi.lib()
+    h = C.c_void_p()
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    for barrier, rate in ((0.0, 0.995), (-1e-4, 0.995), (1e-4, 0.0), (1e-4, 1.5), (float("nan"), 0.995)):
+        bad = copy.copy(cons)
+        bad.barrier, bad.fraction_to_boundary_rate = barrier, rate
+        assert lib.idocp_ocp_create_hybrid(C.byref(m), C.byref(cost), C.byref(bad), 1.0, 20, 0, 1, 0, C.byref(h)) == E_ARG
+        assert ("barrier" in capi.last_error()) or ("fraction_to_boundary_rate" in capi.last_error())
+    mi = iiwa14_model()
+    costi, consi = unocp_problem(mi)
+    for fn in (lib.idocp_unocp_create, lib.idocp_unparnmpc_create):
+        bad = copy.copy(consi)
+        bad.barrier = 0.0
+        assert fn(C.byref(mi), C.byref(costi), C.byref(bad), 1.0, 10, 1, 0, C.byref(h)) == E_ARG
+        assert "barrier" in capi.last_error()
