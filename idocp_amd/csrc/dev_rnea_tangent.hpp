@@ -1,0 +1,398 @@
+// Inverse dynamics + contact (Baumgarte) constraint and ALL their derivatives for one stage of a legged robot:
+// ONE nominal Newton-Euler sweep per leg, TANGENT-ONLY sweeps per (seed, leg) item.
+//
+// Replaces the rigid-body part of ContactDynamics::linearizeContactDynamics (include/idocp/ocp/contact_dynamics.hxx:48-102):
+//   robot.updateKinematics(q,v,a); robot.setContactForces; robot.RNEA; robot.RNEADerivatives;
+//   robot.computeBaumgarteResidual / computeBaumgarteDerivatives
+// (include/idocp/robot/robot.hxx:193-203,237-279,408-500; point_contact.hxx:15-144).
+//
+// Round 1 carried a dual number (value, tangent) per lane through the sweep (ocp_rnea_kernel.hip): every lane recomputed the
+// SAME nominal values next to its own tangent -- a third to a half of the FP64 work and half of the 256 VGPRs.  Here the nominal
+// sweep runs once per leg (lane = leg) and leaves a per-joint record in LDS (rotation, motion, momenta, accumulated forces, the
+// model constants of the joint); an item lane then propagates only its tangent, reading the nominal operands as LDS broadcasts:
+//   d(R^T a) = R^T da - dq (u x R^T a),   d(R f) = R (df + dq u x f)        (R = P Rot(u, q): dR/dq = R skew(u))
+// The world pose is not differentiated at all: the only place it enters is the position term of the Baumgarte residual, and
+//   d p_foot(world) / dq_k = R_world,foot (d v_foot / d qdot_k)             (position Jacobian = velocity Jacobian in the local
+// tangent), i.e. (1 / D^2) R_wf Rc J is added to dC/dq after the sweep, with J = dC/da the frame Jacobian the a-seeds emit.
+// The gravity field acceleration a_gf = a - R_w^T g needs the tangent of one row of the world rotation only (dz, 3 doubles).
+// Live tangent state: 15 doubles out, 21 in (was ~130): the sweep fits the 128-VGPR budget of the condensation kernel it is fused into.
+//
+// The Baumgarte derivative keeps THE REFERENCE'S OWN FORMULA (point_contact.hxx:117-143 adds skew(v_lin) d(omega); an exact
+// derivative would subtract it) so that the Newton direction matches the reference, not just the mathematics.
+#ifndef IDOCP_DEV_RNEA_TANGENT_HPP_
+#define IDOCP_DEV_RNEA_TANGENT_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include "dev_rbd.hpp"
+#include "ocp_device.hpp"
+
+namespace idocp_dev {
+
+namespace rt {
+// plain 3-vector helpers on registers
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(double* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// R row-major 3 x 3
+__device__ __forceinline__ V3 mul(const double* R, V3 a) {
+  return v3(R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z, R[6] * a.x + R[7] * a.y + R[8] * a.z);
+}
+__device__ __forceinline__ V3 mulT(const double* R, V3 a) {
+  return v3(R[0] * a.x + R[3] * a.y + R[6] * a.z, R[1] * a.x + R[4] * a.y + R[7] * a.z, R[2] * a.x + R[5] * a.y + R[8] * a.z);
+}
+// Y (v, w) with the inertia about the joint origin: f = m v - mc x w ; n = Io w + mc x v   (inertiaMul of dev_rbd.hpp)
+__device__ __forceinline__ void inertia(double mass, V3 mc, const double* I, V3 v, V3 w, V3& f, V3& n) {
+  f = mass * v - cross(mc, w);
+  const V3 mcxv = cross(mc, v);
+  n = v3(I[0] * w.x + I[1] * w.y + I[2] * w.z + mcxv.x, I[1] * w.x + I[3] * w.y + I[4] * w.z + mcxv.y, I[2] * w.x + I[4] * w.y + I[5] * w.z + mcxv.z);
+}
+}  // namespace rt
+
+// LDS scratch of one stage (doubles).
+template <typename D>
+struct RneaScratch {
+  static constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NJL = NL * LJ;
+  // JOINT record, one per leg joint: rotation R = P Rot(u, q) (row-major), axis, placement translation, the child-frame
+  // motion before the joint's own velocity is added (wc, vc, bwc, blc; zc = R_w,child^T e_z), the joint velocity vJ = u qd,
+  // the body's motion (w, v = vc, bw, bl), momenta hl, hn, the force accumulated up to and including this body (Fl, Fn),
+  // and the inertia constants of the body
+  static constexpr int J_R = 0, J_U = 9, J_P = 12, J_WC = 15, J_VC = 18, J_BWC = 21, J_BLC = 24, J_ZC = 27, J_VJ = 30, J_W = 33, J_BW = 36,
+                       J_BL = 39, J_HL = 42, J_HN = 45, J_FL = 48, J_FN = 51, J_MASS = 54, J_MC = 55, J_IO = 58, JREC = 64;
+  // FOOT record, one per leg: R_world,foot Rc (row-major), local frame velocity fv / angular velocity fw (nominal), the frame
+  // placement (Rc, pc) in the tip joint, the pose-dependent part of the Baumgarte residual, contact flag and first packed row
+  static constexpr int F_RWC = 0, F_FV = 9, F_FW = 12, F_RC = 15, F_PC = 24, F_CP = 27, F_ACT = 30, F_ROW = 31, FREC = 32;
+  // BASE record: z = R_w^T e_z, v, w, momenta hl, hn of the base body, its inertia constants
+  static constexpr int B_Z = 0, B_V = 3, B_W = 6, B_HL = 9, B_HN = 12, B_MASS = 15, B_MC = 16, B_IO = 19, BREC = 26;
+  // inputs of the stage: q, v, a, f
+  static constexpr int I_Q = 0, I_V = NQ + 1, I_A = I_V + NV, I_F = I_A + NV, IREC = I_F + NF;
+  static constexpr int IPL = 18 + 3 * LJ, NITEMS = NL * IPL;
+  static constexpr int JOINTS = 0, FEET = JOINTS + NJL * JREC, BASE = FEET + NL * FREC, INP = BASE + BREC,
+                       BT = INP + IREC,                        // [NITEMS][6] tangent of the force each item's leg transmits to the base
+                       BOWN = BT + NITEMS * 6,                 // [18][6] tangent of the base's own inertial force, per base seed
+                       BN = BOWN + 18 * 6,                     // [NL + 1][6] nominal base force: own, then per leg
+                       TOTAL = BN + (NL + 1) * 6 + 2;
+};
+
+// Where the derivative columns go: [dID; dC] / d(q, v) as one (NV + contact rows) x 2 NV block (leading dimension ldd), dID/da = M
+// (NV x NV), dC/da = J (leading dimension ldj), and the nominal [ID; C].  The LDS blocks of the condensation kernel have this shape.
+struct RneaOut {
+  double* didc; int ldd;     // rows: NV dynamics rows, then the packed contact rows
+  double* mm;                // NV x NV
+  double* jm; int ldj;
+  double* idc;
+};
+
+// ---- setup, all threads: inputs and every constant the sweeps read go to LDS once (the sweeps then touch no global memory);
+// one thread per leg joint evaluates cos / sin and the joint rotation ----
+template <typename D>
+__device__ __forceinline__ void rneaSetup(const DevModel* __restrict__ m, const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd,
+                                          const double* __restrict__ s_g, int tid, double* sc) {
+  using S = RneaScratch<D>;
+  using L = OcpLayout<D>;
+  using namespace rt;
+  constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NJL = NL * LJ;
+  if (tid < NQ) sc[S::INP + S::I_Q + tid] = s_g[L::S_Q + tid];
+  else if (tid >= 32 && tid < 32 + NV) { sc[S::INP + S::I_V + tid - 32] = s_g[L::S_V + tid - 32]; sc[S::INP + S::I_A + tid - 32] = s_g[L::S_A + tid - 32]; }
+  else if (tid >= 64 && tid < 64 + NF) sc[S::INP + S::I_F + tid - 64] = s_g[L::S_F + tid - 64];
+  else if (tid >= 128 && tid < 128 + NJL) {
+    const int t = tid - 128, ji = 1 + t, dof = 6 + t;
+    double* jr = sc + S::JOINTS + t * S::JREC;
+    double sj, cj;
+    sincos(s_g[L::S_Q + dof + 1], &sj, &cj);
+    Mat3<double> Rm;
+    revoluteRotation<double>(m->R[ji], m->axis[ji], cj, sj, Rm);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) jr[S::J_R + e] = Rm.m[e];
+    st3(jr + S::J_U, ld3(m->axis[ji])); st3(jr + S::J_P, ld3(m->p[ji]));
+    jr[S::J_MASS] = m->mass[ji]; st3(jr + S::J_MC, ld3(m->mc[ji]));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) jr[S::J_IO + e] = m->Io[ji][e];
+  } else if (tid >= 192 && tid < 192 + NL) {
+    const int leg = tid - 192;
+    double* fr = sc + S::FEET + leg * S::FREC;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) fr[S::F_RC + e] = P->contact_R[leg][e];
+    st3(fr + S::F_PC, ld3(P->contact_p[leg]));
+    fr[S::F_ACT] = nd->active[leg] ? 1.0 : 0.0;
+    fr[S::F_ROW] = (double)nd->row_of[leg];
+  } else if (tid == 192 + NL) {
+    double* br = sc + S::BASE;
+    br[S::B_MASS] = m->mass[0]; st3(br + S::B_MC, ld3(m->mc[0]));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) br[S::B_IO + e] = m->Io[0][e];
+  }
+}
+
+// world rotation of the base from the quaternion (x y z w)
+__device__ __forceinline__ void rneaBaseRotation(const double* q, double* Rw) {
+  const double x = q[3], y = q[4], z = q[5], w = q[6];
+  Rw[0] = 1 - 2 * (y * y + z * z); Rw[1] = 2 * (x * y - z * w);     Rw[2] = 2 * (x * z + y * w);
+  Rw[3] = 2 * (x * y + z * w);     Rw[4] = 1 - 2 * (x * x + z * z); Rw[5] = 2 * (y * z - x * w);
+  Rw[6] = 2 * (x * z - y * w);     Rw[7] = 2 * (y * z + x * w);     Rw[8] = 1 - 2 * (x * x + y * y);
+}
+
+// ---- nominal sweep, MOTION half: lane `who` < NL walks its leg outward (velocities, accelerations in the gravity field) and back
+// (forces, tau), lane NL does the base body.  Reads LDS only. ----
+template <typename D>
+__device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  using namespace rt;
+  constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV;
+  if (who > NL) return;
+  const double* in = sc + S::INP;
+  const double* sv = in + S::I_V;
+  const double* sa = in + S::I_A;
+  const double qx = in[3], qy = in[4], qz = in[5], qw = in[6];
+  const V3 zb = v3(2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy));      // third row of R_w
+  V3 v = ld3(sv), w = ld3(sv + 3);
+  V3 bl = ld3(sa) - gz * zb, bw = ld3(sa + 3);      // a_gf = a - R^T g
+  if (who == NL) {
+    double* br = sc + S::BASE;
+    V3 hl, hn, f, n;
+    const V3 mc = ld3(br + S::B_MC);
+    inertia(br[S::B_MASS], mc, br + S::B_IO, v, w, hl, hn);
+    inertia(br[S::B_MASS], mc, br + S::B_IO, bl, bw, f, n);
+    st3(br + S::B_Z, zb); st3(br + S::B_V, v); st3(br + S::B_W, w); st3(br + S::B_HL, hl); st3(br + S::B_HN, hn);
+    double* bn = sc + S::BN;
+    st3(bn, f + cross(w, hl)); st3(bn + 3, n + cross(w, hn) + cross(v, hl));
+    return;
+  }
+  const int leg = who;
+#pragma unroll 1
+  for (int j = 0; j < LJ; ++j) {
+    const int dof = 6 + leg * LJ + j;
+    double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const double* R = jr + S::J_R;
+    const V3 p = ld3(jr + S::J_P), u = ld3(jr + S::J_U);
+    const V3 wc = mulT(R, w), vc = mulT(R, v + cross(w, p)), bwc = mulT(R, bw), blc = mulT(R, bl + cross(bw, p));
+    const V3 vJ = sv[dof] * u;
+    w = wc + vJ; v = vc;
+    bw = bwc + sa[dof] * u + cross(w, vJ);
+    bl = blc + cross(v, vJ);
+    st3(jr + S::J_WC, wc); st3(jr + S::J_VC, vc); st3(jr + S::J_BWC, bwc); st3(jr + S::J_BLC, blc);
+    st3(jr + S::J_VJ, vJ); st3(jr + S::J_W, w); st3(jr + S::J_BW, bw); st3(jr + S::J_BL, bl);
+  }
+  // ---- contact frame at the foot (tip joint of this leg): the motion-dependent part of the residual (point_contact.hxx:67-87) ----
+  double* fr = sc + S::FEET + leg * S::FREC;
+  V3 fel = v3(0, 0, 0), fen = fel;
+  if (fr[S::F_ACT] != 0.0) {
+    const double* Rc = fr + S::F_RC;
+    const V3 pc = ld3(fr + S::F_PC);
+    const int row = NV + (int)fr[S::F_ROW];
+    const V3 fv = mulT(Rc, v + cross(w, pc)), fw = mulT(Rc, w), fam = mulT(Rc, bl + cross(bw, pc));      // fam: still in the gravity field
+    const V3 wxv = cross(fw, fv);
+    out.idc[row] = fam.x + wxv.x + wv * fv.x;
+    out.idc[row + 1] = fam.y + wxv.y + wv * fv.y;
+    out.idc[row + 2] = fam.z + wxv.z + wv * fv.z;
+    st3(fr + S::F_FV, fv); st3(fr + S::F_FW, fw);
+    // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
+    fel = mul(Rc, ld3(in + S::I_F + 3 * leg));
+    fen = cross(pc, fel);
+  }
+  // ---- inward sweep: accumulate forces, emit tau ----
+  V3 Fl = v3(0, 0, 0) - fel, Fn = v3(0, 0, 0) - fen;
+#pragma unroll 1
+  for (int j = LJ - 1; j >= 0; --j) {
+    const int dof = 6 + leg * LJ + j;
+    double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), bwj = ld3(jr + S::J_BW), blj = ld3(jr + S::J_BL);
+    const V3 mc = ld3(jr + S::J_MC), u = ld3(jr + S::J_U), p = ld3(jr + S::J_P);
+    V3 hl, hn, f, n;
+    inertia(jr[S::J_MASS], mc, jr + S::J_IO, vj, wj, hl, hn);
+    inertia(jr[S::J_MASS], mc, jr + S::J_IO, blj, bwj, f, n);
+    Fl = Fl + f + cross(wj, hl);
+    Fn = Fn + n + cross(wj, hn) + cross(vj, hl);
+    out.idc[dof] = dot(u, Fn);
+    st3(jr + S::J_HL, hl); st3(jr + S::J_HN, hn); st3(jr + S::J_FL, Fl); st3(jr + S::J_FN, Fn);
+    const V3 Rf = mul(jr + S::J_R, Fl);
+    Fn = mul(jr + S::J_R, Fn) + cross(p, Rf);
+    Fl = Rf;
+  }
+  double* bn = sc + S::BN + 6 * (1 + leg);
+  st3(bn, Fl); st3(bn + 3, Fn);
+}
+
+// ---- nominal sweep, POSE half (runs on another wavefront next to the motion half): world rotation and position along the leg;
+// leaves zc = R_w,child^T e_z per joint and, at the foot, R_wf Rc and the pose-dependent part of the residual
+//   Rc^T (g_z z_f)  [takes the gravity field out of the frame acceleration]  +  (1 / D^2) (p_foot - p_contact) ----
+template <typename D>
+__device__ __forceinline__ void rneaNominalPose(double gz, double wp, const OcpNode* __restrict__ nd, int leg, double* sc) {
+  using S = RneaScratch<D>;
+  using namespace rt;
+  constexpr int NL = D::NL, LJ = D::LJ;
+  if (leg < 0 || leg >= NL) return;
+  const double* in = sc + S::INP;
+  double Rw[9];
+  rneaBaseRotation(in, Rw);
+  V3 pw = ld3(in);
+#pragma unroll 1
+  for (int j = 0; j < LJ; ++j) {
+    double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const double* R = jr + S::J_R;
+    pw = pw + mul(Rw, ld3(jr + S::J_P));
+    double Rn[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Rn[3 * r + c] = Rw[3 * r] * R[c] + Rw[3 * r + 1] * R[3 + c] + Rw[3 * r + 2] * R[6 + c];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rw[e] = Rn[e];
+    st3(jr + S::J_ZC, v3(Rw[6], Rw[7], Rw[8]));
+  }
+  double* fr = sc + S::FEET + leg * S::FREC;
+  if (fr[S::F_ACT] != 0.0) {
+    const double* Rc = fr + S::F_RC;
+    const V3 pf = pw + mul(Rw, ld3(fr + S::F_PC));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) fr[S::F_RWC + 3 * r + c] = Rw[3 * r] * Rc[c] + Rw[3 * r + 1] * Rc[3 + c] + Rw[3 * r + 2] * Rc[6 + c];
+    const V3 g = mulT(Rc, gz * v3(Rw[6], Rw[7], Rw[8]));
+    st3(fr + S::F_CP, v3(g.x + wp * (pf.x - nd->contact_point[leg][0]), g.y + wp * (pf.y - nd->contact_point[leg][1]),
+                         g.z + wp * (pf.z - nd->contact_point[leg][2])));
+  }
+}
+
+// ---- one tangent item = (seed, leg): columns of dID and dC for the rows of this leg, and the base-force tangent ----
+template <typename D>
+__device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  using namespace rt;
+  constexpr int LJ = D::LJ, NV = D::NV;
+  const int leg = item / S::IPL, j0 = item - leg * S::IPL;
+  const bool base_seed = j0 < 18;
+  const int kind = base_seed ? j0 / 6 : (j0 - 18) / LJ;                           // 0: q, 1: v, 2: a
+  const int k = base_seed ? j0 - 6 * kind : 6 + leg * LJ + (j0 - 18 - LJ * kind);   // velocity index of the seed
+  double* __restrict__ colp = (kind < 2) ? out.didc + (long)out.ldd * (kind * NV + k) : out.mm + NV * k;     // dynamics rows of this column
+  double* __restrict__ colc = (kind < 2) ? colp + NV : out.jm + (long)out.ldj * k;                            // its contact rows
+  const double* br = sc + S::BASE;
+  auto e3 = [](int i) { return v3(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0); };
+  const V3 zero = v3(0, 0, 0);
+  // ---- base: tangents of (z, v, w, a_gf linear, a angular) ----
+  V3 dz = (kind == 0 && k >= 3 && k < 6) ? cross(ld3(br + S::B_Z), e3(k - 3)) : zero;      // d(R_w^T e_z) for R_w <- R_w exp(e_ang)
+  V3 dv = (kind == 1 && k < 3) ? e3(k) : zero, dw = (kind == 1 && k >= 3 && k < 6) ? e3(k - 3) : zero;
+  V3 dbl = ((kind == 2 && k < 3) ? e3(k) : zero) - gz * dz, dbw = (kind == 2 && k >= 3 && k < 6) ? e3(k - 3) : zero;
+  if (leg == 0 && base_seed) {
+    // the base's own inertial force: once per base seed
+    V3 dhl, dhn, df, dn;
+    const V3 mc = ld3(br + S::B_MC), w0 = ld3(br + S::B_W), v0 = ld3(br + S::B_V), hl0 = ld3(br + S::B_HL), hn0 = ld3(br + S::B_HN);
+    inertia(br[S::B_MASS], mc, br + S::B_IO, dv, dw, dhl, dhn);
+    inertia(br[S::B_MASS], mc, br + S::B_IO, dbl, dbw, df, dn);
+    double* o = sc + S::BOWN + 6 * j0;
+    st3(o, df + cross(dw, hl0) + cross(w0, dhl));
+    st3(o + 3, dn + cross(dw, hn0) + cross(w0, dhn) + cross(dv, hl0) + cross(v0, dhl));
+  }
+  // ---- outward along the leg ----
+#pragma unroll 1
+  for (int j = 0; j < LJ; ++j) {
+    const int dof = 6 + leg * LJ + j;
+    const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const bool mine = (k == dof);
+    const double sq = (mine && kind == 0) ? 1.0 : 0.0, sv = (mine && kind == 1) ? 1.0 : 0.0, sa = (mine && kind == 2) ? 1.0 : 0.0;
+    const double* R = jr + S::J_R;
+    const V3 u = ld3(jr + S::J_U), p = ld3(jr + S::J_P), vJ = ld3(jr + S::J_VJ);
+    const V3 dwc = mulT(R, dw) - sq * cross(u, ld3(jr + S::J_WC));
+    const V3 dvc = mulT(R, dv + cross(dw, p)) - sq * cross(u, ld3(jr + S::J_VC));
+    const V3 dbwc = mulT(R, dbw) - sq * cross(u, ld3(jr + S::J_BWC));
+    const V3 dblc = mulT(R, dbl + cross(dbw, p)) - sq * cross(u, ld3(jr + S::J_BLC));
+    dz = mulT(R, dz) - sq * cross(u, ld3(jr + S::J_ZC));
+    const V3 dvJ = sv * u;
+    dw = dwc + dvJ; dv = dvc;
+    dbw = dbwc + sa * u + cross(dw, vJ) + cross(ld3(jr + S::J_W), dvJ);
+    dbl = dblc + cross(dv, vJ) + cross(ld3(jr + S::J_VC), dvJ);
+  }
+  // ---- contact frame at the foot: Baumgarte derivative column (point_contact.hxx:117-143) without its position term ----
+  const double* fr = sc + S::FEET + leg * S::FREC;
+  if (fr[S::F_ACT] != 0.0) {
+    const double* Rc = fr + S::F_RC;
+    const V3 pc = ld3(fr + S::F_PC);
+    const V3 dal = dbl + gz * dz;
+    const V3 dfv = mulT(Rc, dv + cross(dw, pc)), dfw = mulT(Rc, dw), dfa = mulT(Rc, dal + cross(dbw, pc));
+    const V3 dc = dfa + cross(ld3(fr + S::F_FW), dfv) + cross(ld3(fr + S::F_FV), dfw) + wv * dfv;
+    st3(colc + (int)fr[S::F_ROW], dc);
+  }
+  // ---- inward sweep: force tangents, tau tangents, undo the kinematic steps ----
+  V3 dFl = zero, dFn = zero;
+#pragma unroll 1
+  for (int j = LJ - 1; j >= 0; --j) {
+    const int dof = 6 + leg * LJ + j;
+    const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const bool mine = (k == dof);
+    const double sq = (mine && kind == 0) ? 1.0 : 0.0, sv = (mine && kind == 1) ? 1.0 : 0.0, sa = (mine && kind == 2) ? 1.0 : 0.0;
+    const double* R = jr + S::J_R;
+    const V3 u = ld3(jr + S::J_U), p = ld3(jr + S::J_P), mc = ld3(jr + S::J_MC);
+    const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), hl = ld3(jr + S::J_HL), hn = ld3(jr + S::J_HN);
+    V3 dhl, dhn, df, dn;
+    inertia(jr[S::J_MASS], mc, jr + S::J_IO, dv, dw, dhl, dhn);
+    inertia(jr[S::J_MASS], mc, jr + S::J_IO, dbl, dbw, df, dn);
+    dFl = dFl + df + cross(dw, hl) + cross(wj, dhl);
+    dFn = dFn + dn + cross(dw, hn) + cross(wj, dhn) + cross(dv, hl) + cross(vj, dhl);
+    colp[dof] = dot(u, dFn);
+    const V3 dRf = mul(R, dFl + sq * cross(u, ld3(jr + S::J_FL)));
+    dFn = mul(R, dFn + sq * cross(u, ld3(jr + S::J_FN))) + cross(p, dRf);
+    dFl = dRf;
+    if (j > 0) {
+      const V3 vJ = ld3(jr + S::J_VJ), dvJ = sv * u;
+      const V3 dbwc = dbw - sa * u - cross(dw, vJ) - cross(wj, dvJ);
+      const V3 dblc = dbl - cross(dv, vJ) - cross(vj, dvJ);
+      const V3 dwc = dw - dvJ;
+      dw = mul(R, dwc + sq * cross(u, ld3(jr + S::J_WC)));
+      dv = mul(R, dv + sq * cross(u, ld3(jr + S::J_VC))) - cross(dw, p);
+      dbw = mul(R, dbwc + sq * cross(u, ld3(jr + S::J_BWC)));
+      dbl = mul(R, dblc + sq * cross(u, ld3(jr + S::J_BLC))) - cross(dbw, p);
+    }
+  }
+  double* o = sc + S::BT + 6 * item;
+  st3(o, dFl); st3(o + 3, dFn);
+}
+
+// ---- after the items: base rows of every column, nominal base rows, and the position term of dC/dq ----
+//   tau[0:6] = total spatial force on the base (S = identity): own term + legs, in leg order
+//   dC/dq[contact rows of leg c, :] += (1 / D^2) (R_wf Rc) J[contact rows of leg c, :]
+template <typename D>
+__device__ __forceinline__ void rneaAssemble(double wp, int tid, int nt, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV, NC = D::NC;
+  for (int e = tid; e < 3 * NV * 6; e += nt) {
+    const int c = e / 6, r = e - 6 * c, kind = c / NV, k = c - kind * NV;
+    double acc;
+    if (k < 6) {
+      acc = sc[S::BOWN + 6 * (kind * 6 + k) + r];
+      for (int leg = 0; leg < NL; ++leg) acc += sc[S::BT + 6 * (leg * S::IPL + kind * 6 + k) + r];
+    } else {
+      const int leg = (k - 6) / LJ;
+      acc = sc[S::BT + 6 * (leg * S::IPL + 18 + LJ * kind + (k - 6 - leg * LJ)) + r];
+    }
+    if (kind < 2) out.didc[r + (long)out.ldd * c] = acc; else out.mm[r + NV * k] = acc;
+  }
+  if (tid < 6) {
+    double acc = sc[S::BN + tid];
+    for (int leg = 0; leg < NL; ++leg) acc += sc[S::BN + 6 * (1 + leg) + tid];
+    out.idc[tid] = acc;
+  }
+  // nominal residual: + the pose-dependent part left by rneaNominalPose
+  if (tid >= 64 && tid < 64 + 3 * NC) {
+    const int c = (tid - 64) / 3, x = tid - 64 - 3 * c;
+    const double* fr = sc + S::FEET + c * S::FREC;
+    if (fr[S::F_ACT] != 0.0) out.idc[NV + (int)fr[S::F_ROW] + x] += fr[S::F_CP + x];
+  }
+  for (int e = tid; e < NC * 3 * NV; e += nt) {
+    const int k = e / (3 * NC), rem = e - k * 3 * NC, c = rem / 3, x = rem - 3 * c;
+    const double* fr = sc + S::FEET + c * S::FREC;
+    if (fr[S::F_ACT] == 0.0) continue;
+    const int row = (int)fr[S::F_ROW];
+    const double* rwc = fr + S::F_RWC + 3 * x;
+    const double* jc = out.jm + row + (long)out.ldj * k;
+    out.didc[NV + row + x + (long)out.ldd * k] += wp * (rwc[0] * jc[0] + rwc[1] * jc[1] + rwc[2] * jc[2]);
+  }
+}
+
+}  // namespace idocp_dev
+#endif  // IDOCP_DEV_RNEA_TANGENT_HPP_

@@ -18,6 +18,7 @@
 
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
+#include "dev_rnea_tangent.hpp"
 #include "ocp_device.hpp"
 #include "ocp_launch.hpp"
 
@@ -87,7 +88,7 @@ struct CondenseSmem {
 // FQ6 = (q_prev (-) q).head(6) (parnmpc_lie_kernel).  The chain ends with an unused placeholder stage; the last real
 // stage (position M - 2) carries the terminal cost.
 template <typename D, bool RESIDUAL, int DIMF, bool BWD = false>
-__global__ __launch_bounds__(256, (DIMF > 0 && DIMF < D::NF) ? 5 : 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
+__global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
   using S = CondenseSmem<D, (DIMF > 0) ? DIMF : D::NF>;
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256, (DIMF > 0 && DIMF < D::NF) ? 5 : 4) void ocp_c
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
-  const int tid = threadIdx.x, nt = 256;
+  int tid = threadIdx.x;
+  constexpr int nt = 256;
   const long unit = blockIdx.x;                   // over batch * M: one stage of the chain per workgroup
   const int per = plist ? nlist : M;              // (or over batch * nlist: the chain positions of one stage class, launchCondenseMixed)
   const long b = unit / per;
@@ -136,32 +138,74 @@ __global__ __launch_bounds__(256, (DIMF > 0 && DIMF < D::NF) ? 5 : 4) void ocp_c
   const double* __restrict__ w_v = impulse ? P->vi_weight : P->v_weight;
   const double* __restrict__ w_a = impulse ? P->dvi_weight : P->a_weight;
 
-  // ---- A. load the lin record, clear the accumulators ----
+  // ---- A. inverse dynamics, contact constraint and their derivatives, straight into the LDS blocks (round 1 read them back from
+  // the lin record of a separate kernel); the small records of the stage are fetched into registers meanwhile ----
+  using RS = RneaScratch<D>;
+  static_assert(S::VEC - S::MJ >= RS::TOTAL, "the RNEA scratch aliases MJ .. TMP");
+  constexpr int NPRE = (2 * L::SOL + 2 * L::CON + nt - 1) / nt;
+  double pre[NPRE], prez[7];
+  // (every address below is a valid record of this instance, so the loads are unconditional: no branches, all in flight at once;
+  //  on the terminal stage sn_g = s_g and the slack / dual copies are simply not used)
+#pragma unroll
+  for (int t = 0; t < NPRE; ++t) {
+    const int e = tid + nt * t;
+    const double* src = e < L::SOL ? s_g + e : (e < 2 * L::SOL ? sn_g + (e - L::SOL) : (e < 2 * L::SOL + L::CON ? B.slack + su * L::CON + (e - 2 * L::SOL)
+                                                                       : B.dual + su * L::CON + (e < 2 * L::SOL + 2 * L::CON ? e - 2 * L::SOL - L::CON : 0)));
+    pre[t] = *src;
+  }
+  {
+    const double* __restrict__ zz = B.lie + rec * L::LIE;
+    if (tid < 36) { prez[0] = zz[L::Z_JQ + tid]; prez[1] = zz[L::Z_FQQ + tid]; prez[2] = zz[L::Z_FQQI + tid]; prez[3] = zz[L::Z_FQQP + tid]; prez[4] = zz[L::Z_FQQPI + tid]; }
+    if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
+  }
+  if (tid == 0) s_ok = 1;
   if (!terminal) {
-    const double* __restrict__ lin = B.lin + su * L::LIN;
-    if (SF == NF) {
-      for (int e = tid; e < NVF * NX + NV * NV + NF * NV; e += nt) sm[S::DIDC + e] = lin[e];     // DIDC, MM, JM are contiguous in both
-    } else {                                                                                     // narrower LDS blocks: column by column
+    if (impulse) {
+      // impulse stages keep the two-pass dual-number sweep of ocp_rnea_kernel<D, true> and its lin record
+      const double* __restrict__ lin = B.lin + su * L::LIN;
       for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; sm[S::DIDC + e] = lin[L::L_DIDC + r + NVF * c]; }
       for (int e = tid; e < NV * NV; e += nt) sm[S::MM + e] = lin[L::L_M + e];
       for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
+      if (tid < SVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
+    } else {
+      RneaOut out;
+      out.didc = &sm[S::DIDC]; out.ldd = SVF; out.mm = &sm[S::MM]; out.jm = &sm[S::JM]; out.ldj = SF; out.idc = &sm[S::IDC];
+      double* sc = &sm[S::MJ];
+      const double gz = B.model->gravity[2];
+      const double bwv = 2.0 / P->baumgarte_time_step, bwp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
+      STAMP(32);
+      for (int e = tid; e < S::MJ - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
+      rneaSetup<D>(B.model, P, nd, s_g, tid, sc);
+      __syncthreads();
+      STAMP(33);
+      if (tid < 64) rneaNominalMotion<D>(gz, bwv, tid, sc, out);
+      else if (tid < 128) rneaNominalPose<D>(gz, bwp, nd, tid - 64, sc);
+      __syncthreads();
+      STAMP(34);
+      if (tid < RS::NITEMS) rneaTangentItem<D>(gz, bwv, tid, sc, out);
+      __syncthreads();
+      STAMP(35);
+      rneaAssemble<D>(bwp, tid, nt, sc, out);
+      if (tid >= 128 + 6 && tid < 128 + NV) sm[S::IDC + tid - 128] -= s_g[L::S_U + tid - 128 - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88); the tau rows are final since the nominal sweep
     }
-    if (tid < SVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
+    __syncthreads();       // the scratch (MJ .. TMP) is dead from here
+    STAMP(36);
   }
-  for (int e = tid; e < L::SOL; e += nt) { sm[S::SOLS + e] = s_g[e]; if (!terminal) sm[S::SOLN + e] = sn_g[e]; }     // this and the next stage of the chain
-  if (!terminal) for (int e = tid; e < L::CON; e += nt) { sm[S::SLK + e] = B.slack[su * L::CON + e]; sm[S::DUL + e] = B.dual[su * L::CON + e]; }
+  // Everything below indexes by `tid` and reads the problem / node constants; making `tid` opaque and ordering memory here keeps
+  // the compiler from hoisting those index computations and loads ABOVE the sweep and carrying them through it in registers
+  // (the sweep needs the whole 128-VGPR budget: 82 spilled registers without, and the kernel ran at 10.3 instead of 4.5 ms).
+  asm volatile("" : "+v"(tid) :: "memory");
+#pragma unroll
+  for (int t = 0; t < NPRE; ++t) {
+    const int e = tid + nt * t;
+    if (e < 2 * L::SOL + 2 * L::CON) sm[S::SOLS + e] = pre[t];
+  }
+  static_assert(S::SOLN == S::SOLS + L::SOL && S::SLK == S::SOLN + L::SOL && S::DUL == S::SLK + L::CON, "the prefetched records are contiguous in LDS");
   for (int e = tid; e < SF * SF; e += nt) sm[S::QFF + e] = 0.0;
-  if (tid == 0) s_ok = 1;
   STAMP(1);
   // ---- B. Lie-group terms of the floating base (from ocp_lie_kernel) ----
-  {
-    const double* __restrict__ zz = B.lie + rec * L::LIE;
-    if (tid < 36) {
-      sm[S::JQ + tid] = zz[L::Z_JQ + tid]; sm[S::FQQ + tid] = zz[L::Z_FQQ + tid]; sm[S::FQQI + tid] = zz[L::Z_FQQI + tid];
-      sm[S::FQQP + tid] = zz[L::Z_FQQP + tid]; sm[S::FQQPI + tid] = zz[L::Z_FQQPI + tid];
-    }
-    if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = zz[L::Z_QDIFF + tid - 64]; sm[S::FQ6 + tid - 64] = zz[L::Z_FQ6 + tid - 64]; }
-  }
+  if (tid < 36) { sm[S::JQ + tid] = prez[0]; sm[S::FQQ + tid] = prez[1]; sm[S::FQQI + tid] = prez[2]; sm[S::FQQP + tid] = prez[3]; sm[S::FQQPI + tid] = prez[4]; }
+  if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = prez[5]; sm[S::FQ6 + tid - 64] = prez[6]; }
   __syncthreads();
 
   const double vref_on = nd->vref_on;          // TimeVaryingConfigurationSpaceCost::v_ref(t): zero outside the window

@@ -296,9 +296,12 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
   if (lane < NVF) lin[L::L_IDC + lane] = s_idc[lane] - ((nd->has_u && lane >= 6 && lane < NV) ? s[L::S_U + lane - 6] : 0.0);
 }
 
+// The regular stages no longer have a kernel of their own: the condensation kernel runs the tangent-only sweep of
+// dev_rnea_tangent.hpp in its first phase (ocp_condense_kernel.hip, phase A) and the lin record is only written for the
+// impulse stages (consumed by the general instantiation of K5b and by K9i).
 template <typename D>
 void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, int n_impulse, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_rnea_kernel<D, false>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B, 0);
+  (void)M;
   if (n_impulse > 0) hipLaunchKernelGGL((ocp_rnea_kernel<D, true>), dim3((unsigned)(batch * n_impulse)), dim3(64), 0, st, B, n_impulse);
 }
 
