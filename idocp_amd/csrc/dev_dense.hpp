@@ -206,6 +206,127 @@ __device__ __forceinline__ void spdInverseRows(double* A, int ld, int n, int lan
   for (int j = 0; j < N; ++j) if (on && j < n) A[lane + ld * j] = a[j];
 }
 
+// ordering point between LDS writes and reads of ONE wavefront (no workgroup barrier: its LDS operations execute in order)
+__device__ __forceinline__ void waveLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Inverse of the joint-space inertia matrix of a floating base with NL independent legs of LJ joints, by ONE wavefront, in
+// place (column-major, leading dimension ld, n = NB + NL LJ; only the UPPER triangle is read, like the reference, which mirrors
+// the upper triangle of dRNEA/da, robot.hxx:496-499).  The matrix is a block arrow
+//     M = [ A  B ; B^T  D ],   A: NB x NB base block,  D = blockdiag(D_1 .. D_NL),  B = [B_1 .. B_NL]
+// (different legs only couple through the base), so instead of n dependent pivot steps on the whole matrix:
+//     D_i^-1 (NL lanes, LJ pivots each, all at once),  E = B D^-1,  S = A - E B^T,  S^-1 (NB pivots in the registers of NB lanes),
+//     M^-1 = [ S^-1   -S^-1 E ; -E^T S^-1   D^-1 + E^T S^-1 E ]
+// -- NB + LJ = 9 dependent pivot steps instead of 18 and a quarter of the multiply-adds; pinocchio's sparse Cholesky
+// (Robot::computeMJtJinv, robot.hxx:576-615) exploits the same tree structure.  E is kept in the (redundant) lower-left block
+// while it is needed.  Every lane of the wavefront must call this.
+template <int NB, int NL, int LJ>
+__device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, int* ok) {
+  constexpr int NJ = NL * LJ;
+  // (i) D_i^-1 in place (full symmetric blocks)
+  if (lane < NL) {
+    const int o = NB + lane * LJ;
+    double d[LJ][LJ];
+#pragma unroll
+    for (int r = 0; r < LJ; ++r)
+#pragma unroll
+      for (int c = 0; c < LJ; ++c) d[r][c] = M[(o + (r < c ? r : c)) + ld * (o + (r < c ? c : r))];
+#pragma unroll
+    for (int k = 0; k < LJ; ++k) {
+      const double p = d[k][k];
+      if (!(p > 0.0)) *ok = 0;
+      const double ip = recipNewton(p);
+#pragma unroll
+      for (int r = 0; r < LJ; ++r)
+#pragma unroll
+        for (int c = 0; c < LJ; ++c) {
+          if (r == k || c == k) continue;
+          d[r][c] -= d[r][k] * d[k][c] * ip;
+        }
+#pragma unroll
+      for (int c = 0; c < LJ; ++c) if (c != k) { d[k][c] *= ip; }
+#pragma unroll
+      for (int r = 0; r < LJ; ++r) if (r != k) { d[r][k] *= -ip; }
+      d[k][k] = ip;
+    }
+#pragma unroll
+    for (int r = 0; r < LJ; ++r)
+#pragma unroll
+      for (int c = 0; c < LJ; ++c) M[(o + r) + ld * (o + c)] = d[r][c];
+  }
+  waveLdsSync();
+  // (ii) E = B D^-1 (NB x NJ), stored transposed in the lower-left block: M[NB + c, r] = E[r, c]
+  for (int e = lane; e < NB * NJ; e += 64) {
+    const int c = e / NB, r = e - c * NB, o = NB + (c / LJ) * LJ;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < LJ; ++m) acc += M[r + ld * (o + m)] * M[(o + m) + ld * (NB + c)];
+    M[(NB + c) + ld * r] = acc;
+  }
+  waveLdsSync();
+  // (iii) S = A - E B^T, row r in the registers of lane r; S^-1 by Gauss-Jordan through v_readlane
+  {
+    double a[NB];
+    const bool on = lane < NB;
+    const int r = on ? lane : 0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      double acc = M[(r < c ? r : c) + ld * (r < c ? c : r)];
+      for (int m = 0; m < NJ; ++m) acc -= M[(NB + m) + ld * r] * M[c + ld * (NB + m)];
+      a[c] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      double prow[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) prow[j] = readLaneF64(a[j], k);
+      const double p = prow[k];
+      if (lane == 0 && !(p > 0.0)) *ok = 0;
+      const double ip = recipNewton(p);
+      const double aik = a[k];
+      const bool isk = lane == k;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j == k) continue;
+        a[j] = isk ? prow[j] * ip : a[j] - aik * prow[j] * ip;
+      }
+      a[k] = isk ? ip : -aik * ip;
+    }
+    waveLdsSync();                               // every lane has read A before it is overwritten
+    if (on) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) M[r + ld * c] = a[c];
+    }
+  }
+  waveLdsSync();
+  // (iv) top-right = -S^-1 E (B is dead)
+  for (int e = lane; e < NB * NJ; e += 64) {
+    const int c = e / NB, r = e - c * NB;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc += M[r + ld * m] * M[(NB + c) + ld * m];
+    M[r + ld * (NB + c)] = -acc;
+  }
+  waveLdsSync();
+  // (v) bottom-right = D^-1 - E^T (top-right)
+  for (int e = lane; e < NJ * NJ; e += 64) {
+    const int c = e / NJ, i = e - c * NJ;
+    double acc = (i / LJ == c / LJ) ? M[(NB + i) + ld * (NB + c)] : 0.0;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc -= M[(NB + i) + ld * m] * M[m + ld * (NB + c)];
+    M[(NB + i) + ld * (NB + c)] = acc;
+  }
+  waveLdsSync();
+  // (vi) lower-left = (top-right)^T
+  for (int e = lane; e < NB * NJ; e += 64) {
+    const int c = e / NB, r = e - c * NB;
+    M[(NB + c) + ld * r] = M[r + ld * (NB + c)];
+  }
+  waveLdsSync();
+}
+
 // The same register-resident elimination for G independent n = N matrices at once: lanes [g N, (g + 1) N) of the wavefront
 // hold the rows of matrix g (column-major, leading dimension N, `gstride` doubles apart), the pivot rows travel through
 // ds_bpermute (__shfl) instead of v_readlane, so one pass of N dependent pivot steps serves all G matrices.  G N <= 64;

@@ -353,15 +353,113 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
   st3(o, dFl); st3(o + 3, dFn);
 }
 
-// ---- after the items: base rows of every column, nominal base rows, and the position term of dC/dq ----
+// ---- the acceleration seeds on their own: with dv = dw = dz = 0 only (dbl, dbw) travel, a third of the full item's work.
+// Their columns are dID/da = M (the joint-space inertia matrix) and dC/da = J (the contact Jacobian) -- all that
+// Robot::computeMJtJinv needs, so the wavefront that runs these items goes straight on to the inverses while another
+// wavefront is still busy with the q and v seeds. ----
+template <typename D>
+__device__ __forceinline__ void rneaTangentItemA(int item, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  using namespace rt;
+  constexpr int LJ = D::LJ, NV = D::NV;
+  const int leg = item / S::IPL, j0 = item - leg * S::IPL;
+  const bool base_seed = j0 < 18;
+  const int k = base_seed ? j0 - 12 : 6 + leg * LJ + (j0 - 18 - 2 * LJ);      // velocity index of the seed (kind = 2)
+  double* __restrict__ colp = out.mm + NV * k;
+  double* __restrict__ colc = out.jm + (long)out.ldj * k;
+  const double* br = sc + S::BASE;
+  auto e3 = [](int i) { return v3(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0); };
+  const V3 zero = v3(0, 0, 0);
+  V3 dbl = (k < 3) ? e3(k) : zero, dbw = (k >= 3 && k < 6) ? e3(k - 3) : zero;
+  if (leg == 0 && base_seed) {
+    V3 df, dn;
+    inertia(br[S::B_MASS], ld3(br + S::B_MC), br + S::B_IO, dbl, dbw, df, dn);
+    double* o = sc + S::BOWN + 6 * j0;
+    st3(o, df); st3(o + 3, dn);
+  }
+#pragma unroll 1
+  for (int j = 0; j < LJ; ++j) {
+    const int dof = 6 + leg * LJ + j;
+    const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const double* R = jr + S::J_R;
+    const double sa = (k == dof) ? 1.0 : 0.0;
+    const V3 t = dbl + cross(dbw, ld3(jr + S::J_P));
+    dbw = mulT(R, dbw) + sa * ld3(jr + S::J_U);
+    dbl = mulT(R, t);
+  }
+  const double* fr = sc + S::FEET + leg * S::FREC;
+  if (fr[S::F_ACT] != 0.0) st3(colc + (int)fr[S::F_ROW], mulT(fr + S::F_RC, dbl + cross(dbw, ld3(fr + S::F_PC))));      // column of the frame Jacobian
+  V3 dFl = zero, dFn = zero;
+#pragma unroll 1
+  for (int j = LJ - 1; j >= 0; --j) {
+    const int dof = 6 + leg * LJ + j;
+    const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const double* R = jr + S::J_R;
+    const V3 u = ld3(jr + S::J_U), p = ld3(jr + S::J_P);
+    V3 df, dn;
+    inertia(jr[S::J_MASS], ld3(jr + S::J_MC), jr + S::J_IO, dbl, dbw, df, dn);
+    dFl = dFl + df; dFn = dFn + dn;
+    colp[dof] = dot(u, dFn);
+    const V3 dRf = mul(R, dFl);
+    dFn = mul(R, dFn) + cross(p, dRf);
+    dFl = dRf;
+    if (j > 0) {
+      const double sa = (k == dof) ? 1.0 : 0.0;
+      dbw = mul(R, dbw - sa * u);
+      dbl = mul(R, dbl) - cross(dbw, p);
+    }
+  }
+  double* o = sc + S::BT + 6 * item;
+  st3(o, dFl); st3(o + 3, dFn);
+}
+
+// item lists (positions in the (leg, j0) numbering of BT: j0 < 18 base seeds by kind, then the leg's joint seeds by kind):
+//   q / v seeds: per leg 3 base orientation seeds (a base POSITION seed changes nothing but the position term, which rneaAssembleQV
+//   adds), 6 base velocity seeds, LJ joint angle and LJ joint velocity seeds -- (9 + 2 LJ) NL items, 60 for a quadruped: one wavefront
+//   a seeds: per leg 6 base + LJ joint seeds -- (6 + LJ) NL items
+template <typename D> struct RneaItems {
+  static constexpr int LJ = D::LJ, NL = D::NL, QV_PER_LEG = 9 + 2 * LJ, NQV = NL * QV_PER_LEG, A_PER_LEG = 6 + LJ, NA = NL * A_PER_LEG;
+  using S = RneaScratch<D>;
+  __device__ static __forceinline__ int qv(int idx) {
+    const int leg = idx / QV_PER_LEG, e = idx - leg * QV_PER_LEG;
+    const int j0 = e < 3 ? 3 + e : (e < 9 ? 6 + (e - 3) : (e < 9 + LJ ? 18 + (e - 9) : 18 + LJ + (e - 9 - LJ)));
+    return leg * S::IPL + j0;
+  }
+  __device__ static __forceinline__ int a(int idx) {
+    const int leg = idx / A_PER_LEG, e = idx - leg * A_PER_LEG;
+    return leg * S::IPL + (e < 6 ? 12 + e : 18 + 2 * LJ + (e - 6));
+  }
+};
+
+// ---- after the a items, by the SAME wavefront (lane = 0 .. 63, no workgroup barrier): base rows of M ----
 //   tau[0:6] = total spatial force on the base (S = identity): own term + legs, in leg order
+template <typename D>
+__device__ __forceinline__ void rneaAssembleA(int lane, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV;
+  for (int e = lane; e < NV * 6; e += 64) {
+    const int k = e / 6, r = e - 6 * k;
+    double acc;
+    if (k < 6) {
+      acc = sc[S::BOWN + 6 * (12 + k) + r];
+      for (int leg = 0; leg < NL; ++leg) acc += sc[S::BT + 6 * (leg * S::IPL + 12 + k) + r];
+    } else {
+      const int leg = (k - 6) / LJ;
+      acc = sc[S::BT + 6 * (leg * S::IPL + 18 + 2 * LJ + (k - 6 - leg * LJ)) + r];
+    }
+    out.mm[r + NV * k] = acc;
+  }
+}
+
+// ---- after the q / v items, all threads: base rows of the q and v columns, nominal base rows, and the pose-dependent terms ----
 //   dC/dq[contact rows of leg c, :] += (1 / D^2) (R_wf Rc) J[contact rows of leg c, :]
 template <typename D>
-__device__ __forceinline__ void rneaAssemble(double wp, int tid, int nt, double* sc, const RneaOut& out) {
+__device__ __forceinline__ void rneaAssembleQV(double wp, int tid, int nt, double* sc, const RneaOut& out) {
   using S = RneaScratch<D>;
   constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV, NC = D::NC;
-  for (int e = tid; e < 3 * NV * 6; e += nt) {
+  for (int e = tid; e < 2 * NV * 6; e += nt) {
     const int c = e / 6, r = e - 6 * c, kind = c / NV, k = c - kind * NV;
+    if (kind == 0 && k < 3) continue;                      // base position seeds: zero columns (zero-filled by the caller)
     double acc;
     if (k < 6) {
       acc = sc[S::BOWN + 6 * (kind * 6 + k) + r];
@@ -370,7 +468,7 @@ __device__ __forceinline__ void rneaAssemble(double wp, int tid, int nt, double*
       const int leg = (k - 6) / LJ;
       acc = sc[S::BT + 6 * (leg * S::IPL + 18 + LJ * kind + (k - 6 - leg * LJ)) + r];
     }
-    if (kind < 2) out.didc[r + (long)out.ldd * c] = acc; else out.mm[r + NV * k] = acc;
+    out.didc[r + (long)out.ldd * c] = acc;
   }
   if (tid < 6) {
     double acc = sc[S::BN + tid];

@@ -66,7 +66,9 @@ struct CondenseSmem {
   //   ERR   = MJ            (RESIDUAL variant only, which never forms MJtJinv)
   // The condensed Hessian blocks are never staged in LDS: phase H writes them to the kkt record.
   static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV, IDC = JM + NF * NV, MJ = IDC + 32,
-                       MJD = MJ + NVF * NVF, QFF = MJD + NVF * NX, TMP = QFF + NF * NF,
+                       MJD = MJ + NVF * NVF,
+                       // MJ .. MJD also hold the scratch of the RNEA sweeps (dead before MJtJinv is assembled); the narrow layouts are padded for it
+                       QFF = (MJD + NVF * NX > MJ + RneaScratch<D>::TOTAL) ? MJD + NVF * NX : MJ + RneaScratch<D>::TOTAL, TMP = QFF + NF * NF,
                        MINV = MM, QAFQV = DIDC, QAFU = MM, ERR = MJ;
   static constexpr int SOLS = TMP, SOLN = SOLS + L::SOL, SLK = SOLN + L::SOL, DUL = SLK + L::CON, TMP_EARLY = DUL + L::CON - TMP;
   static constexpr int BL = TMP, SM = BL + NF * NV, BR = SM + NF * NF, TMP_LATE = BR + NF * NF - TMP;
@@ -138,75 +140,70 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* __restrict__ w_v = impulse ? P->vi_weight : P->v_weight;
   const double* __restrict__ w_a = impulse ? P->dvi_weight : P->a_weight;
 
-  // ---- A. inverse dynamics, contact constraint and their derivatives, straight into the LDS blocks (round 1 read them back from
-  // the lin record of a separate kernel); the small records of the stage are fetched into registers meanwhile ----
+  // ======================================================================================================================
+  // Front half, WAVE-SPECIALISED (round 2).  Round 1 ran K5a -> lin record -> phases A .. E of this kernel one after the other,
+  // nineteen workgroup barriers in all.  Here the rigid-body terms are produced in place (dev_rnea_tangent.hpp) and the four
+  // wavefronts of the workgroup work on different things at the same time, joined by four barriers:
+  //   stage 0  all      fetch the small records (registers), clear the output blocks, joint constants + rotations -> LDS
+  //   stage 1  wave 0   nominal Newton-Euler sweep (motion)        wave 1   nominal sweep (world pose)
+  //            wave 2/3 C1: every term of the gradients / Hessian diagonals that does not need the rigid-body derivatives
+  //   stage 2  wave 0   the 60 q- and v-seed tangent items          wave 1   the 36 a-seed items (M, J) and then, without waiting for
+  //                     anybody, Robot::computeMJtJinv: block-arrow M^-1, J M^-1, (J M^-1 J^T)^-1
+  //   stage 3  all      base rows + position term of the q / v columns, assembly of MJtJinv
+  //   (then F: MJtJinv [dIDCdqv, IDC] together with C2, the multiplier terms l += dt [dID; dC]^T [beta; mu])
+  // ======================================================================================================================
   using RS = RneaScratch<D>;
-  static_assert(S::VEC - S::MJ >= RS::TOTAL, "the RNEA scratch aliases MJ .. TMP");
+  using RI = RneaItems<D>;
+  static_assert(S::QFF - S::MJ >= RS::TOTAL, "the RNEA scratch lives in MJ .. MJD (dead until stage 3)");
+  static_assert(RI::NQV <= 64 && RI::NA <= 64, "one wavefront per item list");
   constexpr int NPRE = (2 * L::SOL + 2 * L::CON + nt - 1) / nt;
-  double pre[NPRE], prez[7];
-  // (every address below is a valid record of this instance, so the loads are unconditional: no branches, all in flight at once;
-  //  on the terminal stage sn_g = s_g and the slack / dual copies are simply not used)
-#pragma unroll
-  for (int t = 0; t < NPRE; ++t) {
-    const int e = tid + nt * t;
-    const double* src = e < L::SOL ? s_g + e : (e < 2 * L::SOL ? sn_g + (e - L::SOL) : (e < 2 * L::SOL + L::CON ? B.slack + su * L::CON + (e - 2 * L::SOL)
-                                                                       : B.dual + su * L::CON + (e < 2 * L::SOL + 2 * L::CON ? e - 2 * L::SOL - L::CON : 0)));
-    pre[t] = *src;
-  }
+  static_assert(S::SOLN == S::SOLS + L::SOL && S::SLK == S::SOLN + L::SOL && S::DUL == S::SLK + L::CON, "the fetched records are contiguous in LDS");
+  const int wave = tid >> 6, lane = tid & 63;
+  double* const sc = &sm[S::MJ];
+  RneaOut out;
+  out.didc = &sm[S::DIDC]; out.ldd = SVF; out.mm = &sm[S::MM]; out.jm = &sm[S::JM]; out.ldj = SF; out.idc = &sm[S::IDC];
+  // ---- stage 0 ----
   {
-    const double* __restrict__ zz = B.lie + rec * L::LIE;
-    if (tid < 36) { prez[0] = zz[L::Z_JQ + tid]; prez[1] = zz[L::Z_FQQ + tid]; prez[2] = zz[L::Z_FQQI + tid]; prez[3] = zz[L::Z_FQQP + tid]; prez[4] = zz[L::Z_FQQPI + tid]; }
-    if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
-  }
-  if (tid == 0) s_ok = 1;
-  if (!terminal) {
-    if (impulse) {
-      // impulse stages keep the two-pass dual-number sweep of ocp_rnea_kernel<D, true> and its lin record
-      const double* __restrict__ lin = B.lin + su * L::LIN;
-      for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; sm[S::DIDC + e] = lin[L::L_DIDC + r + NVF * c]; }
-      for (int e = tid; e < NV * NV; e += nt) sm[S::MM + e] = lin[L::L_M + e];
-      for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
-      if (tid < SVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
-    } else {
-      RneaOut out;
-      out.didc = &sm[S::DIDC]; out.ldd = SVF; out.mm = &sm[S::MM]; out.jm = &sm[S::JM]; out.ldj = SF; out.idc = &sm[S::IDC];
-      double* sc = &sm[S::MJ];
-      const double gz = B.model->gravity[2];
-      const double bwv = 2.0 / P->baumgarte_time_step, bwp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
-      STAMP(32);
-      for (int e = tid; e < S::MJ - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
-      rneaSetup<D>(B.model, P, nd, s_g, tid, sc);
-      __syncthreads();
-      STAMP(33);
-      if (tid < 64) rneaNominalMotion<D>(gz, bwv, tid, sc, out);
-      else if (tid < 128) rneaNominalPose<D>(gz, bwp, nd, tid - 64, sc);
-      __syncthreads();
-      STAMP(34);
-      if (tid < RS::NITEMS) rneaTangentItem<D>(gz, bwv, tid, sc, out);
-      __syncthreads();
-      STAMP(35);
-      rneaAssemble<D>(bwp, tid, nt, sc, out);
-      if (tid >= 128 + 6 && tid < 128 + NV) sm[S::IDC + tid - 128] -= s_g[L::S_U + tid - 128 - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88); the tau rows are final since the nominal sweep
-    }
-    __syncthreads();       // the scratch (MJ .. TMP) is dead from here
-    STAMP(36);
-  }
-  // Everything below indexes by `tid` and reads the problem / node constants; making `tid` opaque and ordering memory here keeps
-  // the compiler from hoisting those index computations and loads ABOVE the sweep and carrying them through it in registers
-  // (the sweep needs the whole 128-VGPR budget: 82 spilled registers without, and the kernel ran at 10.3 instead of 4.5 ms).
-  asm volatile("" : "+v"(tid) :: "memory");
+    // (every address below is a valid record of this instance, so the loads are unconditional: no branches, all in flight at once;
+    //  on the terminal stage sn_g = s_g and the slack / dual copies are simply not used)
+    double pre[NPRE], prez[7];
 #pragma unroll
-  for (int t = 0; t < NPRE; ++t) {
-    const int e = tid + nt * t;
-    if (e < 2 * L::SOL + 2 * L::CON) sm[S::SOLS + e] = pre[t];
+    for (int t = 0; t < NPRE; ++t) {
+      const int e = tid + nt * t;
+      const double* src = e < L::SOL ? s_g + e : (e < 2 * L::SOL ? sn_g + (e - L::SOL) : (e < 2 * L::SOL + L::CON ? B.slack + su * L::CON + (e - 2 * L::SOL)
+                                                                         : B.dual + su * L::CON + (e < 2 * L::SOL + 2 * L::CON ? e - 2 * L::SOL - L::CON : 0)));
+      pre[t] = *src;
+    }
+    {
+      const double* __restrict__ zz = B.lie + rec * L::LIE;
+      if (tid < 36) { prez[0] = zz[L::Z_JQ + tid]; prez[1] = zz[L::Z_FQQ + tid]; prez[2] = zz[L::Z_FQQI + tid]; prez[3] = zz[L::Z_FQQP + tid]; prez[4] = zz[L::Z_FQQPI + tid]; }
+      if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
+    }
+    if (tid == 0) s_ok = 1;
+    if (!terminal) {
+      if (impulse) {
+        // impulse stages keep the two-pass dual-number sweep of ocp_rnea_kernel<D, true> and its lin record
+        const double* __restrict__ lin = B.lin + su * L::LIN;
+        for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; sm[S::DIDC + e] = lin[L::L_DIDC + r + NVF * c]; }
+        for (int e = tid; e < NV * NV; e += nt) sm[S::MM + e] = lin[L::L_M + e];
+        for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
+        if (tid < SVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
+      } else {
+        for (int e = tid; e < S::MJ - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
+        rneaSetup<D>(B.model, P, nd, s_g, tid, sc);
+      }
+    }
+    for (int e = tid; e < SF * SF; e += nt) sm[S::QFF + e] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {
+      const int e = tid + nt * t;
+      if (e < 2 * L::SOL + 2 * L::CON) sm[S::SOLS + e] = pre[t];
+    }
+    if (tid < 36) { sm[S::JQ + tid] = prez[0]; sm[S::FQQ + tid] = prez[1]; sm[S::FQQI + tid] = prez[2]; sm[S::FQQP + tid] = prez[3]; sm[S::FQQPI + tid] = prez[4]; }
+    if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = prez[5]; sm[S::FQ6 + tid - 64] = prez[6]; }
   }
-  static_assert(S::SOLN == S::SOLS + L::SOL && S::SLK == S::SOLN + L::SOL && S::DUL == S::SLK + L::CON, "the prefetched records are contiguous in LDS");
-  for (int e = tid; e < SF * SF; e += nt) sm[S::QFF + e] = 0.0;
-  STAMP(1);
-  // ---- B. Lie-group terms of the floating base (from ocp_lie_kernel) ----
-  if (tid < 36) { sm[S::JQ + tid] = prez[0]; sm[S::FQQ + tid] = prez[1]; sm[S::FQQI + tid] = prez[2]; sm[S::FQQP + tid] = prez[3]; sm[S::FQQPI + tid] = prez[4]; }
-  if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = prez[5]; sm[S::FQ6 + tid - 64] = prez[6]; }
   __syncthreads();
+  STAMP(1);
 
   const double vref_on = nd->vref_on;          // TimeVaryingConfigurationSpaceCost::v_ref(t): zero outside the window
   const double v_ref0 = vref_on * P->v_ref[0];
@@ -246,17 +243,19 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     return;
   }
 
-  STAMP(2);
-  // ---- C. gradients, residuals, diagonal Hessian terms ----
+  // ---- stage 1: nominal sweeps (waves 0, 1) next to C1 (waves 2, 3) ----
+  const double gz = B.model->gravity[2];
+  const double bwv = 2.0 / P->baumgarte_time_step, bwp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
   const double* slack = &sm[S::SLK];
   const double* dual = &sm[S::DUL];
-  // bm = [beta ; mu_stack]
-  if (tid < NV) sm[S::BM + tid] = s[L::S_BETA + tid];
-  if (tid < NC && nd->active[tid]) for (int x = 0; x < 3; ++x) sm[S::BM + NV + nd->row_of[tid] + x] = s[L::S_MU + 3 * tid + x];
-  __syncthreads();
-  double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below)
-  if (tid < NV) {
-    const int r = tid;
+  double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below), per thread
+  if (wave == 0) {
+    if (!impulse) rneaNominalMotion<D>(gz, bwv, lane, sc, out);
+  } else if (wave == 1) {
+    if (!impulse) rneaNominalPose<D>(gz, bwp, nd, lane, sc);
+  } else if (tid < 128 + NV) {
+    // ---- C1, one row of (q, v, a) per thread: cost, state equation, joint limits, switching-constraint multipliers ----
+    const int r = tid - 128;
     const double vr = s[L::S_V + r], ar = s[L::S_A + r];
     const double lmd = s[L::S_LMD + r], gmm = s[L::S_GMM + r], lmdn = sn[L::S_LMD + r], gmmn = sn[L::S_GMM + r];
     double lq, lv, la, hq = 0.0, hv, ha;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const double* __restrict__ sp_g = (BWD && nd->prev >= 0) ? B.sol + (b * P->NS + nd->prev) * L::SOL : nullptr;
     const double qpr = !BWD ? 0.0 : (sp_g ? sp_g[L::S_Q + r + 1] : q0[b * NQ + r + 1]);
     const double vpr = !BWD ? 0.0 : (sp_g ? sp_g[L::S_V + r] : v0[b * NV + r]);
-    // cost + state equation
+    double fq;
     if (r < 6) {
       lq = 0.0;
       for (int m2 = 0; m2 < 6; ++m2) lq += sm[S::JQ + m2 + 6 * r] * w_q[m2] * sm[S::QDIFF + m2];
@@ -272,17 +271,19 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       double t1 = 0.0;
       for (int m2 = 0; m2 < 6; ++m2) t1 += sm[S::FQQ + m2 + 6 * r] * sn[L::S_LMD + m2] + sm[S::FQQP + m2 + 6 * r] * s[L::S_LMD + m2];
       lq += t1;
-      sm[S::FQ + r] = sm[S::FQ6 + r] + dtq * vr;
+      fq = sm[S::FQ6 + r] + dtq * vr;
     } else {
       lq = dt * w_q[r] * (q[r + 1] - qref[r + 1]) + lmdn - lmd;
       hq = dt * w_q[r];
-      sm[S::FQ + r] = BWD ? (qpr - q[r + 1] + dtq * vr) : (q[r + 1] - sn[L::S_Q + r + 1] + dtq * vr);
+      fq = BWD ? (qpr - q[r + 1] + dtq * vr) : (q[r + 1] - sn[L::S_Q + r + 1] + dtq * vr);
     }
+    sm[S::FQ + r] = fq;
     lv = dt * w_v[r] * (vr - (r == 0 ? v_ref0 : vref_on * P->v_ref[r])) + (BWD ? dtq * lmd : dtq * lmdn) + gmmn - gmm;
     la = dt * w_a[r] * ar + dt * (BWD ? gmm : gmmn);
     hv = dt * w_v[r];
     ha = dt * w_a[r];
-    sm[S::FV + r] = BWD ? (vpr - vr + dt * ar) : (vr + dt * ar - sn[L::S_V + r]);
+    const double fv = BWD ? (vpr - vr + dt * ar) : (vr + dt * ar - sn[L::S_V + r]);
+    sm[S::FV + r] = fv;
     if (last) {
       // TerminalParNMPC: + terminal cost (computeTerminalCostDerivatives / Hessian) on the last stage
       if (r < 6) {
@@ -311,11 +312,6 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         if (c < 2) { lq += g; hq += h; } else { lv += g; hv += h; }
       }
     }
-    // multipliers of [ID; C]:  l += dt [dID;dC]^T [beta; mu]
-    const double dq = dotAny(&sm[S::DIDC + SVF * r], 1, &sm[S::BM], 1, dimvf);
-    const double dv = dotAny(&sm[S::DIDC + SVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
-    const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + SF * r], 1, &sm[S::BM + NV], 1, dimf);
-    lq += dt * dq; lv += dt * dv; la += dt * da;
     // ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:49-51): + Phi^T xi
     if (sw_dimi > 0) {
       const double* __restrict__ W = B.swc + rec * L::SWC;
@@ -324,18 +320,15 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         lq += W[L::W_PHIX + j + NF * r] * xi; lv += W[L::W_PHIX + j + NF * (NV + r)] * xi; la += W[L::W_PHIA + j + NF * r] * xi;
       }
     }
+    // the multipliers of [ID; C] are added in C2; bm = [beta ; mu_stack] for them
     sm[S::LQ + r] = lq; sm[S::LV + r] = lv; sm[S::LA + r] = la; sm[S::QAA + r] = ha;
-    if (!RESIDUAL) {
-      sm[S::HQD + r] = hq;
-      sm[S::HVD + r] = hv;
-    } else {
-      const double idr = sm[S::IDC + r];
-      err_local += lq * lq + lv * lv + la * la + sm[S::FQ + r] * sm[S::FQ + r] + sm[S::FV + r] * sm[S::FV + r] + dt * dt * idr * idr;
-    }
-  } else if (tid >= 64 && tid < 64 + NU) {
+    sm[S::BM + r] = s[L::S_BETA + r];
+    if (!RESIDUAL) { sm[S::HQD + r] = hq; sm[S::HVD + r] = hv; }
+    else err_local += fq * fq + fv * fv;
+  } else if (tid >= 128 + 32 && tid < 128 + 32 + NU) {
     // torque rows: lu, Quu diagonal.  An impulse stage has no torques: lu = 0 and a unit Quu make the
     // Riccati step below return K = 0, k = 0 and P = F, i.e. ImpulseSplitRiccatiFactorizer's recursion.
-    const int j = tid - 64;
+    const int j = tid - 128 - 32;
     const double u = s[L::S_U + j];
     double lu = dt * P->u_weight[j] * (u - P->u_ref[j]) - dt * s[L::S_BETA + 6 + j];
     double h = dt * P->u_weight[j];
@@ -352,14 +345,14 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::LU + j] = lu;
     if (!RESIDUAL) sm[S::HUD + j] = h;
     else err_local += lu * lu;
-  } else if (tid >= 128 && tid < 128 + 6) {
+  } else if (tid >= 128 + 48 && tid < 128 + 48 + 6) {
     // passive (floating-base) rows: lu_passive = dt nu_passive - dt beta.head(6)
-    const int r = tid - 128;
+    const int r = tid - 128 - 48;
     const double lup = impulse ? 0.0 : dt * s[L::S_NUP + r] - dt * s[L::S_BETA + r];
     sm[S::LUP + r] = lup;
     if (RESIDUAL) err_local += lup * lup;
   } else if (tid >= 192 && tid < 192 + NC) {
-    // contact-force rows: ContactForceCost + LinearizedFrictionCone + (- dt J beta)
+    // contact-force rows: ContactForceCost + LinearizedFrictionCone (the - dt J beta term follows in C2)
     const int c = tid - 192;
     if (nd->active[c]) {
       const int row = nd->row_of[c];
@@ -369,6 +362,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         const double wf = impulse ? P->fi_weight[c][x] : P->f_weight[c][x], rf = impulse ? P->fi_ref[c][x] : P->f_ref[c][x];
         lf[x] = dt * wf * (f[x] - rf);
         if (!RESIDUAL) sm[S::QFF + (row + x) + SF * (row + x)] = dt * wf;
+        sm[S::BM + NV + row + x] = s[L::S_MU + 3 * c + x];
       }
       if (ocpRowValid(P, 6, i, impulse)) {
         double dd[5];
@@ -392,87 +386,142 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
           }
         }
       }
-      for (int x = 0; x < 3; ++x) {
-        double jb = 0.0;
-        for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + SF * col] * s[L::S_BETA + col];
-        lf[x] -= dt * jb;
-        sm[S::LF + row + x] = lf[x];
-        if (RESIDUAL) { const double cr = sm[S::IDC + NV + row + x]; err_local += lf[x] * lf[x] + dt * dt * cr * cr; }
+      for (int x = 0; x < 3; ++x) sm[S::LF + row + x] = lf[x];
+    }
+  } else if (!RESIDUAL && tid >= 192 + 8 && tid < 192 + 8 + 36) {
+    // cost Hessian of the base block dt Jq^T W Jq (6 x 6), and condenseForwardEuler (state_equation.hxx:40-63)
+    const int e = tid - 192 - 8, c = e / 6, r = e - 6 * c;
+    double acc = 0.0;
+    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * w_q[m2] * sm[S::JQ + m2 + 6 * c];
+    double accf = 0.0;
+    if (last) for (int m2 = 0; m2 < 6; ++m2) accf += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c];
+    sm[S::QB6 + e] = dt * acc + accf;
+    double fqq = 0.0;
+    for (int m2 = 0; m2 < 6; ++m2) fqq += sm[S::FQQI + r + 6 * m2] * sm[(BWD ? S::FQQP : S::FQQ) + m2 + 6 * c];
+    kk[L::K_FQQ + e] = BWD ? fqq : -fqq;                              // Fqq = -Fqq_inv * Fqq  (backward Euler: + Fqq_inv * Fqq)
+    kk[L::K_FQV + e] = (BWD ? dtq : -dtq) * sm[S::FQQI + e];          // Fqv = -dt Fqq_inv (0 on impulse stages; backward: + dt Fqq_inv)
+    ee[L::E_FQQPI + e] = sm[(BWD ? S::FQQI : S::FQQPI) + e];          // what the costate correction needs
+  }
+  __syncthreads();
+  STAMP(2);
+
+  // ---- stage 2: tangent items (wave 0: q, v seeds; wave 1: a seeds) and Robot::computeMJtJinv (wave 1) (robot.hxx:576-615) ----
+  // M^-1 and (J M^-1 J^T)^-1 by Gauss-Jordan on the SPD blocks (the reference uses pinocchio's sparse Cholesky + Eigen::LLT; same
+  // inverses up to rounding).  BL, SM live in the block that held the solution / slack / dual copies (dead since C1).
+  if (wave == 0) {
+    if (!impulse && lane < RI::NQV) rneaTangentItem<D>(gz, bwv, RI::qv(lane), sc, out);
+  } else if (wave == 1) {
+    if (!impulse) {
+      if (lane < RI::NA) rneaTangentItemA<D>(RI::a(lane), sc, out);
+      waveLdsSync();
+      rneaAssembleA<D>(lane, sc, out);
+      waveLdsSync();
+    }
+    if (!RESIDUAL) {
+      // C2 for the acceleration rows, while M is still M: la += dt (M^T beta + J^T mu)
+      if (lane < NV) sm[S::LA + lane] += dt * (dotAny(&sm[S::MM + NV * lane], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + SF * lane], 1, &sm[S::BM + NV], 1, dimf));
+      waveLdsSync();
+      blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok);
+      if (dimf > 0) {
+        for (int e = lane; e < dimf * NV; e += 64) {                 // BL = J Minv
+          const int c = e / dimf, r = e - c * dimf;
+          sm[S::BL + r + SF * c] = dotAny(&sm[S::JM + r], SF, &sm[S::MINV + NV * c], 1, NV);
+        }
+        waveLdsSync();
+        for (int e = lane; e < dimf * dimf; e += 64) {               // SM = BL J^T
+          const int c = e / dimf, r = e - c * dimf;
+          sm[S::SM + r + SF * c] = dotAny(&sm[S::BL + r], SF, &sm[S::JM + c], SF, NV);
+        }
+        waveLdsSync();
+        spdInverseRows<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
       }
     }
   }
+  __syncthreads();
+  STAMP(5);
+  // Everything below indexes by `tid` and reads the problem / node constants; making `tid` opaque and ordering memory here keeps the
+  // compiler from hoisting those index computations and loads ABOVE the sweeps and carrying them through in registers (the q / v
+  // items need the whole 128-VGPR budget).
+  asm volatile("" : "+v"(tid) :: "memory");
   if (RESIDUAL) {
-    // SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264)
+    // ---- C2 + SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264) ----
+    if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);
+    __syncthreads();
+    if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88)
+    __syncthreads();
+    if (tid >= 128 && tid < 128 + NV) {
+      const int r = tid - 128;
+      const double dq = dotAny(&sm[S::DIDC + SVF * r], 1, &sm[S::BM], 1, dimvf);
+      const double dv = dotAny(&sm[S::DIDC + SVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
+      const double da = dotAny(&sm[S::MM + NV * r], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + SF * r], 1, &sm[S::BM + NV], 1, dimf);
+      const double lq = sm[S::LQ + r] + dt * dq, lv = sm[S::LV + r] + dt * dv, la = sm[S::LA + r] + dt * da;
+      const double idr = sm[S::IDC + r];
+      err_local += lq * lq + lv * lv + la * la + dt * dt * idr * idr;
+    } else if (tid >= 192 && tid < 192 + NC) {
+      const int c = tid - 192;
+      if (nd->active[c]) {
+        const int row = nd->row_of[c];
+        for (int x = 0; x < 3; ++x) {
+          double jb = 0.0;
+          for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + SF * col] * sm[S::BM + col];
+          const double lf = sm[S::LF + row + x] - dt * jb;
+          const double cr = sm[S::IDC + NV + row + x];
+          err_local += lf * lf + dt * dt * cr * cr;
+        }
+      }
+    }
     if (sw_dimi > 0 && tid >= 200 && tid < 200 + sw_dimi) {
       const double pr = B.swc[rec * L::SWC + L::W_P + tid - 200];
       err_local += pr * pr;
     }
+    __syncthreads();                                                   // ERR aliases the scratch
     sm[S::ERR + tid] = err_local + (BWD ? 1.0 : dt * dt) * err_ipm;      // split_parnmpc.hxx:263 does not weight by dt^2
     __syncthreads();
     if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[rec] = e; }
     return;
   }
-  __syncthreads();
-  STAMP(3);
-  // cost Hessian of the base block: dt Jq^T W Jq  (6 x 6)
-  if (tid < 36) {
-    const int c = tid / 6, r = tid - 6 * c;
-    double acc = 0.0;
-    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::JQ + m2 + 6 * r] * w_q[m2] * sm[S::JQ + m2 + 6 * c];
-    double accf = 0.0;
-    if (last) for (int m2 = 0; m2 < 6; ++m2) accf += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c];
-    sm[S::QB6 + tid] = dt * acc + accf;
-  }
-  // ---- D. condenseForwardEuler (state_equation.hxx:40-63) ----
-  if (tid >= 64 && tid < 64 + 36) {
-    const int e = tid - 64, c = e / 6, r = e - 6 * c;
-    double acc = 0.0;
-    for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[(BWD ? S::FQQP : S::FQQ) + m2 + 6 * c];
-    kk[L::K_FQQ + e] = BWD ? acc : -acc;                              // Fqq = -Fqq_inv * Fqq  (backward Euler: + Fqq_inv * Fqq)
-    kk[L::K_FQV + e] = (BWD ? dtq : -dtq) * sm[S::FQQI + e];          // Fqv = -dt Fqq_inv (0 on impulse stages; backward: + dt Fqq_inv)
-    ee[L::E_FQQPI + e] = sm[(BWD ? S::FQQI : S::FQQPI) + e];          // what the costate correction needs
-  }
+  // ---- stage 3: finish the q / v columns; assemble MJtJinv = [Minv - TR BL, TR; TR^T, -SM], TR = BL^T SM ----
+  if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);             // reads the scratch: MJ is written only after the next barrier
   if (tid >= 128 && tid < 128 + 6) {
+    // condenseForwardEuler: Fq.head(6) <- -+ Fqq_inv Fq.head(6)
     const int r = tid - 128;
     double acc = 0.0;
     for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQ + m2];
     sm[S::FQ6 + r] = BWD ? acc : -acc;
   }
   __syncthreads();
-  if (tid < 6) sm[S::FQ + tid] = sm[S::FQ6 + tid];
-
-  STAMP(4);
-  // ---- E. Robot::computeMJtJinv (robot.hxx:576-615) ----
-  // M^-1 and (J M^-1 J^T)^-1 by in-place Gauss-Jordan on the SPD blocks (the reference uses
-  // pinocchio's sparse Cholesky + Eigen::LLT; same inverses up to rounding)
-  // (in place, MINV aliases MM.  Measured: the event-free instantiation is faster with the block-wide sweep through LDS
-  // (scratch: MJ, not yet written), the general one with the elimination in the registers of one wavefront)
-  if (PLAIN) spdInverse(&sm[S::MINV], &sm[S::MJ], NV, NV, tid, nt, &s_ok);
-  else {
-    __syncthreads();
-    if (tid < 64) spdInverseRows<NV>(&sm[S::MINV], NV, NV, tid, &s_ok);
-    __syncthreads();
+  if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88)
+  if (tid >= 64 && tid < 64 + 6) sm[S::FQ + tid - 64] = sm[S::FQ6 + tid - 64];
+  for (int e = tid; e < dimf * NV; e += nt) {
+    const int c = e / NV, r = e - c * NV;                              // TR(r, c) = sum_p BL(p, r) SM(p, c)
+    const double tr = dotAny(&sm[S::BL + SF * r], 1, &sm[S::SM + SF * c], 1, dimf);
+    sm[S::MJ + r + SVF * (NV + c)] = tr;
+    sm[S::MJ + (NV + c) + SVF * r] = tr;
   }
-  STAMP(5);
-  if (dimf > 0) {
-    mm(colMajor(&sm[S::BL], SF), colMajor(&sm[S::JM], SF), colMajor(&sm[S::MINV], NV), dimf, NV, NV, 1.0, false, tid, nt);   // BL = J Minv
-    __syncthreads();
-    mm(colMajor(&sm[S::SM], SF), colMajor(&sm[S::BL], SF), transposed(colMajor(&sm[S::JM], SF)), dimf, dimf, NV, 1.0, false, tid, nt);
-    __syncthreads();
-    if (tid < 64) spdInverseRows<SF>(&sm[S::SM], SF, dimf, tid, &s_ok);      // SM = (J Minv J^T)^-1
-    __syncthreads();
-    // TR = BL^T SM -> MJ top-right ; its transpose -> bottom-left ; -SM -> bottom-right
-    mm(sub(colMajor(&sm[S::MJ], SVF), 0, NV), transposed(colMajor(&sm[S::BL], SF)), colMajor(&sm[S::SM], SF), NV, dimf, dimf, 1.0, false, tid, nt);
-    __syncthreads();
-    for (int e = tid; e < dimf * NV; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * c] = sm[S::MJ + c + SVF * (NV + r)]; }
-    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
-    __syncthreads();
-  }
+  for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
+  __syncthreads();
   STAMP(6);
   // TL = Minv - TR BL
   for (int e = tid; e < NV * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;
     sm[S::MJ + r + SVF * c] = sm[S::MINV + e] - dotAny(&sm[S::MJ + r + SVF * NV], SVF, &sm[S::BL + SF * c], 1, dimf);
+  }
+  // ---- C2: multipliers of [ID; C]:  l += dt [dID;dC]^T [beta; mu]; contact rows: - dt J beta ----
+  if (tid >= 192 && tid < 192 + NV) {
+    const int r = tid - 192;
+    const double dq = dotAny(&sm[S::DIDC + SVF * r], 1, &sm[S::BM], 1, dimvf);
+    const double dv = dotAny(&sm[S::DIDC + SVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
+    sm[S::LQ + r] += dt * dq; sm[S::LV + r] += dt * dv;      // (the acceleration rows were completed by wave 1 before it inverted M)
+  } else if (tid >= 224 && tid < 224 + NC) {
+    const int c = tid - 224;
+    if (nd->active[c]) {
+      const int row = nd->row_of[c];
+      for (int x = 0; x < 3; ++x) {
+        double jb = 0.0;
+        for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + SF * col] * sm[S::BM + col];
+        sm[S::LF + row + x] -= dt * jb;
+      }
+    }
   }
   __syncthreads();
 
