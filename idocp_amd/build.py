@@ -1,7 +1,7 @@
 """Build the native pieces in-tree.
 
   build_extension()  hipcc --offload-arch=gfx950  ->  idocp_amd/lib/libidocp_hip.so   (the product)
-  build_oracle()     g++                          ->  oracle/liboracle.so             (test infrastructure)
+  build_oracle()     g++                          ->  oracle/liboracle.so, oracle/liboracle_hp.so (long double referee)   (test infrastructure)
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the
 resulting .so files travel to the GPU box with the tree (they are git-ignored,
@@ -59,7 +59,7 @@ def build_extension(verbose=False, force=False):
 
 
 def build_oracle(verbose=False):
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], capture_output=True, text=True)
     if verbose:
         print(r.stdout)
     if r.returncode != 0:

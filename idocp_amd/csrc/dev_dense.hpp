@@ -206,6 +206,104 @@ __device__ __forceinline__ void spdInverseRows(double* A, int ld, int n, int lan
   for (int j = 0; j < N; ++j) if (on && j < n) A[lane + ld * j] = a[j];
 }
 
+// 1 / sqrt(p) and sqrt(p) for a positive, normal p: hardware estimate + Newton steps (same idea as recipNewton)
+__device__ __forceinline__ void rsqrtNewton(double p, double& rs, double& s) {
+  double x = __builtin_amdgcn_rsq(p);
+  double e = __builtin_fma(-p * x, x, 1.0);
+  x = __builtin_fma(0.5 * x, e, x);
+  e = __builtin_fma(-p * x, x, 1.0);
+  x = __builtin_fma(0.5 * x, e, x);
+  double sq = p * x;
+  const double r = __builtin_fma(-sq, sq, p);
+  sq = __builtin_fma(r, 0.5 * x, sq);
+  rs = x; s = sq;
+}
+
+// Cholesky A = L L^T of an SPD n x n block (n <= N <= 64) in the REGISTERS of one wavefront: lane r keeps row r, the entries of
+// column k travel through v_readlane.  On exit the lower triangle of A (column-major, ld) holds L and invd[k] = 1 / L_kk.
+// Every lane of the wavefront must call it.  With cholSolveLane this is Eigen::LLT compute + solve: backward stable, where a
+// product with an explicit inverse leaves a residual that is cond(A) times larger (what matters for P = F - K^T G K on the
+// stages whose G = Quu + B^T P B is ill-conditioned, split_riccati_factorizer.hxx:43-46).
+template <int N>
+__device__ __forceinline__ void choleskyRows(double* A, int ld, int n, int lane, int* ok, double* invd) {
+  double a[N];
+  const bool on = lane < n;
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (on && j < n) ? A[lane + ld * j] : ((j == lane) ? 1.0 : 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {
+      const double p = readLaneF64(a[k], k);
+      if (lane == 0 && !(p > 0.0)) *ok = 0;
+      double is, sq;
+      rsqrtNewton(p, is, sq);
+      const double lrk = (lane == k) ? sq : a[k] * is;
+      a[k] = lrk;
+      if (lane == 0) invd[k] = is;
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) {
+        const double lck = readLaneF64(lrk, c);
+        a[c] -= lrk * lck;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) if (on && j < n && j <= lane) A[lane + ld * j] = a[j];
+}
+// Cholesky + solve in one pass, everything in registers: lane r keeps row r of the SPD N x N block A (read from LDS, never
+// written back), EVERY lane of the wavefront keeps a right-hand side x of its own and leaves with x <- A^-1 x.  The entries of
+// column k of L travel through v_readlane once and serve both the trailing update and the forward substitution; the backward
+// substitution reads L back out of the row registers the same way.  No LDS traffic, no wait between the steps.
+// n <= N: the block is padded with the identity (the caller keeps x[j] = 0 for j >= n).
+template <int N>
+__device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int lane, int* ok, double (&x)[N], int n = N) {
+  double a[N], dinv = 1.0;      // dinv: 1 / L_kk, kept by lane k
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (lane < n && j < n) ? A[lane + ld * j] : ((j == lane) ? 1.0 : 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double p = readLaneF64(a[k], k);
+    if (lane == 0 && !(p > 0.0)) *ok = 0;
+    double is, sq;
+    rsqrtNewton(p, is, sq);
+    dinv = (lane == k) ? is : dinv;
+    const double lrk = (lane == k) ? sq : a[k] * is;
+    a[k] = lrk;
+    x[k] *= is;
+#pragma unroll
+    for (int c = k + 1; c < N; ++c) {
+      const double lck = readLaneF64(lrk, c);
+      a[c] -= lrk * lck;
+      x[c] -= lck * x[k];
+    }
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    x[i] *= readLaneF64(dinv, i);
+#pragma unroll
+    for (int r = 0; r < i; ++r) x[r] -= readLaneF64(a[r], i) * x[i];
+  }
+}
+
+// x <- (L L^T)^-1 x for the right-hand side held by this lane (n = N); L is read as LDS broadcasts
+template <int N>
+__device__ __forceinline__ void cholSolveLane(const double* Lm, int ld, const double* invd, double (&x)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    x[i] *= invd[i];
+#pragma unroll
+    for (int r = i + 1; r < N; ++r) x[r] -= Lm[r + ld * i] * x[i];
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads of L column by column (hoisted all at once they cost 2 N^2 registers)
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    x[i] *= invd[i];
+#pragma unroll
+    for (int r = 0; r < i; ++r) x[r] -= Lm[i + ld * r] * x[i];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ordering point between LDS writes and reads of ONE wavefront (no workgroup barrier: its LDS operations execute in order)
 __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -32,7 +32,7 @@ struct RiccatiSmem {
                        BTPQ = ATPVV + NV * NV, BTPV = BTPQ + NU * NV, KM = BTPV + NU * NV,
                        GK = BTPQ,                                            // Quu K reuses the B^T P scratch
                        KV = KM + NU * NX,
-                       GW = KV + 16, SQN = GW + NU * NU, SVN = SQN + NV, TOTAL = SVN + NV + 4;
+                       GW = KV + 16, SQN = GW + NU * NU, SVN = SQN + NV, INVD = SVN + NV + 4, TOTAL = INVD + NU + 4;
   static_assert(2 * NU * NV == NU * NX, "GK aliases B^T P");
   // extra blocks of the HYBRID instantiation (stages that carry a switching constraint: Schur-complement step of
   // SplitRiccatiFactorizer::backwardRiccatiRecursion, split_riccati_factorizer.hxx:43-101)
@@ -317,10 +317,32 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     // ---- LLT(Quu), K = -Quu^-1 Qxu^T, k = -Quu^-1 lu (split_riccati_factorizer.hxx:43-46) ----
     // (the reference factorises with Eigen::LLT; here Quu^-1 is formed by Gauss-Jordan on one
     // wavefront and applied with two small products -- same K, k up to rounding)
-    for (int e = tid; e < NU * NU; e += nt) sm[S::GW + e] = Quu[e];
-    __syncthreads();
     RSTAMP(9);
-    if (tid < 64) spdInverseRows<NU>(&sm[S::GW], NU, NU, tid, &s_ok);
+    // Quu = L L^T and the solves K = -Quu^-1 Qxu^T, k = -Quu^-1 lu in the registers of one wavefront, one right-hand side per lane
+    // (Eigen::LLT compute + solve, split_riccati_factorizer.hxx:43-46).  Round 1 multiplied with an explicit Gauss-Jordan
+    // inverse: on the stage behind a switching constraint G = Quu + B^T P B has a condition number of 1e8 and P = F - K^T G K came
+    // out 6e-9 off (5e-12 with the solves; long double referee, tests/test_hybrid_gpu.py).
+    const bool constrained = HYBRID && dimi > 0;
+    if (tid < 64) {
+      double x[NU];
+      if (!constrained) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) x[m] = (tid < NX) ? Qxu[tid + NX * m] : lu[m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) x[m] = (m == tid) ? 1.0 : 0.0;      // Ginv = llt.solve(I) (:60): the Schur-complement step works with the explicit inverse, like the reference
+      }
+      choleskySolveRows<NU>(Quu, NU, tid, &s_ok, x);
+      if (!constrained) {
+        if (tid <= NX) {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) { if (tid < NX) sm[S::KM + m + NU * tid] = -x[m]; else sm[S::KV + m] = -x[m]; }
+        }
+      } else if (tid < NU) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) sm[S::GW + m + NU * tid] = x[m];
+      }
+    }
     __syncthreads();
     RSTAMP(10);
     if (HYBRID && dimi > 0) {
@@ -341,13 +363,29 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
         sm[S::SS + j + NF * c] = acc;
       }
       __syncthreads();
-      if (tid < 64) spdInverseRows<NF>(&sm[S::SS], NF, dimi, tid, &s_ok);      // S^-1 (LLT in the reference)
-      __syncthreads();
-      for (int e = tid; e < dimi * NU; e += nt) {                // SinvDGinv
-        const int c = e / dimi, j = e - c * dimi;
-        double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += sm[S::SS + j + NF * l] * sm[S::DG + l + NF * c];
-        sm[S::SDG + j + NF * c] = acc;
+      // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves like the reference's llt_s_.solve (:64-66, 71-74): Cholesky and the
+      // 49 right-hand sides in the registers of one wavefront (lane = column).  Round 1 formed S^-1 by unpivoted Gauss-Jordan and
+      // multiplied: on a stage a few milliseconds in front of a touch-down S is ill-conditioned and the explicit inverse added its
+      // share to a direction 1e-6 off (now 1e-10, as far as the FP64 oracle itself is from the long double build, tests/test_hybrid_gpu.py).
+      if (tid < 64) {
+        static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
+        const double* __restrict__ Wc = B.swc + rec * L::SWC;
+        double x[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          double val = 0.0;
+          if (j < dimi) val = tid < NU ? sm[S::DG + j + NF * tid] : (tid < NU + NX ? Wc[L::W_PHIX + j + NF * (tid - NU)] : (tid == NU + NX ? Wc[L::W_P + j] : 0.0));
+          x[j] = val;
+        }
+        choleskySolveRows<NF>(&sm[S::SS], NF, tid, &s_ok, x, dimi);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          if (j < dimi) {
+            if (tid < NU) sm[S::SDG + j + NF * tid] = x[j];
+            else if (tid < NU + NX) sm[S::MMX + j + NF * (tid - NU)] = x[j];      // S^-1 Phix; - SinvDGinv Qxu^T follows below
+            else if (tid == NU + NX) sm[S::MV + j] = x[j];
+          }
+        }
       }
       __syncthreads();
       for (int e = tid; e < NU * NU; e += nt) {                  // Ginv -= SinvDGinv^T DGinv
@@ -358,37 +396,40 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
       }
       __syncthreads();
     }
-    for (int e = tid; e < NU * NX; e += nt) {
-      const int c = e / NU, j = e - c * NU;
-      double acc = 0.0;
+    if (constrained) {
+      // K = -Ginv Qxu^T - SinvDGinv^T Phix, k = -Ginv lu - SinvDGinv^T P with the updated Ginv (:67-70)
+      const double* __restrict__ Phix = B.swc + rec * L::SWC + L::W_PHIX;
+      const double* __restrict__ Pv = B.swc + rec * L::SWC + L::W_P;
+      for (int e = tid; e < NU * NX; e += nt) {
+        const int c = e / NU, j = e - c * NU;
+        double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
-      if (HYBRID && dimi > 0) { const double* __restrict__ Phix = B.swc + rec * L::SWC + L::W_PHIX; for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Phix[l + NF * c]; }     // K -= SinvDGinv^T Phix
-      sm[S::KM + e] = -acc;
-    }
-    if (tid >= NT - NU) {
-      const int j = tid - (NT - NU);
-      double acc = 0.0;
+        for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
+        for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Phix[l + NF * c];
+        sm[S::KM + e] = -acc;
+      }
+      if (tid >= NT - NU) {
+        const int j = tid - (NT - NU);
+        double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
-      if (HYBRID && dimi > 0) { const double* __restrict__ Pv = B.swc + rec * L::SWC + L::W_P; for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Pv[l]; }              // k -= SinvDGinv^T P
-      sm[S::KV + j] = -acc;
+        for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
+        for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Pv[l];
+        sm[S::KV + j] = -acc;
+      }
     }
     if (HYBRID && dimi > 0) {
-      // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu
+      // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu (S^-1 Phix, S^-1 P: see above)
       double* __restrict__ W = B.swc + rec * L::SWC;
       for (int e = tid; e < dimi * NX; e += nt) {
         const int c = e / dimi, l = e - c * dimi;
-        double acc = 0.0;
-        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * W[L::W_PHIX + j + NF * c];
+        double acc = sm[S::MMX + l + NF * c];
         for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
         sm[S::MMX + l + NF * c] = acc;
         W[L::W_M + l + NF * c] = acc;
       }
       if (tid < dimi) {
         const int l = tid;
-        double acc = 0.0;
-        for (int j = 0; j < dimi; ++j) acc += sm[S::SS + l + NF * j] * W[L::W_P + j];
+        double acc = sm[S::MV + l];
         for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * lu[m];
         sm[S::MV + l] = acc;
         W[L::W_m + l] = acc;

@@ -43,7 +43,7 @@ int ContactSequenceC::eventOfLift(int k) const {
   return -1;
 }
 
-OCPSolver::OCPSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N,
+OCPSolver::OCPSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
                      int max_num_impulse)
     : robot(model), cost(cost_), cons(constraints), N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts),
       max_events_(max_num_impulse), T_(T), dt_(T / N) {
@@ -89,7 +89,7 @@ void OCPSolver::setContactStatusUniformly(const std::vector<int>& active, const 
 }
 
 // ContactSequence::push_back (contact_sequence.hxx:52-104) + DiscreteEvent::setDiscreteEvent (discrete_event.hxx:57-84)
-void OCPSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, double switching_time) {
+void OCPSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, real switching_time) {
   // the sequence itself holds up to N events (ocp_solver.cpp:16: contact_sequence_(robot, N)); the event stages live in
   // containers of max_num_impulse impulse / aux / lift entries each (hybrid_container.hpp:39-96), checked below
   if (seq.numEvents() + 1 > N_ideal_) throw std::runtime_error("Number of discrete events exceeds predefined max_num_events!");
@@ -137,17 +137,17 @@ void OCPSolver::setSolution(const std::string& name, const Mat& value) {
 
 // ------------------------------------------------------------ discretiser ----
 // OCPDiscretizer::discretizeOCP (ocp_discretizer.hxx:65-374), transcribed step by step.
-void OCPSolver::discretize(double t) {
-  const double min_dt = std::sqrt(std::numeric_limits<double>::epsilon());    // ocp_discretizer.hpp:108-109
-  const double dt_ideal = T_ / N_ideal_, max_dt = dt_ideal - min_dt;
+void OCPSolver::discretize(real t) {
+  const real min_dt = std::sqrt(std::numeric_limits<real>::epsilon());    // ocp_discretizer.hpp:108-109
+  const real dt_ideal = T_ / N_ideal_, max_dt = dt_ideal - min_dt;
   const int Ni = seq.numImpulse(), Nl = seq.numLift();
   std::vector<int> tsbi(Ni + 1, -1), tsbl(Nl + 1, -1);
-  std::vector<double> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
+  std::vector<real> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
   // countDiscreteEvents (:271-288)
   for (int kx = 0; kx < Ni; ++kx) { t_imp[kx] = seq.event_time[seq.eventOfImpulse(kx)]; tsbi[kx] = (int)std::floor((t_imp[kx] - t) / dt_ideal); }
   for (int kx = 0; kx < Nl; ++kx) { t_lift[kx] = seq.event_time[seq.eventOfLift(kx)]; tsbl[kx] = (int)std::floor((t_lift[kx] - t) / dt_ideal); }
   // countTimeSteps (:291-345)
-  std::vector<double> dts(N_ideal_ + 1, dt_ideal), ts(N_ideal_ + 1, 0.0);
+  std::vector<real> dts(N_ideal_ + 1, dt_ideal), ts(N_ideal_ + 1, 0.0);
   int ii = 0, li = 0, on_grid = 0;
   for (int i = 0; i < N_ideal_; ++i) {
     const int stage = i - on_grid;
@@ -181,7 +181,7 @@ void OCPSolver::discretize(double t) {
   for (int i = 0; i < N_; ++i) if (imp_after[i] >= 0 && lift_after[i] >= 0) throw std::runtime_error("OCPDiscretizer: not well defined");
   // the chain
   chain.clear();
-  auto node = [&](int kind, int index, double tt, double dtt, int ph, int level) {
+  auto node = [&](int kind, int index, real tt, real dtt, int ph, int level) {
     NodeC nd; nd.kind = kind; nd.index = index; nd.slot = slotOf(kind, index); nd.t = tt; nd.dt = dtt; nd.phase = ph; nd.level = level;
     chain.push_back(nd);
   };
@@ -232,7 +232,7 @@ bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraint
 int OCPSolver::componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
 int OCPSolver::dimc() const { int n = 0; for (int c = 0; c < 7; ++c) if (componentEnabled(c, false)) n += componentDim(c); return n; }
 
-static double limitOf(const idocp_model_t& m, int c, int k2) {
+static real limitOf(const RModel& m, int c, int k2) {
   switch (c) {
     case 0: return m.q_min[k2];
     case 1: return m.q_max[k2];
@@ -243,19 +243,19 @@ static double limitOf(const idocp_model_t& m, int c, int k2) {
   }
 }
 // value of the limited variable (joint part)
-static double limitedVar(const SplitSolutionC& s, int c, int k2, int nv, int nu) {
+static real limitedVar(const SplitSolutionC& s, int c, int k2, int nv, int nu) {
   if (c < 2) return s.q[s.q.size() - nu + k2];
   if (c < 4) return s.v[nv - nu + k2];
   return s.u[k2];
 }
 // LinearizedFrictionCone::frictionConeResidual (linearized_friction_cone.hpp:72-84)
-static void frictionConeResidual(double mu, const Mat& f, double* res) {
-  const double m2 = mu / std::sqrt(2.0);
+static void frictionConeResidual(real mu, const Mat& f, real* res) {
+  const real m2 = mu / std::sqrt(2.0);
   res[0] = -f[2]; res[1] = f[0] - m2 * f[2]; res[2] = -f[0] - m2 * f[2]; res[3] = f[1] - m2 * f[2]; res[4] = -f[1] - m2 * f[2];
 }
-static void frictionJac(double mu, double J[5][3]) {        // linearized_friction_cone.cpp:25-29
-  const double m2 = mu / std::sqrt(2.0);
-  const double Jc[5][3] = {{0, 0, -1}, {1, 0, -m2}, {-1, 0, -m2}, {0, 1, -m2}, {0, -1, -m2}};
+static void frictionJac(real mu, real J[5][3]) {        // linearized_friction_cone.cpp:25-29
+  const real m2 = mu / std::sqrt(2.0);
+  const real Jc[5][3] = {{0, 0, -1}, {1, 0, -m2}, {-1, 0, -m2}, {0, 1, -m2}, {0, -1, -m2}};
   for (int r = 0; r < 5; ++r) for (int c = 0; c < 3; ++c) J[r][c] = Jc[r][c];
 }
 
@@ -268,11 +268,11 @@ void OCPSolver::initNodeConstraints(const NodeC& nd) {
     IpmData data(componentDim(c));
     if (componentValid(c, nd)) {
       if (c < 6) {
-        const double sgn = (c & 1) ? 1.0 : -1.0;
+        const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(sp, c, r, nv_, nu_) - limitOf(robot.model(), c, r));
       } else {
         for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
-          double res[5]; frictionConeResidual(cons.mu, sp.f[cc], res);
+          real res[5]; frictionConeResidual(cons.mu, sp.f[cc], res);
           for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
         }
       }
@@ -286,7 +286,7 @@ void OCPSolver::initNodeConstraints(const NodeC& nd) {
 }
 
 // OCPSolver::initConstraints (ocp_solver.cpp:60-64) -> OCPLinearizer::initConstraints (ocp_linearizer.cpp:40-70)
-void OCPSolver::initConstraints(double t) {
+void OCPSolver::initConstraints(real t) {
   discretize(t);
   // every slot gets constraint data (the reference initialises all N_ideal stages and every event stage in use)
   for (int i = 0; i <= N_ideal_; ++i) { NodeC nd; nd.kind = i < N_ideal_ ? NodeC::Stage : NodeC::Terminal; nd.slot = i; nd.index = i; nd.level = i; initNodeConstraints(nd); }
@@ -295,16 +295,16 @@ void OCPSolver::initConstraints(double t) {
 
 // ------------------------------------------------------------------ cost ----
 // TimeVaryingConfigurationSpaceCost::v_ref(t) (include/idocp/cost/time_varying_configuration_space_cost.hpp:111-118)
-static double vRefScale(const idocp_cost_t& cost, double t) {
+static real vRefScale(const RCost& cost, real t) {
   if (!cost.use_time_varying_ref) return 1.0;
   return (t > cost.tv_t_begin && t < cost.tv_t_end) ? 1.0 : 0.0;
 }
 
-void OCPSolver::qRef(double t, Mat& q_ref) const {
+void OCPSolver::qRef(real t, Mat& q_ref) const {
   q_ref = Mat(robot.dimq());
   for (int i = 0; i < robot.dimq(); ++i) q_ref[i] = cost.q_ref[i];
   if (cost.use_time_varying_ref) {      // set_q_ref (time_varying_configuration_space_cost.hpp:98-109)
-    const double tau = t <= cost.tv_t_begin ? 0.0 : ((t < cost.tv_t_end ? t : cost.tv_t_end) - cost.tv_t_begin);
+    const real tau = t <= cost.tv_t_begin ? 0.0 : ((t < cost.tv_t_end ? t : cost.tv_t_end) - cost.tv_t_begin);
     if (tau > 0.0) {
       Mat qb = q_ref, v(robot.dimv());
       for (int i = 0; i < robot.dimv(); ++i) v[i] = cost.v_ref[i];
@@ -313,10 +313,10 @@ void OCPSolver::qRef(double t, Mat& q_ref) const {
     return;
   }
   if (!cost.use_trotting_ref || !(t > cost.t_start)) return;
-  const double tau = t - cost.t_start;
+  const real tau = t - cost.t_start;
   const int steps = (int)std::floor(tau / cost.t_period);
-  const double rate = (tau - steps * cost.t_period) / cost.t_period;
-  const double sin2 = std::sin(M_PI_2 * rate);
+  const real rate = (tau - steps * cost.t_period) / cost.t_period;
+  const real sin2 = std::sin(M_PI_2 * rate);
   q_ref[0] += (steps + rate) * cost.step_length;
   if (steps % 2 == 0) {
     q_ref[9] -= sin2 * cost.front_swing_knee;  q_ref[12] -= sin2 * cost.hip_stance_knee;
@@ -343,9 +343,9 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
   ContactDynamicsDataC& D = cd[nd.slot];
   const ContactStatus& cs = nodeContacts(p);
   const int nv = nv_, nu = nu_, dimf = cs.dimf();
-  const double dt = impulse ? 1.0 : nd.dt;          // scaling of cost / constraints / dynamics multipliers
-  const double dtq = impulse ? 0.0 : nd.dt;         // q+ = q (+) dtq v
-  const double t = nd.t;
+  const real dt = impulse ? 1.0 : nd.dt;          // scaling of cost / constraints / dynamics multipliers
+  const real dtq = impulse ? 0.0 : nd.dt;         // q+ = q (+) dtq v
+  const real t = nd.t;
   if (impulse) robot.updateKinematics(si.q, si.v + si.a, Mat(nv));     // impulse_split_ocp.hxx:47
   else robot.updateKinematics(si.q, si.v, si.a);
   if (!residual_only) {
@@ -354,11 +354,11 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
   }
   R.Fq.setZero(); R.Fv.setZero(); R.lq.setZero(); R.lv.setZero(); R.la.setZero(); R.lf = Mat(dimf); R.lu.setZero(); R.lu_passive.setZero();
   R.P = Mat(0);
-  const double* wq = impulse ? cost.qi_weight : cost.q_weight;
-  const double* wv = impulse ? cost.vi_weight : cost.v_weight;
-  const double* wa = impulse ? cost.dvi_weight : cost.a_weight;
-  const double (*wf)[3] = impulse ? cost.fi_weight : cost.f_weight;
-  const double (*rf)[3] = impulse ? cost.fi_ref : cost.f_ref;
+  const real* wq = impulse ? cost.qi_weight : cost.q_weight;
+  const real* wv = impulse ? cost.vi_weight : cost.v_weight;
+  const real* wa = impulse ? cost.dvi_weight : cost.a_weight;
+  const real (*wf)[3] = impulse ? cost.fi_weight : cost.f_weight;
+  const real (*rf)[3] = impulse ? cost.fi_ref : cost.f_ref;
   // ---- cost: (Trotting)ConfigurationSpaceCost + ContactForceCost
   // (configuration_space_cost.cpp:292-310, trotting_configuration_space_cost.cpp:269-327, contact_force_cost.cpp:153-179)
   Mat q_ref, qdiff, Jq;
@@ -367,8 +367,8 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
   robot.dSubtractdConfigurationPlus(si.q, q_ref, Jq);
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = wq[r] * qdiff[r];
   R.lq += dt * (Jq.t() * Wq);
-  const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
-  const double vs = vRefScale(cost, t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
+  const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const real vs = vRefScale(cost, t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) {
     R.lv[r] += dt * wv[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
     R.la[r] += dt * wa[r] * si.a[r];
@@ -382,12 +382,12 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
     }
   }
   // ---- constraints: [computePrimalAndDualResidual] + augmentDualResidual
-  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int c = 0; c < 7; ++c) {
     if (!componentValid(c, nd)) continue;
     IpmData& data = ipm[nd.slot][c];
     if (c < 6) {
-      const double sgn = (c & 1) ? 1.0 : -1.0;
+      const real sgn = (c & 1) ? 1.0 : -1.0;
       Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
@@ -402,7 +402,7 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
         if (residual_only) {
-          double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+          real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
           for (int r = 0; r < 5; ++r) {
             data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
             data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
@@ -482,7 +482,7 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
   if (nd.sw_event >= 0) {
     const ContactStatus& is = seq.impulse_status[nd.sw_event];
     const int dimi = is.dimf();
-    const double dt1 = nd.dt, dt2 = nd.sw_dt_next;
+    const real dt1 = nd.dt, dt2 = nd.sw_dt_next;
     Mat dq_ = (dt1 + dt2) * si.v + (dt1 * dt2) * si.a, q_;
     robot.integrateConfiguration(si.q, dq_, 1.0, q_);
     robot.updateKinematics(q_, Mat(nv), Mat(nv));
@@ -517,11 +517,11 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
     if (!componentValid(c, nd)) continue;
     IpmData& data = ipm[nd.slot][c];
     if (c < 6) {
-      const double sgn = (c & 1) ? 1.0 : -1.0;
+      const real sgn = (c & 1) ? 1.0 : -1.0;
       Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
-        const double h = dt * data.dual[r] / data.slack[r];
+        const real h = dt * data.dual[r] / data.slack[r];
         if (c < 2) M.Qxx(kP + r, kP + r) += h;
         else if (c < 4) M.Qxx(nv + kP + r, nv + kP + r) += h;
         else M.Quu_full(kP + r, kP + r) += h;
@@ -534,8 +534,8 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
       data.residual.setZero(); data.duality.setZero();
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-        double rr[5], dd[5];
+        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        real rr[5], dd[5];
         for (int r = 0; r < 5; ++r) {
           const int idx = 5 * cc + r;
           data.residual[idx] = res[r] + data.slack[idx];
@@ -545,7 +545,7 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
         }
         for (int x = 0; x < 3; ++x) {
           for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
-          for (int y = 0; y < 3; ++y) { double acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
+          for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
         }
         st += 3;
       }
@@ -605,8 +605,8 @@ void OCPSolver::linearizeTerminal(int p, const Mat& q_prev, bool residual_only) 
   robot.dSubtractdConfigurationPlus(sN.q, q_ref, Jq);
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.qf_weight[r] * qdiff[r];
   R.lq += Jq.t() * Wq;
-  const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
-  const double vs = vRefScale(cost, nd.t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
+  const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const real vs = vRefScale(cost, nd.t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (sN.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   // linearizeForwardEulerTerminal (state_equation.hxx:66-83)
   Mat Fqq_prev; robot.dSubtractdConfigurationMinus(q_prev, sN.q, Fqq_prev);
@@ -624,7 +624,7 @@ void OCPSolver::linearizeTerminal(int p, const Mat& q_prev, bool residual_only) 
 }
 
 // OCPLinearizer::runParallel (ocp_linearizer.hxx:113-228); q_prev (:231-248) is the chain predecessor's q
-void OCPSolver::linearizeOCP(double t, const Mat& q) {
+void OCPSolver::linearizeOCP(real t, const Mat& q) {
   discretize(t);
   for (int p = 0; p < M(); ++p) {
     const Mat& q_prev = (p == 0) ? q : s[chain[p - 1].slot].q;
@@ -633,7 +633,7 @@ void OCPSolver::linearizeOCP(double t, const Mat& q) {
   }
 }
 
-void OCPSolver::computeKKTResidual(double t, const Mat& q, const Mat& /*v*/) {
+void OCPSolver::computeKKTResidual(real t, const Mat& q, const Mat& /*v*/) {
   discretize(t);
   for (int p = 0; p < M(); ++p) {
     const Mat& q_prev = (p == 0) ? q : s[chain[p - 1].slot].q;
@@ -655,29 +655,29 @@ int OCPSolver::isCurrentSolutionFeasible() const {
       for (int c = 0; c < 6; ++c) {
         if (!componentValid(c, nd)) continue;
         for (int r = 0; r < nu_; ++r) {
-          const double x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
+          const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
       }
       if (!componentValid(6, nd)) continue;
       const ContactStatus& cs = nodeContacts(p);
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
         for (int r = 0; r < 5; ++r) if (res[r] > 0) return p;
       }
     }
   return -1;
 }
 
-double OCPSolver::KKTError() {
-  double sum = 0;
+real OCPSolver::KKTError() {
+  real sum = 0;
   for (int p = 0; p < M() - 1; ++p) {
     const NodeC& nd = chain[p];
     const SplitKKTResidualC& R = kkt_residual[nd.slot];
-    const double dt = nd.kind == NodeC::Impulse ? 1.0 : nd.dt;
-    double e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
+    const real dt = nd.kind == NodeC::Impulse ? 1.0 : nd.dt;
+    real e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
                R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt * dt * cd[nd.slot].IDC.squaredNorm();
-    double c2 = 0;
+    real c2 = 0;
     for (int c = 0; c < 7; ++c) if (componentValid(c, nd)) c2 += ipm[nd.slot][c].residual.squaredNorm() + ipm[nd.slot][c].duality.squaredNorm();
     sum += e + dt * dt * c2 + R.P.squaredNorm();
   }
@@ -705,7 +705,7 @@ void OCPSolver::backwardRiccatiRecursion() {
   for (int p = M() - 2; p >= 0; --p) {
     const NodeC& nd = chain[p];
     const bool impulse = nd.kind == NodeC::Impulse;
-    const double dt = impulse ? 0.0 : nd.dt;
+    const real dt = impulse ? 0.0 : nd.dt;
     const int sl = nd.slot;
     const RiccatiC& rn = riccati[chain[p + 1].slot];
     SplitKKTMatrixC& Mx = kkt_matrix[sl];
@@ -835,7 +835,7 @@ void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
     const NodeC& nd = chain[p];
     const int sl = nd.slot, sn = chain[p + 1].slot;
     const bool impulse = nd.kind == NodeC::Impulse;
-    const double dt = impulse ? 0.0 : nd.dt;
+    const real dt = impulse ? 0.0 : nd.dt;
     const SplitKKTMatrixC& Mx = kkt_matrix[sl];
     const SplitKKTResidualC& R = kkt_residual[sl];
     Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
@@ -852,10 +852,10 @@ void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
   }
 }
 
-static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {      // pdipm.hxx:52-73
-  double m = 1;
+static real fractionToBoundary(real rate, const Mat& vec, const Mat& dvec) {      // pdipm.hxx:52-73
+  real m = 1;
   for (int i = 0; i < vec.size(); ++i) {
-    const double f = -rate * (vec[i] / dvec[i]);
+    const real f = -rate * (vec[i] / dvec[i]);
     if (f > 0 && f < 1 && f < m) m = f;
   }
   return m;
@@ -865,8 +865,8 @@ static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {
 // RiccatiRecursionSolver::computeDirection (riccati_recursion_solver.cpp:165-251)
 void OCPSolver::computeDirection() {
   const int nv = nv_, nu = nu_;
-  double pmin = 1, dmin = 1;
-  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  real pmin = 1, dmin = 1;
+  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int p = 0; p < M(); ++p) {
     const NodeC& nd = chain[p];
     const int sl = nd.slot;
@@ -892,9 +892,9 @@ void OCPSolver::computeDirection() {
       if (!componentValid(c, nd)) continue;
       IpmData& data = ipm[sl][c];
       if (c < 6) {
-        const double sgn = (c & 1) ? 1.0 : -1.0;
+        const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r2 = 0; r2 < nu; ++r2) {
-          const double dxr = c < 2 ? d[sl].dq[kP + r2] : (c < 4 ? d[sl].dv[kP + r2] : d[sl].du[r2]);
+          const real dxr = c < 2 ? d[sl].dq[kP + r2] : (c < 4 ? d[sl].dv[kP + r2] : d[sl].du[r2]);
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
@@ -904,7 +904,7 @@ void OCPSolver::computeDirection() {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           for (int r2 = 0; r2 < 5; ++r2) {
             const int idx = 5 * cc + r2;
-            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[sl].daf[nv + st + x];
+            real Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[sl].daf[nv + st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
           }
@@ -921,7 +921,7 @@ void OCPSolver::computeDirection() {
 // OCPLinearizer::integrateSolution (ocp_linearizer.cpp:140-221)
 void OCPSolver::integrateSolution() {
   const int nv = nv_, nu = nu_;
-  const double ap = primal_step_size, ad = dual_step_size;
+  const real ap = primal_step_size, ad = dual_step_size;
   for (int p = 0; p < M(); ++p) {
     const NodeC& nd = chain[p];
     const int sl = nd.slot;
@@ -931,7 +931,7 @@ void OCPSolver::integrateSolution() {
     if (!terminal) {
       ContactDynamicsDataC& D = cd[sl];
       SplitKKTResidualC& R = kkt_residual[sl];
-      const double dt = impulse ? 1.0 : nd.dt;
+      const real dt = impulse ? 1.0 : nd.dt;
       const int dimf = cs.dimf();
       Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
       const Mat& dgmm = d[chain[p + 1].slot].dgmm;
@@ -981,18 +981,18 @@ void OCPSolver::integrateSolution() {
   }
 }
 
-void OCPSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+void OCPSolver::updateSolution(real t, const Mat& q, const Mat& v) {
   linearizeOCP(t, q);
   auto t0 = std::chrono::steady_clock::now();
   backwardRiccatiRecursion();
   forwardRiccatiRecursion(q, v);
-  riccati_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  riccati_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
   computeDirection();
   integrateSolution();
 }
 
 // =============================================================================================== ParNMPC ====
-ParNMPCSolver::ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& constraints, double T, int N,
+ParNMPCSolver::ParNMPCSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
                              int max_num_impulse)
     : robot(model), cost(cost_), cons(constraints), next_s(robot), next_snew(robot), prev_s(robot), prev_snew(robot),
       N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), max_events_(max_num_impulse), T_(T), dt_(T / N) {
@@ -1031,7 +1031,7 @@ int ParNMPCSolver::haloSize(int kind) const {
   const int nq = robot.dimq(), nv = nv_, nx = 2 * nv;
   switch (kind) { case 0: case 4: return nq + nv; case 1: return 2 * nv + nq; case 2: return nx * nx; case 3: return 2 * nv; default: return nx * nx; }
 }
-void ParNMPCSolver::exportHalo(int kind, double* out) const {
+void ParNMPCSolver::exportHalo(int kind, real* out) const {
   const int nq = robot.dimq(), nv = nv_;
   auto put = [&](const Mat& m, int off) { for (int k = 0; k < m.size(); ++k) out[off + k] = m[k]; };
   // first / last stage of this shard's chain (slots 0 and N - 1 of an event-free shard)
@@ -1045,7 +1045,7 @@ void ParNMPCSolver::exportHalo(int kind, double* out) const {
     default: put(aux_mat[first], 0); break;
   }
 }
-void ParNMPCSolver::importHalo(int kind, const double* in) {
+void ParNMPCSolver::importHalo(int kind, const real* in) {
   const int nq = robot.dimq(), nv = nv_;
   auto get = [&](Mat& m, int off) { for (int k = 0; k < m.size(); ++k) m[k] = in[off + k]; };
   switch (kind) {
@@ -1069,7 +1069,7 @@ void ParNMPCSolver::setContactStatusUniformly(const std::vector<int>& active, co
 }
 
 // ContactSequence::push_back (contact_sequence.hxx:63-117); capacities as in OCPSolver (see OCPSolver::pushBackContactStatus)
-void ParNMPCSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, double switching_time) {
+void ParNMPCSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, real switching_time) {
   if (seq.numEvents() + 1 > N_ideal_) throw std::runtime_error("Number of discrete events exceeds predefined max_num_events!");
   if (seq.numEvents() > 0 && switching_time <= seq.event_time.back()) throw std::runtime_error("event_time must be larger than the last event time!");
   const ContactStatus& pre = seq.phases.back();
@@ -1106,7 +1106,7 @@ void ParNMPCSolver::setSolution(const std::string& name, const Mat& value) {
 
 // ParNMPCDiscretizer::discretizeOCP (parnmpc_discretizer.hxx:65-72): countDiscreteEvents (:246-262), countTimeSteps
 // (:265-324), countTimeStages (:327-361), countContactPhase (:364-373)
-void ParNMPCSolver::discretize(double t) {
+void ParNMPCSolver::discretize(real t) {
   if (discretized_ && disc_t_ == t) return;
   chain.clear();
   const int Ne = seq.numEvents();
@@ -1123,12 +1123,12 @@ void ParNMPCSolver::discretize(double t) {
   }
   if (stage_offset != 0) throw std::logic_error("ParNMPC oracle: a horizon with discrete events is sharded by setChainSlice");
   const int Nid = N_ideal_, Ni = seq.numImpulse(), Nl = seq.numLift();
-  const double dt_ideal = dt_, min_dt = std::sqrt(std::numeric_limits<double>::epsilon()), max_dt = dt_ideal - min_dt;
+  const real dt_ideal = dt_, min_dt = std::sqrt(std::numeric_limits<real>::epsilon()), max_dt = dt_ideal - min_dt;
   std::vector<int> tsai(Ni + 1, -1), tsal(Nl + 1, -1);      // time stage AFTER the impulse / lift
-  std::vector<double> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
+  std::vector<real> t_imp(Ni + 1, 0.0), t_lift(Nl + 1, 0.0), dt_aux(Ni + 1, 0.0), dt_lift(Nl + 1, 0.0);
   for (int k = 0; k < Ni; ++k) { t_imp[k] = seq.event_time[seq.eventOfImpulse(k)]; tsai[k] = (int)std::floor((t_imp[k] - t) / dt_ideal); }
   for (int k = 0; k < Nl; ++k) { t_lift[k] = seq.event_time[seq.eventOfLift(k)]; tsal[k] = (int)std::floor((t_lift[k] - t) / dt_ideal); }
-  std::vector<double> dts(Nid + 1, dt_ideal), ts(Nid + 1, 0.0);
+  std::vector<real> dts(Nid + 1, dt_ideal), ts(Nid + 1, 0.0);
   int ii = 0, li = 0, on_grid = 0;
   for (int i = 0; i < Nid; ++i) {
     const int stage = i - on_grid;
@@ -1212,7 +1212,7 @@ bool ParNMPCSolver::componentValid(int c, const PNode& nd) const {     // constr
   return cons.linearized_friction_cone != 0;
 }
 
-void ParNMPCSolver::qRef(double t, Mat& q_ref) const {
+void ParNMPCSolver::qRef(real t, Mat& q_ref) const {
   OCPSolver tmp_unused_guard(robot.model(), cost, cons, 1.0, 1);     // reuse the reference generator of the OCP oracle
   tmp_unused_guard.qRef(t, q_ref);
 }
@@ -1223,7 +1223,7 @@ const SplitSolutionC* ParNMPCSolver::nextSolution(int p) const {
 }
 
 // BackwardCorrectionSolver::initAuxMat (backward_correction_solver.cpp:54-92): every aux_mat = terminal cost Hessian at s[N-1]
-void ParNMPCSolver::initBackwardCorrection(double t) {
+void ParNMPCSolver::initBackwardCorrection(real t) {
   discretize(t);
   const int nv = nv_;
   Mat q_ref, Jq;
@@ -1245,12 +1245,12 @@ void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
     IpmData data(componentDim(c));
     if (componentValid(c, nd)) {
       if (c < 6) {
-        const double sgn = (c & 1) ? 1.0 : -1.0;
+        const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
       } else {
         for (int cc = 0; cc < nc_; ++cc) {
           if (seq.numEvents() > 0 && !cs.active[cc]) { for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = cons.barrier; continue; }
-          double res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
+          real res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
           for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
         }
       }
@@ -1264,7 +1264,7 @@ void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
 }
 
 // ParNMPCLinearizer::initConstraints (parnmpc_linearizer.cpp:43-75): stage i with time step i + 1, aux / lift with 0
-void ParNMPCSolver::initConstraints(double t) {
+void ParNMPCSolver::initConstraints(real t) {
   discretize(t);
   if (seq.numEvents() == 0) {
     for (const PNode& nd : chain) initNodeConstraints(nd);
@@ -1292,7 +1292,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   ContactDynamicsDataC& D = cd[i];
   const ContactStatus& cs = nodeContacts(nd);
   const int nv = nv_, nu = nu_, dimf = cs.dimf();
-  const double dt = nd.dt, t = nd.t;
+  const real dt = nd.dt, t = nd.t;
   robot.updateKinematics(si.q, si.v, si.a);
   if (!residual_only) {
     M.Qxx.setZero(); M.Qxu_full.setZero(); M.Quu_full.setZero(); M.Qaa_diag.setZero(); M.Qff = Mat(dimf, dimf);
@@ -1307,8 +1307,8 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   robot.dSubtractdConfigurationPlus(si.q, q_ref, Jq);
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.q_weight[r] * qdiff[r];
   R.lq += dt * (Jq.t() * Wq);
-  const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
-  const double vs = vRefScale(cost, t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
+  const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const real vs = vRefScale(cost, t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) {
     R.lv[r] += dt * cost.v_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
     R.la[r] += dt * cost.a_weight[r] * si.a[r];
@@ -1327,12 +1327,12 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   }
   // ---- constraints
-  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int c = 0; c < 7; ++c) {
     if (!componentValid(c, nd)) continue;
     IpmData& data = ipm[i][c];
     if (c < 6) {
-      const double sgn = (c & 1) ? 1.0 : -1.0;
+      const real sgn = (c & 1) ? 1.0 : -1.0;
       Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
@@ -1347,7 +1347,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
         if (residual_only) {
-          double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+          real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
           for (int r = 0; r < 5; ++r) {
             data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
             data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
@@ -1442,11 +1442,11 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     if (!componentValid(c, nd)) continue;
     IpmData& data = ipm[i][c];
     if (c < 6) {
-      const double sgn = (c & 1) ? 1.0 : -1.0;
+      const real sgn = (c & 1) ? 1.0 : -1.0;
       Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
-        const double h = dt * data.dual[r] / data.slack[r];
+        const real h = dt * data.dual[r] / data.slack[r];
         if (c < 2) M.Qxx(kP + r, kP + r) += h;
         else if (c < 4) M.Qxx(nv + kP + r, nv + kP + r) += h;
         else M.Quu_full(kP + r, kP + r) += h;
@@ -1458,8 +1458,8 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
       data.residual.setZero(); data.duality.setZero();
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-        double rr[5], dd[5];
+        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        real rr[5], dd[5];
         for (int r = 0; r < 5; ++r) {
           const int idx = 5 * cc + r;
           data.residual[idx] = res[r] + data.slack[idx];
@@ -1469,7 +1469,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
         }
         for (int x = 0; x < 3; ++x) {
           for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
-          for (int y = 0; y < 3; ++y) { double acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
+          for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
         }
         st += 3;
       }
@@ -1532,8 +1532,8 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
   robot.dSubtractdConfigurationPlus(si.q, q_ref, Jq);
   Mat Wq(nv); for (int r = 0; r < nv; ++r) Wq[r] = cost.qi_weight[r] * qdiff[r];
   R.lq += Jq.t() * Wq;
-  const double v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
-  const double vs = vRefScale(cost, nd.t);
+  const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+  const real vs = vRefScale(cost, nd.t);
   for (int r = 0; r < nv; ++r) {
     R.lv[r] += cost.vi_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
     R.la[r] += cost.dvi_weight[r] * si.a[r];
@@ -1546,7 +1546,7 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
     }
   }
   // ---- impulse friction cone: augmentDualResidual
-  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  real Jc[5][3]; frictionJac(cons.mu, Jc);
   const bool cone = componentValid(6, nd);
   if (cone) {
     IpmData& data = ipm[i][6];
@@ -1554,7 +1554,7 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
     int st = 0;
     for (int cc = 0; cc < nc_; ++cc) if (is.active[cc]) {
       if (residual_only) {
-        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
         for (int r = 0; r < 5; ++r) {
           data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
           data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
@@ -1621,8 +1621,8 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
     data.residual.setZero(); data.duality.setZero();
     int st = 0;
     for (int cc = 0; cc < nc_; ++cc) if (is.active[cc]) {
-      double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-      double rr[5], dd[5];
+      real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+      real rr[5], dd[5];
       for (int r = 0; r < 5; ++r) {
         const int idx = 5 * cc + r;
         data.residual[idx] = res[r] + data.slack[idx];
@@ -1632,7 +1632,7 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
       }
       for (int x = 0; x < 3; ++x) {
         for (int r = 0; r < 5; ++r) R.lf[st + x] += Jc[r][x] * rr[r];
-        for (int y = 0; y < 3; ++y) { double acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += acc; }
+        for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += acc; }
       }
       st += 3;
     }
@@ -1664,7 +1664,7 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
 // ImpulseSplitKKTMatrixInverter::invert (impulse_split_kkt_matrix_inverter.hxx:34-80).  One code path: the stage's KKT matrix is
 //   [ 0  J ; J^T  Q ]  with  J = [F ; C] (C = Pq rows of an aux stage / V rows of an impulse stage) and Q over (w, q, v),
 // w = u (regular, aux, lift, terminal) or f (impulse).
-void ParNMPCSolver::coarseUpdate(double t, const Mat& q, const Mat& v) {
+void ParNMPCSolver::coarseUpdate(real t, const Mat& q, const Mat& v) {
   discretize(t);
   const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
   for (int p = 0; p < Mc; ++p) {
@@ -1805,8 +1805,8 @@ void ParNMPCSolver::forwardCorrectionSerial() {
 // SplitParNMPC / ImpulseSplitParNMPC::computeCondensed{Primal,Dual}Direction
 void ParNMPCSolver::forwardCorrectionParallel() {
   const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
-  double pmin = 1, dmin = 1;
-  double Jc[5][3]; frictionJac(cons.mu, Jc);
+  real pmin = 1, dmin = 1;
+  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int p = 0; p < Mc; ++p) {
     const PNode& nd = chain[p];
     const int i = nd.slot;
@@ -1815,7 +1815,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
     const int ni = (impulse || aux) ? seq.impulse_status[nd.event].dimf() : 0;
     const ContactStatus& cs = nodeContacts(nd);
     const int dimf = cs.dimf();
-    const double dt = nd.dt;
+    const real dt = nd.dt;
     if (p > 0 || has_prev) {
       Mat dh = KKT_mat_inv[i].block(0, 0, nK - nx, nx) * x_res[i];             // (dlmd, dgmm, dxi | dmu, du | df)
       s_new[i].lmd -= dh.segment(0, nv);
@@ -1860,7 +1860,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           for (int r2 = 0; r2 < 5; ++r2) {
             const int idx = 5 * cc + r2;
-            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * df[st + x];
+            real Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * df[st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
           }
@@ -1890,9 +1890,9 @@ void ParNMPCSolver::forwardCorrectionParallel() {
       if (!componentValid(c, nd)) continue;
       IpmData& data = ipm[i][c];
       if (c < 6) {
-        const double sgn = (c & 1) ? 1.0 : -1.0;
+        const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r2 = 0; r2 < nu; ++r2) {
-          const double dxr = c < 2 ? d[i].dq[kP + r2] : (c < 4 ? d[i].dv[kP + r2] : d[i].du[r2]);
+          const real dxr = c < 2 ? d[i].dq[kP + r2] : (c < 4 ? d[i].dv[kP + r2] : d[i].du[r2]);
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
@@ -1902,7 +1902,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           for (int r2 = 0; r2 < 5; ++r2) {
             const int idx = 5 * cc + r2;
-            double Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[i].daf[nv + st + x];
+            real Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[i].daf[nv + st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
           }
@@ -1932,7 +1932,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
 // ParNMPCLinearizer::integrateSolution (parnmpc_linearizer.cpp:248-300); SplitSolution::integrate / ImpulseSplitSolution::integrate
 void ParNMPCSolver::integrateSolution() {
   const int nv = nv_;
-  const double ap = primal_step_size, ad = dual_step_size;
+  const real ap = primal_step_size, ad = dual_step_size;
   for (const PNode& nd : chain) {
     const int i = nd.slot;
     const ContactStatus& cs = nodeContacts(nd);
@@ -1961,20 +1961,20 @@ void ParNMPCSolver::integrateSolution() {
   }
 }
 
-void ParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v) {
+void ParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v) {
   coarseUpdate(t, q, v);
   auto t0 = std::chrono::steady_clock::now();
   backwardCorrectionSerial();
-  serial_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  serial_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
   backwardCorrectionParallel();
   t0 = std::chrono::steady_clock::now();
   forwardCorrectionSerial();
-  serial_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  serial_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
   forwardCorrectionParallel();
   integrateSolution();
 }
 
-void ParNMPCSolver::computeKKTResidual(double t, const Mat& q, const Mat& v) {
+void ParNMPCSolver::computeKKTResidual(real t, const Mat& q, const Mat& v) {
   discretize(t);
   for (int p = 0; p < (int)chain.size(); ++p)
     linearizeNode(p, p == 0 ? q : s[chain[p - 1].slot].q, p == 0 ? v : s[chain[p - 1].slot].v, true);
@@ -1994,27 +1994,27 @@ int ParNMPCSolver::isCurrentSolutionFeasible() const {
       for (int c = 0; c < 6; ++c) {
         if (!componentValid(c, nd)) continue;
         for (int r = 0; r < nu_; ++r) {
-          const double x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
+          const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
       }
       if (!componentValid(6, nd)) continue;
       const ContactStatus& cs = nodeContacts(nd);
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        double res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
         for (int r = 0; r < 5; ++r) if (res[r] > 0) return p;
       }
     }
   return -1;
 }
 
-double ParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
-double ParNMPCSolver::KKTErrorSquared() {
-  double sum = 0;
+real ParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
+real ParNMPCSolver::KKTErrorSquared() {
+  real sum = 0;
   for (const PNode& nd : chain) {
     const int i = nd.slot;
     const SplitKKTResidualC& R = kkt_residual[i];
-    double e;
+    real e;
     if (nd.kind == NodeC::Impulse) {
       e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() +
           imp[i].ImD.squaredNorm() + R.P.squaredNorm();
@@ -2023,7 +2023,7 @@ double ParNMPCSolver::KKTErrorSquared() {
           R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + nd.dt * nd.dt * cd[i].IDC.squaredNorm();
       if (nd.kind == NodeC::Aux) e += R.P.squaredNorm();
     }
-    double c2 = 0;
+    real c2 = 0;
     for (int c = 0; c < 7; ++c) if (componentValid(c, nd)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
     sum += e + c2;
   }

@@ -38,7 +38,7 @@ struct ContactStatus {
 // include/idocp/hybrid/contact_sequence.hxx:56-333
 struct ContactSequenceC {
   std::vector<ContactStatus> phases;           // contact_statuses_
-  std::vector<double> event_time;              // one per discrete event
+  std::vector<real> event_time;              // one per discrete event
   std::vector<bool> is_impulse;                // DiscreteEvent::existImpulse (discrete_event.hxx:57-84)
   std::vector<ContactStatus> impulse_status;   // per EVENT (only meaningful where is_impulse)
   int numEvents() const { return (int)event_time.size(); }
@@ -54,11 +54,11 @@ struct NodeC {
   int kind = Stage;
   int slot = 0;           // storage slot of this stage
   int index = 0;          // grid stage (Stage / Terminal), impulse index (Impulse / Aux), lift index (Lift)
-  double t = 0, dt = 0;   // dt = 0 for Impulse / Terminal
+  real t = 0, dt = 0;   // dt = 0 for Impulse / Terminal
   int phase = 0;          // contact phase (Stage / Aux / Lift); for Impulse: the event index
   int level = 0;          // time step handed to Constraints::createConstraintsData: grid stage, 0 (aux, lift), -1 (impulse)
   int sw_event = -1;      // event index of the impulse whose switching constraint sits on this stage (or -1)
-  double sw_dt_next = 0;  // dt of the stage between this one and the impulse
+  real sw_dt_next = 0;  // dt of the stage between this one and the impulse
 };
 
 // include/idocp/ocp/split_solution.hxx:10-31, impulse/impulse_split_solution.hxx (a = dv on impulse stages)
@@ -116,20 +116,20 @@ struct RiccatiC {
 
 class OCPSolver {
  public:
-  OCPSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N,
+  OCPSolver(const RModel& model, const RCost& cost, const idocp_constraints_t& constraints, real T, int N,
             int max_num_impulse = 0);
   void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points /*[nc][3]*/);   // ocp_solver.cpp:169-171
-  void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, double switching_time);   // :174-177
+  void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, real switching_time);   // :174-177
   void setContactPoints(int contact_phase, const double* contact_points);                                     // :180-184
   void setSolution(const std::string& name, const Mat& value);      // ocp_solver.cpp:95-165
-  void initConstraints(double t);                                   // ocp_solver.cpp:60-64
-  void updateSolution(double t, const Mat& q, const Mat& v);         // ocp_solver.cpp:67-92
-  void computeKKTResidual(double t, const Mat& q, const Mat& v);     // ocp_solver.cpp:202-207
-  double KKTError();                                                 // ocp_linearizer.cpp:98-137
+  void initConstraints(real t);                                   // ocp_solver.cpp:60-64
+  void updateSolution(real t, const Mat& q, const Mat& v);         // ocp_solver.cpp:67-92
+  void computeKKTResidual(real t, const Mat& q, const Mat& v);     // ocp_solver.cpp:202-207
+  real KKTError();                                                 // ocp_linearizer.cpp:98-137
   int isCurrentSolutionFeasible() const;                             // ocp_solver.cpp:216-248: first offending chain position or -1
 
-  void discretize(double t);                                         // OCPDiscretizer::discretizeOCP (ocp_discretizer.hxx:65-374)
-  void linearizeOCP(double t, const Mat& q);                         // K5
+  void discretize(real t);                                         // OCPDiscretizer::discretizeOCP (ocp_discretizer.hxx:65-374)
+  void linearizeOCP(real t, const Mat& q);                         // K5
   void backwardRiccatiRecursion();                                   // S3
   void forwardRiccatiRecursion(const Mat& q, const Mat& v);          // S4 (+ initial state direction)
   void computeDirection();                                           // K6
@@ -137,11 +137,11 @@ class OCPSolver {
 
   int N() const { return N_; }                 // grid stages after discretisation (N_ideal minus events on the grid)
   int M() const { return (int)chain.size(); }  // chain length = N + 1 + 2 N_impulse + N_lift
-  double stepDt() const { return dt_; }
+  real stepDt() const { return dt_; }
   int dimc() const;
   const ContactStatus& nodeContacts(int p) const;     // contact (or impulse) status a node is linearised with
   Robot robot;
-  idocp_cost_t cost;
+  RCost cost;
   idocp_constraints_t cons;
   ContactSequenceC seq;
   std::vector<NodeC> chain;
@@ -158,13 +158,13 @@ class OCPSolver {
   std::vector<std::vector<IpmData>> ipm;    // [node][component]
   std::vector<RiccatiC> riccati;
   std::vector<Mat> K, k;
-  double primal_step_size = 1, dual_step_size = 1;
-  double riccati_seconds = 0;
-  void qRef(double t, Mat& q_ref) const;                              // trotting_configuration_space_cost.hpp:126-164
+  real primal_step_size = 1, dual_step_size = 1;
+  real riccati_seconds = 0;
+  void qRef(real t, Mat& q_ref) const;                              // trotting_configuration_space_cost.hpp:126-164
 
  private:
   int N_ideal_, N_, nv_, nu_, nc_, max_events_;
-  double T_, dt_;
+  real T_, dt_;
   bool discretized_ = false;
   // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone (impulse cone on impulse stages)
   bool componentEnabled(int c, bool impulse) const;
@@ -193,19 +193,19 @@ class OCPSolver {
 // aux k -> N + E + k, lift k -> N + 2E + k.
 class ParNMPCSolver {
  public:
-  ParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N,
+  ParNMPCSolver(const RModel& model, const RCost& cost, const idocp_constraints_t& constraints, real T, int N,
                 int max_num_impulse = 0);
   void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points);
-  void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, double switching_time);
+  void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, real switching_time);
   void setSolution(const std::string& name, const Mat& value);
-  void initBackwardCorrection(double t);                              // parnmpc_solver.cpp:66-70
-  void initConstraints(double t);                                     // parnmpc_linearizer.cpp:43-75
-  void updateSolution(double t, const Mat& q, const Mat& v);           // parnmpc_solver.cpp:73-103
-  void computeKKTResidual(double t, const Mat& q, const Mat& v);
-  double KKTError();                                                   // parnmpc_linearizer.cpp:203-247
+  void initBackwardCorrection(real t);                              // parnmpc_solver.cpp:66-70
+  void initConstraints(real t);                                     // parnmpc_linearizer.cpp:43-75
+  void updateSolution(real t, const Mat& q, const Mat& v);           // parnmpc_solver.cpp:73-103
+  void computeKKTResidual(real t, const Mat& q, const Mat& v);
+  real KKTError();                                                   // parnmpc_linearizer.cpp:203-247
   int isCurrentSolutionFeasible() const;                               // parnmpc_solver.cpp:231-273: first offending chain position or -1
   // the phases of updateSolution, separately callable
-  void coarseUpdate(double t, const Mat& q, const Mat& v);
+  void coarseUpdate(real t, const Mat& q, const Mat& v);
   void backwardCorrectionSerial();
   void backwardCorrectionParallel();
   void forwardCorrectionSerial();
@@ -216,19 +216,19 @@ class ParNMPCSolver {
   struct PNode {
     int kind = NodeC::Stage;   // Stage, Impulse, Aux, Lift, Terminal (= the last grid stage, which carries the terminal cost)
     int slot = 0, index = 0;   // index: grid stage / impulse index / lift index
-    double t = 0, dt = 0;
+    real t = 0, dt = 0;
     int phase = 0;             // contact phase (Stage / Aux / Lift / Terminal)
     int level = 0;             // time step of Constraints::createConstraintsData: i + 1 (stage i), 0 (aux, lift), -1 (impulse)
     int event = -1;            // Aux / Impulse: event index of the impulse
   };
-  void discretize(double t);                                           // ParNMPCDiscretizer::discretizeOCP
+  void discretize(real t);                                           // ParNMPCDiscretizer::discretizeOCP
   std::vector<PNode> chain;
   ContactSequenceC seq;
   const ContactStatus& nodeContacts(const PNode& nd) const { return nd.kind == NodeC::Impulse ? seq.impulse_status[nd.event] : seq.phases[nd.phase]; }
   int slotOf(int kind, int index) const;
   int nslots() const { return N_ideal_ + 3 * max_events_; }
   Robot robot;
-  idocp_cost_t cost;
+  RCost cost;
   idocp_constraints_t cons;
   ContactStatus contact_status;      // the first contact phase (the only one of an event-free horizon)
   // all per-stage arrays are indexed by SLOT
@@ -243,8 +243,8 @@ class ParNMPCSolver {
   // ImpulseDynamicsBackwardEulerData + the impulse blocks of ImpulseSplitKKTMatrix (per impulse slot)
   struct ImpulseDataC { Mat ImD, dImDdq, dImDddv, Minv, Minv_ImD, Qdvq, Qdvf, ldv, Fvq, Fvf, Vq, Vv, Qqf, Qdvdv; };
   std::vector<ImpulseDataC> imp;
-  double primal_step_size = 1, dual_step_size = 1;
-  double serial_seconds = 0;
+  real primal_step_size = 1, dual_step_size = 1;
+  real serial_seconds = 0;
   // ---- horizon sharding (stages of one horizon spread over several processes; event-free
   // horizons only) ----
   // This object then owns the stages [stage_offset, stage_offset + N) of a longer horizon.  What it needs from its
@@ -264,18 +264,18 @@ class ParNMPCSolver {
   //        2 aux_first (-> left), 3 bwd_first (s_new.lmd, s_new.gmm of the first stage -> left),
   //        4 fwd_last (s_new.q, s_new.v of the last stage -> right), 5 aux_all (aux_mat of every stage, init only)
   int haloSize(int kind) const;
-  void exportHalo(int kind, double* out) const;
-  void importHalo(int kind, const double* in);
-  double KKTErrorSquared();
+  void exportHalo(int kind, real* out) const;
+  void importHalo(int kind, const real* in);
+  real KKTErrorSquared();
 
  private:
   int N_ideal_, N_, nv_, nu_, nc_, max_events_;
-  double T_, dt_;
-  double disc_t_ = 0;
+  real T_, dt_;
+  real disc_t_ = 0;
   bool discretized_ = false;
   bool componentValid(int c, const PNode& nd) const;
   int componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
-  void qRef(double t, Mat& q_ref) const;
+  void qRef(real t, Mat& q_ref) const;
   void initNodeConstraints(const PNode& nd);
   void linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only);
   void linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only);

@@ -13,7 +13,10 @@
 
 using namespace oracle;
 
-static Mat toVec(const double* p, int n) { Mat v(n); std::memcpy(v.d.data(), p, sizeof(double) * n); return v; }
+// copy between the caller's FP64 buffers and the restatement's scalar (`nbytes` counts FP64 bytes, as in the memcpy it replaces)
+template <typename A, typename Bt>
+static inline void xcpy(A* dst, const Bt* src, size_t nbytes) { const size_t n = nbytes / sizeof(double); for (size_t i = 0; i < n; ++i) dst[i] = (A)src[i]; }
+static Mat toVec(const double* p, int n) { Mat v(n); xcpy(v.d.data(), p, sizeof(double) * n); return v; }
 
 static std::string g_oracle_error;
 extern "C" {
@@ -29,7 +32,7 @@ int oracle_rnea(const idocp_model_t* m, const double* q, const double* v, const 
   }
   Mat t;
   r.RNEA(toVec(q, m->nq), toVec(v, m->nv), toVec(a, m->nv), t, gravity != 0);
-  std::memcpy(tau, t.d.data(), sizeof(double) * m->nv);
+  xcpy(tau, t.d.data(), sizeof(double) * m->nv);
   return 0;
 }
 
@@ -44,7 +47,7 @@ int oracle_rnea_derivatives(const idocp_model_t* m, const double* q, const doubl
   Mat Dq, Dv, Da;
   r.RNEADerivatives(toVec(q, m->nq), toVec(v, m->nv), toVec(a, m->nv), Dq, Dv, Da, gravity != 0);
   const size_t n = sizeof(double) * m->nv * m->nv;
-  std::memcpy(dq, Dq.d.data(), n); std::memcpy(dv, Dv.d.data(), n); std::memcpy(da, Da.d.data(), n);
+  xcpy(dq, Dq.d.data(), n); xcpy(dv, Dv.d.data(), n); xcpy(da, Da.d.data(), n);
   return 0;
 }
 
@@ -64,23 +67,25 @@ int oracle_contact_kinematics(const idocp_model_t* m, const double* q, const dou
   Mat Cm, Dq, Dv, Da;
   r.computeBaumgarteResidual(act, time_step, cp, Cm);
   r.computeBaumgarteDerivatives(act, time_step, Dq, Dv, Da);
-  std::memcpy(C, Cm.d.data(), sizeof(double) * 3 * nc);
-  std::memcpy(dCdq, Dq.d.data(), sizeof(double) * 3 * nc * nv);
-  std::memcpy(dCdv, Dv.d.data(), sizeof(double) * 3 * nc * nv);
-  std::memcpy(dCda, Da.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(C, Cm.d.data(), sizeof(double) * 3 * nc);
+  xcpy(dCdq, Dq.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(dCdv, Dv.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(dCda, Da.d.data(), sizeof(double) * 3 * nc * nv);
   for (int c = 0; c < nc; ++c) {
-    r.contactFrame(c, fp + 3 * c, fR + 9 * c, fv + 6 * c, fa + 6 * c);
+    real tp[3], tR[9], tv[6], ta[6];
+    r.contactFrame(c, tp, tR, tv, ta);
+    xcpy(fp + 3 * c, tp, sizeof(double) * 3); xcpy(fR + 9 * c, tR, sizeof(double) * 9); xcpy(fv + 6 * c, tv, sizeof(double) * 6); xcpy(fa + 6 * c, ta, sizeof(double) * 6);
     Mat a1, a2, a3, a4;
     r.frameDerivatives(c, a1, a2, a3, a4);
     const size_t n = (size_t)6 * nv;
-    std::memcpy(vdq + c * n, a1.d.data(), sizeof(double) * n); std::memcpy(adq + c * n, a2.d.data(), sizeof(double) * n);
-    std::memcpy(adv + c * n, a3.d.data(), sizeof(double) * n); std::memcpy(ada + c * n, a4.d.data(), sizeof(double) * n);
+    xcpy(vdq + c * n, a1.d.data(), sizeof(double) * n); xcpy(adq + c * n, a2.d.data(), sizeof(double) * n);
+    xcpy(adv + c * n, a3.d.data(), sizeof(double) * n); xcpy(ada + c * n, a4.d.data(), sizeof(double) * n);
   }
   if (MJtJinv) {
     Mat dq, dv, Mm, out;
     r.RNEADerivatives(Q, V, A, dq, dv, Mm);
     Robot::computeMJtJinv(Mm, Da, out);
-    std::memcpy(MJtJinv, out.d.data(), sizeof(double) * out.size());
+    xcpy(MJtJinv, out.d.data(), sizeof(double) * out.size());
   }
   return 0;
 }
@@ -103,10 +108,10 @@ int oracle_switching_terms(const idocp_model_t* m, const double* q, const double
   r.dIntegratedConfiguration(Q, dq, Jq);
   r.dIntegratedVelocity(Q, dq, Jv);
   Mat a1 = Pq * Jq, a2 = (dt1 + dt2) * (Pq * Jv), a3 = (dt1 * dt2) * (Pq * Jv);
-  std::memcpy(Pout, Pm.d.data(), sizeof(double) * 3 * nc);
-  std::memcpy(Phiq, a1.d.data(), sizeof(double) * 3 * nc * nv);
-  std::memcpy(Phiv, a2.d.data(), sizeof(double) * 3 * nc * nv);
-  std::memcpy(Phia, a3.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(Pout, Pm.d.data(), sizeof(double) * 3 * nc);
+  xcpy(Phiq, a1.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(Phiv, a2.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(Phia, a3.d.data(), sizeof(double) * 3 * nc * nv);
   return 0;
 }
 
@@ -127,12 +132,12 @@ int oracle_impulse_terms(const idocp_model_t* m, const double* q, const double* 
   r.RNEADerivatives(Q, zero, DV, dq, dvv, da, false);
   r.computeImpulseVelocityResidual(act, Cm);
   r.computeImpulseVelocityDerivatives(act, Cq, Cv);
-  std::memcpy(ImD, tau.d.data(), sizeof(double) * nv);
-  std::memcpy(dImDdq, dq.d.data(), sizeof(double) * nv * nv);
-  std::memcpy(dImDddv, da.d.data(), sizeof(double) * nv * nv);
-  std::memcpy(C, Cm.d.data(), sizeof(double) * 3 * nc);
-  std::memcpy(dCdq, Cq.d.data(), sizeof(double) * 3 * nc * nv);
-  std::memcpy(dCdv, Cv.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(ImD, tau.d.data(), sizeof(double) * nv);
+  xcpy(dImDdq, dq.d.data(), sizeof(double) * nv * nv);
+  xcpy(dImDddv, da.d.data(), sizeof(double) * nv * nv);
+  xcpy(C, Cm.d.data(), sizeof(double) * 3 * nc);
+  xcpy(dCdq, Cq.d.data(), sizeof(double) * 3 * nc * nv);
+  xcpy(dCdv, Cv.d.data(), sizeof(double) * 3 * nc * nv);
   return 0;
 }
 
@@ -145,10 +150,10 @@ int oracle_lie_ops(const idocp_model_t* m, const double* q, const double* q1, co
   r.subtractConfiguration(Q1, Q, d);
   r.dSubtractdConfigurationMinus(Q1, Q, j0);
   r.dSubtractdConfigurationPlus(Q1, Q, j1);
-  std::memcpy(q_int, out.d.data(), sizeof(double) * m->nq);
-  std::memcpy(diff, d.d.data(), sizeof(double) * m->nv);
-  std::memcpy(J0, j0.d.data(), sizeof(double) * m->nv * m->nv);
-  std::memcpy(J1, j1.d.data(), sizeof(double) * m->nv * m->nv);
+  xcpy(q_int, out.d.data(), sizeof(double) * m->nq);
+  xcpy(diff, d.d.data(), sizeof(double) * m->nv);
+  xcpy(J0, j0.d.data(), sizeof(double) * m->nv * m->nv);
+  xcpy(J1, j1.d.data(), sizeof(double) * m->nv * m->nv);
   return 0;
 }
 
@@ -220,7 +225,7 @@ int oracle_unocp_get_solution(void* h, const char* name, double* out) {
   for (int i = 0; i <= s->N(); ++i) {
     const Mat* f = solField(s->s[i], name);
     if (!f) return -1;
-    std::memcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
+    xcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
   }
   return 0;
 }
@@ -229,7 +234,7 @@ int oracle_unocp_get_direction(void* h, const char* name, double* out) {
   for (int i = 0; i <= s->N(); ++i) {
     const Mat* f = dirField(s->d[i], name);
     if (!f) return -1;
-    std::memcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
+    xcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
   }
   return 0;
 }
@@ -246,12 +251,12 @@ int oracle_unocp_get_riccati(void* h, double* P, double* sv, double* K, double* 
     if (P) {
       Mat Pm(nx, nx);
       Pm.setBlock(0, 0, r.Pqq); Pm.setBlock(0, nv, r.Pqv); Pm.setBlock(nv, 0, r.Pqv.t()); Pm.setBlock(nv, nv, r.Pvv);
-      std::memcpy(P + (size_t)i * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
+      xcpy(P + (size_t)i * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
     }
-    if (sv) { std::memcpy(sv + (size_t)i * nx, r.sq.d.data(), sizeof(double) * nv); std::memcpy(sv + (size_t)i * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
+    if (sv) { xcpy(sv + (size_t)i * nx, r.sq.d.data(), sizeof(double) * nv); xcpy(sv + (size_t)i * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
     if (i < s->N()) {
-      if (K) std::memcpy(K + (size_t)i * nv * nx, s->K[i].d.data(), sizeof(double) * nv * nx);
-      if (k) std::memcpy(k + (size_t)i * nv, s->k[i].d.data(), sizeof(double) * nv);
+      if (K) xcpy(K + (size_t)i * nv * nx, s->K[i].d.data(), sizeof(double) * nv * nx);
+      if (k) xcpy(k + (size_t)i * nv, s->k[i].d.data(), sizeof(double) * nv);
     }
   }
   return 0;
@@ -312,11 +317,11 @@ int oracle_unparnmpc_set_slice(void* h, int lo, int hi) { static_cast<UnParNMPCS
 int oracle_unparnmpc_export(void* h, int kind, double* out) {
   UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
   const int nv = s->robot.dimv(), lo = s->lo(), hi = s->hi();
-  auto put2 = [&](const Mat& a, const Mat& b) { std::memcpy(out, a.d.data(), sizeof(double) * nv); std::memcpy(out + nv, b.d.data(), sizeof(double) * nv); };
+  auto put2 = [&](const Mat& a, const Mat& b) { xcpy(out, a.d.data(), sizeof(double) * nv); xcpy(out + nv, b.d.data(), sizeof(double) * nv); };
   switch (kind) {
     case 0: put2(s->s[hi - 1].q, s->s[hi - 1].v); break;
     case 1: put2(s->s[lo].lmd, s->s[lo].gmm); break;
-    case 2: std::memcpy(out, s->aux_mat[lo].d.data(), sizeof(double) * 4 * nv * nv); break;
+    case 2: xcpy(out, s->aux_mat[lo].d.data(), sizeof(double) * 4 * nv * nv); break;
     case 3: put2(s->s_new[lo].lmd, s->s_new[lo].gmm); break;
     case 4: put2(s->s_new[hi - 1].q, s->s_new[hi - 1].v); break;
     default: return -1;
@@ -330,7 +335,7 @@ int oracle_unparnmpc_import(void* h, int kind, const double* in) {
   switch (kind) {
     case 0: get2(s->s[lo - 1].q, s->s[lo - 1].v); break;
     case 1: get2(s->s[hi].lmd, s->s[hi].gmm); break;
-    case 2: std::memcpy(s->aux_mat[hi].d.data(), in, sizeof(double) * 4 * nv * nv); break;
+    case 2: xcpy(s->aux_mat[hi].d.data(), in, sizeof(double) * 4 * nv * nv); break;
     case 3: get2(s->s_new[hi].lmd, s->s_new[hi].gmm); break;
     case 4: get2(s->s_new[lo - 1].q, s->s_new[lo - 1].v); break;
     default: return -1;
@@ -363,7 +368,7 @@ int oracle_unparnmpc_get(void* h, const char* name, double* out) {
   for (int i = 0; i < s->N(); ++i) {
     const Mat* f = n.rfind("new_", 0) == 0 ? solField(s->s_new[i], n.substr(4)) : (n[0] == 'd' ? dirField(s->d[i], n) : solField(s->s[i], n));
     if (!f) return -1;
-    std::memcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
+    xcpy(out + (size_t)i * f->size(), f->d.data(), sizeof(double) * f->size());
   }
   return 0;
 }
@@ -376,8 +381,8 @@ int oracle_unparnmpc_get_matrices(void* h, double* kkt_inv, double* aux) {
   UnParNMPCSolver* s = static_cast<UnParNMPCSolver*>(h);
   const int nv = s->robot.dimv(), nk = 5 * nv, nx = 2 * nv;
   for (int i = 0; i < s->N(); ++i) {
-    if (kkt_inv) std::memcpy(kkt_inv + (size_t)i * nk * nk, s->kkt_inv[i].d.data(), sizeof(double) * nk * nk);
-    if (aux) std::memcpy(aux + (size_t)i * nx * nx, s->aux_mat[i].d.data(), sizeof(double) * nx * nx);
+    if (kkt_inv) xcpy(kkt_inv + (size_t)i * nk * nk, s->kkt_inv[i].d.data(), sizeof(double) * nk * nk);
+    if (aux) xcpy(aux + (size_t)i * nx * nx, s->aux_mat[i].d.data(), sizeof(double) * nx * nx);
   }
   return 0;
 }
@@ -427,11 +432,11 @@ int oracle_unocp_get_unkkt(void* h, double* Q, double* res) {
   UnOCPSolver* s = static_cast<UnOCPSolver*>(h);
   const int nv = s->robot.dimv(), n3 = 3 * nv;
   for (int i = 0; i < s->N(); ++i) {
-    if (Q) std::memcpy(Q + (size_t)i * n3 * n3, s->unkkt_matrix[i].Q.d.data(), sizeof(double) * n3 * n3);
+    if (Q) xcpy(Q + (size_t)i * n3 * n3, s->unkkt_matrix[i].Q.d.data(), sizeof(double) * n3 * n3);
     if (res) {
       const SplitUnKKTResidual& r = s->unkkt_residual[i];
       const Mat* parts[5] = {&r.Fq, &r.Fv, &r.la, &r.lq, &r.lv};
-      for (int p = 0; p < 5; ++p) std::memcpy(res + (size_t)i * 5 * nv + p * nv, parts[p]->d.data(), sizeof(double) * nv);
+      for (int p = 0; p < 5; ++p) xcpy(res + (size_t)i * 5 * nv + p * nv, parts[p]->d.data(), sizeof(double) * nv);
     }
   }
   return 0;
@@ -598,12 +603,12 @@ int oracle_ocp_get_riccati_chain(void* h, double* P, double* sv, double* K, doub
     if (P) {
       Mat Pm(nx, nx);
       Pm.setBlock(0, 0, r.Pqq); Pm.setBlock(0, nv, r.Pqv); Pm.setBlock(nv, 0, r.Pqv.t()); Pm.setBlock(nv, nv, r.Pvv);
-      std::memcpy(P + (size_t)p * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
+      xcpy(P + (size_t)p * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
     }
-    if (sv) { std::memcpy(sv + (size_t)p * nx, r.sq.d.data(), sizeof(double) * nv); std::memcpy(sv + (size_t)p * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
+    if (sv) { xcpy(sv + (size_t)p * nx, r.sq.d.data(), sizeof(double) * nv); xcpy(sv + (size_t)p * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
     if (p < s->M() - 1) {
-      if (K) std::memcpy(K + (size_t)p * nu * nx, s->K[sl].d.data(), sizeof(double) * nu * nx);
-      if (k) std::memcpy(k + (size_t)p * nu, s->k[sl].d.data(), sizeof(double) * nu);
+      if (K) xcpy(K + (size_t)p * nu * nx, s->K[sl].d.data(), sizeof(double) * nu * nx);
+      if (k) xcpy(k + (size_t)p * nu, s->k[sl].d.data(), sizeof(double) * nu);
     }
   }
   return 0;
@@ -621,12 +626,12 @@ int oracle_ocp_get_riccati(void* h, double* P, double* sv, double* K, double* k)
     if (P) {
       Mat Pm(nx, nx);
       Pm.setBlock(0, 0, r.Pqq); Pm.setBlock(0, nv, r.Pqv); Pm.setBlock(nv, 0, r.Pqv.t()); Pm.setBlock(nv, nv, r.Pvv);
-      std::memcpy(P + (size_t)i * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
+      xcpy(P + (size_t)i * nx * nx, Pm.d.data(), sizeof(double) * nx * nx);
     }
-    if (sv) { std::memcpy(sv + (size_t)i * nx, r.sq.d.data(), sizeof(double) * nv); std::memcpy(sv + (size_t)i * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
+    if (sv) { xcpy(sv + (size_t)i * nx, r.sq.d.data(), sizeof(double) * nv); xcpy(sv + (size_t)i * nx + nv, r.sv.d.data(), sizeof(double) * nv); }
     if (i < s->N()) {
-      if (K) std::memcpy(K + (size_t)i * nu * nx, s->K[i].d.data(), sizeof(double) * nu * nx);
-      if (k) std::memcpy(k + (size_t)i * nu, s->k[i].d.data(), sizeof(double) * nu);
+      if (K) xcpy(K + (size_t)i * nu * nx, s->K[i].d.data(), sizeof(double) * nu * nx);
+      if (k) xcpy(k + (size_t)i * nu, s->k[i].d.data(), sizeof(double) * nu);
     }
   }
   return 0;
@@ -663,10 +668,10 @@ int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Q
   const int nv = s->robot.dimv(), nu = s->robot.dimu(), nx = 2 * nv;
   const SplitKKTMatrixC& M = s->kkt_matrix[i];
   const SplitKKTResidualC& R = s->kkt_residual[i];
-  std::memcpy(Qxx, M.Qxx.d.data(), sizeof(double) * nx * nx);
+  xcpy(Qxx, M.Qxx.d.data(), sizeof(double) * nx * nx);
   Mat qxu = M.Qxu_full.block(0, 6, nx, nu), quu = M.Quu_full.block(6, 6, nu, nu);
-  std::memcpy(Qxu, qxu.d.data(), sizeof(double) * nx * nu);
-  std::memcpy(Quu, quu.d.data(), sizeof(double) * nu * nu);
+  xcpy(Qxu, qxu.d.data(), sizeof(double) * nx * nu);
+  xcpy(Quu, quu.d.data(), sizeof(double) * nu * nu);
   Mat Am(nx, nx), Bm(nx, nu);
   // implicit parts: Fqq = I, Fqv = dt I outside the leading 6x6 blocks
   // (backward_riccati_recursion_factorizer.hxx:66-71, 96-100)
@@ -678,10 +683,10 @@ int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Q
   Fqv_full.setBlock(0, 0, M.Fqv6);
   Am.setBlock(0, 0, Fqq); Am.setBlock(0, nv, Fqv_full); Am.setBlock(nv, 0, M.Fvq); Am.setBlock(nv, nv, M.Fvv);
   Bm.setBlock(nv, 0, M.Fvu);
-  std::memcpy(A, Am.d.data(), sizeof(double) * nx * nx);
-  std::memcpy(B, Bm.d.data(), sizeof(double) * nx * nu);
+  xcpy(A, Am.d.data(), sizeof(double) * nx * nx);
+  xcpy(B, Bm.d.data(), sizeof(double) * nx * nu);
   for (int r = 0; r < nv; ++r) { lx[r] = R.lq[r]; lx[nv + r] = R.lv[r]; Fx[r] = R.Fq[r]; Fx[nv + r] = R.Fv[r]; }
-  std::memcpy(lu, R.lu.d.data(), sizeof(double) * nu);
+  xcpy(lu, R.lu.d.data(), sizeof(double) * nu);
   return 0;
 }
 double oracle_ocp_bench(void* h, double t, const double* q, const double* v, int iters, double* riccati_seconds) {
@@ -850,8 +855,20 @@ int oracle_parnmpc_phase(void* h, int phase, double t, const double* q, const do
 int oracle_parnmpc_init_constraints_only(void* h, double t) { static_cast<ParNMPCSolver*>(h)->initConstraints(t); return 0; }
 int oracle_parnmpc_init_aux_only(void* h, double t) { static_cast<ParNMPCSolver*>(h)->initBackwardCorrection(t); return 0; }
 int oracle_parnmpc_halo_size(void* h, int kind) { return static_cast<ParNMPCSolver*>(h)->haloSize(kind); }
-int oracle_parnmpc_export(void* h, int kind, double* out) { static_cast<ParNMPCSolver*>(h)->exportHalo(kind, out); return 0; }
-int oracle_parnmpc_import(void* h, int kind, const double* in) { static_cast<ParNMPCSolver*>(h)->importHalo(kind, in); return 0; }
+int oracle_parnmpc_export(void* h, int kind, double* out) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  std::vector<real> t(s->haloSize(kind));
+  s->exportHalo(kind, t.data());
+  xcpy(out, t.data(), sizeof(double) * t.size());
+  return 0;
+}
+int oracle_parnmpc_import(void* h, int kind, const double* in) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  std::vector<real> t(s->haloSize(kind));
+  xcpy(t.data(), in, sizeof(double) * t.size());
+  s->importHalo(kind, t.data());
+  return 0;
+}
 int oracle_parnmpc_set_step_sizes(void* h, double primal, double dual) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
   s->primal_step_size = primal; s->dual_step_size = dual; return 0;

@@ -7,72 +7,72 @@
 namespace oracle {
 
 // ------------------------------------------------------------ helpers ----
-static inline void cross3(const double* a, const double* b, double* c) {
-  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+static inline void cross3(const real* a, const real* b, real* c) {
+  const real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   c[0] = x; c[1] = y; c[2] = z;
 }
-static inline void matvec3(const double* R, const double* x, double* y) {
-  const double a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
-  const double b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
-  const double c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+static inline void matvec3(const real* R, const real* x, real* y) {
+  const real a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  const real b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  const real c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
   y[0] = a; y[1] = b; y[2] = c;
 }
-static inline void matmul3(const double* A, const double* B, double* C) {
-  double T[9];
+static inline void matmul3(const real* A, const real* B, real* C) {
+  real T[9];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
     T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
   std::memcpy(C, T, sizeof(T));
 }
 // motion x motion:  (v,w) x (v2,w2) = (w x v2 + v x w2, w x w2)
-static inline void crossMM(const double* a, const double* b, double* o) {
-  double t1[3], t2[3], t3[3];
+static inline void crossMM(const real* a, const real* b, real* o) {
+  real t1[3], t2[3], t3[3];
   cross3(a + 3, b, t1); cross3(a, b + 3, t2); cross3(a + 3, b + 3, t3);
   for (int k = 0; k < 3; ++k) { o[k] = t1[k] + t2[k]; o[3 + k] = t3[k]; }
 }
 // motion x* force:  (v,w) x* (f,n) = (w x f, w x n + v x f)
-static inline void crossMF(const double* m, const double* f, double* o) {
-  double t1[3], t2[3], t3[3];
+static inline void crossMF(const real* m, const real* f, real* o) {
+  real t1[3], t2[3], t3[3];
   cross3(m + 3, f, t1); cross3(m + 3, f + 3, t2); cross3(m, f, t3);
   for (int k = 0; k < 3; ++k) { o[k] = t1[k]; o[3 + k] = t2[k] + t3[k]; }
 }
-static inline void skew(const double* v, double* S) {   // row-major 3x3
+static inline void skew(const real* v, real* S) {   // row-major 3x3
   S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
 }
-static Mat crm(const double* v) {        // 6x6: crm(v) m = v x m
-  Mat X(6, 6); double Sv[9], Sw[9]; skew(v, Sv); skew(v + 3, Sw);
+static Mat crm(const real* v) {        // 6x6: crm(v) m = v x m
+  Mat X(6, 6); real Sv[9], Sw[9]; skew(v, Sv); skew(v + 3, Sw);
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
     X(i, j) = Sw[3 * i + j]; X(i, 3 + j) = Sv[3 * i + j]; X(3 + i, 3 + j) = Sw[3 * i + j];
   }
   return X;
 }
-static Mat crf(const double* v) {        // 6x6: crf(v) f = v x* f
-  Mat X(6, 6); double Sv[9], Sw[9]; skew(v, Sv); skew(v + 3, Sw);
+static Mat crf(const real* v) {        // 6x6: crf(v) f = v x* f
+  Mat X(6, 6); real Sv[9], Sw[9]; skew(v, Sv); skew(v + 3, Sw);
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
     X(i, j) = Sw[3 * i + j]; X(3 + i, j) = Sv[3 * i + j]; X(3 + i, 3 + j) = Sw[3 * i + j];
   }
   return X;
 }
-static inline double dot6(const double* a, const double* b) {
+static inline real dot6(const real* a, const real* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 
-static void rotAxis(const double* u, double q, double* R) {
-  const double c = std::cos(q), s = std::sin(q), t = 1 - c;
+static void rotAxis(const real* u, real q, real* R) {
+  const real c = std::cos(q), s = std::sin(q), t = 1 - c;
   R[0] = c + t * u[0] * u[0];        R[1] = t * u[0] * u[1] - s * u[2]; R[2] = t * u[0] * u[2] + s * u[1];
   R[3] = t * u[1] * u[0] + s * u[2]; R[4] = c + t * u[1] * u[1];        R[5] = t * u[1] * u[2] - s * u[0];
   R[6] = t * u[2] * u[0] - s * u[1]; R[7] = t * u[2] * u[1] + s * u[0]; R[8] = c + t * u[2] * u[2];
 }
-static void quatToR(const double* qt, double* R) {  // xyzw
-  const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+static void quatToR(const real* qt, real* R) {  // xyzw
+  const real x = qt[0], y = qt[1], z = qt[2], w = qt[3];
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
   R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
 // ---------------------------------------------------------------- Robot ----
-Robot::Robot(const idocp_model_t& model) : m_(model) {
+Robot::Robot(const RModel& model) : m_(model) {
   const int n = m_.njoints, nv = m_.nv;
-  fjoint_.assign(n, std::vector<double>(6, 0.0));
+  fjoint_.assign(n, std::vector<real>(6, 0.0));
   in_subtree_.assign(n, std::vector<bool>(n, false));
   for (int j = 0; j < n; ++j) for (int a = j; a >= 0; a = m_.parent[a]) in_subtree_[a][j] = true;
   oMi_.resize(n);
@@ -92,7 +92,7 @@ void Robot::setContactForces(const std::vector<bool>& active, const std::vector<
   for (auto& fj : fjoint_) std::fill(fj.begin(), fj.end(), 0.0);
   for (int c = 0; c < m_.ncontacts; ++c) {
     if (!active[c]) continue;
-    double fl[3], n[3];
+    real fl[3], n[3];
     matvec3(m_.contact_R[c], f[c].d.data(), fl);
     cross3(m_.contact_p[c], fl, n);
     auto& fj = fjoint_[m_.contact_joint[c]];
@@ -101,7 +101,7 @@ void Robot::setContactForces(const std::vector<bool>& active, const std::vector<
 }
 
 void Robot::jointPlacement(int i, const Mat& q, SE3& M) const {
-  double Rj[9], pj[3] = {0, 0, 0};
+  real Rj[9], pj[3] = {0, 0, 0};
   if (m_.jtype[i] == IDOCP_JOINT_REVOLUTE) {
     rotAxis(m_.axis[i], q[m_.idx_q[i]], Rj);
   } else {
@@ -110,7 +110,7 @@ void Robot::jointPlacement(int i, const Mat& q, SE3& M) const {
     pj[0] = q[iq]; pj[1] = q[iq + 1]; pj[2] = q[iq + 2];
   }
   matmul3(m_.plc_R[i], Rj, M.R);
-  double t[3]; matvec3(m_.plc_R[i], pj, t);
+  real t[3]; matvec3(m_.plc_R[i], pj, t);
   for (int k = 0; k < 3; ++k) M.p[k] = m_.plc_p[i][k] + t[k];
 }
 
@@ -119,28 +119,28 @@ void Robot::jointPlacement(int i, const Mat& q, SE3& M) const {
 // column sets dVdq, dAdq, dAdv.
 void Robot::forwardPass(const Mat& q, const Mat& v, const Mat& a, bool gravity) {
   const int n = m_.njoints;
-  double a0[6] = {0, 0, 0, 0, 0, 0};
+  real a0[6] = {0, 0, 0, 0, 0, 0};
   if (gravity) for (int k = 0; k < 3; ++k) a0[k] = -m_.gravity[k];
   for (int i = 0; i < n; ++i) {
     const int pa = m_.parent[i];
     SE3 li; jointPlacement(i, q, li);
     if (pa >= 0) {
       matmul3(oMi_[pa].R, li.R, oMi_[i].R);
-      double t[3]; matvec3(oMi_[pa].R, li.p, t);
+      real t[3]; matvec3(oMi_[pa].R, li.p, t);
       for (int k = 0; k < 3; ++k) oMi_[i].p[k] = oMi_[pa].p[k] + t[k];
     } else {
       oMi_[i] = li;
     }
-    const double* R = oMi_[i].R; const double* p = oMi_[i].p;
+    const real* R = oMi_[i].R; const real* p = oMi_[i].p;
     const int iv = m_.idx_v[i];
     const int ndof = m_.jtype[i] == IDOCP_JOINT_FREEFLYER ? 6 : 1;
     // J columns = oMi.act(S)
     if (ndof == 1) {
-      double w[3], l[3]; matvec3(R, m_.axis[i], w); cross3(p, w, l);
+      real w[3], l[3]; matvec3(R, m_.axis[i], w); cross3(p, w, l);
       for (int k = 0; k < 3; ++k) { S_(k, iv) = l[k]; S_(3 + k, iv) = w[k]; }
     } else {
       for (int c = 0; c < 3; ++c) {
-        double e[3] = {0, 0, 0}; e[c] = 1; double Re[3], l[3];
+        real e[3] = {0, 0, 0}; e[c] = 1; real Re[3], l[3];
         matvec3(R, e, Re); cross3(p, Re, l);
         for (int k = 0; k < 3; ++k) {
           S_(k, iv + c) = Re[k]; S_(3 + k, iv + c) = 0;
@@ -148,39 +148,39 @@ void Robot::forwardPass(const Mat& q, const Mat& v, const Mat& a, bool gravity) 
         }
       }
     }
-    double vJ[6] = {0, 0, 0, 0, 0, 0}, aJ[6] = {0, 0, 0, 0, 0, 0};
+    real vJ[6] = {0, 0, 0, 0, 0, 0}, aJ[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ndof; ++c) for (int k = 0; k < 6; ++k) {
       vJ[k] += S_(k, iv + c) * v[iv + c]; aJ[k] += S_(k, iv + c) * a[iv + c];
     }
-    const double* ovp = pa >= 0 ? ov_[pa].d.data() : nullptr;
-    const double* oap = pa >= 0 ? oa_[pa].d.data() : a0;
+    const real* ovp = pa >= 0 ? ov_[pa].d.data() : nullptr;
+    const real* oap = pa >= 0 ? oa_[pa].d.data() : a0;
     for (int k = 0; k < 6; ++k) ov_[i][k] = (ovp ? ovp[k] : 0.0) + vJ[k];
-    double vxvJ[6]; crossMM(ov_[i].d.data(), vJ, vxvJ);
+    real vxvJ[6]; crossMM(ov_[i].d.data(), vJ, vxvJ);
     for (int k = 0; k < 6; ++k) oa_[i][k] = oap[k] + aJ[k] + vxvJ[k];
     // oYcrb = oMi.act(inertia) as a 6x6 matrix about the world origin
-    double c[3], Rc[3]; matvec3(R, m_.com[i], Rc);
+    real c[3], Rc[3]; matvec3(R, m_.com[i], Rc);
     for (int k = 0; k < 3; ++k) c[k] = p[k] + Rc[k];
-    double RI[9], Rt[9], Iw[9];
+    real RI[9], Rt[9], Iw[9];
     matmul3(R, m_.inertia[i], RI);
     for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
     matmul3(RI, Rt, Iw);
-    const double mass = m_.mass[i];
-    double Sc[9]; skew(c, Sc);
+    const real mass = m_.mass[i];
+    real Sc[9]; skew(c, Sc);
     Mat& Y = oY_[i]; Y.setZero();
     for (int r = 0; r < 3; ++r) {
       Y(r, r) = mass;
       for (int s = 0; s < 3; ++s) {
         Y(r, 3 + s) = -mass * Sc[3 * r + s];
         Y(3 + r, s) = mass * Sc[3 * r + s];
-        double scsc = 0; for (int k = 0; k < 3; ++k) scsc += Sc[3 * r + k] * Sc[3 * k + s];
+        real scsc = 0; for (int k = 0; k < 3; ++k) scsc += Sc[3 * r + k] * Sc[3 * k + s];
         Y(3 + r, 3 + s) = Iw[3 * r + s] - mass * scsc;
       }
     }
     Mat oh = Y * ov_[i];
     Mat Ya = Y * oa_[i];
-    double vxh[6]; crossMF(ov_[i].d.data(), oh.d.data(), vxh);
+    real vxh[6]; crossMF(ov_[i].d.data(), oh.d.data(), vxh);
     // external force: of -= oMi.act(fext)
-    double fw[3], nw[3], pxf[3];
+    real fw[3], nw[3], pxf[3];
     matvec3(R, fjoint_[i].data(), fw); matvec3(R, fjoint_[i].data() + 3, nw); cross3(p, fw, pxf);
     for (int k = 0; k < 3; ++k) {
       of_[i][k] = Ya[k] + vxh[k] - fw[k];
@@ -188,14 +188,14 @@ void Robot::forwardPass(const Mat& q, const Mat& v, const Mat& a, bool gravity) 
     }
     // doYcrb = oYcrb.variation(ov) + forceCrossMatrix(oh)
     Mat B = crf(ov_[i].d.data()) * Y - Y * crm(ov_[i].d.data());
-    double Sf[9], Sn[9]; skew(oh.d.data(), Sf); skew(oh.d.data() + 3, Sn);
+    real Sf[9], Sn[9]; skew(oh.d.data(), Sf); skew(oh.d.data() + 3, Sn);
     for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) {
       B(r, 3 + s) -= Sf[3 * r + s]; B(3 + r, s) -= Sf[3 * r + s]; B(3 + r, 3 + s) -= Sn[3 * r + s];
     }
     oB_[i] = B;
     for (int cidx = 0; cidx < ndof; ++cidx) {
       const int col = iv + cidx;
-      double Sk[6], dJ[6], dV[6] = {0, 0, 0, 0, 0, 0}, dA[6], t[6];
+      real Sk[6], dJ[6], dV[6] = {0, 0, 0, 0, 0, 0}, dA[6], t[6];
       for (int k = 0; k < 6; ++k) Sk[k] = S_(k, col);
       crossMM(ov_[i].d.data(), Sk, dJ);
       crossMM(oap, Sk, dA);
@@ -249,7 +249,7 @@ void Robot::RNEADerivatives(const Mat& q, const Mat& v, const Mat& a, Mat& dq, M
         dq(r, col) = dot6(&S_.d[6 * r], &dFdq.d[6 * col]);
       }
     for (int c = 0; c < ndof; ++c) {
-      double t[6]; crossMF(&S_.d[6 * (iv + c)], of_[i].d.data(), t);
+      real t[6]; crossMF(&S_.d[6 * (iv + c)], of_[i].d.data(), t);
       for (int k = 0; k < 6; ++k) dFdq(k, iv + c) += t[k];
     }
     if (pa >= 0) {
@@ -276,10 +276,10 @@ void Robot::RNEADerivatives(const Mat& q, const Mat& v, const Mat& a, Mat& dq, M
 // ======================================================================= contact
 namespace oracle {
 
-static void actInvMotion(const double* R, const double* p, const double* m, double* out) {
+static void actInvMotion(const real* R, const real* p, const real* m, real* out) {
   // SE3::actInv on a motion: lin = R^T (v - p x w), ang = R^T w
-  double pxw[3]; cross3(p, m + 3, pxw);
-  double t[3] = {m[0] - pxw[0], m[1] - pxw[1], m[2] - pxw[2]};
+  real pxw[3]; cross3(p, m + 3, pxw);
+  real t[3] = {m[0] - pxw[0], m[1] - pxw[1], m[2] - pxw[2]};
   for (int i = 0; i < 3; ++i) {
     out[i] = R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2];
     out[3 + i] = R[i] * m[3] + R[3 + i] * m[4] + R[6 + i] * m[5];
@@ -294,20 +294,20 @@ void Robot::updateKinematics(const Mat& q, const Mat& v, const Mat& a) {
     SE3 li; jointPlacement(i, q, li);
     if (pa >= 0) {
       matmul3(kMi_[pa].R, li.R, kMi_[i].R);
-      double t[3]; matvec3(kMi_[pa].R, li.p, t);
+      real t[3]; matvec3(kMi_[pa].R, li.p, t);
       for (int k = 0; k < 3; ++k) kMi_[i].p[k] = kMi_[pa].p[k] + t[k];
     } else {
       kMi_[i] = li;
     }
-    const double* R = kMi_[i].R; const double* p = kMi_[i].p;
+    const real* R = kMi_[i].R; const real* p = kMi_[i].p;
     const int iv = m_.idx_v[i];
     const int ndof = m_.jtype[i] == IDOCP_JOINT_FREEFLYER ? 6 : 1;
     if (ndof == 1) {
-      double w[3], l[3]; matvec3(R, m_.axis[i], w); cross3(p, w, l);
+      real w[3], l[3]; matvec3(R, m_.axis[i], w); cross3(p, w, l);
       for (int k = 0; k < 3; ++k) { kS_(k, iv) = l[k]; kS_(3 + k, iv) = w[k]; }
     } else {
       for (int c = 0; c < 3; ++c) {
-        double e[3] = {0, 0, 0}; e[c] = 1; double Re[3], l[3];
+        real e[3] = {0, 0, 0}; e[c] = 1; real Re[3], l[3];
         matvec3(R, e, Re); cross3(p, Re, l);
         for (int k = 0; k < 3; ++k) {
           kS_(k, iv + c) = Re[k]; kS_(3 + k, iv + c) = 0;
@@ -315,25 +315,25 @@ void Robot::updateKinematics(const Mat& q, const Mat& v, const Mat& a) {
         }
       }
     }
-    double vJ[6] = {0, 0, 0, 0, 0, 0}, aJ[6] = {0, 0, 0, 0, 0, 0};
+    real vJ[6] = {0, 0, 0, 0, 0, 0}, aJ[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ndof; ++c) for (int k = 0; k < 6; ++k) {
       vJ[k] += kS_(k, iv + c) * v[iv + c]; aJ[k] += kS_(k, iv + c) * a[iv + c];
     }
     for (int k = 0; k < 6; ++k) kv_[i][k] = (pa >= 0 ? kv_[pa][k] : 0.0) + vJ[k];
-    double vxvJ[6]; crossMM(kv_[i].d.data(), vJ, vxvJ);
+    real vxvJ[6]; crossMM(kv_[i].d.data(), vJ, vxvJ);
     for (int k = 0; k < 6; ++k) ka_[i][k] = (pa >= 0 ? ka_[pa][k] : 0.0) + aJ[k] + vxvJ[k];
   }
 }
 
-static void framePlacement(const idocp_model_t& m, const std::vector<SE3>& kMi, int c, double* R, double* p) {
+static void framePlacement(const RModel& m, const std::vector<SE3>& kMi, int c, real* R, real* p) {
   const int j = m.contact_joint[c];
   matmul3(kMi[j].R, m.contact_R[c], R);
-  double t[3]; matvec3(kMi[j].R, m.contact_p[c], t);
+  real t[3]; matvec3(kMi[j].R, m.contact_p[c], t);
   for (int k = 0; k < 3; ++k) p[k] = kMi[j].p[k] + t[k];
 }
 
-void Robot::contactFrame(int c, double* p_world, double* R_world, double* v_local, double* a_local) const {
-  double R[9], p[3];
+void Robot::contactFrame(int c, real* p_world, real* R_world, real* v_local, real* a_local) const {
+  real R[9], p[3];
   framePlacement(m_, kMi_, c, R, p);
   const int j = m_.contact_joint[c];
   if (p_world) std::memcpy(p_world, p, sizeof(p));
@@ -354,18 +354,18 @@ void Robot::contactFrame(int c, double* p_world, double* R_world, double* v_loca
 void Robot::frameDerivatives(int c, Mat& vdq, Mat& adq, Mat& adv, Mat& ada) const {
   const int nv = m_.nv, ji = m_.contact_joint[c];
   vdq = Mat(6, nv); adq = Mat(6, nv); adv = Mat(6, nv); ada = Mat(6, nv);
-  double R[9], p[3];
+  real R[9], p[3];
   framePlacement(m_, kMi_, c, R, p);
-  const double zero[6] = {0, 0, 0, 0, 0, 0};
+  const real zero[6] = {0, 0, 0, 0, 0, 0};
   for (int col = 0; col < nv; ++col) {
     const int jc = dof_joint_[col];
     if (!in_subtree_[jc][ji]) continue;
     const int pa = m_.parent[jc];
-    const double* Vm = pa >= 0 ? kv_[pa].d.data() : zero;
-    const double* Am = pa >= 0 ? ka_[pa].d.data() : zero;
-    const double* Sj = &kS_.d[6 * col];
-    const double* ovi = kv_[ji].d.data();
-    double VxS[6], AxS[6], d[6], t[6], JxS[6], ixS[6], w[6];
+    const real* Vm = pa >= 0 ? kv_[pa].d.data() : zero;
+    const real* Am = pa >= 0 ? ka_[pa].d.data() : zero;
+    const real* Sj = &kS_.d[6 * col];
+    const real* ovi = kv_[ji].d.data();
+    real VxS[6], AxS[6], d[6], t[6], JxS[6], ixS[6], w[6];
     crossMM(Vm, Sj, VxS); crossMM(Am, Sj, AxS);
     for (int k = 0; k < 6; ++k) d[k] = ovi[k] - Vm[k];
     crossMM(VxS, d, t);
@@ -379,15 +379,15 @@ void Robot::frameDerivatives(int c, Mat& vdq, Mat& adq, Mat& adv, Mat& ada) cons
   }
 }
 
-void Robot::computeBaumgarteResidual(const std::vector<bool>& active, double time_step,
+void Robot::computeBaumgarteResidual(const std::vector<bool>& active, real time_step,
                                      const std::vector<Mat>& contact_points, Mat& C) const {
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   C = Mat(3 * na);
-  const double wv = 2 / time_step, wp = 1 / (time_step * time_step);
+  const real wv = 2 / time_step, wp = 1 / (time_step * time_step);
   int row = 0;
   for (int c = 0; c < m_.ncontacts; ++c) {
     if (!active[c]) continue;
-    double p[3], v[6], a[6], wxv[3];
+    real p[3], v[6], a[6], wxv[3];
     contactFrame(c, p, nullptr, v, a);
     cross3(v + 3, v, wxv);                       // classical acceleration = a_lin + w x v_lin
     for (int k = 0; k < 3; ++k)
@@ -396,31 +396,31 @@ void Robot::computeBaumgarteResidual(const std::vector<bool>& active, double tim
   }
 }
 
-void Robot::computeBaumgarteDerivatives(const std::vector<bool>& active, double time_step, Mat& dCdq, Mat& dCdv,
+void Robot::computeBaumgarteDerivatives(const std::vector<bool>& active, real time_step, Mat& dCdq, Mat& dCdv,
                                         Mat& dCda) const {
   const int nv = m_.nv;
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   dCdq = Mat(3 * na, nv); dCdv = Mat(3 * na, nv); dCda = Mat(3 * na, nv);
-  const double wv = 2 / time_step, wp = 1 / (time_step * time_step);
+  const real wv = 2 / time_step, wp = 1 / (time_step * time_step);
   int row = 0;
   for (int c = 0; c < m_.ncontacts; ++c) {
     if (!active[c]) continue;
     Mat vdq, adq, adv, J;
     frameDerivatives(c, vdq, adq, adv, J);
-    double R[9], v[6], Sl[9], Sw[9];
+    real R[9], v[6], Sl[9], Sw[9];
     contactFrame(c, nullptr, R, v, nullptr);
     skew(v, Sl); skew(v + 3, Sw);
     // point_contact.hxx:117-143, term by term (note the reference ADDS v_linear_skew * d(omega))
     for (int col = 0; col < nv; ++col) {
       for (int r = 0; r < 3; ++r) {
-        double dq = adq(r, col), dv = adv(r, col);
+        real dq = adq(r, col), dv = adv(r, col);
         for (int k = 0; k < 3; ++k) {
           dq += Sw[3 * r + k] * vdq(k, col) + Sl[3 * r + k] * vdq(3 + k, col);
           dv += Sw[3 * r + k] * J(k, col) + Sl[3 * r + k] * J(3 + k, col);
         }
         dq += wv * vdq(r, col);
         dv += wv * J(r, col);
-        double RJ = 0; for (int k = 0; k < 3; ++k) RJ += R[3 * r + k] * J(k, col);
+        real RJ = 0; for (int k = 0; k < 3; ++k) RJ += R[3 * r + k] * J(k, col);
         dq += wp * RJ;
         dCdq(row + r, col) = dq; dCdv(row + r, col) = dv; dCda(row + r, col) = J(r, col);
       }
@@ -435,7 +435,7 @@ void Robot::computeImpulseVelocityResidual(const std::vector<bool>& active, Mat&
   int row = 0;
   for (int c = 0; c < m_.ncontacts; ++c) {
     if (!active[c]) continue;
-    double v[6];
+    real v[6];
     contactFrame(c, nullptr, nullptr, v, nullptr);
     for (int k = 0; k < 3; ++k) C[row + k] = v[k];
     row += 3;
@@ -462,7 +462,7 @@ void Robot::computeContactResidual(const std::vector<bool>& active, const std::v
   int row = 0;
   for (int c = 0; c < m_.ncontacts; ++c) {
     if (!active[c]) continue;
-    double p[3];
+    real p[3];
     contactFrame(c, p, nullptr, nullptr, nullptr);
     for (int k = 0; k < 3; ++k) P[row + k] = p[k] - contact_points[c][k];
     row += 3;
@@ -478,10 +478,10 @@ void Robot::computeContactDerivative(const std::vector<bool>& active, Mat& Pq) c
     if (!active[c]) continue;
     Mat vdq, adq, adv, J;
     frameDerivatives(c, vdq, adq, adv, J);
-    double R[9];
+    real R[9];
     contactFrame(c, nullptr, R, nullptr, nullptr);
     for (int col = 0; col < nv; ++col)
-      for (int r = 0; r < 3; ++r) { double acc = 0; for (int k = 0; k < 3; ++k) acc += R[3 * r + k] * J(k, col); Pq(row + r, col) = acc; }
+      for (int r = 0; r < 3; ++r) { real acc = 0; for (int k = 0; k < 3; ++k) acc += R[3 * r + k] * J(k, col); Pq(row + r, col) = acc; }
     row += 3;
   }
 }
@@ -505,64 +505,64 @@ void Robot::computeMJtJinv(const Mat& M, const Mat& J, Mat& out) {
 }
 
 // ------------------------------------------------------------- Lie group ----
-static void exp3(const double* w, double* R) {
-  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
-  double a, b;                      // R = I + a K + b K^2
+static void exp3(const real* w, real* R) {
+  const real t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  real a, b;                      // R = I + a K + b K^2
   if (t < 1e-8) { a = 1 - t2 / 6; b = 0.5 - t2 / 24; } else { a = std::sin(t) / t; b = (1 - std::cos(t)) / t2; }
-  double K[9]; skew(w, K);
-  double K2[9]; matmul3(K, K, K2);
+  real K[9]; skew(w, K);
+  real K2[9]; matmul3(K, K, K2);
   for (int i = 0; i < 9; ++i) R[i] = a * K[i] + b * K2[i];
   R[0] += 1; R[4] += 1; R[8] += 1;
 }
-static void log3(const double* R, double* w, double* theta) {
-  double c = (R[0] + R[4] + R[8] - 1) / 2; c = c > 1 ? 1 : (c < -1 ? -1 : c);
-  const double t = std::acos(c);
-  const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
-  const double s = t < 1e-8 ? 0.5 + t * t / 12 : t / (2 * std::sin(t));
+static void log3(const real* R, real* w, real* theta) {
+  real c = (R[0] + R[4] + R[8] - 1) / 2; c = c > 1 ? 1 : (c < -1 ? -1 : c);
+  const real t = std::acos(c);
+  const real ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const real s = t < 1e-8 ? 0.5 + t * t / 12 : t / (2 * std::sin(t));
   for (int k = 0; k < 3; ++k) w[k] = s * ax[k];
   *theta = t;
 }
-static void Vmat(const double* w, double* V) {   // exp6: t = V(w) v
-  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
-  double b, c;
+static void Vmat(const real* w, real* V) {   // exp6: t = V(w) v
+  const real t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  real b, c;
   if (t < 1e-8) { b = 0.5 - t2 / 24; c = 1.0 / 6 - t2 / 120; } else { b = (1 - std::cos(t)) / t2; c = (t - std::sin(t)) / (t2 * t); }
-  double K[9]; skew(w, K);
-  double K2[9]; matmul3(K, K, K2);
+  real K[9]; skew(w, K);
+  real K2[9]; matmul3(K, K, K2);
   for (int i = 0; i < 9; ++i) V[i] = b * K[i] + c * K2[i];
   V[0] += 1; V[4] += 1; V[8] += 1;
 }
-static void VmatInv(const double* w, double* Vi) {   // log6: v = V(w)^-1 t
-  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
-  double beta;
+static void VmatInv(const real* w, real* Vi) {   // log6: v = V(w)^-1 t
+  const real t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  real beta;
   if (t < 1e-4) beta = 1.0 / 12 + t2 / 720; else beta = 1 / t2 - std::sin(t) / (2 * t * (1 - std::cos(t)));
-  double K[9]; skew(w, K);
-  double K2[9]; matmul3(K, K, K2);
+  real K[9]; skew(w, K);
+  real K2[9]; matmul3(K, K, K2);
   for (int i = 0; i < 9; ++i) Vi[i] = -0.5 * K[i] + beta * K2[i];
   Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
 }
-static void RtoQuat(const double* R, double* q) {   // xyzw
-  const double tr = R[0] + R[4] + R[8];
-  if (tr > 0) { const double s = std::sqrt(tr + 1) * 2; q[3] = s / 4; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
-  else if (R[0] > R[4] && R[0] > R[8]) { const double s = std::sqrt(1 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = s / 4; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
-  else if (R[4] > R[8]) { const double s = std::sqrt(1 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = s / 4; q[2] = (R[5] + R[7]) / s; }
-  else { const double s = std::sqrt(1 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = s / 4; }
+static void RtoQuat(const real* R, real* q) {   // xyzw
+  const real tr = R[0] + R[4] + R[8];
+  if (tr > 0) { const real s = std::sqrt(tr + 1) * 2; q[3] = s / 4; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const real s = std::sqrt(1 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = s / 4; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { const real s = std::sqrt(1 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = s / 4; q[2] = (R[5] + R[7]) / s; }
+  else { const real s = std::sqrt(1 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = s / 4; }
 }
 
 // pinocchio::integrate (SpecialEuclideanOperation<3>: q (+) v = q * exp6(v))
-void Robot::integrateConfiguration(const Mat& q, const Mat& v, double length, Mat& q_out) const {
+void Robot::integrateConfiguration(const Mat& q, const Mat& v, real length, Mat& q_out) const {
   Mat out = q;
   for (int i = 0; i < m_.njoints; ++i) {
     const int iq = m_.idx_q[i], iv = m_.idx_v[i];
     if (m_.jtype[i] == IDOCP_JOINT_REVOLUTE) { out[iq] = q[iq] + length * v[iv]; continue; }
-    double R[9], w[3], vl[3], V[9], E[9], t[3], Rt[3], Rn[9], qt[4];
+    real R[9], w[3], vl[3], V[9], E[9], t[3], Rt[3], Rn[9], qt[4];
     quatToR(&q.d[iq + 3], R);
     for (int k = 0; k < 3; ++k) { vl[k] = length * v[iv + k]; w[k] = length * v[iv + 3 + k]; }
     Vmat(w, V); matvec3(V, vl, t); matvec3(R, t, Rt);
     exp3(w, E); matmul3(R, E, Rn); RtoQuat(Rn, qt);
     // keep the quaternion on the same hemisphere as the input
-    double dotq = 0; for (int k = 0; k < 4; ++k) dotq += qt[k] * q[iq + 3 + k];
-    const double sgn = dotq < 0 ? -1.0 : 1.0;
-    double nrm = 0; for (int k = 0; k < 4; ++k) nrm += qt[k] * qt[k];
+    real dotq = 0; for (int k = 0; k < 4; ++k) dotq += qt[k] * q[iq + 3 + k];
+    const real sgn = dotq < 0 ? -1.0 : 1.0;
+    real nrm = 0; for (int k = 0; k < 4; ++k) nrm += qt[k] * qt[k];
     nrm = std::sqrt(nrm);
     for (int k = 0; k < 3; ++k) out[iq + k] = q[iq + k] + Rt[k];
     for (int k = 0; k < 4; ++k) out[iq + 3 + k] = sgn * qt[k] / nrm;
@@ -571,8 +571,8 @@ void Robot::integrateConfiguration(const Mat& q, const Mat& v, double length, Ma
 }
 
 // M = M_minus^-1 M_plus of the free-flyer (R, p)
-static void relativePlacement(const double* qm, const double* qp, double* R, double* p) {
-  double Rm[9], Rp[9], Rmt[9], d[3];
+static void relativePlacement(const real* qm, const real* qp, real* R, real* p) {
+  real Rm[9], Rp[9], Rmt[9], d[3];
   quatToR(qm + 3, Rm); quatToR(qp + 3, Rp);
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rmt[3 * r + s] = Rm[3 * s + r];
   matmul3(Rmt, Rp, R);
@@ -586,7 +586,7 @@ void Robot::subtractConfiguration(const Mat& q_plus, const Mat& q_minus, Mat& di
   for (int i = 0; i < m_.njoints; ++i) {
     const int iq = m_.idx_q[i], iv = m_.idx_v[i];
     if (m_.jtype[i] == IDOCP_JOINT_REVOLUTE) { diff[iv] = q_plus[iq] - q_minus[iq]; continue; }
-    double R[9], p[3], w[3], th, Vi[9], vl[3];
+    real R[9], p[3], w[3], th, Vi[9], vl[3];
     relativePlacement(&q_minus.d[iq], &q_plus.d[iq], R, p);
     log3(R, w, &th); VmatInv(w, Vi); matvec3(Vi, p, vl);
     for (int k = 0; k < 3; ++k) { diff[iv + k] = vl[k]; diff[iv + 3 + k] = w[k]; }
@@ -594,34 +594,34 @@ void Robot::subtractConfiguration(const Mat& q_plus, const Mat& q_minus, Mat& di
 }
 
 // Jlog6 of pinocchio's explog.hpp: derivative of log6(M exp6(d)) w.r.t. d.
-static void Jlog6(const double* R, const double* p, Mat& J) {
-  double w[3], t;
+static void Jlog6(const real* R, const real* p, Mat& J) {
+  real w[3], t;
   log3(R, w, &t);
-  const double t2 = t * t;
-  double alpha, diag;
+  const real t2 = t * t;
+  real alpha, diag;
   if (t < 1e-4) { alpha = 1.0 / 12 + t2 / 720; diag = 0.5 * (2 - t2 / 6); }
-  else { const double st = std::sin(t), ct = std::cos(t), st_1mct = st / (1 - ct); alpha = 1 / t2 - st_1mct / (2 * t); diag = 0.5 * t * st_1mct; }
-  double A[9];
+  else { const real st = std::sin(t), ct = std::cos(t), st_1mct = st / (1 - ct); alpha = 1 / t2 - st_1mct / (2 * t); diag = 0.5 * t * st_1mct; }
+  real A[9];
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) A[3 * r + s] = alpha * w[r] * w[s];
   A[0] += diag; A[4] += diag; A[8] += diag;
-  double Kw[9]; skew(w, Kw);
+  real Kw[9]; skew(w, Kw);
   for (int k = 0; k < 9; ++k) A[k] += 0.5 * Kw[k];
-  double beta, bdot;
+  real beta, bdot;
   if (t < 1e-4) { beta = 1.0 / 12 + t2 / 720; bdot = 1.0 / 360; }
   else {
-    const double tinv = 1 / t, t2inv = tinv * tinv, st = std::sin(t), ct = std::cos(t), inv22ct = 1 / (2 * (1 - ct));
+    const real tinv = 1 / t, t2inv = tinv * tinv, st = std::sin(t), ct = std::cos(t), inv22ct = 1 / (2 * (1 - ct));
     beta = t2inv - st * tinv * inv22ct;
     bdot = -2 * t2inv * t2inv + (1 + st * tinv) * t2inv * inv22ct;
   }
-  const double wTp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
-  double v3[3];
+  const real wTp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  real v3[3];
   for (int k = 0; k < 3; ++k) v3[k] = (bdot * wTp) * w[k] - (t2 * bdot + 2 * beta) * p[k];
-  double Cm[9];
+  real Cm[9];
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Cm[3 * r + s] = v3[r] * w[s] + beta * w[r] * p[s];
   Cm[0] += wTp * beta; Cm[4] += wTp * beta; Cm[8] += wTp * beta;
-  double Kp[9]; skew(p, Kp);
+  real Kp[9]; skew(p, Kp);
   for (int k = 0; k < 9; ++k) Cm[k] += 0.5 * Kp[k];
-  double B[9]; matmul3(Cm, A, B);
+  real B[9]; matmul3(Cm, A, B);
   J = Mat(6, 6);
   for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) { J(r, s) = A[3 * r + s]; J(3 + r, 3 + s) = A[3 * r + s]; J(r, 3 + s) = B[3 * r + s]; }
 }
@@ -631,7 +631,7 @@ void Robot::dSubtractdConfigurationPlus(const Mat& q_plus, const Mat& q_minus, M
   J = Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
-    double R[9], p[3]; Mat J6;
+    real R[9], p[3]; Mat J6;
     relativePlacement(&q_minus.d[m_.idx_q[i]], &q_plus.d[m_.idx_q[i]], R, p);
     Jlog6(R, p, J6);
     J.setBlock(m_.idx_v[i], m_.idx_v[i], J6);
@@ -643,11 +643,11 @@ void Robot::dSubtractdConfigurationMinus(const Mat& q_plus, const Mat& q_minus, 
   J = -1.0 * Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
-    double R[9], p[3]; Mat J6;
+    real R[9], p[3]; Mat J6;
     relativePlacement(&q_minus.d[m_.idx_q[i]], &q_plus.d[m_.idx_q[i]], R, p);
     Jlog6(R, p, J6);
     // action matrix of M^-1 = (R^T, -R^T p): [[R^T, [-R^T p]x R^T],[0, R^T]]
-    double Rt[9], mp[3], K[9], KRt[9];
+    real Rt[9], mp[3], K[9], KRt[9];
     for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
     matvec3(Rt, p, mp); for (int k = 0; k < 3; ++k) mp[k] = -mp[k];
     skew(mp, K); matmul3(K, Rt, KRt);
@@ -658,8 +658,8 @@ void Robot::dSubtractdConfigurationMinus(const Mat& q_plus, const Mat& q_minus, 
 }
 
 // exp6(v) of the free-flyer tangent v = (lin, ang): (R, p) = (exp3(w), V(w) lin)
-static void exp6(const double* v6, double* R, double* p) {
-  double V[9];
+static void exp6(const real* v6, real* R, real* p) {
+  real V[9];
   exp3(v6 + 3, R); Vmat(v6 + 3, V); matvec3(V, v6, p);
 }
 
@@ -668,7 +668,7 @@ void Robot::dIntegratedConfiguration(const Mat& /*q*/, const Mat& v, Mat& J) con
   J = Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
-    double R[9], p[3], Rt[9], mp[3], K[9], KRt[9];
+    real R[9], p[3], Rt[9], mp[3], K[9], KRt[9];
     exp6(&v.d[m_.idx_v[i]], R, p);
     for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Rt[3 * r + s] = R[3 * s + r];
     matvec3(Rt, p, mp); for (int k = 0; k < 3; ++k) mp[k] = -mp[k];
@@ -684,7 +684,7 @@ void Robot::dIntegratedVelocity(const Mat& /*q*/, const Mat& v, Mat& J) const {
   J = Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
-    double R[9], p[3];
+    real R[9], p[3];
     exp6(&v.d[m_.idx_v[i]], R, p);
     Mat Jl, Je;
     Jlog6(R, p, Jl);
@@ -697,7 +697,7 @@ void Robot::dIntegratedVelocity(const Mat& /*q*/, const Mat& v, Mat& J) const {
 void Robot::dSubtractdConfigurationInverse(const Mat& J, Mat& Jinv) {
   auto inv3 = [](const Mat& A) {
     Mat I(3, 3);
-    const double det = A(0, 0) * (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(1, 2) * A(2, 0)) +
+    const real det = A(0, 0) * (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(1, 2) * A(2, 0)) +
                        A(0, 2) * (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0));
     I(0, 0) = (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) / det; I(0, 1) = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) / det; I(0, 2) = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) / det;
     I(1, 0) = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) / det; I(1, 1) = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) / det; I(1, 2) = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) / det;

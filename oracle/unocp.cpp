@@ -12,9 +12,9 @@ namespace oracle {
 // ------------------------------------------------------------ constraints ----
 Constraints::Constraints(const Robot& robot, const idocp_constraints_t& c)
     : barrier(c.barrier), fraction_to_boundary_rate(c.fraction_to_boundary_rate) {
-  const idocp_model_t& m = robot.model();
+  const RModel& m = robot.model();
   const int nu = m.nu;
-  auto vec = [&](const double* p, double sgn) { Mat v(nu); for (int i = 0; i < nu; ++i) v[i] = sgn * p[i]; return v; };
+  auto vec = [&](const real* p, real sgn) { Mat v(nu); for (int i = 0; i < nu; ++i) v[i] = sgn * p[i]; return v; };
   // Constraints::push_back sorts components into position / velocity /
   // acceleration level lists (constraints.hxx:24-36); JointConstraintsFactory
   // pushes lower before upper (joint_constraints_factory.cpp:21-38).
@@ -61,8 +61,8 @@ SplitUnOCP::SplitUnOCP(int nv_)
       Qqq(nv_, nv_), Qvv_diag(nv_), Qaa_diag(nv_), Quu_diag(nv_),
       Fq(nv_), Fv(nv_), lq(nv_), lv(nv_), la(nv_), lu(nv_) {}
 
-UnOCPSolver::UnOCPSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& cons,
-                         double T, int N)
+UnOCPSolver::UnOCPSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& cons,
+                         real T, int N)
     : robot(model), cost(cost_), constraints(robot, cons),
       s(N + 1, SplitSolution(robot)), d(N + 1, SplitDirection(robot)),
       ocp(N, SplitUnOCP(model.nv)),
@@ -113,7 +113,7 @@ void UnOCPSolver::initConstraints() {
 }
 
 // ConfigurationSpaceCost::computeStageCostDerivatives (configuration_space_cost.cpp:292-310)
-static void stageCostDerivatives(const idocp_cost_t& c, double dt, const SplitSolution& s, SplitUnOCP& o) {
+static void stageCostDerivatives(const RCost& c, real dt, const SplitSolution& s, SplitUnOCP& o) {
   const int nv = o.nv;
   for (int i = 0; i < nv; ++i) {
     o.lq[i] += dt * c.q_weight[i] * (s.q[i] - c.q_ref[i]);
@@ -131,7 +131,7 @@ static Mat& hessianDiagOf(const JointLimit& jl, SplitUnOCP& o, Mat& qqdiag) {
 }
 
 // stateequation::linearizeForwardEuler, fixed base (state_equation.hxx:12-37,210-221)
-static void linearizeForwardEuler(double dt, const SplitSolution& s, const SplitSolution& sn, SplitUnOCP& o) {
+static void linearizeForwardEuler(real dt, const SplitSolution& s, const SplitSolution& sn, SplitUnOCP& o) {
   const int nv = o.nv;
   for (int i = 0; i < nv; ++i) {
     o.Fq[i] = s.q[i] - sn.q[i] + dt * s.v[i];
@@ -144,7 +144,7 @@ static void linearizeForwardEuler(double dt, const SplitSolution& s, const Split
 
 // SplitUnOCP::computeKKTResidual up to (and including) the dynamics
 // (split_unocp.hxx:141-161); with_hessian=false.  linearizeOCP shares it.
-void UnOCPSolver::computeStageResidual(int i, double /*t*/) {
+void UnOCPSolver::computeStageResidual(int i, real /*t*/) {
   SplitUnOCP& o = ocp[i];
   const SplitSolution& si = s[i];
   o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero(); o.Fq.setZero(); o.Fv.setZero();
@@ -171,7 +171,7 @@ void UnOCPSolver::computeStageResidual(int i, double /*t*/) {
 }
 
 // SplitUnOCP::linearizeOCP (split_unocp.hxx:69-99)
-void UnOCPSolver::linearizeStage(int i, double t, const Mat& /*q_prev*/) {
+void UnOCPSolver::linearizeStage(int i, real t, const Mat& /*q_prev*/) {
   SplitUnOCP& o = ocp[i];
   const SplitSolution& si = s[i];
   const int nv = o.nv;
@@ -242,7 +242,7 @@ void UnOCPSolver::linearizeStage(int i, double t, const Mat& /*q_prev*/) {
 }
 
 // TerminalOCP::linearizeOCP (terminal_ocp.hxx:50-66), fixed base
-void UnOCPSolver::linearizeTerminal(double /*t*/) {
+void UnOCPSolver::linearizeTerminal(real /*t*/) {
   const SplitSolution& sN = s[N_];
   const int nv = robot.dimv();
   terminal_lq.setZero(); terminal_lv.setZero();
@@ -256,7 +256,7 @@ void UnOCPSolver::linearizeTerminal(double /*t*/) {
   for (int i = 0; i < nv; ++i) { terminal_Qqq(i, i) += cost.qf_weight[i]; terminal_Qvv(i, i) += cost.vf_weight[i]; }
 }
 
-void UnOCPSolver::linearizeOCP(double t, const Mat& q) {
+void UnOCPSolver::linearizeOCP(real t, const Mat& q) {
   for (int i = 0; i <= N_; ++i) {
     if (i == 0) linearizeStage(0, t, q);
     else if (i < N_) linearizeStage(i, t + i * dt_, s[i - 1].q);
@@ -272,7 +272,7 @@ void UnOCPSolver::backwardRiccatiRecursion() {
   riccati[N_].Pvv = terminal_Qvv;
   riccati[N_].sq = -terminal_lq;
   riccati[N_].sv = -terminal_lv;
-  const double dt = dt_;
+  const real dt = dt_;
   for (int i = N_ - 1; i >= 0; --i) {
     const SplitRiccatiFactorization& rn = riccati[i + 1];
     SplitUnKKTMatrix& Q = unkkt_matrix[i];
@@ -343,10 +343,10 @@ void UnOCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
 }
 
 // pdipm::FractionToBoundary (pdipm.hxx:52-73)
-static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {
-  double m = 1;
+static real fractionToBoundary(real rate, const Mat& vec, const Mat& dvec) {
+  real m = 1;
   for (int i = 0; i < vec.size(); ++i) {
-    const double f = -rate * (vec[i] / dvec[i]);
+    const real f = -rate * (vec[i] / dvec[i]);
     if (f > 0 && f < 1 && f < m) m = f;
   }
   return m;
@@ -357,33 +357,33 @@ static double fractionToBoundary(double rate, const Mat& vec, const Mat& dvec) {
 // (configuration_space_cost.cpp:241-256), the barrier on slack + alpha dslack (pdipm.hxx:84-87), dt |ID|_1 and
 // dt |g(x_try) + slack|_1 with the CURRENT slack.
 struct TrialPoint { Mat q, v, a, u; };
-static TrialPoint trialPoint(const SplitSolution& s, const SplitDirection& d, double alpha) {
+static TrialPoint trialPoint(const SplitSolution& s, const SplitDirection& d, real alpha) {
   return {s.q + alpha * d.dq, s.v + alpha * d.dv, s.a + alpha * d.da, s.u + alpha * d.du};
 }
-static double trialStageCost(const idocp_cost_t& c, const Constraints& cs, const ConstraintsData& cd, int level, double dt,
-                             const TrialPoint& x, double alpha, bool terminal_cost) {
+static real trialStageCost(const RCost& c, const Constraints& cs, const ConstraintsData& cd, int level, real dt,
+                             const TrialPoint& x, real alpha, bool terminal_cost) {
   const int nv = x.v.size();
-  double l = 0, lf = 0;
+  real l = 0, lf = 0;
   for (int r = 0; r < nv; ++r) {
     l += c.q_weight[r] * (x.q[r] - c.q_ref[r]) * (x.q[r] - c.q_ref[r]) + c.v_weight[r] * (x.v[r] - c.v_ref[r]) * (x.v[r] - c.v_ref[r]) +
          c.a_weight[r] * x.a[r] * x.a[r] + c.u_weight[r] * (x.u[r] - c.u_ref[r]) * (x.u[r] - c.u_ref[r]);
     lf += c.qf_weight[r] * (x.q[r] - c.q_ref[r]) * (x.q[r] - c.q_ref[r]) + c.vf_weight[r] * (x.v[r] - c.v_ref[r]) * (x.v[r] - c.v_ref[r]);
   }
-  double cost = 0.5 * dt * l + (terminal_cost ? 0.5 * lf : 0.0);
+  real cost = 0.5 * dt * l + (terminal_cost ? 0.5 * lf : 0.0);
   for (size_t j = 0; j < cs.components.size(); ++j) {
     if (!cs.valid(cs.components[j], level)) continue;
     const ConstraintComponentData& data = cd.data[j];
-    double sum = 0;
+    real sum = 0;
     for (int r = 0; r < data.slack.size(); ++r) sum += std::log(data.slack[r] + alpha * data.dslack[r]);
     cost += dt * (-cs.barrier * sum);
   }
   return cost;
 }
-static double trialConstraintViolation(Robot& robot, const Constraints& cs, const ConstraintsData& cd, int level, double dt,
+static real trialConstraintViolation(Robot& robot, const Constraints& cs, const ConstraintsData& cd, int level, real dt,
                                        const TrialPoint& x) {
   Mat ID(x.v.size());
   robot.RNEA(x.q, x.v, x.a, ID);
-  double viol = 0;
+  real viol = 0;
   for (int r = 0; r < ID.size(); ++r) viol += dt * std::fabs(ID[r] - x.u[r]);
   for (size_t j = 0; j < cs.components.size(); ++j) {
     const JointLimit& jl = cs.components[j];
@@ -397,7 +397,7 @@ static double trialConstraintViolation(Robot& robot, const Constraints& cs, cons
 
 // second parallel loop of UnOCPSolver::updateSolution (unocp_solver.cpp:103-115)
 void UnOCPSolver::computeDirection() {
-  double pmin = 1, dmin = 1;
+  real pmin = 1, dmin = 1;
   for (int i = 0; i <= N_; ++i) {
     const SplitRiccatiFactorization& r = riccati[i];
     // SplitUnRiccatiFactorizer::computeCostateDirection (split_unriccati_factorizer.hxx:60-68)
@@ -426,8 +426,8 @@ void UnOCPSolver::computeDirection() {
           data.dslack[r2] = -jl.sign * dx[off + r2] - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];   // pdipm.hxx:76-81
         }
-        const double ps = fractionToBoundary(constraints.fraction_to_boundary_rate, data.slack, data.dslack);
-        const double ds = fractionToBoundary(constraints.fraction_to_boundary_rate, data.dual, data.ddual);
+        const real ps = fractionToBoundary(constraints.fraction_to_boundary_rate, data.slack, data.dslack);
+        const real ds = fractionToBoundary(constraints.fraction_to_boundary_rate, data.dual, data.ddual);
         if (ps < pmin) pmin = ps;
         if (ds < dmin) dmin = ds;
       }
@@ -438,7 +438,7 @@ void UnOCPSolver::computeDirection() {
 
 // third parallel loop (unocp_solver.cpp:121-133): updatePrimal / updateDual
 void UnOCPSolver::integrate() {
-  const double ap = primal_step_size, ad = dual_step_size;
+  const real ap = primal_step_size, ad = dual_step_size;
   for (int i = 0; i <= N_; ++i) {
     s[i].lmd += ap * d[i].dlmd;
     s[i].gmm += ap * d[i].dgmm;
@@ -460,9 +460,9 @@ void UnOCPSolver::integrate() {
 
 // UnLineSearch::computeCostAndViolation(UnOCP&, ...) (unline_search.cpp:55-82): forward-Euler residual against the trial
 // point of the next stage, terminal cost of stage N
-std::pair<double, double> UnOCPSolver::costAndViolation(double alpha) const {
+std::pair<real, real> UnOCPSolver::costAndViolation(real alpha) const {
   Robot rb = robot;
-  double cost_sum = 0, viol = 0;
+  real cost_sum = 0, viol = 0;
   for (int i = 0; i < N_; ++i) {
     const TrialPoint x = trialPoint(s[i], d[i], alpha);
     const Mat qn = s[i + 1].q + alpha * d[i + 1].dq, vn = s[i + 1].v + alpha * d[i + 1].dv;
@@ -471,25 +471,25 @@ std::pair<double, double> UnOCPSolver::costAndViolation(double alpha) const {
     viol += trialConstraintViolation(rb, constraints, ocp[i].cdata, i, dt_, x);
   }
   const Mat qN = s[N_].q + alpha * d[N_].dq, vN = s[N_].v + alpha * d[N_].dv;
-  double lf = 0;
+  real lf = 0;
   for (int r = 0; r < rb.dimv(); ++r)
     lf += cost.qf_weight[r] * (qN[r] - cost.q_ref[r]) * (qN[r] - cost.q_ref[r]) + cost.vf_weight[r] * (vN[r] - cost.v_ref[r]) * (vN[r] - cost.v_ref[r]);
   return {cost_sum + 0.5 * lf, viol};
 }
 
-void UnOCPSolver::updateSolution(double t, const Mat& q, const Mat& v, bool use_line_search) {
+void UnOCPSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line_search) {
   linearizeOCP(t, q);
   auto t0 = std::chrono::steady_clock::now();
   backwardRiccatiRecursion();
   forwardRiccatiRecursion(q, v);
-  riccati_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  riccati_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
   computeDirection();
   if (use_line_search)            // unocp_solver.cpp:116-120
-    primal_step_size = line_search.computeStepSize([&](double a) { return costAndViolation(a); }, primal_step_size);
+    primal_step_size = line_search.computeStepSize([&](real a) { return costAndViolation(a); }, primal_step_size);
   integrate();
 }
 
-void UnOCPSolver::computeKKTResidual(double t, const Mat& /*q*/, const Mat& /*v*/) {
+void UnOCPSolver::computeKKTResidual(real t, const Mat& /*q*/, const Mat& /*v*/) {
   for (int i = 0; i < N_; ++i) computeStageResidual(i, t + i * dt_);
   // TerminalOCP::computeKKTResidual (terminal_ocp.hxx:118-131)
   const SplitSolution& sN = s[N_];
@@ -517,14 +517,14 @@ int UnOCPSolver::isCurrentSolutionFeasible() const {
   return -1;
 }
 
-double UnOCPSolver::KKTError() {
-  double sum = 0;
+real UnOCPSolver::KKTError() {
+  real sum = 0;
   for (int i = 0; i < N_; ++i) {
     const SplitUnOCP& o = ocp[i];
-    double e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
+    real e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
     e += o.Fq.squaredNorm() + o.Fv.squaredNorm();
     e += dt_ * dt_ * o.ID.squaredNorm();
-    double c = 0;
+    real c = 0;
     for (size_t j = 0; j < constraints.components.size(); ++j) {
       if (!constraints.valid(constraints.components[j], i)) continue;
       c += o.cdata.data[j].residual.squaredNorm() + o.cdata.data[j].duality.squaredNorm();
@@ -538,7 +538,7 @@ double UnOCPSolver::KKTError() {
 
 
 // ======================================================================= UnParNMPC ====
-UnParNMPCSolver::UnParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost_, const idocp_constraints_t& cons, double T, int N)
+UnParNMPCSolver::UnParNMPCSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& cons, real T, int N)
     : robot(model), cost(cost_), constraints(robot, cons),
       s(N, SplitSolution(robot)), s_new(N, SplitSolution(robot)), d(N, SplitDirection(robot)), ocp(N, SplitUnOCP(model.nv)),
       unkkt_matrix(N, SplitUnKKTMatrix(model.nv)), unkkt_residual(N, SplitUnKKTResidual(model.nv)),
@@ -585,7 +585,7 @@ void UnParNMPCSolver::initConstraints() {
 }
 
 // UnBackwardCorrection::initAuxMat: the terminal cost Hessian (configuration_space_cost.cpp:368-380) on every stage
-void UnParNMPCSolver::initBackwardCorrection(double /*t*/) {
+void UnParNMPCSolver::initBackwardCorrection(real /*t*/) {
   const int nv = robot.dimv();
   for (int i = 0; i < N_; ++i) {
     aux_mat[i].setZero();
@@ -680,7 +680,7 @@ void UnParNMPCSolver::linearizeStage(int i, const Mat& q_prev, const Mat& v_prev
 
 // UnBackwardCorrection::coarseUpdate (unbackward_correction.cpp:67-97) with SplitUnBackwardCorrection::coarseUpdate
 // (split_unbackward_correction.hxx:38-64) and SplitUnKKTMatrixInverter::invert (split_unkkt_matrix_inverter.hxx:37-80)
-void UnParNMPCSolver::coarseUpdate(double /*t*/, const Mat& q, const Mat& v) {
+void UnParNMPCSolver::coarseUpdate(real /*t*/, const Mat& q, const Mat& v) {
   const int nv = robot.dimv(), nx = 2 * nv, nq3 = 3 * nv, nk = 5 * nv;
   for (int i = lo_; i < hi_; ++i) {
     linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, false);
@@ -763,7 +763,7 @@ void UnParNMPCSolver::forwardCorrectionSerial() {
 // direction (unconstrained_dynamics.hxx:97-106), slack / dual directions and the step sizes
 void UnParNMPCSolver::forwardCorrectionParallel() {
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
-  double pmin = 1, dmin = 1;
+  real pmin = 1, dmin = 1;
   for (int i = lo_; i < hi_; ++i) {
     if (i > 0) {
       const Mat dd = kkt_inv[i].block(0, 0, nk - nx, nx) * x_res[i];
@@ -793,8 +793,8 @@ void UnParNMPCSolver::forwardCorrectionParallel() {
         data.dslack[r2] = -jl.sign * dx[off + r2] - data.residual[r2];
         data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
       }
-      const double ps = fractionToBoundary(constraints.fraction_to_boundary_rate, data.slack, data.dslack);
-      const double ds = fractionToBoundary(constraints.fraction_to_boundary_rate, data.dual, data.ddual);
+      const real ps = fractionToBoundary(constraints.fraction_to_boundary_rate, data.slack, data.dslack);
+      const real ds = fractionToBoundary(constraints.fraction_to_boundary_rate, data.dual, data.ddual);
       if (ps < pmin) pmin = ps;
       if (ds < dmin) dmin = ds;
     }
@@ -804,7 +804,7 @@ void UnParNMPCSolver::forwardCorrectionParallel() {
 
 // updatePrimal / updateDual of every stage (unparnmpc_solver.cpp:88-102; split_solution.hxx:215-240)
 void UnParNMPCSolver::integrate() {
-  const double ap = primal_step_size, ad = dual_step_size;
+  const real ap = primal_step_size, ad = dual_step_size;
   for (int i = lo_; i < hi_; ++i) {
     s[i].lmd += ap * d[i].dlmd; s[i].gmm += ap * d[i].dgmm; s[i].q += ap * d[i].dq; s[i].v += ap * d[i].dv;
     s[i].a += ap * d[i].da; s[i].u += ap * d[i].du; s[i].beta += ap * d[i].dbeta;
@@ -819,9 +819,9 @@ void UnParNMPCSolver::integrate() {
 
 // UnLineSearch::computeCostAndViolation(UnParNMPC&, ...) (unline_search.cpp:85-121): backward-Euler residual against the
 // trial point of the previous stage (the measured state for stage 0), terminal cost on the last stage
-std::pair<double, double> UnParNMPCSolver::costAndViolation(double alpha, const Mat& q, const Mat& v) const {
+std::pair<real, real> UnParNMPCSolver::costAndViolation(real alpha, const Mat& q, const Mat& v) const {
   Robot rb = robot;
-  double cost_sum = 0, viol = 0;
+  real cost_sum = 0, viol = 0;
   for (int i = 0; i < N_; ++i) {
     const TrialPoint x = trialPoint(s[i], d[i], alpha);
     const Mat qp = i == 0 ? q : s[i - 1].q + alpha * d[i - 1].dq, vp = i == 0 ? v : s[i - 1].v + alpha * d[i - 1].dv;
@@ -832,31 +832,31 @@ std::pair<double, double> UnParNMPCSolver::costAndViolation(double alpha, const 
   return {cost_sum, viol};
 }
 
-void UnParNMPCSolver::updateSolution(double t, const Mat& q, const Mat& v, bool use_line_search) {
+void UnParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line_search) {
   coarseUpdate(t, q, v);
   backwardCorrectionSerial();
   backwardCorrectionParallel();
   forwardCorrectionSerial();
   forwardCorrectionParallel();
   if (use_line_search)            // unparnmpc_solver.cpp:81-86
-    primal_step_size = line_search.computeStepSize([&](double a) { return costAndViolation(a, q, v); }, primal_step_size);
+    primal_step_size = line_search.computeStepSize([&](real a) { return costAndViolation(a, q, v); }, primal_step_size);
   integrate();
 }
 
-void UnParNMPCSolver::computeKKTResidual(double /*t*/, const Mat& q, const Mat& v) {
+void UnParNMPCSolver::computeKKTResidual(real /*t*/, const Mat& q, const Mat& v) {
   for (int i = lo_; i < hi_; ++i) linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, true);
 }
 
 // squaredNormKKTResidual of every stage (split_unparnmpc.hxx:166-176, terminal_unparnmpc.hxx:171-181)
-double UnParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
-double UnParNMPCSolver::KKTErrorSquared() {
-  double sum = 0;
+real UnParNMPCSolver::KKTError() { return std::sqrt(KKTErrorSquared()); }
+real UnParNMPCSolver::KKTErrorSquared() {
+  real sum = 0;
   for (int i = lo_; i < hi_; ++i) {
     const SplitUnOCP& o = ocp[i];
-    double e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
+    real e = o.lq.squaredNorm() + o.lv.squaredNorm() + o.la.squaredNorm() + o.lu.squaredNorm();
     e += o.Fq.squaredNorm() + o.Fv.squaredNorm();
     e += dt_ * dt_ * o.ID.squaredNorm();
-    double c = 0;
+    real c = 0;
     for (size_t j = 0; j < constraints.components.size(); ++j) {
       if (!constraints.valid(constraints.components[j], i + 1)) continue;
       c += o.cdata.data[j].residual.squaredNorm() + o.cdata.data[j].duality.squaredNorm();

@@ -51,7 +51,7 @@ struct JointLimit {
 // include/idocp/constraints/constraints.hxx + constraints_data.hpp:18-42
 struct Constraints {
   std::vector<JointLimit> components;   // stored level by level like the reference
-  double barrier = 1.0e-04, fraction_to_boundary_rate = 0.995;
+  real barrier = 1.0e-04, fraction_to_boundary_rate = 0.995;
   Constraints(const Robot& robot, const idocp_constraints_t& c);
   int dimc_total() const;
   bool valid(const JointLimit& jl, int time_stage) const {
@@ -74,7 +74,7 @@ struct SplitUnKKTMatrix {
   explicit SplitUnKKTMatrix(int nv_) : nv(nv_), Q(3 * nv_, 3 * nv_) {}
   Mat blk(int bi, int bj) const { return Q.block(bi * nv, bj * nv, nv, nv); }
   void set(int bi, int bj, const Mat& m) { Q.setBlock(bi * nv, bj * nv, m); }
-  void add(int bi, int bj, const Mat& m, double al = 1.0) { Q.addBlock(bi * nv, bj * nv, m, al); }
+  void add(int bi, int bj, const Mat& m, real al = 1.0) { Q.addBlock(bi * nv, bj * nv, m, al); }
 };
 // include/idocp/unocp/split_unkkt_residual.hxx:29-103 -- (Fq, Fv, la, lq, lv)
 struct SplitUnKKTResidual {
@@ -92,14 +92,14 @@ struct SplitRiccatiFactorization {
 // step-size schedule of UnLineSearch::computeStepSize (include/idocp/line_search/unline_search.hpp:62-92, defaults
 // line_search.hpp:25-26)
 struct LineSearchFilterC {
-  std::vector<std::pair<double, double>> filter;
-  double cost_reduction_rate = 0.005, constraints_reduction_rate = 0.005;
-  double step_size_reduction_rate = 0.75, min_step_size = 0.05;
-  bool isAccepted(double cost, double violation) const {
+  std::vector<std::pair<real, real>> filter;
+  real cost_reduction_rate = 0.005, constraints_reduction_rate = 0.005;
+  real step_size_reduction_rate = 0.75, min_step_size = 0.05;
+  bool isAccepted(real cost, real violation) const {
     for (const auto& p : filter) if (cost >= p.first && violation >= p.second) return false;
     return true;
   }
-  void augment(double cost, double violation) {
+  void augment(real cost, real violation) {
     for (auto it = filter.begin(); it != filter.end();) {
       if (cost <= it->first && violation <= it->second) it = filter.erase(it); else ++it;
     }
@@ -107,9 +107,9 @@ struct LineSearchFilterC {
   }
   // eval(alpha) -> (total cost, total violation) of the trial iterate s + alpha d (alpha = 0: the iterate itself)
   template <typename Eval>
-  double computeStepSize(Eval eval, double max_primal_step_size) {
+  real computeStepSize(Eval eval, real max_primal_step_size) {
     if (filter.empty()) { const auto cv = eval(0.0); augment(cv.first, cv.second); }
-    double a = max_primal_step_size;
+    real a = max_primal_step_size;
     while (a > min_step_size) {
       const auto cv = eval(a);
       if (isAccepted(cv.first, cv.second)) { augment(cv.first, cv.second); break; }
@@ -132,19 +132,19 @@ struct SplitUnOCP {
 
 class UnOCPSolver {
  public:
-  UnOCPSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints,
-              double T, int N);
+  UnOCPSolver(const RModel& model, const RCost& cost, const idocp_constraints_t& constraints,
+              real T, int N);
   void setSolution(const std::string& name, const Mat& value);   // unocp_solver.cpp:157-181
   void initConstraints();                                        // unocp_solver.cpp:59-70
-  void updateSolution(double t, const Mat& q, const Mat& v, bool line_search = false);      // unocp_solver.cpp:73-134
-  std::pair<double, double> costAndViolation(double alpha) const;  // UnLineSearch::computeCostAndViolation (unline_search.cpp:55-82)
+  void updateSolution(real t, const Mat& q, const Mat& v, bool line_search = false);      // unocp_solver.cpp:73-134
+  std::pair<real, real> costAndViolation(real alpha) const;  // UnLineSearch::computeCostAndViolation (unline_search.cpp:55-82)
   LineSearchFilterC line_search;                                   // clearLineSearchFilter = line_search.filter.clear()
-  void computeKKTResidual(double t, const Mat& q, const Mat& v);  // unocp_solver.cpp:205-225
-  double KKTError();                                              // unocp_solver.cpp:190-202
+  void computeKKTResidual(real t, const Mat& q, const Mat& v);  // unocp_solver.cpp:205-225
+  real KKTError();                                              // unocp_solver.cpp:190-202
   int isCurrentSolutionFeasible() const;                          // unocp_solver.cpp:228-237: first offending stage or -1
 
   // hot-path pieces, exposed so kernel-level parity tests can stop in between
-  void linearizeOCP(double t, const Mat& q);                      // K1
+  void linearizeOCP(real t, const Mat& q);                      // K1
   void backwardRiccatiRecursion();                                // S1
   void forwardRiccatiRecursion(const Mat& q, const Mat& v);       // S2
   void computeDirection();                                        // K2 (+ step sizes)
@@ -152,7 +152,7 @@ class UnOCPSolver {
 
   int N() const { return N_; }
   Robot robot;
-  idocp_cost_t cost;
+  RCost cost;
   Constraints constraints;
   std::vector<SplitSolution> s;
   std::vector<SplitDirection> d;
@@ -162,14 +162,14 @@ class UnOCPSolver {
   Mat terminal_Qqq, terminal_Qvv, terminal_lq, terminal_lv;
   std::vector<SplitRiccatiFactorization> riccati;
   std::vector<Mat> K, k;                      // LQRStateFeedbackPolicy per stage
-  double primal_step_size = 1, dual_step_size = 1;
-  double riccati_seconds = 0;                 // accumulated wall time of S1+S2
+  real primal_step_size = 1, dual_step_size = 1;
+  real riccati_seconds = 0;                 // accumulated wall time of S1+S2
 
  private:
-  int N_; double T_, dt_;
-  void linearizeStage(int i, double t, const Mat& q_prev);
-  void linearizeTerminal(double t);
-  void computeStageResidual(int i, double t);
+  int N_; real T_, dt_;
+  void linearizeStage(int i, real t, const Mat& q_prev);
+  void linearizeTerminal(real t);
+  void computeStageResidual(int i, real t);
 };
 
 
@@ -181,24 +181,24 @@ class UnOCPSolver {
 // KKT ordering (lmd, gmm, a, q, v): rows [Fq, Fv, la, lq, lv].
 class UnParNMPCSolver {
  public:
-  UnParNMPCSolver(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N);
+  UnParNMPCSolver(const RModel& model, const RCost& cost, const idocp_constraints_t& constraints, real T, int N);
   void setSolution(const std::string& name, const Mat& value);    // unparnmpc_solver.cpp:121-146
   void initConstraints();                                         // unparnmpc_solver.cpp:55-66
-  void initBackwardCorrection(double t);                          // unbackward_correction.cpp:55-64
-  void updateSolution(double t, const Mat& q, const Mat& v, bool line_search = false);       // unparnmpc_solver.cpp:74-103
-  std::pair<double, double> costAndViolation(double alpha, const Mat& q, const Mat& v) const;   // unline_search.cpp:85-121
+  void initBackwardCorrection(real t);                          // unbackward_correction.cpp:55-64
+  void updateSolution(real t, const Mat& q, const Mat& v, bool line_search = false);       // unparnmpc_solver.cpp:74-103
+  std::pair<real, real> costAndViolation(real alpha, const Mat& q, const Mat& v) const;   // unline_search.cpp:85-121
   LineSearchFilterC line_search;
-  void computeKKTResidual(double t, const Mat& q, const Mat& v);   // unparnmpc_solver.cpp:169-187
-  double KKTError();                                               // unparnmpc_solver.cpp:154-166
+  void computeKKTResidual(real t, const Mat& q, const Mat& v);   // unparnmpc_solver.cpp:169-187
+  real KKTError();                                               // unparnmpc_solver.cpp:154-166
   int isCurrentSolutionFeasible() const;                           // unparnmpc_solver.cpp:190-209
   // horizon shard (test twin of idocp_unparnmpc_create_shard): every loop runs over the stages [lo, hi) only; the
   // neighbours' stages lo - 1 and hi are filled by the halo imports (oracle_unparnmpc_import)
   void setSlice(int lo, int hi) { lo_ = lo; hi_ = hi; }
   int lo() const { return lo_; }
   int hi() const { return hi_; }
-  double KKTErrorSquared();
+  real KKTErrorSquared();
   // the phases of updateSolution, separately callable
-  void coarseUpdate(double t, const Mat& q, const Mat& v);         // unbackward_correction.cpp:67-97
+  void coarseUpdate(real t, const Mat& q, const Mat& v);         // unbackward_correction.cpp:67-97
   void backwardCorrectionSerial();                                 // :104-106
   void backwardCorrectionParallel();                               // :107-110
   void forwardCorrectionSerial();                                  // :111-113
@@ -207,7 +207,7 @@ class UnParNMPCSolver {
 
   int N() const { return N_; }
   Robot robot;
-  idocp_cost_t cost;
+  RCost cost;
   Constraints constraints;
   std::vector<SplitSolution> s, s_new;        // N stages
   std::vector<SplitDirection> d;
@@ -215,10 +215,10 @@ class UnParNMPCSolver {
   std::vector<SplitUnKKTMatrix> unkkt_matrix;
   std::vector<SplitUnKKTResidual> unkkt_residual;
   std::vector<Mat> aux_mat, kkt_inv, x_res;   // 2nv x 2nv, 5nv x 5nv, 2nv
-  double primal_step_size = 1, dual_step_size = 1;
+  real primal_step_size = 1, dual_step_size = 1;
 
  private:
-  int N_; double T_, dt_;
+  int N_; real T_, dt_;
   int lo_ = 0, hi_ = 0;
   void linearizeStage(int i, const Mat& q_prev, const Mat& v_prev, bool residual_only);
 };

@@ -16,15 +16,17 @@ ANYMAL_URDF = os.path.join(GOLDEN, "urdf", "anymal.urdf")
 ANYMAL_CONTACT_FRAMES = (14, 24, 34, 44)
 dp = capi.c_double_p
 
-_oracle = None
+_oracles = {}
 
 
-def oracle():
-    """liboracle.so; (re)built with make if missing or stale."""
-    global _oracle
+def oracle(hp=False):
+    """liboracle.so, or with hp=True liboracle_hp.so -- the SAME restatement built with a long double scalar, the referee
+    of the parity tests on ill-conditioned problems; (re)built with make if missing or stale."""
+    global _oracles
+    _oracle = _oracles.get(hp)
     if _oracle is None:
-        path = os.path.join(ROOT, "oracle", "liboracle.so")
-        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
+        path = os.path.join(ROOT, "oracle", "liboracle_hp.so" if hp else "liboracle.so")
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], capture_output=True, text=True)
         if r.returncode != 0 and not os.path.exists(path):
             raise RuntimeError("cannot build the oracle:\n" + r.stderr)
         lib = C.CDLL(path)
@@ -82,7 +84,7 @@ def oracle():
         lib.oracle_unparnmpc_update_solution_ls.argtypes = [vp, cd, dp, dp]
         lib.oracle_unparnmpc_clear_line_search_filter.argtypes = [vp]
         lib.oracle_unparnmpc_cost_and_violation.argtypes = [vp, cd, dp, dp, dp]
-        _oracle = lib
+        _oracle = _oracles[hp] = lib
     return _oracle
 
 
@@ -127,8 +129,8 @@ def stages_of(name, N):
 
 
 class OracleUnOCP:
-    def __init__(self, model, cost, cons, T, N):
-        self.lib = oracle()
+    def __init__(self, model, cost, cons, T, N, hp=False):
+        self.lib = oracle(hp)
         self.N, self.nv = N, model.nv
         self.h = self.lib.oracle_unocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
         assert self.h
@@ -202,8 +204,8 @@ class OracleUnOCP:
 class OracleUnParNMPC:
     """oracle::UnParNMPCSolver: N backward-Euler stages, every field is [N][nv]"""
 
-    def __init__(self, model, cost, cons, T, N):
-        self.lib = oracle()
+    def __init__(self, model, cost, cons, T, N, hp=False):
+        self.lib = oracle(hp)
         self.N, self.nv = N, model.nv
         self.h = self.lib.oracle_unparnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N)
         assert self.h
@@ -408,6 +410,21 @@ class HipUnParNMPC(HipUnOCP):
         return out[:self.N]
 
 
+def referee_check(g, o, h, what, tol=1e-10, factor=4.0, window=3):
+    """Parity on an ill-conditioned problem, decided by a higher-precision referee.  g, o, h: the same quantity [stages, dim]
+    from the GPU, the FP64 oracle and the long double build of the oracle (`hp=True`).  Stage by stage the GPU may be at most
+    `factor` times as far from the referee as the FP64 oracle is (largest oracle error within +-`window` stages: rounding
+    differences travel along the sweep), plus the 1e-10 bar itself.  Returns (worst GPU error, worst oracle error), relative
+    to the largest entry."""
+    g, o, h = (np.asarray(x, dtype=np.float64).reshape(len(h), -1) for x in (g, o, h))
+    scale = max(1.0, np.abs(h).max())
+    eg, eo = np.abs(g - h).max(axis=1) / scale, np.abs(o - h).max(axis=1) / scale
+    eo_w = np.array([eo[max(0, i - window):i + window + 1].max() for i in range(len(eo))])
+    bad = np.nonzero(eg > factor * eo_w + tol)[0]
+    assert bad.size == 0, (what, "stage %d: gpu-referee %.2e, oracle-referee %.2e" % (bad[0], eg[bad[0]], eo_w[bad[0]]))
+    return eg.max(), eo.max()
+
+
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
@@ -608,8 +625,8 @@ NODE_KINDS = ("stage", "impulse", "aux", "lift", "terminal")
 
 
 class OracleOCP:
-    def __init__(self, model, cost, cons, T, N, max_num_impulse=0):
-        self.lib = oracle()
+    def __init__(self, model, cost, cons, T, N, max_num_impulse=0, hp=False):
+        self.lib = oracle(hp)
         _setup_oracle_ocp(self.lib)
         self.N, self.nv, self.nu, self.nq = N, model.nv, model.nu, model.nq
         self.max_events = max_num_impulse
@@ -717,8 +734,8 @@ class OracleParNMPC:
     with discrete events (examples/anymal/anymal_trotting_parnmpc.cpp)."""
     KINDS = ("stage", "impulse", "aux", "lift", "terminal")
 
-    def __init__(self, model, cost, cons, T, N, max_num_impulse=0):
-        self.lib = lib = oracle()
+    def __init__(self, model, cost, cons, T, N, max_num_impulse=0, hp=False):
+        self.lib = lib = oracle(hp)
         vp, ci, cd, cs = C.c_void_p, C.c_int, C.c_double, C.c_char_p
         if not getattr(lib, "_parnmpc_ready", False):
             lib.oracle_parnmpc_create.argtypes = [C.POINTER(capi.Model), C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]

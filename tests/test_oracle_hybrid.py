@@ -205,3 +205,27 @@ def test_running_example_converges():
         assert o.update(0.0, q, v) == 0
         e.append(o.kkt_error(0.0, q, v))
     assert np.isfinite(e).all() and e[30] < 1.0 and e[60] < 0.5 * e[45] < 0.25 * e[30], e[::15]
+
+
+def test_long_double_referee_build_agrees_with_the_fp64_oracle():
+    """oracle/liboracle_hp.so is the same restatement compiled with a long double scalar (the referee of the GPU parity tests on
+    ill-conditioned stages).  On a normally conditioned grid the two builds agree to 1e-12; on BASELINE configs[2] at its own size
+    (N = 100, T = 5.05, 10 events), where the stage behind the last switching constraint has cond(Quu + B^T P B) = 3e8, the FP64
+    build is a few 1e-10 away from the long double one -- the size of error the GPU is allowed on that problem."""
+    import numpy as np
+    from helpers import ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OracleOCP, anymal_model, anymal_problem, rel_err, trotting_sequence
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    for (N, T, nimp, lo, hi) in ((31, 1.55, 2, 0.0, 1e-12), (100, 5.05, 9, 1e-11, 2e-9)):
+        pair = [OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=hp) for hp in (False, True)]
+        q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+        for s in pair:
+            trotting_sequence(s, m, nimp)
+            s.set_solution("q", q)
+            s.set_solution("v", v)
+            s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+            s.init_constraints(0.0)
+            assert s.update(0.0, q, v) == 0
+        M = len(pair[0].chain(0.0))
+        worst = max(rel_err(pair[0].get_chain(f, M), pair[1].get_chain(f, M)) for f in OCP_DIR_FIELDS)
+        assert lo <= worst < hi, (N, worst)
