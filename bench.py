@@ -68,12 +68,42 @@ class Hip:
         return ms.value
 
 
-def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=12.0, nimp=0):
-    """CPU restatement (oracle, kind "port") timed on this host with the
-    reference's CPUTime protocol, single thread, on a bounded sample."""
-    from helpers import OracleOCP, OracleUnOCP, OracleUnParNMPC, P, arr, oracle, running_sequence, trotting_sequence
-    lib = oracle()
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def native_oracle():
+    """The CPU baseline library: oracle/ built ON THIS HOST with -O3 -march=native -fopenmp (oracle/Makefile, target
+    liboracle_native.so; a few seconds of g++).  Falls back to the portable build (-march=x86-64-v3 -fopenmp) that travelled with
+    the tree when there is no compiler.  Returns (path, flags)."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    r = subprocess.run(["make", "-C", odir, "liboracle_native.so"], capture_output=True, text=True)
+    path = os.path.join(odir, "liboracle_native.so")
+    if r.returncode == 0 and os.path.exists(path):
+        return path, "-O3 -march=native -fopenmp"
+    return os.path.join(odir, "liboracle.so"), "-O3 -march=x86-64-v3 -fopenmp"
+
+
+def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_seconds=6.0, nimp=0):
+    """CPU restatement (oracle, kind "port") timed on this host with the reference's CPUTime protocol
+    (ocp_benchmarker.hxx:13-34: repeated updateSolution at fixed (t, q, v) after convergence) on a bounded sample, with the
+    reference's OpenMP stage loops on nthreads = 1, 4 and all cores.  `value` is the best row."""
+    import helpers
+    from helpers import OracleOCP, OracleUnOCP, OracleUnParNMPC, P, arr, running_sequence, trotting_sequence
+    path, flags = native_oracle()
+    helpers.ORACLE_PATH_OVERRIDE = path            # the wrappers below load this build
+    helpers._oracles.pop(False, None)
+    lib = helpers.oracle()
+    ncores = os.cpu_count() or 1
     ric = C.c_double()
+    set_threads = None
     if workload == "anymal_running":
         o = OracleOCP(model, cost, cons, T, N, max_num_impulse=nimp)
         running_sequence(o, model, 10)
@@ -82,6 +112,7 @@ def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_secon
         o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
         o.init_constraints(0.0)
         bench = lib.oracle_ocp_bench
+        set_threads = lib.oracle_ocp_set_num_threads
         nconv = 10
     elif workload == "anymal_trotting":
         o = OracleOCP(model, cost, cons, T, N, max_num_impulse=nimp + 1)
@@ -91,12 +122,14 @@ def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_secon
         o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
         o.init_constraints(0.0)
         bench = lib.oracle_ocp_bench
+        set_threads = lib.oracle_ocp_set_num_threads
         nconv = 10
     elif workload == "iiwa14":
         o = OracleUnOCP(model, cost, cons, T, N)
         o.set_solution("q", q)
         o.set_solution("v", v)
         bench = lib.oracle_unocp_bench
+        set_threads = lib.oracle_unocp_set_num_threads
         nconv = 50
     elif workload == "iiwa14_unparnmpc":
         o = OracleUnParNMPC(model, cost, cons, T, N)
@@ -113,15 +146,28 @@ def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_secon
         o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
         o.init_constraints(0.0)
         bench = lib.oracle_ocp_bench
+        set_threads = lib.oracle_ocp_set_num_threads
         nconv = 10
     for _ in range(nconv):                    # converge first (examples/*/…_benchmark.cpp call Convergence before CPUTime)
         o.update(0.0, q, v)
-    t_probe = bench(o.h, 0.0, P(arr(q)), P(arr(v)), 5, C.byref(ric))
-    iters = int(max(5, min(20000, target_seconds / max(t_probe / 5, 1e-9))))
-    el = bench(o.h, 0.0, P(arr(q)), P(arr(v)), iters, C.byref(ric))
-    return {"value": iters / el, "unit": "SQP iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d updateSolution calls of one %s N=%d instance, single thread (oracle/, -O3)" % (iters, workload, N),
-            "ms_per_update": 1e3 * el / iters, "ms_per_riccati_sweep": 1e3 * ric.value / iters}
+    rows = []
+    threads = sorted({1, min(4, ncores), ncores}) if (set_threads is not None and lib.oracle_openmp_enabled()) else [1]
+    for nt in threads:
+        if set_threads is not None:
+            set_threads(o.h, nt)
+        t_probe = bench(o.h, 0.0, P(arr(q)), P(arr(v)), 5, C.byref(ric))
+        iters = int(max(5, min(20000, target_seconds / max(t_probe / 5, 1e-9))))
+        el = bench(o.h, 0.0, P(arr(q)), P(arr(v)), iters, C.byref(ric))
+        rows.append({"nthreads": nt, "value": iters / el, "ms_per_update": 1e3 * el / iters, "ms_per_riccati_sweep": 1e3 * ric.value / iters,
+                     "updates": iters})
+    best = max(rows, key=lambda r: r["value"])
+    helpers.ORACLE_PATH_OVERRIDE = None
+    helpers._oracles.pop(False, None)
+    return {"value": best["value"], "unit": "SQP iterations/s", "cores": best["nthreads"], "kind": "port",
+            "sample": "updateSolution calls of ONE %s N=%d instance after convergence (reference protocol ocpbenchmarker::CPUTime), ~%.0f s per row; "
+                      "oracle/ (%s), OpenMP over the stage loops like the reference" % (workload, N, target_seconds, flags),
+            "cpu": cpu_model_string(), "host_cores": ncores, "rows": rows,
+            "ms_per_update": best["ms_per_update"], "ms_per_riccati_sweep": best["ms_per_riccati_sweep"]}
 
 
 def init_distributed(backend, local_rank):
@@ -322,6 +368,49 @@ def run_parnmpc(args, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def latency_mode(lib, hip, build, q0, v0, iters=40):
+    """The "ms / Riccati sweep" half of the metric: ONE OCP instance (batch 1, what one reference solver object is), the same
+    problem as the throughput run.  ms per SQP iteration with plain launches and with the hipGraph replay
+    (idocp_ocp_update_solution_graph), and the backward + forward Riccati sweep over the chain from HIP events."""
+    from idocp_amd import capi
+    sv = build(1)
+    q1, v1 = np.ascontiguousarray(q0[:1]), np.ascontiguousarray(v0[:1])
+    d_q, d_v = C.c_void_p(), C.c_void_p()
+    capi.check(lib.idocp_device_alloc(C.byref(d_q), q1.nbytes))
+    capi.check(lib.idocp_device_alloc(C.byref(d_v), v1.nbytes))
+    capi.check(lib.idocp_device_upload(d_q, q1.ctypes.data, q1.nbytes))
+    capi.check(lib.idocp_device_upload(d_v, v1.ctypes.data, v1.nbytes))
+    stream = lib.idocp_ocp_stream(sv.h)
+    out = {"batch": 1}
+    for name, fn in (("ms_per_iteration", lib.idocp_ocp_update_solution_device), ("ms_per_iteration_hipgraph", lib.idocp_ocp_update_solution_graph)):
+        for _ in range(5):
+            capi.check(fn(sv.h, 0.0, d_q, d_v), name)
+        capi.check(lib.idocp_ocp_synchronize(sv.h))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            capi.check(fn(sv.h, 0.0, d_q, d_v), name)
+        capi.check(lib.idocp_ocp_synchronize(sv.h))
+        out[name] = 1e3 * (time.perf_counter() - t0) / iters
+    ev = [hip.event() for _ in range(3)]
+    acc = [0.0, 0.0]
+    for _ in range(iters):
+        for kid in range(len(KERNELS_OCP)):
+            if kid in (2, 3):
+                hip.record(ev[kid - 2], stream)
+            capi.check(lib.idocp_ocp_launch_kernel(sv.h, kid, d_q, d_v), "kernel %d" % kid)
+            if kid == 3:
+                hip.record(ev[2], stream)
+        capi.check(lib.idocp_ocp_synchronize(sv.h))
+        acc[0] += hip.elapsed_ms(ev[0], ev[1])
+        acc[1] += hip.elapsed_ms(ev[1], ev[2])
+    out["ms_riccati_backward"] = acc[0] / iters
+    out["ms_riccati_forward"] = acc[1] / iters
+    out["ms_per_riccati_sweep"] = (acc[0] + acc[1]) / iters
+    kkt = sv.kkt_error(0.0, q1, v1)
+    assert np.isfinite(kkt).all()
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with
     torch.distributed.run and hand back their exit code.  Called BEFORE this process imports torch or makes any
@@ -378,6 +467,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="independent OCP instances per GPU (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (config.latency)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -421,12 +511,15 @@ def main():
         nq, nv = model.nq, model.nv
         q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
         v0 = np.zeros((B, nv))
-        solver = HipOCP(model, cost, cons, T, N, batch=B, device=local_rank, max_num_impulse=nimp + 1)
-        trotting_sequence(solver, model, nimp)
-        solver.set_solution("q", q0[0])
-        solver.set_solution("v", v0[0])
-        solver.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
-        solver.init_constraints(0.0)
+        def build(batch):
+            sv = HipOCP(model, cost, cons, T, N, batch=batch, device=local_rank, max_num_impulse=nimp + 1)
+            trotting_sequence(sv, model, nimp)
+            sv.set_solution("q", ANYMAL_Q_STANDING)
+            sv.set_solution("v", np.zeros(nv))
+            sv.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+            sv.init_constraints(0.0)
+            return sv
+        solver = build(B)
         Mc = len(solver.chain(0.0))
         KERNELS = KERNELS_OCP
         launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
@@ -448,12 +541,15 @@ def main():
         nq, nv = model.nq, model.nv
         q0 = np.tile(ANYMAL_Q_RUNNING_START, (B, 1))
         v0 = np.zeros((B, nv))
-        solver = HipOCP(model, cost, cons, T, N, batch=B, device=local_rank, max_num_impulse=nimp)
-        running_sequence(solver, model, 10)
-        solver.set_solution("q", q0[0])
-        solver.set_solution("v", v0[0])
-        solver.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
-        solver.init_constraints(0.0)
+        def build(batch):
+            sv = HipOCP(model, cost, cons, T, N, batch=batch, device=local_rank, max_num_impulse=nimp)
+            running_sequence(sv, model, 10)
+            sv.set_solution("q", ANYMAL_Q_RUNNING_START)
+            sv.set_solution("v", np.zeros(nv))
+            sv.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+            sv.init_constraints(0.0)
+            return sv
+        solver = build(B)
         Mc = len(solver.chain(0.0))
         KERNELS = KERNELS_OCP
         launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
@@ -475,12 +571,15 @@ def main():
         q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
         q0 = np.ascontiguousarray(q0)
         v0 = np.zeros((B, nv))
-        solver = HipOCP(model, cost, cons, T, N, batch=B, device=local_rank)
-        solver.set_contact_status([1, 1, 1, 1], pts)
-        solver.set_solution_batch("q", q0)
-        solver.set_solution("v", v0[0])
-        solver.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
-        solver.init_constraints(0.0)
+        def build(batch):
+            sv = HipOCP(model, cost, cons, T, N, batch=batch, device=local_rank)
+            sv.set_contact_status([1, 1, 1, 1], pts)
+            sv.set_solution_batch("q", np.ascontiguousarray(q0[:batch]))
+            sv.set_solution("v", v0[0])
+            sv.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+            sv.init_constraints(0.0)
+            return sv
+        solver = build(B)
         KERNELS = KERNELS_OCP
         launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
         units = {0: B * N, 1: B * (N + 1), 2: B * N, 3: B * N, 4: B * (N + 1), 5: B * N, 6: B * (N + 1)}
@@ -575,6 +674,9 @@ def main():
     kkt = solver.kkt_error(0.0, q0, v0)
     assert np.isfinite(kkt).all(), "non-finite KKT error after the timed region"
 
+    latency = None
+    if rank == 0 and world == 1 and args.workload in ("anymal_trotting", "anymal", "anymal_running") and not args.no_latency:
+        latency = latency_mode(lib, hip, build, q0, v0)
     if rank == 0:
         ms_step = 1e3 * el / args.steps
         out = {
@@ -585,7 +687,7 @@ def main():
                        "horizon": N, "batch_per_gpu": B, "parallelism": "replicas x%d" % world,
                        "ms_per_riccati_sweep": float(sum(kms[i] for i in riccati_ids)),
                        "kernel_ms": {KERNELS[i]: float(kms[i]) for i in range(len(KERNELS))},
-                       "max_kkt_error_after": float(np.max(kkt))},
+                       "max_kkt_error_after": float(np.max(kkt)), "latency": latency},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kms[dom]),

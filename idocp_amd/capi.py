@@ -218,6 +218,7 @@ def _proto(lib):
         ("idocp_ocp_init_constraints", [vp, cd]),
         ("idocp_ocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
         ("idocp_ocp_update_solution_device", [vp, cd, vp, vp]),
+        ("idocp_ocp_update_solution_graph", [vp, cd, vp, vp]),
         ("idocp_ocp_synchronize", [vp]),
         ("idocp_ocp_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
         ("idocp_ocp_kkt_error", [vp, c_double_p]),

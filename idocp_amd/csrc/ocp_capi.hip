@@ -119,6 +119,12 @@ struct idocp_ocp {
   int slice_begin = 0, slice_end = -1;   // ParNMPC with events: this handle keeps the grid stages [slice_begin, slice_end) of the chain (-1: all)
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
   int M() const { return (int)chain.size(); }
+  // hipGraph of one updateSolution (idocp_ocp_update_solution_graph): valid while the discretisation and the input buffers stay
+  long disc_epoch = 0, graph_epoch = -1;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  const double *graph_q = nullptr, *graph_v = nullptr;
+  bool launched_eagerly = false;
 };
 
 namespace {
@@ -306,7 +312,7 @@ int discretize(idocp_ocp* h, double t) {
   HIP_TRY(hipMemcpyAsync(h->d_cond_pos, cpos.data(), sizeof(int) * cpos.size(), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
-  h->disc_time = t; h->seq_dirty = false;
+  h->disc_time = t; h->seq_dirty = false; ++h->disc_epoch;
   return IDOCP_OK;
 }
 
@@ -676,6 +682,8 @@ void idocp_ocp_destroy(idocp_ocp_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -830,6 +838,20 @@ static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q) {
   else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream);
 }
 
+// one SQP iteration on the handle's stream: K5 (+ K5a on impulse stages, K5s), S3, S4, K6, K7
+static int launchUpdateO(idocp_ocp_t* h, int M, const double* d_q, const double* d_v) {
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
+  launchCondenseO(h, M, d_q);
+  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream);
+  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+
 int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
   if (!h || kernel_id < 0 || kernel_id > 6 || !d_q || !d_v) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
@@ -855,15 +877,32 @@ int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q
   int rc = setDev(h); if (rc) return rc;
   if ((rc = discretize(h, t))) return rc;                 // ocp_.discretize(contact_sequence_, t) (ocp_solver.cpp:72)
   const int M = h->M();
-  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
-  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
-  launchCondenseO(h, M, d_q);
-  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
-  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream);
-  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
-  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
-  HIP_TRY(hipGetLastError());
+  if ((rc = launchUpdateO(h, M, d_q, d_v))) return rc;
+  h->launched_eagerly = true;
+  return IDOCP_OK;
+}
+
+// The same iteration replayed from a hipGraph: at small batch sizes the nine launches of an iteration are launch-bound (latency
+// mode: one OCP instance, 2 ms per iteration), the graph submits them in one call.  Captured on first use and again whenever the
+// discretisation (chain length, stage classes, events) or the input buffers change; the host-side discretiser itself stays outside.
+int idocp_ocp_update_solution_graph(idocp_ocp_t* h, double t, const double* d_q, const double* d_v) {
+  if (!h || !d_q || !d_v) return IDOCP_E_ARG;
+  if (!h->contact_status_set) { set_last_error("idocp_ocp_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  if (!h->launched_eagerly) return idocp_ocp_update_solution_device(h, t, d_q, d_v);      // first call: plain launches (one-time kernel attributes)
+  if ((rc = discretize(h, t))) return rc;
+  if (!h->graph_exec || h->graph_epoch != h->disc_epoch || h->graph_q != d_q || h->graph_v != d_v) {
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    rc = launchUpdateO(h, h->M(), d_q, d_v);
+    const hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+    if (rc) return rc;
+    HIP_TRY(e);
+    HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    h->graph_epoch = h->disc_epoch; h->graph_q = d_q; h->graph_v = d_v;
+  }
+  HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
   return IDOCP_OK;
 }
 

@@ -367,6 +367,10 @@ int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q,
                               const double* v, int line_search);
 int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
                                      const double* d_v);
+/* The same iteration submitted as ONE hipGraph launch (captured on first use, re-captured when the discretisation or the input
+ * buffers change): the latency mode of the solver -- at batch 1 the launches, not the kernels, set the pace. */
+int idocp_ocp_update_solution_graph(idocp_ocp_t* h, double t, const double* d_q,
+                                    const double* d_v);
 int idocp_ocp_synchronize(idocp_ocp_t* h);
 void* idocp_ocp_stream(idocp_ocp_t* h);
 /* OCPSolver::computeKKTResidual + KKTError (ocp_solver.cpp:202-213). */

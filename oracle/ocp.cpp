@@ -6,6 +6,13 @@
 #include <limits>
 #include <stdexcept>
 
+#ifdef _OPENMP
+#include <omp.h>
+#define ORACLE_THREAD_NUM omp_get_thread_num()
+#else
+#define ORACLE_THREAD_NUM 0
+#endif
+
 namespace oracle {
 
 static const int kP = 6;   // kDimFloatingBase
@@ -333,7 +340,7 @@ void OCPSolver::qRef(real t, Mat& q_ref) const {
 // ImpulseSplitOCP::linearizeOCP / computeKKTResidual (impulse_split_ocp.hxx:40-66, 107-124) for Impulse nodes.
 // The two are the same computation with (dt_dyn, dt_q) = (dt, dt) vs (1, 0), "a" playing the role of dv, no torque
 // variables on the impulse stage, and the contact VELOCITY constraint instead of the Baumgarte constraint.
-void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
+void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool residual_only) {
   const NodeC& nd = chain[p];
   const bool impulse = nd.kind == NodeC::Impulse;
   const SplitSolutionC& si = s[nd.slot];
@@ -592,7 +599,7 @@ void OCPSolver::linearizeNode(int p, const Mat& q_prev, bool residual_only) {
 }
 
 // TerminalOCP::linearizeOCP / computeKKTResidual (terminal_ocp.hxx:50-66, 118-131)
-void OCPSolver::linearizeTerminal(int p, const Mat& q_prev, bool residual_only) {
+void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool residual_only) {
   const NodeC& nd = chain[p];
   const SplitSolutionC& sN = s[nd.slot];
   SplitKKTMatrixC& M = kkt_matrix[nd.slot];
@@ -626,19 +633,27 @@ void OCPSolver::linearizeTerminal(int p, const Mat& q_prev, bool residual_only) 
 // OCPLinearizer::runParallel (ocp_linearizer.hxx:113-228); q_prev (:231-248) is the chain predecessor's q
 void OCPSolver::linearizeOCP(real t, const Mat& q) {
   discretize(t);
-  for (int p = 0; p < M(); ++p) {
+  if ((int)robots_.size() != nthreads) setNumThreads(nthreads);
+  const int Mc = M();
+  #pragma omp parallel for num_threads(nthreads)
+  for (int p = 0; p < Mc; ++p) {
+    Robot& rb = robots_[ORACLE_THREAD_NUM];
     const Mat& q_prev = (p == 0) ? q : s[chain[p - 1].slot].q;
-    if (p < M() - 1) linearizeNode(p, q_prev, false);
-    else linearizeTerminal(p, q_prev, false);
+    if (p < Mc - 1) linearizeNode(rb, p, q_prev, false);
+    else linearizeTerminal(rb, p, q_prev, false);
   }
 }
 
 void OCPSolver::computeKKTResidual(real t, const Mat& q, const Mat& /*v*/) {
   discretize(t);
-  for (int p = 0; p < M(); ++p) {
+  if ((int)robots_.size() != nthreads) setNumThreads(nthreads);
+  const int Mc = M();
+  #pragma omp parallel for num_threads(nthreads)
+  for (int p = 0; p < Mc; ++p) {
+    Robot& rb = robots_[ORACLE_THREAD_NUM];
     const Mat& q_prev = (p == 0) ? q : s[chain[p - 1].slot].q;
-    if (p < M() - 1) linearizeNode(p, q_prev, true);
-    else linearizeTerminal(p, q_prev, true);
+    if (p < Mc - 1) linearizeNode(rb, p, q_prev, true);
+    else linearizeTerminal(rb, p, q_prev, true);
   }
 }
 
@@ -867,7 +882,9 @@ void OCPSolver::computeDirection() {
   const int nv = nv_, nu = nu_;
   real pmin = 1, dmin = 1;
   real Jc[5][3]; frictionJac(cons.mu, Jc);
-  for (int p = 0; p < M(); ++p) {
+  const int Mc = M();
+  #pragma omp parallel for num_threads(nthreads) reduction(min : pmin, dmin)
+  for (int p = 0; p < Mc; ++p) {
     const NodeC& nd = chain[p];
     const int sl = nd.slot;
     const RiccatiC& r = riccati[sl];
@@ -922,7 +939,9 @@ void OCPSolver::computeDirection() {
 void OCPSolver::integrateSolution() {
   const int nv = nv_, nu = nu_;
   const real ap = primal_step_size, ad = dual_step_size;
-  for (int p = 0; p < M(); ++p) {
+  const int Mc = M();
+  #pragma omp parallel for num_threads(nthreads)
+  for (int p = 0; p < Mc; ++p) {
     const NodeC& nd = chain[p];
     const int sl = nd.slot;
     SplitKKTMatrixC& Mx = kkt_matrix[sl];

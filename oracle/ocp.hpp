@@ -171,8 +171,15 @@ class OCPSolver {
   bool componentValid(int c, const NodeC& nd) const;
   int componentDim(int c) const;
   void initNodeConstraints(const NodeC& nd);
-  void linearizeNode(int p, const Mat& q_prev, bool residual_only);
-  void linearizeTerminal(int p, const Mat& q_prev, bool residual_only);
+  // the stage loops run under `#pragma omp parallel for num_threads(nthreads)` where the reference's do (ocp_linearizer.cpp:47,
+  // 74-83, 104, 152; riccati_recursion_solver.cpp:174-239), each thread with a Robot of its own like the reference's
+  // robots[omp_get_thread_num()] (the parameter shadows the member on purpose)
+  void linearizeNode(Robot& robot, int p, const Mat& q_prev, bool residual_only);
+  void linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool residual_only);
+  std::vector<Robot> robots_;
+ public:
+  int nthreads = 1;
+  void setNumThreads(int n) { nthreads = n < 1 ? 1 : n; robots_.assign(nthreads, robot); }
 };
 
 // ParNMPCSolver (src/ocp/parnmpc_solver.cpp:66-103): backward-Euler stages (SplitParNMPC / TerminalParNMPC,

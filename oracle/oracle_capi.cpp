@@ -262,6 +262,14 @@ int oracle_unocp_get_riccati(void* h, double* P, double* sv, double* K, double* 
   return 0;
 }
 // ---- UnParNMPCSolver -----------------------------------------------------
+int oracle_unocp_set_num_threads(void* h, int n) { static_cast<UnOCPSolver*>(h)->setNumThreads(n); return 0; }
+int oracle_openmp_enabled(void) {
+#ifdef _OPENMP
+  return 1;
+#else
+  return 0;
+#endif
+}
 void* oracle_unparnmpc_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
   try { return new UnParNMPCSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
 }
@@ -498,6 +506,8 @@ int oracle_ocp_chain(void* h, double t, int* kind, int* index, int* slot, double
   return s->M();
 }
 void oracle_ocp_destroy(void* h) { delete static_cast<OCPSolver*>(h); }
+// OCPSolver(..., nthreads) of the reference: the stage loops run on `n` OpenMP threads (1 without -fopenmp)
+int oracle_ocp_set_num_threads(void* h, int n) { static_cast<OCPSolver*>(h)->setNumThreads(n); return 0; }
 int oracle_ocp_set_contact_status(void* h, const int* active, const double* points) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   std::vector<int> a(active, active + s->robot.maxPointContacts());

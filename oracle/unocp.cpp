@@ -7,6 +7,13 @@
 #include <stdexcept>
 #include <string>
 
+#ifdef _OPENMP
+#include <omp.h>
+#define ORACLE_THREAD_NUM omp_get_thread_num()
+#else
+#define ORACLE_THREAD_NUM 0
+#endif
+
 namespace oracle {
 
 // ------------------------------------------------------------ constraints ----
@@ -144,7 +151,7 @@ static void linearizeForwardEuler(real dt, const SplitSolution& s, const SplitSo
 
 // SplitUnOCP::computeKKTResidual up to (and including) the dynamics
 // (split_unocp.hxx:141-161); with_hessian=false.  linearizeOCP shares it.
-void UnOCPSolver::computeStageResidual(int i, real /*t*/) {
+void UnOCPSolver::computeStageResidual(Robot& robot, int i, real /*t*/) {
   SplitUnOCP& o = ocp[i];
   const SplitSolution& si = s[i];
   o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero(); o.Fq.setZero(); o.Fv.setZero();
@@ -171,7 +178,7 @@ void UnOCPSolver::computeStageResidual(int i, real /*t*/) {
 }
 
 // SplitUnOCP::linearizeOCP (split_unocp.hxx:69-99)
-void UnOCPSolver::linearizeStage(int i, real t, const Mat& /*q_prev*/) {
+void UnOCPSolver::linearizeStage(Robot& robot, int i, real t, const Mat& /*q_prev*/) {
   SplitUnOCP& o = ocp[i];
   const SplitSolution& si = s[i];
   const int nv = o.nv;
@@ -257,9 +264,12 @@ void UnOCPSolver::linearizeTerminal(real /*t*/) {
 }
 
 void UnOCPSolver::linearizeOCP(real t, const Mat& q) {
+  if ((int)robots_.size() != nthreads) setNumThreads(nthreads);
+  #pragma omp parallel for num_threads(nthreads)
   for (int i = 0; i <= N_; ++i) {
-    if (i == 0) linearizeStage(0, t, q);
-    else if (i < N_) linearizeStage(i, t + i * dt_, s[i - 1].q);
+    Robot& rb = robots_[ORACLE_THREAD_NUM];
+    if (i == 0) linearizeStage(rb, 0, t, q);
+    else if (i < N_) linearizeStage(rb, i, t + i * dt_, s[i - 1].q);
     else linearizeTerminal(t + T_);
   }
 }
@@ -398,6 +408,7 @@ static real trialConstraintViolation(Robot& robot, const Constraints& cs, const 
 // second parallel loop of UnOCPSolver::updateSolution (unocp_solver.cpp:103-115)
 void UnOCPSolver::computeDirection() {
   real pmin = 1, dmin = 1;
+  #pragma omp parallel for num_threads(nthreads) reduction(min : pmin, dmin)
   for (int i = 0; i <= N_; ++i) {
     const SplitRiccatiFactorization& r = riccati[i];
     // SplitUnRiccatiFactorizer::computeCostateDirection (split_unriccati_factorizer.hxx:60-68)
@@ -439,6 +450,7 @@ void UnOCPSolver::computeDirection() {
 // third parallel loop (unocp_solver.cpp:121-133): updatePrimal / updateDual
 void UnOCPSolver::integrate() {
   const real ap = primal_step_size, ad = dual_step_size;
+  #pragma omp parallel for num_threads(nthreads)
   for (int i = 0; i <= N_; ++i) {
     s[i].lmd += ap * d[i].dlmd;
     s[i].gmm += ap * d[i].dgmm;
@@ -490,7 +502,9 @@ void UnOCPSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_li
 }
 
 void UnOCPSolver::computeKKTResidual(real t, const Mat& /*q*/, const Mat& /*v*/) {
-  for (int i = 0; i < N_; ++i) computeStageResidual(i, t + i * dt_);
+  if ((int)robots_.size() != nthreads) setNumThreads(nthreads);
+  #pragma omp parallel for num_threads(nthreads)
+  for (int i = 0; i < N_; ++i) computeStageResidual(robots_[ORACLE_THREAD_NUM], i, t + i * dt_);
   // TerminalOCP::computeKKTResidual (terminal_ocp.hxx:118-131)
   const SplitSolution& sN = s[N_];
   terminal_lq.setZero(); terminal_lv.setZero();

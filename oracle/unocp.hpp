@@ -167,9 +167,16 @@ class UnOCPSolver {
 
  private:
   int N_; real T_, dt_;
-  void linearizeStage(int i, real t, const Mat& q_prev);
+  // stage loops under `#pragma omp parallel for num_threads(nthreads)` like unocp_solver.cpp:78-94, 103-115, 121-133; every
+  // thread works on a Robot of its own (the parameter shadows the member on purpose)
+  void linearizeStage(Robot& robot, int i, real t, const Mat& q_prev);
   void linearizeTerminal(real t);
-  void computeStageResidual(int i, real t);
+  void computeStageResidual(Robot& robot, int i, real t);
+  std::vector<Robot> robots_;
+ public:
+  int nthreads = 1;
+  void setNumThreads(int n) { nthreads = n < 1 ? 1 : n; robots_.assign(nthreads, robot); }
+ private:
 };
 
 

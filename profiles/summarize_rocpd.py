@@ -30,15 +30,17 @@ def main():
                   (short(name), n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, vg, ag, lds))
         try:
             rows = list(cur.execute(
-                "select k.name, p.name, count(*), avg(e.value), sum(e.value) "
+                "select k.name, p.name, count(distinct e.event_id), count(*), sum(e.value) "
                 "from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
-                "join kernels k on k.id = e.event_id group by k.name, p.name"))
-        except sqlite3.Error:
+                "join kernels k on k.id = e.event_id group by k.name, p.name order by k.name, p.name"))
+        except sqlite3.Error as err:
+            print("# no counter table: %s" % err)
             rows = []
         if rows:
-            print("\n%-62s %-22s %7s %16s" % ("kernel", "counter", "samples", "avg_per_dispatch"))
-            for kname, cname, n, avg, tot in rows:
-                print("%-62s %-22s %7d %16.1f" % (kshort(name), cname, n, avg))
+            # one row per (kernel, counter): the counter summed over the samples of a dispatch (one per XCD / SE), averaged over dispatches
+            print("\n%-62s %-24s %10s %8s %18s" % ("kernel", "counter", "dispatches", "samples", "sum_per_dispatch"))
+            for kname, cname, nd, n, tot in rows:
+                print("%-62s %-24s %10d %8d %18.1f" % (short(kname), cname, nd, n, tot / max(nd, 1)))
         print()
 
 

@@ -17,6 +17,7 @@ ANYMAL_CONTACT_FRAMES = (14, 24, 34, 44)
 dp = capi.c_double_p
 
 _oracles = {}
+ORACLE_PATH_OVERRIDE = None       # bench.py's cpu_baseline leg points this at the natively built library
 
 
 def oracle(hp=False):
@@ -26,6 +27,8 @@ def oracle(hp=False):
     _oracle = _oracles.get(hp)
     if _oracle is None:
         path = os.path.join(ROOT, "oracle", "liboracle_hp.so" if hp else "liboracle.so")
+        if ORACLE_PATH_OVERRIDE and not hp:
+            path = ORACLE_PATH_OVERRIDE
         r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], capture_output=True, text=True)
         if r.returncode != 0 and not os.path.exists(path):
             raise RuntimeError("cannot build the oracle:\n" + r.stderr)
@@ -56,6 +59,8 @@ def oracle(hp=False):
         lib.oracle_unocp_get_unkkt.argtypes = [vp, dp, dp]
         lib.oracle_unocp_bench.argtypes = [vp, cd, dp, dp, ci, dp]
         lib.oracle_unocp_bench.restype = cd
+        lib.oracle_unocp_set_num_threads.argtypes = [vp, ci]
+        lib.oracle_openmp_enabled.restype = ci
         lib.oracle_unparnmpc_create.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci]
         lib.oracle_unparnmpc_create.restype = vp
         lib.oracle_unparnmpc_destroy.argtypes = [vp]
@@ -603,6 +608,7 @@ def _setup_oracle_ocp(lib):
     lib.oracle_ocp_get_lqr_stage.argtypes = [vp, ci] + [dp] * 8
     lib.oracle_ocp_bench.argtypes = [vp, cd, dp, dp, ci, dp]
     lib.oracle_ocp_bench.restype = cd
+    lib.oracle_ocp_set_num_threads.argtypes = [vp, ci]
     lib.oracle_ocp_create_hybrid.argtypes = [PM, C.POINTER(capi.Cost), C.POINTER(capi.Constraints), cd, ci, ci]
     lib.oracle_ocp_create_hybrid.restype = vp
     lib.oracle_ocp_push_back_contact_status.argtypes = [vp, C.POINTER(ci), dp, cd]

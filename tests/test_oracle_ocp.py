@@ -89,3 +89,29 @@ def test_forward_recursion_costate_and_feasible_full_step():
         np.testing.assert_allclose(np.concatenate([dl[i], dg[i]]), P[i] @ dx - s[i], rtol=1e-9, atol=1e-8)
     a, b = o.step_sizes()
     assert 0 < a <= 1 and 0 < b <= 1
+
+
+def test_openmp_stage_loops_give_the_single_thread_result():
+    """The oracle's stage loops run under `#pragma omp parallel for num_threads(nthreads)` where the reference's do
+    (ocp_linearizer.cpp:74-83, unocp_solver.cpp:78-94): per-stage work is independent, so 1 and 4 threads must agree bit for bit."""
+    import numpy as np
+    from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OracleOCP, anymal_contact_points, anymal_model, anymal_problem, oracle)
+    lib = oracle()
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    outs = []
+    for nt in (1, 4):
+        o = OracleOCP(m, cost, cons, 1.0, 20)
+        lib.oracle_ocp_set_num_threads(o.h, nt)
+        q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+        o.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+        o.set_solution("q", q)
+        o.set_solution("v", v)
+        o.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        o.init_constraints(0.0)
+        q[7:] += 0.02
+        for _ in range(3):
+            assert o.update(0.0, q, v) == 0
+        outs.append([o.get(f) for f in OCP_DIR_FIELDS] + [np.array(o.step_sizes())])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
