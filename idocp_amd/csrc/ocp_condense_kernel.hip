@@ -57,7 +57,10 @@ __device__ __forceinline__ double frictionJacEntry(double mu, int r, int x) {
 template <typename D, int SFP = D::NF>
 struct CondenseSmem {
   using L = OcpLayout<D>;
-  static constexpr int NV = D::NV, NX = D::NX, NF = SFP, NVF = D::NV + SFP, NU = D::NU;
+  // NVF: leading dimension of the (a, f)-sized blocks.  A multiple of 8 doubles (24, the half-contact layout) would put the columns
+  // that the 2 x 2 products read side by side (stride 2 NVF) on two bank groups only -- SQ_LDS_BANK_CONFLICT was 46 % of the LDS
+  // cycles of that class against 25 % with NVF = 30 -- so it is padded by two rows.
+  static constexpr int NV = D::NV, NX = D::NX, NF = SFP, NVF = D::NV + SFP + (((D::NV + SFP) % 8 == 0) ? 2 : 0), NU = D::NU;
   // matrices.  Aliases (lifetimes in the kernel body):
   //   MINV  = MM            the mass matrix is inverted in place (scratch: MJ, not yet written)
   //   QAFQV = DIDC          dIDCdqv is dead once MJD = MJtJinv * dIDCdqv is formed
@@ -65,7 +68,9 @@ struct CondenseSmem {
   //   BL, SM, BR  share the block that holds the solution / slack / dual copies during phase C
   //   ERR   = MJ            (RESIDUAL variant only, which never forms MJtJinv)
   // The condensed Hessian blocks are never staged in LDS: phase H writes them to the kkt record.
-  static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV, IDC = JM + NF * NV, MJ = IDC + 32,
+  static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV,
+                       IDC = JM + ((NF * NV > NVF * NV - NV * NV) ? NF * NV : NVF * NV - NV * NV),      // (Qafu_full, NVF x NV, later takes the M .. J blocks)
+                       MJ = IDC + 32,
                        MJD = MJ + NVF * NVF,
                        // MJ .. MJD also hold the scratch of the RNEA sweeps (dead before MJtJinv is assembled); the narrow layouts are padded for it
                        QFF = (MJD + NVF * NX > MJ + RneaScratch<D>::TOTAL) ? MJD + NVF * NX : MJ + RneaScratch<D>::TOTAL, TMP = QFF + NF * NF,
@@ -73,7 +78,7 @@ struct CondenseSmem {
   static constexpr int SOLS = TMP, SOLN = SOLS + L::SOL, SLK = SOLN + L::SOL, DUL = SLK + L::CON, TMP_EARLY = DUL + L::CON - TMP;
   static constexpr int BL = TMP, SM = BL + NF * NV, BR = SM + NF * NF, TMP_LATE = BR + NF * NF - TMP;
   static constexpr int VEC = TMP + (TMP_EARLY > TMP_LATE ? TMP_EARLY : TMP_LATE);
-  static_assert(NVF * NV <= NV * NV + NF * NV, "Qafu_full must fit in the M / J blocks");
+  static_assert(NVF * NV <= IDC - MM, "Qafu_full must fit in the M / J blocks");
   static_assert(256 <= NVF * NVF, "ERR aliases MJ");
   // vectors
   static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   using L = OcpLayout<D>;
   using S = CondenseSmem<D, (DIMF > 0) ? DIMF : D::NF>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
-  constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>); NF / NVF: the HBM records'
+  constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = S::NVF, RVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>) and rows; NF / NVF: the HBM records'
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
@@ -184,10 +189,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (impulse) {
         // impulse stages keep the two-pass dual-number sweep of ocp_rnea_kernel<D, true> and its lin record
         const double* __restrict__ lin = B.lin + su * L::LIN;
-        for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; sm[S::DIDC + e] = lin[L::L_DIDC + r + NVF * c]; }
+        for (int e = tid; e < RVF * NX; e += nt) { const int c = e / RVF, r = e - c * RVF; sm[S::DIDC + r + SVF * c] = lin[L::L_DIDC + r + NVF * c]; }
         for (int e = tid; e < NV * NV; e += nt) sm[S::MM + e] = lin[L::L_M + e];
         for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
-        if (tid < SVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
+        if (tid < RVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
       } else {
         for (int e = tid; e < S::MJ - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
         rneaSetup<D>(B.model, P, nd, s_g, tid, sc);
@@ -600,12 +605,12 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     for (int e = tid; e < NVF * NVF; e += nt) ee[L::E_MJ + e] = sm[S::MJ + e];
     for (int e = tid; e < NVF * NX; e += nt) ee[L::E_MJD + e] = sm[S::MJD + e];
   } else {
-    for (int e = tid; e < SVF * SVF; e += nt) { const int c = e / SVF, r = e - c * SVF; ee[L::E_MJ + r + NVF * c] = sm[S::MJ + e]; }
-    for (int e = tid; e < SVF * NX; e += nt) { const int c = e / SVF, r = e - c * SVF; ee[L::E_MJD + r + NVF * c] = sm[S::MJD + e]; }
+    for (int e = tid; e < RVF * RVF; e += nt) { const int c = e / RVF, r = e - c * RVF; ee[L::E_MJ + r + NVF * c] = sm[S::MJ + r + SVF * c]; }
+    for (int e = tid; e < RVF * NX; e += nt) { const int c = e / RVF, r = e - c * RVF; ee[L::E_MJD + r + NVF * c] = sm[S::MJD + r + SVF * c]; }
   }
   if (tid < NV) ee[L::E_QAA + tid] = sm[S::QAA + tid];
   for (int e = tid; e < SF * SF; e += nt) { const int c = e / SF, r = e - c * SF; ee[L::E_QFF + r + NF * c] = sm[S::QFF + e]; }
-  if (tid < SVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
+  if (tid < RVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
   // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199) ----
   if (sw_dimi > 0) {
