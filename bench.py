@@ -446,6 +446,167 @@ def run_stub(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def run_parnmpc_cxx(args, rank, local_rank, world, dist):
+    """BASELINE.json configs[3]: ANYmal ParNMPCSolver, N = 256 (T = 12.8, dt = 0.05), 4 point contacts on every stage, the stages of
+    every instance sharded over the ranks and driven by the library's C++ multi-GPU driver (idocp_amd/csrc/parnmpc_dist.hip:
+    RCCL point-to-point halos with the two neighbours + all-reduce of the step sizes, everything enqueued on the shard's
+    stream).  Strong scaling: the batch of instances is the same whatever the number of GPUs.  The iterate is WARM-STARTED from
+    the converged Riccati solution of the same OCP (helpers.warm_start_parnmpc; the MPC use of the solver): from the reference's
+    cold start the forward correction sweep amplifies by 1.15 per stage and a 256-stage horizon is numerically meaningless."""
+    import helpers
+    from idocp_amd import capi
+    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    from helpers import ANYMAL_Q_STANDING, HipOCP, OracleParNMPC, P, anymal_contact_points, anymal_model, anymal_problem, arr
+    lib = capi.lib()
+    hip = Hip()
+    hip.rt.hipSetDevice(local_rank)
+    N = args.horizon if args.horizon != 100 else 256
+    T = 0.05 * N
+    B = args.batch or 256
+    if N % world:
+        raise SystemExit("--horizon must be divisible by the number of GPUs")
+    Nl = N // world
+    model = anymal_model()
+    cost, cons = anymal_problem(model, trotting_ref=True)
+    pts = anymal_contact_points(model)
+    nq, nv = model.nq, model.nv
+    rng = np.random.default_rng(20250)
+    q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
+    q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
+    q0 = np.ascontiguousarray(q0)
+    v0 = np.zeros((B, nv))
+    fz = [0, 0, 0.25 * (-model.total_mass * model.gravity[2])]
+    # ---- warm start: the OCP of the same problem (nominal initial state), converged on this GPU ----
+    src = HipOCP(model, cost, cons, T, N, batch=1, device=local_rank)
+    src.set_contact_status([1, 1, 1, 1], pts)
+    src.set_solution("q", ANYMAL_Q_STANDING)
+    src.set_solution("v", np.zeros(nv))
+    src.set_solution("f", fz)
+    src.init_constraints(0.0)
+    qn, vn = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
+    for _ in range(40):
+        assert src.update(0.0, qn, vn) == 0
+        if src.kkt_error(0.0, qn, vn)[0] < 1e-9:
+            break
+    # ---- this rank's shard + communicator ----
+    shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
+    capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, (C.c_int * 4)(1, 1, 1, 1), P(arr(pts))))
+    for name, val in (("q", ANYMAL_Q_STANDING), ("v", np.zeros(nv)), ("f", fz)):
+        capi.check(lib.idocp_ocp_set_solution(shard.h, name.encode(), P(arr(val))))
+    comm = C.c_void_p()
+    if world > 1:
+        import torch
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_char * 128)()
+            capi.check(lib.idocp_comm_get_unique_id(raw), "comm_get_unique_id")
+            idbuf = torch.tensor(list(raw.raw), dtype=torch.uint8)
+        dist.broadcast(idbuf, src=0)
+        raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.tolist()))
+        capi.check(lib.idocp_comm_init_rank(raw, rank, world, local_rank, C.byref(comm)), "comm_init_rank")
+    else:
+        one = (C.c_void_p * 1)()
+        capi.check(lib.idocp_comm_init_local(1, local_rank, one), "comm_init_local")
+        comm = C.c_void_p(one[0])
+    capi.check(lib.idocp_parnmpc_dist_attach(shard.h, comm), "dist_attach")
+    if rank == 0:
+        capi.check(lib.idocp_parnmpc_dist_set_initial_state(shard.h, P(q0), P(v0), nq, nv))
+    capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shard.h, 0.0), "dist_init_backward_correction")
+
+    class _Slice:                                   # helpers.warm_start_parnmpc target: this rank's stages of the horizon
+        def set_stage_values(self, name, values):
+            vals = arr(values[rank * Nl:(rank + 1) * Nl])
+            capi.check(lib.idocp_ocp_set_solution_stages(shard.h, name.encode(), Nl, P(vals)), "set_solution_stages")
+
+        def set_aux_mats(self, mats):
+            cm = arr(np.asarray(mats[rank * Nl:(rank + 1) * Nl]).transpose(0, 2, 1))
+            capi.check(lib.idocp_parnmpc_set_aux_mat(shard.h, Nl, P(cm)), "set_aux_mat")
+    helpers.warm_start_parnmpc(src, [_Slice()], N)
+    capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
+    del src
+
+    def step(_events):
+        capi.check(lib.idocp_parnmpc_dist_update_solution(shard.h, 0.0), "dist_update_solution")
+
+    def sync():
+        capi.check(lib.idocp_ocp_synchronize(shard.h))
+        hip.rt.hipDeviceSynchronize()
+
+    el = run_timed(step, sync, args.steps, args.warmup, dist, "cpu")
+    kkt = np.zeros(B)
+    capi.check(lib.idocp_parnmpc_dist_kkt_error(shard.h, 0.0, P(kkt)), "dist_kkt_error")
+    assert np.isfinite(kkt).all(), "non-finite KKT error after the timed region"
+    # per-kernel durations (HIP events on the shard's stream, one extra iteration phase by phase; single GPU only: with several
+    # ranks the phases interleave with the halo traffic and are timed by the iteration as a whole)
+    ker = {}
+    if world == 1:
+        stream = lib.idocp_ocp_stream(shard.h)
+        PH = ["ocp_rnea", "ocp_condense", "parnmpc_kkt_inverse", "parnmpc_backward_serial", "parnmpc_backward_parallel",
+              "parnmpc_forward_serial", "parnmpc_forward_parallel", "ocp_expand_primal", "ocp_reduce_steps", "ocp_expand_dual_integrate"]
+        reps = 3
+        for _ in range(reps):
+            capi.check(lib.idocp_parnmpc_discretize(shard.h, 0.0))
+            ev = [hip.event() for _ in range(len(PH) + 1)]
+            for k in range(len(PH)):
+                hip.record(ev[k], stream)
+                capi.check(lib.idocp_parnmpc_launch_phase(shard.h, k, shard.d_q, shard.d_v), PH[k])
+            hip.record(ev[len(PH)], stream)
+            capi.check(lib.idocp_ocp_synchronize(shard.h))
+            for k in range(len(PH)):
+                ker[PH[k]] = ker.get(PH[k], 0.0) + hip.elapsed_ms(ev[k], ev[k + 1]) / reps
+    if rank == 0:
+        ms_step = 1e3 * el / args.steps
+        out = {
+            "metric": "SQP iterations/sec (whole node)", "value": B * args.steps / el, "unit": "SQP iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("ANYmal ParNMPCSolver N=%d T=%.2f FP64, 4 point contacts on every stage (BASELINE.json configs[3]), warm-started "
+                                    "from the converged Riccati solution of the same OCP; batch=%d OCP instances, the %d stages of every instance "
+                                    "sharded over %d GPU(s), C++ driver with RCCL halo exchange (idocp_parnmpc_dist_*)" % (N, T, B, N, world)),
+                       "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
+                       "kernel_ms": ker, "max_kkt_error_after": float(kkt.max())},
+        }
+        if ker:
+            dom = max(ker, key=ker.get)
+            alg_bytes = A_STAGE["anymal_parnmpc"] * B * Nl
+            achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
+            traffic = None
+            import glob
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
+                try:
+                    rec = json.load(open(pmc))
+                    if rec.get("batch") == B and rec.get("horizon") == N:
+                        traffic = rec.get("hbm_bytes_per_launch", {}).get(dom)
+                        break
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                               "avg_launch_ms": ker[dom],
+                               "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world}
+        if not args.no_cpu_baseline:
+            o = OracleParNMPC(model, cost, cons, T, N)
+            o.set_contact_status([1, 1, 1, 1], pts)
+            o.set_solution("q", ANYMAL_Q_STANDING)
+            o.set_solution("v", np.zeros(nv))
+            o.set_solution("f", fz)
+            o.init(0.0)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 12.0:
+                o.update(0.0, q0[0], v0[0])
+                n += 1
+            elc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n / elc, "unit": "SQP iterations/s", "cores": 1, "kind": "port", "cpu": cpu_model_string(),
+                                   "sample": "%d updateSolution calls of one ParNMPC N=%d instance, single thread (oracle/, -O3)" % (n, N),
+                                   "ms_per_update": 1e3 * elc / n}
+        print(json.dumps(out), flush=True)
+    capi.check(lib.idocp_parnmpc_dist_detach(shard.h))
+    lib.idocp_comm_destroy(comm)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 class _NoDist:
     """world = 1: the driver never communicates"""
     class ReduceOp:
@@ -479,13 +640,18 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     backend = os.environ.get("IDOCP_BENCH_BACKEND", "nccl")
+    if args.workload == "anymal_parnmpc" and not os.environ.get("IDOCP_BENCH_STUB"):
+        # the data path is the library's own RCCL communicator (idocp_parnmpc_dist_*); torch.distributed only carries the
+        # rendezvous of its id and the barrier / max-reduction of the timing -> gloo, so that one RCCL instance owns the GPUs
+        dist = init_distributed("gloo", local_rank) if world > 1 else None
+        return run_parnmpc_cxx(args, rank, local_rank, world, dist)
     dist = None
     if world > 1 or os.environ.get("IDOCP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL scaffolding on one GPU
         dist = init_distributed(backend, local_rank)
     if os.environ.get("IDOCP_BENCH_STUB"):
         return run_stub(args, rank, world, dist)
 
-    if args.workload in ("anymal_parnmpc", "anymal_parnmpc_trotting"):
+    if args.workload == "anymal_parnmpc_trotting":
         return run_parnmpc(args, rank, local_rank, world, dist)
 
     from idocp_amd import capi

@@ -211,6 +211,8 @@ def _proto(lib):
     lib.idocp_ocp_destroy.restype = None
     lib.idocp_ocp_stream.argtypes = [vp]
     lib.idocp_ocp_stream.restype = vp
+    lib.idocp_comm_destroy.argtypes = [vp]
+    lib.idocp_comm_destroy.restype = None
     for name, args in [
         ("idocp_ocp_set_contact_status_uniformly", [vp, P(ci), c_double_p]),
         ("idocp_ocp_set_solution", [vp, cs, c_double_p]),
@@ -219,6 +221,20 @@ def _proto(lib):
         ("idocp_ocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
         ("idocp_ocp_update_solution_device", [vp, cd, vp, vp]),
         ("idocp_ocp_update_solution_graph", [vp, cd, vp, vp]),
+        ("idocp_ocp_set_solution_stages", [vp, C.c_char_p, ci, c_double_p]),
+        ("idocp_parnmpc_set_aux_mat", [vp, ci, c_double_p]),
+        ("idocp_comm_get_unique_id", [vp]),
+        ("idocp_comm_init_rank", [vp, ci, ci, ci, C.POINTER(vp)]),
+        ("idocp_comm_init_local", [ci, ci, C.POINTER(vp)]),
+        ("idocp_comm_rank", [vp]),
+        ("idocp_comm_world", [vp]),
+        ("idocp_parnmpc_dist_attach", [vp, vp]),
+        ("idocp_parnmpc_dist_detach", [vp]),
+        ("idocp_parnmpc_dist_set_initial_state", [vp, c_double_p, c_double_p, ci, ci]),
+        ("idocp_parnmpc_dist_init_backward_correction", [vp, cd]),
+        ("idocp_parnmpc_dist_update_solution", [vp, cd]),
+        ("idocp_parnmpc_dist_kkt_error", [vp, cd, c_double_p]),
+        ("idocp_ocp_batch", [vp]),
         ("idocp_ocp_synchronize", [vp]),
         ("idocp_ocp_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
         ("idocp_ocp_kkt_error", [vp, c_double_p]),

@@ -820,6 +820,33 @@ static int setSolutionO(idocp_ocp_t* h, const char* name, const double* values, 
   return IDOCP_OK;
 }
 int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value) { return setSolutionO(h, name, value, 0); }
+
+// Warm start of an MPC loop: a field of every grid stage (slots 0 .. nstages - 1), the same for all instances.
+static int fillStagesO(idocp_ocp_t* h, double* rec, int stride, int offset, int dim, int nstages, const double* values) {
+  double* d_vals = nullptr;
+  const size_t bytes = (size_t)nstages * dim * sizeof(double);
+  HIP_TRY(hipMalloc((void**)&d_vals, bytes));
+  hipError_t e = hipMemcpyAsync(d_vals, values, bytes, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) { ocpFillStages(rec, stride, offset, dim, h->NS, nstages, h->batch, d_vals, h->stream); e = hipStreamSynchronize(h->stream); }
+  (void)hipFree(d_vals);
+  HIP_TRY(e);
+  return IDOCP_OK;
+}
+int idocp_ocp_set_solution_stages(idocp_ocp_t* h, const char* name, int nstages, const double* values) {
+  if (!h || !name || !values) return IDOCP_E_ARG;
+  Field f;
+  if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  const int nmax = h->parnmpc ? h->N : h->N + f.extra;        // grid stages that carry the field (the terminal stage: lmd gmm q v)
+  if (nstages <= 0 || nstages > nmax) { set_last_error("idocp_ocp_set_solution_stages: nstages out of range"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  return fillStagesO(h, h->B.sol, LQ::SOL, f.offset, f.dim, nstages, values);
+}
+int idocp_parnmpc_set_aux_mat(idocp_ocp_t* h, int nstages, const double* values) {
+  if (!h || !values || !h->parnmpc) { set_last_error("idocp_parnmpc_set_aux_mat: not a ParNMPC handle"); return IDOCP_E_ARG; }
+  if (nstages <= 0 || nstages > h->N) { set_last_error("idocp_parnmpc_set_aux_mat: nstages out of range"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  return fillStagesO(h, h->B.aux, LQ::AUX, 0, DQ::NX * DQ::NX, nstages, values);
+}
 int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double* values) { return setSolutionO(h, name, values, 1); }
 
 int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
@@ -1345,15 +1372,12 @@ int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_e
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   OcpLaunch<DQ>::condenseBackwardEuler(h->B, h->batch, M, h->d_q0, h->d_v0, true, h->stream);
   OcpLaunch<DQ>::parnmpcImpulseCondense(h->B, h->batch, h->n_impulse, true, h->d_q0, h->d_v0, h->stream);
-  ocpKktErrorReduce(h->B, h->batch, h->stream);
+  ocpKktErrorReduce(h->B, h->batch, h->stream, d_err2);      // stays on the device and on the stream
   HIP_TRY(hipGetLastError());
-  std::vector<double> e(h->batch);
-  HIP_TRY(hipMemcpyAsync(e.data(), h->B.err, sizeof(double) * h->batch, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  for (double& x : e) x *= x;
-  HIP_TRY(hipMemcpy(d_err2, e.data(), sizeof(double) * h->batch, hipMemcpyHostToDevice));
   return IDOCP_OK;
 }
+int idocp_ocp_batch(idocp_ocp_t* h) { return h ? h->batch : 0; }
+extern "C" void idocp_set_last_error_string(const char* msg) { set_last_error(msg ? msg : ""); }
 int idocp_device_copy(void* d_dst, const void* d_src, unsigned long nbytes) {
   if (!d_dst || !d_src) return IDOCP_E_ARG;
   HIP_TRY(hipMemcpy(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice));

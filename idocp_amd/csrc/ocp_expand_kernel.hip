@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
   if (threadIdx.x == 0) { B.step[b * 2] = ps; B.step[b * 2 + 1] = ds; }
 }
 
-__global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B, double* __restrict__ squared_out) {
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const long b = blockIdx.x;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B) {
   for (int i = threadIdx.x; i < M; i += 64) e += B.err_stage[b * P->NS + B.nodes[i].slot];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
-  if (threadIdx.x == 0) B.err[b] = sqrt(e);
+  if (threadIdx.x == 0) { if (squared_out) squared_out[b] = e; else B.err[b] = sqrt(e); }
 }
 
 template <typename D>
@@ -385,6 +385,21 @@ __global__ void ocp_fill_field_kernel(double* __restrict__ sol, int stride, int 
   sol[rec * stride + offset + e] = value[(per_instance ? b * dim : 0) + (e % dim)];
 }
 
+// warm start: values[nstages][dim] -> field `offset` of the records of slots 0 .. nstages-1 of every instance
+__global__ void ocp_fill_stages_kernel(double* __restrict__ rec, int stride, int offset, int dim, long NS, int nstages, long batch,
+                                       const double* __restrict__ values) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)nstages * dim;
+  if (idx >= batch * per) return;
+  const long b = idx / per;
+  const int rem = (int)(idx - b * per), i = rem / dim, e = rem - i * dim;
+  rec[(b * NS + i) * stride + offset + e] = values[rem];
+}
+void ocpFillStages(double* rec, int stride, int offset, int dim, long NS, int nstages, long batch, const double* values, hipStream_t st) {
+  const long total = batch * nstages * dim;
+  hipLaunchKernelGGL(ocp_fill_stages_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, stride, offset, dim, NS, nstages, batch, values);
+}
+
 template <typename D>
 void OcpLaunch<D>::expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st) {
   hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
@@ -406,8 +421,9 @@ void OcpLaunch<D>::single(int kernel_id, const OcpBuffers& B, long batch, int M,
   else hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
 }
 
-void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st) {
-  hipLaunchKernelGGL(ocp_kkt_error_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+// squared_out != nullptr: the SUM of the squared stage residuals goes there (horizon shards add theirs up before the root)
+void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st, double* squared_out) {
+  hipLaunchKernelGGL(ocp_kkt_error_kernel, dim3((unsigned)batch), dim3(64), 0, st, B, squared_out);
 }
 
 void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,

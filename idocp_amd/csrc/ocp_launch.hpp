@@ -33,7 +33,8 @@ struct OcpLaunch {
   static void single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st);   // ids 4, 5, 6
 };
 
-void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st);
+void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st, double* squared_out = nullptr);
+void ocpFillStages(double* rec, int stride, int offset, int dim, long NS, int nstages, long batch, const double* values, hipStream_t st);
 void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,
                   int per_instance, int repeat, hipStream_t st);
 

@@ -1,0 +1,363 @@
+// Horizon-sharded ParNMPC: the multi-GPU driver behind the C ABI (BASELINE.json configs[3]).
+//
+// Counterpart of BackwardCorrectionSolver (src/ocp/backward_correction_solver.cpp:255-366), whose four correction sweeps the
+// reference runs over ONE horizon with OpenMP: here rank r owns the stages [r N/G, (r+1) N/G) of every instance (one process per
+// GPU, idocp_parnmpc_create_shard / _create_hybrid_shard) and per iteration exchanges with its two neighbours only
+//     state_last (q, v -> right)   costate_first (lmd, gmm, q -> left)   aux_first (aux_mat -> left)
+//     bwd_first (corrected lmd, gmm, right -> left pipeline)             fwd_last (corrected q, v, left -> right pipeline)
+// plus an all-reduce(min) of the step sizes and an all-reduce(sum) of the squared KKT error.  Everything is enqueued on the
+// shard's own HIP stream: pack kernel -> ncclSend / ncclRecv (RCCL, point-to-point over xGMI) -> unpack kernel -> phase kernels,
+// with persistent halo buffers and NO host synchronisation inside an iteration (round 1 drove the same protocol from Python
+// with a stream sync and a blocking send / recv per phase).  The halos are small (2.7 MB per neighbour and iteration at batch
+// 256, dominated by aux_first), so the boundary exchange is simply issued at the head of the iteration; the two serial sweeps are
+// pipelines across the ranks by construction and cost G hops of latency.
+//
+// RCCL is loaded with dlopen on first use (no link-time dependency: a host process that already carries another copy of the
+// library, e.g. torch's, keeps its own).  A second transport, `local`, connects several shard handles living on ONE GPU in one
+// process (one host thread per endpoint, host-side rendezvous): it exists so that this very driver is covered by a test on a
+// single-GPU box (tests/test_parnmpc_gpu.py) -- it is not a fallback of the product path.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "idocp_hip.h"
+
+extern "C" void idocp_set_last_error_string(const char* msg);
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    if (!lib) return false;
+#define SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(lib, "nccl" #f)); if (!f) return false;
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(Send) SYM(Recv) SYM(AllReduce) SYM(Broadcast) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+#undef SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+// in-process transport (tests): mailboxes in device memory, host-side rendezvous between the endpoints' threads
+struct LocalHub {
+  int world;
+  std::mutex m;
+  std::condition_variable cv;
+  std::map<std::pair<int, int>, std::vector<std::pair<double*, size_t>>> box;      // (src, dst) -> queue of device buffers
+  std::vector<std::vector<double>> reduce_in;     // all-reduce staging (host)
+  int reduce_count = 0, reduce_gen = 0;
+  std::vector<double> reduce_out;
+  int refs = 0;
+};
+
+}  // namespace
+
+struct idocp_comm {
+  int rank = 0, world = 1, device = 0;
+  ncclComm_t nccl = nullptr;
+  LocalHub* hub = nullptr;
+};
+
+namespace {
+
+enum { STATE_LAST = 0, COSTATE_FIRST = 1, AUX_FIRST = 2, BWD_FIRST = 3, FWD_LAST = 4, AUX_ALL = 5, NKINDS = 6 };
+
+struct DistState {
+  idocp_comm* comm = nullptr;
+  int batch = 0;
+  hipStream_t stream = nullptr;
+  double *sendb[NKINDS] = {}, *recvb[NKINDS] = {};
+  size_t count[NKINDS] = {};
+  double *d_q = nullptr, *d_v = nullptr, *d_steps = nullptr, *d_err2 = nullptr;
+};
+std::map<idocp_ocp_t*, DistState> g_dist;
+std::mutex g_dist_mutex;
+
+int fail(int code, const std::string& msg) { idocp_set_last_error_string(msg.c_str()); return code; }
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(IDOCP_E_DEVICE, std::string(#x " failed: ") + hipGetErrorString(e_)); } while (0)
+#define NCCLC(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(IDOCP_E_DEVICE, std::string(#x " failed: ") + g_rccl.GetErrorString(r_)); } while (0)
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+DistState* stateOf(idocp_ocp_t* h) {
+  std::lock_guard<std::mutex> lk(g_dist_mutex);
+  auto it = g_dist.find(h);
+  return it == g_dist.end() ? nullptr : &it->second;
+}
+
+// ---- transport: point-to-point and collectives, stream-ordered (RCCL) or host-rendezvous (local) ----
+int xsend(DistState& s, int kind, int peer) {
+  idocp_comm* c = s.comm;
+  if (c->nccl) { NCCLC(g_rccl.Send(s.sendb[kind], s.count[kind], ncclDouble, peer, c->nccl, s.stream)); return IDOCP_OK; }
+  LocalHub* hub = c->hub;
+  double* copy = nullptr;
+  HIPC(hipMalloc((void**)&copy, s.count[kind] * sizeof(double)));
+  HIPC(hipMemcpyAsync(copy, s.sendb[kind], s.count[kind] * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
+  HIPC(hipStreamSynchronize(s.stream));
+  { std::lock_guard<std::mutex> lk(hub->m); hub->box[{c->rank, peer}].push_back({copy, s.count[kind]}); }
+  hub->cv.notify_all();
+  return IDOCP_OK;
+}
+int xrecv(DistState& s, int kind, int peer) {
+  idocp_comm* c = s.comm;
+  if (c->nccl) { NCCLC(g_rccl.Recv(s.recvb[kind], s.count[kind], ncclDouble, peer, c->nccl, s.stream)); return IDOCP_OK; }
+  LocalHub* hub = c->hub;
+  std::pair<double*, size_t> msg;
+  {
+    std::unique_lock<std::mutex> lk(hub->m);
+    auto& q = hub->box[{peer, c->rank}];
+    hub->cv.wait(lk, [&] { return !q.empty(); });
+    msg = q.front(); q.erase(q.begin());
+  }
+  if (msg.second != s.count[kind]) return fail(IDOCP_E_ARG, "local transport: halo size mismatch");
+  HIPC(hipMemcpyAsync(s.recvb[kind], msg.first, msg.second * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
+  HIPC(hipStreamSynchronize(s.stream));
+  HIPC(hipFree(msg.first));
+  return IDOCP_OK;
+}
+int xgroupStart(DistState& s) { if (s.comm->nccl) NCCLC(g_rccl.GroupStart()); return IDOCP_OK; }
+int xgroupEnd(DistState& s) { if (s.comm->nccl) NCCLC(g_rccl.GroupEnd()); return IDOCP_OK; }
+// in place on a device buffer of n doubles; op: 0 sum, 1 min
+int xallreduce(DistState& s, double* d_buf, size_t n, int op) {
+  idocp_comm* c = s.comm;
+  if (c->world == 1) return IDOCP_OK;
+  if (c->nccl) { NCCLC(g_rccl.AllReduce(d_buf, d_buf, n, ncclDouble, op == 0 ? ncclSum : ncclMin, c->nccl, s.stream)); return IDOCP_OK; }
+  LocalHub* hub = c->hub;
+  std::vector<double> mine(n);
+  HIPC(hipMemcpyAsync(mine.data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIPC(hipStreamSynchronize(s.stream));
+  std::vector<double> out;
+  {
+    std::unique_lock<std::mutex> lk(hub->m);
+    const int gen = hub->reduce_gen;
+    hub->reduce_in.push_back(mine);
+    if (++hub->reduce_count == hub->world) {
+      hub->reduce_out.assign(n, op == 0 ? 0.0 : 1e300);
+      for (const auto& v : hub->reduce_in) for (size_t i = 0; i < n; ++i) hub->reduce_out[i] = op == 0 ? hub->reduce_out[i] + v[i] : (v[i] < hub->reduce_out[i] ? v[i] : hub->reduce_out[i]);
+      hub->reduce_in.clear(); hub->reduce_count = 0; ++hub->reduce_gen;
+      hub->cv.notify_all();
+    } else {
+      hub->cv.wait(lk, [&] { return hub->reduce_gen != gen; });
+    }
+    out = hub->reduce_out;
+  }
+  HIPC(hipMemcpyAsync(d_buf, out.data(), n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+  HIPC(hipStreamSynchronize(s.stream));
+  return IDOCP_OK;
+}
+int xbroadcast(DistState& s, int kind, int root) {      // sendb[kind] of `root` -> recvb[kind] of everybody
+  idocp_comm* c = s.comm;
+  if (c->nccl) { NCCLC(g_rccl.Broadcast(s.sendb[kind], s.recvb[kind], s.count[kind], ncclDouble, root, c->nccl, s.stream)); return IDOCP_OK; }
+  if (c->rank == root) {
+    for (int p = 0; p < c->world; ++p) if (p != root) RC(xsend(s, kind, p));
+    HIPC(hipMemcpyAsync(s.recvb[kind], s.sendb[kind], s.count[kind] * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
+  } else {
+    RC(xrecv(s, kind, root));
+  }
+  return IDOCP_OK;
+}
+
+int phases(idocp_ocp_t* h, DistState& s, std::initializer_list<int> ids) {
+  for (int ph : ids) RC(idocp_parnmpc_launch_phase(h, ph, s.d_q, s.d_v));
+  return IDOCP_OK;
+}
+
+// state_last -> right, costate_first and aux_first -> left; everything of the previous iterate, so it is simply issued first
+int exchangeBoundary(idocp_ocp_t* h, DistState& s) {
+  const int rank = s.comm->rank, world = s.comm->world;
+  if (world == 1) return IDOCP_OK;
+  const bool left = rank > 0, right = rank < world - 1;
+  if (right) RC(idocp_parnmpc_export_halo(h, STATE_LAST, s.sendb[STATE_LAST]));
+  if (left) { RC(idocp_parnmpc_export_halo(h, COSTATE_FIRST, s.sendb[COSTATE_FIRST])); RC(idocp_parnmpc_export_halo(h, AUX_FIRST, s.sendb[AUX_FIRST])); }
+  RC(xgroupStart(s));
+  if (s.comm->nccl) {
+    if (right) RC(xsend(s, STATE_LAST, rank + 1));
+    if (left) { RC(xrecv(s, STATE_LAST, rank - 1)); RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
+    if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
+  } else {
+    // host rendezvous: all sends first (they never block), then the receives
+    if (right) RC(xsend(s, STATE_LAST, rank + 1));
+    if (left) { RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
+    if (left) RC(xrecv(s, STATE_LAST, rank - 1));
+    if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
+  }
+  RC(xgroupEnd(s));
+  if (left) RC(idocp_parnmpc_import_halo(h, STATE_LAST, s.recvb[STATE_LAST]));
+  if (right) { RC(idocp_parnmpc_import_halo(h, COSTATE_FIRST, s.recvb[COSTATE_FIRST])); RC(idocp_parnmpc_import_halo(h, AUX_FIRST, s.recvb[AUX_FIRST])); }
+  return IDOCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idocp_comm_get_unique_id(void* id) {
+  if (!id) return IDOCP_E_ARG;
+  std::lock_guard<std::mutex> lk(g_rccl_mutex);
+  if (!g_rccl.load()) return fail(IDOCP_E_DEVICE, "idocp_comm: cannot load librccl.so");
+  ncclUniqueId uid;
+  NCCLC(g_rccl.GetUniqueId(&uid));
+  static_assert(sizeof(uid) == IDOCP_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id, &uid, sizeof(uid));
+  return IDOCP_OK;
+}
+
+int idocp_comm_init_rank(const void* id, int rank, int world, int device, idocp_comm_t** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(IDOCP_E_ARG, "idocp_comm_init_rank: invalid argument");
+  {
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (!g_rccl.load()) return fail(IDOCP_E_DEVICE, "idocp_comm: cannot load librccl.so");
+  }
+  HIPC(hipSetDevice(device));
+  idocp_comm* c = new idocp_comm();
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
+  if (r != ncclSuccess) { const std::string msg = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r); delete c; return fail(IDOCP_E_DEVICE, msg); }
+  *out = c;
+  return IDOCP_OK;
+}
+
+int idocp_comm_init_local(int world, int device, idocp_comm_t** out) {
+  if (!out || world < 1) return fail(IDOCP_E_ARG, "idocp_comm_init_local: invalid argument");
+  LocalHub* hub = new LocalHub();
+  hub->world = world; hub->refs = world;
+  for (int r = 0; r < world; ++r) {
+    idocp_comm* c = new idocp_comm();
+    c->rank = r; c->world = world; c->device = device; c->hub = hub;
+    out[r] = c;
+  }
+  return IDOCP_OK;
+}
+
+void idocp_comm_destroy(idocp_comm_t* c) {
+  if (!c) return;
+  if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->hub) {
+    bool last;
+    { std::lock_guard<std::mutex> lk(c->hub->m); last = (--c->hub->refs == 0); }
+    if (last) delete c->hub;
+  }
+  delete c;
+}
+
+int idocp_comm_rank(const idocp_comm_t* c) { return c ? c->rank : -1; }
+int idocp_comm_world(const idocp_comm_t* c) { return c ? c->world : -1; }
+
+int idocp_parnmpc_dist_attach(idocp_ocp_t* h, idocp_comm_t* comm) {
+  if (!h || !comm) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_attach: null argument");
+  DistState s;
+  s.comm = comm;
+  s.batch = idocp_ocp_batch(h);
+  if (s.batch <= 0) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_attach: not a solver handle");
+  s.stream = static_cast<hipStream_t>(idocp_ocp_stream(h));
+  HIPC(hipSetDevice(comm->device));
+  for (int k = 0; k < NKINDS; ++k) {
+    const int sz = idocp_parnmpc_halo_size(k);
+    if (sz <= 0) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_attach: unknown halo kind");
+    s.count[k] = (size_t)s.batch * sz;
+    HIPC(hipMalloc((void**)&s.sendb[k], s.count[k] * sizeof(double)));
+    HIPC(hipMalloc((void**)&s.recvb[k], s.count[k] * sizeof(double)));
+  }
+  HIPC(hipMalloc((void**)&s.d_err2, (size_t)s.batch * sizeof(double)));
+  RC(idocp_parnmpc_prev_state(h, &s.d_q, &s.d_v));
+  RC(idocp_parnmpc_step_sizes_device(h, &s.d_steps));
+  std::lock_guard<std::mutex> lk(g_dist_mutex);
+  g_dist[h] = s;
+  return IDOCP_OK;
+}
+
+int idocp_parnmpc_dist_detach(idocp_ocp_t* h) {
+  std::lock_guard<std::mutex> lk(g_dist_mutex);
+  auto it = g_dist.find(h);
+  if (it == g_dist.end()) return IDOCP_E_ARG;
+  for (int k = 0; k < NKINDS; ++k) { (void)hipFree(it->second.sendb[k]); (void)hipFree(it->second.recvb[k]); }
+  (void)hipFree(it->second.d_err2);
+  g_dist.erase(it);
+  return IDOCP_OK;
+}
+
+// rank 0: the measured state q[batch][nq], v[batch][nv] (host buffers); the other ranks receive theirs through the halos
+int idocp_parnmpc_dist_set_initial_state(idocp_ocp_t* h, const double* q, const double* v, int nq, int nv) {
+  DistState* s = stateOf(h);
+  if (!s || !q || !v) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_set_initial_state: attach a communicator first");
+  HIPC(hipMemcpyAsync(s->d_q, q, sizeof(double) * s->batch * nq, hipMemcpyHostToDevice, s->stream));
+  HIPC(hipMemcpyAsync(s->d_v, v, sizeof(double) * s->batch * nv, hipMemcpyHostToDevice, s->stream));
+  HIPC(hipStreamSynchronize(s->stream));
+  return IDOCP_OK;
+}
+
+// ParNMPCSolver::initBackwardCorrection: aux_mat = terminal cost Hessian at the LAST stage of the horizon -> computed by the last
+// rank, broadcast to everybody
+int idocp_parnmpc_dist_init_backward_correction(idocp_ocp_t* h, double t) {
+  DistState* s = stateOf(h);
+  if (!s) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
+  RC(idocp_parnmpc_init_backward_correction(h, t));
+  if (s->comm->world == 1) return IDOCP_OK;
+  RC(idocp_parnmpc_export_halo(h, AUX_ALL, s->sendb[AUX_ALL]));
+  RC(xbroadcast(*s, AUX_ALL, s->comm->world - 1));
+  RC(idocp_parnmpc_import_halo(h, AUX_ALL, s->recvb[AUX_ALL]));
+  return IDOCP_OK;
+}
+
+// One iteration (ParNMPCSolver::updateSolution, parnmpc_solver.cpp:73-103) of the sharded horizon.  Returns once everything is
+// ENQUEUED (RCCL transport): synchronise with idocp_ocp_synchronize before reading results on the host.
+int idocp_parnmpc_dist_update_solution(idocp_ocp_t* h, double t) {
+  DistState* sp = stateOf(h);
+  if (!sp) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
+  DistState& s = *sp;
+  const int rank = s.comm->rank, world = s.comm->world;
+  const bool left = rank > 0, right = rank < world - 1;
+  RC(idocp_parnmpc_discretize(h, t));
+  RC(exchangeBoundary(h, s));
+  RC(phases(h, s, {0, 1, 2}));                                   // linearise, condense, KKT inverse + coarse update
+  if (right) { RC(xrecv(s, BWD_FIRST, rank + 1)); RC(idocp_parnmpc_import_halo(h, BWD_FIRST, s.recvb[BWD_FIRST])); }
+  RC(phases(h, s, {3}));                                         // backward serial sweep, right -> left across the ranks
+  if (left) { RC(idocp_parnmpc_export_halo(h, BWD_FIRST, s.sendb[BWD_FIRST])); RC(xsend(s, BWD_FIRST, rank - 1)); }
+  RC(phases(h, s, {4}));                                         // backward parallel: overlaps the left neighbours' serial sweeps
+  if (left) { RC(xrecv(s, FWD_LAST, rank - 1)); RC(idocp_parnmpc_import_halo(h, FWD_LAST, s.recvb[FWD_LAST])); }
+  RC(phases(h, s, {5}));                                         // forward serial sweep, left -> right
+  if (right) { RC(idocp_parnmpc_export_halo(h, FWD_LAST, s.sendb[FWD_LAST])); RC(xsend(s, FWD_LAST, rank + 1)); }
+  RC(phases(h, s, {6, 7, 8}));                                   // forward parallel, expansion, local step sizes
+  RC(xallreduce(s, s.d_steps, (size_t)s.batch * 2, 1));          // min over the horizon
+  RC(phases(h, s, {9}));                                         // dual expansion + integration
+  return IDOCP_OK;
+}
+
+// ParNMPCSolver::computeKKTResidual + KKTError of the whole horizon: sqrt(sum over ranks of the shards' squared errors)
+int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* h, double t, double* kkt_error) {
+  DistState* sp = stateOf(h);
+  if (!sp || !kkt_error) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
+  DistState& s = *sp;
+  RC(idocp_parnmpc_discretize(h, t));
+  RC(exchangeBoundary(h, s));
+  RC(idocp_parnmpc_kkt_error_squared_device(h, t, s.d_err2));
+  RC(xallreduce(s, s.d_err2, (size_t)s.batch, 0));
+  HIPC(hipMemcpyAsync(kkt_error, s.d_err2, sizeof(double) * s.batch, hipMemcpyDeviceToHost, s.stream));
+  HIPC(hipStreamSynchronize(s.stream));
+  for (int b = 0; b < s.batch; ++b) kkt_error[b] = std::sqrt(kkt_error[b]);
+  return IDOCP_OK;
+}
+
+}  // extern "C"

@@ -359,6 +359,10 @@ int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* 
  * constraints (like the reference). */
 int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value);
 int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double* values);
+/* Warm start (an MPC loop keeps the iterate of the previous sampling instant; the reference does so implicitly because the solver
+ * object lives on): one field of every grid stage, values[nstages][dim], the same for all instances.  name: q v a u beta f mu
+ * (dim 3 * max contacts) lmd gmm nu_passive; nstages <= N + 1 for lmd gmm q v of an OCPSolver, <= N otherwise. */
+int idocp_ocp_set_solution_stages(idocp_ocp_t* h, const char* name, int nstages, const double* values);
 /* OCPSolver::initConstraints(t) (ocp_solver.cpp:60-64). */
 int idocp_ocp_init_constraints(idocp_ocp_t* h, double t);
 /* OCPSolver::updateSolution (ocp_solver.cpp:67-92). q[batch][nq], v[batch][nv].  line_search must be 0: the filter line
@@ -431,6 +435,9 @@ int idocp_parnmpc_create_hybrid(const idocp_model_t* model, const idocp_cost_t* 
 /* ParNMPCSolver::initBackwardCorrection (parnmpc_solver.cpp:66-70): aux_mat of every stage
  * = terminal cost Hessian. */
 int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t);
+/* Warm start of the correction state: BackwardCorrectionSolver::aux_mat_ of stages 0 .. nstages - 1, values[nstages][nx * nx]
+ * column-major (what initBackwardCorrection fills with the terminal cost Hessian, backward_correction_solver.cpp:62-80). */
+int idocp_parnmpc_set_aux_mat(idocp_ocp_t* h, int nstages, const double* values);
 /* ParNMPCSolver::updateSolution (parnmpc_solver.cpp:73-103): coarseUpdate,
  * backwardCorrectionSerial / Parallel, forwardCorrectionSerial / Parallel, step sizes,
  * integrateSolution.  q[batch][nq], v[batch][nv]; line_search must be 0 (see idocp_ocp_update_solution). */
@@ -464,6 +471,32 @@ int idocp_parnmpc_create_hybrid_shard(const idocp_model_t* model, const idocp_co
 int idocp_parnmpc_halo_size(int kind);
 int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf);
 int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf);
+/* ---- multi-GPU driver of the sharded horizon, in C++ over RCCL (idocp_amd/csrc/parnmpc_dist.hip) ------------------------
+ * Counterpart of BackwardCorrectionSolver (src/ocp/backward_correction_solver.cpp:255-366) for one process per GPU: every rank
+ * creates its shard (idocp_parnmpc_create_shard / _create_hybrid_shard), a communicator, attaches one to the other and then calls
+ * the idocp_parnmpc_dist_* entry points collectively.  The halo exchange (point-to-point ncclSend / ncclRecv with the two
+ * neighbours, all-reduce of step sizes and KKT error) is enqueued on the shard's stream between its kernels; nothing in an
+ * iteration synchronises with the host.  The unique id is made on rank 0 and distributed by the caller (MPI, a file, a store). */
+#define IDOCP_COMM_ID_BYTES 128
+typedef struct idocp_comm idocp_comm_t;
+int idocp_comm_get_unique_id(void* id /* IDOCP_COMM_ID_BYTES */);
+int idocp_comm_init_rank(const void* id, int rank, int world, int device, idocp_comm_t** out);
+/* `world` endpoints on ONE GPU in one process (out[world]; one host thread per endpoint): the transport of the single-GPU test
+ * of this driver, not a product path. */
+int idocp_comm_init_local(int world, int device, idocp_comm_t** out);
+void idocp_comm_destroy(idocp_comm_t* c);
+int idocp_comm_rank(const idocp_comm_t* c);
+int idocp_comm_world(const idocp_comm_t* c);
+int idocp_parnmpc_dist_attach(idocp_ocp_t* shard, idocp_comm_t* comm);
+int idocp_parnmpc_dist_detach(idocp_ocp_t* shard);
+/* rank 0: the measured state q[batch][nq], v[batch][nv] (host buffers) */
+int idocp_parnmpc_dist_set_initial_state(idocp_ocp_t* shard, const double* q, const double* v, int nq, int nv);
+int idocp_parnmpc_dist_init_backward_correction(idocp_ocp_t* shard, double t);
+/* One iteration of the whole horizon; returns when everything is enqueued (idocp_ocp_synchronize before reading results). */
+int idocp_parnmpc_dist_update_solution(idocp_ocp_t* shard, double t);
+/* KKT error of the whole horizon on every rank, kkt_error[batch] (host). */
+int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* shard, double t, double* kkt_error);
+int idocp_ocp_batch(idocp_ocp_t* h);
 /* Device pointers of the state in front of the first stage (q[batch][nq], v[batch][nv]) and of
  * the step sizes ([batch][2]: primal, dual) -- the latter is all-reduced (min) between phases 8 and 9. */
 int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v);

@@ -784,6 +784,35 @@ int oracle_parnmpc_set_solution(void* h, const char* name, const double* value) 
   try { s->setSolution(n, toVec(value, dim)); } catch (...) { return -1; }
   return 0;
 }
+// Warm start (the MPC use of the solver: the iterate and the correction state persist between calls): one field of ONE stage,
+// name in q v a u f (all contacts stacked) lmd gmm beta mu (stacked); and BackwardCorrectionSolver::aux_mat_ of one stage
+int oracle_parnmpc_set_stage(void* h, int i, const char* name, const double* value) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  if (i < 0 || i >= (int)s->s.size()) return -1;
+  const std::string n(name);
+  SplitSolutionC& x = s->s[i];
+  const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
+  if (n == "q") x.q = toVec(value, s->robot.dimq());
+  else if (n == "v") x.v = toVec(value, nv);
+  else if (n == "a") x.a = toVec(value, nv);
+  else if (n == "u") x.u = toVec(value, s->robot.dimu());
+  else if (n == "lmd") x.lmd = toVec(value, nv);
+  else if (n == "gmm") x.gmm = toVec(value, nv);
+  else if (n == "beta") x.beta = toVec(value, nv);
+  else if (n == "f") for (int c = 0; c < nc; ++c) x.f[c] = toVec(value + 3 * c, 3);
+  else if (n == "mu") for (int c = 0; c < nc; ++c) x.mu[c] = toVec(value + 3 * c, 3);
+  else return -1;
+  return 0;
+}
+int oracle_parnmpc_set_aux_mat(void* h, int i, const double* mat /* nx x nx col-major */) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  if (i < 0 || i >= (int)s->aux_mat.size()) return -1;
+  const int nx = 2 * s->robot.dimv();
+  Mat m(nx, nx);
+  xcpy(m.d.data(), mat, sizeof(double) * nx * nx);
+  s->aux_mat[i] = m;
+  return 0;
+}
 int oracle_parnmpc_init(void* h, double t) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
   s->initBackwardCorrection(t);

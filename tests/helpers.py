@@ -811,8 +811,21 @@ class OracleParNMPC:
         assert self.lib.oracle_parnmpc_get_chain(self.h, name.encode(), dim, P(out)) == 0
         return out
 
+    def set_stage_values(self, name, values):
+        self.lib.oracle_parnmpc_set_stage.argtypes = [C.c_void_p, C.c_int, C.c_char_p, dp]
+        for i, v in enumerate(np.asarray(values)):
+            assert self.lib.oracle_parnmpc_set_stage(self.h, i, name.encode(), P(arr(v))) == 0
+
+    def set_aux_mats(self, mats):
+        self.lib.oracle_parnmpc_set_aux_mat.argtypes = [C.c_void_p, C.c_int, dp]
+        for i, mth in enumerate(np.asarray(mats)):
+            assert self.lib.oracle_parnmpc_set_aux_mat(self.h, i, P(arr(np.asarray(mth).T))) == 0
+
     def init(self, t=0.0):                      # initBackwardCorrection(t) + initConstraints(t)
         self.lib.oracle_parnmpc_init(self.h, t)
+
+    def init_constraints(self, t=0.0):          # initConstraints(t) alone (after a warm start of the iterate)
+        self.lib.oracle_parnmpc_init_constraints_only(self.h, t)
 
     def update(self, t, q, v):
         return self.lib.oracle_parnmpc_update_solution(self.h, t, P(arr(q)), P(arr(v)))
@@ -972,6 +985,16 @@ class HipOCP:
 class HipParNMPC(HipOCP):
     """ParNMPCSolver through the C ABI (idocp_parnmpc_* + the shared idocp_ocp_* entry points)."""
 
+    def set_stage_values(self, name, values):
+        """warm start: one field of stages 0 .. len(values) - 1, all instances"""
+        values = arr(values)
+        capi.check(self.lib.idocp_ocp_set_solution_stages(self.h, name.encode(), values.shape[0], P(values)), "set_solution_stages " + name)
+
+    def set_aux_mats(self, mats):
+        """warm start: aux_mat [stages, nx, nx] (row, col)"""
+        cm = arr(np.asarray(mats).transpose(0, 2, 1))      # column-major per stage
+        capi.check(self.lib.idocp_parnmpc_set_aux_mat(self.h, cm.shape[0], P(cm)), "set_aux_mat")
+
     def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
         self.lib = capi.lib()
         self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
@@ -1007,6 +1030,24 @@ class HipParNMPC(HipOCP):
         out = np.zeros((self.N, dim))
         capi.check(fn(self.h, name.encode(), instance, P(out)), "get " + name)
         return out
+
+
+def warm_start_parnmpc(ocp, targets, N):
+    """The well-posed N = 256 workload of BASELINE configs[3]: ParNMPC started, like in an MPC loop, from the converged Riccati
+    solution of the same problem -- stage i of ParNMPC lives at the time of grid stage i + 1 of the OCP: (q, v, lmd, gmm) and
+    aux_mat = P of stage i + 1, (a, u, f, beta, mu) of stage min(i + 1, N - 1).  From the reference's cold start (aux_mat = terminal
+    Hessian everywhere) the forward correction sweep amplifies by 1.15 per stage and the first direction reaches 3e12 at N = 256;
+    from here it is O(1) and the iteration converges.  `ocp`: a converged OracleOCP / HipOCP; `targets`: ParNMPC solvers."""
+    sol = {f: np.asarray(ocp.get(f)) for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu")}
+    Pm = ocp.riccati()[0]
+    vals = {f: sol[f][1:N + 1] for f in ("q", "v", "lmd", "gmm")}
+    for f in ("a", "u", "f", "beta", "mu"):
+        vals[f] = np.stack([sol[f][min(i + 1, N - 1)] for i in range(N)])
+    aux = Pm[1:N + 1]
+    for t in targets:
+        for f, v in vals.items():
+            t.set_stage_values(f, v)
+        t.set_aux_mats(aux)
 
 
 class OracleParNMPCShard:

@@ -135,26 +135,111 @@ def test_two_shards_on_one_gpu_equal_the_whole_horizon():
     assert abs(np.sqrt(e2) - g.kkt_error(0.0, q, v)[0]) < 1e-9 * max(1.0, np.sqrt(e2))
 
 
+def test_cxx_sharded_driver_equals_the_whole_horizon():
+    """The multi-GPU driver of the product (idocp_amd/csrc/parnmpc_dist.hip: idocp_parnmpc_dist_*, RCCL point-to-point halos +
+    all-reduces enqueued on the shard's stream) exercised on ONE GPU: two shard handles of 10 stages, one host thread per
+    endpoint, connected by the in-process transport (idocp_comm_init_local) -- the same driver code, only send / recv differ.
+    Against one handle of 20 stages over four iterations, and the whole-horizon KKT error."""
+    import ctypes as C
+    import threading
+    from helpers import P, arr
+    from idocp_amd import capi
+    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    m, o, g, q, v = make_pair(20, 0.5)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    lib = capi.lib()
+    shards = [HipParNMPCShard(m, cost, cons, 0.5, 20, r, 2, 1, 0) for r in range(2)]
+    comms = (C.c_void_p * 2)()
+    capi.check(lib.idocp_comm_init_local(2, 0, comms), "comm_init_local")
+    for r, sh in enumerate(shards):
+        a = (C.c_int * 4)(1, 1, 1, 1)
+        capi.check(lib.idocp_ocp_set_contact_status_uniformly(sh.h, a, P(arr(pts))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"q", P(arr(ANYMAL_Q_STANDING))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"v", P(np.zeros(m.nv))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"f", P(arr([0, 0, 0.25 * (-m.total_mass * m.gravity[2])]))))
+        capi.check(lib.idocp_parnmpc_dist_attach(sh.h, comms[r]), "attach")
+    capi.check(lib.idocp_parnmpc_dist_set_initial_state(shards[0].h, P(arr(q[None, :])), P(arr(v[None, :])), m.nq, m.nv))
+    errors, kkt = [], [np.zeros(1), np.zeros(1)]
+
+    def collective(fn):
+        """call fn(rank) on one thread per endpoint (ctypes drops the GIL inside the library)"""
+        def run(r):
+            try:
+                fn(r)
+            except Exception as e:      # noqa: BLE001
+                errors.append((r, e))
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not errors, errors
+
+    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shards[r].h, 0.0), "init"))
+    for sh in shards:
+        capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
+
+    def get(sh, name, dim):
+        out = np.zeros((10, dim))
+        capi.check(lib.idocp_ocp_get_solution(sh.h, name.encode(), 0, P(out)))
+        return out
+
+    for it in range(4):
+        assert g.update(0.0, q, v) == 0
+        collective(lambda r: capi.check(lib.idocp_parnmpc_dist_update_solution(shards[r].h, 0.0), "update"))
+        for sh in shards:
+            capi.check(lib.idocp_ocp_synchronize(sh.h))
+        for name, dim in (("q", 19), ("v", 18), ("u", 12), ("lmd", 18), ("a", 18), ("f", 12)):
+            both = np.concatenate([get(shards[0], name, dim), get(shards[1], name, dim)])
+            assert rel_err(both, g.get(name)) < 1e-9, (it, name)
+    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_kkt_error(shards[r].h, 0.0, P(kkt[r])), "kkt"))
+    e_g = g.kkt_error(0.0, q, v)[0]
+    assert abs(kkt[0][0] - e_g) < 1e-9 * max(1.0, e_g) and kkt[0][0] == kkt[1][0]
+    for r, sh in enumerate(shards):
+        capi.check(lib.idocp_parnmpc_dist_detach(sh.h))
+        lib.idocp_comm_destroy(comms[r])
+
+
 def test_full_size_c4_parity_and_properties():
-    # BASELINE configs[3] at its own size (ANYmal ParNMPC, N = 256, T = 12.8): the first iteration against the oracle
-    # (the tolerance grows with the number of 84 x 84 KKT inverses the serial sweeps pass through, see above), then
-    # size-independent properties on a small batch
-    m, o, g, q, v = make_pair(256, 12.8, batch=3)
+    """BASELINE configs[3] at its own size (ANYmal ParNMPC, N = 256, T = 12.8) as a WELL-POSED problem: warm start from the converged
+    Riccati solution of the same OCP (helpers.warm_start_parnmpc; the MPC use of the solver).  The first direction is then O(1)
+    -- from the reference's cold start it grows to 3e12 along the forward correction sweep, a number no tolerance is meaningful
+    on -- and must meet the 1e-10 bar stage by stage; a long double referee stands by for the stages where two FP64 evaluations
+    separate by more.  Then the iteration converges, GPU and oracle side by side."""
+    from helpers import OracleOCP, warm_start_parnmpc
+    N, T = 256, 12.8
+    m, o, g, q, v, h = make_pair(N, T, batch=3, referee=True)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    src = OracleOCP(m, cost, cons, T, N)
+    src.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+    src.set_solution("q", ANYMAL_Q_STANDING)
+    src.set_solution("v", np.zeros(m.nv))
+    src.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    src.init_constraints(0.0)
+    for it in range(40):
+        assert src.update(0.0, q, v) == 0
+        if src.kkt_error(0.0, q, v) < 1e-9:
+            break
+    assert src.kkt_error(0.0, q, v) < 1e-9
+    warm_start_parnmpc(src, (o, g, h), N)
+    for s in (o, g, h):
+        s.init_constraints(0.0)
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
     assert abs(e_g[0] - e_o) <= 1e-10 * max(1.0, e_o)
-    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
-    # From this cold start the forward correction sweep is not contractive: the direction grows by ~1.15 per stage (|dq| = 2e1
-    # at N = 64, 6e4 at N = 128, 3e12 at N = 256) and so does the distance between two FP64 evaluations of it that start
-    # 1e-14 apart (Gauss-Jordan here, LLT in the oracle): 2e-10 at N = 64, 1e-5 at N = 128, 1e-6 of the 3e12 at N = 256.  The
-    # bar that can be held at full size is therefore relative to the largest entry, and tight only on the leading stages.
-    worst = max(rel_err(g.get(f), o.get(f)) for f in OCP_DIR_FIELDS)
-    assert worst < 1e-4, worst
-    lead = max(np.abs(g.get(f)[:2] - o.get(f)[:2]).max() / max(1.0, np.abs(o.get(f)).max()) for f in OCP_DIR_FIELDS)
-    assert lead < 1e-12, lead
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
+        d_o, d_g, d_h = o.get(f), g.get(f), h.get(f)
+        assert np.abs(d_o).max() < 1e3, (f, np.abs(d_o).max())              # a direction one can step along
+        referee_check(d_g, d_o, d_h, f)
+        # stage by stage, relative to the stage's own entries (not to the largest entry of the horizon)
+        per_stage = np.abs(d_g - d_o).max(axis=1) / np.maximum(1.0, np.abs(d_o).max(axis=1))
+        assert per_stage.max() < 1e-9, (f, per_stage.max(), per_stage.argmax())
         assert np.array_equal(g.get(f, 0), g.get(f, 2))                         # identical instances, identical results
-    for _ in range(3):
-        assert g.update(0.0, q, v) == 0
+    for it in range(6):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+        assert abs(e_g[0] - e_o) <= 1e-6 * max(1.0, e_o) + 1e-9, (it, e_g[0], e_o)
+    assert e_g[0] < 1e-3 * 138.0                                                # converging (138 after the first step, 3.6e-6 after six)
     qs = g.get("q", 1)
     assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12        # quaternions stay normalised
-    assert np.isfinite(g.kkt_error(0.0, q, v)).all()
