@@ -221,7 +221,7 @@ def run_parnmpc(args, rank, local_rank, world, dist):
     import torch
     from idocp_amd import capi
     from idocp_amd.parnmpc_dist import HipParNMPCShard, ShardedParNMPC
-    from helpers import ANYMAL_Q_STANDING, OracleParNMPC, P, anymal_contact_points, anymal_model, anymal_problem, arr
+    from idocp_amd.workloads import ANYMAL_Q_STANDING, P, anymal_contact_points, anymal_model, anymal_problem, arr
     torch.cuda.set_device(local_rank)
     torch.cuda.init()                      # torch's HIP runtime first (see tests/conftest.py)
     lib = capi.lib()
@@ -258,7 +258,7 @@ def run_parnmpc(args, rank, local_rank, world, dist):
 
             def push_back_contact_status(self, active, points, t_ev):
                 capi.check(lib.idocp_ocp_push_back_contact_status(shard.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points)), t_ev))
-        from helpers import trotting_sequence
+        from idocp_amd.workloads import trotting_sequence
         trotting_sequence(_Seq(), model, n_events - 1, t_start=0.5125)
     else:
         shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
@@ -453,10 +453,9 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     stream).  Strong scaling: the batch of instances is the same whatever the number of GPUs.  The iterate is WARM-STARTED from
     the converged Riccati solution of the same OCP (helpers.warm_start_parnmpc; the MPC use of the solver): from the reference's
     cold start the forward correction sweep amplifies by 1.15 per stage and a 256-stage horizon is numerically meaningless."""
-    import helpers
-    from idocp_amd import capi
+    from idocp_amd import capi, workloads
     from idocp_amd.parnmpc_dist import HipParNMPCShard
-    from helpers import ANYMAL_Q_STANDING, HipOCP, OracleParNMPC, P, anymal_contact_points, anymal_model, anymal_problem, arr
+    from idocp_amd.workloads import ANYMAL_Q_STANDING, HipOCP, P, anymal_contact_points, anymal_model, anymal_problem, arr
     lib = capi.lib()
     hip = Hip()
     hip.rt.hipSetDevice(local_rank)
@@ -521,7 +520,7 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
         def set_aux_mats(self, mats):
             cm = arr(np.asarray(mats[rank * Nl:(rank + 1) * Nl]).transpose(0, 2, 1))
             capi.check(lib.idocp_parnmpc_set_aux_mat(shard.h, Nl, P(cm)), "set_aux_mat")
-    helpers.warm_start_parnmpc(src, [_Slice()], N)
+    workloads.warm_start_parnmpc(src, [_Slice()], N)
     capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
     del src
 
@@ -585,6 +584,7 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
                                "avg_launch_ms": ker[dom],
                                "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world}
         if not args.no_cpu_baseline:
+            from helpers import OracleParNMPC      # the CPU restatement: checker / baseline only
             o = OracleParNMPC(model, cost, cons, T, N)
             o.set_contact_status([1, 1, 1, 1], pts)
             o.set_solution("q", ANYMAL_Q_STANDING)
@@ -655,8 +655,8 @@ def main():
         return run_parnmpc(args, rank, local_rank, world, dist)
 
     from idocp_amd import capi
-    from helpers import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, HipUnParNMPC, anymal_contact_points, anymal_model, anymal_problem, iiwa14_model,
-                         trotting_sequence, unocp_problem)
+    from idocp_amd.workloads import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, HipUnParNMPC, anymal_contact_points, anymal_model, anymal_problem,
+                                     iiwa14_model, trotting_sequence, unocp_problem)
     lib = capi.lib()                       # fails loudly if the HIP extension is missing
     hip = Hip()
     hip.rt.hipSetDevice(local_rank)
@@ -697,7 +697,7 @@ def main():
     elif args.workload == "anymal_running":
         # BASELINE.json configs[4] in FP64: ANYmal OCPSolver on the running gait of examples/anymal/anymal_running.cpp:29-231
         # (40 discrete events: 26 touch-downs, 14 lift-offs, flight phases without any contact), N = 200, T = 7
-        from helpers import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
+        from idocp_amd.workloads import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
         N = args.horizon if args.horizon != 100 else 200
         T = 7.0
         nimp = 26

@@ -91,6 +91,7 @@ struct idocp_ocp {
   OcpBuffers B{};
   OcpProblem prob;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;   // parallel to allocs (idocp_ocp_clone copies buffer by buffer)
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr, *d_qref = nullptr;
   void* d_prob = nullptr;
   OcpNode* d_nodes = nullptr;
@@ -131,7 +132,7 @@ namespace {
 
 int allocBufO(idocp_ocp* h, double** p, size_t n) {
   HIP_TRY(hipMalloc((void**)p, n * sizeof(double)));
-  h->allocs.push_back(*p);
+  h->allocs.push_back(*p); h->alloc_bytes.push_back(n * sizeof(double));
   HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(double), h->stream));
   return IDOCP_OK;
 }
@@ -652,7 +653,8 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&h->d_prob, sizeof(OcpProblem)) != hipSuccess) {
     set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
   }
-  h->allocs.push_back(d_model); h->allocs.push_back(h->d_prob);
+  h->allocs.push_back(d_model); h->alloc_bytes.push_back(sizeof(DevModel));
+  h->allocs.push_back(h->d_prob); h->alloc_bytes.push_back(sizeof(OcpProblem));
   if (hipMemcpyAsync(d_model, &dm, sizeof(dm), hipMemcpyHostToDevice, h->stream) != hipSuccess) { set_last_error("hipMemcpy failed"); return fail(IDOCP_E_DEVICE); }
   B.model = static_cast<const DevModel*>(d_model);
   B.prob = static_cast<const OcpProblem*>(h->d_prob);
@@ -1377,6 +1379,31 @@ int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_e
   return IDOCP_OK;
 }
 int idocp_ocp_batch(idocp_ocp_t* h) { return h ? h->batch : 0; }
+
+// Deep copy (the reference's solver classes are copyable, `= default`: ocp_solver.hpp:171-186): a new handle of the same
+// configuration whose device records, contact sequence and discretisation state equal the source's.
+int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
+  if (!src || !out) return IDOCP_E_ARG;
+  int rc = setDev(src); if (rc) return rc;
+  idocp_ocp_t* h = nullptr;
+  if ((rc = createOcpImpl(&src->model, &src->cost, &src->cons, src->T, src->N, src->E, src->batch, src->device, src->parnmpc, &h))) return rc;
+  auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
+  if (h->allocs.size() != src->allocs.size()) { set_last_error("idocp_ocp_clone: allocation tables differ"); return fail(IDOCP_E_DEVICE); }
+  if (hipStreamSynchronize(src->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  for (size_t i = 0; i < h->allocs.size(); ++i) {
+    if (h->alloc_bytes[i] != src->alloc_bytes[i]) { set_last_error("idocp_ocp_clone: allocation tables differ"); return fail(IDOCP_E_DEVICE); }
+    if (hipMemcpyAsync(h->allocs[i], src->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  }
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  h->contact_status_set = src->contact_status_set; h->stage_offset = src->stage_offset; h->has_terminal = src->has_terminal; h->has_prev = src->has_prev;
+  h->phases = src->phases; h->event_time = src->event_time; h->is_impulse = src->is_impulse; h->impulse_status = src->impulse_status;
+  h->slice_begin = src->slice_begin; h->slice_end = src->slice_end;
+  h->prob = src->prob;
+  h->seq_dirty = true;                       // the chain is rebuilt (and uploaded) on first use
+  if (src->disc_time == src->disc_time) { if ((rc = discretize(h, src->disc_time))) return fail(rc); }
+  *out = h;
+  return IDOCP_OK;
+}
 extern "C" void idocp_set_last_error_string(const char* msg) { set_last_error(msg ? msg : ""); }
 int idocp_device_copy(void* d_dst, const void* d_src, unsigned long nbytes) {
   if (!d_dst || !d_src) return IDOCP_E_ARG;

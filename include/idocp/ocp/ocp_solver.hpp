@@ -49,8 +49,18 @@ class OCPSolver {
     cache_.resize(N + 1);
   }
   ~OCPSolver() { idocp_ocp_destroy(h_); }
-  OCPSolver(const OCPSolver&) = delete;
-  OCPSolver& operator=(const OCPSolver&) = delete;
+  // copyable and movable like the reference class (ocp_solver.hpp:171-186, `= default`): a copy is a DEEP copy of the solver
+  // state on the device (idocp_ocp_clone)
+  OCPSolver(const OCPSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_) { check(idocp_ocp_clone(other.h_, &h_)); }
+  OCPSolver& operator=(const OCPSolver& other) {
+    if (this != &other) { idocp_ocp_t* n = nullptr; check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_; }
+    return *this;
+  }
+  OCPSolver(OCPSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
+  OCPSolver& operator=(OCPSolver&& other) noexcept {
+    if (this != &other) { idocp_ocp_destroy(h_); h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; N_ = other.N_; cache_ = std::move(other.cache_); }
+    return *this;
+  }
 
   void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
 

@@ -28,21 +28,61 @@ class ParNMPCSolver {
  public:
   ParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
                 const double T, const int N, const int max_num_impulse = 0, const int nthreads = 1, const int device = 0)
-      : robot_(robot), N_(N), h_(nullptr) {
+      : robot_(robot), N_(N), h_(nullptr), comm_(nullptr) {
     (void)nthreads;
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
     if (max_num_impulse > 0) check(idocp_parnmpc_create_hybrid(&robot.model(), &c, &k, T, N, max_num_impulse, 1, device, &h_));
     else check(idocp_parnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
   }
-  ~ParNMPCSolver() { idocp_ocp_destroy(h_); }
-  ParNMPCSolver(const ParNMPCSolver&) = delete;
-  ParNMPCSolver& operator=(const ParNMPCSolver&) = delete;
+  // Multi-GPU (BASELINE configs[3]): ONE process per GPU, every process constructs the solver with the same arguments plus its
+  // communicator (idocp_comm_init_rank over an id made by idocp_comm_get_unique_id on rank 0).  The process then owns the grid
+  // stages [rank N / world, (rank + 1) N / world) of the horizon; initBackwardCorrection / updateSolution / KKTError are collective
+  // calls (RCCL halo exchange with the two neighbours, idocp_amd/csrc/parnmpc_dist.hip -- the counterpart of the reference's OpenMP
+  // loops over one horizon, backward_correction_solver.cpp:255-366).  getSolution returns the local stages.
+  ParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
+                const double T, const int N, idocp_comm_t* comm, const int max_num_impulse = 0, const int device = 0)
+      : robot_(robot), N_(N), h_(nullptr), comm_(comm) {
+    const idocp_cost_t c = cost->native();
+    const idocp_constraints_t k = constraints->native();
+    const int rank = idocp_comm_rank(comm), world = idocp_comm_world(comm);
+    if (world < 1 || N % world != 0) { std::cerr << "invalid value: N must be divisible by the number of ranks!\n"; std::exit(EXIT_FAILURE); }
+    const int Nl = N / world;
+    if (max_num_impulse > 0) check(idocp_parnmpc_create_hybrid_shard(&robot.model(), &c, &k, T, N, max_num_impulse, rank * Nl, (rank + 1) * Nl, 1, device, &h_));
+    else check(idocp_parnmpc_create_shard(&robot.model(), &c, &k, T / world, Nl, rank * Nl, rank == world - 1 ? 1 : 0, rank > 0 ? 1 : 0, 1, device, &h_));
+    check(idocp_parnmpc_dist_attach(h_, comm_));
+    N_ = Nl;
+  }
+  ~ParNMPCSolver() { if (comm_) idocp_parnmpc_dist_detach(h_); idocp_ocp_destroy(h_); }
+  // copyable and movable like the reference class (a copy is a deep copy of the device state; a sharded solver is bound to its
+  // communicator and can only be moved)
+  ParNMPCSolver(const ParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), comm_(nullptr) {
+    if (other.comm_) { std::cerr << "a sharded ParNMPCSolver cannot be copied\n"; std::exit(EXIT_FAILURE); }
+    check(idocp_ocp_clone(other.h_, &h_));
+  }
+  ParNMPCSolver& operator=(const ParNMPCSolver& other) {
+    if (this != &other) {
+      if (other.comm_ || comm_) { std::cerr << "a sharded ParNMPCSolver cannot be copied\n"; std::exit(EXIT_FAILURE); }
+      idocp_ocp_t* n = nullptr; check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_;
+    }
+    return *this;
+  }
+  ParNMPCSolver(ParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), comm_(other.comm_), kkt_error_(other.kkt_error_) { other.h_ = nullptr; other.comm_ = nullptr; }
 
   void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
-  void initBackwardCorrection(const double t) { check(idocp_parnmpc_init_backward_correction(h_, t)); }
+  void initBackwardCorrection(const double t) {
+    if (comm_) check(idocp_parnmpc_dist_init_backward_correction(h_, t));
+    else check(idocp_parnmpc_init_backward_correction(h_, t));
+  }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    if (comm_) {
+      if (line_search) { std::cerr << "line_search=true is not supported on a sharded horizon\n"; std::exit(EXIT_FAILURE); }
+      if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
+      check(idocp_parnmpc_dist_update_solution(h_, t));
+      check(idocp_ocp_synchronize(h_));
+      return;
+    }
     check(idocp_parnmpc_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
 
@@ -98,11 +138,17 @@ class ParNMPCSolver {
   }
 
   double KKTError() {
+    if (comm_) return kkt_error_;
     double e = 0;
     check(idocp_ocp_kkt_error(h_, &e));
     return e;
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    if (comm_) {
+      if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
+      check(idocp_parnmpc_dist_kkt_error(h_, t, &kkt_error_));
+      return;
+    }
     check(idocp_parnmpc_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
   idocp_ocp_t* handle() { return h_; }
@@ -111,6 +157,8 @@ class ParNMPCSolver {
   Robot robot_;
   int N_;
   idocp_ocp_t* h_;
+  idocp_comm_t* comm_ = nullptr;      // not owned
+  double kkt_error_ = 0.0;
   static void check(int rc) {
     if (rc != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';

@@ -497,6 +497,9 @@ int idocp_parnmpc_dist_update_solution(idocp_ocp_t* shard, double t);
 /* KKT error of the whole horizon on every rank, kkt_error[batch] (host). */
 int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* shard, double t, double* kkt_error);
 int idocp_ocp_batch(idocp_ocp_t* h);
+/* Deep copy of a solver handle (the reference's solver classes are copyable): same configuration, device records, contact
+ * sequence and discretisation. */
+int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out);
 /* Device pointers of the state in front of the first stage (q[batch][nq], v[batch][nv]) and of
  * the step sizes ([batch][2]: primal, dual) -- the latter is all-reduced (min) between phases 8 and 9. */
 int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v);

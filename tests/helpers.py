@@ -8,17 +8,13 @@ import subprocess
 import numpy as np
 
 from idocp_amd import capi
+from idocp_amd.workloads import *      # noqa: F401,F403  (models, problems, sequences, Hip* wrappers: shared with bench.py)
+from idocp_amd.workloads import P, arr, dp, ROOT, GOLDEN
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = os.path.join(ROOT, "tests", "golden")
-IIWA_URDF = os.path.join(GOLDEN, "urdf", "iiwa14.urdf")
-ANYMAL_URDF = os.path.join(GOLDEN, "urdf", "anymal.urdf")
-ANYMAL_CONTACT_FRAMES = (14, 24, 34, 44)
-dp = capi.c_double_p
 
 _oracles = {}
-ORACLE_PATH_OVERRIDE = None       # bench.py's cpu_baseline leg points this at the natively built library
 
+ORACLE_PATH_OVERRIDE = None       # bench.py's cpu_baseline leg points this at the natively built library
 
 def oracle(hp=False):
     """liboracle.so, or with hp=True liboracle_hp.so -- the SAME restatement built with a long double scalar, the referee
@@ -92,46 +88,9 @@ def oracle(hp=False):
         _oracle = _oracles[hp] = lib
     return _oracle
 
-
-def arr(x):
-    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
-
-
-def P(a):
-    return a.ctypes.data_as(dp)
-
-
 def load_golden(robot):
     with open(os.path.join(GOLDEN, "rbd_%s.json" % robot)) as f:
         return json.load(f)
-
-
-def iiwa14_model():
-    return capi.model_from_urdf(IIWA_URDF)
-
-
-def unocp_problem(model):
-    """Workload of examples/iiwa14/unocp_benchmark.cpp:20-43."""
-    nv = model.nv
-    cost = capi.Cost()
-    cost.set("q_ref", np.full(nv, -5.0)).set("v_ref", np.full(nv, -9.0))
-    cost.set("q_weight", np.full(nv, 10.0)).set("qf_weight", np.full(nv, 10.0))
-    cost.set("v_weight", np.full(nv, 0.1)).set("vf_weight", np.full(nv, 0.1))
-    cost.set("a_weight", np.full(nv, 0.01)).set("u_weight", np.zeros(nv))
-    cons = capi.Constraints()
-    capi.lib().idocp_constraints_init(C.byref(cons))
-    for i in range(model.nu):           # robot.setJointEffortLimit(Constant(200))
-        model.u_max[i] = 200.0
-    return cost, cons
-
-
-SOL_FIELDS = ("q", "v", "a", "u", "lmd", "gmm", "beta")
-DIR_FIELDS = tuple("d" + f for f in SOL_FIELDS)
-
-
-def stages_of(name, N):
-    return N if name in ("a", "u", "beta", "da", "du", "dbeta") else N + 1
-
 
 class OracleUnOCP:
     def __init__(self, model, cost, cons, T, N, hp=False):
@@ -205,7 +164,6 @@ class OracleUnOCP:
         self.lib.oracle_unocp_get_unkkt(self.h, P(Q), P(r))
         return Q.transpose(0, 2, 1), r
 
-
 class OracleUnParNMPC:
     """oracle::UnParNMPCSolver: N backward-Euler stages, every field is [N][nv]"""
 
@@ -269,152 +227,6 @@ class OracleUnParNMPC:
         self.lib.oracle_unparnmpc_get_constraint_data(self.h, P(sl), P(du))
         return sl, du
 
-
-class HipUnOCP:
-    """Product path through the C ABI (idocp_unocp_*)."""
-
-    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
-        self.lib = capi.lib()
-        self.N, self.nv, self.batch = N, model.nv, batch
-        h = C.c_void_p()
-        capi.check(self.lib.idocp_unocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
-                   "idocp_unocp_create")
-        self.h = h
-
-    def __del__(self):
-        if getattr(self, "h", None):
-            self.lib.idocp_unocp_destroy(self.h)
-            self.h = None
-
-    def set_solution(self, name, value):
-        capi.check(self.lib.idocp_unocp_set_solution(self.h, name.encode(), P(arr(value))), "set_solution")
-
-    def set_solution_batch(self, name, values):
-        capi.check(self.lib.idocp_unocp_set_solution_batch(self.h, name.encode(), P(arr(values))), "set_solution_batch")
-
-    def update(self, t, q, v, line_search=False):
-        q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
-        v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
-        return self.lib.idocp_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)), 1 if line_search else 0)
-
-    def launch(self, kernel_id, q, v):
-        """one kernel of updateSolution (0 linearize, 1 / 2 Riccati backward / forward, 3 expand, 4 reduce steps, 5 integrate)"""
-        if getattr(self, "_dq", None) is None:
-            self._dq, self._dv = C.c_void_p(), C.c_void_p()
-            capi.check(self.lib.idocp_device_alloc(C.byref(self._dq), 8 * self.batch * self.nv), "alloc")
-            capi.check(self.lib.idocp_device_alloc(C.byref(self._dv), 8 * self.batch * self.nv), "alloc")
-        qq = arr(np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q)
-        vv = arr(np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v)
-        capi.check(self.lib.idocp_device_upload(self._dq, qq.ctypes.data, qq.nbytes), "upload")
-        capi.check(self.lib.idocp_device_upload(self._dv, vv.ctypes.data, vv.nbytes), "upload")
-        capi.check(self.lib.idocp_unocp_launch_kernel(self.h, kernel_id, self._dq, self._dv), "launch_kernel")
-        capi.check(self.lib.idocp_unocp_synchronize(self.h), "synchronize")
-
-    def clear_line_search_filter(self):
-        capi.check(self.lib.idocp_unocp_clear_line_search_filter(self.h), "clear_line_search_filter")
-
-    def cost_and_violation(self, alpha):
-        """UnLineSearch::computeCostAndViolation at s + alpha d (scalar or per instance) -> (cost[batch], violation[batch])"""
-        a = arr(np.broadcast_to(arr(alpha), (self.batch,)))
-        c, v = np.zeros(self.batch), np.zeros(self.batch)
-        capi.check(self.lib.idocp_unocp_line_search_eval(self.h, P(a), P(c), P(v)), "line_search_eval")
-        return c, v
-
-    def infeasible_stage(self):
-        ok, where = np.zeros(self.batch, dtype=np.int32), np.zeros(self.batch, dtype=np.int32)
-        capi.check(self.lib.idocp_unocp_is_current_solution_feasible(self.h, ok.ctypes.data_as(capi.c_int_p),
-                                                                     where.ctypes.data_as(capi.c_int_p)), "is_feasible")
-        assert np.all((where < 0) == (ok == 1))
-        return where
-
-    def kkt_error(self, t, q, v):
-        q = np.broadcast_to(arr(q), (self.batch, self.nv)) if np.ndim(q) == 1 else q
-        v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
-        capi.check(self.lib.idocp_unocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v))), "compute_kkt_residual")
-        out = np.zeros(self.batch)
-        capi.check(self.lib.idocp_unocp_kkt_error(self.h, P(out)), "kkt_error")
-        return out
-
-    def solution(self, name, instance=0):
-        out = np.zeros((self.N + 1, self.nv))
-        capi.check(self.lib.idocp_unocp_get_solution(self.h, name.encode(), instance, P(out)), "get_solution")
-        return out[:stages_of(name, self.N)]
-
-    def direction(self, name, instance=0):
-        out = np.zeros((self.N + 1, self.nv))
-        capi.check(self.lib.idocp_unocp_get_direction(self.h, name.encode(), instance, P(out)), "get_direction")
-        return out[:stages_of(name, self.N)]
-
-    def step_sizes(self):
-        a, b = np.zeros(self.batch), np.zeros(self.batch)
-        capi.check(self.lib.idocp_unocp_get_step_sizes(self.h, P(a), P(b)), "get_step_sizes")
-        return a, b
-
-    def riccati(self, instance=0):
-        nv, N = self.nv, self.N
-        Pm, s = np.zeros((N + 1, 2 * nv, 2 * nv)), np.zeros((N + 1, 2 * nv))
-        K, k = np.zeros((N, 2 * nv, nv)), np.zeros((N, nv))
-        capi.check(self.lib.idocp_unocp_get_riccati(self.h, instance, P(Pm), P(s), P(K), P(k)), "get_riccati")
-        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
-
-    def constraint_data(self, instance=0):
-        dimc = self.lib.idocp_unocp_dimc(self.h)
-        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
-        capi.check(self.lib.idocp_unocp_get_constraint_data(self.h, instance, P(sl), P(du)), "get_constraint_data")
-        return sl, du
-
-
-class HipUnParNMPC(HipUnOCP):
-    """Product path of UnParNMPCSolver through the C ABI (idocp_unparnmpc_* on the shared handle type); fields are [N][nv]."""
-
-    def __init__(self, model, cost, cons, T, N, batch=1, device=0):
-        self.lib = capi.lib()
-        self.N, self.nv, self.batch = N, model.nv, batch
-        h = C.c_void_p()
-        capi.check(self.lib.idocp_unparnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
-                   "idocp_unparnmpc_create")
-        self.h = h
-        self._dq = self._dv = None
-
-    def init(self, t=0.0):
-        capi.check(self.lib.idocp_unocp_init_constraints(self.h), "init_constraints")
-        capi.check(self.lib.idocp_unparnmpc_init_backward_correction(self.h, t), "init_backward_correction")
-
-    def _bc(self, x):
-        return arr(np.broadcast_to(arr(x), (self.batch, self.nv)) if np.ndim(x) == 1 else x)
-
-    def update(self, t, q, v, line_search=False):
-        return self.lib.idocp_unparnmpc_update_solution(self.h, t, P(self._bc(q)), P(self._bc(v)), 1 if line_search else 0)
-
-    def phase(self, phase, q, v):
-        """one phase of updateSolution (0 linearize ... 6 integrate) with (q, v) uploaded once"""
-        if self._dq is None:
-            self._dq, self._dv = C.c_void_p(), C.c_void_p()
-            capi.check(self.lib.idocp_device_alloc(C.byref(self._dq), 8 * self.batch * self.nv), "alloc")
-            capi.check(self.lib.idocp_device_alloc(C.byref(self._dv), 8 * self.batch * self.nv), "alloc")
-        qq, vv = self._bc(q), self._bc(v)
-        capi.check(self.lib.idocp_device_upload(self._dq, qq.ctypes.data, qq.nbytes), "upload")
-        capi.check(self.lib.idocp_device_upload(self._dv, vv.ctypes.data, vv.nbytes), "upload")
-        capi.check(self.lib.idocp_unparnmpc_launch_phase(self.h, phase, self._dq, self._dv), "launch_phase")
-        capi.check(self.lib.idocp_unocp_synchronize(self.h), "synchronize")
-
-    def kkt_error(self, t, q, v):
-        capi.check(self.lib.idocp_unparnmpc_compute_kkt_residual(self.h, t, P(self._bc(q)), P(self._bc(v))), "compute_kkt_residual")
-        out = np.zeros(self.batch)
-        capi.check(self.lib.idocp_unocp_kkt_error(self.h, P(out)), "kkt_error")
-        return out
-
-    def get(self, name, instance=0):
-        out = np.zeros((self.N + 1, self.nv))
-        if name.startswith("new_"):
-            capi.check(self.lib.idocp_unparnmpc_get_new_solution(self.h, name[4:].encode(), instance, P(out)), "get_new_solution")
-        elif name[0] == "d":
-            capi.check(self.lib.idocp_unocp_get_direction(self.h, name.encode(), instance, P(out)), "get_direction")
-        else:
-            capi.check(self.lib.idocp_unocp_get_solution(self.h, name.encode(), instance, P(out)), "get_solution")
-        return out[:self.N]
-
-
 def referee_check(g, o, h, what, tol=1e-10, factor=4.0, window=3):
     """Parity on an ill-conditioned problem, decided by a higher-precision referee.  g, o, h: the same quantity [stages, dim]
     from the GPU, the FP64 oracle and the long double build of the oracle (`hp=True`).  Stage by stage the GPU may be at most
@@ -429,158 +241,12 @@ def referee_check(g, o, h, what, tol=1e-10, factor=4.0, window=3):
     assert bad.size == 0, (what, "stage %d: gpu-referee %.2e, oracle-referee %.2e" % (bad[0], eg[bad[0]], eo_w[bad[0]]))
     return eg.max(), eo.max()
 
-
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
 # ------------------------------------------------------------------ contact path
-def anymal_model():
-    return capi.model_from_urdf(ANYMAL_URDF, ANYMAL_CONTACT_FRAMES)
-
-
-ANYMAL_Q_STANDING = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])
-
-
-def anymal_problem(model, trotting_ref=True):
-    """Cost / constraints of examples/anymal/anymal_trotting.cpp:33-107:
-    TrottingConfigurationSpaceCost + ContactForceCost, 6 joint limits + LinearizedFrictionCone(mu=0.7)."""
-    nv = model.nv
-    cost = capi.Cost()
-    cost.set("q_ref", ANYMAL_Q_STANDING)
-    cost.set("q_weight", np.full(nv, 10.0)).set("qf_weight", np.full(nv, 10.0))
-    vw = np.concatenate([np.ones(6), np.full(12, 0.1)])
-    aw = np.concatenate([np.full(6, 0.1), np.full(12, 0.01)])
-    cost.set("v_weight", vw).set("vf_weight", vw).set("a_weight", aw)
-    w = -model.total_mass * model.gravity[2]
-    for c in range(4):
-        for k in range(3):
-            cost.f_weight[c][k] = 0.001
-            cost.f_ref[c][k] = 0.0
-        cost.f_ref[c][2] = 0.25 * w                      # ContactForceCost::set_f_ref(robot)
-    if trotting_ref:
-        cost.use_trotting_ref = 1
-        cost.t_start, cost.t_period, cost.step_length = 0.5, 0.5, 0.15
-        cost.front_swing_knee, cost.hip_swing_knee = 1.7, 1.7
-        cost.front_stance_knee, cost.hip_stance_knee = 0.0, 0.0
-    # impulse-stage weights of the same example (:74-82, :93): qi = q, vi = v, dvi = a, fi = f weights
-    cost.set("qi_weight", np.full(nv, 10.0)).set("vi_weight", vw).set("dvi_weight", aw)
-    for c in range(4):
-        for k in range(3):
-            cost.fi_weight[c][k] = 0.001
-            cost.fi_ref[c][k] = 0.0
-    cons = capi.Constraints()
-    capi.lib().idocp_constraints_init(C.byref(cons))
-    cons.linearized_friction_cone = 1
-    cons.linearized_impulse_friction_cone = 1
-    cons.mu = 0.7
-    return cost, cons
-
-
-def trotting_sequence(solver, model, num_impulse_phases, t_start=0.5, t_period=0.5, step_length=0.15):
-    """Contact sequence of examples/anymal/anymal_trotting.cpp:141-177, transcribed as data: all feet ->
-    {LH, RF} at t_start -> {LF, RH} at t_start + t_period -> ... (feet advance by step_length)."""
-    pts = anymal_contact_points(model).copy()
-    solver.set_contact_status([1, 1, 1, 1], pts)
-    solver.push_back_contact_status([0, 1, 1, 0], pts, t_start)
-    pts[0, 0] += 0.5 * step_length
-    pts[3, 0] += 0.5 * step_length
-    solver.push_back_contact_status([1, 0, 0, 1], pts, t_start + t_period)
-    for i in range(2, num_impulse_phases + 1):
-        if i % 2 == 0:
-            pts[1, 0] += step_length
-            pts[2, 0] += step_length
-            solver.push_back_contact_status([0, 1, 1, 0], pts, t_start + i * t_period)
-        else:
-            pts[0, 0] += step_length
-            pts[3, 0] += step_length
-            solver.push_back_contact_status([1, 0, 0, 1], pts, t_start + i * t_period)
-
-
-ANYMAL_Q_RUNNING_START = ANYMAL_Q_STANDING.copy()
-ANYMAL_Q_RUNNING_START[0] = -3.0
-
-
-def running_problem(model, steps=10):
-    """Cost / constraints of examples/anymal/anymal_running.cpp:34-128 (BASELINE.json configs[4]):
-    TimeVaryingConfigurationSpaceCost (reference moving with stride / t_period inside the running window) +
-    ContactForceCost(f_ref = (0, 0, 70)), six joint limits, linearized (impulse) friction cones with mu = 0.8."""
-    nv = model.nv
-    stride, t_start = 0.4, 1.0
-    t_period = 0.135 + 0.05 + 0.165
-    cost = capi.Cost()
-    cost.set("q_ref", ANYMAL_Q_RUNNING_START)
-    qw = np.concatenate([np.ones(3), np.full(15, 10.0)])
-    vw = np.concatenate([np.full(3, 0.01), np.full(15, 0.1)])
-    aw = np.full(nv, 0.01)
-    cost.set("q_weight", qw).set("qf_weight", qw).set("qi_weight", qw)
-    cost.set("v_weight", vw).set("vf_weight", vw).set("vi_weight", vw)
-    cost.set("a_weight", aw).set("dvi_weight", aw)
-    v_ref = np.zeros(nv)
-    v_ref[0] = stride / t_period
-    cost.set("v_ref", v_ref)
-    cost.use_time_varying_ref = 1
-    cost.tv_t_begin, cost.tv_t_end = t_start, t_start + (0.5 + steps) * t_period
-    for c in range(4):
-        for k, wk in enumerate((1e-1, 1e-1, 1e-7)):
-            cost.f_weight[c][k] = wk
-            cost.fi_weight[c][k] = wk
-            cost.f_ref[c][k] = 0.0
-            cost.fi_ref[c][k] = 0.0
-        cost.f_ref[c][2] = 70.0
-    cons = capi.Constraints()
-    capi.lib().idocp_constraints_init(C.byref(cons))
-    cons.linearized_friction_cone = 1
-    cons.linearized_impulse_friction_cone = 1
-    cons.mu = 0.8
-    return cost, cons
-
-
-def running_sequence(solver, model, steps=10):
-    """Contact sequence of examples/anymal/anymal_running.cpp:137-215, transcribed as data: all feet -> hind feet {LH, RH}
-    -> flight -> front feet {LF, RF} -> hind feet -> ... -> all feet; 3 steps + 2 * (steps + 2) + ... = 6 + 3 steps + 4
-    discrete events.  Returns the number of events pushed."""
-    stride, hip, t_start = 0.4, 0.2, 1.0
-    t_fs, t_fhs, t_hs = 0.135, 0.05, 0.165
-    t_period = t_fs + t_fhs + t_hs
-    pts = anymal_contact_points(model, ANYMAL_Q_RUNNING_START).copy()
-    ALL, HIND, FRONT, NONE = [1, 1, 1, 1], [0, 1, 0, 1], [1, 0, 1, 0], [0, 0, 0, 0]
-    n = [0]
-
-    def push(status, t):
-        solver.push_back_contact_status(status, pts, t)
-        n[0] += 1
-    solver.set_contact_status(ALL, pts)
-    i_fs, i_fhs, i_hs = 0.125, 0.05, 0.125
-    t_initial = i_fs + i_fhs + i_hs
-    i_fs2, i_fhs2, i_hs2 = 0.135, 0.055, 0.15
-    t_initial2 = i_fs2 + i_fhs2 + i_hs2
-    push(HIND, t_start)
-    push(NONE, t_start + i_fs)
-    pts[[0, 2], 0] += 0.25 * stride
-    pts[[1, 3], 0] += 0.25 * stride + 0.5 * hip
-    push(FRONT, t_start + i_fs + i_fhs)
-    push(HIND, t_start + t_initial)
-    push(NONE, t_start + t_initial + i_fs2)
-    pts[[0, 2], 0] += 0.5 * stride
-    pts[[1, 3], 0] += 0.5 * stride + 0.5 * hip
-    push(FRONT, t_start + t_initial + i_fs2 + i_fhs2)
-    t_end_init = t_start + t_initial + t_initial2
-    for i in range(steps):
-        push(HIND, t_end_init + i * t_period)
-        push(NONE, t_end_init + i * t_period + t_fs)
-        pts[:, 0] += stride
-        push(FRONT, t_end_init + i * t_period + t_fs + t_fhs)
-    push(HIND, t_end_init + steps * t_period)
-    e_fs, e_fhs, e_hs = 0.15, 0.05, 0.15
-    push(NONE, t_end_init + steps * t_period + e_fs)
-    pts[[0, 2], 0] += 0.5 * stride
-    pts[[1, 3], 0] += 0.5 * stride - hip
-    push(FRONT, t_end_init + steps * t_period + e_fs + e_fhs)
-    push(ALL, t_end_init + steps * t_period + e_fs + e_fhs + e_hs)
-    return n[0]
-
 
 def _setup_oracle_ocp(lib):
     if getattr(lib, "_ocp_ready", False):
@@ -618,17 +284,6 @@ def _setup_oracle_ocp(lib):
     lib.oracle_ocp_get_chain.argtypes = [vp, cs, ci, dp]
     lib.oracle_ocp_get_riccati_chain.argtypes = [vp, dp, dp, dp, dp]
     lib._ocp_ready = True
-
-
-OCP_SOL_FIELDS = {"q": 19, "v": 18, "a": 18, "u": 12, "f": 12, "lmd": 18, "gmm": 18, "beta": 18, "mu": 12, "nu_passive": 6}
-OCP_DIR_FIELDS = {"dq": 18, "dv": 18, "da": 18, "du": 12, "df": 12, "dlmd": 18, "dgmm": 18, "dbeta": 18, "dmu": 12,
-                  "dnu_passive": 6}
-OCP_STAGE_ONLY = ("a", "u", "f", "beta", "mu", "nu_passive", "da", "du", "df", "dbeta", "dmu", "dnu_passive")
-
-
-OCP_CHAIN_EXTRA = {"xi": 12, "dxi": 12}
-NODE_KINDS = ("stage", "impulse", "aux", "lift", "terminal")
-
 
 class OracleOCP:
     def __init__(self, model, cost, cons, T, N, max_num_impulse=0, hp=False):
@@ -733,7 +388,6 @@ class OracleOCP:
         lx, lu, Fx = np.zeros(nx), np.zeros(nu), np.zeros(nx)
         self.lib.oracle_ocp_get_lqr_stage(self.h, i, P(Qxx), P(Qxu), P(Quu), P(A), P(B), P(lx), P(lu), P(Fx))
         return Qxx.T, Qxu.T, Quu.T, A.T, B.T, lx, lu, Fx
-
 
 class OracleParNMPC:
     """ParNMPCSolver of the oracle: examples/anymal/parnmpc_benchmark.cpp call order; with max_num_impulse > 0 also horizons
@@ -847,209 +501,6 @@ class OracleParNMPC:
         self.lib.oracle_parnmpc_get_step_sizes(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
-
-def anymal_contact_points(model, q_at=None):
-    """World positions of the four feet at q_standing (robot.getContactPoints after
-    updateFrameKinematics(q_standing), examples/anymal/anymal_trotting.cpp:141-143): problem set-up, done by the PRODUCT's host
-    kinematics (idocp_model_contact_positions) so that neither bench.py nor the GPU tests route their inputs through the
-    oracle; tests/test_capi_symbols.py checks that entry against the oracle's frame kinematics."""
-    q = arr(ANYMAL_Q_STANDING if q_at is None else q_at)
-    pts = np.zeros((model.ncontacts, 3))
-    capi.check(capi.lib().idocp_model_contact_positions(C.byref(model), P(q), P(pts)), "idocp_model_contact_positions")
-    return pts
-
-
-class HipOCP:
-    """Contact path through the C ABI (idocp_ocp_*)."""
-
-    def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
-        self.lib = capi.lib()
-        self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
-        self.max_events = max_num_impulse
-        h = C.c_void_p()
-        if max_num_impulse > 0:
-            capi.check(self.lib.idocp_ocp_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse, batch,
-                                                        device, C.byref(h)), "idocp_ocp_create_hybrid")
-        else:
-            capi.check(self.lib.idocp_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
-                       "idocp_ocp_create")
-        self.h = h
-
-    # ---- contact sequences with discrete events
-    def push_back_contact_status(self, active, points, switching_time):
-        a = (C.c_int * 4)(*[int(x) for x in active])
-        capi.check(self.lib.idocp_ocp_push_back_contact_status(self.h, a, P(arr(points)), switching_time), "push_back_contact_status")
-
-    def set_contact_points(self, phase, points):
-        capi.check(self.lib.idocp_ocp_set_contact_points(self.h, phase, P(arr(points))), "set_contact_points")
-
-    def chain(self, t):
-        cap = self.N + 1 + 3 * max(self.max_events, 1)
-        IA = lambda: (C.c_int * cap)()
-        kind, index, slot, dimf, sw = IA(), IA(), IA(), IA(), IA()
-        dt = np.zeros(cap)
-        M = self.lib.idocp_ocp_get_chain(self.h, t, cap, kind, index, slot, P(dt), dimf, sw)
-        assert M > 0, capi.lib().idocp_last_error()
-        return [dict(kind=NODE_KINDS[kind[p]], index=index[p], slot=slot[p], dt=dt[p], dimf=dimf[p], sw_dimi=sw[p]) for p in range(M)]
-
-    def get_chain(self, name, M, instance=0):
-        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or OCP_CHAIN_EXTRA[name]
-        out = np.zeros((M, dim))
-        fn = self.lib.idocp_ocp_get_solution_chain if (name in OCP_SOL_FIELDS or name == "xi") else self.lib.idocp_ocp_get_direction_chain
-        capi.check(fn(self.h, name.encode(), instance, P(out)), "get_chain")
-        return out
-
-    def riccati_chain(self, M, instance=0):
-        nv, nu = self.nv, self.nu
-        Pm, s = np.zeros((M, 2 * nv, 2 * nv)), np.zeros((M, 2 * nv))
-        K, k = np.zeros((M - 1, 2 * nv, nu)), np.zeros((M - 1, nu))
-        capi.check(self.lib.idocp_ocp_get_riccati_chain(self.h, instance, P(Pm), P(s), P(K), P(k)), "get_riccati_chain")
-        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
-
-    def __del__(self):
-        if getattr(self, "h", None):
-            self.lib.idocp_ocp_destroy(self.h)
-            self.h = None
-
-    def set_contact_status(self, active, points):
-        a = (C.c_int * 4)(*[int(x) for x in active])
-        capi.check(self.lib.idocp_ocp_set_contact_status_uniformly(self.h, a, P(arr(points))), "set_contact_status")
-
-    def set_solution(self, name, value):
-        capi.check(self.lib.idocp_ocp_set_solution(self.h, name.encode(), P(arr(value))), "set_solution")
-
-    def set_solution_batch(self, name, values):
-        capi.check(self.lib.idocp_ocp_set_solution_batch(self.h, name.encode(), P(arr(values))), "set_solution_batch")
-
-    def init_constraints(self, t=0.0):
-        capi.check(self.lib.idocp_ocp_init_constraints(self.h, t), "init_constraints")
-
-    def _bc(self, x, dim):
-        x = arr(x)
-        return arr(np.broadcast_to(x, (self.batch, dim))) if x.ndim == 1 else x
-
-    def update(self, t, q, v):
-        return self.lib.idocp_ocp_update_solution(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv)), 0)
-
-    def infeasible_stage(self):
-        ok, where = np.zeros(self.batch, dtype=np.int32), np.zeros(self.batch, dtype=np.int32)
-        capi.check(self.lib.idocp_ocp_is_current_solution_feasible(self.h, ok.ctypes.data_as(capi.c_int_p),
-                                                                   where.ctypes.data_as(capi.c_int_p)), "is_feasible")
-        assert np.all((where < 0) == (ok == 1))
-        return where
-
-    def kkt_error(self, t, q, v):
-        capi.check(self.lib.idocp_ocp_compute_kkt_residual(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv))),
-                   "compute_kkt_residual")
-        out = np.zeros(self.batch)
-        capi.check(self.lib.idocp_ocp_kkt_error(self.h, P(out)), "kkt_error")
-        return out
-
-    def get(self, name, instance=0):
-        if name in OCP_SOL_FIELDS:
-            dim, fn = OCP_SOL_FIELDS[name], self.lib.idocp_ocp_get_solution
-        else:
-            dim, fn = OCP_DIR_FIELDS[name], self.lib.idocp_ocp_get_direction
-        out = np.zeros((self.N + 1, dim))
-        capi.check(fn(self.h, name.encode(), instance, P(out)), "get " + name)
-        return out[:self.N] if name in OCP_STAGE_ONLY else out
-
-    def step_sizes(self):
-        a, b = np.zeros(self.batch), np.zeros(self.batch)
-        capi.check(self.lib.idocp_ocp_get_step_sizes(self.h, P(a), P(b)), "get_step_sizes")
-        return a, b
-
-    def riccati(self, instance=0):
-        nv, nu, N = self.nv, self.nu, self.N
-        Pm, s = np.zeros((N + 1, 2 * nv, 2 * nv)), np.zeros((N + 1, 2 * nv))
-        K, k = np.zeros((N, 2 * nv, nu)), np.zeros((N, nu))
-        capi.check(self.lib.idocp_ocp_get_riccati(self.h, instance, P(Pm), P(s), P(K), P(k)), "get_riccati")
-        return Pm.transpose(0, 2, 1), s, K.transpose(0, 2, 1), k
-
-    def constraint_data(self, instance=0):
-        dimc = self.lib.idocp_ocp_dimc(self.h)
-        sl, du = np.zeros((self.N, dimc)), np.zeros((self.N, dimc))
-        capi.check(self.lib.idocp_ocp_get_constraint_data(self.h, instance, P(sl), P(du)), "get_constraint_data")
-        return sl, du
-
-    def lqr_stage(self, i, instance=0):
-        nv, nu = self.nv, self.nu
-        nx = 2 * nv
-        Qxx, Qxu, Quu, A, B = np.zeros((nx, nx)), np.zeros((nu, nx)), np.zeros((nu, nu)), np.zeros((nx, nx)), np.zeros((nu, nx))
-        lx, lu, Fx = np.zeros(nx), np.zeros(nu), np.zeros(nx)
-        capi.check(self.lib.idocp_ocp_get_lqr_stage(self.h, instance, i, P(Qxx), P(Qxu), P(Quu), P(A), P(B), P(lx), P(lu), P(Fx)),
-                   "get_lqr_stage")
-        return Qxx.T, Qxu.T, Quu.T, A.T, B.T, lx, lu, Fx
-
-
-class HipParNMPC(HipOCP):
-    """ParNMPCSolver through the C ABI (idocp_parnmpc_* + the shared idocp_ocp_* entry points)."""
-
-    def set_stage_values(self, name, values):
-        """warm start: one field of stages 0 .. len(values) - 1, all instances"""
-        values = arr(values)
-        capi.check(self.lib.idocp_ocp_set_solution_stages(self.h, name.encode(), values.shape[0], P(values)), "set_solution_stages " + name)
-
-    def set_aux_mats(self, mats):
-        """warm start: aux_mat [stages, nx, nx] (row, col)"""
-        cm = arr(np.asarray(mats).transpose(0, 2, 1))      # column-major per stage
-        capi.check(self.lib.idocp_parnmpc_set_aux_mat(self.h, cm.shape[0], P(cm)), "set_aux_mat")
-
-    def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
-        self.lib = capi.lib()
-        self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
-        self.max_events = max_num_impulse
-        h = C.c_void_p()
-        if max_num_impulse > 0:
-            capi.check(self.lib.idocp_parnmpc_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse, batch, device,
-                                                            C.byref(h)), "idocp_parnmpc_create_hybrid")
-        else:
-            capi.check(self.lib.idocp_parnmpc_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
-                       "idocp_parnmpc_create")
-        self.h = h
-
-    def init(self, t=0.0):
-        capi.check(self.lib.idocp_parnmpc_init_backward_correction(self.h, t), "init_backward_correction")
-        self.init_constraints(t)
-
-    def update(self, t, q, v):
-        return self.lib.idocp_parnmpc_update_solution(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv)), 0)
-
-    def kkt_error(self, t, q, v):
-        capi.check(self.lib.idocp_parnmpc_compute_kkt_residual(self.h, t, P(self._bc(q, self.nq)), P(self._bc(v, self.nv))),
-                   "compute_kkt_residual")
-        out = np.zeros(self.batch)
-        capi.check(self.lib.idocp_ocp_kkt_error(self.h, P(out)), "kkt_error")
-        return out
-
-    def get(self, name, instance=0):
-        if name in OCP_SOL_FIELDS:
-            dim, fn = OCP_SOL_FIELDS[name], self.lib.idocp_ocp_get_solution
-        else:
-            dim, fn = OCP_DIR_FIELDS[name], self.lib.idocp_ocp_get_direction
-        out = np.zeros((self.N, dim))
-        capi.check(fn(self.h, name.encode(), instance, P(out)), "get " + name)
-        return out
-
-
-def warm_start_parnmpc(ocp, targets, N):
-    """The well-posed N = 256 workload of BASELINE configs[3]: ParNMPC started, like in an MPC loop, from the converged Riccati
-    solution of the same problem -- stage i of ParNMPC lives at the time of grid stage i + 1 of the OCP: (q, v, lmd, gmm) and
-    aux_mat = P of stage i + 1, (a, u, f, beta, mu) of stage min(i + 1, N - 1).  From the reference's cold start (aux_mat = terminal
-    Hessian everywhere) the forward correction sweep amplifies by 1.15 per stage and the first direction reaches 3e12 at N = 256;
-    from here it is O(1) and the iteration converges.  `ocp`: a converged OracleOCP / HipOCP; `targets`: ParNMPC solvers."""
-    sol = {f: np.asarray(ocp.get(f)) for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu")}
-    Pm = ocp.riccati()[0]
-    vals = {f: sol[f][1:N + 1] for f in ("q", "v", "lmd", "gmm")}
-    for f in ("a", "u", "f", "beta", "mu"):
-        vals[f] = np.stack([sol[f][min(i + 1, N - 1)] for i in range(N)])
-    aux = Pm[1:N + 1]
-    for t in targets:
-        for f, v in vals.items():
-            t.set_stage_values(f, v)
-        t.set_aux_mats(aux)
-
-
 class OracleParNMPCShard:
     """Shard backend of idocp_amd.parnmpc_dist.ShardedParNMPC on top of the oracle (one instance, CPU tensors)."""
     PHASES = {"linearize": 0, "bwd_serial": 1, "bwd_parallel": 2, "fwd_serial": 3, "fwd_parallel": 4, "integrate": 5}
@@ -1101,7 +552,6 @@ class OracleParNMPCShard:
     def err2(self, t):
         import torch
         return torch.tensor([self.o.lib.oracle_parnmpc_kkt_error_squared(self.o.h, t, P(self.q_prev), P(self.v_prev))], dtype=torch.float64)
-
 
 class OracleUnParNMPCShard:
     """Shard backend of idocp_amd.parnmpc_dist.ShardedParNMPC on top of the fixed-base oracle (one instance, CPU tensors):

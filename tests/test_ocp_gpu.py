@@ -172,3 +172,37 @@ def test_full_size_properties_c3():
     assert np.abs(Pm - Pm.transpose(0, 2, 1)).max() < 1e-8 * np.abs(Pm).max()
     sl, du = g.constraint_data(5)
     assert (sl[2:] > 0).all() and (du[2:] > 0).all()
+
+
+def test_clone_is_a_deep_copy_of_the_solver_state():
+    """idocp_ocp_clone (the copy constructor of the facade's OCPSolver / ParNMPCSolver; the reference's classes are copyable): the
+    copy continues exactly like the original, and the two do not share state."""
+    import copy
+    import ctypes as C
+    from idocp_amd import capi
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    g = HipOCP(m, cost, cons, 0.5, 10, batch=2)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    g.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+    g.set_solution("q", q)
+    g.set_solution("v", v)
+    g.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    g.init_constraints(0.0)
+    q[7:] += 0.03
+    for _ in range(2):
+        assert g.update(0.0, q, v) == 0
+    h2 = C.c_void_p()
+    capi.check(g.lib.idocp_ocp_clone(g.h, C.byref(h2)), "clone")
+    c = copy.copy(g)
+    c.h = h2
+    before = {f: g.get(f, 1).copy() for f in ("q", "v", "lmd")}
+    for _ in range(2):
+        assert c.update(0.0, q, v) == 0
+    for f in before:                                    # the original did not move
+        assert np.array_equal(g.get(f, 1), before[f])
+    for _ in range(2):
+        assert g.update(0.0, q, v) == 0
+    for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu"):
+        assert np.array_equal(g.get(f, 1), c.get(f, 1)), f
+    assert np.array_equal(g.kkt_error(0.0, q, v), c.kkt_error(0.0, q, v))
