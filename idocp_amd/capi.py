@@ -236,6 +236,9 @@ def _proto(lib):
         ("idocp_parnmpc_dist_kkt_error", [vp, cd, c_double_p]),
         ("idocp_ocp_batch", [vp]),
         ("idocp_ocp_clone", [vp, C.POINTER(vp)]),
+        ("idocp_ocp_clear_line_search_filter", [vp]),
+        ("idocp_ocp_compute_direction", [vp, cd, c_double_p, c_double_p]),
+        ("idocp_ocp_line_search_eval", [vp, c_double_p, c_double_p, c_double_p]),
         ("idocp_ocp_synchronize", [vp]),
         ("idocp_ocp_compute_kkt_residual", [vp, cd, c_double_p, c_double_p]),
         ("idocp_ocp_kkt_error", [vp, c_double_p]),

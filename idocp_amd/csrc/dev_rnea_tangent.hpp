@@ -451,6 +451,23 @@ __device__ __forceinline__ void rneaAssembleA(int lane, double* sc, const RneaOu
   }
 }
 
+// ---- nominal values only (the line search evaluates residuals, no derivatives): base rows of ID and the pose part of C ----
+template <typename D>
+__device__ __forceinline__ void rneaAssembleNominal(int tid, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  constexpr int NL = D::NL, NV = D::NV, NC = D::NC;
+  if (tid < 6) {
+    double acc = sc[S::BN + tid];
+    for (int leg = 0; leg < NL; ++leg) acc += sc[S::BN + 6 * (1 + leg) + tid];
+    out.idc[tid] = acc;
+  }
+  if (tid >= 64 && tid < 64 + 3 * NC) {
+    const int c = (tid - 64) / 3, x = tid - 64 - 3 * c;
+    const double* fr = sc + S::FEET + c * S::FREC;
+    if (fr[S::F_ACT] != 0.0) out.idc[NV + (int)fr[S::F_ROW] + x] += fr[S::F_CP + x];
+  }
+}
+
 // ---- after the q / v items, all threads: base rows of the q and v columns, nominal base rows, and the pose-dependent terms ----
 //   dC/dq[contact rows of leg c, :] += (1 / D^2) (R_wf Rc) J[contact rows of leg c, :]
 template <typename D>

@@ -126,6 +126,9 @@ struct idocp_ocp {
   hipGraphExec_t graph_exec = nullptr;
   const double *graph_q = nullptr, *graph_v = nullptr;
   bool launched_eagerly = false;
+  // filter line search (LineSearchFilter, src/line_search/line_search_filter.cpp): one filter per instance
+  std::vector<std::vector<std::pair<double, double>>> filters;
+  OcpNode* d_nodes_ls = nullptr;
 };
 
 namespace {
@@ -297,6 +300,16 @@ int discretize(idocp_ocp* h, double t) {
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
+  // The chain as the line search pairs it (line_search.cpp:80-113): the state-equation residual of a grid stage in front of an
+  // impulse / lift is evaluated against the NEXT GRID STAGE (the value computed against the event stage is overwritten there).
+  std::vector<OcpNode> chain_ls = h->chain;
+  for (int p = 0; p + 1 < M; ++p)
+    if (chain_ls[p].kind == 0 && (chain_ls[p + 1].kind == 1 || chain_ls[p + 1].kind == 3)) {
+      int pn = p + 2;
+      while (pn < M && chain_ls[pn].kind != 0 && chain_ls[pn].kind != 4) ++pn;
+      if (pn < M) chain_ls[p].next = chain_ls[pn].slot;
+    }
+  HIP_TRY(hipMemcpyAsync(h->d_nodes_ls, chain_ls.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
   std::vector<int> ipos;
   for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
   h->n_impulse = (int)ipos.size();
@@ -601,6 +614,12 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &B.step, (size_t)batch * 2))) return fail(rc);
   if ((rc = allocBufO(h, &B.err_stage, ns))) return fail(rc);
   if ((rc = allocBufO(h, &B.err, (size_t)batch))) return fail(rc);
+  if ((rc = allocBufO(h, &B.sol_try, ns * LQ::SOL))) return fail(rc);
+  if ((rc = allocBufO(h, &B.merit_stage, ns * 4))) return fail(rc);
+  if ((rc = allocBufO(h, &B.merit, (size_t)batch * 2))) return fail(rc);
+  if ((rc = allocBufO(h, &B.ls_alpha, (size_t)batch))) return fail(rc);
+  { double* tmp_ls = nullptr; if ((rc = allocBufO(h, &tmp_ls, ((size_t)h->NS * sizeof(OcpNode) + 7) / 8))) return fail(rc); h->d_nodes_ls = reinterpret_cast<OcpNode*>(tmp_ls); B.nodes_ls = h->d_nodes_ls; }
+  h->filters.assign(batch, {});
   if ((rc = allocBufO(h, &h->d_q0, (size_t)batch * DQ::NQ))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_v0, (size_t)batch * DQ::NV))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
@@ -943,12 +962,126 @@ int idocp_ocp_synchronize(idocp_ocp_t* h) {
 }
 void* idocp_ocp_stream(idocp_ocp_t* h) { return h ? (void*)h->stream : nullptr; }
 
-int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v, int line_search) {
+// LineSearch::computeCostAndViolation (src/line_search/line_search.cpp:63-196) of s (+) alpha[b] d for every instance: trial
+// iterate + barrier cost (ocp_trial_kernel), then the rigid-body residual kernels and the MERIT variant of the condensation
+// kernel on a copy of the buffers whose `sol` is the trial iterate, then the sums over the chain.  out[2 b] = cost, [2 b + 1] = violation.
+static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, const double* d_q, std::vector<double>& out) {
+  const int M = h->M();
+  HIP_TRY(hipMemcpyAsync(h->B.ls_alpha, alpha.data(), sizeof(double) * h->batch, hipMemcpyHostToDevice, h->stream));
+  OcpLaunch<DQ>::trialIterate(h->B, h->batch, M, h->stream);
+  OcpBuffers Bt = h->B;
+  Bt.sol = h->B.sol_try; Bt.nodes = h->B.nodes_ls;
+  OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(Bt, h->batch, M, h->stream);
+  OcpLaunch<DQ>::merit(Bt, h->batch, M, d_q, h->stream);
+  OcpLaunch<DQ>::meritReduce(h->B, h->batch, h->stream);
+  HIP_TRY(hipGetLastError());
+  out.resize((size_t)h->batch * 2);
+  HIP_TRY(hipMemcpyAsync(out.data(), h->B.merit, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+// LineSearch::computeStepSize (include/idocp/line_search/line_search.hpp:62-92) for every instance of the batch; the filter
+// (line_search_filter.cpp:33-63, defaults line_search_filter.hpp:16-17, line_search.hpp:25-26) runs on the host.  On return
+// B.step holds the accepted primal step of every instance.
+static int runLineSearchO(idocp_ocp_t* h, const double* d_q) {
+  const double cost_rate = 0.005, con_rate = 0.005, reduction = 0.75, min_step = 0.05;
+  const int B = h->batch;
+  auto accepted = [](const std::vector<std::pair<double, double>>& f, double c, double v) {
+    for (const auto& p : f) if (c >= p.first && v >= p.second) return false;
+    return true;
+  };
+  auto augment = [&](std::vector<std::pair<double, double>>& f, double c, double v) {
+    for (auto it = f.begin(); it != f.end();) { if (c <= it->first && v <= it->second) it = f.erase(it); else ++it; }
+    f.push_back({c - cost_rate * v, (1 - con_rate) * v});
+  };
+  std::vector<double> step((size_t)B * 2), alpha(B, 0.0), cv;
+  int rc;
+  bool any_empty = false;
+  for (int b = 0; b < B; ++b) any_empty = any_empty || h->filters[b].empty();
+  if (any_empty) {                                  // "if filter is empty, augment the current solution to the filter"
+    if ((rc = lineSearchEvalO(h, alpha, d_q, cv))) return rc;
+    for (int b = 0; b < B; ++b) if (h->filters[b].empty()) augment(h->filters[b], cv[2 * b], cv[2 * b + 1]);
+  }
+  HIP_TRY(hipMemcpyAsync(step.data(), h->B.step, sizeof(double) * step.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<char> done(B, 0);
+  int open = 0;
+  for (int b = 0; b < B; ++b) { alpha[b] = step[2 * b]; if (!(alpha[b] > min_step)) done[b] = 1; else ++open; }
+  while (open > 0) {
+    if ((rc = lineSearchEvalO(h, alpha, d_q, cv))) return rc;
+    for (int b = 0; b < B; ++b) {
+      if (done[b]) continue;
+      if (accepted(h->filters[b], cv[2 * b], cv[2 * b + 1])) { augment(h->filters[b], cv[2 * b], cv[2 * b + 1]); done[b] = 1; --open; continue; }
+      alpha[b] *= reduction;
+      if (!(alpha[b] > min_step)) { done[b] = 1; --open; }
+    }
+  }
+  for (int b = 0; b < B; ++b) step[2 * b] = alpha[b] > min_step ? alpha[b] : min_step;
+  HIP_TRY(hipMemcpyAsync(h->B.step, step.data(), sizeof(double) * step.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));         // `step` is a stack temporary
+  return IDOCP_OK;
+}
+
+// linearise + Riccati + direction + step sizes WITHOUT integrating (kernels 0 .. 5): the state in which
+// idocp_ocp_line_search_eval probes trial steps
+int idocp_ocp_compute_direction(idocp_ocp_t* h, double t, const double* q, const double* v) {
   if (!h || !q || !v) return IDOCP_E_ARG;
-  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  if (!h->contact_status_set) { set_last_error("idocp_ocp_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
+  if ((rc = discretize(h, t))) return rc;
+  const int M = h->M();
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
+  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
+  launchCondenseO(h, M, h->d_q0);
+  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, h->d_q0, h->d_v0, h->stream);
+  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+// (total cost, total constraint violation) of s (+) alpha[b] d for every instance (alpha = 0: the iterate itself, current slacks)
+int idocp_ocp_line_search_eval(idocp_ocp_t* h, const double* alpha, double* cost, double* violation) {
+  if (!h || !alpha || !cost || !violation) return IDOCP_E_ARG;
+  if (h->parnmpc) { set_last_error("idocp_ocp_line_search_eval: OCPSolver handles only"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDev(h); if (rc) return rc;
+  std::vector<double> a(alpha, alpha + h->batch), cv;
+  if ((rc = lineSearchEvalO(h, a, h->d_q0, cv))) return rc;
+  for (int b = 0; b < h->batch; ++b) { cost[b] = cv[2 * b]; violation[b] = cv[2 * b + 1]; }
+  return IDOCP_OK;
+}
+int idocp_ocp_clear_line_search_filter(idocp_ocp_t* h) {
+  if (!h) return IDOCP_E_ARG;
+  for (auto& f : h->filters) f.clear();
+  return IDOCP_OK;
+}
+
+int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v, int line_search) {
+  if (!h || !q || !v) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
+  if (line_search) {
+    // OCPSolver::updateSolution(t, q, v, true) (ocp_solver.cpp:67-92): direction, filter line search on the primal step, integration
+    if (!h->contact_status_set) { set_last_error("idocp_ocp_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
+    if ((rc = discretize(h, t))) return rc;
+    const int M = h->M();
+    HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+    OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
+    if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
+    launchCondenseO(h, M, h->d_q0);
+    OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+    OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, h->d_q0, h->d_v0, h->stream);
+    OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+    HIP_TRY(hipGetLastError());
+    if ((rc = runLineSearchO(h, h->d_q0))) return rc;
+    OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
+    HIP_TRY(hipGetLastError());
+  } else
   if ((rc = idocp_ocp_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
   std::vector<int> st(h->batch);
   HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));

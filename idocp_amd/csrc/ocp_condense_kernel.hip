@@ -79,7 +79,7 @@ struct CondenseSmem {
   static constexpr int BL = TMP, SM = BL + NF * NV, BR = SM + NF * NF, TMP_LATE = BR + NF * NF - TMP;
   static constexpr int VEC = TMP + (TMP_EARLY > TMP_LATE ? TMP_EARLY : TMP_LATE);
   static_assert(NVF * NV <= IDC - MM, "Qafu_full must fit in the M / J blocks");
-  static_assert(256 <= NVF * NVF, "ERR aliases MJ");
+  static_assert(512 <= NVF * NVF, "ERR (two accumulators per thread in the MERIT variant) aliases MJ");
   // vectors
   static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
                        LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV, JQ = BM + 32, FQQ = JQ + 36, FQQP = FQQ + 36,
@@ -94,7 +94,11 @@ struct CondenseSmem {
 // places: FQQ = dSubtract_dPlus(q, q_next), FQQP = dSubtract_dMinus(q_prev, q), FQQI = dSubtract_dPlus(q_prev, q)^-1,
 // FQ6 = (q_prev (-) q).head(6) (parnmpc_lie_kernel).  The chain ends with an unused placeholder stage; the last real
 // stage (position M - 2) carries the terminal cost.
-template <typename D, bool RESIDUAL, int DIMF, bool BWD = false>
+// MERIT = true (with RESIDUAL): the filter line search's evaluation of a trial iterate (src/line_search/line_search.cpp:63-196):
+// per stage SplitOCP::stageCost without the barrier term (split_ocp.hxx:270-289; the barrier part comes from ocp_trial_kernel) and
+// SplitOCP::constraintViolation (:292-346), |Fx|_1 + dt |[ID - u; C]|_1 + dt |g + slack|_1 + |P|_1; only the NOMINAL rigid-body
+// sweeps run (no tangent items).  Launched on a copy of the buffers whose sol points at the trial iterate.
+template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = false>
 __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
@@ -227,14 +231,21 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         lq = P->qf_weight[r] * (q[r + 1] - qref[r + 1]) - s[L::S_LMD + r];
       }
       lv = P->vf_weight[r] * (s[L::S_V + r] - (r == 0 ? v_ref0 : vref_on * P->v_ref[r])) - s[L::S_GMM + r];
-      if (RESIDUAL) { sm[S::ERR + tid] = lq * lq + lv * lv; }
+      if (MERIT) {      // TerminalOCP::terminalCost (terminal_ocp.hxx:81-87)
+        const double qd = r < 6 ? sm[S::QDIFF + r] : q[r + 1] - qref[r + 1], dvr = s[L::S_V + r] - (r == 0 ? v_ref0 : vref_on * P->v_ref[r]);
+        sm[S::ERR + tid] = 0.5 * (P->qf_weight[r] * qd * qd + P->vf_weight[r] * dvr * dvr);
+      }
+      else if (RESIDUAL) { sm[S::ERR + tid] = lq * lq + lv * lv; }
       else { kk[L::K_LX + r] = lq; kk[L::K_LX + NV + r] = lv; }
     } else if (RESIDUAL) {
       sm[S::ERR + tid] = 0.0;
     }
     if (RESIDUAL) {
       __syncthreads();
-      if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[rec] = e; }
+      if (tid == 0) {
+        double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t];
+        if (MERIT) { B.merit_stage[rec * 4] = e; B.merit_stage[rec * 4 + 1] = 0.0; } else B.err_stage[rec] = e;
+      }
       return;
     }
     for (int e = tid; e < NX * NX; e += nt) {
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* slack = &sm[S::SLK];
   const double* dual = &sm[S::DUL];
   double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below), per thread
+  double merit_cost = 0.0, merit_viol = 0.0; // MERIT: this thread's share of the stage cost / l1 constraint violation
   if (wave == 0) {
     if (!impulse) rneaNominalMotion<D>(gz, bwv, lane, sc, out);
   } else if (wave == 1) {
@@ -289,6 +301,11 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     ha = dt * w_a[r];
     const double fv = BWD ? (vpr - vr + dt * ar) : (vr + dt * ar - sn[L::S_V + r]);
     sm[S::FV + r] = fv;
+    if (MERIT) {      // (Trotting / TimeVarying)ConfigurationSpaceCost::computeStageCost / computeImpulseCost; |Fq|_1 + |Fv|_1
+      const double qd = r < 6 ? sm[S::QDIFF + r] : q[r + 1] - qref[r + 1], dvr = vr - (r == 0 ? v_ref0 : vref_on * P->v_ref[r]);
+      merit_cost += 0.5 * dt * (w_q[r] * qd * qd + w_v[r] * dvr * dvr + w_a[r] * ar * ar);
+      merit_viol += fabs(fq) + fabs(fv);
+    }
     if (last) {
       // TerminalParNMPC: + terminal cost (computeTerminalCostDerivatives / Hessian) on the last stage
       if (r < 6) {
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         const double sl = slack[c * NU + j], du = dual[c * NU + j];
         const double res = sgn * (x - ocpLimit(P, c, j)) + sl, duality = sl * du - P->barrier;
         double g = sgn * dt * du, h = 0.0;
+        if (MERIT) merit_viol += dt * fabs(res);
         if (RESIDUAL) err_ipm += res * res + duality * duality;
         else { g += sgn * dt * (du * res - duality) / sl; h = dt * du / sl; }
         if (c < 2) { lq += g; hq += h; } else { lv += g; hv += h; }
@@ -338,11 +356,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     double lu = dt * P->u_weight[j] * (u - P->u_ref[j]) - dt * s[L::S_BETA + 6 + j];
     double h = dt * P->u_weight[j];
     if (impulse) { lu = 0.0; h = 1.0; }
+    if (MERIT && !impulse) merit_cost += 0.5 * dt * P->u_weight[j] * (u - P->u_ref[j]) * (u - P->u_ref[j]);
     for (int c = 4; c < 6; ++c) {
       if (!ocpRowValid(P, c, i, impulse)) continue;
       const double sgn = (c & 1) ? 1.0 : -1.0;
       const double sl = slack[c * NU + j], du = dual[c * NU + j];
       const double res = sgn * (u - ocpLimit(P, c, j)) + sl, duality = sl * du - P->barrier;
+      if (MERIT) merit_viol += dt * fabs(res);
       lu += sgn * dt * du;
       if (RESIDUAL) err_ipm += res * res + duality * duality;
       else { lu += sgn * dt * (du * res - duality) / sl; h += dt * du / sl; }
@@ -366,6 +386,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         f[x] = s[L::S_F + 3 * c + x];
         const double wf = impulse ? P->fi_weight[c][x] : P->f_weight[c][x], rf = impulse ? P->fi_ref[c][x] : P->f_ref[c][x];
         lf[x] = dt * wf * (f[x] - rf);
+        if (MERIT) merit_cost += 0.5 * dt * wf * (f[x] - rf) * (f[x] - rf);      // ContactForceCost::computeStageCost / computeImpulseCost
         if (!RESIDUAL) sm[S::QFF + (row + x) + SF * (row + x)] = dt * wf;
         sm[S::BM + NV + row + x] = s[L::S_MU + 3 * c + x];
       }
@@ -378,6 +399,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
           for (int x = 0; x < 3; ++x) g += frictionJacEntry(P->mu, r, x) * f[x];
           const double res = g + sl, duality = sl * du - P->barrier;
           double coef = du;
+          if (MERIT) merit_viol += dt * fabs(res);
           if (RESIDUAL) err_ipm += res * res + duality * duality;
           else coef += (du * res - duality) / sl;
           dd[r] = du / sl;
@@ -409,6 +431,21 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   __syncthreads();
   STAMP(2);
+  if (MERIT) {
+    // nominal [ID - u; C] (contact_dynamics.hxx:202-217; impulse stages: [ImD; C] from the lin record), the switching-constraint
+    // residual P (forward_switching_constraint.hxx:27-47, from ocp_switch_kernel on the trial iterate), and the stage's totals
+    if (!impulse) rneaAssembleNominal<D>(tid, sc, out);
+    __syncthreads();
+    if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];
+    __syncthreads();
+    if (tid < dimvf) merit_viol += dt * fabs(sm[S::IDC + tid]);
+    if (sw_dimi > 0 && tid >= 200 && tid < 200 + sw_dimi) merit_viol += fabs(B.swc[rec * L::SWC + L::W_P + tid - 200]);
+    __syncthreads();                                                   // ERR aliases the scratch
+    sm[S::ERR + tid] = merit_cost; sm[S::ERR + nt + tid] = merit_viol;
+    __syncthreads();
+    if (tid < 2) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + nt * tid + t]; B.merit_stage[rec * 4 + tid] = e; }
+    return;
+  }
 
   // ---- stage 2: tangent items (wave 0: q, v seeds; wave 1: a seeds) and Robot::computeMJtJinv (wave 1) (robot.hxx:576-615) ----
   // M^-1 and (J M^-1 J^T)^-1 by Gauss-Jordan on the SPD blocks (the reference uses pinocchio's sparse Cholesky + Eigen::LLT; same
@@ -779,6 +816,20 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   if (n[0] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]);
   if (n[2] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]);
 }
+// Line search: cost and l1 violation of every stage of the chain for the iterate Btry.sol points at (Btry.nodes: the chain with the
+// reference's pairing of the successors).  The caller has run the impulse RNEA and the switching kernel on Btry.
+template <typename D>
+void OcpLaunch<D>::merit(const OcpBuffers& Btry, long batch, int M, const double* q0, hipStream_t st) {
+  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  const unsigned blocks = (unsigned)(batch * M);
+  hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
+  hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, false, true>), dim3(blocks), dim3(256), smem, st, Btry, q0);
+}
 template <typename D>
 void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st) {
   launchCondense<D>(B, batch, M, -1, q0, st, true);
@@ -802,6 +853,7 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::merit(const OcpBuffers&, long, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::condenseBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, bool, hipStream_t);
 

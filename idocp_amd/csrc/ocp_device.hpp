@@ -171,6 +171,12 @@ struct OcpBuffers {
   double* err;           // [batch]
   int* status;           // [batch]
   long long* prof;       // [64] diagnostic: wall-clock stamps of one workgroup of the condensation kernel
+  // filter line search (src/line_search/line_search.cpp): trial iterate s (+) alpha d, per-stage (cost, violation, barrier) and their sums
+  double* sol_try;       // [batch][NS][SOL]
+  double* merit_stage;   // [batch][NS][4]   cost, l1 violation, dt * barrier cost, -
+  double* merit;         // [batch][2]
+  double* ls_alpha;      // [batch]
+  const OcpNode* nodes_ls;   // the chain with the reference's pairing of the stages in front of an event (line_search.cpp:80-113)
 };
 
 }  // namespace idocp_dev

@@ -329,6 +329,79 @@ __global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuf
   }
 }
 
+// LineSearch::computeSolution (include/idocp/line_search/line_search.hpp:134-158): the trial iterate s (+) alpha d of every stage,
+// alpha = B.ls_alpha[instance], into B.sol_try; and the barrier part of SplitOCP::stageCost at that step,
+// dt * barrier(slack + alpha dslack) (split_ocp.hxx:281-287, pdipm.hxx:84-87; rows of inactive contacts count with dslack = 1,
+// linearized_friction_cone.cpp:162-163).  One wavefront per stage of the chain.
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF;
+  __shared__ double dx[NX], du[NU], dfs[NF];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const int lane = threadIdx.x;
+  const long unit = blockIdx.x;
+  const long b = unit / M;
+  const int pos = (int)(unit - b * M);
+  const OcpNode* __restrict__ nd = B.nodes + pos;
+  const bool stage = (pos < M - 1);
+  const long rec = b * P->NS + nd->slot;
+  const double a = B.ls_alpha[b];
+  const double* __restrict__ dd = B.dir + rec * L::DIR;
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  double* __restrict__ st = B.sol_try + rec * L::SOL;
+  if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
+  if (stage) {
+    if (lane < NU) du[lane] = dd[L::D_U + lane];
+    if (lane < NF) dfs[lane] = dd[L::D_F + lane];
+  }
+  for (int e = lane; e < L::SOL; e += 64) st[e] = s[e];
+  __syncthreads();
+  if (lane < NV) {
+    const int r = lane;
+    st[L::S_V + r] = s[L::S_V + r] + a * dx[NV + r];
+    if (r >= 6) st[L::S_Q + r + 1] = s[L::S_Q + r + 1] + a * dx[r];
+    if (stage) st[L::S_A + r] = s[L::S_A + r] + a * dd[L::D_A + r];
+  }
+  if (lane == 32) {
+    double qn[7];
+    lieIntegrateBase(s + L::S_Q, dx, a, qn);
+    for (int k = 0; k < 7; ++k) st[L::S_Q + k] = qn[k];
+  }
+  double bar = 0.0;
+  if (stage) {
+    if (nd->has_u && lane >= 40 && lane < 40 + NU) st[L::S_U + lane - 40] = s[L::S_U + lane - 40] + a * du[lane - 40];
+    if (lane < NF && nd->active[lane / 3]) st[L::S_F + lane] = s[L::S_F + lane] + a * dfs[lane];
+    const double* __restrict__ slack = B.slack + rec * L::CON;
+    for (int row = lane; row < L::NCON; row += 64) {
+      double g, dg, dslack;
+      if (ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) dslack = -dg - (g + slack[row]);
+      else if (row >= L::C_FRIC && ocpRowValid2(P, 6, nd->level, nd->kind == 1)) dslack = 1.0;
+      else continue;
+      bar -= log(slack[row] + a * dslack);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bar += __shfl_xor(bar, off);
+  if (lane == 0) B.merit_stage[rec * 4 + 2] = stage ? nd->dt * P->barrier * bar : 0.0;
+}
+
+// totals of the chain: merit[b] = (sum of stage costs + barrier costs, sum of violations)
+__global__ __launch_bounds__(64) void ocp_merit_reduce_kernel(OcpBuffers B) {
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = P->M;
+  const long b = blockIdx.x;
+  double c = 0.0, v = 0.0;
+  for (int i = threadIdx.x; i < M; i += 64) {
+    const double* __restrict__ ms = B.merit_stage + (b * P->NS + B.nodes[i].slot) * 4;
+    c += ms[0] + ms[2]; v += ms[1];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { c += __shfl_xor(c, off); v += __shfl_xor(v, off); }
+  if (threadIdx.x == 0) { B.merit[b * 2] = c; B.merit[b * 2 + 1] = v; }
+}
+
 // SplitOCP::initConstraints -> setSlackAndDual -> pdipm::SetSlackAndDualPositive (split_ocp.hxx:50-55; pdipm.hxx:13-23)
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) {
@@ -410,6 +483,14 @@ void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, h
   hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
 }
 template <typename D>
+void OcpLaunch<D>::trialIterate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  hipLaunchKernelGGL((ocp_trial_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
+}
+template <typename D>
+void OcpLaunch<D>::meritReduce(const OcpBuffers& B, long batch, hipStream_t st) {
+  hipLaunchKernelGGL(ocp_merit_reduce_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
+}
+template <typename D>
 void OcpLaunch<D>::initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st) {
   hipLaunchKernelGGL((ocp_init_constraints_kernel<D>), dim3((unsigned)(batch * NS)), dim3(64), 0, st, B);
 }
@@ -435,6 +516,8 @@ void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_in
 
 template void OcpLaunch<LeggedDims<4, 3>>::expandPrimal(const OcpBuffers&, long, int, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::expandDualIntegrate(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::trialIterate(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::meritReduce(const OcpBuffers&, long, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::initConstraints(const OcpBuffers&, long, int, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::single(int, const OcpBuffers&, long, int, hipStream_t);
 

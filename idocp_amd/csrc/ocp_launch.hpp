@@ -27,6 +27,10 @@ struct OcpLaunch {
   static void parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, bool has_terminal, const double* q0, const double* v0,
                            hipStream_t st);                                                       // 0 S5, 1 K10a, 2 S6, 3 K10b, 4 init aux_mat
   static void parnmpcHalo(const OcpBuffers& B, long batch, int kind, bool do_import, double* buf, double* q0, double* v0, hipStream_t st);
+  // filter line search of the floating-base solvers (src/line_search/line_search.cpp)
+  static void trialIterate(const OcpBuffers& B, long batch, int M, hipStream_t st);             // s (+) alpha d -> sol_try, barrier cost
+  static void merit(const OcpBuffers& Btry, long batch, int M, const double* q0, hipStream_t st);  // per-stage cost + l1 violation of sol_try
+  static void meritReduce(const OcpBuffers& B, long batch, hipStream_t st);
   static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
   static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7
   static void initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st);     // every slot

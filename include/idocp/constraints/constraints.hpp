@@ -70,15 +70,22 @@ class Constraints {
     c_.joint_position_limits = c_.joint_velocity_limits = c_.joint_torque_limits = 0;
     c_.linearized_friction_cone = 0;
   }
+  // The reference keeps barrier and fraction-to-boundary rate per component (constraint_component_base.hxx:10-24); the kernels take
+  // ONE pair for the whole stage.  Components that disagree are rejected loudly instead of letting the last one win.
   void push_back(const std::shared_ptr<ConstraintComponentBase>& c) {
+    if (have_ipm_ && (c->barrier != c_.barrier || c->fraction_to_boundary_rate != c_.fraction_to_boundary_rate)) {
+      std::cerr << "unsupported constraints: every component must use the same barrier and fraction_to_boundary_rate on the HIP path" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    c_.barrier = c->barrier;
+    c_.fraction_to_boundary_rate = c->fraction_to_boundary_rate;
+    have_ipm_ = true;
     if (c->family == ConstraintComponentBase::LinearFrictionCone) {
       if (!c->upper) c_.linearized_friction_cone = 1; else c_.linearized_impulse_friction_cone = 1;     // upper = impulse twin
       c_.mu = c->mu;
       return;
     }
     (c->upper ? hi_ : lo_)[c->family] = 1;
-    c_.barrier = c->barrier;
-    c_.fraction_to_boundary_rate = c->fraction_to_boundary_rate;
   }
   // The kernels treat a limit family as a lower+upper pair (what
   // JointConstraintsFactory::create() builds); a lone lower or upper limit is rejected.
@@ -98,6 +105,7 @@ class Constraints {
  private:
   idocp_constraints_t c_;
   int lo_[3], hi_[3];
+  bool have_ipm_ = false;
 };
 
 }  // namespace idocp

@@ -128,7 +128,7 @@ class OCPSolver {
   }
   void popBackContactStatus() { check(idocp_ocp_pop_back_contact_status(h_)); }
   void popFrontContactStatus() { check(idocp_ocp_pop_front_contact_status(h_)); }
-  void clearLineSearchFilter() {}
+  void clearLineSearchFilter() { check(idocp_ocp_clear_line_search_filter(h_)); }      // ocp_solver.cpp:196-199
 
   double KKTError() {
     double e = 0;

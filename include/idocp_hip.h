@@ -365,12 +365,19 @@ int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double*
 int idocp_ocp_set_solution_stages(idocp_ocp_t* h, const char* name, int nstages, const double* values);
 /* OCPSolver::initConstraints(t) (ocp_solver.cpp:60-64). */
 int idocp_ocp_init_constraints(idocp_ocp_t* h, double t);
-/* OCPSolver::updateSolution (ocp_solver.cpp:67-92). q[batch][nq], v[batch][nv].  line_search must be 0: the filter line
- * search of the floating-base solvers (src/line_search/line_search.cpp) is not carried; IDOCP_E_UNSUPPORTED otherwise. */
+/* OCPSolver::updateSolution (ocp_solver.cpp:67-92). q[batch][nq], v[batch][nv].  line_search != 0: the filter line search of
+ * src/line_search/line_search.cpp on the primal step (one filter per instance; cost and l1 constraint violation of the trial
+ * iterates are evaluated on the device, the filter logic runs on the host). */
 int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q,
                               const double* v, int line_search);
 int idocp_ocp_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
                                      const double* d_v);
+/* OCPSolver::clearLineSearchFilter (ocp_solver.cpp:196-199). */
+int idocp_ocp_clear_line_search_filter(idocp_ocp_t* h);
+/* Probing the line search (tests): the Newton direction and step sizes of the current iterate WITHOUT integrating, then
+ * LineSearch::computeCostAndViolation of s (+) alpha[b] d per instance (alpha = 0: the iterate itself). */
+int idocp_ocp_compute_direction(idocp_ocp_t* h, double t, const double* q, const double* v);
+int idocp_ocp_line_search_eval(idocp_ocp_t* h, const double* alpha, double* cost, double* violation);
 /* The same iteration submitted as ONE hipGraph launch (captured on first use, re-captured when the discretisation or the input
  * buffers change): the latency mode of the solver -- at batch 1 the launches, not the kernels, set the pace. */
 int idocp_ocp_update_solution_graph(idocp_ocp_t* h, double t, const double* d_q,

@@ -1000,14 +1000,125 @@ void OCPSolver::integrateSolution() {
   }
 }
 
-void OCPSolver::updateSolution(real t, const Mat& q, const Mat& v) {
+void OCPSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line_search) {
   linearizeOCP(t, q);
   auto t0 = std::chrono::steady_clock::now();
   backwardRiccatiRecursion();
   forwardRiccatiRecursion(q, v);
   riccati_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
   computeDirection();
+  if (use_line_search)            // ocp_solver.cpp:84-90
+    primal_step_size = line_search.computeStepSize([&](real a) { return costAndViolation(a); }, primal_step_size);
   integrateSolution();
+}
+
+// LineSearch::computeSolution + computeCostAndViolation for the OCP (src/line_search/line_search.cpp:63-196, 305-343;
+// line_search.hpp:134-158).  Per stage of the chain:
+//   cost      = SplitOCP::stageCost (split_ocp.hxx:270-289): stage cost + dt * barrier(slack + alpha dslack)
+//               ImpulseSplitOCP::stageCost (impulse_split_ocp.hxx:155-170), TerminalOCP::terminalCost (terminal_ocp.hxx:81-87)
+//   violation = SplitOCP::constraintViolation (split_ocp.hxx:292-346): |Fx|_1 + dt |[ID - u; C]|_1 + dt |g + slack|_1 (+ |P|_1 of the
+//               switching constraint), with the CURRENT slack; the impulse stage with dt = 1 (impulse_split_ocp.hxx:173-192)
+// The reference evaluates the state-equation residual of a grid stage in front of an event against the NEXT GRID STAGE (the
+// value written for the event stage is overwritten a few lines further down, line_search.cpp:80-113); reproduced here.
+std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
+  const int nv = nv_, nu = nu_;
+  Robot rb = robot;
+  real Jc[5][3]; frictionJac(cons.mu, Jc);
+  real cost_sum = 0, viol_sum = 0;
+  auto trial = [&](int p) {
+    const NodeC& nd = chain[p];
+    const int sl = nd.slot;
+    SplitSolutionC x = s[sl];
+    if (alpha > 0) {
+      Mat qn; rb.integrateConfiguration(s[sl].q, d[sl].dq, alpha, qn); x.q = qn;
+      x.v = s[sl].v + alpha * d[sl].dv;
+      if (nd.kind != NodeC::Terminal) {
+        const ContactStatus& cs = nodeContacts(p);
+        x.a = s[sl].a + alpha * d[sl].daf.segment(0, nv);
+        if (nd.kind != NodeC::Impulse) x.u = s[sl].u + alpha * d[sl].du;
+        int st = 0;
+        for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int k2 = 0; k2 < 3; ++k2) x.f[c][k2] = s[sl].f[c][k2] + alpha * d[sl].daf[nv + st + k2]; st += 3; }
+      }
+    }
+    return x;
+  };
+  for (int p = 0; p < M(); ++p) {
+    const NodeC& nd = chain[p];
+    const int sl = nd.slot;
+    const SplitSolutionC x = trial(p);
+    Mat q_ref, qdiff;
+    qRef(nd.t, q_ref);
+    rb.subtractConfiguration(x.q, q_ref, qdiff);
+    const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+    const real vs = vRefScale(cost, nd.t);
+    if (nd.kind == NodeC::Terminal) {
+      real l = 0;
+      for (int r = 0; r < nv; ++r) {
+        const real dvr = x.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]);
+        l += cost.qf_weight[r] * qdiff[r] * qdiff[r] + cost.vf_weight[r] * dvr * dvr;
+      }
+      cost_sum += 0.5 * l;
+      continue;
+    }
+    const bool impulse = nd.kind == NodeC::Impulse;
+    const ContactStatus& cs = nodeContacts(p);
+    const real dt = impulse ? 1.0 : nd.dt, dtq = impulse ? 0.0 : nd.dt;
+    const real* wq = impulse ? cost.qi_weight : cost.q_weight;
+    const real* wv = impulse ? cost.vi_weight : cost.v_weight;
+    const real* wa = impulse ? cost.dvi_weight : cost.a_weight;
+    const real (*wf)[3] = impulse ? cost.fi_weight : cost.f_weight;
+    const real (*rf)[3] = impulse ? cost.fi_ref : cost.f_ref;
+    // ---- cost
+    real l = 0;
+    for (int r = 0; r < nv; ++r) {
+      const real dvr = x.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]);
+      l += wq[r] * qdiff[r] * qdiff[r] + wv[r] * dvr * dvr + wa[r] * x.a[r] * x.a[r];
+    }
+    if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) l += wf[c][k2] * (x.f[c][k2] - rf[c][k2]) * (x.f[c][k2] - rf[c][k2]);
+    real barrier = 0, primal = 0;
+    for (int c = 0; c < 7; ++c) {
+      if (!componentValid(c, nd)) continue;
+      const IpmData& data = ipm[sl][c];
+      for (int r = 0; r < data.slack.size(); ++r) barrier -= cons.barrier * std::log(data.slack[r] + alpha * data.dslack[r]);      // pdipm.hxx:84-87
+      if (c < 6) {
+        const real sgn = (c & 1) ? 1.0 : -1.0;
+        for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), c, r)) + data.slack[r]);
+      } else {
+        for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+          real res[5]; frictionConeResidual(cons.mu, x.f[cc], res);
+          for (int r = 0; r < 5; ++r) primal += std::fabs(res[r] + data.slack[5 * cc + r]);
+        }
+      }
+    }
+    cost_sum += 0.5 * dt * l + dt * barrier;
+    // ---- violation: state equation against the successor the reference pairs the stage with
+    int pn = p + 1;
+    if (nd.kind == NodeC::Stage && (chain[pn].kind == NodeC::Impulse || chain[pn].kind == NodeC::Lift)) { ++pn; while (chain[pn].kind != NodeC::Stage && chain[pn].kind != NodeC::Terminal) ++pn; }
+    const SplitSolutionC xn = trial(pn);
+    Mat diff; rb.subtractConfiguration(x.q, xn.q, diff);
+    real viol = 0;
+    for (int r = 0; r < nv; ++r) viol += std::fabs(diff[r] + dtq * x.v[r]) + std::fabs(x.v[r] + dt * x.a[r] - xn.v[r]);
+    // contact dynamics residual (contact_dynamics.hxx:202-217; impulse_dynamics_forward_euler.hxx:145-158)
+    Mat ID, C, zero(nv);
+    if (impulse) rb.updateKinematics(x.q, x.v + x.a, Mat(nv)); else rb.updateKinematics(x.q, x.v, x.a);
+    rb.setContactForces(cs.active, x.f);
+    if (impulse) { rb.RNEA(x.q, zero, x.a, ID, false); rb.computeImpulseVelocityResidual(cs.active, C); }
+    else { rb.RNEA(x.q, x.v, x.a, ID); for (int r = 0; r < nu; ++r) ID[kP + r] -= x.u[r]; rb.computeBaumgarteResidual(cs.active, dt_, cs.points, C); }
+    viol += dt * (ID.lpNorm1() + C.lpNorm1());
+    viol += dt * primal;
+    if (nd.sw_event >= 0) {        // forward_switching_constraint.hxx:27-47
+      const ContactStatus& is = seq.impulse_status[nd.sw_event];
+      const real dt1 = nd.dt, dt2 = nd.sw_dt_next;
+      Mat dq_ = (dt1 + dt2) * x.v + (dt1 * dt2) * x.a, q_, Pm;
+      rb.integrateConfiguration(x.q, dq_, 1.0, q_);
+      rb.updateKinematics(q_, Mat(nv), Mat(nv));
+      rb.computeContactResidual(is.active, is.points, Pm);
+      viol += Pm.lpNorm1();
+    }
+    viol_sum += viol;
+  }
+  return {cost_sum, viol_sum};
 }
 
 // =============================================================================================== ParNMPC ====

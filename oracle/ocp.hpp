@@ -24,6 +24,7 @@
 #include "idocp_hip.h"
 #include "mat.hpp"
 #include "rbd.hpp"
+#include "unocp.hpp"      // LineSearchFilterC
 
 namespace oracle {
 
@@ -123,7 +124,11 @@ class OCPSolver {
   void setContactPoints(int contact_phase, const double* contact_points);                                     // :180-184
   void setSolution(const std::string& name, const Mat& value);      // ocp_solver.cpp:95-165
   void initConstraints(real t);                                   // ocp_solver.cpp:60-64
-  void updateSolution(real t, const Mat& q, const Mat& v);         // ocp_solver.cpp:67-92
+  void updateSolution(real t, const Mat& q, const Mat& v, bool line_search = false);         // ocp_solver.cpp:67-92
+  // LineSearch::computeCostAndViolation of the trial iterate s (+) alpha d (src/line_search/line_search.cpp:63-196;
+  // alpha = 0: the current iterate with the current slacks) and the filter of OCPSolver (ocp_solver.cpp:84-90, 196-199)
+  std::pair<real, real> costAndViolation(real alpha);
+  LineSearchFilterC line_search;
   void computeKKTResidual(real t, const Mat& q, const Mat& v);     // ocp_solver.cpp:202-207
   real KKTError();                                                 // ocp_linearizer.cpp:98-137
   int isCurrentSolutionFeasible() const;                             // ocp_solver.cpp:216-248: first offending chain position or -1

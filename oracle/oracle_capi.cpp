@@ -507,6 +507,29 @@ int oracle_ocp_chain(void* h, double t, int* kind, int* index, int* slot, double
 }
 void oracle_ocp_destroy(void* h) { delete static_cast<OCPSolver*>(h); }
 // OCPSolver(..., nthreads) of the reference: the stage loops run on `n` OpenMP threads (1 without -fopenmp)
+int oracle_ocp_update_solution_ls(void* h, double t, const double* q, const double* v) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()), true); }
+  catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
+// linearise + Riccati + direction, WITHOUT integrating (so that cost / violation of trial steps can be probed)
+int oracle_ocp_compute_direction(void* h, double t, const double* q, const double* v) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  try {
+    const Mat Q = toVec(q, s->robot.dimq()), V = toVec(v, s->robot.dimv());
+    s->linearizeOCP(t, Q); s->backwardRiccatiRecursion(); s->forwardRiccatiRecursion(Q, V); s->computeDirection();
+  } catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
+void oracle_ocp_clear_line_search_filter(void* h) { static_cast<OCPSolver*>(h)->line_search.filter.clear(); }
+// cost and l1 constraint violation of s (+) alpha d (the direction of the last linearisation); out[2]
+int oracle_ocp_cost_and_violation(void* h, double alpha, double* out) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  try { const auto cv = s->costAndViolation(alpha); out[0] = (double)cv.first; out[1] = (double)cv.second; }
+  catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
 int oracle_ocp_set_num_threads(void* h, int n) { static_cast<OCPSolver*>(h)->setNumThreads(n); return 0; }
 int oracle_ocp_set_contact_status(void* h, const int* active, const double* points) {
   OCPSolver* s = static_cast<OCPSolver*>(h);

@@ -7,6 +7,8 @@
 #ifndef ORACLE_UNOCP_HPP_
 #define ORACLE_UNOCP_HPP_
 
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -112,6 +114,7 @@ struct LineSearchFilterC {
     real a = max_primal_step_size;
     while (a > min_step_size) {
       const auto cv = eval(a);
+      if (getenv("ORACLE_LS_DEBUG")) fprintf(stderr, "  ls try a=%.4f cost=%.10g viol=%.10g accepted=%d (filter %zu)\n", (double)a, (double)cv.first, (double)cv.second, (int)isAccepted(cv.first, cv.second), filter.size());
       if (isAccepted(cv.first, cv.second)) { augment(cv.first, cv.second); break; }
       a *= step_size_reduction_rate;
     }

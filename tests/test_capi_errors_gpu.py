@@ -60,11 +60,10 @@ def test_solver_argument_errors():
     assert lib.idocp_ocp_set_solution(g.h, b"w", P(np.zeros(19))) == E_ARG
     assert "name must be q, v, a, f, or u" in capi.last_error()
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
-    # updateSolution before a contact status was given; line search is not carried
+    # updateSolution before a contact status was given (with and without the line search)
     assert lib.idocp_ocp_update_solution(g.h, 0.0, P(q), P(v), 0) == E_ARG
+    assert lib.idocp_ocp_update_solution(g.h, 0.0, P(q), P(v), 1) == E_ARG
     g.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
-    assert lib.idocp_ocp_update_solution(g.h, 0.0, P(q), P(v), 1) == E_UNSUPPORTED
-    assert "line_search" in capi.last_error()
     # getters: unknown field, instance out of range
     out = np.zeros((21, 19))
     assert lib.idocp_ocp_get_solution(g.h, b"nope", 0, P(out)) == E_ARG

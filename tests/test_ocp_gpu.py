@@ -132,7 +132,7 @@ def test_batch_instances_and_ragged_sizes():
                 assert rel_err(g.get(f, b), o.get(f)) < TOL, (batch, b, f)
 
 
-def test_state_feedback_gain_and_unsupported_inputs():
+def test_state_feedback_gain():
     m, o, g, q, v = make_pair(8, 0.4)
     o.update(0.0, q, v)
     g.update(0.0, q, v)
@@ -140,7 +140,8 @@ def test_state_feedback_gain_and_unsupported_inputs():
     Kq, Kv = np.zeros((m.nv, m.nu)), np.zeros((m.nv, m.nu))
     capi.check(g.lib.idocp_ocp_get_state_feedback_gain(g.h, 0, 3, P(Kq), P(Kv)))
     assert rel_err(Kq.T, Ko[3][:, :m.nv]) < TOL and rel_err(Kv.T, Ko[3][:, m.nv:]) < TOL
-    assert g.lib.idocp_ocp_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 1) == -4      # line search: unsupported
+    # ParNMPC handles do not carry the line search (the OCPSolver does since round 2: test_line_search_*)
+    assert g.lib.idocp_ocp_update_solution(g.h, 0.0, P(arr(q)), P(arr(v)), 1) == 0
 
 
 def test_full_size_properties_c3():
@@ -206,3 +207,62 @@ def test_clone_is_a_deep_copy_of_the_solver_state():
     for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu"):
         assert np.array_equal(g.get(f, 1), c.get(f, 1)), f
     assert np.array_equal(g.kkt_error(0.0, q, v), c.kkt_error(0.0, q, v))
+
+
+def _ls_pair(N, T, nimp, batch=2):
+    import ctypes as C
+    from helpers import oracle, trotting_sequence
+    lib_o = oracle()
+    lib_o.oracle_ocp_cost_and_violation.argtypes = [C.c_void_p, C.c_double, capi.c_double_p]
+    lib_o.oracle_ocp_compute_direction.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
+    lib_o.oracle_ocp_update_solution_ls.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1 if nimp else 0)
+    g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1 if nimp else 0)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in (o, g):
+        if nimp:
+            trotting_sequence(s, m, nimp)
+        else:
+            s.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    q[7:] += 0.05
+    return lib_o, m, o, g, q, v
+
+
+@pytest.mark.parametrize("N,T,nimp", [(20, 1.0, 0), (31, 1.55, 2)])
+def test_line_search_cost_and_violation_parity(N, T, nimp):
+    """Floating-base filter line search (src/line_search/line_search.cpp:63-196): total cost and l1 constraint violation of the
+    trial iterates s (+) alpha d against the oracle, on an event-free horizon and on the trotting chain (impulse / aux / lift
+    stages, switching constraints, the reference's pairing of the stages in front of an event)."""
+    lib_o, m, o, g, q, v = _ls_pair(N, T, nimp)
+    assert lib_o.oracle_ocp_compute_direction(o.h, 0.0, P(q), P(v)) == 0
+    capi.check(g.lib.idocp_ocp_compute_direction(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv))), "compute_direction")
+    ap, ad = g.step_sizes()
+    for alpha in (0.0, 1e-3, 0.1, 0.5 * ap[0], ap[0]):
+        ref = np.zeros(2)
+        assert lib_o.oracle_ocp_cost_and_violation(o.h, alpha, P(ref)) == 0
+        c, vi = np.zeros(g.batch), np.zeros(g.batch)
+        capi.check(g.lib.idocp_ocp_line_search_eval(g.h, P(np.full(g.batch, alpha)), P(c), P(vi)), "line_search_eval")
+        assert abs(c[0] - ref[0]) <= 1e-10 * max(1.0, abs(ref[0])), (alpha, c[0], ref[0])
+        assert abs(vi[0] - ref[1]) <= 1e-10 * max(1.0, abs(ref[1])), (alpha, vi[0], ref[1])
+        assert c[0] == c[-1] and vi[0] == vi[-1]
+
+
+def test_line_search_accepted_steps_follow_the_oracle():
+    """updateSolution(t, q, v, line_search = true) (ocp_solver.cpp:84-90): the accepted primal steps and the iterates of GPU and
+    oracle over several iterations (one filter per instance), then clearLineSearchFilter."""
+    lib_o, m, o, g, q, v = _ls_pair(20, 1.0, 0)
+    for it in range(6):
+        assert lib_o.oracle_ocp_update_solution_ls(o.h, 0.0, P(q), P(v)) == 0
+        assert g.lib.idocp_ocp_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1) == 0
+        ao, bo = o.step_sizes()
+        ag, bg = g.step_sizes()
+        assert abs(ag[0] - ao) < 1e-12 and abs(bg[0] - bo) < 1e-9, (it, ag[0], ao)
+        for f in ("q", "v", "a", "u", "f"):
+            assert rel_err(g.get(f, 1), o.get(f)) < 1e-8, (it, f)
+    capi.check(g.lib.idocp_ocp_clear_line_search_filter(g.h))
