@@ -294,6 +294,49 @@ def running_problem(model, steps=10):
     cons.mu = 0.8
     return cost, cons
 
+def jumping_problem(model):
+    """Cost / constraints of examples/anymal/anymal_jumping.cpp:39-111: ConfigurationSpaceCost around the standing posture +
+    ContactForceCost(f_ref = (0, 0, 70), weights (1, 1, 0.1)), six joint limits, linearized (impulse) friction cones, mu = 0.7."""
+    nv = model.nv
+    cost = capi.Cost()
+    cost.set("q_ref", ANYMAL_Q_STANDING)
+    qw = np.concatenate([np.ones(3), np.full(15, 10.0)])
+    vw = np.concatenate([np.full(3, 0.01), np.full(15, 0.1)])
+    aw = np.full(nv, 0.01)
+    cost.set("q_weight", qw).set("qf_weight", qw).set("qi_weight", qw)
+    cost.set("v_weight", vw).set("vf_weight", vw).set("vi_weight", vw)
+    cost.set("a_weight", aw).set("dvi_weight", aw)
+    for c in range(4):
+        for k, wk in enumerate((1.0, 1.0, 0.1)):
+            cost.f_weight[c][k] = wk
+            cost.fi_weight[c][k] = wk
+            cost.f_ref[c][k] = 0.0
+            cost.fi_ref[c][k] = 0.0
+        cost.f_ref[c][2] = 70.0
+    cons = capi.Constraints()
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    cons.linearized_friction_cone = 1
+    cons.linearized_impulse_friction_cone = 1
+    cons.mu = 0.7
+    return cost, cons
+
+
+def jumping_sequence(solver, model, jumps=3, jump_length=0.25, t_start=1.0, t_jumping=0.15, t_ground=1.0):
+    """Contact sequence of examples/anymal/anymal_jumping.cpp:120-142: all feet on the ground, then per jump a flight phase (no
+    contacts; the contact points stay the ones just left) and a landing `jump_length` further on all four feet."""
+    pts = anymal_contact_points(model).copy()
+    solver.set_contact_status([1, 1, 1, 1], pts)
+    events = 0
+    for k in range(jumps):
+        t_off = t_start + k * (t_jumping + t_ground)
+        solver.push_back_contact_status([0, 0, 0, 0], pts, t_off)
+        pts = pts.copy()
+        pts[:, 0] += jump_length
+        solver.push_back_contact_status([1, 1, 1, 1], pts, t_off + t_jumping)
+        events += 2
+    return events
+
+
 def running_sequence(solver, model, steps=10):
     """Contact sequence of examples/anymal/anymal_running.cpp:137-215, transcribed as data: all feet -> hind feet {LH, RH}
     -> flight -> front feet {LF, RF} -> hind feet -> ... -> all feet; 3 steps + 2 * (steps + 2) + ... = 6 + 3 steps + 4

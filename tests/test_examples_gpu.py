@@ -163,6 +163,33 @@ def test_anymal_running_example_matches_oracle():
     assert its[-1] < 0.05 * init
 
 
+def test_anymal_jumping_example_matches_oracle():
+    """examples/anymal_jumping.cpp = the reference's examples/anymal/anymal_jumping.cpp driver (three jumps: flight phases without
+    contacts, landings as impulse stages with all twelve rows and twelve-row switching constraints; N = 100, T = 5) through the
+    facade, 25 SQP iterations against the oracle on the same problem."""
+    from helpers import jumping_problem, jumping_sequence
+    build_examples()
+    r = subprocess.run([os.path.join(ROOT, "examples", "anymal_jumping"), ANYMAL_URDF, "25"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    init, its = kkt_errors(r.stdout)
+    assert len(its) == 25
+    model = anymal_model()
+    cost, cons = jumping_problem(model)
+    o = OracleOCP(model, cost, cons, 5.0, 100, max_num_impulse=3)
+    assert jumping_sequence(o, model, 3) == 6
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(model.nv)
+    o.set_solution("q", q)
+    o.set_solution("v", v)
+    o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    o.init_constraints(0.0)
+    ref_init = o.kkt_error(0.0, q, v)
+    assert abs(init - ref_init) <= 1e-5 * max(1.0, ref_init)          # printed with 6 significant digits
+    for k in range(25):
+        o.update(0.0, q, v)
+        ref = o.kkt_error(0.0, q, v)
+        assert abs(its[k] - ref) <= 5e-5 * max(1.0, ref), (k, its[k], ref)
+
+
 def test_anymal_parnmpc_benchmark_example_matches_oracle():
     from helpers import OracleParNMPC
     import ctypes as C
