@@ -522,6 +522,59 @@ __device__ __forceinline__ void mmTN22Epi(const double* X, int ldx, const double
   }
 }
 
+// ---- 16 x 16 output tiles on the matrix cores ----
+// One tile of C = X^T Y (X: k x m, Y: k x n, both contiguous along the contraction index) per call and wavefront with
+// v_mfma_f64_16x16x4_f64.  FP64 MFMA has the rate of the FP64 vector pipe on CDNA4; what it buys here is operand traffic: a
+// lane reads ONE double of each operand per 16 multiply-adds it contributes to (the 2 x 2 register tiles above read one per
+// multiply-add), and the stage kernels' products are bound by LDS bandwidth, not by FP64 issue.
+// Lane map of the instruction (lane = 16 g + li): A[i = li][k = g], B[k = g][j = li], D[i = g + 4 reg][j = li], reg = 0..3.
+// Here A is taken from Y (i = column of C) and B from X (j = row of C), so that the 16 lanes li run along a COLUMN of C, i.e.
+// along contiguous addresses of a column-major result.  Every lane reads two consecutive k's (16 B) per step and feeds them to
+// two instructions (the sum over k does not care which k's share an instruction).  xr / yc = number of valid rows / columns of
+// the tile (lanes beyond re-read the last valid one; their results are never stored), k is masked against KMAX's padding.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+template <int KMAX>
+__device__ __forceinline__ mfma_d4 mfmaTileTN(const double* X, int ldx, int xr, const double* Y, int ldy, int yc, int k, int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int KS = (KMAX + 7) / 8;
+  const int li = lane & 15, g = lane >> 4;
+  const double* xp = X + ldx * (li < xr ? li : xr - 1) + 2 * g;
+  const double* yp = Y + ldy * (li < yc ? li : yc - 1) + 2 * g;
+  d2 xa[KS], ya[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) { xa[s] = *reinterpret_cast<const d2*>(xp + 8 * s); ya[s] = *reinterpret_cast<const d2*>(yp + 8 * s); }
+  mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int kk = 8 * s + 2 * g;
+    const bool v0 = kk < k, v1 = kk + 1 < k;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0 ? ya[s].x : 0.0, v0 ? xa[s].x : 0.0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1 ? ya[s].y : 0.0, v1 ? xa[s].y : 0.0, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// store(r, c, value) for the elements of a tile at (r0, c0) that lie inside m x n
+template <typename Store>
+__device__ __forceinline__ void mfmaTileStore(const mfma_d4& acc, int r0, int c0, int m, int n, int lane, Store store) {
+  const int r = r0 + (lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + g + 4 * q;
+    if (r < m && c < n) store(r, c, acc[q]);
+  }
+}
+// C = X^T Y, tiles dealt round-robin to the wavefronts of the workgroup
+template <int KMAX, typename Store>
+__device__ __forceinline__ void mmTNmfma(const double* X, int ldx, const double* Y, int ldy, int m, int n, int k, int tid, int nthreads, Store store) {
+  const int wave = tid >> 6, nw = nthreads >> 6, lane = tid & 63;
+  const int mt = (m + 15) >> 4, nt = (n + 15) >> 4;
+  for (int e = wave; e < mt * nt; e += nw) {
+    const int jb = e / mt, ib = e - jb * mt;
+    const mfma_d4 acc = mfmaTileTN<KMAX>(X + ldx * 16 * ib, ldx, m - 16 * ib, Y + ldy * 16 * jb, ldy, n - 16 * jb, k, lane);
+    mfmaTileStore(acc, 16 * ib, 16 * jb, m, n, lane, store);
+  }
+}
+
 // ---- 3 x 3 register tiles ----
 // K9b / K9g keep every matrix it factorises or multiplies as 3 x 3 tiles in registers, thread (bi, bj) owning rows 3 bi .. 3 bi + 2 and
 // columns 3 bj .. 3 bj + 2: an inner-product step is 6 LDS reads for 9 multiply-adds, a Gauss-Jordan pivot step shares only the

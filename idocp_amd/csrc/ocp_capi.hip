@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -628,6 +629,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   B.status = reinterpret_cast<int*>(tmp);
   if ((rc = allocBufO(h, &tmp, 64))) return fail(rc);
   B.prof = reinterpret_cast<long long*>(tmp);
+  B.prof_dimf = getenv("IDOCP_PROF_DIMF") ? atoi(getenv("IDOCP_PROF_DIMF")) : 12;
   if ((rc = allocBufO(h, &tmp, ((size_t)h->NS * sizeof(OcpNode) + 7) / 8))) return fail(rc);
   h->d_nodes = reinterpret_cast<OcpNode*>(tmp);
   B.nodes = h->d_nodes;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* q = s + L::S_Q;
   const double* __restrict__ qref = B.q_ref + (long)pos * NQ;
   const long su = rec;
-  const bool stamp = (!RESIDUAL) && tid == 0 && unit == 7 && B.prof != nullptr;
+  const bool stamp = (!RESIDUAL) && tid == 0 && unit == 7 && B.prof != nullptr && DIMF == B.prof_dimf;
 #define STAMP(k) do { if (stamp) B.prof[k] = wall_clock64(); } while (0)
   STAMP(0);
   double* kk = B.kkt + rec * L::KKT;
@@ -570,23 +570,33 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double hu = (PLAIN || nd->has_u) ? 1.0 : 0.0;          // impulse stages have no torque variables: Qafu = 0, Fvu = 0
   STAMP(7);
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
-  if ((dimvf & 1) == 0) mmTN22(&sm[S::MJD], SVF, &sm[S::MJ], SVF, &sm[S::DIDC], SVF, dimvf, NX, dimvf, 1.0, false, tid, nt);   // MJ symmetric
-  else mm(colMajor(&sm[S::MJD], SVF), colMajor(&sm[S::MJ], SVF), colMajor(&sm[S::DIDC], SVF), dimvf, NX, dimvf, 1.0, false, tid, nt);
+  // (MJ symmetric: MJ * dIDC = MJ^T dIDC, both operands contiguous along the contraction index; 16 x 16 tiles on the matrix cores)
+  mmTNmfma<RVF>(&sm[S::MJ], SVF, &sm[S::DIDC], SVF, dimvf, NX, dimvf, tid, nt, [&](int r, int c, double v) { sm[S::MJD + r + SVF * c] = v; });
+  STAMP(11);
   mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], SVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
-  __syncthreads();
-  for (int e = tid; e < dimvf * NX; e += nt) {
-    const int c = e / dimvf, r = e - c * dimvf;
-    double val;
-    if (r < NV) val = -sm[S::QAA + r] * sm[S::MJD + r + SVF * c];
-    else val = -dotAny(&sm[S::QFF + (r - NV)], SF, &sm[S::MJD + NV + SVF * c], 1, dimf);
-    sm[S::QAFQV + r + SVF * c] = val;
+  // Qafu_full = Qaf MJ.leftCols(nv) needs only MJ: it runs next to the product above (QAFU aliases M, J, dead since the last barrier).
+  // Acceleration rows (Qaa diagonal) and contact rows (Qff dense) as loops of their own: no divergence, constant trip counts.
+#pragma unroll
+  for (int t = 0; t < (NV * NV + nt - 1) / nt; ++t) {
+    const int e = tid + nt * t;
+    if (e < NV * NV) { const int c = e / NV, r = e - c * NV; sm[S::QAFU + r + SVF * c] = hu * sm[S::QAA + r] * sm[S::MJ + r + SVF * c]; }
   }
-  for (int e = tid; e < dimvf * NV; e += nt) {
-    const int c = e / dimvf, r = e - c * dimvf;
-    double val;
-    if (r < NV) val = sm[S::QAA + r] * sm[S::MJ + r + SVF * c];
-    else val = dotAny(&sm[S::QFF + (r - NV)], SF, &sm[S::MJ + NV + SVF * c], 1, dimf);
-    sm[S::QAFU + r + SVF * c] = hu * val;
+  for (int e = tid; e < dimf * NV; e += nt) {
+    const int c = e / dimf, r = e - c * dimf;
+    sm[S::QAFU + NV + r + SVF * c] = hu * dotAny(&sm[S::QFF + r], SF, &sm[S::MJ + NV + SVF * c], 1, dimf);
+  }
+  STAMP(12);
+  __syncthreads();
+  STAMP(13);
+  // Qafqv = -Qaf MJD (QAFQV aliases dIDC, which the product above was still reading)
+#pragma unroll
+  for (int t = 0; t < (NV * NX + nt - 1) / nt; ++t) {
+    const int e = tid + nt * t;
+    if (e < NV * NX) { const int c = e / NV, r = e - c * NV; sm[S::QAFQV + r + SVF * c] = -sm[S::QAA + r] * sm[S::MJD + r + SVF * c]; }
+  }
+  for (int e = tid; e < dimf * NX; e += nt) {
+    const int c = e / dimf, r = e - c * dimf;
+    sm[S::QAFQV + NV + r + SVF * c] = -dotAny(&sm[S::QFF + r], SF, &sm[S::MJD + NV + SVF * c], 1, dimf);
   }
   if (tid < dimvf) {
     const int r = tid;
@@ -600,20 +610,38 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // ---- H. condensed Hessian / gradients / dynamics (contact_dynamics.hxx:129-157) ----
   // Qxx = (cost + IPM terms) - MJD^T Qafqv ; Qxu_full = -MJD^T Qafu_full ; Quu_full = diag + MJ.topRows^T Qafu_full.
   // The products go straight to the kkt / exp records.
-  mmTN22Epi(&sm[S::MJD], SVF, &sm[S::QAFQV], SVF, NX, NX, dimvf, tid, nt, [&](int r, int c, double v) {
-    double base = 0.0;
-    if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
-    else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
-    kk[L::K_QXX + r + NX * c] = base - v;
-  });
-  mmTN22Epi(&sm[S::MJD], SVF, &sm[S::QAFU], SVF, NX, NV, dimvf, tid, nt, [&](int r, int c, double v) {
-    if (c < 6) ee[L::E_QXUP + r + NX * c] = -v;            // passive columns of Qxu_full
-    else kk[L::K_QXU + r + NX * (c - 6)] = -v;
-  });
-  mmTN22Epi(&sm[S::MJ], SVF, &sm[S::QAFU + SVF * 6], SVF, NV, NU, dimvf, tid, nt, [&](int r, int c, double v) {      // MJ symmetric
-    if (r < 6) ee[L::E_QUUP + r + 6 * c] = v;              // Quu_passive_topRight
-    else kk[L::K_QUU + (r - 6) + NU * c] = v + ((r - 6 == c) ? sm[S::HUD + c] : 0.0);
-  });
+  {
+    // one job list for the three products, dealt round-robin to the four wavefronts: 9 tiles of Qxx, 6 of Qxu_full, 2 of Quu_full
+    constexpr int TX = (NX + 15) / 16, TV = (NV + 15) / 16, TU = (NU + 15) / 16, J0 = TX * TX, J1 = J0 + TX * TV, J2 = J1 + TV * TU;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int job = wave; job < J2; job += nt >> 6) {
+      if (job < J0) {
+        const int jb = job / TX, ib = job - jb * TX;
+        const mfma_d4 acc = mfmaTileTN<RVF>(&sm[S::MJD + SVF * 16 * ib], SVF, NX - 16 * ib, &sm[S::QAFQV + SVF * 16 * jb], SVF, NX - 16 * jb, dimvf, lane);
+        mfmaTileStore(acc, 16 * ib, 16 * jb, NX, NX, lane, [&](int r, int c, double v) {
+          double base = 0.0;
+          if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
+          else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
+          kk[L::K_QXX + r + NX * c] = base - v;
+        });
+      } else if (job < J1) {
+        const int t = job - J0, jb = t / TX, ib = t - jb * TX;
+        const mfma_d4 acc = mfmaTileTN<RVF>(&sm[S::MJD + SVF * 16 * ib], SVF, NX - 16 * ib, &sm[S::QAFU + SVF * 16 * jb], SVF, NV - 16 * jb, dimvf, lane);
+        mfmaTileStore(acc, 16 * ib, 16 * jb, NX, NV, lane, [&](int r, int c, double v) {
+          if (c < 6) ee[L::E_QXUP + r + NX * c] = -v;            // passive columns of Qxu_full
+          else kk[L::K_QXU + r + NX * (c - 6)] = -v;
+        });
+      } else {
+        const int t = job - J1, jb = t / TV, ib = t - jb * TV;
+        const mfma_d4 acc = mfmaTileTN<RVF>(&sm[S::MJ + SVF * 16 * ib], SVF, NV - 16 * ib, &sm[S::QAFU + SVF * (6 + 16 * jb)], SVF, NU - 16 * jb, dimvf, lane);   // MJ symmetric
+        mfmaTileStore(acc, 16 * ib, 16 * jb, NV, NU, lane, [&](int r, int c, double v) {
+          if (r < 6) ee[L::E_QUUP + r + 6 * c] = v;              // Quu_passive_topRight
+          else kk[L::K_QUU + (r - 6) + NU * c] = v + ((r - 6 == c) ? sm[S::HUD + c] : 0.0);
+        });
+      }
+    }
+  }
+  STAMP(14);
   if (tid < NX) {                                   // lx -= MJD^T laf
     const double acc = dotAny(&sm[S::MJD + SVF * tid], 1, &sm[S::LAF], 1, dimvf);
     if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;

@@ -171,6 +171,7 @@ struct OcpBuffers {
   double* err;           // [batch]
   int* status;           // [batch]
   long long* prof;       // [64] diagnostic: wall-clock stamps of one workgroup of the condensation kernel
+  int prof_dimf;         // which instantiation of the condensation kernel stamps (its DIMF; IDOCP_PROF_DIMF, default: all feet)
   // filter line search (src/line_search/line_search.cpp): trial iterate s (+) alpha d, per-stage (cost, violation, barrier) and their sums
   double* sol_try;       // [batch][NS][SOL]
   double* merit_stage;   // [batch][NS][4]   cost, l1 violation, dt * barrier cost, -

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     const double dt = nd->dtq;
     const long rec = base + nd->slot;
     const int dimi = HYBRID ? nd->sw_dimi : 0;
-    const bool stamp = tid == 0 && b == 7 && i == M / 2 && B.prof != nullptr;
+    const bool stamp = tid == 0 && b == (gridDim.x > 7 ? 7 : 0) && i == M / 2 && B.prof != nullptr;
 #define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
     RSTAMP(0);
     // software pipeline: the record of stage i was staged into LDS at the end of the previous
