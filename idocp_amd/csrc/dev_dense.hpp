@@ -553,6 +553,25 @@ __device__ __forceinline__ mfma_d4 mfmaTileTN(const double* X, int ldx, int xr, 
   }
   return acc;
 }
+// The same tile with operands that are NOT contiguous along k (or whose layout differs from lane to lane): every lane passes the
+// address of entry k = 0 of ITS row of C in the left operand (xp, stride xs between consecutive k) and of ITS column index li of the
+// right operand (yp, ys); 8-byte reads, one instruction per four k's.  Result as above: lane (li, g), register q holds C(li, g + 4 q).
+template <int K>
+__device__ __forceinline__ mfma_d4 mfmaTileStrided(const double* xp, int xs, const double* yp, int ys, int lane) {
+  constexpr int KS = (K + 3) / 4;
+  const int g = lane >> 4;
+  double xa[KS], ya[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + g, kc = (4 * s + 3 < K) ? k : (k < K ? k : K - 1);
+    xa[s] = xp[xs * kc]; ya[s] = yp[ys * kc];
+    if (4 * s + 3 >= K && k >= K) { xa[s] = 0.0; ya[s] = 0.0; }
+  }
+  mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s], xa[s], acc, 0, 0, 0);
+  return acc;
+}
 // store(r, c, value) for the elements of a tile at (r0, c0) that lie inside m x n
 template <typename Store>
 __device__ __forceinline__ void mfmaTileStore(const mfma_d4& acc, int r0, int c0, int m, int n, int lane, Store store) {

@@ -24,34 +24,242 @@ namespace idocp_dev {
 
 template <typename D>
 struct RiccatiSmem {
-  static constexpr int NV = D::NV, NX = D::NX, NU = D::NU;
+  static constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF;
+  static constexpr int LDW = NX + 2;                                         // 38: rows of W start 12 banks apart, 16 lanes hit 16 bank groups
   static constexpr int PQQ = 0, PQV = PQQ + NV * NV, PVV = PQV + NV * NV, SQ = PVV + NV * NV, SV = SQ + NV,
                        STAGE = SV + NV + 4,                                  // copy of the kkt record without Qxx
                        STAGE_LEN = OcpLayout<D>::KKT - OcpLayout<D>::K_QXU,
-                       ATPQQ = STAGE + STAGE_LEN, ATPQV = ATPQQ + NV * NV, ATPVQ = ATPQV + NV * NV, ATPVV = ATPVQ + NV * NV,
-                       BTPQ = ATPVV + NV * NV, BTPV = BTPQ + NU * NV, KM = BTPV + NU * NV,
-                       GK = BTPQ,                                            // Quu K reuses the B^T P scratch
-                       KV = KM + NU * NX,
+                       // W = [A^T P; B^T P] (NX + NU rows, NX columns) stored row by row: W(i, c) at WT + c + LDW i
+                       WT = STAGE + STAGE_LEN, GK = WT + LDW * NX,           // Quu K reuses the rows of B^T P
+                       KM = WT + LDW * (NX + NU), KV = KM + NU * NX,
                        GW = KV + 16, SQN = GW + NU * NU, SVN = SQN + NV, INVD = SVN + NV + 4, TOTAL = INVD + NU + 4;
-  static_assert(2 * NU * NV == NU * NX, "GK aliases B^T P");
+  static_assert(NU * NX <= NU * LDW, "GK aliases B^T P");
   // extra blocks of the HYBRID instantiation (stages that carry a switching constraint: Schur-complement step of
-  // SplitRiccatiFactorizer::backwardRiccatiRecursion, split_riccati_factorizer.hxx:43-101)
-  // They alias blocks that are dead at that point, so the HYBRID instantiation needs no extra LDS:
-  //   A^T P (dead once F, H, G and the k-independent part of the s recursion are done; only ATPQQ / ATPVV are reused
-  //   later, as symmetrisation scratch):  DG, SS -> ATPQQ ;  DtM (lives until the write-back) -> ATPQV..ATPVQ ;
-  //   SDG, m, Phix^T m -> ATPVV (consumed before the symmetrisation)
-  //   B^T P / GK: M (dead once DtM is formed, before GK = Quu K is written)
-  // Phix, Phiu, P are read from the swc record (L2) where needed.
-  static constexpr int NF = D::NF;
-  static constexpr int DG = ATPQQ, SS = DG + NF * NU, DTM = ATPQV, SDG = ATPVV, MV = SDG + NF * NU, SCORR = MV + NF, MMX = BTPQ;
-  static_assert(2 * NF * NU <= NV * NV && NU * NX <= 2 * NV * NV && NF * NU + NF + NX <= NV * NV && NF * NX <= 2 * NU * NV, "hybrid aliases");
+  // SplitRiccatiFactorizer::backwardRiccatiRecursion, split_riccati_factorizer.hxx:43-101).  They alias the rows of A^T P, dead once
+  // F, H, G and the k-independent part of the s recursion are done, so the HYBRID instantiation needs no extra LDS; M aliases
+  // B^T P / GK (dead once DtM is formed, before GK = Quu K is written).  Phix, Phiu, P are read from the swc record (L2) where needed.
+  static constexpr int DG = WT, SS = DG + NF * NU, DTM = SS + NF * NF, SDG = DTM + NU * NX, MV = SDG + NF * NU, SCORR = MV + NF,
+                       MMX = GK;
+  static_assert(SCORR + NX <= GK && NF * NX <= NU * LDW, "hybrid aliases");
+  static_assert(TOTAL * 8 + 64 <= 40960, "four instances per CU");
 };
+
+// tile (ib, jb) number t of the upper block triangle of a 3 x 3 tiling: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+__device__ __forceinline__ void upperTile3(int t, int& ib, int& jb) {
+  if (t < 3) { ib = 0; jb = t; } else if (t < 5) { ib = 1; jb = t - 2; } else { ib = 2; jb = 2; }
+}
+
+// ---- the four tiled products of a stage.  A wavefront owns the tiles [TB, TE) of a phase (compile-time, so that every operand
+// set and accumulator is a named register): it reads the operand sets its tiles share ONCE, runs the k-steps of all its tiles
+// interleaved (independent accumulators: the matrix core issues back to back) and finishes with the epilogues. ----
+constexpr int tileBegin(int ntiles, int w, int nw) { return (ntiles * w + nw - 1) / nw; }
+constexpr bool tilesUseMod3(int tb, int te, int v) { for (int t = tb; t < te; ++t) if (t % 3 == v) return true; return false; }
+constexpr bool tilesUseDiv3(int tb, int te, int v) { for (int t = tb; t < te; ++t) if (t / 3 == v) return true; return false; }
+constexpr int upperIb(int t) { return t < 3 ? 0 : (t < 5 ? 1 : 2); }
+constexpr int upperJb(int t) { return t < 3 ? t : (t < 5 ? t - 2 : 2); }
+constexpr bool tilesUseUpperIb(int tb, int te, int v) { for (int t = tb; t < te; ++t) if (upperIb(t) == v) return true; return false; }
+constexpr bool tilesUseUpperJb(int tb, int te, int v) { for (int t = tb; t < te; ++t) if (upperJb(t) == v) return true; return false; }
+
+template <int K>
+__device__ __forceinline__ void mfmaLoadOp(double (&o)[(K + 3) / 4], const double* p, int stride, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < (K + 3) / 4; ++s) {
+    const int k = 4 * s + g;
+    if (4 * s + 3 < K) o[s] = p[stride * k];
+    else { const double v = p[stride * (k < K ? k : K - 1)]; o[s] = k < K ? v : 0.0; }
+  }
+}
+
+// phase 1: W = [A^T P; B^T P], tile t = 3 ib + cb covers rows 16 ib .. of W and columns 16 cb .. of P
+template <typename D, int TB, int TE>
+__device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* Pqv, const double* Pvv, const double* Fall, const double* Fqq6,
+                                              const double* Fqv6, double dt, double* Wt, int lane) {
+  constexpr int NV = D::NV, NX = D::NX, KS = (NV + 3) / 4, LDW = RiccatiSmem<D>::LDW, NTL = TE - TB;
+  if constexpr (NTL > 0) {
+    const int li = lane & 15, g = lane >> 4;
+    double xo[3][KS], yo[3][KS];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      if (tilesUseMod3(TB, TE, v)) {
+        const int c = 16 * v + li, cc = c < NX ? c : NX - 1;
+        mfmaLoadOp<NV>(xo[v], cc < NV ? Pqv + cc : Pvv + NV * (cc - NV), cc < NV ? NV : 1, lane);      // P(v, c): column c of Pvq = row c of Pqv
+      }
+      if (tilesUseDiv3(TB, TE, v)) mfmaLoadOp<NV>(yo[v], Fall + NV * (16 * v + li), 1, lane);
+    }
+    mfma_d4 acc[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[(TB + j) / 3][s], xo[(TB + j) % 3][s], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int cb = (TB + j) % 3, ib = (TB + j) / 3;
+      const int c = 16 * cb + li, cc = c < NX ? c : NX - 1;
+      const double* pq = cc < NV ? Pqq + NV * cc : Pqv + NV * (cc - NV);          // P(q, c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ib + g + 4 * q;                                      // row of W
+        double val = acc[j][q];
+        if (r < NX) {
+          const int rr6 = r < NV ? r : r - NV;
+          if (rr6 >= 6) {
+            val += (r < NV) ? pq[rr6] : dt * pq[rr6];
+          } else {
+            const double* F6 = (r < NV ? Fqq6 : Fqv6) + 6 * rr6;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) val += F6[m] * pq[m];
+          }
+        }
+        if (c < NX) Wt[c + LDW * r] = val;
+      }
+    }
+  }
+}
+
+// phase 2: [F H; . G] on the upper block triangle, tile t -> (upperIb, upperJb); qxx[j][q]: Qxx entry of local tile j, register q
+template <typename D, int TB, int TE, int T2W>
+__device__ __forceinline__ void riccatiPhase2(const double* Wt, const double* Fall, const double* Fqq6, const double* Fqv6, double dt,
+                                              const double (&qxx)[T2W][4], double* Pqq, double* Pqv, double* Pvv, double* Qxu, double* Quu,
+                                              int lane) {
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, KS = (NV + 3) / 4, LDW = RiccatiSmem<D>::LDW, NTL = TE - TB;
+  static_assert(NTL <= T2W, "Qxx registers");
+  if constexpr (NTL > 0) {
+    const int li = lane & 15, g = lane >> 4;
+    double xo[3][KS], yo[3][KS];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      if (tilesUseUpperIb(TB, TE, v)) mfmaLoadOp<NV>(xo[v], Wt + LDW * (16 * v + li) + NV, 1, lane);
+      if (tilesUseUpperJb(TB, TE, v)) mfmaLoadOp<NV>(yo[v], Fall + NV * (16 * v + li), 1, lane);
+    }
+    mfma_d4 acc[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[upperJb(TB + j)][s], xo[upperIb(TB + j)][s], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int ib = upperIb(TB + j), jb = upperJb(TB + j);
+      const int r = 16 * ib + li;                                             // row of [F H; . G]
+      const double* wr = Wt + LDW * r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 16 * jb + g + 4 * q;
+        double val = acc[j][q] + qxx[j][q];
+        if (c < NX) {
+          const int c6 = c < NV ? c : c - NV;
+          if (c6 >= 6) {
+            val += (c < NV) ? wr[c6] : dt * wr[c6];
+          } else {
+            const double* F6 = (c < NV ? Fqq6 : Fqv6) + 6 * c6;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) val += wr[m] * F6[m];
+          }
+        }
+        // Only the entries on and above the diagonal are used and mirrored (also inside the diagonal tiles): P stays EXACTLY
+        // symmetric.  An antisymmetric rounding residue would not be damped by the feedback term and grows with the open-loop
+        // dynamics from stage to stage (measured: 2.9 x per stage) -- the reason for the reference's (P + P^T) / 2.
+        if (c >= NX) {
+          if (r < NX) Qxu[r + NX * (c - NX)] += val; else Quu[(r - NX) + NU * (c - NX)] += val;
+        } else if (r <= c) {
+          if (c < NV) { Pqq[r + NV * c] = val; if (r != c) Pqq[c + NV * r] = val; }
+          else if (r < NV) Pqv[r + NV * (c - NV)] = val;
+          else { Pvv[(r - NV) + NV * (c - NV)] = val; if (r != c) Pvv[(c - NV) + NV * (r - NV)] = val; }
+        }
+      }
+    }
+  }
+}
+
+// phase 4: GK = Quu K, tile t covers the columns 16 t .. of K
+template <typename D, int TB, int TE>
+__device__ __forceinline__ void riccatiPhase4(const double* Quu, const double* KM, double* GK, int lane) {
+  constexpr int NX = D::NX, NU = D::NU, KS = (NU + 3) / 4, NTL = TE - TB;
+  if constexpr (NTL > 0) {
+    const int li = lane & 15, g = lane >> 4;
+    double xo[KS], yo[NTL][KS];
+    mfmaLoadOp<NU>(xo, Quu + NU * (li < NU ? li : NU - 1), 1, lane);           // Quu symmetric
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) { const int c = 16 * (TB + j) + li; mfmaLoadOp<NU>(yo[j], KM + NU * (c < NX ? c : NX - 1), 1, lane); }
+    mfma_d4 acc[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[j][s], xo[s], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 16 * (TB + j) + g + 4 * q;
+        if (li < NU && c < NX) GK[li + NU * c] = acc[j][q];
+      }
+  }
+}
+
+// phase 5: P = F - K^T GK on the upper block triangle
+template <typename D, int TB, int TE>
+__device__ __forceinline__ void riccatiPhase5(const double* KM, const double* GK, double* Pqq, double* Pqv, double* Pvv, int lane) {
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, KS = (NU + 3) / 4, NTL = TE - TB;
+  if constexpr (NTL > 0) {
+    const int li = lane & 15, g = lane >> 4;
+    double xo[3][KS], yo[3][KS];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int e = 16 * v + li, ec = e < NX ? e : NX - 1;
+      if (tilesUseUpperIb(TB, TE, v)) mfmaLoadOp<NU>(xo[v], KM + NU * ec, 1, lane);
+      if (tilesUseUpperJb(TB, TE, v)) mfmaLoadOp<NU>(yo[v], GK + NU * ec, 1, lane);
+    }
+    mfma_d4 acc[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[upperJb(TB + j)][s], xo[upperIb(TB + j)][s], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int r = 16 * upperIb(TB + j) + li;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 16 * upperJb(TB + j) + g + 4 * q;
+        const double val = acc[j][q];
+        if (r <= c && c < NX) {
+          if (c < NV) { Pqq[r + NV * c] -= val; if (r != c) Pqq[c + NV * r] -= val; }
+          else if (r < NV) Pqv[r + NV * (c - NV)] -= val;
+          else { Pvv[(r - NV) + NV * (c - NV)] -= val; if (r != c) Pvv[(c - NV) + NV * (r - NV)] -= val; }
+        }
+      }
+    }
+  }
+}
+
+// the wavefront's share of a phase: FN<D, tile range of wave w>(args)
+#define RICCATI_TILES(FN, NTILES, ...)                                                                                                 \
+  do {                                                                                                                                 \
+    if constexpr (NW == 1) { FN<D, 0, NTILES>(__VA_ARGS__); }                                                                          \
+    else if constexpr (NW == 2) {                                                                                                      \
+      if (wave == 0) FN<D, tileBegin(NTILES, 0, 2), tileBegin(NTILES, 1, 2)>(__VA_ARGS__);                                            \
+      else FN<D, tileBegin(NTILES, 1, 2), tileBegin(NTILES, 2, 2)>(__VA_ARGS__);                                                      \
+    } else {                                                                                                                           \
+      if (wave == 0) FN<D, tileBegin(NTILES, 0, 4), tileBegin(NTILES, 1, 4)>(__VA_ARGS__);                                            \
+      else if (wave == 1) FN<D, tileBegin(NTILES, 1, 4), tileBegin(NTILES, 2, 4)>(__VA_ARGS__);                                       \
+      else if (wave == 2) FN<D, tileBegin(NTILES, 2, 4), tileBegin(NTILES, 3, 4)>(__VA_ARGS__);                                       \
+      else FN<D, tileBegin(NTILES, 3, 4), tileBegin(NTILES, 4, 4)>(__VA_ARGS__);                                                      \
+    }                                                                                                                                  \
+  } while (0)
 
 template <typename D, int NT, bool HYBRID>
 __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = RiccatiSmem<D>;
-  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV, NF = D::NF;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV, NF = D::NF, LDW = S::LDW, NW = NT / 64;
+  static_assert(NX + NU == 48 && NX <= 48, "3 x 3 tiles of 16");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
@@ -59,11 +267,13 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
   const OcpNode* __restrict__ nodes = B.nodes;
   const int tid = threadIdx.x;
   constexpr int nt = NT;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const long b = blockIdx.x;
   const long base = b * P->NS;                    // first record of this instance
   double* Pqq = &sm[S::PQQ];
   double* Pqv = &sm[S::PQV];
   double* Pvv = &sm[S::PVV];
+  double* Wt = &sm[S::WT];
   double* st = &sm[S::STAGE];     // st[k - K_QXU] holds kkt[k] for k >= K_QXU
   constexpr int KO = L::K_QXU, SL = S::STAGE_LEN;
   if (tid == 0) s_ok = 1;
@@ -98,39 +308,35 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     const bool stamp = tid == 0 && b == (gridDim.x > 7 ? 7 : 0) && i == M / 2 && B.prof != nullptr;
 #define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
     RSTAMP(0);
-    // software pipeline: the record of stage i was staged into LDS at the end of the previous
-    // iteration; issue the global loads of stage i-1 now and park them in registers
-    constexpr int PF = (SL + NT - 1) / NT;
-    // Phases 1 and 2 below work on 3 x 3 register tiles, one JOB per thread and round (a job = one tile position of
-    // one or two output blocks that share an operand):
-    //   phase 1 (96 jobs):  0..35 (A^T P)qq|qv   36..71 (A^T P)vq|vv   72..95 (B^T P)q|v
-    //   phase 2 (112 jobs): 0..35 F_qq|F_qv      36..71 F_vv           72..95 H_q|H_v     96..111 G
-    constexpr int T6 = NV / 3, T4 = NU / 3, J1 = 2 * T6 * T6 + T4 * T6, J2A = T6 * T6, J2B = 2 * T6 * T6, J2C = J2B + T6 * T4,
-                  J2D = J2C + T4 * T4, JPT = (J2D + NT - 1) / NT;
-    static_assert(NV % 3 == 0 && NU % 3 == 0 && NV >= 6, "3 x 3 tiles aligned with the 6 x 6 base block");
-    double pre[PF], qxx[JPT][2][3][3];
+    // The matrix products of a stage run as 16 x 16 tiles on the matrix cores (mfmaTileStrided, dev_dense.hpp), a tile per
+    // wavefront and round, with the structured part of the dynamics (A = [Fqq Fqv; Fvq Fvv], Fqq = diag(Fqq6, I), Fqv = diag(Fqv6, dt I))
+    // added in the epilogue of the tile:
+    //   phase 1 (9 tiles):  W = [A^T P; B^T P] = [Fvq Fvv Fvu]^T P(v, :)  +  [Fqq Fqv 0]^T P(q, :)
+    //   phase 2 (6 tiles):  [F H; . G] = [Qxx Qxu; . Quu] + W(:, v) [Fvq Fvv Fvu]  +  W(:, q) [Fqq Fqv 0], upper block triangle, mirrored
+    //   phase 4 (3 tiles):  GK = Quu K            phase 5 (6 tiles):  P = F - K^T GK, upper block triangle, mirrored
+    // P and F are symmetric; computing the tiles above the diagonal and mirroring them replaces the reference's P = (P + P^T) / 2
+    // (backward_riccati_recursion_factorizer.hxx:133-135).
+    constexpr int PF = (SL + NT - 1) / NT, T1 = 9, T2 = 6, T2W = (T2 + NW - 1) / NW;
+    double pre[PF], qxx[T2W][4];
     {
-      // Qxx of THIS stage is consumed once per element in the F phase: straight to the registers of the job that adds it
+      // Qxx of THIS stage is consumed once per element in phase 2: straight to the registers of the lane that adds it
       const double* __restrict__ kc = B.kkt + rec * L::KKT;
+      const int t2b = tileBegin(T2, wave, NW), t2e = tileBegin(T2, wave + 1, NW);      // this wavefront's tiles of phase 2
 #pragma unroll
-      for (int jj = 0; jj < JPT; ++jj) {
-        const int job = tid + NT * jj;
-        if (job < J2B) {
-          const int t = job < J2A ? job : job - J2A, r0 = 3 * (t % T6), c0 = 3 * (t / T6);
+      for (int jj = 0; jj < T2W; ++jj) {
+        const int t = t2b + jj;
+        int ib, jb;
+        upperTile3(t < t2e ? t : 0, ib, jb);
+        const int r = 16 * ib + li;
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              if (job < J2A) {
-                qxx[jj][0][a][c] = kc[L::K_QXX + (r0 + a) + NX * (c0 + c)];
-                qxx[jj][1][a][c] = kc[L::K_QXX + (r0 + a) + NX * (NV + c0 + c)];
-              } else {
-                qxx[jj][0][a][c] = kc[L::K_QXX + (NV + r0 + a) + NX * (NV + c0 + c)];
-              }
-            }
+        for (int q = 0; q < 4; ++q) {
+          const int c = 16 * jb + g + 4 * q;
+          qxx[jj][q] = (t < t2e && r <= c && c < NX) ? kc[L::K_QXX + r + NX * c] : 0.0;
         }
       }
     }
+    // software pipeline: the record of stage i was staged into LDS at the end of the previous
+    // iteration; issue the global loads of stage i-1 now and park them in registers
     if (i > 0) {
       const double* __restrict__ kn = B.kkt + (base + nodes[i - 1].slot) * L::KKT + KO;
 #pragma unroll
@@ -140,6 +346,8 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     double* Quu = st + (L::K_QUU - KO);
     const double* Fqq6 = st + (L::K_FQQ - KO);
     const double* Fqv6 = st + (L::K_FQV - KO);
+    const double* Fall = st + (L::K_FVQ - KO);       // [Fvq Fvv Fvu]: NV rows, NX + NU columns
+    static_assert(L::K_FVV == L::K_FVQ + NV * NV && L::K_FVU == L::K_FVV + NV * NV, "[Fvq Fvv Fvu] contiguous");
     const double* Fvq = st + (L::K_FVQ - KO);
     const double* Fvv = st + (L::K_FVV - KO);
     const double* Fvu = st + (L::K_FVU - KO);
@@ -147,181 +355,62 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     double* lu = st + (L::K_LU - KO);
     const double* Fx = st + (L::K_FX - KO);
     RSTAMP(1);
-    // ---- A^T P blocks and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
-    for (int job = tid; job < J1; job += nt) {
-      // out1 = X^T Pvq (+ base1), out2 = X^T Pvv (+ base2) on one tile: X = Fvq (qq|qv), Fvv (vq|vv) or Fvu (B^T P)
-      const bool bt = job >= 2 * T6 * T6, vhalf = !bt && job >= T6 * T6;
-      const int t = bt ? job - 2 * T6 * T6 : (vhalf ? job - T6 * T6 : job);
-      const int nr = bt ? T4 : T6, r0 = 3 * (t % nr), c0 = 3 * (t / nr);
-      const double* X = (bt ? Fvu : (vhalf ? Fvv : Fvq)) + NV * r0;
-      double a1[3][3], a2[3][3];
-      if (bt) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) a1[a][c] = a2[a][c] = 0.0;
-      } else if (r0 < 6) {
-        const double* F6 = (vhalf ? Fqv6 : Fqq6) + 6 * r0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) a1[a][c] = a2[a][c] = 0.0;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          double f[3], pq[3], pv[3];
-#pragma unroll
-          for (int a = 0; a < 3; ++a) { f[a] = F6[m + 6 * a]; pq[a] = Pqq[m + NV * (c0 + a)]; pv[a] = Pqv[m + NV * (c0 + a)]; }
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a1[a][c] += f[a] * pq[c]; a2[a][c] += f[a] * pv[c]; }
-        }
-      } else {
-        const double sc = vhalf ? dt : 1.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int e = (r0 + a) + NV * (c0 + c);
-            a1[a][c] = vhalf ? sc * Pqq[e] : Pqq[e];
-            a2[a][c] = vhalf ? sc * Pqv[e] : Pqv[e];
-          }
-      }
-#pragma unroll 6
-      for (int m = 0; m < NV; ++m) {
-        double f[3], pvq[3], pvv[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { f[a] = X[m + NV * a]; pvq[a] = Pqv[(c0 + a) + NV * m]; pvv[a] = Pvv[m + NV * (c0 + a)]; }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { a1[a][c] += f[a] * pvq[c]; a2[a][c] += f[a] * pvv[c]; }
-      }
-      double* o1 = bt ? &sm[S::BTPQ] : (vhalf ? &sm[S::ATPVQ] : &sm[S::ATPQQ]);
-      double* o2 = bt ? &sm[S::BTPV] : (vhalf ? &sm[S::ATPVV] : &sm[S::ATPQV]);
-      const int ldo = bt ? NU : NV;
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { o1[(r0 + a) + ldo * (c0 + c)] = a1[a][c]; o2[(r0 + a) + ldo * (c0 + c)] = a2[a][c]; }
-    }
+    // ---- phase 1: A^T P and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
+    RICCATI_TILES(riccatiPhase1, T1, Pqq, Pqv, Pvv, Fall, Fqq6, Fqv6, dt, Wt, lane);
     __syncthreads();
-    const double* AtPqq = &sm[S::ATPQQ];
-    const double* AtPqv = &sm[S::ATPQV];
-    const double* AtPvq = &sm[S::ATPVQ];
-    const double* AtPvv = &sm[S::ATPVV];
-    const double* BtPq = &sm[S::BTPQ];
-    const double* BtPv = &sm[S::BTPV];
     RSTAMP(2);
-    // ---- F, H, G and the vector term (:79-113); F overwrites P_{i+1}, which is dead from here ----
-#pragma unroll
-    for (int jj = 0; jj < JPT; ++jj) {
-      const int job = tid + NT * jj;
-      // Every tile job runs the same instruction stream (no divergence inside a wavefront):
-      //   out1 = base1 + X1 Y1, out2 = base2 + X2 Y2 with per-job operand pointers
-      //   F_qq | F_qv : X1 = X2 = (A^T P)qv, Y1 = Fvq, Y2 = Fvv ;  F_vv : X2 = (A^T P)vv, Y2 = Fvv (out1 unused)
-      //   H_q | H_v   : X1 = (A^T P)qv, X2 = (A^T P)vv, Y1 = Y2 = Fvu ;  G : X1 = (B^T P)v, Y1 = Fvu (out2 unused)
-      if (job < J2D) {
-        int type, t, nr;
-        if (job < J2A) { type = 0; t = job; nr = T6; }
-        else if (job < J2B) { type = 1; t = job - J2A; nr = T6; }
-        else if (job < J2C) { type = 2; t = job - J2B; nr = T6; }
-        else { type = 3; t = job - J2C; nr = T4; }
-        const int r0 = 3 * (t % nr), c0 = 3 * (t / nr);
-        const double* X1 = (type == 3 ? BtPv : AtPqv) + r0;
-        const double* X2 = (type == 0 ? AtPqv : AtPvv) + (type == 3 ? 0 : r0);
-        const int ldx1 = type == 3 ? NU : NV;
-        const double* Y1 = (type == 0 || type == 1 ? Fvq : Fvu) + NV * c0;
-        const double* Y2 = (type == 0 || type == 1 ? Fvv : Fvu) + NV * c0;
-        double a1[3][3], a2[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) a1[a][c] = a2[a][c] = 0.0;
-        if (type <= 1) {
-          const double* Ab = (type == 1 ? AtPvq : AtPqq) + r0;          // multiplies the 6 x 6 / identity part of A
-          if (c0 < 6) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-              double x[3], fq[3], fv[3];
-#pragma unroll
-              for (int a = 0; a < 3; ++a) { x[a] = Ab[a + NV * m]; fq[a] = Fqq6[m + 6 * (c0 + a)]; fv[a] = Fqv6[m + 6 * (c0 + a)]; }
-#pragma unroll
-              for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { a1[a][c] += x[a] * fq[c]; a2[a][c] += x[a] * fv[c]; }
-            }
-          } else {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-              for (int c = 0; c < 3; ++c) { const double x = Ab[a + NV * (c0 + c)]; a1[a][c] = x; a2[a][c] = dt * x; }
-          }
-        }
-#pragma unroll 6
-        for (int m = 0; m < NV; ++m) {
-          double x1[3], x2[3], y1[3], y2[3];
-#pragma unroll
-          for (int a = 0; a < 3; ++a) { x1[a] = X1[a + ldx1 * m]; x2[a] = X2[a + NV * m]; y1[a] = Y1[m + NV * a]; y2[a] = Y2[m + NV * a]; }
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a1[a][c] += x1[a] * y1[c]; a2[a][c] += x2[a] * y2[c]; }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int e = (r0 + a) + NV * (c0 + c);
-            if (type == 0) { Pqq[e] = qxx[jj][0][a][c] + a1[a][c]; Pqv[e] = qxx[jj][1][a][c] + a2[a][c]; }
-            else if (type == 1) Pvv[e] = qxx[jj][0][a][c] + a2[a][c];
-            else if (type == 2) { Qxu[(r0 + a) + NX * (c0 + c)] += a1[a][c]; Qxu[(NV + r0 + a) + NX * (c0 + c)] += a2[a][c]; }
-            else Quu[(r0 + a) + NU * (c0 + c)] += a1[a][c];
-          }
-      }
-    }
+    // ---- phase 2: F, H, G (:79-113); F overwrites P_{i+1}, which is dead from here ----
+    RICCATI_TILES(riccatiPhase2, T2, Wt, Fall, Fqq6, Fqv6, dt, qxx, Pqq, Pqv, Pvv, Qxu, Quu, lane);
     // The two vector terms run behind the tile jobs of different wavefronts (NT >= 128): lu on the last NU threads,
     // the k-independent part of the s recursion (:141-160) on the first 2 NV.  Neither reads anything the tile jobs write
-    // (P_{i+1} is only read through A^T P here).
+    // (P_{i+1} is only read through W here).
     RSTAMP(11);
-    if (tid >= NT - NU) {
-      const int j = tid - (NT - NU);
+    if (tid >= NT - 64 && lane < 4 * NU) {
+      // lu += (B^T P) Fx - Fvu^T sv: four lanes per row, nine + five terms each
+      const int j = lane >> 2, part = lane & 3;
+      const double* wj = Wt + LDW * (NX + j) + (NX / 4) * part;              // row j of B^T P
       double acc = 0.0;
-      for (int c = 0; c < NV; ++c) acc += BtPq[j + NU * c] * Fx[c] + BtPv[j + NU * c] * Fx[NV + c];
-      for (int m = 0; m < NV; ++m) acc -= Fvu[m + NV * j] * sm[S::SV + m];
-      lu[j] += acc;
+#pragma unroll
+      for (int c = 0; c < NX / 4; ++c) acc += wj[c] * Fx[(NX / 4) * part + c];
+#pragma unroll
+      for (int t = 0; t < (NV + 3) / 4; ++t) { const int m = part + 4 * t; if (m < NV) acc -= Fvu[m + NV * j] * sm[S::SV + m]; }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (part == 0) lu[j] += acc;
     }
-    if (tid < 2 * NV) {
-      const bool isv = tid >= NV;
-      const int r = isv ? tid - NV : tid;
+    // k-independent part of the s recursion (:141-160): one lane per row of x; it needs W and the old s only, so with more than one
+    // wavefront it runs on the second one BEHIND the barrier, next to the factorisation on the first
+    auto sPart1 = [&](int row) {
+      const bool isv = row >= NV;
+      const int r = isv ? row - NV : row;
       const double* F6 = isv ? Fqv6 : Fqq6;
       const double* Fm = isv ? Fvv : Fvq;
-      const double* A1 = isv ? AtPvq : AtPqq;
-      const double* A2 = isv ? AtPvv : AtPqv;
+      const double* wr = Wt + LDW * row;                                    // row of A^T P
       double acc;
       if (r < 6) {
         acc = 0.0;
+#pragma unroll
         for (int m = 0; m < 6; ++m) acc += F6[m + 6 * r] * sm[S::SQ + m];
       } else {
         acc = isv ? dt * sm[S::SQ + r] : sm[S::SQ + r];
       }
+      double a2 = 0.0;
+#pragma unroll
       for (int m = 0; m < NV; ++m) acc += Fm[m + NV * r] * sm[S::SV + m];
-      for (int c = 0; c < NV; ++c) acc -= A1[r + NV * c] * Fx[c] + A2[r + NV * c] * Fx[NV + c];
-      acc -= lx[isv ? NV + r : r];
-      sm[(isv ? S::SVN : S::SQN) + r] = acc;
-    }
+#pragma unroll
+      for (int c = 0; c < NX; ++c) a2 += wr[c] * Fx[c];
+      sm[(isv ? S::SVN : S::SQN) + r] = acc - a2 - lx[row];
+    };
+    if (NW == 1 && tid < NX) sPart1(tid);
     RSTAMP(12);
     __syncthreads();
     RSTAMP(3);
-    // Qvq = Qqv^T (:94) -- only read through Qqv below, kept for completeness of the record
-    // ---- LLT(Quu), K = -Quu^-1 Qxu^T, k = -Quu^-1 lu (split_riccati_factorizer.hxx:43-46) ----
-    // (the reference factorises with Eigen::LLT; here Quu^-1 is formed by Gauss-Jordan on one
-    // wavefront and applied with two small products -- same K, k up to rounding)
     RSTAMP(9);
     // Quu = L L^T and the solves K = -Quu^-1 Qxu^T, k = -Quu^-1 lu in the registers of one wavefront, one right-hand side per lane
     // (Eigen::LLT compute + solve, split_riccati_factorizer.hxx:43-46).  Round 1 multiplied with an explicit Gauss-Jordan
     // inverse: on the stage behind a switching constraint G = Quu + B^T P B has a condition number of 1e8 and P = F - K^T G K came
     // out 6e-9 off (5e-12 with the solves; long double referee, tests/test_hybrid_gpu.py).
+    if (NW > 1 && tid >= 64 && tid < 64 + NX) sPart1(tid - 64);
     const bool constrained = HYBRID && dimi > 0;
     if (tid < 64) {
       double x[NU];
@@ -452,48 +541,26 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
       __syncthreads();                                           // M (aliasing GK) is dead from here
     }
     RSTAMP(4);
-    // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
-    mm(colMajor(&sm[S::GK], NU), colMajor(Quu, NU), colMajor(&sm[S::KM], NU), NU, NX, NU, 1.0, false, tid, nt);
+    // ---- phase 4: GK = Quu K (backward_riccati_recursion_factorizer.hxx:128) ----
+    RICCATI_TILES(riccatiPhase4, 3, Quu, &sm[S::KM], &sm[S::GK], lane);
     // s recursion, part 2: - Qxu k
-    if (tid < NV) {
-      const int r = tid;
+    if (tid >= NT - NV) {
+      const int r = tid - (NT - NV);
       double sq = sm[S::SQN + r], sv = sm[S::SVN + r];
       for (int j = 0; j < NU; ++j) { sq -= Qxu[r + NX * j] * sm[S::KV + j]; sv -= Qxu[(NV + r) + NX * j] * sm[S::KV + j]; }
       sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
     }
     __syncthreads();
     RSTAMP(5);
-    // P = F - K^T G K (:122-131)
-    for (int e = tid; e < NN; e += nt) {
-      const int c = e / NV, r = e - c * NV;
-      double a = 0.0, b2 = 0.0, d2 = 0.0;
-      for (int j = 0; j < NU; ++j) {
-        const double kq = sm[S::KM + j + NU * r], kv = sm[S::KM + j + NU * (NV + r)];
-        a += kq * sm[S::GK + j + NU * c];
-        b2 += kq * sm[S::GK + j + NU * (NV + c)];
-        d2 += kv * sm[S::GK + j + NU * (NV + c)];
-      }
-      Pqq[e] -= a;
-      Pqv[e] -= b2;
-      Pvv[e] -= d2;
-    }
+    // ---- phase 5: P = F - K^T G K (:122-131) ----
+    RICCATI_TILES(riccatiPhase5, T2, &sm[S::KM], &sm[S::GK], Pqq, Pqv, Pvv, lane);
     __syncthreads();
     RSTAMP(6);
-    double sc_q = 0.0, sc_v = 0.0;                    // Phix^T m of this thread's row, read before ATPVV becomes scratch
-    if (HYBRID && dimi > 0 && tid < NV) { sc_q = sm[S::SCORR + tid]; sc_v = sm[S::SCORR + NV + tid]; }
-    __syncthreads();
-    // preserve the symmetry (:133-135) -- symmetrised values staged in the A^T P scratch
-    for (int e = tid; e < NN; e += nt) {
-      const int c = e / NV, r = e - c * NV;
-      sm[S::ATPQQ + e] = 0.5 * (Pqq[e] + Pqq[c + NV * r]);
-      sm[S::ATPVV + e] = 0.5 * (Pvv[e] + Pvv[c + NV * r]);
-    }
-    __syncthreads();
     RSTAMP(7);
     double* __restrict__ rr = B.ric + rec * L::RIC;
     double* __restrict__ gg = B.gain + rec * L::GAIN;
     for (int e = tid; e < NN; e += nt) {
-      double pqq = sm[S::ATPQQ + e], pqv = Pqv[e], pvv = sm[S::ATPVV + e];
+      double pqq = Pqq[e], pqv = Pqv[e], pvv = Pvv[e];
       if (HYBRID && dimi > 0) {
         // P -= K^T D^T M + (K^T D^T M)^T, block by block (split_riccati_factorizer.hxx:88-97)
         const int c = e / NV, r = e - c * NV;
@@ -506,19 +573,19 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
           avv += kvr * dvc + kvc * dvr;
         }
         pqq -= aqq; pqv -= aqv; pvv -= avv;
+        Pqq[e] = pqq; Pqv[e] = pqv; Pvv[e] = pvv;
       }
-      Pqq[e] = pqq; Pqv[e] = pqv; Pvv[e] = pvv;
       rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
     }
     if (tid < NV) {
       double sq = sm[S::SQN + tid], sv = sm[S::SVN + tid];
-      if (HYBRID && dimi > 0) { sq -= sc_q; sv -= sc_v; }     // (:98-99)
+      if (HYBRID && dimi > 0) { sq -= sm[S::SCORR + tid]; sv -= sm[S::SCORR + NV + tid]; }     // Phix^T m (:98-99)
       sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
       rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }
     for (int e = tid; e < NU * NX; e += nt) gg[L::G_K + e] = sm[S::KM + e];
     if (tid < NU) gg[L::G_k + tid] = sm[S::KV + tid];
-    __syncthreads();
+    // nothing above reads the stage copy any more: stage i - 1 moves from the registers into LDS
     if (i > 0) {
 #pragma unroll
       for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; if (e < SL) st[e] = pre[t]; }
@@ -599,18 +666,20 @@ void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool 
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     configured = true;
   }
+  static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
   // A chain with switching constraints takes the HYBRID instantiation (same LDS footprint).
   if (hybrid) {
-    hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, true>), dim3((unsigned)batch), dim3(128), smem_h, st, B);
+    if (nt_env == 256 || (nt_env == 0 && batch < 512)) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256, true>), dim3((unsigned)batch), dim3(256), smem_h, st, B);
+    else hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, true>), dim3((unsigned)batch), dim3(128), smem_h, st, B);
     return;
   }
   // Throughput mode (many instances): two wavefronts per instance, four instances per CU (39.8 kB
   // of LDS each) -- measured best at batch 1024 (2.48 ms vs 3.22 ms with one and 2.96 ms with four
   // wavefronts).  Latency mode (few instances): four wavefronts per instance.
   // IDOCP_RICCATI_NT={64,128,256} overrides the choice (tuning aid).
-  static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
   if (nt_env == 128) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, false>), dim3((unsigned)batch), dim3(128), smem, st, B);
   else if (nt_env == 256) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256, false>), dim3((unsigned)batch), dim3(256), smem, st, B);
   else if (nt_env == 64) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 64, false>), dim3((unsigned)batch), dim3(64), smem, st, B);
