@@ -597,12 +597,20 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1;
 }
 
-// S4: forward sweep, one wavefront per instance.
+// S4: forward sweep, one wavefront per instance.  The sweep is a chain of small matrix-vector products whose operands (the gain
+// K, k and the dynamics blocks of the stage, 11.7 kB) do not depend on the state: the records of stage i + 1 are fetched with
+// 16-byte loads into registers (two stages ahead) while stage i is computed out of LDS, so that the chain never waits for HBM.
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, const double* __restrict__ q0,
                                                                 const double* __restrict__ v0) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NU = D::NU;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  // the part of the kkt record the sweep reads: Fqq6 Fqv6 Fvq Fvv Fvu (lx lu) Fx, contiguous
+  constexpr int FO = L::K_FQQ, FL = L::K_FX + NX - L::K_FQQ, GL = L::GAIN;
+  static_assert(FO % 2 == 0 && FL % 2 == 0 && GL % 2 == 0 && L::KKT % 2 == 0, "16-byte loads");
+  constexpr int F2 = FL / 2, G2 = GL / 2, NF2 = (F2 + 63) / 64, NG2 = (G2 + 63) / 64;
+  __shared__ __attribute__((aligned(16))) double fb[FL], gb[GL];
   __shared__ double dx[NX], du[NU], dxn[NX];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
@@ -610,6 +618,18 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
   const long base = b * P->NS;
+  d2 frA[NF2], grA[NG2], frB[NF2], grB[NG2];        // two stages in flight
+  auto fetch = [&](int i, d2 (&fr)[NF2], d2 (&gr)[NG2]) {
+    const long rec = base + nodes[i].slot;
+    const d2* __restrict__ fp = reinterpret_cast<const d2*>(B.kkt + rec * L::KKT + FO);
+    const d2* __restrict__ gp = reinterpret_cast<const d2*>(B.gain + rec * L::GAIN);
+#pragma unroll
+    for (int t = 0; t < NF2; ++t) { const int e = lane + 64 * t; fr[t] = fp[e < F2 ? e : F2 - 1]; }
+#pragma unroll
+    for (int t = 0; t < NG2; ++t) { const int e = lane + 64 * t; gr[t] = gp[e < G2 ? e : G2 - 1]; }
+  };
+  if (M > 1) fetch(0, frA, grA);
+  if (M > 2) fetch(1, frB, grB);
   const double* __restrict__ s0 = B.sol + (base + nodes[0].slot) * L::SOL;
   // RiccatiRecursionSolver::computeInitialStateDirection (riccati_recursion_solver.cpp:110-126)
   if (lane == 0) {
@@ -621,36 +641,69 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   }
   if (lane >= 6 && lane < NV) dx[lane] = q0[b * NQ + lane + 1] - s0[L::S_Q + lane + 1];
   if (lane < NV) dx[NV + lane] = v0[b * NV + lane] - s0[L::S_V + lane];
-  __syncthreads();
-  for (int i = 0; i < M - 1; ++i) {                 // forwardRiccatiRecursion along the chain (riccati_recursion_solver.cpp:129-162)
+  const double* Fqq6 = fb + (L::K_FQQ - FO);
+  const double* Fqv6 = fb + (L::K_FQV - FO);
+  const double* Fvq = fb + (L::K_FVQ - FO);
+  const double* Fvv = fb + (L::K_FVV - FO);
+  const double* Fvu = fb + (L::K_FVU - FO);
+  const double* Fx = fb + (L::K_FX - FO);
+  auto step = [&](int i, d2 (&fr)[NF2], d2 (&gr)[NG2]) {       // forwardRiccatiRecursion along the chain (riccati_recursion_solver.cpp:129-162)
     const long rec = base + nodes[i].slot;
     const double dt = nodes[i].dtq;
-    const double* __restrict__ gg = B.gain + rec * L::GAIN;
-    const double* __restrict__ kk = B.kkt + rec * L::KKT;
     double* __restrict__ dd = B.dir + rec * L::DIR;
-    if (lane < NU) {
-      double acc = gg[L::G_k + lane];
-      for (int c = 0; c < NX; ++c) acc += gg[L::G_K + lane + NU * c] * dx[c];
-      du[lane] = acc;
-      dd[L::D_U + lane] = acc;
+#pragma unroll
+    for (int t = 0; t < NF2; ++t) { const int e = lane + 64 * t; if (e < F2) reinterpret_cast<d2*>(fb)[e] = fr[t]; }
+#pragma unroll
+    for (int t = 0; t < NG2; ++t) { const int e = lane + 64 * t; if (e < G2) reinterpret_cast<d2*>(gb)[e] = gr[t]; }
+    waveLdsSync();
+    if (i + 2 < M - 1) fetch(i + 2, fr, gr);
+    // du = K dx + k: four lanes per row, nine terms each
+    {
+      const int j = lane >> 2, part = lane & 3;
+      double acc = 0.0;
+      if (lane < 4 * NU) {
+#pragma unroll
+        for (int t = 0; t < NX / 4; ++t) { const int c = (NX / 4) * part + t; acc += gb[L::G_K + j + NU * c] * dx[c]; }
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (lane < 4 * NU && part == 0) { acc += gb[L::G_k + j]; du[j] = acc; dd[L::D_U + j] = acc; }
     }
     if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
-    __syncthreads();
-    if (lane < NV) {
-      const int r = lane;
-      double dq = kk[L::K_FX + r], dv = kk[L::K_FX + NV + r];
-      if (r < 6) {
-        for (int m = 0; m < 6; ++m) dq += kk[L::K_FQQ + r + 6 * m] * dx[m] + kk[L::K_FQV + r + 6 * m] * dx[NV + m];
-      } else {
-        dq += dx[r] + dt * dx[NV + r];
+    waveLdsSync();
+    // dx+ = A dx + B du + Fx: two lanes per velocity row (Fvq dq + half of Fvu du | Fvv dv + the other half), one per configuration row
+    {
+      double acc = 0.0;
+      if (lane < 2 * NV) {
+        const int r = lane >> 1, half = lane & 1;
+        const double* Fm = half ? Fvv : Fvq;
+        const double* xs = half ? dx + NV : dx;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) acc += Fm[r + NV * c] * xs[c];
+#pragma unroll
+        for (int j = 0; j < NU / 2; ++j) acc += Fvu[r + NV * ((NU / 2) * half + j)] * du[(NU / 2) * half + j];
       }
-      for (int c = 0; c < NV; ++c) dv += kk[L::K_FVQ + r + NV * c] * dx[c] + kk[L::K_FVV + r + NV * c] * dx[NV + c];
-      for (int j = 0; j < NU; ++j) dv += kk[L::K_FVU + r + NV * j] * du[j];
-      dxn[r] = dq; dxn[NV + r] = dv;
+      acc += __shfl_xor(acc, 1);
+      if (lane < 2 * NV && (lane & 1) == 0) dxn[NV + (lane >> 1)] = acc + Fx[NV + (lane >> 1)];
+      if (lane >= 2 * NV && lane < 3 * NV) {
+        const int r = lane - 2 * NV;
+        double dq = Fx[r];
+        if (r < 6) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) dq += Fqq6[r + 6 * m] * dx[m] + Fqv6[r + 6 * m] * dx[NV + m];
+        } else {
+          dq += dx[r] + dt * dx[NV + r];
+        }
+        dxn[r] = dq;
+      }
     }
-    __syncthreads();
+    waveLdsSync();
     if (lane < NX) dx[lane] = dxn[lane];
-    __syncthreads();
+    waveLdsSync();
+  };
+  for (int i = 0; i < M - 1; i += 2) {
+    step(i, frA, grA);
+    if (i + 1 < M - 1) step(i + 1, frB, grB);
   }
   double* __restrict__ dd = B.dir + (base + nodes[M - 1].slot) * L::DIR;
   if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
