@@ -71,10 +71,30 @@ __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const O
   return true;
 }
 
+// 16-byte loads of n2 double2's into registers (all in flight at once), and their way into LDS
+typedef double ex_d2 __attribute__((ext_vector_type(2)));
+template <int N2>
+__device__ __forceinline__ void wideLoad(ex_d2 (&r)[(N2 + 63) / 64], const double* __restrict__ src, int lane) {
+  const ex_d2* __restrict__ p = reinterpret_cast<const ex_d2*>(src);
+#pragma unroll
+  for (int t = 0; t < (N2 + 63) / 64; ++t) { const int e = lane + 64 * t; r[t] = p[e < N2 ? e : N2 - 1]; }
+}
+template <int N2>
+__device__ __forceinline__ void wideStoreLds(double* dst, const ex_d2 (&r)[(N2 + 63) / 64], int lane) {
+#pragma unroll
+  for (int t = 0; t < (N2 + 63) / 64; ++t) { const int e = lane + 64 * t; if (e < N2) reinterpret_cast<ex_d2*>(dst)[e] = r[t]; }
+}
+
+// K6.  One wavefront per stage.  The stage's matrices (P, MJtJinv_dIDCdqv and the torque columns of MJtJinv, 19 kB) are fetched
+// with 16-byte loads issued back to back at the top of the kernel and staged through LDS; the matrix-vector products then read
+// LDS with one row per lane.  (Round 1 read the columns straight from global memory: 30 of 64 lanes, 8 bytes each, per load.)
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
+  constexpr int RL = L::R_SV + NV, MJDL = NVF * NX, MJUL = NVF * NU;
+  static_assert(RL % 2 == 0 && MJDL % 2 == 0 && MJUL % 2 == 0 && L::E_MJD % 2 == 0 && (NVF * 6) % 2 == 0 && L::EXP % 2 == 0 && L::RIC % 2 == 0, "16-byte loads");
+  __shared__ __attribute__((aligned(16))) double pb[RL], mjd[MJDL], mju[MJUL];
   __shared__ double dx[NX], du[NU], dfs[NF];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
@@ -86,20 +106,35 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   const bool terminal = (pos == M - 1);
   const long rec = b * P->NS + nd->slot;
   double* __restrict__ dd = B.dir + rec * L::DIR;
-  const double* __restrict__ rr = B.ric + rec * L::RIC;
   if (P->backward_euler && terminal) return;        // ParNMPC: placeholder stage
+  const bool costate = !P->backward_euler;          // ParNMPC: dlmd, dgmm come from the backward correction (K10b)
+  const bool bimp = P->backward_euler && nd->kind == 1;      // ParNMPC impulse stage: df, dmu come from the backward correction
+  const bool expand = !terminal && !bimp;
+  ex_d2 pw[(RL / 2 + 63) / 64], mw[(MJDL / 2 + 63) / 64], uw[(MJUL / 2 + 63) / 64];
+  if (costate) wideLoad<RL / 2>(pw, B.ric + rec * L::RIC, lane);
+  if (expand) {
+    wideLoad<MJDL / 2>(mw, B.exp + rec * L::EXP + L::E_MJD, lane);
+    wideLoad<MJUL / 2>(uw, B.exp + rec * L::EXP + L::E_MJ + NVF * 6, lane);
+  }
   if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
   if (lane < NU && !terminal) du[lane] = dd[L::D_U + lane];
   if (lane < NF) dfs[lane] = 0.0;
+  if (costate) wideStoreLds<RL / 2>(pb, pw, lane);
+  if (expand) { wideStoreLds<MJDL / 2>(mjd, mw, lane); wideStoreLds<MJUL / 2>(mju, uw, lane); }
   __syncthreads();
-  if (lane < NV && !P->backward_euler) {            // ParNMPC: dlmd, dgmm come from the backward correction (K10b)
-    const int r = lane;
-    double dl = -rr[L::R_SQ + r], dg = -rr[L::R_SV + r];
-    for (int c = 0; c < NV; ++c) {
-      dl += rr[L::R_PQQ + r + NV * c] * dx[c] + rr[L::R_PQV + r + NV * c] * dx[NV + c];
-      dg += rr[L::R_PQV + c + NV * r] * dx[c] + rr[L::R_PVV + r + NV * c] * dx[NV + c];
+  if (lane < NX && costate) {
+    // costate direction (split_riccati_factorizer.hxx:131-139): [dlmd; dgmm] = P dx - s, one row per lane
+    const bool isv = lane >= NV;
+    const int r = isv ? lane - NV : lane;
+    double acc = -pb[(isv ? L::R_SV : L::R_SQ) + r];
+    if (!isv) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc += pb[L::R_PQQ + r + NV * c] * dx[c] + pb[L::R_PQV + r + NV * c] * dx[NV + c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc += pb[L::R_PQV + c + NV * r] * dx[c] + pb[L::R_PVV + r + NV * c] * dx[NV + c];
     }
-    dd[L::D_LMD + r] = dl; dd[L::D_GMM + r] = dg;
+    dd[(isv ? L::D_GMM : L::D_LMD) + r] = acc;
   }
   if (terminal) return;
   const long su = rec;
@@ -107,7 +142,6 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const int dimf = nd->dimf, dimvf = NV + dimf;
   // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145): dxi = M dx + m
-  const bool bimp = P->backward_euler && nd->kind == 1;      // ParNMPC impulse stage: df, dmu come from the backward correction
   if (bimp) {
     // ImpulseDynamicsBackwardEuler::computeCondensedPrimalDirection (impulse_dynamics_backward_euler.hxx:98-104):
     // ddv = - Minv ImD + Fvq dq + Fvf df   (K9i left Fvq / Fvf in the kkt record, du holds df in packed rows)
@@ -134,8 +168,11 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   if (!bimp && lane < dimvf) {
     const int r = lane;
     double acc = -ee[L::E_MJIDC + r], tt = 0.0, ww = 0.0;
-    for (int c = 0; c < NX; ++c) { const double mjd = ee[L::E_MJD + r + NVF * c]; acc -= mjd * dx[c]; tt += mjd * dx[c]; }
-    for (int j = 0; j < NU; ++j) { const double mj = ee[L::E_MJ + r + NVF * (6 + j)]; acc += mj * du[j]; ww += mj * du[j]; }
+#pragma unroll
+    for (int c = 0; c < NX; ++c) tt += mjd[r + NVF * c] * dx[c];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) ww += mju[r + NVF * j] * du[j];
+    acc += ww - tt;
     dd[L::D_T + r] = tt; dd[L::D_W + r] = ww;        // for the dual expansion (K7)
     if (r < NV) dd[L::D_A + r] = acc;
     else {
@@ -191,11 +228,18 @@ __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B, double*
   if (threadIdx.x == 0) { if (squared_out) squared_out[b] = e; else B.err[b] = sqrt(e); }
 }
 
+// K7.  One wavefront per stage.  EVERY global read of the stage (MJtJinv and the small blocks behind it in the exp record: Qaa, Qff,
+// MJtJinv_IDC, laf, lu_passive, Quu_passive, Qxu_passive, Fqq_prev_inv, contiguous; the direction and solution records, slack and
+// dual, dgmm of the next stage) is issued at the top with 16-byte loads and staged through LDS: one trip to memory per stage
+// instead of a chain of dependent ones.
 template <typename D>
-__global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
-  __shared__ double dx[NX], du[NU], dfs[NF], laf[NVF + 2], dbm[NVF + 2], dlh[6];
+  constexpr int MJL = NVF * NVF, TO = L::E_QAA, TL = L::E_FQQPI + 36 - L::E_QAA;
+  static_assert(MJL % 2 == 0 && TO % 2 == 0 && TL % 2 == 0 && L::E_MJ == 0 && L::DIR % 2 == 0 && L::SOL % 2 == 0 && L::CON % 2 == 0, "16-byte loads");
+  __shared__ __attribute__((aligned(16))) double mj[MJL], tl[TL], dr[L::DIR], sr[L::SOL], slk[L::CON], dul[L::CON];
+  __shared__ double dgn[NV], laf[NVF + 2], dbm[NVF + 2], nup[6], dmu[NF];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const int lane = threadIdx.x;
@@ -211,34 +255,49 @@ __global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuf
   const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
   double* __restrict__ dd = B.dir + rec * L::DIR;
   double* __restrict__ s = B.sol + rec * L::SOL;
-  const double* __restrict__ ee = B.exp + rec * L::EXP;
+  double* __restrict__ slack = B.slack + rec * L::CON;
+  double* __restrict__ dual = B.dual + rec * L::CON;
+  ex_d2 mw[(MJL / 2 + 63) / 64], tw[(TL / 2 + 63) / 64], dw[(L::DIR / 2 + 63) / 64], sw[(L::SOL / 2 + 63) / 64], kw[(L::CON / 2 + 63) / 64], uw[(L::CON / 2 + 63) / 64];
+  if (stage) wideLoad<MJL / 2>(mw, B.exp + rec * L::EXP, lane);
+  wideLoad<TL / 2>(tw, B.exp + rec * L::EXP + TO, lane);
+  wideLoad<L::DIR / 2>(dw, dd, lane);
+  wideLoad<L::SOL / 2>(sw, s, lane);
+  double dgn_r = 0.0;
+  if (stage) {
+    wideLoad<L::CON / 2>(kw, slack, lane);
+    wideLoad<L::CON / 2>(uw, dual, lane);
+    // dgmm of the next stage of the chain (backward Euler: of this stage)
+    if (lane < NV) dgn_r = B.dir[(b * P->NS + (bwd ? nd->slot : nd->next)) * L::DIR + L::D_GMM + lane];
+  }
   const bool bimp = bwd && nd->kind == 1;           // ParNMPC impulse stage (K9i filled the exp record): only the dv rows, dmu from K10b
   const int dimf = nd->dimf, dimvf = bimp ? NV : NV + dimf;
-  if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
-  if (lane < 6) dlh[lane] = dd[L::D_LMD + lane];
-  if (stage) {
-    if (lane < NU) du[lane] = dd[L::D_U + lane];
-    if (lane < NF) dfs[lane] = dd[L::D_F + lane];
-  }
+  if (stage) { wideStoreLds<MJL / 2>(mj, mw, lane); wideStoreLds<L::CON / 2>(slk, kw, lane); wideStoreLds<L::CON / 2>(dul, uw, lane); if (lane < NV) dgn[lane] = dgn_r; }
+  wideStoreLds<TL / 2>(tl, tw, lane);
+  wideStoreLds<L::DIR / 2>(dr, dw, lane);
+  wideStoreLds<L::SOL / 2>(sr, sw, lane);
   __syncthreads();
+  const double* dx = dr + L::D_Q;                   // dq, dv are contiguous in the record
+  static_assert(L::D_V == L::D_Q + NV, "dx = [dq; dv]");
+  const double* du = dr + L::D_U;
+  const double* dfs = dr + L::D_F;
+  if (lane < NF) dmu[lane] = dr[L::D_MU + lane];     // ParNMPC impulse stages: dmu comes from the backward correction (K10b); overwritten below otherwise
   if (stage) {
-    const double* __restrict__ dgn = B.dir + (b * P->NS + (bwd ? nd->slot : nd->next)) * L::DIR + L::D_GMM;   // dgmm of the next stage of the chain (backward Euler: of this stage)
     // ---- ContactDynamics::computeCondensedDualDirection ----
     if (lane < dimvf) {
       const int r = lane;
-      double acc = ee[L::E_LAF + r];
+      double acc = tl[L::E_LAF - TO + r];
       if (bimp) {
         // ImpulseDynamicsBackwardEuler::computeCondensedDualDirection (impulse_dynamics_backward_euler.hxx:105-111):
         // ldv += Qdvdv (Fvq dq + Fvf df) + dgmm, with Fvq dq + Fvf df = ddv + Minv ImD
-        acc += ee[L::E_QAA + r] * (dd[L::D_A + r] + ee[L::E_MJIDC + r]);
+        acc += tl[L::E_QAA - TO + r] * (dr[L::D_A + r] + tl[L::E_MJIDC - TO + r]);
       } else if (r < NV) {
         // Qafqv dx + Qafu du with Qafqv = -diag(Qaa) MJD, Qafu = diag(Qaa) MJ[:, u] (contact_dynamics.hxx:112-123)
-        const double qaa = ee[L::E_QAA + r];
-        acc += -qaa * dd[L::D_T + r];
-        acc += (nd->has_u ? qaa : 0.0) * dd[L::D_W + r];
+        const double qaa = tl[L::E_QAA - TO + r];
+        acc += -qaa * dr[L::D_T + r];
+        acc += (nd->has_u ? qaa : 0.0) * dr[L::D_W + r];
       } else {
         double a1 = 0.0, a2 = 0.0;
-        for (int p = 0; p < dimf; ++p) { const double qff = ee[L::E_QFF + (r - NV) + NF * p]; a1 += qff * dd[L::D_T + NV + p]; a2 += qff * dd[L::D_W + NV + p]; }
+        for (int p = 0; p < dimf; ++p) { const double qff = tl[L::E_QFF - TO + (r - NV) + NF * p]; a1 += qff * dr[L::D_T + NV + p]; a2 += qff * dr[L::D_W + NV + p]; }
         acc += -a1;
         acc += nd->has_u ? a2 : 0.0;
       }
@@ -247,22 +306,27 @@ __global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuf
     }
     if (lane >= 32 && lane < 38) {
       const int r = lane - 32;
-      double acc = ee[L::E_LUP + r];
-      for (int j = 0; j < NU; ++j) acc += ee[L::E_QUUP + r + 6 * j] * du[j];
-      for (int c = 0; c < NX; ++c) acc += ee[L::E_QXUP + c + NX * r] * dx[c];
-      for (int c = 0; c < NV; ++c) acc += dt * ee[L::E_MJ + r + NVF * c] * dgn[c];
-      dd[L::D_NUP + r] = nd->has_u ? -acc / dt : 0.0;
+      double acc = tl[L::E_LUP - TO + r];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) acc += tl[L::E_QUUP - TO + r + 6 * j] * du[j];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc += tl[L::E_QXUP - TO + c + NX * r] * dx[c];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc += dt * mj[r + NVF * c] * dgn[c];
+      const double v = nd->has_u ? -acc / dt : 0.0;
+      nup[r] = v; dd[L::D_NUP + r] = v;
     }
     __syncthreads();
     if (lane < dimvf) {
       const int r = lane;
       double acc = 0.0;
-      for (int p = 0; p < dimvf; ++p) acc += ee[L::E_MJ + r + NVF * p] * laf[p];
-      dbm[r] = -acc / dt;
-      if (r < NV) dd[L::D_BETA + r] = dbm[r];
+      for (int p = 0; p < dimvf; ++p) acc += mj[r + NVF * p] * laf[p];
+      const double v = -acc / dt;
+      dbm[r] = v;
+      if (r < NV) dd[L::D_BETA + r] = v;
       else {
         const int pr = r - NV;
-        for (int c = 0; c < NC; ++c) if (nd->active[c] && pr >= nd->row_of[c] && pr < nd->row_of[c] + 3) dd[L::D_MU + 3 * c + (pr - nd->row_of[c])] = dbm[r];
+        for (int c = 0; c < NC; ++c) if (nd->active[c] && pr >= nd->row_of[c] && pr < nd->row_of[c] + 3) { const int slot = 3 * c + (pr - nd->row_of[c]); dmu[slot] = v; dd[L::D_MU + slot] = v; }
       }
     }
   }
@@ -270,20 +334,17 @@ __global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuf
   double dl_corr = 0.0;
   if (lane < 6) {
     double acc = 0.0;
-    for (int m = 0; m < 6; ++m) acc += ee[L::E_FQQPI + m + 6 * lane] * dlh[m];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) acc += tl[L::E_FQQPI - TO + m + 6 * lane] * dr[L::D_LMD + m];
     dl_corr = bwd ? acc : -acc;                     // state_equation.hxx:96-108 / 172-181
     dd[L::D_LMD + lane] = dl_corr;
   }
-  __syncthreads();
   // ---- IPM slack / dual update (needs the pre-update primal variables) ----
   if (stage) {
-    const long su = rec;
-    double* __restrict__ slack = B.slack + su * L::CON;
-    double* __restrict__ dual = B.dual + su * L::CON;
     for (int row = lane; row < L::NCON; row += 64) {
       double g, dg;
-      const bool valid = ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg);
-      const double sl = slack[row], dl = dual[row];
+      const bool valid = ipmRow<D>(P, nd, row, sr, dx, dx + NV, du, dfs, &g, &dg);
+      const double sl = slk[row], dl = dul[row];
       double dslack, ddual;
       if (valid) {
         const double res = g + sl, duality = sl * dl - P->barrier;
@@ -302,37 +363,33 @@ __global__ __launch_bounds__(64, 5) void ocp_expand_dual_integrate_kernel(OcpBuf
   // ---- SplitSolution::integrate ----
   if (lane < NV) {
     const int r = lane;
-    s[L::S_LMD + r] += ap * (r < 6 ? dl_corr : dd[L::D_LMD + r]);
-    s[L::S_GMM + r] += ap * dd[L::D_GMM + r];
-    s[L::S_V + r] += ap * dx[NV + r];
-    if (r >= 6) s[L::S_Q + r + 1] += ap * dx[r];
+    s[L::S_LMD + r] = sr[L::S_LMD + r] + ap * (r < 6 ? dl_corr : dr[L::D_LMD + r]);
+    s[L::S_GMM + r] = sr[L::S_GMM + r] + ap * dr[L::D_GMM + r];
+    s[L::S_V + r] = sr[L::S_V + r] + ap * dx[NV + r];
+    if (r >= 6) s[L::S_Q + r + 1] = sr[L::S_Q + r + 1] + ap * dx[r];
     if (stage) {
-      s[L::S_A + r] += ap * dd[L::D_A + r];
-      s[L::S_BETA + r] += ap * dbm[r];
+      s[L::S_A + r] = sr[L::S_A + r] + ap * dr[L::D_A + r];
+      s[L::S_BETA + r] = sr[L::S_BETA + r] + ap * dbm[r];
     }
   }
   if (lane == 32) {
     double qn[7];
-    lieIntegrateBase(s + L::S_Q, dx, ap, qn);
+    lieIntegrateBase(sr + L::S_Q, dx, ap, qn);
     for (int k = 0; k < 7; ++k) s[L::S_Q + k] = qn[k];
   }
   if (stage) {
     if (nd->has_u) {
-      if (lane >= 40 && lane < 40 + NU) s[L::S_U + lane - 40] += ap * du[lane - 40];
-      if (lane >= 52 && lane < 58) s[L::S_NUP + lane - 52] += ap * dd[L::D_NUP + lane - 52];
+      if (lane >= 40 && lane < 40 + NU) s[L::S_U + lane - 40] = sr[L::S_U + lane - 40] + ap * du[lane - 40];
+      if (lane >= 52 && lane < 58) s[L::S_NUP + lane - 52] = sr[L::S_NUP + lane - 52] + ap * nup[lane - 52];
     }
     if (lane < NF) {
       const int c = lane / 3;
-      if (nd->active[c]) { s[L::S_F + lane] += ap * dfs[lane]; s[L::S_MU + lane] += ap * dd[L::D_MU + lane]; }
-      if (lane < nd->sw_dimi) s[L::S_XI + lane] += ap * dd[L::D_XI + lane];       // split_solution.hxx:235-238
+      if (nd->active[c]) { s[L::S_F + lane] = sr[L::S_F + lane] + ap * dfs[lane]; s[L::S_MU + lane] = sr[L::S_MU + lane] + ap * dmu[lane]; }
+      if (lane < nd->sw_dimi) s[L::S_XI + lane] = sr[L::S_XI + lane] + ap * dr[L::D_XI + lane];       // split_solution.hxx:235-238
     }
   }
 }
 
-// LineSearch::computeSolution (include/idocp/line_search/line_search.hpp:134-158): the trial iterate s (+) alpha d of every stage,
-// alpha = B.ls_alpha[instance], into B.sol_try; and the barrier part of SplitOCP::stageCost at that step,
-// dt * barrier(slack + alpha dslack) (split_ocp.hxx:281-287, pdipm.hxx:84-87; rows of inactive contacts count with dslack = 1,
-// linearized_friction_cone.cpp:162-163).  One wavefront per stage of the chain.
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;

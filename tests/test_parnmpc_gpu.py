@@ -51,9 +51,10 @@ def test_first_iteration_direction_parity(N, T):
     ag, bg = g.step_sizes()
     assert abs(ag[0] - ao) < 1e-10 and abs(bg[0] - bo) < 1e-10
     # the updated iterate s + alpha d: same bar on the short horizon; the 84 x 84 KKT inverses of the long one (Gauss-Jordan
-    # here, two LLTs in the oracle) leave 1.1e-10 on u
+    # here, two LLTs in the oracle) leave 1e-9 on lmd; the referee rule decides there as well
     for f in OCP_SOL_FIELDS:
-        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 1e-9), f
+        referee_check(g.get(f), o.get(f), h.get(f), f)
+        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 5e-9), f
 
 
 def test_convergence_and_batch():
