@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
   constexpr int RL = L::R_SV + NV, MJDL = NVF * NX, MJUL = NVF * NU;
   static_assert(RL % 2 == 0 && MJDL % 2 == 0 && MJUL % 2 == 0 && L::E_MJD % 2 == 0 && (NVF * 6) % 2 == 0 && L::EXP % 2 == 0 && L::RIC % 2 == 0, "16-byte loads");
-  __shared__ __attribute__((aligned(16))) double pb[RL], mjd[MJDL], mju[MJUL];
+  __shared__ __attribute__((aligned(16))) double pb[RL], mjd[MJDL], mju[MJUL], sr[L::SOL];
   __shared__ double dx[NX], du[NU], dfs[NF];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
@@ -116,11 +116,25 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     wideLoad<MJDL / 2>(mw, B.exp + rec * L::EXP + L::E_MJD, lane);
     wideLoad<MJUL / 2>(uw, B.exp + rec * L::EXP + L::E_MJ + NVF * 6, lane);
   }
+  // the small operands of the second half (solution, slack / dual rows of this lane, MJtJinv_IDC) travel with the matrices
+  static_assert(L::SOL % 2 == 0 && L::NCON <= 128, "two IPM rows per lane");
+  ex_d2 sw[(L::SOL / 2 + 63) / 64];
+  double sl_r[2] = {1.0, 1.0}, dl_r[2] = {1.0, 1.0}, mjidc_r = 0.0;
+  if (!terminal) {
+    wideLoad<L::SOL / 2>(sw, B.sol + rec * L::SOL, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = lane + 64 * t;
+      if (row < L::NCON) { sl_r[t] = B.slack[rec * L::CON + row]; dl_r[t] = B.dual[rec * L::CON + row]; }
+    }
+    if (lane < NVF) mjidc_r = B.exp[rec * L::EXP + L::E_MJIDC + lane];
+  }
   if (lane < NV) { dx[lane] = dd[L::D_Q + lane]; dx[NV + lane] = dd[L::D_V + lane]; }
   if (lane < NU && !terminal) du[lane] = dd[L::D_U + lane];
   if (lane < NF) dfs[lane] = 0.0;
   if (costate) wideStoreLds<RL / 2>(pb, pw, lane);
   if (expand) { wideStoreLds<MJDL / 2>(mjd, mw, lane); wideStoreLds<MJUL / 2>(mju, uw, lane); }
+  if (!terminal) wideStoreLds<L::SOL / 2>(sr, sw, lane);
   __syncthreads();
   if (lane < NX && costate) {
     // costate direction (split_riccati_factorizer.hxx:131-139): [dlmd; dgmm] = P dx - s, one row per lane
@@ -138,8 +152,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   }
   if (terminal) return;
   const long su = rec;
-  const double* __restrict__ ee = B.exp + rec * L::EXP;
-  const double* __restrict__ s = B.sol + rec * L::SOL;
+  const double* s = sr;
   const int dimf = nd->dimf, dimvf = NV + dimf;
   // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145): dxi = M dx + m
   if (bimp) {
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     const double* __restrict__ kk = B.kkt + rec * L::KKT;
     if (lane < NF) dfs[lane] = dd[L::D_F + lane];
     if (lane < NV) {
-      double acc = -ee[L::E_MJIDC + lane];
+      double acc = -mjidc_r;
       double t1 = 0.0;
       for (int c = 0; c < NV; ++c) t1 += kk[L::K_FVQ + lane + NV * c] * dx[c];
       acc += t1;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   }
   if (!bimp && lane < dimvf) {
     const int r = lane;
-    double acc = -ee[L::E_MJIDC + r], tt = 0.0, ww = 0.0;
+    double acc = -mjidc_r, tt = 0.0, ww = 0.0;
 #pragma unroll
     for (int c = 0; c < NX; ++c) tt += mjd[r + NVF * c] * dx[c];
 #pragma unroll
@@ -185,13 +198,13 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     }
   }
   __syncthreads();
-  const double* __restrict__ slack = B.slack + su * L::CON;
-  const double* __restrict__ dual = B.dual + su * L::CON;
   double ps = 1.0, ds = 1.0;
-  for (int row = lane; row < L::NCON; row += 64) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = lane + 64 * t;
     double g, dg;
-    if (!ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) continue;
-    const double sl = slack[row], dl = dual[row];
+    if (row >= L::NCON || !ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) continue;
+    const double sl = sl_r[t], dl = dl_r[t];
     const double res = g + sl, duality = sl * dl - P->barrier;
     const double dslack = -dg - res;
     const double ddual = -(dl * dslack + duality) / sl;
