@@ -553,6 +553,37 @@ __device__ __forceinline__ mfma_d4 mfmaTileTN(const double* X, int ldx, int xr, 
   }
   return acc;
 }
+// Two tiles at once: the operand reads of both are issued before the first multiply, and the two accumulation chains alternate on
+// the matrix core (a chain of dependent 16-pass instructions alone leaves it idle between them).
+template <int KMAX>
+__device__ __forceinline__ void mfmaTilePairTN(const double* X0, int xr0, const double* Y0, int yc0, const double* X1, int xr1, const double* Y1,
+                                               int yc1, int ldx, int ldy, int k, int lane, mfma_d4& acc0, mfma_d4& acc1) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int KS = (KMAX + 7) / 8;
+  const int li = lane & 15, g = lane >> 4;
+  const double* xp0 = X0 + ldx * (li < xr0 ? li : xr0 - 1) + 2 * g;
+  const double* yp0 = Y0 + ldy * (li < yc0 ? li : yc0 - 1) + 2 * g;
+  const double* xp1 = X1 + ldx * (li < xr1 ? li : xr1 - 1) + 2 * g;
+  const double* yp1 = Y1 + ldy * (li < yc1 ? li : yc1 - 1) + 2 * g;
+  d2 xa0[KS], ya0[KS], xa1[KS], ya1[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    xa0[s] = *reinterpret_cast<const d2*>(xp0 + 8 * s); ya0[s] = *reinterpret_cast<const d2*>(yp0 + 8 * s);
+    xa1[s] = *reinterpret_cast<const d2*>(xp1 + 8 * s); ya1[s] = *reinterpret_cast<const d2*>(yp1 + 8 * s);
+  }
+  acc0 = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  acc1 = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int kk = 8 * s + 2 * g;
+    const bool v0 = kk < k, v1 = kk + 1 < k;
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0 ? ya0[s].x : 0.0, v0 ? xa0[s].x : 0.0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0 ? ya1[s].x : 0.0, v0 ? xa1[s].x : 0.0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1 ? ya0[s].y : 0.0, v1 ? xa0[s].y : 0.0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1 ? ya1[s].y : 0.0, v1 ? xa1[s].y : 0.0, acc1, 0, 0, 0);
+  }
+}
+
 // The same tile with operands that are NOT contiguous along k (or whose layout differs from lane to lane): every lane passes the
 // address of entry k = 0 of ITS row of C in the left operand (xp, stride xs between consecutive k) and of ITS column index li of the
 // right operand (yp, ys); 8-byte reads, one instruction per four k's.  Result as above: lane (li, g), register q holds C(li, g + 4 q).

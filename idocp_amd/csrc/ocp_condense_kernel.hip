@@ -571,7 +571,21 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   STAMP(7);
   // ---- F/G. MJtJinv * [dIDCdqv, IDC], Qafqv, Qafu_full, laf (contact_dynamics.hxx:112-128) ----
   // (MJ symmetric: MJ * dIDC = MJ^T dIDC, both operands contiguous along the contraction index; 16 x 16 tiles on the matrix cores)
-  mmTNmfma<RVF>(&sm[S::MJ], SVF, &sm[S::DIDC], SVF, dimvf, NX, dimvf, tid, nt, [&](int r, int c, double v) { sm[S::MJD + r + SVF * c] = v; });
+  {
+    // tile pairs (rows 0..15 | 16..) x (columns 16 jb ..): the pair shares its dIDC operand; wavefront jb takes pair jb
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int TX = (NX + 15) / 16;
+    static_assert(RVF <= 32, "two row tiles");
+    for (int jb = wave; jb < TX; jb += nt >> 6) {
+      mfma_d4 a0, a1;
+      const int r1 = dimvf > 16 ? dimvf - 16 : 1;
+      mfmaTilePairTN<RVF>(&sm[S::MJ], dimvf < 16 ? dimvf : 16, &sm[S::DIDC + SVF * 16 * jb], NX - 16 * jb, &sm[S::MJ + SVF * 16], r1,
+                          &sm[S::DIDC + SVF * 16 * jb], NX - 16 * jb, SVF, SVF, dimvf, lane, a0, a1);
+      auto put = [&](int r, int c, double v) { sm[S::MJD + r + SVF * c] = v; };
+      mfmaTileStore(a0, 0, 16 * jb, dimvf, NX, lane, put);
+      mfmaTileStore(a1, 16, 16 * jb, dimvf, NX, lane, put);
+    }
+  }
   STAMP(11);
   mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], SVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
   // Qafu_full = Qaf MJ.leftCols(nv) needs only MJ: it runs next to the product above (QAFU aliases M, J, dead since the last barrier).
@@ -611,34 +625,53 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // Qxx = (cost + IPM terms) - MJD^T Qafqv ; Qxu_full = -MJD^T Qafu_full ; Quu_full = diag + MJ.topRows^T Qafu_full.
   // The products go straight to the kkt / exp records.
   {
-    // one job list for the three products, dealt round-robin to the four wavefronts: 9 tiles of Qxx, 6 of Qxu_full, 2 of Quu_full
-    constexpr int TX = (NX + 15) / 16, TV = (NV + 15) / 16, TU = (NU + 15) / 16, J0 = TX * TX, J1 = J0 + TX * TV, J2 = J1 + TV * TU;
+    // One job list for the three products.  Qxx is symmetric and its consumers (S3, K9b) read the block triangle on and above the
+    // diagonal: 6 tiles of Qxx, 6 of Qxu_full, 2 of Quu_full, taken two at a time (neighbours in the list share an operand) by
+    // the four wavefronts.  Job j:  0..5 Qxx (0,0) (0,1) (0,2) (1,1) (1,2) (2,2);  6..11 Qxu_full (ib, jb) = (j - 6) / 2, (j - 6) % 2;  12, 13 Quu_full ib
     const int wave = tid >> 6, lane = tid & 63;
-    for (int job = wave; job < J2; job += nt >> 6) {
-      if (job < J0) {
-        const int jb = job / TX, ib = job - jb * TX;
-        const mfma_d4 acc = mfmaTileTN<RVF>(&sm[S::MJD + SVF * 16 * ib], SVF, NX - 16 * ib, &sm[S::QAFQV + SVF * 16 * jb], SVF, NX - 16 * jb, dimvf, lane);
-        mfmaTileStore(acc, 16 * ib, 16 * jb, NX, NX, lane, [&](int r, int c, double v) {
+    constexpr int NJOB = 14;
+    static_assert(NX <= 48 && NV <= 32 && NU <= 16, "tile counts of the job list");
+    auto operands = [&](int j, const double*& X, int& xr, const double*& Y, int& yc, int& r0, int& c0) {
+      if (j < 6) {
+        const int ib = j < 3 ? 0 : (j < 5 ? 1 : 2), jb = j < 3 ? j : (j < 5 ? j - 2 : 2);
+        X = &sm[S::MJD + SVF * 16 * ib]; xr = NX - 16 * ib; Y = &sm[S::QAFQV + SVF * 16 * jb]; yc = NX - 16 * jb; r0 = 16 * ib; c0 = 16 * jb;
+      } else if (j < 12) {
+        const int ib = (j - 6) >> 1, jb = (j - 6) & 1;
+        X = &sm[S::MJD + SVF * 16 * ib]; xr = NX - 16 * ib; Y = &sm[S::QAFU + SVF * 16 * jb]; yc = NV - 16 * jb; r0 = 16 * ib; c0 = 16 * jb;
+      } else {
+        const int ib = j - 12;
+        X = &sm[S::MJ + SVF * 16 * ib]; xr = NV - 16 * ib; Y = &sm[S::QAFU + SVF * 6]; yc = NU; r0 = 16 * ib; c0 = 0;      // MJ symmetric
+      }
+    };
+    auto finish = [&](int j, const mfma_d4& acc, int r0, int c0) {
+      if (j < 6) {
+        mfmaTileStore(acc, r0, c0, NX, NX, lane, [&](int r, int c, double v) {
           double base = 0.0;
           if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
           else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
           kk[L::K_QXX + r + NX * c] = base - v;
         });
-      } else if (job < J1) {
-        const int t = job - J0, jb = t / TX, ib = t - jb * TX;
-        const mfma_d4 acc = mfmaTileTN<RVF>(&sm[S::MJD + SVF * 16 * ib], SVF, NX - 16 * ib, &sm[S::QAFU + SVF * 16 * jb], SVF, NV - 16 * jb, dimvf, lane);
-        mfmaTileStore(acc, 16 * ib, 16 * jb, NX, NV, lane, [&](int r, int c, double v) {
+      } else if (j < 12) {
+        mfmaTileStore(acc, r0, c0, NX, NV, lane, [&](int r, int c, double v) {
           if (c < 6) ee[L::E_QXUP + r + NX * c] = -v;            // passive columns of Qxu_full
           else kk[L::K_QXU + r + NX * (c - 6)] = -v;
         });
       } else {
-        const int t = job - J1, jb = t / TV, ib = t - jb * TV;
-        const mfma_d4 acc = mfmaTileTN<RVF>(&sm[S::MJ + SVF * 16 * ib], SVF, NV - 16 * ib, &sm[S::QAFU + SVF * (6 + 16 * jb)], SVF, NU - 16 * jb, dimvf, lane);   // MJ symmetric
-        mfmaTileStore(acc, 16 * ib, 16 * jb, NV, NU, lane, [&](int r, int c, double v) {
+        mfmaTileStore(acc, r0, c0, NV, NU, lane, [&](int r, int c, double v) {
           if (r < 6) ee[L::E_QUUP + r + 6 * c] = v;              // Quu_passive_topRight
           else kk[L::K_QUU + (r - 6) + NU * c] = v + ((r - 6 == c) ? sm[S::HUD + c] : 0.0);
         });
       }
+    };
+    for (int j = 2 * wave; j < NJOB; j += 2 * (nt >> 6)) {
+      const double *X0, *Y0, *X1, *Y1;
+      int xr0, yc0, r00, c00, xr1, yc1, r01, c01;
+      operands(j, X0, xr0, Y0, yc0, r00, c00);
+      operands(j + 1, X1, xr1, Y1, yc1, r01, c01);
+      mfma_d4 a0, a1;
+      mfmaTilePairTN<RVF>(X0, xr0, Y0, yc0, X1, xr1, Y1, yc1, SVF, SVF, dimvf, lane, a0, a1);
+      finish(j, a0, r00, c00);
+      finish(j + 1, a1, r01, c01);
     }
   }
   STAMP(14);
