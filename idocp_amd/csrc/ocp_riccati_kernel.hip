@@ -72,9 +72,11 @@ __device__ __forceinline__ void mfmaLoadOp(double (&o)[(K + 3) / 4], const doubl
 }
 
 // phase 1: W = [A^T P; B^T P], tile t = 3 ib + cb covers rows 16 ib .. of W and columns 16 cb .. of P
-template <typename D, int TB, int TE>
+// (mid() runs between the k-steps and the epilogues: the place where the operand registers are free again -- the caller issues
+// the global loads of phase 2 there)
+template <typename D, int TB, int TE, typename Mid>
 __device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* Pqv, const double* Pvv, const double* Fall, const double* Fqq6,
-                                              const double* Fqv6, double dt, double* Wt, int lane) {
+                                              const double* Fqv6, double dt, double* Wt, int lane, Mid mid) {
   constexpr int NV = D::NV, NX = D::NX, KS = (NV + 3) / 4, LDW = RiccatiSmem<D>::LDW, NTL = TE - TB;
   if constexpr (NTL > 0) {
     const int li = lane & 15, g = lane >> 4;
@@ -94,28 +96,42 @@ __device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* P
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[(TB + j) / 3][s], xo[(TB + j) % 3][s], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mid();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
+      __builtin_amdgcn_sched_barrier(0);              // one epilogue at a time: hoisted together their LDS reads overflow the registers
       const int cb = (TB + j) % 3, ib = (TB + j) / 3;
       const int c = 16 * cb + li, cc = c < NX ? c : NX - 1;
       const double* pq = cc < NV ? Pqq + NV * cc : Pqv + NV * (cc - NV);          // P(q, c)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int r = 16 * ib + g + 4 * q;                                      // row of W
+        // rows lo .. lo + 3 of W over the four lane groups; which of them meet the 6 x 6 base blocks of Fqq / Fqv is known at compile time
+        const int lo = 16 * ib + 4 * q, r = lo + g;
         double val = acc[j][q];
-        if (r < NX) {
-          const int rr6 = r < NV ? r : r - NV;
-          if (rr6 >= 6) {
-            val += (r < NV) ? pq[rr6] : dt * pq[rr6];
-          } else {
-            const double* F6 = (r < NV ? Fqq6 : Fqv6) + 6 * rr6;
+        if (lo < NX) {
+          const int lo6 = lo < NV ? lo : lo - NV;                               // (a group of four never straddles NV = 18: 16 | 20)
+          const bool isv = r >= NV;
+          const int rr6 = isv ? r - NV : r;
+          const bool any6 = lo6 < 6 || (lo < NV && lo + 3 >= NV), all6 = lo6 + 3 < 6 && !(lo < NV && lo + 3 >= NV);
+          double dot6 = 0.0;
+          if (any6) {
+            const double* F6 = (isv ? Fqv6 : Fqq6) + 6 * (rr6 < 6 ? rr6 : 0);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) val += F6[m] * pq[m];
+            for (int m = 0; m < 6; ++m) dot6 += F6[m] * pq[m];
+          }
+          if (all6) val += dot6;
+          else {
+            const double direct = (isv ? dt : 1.0) * pq[rr6 < NV ? rr6 : 0];
+            val += (any6 && rr6 < 6) ? dot6 : direct;
           }
         }
         if (c < NX) Wt[c + LDW * r] = val;
       }
     }
+  } else {
+    mid();
   }
 }
 
@@ -143,32 +159,43 @@ __device__ __forceinline__ void riccatiPhase2(const double* Wt, const double* Fa
       for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[upperJb(TB + j)][s], xo[upperIb(TB + j)][s], acc[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
       const int ib = upperIb(TB + j), jb = upperJb(TB + j);
       const int r = 16 * ib + li;                                             // row of [F H; . G]
       const double* wr = Wt + LDW * r;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int c = 16 * jb + g + 4 * q;
+        const int lo = 16 * jb + 4 * q, c = lo + g;                             // columns lo .. lo + 3 over the four lane groups
         double val = acc[j][q] + qxx[j][q];
-        if (c < NX) {
-          const int c6 = c < NV ? c : c - NV;
-          if (c6 >= 6) {
-            val += (c < NV) ? wr[c6] : dt * wr[c6];
-          } else {
-            const double* F6 = (c < NV ? Fqq6 : Fqv6) + 6 * c6;
+        if (lo < NX) {
+          const bool isv = c >= NV;
+          const int c6 = isv ? c - NV : c, lo6 = lo < NV ? lo : lo - NV;
+          const bool any6 = lo6 < 6 || (lo < NV && lo + 3 >= NV), all6 = lo6 + 3 < 6 && !(lo < NV && lo + 3 >= NV);
+          double dot6 = 0.0;
+          if (any6) {
+            const double* F6 = (isv ? Fqv6 : Fqq6) + 6 * (c6 < 6 ? c6 : 0);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) val += wr[m] * F6[m];
+            for (int m = 0; m < 6; ++m) dot6 += wr[m] * F6[m];
+          }
+          if (all6) val += dot6;
+          else {
+            const double direct = (isv ? dt : 1.0) * wr[c6 < NV ? c6 : 0];
+            val += (any6 && c6 < 6) ? dot6 : direct;
           }
         }
         // Only the entries on and above the diagonal are used and mirrored (also inside the diagonal tiles): P stays EXACTLY
         // symmetric.  An antisymmetric rounding residue would not be damped by the feedback term and grows with the open-loop
         // dynamics from stage to stage (measured: 2.9 x per stage) -- the reason for the reference's (P + P^T) / 2.
-        if (c >= NX) {
-          if (r < NX) Qxu[r + NX * (c - NX)] += val; else Quu[(r - NX) + NU * (c - NX)] += val;
-        } else if (r <= c) {
-          if (c < NV) { Pqq[r + NV * c] = val; if (r != c) Pqq[c + NV * r] = val; }
-          else if (r < NV) Pqv[r + NV * (c - NV)] = val;
-          else { Pvv[(r - NV) + NV * (c - NV)] = val; if (r != c) Pvv[(c - NV) + NV * (r - NV)] = val; }
+        // Pqq, Pqv, Pvv are consecutive NV x NV blocks: entry (r, c), r <= c, lives in block [r >= NV] + [c >= NV]; its mirror image
+        // exists inside the two diagonal blocks (for Pqv the "mirror" address is the entry itself).
+        if (lo + 3 >= NX) {
+          if (c >= NX) { if (r < NX) Qxu[r + NX * (c - NX)] += val; else Quu[(r - NX) + NU * (c - NX)] += val; }
+        }
+        if (lo < NX && r <= c && c < NX) {
+          const int rb = r >= NV, cb = c >= NV, rr = r - NV * rb, cc = c - NV * cb;
+          double* blk = Pqq + NV * NV * (rb + cb);
+          blk[rr + NV * cc] = val;
+          blk[(rb == cb) ? cc + NV * rr : rr + NV * cc] = val;
         }
       }
     }
@@ -224,15 +251,17 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* GK
       for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[upperJb(TB + j)][s], xo[upperIb(TB + j)][s], acc[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
       const int r = 16 * upperIb(TB + j) + li;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = 16 * upperJb(TB + j) + g + 4 * q;
-        const double val = acc[j][q];
         if (r <= c && c < NX) {
-          if (c < NV) { Pqq[r + NV * c] -= val; if (r != c) Pqq[c + NV * r] -= val; }
-          else if (r < NV) Pqv[r + NV * (c - NV)] -= val;
-          else { Pvv[(r - NV) + NV * (c - NV)] -= val; if (r != c) Pvv[(c - NV) + NV * (r - NV)] -= val; }
+          const int rb = r >= NV, cb = c >= NV, rr = r - NV * rb, cc = c - NV * cb;
+          double* blk = Pqq + NV * NV * (rb + cb);
+          const double val = blk[rr + NV * cc] - acc[j][q];                      // the mirror image holds the same value: store, don't update
+          blk[rr + NV * cc] = val;
+          blk[(rb == cb) ? cc + NV * rr : rr + NV * cc] = val;
         }
       }
     }
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     // (backward_riccati_recursion_factorizer.hxx:133-135).
     constexpr int PF = (SL + NT - 1) / NT, T1 = 9, T2 = 6, T2W = (T2 + NW - 1) / NW;
     double pre[PF], qxx[T2W][4];
-    {
+    auto loadQxx = [&]() {
       // Qxx of THIS stage is consumed once per element in phase 2: straight to the registers of the lane that adds it
       const double* __restrict__ kc = B.kkt + rec * L::KKT;
       const int t2b = tileBegin(T2, wave, NW), t2e = tileBegin(T2, wave + 1, NW);      // this wavefront's tiles of phase 2
@@ -334,14 +363,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
           qxx[jj][q] = (t < t2e && r <= c && c < NX) ? kc[L::K_QXX + r + NX * c] : 0.0;
         }
       }
-    }
-    // software pipeline: the record of stage i was staged into LDS at the end of the previous
-    // iteration; issue the global loads of stage i-1 now and park them in registers
-    if (i > 0) {
-      const double* __restrict__ kn = B.kkt + (base + nodes[i - 1].slot) * L::KKT + KO;
-#pragma unroll
-      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; pre[t] = (e < SL) ? kn[e] : 0.0; }
-    }
+    };
     double* Qxu = st + (L::K_QXU - KO);
     double* Quu = st + (L::K_QUU - KO);
     const double* Fqq6 = st + (L::K_FQQ - KO);
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     const double* Fx = st + (L::K_FX - KO);
     RSTAMP(1);
     // ---- phase 1: A^T P and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
-    RICCATI_TILES(riccatiPhase1, T1, Pqq, Pqv, Pvv, Fall, Fqq6, Fqv6, dt, Wt, lane);
+    RICCATI_TILES(riccatiPhase1, T1, Pqq, Pqv, Pvv, Fall, Fqq6, Fqv6, dt, Wt, lane, loadQxx);
     __syncthreads();
     RSTAMP(2);
     // ---- phase 2: F, H, G (:79-113); F overwrites P_{i+1}, which is dead from here ----
@@ -405,6 +427,13 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
     RSTAMP(12);
     __syncthreads();
     RSTAMP(3);
+    // software pipeline: the record of stage i was staged into LDS at the end of the previous iteration; the global loads of
+    // stage i - 1 are issued here (factorisation, phases 4 and 5 ahead of them) and parked in registers
+    if (i > 0) {
+      const double* __restrict__ kn = B.kkt + (base + nodes[i - 1].slot) * L::KKT + KO;
+#pragma unroll
+      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; pre[t] = (e < SL) ? kn[e] : 0.0; }
+    }
     RSTAMP(9);
     // Quu = L L^T and the solves K = -Quu^-1 Qxu^T, k = -Quu^-1 lu in the registers of one wavefront, one right-hand side per lane
     // (Eigen::LLT compute + solve, split_riccati_factorizer.hxx:43-46).  Round 1 multiplied with an explicit Gauss-Jordan
