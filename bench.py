@@ -676,7 +676,8 @@ def main():
         cost, cons = anymal_problem(model, trotting_ref=True)
         nq, nv = model.nq, model.nv
         q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
-        v0 = np.zeros((B, nv))
+        q0[:, 7:] += 0.01 * rng.uniform(-1, 1, (B, 12))          # every instance of the batch starts from a state of its own
+        v0 = 0.01 * rng.uniform(-1, 1, (B, nv))
         def build(batch):
             sv = HipOCP(model, cost, cons, T, N, batch=batch, device=local_rank, max_num_impulse=nimp + 1)
             trotting_sequence(sv, model, nimp)

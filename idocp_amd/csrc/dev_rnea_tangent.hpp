@@ -64,10 +64,12 @@ struct RneaScratch {
   // the body's motion (w, v = vc, bw, bl), momenta hl, hn, the force accumulated up to and including this body (Fl, Fn),
   // and the inertia constants of the body
   static constexpr int J_R = 0, J_U = 9, J_P = 12, J_WC = 15, J_VC = 18, J_BWC = 21, J_BLC = 24, J_ZC = 27, J_VJ = 30, J_W = 33, J_BW = 36,
-                       J_BL = 39, J_HL = 42, J_HN = 45, J_FL = 48, J_FN = 51, J_MASS = 54, J_MC = 55, J_IO = 58, JREC = 64;
+                       J_BL = 39, J_HL = 42, J_HN = 45, J_FL = 48, J_FN = 51, J_MASS = 54, J_MC = 55, J_IO = 58,
+                       JREC = 66;     // 64 used; 66 puts the records of the four legs (3 JREC apart) into different LDS banks: the item lanes of a
+                                      // wavefront read the SAME field of four different legs at once (64: all four in one bank, 4-way conflicts)
   // FOOT record, one per leg: R_world,foot Rc (row-major), local frame velocity fv / angular velocity fw (nominal), the frame
   // placement (Rc, pc) in the tip joint, the pose-dependent part of the Baumgarte residual, contact flag and first packed row
-  static constexpr int F_RWC = 0, F_FV = 9, F_FW = 12, F_RC = 15, F_PC = 24, F_CP = 27, F_ACT = 30, F_ROW = 31, FREC = 32;
+  static constexpr int F_RWC = 0, F_FV = 9, F_FW = 12, F_RC = 15, F_PC = 24, F_CP = 27, F_ACT = 30, F_ROW = 31, FREC = 34;      // (32 used; see JREC)
   // BASE record: z = R_w^T e_z, v, w, momenta hl, hn of the base body, its inertia constants
   static constexpr int B_Z = 0, B_V = 3, B_W = 6, B_HL = 9, B_HN = 12, B_MASS = 15, B_MC = 16, B_IO = 19, BREC = 26;
   // inputs of the stage: q, v, a, f

@@ -25,9 +25,11 @@ if [ "${3:-}" = "sq" ]; then
   cd /tmp
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $out -o ${wl}_sq1 -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $out/${wl}_sq1.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM -d $out -o ${wl}_sq2 -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $out/${wl}_sq2.log 2>&1
+  # matrix-core utilisation of the kernels that run their products on FP64 MFMA (K5, S3): busy cycles of the MFMA pipe next to the CU-busy cycles
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA -d $out -o ${wl}_sq3 -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $out/${wl}_sq3.log 2>&1
   cd $R
-  python3 profiles/summarize_rocpd.py $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db > $out/r${rnd}_${wl}_pmc_sq.txt
-  rm -f $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db
+  python3 profiles/summarize_rocpd.py $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db $out/${wl}_sq3_results.db > $out/r${rnd}_${wl}_pmc_sq.txt
+  rm -f $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db $out/${wl}_sq3_results.db
 fi
 python3 profiles/make_traffic_json.py $out/${wl}_fetch_results.db $out/${wl}_write_results.db $wl $batch $hor $rnd > $out/r${rnd}_pmc_traffic_${wl}.json
 rm -f $out/${wl}_trace_results.db $out/${wl}_fetch_results.db $out/${wl}_write_results.db      # the summaries above are what is kept (gpurun_out/ is capped at 64 MiB)
