@@ -627,6 +627,8 @@ def main():
                          "sharded over the ranks, strong scaling)")
     ap.add_argument("--batch", type=int, default=0, help="independent OCP instances per GPU (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--friction-cone", choices=["linearized", "nonlinear"], default="linearized",
+                    help="ANYmal workloads: LinearizedFrictionCone (the trotting / running examples) or FrictionCone (examples/anymal/ocp_benchmark.cpp:76)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (config.latency)")
     args = ap.parse_args()
@@ -673,7 +675,7 @@ def main():
         T = 0.5 + nimp * 0.5 + 0.05
         B = args.batch or 1024
         model = anymal_model()
-        cost, cons = anymal_problem(model, trotting_ref=True)
+        cost, cons = anymal_problem(model, trotting_ref=True, cone=args.friction_cone)
         nq, nv = model.nq, model.nv
         q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
         q0[:, 7:] += 0.01 * rng.uniform(-1, 1, (B, 12))          # every instance of the batch starts from a state of its own
@@ -730,7 +732,7 @@ def main():
         # every stage (the uniform-contact variant of SURVEY 8d C3: trotting cost + linearized friction cone), FP64
         B = args.batch or 1024
         model = anymal_model()
-        cost, cons = anymal_problem(model, trotting_ref=True)
+        cost, cons = anymal_problem(model, trotting_ref=True, cone=args.friction_cone)
         pts = anymal_contact_points(model)
         nq, nv = model.nq, model.nv
         q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))

@@ -69,6 +69,7 @@ class Constraints(C.Structure):
         ("linearized_friction_cone", C.c_int), ("mu", C.c_double),
         ("barrier", C.c_double), ("fraction_to_boundary_rate", C.c_double),
         ("linearized_impulse_friction_cone", C.c_int),
+        ("friction_cone", C.c_int), ("impulse_friction_cone", C.c_int),
     ]
 
 

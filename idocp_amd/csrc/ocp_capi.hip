@@ -570,6 +570,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   // ConstraintComponentBase::setBarrier / setFractionToBoundaryRate (constraint_component_base.hxx:10-24) assert these; a
   // non-positive barrier would make the slack initialisation (pdipm.hxx:13-24) loop forever on the device
   if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }
+  if ((constraints->linearized_friction_cone && constraints->friction_cone) || (constraints->linearized_impulse_friction_cone && constraints->impulse_friction_cone)) {
+    set_last_error("unsupported constraints: LinearizedFrictionCone and FrictionCone (or their impulse twins) together; the stage kernels carry one cone per kind of stage");
+    return IDOCP_E_UNSUPPORTED;
+  }
   if (!(constraints->fraction_to_boundary_rate > 0 && constraints->fraction_to_boundary_rate <= 1)) {
     set_last_error("invalid value: fraction_to_boundary_rate must be in (0, 1]!"); return IDOCP_E_ARG;
   }
@@ -667,8 +671,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
     std::memcpy(p.contact_R[c], model->contact_R[c], sizeof(double) * 9);
   }
   p.use_q_limits = constraints->joint_position_limits; p.use_v_limits = constraints->joint_velocity_limits;
-  p.use_u_limits = constraints->joint_torque_limits; p.use_friction_cone = constraints->linearized_friction_cone;
-  p.use_impulse_friction_cone = constraints->linearized_impulse_friction_cone;
+  p.use_u_limits = constraints->joint_torque_limits;
+  p.use_friction_cone = (constraints->linearized_friction_cone || constraints->friction_cone) ? 1 : 0;
+  p.use_impulse_friction_cone = (constraints->linearized_impulse_friction_cone || constraints->impulse_friction_cone) ? 1 : 0;
+  p.cone_kind = constraints->friction_cone ? 1 : 0; p.impulse_cone_kind = constraints->impulse_friction_cone ? 1 : 0;
   p.mu = constraints->mu; p.barrier = constraints->barrier; p.fraction_rate = constraints->fraction_to_boundary_rate;
   void* d_model = nullptr;
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&h->d_prob, sizeof(OcpProblem)) != hipSuccess) {
@@ -1224,7 +1230,6 @@ int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* w
   std::vector<double> sol((size_t)h->batch * h->NS * LQ::SOL);
   HIP_TRY(hipMemcpyAsync(sol.data(), h->B.sol, sol.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const double m2 = P.mu * 0.70710678118654752440;
   auto stageOk = [&](const OcpNode& nd, const double* s) {
     if (nd.kind == 1) {                                               // linearized_impulse_friction_cone.cpp:82-94
       if (!P.use_impulse_friction_cone) return true;
@@ -1237,10 +1242,11 @@ int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* w
         for (int r = 0; r < nu; ++r) { const double u = s[LQ::S_U + r]; if (u < -P.u_max[r] || u > P.u_max[r]) return false; }
       if (!P.use_friction_cone) return true;
     }
-    for (int c = 0; c < DQ::NC; ++c) {                                // linearized_friction_cone.cpp:87-99
+    const int ck = nd.kind == 1 ? P.impulse_cone_kind : P.cone_kind;
+    for (int c = 0; c < DQ::NC; ++c) {                                // linearized_friction_cone.cpp:87-99, friction_cone.cpp:70-84
       if (!nd.active[c]) continue;
-      const double fx = s[LQ::S_F + 3 * c], fy = s[LQ::S_F + 3 * c + 1], fz = s[LQ::S_F + 3 * c + 2];
-      if (-fz > 0 || fx - m2 * fz > 0 || -fx - m2 * fz > 0 || fy - m2 * fz > 0 || -fy - m2 * fz > 0) return false;
+      double J[3];
+      for (int r = 0; r < coneRows(ck); ++r) if (coneRow(ck, P.mu, r, s + LQ::S_F + 3 * c, J) > 0) return false;
     }
     return true;
   };
@@ -1262,7 +1268,7 @@ int idocp_ocp_dimc(const idocp_ocp_t* h) {
   if (!h) return 0;
   const idocp_constraints_t& c = h->cons;
   return 2 * DQ::NU * ((c.joint_position_limits ? 1 : 0) + (c.joint_velocity_limits ? 1 : 0) + (c.joint_torque_limits ? 1 : 0)) +
-         (c.linearized_friction_cone ? 5 * DQ::NC : 0);
+         (c.linearized_friction_cone ? 5 * DQ::NC : 0) + (c.friction_cone ? 2 * DQ::NC : 0);
 }
 
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual) {
@@ -1274,16 +1280,18 @@ int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, d
   HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * h->NS * LQ::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const idocp_constraints_t& c = h->cons;
-  const int use[4] = {c.joint_position_limits, c.joint_velocity_limits, c.joint_torque_limits, c.linearized_friction_cone};
+  const int use[4] = {c.joint_position_limits, c.joint_velocity_limits, c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone};
+  const int cr = coneRows(h->prob.cone_kind);        // rows per contact of the cone in use (the records keep five slots per contact)
   for (int i = 0; i < N; ++i) {
     int off = 0;
     for (int comp = 0; comp < 7; ++comp) {
       if (!use[comp < 6 ? comp / 2 : 3]) continue;
-      const int n = comp < 6 ? DQ::NU : 5 * DQ::NC, base = comp < 6 ? comp * DQ::NU : LQ::C_FRIC;
+      const int n = comp < 6 ? DQ::NU : cr * DQ::NC;
       const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
       for (int r = 0; r < n; ++r) {
-        if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * LQ::CON + base + r] : 0.0;
-        if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * LQ::CON + base + r] : 0.0;
+        const int src = comp < 6 ? comp * DQ::NU + r : LQ::C_FRIC + 5 * (r / cr) + r % cr;
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * LQ::CON + src] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * LQ::CON + src] : 0.0;
       }
       off += n;
     }

@@ -391,24 +391,26 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         sm[S::BM + NV + row + x] = s[L::S_MU + 3 * c + x];
       }
       if (ocpRowValid(P, 6, i, impulse)) {
-        double dd[5];
+        // (Linearized)(Impulse)FrictionCone: augmentDualResidual + condenseSlackAndDual, row by row (coneRow, ocp_device.hpp)
+        const int ck = impulse ? P->impulse_cone_kind : P->cone_kind, nr = coneRows(ck);
+        double dd[5], Jr[5][3];
         for (int r = 0; r < 5; ++r) {
+          if (r >= nr) { dd[r] = 0.0; Jr[r][0] = Jr[r][1] = Jr[r][2] = 0.0; continue; }
           const int idx = L::C_FRIC + 5 * c + r;
           const double sl = slack[idx], du = dual[idx];
-          double g = 0.0;
-          for (int x = 0; x < 3; ++x) g += frictionJacEntry(P->mu, r, x) * f[x];
+          const double g = coneRow(ck, P->mu, r, f, Jr[r]);
           const double res = g + sl, duality = sl * du - P->barrier;
           double coef = du;
           if (MERIT) merit_viol += dt * fabs(res);
           if (RESIDUAL) err_ipm += res * res + duality * duality;
           else coef += (du * res - duality) / sl;
           dd[r] = du / sl;
-          for (int x = 0; x < 3; ++x) lf[x] += dt * frictionJacEntry(P->mu, r, x) * coef;
+          for (int x = 0; x < 3; ++x) lf[x] += dt * Jr[r][x] * coef;
         }
         if (!RESIDUAL) {
           for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) {
             double acc = 0.0;
-            for (int r = 0; r < 5; ++r) acc += frictionJacEntry(P->mu, r, x) * dd[r] * frictionJacEntry(P->mu, r, y);
+            for (int r = 0; r < 5; ++r) acc += Jr[r][x] * dd[r] * Jr[r][y];
             sm[S::QFF + (row + x) + SF * (row + y)] += dt * acc;
           }
         }

@@ -119,6 +119,27 @@ __host__ __device__ inline ParnmpcShape parnmpcShape(const OcpNode& nd) {
   return s;
 }
 
+// The friction-cone component of ONE contact with force f: value g_r(f) (<= 0 inside the cone) and gradient J_r(f) of row r.
+//   kind 0  LinearizedFrictionCone, 5 rows:  g = Jc f, Jc = [0 0 -1; 1 0 -m; -1 0 -m; 0 1 -m; 0 -1 -m], m = mu / sqrt(2)
+//           (linearized_friction_cone.cpp:25-29, linearized_friction_cone.hpp:72-84)
+//   kind 1  FrictionCone, 2 rows:  g0 = -fz,  g1 = fx^2 + fy^2 - mu^2 fz^2  (friction_cone.hpp:70-80); J1 = (2 fx, 2 fy, -2 mu^2 fz) is the
+//           reference's data.r[i] (friction_cone.cpp:100-118) and the Hessian term is the Gauss-Newton one, J^T diag(dual / slack) J
+//           (:121-146): every formula of the component is the same for the two kinds.
+// The IPM records keep five slots per contact; rows >= coneRows(kind) do not exist (never read, never updated).
+__host__ __device__ inline int coneRows(int kind) { return kind == 1 ? 2 : 5; }
+__host__ __device__ inline double coneRow(int kind, double mu, int r, const double* f, double* J) {
+  if (kind == 1) {
+    if (r == 0) { J[0] = 0.0; J[1] = 0.0; J[2] = -1.0; return -f[2]; }
+    J[0] = 2.0 * f[0]; J[1] = 2.0 * f[1]; J[2] = -2.0 * mu * mu * f[2];
+    return f[0] * f[0] + f[1] * f[1] - mu * mu * f[2] * f[2];
+  }
+  const double m2 = mu * 0.70710678118654752440;
+  J[0] = (r == 1) ? 1.0 : (r == 2 ? -1.0 : 0.0);
+  J[1] = (r == 3) ? 1.0 : (r == 4 ? -1.0 : 0.0);
+  J[2] = (r == 0) ? -1.0 : -m2;
+  return J[0] * f[0] + J[1] * f[1] + J[2] * f[2];
+}
+
 struct OcpProblem {
   int N, batch;            // N = grid intervals (N_ideal)
   int M, NS, E;            // chain length of the current discretisation; storage slots per instance; max events
@@ -134,6 +155,7 @@ struct OcpProblem {
   double qi_weight[IDOCP_MAX_NV], vi_weight[IDOCP_MAX_NV], dvi_weight[IDOCP_MAX_NV];         // impulse stages
   double fi_weight[IDOCP_MAX_CONTACTS][3], fi_ref[IDOCP_MAX_CONTACTS][3];
   int use_q_limits, use_v_limits, use_u_limits, use_friction_cone, use_impulse_friction_cone;
+  int cone_kind, impulse_cone_kind;     // 0: Linearized(Impulse)FrictionCone (5 rows per contact), 1: (Impulse)FrictionCone (2 rows); coneRow below
   double mu, barrier, fraction_rate;
   double contact_R[IDOCP_MAX_CONTACTS][9], contact_p[IDOCP_MAX_CONTACTS][3];   // frame placement in the tip joint
   double baumgarte_time_step;

@@ -64,11 +64,22 @@ __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const O
     return true;
   }
   const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
-  if (!ocpRowValid2(P, 6, nd->level, nd->kind == 1) || !nd->active[c]) return false;
-  double gg = 0.0, dd = 0.0;
-  for (int x = 0; x < 3; ++x) { const double j = frictionJacEntry2(P->mu, r, x); gg += j * s[L::S_F + 3 * c + x]; dd += j * df_slot[3 * c + x]; }
-  *g = gg; *dg = dd;
+  const int ck = nd->kind == 1 ? P->impulse_cone_kind : P->cone_kind;
+  if (r >= coneRows(ck) || !ocpRowValid2(P, 6, nd->level, nd->kind == 1) || !nd->active[c]) return false;
+  double J[3];
+  const double f[3] = {s[L::S_F + 3 * c], s[L::S_F + 3 * c + 1], s[L::S_F + 3 * c + 2]};
+  *g = coneRow(ck, P->mu, r, f, J);              // (FrictionCone: J is the reference's data.r[i], the gradient at the linearisation point)
+  *dg = J[0] * df_slot[3 * c] + J[1] * df_slot[3 * c + 1] + J[2] * df_slot[3 * c + 2];
   return true;
+}
+// a cone row of a contact that is NOT active on this stage: dslack = ddual = 1, so that it never limits the step
+// (linearized_friction_cone.cpp:162-163, friction_cone.cpp:155-156)
+template <typename D>
+__device__ __forceinline__ bool ipmIdleConeRow(const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd, int row) {
+  using L = OcpLayout<D>;
+  if (row < L::C_FRIC || !ocpRowValid2(P, 6, nd->level, nd->kind == 1)) return false;
+  const int r = (row - L::C_FRIC) % 5;
+  return r < coneRows(nd->kind == 1 ? P->impulse_cone_kind : P->cone_kind);
 }
 
 // 16-byte loads of n2 double2's into registers (all in flight at once), and their way into LDS
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
         const double res = g + sl, duality = sl * dl - P->barrier;
         dslack = -dg - res;
         ddual = -(dl * dslack + duality) / sl;
-      } else if (row >= L::C_FRIC && ocpRowValid2(P, 6, nd->level, nd->kind == 1)) {
+      } else if (ipmIdleConeRow<D>(P, nd, row)) {
         dslack = 1.0; ddual = 1.0;       // rows of inactive contacts (linearized_friction_cone.cpp:162-163)
       } else {
         continue;
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
     for (int row = lane; row < L::NCON; row += 64) {
       double g, dg, dslack;
       if (ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) dslack = -dg - (g + slack[row]);
-      else if (row >= L::C_FRIC && ocpRowValid2(P, 6, nd->level, nd->kind == 1)) dslack = 1.0;
+      else if (ipmIdleConeRow<D>(P, nd, row)) dslack = 1.0;
       else continue;
       bar -= log(slack[row] + a * dslack);
     }
@@ -502,8 +513,9 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
     } else {
       // all contacts, active or not (linearized_friction_cone.cpp:96-104)
       const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
-      valid = ocpRowValid2(P, 6, i, impulse);
-      if (valid) for (int x = 0; x < 3; ++x) g += frictionJacEntry2(P->mu, r, x) * s[L::S_F + 3 * c + x];
+      const int ck = impulse ? P->impulse_cone_kind : P->cone_kind;
+      valid = ocpRowValid2(P, 6, i, impulse) && r < coneRows(ck);
+      if (valid) { double J[3]; const double f[3] = {s[L::S_F + 3 * c], s[L::S_F + 3 * c + 1], s[L::S_F + 3 * c + 2]}; g = coneRow(ck, P->mu, r, f, J); }
     }
     if (valid) {
       sl = -g;

@@ -119,11 +119,14 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
   double e_ipm = 0.0;
   if (tid >= 64 && tid < 64 + NC && nd->active[tid - 64]) {
     const int c = tid - 64, row = nd->row_of[c];
-    double rr[5], ddv[5];
+    // (Linearized)ImpulseFrictionCone, row by row (coneRow, ocp_device.hpp)
+    const int ck = P->impulse_cone_kind, nr = coneRows(ck);
+    const double fc[3] = {s[L::S_F + 3 * c], s[L::S_F + 3 * c + 1], s[L::S_F + 3 * c + 2]};
+    double rr[5], ddv[5], Jr[5][3];
     for (int r = 0; r < 5; ++r) {
+      if (r >= nr) { rr[r] = 0.0; ddv[r] = 0.0; Jr[r][0] = Jr[r][1] = Jr[r][2] = 0.0; continue; }
       const int idx = L::C_FRIC + 5 * c + r;
-      double g = 0.0;
-      for (int x = 0; x < 3; ++x) g += coneJac(P->mu, r, x) * s[L::S_F + 3 * c + x];
+      const double g = coneRow(ck, P->mu, r, fc, Jr[r]);
       const double sl = slack[idx], du = dual[idx];
       const double res = g + sl, duality = sl * du - P->barrier;
       if (RESIDUAL) { rr[r] = du; ddv[r] = 0.0; e_ipm += res * res + duality * duality; }
@@ -131,14 +134,14 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     }
     for (int x = 0; x < 3; ++x) {
       double a = P->fi_weight[c][x] * (s[L::S_F + 3 * c + x] - P->fi_ref[c][x]);
-      if (cone) for (int r = 0; r < 5; ++r) a += coneJac(P->mu, r, x) * rr[r];
+      if (cone) for (int r = 0; r < 5; ++r) a += Jr[r][x] * rr[r];
       double vb = 0.0;
       for (int m = 0; m < NV; ++m) vb += Vv[(row + x) + NF * m] * s[L::S_BETA + m];
       lf[row + x] = a - vb;
       if (!RESIDUAL) {
         for (int y = 0; y < 3; ++y) {
           double h = (x == y) ? P->fi_weight[c][x] : 0.0;
-          if (cone) for (int r = 0; r < 5; ++r) h += coneJac(P->mu, r, x) * ddv[r] * coneJac(P->mu, r, y);
+          if (cone) for (int r = 0; r < 5; ++r) h += Jr[r][x] * ddv[r] * Jr[r][y];
           Qff[(row + x) + NF * (row + y)] = h;
         }
       }

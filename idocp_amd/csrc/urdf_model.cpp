@@ -372,4 +372,5 @@ extern "C" void idocp_constraints_init(idocp_constraints_t* c) {
   c->linearized_friction_cone = 0; c->mu = 0.7;
   c->barrier = 1.0e-04; c->fraction_to_boundary_rate = 0.995;
   c->linearized_impulse_friction_cone = 0;
+  c->friction_cone = 0; c->impulse_friction_cone = 0;
 }

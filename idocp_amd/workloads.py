@@ -204,9 +204,10 @@ def anymal_model():
 
 ANYMAL_Q_STANDING = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])
 
-def anymal_problem(model, trotting_ref=True):
+def anymal_problem(model, trotting_ref=True, cone="linearized"):
     """Cost / constraints of examples/anymal/anymal_trotting.cpp:33-107:
-    TrottingConfigurationSpaceCost + ContactForceCost, 6 joint limits + LinearizedFrictionCone(mu=0.7)."""
+    TrottingConfigurationSpaceCost + ContactForceCost, 6 joint limits + LinearizedFrictionCone(mu=0.7).
+    cone="nonlinear": FrictionCone / ImpulseFrictionCone instead (examples/anymal/ocp_benchmark.cpp:76)."""
     nv = model.nv
     cost = capi.Cost()
     cost.set("q_ref", ANYMAL_Q_STANDING)
@@ -233,8 +234,12 @@ def anymal_problem(model, trotting_ref=True):
             cost.fi_ref[c][k] = 0.0
     cons = capi.Constraints()
     capi.lib().idocp_constraints_init(C.byref(cons))
-    cons.linearized_friction_cone = 1
-    cons.linearized_impulse_friction_cone = 1
+    if cone == "nonlinear":
+        cons.friction_cone = 1
+        cons.impulse_friction_cone = 1
+    else:
+        cons.linearized_friction_cone = 1
+        cons.linearized_impulse_friction_cone = 1
     cons.mu = 0.7
     return cost, cons
 

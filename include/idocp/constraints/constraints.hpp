@@ -17,7 +17,7 @@ namespace idocp {
 
 class ConstraintComponentBase {
  public:
-  enum Family { Position, Velocity, Torque, LinearFrictionCone };
+  enum Family { Position, Velocity, Torque, LinearFrictionCone, QuadraticFrictionCone };
   ConstraintComponentBase(Family f, bool upper, double barrier, double rate)
       : family(f), upper(upper), barrier(barrier), fraction_to_boundary_rate(rate) {}
   virtual ~ConstraintComponentBase() {}
@@ -63,6 +63,27 @@ class LinearizedImpulseFrictionCone final : public ConstraintComponentBase {
       : ConstraintComponentBase(LinearFrictionCone, true, barrier, fraction_to_boundary_rate) { mu = mu_in; }
 };
 
+// FrictionCone (include/idocp/constraints/friction_cone.hpp, src/constraints/friction_cone.cpp; the cone of
+// examples/anymal/ocp_benchmark.cpp:76): two rows per active contact, -fz <= 0 and fx^2 + fy^2 - mu^2 fz^2 <= 0.
+class FrictionCone final : public ConstraintComponentBase {
+ public:
+  FrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(QuadraticFrictionCone, false, barrier, fraction_to_boundary_rate) { setFrictionCoefficient(mu_in); }
+  void setFrictionCoefficient(const double mu_in) {
+    if (mu_in <= 0) {      // friction_cone.cpp:13-22
+      std::cerr << "invalid value: mu must be positive!" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    mu = mu_in;
+  }
+};
+// Impulse twin (src/constraints/impulse_friction_cone.cpp)
+class ImpulseFrictionCone final : public ConstraintComponentBase {
+ public:
+  ImpulseFrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(QuadraticFrictionCone, true, barrier, fraction_to_boundary_rate) { mu = mu_in; }
+};
+
 class Constraints {
  public:
   Constraints() : lo_{0, 0, 0}, hi_{0, 0, 0} {
@@ -82,6 +103,11 @@ class Constraints {
     have_ipm_ = true;
     if (c->family == ConstraintComponentBase::LinearFrictionCone) {
       if (!c->upper) c_.linearized_friction_cone = 1; else c_.linearized_impulse_friction_cone = 1;     // upper = impulse twin
+      c_.mu = c->mu;
+      return;
+    }
+    if (c->family == ConstraintComponentBase::QuadraticFrictionCone) {
+      if (!c->upper) c_.friction_cone = 1; else c_.impulse_friction_cone = 1;
       c_.mu = c->mu;
       return;
     }

@@ -132,6 +132,11 @@ typedef struct idocp_constraints {
   double fraction_to_boundary_rate;   /* default 0.995   */
   int linearized_impulse_friction_cone; /* 0/1: LinearizedImpulseFrictionCone on impulse stages
                                          * (src/constraints/linearized_impulse_friction_cone.cpp), same mu */
+  int friction_cone;                    /* 0/1: FrictionCone, two rows per contact: -fz <= 0, fx^2 + fy^2 - mu^2 fz^2 <= 0
+                                         * (src/constraints/friction_cone.cpp; the cone of examples/anymal/ocp_benchmark.cpp:76).
+                                         * Exclusive with linearized_friction_cone */
+  int impulse_friction_cone;            /* 0/1: ImpulseFrictionCone on impulse stages (src/constraints/impulse_friction_cone.cpp).
+                                         * Exclusive with linearized_impulse_friction_cone */
 } idocp_constraints_t;
 
 /* ---- Robot ------------------------------------------------------------ */

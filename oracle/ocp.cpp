@@ -223,11 +223,11 @@ const ContactStatus& OCPSolver::nodeContacts(int p) const {
 
 // ------------------------------------------------------------ constraints ----
 bool OCPSolver::componentEnabled(int c, bool impulse) const {
-  if (impulse) return c == 6 && cons.linearized_impulse_friction_cone != 0;
+  if (impulse) return c == 6 && (cons.linearized_impulse_friction_cone != 0 || cons.impulse_friction_cone != 0);
   if (c < 2) return cons.joint_position_limits != 0;
   if (c < 4) return cons.joint_velocity_limits != 0;
   if (c < 6) return cons.joint_torque_limits != 0;
-  return cons.linearized_friction_cone != 0;
+  return cons.linearized_friction_cone != 0 || cons.friction_cone != 0;
 }
 bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraints_data.hpp:18-42
   if (nd.kind == NodeC::Impulse) return componentEnabled(c, true);
@@ -236,7 +236,6 @@ bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraint
   if (c < 4) return nd.level >= 1;
   return true;
 }
-int OCPSolver::componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
 int OCPSolver::dimc() const { int n = 0; for (int c = 0; c < 7; ++c) if (componentEnabled(c, false)) n += componentDim(c); return n; }
 
 static real limitOf(const RModel& m, int c, int k2) {
@@ -255,15 +254,26 @@ static real limitedVar(const SplitSolutionC& s, int c, int k2, int nv, int nu) {
   if (c < 4) return s.v[nv - nu + k2];
   return s.u[k2];
 }
-// LinearizedFrictionCone::frictionConeResidual (linearized_friction_cone.hpp:72-84)
-static void frictionConeResidual(real mu, const Mat& f, real* res) {
-  const real m2 = mu / std::sqrt(2.0);
-  res[0] = -f[2]; res[1] = f[0] - m2 * f[2]; res[2] = -f[0] - m2 * f[2]; res[3] = f[1] - m2 * f[2]; res[4] = -f[1] - m2 * f[2];
-}
-static void frictionJac(real mu, real J[5][3]) {        // linearized_friction_cone.cpp:25-29
+// The friction-cone component of one contact with force f: values g_r(f) <= 0 and gradients J_r(f) of its rows.
+//   kind 0  LinearizedFrictionCone (5 rows): g = Jc f (linearized_friction_cone.hpp:72-84, linearized_friction_cone.cpp:25-29)
+//   kind 1  FrictionCone (2 rows): g0 = -fz, g1 = fx^2 + fy^2 - mu^2 fz^2 (friction_cone.hpp:70-80); J1 is the reference's data.r[i] =
+//           (2 fx, 2 fy, -2 mu^2 fz) (friction_cone.cpp:100-118); the Hessian contribution is the Gauss-Newton term J^T diag(dual / slack) J
+//           in both cases (friction_cone.cpp:121-146), i.e. every formula below is the same for the two kinds
+// (Linearized)ImpulseFrictionCone: the same rows on an impulse stage, with dt = 1.
+ConeEval coneEval(int kind, real mu, const Mat& f) {
+  ConeEval e;
+  if (kind == 1) {
+    e.nr = 2;
+    e.res[0] = -f[2]; e.J[0][0] = 0; e.J[0][1] = 0; e.J[0][2] = -1;
+    e.res[1] = f[0] * f[0] + f[1] * f[1] - mu * mu * f[2] * f[2];
+    e.J[1][0] = 2 * f[0]; e.J[1][1] = 2 * f[1]; e.J[1][2] = -2 * mu * mu * f[2];
+    return e;
+  }
+  e.nr = 5;
   const real m2 = mu / std::sqrt(2.0);
   const real Jc[5][3] = {{0, 0, -1}, {1, 0, -m2}, {-1, 0, -m2}, {0, 1, -m2}, {0, -1, -m2}};
-  for (int r = 0; r < 5; ++r) for (int c = 0; c < 3; ++c) J[r][c] = Jc[r][c];
+  for (int r = 0; r < 5; ++r) { e.res[r] = 0; for (int c = 0; c < 3; ++c) { e.J[r][c] = Jc[r][c]; e.res[r] += Jc[r][c] * f[c]; } }
+  return e;
 }
 
 
@@ -272,15 +282,16 @@ void OCPSolver::initNodeConstraints(const NodeC& nd) {
   const SplitSolutionC& sp = s[nd.slot];
   ipm[nd.slot].clear();
   for (int c = 0; c < 7; ++c) {
-    IpmData data(componentDim(c));
+    IpmData data(componentDim(c, nd.kind == NodeC::Impulse));
+    const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     if (componentValid(c, nd)) {
       if (c < 6) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(sp, c, r, nv_, nu_) - limitOf(robot.model(), c, r));
       } else {
         for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
-          real res[5]; frictionConeResidual(cons.mu, sp.f[cc], res);
-          for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
+          const ConeEval ce = coneEval(CK, cons.mu, sp.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
+          for (int r = 0; r < CR; ++r) data.slack[CR * cc + r] = -res[r];
         }
       }
       for (int r = 0; r < data.slack.size(); ++r) {
@@ -389,9 +400,9 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     }
   }
   // ---- constraints: [computePrimalAndDualResidual] + augmentDualResidual
-  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int c = 0; c < 7; ++c) {
     if (!componentValid(c, nd)) continue;
+    const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[nd.slot][c];
     if (c < 6) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
@@ -408,14 +419,14 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
       if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+        const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J;
         if (residual_only) {
-          real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-          for (int r = 0; r < 5; ++r) {
-            data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
-            data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
+          for (int r = 0; r < CR; ++r) {
+            data.residual[CR * cc + r] = res[r] + data.slack[CR * cc + r];
+            data.duality[CR * cc + r] = data.slack[CR * cc + r] * data.dual[CR * cc + r] - cons.barrier;
           }
         }
-        for (int x = 0; x < 3; ++x) for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * data.dual[5 * cc + r];
+        for (int x = 0; x < 3; ++x) for (int r = 0; r < CR; ++r) R.lf[st + x] += dt * Jc[r][x] * data.dual[CR * cc + r];
         st += 3;
       }
     }
@@ -522,6 +533,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   // ---- Constraints::condenseSlackAndDual
   for (int c = 0; c < 7; ++c) {
     if (!componentValid(c, nd)) continue;
+    const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[nd.slot][c];
     if (c < 6) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
@@ -541,18 +553,18 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
       data.residual.setZero(); data.duality.setZero();
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
         real rr[5], dd[5];
-        for (int r = 0; r < 5; ++r) {
-          const int idx = 5 * cc + r;
+        for (int r = 0; r < CR; ++r) {
+          const int idx = CR * cc + r;
           data.residual[idx] = res[r] + data.slack[idx];
           data.duality[idx] = data.slack[idx] * data.dual[idx] - cons.barrier;
           rr[r] = (data.dual[idx] * data.residual[idx] - data.duality[idx]) / data.slack[idx];
           dd[r] = data.dual[idx] / data.slack[idx];
         }
         for (int x = 0; x < 3; ++x) {
-          for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
-          for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
+          for (int r = 0; r < CR; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
+          for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < CR; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
         }
         st += 3;
       }
@@ -669,16 +681,18 @@ int OCPSolver::isCurrentSolutionFeasible() const {
       const SplitSolutionC& si = s[nd.slot];
       for (int c = 0; c < 6; ++c) {
         if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
         for (int r = 0; r < nu_; ++r) {
           const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
       }
       if (!componentValid(6, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       const ContactStatus& cs = nodeContacts(p);
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-        for (int r = 0; r < 5; ++r) if (res[r] > 0) return p;
+        const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
+        for (int r = 0; r < CR; ++r) if (res[r] > 0) return p;
       }
     }
   return -1;
@@ -881,7 +895,6 @@ static real fractionToBoundary(real rate, const Mat& vec, const Mat& dvec) {    
 void OCPSolver::computeDirection() {
   const int nv = nv_, nu = nu_;
   real pmin = 1, dmin = 1;
-  real Jc[5][3]; frictionJac(cons.mu, Jc);
   const int Mc = M();
   #pragma omp parallel for num_threads(nthreads) reduction(min : pmin, dmin)
   for (int p = 0; p < Mc; ++p) {
@@ -907,6 +920,7 @@ void OCPSolver::computeDirection() {
     // Constraints::computeSlackAndDualDirection + step sizes
     for (int c = 0; c < 7; ++c) {
       if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       IpmData& data = ipm[sl][c];
       if (c < 6) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
@@ -919,8 +933,9 @@ void OCPSolver::computeDirection() {
         for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }   // linearized_friction_cone.cpp:162-163
         int st = 0;
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-          for (int r2 = 0; r2 < 5; ++r2) {
-            const int idx = 5 * cc + r2;
+          const ConeEval ce = coneEval(CK, cons.mu, s[sl].f[cc]); const real (*Jc)[3] = ce.J;     // (FrictionCone: data.r[i] of the linearisation)
+          for (int r2 = 0; r2 < CR; ++r2) {
+            const int idx = CR * cc + r2;
             real Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[sl].daf[nv + st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
@@ -994,6 +1009,7 @@ void OCPSolver::integrateSolution() {
     if (nd.sw_event >= 0) for (int r = 0; r < d[sl].dxi.size(); ++r) si.xi[r] += ap * d[sl].dxi[r];
     for (int c = 0; c < 7; ++c) {
       if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       ipm[sl][c].slack += ap * ipm[sl][c].dslack;
       ipm[sl][c].dual += ad * ipm[sl][c].ddual;
     }
@@ -1023,7 +1039,6 @@ void OCPSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line
 std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
   const int nv = nv_, nu = nu_;
   Robot rb = robot;
-  real Jc[5][3]; frictionJac(cons.mu, Jc);
   real cost_sum = 0, viol_sum = 0;
   auto trial = [&](int p) {
     const NodeC& nd = chain[p];
@@ -1079,6 +1094,7 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
     real barrier = 0, primal = 0;
     for (int c = 0; c < 7; ++c) {
       if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       const IpmData& data = ipm[sl][c];
       for (int r = 0; r < data.slack.size(); ++r) barrier -= cons.barrier * std::log(data.slack[r] + alpha * data.dslack[r]);      // pdipm.hxx:84-87
       if (c < 6) {
@@ -1086,8 +1102,8 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
         for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), c, r)) + data.slack[r]);
       } else {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-          real res[5]; frictionConeResidual(cons.mu, x.f[cc], res);
-          for (int r = 0; r < 5; ++r) primal += std::fabs(res[r] + data.slack[5 * cc + r]);
+          const ConeEval ce = coneEval(CK, cons.mu, x.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
+          for (int r = 0; r < CR; ++r) primal += std::fabs(res[r] + data.slack[CR * cc + r]);
         }
       }
     }
@@ -1335,11 +1351,11 @@ void ParNMPCSolver::discretize(real t) {
 }
 
 bool ParNMPCSolver::componentValid(int c, const PNode& nd) const {     // constraints_data.hpp:18-42
-  if (nd.kind == NodeC::Impulse) return c == 6 && cons.linearized_impulse_friction_cone != 0;
+  if (nd.kind == NodeC::Impulse) return c == 6 && (cons.linearized_impulse_friction_cone != 0 || cons.impulse_friction_cone != 0);
   if (c < 2) return cons.joint_position_limits != 0 && nd.level >= 2;
   if (c < 4) return cons.joint_velocity_limits != 0 && nd.level >= 1;
   if (c < 6) return cons.joint_torque_limits != 0;
-  return cons.linearized_friction_cone != 0;
+  return cons.linearized_friction_cone != 0 || cons.friction_cone != 0;
 }
 
 void ParNMPCSolver::qRef(real t, Mat& q_ref) const {
@@ -1372,16 +1388,17 @@ void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
   const ContactStatus& cs = nodeContacts(nd);
   ipm[i].clear();
   for (int c = 0; c < 7; ++c) {
-    IpmData data(componentDim(c));
+    IpmData data(componentDim(c, nd.kind == NodeC::Impulse));
+    const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     if (componentValid(c, nd)) {
       if (c < 6) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
       } else {
         for (int cc = 0; cc < nc_; ++cc) {
-          if (seq.numEvents() > 0 && !cs.active[cc]) { for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = cons.barrier; continue; }
-          real res[5]; frictionConeResidual(cons.mu, s[i].f[cc], res);
-          for (int r = 0; r < 5; ++r) data.slack[5 * cc + r] = -res[r];
+          if (seq.numEvents() > 0 && !cs.active[cc]) { for (int r = 0; r < CR; ++r) data.slack[CR * cc + r] = cons.barrier; continue; }
+          const ConeEval ce = coneEval(CK, cons.mu, s[i].f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
+          for (int r = 0; r < CR; ++r) data.slack[CR * cc + r] = -res[r];
         }
       }
       for (int r = 0; r < data.slack.size(); ++r) {
@@ -1457,9 +1474,9 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   }
   // ---- constraints
-  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int c = 0; c < 7; ++c) {
     if (!componentValid(c, nd)) continue;
+    const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[i][c];
     if (c < 6) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
@@ -1476,14 +1493,14 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
       if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+        const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J;
         if (residual_only) {
-          real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-          for (int r = 0; r < 5; ++r) {
-            data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
-            data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
+          for (int r = 0; r < CR; ++r) {
+            data.residual[CR * cc + r] = res[r] + data.slack[CR * cc + r];
+            data.duality[CR * cc + r] = data.slack[CR * cc + r] * data.dual[CR * cc + r] - cons.barrier;
           }
         }
-        for (int x = 0; x < 3; ++x) for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * data.dual[5 * cc + r];
+        for (int x = 0; x < 3; ++x) for (int r = 0; r < CR; ++r) R.lf[st + x] += dt * Jc[r][x] * data.dual[CR * cc + r];
         st += 3;
       }
     }
@@ -1570,6 +1587,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   // ---- Constraints::condenseSlackAndDual
   for (int c = 0; c < 7; ++c) {
     if (!componentValid(c, nd)) continue;
+    const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[i][c];
     if (c < 6) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
@@ -1588,18 +1606,18 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
       data.residual.setZero(); data.duality.setZero();
       int st = 0;
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+        const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
         real rr[5], dd[5];
-        for (int r = 0; r < 5; ++r) {
-          const int idx = 5 * cc + r;
+        for (int r = 0; r < CR; ++r) {
+          const int idx = CR * cc + r;
           data.residual[idx] = res[r] + data.slack[idx];
           data.duality[idx] = data.slack[idx] * data.dual[idx] - cons.barrier;
           rr[r] = (data.dual[idx] * data.residual[idx] - data.duality[idx]) / data.slack[idx];
           dd[r] = data.dual[idx] / data.slack[idx];
         }
         for (int x = 0; x < 3; ++x) {
-          for (int r = 0; r < 5; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
-          for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
+          for (int r = 0; r < CR; ++r) R.lf[st + x] += dt * Jc[r][x] * rr[r];
+          for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < CR; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += dt * acc; }
         }
         st += 3;
       }
@@ -1676,21 +1694,21 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
     }
   }
   // ---- impulse friction cone: augmentDualResidual
-  real Jc[5][3]; frictionJac(cons.mu, Jc);
   const bool cone = componentValid(6, nd);
+  const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
   if (cone) {
     IpmData& data = ipm[i][6];
     if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
     int st = 0;
     for (int cc = 0; cc < nc_; ++cc) if (is.active[cc]) {
+      const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J;
       if (residual_only) {
-        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-        for (int r = 0; r < 5; ++r) {
-          data.residual[5 * cc + r] = res[r] + data.slack[5 * cc + r];
-          data.duality[5 * cc + r] = data.slack[5 * cc + r] * data.dual[5 * cc + r] - cons.barrier;
+        for (int r = 0; r < CR; ++r) {
+          data.residual[CR * cc + r] = res[r] + data.slack[CR * cc + r];
+          data.duality[CR * cc + r] = data.slack[CR * cc + r] * data.dual[CR * cc + r] - cons.barrier;
         }
       }
-      for (int x = 0; x < 3; ++x) for (int r = 0; r < 5; ++r) R.lf[st + x] += Jc[r][x] * data.dual[5 * cc + r];
+      for (int x = 0; x < 3; ++x) for (int r = 0; r < CR; ++r) R.lf[st + x] += Jc[r][x] * data.dual[CR * cc + r];
       st += 3;
     }
   }
@@ -1751,18 +1769,18 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
     data.residual.setZero(); data.duality.setZero();
     int st = 0;
     for (int cc = 0; cc < nc_; ++cc) if (is.active[cc]) {
-      real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
+      const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
       real rr[5], dd[5];
-      for (int r = 0; r < 5; ++r) {
-        const int idx = 5 * cc + r;
+      for (int r = 0; r < CR; ++r) {
+        const int idx = CR * cc + r;
         data.residual[idx] = res[r] + data.slack[idx];
         data.duality[idx] = data.slack[idx] * data.dual[idx] - cons.barrier;
         rr[r] = (data.dual[idx] * data.residual[idx] - data.duality[idx]) / data.slack[idx];
         dd[r] = data.dual[idx] / data.slack[idx];
       }
       for (int x = 0; x < 3; ++x) {
-        for (int r = 0; r < 5; ++r) R.lf[st + x] += Jc[r][x] * rr[r];
-        for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < 5; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += acc; }
+        for (int r = 0; r < CR; ++r) R.lf[st + x] += Jc[r][x] * rr[r];
+        for (int y = 0; y < 3; ++y) { real acc = 0; for (int r = 0; r < CR; ++r) acc += Jc[r][x] * dd[r] * Jc[r][y]; M.Qff(st + x, st + y) += acc; }
       }
       st += 3;
     }
@@ -1936,7 +1954,6 @@ void ParNMPCSolver::forwardCorrectionSerial() {
 void ParNMPCSolver::forwardCorrectionParallel() {
   const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
   real pmin = 1, dmin = 1;
-  real Jc[5][3]; frictionJac(cons.mu, Jc);
   for (int p = 0; p < Mc; ++p) {
     const PNode& nd = chain[p];
     const int i = nd.slot;
@@ -1984,12 +2001,14 @@ void ParNMPCSolver::forwardCorrectionParallel() {
       if (dimf > 0) ddv += I.Fvf * df;
       d[i].daf = Mat(nv + dimf); d[i].daf.setSegment(0, ddv); d[i].daf.setSegment(nv, df);
       if (componentValid(6, nd)) {
+        const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
         IpmData& data = ipm[i][6];
         for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
         st = 0;
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-          for (int r2 = 0; r2 < 5; ++r2) {
-            const int idx = 5 * cc + r2;
+          const ConeEval ce = coneEval(CK, cons.mu, s[i].f[cc]); const real (*Jc)[3] = ce.J;     // (FrictionCone: data.r[i] of the linearisation)
+          for (int r2 = 0; r2 < CR; ++r2) {
+            const int idx = CR * cc + r2;
             real Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * df[st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
@@ -2018,6 +2037,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
     for (int r2 = 0; r2 < dimf; ++r2) d[i].daf[nv + r2] *= -1;
     for (int c = 0; c < 7; ++c) {
       if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       IpmData& data = ipm[i][c];
       if (c < 6) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
@@ -2030,8 +2050,9 @@ void ParNMPCSolver::forwardCorrectionParallel() {
         for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
         int st = 0;
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-          for (int r2 = 0; r2 < 5; ++r2) {
-            const int idx = 5 * cc + r2;
+          const ConeEval ce = coneEval(CK, cons.mu, s[i].f[cc]); const real (*Jc)[3] = ce.J;     // (FrictionCone: data.r[i] of the linearisation)
+          for (int r2 = 0; r2 < CR; ++r2) {
+            const int idx = CR * cc + r2;
             real Jdf = 0; for (int x = 0; x < 3; ++x) Jdf += Jc[r2][x] * d[i].daf[nv + st + x];
             data.dslack[idx] = -Jdf - data.residual[idx];
             data.ddual[idx] = -(data.dual[idx] * data.dslack[idx] + data.duality[idx]) / data.slack[idx];
@@ -2085,6 +2106,7 @@ void ParNMPCSolver::integrateSolution() {
     }
     for (int c = 0; c < 7; ++c) {
       if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       ipm[i][c].slack += ap * ipm[i][c].dslack;
       ipm[i][c].dual += ad * ipm[i][c].ddual;
     }
@@ -2123,16 +2145,18 @@ int ParNMPCSolver::isCurrentSolutionFeasible() const {
       const SplitSolutionC& si = s[nd.slot];
       for (int c = 0; c < 6; ++c) {
         if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
         for (int r = 0; r < nu_; ++r) {
           const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
       }
       if (!componentValid(6, nd)) continue;
+      const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       const ContactStatus& cs = nodeContacts(nd);
       for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
-        real res[5]; frictionConeResidual(cons.mu, si.f[cc], res);
-        for (int r = 0; r < 5; ++r) if (res[r] > 0) return p;
+        const ConeEval ce = coneEval(CK, cons.mu, si.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
+        for (int r = 0; r < CR; ++r) if (res[r] > 0) return p;
       }
     }
   return -1;

@@ -77,6 +77,10 @@ struct SplitDirectionC {
   explicit SplitDirectionC(const Robot& r);
 };
 
+// rows of the friction-cone component of one contact (coneEval, ocp.cpp)
+struct ConeEval { int nr; real res[5]; real J[5][3]; };
+ConeEval coneEval(int kind, real mu, const Mat& f);
+
 struct IpmData {                  // ConstraintComponentData
   Mat slack, dual, residual, duality, dslack, ddual;
   explicit IpmData(int n = 0) : slack(n), dual(n), residual(n), duality(n), dslack(n), ddual(n) {}
@@ -174,7 +178,9 @@ class OCPSolver {
   // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone (impulse cone on impulse stages)
   bool componentEnabled(int c, bool impulse) const;
   bool componentValid(int c, const NodeC& nd) const;
-  int componentDim(int c) const;
+  int componentDim(int c, bool impulse = false) const { return c < 6 ? nu_ : coneRows(impulse) * nc_; }
+  int coneKind(bool impulse) const { return (impulse ? cons.impulse_friction_cone : cons.friction_cone) ? 1 : 0; }
+  int coneRows(bool impulse) const { return coneKind(impulse) == 1 ? 2 : 5; }
   void initNodeConstraints(const NodeC& nd);
   // the stage loops run under `#pragma omp parallel for num_threads(nthreads)` where the reference's do (ocp_linearizer.cpp:47,
   // 74-83, 104, 152; riccati_recursion_solver.cpp:174-239), each thread with a Robot of its own like the reference's
@@ -286,7 +292,9 @@ class ParNMPCSolver {
   real disc_t_ = 0;
   bool discretized_ = false;
   bool componentValid(int c, const PNode& nd) const;
-  int componentDim(int c) const { return c < 6 ? nu_ : 5 * nc_; }
+  int componentDim(int c, bool impulse = false) const { return c < 6 ? nu_ : coneRows(impulse) * nc_; }
+  int coneKind(bool impulse) const { return (impulse ? cons.impulse_friction_cone : cons.friction_cone) ? 1 : 0; }
+  int coneRows(bool impulse) const { return coneKind(impulse) == 1 ? 2 : 5; }
   void qRef(real t, Mat& q_ref) const;
   void initNodeConstraints(const PNode& nd);
   void linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only);

@@ -669,6 +669,13 @@ int oracle_ocp_get_riccati(void* h, double* P, double* sv, double* K, double* k)
   }
   return 0;
 }
+// rows of the friction-cone component of one contact (coneEval, ocp.cpp): returns the number of rows, res[5], J[5][3] row-major
+int oracle_cone_eval(int kind, double mu, const double* f, double* res, double* J) {
+  Mat fm(3); for (int k = 0; k < 3; ++k) fm[k] = f[k];
+  const ConeEval e = coneEval(kind, mu, fm);
+  for (int r = 0; r < e.nr; ++r) { res[r] = (double)e.res[r]; for (int c = 0; c < 3; ++c) J[3 * r + c] = (double)e.J[r][c]; }
+  return e.nr;
+}
 int oracle_ocp_dimc(void* h) { return static_cast<OCPSolver*>(h)->dimc(); }
 // slack / dual [N][dimc]: enabled components in order; rows invalid at a stage read 0
 int oracle_ocp_get_constraint_data(void* h, double* slack, double* dual) {
@@ -676,7 +683,7 @@ int oracle_ocp_get_constraint_data(void* h, double* slack, double* dual) {
   const int dimc = s->dimc();
   const idocp_constraints_t& c = s->cons;
   const int en[7] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits,
-                     c.joint_torque_limits, c.joint_torque_limits, c.linearized_friction_cone};
+                     c.joint_torque_limits, c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone};
   for (int i = 0; i < s->N(); ++i) {
     int off = 0;
     for (int comp = 0; comp < 7; ++comp) {
