@@ -1,6 +1,6 @@
 // ANYmal standing on four feet, idocp::OCPSolver on the HIP path: convergence and time per update.
 // Workload: the one of the reference's examples/anymal/ocp_benchmark.cpp (configuration-space cost around the standing
-// pose, contact-force cost around 70 N per foot, joint limits, friction cone mu = 0.7; N = 20, T = 0.5).
+// pose, contact-force cost around 70 N per foot, joint limits, FrictionCone mu = 0.7; N = 20, T = 0.5).
 //   usage: anymal_ocp_benchmark <anymal.urdf> [timed updates = 1000]
 #include "common.hpp"
 #include "idocp/cost/configuration_space_cost.hpp"
@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   cost->push_back(pose_cost);
   cost->push_back(ex::forceCost(robot, ex::V3(0.001, 0.001, 0.001), false, &share));
 
-  idocp::OCPSolver solver(robot, cost, ex::jointLimits(robot, 0.7), 0.5, 20, 4, 4);
+  idocp::OCPSolver solver(robot, cost, ex::jointLimits(robot, 0.7, false, true), 0.5, 20, 4, 4);      // FrictionCone(robot, 0.7), as in the reference driver (:76)
   ex::Schedule standing(ex::footholds(robot, stand));
   standing.add({0, 1, 2, 3}, 0.0);
   standing.install(solver, robot);

@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   cost->push_back(pose_cost);
   cost->push_back(ex::forceCost(robot, ex::V3(0.001, 0.001, 0.001), false, &share));
 
-  idocp::ParNMPCSolver solver(robot, cost, ex::jointLimits(robot, 0.7), 0.5, 20, 4, 4);
+  idocp::ParNMPCSolver solver(robot, cost, ex::jointLimits(robot, 0.7, false, true), 0.5, 20, 4, 4);      // FrictionCone(robot, 0.7), as in the reference driver (:76)
   ex::Schedule standing(ex::footholds(robot, stand));
   standing.add({0, 1, 2, 3}, 0.0);
   standing.install(solver, robot);

@@ -75,7 +75,8 @@ inline std::shared_ptr<idocp::ContactForceCost> forceCost(const idocp::Robot& ro
 }
 
 // position / velocity / torque limits of the actuated joints, plus the linearised friction cones when mu > 0
-inline std::shared_ptr<idocp::Constraints> jointLimits(const idocp::Robot& robot, double mu = 0.0, bool impulse_cone = false) {
+// quadratic = true: FrictionCone / ImpulseFrictionCone (the benchmark drivers of the reference) instead of the linearized pair
+inline std::shared_ptr<idocp::Constraints> jointLimits(const idocp::Robot& robot, double mu = 0.0, bool impulse_cone = false, bool quadratic = false) {
   auto k = std::make_shared<idocp::Constraints>();
   k->push_back(std::make_shared<idocp::JointPositionLowerLimit>(robot));
   k->push_back(std::make_shared<idocp::JointPositionUpperLimit>(robot));
@@ -83,8 +84,10 @@ inline std::shared_ptr<idocp::Constraints> jointLimits(const idocp::Robot& robot
   k->push_back(std::make_shared<idocp::JointVelocityUpperLimit>(robot));
   k->push_back(std::make_shared<idocp::JointTorquesLowerLimit>(robot));
   k->push_back(std::make_shared<idocp::JointTorquesUpperLimit>(robot));
-  if (mu > 0.0) k->push_back(std::make_shared<idocp::LinearizedFrictionCone>(robot, mu));
-  if (mu > 0.0 && impulse_cone) k->push_back(std::make_shared<idocp::LinearizedImpulseFrictionCone>(robot, mu));
+  if (mu > 0.0 && !quadratic) k->push_back(std::make_shared<idocp::LinearizedFrictionCone>(robot, mu));
+  if (mu > 0.0 && !quadratic && impulse_cone) k->push_back(std::make_shared<idocp::LinearizedImpulseFrictionCone>(robot, mu));
+  if (mu > 0.0 && quadratic) k->push_back(std::make_shared<idocp::FrictionCone>(robot, mu));
+  if (mu > 0.0 && quadratic && impulse_cone) k->push_back(std::make_shared<idocp::ImpulseFrictionCone>(robot, mu));
   return k;
 }
 

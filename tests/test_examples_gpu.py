@@ -48,7 +48,7 @@ def test_anymal_ocp_benchmark_example_matches_oracle():
     cons = capi.Constraints()
     import ctypes as C
     capi.lib().idocp_constraints_init(C.byref(cons))
-    cons.linearized_friction_cone = 1
+    cons.friction_cone = 1                                  # FrictionCone(robot, 0.7), ocp_benchmark.cpp:76
     cons.mu = 0.7
     o = OracleOCP(model, cost, cons, 0.5, 20)
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
@@ -212,7 +212,7 @@ def test_anymal_parnmpc_benchmark_example_matches_oracle():
         cost.f_ref[c][2] = 70.0
     cons = capi.Constraints()
     capi.lib().idocp_constraints_init(C.byref(cons))
-    cons.linearized_friction_cone = 1
+    cons.friction_cone = 1                                  # FrictionCone(robot, 0.7), parnmpc_benchmark.cpp:76
     cons.mu = 0.7
     o = OracleParNMPC(model, cost, cons, 0.5, 20)
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
