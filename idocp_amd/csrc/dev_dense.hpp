@@ -250,39 +250,71 @@ __device__ __forceinline__ void choleskyRows(double* A, int ld, int n, int lane,
 #pragma unroll
   for (int j = 0; j < N; ++j) if (on && j < n && j <= lane) A[lane + ld * j] = a[j];
 }
-// Cholesky + solve in one pass, everything in registers: lane r keeps row r of the SPD N x N block A (read from LDS, never
-// written back), EVERY lane of the wavefront keeps a right-hand side x of its own and leaves with x <- A^-1 x.  The entries of
-// column k of L travel through v_readlane once and serve both the trailing update and the forward substitution; the backward
-// substitution reads L back out of the row registers the same way.  No LDS traffic, no wait between the steps.
+// Cholesky + solve in one pass, everything in registers: EVERY lane of the wavefront keeps a right-hand side x of its own and leaves
+// with x <- A^-1 x; lane l also keeps row (l mod 16) of the SPD N x N block A (N <= 16; read from LDS, never written back), i.e. each
+// row of 16 lanes holds its own copy of the matrix and factorises it (redundant, but free in SIMT) so that the entries of column k
+// of L reach every lane as a DPP row broadcast (row_newbcast: lane k of the reader's own row of 16) -- VGPR to VGPR.  (Round 2 first
+// used v_readlane: the column entries then live in scalar registers, and in the Riccati kernel, whose scalar file is full of
+// pointers and strides, every one of them was spilled to a VGPR lane and reloaded -- two thirds of the instructions of a step.)
+// The entries of column k serve both the trailing update and the forward substitution; the backward substitution reads L back out
+// of the row registers the same way.  No LDS traffic, no wait between the steps.
 // n <= N: the block is padded with the identity (the caller keeps x[j] = 0 for j >= n).
+template <int LANE>
+__device__ __forceinline__ double rowBcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + LANE, 0xF, 0xF, true);      // row_newbcast:LANE (every lane has a valid source: "old" is never used)
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + LANE, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// (n is a constant after unrolling: the switch folds to one DPP move pair)
+__device__ __forceinline__ double rowBcastN(double v, int n) {
+  switch (n) {
+    case 0: return rowBcast<0>(v);   case 1: return rowBcast<1>(v);   case 2: return rowBcast<2>(v);   case 3: return rowBcast<3>(v);
+    case 4: return rowBcast<4>(v);   case 5: return rowBcast<5>(v);   case 6: return rowBcast<6>(v);   case 7: return rowBcast<7>(v);
+    case 8: return rowBcast<8>(v);   case 9: return rowBcast<9>(v);   case 10: return rowBcast<10>(v); case 11: return rowBcast<11>(v);
+    case 12: return rowBcast<12>(v); case 13: return rowBcast<13>(v); case 14: return rowBcast<14>(v); default: return rowBcast<15>(v);
+  }
+}
 template <int N>
 __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int lane, int* ok, double (&x)[N], int n = N) {
-  double a[N], dinv = 1.0;      // dinv: 1 / L_kk, kept by lane k
+  static_assert(N <= 16, "one matrix row per lane of a DPP row");
+  const int row = lane & 15;
+  double a[N], dinv = 1.0;      // dinv: 1 / L_kk, kept by the lanes of row k
+  bool bad = false;
 #pragma unroll
-  for (int j = 0; j < N; ++j) a[j] = (lane < n && j < n) ? A[lane + ld * j] : ((j == lane) ? 1.0 : 0.0);
+  for (int j = 0; j < N; ++j) a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0);
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const double p = readLaneF64(a[k], k);
-    if (lane == 0 && !(p > 0.0)) *ok = 0;
+    const double p = rowBcastN(a[k], k);
+    bad = bad || !(p > 0.0);             // (one store at the end: a branch per step would split the steps into separate blocks)
     double is, sq;
     rsqrtNewton(p, is, sq);
-    dinv = (lane == k) ? is : dinv;
-    const double lrk = (lane == k) ? sq : a[k] * is;
+    dinv = (row == k) ? is : dinv;
+    const double lrk = (row == k) ? sq : a[k] * is;
     a[k] = lrk;
     x[k] *= is;
 #pragma unroll
     for (int c = k + 1; c < N; ++c) {
-      const double lck = readLaneF64(lrk, c);
+      const double lck = rowBcastN(lrk, c);
       a[c] -= lrk * lck;
       x[c] -= lck * x[k];
     }
+    // The right-hand-side updates are off the critical path (the pivots), and the compiler postpones them -- ALL of them, keeping
+    // the 66 broadcast values of all steps alive (200 VGPRs instead of 74).  An empty asm that "redefines" x[c] pins each update to its step.
+#pragma unroll
+    for (int c = k + 1; c < N; ++c) asm volatile("" : "+v"(x[c]));
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    x[i] *= readLaneF64(dinv, i);
 #pragma unroll
-    for (int r = 0; r < i; ++r) x[r] -= readLaneF64(a[r], i) * x[i];
+    for (int r = 0; r < i; ++r) asm volatile("" : "+v"(a[r]));      // likewise: the broadcasts of L for step i are not hoisted above it
+    x[i] *= rowBcastN(dinv, i);
+#pragma unroll
+    for (int r = 0; r < i; ++r) x[r] -= rowBcastN(a[r], i) * x[i];
+#pragma unroll
+    for (int r = 0; r < i; ++r) asm volatile("" : "+v"(x[r]));
   }
+  if (bad && lane == 0) *ok = 0;
 }
 
 // x <- (L L^T)^-1 x for the right-hand side held by this lane (n = N); L is read as LDS broadcasts
