@@ -229,9 +229,13 @@ __device__ __forceinline__ void riccatiPhase4(const double* Quu, const double* K
   }
 }
 
-// phase 5: P = F - K^T GK on the upper block triangle
+// phase 5: P = F - K^T Y on the upper block triangle, Y (NU x NX) = GK.  Where K comes straight out of the solve G K = -H^T (every
+// stage without a switching constraint), GK IS -H^T up to the residual of a backward-stable solve (|G K + H^T| ~ eps |G| |K|, not
+// amplified by the condition of G), so the product Quu K (phase 4, one more barrier) is skipped and Y = -Qxu^T is read in place:
+// entry (j, c) of Y at Y + ycs c + yks j, sign = +1 for GK, -1 for Qxu^T.
 template <typename D, int TB, int TE>
-__device__ __forceinline__ void riccatiPhase5(const double* KM, const double* GK, double* Pqq, double* Pqv, double* Pvv, int lane) {
+__device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y, int ycs, int yks, double sign, double* Pqq, double* Pqv,
+                                              double* Pvv, int lane) {
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, KS = (NU + 3) / 4, NTL = TE - TB;
   if constexpr (NTL > 0) {
     const int li = lane & 15, g = lane >> 4;
@@ -240,7 +244,7 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* GK
     for (int v = 0; v < 3; ++v) {
       const int e = 16 * v + li, ec = e < NX ? e : NX - 1;
       if (tilesUseUpperIb(TB, TE, v)) mfmaLoadOp<NU>(xo[v], KM + NU * ec, 1, lane);
-      if (tilesUseUpperJb(TB, TE, v)) mfmaLoadOp<NU>(yo[v], GK + NU * ec, 1, lane);
+      if (tilesUseUpperJb(TB, TE, v)) mfmaLoadOp<NU>(yo[v], Y + ycs * ec, yks, lane);
     }
     mfma_d4 acc[NTL];
 #pragma unroll
@@ -259,7 +263,7 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* GK
         if (r <= c && c < NX) {
           const int rb = r >= NV, cb = c >= NV, rr = r - NV * rb, cc = c - NV * cb;
           double* blk = Pqq + NV * NV * (rb + cb);
-          const double val = blk[rr + NV * cc] - acc[j][q];                      // the mirror image holds the same value: store, don't update
+          const double val = blk[rr + NV * cc] - sign * acc[j][q];               // the mirror image holds the same value: store, don't update
           blk[rr + NV * cc] = val;
           blk[(rb == cb) ? cc + NV * rr : rr + NV * cc] = val;
         }
@@ -570,19 +574,28 @@ __global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers 
       __syncthreads();                                           // M (aliasing GK) is dead from here
     }
     RSTAMP(4);
-    // ---- phase 4: GK = Quu K (backward_riccati_recursion_factorizer.hxx:128) ----
-    RICCATI_TILES(riccatiPhase4, 3, Quu, &sm[S::KM], &sm[S::GK], lane);
-    // s recursion, part 2: - Qxu k
+    // ---- phase 4: GK = Quu K (backward_riccati_recursion_factorizer.hxx:128) -- only where K is not the plain solution of
+    //      G K = -H^T (the stages with a switching constraint); see riccatiPhase5 ----
+    if (constrained) {
+      RICCATI_TILES(riccatiPhase4, 3, Quu, &sm[S::KM], &sm[S::GK], lane);
+      __syncthreads();
+    }
+    RSTAMP(5);
+    // s recursion, part 2: - Qxu k (next to the tiles below: it reads Qxu and k, they read K and Qxu / GK)
     if (tid >= NT - NV) {
       const int r = tid - (NT - NV);
       double sq = sm[S::SQN + r], sv = sm[S::SVN + r];
+#pragma unroll
       for (int j = 0; j < NU; ++j) { sq -= Qxu[r + NX * j] * sm[S::KV + j]; sv -= Qxu[(NV + r) + NX * j] * sm[S::KV + j]; }
       sm[S::SQN + r] = sq; sm[S::SVN + r] = sv;
     }
-    __syncthreads();
-    RSTAMP(5);
     // ---- phase 5: P = F - K^T G K (:122-131) ----
-    RICCATI_TILES(riccatiPhase5, T2, &sm[S::KM], &sm[S::GK], Pqq, Pqv, Pvv, lane);
+    {
+      const double* Y = constrained ? &sm[S::GK] : Qxu;
+      const int ycs = constrained ? NU : 1, yks = constrained ? 1 : NX;
+      const double sign = constrained ? 1.0 : -1.0;
+      RICCATI_TILES(riccatiPhase5, T2, &sm[S::KM], Y, ycs, yks, sign, Pqq, Pqv, Pvv, lane);
+    }
     __syncthreads();
     RSTAMP(6);
     RSTAMP(7);
