@@ -288,7 +288,7 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y,
   } while (0)
 
 template <typename D, int NT, bool HYBRID>
-__global__ __launch_bounds__(NT, 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = RiccatiSmem<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV, NF = D::NF, LDW = S::LDW, NW = NT / 64;
@@ -762,12 +762,16 @@ void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool 
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     configured = true;
   }
   static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
   // A chain with switching constraints takes the HYBRID instantiation (same LDS footprint).
   if (hybrid) {
-    if (nt_env == 256 || (nt_env == 0 && batch < 512)) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256, true>), dim3((unsigned)batch), dim3(256), smem_h, st, B);
+    // measured on the trotting / running chains: four instances per CU (batch 1024) are fastest with ONE wavefront each (512 registers,
+    // nothing spilled, no wavefront waits for another: 2.02 vs 2.15 ms), two per CU with two wavefronts each (4.08 vs 4.43 ms)
+    if (nt_env == 64 || (nt_env == 0 && batch >= 1024)) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 64, true>), dim3((unsigned)batch), dim3(64), smem_h, st, B);
+    else if (nt_env == 256 || (nt_env == 0 && batch < 512)) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 256, true>), dim3((unsigned)batch), dim3(256), smem_h, st, B);
     else hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 128, true>), dim3((unsigned)batch), dim3(128), smem_h, st, B);
     return;
   }
