@@ -64,27 +64,6 @@ __device__ __forceinline__ void mv(double* y, MatView A, const double* x, int m,
   }
 }
 
-// In-place Cholesky A = L L^T of an n x n column-major block (lower triangle
-// holds L on exit).  Right-looking, one barrier pair per column.  Returns via
-// *ok (shared) whether every pivot was positive.
-__device__ __forceinline__ void choleskyInPlace(double* A, int ld, int n, int tid, int nthreads, int* ok) {
-  for (int j = 0; j < n; ++j) {
-    __syncthreads();
-    const double d = A[j + j * ld];
-    if (tid == 0 && !(d > 0.0)) *ok = 0;
-    const double ljj = sqrt(d);
-    __syncthreads();
-    for (int i = j + tid; i < n; i += nthreads) A[i + j * ld] = (i == j) ? ljj : A[i + j * ld] / ljj;
-    __syncthreads();
-    const int rem = n - j - 1;
-    for (int e = tid; e < rem * rem; e += nthreads) {
-      const int c = e / rem, r = e - c * rem;
-      if (r >= c) A[(j + 1 + r) + (j + 1 + c) * ld] -= A[(j + 1 + r) + j * ld] * A[(j + 1 + c) + j * ld];
-    }
-  }
-  __syncthreads();
-}
-
 // Inverse of an SPD n x n column-major block by Gauss-Jordan elimination without
 // pivoting (stable for SPD: every pivot is a positive Schur complement).  n steps
 // of fully parallel O(n^2) work with ONE barrier each: the sweep ping-pongs
@@ -219,37 +198,6 @@ __device__ __forceinline__ void rsqrtNewton(double p, double& rs, double& s) {
   rs = x; s = sq;
 }
 
-// Cholesky A = L L^T of an SPD n x n block (n <= N <= 64) in the REGISTERS of one wavefront: lane r keeps row r, the entries of
-// column k travel through v_readlane.  On exit the lower triangle of A (column-major, ld) holds L and invd[k] = 1 / L_kk.
-// Every lane of the wavefront must call it.  With cholSolveLane this is Eigen::LLT compute + solve: backward stable, where a
-// product with an explicit inverse leaves a residual that is cond(A) times larger (what matters for P = F - K^T G K on the
-// stages whose G = Quu + B^T P B is ill-conditioned, split_riccati_factorizer.hxx:43-46).
-template <int N>
-__device__ __forceinline__ void choleskyRows(double* A, int ld, int n, int lane, int* ok, double* invd) {
-  double a[N];
-  const bool on = lane < n;
-#pragma unroll
-  for (int j = 0; j < N; ++j) a[j] = (on && j < n) ? A[lane + ld * j] : ((j == lane) ? 1.0 : 0.0);
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < n) {
-      const double p = readLaneF64(a[k], k);
-      if (lane == 0 && !(p > 0.0)) *ok = 0;
-      double is, sq;
-      rsqrtNewton(p, is, sq);
-      const double lrk = (lane == k) ? sq : a[k] * is;
-      a[k] = lrk;
-      if (lane == 0) invd[k] = is;
-#pragma unroll
-      for (int c = k + 1; c < N; ++c) {
-        const double lck = readLaneF64(lrk, c);
-        a[c] -= lrk * lck;
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < N; ++j) if (on && j < n && j <= lane) A[lane + ld * j] = a[j];
-}
 // Cholesky + solve in one pass, everything in registers: EVERY lane of the wavefront keeps a right-hand side x of its own and leaves
 // with x <- A^-1 x; lane l also keeps row (l mod 16) of the SPD N x N block A (N <= 16; read from LDS, never written back), i.e. each
 // row of 16 lanes holds its own copy of the matrix and factorises it (redundant, but free in SIMT) so that the entries of column k
@@ -315,25 +263,6 @@ __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int l
     for (int r = 0; r < i; ++r) asm volatile("" : "+v"(x[r]));
   }
   if (bad && lane == 0) *ok = 0;
-}
-
-// x <- (L L^T)^-1 x for the right-hand side held by this lane (n = N); L is read as LDS broadcasts
-template <int N>
-__device__ __forceinline__ void cholSolveLane(const double* Lm, int ld, const double* invd, double (&x)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    x[i] *= invd[i];
-#pragma unroll
-    for (int r = i + 1; r < N; ++r) x[r] -= Lm[r + ld * i] * x[i];
-    __builtin_amdgcn_sched_barrier(0);      // keep the loads of L column by column (hoisted all at once they cost 2 N^2 registers)
-  }
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    x[i] *= invd[i];
-#pragma unroll
-    for (int r = 0; r < i; ++r) x[r] -= Lm[i + ld * r] * x[i];
-    __builtin_amdgcn_sched_barrier(0);
-  }
 }
 
 // ordering point between LDS writes and reads of ONE wavefront (no workgroup barrier: its LDS operations execute in order)
@@ -493,98 +422,17 @@ __device__ __forceinline__ void spdInverseRowsGrouped(double* A, int gstride, in
   for (int j = 0; j < N; ++j) if (on) Ag[r + N * j] = a[j];
 }
 
-// C (m x n) (+)= alpha * X^T Y with X (k x m, ldx) and Y (k x n, ldy) column-major,
-// i.e. both operands contiguous along the contraction index: 2 x 2 register blocks,
-// 16-byte LDS reads (two k's per read): 0.5 LDS instruction per FMA instead of 2.
-// m, n even; column starts 16-byte aligned (ldx, ldy even, even base offsets).
-__device__ __forceinline__ void mmTN22(double* C, int ldc, const double* X, int ldx, const double* Y, int ldy, int m, int n, int k,
-                                       double alpha, bool accumulate, int tid, int nthreads) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  const int mb = m >> 1, nb = n >> 1, k2 = k >> 1;
-  for (int e = tid; e < mb * nb; e += nthreads) {
-    const int jb = e / mb, ib = e - jb * mb;
-    const double* x0 = X + (2 * ib) * ldx;
-    const double* x1 = x0 + ldx;
-    const double* y0 = Y + (2 * jb) * ldy;
-    const double* y1 = y0 + ldy;
-    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
-#pragma unroll 3
-    for (int p = 0; p < k2; ++p) {
-      const d2 a0 = *reinterpret_cast<const d2*>(x0 + 2 * p), a1 = *reinterpret_cast<const d2*>(x1 + 2 * p);
-      const d2 b0 = *reinterpret_cast<const d2*>(y0 + 2 * p), b1 = *reinterpret_cast<const d2*>(y1 + 2 * p);
-      c00 += a0.x * b0.x + a0.y * b0.y; c01 += a0.x * b1.x + a0.y * b1.y;
-      c10 += a1.x * b0.x + a1.y * b0.y; c11 += a1.x * b1.x + a1.y * b1.y;
-    }
-    if (k & 1) {
-      const int p = k - 1;
-      c00 += x0[p] * y0[p]; c01 += x0[p] * y1[p]; c10 += x1[p] * y0[p]; c11 += x1[p] * y1[p];
-    }
-    double* c = C + 2 * ib + (2 * jb) * ldc;
-    if (accumulate) { c[0] += alpha * c00; c[1] += alpha * c10; c[ldc] += alpha * c01; c[ldc + 1] += alpha * c11; }
-    else { c[0] = alpha * c00; c[1] = alpha * c10; c[ldc] = alpha * c01; c[ldc + 1] = alpha * c11; }
-  }
-}
-
-// Same product with a caller-supplied epilogue: store(r, c, dot) is invoked once per
-// output element, so results can go straight to global memory (no LDS accumulator).
-template <typename Store>
-__device__ __forceinline__ void mmTN22Epi(const double* X, int ldx, const double* Y, int ldy, int m, int n, int k, int tid, int nthreads,
-                                          Store store) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  const int mb = m >> 1, nb = n >> 1, k2 = k >> 1;
-  for (int e = tid; e < mb * nb; e += nthreads) {
-    const int jb = e / mb, ib = e - jb * mb;
-    const double* x0 = X + (2 * ib) * ldx;
-    const double* x1 = x0 + ldx;
-    const double* y0 = Y + (2 * jb) * ldy;
-    const double* y1 = y0 + ldy;
-    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
-#pragma unroll 3
-    for (int p = 0; p < k2; ++p) {
-      const d2 a0 = *reinterpret_cast<const d2*>(x0 + 2 * p), a1 = *reinterpret_cast<const d2*>(x1 + 2 * p);
-      const d2 b0 = *reinterpret_cast<const d2*>(y0 + 2 * p), b1 = *reinterpret_cast<const d2*>(y1 + 2 * p);
-      c00 += a0.x * b0.x + a0.y * b0.y; c01 += a0.x * b1.x + a0.y * b1.y;
-      c10 += a1.x * b0.x + a1.y * b0.y; c11 += a1.x * b1.x + a1.y * b1.y;
-    }
-    if (k & 1) {
-      const int p = k - 1;
-      c00 += x0[p] * y0[p]; c01 += x0[p] * y1[p]; c10 += x1[p] * y0[p]; c11 += x1[p] * y1[p];
-    }
-    store(2 * ib, 2 * jb, c00); store(2 * ib + 1, 2 * jb, c10); store(2 * ib, 2 * jb + 1, c01); store(2 * ib + 1, 2 * jb + 1, c11);
-  }
-}
-
 // ---- 16 x 16 output tiles on the matrix cores ----
-// One tile of C = X^T Y (X: k x m, Y: k x n, both contiguous along the contraction index) per call and wavefront with
-// v_mfma_f64_16x16x4_f64.  FP64 MFMA has the rate of the FP64 vector pipe on CDNA4; what it buys here is operand traffic: a
-// lane reads ONE double of each operand per 16 multiply-adds it contributes to (the 2 x 2 register tiles above read one per
-// multiply-add), and the stage kernels' products are bound by LDS bandwidth, not by FP64 issue.
+// Tiles of C = X^T Y (X: k x m, Y: k x n, both contiguous along the contraction index) with v_mfma_f64_16x16x4_f64.  FP64 MFMA has
+// the rate of the FP64 vector pipe on CDNA4; what it buys here is operand traffic: a lane reads ONE double of each operand per 16
+// multiply-adds it contributes to (2 x 2 register tiles on the vector pipe read one per multiply-add), and the stage kernels'
+// products were bound by LDS bandwidth, not by FP64 issue.
 // Lane map of the instruction (lane = 16 g + li): A[i = li][k = g], B[k = g][j = li], D[i = g + 4 reg][j = li], reg = 0..3.
 // Here A is taken from Y (i = column of C) and B from X (j = row of C), so that the 16 lanes li run along a COLUMN of C, i.e.
 // along contiguous addresses of a column-major result.  Every lane reads two consecutive k's (16 B) per step and feeds them to
 // two instructions (the sum over k does not care which k's share an instruction).  xr / yc = number of valid rows / columns of
 // the tile (lanes beyond re-read the last valid one; their results are never stored), k is masked against KMAX's padding.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-template <int KMAX>
-__device__ __forceinline__ mfma_d4 mfmaTileTN(const double* X, int ldx, int xr, const double* Y, int ldy, int yc, int k, int lane) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  constexpr int KS = (KMAX + 7) / 8;
-  const int li = lane & 15, g = lane >> 4;
-  const double* xp = X + ldx * (li < xr ? li : xr - 1) + 2 * g;
-  const double* yp = Y + ldy * (li < yc ? li : yc - 1) + 2 * g;
-  d2 xa[KS], ya[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) { xa[s] = *reinterpret_cast<const d2*>(xp + 8 * s); ya[s] = *reinterpret_cast<const d2*>(yp + 8 * s); }
-  mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int kk = 8 * s + 2 * g;
-    const bool v0 = kk < k, v1 = kk + 1 < k;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0 ? ya[s].x : 0.0, v0 ? xa[s].x : 0.0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1 ? ya[s].y : 0.0, v1 ? xa[s].y : 0.0, acc, 0, 0, 0);
-  }
-  return acc;
-}
 // Two tiles at once: the operand reads of both are issued before the first multiply, and the two accumulation chains alternate on
 // the matrix core (a chain of dependent 16-pass instructions alone leaves it idle between them).
 template <int KMAX>
@@ -616,25 +464,6 @@ __device__ __forceinline__ void mfmaTilePairTN(const double* X0, int xr0, const 
   }
 }
 
-// The same tile with operands that are NOT contiguous along k (or whose layout differs from lane to lane): every lane passes the
-// address of entry k = 0 of ITS row of C in the left operand (xp, stride xs between consecutive k) and of ITS column index li of the
-// right operand (yp, ys); 8-byte reads, one instruction per four k's.  Result as above: lane (li, g), register q holds C(li, g + 4 q).
-template <int K>
-__device__ __forceinline__ mfma_d4 mfmaTileStrided(const double* xp, int xs, const double* yp, int ys, int lane) {
-  constexpr int KS = (K + 3) / 4;
-  const int g = lane >> 4;
-  double xa[KS], ya[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int k = 4 * s + g, kc = (4 * s + 3 < K) ? k : (k < K ? k : K - 1);
-    xa[s] = xp[xs * kc]; ya[s] = yp[ys * kc];
-    if (4 * s + 3 >= K && k >= K) { xa[s] = 0.0; ya[s] = 0.0; }
-  }
-  mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s], xa[s], acc, 0, 0, 0);
-  return acc;
-}
 // store(r, c, value) for the elements of a tile at (r0, c0) that lie inside m x n
 template <typename Store>
 __device__ __forceinline__ void mfmaTileStore(const mfma_d4& acc, int r0, int c0, int m, int n, int lane, Store store) {
@@ -645,18 +474,6 @@ __device__ __forceinline__ void mfmaTileStore(const mfma_d4& acc, int r0, int c0
     if (r < m && c < n) store(r, c, acc[q]);
   }
 }
-// C = X^T Y, tiles dealt round-robin to the wavefronts of the workgroup
-template <int KMAX, typename Store>
-__device__ __forceinline__ void mmTNmfma(const double* X, int ldx, const double* Y, int ldy, int m, int n, int k, int tid, int nthreads, Store store) {
-  const int wave = tid >> 6, nw = nthreads >> 6, lane = tid & 63;
-  const int mt = (m + 15) >> 4, nt = (n + 15) >> 4;
-  for (int e = wave; e < mt * nt; e += nw) {
-    const int jb = e / mt, ib = e - jb * mt;
-    const mfma_d4 acc = mfmaTileTN<KMAX>(X + ldx * 16 * ib, ldx, m - 16 * ib, Y + ldy * 16 * jb, ldy, n - 16 * jb, k, lane);
-    mfmaTileStore(acc, 16 * ib, 16 * jb, m, n, lane, store);
-  }
-}
-
 // ---- 3 x 3 register tiles ----
 // K9b / K9g keep every matrix it factorises or multiplies as 3 x 3 tiles in registers, thread (bi, bj) owning rows 3 bi .. 3 bi + 2 and
 // columns 3 bj .. 3 bj + 2: an inner-product step is 6 LDS reads for 9 multiply-adds, a Gauss-Jordan pivot step shares only the
@@ -723,23 +540,6 @@ __device__ __forceinline__ void gaussJordanTiles(double (&a)[3][3], const bool a
             a[r][c] = ik ? (jk ? ip : rj[c] * ip) : (jk ? -ci[r] * ip : a[r][c] - ci[r] * rj[c] * ip);
           }
       }
-    }
-  }
-}
-
-// Solve L L^T X = Bm for nrhs columns, one thread per right-hand side (in place).
-__device__ __forceinline__ void choleskySolve(const double* Lm, int ld, int n, double* X, int ldx, int nrhs, int tid, int nthreads) {
-  for (int c = tid; c < nrhs; c += nthreads) {
-    double* x = X + c * ldx;
-    for (int i = 0; i < n; ++i) {
-      double t = x[i];
-      for (int p = 0; p < i; ++p) t -= Lm[i + p * ld] * x[p];
-      x[i] = t / Lm[i + i * ld];
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double t = x[i];
-      for (int p = i + 1; p < n; ++p) t -= Lm[p + i * ld] * x[p];
-      x[i] = t / Lm[i + i * ld];
     }
   }
 }

@@ -43,13 +43,6 @@ __device__ __forceinline__ bool ocpRowValid(const OcpProblem* __restrict__ P, in
   if (comp < 6) return P->use_u_limits != 0;
   return P->use_friction_cone != 0;
 }
-// LinearizedFrictionCone: g(f) = Jc f (linearized_friction_cone.cpp:25-29, .hpp:72-84)
-__device__ __forceinline__ double frictionJacEntry(double mu, int r, int x) {
-  const double m2 = mu * 0.70710678118654752440;
-  if (x == 2) return r == 0 ? -1.0 : -m2;
-  if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
-  return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
-}
 
 // SFP: number of contact rows the LDS blocks are laid out for (= leading dimension of J, Qff, BL, SM; NV + SFP for the
 // (a, f)-sized blocks).  D::NF in general; the instantiations with a compile-time contact count use that count, which

@@ -34,12 +34,6 @@ __device__ __forceinline__ bool ocpRowValid2(const OcpProblem* __restrict__ P, i
   if (comp < 6) return P->use_u_limits != 0;
   return P->use_friction_cone != 0;
 }
-__device__ __forceinline__ double frictionJacEntry2(double mu, int r, int x) {
-  const double m2 = mu * 0.70710678118654752440;
-  if (x == 2) return r == 0 ? -1.0 : -m2;
-  if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
-  return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
-}
 __device__ __forceinline__ double f2b(double rate, double x, double dx, double cur) {
   const double f = -rate * (x / dx);
   return (f > 0.0 && f < 1.0 && f < cur) ? f : cur;

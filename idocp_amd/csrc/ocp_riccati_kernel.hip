@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     const bool stamp = tid == 0 && b == (gridDim.x > 7 ? 7 : 0) && i == M / 2 && B.prof != nullptr;
 #define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
     RSTAMP(0);
-    // The matrix products of a stage run as 16 x 16 tiles on the matrix cores (mfmaTileStrided, dev_dense.hpp), a tile per
+    // The matrix products of a stage run as 16 x 16 tiles on the matrix cores (riccatiPhase1 .. 5 above), a tile per
     // wavefront and round, with the structured part of the dynamics (A = [Fqq Fqv; Fvq Fvv], Fqq = diag(Fqq6, I), Fqv = diag(Fqv6, dt I))
     // added in the epilogue of the tile:
     //   phase 1 (9 tiles):  W = [A^T P; B^T P] = [Fvq Fvv Fvu]^T P(v, :)  +  [Fqq Fqv 0]^T P(q, :)

@@ -29,13 +29,6 @@ namespace idocp_dev {
 
 namespace {
 
-// LinearizedImpulseFrictionCone: same cone as LinearizedFrictionCone (linearized_friction_cone.cpp:25-29)
-__device__ __forceinline__ double coneJac(double mu, int r, int x) {
-  const double m2 = mu * 0.70710678118654752440;
-  if (x == 2) return r == 0 ? -1.0 : -m2;
-  if (x == 0) return r == 1 ? 1.0 : (r == 2 ? -1.0 : 0.0);
-  return r == 3 ? 1.0 : (r == 4 ? -1.0 : 0.0);
-}
 
 }  // namespace
 
