@@ -22,6 +22,8 @@
 
 namespace idocp_dev {
 
+typedef double rd2 __attribute__((ext_vector_type(2)));      // 16-byte pair
+
 template <typename D>
 struct RiccatiSmem {
   static constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF;
@@ -349,8 +351,10 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     //   phase 4 (3 tiles):  GK = Quu K            phase 5 (6 tiles):  P = F - K^T GK, upper block triangle, mirrored
     // P and F are symmetric; computing the tiles above the diagonal and mirroring them replaces the reference's P = (P + P^T) / 2
     // (backward_riccati_recursion_factorizer.hxx:133-135).
-    constexpr int PF = (SL + NT - 1) / NT, T1 = 9, T2 = 6, T2W = (T2 + NW - 1) / NW;
-    double pre[PF], qxx[T2W][4];
+    constexpr int PF = (SL / 2 + NT - 1) / NT, T1 = 9, T2 = 6, T2W = (T2 + NW - 1) / NW;      // the next record travels as 16-byte pairs
+    static_assert(SL % 2 == 0 && KO % 2 == 0 && S::STAGE % 2 == 0 && L::KKT % 2 == 0, "16-byte loads of the stage record");
+    rd2 pre[PF];
+    double qxx[T2W][4];
     auto loadQxx = [&]() {
       // Qxx of THIS stage is consumed once per element in phase 2: straight to the registers of the lane that adds it
       const double* __restrict__ kc = B.kkt + rec * L::KKT;
@@ -392,12 +396,15 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     // (P_{i+1} is only read through W here).
     RSTAMP(11);
     if (tid >= NT - 64 && lane < 4 * NU) {
-      // lu += (B^T P) Fx - Fvu^T sv: four lanes per row, nine + five terms each
+      // lu += (B^T P) Fx - Fvu^T sv: four lanes per row (10 | 8 | 10 | 8 and 5 | 5 | 4 | 4 terms), 16-byte LDS reads
       const int j = lane >> 2, part = lane & 3;
-      const double* wj = Wt + LDW * (NX + j) + (NX / 4) * part;              // row j of B^T P
+      const int c0 = (part >> 1) * (NX / 2) + (part & 1) * 10, nc2 = (part & 1) ? 4 : 5;      // first column, pairs of columns
+      static_assert(NX == 36 && LDW % 2 == 0, "column split of the lu rows");
+      const rd2* wj = reinterpret_cast<const rd2*>(Wt + LDW * (NX + j) + c0);                 // row j of B^T P
+      const rd2* fx = reinterpret_cast<const rd2*>(Fx + c0);
       double acc = 0.0;
 #pragma unroll
-      for (int c = 0; c < NX / 4; ++c) acc += wj[c] * Fx[(NX / 4) * part + c];
+      for (int c = 0; c < 5; ++c) if (c < nc2) { const rd2 w = wj[c], f = fx[c]; acc += w.x * f.x + w.y * f.y; }
 #pragma unroll
       for (int t = 0; t < (NV + 3) / 4; ++t) { const int m = part + 4 * t; if (m < NV) acc -= Fvu[m + NV * j] * sm[S::SV + m]; }
       acc += __shfl_xor(acc, 1);
@@ -410,8 +417,11 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
       const bool isv = row >= NV;
       const int r = isv ? row - NV : row;
       const double* F6 = isv ? Fqv6 : Fqq6;
-      const double* Fm = isv ? Fvv : Fvq;
-      const double* wr = Wt + LDW * row;                                    // row of A^T P
+      const rd2* Fm = reinterpret_cast<const rd2*>((isv ? Fvv : Fvq) + NV * r);
+      const rd2* wr = reinterpret_cast<const rd2*>(Wt + LDW * row);                            // row of A^T P
+      const rd2* svp = reinterpret_cast<const rd2*>(&sm[S::SV]);
+      const rd2* fx = reinterpret_cast<const rd2*>(Fx);
+      static_assert(NV % 2 == 0 && S::SV % 2 == 0 && (L::K_FX - KO) % 2 == 0 && (L::K_FVQ - KO) % 2 == 0, "16-byte reads of the vector terms");
       double acc;
       if (r < 6) {
         acc = 0.0;
@@ -420,12 +430,16 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
       } else {
         acc = isv ? dt * sm[S::SQ + r] : sm[S::SQ + r];
       }
-      double a2 = 0.0;
+      double a2 = 0.0, a3 = 0.0;
 #pragma unroll
-      for (int m = 0; m < NV; ++m) acc += Fm[m + NV * r] * sm[S::SV + m];
+      for (int m = 0; m < NV / 2; ++m) { const rd2 f = Fm[m], sv2 = svp[m]; acc += f.x * sv2.x + f.y * sv2.y; }
 #pragma unroll
-      for (int c = 0; c < NX; ++c) a2 += wr[c] * Fx[c];
-      sm[(isv ? S::SVN : S::SQN) + r] = acc - a2 - lx[row];
+      for (int c = 0; c < NX / 2; c += 2) {
+        const rd2 w0 = wr[c], f0 = fx[c], w1 = wr[c + 1], f1 = fx[c + 1];
+        a2 += w0.x * f0.x + w0.y * f0.y;
+        a3 += w1.x * f1.x + w1.y * f1.y;
+      }
+      sm[(isv ? S::SVN : S::SQN) + r] = acc - (a2 + a3) - lx[row];
     };
     if (NW == 1 && tid < NX) sPart1(tid);
     RSTAMP(12);
@@ -434,9 +448,9 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     // software pipeline: the record of stage i was staged into LDS at the end of the previous iteration; the global loads of
     // stage i - 1 are issued here (factorisation, phases 4 and 5 ahead of them) and parked in registers
     if (i > 0) {
-      const double* __restrict__ kn = B.kkt + (base + nodes[i - 1].slot) * L::KKT + KO;
+      const rd2* __restrict__ kn = reinterpret_cast<const rd2*>(B.kkt + (base + nodes[i - 1].slot) * L::KKT + KO);
 #pragma unroll
-      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; pre[t] = (e < SL) ? kn[e] : 0.0; }
+      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; pre[t] = kn[e < SL / 2 ? e : SL / 2 - 1]; }
     }
     RSTAMP(9);
     // Quu = L L^T and the solves K = -Quu^-1 Qxu^T, k = -Quu^-1 lu in the registers of one wavefront, one right-hand side per lane
@@ -601,9 +615,9 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     RSTAMP(7);
     double* __restrict__ rr = B.ric + rec * L::RIC;
     double* __restrict__ gg = B.gain + rec * L::GAIN;
-    for (int e = tid; e < NN; e += nt) {
-      double pqq = Pqq[e], pqv = Pqv[e], pvv = Pvv[e];
-      if (HYBRID && dimi > 0) {
+    static_assert(S::PQQ == 0 && L::R_PQQ == 0 && L::R_PQV == NN && L::R_PVV == 2 * NN && NN % 2 == 0 && L::RIC % 2 == 0, "P is one contiguous copy");
+    if (HYBRID && dimi > 0) {
+      for (int e = tid; e < NN; e += nt) {
         // P -= K^T D^T M + (K^T D^T M)^T, block by block (split_riccati_factorizer.hxx:88-97)
         const int c = e / NV, r = e - c * NV;
         double aqq = 0.0, aqv = 0.0, avv = 0.0;
@@ -614,10 +628,12 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
           aqv += kqr * dvc + kvc * dqr;
           avv += kvr * dvc + kvc * dvr;
         }
-        pqq -= aqq; pqv -= aqv; pvv -= avv;
+        const double pqq = Pqq[e] - aqq, pqv = Pqv[e] - aqv, pvv = Pvv[e] - avv;
         Pqq[e] = pqq; Pqv[e] = pqv; Pvv[e] = pvv;
+        rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
       }
-      rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
+    } else {
+      for (int e = tid; e < 3 * NN / 2; e += nt) reinterpret_cast<rd2*>(rr)[e] = reinterpret_cast<const rd2*>(Pqq)[e];
     }
     if (tid < NV) {
       double sq = sm[S::SQN + tid], sv = sm[S::SVN + tid];
@@ -625,12 +641,13 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
       sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
       rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }
-    for (int e = tid; e < NU * NX; e += nt) gg[L::G_K + e] = sm[S::KM + e];
+    static_assert(S::KM % 2 == 0 && L::G_K == 0 && (NU * NX) % 2 == 0 && L::GAIN % 2 == 0, "K is one contiguous copy");
+    for (int e = tid; e < NU * NX / 2; e += nt) reinterpret_cast<rd2*>(gg)[e] = reinterpret_cast<const rd2*>(&sm[S::KM])[e];
     if (tid < NU) gg[L::G_k + tid] = sm[S::KV + tid];
     // nothing above reads the stage copy any more: stage i - 1 moves from the registers into LDS
     if (i > 0) {
 #pragma unroll
-      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; if (e < SL) st[e] = pre[t]; }
+      for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; if (e < SL / 2) reinterpret_cast<rd2*>(st)[e] = pre[t]; }
     }
     __syncthreads();
     RSTAMP(8);
