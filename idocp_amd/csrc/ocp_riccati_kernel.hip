@@ -76,7 +76,9 @@ __device__ __forceinline__ void mfmaLoadOp(double (&o)[(K + 3) / 4], const doubl
 // phase 1: W = [A^T P; B^T P], tile t = 3 ib + cb covers rows 16 ib .. of W and columns 16 cb .. of P
 // (mid() runs between the k-steps and the epilogues: the place where the operand registers are free again -- the caller issues
 // the global loads of phase 2 there)
-template <typename D, int TB, int TE, typename Mid>
+// WIDE (one wavefront per instance, 512 registers): the part of an epilogue that does not depend on the accumulators is computed
+// in the same scheduling region as the k-steps, i.e. while the matrix core works; otherwise one epilogue at a time behind them.
+template <typename D, bool WIDE, int TB, int TE, typename Mid>
 __device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* Pqv, const double* Pvv, const double* Fall, const double* Fqq6,
                                               const double* Fqv6, double dt, double* Wt, int lane, Mid mid) {
   constexpr int NV = D::NV, NX = D::NX, KS = (NV + 3) / 4, LDW = RiccatiSmem<D>::LDW, NTL = TE - TB;
@@ -91,6 +93,36 @@ __device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* P
       }
       if (tilesUseDiv3(TB, TE, v)) mfmaLoadOp<NV>(yo[v], Fall + NV * (16 * v + li), 1, lane);
     }
+    // the structured part of tile j, register q: rows outside the 6 x 6 base blocks of Fqq / Fqv are one term (P(q,:) or dt P(q,:)),
+    // the others a 6-term dot; which (tile, register) pairs meet a base block is known at compile time
+    auto structured = [&](int j, int q) -> double {
+      const int cb = (TB + j) % 3, ib = (TB + j) / 3;
+      const int c = 16 * cb + li, cc = c < NX ? c : NX - 1;
+      const double* pq = cc < NV ? Pqq + NV * cc : Pqv + NV * (cc - NV);          // P(q, c)
+      const int lo = 16 * ib + 4 * q, r = lo + g;                                // rows lo .. lo + 3 of W over the four lane groups
+      if (lo >= NX) return 0.0;
+      const int lo6 = lo < NV ? lo : lo - NV;                                   // (a group of four never straddles NV = 18: 16 | 20)
+      const bool isv = r >= NV;
+      const int rr6 = isv ? r - NV : r;
+      const bool any6 = lo6 < 6 || (lo < NV && lo + 3 >= NV), all6 = lo6 + 3 < 6 && !(lo < NV && lo + 3 >= NV);
+      double dot6 = 0.0;
+      if (any6) {
+        const double* F6 = (isv ? Fqv6 : Fqq6) + 6 * (rr6 < 6 ? rr6 : 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) dot6 += F6[m] * pq[m];
+      }
+      if (all6) return dot6;
+      const double direct = (isv ? dt : 1.0) * pq[rr6 < NV ? rr6 : 0];
+      return (any6 && rr6 < 6) ? dot6 : direct;
+    };
+    constexpr bool EARLY = false;      // (measured with WIDE: nine tiles' worth of early terms push the factorisation's registers into AGPRs)
+    double extra[EARLY ? NTL : 1][4];
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) extra[j][q] = structured(j, q);
+    }
     mfma_d4 acc[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
@@ -103,33 +135,15 @@ __device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* P
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-      __builtin_amdgcn_sched_barrier(0);              // one epilogue at a time: hoisted together their LDS reads overflow the registers
+      __builtin_amdgcn_sched_barrier(0);      // one epilogue at a time: hoisted together their LDS reads overflow the registers
       const int cb = (TB + j) % 3, ib = (TB + j) / 3;
-      const int c = 16 * cb + li, cc = c < NX ? c : NX - 1;
-      const double* pq = cc < NV ? Pqq + NV * cc : Pqv + NV * (cc - NV);          // P(q, c)
+      const int c = 16 * cb + li;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        // rows lo .. lo + 3 of W over the four lane groups; which of them meet the 6 x 6 base blocks of Fqq / Fqv is known at compile time
-        const int lo = 16 * ib + 4 * q, r = lo + g;
-        double val = acc[j][q];
-        if (lo < NX) {
-          const int lo6 = lo < NV ? lo : lo - NV;                               // (a group of four never straddles NV = 18: 16 | 20)
-          const bool isv = r >= NV;
-          const int rr6 = isv ? r - NV : r;
-          const bool any6 = lo6 < 6 || (lo < NV && lo + 3 >= NV), all6 = lo6 + 3 < 6 && !(lo < NV && lo + 3 >= NV);
-          double dot6 = 0.0;
-          if (any6) {
-            const double* F6 = (isv ? Fqv6 : Fqq6) + 6 * (rr6 < 6 ? rr6 : 0);
-#pragma unroll
-            for (int m = 0; m < 6; ++m) dot6 += F6[m] * pq[m];
-          }
-          if (all6) val += dot6;
-          else {
-            const double direct = (isv ? dt : 1.0) * pq[rr6 < NV ? rr6 : 0];
-            val += (any6 && rr6 < 6) ? dot6 : direct;
-          }
-        }
-        if (c < NX) Wt[c + LDW * r] = val;
+        const int r = 16 * ib + 4 * q + g;
+        double sx;
+        if constexpr (EARLY) sx = extra[j][q]; else sx = structured(j, q);
+        if (c < NX) Wt[c + LDW * r] = acc[j][q] + sx;
       }
     }
   } else {
@@ -138,7 +152,7 @@ __device__ __forceinline__ void riccatiPhase1(const double* Pqq, const double* P
 }
 
 // phase 2: [F H; . G] on the upper block triangle, tile t -> (upperIb, upperJb); qxx[j][q]: Qxx entry of local tile j, register q
-template <typename D, int TB, int TE, int T2W>
+template <typename D, bool WIDE, int TB, int TE, int T2W>
 __device__ __forceinline__ void riccatiPhase2(const double* Wt, const double* Fall, const double* Fqq6, const double* Fqv6, double dt,
                                               const double (&qxx)[T2W][4], double* Pqq, double* Pqv, double* Pvv, double* Qxu, double* Quu,
                                               int lane) {
@@ -152,6 +166,32 @@ __device__ __forceinline__ void riccatiPhase2(const double* Wt, const double* Fa
       if (tilesUseUpperIb(TB, TE, v)) mfmaLoadOp<NV>(xo[v], Wt + LDW * (16 * v + li) + NV, 1, lane);
       if (tilesUseUpperJb(TB, TE, v)) mfmaLoadOp<NV>(yo[v], Fall + NV * (16 * v + li), 1, lane);
     }
+    // the structured part of tile j, register q (see riccatiPhase1): W(:, q) [Fqq Fqv 0]
+    auto structured = [&](int j, int q) -> double {
+      const int ib = upperIb(TB + j), jb = upperJb(TB + j);
+      const double* wr = Wt + LDW * (16 * ib + li);
+      const int lo = 16 * jb + 4 * q, c = lo + g;                               // columns lo .. lo + 3 over the four lane groups
+      if (lo >= NX) return 0.0;
+      const bool isv = c >= NV;
+      const int c6 = isv ? c - NV : c, lo6 = lo < NV ? lo : lo - NV;
+      const bool any6 = lo6 < 6 || (lo < NV && lo + 3 >= NV), all6 = lo6 + 3 < 6 && !(lo < NV && lo + 3 >= NV);
+      double dot6 = 0.0;
+      if (any6) {
+        const double* F6 = (isv ? Fqv6 : Fqq6) + 6 * (c6 < 6 ? c6 : 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) dot6 += wr[m] * F6[m];
+      }
+      if (all6) return dot6;
+      const double direct = (isv ? dt : 1.0) * wr[c6 < NV ? c6 : 0];
+      return (any6 && c6 < 6) ? dot6 : direct;
+    };
+    double extra[WIDE ? NTL : 1][4];
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) extra[j][q] = structured(j, q) + qxx[j][q];
+    }
     mfma_d4 acc[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
@@ -161,30 +201,14 @@ __device__ __forceinline__ void riccatiPhase2(const double* Wt, const double* Fa
       for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[upperJb(TB + j)][s], xo[upperIb(TB + j)][s], acc[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!WIDE) __builtin_amdgcn_sched_barrier(0);
       const int ib = upperIb(TB + j), jb = upperJb(TB + j);
       const int r = 16 * ib + li;                                             // row of [F H; . G]
-      const double* wr = Wt + LDW * r;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int lo = 16 * jb + 4 * q, c = lo + g;                             // columns lo .. lo + 3 over the four lane groups
-        double val = acc[j][q] + qxx[j][q];
-        if (lo < NX) {
-          const bool isv = c >= NV;
-          const int c6 = isv ? c - NV : c, lo6 = lo < NV ? lo : lo - NV;
-          const bool any6 = lo6 < 6 || (lo < NV && lo + 3 >= NV), all6 = lo6 + 3 < 6 && !(lo < NV && lo + 3 >= NV);
-          double dot6 = 0.0;
-          if (any6) {
-            const double* F6 = (isv ? Fqv6 : Fqq6) + 6 * (c6 < 6 ? c6 : 0);
-#pragma unroll
-            for (int m = 0; m < 6; ++m) dot6 += wr[m] * F6[m];
-          }
-          if (all6) val += dot6;
-          else {
-            const double direct = (isv ? dt : 1.0) * wr[c6 < NV ? c6 : 0];
-            val += (any6 && c6 < 6) ? dot6 : direct;
-          }
-        }
+        const int lo = 16 * jb + 4 * q, c = lo + g;
+        double val;
+        if constexpr (WIDE) val = acc[j][q] + extra[j][q]; else val = acc[j][q] + qxx[j][q] + structured(j, q);
         // Only the entries on and above the diagonal are used and mirrored (also inside the diagonal tiles): P stays EXACTLY
         // symmetric.  An antisymmetric rounding residue would not be damped by the feedback term and grows with the open-loop
         // dynamics from stage to stage (measured: 2.9 x per stage) -- the reason for the reference's (P + P^T) / 2.
@@ -205,7 +229,7 @@ __device__ __forceinline__ void riccatiPhase2(const double* Wt, const double* Fa
 }
 
 // phase 4: GK = Quu K, tile t covers the columns 16 t .. of K
-template <typename D, int TB, int TE>
+template <typename D, bool WIDE, int TB, int TE>
 __device__ __forceinline__ void riccatiPhase4(const double* Quu, const double* KM, double* GK, int lane) {
   constexpr int NX = D::NX, NU = D::NU, KS = (NU + 3) / 4, NTL = TE - TB;
   if constexpr (NTL > 0) {
@@ -235,7 +259,7 @@ __device__ __forceinline__ void riccatiPhase4(const double* Quu, const double* K
 // stage without a switching constraint), GK IS -H^T up to the residual of a backward-stable solve (|G K + H^T| ~ eps |G| |K|, not
 // amplified by the condition of G), so the product Quu K (phase 4, one more barrier) is skipped and Y = -Qxu^T is read in place:
 // entry (j, c) of Y at Y + ycs c + yks j, sign = +1 for GK, -1 for Qxu^T.
-template <typename D, int TB, int TE>
+template <typename D, bool WIDE, int TB, int TE>
 __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y, int ycs, int yks, double sign, double* Pqq, double* Pqv,
                                               double* Pvv, int lane) {
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, KS = (NU + 3) / 4, NTL = TE - TB;
@@ -257,7 +281,7 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y,
       for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[upperJb(TB + j)][s], xo[upperIb(TB + j)][s], acc[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!WIDE) __builtin_amdgcn_sched_barrier(0);
       const int r = 16 * upperIb(TB + j) + li;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -277,15 +301,15 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y,
 // the wavefront's share of a phase: FN<D, tile range of wave w>(args)
 #define RICCATI_TILES(FN, NTILES, ...)                                                                                                 \
   do {                                                                                                                                 \
-    if constexpr (NW == 1) { FN<D, 0, NTILES>(__VA_ARGS__); }                                                                          \
+    if constexpr (NW == 1) { FN<D, true, 0, NTILES>(__VA_ARGS__); }                                                                          \
     else if constexpr (NW == 2) {                                                                                                      \
-      if (wave == 0) FN<D, tileBegin(NTILES, 0, 2), tileBegin(NTILES, 1, 2)>(__VA_ARGS__);                                            \
-      else FN<D, tileBegin(NTILES, 1, 2), tileBegin(NTILES, 2, 2)>(__VA_ARGS__);                                                      \
+      if (wave == 0) FN<D, false, tileBegin(NTILES, 0, 2), tileBegin(NTILES, 1, 2)>(__VA_ARGS__);                                            \
+      else FN<D, false, tileBegin(NTILES, 1, 2), tileBegin(NTILES, 2, 2)>(__VA_ARGS__);                                                      \
     } else {                                                                                                                           \
-      if (wave == 0) FN<D, tileBegin(NTILES, 0, 4), tileBegin(NTILES, 1, 4)>(__VA_ARGS__);                                            \
-      else if (wave == 1) FN<D, tileBegin(NTILES, 1, 4), tileBegin(NTILES, 2, 4)>(__VA_ARGS__);                                       \
-      else if (wave == 2) FN<D, tileBegin(NTILES, 2, 4), tileBegin(NTILES, 3, 4)>(__VA_ARGS__);                                       \
-      else FN<D, tileBegin(NTILES, 3, 4), tileBegin(NTILES, 4, 4)>(__VA_ARGS__);                                                      \
+      if (wave == 0) FN<D, false, tileBegin(NTILES, 0, 4), tileBegin(NTILES, 1, 4)>(__VA_ARGS__);                                            \
+      else if (wave == 1) FN<D, false, tileBegin(NTILES, 1, 4), tileBegin(NTILES, 2, 4)>(__VA_ARGS__);                                       \
+      else if (wave == 2) FN<D, false, tileBegin(NTILES, 2, 4), tileBegin(NTILES, 3, 4)>(__VA_ARGS__);                                       \
+      else FN<D, false, tileBegin(NTILES, 3, 4), tileBegin(NTILES, 4, 4)>(__VA_ARGS__);                                                      \
     }                                                                                                                                  \
   } while (0)
 
