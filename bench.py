@@ -347,7 +347,7 @@ def run_parnmpc(args, rank, local_rank, world, dist):
                          "avg_launch_ms": ker[dom],
                          "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
         }
-        if not args.no_cpu_baseline and not trot:
+        if not args.no_cpu_baseline and not trot and world == 1:
             o = OracleParNMPC(model, cost, cons, T, N)
             o.set_contact_status([1, 1, 1, 1], pts)
             o.set_solution("q", ANYMAL_Q_STANDING)
@@ -583,7 +583,7 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_ms": ker[dom],
                                "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             from helpers import OracleParNMPC      # the CPU restatement: checker / baseline only
             o = OracleParNMPC(model, cost, cons, T, N)
             o.set_contact_status([1, 1, 1, 1], pts)
@@ -862,7 +862,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kms[dom]),
                          "whole_step_frac": a_stage * B * (N + 1) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # a reported baseline: rank 0 of the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts, nimp=nimp)
         print(json.dumps(out), flush=True)
     if dist is not None:
