@@ -209,7 +209,7 @@ def test_clone_is_a_deep_copy_of_the_solver_state():
     assert np.array_equal(g.kkt_error(0.0, q, v), c.kkt_error(0.0, q, v))
 
 
-def _ls_pair(N, T, nimp, batch=2):
+def _ls_pair(N, T, nimp, batch=2, cone="linearized"):
     import ctypes as C
     from helpers import oracle, trotting_sequence
     lib_o = oracle()
@@ -217,7 +217,7 @@ def _ls_pair(N, T, nimp, batch=2):
     lib_o.oracle_ocp_compute_direction.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
     lib_o.oracle_ocp_update_solution_ls.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
     m = anymal_model()
-    cost, cons = anymal_problem(m, trotting_ref=True)
+    cost, cons = anymal_problem(m, trotting_ref=True, cone=cone)
     o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1 if nimp else 0)
     g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1 if nimp else 0)
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
@@ -234,12 +234,13 @@ def _ls_pair(N, T, nimp, batch=2):
     return lib_o, m, o, g, q, v
 
 
+@pytest.mark.parametrize("cone", ["linearized", "nonlinear"])
 @pytest.mark.parametrize("N,T,nimp", [(20, 1.0, 0), (31, 1.55, 2)])
-def test_line_search_cost_and_violation_parity(N, T, nimp):
+def test_line_search_cost_and_violation_parity(N, T, nimp, cone):
     """Floating-base filter line search (src/line_search/line_search.cpp:63-196): total cost and l1 constraint violation of the
     trial iterates s (+) alpha d against the oracle, on an event-free horizon and on the trotting chain (impulse / aux / lift
     stages, switching constraints, the reference's pairing of the stages in front of an event)."""
-    lib_o, m, o, g, q, v = _ls_pair(N, T, nimp)
+    lib_o, m, o, g, q, v = _ls_pair(N, T, nimp, cone=cone)          # (nonlinear: FrictionCone / ImpulseFrictionCone rows in the barrier and the violation)
     assert lib_o.oracle_ocp_compute_direction(o.h, 0.0, P(q), P(v)) == 0
     capi.check(g.lib.idocp_ocp_compute_direction(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv))), "compute_direction")
     ap, ad = g.step_sizes()
