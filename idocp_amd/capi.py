@@ -164,6 +164,8 @@ def _proto(lib):
     lib.idocp_parnmpc_init_backward_correction.restype = ci
     lib.idocp_parnmpc_update_solution.argtypes = [vp, cd, vp, vp, ci]
     lib.idocp_parnmpc_update_solution.restype = ci
+    lib.idocp_parnmpc_compute_direction.argtypes = [vp, cd, vp, vp]
+    lib.idocp_parnmpc_compute_direction.restype = ci
     lib.idocp_parnmpc_update_solution_device.argtypes = [vp, cd, vp, vp]
     lib.idocp_parnmpc_update_solution_device.restype = ci
     lib.idocp_parnmpc_launch_phase.argtypes = [vp, ci, vp, vp]

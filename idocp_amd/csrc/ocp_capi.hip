@@ -973,15 +973,29 @@ void* idocp_ocp_stream(idocp_ocp_t* h) { return h ? (void*)h->stream : nullptr; 
 // LineSearch::computeCostAndViolation (src/line_search/line_search.cpp:63-196) of s (+) alpha[b] d for every instance: trial
 // iterate + barrier cost (ocp_trial_kernel), then the rigid-body residual kernels and the MERIT variant of the condensation
 // kernel on a copy of the buffers whose `sol` is the trial iterate, then the sums over the chain.  out[2 b] = cost, [2 b + 1] = violation.
+// The filter line search of ParNMPCSolver is carried for event-free horizons on one shard (LineSearch::computeCostAndViolation of a
+// horizon with events pairs aux / lift stages with grid stages in its own way, src/line_search/line_search.cpp:238-301: not restated).
+static int parnmpcLineSearchSupported(const idocp_ocp_t* h) {
+  for (const OcpNode& nd : h->chain)
+    if (nd.kind != 0 && nd.kind != 4) { set_last_error("line_search=true on a ParNMPC horizon with discrete events is not supported by the HIP path"); return IDOCP_E_UNSUPPORTED; }
+  if (h->has_prev || !h->has_terminal) { set_last_error("line_search=true on a shard of a ParNMPC horizon is not supported by the HIP path"); return IDOCP_E_UNSUPPORTED; }
+  return IDOCP_OK;
+}
 static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, const double* d_q, std::vector<double>& out) {
   const int M = h->M();
   HIP_TRY(hipMemcpyAsync(h->B.ls_alpha, alpha.data(), sizeof(double) * h->batch, hipMemcpyHostToDevice, h->stream));
   OcpLaunch<DQ>::trialIterate(h->B, h->batch, M, h->stream);
   OcpBuffers Bt = h->B;
-  Bt.sol = h->B.sol_try; Bt.nodes = h->B.nodes_ls;
-  OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);
-  if (h->has_switch) OcpLaunch<DQ>::switching(Bt, h->batch, M, h->stream);
-  OcpLaunch<DQ>::merit(Bt, h->batch, M, d_q, h->stream);
+  Bt.sol = h->B.sol_try;
+  if (h->parnmpc) {
+    // ParNMPC, event-free horizon: backward-Euler stages against the trial predecessor (the measured state in front of stage 0)
+    OcpLaunch<DQ>::meritBackwardEuler(Bt, h->batch, M, d_q, h->d_v0, h->stream);
+  } else {
+    Bt.nodes = h->B.nodes_ls;
+    OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);
+    if (h->has_switch) OcpLaunch<DQ>::switching(Bt, h->batch, M, h->stream);
+    OcpLaunch<DQ>::merit(Bt, h->batch, M, d_q, h->stream);
+  }
   OcpLaunch<DQ>::meritReduce(h->B, h->batch, h->stream);
   HIP_TRY(hipGetLastError());
   out.resize((size_t)h->batch * 2);
@@ -1055,8 +1069,8 @@ int idocp_ocp_compute_direction(idocp_ocp_t* h, double t, const double* q, const
 // (total cost, total constraint violation) of s (+) alpha[b] d for every instance (alpha = 0: the iterate itself, current slacks)
 int idocp_ocp_line_search_eval(idocp_ocp_t* h, const double* alpha, double* cost, double* violation) {
   if (!h || !alpha || !cost || !violation) return IDOCP_E_ARG;
-  if (h->parnmpc) { set_last_error("idocp_ocp_line_search_eval: OCPSolver handles only"); return IDOCP_E_UNSUPPORTED; }
   int rc = setDev(h); if (rc) return rc;
+  if (h->parnmpc && (rc = parnmpcLineSearchSupported(h))) return rc;
   std::vector<double> a(alpha, alpha + h->batch), cv;
   if ((rc = lineSearchEvalO(h, a, h->d_q0, cv))) return rc;
   for (int b = 0; b < h->batch; ++b) { cost[b] = cv[2 * b]; violation[b] = cv[2 * b + 1]; }
@@ -1399,13 +1413,35 @@ int idocp_parnmpc_update_solution_device(idocp_ocp_t* h, double t, const double*
   return IDOCP_OK;
 }
 
-int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v, int line_search) {
+// coarse update + the four correction sweeps + direction + step sizes WITHOUT integrating (phases 0 .. 8): the state in which
+// idocp_ocp_line_search_eval probes trial steps
+int idocp_parnmpc_compute_direction(idocp_ocp_t* h, double t, const double* q, const double* v) {
   if (!h || !h->parnmpc || !q || !v) return IDOCP_E_ARG;
-  if (line_search) { set_last_error("line_search=true is not supported by the HIP path (SURVEY 8f)"); return IDOCP_E_UNSUPPORTED; }
+  if (!h->contact_status_set) { set_last_error("idocp_parnmpc_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
-  if ((rc = idocp_parnmpc_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  if ((rc = discretize(h, t))) return rc;
+  HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
+  for (int phase = 0; phase <= 8; ++phase) if ((rc = idocp_parnmpc_launch_phase(h, phase, h->d_q0, h->d_v0))) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
+int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v, int line_search) {
+  if (!h || !h->parnmpc || !q || !v) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if (line_search) {
+    // ParNMPCSolver::updateSolution(t, q, v, true) (parnmpc_solver.cpp:73-103): direction, filter line search on the primal step, integration
+    if ((rc = idocp_parnmpc_compute_direction(h, t, q, v))) return rc;
+    if ((rc = parnmpcLineSearchSupported(h))) return rc;
+    if ((rc = runLineSearchO(h, h->d_q0))) return rc;
+    if ((rc = idocp_parnmpc_launch_phase(h, 9, h->d_q0, h->d_v0))) return rc;
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->d_q0, q, sizeof(double) * h->batch * DQ::NQ, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_v0, v, sizeof(double) * h->batch * DQ::NV, hipMemcpyHostToDevice, h->stream));
+    if ((rc = idocp_parnmpc_update_solution_device(h, t, h->d_q0, h->d_v0))) return rc;
+  }
   std::vector<int> st(h->batch);
   HIP_TRY(hipMemcpyAsync(st.data(), h->B.status, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const int pos = plist ? plist[unit - b * per] : (int)(unit - b * per);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
-  if (BWD && terminal) return;                      // placeholder stage
+  if (BWD && terminal) {                            // placeholder stage (no cost, no constraint: the line search sums zeros)
+    if (MERIT && threadIdx.x < 2) B.merit_stage[(b * P->NS + nd->slot) * 4 + threadIdx.x] = 0.0;
+    return;
+  }
   const bool last = BWD && P->has_terminal && (pos == M - 2);   // ParNMPC: the stage that carries the terminal cost
   // DIMF >= 0 is only launched on stages without an impulse or a switching constraint (launchCondense: event-free chains;
   // launchCondenseMixed: those stages of a chain with events, grouped by their number of contact rows)
@@ -886,6 +889,20 @@ void OcpLaunch<D>::merit(const OcpBuffers& Btry, long batch, int M, const double
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
   hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, false, true>), dim3(blocks), dim3(256), smem, st, Btry, q0);
 }
+// The same for ParNMPC (backward-Euler stages; event-free horizons): Split / TerminalParNMPC::stageCost and constraintViolation
+// (split_parnmpc.hxx:269-311, terminal_parnmpc.hxx:188-229) -- the terminal cost is NOT part of the reference's merit.
+template <typename D>
+void OcpLaunch<D>::meritBackwardEuler(const OcpBuffers& Btry, long batch, int M, const double* q0, const double* v0, hipStream_t st) {
+  const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  const unsigned stages = (unsigned)(batch * (M - 1));
+  hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
+  hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, Btry, q0, v0);
+}
 template <typename D>
 void OcpLaunch<D>::residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st) {
   launchCondense<D>(B, batch, M, -1, q0, st, true);
@@ -910,6 +927,7 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::merit(const OcpBuffers&, long, int, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::meritBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::condenseBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, bool, hipStream_t);
 

@@ -30,6 +30,7 @@ struct OcpLaunch {
   // filter line search of the floating-base solvers (src/line_search/line_search.cpp)
   static void trialIterate(const OcpBuffers& B, long batch, int M, hipStream_t st);             // s (+) alpha d -> sol_try, barrier cost
   static void merit(const OcpBuffers& Btry, long batch, int M, const double* q0, hipStream_t st);  // per-stage cost + l1 violation of sol_try
+  static void meritBackwardEuler(const OcpBuffers& Btry, long batch, int M, const double* q0, const double* v0, hipStream_t st);      // the same for ParNMPC (event-free)
   static void meritReduce(const OcpBuffers& B, long batch, hipStream_t st);
   static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
   static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7

@@ -127,7 +127,7 @@ class ParNMPCSolver {
   }
   void popBackContactStatus() { check(idocp_ocp_pop_back_contact_status(h_)); }
   void popFrontContactStatus() { check(idocp_ocp_pop_front_contact_status(h_)); }
-  void clearLineSearchFilter() {}
+  void clearLineSearchFilter() { check(idocp_ocp_clear_line_search_filter(h_)); }      // ParNMPCSolver::clearLineSearchFilter (parnmpc_solver.cpp:226-228)
 
   // ParNMPCSolver::isCurrentSolutionFeasible (parnmpc_solver.cpp:231-273)
   bool isCurrentSolutionFeasible() {

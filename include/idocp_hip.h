@@ -452,9 +452,14 @@ int idocp_parnmpc_init_backward_correction(idocp_ocp_t* h, double t);
 int idocp_parnmpc_set_aux_mat(idocp_ocp_t* h, int nstages, const double* values);
 /* ParNMPCSolver::updateSolution (parnmpc_solver.cpp:73-103): coarseUpdate,
  * backwardCorrectionSerial / Parallel, forwardCorrectionSerial / Parallel, step sizes,
- * integrateSolution.  q[batch][nq], v[batch][nv]; line_search must be 0 (see idocp_ocp_update_solution). */
+ * integrateSolution.  q[batch][nq], v[batch][nv]; line_search != 0: the filter line search on the primal step
+ * (LineSearch::computeStepSize for ParNMPC, src/line_search/line_search.cpp:199-237) -- event-free horizons on one shard;
+ * with discrete events or on a shard IDOCP_E_UNSUPPORTED.  idocp_ocp_line_search_eval / idocp_ocp_clear_line_search_filter
+ * work on ParNMPC handles as well. */
 int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v,
                                   int line_search);
+/* The same up to and including the step sizes, without integrating (the state idocp_ocp_line_search_eval probes). */
+int idocp_parnmpc_compute_direction(idocp_ocp_t* h, double t, const double* q, const double* v);
 int idocp_parnmpc_update_solution_device(idocp_ocp_t* h, double t, const double* d_q,
                                          const double* d_v);
 /* One phase of updateSolution (bench / tests): 0 tangent RNEA, 1 backward-Euler condensation,

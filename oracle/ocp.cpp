@@ -2113,7 +2113,7 @@ void ParNMPCSolver::integrateSolution() {
   }
 }
 
-void ParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v) {
+void ParNMPCSolver::computeDirection(real t, const Mat& q, const Mat& v) {
   coarseUpdate(t, q, v);
   auto t0 = std::chrono::steady_clock::now();
   backwardCorrectionSerial();
@@ -2123,7 +2123,92 @@ void ParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v) {
   forwardCorrectionSerial();
   serial_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
   forwardCorrectionParallel();
+}
+void ParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line_search) {
+  computeDirection(t, q, v);
+  if (use_line_search)            // parnmpc_solver.cpp:94-99
+    primal_step_size = line_search.computeStepSize([&](real a) { return costAndViolation(a, q, v); }, primal_step_size);
   integrateSolution();
+}
+
+// LineSearch::computeSolution + computeCostAndViolation for ParNMPC (src/line_search/line_search.cpp:199-237, 346-399) on an
+// event-free horizon.  Per stage i of the N stages (the last one is TerminalParNMPC):
+//   cost      = Split / TerminalParNMPC::stageCost (split_parnmpc.hxx:269-288, terminal_parnmpc.hxx:188-207): stage cost + dt *
+//               barrier(slack + alpha dslack) -- NOT the terminal cost, which the reference leaves out of its line search
+//   violation = constraintViolation (split_parnmpc.hxx:291-311, terminal_parnmpc.hxx:210-229): backward-Euler residual against the
+//               TRIAL predecessor (the measured state in front of stage 0) |Fx|_1 + dt |[ID - u; C]|_1 + dt |g + slack|_1
+std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, const Mat& v) {
+  const int nv = nv_, nu = nu_, kP = nv - nu;
+  Robot rb = robot;
+  for (const PNode& nd : chain) if (nd.kind != NodeC::Stage && nd.kind != NodeC::Terminal) throw std::logic_error("ParNMPC line search: event-free horizons only");
+  auto trial = [&](int p) {
+    const int sl = chain[p].slot;
+    SplitSolutionC x = s[sl];
+    if (alpha > 0) {
+      const ContactStatus& cs = nodeContacts(chain[p]);
+      Mat qn; rb.integrateConfiguration(s[sl].q, d[sl].dq, alpha, qn); x.q = qn;
+      x.v = s[sl].v + alpha * d[sl].dv;
+      x.a = s[sl].a + alpha * d[sl].daf.segment(0, nv);
+      x.u = s[sl].u + alpha * d[sl].du;
+      int st = 0;
+      for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int k2 = 0; k2 < 3; ++k2) x.f[c][k2] = s[sl].f[c][k2] + alpha * d[sl].daf[nv + st + k2]; st += 3; }
+    }
+    return x;
+  };
+  real cost_sum = 0, viol_sum = 0;
+  SplitSolutionC xp(robot);
+  for (int p = 0; p < (int)chain.size(); ++p) {
+    const PNode& nd = chain[p];
+    const int sl = nd.slot;
+    const SplitSolutionC x = trial(p);
+    const ContactStatus& cs = nodeContacts(nd);
+    const real dt = nd.dt;
+    Mat q_ref, qdiff;
+    qRef(nd.t, q_ref);
+    rb.subtractConfiguration(x.q, q_ref, qdiff);
+    const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
+    const real vs = vRefScale(cost, nd.t);
+    real l = 0;
+    for (int r = 0; r < nv; ++r) {
+      const real dvr = x.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]);
+      l += cost.q_weight[r] * qdiff[r] * qdiff[r] + cost.v_weight[r] * dvr * dvr + cost.a_weight[r] * x.a[r] * x.a[r];
+    }
+    for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) l += cost.f_weight[c][k2] * (x.f[c][k2] - cost.f_ref[c][k2]) * (x.f[c][k2] - cost.f_ref[c][k2]);
+    real barrier = 0, primal = 0;
+    for (int c = 0; c < 7; ++c) {
+      if (!componentValid(c, nd)) continue;
+      const int CK = coneKind(false), CR = coneRows(false);
+      const IpmData& data = ipm[sl][c];
+      for (int r = 0; r < data.slack.size(); ++r) barrier -= cons.barrier * std::log(data.slack[r] + alpha * data.dslack[r]);      // pdipm.hxx:84-87
+      if (c < 6) {
+        const real sgn = (c & 1) ? 1.0 : -1.0;
+        for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), c, r)) + data.slack[r]);
+      } else {
+        for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
+          const ConeEval ce = coneEval(CK, cons.mu, x.f[cc]);
+          for (int r = 0; r < CR; ++r) primal += std::fabs(ce.res[r] + data.slack[CR * cc + r]);
+        }
+      }
+    }
+    cost_sum += 0.5 * dt * l + dt * barrier;
+    // backward-Euler residual against the trial predecessor (state_equation.hxx:225-236)
+    const Mat& qpv = p == 0 ? q : xp.q;
+    const Mat& vpv = p == 0 ? v : xp.v;
+    Mat diff; rb.subtractConfiguration(qpv, x.q, diff);
+    real viol = 0;
+    for (int r = 0; r < nv; ++r) viol += std::fabs(diff[r] + dt * x.v[r]) + std::fabs(vpv[r] - x.v[r] + dt * x.a[r]);
+    Mat ID, C;
+    rb.updateKinematics(x.q, x.v, x.a);
+    rb.setContactForces(cs.active, x.f);
+    rb.RNEA(x.q, x.v, x.a, ID);
+    for (int r = 0; r < nu; ++r) ID[kP + r] -= x.u[r];
+    rb.computeBaumgarteResidual(cs.active, dt_, cs.points, C);
+    viol += dt * (ID.lpNorm1() + C.lpNorm1()) + dt * primal;
+    viol_sum += viol;
+    xp = x;
+  }
+  return {cost_sum, viol_sum};
 }
 
 void ParNMPCSolver::computeKKTResidual(real t, const Mat& q, const Mat& v) {

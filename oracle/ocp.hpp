@@ -218,7 +218,12 @@ class ParNMPCSolver {
   void setSolution(const std::string& name, const Mat& value);
   void initBackwardCorrection(real t);                              // parnmpc_solver.cpp:66-70
   void initConstraints(real t);                                     // parnmpc_linearizer.cpp:43-75
-  void updateSolution(real t, const Mat& q, const Mat& v);           // parnmpc_solver.cpp:73-103
+  void updateSolution(real t, const Mat& q, const Mat& v, bool line_search = false);           // parnmpc_solver.cpp:73-103
+  void computeDirection(real t, const Mat& q, const Mat& v);          // the same without integrateSolution (line-search tests)
+  // LineSearch::computeCostAndViolation of the trial iterate s (+) alpha d for ParNMPC (src/line_search/line_search.cpp:199-237;
+  // event-free horizons only: throws std::logic_error when the chain holds impulse / aux / lift stages)
+  std::pair<real, real> costAndViolation(real alpha, const Mat& q, const Mat& v);
+  LineSearchFilterC line_search;
   void computeKKTResidual(real t, const Mat& q, const Mat& v);
   real KKTError();                                                   // parnmpc_linearizer.cpp:203-247
   int isCurrentSolutionFeasible() const;                               // parnmpc_solver.cpp:231-273: first offending chain position or -1

@@ -855,6 +855,26 @@ int oracle_parnmpc_update_solution(void* h, double t, const double* q, const dou
   catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
   return 0;
 }
+// filter line search of ParNMPCSolver (event-free horizons): updateSolution(t, q, v, true); the direction alone; cost / violation of a trial step
+int oracle_parnmpc_update_solution_ls(void* h, double t, const double* q, const double* v) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  try { s->updateSolution(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()), true); }
+  catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
+int oracle_parnmpc_compute_direction(void* h, double t, const double* q, const double* v) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  try { s->computeDirection(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); }
+  catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
+int oracle_parnmpc_cost_and_violation(void* h, double alpha, const double* q, const double* v, double* out2) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  try { const auto cv = s->costAndViolation(alpha, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv())); out2[0] = (double)cv.first; out2[1] = (double)cv.second; }
+  catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
+void oracle_parnmpc_clear_line_search_filter(void* h) { static_cast<ParNMPCSolver*>(h)->line_search.filter.clear(); }
 int oracle_parnmpc_is_current_solution_feasible(void* h) { return static_cast<ParNMPCSolver*>(h)->isCurrentSolutionFeasible(); }
 double oracle_parnmpc_kkt_error(void* h, double t, const double* q, const double* v) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);

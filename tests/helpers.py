@@ -405,6 +405,10 @@ class OracleParNMPC:
             lib.oracle_parnmpc_set_solution.argtypes = [vp, cs, dp]
             lib.oracle_parnmpc_init.argtypes = [vp, cd]
             lib.oracle_parnmpc_update_solution.argtypes = [vp, cd, dp, dp]
+            lib.oracle_parnmpc_update_solution_ls.argtypes = [vp, cd, dp, dp]
+            lib.oracle_parnmpc_compute_direction.argtypes = [vp, cd, dp, dp]
+            lib.oracle_parnmpc_cost_and_violation.argtypes = [vp, cd, dp, dp, dp]
+            lib.oracle_parnmpc_clear_line_search_filter.argtypes = [vp]
             lib.oracle_parnmpc_kkt_error.argtypes = [vp, cd, dp, dp]
             lib.oracle_parnmpc_kkt_error.restype = cd
             lib.oracle_parnmpc_is_current_solution_feasible.argtypes = [vp]

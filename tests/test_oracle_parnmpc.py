@@ -39,6 +39,36 @@ def test_parnmpc_converges_to_a_kkt_point():
         prev_q, prev_v = Q[i], V[i]
 
 
+def test_line_search_merit_of_the_event_free_horizon():
+    """ParNMPC half of LineSearch::computeCostAndViolation (src/line_search/line_search.cpp:199-237): at alpha = 0 the violation is the
+    l1 norm of the residuals the KKT error squares (state equation, [ID - u; C], IPM primal residuals), the converged point has none
+    left, and updateSolution(t, q, v, true) converges with accepted steps no larger than the fraction-to-boundary step."""
+    from helpers import P
+    m, cost, cons, p, q, v = make()
+    qq = q.copy()
+    qq[7:] += 0.05
+    assert p.lib.oracle_parnmpc_compute_direction(p.h, 0.0, P(qq), P(v)) == 0
+    cv0, cv1 = np.zeros(2), np.zeros(2)
+    assert p.lib.oracle_parnmpc_cost_and_violation(p.h, 0.0, P(qq), P(v), P(cv0)) == 0
+    amax, _ = p.step_sizes()
+    assert p.lib.oracle_parnmpc_cost_and_violation(p.h, amax, P(qq), P(v), P(cv1)) == 0
+    assert cv0[1] > 1e-3 and np.isfinite(cv0).all() and np.isfinite(cv1).all()
+    # (no monotonicity along the step: the reference measures the IPM residual with the CURRENT slack, and the first ParNMPC
+    #  direction from a cold start is not a Newton direction of the whole horizon)
+    m, cost, cons, p, q, v = make()
+    steps = []
+    e0 = p.kkt_error(0.0, qq, v)
+    for it in range(60):
+        assert p.lib.oracle_parnmpc_update_solution_ls(p.h, 0.0, P(qq), P(v)) == 0
+        steps.append(p.step_sizes()[0])
+    assert p.kkt_error(0.0, qq, v) < 1e-6 * e0
+    assert min(steps) >= 0.05 and max(steps) <= 1.0
+    cv = np.zeros(2)
+    assert p.lib.oracle_parnmpc_compute_direction(p.h, 0.0, P(qq), P(v)) == 0
+    assert p.lib.oracle_parnmpc_cost_and_violation(p.h, 0.0, P(qq), P(v), P(cv)) == 0
+    assert cv[1] < 1e-6
+
+
 # ---- horizons with discrete events (ParNMPCDiscretizer, aux / impulse / lift stages of the backward-Euler formulation) ----
 def make_hybrid(N=20, T=1.0, t_lift=0.52, t_touch=0.83):
     """All feet -> {LH, RF} at t_lift -> all feet again at t_touch: one lift and one impulse event off the grid."""

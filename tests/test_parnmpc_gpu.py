@@ -244,3 +244,36 @@ def test_full_size_c4_parity_and_properties():
     assert e_g[0] < 1e-3 * 138.0                                                # converging (138 after the first step, 3.6e-6 after six)
     qs = g.get("q", 1)
     assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12        # quaternions stay normalised
+
+
+def test_filter_line_search_cost_violation_and_accepted_steps():
+    """ParNMPCSolver::updateSolution(t, q, v, line_search = true) (parnmpc_solver.cpp:73-103) on an event-free horizon: total cost and
+    l1 constraint violation of the trial iterates s (+) alpha d (src/line_search/line_search.cpp:199-237: backward-Euler residual
+    against the TRIAL predecessor, no terminal cost in the merit) against the oracle, then the accepted steps over several iterations."""
+    import ctypes as C
+    from helpers import P
+    m, o, g, q, v = make_pair(20, 0.5, batch=2)
+    assert o.lib.oracle_parnmpc_compute_direction(o.h, 0.0, P(q), P(v)) == 0
+    assert g.lib.idocp_parnmpc_compute_direction(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv))) == 0
+    ap, ad = g.step_sizes()
+    ao, _ = o.step_sizes()
+    assert abs(ap[0] - ao) < 1e-10
+    for alpha in (0.0, 1e-3, 0.1, 0.5 * ap[0], ap[0]):
+        ref = np.zeros(2)
+        assert o.lib.oracle_parnmpc_cost_and_violation(o.h, alpha, P(q), P(v), P(ref)) == 0
+        c, vi = np.zeros(g.batch), np.zeros(g.batch)
+        assert g.lib.idocp_ocp_line_search_eval(g.h, P(np.full(g.batch, alpha)), P(c), P(vi)) == 0
+        assert abs(c[0] - ref[0]) <= 1e-10 * max(1.0, abs(ref[0])), (alpha, c[0], ref[0])
+        assert abs(vi[0] - ref[1]) <= 1e-10 * max(1.0, abs(ref[1])), (alpha, vi[0], ref[1])
+        assert c[0] == c[-1] and vi[0] == vi[-1]
+    # accepted steps: fresh pair (the probes above did not touch the filters, but the direction state is mid-iteration)
+    m, o, g, q, v = make_pair(20, 0.5, batch=2)
+    for it in range(6):
+        assert o.lib.oracle_parnmpc_update_solution_ls(o.h, 0.0, P(q), P(v)) == 0
+        assert g.lib.idocp_parnmpc_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1) == 0
+        ao, bo = o.step_sizes()
+        ag, bg = g.step_sizes()
+        assert abs(ag[0] - ao) < 1e-12 and abs(bg[0] - bo) < 1e-9, (it, ag[0], ao)
+        for f in ("q", "v", "a", "u", "f"):
+            assert rel_err(g.get(f, 1), o.get(f)) < 1e-8, (it, f)
+    assert g.lib.idocp_ocp_clear_line_search_filter(g.h) == 0
