@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-A_STAGE = {"iiwa14": 5544, "iiwa14_unparnmpc": 5656, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
+A_STAGE = {"iiwa14": 5544, "iiwa14_task_space": 5544, "iiwa14_unparnmpc": 5656, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
            "anymal_parnmpc_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
 KERNELS_UNP = ["un_linearize", "unparnmpc_coarse_update", "unparnmpc_backward_serial", "unparnmpc_backward_parallel",
@@ -124,10 +124,13 @@ def cpu_baseline(workload, model, cost, cons, T, N, q, v, pts=None, target_secon
         bench = lib.oracle_ocp_bench
         set_threads = lib.oracle_ocp_set_num_threads
         nconv = 10
-    elif workload == "iiwa14":
+    elif workload in ("iiwa14", "iiwa14_task_space"):
         o = OracleUnOCP(model, cost, cons, T, N)
         o.set_solution("q", q)
         o.set_solution("v", v)
+        if workload == "iiwa14_task_space":
+            from idocp_amd.workloads import task_circle_refs
+            o.set_task_refs(task_circle_refs(0.0, T / N, N))
         bench = lib.oracle_unocp_bench
         set_threads = lib.oracle_unocp_set_num_threads
         nconv = 50
@@ -621,7 +624,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "anymal_parnmpc_trotting", "iiwa14", "iiwa14_unparnmpc"], default="anymal_trotting",
+    ap.add_argument("--workload", choices=["anymal", "anymal_trotting", "anymal_running", "anymal_parnmpc", "anymal_parnmpc_trotting", "iiwa14", "iiwa14_task_space", "iiwa14_unparnmpc"], default="anymal_trotting",
                     help="anymal_trotting = BASELINE.json configs[2] (trotting contact sequence); anymal = its uniform 4-contact variant "
                          "(SURVEY 8d roofline case); iiwa14 = configs[1]; anymal_parnmpc = configs[3] (ParNMPC, N=256, the horizon "
                          "sharded over the ranks, strong scaling)")
@@ -779,11 +782,21 @@ def main():
         # BASELINE.json configs[1]: iiwa14 UnOCPSolver, N=100, T=5, FP64
         B = args.batch or 16384
         model = iiwa14_model()
-        cost, cons = unocp_problem(model)
         nq, nv = model.nq, model.nv
-        q0 = np.ascontiguousarray(2.0 + 0.1 * rng.uniform(-1, 1, (B, nv)))
         v0 = np.zeros((B, nv))
+        if args.workload == "iiwa14_task_space":
+            # examples/iiwa14/task_space_ocp.cpp (TimeVaryingTaskSpace6DCost on the end-effector frame) as data
+            from idocp_amd.workloads import task_circle_refs, task_space_problem
+            for k in range(nv):
+                model.u_max[k], model.v_max[k] = 50.0, np.pi / 2
+            cost, cons = task_space_problem(model, dim=6, time_varying=True)
+            q0 = np.ascontiguousarray(np.array([0, np.pi / 2, 0, np.pi / 2, 0, np.pi / 2, 0.0]) + 0.05 * rng.uniform(-1, 1, (B, nv)))
+        else:
+            cost, cons = unocp_problem(model)
+            q0 = np.ascontiguousarray(2.0 + 0.1 * rng.uniform(-1, 1, (B, nv)))
         solver = HipUnOCP(model, cost, cons, T, N, batch=B, device=local_rank)
+        if args.workload == "iiwa14_task_space":
+            solver.set_task_refs(task_circle_refs(0.0, T / N, N))
         solver.set_solution_batch("q", q0)
         solver.set_solution("v", v0[0])
         KERNELS = KERNELS_UN
@@ -791,6 +804,8 @@ def main():
         units = {0: B * N, 1: B * N, 2: B * N, 3: B * (N + 1), 4: B * N, 5: B * (N + 1)}
         riccati_ids = (1, 2)
         desc = "iiwa14 UnOCPSolver N=%d T=%.2f FP64 (BASELINE.json configs[1]); " % (N, T)
+        if args.workload == "iiwa14_task_space":
+            desc = "iiwa14 UnOCPSolver N=%d T=%.2f FP64 with a TimeVaryingTaskSpace6DCost (SURVEY 8f row 3; examples/iiwa14/task_space_ocp.cpp); " % (N, T)
     d_q, d_v = C.c_void_p(), C.c_void_p()
     capi.check(lib.idocp_device_alloc(C.byref(d_q), q0.nbytes))
     capi.check(lib.idocp_device_alloc(C.byref(d_v), v0.nbytes))

@@ -52,6 +52,8 @@ class Cost(C.Structure):
         ("qi_weight", C.c_double * MAX_NV), ("vi_weight", C.c_double * MAX_NV), ("dvi_weight", C.c_double * MAX_NV),
         ("fi_weight", (C.c_double * 3) * MAX_CONTACTS), ("fi_ref", (C.c_double * 3) * MAX_CONTACTS),
         ("use_time_varying_ref", C.c_int), ("tv_t_begin", C.c_double), ("tv_t_end", C.c_double),
+        ("task_dim", C.c_int), ("task_joint", C.c_int), ("task_frame_R", C.c_double * 9), ("task_frame_p", C.c_double * 3),
+        ("task_weight", C.c_double * 6), ("task_weightf", C.c_double * 6), ("task_ref", C.c_double * 12), ("task_time_varying", C.c_int),
     ]
 
     def set(self, name, values):
@@ -87,6 +89,8 @@ def _proto(lib):
     lib.idocp_model_from_urdf.restype = ci
     lib.idocp_model_frame_id.argtypes = [cs, cs]
     lib.idocp_model_frame_id.restype = ci
+    lib.idocp_model_frame_placement.argtypes = [cs, ci, P(ci), P(cd), P(cd)]
+    lib.idocp_model_frame_placement.restype = ci
     lib.idocp_abi_check.argtypes = [C.c_ulong, C.c_ulong, C.c_ulong]
     lib.idocp_abi_check.restype = ci
     if lib.idocp_abi_check(C.sizeof(Model), C.sizeof(Cost), C.sizeof(Constraints)) != 0:
@@ -111,6 +115,7 @@ def _proto(lib):
         ("idocp_unocp_set_solution", [vp, cs, c_double_p]),
         ("idocp_unocp_set_solution_batch", [vp, cs, c_double_p]),
         ("idocp_unocp_init_constraints", [vp]),
+        ("idocp_unocp_set_task_refs", [vp, c_double_p]),
         ("idocp_unocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
         ("idocp_unocp_update_solution_device", [vp, cd, vp, vp]),
         ("idocp_unocp_synchronize", [vp]),

@@ -91,6 +91,46 @@ __host__ __device__ __forceinline__ void lieJlog6(const double* R, const double*
     J[r + 6 * s] = A[3 * r + s]; J[3 + r + 6 * (3 + s)] = A[3 * r + s]; J[r + 6 * (3 + s)] = Bm[3 * r + s]; J[3 + r + 6 * s] = 0.0;
   }
 }
+// log6(M) and Jlog6(M) together: the angle, sin, cos and the Taylor switches are evaluated once (same closed forms as
+// lieLog6 / lieJlog6 above; used where both are needed, dev_task.hpp)
+__host__ __device__ __forceinline__ void lieLog6Jlog6(const double* R, const double* p, double* out, double* J) {
+  double w[3], t;
+  lieLog3(R, w, &t);
+  const double t2 = t * t;
+  double alpha, diag, beta, bdot;
+  if (t < 1e-4) { alpha = beta = 1.0 / 12 + t2 / 720; diag = 0.5 * (2 - t2 / 6); bdot = 1.0 / 360; }
+  else {
+    const double st = sin(t), ct = cos(t), tinv = 1 / t, t2inv = tinv * tinv, i22 = 1 / (2 * (1 - ct)), q = st / (1 - ct);
+    alpha = 1 / t2 - q / (2 * t); diag = 0.5 * t * q;
+    beta = t2inv - st * tinv * i22;
+    bdot = -2 * t2inv * t2inv + (1 + st * tinv) * t2inv * i22;
+  }
+  // log6: beta of lieLog6 is 1/t^2 - sin t / (2 t (1 - cos t)) = the beta above
+  double K[9], K2[9];
+  lieSkew(w, K); lieMatmul3(K, K, K2);
+  {
+    double Vi[9];
+    for (int i = 0; i < 9; ++i) Vi[i] = -0.5 * K[i] + beta * K2[i];
+    Vi[0] += 1; Vi[4] += 1; Vi[8] += 1;
+    lieMatvec3(Vi, p, out);
+    out[3] = w[0]; out[4] = w[1]; out[5] = w[2];
+  }
+  double A[9];
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) A[3 * r + s] = alpha * w[r] * w[s];
+  A[0] += diag; A[4] += diag; A[8] += diag;
+  for (int k = 0; k < 9; ++k) A[k] += 0.5 * K[k];
+  const double wTp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  double v3[3], Cm[9], Kp[9], Bm[9];
+  for (int k = 0; k < 3; ++k) v3[k] = (bdot * wTp) * w[k] - (t2 * bdot + 2 * beta) * p[k];
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) Cm[3 * r + s] = v3[r] * w[s] + beta * w[r] * p[s];
+  Cm[0] += wTp * beta; Cm[4] += wTp * beta; Cm[8] += wTp * beta;
+  lieSkew(p, Kp);
+  for (int k = 0; k < 9; ++k) Cm[k] += 0.5 * Kp[k];
+  lieMatmul3(Cm, A, Bm);
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) {
+    J[r + 6 * s] = A[3 * r + s]; J[3 + r + 6 * (3 + s)] = A[3 * r + s]; J[r + 6 * (3 + s)] = Bm[3 * r + s]; J[3 + r + 6 * s] = 0.0;
+  }
+}
 // dDifference ARG0 = -Jlog6(M) Ad(M^-1); J1 = Jlog6(M) given (col-major 6x6) -> J0 (col-major 6x6)
 __host__ __device__ __forceinline__ void lieDDiffArg0(const double* R, const double* p, const double* J1, double* J0) {
   double Rt[9], mp[3], K[9], KRt[9], Ad[36];

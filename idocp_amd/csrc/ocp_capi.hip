@@ -577,6 +577,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if (!(constraints->fraction_to_boundary_rate > 0 && constraints->fraction_to_boundary_rate <= 1)) {
     set_last_error("invalid value: fraction_to_boundary_rate must be in (0, 1]!"); return IDOCP_E_ARG;
   }
+  if (cost->task_dim != 0) {
+    set_last_error("unsupported cost: the task-space costs are carried by UnOCPSolver (fixed-base robots) only");
+    return IDOCP_E_UNSUPPORTED;
+  }
   if (!isQuadruped(*model)) {
     set_last_error("idocp_ocp_create: this build carries OCP kernels for a floating-base quadruped (4 legs x 3 joints, 4 point contacts) only");
     return IDOCP_E_UNSUPPORTED;

@@ -167,6 +167,11 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     set_last_error("idocp_unocp_create: this build carries UnOCP kernels for a 7-dof revolute chain (iiwa14) only");
     return IDOCP_E_UNSUPPORTED;
   }
+  if (cost->task_dim != 0) {
+    if (cost->task_dim != 3 && cost->task_dim != 6) { set_last_error("invalid value: task_dim must be 0, 3 or 6!"); return IDOCP_E_ARG; }
+    if (cost->task_joint < 0 || cost->task_joint >= model->njoints) { set_last_error("invalid value: task_joint is not a joint of the model!"); return IDOCP_E_ARG; }
+    if (bwd) { set_last_error("idocp_unparnmpc_create: the task-space costs are carried by UnOCPSolver only"); return IDOCP_E_UNSUPPORTED; }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_last_error("no HIP device available: the idocp HIP path has no CPU fallback");
@@ -214,6 +219,15 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     if ((rc = allocBuf(h, &B.xres, nrec1 * L7::XRES))) return fail(rc);
     if ((rc = allocBuf(h, &B.xprev, (size_t)batch * L7::NX))) return fail(rc);
   }
+  if (cost->task_dim != 0) {
+    if ((rc = allocBuf(h, &B.task_ref, (size_t)(N + 1) * 12))) return fail(rc);
+    if ((rc = allocBuf(h, &B.task_term, (size_t)batch * L7::TASK))) return fail(rc);
+    B.task = 1; B.task_stride = L7::TASK;
+    std::vector<double> refs((size_t)(N + 1) * 12);
+    for (int i = 0; i <= N; ++i) std::memcpy(&refs[12 * i], cost->task_ref, sizeof(double) * 12);
+    if (hipMemcpyAsync(B.task_ref, refs.data(), refs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("hipMemcpy failed"); return fail(IDOCP_E_DEVICE); }
+  }
   DevModel dm; toDevModel(*model, dm);
   UnProblem up; std::memset(&up, 0, sizeof(up));
   up.N = N; up.batch = batch; up.T = T; up.dt = dt > 0.0 ? dt : T / N;
@@ -228,6 +242,10 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   up.use_u_limits = constraints->joint_torque_limits;
   up.barrier = constraints->barrier; up.fraction_rate = constraints->fraction_to_boundary_rate;
   up.backward_euler = bwd;
+  up.task.dim = cost->task_dim; up.task.joint = cost->task_joint;
+  std::memcpy(up.task.R, cost->task_frame_R, sizeof(up.task.R)); std::memcpy(up.task.p, cost->task_frame_p, sizeof(up.task.p));
+  std::memcpy(up.task.weight, cost->task_weight, sizeof(up.task.weight)); std::memcpy(up.task.weightf, cost->task_weightf, sizeof(up.task.weightf));
+  if (cost->task_dim == 3) for (int k = 3; k < 6; ++k) up.task.weight[k] = up.task.weightf[k] = 0.0;
   void *d_model = nullptr, *d_prob = nullptr;
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&d_prob, sizeof(UnProblem)) != hipSuccess) {
     set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
@@ -364,6 +382,18 @@ static int setSolutionImpl(idocp_unocp_t* h, const char* name, const double* val
 }
 int idocp_unocp_set_solution(idocp_unocp_t* h, const char* name, const double* value) { return setSolutionImpl(h, name, value, 0); }
 int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name, const double* values) { return setSolutionImpl(h, name, values, 1); }
+
+// TimeVaryingTaskSpace{3D,6D}Cost: the reference asks its TimeVaryingTaskSpace*RefBase for the pose at the time of every
+// stage (time_varying_task_space_6d_cost.cpp:65-67 with t = t0 + i dt from unocp_solver.cpp:78-94); here the caller evaluates
+// them and hands over the N + 1 poses.  refs: host, [N + 1][12] (rotation row-major, position).
+int idocp_unocp_set_task_refs(idocp_unocp_t* h, const double* refs) {
+  if (!h || !refs) { set_last_error("idocp_unocp_set_task_refs: null argument"); return IDOCP_E_ARG; }
+  if (!h->B.task) { set_last_error("idocp_unocp_set_task_refs: the cost of this solver has no task-space component"); return IDOCP_E_ARG; }
+  int rc = setDevice(h); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->B.task_ref, refs, sizeof(double) * 12 * (h->N + 1), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
 
 int idocp_unocp_init_constraints(idocp_unocp_t* h) {
   if (!h) return IDOCP_E_ARG;

@@ -11,6 +11,7 @@
 #define IDOCP_UNOCP_DEVICE_HPP_
 
 #include "dev_rbd.hpp"
+#include "dev_task.hpp"
 
 namespace idocp_dev {
 
@@ -49,6 +50,9 @@ struct UnLayout {
   static constexpr int KINV = roundUp16(I_BRC + NQ3 * NX);
   static constexpr int AUX = roundUp16(NX * NX);            // aux_mat of a stage (unbackward_correction.hpp)
   static constexpr int XRES = roundUp16(2 * NX);            // x_res of the backward [0, NX) and of the forward [NX, 2NX) sweep
+  // terminal task-space terms of an instance (TaskSpace*Cost::computeTerminalCost / Derivatives / Hessian): cost, gradient, Hessian
+  static constexpr int T_COST = 0, T_G = 1, T_H = 1 + NV;
+  static constexpr int TASK = roundUp16(1 + NV + NV * NV);
 };
 
 // Problem constants (cost, limits, IPM parameters), uniform across the grid.
@@ -66,6 +70,7 @@ struct UnProblem {
   // has_terminal: the shard ends with the terminal stage (else record N holds the right neighbour's first stage: lmd, gmm,
   // aux, corrected lmd, gmm); has_prev: (q0, v0) is the left neighbour's last stage and B.xprev its corrected (q, v)
   int stage_offset, has_terminal, has_prev;
+  TaskCost task;          // TaskSpace3DCost / TaskSpace6DCost (UnOCP only); task.dim = 0: none
 };
 
 // All device pointers of one handle.
@@ -95,6 +100,11 @@ struct UnBuffers {
   double* aux;         // [batch][N+1][AUX]
   double* xres;        // [batch][N+1][XRES]
   double* xprev;       // [batch][2 NV]  shard with has_prev: corrected (q, v) of the left neighbour's last stage
+  // task-space cost (null / 0 without one)
+  int task;              // host-side copy of prob->task.dim != 0: selects the kernel instantiations
+  int task_stride;       // UnLayout<NV>::TASK for the kernels that are not templated on NV
+  double* task_ref;      // [N+1][12]  reference pose of every stage: rotation (row-major) + position, shared by the batch
+  double* task_term;     // [batch][TASK]  terminal cost, gradient, Gauss-Newton Hessian (un_task_terminal_kernel)
 };
 
 }  // namespace idocp_dev

@@ -68,13 +68,16 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
 // BWD: the backward-Euler stage of UnParNMPC (SplitUnParNMPC / TerminalUnParNMPC::linearizeOCP, split_unparnmpc.hxx:69-102,
 // terminal_unparnmpc.hxx:69-102; stateequation::linearizeBackwardEuler[Terminal], state_equation.hxx:111-167): the state
 // equation couples to the PREVIOUS stage (the measured state q0, v0 for stage 0), the last stage carries the terminal cost.
-template <int NV, int MODE, bool BWD = false>
-__global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
+// TASK: the cost carries a TaskSpace3DCost / TaskSpace6DCost (dev_task.hpp); lane (0, k) adds dt JJ^T W diff to lq[k] and
+// column k of dt JJ^T W JJ to Qqq.
+template <int NV, int MODE, bool BWD = false, bool TASK = false>
+__global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
                                                           const double* __restrict__ v0 = nullptr) {
   using L = UnLayout<NV>;
   constexpr int LPS = 3 * NV;        // lanes per stage
   constexpr int SPW = 64 / LPS;      // stages per wavefront
   __shared__ double s_dID[SPW][3][NV * NV];
+  __shared__ double s_tJ[TASK ? SPW : 1][6][NV];     // TASK: the columns JJ[:, k] of the stage group
   __shared__ double s_err[SPW][LPS];
   __shared__ double s_cs[SPW][NV][2];
   __shared__ double s_tau[SPW][NV];
@@ -115,6 +118,21 @@ __global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const dou
   double tau_d[NV], ID[NV];
 #pragma unroll
   for (int r = 0; r < NV; ++r) { tau_d[r] = s_dID[g][kind][k * NV + r]; ID[r] = s_tau[g][r] - s[L::S_U + r]; }
+
+  // ---- task-space cost: gradient element k and the weighted column dt W JJ[:, k] (kept by the kind-0 lanes) ----
+  double task_g = 0.0, task_wc[6];
+  if (TASK) {
+    double tdiff[6], tcol[6];
+    taskSpaceColumn<NV>(B.model, P->task, &s_cs[g][0][0], B.task_ref + 12 * i, k, tdiff, tcol);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double wc = P->task.weight[c] * tcol[c];
+      task_g += wc * tdiff[c];
+      task_wc[c] = dt * wc;
+      if (MODE == 0 && g0 < SPW && kind == 0) s_tJ[g][c][k] = tcol[c];
+    }
+    if (MODE == 0) WAVE_SYNC();
+  }
 
   // ---- torque-level rows: needed by every lane (lu_condensed couples all rows) ----
   // UnconstrainedDynamics::linearize/condense (unconstrained_dynamics.hxx:55-94)
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const dou
     }
     l += dt * w * (x - ref);
     h = dt * w;
+    if (TASK && kind == 0) l += dt * task_g;     // TaskSpace*Cost::computeStageCostDerivatives
     if (term && kind < 2) {          // computeTerminalCostDerivatives / Hessian (configuration_space_cost.cpp:313-329, 368-380)
       const double wf = (kind == 0) ? P->qf_weight[k] : P->vf_weight[k];
       l += wf * (x - ref);
@@ -249,6 +268,10 @@ __global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const dou
       double acc = (k1kind == kind && k1 == k) ? h : 0.0;
 #pragma unroll
       for (int r = 0; r < NV; ++r) acc += A[k1 * NV + r] * dcol[r];
+      if (TASK && k1kind == 0 && kind == 0) {     // TaskSpace*Cost::computeStageCostHessian: Qqq += dt JJ^T W JJ
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc += s_tJ[g][c][k1] * task_wc[c];
+      }
       if (active && dst >= 0) kk[dst + k * NV + k1] = acc;
     }
   }
@@ -258,6 +281,57 @@ __global__ __launch_bounds__(64) void un_linearize_kernel(UnBuffers B, const dou
     else { kk[L::K_LA + k] = l_c; dy[L::D_QUU + k] = quu[k]; }
 #pragma unroll
     for (int r = 0; r < NV; ++r) dy[kind * NV * NV + k * NV + r] = tau_d[r];
+  }
+}
+
+// ------------------------------------------------------- terminal task cost ----
+// TaskSpace*Cost::computeTerminalCost / computeTerminalCostDerivatives / computeTerminalCostHessian at stage N of every
+// instance (task_space_6d_cost.cpp; terminal_ocp.hxx:50-66, 118-144) -> B.task_term.  8 lanes per instance, lane k = joint k.
+// TRIAL: at the line-search trial point q_N + alpha dq_N (cost only is read).
+template <int NV, bool TRIAL>
+__global__ __launch_bounds__(64) void un_task_terminal_kernel(UnBuffers B) {
+  using L = UnLayout<NV>;
+  static_assert(NV <= 8, "one joint per lane of an 8-lane group");
+  __shared__ double s_cs[8][NV][2];
+  __shared__ double s_J[8][6][NV];
+  const UnProblem* __restrict__ P = B.prob;
+  const int N = P->N;
+  const int lane = threadIdx.x;
+  const int g = lane >> 3;
+  const int k0 = lane & 7;
+  const int k = k0 < NV ? k0 : NV - 1;
+  long inst = (long)blockIdx.x * 8 + g;
+  const bool active = (inst < P->batch) && (k0 < NV);
+  if (inst >= P->batch) inst = P->batch - 1;
+  const double* __restrict__ sN = B.sol + (inst * (N + 1) + N) * L::SOL;
+  double qk = sN[L::S_Q + k];
+  if (TRIAL) qk += B.ls_alpha[inst] * (B.dir + (inst * (N + 1) + N) * L::SOL)[L::S_Q + k];
+  double sj, cj;
+  sincos(qk, &sj, &cj);
+  s_cs[g][k][0] = cj; s_cs[g][k][1] = sj;
+  WAVE_SYNC();
+  double diff[6], col[6], wc[6];
+  taskSpaceColumn<NV>(B.model, P->task, &s_cs[g][0][0], B.task_ref + 12 * N, k, diff, col);
+  double cost = 0.0, gk = 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double w = P->task.weightf[c];
+    cost += 0.5 * w * diff[c] * diff[c];
+    wc[c] = w * col[c];
+    gk += wc[c] * diff[c];
+    s_J[g][c][k] = col[c];
+  }
+  WAVE_SYNC();
+  if (!active) return;
+  double* __restrict__ out = B.task_term + inst * L::TASK;
+  if (k == 0) out[L::T_COST] = cost;
+  out[L::T_G + k] = gk;
+#pragma unroll
+  for (int r = 0; r < NV; ++r) {
+    double h = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) h += s_J[g][c][r] * wc[c];
+    out[L::T_H + k * NV + r] = h;
   }
 }
 
@@ -302,6 +376,12 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
     }
     sq = -(P->qf_weight[c] * (sN[L::S_Q + c] - P->q_ref[c]) - sN[L::S_LMD + c]);
     sv = -(P->vf_weight[c] * (sN[L::S_V + c] - P->v_ref[c]) - sN[L::S_GMM + c]);
+    if (P->task.dim) {       // terminal TaskSpace*Cost: dense Pqq (un_task_terminal_kernel ran before this sweep)
+      const double* __restrict__ tt = B.task_term + inst * L::TASK;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) Pqq[r] += tt[L::T_H + c * NV + r];
+      sq -= tt[L::T_G + c];
+    }
     double* __restrict__ rr = B.ric + (inst * (N + 1) + N) * L::RIC;
     if (active) {
 #pragma unroll
@@ -692,8 +772,9 @@ __global__ __launch_bounds__(64) void un_kkt_error_kernel(UnBuffers B) {
   if (threadIdx.x < NV && !P->backward_euler) {     // UnParNMPC: the last STAGE carries the terminal cost
     const int r = threadIdx.x;
     const double* __restrict__ sN = B.sol + (b * (N + 1) + N) * L::SOL;
-    const double lq = P->qf_weight[r] * (sN[L::S_Q + r] - P->q_ref[r]) - sN[L::S_LMD + r];
+    double lq = P->qf_weight[r] * (sN[L::S_Q + r] - P->q_ref[r]) - sN[L::S_LMD + r];
     const double lv = P->vf_weight[r] * (sN[L::S_V + r] - P->v_ref[r]) - sN[L::S_GMM + r];
+    if (P->task.dim) lq += B.task_term[b * L::TASK + L::T_G + r];
     e += lq * lq + lv * lv;
   }
 #pragma unroll
@@ -1134,6 +1215,14 @@ __global__ __launch_bounds__(64) void un_line_search_kernel(UnBuffers B, const d
   double cost = 0.0, viol = 0.0;
   const double qt = s_x[g][0][k], vt = s_x[g][1][k], at = s_x[g][2][k], ut = s_x[g][3][k];
   const bool term = BWD ? (P->has_terminal && i == N - 1) : false;
+  if (!BWD && P->task.dim) {       // TaskSpace*Cost::computeStageCost at the trial configuration (one lane of the group adds it)
+    double tdiff[6], tcol[6];
+    taskSpaceColumn<NV>(B.model, P->task, &s_cs[g][0][0], B.task_ref + 12 * i, k, tdiff, tcol);
+    if (seed == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) cost += 0.5 * dt * P->task.weight[c] * tdiff[c] * tdiff[c];
+    }
+  }
   // the neighbour of the state equation at ITS trial point (the measured state is fixed)
   double qo, vo;
   if (BWD) {
@@ -1189,7 +1278,10 @@ __global__ __launch_bounds__(64) void un_line_search_reduce_kernel(UnBuffers B) 
   for (int i = threadIdx.x; i < N; i += 64) { c += B.ls_stage[(b * (N + 1) + i) * 2]; v += B.ls_stage[(b * (N + 1) + i) * 2 + 1]; }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { c += __shfl_xor(c, off); v += __shfl_xor(v, off); }
-  if (threadIdx.x == 0) { B.ls_out[b * 2] = c; B.ls_out[b * 2 + 1] = v; }
+  if (threadIdx.x == 0) {
+    if (B.task) c += B.task_term[b * B.task_stride];      // terminal TaskSpace*Cost at the trial point (un_task_terminal_kernel<TRIAL>)
+    B.ls_out[b * 2] = c; B.ls_out[b * 2 + 1] = v;
+  }
 }
 
 // Halo exchange of a horizon shard: dst[b][dst_off + e] = src[b][src_off + e], e < n, with per-instance strides
@@ -1212,18 +1304,25 @@ template <int NV>
 void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t st) {
     constexpr int SPW = 64 / (3 * NV);
     const long units = batch * N;
-    hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+    if (B.task) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+    else hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
   }
 template <int NV>
 void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t st) {
     constexpr int SPW = 64 / (3 * NV);
     const long units = batch * N;
-    hipLaunchKernelGGL((un_linearize_kernel<NV, 1>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+    if (B.task) {
+      hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+      hipLaunchKernelGGL((un_task_terminal_kernel<NV, false>), dim3((unsigned)((batch + 7) / 8)), dim3(64), 0, st, B);
+    } else {
+      hipLaunchKernelGGL((un_linearize_kernel<NV, 1>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+    }
     hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
   }
 template <int NV>
 void UnLaunch<NV>::riccati(const UnBuffers& B, long batch, int /*N*/, const double* q0, const double* v0, hipStream_t st) {
     const unsigned blocks = (unsigned)((batch + 7) / 8);
+    if (B.task) hipLaunchKernelGGL((un_task_terminal_kernel<NV, false>), dim3(blocks), dim3(64), 0, st, B);
     hipLaunchKernelGGL((un_riccati_backward_kernel<NV>), dim3(blocks), dim3(64), 0, st, B);
     hipLaunchKernelGGL((un_riccati_forward_kernel<NV>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
   }
@@ -1258,8 +1357,11 @@ void UnLaunch<NV>::single(int kernel_id, const UnBuffers& B, long batch, int N, 
   const unsigned inst_blocks = (unsigned)((batch + 7) / 8);
   const unsigned stage_blocks = (unsigned)((batch * (N + 1) + 7) / 8);
   switch (kernel_id) {
-    case 0: hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B); break;
-    case 1: hipLaunchKernelGGL((un_riccati_backward_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
+    case 0: linearize(B, batch, N, st); break;
+    case 1:
+      if (B.task) hipLaunchKernelGGL((un_task_terminal_kernel<NV, false>), dim3(inst_blocks), dim3(64), 0, st, B);
+      hipLaunchKernelGGL((un_riccati_backward_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B);
+      break;
     case 2: hipLaunchKernelGGL((un_riccati_forward_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B, q0, v0); break;
     case 3: hipLaunchKernelGGL((un_expand_kernel<NV>), dim3(stage_blocks), dim3(64), 0, st, B); break;
     case 4: hipLaunchKernelGGL(un_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B); break;
@@ -1304,6 +1406,7 @@ void UnLaunch<NV>::lineSearchEval(const UnBuffers& B, long batch, int N, bool bw
   const unsigned blocks = (unsigned)((batch * N + SPW - 1) / SPW);
   if (bwd) hipLaunchKernelGGL((un_line_search_kernel<NV, true>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
   else hipLaunchKernelGGL((un_line_search_kernel<NV, false>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
+  if (B.task && !bwd) hipLaunchKernelGGL((un_task_terminal_kernel<NV, true>), dim3((unsigned)((batch + 7) / 8)), dim3(64), 0, st, B);
   hipLaunchKernelGGL(un_line_search_reduce_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
 }
 

@@ -356,6 +356,20 @@ extern "C" int idocp_model_from_urdf(const char* path_to_urdf, const int* contac
   return IDOCP_OK;
 }
 
+extern "C" int idocp_model_frame_placement(const char* path_to_urdf, int frame_id, int* joint, double* R, double* p) {
+  if (!path_to_urdf || !joint || !R || !p) return IDOCP_E_ARG;
+  idocp_model_t m; std::vector<FrameEntry> frames; std::string err;
+  if (!buildFrames(path_to_urdf, m, frames, err)) { set_last_error(err); return IDOCP_E_IO; }
+  if (frame_id < 0 || frame_id >= (int)frames.size() || frames[frame_id].joint < 0) {
+    set_last_error("idocp_model_frame_placement: frame " + std::to_string(frame_id) + " does not exist or is not attached to a joint");
+    return IDOCP_E_ARG;
+  }
+  *joint = frames[frame_id].joint;
+  std::memcpy(R, frames[frame_id].placement.R, sizeof(double) * 9);
+  std::memcpy(p, frames[frame_id].placement.p, sizeof(double) * 3);
+  return IDOCP_OK;
+}
+
 extern "C" int idocp_model_frame_id(const char* path_to_urdf, const char* frame_name) {
   if (!path_to_urdf || !frame_name) return -1;
   idocp_model_t m; std::vector<FrameEntry> frames; std::string err;

@@ -83,6 +83,12 @@ class HipUnOCP:
         v = np.broadcast_to(arr(v), (self.batch, self.nv)) if np.ndim(v) == 1 else v
         return self.lib.idocp_unocp_update_solution(self.h, t, P(arr(q)), P(arr(v)), 1 if line_search else 0)
 
+    def set_task_refs(self, refs):
+        """reference poses of a TimeVaryingTaskSpace*Cost at the stage times, [N + 1][12] (rotation row-major, position)"""
+        refs = arr(refs)
+        assert refs.shape == (self.N + 1, 12)
+        capi.check(self.lib.idocp_unocp_set_task_refs(self.h, P(refs)), "set_task_refs")
+
     def launch(self, kernel_id, q, v):
         """one kernel of updateSolution (0 linearize, 1 / 2 Riccati backward / forward, 3 expand, 4 reduce steps, 5 integrate)"""
         if getattr(self, "_dq", None) is None:
@@ -242,6 +248,49 @@ def anymal_problem(model, trotting_ref=True, cone="linearized"):
         cons.linearized_impulse_friction_cone = 1
     cons.mu = 0.7
     return cost, cons
+
+def task_space_problem(model, dim=6, frame_id=22, weight=1000.0, time_varying=False):
+    """Cost / constraints of examples/iiwa14/task_space_ocp.cpp:54-76 as data: ConfigurationSpaceCost with zero position weights and
+    0.01 on v, a (u weights zero), a TaskSpace6DCost (dim=3: TaskSpace3DCost) of weight 1000 on the end-effector frame (pinocchio
+    frame 22 = iiwa_link_ee_kuka) with the reference pose of the example's circle at t = 0; six joint limits.
+    Returns (cost, cons); time_varying=True leaves the per-stage references to `task_circle_refs`."""
+    nv = model.nv
+    cost = capi.Cost()
+    cost.set("q_ref", np.zeros(nv))
+    cost.set("q_weight", np.zeros(nv)).set("qf_weight", np.zeros(nv))
+    cost.set("v_weight", np.full(nv, 0.01)).set("vf_weight", np.full(nv, 0.01)).set("a_weight", np.full(nv, 0.01))
+    cost.set("u_weight", np.zeros(nv))
+    joint = C.c_int()
+    R, p = (C.c_double * 9)(), (C.c_double * 3)()
+    capi.check(capi.lib().idocp_model_frame_placement(IIWA_URDF.encode(), frame_id, C.byref(joint), R, p), "frame_placement")
+    cost.task_dim = dim
+    cost.task_joint = joint.value
+    for k in range(9):
+        cost.task_frame_R[k] = R[k]
+    for k in range(3):
+        cost.task_frame_p[k] = p[k]
+    for k in range(6):
+        cost.task_weight[k] = weight
+        cost.task_weightf[k] = weight
+    ref = task_circle_refs(0.0, 0.0, 0)[0]
+    for k in range(12):
+        cost.task_ref[k] = ref[k]
+    cost.task_time_varying = 1 if time_varying else 0
+    cons = capi.Constraints()
+    capi.lib().idocp_constraints_init(C.byref(cons))
+    return cost, cons
+
+
+def task_circle_refs(t, dt, N):
+    """TimeVaryingTaskSpace6DRef of examples/iiwa14/task_space_ocp.cpp:21-46 at the stage times t + i dt, i = 0 .. N:
+    rotation [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], position (0.546, 0.1 sin(pi t), 0.76 + 0.1 cos(pi t)).  [N + 1][12]"""
+    refs = np.zeros((N + 1, 12))
+    for i in range(N + 1):
+        ti = t + i * dt
+        refs[i, :9] = [0, 0, 1, 0, 1, 0, -1, 0, 0]
+        refs[i, 9:] = [0.546, 0.1 * np.sin(np.pi * ti), 0.76 + 0.1 * np.cos(np.pi * ti)]
+    return refs
+
 
 def trotting_sequence(solver, model, num_impulse_phases, t_start=0.5, t_period=0.5, step_length=0.15):
     """Contact sequence of examples/anymal/anymal_trotting.cpp:141-177, transcribed as data: all feet ->

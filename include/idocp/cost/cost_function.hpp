@@ -5,8 +5,9 @@
 // evaluates the cost inside the stage kernels, so only the components it carries
 // natively can be pushed: one configuration-space cost (ConfigurationSpaceCost,
 // src/cost/configuration_space_cost.cpp:241-397, or TrottingConfigurationSpaceCost,
-// src/cost/trotting_configuration_space_cost.cpp) and one ContactForceCost
-// (src/cost/contact_force_cost.cpp:153-194).  Anything else -- or a second
+// src/cost/trotting_configuration_space_cost.cpp), one ContactForceCost
+// (src/cost/contact_force_cost.cpp:153-194) and one task-space cost
+// (task_space_cost.hpp; UnOCPSolver only).  Anything else -- or a second
 // component of the same kind -- is rejected at push_back: there is no silent
 // CPU fallback.
 #ifndef IDOCP_COST_FUNCTION_HPP_
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <memory>
+#include <vector>
 
 #include "idocp/eigen_shim.hpp"
 #include "idocp/robot/robot.hpp"
@@ -25,12 +27,23 @@ namespace idocp {
 class CostFunctionComponentBase {
  public:
   virtual ~CostFunctionComponentBase() {}
-  enum Kind { ConfigurationSpace = 0, ContactForce = 1 };
+  enum Kind { ConfigurationSpace = 0, ContactForce = 1, TaskSpace = 2 };
   virtual Kind kind() const { return ConfigurationSpace; }
   // writes this component's parameters into its fields of the flat cost block;
   // false = cannot be represented
   virtual bool exportTo(idocp_cost_t& cost) const = 0;
+  // time-varying task-space costs: the reference poses at t + i dt, i = 0 .. N ([N + 1][12]); false = constant reference
+  virtual bool stageRefs(const double /*t*/, const double /*dt*/, const int /*N*/, std::vector<double>& /*refs*/) const { return false; }
 };
+
+// the task-space fields of the flat cost block (written by the components of task_space_cost.hpp)
+inline void keepTaskFields(const idocp_cost_t& from, idocp_cost_t& to) {
+  to.task_dim = from.task_dim; to.task_joint = from.task_joint; to.task_time_varying = from.task_time_varying;
+  for (int k = 0; k < 9; ++k) to.task_frame_R[k] = from.task_frame_R[k];
+  for (int k = 0; k < 3; ++k) to.task_frame_p[k] = from.task_frame_p[k];
+  for (int k = 0; k < 6; ++k) { to.task_weight[k] = from.task_weight[k]; to.task_weightf[k] = from.task_weightf[k]; }
+  for (int k = 0; k < 12; ++k) to.task_ref[k] = from.task_ref[k];
+}
 
 class ConfigurationSpaceCost final : public CostFunctionComponentBase {
  public:
@@ -51,12 +64,13 @@ class ConfigurationSpaceCost final : public CostFunctionComponentBase {
   void set_vi_weight(const Eigen::VectorXd& v) { put(c_.vi_weight, v, dimv_, "vi_weight"); }
   void set_dvi_weight(const Eigen::VectorXd& v) { put(c_.dvi_weight, v, dimv_, "dvi_weight"); }
   bool exportTo(idocp_cost_t& cost) const override {
-    idocp_cost_t keep = cost;                       // contact-force fields belong to another component
+    idocp_cost_t keep = cost;                       // contact-force and task-space fields belong to other components
     cost = c_;
     for (int i = 0; i < IDOCP_MAX_CONTACTS; ++i) for (int k = 0; k < 3; ++k) {
       cost.f_weight[i][k] = keep.f_weight[i][k]; cost.f_ref[i][k] = keep.f_ref[i][k];
       cost.fi_weight[i][k] = keep.fi_weight[i][k]; cost.fi_ref[i][k] = keep.fi_ref[i][k];
     }
+    keepTaskFields(keep, cost);
     return true;
   }
 
@@ -74,20 +88,26 @@ class ConfigurationSpaceCost final : public CostFunctionComponentBase {
 
 class CostFunction {
  public:
-  CostFunction() : have_{false, false} { idocp_cost_init(&c_); }
+  CostFunction() : have_{false, false, false} { idocp_cost_init(&c_); }
   void push_back(const std::shared_ptr<CostFunctionComponentBase>& c) {
     const int k = (int)c->kind();
     if (have_[k] || !c->exportTo(c_)) {
-      std::cerr << "unsupported cost: the HIP path carries one configuration-space cost and one ContactForceCost" << '\n';
+      std::cerr << "unsupported cost: the HIP path carries one configuration-space cost, one ContactForceCost and one task-space cost" << '\n';
       std::exit(EXIT_FAILURE);
     }
     have_[k] = true;
+    if (k == (int)CostFunctionComponentBase::TaskSpace) task_ = c;
   }
   const idocp_cost_t& native() const { return c_; }
+  // reference poses of a time-varying task-space cost at the stage times; false: none pushed / constant reference
+  bool taskRefs(const double t, const double dt, const int N, std::vector<double>& refs) const {
+    return task_ ? task_->stageRefs(t, dt, N, refs) : false;
+  }
 
  private:
-  bool have_[2];
+  bool have_[3];
   idocp_cost_t c_;
+  std::shared_ptr<CostFunctionComponentBase> task_;
 };
 
 }  // namespace idocp

@@ -1,0 +1,5 @@
+// include/idocp/cost/task_space_3d_cost.hpp of the reference: the class lives in task_space_cost.hpp
+#ifndef IDOCP_TASK_SPACE_3D_COST_FWD_HPP_
+#define IDOCP_TASK_SPACE_3D_COST_FWD_HPP_
+#include "idocp/cost/task_space_cost.hpp"
+#endif  // IDOCP_TASK_SPACE_3D_COST_FWD_HPP_

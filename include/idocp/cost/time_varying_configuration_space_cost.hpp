@@ -45,6 +45,7 @@ class TimeVaryingConfigurationSpaceCost final : public CostFunctionComponentBase
       cost.f_weight[i][k] = keep.f_weight[i][k]; cost.f_ref[i][k] = keep.f_ref[i][k];
       cost.fi_weight[i][k] = keep.fi_weight[i][k]; cost.fi_ref[i][k] = keep.fi_ref[i][k];
     }
+    keepTaskFields(keep, cost);
     return true;
   }
 

@@ -64,6 +64,7 @@ class Vector3d {
   Vector3d() : d_{0.0, 0.0, 0.0} {}
   Vector3d(double x, double y, double z) : d_{x, y, z} {}
   static Vector3d Zero() { return Vector3d(); }
+  static Vector3d Constant(double v) { return Vector3d(v, v, v); }
   int size() const { return 3; }
   double* data() { return d_; }
   const double* data() const { return d_; }
@@ -76,6 +77,31 @@ class Vector3d {
   CommaInit<Vector3d> operator<<(double first) { return CommaInit<Vector3d>(*this, first); }
  private:
   double d_[3];
+};
+
+class Matrix3d {   // column-major storage; `m << ...` fills row by row like Eigen's comma initializer
+ public:
+  Matrix3d() : d_{0, 0, 0, 0, 0, 0, 0, 0, 0} {}
+  static Matrix3d Zero() { return Matrix3d(); }
+  static Matrix3d Identity() { Matrix3d m; m(0, 0) = m(1, 1) = m(2, 2) = 1.0; return m; }
+  int rows() const { return 3; }
+  int cols() const { return 3; }
+  double* data() { return d_; }
+  const double* data() const { return d_; }
+  double& operator()(int i, int j) { assert(i >= 0 && i < 3 && j >= 0 && j < 3); return d_[3 * j + i]; }
+  double operator()(int i, int j) const { assert(i >= 0 && i < 3 && j >= 0 && j < 3); return d_[3 * j + i]; }
+  class RowFill {
+   public:
+    RowFill(Matrix3d& m, double first) : m_(m), i_(0) { put(first); }
+    RowFill& operator,(double x) { put(x); return *this; }
+   private:
+    Matrix3d& m_;
+    int i_;
+    void put(double x) { assert(i_ < 9); m_(i_ / 3, i_ % 3) = x; ++i_; }
+  };
+  RowFill operator<<(double first) { return RowFill(*this, first); }
+ private:
+  double d_[9];
 };
 
 class MatrixXd {   // column-major

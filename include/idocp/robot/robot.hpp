@@ -20,7 +20,7 @@ class Robot {
  public:
   // Robot(path_to_urdf) / Robot(path_to_urdf, contact_frames): errors follow the
   // reference convention -- message on stderr, std::exit(EXIT_FAILURE).
-  explicit Robot(const std::string& path_to_urdf, const std::vector<int>& contact_frames = {}) {
+  explicit Robot(const std::string& path_to_urdf, const std::vector<int>& contact_frames = {}) : path_(path_to_urdf) {
     if (idocp_abi_check(sizeof(idocp_model_t), sizeof(idocp_cost_t), sizeof(idocp_constraints_t)) != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';
       std::exit(EXIT_FAILURE);
@@ -78,9 +78,12 @@ class Robot {
   }
 
   const idocp_model_t& model() const { return model_; }
+  // the URDF this robot was built from (frame lookups of the task-space costs)
+  const std::string& pathToUrdf() const { return path_; }
 
  private:
   idocp_model_t model_;
+  std::string path_;
   std::vector<double> points_;     // contact-frame positions of the last updateFrameKinematics(q)
   Eigen::VectorXd get(const double* p) const {
     Eigen::VectorXd v(model_.nu);

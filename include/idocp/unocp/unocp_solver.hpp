@@ -33,7 +33,7 @@ class UnOCPSolver {
  public:
   UnOCPSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
               const double T, const int N, const int nthreads = 1, const int device = 0)
-      : robot_(robot), N_(N), h_(nullptr) {
+      : robot_(robot), cost_(cost), N_(N), dt_(T / N), h_(nullptr) {
     (void)nthreads;
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
@@ -47,6 +47,7 @@ class UnOCPSolver {
   void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    uploadTaskRefs(t);
     check(idocp_unocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
 
@@ -134,15 +135,24 @@ class UnOCPSolver {
     return e;
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    uploadTaskRefs(t);
     check(idocp_unocp_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
   idocp_unocp_t* handle() { return h_; }
 
  private:
   Robot robot_;
+  std::shared_ptr<CostFunction> cost_;
   int N_;
+  double dt_;
   idocp_unocp_t* h_;
   std::vector<SplitSolution> cache_;
+  std::vector<double> task_refs_;
+  // TimeVaryingTaskSpace*Cost: the reference asks the user's ref object at the time of every stage inside linearizeOCP
+  // (unocp_solver.cpp:78-94 -> time_varying_task_space_6d_cost.cpp:65-67); here the poses are evaluated up front and uploaded
+  void uploadTaskRefs(const double t) {
+    if (cost_->taskRefs(t, dt_, N_, task_refs_)) check(idocp_unocp_set_task_refs(h_, task_refs_.data()));
+  }
   static void check(int rc) {
     if (rc != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';

@@ -113,6 +113,20 @@ typedef struct idocp_cost {
    * the velocity reference is v_ref inside the window and zero outside. */
   int use_time_varying_ref;
   double tv_t_begin, tv_t_end;
+  /* TaskSpace3DCost / TaskSpace6DCost and their TimeVarying variants (src/cost/task_space_{3d,6d}_cost.cpp,
+   * time_varying_task_space_{3d,6d}_cost.cpp) on one frame of a FIXED-BASE robot (UnOCPSolver).
+   * task_dim 0: none; 3: l = 1/2 dt |p_frame(q) - p_ref|^2_W; 6: l = 1/2 dt |log6(M_ref^-1 M_frame(q))|^2_W with the
+   * Gauss-Newton Hessian of the reference.  The frame is given by its parent joint and its placement in that joint's
+   * frame (idocp_model_frame_placement). */
+  int task_dim;
+  int task_joint;
+  double task_frame_R[9];        /* row-major */
+  double task_frame_p[3];
+  double task_weight[6];         /* 3D: q_3d_weight; 6D: the vector the reference stores, [rotation_weight; position_weight], which
+                                  * multiplies log6 = [linear; angular] entry by entry (time_varying_task_space_6d_cost.cpp:33-38, 60-62) */
+  double task_weightf[6];        /* terminal weights (qf_3d_weight / qf_6d_weight), same layout */
+  double task_ref[12];           /* constant reference: rotation (row-major, 9) then position (3); 3D uses the position only */
+  int task_time_varying;         /* != 0: the references of the N + 1 stages come from idocp_unocp_set_task_refs */
 } idocp_cost_t;
 
 /*
@@ -147,6 +161,9 @@ typedef struct idocp_constraints {
 int idocp_model_from_urdf(const char* path_to_urdf, const int* contact_frames,
                           int ncontacts, idocp_model_t* out);
 
+/* Parent joint (index into the model's joint arrays) and placement (R row-major, p) in that joint's frame of the frame with
+ * pinocchio-compatible index frame_id: what Robot::framePlacement / getFrameJacobian (robot.hxx:166-188) are evaluated on. */
+int idocp_model_frame_placement(const char* path_to_urdf, int frame_id, int* joint, double* R, double* p);
 /* Frame name -> pinocchio-compatible frame index (robot.cpp printRobotModel
  * enumerates the same table); returns -1 if absent. */
 int idocp_model_frame_id(const char* path_to_urdf, const char* frame_name);
@@ -186,6 +203,11 @@ int idocp_unocp_set_solution(idocp_unocp_t* h, const char* name,
 /* Same, one value per instance: values[batch][dim]. */
 int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name,
                                    const double* values);
+/* Per-stage reference poses of a TimeVaryingTaskSpace3DCost / TimeVaryingTaskSpace6DCost (cost.task_dim != 0): the values of
+ * TimeVaryingTaskSpace6DRefBase::compute_q_6d_ref (time_varying_task_space_6d_cost.hpp:21-42) at t + i dt, i = 0 .. N.
+ * refs: host, [N + 1][12] = rotation (row-major) then position; a 3D cost reads the position only.  Without a call the
+ * constant cost.task_ref applies to every stage. */
+int idocp_unocp_set_task_refs(idocp_unocp_t* h, const double* refs);
 /* UnOCPSolver::initConstraints() (unocp_solver.cpp:59-70). */
 int idocp_unocp_init_constraints(idocp_unocp_t* h);
 

@@ -270,6 +270,25 @@ int oracle_openmp_enabled(void) {
   return 0;
 #endif
 }
+// TaskSpace*Cost: references of stages 0 .. N, refs[N + 1][12] (rotation row-major, position)
+int oracle_unocp_set_task_refs(void* h, const double* refs) {
+  UnOCPSolver* s = static_cast<UnOCPSolver*>(h);
+  if (s->cost.task_dim == 0) return 1;
+  s->setTaskRefs(refs);
+  return 0;
+}
+// cost (no dt), gradient[nv], Gauss-Newton Hessian[nv x nv] (row-major) of the task term of stage i at configuration q
+int oracle_unocp_task_terms(void* h, int stage, const double* q, double* c, double* g, double* H) {
+  UnOCPSolver* s = static_cast<UnOCPSolver*>(h);
+  const int nv = s->robot.dimv();
+  try {
+    real cc; Mat gg, HH;
+    s->taskTerms(stage, toVec(q, nv), cc, gg, HH);
+    *c = (double)cc;
+    for (int r = 0; r < nv; ++r) { g[r] = (double)gg[r]; for (int k2 = 0; k2 < nv; ++k2) H[r * nv + k2] = (double)HH(r, k2); }
+  } catch (const std::exception& e) { g_oracle_error = e.what(); return 1; } catch (...) { g_oracle_error = "unknown"; return 1; }
+  return 0;
+}
 void* oracle_unparnmpc_create(const idocp_model_t* m, const idocp_cost_t* c, const idocp_constraints_t* k, double T, int N) {
   try { return new UnParNMPCSolver(*m, *c, *k, T, N); } catch (...) { return nullptr; }
 }

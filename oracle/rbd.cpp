@@ -486,6 +486,47 @@ void Robot::computeContactDerivative(const std::vector<bool>& active, Mat& Pq) c
   }
 }
 
+static void log3(const real* R, real* w, real* theta);
+static void VmatInv(const real* w, real* Vi);
+static void Jlog6(const real* R, const real* p, Mat& J);
+void Robot::taskSpaceTerms(int dim, const real* ref, const real* w, const Mat& q, real& cost, Mat& grad, Mat& hess) {
+  const int nv = m_.nv;
+  const Mat zero(nv);
+  updateKinematics(q, zero, zero);
+  real R[9], p[3];
+  contactFrame(0, p, R, nullptr, nullptr);             // Robot::framePlacement (robot.hxx:166-178)
+  Mat vdq, adq, adv, J;
+  frameDerivatives(0, vdq, adq, adv, J);                // J = getFrameJacobian(LOCAL) (robot.hxx:181-188), rows: linear, angular
+  const int m = dim == 6 ? 6 : 3;
+  Mat JJ(m, nv), diff(m);
+  if (dim == 6) {
+    // diff_SE3 = SE3_ref^-1 * oMf ; diff_6d = log6(diff_SE3) = [linear; angular] ; J_66 = Jlog6(diff_SE3)
+    real Rd[9], pd[3], t[3] = {p[0] - ref[9], p[1] - ref[10], p[2] - ref[11]};
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) { real a = 0; for (int k = 0; k < 3; ++k) a += ref[3 * k + r] * R[3 * k + c]; Rd[3 * r + c] = a; }
+      pd[r] = ref[r] * t[0] + ref[3 + r] * t[1] + ref[6 + r] * t[2];
+    }
+    real wv[3], th, Vi[9], vl[3];
+    log3(Rd, wv, &th); VmatInv(wv, Vi); matvec3(Vi, pd, vl);
+    for (int k = 0; k < 3; ++k) { diff[k] = vl[k]; diff[3 + k] = wv[k]; }
+    Mat J66; Jlog6(Rd, pd, J66);
+    JJ = J66 * J;
+  } else {
+    for (int k = 0; k < 3; ++k) diff[k] = p[k] - ref[9 + k];
+    for (int col = 0; col < nv; ++col)
+      for (int r = 0; r < 3; ++r) { real a = 0; for (int k = 0; k < 3; ++k) a += R[3 * r + k] * J(k, col); JJ(r, col) = a; }
+  }
+  cost = 0;
+  for (int r = 0; r < m; ++r) cost += 0.5 * w[r] * diff[r] * diff[r];
+  grad = Mat(nv); hess = Mat(nv, nv);
+  for (int c = 0; c < nv; ++c) {
+    real g = 0;
+    for (int r = 0; r < m; ++r) g += JJ(r, c) * w[r] * diff[r];
+    grad[c] = g;
+    for (int c2 = 0; c2 < nv; ++c2) { real h = 0; for (int r = 0; r < m; ++r) h += JJ(r, c) * w[r] * JJ(r, c2); hess(c, c2) = h; }
+  }
+}
+
 void Robot::computeMJtJinv(const Mat& M, const Mat& J, Mat& out) {
   // robot.hxx:576-615.  pinocchio's sparse U D U^T factorisation of M is replaced
   // by a dense Cholesky (same solution); the block algebra follows the reference.

@@ -77,12 +77,30 @@ UnOCPSolver::UnOCPSolver(const RModel& model, const RCost& cost_, const idocp_co
       terminal_Qqq(model.nv, model.nv), terminal_Qvv(model.nv, model.nv), terminal_lq(model.nv), terminal_lv(model.nv),
       riccati(N + 1, SplitRiccatiFactorization(model.nv)),
       K(N, Mat(model.nv, 2 * model.nv)), k(N, Mat(model.nv)),
-      N_(N), T_(T), dt_(T / N) {
+      task_robot_(model), N_(N), T_(T), dt_(T / N) {
+  if (cost.task_dim != 0) {
+    if (cost.task_dim != 3 && cost.task_dim != 6) throw std::invalid_argument("task_dim must be 0, 3 or 6");
+    RModel mt = model;                      // the task frame as contact 0: framePlacement / getFrameJacobian come from the contact kinematics
+    mt.ncontacts = 1; mt.contact_frame_id[0] = -1; mt.contact_joint[0] = cost.task_joint;
+    for (int k2 = 0; k2 < 9; ++k2) mt.contact_R[0][k2] = cost.task_frame_R[k2];
+    for (int k2 = 0; k2 < 3; ++k2) mt.contact_p[0][k2] = cost.task_frame_p[k2];
+    task_robot_ = Robot(mt);
+    std::array<real, 12> r0; for (int k2 = 0; k2 < 12; ++k2) r0[k2] = cost.task_ref[k2];
+    task_refs.assign(N + 1, r0);
+  }
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (robot.hasFloatingBase() || robot.maxPointContacts() > 0)
     throw std::logic_error("robot has floating base or contacts: use OCPSolver");   // split_unocp.hxx:27-33
   initConstraints();
+}
+
+void UnOCPSolver::setTaskRefs(const double* refs) {
+  for (int i = 0; i <= N_ && i < (int)task_refs.size(); ++i) for (int k2 = 0; k2 < 12; ++k2) task_refs[i][k2] = refs[12 * i + k2];
+}
+void UnOCPSolver::taskTerms(int i, const Mat& q, real& c, Mat& g, Mat& H) const {
+  Robot rb = task_robot_;
+  rb.taskSpaceTerms(cost.task_dim, task_refs[i].data(), i == N_ ? cost.task_weightf : cost.task_weight, q, c, g, H);
 }
 
 void UnOCPSolver::setSolution(const std::string& name, const Mat& value) {
@@ -156,6 +174,7 @@ void UnOCPSolver::computeStageResidual(Robot& robot, int i, real /*t*/) {
   const SplitSolution& si = s[i];
   o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero(); o.Fq.setZero(); o.Fv.setZero();
   stageCostDerivatives(cost, dt_, si, o);
+  if (cost.task_dim) { real c; Mat g, H; taskTerms(i, si.q, c, g, H); o.lq += dt_ * g; }      // TaskSpace*Cost::computeStageCostDerivatives
   // Constraints::computePrimalAndDualResidual + augmentDualResidual
   for (size_t c = 0; c < constraints.components.size(); ++c) {
     const JointLimit& jl = constraints.components[c];
@@ -185,6 +204,8 @@ void UnOCPSolver::linearizeStage(Robot& robot, int i, real t, const Mat& /*q_pre
   o.Qqq.setZero(); o.Qvv_diag.setZero(); o.Qaa_diag.setZero(); o.Quu_diag.setZero();
   o.lq.setZero(); o.lv.setZero(); o.la.setZero(); o.lu.setZero();
   stageCostDerivatives(cost, dt_, si, o);
+  Mat task_H;
+  if (cost.task_dim) { real c; Mat g; taskTerms(i, si.q, c, g, task_H); o.lq += dt_ * g; }    // TaskSpace*Cost::computeStageCostDerivatives
   for (size_t c = 0; c < constraints.components.size(); ++c) {          // augmentDualResidual
     const JointLimit& jl = constraints.components[c];
     if (!constraints.valid(jl, i)) continue;
@@ -223,6 +244,7 @@ void UnOCPSolver::linearizeStage(Robot& robot, int i, real t, const Mat& /*q_pre
       l[off + r] += jl.sign * dt_ * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
   }
   for (int r = 0; r < nv; ++r) o.Qqq(r, r) = Qqq_diag[r];
+  if (cost.task_dim) o.Qqq += dt_ * task_H;                        // TaskSpace*Cost::computeStageCostHessian (Gauss-Newton)
   // UnconstrainedDynamics::condenseUnconstrainedDynamics (unconstrained_dynamics.hxx:68-94)
   SplitUnKKTMatrix& Q = unkkt_matrix[i];
   SplitUnKKTResidual& R = unkkt_residual[i];
@@ -261,6 +283,7 @@ void UnOCPSolver::linearizeTerminal(real /*t*/) {
   terminal_lv -= sN.gmm;
   terminal_Qqq.setZero(); terminal_Qvv.setZero();
   for (int i = 0; i < nv; ++i) { terminal_Qqq(i, i) += cost.qf_weight[i]; terminal_Qvv(i, i) += cost.vf_weight[i]; }
+  if (cost.task_dim) { real c; Mat g, H; taskTerms(N_, sN.q, c, g, H); terminal_lq += g; terminal_Qqq += H; }     // computeTerminalCostDerivatives / Hessian
 }
 
 void UnOCPSolver::linearizeOCP(real t, const Mat& q) {
@@ -479,6 +502,7 @@ std::pair<real, real> UnOCPSolver::costAndViolation(real alpha) const {
     const TrialPoint x = trialPoint(s[i], d[i], alpha);
     const Mat qn = s[i + 1].q + alpha * d[i + 1].dq, vn = s[i + 1].v + alpha * d[i + 1].dv;
     cost_sum += trialStageCost(cost, constraints, ocp[i].cdata, i, dt_, x, alpha, false);
+    if (cost.task_dim) { real c; Mat g, H; taskTerms(i, x.q, c, g, H); cost_sum += dt_ * c; }
     for (int r = 0; r < rb.dimv(); ++r) viol += std::fabs(x.q[r] - qn[r] + dt_ * x.v[r]) + std::fabs(x.v[r] + dt_ * x.a[r] - vn[r]);
     viol += trialConstraintViolation(rb, constraints, ocp[i].cdata, i, dt_, x);
   }
@@ -486,6 +510,7 @@ std::pair<real, real> UnOCPSolver::costAndViolation(real alpha) const {
   real lf = 0;
   for (int r = 0; r < rb.dimv(); ++r)
     lf += cost.qf_weight[r] * (qN[r] - cost.q_ref[r]) * (qN[r] - cost.q_ref[r]) + cost.vf_weight[r] * (vN[r] - cost.v_ref[r]) * (vN[r] - cost.v_ref[r]);
+  if (cost.task_dim) { real c; Mat g, H; taskTerms(N_, qN, c, g, H); cost_sum += c; }
   return {cost_sum + 0.5 * lf, viol};
 }
 
@@ -512,6 +537,7 @@ void UnOCPSolver::computeKKTResidual(real t, const Mat& /*q*/, const Mat& /*v*/)
     terminal_lq[i] += cost.qf_weight[i] * (sN.q[i] - cost.q_ref[i]);
     terminal_lv[i] += cost.vf_weight[i] * (sN.v[i] - cost.v_ref[i]);
   }
+  if (cost.task_dim) { real c; Mat g, H; taskTerms(N_, sN.q, c, g, H); terminal_lq += g; }
   terminal_lq -= sN.lmd;
   terminal_lv -= sN.gmm;
 }
@@ -562,6 +588,7 @@ UnParNMPCSolver::UnParNMPCSolver(const RModel& model, const RCost& cost_, const 
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (robot.hasFloatingBase() || robot.maxPointContacts() > 0)
     throw std::logic_error("robot has floating base or contacts: use ParNMPCSolver");   // split_unparnmpc.hxx:27-33
+  if (cost.task_dim != 0) throw std::logic_error("task-space costs are restated for UnOCPSolver only");
   initConstraints();
 }
 

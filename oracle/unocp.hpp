@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <memory>
 #include <utility>
+#include <array>
 #include <vector>
 
 #include "idocp_hip.h"
@@ -179,6 +180,12 @@ class UnOCPSolver {
  public:
   int nthreads = 1;
   void setNumThreads(int n) { nthreads = n < 1 ? 1 : n; robots_.assign(nthreads, robot); }
+  // TaskSpace3DCost / TaskSpace6DCost (+ TimeVarying variants): the references of stages 0 .. N (rotation row-major, position)
+  std::vector<std::array<real, 12>> task_refs;
+  void setTaskRefs(const double* refs);          // [N + 1][12]
+  // cost (without dt), gradient and Gauss-Newton Hessian of the task term at stage i (terminal weights for i = N)
+  void taskTerms(int i, const Mat& q, real& c, Mat& g, Mat& H) const;
+  Robot task_robot_;                             // the robot with the task frame as its contact 0
  private:
 };
 

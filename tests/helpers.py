@@ -119,6 +119,18 @@ class OracleUnOCP:
         self.lib.oracle_unocp_cost_and_violation(self.h, alpha, P(out))
         return out
 
+    def set_task_refs(self, refs):
+        """TaskSpace*Cost references of stages 0 .. N, [N + 1][12] (rotation row-major, position)"""
+        self.lib.oracle_unocp_set_task_refs.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        assert self.lib.oracle_unocp_set_task_refs(self.h, P(arr(refs))) == 0
+
+    def task_terms(self, stage, q):
+        """(cost without dt, gradient, Gauss-Newton Hessian) of the task-space term of a stage at configuration q"""
+        self.lib.oracle_unocp_task_terms.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 4
+        c, g, H = np.zeros(1), np.zeros(self.nv), np.zeros((self.nv, self.nv))
+        assert self.lib.oracle_unocp_task_terms(self.h, stage, P(arr(q)), P(c), P(g), P(H)) == 0
+        return c[0], g, H
+
     def stage(self, what, t, q, v):
         return self.lib.oracle_unocp_stage(self.h, what, t, P(arr(q)), P(arr(v)))
 
