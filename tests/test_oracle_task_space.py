@@ -89,3 +89,44 @@ def test_sqp_of_the_task_space_example_converges():
     qN = o.solution("q")[-1]
     cN = o.task_terms(30, qN)[0]
     assert cN < 1.0          # 1000/2 |log6|^2 < 1: the pose error is below 5 cm / 3 deg
+
+
+def test_facade_components_export_the_reference_layout(tmp_path):
+    # include/idocp/cost/task_space_cost.hpp: what TaskSpace3DCost / TaskSpace6DCost / TimeVarying* write into the flat cost block
+    # (weights in the reference's storage order [rotation; position], refs row-major + position, one pose per stage from the user's
+    # TimeVaryingTaskSpace*RefBase), and that pushing a ConfigurationSpaceCost before or after keeps them.  No GPU involved.
+    import os
+    import subprocess
+    from helpers import ROOT, IIWA_URDF
+    exe = str(tmp_path / "task_cost_fields")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests/cpp/task_cost_fields.cpp"),
+                    "-L" + os.path.join(ROOT, "idocp_amd/lib"), "-lidocp_hip", "-Wl,-rpath," + os.path.join(ROOT, "idocp_amd/lib"), "-o", exe],
+                   check=True, capture_output=True)
+    out = subprocess.run([exe, IIWA_URDF], check=True, capture_output=True, text=True).stdout
+    rec = {}
+    for line in out.splitlines():
+        tok = line.split()
+        d, key = {"name": tok[0]}, None
+        for t in tok[1:]:
+            try:
+                d.setdefault(key, []).append(float(t))
+            except ValueError:
+                key = t
+                d[key] = []
+        rec[tok[0]] = d
+    m = iiwa14_model()
+    ref_cost, _ = task_space_problem(m, dim=6)
+    frame = list(ref_cost.task_frame_R) + list(ref_cost.task_frame_p)
+    for name, dim, tv in (("3d", 3, 0), ("6d", 6, 0), ("tv3d", 3, 1), ("tv6d", 6, 1)):
+        r = rec[name]
+        assert r["dim"] == [dim] and r["joint"] == [ref_cost.task_joint] and r["tv"] == [tv] and r["frame"] == frame, name
+    assert rec["3d"]["weight"] == [1, 2, 3, 0, 0, 0] and rec["3d"]["weightf"] == [4, 5, 6, 0, 0, 0]
+    assert rec["3d"]["ref"][9:] == [0.1, 0.2, 0.3] and rec["3d"]["vweight"] == [0.5] and rec["3d"]["refs"] == []
+    # set_q_6d_weight(position, rotation) -> [rotation; position]  (task_space_6d_cost.cpp:48-60)
+    assert rec["6d"]["weight"] == [7, 8, 9, 1, 2, 3] and rec["6d"]["weightf"] == [10, 11, 12, 4, 5, 6] and rec["6d"]["vweight"] == [0.5]
+    assert rec["6d"]["ref"] == [0, -1, 0, 1, 0, 0, 0, 0, 1, 0.1, 0.2, 0.3]
+    eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    assert rec["tv3d"]["refs"] == eye + [1.5, -0.25, 0.75] + eye + [2.0, -0.375, 0.75] + eye + [2.5, -0.5, 0.75]
+    R = [0, 0, 1, 0, 1, 0, -1, 0, 0]
+    assert rec["tv6d"]["weight"] == [100] * 3 + [1000] * 3 and rec["tv6d"]["weightf"] == [1] * 3 + [10] * 3
+    assert np.allclose(rec["tv6d"]["refs"], R + [0.5, 0.1, 0.7] + R + [0.5, 0.15, 0.7] + R + [0.5, 0.2, 0.7], atol=1e-15)
