@@ -567,21 +567,35 @@ __global__ __launch_bounds__(64) void un_riccati_forward_kernel(UnBuffers B, con
   const double* __restrict__ s0 = B.sol + inst * (N + 1) * L::SOL;
   double dq = q0[inst * NV + r] - s0[L::S_Q + r];
   double dv = v0[inst * NV + r] - s0[L::S_V + r];
-  for (int i = 0; i < N; ++i) {
+  // the operands of a stage (row r of K, k, Fq, Fv: 2 NV + 3 doubles per lane) do not depend on the sweep: they are fetched one stage
+  // ahead, so that the chain dq -> da -> dq_next never waits for memory
+  double Kq[NV], Kv[NV], kr, fq, fv;
+  auto fetch = [&](int i, double (&kq)[NV], double (&kv)[NV], double& k0, double& f0, double& f1) {
     const double* __restrict__ gg = B.gain + (inst * N + i) * L::GAIN;
     const double* __restrict__ kk = B.kkt + (inst * N + i) * L::KKT;
-    double da = gg[L::G_k + r];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) { kq[c] = gg[L::G_K + c * NV + r]; kv[c] = gg[L::G_K + NN + c * NV + r]; }
+    k0 = gg[L::G_k + r]; f0 = kk[L::K_FQ + r]; f1 = kk[L::K_FV + r];
+  };
+  fetch(0, Kq, Kv, kr, fq, fv);
+  for (int i = 0; i < N; ++i) {
+    double Kqn[NV], Kvn[NV], krn, fqn, fvn;
+    fetch(i + 1 < N ? i + 1 : i, Kqn, Kvn, krn, fqn, fvn);
+    double da = kr;
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
       const double dqc = __shfl(dq, (g << 3) + c);
       const double dvc = __shfl(dv, (g << 3) + c);
-      da += gg[L::G_K + c * NV + r] * dqc + gg[L::G_K + NN + c * NV + r] * dvc;
+      da += Kq[c] * dqc + Kv[c] * dvc;
     }
     double* __restrict__ dd = B.dir + (inst * (N + 1) + i) * L::SOL;
     if (active) { dd[L::S_Q + r] = dq; dd[L::S_V + r] = dv; dd[L::S_A + r] = da; }
-    const double dqn = kk[L::K_FQ + r] + dq + dt * dv;
-    const double dvn = kk[L::K_FV + r] + dv + dt * da;
+    const double dqn = fq + dq + dt * dv;
+    const double dvn = fv + dv + dt * da;
     dq = dqn; dv = dvn;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) { Kq[c] = Kqn[c]; Kv[c] = Kvn[c]; }
+    kr = krn; fq = fqn; fv = fvn;
   }
   double* __restrict__ dd = B.dir + (inst * (N + 1) + N) * L::SOL;
   if (active) { dd[L::S_Q + r] = dq; dd[L::S_V + r] = dv; }
