@@ -257,14 +257,19 @@ __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B, double*
 // K7.  One wavefront per stage.  EVERY global read of the stage (MJtJinv and the small blocks behind it in the exp record: Qaa, Qff,
 // MJtJinv_IDC, laf, lu_passive, Quu_passive, Qxu_passive, Fqq_prev_inv, contiguous; the direction and solution records, slack and
 // dual, dgmm of the next stage) is issued at the top with 16-byte loads and staged through LDS: one trip to memory per stage
-// instead of a chain of dependent ones.
+// instead of a chain of dependent ones.  The kernel is bound by the bytes its resident wavefronts keep in flight (adding 4 kB of LDS
+// per wavefront, i.e. seven instead of nine of them per CU, took it from 0.65 to 0.75 ms), so LDS is kept small: MJtJinv, which is
+// symmetric, is staged as its lower triangle (3.7 instead of 7.2 kB), and slack / dual stay in the registers of the lane that owns the row.
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
   constexpr int MJL = NVF * NVF, TO = L::E_QAA, TL = L::E_FQQPI + 36 - L::E_QAA;
   static_assert(MJL % 2 == 0 && TO % 2 == 0 && TL % 2 == 0 && L::E_MJ == 0 && L::DIR % 2 == 0 && L::SOL % 2 == 0 && L::CON % 2 == 0, "16-byte loads");
-  __shared__ __attribute__((aligned(16))) double mj[MJL], tl[TL], dr[L::DIR], sr[L::SOL], slk[L::CON], dul[L::CON];
+  constexpr int TRI = NVF * (NVF + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double mjt[TRI], tl[TL], dr[L::DIR], sr[L::SOL];
+  auto mj = [&](int r, int c) -> double { return r >= c ? mjt[r * (r + 1) / 2 + c] : mjt[c * (c + 1) / 2 + r]; };      // MJtJinv(r, c)
+  static_assert(L::NCON <= 128, "two IPM rows per lane");
   __shared__ double dgn[NV], laf[NVF + 2], dbm[NVF + 2], nup[6], dmu[NF];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
@@ -283,21 +288,35 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   double* __restrict__ s = B.sol + rec * L::SOL;
   double* __restrict__ slack = B.slack + rec * L::CON;
   double* __restrict__ dual = B.dual + rec * L::CON;
-  ex_d2 mw[(MJL / 2 + 63) / 64], tw[(TL / 2 + 63) / 64], dw[(L::DIR / 2 + 63) / 64], sw[(L::SOL / 2 + 63) / 64], kw[(L::CON / 2 + 63) / 64], uw[(L::CON / 2 + 63) / 64];
+  ex_d2 mw[(MJL / 2 + 63) / 64], tw[(TL / 2 + 63) / 64], dw[(L::DIR / 2 + 63) / 64], sw[(L::SOL / 2 + 63) / 64];
+  double sl_r[2] = {1.0, 1.0}, dl_r[2] = {1.0, 1.0};
   if (stage) wideLoad<MJL / 2>(mw, B.exp + rec * L::EXP, lane);
   wideLoad<TL / 2>(tw, B.exp + rec * L::EXP + TO, lane);
   wideLoad<L::DIR / 2>(dw, dd, lane);
   wideLoad<L::SOL / 2>(sw, s, lane);
   double dgn_r = 0.0;
   if (stage) {
-    wideLoad<L::CON / 2>(kw, slack, lane);
-    wideLoad<L::CON / 2>(uw, dual, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { const int row = lane + 64 * t; if (row < L::NCON) { sl_r[t] = slack[row]; dl_r[t] = dual[row]; } }
     // dgmm of the next stage of the chain (backward Euler: of this stage)
     if (lane < NV) dgn_r = B.dir[(b * P->NS + (bwd ? nd->slot : nd->next)) * L::DIR + L::D_GMM + lane];
   }
   const bool bimp = bwd && nd->kind == 1;           // ParNMPC impulse stage (K9i filled the exp record): only the dv rows, dmu from K10b
   const int dimf = nd->dimf, dimvf = bimp ? NV : NV + dimf;
-  if (stage) { wideStoreLds<MJL / 2>(mj, mw, lane); wideStoreLds<L::CON / 2>(slk, kw, lane); wideStoreLds<L::CON / 2>(dul, uw, lane); if (lane < NV) dgn[lane] = dgn_r; }
+  if (stage) {
+    // lower triangle of MJtJinv: the lane holds the elements 2 e, 2 e + 1 of the column-major block
+#pragma unroll
+    for (int t = 0; t < (MJL / 2 + 63) / 64; ++t) {
+      const int e = 2 * (lane + 64 * t);
+      if (e < MJL) {
+        const int c = e / NVF, r = e - c * NVF;            // (r, c) and (r + 1, c) -- or (0, c + 1) at the end of a column
+        if (r >= c) mjt[r * (r + 1) / 2 + c] = mw[t].x;
+        const int r1 = (r + 1 < NVF) ? r + 1 : 0, c1 = (r + 1 < NVF) ? c : c + 1;
+        if (r1 >= c1 && c1 < NVF) mjt[r1 * (r1 + 1) / 2 + c1] = mw[t].y;
+      }
+    }
+    if (lane < NV) dgn[lane] = dgn_r;
+  }
   wideStoreLds<TL / 2>(tl, tw, lane);
   wideStoreLds<L::DIR / 2>(dr, dw, lane);
   wideStoreLds<L::SOL / 2>(sr, sw, lane);
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
 #pragma unroll
       for (int c = 0; c < NX; ++c) acc += tl[L::E_QXUP - TO + c + NX * r] * dx[c];
 #pragma unroll
-      for (int c = 0; c < NV; ++c) acc += dt * mj[r + NVF * c] * dgn[c];
+      for (int c = 0; c < NV; ++c) acc += dt * mj(r, c) * dgn[c];
       const double v = nd->has_u ? -acc / dt : 0.0;
       nup[r] = v; dd[L::D_NUP + r] = v;
     }
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
     if (lane < dimvf) {
       const int r = lane;
       double acc = 0.0;
-      for (int p = 0; p < dimvf; ++p) acc += mj[r + NVF * p] * laf[p];
+      for (int p = 0; p < dimvf; ++p) acc += mj(r, p) * laf[p];
       const double v = -acc / dt;
       dbm[r] = v;
       if (r < NV) dd[L::D_BETA + r] = v;
@@ -367,10 +386,13 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   }
   // ---- IPM slack / dual update (needs the pre-update primal variables) ----
   if (stage) {
-    for (int row = lane; row < L::NCON; row += 64) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = lane + 64 * t;
+      if (row >= L::NCON) continue;
       double g, dg;
       const bool valid = ipmRow<D>(P, nd, row, sr, dx, dx + NV, du, dfs, &g, &dg);
-      const double sl = slk[row], dl = dul[row];
+      const double sl = sl_r[t], dl = dl_r[t];
       double dslack, ddual;
       if (valid) {
         const double res = g + sl, duality = sl * dl - P->barrier;
