@@ -46,7 +46,7 @@ __device__ __forceinline__ bool ocpRowValid(const OcpProblem* __restrict__ P, in
 
 // SFP: number of contact rows the LDS blocks are laid out for (= leading dimension of J, Qff, BL, SM; NV + SFP for the
 // (a, f)-sized blocks).  D::NF in general; the instantiations with a compile-time contact count use that count, which
-// takes the footprint from 38.7 kB (12 rows) to 30.9 kB (6 rows): a fifth workgroup per CU.
+// takes the footprint from 38.7 kB (12 rows) to 35.0 kB (6 rows; the RNEA scratch that lives in MJ .. MJD pads the narrow layout).
 template <typename D, int SFP = D::NF>
 struct CondenseSmem {
   using L = OcpLayout<D>;
