@@ -88,8 +88,19 @@ template <typename T> __device__ __forceinline__ Vec3<T> mulT(const Mat3<T>& R, 
 }
 
 // liMi rotation of a revolute joint: R = P * Rot(axis, q), from cached cos/sin.
-template <typename T>
+template <typename T, bool ZAX = false>
 __device__ __forceinline__ void revoluteRotation(const double* __restrict__ P, const double* __restrict__ u, T c, T s, Mat3<T>& R) {
+  // joint axis = +z (every joint of the iiwa14 chain; ZAX: known at compile time, else a uniform branch on scalar loads): Rot(z, q) only
+  // mixes the first two columns of P -- 12 multiply-adds instead of ~70
+  if (ZAX || (u[0] == 0.0 && u[1] == 0.0 && u[2] == 1.0)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      R.m[3 * i] = P[3 * i] * c + P[3 * i + 1] * s;
+      R.m[3 * i + 1] = P[3 * i + 1] * c - P[3 * i] * s;
+      R.m[3 * i + 2] = T(P[3 * i + 2]);
+    }
+    return;
+  }
   const T t = 1.0 - c;
   T J[9];
   J[0] = c + t * (u[0] * u[0]);        J[1] = t * (u[0] * u[1]) - s * u[2]; J[2] = t * (u[0] * u[2]) + s * u[1];
@@ -138,7 +149,9 @@ __device__ __forceinline__ void inertiaMul(const DevModel* __restrict__ m, int i
 // every joint's rotation and model constants to the top of a 20k-instruction
 // block (450+ VGPRs, 160 KB of code, far beyond the instruction cache); rolled,
 // the body is ~1.5k instructions and the live state is the recursion state.
-template <int NJ>
+// ZAX: every joint axis is +z (checked by the host, unocp_capi.hip): S qd = (0, 0, qd), so the joint-velocity products and the
+// projection tau_i = S_i . f_i lose their zero terms at compile time.
+template <int NJ, bool ZAX = false>
 __device__ __forceinline__ void rneaChain(const DevModel* m, const double* cs, const double* qdn,
                                           const double* qddn, int kind, int k, bool write_nominal,
                                           double* tau_v, double* tau_d) {
@@ -153,7 +166,7 @@ __device__ __forceinline__ void rneaChain(const DevModel* m, const double* cs, c
     const T qdi(qdn[i], (mine && kind == 1) ? 1.0 : 0.0);
     const T qddi(qddn[i], (mine && kind == 2) ? 1.0 : 0.0);
     Mat3<T> R;
-    revoluteRotation<T>(m->R[i], m->axis[i], cqi, sqi, R);
+    revoluteRotation<T, ZAX>(m->R[i], m->axis[i], cqi, sqi, R);
     const double* p = m->p[i];
     const double* u = m->axis[i];
     // motion transform into the child frame: w = R^T w_p ; v = R^T (v_p + w_p x p)
@@ -161,12 +174,20 @@ __device__ __forceinline__ void rneaChain(const DevModel* m, const double* cs, c
     const Vec3<T> vc = mulT(R, v + crossVC<T>(w, p));
     const Vec3<T> bwc = mulT(R, bw);
     const Vec3<T> blc = mulT(R, bl + crossVC<T>(bw, p));
-    const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
-    w = wc + vJ;
-    v = vc;
-    // a_i = X a_p + S qdd + v_i x (S qd)
-    bw = bwc + mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) + cross(w, vJ);
-    bl = blc + cross(v, vJ);
+    if (ZAX) {
+      // S qd = (0, 0, qd), x (S qd) = (y qd, -x qd, 0)
+      w = wc; w.z = w.z + qdi;
+      v = vc;
+      bw = mk<T>(bwc.x + w.y * qdi, bwc.y - w.x * qdi, bwc.z + qddi);
+      bl = mk<T>(blc.x + v.y * qdi, blc.y - v.x * qdi, blc.z);
+    } else {
+      const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
+      w = wc + vJ;
+      v = vc;
+      // a_i = X a_p + S qdd + v_i x (S qd)
+      bw = bwc + mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) + cross(w, vJ);
+      bl = blc + cross(v, vJ);
+    }
   }
   Vec3<T> Fl = mk<T>(0.0, 0.0, 0.0), Fn = Fl;
 #pragma unroll 1
@@ -177,7 +198,7 @@ __device__ __forceinline__ void rneaChain(const DevModel* m, const double* cs, c
     inertiaMul<T>(m, i, bl, bw, f, n);
     Fl = Fl + f + cross(w, hl);
     Fn = Fn + n + cross(w, hn) + cross(v, hl);
-    const T ti = u[0] * Fn.x + u[1] * Fn.y + u[2] * Fn.z;
+    const T ti = ZAX ? Fn.z : u[0] * Fn.x + u[1] * Fn.y + u[2] * Fn.z;
     tau_d[i] = ti.d;
     if (write_nominal) tau_v[i] = ti.v;
     if (i > 0) {
@@ -187,17 +208,24 @@ __device__ __forceinline__ void rneaChain(const DevModel* m, const double* cs, c
       const T qdi(qdn[i], (mine && kind == 1) ? 1.0 : 0.0);
       const T qddi(qddn[i], (mine && kind == 2) ? 1.0 : 0.0);
       Mat3<T> R;
-      revoluteRotation<T>(m->R[i], m->axis[i], cqi, sqi, R);
+      revoluteRotation<T, ZAX>(m->R[i], m->axis[i], cqi, sqi, R);
       const double* p = m->p[i];
       // force into the parent frame: f_p = R f ; n_p = R n + p x (R f)
       const Vec3<T> Rf = mul(R, Fl);
       Fn = mul(R, Fn) + crossC<T>(p, Rf);
       Fl = Rf;
       // undo the kinematic step, then map the motion back to the parent frame
-      const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
-      const Vec3<T> bwc = bw - mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) - cross(w, vJ);
-      const Vec3<T> blc = bl - cross(v, vJ);
-      const Vec3<T> wc = w - vJ;
+      Vec3<T> bwc, blc, wc;
+      if (ZAX) {
+        bwc = mk<T>(bw.x - w.y * qdi, bw.y + w.x * qdi, bw.z - qddi);
+        blc = mk<T>(bl.x - v.y * qdi, bl.y + v.x * qdi, bl.z);
+        wc = w; wc.z = wc.z - qdi;
+      } else {
+        const Vec3<T> vJ = mk<T>(u[0] * qdi, u[1] * qdi, u[2] * qdi);
+        bwc = bw - mk<T>(u[0] * qddi, u[1] * qddi, u[2] * qddi) - cross(w, vJ);
+        blc = bl - cross(v, vJ);
+        wc = w - vJ;
+      }
       w = mul(R, wc);
       v = mul(R, v) - crossVC<T>(w, p);
       bw = mul(R, bwc);

@@ -228,6 +228,8 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     if (hipMemcpyAsync(B.task_ref, refs.data(), refs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) { set_last_error("hipMemcpy failed"); return fail(IDOCP_E_DEVICE); }
   }
+  B.zaxes = 1;
+  for (int i = 0; i < model->njoints; ++i) if (!(model->axis[i][0] == 0.0 && model->axis[i][1] == 0.0 && model->axis[i][2] == 1.0)) B.zaxes = 0;
   DevModel dm; toDevModel(*model, dm);
   UnProblem up; std::memset(&up, 0, sizeof(up));
   up.N = N; up.batch = batch; up.T = T; up.dt = dt > 0.0 ? dt : T / N;

@@ -100,6 +100,7 @@ struct UnBuffers {
   double* aux;         // [batch][N+1][AUX]
   double* xres;        // [batch][N+1][XRES]
   double* xprev;       // [batch][2 NV]  shard with has_prev: corrected (q, v) of the left neighbour's last stage
+  int zaxes;             // host-side: every joint axis of the chain is +z (selects the compile-time variant of the rigid-body sweep)
   // task-space cost (null / 0 without one)
   int task;              // host-side copy of prob->task.dim != 0: selects the kernel instantiations
   int task_stride;       // UnLayout<NV>::TASK for the kernels that are not templated on NV

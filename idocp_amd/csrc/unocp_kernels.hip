@@ -70,7 +70,8 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
 // equation couples to the PREVIOUS stage (the measured state q0, v0 for stage 0), the last stage carries the terminal cost.
 // TASK: the cost carries a TaskSpace3DCost / TaskSpace6DCost (dev_task.hpp); lane (0, k) adds dt JJ^T W diff to lq[k] and
 // column k of dt JJ^T W JJ to Qqq.
-template <int NV, int MODE, bool BWD = false, bool TASK = false>
+// ZAX: every joint axis of the chain is +z (iiwa14): the compile-time variant of the rigid-body sweep (dev_rbd.hpp).
+template <int NV, int MODE, bool BWD = false, bool TASK = false, bool ZAX = false>
 __global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
                                                           const double* __restrict__ v0 = nullptr) {
   using L = UnLayout<NV>;
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const 
   WAVE_SYNC();
   // each lane writes its column d tau / d seed straight into the LDS copy of
   // dID/d(q|v|a); the seed-0 lane also writes the nominal tau
-  rneaChain<NV>(B.model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, (g0 < SPW) && seed == 0, &s_tau[g][0],
-                (g0 < SPW) ? &s_dID[g][kind][k * NV] : &s_dummy[0]);
+  rneaChain<NV, ZAX>(B.model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, (g0 < SPW) && seed == 0, &s_tau[g][0],
+                     (g0 < SPW) ? &s_dID[g][kind][k * NV] : &s_dummy[0]);
   WAVE_SYNC();
   double tau_d[NV], ID[NV];
 #pragma unroll
@@ -1318,18 +1319,29 @@ template <int NV>
 void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t st) {
     constexpr int SPW = 64 / (3 * NV);
     const long units = batch * N;
-    if (B.task) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
-    else hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+    const dim3 grid((unsigned)((units + SPW - 1) / SPW));
+    const double* none = nullptr;
+    if (B.task) {
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true, true>), grid, dim3(64), 0, st, B, none, none);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true>), grid, dim3(64), 0, st, B, none, none);
+    } else {
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, false, true>), grid, dim3(64), 0, st, B, none, none);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0>), grid, dim3(64), 0, st, B, none, none);
+    }
   }
 template <int NV>
 void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t st) {
     constexpr int SPW = 64 / (3 * NV);
     const long units = batch * N;
+    const dim3 grid((unsigned)((units + SPW - 1) / SPW));
+    const double* none = nullptr;
     if (B.task) {
-      hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true, true>), grid, dim3(64), 0, st, B, none, none);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true>), grid, dim3(64), 0, st, B, none, none);
       hipLaunchKernelGGL((un_task_terminal_kernel<NV, false>), dim3((unsigned)((batch + 7) / 8)), dim3(64), 0, st, B);
     } else {
-      hipLaunchKernelGGL((un_linearize_kernel<NV, 1>), dim3((unsigned)((units + SPW - 1) / SPW)), dim3(64), 0, st, B);
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, false, true>), grid, dim3(64), 0, st, B, none, none);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 1>), grid, dim3(64), 0, st, B, none, none);
     }
     hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
   }
@@ -1390,7 +1402,10 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
   constexpr int SPW = 64 / (3 * NV);
   const unsigned inst_blocks = (unsigned)((batch + 3) / 4);
   switch (phase) {
-    case 0: hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0); break;
+    case 0:
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true, false, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+      break;
     case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + 2) / 3)), dim3(192), 0, st, B); break;
     case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
     case 3: hipLaunchKernelGGL((unparnmpc_backward_parallel_kernel<NV>), dim3((unsigned)((batch * N + 1) / 2)), dim3(64), 0, st, B); break;
@@ -1405,7 +1420,8 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
 template <int NV>
 void UnLaunch<NV>::parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
   constexpr int SPW = 64 / (3 * NV);
-  hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+  if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true, false, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+  else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
   hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
 }
 template <int NV>
