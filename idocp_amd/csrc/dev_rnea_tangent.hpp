@@ -53,6 +53,69 @@ __device__ __forceinline__ void inertia(double mass, V3 mc, const double* I, V3 
   const V3 mcxv = cross(mc, v);
   n = v3(I[0] * w.x + I[1] * w.y + I[2] * w.z + mcxv.x, I[1] * w.x + I[3] * w.y + I[4] * w.z + mcxv.y, I[2] * w.x + I[4] * w.y + I[5] * w.z + mcxv.z);
 }
+// The transform of one revolute joint as the sweeps use it: R = P Rot(u, q) and the axis u.
+// AX = -1: general (the 3 x 3 record and the axis vector from LDS).  AX = 0 / 1: the placement rotation P is the identity and the axis is
+// +x / +y (every leg joint of ANYmal: HAA about x, HFE and KFE about y), so R^T a, R a, u x a, u . a and a x (k u) lose their zero
+// terms: two numbers (cos, sin) instead of twelve come from LDS and a rotation is four multiply-adds instead of nine.
+template <int AX> struct JointFrame;
+template <> struct JointFrame<-1> {
+  const double* R; V3 u;
+  __device__ __forceinline__ explicit JointFrame(const double* jr, int jR, int jU) : R(jr + jR), u(ld3(jr + jU)) {}
+  __device__ __forceinline__ V3 mulT(V3 a) const { return rt::mulT(R, a); }
+  __device__ __forceinline__ V3 mul(V3 a) const { return rt::mul(R, a); }
+  __device__ __forceinline__ V3 crossU(V3 a) const { return cross(u, a); }             // u x a
+  __device__ __forceinline__ V3 crossUk(V3 a, double k) const { return k * cross(u, a); }      // k (u x a)
+  __device__ __forceinline__ double dotU(V3 a) const { return dot(u, a); }
+  __device__ __forceinline__ V3 timesU(double k) const { return k * u; }
+  __device__ __forceinline__ V3 crossKU(V3 a, double k) const { return cross(a, k * u); }      // a x (k u)
+};
+template <> struct JointFrame<0> {      // R = [1 0 0; 0 c -s; 0 s c]
+  double c, s;
+  __device__ __forceinline__ explicit JointFrame(const double* jr, int jR, int) : c(jr[jR + 4]), s(jr[jR + 7]) {}
+  __device__ __forceinline__ V3 mulT(V3 a) const { return v3(a.x, c * a.y + s * a.z, c * a.z - s * a.y); }
+  __device__ __forceinline__ V3 mul(V3 a) const { return v3(a.x, c * a.y - s * a.z, s * a.y + c * a.z); }
+  __device__ __forceinline__ V3 crossU(V3 a) const { return v3(0.0, -a.z, a.y); }
+  __device__ __forceinline__ V3 crossUk(V3 a, double k) const { return v3(0.0, -(a.z * k), a.y * k); }
+  __device__ __forceinline__ double dotU(V3 a) const { return a.x; }
+  __device__ __forceinline__ V3 timesU(double k) const { return v3(k, 0.0, 0.0); }
+  __device__ __forceinline__ V3 crossKU(V3 a, double k) const { return v3(0.0, a.z * k, -(a.y * k)); }
+};
+template <> struct JointFrame<1> {      // R = [c 0 s; 0 1 0; -s 0 c]
+  double c, s;
+  __device__ __forceinline__ explicit JointFrame(const double* jr, int jR, int) : c(jr[jR]), s(jr[jR + 2]) {}
+  __device__ __forceinline__ V3 mulT(V3 a) const { return v3(c * a.x - s * a.z, a.y, s * a.x + c * a.z); }
+  __device__ __forceinline__ V3 mul(V3 a) const { return v3(c * a.x + s * a.z, a.y, c * a.z - s * a.x); }
+  __device__ __forceinline__ V3 crossU(V3 a) const { return v3(a.z, 0.0, -a.x); }
+  __device__ __forceinline__ V3 crossUk(V3 a, double k) const { return v3(a.z * k, 0.0, -(a.x * k)); }
+  __device__ __forceinline__ double dotU(V3 a) const { return a.y; }
+  __device__ __forceinline__ V3 timesU(double k) const { return v3(0.0, k, 0.0); }
+  __device__ __forceinline__ V3 crossKU(V3 a, double k) const { return v3(-(a.z * k), 0.0, a.x * k); }
+};
+template <int AX> struct AxisTag { static constexpr int value = AX; };
+// Walks the joints of a leg outward (FWD) or inward with the frame type of each joint: XYY = the ANYmal pattern (joint 0 about x,
+// the others about y), else the general frame for every joint.  The loops stay rolled (see dev_rbd.hpp on why).
+template <bool XYY, bool FWD, int LJ, typename Body>
+__device__ __forceinline__ void forEachLegJoint(Body body) {
+  if constexpr (XYY) {
+    if constexpr (FWD) {
+      body(AxisTag<0>{}, 0);
+#pragma unroll 1
+      for (int j = 1; j < LJ; ++j) body(AxisTag<1>{}, j);
+    } else {
+#pragma unroll 1
+      for (int j = LJ - 1; j >= 1; --j) body(AxisTag<1>{}, j);
+      body(AxisTag<0>{}, 0);
+    }
+  } else {
+    if constexpr (FWD) {
+#pragma unroll 1
+      for (int j = 0; j < LJ; ++j) body(AxisTag<-1>{}, j);
+    } else {
+#pragma unroll 1
+      for (int j = LJ - 1; j >= 0; --j) body(AxisTag<-1>{}, j);
+    }
+  }
+}
 }  // namespace rt
 
 // LDS scratch of one stage (doubles).
@@ -142,7 +205,7 @@ __device__ __forceinline__ void rneaBaseRotation(const double* q, double* Rw) {
 
 // ---- nominal sweep, MOTION half: lane `who` < NL walks its leg outward (velocities, accelerations in the gravity field) and back
 // (forces, tau), lane NL does the base body.  Reads LDS only. ----
-template <typename D>
+template <typename D, bool XYY = false>
 __device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who, double* sc, const RneaOut& out) {
   using S = RneaScratch<D>;
   using namespace rt;
@@ -167,20 +230,20 @@ __device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who,
     return;
   }
   const int leg = who;
-#pragma unroll 1
-  for (int j = 0; j < LJ; ++j) {
+  forEachLegJoint<XYY, true, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     const int dof = 6 + leg * LJ + j;
     double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const double* R = jr + S::J_R;
-    const V3 p = ld3(jr + S::J_P), u = ld3(jr + S::J_U);
-    const V3 wc = mulT(R, w), vc = mulT(R, v + cross(w, p)), bwc = mulT(R, bw), blc = mulT(R, bl + cross(bw, p));
-    const V3 vJ = sv[dof] * u;
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
+    const V3 p = ld3(jr + S::J_P);
+    const V3 wc = F.mulT(w), vc = F.mulT(v + cross(w, p)), bwc = F.mulT(bw), blc = F.mulT(bl + cross(bw, p));
+    const V3 vJ = F.timesU(sv[dof]);
     w = wc + vJ; v = vc;
-    bw = bwc + sa[dof] * u + cross(w, vJ);
-    bl = blc + cross(v, vJ);
+    bw = bwc + F.timesU(sa[dof]) + F.crossKU(w, sv[dof]);
+    bl = blc + F.crossKU(v, sv[dof]);
     st3(jr + S::J_WC, wc); st3(jr + S::J_VC, vc); st3(jr + S::J_BWC, bwc); st3(jr + S::J_BLC, blc);
     st3(jr + S::J_VJ, vJ); st3(jr + S::J_W, w); st3(jr + S::J_BW, bw); st3(jr + S::J_BL, bl);
-  }
+  });
   // ---- contact frame at the foot (tip joint of this leg): the motion-dependent part of the residual (point_contact.hxx:67-87) ----
   double* fr = sc + S::FEET + leg * S::FREC;
   V3 fel = v3(0, 0, 0), fen = fel;
@@ -200,23 +263,24 @@ __device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who,
   }
   // ---- inward sweep: accumulate forces, emit tau ----
   V3 Fl = v3(0, 0, 0) - fel, Fn = v3(0, 0, 0) - fen;
-#pragma unroll 1
-  for (int j = LJ - 1; j >= 0; --j) {
+  forEachLegJoint<XYY, false, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     const int dof = 6 + leg * LJ + j;
     double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
     const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), bwj = ld3(jr + S::J_BW), blj = ld3(jr + S::J_BL);
-    const V3 mc = ld3(jr + S::J_MC), u = ld3(jr + S::J_U), p = ld3(jr + S::J_P);
+    const V3 mc = ld3(jr + S::J_MC), p = ld3(jr + S::J_P);
     V3 hl, hn, f, n;
     inertia(jr[S::J_MASS], mc, jr + S::J_IO, vj, wj, hl, hn);
     inertia(jr[S::J_MASS], mc, jr + S::J_IO, blj, bwj, f, n);
     Fl = Fl + f + cross(wj, hl);
     Fn = Fn + n + cross(wj, hn) + cross(vj, hl);
-    out.idc[dof] = dot(u, Fn);
+    out.idc[dof] = F.dotU(Fn);
     st3(jr + S::J_HL, hl); st3(jr + S::J_HN, hn); st3(jr + S::J_FL, Fl); st3(jr + S::J_FN, Fn);
-    const V3 Rf = mul(jr + S::J_R, Fl);
-    Fn = mul(jr + S::J_R, Fn) + cross(p, Rf);
+    const V3 Rf = F.mul(Fl);
+    Fn = F.mul(Fn) + cross(p, Rf);
     Fl = Rf;
-  }
+  });
   double* bn = sc + S::BN + 6 * (1 + leg);
   st3(bn, Fl); st3(bn + 3, Fn);
 }
@@ -224,7 +288,7 @@ __device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who,
 // ---- nominal sweep, POSE half (runs on another wavefront next to the motion half): world rotation and position along the leg;
 // leaves zc = R_w,child^T e_z per joint and, at the foot, R_wf Rc and the pose-dependent part of the residual
 //   Rc^T (g_z z_f)  [takes the gravity field out of the frame acceleration]  +  (1 / D^2) (p_foot - p_contact) ----
-template <typename D>
+template <typename D, bool XYY = false>
 __device__ __forceinline__ void rneaNominalPose(double gz, double wp, const OcpNode* __restrict__ nd, int leg, double* sc) {
   using S = RneaScratch<D>;
   using namespace rt;
@@ -234,20 +298,19 @@ __device__ __forceinline__ void rneaNominalPose(double gz, double wp, const OcpN
   double Rw[9];
   rneaBaseRotation(in, Rw);
   V3 pw = ld3(in);
-#pragma unroll 1
-  for (int j = 0; j < LJ; ++j) {
+  forEachLegJoint<XYY, true, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const double* R = jr + S::J_R;
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
     pw = pw + mul(Rw, ld3(jr + S::J_P));
-    double Rn[9];
+    // Rw <- Rw R: row r of the product is (R^T applied to row r of Rw)
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Rn[3 * r + c] = Rw[3 * r] * R[c] + Rw[3 * r + 1] * R[3 + c] + Rw[3 * r + 2] * R[6 + c];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) Rw[e] = Rn[e];
+    for (int r = 0; r < 3; ++r) {
+      const V3 row = F.mulT(v3(Rw[3 * r], Rw[3 * r + 1], Rw[3 * r + 2]));
+      Rw[3 * r] = row.x; Rw[3 * r + 1] = row.y; Rw[3 * r + 2] = row.z;
+    }
     st3(jr + S::J_ZC, v3(Rw[6], Rw[7], Rw[8]));
-  }
+  });
   double* fr = sc + S::FEET + leg * S::FREC;
   if (fr[S::F_ACT] != 0.0) {
     const double* Rc = fr + S::F_RC;
@@ -263,7 +326,7 @@ __device__ __forceinline__ void rneaNominalPose(double gz, double wp, const OcpN
 }
 
 // ---- one tangent item = (seed, leg): columns of dID and dC for the rows of this leg, and the base-force tangent ----
-template <typename D>
+template <typename D, bool XYY = false>
 __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, double* sc, const RneaOut& out) {
   using S = RneaScratch<D>;
   using namespace rt;
@@ -292,24 +355,30 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
     st3(o + 3, dn + cross(dw, hn0) + cross(w0, dhn) + cross(dv, hl0) + cross(v0, dhl));
   }
   // ---- outward along the leg ----
-#pragma unroll 1
-  for (int j = 0; j < LJ; ++j) {
+  forEachLegJoint<XYY, true, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     const int dof = 6 + leg * LJ + j;
     const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
     const bool mine = (k == dof);
     const double sq = (mine && kind == 0) ? 1.0 : 0.0, sv = (mine && kind == 1) ? 1.0 : 0.0, sa = (mine && kind == 2) ? 1.0 : 0.0;
-    const double* R = jr + S::J_R;
-    const V3 u = ld3(jr + S::J_U), p = ld3(jr + S::J_P), vJ = ld3(jr + S::J_VJ);
-    const V3 dwc = mulT(R, dw) - sq * cross(u, ld3(jr + S::J_WC));
-    const V3 dvc = mulT(R, dv + cross(dw, p)) - sq * cross(u, ld3(jr + S::J_VC));
-    const V3 dbwc = mulT(R, dbw) - sq * cross(u, ld3(jr + S::J_BWC));
-    const V3 dblc = mulT(R, dbl + cross(dbw, p)) - sq * cross(u, ld3(jr + S::J_BLC));
-    dz = mulT(R, dz) - sq * cross(u, ld3(jr + S::J_ZC));
-    const V3 dvJ = sv * u;
-    dw = dwc + dvJ; dv = dvc;
-    dbw = dbwc + sa * u + cross(dw, vJ) + cross(ld3(jr + S::J_W), dvJ);
-    dbl = dblc + cross(dv, vJ) + cross(ld3(jr + S::J_VC), dvJ);
-  }
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
+    const V3 p = ld3(jr + S::J_P);
+    const double qd = AX < 0 ? 0.0 : jr[S::J_VJ + (AX < 0 ? 0 : AX)];      // S qd = qd u (coordinate axis: one component)
+    const V3 dwc = F.mulT(dw) - F.crossUk(ld3(jr + S::J_WC), sq);
+    const V3 dvc = F.mulT(dv + cross(dw, p)) - F.crossUk(ld3(jr + S::J_VC), sq);
+    const V3 dbwc = F.mulT(dbw) - F.crossUk(ld3(jr + S::J_BWC), sq);
+    const V3 dblc = F.mulT(dbl + cross(dbw, p)) - F.crossUk(ld3(jr + S::J_BLC), sq);
+    dz = F.mulT(dz) - F.crossUk(ld3(jr + S::J_ZC), sq);
+    dw = dwc + F.timesU(sv); dv = dvc;
+    if constexpr (AX < 0) {
+      const V3 vJ = ld3(jr + S::J_VJ), dvJ = F.timesU(sv);
+      dbw = dbwc + F.timesU(sa) + cross(dw, vJ) + cross(ld3(jr + S::J_W), dvJ);
+      dbl = dblc + cross(dv, vJ) + cross(ld3(jr + S::J_VC), dvJ);
+    } else {
+      dbw = dbwc + F.timesU(sa) + F.crossKU(dw, qd) + F.crossKU(ld3(jr + S::J_W), sv);
+      dbl = dblc + F.crossKU(dv, qd) + F.crossKU(ld3(jr + S::J_VC), sv);
+    }
+  });
   // ---- contact frame at the foot: Baumgarte derivative column (point_contact.hxx:117-143) without its position term ----
   const double* fr = sc + S::FEET + leg * S::FREC;
   if (fr[S::F_ACT] != 0.0) {
@@ -322,35 +391,42 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
   }
   // ---- inward sweep: force tangents, tau tangents, undo the kinematic steps ----
   V3 dFl = zero, dFn = zero;
-#pragma unroll 1
-  for (int j = LJ - 1; j >= 0; --j) {
+  forEachLegJoint<XYY, false, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     const int dof = 6 + leg * LJ + j;
     const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
     const bool mine = (k == dof);
     const double sq = (mine && kind == 0) ? 1.0 : 0.0, sv = (mine && kind == 1) ? 1.0 : 0.0, sa = (mine && kind == 2) ? 1.0 : 0.0;
-    const double* R = jr + S::J_R;
-    const V3 u = ld3(jr + S::J_U), p = ld3(jr + S::J_P), mc = ld3(jr + S::J_MC);
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
+    const V3 p = ld3(jr + S::J_P), mc = ld3(jr + S::J_MC);
     const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), hl = ld3(jr + S::J_HL), hn = ld3(jr + S::J_HN);
     V3 dhl, dhn, df, dn;
     inertia(jr[S::J_MASS], mc, jr + S::J_IO, dv, dw, dhl, dhn);
     inertia(jr[S::J_MASS], mc, jr + S::J_IO, dbl, dbw, df, dn);
     dFl = dFl + df + cross(dw, hl) + cross(wj, dhl);
     dFn = dFn + dn + cross(dw, hn) + cross(wj, dhn) + cross(dv, hl) + cross(vj, dhl);
-    colp[dof] = dot(u, dFn);
-    const V3 dRf = mul(R, dFl + sq * cross(u, ld3(jr + S::J_FL)));
-    dFn = mul(R, dFn + sq * cross(u, ld3(jr + S::J_FN))) + cross(p, dRf);
+    colp[dof] = F.dotU(dFn);
+    const V3 dRf = F.mul(dFl + F.crossUk(ld3(jr + S::J_FL), sq));
+    dFn = F.mul(dFn + F.crossUk(ld3(jr + S::J_FN), sq)) + cross(p, dRf);
     dFl = dRf;
     if (j > 0) {
-      const V3 vJ = ld3(jr + S::J_VJ), dvJ = sv * u;
-      const V3 dbwc = dbw - sa * u - cross(dw, vJ) - cross(wj, dvJ);
-      const V3 dblc = dbl - cross(dv, vJ) - cross(vj, dvJ);
-      const V3 dwc = dw - dvJ;
-      dw = mul(R, dwc + sq * cross(u, ld3(jr + S::J_WC)));
-      dv = mul(R, dv + sq * cross(u, ld3(jr + S::J_VC))) - cross(dw, p);
-      dbw = mul(R, dbwc + sq * cross(u, ld3(jr + S::J_BWC)));
-      dbl = mul(R, dblc + sq * cross(u, ld3(jr + S::J_BLC))) - cross(dbw, p);
+      V3 dbwc, dblc;
+      if constexpr (AX < 0) {
+        const V3 vJ = ld3(jr + S::J_VJ), dvJ = F.timesU(sv);
+        dbwc = dbw - F.timesU(sa) - cross(dw, vJ) - cross(wj, dvJ);
+        dblc = dbl - cross(dv, vJ) - cross(vj, dvJ);
+      } else {
+        const double qd = jr[S::J_VJ + (AX < 0 ? 0 : AX)];
+        dbwc = dbw - F.timesU(sa) - F.crossKU(dw, qd) - F.crossKU(wj, sv);
+        dblc = dbl - F.crossKU(dv, qd) - F.crossKU(vj, sv);
+      }
+      const V3 dwc = dw - F.timesU(sv);
+      dw = F.mul(dwc + F.crossUk(ld3(jr + S::J_WC), sq));
+      dv = F.mul(dv + F.crossUk(ld3(jr + S::J_VC), sq)) - cross(dw, p);
+      dbw = F.mul(dbwc + F.crossUk(ld3(jr + S::J_BWC), sq));
+      dbl = F.mul(dblc + F.crossUk(ld3(jr + S::J_BLC), sq)) - cross(dbw, p);
     }
-  }
+  });
   double* o = sc + S::BT + 6 * item;
   st3(o, dFl); st3(o + 3, dFn);
 }
@@ -359,7 +435,7 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
 // Their columns are dID/da = M (the joint-space inertia matrix) and dC/da = J (the contact Jacobian) -- all that
 // Robot::computeMJtJinv needs, so the wavefront that runs these items goes straight on to the inverses while another
 // wavefront is still busy with the q and v seeds. ----
-template <typename D>
+template <typename D, bool XYY = false>
 __device__ __forceinline__ void rneaTangentItemA(int item, double* sc, const RneaOut& out) {
   using S = RneaScratch<D>;
   using namespace rt;
@@ -379,38 +455,38 @@ __device__ __forceinline__ void rneaTangentItemA(int item, double* sc, const Rne
     double* o = sc + S::BOWN + 6 * j0;
     st3(o, df); st3(o + 3, dn);
   }
-#pragma unroll 1
-  for (int j = 0; j < LJ; ++j) {
+  forEachLegJoint<XYY, true, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     const int dof = 6 + leg * LJ + j;
     const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const double* R = jr + S::J_R;
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
     const double sa = (k == dof) ? 1.0 : 0.0;
     const V3 t = dbl + cross(dbw, ld3(jr + S::J_P));
-    dbw = mulT(R, dbw) + sa * ld3(jr + S::J_U);
-    dbl = mulT(R, t);
-  }
+    dbw = F.mulT(dbw) + F.timesU(sa);
+    dbl = F.mulT(t);
+  });
   const double* fr = sc + S::FEET + leg * S::FREC;
   if (fr[S::F_ACT] != 0.0) st3(colc + (int)fr[S::F_ROW], mulT(fr + S::F_RC, dbl + cross(dbw, ld3(fr + S::F_PC))));      // column of the frame Jacobian
   V3 dFl = zero, dFn = zero;
-#pragma unroll 1
-  for (int j = LJ - 1; j >= 0; --j) {
+  forEachLegJoint<XYY, false, LJ>([&](auto tag, int j) {
+    constexpr int AX = decltype(tag)::value;
     const int dof = 6 + leg * LJ + j;
     const double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const double* R = jr + S::J_R;
-    const V3 u = ld3(jr + S::J_U), p = ld3(jr + S::J_P);
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
+    const V3 p = ld3(jr + S::J_P);
     V3 df, dn;
     inertia(jr[S::J_MASS], ld3(jr + S::J_MC), jr + S::J_IO, dbl, dbw, df, dn);
     dFl = dFl + df; dFn = dFn + dn;
-    colp[dof] = dot(u, dFn);
-    const V3 dRf = mul(R, dFl);
-    dFn = mul(R, dFn) + cross(p, dRf);
+    colp[dof] = F.dotU(dFn);
+    const V3 dRf = F.mul(dFl);
+    dFn = F.mul(dFn) + cross(p, dRf);
     dFl = dRf;
     if (j > 0) {
       const double sa = (k == dof) ? 1.0 : 0.0;
-      dbw = mul(R, dbw - sa * u);
-      dbl = mul(R, dbl) - cross(dbw, p);
+      dbw = F.mul(dbw - F.timesU(sa));
+      dbl = F.mul(dbl) - cross(dbw, p);
     }
-  }
+  });
   double* o = sc + S::BT + 6 * item;
   st3(o, dFl); st3(o + 3, dFn);
 }

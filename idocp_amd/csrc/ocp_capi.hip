@@ -651,6 +651,15 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   h->d_cond_pos = reinterpret_cast<int*>(tmp);
   B.cond_pos = h->d_cond_pos;
   B.q_ref = h->d_qref;
+  B.leg_axes_xyy = 1;
+  for (int leg = 0; leg < DQ::NL; ++leg)
+    for (int j = 0; j < DQ::LJ; ++j) {
+      const int ji = 1 + leg * DQ::LJ + j;
+      const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const double ax[3] = {j == 0 ? 1.0 : 0.0, j == 0 ? 0.0 : 1.0, 0.0};
+      for (int k = 0; k < 9; ++k) if (model->plc_R[ji][k] != I3[k]) B.leg_axes_xyy = 0;
+      for (int k = 0; k < 3; ++k) if (model->axis[ji][k] != ax[k]) B.leg_axes_xyy = 0;
+    }
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
   std::memset(&p, 0, sizeof(p));

@@ -91,7 +91,8 @@ struct CondenseSmem {
 // per stage SplitOCP::stageCost without the barrier term (split_ocp.hxx:270-289; the barrier part comes from ocp_trial_kernel) and
 // SplitOCP::constraintViolation (:292-346), |Fx|_1 + dt |[ID - u; C]|_1 + dt |g + slack|_1 + |P|_1; only the NOMINAL rigid-body
 // sweeps run (no tangent items).  Launched on a copy of the buffers whose sol points at the trial iterate.
-template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = false>
+// XYY: the joint axes of the legs are known at compile time (OcpBuffers::leg_axes_xyy, dev_rnea_tangent.hpp JointFrame).
+template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = false, bool XYY = false>
 __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
@@ -263,9 +264,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below), per thread
   double merit_cost = 0.0, merit_viol = 0.0; // MERIT: this thread's share of the stage cost / l1 constraint violation
   if (wave == 0) {
-    if (!impulse) rneaNominalMotion<D>(gz, bwv, lane, sc, out);
+    if (!impulse) rneaNominalMotion<D, XYY>(gz, bwv, lane, sc, out);
   } else if (wave == 1) {
-    if (!impulse) rneaNominalPose<D>(gz, bwp, nd, lane, sc);
+    if (!impulse) rneaNominalPose<D, XYY>(gz, bwp, nd, lane, sc);
   } else if (tid < 128 + NV) {
     // ---- C1, one row of (q, v, a) per thread: cost, state equation, joint limits, switching-constraint multipliers ----
     const int r = tid - 128;
@@ -449,10 +450,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // M^-1 and (J M^-1 J^T)^-1 by Gauss-Jordan on the SPD blocks (the reference uses pinocchio's sparse Cholesky + Eigen::LLT; same
   // inverses up to rounding).  BL, SM live in the block that held the solution / slack / dual copies (dead since C1).
   if (wave == 0) {
-    if (!impulse && lane < RI::NQV) rneaTangentItem<D>(gz, bwv, RI::qv(lane), sc, out);
+    if (!impulse && lane < RI::NQV) rneaTangentItem<D, XYY>(gz, bwv, RI::qv(lane), sc, out);
   } else if (wave == 1) {
     if (!impulse) {
-      if (lane < RI::NA) rneaTangentItemA<D>(RI::a(lane), sc, out);
+      if (lane < RI::NA) rneaTangentItemA<D, XYY>(RI::a(lane), sc, out);
       waveLdsSync();
       rneaAssembleA<D>(lane, sc, out);
       waveLdsSync();
@@ -838,15 +839,17 @@ static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, con
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
-  else if (dimf == D::NF) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0);      // all feet in contact
-  else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
+  else if (dimf == D::NF) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0); }
+  else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0); }
 }
 
 template <typename D>
@@ -863,17 +866,20 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
   // the largest class first; the launches are independent (every stage writes its own records)
-  if (n[1] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]);
-  if (n[0] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]);
-  if (n[2] > 0) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]);
+  if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
+  if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
+  if (n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
 }
 // Line search: cost and l1 violation of every stage of the chain for the iterate Btry.sol points at (Btry.nodes: the chain with the
 // reference's pairing of the successors).  The caller has run the impulse RNEA and the switching kernel on Btry.
@@ -915,13 +921,14 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, -1, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, true, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
   const unsigned stages = (unsigned)(batch * (M - 1));
   hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, B, q0);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0);
-  else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0);
+  else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true, false, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0); }
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);

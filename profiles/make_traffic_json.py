@@ -26,7 +26,7 @@ def per_launch(path, counter):
         if not m:
             continue
         key = m.group(1)
-        if "condense" in key and re.search(r",\s*true", name):
+        if "condense" in key and re.search(r"_kernel<[^,>]+,\s*true", name):      # RESIDUAL is the second template argument
             key += "_residual"
         elif key.startswith("un_linearize") and re.search(r"_kernel<\d+,\s*1\b", name):
             key += "_residual"
