@@ -251,14 +251,15 @@ __device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who,
     const double* Rc = fr + S::F_RC;
     const V3 pc = ld3(fr + S::F_PC);
     const int row = NV + (int)fr[S::F_ROW];
-    const V3 fv = mulT(Rc, v + cross(w, pc)), fw = mulT(Rc, w), fam = mulT(Rc, bl + cross(bw, pc));      // fam: still in the gravity field
+    const V3 fv = XYY ? v + cross(w, pc) : mulT(Rc, v + cross(w, pc)), fw = XYY ? w : mulT(Rc, w),
+             fam = XYY ? bl + cross(bw, pc) : mulT(Rc, bl + cross(bw, pc));      // fam: still in the gravity field
     const V3 wxv = cross(fw, fv);
     out.idc[row] = fam.x + wxv.x + wv * fv.x;
     out.idc[row + 1] = fam.y + wxv.y + wv * fv.y;
     out.idc[row + 2] = fam.z + wxv.z + wv * fv.z;
     st3(fr + S::F_FV, fv); st3(fr + S::F_FW, fw);
     // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
-    fel = mul(Rc, ld3(in + S::I_F + 3 * leg));
+    fel = XYY ? ld3(in + S::I_F + 3 * leg) : mul(Rc, ld3(in + S::I_F + 3 * leg));
     fen = cross(pc, fel);
   }
   // ---- inward sweep: accumulate forces, emit tau ----
@@ -318,8 +319,9 @@ __device__ __forceinline__ void rneaNominalPose(double gz, double wp, const OcpN
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fr[S::F_RWC + 3 * r + c] = Rw[3 * r] * Rc[c] + Rw[3 * r + 1] * Rc[3 + c] + Rw[3 * r + 2] * Rc[6 + c];
-    const V3 g = mulT(Rc, gz * v3(Rw[6], Rw[7], Rw[8]));
+      for (int c = 0; c < 3; ++c)
+        fr[S::F_RWC + 3 * r + c] = XYY ? Rw[3 * r + c] : Rw[3 * r] * Rc[c] + Rw[3 * r + 1] * Rc[3 + c] + Rw[3 * r + 2] * Rc[6 + c];
+    const V3 g = XYY ? gz * v3(Rw[6], Rw[7], Rw[8]) : mulT(Rc, gz * v3(Rw[6], Rw[7], Rw[8]));
     st3(fr + S::F_CP, v3(g.x + wp * (pf.x - nd->contact_point[leg][0]), g.y + wp * (pf.y - nd->contact_point[leg][1]),
                          g.z + wp * (pf.z - nd->contact_point[leg][2])));
   }
@@ -385,7 +387,9 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
     const double* Rc = fr + S::F_RC;
     const V3 pc = ld3(fr + S::F_PC);
     const V3 dal = dbl + gz * dz;
-    const V3 dfv = mulT(Rc, dv + cross(dw, pc)), dfw = mulT(Rc, dw), dfa = mulT(Rc, dal + cross(dbw, pc));
+    // (XYY also promises an identity rotation of the contact frame in its joint, like ANYmal's feet: Rc^T a = a)
+    const V3 dfv = XYY ? dv + cross(dw, pc) : mulT(Rc, dv + cross(dw, pc)), dfw = XYY ? dw : mulT(Rc, dw),
+             dfa = XYY ? dal + cross(dbw, pc) : mulT(Rc, dal + cross(dbw, pc));
     const V3 dc = dfa + cross(ld3(fr + S::F_FW), dfv) + cross(ld3(fr + S::F_FV), dfw) + wv * dfv;
     st3(colc + (int)fr[S::F_ROW], dc);
   }
@@ -466,7 +470,10 @@ __device__ __forceinline__ void rneaTangentItemA(int item, double* sc, const Rne
     dbl = F.mulT(t);
   });
   const double* fr = sc + S::FEET + leg * S::FREC;
-  if (fr[S::F_ACT] != 0.0) st3(colc + (int)fr[S::F_ROW], mulT(fr + S::F_RC, dbl + cross(dbw, ld3(fr + S::F_PC))));      // column of the frame Jacobian
+  if (fr[S::F_ACT] != 0.0) {                                     // column of the frame Jacobian
+    const V3 t = dbl + cross(dbw, ld3(fr + S::F_PC));
+    st3(colc + (int)fr[S::F_ROW], XYY ? t : mulT(fr + S::F_RC, t));
+  }
   V3 dFl = zero, dFn = zero;
   forEachLegJoint<XYY, false, LJ>([&](auto tag, int j) {
     constexpr int AX = decltype(tag)::value;

@@ -660,6 +660,11 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
       for (int k = 0; k < 9; ++k) if (model->plc_R[ji][k] != I3[k]) B.leg_axes_xyy = 0;
       for (int k = 0; k < 3; ++k) if (model->axis[ji][k] != ax[k]) B.leg_axes_xyy = 0;
     }
+  for (int c = 0; c < DQ::NC; ++c) {      // ... and contact frames that are not rotated against their joint
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k) if (model->contact_R[c][k] != I3[k]) B.leg_axes_xyy = 0;
+  }
+  if (std::getenv("IDOCP_GENERAL_AXES")) B.leg_axes_xyy = 0;      // tests: the general instantiations on a model that qualifies for the special ones
   DevModel dm; toDevModelOcp(*model, dm);
   OcpProblem& p = h->prob;
   std::memset(&p, 0, sizeof(p));

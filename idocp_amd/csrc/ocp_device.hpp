@@ -168,7 +168,8 @@ struct OcpBuffers {
   const int* impulse_pos; // chain positions of the impulse stages
   const int* general_pos; // ParNMPC: chain positions of the stages with a general KKT shape (aux with switching rows, impulse)
   const int* cond_pos;    // chain positions grouped by stage class of K5b (OcpLaunch::condenseMixed)
-  int leg_axes_xyy;       // host-side: every leg is (joint about +x, about +y, about +y) with identity placement rotations (ANYmal):
+  int leg_axes_xyy;       // host-side: every leg is (joint about +x, about +y, about +y) with identity placement rotations, and the
+                          // contact frames are not rotated against their joints (ANYmal):
                           // selects the instantiations of K5 whose rigid-body sweeps know the joint axes at compile time
   const double* q_ref;   // [M][NQ] reference configuration of every stage of the chain (time-varying cost)
   // per-stage arrays, indexed [instance][slot] (NS slots per instance)

@@ -10,6 +10,7 @@
 // device returns IDOCP_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -230,6 +231,7 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   }
   B.zaxes = 1;
   for (int i = 0; i < model->njoints; ++i) if (!(model->axis[i][0] == 0.0 && model->axis[i][1] == 0.0 && model->axis[i][2] == 1.0)) B.zaxes = 0;
+  if (std::getenv("IDOCP_GENERAL_AXES")) B.zaxes = 0;      // tests: the general instantiation on a chain that qualifies for the special one
   DevModel dm; toDevModel(*model, dm);
   UnProblem up; std::memset(&up, 0, sizeof(up));
   up.N = N; up.batch = batch; up.T = T; up.dt = dt > 0.0 ? dt : T / N;

@@ -231,3 +231,23 @@ def test_full_size_c3_trotting_parity_and_properties():
     assert abs(e_g[0] - e_o) <= 1e-4 * max(1.0, e_o) and e_g[0] == e_g[2]
     qs = g.get_chain("q", M, 1)
     assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12
+
+
+def test_general_axes_instantiations_direction_parity(monkeypatch):
+    """ANYmal qualifies for the instantiations of K5 that know the joint axes of the legs at compile time (OcpBuffers::leg_axes_xyy,
+    dev_rnea_tangent.hpp JointFrame).  IDOCP_GENERAL_AXES forces the general instantiations -- what any other quadruped would run -- on the
+    same problem: both must match the oracle, and each other, on a chain with lift, impulse and aux stages."""
+    monkeypatch.setenv("IDOCP_GENERAL_AXES", "1")
+    m, o, g_general, q, v = make_pair(30, 1.55, 2)
+    monkeypatch.delenv("IDOCP_GENERAL_AXES")
+    _, _, g_special, _, _ = make_pair(30, 1.55, 2)
+    qq = q.copy()
+    qq[7:] += 0.02 * np.random.default_rng(4).uniform(-1, 1, 12)
+    assert o.update(0.0, qq, v) == 0 and g_general.update(0.0, qq, v) == 0 and g_special.update(0.0, qq, v) == 0
+    M = len(o.chain(0.0))
+    dirs = list(OCP_DIR_FIELDS) + ["dxi"]
+    compare_chain(o, g_general, M, dirs, 1e-10, "direction (general axes)")
+    compare_chain(o, g_special, M, dirs, 1e-10, "direction (compile-time axes)")
+    for f in dirs:
+        a, b = np.asarray(g_general.get_chain(f, M)), np.asarray(g_special.get_chain(f, M))
+        assert rel_err(a, b) < 1e-10, f

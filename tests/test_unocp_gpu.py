@@ -212,3 +212,17 @@ def test_filter_line_search_parity():
     g.clear_line_search_filter()
     assert o.update(0.0, q, v, line_search=True) == 0 and g.update(0.0, q, v, line_search=True) == 0
     assert abs(g.step_sizes()[0][0] - o.step_sizes()[0]) < 1e-9
+
+
+def test_general_axes_instantiation_direction_parity(monkeypatch):
+    # iiwa14 qualifies for the K1 instantiation that knows at compile time that every joint turns about +z (UnBuffers::zaxes,
+    # dev_rbd.hpp rneaChain<NJ, ZAX>); IDOCP_GENERAL_AXES forces the general one, which any other 7-joint chain would run
+    monkeypatch.setenv("IDOCP_GENERAL_AXES", "1")
+    m, o, g_general, q, v = make_pair(20, 1.0)
+    monkeypatch.delenv("IDOCP_GENERAL_AXES")
+    _, _, g_special, _, _ = make_pair(20, 1.0)
+    assert o.update(0.0, q, v) == 0 and g_general.update(0.0, q, v) == 0 and g_special.update(0.0, q, v) == 0
+    for f in DIR_FIELDS:
+        assert rel_err(g_general.direction(f), o.direction(f)) < TOL, f
+        assert rel_err(g_special.direction(f), o.direction(f)) < TOL, f
+        assert rel_err(g_general.direction(f), g_special.direction(f)) < TOL, f
