@@ -698,11 +698,18 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     kk[L::K_FX + tid] = sm[S::FQ + tid]; kk[L::K_FX + NV + tid] = sm[S::FV + tid];
   }
   if (tid < NU) kk[L::K_LU + tid] = sm[S::LU + tid];
+  // MJtJinv: the lower triangle, row by row (consecutive threads write consecutive addresses); element t of the triangle is (r, c) with
+  // r = the largest integer with r (r + 1) / 2 <= t
+  for (int t = tid; t < RVF * (RVF + 1) / 2; t += nt) {
+    int r = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    if ((r + 1) * (r + 2) / 2 <= t) ++r;
+    if (r * (r + 1) / 2 > t) --r;
+    const int c = t - r * (r + 1) / 2;
+    ee[L::E_MJ + t] = sm[S::MJ + r + SVF * c];
+  }
   if (SF == NF) {
-    for (int e = tid; e < NVF * NVF; e += nt) ee[L::E_MJ + e] = sm[S::MJ + e];
     for (int e = tid; e < NVF * NX; e += nt) ee[L::E_MJD + e] = sm[S::MJD + e];
   } else {
-    for (int e = tid; e < RVF * RVF; e += nt) { const int c = e / RVF, r = e - c * RVF; ee[L::E_MJ + r + NVF * c] = sm[S::MJ + r + SVF * c]; }
     for (int e = tid; e < RVF * NX; e += nt) { const int c = e / RVF, r = e - c * RVF; ee[L::E_MJD + r + NVF * c] = sm[S::MJD + r + SVF * c]; }
   }
   if (tid < NV) ee[L::E_QAA + tid] = sm[S::QAA + tid];

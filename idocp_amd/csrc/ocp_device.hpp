@@ -48,7 +48,10 @@ struct OcpLayout {
   // expansion cache (ContactDynamicsData members + passive blocks + Fqq_prev_inv)
   // (Qafqv = -[Qaa; Qff] MJD and Qafu = [Qaa; Qff] MJ[:, u] are NOT stored: K6 leaves t = MJD dx and w = MJ[:, u] du in the
   //  dir record and K7 applies diag(Qaa) / Qff to them -- 11.5 kB less HBM traffic per stage, once written and once read)
-  static constexpr int E_MJ = 0, E_MJD = NVF * NVF, E_QAA = E_MJD + NVF * NX, E_QFF = E_QAA + NV,
+  // MJtJinv is symmetric: its lower triangle, row by row -- element (r, c), r >= c, at E_MJ + r (r + 1) / 2 + c (3.7 instead of 7.2 kB
+  // per stage, written once by K5 and read by K6 and K7)
+  static constexpr int MJ_TRI = (NVF * (NVF + 1) / 2 + 1) / 2 * 2;
+  static constexpr int E_MJ = 0, E_MJD = MJ_TRI, E_QAA = E_MJD + NVF * NX, E_QFF = E_QAA + NV,
                        E_MJIDC = E_QFF + NF * NF, E_LAF = E_MJIDC + NVF, E_LUP = E_LAF + NVF, E_QUUP = E_LUP + 6,
                        E_QXUP = E_QUUP + 6 * NU, E_FQQPI = E_QXUP + NX * 6;
   static constexpr int EXP = roundUp16(E_FQQPI + 36);

@@ -97,8 +97,8 @@ template <typename D>
 __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
-  constexpr int RL = L::R_SV + NV, MJDL = NVF * NX, MJUL = NVF * NU;
-  static_assert(RL % 2 == 0 && MJDL % 2 == 0 && MJUL % 2 == 0 && L::E_MJD % 2 == 0 && (NVF * 6) % 2 == 0 && L::EXP % 2 == 0 && L::RIC % 2 == 0, "16-byte loads");
+  constexpr int RL = L::R_SV + NV, MJDL = NVF * NX, MJUL = L::MJ_TRI;      // MJtJinv: the packed lower triangle (its torque columns are read out of it)
+  static_assert(RL % 2 == 0 && MJDL % 2 == 0 && MJUL % 2 == 0 && L::E_MJD % 2 == 0 && L::EXP % 2 == 0 && L::RIC % 2 == 0, "16-byte loads");
   // P and MJtJinv_dIDCdqv take turns in ONE buffer (both wait in registers; 13 instead of 21 kB per wavefront: eleven instead of
   // seven stages in flight per CU)
   constexpr int PML = RL > MJDL ? RL : MJDL;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   if (costate) wideLoad<RL / 2>(pw, B.ric + rec * L::RIC, lane);
   if (expand) {
     wideLoad<MJDL / 2>(mw, B.exp + rec * L::EXP + L::E_MJD, lane);
-    wideLoad<MJUL / 2>(uw, B.exp + rec * L::EXP + L::E_MJ + NVF * 6, lane);
+    wideLoad<MJUL / 2>(uw, B.exp + rec * L::EXP + L::E_MJ, lane);
   }
   // the small operands of the second half (solution, slack / dual rows of this lane, MJtJinv_IDC) travel with the matrices
   static_assert(L::SOL % 2 == 0 && L::NCON <= 128, "two IPM rows per lane");
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
 #pragma unroll
     for (int c = 0; c < NX; ++c) tt += mjd[r + NVF * c] * dx[c];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) ww += mju[r + NVF * j] * du[j];
+    for (int j = 0; j < NU; ++j) { const int c = 6 + j; ww += (r >= c ? mju[r * (r + 1) / 2 + c] : mju[c * (c + 1) / 2 + r]) * du[j]; }      // MJtJinv(r, 6 + j)
     acc += ww - tt;
     dd[L::D_T + r] = tt; dd[L::D_W + r] = ww;        // for the dual expansion (K7)
     if (r < NV) dd[L::D_A + r] = acc;
@@ -259,15 +259,15 @@ __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B, double*
 // dual, dgmm of the next stage) is issued at the top with 16-byte loads and staged through LDS: one trip to memory per stage
 // instead of a chain of dependent ones.  The kernel is bound by the bytes its resident wavefronts keep in flight (adding 4 kB of LDS
 // per wavefront, i.e. seven instead of nine of them per CU, took it from 0.65 to 0.75 ms), so LDS is kept small: MJtJinv, which is
-// symmetric, is staged as its lower triangle (3.7 instead of 7.2 kB), and slack / dual stay in the registers of the lane that owns the row.
+// symmetric, travels and is staged as its lower triangle (3.7 instead of 7.2 kB), and slack / dual stay in the registers of the lane
+// that owns the row.
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
-  constexpr int MJL = NVF * NVF, TO = L::E_QAA, TL = L::E_FQQPI + 36 - L::E_QAA;
+  constexpr int MJL = L::MJ_TRI, TO = L::E_QAA, TL = L::E_FQQPI + 36 - L::E_QAA;
   static_assert(MJL % 2 == 0 && TO % 2 == 0 && TL % 2 == 0 && L::E_MJ == 0 && L::DIR % 2 == 0 && L::SOL % 2 == 0 && L::CON % 2 == 0, "16-byte loads");
-  constexpr int TRI = NVF * (NVF + 1) / 2;
-  __shared__ __attribute__((aligned(16))) double mjt[TRI], tl[TL], dr[L::DIR], sr[L::SOL];
+  __shared__ __attribute__((aligned(16))) double mjt[MJL], tl[TL], dr[L::DIR], sr[L::SOL];
   auto mj = [&](int r, int c) -> double { return r >= c ? mjt[r * (r + 1) / 2 + c] : mjt[c * (c + 1) / 2 + r]; };      // MJtJinv(r, c)
   static_assert(L::NCON <= 128, "two IPM rows per lane");
   __shared__ double dgn[NV], laf[NVF + 2], dbm[NVF + 2], nup[6], dmu[NF];
@@ -304,17 +304,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   const bool bimp = bwd && nd->kind == 1;           // ParNMPC impulse stage (K9i filled the exp record): only the dv rows, dmu from K10b
   const int dimf = nd->dimf, dimvf = bimp ? NV : NV + dimf;
   if (stage) {
-    // lower triangle of MJtJinv: the lane holds the elements 2 e, 2 e + 1 of the column-major block
-#pragma unroll
-    for (int t = 0; t < (MJL / 2 + 63) / 64; ++t) {
-      const int e = 2 * (lane + 64 * t);
-      if (e < MJL) {
-        const int c = e / NVF, r = e - c * NVF;            // (r, c) and (r + 1, c) -- or (0, c + 1) at the end of a column
-        if (r >= c) mjt[r * (r + 1) / 2 + c] = mw[t].x;
-        const int r1 = (r + 1 < NVF) ? r + 1 : 0, c1 = (r + 1 < NVF) ? c : c + 1;
-        if (r1 >= c1 && c1 < NVF) mjt[r1 * (r1 + 1) / 2 + c1] = mw[t].y;
-      }
-    }
+    wideStoreLds<MJL / 2>(mjt, mw, lane);                // the packed lower triangle, as it lies in the exp record
     if (lane < NV) dgn[lane] = dgn_r;
   }
   wideStoreLds<TL / 2>(tl, tw, lane);

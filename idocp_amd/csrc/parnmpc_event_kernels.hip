@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     const int c = e / NV, r = e - c * NV;
     kk[L::K_FVQ + e] = Fvq[e];
     kk[L::K_FVV + e] = (r == c) ? -1.0 : 0.0;
-    ee[L::E_MJ + r + NVF * c] = Mi[e];
+    if (r >= c) ee[L::E_MJ + r * (r + 1) / 2 + c] = Mi[e];      // Minv is symmetric: the exp record keeps the lower triangle (ocp_device.hpp)
   }
   for (int e = tid; e < NV * NU; e += 256) {
     const int j = e / NV;
