@@ -449,6 +449,72 @@ def run_stub(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def exchange_unique_id(lib, dist, rank, world):
+    """The 128-byte RCCL unique id: made on rank 0 by the library (idocp_comm_get_unique_id), handed to the other ranks over the
+    gloo group that otherwise only carries the barrier / max-reduction of the timing.  Returns the ctypes buffer every rank passes to
+    idocp_comm_init_rank.  (tests/test_bench_dist.py runs this on two gloo processes.)"""
+    nbytes = 128                                     # IDOCP_COMM_ID_BYTES
+    raw = (C.c_char * nbytes)()
+    if rank == 0:
+        rc = lib.idocp_comm_get_unique_id(raw)
+        if rc != 0:
+            raise RuntimeError("idocp_comm_get_unique_id failed (%d)" % rc)
+    if world > 1:
+        import torch
+        idbuf = torch.tensor(list(raw.raw), dtype=torch.uint8) if rank == 0 else torch.zeros(nbytes, dtype=torch.uint8)
+        dist.broadcast(idbuf, src=0)
+        raw = (C.c_char * nbytes).from_buffer_copy(bytes(idbuf.tolist()))
+    return raw
+
+
+class _StubDistLib:
+    """IDOCP_BENCH_STUB=1 (no GPU): stands in for the idocp_comm_* / idocp_parnmpc_dist_* entry points so that the launcher, the
+    unique-id hand-off over gloo, the shard arithmetic and the JSON line of `--workload anymal_parnmpc --gpus N` run on CPU."""
+
+    def __init__(self):
+        self.id_seen = None
+        self.updates = 0
+
+    def idocp_comm_get_unique_id(self, raw):
+        pattern = bytes((37 * i + 11) % 251 for i in range(128))
+        C.memmove(raw, pattern, 128)
+        return 0
+
+    def idocp_comm_init_rank(self, raw, rank, world, device, out):
+        self.id_seen = bytes(raw.raw)
+        assert self.id_seen == bytes((37 * i + 11) % 251 for i in range(128)), "rank %d received a corrupted unique id" % rank
+        return 0
+
+    def idocp_parnmpc_dist_update_solution(self, h, t):
+        self.updates += 1
+        time.sleep(0.002)
+        return 0
+
+
+def run_parnmpc_stub(args, rank, local_rank, world, dist):
+    """The anymal_parnmpc bench path with the library calls replaced by _StubDistLib (CPU test of the multi-rank plumbing)."""
+    N = args.horizon if args.horizon != 100 else 256
+    B = args.batch or 256
+    if N % world:
+        raise SystemExit("--horizon must be divisible by the number of GPUs")
+    lib = _StubDistLib()
+    raw = exchange_unique_id(lib, dist, rank, world)
+    assert lib.idocp_comm_init_rank(raw, rank, world, local_rank, None) == 0
+
+    def step(_events):
+        assert lib.idocp_parnmpc_dist_update_solution(None, 0.0) == 0
+
+    el = run_timed(step, lambda: None, args.steps, args.warmup, dist, "cpu")
+    assert lib.updates == args.steps + args.warmup
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": B * args.steps / el, "unit": "SQP iterations/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "scaling": "strong",
+                          "config": {"workload": "stub (no GPU): anymal_parnmpc plumbing", "horizon": N, "batch_per_gpu": B,
+                                     "parallelism": "horizon shards x%d" % world, "stages_per_rank": N // world}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     """BASELINE.json configs[3]: ANYmal ParNMPCSolver, N = 256 (T = 12.8, dt = 0.05), 4 point contacts on every stage, the stages of
     every instance sharded over the ranks and driven by the library's C++ multi-GPU driver (idocp_amd/csrc/parnmpc_dist.hip:
@@ -495,21 +561,11 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, (C.c_int * 4)(1, 1, 1, 1), P(arr(pts))))
     for name, val in (("q", ANYMAL_Q_STANDING), ("v", np.zeros(nv)), ("f", fz)):
         capi.check(lib.idocp_ocp_set_solution(shard.h, name.encode(), P(arr(val))))
+    # the real RCCL communicator at every world size, one GPU included: `--gpus 1` runs ncclCommInitRank and the driver's stream-ordered
+    # transport exactly like a rank of the 8-GPU job (no in-process substitute)
     comm = C.c_void_p()
-    if world > 1:
-        import torch
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = (C.c_char * 128)()
-            capi.check(lib.idocp_comm_get_unique_id(raw), "comm_get_unique_id")
-            idbuf = torch.tensor(list(raw.raw), dtype=torch.uint8)
-        dist.broadcast(idbuf, src=0)
-        raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.tolist()))
-        capi.check(lib.idocp_comm_init_rank(raw, rank, world, local_rank, C.byref(comm)), "comm_init_rank")
-    else:
-        one = (C.c_void_p * 1)()
-        capi.check(lib.idocp_comm_init_local(1, local_rank, one), "comm_init_local")
-        comm = C.c_void_p(one[0])
+    raw = exchange_unique_id(lib, dist, rank, world)
+    capi.check(lib.idocp_comm_init_rank(raw, rank, world, local_rank, C.byref(comm)), "comm_init_rank")
     capi.check(lib.idocp_parnmpc_dist_attach(shard.h, comm), "dist_attach")
     if rank == 0:
         capi.check(lib.idocp_parnmpc_dist_set_initial_state(shard.h, P(q0), P(v0), nq, nv))
@@ -645,10 +701,12 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     backend = os.environ.get("IDOCP_BENCH_BACKEND", "nccl")
-    if args.workload == "anymal_parnmpc" and not os.environ.get("IDOCP_BENCH_STUB"):
+    if args.workload == "anymal_parnmpc":
         # the data path is the library's own RCCL communicator (idocp_parnmpc_dist_*); torch.distributed only carries the
         # rendezvous of its id and the barrier / max-reduction of the timing -> gloo, so that one RCCL instance owns the GPUs
         dist = init_distributed("gloo", local_rank) if world > 1 else None
+        if os.environ.get("IDOCP_BENCH_STUB"):
+            return run_parnmpc_stub(args, rank, local_rank, world, dist)
         return run_parnmpc_cxx(args, rank, local_rank, world, dist)
     dist = None
     if world > 1 or os.environ.get("IDOCP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL scaffolding on one GPU

@@ -235,6 +235,9 @@ def _proto(lib):
         ("idocp_comm_init_rank", [vp, ci, ci, ci, C.POINTER(vp)]),
         ("idocp_comm_init_local", [ci, ci, C.POINTER(vp)]),
         ("idocp_comm_rank", [vp]),
+        ("idocp_comm_set_force_collectives", [vp, ci]),
+        ("idocp_parnmpc_dist_transport_selftest", [vp, c_double_p]),
+        ("idocp_ocp_state_dims", [vp, C.POINTER(ci), C.POINTER(ci)]),
         ("idocp_comm_world", [vp]),
         ("idocp_parnmpc_dist_attach", [vp, vp]),
         ("idocp_parnmpc_dist_detach", [vp]),

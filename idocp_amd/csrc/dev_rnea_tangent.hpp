@@ -118,31 +118,47 @@ __device__ __forceinline__ void forEachLegJoint(Body body) {
 }
 }  // namespace rt
 
-// LDS scratch of one stage (doubles).
+// LDS scratch of one stage (doubles).  The records keep their DYNAMIC fields first, in the order of the nominal record in HBM
+// (OcpLayout: O_JOINT .. O_IDC, written by ocp_nominal_kernel), so that stage 0 of the condensation kernel copies that record in
+// 16-byte pieces; the model constants behind them are filled from the model.
 template <typename D>
 struct RneaScratch {
+  using L = OcpLayout<D>;
   static constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NJL = NL * LJ;
-  // JOINT record, one per leg joint: rotation R = P Rot(u, q) (row-major), axis, placement translation, the child-frame
-  // motion before the joint's own velocity is added (wc, vc, bwc, blc; zc = R_w,child^T e_z), the joint velocity vJ = u qd,
-  // the body's motion (w, v = vc, bw, bl), momenta hl, hn, the force accumulated up to and including this body (Fl, Fn),
-  // and the inertia constants of the body
-  static constexpr int J_R = 0, J_U = 9, J_P = 12, J_WC = 15, J_VC = 18, J_BWC = 21, J_BLC = 24, J_ZC = 27, J_VJ = 30, J_W = 33, J_BW = 36,
-                       J_BL = 39, J_HL = 42, J_HN = 45, J_FL = 48, J_FN = 51, J_MASS = 54, J_MC = 55, J_IO = 58,
-                       JREC = 66;     // 64 used; 66 puts the records of the four legs (3 JREC apart) into different LDS banks: the item lanes of a
-                                      // wavefront read the SAME field of four different legs at once (64: all four in one bank, 4-way conflicts)
-  // FOOT record, one per leg: R_world,foot Rc (row-major), local frame velocity fv / angular velocity fw (nominal), the frame
-  // placement (Rc, pc) in the tip joint, the pose-dependent part of the Baumgarte residual, contact flag and first packed row
-  static constexpr int F_RWC = 0, F_FV = 9, F_FW = 12, F_RC = 15, F_PC = 24, F_CP = 27, F_ACT = 30, F_ROW = 31, FREC = 34;      // (32 used; see JREC)
-  // BASE record: z = R_w^T e_z, v, w, momenta hl, hn of the base body, its inertia constants
-  static constexpr int B_Z = 0, B_V = 3, B_W = 6, B_HL = 9, B_HN = 12, B_MASS = 15, B_MC = 16, B_IO = 19, BREC = 26;
-  // inputs of the stage: q, v, a, f
-  static constexpr int I_Q = 0, I_V = NQ + 1, I_A = I_V + NV, I_F = I_A + NV, IREC = I_F + NF;
+  // JOINT record, one per leg joint: rotation R = P Rot(u, q) (row-major), the child-frame motion before the joint's own velocity
+  // is added (wc, vc, bwc, blc; zc = R_w,child^T e_z), the joint velocity vJ = u qd, the body's angular velocity w (its linear
+  // velocity is vc), momenta hl, hn, the force accumulated up to and including this body (Fl, Fn) | axis, placement translation and
+  // the inertia constants of the body
+  static constexpr int J_R = 0, J_WC = 9, J_VC = 12, J_BWC = 15, J_BLC = 18, J_ZC = 21, J_VJ = 24, J_W = 27, J_HL = 30, J_HN = 33,
+                       J_FL = 36, J_FN = 39, J_U = 42, J_P = 45, J_MASS = 48, J_MC = 49, J_IO = 52,
+                       JREC = 58;     // the records of the four legs (3 JREC apart = 348 dwords) start in different LDS banks: the item lanes
+                                      // of a wavefront read the SAME field of four different legs at once
+  static_assert(J_U == L::NJ_DYN, "dynamic part of the joint record = the nominal record's");
+  // FOOT record, one per leg: R_world,foot Rc (row-major), local frame velocity fv / angular velocity fw (nominal), the pose-dependent
+  // part of the Baumgarte residual | the frame placement (Rc, pc) in the tip joint, contact flag and first packed row
+  static constexpr int F_RWC = 0, F_FV = 9, F_FW = 12, F_CP = 15, F_RC = 18, F_PC = 27, F_ACT = 30, F_ROW = 31, FREC = 34;
+  static_assert(F_RC == L::NF_DYN, "dynamic part of the foot record");
+  // BASE record: z = R_w^T e_z, v, w, momenta hl, hn of the base body (+ 1 pad) | its inertia constants
+  static constexpr int B_Z = 0, B_V = 3, B_W = 6, B_HL = 9, B_HN = 12, B_MASS = 16, B_MC = 17, B_IO = 20, BREC = 26;
+  static_assert(B_MASS == L::NB_DYN, "dynamic part of the base record");
   static constexpr int IPL = 18 + 3 * LJ, NITEMS = NL * IPL;
-  static constexpr int JOINTS = 0, FEET = JOINTS + NJL * JREC, BASE = FEET + NL * FREC, INP = BASE + BREC,
-                       BT = INP + IREC,                        // [NITEMS][6] tangent of the force each item's leg transmits to the base
+  static constexpr int JOINTS = 0, FEET = JOINTS + NJL * JREC, BASE = FEET + NL * FREC,
+                       BT = BASE + BREC,                       // [NITEMS][6] tangent of the force each item's leg transmits to the base
                        BOWN = BT + NITEMS * 6,                 // [18][6] tangent of the base's own inertial force, per base seed
                        BN = BOWN + 18 * 6,                     // [NL + 1][6] nominal base force: own, then per leg
                        TOTAL = BN + (NL + 1) * 6 + 2;
+  static_assert(JREC % 2 == 0 && FEET % 2 == 0 && BASE % 2 == 0 && BN % 2 == 0, "16-byte pieces");
+  // the nominal record in 16-byte pieces: joints, feet, base, BN, [ID; C]
+  static constexpr int C_J = NJL * (L::NJ_DYN / 2), C_F = C_J + NL * (L::NF_DYN / 2), C_B = C_F + L::NB_DYN / 2, C_BN = C_B + (NL + 1) * 3,
+                       C_ALL = C_BN + L::NVF / 2;
+  static_assert(2 * C_ALL == L::O_IDC + L::NVF, "piece count of the nominal record");
+  // piece c -> destination (doubles) in the scratch; pieces >= C_BN go to the [ID; C] vector of the caller (index 2 (c - C_BN))
+  __device__ static __forceinline__ int pieceDst(int c) {
+    if (c < C_J) { const int j = c / (L::NJ_DYN / 2); return JOINTS + j * JREC + 2 * (c - j * (L::NJ_DYN / 2)); }
+    if (c < C_F) { const int e = c - C_J, l = e / (L::NF_DYN / 2); return FEET + l * FREC + 2 * (e - l * (L::NF_DYN / 2)); }
+    if (c < C_B) return BASE + 2 * (c - C_F);
+    return BN + 2 * (c - C_B);
+  }
 };
 
 // Where the derivative columns go: [dID; dC] / d(q, v) as one (NV + contact rows) x 2 NV block (leading dimension ldd), dID/da = M
@@ -154,27 +170,17 @@ struct RneaOut {
   double* idc;
 };
 
-// ---- setup, all threads: inputs and every constant the sweeps read go to LDS once (the sweeps then touch no global memory);
-// one thread per leg joint evaluates cos / sin and the joint rotation ----
+// ---- setup, all threads: the model constants the item sweeps read go to LDS once (the sweeps then touch no global memory); the
+// dynamic fields of the same records arrive from the nominal record (rneaNominalFetch / rneaNominalStore) ----
 template <typename D>
 __device__ __forceinline__ void rneaSetup(const DevModel* __restrict__ m, const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd,
-                                          const double* __restrict__ s_g, int tid, double* sc) {
+                                          int tid, double* sc) {
   using S = RneaScratch<D>;
-  using L = OcpLayout<D>;
   using namespace rt;
-  constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NJL = NL * LJ;
-  if (tid < NQ) sc[S::INP + S::I_Q + tid] = s_g[L::S_Q + tid];
-  else if (tid >= 32 && tid < 32 + NV) { sc[S::INP + S::I_V + tid - 32] = s_g[L::S_V + tid - 32]; sc[S::INP + S::I_A + tid - 32] = s_g[L::S_A + tid - 32]; }
-  else if (tid >= 64 && tid < 64 + NF) sc[S::INP + S::I_F + tid - 64] = s_g[L::S_F + tid - 64];
-  else if (tid >= 128 && tid < 128 + NJL) {
-    const int t = tid - 128, ji = 1 + t, dof = 6 + t;
+  constexpr int NL = D::NL, LJ = D::LJ, NJL = NL * LJ;
+  if (tid >= 128 && tid < 128 + NJL) {
+    const int t = tid - 128, ji = 1 + t;
     double* jr = sc + S::JOINTS + t * S::JREC;
-    double sj, cj;
-    sincos(s_g[L::S_Q + dof + 1], &sj, &cj);
-    Mat3<double> Rm;
-    revoluteRotation<double>(m->R[ji], m->axis[ji], cj, sj, Rm);
-#pragma unroll
-    for (int e = 0; e < 9; ++e) jr[S::J_R + e] = Rm.m[e];
     st3(jr + S::J_U, ld3(m->axis[ji])); st3(jr + S::J_P, ld3(m->p[ji]));
     jr[S::J_MASS] = m->mass[ji]; st3(jr + S::J_MC, ld3(m->mc[ji]));
 #pragma unroll
@@ -195,137 +201,29 @@ __device__ __forceinline__ void rneaSetup(const DevModel* __restrict__ m, const 
   }
 }
 
-// world rotation of the base from the quaternion (x y z w)
-__device__ __forceinline__ void rneaBaseRotation(const double* q, double* Rw) {
-  const double x = q[3], y = q[4], z = q[5], w = q[6];
-  Rw[0] = 1 - 2 * (y * y + z * z); Rw[1] = 2 * (x * y - z * w);     Rw[2] = 2 * (x * z + y * w);
-  Rw[3] = 2 * (x * y + z * w);     Rw[4] = 1 - 2 * (x * x + z * z); Rw[5] = 2 * (y * z - x * w);
-  Rw[6] = 2 * (x * z - y * w);     Rw[7] = 2 * (y * z + x * w);     Rw[8] = 1 - 2 * (x * x + y * y);
-}
-
-// ---- nominal sweep, MOTION half: lane `who` < NL walks its leg outward (velocities, accelerations in the gravity field) and back
-// (forces, tau), lane NL does the base body.  Reads LDS only. ----
-template <typename D, bool XYY = false>
-__device__ __forceinline__ void rneaNominalMotion(double gz, double wv, int who, double* sc, const RneaOut& out) {
+// The nominal record of the stage (HBM, ocp_nominal_kernel) -> registers (issued with the other loads of stage 0) -> LDS scratch.
+template <typename D, int NT>
+struct RneaNominalCopy {
   using S = RneaScratch<D>;
-  using namespace rt;
-  constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV;
-  if (who > NL) return;
-  const double* in = sc + S::INP;
-  const double* sv = in + S::I_V;
-  const double* sa = in + S::I_A;
-  const double qx = in[3], qy = in[4], qz = in[5], qw = in[6];
-  const V3 zb = v3(2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy));      // third row of R_w
-  V3 v = ld3(sv), w = ld3(sv + 3);
-  V3 bl = ld3(sa) - gz * zb, bw = ld3(sa + 3);      // a_gf = a - R^T g
-  if (who == NL) {
-    double* br = sc + S::BASE;
-    V3 hl, hn, f, n;
-    const V3 mc = ld3(br + S::B_MC);
-    inertia(br[S::B_MASS], mc, br + S::B_IO, v, w, hl, hn);
-    inertia(br[S::B_MASS], mc, br + S::B_IO, bl, bw, f, n);
-    st3(br + S::B_Z, zb); st3(br + S::B_V, v); st3(br + S::B_W, w); st3(br + S::B_HL, hl); st3(br + S::B_HN, hn);
-    double* bn = sc + S::BN;
-    st3(bn, f + cross(w, hl)); st3(bn + 3, n + cross(w, hn) + cross(v, hl));
-    return;
-  }
-  const int leg = who;
-  forEachLegJoint<XYY, true, LJ>([&](auto tag, int j) {
-    constexpr int AX = decltype(tag)::value;
-    const int dof = 6 + leg * LJ + j;
-    double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const JointFrame<AX> F(jr, S::J_R, S::J_U);
-    const V3 p = ld3(jr + S::J_P);
-    const V3 wc = F.mulT(w), vc = F.mulT(v + cross(w, p)), bwc = F.mulT(bw), blc = F.mulT(bl + cross(bw, p));
-    const V3 vJ = F.timesU(sv[dof]);
-    w = wc + vJ; v = vc;
-    bw = bwc + F.timesU(sa[dof]) + F.crossKU(w, sv[dof]);
-    bl = blc + F.crossKU(v, sv[dof]);
-    st3(jr + S::J_WC, wc); st3(jr + S::J_VC, vc); st3(jr + S::J_BWC, bwc); st3(jr + S::J_BLC, blc);
-    st3(jr + S::J_VJ, vJ); st3(jr + S::J_W, w); st3(jr + S::J_BW, bw); st3(jr + S::J_BL, bl);
-  });
-  // ---- contact frame at the foot (tip joint of this leg): the motion-dependent part of the residual (point_contact.hxx:67-87) ----
-  double* fr = sc + S::FEET + leg * S::FREC;
-  V3 fel = v3(0, 0, 0), fen = fel;
-  if (fr[S::F_ACT] != 0.0) {
-    const double* Rc = fr + S::F_RC;
-    const V3 pc = ld3(fr + S::F_PC);
-    const int row = NV + (int)fr[S::F_ROW];
-    const V3 fv = XYY ? v + cross(w, pc) : mulT(Rc, v + cross(w, pc)), fw = XYY ? w : mulT(Rc, w),
-             fam = XYY ? bl + cross(bw, pc) : mulT(Rc, bl + cross(bw, pc));      // fam: still in the gravity field
-    const V3 wxv = cross(fw, fv);
-    out.idc[row] = fam.x + wxv.x + wv * fv.x;
-    out.idc[row + 1] = fam.y + wxv.y + wv * fv.y;
-    out.idc[row + 2] = fam.z + wxv.z + wv * fv.z;
-    st3(fr + S::F_FV, fv); st3(fr + S::F_FW, fw);
-    // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
-    fel = XYY ? ld3(in + S::I_F + 3 * leg) : mul(Rc, ld3(in + S::I_F + 3 * leg));
-    fen = cross(pc, fel);
-  }
-  // ---- inward sweep: accumulate forces, emit tau ----
-  V3 Fl = v3(0, 0, 0) - fel, Fn = v3(0, 0, 0) - fen;
-  forEachLegJoint<XYY, false, LJ>([&](auto tag, int j) {
-    constexpr int AX = decltype(tag)::value;
-    const int dof = 6 + leg * LJ + j;
-    double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const JointFrame<AX> F(jr, S::J_R, S::J_U);
-    const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), bwj = ld3(jr + S::J_BW), blj = ld3(jr + S::J_BL);
-    const V3 mc = ld3(jr + S::J_MC), p = ld3(jr + S::J_P);
-    V3 hl, hn, f, n;
-    inertia(jr[S::J_MASS], mc, jr + S::J_IO, vj, wj, hl, hn);
-    inertia(jr[S::J_MASS], mc, jr + S::J_IO, blj, bwj, f, n);
-    Fl = Fl + f + cross(wj, hl);
-    Fn = Fn + n + cross(wj, hn) + cross(vj, hl);
-    out.idc[dof] = F.dotU(Fn);
-    st3(jr + S::J_HL, hl); st3(jr + S::J_HN, hn); st3(jr + S::J_FL, Fl); st3(jr + S::J_FN, Fn);
-    const V3 Rf = F.mul(Fl);
-    Fn = F.mul(Fn) + cross(p, Rf);
-    Fl = Rf;
-  });
-  double* bn = sc + S::BN + 6 * (1 + leg);
-  st3(bn, Fl); st3(bn + 3, Fn);
-}
-
-// ---- nominal sweep, POSE half (runs on another wavefront next to the motion half): world rotation and position along the leg;
-// leaves zc = R_w,child^T e_z per joint and, at the foot, R_wf Rc and the pose-dependent part of the residual
-//   Rc^T (g_z z_f)  [takes the gravity field out of the frame acceleration]  +  (1 / D^2) (p_foot - p_contact) ----
-template <typename D, bool XYY = false>
-__device__ __forceinline__ void rneaNominalPose(double gz, double wp, const OcpNode* __restrict__ nd, int leg, double* sc) {
-  using S = RneaScratch<D>;
-  using namespace rt;
-  constexpr int NL = D::NL, LJ = D::LJ;
-  if (leg < 0 || leg >= NL) return;
-  const double* in = sc + S::INP;
-  double Rw[9];
-  rneaBaseRotation(in, Rw);
-  V3 pw = ld3(in);
-  forEachLegJoint<XYY, true, LJ>([&](auto tag, int j) {
-    constexpr int AX = decltype(tag)::value;
-    double* jr = sc + S::JOINTS + (leg * LJ + j) * S::JREC;
-    const JointFrame<AX> F(jr, S::J_R, S::J_U);
-    pw = pw + mul(Rw, ld3(jr + S::J_P));
-    // Rw <- Rw R: row r of the product is (R^T applied to row r of Rw)
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  static constexpr int PER = (S::C_ALL + NT - 1) / NT;
+  d2 r[PER];
+  __device__ __forceinline__ void fetch(const double* __restrict__ nom, int tid) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const V3 row = F.mulT(v3(Rw[3 * r], Rw[3 * r + 1], Rw[3 * r + 2]));
-      Rw[3 * r] = row.x; Rw[3 * r + 1] = row.y; Rw[3 * r + 2] = row.z;
+    for (int t = 0; t < PER; ++t) {
+      const int c = tid + NT * t;
+      r[t] = *reinterpret_cast<const d2*>(nom + 2 * (c < S::C_ALL ? c : 0));
     }
-    st3(jr + S::J_ZC, v3(Rw[6], Rw[7], Rw[8]));
-  });
-  double* fr = sc + S::FEET + leg * S::FREC;
-  if (fr[S::F_ACT] != 0.0) {
-    const double* Rc = fr + S::F_RC;
-    const V3 pf = pw + mul(Rw, ld3(fr + S::F_PC));
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        fr[S::F_RWC + 3 * r + c] = XYY ? Rw[3 * r + c] : Rw[3 * r] * Rc[c] + Rw[3 * r + 1] * Rc[3 + c] + Rw[3 * r + 2] * Rc[6 + c];
-    const V3 g = XYY ? gz * v3(Rw[6], Rw[7], Rw[8]) : mulT(Rc, gz * v3(Rw[6], Rw[7], Rw[8]));
-    st3(fr + S::F_CP, v3(g.x + wp * (pf.x - nd->contact_point[leg][0]), g.y + wp * (pf.y - nd->contact_point[leg][1]),
-                         g.z + wp * (pf.z - nd->contact_point[leg][2])));
   }
-}
+  __device__ __forceinline__ void store(int tid, double* sc, double* idc) const {
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int c = tid + NT * t;
+      if (c < S::C_BN) *reinterpret_cast<d2*>(sc + S::pieceDst(c)) = r[t];
+      else if (c < S::C_ALL) *reinterpret_cast<d2*>(idc + 2 * (c - S::C_BN)) = r[t];
+    }
+  }
+};
 
 // ---- one tangent item = (seed, leg): columns of dID and dC for the rows of this leg, and the base-force tangent ----
 template <typename D, bool XYY = false>

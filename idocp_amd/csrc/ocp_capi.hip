@@ -606,6 +606,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &B.dual, ns * LQ::CON))) return fail(rc);
   if ((rc = allocBufO(h, &B.lin, ns * LQ::LIN))) return fail(rc);
   if ((rc = allocBufO(h, &B.lie, ns * LQ::LIE))) return fail(rc);
+  if ((rc = allocBufO(h, &B.nom, ns * LQ::NOM))) return fail(rc);
   if ((rc = allocBufO(h, &B.kkt, ns * LQ::KKT))) return fail(rc);
   if ((rc = allocBufO(h, &B.exp, ns * LQ::EXP))) return fail(rc);
   if ((rc = allocBufO(h, &B.ric, ns * LQ::RIC))) return fail(rc);
@@ -725,9 +726,11 @@ int idocp_ocp_create(const idocp_model_t* model, const idocp_cost_t* cost, const
   return createOcpImpl(model, cost, constraints, T, N, 0, batch, device, false, out);
 }
 
+extern "C" void idocp_parnmpc_dist_on_destroy(idocp_ocp_t* h);      // parnmpc_dist.hip: drops the handle's communicator attachment, if any
 void idocp_ocp_destroy(idocp_ocp_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  idocp_parnmpc_dist_on_destroy(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
@@ -1451,8 +1454,11 @@ int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, con
   int rc = setDev(h); if (rc) return rc;
   if (line_search) {
     // ParNMPCSolver::updateSolution(t, q, v, true) (parnmpc_solver.cpp:73-103): direction, filter line search on the primal step, integration
-    if ((rc = idocp_parnmpc_compute_direction(h, t, q, v))) return rc;
+    // (the support check needs the chain of this t; nothing has touched the direction / Riccati records when it refuses)
+    if (!h->contact_status_set) { set_last_error("idocp_parnmpc_update_solution: call setContactStatusUniformly first"); return IDOCP_E_ARG; }
+    if ((rc = discretize(h, t))) return rc;
     if ((rc = parnmpcLineSearchSupported(h))) return rc;
+    if ((rc = idocp_parnmpc_compute_direction(h, t, q, v))) return rc;
     if ((rc = runLineSearchO(h, h->d_q0))) return rc;
     if ((rc = idocp_parnmpc_launch_phase(h, 9, h->d_q0, h->d_v0))) return rc;
   } else {
@@ -1576,6 +1582,11 @@ int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_e
   return IDOCP_OK;
 }
 int idocp_ocp_batch(idocp_ocp_t* h) { return h ? h->batch : 0; }
+int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv) {
+  if (!h || !nq || !nv) return IDOCP_E_ARG;
+  *nq = DQ::NQ; *nv = DQ::NV;
+  return IDOCP_OK;
+}
 
 // Deep copy (the reference's solver classes are copyable, `= default`: ocp_solver.hpp:171-186): a new handle of the same
 // configuration whose device records, contact sequence and discretisation state equal the source's.
@@ -1595,6 +1606,7 @@ int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
   h->contact_status_set = src->contact_status_set; h->stage_offset = src->stage_offset; h->has_terminal = src->has_terminal; h->has_prev = src->has_prev;
   h->phases = src->phases; h->event_time = src->event_time; h->is_impulse = src->is_impulse; h->impulse_status = src->impulse_status;
   h->slice_begin = src->slice_begin; h->slice_end = src->slice_end;
+  h->filters = src->filters;                 // the line-search filter is part of the solver's state (LineSearch is a member of the reference's solvers)
   h->prob = src->prob;
   h->seq_dirty = true;                       // the chain is rebuilt (and uploaded) on first use
   if (src->disc_time == src->disc_time) { if ((rc = discretize(h, src->disc_time))) return fail(rc); }

@@ -12,8 +12,9 @@
 // and TerminalOCP::linearizeOCP (include/idocp/ocp/terminal_ocp.hxx:50-66) for the last stage.
 //
 // One 256-thread workgroup per stage; every block of the stage lives in LDS
-// (~38 kB after aliasing, four workgroups per CU).  Reads the lin record of K5a, writes the kkt
-// record (LQR stage for the Riccati sweep) and the exp record (expansion cache).
+// (~35 - 39 kB after aliasing, four workgroups per CU).  Reads the stage's solution / slack / dual / lie records and the nominal
+// rigid-body record of ocp_nominal_kernel (impulse stages: the lin record of ocp_rnea_kernel<D, true> instead), runs the tangent
+// items of dev_rnea_tangent.hpp, writes the kkt record (LQR stage for the Riccati sweep) and the exp record (expansion cache).
 #include <hip/hip_runtime.h>
 
 #include "dev_dense.hpp"
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
   constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = S::NVF, RVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>) and rows; NF / NVF: the HBM records'
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_ok;
+  __shared__ int s_ok, s_c1;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   int tid = threadIdx.x;
@@ -122,6 +123,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const bool impulse = PLAIN ? false : (nd->kind == 1);
   if (BWD && impulse) return;                       // ParNMPC: the backward-Euler impulse stage is K9i (parnmpc_event_kernels.hip)
   const int sw_dimi = PLAIN ? 0 : nd->sw_dimi;
+  int c_act[NC], c_row[NC];                        // contact status of the stage (uniform; fetched once, up front)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { c_act[c] = nd->active[c]; c_row[c] = nd->row_of[c]; }
   const int i = nd->level;                          // constraint gating level
   const double dt = nd->dt;                         // scaling of cost / constraints / dynamics multipliers (1 on impulse stages)
   const double dtq = nd->dtq;                       // q+ = q (+) dtq v (0 on impulse stages)
@@ -138,6 +142,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const long su = rec;
   const bool stamp = (!RESIDUAL) && tid == 0 && unit == 7 && B.prof != nullptr && DIMF == B.prof_dimf;
 #define STAMP(k) do { if (stamp) B.prof[k] = wall_clock64(); } while (0)
+  // per-wavefront stamps of the wave-specialised stage: slot 32 + 8 wave + k
+  const bool stampw = (!RESIDUAL) && (tid & 63) == 0 && unit == 7 && B.prof != nullptr && DIMF == B.prof_dimf;
+#define STAMPW(k) do { if (stampw) B.prof[32 + 8 * (tid >> 6) + (k)] = wall_clock64(); } while (0)
   STAMP(0);
   double* kk = B.kkt + rec * L::KKT;
   double* ee = B.exp + rec * L::EXP;
@@ -147,20 +154,23 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* __restrict__ w_a = impulse ? P->dvi_weight : P->a_weight;
 
   // ======================================================================================================================
-  // Front half, WAVE-SPECIALISED (round 2).  Round 1 ran K5a -> lin record -> phases A .. E of this kernel one after the other,
-  // nineteen workgroup barriers in all.  Here the rigid-body terms are produced in place (dev_rnea_tangent.hpp) and the four
-  // wavefronts of the workgroup work on different things at the same time, joined by four barriers:
-  //   stage 0  all      fetch the small records (registers), clear the output blocks, joint constants + rotations -> LDS
-  //   stage 1  wave 0   nominal Newton-Euler sweep (motion)        wave 1   nominal sweep (world pose)
+  // Front half, WAVE-SPECIALISED.  Round 1 ran K5a -> lin record -> phases A .. E of this kernel one after the other, nineteen
+  // workgroup barriers in all; round 2 produced the rigid-body terms in place (dev_rnea_tangent.hpp) with the NOMINAL sweeps on five
+  // lanes of two wavefronts (5 us of the 28 us a stage spent here).  Round 3: the nominal sweeps are a kernel of their own
+  // (ocp_nominal_kernel: one lane per stage and leg) whose record stage 0 copies into the scratch, so the tangent items start at once:
+  //   stage 0  all      fetch the small records and the nominal record (registers), clear the output blocks, model constants -> LDS
+  //   stage 1  wave 0   the 60 q- and v-seed tangent items
+  //            wave 1   the 36 a-seed items (M, J) and then, without waiting for the q / v items, Robot::computeMJtJinv:
+  //                     block-arrow M^-1, J M^-1, (J M^-1 J^T)^-1
   //            wave 2/3 C1: every term of the gradients / Hessian diagonals that does not need the rigid-body derivatives
-  //   stage 2  wave 0   the 60 q- and v-seed tangent items          wave 1   the 36 a-seed items (M, J) and then, without waiting for
-  //                     anybody, Robot::computeMJtJinv: block-arrow M^-1, J M^-1, (J M^-1 J^T)^-1
+  //                     (wave 1 waits for them through an LDS flag before it reads their vectors / reuses their input block)
   //   stage 3  all      base rows + position term of the q / v columns, assembly of MJtJinv
   //   (then F: MJtJinv [dIDCdqv, IDC] together with C2, the multiplier terms l += dt [dID; dC]^T [beta; mu])
   // ======================================================================================================================
   using RS = RneaScratch<D>;
   using RI = RneaItems<D>;
   static_assert(S::QFF - S::MJ >= RS::TOTAL, "the RNEA scratch lives in MJ .. MJD (dead until stage 3)");
+  static_assert(S::MJ % 2 == 0 && S::IDC % 2 == 0, "16-byte pieces of the nominal record");
   static_assert(RI::NQV <= 64 && RI::NA <= 64, "one wavefront per item list");
   constexpr int NPRE = (2 * L::SOL + 2 * L::CON + nt - 1) / nt;
   static_assert(S::SOLN == S::SOLS + L::SOL && S::SLK == S::SOLN + L::SOL && S::DUL == S::SLK + L::CON, "the fetched records are contiguous in LDS");
@@ -173,6 +183,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     // (every address below is a valid record of this instance, so the loads are unconditional: no branches, all in flight at once;
     //  on the terminal stage sn_g = s_g and the slack / dual copies are simply not used)
     double pre[NPRE], prez[7];
+    RneaNominalCopy<D, nt> nomc;
+    const bool has_nom = !terminal && !impulse;
+    if (has_nom) nomc.fetch(B.nom + rec * L::NOM, tid);
 #pragma unroll
     for (int t = 0; t < NPRE; ++t) {
       const int e = tid + nt * t;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (tid < 36) { prez[0] = zz[L::Z_JQ + tid]; prez[1] = zz[L::Z_FQQ + tid]; prez[2] = zz[L::Z_FQQI + tid]; prez[3] = zz[L::Z_FQQP + tid]; prez[4] = zz[L::Z_FQQPI + tid]; }
       if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
     }
-    if (tid == 0) s_ok = 1;
+    if (tid == 0) { s_ok = 1; s_c1 = 0; }
     if (!terminal) {
       if (impulse) {
         // impulse stages keep the two-pass dual-number sweep of ocp_rnea_kernel<D, true> and its lin record
@@ -195,8 +208,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
         if (tid < RVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
       } else {
-        for (int e = tid; e < S::MJ - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
-        rneaSetup<D>(B.model, P, nd, s_g, tid, sc);
+        for (int e = tid; e < S::IDC - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
+        rneaSetup<D>(B.model, P, nd, tid, sc);
+        nomc.store(tid, sc, &sm[S::IDC]);
       }
     }
     for (int e = tid; e < SF * SF; e += nt) sm[S::QFF + e] = 0.0;
@@ -256,7 +270,11 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     return;
   }
 
-  // ---- stage 1: nominal sweeps (waves 0, 1) next to C1 (waves 2, 3) ----
+  // ---- stage 1: tangent items (wave 0: q, v seeds; wave 1: a seeds) and Robot::computeMJtJinv (wave 1) (robot.hxx:576-615), next to
+  // C1 (waves 2, 3) ----
+  // M^-1 and (J M^-1 J^T)^-1 by Gauss-Jordan on the SPD blocks (the reference uses pinocchio's sparse Cholesky + Eigen::LLT; same
+  // inverses up to rounding).  BL, SM live in the block that holds the solution / slack / dual copies C1 reads: wave 1 waits for C1
+  // (s_c1: one count per C1 wavefront) before it reads C1's vectors and before it writes there.
   const double gz = B.model->gravity[2];
   const double bwv = 2.0 / P->baumgarte_time_step, bwp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
   const double* slack = &sm[S::SLK];
@@ -264,9 +282,54 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below), per thread
   double merit_cost = 0.0, merit_viol = 0.0; // MERIT: this thread's share of the stage cost / l1 constraint violation
   if (wave == 0) {
-    if (!impulse) rneaNominalMotion<D, XYY>(gz, bwv, lane, sc, out);
+    if (!MERIT && !impulse && lane < RI::NQV) rneaTangentItem<D, XYY>(gz, bwv, RI::qv(lane), sc, out);
+    STAMPW(0);
   } else if (wave == 1) {
-    if (!impulse) rneaNominalPose<D, XYY>(gz, bwp, nd, lane, sc);
+    if (!MERIT) {
+      if (!impulse) {
+        if (lane < RI::NA) rneaTangentItemA<D, XYY>(RI::a(lane), sc, out);
+        waveLdsSync();
+        rneaAssembleA<D>(lane, sc, out);
+        waveLdsSync();
+      }
+      STAMPW(0);
+      if (!RESIDUAL) {
+        // C2 for the acceleration rows, while M is still M: t = M^T beta + J^T mu (beta, mu from the LDS copy of the solution record;
+        // la += dt t follows in stage 3 -- nothing here waits for C1)
+        if (lane < NV) {
+          double acc = dotAny(&sm[S::MM + NV * lane], 1, s + L::S_BETA, 1, NV);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            if (!c_act[c]) continue;
+            const double* jc = &sm[S::JM + c_row[c] + SF * lane];
+            acc += jc[0] * s[L::S_MU + 3 * c] + jc[1] * s[L::S_MU + 3 * c + 1] + jc[2] * s[L::S_MU + 3 * c + 2];
+          }
+          sm[S::MJIDC + lane] = acc;
+        }
+        waveLdsSync();
+        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok);
+        STAMPW(1);
+        // C1 done?  BL, SM reuse its input block.  (Its two wavefronts each add one; LDS operations of a wavefront complete in order.)
+        if (lane == 0) while (__hip_atomic_load(&s_c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        STAMPW(2);
+        if (dimf > 0) {
+          for (int e = lane; e < dimf * NV; e += 64) {                 // BL = J Minv
+            const int c = e / dimf, r = e - c * dimf;
+            sm[S::BL + r + SF * c] = dotAny(&sm[S::JM + r], SF, &sm[S::MINV + NV * c], 1, NV);
+          }
+          waveLdsSync();
+          for (int e = lane; e < dimf * dimf; e += 64) {               // SM = BL J^T
+            const int c = e / dimf, r = e - c * dimf;
+            sm[S::SM + r + SF * c] = dotAny(&sm[S::BL + r], SF, &sm[S::JM + c], SF, NV);
+          }
+          waveLdsSync();
+          spdInverseRows<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
+        }
+        STAMPW(3);
+      }
+    }
   } else if (tid < 128 + NV) {
     // ---- C1, one row of (q, v, a) per thread: cost, state equation, joint limits, switching-constraint multipliers ----
     const int r = tid - 128;
@@ -328,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         double g = sgn * dt * du, h = 0.0;
         if (MERIT) merit_viol += dt * fabs(res);
         if (RESIDUAL) err_ipm += res * res + duality * duality;
-        else { g += sgn * dt * (du * res - duality) / sl; h = dt * du / sl; }
+        else { const double isl = recipNewton(sl); g += sgn * dt * (du * res - duality) * isl; h = dt * du * isl; }
         if (c < 2) { lq += g; hq += h; } else { lv += g; hv += h; }
       }
     }
@@ -362,7 +425,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (MERIT) merit_viol += dt * fabs(res);
       lu += sgn * dt * du;
       if (RESIDUAL) err_ipm += res * res + duality * duality;
-      else { lu += sgn * dt * (du * res - duality) / sl; h += dt * du / sl; }
+      else { const double isl = recipNewton(sl); lu += sgn * dt * (du * res - duality) * isl; h += dt * du * isl; }
     }
     sm[S::LU + j] = lu;
     if (!RESIDUAL) sm[S::HUD + j] = h;
@@ -398,10 +461,11 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
           const double g = coneRow(ck, P->mu, r, f, Jr[r]);
           const double res = g + sl, duality = sl * du - P->barrier;
           double coef = du;
+          const double isl = recipNewton(sl);
           if (MERIT) merit_viol += dt * fabs(res);
           if (RESIDUAL) err_ipm += res * res + duality * duality;
-          else coef += (du * res - duality) / sl;
-          dd[r] = du / sl;
+          else coef += (du * res - duality) * isl;
+          dd[r] = du * isl;
           for (int x = 0; x < 3; ++x) lf[x] += dt * Jr[r][x] * coef;
         }
         if (!RESIDUAL) {
@@ -428,6 +492,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     kk[L::K_FQV + e] = (BWD ? dtq : -dtq) * sm[S::FQQI + e];          // Fqv = -dt Fqq_inv (0 on impulse stages; backward: + dt Fqq_inv)
     ee[L::E_FQQPI + e] = sm[(BWD ? S::FQQI : S::FQQPI) + e];          // what the costate correction needs
   }
+  if (wave >= 2) STAMPW(0);
+  if (wave >= 2 && !MERIT && !RESIDUAL) {
+    // C1 of this wavefront is in LDS: tell wave 1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_fetch_add(&s_c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   __syncthreads();
   STAMP(2);
   if (MERIT) {
@@ -445,40 +516,6 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     if (tid < 2) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + nt * tid + t]; B.merit_stage[rec * 4 + tid] = e; }
     return;
   }
-
-  // ---- stage 2: tangent items (wave 0: q, v seeds; wave 1: a seeds) and Robot::computeMJtJinv (wave 1) (robot.hxx:576-615) ----
-  // M^-1 and (J M^-1 J^T)^-1 by Gauss-Jordan on the SPD blocks (the reference uses pinocchio's sparse Cholesky + Eigen::LLT; same
-  // inverses up to rounding).  BL, SM live in the block that held the solution / slack / dual copies (dead since C1).
-  if (wave == 0) {
-    if (!impulse && lane < RI::NQV) rneaTangentItem<D, XYY>(gz, bwv, RI::qv(lane), sc, out);
-  } else if (wave == 1) {
-    if (!impulse) {
-      if (lane < RI::NA) rneaTangentItemA<D, XYY>(RI::a(lane), sc, out);
-      waveLdsSync();
-      rneaAssembleA<D>(lane, sc, out);
-      waveLdsSync();
-    }
-    if (!RESIDUAL) {
-      // C2 for the acceleration rows, while M is still M: la += dt (M^T beta + J^T mu)
-      if (lane < NV) sm[S::LA + lane] += dt * (dotAny(&sm[S::MM + NV * lane], 1, &sm[S::BM], 1, NV) + dotAny(&sm[S::JM + SF * lane], 1, &sm[S::BM + NV], 1, dimf));
-      waveLdsSync();
-      blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok);
-      if (dimf > 0) {
-        for (int e = lane; e < dimf * NV; e += 64) {                 // BL = J Minv
-          const int c = e / dimf, r = e - c * dimf;
-          sm[S::BL + r + SF * c] = dotAny(&sm[S::JM + r], SF, &sm[S::MINV + NV * c], 1, NV);
-        }
-        waveLdsSync();
-        for (int e = lane; e < dimf * dimf; e += 64) {               // SM = BL J^T
-          const int c = e / dimf, r = e - c * dimf;
-          sm[S::SM + r + SF * c] = dotAny(&sm[S::BL + r], SF, &sm[S::JM + c], SF, NV);
-        }
-        waveLdsSync();
-        spdInverseRows<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
-      }
-    }
-  }
-  __syncthreads();
   STAMP(5);
   // Everything below indexes by `tid` and reads the problem / node constants; making `tid` opaque and ordering memory here keeps the
   // compiler from hoisting those index computations and loads ABOVE the sweeps and carrying them through in registers (the q / v
@@ -523,6 +560,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   // ---- stage 3: finish the q / v columns; assemble MJtJinv = [Minv - TR BL, TR; TR^T, -SM], TR = BL^T SM ----
   if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);             // reads the scratch: MJ is written only after the next barrier
+  if (tid >= 160 && tid < 160 + NV) sm[S::LA + tid - 160] += dt * sm[S::MJIDC + tid - 160];      // C2, acceleration rows (t of wave 1, stage 1)
   if (tid >= 128 && tid < 128 + 6) {
     // condenseForwardEuler: Fq.head(6) <- -+ Fqq_inv Fq.head(6)
     const int r = tid - 128;
@@ -741,6 +779,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   STAMP(10);
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + pos;
 #undef STAMP
+#undef STAMPW
 }
 
 // Lie-group terms of the floating base for every stage (state_equation.hxx:12-63, cost Jacobian
@@ -854,6 +893,7 @@ static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, con
   }
   const unsigned blocks = (unsigned)(batch * M);
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
+  OcpLaunch<D>::nominal(B, batch, M, st);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
   else if (dimf == D::NF) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0); }
   else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0); }
@@ -883,6 +923,7 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
+  OcpLaunch<D>::nominal(B, batch, M, st);
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
@@ -900,6 +941,7 @@ void OcpLaunch<D>::merit(const OcpBuffers& Btry, long batch, int M, const double
   }
   const unsigned blocks = (unsigned)(batch * M);
   hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
+  OcpLaunch<D>::nominal(Btry, batch, M, st);
   hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, false, true>), dim3(blocks), dim3(256), smem, st, Btry, q0);
 }
 // The same for ParNMPC (backward-Euler stages; event-free horizons): Split / TerminalParNMPC::stageCost and constraintViolation
@@ -914,6 +956,7 @@ void OcpLaunch<D>::meritBackwardEuler(const OcpBuffers& Btry, long batch, int M,
   }
   const unsigned stages = (unsigned)(batch * (M - 1));
   hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
+  OcpLaunch<D>::nominal(Btry, batch, M, st);
   hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, Btry, q0, v0);
 }
 template <typename D>
@@ -934,6 +977,7 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
   }
   const unsigned stages = (unsigned)(batch * (M - 1));
   hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, B, q0);
+  OcpLaunch<D>::nominal(B, batch, M, st);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0);
   else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true, false, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0); }
 }

@@ -60,6 +60,16 @@ struct OcpLayout {
   // Lie-group terms of the floating base, produced by the small pre-kernel (6x6 blocks column-major)
   static constexpr int Z_JQ = 0, Z_QDIFF = 36, Z_FQQ = 44, Z_FQ6 = 80, Z_FQQI = 88, Z_FQQP = 124, Z_FQQPI = 160;
   static constexpr int LIE = roundUp16(196);
+  // nominal rigid-body record written by ocp_nominal_kernel (one lane per stage and leg) and copied into the LDS scratch of the
+  // condensation kernel (dev_rnea_tangent.hpp, RneaScratch: the records keep their dynamic fields first, in this order):
+  //   per leg joint (NJL = NL LJ of them) NJ_DYN = 42: R (9, row-major), wc, vc, bwc, blc, zc, vJ, w, hl, hn, Fl, Fn
+  //   per foot 18: R_world,foot Rc (9), fv, fw, pose part of the Baumgarte residual
+  //   base 16: z, v, w, hl, hn (+ 1 pad);  (NL + 1) x 6 nominal base force: own, then per leg;  nominal [ID; C] (NVF)
+  static constexpr int NJL = NV - 6, NJ_DYN = 42, NF_DYN = 18, NB_DYN = 16;
+  static constexpr int O_JOINT = 0, O_FEET = NJL * NJ_DYN, O_BASE = O_FEET + NC * NF_DYN, O_BN = O_BASE + NB_DYN,
+                       O_IDC = O_BN + (NC + 1) * 6;
+  static constexpr int NOM = roundUp16(O_IDC + NVF);
+  static_assert(NVF % 2 == 0, "the nominal record is copied in 16-byte pieces");
   static constexpr int G_K = 0, G_k = NU * NX;
   static constexpr int GAIN = roundUp16(G_k + NU);
   // switching-constraint record of a stage two steps ahead of an impulse (SplitStateConstraintJacobian +
@@ -182,6 +192,7 @@ struct OcpBuffers {
   double* dual;          // [batch][NS][CON]
   double* lin;           // [batch][NS][LIN]
   double* lie;           // [batch][NS][LIE]
+  double* nom;           // [batch][NS][NOM]   nominal rigid-body record (ocp_nominal_kernel -> K5 / K8 / merit)
   double* kkt;           // [batch][NS][KKT]   (terminal record holds Qxx and lx only)
   double* exp;           // [batch][NS][EXP]   (terminal record holds Fqq_prev_inv only)
   double* ric;           // [batch][NS][RIC]

@@ -77,6 +77,7 @@ struct idocp_comm {
   int rank = 0, world = 1, device = 0;
   ncclComm_t nccl = nullptr;
   LocalHub* hub = nullptr;
+  bool force_collectives = false;     // world == 1: issue the collectives through RCCL anyway (idocp_comm_set_force_collectives)
 };
 
 namespace {
@@ -137,10 +138,19 @@ int xrecv(DistState& s, int kind, int peer) {
 }
 int xgroupStart(DistState& s) { if (s.comm->nccl) NCCLC(g_rccl.GroupStart()); return IDOCP_OK; }
 int xgroupEnd(DistState& s) { if (s.comm->nccl) NCCLC(g_rccl.GroupEnd()); return IDOCP_OK; }
+// Runs `body` between ncclGroupStart and ncclGroupEnd.  The group is ALWAYS closed: a failed send / recv inside an open group would
+// otherwise leave every later RCCL call of this thread queued in a group that never ends (and the peers hanging).  The first error wins.
+template <typename Body>
+int xgrouped(DistState& s, Body body) {
+  RC(xgroupStart(s));
+  const int rc_body = body();
+  const int rc_end = xgroupEnd(s);
+  return rc_body ? rc_body : rc_end;
+}
 // in place on a device buffer of n doubles; op: 0 sum, 1 min
 int xallreduce(DistState& s, double* d_buf, size_t n, int op) {
   idocp_comm* c = s.comm;
-  if (c->world == 1) return IDOCP_OK;
+  if (c->world == 1 && !c->force_collectives) return IDOCP_OK;
   if (c->nccl) { NCCLC(g_rccl.AllReduce(d_buf, d_buf, n, ncclDouble, op == 0 ? ncclSum : ncclMin, c->nccl, s.stream)); return IDOCP_OK; }
   LocalHub* hub = c->hub;
   std::vector<double> mine(n);
@@ -189,19 +199,20 @@ int exchangeBoundary(idocp_ocp_t* h, DistState& s) {
   const bool left = rank > 0, right = rank < world - 1;
   if (right) RC(idocp_parnmpc_export_halo(h, STATE_LAST, s.sendb[STATE_LAST]));
   if (left) { RC(idocp_parnmpc_export_halo(h, COSTATE_FIRST, s.sendb[COSTATE_FIRST])); RC(idocp_parnmpc_export_halo(h, AUX_FIRST, s.sendb[AUX_FIRST])); }
-  RC(xgroupStart(s));
-  if (s.comm->nccl) {
-    if (right) RC(xsend(s, STATE_LAST, rank + 1));
-    if (left) { RC(xrecv(s, STATE_LAST, rank - 1)); RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
-    if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
-  } else {
-    // host rendezvous: all sends first (they never block), then the receives
-    if (right) RC(xsend(s, STATE_LAST, rank + 1));
-    if (left) { RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
-    if (left) RC(xrecv(s, STATE_LAST, rank - 1));
-    if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
-  }
-  RC(xgroupEnd(s));
+  RC(xgrouped(s, [&]() -> int {
+    if (s.comm->nccl) {
+      if (right) RC(xsend(s, STATE_LAST, rank + 1));
+      if (left) { RC(xrecv(s, STATE_LAST, rank - 1)); RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
+      if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
+    } else {
+      // host rendezvous: all sends first (they never block), then the receives
+      if (right) RC(xsend(s, STATE_LAST, rank + 1));
+      if (left) { RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
+      if (left) RC(xrecv(s, STATE_LAST, rank - 1));
+      if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
+    }
+    return IDOCP_OK;
+  }));
   if (left) RC(idocp_parnmpc_import_halo(h, STATE_LAST, s.recvb[STATE_LAST]));
   if (right) { RC(idocp_parnmpc_import_halo(h, COSTATE_FIRST, s.recvb[COSTATE_FIRST])); RC(idocp_parnmpc_import_halo(h, AUX_FIRST, s.recvb[AUX_FIRST])); }
   return IDOCP_OK;
@@ -267,6 +278,7 @@ int idocp_comm_world(const idocp_comm_t* c) { return c ? c->world : -1; }
 
 int idocp_parnmpc_dist_attach(idocp_ocp_t* h, idocp_comm_t* comm) {
   if (!h || !comm) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_attach: null argument");
+  if (stateOf(h)) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_attach: the handle is attached already (detach it first)");
   DistState s;
   s.comm = comm;
   s.batch = idocp_ocp_batch(h);
@@ -298,10 +310,76 @@ int idocp_parnmpc_dist_detach(idocp_ocp_t* h) {
   return IDOCP_OK;
 }
 
+// called by idocp_ocp_destroy: a handle that dies attached must not leave its halo buffers (and a key that a later handle at the
+// same address would inherit) behind
+void idocp_parnmpc_dist_on_destroy(idocp_ocp_t* h) { (void)idocp_parnmpc_dist_detach(h); }
+
+int idocp_comm_set_force_collectives(idocp_comm_t* c, int on) {
+  if (!c) return IDOCP_E_ARG;
+  c->force_collectives = on != 0;
+  return IDOCP_OK;
+}
+
+// Exercises every RCCL entry point the driver uses on THIS rank alone: grouped ncclSend / ncclRecv to itself for every halo kind
+// (buffers filled by a device pattern), all-reduce (sum, min) and broadcast, all on the shard's stream, and compares what came back.
+// With world == 1 the all-reduce / broadcast results must equal the inputs.  max_abs_diff: largest deviation seen (0 expected).
+int idocp_parnmpc_dist_transport_selftest(idocp_ocp_t* h, double* max_abs_diff) {
+  DistState* sp = stateOf(h);
+  if (!sp || !max_abs_diff) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_transport_selftest: attach a communicator first");
+  DistState& s = *sp;
+  idocp_comm* c = s.comm;
+  if (!c->nccl) return fail(IDOCP_E_UNSUPPORTED, "idocp_parnmpc_dist_transport_selftest: needs the RCCL transport (idocp_comm_init_rank)");
+  double worst = 0.0;
+  std::vector<std::vector<double>> sent(NKINDS);
+  for (int k = 0; k < NKINDS; ++k) {
+    sent[k].resize(s.count[k]);
+    for (size_t i = 0; i < s.count[k]; ++i) sent[k][i] = 1.0 + k + 1e-3 * (double)(i % 9973) + c->rank;
+    HIPC(hipMemcpyAsync(s.sendb[k], sent[k].data(), s.count[k] * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPC(hipMemsetAsync(s.recvb[k], 0, s.count[k] * sizeof(double), s.stream));
+  }
+  // every halo kind to ourselves, all in ONE group (a send to self only completes next to its receive)
+  RC(xgrouped(s, [&]() -> int {
+    for (int k = 0; k < NKINDS; ++k) { RC(xsend(s, k, c->rank)); RC(xrecv(s, k, c->rank)); }
+    return IDOCP_OK;
+  }));
+  std::vector<double> got;
+  for (int k = 0; k < NKINDS; ++k) {
+    got.resize(s.count[k]);
+    HIPC(hipMemcpyAsync(got.data(), s.recvb[k], s.count[k] * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    for (size_t i = 0; i < s.count[k]; ++i) worst = std::fmax(worst, std::fabs(got[i] - sent[k][i]));
+  }
+  // collectives: in place on a scratch copy of the first halo buffer
+  const bool forced = c->force_collectives;
+  c->force_collectives = true;
+  int rc = IDOCP_OK;
+  for (int op = 0; op < 2 && !rc; ++op) {
+    rc = xallreduce(s, s.sendb[STATE_LAST], s.count[STATE_LAST], op);
+    if (rc) break;
+    got.resize(s.count[STATE_LAST]);
+    if (hipMemcpyAsync(got.data(), s.sendb[STATE_LAST], got.size() * sizeof(double), hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+        hipStreamSynchronize(s.stream) != hipSuccess) { rc = fail(IDOCP_E_DEVICE, "selftest: copy back failed"); break; }
+    if (c->world == 1) for (size_t i = 0; i < got.size(); ++i) worst = std::fmax(worst, std::fabs(got[i] - sent[STATE_LAST][i]));
+  }
+  c->force_collectives = forced;
+  RC(rc);
+  HIPC(hipMemsetAsync(s.recvb[AUX_ALL], 0, s.count[AUX_ALL] * sizeof(double), s.stream));
+  RC(xbroadcast(s, AUX_ALL, c->world - 1));
+  got.resize(s.count[AUX_ALL]);
+  HIPC(hipMemcpyAsync(got.data(), s.recvb[AUX_ALL], got.size() * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIPC(hipStreamSynchronize(s.stream));
+  if (c->world == 1) for (size_t i = 0; i < got.size(); ++i) worst = std::fmax(worst, std::fabs(got[i] - sent[AUX_ALL][i]));
+  *max_abs_diff = worst;
+  return IDOCP_OK;
+}
+
 // rank 0: the measured state q[batch][nq], v[batch][nv] (host buffers); the other ranks receive theirs through the halos
 int idocp_parnmpc_dist_set_initial_state(idocp_ocp_t* h, const double* q, const double* v, int nq, int nv) {
   DistState* s = stateOf(h);
   if (!s || !q || !v) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_set_initial_state: attach a communicator first");
+  int mq = 0, mv = 0;
+  RC(idocp_ocp_state_dims(h, &mq, &mv));
+  if (nq != mq || nv != mv) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_set_initial_state: nq / nv do not match the model");
   HIPC(hipMemcpyAsync(s->d_q, q, sizeof(double) * s->batch * nq, hipMemcpyHostToDevice, s->stream));
   HIPC(hipMemcpyAsync(s->d_v, v, sizeof(double) * s->batch * nv, hipMemcpyHostToDevice, s->stream));
   HIPC(hipStreamSynchronize(s->stream));
@@ -314,7 +392,7 @@ int idocp_parnmpc_dist_init_backward_correction(idocp_ocp_t* h, double t) {
   DistState* s = stateOf(h);
   if (!s) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
   RC(idocp_parnmpc_init_backward_correction(h, t));
-  if (s->comm->world == 1) return IDOCP_OK;
+  if (s->comm->world == 1 && !(s->comm->nccl && s->comm->force_collectives)) return IDOCP_OK;
   RC(idocp_parnmpc_export_halo(h, AUX_ALL, s->sendb[AUX_ALL]));
   RC(xbroadcast(*s, AUX_ALL, s->comm->world - 1));
   RC(idocp_parnmpc_import_halo(h, AUX_ALL, s->recvb[AUX_ALL]));

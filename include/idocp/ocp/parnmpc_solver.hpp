@@ -68,6 +68,14 @@ class ParNMPCSolver {
     return *this;
   }
   ParNMPCSolver(ParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), comm_(other.comm_), kkt_error_(other.kkt_error_) { other.h_ = nullptr; other.comm_ = nullptr; }
+  ParNMPCSolver& operator=(ParNMPCSolver&& other) noexcept {
+    if (this != &other) {
+      idocp_ocp_destroy(h_);                 // (drops this solver's own attachment, if any)
+      h_ = other.h_; comm_ = other.comm_; robot_ = other.robot_; N_ = other.N_; kkt_error_ = other.kkt_error_;
+      other.h_ = nullptr; other.comm_ = nullptr;
+    }
+    return *this;
+  }
 
   void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
   void initBackwardCorrection(const double t) {

@@ -536,6 +536,14 @@ int idocp_parnmpc_dist_update_solution(idocp_ocp_t* shard, double t);
 /* KKT error of the whole horizon on every rank, kkt_error[batch] (host). */
 int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* shard, double t, double* kkt_error);
 int idocp_ocp_batch(idocp_ocp_t* h);
+/* dimensions of the configuration / velocity the handle's model has (q[batch][nq], v[batch][nv] of the update entries) */
+int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv);
+/* Test switches of the transport (tests/test_rccl_gpu.py; the one-GPU box cannot run more than one rank):
+ *  idocp_comm_set_force_collectives   world == 1: issue all-reduce / broadcast through RCCL anyway instead of skipping them
+ *  idocp_parnmpc_dist_transport_selftest   grouped ncclSend / ncclRecv of every halo kind to this very rank, all-reduce (sum, min) and
+ *                                          broadcast on the shard's stream; *max_abs_diff = deviation of what came back (0 expected) */
+int idocp_comm_set_force_collectives(idocp_comm_t* c, int on);
+int idocp_parnmpc_dist_transport_selftest(idocp_ocp_t* shard, double* max_abs_diff);
 /* Deep copy of a solver handle (the reference's solver classes are copyable): same configuration, device records, contact
  * sequence and discretisation. */
 int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out);

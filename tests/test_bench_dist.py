@@ -90,3 +90,27 @@ def test_bench_rejects_mismatched_world():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", IDOCP_BENCH_STUB="1", IDOCP_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_parnmpc_gpus2_plumbing_on_gloo():
+    """`python bench.py --workload anymal_parnmpc --gpus 2` end to end with the library calls stubbed (IDOCP_BENCH_STUB): the launcher
+    starts two ranks, the 128-byte communicator id made on rank 0 reaches rank 1 intact over gloo (the stub checks its bytes in
+    idocp_comm_init_rank), both ranks step in lock-step, ONE JSON line with strong scaling and 128 stages per rank comes out."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IDOCP_BENCH_STUB="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "anymal_parnmpc", "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["stages_per_rank"] == 128
+    assert out["config"]["parallelism"] == "horizon shards x2"
+
+
+def test_unique_id_exchange_is_a_no_op_on_one_rank():
+    sys.path.insert(0, ROOT)
+    import bench
+    lib = bench._StubDistLib()
+    raw = bench.exchange_unique_id(lib, None, 0, 1)
+    assert lib.idocp_comm_init_rank(raw, 0, 1, 0, None) == 0
