@@ -265,6 +265,42 @@ __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int l
   if (bad && lane == 0) *ok = 0;
 }
 
+
+// spdInverseRows for N <= 16 with the pivot row travelling as DPP row broadcasts (VGPR to VGPR, lane k of the row of 16 the matrix
+// lives in) instead of v_readlane: no scalar registers, no VALU-reads-SGPR wait states on the critical path of every pivot.
+template <int N>
+__device__ __forceinline__ void spdInverseRowsDpp(double* A, int ld, int n, int lane, int* ok) {
+  static_assert(N <= 16, "one matrix row per lane of a DPP row");
+  double a[N];
+  const bool on = lane < n;
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (on && j < n) ? A[lane + ld * j] : ((j == lane) ? 1.0 : 0.0);      // identity padding
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {
+      double prow[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) prow[j] = rowBcastN(a[j], k);
+      const double p = prow[k];
+      bad = bad || !(p > 0.0);
+      const double ip = recipNewton(p);
+      const double aik = a[k];
+      const bool isk = lane == k;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (j == k) continue;
+        const double akj = prow[j];
+        a[j] = isk ? akj * ip : a[j] - aik * akj * ip;      // (same order of operations as spdInverseRows)
+      }
+      a[k] = isk ? ip : -aik * ip;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) if (on && j < n) A[lane + ld * j] = a[j];
+  if (bad && lane == 0) *ok = 0;
+}
+
 // ordering point between LDS writes and reads of ONE wavefront (no workgroup barrier: its LDS operations execute in order)
 __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -282,7 +318,8 @@ __device__ __forceinline__ void waveLdsSync() {
 // (Robot::computeMJtJinv, robot.hxx:576-615) exploits the same tree structure.  E is kept in the (redundant) lower-left block
 // while it is needed.  Every lane of the wavefront must call this.
 template <int NB, int NL, int LJ>
-__device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, int* ok) {
+__device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, int* ok, long long* prof = nullptr) {
+#define BA_STAMP(k) do { if (prof) prof[k] = wall_clock64(); } while (0)
   constexpr int NJ = NL * LJ;
   // (i) D_i^-1 in place (full symmetric blocks)
   if (lane < NL) {
@@ -316,6 +353,7 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
       for (int c = 0; c < LJ; ++c) M[(o + r) + ld * (o + c)] = d[r][c];
   }
   waveLdsSync();
+  BA_STAMP(0);
   // (ii) E = B D^-1 (NB x NJ), stored transposed in the lower-left block: M[NB + c, r] = E[r, c]
   for (int e = lane; e < NB * NJ; e += 64) {
     const int c = e / NB, r = e - c * NB, o = NB + (c / LJ) * LJ;
@@ -325,41 +363,28 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     M[(NB + c) + ld * r] = acc;
   }
   waveLdsSync();
-  // (iii) S = A - E B^T, row r in the registers of lane r; S^-1 by Gauss-Jordan through v_readlane
+  BA_STAMP(1);
+  // (iii) S = A - E B^T: one entry per lane (NB NB lanes, NJ-term dots) written over the A block, then row r
+  // into the registers of lane r; S^-1 by Gauss-Jordan, the pivot row as DPP row broadcasts.  (Round 2: lane r formed its whole row
+  // itself -- 2 NB NJ serialised LDS reads on NB lanes -- and fetched pivot rows with v_readlane.)
   {
-    double a[NB];
-    const bool on = lane < NB;
-    const int r = on ? lane : 0;
+    static_assert(NB * NB <= 64 && NB <= 16 && NJ % 2 == 0, "block-arrow Schur complement on one wavefront");
+    double sval = 0.0;
+    const int sc = lane / NB, sr = lane - sc * NB;
+    if (lane < NB * NB) {
+      double acc = M[(sr < sc ? sr : sc) + ld * (sr < sc ? sc : sr)];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      double acc = M[(r < c ? r : c) + ld * (r < c ? c : r)];
-      for (int m = 0; m < NJ; ++m) acc -= M[(NB + m) + ld * r] * M[c + ld * (NB + m)];
-      a[c] = acc;
+      for (int m = 0; m < NJ; ++m) acc -= M[(NB + m) + ld * sr] * M[sc + ld * (NB + m)];      // (the operands are all fetched up front)
+      sval = acc;
     }
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      double prow[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) prow[j] = readLaneF64(a[j], k);
-      const double p = prow[k];
-      if (lane == 0 && !(p > 0.0)) *ok = 0;
-      const double ip = recipNewton(p);
-      const double aik = a[k];
-      const bool isk = lane == k;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        if (j == k) continue;
-        a[j] = isk ? prow[j] * ip : a[j] - aik * prow[j] * ip;
-      }
-      a[k] = isk ? ip : -aik * ip;
-    }
-    waveLdsSync();                               // every lane has read A before it is overwritten
-    if (on) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c) M[r + ld * c] = a[c];
-    }
+    waveLdsSync();                               // every lane has read A (and B) before A is overwritten
+    if (lane < NB * NB) M[sr + ld * sc] = sval;
+    waveLdsSync();
+    BA_STAMP(2);
+    spdInverseRowsDpp<NB>(M, ld, NB, lane, ok);
   }
   waveLdsSync();
+  BA_STAMP(3);
   // (iv) top-right = -S^-1 E (B is dead)
   for (int e = lane; e < NB * NJ; e += 64) {
     const int c = e / NB, r = e - c * NB;
@@ -369,6 +394,7 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     M[r + ld * (NB + c)] = -acc;
   }
   waveLdsSync();
+  BA_STAMP(4);
   // (v) bottom-right = D^-1 - E^T (top-right)
   for (int e = lane; e < NJ * NJ; e += 64) {
     const int c = e / NJ, i = e - c * NJ;
@@ -384,6 +410,8 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     M[(NB + c) + ld * r] = M[r + ld * (NB + c)];
   }
   waveLdsSync();
+  BA_STAMP(5);
+#undef BA_STAMP
 }
 
 // The same register-resident elimination for G independent n = N matrices at once: lanes [g N, (g + 1) N) of the wavefront

@@ -116,6 +116,49 @@ __device__ __forceinline__ void forEachLegJoint(Body body) {
     }
   }
 }
+// keeps the scheduler (and the load hoisting in front of it) from moving anything across: the item sweeps are written phase by phase
+// so that the operands of a phase are fetched only when the previous phase's are dead -- left alone, every LDS load of the item is
+// issued at its top and two hundred registers spill
+__device__ __forceinline__ void phaseFence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// ... and ties a value to its place in that order: instruction selection works on the whole straight-line item as ONE block and is free
+// to sink the arithmetic below every fence (it did: all loads first, all arithmetic last); a value that passes through an (empty) asm
+// has to exist at that point
+__device__ __forceinline__ void pin(V3& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)); }
+__device__ __forceinline__ void pin(double& a) { asm volatile("" : "+v"(a)); }
+// The same walk fully unrolled, the joint index a compile-time constant (body(axis tag, integral constant)): per-joint values can
+// then live in arrays that stay in registers.
+template <int J> struct JointIdx { static constexpr int value = J; };
+template <bool XYY, int J, typename Body>
+__device__ __forceinline__ void callLegJoint(Body& body) {
+  phaseFence();      // one joint step at a time
+  if constexpr (XYY) { if constexpr (J == 0) body(AxisTag<0>{}, JointIdx<J>{}); else body(AxisTag<1>{}, JointIdx<J>{}); }
+  else body(AxisTag<-1>{}, JointIdx<J>{});
+}
+template <bool XYY, bool FWD, int LJ, typename Body>
+__device__ __forceinline__ void forEachLegJointUnrolled(Body body) {
+  static_assert(LJ <= 4, "unrolled by hand");
+  if constexpr (FWD) {
+    if constexpr (LJ > 0) callLegJoint<XYY, 0>(body);
+    if constexpr (LJ > 1) callLegJoint<XYY, 1>(body);
+    if constexpr (LJ > 2) callLegJoint<XYY, 2>(body);
+    if constexpr (LJ > 3) callLegJoint<XYY, 3>(body);
+  } else {
+    if constexpr (LJ > 3) callLegJoint<XYY, 3>(body);
+    if constexpr (LJ > 2) callLegJoint<XYY, 2>(body);
+    if constexpr (LJ > 1) callLegJoint<XYY, 1>(body);
+    if constexpr (LJ > 0) callLegJoint<XYY, 0>(body);
+  }
+}
+template <bool XYY, int J> using LegFrame = JointFrame<XYY ? (J == 0 ? 0 : 1) : -1>;
+// fn(JointIdx<J>), fn(JointIdx<J - 1>), ..., fn(JointIdx<0>)
+template <int J, typename Fn>
+__device__ __forceinline__ void downFrom(Fn& fn) {
+  fn(JointIdx<J>{});
+  if constexpr (J > 0) downFrom<J - 1>(fn);
+}
 }  // namespace rt
 
 // LDS scratch of one stage (doubles).  The records keep their DYNAMIC fields first, in the order of the nominal record in HBM
@@ -225,9 +268,134 @@ struct RneaNominalCopy {
   }
 };
 
-// ---- one tangent item = (seed, leg): columns of dID and dC for the rows of this leg, and the base-force tangent ----
+// ---- one tangent item = (seed, leg), round 3: NO inward sweep.  The force tangent of a body is formed on the way out, as soon as that
+// body's motion tangent exists, and is walked back to the base at once (through the joints passed so far: j + 1 transforms for body j),
+// leaving its share in the tau tangents of those joints and in the base force.  Live state: the motion tangent (30 registers), the tau
+// tangents (LJ) and the base force (6 doubles).  Round 2 carried no per-body state either but UNDID the kinematic recursion on an inward
+// sweep (dev_rbd.hpp's trick for chains): the whole inertia / momentum algebra sat on the inward dependency chain, a fifth more
+// arithmetic, and 13 - 27 registers spilled.  Same columns as rneaTangentItemUndo up to the order of the sums. ----
 template <typename D, bool XYY = false>
 __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, double* sc, const RneaOut& out) {
+  using S = RneaScratch<D>;
+  using namespace rt;
+  constexpr int LJ = D::LJ, NV = D::NV;
+  const int leg = item / S::IPL, j0 = item - leg * S::IPL;
+  const bool base_seed = j0 < 18;
+  const int kind = base_seed ? j0 / 6 : (j0 - 18) / LJ;                           // 0: q, 1: v, 2: a
+  const int k = base_seed ? j0 - 6 * kind : 6 + leg * LJ + (j0 - 18 - LJ * kind);   // velocity index of the seed
+  double* __restrict__ colp = (kind < 2) ? out.didc + (long)out.ldd * (kind * NV + k) : out.mm + NV * k;     // dynamics rows of this column
+  double* __restrict__ colc = (kind < 2) ? colp + NV : out.jm + (long)out.ldj * k;                            // its contact rows
+  const double* br = sc + S::BASE;
+  auto e3 = [](int i) { return v3(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0); };
+  const V3 zero = v3(0, 0, 0);
+  // ---- base: tangents of (z, v, w, a_gf linear, a angular) ----
+  V3 dz = (kind == 0 && k >= 3 && k < 6) ? cross(ld3(br + S::B_Z), e3(k - 3)) : zero;      // d(R_w^T e_z) for R_w <- R_w exp(e_ang)
+  V3 dv = (kind == 1 && k < 3) ? e3(k) : zero, dw = (kind == 1 && k >= 3 && k < 6) ? e3(k - 3) : zero;
+  V3 dbl = ((kind == 2 && k < 3) ? e3(k) : zero) - gz * dz, dbw = (kind == 2 && k >= 3 && k < 6) ? e3(k - 3) : zero;
+  if (leg == 0 && base_seed) {
+    // the base's own inertial force: once per base seed
+    V3 dhl, dhn, df, dn;
+    const V3 mc = ld3(br + S::B_MC), w0 = ld3(br + S::B_W), v0 = ld3(br + S::B_V), hl0 = ld3(br + S::B_HL), hn0 = ld3(br + S::B_HN);
+    inertia(br[S::B_MASS], mc, br + S::B_IO, dv, dw, dhl, dhn);
+    inertia(br[S::B_MASS], mc, br + S::B_IO, dbl, dbw, df, dn);
+    double* o = sc + S::BOWN + 6 * j0;
+    st3(o, df + cross(dw, hl0) + cross(w0, dhl));
+    st3(o + 3, dn + cross(dw, hn0) + cross(w0, dhn) + cross(dv, hl0) + cross(v0, dhl));
+  }
+  double tau[LJ];
+#pragma unroll
+  for (int j = 0; j < LJ; ++j) tau[j] = 0.0;
+  V3 baseFl = zero, baseFn = zero;
+  const double* jleg = sc + S::JOINTS + leg * LJ * S::JREC;
+  forEachLegJointUnrolled<XYY, true, LJ>([&](auto tag, auto jc) {
+    constexpr int AX = decltype(tag)::value, j = decltype(jc)::value;
+    const int dof = 6 + leg * LJ + j;
+    const double* jr = jleg + j * S::JREC;
+    const bool mine = (k == dof);
+    const double sq = (mine && kind == 0) ? 1.0 : 0.0, sv = (mine && kind == 1) ? 1.0 : 0.0, sa = (mine && kind == 2) ? 1.0 : 0.0;
+    const JointFrame<AX> F(jr, S::J_R, S::J_U);
+    // ---- phase 1: the motion tangent of this body ----
+    {
+      const V3 p = ld3(jr + S::J_P);
+      const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC);
+      const V3 dwc = F.mulT(dw) - F.crossUk(ld3(jr + S::J_WC), sq);
+      const V3 dvc = F.mulT(dv + cross(dw, p)) - F.crossUk(vj, sq);
+      const V3 dbwc = F.mulT(dbw) - F.crossUk(ld3(jr + S::J_BWC), sq);
+      const V3 dblc = F.mulT(dbl + cross(dbw, p)) - F.crossUk(ld3(jr + S::J_BLC), sq);
+      dz = F.mulT(dz) - F.crossUk(ld3(jr + S::J_ZC), sq);
+      dw = dwc + F.timesU(sv); dv = dvc;
+      if constexpr (AX < 0) {
+        const V3 vJ = ld3(jr + S::J_VJ), dvJ = F.timesU(sv);
+        dbw = dbwc + F.timesU(sa) + cross(dw, vJ) + cross(wj, dvJ);
+        dbl = dblc + cross(dv, vJ) + cross(vj, dvJ);
+      } else {
+        const double qd = jr[S::J_VJ + (AX < 0 ? 0 : AX)];      // S qd = qd u (coordinate axis: one component)
+        dbw = dbwc + F.timesU(sa) + F.crossKU(dw, qd) + F.crossKU(wj, sv);
+        dbl = dblc + F.crossKU(dv, qd) + F.crossKU(vj, sv);
+      }
+    }
+    pin(dw); pin(dv); pin(dbw); pin(dbl); pin(dz);
+    phaseFence();
+    // ---- phase 2: d(I a + w x I v) of this body: inertia products first (their operands are dead before the momenta are fetched) ----
+    V3 Fl, Fn;
+    {
+      V3 dhl, dhn;
+      {
+        const V3 mc = ld3(jr + S::J_MC);
+        inertia(jr[S::J_MASS], mc, jr + S::J_IO, dv, dw, dhl, dhn);
+        inertia(jr[S::J_MASS], mc, jr + S::J_IO, dbl, dbw, Fl, Fn);
+      }
+      pin(dhl); pin(dhn); pin(Fl); pin(Fn);
+      phaseFence();
+      const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), hl = ld3(jr + S::J_HL), hn = ld3(jr + S::J_HN);
+      Fl = Fl + cross(dw, hl) + cross(wj, dhl);
+      Fn = Fn + cross(dw, hn) + cross(wj, dhn) + cross(dv, hl) + cross(vj, dhl);
+    }
+    pin(Fl); pin(Fn);
+    phaseFence();
+    // ---- phase 3: walk the force back to the base through joints j .. 0 ----
+    auto hop = [&](auto jjc) {
+      constexpr int jj = decltype(jjc)::value;
+      const double* jq = jleg + jj * S::JREC;
+      const LegFrame<XYY, jj> G(jq, S::J_R, S::J_U);
+      tau[jj] += G.dotU(Fn);
+      if constexpr (jj == j) {      // the joint's own transform turns with a q seed: + d(R)/dq applied to the nominal accumulated force
+        Fl = Fl + G.crossUk(ld3(jq + S::J_FL), sq);
+        Fn = Fn + G.crossUk(ld3(jq + S::J_FN), sq);
+      }
+      const V3 Rf = G.mul(Fl);
+      Fn = G.mul(Fn) + cross(ld3(jq + S::J_P), Rf);
+      Fl = Rf;
+    };
+    downFrom<j>(hop);
+    baseFl = baseFl + Fl; baseFn = baseFn + Fn;
+    pin(baseFl); pin(baseFn);
+#pragma unroll
+    for (int t = 0; t <= j; ++t) pin(tau[t]);
+  });
+  phaseFence();
+  // ---- contact frame at the foot: Baumgarte derivative column (point_contact.hxx:117-143) without its position term ----
+  const double* fr = sc + S::FEET + leg * S::FREC;
+  if (fr[S::F_ACT] != 0.0) {
+    const double* Rc = fr + S::F_RC;
+    const V3 pc = ld3(fr + S::F_PC);
+    const V3 dal = dbl + gz * dz;
+    // (XYY also promises an identity rotation of the contact frame in its joint, like ANYmal's feet: Rc^T a = a)
+    const V3 dfv = XYY ? dv + cross(dw, pc) : mulT(Rc, dv + cross(dw, pc)), dfw = XYY ? dw : mulT(Rc, dw),
+             dfa = XYY ? dal + cross(dbw, pc) : mulT(Rc, dal + cross(dbw, pc));
+    const V3 dc = dfa + cross(ld3(fr + S::F_FW), dfv) + cross(ld3(fr + S::F_FV), dfw) + wv * dfv;
+    st3(colc + (int)fr[S::F_ROW], dc);
+  }
+#pragma unroll
+  for (int j = 0; j < LJ; ++j) colp[6 + leg * LJ + j] = tau[j];
+  double* o = sc + S::BT + 6 * item;
+  st3(o, baseFl); st3(o + 3, baseFn);
+}
+
+// ---- the round-2 form of the item (no per-body state, the kinematic steps undone on the way in); kept for comparison
+// (IDOCP_ITEM_UNDO at build time selects it) ----
+template <typename D, bool XYY = false>
+__device__ __forceinline__ void rneaTangentItemUndo(double gz, double wv, int item, double* sc, const RneaOut& out) {
   using S = RneaScratch<D>;
   using namespace rt;
   constexpr int LJ = D::LJ, NV = D::NV;

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
           sm[S::MJIDC + lane] = acc;
         }
         waveLdsSync();
+        STAMPW(4);
         blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok);
         STAMPW(1);
         // C1 done?  BL, SM reuse its input block.  (Its two wavefronts each add one; LDS operations of a wavefront complete in order.)
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
             sm[S::SM + r + SF * c] = dotAny(&sm[S::BL + r], SF, &sm[S::JM + c], SF, NV);
           }
           waveLdsSync();
-          spdInverseRows<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
+          spdInverseRowsDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
         }
         STAMPW(3);
       }
