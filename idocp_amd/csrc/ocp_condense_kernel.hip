@@ -17,6 +17,8 @@
 // items of dev_rnea_tangent.hpp, writes the kkt record (LQR stage for the Riccati sweep) and the exp record (expansion cache).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
 #include "dev_rnea_tangent.hpp"
@@ -59,7 +61,7 @@ struct CondenseSmem {
   //   MINV  = MM            the mass matrix is inverted in place (scratch: MJ, not yet written)
   //   QAFQV = DIDC          dIDCdqv is dead once MJD = MJtJinv * dIDCdqv is formed
   //   QAFU  = MM .. JM      M^-1 and J are dead once MJtJinv is assembled
-  //   BL, SM, BR  share the block that holds the solution / slack / dual copies during phase C
+  //   BL, SM  share the block that holds the solution / slack / dual copies during phase C
   //   ERR   = MJ            (RESIDUAL variant only, which never forms MJtJinv)
   // The condensed Hessian blocks are never staged in LDS: phase H writes them to the kkt record.
   static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV,
@@ -70,16 +72,19 @@ struct CondenseSmem {
                        QFF = (MJD + NVF * NX > MJ + RneaScratch<D>::TOTAL) ? MJD + NVF * NX : MJ + RneaScratch<D>::TOTAL, TMP = QFF + NF * NF,
                        MINV = MM, QAFQV = DIDC, QAFU = MM, ERR = MJ;
   static constexpr int SOLS = TMP, SOLN = SOLS + L::SOL, SLK = SOLN + L::SOL, DUL = SLK + L::CON, TMP_EARLY = DUL + L::CON - TMP;
-  static constexpr int BL = TMP, SM = BL + NF * NV, BR = SM + NF * NF, TMP_LATE = BR + NF * NF - TMP;
+  static constexpr int BL = TMP, SM = BL + NF * NV, TMP_LATE = SM + NF * NF - TMP;
   static constexpr int VEC = TMP + (TMP_EARLY > TMP_LATE ? TMP_EARLY : TMP_LATE);
   static_assert(NVF * NV <= IDC - MM, "Qafu_full must fit in the M / J blocks");
   static_assert(512 <= NVF * NVF, "ERR (two accumulators per thread in the MERIT variant) aliases MJ");
   // vectors
   static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
-                       LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV, JQ = BM + 32, FQQ = JQ + 36, FQQP = FQQ + 36,
-                       FQQI = FQQP + 36, FQQPI = FQQI + 36, FQV = FQQPI + 36, QDIFF = FQV + 36, FQ6 = QDIFF + 8,
-                       HQD = FQ6 + 8, HVD = HQD + NV, HUD = HVD + NV, QB6 = HUD + NU,       // diagonal / base-block Hessian terms before condensing
+                       LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV,
+                       // the Lie-group terms of the base in the order of the lie record (OcpLayout Z_*)
+                       LIEB = BM + 32, JQ = LIEB + L::Z_JQ, QDIFF = LIEB + L::Z_QDIFF, FQQ = LIEB + L::Z_FQQ, FQ6 = LIEB + L::Z_FQ6,
+                       FQQI = LIEB + L::Z_FQQI, FQQP = LIEB + L::Z_FQQP, FQQPI = LIEB + L::Z_FQQPI,
+                       HQD = LIEB + 196, HVD = HQD + NV, HUD = HVD + NV, QB6 = HUD + NU,       // diagonal / base-block Hessian terms before condensing
                        TOTAL = QB6 + 36 + 2;
+  static_assert(SOLS % 2 == 0 && LIEB % 2 == 0 && IDC % 2 == 0 && MJ % 2 == 0, "16-byte pieces");
 };
 
 // BWD = true: the backward-Euler stage of ParNMPC (SplitParNMPC / TerminalParNMPC::linearizeOCP,
@@ -106,8 +111,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const int M = P->M;
   int tid = threadIdx.x;
   constexpr int nt = 256;
-  const long unit = blockIdx.x;                   // over batch * M: one stage of the chain per workgroup
-  const int per = plist ? nlist : M;              // (or over batch * nlist: the chain positions of one stage class, launchCondenseMixed)
+  const int per = plist ? nlist : M;              // units: batch * M, one stage of the chain each (or batch * nlist: the chain positions of one
+                                                  // stage class, launchCondenseMixed)
+  // (The body is a lambda on purpose: as the kernel's own top-level block the same code spilled 4 - 26 registers in the tangent
+  //  items; a persistent variant -- a workgroup walking over several units, the next unit's records fetched by LDS DMA during the
+  //  back half -- was measured as well: loop-invariant hoisting out of the unit loop brings the spills back and the stage-0 wait
+  //  then also covers the previous unit's output stores: 4.16 instead of 3.44 ms, not kept.)
+  auto stage = [&](const long unit) {
   const long b = unit / per;
   const int pos = plist ? plist[unit - b * per] : (int)(unit - b * per);
   const OcpNode* __restrict__ nd = B.nodes + pos;
@@ -779,6 +789,8 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   STAMP(10);
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1 + pos;
+  };      // stage
+  stage((long)blockIdx.x);
 #undef STAMP
 #undef STAMPW
 }
