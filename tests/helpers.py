@@ -246,7 +246,7 @@ def referee_check(g, o, h, what, tol=1e-10, factor=4.0, window=3):
     differences travel along the sweep), plus the 1e-10 bar itself.  Returns (worst GPU error, worst oracle error), relative
     to the largest entry."""
     g, o, h = (np.asarray(x, dtype=np.float64).reshape(len(h), -1) for x in (g, o, h))
-    scale = max(1.0, np.abs(h).max())
+    scale = np.maximum(1.0, np.abs(h).max(axis=1))             # per stage, like rel_err
     eg, eo = np.abs(g - h).max(axis=1) / scale, np.abs(o - h).max(axis=1) / scale
     eo_w = np.array([eo[max(0, i - window):i + window + 1].max() for i in range(len(eo))])
     bad = np.nonzero(eg > factor * eo_w + tol)[0]
@@ -254,8 +254,17 @@ def referee_check(g, o, h, what, tol=1e-10, factor=4.0, window=3):
     return eg.max(), eo.max()
 
 def rel_err(a, b):
-    a, b = np.asarray(a), np.asarray(b)
-    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    """Largest deviation of a from b, STAGE BY STAGE: arrays with a leading stage (or instance) axis are compared entry-wise and
+    every stage's error is taken relative to the largest entry of that very stage of b (never less than 1: entries below one are
+    held to the absolute bar).  Along a trotting chain |P| and the direction vary by orders of magnitude from stage to stage; a
+    norm over the whole horizon would let the large stages hide an error in the small ones."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.ndim < 2 or a.shape != b.shape:
+        return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    n = a.shape[0]
+    err = np.abs(a - b).reshape(n, -1).max(axis=1)
+    scale = np.maximum(1.0, np.abs(b).reshape(n, -1).max(axis=1))
+    return float((err / scale).max())
 
 
 # ------------------------------------------------------------------ contact path

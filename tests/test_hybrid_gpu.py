@@ -212,25 +212,36 @@ def test_full_size_c3_trotting_parity_and_properties():
     assert abs(e_g[0] - e_o) <= 1e-9 * max(1.0, e_o)
     assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
     # The last touch-down of this schedule sits 5 ms after a grid point: on the stage behind that switching constraint
-    # G = Quu + B^T P B has a condition number of 3e8 and the FP64 oracle itself is 3.4e-10 away from its long double build
-    # (1e-13 on the first half of the chain).  The bar here is the referee's: stage by stage the GPU is at most 4x as far from
-    # the long double result as the FP64 oracle is, + 1e-10 (measured: GPU 4.0e-10, oracle 3.4e-10; round 1, with explicit
-    # Gauss-Jordan inverses in the Riccati step, was 1e-6 away).  Against the oracle itself: 1e-10 on the first half, 2e-9 overall.
+    # G = Quu + B^T P B has a condition number of 3e8 and the FP64 oracle itself is 5e-9 away from its long double build THERE
+    # (every stage measured against its own largest entry, helpers.rel_err; 1e-13 on the first half of the chain; round 2 quoted
+    # 3.4e-10, with the whole horizon's largest entry as the scale).  The bar is the referee's: stage by stage the GPU is at most 4x as
+    # far from the long double result as the FP64 oracle is, + 1e-10 (round 1, with explicit Gauss-Jordan inverses in the Riccati
+    # step, was 1e-6 away).  Against the oracle itself: 1e-10 on the first half of the chain, 2e-8 overall.
     worst_g = worst_o = 0.0
     for f in OCP_DIR_FIELDS:
         eg, eo = referee_check(g.get_chain(f, M), o.get_chain(f, M), h.get_chain(f, M), f)
         worst_g, worst_o = max(worst_g, eg), max(worst_o, eo)
-    assert worst_g < 2e-9 and worst_o < 2e-9, (worst_g, worst_o)
-    compare_chain(o, g, M, list(OCP_DIR_FIELDS), 2e-9, "first iteration, full size")
+    assert worst_g < 2e-8 and worst_o < 2e-8, (worst_g, worst_o)
+    compare_chain(o, g, M, list(OCP_DIR_FIELDS), 2e-8, "first iteration, full size")
     for f in OCP_DIR_FIELDS:
-        a, b = g.get_chain(f, M), o.get_chain(f, M)
-        assert np.abs(a[:60] - b[:60]).max() / max(1.0, np.abs(b).max()) < 1e-10, f
+        a, b = np.asarray(g.get_chain(f, M)), np.asarray(o.get_chain(f, M))
+        assert rel_err(a[:60], b[:60]) < 1e-10, f
     for it in range(9):
-        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
     assert abs(e_g[0] - e_o) <= 1e-4 * max(1.0, e_o) and e_g[0] == e_g[2]
     qs = g.get_chain("q", M, 1)
     assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12
+    # THE CONVERGED SOLUTION against the referee's: the three solvers iterate on until the KKT error has stalled (GPU and FP64
+    # oracle at their rounding floors), then the GPU's primal solution may be at most 4x as far from the long double solver's as the
+    # FP64 oracle's is, + 1e-8 (a solution is only determined to cond(KKT) eps), stage by stage.
+    for it in range(30):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
+    e_o, e_g, e_h = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0], h.kkt_error(0.0, q, v)
+    assert e_g < 1e-6 and e_o < 1e-6 and e_h < 1e-6, (e_g, e_o, e_h)
+    for f in ("q", "v", "a", "u", "f"):
+        sg, so, sh = (np.asarray(x.get_chain(f, M)) for x in (g, o, h))
+        referee_check(sg, so, sh, "converged " + f, tol=1e-8)
 
 
 def test_general_axes_instantiations_direction_parity(monkeypatch):
@@ -238,16 +249,22 @@ def test_general_axes_instantiations_direction_parity(monkeypatch):
     dev_rnea_tangent.hpp JointFrame).  IDOCP_GENERAL_AXES forces the general instantiations -- what any other quadruped would run -- on the
     same problem: both must match the oracle, and each other, on a chain with lift, impulse and aux stages."""
     monkeypatch.setenv("IDOCP_GENERAL_AXES", "1")
-    m, o, g_general, q, v = make_pair(30, 1.55, 2)
+    m, o, g_general, q, v, h = make_pair(30, 1.55, 2, referee=True)
     monkeypatch.delenv("IDOCP_GENERAL_AXES")
     _, _, g_special, _, _ = make_pair(30, 1.55, 2)
     qq = q.copy()
     qq[7:] += 0.02 * np.random.default_rng(4).uniform(-1, 1, 12)
-    assert o.update(0.0, qq, v) == 0 and g_general.update(0.0, qq, v) == 0 and g_special.update(0.0, qq, v) == 0
+    assert o.update(0.0, qq, v) == 0 and g_general.update(0.0, qq, v) == 0 and g_special.update(0.0, qq, v) == 0 and h.update(0.0, qq, v) == 0
     M = len(o.chain(0.0))
     dirs = list(OCP_DIR_FIELDS) + ["dxi"]
-    compare_chain(o, g_general, M, dirs, 1e-10, "direction (general axes)")
-    compare_chain(o, g_special, M, dirs, 1e-10, "direction (compile-time axes)")
+    # (this grid has a 1.7 ms stage in front of the second impulse: stage by stage the FP64 oracle is itself a few 1e-10 away from its
+    #  long double build there, so the referee decides; 1e-8 is the cap against the oracle and between the two instantiations)
+    for f in dirs:
+        hf = h.get_chain(f, M)
+        referee_check(g_general.get_chain(f, M), o.get_chain(f, M), hf, f + " (general axes)")
+        referee_check(g_special.get_chain(f, M), o.get_chain(f, M), hf, f + " (compile-time axes)")
+    compare_chain(o, g_general, M, dirs, 1e-8, "direction (general axes)")
+    compare_chain(o, g_special, M, dirs, 1e-8, "direction (compile-time axes)")
     for f in dirs:
         a, b = np.asarray(g_general.get_chain(f, M)), np.asarray(g_special.get_chain(f, M))
-        assert rel_err(a, b) < 1e-10, f
+        assert rel_err(a, b) < 1e-8, f

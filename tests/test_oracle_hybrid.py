@@ -209,14 +209,15 @@ def test_running_example_converges():
 
 def test_long_double_referee_build_agrees_with_the_fp64_oracle():
     """oracle/liboracle_hp.so is the same restatement compiled with a long double scalar (the referee of the GPU parity tests on
-    ill-conditioned stages).  On a normally conditioned grid the two builds agree to 1e-12; on BASELINE configs[2] at its own size
-    (N = 100, T = 5.05, 10 events), where the stage behind the last switching constraint has cond(Quu + B^T P B) = 3e8, the FP64
-    build is a few 1e-10 away from the long double one -- the size of error the GPU is allowed on that problem."""
+    ill-conditioned stages).  Every stage is measured against its own largest entry (helpers.rel_err).  On a normally conditioned
+    grid the two builds agree to 1e-11; on BASELINE configs[2] at its own size (N = 100, T = 5.05, 10 events), where the stage
+    behind the last switching constraint has cond(Quu + B^T P B) = 3e8, the FP64 build is 5e-9 away from the long double one on
+    that stage -- the size of error the GPU is allowed there."""
     import numpy as np
     from helpers import ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OracleOCP, anymal_model, anymal_problem, rel_err, trotting_sequence
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=True)
-    for (N, T, nimp, lo, hi) in ((31, 1.55, 2, 0.0, 1e-12), (100, 5.05, 9, 1e-11, 2e-9)):
+    for (N, T, nimp, lo, hi) in ((31, 1.55, 2, 0.0, 1e-11), (100, 5.05, 9, 1e-10, 2e-8)):
         pair = [OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=hp) for hp in (False, True)]
         q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
         for s in pair:

@@ -206,8 +206,10 @@ def test_full_size_c4_parity_and_properties():
     """BASELINE configs[3] at its own size (ANYmal ParNMPC, N = 256, T = 12.8) as a WELL-POSED problem: warm start from the converged
     Riccati solution of the same OCP (helpers.warm_start_parnmpc; the MPC use of the solver).  The first direction is then O(1)
     -- from the reference's cold start it grows to 3e12 along the forward correction sweep, a number no tolerance is meaningful
-    on -- and must meet the 1e-10 bar stage by stage; a long double referee stands by for the stages where two FP64 evaluations
-    separate by more.  Then the iteration converges, GPU and oracle side by side."""
+    on.  Stage by stage (every stage against its own largest entry) the GPU direction is held to 1e-9 of the oracle's and to the
+    referee rule -- at most 4x as far from a long double evaluation as the FP64 oracle is, + 1e-10 -- because over 256 stages of
+    the correction sweeps two FP64 evaluation orders separate by more than 1e-10.  Then the iteration converges, GPU and oracle side
+    by side."""
     from helpers import OracleOCP, warm_start_parnmpc
     N, T = 256, 12.8
     m, o, g, q, v, h = make_pair(N, T, batch=3, referee=True)
@@ -233,9 +235,7 @@ def test_full_size_c4_parity_and_properties():
         d_o, d_g, d_h = o.get(f), g.get(f), h.get(f)
         assert np.abs(d_o).max() < 1e3, (f, np.abs(d_o).max())              # a direction one can step along
         referee_check(d_g, d_o, d_h, f)
-        # stage by stage, relative to the stage's own entries (not to the largest entry of the horizon)
-        per_stage = np.abs(d_g - d_o).max(axis=1) / np.maximum(1.0, np.abs(d_o).max(axis=1))
-        assert per_stage.max() < 1e-9, (f, per_stage.max(), per_stage.argmax())
+        assert rel_err(d_g, d_o) < 1e-9, (f, rel_err(d_g, d_o))                  # stage by stage (helpers.rel_err)
         assert np.array_equal(g.get(f, 0), g.get(f, 2))                         # identical instances, identical results
     for it in range(6):
         assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
