@@ -64,12 +64,13 @@ struct CondenseSmem {
   //   BL, SM  share the block that holds the solution / slack / dual copies during phase C
   //   ERR   = MJ            (RESIDUAL variant only, which never forms MJtJinv)
   // The condensed Hessian blocks are never staged in LDS: phase H writes them to the kkt record.
-  static constexpr int DIDC = 0, MM = DIDC + NVF * NX, JM = MM + NV * NV,
+  // (dIDCdqv and MJD carry one more column: [ID; C] itself, so that MJtJinv [ID; C] falls out of the tile product MJtJinv dIDCdqv)
+  static constexpr int DIDC = 0, MM = DIDC + NVF * (NX + 1), JM = MM + NV * NV,
                        IDC = JM + ((NF * NV > NVF * NV - NV * NV) ? NF * NV : NVF * NV - NV * NV),      // (Qafu_full, NVF x NV, later takes the M .. J blocks)
                        MJ = IDC + 32,
                        MJD = MJ + NVF * NVF,
                        // MJ .. MJD also hold the scratch of the RNEA sweeps (dead before MJtJinv is assembled); the narrow layouts are padded for it
-                       QFF = (MJD + NVF * NX > MJ + RneaScratch<D>::TOTAL) ? MJD + NVF * NX : MJ + RneaScratch<D>::TOTAL, TMP = QFF + NF * NF,
+                       QFF = (MJD + NVF * (NX + 1) > MJ + RneaScratch<D>::TOTAL) ? MJD + NVF * (NX + 1) : MJ + RneaScratch<D>::TOTAL, TMP = QFF + NF * NF,
                        MINV = MM, QAFQV = DIDC, QAFU = MM, ERR = MJ;
   static constexpr int SOLS = TMP, SOLN = SOLS + L::SOL, SLK = SOLN + L::SOL, DUL = SLK + L::CON, TMP_EARLY = DUL + L::CON - TMP;
   static constexpr int BL = TMP, SM = BL + NF * NV, TMP_LATE = SM + NF * NF - TMP;
@@ -78,7 +79,8 @@ struct CondenseSmem {
   static_assert(512 <= NVF * NVF, "ERR (two accumulators per thread in the MERIT variant) aliases MJ");
   // vectors
   static constexpr int LQ = VEC, LV = LQ + NV, LA = LV + NV, LF = LA + NV, LU = LF + NF, LUP = LU + NU, FQ = LUP + 6, FV = FQ + NV,
-                       LAF = FV + NV, MJIDC = LAF + 32, QAA = MJIDC + 32, BM = QAA + NV,
+                       LAF = FV + NV, TLA = LAF + 32, QAA = TLA + 32,      // TLA: t = M^T beta + J^T mu (wave 1 -> stage 3)
+                       BM = QAA + NV,
                        // the Lie-group terms of the base in the order of the lie record (OcpLayout Z_*)
                        LIEB = BM + 32, JQ = LIEB + L::Z_JQ, QDIFF = LIEB + L::Z_QDIFF, FQQ = LIEB + L::Z_FQQ, FQ6 = LIEB + L::Z_FQ6,
                        FQQI = LIEB + L::Z_FQQI, FQQP = LIEB + L::Z_FQQP, FQQPI = LIEB + L::Z_FQQPI,
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
             const double* jc = &sm[S::JM + c_row[c] + SF * lane];
             acc += jc[0] * s[L::S_MU + 3 * c] + jc[1] * s[L::S_MU + 3 * c + 1] + jc[2] * s[L::S_MU + 3 * c + 2];
           }
-          sm[S::MJIDC + lane] = acc;
+          sm[S::TLA + lane] = acc;
         }
         waveLdsSync();
         STAMPW(4);
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   // ---- stage 3: finish the q / v columns; assemble MJtJinv = [Minv - TR BL, TR; TR^T, -SM], TR = BL^T SM ----
   if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);             // reads the scratch: MJ is written only after the next barrier
-  if (tid >= 160 && tid < 160 + NV) sm[S::LA + tid - 160] += dt * sm[S::MJIDC + tid - 160];      // C2, acceleration rows (t of wave 1, stage 1)
+  if (tid >= 160 && tid < 160 + NV) sm[S::LA + tid - 160] += dt * sm[S::TLA + tid - 160];      // C2, acceleration rows (t of wave 1, stage 1)
   if (tid >= 128 && tid < 128 + 6) {
     // condenseForwardEuler: Fq.head(6) <- -+ Fqq_inv Fq.head(6)
     const int r = tid - 128;
@@ -580,7 +582,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::FQ6 + r] = BWD ? acc : -acc;
   }
   __syncthreads();
-  if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88)
+  if (tid < dimvf) {
+    // ID - u on the actuated rows (contact_dynamics.hxx:88); [ID; C] also becomes column NX of dIDCdqv: MJtJinv [ID; C] then falls out
+    // of the tile product below (round 2: a 24-term dot product per row on 24 threads, 1 us)
+    double val = sm[S::IDC + tid];
+    if (!impulse && tid >= 6 && tid < NV && nd->has_u) { val -= s_g[L::S_U + tid - 6]; sm[S::IDC + tid] = val; }
+    sm[S::DIDC + tid + SVF * NX] = val;
+  }
   if (tid >= 64 && tid < 64 + 6) sm[S::FQ + tid - 64] = sm[S::FQ6 + tid - 64];
   for (int e = tid; e < dimf * NV; e += nt) {
     const int c = e / NV, r = e - c * NV;                              // TR(r, c) = sum_p BL(p, r) SM(p, c)
@@ -627,15 +635,15 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     for (int jb = wave; jb < TX; jb += nt >> 6) {
       mfma_d4 a0, a1;
       const int r1 = dimvf > 16 ? dimvf - 16 : 1;
-      mfmaTilePairTN<RVF>(&sm[S::MJ], dimvf < 16 ? dimvf : 16, &sm[S::DIDC + SVF * 16 * jb], NX - 16 * jb, &sm[S::MJ + SVF * 16], r1,
-                          &sm[S::DIDC + SVF * 16 * jb], NX - 16 * jb, SVF, SVF, dimvf, lane, a0, a1);
+      mfmaTilePairTN<RVF>(&sm[S::MJ], dimvf < 16 ? dimvf : 16, &sm[S::DIDC + SVF * 16 * jb], NX + 1 - 16 * jb, &sm[S::MJ + SVF * 16], r1,
+                          &sm[S::DIDC + SVF * 16 * jb], NX + 1 - 16 * jb, SVF, SVF, dimvf, lane, a0, a1);
       auto put = [&](int r, int c, double v) { sm[S::MJD + r + SVF * c] = v; };
-      mfmaTileStore(a0, 0, 16 * jb, dimvf, NX, lane, put);
-      mfmaTileStore(a1, 16, 16 * jb, dimvf, NX, lane, put);
+      mfmaTileStore(a0, 0, 16 * jb, dimvf, NX + 1, lane, put);
+      mfmaTileStore(a1, 16, 16 * jb, dimvf, NX + 1, lane, put);
     }
   }
   STAMP(11);
-  mv(&sm[S::MJIDC], colMajor(&sm[S::MJ], SVF), &sm[S::IDC], dimvf, dimvf, 1.0, false, tid, nt);
+  const double* const mjidc = &sm[S::MJD + SVF * NX];      // MJtJinv [ID; C]: column NX of the product above
   // Qafu_full = Qaf MJ.leftCols(nv) needs only MJ: it runs next to the product above (QAFU aliases M, J, dead since the last barrier).
   // Acceleration rows (Qaa diagonal) and contact rows (Qff dense) as loops of their own: no divergence, constant trip counts.
 #pragma unroll
@@ -663,8 +671,8 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   if (tid < dimvf) {
     const int r = tid;
     double val;
-    if (r < NV) val = sm[S::LA + r] - sm[S::QAA + r] * sm[S::MJIDC + r];
-    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + SF * p] * sm[S::MJIDC + NV + p]; val = -sm[S::LF + r - NV] - acc; }
+    if (r < NV) val = sm[S::LA + r] - sm[S::QAA + r] * mjidc[r];
+    else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + SF * p] * mjidc[NV + p]; val = -sm[S::LF + r - NV] - acc; }
     sm[S::LAF + r] = val;
   }
   __syncthreads();
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const int r = tid - 64;
     const double acc = hu * dotAny(&sm[S::MJ + r], SVF, &sm[S::LAF], 1, dimvf);
     if (r < 6) sm[S::LUP + r] += acc; else sm[S::LU + r - 6] += acc;
-    sm[S::FV + r] -= dt * sm[S::MJIDC + r];
+    sm[S::FV + r] -= dt * mjidc[r];
   }
   __syncthreads();
 
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // MJtJinv: the lower triangle, row by row (consecutive threads write consecutive addresses); element t of the triangle is (r, c) with
   // r = the largest integer with r (r + 1) / 2 <= t
   for (int t = tid; t < RVF * (RVF + 1) / 2; t += nt) {
-    int r = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    int r = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);      // (single precision + the two corrections: exact here)
     if ((r + 1) * (r + 2) / 2 <= t) ++r;
     if (r * (r + 1) / 2 > t) --r;
     const int c = t - r * (r + 1) / 2;
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   if (tid < NV) ee[L::E_QAA + tid] = sm[S::QAA + tid];
   for (int e = tid; e < SF * SF; e += nt) { const int c = e / SF, r = e - c * SF; ee[L::E_QFF + r + NF * c] = sm[S::QFF + e]; }
-  if (tid < RVF) { ee[L::E_MJIDC + tid] = sm[S::MJIDC + tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
+  if (tid < RVF) { ee[L::E_MJIDC + tid] = mjidc[tid]; ee[L::E_LAF + tid] = sm[S::LAF + tid]; }
   if (tid < 6) ee[L::E_LUP + tid] = sm[S::LUP + tid];
   // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199) ----
   if (sw_dimi > 0) {
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
     if (tid < dimi) {                                     // P -= Phia MJtJinv_IDC.head(nv)
       double acc = 0.0;
-      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + tid + NF * m2] * sm[S::MJIDC + m2];
+      for (int m2 = 0; m2 < NV; ++m2) acc += W[L::W_PHIA + tid + NF * m2] * mjidc[m2];
       W[L::W_P + tid] -= acc;
     }
   }
