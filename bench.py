@@ -817,7 +817,7 @@ def main():
         # (40 discrete events: 26 touch-downs, 14 lift-offs, flight phases without any contact), N = 200, T = 7
         from idocp_amd.workloads import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
         N = args.horizon if args.horizon != 100 else 200
-        T = 7.0
+        T = 7.0 * N / 240                           # the example's own time step (examples/anymal/anymal_running.cpp: T = 7, N = 240)
         nimp = 26
         B = args.batch or 512
         model = anymal_model()

@@ -246,6 +246,7 @@ def _proto(lib):
         ("idocp_parnmpc_dist_update_solution", [vp, cd]),
         ("idocp_parnmpc_dist_kkt_error", [vp, cd, c_double_p]),
         ("idocp_ocp_batch", [vp]),
+        ("idocp_ocp_set_riccati_storage", [vp, ci]),
         ("idocp_ocp_clone", [vp, C.POINTER(vp)]),
         ("idocp_ocp_clear_line_search_filter", [vp]),
         ("idocp_ocp_compute_direction", [vp, cd, c_double_p, c_double_p]),

@@ -1582,6 +1582,17 @@ int idocp_parnmpc_kkt_error_squared_device(idocp_ocp_t* h, double t, double* d_e
   return IDOCP_OK;
 }
 int idocp_ocp_batch(idocp_ocp_t* h) { return h ? h->batch : 0; }
+// Storage precision of the Riccati factorisation P, s (64 = default; 32 = rounded to single precision after every stage of the
+// backward sweep, the device side of BASELINE configs[4]'s tolerance study).  Everything else stays FP64.
+int idocp_ocp_set_riccati_storage(idocp_ocp_t* h, int bits) {
+  if (!h || (bits != 32 && bits != 64)) return IDOCP_E_ARG;
+  if (h->parnmpc) { set_last_error("idocp_ocp_set_riccati_storage: the Riccati sweep belongs to OCPSolver"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDev(h); if (rc) return rc;
+  h->prob.ric_fp32 = bits == 32 ? 1 : 0;
+  HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
 int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv) {
   if (!h || !nq || !nv) return IDOCP_E_ARG;
   *nq = DQ::NQ; *nv = DQ::NV;

@@ -172,6 +172,7 @@ struct OcpProblem {
   double mu, barrier, fraction_rate;
   double contact_R[IDOCP_MAX_CONTACTS][9], contact_p[IDOCP_MAX_CONTACTS][3];   // frame placement in the tip joint
   double baumgarte_time_step;
+  int ric_fp32;            // 1: the cost-to-go P, s is STORED in single precision (rounded after every stage of the backward sweep; BASELINE configs[4]'s tolerance study)
 };
 
 struct OcpBuffers {

@@ -336,18 +336,22 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
   double* st = &sm[S::STAGE];     // st[k - K_QXU] holds kkt[k] for k >= K_QXU
   constexpr int KO = L::K_QXU, SL = S::STAGE_LEN;
   if (tid == 0) s_ok = 1;
+  // P, s stored in single precision (opt-in, OcpProblem::ric_fp32): every value of the cost-to-go is rounded to FP32 when it is
+  // written (the arithmetic of a stage stays FP64), which is exactly what an FP32 ric record / FP32 copy in LDS would hold
+  const bool p32 = P->ric_fp32 != 0;
+  auto st32 = [&](double x) { return p32 ? (double)(float)x : x; };
   // terminal stage (riccati_recursion_solver.cpp:53-56)
   {
     const double* __restrict__ kk = B.kkt + (base + nodes[M - 1].slot) * L::KKT;
     double* __restrict__ rr = B.ric + (base + nodes[M - 1].slot) * L::RIC;
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
-      const double pqq = kk[L::K_QXX + r + NX * c], pvv = kk[L::K_QXX + (NV + r) + NX * (NV + c)];
+      const double pqq = st32(kk[L::K_QXX + r + NX * c]), pvv = st32(kk[L::K_QXX + (NV + r) + NX * (NV + c)]);
       Pqq[e] = pqq; Pqv[e] = 0.0; Pvv[e] = pvv;
       rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = 0.0; rr[L::R_PVV + e] = pvv;
     }
     if (tid < NV) {
-      const double sq = -kk[L::K_LX + tid], sv = -kk[L::K_LX + NV + tid];
+      const double sq = st32(-kk[L::K_LX + tid]), sv = st32(-kk[L::K_LX + NV + tid]);
       sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
       rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }
@@ -652,16 +656,18 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
           aqv += kqr * dvc + kvc * dqr;
           avv += kvr * dvc + kvc * dvr;
         }
-        const double pqq = Pqq[e] - aqq, pqv = Pqv[e] - aqv, pvv = Pvv[e] - avv;
+        const double pqq = st32(Pqq[e] - aqq), pqv = st32(Pqv[e] - aqv), pvv = st32(Pvv[e] - avv);
         Pqq[e] = pqq; Pqv[e] = pqv; Pvv[e] = pvv;
         rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
       }
     } else {
+      if (p32) { for (int e = tid; e < 3 * NN; e += nt) Pqq[e] = (double)(float)Pqq[e]; __syncthreads(); }      // (uniform branch)
       for (int e = tid; e < 3 * NN / 2; e += nt) reinterpret_cast<rd2*>(rr)[e] = reinterpret_cast<const rd2*>(Pqq)[e];
     }
     if (tid < NV) {
       double sq = sm[S::SQN + tid], sv = sm[S::SVN + tid];
       if (HYBRID && dimi > 0) { sq -= sm[S::SCORR + tid]; sv -= sm[S::SCORR + NV + tid]; }     // Phix^T m (:98-99)
+      sq = st32(sq); sv = st32(sv);
       sm[S::SQ + tid] = sq; sm[S::SV + tid] = sv;
       rr[L::R_SQ + tid] = sq; rr[L::R_SV + tid] = sv;
     }

@@ -536,6 +536,10 @@ int idocp_parnmpc_dist_update_solution(idocp_ocp_t* shard, double t);
 /* KKT error of the whole horizon on every rank, kkt_error[batch] (host). */
 int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* shard, double t, double* kkt_error);
 int idocp_ocp_batch(idocp_ocp_t* h);
+/* Storage precision of the Riccati factorisation P, s of OCPSolver: bits = 64 (default) or 32 (every entry of the cost-to-go rounded to
+ * single precision when a stage of the backward sweep stores it; the arithmetic stays FP64).  BASELINE.json configs[4]'s tolerance study
+ * on the device (tests/test_hybrid_gpu.py::test_configs4_grid_and_fp32_storage); FP64 is the product's precision. */
+int idocp_ocp_set_riccati_storage(idocp_ocp_t* h, int bits);
 /* dimensions of the configuration / velocity the handle's model has (q[batch][nq], v[batch][nv] of the update entries) */
 int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv);
 /* Test switches of the transport (tests/test_rccl_gpu.py; the one-GPU box cannot run more than one rank):
