@@ -208,7 +208,8 @@ def threaded_ok(lib, set_threads):
 
 
 def physical_cores():
-    """Physical cores this process may run on (distinct (package, core) pairs of /proc/cpuinfo among the allowed CPUs)."""
+    """Physical cores this process may run on: distinct (package, core) pairs of /proc/cpuinfo among the allowed CPUs, capped by the
+    cgroup CPU quota (the GPU boxes of this pool show 256 hardware threads but grant 16 CPUs)."""
     try:
         allowed = os.sched_getaffinity(0)
     except AttributeError:
@@ -224,7 +225,21 @@ def physical_cores():
                 cores.add((pkg, int(line.split(":")[1])))
     except (OSError, ValueError):
         pass
-    return len(cores) or len(allowed) or 1
+    n = len(cores) or len(allowed) or 1
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) bounds what those cores can deliver
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = max(1, min(n, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def init_distributed(backend, local_rank):
@@ -579,6 +594,7 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     from idocp_amd import capi, workloads
     from idocp_amd.parnmpc_dist import HipParNMPCShard
     from idocp_amd.workloads import ANYMAL_Q_STANDING, HipOCP, P, anymal_contact_points, anymal_model, anymal_problem, arr
+    os.environ["NCCL_DEBUG"] = "WARN"               # (the pool exports NCCL_DEBUG=VERSION: RCCL's banner would follow the JSON line on stdout)
     lib = capi.lib()
     hip = Hip()
     hip.rt.hipSetDevice(local_rank)
