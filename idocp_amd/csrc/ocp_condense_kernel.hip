@@ -572,7 +572,20 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     return;
   }
   // ---- stage 3: finish the q / v columns; assemble MJtJinv = [Minv - TR BL, TR; TR^T, -SM], TR = BL^T SM ----
-  if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);             // reads the scratch: MJ is written only after the next barrier
+  // EARLY_MJ: where MJtJinv only covers the JOINT records of the scratch (the narrow layouts; dead since the items are done) its TR
+  // and -SM blocks are written NEXT to the assembly of the q / v columns, which reads the foot / base / base-force records behind
+  // them: one barrier and a phase less.  The wide layouts keep the order assemble | TR, -SM | TL.
+  constexpr bool EARLY_MJ = (SVF * SVF <= RS::FEET);
+  auto assembleTR = [&]() {
+    for (int e = tid; e < dimf * NV; e += nt) {
+      const int c = e / NV, r = e - c * NV;                              // TR(r, c) = sum_p BL(p, r) SM(p, c)
+      const double tr = dotAny(&sm[S::BL + SF * r], 1, &sm[S::SM + SF * c], 1, dimf);
+      sm[S::MJ + r + SVF * (NV + c)] = tr;
+      sm[S::MJ + (NV + c) + SVF * r] = tr;
+    }
+    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
+  };
+  if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);             // reads the scratch behind the joint records
   if (tid >= 160 && tid < 160 + NV) sm[S::LA + tid - 160] += dt * sm[S::TLA + tid - 160];      // C2, acceleration rows (t of wave 1, stage 1)
   if (tid >= 128 && tid < 128 + 6) {
     // condenseForwardEuler: Fq.head(6) <- -+ Fqq_inv Fq.head(6)
@@ -581,6 +594,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     for (int m2 = 0; m2 < 6; ++m2) acc += sm[S::FQQI + r + 6 * m2] * sm[S::FQ + m2];
     sm[S::FQ6 + r] = BWD ? acc : -acc;
   }
+  if constexpr (EARLY_MJ) assembleTR();
   __syncthreads();
   if (tid < dimvf) {
     // ID - u on the actuated rows (contact_dynamics.hxx:88); [ID; C] also becomes column NX of dIDCdqv: MJtJinv [ID; C] then falls out
@@ -590,14 +604,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::DIDC + tid + SVF * NX] = val;
   }
   if (tid >= 64 && tid < 64 + 6) sm[S::FQ + tid - 64] = sm[S::FQ6 + tid - 64];
-  for (int e = tid; e < dimf * NV; e += nt) {
-    const int c = e / NV, r = e - c * NV;                              // TR(r, c) = sum_p BL(p, r) SM(p, c)
-    const double tr = dotAny(&sm[S::BL + SF * r], 1, &sm[S::SM + SF * c], 1, dimf);
-    sm[S::MJ + r + SVF * (NV + c)] = tr;
-    sm[S::MJ + (NV + c) + SVF * r] = tr;
+  if constexpr (!EARLY_MJ) {
+    assembleTR();
+    __syncthreads();
   }
-  for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
-  __syncthreads();
   STAMP(6);
   // TL = Minv - TR BL
   for (int e = tid; e < NV * NV; e += nt) {
