@@ -615,21 +615,30 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::MJ + r + SVF * c] = sm[S::MINV + e] - dotAny(&sm[S::MJ + r + SVF * NV], SVF, &sm[S::BL + SF * c], 1, dimf);
   }
   // ---- C2: multipliers of [ID; C]:  l += dt [dID;dC]^T [beta; mu]; contact rows: - dt J beta ----
-  if (tid >= 192 && tid < 192 + NV) {
-    const int r = tid - 192;
-    const double dq = dotAny(&sm[S::DIDC + SVF * r], 1, &sm[S::BM], 1, dimvf);
-    const double dv = dotAny(&sm[S::DIDC + SVF * (NV + r)], 1, &sm[S::BM], 1, dimvf);
-    sm[S::LQ + r] += dt * dq; sm[S::LV + r] += dt * dv;      // (the acceleration rows were completed by wave 1 before it inverted M)
-  } else if (tid >= 224 && tid < 224 + NC) {
-    const int c = tid - 224;
-    if (nd->active[c]) {
-      const int row = nd->row_of[c];
-      for (int x = 0; x < 3; ++x) {
-        double jb = 0.0;
-        for (int col = 0; col < NV; ++col) jb += sm[S::JM + (row + x) + SF * col] * sm[S::BM + col];
-        sm[S::LF + row + x] -= dt * jb;
+  // four lanes per dot product (a quarter of the terms each, summed over the quad): round 2 had 18 + 4 threads walk 24-term products
+  {
+    const int part = tid & 3;
+    double acc = 0.0;
+    int dst = -1;
+    double sgn = dt;
+    if (tid < 4 * NX) {
+      const int g = tid >> 2;                                           // column g of [dID; dC] / d(q, v)
+      const int q4 = (dimvf + 3) >> 2, k0 = part * q4, k1 = (k0 + q4 < dimvf) ? k0 + q4 : dimvf;
+      const double* col = &sm[S::DIDC + SVF * g];
+      for (int k = k0; k < k1; ++k) acc += col[k] * sm[S::BM + k];
+      dst = (g < NV) ? S::LQ + g : S::LV + g - NV;      // (the acceleration rows were completed by wave 1 before it inverted M)
+    } else if (tid >= 160 && tid < 160 + 4 * SF) {
+      const int r = (tid - 160) >> 2;                                   // packed contact row r: - dt (J beta)_r
+      if (r < dimf) {
+        constexpr int q4 = (NV + 3) / 4;
+        const int k0 = part * q4, k1 = (k0 + q4 < NV) ? k0 + q4 : NV;
+        for (int col = k0; col < k1; ++col) acc += sm[S::JM + r + SF * col] * sm[S::BM + col];
+        dst = S::LF + r; sgn = -dt;
       }
     }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0 && dst >= 0) sm[dst] += sgn * acc;
   }
   __syncthreads();
 
