@@ -750,23 +750,41 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
   }
   STAMP(14);
-  if (tid < NX) {                                   // lx -= MJD^T laf
-    const double acc = dotAny(&sm[S::MJD + SVF * tid], 1, &sm[S::LAF], 1, dimvf);
-    if (tid < NV) sm[S::LQ + tid] -= acc; else sm[S::LV + tid - NV] -= acc;
-  } else if (tid >= 64 && tid < 64 + NV) {          // [lu_passive; lu] += MJ.topRows(NV) laf ; Fv -= dt MJIDC
-    const int r = tid - 64;
-    const double acc = hu * dotAny(&sm[S::MJ + r], SVF, &sm[S::LAF], 1, dimvf);
-    if (r < 6) sm[S::LUP + r] += acc; else sm[S::LU + r - 6] += acc;
-    sm[S::FV + r] -= dt * mjidc[r];
+  {
+    // lx -= MJD^T laf ; [lu_passive; lu] += MJ.topRows(NV) laf ; Fv -= dt MJIDC -- four lanes per dot product, like C2
+    const int part = tid & 3, g = tid >> 2;
+    const int q4 = (dimvf + 3) >> 2, k0 = part * q4, k1 = (k0 + q4 < dimvf) ? k0 + q4 : dimvf;
+    double acc = 0.0;
+    if (g < NX) { const double* col = &sm[S::MJD + SVF * g]; for (int k = k0; k < k1; ++k) acc += col[k] * sm[S::LAF + k]; }
+    else if (g < NX + NV) { const double* row = &sm[S::MJ + (g - NX)]; for (int k = k0; k < k1; ++k) acc += row[SVF * k] * sm[S::LAF + k]; }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0) {
+      if (g < NV) sm[S::LQ + g] -= acc;
+      else if (g < NX) sm[S::LV + g - NV] -= acc;
+      else if (g < NX + NV) {
+        const int r = g - NX;
+        if (r < 6) sm[S::LUP + r] += hu * acc; else sm[S::LU + r - 6] += hu * acc;
+        sm[S::FV + r] -= dt * mjidc[r];
+      }
+    }
   }
+  static_assert(4 * (NX + NV) <= nt, "a quad per row of the vector updates");
   __syncthreads();
 
   STAMP(9);
   // ---- I. write the kkt and exp records ----
-  for (int e = tid; e < NV * NV; e += nt) {
-    const int c = e / NV, r = e - c * NV;
-    kk[L::K_FVQ + e] = -dt * sm[S::MJD + r + SVF * c];
-    kk[L::K_FVV + e] = -dt * sm[S::MJD + r + SVF * (NV + c)] + (r == c ? (BWD ? -1.0 : 1.0) : 0.0);
+  typedef double wd2 __attribute__((ext_vector_type(2)));      // 16-byte pieces: two consecutive rows of a column
+  static_assert(NV % 2 == 0 && SVF % 2 == 0 && S::MJD % 2 == 0 && L::K_FVQ % 2 == 0 && L::K_FVV % 2 == 0 && L::KKT % 2 == 0, "16-byte stores of Fvq / Fvv");
+  for (int e = tid; e < NV * NV / 2; e += nt) {
+    const int c = e / (NV / 2), r = 2 * (e - c * (NV / 2));
+    const wd2 mq = *reinterpret_cast<const wd2*>(&sm[S::MJD + r + SVF * c]), mvv = *reinterpret_cast<const wd2*>(&sm[S::MJD + r + SVF * (NV + c)]);
+    const double one = BWD ? -1.0 : 1.0;
+    wd2 fq, fv;
+    fq.x = -dt * mq.x; fq.y = -dt * mq.y;
+    fv.x = -dt * mvv.x + (r == c ? one : 0.0); fv.y = -dt * mvv.y + (r + 1 == c ? one : 0.0);
+    *reinterpret_cast<wd2*>(&kk[L::K_FVQ + r + NV * c]) = fq;
+    *reinterpret_cast<wd2*>(&kk[L::K_FVV + r + NV * c]) = fv;
   }
   for (int e = tid; e < NV * NU; e += nt) { const int c = e / NV, r = e - c * NV; kk[L::K_FVU + e] = hu * dt * sm[S::MJ + r + SVF * (6 + c)]; }
   if (tid < NV) {
@@ -783,10 +801,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const int c = t - r * (r + 1) / 2;
     ee[L::E_MJ + t] = sm[S::MJ + r + SVF * c];
   }
-  if (SF == NF) {
-    for (int e = tid; e < NVF * NX; e += nt) ee[L::E_MJD + e] = sm[S::MJD + e];
-  } else {
-    for (int e = tid; e < RVF * NX; e += nt) { const int c = e / RVF, r = e - c * RVF; ee[L::E_MJD + r + NVF * c] = sm[S::MJD + r + SVF * c]; }
+  static_assert(RVF % 2 == 0 && NVF % 2 == 0 && L::E_MJD % 2 == 0 && L::EXP % 2 == 0, "16-byte stores of MJtJinv_dIDCdqv");
+  for (int e = tid; e < (RVF / 2) * NX; e += nt) {
+    const int c = e / (RVF / 2), r = 2 * (e - c * (RVF / 2));
+    *reinterpret_cast<wd2*>(&ee[L::E_MJD + r + NVF * c]) = *reinterpret_cast<const wd2*>(&sm[S::MJD + r + SVF * c]);
   }
   if (tid < NV) ee[L::E_QAA + tid] = sm[S::QAA + tid];
   for (int e = tid; e < SF * SF; e += nt) { const int c = e / SF, r = e - c * SF; ee[L::E_QFF + r + NF * c] = sm[S::QFF + e]; }
