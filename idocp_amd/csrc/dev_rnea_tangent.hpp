@@ -274,7 +274,13 @@ struct RneaNominalCopy {
 // tangents (LJ) and the base force (6 doubles).  Round 2 carried no per-body state either but UNDID the kinematic recursion on an inward
 // sweep (dev_rbd.hpp's trick for chains): the whole inertia / momentum algebra sat on the inward dependency chain, a fifth more
 // arithmetic, and 13 - 27 registers spilled.  Same columns as rneaTangentItemUndo up to the order of the sums. ----
-template <typename D, bool XYY = false>
+// IMPULSE: the item of an impulse stage (ImpulseDynamicsForwardEuler::linearizeImpulseDynamics, impulse_dynamics_forward_euler.hxx:18-58;
+// robot.hxx:283-320, 505-541).  The dynamics ImD = rnea_impulse(q, dv) are linearised at ZERO velocity without gravity, the contact
+// constraint is the LOCAL linear velocity of the frame at v + dv (point_contact.hxx:145-175): the nominal record carries the
+// velocity-level fields of the (v + dv) sweep next to the acceleration-level and force fields of the (0, dv) sweep (ocp_nominal_kernel),
+// and the item drops everything that couples the two levels -- velocity products in the acceleration recursion and in the body forces --
+// and emits d(frame velocity) as its contact rows.  A v seed then yields the frame Jacobian (dC/dv = J) and zero dynamics rows.
+template <typename D, bool XYY = false, bool IMPULSE = false>
 __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, double* sc, const RneaOut& out) {
   using S = RneaScratch<D>;
   using namespace rt;
@@ -295,12 +301,17 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
   if (leg == 0 && base_seed) {
     // the base's own inertial force: once per base seed
     V3 dhl, dhn, df, dn;
-    const V3 mc = ld3(br + S::B_MC), w0 = ld3(br + S::B_W), v0 = ld3(br + S::B_V), hl0 = ld3(br + S::B_HL), hn0 = ld3(br + S::B_HN);
-    inertia(br[S::B_MASS], mc, br + S::B_IO, dv, dw, dhl, dhn);
+    const V3 mc = ld3(br + S::B_MC);
     inertia(br[S::B_MASS], mc, br + S::B_IO, dbl, dbw, df, dn);
     double* o = sc + S::BOWN + 6 * j0;
-    st3(o, df + cross(dw, hl0) + cross(w0, dhl));
-    st3(o + 3, dn + cross(dw, hn0) + cross(w0, dhn) + cross(dv, hl0) + cross(v0, dhl));
+    if constexpr (IMPULSE) {
+      st3(o, df); st3(o + 3, dn);
+    } else {
+      const V3 w0 = ld3(br + S::B_W), v0 = ld3(br + S::B_V), hl0 = ld3(br + S::B_HL), hn0 = ld3(br + S::B_HN);
+      inertia(br[S::B_MASS], mc, br + S::B_IO, dv, dw, dhl, dhn);
+      st3(o, df + cross(dw, hl0) + cross(w0, dhl));
+      st3(o + 3, dn + cross(dw, hn0) + cross(w0, dhn) + cross(dv, hl0) + cross(v0, dhl));
+    }
   }
   double tau[LJ];
 #pragma unroll
@@ -324,7 +335,9 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
       const V3 dblc = F.mulT(dbl + cross(dbw, p)) - F.crossUk(ld3(jr + S::J_BLC), sq);
       dz = F.mulT(dz) - F.crossUk(ld3(jr + S::J_ZC), sq);
       dw = dwc + F.timesU(sv); dv = dvc;
-      if constexpr (AX < 0) {
+      if constexpr (IMPULSE) {
+        dbw = dbwc + F.timesU(sa); dbl = dblc;          // (the acceleration level sees no velocity)
+      } else if constexpr (AX < 0) {
         const V3 vJ = ld3(jr + S::J_VJ), dvJ = F.timesU(sv);
         dbw = dbwc + F.timesU(sa) + cross(dw, vJ) + cross(wj, dvJ);
         dbl = dblc + cross(dv, vJ) + cross(vj, dvJ);
@@ -339,17 +352,21 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
     // ---- phase 2: d(I a + w x I v) of this body: inertia products first (their operands are dead before the momenta are fetched) ----
     V3 Fl, Fn;
     {
-      V3 dhl, dhn;
-      {
-        const V3 mc = ld3(jr + S::J_MC);
-        inertia(jr[S::J_MASS], mc, jr + S::J_IO, dv, dw, dhl, dhn);
-        inertia(jr[S::J_MASS], mc, jr + S::J_IO, dbl, dbw, Fl, Fn);
+      if constexpr (IMPULSE) {
+        inertia(jr[S::J_MASS], ld3(jr + S::J_MC), jr + S::J_IO, dbl, dbw, Fl, Fn);
+      } else {
+        V3 dhl, dhn;
+        {
+          const V3 mc = ld3(jr + S::J_MC);
+          inertia(jr[S::J_MASS], mc, jr + S::J_IO, dv, dw, dhl, dhn);
+          inertia(jr[S::J_MASS], mc, jr + S::J_IO, dbl, dbw, Fl, Fn);
+        }
+        pin(dhl); pin(dhn); pin(Fl); pin(Fn);
+        phaseFence();
+        const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), hl = ld3(jr + S::J_HL), hn = ld3(jr + S::J_HN);
+        Fl = Fl + cross(dw, hl) + cross(wj, dhl);
+        Fn = Fn + cross(dw, hn) + cross(wj, dhn) + cross(dv, hl) + cross(vj, dhl);
       }
-      pin(dhl); pin(dhn); pin(Fl); pin(Fn);
-      phaseFence();
-      const V3 wj = ld3(jr + S::J_W), vj = ld3(jr + S::J_VC), hl = ld3(jr + S::J_HL), hn = ld3(jr + S::J_HN);
-      Fl = Fl + cross(dw, hl) + cross(wj, dhl);
-      Fn = Fn + cross(dw, hn) + cross(wj, dhn) + cross(dv, hl) + cross(vj, dhl);
     }
     pin(Fl); pin(Fn);
     phaseFence();
@@ -381,10 +398,14 @@ __device__ __forceinline__ void rneaTangentItem(double gz, double wv, int item, 
     const V3 pc = ld3(fr + S::F_PC);
     const V3 dal = dbl + gz * dz;
     // (XYY also promises an identity rotation of the contact frame in its joint, like ANYmal's feet: Rc^T a = a)
-    const V3 dfv = XYY ? dv + cross(dw, pc) : mulT(Rc, dv + cross(dw, pc)), dfw = XYY ? dw : mulT(Rc, dw),
-             dfa = XYY ? dal + cross(dbw, pc) : mulT(Rc, dal + cross(dbw, pc));
-    const V3 dc = dfa + cross(ld3(fr + S::F_FW), dfv) + cross(ld3(fr + S::F_FV), dfw) + wv * dfv;
-    st3(colc + (int)fr[S::F_ROW], dc);
+    const V3 dfv = XYY ? dv + cross(dw, pc) : mulT(Rc, dv + cross(dw, pc));
+    if constexpr (IMPULSE) {
+      st3(colc + (int)fr[S::F_ROW], dfv);            // contact-velocity constraint: d(local linear velocity of the frame)
+    } else {
+      const V3 dfw = XYY ? dw : mulT(Rc, dw), dfa = XYY ? dal + cross(dbw, pc) : mulT(Rc, dal + cross(dbw, pc));
+      const V3 dc = dfa + cross(ld3(fr + S::F_FW), dfv) + cross(ld3(fr + S::F_FV), dfw) + wv * dfv;
+      st3(colc + (int)fr[S::F_ROW], dc);
+    }
   }
 #pragma unroll
   for (int j = 0; j < LJ; ++j) colp[6 + leg * LJ + j] = tau[j];

@@ -314,6 +314,7 @@ int discretize(idocp_ocp* h, double t) {
   std::vector<int> ipos;
   for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
   h->n_impulse = (int)ipos.size();
+  h->B.n_impulse_fe = h->parnmpc ? 0 : h->n_impulse;
   if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
   // stage classes of K5b (OcpLaunch::condenseMixed)
   std::vector<int> cls[3];
@@ -474,6 +475,7 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   std::vector<int> ipos;
   for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
   h->n_impulse = (int)ipos.size();
+  h->B.n_impulse_fe = h->parnmpc ? 0 : h->n_impulse;
   if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
   std::vector<int> gpos;
   for (int p = 0; p < M; ++p) if (parnmpcShape<LQ>(h->chain[p]).general) gpos.push_back(p);
@@ -504,7 +506,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   h->chain_t[N] = t + (h->stage_offset + N) * dt;
   h->prob.has_terminal = h->has_terminal ? 1 : 0; h->prob.has_prev = h->has_prev ? 1 : 0; h->prob.stage_offset = h->stage_offset;
   h->Ngrid = N - 1;                  // getters: stages 0 .. N-1
-  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0; h->n_general = 0;
+  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0; h->B.n_impulse_fe = 0; h->n_general = 0;
   const int M = N + 1;
   std::vector<double> tab((size_t)M * DQ::NQ);
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }

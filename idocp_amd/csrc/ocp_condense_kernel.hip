@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     //  on the terminal stage sn_g = s_g and the slack / dual copies are simply not used)
     double pre[NPRE], prez[7];
     RneaNominalCopy<D, nt> nomc;
-    const bool has_nom = !terminal && !impulse;
+    const bool has_nom = !terminal;      // (impulse stages have nominal records of their own kind, ocp_nominal_kernel<.., IMP>)
     if (has_nom) nomc.fetch(B.nom + rec * L::NOM, tid);
 #pragma unroll
     for (int t = 0; t < NPRE; ++t) {
@@ -212,18 +212,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
     if (tid == 0) { s_ok = 1; s_c1 = 0; }
     if (!terminal) {
-      if (impulse) {
-        // impulse stages keep the two-pass dual-number sweep of ocp_rnea_kernel<D, true> and its lin record
-        const double* __restrict__ lin = B.lin + su * L::LIN;
-        for (int e = tid; e < RVF * NX; e += nt) { const int c = e / RVF, r = e - c * RVF; sm[S::DIDC + r + SVF * c] = lin[L::L_DIDC + r + NVF * c]; }
-        for (int e = tid; e < NV * NV; e += nt) sm[S::MM + e] = lin[L::L_M + e];
-        for (int e = tid; e < SF * NV; e += nt) { const int c = e / SF, r = e - c * SF; sm[S::JM + e] = lin[L::L_J + r + NF * c]; }
-        if (tid < RVF) sm[S::IDC + tid] = lin[L::L_IDC + tid];
-      } else {
-        for (int e = tid; e < S::IDC - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
-        rneaSetup<D>(B.model, P, nd, tid, sc);
-        nomc.store(tid, sc, &sm[S::IDC]);
-      }
+      for (int e = tid; e < S::IDC - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
+      rneaSetup<D>(B.model, P, nd, tid, sc);
+      nomc.store(tid, sc, &sm[S::IDC]);
     }
     for (int e = tid; e < SF * SF; e += nt) sm[S::QFF + e] = 0.0;
 #pragma unroll
@@ -294,11 +285,14 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below), per thread
   double merit_cost = 0.0, merit_viol = 0.0; // MERIT: this thread's share of the stage cost / l1 constraint violation
   if (wave == 0) {
-    if (!MERIT && !impulse && lane < RI::NQV) rneaTangentItem<D, XYY>(gz, bwv, RI::qv(lane), sc, out);
+    if (!MERIT && lane < RI::NQV) {
+      if (!PLAIN && impulse) rneaTangentItem<D, XYY, true>(0.0, bwv, RI::qv(lane), sc, out);      // impulse stage: dynamics at zero velocity, contact velocity
+      else rneaTangentItem<D, XYY, false>(gz, bwv, RI::qv(lane), sc, out);
+    }
     STAMPW(0);
   } else if (wave == 1) {
     if (!MERIT) {
-      if (!impulse) {
+      {
         if (lane < RI::NA) rneaTangentItemA<D, XYY>(RI::a(lane), sc, out);
         waveLdsSync();
         rneaAssembleA<D>(lane, sc, out);
@@ -517,7 +511,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   if (MERIT) {
     // nominal [ID - u; C] (contact_dynamics.hxx:202-217; impulse stages: [ImD; C] from the lin record), the switching-constraint
     // residual P (forward_switching_constraint.hxx:27-47, from ocp_switch_kernel on the trial iterate), and the stage's totals
-    if (!impulse) rneaAssembleNominal<D>(tid, sc, out);
+    rneaAssembleNominal<D>(tid, sc, out);
     __syncthreads();
     if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];
     __syncthreads();
@@ -536,7 +530,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   asm volatile("" : "+v"(tid) :: "memory");
   if (RESIDUAL) {
     // ---- C2 + SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264) ----
-    if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);
+    rneaAssembleQV<D>(bwp, tid, nt, sc, out);
     __syncthreads();
     if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88)
     __syncthreads();
@@ -585,7 +579,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
     for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
   };
-  if (!impulse) rneaAssembleQV<D>(bwp, tid, nt, sc, out);             // reads the scratch behind the joint records
+  rneaAssembleQV<D>(bwp, tid, nt, sc, out);                           // reads the scratch behind the joint records
   if (tid >= 160 && tid < 160 + NV) sm[S::LA + tid - 160] += dt * sm[S::TLA + tid - 160];      // C2, acceleration rows (t of wave 1, stage 1)
   if (tid >= 128 && tid < 128 + 6) {
     // condenseForwardEuler: Fq.head(6) <- -+ Fqq_inv Fq.head(6)

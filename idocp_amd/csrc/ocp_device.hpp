@@ -180,6 +180,7 @@ struct OcpBuffers {
   const OcpProblem* prob;
   const OcpNode* nodes;  // [M] the chain
   const int* impulse_pos; // chain positions of the impulse stages
+  int n_impulse_fe;       // host-side: number of impulse stages of a FORWARD-EULER chain (OCPSolver): nominal records + tangent items; 0 under ParNMPC (K5a / K9i)
   const int* general_pos; // ParNMPC: chain positions of the stages with a general KKT shape (aux with switching rows, impulse)
   const int* cond_pos;    // chain positions grouped by stage class of K5b (OcpLaunch::condenseMixed)
   int leg_axes_xyy;       // host-side: every leg is (joint about +x, about +y, about +y) with identity placement rotations, and the

@@ -33,8 +33,14 @@ __device__ __forceinline__ void st3g(double* __restrict__ p, V3 a) { p[0] = a.x;
 // store instruction would touch 64 different lines with 8 bytes each (the first version: 0.40 ms, bound by write requests).  The
 // joint records -- four fifths of the bytes -- therefore go through a transposition in LDS ([lane][field] -> runs of consecutive
 // fields of one stage over consecutive lanes), twice per joint: the outward part (30 doubles) and the inward part (12 doubles).
-template <typename D, bool XYY>
-__global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) {
+// IMP: the IMPULSE stages of a forward-Euler chain (launched over B.impulse_pos; ImpulseDynamicsForwardEuler::linearizeImpulseDynamics,
+// impulse_dynamics_forward_euler.hxx:18-58; robot.hxx:283-320, 505-541).  Their dynamics ImD = rnea_impulse(q, dv) are evaluated at ZERO
+// velocity without gravity, their constraint is the local linear velocity of the contact frame at v + dv: the record carries the
+// velocity-level fields (wc, vc, vJ, w; the foot's velocity) of the (v + dv) motion next to the acceleration-level and force fields of the
+// (0, dv) motion -- one outward sweep with both recursions, uncoupled (rounds 1 / 2: a kernel of its own, two passes of dual numbers per
+// lane, a 13 kB record per impulse stage).
+template <typename D, bool XYY, bool IMP>
+__global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, int nlist) {
   using L = OcpLayout<D>;
   constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV;
   constexpr int NOUT = 30, NIN = L::NJ_DYN - NOUT, TS = 31;      // outward / inward part of a joint record; row stride of the transposition
@@ -53,16 +59,17 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
   const unsigned g_hi = tg / NTASK;
   const int task = (int)(tg - g_hi * NTASK);   // uniform: 0 .. NL-1 motion of a leg, NL base, NL+1 .. 2 NL pose of a leg
   const long unit = (long)(g_hi * 8u + g_lo) * 64 + lane;
-  const bool in_range = unit < (long)P->batch * M;
-  const long b = in_range ? unit / M : 0;
-  const int pos = in_range ? (int)(unit - b * M) : 0;
+  const int per = IMP ? nlist : M;
+  const bool in_range = unit < (long)P->batch * per;
+  const long b = in_range ? unit / per : 0;
+  const int pos = in_range ? (IMP ? B.impulse_pos[(int)(unit - b * per)] : (int)(unit - b * per)) : (IMP ? B.impulse_pos[0] : 0);
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  // the terminal stage has no dynamics; impulse stages keep the two-pass kernel and its lin record (ocp_rnea_kernel<D, true>)
-  const bool valid = in_range && pos != M - 1 && nd->kind != 1;
+  // the terminal stage has no dynamics; impulse stages have a launch of their own (IMP)
+  const bool valid = in_range && pos != M - 1 && (IMP || nd->kind != 1);
   const long rec = (dbg & 2) ? 0 : b * P->NS + nd->slot;       // (lanes that are not valid compute on this record too and store nothing)
   const double* __restrict__ s = B.sol + rec * L::SOL;
   double* __restrict__ nom = B.nom + rec * L::NOM;
-  const double gz = m->gravity[2];
+  const double gz = IMP ? 0.0 : m->gravity[2];
   const double wv = 2.0 / P->baumgarte_time_step, wp = 1.0 / (P->baumgarte_time_step * P->baumgarte_time_step);
   const double* __restrict__ sq = s + L::S_Q;
   const double* __restrict__ sv = s + L::S_V;
@@ -72,18 +79,20 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
   if (task <= NL) {
     // ---- motion: velocities, accelerations in the gravity field (a_gf = a - R_w^T g), forces, tau ----
     const V3 zb = v3(2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy));      // third row of R_w
-    V3 v = ld3(sv), w = ld3(sv + 3);
+    // IMP: (v, w) is the motion at v + dv -- it only feeds the velocity-level fields and the contact velocity, never a force
+    V3 v = IMP ? ld3(sv) + ld3(sa) : ld3(sv), w = IMP ? ld3(sv + 3) + ld3(sa + 3) : ld3(sv + 3);
     V3 bl = ld3(sa) - gz * zb, bw = ld3(sa + 3);
     if (task == NL) {
       if (!valid) return;
-      V3 hl, hn, f, n;
+      V3 hl = v3(0, 0, 0), hn = hl, f, n;
       const V3 mc = ld3(m->mc[0]);
-      inertia(m->mass[0], mc, m->Io[0], v, w, hl, hn);
+      if (!IMP) inertia(m->mass[0], mc, m->Io[0], v, w, hl, hn);
       inertia(m->mass[0], mc, m->Io[0], bl, bw, f, n);
       double* br = nom + L::O_BASE;
       st3g(br + 0, zb); st3g(br + 3, v); st3g(br + 6, w); st3g(br + 9, hl); st3g(br + 12, hn); br[15] = 0.0;
       double* bn = nom + L::O_BN;
-      st3g(bn, f + cross(w, hl)); st3g(bn + 3, n + cross(w, hn) + cross(v, hl));
+      if (IMP) { st3g(bn, f); st3g(bn + 3, n); }
+      else { st3g(bn, f + cross(w, hl)); st3g(bn + 3, n + cross(w, hn) + cross(v, hl)); }
       // rows of [ID; C] no leg writes: the base rows (assembled from BN by the consumer) and the rows of inactive contacts
       double* idc = nom + L::O_IDC;
 #pragma unroll
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
       for (int e = 0; e < 9; ++e) Rj[j][e] = Rm.m[e];
       const V3 u = ld3(m->axis[ji]), p = ld3(m->p[ji]);
       st3(&Rj[j][9], u);
-      const double qd = sv[dof], qdd = sa[dof];
+      const double qdd = sa[dof], qd = IMP ? sv[dof] + qdd : sv[dof];
       V3 wc, vc, bwc, blc, vJ;
       auto step = [&](auto tag) {
         const JointFrame<decltype(tag)::value> F(Rj[j], 0, 9);
@@ -128,8 +137,11 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
         zc = F.mulT(zc);                 // R_w,child^T e_z: the third row of the world rotation, carried along the leg
         vJ = F.timesU(qd);
         w = wc + vJ; v = vc;
-        bw = bwc + F.timesU(qdd) + F.crossKU(w, qd);
-        bl = blc + F.crossKU(v, qd);
+        if constexpr (IMP) { bw = bwc + F.timesU(qdd); bl = blc; }      // (the dynamics of an impulse see no velocity)
+        else {
+          bw = bwc + F.timesU(qdd) + F.crossKU(w, qd);
+          bl = blc + F.crossKU(v, qd);
+        }
       };
       if constexpr (XYY) { if (j == 0) step(AxisTag<0>{}); else step(AxisTag<1>{}); } else step(AxisTag<-1>{});
       wj[j] = w; vj[j] = v; bwj[j] = bw; blj[j] = bl;
@@ -148,11 +160,16 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
       const int row = NV + nd->row_of[leg];
       // (XYY also promises an identity rotation of the contact frame in its joint, like ANYmal's feet: Rc^T a = a)
       fv = XYY ? v + cross(w, pc) : mulT(Rc, v + cross(w, pc)); fw = XYY ? w : mulT(Rc, w);
-      const V3 fam = XYY ? bl + cross(bw, pc) : mulT(Rc, bl + cross(bw, pc));      // still in the gravity field
-      const V3 wxv = cross(fw, fv);
-      idc[row] = fam.x + wxv.x + wv * fv.x;
-      idc[row + 1] = fam.y + wxv.y + wv * fv.y;
-      idc[row + 2] = fam.z + wxv.z + wv * fv.z;
+      if constexpr (IMP) {
+        // contact-velocity constraint (point_contact.hxx:145-175): LOCAL linear velocity of the frame at v + dv
+        idc[row] = fv.x; idc[row + 1] = fv.y; idc[row + 2] = fv.z;
+      } else {
+        const V3 fam = XYY ? bl + cross(bw, pc) : mulT(Rc, bl + cross(bw, pc));      // still in the gravity field
+        const V3 wxv = cross(fw, fv);
+        idc[row] = fam.x + wxv.x + wv * fv.x;
+        idc[row + 1] = fam.y + wxv.y + wv * fv.y;
+        idc[row + 2] = fam.z + wxv.z + wv * fv.z;
+      }
       // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20): jXf.act(Force(f, 0))
       fel = XYY ? ld3(s + L::S_F + 3 * leg) : mul(Rc, ld3(s + L::S_F + 3 * leg));
       fen = cross(pc, fel);
@@ -164,11 +181,14 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
     for (int j = LJ - 1; j >= 0; --j) {
       const int ji = 1 + leg * LJ + j, dof = 6 + leg * LJ + j;
       const V3 p = ld3(m->p[ji]), mc = ld3(m->mc[ji]);
-      V3 hl, hn, f, n;
-      inertia(m->mass[ji], mc, m->Io[ji], vj[j], wj[j], hl, hn);
+      V3 hl = v3(0, 0, 0), hn = hl, f, n;
       inertia(m->mass[ji], mc, m->Io[ji], blj[j], bwj[j], f, n);
-      Fl = Fl + f + cross(wj[j], hl);
-      Fn = Fn + n + cross(wj[j], hn) + cross(vj[j], hl);
+      if constexpr (IMP) { Fl = Fl + f; Fn = Fn + n; }
+      else {
+        inertia(m->mass[ji], mc, m->Io[ji], vj[j], wj[j], hl, hn);
+        Fl = Fl + f + cross(wj[j], hl);
+        Fn = Fn + n + cross(wj[j], hn) + cross(vj[j], hl);
+      }
       st3(my, hl); st3(my + 3, hn); st3(my + 6, Fl); st3(my + 9, Fn);
       flush(AxisTag<NIN>{}, L::O_JOINT + (leg * LJ + j) * L::NJ_DYN + NOUT);
       auto back = [&](auto tag) {
@@ -192,7 +212,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg) 
   double rwc[9];
 #pragma unroll
   for (int e = 0; e < 9; ++e) rwc[e] = 0.0;
-  if (nd->active[leg]) {
+  if (!IMP && nd->active[leg]) {      // (an impulse stage has no position term: zeros)
     double Rw[9];
     Rw[0] = 1 - 2 * (qy * qy + qz * qz); Rw[1] = 2 * (qx * qy - qz * qw);     Rw[2] = 2 * (qx * qz + qy * qw);
     Rw[3] = 2 * (qx * qy + qz * qw);     Rw[4] = 1 - 2 * (qx * qx + qz * qz); Rw[5] = 2 * (qy * qz - qx * qw);
@@ -240,8 +260,14 @@ template <typename D>
 void OcpLaunch<D>::nominal(const OcpBuffers& B, long batch, int M, hipStream_t st) {
   const unsigned groups = (unsigned)((batch * M + 63) / 64), blocks = ((groups + 7) / 8) * 8 * (2 * D::NL + 1);
   static const int dbg = getenv("IDOCP_NOM_DBG") ? atoi(getenv("IDOCP_NOM_DBG")) : 0;
-  if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true>), dim3(blocks), dim3(64), 0, st, B, dbg);
-  else hipLaunchKernelGGL((ocp_nominal_kernel<D, false>), dim3(blocks), dim3(64), 0, st, B, dbg);
+  if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, false>), dim3(blocks), dim3(64), 0, st, B, dbg, 0);
+  else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, false>), dim3(blocks), dim3(64), 0, st, B, dbg, 0);
+  // the impulse stages of a forward-Euler chain (ParNMPC's go through K5a / K9i)
+  if (B.n_impulse_fe > 0) {
+    const unsigned gi = (unsigned)((batch * B.n_impulse_fe + 63) / 64), bi = ((gi + 7) / 8) * 8 * (2 * D::NL + 1);
+    if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe);
+    else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe);
+  }
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::nominal(const OcpBuffers&, long, int, hipStream_t);

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
 template <typename D>
 void OcpLaunch<D>::rnea(const OcpBuffers& B, long batch, int M, int n_impulse, hipStream_t st) {
   (void)M;
+  if (B.n_impulse_fe > 0) return;      // forward-Euler chains (OCPSolver): the impulse stages have nominal records and tangent items like every other stage (round 3)
   if (n_impulse > 0) hipLaunchKernelGGL((ocp_rnea_kernel<D, true>), dim3((unsigned)(batch * n_impulse)), dim3(64), 0, st, B, n_impulse);
 }
 
