@@ -834,57 +834,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
 #undef STAMPW
 }
 
-// Lie-group terms of the floating base for every stage (state_equation.hxx:12-63, cost Jacobian
-// of q (-) q_ref): blockIdx.y selects the task so that a wavefront never diverges between tasks.
-//   task 0: qdiff = q (-) q_ref and Jq = dSubtractdConfigurationPlus(q, q_ref)
-//   task 1: Fq.head(6) = (q (-) q_next).head(6), Fqq = dSubtractdConfigurationPlus(q, q_next),
-//           Fqq_inv = inverse of dSubtractdConfigurationMinus(q, q_next)
-//   task 2: Fqq_prev = dSubtractdConfigurationMinus(q_prev, q), Fqq_prev_inv
-template <typename D>
-__global__ __launch_bounds__(64) void ocp_lie_kernel(OcpBuffers B, const double* __restrict__ q0) {
-  using L = OcpLayout<D>;
-  constexpr int NQ = D::NQ;
-  const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
-  const long unit = (long)blockIdx.x * 64 + threadIdx.x;
-  if (unit >= (long)P->batch * M) return;
-  const long b = unit / M;
-  const int pos = (int)(unit - b * M);
-  const OcpNode* __restrict__ nd = B.nodes + pos;
-  const int task = blockIdx.y;
-  const long rec = b * P->NS + nd->slot;
-  const double* __restrict__ s = B.sol + rec * L::SOL;
-  const double* __restrict__ q = s + L::S_Q;
-  double* __restrict__ zz = B.lie + rec * L::LIE;
-  double R[9], p[3], Ja[36], Jb[36], d6[6];
-  if (task == 0) {
-    lieRelative(B.q_ref + (long)pos * NQ, q, R, p);
-    lieLog6(R, p, d6);
-    lieJlog6(R, p, Ja);
-    for (int k = 0; k < 36; ++k) zz[L::Z_JQ + k] = Ja[k];
-    for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
-  } else if (task == 1) {
-    if (pos == M - 1) return;
-    lieRelative(B.sol + (b * P->NS + nd->next) * L::SOL + L::S_Q, q, R, p);
-    lieLog6(R, p, d6);
-    lieJlog6(R, p, Ja);
-    for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
-    for (int k = 0; k < 6; ++k) zz[L::Z_FQ6 + k] = d6[k];
-    lieDDiffArg0(R, p, Ja, Jb);
-    lieBlockInverse(Jb, Ja);
-    for (int k = 0; k < 36; ++k) zz[L::Z_FQQI + k] = Ja[k];
-  } else {
-    const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * NQ) : (B.sol + (b * P->NS + nd->prev) * L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
-    lieRelative(q, q_prev, R, p);
-    lieJlog6(R, p, Ja);
-    lieDDiffArg0(R, p, Ja, Jb);
-    for (int k = 0; k < 36; ++k) zz[L::Z_FQQP + k] = Jb[k];
-    lieBlockInverse(Jb, Ja);
-    for (int k = 0; k < 36; ++k) zz[L::Z_FQQPI + k] = Ja[k];
-  }
-}
+// (The Lie-group terms of the forward-Euler stages are tasks of ocp_nominal_kernel since round 3.)
 
-// Lie-group terms of the backward-Euler stage (state_equation.hxx:96-170): same record, same places as ocp_lie_kernel
+// Lie-group terms of the backward-Euler stage (state_equation.hxx:96-170): same record, same places as the forward-Euler tasks of ocp_nominal_kernel
 //   task 0: qdiff = q (-) q_ref and Jq
 //   task 1: FQQ = dSubtractdConfigurationPlus(q, q_next)                      (coupling with the next stage's lmd)
 //   task 2: FQ6 = (q_prev (-) q).head(6), FQQP = dSubtractdConfigurationMinus(q_prev, q),
@@ -944,8 +896,7 @@ static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, con
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
-  hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
-  OcpLaunch<D>::nominal(B, batch, M, st);
+  OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
   else if (dimf == D::NF) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0); }
   else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0); }
@@ -974,8 +925,7 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   }
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
-  hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, B, q0);
-  OcpLaunch<D>::nominal(B, batch, M, st);
+  OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
@@ -992,8 +942,7 @@ void OcpLaunch<D>::merit(const OcpBuffers& Btry, long batch, int M, const double
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
-  hipLaunchKernelGGL((ocp_lie_kernel<D>), dim3((blocks + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
-  OcpLaunch<D>::nominal(Btry, batch, M, st);
+  OcpLaunch<D>::nominal(Btry, batch, M, st, q0);
   hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, false, true>), dim3(blocks), dim3(256), smem, st, Btry, q0);
 }
 // The same for ParNMPC (backward-Euler stages; event-free horizons): Split / TerminalParNMPC::stageCost and constraintViolation

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "dev_dense.hpp"
+#include "dev_lie.hpp"
 #include "dev_rnea_tangent.hpp"
 #include "ocp_device.hpp"
 #include "ocp_launch.hpp"
@@ -40,7 +41,7 @@ __device__ __forceinline__ void st3g(double* __restrict__ p, V3 a) { p[0] = a.x;
 // (0, dv) motion -- one outward sweep with both recursions, uncoupled (rounds 1 / 2: a kernel of its own, two passes of dual numbers per
 // lane, a 13 kB record per impulse stage).
 template <typename D, bool XYY, bool IMP>
-__global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, int nlist) {
+__global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, int nlist, const double* __restrict__ q0) {
   using L = OcpLayout<D>;
   constexpr int NL = D::NL, LJ = D::LJ, NV = D::NV;
   constexpr int NOUT = 30, NIN = L::NJ_DYN - NOUT, TS = 31;      // outward / inward part of a joint record; row stride of the transposition
@@ -53,7 +54,9 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
   // XCD-aware block order: workgroup n runs on XCD n % 8 and every XCD has an L2 of its own, so the 2 NL + 1 task blocks that read the
   // SAME 64 solution records are given ids that agree mod 8 and lie within 8 (2 NL + 1) of each other: n = (g_hi (2 NL + 1) + task) 8 + g_lo
   // for the stage group g = 8 g_hi + g_lo.
-  constexpr int NTASK = 2 * NL + 1;
+  // q0 != nullptr: three more tasks per stage group, the Lie-group terms of the floating base (rounds 1 / 2: ocp_lie_kernel, a launch
+  // of its own in front of this one; its latency-bound lanes now run next to the store-bound sweeps)
+  const int NTASK = 2 * NL + 1 + ((!IMP && q0 != nullptr) ? 3 : 0);
   const unsigned n_blk = blockIdx.x;
   const unsigned g_lo = n_blk & 7u, tg = n_blk >> 3;
   const unsigned g_hi = tg / NTASK;
@@ -76,6 +79,43 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
   const double* __restrict__ sa = s + L::S_A;
   const double qx = sq[3], qy = sq[4], qz = sq[5], qw = sq[6];
 
+  if (!IMP && task > 2 * NL) {
+    // ---- Lie-group terms of the floating base (state_equation.hxx:12-63, cost Jacobian of q (-) q_ref); every stage of the chain,
+    // the terminal and the impulse stages included ----
+    //   lt 0: qdiff = q (-) q_ref and Jq = dSubtractdConfigurationPlus(q, q_ref)
+    //   lt 1: Fq.head(6) = (q (-) q_next).head(6), Fqq = dSubtractdConfigurationPlus(q, q_next), Fqq_inv = dSubtractdConfigurationMinus(q, q_next)^-1
+    //   lt 2: Fqq_prev = dSubtractdConfigurationMinus(q_prev, q), Fqq_prev_inv
+    if (!in_range) return;
+    const int lt = task - 2 * NL - 1;
+    double* __restrict__ zz = B.lie + rec * L::LIE;
+    double R[9], p[3], Ja[36], Jb[36], d6[6];
+    if (lt == 0) {
+      lieRelative(B.q_ref + (long)pos * D::NQ, sq, R, p);
+      lieLog6(R, p, d6);
+      lieJlog6(R, p, Ja);
+      for (int k = 0; k < 36; ++k) zz[L::Z_JQ + k] = Ja[k];
+      for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
+    } else if (lt == 1) {
+      if (pos == M - 1) return;
+      lieRelative(B.sol + (b * P->NS + nd->next) * L::SOL + L::S_Q, sq, R, p);
+      lieLog6(R, p, d6);
+      lieJlog6(R, p, Ja);
+      for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
+      for (int k = 0; k < 6; ++k) zz[L::Z_FQ6 + k] = d6[k];
+      lieDDiffArg0(R, p, Ja, Jb);
+      lieBlockInverse(Jb, Ja);
+      for (int k = 0; k < 36; ++k) zz[L::Z_FQQI + k] = Ja[k];
+    } else {
+      const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * D::NQ) : (B.sol + (b * P->NS + nd->prev) * L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
+      lieRelative(sq, q_prev, R, p);
+      lieJlog6(R, p, Ja);
+      lieDDiffArg0(R, p, Ja, Jb);
+      for (int k = 0; k < 36; ++k) zz[L::Z_FQQP + k] = Jb[k];
+      lieBlockInverse(Jb, Ja);
+      for (int k = 0; k < 36; ++k) zz[L::Z_FQQPI + k] = Ja[k];
+    }
+    return;
+  }
   if (task <= NL) {
     // ---- motion: velocities, accelerations in the gravity field (a_gf = a - R_w^T g), forces, tau ----
     const V3 zb = v3(2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy));      // third row of R_w
@@ -257,19 +297,21 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
 }
 
 template <typename D>
-void OcpLaunch<D>::nominal(const OcpBuffers& B, long batch, int M, hipStream_t st) {
-  const unsigned groups = (unsigned)((batch * M + 63) / 64), blocks = ((groups + 7) / 8) * 8 * (2 * D::NL + 1);
+void OcpLaunch<D>::nominal(const OcpBuffers& B, long batch, int M, hipStream_t st, const double* q0_lie) {
+  const unsigned ntask = 2 * D::NL + 1 + (q0_lie ? 3 : 0);
+  const unsigned groups = (unsigned)((batch * M + 63) / 64), blocks = ((groups + 7) / 8) * 8 * ntask;
   static const int dbg = getenv("IDOCP_NOM_DBG") ? atoi(getenv("IDOCP_NOM_DBG")) : 0;
-  if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, false>), dim3(blocks), dim3(64), 0, st, B, dbg, 0);
-  else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, false>), dim3(blocks), dim3(64), 0, st, B, dbg, 0);
+  if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, false>), dim3(blocks), dim3(64), 0, st, B, dbg, 0, q0_lie);
+  else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, false>), dim3(blocks), dim3(64), 0, st, B, dbg, 0, q0_lie);
   // the impulse stages of a forward-Euler chain (ParNMPC's go through K5a / K9i)
   if (B.n_impulse_fe > 0) {
     const unsigned gi = (unsigned)((batch * B.n_impulse_fe + 63) / 64), bi = ((gi + 7) / 8) * 8 * (2 * D::NL + 1);
-    if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe);
-    else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe);
+    const double* none = nullptr;
+    if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe, none);
+    else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe, none);
   }
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::nominal(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::nominal(const OcpBuffers&, long, int, hipStream_t, const double*);
 
 }  // namespace idocp_dev
