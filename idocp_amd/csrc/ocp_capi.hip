@@ -381,9 +381,10 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   if (ii != Ni || li != Nl) { set_last_error("ParNMPCDiscretizer: a discrete event lies outside the horizon"); return IDOCP_E_ARG; }
   for (int i = 0; i + 1 < Ng; ++i)
     if (imp_before[i] >= 0 && imp_before[i + 1] >= 0) { set_last_error("ParNMPCDiscretizer: impulses in consecutive time stages"); return IDOCP_E_ARG; }
-  // a lift in front of the first time stage is an ordinary first element of the chain; an impulse there is not carried (the
-  // reference linearises that aux stage without the switching constraint but inverts with it, backward_correction_solver.cpp:214-231)
-  if (imp_before[0] >= 0) { set_last_error("ParNMPC: an impulse in front of the first time stage is not carried"); return IDOCP_E_UNSUPPORTED; }
+  // a lift or an impulse in front of the first time stage: the event stages are the first elements of the chain and their
+  // predecessor is the measured state (backward_correction_solver.cpp:201-217, 232-246).  The aux stage carries the switching
+  // constraint like every other aux stage: the reference's call at :203-211 omits the impulse status and then sizes the KKT
+  // inverse with it (split_backward_correction.hxx:46-52), which is not defined as written (oracle/ocp.cpp, same place)
   h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
   auto node = [&](int kind, int index, double tt, double dtt, const HostStatus& st, int level) {
     OcpNode nd;

@@ -1306,10 +1306,12 @@ void ParNMPCSolver::discretize(real t) {
   }
   if (ii != Ni || li != Nl) throw std::runtime_error("ParNMPCDiscretizer: a discrete event lies outside the horizon");
   for (int i = 0; i + 1 < N_; ++i) if (imp_before[i] >= 0 && imp_before[i + 1] >= 0) throw std::runtime_error("ParNMPCDiscretizer: impulses in consecutive time stages");
-  // A lift in front of the first time stage is an ordinary first element of the chain (its predecessor is the measured state,
-  // backward_correction_solver.cpp:232-246).  An impulse there is not carried: the reference linearises that aux stage without
-  // the switching constraint but inverts its KKT matrix with it (:214-231).
-  if (imp_before[0] >= 0) throw std::logic_error("ParNMPC oracle: an impulse in front of the first time stage is not carried");
+  // A lift or an impulse in front of the first time stage makes the event stages the first elements of the chain; their predecessor
+  // is the measured state (backward_correction_solver.cpp:201-217, 232-246; the serial sweeps :283-292, :326-339 walk them like any
+  // other).  For the impulse the reference's call at :203-211 leaves out the impulse status, so that SplitKKTMatrix::dimi() = 0
+  // while SplitBackwardCorrection::coarseUpdate sizes the KKT inverse with s.aux.dimi() > 0 (split_backward_correction.hxx:46-52):
+  // the two disagree and the inversion is not defined as written.  Restated here with the status passed -- the same aux stage as
+  // everywhere else in the chain (:185-199), its predecessor being (q, v).
   for (int i = 0; i < N_; ++i) {
     const int phase_before = i > 0 ? phase[i - 1] : 0;
     if (imp_before[i] >= 0) {

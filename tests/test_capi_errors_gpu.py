@@ -80,12 +80,11 @@ def test_parnmpc_unsupported_cases_fail_loudly():
     g.set_contact_status([1, 1, 1, 1], pts)
     a = (C.c_int * 4)(0, 1, 1, 0)
     assert lib.idocp_ocp_push_back_contact_status(g.h, a, P(arr(pts)), 0.52) == E_ARG
-    # an impulse inside the first interval of a ParNMPC horizon (a lift there is fine)
+    # an impulse inside the first interval of a ParNMPC horizon is carried (tests/test_parnmpc_hybrid_gpu.py, "impulse-first")
     g2 = HipParNMPC(m, cost, cons, 1.0, 20, max_num_impulse=2)
     g2.set_contact_status([0, 1, 1, 0], pts)
     g2.push_back_contact_status([1, 1, 1, 1], pts, 0.02)
-    assert lib.idocp_parnmpc_init_backward_correction(g2.h, 0.0) == E_UNSUPPORTED
-    assert "first time stage" in capi.last_error()
+    assert lib.idocp_parnmpc_init_backward_correction(g2.h, 0.0) == 0
 
 
 def test_fixed_base_solver_argument_errors():

@@ -9,7 +9,7 @@ from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, HipParNMPC, OracleParNMP
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(N, T, events, batch=1):
+def make_pair(N, T, events, batch=1, initial=(1, 1, 1, 1)):
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=False)
     o = OracleParNMPC(m, cost, cons, T, N, max_num_impulse=3)
@@ -17,7 +17,7 @@ def make_pair(N, T, events, batch=1):
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
     for s in (o, g):
         pts = anymal_contact_points(m).copy()
-        s.set_contact_status([1, 1, 1, 1], pts)
+        s.set_contact_status(list(initial), pts)
         for status, t_ev in events:
             s.push_back_contact_status(status, pts, t_ev)
         s.set_solution("q", q)
@@ -58,11 +58,19 @@ ON_GRID = [([0, 1, 1, 0], 0.5), ([1, 1, 1, 1], 0.8)]          # both events on g
 LIFT_FIRST = [([0, 1, 1, 0], 0.02), ([1, 1, 1, 1], 0.43)]      # the lift inside the first interval: the chain starts with the lift stage
 
 
-@pytest.mark.parametrize("events,tol", [(LIFT, 1e-10), (LIFT_TOUCH, 1e-9), (ON_GRID, 1e-9), (LIFT_FIRST, 1e-9)],
-                         ids=["lift", "lift+impulse", "on-grid", "lift-first"])
+# the touch-down of two feet inside the first interval: the chain starts with the aux / impulse pair, whose predecessor is the measured
+# state (backward_correction_solver.cpp:201-217; the aux stage with its switching constraint, see oracle/ocp.cpp ParNMPCSolver::discretize)
+IMPULSE_FIRST = [([1, 1, 1, 1], 0.02), ([0, 1, 1, 0], 0.43)]
+
+
+@pytest.mark.parametrize("events,tol", [(LIFT, 1e-10), (LIFT_TOUCH, 1e-9), (ON_GRID, 1e-9), (LIFT_FIRST, 1e-9), (IMPULSE_FIRST, 1e-9)],
+                         ids=["lift", "lift+impulse", "on-grid", "lift-first", "impulse-first"])
 def test_first_iteration_direction_parity_along_the_chain(events, tol):
-    m, o, g, q, v = make_pair(20, 1.0, events)
+    first = events is IMPULSE_FIRST
+    m, o, g, q, v = make_pair(20, 1.0, events, initial=(0, 1, 1, 0) if first else (1, 1, 1, 1))
     M = check_chain(o, g)
+    if first:
+        assert "".join(c["kind"][0] for c in o.chain(0.0)).startswith("ais")
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
     assert abs(e_g[0] - e_o) <= 1e-9 * e_o, (e_g, e_o)
     assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
