@@ -997,11 +997,9 @@ void* idocp_ocp_stream(idocp_ocp_t* h) { return h ? (void*)h->stream : nullptr; 
 // LineSearch::computeCostAndViolation (src/line_search/line_search.cpp:63-196) of s (+) alpha[b] d for every instance: trial
 // iterate + barrier cost (ocp_trial_kernel), then the rigid-body residual kernels and the MERIT variant of the condensation
 // kernel on a copy of the buffers whose `sol` is the trial iterate, then the sums over the chain.  out[2 b] = cost, [2 b + 1] = violation.
-// The filter line search of ParNMPCSolver is carried for event-free horizons on one shard (LineSearch::computeCostAndViolation of a
-// horizon with events pairs aux / lift stages with grid stages in its own way, src/line_search/line_search.cpp:238-301: not restated).
+// The filter line search of ParNMPCSolver runs on one shard (horizons with discrete events included: every stage of the chain is
+// evaluated against the trial iterate of its chain predecessor, src/line_search/line_search.cpp:199-301, line_search.hpp:224-264).
 static int parnmpcLineSearchSupported(const idocp_ocp_t* h) {
-  for (const OcpNode& nd : h->chain)
-    if (nd.kind != 0 && nd.kind != 4) { set_last_error("line_search=true on a ParNMPC horizon with discrete events is not supported by the HIP path"); return IDOCP_E_UNSUPPORTED; }
   if (h->has_prev || !h->has_terminal) { set_last_error("line_search=true on a shard of a ParNMPC horizon is not supported by the HIP path"); return IDOCP_E_UNSUPPORTED; }
   return IDOCP_OK;
 }
@@ -1012,8 +1010,12 @@ static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, con
   OcpBuffers Bt = h->B;
   Bt.sol = h->B.sol_try;
   if (h->parnmpc) {
-    // ParNMPC, event-free horizon: backward-Euler stages against the trial predecessor (the measured state in front of stage 0)
+    // ParNMPC: backward-Euler stages against the trial predecessor (the measured state in front of the first element of the chain);
+    // aux stages add the l1 norm of their switching constraint (K5s on the trial iterate), impulse stages have a kernel of their own
+    OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);
+    if (h->has_switch) OcpLaunch<DQ>::switching(Bt, h->batch, M, h->stream);
     OcpLaunch<DQ>::meritBackwardEuler(Bt, h->batch, M, d_q, h->d_v0, h->stream);
+    OcpLaunch<DQ>::parnmpcImpulseMerit(Bt, h->batch, h->n_impulse, d_q, h->d_v0, h->stream);
   } else {
     Bt.nodes = h->B.nodes_ls;
     OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);

@@ -23,6 +23,7 @@ struct OcpLaunch {
   static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
   static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9b
+  static void parnmpcImpulseMerit(const OcpBuffers& Btry, long batch, int n_impulse, const double* q0, const double* v0, hipStream_t st);      // line search on the impulse stages
   static void parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n_impulse, bool residual, const double* q0, const double* v0,
                                      hipStream_t st);                                               // K9i: impulse stages of a ParNMPC chain
   static void parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st); // K9g: aux (switching rows) and impulse stages

@@ -33,7 +33,9 @@ namespace {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------- K9i ----
-template <typename D, bool RESIDUAL>
+// MERIT (with RESIDUAL): the line search's evaluation of a trial iterate on the impulse stage -- ImpulseSplitParNMPC::stageCost and
+// constraintViolation (impulse_split_parnmpc.hxx:147-194): B.sol is the trial iterate, the lin / lie records have been rebuilt on it.
+template <typename D, bool RESIDUAL, bool MERIT = false>
 __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     lq[r] = a_q; lv[r] = a_v; ldv[r] = a_dv;
   }
   // lf of the contacts that touch down: impulse force cost + cone + (- Vv beta)
-  double e_ipm = 0.0;
+  double e_ipm = 0.0, m_cost = 0.0, m_viol = 0.0;
   if (tid >= 64 && tid < 64 + NC && nd->active[tid - 64]) {
     const int c = tid - 64, row = nd->row_of[c];
     // (Linearized)ImpulseFrictionCone, row by row (coneRow, ocp_device.hpp)
@@ -122,11 +124,12 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
       const double g = coneRow(ck, P->mu, r, fc, Jr[r]);
       const double sl = slack[idx], du = dual[idx];
       const double res = g + sl, duality = sl * du - P->barrier;
-      if (RESIDUAL) { rr[r] = du; ddv[r] = 0.0; e_ipm += res * res + duality * duality; }
+      if (RESIDUAL) { rr[r] = du; ddv[r] = 0.0; e_ipm += res * res + duality * duality; if (MERIT && cone) m_viol += fabs(res); }
       else { rr[r] = du + (du * res - duality) / sl; ddv[r] = du / sl; }
     }
     for (int x = 0; x < 3; ++x) {
       double a = P->fi_weight[c][x] * (s[L::S_F + 3 * c + x] - P->fi_ref[c][x]);
+      if (MERIT) m_cost += 0.5 * a * (s[L::S_F + 3 * c + x] - P->fi_ref[c][x]);      // ImpulseForceCost::computeImpulseCost
       if (cone) for (int r = 0; r < 5; ++r) a += Jr[r][x] * rr[r];
       double vb = 0.0;
       for (int m = 0; m < NV; ++m) vb += Vv[(row + x) + NF * m] * s[L::S_BETA + m];
@@ -142,6 +145,24 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     if (!cone) e_ipm = 0.0;
   }
   __syncthreads();
+  if (MERIT) {
+    if (tid < NV) {
+      const int r = tid;
+      const double qd = r < 6 ? qdd[r] : s[L::S_Q + r + 1] - qref[r + 1];
+      const double dvr = s[L::S_V + r] - vref_on * P->v_ref[r], ddv = s[L::S_A + r];
+      m_cost += 0.5 * (P->qi_weight[r] * qd * qd + P->vi_weight[r] * dvr * dvr + P->dvi_weight[r] * ddv * ddv);
+      m_viol += fabs(Fq[r]) + fabs(Fv[r]) + fabs(ImD[r]);
+    }
+    if (tid < ni) m_viol += fabs(Vr[tid]);
+    err[tid] = m_cost;
+    __syncthreads();
+    if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.merit_stage[rec * 4] = acc; }
+    __syncthreads();
+    err[tid] = m_viol;
+    __syncthreads();
+    if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.merit_stage[rec * 4 + 1] = acc; }
+    return;
+  }
   if (RESIDUAL) {
     // ImpulseSplitParNMPC::squaredNormKKTResidual (impulse_split_parnmpc.hxx:114-124)
     double e = e_ipm;
@@ -487,6 +508,14 @@ void OcpLaunch<D>::parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n
   else hipLaunchKernelGGL((parnmpc_impulse_condense_kernel<D, false>), dim3((unsigned)batch, (unsigned)n_impulse), dim3(256), 0, st, B, q0, v0);
 }
 
+// line search: stage cost and l1 violation of the impulse stages of the trial iterate Btry.sol points at (after K5a's impulse pass and
+// the Lie-group kernel on Btry; overwrites what the stage kernel left in merit_stage for these slots)
+template <typename D>
+void OcpLaunch<D>::parnmpcImpulseMerit(const OcpBuffers& Btry, long batch, int n_impulse, const double* q0, const double* v0, hipStream_t st) {
+  if (n_impulse <= 0) return;
+  hipLaunchKernelGGL((parnmpc_impulse_condense_kernel<D, true, true>), dim3((unsigned)batch, (unsigned)n_impulse), dim3(256), 0, st, Btry, q0, v0);
+}
+
 template <typename D>
 void OcpLaunch<D>::parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st) {
   if (n_general <= 0) return;
@@ -500,6 +529,7 @@ void OcpLaunch<D>::parnmpcEventInverse(const OcpBuffers& B, long batch, int n_ge
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::parnmpcImpulseCondense(const OcpBuffers&, long, int, bool, const double*, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::parnmpcImpulseMerit(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::parnmpcEventInverse(const OcpBuffers&, long, int, hipStream_t);
 
 }  // namespace idocp_dev

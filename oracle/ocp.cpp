@@ -1397,8 +1397,7 @@ void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
       } else {
-        for (int cc = 0; cc < nc_; ++cc) {
-          if (seq.numEvents() > 0 && !cs.active[cc]) { for (int r = 0; r < CR; ++r) data.slack[CR * cc + r] = cons.barrier; continue; }
+        for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:100-108)
           const ConeEval ce = coneEval(CK, cons.mu, s[i].f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
           for (int r = 0; r < CR; ++r) data.slack[CR * cc + r] = -res[r];
         }
@@ -2133,16 +2132,20 @@ void ParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_
   integrateSolution();
 }
 
-// LineSearch::computeSolution + computeCostAndViolation for ParNMPC (src/line_search/line_search.cpp:199-237, 346-399) on an
-// event-free horizon.  Per stage i of the N stages (the last one is TerminalParNMPC):
-//   cost      = Split / TerminalParNMPC::stageCost (split_parnmpc.hxx:269-288, terminal_parnmpc.hxx:188-207): stage cost + dt *
-//               barrier(slack + alpha dslack) -- NOT the terminal cost, which the reference leaves out of its line search
-//   violation = constraintViolation (split_parnmpc.hxx:291-311, terminal_parnmpc.hxx:210-229): backward-Euler residual against the
-//               TRIAL predecessor (the measured state in front of stage 0) |Fx|_1 + dt |[ID - u; C]|_1 + dt |g + slack|_1
+// LineSearch::computeSolution + computeCostAndViolation for ParNMPC (src/line_search/line_search.cpp:199-301, 346-399).  Every stage
+// of the chain is evaluated against the TRIAL iterate of its chain predecessor (line_search.hpp:224-264 for the grid stages,
+// line_search.cpp:240-300 for the event stages: impulse <- aux, aux / lift <- the grid stage in front of them or the measured state):
+//   grid / aux / lift stage (the last grid stage is TerminalParNMPC):
+//     cost      = Split / TerminalParNMPC::stageCost (split_parnmpc.hxx:269-288, terminal_parnmpc.hxx:188-207): stage cost + dt *
+//                 barrier(slack + alpha dslack) -- NOT the terminal cost, which the reference leaves out of its line search
+//     violation = constraintViolation (split_parnmpc.hxx:291-342, terminal_parnmpc.hxx:210-229): |Fx|_1 + dt |[ID - u; C]|_1
+//                 + dt |g + slack|_1, on an aux stage + |P|_1 of the switching constraint (no dt)
+//   impulse stage:
+//     cost      = ImpulseSplitParNMPC::stageCost (impulse_split_parnmpc.hxx:147-163): impulse cost + barrier, no dt
+//     violation = constraintViolation (:166-194): |g + slack|_1 + |Fx|_1 + |ImD|_1 + |V|_1
 std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, const Mat& v) {
   const int nv = nv_, nu = nu_, kP = nv - nu;
   Robot rb = robot;
-  for (const PNode& nd : chain) if (nd.kind != NodeC::Stage && nd.kind != NodeC::Terminal) throw std::logic_error("ParNMPC line search: event-free horizons only");
   auto trial = [&](int p) {
     const int sl = chain[p].slot;
     SplitSolutionC x = s[sl];
@@ -2151,7 +2154,7 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       Mat qn; rb.integrateConfiguration(s[sl].q, d[sl].dq, alpha, qn); x.q = qn;
       x.v = s[sl].v + alpha * d[sl].dv;
       x.a = s[sl].a + alpha * d[sl].daf.segment(0, nv);
-      x.u = s[sl].u + alpha * d[sl].du;
+      if (chain[p].kind != NodeC::Impulse) x.u = s[sl].u + alpha * d[sl].du;
       int st = 0;
       for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int k2 = 0; k2 < 3; ++k2) x.f[c][k2] = s[sl].f[c][k2] + alpha * d[sl].daf[nv + st + k2]; st += 3; }
     }
@@ -2162,9 +2165,10 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
   for (int p = 0; p < (int)chain.size(); ++p) {
     const PNode& nd = chain[p];
     const int sl = nd.slot;
+    const bool impulse = nd.kind == NodeC::Impulse;
     const SplitSolutionC x = trial(p);
     const ContactStatus& cs = nodeContacts(nd);
-    const real dt = nd.dt;
+    const real dt = impulse ? 1.0 : nd.dt;
     Mat q_ref, qdiff;
     qRef(nd.t, q_ref);
     rb.subtractConfiguration(x.q, q_ref, qdiff);
@@ -2173,14 +2177,18 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
     real l = 0;
     for (int r = 0; r < nv; ++r) {
       const real dvr = x.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]);
-      l += cost.q_weight[r] * qdiff[r] * qdiff[r] + cost.v_weight[r] * dvr * dvr + cost.a_weight[r] * x.a[r] * x.a[r];
+      if (impulse) l += cost.qi_weight[r] * qdiff[r] * qdiff[r] + cost.vi_weight[r] * dvr * dvr + cost.dvi_weight[r] * x.a[r] * x.a[r];
+      else l += cost.q_weight[r] * qdiff[r] * qdiff[r] + cost.v_weight[r] * dvr * dvr + cost.a_weight[r] * x.a[r] * x.a[r];
     }
-    for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
-    for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) l += cost.f_weight[c][k2] * (x.f[c][k2] - cost.f_ref[c][k2]) * (x.f[c][k2] - cost.f_ref[c][k2]);
+    if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
+    for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) {
+      const real w = impulse ? cost.fi_weight[c][k2] : cost.f_weight[c][k2], fr = impulse ? cost.fi_ref[c][k2] : cost.f_ref[c][k2];
+      l += w * (x.f[c][k2] - fr) * (x.f[c][k2] - fr);
+    }
     real barrier = 0, primal = 0;
     for (int c = 0; c < 7; ++c) {
       if (!componentValid(c, nd)) continue;
-      const int CK = coneKind(false), CR = coneRows(false);
+      const int CK = coneKind(impulse), CR = coneRows(impulse);
       const IpmData& data = ipm[sl][c];
       for (int r = 0; r < data.slack.size(); ++r) barrier -= cons.barrier * std::log(data.slack[r] + alpha * data.dslack[r]);      // pdipm.hxx:84-87
       if (c < 6) {
@@ -2194,19 +2202,38 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       }
     }
     cost_sum += 0.5 * dt * l + dt * barrier;
-    // backward-Euler residual against the trial predecessor (state_equation.hxx:225-236)
     const Mat& qpv = p == 0 ? q : xp.q;
     const Mat& vpv = p == 0 ? v : xp.v;
     Mat diff; rb.subtractConfiguration(qpv, x.q, diff);
     real viol = 0;
-    for (int r = 0; r < nv; ++r) viol += std::fabs(diff[r] + dt * x.v[r]) + std::fabs(vpv[r] - x.v[r] + dt * x.a[r]);
-    Mat ID, C;
-    rb.updateKinematics(x.q, x.v, x.a);
-    rb.setContactForces(cs.active, x.f);
-    rb.RNEA(x.q, x.v, x.a, ID);
-    for (int r = 0; r < nu; ++r) ID[kP + r] -= x.u[r];
-    rb.computeBaumgarteResidual(cs.active, dt_, cs.points, C);
-    viol += dt * (ID.lpNorm1() + C.lpNorm1()) + dt * primal;
+    if (impulse) {
+      // impulse_state_equation.hxx:113-124, impulse_dynamics_backward_euler.hxx:117-134
+      for (int r = 0; r < nv; ++r) viol += std::fabs(diff[r]) + std::fabs(vpv[r] - x.v[r] + x.a[r]);
+      Mat ImD, V;
+      const Mat zero(nv);
+      rb.updateKinematics(x.q, x.v, zero);
+      rb.setContactForces(cs.active, x.f);
+      rb.RNEA(x.q, zero, x.a, ImD, false);
+      rb.computeImpulseVelocityResidual(cs.active, V);
+      viol += ImD.lpNorm1() + V.lpNorm1() + primal;
+    } else {
+      // backward-Euler residual against the trial predecessor (state_equation.hxx:225-236)
+      for (int r = 0; r < nv; ++r) viol += std::fabs(diff[r] + dt * x.v[r]) + std::fabs(vpv[r] - x.v[r] + dt * x.a[r]);
+      Mat ID, C;
+      rb.updateKinematics(x.q, x.v, x.a);
+      rb.setContactForces(cs.active, x.f);
+      rb.RNEA(x.q, x.v, x.a, ID);
+      for (int r = 0; r < nu; ++r) ID[kP + r] -= x.u[r];
+      rb.computeBaumgarteResidual(cs.active, dt_, cs.points, C);
+      viol += dt * (ID.lpNorm1() + C.lpNorm1()) + dt * primal;
+      if (nd.kind == NodeC::Aux) {
+        // switchingconstraint::computeSwitchingConstraintResidual on the aux stage's own configuration (switching_constraint.hxx:24-33)
+        const ContactStatus& is = seq.impulse_status[nd.event];
+        Mat Pr;
+        rb.computeContactResidual(is.active, is.points, Pr);
+        viol += Pr.lpNorm1();
+      }
+    }
     viol_sum += viol;
     xp = x;
   }

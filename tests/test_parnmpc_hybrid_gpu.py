@@ -217,3 +217,39 @@ def test_two_shards_of_a_chain_with_events_on_one_gpu_equal_the_whole_chain():
     boundary()
     e2 = float(s0.err2(0.0)[0] + s1.err2(0.0)[0])
     assert abs(np.sqrt(e2) - g.kkt_error(0.0, q, v)[0]) < 1e-9 * max(1.0, np.sqrt(e2))
+
+
+@pytest.mark.parametrize("events,initial", [(LIFT_TOUCH, (1, 1, 1, 1)), (IMPULSE_FIRST, (0, 1, 1, 0))], ids=["lift+impulse", "impulse-first"])
+def test_filter_line_search_on_a_chain_with_events(events, initial):
+    """ParNMPCSolver::updateSolution(t, q, v, line_search = true) on a horizon with discrete events: LineSearch::computeCostAndViolation
+    (src/line_search/line_search.cpp:199-301) evaluates every stage of the chain against the TRIAL iterate of its chain predecessor --
+    grid / aux / lift stages with Split / TerminalParNMPC::stageCost + constraintViolation (the aux stage adds |P|_1 of its switching
+    constraint), the impulse stage with ImpulseSplitParNMPC's (impulse cost, |Fx|_1 + |ImD|_1 + |V|_1 + cone residual).  Totals against
+    the oracle for several trial steps, then the accepted steps of the first iterations."""
+    from helpers import P
+    m, o, g, q, v = make_pair(20, 1.0, events, batch=2, initial=initial)
+    check_chain(o, g)
+    assert o.lib.oracle_parnmpc_compute_direction(o.h, 0.0, P(q), P(v)) == 0
+    assert g.lib.idocp_parnmpc_compute_direction(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv))) == 0
+    ap, _ = g.step_sizes()
+    ao, _ = o.step_sizes()
+    assert abs(ap[0] - ao) < 1e-9
+    for alpha in (0.0, 0.01 * ap[0], 0.3 * ap[0], 0.5 * ap[0], ap[0]):      # (beyond the fraction-to-boundary step the barrier is undefined)
+        ref = np.zeros(2)
+        assert o.lib.oracle_parnmpc_cost_and_violation(o.h, alpha, P(q), P(v), P(ref)) == 0
+        assert np.isfinite(ref).all()
+        c, vi = np.zeros(g.batch), np.zeros(g.batch)
+        assert g.lib.idocp_ocp_line_search_eval(g.h, P(np.full(g.batch, alpha)), P(c), P(vi)) == 0
+        # the direction itself agrees to 1e-9 on these chains (see above): the trial iterates inherit that
+        assert abs(c[0] - ref[0]) <= 1e-8 * max(1.0, abs(ref[0])), (alpha, c[0], ref[0])
+        assert abs(vi[0] - ref[1]) <= 1e-8 * max(1.0, abs(ref[1])), (alpha, vi[0], ref[1])
+        assert c[0] == c[-1] and vi[0] == vi[-1]
+    m, o, g, q, v = make_pair(20, 1.0, events, batch=2, initial=initial)
+    M = check_chain(o, g)
+    for it in range(3):
+        assert o.lib.oracle_parnmpc_update_solution_ls(o.h, 0.0, P(q), P(v)) == 0
+        assert g.lib.idocp_parnmpc_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1) == 0
+        ao, bo = o.step_sizes()
+        ag, bg = g.step_sizes()
+        assert abs(ag[0] - ao) < 1e-9 and abs(bg[0] - bo) < 1e-8, (it, ag[0], ao)
+        compare(o, g, M, ("q", "v", "a", "u", "f"), 1e-7, "iterate %d" % it)
