@@ -72,6 +72,8 @@ class Constraints(C.Structure):
         ("barrier", C.c_double), ("fraction_to_boundary_rate", C.c_double),
         ("linearized_impulse_friction_cone", C.c_int),
         ("friction_cone", C.c_int), ("impulse_friction_cone", C.c_int),
+        ("joint_acceleration_lower_limit", C.c_int), ("joint_acceleration_upper_limit", C.c_int),
+        ("a_min", C.c_double * MAX_NV), ("a_max", C.c_double * MAX_NV),
     ]
 
 

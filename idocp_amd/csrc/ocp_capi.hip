@@ -694,6 +694,9 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   }
   p.use_q_limits = constraints->joint_position_limits; p.use_v_limits = constraints->joint_velocity_limits;
   p.use_u_limits = constraints->joint_torque_limits;
+  p.use_a_lower = constraints->joint_acceleration_lower_limit ? 1 : 0;
+  p.use_a_upper = constraints->joint_acceleration_upper_limit ? 1 : 0;
+  for (int r = 0; r < IDOCP_MAX_NV; ++r) { p.a_min[r] = constraints->a_min[r]; p.a_max[r] = constraints->a_max[r]; }
   p.use_friction_cone = (constraints->linearized_friction_cone || constraints->friction_cone) ? 1 : 0;
   p.use_impulse_friction_cone = (constraints->linearized_impulse_friction_cone || constraints->impulse_friction_cone) ? 1 : 0;
   p.cone_kind = constraints->friction_cone ? 1 : 0; p.impulse_cone_kind = constraints->impulse_friction_cone ? 1 : 0;
@@ -1280,6 +1283,11 @@ int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* w
         for (int r = 0; r < nu; ++r) { const double v = s[LQ::S_V + DQ::NV - nu + r]; if (v < -P.v_max[r] || v > P.v_max[r]) return false; }
       if (P.use_u_limits && nd.has_u)
         for (int r = 0; r < nu; ++r) { const double u = s[LQ::S_U + r]; if (u < -P.u_max[r] || u > P.u_max[r]) return false; }
+      if (nd.kind != 4)                                               // joint_acceleration_{lower,upper}_limit.cpp:38-47
+        for (int r = 0; r < nu; ++r) {
+          const double a = s[LQ::S_A + DQ::NV - nu + r];
+          if ((P.use_a_lower && a < P.a_min[r]) || (P.use_a_upper && a > P.a_max[r])) return false;
+        }
       if (!P.use_friction_cone) return true;
     }
     const int ck = nd.kind == 1 ? P.impulse_cone_kind : P.cone_kind;
@@ -1308,7 +1316,8 @@ int idocp_ocp_dimc(const idocp_ocp_t* h) {
   if (!h) return 0;
   const idocp_constraints_t& c = h->cons;
   return 2 * DQ::NU * ((c.joint_position_limits ? 1 : 0) + (c.joint_velocity_limits ? 1 : 0) + (c.joint_torque_limits ? 1 : 0)) +
-         (c.linearized_friction_cone ? 5 * DQ::NC : 0) + (c.friction_cone ? 2 * DQ::NC : 0);
+         (c.linearized_friction_cone ? 5 * DQ::NC : 0) + (c.friction_cone ? 2 * DQ::NC : 0) +
+         DQ::NU * ((c.joint_acceleration_lower_limit ? 1 : 0) + (c.joint_acceleration_upper_limit ? 1 : 0));
 }
 
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual) {
@@ -1320,16 +1329,18 @@ int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, d
   HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * h->NS * LQ::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const idocp_constraints_t& c = h->cons;
-  const int use[4] = {c.joint_position_limits, c.joint_velocity_limits, c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone};
+  // components in the order 0 .. 5 joint position / velocity / torque (lower, upper), 6 cone, 8 / 9 joint acceleration lower / upper
+  const int use[10] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits, c.joint_torque_limits,
+                       c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone, 0, c.joint_acceleration_lower_limit, c.joint_acceleration_upper_limit};
   const int cr = coneRows(h->prob.cone_kind);        // rows per contact of the cone in use (the records keep five slots per contact)
   for (int i = 0; i < N; ++i) {
     int off = 0;
-    for (int comp = 0; comp < 7; ++comp) {
-      if (!use[comp < 6 ? comp / 2 : 3]) continue;
-      const int n = comp < 6 ? DQ::NU : cr * DQ::NC;
+    for (int comp = 0; comp < 10; ++comp) {
+      if (!use[comp]) continue;
+      const int n = comp != 6 ? DQ::NU : cr * DQ::NC;
       const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
       for (int r = 0; r < n; ++r) {
-        const int src = comp < 6 ? comp * DQ::NU + r : LQ::C_FRIC + 5 * (r / cr) + r % cr;
+        const int src = comp != 6 ? ipmCompRow<LQ>(comp) + r : LQ::C_FRIC + 5 * (r / cr) + r % cr;
         if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * LQ::CON + src] : 0.0;
         if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * LQ::CON + src] : 0.0;
       }

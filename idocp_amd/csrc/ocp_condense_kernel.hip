@@ -34,6 +34,8 @@ __device__ __forceinline__ double ocpLimit(const OcpProblem* __restrict__ P, int
     case 2: return -P->v_max[r];
     case 3: return P->v_max[r];
     case 4: return -P->u_max[r];
+    case 8: return P->a_min[r];
+    case 9: return P->a_max[r];
     default: return P->u_max[r];
   }
 }
@@ -44,7 +46,9 @@ __device__ __forceinline__ bool ocpRowValid(const OcpProblem* __restrict__ P, in
   if (comp < 2) return P->use_q_limits && level >= 2;
   if (comp < 4) return P->use_v_limits && level >= 1;
   if (comp < 6) return P->use_u_limits != 0;
-  return P->use_friction_cone != 0;
+  if (comp == 8) return P->use_a_lower != 0;
+  if (comp == 9) return P->use_a_upper != 0;
+  return comp == 6 && P->use_friction_cone != 0;
 }
 
 // SFP: number of contact rows the LDS blocks are laid out for (= leading dimension of J, Qff, BL, SM; NV + SFP for the
@@ -400,6 +404,21 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         if (RESIDUAL) err_ipm += res * res + duality * duality;
         else { const double isl = recipNewton(sl); g += sgn * dt * (du * res - duality) * isl; h = dt * du * isl; }
         if (c < 2) { lq += g; hq += h; } else { lv += g; hv += h; }
+      }
+      // JointAccelerationLowerLimit / UpperLimit (joint_acceleration_{lower,upper}_limit.cpp:57-75): la, Qaa diagonal
+      if (P->use_a_lower | P->use_a_upper) {
+        for (int c = 8; c < 10; ++c) {
+          if (!ocpRowValid(P, c, i, impulse)) continue;
+          const double sgn = (c & 1) ? 1.0 : -1.0;
+          const int row = L::C_ACC + (c - 8) * NU + j;
+          const double sl = slack[row], du = dual[row];
+          const double res = sgn * (ar - ocpLimit(P, c, j)) + sl, duality = sl * du - P->barrier;
+          double g = sgn * dt * du, h = 0.0;
+          if (MERIT) merit_viol += dt * fabs(res);
+          if (RESIDUAL) err_ipm += res * res + duality * duality;
+          else { const double isl = recipNewton(sl); g += sgn * dt * (du * res - duality) * isl; h = dt * du * isl; }
+          la += g; ha += h;
+        }
       }
     }
     // ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:49-51): + Phi^T xi

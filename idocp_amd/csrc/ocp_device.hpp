@@ -33,8 +33,9 @@ struct OcpLayout {
                        D_F = D_BETA + NV, D_MU = D_F + NF, D_NUP = D_MU + NF, D_XI = D_NUP + 6,
                        D_T = D_XI + NF, D_W = D_T + NVF;       // scratch of the expansion: MJD dx and MJ[:, u] du (K6 -> K7)
   static constexpr int DIR = roundUp16(D_W + NVF);
-  // IPM rows: 6 joint-limit components x NU, then 5 friction-cone rows per contact
-  static constexpr int C_FRIC = 6 * NU, NCON = 6 * NU + 5 * NC;
+  // IPM rows: 6 joint-limit components x NU (position / velocity / torque, lower then upper), 5 friction-cone rows per contact, then the
+  // joint-acceleration limits (components 8 = lower, 9 = upper; component 6 is the cone, 7 is not used: odd components are upper bounds)
+  static constexpr int C_FRIC = 6 * NU, C_ACC = C_FRIC + 5 * NC, NCON = C_ACC + 2 * NU;
   static constexpr int CON = roundUp16(NCON);
   // linearisation record written by the tangent-RNEA kernel: [dID;dC]/d(q,v) (NVF x NX, ld NVF),
   // dID/da = M (NV x NV), dC/da = J (NF x NV, ld NF), [ID; C]
@@ -153,6 +154,11 @@ __host__ __device__ inline double coneRow(int kind, double mu, int r, const doub
   return J[0] * f[0] + J[1] * f[1] + J[2] * f[2];
 }
 
+struct OcpProblem;
+// first IPM row of a joint-limit component (0 .. 5, 8, 9)
+template <typename L>
+__host__ __device__ inline int ipmCompRow(int comp) { return comp < 6 ? comp * L::NU : L::C_ACC + (comp - 8) * L::NU; }
+
 struct OcpProblem {
   int N, batch;            // N = grid intervals (N_ideal)
   int M, NS, E;            // chain length of the current discretisation; storage slots per instance; max events
@@ -168,6 +174,8 @@ struct OcpProblem {
   double qi_weight[IDOCP_MAX_NV], vi_weight[IDOCP_MAX_NV], dvi_weight[IDOCP_MAX_NV];         // impulse stages
   double fi_weight[IDOCP_MAX_CONTACTS][3], fi_ref[IDOCP_MAX_CONTACTS][3];
   int use_q_limits, use_v_limits, use_u_limits, use_friction_cone, use_impulse_friction_cone;
+  int use_a_lower, use_a_upper;         // JointAccelerationLowerLimit / UpperLimit (acceleration level: every stage with torques)
+  double a_min[IDOCP_MAX_NV], a_max[IDOCP_MAX_NV];
   int cone_kind, impulse_cone_kind;     // 0: Linearized(Impulse)FrictionCone (5 rows per contact), 1: (Impulse)FrictionCone (2 rows); coneRow below
   double mu, barrier, fraction_rate;
   double contact_R[IDOCP_MAX_CONTACTS][9], contact_p[IDOCP_MAX_CONTACTS][3];   // frame placement in the tip joint

@@ -23,6 +23,8 @@ __device__ __forceinline__ double ocpLimit2(const OcpProblem* __restrict__ P, in
     case 2: return -P->v_max[r];
     case 3: return P->v_max[r];
     case 4: return -P->u_max[r];
+    case 8: return P->a_min[r];
+    case 9: return P->a_max[r];
     default: return P->u_max[r];
   }
 }
@@ -32,7 +34,9 @@ __device__ __forceinline__ bool ocpRowValid2(const OcpProblem* __restrict__ P, i
   if (comp < 2) return P->use_q_limits && level >= 2;
   if (comp < 4) return P->use_v_limits && level >= 1;
   if (comp < 6) return P->use_u_limits != 0;
-  return P->use_friction_cone != 0;
+  if (comp == 8) return P->use_a_lower != 0;
+  if (comp == 9) return P->use_a_upper != 0;
+  return comp == 6 && P->use_friction_cone != 0;
 }
 __device__ __forceinline__ double f2b(double rate, double x, double dx, double cur) {
   const double f = -rate * (x / dx);
@@ -43,10 +47,19 @@ __device__ __forceinline__ double f2b(double rate, double x, double dx, double c
 // constrained function g(x) and its directional derivative dg.
 template <typename D>
 __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd, int row, const double* __restrict__ s,
-                                       const double* dq, const double* dv, const double* du, const double* df_slot, double* g,
-                                       double* dg) {
+                                       const double* dq, const double* dv, const double* du, const double* df_slot, const double* da,
+                                       double* g, double* dg) {
   using L = OcpLayout<D>;
   constexpr int NU = D::NU;
+  if (row >= L::C_ACC) {
+    // JointAccelerationLowerLimit / UpperLimit on a.tail(dimu) (joint_acceleration_{lower,upper}_limit.cpp:78-93)
+    const int c = 8 + (row - L::C_ACC) / NU, j = (row - L::C_ACC) % NU;
+    if (!ocpRowValid2(P, c, nd->level, nd->kind == 1)) return false;
+    const double sgn = (c & 1) ? 1.0 : -1.0;
+    *g = sgn * (s[L::S_A + 6 + j] - ocpLimit2(P, c, j));
+    *dg = sgn * da[6 + j];
+    return true;
+  }
   if (row < L::C_FRIC) {
     const int c = row / NU, j = row - c * NU;
     if (!ocpRowValid2(P, c, nd->level, nd->kind == 1)) return false;
@@ -71,7 +84,7 @@ __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const O
 template <typename D>
 __device__ __forceinline__ bool ipmIdleConeRow(const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd, int row) {
   using L = OcpLayout<D>;
-  if (row < L::C_FRIC || !ocpRowValid2(P, 6, nd->level, nd->kind == 1)) return false;
+  if (row < L::C_FRIC || row >= L::C_ACC || !ocpRowValid2(P, 6, nd->level, nd->kind == 1)) return false;
   const int r = (row - L::C_FRIC) % 5;
   return r < coneRows(nd->kind == 1 ? P->impulse_cone_kind : P->cone_kind);
 }
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   __shared__ __attribute__((aligned(16))) double pm[PML], mju[MJUL], sr[L::SOL];
   double* pb = pm;
   double* mjd = pm;
-  __shared__ double dx[NX], du[NU], dfs[NF];
+  __shared__ double dx[NX], du[NU], dfs[NF], das[NV];
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
   const int lane = threadIdx.x;
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
       double t2 = 0.0;
       for (int j = 0; j < dimf; ++j) t2 += kk[L::K_FVU + lane + NV * j] * du[j];
       acc += t2;
-      dd[L::D_A + lane] = acc;
+      dd[L::D_A + lane] = acc; das[lane] = acc;
     }
   }
   if (!P->backward_euler && nd->sw_dimi > 0 && lane >= 32 && lane < 32 + nd->sw_dimi) {
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     for (int j = 0; j < NU; ++j) { const int c = 6 + j; ww += (r >= c ? mju[r * (r + 1) / 2 + c] : mju[c * (c + 1) / 2 + r]) * du[j]; }      // MJtJinv(r, 6 + j)
     acc += ww - tt;
     dd[L::D_T + r] = tt; dd[L::D_W + r] = ww;        // for the dual expansion (K7)
-    if (r < NV) dd[L::D_A + r] = acc;
+    if (r < NV) { dd[L::D_A + r] = acc; das[r] = acc; }
     else {
       // d.df() *= -1; packed active row -> contact slot
       const int pr = r - NV;
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   for (int t = 0; t < 2; ++t) {
     const int row = lane + 64 * t;
     double g, dg;
-    if (row >= L::NCON || !ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) continue;
+    if (row >= L::NCON || !ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, das, &g, &dg)) continue;
     const double sl = sl_r[t], dl = dl_r[t];
     const double res = g + sl, duality = sl * dl - P->barrier;
     const double dslack = -dg - res;
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       const int row = lane + 64 * t;
       if (row >= L::NCON) continue;
       double g, dg;
-      const bool valid = ipmRow<D>(P, nd, row, sr, dx, dx + NV, du, dfs, &g, &dg);
+      const bool valid = ipmRow<D>(P, nd, row, sr, dx, dx + NV, du, dfs, dr + L::D_A, &g, &dg);
       const double sl = sl_r[t], dl = dl_r[t];
       double dslack, ddual;
       if (valid) {
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
     const double* __restrict__ slack = B.slack + rec * L::CON;
     for (int row = lane; row < L::NCON; row += 64) {
       double g, dg, dslack;
-      if (ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, &g, &dg)) dslack = -dg - (g + slack[row]);
+      if (ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, dd + L::D_A, &g, &dg)) dslack = -dg - (g + slack[row]);
       else if (ipmIdleConeRow<D>(P, nd, row)) dslack = 1.0;
       else continue;
       bar -= log(slack[row] + a * dslack);
@@ -516,7 +529,11 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
     double sl = 1.0, dl = 0.0;
     bool valid;
     double g = 0.0;
-    if (row < L::C_FRIC) {
+    if (row >= L::C_ACC) {
+      const int c = 8 + (row - L::C_ACC) / NU, j = (row - L::C_ACC) % NU;
+      valid = ocpRowValid2(P, c, i, impulse);
+      if (valid) g = ((c & 1) ? 1.0 : -1.0) * (s[L::S_A + 6 + j] - ocpLimit2(P, c, j));      // joint_acceleration_{lower,upper}_limit.cpp:50-54
+    } else if (row < L::C_FRIC) {
       const int c = row / NU, j = row - c * NU;
       valid = ocpRowValid2(P, c, i, impulse);
       if (valid) {

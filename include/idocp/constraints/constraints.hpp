@@ -10,6 +10,7 @@
 #include <iostream>
 #include <memory>
 
+#include "idocp/eigen_shim.hpp"
 #include "idocp/robot/robot.hpp"
 #include "idocp_hip.h"
 
@@ -17,7 +18,7 @@ namespace idocp {
 
 class ConstraintComponentBase {
  public:
-  enum Family { Position, Velocity, Torque, LinearFrictionCone, QuadraticFrictionCone };
+  enum Family { Position, Velocity, Torque, LinearFrictionCone, QuadraticFrictionCone, Acceleration };
   ConstraintComponentBase(Family f, bool upper, double barrier, double rate)
       : family(f), upper(upper), barrier(barrier), fraction_to_boundary_rate(rate) {}
   virtual ~ConstraintComponentBase() {}
@@ -25,6 +26,7 @@ class ConstraintComponentBase {
   bool upper;
   double barrier, fraction_to_boundary_rate;
   double mu = 0.0;
+  Eigen::VectorXd bound;      // JointAcceleration*Limit: amin / amax, one entry per actuated joint
 };
 
 #define IDOCP_LIMIT_CLASS(NAME, FAMILY, UPPER)                                                        \
@@ -40,6 +42,19 @@ IDOCP_LIMIT_CLASS(JointVelocityUpperLimit, Velocity, true);
 IDOCP_LIMIT_CLASS(JointTorquesLowerLimit, Torque, false);
 IDOCP_LIMIT_CLASS(JointTorquesUpperLimit, Torque, true);
 #undef IDOCP_LIMIT_CLASS
+
+// JointAccelerationLowerLimit / UpperLimit (src/constraints/joint_acceleration_{lower,upper}_limit.cpp): a.tail(dimc) >= amin resp.
+// <= amax with the bounds passed to the constructor (the robot model has none); each may be used on its own.
+class JointAccelerationLowerLimit final : public ConstraintComponentBase {
+ public:
+  JointAccelerationLowerLimit(const Robot&, const Eigen::VectorXd& amin, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(Acceleration, false, barrier, fraction_to_boundary_rate) { bound = amin; }
+};
+class JointAccelerationUpperLimit final : public ConstraintComponentBase {
+ public:
+  JointAccelerationUpperLimit(const Robot&, const Eigen::VectorXd& amax, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(Acceleration, true, barrier, fraction_to_boundary_rate) { bound = amax; }
+};
 
 // LinearizedFrictionCone (include/idocp/constraints/linearized_friction_cone.hpp:17-120,
 // src/constraints/linearized_friction_cone.cpp): five rows per active contact, evaluated in K5b.
@@ -109,6 +124,12 @@ class Constraints {
     if (c->family == ConstraintComponentBase::QuadraticFrictionCone) {
       if (!c->upper) c_.friction_cone = 1; else c_.impulse_friction_cone = 1;
       c_.mu = c->mu;
+      return;
+    }
+    if (c->family == ConstraintComponentBase::Acceleration) {
+      if (c->bound.size() > IDOCP_MAX_NV) { std::cerr << "invalid argument: too many acceleration bounds" << '\n'; std::exit(EXIT_FAILURE); }
+      (c->upper ? c_.joint_acceleration_upper_limit : c_.joint_acceleration_lower_limit) = 1;
+      for (int i = 0; i < c->bound.size(); ++i) (c->upper ? c_.a_max : c_.a_min)[i] = c->bound[i];
       return;
     }
     (c->upper ? hi_ : lo_)[c->family] = 1;

@@ -1,0 +1,3 @@
+// include-path compatibility with the reference (include/idocp/constraints/joint_acceleration_upper_limit.hpp); the component lives in
+// constraints.hpp.
+#include "idocp/constraints/constraints.hpp"

@@ -151,6 +151,10 @@ typedef struct idocp_constraints {
                                          * Exclusive with linearized_friction_cone */
   int impulse_friction_cone;            /* 0/1: ImpulseFrictionCone on impulse stages (src/constraints/impulse_friction_cone.cpp).
                                          * Exclusive with linearized_impulse_friction_cone */
+  int joint_acceleration_lower_limit;   /* 0/1: JointAccelerationLowerLimit, a.tail(dimu) >= a_min (src/constraints/joint_acceleration_lower_limit.cpp) */
+  int joint_acceleration_upper_limit;   /* 0/1: JointAccelerationUpperLimit, a.tail(dimu) <= a_max (src/constraints/joint_acceleration_upper_limit.cpp) */
+  double a_min[IDOCP_MAX_NV];           /* the components carry their own bounds (constructor argument amin / amax), one per actuated joint */
+  double a_max[IDOCP_MAX_NV];
 } idocp_constraints_t;
 
 /* ---- Robot ------------------------------------------------------------ */

@@ -227,6 +227,9 @@ bool OCPSolver::componentEnabled(int c, bool impulse) const {
   if (c < 2) return cons.joint_position_limits != 0;
   if (c < 4) return cons.joint_velocity_limits != 0;
   if (c < 6) return cons.joint_torque_limits != 0;
+  if (c == 7) return false;
+  if (c == 8) return cons.joint_acceleration_lower_limit != 0;       // acceleration level: every time stage (constraints_data.hpp:18-42)
+  if (c == 9) return cons.joint_acceleration_upper_limit != 0;
   return cons.linearized_friction_cone != 0 || cons.friction_cone != 0;
 }
 bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraints_data.hpp:18-42
@@ -236,10 +239,12 @@ bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraint
   if (c < 4) return nd.level >= 1;
   return true;
 }
-int OCPSolver::dimc() const { int n = 0; for (int c = 0; c < 7; ++c) if (componentEnabled(c, false)) n += componentDim(c); return n; }
+int OCPSolver::dimc() const { int n = 0; for (int c = 0; c < NCOMP; ++c) if (componentEnabled(c, false)) n += componentDim(c); return n; }
 
-static real limitOf(const RModel& m, int c, int k2) {
+static real limitOf(const RModel& m, const idocp_constraints_t& k, int c, int k2) {
   switch (c) {
+    case 8: return k.a_min[k2];       // JointAccelerationLowerLimit / UpperLimit carry their own bounds (joint_acceleration_*_limit.cpp:6-13)
+    case 9: return k.a_max[k2];
     case 0: return m.q_min[k2];
     case 1: return m.q_max[k2];
     case 2: return -m.v_max[k2];
@@ -252,6 +257,7 @@ static real limitOf(const RModel& m, int c, int k2) {
 static real limitedVar(const SplitSolutionC& s, int c, int k2, int nv, int nu) {
   if (c < 2) return s.q[s.q.size() - nu + k2];
   if (c < 4) return s.v[nv - nu + k2];
+  if (c >= 8) return s.a[nv - nu + k2];
   return s.u[k2];
 }
 // The friction-cone component of one contact with force f: values g_r(f) <= 0 and gradients J_r(f) of its rows.
@@ -281,13 +287,13 @@ ConeEval coneEval(int kind, real mu, const Mat& f) {
 void OCPSolver::initNodeConstraints(const NodeC& nd) {
   const SplitSolutionC& sp = s[nd.slot];
   ipm[nd.slot].clear();
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < NCOMP; ++c) {
     IpmData data(componentDim(c, nd.kind == NodeC::Impulse));
     const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     if (componentValid(c, nd)) {
-      if (c < 6) {
+      if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
-        for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(sp, c, r, nv_, nu_) - limitOf(robot.model(), c, r));
+        for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(sp, c, r, nv_, nu_) - limitOf(robot.model(), cons, c, r));
       } else {
         for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
           const ConeEval ce = coneEval(CK, cons.mu, sp.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
@@ -400,17 +406,17 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     }
   }
   // ---- constraints: [computePrimalAndDualResidual] + augmentDualResidual
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < NCOMP; ++c) {
     if (!componentValid(c, nd)) continue;
     const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[nd.slot][c];
-    if (c < 6) {
+    if (jointComp(c)) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
-      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
+      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : (c < 6 ? R.lu : R.la));
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
         if (residual_only) {
-          data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), c, r)) + data.slack[r];
+          data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), cons, c, r)) + data.slack[r];
           data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         }
         l[off + r] += sgn * dt * data.dual[r];
@@ -531,20 +537,21 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += dt * wf[c][r]; st += 3; }
   }
   // ---- Constraints::condenseSlackAndDual
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < NCOMP; ++c) {
     if (!componentValid(c, nd)) continue;
     const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[nd.slot][c];
-    if (c < 6) {
+    if (jointComp(c)) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
-      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
+      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : (c < 6 ? R.lu : R.la));
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
         const real h = dt * data.dual[r] / data.slack[r];
         if (c < 2) M.Qxx(kP + r, kP + r) += h;
         else if (c < 4) M.Qxx(nv + kP + r, nv + kP + r) += h;
-        else M.Quu_full(kP + r, kP + r) += h;
-        data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), c, r)) + data.slack[r];
+        else if (c < 6) M.Quu_full(kP + r, kP + r) += h;
+        else M.Qaa_diag[kP + r] += h;
+        data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), cons, c, r)) + data.slack[r];
         data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         l[off + r] += sgn * dt * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
       }
@@ -679,11 +686,11 @@ int OCPSolver::isCurrentSolutionFeasible() const {
       const auto& nd = chain[p];
       if (!(nd.kind == kind)) continue;
       const SplitSolutionC& si = s[nd.slot];
-      for (int c = 0; c < 6; ++c) {
-        if (!componentValid(c, nd)) continue;
+      for (int c = 0; c < NCOMP; ++c) {
+        if (!jointComp(c) || !componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
         for (int r = 0; r < nu_; ++r) {
-          const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
+          const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), cons, c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
       }
@@ -707,7 +714,7 @@ real OCPSolver::KKTError() {
     real e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
                R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt * dt * cd[nd.slot].IDC.squaredNorm();
     real c2 = 0;
-    for (int c = 0; c < 7; ++c) if (componentValid(c, nd)) c2 += ipm[nd.slot][c].residual.squaredNorm() + ipm[nd.slot][c].duality.squaredNorm();
+    for (int c = 0; c < NCOMP; ++c) if (componentValid(c, nd)) c2 += ipm[nd.slot][c].residual.squaredNorm() + ipm[nd.slot][c].duality.squaredNorm();
     sum += e + dt * dt * c2 + R.P.squaredNorm();
   }
   const SplitKKTResidualC& RN = kkt_residual[chain.back().slot];
@@ -918,14 +925,14 @@ void OCPSolver::computeDirection() {
     // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145)
     if (nd.sw_event >= 0) d[sl].dxi = sw[sl].M * dx + sw[sl].m; else d[sl].dxi = Mat(0);
     // Constraints::computeSlackAndDualDirection + step sizes
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < NCOMP; ++c) {
       if (!componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       IpmData& data = ipm[sl][c];
-      if (c < 6) {
+      if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r2 = 0; r2 < nu; ++r2) {
-          const real dxr = c < 2 ? d[sl].dq[kP + r2] : (c < 4 ? d[sl].dv[kP + r2] : d[sl].du[r2]);
+          const real dxr = c < 2 ? d[sl].dq[kP + r2] : (c < 4 ? d[sl].dv[kP + r2] : (c < 6 ? d[sl].du[r2] : d[sl].daf[kP + r2]));
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
@@ -1007,7 +1014,7 @@ void OCPSolver::integrateSolution() {
       st += 3;
     }
     if (nd.sw_event >= 0) for (int r = 0; r < d[sl].dxi.size(); ++r) si.xi[r] += ap * d[sl].dxi[r];
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < NCOMP; ++c) {
       if (!componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       ipm[sl][c].slack += ap * ipm[sl][c].dslack;
@@ -1092,14 +1099,14 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
     if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) l += wf[c][k2] * (x.f[c][k2] - rf[c][k2]) * (x.f[c][k2] - rf[c][k2]);
     real barrier = 0, primal = 0;
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < NCOMP; ++c) {
       if (!componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       const IpmData& data = ipm[sl][c];
       for (int r = 0; r < data.slack.size(); ++r) barrier -= cons.barrier * std::log(data.slack[r] + alpha * data.dslack[r]);      // pdipm.hxx:84-87
-      if (c < 6) {
+      if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
-        for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), c, r)) + data.slack[r]);
+        for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), cons, c, r)) + data.slack[r]);
       } else {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           const ConeEval ce = coneEval(CK, cons.mu, x.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
@@ -1357,6 +1364,9 @@ bool ParNMPCSolver::componentValid(int c, const PNode& nd) const {     // constr
   if (c < 2) return cons.joint_position_limits != 0 && nd.level >= 2;
   if (c < 4) return cons.joint_velocity_limits != 0 && nd.level >= 1;
   if (c < 6) return cons.joint_torque_limits != 0;
+  if (c == 7) return false;
+  if (c == 8) return cons.joint_acceleration_lower_limit != 0;
+  if (c == 9) return cons.joint_acceleration_upper_limit != 0;
   return cons.linearized_friction_cone != 0 || cons.friction_cone != 0;
 }
 
@@ -1389,13 +1399,13 @@ void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
   const int i = nd.slot;
   const ContactStatus& cs = nodeContacts(nd);
   ipm[i].clear();
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < NCOMP; ++c) {
     IpmData data(componentDim(c, nd.kind == NodeC::Impulse));
     const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     if (componentValid(c, nd)) {
-      if (c < 6) {
+      if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
-        for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), c, r));
+        for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), cons, c, r));
       } else {
         for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:100-108)
           const ConeEval ce = coneEval(CK, cons.mu, s[i].f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
@@ -1475,17 +1485,17 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   }
   // ---- constraints
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < NCOMP; ++c) {
     if (!componentValid(c, nd)) continue;
     const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[i][c];
-    if (c < 6) {
+    if (jointComp(c)) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
-      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
+      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : (c < 6 ? R.lu : R.la));
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
         if (residual_only) {
-          data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), c, r)) + data.slack[r];
+          data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), cons, c, r)) + data.slack[r];
           data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         }
         l[off + r] += sgn * dt * data.dual[r];
@@ -1586,20 +1596,21 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     }
   }
   // ---- Constraints::condenseSlackAndDual
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < NCOMP; ++c) {
     if (!componentValid(c, nd)) continue;
     const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
     IpmData& data = ipm[i][c];
-    if (c < 6) {
+    if (jointComp(c)) {
       const real sgn = (c & 1) ? 1.0 : -1.0;
-      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : R.lu);
+      Mat& l = c < 2 ? R.lq : (c < 4 ? R.lv : (c < 6 ? R.lu : R.la));
       const int off = l.size() - nu;
       for (int r = 0; r < nu; ++r) {
         const real h = dt * data.dual[r] / data.slack[r];
         if (c < 2) M.Qxx(kP + r, kP + r) += h;
         else if (c < 4) M.Qxx(nv + kP + r, nv + kP + r) += h;
-        else M.Quu_full(kP + r, kP + r) += h;
-        data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), c, r)) + data.slack[r];
+        else if (c < 6) M.Quu_full(kP + r, kP + r) += h;
+        else M.Qaa_diag[kP + r] += h;
+        data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), cons, c, r)) + data.slack[r];
         data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         l[off + r] += sgn * dt * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
       }
@@ -2036,14 +2047,14 @@ void ParNMPCSolver::forwardCorrectionParallel() {
     d[i].daf += D.MJtJinv.block(0, kP, nv + dimf, nu) * d[i].du;
     d[i].daf -= D.MJtJinv_IDC;
     for (int r2 = 0; r2 < dimf; ++r2) d[i].daf[nv + r2] *= -1;
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < NCOMP; ++c) {
       if (!componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       IpmData& data = ipm[i][c];
-      if (c < 6) {
+      if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r2 = 0; r2 < nu; ++r2) {
-          const real dxr = c < 2 ? d[i].dq[kP + r2] : (c < 4 ? d[i].dv[kP + r2] : d[i].du[r2]);
+          const real dxr = c < 2 ? d[i].dq[kP + r2] : (c < 4 ? d[i].dv[kP + r2] : (c < 6 ? d[i].du[r2] : d[i].daf[kP + r2]));
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
@@ -2105,7 +2116,7 @@ void ParNMPCSolver::integrateSolution() {
       for (int r = 0; r < 3; ++r) { si.f[c][r] += ap * d[i].daf[nv + st + r]; si.mu[c][r] += ap * d[i].dbetamu[nv + st + r]; }
       st += 3;
     }
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < NCOMP; ++c) {
       if (!componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
       ipm[i][c].slack += ap * ipm[i][c].dslack;
@@ -2186,14 +2197,14 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       l += w * (x.f[c][k2] - fr) * (x.f[c][k2] - fr);
     }
     real barrier = 0, primal = 0;
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < NCOMP; ++c) {
       if (!componentValid(c, nd)) continue;
       const int CK = coneKind(impulse), CR = coneRows(impulse);
       const IpmData& data = ipm[sl][c];
       for (int r = 0; r < data.slack.size(); ++r) barrier -= cons.barrier * std::log(data.slack[r] + alpha * data.dslack[r]);      // pdipm.hxx:84-87
-      if (c < 6) {
+      if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
-        for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), c, r)) + data.slack[r]);
+        for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), cons, c, r)) + data.slack[r]);
       } else {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           const ConeEval ce = coneEval(CK, cons.mu, x.f[cc]);
@@ -2257,11 +2268,11 @@ int ParNMPCSolver::isCurrentSolutionFeasible() const {
       const auto& nd = chain[p];
       if (!(nd.kind == kind || (kind == NodeC::Stage && nd.kind == NodeC::Terminal))) continue;
       const SplitSolutionC& si = s[nd.slot];
-      for (int c = 0; c < 6; ++c) {
-        if (!componentValid(c, nd)) continue;
+      for (int c = 0; c < NCOMP; ++c) {
+        if (!jointComp(c) || !componentValid(c, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
         for (int r = 0; r < nu_; ++r) {
-          const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), c, r);
+          const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), cons, c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
       }
@@ -2292,7 +2303,7 @@ real ParNMPCSolver::KKTErrorSquared() {
       if (nd.kind == NodeC::Aux) e += R.P.squaredNorm();
     }
     real c2 = 0;
-    for (int c = 0; c < 7; ++c) if (componentValid(c, nd)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
+    for (int c = 0; c < NCOMP; ++c) if (componentValid(c, nd)) c2 += ipm[i][c].residual.squaredNorm() + ipm[i][c].duality.squaredNorm();
     sum += e + c2;
   }
   return sum;

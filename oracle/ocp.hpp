@@ -81,6 +81,10 @@ struct SplitDirectionC {
 struct ConeEval { int nr; real res[5]; real J[5][3]; };
 ConeEval coneEval(int kind, real mu, const Mat& f);
 
+// IPM components: 0/1 joint position lower/upper, 2/3 velocity, 4/5 torque, 6 (linearized) friction cone, 7 unused, 8/9 joint
+// acceleration lower/upper; odd = upper bound (sign +1)
+constexpr int NCOMP = 10;
+inline bool jointComp(int c) { return c < 6 || c >= 8; }
 struct IpmData {                  // ConstraintComponentData
   Mat slack, dual, residual, duality, dslack, ddual;
   explicit IpmData(int n = 0) : slack(n), dual(n), residual(n), duality(n), dslack(n), ddual(n) {}
@@ -178,7 +182,7 @@ class OCPSolver {
   // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone (impulse cone on impulse stages)
   bool componentEnabled(int c, bool impulse) const;
   bool componentValid(int c, const NodeC& nd) const;
-  int componentDim(int c, bool impulse = false) const { return c < 6 ? nu_ : coneRows(impulse) * nc_; }
+  int componentDim(int c, bool impulse = false) const { return jointComp(c) ? nu_ : (c == 6 ? coneRows(impulse) * nc_ : 0); }
   int coneKind(bool impulse) const { return (impulse ? cons.impulse_friction_cone : cons.friction_cone) ? 1 : 0; }
   int coneRows(bool impulse) const { return coneKind(impulse) == 1 ? 2 : 5; }
   void initNodeConstraints(const NodeC& nd);
@@ -297,7 +301,7 @@ class ParNMPCSolver {
   real disc_t_ = 0;
   bool discretized_ = false;
   bool componentValid(int c, const PNode& nd) const;
-  int componentDim(int c, bool impulse = false) const { return c < 6 ? nu_ : coneRows(impulse) * nc_; }
+  int componentDim(int c, bool impulse = false) const { return jointComp(c) ? nu_ : (c == 6 ? coneRows(impulse) * nc_ : 0); }
   int coneKind(bool impulse) const { return (impulse ? cons.impulse_friction_cone : cons.friction_cone) ? 1 : 0; }
   int coneRows(bool impulse) const { return coneKind(impulse) == 1 ? 2 : 5; }
   void qRef(real t, Mat& q_ref) const;

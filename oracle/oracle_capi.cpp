@@ -701,11 +701,12 @@ int oracle_ocp_get_constraint_data(void* h, double* slack, double* dual) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   const int dimc = s->dimc();
   const idocp_constraints_t& c = s->cons;
-  const int en[7] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits,
-                     c.joint_torque_limits, c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone};
+  const int en[NCOMP] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits,
+                         c.joint_torque_limits, c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone, 0,
+                         c.joint_acceleration_lower_limit, c.joint_acceleration_upper_limit};
   for (int i = 0; i < s->N(); ++i) {
     int off = 0;
-    for (int comp = 0; comp < 7; ++comp) {
+    for (int comp = 0; comp < NCOMP; ++comp) {
       if (!en[comp]) continue;
       const IpmData& data = s->ipm[i][comp];
       const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
