@@ -878,12 +878,12 @@ static int setSolutionO(idocp_ocp_t* h, const char* name, const double* values, 
 int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value) { return setSolutionO(h, name, value, 0); }
 
 // Warm start of an MPC loop: a field of every grid stage (slots 0 .. nstages - 1), the same for all instances.
-static int fillStagesO(idocp_ocp_t* h, double* rec, int stride, int offset, int dim, int nstages, const double* values) {
+static int fillStagesO(idocp_ocp_t* h, double* rec, int stride, int offset, int dim, int nstages, const double* values, bool chain = false) {
   double* d_vals = nullptr;
   const size_t bytes = (size_t)nstages * dim * sizeof(double);
   HIP_TRY(hipMalloc((void**)&d_vals, bytes));
   hipError_t e = hipMemcpyAsync(d_vals, values, bytes, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) { ocpFillStages(rec, stride, offset, dim, h->NS, nstages, h->batch, d_vals, h->stream); e = hipStreamSynchronize(h->stream); }
+  if (e == hipSuccess) { ocpFillStages(rec, stride, offset, dim, h->NS, nstages, h->batch, d_vals, h->stream, chain ? h->d_nodes : nullptr); e = hipStreamSynchronize(h->stream); }
   (void)hipFree(d_vals);
   HIP_TRY(e);
   return IDOCP_OK;
@@ -902,6 +902,26 @@ int idocp_parnmpc_set_aux_mat(idocp_ocp_t* h, int nstages, const double* values)
   if (nstages <= 0 || nstages > h->N) { set_last_error("idocp_parnmpc_set_aux_mat: nstages out of range"); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
   return fillStagesO(h, h->B.aux, LQ::AUX, 0, DQ::NX * DQ::NX, nstages, values);
+}
+// warm start along the CHAIN of the current discretisation (event stages included): values[M][dim] in the order of idocp_ocp_get_chain
+static int chainLength(idocp_ocp_t* h, int M) {
+  if (h->chain.empty()) { set_last_error("no chain yet: discretise first (initConstraints / initBackwardCorrection / updateSolution)"); return IDOCP_E_ARG; }
+  if (M <= 0 || M > h->M()) { set_last_error("chain setter: M out of range"); return IDOCP_E_ARG; }
+  return IDOCP_OK;
+}
+int idocp_ocp_set_solution_chain(idocp_ocp_t* h, const char* name, int M, const double* values) {
+  if (!h || !name || !values) return IDOCP_E_ARG;
+  Field f;
+  if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = chainLength(h, M))) return rc;
+  return fillStagesO(h, h->B.sol, LQ::SOL, f.offset, f.dim, M, values, true);
+}
+int idocp_parnmpc_set_aux_mat_chain(idocp_ocp_t* h, int M, const double* values) {
+  if (!h || !values || !h->parnmpc) { set_last_error("idocp_parnmpc_set_aux_mat_chain: not a ParNMPC handle"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = chainLength(h, M))) return rc;
+  return fillStagesO(h, h->B.aux, LQ::AUX, 0, DQ::NX * DQ::NX, M, values, true);
 }
 int idocp_ocp_set_solution_batch(idocp_ocp_t* h, const char* name, const double* values) { return setSolutionO(h, name, values, 1); }
 

@@ -572,18 +572,20 @@ __global__ void ocp_fill_field_kernel(double* __restrict__ sol, int stride, int 
 }
 
 // warm start: values[nstages][dim] -> field `offset` of the records of slots 0 .. nstages-1 of every instance
+// (nodes != nullptr: values[nstages][dim] in CHAIN order, entry p goes to the slot of chain position p)
 __global__ void ocp_fill_stages_kernel(double* __restrict__ rec, int stride, int offset, int dim, long NS, int nstages, long batch,
-                                       const double* __restrict__ values) {
+                                       const double* __restrict__ values, const OcpNode* __restrict__ nodes) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per = (long)nstages * dim;
   if (idx >= batch * per) return;
   const long b = idx / per;
   const int rem = (int)(idx - b * per), i = rem / dim, e = rem - i * dim;
-  rec[(b * NS + i) * stride + offset + e] = values[rem];
+  rec[(b * NS + (nodes ? nodes[i].slot : i)) * stride + offset + e] = values[rem];
 }
-void ocpFillStages(double* rec, int stride, int offset, int dim, long NS, int nstages, long batch, const double* values, hipStream_t st) {
+void ocpFillStages(double* rec, int stride, int offset, int dim, long NS, int nstages, long batch, const double* values, hipStream_t st,
+                   const OcpNode* nodes) {
   const long total = batch * nstages * dim;
-  hipLaunchKernelGGL(ocp_fill_stages_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, stride, offset, dim, NS, nstages, batch, values);
+  hipLaunchKernelGGL(ocp_fill_stages_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, stride, offset, dim, NS, nstages, batch, values, nodes);
 }
 
 template <typename D>

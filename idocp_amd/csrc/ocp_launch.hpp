@@ -42,7 +42,8 @@ struct OcpLaunch {
 };
 
 void ocpKktErrorReduce(const OcpBuffers& B, long batch, hipStream_t st, double* squared_out = nullptr);
-void ocpFillStages(double* rec, int stride, int offset, int dim, long NS, int nstages, long batch, const double* values, hipStream_t st);
+void ocpFillStages(double* rec, int stride, int offset, int dim, long NS, int nstages, long batch, const double* values, hipStream_t st,
+                   const OcpNode* nodes = nullptr);
 void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_inst, long batch, const double* value,
                   int per_instance, int repeat, hipStream_t st);
 

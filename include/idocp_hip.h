@@ -383,6 +383,12 @@ int idocp_ocp_pop_front_contact_status(idocp_ocp_t* h);
  * entries, any may be NULL: kind (0 stage, 1 impulse, 2 aux, 3 lift, 4 terminal), index
  * (grid stage / impulse index / lift index), storage slot, time step, dimf, rows of the
  * switching constraint carried by the stage. */
+/* Warm start along the chain of the current discretisation (event stages included): values[M][dim] in the order of
+ * idocp_ocp_get_chain, written to every instance.  (The grid-stage setters idocp_ocp_set_solution_stages /
+ * idocp_parnmpc_set_aux_mat cannot reach the impulse / aux / lift slots; this is what an MPC loop that shifts a solution with
+ * discrete events along the horizon needs -- the reference does it through the public members of its Solution container.) */
+int idocp_ocp_set_solution_chain(idocp_ocp_t* h, const char* name, int M, const double* values);
+int idocp_parnmpc_set_aux_mat_chain(idocp_ocp_t* h, int M, const double* values);
 int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot,
                         double* dt, int* dimf, int* sw_dimi);
 /* OCPSolver::setSolution (ocp_solver.cpp:95-165): name in {"q","v","a","f","u"};

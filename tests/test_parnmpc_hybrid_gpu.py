@@ -253,3 +253,21 @@ def test_filter_line_search_on_a_chain_with_events(events, initial):
         ag, bg = g.step_sizes()
         assert abs(ag[0] - ao) < 1e-9 and abs(bg[0] - bo) < 1e-8, (it, ag[0], ao)
         compare(o, g, M, ("q", "v", "a", "u", "f"), 1e-7, "iterate %d" % it)
+
+
+def test_chain_warm_start_setters_reach_the_event_stages():
+    """idocp_ocp_set_solution_chain / idocp_parnmpc_set_aux_mat_chain: values in chain order land in the slots of the aux / impulse /
+    lift stages too (the grid-stage setters cannot address them) and come back through the chain getters, for every instance."""
+    from helpers import P
+    m, o, g, q, v = make_pair(20, 1.0, LIFT_TOUCH, batch=2)
+    M = check_chain(o, g)
+    rng = np.random.default_rng(0)
+    for name, dim in (("v", m.nv), ("lmd", m.nv), ("f", 12), ("u", 12)):
+        vals = np.ascontiguousarray(rng.uniform(-1, 1, (M, dim)))
+        assert g.lib.idocp_ocp_set_solution_chain(g.h, name.encode(), M, P(vals)) == 0
+        for inst in (0, 1):
+            assert np.array_equal(g.get_chain(name, M + 1, instance=inst)[:M], vals), name
+    aux = np.ascontiguousarray(rng.uniform(-1, 1, (M, 36, 36)))
+    assert g.lib.idocp_parnmpc_set_aux_mat_chain(g.h, M, P(aux)) == 0
+    assert g.lib.idocp_parnmpc_set_aux_mat_chain(g.h, M + 5, P(aux)) != 0           # longer than the chain
+    assert g.lib.idocp_ocp_set_solution_chain(g.h, b"nonsense", M, P(aux)) != 0
