@@ -74,6 +74,7 @@ class Constraints(C.Structure):
         ("friction_cone", C.c_int), ("impulse_friction_cone", C.c_int),
         ("joint_acceleration_lower_limit", C.c_int), ("joint_acceleration_upper_limit", C.c_int),
         ("a_min", C.c_double * MAX_NV), ("a_max", C.c_double * MAX_NV),
+        ("contact_distance", C.c_int),
     ]
 
 

@@ -130,6 +130,7 @@ struct idocp_ocp {
   // filter line search (LineSearchFilter, src/line_search/line_search_filter.cpp): one filter per instance
   std::vector<std::vector<std::pair<double, double>>> filters;
   OcpNode* d_nodes_ls = nullptr;
+  double* ext_try = nullptr;
 };
 
 namespace {
@@ -628,6 +629,11 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &B.err_stage, ns))) return fail(rc);
   if ((rc = allocBufO(h, &B.err, (size_t)batch))) return fail(rc);
   if ((rc = allocBufO(h, &B.sol_try, ns * LQ::SOL))) return fail(rc);
+  B.ext = nullptr; h->ext_try = nullptr;
+  if (constraints->contact_distance) {                     // terms with frame Jacobians of their own (ocp_ext_kernel.hip), of the iterate and of the line search's trial iterate
+    if ((rc = allocBufO(h, &B.ext, ns * LQ::EXT))) return fail(rc);
+    if ((rc = allocBufO(h, &h->ext_try, ns * LQ::EXT))) return fail(rc);
+  }
   if ((rc = allocBufO(h, &B.merit_stage, ns * 4))) return fail(rc);
   if ((rc = allocBufO(h, &B.merit, (size_t)batch * 2))) return fail(rc);
   if ((rc = allocBufO(h, &B.ls_alpha, (size_t)batch))) return fail(rc);
@@ -695,6 +701,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   p.use_q_limits = constraints->joint_position_limits; p.use_v_limits = constraints->joint_velocity_limits;
   p.use_u_limits = constraints->joint_torque_limits;
   p.use_a_lower = constraints->joint_acceleration_lower_limit ? 1 : 0;
+  p.use_contact_distance = constraints->contact_distance ? 1 : 0;
   p.use_a_upper = constraints->joint_acceleration_upper_limit ? 1 : 0;
   for (int r = 0; r < IDOCP_MAX_NV; ++r) { p.a_min[r] = constraints->a_min[r]; p.a_max[r] = constraints->a_max[r]; }
   p.use_friction_cone = (constraints->linearized_friction_cone || constraints->friction_cone) ? 1 : 0;
@@ -930,6 +937,7 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
   int rc = setDev(h); if (rc) return rc;
   if ((rc = discretize(h, t))) return rc;                 // ocp_solver.cpp:60-64
   OcpLaunch<DQ>::initConstraints(h->B, h->batch, h->NS, h->stream);
+  OcpLaunch<DQ>::extInit(h->B, h->batch, h->NS, h->stream);      // ContactDistance rows
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
@@ -1032,6 +1040,7 @@ static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, con
   OcpLaunch<DQ>::trialIterate(h->B, h->batch, M, h->stream);
   OcpBuffers Bt = h->B;
   Bt.sol = h->B.sol_try;
+  Bt.ext = h->ext_try;                              // (the trial iterate's heights / rows; the expansion kernels keep reading the linearisation's)
   if (h->parnmpc) {
     // ParNMPC: backward-Euler stages against the trial predecessor (the measured state in front of the first element of the chain);
     // aux stages add the l1 norm of their switching constraint (K5s on the trial iterate), impulse stages have a kernel of their own
@@ -1308,6 +1317,11 @@ int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* w
           const double a = s[LQ::S_A + DQ::NV - nu + r];
           if ((P.use_a_lower && a < P.a_min[r]) || (P.use_a_upper && a > P.a_max[r])) return false;
         }
+      if (P.use_contact_distance && nd.level >= 2 && nd.kind != 4) {   // contact_distance.cpp:44-55: the frames of the contacts that are not active
+        double pts[DQ::NC * 3];
+        idocp_model_contact_positions(&h->model, s + LQ::S_Q, pts);
+        for (int c = 0; c < DQ::NC; ++c) if (!nd.active[c] && pts[3 * c + 2] <= 0) return false;
+      }
       if (!P.use_friction_cone) return true;
     }
     const int ck = nd.kind == 1 ? P.impulse_cone_kind : P.cone_kind;
@@ -1337,7 +1351,7 @@ int idocp_ocp_dimc(const idocp_ocp_t* h) {
   const idocp_constraints_t& c = h->cons;
   return 2 * DQ::NU * ((c.joint_position_limits ? 1 : 0) + (c.joint_velocity_limits ? 1 : 0) + (c.joint_torque_limits ? 1 : 0)) +
          (c.linearized_friction_cone ? 5 * DQ::NC : 0) + (c.friction_cone ? 2 * DQ::NC : 0) +
-         DQ::NU * ((c.joint_acceleration_lower_limit ? 1 : 0) + (c.joint_acceleration_upper_limit ? 1 : 0));
+         DQ::NU * ((c.joint_acceleration_lower_limit ? 1 : 0) + (c.joint_acceleration_upper_limit ? 1 : 0)) + (c.contact_distance ? DQ::NC : 0);
 }
 
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual) {
@@ -1349,18 +1363,19 @@ int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, d
   HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * h->NS * LQ::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const idocp_constraints_t& c = h->cons;
-  // components in the order 0 .. 5 joint position / velocity / torque (lower, upper), 6 cone, 8 / 9 joint acceleration lower / upper
-  const int use[10] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits, c.joint_torque_limits,
-                       c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone, 0, c.joint_acceleration_lower_limit, c.joint_acceleration_upper_limit};
+  // components in the order 0 .. 5 joint position / velocity / torque (lower, upper), 6 cone, 8 / 9 joint acceleration lower / upper, 10 contact distance
+  const int use[11] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits, c.joint_torque_limits,
+                       c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone, 0, c.joint_acceleration_lower_limit, c.joint_acceleration_upper_limit,
+                       c.contact_distance};
   const int cr = coneRows(h->prob.cone_kind);        // rows per contact of the cone in use (the records keep five slots per contact)
   for (int i = 0; i < N; ++i) {
     int off = 0;
-    for (int comp = 0; comp < 10; ++comp) {
+    for (int comp = 0; comp < 11; ++comp) {
       if (!use[comp]) continue;
-      const int n = comp != 6 ? DQ::NU : cr * DQ::NC;
-      const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
+      const int n = comp == 10 ? DQ::NC : (comp != 6 ? DQ::NU : cr * DQ::NC);
+      const bool valid = (comp < 2 || comp == 10) ? i >= 2 : (comp < 4 ? i >= 1 : true);
       for (int r = 0; r < n; ++r) {
-        const int src = comp != 6 ? ipmCompRow<LQ>(comp) + r : LQ::C_FRIC + 5 * (r / cr) + r % cr;
+        const int src = comp == 10 ? LQ::C_CD + r : (comp != 6 ? ipmCompRow<LQ>(comp) + r : LQ::C_FRIC + 5 * (r / cr) + r % cr);
         if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * LQ::CON + src] : 0.0;
         if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * LQ::CON + src] : 0.0;
       }

@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       }
     }
     // the multipliers of [ID; C] are added in C2; bm = [beta ; mu_stack] for them
+    if (B.ext) lq += B.ext[rec * L::EXT + L::X_LQ + r];      // terms with frame Jacobians of their own (ocp_ext_kernel.hip; ContactDistance)
     sm[S::LQ + r] = lq; sm[S::LV + r] = lv; sm[S::LA + r] = la; sm[S::QAA + r] = ha;
     sm[S::BM + r] = s[L::S_BETA + r];
     if (!RESIDUAL) { sm[S::HQD + r] = hq; sm[S::HVD + r] = hv; }
@@ -539,7 +540,12 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     __syncthreads();                                                   // ERR aliases the scratch
     sm[S::ERR + tid] = merit_cost; sm[S::ERR + nt + tid] = merit_viol;
     __syncthreads();
-    if (tid < 2) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + nt * tid + t]; B.merit_stage[rec * 4 + tid] = e; }
+    if (tid < 2) {
+      double e = 0.0;
+      for (int t = 0; t < nt; ++t) e += sm[S::ERR + nt * tid + t];
+      if (tid == 1 && B.ext) e += B.ext[rec * L::EXT + L::X_VIOL];
+      B.merit_stage[rec * 4 + tid] = e;
+    }
     return;
   }
   STAMP(5);
@@ -581,7 +587,12 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     __syncthreads();                                                   // ERR aliases the scratch
     sm[S::ERR + tid] = err_local + (BWD ? 1.0 : dt * dt) * err_ipm;      // split_parnmpc.hxx:263 does not weight by dt^2
     __syncthreads();
-    if (tid == 0) { double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t]; B.err_stage[rec] = e; }
+    if (tid == 0) {
+      double e = 0.0;
+      for (int t = 0; t < nt; ++t) e += sm[S::ERR + t];
+      if (B.ext) e += (BWD ? 1.0 : dt * dt) * B.ext[rec * L::EXT + L::X_ERR];
+      B.err_stage[rec] = e;
+    }
     return;
   }
   // ---- stage 3: finish the q / v columns; assemble MJtJinv = [Minv - TR BL, TR; TR^T, -SM], TR = BL^T SM ----
@@ -916,9 +927,11 @@ static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, con
   }
   const unsigned blocks = (unsigned)(batch * M);
   OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
+  OcpLaunch<D>::extRows(B, batch, M, residual, st);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
   else if (dimf == D::NF) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0); }
   else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0); }
+  if (!residual) OcpLaunch<D>::extHessian(B, batch, M, st);
 }
 
 template <typename D>
@@ -945,10 +958,12 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
   OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
+  OcpLaunch<D>::extRows(B, batch, M, false, st);
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
   if (n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
+  OcpLaunch<D>::extHessian(B, batch, M, st);
 }
 // Line search: cost and l1 violation of every stage of the chain for the iterate Btry.sol points at (Btry.nodes: the chain with the
 // reference's pairing of the successors).  The caller has run the impulse RNEA and the switching kernel on Btry.
@@ -962,6 +977,7 @@ void OcpLaunch<D>::merit(const OcpBuffers& Btry, long batch, int M, const double
   }
   const unsigned blocks = (unsigned)(batch * M);
   OcpLaunch<D>::nominal(Btry, batch, M, st, q0);
+  OcpLaunch<D>::extRows(Btry, batch, M, true, st);
   hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, false, true>), dim3(blocks), dim3(256), smem, st, Btry, q0);
 }
 // The same for ParNMPC (backward-Euler stages; event-free horizons): Split / TerminalParNMPC::stageCost and constraintViolation
@@ -977,6 +993,7 @@ void OcpLaunch<D>::meritBackwardEuler(const OcpBuffers& Btry, long batch, int M,
   const unsigned stages = (unsigned)(batch * (M - 1));
   hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, Btry, q0);
   OcpLaunch<D>::nominal(Btry, batch, M, st);
+  OcpLaunch<D>::extRows(Btry, batch, M, true, st);
   hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, Btry, q0, v0);
 }
 template <typename D>
@@ -998,8 +1015,10 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
   const unsigned stages = (unsigned)(batch * (M - 1));
   hipLaunchKernelGGL((parnmpc_lie_kernel<D>), dim3((stages + 63) / 64, 3), dim3(64), 0, st, B, q0);
   OcpLaunch<D>::nominal(B, batch, M, st);
+  OcpLaunch<D>::extRows(B, batch, M, residual, st);
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0);
   else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true, false, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, true>), dim3((unsigned)(batch * M)), dim3(256), smem, st, B, q0, v0); }
+  if (!residual) OcpLaunch<D>::extHessian(B, batch, M, st);
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);

@@ -35,7 +35,7 @@ struct OcpLayout {
   static constexpr int DIR = roundUp16(D_W + NVF);
   // IPM rows: 6 joint-limit components x NU (position / velocity / torque, lower then upper), 5 friction-cone rows per contact, then the
   // joint-acceleration limits (components 8 = lower, 9 = upper; component 6 is the cone, 7 is not used: odd components are upper bounds)
-  static constexpr int C_FRIC = 6 * NU, C_ACC = C_FRIC + 5 * NC, NCON = C_ACC + 2 * NU;
+  static constexpr int C_FRIC = 6 * NU, C_ACC = C_FRIC + 5 * NC, C_CD = C_ACC + 2 * NU, NCON = C_CD + NC;      // C_CD: ContactDistance, one row per contact
   static constexpr int CON = roundUp16(NCON);
   // linearisation record written by the tangent-RNEA kernel: [dID;dC]/d(q,v) (NVF x NX, ld NVF),
   // dID/da = M (NV x NV), dC/da = J (NF x NV, ld NF), [ID; C]
@@ -71,6 +71,10 @@ struct OcpLayout {
                        O_IDC = O_BN + (NC + 1) * 6;
   static constexpr int NOM = roundUp16(O_IDC + NVF);
   static_assert(NVF % 2 == 0, "the nominal record is copied in 16-byte pieces");
+  // ext record (ocp_ext_kernel.hip; allocated only when a term of it is in use): the ContactDistance rows J_c (NC x NV, row-major), the
+  // heights z_c, the gradient term to be added to lq, the Hessian weights, the stage's share of the KKT error / line-search violation
+  static constexpr int X_CDJ = 0, X_Z = NC * NV, X_LQ = X_Z + NC, X_W = X_LQ + NV, X_ERR = X_W + NC, X_VIOL = X_ERR + 1;
+  static constexpr int EXT = roundUp16(X_VIOL + 1);
   static constexpr int G_K = 0, G_k = NU * NX;
   static constexpr int GAIN = roundUp16(G_k + NU);
   // switching-constraint record of a stage two steps ahead of an impulse (SplitStateConstraintJacobian +
@@ -174,6 +178,7 @@ struct OcpProblem {
   double qi_weight[IDOCP_MAX_NV], vi_weight[IDOCP_MAX_NV], dvi_weight[IDOCP_MAX_NV];         // impulse stages
   double fi_weight[IDOCP_MAX_CONTACTS][3], fi_ref[IDOCP_MAX_CONTACTS][3];
   int use_q_limits, use_v_limits, use_u_limits, use_friction_cone, use_impulse_friction_cone;
+  int use_contact_distance;             // ContactDistance rows (ext record)
   int use_a_lower, use_a_upper;         // JointAccelerationLowerLimit / UpperLimit (acceleration level: every stage with torques)
   double a_min[IDOCP_MAX_NV], a_max[IDOCP_MAX_NV];
   int cone_kind, impulse_cone_kind;     // 0: Linearized(Impulse)FrictionCone (5 rows per contact), 1: (Impulse)FrictionCone (2 rows); coneRow below
@@ -203,6 +208,7 @@ struct OcpBuffers {
   double* lin;           // [batch][NS][LIN]
   double* lie;           // [batch][NS][LIE]
   double* nom;           // [batch][NS][NOM]   nominal rigid-body record (ocp_nominal_kernel -> K5 / K8 / merit)
+  double* ext;           // [batch][NS][EXT]   nullptr unless a term of ocp_ext_kernel.hip is in use (ContactDistance)
   double* kkt;           // [batch][NS][KKT]   (terminal record holds Qxx and lx only)
   double* exp;           // [batch][NS][EXP]   (terminal record holds Fqq_prev_inv only)
   double* ric;           // [batch][NS][RIC]

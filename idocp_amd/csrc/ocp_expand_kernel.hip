@@ -48,9 +48,19 @@ __device__ __forceinline__ double f2b(double rate, double x, double dx, double c
 template <typename D>
 __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd, int row, const double* __restrict__ s,
                                        const double* dq, const double* dv, const double* du, const double* df_slot, const double* da,
-                                       double* g, double* dg) {
+                                       const double* __restrict__ xx, double* g, double* dg) {
   using L = OcpLayout<D>;
   constexpr int NU = D::NU;
+  if (row >= L::C_CD) {
+    // ContactDistance of a contact that is not active (contact_distance.cpp:105-146): g = - z, dg = - J_c dq, both from the ext record
+    const int c = row - L::C_CD;
+    if (!xx || !P->use_contact_distance || nd->kind == 1 || nd->level < 2 || nd->active[c]) return false;
+    *g = -xx[L::X_Z + c];
+    double acc = 0.0;
+    for (int t = 0; t < D::NV; ++t) acc += xx[L::X_CDJ + c * D::NV + t] * dq[t];
+    *dg = -acc;
+    return true;
+  }
   if (row >= L::C_ACC) {
     // JointAccelerationLowerLimit / UpperLimit on a.tail(dimu) (joint_acceleration_{lower,upper}_limit.cpp:78-93)
     const int c = 8 + (row - L::C_ACC) / NU, j = (row - L::C_ACC) % NU;
@@ -81,9 +91,11 @@ __device__ __forceinline__ bool ipmRow(const OcpProblem* __restrict__ P, const O
 }
 // a cone row of a contact that is NOT active on this stage: dslack = ddual = 1, so that it never limits the step
 // (linearized_friction_cone.cpp:162-163, friction_cone.cpp:155-156)
+// (likewise the ContactDistance row of a contact that IS active, contact_distance.cpp:113-114)
 template <typename D>
 __device__ __forceinline__ bool ipmIdleConeRow(const OcpProblem* __restrict__ P, const OcpNode* __restrict__ nd, int row) {
   using L = OcpLayout<D>;
+  if (row >= L::C_CD) return P->use_contact_distance && nd->kind != 1 && nd->level >= 2 && nd->active[row - L::C_CD];
   if (row < L::C_FRIC || row >= L::C_ACC || !ocpRowValid2(P, 6, nd->level, nd->kind == 1)) return false;
   const int r = (row - L::C_FRIC) % 5;
   return r < coneRows(nd->kind == 1 ? P->impulse_cone_kind : P->cone_kind);
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   for (int t = 0; t < 2; ++t) {
     const int row = lane + 64 * t;
     double g, dg;
-    if (row >= L::NCON || !ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, das, &g, &dg)) continue;
+    if (row >= L::NCON || !ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, das, B.ext ? B.ext + rec * L::EXT : nullptr, &g, &dg)) continue;
     const double sl = sl_r[t], dl = dl_r[t];
     const double res = g + sl, duality = sl * dl - P->barrier;
     const double dslack = -dg - res;
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       const int row = lane + 64 * t;
       if (row >= L::NCON) continue;
       double g, dg;
-      const bool valid = ipmRow<D>(P, nd, row, sr, dx, dx + NV, du, dfs, dr + L::D_A, &g, &dg);
+      const bool valid = ipmRow<D>(P, nd, row, sr, dx, dx + NV, du, dfs, dr + L::D_A, B.ext ? B.ext + rec * L::EXT : nullptr, &g, &dg);
       const double sl = sl_r[t], dl = dl_r[t];
       double dslack, ddual;
       if (valid) {
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
     const double* __restrict__ slack = B.slack + rec * L::CON;
     for (int row = lane; row < L::NCON; row += 64) {
       double g, dg, dslack;
-      if (ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, dd + L::D_A, &g, &dg)) dslack = -dg - (g + slack[row]);
+      if (ipmRow<D>(P, nd, row, s, dx, dx + NV, du, dfs, dd + L::D_A, B.ext ? B.ext + rec * L::EXT : nullptr, &g, &dg)) dslack = -dg - (g + slack[row]);
       else if (ipmIdleConeRow<D>(P, nd, row)) dslack = 1.0;
       else continue;
       bar -= log(slack[row] + a * dslack);
@@ -529,7 +541,10 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
     double sl = 1.0, dl = 0.0;
     bool valid;
     double g = 0.0;
-    if (row >= L::C_ACC) {
+    if (row >= L::C_CD) {
+      if (B.ext) continue;                              // ContactDistance rows: ocp_ext_init_kernel (needs the kinematics of the feet)
+      valid = false;
+    } else if (row >= L::C_ACC) {
       const int c = 8 + (row - L::C_ACC) / NU, j = (row - L::C_ACC) % NU;
       valid = ocpRowValid2(P, c, i, impulse);
       if (valid) g = ((c & 1) ? 1.0 : -1.0) * (s[L::S_A + 6 + j] - ocpLimit2(P, c, j));      // joint_acceleration_{lower,upper}_limit.cpp:50-54

@@ -23,6 +23,10 @@ struct OcpLaunch {
   static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
   static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9b
+  // terms with frame Jacobians of their own (ocp_ext_kernel.hip): no-ops when B.ext == nullptr
+  static void extRows(const OcpBuffers& B, long batch, int M, bool residual, hipStream_t st);
+  static void extHessian(const OcpBuffers& B, long batch, int M, hipStream_t st);
+  static void extInit(const OcpBuffers& B, long batch, int NS, hipStream_t st);
   static void parnmpcImpulseMerit(const OcpBuffers& Btry, long batch, int n_impulse, const double* q0, const double* v0, hipStream_t st);      // line search on the impulse stages
   static void parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n_impulse, bool residual, const double* q0, const double* v0,
                                      hipStream_t st);                                               // K9i: impulse stages of a ParNMPC chain

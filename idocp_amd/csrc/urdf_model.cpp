@@ -389,4 +389,5 @@ extern "C" void idocp_constraints_init(idocp_constraints_t* c) {
   c->friction_cone = 0; c->impulse_friction_cone = 0;
   c->joint_acceleration_lower_limit = 0; c->joint_acceleration_upper_limit = 0;
   for (int i = 0; i < IDOCP_MAX_NV; ++i) { c->a_min[i] = 0.0; c->a_max[i] = 0.0; }
+  c->contact_distance = 0;
 }

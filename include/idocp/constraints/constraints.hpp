@@ -18,7 +18,7 @@ namespace idocp {
 
 class ConstraintComponentBase {
  public:
-  enum Family { Position, Velocity, Torque, LinearFrictionCone, QuadraticFrictionCone, Acceleration };
+  enum Family { Position, Velocity, Torque, LinearFrictionCone, QuadraticFrictionCone, Acceleration, Distance };
   ConstraintComponentBase(Family f, bool upper, double barrier, double rate)
       : family(f), upper(upper), barrier(barrier), fraction_to_boundary_rate(rate) {}
   virtual ~ConstraintComponentBase() {}
@@ -54,6 +54,14 @@ class JointAccelerationUpperLimit final : public ConstraintComponentBase {
  public:
   JointAccelerationUpperLimit(const Robot&, const Eigen::VectorXd& amax, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
       : ConstraintComponentBase(Acceleration, true, barrier, fraction_to_boundary_rate) { bound = amax; }
+};
+
+// ContactDistance (src/constraints/contact_distance.cpp): the frames of the contacts that are not active on a stage stay above z = 0
+// (floating-base solvers).
+class ContactDistance final : public ConstraintComponentBase {
+ public:
+  explicit ContactDistance(const Robot&, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(Distance, false, barrier, fraction_to_boundary_rate) {}
 };
 
 // LinearizedFrictionCone (include/idocp/constraints/linearized_friction_cone.hpp:17-120,
@@ -126,6 +134,7 @@ class Constraints {
       c_.mu = c->mu;
       return;
     }
+    if (c->family == ConstraintComponentBase::Distance) { c_.contact_distance = 1; return; }
     if (c->family == ConstraintComponentBase::Acceleration) {
       if (c->bound.size() > IDOCP_MAX_NV) { std::cerr << "invalid argument: too many acceleration bounds" << '\n'; std::exit(EXIT_FAILURE); }
       (c->upper ? c_.joint_acceleration_upper_limit : c_.joint_acceleration_lower_limit) = 1;

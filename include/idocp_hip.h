@@ -155,6 +155,8 @@ typedef struct idocp_constraints {
   int joint_acceleration_upper_limit;   /* 0/1: JointAccelerationUpperLimit, a.tail(dimu) <= a_max (src/constraints/joint_acceleration_upper_limit.cpp) */
   double a_min[IDOCP_MAX_NV];           /* the components carry their own bounds (constructor argument amin / amax), one per actuated joint */
   double a_max[IDOCP_MAX_NV];
+  int contact_distance;                 /* 0/1: ContactDistance, the frames of the contacts that are NOT active stay above z = 0
+                                         * (src/constraints/contact_distance.cpp); floating-base solvers */
 } idocp_constraints_t;
 
 /* ---- Robot ------------------------------------------------------------ */

@@ -63,7 +63,7 @@ OCPSolver::OCPSolver(const RModel& model, const RCost& cost_, const idocp_constr
   d.assign(ns, SplitDirectionC(robot));
   kkt_matrix.assign(ns, SplitKKTMatrixC(model.nv, model.nu));
   kkt_residual.assign(ns, SplitKKTResidualC(model.nv, model.nu));
-  cd.resize(ns); sw.resize(ns); ipm.resize(ns);
+  cd.resize(ns); sw.resize(ns); ipm.resize(ns); cd_J.resize(ns);
   riccati.assign(ns, RiccatiC(model.nv));
   K.assign(ns, Mat(model.nu, 2 * model.nv)); k.assign(ns, Mat(model.nu));
   ContactStatus cs0;
@@ -230,12 +230,13 @@ bool OCPSolver::componentEnabled(int c, bool impulse) const {
   if (c == 7) return false;
   if (c == 8) return cons.joint_acceleration_lower_limit != 0;       // acceleration level: every time stage (constraints_data.hpp:18-42)
   if (c == 9) return cons.joint_acceleration_upper_limit != 0;
+  if (c == 10) return cons.contact_distance != 0;
   return cons.linearized_friction_cone != 0 || cons.friction_cone != 0;
 }
 bool OCPSolver::componentValid(int c, const NodeC& nd) const {     // constraints_data.hpp:18-42
   if (nd.kind == NodeC::Impulse) return componentEnabled(c, true);
   if (!componentEnabled(c, false)) return false;
-  if (c < 2) return nd.level >= 2;
+  if (c < 2 || c == 10) return nd.level >= 2;                       // position level
   if (c < 4) return nd.level >= 1;
   return true;
 }
@@ -294,6 +295,13 @@ void OCPSolver::initNodeConstraints(const NodeC& nd) {
       if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(sp, c, r, nv_, nu_) - limitOf(robot.model(), cons, c, r));
+      } else if (c == 10) {
+        // ContactDistance::setSlackAndDual (contact_distance.cpp:58-65): the height of every contact frame, active or not
+        {
+          const Mat zero(nv_);
+          robot.updateKinematics(sp.q, zero, zero);
+          for (int cc = 0; cc < nc_; ++cc) { real pw[3]; robot.contactFrame(cc, pw, nullptr, nullptr, nullptr); data.slack[cc] = pw[2]; }
+        }
       } else {
         for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:96-104)
           const ConeEval ce = coneEval(CK, cons.mu, sp.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
@@ -420,6 +428,22 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
           data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         }
         l[off + r] += sgn * dt * data.dual[r];
+      }
+    } else if (c == 10) {
+      // ContactDistance::augmentDualResidual (contact_distance.cpp:68-78) [+ computePrimalAndDualResidual :132-146]: the contacts that are
+      // NOT active keep their frame above the ground; J = LOCAL frame Jacobian (Robot::getFrameJacobian), its row 2
+      if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
+      robot.updateKinematics(si.q, si.v, si.a);
+      cd_J[nd.slot] = Mat(nc_, nv);
+      for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) {
+        Mat vdq, adq, adv, J;
+        robot.frameDerivatives(cc, vdq, adq, adv, J);
+        for (int col = 0; col < nv; ++col) { cd_J[nd.slot](cc, col) = J(2, col); R.lq[col] -= dt * data.dual[cc] * J(2, col); }
+        if (residual_only) {
+          real pw[3]; robot.contactFrame(cc, pw, nullptr, nullptr, nullptr);
+          data.residual[cc] = -pw[2] + data.slack[cc];
+          data.duality[cc] = data.slack[cc] * data.dual[cc] - cons.barrier;
+        }
       }
     } else {
       if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
@@ -554,6 +578,21 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
         data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), cons, c, r)) + data.slack[r];
         data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         l[off + r] += sgn * dt * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
+      }
+    } else if (c == 10) {
+      // ContactDistance::condenseSlackAndDual (contact_distance.cpp:81-102); the kinematics of s.q (the reference condenses the
+      // constraints before it moves the robot to the predicted configuration of the switching constraint, split_ocp.hxx:124-129)
+      data.residual.setZero(); data.duality.setZero();
+      robot.updateKinematics(si.q, si.v, si.a);
+      for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) {
+        const Mat& Jm = cd_J[nd.slot];
+        const real h = dt * data.dual[cc] / data.slack[cc];
+        for (int r2 = 0; r2 < nv; ++r2) for (int c2 = 0; c2 < nv; ++c2) M.Qxx(r2, c2) += h * Jm(cc, r2) * Jm(cc, c2);
+        real pw[3]; robot.contactFrame(cc, pw, nullptr, nullptr, nullptr);
+        data.residual[cc] = -pw[2] + data.slack[cc];
+        data.duality[cc] = data.slack[cc] * data.dual[cc] - cons.barrier;
+        const real g = dt * (data.dual[cc] * data.residual[cc] - data.duality[cc]) / data.slack[cc];
+        for (int col = 0; col < nv; ++col) R.lq[col] -= g * Jm(cc, col);
       }
     } else {
       // linearized_friction_cone.cpp:125-152, 184-202 ; linearized_impulse_friction_cone.cpp (same with dt = 1)
@@ -693,6 +732,13 @@ int OCPSolver::isCurrentSolutionFeasible() const {
           const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), cons, c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
+      }
+      if (componentValid(10, nd)) {                        // ContactDistance::isFeasible (contact_distance.cpp:44-55)
+        Robot rb2 = robot;
+        const Mat zero(nv_);
+        rb2.updateKinematics(si.q, zero, zero);
+        const ContactStatus& cs2 = nodeContacts(p);
+        for (int cc = 0; cc < nc_; ++cc) if (!cs2.active[cc]) { real pw[3]; rb2.contactFrame(cc, pw, nullptr, nullptr, nullptr); if (pw[2] <= 0) return p; }
       }
       if (!componentValid(6, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;
@@ -936,6 +982,14 @@ void OCPSolver::computeDirection() {
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
+      } else if (c == 10) {
+        // ContactDistance::computeSlackAndDualDirection (contact_distance.cpp:105-129)
+        for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
+        for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) {
+          real Jdq = 0; for (int col = 0; col < nv; ++col) Jdq += cd_J[sl](cc, col) * d[sl].dq[col];
+          data.dslack[cc] = Jdq - data.residual[cc];
+          data.ddual[cc] = -(data.dual[cc] * data.dslack[cc] + data.duality[cc]) / data.slack[cc];
+        }
       } else {
         for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }   // linearized_friction_cone.cpp:162-163
         int st = 0;
@@ -1107,6 +1161,10 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
       if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), cons, c, r)) + data.slack[r]);
+      } else if (c == 10) {
+        // ContactDistance::computePrimalAndDualResidual at the trial configuration (contact_distance.cpp:132-146)
+        rb.updateKinematics(x.q, x.v, x.a);
+        for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) { real pw[3]; rb.contactFrame(cc, pw, nullptr, nullptr, nullptr); primal += std::fabs(-pw[2] + data.slack[cc]); }
       } else {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           const ConeEval ce = coneEval(CK, cons.mu, x.f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
@@ -1158,7 +1216,7 @@ ParNMPCSolver::ParNMPCSolver(const RModel& model, const RCost& cost_, const idoc
   d.assign(ns, SplitDirectionC(robot));
   kkt_matrix.assign(ns, SplitKKTMatrixC(model.nv, model.nu));
   kkt_residual.assign(ns, SplitKKTResidualC(model.nv, model.nu));
-  cd.resize(ns); ipm.resize(ns);
+  cd.resize(ns); ipm.resize(ns); cd_J.resize(ns);
   const int nx = 2 * nv_;
   KKT_mat_inv.assign(ns, Mat(2 * nx + nu_, 2 * nx + nu_));
   aux_mat.assign(ns, Mat(nx, nx));
@@ -1367,6 +1425,7 @@ bool ParNMPCSolver::componentValid(int c, const PNode& nd) const {     // constr
   if (c == 7) return false;
   if (c == 8) return cons.joint_acceleration_lower_limit != 0;
   if (c == 9) return cons.joint_acceleration_upper_limit != 0;
+  if (c == 10) return cons.contact_distance != 0 && nd.level >= 2;
   return cons.linearized_friction_cone != 0 || cons.friction_cone != 0;
 }
 
@@ -1406,6 +1465,13 @@ void ParNMPCSolver::initNodeConstraints(const PNode& nd) {
       if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu_; ++r) data.slack[r] = -sgn * (limitedVar(s[i], c, r, nv_, nu_) - limitOf(robot.model(), cons, c, r));
+      } else if (c == 10) {
+        // ContactDistance::setSlackAndDual (contact_distance.cpp:58-65): the height of every contact frame, active or not
+        {
+          const Mat zero(nv_);
+          robot.updateKinematics(s[i].q, zero, zero);
+          for (int cc = 0; cc < nc_; ++cc) { real pw[3]; robot.contactFrame(cc, pw, nullptr, nullptr, nullptr); data.slack[cc] = pw[2]; }
+        }
       } else {
         for (int cc = 0; cc < nc_; ++cc) {      // all contacts, active or not (linearized_friction_cone.cpp:100-108)
           const ConeEval ce = coneEval(CK, cons.mu, s[i].f[cc]); const real* res = ce.res; const real (*Jc)[3] = ce.J; (void)Jc;
@@ -1499,6 +1565,22 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
           data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         }
         l[off + r] += sgn * dt * data.dual[r];
+      }
+    } else if (c == 10) {
+      // ContactDistance::augmentDualResidual (contact_distance.cpp:68-78) [+ computePrimalAndDualResidual :132-146]: the contacts that are
+      // NOT active keep their frame above the ground; J = LOCAL frame Jacobian (Robot::getFrameJacobian), its row 2
+      if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
+      robot.updateKinematics(si.q, si.v, si.a);
+      cd_J[i] = Mat(nc_, nv);
+      for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) {
+        Mat vdq, adq, adv, J;
+        robot.frameDerivatives(cc, vdq, adq, adv, J);
+        for (int col = 0; col < nv; ++col) { cd_J[i](cc, col) = J(2, col); R.lq[col] -= dt * data.dual[cc] * J(2, col); }
+        if (residual_only) {
+          real pw[3]; robot.contactFrame(cc, pw, nullptr, nullptr, nullptr);
+          data.residual[cc] = -pw[2] + data.slack[cc];
+          data.duality[cc] = data.slack[cc] * data.dual[cc] - cons.barrier;
+        }
       }
     } else {
       if (residual_only) { data.residual.setZero(); data.duality.setZero(); }
@@ -1613,6 +1695,21 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
         data.residual[r] = sgn * (limitedVar(si, c, r, nv, nu) - limitOf(robot.model(), cons, c, r)) + data.slack[r];
         data.duality[r] = data.slack[r] * data.dual[r] - cons.barrier;
         l[off + r] += sgn * dt * (data.dual[r] * data.residual[r] - data.duality[r]) / data.slack[r];
+      }
+    } else if (c == 10) {
+      // ContactDistance::condenseSlackAndDual (contact_distance.cpp:81-102); the kinematics of s.q (the reference condenses the
+      // constraints before it moves the robot to the predicted configuration of the switching constraint, split_ocp.hxx:124-129)
+      data.residual.setZero(); data.duality.setZero();
+      robot.updateKinematics(si.q, si.v, si.a);
+      for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) {
+        const Mat& Jm = cd_J[i];
+        const real h = dt * data.dual[cc] / data.slack[cc];
+        for (int r2 = 0; r2 < nv; ++r2) for (int c2 = 0; c2 < nv; ++c2) M.Qxx(r2, c2) += h * Jm(cc, r2) * Jm(cc, c2);
+        real pw[3]; robot.contactFrame(cc, pw, nullptr, nullptr, nullptr);
+        data.residual[cc] = -pw[2] + data.slack[cc];
+        data.duality[cc] = data.slack[cc] * data.dual[cc] - cons.barrier;
+        const real g = dt * (data.dual[cc] * data.residual[cc] - data.duality[cc]) / data.slack[cc];
+        for (int col = 0; col < nv; ++col) R.lq[col] -= g * Jm(cc, col);
       }
     } else {
       data.residual.setZero(); data.duality.setZero();
@@ -2058,6 +2155,14 @@ void ParNMPCSolver::forwardCorrectionParallel() {
           data.dslack[r2] = -sgn * dxr - data.residual[r2];
           data.ddual[r2] = -(data.dual[r2] * data.dslack[r2] + data.duality[r2]) / data.slack[r2];
         }
+      } else if (c == 10) {
+        // ContactDistance::computeSlackAndDualDirection (contact_distance.cpp:105-129)
+        for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
+        for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) {
+          real Jdq = 0; for (int col = 0; col < nv; ++col) Jdq += cd_J[i](cc, col) * d[i].dq[col];
+          data.dslack[cc] = Jdq - data.residual[cc];
+          data.ddual[cc] = -(data.dual[cc] * data.dslack[cc] + data.duality[cc]) / data.slack[cc];
+        }
       } else {
         for (int r2 = 0; r2 < data.dslack.size(); ++r2) { data.dslack[r2] = 1.0; data.ddual[r2] = 1.0; }
         int st = 0;
@@ -2205,6 +2310,10 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       if (jointComp(c)) {
         const real sgn = (c & 1) ? 1.0 : -1.0;
         for (int r = 0; r < nu; ++r) primal += std::fabs(sgn * (limitedVar(x, c, r, nv, nu) - limitOf(rb.model(), cons, c, r)) + data.slack[r]);
+      } else if (c == 10) {
+        // ContactDistance::computePrimalAndDualResidual at the trial configuration (contact_distance.cpp:132-146)
+        rb.updateKinematics(x.q, x.v, x.a);
+        for (int cc = 0; cc < nc_; ++cc) if (!cs.active[cc]) { real pw[3]; rb.contactFrame(cc, pw, nullptr, nullptr, nullptr); primal += std::fabs(-pw[2] + data.slack[cc]); }
       } else {
         for (int cc = 0; cc < nc_; ++cc) if (cs.active[cc]) {
           const ConeEval ce = coneEval(CK, cons.mu, x.f[cc]);
@@ -2275,6 +2384,13 @@ int ParNMPCSolver::isCurrentSolutionFeasible() const {
           const real x = limitedVar(si, c, r, nv_, nu_), lim = limitOf(robot.model(), cons, c, r);
           if ((c & 1) ? x > lim : x < lim) return p;
         }
+      }
+      if (componentValid(10, nd)) {                        // ContactDistance::isFeasible (contact_distance.cpp:44-55)
+        Robot rb2 = robot;
+        const Mat zero(nv_);
+        rb2.updateKinematics(si.q, zero, zero);
+        const ContactStatus& cs2 = nodeContacts(nd);
+        for (int cc = 0; cc < nc_; ++cc) if (!cs2.active[cc]) { real pw[3]; rb2.contactFrame(cc, pw, nullptr, nullptr, nullptr); if (pw[2] <= 0) return p; }
       }
       if (!componentValid(6, nd)) continue;
       const int CK = coneKind(nd.kind == NodeC::Impulse), CR = coneRows(nd.kind == NodeC::Impulse); (void)CK; (void)CR;

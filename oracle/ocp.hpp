@@ -82,9 +82,9 @@ struct ConeEval { int nr; real res[5]; real J[5][3]; };
 ConeEval coneEval(int kind, real mu, const Mat& f);
 
 // IPM components: 0/1 joint position lower/upper, 2/3 velocity, 4/5 torque, 6 (linearized) friction cone, 7 unused, 8/9 joint
-// acceleration lower/upper; odd = upper bound (sign +1)
-constexpr int NCOMP = 10;
-inline bool jointComp(int c) { return c < 6 || c >= 8; }
+// acceleration lower/upper; odd = upper bound (sign +1); 10 contact distance
+constexpr int NCOMP = 11;      // 10: ContactDistance (one row per contact)
+inline bool jointComp(int c) { return c < 6 || c == 8 || c == 9; }
 struct IpmData {                  // ConstraintComponentData
   Mat slack, dual, residual, duality, dslack, ddual;
   explicit IpmData(int n = 0) : slack(n), dual(n), residual(n), duality(n), dslack(n), ddual(n) {}
@@ -169,6 +169,7 @@ class OCPSolver {
   std::vector<ContactDynamicsDataC> cd;
   std::vector<SwitchingC> sw;
   std::vector<std::vector<IpmData>> ipm;    // [node][component]
+  std::vector<Mat> cd_J;                    // ContactDistance: row 2 of the LOCAL frame Jacobians of the linearisation (nc x nv per slot)
   std::vector<RiccatiC> riccati;
   std::vector<Mat> K, k;
   real primal_step_size = 1, dual_step_size = 1;
@@ -182,7 +183,7 @@ class OCPSolver {
   // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone (impulse cone on impulse stages)
   bool componentEnabled(int c, bool impulse) const;
   bool componentValid(int c, const NodeC& nd) const;
-  int componentDim(int c, bool impulse = false) const { return jointComp(c) ? nu_ : (c == 6 ? coneRows(impulse) * nc_ : 0); }
+  int componentDim(int c, bool impulse = false) const { return jointComp(c) ? nu_ : (c == 6 ? coneRows(impulse) * nc_ : (c == 10 ? nc_ : 0)); }
   int coneKind(bool impulse) const { return (impulse ? cons.impulse_friction_cone : cons.friction_cone) ? 1 : 0; }
   int coneRows(bool impulse) const { return coneKind(impulse) == 1 ? 2 : 5; }
   void initNodeConstraints(const NodeC& nd);
@@ -265,6 +266,7 @@ class ParNMPCSolver {
   std::vector<SplitKKTResidualC> kkt_residual;
   std::vector<ContactDynamicsDataC> cd;
   std::vector<std::vector<IpmData>> ipm;
+  std::vector<Mat> cd_J;                             // ContactDistance rows of the linearisation (nc x nv per slot)
   std::vector<Mat> KKT_mat_inv, aux_mat, x_res;      // dimKKT^2, nx^2, nx per stage
   std::vector<Mat> sw_Pq;                            // aux stages: Pq (dimi x nv); the residual P sits in kkt_residual.P
   // ImpulseDynamicsBackwardEulerData + the impulse blocks of ImpulseSplitKKTMatrix (per impulse slot)
@@ -301,7 +303,7 @@ class ParNMPCSolver {
   real disc_t_ = 0;
   bool discretized_ = false;
   bool componentValid(int c, const PNode& nd) const;
-  int componentDim(int c, bool impulse = false) const { return jointComp(c) ? nu_ : (c == 6 ? coneRows(impulse) * nc_ : 0); }
+  int componentDim(int c, bool impulse = false) const { return jointComp(c) ? nu_ : (c == 6 ? coneRows(impulse) * nc_ : (c == 10 ? nc_ : 0)); }
   int coneKind(bool impulse) const { return (impulse ? cons.impulse_friction_cone : cons.friction_cone) ? 1 : 0; }
   int coneRows(bool impulse) const { return coneKind(impulse) == 1 ? 2 : 5; }
   void qRef(real t, Mat& q_ref) const;

@@ -703,7 +703,7 @@ int oracle_ocp_get_constraint_data(void* h, double* slack, double* dual) {
   const idocp_constraints_t& c = s->cons;
   const int en[NCOMP] = {c.joint_position_limits, c.joint_position_limits, c.joint_velocity_limits, c.joint_velocity_limits,
                          c.joint_torque_limits, c.joint_torque_limits, c.linearized_friction_cone || c.friction_cone, 0,
-                         c.joint_acceleration_lower_limit, c.joint_acceleration_upper_limit};
+                         c.joint_acceleration_lower_limit, c.joint_acceleration_upper_limit, c.contact_distance};
   for (int i = 0; i < s->N(); ++i) {
     int off = 0;
     for (int comp = 0; comp < NCOMP; ++comp) {
