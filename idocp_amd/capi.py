@@ -54,6 +54,7 @@ class Cost(C.Structure):
         ("use_time_varying_ref", C.c_int), ("tv_t_begin", C.c_double), ("tv_t_end", C.c_double),
         ("task_dim", C.c_int), ("task_joint", C.c_int), ("task_frame_R", C.c_double * 9), ("task_frame_p", C.c_double * 3),
         ("task_weight", C.c_double * 6), ("task_weightf", C.c_double * 6), ("task_ref", C.c_double * 12), ("task_time_varying", C.c_int),
+        ("task_weighti", C.c_double * 6),
     ]
 
     def set(self, name, values):

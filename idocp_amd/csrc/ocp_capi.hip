@@ -582,8 +582,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
     set_last_error("invalid value: fraction_to_boundary_rate must be in (0, 1]!"); return IDOCP_E_ARG;
   }
   if (cost->task_dim != 0) {
-    set_last_error("unsupported cost: the task-space costs are carried by UnOCPSolver (fixed-base robots) only");
-    return IDOCP_E_UNSUPPORTED;
+    if (cost->task_dim != 3 && cost->task_dim != 6) { set_last_error("invalid value: task_dim must be 0, 3 or 6"); return IDOCP_E_ARG; }
+    if (cost->task_time_varying) { set_last_error("unsupported cost: the TimeVarying task-space costs are carried by UnOCPSolver (fixed-base robots) only"); return IDOCP_E_UNSUPPORTED; }
+    if (parnmpc && max_num_impulse > 0) { set_last_error("unsupported cost: task-space costs on a ParNMPC horizon with discrete events (the impulse-stage kernel has no such term)"); return IDOCP_E_UNSUPPORTED; }
+    if (cost->task_joint < 0 || cost->task_joint > DQ::NU) { set_last_error("invalid value: the task frame must sit on the floating base or on a leg link"); return IDOCP_E_ARG; }
   }
   if (!isQuadruped(*model)) {
     set_last_error("idocp_ocp_create: this build carries OCP kernels for a floating-base quadruped (4 legs x 3 joints, 4 point contacts) only");
@@ -630,7 +632,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &B.err, (size_t)batch))) return fail(rc);
   if ((rc = allocBufO(h, &B.sol_try, ns * LQ::SOL))) return fail(rc);
   B.ext = nullptr; h->ext_try = nullptr;
-  if (constraints->contact_distance) {                     // terms with frame Jacobians of their own (ocp_ext_kernel.hip), of the iterate and of the line search's trial iterate
+  if (constraints->contact_distance || cost->task_dim != 0) {      // terms with frame Jacobians of their own (ocp_ext_kernel.hip), of the iterate and of the line search's trial iterate
     if ((rc = allocBufO(h, &B.ext, ns * LQ::EXT))) return fail(rc);
     if ((rc = allocBufO(h, &h->ext_try, ns * LQ::EXT))) return fail(rc);
   }
@@ -702,6 +704,11 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   p.use_u_limits = constraints->joint_torque_limits;
   p.use_a_lower = constraints->joint_acceleration_lower_limit ? 1 : 0;
   p.use_contact_distance = constraints->contact_distance ? 1 : 0;
+  p.task_dim = cost->task_dim; p.task_joint = cost->task_joint;
+  for (int k = 0; k < 9; ++k) p.task_R[k] = cost->task_frame_R[k];
+  for (int k = 0; k < 3; ++k) p.task_p[k] = cost->task_frame_p[k];
+  for (int k = 0; k < 6; ++k) { p.task_weight[k] = cost->task_weight[k]; p.task_weightf[k] = cost->task_weightf[k]; p.task_weighti[k] = cost->task_weighti[k]; }
+  for (int k = 0; k < 12; ++k) p.task_ref[k] = cost->task_ref[k];
   p.use_a_upper = constraints->joint_acceleration_upper_limit ? 1 : 0;
   for (int r = 0; r < IDOCP_MAX_NV; ++r) { p.a_min[r] = constraints->a_min[r]; p.a_max[r] = constraints->a_max[r]; }
   p.use_friction_cone = (constraints->linearized_friction_cone || constraints->friction_cone) ? 1 : 0;

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         lq = P->qf_weight[r] * (q[r + 1] - qref[r + 1]) - s[L::S_LMD + r];
       }
       lv = P->vf_weight[r] * (s[L::S_V + r] - (r == 0 ? v_ref0 : vref_on * P->v_ref[r])) - s[L::S_GMM + r];
+      if (B.ext) lq += B.ext[rec * L::EXT + L::X_LQ + r];      // task-space cost with its terminal weights (ocp_ext_kernel.hip)
       if (MERIT) {      // TerminalOCP::terminalCost (terminal_ocp.hxx:81-87)
         const double qd = r < 6 ? sm[S::QDIFF + r] : q[r + 1] - qref[r + 1], dvr = s[L::S_V + r] - (r == 0 ? v_ref0 : vref_on * P->v_ref[r]);
         sm[S::ERR + tid] = 0.5 * (P->qf_weight[r] * qd * qd + P->vf_weight[r] * dvr * dvr);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       __syncthreads();
       if (tid == 0) {
         double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t];
-        if (MERIT) { B.merit_stage[rec * 4] = e; B.merit_stage[rec * 4 + 1] = 0.0; } else B.err_stage[rec] = e;
+        if (MERIT) { B.merit_stage[rec * 4] = e + (B.ext ? B.ext[rec * L::EXT + L::X_COST] : 0.0); B.merit_stage[rec * 4 + 1] = 0.0; } else B.err_stage[rec] = e;
       }
       return;
     }
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     if (tid < 2) {
       double e = 0.0;
       for (int t = 0; t < nt; ++t) e += sm[S::ERR + nt * tid + t];
-      if (tid == 1 && B.ext) e += B.ext[rec * L::EXT + L::X_VIOL];
+      if (B.ext) e += B.ext[rec * L::EXT + (tid == 1 ? L::X_VIOL : L::X_COST)];
       B.merit_stage[rec * 4 + tid] = e;
     }
     return;

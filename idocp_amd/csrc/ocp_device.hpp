@@ -73,8 +73,10 @@ struct OcpLayout {
   static_assert(NVF % 2 == 0, "the nominal record is copied in 16-byte pieces");
   // ext record (ocp_ext_kernel.hip; allocated only when a term of it is in use): the ContactDistance rows J_c (NC x NV, row-major), the
   // heights z_c, the gradient term to be added to lq, the Hessian weights, the stage's share of the KKT error / line-search violation
+  // then the task-space cost (TaskSpace3DCost / TaskSpace6DCost): the rows JJ (6 x NV, row-major), their weights (time step included), the cost
   static constexpr int X_CDJ = 0, X_Z = NC * NV, X_LQ = X_Z + NC, X_W = X_LQ + NV, X_ERR = X_W + NC, X_VIOL = X_ERR + 1;
-  static constexpr int EXT = roundUp16(X_VIOL + 1);
+  static constexpr int X_TJ = X_VIOL + 1, X_TW = X_TJ + 6 * NV, X_COST = X_TW + 6;
+  static constexpr int EXT = roundUp16(X_COST + 1);
   static constexpr int G_K = 0, G_k = NU * NX;
   static constexpr int GAIN = roundUp16(G_k + NU);
   // switching-constraint record of a stage two steps ahead of an impulse (SplitStateConstraintJacobian +
@@ -179,6 +181,10 @@ struct OcpProblem {
   double fi_weight[IDOCP_MAX_CONTACTS][3], fi_ref[IDOCP_MAX_CONTACTS][3];
   int use_q_limits, use_v_limits, use_u_limits, use_friction_cone, use_impulse_friction_cone;
   int use_contact_distance;             // ContactDistance rows (ext record)
+  // TaskSpace3DCost / TaskSpace6DCost on one frame (ext record): parent joint (0 = the floating base), placement in it, weights of the
+  // stages / the terminal stage / the impulse stages, constant reference (rotation row-major, position)
+  int task_dim, task_joint;
+  double task_R[9], task_p[3], task_weight[6], task_weightf[6], task_weighti[6], task_ref[12];
   int use_a_lower, use_a_upper;         // JointAccelerationLowerLimit / UpperLimit (acceleration level: every stage with torques)
   double a_min[IDOCP_MAX_NV], a_max[IDOCP_MAX_NV];
   int cone_kind, impulse_cone_kind;     // 0: Linearized(Impulse)FrictionCone (5 rows per contact), 1: (Impulse)FrictionCone (2 rows); coneRow below

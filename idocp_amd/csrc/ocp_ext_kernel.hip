@@ -14,6 +14,7 @@
 // The expansion kernels (K6 / K7 / trial iterate) read z_c and J_c from the ext record through ipmRow (ocp_expand_kernel.hip).
 #include <hip/hip_runtime.h>
 
+#include "dev_lie.hpp"
 #include "dev_rbd.hpp"
 #include "ocp_device.hpp"
 #include "ocp_launch.hpp"
@@ -39,13 +40,15 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 
 }  // namespace
 
-// World placement of the contact frame of leg `leg` at configuration q (Robot::updateFrameKinematics + framePosition /
-// frameRotation, robot.hxx:166-188) and, for the velocity index `dof` (< 0: none), the world-frame motion the unit velocity of that
-// degree of freedom gives the frame: angular part w, linear part v at the frame origin (zero if the frame does not move with it).
+// World placement of a frame at configuration q (Robot::updateFrameKinematics + framePosition / frameRotation, robot.hxx:166-188) --
+// parent joint jf of the model (0: the floating base, 1 + leg LJ + j: joint j of a leg), placement (Rf, pf) in the joint frame -- and,
+// for the velocity index `dof` (< 0: none), the world-frame motion the unit velocity of that degree of freedom gives the frame: angular
+// part w, linear part v at the frame origin (zero if the frame does not move with it).
 template <typename D>
-__device__ inline void contactFrameKinematics(const DevModel* __restrict__ m, const OcpProblem* __restrict__ P, const double* __restrict__ q,
-                                              int leg, int dof, double* pF, double* RF, double* w, double* v) {
+__device__ inline void frameKinematics(const DevModel* __restrict__ m, const double* __restrict__ q, int jf, const double* __restrict__ Rf,
+                                       const double* __restrict__ pf, int dof, double* pF, double* RF, double* w, double* v) {
   constexpr int LJ = D::LJ;
+  const int leg = jf > 0 ? (jf - 1) / LJ : 0, njoints = jf > 0 ? (jf - 1) % LJ + 1 : 0;
   const double qx = q[3], qy = q[4], qz = q[5], qw = q[6];
   double Rw[9];
   Rw[0] = 1 - 2 * (qy * qy + qz * qz); Rw[1] = 2 * (qx * qy - qz * qw);     Rw[2] = 2 * (qx * qz + qy * qw);
@@ -56,7 +59,7 @@ __device__ inline void contactFrameKinematics(const DevModel* __restrict__ m, co
   bool lin = false, moves = false;
   if (dof >= 0 && dof < 3) { lin = true; moves = true; wdof[0] = Rw[dof]; wdof[1] = Rw[3 + dof]; wdof[2] = Rw[6 + dof]; }       // R_wb e_dof
   else if (dof >= 3 && dof < 6) { moves = true; wdof[0] = Rw[dof - 3]; wdof[1] = Rw[3 + dof - 3]; wdof[2] = Rw[6 + dof - 3]; odof[0] = pw[0]; odof[1] = pw[1]; odof[2] = pw[2]; }
-  for (int j = 0; j < LJ; ++j) {
+  for (int j = 0; j < njoints; ++j) {
     const int ji = 1 + leg * LJ + j, d = 6 + leg * LJ + j;
     double s, c;
     sincos(q[d + 1], &s, &c);
@@ -72,14 +75,20 @@ __device__ inline void contactFrameKinematics(const DevModel* __restrict__ m, co
     if (d == dof) { moves = true; matvec(Rw, m->axis[ji], wdof); odof[0] = pw[0]; odof[1] = pw[1]; odof[2] = pw[2]; }      // (the axis is invariant under its own rotation)
   }
   double t[3];
-  matvec(Rw, P->contact_p[leg], t);
+  matvec(Rw, pf, t);
   pF[0] = pw[0] + t[0]; pF[1] = pw[1] + t[1]; pF[2] = pw[2] + t[2];
-  matmul(Rw, P->contact_R[leg], RF);
+  matmul(Rw, Rf, RF);
   if (!moves) { w[0] = w[1] = w[2] = 0.0; v[0] = v[1] = v[2] = 0.0; return; }
   if (lin) { w[0] = w[1] = w[2] = 0.0; v[0] = wdof[0]; v[1] = wdof[1]; v[2] = wdof[2]; return; }
   w[0] = wdof[0]; w[1] = wdof[1]; w[2] = wdof[2];
   const double r[3] = {pF[0] - odof[0], pF[1] - odof[1], pF[2] - odof[2]};
   cross3(wdof, r, v);
+}
+// the contact frame of leg `leg` (the tip joint of the leg)
+template <typename D>
+__device__ inline void contactFrameKinematics(const DevModel* __restrict__ m, const OcpProblem* __restrict__ P, const double* __restrict__ q,
+                                              int leg, int dof, double* pF, double* RF, double* w, double* v) {
+  frameKinematics<D>(m, q, 1 + leg * D::LJ + D::LJ - 1, P->contact_R[leg], P->contact_p[leg], dof, pF, RF, w, v);
 }
 
 template <typename D>
@@ -95,40 +104,84 @@ __global__ __launch_bounds__(64) void ocp_ext_kernel(OcpBuffers B, int residual)
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const long rec = b * P->NS + nd->slot;
   double* __restrict__ xx = B.ext + rec * L::EXT;
-  const bool cd = P->use_contact_distance && nd->kind != 1 && nd->kind != 4 && nd->level >= 2;
-  if (!cd) {
+  const bool bwd = P->backward_euler != 0;
+  if (bwd && pos == M - 1) {                        // ParNMPC: placeholder behind the last stage
     for (int e = lane; e < L::EXT; e += 64) xx[e] = 0.0;
     return;
   }
   const double* __restrict__ q = B.sol + rec * L::SOL + L::S_Q;
+  const int dof = lane < NV ? lane : -1;
+  const double dt = nd->dt;                         // (1 on impulse stages)
+  double lq = 0.0, err = 0.0, viol = 0.0;
+  // ---- ContactDistance ----
+  const bool cd = P->use_contact_distance && nd->kind != 1 && nd->kind != 4 && nd->level >= 2;
   const double* __restrict__ slack = B.slack + rec * L::CON + L::C_CD;
   const double* __restrict__ dual = B.dual + rec * L::CON + L::C_CD;
-  const double dt = nd->dt;
-  const int dof = lane < NV ? lane : -1;
-  double lq = 0.0, err = 0.0, viol = 0.0;
   for (int c = 0; c < NC; ++c) {
-    double pF[3], RF[9], w[3], v[3];
-    contactFrameKinematics<D>(B.model, P, q, c, dof, pF, RF, w, v);
-    const bool live = !nd->active[c];
-    const double e = live ? RF[2] * v[0] + RF[5] * v[1] + RF[8] * v[2] : 0.0;      // (R_wF^T v)_z: row 2 of the LOCAL frame Jacobian
-    const double sl = slack[c], du = dual[c];
-    const double res = -pF[2] + sl, duality = sl * du - P->barrier;
-    double g = 0.0, h = 0.0;
-    if (live) {
-      g = -dt * du;                                                          // augmentDualResidual (contact_distance.cpp:68-78)
-      if (!residual) { g -= dt * (du * res - duality) / sl; h = dt * du / sl; }      // condenseSlackAndDual (:81-102)
-      err += res * res + duality * duality;
-      viol += dt * fabs(res);
+    double e = 0.0, z = 0.0, h = 0.0;
+    if (cd) {
+      double pF[3], RF[9], w[3], v[3];
+      contactFrameKinematics<D>(B.model, P, q, c, dof, pF, RF, w, v);
+      z = pF[2];
+      if (!nd->active[c]) {
+        e = RF[2] * v[0] + RF[5] * v[1] + RF[8] * v[2];      // (R_wF^T v)_z: row 2 of the LOCAL frame Jacobian
+        const double sl = slack[c], du = dual[c];
+        const double res = -z + sl, duality = sl * du - P->barrier;
+        double g = -dt * du;                                                   // augmentDualResidual (contact_distance.cpp:68-78)
+        if (!residual) { g -= dt * (du * res - duality) / sl; h = dt * du / sl; }      // condenseSlackAndDual (:81-102)
+        err += res * res + duality * duality;
+        viol += dt * fabs(res);
+        lq += g * e;
+      }
     }
-    lq += g * e;
     if (lane < NV) xx[L::X_CDJ + c * NV + lane] = e;
-    if (lane == 0) { xx[L::X_Z + c] = pF[2]; xx[L::X_W + c] = h; }
+    if (lane == 0) { xx[L::X_Z + c] = z; xx[L::X_W + c] = h; }
+  }
+  // ---- TaskSpace3DCost / TaskSpace6DCost (task_space_3d_cost.cpp:60-157, task_space_6d_cost.cpp:68-178) ----
+  double cost = 0.0;
+  if (P->task_dim != 0) {
+    double pF[3], RF[9], w[3], v[3], diff[6], col[6];
+    frameKinematics<D>(B.model, q, P->task_joint, P->task_R, P->task_p, dof, pF, RF, w, v);
+    const double* __restrict__ ref = P->task_ref;
+    const double ev[3] = {pF[0] - ref[9], pF[1] - ref[10], pF[2] - ref[11]};
+    if (P->task_dim == 3) {
+      // diff = p - p_ref ; J_3d = R_frame J_lin,LOCAL = the world-frame linear column
+      for (int r = 0; r < 3; ++r) { diff[r] = ev[r]; col[r] = v[r]; diff[3 + r] = 0.0; col[3 + r] = 0.0; }
+    } else {
+      // diff = log6(M_ref^-1 M_frame), JJ = Jlog6(M_ref^-1 M_frame) J_frame,LOCAL
+      double Rd[9], pd[3], tw[6], J[36];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Rd[3 * r + c] = ref[r] * RF[c] + ref[3 + r] * RF[3 + c] + ref[6 + r] * RF[6 + c];
+        pd[r] = ref[r] * ev[0] + ref[3 + r] * ev[1] + ref[6 + r] * ev[2];
+        tw[r] = RF[r] * v[0] + RF[3 + r] * v[1] + RF[6 + r] * v[2];
+        tw[3 + r] = RF[r] * w[0] + RF[3 + r] * w[1] + RF[6 + r] * w[2];
+      }
+      lieLog6Jlog6(Rd, pd, diff, J);
+      for (int r = 0; r < 6; ++r) {
+        double acc = 0.0;
+        for (int c = 0; c < 6; ++c) acc += J[r + 6 * c] * tw[c];
+        col[r] = acc;
+      }
+    }
+    // weights: stage dt w; impulse stage w_i; terminal stage w_f; ParNMPC's last stage carries stage AND terminal cost (terminal_parnmpc.hxx),
+    // its terminal part is not in the line search's merit (line_search.cpp:228-237)
+    const bool last = bwd && P->has_terminal && pos == M - 2;
+    for (int k = 0; k < 6; ++k) {
+      const double wm = nd->kind == 1 ? P->task_weighti[k] : (nd->kind == 4 ? P->task_weightf[k] : dt * P->task_weight[k]);
+      const double wk = wm + (last ? P->task_weightf[k] : 0.0);
+      lq += wk * diff[k] * col[k];
+      cost += 0.5 * wm * diff[k] * diff[k];
+      if (lane < NV) xx[L::X_TJ + k * NV + lane] = col[k];
+      if (lane == 0) xx[L::X_TW + k] = residual ? 0.0 : wk;
+    }
+  } else {
+    for (int e = lane; e < 6 * NV + 6; e += 64) xx[L::X_TJ + e] = 0.0;
   }
   if (lane < NV) xx[L::X_LQ + lane] = lq;
-  if (lane == 0) { xx[L::X_ERR] = err; xx[L::X_VIOL] = viol; }
+  if (lane == 0) { xx[L::X_ERR] = err; xx[L::X_VIOL] = viol; xx[L::X_COST] = cost; }
 }
 
-// Qqq += sum_c w_c J_c^T J_c on the kkt record the condensation kernel has just written
+// Qqq += sum_c w_c J_c^T J_c + JJ^T diag(w) JJ on the kkt record the condensation kernel has just written (the terminal record included)
 template <typename D>
 __global__ __launch_bounds__(64) void ocp_ext_hessian_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
@@ -139,20 +192,22 @@ __global__ __launch_bounds__(64) void ocp_ext_hessian_kernel(OcpBuffers B) {
   const long b = unit / M;
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  if (nd->kind == 1 || nd->kind == 4) return;
+  if (P->backward_euler && pos == M - 1) return;
   const long rec = b * P->NS + nd->slot;
   const double* __restrict__ xx = B.ext + rec * L::EXT;
   double* __restrict__ kk = B.kkt + rec * L::KKT;
-  double w[NC];
+  double w[NC + 6];
   bool any = false;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) { w[c] = xx[L::X_W + c]; any = any || w[c] != 0.0; }
+  for (int c = 0; c < NC + 6; ++c) { w[c] = c < NC ? xx[L::X_W + c] : xx[L::X_TW + c - NC]; any = any || w[c] != 0.0; }
   if (!any) return;
   for (int e = threadIdx.x; e < NV * NV; e += 64) {
     const int c2 = e / NV, r = e - c2 * NV;
     double acc = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc += w[c] * xx[L::X_CDJ + c * NV + r] * xx[L::X_CDJ + c * NV + c2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += w[NC + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c2];
     kk[L::K_QXX + r + NX * c2] += acc;
   }
 }

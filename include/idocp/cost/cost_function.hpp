@@ -41,7 +41,7 @@ inline void keepTaskFields(const idocp_cost_t& from, idocp_cost_t& to) {
   to.task_dim = from.task_dim; to.task_joint = from.task_joint; to.task_time_varying = from.task_time_varying;
   for (int k = 0; k < 9; ++k) to.task_frame_R[k] = from.task_frame_R[k];
   for (int k = 0; k < 3; ++k) to.task_frame_p[k] = from.task_frame_p[k];
-  for (int k = 0; k < 6; ++k) { to.task_weight[k] = from.task_weight[k]; to.task_weightf[k] = from.task_weightf[k]; }
+  for (int k = 0; k < 6; ++k) { to.task_weight[k] = from.task_weight[k]; to.task_weightf[k] = from.task_weightf[k]; to.task_weighti[k] = from.task_weighti[k]; }
   for (int k = 0; k < 12; ++k) to.task_ref[k] = from.task_ref[k];
 }
 

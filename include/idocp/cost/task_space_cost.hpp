@@ -43,7 +43,7 @@ class TaskSpace3DCost final : public CostFunctionComponentBase {
   void set_q_3d_ref(const Eigen::Vector3d& q_3d_ref) { for (int k = 0; k < 3; ++k) c_.task_ref[9 + k] = q_3d_ref[k]; }
   void set_q_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weight[k] = w[k]; }
   void set_qf_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weightf[k] = w[k]; }
-  void set_qi_3d_weight(const Eigen::Vector3d&) {}      // impulse stages do not exist on a fixed-base horizon
+  void set_qi_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weighti[k] = w[k]; }
   bool exportTo(idocp_cost_t& cost) const override { keepTaskFields(c_, cost); return true; }
  private:
   idocp_cost_t c_;
@@ -58,7 +58,7 @@ class TaskSpace6DCost final : public CostFunctionComponentBase {
   }
   void set_q_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weight, position_weight, rotation_weight); }
   void set_qf_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weightf, position_weight, rotation_weight); }
-  void set_qi_6d_weight(const Eigen::Vector3d&, const Eigen::Vector3d&) {}
+  void set_qi_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weighti, position_weight, rotation_weight); }
   bool exportTo(idocp_cost_t& cost) const override { keepTaskFields(c_, cost); return true; }
  private:
   idocp_cost_t c_;
@@ -81,7 +81,7 @@ class TimeVaryingTaskSpace3DCost final : public CostFunctionComponentBase {
   void set_ref(const std::shared_ptr<TimeVaryingTaskSpace3DRefBase>& ref) { ref_ = ref; }
   void set_q_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weight[k] = w[k]; }
   void set_qf_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weightf[k] = w[k]; }
-  void set_qi_3d_weight(const Eigen::Vector3d&) {}
+  void set_qi_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weighti[k] = w[k]; }
   bool exportTo(idocp_cost_t& cost) const override { keepTaskFields(c_, cost); return true; }
   bool stageRefs(const double t, const double dt, const int N, std::vector<double>& refs) const override {
     refs.assign((size_t)(N + 1) * 12, 0.0);
@@ -116,7 +116,7 @@ class TimeVaryingTaskSpace6DCost final : public CostFunctionComponentBase {
   void set_ref(const std::shared_ptr<TimeVaryingTaskSpace6DRefBase>& ref) { ref_ = ref; }
   void set_q_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weight, position_weight, rotation_weight); }
   void set_qf_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weightf, position_weight, rotation_weight); }
-  void set_qi_6d_weight(const Eigen::Vector3d&, const Eigen::Vector3d&) {}
+  void set_qi_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weighti, position_weight, rotation_weight); }
   bool exportTo(idocp_cost_t& cost) const override { keepTaskFields(c_, cost); return true; }
   bool stageRefs(const double t, const double dt, const int N, std::vector<double>& refs) const override {
     refs.assign((size_t)(N + 1) * 12, 0.0);

@@ -114,7 +114,9 @@ typedef struct idocp_cost {
   int use_time_varying_ref;
   double tv_t_begin, tv_t_end;
   /* TaskSpace3DCost / TaskSpace6DCost and their TimeVarying variants (src/cost/task_space_{3d,6d}_cost.cpp,
-   * time_varying_task_space_{3d,6d}_cost.cpp) on one frame of a FIXED-BASE robot (UnOCPSolver).
+   * time_varying_task_space_{3d,6d}_cost.cpp) on one frame: of a fixed-base robot (UnOCPSolver, also the TimeVarying variants) or of a
+   * floating-base one (OCPSolver on any chain, ParNMPCSolver on event-free horizons; constant reference; the frame sits on the base
+   * or on a link of a leg).  SURVEY 8f row 3.
    * task_dim 0: none; 3: l = 1/2 dt |p_frame(q) - p_ref|^2_W; 6: l = 1/2 dt |log6(M_ref^-1 M_frame(q))|^2_W with the
    * Gauss-Newton Hessian of the reference.  The frame is given by its parent joint and its placement in that joint's
    * frame (idocp_model_frame_placement). */
@@ -127,6 +129,7 @@ typedef struct idocp_cost {
   double task_weightf[6];        /* terminal weights (qf_3d_weight / qf_6d_weight), same layout */
   double task_ref[12];           /* constant reference: rotation (row-major, 9) then position (3); 3D uses the position only */
   int task_time_varying;         /* != 0: the references of the N + 1 stages come from idocp_unocp_set_task_refs */
+  double task_weighti[6];        /* impulse-stage weights (qi_3d_weight / qi_6d_weight), same layout: OCPSolver on chains with impulse stages */
 } idocp_cost_t;
 
 /*

@@ -50,9 +50,26 @@ int ContactSequenceC::eventOfLift(int k) const {
   return -1;
 }
 
+// TaskSpace3DCost / TaskSpace6DCost on the floating-base solvers (task_space_3d_cost.cpp:60-157, task_space_6d_cost.cpp:68-178): a copy of the
+// robot with the task frame as its contact 0 evaluates cost = 1/2 sum w diff^2, grad = JJ^T (w o diff), hess = JJ^T diag(w) JJ
+static Robot makeTaskRobot(const RModel& model, const RCost& cost) {
+  if (cost.task_dim == 0) return Robot(model);
+  if (cost.task_dim != 3 && cost.task_dim != 6) throw std::invalid_argument("task_dim must be 0, 3 or 6");
+  if (cost.task_time_varying) throw std::logic_error("TimeVarying task-space costs are restated for UnOCPSolver only");
+  RModel mt = model;
+  mt.contact_frame_id[0] = -1; mt.contact_joint[0] = cost.task_joint;
+  for (int k2 = 0; k2 < 9; ++k2) mt.contact_R[0][k2] = cost.task_frame_R[k2];
+  for (int k2 = 0; k2 < 3; ++k2) mt.contact_p[0][k2] = cost.task_frame_p[k2];
+  return Robot(mt);
+}
+static void taskTerms(const Robot& task_robot, const RCost& cost, const real* w, const Mat& q, real& c, Mat& g, Mat& H) {
+  Robot rb = task_robot;
+  rb.taskSpaceTerms(cost.task_dim, cost.task_ref, w, q, c, g, H);
+}
+
 OCPSolver::OCPSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
                      int max_num_impulse)
-    : robot(model), cost(cost_), cons(constraints), N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts),
+    : robot(model), task_robot(makeTaskRobot(model, cost_)), cost(cost_), cons(constraints), N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts),
       max_events_(max_num_impulse), T_(T), dt_(T / N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
@@ -406,6 +423,8 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     R.la[r] += dt * wa[r] * si.a[r];
   }
   if (!impulse) for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
+  Mat task_H;
+  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, impulse ? cost.task_weighti : cost.task_weight, si.q, c_, g_, task_H); R.lq += dt * g_; }      // (dt = 1 on impulse stages)
   {
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
@@ -557,6 +576,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     M.Qxx.addBlock(0, 0, Jq.t() * WJ, dt);
     for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += dt * wv[r]; M.Qaa_diag[r] += dt * wa[r]; }
     if (!impulse) for (int r = 0; r < nu; ++r) M.Quu_full(kP + r, kP + r) += dt * cost.u_weight[r];
+    if (cost.task_dim) M.Qxx.addBlock(0, 0, task_H, dt);
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += dt * wf[c][r]; st += 3; }
   }
@@ -673,6 +693,8 @@ void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool r
   const real v_ref0 = cost.use_trotting_ref ? cost.step_length / cost.t_period : cost.v_ref[0];
   const real vs = vRefScale(cost, nd.t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (sN.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
+  Mat task_H;
+  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, cost.task_weightf, sN.q, c_, g_, task_H); R.lq += g_; }
   // linearizeForwardEulerTerminal (state_equation.hxx:66-83)
   Mat Fqq_prev; robot.dSubtractdConfigurationMinus(q_prev, sN.q, Fqq_prev);
   M.Fqq_prev6 = Fqq_prev.block(0, 0, 6, 6);
@@ -686,6 +708,7 @@ void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool r
   Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.qf_weight[r];
   M.Qxx.addBlock(0, 0, Jq.t() * WJ);
   for (int r = 0; r < nv; ++r) M.Qxx(nv + r, nv + r) += cost.vf_weight[r];
+  if (cost.task_dim) M.Qxx.addBlock(0, 0, task_H);
 }
 
 // OCPLinearizer::runParallel (ocp_linearizer.hxx:113-228); q_prev (:231-248) is the chain predecessor's q
@@ -1134,6 +1157,7 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
         l += cost.qf_weight[r] * qdiff[r] * qdiff[r] + cost.vf_weight[r] * dvr * dvr;
       }
       cost_sum += 0.5 * l;
+      if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, cost.task_weightf, x.q, c_, g_, H_); cost_sum += c_; }
       continue;
     }
     const bool impulse = nd.kind == NodeC::Impulse;
@@ -1151,6 +1175,7 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
       l += wq[r] * qdiff[r] * qdiff[r] + wv[r] * dvr * dvr + wa[r] * x.a[r] * x.a[r];
     }
     if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
+    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, impulse ? cost.task_weighti : cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) l += wf[c][k2] * (x.f[c][k2] - rf[c][k2]) * (x.f[c][k2] - rf[c][k2]);
     real barrier = 0, primal = 0;
     for (int c = 0; c < NCOMP; ++c) {
@@ -1205,12 +1230,13 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
 // =============================================================================================== ParNMPC ====
 ParNMPCSolver::ParNMPCSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
                              int max_num_impulse)
-    : robot(model), cost(cost_), cons(constraints), next_s(robot), next_snew(robot), prev_s(robot), prev_snew(robot),
+    : robot(model), task_robot(makeTaskRobot(model, cost_)), cost(cost_), cons(constraints), next_s(robot), next_snew(robot), prev_s(robot), prev_snew(robot),
       N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), max_events_(max_num_impulse), T_(T), dt_(T / N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (max_num_impulse < 0) throw std::out_of_range("invalid value: max_num_impulse must be non-negative!");
   if (!robot.hasFloatingBase()) throw std::logic_error("ParNMPCSolver oracle: floating-base robots only");
+  if (cost.task_dim != 0 && max_num_impulse > 0) throw std::logic_error("ParNMPC oracle: task-space costs on event-free horizons only");
   const int ns = nslots();
   s.assign(ns, SplitSolutionC(robot)); s_new = s;
   d.assign(ns, SplitDirectionC(robot));
@@ -1538,6 +1564,12 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     R.la[r] += dt * cost.a_weight[r] * si.a[r];
   }
   for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
+  Mat task_H, task_Hf;
+  if (cost.task_dim) {
+    real c_; Mat g_;
+    taskTerms(task_robot, cost, cost.task_weight, si.q, c_, g_, task_H); R.lq += dt * g_;
+    if (terminal) { taskTerms(task_robot, cost, cost.task_weightf, si.q, c_, g_, task_Hf); R.lq += g_; }
+  }
   {
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
@@ -1669,6 +1701,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     M.Qxx.addBlock(0, 0, Jq.t() * WJ, dt);
     for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += dt * cost.v_weight[r]; M.Qaa_diag[r] += dt * cost.a_weight[r]; }
     for (int r = 0; r < nu; ++r) M.Quu_full(kP + r, kP + r) += dt * cost.u_weight[r];
+    if (cost.task_dim) { M.Qxx.addBlock(0, 0, task_H, dt); if (terminal) M.Qxx.addBlock(0, 0, task_Hf); }
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += dt * cost.f_weight[c][r]; st += 3; }
     if (terminal) {
@@ -2297,6 +2330,7 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       else l += cost.q_weight[r] * qdiff[r] * qdiff[r] + cost.v_weight[r] * dvr * dvr + cost.a_weight[r] * x.a[r] * x.a[r];
     }
     if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
+    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }      // (stage part only: no terminal cost in the merit)
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) {
       const real w = impulse ? cost.fi_weight[c][k2] : cost.f_weight[c][k2], fr = impulse ? cost.fi_ref[c][k2] : cost.f_ref[c][k2];
       l += w * (x.f[c][k2] - fr) * (x.f[c][k2] - fr);

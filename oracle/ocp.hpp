@@ -154,6 +154,7 @@ class OCPSolver {
   int dimc() const;
   const ContactStatus& nodeContacts(int p) const;     // contact (or impulse) status a node is linearised with
   Robot robot;
+  Robot task_robot;                          // the robot with the task frame of a TaskSpace3D / 6D cost as its contact 0
   RCost cost;
   idocp_constraints_t cons;
   ContactSequenceC seq;
@@ -256,6 +257,7 @@ class ParNMPCSolver {
   int slotOf(int kind, int index) const;
   int nslots() const { return N_ideal_ + 3 * max_events_; }
   Robot robot;
+  Robot task_robot;                          // the robot with the task frame of a TaskSpace3D / 6D cost as its contact 0
   RCost cost;
   idocp_constraints_t cons;
   ContactStatus contact_status;      // the first contact phase (the only one of an event-free horizon)

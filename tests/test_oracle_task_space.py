@@ -130,3 +130,44 @@ def test_facade_components_export_the_reference_layout(tmp_path):
     R = [0, 0, 1, 0, 1, 0, -1, 0, 0]
     assert rec["tv6d"]["weight"] == [100] * 3 + [1000] * 3 and rec["tv6d"]["weightf"] == [1] * 3 + [10] * 3
     assert np.allclose(rec["tv6d"]["refs"], R + [0.5, 0.1, 0.7] + R + [0.5, 0.15, 0.7] + R + [0.5, 0.2, 0.7], atol=1e-15)
+
+
+def test_task_space_cost_on_the_floating_base_oracle_converges():
+    """TaskSpace3DCost on a foot-less frame of ANYmal (the thigh of RH) in OCPSolver's oracle: stage, terminal weights; the SQP converges
+    and the frame moves towards its reference."""
+    import ctypes as C
+    from idocp_amd import capi
+    from idocp_amd.workloads import ANYMAL_URDF
+    from helpers import ANYMAL_Q_STANDING, OracleOCP, anymal_contact_points, anymal_model, anymal_problem
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    lib = capi.lib()
+    fid = lib.idocp_model_frame_id(ANYMAL_URDF.encode(), b"RH_THIGH")
+    joint = C.c_int()
+    R, p = (C.c_double * 9)(), (C.c_double * 3)()
+    assert lib.idocp_model_frame_placement(ANYMAL_URDF.encode(), fid, C.byref(joint), R, p) == 0
+    cost.task_dim, cost.task_joint = 3, joint.value
+    for k in range(9):
+        cost.task_frame_R[k] = R[k]
+        cost.task_ref[k] = 1.0 if k % 4 == 0 else 0.0
+    for k in range(3):
+        cost.task_frame_p[k] = p[k]
+        cost.task_weight[k] = 200.0
+        cost.task_weightf[k] = 200.0
+    results = []
+    for shift in (0.0, 0.03):
+        for k, x in enumerate((-0.277 , -0.116 + shift, 0.4792)):       # near the hip of RH in the standing pose, then 3 cm to the side
+            cost.task_ref[9 + k] = x
+        o = OracleOCP(m, cost, cons, 0.5, 20)
+        q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+        o.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+        o.set_solution("q", q); o.set_solution("v", v)
+        o.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        o.init_constraints(0.0)
+        e0 = o.kkt_error(0.0, q, v)
+        for _ in range(40):
+            assert o.update(0.0, q, v) == 0
+        assert o.kkt_error(0.0, q, v) < 1e-8 * max(1.0, e0)
+        results.append(o.get("q")[-1].copy())
+    # the base follows the reference: it ends further in +y when the reference is shifted in +y
+    assert results[1][1] - results[0][1] > 0.005
