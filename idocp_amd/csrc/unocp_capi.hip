@@ -159,6 +159,10 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
   if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
   if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }      // constraint_component_base.hxx:10-24
+  if (constraints->joint_acceleration_lower_limit || constraints->joint_acceleration_upper_limit || constraints->contact_distance) {
+    set_last_error("unsupported constraints: JointAccelerationLowerLimit / UpperLimit and ContactDistance are carried by the floating-base solvers (OCPSolver, ParNMPCSolver) only");
+    return IDOCP_E_UNSUPPORTED;
+  }
   if (!(constraints->fraction_to_boundary_rate > 0 && constraints->fraction_to_boundary_rate <= 1)) {
     set_last_error("invalid value: fraction_to_boundary_rate must be in (0, 1]!"); return IDOCP_E_ARG;
   }
