@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dev_dense.hpp"
+#include "dev_rnea_analytic.hpp"
 #include "unocp_launch.hpp"
 
 namespace idocp_dev {
@@ -72,12 +73,19 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
 // column k of dt JJ^T W JJ to Qqq.
 // ZAX: every joint axis of the chain is +z (iiwa14): the compile-time variant of the rigid-body sweep (dev_rbd.hpp).
 template <int NV, int MODE, bool BWD = false, bool TASK = false, bool ZAX = false>
-__global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
+__global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
                                                           const double* __restrict__ v0 = nullptr) {
   using L = UnLayout<NV>;
   constexpr int LPS = 3 * NV;        // lanes per stage
   constexpr int SPW = 64 / LPS;      // stages per wavefront
   __shared__ double s_dID[SPW][3][NV * NV];
+  __shared__ RneaAnalyticLds<NV> s_ra[SPW];
+  __shared__ ChainConsts<NV> s_model;
+  // the stage group's records (solution of the stage and of its successor -- contiguous --, slack, dual) arrive with 16-byte loads issued
+  // back to back at the top of the kernel: round 2 read them field by field where they were needed, and the wavefronts spent 57 % of
+  // their cycles in s_waitcnt (SQ_WAIT_ANY, profiles/r03_iiwa14_pmc_sq.txt)
+  constexpr int IN_SN = L::SOL, IN_SLACK = 2 * L::SOL, IN_DUAL = 2 * L::SOL + L::CON, IN_LEN = 2 * L::SOL + 2 * L::CON;
+  __shared__ __attribute__((aligned(16))) double s_in[SPW][IN_LEN];
   __shared__ double s_tJ[TASK ? SPW : 1][6][NV];     // TASK: the columns JJ[:, k] of the stage group
   __shared__ double s_err[SPW][LPS];
   __shared__ double s_cs[SPW][NV][2];
@@ -98,10 +106,33 @@ __global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const 
   if (unit >= total) unit = total - 1;
   const long b = unit / N;
   const int i = (int)(unit - b * N);
-  const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
-  const double* __restrict__ sn = s + L::SOL;
-  const double* __restrict__ slack = B.slack + unit * L::CON;
-  const double* __restrict__ dual = B.dual + unit * L::CON;
+  const double* __restrict__ s_g = B.sol + (b * (N + 1) + i) * L::SOL;
+  {
+    typedef double in_d2 __attribute__((ext_vector_type(2)));
+    static_assert(L::SOL % 2 == 0 && L::CON % 2 == 0 && 2 * L::SOL / 2 <= 64 && L::CON / 2 <= 64, "one 16-byte piece per lane and record");
+    in_d2 rs[SPW], rl[SPW], rd[SPW];
+    const long unit0 = (long)blockIdx.x * SPW;
+#pragma unroll
+    for (int gg = 0; gg < SPW; ++gg) {
+      long u = unit0 + gg; if (u >= total) u = total - 1;
+      const long bb = u / N;
+      const double* sg = B.sol + (bb * (N + 1) + (u - bb * N)) * L::SOL;
+      rs[gg] = reinterpret_cast<const in_d2*>(sg)[lane < L::SOL ? lane : 0];                       // s and sn: 2 SOL doubles = SOL pieces
+      rl[gg] = reinterpret_cast<const in_d2*>(B.slack + u * L::CON)[lane < L::CON / 2 ? lane : 0];
+      rd[gg] = reinterpret_cast<const in_d2*>(B.dual + u * L::CON)[lane < L::CON / 2 ? lane : 0];
+    }
+    s_model.load(B.model, lane, 64);
+#pragma unroll
+    for (int gg = 0; gg < SPW; ++gg) {
+      if (lane < L::SOL) reinterpret_cast<in_d2*>(&s_in[gg][0])[lane] = rs[gg];
+      if (lane < L::CON / 2) { reinterpret_cast<in_d2*>(&s_in[gg][IN_SLACK])[lane] = rl[gg]; reinterpret_cast<in_d2*>(&s_in[gg][IN_DUAL])[lane] = rd[gg]; }
+    }
+    WAVE_SYNC();
+  }
+  const double* s = &s_in[g][0];
+  const double* sn = &s_in[g][IN_SN];
+  const double* slack = &s_in[g][IN_SLACK];
+  const double* dual = &s_in[g][IN_DUAL];
 
   // ---- inverse dynamics with one tangent per lane (registers only) ----
   // cos/sin of the joint angles are shared by the stage group through LDS
@@ -113,8 +144,10 @@ __global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const 
   WAVE_SYNC();
   // each lane writes its column d tau / d seed straight into the LDS copy of
   // dID/d(q|v|a); the seed-0 lane also writes the nominal tau
-  rneaChain<NV, ZAX>(B.model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, (g0 < SPW) && seed == 0, &s_tau[g][0],
-                     (g0 < SPW) ? &s_dID[g][kind][k * NV] : &s_dummy[0]);
+  // (round 3: ONE analytic evaluation shared by the 3 NV lanes of the stage group, dev_rnea_analytic.hpp, instead of a forward-mode
+  //  sweep per lane -- rneaChain<Dual>, kept in dev_rbd.hpp for the kernels that want a single tangent)
+  rneaDerivativesChain<NV, ZAX>(&s_model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, g0 < SPW, s_ra[g], &s_dID[g][0][0], &s_dID[g][1][0],
+                                &s_dID[g][2][0], &s_tau[g][0], [] { __syncthreads(); });
   WAVE_SYNC();
   double tau_d[NV], ID[NV];
 #pragma unroll
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const 
       x = qk; w = P->q_weight[k]; ref = P->q_ref[k];
       if (BWD) {
         l = (term ? 0.0 : lmdn) - lmd;
-        F = (i > 0 ? (s - L::SOL)[L::S_Q + k] : q0[b * NV + k]) - qk + dt * vk;
+        F = (i > 0 ? (s_g - L::SOL)[L::S_Q + k] : q0[b * NV + k]) - qk + dt * vk;
       } else {
         l = lmdn - lmd;
         F = qk - sn[L::S_Q + k] + dt * vk;
@@ -187,7 +220,7 @@ __global__ __launch_bounds__(64, 3) void un_linearize_kernel(UnBuffers B, const 
       x = vk; w = P->v_weight[k]; ref = P->v_ref[k];
       if (BWD) {
         l = dt * lmd - gmm + (term ? 0.0 : gmmn);
-        F = (i > 0 ? (s - L::SOL)[L::S_V + k] : v0[b * NV + k]) - vk + dt * ak;
+        F = (i > 0 ? (s_g - L::SOL)[L::S_V + k] : v0[b * NV + k]) - vk + dt * ak;
       } else {
         l = dt * lmdn + gmmn - gmm;
         F = vk + dt * ak - sn[L::S_V + k];
