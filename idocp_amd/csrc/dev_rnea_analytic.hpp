@@ -64,7 +64,7 @@ __device__ __forceinline__ Mot ldm(const double* p) { Mot r; r.l = ldv(p); r.a =
 template <int NJ> struct RneaAnalyticLds {
   union {
     double comp[NJ][ra::CREC];
-    double pub[3][NJ][18];
+    double pub[NJ][42];      // per joint: S, dAdq, dVdq, dAdv, dFdq (corrected), dFdv, dFda -- each written by the lane of the kind that owns it
   };
 };
 // The constants of the chain the recursion reads, compact (a workgroup keeps one copy in LDS: from the DevModel in global memory every
@@ -202,9 +202,14 @@ __device__ __forceinline__ void rneaDerivativesChain(const Model* m, const doubl
     own = YS;
     P1 = YS; P2 = S; P3.l = v3(0, 0, 0); P3.a = v3(0, 0, 0);
   }
+  // offsets of (P1, P2, P3) of a kind inside the joint's published block
+  const int o1 = kind == 0 ? 24 : (kind == 1 ? 30 : 36), o2 = kind == 0 ? 6 : (kind == 1 ? 18 : 0), o3 = kind == 0 ? 12 : 0;
   if (valid) {
-    double* o = L.pub[kind][k];
-    stm(o, P1); stm(o + 6, P2); stm(o + 12, P3);
+    double* o = L.pub[k];
+    stm(o + o1, P1);
+    if (kind < 2) stm(o + o2, P2);
+    if (kind == 0) stm(o + o3, P3);             // (S: written by the kind-1 lane as its P3 at offset 0 -- see o3 -- and read by kind 2 as P2)
+    if (kind == 1) stm(o, S);
     if (kind == 0) tau[k] = dot6(S, fc);
   }
   sync();
@@ -212,11 +217,11 @@ __device__ __forceinline__ void rneaDerivativesChain(const Model* m, const doubl
   double* dID = kind == 0 ? dID0 : (kind == 1 ? dID1 : dID2);
 #pragma unroll 1
   for (int c = 0; c < NJ; ++c) {
-    const double* o = L.pub[kind][c];
+    const double* o = L.pub[c];
     double val;
     if (c == k) val = dot6(S, own);
-    else if (c > k) val = dot6(S, ldm(o));
-    else val = dot6(YS, ldm(o + 6)) + dot6(BtS, ldm(o + 12));
+    else if (c > k) val = dot6(S, ldm(o + o1));
+    else val = dot6(YS, ldm(o + o2)) + (kind < 2 ? dot6(BtS, ldm(o + o3)) : 0.0);
     if (valid) dID[c * NJ + k] = val;
   }
 }

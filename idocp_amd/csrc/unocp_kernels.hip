@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   __shared__ double s_err[SPW][LPS];
   __shared__ double s_cs[SPW][NV][2];
   __shared__ double s_tau[SPW][NV];
+  __shared__ double s_lu[SPW][NV], s_quu[SPW][NV];      // torque-level rows of the stage group: lu and diag(Quu)
   __shared__ double s_dummy[NV];
   const UnProblem* __restrict__ P = B.prob;
   const int N = P->N;
@@ -170,10 +171,12 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
 
   // ---- torque-level rows: needed by every lane (lu_condensed couples all rows) ----
   // UnconstrainedDynamics::linearize/condense (unconstrained_dynamics.hxx:55-94)
+  // (each row is evaluated ONCE, by the a-seed lane of its joint, and shared through LDS: with every lane evaluating all NV rows the
+  //  28 FP64 divisions of the IPM terms were a third of the kernel's vector instructions)
   double lu_c[NV], quu[NV], lu_mine = 0.0;
   double e_con = 0.0;   // MODE 1: squared IPM residuals owned by this lane
-#pragma unroll
-  for (int r = 0; r < NV; ++r) {
+  if (g0 < SPW && kind == 2) {
+    const int r = k;
     const double u = s[L::S_U + r];
     double lu = dt * P->u_weight[r] * (u - P->u_ref[r]) - dt * s[L::S_BETA + r];
     double h = dt * P->u_weight[r];
@@ -187,15 +190,17 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
         if (MODE == 0) {
           lu += sgn * dt * (du * row.residual - row.duality) / sl;
           h += dt * du / sl;
-        } else if (kind == 2 && k == r) {
+        } else {
           e_con += row.residual * row.residual + row.duality * row.duality;
         }
       }
     }
-    quu[r] = h;
-    lu_c[r] = lu + h * ID[r];
-    if (r == k) lu_mine = lu;
+    s_lu[g][r] = lu; s_quu[g][r] = h;
   }
+  WAVE_SYNC();
+#pragma unroll
+  for (int r = 0; r < NV; ++r) { quu[r] = s_quu[g][r]; lu_c[r] = s_lu[g][r] + quu[r] * ID[r]; }
+  lu_mine = s_lu[g][k];
 
   // ---- this lane's own gradient element: lq[k] / lv[k] / la[k] ----
   // cost (configuration_space_cost.cpp:292-310), dual residual, state equation
