@@ -16,32 +16,35 @@
 namespace idocp_dev {
 
 __host__ __device__ constexpr int roundUp16(int n) { return (n + 15) / 16 * 16; }
+// records of the fixed-base path: even length (16-byte accesses stay aligned), no padding to 128 bytes -- the kernels that stream them walk
+// consecutive records, and with seven joints the padding was 7.5 % of the bytes of a step (solution record: 49 -> 64 doubles)
+__host__ __device__ constexpr int roundUp2(int n) { return (n + 1) / 2 * 2; }
 
 template <int NV>
 struct UnLayout {
   // solution record  (SplitSolution, include/idocp/ocp/split_solution.hxx:10-31)
   static constexpr int S_LMD = 0, S_GMM = NV, S_Q = 2 * NV, S_V = 3 * NV, S_A = 4 * NV, S_U = 5 * NV, S_BETA = 6 * NV;
-  static constexpr int SOL = roundUp16(7 * NV);
+  static constexpr int SOL = roundUp2(7 * NV);
   // direction record (SplitDirection, split_direction.hxx:8-23): same field order with d-prefix
   // IPM rows: [q_lower, q_upper, v_lower, v_upper, u_lower, u_upper] x NV
   static constexpr int NC = 6 * NV;
-  static constexpr int CON = roundUp16(NC);
+  static constexpr int CON = roundUp2(NC);
   // condensed stage KKT (SplitUnKKTMatrix / SplitUnKKTResidual, split_unkkt_matrix.hxx:31-147,
   // split_unkkt_residual.hxx:29-103); only the blocks the Riccati step reads
   static constexpr int K_QAA = 0, K_QAQ = NV * NV, K_QAV = 2 * NV * NV, K_QQQ = 3 * NV * NV, K_QQV = 4 * NV * NV,
                        K_QVV = 5 * NV * NV, K_FQ = 6 * NV * NV, K_FV = K_FQ + NV, K_LA = K_FV + NV, K_LQ = K_LA + NV,
                        K_LV = K_LQ + NV;
-  static constexpr int KKT = roundUp16(6 * NV * NV + 5 * NV);
+  static constexpr int KKT = roundUp2(6 * NV * NV + 5 * NV);
   // inverse-dynamics cache needed by the expansion (UnconstrainedDynamics members,
   // unconstrained_dynamics.hpp): dID/dq, dID/dv, dID/da, ID, lu, diag(Quu)
   static constexpr int D_DQ = 0, D_DV = NV * NV, D_DA = 2 * NV * NV, D_ID = 3 * NV * NV, D_LU = D_ID + NV, D_QUU = D_LU + NV;
-  static constexpr int DYN = roundUp16(3 * NV * NV + 3 * NV);
+  static constexpr int DYN = roundUp2(3 * NV * NV + 3 * NV);
   // Riccati factorization (SplitRiccatiFactorization, split_riccati_factorization.hpp:15-134)
   static constexpr int R_PQQ = 0, R_PQV = NV * NV, R_PVV = 2 * NV * NV, R_SQ = 3 * NV * NV, R_SV = R_SQ + NV;
-  static constexpr int RIC = roundUp16(3 * NV * NV + 2 * NV);
+  static constexpr int RIC = roundUp2(3 * NV * NV + 2 * NV);
   // LQR policy (lqr_state_feedback_policy.hpp:11-28): K (NV x 2NV col-major), k
   static constexpr int G_K = 0, G_k = 2 * NV * NV;
-  static constexpr int GAIN = roundUp16(2 * NV * NV + NV);
+  static constexpr int GAIN = roundUp2(2 * NV * NV + NV);
   // UnParNMPC: the blocks of the per-stage KKT inverse the correction sweeps read (KKT ordering lmd, gmm | a, q, v;
   // split_unbackward_correction.hxx:72-104): TL = -S^-1 (NX x NX), TR = S^-1 F Q^-1 (NX x 3NV), BRC = the (q, v) columns
   // of the bottom-right block (3NV x NX); all column-major
