@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats -d $out -o ${wl}_trace -- python3 $R/bench.py -
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out -o ${wl}_fetch -- python3 $R/bench.py --workload $wl $extra --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $out/${wl}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out -o ${wl}_write -- python3 $R/bench.py --workload $wl $extra --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $out/${wl}_write.log 2>&1
 cd $R
-line=$(grep '^{"metric"' $out/${wl}_trace.log | tail -1)
+line=$(grep -o '{"metric".*' $out/${wl}_trace.log | tail -1)
 batch=$(echo "$line" | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['config']['batch_per_gpu'])")
 hor=$(echo "$line" | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['config']['horizon'])")
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $wl $extra --steps 5 --warmup 2 --no-cpu-baseline"; echo "# bench line: $line"; python3 profiles/summarize_rocpd.py $out/${wl}_trace_results.db; } > $out/r${rnd}_${wl}_kernel_trace.txt
