@@ -719,10 +719,10 @@ int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s
     if (P) {
       double* Pm = P + (size_t)i * nx * nx;
       for (int c = 0; c < nv; ++c) for (int rr = 0; rr < nv; ++rr) {
-        Pm[c * nx + rr] = r[L7::R_PQQ + c * nv + rr];              // Pqq
+        Pm[c * nx + rr] = r[L7::R_PQQ + L7::sym(rr, c)];           // Pqq (packed upper triangle)
         Pm[(nv + c) * nx + rr] = r[L7::R_PQV + c * nv + rr];       // Pqv
         Pm[c * nx + nv + rr] = r[L7::R_PQV + rr * nv + c];         // Pvq = Pqv^T
-        Pm[(nv + c) * nx + nv + rr] = r[L7::R_PVV + c * nv + rr];  // Pvv
+        Pm[(nv + c) * nx + nv + rr] = r[L7::R_PVV + L7::sym(rr, c)];  // Pvv
       }
     }
     if (s) { std::memcpy(s + (size_t)i * nx, r + L7::R_SQ, sizeof(double) * nv); std::memcpy(s + (size_t)i * nx + nv, r + L7::R_SV, sizeof(double) * nv); }

@@ -31,17 +31,21 @@ struct UnLayout {
   static constexpr int CON = roundUp2(NC);
   // condensed stage KKT (SplitUnKKTMatrix / SplitUnKKTResidual, split_unkkt_matrix.hxx:31-147,
   // split_unkkt_residual.hxx:29-103); only the blocks the Riccati step reads
-  static constexpr int K_QAA = 0, K_QAQ = NV * NV, K_QAV = 2 * NV * NV, K_QQQ = 3 * NV * NV, K_QQV = 4 * NV * NV,
-                       K_QVV = 5 * NV * NV, K_FQ = 6 * NV * NV, K_FV = K_FQ + NV, K_LA = K_FV + NV, K_LQ = K_LA + NV,
+  // The symmetric blocks (Qaa, Qqq, Qvv here; Pqq, Pvv below) travel as their UPPER triangle, column by column: entry (r, c), r <= c,
+  // at c (c + 1) / 2 + r  (round 3: 105 of the 492 doubles of the kkt + ric records were the mirror image of another 105)
+  static constexpr int NS = NV * (NV + 1) / 2;
+  __host__ __device__ static constexpr int sym(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
+  static constexpr int K_QAA = 0, K_QAQ = NS, K_QAV = K_QAQ + NV * NV, K_QQQ = K_QAV + NV * NV, K_QQV = K_QQQ + NS,
+                       K_QVV = K_QQV + NV * NV, K_FQ = K_QVV + NS, K_FV = K_FQ + NV, K_LA = K_FV + NV, K_LQ = K_LA + NV,
                        K_LV = K_LQ + NV;
-  static constexpr int KKT = roundUp2(6 * NV * NV + 5 * NV);
+  static constexpr int KKT = roundUp2(K_LV + NV);
   // inverse-dynamics cache needed by the expansion (UnconstrainedDynamics members,
   // unconstrained_dynamics.hpp): dID/dq, dID/dv, dID/da, ID, lu, diag(Quu)
   static constexpr int D_DQ = 0, D_DV = NV * NV, D_DA = 2 * NV * NV, D_ID = 3 * NV * NV, D_LU = D_ID + NV, D_QUU = D_LU + NV;
   static constexpr int DYN = roundUp2(3 * NV * NV + 3 * NV);
   // Riccati factorization (SplitRiccatiFactorization, split_riccati_factorization.hpp:15-134)
-  static constexpr int R_PQQ = 0, R_PQV = NV * NV, R_PVV = 2 * NV * NV, R_SQ = 3 * NV * NV, R_SV = R_SQ + NV;
-  static constexpr int RIC = roundUp2(3 * NV * NV + 2 * NV);
+  static constexpr int R_PQQ = 0, R_PQV = NS, R_PVV = R_PQV + NV * NV, R_SQ = R_PVV + NS, R_SV = R_SQ + NV;
+  static constexpr int RIC = roundUp2(R_SV + NV);
   // LQR policy (lqr_state_feedback_policy.hpp:11-28): K (NV x 2NV col-major), k
   static constexpr int G_K = 0, G_k = 2 * NV * NV;
   static constexpr int GAIN = roundUp2(2 * NV * NV + NV);

@@ -311,7 +311,10 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc += s_tJ[g][c][k1] * task_wc[c];
       }
-      if (active && dst >= 0) kk[dst + k * NV + k1] = acc;
+      if (active && dst >= 0) {
+        if (k1kind != kind) kk[dst + k * NV + k1] = acc;
+        else if (k1 <= k) kk[dst + k * (k + 1) / 2 + k1] = acc;       // diagonal block: its upper triangle
+      }
     }
   }
   if (active) {
@@ -425,7 +428,8 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
     if (active) {
 #pragma unroll
       for (int r = 0; r < NV; ++r) {
-        rr[L::R_PQQ + c * NV + r] = Pqq[r]; rr[L::R_PQV + c * NV + r] = Pqv[r]; rr[L::R_PVV + c * NV + r] = Pvv[r];
+        rr[L::R_PQV + c * NV + r] = Pqv[r];
+        if (r <= c) { rr[L::R_PQQ + L::sym(r, c)] = Pqq[r]; rr[L::R_PVV + L::sym(r, c)] = Pvv[r]; }
         pqq[c * NV + r] = Pqq[r]; pqv[c * NV + r] = Pqv[r]; pvv[c * NV + r] = Pvv[r];
       }
       rr[L::R_SQ + c] = sq; rr[L::R_SV + c] = sv;
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
     double Qaa[NV], Qaq[NV], Qav[NV], Qqq[NV], Qqv[NV], Qvv[NV], Fq[NV], Fv[NV];
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
-      Qaa[r] = kk[L::K_QAA + c * NV + r]; Qaq[r] = kk[L::K_QAQ + c * NV + r]; Qav[r] = kk[L::K_QAV + c * NV + r];
-      Qqq[r] = kk[L::K_QQQ + c * NV + r]; Qqv[r] = kk[L::K_QQV + c * NV + r]; Qvv[r] = kk[L::K_QVV + c * NV + r];
+      Qaa[r] = kk[L::K_QAA + L::sym(r, c)]; Qaq[r] = kk[L::K_QAQ + c * NV + r]; Qav[r] = kk[L::K_QAV + c * NV + r];
+      Qqq[r] = kk[L::K_QQQ + L::sym(r, c)]; Qqv[r] = kk[L::K_QQV + c * NV + r]; Qvv[r] = kk[L::K_QVV + L::sym(r, c)];
       Fq[r] = kk[L::K_FQ + r]; Fv[r] = kk[L::K_FV + r];
     }
     double la = kk[L::K_LA + c];
@@ -575,7 +579,8 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
 #pragma unroll
       for (int r = 0; r < NV; ++r) {
         pqq[c * NV + r] = Pqq[r]; pvv[c * NV + r] = Pvv[r];
-        rr[L::R_PQQ + c * NV + r] = Pqq[r]; rr[L::R_PQV + c * NV + r] = Pqv[r]; rr[L::R_PVV + c * NV + r] = Pvv[r];
+        rr[L::R_PQV + c * NV + r] = Pqv[r];
+        if (r <= c) { rr[L::R_PQQ + L::sym(r, c)] = Pqq[r]; rr[L::R_PVV + L::sym(r, c)] = Pvv[r]; }
         gg[L::G_K + c * NV + r] = Kq[r]; gg[L::G_K + NN + c * NV + r] = Kv[r];
       }
       rr[L::R_SQ + c] = sq; rr[L::R_SV + c] = sv;
@@ -670,8 +675,8 @@ __global__ __launch_bounds__(64) void un_expand_kernel(UnBuffers B) {
   double dlmd = -rr[L::R_SQ + r], dgmm = -rr[L::R_SV + r];
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
-    dlmd += rr[L::R_PQQ + c * NV + r] * dq[c] + rr[L::R_PQV + c * NV + r] * dv[c];
-    dgmm += rr[L::R_PQV + r * NV + c] * dq[c] + rr[L::R_PVV + c * NV + r] * dv[c];
+    dlmd += rr[L::R_PQQ + L::sym(r, c)] * dq[c] + rr[L::R_PQV + c * NV + r] * dv[c];
+    dgmm += rr[L::R_PQV + r * NV + c] * dq[c] + rr[L::R_PVV + L::sym(r, c)] * dv[c];
   }
   if (active) { dd[L::S_LMD + r] = dlmd; dd[L::S_GMM + r] = dgmm; }
   if (i == N) return;          // uniform within the 8-lane group; other groups continue
@@ -927,8 +932,8 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
     const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
     const int rr = bi <= bj ? ri : cj, cc = bi <= bj ? cj : ri;
     const int off = lo == 0 ? (hi == 0 ? L::K_QAA : (hi == 1 ? L::K_QAQ : L::K_QAV)) : (lo == 1 ? (hi == 1 ? L::K_QQQ : L::K_QQV) : L::K_QVV);
-    double val = kk[off + cc * NV + rr];
-    if (lo == hi && ri > cj) val = kk[off + ri * NV + cj];           // diagonal blocks: read the upper triangle only
+    const double val0 = lo == hi ? kk[off + L::sym(ri, cj)] : kk[off + cc * NV + rr];      // diagonal blocks: packed upper triangle
+    double val = val0;
     if ((i < N - 1 || !P->has_terminal) && bi >= 1 && bj >= 1) val += aux[(c - NV) * NX + (r - NV)];
     sQ[e] = val;
   }
