@@ -87,7 +87,7 @@ template <int NJ, bool ZAX, typename Model, typename Sync>
 __device__ __forceinline__ void rneaDerivativesChain(const Model* m, const double* cs, const double* qd,
                                                      const double* qdd, int kind, int k, bool valid,
                                                      RneaAnalyticLds<NJ>& L, double* dID0, double* dID1, double* dID2, double* tau,
-                                                     Sync sync) {
+                                                     Sync sync, double* kin_out = nullptr) {
   using namespace ra;
   // ---- walk to joint k: world placement, motion subspace, velocity / acceleration of body k and of its parent ----
   double Rw[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -124,6 +124,12 @@ __device__ __forceinline__ void rneaDerivativesChain(const Model* m, const doubl
       for (int e = 0; e < 9; ++e) Rk[e] = Rw[e];
     }
     vel = vn; acc = an;
+  }
+  // (for a task-space cost on the chain: the world placement of joint k and its motion subspace, 18 doubles)
+  if (kin_out) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) kin_out[e] = Rk[e];
+    stv(kin_out + 9, pk); stm(kin_out + 12, S);
   }
   // ---- body k: spatial inertia about the world origin, momentum, force, B ----
   double rec[CREC];

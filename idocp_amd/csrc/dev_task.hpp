@@ -28,8 +28,8 @@ struct TaskCost {
 
 // diff[6] and, for joint k, col[6] = JJ[:, k].  cs = {cos q_i, sin q_i}; ref = rotation (row-major) + position.
 // dim 3 leaves entries 3..5 zero, so that the callers always sum six weighted terms.
-template <int NJ>
-__device__ __forceinline__ void taskSpaceColumn(const DevModel* __restrict__ m, const TaskCost& tc, const double* cs,
+template <int NJ, typename Model>
+__device__ __forceinline__ void taskSpaceColumn(const Model* m, const TaskCost& tc, const double* cs,
                                                 const double* __restrict__ ref, int k, double* diff, double* col) {
   double oR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, op[3] = {0, 0, 0};
   double ak[3] = {0, 0, 0}, ok[3] = {0, 0, 0};

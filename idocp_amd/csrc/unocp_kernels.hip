@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   constexpr int IN_SN = L::SOL, IN_SLACK = 2 * L::SOL, IN_DUAL = 2 * L::SOL + L::CON, IN_LEN = 2 * L::SOL + 2 * L::CON;
   __shared__ __attribute__((aligned(16))) double s_in[SPW][IN_LEN];
   __shared__ double s_tJ[TASK ? SPW : 1][6][NV];     // TASK: the columns JJ[:, k] of the stage group
+  __shared__ double s_task[TASK ? SPW : 1][TASK ? 54 : 1];      // TASK: the frame's world placement (12), diff (6), Jlog6 (36)
   __shared__ double s_err[SPW][LPS];
   __shared__ double s_cs[SPW][NV][2];
   __shared__ double s_tau[SPW][NV];
@@ -147,8 +148,9 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   // dID/d(q|v|a); the seed-0 lane also writes the nominal tau
   // (round 3: ONE analytic evaluation shared by the 3 NV lanes of the stage group, dev_rnea_analytic.hpp, instead of a forward-mode
   //  sweep per lane -- rneaChain<Dual>, kept in dev_rbd.hpp for the kernels that want a single tangent)
+  double kin[TASK ? 18 : 1];        // TASK: world placement (R, p) of joint k and its motion subspace S = (p x w, w), from the walk
   rneaDerivativesChain<NV, ZAX>(&s_model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, g0 < SPW, s_ra[g], &s_dID[g][0][0], &s_dID[g][1][0],
-                                &s_dID[g][2][0], &s_tau[g][0], [] { __syncthreads(); });
+                                &s_dID[g][2][0], &s_tau[g][0], [] { __syncthreads(); }, TASK ? kin : nullptr);
   WAVE_SYNC();
   double tau_d[NV], ID[NV];
 #pragma unroll
@@ -157,8 +159,69 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   // ---- task-space cost: gradient element k and the weighted column dt W JJ[:, k] (kept by the kind-0 lanes) ----
   double task_g = 0.0, task_wc[6];
   if (TASK) {
+    // The frame's world placement, diff = log6(M_ref^-1 M_frame) and Jlog6 are evaluated ONCE per stage, by the q-seed lane of the
+    // frame's joint, out of the walk of the analytic recursion; every lane then turns its own motion subspace into its column
+    // JJ[:, k] = Jlog6 (R_f^T (S.l + S.a x p_f), R_f^T S.a)  (3D: the world-frame linear part).  Round 2 walked the chain a second
+    // time in every lane (taskSpaceColumn, dev_task.hpp -- still what the terminal and the line-search kernels use).
     double tdiff[6], tcol[6];
-    taskSpaceColumn<NV>(B.model, P->task, &s_cs[g][0][0], B.task_ref + 12 * i, k, tdiff, tcol);
+    {
+      const TaskCost& tc = P->task;
+      const double* __restrict__ ref = B.task_ref + 12 * i;
+      if (g0 < SPW && kind == 0 && k == tc.joint) {
+        double fR[9], fp[3], e[3];
+        lieMatmul3(kin, tc.R, fR);
+        lieMatvec3(kin, tc.p, fp);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { fp[r] += kin[9 + r]; e[r] = fp[r] - ref[9 + r]; }
+        double* o = s_task[g];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) o[r] = fR[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[9 + r] = fp[r];
+        if (tc.dim == 3) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { o[12 + r] = e[r]; o[15 + r] = 0.0; }
+        } else {
+          double Rd[9], pd[3], df[6], J[36];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rd[3 * r + c] = ref[r] * fR[c] + ref[3 + r] * fR[3 + c] + ref[6 + r] * fR[6 + c];
+            pd[r] = ref[r] * e[0] + ref[3 + r] * e[1] + ref[6 + r] * e[2];
+          }
+          lieLog6Jlog6(Rd, pd, df, J);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) o[12 + r] = df[r];
+#pragma unroll
+          for (int r = 0; r < 36; ++r) o[18 + r] = J[r];
+        }
+      }
+      WAVE_SYNC();
+      const double* o = s_task[g];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tdiff[r] = o[12 + r];
+      // world-frame velocity of the frame origin per unit rate of joint k: S.l + S.a x p_f; zero past the frame's joint
+      const bool moves = k <= tc.joint;
+      const double Sl[3] = {kin[12], kin[13], kin[14]}, Sa[3] = {kin[15], kin[16], kin[17]};
+      const double lw[3] = {Sl[0] + Sa[1] * o[11] - Sa[2] * o[10], Sl[1] + Sa[2] * o[9] - Sa[0] * o[11], Sl[2] + Sa[0] * o[10] - Sa[1] * o[9]};
+      if (tc.dim == 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { tcol[r] = moves ? lw[r] : 0.0; tcol[3 + r] = 0.0; }
+      } else {
+        double tw[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          tw[r] = o[r] * lw[0] + o[3 + r] * lw[1] + o[6 + r] * lw[2];
+          tw[3 + r] = o[r] * Sa[0] + o[3 + r] * Sa[1] + o[6 + r] * Sa[2];
+        }
+        const double* J = o + 18;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          tcol[r] = moves ? J[r] * tw[0] + J[r + 6] * tw[1] + J[r + 12] * tw[2] + J[r + 18] * tw[3] + J[r + 24] * tw[4] + J[r + 30] * tw[5] : 0.0;
+          tcol[3 + r] = moves ? J[3 + r + 18] * tw[3] + J[3 + r + 24] * tw[4] + J[3 + r + 30] * tw[5] : 0.0;
+        }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const double wc = P->task.weight[c] * tcol[c];
