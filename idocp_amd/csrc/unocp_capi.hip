@@ -159,8 +159,8 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
   if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
   if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }      // constraint_component_base.hxx:10-24
-  if (constraints->joint_acceleration_lower_limit || constraints->joint_acceleration_upper_limit || constraints->contact_distance) {
-    set_last_error("unsupported constraints: JointAccelerationLowerLimit / UpperLimit and ContactDistance are carried by the floating-base solvers (OCPSolver, ParNMPCSolver) only");
+  if (constraints->contact_distance) {
+    set_last_error("unsupported constraints: ContactDistance belongs to the floating-base solvers (a fixed-base chain has no contacts here)");
     return IDOCP_E_UNSUPPORTED;
   }
   if (!(constraints->fraction_to_boundary_rate > 0 && constraints->fraction_to_boundary_rate <= 1)) {
@@ -200,6 +200,11 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   if ((rc = allocBuf(h, &B.dir, nrec1 * L7::SOL))) return fail(rc);
   if ((rc = allocBuf(h, &B.slack, nrec0 * L7::CON))) return fail(rc);
   if ((rc = allocBuf(h, &B.dual, nrec0 * L7::CON))) return fail(rc);
+  B.slack_a = nullptr; B.dual_a = nullptr;
+  if (constraints->joint_acceleration_lower_limit || constraints->joint_acceleration_upper_limit) {      // rows of components 6, 7
+    if ((rc = allocBuf(h, &B.slack_a, nrec0 * 2 * model->nv))) return fail(rc);
+    if ((rc = allocBuf(h, &B.dual_a, nrec0 * 2 * model->nv))) return fail(rc);
+  }
   if ((rc = allocBuf(h, &B.kkt, nrec0 * L7::KKT))) return fail(rc);
   if ((rc = allocBuf(h, &B.dyn, nrec0 * L7::DYN))) return fail(rc);
   if ((rc = allocBuf(h, &B.ric, nrec1 * L7::RIC))) return fail(rc);
@@ -248,6 +253,9 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   }
   up.use_q_limits = constraints->joint_position_limits; up.use_v_limits = constraints->joint_velocity_limits;
   up.use_u_limits = constraints->joint_torque_limits;
+  up.use_a_lower = constraints->joint_acceleration_lower_limit ? 1 : 0;
+  up.use_a_upper = constraints->joint_acceleration_upper_limit ? 1 : 0;
+  for (int i = 0; i < IDOCP_MAX_NV; ++i) { up.a_min[i] = constraints->a_min[i]; up.a_max[i] = constraints->a_max[i]; }
   up.barrier = constraints->barrier; up.fraction_rate = constraints->fraction_to_boundary_rate;
   up.backward_euler = bwd;
   up.task.dim = cost->task_dim; up.task.joint = cost->task_joint;
@@ -753,6 +761,8 @@ int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, in
         if (h->cons.joint_position_limits && i + h->level_offset >= 2 && (s[L7::S_Q + r] < m.q_min[r] || s[L7::S_Q + r] > m.q_max[r])) bad = i;
         if (h->cons.joint_velocity_limits && i + h->level_offset >= 1 && (s[L7::S_V + r] < -m.v_max[r] || s[L7::S_V + r] > m.v_max[r])) bad = i;
         if (h->cons.joint_torque_limits && (s[L7::S_U + r] < -m.u_max[r] || s[L7::S_U + r] > m.u_max[r])) bad = i;
+        if (h->cons.joint_acceleration_lower_limit && s[L7::S_A + r] < h->cons.a_min[r]) bad = i;      // joint_acceleration_lower_limit.cpp:38-47
+        if (h->cons.joint_acceleration_upper_limit && s[L7::S_A + r] > h->cons.a_max[r]) bad = i;
       }
     }
     feasible[b] = bad < 0 ? 1 : 0;
@@ -763,7 +773,8 @@ int idocp_unocp_is_current_solution_feasible(idocp_unocp_t* h, int* feasible, in
 
 int idocp_unocp_dimc(const idocp_unocp_t* h) {
   if (!h) return 0;
-  return h->nv * 2 * ((h->cons.joint_position_limits ? 1 : 0) + (h->cons.joint_velocity_limits ? 1 : 0) + (h->cons.joint_torque_limits ? 1 : 0));
+  return h->nv * 2 * ((h->cons.joint_position_limits ? 1 : 0) + (h->cons.joint_velocity_limits ? 1 : 0) + (h->cons.joint_torque_limits ? 1 : 0)) +
+         h->nv * ((h->cons.joint_acceleration_lower_limit ? 1 : 0) + (h->cons.joint_acceleration_upper_limit ? 1 : 0));
 }
 
 // [N][dimc] with the enabled components in the reference's order; rows that are
@@ -776,15 +787,25 @@ int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance, double* slac
   HIP_TRY(hipMemcpyAsync(sl.data(), h->B.slack + (size_t)instance * N * L7::CON, sl.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(du.data(), h->B.dual + (size_t)instance * N * L7::CON, du.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const int use[3] = {h->cons.joint_position_limits, h->cons.joint_velocity_limits, h->cons.joint_torque_limits};
+  std::vector<double> sa, da;
+  if (h->B.slack_a) {
+    sa.resize((size_t)N * 2 * nv); da.resize(sa.size());
+    HIP_TRY(hipMemcpyAsync(sa.data(), h->B.slack_a + (size_t)instance * N * 2 * nv, sa.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(da.data(), h->B.dual_a + (size_t)instance * N * 2 * nv, da.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  const int use[8] = {h->cons.joint_position_limits, h->cons.joint_position_limits, h->cons.joint_velocity_limits, h->cons.joint_velocity_limits,
+                      h->cons.joint_torque_limits, h->cons.joint_torque_limits, h->cons.joint_acceleration_lower_limit, h->cons.joint_acceleration_upper_limit};
   for (int i = 0; i < N; ++i) {
     int off = 0;
-    for (int c = 0; c < 6; ++c) {
-      if (!use[c / 2]) continue;
+    for (int c = 0; c < 8; ++c) {
+      if (!use[c]) continue;
       const bool valid = (c < 2) ? i + h->level_offset >= 2 : ((c < 4) ? i + h->level_offset >= 1 : true);
       for (int r = 0; r < nv; ++r) {
-        if (slack) slack[(size_t)i * dimc + off + r] = valid ? sl[(size_t)i * L7::CON + c * nv + r] : 0.0;
-        if (dual) dual[(size_t)i * dimc + off + r] = valid ? du[(size_t)i * L7::CON + c * nv + r] : 0.0;
+        const double sv = c < 6 ? sl[(size_t)i * L7::CON + c * nv + r] : sa[(size_t)i * 2 * nv + (c - 6) * nv + r];
+        const double dv = c < 6 ? du[(size_t)i * L7::CON + c * nv + r] : da[(size_t)i * 2 * nv + (c - 6) * nv + r];
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? sv : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? dv : 0.0;
       }
       off += nv;
     }

@@ -70,6 +70,8 @@ struct UnProblem {
   double q_weight[IDOCP_MAX_NV], v_weight[IDOCP_MAX_NV], a_weight[IDOCP_MAX_NV], u_weight[IDOCP_MAX_NV];
   double qf_weight[IDOCP_MAX_NV], vf_weight[IDOCP_MAX_NV];
   double q_min[IDOCP_MAX_NV], q_max[IDOCP_MAX_NV], v_max[IDOCP_MAX_NV], u_max[IDOCP_MAX_NV];
+  double a_min[IDOCP_MAX_NV], a_max[IDOCP_MAX_NV];      // JointAccelerationLowerLimit / UpperLimit (components 6 / 7; rows in slack_a / dual_a)
+  int use_a_lower, use_a_upper;
   int use_q_limits, use_v_limits, use_u_limits;
   double barrier, fraction_rate;
   int backward_euler;     // UnParNMPC: stage i sits at t + (i + 1) dt, constraint time step i + 1, the last stage is terminal
@@ -88,6 +90,8 @@ struct UnBuffers {
   double* dir;       // [batch][N+1][SOL]
   double* slack;     // [batch][N][CON]
   double* dual;      // [batch][N][CON]
+  double* slack_a;   // [batch][N][2 NV]   rows of the acceleration limits (components 6, 7); nullptr unless one of them is in use
+  double* dual_a;    // [batch][N][2 NV]
   double* kkt;       // [batch][N][KKT]
   double* dyn;       // [batch][N][DYN]
   double* ric;       // [batch][N+1][RIC]

@@ -50,6 +50,8 @@ __device__ __forceinline__ double limitOf(const UnProblem* __restrict__ P, int c
     case 1: return P->q_max[k];
     case 2: return -P->v_max[k];
     case 3: return P->v_max[k];
+    case 6: return P->a_min[k];       // JointAccelerationLowerLimit / UpperLimit carry their own bounds
+    case 7: return P->a_max[k];
     case 4: return -P->u_max[k];
     default: return P->u_max[k];
   }
@@ -59,6 +61,8 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
   if (P->backward_euler) stage += 1 + P->stage_offset;     // UnParNMPC creates stage i with time step i + 1 (unparnmpc_solver.cpp:55-66)
   if (comp < 2) return P->use_q_limits && stage >= 2;
   if (comp < 4) return P->use_v_limits && stage >= 1;
+  if (comp == 6) return P->use_a_lower != 0;       // acceleration level: every stage
+  if (comp == 7) return P->use_a_upper != 0;
   return P->use_u_limits != 0;
 }
 
@@ -305,13 +309,13 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
       l += wf * (x - ref);
       h += wf;
     }
-    if (kind < 2) {
+    {      // own-row limits: position / velocity rows on the q / v seed lanes, acceleration rows (components 6, 7) on the a seed lanes
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
-        const int c = 2 * kind + cc;
+        const int c = kind < 2 ? 2 * kind + cc : 6 + cc;
         if (rowValid(P, c, i)) {
           const double sgn = (cc == 0) ? -1.0 : 1.0;
-          const double sl = slack[c * NV + k], du = dual[c * NV + k];
+          const double sl = c < 6 ? slack[c * NV + k] : B.slack_a[unit * 2 * NV + (c - 6) * NV + k], du = c < 6 ? dual[c * NV + k] : B.dual_a[unit * 2 * NV + (c - 6) * NV + k];
           const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, k), sl, du, P->barrier);
           l += sgn * dt * du;
           if (MODE == 0) {
@@ -759,12 +763,12 @@ __global__ __launch_bounds__(64) void un_expand_kernel(UnBuffers B) {
   const double* __restrict__ dual = B.dual + su * L::CON;
   double ps = 1.0, ds = 1.0;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < 8; ++c) {      // 6, 7: joint acceleration limits (rows in slack_a / dual_a, joint_acceleration_{lower,upper}_limit.cpp:78-93)
     if (!rowValid(P, c, i)) continue;
     const double sgn = (c & 1) ? 1.0 : -1.0;
-    const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
-    const double dx = (c < 2) ? dq[r] : ((c < 4) ? dv[r] : du);
-    const double sl = slack[c * NV + r], dl = dual[c * NV + r];
+    const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : (c < 6 ? s[L::S_U + r] : s[L::S_A + r]));
+    const double dx = (c < 2) ? dq[r] : ((c < 4) ? dv[r] : (c < 6 ? du : dd[L::S_A + r]));
+    const double sl = c < 6 ? slack[c * NV + r] : B.slack_a[su * 2 * NV + (c - 6) * NV + r], dl = c < 6 ? dual[c * NV + r] : B.dual_a[su * 2 * NV + (c - 6) * NV + r];
     const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
     const double dslack = -sgn * dx - row.residual;
     const double ddual = -(dl * dslack + row.duality) / sl;
@@ -829,8 +833,9 @@ __global__ __launch_bounds__(64) void un_integrate_kernel(UnBuffers B) {
     s[L::S_V + r] = v + ap * dv;
   }
   if (i == N) return;
+  const double a_old = s[L::S_A + r], da_dir = dd[L::S_A + r];
   if (active) {
-    s[L::S_A + r] += ap * dd[L::S_A + r];
+    s[L::S_A + r] = a_old + ap * da_dir;
     s[L::S_U + r] = u + ap * du;
     s[L::S_BETA + r] += ap * dd[L::S_BETA + r];
   }
@@ -838,16 +843,18 @@ __global__ __launch_bounds__(64) void un_integrate_kernel(UnBuffers B) {
   double* __restrict__ slack = B.slack + su * L::CON;
   double* __restrict__ dual = B.dual + su * L::CON;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < 8; ++c) {
     if (!rowValid(P, c, i)) continue;
     const double sgn = (c & 1) ? 1.0 : -1.0;
-    const double x = (c < 2) ? q : ((c < 4) ? v : u);
-    const double dx = (c < 2) ? dq : ((c < 4) ? dv : du);
-    const double sl = slack[c * NV + r], dl = dual[c * NV + r];
+    const double x = (c < 2) ? q : ((c < 4) ? v : (c < 6 ? u : a_old));
+    const double dx = (c < 2) ? dq : ((c < 4) ? dv : (c < 6 ? du : da_dir));
+    double* slp = c < 6 ? slack + c * NV + r : B.slack_a + su * 2 * NV + (c - 6) * NV + r;
+    double* dlp = c < 6 ? dual + c * NV + r : B.dual_a + su * 2 * NV + (c - 6) * NV + r;
+    const double sl = *slp, dl = *dlp;
     const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
     const double dslack = -sgn * dx - row.residual;
     const double ddual = -(dl * dslack + row.duality) / sl;
-    if (active) { slack[c * NV + r] = sl + ap * dslack; dual[c * NV + r] = dl + ad * ddual; }
+    if (active) { *slp = sl + ap * dslack; *dlp = dl + ad * ddual; }
   }
 }
 
@@ -866,17 +873,18 @@ __global__ __launch_bounds__(64) void un_init_constraints_kernel(UnBuffers B) {
   const long b = su / N;
   const int i = (int)(su - b * N);
   const double* __restrict__ s = B.sol + (b * (N + 1) + i) * L::SOL;
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < 8; ++c) {
+    if (c >= 6 && !B.slack_a) continue;
     double sl = 1.0, dl = 0.0;
     if (rowValid(P, c, i)) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
-      const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
+      const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : (c < 6 ? s[L::S_U + r] : s[L::S_A + r]));
       sl = -sgn * (x - limitOf(P, c, r));
       for (int it = 0; it < (1 << 26) && sl < P->barrier; ++it) sl += P->barrier;      // pdipm.hxx:17-20, bounded
       dl = P->barrier / sl;
     }
-    B.slack[su * L::CON + c * NV + r] = sl;
-    B.dual[su * L::CON + c * NV + r] = dl;
+    if (c < 6) { B.slack[su * L::CON + c * NV + r] = sl; B.dual[su * L::CON + c * NV + r] = dl; }
+    else { B.slack_a[su * 2 * NV + (c - 6) * NV + r] = sl; B.dual_a[su * 2 * NV + (c - 6) * NV + r] = dl; }
   }
 }
 
@@ -1244,12 +1252,12 @@ __global__ __launch_bounds__(64) void unparnmpc_expand_kernel(UnBuffers B) {
   const double* __restrict__ dual = B.dual + su * L::CON;
   double ps = 1.0, ds = 1.0;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < 8; ++c) {      // 6, 7: joint acceleration limits (rows in slack_a / dual_a, joint_acceleration_{lower,upper}_limit.cpp:78-93)
     if (!rowValid(P, c, i)) continue;
     const double sgn = (c & 1) ? 1.0 : -1.0;
-    const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : s[L::S_U + r]);
-    const double dx = (c < 2) ? dq[r] : ((c < 4) ? dv[r] : du);
-    const double sl = slack[c * NV + r], dl = dual[c * NV + r];
+    const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : (c < 6 ? s[L::S_U + r] : s[L::S_A + r]));
+    const double dx = (c < 2) ? dq[r] : ((c < 4) ? dv[r] : (c < 6 ? du : da_r));
+    const double sl = c < 6 ? slack[c * NV + r] : B.slack_a[su * 2 * NV + (c - 6) * NV + r], dl = c < 6 ? dual[c * NV + r] : B.dual_a[su * 2 * NV + (c - 6) * NV + r];
     const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
     const double dslack = -sgn * dx - row.residual;
     const double ddual = -(dl * dslack + row.duality) / sl;
@@ -1379,6 +1387,18 @@ __global__ __launch_bounds__(64) void un_line_search_kernel(UnBuffers B, const d
     const double dslack = -sgn * dx - (sgn * (x_cur - lim) + sl);
     cost -= dt * P->barrier * log(sl + al * dslack);
     viol += dt * fabs(sgn * (x_try - lim) + sl);
+  }
+  if (kind == 2) {      // joint acceleration limits (components 6, 7) on the a seed lanes
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = 6 + cc;
+      if (!rowValid(P, c, i)) continue;
+      const double sgn = (cc == 0) ? -1.0 : 1.0;
+      const double lim = limitOf(P, c, k), sl = B.slack_a[unit * 2 * NV + cc * NV + k];
+      const double dslack = -sgn * dd[L::S_A + k] - (sgn * (s[L::S_A + k] - lim) + sl);
+      cost -= dt * P->barrier * log(sl + al * dslack);
+      viol += dt * fabs(sgn * (at - lim) + sl);
+    }
   }
   if (g0 < SPW) { s_sum[g][seed][0] = active ? cost : 0.0; s_sum[g][seed][1] = active ? viol : 0.0; }
   WAVE_SYNC();

@@ -37,6 +37,10 @@ Constraints::Constraints(const Robot& robot, const idocp_constraints_t& c)
     components.push_back({JointLimit::U, -1, vec(m.u_max, -1.0)});
     components.push_back({JointLimit::U, +1, vec(m.u_max, 1.0)});
   }
+  // JointAccelerationLowerLimit / UpperLimit (joint_acceleration_{lower,upper}_limit.cpp): bounds of the components' own, acceleration level
+  auto vecd = [&](const double* p) { Mat v(nu); for (int i = 0; i < nu; ++i) v[i] = p[i]; return v; };
+  if (c.joint_acceleration_lower_limit) components.push_back({JointLimit::A, -1, vecd(c.a_min)});
+  if (c.joint_acceleration_upper_limit) components.push_back({JointLimit::A, +1, vecd(c.a_max)});
 }
 
 int Constraints::dimc_total() const {
@@ -44,10 +48,10 @@ int Constraints::dimc_total() const {
 }
 
 static const Mat& varOf(const JointLimit& jl, const SplitSolution& s) {
-  return jl.var == JointLimit::Q ? s.q : (jl.var == JointLimit::V ? s.v : s.u);
+  return jl.var == JointLimit::Q ? s.q : (jl.var == JointLimit::V ? s.v : (jl.var == JointLimit::A ? s.a : s.u));
 }
 static const Mat& dvarOf(const JointLimit& jl, const SplitDirection& d) {
-  return jl.var == JointLimit::Q ? d.dq : (jl.var == JointLimit::V ? d.dv : d.du);
+  return jl.var == JointLimit::Q ? d.dq : (jl.var == JointLimit::V ? d.dv : (jl.var == JointLimit::A ? d.da : d.du));
 }
 
 // pdipm::ComputeDuality + the component's computePrimalAndDualResidual
@@ -149,10 +153,10 @@ static void stageCostDerivatives(const RCost& c, real dt, const SplitSolution& s
 }
 
 static Mat& residualOf(const JointLimit& jl, SplitUnOCP& o) {
-  return jl.var == JointLimit::Q ? o.lq : (jl.var == JointLimit::V ? o.lv : o.lu);
+  return jl.var == JointLimit::Q ? o.lq : (jl.var == JointLimit::V ? o.lv : (jl.var == JointLimit::A ? o.la : o.lu));
 }
 static Mat& hessianDiagOf(const JointLimit& jl, SplitUnOCP& o, Mat& qqdiag) {
-  return jl.var == JointLimit::Q ? qqdiag : (jl.var == JointLimit::V ? o.Qvv_diag : o.Quu_diag);
+  return jl.var == JointLimit::Q ? qqdiag : (jl.var == JointLimit::V ? o.Qvv_diag : (jl.var == JointLimit::A ? o.Qaa_diag : o.Quu_diag));
 }
 
 // stateequation::linearizeForwardEuler, fixed base (state_equation.hxx:12-37,210-221)
@@ -421,7 +425,7 @@ static real trialConstraintViolation(Robot& robot, const Constraints& cs, const 
   for (size_t j = 0; j < cs.components.size(); ++j) {
     const JointLimit& jl = cs.components[j];
     if (!cs.valid(jl, level)) continue;
-    const Mat& var = jl.var == JointLimit::Q ? x.q : (jl.var == JointLimit::V ? x.v : x.u);
+    const Mat& var = jl.var == JointLimit::Q ? x.q : (jl.var == JointLimit::V ? x.v : (jl.var == JointLimit::A ? x.a : x.u));
     const int n = jl.lim.size(), off = var.size() - n;
     for (int r = 0; r < n; ++r) viol += dt * std::fabs(jl.sign * (var[off + r] - jl.lim[r]) + cd.data[j].slack[r]);
   }

@@ -44,7 +44,7 @@ struct ConstraintComponentData {
 // One joint-limit component (src/constraints/joint_*_limit.cpp); the six
 // reference classes differ only in the variable, the bound and a sign.
 struct JointLimit {
-  enum Var { Q = 0, V = 1, U = 2 };
+  enum Var { Q = 0, V = 1, U = 2, A = 3 };
   Var var;
   int sign;            // -1 lower limit, +1 upper limit
   Mat lim;             // bound (xmin for lower, xmax for upper)

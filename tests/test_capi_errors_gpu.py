@@ -103,11 +103,10 @@ def test_fixed_base_solver_argument_errors():
         assert fn(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 0, 1, 0, C.byref(h)) == E_ARG
         assert b"N must be positive" in lib.idocp_last_error()
     # the components the fixed-base solvers do not carry are refused, not dropped
-    for flag in ("joint_acceleration_lower_limit", "joint_acceleration_upper_limit", "contact_distance"):
-        setattr(cons, flag, 1)
-        for fn in (lib.idocp_unocp_create, lib.idocp_unparnmpc_create):
-            assert fn(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 10, 1, 0, C.byref(h)) == E_UNSUPPORTED
-        setattr(cons, flag, 0)
+    cons.contact_distance = 1          # (the acceleration limits are carried: tests/test_unocp_acceleration_limits_gpu.py)
+    for fn in (lib.idocp_unocp_create, lib.idocp_unparnmpc_create):
+        assert fn(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 10, 1, 0, C.byref(h)) == E_UNSUPPORTED
+    cons.contact_distance = 0
     am = anymal_model()
     assert lib.idocp_unparnmpc_create(C.byref(am), C.byref(cost), C.byref(cons), 1.0, 10, 1, 0, C.byref(h)) == E_ARG     # floating base
     for lo, hi in ((-1, 5), (5, 5), (8, 11)):
