@@ -364,17 +364,29 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       if (r < NV) acc += dt * dgn[r];
       laf[r] = acc;
     }
-    if (lane >= 32 && lane < 38) {
-      const int r = lane - 32;
-      double acc = tl[L::E_LUP - TO + r];
+    {
+      // dnu_passive: six rows of NU + NX + NV = 66 terms; eight lanes per row (six lanes walking 66 terms each was as long as the
+      // 30 x 30 product below, with 58 lanes idle)
+      constexpr int NT66 = NU + NX + NV;
+      const int r = lane >> 3, part = lane & 7;
+      double acc = 0.0;
+      if (r < 6) {
 #pragma unroll
-      for (int j = 0; j < NU; ++j) acc += tl[L::E_QUUP - TO + r + 6 * j] * du[j];
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc += tl[L::E_QXUP - TO + c + NX * r] * dx[c];
-#pragma unroll
-      for (int c = 0; c < NV; ++c) acc += dt * mj(r, c) * dgn[c];
-      const double v = nd->has_u ? -acc / dt : 0.0;
-      nup[r] = v; dd[L::D_NUP + r] = v;
+        for (int t0 = 0; t0 < (NT66 + 7) / 8; ++t0) {
+          const int t = part + 8 * t0;
+          if (t < NU) acc += tl[L::E_QUUP - TO + r + 6 * t] * du[t];
+          else if (t < NU + NX) acc += tl[L::E_QXUP - TO + (t - NU) + NX * r] * dx[t - NU];
+          else if (t < NT66) acc += dt * mj(r, t - NU - NX) * dgn[t - NU - NX];
+        }
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      if (r < 6 && part == 0) {
+        acc += tl[L::E_LUP - TO + r];
+        const double v = nd->has_u ? -acc / dt : 0.0;
+        nup[r] = v; dd[L::D_NUP + r] = v;
+      }
     }
     __syncthreads();
     if (lane < dimvf) {
