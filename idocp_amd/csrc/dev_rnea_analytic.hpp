@@ -232,5 +232,146 @@ __device__ __forceinline__ void rneaDerivativesChain(const Model* m, const doubl
   }
 }
 
+// ---- the same recursion in two phases (un_linearize_kernel) ------------------------------------------------------------------------
+// The walk, the body record, the composites and the columns dF/d(q, v, a) of a joint do not depend on the seed kind: in the
+// single-phase form above the q / v / a lanes of a joint each ran them.  Phase A runs them once per (stage, joint) -- seven lanes
+// per stage, nine stages per wavefront, the composites by a suffix scan over the seven lanes of a stage (shuffles) -- and leaves a block
+// of per-joint vectors in the lane's registers; phase B, three stages at a time with a lane per (stage, kind, joint), assembles the rows
+// out of the blocks of its three stages, which phase A's lanes have just put into LDS.
+struct RneaBlock {
+  // S, dA/dq, dV/dq, dA/dv, dF/dq (+ S x* fc: as the rows above see it), dF/dv, dF/da = Yc S, dF/dq (own row), Bc^T S, tau
+  static constexpr int S = 0, DA = 6, DV = 12, DAV = 18, FQC = 24, FV = 30, FA = 36, FQ = 42, BTS = 48, TAU = 54;
+  static constexpr int LEN = 55;      // (odd: the lanes of a stage then hit distinct LDS banks)
+};
+
+// kin_out (or null): world placement (R, p) of joint k, 12 doubles -- for a task-space cost on the chain
+template <int NJ, bool ZAX, typename Model>
+__device__ __forceinline__ void rneaDerivPhaseA(const Model* m, const double* cs, const double* qd, const double* qdd, int k, double* blk, double* kin_out) {
+  using namespace ra;
+  double Rw[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  V pw = v3(0.0, 0.0, 0.0);
+  Mot vel; vel.l = v3(0, 0, 0); vel.a = v3(0, 0, 0);
+  Mot acc; acc.l = v3(-m->gravity[0], -m->gravity[1], -m->gravity[2]); acc.a = v3(0, 0, 0);
+  Mot S, vk = vel, ak = acc;
+  double Rk[9];
+  V pk = pw;
+  S.l = v3(0, 0, 0); S.a = v3(0, 0, 0);
+#pragma unroll 1
+  for (int j = 0; j < NJ; ++j) {
+    Mat3<double> Rm;
+    revoluteRotation<double, ZAX>(m->R[j], m->axis[j], cs[2 * j], cs[2 * j + 1], Rm);
+    const double* pj = m->p[j];
+    pw = pw + v3(Rw[0] * pj[0] + Rw[1] * pj[1] + Rw[2] * pj[2], Rw[3] * pj[0] + Rw[4] * pj[1] + Rw[5] * pj[2], Rw[6] * pj[0] + Rw[7] * pj[1] + Rw[8] * pj[2]);
+    double Rn[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Rn[3 * r + c] = Rw[3 * r] * Rm.m[c] + Rw[3 * r + 1] * Rm.m[3 + c] + Rw[3 * r + 2] * Rm.m[6 + c];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rw[e] = Rn[e];
+    const double* u = m->axis[j];
+    Mot Sj;
+    Sj.a = ZAX ? v3(Rw[2], Rw[5], Rw[8]) : v3(Rw[0] * u[0] + Rw[1] * u[1] + Rw[2] * u[2], Rw[3] * u[0] + Rw[4] * u[1] + Rw[5] * u[2], Rw[6] * u[0] + Rw[7] * u[1] + Rw[8] * u[2]);
+    Sj.l = cross(pw, Sj.a);
+    const Mot vJ = scale(qd[j], Sj);
+    const Mot vn = vel + vJ;
+    const Mot an = acc + scale(qdd[j], Sj) + crossMM(vn, vJ);
+    if (j == k) {
+      S = Sj; vk = vn; ak = an; pk = pw;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rk[e] = Rw[e];
+    }
+    vel = vn; acc = an;
+  }
+  if (kin_out) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) kin_out[e] = Rk[e];
+    stv(kin_out + 9, pk);
+  }
+  double rec[CREC];
+  {
+    const double mass = m->mass[k];
+    const double* mc = m->mc[k];
+    const double* Io = m->Io[k];
+    const V hc = v3(Rk[0] * mc[0] + Rk[1] * mc[1] + Rk[2] * mc[2], Rk[3] * mc[0] + Rk[4] * mc[1] + Rk[5] * mc[2], Rk[6] * mc[0] + Rk[7] * mc[1] + Rk[8] * mc[2]);
+    const V h = hc + mass * pk;
+    double RI[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      RI[3 * r] = Rk[3 * r] * Io[0] + Rk[3 * r + 1] * Io[1] + Rk[3 * r + 2] * Io[2];
+      RI[3 * r + 1] = Rk[3 * r] * Io[1] + Rk[3 * r + 1] * Io[3] + Rk[3 * r + 2] * Io[4];
+      RI[3 * r + 2] = Rk[3 * r] * Io[2] + Rk[3 * r + 1] * Io[4] + Rk[3 * r + 2] * Io[5];
+    }
+    auto rirt = [&](int r, int c) { return RI[3 * r] * Rk[3 * c] + RI[3 * r + 1] * Rk[3 * c + 1] + RI[3 * r + 2] * Rk[3 * c + 2]; };
+    const double pp = dot(pk, pk), phc = dot(pk, hc);
+    const double dg = mass * pp + 2.0 * phc;
+    const double P[3] = {pk.x, pk.y, pk.z}, H[3] = {hc.x, hc.y, hc.z};
+    auto jel = [&](int r, int c) { return rirt(r, c) - mass * P[r] * P[c] - H[r] * P[c] - P[r] * H[c] + (r == c ? dg : 0.0); };
+    double J[6] = {jel(0, 0), jel(0, 1), jel(0, 2), jel(1, 1), jel(1, 2), jel(2, 2)};
+    rec[C_M] = mass; stv(rec + C_H, h);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) rec[C_J + e] = J[e];
+    const Mot oh = mulY(rec, vk);
+    stv(rec + C_HF, oh.l); stv(rec + C_HN, oh.a);
+    const V w = vk.a, vl = vk.l;
+    const V Jc0 = v3(J[0], J[1], J[2]), Jc1 = v3(J[1], J[3], J[4]), Jc2 = v3(J[2], J[4], J[5]);
+    const V WJ0 = cross(w, Jc0), WJ1 = cross(w, Jc1), WJ2 = cross(w, Jc2);
+    const double vh = dot(vl, h);
+    rec[C_SYM + 0] = 2.0 * WJ0.x - 2.0 * h.x * vl.x + 2.0 * vh;
+    rec[C_SYM + 1] = WJ1.x + WJ0.y - (h.x * vl.y + vl.x * h.y);
+    rec[C_SYM + 2] = WJ2.x + WJ0.z - (h.x * vl.z + vl.x * h.z);
+    rec[C_SYM + 3] = 2.0 * WJ1.y - 2.0 * h.y * vl.y + 2.0 * vh;
+    rec[C_SYM + 4] = WJ2.y + WJ1.z - (h.y * vl.z + vl.y * h.z);
+    rec[C_SYM + 5] = 2.0 * WJ2.z - 2.0 * h.z * vl.z + 2.0 * vh;
+    const Mot f = mulY(rec, ak) + crossMF(vk, oh);
+    stm(rec + C_F, f);
+  }
+  // composites over the bodies j >= k of the stage: suffix scan over its NJ consecutive lanes (the lanes of the next stage are masked out)
+  static_assert(NJ <= 8, "three doubling steps");
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    const bool take = k + off < NJ;
+#pragma unroll
+    for (int e = 0; e < CREC; ++e) {
+      const double t = __shfl_down(rec[e], off);
+      rec[e] += take ? t : 0.0;
+    }
+  }
+  const Mot vJk = scale(qd[k], S);
+  const Mot vpar = vk - vJk;
+  const Mot apar = ak - scale(qdd[k], S) - crossMM(vk, vJk);
+  const Mot dV = crossMM(vpar, S);
+  const Mot dA = crossMM(apar, S) + crossMM(vpar, dV);
+  const Mot dAv = crossMM(vk, S) + dV;
+  const Mot YS = mulY(rec, S);
+  const Mot fc = ldm(rec + C_F);
+  const Mot Fq = mulY(rec, dA) + mulB(rec, dV);
+  stm(blk + RneaBlock::S, S); stm(blk + RneaBlock::DA, dA); stm(blk + RneaBlock::DV, dV); stm(blk + RneaBlock::DAV, dAv);
+  stm(blk + RneaBlock::FQC, Fq + crossMF(S, fc)); stm(blk + RneaBlock::FV, mulB(rec, S) + mulY(rec, dAv)); stm(blk + RneaBlock::FA, YS);
+  stm(blk + RneaBlock::FQ, Fq); stm(blk + RneaBlock::BTS, mulBt(rec, S));
+  blk[RneaBlock::TAU] = dot6(S, fc);
+}
+
+// Row r of the kind's matrix out of the blocks of the stage's joints (LDS, `stride` doubles apart): row[c] = d tau_r / d (q | v | a)_c
+template <int NJ>
+__device__ __forceinline__ void rneaDerivPhaseB(const double* pub, int stride, int kind, int r, double* row) {
+  using namespace ra;
+  const double* me = pub + r * stride;
+  const Mot S = ldm(me + RneaBlock::S), YS = ldm(me + RneaBlock::FA), BtS = ldm(me + RneaBlock::BTS);
+  const Mot own = ldm(me + (kind == 0 ? RneaBlock::FQ : (kind == 1 ? RneaBlock::FV : RneaBlock::FA)));
+  const int o1 = kind == 0 ? RneaBlock::FQC : (kind == 1 ? RneaBlock::FV : RneaBlock::FA);
+  const int o2 = kind == 0 ? RneaBlock::DA : (kind == 1 ? RneaBlock::DAV : RneaBlock::S);
+  const int o3 = kind == 0 ? RneaBlock::DV : RneaBlock::S;
+#pragma unroll
+  for (int c = 0; c < NJ; ++c) {
+    const double* o = pub + c * stride;
+    double val;
+    if (c == r) val = dot6(S, own);
+    else if (c > r) val = dot6(S, ldm(o + o1));
+    else val = dot6(YS, ldm(o + o2)) + (kind < 2 ? dot6(BtS, ldm(o + o3)) : 0.0);
+    row[c] = val;
+  }
+}
+
 }  // namespace idocp_dev
 #endif  // IDOCP_DEV_RNEA_ANALYTIC_HPP_

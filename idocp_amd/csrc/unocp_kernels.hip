@@ -21,7 +21,10 @@
 
 namespace idocp_dev {
 
-#define WAVE_SYNC() __syncthreads()
+// LDS exchange between the lanes of the (only) wavefront of a workgroup: its DS instructions execute in program order, so all that is
+// needed is that the compiler keeps that order.  (__syncthreads() also drains the wavefront's outstanding GLOBAL stores and loads --
+// s_waitcnt vmcnt(0) --: in un_linearize_kernel, which stores records in every round, a third of the wavefront's time.)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // One inequality row of the primal-dual interior point method
 // (include/idocp/constraints/pdipm.hxx:13-87; row formulas e.g.
@@ -76,89 +79,175 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
 // TASK: the cost carries a TaskSpace3DCost / TaskSpace6DCost (dev_task.hpp); lane (0, k) adds dt JJ^T W diff to lq[k] and
 // column k of dt JJ^T W JJ to Qqq.
 // ZAX: every joint axis of the chain is +z (iiwa14): the compile-time variant of the rigid-body sweep (dev_rbd.hpp).
+#ifndef K1_EXP
+#define K1_EXP 0
+#endif
+#ifdef K1_PROF
+__device__ unsigned long long g_k1_prof[16];
+#define K1_T(i) do { if (MODE == 0) { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+#else
+#define K1_T(i) do { } while (0)
+#endif
+#define K1_STORE_OK (K1_EXP != 1 || N < 0)
 template <int NV, int MODE, bool BWD = false, bool TASK = false, bool ZAX = false>
 __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
                                                           const double* __restrict__ v0 = nullptr) {
   using L = UnLayout<NV>;
-  constexpr int LPS = 3 * NV;        // lanes per stage
-  constexpr int SPW = 64 / LPS;      // stages per wavefront
-  __shared__ double s_dID[SPW][3][NV * NV];
-  __shared__ RneaAnalyticLds<NV> s_ra[SPW];
+  constexpr int LPS = 3 * NV;        // lanes per stage (phase B and the rest of the kernel)
+  constexpr int SPW = 64 / LPS;      // stages per round
+  constexpr int SPA = 64 / NV;       // stages per wavefront: phase A of the analytic recursion has a lane per (stage, joint)
+  constexpr int ROUNDS = SPA / SPW;
+  static_assert(SPA == SPW * ROUNDS, "whole rounds");
+  constexpr int BLK = RneaBlock::LEN;
+  // s_dyn: the dyn records of the round's stages as they go to memory -- dID/d(q | v | a) [kind][c * NV + r], which the condensation reads
+  // back, then ID, lu, diag(Quu).  s_po: the blocks of phase A, then (the rows are assembled by then) the kkt records of the round.
+  // Both records leave the wavefront as 16-byte pieces of consecutive lanes: written element by element from the lanes that compute
+  // them, a store instruction touched ~60 different cache lines, and the stores were a third of the kernel's time.
+  __shared__ __attribute__((aligned(16))) double s_dyn[SPW][L::DYN];
+  union PubOut { double pub[SPW][NV][BLK]; double out[SPW][L::KKT]; };
+  __shared__ __attribute__((aligned(16))) PubOut s_po;
+  static_assert(L::KKT % 2 == 0 && L::DYN % 2 == 0 && L::D_DV == NV * NV && L::D_DA == 2 * NV * NV && L::D_LU == L::D_ID + NV && L::D_QUU == L::D_LU + NV, "record images");
   __shared__ ChainConsts<NV> s_model;
-  // the stage group's records (solution of the stage and of its successor -- contiguous --, slack, dual) arrive with 16-byte loads issued
-  // back to back at the top of the kernel: round 2 read them field by field where they were needed, and the wavefronts spent 57 % of
-  // their cycles in s_waitcnt (SQ_WAIT_ANY, profiles/r03_iiwa14_pmc_sq.txt)
-  constexpr int IN_SN = L::SOL, IN_SLACK = 2 * L::SOL, IN_DUAL = 2 * L::SOL + L::CON, IN_LEN = 2 * L::SOL + 2 * L::CON;
-  __shared__ __attribute__((aligned(16))) double s_in[SPW][IN_LEN];
+  // the solution records of the wavefront's stages (and the part of each successor's record the stage reads: lmd, gmm, q, v -- its
+  // first 4 NV numbers, contiguous with the stage's own record) arrive with 16-byte loads issued back to back at the top of the kernel:
+  // round 2 read them field by field where they were needed, and the wavefronts spent 57 % of their cycles in s_waitcnt (SQ_WAIT_ANY,
+  // profiles/r03_iiwa14_pmc_sq.txt)
+  constexpr int IN_SN = L::SOL, IN_LEN = L::SOL + 4 * NV;
+  static_assert(L::S_LMD == 0 && L::S_GMM == NV && L::S_Q == 2 * NV && L::S_V == 3 * NV, "the successor's fields read here are a prefix of its record");
+  __shared__ __attribute__((aligned(16))) double s_in[SPA][IN_LEN];
+  __shared__ long s_inst[SPA];
+  __shared__ int s_stage[SPA];
+  __shared__ double s_kin[TASK ? SPA : 1][12];       // TASK: world placement (R, p) of the frame's joint
   __shared__ double s_tJ[TASK ? SPW : 1][6][NV];     // TASK: the columns JJ[:, k] of the stage group
   __shared__ double s_task[TASK ? SPW : 1][TASK ? 54 : 1];      // TASK: the frame's world placement (12), diff (6), Jlog6 (36)
   __shared__ double s_err[SPW][LPS];
-  __shared__ double s_cs[SPW][NV][2];
-  __shared__ double s_tau[SPW][NV];
+  __shared__ double s_cs[SPA][NV][2];
+  __shared__ double s_tau[SPA][NV];
   __shared__ double s_lu[SPW][NV], s_quu[SPW][NV];      // torque-level rows of the stage group: lu and diag(Quu)
-  __shared__ double s_dummy[NV];
   const UnProblem* __restrict__ P = B.prob;
   const int N = P->N;
   const double dt = P->dt;
   const int lane = threadIdx.x;
+  const long total = (long)P->batch * N;
+  const long unit0 = (long)blockIdx.x * SPA;
+#ifdef K1_PROF
+  unsigned long long t_prev = __builtin_readcyclecounter();
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  {
+    typedef double in_d2 __attribute__((ext_vector_type(2)));
+    static_assert(IN_LEN % 2 == 0 && IN_LEN / 2 <= 64, "one 16-byte piece per lane and stage");
+    in_d2 rs[SPA];
+    // (instance, stage) of the wavefront's units: one 64-bit division, then counted up (unit = instance * N + stage)
+    long bb = unit0 / N;
+    int ii = (int)(unit0 - bb * N);
+    long uu = unit0;
+#pragma unroll
+    for (int gg = 0; gg < SPA; ++gg) {
+      const double* sg = B.sol + (bb * (N + 1) + ii) * L::SOL;
+      rs[gg] = reinterpret_cast<const in_d2*>(sg)[lane < IN_LEN / 2 ? lane : 0];
+      if (lane == 0) { s_inst[gg] = bb; s_stage[gg] = ii; }
+      if (uu + 1 < total) { ++uu; if (++ii == N) { ii = 0; ++bb; } }      // (past the end: the last unit again, masked out below)
+    }
+    s_model.load(B.model, lane, 64);
+#pragma unroll
+    for (int gg = 0; gg < SPA; ++gg)
+      if (lane < IN_LEN / 2) reinterpret_cast<in_d2*>(&s_in[gg][0])[lane] = rs[gg];
+    WAVE_SYNC();
+  }
+  K1_T(0);
+
+  // ---- inverse dynamics and its derivatives, phase A: lane (stage sA of the wavefront, joint jA) ----
+  // (round 3: ONE analytic evaluation per stage, dev_rnea_analytic.hpp, instead of a forward-mode sweep per lane -- rneaChain<Dual>, kept
+  //  in dev_rbd.hpp for the kernels that want a single tangent; its seed-independent part once per (stage, joint), not once per lane)
+  const int sA0 = lane / NV;
+  const int sA = sA0 < SPA ? sA0 : SPA - 1;
+  const int jA = sA0 < SPA ? lane - sA0 * NV : 0;
+  if (sA0 < SPA) {
+    double sj, cj;
+    sincos(s_in[sA][L::S_Q + jA], &sj, &cj);
+    s_cs[sA][jA][0] = cj; s_cs[sA][jA][1] = sj;
+  }
+  WAVE_SYNC();
+  double blk[BLK];
+  rneaDerivPhaseA<NV, ZAX>(&s_model, &s_cs[sA][0][0], &s_in[sA][L::S_V], &s_in[sA][L::S_A], jA, blk, (TASK && sA0 < SPA && jA == P->task.joint) ? &s_kin[sA][0] : nullptr);
+  K1_T(1);
+
+  // ---- phase B, SPW stages at a time: lane (stage g of the round, kind, k) assembles row k of its matrix d tau / d (q | v | a) ----
+  // The rows of all rounds are assembled before the rest of the kernel runs: a lane then carries 7 numbers per round still to come
+  // instead of the 55 of its phase-A block (which did not fit beside the rest of the kernel: the block's spilled part came back from
+  // scratch memory behind the previous round's record stores).
   const int g0 = lane / LPS;
   const int g = g0 < SPW ? g0 : SPW - 1;
   const int seed = lane - g0 * LPS;
   const int kind = (g0 < SPW) ? seed / NV : 0;
   const int k = (g0 < SPW) ? seed - kind * NV : 0;
-  const long total = (long)P->batch * N;
-  long unit = (long)blockIdx.x * SPW + g;
-  const bool active = (g0 < SPW) && (unit < total);
-  if (unit >= total) unit = total - 1;
-  const long b = unit / N;
-  const int i = (int)(unit - b * N);
-  const double* __restrict__ s_g = B.sol + (b * (N + 1) + i) * L::SOL;
-  {
-    typedef double in_d2 __attribute__((ext_vector_type(2)));
-    static_assert(L::SOL % 2 == 0 && L::CON % 2 == 0 && 2 * L::SOL / 2 <= 64 && L::CON / 2 <= 64, "one 16-byte piece per lane and record");
-    in_d2 rs[SPW], rl[SPW], rd[SPW];
-    const long unit0 = (long)blockIdx.x * SPW;
+  if (sA0 < SPA) s_tau[sA][jA] = blk[RneaBlock::TAU];
+  double rows[ROUNDS][NV];
+  double kinS[TASK ? ROUNDS : 1][6];       // TASK: the motion subspace of joint k, per round
 #pragma unroll
-    for (int gg = 0; gg < SPW; ++gg) {
-      long u = unit0 + gg; if (u >= total) u = total - 1;
-      const long bb = u / N;
-      const double* sg = B.sol + (bb * (N + 1) + (u - bb * N)) * L::SOL;
-      rs[gg] = reinterpret_cast<const in_d2*>(sg)[lane < L::SOL ? lane : 0];                       // s and sn: 2 SOL doubles = SOL pieces
-      rl[gg] = reinterpret_cast<const in_d2*>(B.slack + u * L::CON)[lane < L::CON / 2 ? lane : 0];
-      rd[gg] = reinterpret_cast<const in_d2*>(B.dual + u * L::CON)[lane < L::CON / 2 ? lane : 0];
-    }
-    s_model.load(B.model, lane, 64);
+  for (int rho = 0; rho < ROUNDS; ++rho) {
+    WAVE_SYNC();                       // (the previous round has read the table)
+    if (sA0 < SPA && sA0 / SPW == rho) {
+      double* o = &s_po.pub[sA0 - rho * SPW][jA][0];
 #pragma unroll
-    for (int gg = 0; gg < SPW; ++gg) {
-      if (lane < L::SOL) reinterpret_cast<in_d2*>(&s_in[gg][0])[lane] = rs[gg];
-      if (lane < L::CON / 2) { reinterpret_cast<in_d2*>(&s_in[gg][IN_SLACK])[lane] = rl[gg]; reinterpret_cast<in_d2*>(&s_in[gg][IN_DUAL])[lane] = rd[gg]; }
+      for (int e = 0; e < BLK; ++e) o[e] = blk[e];
     }
     WAVE_SYNC();
+    rneaDerivPhaseB<NV>(&s_po.pub[g][0][0], BLK, kind, k, rows[rho]);
+    if (TASK) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) kinS[rho][e] = s_po.pub[g][k][RneaBlock::S + e];
+    }
   }
-  const double* s = &s_in[g][0];
-  const double* sn = &s_in[g][IN_SN];
-  const double* slack = &s_in[g][IN_SLACK];
-  const double* dual = &s_in[g][IN_DUAL];
+  K1_T(2);
 
-  // ---- inverse dynamics with one tangent per lane (registers only) ----
-  // cos/sin of the joint angles are shared by the stage group through LDS
-  if (g0 < SPW && seed < NV) {
-    double sj, cj;
-    sincos(s[L::S_Q + seed], &sj, &cj);
-    s_cs[g][seed][0] = cj; s_cs[g][seed][1] = sj;
+  // ---- the rest of the kernel, SPW stages at a time ----
+#pragma unroll 1
+  for (int rho = 0; rho < ROUNDS; ++rho) {
+  WAVE_SYNC();                       // (the previous round has read the LDS tables written below)
+  long unit = unit0 + rho * SPW + g;
+  const bool active = (g0 < SPW) && (unit < total);
+  if (unit >= total) unit = total - 1;
+  const long b = s_inst[rho * SPW + g];
+  const int i = s_stage[rho * SPW + g];
+  const double* __restrict__ s_g = B.sol + (b * (N + 1) + i) * L::SOL;
+  const double* s = &s_in[rho * SPW + g][0];
+  const double* sn = &s_in[rho * SPW + g][IN_SN];
+  // the IPM rows this lane evaluates: components (0, 1) / (2, 3) / (4, 5) of joint k on the q / v / a seed lane (read here, used below)
+  double sl_own[2], du_own[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    sl_own[cc] = B.slack[unit * L::CON + (2 * kind + cc) * NV + k];
+    du_own[cc] = B.dual[unit * L::CON + (2 * kind + cc) * NV + k];
+  }
+  // the rows of the round into the image of the dyn record (element (r, c) of a matrix at c * NV + r): the lanes read columns below
+  if (g0 < SPW) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) s_dyn[g][kind * NV * NV + c * NV + k] = rows[0][c];
+  }
+#pragma unroll
+  for (int r = 0; r + 1 < ROUNDS; ++r) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) rows[r][c] = rows[r + 1][c];
   }
   WAVE_SYNC();
-  // each lane writes its column d tau / d seed straight into the LDS copy of
-  // dID/d(q|v|a); the seed-0 lane also writes the nominal tau
-  // (round 3: ONE analytic evaluation shared by the 3 NV lanes of the stage group, dev_rnea_analytic.hpp, instead of a forward-mode
-  //  sweep per lane -- rneaChain<Dual>, kept in dev_rbd.hpp for the kernels that want a single tangent)
-  double kin[TASK ? 18 : 1];        // TASK: world placement (R, p) of joint k and its motion subspace S = (p x w, w), from the walk
-  rneaDerivativesChain<NV, ZAX>(&s_model, &s_cs[g][0][0], s + L::S_V, s + L::S_A, kind, k, g0 < SPW, s_ra[g], &s_dID[g][0][0], &s_dID[g][1][0],
-                                &s_dID[g][2][0], &s_tau[g][0], [] { __syncthreads(); }, TASK ? kin : nullptr);
-  WAVE_SYNC();
+  K1_T(3);
   double tau_d[NV], ID[NV];
 #pragma unroll
-  for (int r = 0; r < NV; ++r) { tau_d[r] = s_dID[g][kind][k * NV + r]; ID[r] = s_tau[g][r] - s[L::S_U + r]; }
+  for (int r = 0; r < NV; ++r) { tau_d[r] = s_dyn[g][kind * NV * NV + k * NV + r]; ID[r] = s_tau[rho * SPW + g][r] - s[L::S_U + r]; }
+  double kin[TASK ? 18 : 1];        // TASK: world placement (R, p) of joint k and its motion subspace S = (p x w, w), from the walk
+  if (TASK) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) kin[e] = s_kin[rho * SPW + g][e];      // (only the lane of the frame's joint uses it)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) kin[12 + e] = kinS[0][e];
+#pragma unroll
+    for (int r = 0; r + 1 < ROUNDS; ++r) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) kinS[r][e] = kinS[r + 1][e];
+    }
+  }
 
   // ---- task-space cost: gradient element k and the weighted column dt W JJ[:, k] (kept by the kind-0 lanes) ----
   double task_g = 0.0, task_wc[6];
@@ -251,7 +340,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
 #pragma unroll
       for (int c = 4; c < 6; ++c) {
         const double sgn = (c == 4) ? -1.0 : 1.0;
-        const double sl = slack[c * NV + r], du = dual[c * NV + r];
+        const double sl = sl_own[c - 4], du = du_own[c - 4];
         const IpmRow row = ipmResidual(sgn, u, limitOf(P, c, r), sl, du, P->barrier);
         lu += sgn * dt * du;
         if (MODE == 0) {
@@ -268,6 +357,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
 #pragma unroll
   for (int r = 0; r < NV; ++r) { quu[r] = s_quu[g][r]; lu_c[r] = s_lu[g][r] + quu[r] * ID[r]; }
   lu_mine = s_lu[g][k];
+  K1_T(4);
 
   // ---- this lane's own gradient element: lq[k] / lv[k] / la[k] ----
   // cost (configuration_space_cost.cpp:292-310), dual residual, state equation
@@ -315,7 +405,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
         const int c = kind < 2 ? 2 * kind + cc : 6 + cc;
         if (rowValid(P, c, i)) {
           const double sgn = (cc == 0) ? -1.0 : 1.0;
-          const double sl = c < 6 ? slack[c * NV + k] : B.slack_a[unit * 2 * NV + (c - 6) * NV + k], du = c < 6 ? dual[c * NV + k] : B.dual_a[unit * 2 * NV + (c - 6) * NV + k];
+          const double sl = c < 6 ? sl_own[cc] : B.slack_a[unit * 2 * NV + (c - 6) * NV + k], du = c < 6 ? du_own[cc] : B.dual_a[unit * 2 * NV + (c - 6) * NV + k];
           const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, k), sl, du, P->barrier);
           l += sgn * dt * du;
           if (MODE == 0) {
@@ -332,6 +422,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
     for (int r = 0; r < NV; ++r) dotb += tau_d[r] * s[L::S_BETA + r];
     l += dt * dotb;
   }
+  K1_T(5);
 
   if (MODE == 1) {
     // SplitUnOCP::squaredNormKKTResidual (split_unocp.hxx:164-174)
@@ -346,7 +437,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
       for (int j = 0; j < LPS; ++j) sum += s_err[g][j];
       B.err_stage[b * (N + 1) + i] = sum;
     }
-    return;
+    continue;
   }
 
   // ---- condensation: l += dID^T lu_c ; Q = dID^T diag(Quu) dID + diag ----
@@ -355,8 +446,8 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   for (int r = 0; r < NV; ++r) dotc += tau_d[r] * lu_c[r];
   const double l_c = l + dotc;
 
-  double* __restrict__ kk = B.kkt + unit * L::KKT;
-  double* __restrict__ dy = B.dyn + unit * L::DYN;
+  double* kk = &s_po.out[g][0];        // (LDS images of the records)
+  double* dy = &s_dyn[g][0];
   double dcol[NV];
 #pragma unroll
   for (int r = 0; r < NV; ++r) dcol[r] = quu[r] * tau_d[r];
@@ -368,8 +459,8 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
     if (k1kind == 0) dst = (kind == 0) ? L::K_QQQ : ((kind == 1) ? L::K_QQV : -1);
     else if (k1kind == 1) dst = (kind == 1) ? L::K_QVV : -1;
     else dst = (kind == 0) ? L::K_QAQ : ((kind == 1) ? L::K_QAV : L::K_QAA);
-    const double* __restrict__ A = &s_dID[g][k1kind][0];
-#pragma unroll
+    const double* A = &s_dyn[g][k1kind * NV * NV];
+#pragma unroll 1
     for (int k1 = 0; k1 < NV; ++k1) {
       double acc = (k1kind == kind && k1 == k) ? h : 0.0;
 #pragma unroll
@@ -378,19 +469,40 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc += s_tJ[g][c][k1] * task_wc[c];
       }
-      if (active && dst >= 0) {
+      if (g0 < SPW && dst >= 0) {
         if (k1kind != kind) kk[dst + k * NV + k1] = acc;
         else if (k1 <= k) kk[dst + k * (k + 1) / 2 + k1] = acc;       // diagonal block: its upper triangle
       }
     }
   }
-  if (active) {
+  if (g0 < SPW) {
     if (kind == 0) { kk[L::K_LQ + k] = l_c; kk[L::K_FQ + k] = F; dy[L::D_ID + k] = ID[k]; }
     else if (kind == 1) { kk[L::K_LV + k] = l_c; kk[L::K_FV + k] = F; dy[L::D_LU + k] = lu_mine; }
     else { kk[L::K_LA + k] = l_c; dy[L::D_QUU + k] = quu[k]; }
-#pragma unroll
-    for (int r = 0; r < NV; ++r) dy[kind * NV * NV + k * NV + r] = tau_d[r];
   }
+  WAVE_SYNC();
+  K1_T(6);
+  {      // the round's units are consecutive: so are their records
+    typedef double out_d2 __attribute__((ext_vector_type(2)));
+    const long ubase = unit0 + rho * SPW;
+    const long left = total - ubase;
+    const int nst = left >= SPW ? SPW : (left > 0 ? (int)left : 0);
+    out_d2* __restrict__ gk = reinterpret_cast<out_d2*>(B.kkt + ubase * L::KKT);
+    out_d2* __restrict__ gd = reinterpret_cast<out_d2*>(B.dyn + ubase * L::DYN);
+    const out_d2* lk = reinterpret_cast<const out_d2*>(&s_po.out[0][0]);
+    const out_d2* ld = reinterpret_cast<const out_d2*>(&s_dyn[0][0]);
+    if (K1_STORE_OK) {
+#pragma unroll
+      for (int p0 = 0; p0 < SPW * L::KKT / 2; p0 += 64) { const int p = p0 + lane; if (p < nst * (L::KKT / 2)) gk[p] = lk[p]; }
+#pragma unroll
+      for (int p0 = 0; p0 < SPW * L::DYN / 2; p0 += 64) { const int p = p0 + lane; if (p < nst * (L::DYN / 2)) gd[p] = ld[p]; }
+    }
+  }
+  K1_T(7);
+  }  // rounds
+#ifdef K1_PROF
+  if (MODE == 0 && threadIdx.x == 0) for (int e = 0; e < 8; ++e) atomicAdd(&g_k1_prof[e], t_acc[e]);
+#endif
 }
 
 // ------------------------------------------------------- terminal task cost ----
@@ -1443,9 +1555,9 @@ __global__ void un_square_kernel(double* __restrict__ out, const double* __restr
 // ------------------------------------------------------------ launchers ----
 template <int NV>
 void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t st) {
-    constexpr int SPW = 64 / (3 * NV);
+    constexpr int SPA = 64 / NV;       // stages per wavefront of un_linearize_kernel
     const long units = batch * N;
-    const dim3 grid((unsigned)((units + SPW - 1) / SPW));
+    const dim3 grid((unsigned)((units + SPA - 1) / SPA));
     const double* none = nullptr;
     if (B.task) {
       if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true, true>), grid, dim3(64), 0, st, B, none, none);
@@ -1457,9 +1569,9 @@ void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t 
   }
 template <int NV>
 void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t st) {
-    constexpr int SPW = 64 / (3 * NV);
+    constexpr int SPA = 64 / NV;       // stages per wavefront of un_linearize_kernel
     const long units = batch * N;
-    const dim3 grid((unsigned)((units + SPW - 1) / SPW));
+    const dim3 grid((unsigned)((units + SPA - 1) / SPA));
     const double* none = nullptr;
     if (B.task) {
       if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true, true>), grid, dim3(64), 0, st, B, none, none);
@@ -1529,8 +1641,8 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
   const unsigned inst_blocks = (unsigned)((batch + 3) / 4);
   switch (phase) {
     case 0:
-      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true, false, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
-      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true, false, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
       break;
     case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + 2) / 3)), dim3(192), 0, st, B); break;
     case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
@@ -1546,8 +1658,8 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
 template <int NV>
 void UnLaunch<NV>::parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
   constexpr int SPW = 64 / (3 * NV);
-  if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true, false, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
-  else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + SPW - 1) / SPW)), dim3(64), 0, st, B, q0, v0);
+  if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true, false, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
+  else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
   hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
 }
 template <int NV>
@@ -1584,3 +1696,11 @@ void fillField(double* sol, int stride, int offset, int dim, long nrec_per_inst,
 }
 
 }  // namespace idocp_dev
+
+#ifdef K1_PROF
+extern "C" int idocp_debug_k1_prof(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(idocp_dev::g_k1_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(idocp_dev::g_k1_prof), z, sizeof(z)) != hipSuccess) return 2; }
+  return 0;
+}
+#endif
