@@ -313,6 +313,15 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y,
     }                                                                                                                                  \
   } while (0)
 
+// Barrier of the workgroup.  With ONE wavefront (the batch-wide launch) the exchange through LDS needs no barrier: the wavefront's DS
+// instructions execute in program order, and all the compiler has to be told is not to move LDS accesses across this point.
+// __syncthreads() would also wait for every global access in flight (s_waitcnt vmcnt(0)): the prefetch of the next stage's record and
+// the stores of this stage's would then complete at the first barrier after they were issued instead of under the stage's arithmetic.
+template <int NW> __device__ __forceinline__ void blockSync() {
+  if constexpr (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  else __syncthreads();
+}
+
 template <typename D, int NT, bool HYBRID>
 __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     const double* __restrict__ kk = B.kkt + (base + nodes[M - 2].slot) * L::KKT;
     for (int e = tid; e < SL; e += nt) st[e] = kk[KO + e];
   }
-  __syncthreads();
+  blockSync<NW>();
   // walk the chain backwards (riccati_recursion_solver.cpp:48-107): impulse stages are ordinary steps with
   // Fqv = 0 (dtq = 0), Fvu = 0, Qxu = 0, Quu = I written by K5b, which makes K = 0, k = 0 and P = F
   for (int i = M - 2; i >= 0; --i) {
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     RSTAMP(1);
     // ---- phase 1: A^T P and B^T P (backward_riccati_recursion_factorizer.hxx:48-78) ----
     RICCATI_TILES(riccatiPhase1, T1, Pqq, Pqv, Pvv, Fall, Fqq6, Fqv6, dt, Wt, lane, loadQxx);
-    __syncthreads();
+    blockSync<NW>();
     RSTAMP(2);
     // ---- phase 2: F, H, G (:79-113); F overwrites P_{i+1}, which is dead from here ----
     RICCATI_TILES(riccatiPhase2, T2, Wt, Fall, Fqq6, Fqv6, dt, qxx, Pqq, Pqv, Pvv, Qxu, Quu, lane);
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     };
     if (NW == 1 && tid < NX) sPart1(tid);
     RSTAMP(12);
-    __syncthreads();
+    blockSync<NW>();
     RSTAMP(3);
     // software pipeline: the record of stage i was staged into LDS at the end of the previous iteration; the global loads of
     // stage i - 1 are issued here (factorisation, phases 4 and 5 ahead of them) and parked in registers
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
         for (int m = 0; m < NU; ++m) sm[S::GW + m + NU * tid] = x[m];
       }
     }
-    __syncthreads();
+    blockSync<NW>();
     RSTAMP(10);
     if (HYBRID && dimi > 0) {
       // ---- Schur complement w.r.t. the switching constraint Phix dx + Phiu du + P = 0 (split_riccati_factorizer.hxx:56-70) ----
@@ -519,14 +528,14 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
         for (int m = 0; m < NU; ++m) acc += Phiu[j + NF * m] * sm[S::GW + m + NU * c];
         sm[S::DG + j + NF * c] = acc;
       }
-      __syncthreads();
+      blockSync<NW>();
       for (int e = tid; e < dimi * dimi; e += nt) {              // S = DGinv Phiu^T
         const int c = e / dimi, j = e - c * dimi;
         double acc = 0.0;
         for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * Phiu[c + NF * m];
         sm[S::SS + j + NF * c] = acc;
       }
-      __syncthreads();
+      blockSync<NW>();
       // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves like the reference's llt_s_.solve (:64-66, 71-74): Cholesky and the
       // 49 right-hand sides in the registers of one wavefront (lane = column).  Round 1 formed S^-1 by unpivoted Gauss-Jordan and
       // multiplied: on a stage a few milliseconds in front of a touch-down S is ill-conditioned and the explicit inverse added its
@@ -551,14 +560,14 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
           }
         }
       }
-      __syncthreads();
+      blockSync<NW>();
       for (int e = tid; e < NU * NU; e += nt) {                  // Ginv -= SinvDGinv^T DGinv
         const int c = e / NU, r = e - c * NU;
         double acc = 0.0;
         for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * r] * sm[S::DG + l + NF * c];
         sm[S::GW + e] -= acc;
       }
-      __syncthreads();
+      blockSync<NW>();
     }
     if (constrained) {
       // K = -Ginv Qxu^T - SinvDGinv^T Phix, k = -Ginv lu - SinvDGinv^T P with the updated Ginv (:67-70)
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
         W[L::W_m + l] = acc;
       }
     }
-    __syncthreads();
+    blockSync<NW>();
     if (HYBRID && dimi > 0) {
       const double* __restrict__ W = B.swc + rec * L::SWC;
       for (int e = tid; e < NU * NX; e += nt) {                  // DtM = Phiu^T M (:88)
@@ -613,14 +622,14 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
         for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIX + l + NF * tid] * sm[S::MV + l];
         sm[S::SCORR + tid] = acc;
       }
-      __syncthreads();                                           // M (aliasing GK) is dead from here
+      blockSync<NW>();                                           // M (aliasing GK) is dead from here
     }
     RSTAMP(4);
     // ---- phase 4: GK = Quu K (backward_riccati_recursion_factorizer.hxx:128) -- only where K is not the plain solution of
     //      G K = -H^T (the stages with a switching constraint); see riccatiPhase5 ----
     if (constrained) {
       RICCATI_TILES(riccatiPhase4, 3, Quu, &sm[S::KM], &sm[S::GK], lane);
-      __syncthreads();
+      blockSync<NW>();
     }
     RSTAMP(5);
     // s recursion, part 2: - Qxu k (next to the tiles below: it reads Qxu and k, they read K and Qxu / GK)
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
       const double sign = constrained ? 1.0 : -1.0;
       RICCATI_TILES(riccatiPhase5, T2, &sm[S::KM], Y, ycs, yks, sign, Pqq, Pqv, Pvv, lane);
     }
-    __syncthreads();
+    blockSync<NW>();
     RSTAMP(6);
     RSTAMP(7);
     double* __restrict__ rr = B.ric + rec * L::RIC;
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
         rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
       }
     } else {
-      if (p32) { for (int e = tid; e < 3 * NN; e += nt) Pqq[e] = (double)(float)Pqq[e]; __syncthreads(); }      // (uniform branch)
+      if (p32) { for (int e = tid; e < 3 * NN; e += nt) Pqq[e] = (double)(float)Pqq[e]; blockSync<NW>(); }      // (uniform branch)
       for (int e = tid; e < 3 * NN / 2; e += nt) reinterpret_cast<rd2*>(rr)[e] = reinterpret_cast<const rd2*>(Pqq)[e];
     }
     if (tid < NV) {
@@ -679,7 +688,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
 #pragma unroll
       for (int t = 0; t < PF; ++t) { const int e = tid + NT * t; if (e < SL / 2) reinterpret_cast<rd2*>(st)[e] = pre[t]; }
     }
-    __syncthreads();
+    blockSync<NW>();
     RSTAMP(8);
 #undef RSTAMP
   }

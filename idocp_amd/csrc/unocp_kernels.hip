@@ -79,16 +79,13 @@ __device__ __forceinline__ bool rowValid(const UnProblem* __restrict__ P, int co
 // TASK: the cost carries a TaskSpace3DCost / TaskSpace6DCost (dev_task.hpp); lane (0, k) adds dt JJ^T W diff to lq[k] and
 // column k of dt JJ^T W JJ to Qqq.
 // ZAX: every joint axis of the chain is +z (iiwa14): the compile-time variant of the rigid-body sweep (dev_rbd.hpp).
-#ifndef K1_EXP
-#define K1_EXP 0
-#endif
+// -DK1_PROF: cycle counts per section of un_linearize_kernel<., 0> (sampled wavefronts), read with idocp_debug_k1_prof -- a developer aid
 #ifdef K1_PROF
 __device__ unsigned long long g_k1_prof[16];
 #define K1_T(i) do { if (MODE == 0) { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 #else
 #define K1_T(i) do { } while (0)
 #endif
-#define K1_STORE_OK (K1_EXP != 1 || N < 0)
 template <int NV, int MODE, bool BWD = false, bool TASK = false, bool ZAX = false>
 __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
                                                           const double* __restrict__ v0 = nullptr) {
@@ -103,11 +100,13 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   // back, then ID, lu, diag(Quu).  s_po: the blocks of phase A, then (the rows are assembled by then) the kkt records of the round.
   // Both records leave the wavefront as 16-byte pieces of consecutive lanes: written element by element from the lanes that compute
   // them, a store instruction touched ~60 different cache lines, and the stores were a third of the kernel's time.
-  __shared__ __attribute__((aligned(16))) double s_dyn[SPW][L::DYN];
+  // (the chain's constants and the sines / cosines are read by phase A only: they share the storage of s_dyn)
+  struct PhaseALds { ChainConsts<NV> model; double cs[SPA][NV][2]; };
+  union DynOrPhaseA { double dyn[SPW][L::DYN]; PhaseALds a; };
+  __shared__ __attribute__((aligned(16))) DynOrPhaseA s_da;
   union PubOut { double pub[SPW][NV][BLK]; double out[SPW][L::KKT]; };
   __shared__ __attribute__((aligned(16))) PubOut s_po;
   static_assert(L::KKT % 2 == 0 && L::DYN % 2 == 0 && L::D_DV == NV * NV && L::D_DA == 2 * NV * NV && L::D_LU == L::D_ID + NV && L::D_QUU == L::D_LU + NV, "record images");
-  __shared__ ChainConsts<NV> s_model;
   // the solution records of the wavefront's stages (and the part of each successor's record the stage reads: lmd, gmm, q, v -- its
   // first 4 NV numbers, contiguous with the stage's own record) arrive with 16-byte loads issued back to back at the top of the kernel:
   // round 2 read them field by field where they were needed, and the wavefronts spent 57 % of their cycles in s_waitcnt (SQ_WAIT_ANY,
@@ -121,7 +120,6 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   __shared__ double s_tJ[TASK ? SPW : 1][6][NV];     // TASK: the columns JJ[:, k] of the stage group
   __shared__ double s_task[TASK ? SPW : 1][TASK ? 54 : 1];      // TASK: the frame's world placement (12), diff (6), Jlog6 (36)
   __shared__ double s_err[SPW][LPS];
-  __shared__ double s_cs[SPA][NV][2];
   __shared__ double s_tau[SPA][NV];
   __shared__ double s_lu[SPW][NV], s_quu[SPW][NV];      // torque-level rows of the stage group: lu and diag(Quu)
   const UnProblem* __restrict__ P = B.prob;
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
       if (lane == 0) { s_inst[gg] = bb; s_stage[gg] = ii; }
       if (uu + 1 < total) { ++uu; if (++ii == N) { ii = 0; ++bb; } }      // (past the end: the last unit again, masked out below)
     }
-    s_model.load(B.model, lane, 64);
+    s_da.a.model.load(B.model, lane, 64);
 #pragma unroll
     for (int gg = 0; gg < SPA; ++gg)
       if (lane < IN_LEN / 2) reinterpret_cast<in_d2*>(&s_in[gg][0])[lane] = rs[gg];
@@ -166,11 +164,11 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   if (sA0 < SPA) {
     double sj, cj;
     sincos(s_in[sA][L::S_Q + jA], &sj, &cj);
-    s_cs[sA][jA][0] = cj; s_cs[sA][jA][1] = sj;
+    s_da.a.cs[sA][jA][0] = cj; s_da.a.cs[sA][jA][1] = sj;
   }
   WAVE_SYNC();
   double blk[BLK];
-  rneaDerivPhaseA<NV, ZAX>(&s_model, &s_cs[sA][0][0], &s_in[sA][L::S_V], &s_in[sA][L::S_A], jA, blk, (TASK && sA0 < SPA && jA == P->task.joint) ? &s_kin[sA][0] : nullptr);
+  rneaDerivPhaseA<NV, ZAX>(&s_da.a.model, &s_da.a.cs[sA][0][0], &s_in[sA][L::S_V], &s_in[sA][L::S_A], jA, blk, (TASK && sA0 < SPA && jA == P->task.joint) ? &s_kin[sA][0] : nullptr);
   K1_T(1);
 
   // ---- phase B, SPW stages at a time: lane (stage g of the round, kind, k) assembles row k of its matrix d tau / d (q | v | a) ----
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   // the rows of the round into the image of the dyn record (element (r, c) of a matrix at c * NV + r): the lanes read columns below
   if (g0 < SPW) {
 #pragma unroll
-    for (int c = 0; c < NV; ++c) s_dyn[g][kind * NV * NV + c * NV + k] = rows[0][c];
+    for (int c = 0; c < NV; ++c) s_da.dyn[g][kind * NV * NV + c * NV + k] = rows[0][c];
   }
 #pragma unroll
   for (int r = 0; r + 1 < ROUNDS; ++r) {
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   K1_T(3);
   double tau_d[NV], ID[NV];
 #pragma unroll
-  for (int r = 0; r < NV; ++r) { tau_d[r] = s_dyn[g][kind * NV * NV + k * NV + r]; ID[r] = s_tau[rho * SPW + g][r] - s[L::S_U + r]; }
+  for (int r = 0; r < NV; ++r) { tau_d[r] = s_da.dyn[g][kind * NV * NV + k * NV + r]; ID[r] = s_tau[rho * SPW + g][r] - s[L::S_U + r]; }
   double kin[TASK ? 18 : 1];        // TASK: world placement (R, p) of joint k and its motion subspace S = (p x w, w), from the walk
   if (TASK) {
 #pragma unroll
@@ -447,7 +445,7 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   const double l_c = l + dotc;
 
   double* kk = &s_po.out[g][0];        // (LDS images of the records)
-  double* dy = &s_dyn[g][0];
+  double* dy = &s_da.dyn[g][0];
   double dcol[NV];
 #pragma unroll
   for (int r = 0; r < NV; ++r) dcol[r] = quu[r] * tau_d[r];
@@ -459,8 +457,8 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
     if (k1kind == 0) dst = (kind == 0) ? L::K_QQQ : ((kind == 1) ? L::K_QQV : -1);
     else if (k1kind == 1) dst = (kind == 1) ? L::K_QVV : -1;
     else dst = (kind == 0) ? L::K_QAQ : ((kind == 1) ? L::K_QAV : L::K_QAA);
-    const double* A = &s_dyn[g][k1kind * NV * NV];
-#pragma unroll 1
+    const double* A = &s_da.dyn[g][k1kind * NV * NV];
+#pragma unroll
     for (int k1 = 0; k1 < NV; ++k1) {
       double acc = (k1kind == kind && k1 == k) ? h : 0.0;
 #pragma unroll
@@ -490,18 +488,16 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
     out_d2* __restrict__ gk = reinterpret_cast<out_d2*>(B.kkt + ubase * L::KKT);
     out_d2* __restrict__ gd = reinterpret_cast<out_d2*>(B.dyn + ubase * L::DYN);
     const out_d2* lk = reinterpret_cast<const out_d2*>(&s_po.out[0][0]);
-    const out_d2* ld = reinterpret_cast<const out_d2*>(&s_dyn[0][0]);
-    if (K1_STORE_OK) {
+    const out_d2* ld = reinterpret_cast<const out_d2*>(&s_da.dyn[0][0]);
 #pragma unroll
-      for (int p0 = 0; p0 < SPW * L::KKT / 2; p0 += 64) { const int p = p0 + lane; if (p < nst * (L::KKT / 2)) gk[p] = lk[p]; }
+    for (int p0 = 0; p0 < SPW * L::KKT / 2; p0 += 64) { const int p = p0 + lane; if (p < nst * (L::KKT / 2)) gk[p] = lk[p]; }
 #pragma unroll
-      for (int p0 = 0; p0 < SPW * L::DYN / 2; p0 += 64) { const int p = p0 + lane; if (p < nst * (L::DYN / 2)) gd[p] = ld[p]; }
-    }
+    for (int p0 = 0; p0 < SPW * L::DYN / 2; p0 += 64) { const int p = p0 + lane; if (p < nst * (L::DYN / 2)) gd[p] = ld[p]; }
   }
   K1_T(7);
   }  // rounds
 #ifdef K1_PROF
-  if (MODE == 0 && threadIdx.x == 0) for (int e = 0; e < 8; ++e) atomicAdd(&g_k1_prof[e], t_acc[e]);
+  if (MODE == 0 && threadIdx.x == 0 && blockIdx.x % 61 == 0) for (int e = 0; e < 8; ++e) atomicAdd(&g_k1_prof[e], t_acc[e]);
 #endif
 }
 
