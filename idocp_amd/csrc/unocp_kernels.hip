@@ -1082,6 +1082,13 @@ __global__ __launch_bounds__(64) void rnea_derivatives_kernel(const DevModel* __
 // d = K^-1 [Fq Fv la lq lv], s_new = s - d (split_unbackward_correction.hxx:50-64).  The two inverses are chains of
 // dependent pivot steps that use 21 (14) lanes each: wavefront 0 runs them for the three stages of the workgroup at once in
 // its registers (spdInverseRowsGrouped), everything else is done by each wavefront for its own stage through LDS.
+#ifdef K1_PROF
+#define K9_T0() unsigned long long t_prev = __builtin_readcyclecounter(); unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define K9_T(i) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[i] += t_now - t_prev; t_prev = t_now; if (i == 7 && threadIdx.x == 0 && blockIdx.x % 61 == 0) for (int e = 0; e < 8; ++e) atomicAdd(&g_k1_prof[8 + e], t_acc[e]); } while (0)
+#else
+#define K9_T0() do { } while (0)
+#define K9_T(i) do { } while (0)
+#endif
 template <int NV>
 __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers B) {
   using L = UnLayout<NV>;
@@ -1104,8 +1111,13 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
   const double* __restrict__ kk = B.kkt + unit * L::KKT;
   const double* __restrict__ aux = B.aux + (rec + 1) * L::AUX;       // aux_mat of the NEXT stage (none behind the last one)
   if (lane == 0) s_ok[w] = 1;
+  K9_T0();
   // Q in the ordering (a, q, v) from the six upper blocks K1b stores, + aux_mat_next on the (q, v) block
-  for (int e = lane; e < NQ * NQ; e += 64) {
+  // (unrolled: the loads of all passes are in flight together)
+#pragma unroll
+  for (int e0 = 0; e0 < NQ * NQ; e0 += 64) {
+    const int e1 = e0 + lane;
+    const int e = e1 < NQ * NQ ? e1 : NQ * NQ - 1;      // (the lanes past the end redo the last element)
     const int c = e / NQ, r = e - c * NQ;
     const int bi = r / NV, ri = r - bi * NV, bj = c / NV, cj = c - bj * NV;
     const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
@@ -1118,8 +1130,10 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
   }
   if (lane < NK) sres[lane] = kk[L::K_FQ + lane];                     // [Fq Fv la lq lv] are contiguous in the kkt record
   __syncthreads();
+  K9_T(0);
   if (w == 0) spdInverseRowsGrouped<NQ, SPB>(&sQa[0][0], NQ * NQ, lane, s_ok);
   __syncthreads();
+  K9_T(1);
   for (int e = lane; e < NX * NQ; e += 64) {
     const int c = e / NX, r = e - c * NX;
     sFQ[e] = r < NV ? -sQ[(NV + r) + NQ * c] + dt * sQ[(2 * NV + r) + NQ * c] : dt * sQ[(r - NV) + NQ * c] - sQ[(NV + r) + NQ * c];
@@ -1130,8 +1144,10 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
     sS[e] = c < NV ? -sFQ[r + NX * (NV + c)] + dt * sFQ[r + NX * (2 * NV + c)] : dt * sFQ[r + NX * (c - NV)] - sFQ[r + NX * (NV + c)];
   }
   __syncthreads();
+  K9_T(2);
   if (w == 0) spdInverseRowsGrouped<NX, SPB>(&sSa[0][0], NX * NX, lane, s_ok);
   __syncthreads();
+  K9_T(3);
   for (int e = lane; e < NX * NQ; e += 64) {                          // TR = S^-1 FQ
     const int c = e / NX, r = e - c * NX;
     double acc = 0.0;
@@ -1140,6 +1156,7 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
     sTR[e] = acc;
   }
   __syncthreads();
+  K9_T(4);
   double* __restrict__ ki = B.kinv + unit * L::KINV;
   if (valid) {
     for (int e = lane; e < NX * NX; e += 64) ki[L::I_TL + e] = -sS[e];
@@ -1152,6 +1169,7 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
     for (int k = 0; k < NX; ++k) acc -= sFQ[k + NX * r] * sTR[k + NX * (NV + c)];
     if (valid) ki[L::I_BRC + e] = acc;
   }
+  K9_T(5);
   // d = K^-1 res:  t1 = TR l,  d_top = -S^-1 Fx + t1,  d_bot = TR^T Fx + Q^-1 l - FQ^T t1
   if (lane < NX) {
     double acc = 0.0;
@@ -1175,12 +1193,14 @@ __global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers 
     sd[lane] = acc;
   }
   __syncthreads();
+  K9_T(6);
   // s_new = s - d in the fields (lmd, gmm | a, q, v)
   if (valid && lane < NK) {
     const int f = lane < NX ? L::S_LMD + lane : (lane < NX + NV ? L::S_A + (lane - NX) : L::S_Q + (lane - NX - NV));
     B.snew[rec * L::SOL + f] = B.sol[rec * L::SOL + f] - sd[lane];
   }
   if (valid && lane == 0 && !s_ok[w]) atomicMax(&B.status[b], 1 + i);
+  K9_T(7);
 }
 
 // S5u: 16 lanes per instance, lane r < NX owns row r of the costate pair (lmd, gmm).  Stage i:
