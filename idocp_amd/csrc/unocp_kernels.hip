@@ -116,9 +116,8 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   __shared__ __attribute__((aligned(16))) double s_in[SPA][IN_LEN];
   __shared__ long s_inst[SPA];
   __shared__ int s_stage[SPA];
-  __shared__ double s_kin[TASK ? SPA : 1][12];       // TASK: world placement (R, p) of the frame's joint
   __shared__ double s_tJ[TASK ? SPW : 1][6][NV];     // TASK: the columns JJ[:, k] of the stage group
-  __shared__ double s_task[TASK ? SPW : 1][TASK ? 54 : 1];      // TASK: the frame's world placement (12), diff (6), Jlog6 (36)
+  __shared__ double s_task[TASK ? SPA : 1][TASK ? 54 : 1];      // TASK: the frame's world placement (12), diff (6), Jlog6 (36), per stage
   __shared__ double s_err[SPW][LPS];
   __shared__ double s_tau[SPA][NV];
   __shared__ double s_lu[SPW][NV], s_quu[SPW][NV];      // torque-level rows of the stage group: lu and diag(Quu)
@@ -168,7 +167,44 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   }
   WAVE_SYNC();
   double blk[BLK];
-  rneaDerivPhaseA<NV, ZAX>(&s_da.a.model, &s_da.a.cs[sA][0][0], &s_in[sA][L::S_V], &s_in[sA][L::S_A], jA, blk, (TASK && sA0 < SPA && jA == P->task.joint) ? &s_kin[sA][0] : nullptr);
+  double kinA[TASK ? 12 : 1];         // TASK: world placement (R, p) of the lane's joint
+  rneaDerivPhaseA<NV, ZAX>(&s_da.a.model, &s_da.a.cs[sA][0][0], &s_in[sA][L::S_V], &s_in[sA][L::S_A], jA, blk, TASK ? kinA : nullptr);
+  if (TASK) {
+    // The frame's world placement, diff = log6(M_ref^-1 M_frame) and Jlog6 of a stage are evaluated ONCE, by the phase-A lane of the
+    // frame's joint -- the nine stages of the wavefront side by side -- out of the walk of the analytic recursion.  (Round 2 walked the
+    // chain a second time in every lane: taskSpaceColumn, dev_task.hpp -- still what the terminal and the line-search kernels use.)
+    const TaskCost& tc = P->task;
+    if (sA0 < SPA && jA == tc.joint) {
+      const double* __restrict__ ref = B.task_ref + 12 * s_stage[sA];
+      double fR[9], fp[3], e[3];
+      lieMatmul3(kinA, tc.R, fR);
+      lieMatvec3(kinA, tc.p, fp);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { fp[r] += kinA[9 + r]; e[r] = fp[r] - ref[9 + r]; }
+      double* o = s_task[sA];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) o[r] = fR[r];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) o[9 + r] = fp[r];
+      if (tc.dim == 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { o[12 + r] = e[r]; o[15 + r] = 0.0; }
+      } else {
+        double Rd[9], pd[3], df[6], J[36];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Rd[3 * r + c] = ref[r] * fR[c] + ref[3 + r] * fR[3 + c] + ref[6 + r] * fR[6 + c];
+          pd[r] = ref[r] * e[0] + ref[3 + r] * e[1] + ref[6 + r] * e[2];
+        }
+        lieLog6Jlog6(Rd, pd, df, J);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) o[12 + r] = df[r];
+#pragma unroll
+        for (int r = 0; r < 36; ++r) o[18 + r] = J[r];
+      }
+    }
+  }
   K1_T(1);
 
   // ---- phase B, SPW stages at a time: lane (stage g of the round, kind, k) assembles row k of its matrix d tau / d (q | v | a) ----
@@ -234,10 +270,8 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   double tau_d[NV], ID[NV];
 #pragma unroll
   for (int r = 0; r < NV; ++r) { tau_d[r] = s_da.dyn[g][kind * NV * NV + k * NV + r]; ID[r] = s_tau[rho * SPW + g][r] - s[L::S_U + r]; }
-  double kin[TASK ? 18 : 1];        // TASK: world placement (R, p) of joint k and its motion subspace S = (p x w, w), from the walk
+  double kin[TASK ? 18 : 1];        // TASK: the motion subspace S = (p x w, w) of joint k at [12, 18), from the walk
   if (TASK) {
-#pragma unroll
-    for (int e = 0; e < 12; ++e) kin[e] = s_kin[rho * SPW + g][e];      // (only the lane of the frame's joint uses it)
 #pragma unroll
     for (int e = 0; e < 6; ++e) kin[12 + e] = kinS[0][e];
 #pragma unroll
@@ -250,45 +284,12 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   // ---- task-space cost: gradient element k and the weighted column dt W JJ[:, k] (kept by the kind-0 lanes) ----
   double task_g = 0.0, task_wc[6];
   if (TASK) {
-    // The frame's world placement, diff = log6(M_ref^-1 M_frame) and Jlog6 are evaluated ONCE per stage, by the q-seed lane of the
-    // frame's joint, out of the walk of the analytic recursion; every lane then turns its own motion subspace into its column
-    // JJ[:, k] = Jlog6 (R_f^T (S.l + S.a x p_f), R_f^T S.a)  (3D: the world-frame linear part).  Round 2 walked the chain a second
-    // time in every lane (taskSpaceColumn, dev_task.hpp -- still what the terminal and the line-search kernels use).
+    // every lane turns its own motion subspace into its column JJ[:, k] = Jlog6 (R_f^T (S.l + S.a x p_f), R_f^T S.a)  (3D: the
+    // world-frame linear part) with the frame terms of its stage (s_task, evaluated behind phase A)
     double tdiff[6], tcol[6];
     {
       const TaskCost& tc = P->task;
-      const double* __restrict__ ref = B.task_ref + 12 * i;
-      if (g0 < SPW && kind == 0 && k == tc.joint) {
-        double fR[9], fp[3], e[3];
-        lieMatmul3(kin, tc.R, fR);
-        lieMatvec3(kin, tc.p, fp);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { fp[r] += kin[9 + r]; e[r] = fp[r] - ref[9 + r]; }
-        double* o = s_task[g];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) o[r] = fR[r];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) o[9 + r] = fp[r];
-        if (tc.dim == 3) {
-#pragma unroll
-          for (int r = 0; r < 3; ++r) { o[12 + r] = e[r]; o[15 + r] = 0.0; }
-        } else {
-          double Rd[9], pd[3], df[6], J[36];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Rd[3 * r + c] = ref[r] * fR[c] + ref[3 + r] * fR[3 + c] + ref[6 + r] * fR[6 + c];
-            pd[r] = ref[r] * e[0] + ref[3 + r] * e[1] + ref[6 + r] * e[2];
-          }
-          lieLog6Jlog6(Rd, pd, df, J);
-#pragma unroll
-          for (int r = 0; r < 6; ++r) o[12 + r] = df[r];
-#pragma unroll
-          for (int r = 0; r < 36; ++r) o[18 + r] = J[r];
-        }
-      }
-      WAVE_SYNC();
-      const double* o = s_task[g];
+      const double* o = s_task[rho * SPW + g];
 #pragma unroll
       for (int r = 0; r < 6; ++r) tdiff[r] = o[12 + r];
       // world-frame velocity of the frame origin per unit rate of joint k: S.l + S.a x p_f; zero past the frame's joint
