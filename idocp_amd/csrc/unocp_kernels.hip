@@ -217,6 +217,19 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   const int kind = (g0 < SPW) ? seed / NV : 0;
   const int k = (g0 < SPW) ? seed - kind * NV : 0;
   if (sA0 < SPA) s_tau[sA][jA] = blk[RneaBlock::TAU];
+  // slack and dual of the IPM rows the lane evaluates in each round (two rows of its seed kind): requested here, wanted far below
+  // (not beside a task-space cost: its registers are taken)
+  constexpr bool ROWS_AHEAD = !TASK;
+  double sl_all[ROWS_AHEAD ? ROUNDS : 1][2], du_all[ROWS_AHEAD ? ROUNDS : 1][2];
+#pragma unroll
+  for (int rho = 0; rho < (ROWS_AHEAD ? ROUNDS : 0); ++rho) {
+    long u = unit0 + rho * SPW + g; if (u >= total) u = total - 1;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      sl_all[rho][cc] = B.slack[u * L::CON + (2 * kind + cc) * NV + k];
+      du_all[rho][cc] = B.dual[u * L::CON + (2 * kind + cc) * NV + k];
+    }
+  }
   double rows[ROUNDS][NV];
   double kinS[TASK ? ROUNDS : 1][6];       // TASK: the motion subspace of joint k, per round
 #pragma unroll
@@ -248,12 +261,22 @@ __global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const 
   const double* __restrict__ s_g = B.sol + (b * (N + 1) + i) * L::SOL;
   const double* s = &s_in[rho * SPW + g][0];
   const double* sn = &s_in[rho * SPW + g][IN_SN];
-  // the IPM rows this lane evaluates: components (0, 1) / (2, 3) / (4, 5) of joint k on the q / v / a seed lane (read here, used below)
+  // the IPM rows this lane evaluates: components (0, 1) / (2, 3) / (4, 5) of joint k on the q / v / a seed lane
   double sl_own[2], du_own[2];
+  if (ROWS_AHEAD) {
 #pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
-    sl_own[cc] = B.slack[unit * L::CON + (2 * kind + cc) * NV + k];
-    du_own[cc] = B.dual[unit * L::CON + (2 * kind + cc) * NV + k];
+    for (int cc = 0; cc < 2; ++cc) { sl_own[cc] = sl_all[0][cc]; du_own[cc] = du_all[0][cc]; }
+#pragma unroll
+    for (int r = 0; r + 1 < (ROWS_AHEAD ? ROUNDS : 1); ++r) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) { sl_all[r][cc] = sl_all[r + 1][cc]; du_all[r][cc] = du_all[r + 1][cc]; }
+    }
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      sl_own[cc] = B.slack[unit * L::CON + (2 * kind + cc) * NV + k];
+      du_own[cc] = B.dual[unit * L::CON + (2 * kind + cc) * NV + k];
+    }
   }
   // the rows of the round into the image of the dyn record (element (r, c) of a matrix at c * NV + r): the lanes read columns below
   if (g0 < SPW) {
