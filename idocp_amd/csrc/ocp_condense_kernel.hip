@@ -104,6 +104,16 @@ struct CondenseSmem {
 // SplitOCP::constraintViolation (:292-346), |Fx|_1 + dt |[ID - u; C]|_1 + dt |g + slack|_1 + |P|_1; only the NOMINAL rigid-body
 // sweeps run (no tangent items).  Launched on a copy of the buffers whose sol points at the trial iterate.
 // XYY: the joint axes of the legs are known at compile time (OcpBuffers::leg_axes_xyy, dev_rnea_tangent.hpp JointFrame).
+// Barrier of the workgroup for exchanges through LDS: the LDS accesses of the wavefront are complete (s_waitcnt lgkmcnt(0)) before and
+// visible after; the global stores and loads in flight are NOT waited for, as __syncthreads() would (s_waitcnt vmcnt(0): the kkt / exp
+// entries a phase has just stored would have to reach memory before the next phase may start).  Nothing in the kernel hands data from
+// one wavefront to another through global memory.
+__device__ __forceinline__ void blockLdsBarrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = false, bool XYY = false>
 __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     if (tid < 36) { sm[S::JQ + tid] = prez[0]; sm[S::FQQ + tid] = prez[1]; sm[S::FQQI + tid] = prez[2]; sm[S::FQQP + tid] = prez[3]; sm[S::FQQPI + tid] = prez[4]; }
     if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = prez[5]; sm[S::FQ6 + tid - 64] = prez[6]; }
   }
-  __syncthreads();
+  blockLdsBarrier();
   STAMP(1);
 
   const double vref_on = nd->vref_on;          // TimeVaryingConfigurationSpaceCost::v_ref(t): zero outside the window
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       sm[S::ERR + tid] = 0.0;
     }
     if (RESIDUAL) {
-      __syncthreads();
+      blockLdsBarrier();
       if (tid == 0) {
         double e = 0.0; for (int t = 0; t < nt; ++t) e += sm[S::ERR + t];
         if (MERIT) { B.merit_stage[rec * 4] = e + (B.ext ? B.ext[rec * L::EXT + L::X_COST] : 0.0); B.merit_stage[rec * 4 + 1] = 0.0; } else B.err_stage[rec] = e;
@@ -527,20 +537,20 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_fetch_add(&s_c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  __syncthreads();
+  blockLdsBarrier();
   STAMP(2);
   if (MERIT) {
     // nominal [ID - u; C] (contact_dynamics.hxx:202-217; impulse stages: [ImD; C] from the lin record), the switching-constraint
     // residual P (forward_switching_constraint.hxx:27-47, from ocp_switch_kernel on the trial iterate), and the stage's totals
     rneaAssembleNominal<D>(tid, sc, out);
-    __syncthreads();
+    blockLdsBarrier();
     if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];
-    __syncthreads();
+    blockLdsBarrier();
     if (tid < dimvf) merit_viol += dt * fabs(sm[S::IDC + tid]);
     if (sw_dimi > 0 && tid >= 200 && tid < 200 + sw_dimi) merit_viol += fabs(B.swc[rec * L::SWC + L::W_P + tid - 200]);
-    __syncthreads();                                                   // ERR aliases the scratch
+    blockLdsBarrier();                                                   // ERR aliases the scratch
     sm[S::ERR + tid] = merit_cost; sm[S::ERR + nt + tid] = merit_viol;
-    __syncthreads();
+    blockLdsBarrier();
     if (tid < 2) {
       double e = 0.0;
       for (int t = 0; t < nt; ++t) e += sm[S::ERR + nt * tid + t];
@@ -557,9 +567,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   if (RESIDUAL) {
     // ---- C2 + SplitOCP::squaredNormKKTResidual (split_ocp.hxx:251-267); IPM residuals weighted by dt^2 (:264) ----
     rneaAssembleQV<D>(bwp, tid, nt, sc, out);
-    __syncthreads();
+    blockLdsBarrier();
     if (!impulse && tid >= 6 && tid < NV && nd->has_u) sm[S::IDC + tid] -= s_g[L::S_U + tid - 6];      // ID - u on the actuated rows (contact_dynamics.hxx:88)
-    __syncthreads();
+    blockLdsBarrier();
     if (tid >= 128 && tid < 128 + NV) {
       const int r = tid - 128;
       const double dq = dotAny(&sm[S::DIDC + SVF * r], 1, &sm[S::BM], 1, dimvf);
@@ -585,9 +595,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       const double pr = B.swc[rec * L::SWC + L::W_P + tid - 200];
       err_local += pr * pr;
     }
-    __syncthreads();                                                   // ERR aliases the scratch
+    blockLdsBarrier();                                                   // ERR aliases the scratch
     sm[S::ERR + tid] = err_local + (BWD ? 1.0 : dt * dt) * err_ipm;      // split_parnmpc.hxx:263 does not weight by dt^2
-    __syncthreads();
+    blockLdsBarrier();
     if (tid == 0) {
       double e = 0.0;
       for (int t = 0; t < nt; ++t) e += sm[S::ERR + t];
@@ -620,7 +630,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::FQ6 + r] = BWD ? acc : -acc;
   }
   if constexpr (EARLY_MJ) assembleTR();
-  __syncthreads();
+  blockLdsBarrier();
   if (tid < dimvf) {
     // ID - u on the actuated rows (contact_dynamics.hxx:88); [ID; C] also becomes column NX of dIDCdqv: MJtJinv [ID; C] then falls out
     // of the tile product below (round 2: a 24-term dot product per row on 24 threads, 1 us)
@@ -631,7 +641,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   if (tid >= 64 && tid < 64 + 6) sm[S::FQ + tid - 64] = sm[S::FQ6 + tid - 64];
   if constexpr (!EARLY_MJ) {
     assembleTR();
-    __syncthreads();
+    blockLdsBarrier();
   }
   STAMP(6);
   // TL = Minv - TR BL
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     acc += __shfl_xor(acc, 2);
     if (part == 0 && dst >= 0) sm[dst] += sgn * acc;
   }
-  __syncthreads();
+  blockLdsBarrier();
 
   const double hu = (PLAIN || nd->has_u) ? 1.0 : 0.0;          // impulse stages have no torque variables: Qafu = 0, Fvu = 0
   STAMP(7);
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::QAFU + NV + r + SVF * c] = hu * dotAny(&sm[S::QFF + r], SF, &sm[S::MJ + NV + SVF * c], 1, dimf);
   }
   STAMP(12);
-  __syncthreads();
+  blockLdsBarrier();
   STAMP(13);
   // Qafqv = -Qaf MJD (QAFQV aliases dIDC, which the product above was still reading)
 #pragma unroll
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     else { double acc = 0.0; for (int p = 0; p < dimf; ++p) acc += sm[S::QFF + (r - NV) + SF * p] * mjidc[NV + p]; val = -sm[S::LF + r - NV] - acc; }
     sm[S::LAF + r] = val;
   }
-  __syncthreads();
+  blockLdsBarrier();
   STAMP(8);
   // ---- H. condensed Hessian / gradients / dynamics (contact_dynamics.hxx:129-157) ----
   // Qxx = (cost + IPM terms) - MJD^T Qafqv ; Qxu_full = -MJD^T Qafu_full ; Quu_full = diag + MJ.topRows^T Qafu_full.
@@ -795,7 +805,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
   }
   static_assert(4 * (NX + NV) <= nt, "a quad per row of the vector updates");
-  __syncthreads();
+  blockLdsBarrier();
 
   STAMP(9);
   // ---- I. write the kkt and exp records ----
