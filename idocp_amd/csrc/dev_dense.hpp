@@ -306,6 +306,14 @@ __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// Barrier of a workgroup of several wavefronts for exchanges through LDS: the wavefront's LDS accesses are complete before and visible
+// after, but -- unlike __syncthreads() -- the global loads and stores in flight are not waited for (no s_waitcnt vmcnt(0)).  Only where no
+// data passes from one wavefront to another through global memory.
+__device__ __forceinline__ void blockLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // Inverse of the joint-space inertia matrix of a floating base with NL independent legs of LJ joints, by ONE wavefront, in
 // place (column-major, leading dimension ld, n = NB + NL LJ; only the UPPER triangle is read, like the reference, which mirrors

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dev_lie.hpp"
+#include "dev_dense.hpp"
 #include "ocp_device.hpp"
 #include "ocp_launch.hpp"
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   if (costate) wideStoreLds<RL / 2>(pb, pw, lane);
   if (expand) wideStoreLds<MJUL / 2>(mju, uw, lane);
   if (!terminal) wideStoreLds<L::SOL / 2>(sr, sw, lane);
-  __syncthreads();
+  waveLdsSync();
   if (lane < NX && costate) {
     // costate direction (split_riccati_factorizer.hxx:131-139): [dlmd; dgmm] = P dx - s, one row per lane
     const bool isv = lane >= NV;
@@ -186,9 +187,9 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     dd[(isv ? L::D_GMM : L::D_LMD) + r] = acc;
   }
   if (terminal) return;
-  __syncthreads();                                  // P has been read: the buffer takes MJtJinv_dIDCdqv
+  waveLdsSync();                                  // P has been read: the buffer takes MJtJinv_dIDCdqv
   if (expand) wideStoreLds<MJDL / 2>(mjd, mw, lane);
-  __syncthreads();
+  waveLdsSync();
   const long su = rec;
   const double* s = sr;
   const int dimf = nd->dimf, dimvf = NV + dimf;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
       }
     }
   }
-  __syncthreads();
+  waveLdsSync();
   double ps = 1.0, ds = 1.0;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   wideStoreLds<TL / 2>(tl, tw, lane);
   wideStoreLds<L::DIR / 2>(dr, dw, lane);
   wideStoreLds<L::SOL / 2>(sr, sw, lane);
-  __syncthreads();
+  waveLdsSync();
   const double* dx = dr + L::D_Q;                   // dq, dv are contiguous in the record
   static_assert(L::D_V == L::D_Q + NV, "dx = [dq; dv]");
   const double* du = dr + L::D_U;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
         nup[r] = v; dd[L::D_NUP + r] = v;
       }
     }
-    __syncthreads();
+    waveLdsSync();
     if (lane < dimvf) {
       const int r = lane;
       double acc = 0.0;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       dual[row] = dl + ad * ddual;
     }
   }
-  __syncthreads();
+  waveLdsSync();
   // ---- SplitSolution::integrate ----
   if (lane < NV) {
     const int r = lane;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
     if (lane < NF) dfs[lane] = dd[L::D_F + lane];
   }
   for (int e = lane; e < L::SOL; e += 64) st[e] = s[e];
-  __syncthreads();
+  waveLdsSync();
   if (lane < NV) {
     const int r = lane;
     st[L::S_V + r] = s[L::S_V + r] + a * dx[NV + r];

@@ -25,6 +25,7 @@
 // (= dC/ddv = J, emitted by the v- AND the a-seed lanes).
 #include <hip/hip_runtime.h>
 
+#include "dev_dense.hpp"
 #include "ocp_device.hpp"
 #include "ocp_launch.hpp"
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     const bool do_dyn = (pass == 0), do_con = (!impulse) || (pass == 1);
-    __syncthreads();
+    waveLdsSync();
     if (lane < NV) {
       const double vin = s[L::S_V + lane], ain = s[L::S_A + lane];
       // kinematic pass of an impulse stage: post-impact velocity = v + dv (forward Euler, impulse_split_ocp.hxx:47) or v itself
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
       s_v[lane] = impulse ? (pass == 0 ? 0.0 : (P->backward_euler ? vin : vin + ain)) : vin;
       s_a[lane] = impulse ? (pass == 0 ? ain : 0.0) : ain;
     }
-    __syncthreads();
+    waveLdsSync();
 #pragma unroll 1
     for (int round = 0; round < ROUNDS; ++round) {
       const int item = round * 64 + lane;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
       }
     }
     if (do_dyn) {
-      __syncthreads();
+      waveLdsSync();
       // base rows: tau[0:6] = total spatial force on the base (S = identity): own term + legs, in leg order
       for (int e = lane; e < 3 * NV * 6; e += 64) {
         const int c = e / 6, r = e - 6 * c, kind = c / NV, k = c - kind * NV;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
       }
     }
   }
-  __syncthreads();
+  waveLdsSync();
   // ---- coalesced write of the lin record ----
   double* __restrict__ lin = B.lin + rec * L::LIN;
   for (int e = lane; e < NVF * NX; e += 64) lin[L::L_DIDC + e] = (&s_out[0][0])[e];          // q and v seeds: 2 NV columns of NVF

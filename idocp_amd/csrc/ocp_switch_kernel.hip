@@ -16,6 +16,7 @@
 
 #include "dev_lie.hpp"
 #include "dev_rbd.hpp"
+#include "dev_dense.hpp"
 #include "ocp_device.hpp"
 #include "ocp_launch.hpp"
 
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B) {
   const double dt1 = nd->sw_dt1, dt2 = nd->sw_dt2;
   if (lane < NV) s_dq[lane] = (dt1 + dt2) * s[L::S_V + lane] + (dt1 * dt2) * s[L::S_A + lane];
   for (int e = lane; e < NF * (NV + 1); e += 64) (&s_pq[0][0])[e] = 0.0;
-  __syncthreads();
+  waveLdsSync();
   if (lane == 0) lieIntegrateBase(q, s_dq, 1.0, s_q2);
   if (lane >= 6 && lane < NV) s_q2[lane + 1] = q[lane + 1] + s_dq[lane];
   if (lane == 32) {
@@ -57,13 +58,13 @@ __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B) {
     lieJlog6(R, p, Jl);
     lieBlockInverse(Jl, s_Je);                     // dIntegrate_dv = Jexp6(dq) = Jlog6(exp6(dq))^-1
   }
-  __syncthreads();
+  waveLdsSync();
   if (lane < NU) {
     double sj, cj;
     sincos(s_q2[7 + lane], &sj, &cj);
     s_cs[lane][0] = cj; s_cs[lane][1] = sj;
   }
-  __syncthreads();
+  waveLdsSync();
   if (lane < NV) {
     const int k = lane;
     double Rn[9];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B) {
       }
     }
   }
-  __syncthreads();
+  waveLdsSync();
   double* __restrict__ W = B.swc + rec * L::SWC;
   if (lane < dimi) W[L::W_P + lane] = s_P[lane];
   for (int e = lane; e < dimi * NV; e += 64) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
   if (tid < 6) { Fq6[tid] = zz[L::Z_FQ6 + tid]; qdd[tid] = zz[L::Z_QDIFF + tid]; }
   if (tid < NC && nd->active[tid]) for (int x = 0; x < 3; ++x) { mu_p[nd->row_of[tid] + x] = s[L::S_MU + 3 * tid + x]; f_p[nd->row_of[tid] + x] = s[L::S_F + 3 * tid + x]; }
   for (int e = tid; e < NF * NF; e += 256) Qff[e] = 0.0;
-  __syncthreads();
+  blockLdsSync();
   // ---- impulse cost, state equation, multipliers of the impulse dynamics and of the velocity constraint: gradients ----
   if (tid < NV) {
     const int r = tid;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     }
     if (!cone) e_ipm = 0.0;
   }
-  __syncthreads();
+  blockLdsSync();
   if (MERIT) {
     if (tid < NV) {
       const int r = tid;
@@ -155,11 +155,11 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     }
     if (tid < ni) m_viol += fabs(Vr[tid]);
     err[tid] = m_cost;
-    __syncthreads();
+    blockLdsSync();
     if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.merit_stage[rec * 4] = acc; }
-    __syncthreads();
+    blockLdsSync();
     err[tid] = m_viol;
-    __syncthreads();
+    blockLdsSync();
     if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.merit_stage[rec * 4 + 1] = acc; }
     return;
   }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     if (tid < NV) e += lq[tid] * lq[tid] + lv[tid] * lv[tid] + ldv[tid] * ldv[tid] + Fq[tid] * Fq[tid] + Fv[tid] * Fv[tid] + ImD[tid] * ImD[tid];
     if (tid < ni) e += lf[tid] * lf[tid] + Vr[tid] * Vr[tid];
     err[tid] = e;
-    __syncthreads();
+    blockLdsSync();
     if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.err_stage[rec] = acc; }
     return;
   }
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     Fq[r] = acc;
   }
   // ---- Minv (Robot::computeMinv), Fvq = -Minv dImD/dq, Fvf = Minv Vv^T, Minv ImD ----
-  __syncthreads();
+  blockLdsSync();
   if (tid < 64) spdInverseRows<NV>(Mi, NV, NV, tid, &s_ok);
-  __syncthreads();
+  blockLdsSync();
   for (int e = tid; e < NV * NV; e += 256) {
     const int c = e / NV, r = e - c * NV;
     double acc = 0.0;
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     for (int m = 0; m < NV; ++m) acc += Mi[r + NV * m] * ImD[m];
     MiI[r] = acc;
   }
-  __syncthreads();
+  blockLdsSync();
   if (tid < NV) ldv[tid] -= P->dvi_weight[tid] * MiI[tid];            // data.ldv = ldv - Qdvdv Minv ImD
-  __syncthreads();
+  blockLdsSync();
   // ---- condensed blocks (Qdvq = Qdvdv Fvq, Qdvf = Qdvdv Fvf) ----
   // Qxx = [Qqq 0; 0 Qvv]
   for (int e = tid; e < NX * NX; e += 256) {
@@ -367,14 +367,14 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
   }
   if (tid < NR) sm[S::R1 + tid] = tid < NX ? kk[L::K_FX + tid] : (tid < nr ? Wc[L::W_P + tid - NX] : 0.0);
   if (tid >= 64 && tid < 64 + NQ) { const int r = tid - 64; sm[S::R2 + r] = r < NU ? (r < nw ? kk[L::K_LU + r] : 0.0) : kk[L::K_LX + r - NU]; }
-  __syncthreads();
+  blockLdsSync();
   // ---- Q^-1 ----
   gaussJordanTiles<NQ>(qinv, true, ti, tj, &sm[S::PV], &s_ok);
 #pragma unroll
   for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
     for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * ti + tr + NQ * (3 * tj + tc)] = qinv[tr][tc];
-  __syncthreads();
+  blockLdsSync();
   // ---- JQ = J Q^-1 (all 256 tiles), then w = Q^-1 r2 ----
   double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   tileMM<NQ>(acc, [&](int r, int m) { return sm[S::B + 3 * ti + r + NR * m]; },
@@ -384,12 +384,12 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
     for (int m = 0; m < NQ; ++m) w += sm[S::A + tid + NQ * m] * sm[S::R2 + m];
     sm[S::W + tid] = w;
   }
-  __syncthreads();                                   // Q^-1 is dead in LDS: JQ takes its place
+  blockLdsSync();                                   // Q^-1 is dead in LDS: JQ takes its place
 #pragma unroll
   for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
     for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * ti + tr + NR * (3 * tj + tc)] = acc[tr][tc];
-  __syncthreads();
+  blockLdsSync();
   // ---- S = J JQ^T (+ 1 on the padded diagonal) into register tiles, S^-1 ----
   double sinv[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   tileMM<NQ>(sinv, [&](int r, int m) { return sm[S::B + 3 * ti + r + NR * m]; },
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
   for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
     for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * ti + tr + NR * (3 * tj + tc)] = sinv[tr][tc];
-  __syncthreads();
+  blockLdsSync();
   // ---- TR = S^-1 JQ ; t1 = r1 - JQ r2 ; what else reads S^-1: TL = -S^-1[:, 0:NX] and -S^-1 r1 ----
 #pragma unroll
   for (int tr = 0; tr < 3; ++tr)
@@ -424,12 +424,12 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
     const int c = e / nr, r = e - c * nr;
     ki[L::I_C0 + r + L::NKG * c] = -sm[S::B + r + NR * c];
   }
-  __syncthreads();                                   // S^-1 is dead: TR takes its place
+  blockLdsSync();                                   // S^-1 is dead: TR takes its place
 #pragma unroll
   for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
     for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * ti + tr + NR * (3 * tj + tc)] = acc[tr][tc];
-  __syncthreads();
+  blockLdsSync();
   // ---- BR[:, NU:] = Q^-1[:, NU:] - TR^T JQ[:, NU:] by the threads that hold those tiles of Q^-1 ; coarse direction ----
   const bool b_on = tj >= NU / 3;
   if (b_on) {
@@ -450,14 +450,14 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
     for (int m = 0; m < NR; ++m) d += sm[S::B + m + NR * r] * sm[S::T1 + m];
     sm[S::DIR + NR + r] = d;
   }
-  __syncthreads();                                   // JQ is dead: BR[:, NU:] takes its place (NQ x NX)
+  blockLdsSync();                                   // JQ is dead: BR[:, NU:] takes its place (NQ x NX)
   if (b_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * ti + tr + NQ * (3 * (tj - NU / 3) + tc)] = qinv[tr][tc] - acc[tr][tc];
   }
-  __syncthreads();
+  blockLdsSync();
   // ---- column blocks of the inverse in the true row layout: C0 = KKT_inv[:, 0:NX] (top part written above),
   //      C1 = KKT_inv[:, nK-NX : nK] ----
   for (int e = tid; e < nK * NX; e += nt) {

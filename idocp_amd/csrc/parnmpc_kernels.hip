@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   if (tid < NX) sm[S::R1 + tid] = kk[L::K_FX + tid];
   if (tid >= 64 && tid < 64 + NU) sm[S::R2 + tid - 64] = kk[L::K_LU + tid - 64];
   if (tid >= 128 && tid < 128 + NX) sm[S::R2 + NU + tid - 128] = kk[L::K_LX + tid - 128];
-  __syncthreads();                                   // s_ok
+  blockLdsSync();                                   // s_ok
   // ---- Q^-1 (llt_Q_.solve(I), split_kkt_matrix_inverter.hxx:55-58); the tiles stay in registers for BR ----
   gaussJordanTiles<NQ>(qinv, q_on, qi, qj, &sm[S::PV], &s_ok);
   if (q_on) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * qi + tr + NQ * (3 * qj + tc)] = qinv[tr][tc];
   }
-  __syncthreads();
+  blockLdsSync();
   // ---- FQ = F Q^-1 (multiplyF, :60): TX x TQ tiles ; w = Q^-1 r2 ----
   const int fi = tid % TX, fj = tid / TX;            // tile of an NX x NQ matrix
   const bool f_on = tid < TX * TQ;
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
     for (int m = 0; m < NQ; ++m) w += sm[S::A + r + NQ * m] * sm[S::R2 + m];
     sm[S::W + r] = w;
   }
-  __syncthreads();                                   // Q^-1 is dead in LDS: FQ takes its place
+  blockLdsSync();                                   // Q^-1 is dead in LDS: FQ takes its place
   if (f_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
   }
-  __syncthreads();
+  blockLdsSync();
   // ---- S = F FQ^T (:61) into register tiles, S^-1 (:62-66) ----
   const bool s_on = tid < TX * TX;                   // (fi, fj) is then a tile of an NX x NX matrix as well
   double sinv[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * fi + tr + NX * (3 * fj + tc)] = sinv[tr][tc];
   }
-  __syncthreads();
+  blockLdsSync();
   // ---- TR = S^-1 FQ  (= - topLeft * Jac_Qinv, :67-69) ; t1 = r1 - FQ r2 ; what else reads S^-1: TL = -S^-1 (the top
   //      of C0) and the first half of the top of the coarse direction, -S^-1 r1 ----
 #pragma unroll
@@ -170,14 +170,14 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
     const int c = e / NX, r = e - c * NX;
     ki[L::I_C0 + r + NK * c] = -sm[S::B + e];
   }
-  __syncthreads();                                   // S^-1 is dead: TR takes its place
+  blockLdsSync();                                   // S^-1 is dead: TR takes its place
   if (f_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) sm[S::B + 3 * fi + tr + NX * (3 * fj + tc)] = acc[tr][tc];
   }
-  __syncthreads();
+  blockLdsSync();
   // ---- BR[:, NU:] = Q^-1[:, NU:] - TR^T FQ[:, NU:] (:70-78) by the threads that hold those tiles of Q^-1 ;
   //      coarse direction = KKT_inv * [r1; r2]: top = -S^-1 r1 + TR r2 ; bottom = Q^-1 r2 + TR^T (r1 - FQ r2) ----
   const bool b_on = q_on && qj >= TU;
@@ -199,14 +199,14 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
     for (int m = 0; m < NX; ++m) d += sm[S::B + m + NX * r] * sm[S::T1 + m];
     sm[S::DIR + NX + r] = d;
   }
-  __syncthreads();                                   // FQ is dead: BR[:, NU:] takes its place (NQ x NX)
+  blockLdsSync();                                   // FQ is dead: BR[:, NU:] takes its place (NQ x NX)
   if (b_on) {
 #pragma unroll
     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) sm[S::A + 3 * qi + tr + NQ * (3 * (qj - TU) + tc)] = qinv[tr][tc] - acc[tr][tc];
   }
-  __syncthreads();
+  blockLdsSync();
   // ---- the column blocks of the inverse: C0 = [TL; TR^T] with TL = -S^-1 (above) ; C1 = [TR[:, NU:]; BR[:, NU:]] ----
   for (int e = tid; e < NK * NX; e += nt) {
     const int c = e / NK, r = e - c * NK;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
       sn_i = B.snew[recp * L::SNEW + L::N_LMD + ln];
       loadRows(i - 1, row_next);
     }
-    __syncthreads();
+    waveLdsSync();
     double acc = 0.0;
 #pragma unroll
     for (int m = 0; m < NX; ++m) acc += row[m] * xb[m];
@@ -321,9 +321,9 @@ __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffer
   const ParnmpcShape sh = parnmpcShape<L>(B.nodes[pos]);
   const int ni = sh.ni, nw = sh.nw;
   if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
-  __syncthreads();
+  waveLdsSync();
   if (lane < sh.nk - NX) dz[lane] = blockRowDot<NX>(B.kinv + rec * L::KINV + sh.c1, sh.ld, NX + lane, x);     // (dxi | dmu, du | df, dq, dv)
-  __syncthreads();
+  waveLdsSync();
   double* __restrict__ sn = B.snew + rec * L::SNEW;
   if (lane < ni) sn[L::N_XI + lane] -= dz[lane];
   if (lane < nw) sn[L::N_U + lane] -= dz[ni + lane];
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
     }
     if (lane < NQ) { spL[lane] = sp_q; snL[lane] = sn_q; }
     if (lane < NV) { spL[NQ + lane] = sp_v; snL[NQ + lane] = sn_v; }
-    __syncthreads();
+    waveLdsSync();
     if (lane == 0) {
       double R[9], p[3], d6[6];
       lieRelative(spL, cur, R, p);          // s_new_prev.q (-) s_prev.q
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
     }
     if (lane >= 6 && lane < NV) x[lane] = cur[lane + 1] - spL[lane + 1];
     if (lane < NV) x[NV + lane] = cur[NQ + lane] - spL[NQ + lane];
-    __syncthreads();
+    waveLdsSync();
     if (lane < NX) {
       B.xres[rec * L::XRES + lane] = x[lane];
       double acc = 0.0;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
       for (int m = 0; m < NX; ++m) acc += arow[m] * x[m];
       dx[lane] = acc;
     }
-    __syncthreads();
+    waveLdsSync();
     if (lane < NV) {
       const double nv = snL[NQ + lane] - dx[NV + lane];
       sn[L::N_V + lane] = nv; cur[NQ + lane] = nv;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
       lieIntegrateBase(snL, dx, -1.0, qn);
       for (int k = 0; k < 7; ++k) { sn[L::N_Q + k] = qn[k]; cur[k] = qn[k]; }
     }
-    __syncthreads();
+    waveLdsSync();
   }
 }
 
@@ -433,16 +433,16 @@ __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers
   double* __restrict__ sn = B.snew + rec * L::SNEW;
   if (pos > 0 || P->has_prev) {
     if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
-    __syncthreads();
+    waveLdsSync();
     if (lane < sh.nk - NX) dh[lane] = blockRowDot<NX>(ki + L::I_C0, ld, lane, x);        // (dlmd, dgmm, dxi | dmu, du | df)
-    __syncthreads();
+    waveLdsSync();
     if (lane < NX) sn[L::N_LMD + lane] -= dh[lane];
     if (lane < ni) sn[L::N_XI + lane] -= dh[NX + lane];
     if (lane < nw) sn[L::N_U + lane] -= dh[NX + ni + lane];
   }
   double* __restrict__ aux = B.aux + rec * L::AUX;
   for (int e = lane; e < NX * NX; e += 64) { const int c = e / NX, r = e - c * NX; aux[e] = -ki[L::I_C0 + r + ld * c]; }
-  __syncthreads();
+  waveLdsSync();
   // computeDirection (split_backward_correction.hxx:141-154)
   const double* __restrict__ s = B.sol + rec * L::SOL;
   double* __restrict__ dd = B.dir + rec * L::DIR;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64) void parnmpc_init_aux_kernel(OcpBuffers B) {
     lieRelative(B.q_ref + (long)(M - 2) * NQ, B.sol + (base + B.nodes[M - 2].slot) * L::SOL + L::S_Q, R, p);
     lieJlog6(R, p, Jq);
   }
-  __syncthreads();
+  waveLdsSync();
   for (int pos = 0; pos < M - 1; ++pos) {
     double* __restrict__ aux = B.aux + (base + B.nodes[pos].slot) * L::AUX;
     for (int e = lane; e < NX * NX; e += 64) {
