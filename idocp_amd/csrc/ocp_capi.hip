@@ -951,9 +951,9 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
 }
 
 // K5b: one launch on an event-free chain with all feet in contact, else one launch per stage class
-static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q) {
-  if (h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] == 0) OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream);
-  else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream);
+static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q, int part = 0) {
+  if (h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] == 0) OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream, part);
+  else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, part);
 }
 
 // one SQP iteration on the handle's stream: K5 (+ K5a on impulse stages, K5s), S3, S4, K6, K7
@@ -971,7 +971,7 @@ static int launchUpdateO(idocp_ocp_t* h, int M, const double* d_q, const double*
 }
 
 int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, const double* d_v) {
-  if (!h || kernel_id < 0 || kernel_id > 6 || !d_q || !d_v) return IDOCP_E_ARG;
+  if (!h || kernel_id < 0 || kernel_id > 8 || !d_q || !d_v) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
   const int M = h->M();
@@ -981,6 +981,8 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
       if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
       break;
     case 1: launchCondenseO(h, M, d_q); break;
+    case 7: launchCondenseO(h, M, d_q, 1); break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
+    case 8: launchCondenseO(h, M, d_q, 2); break;      // ... and the condensation launches proper
     case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream); break;
     case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
     default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;

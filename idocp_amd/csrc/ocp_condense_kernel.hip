@@ -925,7 +925,8 @@ __global__ __launch_bounds__(64) void parnmpc_lie_kernel(OcpBuffers B, const dou
 // M = chain length; dimf >= 0: every non-terminal stage of the chain is a regular stage with `dimf` active contact rows
 // (enables the compile-time instantiation), -1: mixed chain.
 template <typename D>
-static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st, bool residual) {
+// part: 0 = everything, 1 = the nominal sweeps and the rows of the external terms only, 2 = the K5 launches only (bench.py brackets them apart)
+static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st, bool residual, int part = 0) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
@@ -937,8 +938,11 @@ static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, con
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
-  OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
-  OcpLaunch<D>::extRows(B, batch, M, residual, st);
+  if (part != 2) {
+    OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
+    OcpLaunch<D>::extRows(B, batch, M, residual, st);
+  }
+  if (part == 1) return;
   if (residual) hipLaunchKernelGGL((ocp_condense_kernel<D, true, -1>), dim3(blocks), dim3(256), smem, st, B, q0);
   else if (dimf == D::NF) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3(blocks), dim3(256), smem, st, B, q0); }
   else { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3(blocks), dim3(256), smem, st, B, q0); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3(blocks), dim3(256), smem, st, B, q0); }
@@ -946,15 +950,15 @@ static void launchCondense(const OcpBuffers& B, long batch, int M, int dimf, con
 }
 
 template <typename D>
-void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st) {
-  launchCondense<D>(B, batch, M, dimf, q0, st, false);
+void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st, int part) {
+  launchCondense<D>(B, batch, M, dimf, q0, st, false, part);
 }
 // Chains with discrete events: the stages are grouped on the host by what the kernel can fold at compile time --
 // class 0: all feet in contact, class 1: half of them (trot, pace, bound), both without impulse / switching constraint;
 // class 2: everything else (impulse stages, stages carrying a switching constraint, other contact counts, the terminal
 // stage) on the general instantiation.  B.cond_pos holds the chain positions class by class, n[c] their counts.
 template <typename D>
-void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[3], const double* q0, hipStream_t st) {
+void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[3], const double* q0, hipStream_t st, int part) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double), smem_half = CondenseSmem<D, D::NF / 2>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
@@ -968,8 +972,11 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   }
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
-  OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
-  OcpLaunch<D>::extRows(B, batch, M, false, st);
+  if (part != 2) {
+    OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
+    OcpLaunch<D>::extRows(B, batch, M, false, st);
+  }
+  if (part == 1) return;
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
@@ -1032,8 +1039,8 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
   if (!residual) OcpLaunch<D>::extHessian(B, batch, M, st);
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t);
-template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t, int);
+template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t, int);
 template void OcpLaunch<LeggedDims<4, 3>>::merit(const OcpBuffers&, long, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::meritBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);

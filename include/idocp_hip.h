@@ -580,7 +580,9 @@ int idocp_device_copy(void* d_dst, const void* d_src, unsigned long nbytes);
 
 /* One kernel launch: 0 = tangent RNEA, 1 = condense, 2 = backward Riccati,
  * 3 = forward Riccati, 4 = expand primal, 5 = step-size reduction,
- * 6 = expand dual + integrate. */
+ * 6 = expand dual + integrate; 7 and 8 = the two halves of 1 (7: the nominal
+ * rigid-body sweeps and the rows of the external terms, 8: the condensation
+ * launches), so that a profiler of the caller can bracket them apart. */
 int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q,
                             const double* d_v);
 
