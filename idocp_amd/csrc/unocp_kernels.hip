@@ -1113,10 +1113,13 @@ __global__ __launch_bounds__(64) void rnea_derivatives_kernel(const DevModel* __
 #define K9_T0() do { } while (0)
 #define K9_T(i) do { } while (0)
 #endif
+#ifndef K9U_SPB
+#define K9U_SPB 3          // stages (= wavefronts) per workgroup of the coarse update
+#endif
 template <int NV>
-__global__ __launch_bounds__(192) void unparnmpc_coarse_update_kernel(UnBuffers B) {
+__global__ __launch_bounds__(64 * K9U_SPB) void unparnmpc_coarse_update_kernel(UnBuffers B) {
   using L = UnLayout<NV>;
-  constexpr int NX = L::NX, NQ = L::NQ3, NK = 5 * NV, SPB = 3;
+  constexpr int NX = L::NX, NQ = L::NQ3, NK = 5 * NV, SPB = K9U_SPB;
   __shared__ double sQa[SPB][NQ * NQ], sFQa[SPB][NX * NQ], sSa[SPB][NX * NX], sTRa[SPB][NX * NQ], sresa[SPB][NK], st1a[SPB][NX], sda[SPB][NK];
   __shared__ int s_ok[SPB];
   const UnProblem* __restrict__ P = B.prob;
@@ -1684,7 +1687,7 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
       if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true, false, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
       else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
       break;
-    case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + 2) / 3)), dim3(192), 0, st, B); break;
+    case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + K9U_SPB - 1) / K9U_SPB)), dim3(64 * K9U_SPB), 0, st, B); break;
     case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
     case 3: hipLaunchKernelGGL((unparnmpc_backward_parallel_kernel<NV>), dim3((unsigned)((batch * N + 1) / 2)), dim3(64), 0, st, B); break;
     case 4: hipLaunchKernelGGL((unparnmpc_forward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B, q0, v0); break;
