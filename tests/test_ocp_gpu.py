@@ -60,6 +60,28 @@ def test_lqr_stage_parity_after_linearisation_kernels():
             assert rel_err(a, b) < TOL, (i, name)
 
 
+def test_condense_launch_in_two_halves_gives_the_same_records():
+    # idocp_ocp_launch_kernel ids 7 + 8 (nominal sweeps | condensation launches, bracketed apart by bench.py) == id 1
+    res = []
+    for ids in ((0, 1), (0, 7, 8)):
+        m, o, g, q, v = make_pair(6, 0.3)
+        assert g.update(0.2, q, v) == 0
+        d_q, d_v = C.c_void_p(), C.c_void_p()
+        lib = capi.lib()
+        capi.check(lib.idocp_device_alloc(C.byref(d_q), q.nbytes))
+        capi.check(lib.idocp_device_alloc(C.byref(d_v), v.nbytes))
+        capi.check(lib.idocp_device_upload(d_q, arr(q).ctypes.data, q.nbytes))
+        capi.check(lib.idocp_device_upload(d_v, arr(v).ctypes.data, v.nbytes))
+        for kid in ids:
+            capi.check(lib.idocp_ocp_launch_kernel(g.h, kid, d_q, d_v))
+        capi.check(lib.idocp_ocp_synchronize(g.h))
+        res.append([g.lqr_stage(i) for i in range(o.N)])
+    for sa, sb in zip(*res):
+        for a, b in zip(sa, sb):
+            assert np.array_equal(np.triu(a) if a.ndim == 2 and a.shape[0] == a.shape[1] else a, np.triu(b) if b.ndim == 2 and b.shape[0] == b.shape[1] else b)
+    assert lib.idocp_ocp_launch_kernel(g.h, 9, d_q, d_v) != 0
+
+
 @pytest.mark.parametrize("N,T,t", [(20, 1.0, 0.0), (100, 5.0, 0.0), (9, 0.45, 0.37)])
 def test_first_iteration_direction_parity(N, T, t):
     m, o, g, q, v = make_pair(N, T)
