@@ -125,12 +125,12 @@ def test_initial_state_offset_and_slack_data():
 
 
 def test_batch_instances_are_independent_and_ragged_batch_sizes():
-    # batch sizes that do not fill the last wavefront (8 instances / wave in S1, 3 stages / wave in K1)
+    # batch sizes that do not fill the last wavefront (8 instances / wave in S1, 9 consecutive stages / wave in K1: with N = 20 the
+    # boundaries between instances fall inside wavefronts; N = 4 and N = 1 put two and nine of them into one)
     m = iiwa14_model()
     cost, cons = unocp_problem(m)
-    N, T = 20, 1.0
     rng = np.random.default_rng(20240)
-    for batch in (1, 3, 11):
+    for N, T, batch in ((20, 1.0, 1), (20, 1.0, 3), (20, 1.0, 11), (4, 0.2, 7), (1, 0.05, 10)):
         g = HipUnOCP(m, cost, cons, T, N, batch=batch)
         q0 = 2.0 + 0.1 * rng.uniform(-1, 1, (batch, m.nv))
         v0 = np.zeros((batch, m.nv))
@@ -143,7 +143,7 @@ def test_batch_instances_are_independent_and_ragged_batch_sizes():
             o.set_solution("v", v0[b])
             o.update(0.0, q0[b], v0[b])
             for f in DIR_FIELDS:
-                assert rel_err(g.direction(f, b), o.direction(f)) < TOL, (batch, b, f)
+                assert rel_err(g.direction(f, b), o.direction(f)) < TOL, (N, batch, b, f)
 
 
 def test_full_size_properties_c2():
