@@ -114,6 +114,7 @@ struct idocp_ocp {
   bool seq_dirty = true, has_switch = false;
   int n_impulse = 0;
   int* d_impulse_pos = nullptr;
+  int* d_switch_pos = nullptr;
   int* d_general_pos = nullptr;     // ParNMPC: chain positions of the aux (switching rows) / impulse stages
   int* d_cond_pos = nullptr;        // chain positions by stage class of K5b (all feet | half of them | the rest)
   int cond_n[3] = {0, 0, 0};
@@ -317,6 +318,10 @@ int discretize(idocp_ocp* h, double t) {
   h->n_impulse = (int)ipos.size();
   h->B.n_impulse_fe = h->parnmpc ? 0 : h->n_impulse;
   if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> spos;
+  for (int p = 0; p + 1 < M; ++p) if (h->chain[p].sw_dimi > 0) spos.push_back(p);
+  h->B.n_switch = (int)spos.size();
+  if (!spos.empty()) HIP_TRY(hipMemcpyAsync(h->d_switch_pos, spos.data(), sizeof(int) * spos.size(), hipMemcpyHostToDevice, h->stream));
   // stage classes of K5b (OcpLaunch::condenseMixed)
   std::vector<int> cls[3];
   for (int p = 0; p < M; ++p) {
@@ -479,6 +484,10 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   h->n_impulse = (int)ipos.size();
   h->B.n_impulse_fe = h->parnmpc ? 0 : h->n_impulse;
   if (!ipos.empty()) HIP_TRY(hipMemcpyAsync(h->d_impulse_pos, ipos.data(), sizeof(int) * ipos.size(), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> spos;
+  for (int p = 0; p + 1 < M; ++p) if (h->chain[p].sw_dimi > 0) spos.push_back(p);
+  h->B.n_switch = (int)spos.size();
+  if (!spos.empty()) HIP_TRY(hipMemcpyAsync(h->d_switch_pos, spos.data(), sizeof(int) * spos.size(), hipMemcpyHostToDevice, h->stream));
   std::vector<int> gpos;
   for (int p = 0; p < M; ++p) if (parnmpcShape<LQ>(h->chain[p]).general) gpos.push_back(p);
   h->n_general = (int)gpos.size();
@@ -508,7 +517,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   h->chain_t[N] = t + (h->stage_offset + N) * dt;
   h->prob.has_terminal = h->has_terminal ? 1 : 0; h->prob.has_prev = h->has_prev ? 1 : 0; h->prob.stage_offset = h->stage_offset;
   h->Ngrid = N - 1;                  // getters: stages 0 .. N-1
-  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0; h->B.n_impulse_fe = 0; h->n_general = 0;
+  h->uniform_dimf = -1; h->has_switch = false; h->n_impulse = 0; h->B.n_impulse_fe = 0; h->n_general = 0; h->B.n_switch = 0;
   const int M = N + 1;
   std::vector<double> tab((size_t)M * DQ::NQ);
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
@@ -656,6 +665,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &tmp, ((size_t)(max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
   h->d_impulse_pos = reinterpret_cast<int*>(tmp);
   B.impulse_pos = h->d_impulse_pos;
+  if ((rc = allocBufO(h, &tmp, ((size_t)(max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
+  h->d_switch_pos = reinterpret_cast<int*>(tmp);
+  B.switch_pos = h->d_switch_pos;
+  B.n_switch = 0;
   if ((rc = allocBufO(h, &tmp, ((size_t)(2 * max_num_impulse + 1) * sizeof(int) + 7) / 8))) return fail(rc);
   h->d_general_pos = reinterpret_cast<int*>(tmp);
   B.general_pos = h->d_general_pos;

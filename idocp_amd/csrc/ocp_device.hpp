@@ -201,6 +201,8 @@ struct OcpBuffers {
   const int* impulse_pos; // chain positions of the impulse stages
   int n_impulse_fe;       // host-side: number of impulse stages of a FORWARD-EULER chain (OCPSolver): nominal records + tangent items; 0 under ParNMPC (K5a / K9i)
   const int* general_pos; // ParNMPC: chain positions of the stages with a general KKT shape (aux with switching rows, impulse)
+  const int* switch_pos;  // chain positions of the stages that carry a switching constraint (K5s runs on these only)
+  int n_switch;           // host-side: their number
   const int* cond_pos;    // chain positions grouped by stage class of K5b (OcpLaunch::condenseMixed)
   int leg_axes_xyy;       // host-side: every leg is (joint about +x, about +y, about +y) with identity placement rotations, and the
                           // contact frames are not rotated against their joints (ANYmal):

@@ -23,15 +23,17 @@
 namespace idocp_dev {
 
 template <typename D>
-__global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B, int nsw) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NL = D::NL, LJ = D::LJ, NF = D::NF, NU = D::NU;
   typedef Dual T;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = P->M;
+  // (a workgroup per instance and stage WITH a switching constraint: launched over every stage of the chain, the 110 of 119 workgroups
+  //  per instance that returned at once still cost their dispatch -- 0.10 ms for a kernel with 0.03 ms of work)
   const long unit = blockIdx.x;
-  const long b = unit / (M - 1);
-  const int pos = (int)(unit - b * (M - 1));
+  const long b = unit / nsw;
+  const int pos = B.switch_pos[(int)(unit - b * nsw)];
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const int dimi = nd->sw_dimi;
   if (dimi == 0) return;
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B) {
 
 template <typename D>
 void OcpLaunch<D>::switching(const OcpBuffers& B, long batch, int M, hipStream_t st) {
-  hipLaunchKernelGGL((ocp_switch_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B);
+  if (B.n_switch <= 0) return;
+  hipLaunchKernelGGL((ocp_switch_kernel<D>), dim3((unsigned)(batch * B.n_switch)), dim3(64), 0, st, B, B.n_switch);
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::switching(const OcpBuffers&, long, int, hipStream_t);
