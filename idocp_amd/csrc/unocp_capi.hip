@@ -832,7 +832,9 @@ int idocp_rnea_derivatives(const idocp_model_t* model, int n, const double* q, c
   HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * n * nv, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_v, v, sizeof(double) * n * nv, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_a, a, sizeof(double) * n * nv, hipMemcpyHostToDevice));
-  UnLaunch<7>::rneaDerivatives(d_m, n, d_q, d_v, d_a, d_tau, d_dq, d_dv, d_da, nullptr);
+  bool zaxes = !std::getenv("IDOCP_GENERAL_AXES");      // (the same choice of the sweep's instantiation as the solvers make)
+  for (int i = 0; i < model->njoints; ++i) if (!(model->axis[i][0] == 0.0 && model->axis[i][1] == 0.0 && model->axis[i][2] == 1.0)) zaxes = false;
+  UnLaunch<7>::rneaDerivatives(d_m, n, d_q, d_v, d_a, d_tau, d_dq, d_dv, d_da, zaxes, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(tau, d_tau, sizeof(double) * n * nv, hipMemcpyDeviceToHost));

@@ -1056,34 +1056,60 @@ __global__ void un_fill_field_kernel(double* __restrict__ sol, int stride, int o
   sol[rec * stride + offset + e] = value[(per_instance ? b * dim : 0) + e];
 }
 
-// Stand-alone inverse dynamics + derivatives for n samples (parity tests of the
-// rigid-body layer): same lane mapping as K1.
-template <int NV>
-__global__ __launch_bounds__(64) void rnea_derivatives_kernel(const DevModel* __restrict__ model, int n,
-                                                             const double* __restrict__ q, const double* __restrict__ v,
-                                                             const double* __restrict__ a, double* __restrict__ tau,
-                                                             double* __restrict__ dq, double* __restrict__ dv,
-                                                             double* __restrict__ da) {
-  constexpr int LPS = 3 * NV, SPW = 64 / LPS;
+// Stand-alone inverse dynamics + derivatives for n samples (parity tests of the rigid-body layer against the reference's golden
+// vectors): the two-phase analytic recursion exactly as K1 runs it -- phase A with a lane per (sample, joint), nine samples per
+// wavefront, then the rows of three samples at a time (dev_rnea_analytic.hpp).
+template <int NV, bool ZAX>
+__global__ __launch_bounds__(64, 2) void rnea_derivatives_kernel(const DevModel* __restrict__ model, int n,
+                                                                const double* __restrict__ q, const double* __restrict__ v,
+                                                                const double* __restrict__ a, double* __restrict__ tau,
+                                                                double* __restrict__ dq, double* __restrict__ dv,
+                                                                double* __restrict__ da) {
+  constexpr int LPS = 3 * NV, SPW = 64 / LPS, SPA = 64 / NV, ROUNDS = SPA / SPW, BLK = RneaBlock::LEN;
+  static_assert(SPA == SPW * ROUNDS, "whole rounds");
+  __shared__ ChainConsts<NV> s_model;
+  __shared__ double s_cs[SPA][NV][2], s_v[SPA][NV], s_a[SPA][NV];
+  __shared__ double s_pub[SPW][NV][BLK];
   const int lane = threadIdx.x;
-  const int g = lane / LPS;
-  const int seed = lane - g * LPS;
-  const int kind = seed / NV, k = seed - kind * NV;
-  const long smp = (long)blockIdx.x * SPW + g;
-  __shared__ double s_cs[SPW][NV][2];
-  const bool on = (g < SPW) && (smp < n);
-  const long sm = on ? smp : 0;
-  const int gg = g < SPW ? g : SPW - 1;
-  if (on && seed < NV) {
+  const long smp0 = (long)blockIdx.x * SPA;
+  const int sA0 = lane / NV;
+  const int sA = sA0 < SPA ? sA0 : SPA - 1;
+  const int jA = sA0 < SPA ? lane - sA0 * NV : 0;
+  const long smpA = smp0 + sA < n ? smp0 + sA : n - 1;
+  s_model.load(model, lane, 64);
+  if (sA0 < SPA) {
     double sj, cj;
-    sincos(q[sm * NV + seed], &sj, &cj);
-    s_cs[gg][seed][0] = cj; s_cs[gg][seed][1] = sj;
+    sincos(q[smpA * NV + jA], &sj, &cj);
+    s_cs[sA][jA][0] = cj; s_cs[sA][jA][1] = sj;
+    s_v[sA][jA] = v[smpA * NV + jA]; s_a[sA][jA] = a[smpA * NV + jA];
   }
   WAVE_SYNC();
-  if (!on) return;
+  double blk[BLK];
+  rneaDerivPhaseA<NV, ZAX>(&s_model, &s_cs[sA][0][0], &s_v[sA][0], &s_a[sA][0], jA, blk, nullptr);
+  if (sA0 < SPA && smp0 + sA0 < n) tau[(smp0 + sA0) * NV + jA] = blk[RneaBlock::TAU];
+  const int g0 = lane / LPS;
+  const int g = g0 < SPW ? g0 : SPW - 1;
+  const int seed = lane - g0 * LPS;
+  const int kind = (g0 < SPW) ? seed / NV : 0;
+  const int k = (g0 < SPW) ? seed - kind * NV : 0;
   double* out = (kind == 0) ? dq : ((kind == 1) ? dv : da);
-  rneaChain<NV>(model, &s_cs[gg][0][0], v + sm * NV, a + sm * NV, kind, k, seed == 0, tau + sm * NV,
-                out + sm * NV * NV + k * NV);
+#pragma unroll
+  for (int rho = 0; rho < ROUNDS; ++rho) {
+    WAVE_SYNC();
+    if (sA0 < SPA && sA0 / SPW == rho) {
+      double* o = &s_pub[sA0 - rho * SPW][jA][0];
+#pragma unroll
+      for (int e = 0; e < BLK; ++e) o[e] = blk[e];
+    }
+    WAVE_SYNC();
+    double row[NV];
+    rneaDerivPhaseB<NV>(&s_pub[g][0][0], BLK, kind, k, row);
+    const long smp = smp0 + rho * SPW + g;
+    if (g0 < SPW && smp < n) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) out[smp * NV * NV + c * NV + k] = row[c];      // element (k, c) of the column-major matrix
+    }
+  }
 }
 
 
@@ -1651,10 +1677,11 @@ void UnLaunch<NV>::initConstraints(const UnBuffers& B, long batch, int N, hipStr
   }
 template <int NV>
 void UnLaunch<NV>::rneaDerivatives(const DevModel* m, int n, const double* q, const double* v, const double* a, double* tau,
-                              double* dq, double* dv, double* da, hipStream_t st) {
-    constexpr int SPW = 64 / (3 * NV);
-    hipLaunchKernelGGL((rnea_derivatives_kernel<NV>), dim3((unsigned)((n + SPW - 1) / SPW)), dim3(64), 0, st, m, n, q, v, a,
-                       tau, dq, dv, da);
+                              double* dq, double* dv, double* da, bool zaxes, hipStream_t st) {
+    constexpr int SPA = 64 / NV;
+    const dim3 grid((unsigned)((n + SPA - 1) / SPA));
+    if (zaxes) hipLaunchKernelGGL((rnea_derivatives_kernel<NV, true>), grid, dim3(64), 0, st, m, n, q, v, a, tau, dq, dv, da);
+    else hipLaunchKernelGGL((rnea_derivatives_kernel<NV, false>), grid, dim3(64), 0, st, m, n, q, v, a, tau, dq, dv, da);
   }
 
 template <int NV>

@@ -24,7 +24,7 @@ struct UnLaunch {
   // UnLineSearch::computeCostAndViolation at the trial steps B.ls_alpha -> B.ls_out
   static void lineSearchEval(const UnBuffers& B, long batch, int N, bool bwd, const double* q0, const double* v0, hipStream_t st);
   static void rneaDerivatives(const DevModel* m, int n, const double* q, const double* v, const double* a, double* tau,
-                              double* dq, double* dv, double* da, hipStream_t st);
+                              double* dq, double* dv, double* da, bool zaxes, hipStream_t st);
 };
 
 void stridedCopy(double* dst, long dst_stride, long dst_off, const double* src, long src_stride, long src_off, int n, long batch, hipStream_t st);
