@@ -1281,10 +1281,10 @@ static int getRiccati(idocp_ocp_t* h, int instance, int chain, double* P, double
     if (P) {
       double* Pm = P + (size_t)i * nx * nx;
       for (int c = 0; c < nv; ++c) for (int rr = 0; rr < nv; ++rr) {
-        Pm[c * nx + rr] = r[LQ::R_PQQ + c * nv + rr];
+        Pm[c * nx + rr] = r[LQ::R_PQQ + LQ::psym(rr, c)];          // (packed upper triangle)
         Pm[(nv + c) * nx + rr] = r[LQ::R_PQV + c * nv + rr];
         Pm[c * nx + nv + rr] = r[LQ::R_PQV + rr * nv + c];
-        Pm[(nv + c) * nx + nv + rr] = r[LQ::R_PVV + c * nv + rr];
+        Pm[(nv + c) * nx + nv + rr] = r[LQ::R_PVV + LQ::psym(rr, c)];
       }
     }
     if (s) { std::memcpy(s + (size_t)i * nx, r + LQ::R_SQ, sizeof(double) * nv); std::memcpy(s + (size_t)i * nx + nv, r + LQ::R_SV, sizeof(double) * nv); }

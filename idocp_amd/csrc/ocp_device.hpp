@@ -56,7 +56,11 @@ struct OcpLayout {
                        E_MJIDC = E_QFF + NF * NF, E_LAF = E_MJIDC + NVF, E_LUP = E_LAF + NVF, E_QUUP = E_LUP + 6,
                        E_QXUP = E_QUUP + 6 * NU, E_FQQPI = E_QXUP + NX * 6;
   static constexpr int EXP = roundUp16(E_FQQPI + 36);
-  static constexpr int R_PQQ = 0, R_PQV = NV * NV, R_PVV = 2 * NV * NV, R_SQ = 3 * NV * NV, R_SV = R_SQ + NV;
+  // Riccati factorisation of a stage: Pqq and Pvv are symmetric and travel as their UPPER triangle, column by column -- entry (r, c),
+  // r <= c, at c (c + 1) / 2 + r (round 3: 2.4 of the record's 8.1 kB were the mirror image of the rest; S3 writes it, K6 reads it)
+  static constexpr int P_TRI = (NV * (NV + 1) / 2 + 1) / 2 * 2;
+  __host__ __device__ static constexpr int psym(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
+  static constexpr int R_PQQ = 0, R_PQV = P_TRI, R_PVV = R_PQV + NV * NV, R_SQ = R_PVV + P_TRI, R_SV = R_SQ + NV;
   static constexpr int RIC = roundUp16(R_SV + NV);
   // Lie-group terms of the floating base, produced by the small pre-kernel (6x6 blocks column-major)
   static constexpr int Z_JQ = 0, Z_QDIFF = 36, Z_FQQ = 44, Z_FQ6 = 80, Z_FQQI = 88, Z_FQQP = 124, Z_FQQPI = 160;

@@ -179,10 +179,10 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     double acc = -pb[(isv ? L::R_SV : L::R_SQ) + r];
     if (!isv) {
 #pragma unroll
-      for (int c = 0; c < NV; ++c) acc += pb[L::R_PQQ + r + NV * c] * dx[c] + pb[L::R_PQV + r + NV * c] * dx[NV + c];
+      for (int c = 0; c < NV; ++c) acc += pb[L::R_PQQ + L::psym(r, c)] * dx[c] + pb[L::R_PQV + r + NV * c] * dx[NV + c];
     } else {
 #pragma unroll
-      for (int c = 0; c < NV; ++c) acc += pb[L::R_PQV + c + NV * r] * dx[c] + pb[L::R_PVV + r + NV * c] * dx[NV + c];
+      for (int c = 0; c < NV; ++c) acc += pb[L::R_PQV + c + NV * r] * dx[c] + pb[L::R_PVV + L::psym(r, c)] * dx[NV + c];
     }
     dd[(isv ? L::D_GMM : L::D_LMD) + r] = acc;
   }

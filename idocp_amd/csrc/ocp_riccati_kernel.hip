@@ -357,7 +357,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
       const int c = e / NV, r = e - c * NV;
       const double pqq = st32(kk[L::K_QXX + r + NX * c]), pvv = st32(kk[L::K_QXX + (NV + r) + NX * (NV + c)]);
       Pqq[e] = pqq; Pqv[e] = 0.0; Pvv[e] = pvv;
-      rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = 0.0; rr[L::R_PVV + e] = pvv;
+      rr[L::R_PQV + e] = 0.0;
+      if (r <= c) { rr[L::R_PQQ + L::psym(r, c)] = pqq; rr[L::R_PVV + L::psym(r, c)] = pvv; }
     }
     if (tid < NV) {
       const double sq = st32(-kk[L::K_LX + tid]), sv = st32(-kk[L::K_LX + NV + tid]);
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     RSTAMP(7);
     double* __restrict__ rr = B.ric + rec * L::RIC;
     double* __restrict__ gg = B.gain + rec * L::GAIN;
-    static_assert(S::PQQ == 0 && L::R_PQQ == 0 && L::R_PQV == NN && L::R_PVV == 2 * NN && NN % 2 == 0 && L::RIC % 2 == 0, "P is one contiguous copy");
+    static_assert(S::PQV % 2 == 0 && L::R_PQV % 2 == 0 && NN % 2 == 0 && L::RIC % 2 == 0, "Pqv is one contiguous copy");
     if (HYBRID && dimi > 0) {
       for (int e = tid; e < NN; e += nt) {
         // P -= K^T D^T M + (K^T D^T M)^T, block by block (split_riccati_factorizer.hxx:88-97)
@@ -667,11 +668,16 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
         }
         const double pqq = st32(Pqq[e] - aqq), pqv = st32(Pqv[e] - aqv), pvv = st32(Pvv[e] - avv);
         Pqq[e] = pqq; Pqv[e] = pqv; Pvv[e] = pvv;
-        rr[L::R_PQQ + e] = pqq; rr[L::R_PQV + e] = pqv; rr[L::R_PVV + e] = pvv;
+        rr[L::R_PQV + e] = pqv;
+        if (r <= c) { rr[L::R_PQQ + L::psym(r, c)] = pqq; rr[L::R_PVV + L::psym(r, c)] = pvv; }
       }
     } else {
       if (p32) { for (int e = tid; e < 3 * NN; e += nt) Pqq[e] = (double)(float)Pqq[e]; blockSync<NW>(); }      // (uniform branch)
-      for (int e = tid; e < 3 * NN / 2; e += nt) reinterpret_cast<rd2*>(rr)[e] = reinterpret_cast<const rd2*>(Pqq)[e];
+      for (int e = tid; e < NN / 2; e += nt) reinterpret_cast<rd2*>(rr + L::R_PQV)[e] = reinterpret_cast<const rd2*>(Pqv)[e];
+      for (int e = tid; e < NN; e += nt) {               // the upper triangles of Pqq, Pvv
+        const int c = e / NV, r = e - c * NV;
+        if (r <= c) { rr[L::R_PQQ + L::psym(r, c)] = Pqq[e]; rr[L::R_PVV + L::psym(r, c)] = Pvv[e]; }
+      }
     }
     if (tid < NV) {
       double sq = sm[S::SQN + tid], sv = sm[S::SVN + tid];
