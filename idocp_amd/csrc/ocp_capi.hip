@@ -1422,7 +1422,7 @@ int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx
   std::vector<double> k(LQ::KKT);
   HIP_TRY(hipMemcpyAsync(k.data(), h->B.kkt + ((size_t)instance * h->NS + stage) * LQ::KKT, k.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  std::memcpy(Qxx, &k[LQ::K_QXX], sizeof(double) * nx * nx);
+  for (int c = 0; c < nx; ++c) for (int r = 0; r < nx; ++r) Qxx[c * nx + r] = k[LQ::K_QXX + LQ::xsym(r, c)];      // (the record holds the upper triangle)
   std::memcpy(Qxu, &k[LQ::K_QXU], sizeof(double) * nx * nu);
   std::memcpy(Quu, &k[LQ::K_QUU], sizeof(double) * nu * nu);
   std::memset(A, 0, sizeof(double) * nx * nx);

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       double val = 0.0;
       if (r < 6 && c < 6) { for (int m2 = 0; m2 < 6; ++m2) val += sm[S::JQ + m2 + 6 * r] * P->qf_weight[m2] * sm[S::JQ + m2 + 6 * c]; }
       else if (r == c) val = (r < NV) ? P->qf_weight[r] : P->vf_weight[r - NV];
-      kk[L::K_QXX + e] = val;
+      if (r <= c) kk[L::K_QXX + L::xsym(r, c)] = val;
     }
     if (tid < 36) ee[L::E_FQQPI + tid] = sm[S::FQQPI + tid];
     return;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
           double base = 0.0;
           if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
           else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
-          kk[L::K_QXX + r + NX * c] = base - v;
+          if (r <= c) kk[L::K_QXX + L::xsym(r, c)] = base - v;      // (the tiles on the diagonal carry both triangles)
         });
       } else if (j < 12) {
         mfmaTileStore(acc, r0, c0, NX, NV, lane, [&](int r, int c, double v) {

@@ -42,7 +42,11 @@ struct OcpLayout {
   static constexpr int L_DIDC = 0, L_M = NVF * NX, L_J = L_M + NV * NV, L_IDC = L_J + NF * NV;
   static constexpr int LIN = roundUp16(L_IDC + NVF);
   // condensed LQR stage for the Riccati sweep
-  static constexpr int K_QXX = 0, K_QXU = NX * NX, K_QUU = K_QXU + NX * NU, K_FQQ = K_QUU + NU * NU, K_FQV = K_FQQ + 36,
+  // Qxx is symmetric and travels as its UPPER triangle, column by column: entry (r, c), r <= c, at K_QXX + c (c + 1) / 2 + r
+  // (round 3: 5 of the record's 23 kB were the mirror image of the rest -- every reader used the upper triangle already)
+  static constexpr int X_TRI = (NX * (NX + 1) / 2 + 1) / 2 * 2;
+  __host__ __device__ static constexpr int xsym(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }
+  static constexpr int K_QXX = 0, K_QXU = X_TRI, K_QUU = K_QXU + NX * NU, K_FQQ = K_QUU + NU * NU, K_FQV = K_FQQ + 36,
                        K_FVQ = K_FQV + 36, K_FVV = K_FVQ + NV * NV, K_FVU = K_FVV + NV * NV, K_LX = K_FVU + NV * NU,
                        K_LU = K_LX + NX, K_FX = K_LU + NU;
   static constexpr int KKT = roundUp16(K_FX + NX);

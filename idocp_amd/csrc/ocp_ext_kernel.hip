@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void ocp_ext_hessian_kernel(OcpBuffers B) {
     for (int c = 0; c < NC; ++c) acc += w[c] * xx[L::X_CDJ + c * NV + r] * xx[L::X_CDJ + c * NV + c2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc += w[NC + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c2];
-    kk[L::K_QXX + r + NX * c2] += acc;
+    if (r <= c2) kk[L::K_QXX + L::xsym(r, c2)] += acc;
   }
 }
 

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
     double* __restrict__ rr = B.ric + (base + nodes[M - 1].slot) * L::RIC;
     for (int e = tid; e < NN; e += nt) {
       const int c = e / NV, r = e - c * NV;
-      const double pqq = st32(kk[L::K_QXX + r + NX * c]), pvv = st32(kk[L::K_QXX + (NV + r) + NX * (NV + c)]);
+      const double pqq = st32(kk[L::K_QXX + L::xsym(r, c)]), pvv = st32(kk[L::K_QXX + L::xsym(NV + r, NV + c)]);
       Pqq[e] = pqq; Pqv[e] = 0.0; Pvv[e] = pvv;
       rr[L::R_PQV + e] = 0.0;
       if (r <= c) { rr[L::R_PQQ + L::psym(r, c)] = pqq; rr[L::R_PVV + L::psym(r, c)] = pvv; }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int c = 16 * jb + g + 4 * q;
-          qxx[jj][q] = (t < t2e && r <= c && c < NX) ? kc[L::K_QXX + r + NX * c] : 0.0;
+          qxx[jj][q] = (t < t2e && r <= c && c < NX) ? kc[L::K_QXX + L::xsym(r, c)] : 0.0;
         }
       }
     };

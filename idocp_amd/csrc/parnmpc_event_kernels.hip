@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     } else if (r == c) {
       v = P->vi_weight[r - NV];
     }
-    kk[L::K_QXX + e] = v;
+    if (r <= c) kk[L::K_QXX + L::xsym(r, c)] = v;
   }
   // Qxf = [Qqf; 0] in the place of Qxu, Qff in the place of Quu, Fvf in the place of Fvu
   for (int e = tid; e < NX * NU; e += 256) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
         int rr = r - NU, cc = c - NU;
         const double ax = last ? 0.0 : aux[rr + NX * cc];
         if (rr > cc) { const int t = rr; rr = cc; cc = t; }      // K5 writes the triangle on and above the diagonal (Qxx symmetric, Qvq = Qqv^T)
-        v = kk[L::K_QXX + rr + NX * cc] + ax;
+        v = kk[L::K_QXX + L::xsym(rr, cc)] + ax;
       }
       qinv[tr][tc] = v;
     }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
           int rr = r - NU, cc = c - NU;
           const double ax = last ? 0.0 : aux[rr + NX * cc];
           if (rr > cc) { const int t = rr; rr = cc; cc = t; }      // K5 writes the triangle on and above the diagonal (Qxx symmetric, Qvq = Qqv^T)
-          v = kk[L::K_QXX + rr + NX * cc] + ax;
+          v = kk[L::K_QXX + L::xsym(rr, cc)] + ax;
         }
       }
       qinv[tr][tc] = v;
