@@ -28,7 +28,6 @@ __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B, int nsw) {
   constexpr int NV = D::NV, NQ = D::NQ, NL = D::NL, LJ = D::LJ, NF = D::NF, NU = D::NU;
   typedef Dual T;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
   // (a workgroup per instance and stage WITH a switching constraint: launched over every stage of the chain, the 110 of 119 workgroups
   //  per instance that returned at once still cost their dispatch -- 0.10 ms for a kernel with 0.03 ms of work)
   const long unit = blockIdx.x;

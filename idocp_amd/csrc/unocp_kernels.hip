@@ -1687,7 +1687,6 @@ void UnLaunch<NV>::rneaDerivatives(const DevModel* m, int n, const double* q, co
 template <int NV>
 void UnLaunch<NV>::single(int kernel_id, const UnBuffers& B, long batch, int N, const double* q0, const double* v0,
                           hipStream_t st) {
-  constexpr int SPW = 64 / (3 * NV);
   const unsigned inst_blocks = (unsigned)((batch + 7) / 8);
   const unsigned stage_blocks = (unsigned)((batch * (N + 1) + 7) / 8);
   switch (kernel_id) {
@@ -1707,7 +1706,6 @@ void UnLaunch<NV>::single(int kernel_id, const UnBuffers& B, long batch, int N, 
 // 5 forward parallel + direction + step sizes, 6 integrate
 template <int NV>
 void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
-  constexpr int SPW = 64 / (3 * NV);
   const unsigned inst_blocks = (unsigned)((batch + 3) / 4);
   switch (phase) {
     case 0:
@@ -1727,7 +1725,6 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
 }
 template <int NV>
 void UnLaunch<NV>::parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
-  constexpr int SPW = 64 / (3 * NV);
   if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true, false, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
   else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
   hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
