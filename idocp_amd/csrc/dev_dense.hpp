@@ -273,8 +273,12 @@ __device__ __forceinline__ void spdInverseRowsDpp(double* A, int ld, int n, int 
   static_assert(N <= 16, "one matrix row per lane of a DPP row");
   double a[N];
   const bool on = lane < n;
+  // identity padding: rows n .. N - 1 of the matrix, and -- in the lanes of the other DPP rows (16 .. 63), which only ride along -- a unit
+  // row each, so that every row of 16 lanes eliminates a non-singular matrix and no lane manufactures inf / NaN (their results are
+  // discarded, but NaNs in idle lanes would mask real ones under debug tooling or in a wave-wide reduction of `bad`)
+  const int prow_id = lane & 15;
 #pragma unroll
-  for (int j = 0; j < N; ++j) a[j] = (on && j < n) ? A[lane + ld * j] : ((j == lane) ? 1.0 : 0.0);      // identity padding
+  for (int j = 0; j < N; ++j) a[j] = (on && j < n) ? A[lane + ld * j] : ((j == prow_id) ? 1.0 : 0.0);
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < N; ++k) {

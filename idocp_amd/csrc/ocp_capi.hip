@@ -583,6 +583,13 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   // ConstraintComponentBase::setBarrier / setFractionToBoundaryRate (constraint_component_base.hxx:10-24) assert these; a
   // non-positive barrier would make the slack initialisation (pdipm.hxx:13-24) loop forever on the device
   if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }
+  // JointAcceleration*Limit bounds: finite, and a_min < a_max where both are in use (an empty interval has no interior point to start the
+  // barrier method from)
+  for (int r = 0; r < model->nu; ++r) {
+    const bool lo = constraints->joint_acceleration_lower_limit != 0, hi = constraints->joint_acceleration_upper_limit != 0;
+    if ((lo && !std::isfinite(constraints->a_min[r])) || (hi && !std::isfinite(constraints->a_max[r]))) { set_last_error("invalid value: joint acceleration bounds must be finite!"); return IDOCP_E_ARG; }
+    if (lo && hi && !(constraints->a_min[r] < constraints->a_max[r])) { set_last_error("invalid value: a_min must be smaller than a_max!"); return IDOCP_E_ARG; }
+  }
   if ((constraints->linearized_friction_cone && constraints->friction_cone) || (constraints->linearized_impulse_friction_cone && constraints->impulse_friction_cone)) {
     set_last_error("unsupported constraints: LinearizedFrictionCone and FrictionCone (or their impulse twins) together; the stage kernels carry one cone per kind of stage");
     return IDOCP_E_UNSUPPORTED;
@@ -1222,6 +1229,18 @@ int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, doubl
   if (!solFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
   return copyField(h, h->B.sol + (size_t)instance * h->NS * LQ::SOL, LQ::SOL, h->parnmpc ? h->N : h->Ngrid + f.extra, f, out);
+}
+// OCPSolver::getSolution(stage) (ocp_solver.hpp:97): the whole split solution of ONE grid stage in one device-to-host copy --
+// what an MPC loop reads every cycle (getSolution(0).u).  out: lmd gmm q v a u beta f mu nu_passive, the order of the sol record
+// (split_solution.hxx:10-31); on the terminal stage only lmd gmm q v are meaningful.
+int idocp_ocp_get_split_solution(idocp_ocp_t* h, int instance, int stage, double* out) {
+  if (!h || !out || instance < 0 || instance >= h->batch || stage < 0 || stage > (h->parnmpc ? h->N - 1 : h->Ngrid)) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  static_assert(LQ::S_LMD == 0 && LQ::S_NUP > LQ::S_MU, "record order = output order");
+  const size_t n = LQ::S_NUP + 6;
+  HIP_TRY(hipMemcpyAsync(out, h->B.sol + ((size_t)instance * h->NS + stage) * LQ::SOL, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
 }
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
     }
     if (valid) {
       sl = -g;
-      for (int it = 0; it < (1 << 26) && sl < P->barrier; ++it) sl += P->barrier;      // pdipm.hxx:17-20, bounded
+      sl = slackPositive(sl, P->barrier);      // pdipm.hxx:17-20
       dl = P->barrier / sl;
     }
     B.slack[su * L::CON + row] = sl;

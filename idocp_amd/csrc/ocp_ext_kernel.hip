@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void ocp_ext_init_kernel(OcpBuffers B, long nre
     double sl = 1.0, dl = 0.0;
     if (valid) {
       sl = z[c];
-      for (int it = 0; it < (1 << 26) && sl < P->barrier; ++it) sl += P->barrier;      // pdipm.hxx:17-20, bounded
+      sl = slackPositive(sl, P->barrier);      // pdipm.hxx:17-20
       dl = P->barrier / sl;
     }
     B.slack[su * L::CON + L::C_CD + c] = sl;

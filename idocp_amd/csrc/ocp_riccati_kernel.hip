@@ -701,6 +701,609 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
   if (tid == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// S3, round 4: the backward sweep with every matrix in the REGISTERS of one wavefront.
+//
+// v_mfma_f64_16x16x4_f64 leaves a 16 x 16 tile T in the accumulator layout "lane (g, li) holds T[4 q + g][li] in register q".  Register
+// s of such a tile is, as it stands, the operand of k-step s of another instruction -- as B operand it is T[4 s + g][li] = B[k = g][j = li],
+// as A operand it is A[i = li][k = g] = T[4 s + g][li], the transpose -- so for two tiles X, Y in that layout
+//     D = X^T Y     (contraction over the ROWS of both)
+// costs no data movement at all.  The backward Riccati step is three such products once P is kept symmetric:
+//     Wt = P C          = P^T C         C = [A B]: x+ = C z + Fx,  z = [x; u]  (NX + NU = 48 = 3 tiles)
+//     Qh = Q + C^T Wt                   [F H; H^T G], Q = [Qxx Qxu; . Quu]
+//     P  = F + K^T H^T                  K = -G^-1 H^T  (G K = -H^T up to the residual of the backward-stable solve, see riccatiPhase5)
+// The round-2 kernel staged P, the stage record, W and K in LDS (40.7 kB, 497 LDS instructions per stage and instance) and one
+// wavefront per SIMD had nothing to hide their latency behind: 15.6 us per stage under load, 8.2 us alone.  Here LDS only carries the
+// 12 rows of [H^T G] to the solve, K back from it, the vector terms and the mirror image of P.
+//
+// SLOTS.  z is permuted so that the rows of C that are NOT dense fall on whole registers of a tile: the twelve leg joints obey
+// q+ = q + dt v exactly (Fqq = diag(Fqq6, I), Fqv = diag(Fqv6, dt I)), i.e. row qj_r of C is e(qj_r) + dt e(vj_r):
+//     slot  0..11 qj   12..15 qb0..3 | 16..27 vj   28..31 vb0..3 | 32 33 qb4 qb5   34 35 vb4 vb5   36..47 u
+// With qj at 0..11 and vj at 16..27 the structured rows become lane-local adds between tiles 0 and 1 (same lane, same register),
+// and the dense rows of C -- 6 base configuration rows + 18 velocity rows -- are exactly six k-steps: (block 0, s = 3), (1, 0..3), (2, 0).
+// x+ uses slots 0..35 of the same table.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename D>
+struct RiccatiSlots {
+  static_assert(D::NV == 18 && D::NU == 12, "slot table of a 6 + 12 dof floating base");
+  __host__ __device__ static constexpr int nat(int s) {           // slot -> natural index of z = [q v u]
+    return s < 12 ? 6 + s : s < 16 ? s - 12 : s < 28 ? 24 + (s - 16) : s < 32 ? 18 + (s - 28) : s < 34 ? 4 + (s - 32) : s < 36 ? 22 + (s - 34) : s;
+  }
+  __host__ __device__ static constexpr int slot(int n) {          // natural -> slot
+    return n < 4 ? 12 + n : n < 6 ? 32 + (n - 4) : n < 18 ? n - 6 : n < 22 ? 28 + (n - 18) : n < 24 ? 34 + (n - 22) : n < 36 ? 16 + (n - 24) : n;
+  }
+};
+
+template <typename D>
+struct RiccatiRegSmem {
+  static constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF;
+  static constexpr int LDH = 48;        // row stride of HT / KT: rows 32 dwords apart mod 64, the two lane groups of a read hit disjoint banks
+  static constexpr int LDP = 49;        // row stride of PM: transposed reads walk 16 rows through 16 bank pairs
+  static constexpr int HT = 0,                    // [NU][LDH]  rows u of Qh: H^T | G, slot columns
+                       KT = HT + NU * LDH,        // [NU][LDH]  K, slot columns
+                       RED = KT + NU * LDH,       // [3][64]    partial sums of the column contractions
+                       VF = RED + 192, VT = VF + 48, LUH = VT + 48, KV = LUH + 16,      // Fx and t by slot, lu_hat, k
+                       PM = KV + 16,              // [48][LDP]  P of the stage, master entries (slot order)
+                       PLAIN = PM + 48 * LDP;
+  // scratch of a stage with a switching constraint, natural layouts of the round-2 code; it lives between the solve and the mirror,
+  // when PM is dead, and extends behind it
+  static constexpr int QXU = PM, QUU = QXU + NX * NU, LU = QUU + NU * NU, KM = LU + 16, KVN = KM + NU * NX, GW = KVN + 16,
+                       DG = GW + NU * NU, SS = DG + NF * NU, DTM = SS + NF * NF, SDG = DTM + NU * NX, MV = SDG + NF * NU,
+                       SCORR = MV + 16, MMX = SCORR + 48, GK = MMX + NF * NX, HYB = GK + NU * NX;
+  static constexpr int NTBL = OcpLayout<D>::R_SQ;                  // doubles of Pqq | Pqv | Pvv in the ric record
+  static constexpr size_t BYTES = (HYB > PLAIN ? HYB : PLAIN) * sizeof(double);
+  static_assert(BYTES + 64 <= 40960, "four instances per CU");
+};
+
+template <typename D, bool HYBRID>
+__global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  using S = RiccatiRegSmem<D>;
+  using SL = RiccatiSlots<D>;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF, LDH = S::LDH, LDP = S::LDP;
+  static_assert(NX + NU == 48 && L::R_PQV == L::R_PQQ + L::P_TRI && L::R_PVV == L::R_PQV + NV * NV && L::R_SQ == L::R_PVV + L::P_TRI &&
+                L::R_SV == L::R_SQ + NV && L::R_PQQ == 0, "ric record: Pqq | Pqv | Pvv | sq | sv");
+  static_assert(L::K_FVV == L::K_FVQ + NV * NV && L::K_FVU == L::K_FVV + NV * NV, "[Fvq Fvv Fvu] contiguous");
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_ok;
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const OcpNode* __restrict__ nodes = B.nodes;
+  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+  const long b = blockIdx.x;
+  // (values that are the same in every lane are made scalar by hand: the node table and the problem block are read with vector loads --
+  // the kernel also stores to global memory, so the compiler will not use the scalar cache -- and everything derived from a vector
+  // load, the record addresses first of all, would live in VGPR pairs)
+  const long base = b * __builtin_amdgcn_readfirstlane(P->NS);
+  const bool p32 = __builtin_amdgcn_readfirstlane(P->ric_fp32) != 0;
+  auto st32 = [&](double x) { return p32 ? (double)(float)x : x; };
+  auto slotOf = [&](int pos) { return (long)__builtin_amdgcn_readfirstlane(nodes[pos].slot); };
+  if (lane == 0) s_ok = 1;
+  // dense k-steps of C: (row block, k-step); the six tiles that are computed of a symmetric 3 x 3 tiling: the others are mirror images
+  constexpr int DC[6] = {0, 1, 1, 1, 1, 2}, DS[6] = {3, 0, 1, 2, 3, 0};
+  constexpr int TA[6] = {2, 2, 2, 0, 0, 1}, TB[6] = {0, 1, 2, 0, 1, 1};       // the rows of [H^T G] first: the solve waits for them
+  // ---- loop-invariant addresses inside a kkt record ----
+  // A structural zero of C is read from the first pad double of the record (records are allocated zeroed and nothing writes their
+  // padding): a select behind the load would need a VALU pass over every loaded value, and with the register file as full as it is
+  // here the compiler then serialises the loads (load, wait, select, move to an AGPR -- measured: 18 x the latency of HBM per stage)
+  constexpr int ZERO_AT = L::K_FX + NX;
+  static_assert(ZERO_AT < L::KKT, "a pad double behind Fx");
+  int cOff[6][3];      // dense rows of C in accumulator layout
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    const int rs = 16 * DC[d] + 4 * DS[d] + g;                 // x+ slot of this lane's row
+    const int rn = SL::nat(rs);                                // natural row of x+ = [q+ v+]
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const int cn = SL::nat(16 * bb + li);
+      int off;
+      if (rn < NV) off = cn < 6 ? L::K_FQQ + rn + 6 * cn : ((cn >= NV && cn < NV + 6) ? L::K_FQV + rn + 6 * (cn - NV) : ZERO_AT);      // base rows of [Fqq Fqv 0]
+      else off = L::K_FVQ + (rn - NV) + NV * cn;
+      cOff[d][bb] = off;
+    }
+  }
+  int qOff[6][4];      // [Qxx Qxu; . Quu] in accumulator layout
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ni = SL::nat(16 * TA[t] + 4 * q + g), nj = SL::nat(16 * TB[t] + li);
+      qOff[t][q] = (ni < NX && nj < NX) ? L::K_QXX + L::xsym(ni, nj)
+                 : (ni < NX ? L::K_QXU + ni + NX * (nj - NX) : (nj < NX ? L::K_QXU + nj + NX * (ni - NX) : L::K_QUU + (ni - NX) + NU * (nj - NX)));
+    }
+  // The 54 gather addresses of a lane are loop invariants that the register allocator spilled in the HYBRID instantiation (and a
+  // reload from scratch behind the stage's stores drains the whole memory queue): they travel as 16-bit BYTE offsets, two to a register
+  unsigned cqPk[21];
+  {
+    static_assert(8 * (L::KKT) < 65536 && 8 * (S::PM + 48 * LDP) < 65536, "16-bit byte offsets");
+#pragma unroll
+    for (int e = 0; e < 21; ++e) {
+      const int e0 = 2 * e, e1 = 2 * e + 1;
+      const int o0 = e0 < 18 ? cOff[e0 / 3][e0 % 3] : qOff[(e0 - 18) / 4][(e0 - 18) % 4];
+      const int o1 = e1 < 18 ? cOff[e1 / 3][e1 % 3] : qOff[(e1 - 18) / 4][(e1 - 18) % 4];
+      cqPk[e] = (unsigned)(8 * o0) | ((unsigned)(8 * o1) << 16);
+    }
+  }
+  const int myNat = SL::nat(lane < 48 ? lane : 47);
+  const int lzOff = myNat < NX ? L::K_LX + myNat : L::K_LU + (myNat - NX);
+  // PM offset of the doubles of Pqq | Pqv | Pvv (packed upper triangles, ric record order) this lane copies to the ric record -- pairs
+  // e = lane + 64 t of consecutive doubles --: the orientation of the entry that a master tile wrote
+  constexpr int N2 = S::NTBL / 2, NP = (N2 + 63) / 64;
+  static_assert(S::NTBL % 2 == 0, "pairs");
+  int pmOff[NP][2];
+#pragma unroll
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      int e = 2 * (lane + 64 * t) + hh;
+      if (e >= S::NTBL) e = S::NTBL - 1;
+      int r = 0, c = 0;
+      if (e < L::R_PQV) { int cc = 0; while ((cc + 1) * (cc + 2) / 2 <= e && cc < NV - 1) ++cc; c = cc; r = e - cc * (cc + 1) / 2; if (r > c) r = c; }
+      else if (e < L::R_PVV) { const int k = e - L::R_PQV; c = k / NV; r = k - c * NV; c += NV; }
+      else { const int k = e - L::R_PVV; int cc = 0; while ((cc + 1) * (cc + 2) / 2 <= k && cc < NV - 1) ++cc; c = cc; r = k - cc * (cc + 1) / 2; if (r > c) r = c; r += NV; c += NV; }
+      int i = SL::slot(r), j = SL::slot(c);
+      const int bi = i >> 4, bj = j >> 4;
+      const bool keep = bi == bj ? i <= j : ((bi == 0 && bj == 1) || bi == 2);
+      if (!keep) { const int tt = i; i = j; j = tt; }
+      pmOff[t][hh] = S::PM + LDP * i + j;
+    }
+  unsigned pmPk[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) pmPk[t] = (unsigned)(8 * pmOff[t][0]) | ((unsigned)(8 * pmOff[t][1]) << 16);
+  auto ldsAt = [&](const double* b0, unsigned byteoff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(b0) + byteoff); };
+  typedef mfma_d4 tile_t;
+  tile_t Pt[3][3];       // P (slot order): [row block][column block]
+  double s_reg = 0.0;    // s of slot `lane`
+  // store the six master tiles into PM
+  auto tilesToPM = [&](const tile_t (&T)[6]) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sm[S::PM + LDP * (16 * TA[t] + 4 * q + g) + 16 * TB[t] + li] = T[t][q];
+  };
+  // P of the stage from PM to its ric record (16-byte stores of consecutive lanes), in two halves: the LDS reads, and the global stores --
+  // issued BEHIND the staging of the next record: s_waitcnt vmcnt counts loads and stores in one queue, so a wait for the prefetched
+  // record in front of which these stores had just been issued would wait for their acknowledgement too
+  rd2 pv[NP];
+  auto readP = [&]() {
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      unsigned pk = pmPk[t];
+      asm volatile("" : "+v"(pk));        // (opaque: the unpacked addresses are loop invariants too, and would be hoisted and spilled)
+      pv[t].x = ldsAt(sm, pk & 0xffffu); pv[t].y = ldsAt(sm, pk >> 16);
+    }
+  };
+  auto writeP = [&](double* __restrict__ rr) {
+#pragma unroll
+    for (int t = 0; t < NP; ++t) if (lane + 64 * t < N2) reinterpret_cast<rd2*>(rr)[lane + 64 * t] = pv[t];
+  };
+  // rebuild the nine tiles of P from the six masters (registers) and their mirror images (PM); entries outside the x slots are zero
+  auto mirrorP = [&](const tile_t (&T)[6]) {
+    // T order: (2,0) (2,1) (2,2) (0,0) (0,1) (1,1)
+    const bool c4 = li < 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool r0 = (q == 0);
+      Pt[2][0][q] = r0 ? T[0][q] : 0.0;
+      Pt[2][1][q] = r0 ? T[1][q] : 0.0;
+      Pt[0][1][q] = T[4][q];
+      Pt[1][0][q] = sm[S::PM + LDP * li + 16 + 4 * q + g];                       // (16 + 4q + g, li)  <-  (li, 16 + 4q + g) of tile (0,1)
+      const double m02 = sm[S::PM + LDP * (32 + (c4 ? li : 0)) + 4 * q + g];     // (4q + g, 32 + li)  <-  (32 + li, 4q + g) of tile (2,0)
+      const double m12 = sm[S::PM + LDP * (32 + (c4 ? li : 0)) + 16 + 4 * q + g];
+      Pt[0][2][q] = c4 ? m02 : 0.0;
+      Pt[1][2][q] = c4 ? m12 : 0.0;
+      const int ir = 4 * q + g;                                                  // row inside a diagonal tile
+      const double d0 = sm[S::PM + LDP * li + ir], d1 = sm[S::PM + LDP * (16 + li) + 16 + ir], d2 = sm[S::PM + LDP * (32 + li) + 32 + ir];
+      Pt[0][0][q] = ir <= li ? T[3][q] : d0;
+      Pt[1][1][q] = ir <= li ? T[5][q] : d1;
+      Pt[2][2][q] = (r0 && c4) ? (ir <= li ? T[2][q] : d2) : 0.0;
+    }
+  };
+  // ---- terminal stage (riccati_recursion_solver.cpp:53-56): P = blockdiag(Qxx_qq, Qxx_vv), s = -lx ----
+  {
+    const double* __restrict__ kk = B.kkt + (base + slotOf(M - 1)) * L::KKT;
+    double* __restrict__ rr = B.ric + (base + slotOf(M - 1)) * L::RIC;
+    tile_t T[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ni = SL::nat(16 * TA[t] + 4 * q + g), nj = SL::nat(16 * TB[t] + li);
+        const bool in = ni < NX && nj < NX && ((ni < NV) == (nj < NV));
+        const double v = kk[in ? L::K_QXX + L::xsym(ni, nj) : 0];
+        T[t][q] = in ? st32(v) : 0.0;
+      }
+    if (lane < NX) { s_reg = st32(-kk[L::K_LX + myNat]); rr[L::R_SQ + myNat] = s_reg; }
+    tilesToPM(T);
+    waveLdsSync();
+    mirrorP(T);
+    readP();
+    writeP(rr);
+    waveLdsSync();
+  }
+  // ---- registers of the stage: dense rows of C, Q, lz, Fx ----
+  // The record travels as 16-byte pieces of consecutive lanes (prefetch: issued in the middle of the previous stage, parked in
+  // registers), is laid down in LDS where PM was (dead by then) and gathered from there into the accumulator layout.  (Gathering
+  // straight from global memory -- 44 loads of 64 scattered 8-byte addresses each -- kept the wavefront in the address path for 3 us
+  // per stage alone and 6 us under load.)
+  constexpr int SL2 = (ZERO_AT + 2) / 2, PF = (SL2 + 63) / 64;
+  static_assert(ZERO_AT % 2 == 0 && 2 * SL2 <= L::KKT && 2 * SL2 <= 48 * LDP && S::PM % 2 == 0 && L::KKT % 2 == 0, "the staged record fits the record and the PM block");
+  rd2 pre[PF];
+  auto prefetch = [&](const double* __restrict__ kk) {
+    const rd2* __restrict__ k2 = reinterpret_cast<const rd2*>(kk);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) { const int e = lane + 64 * t; pre[t] = k2[e < SL2 ? e : SL2 - 1]; }
+  };
+  double Cd[6][3], lz = 0.0, fx = 0.0;
+  tile_t Qc[6];
+  auto stageIn = [&]() {
+#pragma unroll
+    for (int t = 0; t < PF; ++t) { const int e = lane + 64 * t; if (e < SL2) reinterpret_cast<rd2*>(&sm[S::PM])[e] = pre[t]; }
+    waveLdsSync();
+    const double* kk = &sm[S::PM];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      unsigned pk = cqPk[e];
+      asm volatile("" : "+v"(pk));      // (opaque: the unpacked addresses are loop invariants too, and would be hoisted and spilled)
+      const int e0 = 2 * e, e1 = 2 * e + 1;
+      Cd[e0 / 3][e0 % 3] = ldsAt(kk, pk & 0xffffu);
+      Cd[e1 / 3][e1 % 3] = ldsAt(kk, pk >> 16);
+    }
+    lz = kk[lzOff];
+    fx = kk[L::K_FX + (myNat < NX ? myNat : 0)];
+    waveLdsSync();
+  };
+  // Q of the stage is gathered when phase 2 is about to need it (the staged record stays where it is until the end of the stage: PM and
+  // the scratch of a constrained stage are written behind phase 2): 48 registers less while phase 1 holds P, C and Wt
+  auto gatherQ = [&]() {
+    const double* kk = &sm[S::PM];
+#pragma unroll
+    for (int e = 9; e < 21; ++e) {
+      unsigned pk = cqPk[e];
+      asm volatile("" : "+v"(pk));
+      const int e0 = 2 * e - 18, e1 = 2 * e - 17;
+      Qc[e0 / 4][e0 % 4] = ldsAt(kk, pk & 0xffffu);
+      Qc[e1 / 4][e1 % 4] = ldsAt(kk, pk >> 16);
+    }
+  };
+  if (M > 1) { prefetch(B.kkt + (base + slotOf(M - 2)) * L::KKT); stageIn(); }
+  // the node fields of a stage are fetched one stage ahead (a dependent L2 round trip in front of the record's loads otherwise)
+  int n_slot = M > 1 ? nodes[M - 2].slot : 0, n_dimi = (HYBRID && M > 1) ? nodes[M - 2].sw_dimi : 0;
+  double n_dt = M > 1 ? nodes[M - 2].dtq : 0.0;
+  for (int i = M - 2; i >= 0; --i) {
+    const double dt = n_dt;
+    const long rec = base + __builtin_amdgcn_readfirstlane(n_slot);
+    const int dimi = HYBRID ? __builtin_amdgcn_readfirstlane(n_dimi) : 0;
+    if (i > 0) { n_slot = nodes[i - 1].slot; n_dt = nodes[i - 1].dtq; if (HYBRID) n_dimi = nodes[i - 1].sw_dimi; }
+    const bool constrained = HYBRID && dimi > 0;
+    const bool stamp = lane == 0 && b == (gridDim.x > 7 ? 7 : 0) && i == M / 2 && B.prof != nullptr;
+#define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
+    RSTAMP(0);
+    double* __restrict__ rr = B.ric + rec * L::RIC;
+    double* __restrict__ gg = B.gain + rec * L::GAIN;
+    // ---- vector head: t = P Fx - s, lz_hat = [lx; lu] + C^T t (backward_riccati_recursion_factorizer.hxx:141-160 and the lu term) ----
+    // y[j] = sum_i X[i][j] v[i] over tiles in accumulator layout: every lane multiplies its registers with the v of their rows and the
+    // four lane groups add up through LDS
+    if (lane < 48) sm[S::VF + lane] = lane < NX ? fx : 0.0;
+    waveLdsSync();
+    double lzh = 0.0;
+    {
+      double part[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < (a < 2 ? 4 : 1); ++q) {
+          const double f = sm[S::VF + 16 * a + 4 * q + g];
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) part[bb] += Pt[a][bb][q] * f;
+        }
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) sm[S::RED + 64 * bb + lane] = part[bb];
+      waveLdsSync();
+      const int rb = S::RED + 64 * (lane < 48 ? (lane >> 4) : 0) + li;
+      const double y = (sm[rb] + sm[rb + 16]) + (sm[rb + 32] + sm[rb + 48]);
+      const double t = lane < NX ? y - s_reg : 0.0;
+      waveLdsSync();
+      if (lane < 48) sm[S::VT + lane] = t;
+      waveLdsSync();
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) part[bb] = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const double tv = sm[S::VT + 16 * DC[d] + 4 * DS[d] + g];
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) part[bb] += Cd[d][bb] * tv;
+      }
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) sm[S::RED + 64 * bb + lane] = part[bb];
+      waveLdsSync();
+      const double y2 = (sm[rb] + sm[rb + 16]) + (sm[rb + 32] + sm[rb + 48]);
+      // the structured rows: row qj_r of C is e(slot r) + dt e(slot 16 + r)
+      const double ts = sm[S::VT + (lane < 12 ? lane : (lane >= 16 && lane < 28 ? lane - 16 : 0))];
+      lzh = lz + y2 + (lane < 12 ? ts : (lane >= 16 && lane < 28 ? dt * ts : 0.0));
+    }
+    RSTAMP(1);
+    // ---- phase 1: Wt = P C (:48-78): nine tiles, six dense k-steps each, + the structured rows as lane-local adds ----
+    tile_t Wt[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) Wt[a][bb] = tile_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) Wt[a][bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[DC[d]][a][DS[d]], Cd[d][bb], Wt[a][bb], 0, 0, 0);
+    gatherQ();
+    {
+      const bool m12 = li < 12;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < (a < 2 ? 4 : 1); ++q) {
+          const double pv = m12 ? Pt[a][0][q] : 0.0;
+          Wt[a][0][q] += pv;
+          Wt[a][1][q] += dt * pv;
+        }
+    }
+    RSTAMP(2);
+    // ---- phase 2: Qh = Q + C^T Wt (:79-113) on the six master tiles ----
+    tile_t Qh[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) Qh[t] = Qc[t];
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) Qh[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cd[d][TA[t]], Wt[DC[d]][TB[t]][DS[d]], Qh[t], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      Qh[3][q] += Wt[0][0][q];                 // rows qj of tile (0, 0), (0, 1)
+      Qh[4][q] += Wt[0][1][q];
+      Qh[5][q] += dt * Wt[0][1][q];            // rows vj of tile (1, 1)
+    }
+    RSTAMP(3);
+    // ---- the rows of [H^T G] and lu_hat go to the solve ----
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+      for (int q = 1; q < 4; ++q) sm[S::HT + LDH * (4 * (q - 1) + g) + 16 * bb + li] = Qh[bb][q];
+    if (lane >= NX && lane < 48) sm[S::LUH + lane - NX] = lzh;
+    waveLdsSync();
+    // the record of the next stage of the walk: its loads are in flight during the solve and phase 5
+    if (i > 0) prefetch(B.kkt + (base + __builtin_amdgcn_readfirstlane(n_slot)) * L::KKT);
+    RSTAMP(9);
+    double Kr[3][3];      // K as the operand of phase 5: [column block][k-step - 1], NEGATED on a constrained stage (see below)
+    tile_t Pn[6];
+    if (!constrained) {
+      // Quu = L L^T and K = -Quu^-1 Qxu^T, k = -Quu^-1 lu in registers, one right-hand side per lane (Eigen::LLT compute + solve,
+      // split_riccati_factorizer.hxx:43-46)
+      double x[NU], h[NU];
+      int xo = lane < NX ? S::HT + lane : S::LUH, xs = lane < NX ? LDH : 1;      // column `lane` of H^T, or lu_hat
+      asm volatile("" : "+v"(xo), "+v"(xs));                                   // (twelve hoisted addresses otherwise)
+#pragma unroll
+      for (int m = 0; m < NU; ++m) { x[m] = sm[xo + xs * m]; h[m] = x[m]; }
+      choleskySolveRows<NU>(&sm[S::HT + NX], LDH, lane, &s_ok, x);         // G is symmetric: element (row, j) read as (j, row)
+      if (lane < NX) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) sm[S::KT + LDH * m + lane] = -x[m];
+        rd2* __restrict__ gp = reinterpret_cast<rd2*>(gg + L::G_K + NU * myNat);
+#pragma unroll
+        for (int m = 0; m < NU / 2; ++m) { rd2 v; v.x = -x[2 * m]; v.y = -x[2 * m + 1]; gp[m] = v; }
+      } else if (lane == NX) {
+        rd2* __restrict__ gp = reinterpret_cast<rd2*>(gg + L::G_k);
+#pragma unroll
+        for (int m = 0; m < NU / 2; ++m) { rd2 v; v.x = -x[2 * m]; v.y = -x[2 * m + 1]; gp[m] = v; sm[S::KV + 2 * m] = v.x; sm[S::KV + 2 * m + 1] = v.y; }
+      }
+      static_assert(NU % 2 == 0 && L::G_K % 2 == 0 && L::G_k % 2 == 0 && L::GAIN % 2 == 0, "16-byte stores of the gain record");
+      waveLdsSync();
+      RSTAMP(10);
+      // s = -lx_hat - H k (:141-160)
+      double hk = 0.0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) hk += h[m] * sm[S::KV + m];
+      if (lane < NX) { s_reg = st32(-lzh - hk); rr[L::R_SQ + myNat] = s_reg; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { const int c = 16 * a + li; const double v = sm[S::KT + LDH * (4 * s + g) + (c < NX ? c : 0)]; Kr[a][s] = c < NX ? v : 0.0; }
+      RSTAMP(4);
+      // ---- phase 5: P = F - K^T G K = F + K^T H^T (:122-131; G K = -H^T, see riccatiPhase5) ----
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        Pn[t] = Qh[t];
+        if (TA[t] == 2) { Pn[t][1] = 0.0; Pn[t][2] = 0.0; Pn[t][3] = 0.0; }
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) Pn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Kr[TA[t]][s], Qh[TB[t]][s + 1], Pn[t], 0, 0, 0);
+    } else {
+      // ---- stage with a switching constraint (split_riccati_factorizer.hxx:56-101): the Schur-complement step of the round-2 kernel
+      //      on natural-layout copies in LDS ----
+      double* Qxu = &sm[S::QXU];
+      double* Quu = &sm[S::QUU];
+      double* lu = &sm[S::LU];
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const int u = 4 * (q - 1) + g, j = 16 * bb + li;
+          if (j < NX) Qxu[SL::nat(j) + NX * u] = Qh[bb][q]; else Quu[u + NU * (j - NX)] = Qh[bb][q];
+        }
+      if (lane >= NX && lane < 48) lu[lane - NX] = lzh;
+      waveLdsSync();
+      {
+        double x[NU];
+#pragma unroll
+        for (int m = 0; m < NU; ++m) x[m] = (m == lane) ? 1.0 : 0.0;      // Ginv = llt.solve(I) (:60)
+        choleskySolveRows<NU>(Quu, NU, lane, &s_ok, x);
+        if (lane < NU) {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) sm[S::GW + m + NU * lane] = x[m];
+        }
+      }
+      waveLdsSync();
+      const double* __restrict__ W = B.swc + rec * L::SWC;
+      const double* __restrict__ Phiu = W + L::W_PHIU;
+      for (int e = lane; e < dimi * NU; e += 64) {                // DGinv = Phiu Ginv
+        const int c = e / dimi, j = e - c * dimi;
+        double acc = 0.0;
+        for (int m = 0; m < NU; ++m) acc += Phiu[j + NF * m] * sm[S::GW + m + NU * c];
+        sm[S::DG + j + NF * c] = acc;
+      }
+      waveLdsSync();
+      for (int e = lane; e < dimi * dimi; e += 64) {              // S = DGinv Phiu^T
+        const int c = e / dimi, j = e - c * dimi;
+        double acc = 0.0;
+        for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * Phiu[c + NF * m];
+        sm[S::SS + j + NF * c] = acc;
+      }
+      waveLdsSync();
+      {
+        // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves (llt_s_.solve, :64-66, 71-74), lane = column
+        static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
+        double x[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          double val = 0.0;
+          if (j < dimi) val = lane < NU ? sm[S::DG + j + NF * lane] : (lane < NU + NX ? W[L::W_PHIX + j + NF * (lane - NU)] : (lane == NU + NX ? W[L::W_P + j] : 0.0));
+          x[j] = val;
+        }
+        choleskySolveRows<NF>(&sm[S::SS], NF, lane, &s_ok, x, dimi);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          if (j < dimi) {
+            if (lane < NU) sm[S::SDG + j + NF * lane] = x[j];
+            else if (lane < NU + NX) sm[S::MMX + j + NF * (lane - NU)] = x[j];
+            else if (lane == NU + NX) sm[S::MV + j] = x[j];
+          }
+        }
+      }
+      waveLdsSync();
+      for (int e = lane; e < NU * NU; e += 64) {                  // Ginv -= SinvDGinv^T DGinv
+        const int c = e / NU, r = e - c * NU;
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * r] * sm[S::DG + l + NF * c];
+        sm[S::GW + e] -= acc;
+      }
+      waveLdsSync();
+      {
+        // K = -Ginv Qxu^T - SinvDGinv^T Phix, k = -Ginv lu - SinvDGinv^T P with the updated Ginv (:67-70)
+        const double* __restrict__ Phix = W + L::W_PHIX;
+        const double* __restrict__ Pv = W + L::W_P;
+        for (int e = lane; e < NU * NX; e += 64) {
+          const int c = e / NU, j = e - c * NU;
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
+          for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Phix[l + NF * c];
+          sm[S::KM + e] = -acc;
+        }
+        if (lane >= 64 - NU) {
+          const int j = lane - (64 - NU);
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
+          for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Pv[l];
+          sm[S::KVN + j] = -acc;
+        }
+      }
+      {
+        // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu
+        double* __restrict__ Ww = B.swc + rec * L::SWC;
+        for (int e = lane; e < dimi * NX; e += 64) {
+          const int c = e / dimi, l = e - c * dimi;
+          double acc = sm[S::MMX + l + NF * c];
+          for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
+          sm[S::MMX + l + NF * c] = acc;
+          Ww[L::W_M + l + NF * c] = acc;
+        }
+        if (lane < dimi) {
+          const int l = lane;
+          double acc = sm[S::MV + l];
+          for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * lu[m];
+          sm[S::MV + l] = acc;
+          Ww[L::W_m + l] = acc;
+        }
+      }
+      waveLdsSync();
+      for (int e = lane; e < NU * NX; e += 64) {                  // DtM = Phiu^T M (:88)
+        const int c = e / NU, m = e - c * NU;
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIU + l + NF * m] * sm[S::MMX + l + NF * c];
+        sm[S::DTM + m + NU * c] = acc;
+      }
+      if (lane < NX) {                                            // Phix^T m (:98-99)
+        double acc = 0.0;
+        for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIX + l + NF * lane] * sm[S::MV + l];
+        sm[S::SCORR + lane] = acc;
+      }
+      waveLdsSync();
+      riccatiPhase4<D, true, 0, 3>(Quu, &sm[S::KM], &sm[S::GK], lane);     // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
+      waveLdsSync();
+      RSTAMP(10);
+      // gain record, s = -lx_hat - Qxu k - Phix^T m
+      for (int e = lane; e < NU * NX / 2; e += 64) reinterpret_cast<rd2*>(gg)[e] = reinterpret_cast<const rd2*>(&sm[S::KM])[e];
+      if (lane < NU) gg[L::G_k + lane] = sm[S::KVN + lane];
+      static_assert(S::KM % 2 == 0 && L::G_K == 0 && (NU * NX) % 2 == 0, "K is one contiguous copy");
+      if (lane < NX) {
+        double hk = 0.0;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) hk += Qxu[myNat + NX * m] * sm[S::KVN + m];
+        s_reg = st32(-lzh - hk - sm[S::SCORR + myNat]);
+        rr[L::R_SQ + myNat] = s_reg;
+      }
+      RSTAMP(4);
+      // ---- phase 5: P = F - K^T (G K) - K^T DtM - DtM^T K (:122-131, split_riccati_factorizer.hxx:88-97): [K; DtM]^T [G K + DtM; K] ----
+      double Gr[3][3], Dr[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int c = 16 * a + li, cn = NU * SL::nat(c < NX ? c : 0) + 4 * s + g;
+          const double kv = sm[S::KM + cn], gv = sm[S::GK + cn], dv = sm[S::DTM + cn];
+          Kr[a][s] = c < NX ? -kv : 0.0;
+          Gr[a][s] = c < NX ? gv + dv : 0.0;
+          Dr[a][s] = c < NX ? dv : 0.0;
+        }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        Pn[t] = Qh[t];
+        if (TA[t] == 2) { Pn[t][1] = 0.0; Pn[t][2] = 0.0; Pn[t][3] = 0.0; }
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          Pn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Kr[TA[t]][s], Gr[TB[t]][s], Pn[t], 0, 0, 0);      // - K^T (G K + DtM)
+          Pn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dr[TA[t]][s], Kr[TB[t]][s], Pn[t], 0, 0, 0);      // - DtM^T K
+        }
+    }
+    RSTAMP(5);
+    if (p32) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pn[t][q] = (double)(float)Pn[t][q];
+    }
+    // ---- P stays EXACTLY symmetric: master entries (upper triangle in slot order) and their mirror images through LDS.  This replaces
+    //      the reference's P = (P + P^T) / 2 (:133-135); an antisymmetric rounding residue grows 2.9 x per stage otherwise. ----
+    waveLdsSync();                  // (every read of the constrained stage's scratch, which PM overlays, is done)
+    tilesToPM(Pn);
+    waveLdsSync();
+    mirrorP(Pn);
+    readP();
+    waveLdsSync();
+    RSTAMP(7);
+    if (i > 0) stageIn();             // the next record: registers -> LDS (over PM) -> accumulator layout
+    writeP(rr);
+    RSTAMP(8);
+#undef RSTAMP
+  }
+  if (lane == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1;
+}
+
 // S4: forward sweep, one wavefront per instance.  The sweep is a chain of small matrix-vector products whose operands (the gain
 // K, k and the dynamics blocks of the stage, 11.7 kB) do not depend on the state: the records of stage i + 1 are fetched with
 // 16-byte loads into registers (two stages ahead) while stage i is computed out of LDS, so that the chain never waits for HBM.
@@ -828,6 +1431,20 @@ void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool 
     configured = true;
   }
   static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
+  // round 4: the register-resident sweep (one wavefront per instance at every batch size); IDOCP_RICCATI_REG=0 selects the round-2 kernels
+  static const int reg_env = getenv("IDOCP_RICCATI_REG") ? atoi(getenv("IDOCP_RICCATI_REG")) : 1;
+  if (reg_env && nt_env == 0) {
+    const size_t rs = RiccatiRegSmem<D>::BYTES;
+    static bool reg_configured = false;
+    if (!reg_configured) {
+      (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_reg_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs);
+      (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_reg_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs);
+      reg_configured = true;
+    }
+    if (hybrid) hipLaunchKernelGGL((ocp_riccati_backward_reg_kernel<D, true>), dim3((unsigned)batch), dim3(64), rs, st, B);
+    else hipLaunchKernelGGL((ocp_riccati_backward_reg_kernel<D, false>), dim3((unsigned)batch), dim3(64), rs, st, B);
+    return;
+  }
   // A chain with switching constraints takes the HYBRID instantiation (same LDS footprint).
   if (hybrid) {
     // measured on the trotting / running chains: four instances per CU (batch 1024) are fastest with ONE wavefront each (512 registers,

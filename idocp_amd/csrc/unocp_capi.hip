@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -78,6 +79,8 @@ struct idocp_unocp {
   hipStream_t stream = nullptr;
   UnBuffers B{};
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;
+  double shard_dt = 0.0; int shard_offset = 0, shard_terminal = 1, shard_prev = 0;      // the shard arguments of createImpl (idocp_unocp_clone)
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr;   // staging for host-pointer entry points
   bool has_direction = false;
   int bwd = 0;                  // 1: UnParNMPC handle (backward-Euler stages, idocp_unparnmpc_*)
@@ -94,6 +97,7 @@ using L7 = UnLayout<7>;
 int allocBuf(idocp_unocp* h, double** p, size_t n) {
   HIP_TRY(hipMalloc((void**)p, n * sizeof(double)));
   h->allocs.push_back(*p);
+  h->alloc_bytes.push_back(n * sizeof(double));
   HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(double), h->stream));
   return IDOCP_OK;
 }
@@ -159,6 +163,13 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   if (N <= 0) { set_last_error("invalid value: N must be positive!"); return IDOCP_E_ARG; }
   if (batch <= 0) { set_last_error("invalid value: batch must be positive!"); return IDOCP_E_ARG; }
   if (!(constraints->barrier > 0)) { set_last_error("invalid value: barrier must be positive!"); return IDOCP_E_ARG; }      // constraint_component_base.hxx:10-24
+  // JointAcceleration*Limit bounds: finite, and a_min < a_max where both are in use (an empty interval has no interior point to start the
+  // barrier method from)
+  for (int r = 0; r < model->nu; ++r) {
+    const bool lo = constraints->joint_acceleration_lower_limit != 0, hi = constraints->joint_acceleration_upper_limit != 0;
+    if ((lo && !std::isfinite(constraints->a_min[r])) || (hi && !std::isfinite(constraints->a_max[r]))) { set_last_error("invalid value: joint acceleration bounds must be finite!"); return IDOCP_E_ARG; }
+    if (lo && hi && !(constraints->a_min[r] < constraints->a_max[r])) { set_last_error("invalid value: a_min must be smaller than a_max!"); return IDOCP_E_ARG; }
+  }
   if (constraints->contact_distance) {
     set_last_error("unsupported constraints: ContactDistance belongs to the floating-base solvers (a fixed-base chain has no contacts here)");
     return IDOCP_E_UNSUPPORTED;
@@ -187,6 +198,7 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   h->model = *model; h->cost = *cost; h->cons = *constraints;
   h->N = N; h->batch = batch; h->device = device; h->T = T; h->nv = model->nv; h->bwd = bwd;
   h->level_offset = bwd ? 1 + stage_offset : 0; h->shard = (stage_offset != 0 || !has_terminal || has_prev) ? 1 : 0;
+  h->shard_dt = dt; h->shard_offset = stage_offset; h->shard_terminal = has_terminal; h->shard_prev = has_prev;
   int rc = IDOCP_OK;
   auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -267,6 +279,7 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
   }
   h->allocs.push_back(d_model); h->allocs.push_back(d_prob);
+  h->alloc_bytes.push_back(sizeof(DevModel)); h->alloc_bytes.push_back(sizeof(UnProblem));
   if (hipMemcpyAsync(d_model, &dm, sizeof(dm), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
       hipMemcpyAsync(d_prob, &up, sizeof(up), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess) {
@@ -293,6 +306,26 @@ int idocp_unparnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost,
 }
 
 static int wrongKind(const idocp_unocp_t* h, int want_bwd);
+
+// A deep copy of a solver (the reference's UnOCPSolver / UnParNMPCSolver are copyable, unocp_solver.hpp:59-62): the same problem on
+// the same device, every device buffer copied -- iterate, slack / dual, Riccati factors, task references --, the line-search filter too
+int idocp_unocp_clone(idocp_unocp_t* src, idocp_unocp_t** out) {
+  if (!src || !out) return IDOCP_E_ARG;
+  if (hipSetDevice(src->device) != hipSuccess) return IDOCP_E_DEVICE;
+  idocp_unocp_t* h = nullptr;
+  int rc = createImpl(&src->model, &src->cost, &src->cons, src->T, src->N, src->batch, src->device, src->bwd, &h, src->shard_dt, src->shard_offset,
+                      src->shard_terminal, src->shard_prev);
+  if (rc) return rc;
+  auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
+  if (h->allocs.size() != src->allocs.size() || h->alloc_bytes != src->alloc_bytes) { set_last_error("idocp_unocp_clone: allocation tables differ"); return fail(IDOCP_E_DEVICE); }
+  if (hipStreamSynchronize(src->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  for (size_t i = 0; i < h->allocs.size(); ++i)
+    if (hipMemcpyAsync(h->allocs[i], src->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  h->filters = src->filters; h->has_direction = src->has_direction;
+  *out = h;
+  return IDOCP_OK;
+}
 
 // One shard of the horizon of UnParNMPCSolver: the stages [stage_begin, stage_end) of N (include/idocp_hip.h)
 int idocp_unparnmpc_create_shard(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
@@ -695,6 +728,16 @@ static int getRecords(idocp_unocp_t* h, const double* base, const char* name, in
 }
 int idocp_unocp_get_solution(idocp_unocp_t* h, const char* name, int instance, double* out) {
   return getRecords(h, h ? h->B.sol : nullptr, name, instance, out, false);
+}
+// UnOCPSolver / UnParNMPCSolver::getSolution(stage): the split solution of one stage in one device-to-host copy;
+// out: lmd gmm q v a u beta (7 nv doubles, the order of the sol record)
+int idocp_unocp_get_split_solution(idocp_unocp_t* h, int instance, int stage, double* out) {
+  if (!h || !out || instance < 0 || instance >= h->batch || stage < 0 || stage > h->N) return IDOCP_E_ARG;
+  int rc = setDevice(h); if (rc) return rc;
+  static_assert(L7::S_LMD == 0 && L7::S_BETA == 6 * 7, "record order = output order");
+  HIP_TRY(hipMemcpyAsync(out, h->B.sol + ((size_t)instance * (h->N + 1) + stage) * L7::SOL, sizeof(double) * 7 * h->nv, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
 }
 int idocp_unocp_get_direction(idocp_unocp_t* h, const char* name, int instance, double* out) {
   return getRecords(h, h ? h->B.dir : nullptr, name, instance, out, true);

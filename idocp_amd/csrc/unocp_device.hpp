@@ -16,6 +16,21 @@
 namespace idocp_dev {
 
 __host__ __device__ constexpr int roundUp16(int n) { return (n + 15) / 16 * 16; }
+
+// pdipm::SetSlackAndDualPositive for one entry (include/idocp/constraints/pdipm.hxx:13-23: `while (slack < barrier) slack += barrier`).
+// The reference's loop is followed addition by addition as long as it is short (the same roundings: the result is bit-identical in
+// every case a test can reach); a slack that is still below the barrier after 1024 additions -- a constraint violated by more than
+// a thousand barriers, e.g. a foot a metre under the ground with barrier 1e-4 -- is lifted in one step, so that no lane spins through
+// millions of serial iterations and none leaves with a negative slack (a negative slack would make the dual negative and the
+// barrier cost NaN without an error status).
+__host__ __device__ inline double slackPositive(double sl, double barrier) {
+  for (int it = 0; it < 1024 && sl < barrier; ++it) sl += barrier;
+  if (sl < barrier) {
+    sl += ceil((barrier - sl) / barrier) * barrier;
+    while (sl < barrier) sl += barrier;          // (rounding of the product: at most one more)
+  }
+  return sl;
+}
 // records of the fixed-base path: even length (16-byte accesses stay aligned), no padding to 128 bytes -- the kernels that stream them walk
 // consecutive records, and with seven joints the padding was 7.5 % of the bytes of a step (solution record: 49 -> 64 doubles)
 __host__ __device__ constexpr int roundUp2(int n) { return (n + 1) / 2 * 2; }

@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(64) void un_init_constraints_kernel(UnBuffers B) {
       const double sgn = (c & 1) ? 1.0 : -1.0;
       const double x = (c < 2) ? s[L::S_Q + r] : ((c < 4) ? s[L::S_V + r] : (c < 6 ? s[L::S_U + r] : s[L::S_A + r]));
       sl = -sgn * (x - limitOf(P, c, r));
-      for (int it = 0; it < (1 << 26) && sl < P->barrier; ++it) sl += P->barrier;      // pdipm.hxx:17-20, bounded
+      sl = slackPositive(sl, P->barrier);      // pdipm.hxx:17-20
       dl = P->barrier / sl;
     }
     if (c < 6) { B.slack[su * L::CON + c * NV + r] = sl; B.dual[su * L::CON + c * NV + r] = dl; }

@@ -27,6 +27,18 @@ class ConstraintComponentBase {
   double barrier, fraction_to_boundary_rate;
   double mu = 0.0;
   Eigen::VectorXd bound;      // JointAcceleration*Limit: amin / amax, one entry per actuated joint
+
+ protected:
+  // The reference constrains a.tail(amin.size()) (joint_acceleration_lower_limit.cpp:10-24); the kernels carry one row per
+  // actuated joint, so a bound vector of any other length is rejected here instead of silently bounding the joints it does not
+  // name at zero.
+  static Eigen::VectorXd checkedBound(const Robot& robot, const Eigen::VectorXd& b, const char* what) {
+    if (b.size() != robot.dimu()) {
+      std::cerr << "invalid argument: " << what << ".size() must be Robot::dimu() = " << robot.dimu() << " on the HIP path" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    return b;
+  }
 };
 
 #define IDOCP_LIMIT_CLASS(NAME, FAMILY, UPPER)                                                        \
@@ -47,13 +59,13 @@ IDOCP_LIMIT_CLASS(JointTorquesUpperLimit, Torque, true);
 // <= amax with the bounds passed to the constructor (the robot model has none); each may be used on its own.
 class JointAccelerationLowerLimit final : public ConstraintComponentBase {
  public:
-  JointAccelerationLowerLimit(const Robot&, const Eigen::VectorXd& amin, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(Acceleration, false, barrier, fraction_to_boundary_rate) { bound = amin; }
+  JointAccelerationLowerLimit(const Robot& robot, const Eigen::VectorXd& amin, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(Acceleration, false, barrier, fraction_to_boundary_rate) { bound = checkedBound(robot, amin, "amin"); }
 };
 class JointAccelerationUpperLimit final : public ConstraintComponentBase {
  public:
-  JointAccelerationUpperLimit(const Robot&, const Eigen::VectorXd& amax, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(Acceleration, true, barrier, fraction_to_boundary_rate) { bound = amax; }
+  JointAccelerationUpperLimit(const Robot& robot, const Eigen::VectorXd& amax, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
+      : ConstraintComponentBase(Acceleration, true, barrier, fraction_to_boundary_rate) { bound = checkedBound(robot, amax, "amax"); }
 };
 
 // ContactDistance (src/constraints/contact_distance.cpp): the frames of the contacts that are not active on a stage stay above z = 0

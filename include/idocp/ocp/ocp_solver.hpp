@@ -22,16 +22,12 @@
 #include "idocp/constraints/constraints.hpp"
 #include "idocp/cost/cost_function.hpp"
 #include "idocp/eigen_shim.hpp"
+#include "idocp/ocp/split_solution.hpp"
 #include "idocp/robot/contact_status.hpp"
 #include "idocp/robot/robot.hpp"
 #include "idocp_hip.h"
 
 namespace idocp {
-
-// include/idocp/ocp/split_solution.hxx:10-31 (f, mu: one 3-vector per contact, stacked)
-struct SplitSolutionOCP {
-  Eigen::VectorXd lmd, gmm, q, v, a, u, beta, f_stack, mu_stack, nu_passive;
-};
 
 class OCPSolver {
  public:
@@ -48,12 +44,14 @@ class OCPSolver {
     check(idocp_ocp_create_hybrid(&robot.model(), &c, &k, T, N, max_num_impulse, 1, device, &h_));
     cache_.resize(N + 1);
   }
+  // ocp_solver.hpp:44: an empty solver, to be assigned a constructed one before use
+  OCPSolver() : robot_(), N_(0), h_(nullptr) {}
   ~OCPSolver() { idocp_ocp_destroy(h_); }
   // copyable and movable like the reference class (ocp_solver.hpp:171-186, `= default`): a copy is a DEEP copy of the solver
   // state on the device (idocp_ocp_clone)
-  OCPSolver(const OCPSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_) { check(idocp_ocp_clone(other.h_, &h_)); }
+  OCPSolver(const OCPSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_) { if (other.h_) check(idocp_ocp_clone(other.h_, &h_)); }
   OCPSolver& operator=(const OCPSolver& other) {
-    if (this != &other) { idocp_ocp_t* n = nullptr; check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_; }
+    if (this != &other) { idocp_ocp_t* n = nullptr; if (other.h_) check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_; }
     return *this;
   }
   OCPSolver(OCPSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
@@ -79,14 +77,14 @@ class OCPSolver {
     return out;
   }
 
-  const SplitSolutionOCP& getSolution(const int stage) {
-    SplitSolutionOCP& s = cache_.at(stage);
-    const char* names[10] = {"lmd", "gmm", "q", "v", "a", "u", "beta", "f", "mu", "nu_passive"};
-    Eigen::VectorXd* dst[10] = {&s.lmd, &s.gmm, &s.q, &s.v, &s.a, &s.u, &s.beta, &s.f_stack, &s.mu_stack, &s.nu_passive};
-    for (int f = 0; f < 10; ++f) {
-      if (stage == N_ && f >= 4) { dst[f]->resize(dimOf(names[f])); continue; }
-      *dst[f] = getSolution(names[f])[stage];
-    }
+  // ocp_solver.hpp:97: const reference to the split solution of a time stage, e.g. getSolution(0).u -- ONE device-to-host copy of
+  // the stage's record (idocp_ocp_get_split_solution); the reference stays valid until the next call for the same stage
+  const SplitSolution& getSolution(const int stage) const {
+    SplitSolution& s = cache_.at(stage);
+    const int nv = robot_.dimv(), nc = robot_.maxPointContacts();
+    std::vector<double> rec((size_t)5 * nv + robot_.dimq() + robot_.dimu() + 6 * nc + 6);
+    check(idocp_ocp_get_split_solution(h_, 0, stage, rec.data()));
+    s.assign(rec.data(), robot_.dimq(), nv, robot_.dimu(), nc, robot_.dim_passive());
     return s;
   }
 
@@ -139,12 +137,13 @@ class OCPSolver {
     check(idocp_ocp_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
   idocp_ocp_t* handle() { return h_; }
+  idocp_ocp_t* handle() const { return h_; }
 
  private:
   Robot robot_;
   int N_;
   idocp_ocp_t* h_;
-  std::vector<SplitSolutionOCP> cache_;
+  mutable std::vector<SplitSolution> cache_;
   int dimOf(const std::string& name) const {
     if (name == "q") return robot_.dimq();
     if (name == "u") return robot_.dimu();

@@ -18,6 +18,7 @@
 #include "idocp/constraints/constraints.hpp"
 #include "idocp/cost/cost_function.hpp"
 #include "idocp/eigen_shim.hpp"
+#include "idocp/ocp/split_solution.hpp"
 #include "idocp/robot/contact_status.hpp"
 #include "idocp/robot/robot.hpp"
 #include "idocp_hip.h"
@@ -53,17 +54,19 @@ class ParNMPCSolver {
     check(idocp_parnmpc_dist_attach(h_, comm_));
     N_ = Nl;
   }
+  // parnmpc_solver.hpp:47: an empty solver, to be assigned a constructed one before use
+  ParNMPCSolver() : robot_(), N_(0), h_(nullptr), comm_(nullptr) {}
   ~ParNMPCSolver() { if (comm_) idocp_parnmpc_dist_detach(h_); idocp_ocp_destroy(h_); }
   // copyable and movable like the reference class (a copy is a deep copy of the device state; a sharded solver is bound to its
   // communicator and can only be moved)
   ParNMPCSolver(const ParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), comm_(nullptr) {
     if (other.comm_) { std::cerr << "a sharded ParNMPCSolver cannot be copied\n"; std::exit(EXIT_FAILURE); }
-    check(idocp_ocp_clone(other.h_, &h_));
+    if (other.h_) check(idocp_ocp_clone(other.h_, &h_));
   }
   ParNMPCSolver& operator=(const ParNMPCSolver& other) {
     if (this != &other) {
       if (other.comm_ || comm_) { std::cerr << "a sharded ParNMPCSolver cannot be copied\n"; std::exit(EXIT_FAILURE); }
-      idocp_ocp_t* n = nullptr; check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_;
+      idocp_ocp_t* n = nullptr; if (other.h_) check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_;
     }
     return *this;
   }
@@ -102,6 +105,17 @@ class ParNMPCSolver {
     std::vector<Eigen::VectorXd> out(N_, Eigen::VectorXd(dim));
     for (int i = 0; i < N_; ++i) for (int j = 0; j < dim; ++j) out[i][j] = buf[(size_t)i * dim + j];
     return out;
+  }
+
+  // parnmpc_solver.hpp:103: const reference to the split solution of stage 0 .. N-1 (one device-to-host copy of its record)
+  const SplitSolution& getSolution(const int stage) const {
+    if ((int)cache_.size() != N_) cache_.resize(N_);
+    SplitSolution& s = cache_.at(stage);
+    const int nv = robot_.dimv(), nc = robot_.maxPointContacts();
+    std::vector<double> rec((size_t)5 * nv + robot_.dimq() + robot_.dimu() + 6 * nc + 6);
+    check(idocp_ocp_get_split_solution(h_, 0, stage, rec.data()));
+    s.assign(rec.data(), robot_.dimq(), nv, robot_.dimu(), nc, robot_.dim_passive());
+    return s;
   }
 
   void setSolution(const std::string& name, const Eigen::VectorXd& value) { check(idocp_ocp_set_solution(h_, name.c_str(), value.data())); }
@@ -167,6 +181,7 @@ class ParNMPCSolver {
   idocp_ocp_t* h_;
   idocp_comm_t* comm_ = nullptr;      // not owned
   double kkt_error_ = 0.0;
+  mutable std::vector<SplitSolution> cache_;
   static void check(int rc) {
     if (rc != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';

@@ -19,15 +19,11 @@
 #include "idocp/constraints/constraints.hpp"
 #include "idocp/cost/cost_function.hpp"
 #include "idocp/eigen_shim.hpp"
+#include "idocp/ocp/split_solution.hpp"
 #include "idocp/robot/robot.hpp"
 #include "idocp_hip.h"
 
 namespace idocp {
-
-// fixed-base subset of include/idocp/ocp/split_solution.hxx:10-31
-struct SplitSolution {
-  Eigen::VectorXd lmd, gmm, q, v, a, u, beta;
-};
 
 class UnOCPSolver {
  public:
@@ -40,9 +36,32 @@ class UnOCPSolver {
     check(idocp_unocp_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
     cache_.resize(N + 1);
   }
+  // unocp_solver.hpp:49: an empty solver, to be assigned a constructed one before use
+  UnOCPSolver() : robot_(), cost_(), N_(0), dt_(0.0), h_(nullptr) {}
   ~UnOCPSolver() { idocp_unocp_destroy(h_); }
-  UnOCPSolver(const UnOCPSolver&) = delete;
-  UnOCPSolver& operator=(const UnOCPSolver&) = delete;
+  // copyable and movable like the reference class (unocp_solver.hpp:59-74, `= default`): a copy is a DEEP copy of the solver state on
+  // the device (idocp_unocp_clone)
+  UnOCPSolver(const UnOCPSolver& other) : robot_(other.robot_), cost_(other.cost_), N_(other.N_), dt_(other.dt_), h_(nullptr), cache_(other.cache_) {
+    if (other.h_) check(idocp_unocp_clone(other.h_, &h_));
+  }
+  UnOCPSolver& operator=(const UnOCPSolver& other) {
+    if (this != &other) {
+      idocp_unocp_t* n = nullptr;
+      if (other.h_) check(idocp_unocp_clone(other.h_, &n));
+      idocp_unocp_destroy(h_);
+      h_ = n; robot_ = other.robot_; cost_ = other.cost_; N_ = other.N_; dt_ = other.dt_; cache_ = other.cache_;
+    }
+    return *this;
+  }
+  UnOCPSolver(UnOCPSolver&& other) noexcept
+      : robot_(other.robot_), cost_(std::move(other.cost_)), N_(other.N_), dt_(other.dt_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
+  UnOCPSolver& operator=(UnOCPSolver&& other) noexcept {
+    if (this != &other) {
+      idocp_unocp_destroy(h_);
+      h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; cost_ = std::move(other.cost_); N_ = other.N_; dt_ = other.dt_; cache_ = std::move(other.cache_);
+    }
+    return *this;
+  }
 
   void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
 
@@ -51,16 +70,13 @@ class UnOCPSolver {
     check(idocp_unocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
 
-  const SplitSolution& getSolution(const int stage) {
+  // unocp_solver.hpp:96: const reference to the split solution of a time stage -- one device-to-host copy of the stage's record
+  const SplitSolution& getSolution(const int stage) const {
     SplitSolution& s = cache_.at(stage);
-    const char* names[7] = {"lmd", "gmm", "q", "v", "a", "u", "beta"};
-    Eigen::VectorXd* dst[7] = {&s.lmd, &s.gmm, &s.q, &s.v, &s.a, &s.u, &s.beta};
-    for (int f = 0; f < 7; ++f) {
-      const bool terminal_only = (f < 4);
-      if (stage == N_ && !terminal_only) { dst[f]->resize(robot_.dimv()); continue; }
-      const std::vector<Eigen::VectorXd> all = getSolution(names[f]);
-      *dst[f] = all[stage];
-    }
+    const int nv = robot_.dimv();
+    std::vector<double> rec((size_t)7 * nv);
+    check(idocp_unocp_get_split_solution(h_, 0, stage, rec.data()));
+    s.assign(rec.data(), nv, nv, nv, 0, 0);
     return s;
   }
 
@@ -146,7 +162,7 @@ class UnOCPSolver {
   int N_;
   double dt_;
   idocp_unocp_t* h_;
-  std::vector<SplitSolution> cache_;
+  mutable std::vector<SplitSolution> cache_;
   std::vector<double> task_refs_;
   // TimeVaryingTaskSpace*Cost: the reference asks the user's ref object at the time of every stage inside linearizeOCP
   // (unocp_solver.cpp:78-94 -> time_varying_task_space_6d_cost.cpp:65-67); here the poses are evaluated up front and uploaded

@@ -19,6 +19,7 @@
 #include "idocp/constraints/constraints.hpp"
 #include "idocp/cost/cost_function.hpp"
 #include "idocp/eigen_shim.hpp"
+#include "idocp/ocp/split_solution.hpp"
 #include "idocp/robot/robot.hpp"
 #include "idocp/unocp/unocp_solver.hpp"      // SplitSolution
 #include "idocp_hip.h"
@@ -36,9 +37,27 @@ class UnParNMPCSolver {
     check(idocp_unparnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
     cache_.resize(N);
   }
+  // unparnmpc_solver.hpp:48: an empty solver, to be assigned a constructed one before use
+  UnParNMPCSolver() : robot_(), N_(0), h_(nullptr) {}
   ~UnParNMPCSolver() { idocp_unocp_destroy(h_); }
-  UnParNMPCSolver(const UnParNMPCSolver&) = delete;
-  UnParNMPCSolver& operator=(const UnParNMPCSolver&) = delete;
+  // copyable and movable like the reference class (`= default` there): a copy is a DEEP copy of the device state (idocp_unocp_clone)
+  UnParNMPCSolver(const UnParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_) {
+    if (other.h_) check(idocp_unocp_clone(other.h_, &h_));
+  }
+  UnParNMPCSolver& operator=(const UnParNMPCSolver& other) {
+    if (this != &other) {
+      idocp_unocp_t* n = nullptr;
+      if (other.h_) check(idocp_unocp_clone(other.h_, &n));
+      idocp_unocp_destroy(h_);
+      h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_;
+    }
+    return *this;
+  }
+  UnParNMPCSolver(UnParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
+  UnParNMPCSolver& operator=(UnParNMPCSolver&& other) noexcept {
+    if (this != &other) { idocp_unocp_destroy(h_); h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; N_ = other.N_; cache_ = std::move(other.cache_); }
+    return *this;
+  }
 
   void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
   void initBackwardCorrection(const double t) { check(idocp_unparnmpc_init_backward_correction(h_, t)); }
@@ -48,11 +67,12 @@ class UnParNMPCSolver {
   }
 
   // stage in [0, N): the N backward-Euler stages (stage i lives at t + (i + 1) dt)
-  const SplitSolution& getSolution(const int stage) {
+  const SplitSolution& getSolution(const int stage) const {
     SplitSolution& s = cache_.at(stage);
-    const char* names[7] = {"lmd", "gmm", "q", "v", "a", "u", "beta"};
-    Eigen::VectorXd* dst[7] = {&s.lmd, &s.gmm, &s.q, &s.v, &s.a, &s.u, &s.beta};
-    for (int f = 0; f < 7; ++f) *dst[f] = getSolution(names[f])[stage];
+    const int nv = robot_.dimv();
+    std::vector<double> rec((size_t)7 * nv);
+    check(idocp_unocp_get_split_solution(h_, 0, stage, rec.data()));
+    s.assign(rec.data(), nv, nv, nv, 0, 0);
     return s;
   }
 
@@ -124,7 +144,7 @@ class UnParNMPCSolver {
   Robot robot_;
   int N_;
   idocp_unocp_t* h_;
-  std::vector<SplitSolution> cache_;
+  mutable std::vector<SplitSolution> cache_;
   static void check(int rc) {
     if (rc != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';

@@ -203,6 +203,10 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost,
                        const idocp_constraints_t* constraints, double T, int N,
                        int batch, int device, idocp_unocp_t** out);
 void idocp_unocp_destroy(idocp_unocp_t* h);
+/* Deep copy of a UnOCPSolver / UnParNMPCSolver handle (the reference classes are copyable,
+ * unocp_solver.hpp:59-62): same problem, same device, every device buffer and the line-search
+ * filter copied. */
+int idocp_unocp_clone(idocp_unocp_t* src, idocp_unocp_t** out);
 
 /* UnOCPSolver::setSolution(name, value) (unocp_solver.cpp:157-181): name in
  * {"q","v","a","u"}; value[dim] is written to every stage of every instance,
@@ -249,6 +253,10 @@ int idocp_unocp_kkt_error(idocp_unocp_t* h, double* kkt_error);
  * (a, u, beta: N stages). */
 int idocp_unocp_get_solution(idocp_unocp_t* h, const char* name, int instance,
                              double* out);
+/* UnOCPSolver::getSolution(stage) (unocp_solver.hpp: `const SplitSolution& getSolution(int) const`):
+ * the split solution of ONE stage in one device-to-host copy; out[7 nv] = lmd gmm q v a u beta
+ * (a, u, beta are meaningless on the terminal stage N). */
+int idocp_unocp_get_split_solution(idocp_unocp_t* h, int instance, int stage, double* out);
 /* Newton direction of the last updateSolution (parity tests): name in
  * {"dq","dv","da","du","dlmd","dgmm","dbeta"}; same shapes. */
 int idocp_unocp_get_direction(idocp_unocp_t* h, const char* name, int instance,
@@ -433,6 +441,11 @@ int idocp_ocp_kkt_error(idocp_ocp_t* h, double* kkt_error);
 /* OCPSolver::getSolution(name): q v a u f lmd gmm beta mu nu_passive; out[(N+1)][dim]
  * (f, mu: [ncontacts*3] per stage; stage-only fields fill N rows). */
 int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, double* out);
+/* OCPSolver::getSolution(stage) (ocp_solver.hpp:97) / ParNMPCSolver::getSolution(stage): the split
+ * solution of ONE grid stage in one device-to-host copy -- the call an MPC loop makes every cycle.
+ * out[3 nv + nq + nv + nu + nv + 2 * 3 ncontacts + 6] = lmd gmm q v a u beta f mu nu_passive
+ * (split_solution.hxx:10-31); only lmd gmm q v are meaningful on the terminal stage. */
+int idocp_ocp_get_split_solution(idocp_ocp_t* h, int instance, int stage, double* out);
 /* Newton direction: dq dv da du df dlmd dgmm dbeta dmu dnu_passive. */
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out);
 /* The same fields for every stage of the chain (incl. impulse / aux / lift stages), in

@@ -1,0 +1,110 @@
+// The parts of the reference's solver interface that are about C++ object semantics rather than arithmetic
+// (ocp_solver.hpp:44-74,97; unocp_solver.hpp:49-74,96; parnmpc_solver.hpp; unparnmpc_solver.hpp): default construction, copy and
+// move of empty and of live solvers, `getSolution(stage) const` returning a const reference to a SplitSolution.
+//   usage: facade_surface              -> the part that needs no GPU
+//          facade_surface <iiwa14.urdf> <anymal.urdf>   -> also the live solvers
+#include <cmath>
+#include <utility>
+
+#include "../../examples/common.hpp"
+#include "idocp/cost/configuration_space_cost.hpp"
+#include "idocp/ocp/ocp_solver.hpp"
+#include "idocp/ocp/parnmpc_solver.hpp"
+#include "idocp/unocp/unocp_solver.hpp"
+#include "idocp/unocp/unparnmpc_solver.hpp"
+#include "idocp/utils/joint_constraints_factory.hpp"
+
+#define REQUIRE(c) do { if (!(c)) { std::cerr << "FAILED: " #c " (line " << __LINE__ << ")\n"; return 1; } } while (0)
+
+template <typename S>
+static int emptySolverSemantics() {
+  S a;                    // default constructor
+  S b(a);                 // copy of an empty solver
+  S c(std::move(b));      // move
+  a = c;                  // copy assignment
+  c = std::move(a);       // move assignment
+  return 0;
+}
+
+static double maxDiff(const ex::Vec& a, const ex::Vec& b) {
+  if (a.size() != b.size()) return 1e300;
+  double m = 0.0;
+  for (int i = 0; i < a.size(); ++i) m = std::fmax(m, std::fabs(a[i] - b[i]));
+  return m;
+}
+
+int main(int argc, char** argv) {
+  if (emptySolverSemantics<idocp::OCPSolver>() || emptySolverSemantics<idocp::UnOCPSolver>() ||
+      emptySolverSemantics<idocp::ParNMPCSolver>() || emptySolverSemantics<idocp::UnParNMPCSolver>()) return 1;
+  std::cout << "empty solvers: ok" << std::endl;
+  if (argc < 3) return 0;
+
+  {  // ---- fixed base
+    idocp::Robot robot(argv[1]);
+    const int n = robot.dimv();
+    auto reach = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
+    reach->set_q_ref(ex::filled(n, -1));
+    ex::attachWeights(*reach, ex::filled(n, 10), ex::filled(n, 0.1), ex::filled(n, 0.01), false);
+    auto cost = std::make_shared<idocp::CostFunction>();
+    cost->push_back(reach);
+    const int N = 12;
+    idocp::UnOCPSolver solver(robot, cost, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+    const ex::Vec q = ex::filled(n, 0.5), v = ex::Vec::Zero(n);
+    solver.setSolution("q", q);
+    solver.setSolution("v", v);
+    solver.initConstraints();
+    solver.updateSolution(0.0, q, v);
+    const idocp::UnOCPSolver& cs = solver;
+    const idocp::SplitSolution& s3 = cs.getSolution(3);                       // const overload, const reference
+    REQUIRE(maxDiff(s3.u, cs.getSolution("u")[3]) == 0.0 && maxDiff(s3.q, cs.getSolution("q")[3]) == 0.0);
+    REQUIRE(maxDiff(cs.getSolution(N).q, cs.getSolution("q")[N]) == 0.0);
+    idocp::UnOCPSolver copy(solver);                                          // deep copy: same iterate, independent afterwards
+    REQUIRE(maxDiff(copy.getSolution(3).u, s3.u) == 0.0);
+    copy.updateSolution(0.0, q, v);
+    solver.updateSolution(0.0, q, v);
+    REQUIRE(maxDiff(copy.getSolution(5).a, solver.getSolution(5).a) == 0.0);  // the copy carries slack / dual as well: same second step
+    idocp::UnOCPSolver assigned;
+    assigned = solver;
+    REQUIRE(maxDiff(assigned.getSolution(5).a, solver.getSolution(5).a) == 0.0);
+    idocp::UnParNMPCSolver pn(robot, cost, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+    pn.setSolution("q", q);
+    pn.setSolution("v", v);
+    pn.initConstraints();
+    pn.initBackwardCorrection(0.0);
+    pn.updateSolution(0.0, q, v);
+    const idocp::UnParNMPCSolver& cpn = pn;
+    REQUIRE(maxDiff(cpn.getSolution(2).v, cpn.getSolution("v")[2]) == 0.0);
+    idocp::UnParNMPCSolver pn2(pn);
+    REQUIRE(maxDiff(pn2.getSolution(2).lmd, cpn.getSolution(2).lmd) == 0.0);
+    std::cout << "fixed-base solvers: ok" << std::endl;
+  }
+  {  // ---- floating base
+    idocp::Robot robot(argv[2], ex::anymalFeet());
+    const ex::Vec stand = ex::anymalStanding();
+    auto pose_cost = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
+    pose_cost->set_q_ref(stand);
+    ex::attachWeights(*pose_cost, ex::filled(18, 10), ex::filled(18, 1), ex::filled(18, 0.01), false);
+    const ex::V3 share(0, 0, 70);
+    auto cost = std::make_shared<idocp::CostFunction>();
+    cost->push_back(pose_cost);
+    cost->push_back(ex::forceCost(robot, ex::V3(0.001, 0.001, 0.001), false, &share));
+    const int N = 10;
+    idocp::OCPSolver solver(robot, cost, ex::jointLimits(robot, 0.7, false, true), 0.25, N);
+    ex::Schedule standing(ex::footholds(robot, stand));
+    standing.add({0, 1, 2, 3}, 0.0);
+    standing.install(solver, robot);
+    ex::restingGuess(solver, robot, stand);
+    solver.initConstraints(0.0);
+    const ex::Vec v = ex::Vec::Zero(robot.dimv());
+    solver.updateSolution(0.0, stand, v);
+    const idocp::OCPSolver& cs = solver;
+    const idocp::SplitSolution& s0 = cs.getSolution(0);
+    REQUIRE(maxDiff(s0.u, cs.getSolution("u")[0]) == 0.0 && maxDiff(s0.q, cs.getSolution("q")[0]) == 0.0);
+    REQUIRE(maxDiff(s0.f_stack(), cs.getSolution("f")[0]) == 0.0 && maxDiff(s0.mu_stack(), cs.getSolution("mu")[0]) == 0.0);
+    REQUIRE(maxDiff(s0.beta, cs.getSolution("beta")[0]) == 0.0 && maxDiff(s0.nu_passive, cs.getSolution("nu_passive")[0]) == 0.0);
+    REQUIRE((int)s0.f.size() == robot.maxPointContacts() && s0.f[1][2] == s0.f_stack()[5]);
+    REQUIRE(maxDiff(cs.getSolution(N).v, cs.getSolution("v")[N]) == 0.0);
+    std::cout << "floating-base solver: ok" << std::endl;
+  }
+  return 0;
+}

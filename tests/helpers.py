@@ -253,6 +253,34 @@ def referee_check(g, o, h, what, tol=1e-10, factor=4.0, window=3):
     assert bad.size == 0, (what, "stage %d: gpu-referee %.2e, oracle-referee %.2e" % (bad[0], eg[bad[0]], eo_w[bad[0]]))
     return eg.max(), eo.max()
 
+def parity(g, o, h, what, tol=1e-10, cap=None):
+    """The parity bar of north_star: 1e-10 against the oracle, stage by stage (rel_err).  Where two FP64 evaluation orders cannot
+    agree that far the long double referee decides (referee_check: the GPU at most 4x as far from the referee as the FP64 oracle,
+    + 1e-10) -- never a loosened tolerance on its own.  h: the referee's value, or a callable that produces it (only evaluated when
+    needed).  cap: optional hard limit on the GPU-oracle distance even under the referee rule.  Returns the GPU-oracle distance."""
+    e = rel_err(g, o)
+    if e >= tol:
+        hv = h() if callable(h) else h
+        assert hv is not None, (what, "%.2e against the oracle and no referee" % e)
+        referee_check(g, o, hv, what, tol=tol)
+    if cap is not None:
+        assert e < cap, (what, e)
+    return e
+
+def pairwise_check(a, b, o, h, what, tol=1e-10, factor=4.0, window=3):
+    """Two GPU evaluations a, b of the same quantity (e.g. two instantiations of a kernel) against EACH OTHER, stage by stage, at the
+    bar the referee rule implies for the pair: on the stages where the FP64 oracle o sits on its long double build h (to 1e-11, over
+    +-`window` stages) the two must agree to 2 * tol -- no cap hides a regression there --, elsewhere to 2 * (factor * oracle error + tol)."""
+    a, b, o, h = (np.asarray(x, dtype=np.float64).reshape(len(h), -1) for x in (a, b, o, h))
+    scale = np.maximum(1.0, np.abs(h).max(axis=1))
+    eo = np.abs(o - h).max(axis=1) / scale
+    eo_w = np.array([eo[max(0, i - window):i + window + 1].max() for i in range(len(eo))])
+    d = np.abs(a - b).max(axis=1) / scale
+    bound = 2.0 * (np.where(eo_w < 1e-11, 0.0, factor * eo_w) + tol)
+    bad = np.nonzero(d > bound)[0]
+    assert bad.size == 0, (what, "stage %d: the two differ by %.2e, bound %.2e (oracle-referee %.2e)" % (bad[0], d[bad[0]], bound[bad[0]], eo_w[bad[0]]))
+    return float(d.max()), int((eo_w < 1e-11).sum())
+
 def rel_err(a, b):
     """Largest deviation of a from b, STAGE BY STAGE: arrays with a leading stage (or instance) axis are compared entry-wise and
     every stage's error is taken relative to the largest entry of that very stage of b (never less than 1: entries below one are

@@ -88,3 +88,40 @@ def test_contact_positions_host_fk_matches_oracle():
         olib.oracle_contact_kinematics(C.byref(model), P(q), P(z), P(z), P(np.zeros((nc, 3))), C.c_double(0.05), P(tmp[0]), P(tmp[1]),
                                        P(tmp[2]), P(tmp[3]), P(fp), P(fR), P(fv), P(fa), P(d4[0]), P(d4[1]), P(d4[2]), P(d4[3]), None)
         assert np.abs(pts - fp).max() < 1e-13
+
+
+def test_facade_object_semantics_without_gpu(tmp_path):
+    # default construction, copy and move of EMPTY solvers (ocp_solver.hpp:44-74 and its three siblings) need no device
+    import subprocess
+    exe = str(tmp_path / "facade_surface")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests/cpp/facade_surface.cpp"),
+                        "-L" + os.path.join(ROOT, "idocp_amd/lib"), "-lidocp_hip", "-Wl,-rpath," + os.path.join(ROOT, "idocp_amd/lib"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "empty solvers: ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_acceleration_bound_errors():
+    # JointAcceleration*Limit bounds are validated by create (finite; a_min < a_max where both are in use): IDOCP_E_ARG
+    lib = capi.lib()
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    h = C.c_void_p()
+    cons.joint_acceleration_lower_limit = 1
+    cons.joint_acceleration_upper_limit = 1
+    for r in range(m.nu):
+        cons.a_min[r], cons.a_max[r] = -5.0, 5.0
+    cons.a_max[3] = -6.0
+    assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 1, 0, C.byref(h)) == -1
+    assert b"a_min must be smaller than a_max" in lib.idocp_last_error()
+    cons.a_max[3] = float("inf")
+    assert lib.idocp_unocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 1, 0, C.byref(h)) == -1
+    assert b"must be finite" in lib.idocp_last_error()
+    from helpers import anymal_model, anymal_problem
+    ma = anymal_model()
+    costa, consa = anymal_problem(ma)
+    consa.joint_acceleration_upper_limit = 1
+    consa.a_max[0] = float("nan")
+    assert lib.idocp_ocp_create(C.byref(ma), C.byref(costa), C.byref(consa), 1.0, 20, 1, 0, C.byref(h)) == -1
+    assert b"must be finite" in lib.idocp_last_error()

@@ -8,30 +8,33 @@ import pytest
 
 from idocp_amd import capi
 from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, HipOCP, HipParNMPC, OracleOCP, OracleParNMPC, P, anymal_contact_points,
-                     anymal_model, anymal_problem, rel_err, trotting_sequence)
+                     anymal_model, anymal_problem, parity, rel_err, trotting_sequence)
 
 pytestmark = pytest.mark.gpu
 
 
-def ocp_pair(batch=1):
+def ocp_pair(batch=1, referee=False):
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=True)
     cons.contact_distance = 1
     N, T, nimp = 31, 1.55, 2
     o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
     g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1)
+    solvers = [o, g]
+    if referee:
+        solvers.append(OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=True))      # long double referee
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
-    for s in (o, g):
+    for s in solvers:
         trotting_sequence(s, m, nimp)
         s.set_solution("q", q)
         s.set_solution("v", v)
         s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
         s.init_constraints(0.0)
-    return m, o, g, q, v
+    return (m, o, g, q, v, solvers[2]) if referee else (m, o, g, q, v)
 
 
 def test_ocp_trotting_chain():
-    m, o, g, q, v = ocp_pair()
+    m, o, g, q, v, h = ocp_pair(referee=True)
     assert g.lib.idocp_ocp_dimc(g.h) == o.lib.oracle_ocp_dimc(o.h) == 6 * 12 + 5 * 4 + 4
     for a, b in zip(g.constraint_data(), o.constraint_data()):
         assert rel_err(a, b) < 1e-10                                   # setSlackAndDual: heights of the frames (contact_distance.cpp:58-65)
@@ -40,16 +43,19 @@ def test_ocp_trotting_chain():
     assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
     for it in range(12):
         assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        if it <= 3:
+            assert h.update(0.0, q, v) == 0
         if it in (0, 3):
-            # (rows with slack ~ 1e-4 weigh 1e4 in the Hessian: the iterates of two FP64 evaluations separate a little faster than elsewhere)
-            tol = 1e-9 if it == 0 else 2e-8
+            # rows with slack ~ 1e-4 weigh 1e4 in the Hessian: where two FP64 evaluations separate beyond 1e-10 the long double referee
+            # decides (GPU at most 4x as far from it as the FP64 oracle, + 1e-10); 2e-8 is only the cap against the oracle
             for f in ("dq", "dv", "da", "df", "du", "dlmd", "dgmm", "dbeta", "dmu"):
-                assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < tol, (it, f)
+                parity(g.get_chain(f, M), o.get_chain(f, M), lambda f=f: h.get_chain(f, M), (it, f), cap=2e-8)
+            tol = 1e-9 if it == 0 else 2e-8
             ao, bo = o.step_sizes()
             ag, bg = g.step_sizes()
             assert abs(ag[0] - ao) < tol and abs(bg[0] - bo) < tol
-            for a, b in zip(g.constraint_data(), o.constraint_data()):
-                assert rel_err(a, b) < tol, it
+            for a, b, c in zip(g.constraint_data(), o.constraint_data(), h.constraint_data()):
+                parity(a, b, c, ("slack / dual", it), cap=2e-8)
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) < 1e-6 * max(1.0, e_o)
     assert o.infeasible_stage() == -1 and list(g.infeasible_stage()) == [-1]
@@ -85,9 +91,10 @@ def test_parnmpc_chain_with_a_lift():
     cost, cons = anymal_problem(m, trotting_ref=False)
     cons.contact_distance = 1
     o = OracleParNMPC(m, cost, cons, 1.0, 20, max_num_impulse=3)
+    h = OracleParNMPC(m, cost, cons, 1.0, 20, max_num_impulse=3, hp=True)      # long double referee
     g = HipParNMPC(m, cost, cons, 1.0, 20, max_num_impulse=3)
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
-    for s in (o, g):
+    for s in (o, g, h):
         pts = anymal_contact_points(m).copy()
         s.set_contact_status([1, 1, 1, 1], pts)
         s.push_back_contact_status([0, 1, 1, 0], pts, 0.52)
@@ -98,9 +105,9 @@ def test_parnmpc_chain_with_a_lift():
     M = len(o.chain(0.0))
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) <= 1e-9 * e_o
-    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
-        assert rel_err(g.get_chain(f, M + 1)[:M], o.get_chain(f, M)) < 1e-9, f
+        parity(g.get_chain(f, M + 1)[:M], o.get_chain(f, M), lambda f=f: h.get_chain(f, M), f, cap=1e-8)
 
 
 def test_clone_and_hipgraph_carry_the_ext_kernels():
@@ -160,3 +167,32 @@ def test_clone_and_hipgraph_carry_the_ext_kernels():
     capi.check(lib.idocp_ocp_synchronize(e.h)); capi.check(lib.idocp_ocp_synchronize(r.h))
     for f in ("q", "v", "a", "u", "f", "lmd", "gmm"):
         assert np.array_equal(e.get_chain(f, M), r.get_chain(f, M)), f
+
+
+def test_slack_initialisation_far_below_the_ground_stays_positive_and_finite():
+    # pdipm::SetSlackAndDualPositive (pdipm.hxx:13-23) adds the barrier until the slack reaches it.  With the base a metre under the
+    # ground the rows start 1e4 barriers below: the device lifts them in one step behind the first 1024 additions (slackPositive,
+    # unocp_device.hpp) -- the slacks must come out >= barrier, finite, with dual = barrier / slack, and the first Newton step must be
+    # free of NaN (round 3 capped the loop and left such a slack negative: negative dual, log of a negative number in the barrier cost).
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    cons.contact_distance = 1
+    N, T, nimp = 31, 1.55, 2
+    g = HipOCP(m, cost, cons, T, N, batch=1, max_num_impulse=nimp + 1)
+    trotting_sequence(g, m, nimp)
+    q = ANYMAL_Q_STANDING.copy()
+    q[2] -= 1.0
+    g.set_solution("q", q)
+    g.set_solution("v", np.zeros(m.nv))
+    g.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    g.init_constraints(0.0)
+    slack, dual = g.constraint_data()
+    slack, dual = np.asarray(slack), np.asarray(dual)
+    assert np.all(np.isfinite(slack)) and np.all(np.isfinite(dual))
+    rows = slack[:, -4:] if slack.ndim == 2 else slack.reshape(-1, slack.shape[-1])[:, -4:]
+    drows = dual[:, -4:] if dual.ndim == 2 else dual.reshape(-1, dual.shape[-1])[:, -4:]
+    live = drows > 0                                        # rows that exist (stages with level >= 2 that are not impulse stages)
+    assert live.any()
+    assert np.all(rows[live] >= cons.barrier * (1 - 1e-12))
+    assert np.all(rows[live] < cons.barrier * 3)            # lifted just above the barrier, like the reference's loop would
+    assert np.allclose(drows[live], cons.barrier / rows[live], rtol=1e-14)

@@ -263,3 +263,16 @@ def test_anymal_trotting_parnmpc_example_matches_oracle():
     ref = o.kkt_error(0.0, q, v)
     assert abs(its[0] - ref) <= 1e-4 * max(1.0, ref), (its[0], ref)
     assert np.isfinite(its).all()
+
+
+def test_facade_surface_const_getters_copies_and_default_constructors(tmp_path):
+    # ocp_solver.hpp:44,97 and its siblings: `getSolution(stage) const` (one device-to-host copy, idocp_*_get_split_solution) equals
+    # the field getters; deep copies of live solvers continue identically; default-constructed solvers can be assigned
+    exe = str(tmp_path / "facade_surface")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests/cpp/facade_surface.cpp"),
+                        "-L" + os.path.join(ROOT, "idocp_amd/lib"), "-lidocp_hip", "-Wl,-rpath," + os.path.join(ROOT, "idocp_amd/lib"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, IIWA_URDF, ANYMAL_URDF], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "fixed-base solvers: ok" in r.stdout and "floating-base solver: ok" in r.stdout

@@ -4,7 +4,7 @@ the chain (stage, [impulse, aux | lift], ..., terminal), on the reference's trot
 import numpy as np
 import pytest
 
-from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, anymal_model, anymal_problem, referee_check,
+from helpers import (pairwise_check, ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, anymal_model, anymal_problem, referee_check,
                      rel_err, trotting_sequence)
 
 pytestmark = pytest.mark.gpu
@@ -341,6 +341,10 @@ def test_general_axes_instantiations_direction_parity(monkeypatch):
         referee_check(g_special.get_chain(f, M), o.get_chain(f, M), hf, f + " (compile-time axes)")
     compare_chain(o, g_general, M, dirs, 1e-8, "direction (general axes)")
     compare_chain(o, g_special, M, dirs, 1e-8, "direction (compile-time axes)")
+    # the two instantiations against each other: 2e-10 on every stage where the oracle sits on its referee (most of the chain), the
+    # referee-derived bound on the stages around the short one -- no flat 1e-8 that a regression of one instantiation could hide behind
+    exact_stages = M
     for f in dirs:
-        a, b = np.asarray(g_general.get_chain(f, M)), np.asarray(g_special.get_chain(f, M))
-        assert rel_err(a, b) < 1e-8, f
+        _, n_exact = pairwise_check(g_general.get_chain(f, M), g_special.get_chain(f, M), o.get_chain(f, M), h.get_chain(f, M), f)
+        exact_stages = min(exact_stages, n_exact)
+    assert exact_stages >= M // 2, exact_stages

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, HipParNMPC, OracleOCP, OracleParNMPC,
-                     anymal_contact_points, anymal_model, anymal_problem, rel_err, trotting_sequence)
+                     anymal_contact_points, anymal_model, anymal_problem, parity, rel_err, trotting_sequence)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -80,9 +80,10 @@ def test_ocp_trotting_chain_and_line_search():
     cost, cons = problem(m, trotting_ref=True)
     N, T, nimp = 31, 1.55, 2
     o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+    h = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=True)      # long double referee
     g = HipOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
-    q, v = start((o, g), m, seq=nimp)
-    o.init_constraints(0.0); g.init_constraints(0.0)
+    q, v = start((o, g, h), m, seq=nimp)
+    o.init_constraints(0.0); g.init_constraints(0.0); h.init_constraints(0.0)
     M = len(o.chain(0.0))
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
@@ -90,32 +91,35 @@ def test_ocp_trotting_chain_and_line_search():
     import ctypes as C
     from idocp_amd import capi
     from helpers import P
-    o.lib.oracle_ocp_update_solution_ls.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
-    assert o.lib.oracle_ocp_update_solution_ls(o.h, 0.0, P(q), P(v)) == 0
+    for s_ in (o, h):
+        s_.lib.oracle_ocp_update_solution_ls.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
+        assert s_.lib.oracle_ocp_update_solution_ls(s_.h, 0.0, P(q), P(v)) == 0
     assert g.lib.idocp_ocp_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1) == 0
     ao, _ = o.step_sizes()
     ag, _ = g.step_sizes()
     assert abs(ag[0] - ao) < 1e-10
+    # 1e-10 stage by stage; on the short stages around the impulse (1.7 ms on this grid) the long double referee decides
     for f in ("dq", "dv", "da", "df", "du", "dlmd", "dgmm", "dbeta", "dmu"):
-        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, f
+        parity(g.get_chain(f, M), o.get_chain(f, M), lambda f=f: h.get_chain(f, M), f, cap=1e-8)
     for f in ("q", "v", "a", "f", "u", "lmd", "gmm", "beta", "mu"):
-        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, f
+        parity(g.get_chain(f, M), o.get_chain(f, M), lambda f=f: h.get_chain(f, M), f, cap=1e-8)
 
 
 def test_parnmpc_horizon():
     m = anymal_model()
     cost, cons = problem(m, trotting_ref=False)
     o, g = OracleParNMPC(m, cost, cons, 0.5, 20), HipParNMPC(m, cost, cons, 0.5, 20)
-    q, v = start((o, g), m)
-    o.init(0.0); g.init(0.0)
+    h = OracleParNMPC(m, cost, cons, 0.5, 20, hp=True)                         # long double referee
+    q, v = start((o, g, h), m)
+    o.init(0.0); g.init(0.0); h.init(0.0)
     rng = np.random.default_rng(5)
     q[7:] += 0.005 * rng.uniform(-1, 1, 12)
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
-    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
-        # (cold-started ParNMPC: the correction sweeps amplify rounding along the horizon, tests/test_parnmpc_gpu.py)
-        assert rel_err(g.get(f), o.get(f)) < 5e-9, f
+        # (cold-started ParNMPC: the correction sweeps amplify rounding along the horizon, tests/test_parnmpc_gpu.py: the referee decides)
+        parity(g.get(f), o.get(f), lambda f=f: h.get(f), f, cap=5e-8)
     ao, bo = o.step_sizes()
     ag, bg = g.step_sizes()
     assert abs(ag[0] - ao) < 1e-8 and abs(bg[0] - bo) < 1e-8

@@ -10,7 +10,7 @@ import pytest
 from idocp_amd import capi
 from idocp_amd.workloads import ANYMAL_URDF
 from helpers import (ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, HipParNMPC, OracleOCP, OracleParNMPC, P,
-                     anymal_contact_points, anymal_model, anymal_problem, rel_err, trotting_sequence)
+                     anymal_contact_points, anymal_model, anymal_problem, parity, rel_err, trotting_sequence)
 
 pytestmark = pytest.mark.gpu
 
@@ -68,24 +68,26 @@ def test_ocp_uniform_horizon(frame, dim):
     pos = pts[0] if frame == "LF_FOOT" else np.array([0.0, 0.0, 0.45])      # (the reference only has to be near the frame)
     set_reference(cost, m, pos, off)
     o, g = OracleOCP(m, cost, cons, 0.5, 20), HipOCP(m, cost, cons, 0.5, 20)
-    q, v = start((o, g), m)
-    o.init_constraints(0.0); g.init_constraints(0.0)
+    h = OracleOCP(m, cost, cons, 0.5, 20, hp=True)                      # long double referee
+    q, v = start((o, g, h), m)
+    o.init_constraints(0.0); g.init_constraints(0.0); h.init_constraints(0.0)
     rng = np.random.default_rng(11)
     q[7:] += 0.02 * rng.uniform(-1, 1, 12)
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
     for it in range(25):
         assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        if it <= 2:
+            assert h.update(0.0, q, v) == 0
         if it in (0, 2):
-            for f in OCP_DIR_FIELDS:
-                assert rel_err(g.get(f), o.get(f)) < (1e-9 if it == 0 else 1e-8), (it, f)
-            for f in OCP_SOL_FIELDS:
-                assert rel_err(g.get(f), o.get(f)) < (1e-9 if it == 0 else 1e-8), (it, f)
+            # 1e-10, or the referee's word (the Gauss-Newton task Hessian J^T W J with weights of 1e3 stiffens the stage blocks)
+            for f in list(OCP_DIR_FIELDS) + list(OCP_SOL_FIELDS):
+                parity(g.get(f), o.get(f), lambda f=f: h.get(f), (it, f), cap=1e-8)
     e_o2, e_g2 = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert e_g2 < 1e-6 * e_g and abs(np.log10(e_g2 / e_o2)) < 1.0
 
 
-def chain_pair(dim, frame, batch=1):
+def chain_pair(dim, frame, batch=1, referee=False):
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=True)
     add_task(cost, frame, dim)
@@ -93,23 +95,29 @@ def chain_pair(dim, frame, batch=1):
     N, T, nimp = 31, 1.55, 2
     o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
     g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1)
-    q, v = start((o, g), m, seq=nimp)
-    o.init_constraints(0.0); g.init_constraints(0.0)
-    return m, o, g, q, v
+    solvers = [o, g]
+    h = None
+    if referee:
+        h = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=True)      # long double referee
+        solvers.append(h)
+    q, v = start(solvers, m, seq=nimp)
+    for s_ in solvers:
+        s_.init_constraints(0.0)
+    return (m, o, g, q, v, h) if referee else (m, o, g, q, v)
 
 
 @pytest.mark.parametrize("frame,dim", [("base", 6), ("LH_FOOT", 3)])
 def test_ocp_trotting_chain_with_impulse_and_terminal_weights(frame, dim):
-    m, o, g, q, v = chain_pair(dim, frame)
+    m, o, g, q, v, h = chain_pair(dim, frame, referee=True)
     M = len(o.chain(0.0))
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
     for it in range(3):
-        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
         for f in ("dq", "dv", "da", "df", "du", "dlmd", "dgmm", "dbeta", "dmu"):
-            assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, (it, f)
+            parity(g.get_chain(f, M), o.get_chain(f, M), lambda f=f: h.get_chain(f, M), (it, f), cap=1e-8)
     for f in ("q", "v", "a", "f", "u", "lmd", "gmm", "beta", "mu"):
-        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, f
+        parity(g.get_chain(f, M), o.get_chain(f, M), lambda f=f: h.get_chain(f, M), f, cap=1e-8)
 
 
 def test_ocp_line_search_cost():
@@ -135,13 +143,14 @@ def test_parnmpc_event_free_horizon_and_rejections():
     add_task(cost, "RH_THIGH", 6)
     set_reference(cost, m, np.array([-0.3, -0.1, 0.45]), (0.02, 0.0, 0.03))
     o, g = OracleParNMPC(m, cost, cons, 0.5, 20), HipParNMPC(m, cost, cons, 0.5, 20)
-    q, v = start((o, g), m)
-    o.init(0.0); g.init(0.0)
+    hp = OracleParNMPC(m, cost, cons, 0.5, 20, hp=True)                   # long double referee
+    q, v = start((o, g, hp), m)
+    o.init(0.0); g.init(0.0); hp.init(0.0)
     e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
     assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
-    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and hp.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
-        assert rel_err(g.get(f), o.get(f)) < 5e-9, f
+        parity(g.get(f), o.get(f), lambda f=f: hp.get(f), f, cap=5e-8)
     # not carried: a horizon with discrete events under ParNMPC, the TimeVarying variants on a floating base
     h = C.c_void_p()
     lib = capi.lib()
