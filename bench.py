@@ -1010,7 +1010,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kms[dom]),
-                         "whole_step_frac": a_stage * B * (N + 1) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         # the whole iteration's compulsory bytes over the whole step: one unit per stage of the CHAIN (event stages
+                         # included -- 120 for the default workload, not N + 1 = 101), i.e. the largest per-launch unit count
+                         "whole_step_frac": a_stage * max(units.values()) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_cpu_baseline and world == 1:              # a reported baseline: rank 0 of the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts, nimp=nimp)

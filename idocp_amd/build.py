@@ -19,6 +19,7 @@ LIBDIR = os.path.join(ROOT, "idocp_amd", "lib")
 OBJDIR = os.path.join(ROOT, "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+FLAGS += os.environ.get("IDOCP_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic builds, e.g. -DIDOCP_S3_STAMPS (per-phase clock stamps of S3)
 
 
 def _newer(target, deps):

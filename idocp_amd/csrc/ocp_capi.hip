@@ -573,6 +573,27 @@ int copyField(idocp_ocp* h, const double* base, size_t stride, size_t nrec, cons
 
 extern "C" {
 
+// the cost-dependent fields of the device problem block (idocp_ocp_create*, idocp_ocp_set_cost)
+static void fillCostFields(OcpProblem& p, const idocp_cost_t& cost) {
+  for (int i = 0; i < DQ::NV; ++i) {
+    p.v_ref[i] = cost.v_ref[i]; p.q_weight[i] = cost.q_weight[i]; p.v_weight[i] = cost.v_weight[i]; p.a_weight[i] = cost.a_weight[i];
+    p.qf_weight[i] = cost.qf_weight[i]; p.vf_weight[i] = cost.vf_weight[i];
+    p.qi_weight[i] = cost.qi_weight[i]; p.vi_weight[i] = cost.vi_weight[i]; p.dvi_weight[i] = cost.dvi_weight[i];
+  }
+  if (cost.use_trotting_ref) p.v_ref[0] = cost.step_length / cost.t_period;     // trotting_configuration_space_cost.cpp:81-83
+  for (int i = 0; i < DQ::NU; ++i) { p.u_ref[i] = cost.u_ref[i]; p.u_weight[i] = cost.u_weight[i]; }
+  for (int c = 0; c < DQ::NC; ++c)
+    for (int k = 0; k < 3; ++k) {
+      p.f_weight[c][k] = cost.f_weight[c][k]; p.f_ref[c][k] = cost.f_ref[c][k];
+      p.fi_weight[c][k] = cost.fi_weight[c][k]; p.fi_ref[c][k] = cost.fi_ref[c][k];
+    }
+  p.task_dim = cost.task_dim; p.task_joint = cost.task_joint;
+  for (int k = 0; k < 9; ++k) p.task_R[k] = cost.task_frame_R[k];
+  for (int k = 0; k < 3; ++k) p.task_p[k] = cost.task_frame_p[k];
+  for (int k = 0; k < 6; ++k) { p.task_weight[k] = cost.task_weight[k]; p.task_weightf[k] = cost.task_weightf[k]; p.task_weighti[k] = cost.task_weighti[k]; }
+  for (int k = 0; k < 12; ++k) p.task_ref[k] = cost.task_ref[k];
+}
+
 static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
                          int N, int max_num_impulse, int batch, int device, bool parnmpc, idocp_ocp_t** out) {
   if (!model || !cost || !constraints || !out) { set_last_error("idocp_ocp_create: null argument"); return IDOCP_E_ARG; }
@@ -702,33 +723,16 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   std::memset(&p, 0, sizeof(p));
   p.N = N; p.batch = batch; p.T = T; p.dt = T / N; p.NS = h->NS; p.E = max_num_impulse; p.backward_euler = parnmpc ? 1 : 0; p.has_terminal = 1; p.has_prev = 0;
   p.baumgarte_time_step = T / N;                           // hybrid_container.hpp:186-188
-  for (int i = 0; i < DQ::NV; ++i) {
-    p.v_ref[i] = cost->v_ref[i]; p.q_weight[i] = cost->q_weight[i]; p.v_weight[i] = cost->v_weight[i]; p.a_weight[i] = cost->a_weight[i];
-    p.qf_weight[i] = cost->qf_weight[i]; p.vf_weight[i] = cost->vf_weight[i];
-    p.qi_weight[i] = cost->qi_weight[i]; p.vi_weight[i] = cost->vi_weight[i]; p.dvi_weight[i] = cost->dvi_weight[i];
-  }
-  if (cost->use_trotting_ref) p.v_ref[0] = cost->step_length / cost->t_period;     // trotting_configuration_space_cost.cpp:81-83
-  for (int i = 0; i < DQ::NU; ++i) {
-    p.u_ref[i] = cost->u_ref[i]; p.u_weight[i] = cost->u_weight[i];
-    p.q_min[i] = model->q_min[i]; p.q_max[i] = model->q_max[i]; p.v_max[i] = model->v_max[i]; p.u_max[i] = model->u_max[i];
-  }
+  fillCostFields(p, *cost);
+  for (int i = 0; i < DQ::NU; ++i) { p.q_min[i] = model->q_min[i]; p.q_max[i] = model->q_max[i]; p.v_max[i] = model->v_max[i]; p.u_max[i] = model->u_max[i]; }
   for (int c = 0; c < DQ::NC; ++c) {
-    for (int k = 0; k < 3; ++k) {
-      p.f_weight[c][k] = cost->f_weight[c][k]; p.f_ref[c][k] = cost->f_ref[c][k];
-      p.fi_weight[c][k] = cost->fi_weight[c][k]; p.fi_ref[c][k] = cost->fi_ref[c][k];
-      p.contact_p[c][k] = model->contact_p[c][k];
-    }
+    for (int k = 0; k < 3; ++k) p.contact_p[c][k] = model->contact_p[c][k];
     std::memcpy(p.contact_R[c], model->contact_R[c], sizeof(double) * 9);
   }
   p.use_q_limits = constraints->joint_position_limits; p.use_v_limits = constraints->joint_velocity_limits;
   p.use_u_limits = constraints->joint_torque_limits;
   p.use_a_lower = constraints->joint_acceleration_lower_limit ? 1 : 0;
   p.use_contact_distance = constraints->contact_distance ? 1 : 0;
-  p.task_dim = cost->task_dim; p.task_joint = cost->task_joint;
-  for (int k = 0; k < 9; ++k) p.task_R[k] = cost->task_frame_R[k];
-  for (int k = 0; k < 3; ++k) p.task_p[k] = cost->task_frame_p[k];
-  for (int k = 0; k < 6; ++k) { p.task_weight[k] = cost->task_weight[k]; p.task_weightf[k] = cost->task_weightf[k]; p.task_weighti[k] = cost->task_weighti[k]; }
-  for (int k = 0; k < 12; ++k) p.task_ref[k] = cost->task_ref[k];
   p.use_a_upper = constraints->joint_acceleration_upper_limit ? 1 : 0;
   for (int r = 0; r < IDOCP_MAX_NV; ++r) { p.a_min[r] = constraints->a_min[r]; p.a_max[r] = constraints->a_max[r]; }
   p.use_friction_cone = (constraints->linearized_friction_cone || constraints->friction_cone) ? 1 : 0;
@@ -1619,24 +1623,21 @@ int idocp_parnmpc_halo_size(int kind) {
 }
 // d_buf[batch][halo_size(kind)] in device memory.  Importing kind 0 sets the state in front of the first stage (what the
 // *_device entry points otherwise take as d_q, d_v): use idocp_parnmpc_prev_state to get those pointers.
-int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf) {
+static int haloImpl(idocp_ocp_t* h, int kind, bool do_import, double* d_buf, bool sync) {
   if (!h || !h->parnmpc || !d_buf || idocp_parnmpc_halo_size(kind) < 0) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
-  OcpLaunch<DQ>::parnmpcHalo(h->B, h->batch, kind, false, d_buf, h->d_q0, h->d_v0, h->stream);
+  OcpLaunch<DQ>::parnmpcHalo(h->B, h->batch, kind, do_import, d_buf, h->d_q0, h->d_v0, h->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (sync) HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
 }
-int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf) {
-  if (!h || !h->parnmpc || !d_buf || idocp_parnmpc_halo_size(kind) < 0) return IDOCP_E_ARG;
-  int rc = setDev(h); if (rc) return rc;
-  if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
-  OcpLaunch<DQ>::parnmpcHalo(h->B, h->batch, kind, true, const_cast<double*>(d_buf), h->d_q0, h->d_v0, h->stream);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return IDOCP_OK;
-}
+int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf) { return haloImpl(h, kind, false, d_buf, true); }
+int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf) { return haloImpl(h, kind, true, const_cast<double*>(d_buf), true); }
+// the same pack / unpack kernels ENQUEUED on the handle's stream without waiting for them: what a stream-ordered transport needs
+// (idocp_amd/csrc/parnmpc_dist.hip: pack -> ncclSend, ncclRecv -> unpack, all on this stream)
+int idocp_parnmpc_export_halo_async(idocp_ocp_t* h, int kind, double* d_buf) { return haloImpl(h, kind, false, d_buf, false); }
+int idocp_parnmpc_import_halo_async(idocp_ocp_t* h, int kind, const double* d_buf) { return haloImpl(h, kind, true, const_cast<double*>(d_buf), false); }
 // device pointers of the state in front of the first stage, q[batch][nq], v[batch][nv] (rank 0 uploads the measured state
 // there; the other shards receive it through import_halo(0))
 int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v) {
@@ -1693,6 +1694,22 @@ int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv) {
 
 // Deep copy (the reference's solver classes are copyable, `= default`: ocp_solver.hpp:171-186): a new handle of the same
 // configuration whose device records, contact sequence and discretisation state equal the source's.
+// The reference's solvers hold a shared_ptr to the CostFunction (ocp_solver.hpp:37-39): weights and references a driver changes
+// between two updateSolution calls -- an MPC loop moving its goal -- take effect at the next call.  Here the cost was copied at
+// creation; this is the way to change it afterwards.  The KIND of cost must stay what it was (a task-space term cannot appear or
+// disappear: its record is allocated at creation).
+int idocp_ocp_set_cost(idocp_ocp_t* h, const idocp_cost_t* cost) {
+  if (!h || !cost) return IDOCP_E_ARG;
+  if ((cost->task_dim != 0) != (h->cost.task_dim != 0) || cost->task_time_varying != h->cost.task_time_varying) {
+    set_last_error("idocp_ocp_set_cost: a task-space cost cannot be added or removed after creation");
+    return IDOCP_E_UNSUPPORTED;
+  }
+  if (cost->task_dim != 0 && (cost->task_dim != 3 && cost->task_dim != 6)) { set_last_error("invalid value: task_dim must be 0, 3 or 6"); return IDOCP_E_ARG; }
+  h->cost = *cost;
+  fillCostFields(h->prob, *cost);
+  h->seq_dirty = true;              // the problem block and the per-stage reference table are uploaded with the next discretisation
+  return IDOCP_OK;
+}
 int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
   if (!src || !out) return IDOCP_E_ARG;
   int rc = setDev(src); if (rc) return rc;

@@ -14,6 +14,7 @@
 // P_{i+1} and the stage's LQR blocks resident in LDS (~52 kB -> three instances per CU).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
@@ -743,14 +744,15 @@ struct RiccatiRegSmem {
                        KT = HT + NU * LDH,        // [NU][LDH]  K, slot columns
                        RED = KT + NU * LDH,       // [3][64]    partial sums of the column contractions
                        VF = RED + 192, VT = VF + 48, LUH = VT + 48, KV = LUH + 16,      // Fx and t by slot, lu_hat, k
-                       PM = KV + 16,              // [48][LDP]  P of the stage, master entries (slot order)
+                       VS = KV + 16,              // [48]       s of the stage by slot (on its way to the ric record)
+                       PM = VS + 48,              // [48][LDP]  P of the stage, master entries (slot order)
                        PLAIN = PM + 48 * LDP;
   // scratch of a stage with a switching constraint, natural layouts of the round-2 code; it lives between the solve and the mirror,
   // when PM is dead, and extends behind it
   static constexpr int QXU = PM, QUU = QXU + NX * NU, LU = QUU + NU * NU, KM = LU + 16, KVN = KM + NU * NX, GW = KVN + 16,
                        DG = GW + NU * NU, SS = DG + NF * NU, DTM = SS + NF * NF, SDG = DTM + NU * NX, MV = SDG + NF * NU,
                        SCORR = MV + 16, MMX = SCORR + 48, GK = MMX + NF * NX, HYB = GK + NU * NX;
-  static constexpr int NTBL = OcpLayout<D>::R_SQ;                  // doubles of Pqq | Pqv | Pvv in the ric record
+  static constexpr int NTBL = OcpLayout<D>::R_SV + NV;             // doubles of Pqq | Pqv | Pvv | sq | sv in the ric record
   static constexpr size_t BYTES = (HYB > PLAIN ? HYB : PLAIN) * sizeof(double);
   static_assert(BYTES + 64 <= 40960, "four instances per CU");
 };
@@ -829,27 +831,45 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
   // PM offset of the doubles of Pqq | Pqv | Pvv (packed upper triangles, ric record order) this lane copies to the ric record -- pairs
   // e = lane + 64 t of consecutive doubles --: the orientation of the entry that a master tile wrote
   constexpr int N2 = S::NTBL / 2, NP = (N2 + 63) / 64;
-  static_assert(S::NTBL % 2 == 0, "pairs");
+  static_assert(S::NTBL % 2 == 0 && L::R_SQ % 2 == 0, "pairs");
   int pmOff[NP][2];
 #pragma unroll
   for (int t = 0; t < NP; ++t)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      int e = 2 * (lane + 64 * t) + hh;
-      if (e >= S::NTBL) e = S::NTBL - 1;
-      int r = 0, c = 0;
-      if (e < L::R_PQV) { int cc = 0; while ((cc + 1) * (cc + 2) / 2 <= e && cc < NV - 1) ++cc; c = cc; r = e - cc * (cc + 1) / 2; if (r > c) r = c; }
-      else if (e < L::R_PVV) { const int k = e - L::R_PQV; c = k / NV; r = k - c * NV; c += NV; }
-      else { const int k = e - L::R_PVV; int cc = 0; while ((cc + 1) * (cc + 2) / 2 <= k && cc < NV - 1) ++cc; c = cc; r = k - cc * (cc + 1) / 2; if (r > c) r = c; r += NV; c += NV; }
-      int i = SL::slot(r), j = SL::slot(c);
-      const int bi = i >> 4, bj = j >> 4;
-      const bool keep = bi == bj ? i <= j : ((bi == 0 && bj == 1) || bi == 2);
-      if (!keep) { const int tt = i; i = j; j = tt; }
-      pmOff[t][hh] = S::PM + LDP * i + j;
+      // (pairs beyond the record repeat its last pair: every lane stores, without a branch around the store -- see writeP)
+      const int e2 = lane + 64 * t < N2 ? lane + 64 * t : N2 - 1;
+      const int e = 2 * e2 + hh;
+      int off;
+      if (e >= L::R_SQ) {
+        off = S::VS + SL::slot(e - L::R_SQ);                       // sq | sv: natural index -> slot
+      } else {
+        int r = 0, c = 0;
+        if (e < L::R_PQV) { int cc = 0; while ((cc + 1) * (cc + 2) / 2 <= e && cc < NV - 1) ++cc; c = cc; r = e - cc * (cc + 1) / 2; if (r > c) r = c; }
+        else if (e < L::R_PVV) { const int k = e - L::R_PQV; c = k / NV; r = k - c * NV; c += NV; }
+        else { const int k = e - L::R_PVV; int cc = 0; while ((cc + 1) * (cc + 2) / 2 <= k && cc < NV - 1) ++cc; c = cc; r = k - cc * (cc + 1) / 2; if (r > c) r = c; r += NV; c += NV; }
+        int i = SL::slot(r), j = SL::slot(c);
+        const int bi = i >> 4, bj = j >> 4;
+        const bool keep = bi == bj ? i <= j : ((bi == 0 && bj == 1) || bi == 2);
+        if (!keep) { const int tt = i; i = j; j = tt; }
+        off = S::PM + LDP * i + j;
+      }
+      pmOff[t][hh] = off;
     }
   unsigned pmPk[NP];
 #pragma unroll
   for (int t = 0; t < NP; ++t) pmPk[t] = (unsigned)(8 * pmOff[t][0]) | ((unsigned)(8 * pmOff[t][1]) << 16);
+  // the gain record K | k (natural order, K column-major NU x NX) as pairs of consecutive doubles read from KT (slot columns) / KV
+  constexpr int G2 = (NU * NX + NU) / 2, NG = (G2 + 63) / 64;
+  static_assert(L::G_K == 0 && L::G_k == NU * NX && NU % 2 == 0 && 2 * G2 <= L::GAIN, "gain record: K | k");
+  unsigned gnPk[NG];
+#pragma unroll
+  for (int t = 0; t < NG; ++t) {
+    const int e2 = lane + 64 * t < G2 ? lane + 64 * t : G2 - 1, e = 2 * e2;
+    const int o0 = e < NU * NX ? S::KT + LDH * (e % NU) + SL::slot(e / NU) : S::KV + (e - NU * NX);
+    const int o1 = e < NU * NX ? o0 + LDH : o0 + 1;
+    gnPk[t] = (unsigned)(8 * o0) | ((unsigned)(8 * o1) << 16);
+  }
   auto ldsAt = [&](const double* b0, unsigned byteoff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(b0) + byteoff); };
   typedef mfma_d4 tile_t;
   tile_t Pt[3][3];       // P (slot order): [row block][column block]
@@ -873,9 +893,22 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       pv[t].x = ldsAt(sm, pk & 0xffffu); pv[t].y = ldsAt(sm, pk >> 16);
     }
   };
+  // (no branch around a store: lanes beyond the record repeat its last pair.  Behind a store inside a conditional block the compiler
+  // cannot count the stores that are in flight, and its next wait for a LOAD then waits for every store too)
   auto writeP = [&](double* __restrict__ rr) {
 #pragma unroll
-    for (int t = 0; t < NP; ++t) if (lane + 64 * t < N2) reinterpret_cast<rd2*>(rr)[lane + 64 * t] = pv[t];
+    for (int t = 0; t < NP; ++t) { const int e2 = lane + 64 * t < N2 ? lane + 64 * t : N2 - 1; reinterpret_cast<rd2*>(rr)[e2] = pv[t]; }
+  };
+  auto writeGain = [&](double* __restrict__ gg) {
+    rd2 gv[NG];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      unsigned pk = gnPk[t];
+      asm volatile("" : "+v"(pk));
+      gv[t].x = ldsAt(sm, pk & 0xffffu); gv[t].y = ldsAt(sm, pk >> 16);
+    }
+#pragma unroll
+    for (int t = 0; t < NG; ++t) { const int e2 = lane + 64 * t < G2 ? lane + 64 * t : G2 - 1; reinterpret_cast<rd2*>(gg)[e2] = gv[t]; }
   };
   // rebuild the nine tiles of P from the six masters (registers) and their mirror images (PM); entries outside the x slots are zero
   auto mirrorP = [&](const tile_t (&T)[6]) {
@@ -913,7 +946,8 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         const double v = kk[in ? L::K_QXX + L::xsym(ni, nj) : 0];
         T[t][q] = in ? st32(v) : 0.0;
       }
-    if (lane < NX) { s_reg = st32(-kk[L::K_LX + myNat]); rr[L::R_SQ + myNat] = s_reg; }
+    if (lane < NX) s_reg = st32(-kk[L::K_LX + myNat]);
+    if (lane < 48) sm[S::VS + lane] = s_reg;
     tilesToPM(T);
     waveLdsSync();
     mirrorP(T);
@@ -976,65 +1010,87 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
     const int dimi = HYBRID ? __builtin_amdgcn_readfirstlane(n_dimi) : 0;
     if (i > 0) { n_slot = nodes[i - 1].slot; n_dt = nodes[i - 1].dtq; if (HYBRID) n_dimi = nodes[i - 1].sw_dimi; }
     const bool constrained = HYBRID && dimi > 0;
+#ifdef IDOCP_S3_STAMPS      // (diagnostic build: a store inside a conditional block costs the memory-queue bookkeeping of the whole loop)
     const bool stamp = lane == 0 && b == (gridDim.x > 7 ? 7 : 0) && i == M / 2 && B.prof != nullptr;
 #define RSTAMP(k) do { if (stamp) B.prof[16 + k] = wall_clock64(); } while (0)
+    const bool cstamp = lane == 0 && b == (gridDim.x > 7 ? 7 : 0) && constrained && B.prof != nullptr;      // the constrained stages (the last one walked wins)
+#define CSTAMP(k) do { if (cstamp) B.prof[32 + k] = wall_clock64(); } while (0)
+#else
+#define RSTAMP(k) do { } while (0)
+#define CSTAMP(k) do { } while (0)
+#endif
     RSTAMP(0);
     double* __restrict__ rr = B.ric + rec * L::RIC;
     double* __restrict__ gg = B.gain + rec * L::GAIN;
     // ---- vector head: t = P Fx - s, lz_hat = [lx; lu] + C^T t (backward_riccati_recursion_factorizer.hxx:141-160 and the lu term) ----
     // y[j] = sum_i X[i][j] v[i] over tiles in accumulator layout: every lane multiplies its registers with the v of their rows and the
     // four lane groups add up through LDS
-    if (lane < 48) sm[S::VF + lane] = lane < NX ? fx : 0.0;
-    waveLdsSync();
-    double lzh = 0.0;
-    {
-      double part[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int q = 0; q < (a < 2 ? 4 : 1); ++q) {
-          const double f = sm[S::VF + 16 * a + 4 * q + g];
-#pragma unroll
-          for (int bb = 0; bb < 3; ++bb) part[bb] += Pt[a][bb][q] * f;
-        }
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) sm[S::RED + 64 * bb + lane] = part[bb];
-      waveLdsSync();
-      const int rb = S::RED + 64 * (lane < 48 ? (lane >> 4) : 0) + li;
-      const double y = (sm[rb] + sm[rb + 16]) + (sm[rb + 32] + sm[rb + 48]);
-      const double t = lane < NX ? y - s_reg : 0.0;
-      waveLdsSync();
-      if (lane < 48) sm[S::VT + lane] = t;
-      waveLdsSync();
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) part[bb] = 0.0;
-#pragma unroll
-      for (int d = 0; d < 6; ++d) {
-        const double tv = sm[S::VT + 16 * DC[d] + 4 * DS[d] + g];
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb) part[bb] += Cd[d][bb] * tv;
-      }
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) sm[S::RED + 64 * bb + lane] = part[bb];
-      waveLdsSync();
-      const double y2 = (sm[rb] + sm[rb + 16]) + (sm[rb + 32] + sm[rb + 48]);
-      // the structured rows: row qj_r of C is e(slot r) + dt e(slot 16 + r)
-      const double ts = sm[S::VT + (lane < 12 ? lane : (lane >= 16 && lane < 28 ? lane - 16 : 0))];
-      lzh = lz + y2 + (lane < 12 ? ts : (lane >= 16 && lane < 28 ? dt * ts : 0.0));
-    }
-    RSTAMP(1);
-    // ---- phase 1: Wt = P C (:48-78): nine tiles, six dense k-steps each, + the structured rows as lane-local adds ----
+    // The head is a chain of four LDS round trips with a handful of multiply-adds each; phase 1 -- Wt = P C (:48-78): nine tiles, six
+    // dense k-steps each -- needs nothing from it, so its k-steps are issued IN BETWEEN: the matrix core works through nine queued
+    // instructions (576 cycles) while the wavefront waits for LDS.
     tile_t Wt[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int bb = 0; bb < 3; ++bb) Wt[a][bb] = tile_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int d = 0; d < 6; ++d)
+    auto phase1 = [&](auto dtag) {
+      constexpr int d = decltype(dtag)::value;
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) Wt[a][bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[DC[d]][a][DS[d]], Cd[d][bb], Wt[a][bb], 0, 0, 0);
+    };
+    if (lane < 48) sm[S::VF + lane] = lane < NX ? fx : 0.0;
+    waveLdsSync();
+    double lzh = 0.0;
+    {
+      double part[3] = {0.0, 0.0, 0.0};
+      double fr[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < (a < 2 ? 4 : 1); ++q) fr[4 * a + q] = sm[S::VF + 16 * a + 4 * q + g];
+      phase1(std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < (a < 2 ? 4 : 1); ++q)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) part[bb] += Pt[a][bb][q] * fr[4 * a + q];
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) sm[S::RED + 64 * bb + lane] = part[bb];
+      waveLdsSync();
+      const int rb = S::RED + 64 * (lane < 48 ? (lane >> 4) : 0) + li;
+      const double r0 = sm[rb], r1 = sm[rb + 16], r2 = sm[rb + 32], r3 = sm[rb + 48];
+      phase1(std::integral_constant<int, 1>{});
+      const double y = (r0 + r1) + (r2 + r3);
+      const double t = lane < NX ? y - s_reg : 0.0;
+      waveLdsSync();
+      if (lane < 48) sm[S::VT + lane] = t;
+      waveLdsSync();
+      double tv[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) tv[d] = sm[S::VT + 16 * DC[d] + 4 * DS[d] + g];
+      // the structured rows: row qj_r of C is e(slot r) + dt e(slot 16 + r)
+      const double ts = sm[S::VT + (lane < 12 ? lane : (lane >= 16 && lane < 28 ? lane - 16 : 0))];
+      phase1(std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) part[bb] = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) part[bb] += Cd[d][bb] * tv[d];
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) sm[S::RED + 64 * bb + lane] = part[bb];
+      waveLdsSync();
+      const double u0 = sm[rb], u1 = sm[rb + 16], u2 = sm[rb + 32], u3 = sm[rb + 48];
+      phase1(std::integral_constant<int, 3>{});
+      const double y2 = (u0 + u1) + (u2 + u3);
+      lzh = lz + y2 + (lane < 12 ? ts : (lane >= 16 && lane < 28 ? dt * ts : 0.0));
+    }
+    RSTAMP(1);
+    phase1(std::integral_constant<int, 4>{});
+    phase1(std::integral_constant<int, 5>{});
     gatherQ();
     {
       const bool m12 = li < 12;
@@ -1048,14 +1104,29 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         }
     }
     RSTAMP(2);
-    // ---- phase 2: Qh = Q + C^T Wt (:79-113) on the six master tiles ----
+    // ---- phase 2: Qh = Q + C^T Wt (:79-113) on the six master tiles.  The rows of [H^T G] -- tiles (2, b) -- first: they go to the solve
+    //      through LDS while the matrix core works on the three tiles of F ----
     tile_t Qh[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) Qh[t] = Qc[t];
 #pragma unroll
     for (int d = 0; d < 6; ++d)
 #pragma unroll
-      for (int t = 0; t < 6; ++t) Qh[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cd[d][TA[t]], Wt[DC[d]][TB[t]][DS[d]], Qh[t], 0, 0, 0);
+      for (int t = 0; t < 3; ++t) Qh[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cd[d][TA[t]], Wt[DC[d]][TB[t]][DS[d]], Qh[t], 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int t = 3; t < 6; ++t) Qh[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cd[d][TA[t]], Wt[DC[d]][TB[t]][DS[d]], Qh[t], 0, 0, 0);
+    // ---- the rows of [H^T G] and lu_hat go to the solve ----
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+      for (int q = 1; q < 4; ++q) sm[S::HT + LDH * (4 * (q - 1) + g) + 16 * bb + li] = Qh[bb][q];
+    if (lane >= NX && lane < 48) sm[S::LUH + lane - NX] = lzh;
+#pragma unroll
+    for (int d = 2; d < 6; ++d)
+#pragma unroll
+      for (int t = 3; t < 6; ++t) Qh[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cd[d][TA[t]], Wt[DC[d]][TB[t]][DS[d]], Qh[t], 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       Qh[3][q] += Wt[0][0][q];                 // rows qj of tile (0, 0), (0, 1)
@@ -1063,12 +1134,6 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       Qh[5][q] += dt * Wt[0][1][q];            // rows vj of tile (1, 1)
     }
     RSTAMP(3);
-    // ---- the rows of [H^T G] and lu_hat go to the solve ----
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-      for (int q = 1; q < 4; ++q) sm[S::HT + LDH * (4 * (q - 1) + g) + 16 * bb + li] = Qh[bb][q];
-    if (lane >= NX && lane < 48) sm[S::LUH + lane - NX] = lzh;
     waveLdsSync();
     // the record of the next stage of the walk: its loads are in flight during the solve and phase 5
     if (i > 0) prefetch(B.kkt + (base + __builtin_amdgcn_readfirstlane(n_slot)) * L::KKT);
@@ -1084,25 +1149,23 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
 #pragma unroll
       for (int m = 0; m < NU; ++m) { x[m] = sm[xo + xs * m]; h[m] = x[m]; }
       choleskySolveRows<NU>(&sm[S::HT + NX], LDH, lane, &s_ok, x);         // G is symmetric: element (row, j) read as (j, row)
-      if (lane < NX) {
+      {
+        const int kc = lane < 48 ? lane : 47;              // (columns 36 .. 47 of KT are never read: no branch needed)
 #pragma unroll
-        for (int m = 0; m < NU; ++m) sm[S::KT + LDH * m + lane] = -x[m];
-        rd2* __restrict__ gp = reinterpret_cast<rd2*>(gg + L::G_K + NU * myNat);
-#pragma unroll
-        for (int m = 0; m < NU / 2; ++m) { rd2 v; v.x = -x[2 * m]; v.y = -x[2 * m + 1]; gp[m] = v; }
-      } else if (lane == NX) {
-        rd2* __restrict__ gp = reinterpret_cast<rd2*>(gg + L::G_k);
-#pragma unroll
-        for (int m = 0; m < NU / 2; ++m) { rd2 v; v.x = -x[2 * m]; v.y = -x[2 * m + 1]; gp[m] = v; sm[S::KV + 2 * m] = v.x; sm[S::KV + 2 * m + 1] = v.y; }
+        for (int m = 0; m < NU; ++m) sm[S::KT + LDH * m + kc] = -x[m];
       }
-      static_assert(NU % 2 == 0 && L::G_K % 2 == 0 && L::G_k % 2 == 0 && L::GAIN % 2 == 0, "16-byte stores of the gain record");
+      if (lane == NX) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) sm[S::KV + m] = -x[m];
+      }
       waveLdsSync();
       RSTAMP(10);
+      writeGain(gg);                                       // K, k: gathered from KT / KV into the natural order of the record
       // s = -lx_hat - H k (:141-160)
       double hk = 0.0;
 #pragma unroll
       for (int m = 0; m < NU; ++m) hk += h[m] * sm[S::KV + m];
-      if (lane < NX) { s_reg = st32(-lzh - hk); rr[L::R_SQ + myNat] = s_reg; }
+      s_reg = lane < NX ? st32(-lzh - hk) : 0.0;
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1121,6 +1184,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
     } else {
       // ---- stage with a switching constraint (split_riccati_factorizer.hxx:56-101): the Schur-complement step of the round-2 kernel
       //      on natural-layout copies in LDS ----
+      CSTAMP(0);
       double* Qxu = &sm[S::QXU];
       double* Quu = &sm[S::QUU];
       double* lu = &sm[S::LU];
@@ -1144,6 +1208,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         }
       }
       waveLdsSync();
+      CSTAMP(1);
       const double* __restrict__ W = B.swc + rec * L::SWC;
       const double* __restrict__ Phiu = W + L::W_PHIU;
       for (int e = lane; e < dimi * NU; e += 64) {                // DGinv = Phiu Ginv
@@ -1160,6 +1225,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         sm[S::SS + j + NF * c] = acc;
       }
       waveLdsSync();
+      CSTAMP(2);
       {
         // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves (llt_s_.solve, :64-66, 71-74), lane = column
         static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
@@ -1181,6 +1247,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         }
       }
       waveLdsSync();
+      CSTAMP(3);
       for (int e = lane; e < NU * NU; e += 64) {                  // Ginv -= SinvDGinv^T DGinv
         const int c = e / NU, r = e - c * NU;
         double acc = 0.0;
@@ -1209,6 +1276,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
           sm[S::KVN + j] = -acc;
         }
       }
+      CSTAMP(4);
       {
         // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu
         double* __restrict__ Ww = B.swc + rec * L::SWC;
@@ -1228,6 +1296,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         }
       }
       waveLdsSync();
+      CSTAMP(5);
       for (int e = lane; e < NU * NX; e += 64) {                  // DtM = Phiu^T M (:88)
         const int c = e / NU, m = e - c * NU;
         double acc = 0.0;
@@ -1240,6 +1309,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         sm[S::SCORR + lane] = acc;
       }
       waveLdsSync();
+      CSTAMP(6);
       riccatiPhase4<D, true, 0, 3>(Quu, &sm[S::KM], &sm[S::GK], lane);     // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
       waveLdsSync();
       RSTAMP(10);
@@ -1252,9 +1322,9 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
 #pragma unroll
         for (int m = 0; m < NU; ++m) hk += Qxu[myNat + NX * m] * sm[S::KVN + m];
         s_reg = st32(-lzh - hk - sm[S::SCORR + myNat]);
-        rr[L::R_SQ + myNat] = s_reg;
       }
       RSTAMP(4);
+      CSTAMP(7);
       // ---- phase 5: P = F - K^T (G K) - K^T DtM - DtM^T K (:122-131, split_riccati_factorizer.hxx:88-97): [K; DtM]^T [G K + DtM; K] ----
       double Gr[3][3], Dr[3][3];
 #pragma unroll
@@ -1281,6 +1351,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         }
     }
     RSTAMP(5);
+    CSTAMP(8);
     if (p32) {
 #pragma unroll
       for (int t = 0; t < 6; ++t)
@@ -1290,6 +1361,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
     // ---- P stays EXACTLY symmetric: master entries (upper triangle in slot order) and their mirror images through LDS.  This replaces
     //      the reference's P = (P + P^T) / 2 (:133-135); an antisymmetric rounding residue grows 2.9 x per stage otherwise. ----
     waveLdsSync();                  // (every read of the constrained stage's scratch, which PM overlays, is done)
+    if (lane < 48) sm[S::VS + lane] = s_reg;
     tilesToPM(Pn);
     waveLdsSync();
     mirrorP(Pn);
@@ -1299,7 +1371,9 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
     if (i > 0) stageIn();             // the next record: registers -> LDS (over PM) -> accumulator layout
     writeP(rr);
     RSTAMP(8);
+    CSTAMP(15);
 #undef RSTAMP
+#undef CSTAMP
   }
   if (lane == 0 && !s_ok && B.status[b] == 0) B.status[b] = 1;
 }

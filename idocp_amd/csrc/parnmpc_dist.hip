@@ -197,8 +197,8 @@ int exchangeBoundary(idocp_ocp_t* h, DistState& s) {
   const int rank = s.comm->rank, world = s.comm->world;
   if (world == 1) return IDOCP_OK;
   const bool left = rank > 0, right = rank < world - 1;
-  if (right) RC(idocp_parnmpc_export_halo(h, STATE_LAST, s.sendb[STATE_LAST]));
-  if (left) { RC(idocp_parnmpc_export_halo(h, COSTATE_FIRST, s.sendb[COSTATE_FIRST])); RC(idocp_parnmpc_export_halo(h, AUX_FIRST, s.sendb[AUX_FIRST])); }
+  if (right) RC(idocp_parnmpc_export_halo_async(h, STATE_LAST, s.sendb[STATE_LAST]));
+  if (left) { RC(idocp_parnmpc_export_halo_async(h, COSTATE_FIRST, s.sendb[COSTATE_FIRST])); RC(idocp_parnmpc_export_halo_async(h, AUX_FIRST, s.sendb[AUX_FIRST])); }
   RC(xgrouped(s, [&]() -> int {
     if (s.comm->nccl) {
       if (right) RC(xsend(s, STATE_LAST, rank + 1));
@@ -213,8 +213,8 @@ int exchangeBoundary(idocp_ocp_t* h, DistState& s) {
     }
     return IDOCP_OK;
   }));
-  if (left) RC(idocp_parnmpc_import_halo(h, STATE_LAST, s.recvb[STATE_LAST]));
-  if (right) { RC(idocp_parnmpc_import_halo(h, COSTATE_FIRST, s.recvb[COSTATE_FIRST])); RC(idocp_parnmpc_import_halo(h, AUX_FIRST, s.recvb[AUX_FIRST])); }
+  if (left) RC(idocp_parnmpc_import_halo_async(h, STATE_LAST, s.recvb[STATE_LAST]));
+  if (right) { RC(idocp_parnmpc_import_halo_async(h, COSTATE_FIRST, s.recvb[COSTATE_FIRST])); RC(idocp_parnmpc_import_halo_async(h, AUX_FIRST, s.recvb[AUX_FIRST])); }
   return IDOCP_OK;
 }
 
@@ -393,9 +393,9 @@ int idocp_parnmpc_dist_init_backward_correction(idocp_ocp_t* h, double t) {
   if (!s) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
   RC(idocp_parnmpc_init_backward_correction(h, t));
   if (s->comm->world == 1 && !(s->comm->nccl && s->comm->force_collectives)) return IDOCP_OK;
-  RC(idocp_parnmpc_export_halo(h, AUX_ALL, s->sendb[AUX_ALL]));
+  RC(idocp_parnmpc_export_halo_async(h, AUX_ALL, s->sendb[AUX_ALL]));
   RC(xbroadcast(*s, AUX_ALL, s->comm->world - 1));
-  RC(idocp_parnmpc_import_halo(h, AUX_ALL, s->recvb[AUX_ALL]));
+  RC(idocp_parnmpc_import_halo_async(h, AUX_ALL, s->recvb[AUX_ALL]));
   return IDOCP_OK;
 }
 
@@ -410,13 +410,13 @@ int idocp_parnmpc_dist_update_solution(idocp_ocp_t* h, double t) {
   RC(idocp_parnmpc_discretize(h, t));
   RC(exchangeBoundary(h, s));
   RC(phases(h, s, {0, 1, 2}));                                   // linearise, condense, KKT inverse + coarse update
-  if (right) { RC(xrecv(s, BWD_FIRST, rank + 1)); RC(idocp_parnmpc_import_halo(h, BWD_FIRST, s.recvb[BWD_FIRST])); }
+  if (right) { RC(xrecv(s, BWD_FIRST, rank + 1)); RC(idocp_parnmpc_import_halo_async(h, BWD_FIRST, s.recvb[BWD_FIRST])); }
   RC(phases(h, s, {3}));                                         // backward serial sweep, right -> left across the ranks
-  if (left) { RC(idocp_parnmpc_export_halo(h, BWD_FIRST, s.sendb[BWD_FIRST])); RC(xsend(s, BWD_FIRST, rank - 1)); }
+  if (left) { RC(idocp_parnmpc_export_halo_async(h, BWD_FIRST, s.sendb[BWD_FIRST])); RC(xsend(s, BWD_FIRST, rank - 1)); }
   RC(phases(h, s, {4}));                                         // backward parallel: overlaps the left neighbours' serial sweeps
-  if (left) { RC(xrecv(s, FWD_LAST, rank - 1)); RC(idocp_parnmpc_import_halo(h, FWD_LAST, s.recvb[FWD_LAST])); }
+  if (left) { RC(xrecv(s, FWD_LAST, rank - 1)); RC(idocp_parnmpc_import_halo_async(h, FWD_LAST, s.recvb[FWD_LAST])); }
   RC(phases(h, s, {5}));                                         // forward serial sweep, left -> right
-  if (right) { RC(idocp_parnmpc_export_halo(h, FWD_LAST, s.sendb[FWD_LAST])); RC(xsend(s, FWD_LAST, rank + 1)); }
+  if (right) { RC(idocp_parnmpc_export_halo_async(h, FWD_LAST, s.sendb[FWD_LAST])); RC(xsend(s, FWD_LAST, rank + 1)); }
   RC(phases(h, s, {6, 7, 8}));                                   // forward parallel, expansion, local step sizes
   RC(xallreduce(s, s.d_steps, (size_t)s.batch * 2, 1));          // min over the horizon
   RC(phases(h, s, {9}));                                         // dual expansion + integration

@@ -591,6 +591,15 @@ class HipParNMPC(HipOCP):
         cm = arr(np.asarray(mats).transpose(0, 2, 1))      # column-major per stage
         capi.check(self.lib.idocp_parnmpc_set_aux_mat(self.h, cm.shape[0], P(cm)), "set_aux_mat")
 
+    def set_chain_values(self, name, values):
+        """warm start along the CHAIN of the current discretisation (event stages included): values[M, dim]"""
+        values = arr(values)
+        capi.check(self.lib.idocp_ocp_set_solution_chain(self.h, name.encode(), values.shape[0], P(values)), "set_solution_chain " + name)
+
+    def set_chain_aux_mats(self, mats):
+        cm = arr(np.asarray(mats).transpose(0, 2, 1))
+        capi.check(self.lib.idocp_parnmpc_set_aux_mat_chain(self.h, cm.shape[0], P(cm)), "set_aux_mat_chain")
+
     def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
         self.lib = capi.lib()
         self.N, self.nv, self.nu, self.nq, self.batch = N, model.nv, model.nu, model.nq, batch
@@ -643,3 +652,47 @@ def warm_start_parnmpc(ocp, targets, N):
         for f, v in vals.items():
             t.set_stage_values(f, v)
         t.set_aux_mats(aux)
+
+
+def map_ocp_onto_parnmpc_chain(co, cp, sol, Pm):
+    """Warm start of ParNMPC on a horizon WITH discrete events from the converged OCPSolver solution of the same problem (the state an
+    MPC loop that switches solvers is in).  co / cp: the chains of the OCP (forward Euler: stage, [impulse, aux | lift], stage, ...,
+    terminal) and of ParNMPC (backward Euler: [aux, impulse | lift] IN FRONT of the grid stage behind the event; without its
+    placeholder); sol: the OCP's solution fields along its chain; Pm: its Riccati matrices P along the chain.  Node by node in time:
+    ParNMPC's aux stage (state just before the impulse) <- the OCP's impulse stage, its impulse stage (state just after) <- the OCP's
+    aux stage with dv, f, beta, mu of the OCP's impulse stage, a lift stage <- the lift stage, a grid stage <- the OCP node at (or
+    right behind) the same time; (a, u, f, beta, mu) from an OCP node with the same number of active feet; aux_mat = P of the state's
+    node.  Returns (values: dict field -> [Mp, dim], aux: [Mp, nx, nx])."""
+    def times(ch, backward):
+        t, out = 0.0, []
+        for c in ch:
+            d = 0.0 if c["kind"] == "impulse" else c["dt"]
+            if backward:
+                t += d; out.append(t)
+            else:
+                out.append(t); t += d
+        return np.array(out)
+    Mo = len(co)
+    to, tp = times(co, False), times(cp, True)
+    idx = {(c["kind"], c["index"]): p for p, c in enumerate(co)}
+    state_src, dyn_src = [], []
+    for p, c in enumerate(cp):
+        k = c["kind"]
+        if k == "aux":
+            s_ = idx[("impulse", c["index"])]; d_ = max(s_ - 1, 0)
+        elif k == "impulse":
+            s_ = idx[("aux", c["index"])]; d_ = idx[("impulse", c["index"])]
+        elif k == "lift":
+            s_ = idx[("lift", c["index"])]; d_ = s_
+        else:
+            cand = [pp for pp, cc in enumerate(co) if cc["kind"] in ("stage", "aux", "lift", "terminal") and to[pp] >= tp[p] - 1e-9]
+            s_ = cand[0] if cand else Mo - 1
+            d_ = min(s_, Mo - 2)
+            while co[d_]["dimf"] != c["dimf"] or co[d_]["kind"] == "impulse":
+                d_ -= 1
+        state_src.append(s_); dyn_src.append(d_)
+    vals = {f: np.stack([sol[f][s_] for s_ in state_src]) for f in ("q", "v", "lmd", "gmm")}
+    for f in ("a", "u", "f", "beta", "mu"):
+        vals[f] = np.stack([sol[f][d_] for d_ in dyn_src])
+    aux = np.stack([Pm[s_] for s_ in state_src])
+    return vals, aux

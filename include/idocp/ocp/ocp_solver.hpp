@@ -14,6 +14,7 @@
 #define IDOCP_OCP_SOLVER_HPP_
 
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -33,7 +34,7 @@ class OCPSolver {
  public:
   OCPSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
             const double T, const int N, const int max_num_impulse = 0, const int nthreads = 1, const int device = 0)
-      : robot_(robot), N_(N), h_(nullptr) {
+      : robot_(robot), N_(N), h_(nullptr), cost_(cost) {
     (void)nthreads;
     if (max_num_impulse < 0) {      // ocp_solver.cpp:34-36
       std::cerr << "invalid value: max_num_impulse must be non-negative!" << '\n';
@@ -42,6 +43,7 @@ class OCPSolver {
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
     check(idocp_ocp_create_hybrid(&robot.model(), &c, &k, T, N, max_num_impulse, 1, device, &h_));
+    last_cost_ = c;
     cache_.resize(N + 1);
   }
   // ocp_solver.hpp:44: an empty solver, to be assigned a constructed one before use
@@ -49,20 +51,21 @@ class OCPSolver {
   ~OCPSolver() { idocp_ocp_destroy(h_); }
   // copyable and movable like the reference class (ocp_solver.hpp:171-186, `= default`): a copy is a DEEP copy of the solver
   // state on the device (idocp_ocp_clone)
-  OCPSolver(const OCPSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_) { if (other.h_) check(idocp_ocp_clone(other.h_, &h_)); }
+  OCPSolver(const OCPSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cost_(other.cost_), last_cost_(other.last_cost_), cache_(other.cache_) { if (other.h_) check(idocp_ocp_clone(other.h_, &h_)); }
   OCPSolver& operator=(const OCPSolver& other) {
-    if (this != &other) { idocp_ocp_t* n = nullptr; if (other.h_) check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_; }
+    if (this != &other) { idocp_ocp_t* n = nullptr; if (other.h_) check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_; cost_ = other.cost_; last_cost_ = other.last_cost_; }
     return *this;
   }
-  OCPSolver(OCPSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
+  OCPSolver(OCPSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cost_(std::move(other.cost_)), last_cost_(other.last_cost_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
   OCPSolver& operator=(OCPSolver&& other) noexcept {
-    if (this != &other) { idocp_ocp_destroy(h_); h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; N_ = other.N_; cache_ = std::move(other.cache_); }
+    if (this != &other) { idocp_ocp_destroy(h_); h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; N_ = other.N_; cache_ = std::move(other.cache_); cost_ = std::move(other.cost_); last_cost_ = other.last_cost_; }
     return *this;
   }
 
   void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    syncCost();
     check(idocp_ocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
 
@@ -134,6 +137,7 @@ class OCPSolver {
     return e;
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    syncCost();
     check(idocp_ocp_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
   idocp_ocp_t* handle() { return h_; }
@@ -143,6 +147,15 @@ class OCPSolver {
   Robot robot_;
   int N_;
   idocp_ocp_t* h_;
+  // The reference's solver SHARES the cost function with the driver (ocp_solver.hpp:37-39): a reference or weight the driver changes
+  // between two calls takes effect at the next one.  The device holds a copy; it is refreshed when the shared object has changed.
+  std::shared_ptr<CostFunction> cost_;
+  idocp_cost_t last_cost_{};
+  void syncCost() {
+    if (!cost_) return;
+    const idocp_cost_t c = cost_->native();
+    if (std::memcmp(&c, &last_cost_, sizeof(c)) != 0) { check(idocp_ocp_set_cost(h_, &c)); last_cost_ = c; }
+  }
   mutable std::vector<SplitSolution> cache_;
   int dimOf(const std::string& name) const {
     if (name == "q") return robot_.dimq();

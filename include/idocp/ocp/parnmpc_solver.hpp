@@ -10,6 +10,7 @@
 #define IDOCP_PARNMPC_SOLVER_HPP_
 
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <string>

@@ -538,6 +538,10 @@ int idocp_parnmpc_create_hybrid_shard(const idocp_model_t* model, const idocp_co
 int idocp_parnmpc_halo_size(int kind);
 int idocp_parnmpc_export_halo(idocp_ocp_t* h, int kind, double* d_buf);
 int idocp_parnmpc_import_halo(idocp_ocp_t* h, int kind, const double* d_buf);
+/* The same pack / unpack kernels enqueued on the handle's stream WITHOUT the host waiting for them: for a
+ * stream-ordered transport (the C++ driver below: pack -> ncclSend, ncclRecv -> unpack on one stream). */
+int idocp_parnmpc_export_halo_async(idocp_ocp_t* h, int kind, double* d_buf);
+int idocp_parnmpc_import_halo_async(idocp_ocp_t* h, int kind, const double* d_buf);
 /* ---- multi-GPU driver of the sharded horizon, in C++ over RCCL (idocp_amd/csrc/parnmpc_dist.hip) ------------------------
  * Counterpart of BackwardCorrectionSolver (src/ocp/backward_correction_solver.cpp:255-366) for one process per GPU: every rank
  * creates its shard (idocp_parnmpc_create_shard / _create_hybrid_shard), a communicator, attaches one to the other and then calls
@@ -579,6 +583,12 @@ int idocp_parnmpc_dist_transport_selftest(idocp_ocp_t* shard, double* max_abs_di
 /* Deep copy of a solver handle (the reference's solver classes are copyable): same configuration, device records, contact
  * sequence and discretisation. */
 int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out);
+/* Replace the cost of a solver (OCPSolver / ParNMPCSolver handles).  The reference's solvers share the
+ * CostFunction with the driver (ocp_solver.hpp:37-39: shared_ptr), so references and weights changed
+ * between two updateSolution calls take effect at the next one; here the cost is copied at creation and
+ * this call is how an MPC loop moves its goal.  A task-space cost cannot be added or removed
+ * (IDOCP_E_UNSUPPORTED).  Takes effect with the next call that discretises the horizon. */
+int idocp_ocp_set_cost(idocp_ocp_t* h, const idocp_cost_t* cost);
 /* Device pointers of the state in front of the first stage (q[batch][nq], v[batch][nv]) and of
  * the step sizes ([batch][2]: primal, dual) -- the latter is all-reduced (min) between phases 8 and 9. */
 int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v);

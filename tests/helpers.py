@@ -528,6 +528,19 @@ class OracleParNMPC:
         for i, mth in enumerate(np.asarray(mats)):
             assert self.lib.oracle_parnmpc_set_aux_mat(self.h, i, P(arr(np.asarray(mth).T))) == 0
 
+    def set_chain_values(self, name, values):
+        """warm start along the chain of the current discretisation: entry p goes to the slot of chain position p"""
+        self.lib.oracle_parnmpc_set_stage.argtypes = [C.c_void_p, C.c_int, C.c_char_p, dp]
+        ch = self.chain(0.0)
+        for c, v in zip(ch, np.asarray(values)):
+            assert self.lib.oracle_parnmpc_set_stage(self.h, c["slot"], name.encode(), P(arr(v))) == 0
+
+    def set_chain_aux_mats(self, mats):
+        self.lib.oracle_parnmpc_set_aux_mat.argtypes = [C.c_void_p, C.c_int, dp]
+        ch = self.chain(0.0)
+        for c, mth in zip(ch, np.asarray(mats)):
+            assert self.lib.oracle_parnmpc_set_aux_mat(self.h, c["slot"], P(arr(np.asarray(mth).T))) == 0
+
     def init(self, t=0.0):                      # initBackwardCorrection(t) + initConstraints(t)
         self.lib.oracle_parnmpc_init(self.h, t)
 

@@ -108,6 +108,34 @@ def test_bench_parnmpc_gpus2_plumbing_on_gloo():
     assert out["config"]["parallelism"] == "horizon shards x2"
 
 
+def test_bench_parnmpc_gpus4_plumbing_on_gloo():
+    """The same with FOUR ranks (what the driver's scaling run does next: N = 1, 2, 4, 8): every rank past 0 receives the id, the
+    horizon splits into 64 stages per rank, one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IDOCP_BENCH_STUB="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "anymal_parnmpc", "--gpus", "4", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong" and out["config"]["stages_per_rank"] == 64
+    assert out["config"]["parallelism"] == "horizon shards x4"
+
+
+def test_bench_replicas_gpus4_on_gloo():
+    """`python bench.py --gpus 4` on the default (replica) workload: four ranks, one line, whole-job value = 4 x per-rank batches."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IDOCP_BENCH_STUB="1", IDOCP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["scaling"] == "weak"
+
+
 def test_unique_id_exchange_is_a_no_op_on_one_rank():
     sys.path.insert(0, ROOT)
     import bench

@@ -136,23 +136,28 @@ def test_two_shards_on_one_gpu_equal_the_whole_horizon():
     assert abs(np.sqrt(e2) - g.kkt_error(0.0, q, v)[0]) < 1e-9 * max(1.0, np.sqrt(e2))
 
 
-def test_cxx_sharded_driver_equals_the_whole_horizon():
+@pytest.mark.parametrize("N,T,world,iters", [(20, 0.5, 2, 4), (256, 12.8, 4, 2), (256, 12.8, 8, 2)], ids=["N20-2shards", "N256-4shards", "N256-8shards"])
+def test_cxx_sharded_driver_equals_the_whole_horizon(N, T, world, iters):
     """The multi-GPU driver of the product (idocp_amd/csrc/parnmpc_dist.hip: idocp_parnmpc_dist_*, RCCL point-to-point halos +
-    all-reduces enqueued on the shard's stream) exercised on ONE GPU: two shard handles of 10 stages, one host thread per
-    endpoint, connected by the in-process transport (idocp_comm_init_local) -- the same driver code, only send / recv differ.
-    Against one handle of 20 stages over four iterations, and the whole-horizon KKT error."""
+    all-reduces enqueued on the shard's stream) exercised on ONE GPU: `world` shard handles of N / world stages, one host thread
+    per endpoint, connected by the in-process transport (idocp_comm_init_local) -- the same driver code, only send / recv differ.
+    Against one handle of N stages, iteration by iteration, and the whole-horizon KKT error: the shards run the same kernels on the
+    same numbers, so they must reproduce the single handle to rounding (1e-12 of every stage's own entries) -- at BASELINE configs[3]'s
+    own size with 4 and 8 shards (the pipeline order of the two serial sweeps across MORE than two ranks, which two shards cannot
+    show: a middle rank receives, sweeps and sends)."""
     import ctypes as C
     import threading
     from helpers import P, arr
     from idocp_amd import capi
     from idocp_amd.parnmpc_dist import HipParNMPCShard
-    m, o, g, q, v = make_pair(20, 0.5)
+    m, o, g, q, v = make_pair(N, T)
     cost, cons = anymal_problem(m, trotting_ref=False)
     pts = anymal_contact_points(m)
     lib = capi.lib()
-    shards = [HipParNMPCShard(m, cost, cons, 0.5, 20, r, 2, 1, 0) for r in range(2)]
-    comms = (C.c_void_p * 2)()
-    capi.check(lib.idocp_comm_init_local(2, 0, comms), "comm_init_local")
+    Nl = N // world
+    shards = [HipParNMPCShard(m, cost, cons, T, N, r, world, 1, 0) for r in range(world)]
+    comms = (C.c_void_p * world)()
+    capi.check(lib.idocp_comm_init_local(world, 0, comms), "comm_init_local")
     for r, sh in enumerate(shards):
         a = (C.c_int * 4)(1, 1, 1, 1)
         capi.check(lib.idocp_ocp_set_contact_status_uniformly(sh.h, a, P(arr(pts))))
@@ -161,7 +166,7 @@ def test_cxx_sharded_driver_equals_the_whole_horizon():
         capi.check(lib.idocp_ocp_set_solution(sh.h, b"f", P(arr([0, 0, 0.25 * (-m.total_mass * m.gravity[2])]))))
         capi.check(lib.idocp_parnmpc_dist_attach(sh.h, comms[r]), "attach")
     capi.check(lib.idocp_parnmpc_dist_set_initial_state(shards[0].h, P(arr(q[None, :])), P(arr(v[None, :])), m.nq, m.nv))
-    errors, kkt = [], [np.zeros(1), np.zeros(1)]
+    errors, kkt = [], [np.zeros(1) for _ in range(world)]
 
     def collective(fn):
         """call fn(rank) on one thread per endpoint (ctypes drops the GIL inside the library)"""
@@ -170,33 +175,41 @@ def test_cxx_sharded_driver_equals_the_whole_horizon():
                 fn(r)
             except Exception as e:      # noqa: BLE001
                 errors.append((r, e))
-        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         for t in ts:
             t.start()
         for t in ts:
-            t.join(timeout=120)
+            t.join(timeout=300)
         assert not errors, errors
+        assert not any(t.is_alive() for t in ts), "a rank of the sharded driver hangs (pipeline order of the sweeps?)"
 
     collective(lambda r: capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shards[r].h, 0.0), "init"))
     for sh in shards:
         capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
 
     def get(sh, name, dim):
-        out = np.zeros((10, dim))
+        out = np.zeros((Nl, dim))
         capi.check(lib.idocp_ocp_get_solution(sh.h, name.encode(), 0, P(out)))
         return out
 
-    for it in range(4):
+    compared = 0
+    for it in range(iters):
         assert g.update(0.0, q, v) == 0
         collective(lambda r: capi.check(lib.idocp_parnmpc_dist_update_solution(shards[r].h, 0.0), "update"))
         for sh in shards:
             capi.check(lib.idocp_ocp_synchronize(sh.h))
+        whole = {name: g.get(name) for name in ("q", "v", "u", "lmd", "a", "f")}
+        if not all(np.isfinite(x).all() for x in whole.values()):
+            break                                      # (the cold start of N = 256 overflows after a few undamped iterations: nothing left to compare)
         for name, dim in (("q", 19), ("v", 18), ("u", 12), ("lmd", 18), ("a", 18), ("f", 12)):
-            both = np.concatenate([get(shards[0], name, dim), get(shards[1], name, dim)])
-            assert rel_err(both, g.get(name)) < 1e-9, (it, name)
-    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_kkt_error(shards[r].h, 0.0, P(kkt[r])), "kkt"))
+            both = np.concatenate([get(sh, name, dim) for sh in shards])
+            assert rel_err(both, whole[name]) < 1e-12, (it, name, rel_err(both, whole[name]))
+        compared += 1
+    assert compared >= 1
     e_g = g.kkt_error(0.0, q, v)[0]
-    assert abs(kkt[0][0] - e_g) < 1e-9 * max(1.0, e_g) and kkt[0][0] == kkt[1][0]
+    if np.isfinite(e_g):
+        collective(lambda r: capi.check(lib.idocp_parnmpc_dist_kkt_error(shards[r].h, 0.0, P(kkt[r])), "kkt"))
+        assert abs(kkt[0][0] - e_g) < 1e-9 * max(1.0, e_g) and all(kkt[r][0] == kkt[0][0] for r in range(world))
     for r, sh in enumerate(shards):
         capi.check(lib.idocp_parnmpc_dist_detach(sh.h))
         lib.idocp_comm_destroy(comms[r])

@@ -285,3 +285,84 @@ def test_chain_warm_start_setters_reach_the_event_stages():
     assert g.lib.idocp_parnmpc_set_aux_mat_chain(g.h, M, P(aux)) == 0
     assert g.lib.idocp_parnmpc_set_aux_mat_chain(g.h, M + 5, P(aux)) != 0           # longer than the chain
     assert g.lib.idocp_ocp_set_solution_chain(g.h, b"nonsense", M, P(aux)) != 0
+
+
+def test_configs3_trotting_n256_chain_direction_and_iterates():
+    """BASELINE.json configs[3] AS WORDED -- ANYmal TROTTING ParNMPCSolver, N = 256 (T = 12.8, the contact sequence of
+    examples/anymal/anymal_trotting.cpp over the whole horizon: 1 lift + 24 touch-down events a quarter of a time step off the grid,
+    305 stages in the chain) -- at its own size, against the oracle: (i) the chain of the discretiser; (ii) the KKT error and the first
+    Newton direction from the chain warm start of an MPC loop that switches solvers (the converged OCPSolver solution of the SAME
+    trotting problem, mapped node by node: workloads.map_ocp_onto_parnmpc_chain; from the reference's cold start the correction sweeps
+    of a 305-stage chain produce a direction of 1e12 that no tolerance is meaningful on) under the long double referee, capped against
+    the FP64 oracle; (iii) the next iterates side by side for as long as both stay finite (ParNMPC has no globalisation and leaves the
+    basin of this forward-Euler warm start after a few steps -- in the oracle exactly as on the GPU)."""
+    from helpers import HipOCP, P, map_ocp_onto_parnmpc_chain, referee_check, trotting_sequence
+    N = 256
+    T = 0.05 * N
+    n_events = int((T - 0.5125) / 0.5) + 1
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    solvers = [OracleParNMPC(m, cost, cons, T, N, max_num_impulse=n_events), HipParNMPC(m, cost, cons, T, N, batch=2, max_num_impulse=n_events),
+               OracleParNMPC(m, cost, cons, T, N, max_num_impulse=n_events, hp=True)]
+    o, g, h = solvers
+    ocp = HipOCP(m, cost, cons, T, N, batch=1, max_num_impulse=n_events)
+    for s in solvers + [ocp]:
+        trotting_sequence(s, m, n_events - 1, t_start=0.5125)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    for s in solvers:
+        s.init(0.0)
+    # (i) the chain
+    M = check_chain(o, g)
+    kinds = "".join(c["kind"][0] for c in o.chain(0.0))
+    assert M == N + 1 + 2 * (n_events - 1) and kinds.count("l") == 1 and kinds.count("a") == kinds.count("i") == n_events - 1, (M, kinds)
+    # the warm start: OCPSolver on the same problem, converged on the GPU
+    ocp.init_constraints(0.0)
+    for it in range(80):
+        assert ocp.update(0.0, q, v) == 0
+        if it > 20 and ocp.kkt_error(0.0, q, v)[0] < 1e-8:
+            break
+    assert ocp.kkt_error(0.0, q, v)[0] < 1e-8
+    co = ocp.chain(0.0)
+    Mo = len(co)
+    sol = {f: ocp.get_chain(f, Mo) for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu")}
+    vals, aux = map_ocp_onto_parnmpc_chain(co, o.chain(0.0), sol, ocp.riccati_chain(Mo)[0])
+    for s in solvers:
+        for f, x in vals.items():
+            s.set_chain_values(f, x)
+        s.set_chain_aux_mats(aux)
+        s.init_constraints(0.0)
+    # (ii) KKT error and first direction
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) <= 1e-9 * max(1.0, e_o) and e_g[0] == e_g[1], (e_g, e_o)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
+    worst = 0.0
+    for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+        keep = np.array([c["kind"] != "impulse" for c in o.chain(0.0)]) if f in NOT_ON_IMPULSE else np.ones(M, bool)
+        d_g, d_o, d_h = g.get_chain(f, M + 1)[:M][keep], o.get_chain(f, M)[keep], h.get_chain(f, M)[keep]
+        assert np.isfinite(d_g).all() and np.abs(d_o).max() < 1e6, (f, np.abs(d_o).max())      # a direction one can step along
+        referee_check(d_g, d_o, d_h, f)
+        worst = max(worst, rel_err(d_g, d_o))
+    assert worst < 1e-6, worst                 # the cap against the FP64 oracle, stage by stage (the referee rule above is the bar)
+    ao, bo = o.step_sizes()
+    ag, bg = g.step_sizes()
+    assert abs(ag[0] - ao) < 1e-6 and abs(bg[0] - bo) < 1e-6
+    # (iii) side by side while both stay finite.  The undamped iteration is chaotic on this start (KKT error 209 -> 1.4e5 -> 2e4 -> 850 ->
+    # 9e2 -> 1.9e5 ... in the oracle): the first two iterates are held to the oracle, the later ones are followed for as long as the
+    # two KKT errors still agree
+    followed = 0
+    for it in range(8):
+        if o.update(0.0, q, v) != 0 or g.update(0.0, q, v) != 0:
+            break
+        e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
+        if not (np.isfinite(e_o) and np.isfinite(e_g)):
+            break
+        close = abs(e_g - e_o) <= 1e-4 * max(1.0, e_o)
+        if it < 2:
+            assert close, (it, e_g, e_o)
+        elif not close:
+            break
+        followed += 1
+    assert followed >= 2, followed
