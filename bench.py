@@ -292,160 +292,6 @@ def whole_job_value(world, batch_per_rank, steps, elapsed):
     return world * batch_per_rank * steps / elapsed
 
 
-def run_parnmpc(args, rank, local_rank, world, dist):
-    """BASELINE.json configs[3]: ANYmal ParNMPCSolver, N = 256 (T = 12.8, dt = 0.05), 4 point contacts on every stage, the
-    stages of every instance sharded over the ranks (idocp_amd/parnmpc_dist.py): halo exchange with the neighbours over
-    RCCL, all-reduce of step sizes.  Strong scaling: the batch of instances is the same whatever the number of GPUs."""
-    import torch
-    from idocp_amd import capi
-    from idocp_amd.parnmpc_dist import HipParNMPCShard, ShardedParNMPC
-    from idocp_amd.workloads import ANYMAL_Q_STANDING, P, anymal_contact_points, anymal_model, anymal_problem, arr
-    torch.cuda.set_device(local_rank)
-    torch.cuda.init()                      # torch's HIP runtime first (see tests/conftest.py)
-    lib = capi.lib()
-    trot = args.workload == "anymal_parnmpc_trotting"
-    N = args.horizon if args.horizon != 100 else 256
-    T = 0.05 * N
-    B = args.batch or 256
-    if N % world:
-        raise SystemExit("--horizon must be divisible by the number of GPUs")
-    model = anymal_model()
-    cost, cons = anymal_problem(model, trotting_ref=True)
-    pts = anymal_contact_points(model)
-    rng = np.random.default_rng(20250)
-    q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
-    q0[:, 0:2] += 0.02 * rng.uniform(-1, 1, (B, 2))
-    q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
-    v0 = np.zeros((B, model.nv))
-    n_events = 0
-    if trot:
-        # the "trotting variant" of configs[3]: the contact sequence of examples/anymal/anymal_trotting.cpp over the whole horizon
-        # (a lift-off, then a touch-down + lift-off every 0.5 s: one lift stage and an aux / impulse pair per touch-down in the
-        # chain), events a quarter of a time step off the grid; sharded like the event-free horizon (every rank keeps its slice of
-        # the chain, idocp_parnmpc_create_hybrid_shard).  The ITERATE IS FROZEN at the initial guess (the step
-        # sizes are set to 0 after every direction has been computed): ParNMPC has no globalisation, and from a standing cold
-        # start its iteration does not contract on this problem -- in the CPU restatement exactly as here (it does converge, to
-        # 1e-12, on short horizons with the footholds in place: tests/test_oracle_parnmpc.py, tests/test_parnmpc_hybrid_gpu.py).
-        # Every kernel of the iteration runs on the full chain; the integration adds 0 * direction.
-        n_events = int((T - 0.5125) / 0.5) + 1
-        shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank, max_num_impulse=n_events)
-
-        class _Seq:
-            def set_contact_status(self, active, points):
-                capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points))))
-
-            def push_back_contact_status(self, active, points, t_ev):
-                capi.check(lib.idocp_ocp_push_back_contact_status(shard.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points)), t_ev))
-        from idocp_amd.workloads import trotting_sequence
-        trotting_sequence(_Seq(), model, n_events - 1, t_start=0.5125)
-    else:
-        shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
-        a = (C.c_int * 4)(1, 1, 1, 1)
-        capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, a, P(arr(pts))))
-    capi.check(lib.idocp_ocp_set_solution(shard.h, b"q", P(arr(ANYMAL_Q_STANDING))))
-    capi.check(lib.idocp_ocp_set_solution(shard.h, b"v", P(np.zeros(model.nv))))
-    capi.check(lib.idocp_ocp_set_solution(shard.h, b"f", P(arr([0, 0, 0.25 * (-model.total_mass * model.gravity[2])]))))
-    if rank == 0:
-        shard.set_initial_state(q0, v0)
-    drv = ShardedParNMPC(shard, dist if world > 1 else _NoDist(), rank, world, max_step=0.0 if trot else None)
-    drv.init_backward_correction(0.0)
-    capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
-    phase_ms = {}
-    orig_phase = shard.phase
-    # HIP events on the handle's own stream around every kernel launch of the iteration (rocprofv3 names)
-    hip = Hip()
-    stream = lib.idocp_ocp_stream(shard.h)
-    PH_KERNEL = {0: "ocp_rnea", 1: "ocp_condense_residual", 2: "parnmpc_kkt_inverse", 3: "parnmpc_backward_serial",
-                 4: "parnmpc_backward_parallel", 5: "parnmpc_forward_serial", 6: "parnmpc_forward_parallel", 7: "ocp_expand_primal",
-                 8: "ocp_reduce_steps", 9: "ocp_expand_dual_integrate"}
-    kernel_ms, kernel_n = {}, {}
-
-    def timed_phase(name, t):
-        t0 = time.perf_counter()
-        if name == "init_aux":
-            orig_phase(name, t)
-        else:
-            if name == "linearize":
-                capi.check(lib.idocp_parnmpc_discretize(shard.h, t), "discretize")
-            phs = shard.PHASES[name]
-            ev = [hip.event() for _ in range(len(phs) + 1)]
-            for k, ph in enumerate(phs):
-                hip.record(ev[k], stream)
-                capi.check(lib.idocp_parnmpc_launch_phase(shard.h, ph, shard.d_q, shard.d_v), "phase %d" % ph)
-            hip.record(ev[len(phs)], stream)
-            capi.check(lib.idocp_ocp_synchronize(shard.h))
-            for k, ph in enumerate(phs):
-                kernel_ms[PH_KERNEL[ph]] = kernel_ms.get(PH_KERNEL[ph], 0.0) + hip.elapsed_ms(ev[k], ev[k + 1])
-                kernel_n[PH_KERNEL[ph]] = kernel_n.get(PH_KERNEL[ph], 0) + 1
-            for e in ev:
-                hip.rt.hipEventDestroy(e)
-        phase_ms[name] = phase_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
-    shard.phase = timed_phase
-
-    def step(_events):
-        drv.update(0.0)
-
-    def sync():
-        torch.cuda.synchronize()
-
-    el = run_timed(step, sync, args.steps, args.warmup, dist, "cuda")
-    nrun = args.steps + args.warmup
-    kms = {k: v / nrun for k, v in phase_ms.items() if k != "init_aux"}
-    kkt = drv.kkt_error(0.0)
-    assert bool(torch.isfinite(kkt).all()), "non-finite KKT error after the timed region"
-    if rank == 0:
-        ms_step = 1e3 * el / args.steps
-        ker = {k: v / kernel_n[k] for k, v in kernel_ms.items()}
-        dom = max(ker, key=ker.get)
-        stages = B * ((N // world) + (2 * (n_events - 1) + 1 if trot else 0))
-        alg_bytes = A_STAGE["anymal_parnmpc"] * stages
-        achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
-        traffic = None
-        import glob
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("horizon") == N and world == 1:
-                    traffic = rec.get("hbm_bytes_per_launch", {}).get(dom)
-                    break
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "SQP iterations/sec (whole node)", "value": B * args.steps / el, "unit": "SQP iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("ANYmal ParNMPCSolver N=%d T=%.2f FP64, %s (BASELINE.json configs[3]); "
-                                    "batch=%d OCP instances, the %d stages of every instance sharded over %d GPU(s) with halo exchange"
-                                    % (N, T, ("trotting contact sequence (1 lift + %d impulse events in the chain), iterate frozen at the initial guess" % (n_events - 1)) if trot
-                                       else "4 point contacts on every stage", B, N, world)),
-                       "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
-                       "phase_ms": kms, "kernel_ms": ker, "max_kkt_error_after": float(kkt.max())},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": ker[dom],
-                         "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
-        }
-        if not args.no_cpu_baseline and not trot and world == 1:
-            o = OracleParNMPC(model, cost, cons, T, N)
-            o.set_contact_status([1, 1, 1, 1], pts)
-            o.set_solution("q", ANYMAL_Q_STANDING)
-            o.set_solution("v", np.zeros(model.nv))
-            o.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
-            o.init(0.0)
-            t0 = time.perf_counter()
-            n = 0
-            while time.perf_counter() - t0 < 12.0:
-                o.update(0.0, q0[0], v0[0])
-                n += 1
-            elc = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": n / elc, "unit": "SQP iterations/s", "cores": 1, "kind": "port",
-                                   "sample": "%d updateSolution calls of one ParNMPC N=%d instance, single thread (oracle/, -O3)" % (n, N),
-                                   "ms_per_update": 1e3 * elc / n}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
-
-
 def latency_mode(lib, hip, build, q0, v0, iters=40):
     """The "ms / Riccati sweep" half of the metric: ONE OCP instance (batch 1, what one reference solver object is), the same
     problem as the throughput run.  ms per SQP iteration with plain launches and with the hipGraph replay
@@ -591,19 +437,29 @@ def run_parnmpc_stub(args, rank, local_rank, world, dist):
 
 
 def run_parnmpc_cxx(args, rank, local_rank, world, dist):
-    """BASELINE.json configs[3]: ANYmal ParNMPCSolver, N = 256 (T = 12.8, dt = 0.05), 4 point contacts on every stage, the stages of
-    every instance sharded over the ranks and driven by the library's C++ multi-GPU driver (idocp_amd/csrc/parnmpc_dist.hip:
-    RCCL point-to-point halos with the two neighbours + all-reduce of the step sizes, everything enqueued on the shard's
-    stream).  Strong scaling: the batch of instances is the same whatever the number of GPUs.  The iterate is WARM-STARTED from
-    the converged Riccati solution of the same OCP (helpers.warm_start_parnmpc; the MPC use of the solver): from the reference's
-    cold start the forward correction sweep amplifies by 1.15 per stage and a 256-stage horizon is numerically meaningless."""
+    """BASELINE.json configs[3]: ANYmal ParNMPCSolver, N = 256 (T = 12.8, dt = 0.05), the stages of every instance sharded over the
+    ranks and driven by the library's C++ multi-GPU driver (idocp_amd/csrc/parnmpc_dist.hip: RCCL point-to-point halos with the two
+    neighbours + all-reduce of the step sizes, everything enqueued on the shard's stream).  Strong scaling: the batch of instances is
+    the same whatever the number of GPUs.
+    --workload anymal_parnmpc: 4 point contacts on every stage; the iterate is WARM-STARTED from the converged Riccati solution of the
+    same OCP (workloads.warm_start_parnmpc; the MPC use of the solver): from the reference's cold start the forward correction sweep
+    amplifies by 1.15 per stage and a 256-stage horizon is numerically meaningless.
+    --workload anymal_parnmpc_trotting: configs[3] as BASELINE.json words it -- the TROTTING contact sequence of
+    examples/anymal/anymal_trotting.cpp over the whole horizon (1 lift + 24 touch-down events a quarter of a time step off the grid:
+    305 stages in the chain, sharded by idocp_parnmpc_create_hybrid_shard).  The iterate MOVES: it starts from a converged ParNMPC
+    solution of this very problem, found by continuation in the step length from the trot in place (workloads.
+    trotting_parnmpc_by_continuation, untimed set-up on a batch-1 solver; every rank runs it for itself and loads its slice of the chain),
+    the instances' initial states are then spread, and the timed iterations re-converge from there.  (Rounds 1-3 timed this workload with
+    the iterate frozen at a standing guess, through a Python driver.)"""
     from idocp_amd import capi, workloads
-    from idocp_amd.parnmpc_dist import HipParNMPCShard
-    from idocp_amd.workloads import ANYMAL_Q_STANDING, HipOCP, P, anymal_contact_points, anymal_model, anymal_problem, arr
-    os.environ["NCCL_DEBUG"] = "WARN"               # (the pool exports NCCL_DEBUG=VERSION: RCCL's banner would follow the JSON line on stdout)
+    from idocp_amd.workloads import (ANYMAL_Q_STANDING, HipOCP, P, ParNMPCShardHandle, anymal_contact_points, anymal_model, anymal_problem, arr,
+                                     trotting_parnmpc_by_continuation, trotting_sequence)
+    os.environ.pop("NCCL_DEBUG", None)              # (the pool exports NCCL_DEBUG=VERSION, and RCCL logs to STDOUT: its banner -- at WARN its
+                                                    #  "could not read node" notes -- would land inside the one JSON line of the contract)
     lib = capi.lib()
     hip = Hip()
     hip.rt.hipSetDevice(local_rank)
+    trot = args.workload == "anymal_parnmpc_trotting"
     N = args.horizon if args.horizon != 100 else 256
     T = 0.05 * N
     B = args.batch or 256
@@ -616,27 +472,43 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     nq, nv = model.nq, model.nv
     rng = np.random.default_rng(20250)
     q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
-    q0[:, 7:] += 0.02 * rng.uniform(-1, 1, (B, 12))
+    q0[:, 7:] += (0.002 if trot else 0.02) * rng.uniform(-1, 1, (B, 12))
     q0 = np.ascontiguousarray(q0)
     v0 = np.zeros((B, nv))
     fz = [0, 0, 0.25 * (-model.total_mass * model.gravity[2])]
-    # ---- warm start: the OCP of the same problem (nominal initial state), converged on this GPU ----
-    src = HipOCP(model, cost, cons, T, N, batch=1, device=local_rank)
-    src.set_contact_status([1, 1, 1, 1], pts)
-    src.set_solution("q", ANYMAL_Q_STANDING)
-    src.set_solution("v", np.zeros(nv))
-    src.set_solution("f", fz)
-    src.init_constraints(0.0)
-    qn, vn = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
-    for _ in range(40):
-        assert src.update(0.0, qn, vn) == 0
-        if src.kkt_error(0.0, qn, vn)[0] < 1e-9:
-            break
-    # ---- this rank's shard + communicator ----
-    shard = HipParNMPCShard(model, cost, cons, T, N, rank, world, B, local_rank)
-    capi.check(lib.idocp_ocp_set_contact_status_uniformly(shard.h, (C.c_int * 4)(1, 1, 1, 1), P(arr(pts))))
+    n_events = (int((T - 0.5125) / 0.5) + 1) if trot else 0
+    setup = {}
+    if trot:
+        # ---- the converged moving trot (batch 1, this GPU), then this rank's shard ----
+        t0 = time.perf_counter()
+        clog = []
+        cost, pn, Mp = trotting_parnmpc_by_continuation(model, T, N, device=local_rank, log=clog)
+        setup = {"continuation_steps": len(clog), "continuation_failed_steps": sum(1 for c in clog if not c["ok"]),
+                 "continuation_seconds": time.perf_counter() - t0, "kkt_of_the_start": clog[-1]["kkt"]}
+        gchain = pn.chain(0.0)[:-1]
+        gsol = {f: pn.get_chain(f, Mp + 1)[:Mp] for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu")}
+        gaux = np.zeros((Mp + 1, 4 * nv * nv))
+        capi.check(lib.idocp_parnmpc_get_aux_mat_chain(pn.h, 0, P(gaux)), "get_aux_mat_chain")
+        del pn
+        shard = ParNMPCShardHandle(model, cost, cons, T, N, rank, world, B, local_rank, max_num_impulse=n_events)
+        trotting_sequence(shard, model, n_events - 1, t_start=0.5125)
+    else:
+        # ---- warm start: the OCP of the same problem (nominal initial state), converged on this GPU ----
+        src = HipOCP(model, cost, cons, T, N, batch=1, device=local_rank)
+        src.set_contact_status([1, 1, 1, 1], pts)
+        src.set_solution("q", ANYMAL_Q_STANDING)
+        src.set_solution("v", np.zeros(nv))
+        src.set_solution("f", fz)
+        src.init_constraints(0.0)
+        qn, vn = ANYMAL_Q_STANDING.copy(), np.zeros(nv)
+        for _ in range(40):
+            assert src.update(0.0, qn, vn) == 0
+            if src.kkt_error(0.0, qn, vn)[0] < 1e-9:
+                break
+        shard = ParNMPCShardHandle(model, cost, cons, T, N, rank, world, B, local_rank)
+        shard.set_contact_status([1, 1, 1, 1], pts)
     for name, val in (("q", ANYMAL_Q_STANDING), ("v", np.zeros(nv)), ("f", fz)):
-        capi.check(lib.idocp_ocp_set_solution(shard.h, name.encode(), P(arr(val))))
+        shard.set_solution(name, val)
     # the real RCCL communicator at every world size, one GPU included: `--gpus 1` runs ncclCommInitRank and the driver's stream-ordered
     # transport exactly like a rank of the 8-GPU job (no in-process substitute)
     comm = C.c_void_p()
@@ -646,18 +518,27 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     if rank == 0:
         capi.check(lib.idocp_parnmpc_dist_set_initial_state(shard.h, P(q0), P(v0), nq, nv))
     capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shard.h, 0.0), "dist_init_backward_correction")
+    if trot:
+        # this rank's slice of the chain: the nodes of the shard's own chain (without its placeholder), found in the whole chain by kind / index
+        where = {(c["kind"], c["index"]): p for p, c in enumerate(gchain)}
+        lchain = shard.chain(0.0)[:-1]
+        ids = [where[(c["kind"], c["index"])] for c in lchain]
+        for f, x in gsol.items():
+            vals = arr(x[ids])
+            capi.check(lib.idocp_ocp_set_solution_chain(shard.h, f.encode(), len(ids), P(vals)), "set_solution_chain " + f)
+        capi.check(lib.idocp_parnmpc_set_aux_mat_chain(shard.h, len(ids), P(arr(gaux[ids]))), "set_aux_mat_chain")
+    else:
+        class _Slice:                                   # workloads.warm_start_parnmpc target: this rank's stages of the horizon
+            def set_stage_values(self, name, values):
+                vals = arr(values[rank * Nl:(rank + 1) * Nl])
+                capi.check(lib.idocp_ocp_set_solution_stages(shard.h, name.encode(), Nl, P(vals)), "set_solution_stages")
 
-    class _Slice:                                   # helpers.warm_start_parnmpc target: this rank's stages of the horizon
-        def set_stage_values(self, name, values):
-            vals = arr(values[rank * Nl:(rank + 1) * Nl])
-            capi.check(lib.idocp_ocp_set_solution_stages(shard.h, name.encode(), Nl, P(vals)), "set_solution_stages")
-
-        def set_aux_mats(self, mats):
-            cm = arr(np.asarray(mats[rank * Nl:(rank + 1) * Nl]).transpose(0, 2, 1))
-            capi.check(lib.idocp_parnmpc_set_aux_mat(shard.h, Nl, P(cm)), "set_aux_mat")
-    workloads.warm_start_parnmpc(src, [_Slice()], N)
+            def set_aux_mats(self, mats):
+                cm = arr(np.asarray(mats[rank * Nl:(rank + 1) * Nl]).transpose(0, 2, 1))
+                capi.check(lib.idocp_parnmpc_set_aux_mat(shard.h, Nl, P(cm)), "set_aux_mat")
+        workloads.warm_start_parnmpc(src, [_Slice()], N)
+        del src
     capi.check(lib.idocp_ocp_init_constraints(shard.h, 0.0))
-    del src
 
     def step(_events):
         capi.check(lib.idocp_parnmpc_dist_update_solution(shard.h, 0.0), "dist_update_solution")
@@ -694,15 +575,18 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
             "metric": "SQP iterations/sec (whole node)", "value": B * args.steps / el, "unit": "SQP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("ANYmal ParNMPCSolver N=%d T=%.2f FP64, 4 point contacts on every stage (BASELINE.json configs[3]), warm-started "
-                                    "from the converged Riccati solution of the same OCP; batch=%d OCP instances, the %d stages of every instance "
-                                    "sharded over %d GPU(s), C++ driver with RCCL halo exchange (idocp_parnmpc_dist_*)" % (N, T, B, N, world)),
+            "config": {"workload": ("ANYmal ParNMPCSolver N=%d T=%.2f FP64, %s (BASELINE.json configs[3]); batch=%d OCP instances, the %d stages "
+                                    "of every instance sharded over %d GPU(s), C++ driver with RCCL halo exchange (idocp_parnmpc_dist_*)"
+                                    % (N, T, ("TROTTING contact sequence (1 lift + %d impulse events: %d stages in the chain), moving iterate started from "
+                                              "the converged ParNMPC solution of this problem (continuation in the step length)" % (n_events - 1, N + 2 * (n_events - 1) + 1))
+                                       if trot else "4 point contacts on every stage, warm-started from the converged Riccati solution of the same OCP", B, N, world)),
                        "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
+                       "stages_per_rank": Nl, "setup": setup,
                        "kernel_ms": ker, "max_kkt_error_after": float(kkt.max())},
         }
         if ker:
             dom = max(ker, key=ker.get)
-            alg_bytes = A_STAGE["anymal_parnmpc"] * B * Nl
+            alg_bytes = A_STAGE["anymal_parnmpc"] * B * (Nl + (2 * (n_events - 1) + 1 if trot else 0))
             achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
             traffic = None
             import glob
@@ -718,7 +602,7 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_ms": ker[dom],
                                "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not trot:
             from helpers import OracleParNMPC      # the CPU restatement: checker / baseline only
             o = OracleParNMPC(model, cost, cons, T, N)
             o.set_contact_status([1, 1, 1, 1], pts)
@@ -740,15 +624,6 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     lib.idocp_comm_destroy(comm)
     if dist is not None:
         dist.destroy_process_group()
-
-
-class _NoDist:
-    """world = 1: the driver never communicates"""
-    class ReduceOp:
-        MIN = SUM = None
-
-    def broadcast(self, *a, **k):
-        pass
 
 
 def main():
@@ -777,7 +652,7 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     backend = os.environ.get("IDOCP_BENCH_BACKEND", "nccl")
-    if args.workload == "anymal_parnmpc":
+    if args.workload in ("anymal_parnmpc", "anymal_parnmpc_trotting"):
         # the data path is the library's own RCCL communicator (idocp_parnmpc_dist_*); torch.distributed only carries the
         # rendezvous of its id and the barrier / max-reduction of the timing -> gloo, so that one RCCL instance owns the GPUs
         dist = init_distributed("gloo", local_rank) if world > 1 else None
@@ -789,9 +664,6 @@ def main():
         dist = init_distributed(backend, local_rank)
     if os.environ.get("IDOCP_BENCH_STUB"):
         return run_stub(args, rank, world, dist)
-
-    if args.workload == "anymal_parnmpc_trotting":
-        return run_parnmpc(args, rank, local_rank, world, dist)
 
     from idocp_amd import capi
     from idocp_amd.workloads import (ANYMAL_Q_STANDING, HipOCP, HipUnOCP, HipUnParNMPC, anymal_contact_points, anymal_model, anymal_problem,

@@ -1265,6 +1265,14 @@ static int getChainField(idocp_ocp_t* h, const double* base, size_t stride, cons
   for (int p = 0; p < M; ++p) std::memcpy(out + (size_t)p * f.dim, &all[(size_t)h->chain[p].slot * stride + f.offset], sizeof(double) * f.dim);
   return IDOCP_OK;
 }
+// the correction state along the chain: out[M][nx * nx] (column-major per stage), the counterpart of idocp_parnmpc_set_aux_mat_chain --
+// together with idocp_ocp_get_solution_chain it is what carries a converged ParNMPC solver over into another handle (another batch
+// size, another shard of the horizon)
+int idocp_parnmpc_get_aux_mat_chain(idocp_ocp_t* h, int instance, double* out) {
+  if (!h || !out || !h->parnmpc || instance < 0 || instance >= h->batch) { set_last_error("idocp_parnmpc_get_aux_mat_chain: not a ParNMPC handle"); return IDOCP_E_ARG; }
+  Field f{0, DQ::NX * DQ::NX, 0};
+  return getChainField(h, h->B.aux, LQ::AUX, f, instance, out);
+}
 int idocp_ocp_get_solution_chain(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;

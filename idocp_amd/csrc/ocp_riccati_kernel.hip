@@ -751,7 +751,11 @@ struct RiccatiRegSmem {
   // when PM is dead, and extends behind it
   static constexpr int QXU = PM, QUU = QXU + NX * NU, LU = QUU + NU * NU, KM = LU + 16, KVN = KM + NU * NX, GW = KVN + 16,
                        DG = GW + NU * NU, SS = DG + NF * NU, DTM = SS + NF * NF, SDG = DTM + NU * NX, MV = SDG + NF * NU,
-                       SCORR = MV + 16, MMX = SCORR + 48, GK = MMX + NF * NX, HYB = GK + NU * NX;
+                       SCORR = MV + 16, MMX = SCORR + 48,
+                       GK = MMX,                  // Quu K takes the place of M (dead once DtM = Phiu^T M is formed)
+                       WL = MMX + NF * NX,        // P | Phix | Phiu of the swc record (one trip to memory instead of one per step of the algebra)
+                       WL_P = WL, WL_PHIX = WL + NF, WL_PHIU = WL_PHIX + NF * NX, HYB = WL_PHIU + NF * NU;
+  static_assert(NF * NX == NU * NX, "GK aliases MMX");
   static constexpr int NTBL = OcpLayout<D>::R_SV + NV;             // doubles of Pqq | Pqv | Pvv | sq | sv in the ric record
   static constexpr size_t BYTES = (HYB > PLAIN ? HYB : PLAIN) * sizeof(double);
   static_assert(BYTES + 64 <= 40960, "four instances per CU");
@@ -1188,6 +1192,17 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       double* Qxu = &sm[S::QXU];
       double* Quu = &sm[S::QUU];
       double* lu = &sm[S::LU];
+      // the constraint's P | Phix and Phiu (two contiguous pieces of the swc record) on their way to LDS: in flight during the first
+      // factorisation
+      const double* __restrict__ W = B.swc + rec * L::SWC;
+      constexpr int W2A = (L::W_PHIX + NF * NX) / 2, W2B = NF * NU / 2, NWL = (W2A + W2B + 63) / 64;
+      static_assert(L::W_P == 0 && L::W_PHIX == NF && (L::W_PHIX + NF * NX) % 2 == 0 && L::W_PHIU % 2 == 0 && S::WL % 2 == 0 && L::SWC % 2 == 0, "16-byte pieces of the swc record");
+      rd2 wl[NWL];
+#pragma unroll
+      for (int t = 0; t < NWL; ++t) {
+        const int e = lane + 64 * t;
+        wl[t] = reinterpret_cast<const rd2*>(W)[e < W2A ? e : (e < W2A + W2B ? L::W_PHIU / 2 + (e - W2A) : 0)];
+      }
 #pragma unroll
       for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
@@ -1207,13 +1222,17 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
           for (int m = 0; m < NU; ++m) sm[S::GW + m + NU * lane] = x[m];
         }
       }
+#pragma unroll
+      for (int t = 0; t < NWL; ++t) { const int e = lane + 64 * t; if (e < W2A + W2B) reinterpret_cast<rd2*>(&sm[S::WL])[e] = wl[t]; }
       waveLdsSync();
       CSTAMP(1);
-      const double* __restrict__ W = B.swc + rec * L::SWC;
-      const double* __restrict__ Phiu = W + L::W_PHIU;
+      const double* Phiu = &sm[S::WL_PHIU];
+      const double* Phix = &sm[S::WL_PHIX];
+      const double* Pv = &sm[S::WL_P];
       for (int e = lane; e < dimi * NU; e += 64) {                // DGinv = Phiu Ginv
         const int c = e / dimi, j = e - c * dimi;
         double acc = 0.0;
+#pragma unroll
         for (int m = 0; m < NU; ++m) acc += Phiu[j + NF * m] * sm[S::GW + m + NU * c];
         sm[S::DG + j + NF * c] = acc;
       }
@@ -1221,31 +1240,35 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       for (int e = lane; e < dimi * dimi; e += 64) {              // S = DGinv Phiu^T
         const int c = e / dimi, j = e - c * dimi;
         double acc = 0.0;
+#pragma unroll
         for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * Phiu[c + NF * m];
         sm[S::SS + j + NF * c] = acc;
       }
       waveLdsSync();
       CSTAMP(2);
-      {
-        // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves (llt_s_.solve, :64-66, 71-74), lane = column
-        static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
-        double x[NF];
+      // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves (llt_s_.solve, :64-66, 71-74), lane = column.  dimi is 3 per foot that
+      // touches down: the trotting and running gaits bring two feet down at a time, so the 6-row instantiation serves them
+      static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
+      auto sSolve = [&](auto ntag) {
+        constexpr int NR = decltype(ntag)::value;
+        double x[NR];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
+        for (int j = 0; j < NR; ++j) {
           double val = 0.0;
-          if (j < dimi) val = lane < NU ? sm[S::DG + j + NF * lane] : (lane < NU + NX ? W[L::W_PHIX + j + NF * (lane - NU)] : (lane == NU + NX ? W[L::W_P + j] : 0.0));
+          if (j < dimi) val = lane < NU ? sm[S::DG + j + NF * lane] : (lane < NU + NX ? Phix[j + NF * (lane - NU)] : (lane == NU + NX ? Pv[j] : 0.0));
           x[j] = val;
         }
-        choleskySolveRows<NF>(&sm[S::SS], NF, lane, &s_ok, x, dimi);
+        choleskySolveRows<NR>(&sm[S::SS], NF, lane, &s_ok, x, dimi);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
+        for (int j = 0; j < NR; ++j) {
           if (j < dimi) {
             if (lane < NU) sm[S::SDG + j + NF * lane] = x[j];
             else if (lane < NU + NX) sm[S::MMX + j + NF * (lane - NU)] = x[j];
             else if (lane == NU + NX) sm[S::MV + j] = x[j];
           }
         }
-      }
+      };
+      if (dimi <= 6) sSolve(std::integral_constant<int, 6>{}); else sSolve(std::integral_constant<int, NF>{});
       waveLdsSync();
       CSTAMP(3);
       for (int e = lane; e < NU * NU; e += 64) {                  // Ginv -= SinvDGinv^T DGinv
@@ -1257,8 +1280,6 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       waveLdsSync();
       {
         // K = -Ginv Qxu^T - SinvDGinv^T Phix, k = -Ginv lu - SinvDGinv^T P with the updated Ginv (:67-70)
-        const double* __restrict__ Phix = W + L::W_PHIX;
-        const double* __restrict__ Pv = W + L::W_P;
         for (int e = lane; e < NU * NX; e += 64) {
           const int c = e / NU, j = e - c * NU;
           double acc = 0.0;
@@ -1283,6 +1304,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         for (int e = lane; e < dimi * NX; e += 64) {
           const int c = e / dimi, l = e - c * dimi;
           double acc = sm[S::MMX + l + NF * c];
+#pragma unroll
           for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
           sm[S::MMX + l + NF * c] = acc;
           Ww[L::W_M + l + NF * c] = acc;
@@ -1300,12 +1322,12 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       for (int e = lane; e < NU * NX; e += 64) {                  // DtM = Phiu^T M (:88)
         const int c = e / NU, m = e - c * NU;
         double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIU + l + NF * m] * sm[S::MMX + l + NF * c];
+        for (int l = 0; l < dimi; ++l) acc += Phiu[l + NF * m] * sm[S::MMX + l + NF * c];
         sm[S::DTM + m + NU * c] = acc;
       }
       if (lane < NX) {                                            // Phix^T m (:98-99)
         double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += W[L::W_PHIX + l + NF * lane] * sm[S::MV + l];
+        for (int l = 0; l < dimi; ++l) acc += Phix[l + NF * lane] * sm[S::MV + l];
         sm[S::SCORR + lane] = acc;
       }
       waveLdsSync();

@@ -696,3 +696,150 @@ def map_ocp_onto_parnmpc_chain(co, cp, sol, Pm):
         vals[f] = np.stack([sol[f][d_] for d_ in dyn_src])
     aux = np.stack([Pm[s_] for s_ in state_src])
     return vals, aux
+
+
+class ParNMPCShardHandle:
+    """One shard of a ParNMPC horizon on this process's GPU through the C ABI: the grid stages [rank N / world, (rank + 1) N / world)
+    (idocp_parnmpc_create_shard; with max_num_impulse > 0 idocp_parnmpc_create_hybrid_shard: every rank holds the whole contact
+    sequence and keeps its slice of the chain).  Driven by the library's C++ driver (idocp_parnmpc_dist_*)."""
+
+    def __init__(self, model, cost, cons, T, N, rank, world, batch, device, max_num_impulse=0):
+        assert N % world == 0, "the horizon must divide evenly among the ranks"
+        self.lib = capi.lib()
+        self.Nl, self.batch, self.rank, self.world, self.N = N // world, batch, rank, world, N
+        self.nq, self.nv = model.nq, model.nv
+        self.max_events = max_num_impulse
+        h = C.c_void_p()
+        if max_num_impulse > 0:
+            capi.check(self.lib.idocp_parnmpc_create_hybrid_shard(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse,
+                                                                  rank * self.Nl, (rank + 1) * self.Nl, batch, device, C.byref(h)),
+                       "idocp_parnmpc_create_hybrid_shard")
+        else:
+            capi.check(self.lib.idocp_parnmpc_create_shard(C.byref(model), C.byref(cost), C.byref(cons), T / world, self.Nl, rank * self.Nl,
+                                                           1 if rank == world - 1 else 0, 1 if rank > 0 else 0, batch, device, C.byref(h)),
+                       "idocp_parnmpc_create_shard")
+        self.h = h
+        dq, dv = C.c_void_p(), C.c_void_p()
+        capi.check(self.lib.idocp_parnmpc_prev_state(self.h, C.byref(dq), C.byref(dv)))
+        self.d_q, self.d_v = dq, dv
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.idocp_ocp_destroy(self.h)
+            self.h = None
+
+    # the contact-sequence interface of the solvers (trotting_sequence)
+    def set_contact_status(self, active, points):
+        capi.check(self.lib.idocp_ocp_set_contact_status_uniformly(self.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points))))
+
+    def push_back_contact_status(self, active, points, t_ev):
+        capi.check(self.lib.idocp_ocp_push_back_contact_status(self.h, (C.c_int * 4)(*[int(x) for x in active]), P(arr(points)), t_ev))
+
+    def set_solution(self, name, value):
+        capi.check(self.lib.idocp_ocp_set_solution(self.h, name.encode(), P(arr(value))))
+
+    def chain(self, t=0.0):
+        cap = self.N + 1 + 3 * max(self.max_events, 1)
+        IA = lambda: (C.c_int * cap)()
+        kind, index, slot, dimf, sw = IA(), IA(), IA(), IA(), IA()
+        dt = np.zeros(cap)
+        M = self.lib.idocp_ocp_get_chain(self.h, t, cap, kind, index, slot, P(dt), dimf, sw)
+        assert M > 0, capi.lib().idocp_last_error()
+        return [dict(kind=NODE_KINDS[kind[p]], index=index[p], slot=slot[p], dt=dt[p], dimf=dimf[p]) for p in range(M)]
+
+
+def trotting_parnmpc_by_continuation(model, T, N, device=0, K=30, log=None):
+    """A CONVERGED, MOVING trotting solution of ParNMPC at BASELINE configs[3]'s size, by continuation (round 4).  ParNMPC has no
+    globalisation and its undamped iteration does not contract from a standing start on the trotting problem; it does from the converged
+    OCPSolver solution of the trot IN PLACE (step length 0, swing-knee reference 0: forward and backward Euler nearly coincide on a
+    solution that hardly moves), and from there the step length and the knee reference are raised to the example's 0.15 m / 1.7 rad in
+    small steps, re-converging from the previous solution each time (a failed step is retried at half the increment from a clone of the
+    last converged solver).  Returns (cost of the full problem, solver, chain length without the placeholder): a HipParNMPC of batch 1
+    holding the converged solution of the full problem."""
+    n_events = int((T - 0.5125) / 0.5) + 1
+    lib = capi.lib()
+    lib.idocp_ocp_set_cost.argtypes = [C.c_void_p, C.POINTER(capi.Cost)]
+    lib.idocp_ocp_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+
+    def problem(lam):
+        cost, cons = anymal_problem(model, trotting_ref=True)
+        cost.step_length = 0.15 * lam
+        cost.front_swing_knee = cost.hip_swing_knee = 1.7 * lam
+        return cost, cons
+
+    def points(lam):
+        class Rec:
+            def __init__(self):
+                self.pts = []
+
+            def set_contact_status(self, a, p):
+                self.pts.append(np.array(p).copy())
+
+            def push_back_contact_status(self, a, p, t):
+                self.pts.append(np.array(p).copy())
+        r = Rec()
+        trotting_sequence(r, model, n_events - 1, t_start=0.5125, step_length=0.15 * lam)
+        return r.pts
+
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(model.nv)
+    cost0, cons = problem(0.0)
+    ocp = HipOCP(model, cost0, cons, T, N, batch=1, device=device, max_num_impulse=n_events)
+    pn = HipParNMPC(model, cost0, cons, T, N, batch=1, device=device, max_num_impulse=n_events)
+    for s in (ocp, pn):
+        trotting_sequence(s, model, n_events - 1, t_start=0.5125, step_length=0.0)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-model.total_mass * model.gravity[2])])
+    ocp.init_constraints(0.0)
+    pn.init(0.0)
+    for it in range(80):
+        assert ocp.update(0.0, q, v) == 0
+        if it > 10 and ocp.kkt_error(0.0, q, v)[0] < 1e-9:
+            break
+    co, cp = ocp.chain(0.0), pn.chain(0.0)[:-1]
+    Mo, Mp = len(co), len(cp)
+    sol = {f: ocp.get_chain(f, Mo) for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu")}
+    vals, aux = map_ocp_onto_parnmpc_chain(co, cp, sol, ocp.riccati_chain(Mo)[0])
+    for f, x in vals.items():
+        pn.set_chain_values(f, x)
+    pn.set_chain_aux_mats(aux)
+    pn.init_constraints(0.0)
+    del ocp
+
+    def converge(maxit=40, tol=1e-6):
+        e = float("inf")
+        for it in range(maxit):
+            r = lib.idocp_parnmpc_update_solution(pn.h, 0.0, P(pn._bc(q, pn.nq)), P(pn._bc(v, pn.nv)), 0)
+            e = float(pn.kkt_error(0.0, q, v)[0])
+            if r or not np.isfinite(e) or e > 1e6:
+                return False, it + 1, e
+            if e < tol:
+                return True, it + 1, e
+        return False, maxit, e
+
+    ok, its, e = converge()
+    if log is not None:
+        log.append(dict(lam=0.0, ok=ok, iterations=its, kkt=e))
+    assert ok, "ParNMPC does not converge on the trot in place (KKT %.3e)" % e
+    lam, step, tries = 0.0, 1.0 / K, 0
+    while lam < 1.0 - 1e-12:
+        tries += 1
+        assert tries < 600 and step > 1e-5, "the continuation stalls at lam = %.4f" % lam
+        lam_try = min(1.0, lam + step)
+        ck = C.c_void_p()
+        capi.check(lib.idocp_ocp_clone(pn.h, C.byref(ck)), "clone")
+        cost, _ = problem(lam_try)
+        capi.check(lib.idocp_ocp_set_cost(pn.h, C.byref(cost)), "set_cost")
+        for ph, pts in enumerate(points(lam_try)):
+            capi.check(lib.idocp_ocp_set_contact_points(pn.h, ph, P(arr(pts))), "set_contact_points")
+        ok, its, e = converge()
+        if log is not None:
+            log.append(dict(lam=lam_try, step=step, ok=ok, iterations=its, kkt=e))
+        if ok:
+            lib.idocp_ocp_destroy(ck)
+            lam, step = lam_try, min(1.0 / K, step * 1.5)
+        else:
+            lib.idocp_ocp_destroy(pn.h)
+            pn.h = ck
+            step *= 0.5
+    return problem(1.0)[0], pn, Mp

@@ -402,6 +402,9 @@ int idocp_ocp_pop_front_contact_status(idocp_ocp_t* h);
  * discrete events along the horizon needs -- the reference does it through the public members of its Solution container.) */
 int idocp_ocp_set_solution_chain(idocp_ocp_t* h, const char* name, int M, const double* values);
 int idocp_parnmpc_set_aux_mat_chain(idocp_ocp_t* h, int M, const double* values);
+/* ... and its counterpart: aux_mat of every stage of the chain of one instance, out[M][nx * nx] (column-major per stage).  With
+ * idocp_ocp_get_solution_chain this carries a converged ParNMPC solver over into another handle (another batch size, a shard). */
+int idocp_parnmpc_get_aux_mat_chain(idocp_ocp_t* h, int instance, double* out);
 int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot,
                         double* dt, int* dimf, int* sw_dimi);
 /* OCPSolver::setSolution (ocp_solver.cpp:95-165): name in {"q","v","a","f","u"};

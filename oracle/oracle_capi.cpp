@@ -582,6 +582,34 @@ int oracle_ocp_stage(void* h, int what, double t, const double* q, const double*
   } catch (...) { return 1; }
   return 0;
 }
+// Test hook of the Riccati layer (tests/test_golden_riccati.py): overwrite the condensed LQR data of chain stage i -- the blocks
+// RiccatiRecursionSolver consumes, in the reference's storage (Fqq / Fqv: leading 6 x 6 blocks only) -- with the caller's, so that the
+// backward sweep can be held to an INDEPENDENTLY computed solution of the dense KKT system (tests/golden/gen_golden_riccati.py).
+// Matrices column-major.  terminal != 0: stage i is the terminal stage (Qxx, lx only).
+int oracle_ocp_inject_lqr_stage(void* h, int i, int terminal, const double* Qxx, const double* Qxu, const double* Quu, const double* Fqq6,
+                                const double* Fqv6, const double* Fvq, const double* Fvv, const double* Fvu, const double* lx,
+                                const double* lu, const double* Fx) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  const int nv = s->robot.dimv(), nu = s->robot.dimu(), nx = 2 * nv;
+  if (i < 0 || i >= (int)s->kkt_matrix.size()) return -1;
+  SplitKKTMatrixC& M = s->kkt_matrix[i];
+  SplitKKTResidualC& R = s->kkt_residual[i];
+  auto put = [](Mat& m, const double* src, int r, int c) { Mat t(r, c); xcpy(t.d.data(), src, sizeof(double) * r * c); m = t; };
+  put(M.Qxx, Qxx, nx, nx);
+  for (int r = 0; r < nv; ++r) { R.lq[r] = lx[r]; R.lv[r] = lx[nv + r]; }
+  if (terminal) return 0;
+  Mat qxu, quu;
+  put(qxu, Qxu, nx, nu); put(quu, Quu, nu, nu);
+  M.Qxu_full.setBlock(0, 6, qxu); M.Quu_full.setBlock(6, 6, quu);
+  put(M.Fqq6, Fqq6, 6, 6); put(M.Fqv6, Fqv6, 6, 6); put(M.Fvq, Fvq, nv, nv); put(M.Fvv, Fvv, nv, nv); put(M.Fvu, Fvu, nv, nu);
+  for (int r = 0; r < nv; ++r) { R.Fq[r] = Fx[r]; R.Fv[r] = Fx[nv + r]; }
+  for (int r = 0; r < nu; ++r) R.lu[r] = lu[r];
+  return 0;
+}
+int oracle_ocp_backward_riccati_only(void* h) {
+  try { static_cast<OCPSolver*>(h)->backwardRiccatiRecursion(); } catch (...) { return 1; }
+  return 0;
+}
 int oracle_ocp_compute_kkt_residual(void* h, double t, const double* q, const double* v) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   s->computeKKTResidual(t, toVec(q, s->robot.dimq()), toVec(v, s->robot.dimv()));

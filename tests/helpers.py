@@ -568,7 +568,7 @@ class OracleParNMPC:
         return a.value, b.value
 
 class OracleParNMPCShard:
-    """Shard backend of idocp_amd.parnmpc_dist.ShardedParNMPC on top of the oracle (one instance, CPU tensors)."""
+    """Shard backend of tests/parnmpc_dist.py ShardedParNMPC on top of the oracle (one instance, CPU tensors)."""
     PHASES = {"linearize": 0, "bwd_serial": 1, "bwd_parallel": 2, "fwd_serial": 3, "fwd_parallel": 4, "integrate": 5}
 
     def __init__(self, model, cost, cons, T, N, rank, world, q0, v0, max_num_impulse=0):
@@ -620,7 +620,7 @@ class OracleParNMPCShard:
         return torch.tensor([self.o.lib.oracle_parnmpc_kkt_error_squared(self.o.h, t, P(self.q_prev), P(self.v_prev))], dtype=torch.float64)
 
 class OracleUnParNMPCShard:
-    """Shard backend of idocp_amd.parnmpc_dist.ShardedParNMPC on top of the fixed-base oracle (one instance, CPU tensors):
+    """Shard backend of tests/parnmpc_dist.py ShardedParNMPC on top of the fixed-base oracle (one instance, CPU tensors):
     every rank holds a whole-horizon oracle and works on its slice of the stages; the halos fill the neighbours' stages."""
     PHASES = {"linearize": 0, "bwd_serial": 1, "bwd_parallel": 2, "fwd_serial": 3, "fwd_parallel": 4, "integrate": 5}
 

@@ -1,4 +1,9 @@
-"""Horizon-sharded ParNMPC: one process per shard of the horizon, halo exchange between neighbours.
+"""TEST SCAFFOLDING (round 4: moved out of the product package).  The multi-GPU driver of the product is C++
+(idocp_amd/csrc/parnmpc_dist.hip, idocp_parnmpc_dist_*); this Python restatement of the same halo protocol exists so that the
+protocol can be exercised without GPUs -- on gloo, with the CPU oracle as the shard backend (tests/test_parnmpc_dist.py) -- and so
+that single phases of the HIP shards can be driven by hand in a test (tests/test_parnmpc_gpu.py, test_parnmpc_hybrid_gpu.py).
+
+Horizon-sharded ParNMPC: one process per shard of the horizon, halo exchange between neighbours.
 
 ParNMPC (src/ocp/parnmpc_solver.cpp:73-103) is stage-parallel except for two thin serial sweeps (the backward correction
 of (lmd, gmm) and the forward correction of (q, v)), so the stages [r N/G, (r+1) N/G) of one horizon can live on rank r

@@ -1,5 +1,5 @@
 """Horizon-sharded ParNMPC on CPU: two gloo processes, each owning half of the stages, drive the halo protocol of
-idocp_amd/parnmpc_dist.py with the oracle as the shard backend; the result must equal the single-process oracle."""
+tests/parnmpc_dist.py with the oracle as the shard backend; the result must equal the single-process oracle."""
 import json
 import os
 import socket
@@ -15,7 +15,7 @@ import json, os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch, torch.distributed as dist
 from helpers import ANYMAL_Q_STANDING, OracleParNMPCShard, anymal_contact_points, anymal_model, anymal_problem
-from idocp_amd.parnmpc_dist import ShardedParNMPC
+from parnmpc_dist import ShardedParNMPC
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 N, T, iters = 20, 0.5, 6
@@ -91,7 +91,7 @@ import json, os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch, torch.distributed as dist
 from helpers import ANYMAL_Q_STANDING, OracleParNMPCShard, anymal_contact_points, anymal_model, anymal_problem
-from idocp_amd.parnmpc_dist import ShardedParNMPC
+from parnmpc_dist import ShardedParNMPC
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 N, T, iters = 20, 1.0, 8
@@ -172,7 +172,7 @@ import json, os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch, torch.distributed as dist
 from helpers import OracleUnParNMPCShard, iiwa14_model, unocp_problem
-from idocp_amd.parnmpc_dist import ShardedParNMPC
+from parnmpc_dist import ShardedParNMPC
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 N, T, iters = 20, 1.0, 8

@@ -71,11 +71,11 @@ def test_convergence_and_batch():
 
 def test_two_shards_on_one_gpu_equal_the_whole_horizon():
     """Horizon sharding (BASELINE.json configs[3]) without a second GPU: two shard handles of 10 stages each on this GPU,
-    the halo protocol of idocp_amd/parnmpc_dist.py executed by hand in its pipeline order, against one handle of 20."""
+    the halo protocol of tests/parnmpc_dist.py executed by hand in its pipeline order, against one handle of 20."""
     import torch
     from helpers import P, arr
     from idocp_amd import capi
-    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    from parnmpc_dist import HipParNMPCShard
     m, o, g, q, v = make_pair(20, 0.5)
     cost, cons = anymal_problem(m, trotting_ref=False)
     pts = anymal_contact_points(m)
@@ -149,7 +149,7 @@ def test_cxx_sharded_driver_equals_the_whole_horizon(N, T, world, iters):
     import threading
     from helpers import P, arr
     from idocp_amd import capi
-    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    from parnmpc_dist import HipParNMPCShard
     m, o, g, q, v = make_pair(N, T)
     cost, cons = anymal_problem(m, trotting_ref=False)
     pts = anymal_contact_points(m)

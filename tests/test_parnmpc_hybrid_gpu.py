@@ -155,12 +155,12 @@ def test_converges_like_the_oracle(events):
 def test_two_shards_of_a_chain_with_events_on_one_gpu_equal_the_whole_chain():
     """Horizon sharding of a chain with discrete events (idocp_parnmpc_create_hybrid_shard) without a second GPU: two shard
     handles on this GPU -- the lift stage in the first, the aux / impulse pair in the second --, the halo protocol of
-    idocp_amd/parnmpc_dist.py executed by hand in its pipeline order, against one handle that holds the whole chain."""
+    tests/parnmpc_dist.py executed by hand in its pipeline order, against one handle that holds the whole chain."""
     import ctypes as C
     import torch
     from helpers import P, arr
     from idocp_amd import capi
-    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    from parnmpc_dist import HipParNMPCShard
     events = [([0, 1, 1, 0], 0.27), ([1, 1, 1, 1], 0.83)]
     m, o, g, q, v = make_pair(20, 1.0, events)
     cost, cons = anymal_problem(m, trotting_ref=False)

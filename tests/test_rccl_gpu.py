@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def _shard_and_comm(m, cost, cons, T, N, batch=1):
     from idocp_amd import capi
-    from idocp_amd.parnmpc_dist import HipParNMPCShard
+    from parnmpc_dist import HipParNMPCShard
     lib = capi.lib()
     sh = HipParNMPCShard(m, cost, cons, T, N, 0, 1, batch, 0)
     raw = (C.c_char * 128)()

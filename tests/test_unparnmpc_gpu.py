@@ -160,11 +160,11 @@ def test_ragged_batch_sizes(batch):
 
 def test_two_shards_on_one_gpu_equal_the_whole_horizon():
     """Horizon sharding of the fixed-base solver without a second GPU: two shard handles of 10 stages each on this GPU, the
-    halo protocol of idocp_amd/parnmpc_dist.py executed by hand in its pipeline order, against one handle of 20."""
+    halo protocol of tests/parnmpc_dist.py executed by hand in its pipeline order, against one handle of 20."""
     import torch
     from helpers import P, arr
     from idocp_amd import capi
-    from idocp_amd.parnmpc_dist import HipUnParNMPCShard
+    from parnmpc_dist import HipUnParNMPCShard
     m, o, g, q, v = make_pair(20, 1.0, q0=1.0)
     cost, cons = unocp_problem(m)
     lib = capi.lib()
