@@ -280,8 +280,9 @@ def _proto(lib):
 def lib():
     """Load libidocp_hip.so (the HIP extension).  Fails loudly when it is missing:
     there is no CPU fallback for the product path."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        LIB_PATH = os.environ.get("IDOCP_HIP_LIB", LIB_PATH)      # diagnostics: another build of the same library (e.g. with clock stamps)
         if not os.path.exists(LIB_PATH):
             raise LibraryMissing(
                 "HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)

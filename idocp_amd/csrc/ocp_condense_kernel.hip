@@ -166,11 +166,16 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* q = s + L::S_Q;
   const double* __restrict__ qref = B.q_ref + (long)pos * NQ;
   const long su = rec;
-  const bool stamp = (!RESIDUAL) && tid == 0 && unit == 7 && B.prof != nullptr && DIMF == B.prof_dimf;
+#ifdef IDOCP_K5_STAMPS      // diagnostic build (IDOCP_EXTRA_HIPCC_FLAGS=-DIDOCP_K5_STAMPS): clock stamps at the phase boundaries of one workgroup
+  const bool stamp = (!RESIDUAL) && tid == 0 && unit == (long)(gridDim.x / 2 + 7) && B.prof != nullptr && DIMF == B.prof_dimf;
 #define STAMP(k) do { if (stamp) B.prof[k] = wall_clock64(); } while (0)
   // per-wavefront stamps of the wave-specialised stage: slot 32 + 8 wave + k
-  const bool stampw = (!RESIDUAL) && (tid & 63) == 0 && unit == 7 && B.prof != nullptr && DIMF == B.prof_dimf;
+  const bool stampw = (!RESIDUAL) && (tid & 63) == 0 && unit == (long)(gridDim.x / 2 + 7) && B.prof != nullptr && DIMF == B.prof_dimf;
 #define STAMPW(k) do { if (stampw) B.prof[32 + 8 * (tid >> 6) + (k)] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMPW(k) do { } while (0)
+#endif
   STAMP(0);
   double* kk = B.kkt + rec * L::KKT;
   double* ee = B.exp + rec * L::EXP;
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (tid < 36) { prez[0] = zz[L::Z_JQ + tid]; prez[1] = zz[L::Z_FQQ + tid]; prez[2] = zz[L::Z_FQQI + tid]; prez[3] = zz[L::Z_FQQP + tid]; prez[4] = zz[L::Z_FQQPI + tid]; }
       if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
     }
+    STAMP(3);
     if (tid == 0) { s_ok = 1; s_c1 = 0; }
     if (!terminal) {
       for (int e = tid; e < S::IDC - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
     if (tid < 36) { sm[S::JQ + tid] = prez[0]; sm[S::FQQ + tid] = prez[1]; sm[S::FQQI + tid] = prez[2]; sm[S::FQQP + tid] = prez[3]; sm[S::FQQPI + tid] = prez[4]; }
     if (tid >= 64 && tid < 70) { sm[S::QDIFF + tid - 64] = prez[5]; sm[S::FQ6 + tid - 64] = prez[6]; }
+    STAMP(4);
   }
   blockLdsBarrier();
   STAMP(1);
