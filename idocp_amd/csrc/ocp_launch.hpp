@@ -22,7 +22,8 @@ struct OcpLaunch {
                                     hipStream_t st);                                          // K9a: ParNMPC stage (K5b with backward Euler)
   static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
-  static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9b
+  static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9w, or K9b with IDOCP_K9_WAVE=0
+  static void parnmpcInverseWave(const OcpBuffers& B, long batch, int M, hipStream_t st);        // K9w (parnmpc_kkt_wave_kernel.hip)
   // terms with frame Jacobians of their own (ocp_ext_kernel.hip): no-ops when B.ext == nullptr
   static void extRows(const OcpBuffers& B, long batch, int M, bool residual, hipStream_t st);
   static void extHessian(const OcpBuffers& B, long batch, int M, hipStream_t st);

@@ -16,6 +16,8 @@
 // K10b parnmpc_forward_parallel     one wavefront per stage (lmd, gmm, u corrections), aux_mat, Newton direction s_new - s
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
 #include "ocp_device.hpp"
@@ -550,6 +552,9 @@ void OcpLaunch<D>::parnmpcHalo(const OcpBuffers& B, long batch, int kind, bool d
 
 template <typename D>
 void OcpLaunch<D>::parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+  // K9w (one wavefront per stage on the matrix cores, parnmpc_kkt_wave_kernel.hip) unless IDOCP_K9_WAVE=0 asks for the round-1 kernel below
+  static const bool wave = [] { const char* e = getenv("IDOCP_K9_WAVE"); return !(e && e[0] == '0'); }();
+  if (wave) { parnmpcInverseWave(B, batch, M, st); return; }
   const size_t smem = KktInvSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
