@@ -23,6 +23,8 @@
 // One wavefront per stage, no workgroup barrier; against K9b's 256 threads with 84 barriers and ~10^4 vector instructions per thread.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
 #include "ocp_device.hpp"
@@ -31,6 +33,7 @@
 namespace idocp_dev {
 
 typedef mfma_d4 wtile;
+typedef double v2d __attribute__((ext_vector_type(2)));      // (a native vector, not the double2 struct: arrays of it stay in registers)
 
 template <typename D>
 struct KktWaveSmem {
@@ -38,10 +41,18 @@ struct KktWaveSmem {
   static constexpr int NX = D::NX, NU = D::NU, NQ_ = NU + NX;
   static_assert(NQ_ == 48 && NX == 36, "three 16 x 16 blocks for (u, q, v); S = 16 + 16 + 4");
   static constexpr int LDT = 18;                                    // leading dimension of the tile scratch (rows 16 bytes aligned, 16 lanes on 16 bank pairs)
-  static constexpr int RECN = ((L::K_FX + NX + 1) / 2) * 2;         // the staged part of the kkt record
-  static constexpr int REC = 0, AUXM = REC + RECN, CPAD = AUXM + NX * NX,      // CPAD: 0, -1, dt, 1 (structural entries of F read like data)
-                       TS = CPAD + 4, RED = TS + 16 * LDT, DIR = RED + 4 * 48, TOTAL = DIR + NX + NQ_ + 4;
-  static_assert(RECN % 2 == 0 && AUXM % 2 == 0 && TS % 2 == 0, "16-byte pieces");
+  static constexpr int QPART = L::K_QUU + NU * NU;                  // Qxx (packed) | Qxu | Quu: the head of the kkt record
+  static constexpr int FPART = L::K_FX + NX - QPART;                // Fqq Fqv Fvq Fvv Fvu | lx lu | Fx: its tail
+  // BUF, by lifetime: aux_mat (NX x NX) -> the Q part of the record -> its F part -> FQ = F Q^-1 parked during the factorisation of S (six
+  // full tiles, 4 doubles per lane, and the three tiles of its rows 32 .. 35, one double per lane) -> the staging area of the output
+  // (84 rows x 16 columns of a column block)
+  static constexpr int NBUF = 6 * 256 + 3 * 64;
+  static_assert(L::K_QXX == 0 && L::K_QXU < L::K_QUU && L::K_FQQ == QPART && QPART % 2 == 0 && FPART % 2 == 0, "record order");
+  static_assert(NX * NX <= NBUF && QPART <= NBUF && FPART <= NBUF && L::NK * 16 <= NBUF, "everything that passes through BUF");
+  static constexpr int BUF = 0, CPAD = BUF + NBUF,      // CPAD: 0, -1, dt, 1 (structural entries of F^T read like data)
+                       TS = CPAD + 4, RED = TS + 16 * LDT, Y2 = RED + 4 * 48, T1 = Y2 + 48, ZZ = T1 + 48, R1 = ZZ + 48, DIR = R1 + NX,
+                       TOTAL = DIR + NX + NQ_ + 4;
+  static_assert(TS % 2 == 0, "16-byte pieces");
 };
 
 // acc += X^T Y over STEPS k-steps of four rows (X, Y in accumulator layout)
@@ -63,7 +74,11 @@ __device__ __forceinline__ wtile pickByGroup(const double (&v)[16], int g) {
   const bool g1 = g & 1, g2 = g & 2;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const double a = g1 ? v[4 * q + 1] : v[4 * q], b = g1 ? v[4 * q + 3] : v[4 * q + 2];
+    // (the four candidates pass through an empty asm: a select between two array elements would otherwise be folded into ONE load with a
+    //  selected address, i.e. a dynamically indexed array, i.e. the whole array in scratch memory)
+    double v0 = v[4 * q], v1 = v[4 * q + 1], v2 = v[4 * q + 2], v3 = v[4 * q + 3];
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+    const double a = g1 ? v1 : v0, b = g1 ? v3 : v2;
     t[q] = g2 ? b : a;
   }
   return t;
@@ -71,27 +86,30 @@ __device__ __forceinline__ wtile pickByGroup(const double (&v)[16], int g) {
 
 // One diagonal block: lane li of every row of 16 lanes holds row li of the SPD 16 x 16 block in a[]; returns W = L^-1 (A = L L^T) in
 // accumulator layout: the lane's right-hand side is the unit vector e_li, forward substitution only (x = column li of L^-1).
-__device__ __forceinline__ wtile cholInvPass16(double (&a)[16], int lane, bool& bad) {
+// NP < 16: the block is [A 0; 0 I] with A NP x NP -- only its NP pivots are walked.
+template <int NP = 16>
+__device__ __forceinline__ wtile cholInvPass16(double (&a)[16], int lane, int& bad) {
   const int li = lane & 15, g = lane >> 4;
   double x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = (k == li) ? 1.0 : 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < NP; ++k) {
     const double p = rowBcastN(a[k], k);
-    bad = bad || !(p > 0.0);
+    bad |= !(p > 0.0);
+    asm volatile("" : "+v"(bad));      // (evaluated here: postponed to the end, the comparison keeps all sixteen pivots alive -- in scratch)
     double is, sq;
     rsqrtNewton(p, is, sq);
     const double lrk = (li == k) ? sq : a[k] * is;
     x[k] *= is;
 #pragma unroll
-    for (int c = k + 1; c < 16; ++c) {
+    for (int c = k + 1; c < NP; ++c) {
       const double lck = rowBcastN(lrk, c);
       a[c] -= lrk * lck;
       x[c] -= lck * x[k];
     }
 #pragma unroll
-    for (int c = k + 1; c < 16; ++c) asm volatile("" : "+v"(x[c]));      // (pins the updates to their step, see choleskySolveRows)
+    for (int c = k + 1; c < NP; ++c) asm volatile("" : "+v"(x[c]), "+v"(a[c]));      // (pins the updates to their step, see choleskySolveRows)
   }
   return pickByGroup(x, g);
 }
@@ -100,51 +118,58 @@ __device__ __forceinline__ wtile cholInvPass16(double (&a)[16], int lane, bool& 
 __host__ __device__ constexpr int U3(int i, int j) { return i == 0 ? j : (i == 1 ? 2 + j : 5); }
 
 template <typename D>
-__global__ __launch_bounds__(64, 1) void parnmpc_kkt_inverse_wave_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = KktWaveSmem<D>;
-  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NQ = S::NQ_, NK = L::NK, LDT = S::LDT;
+  constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NK = L::NK, LDT = S::LDT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  // (uniform values are made scalar by hand: the kernel stores to global memory, so the problem block and the node table are read with
+  //  vector loads, and addresses derived from them would live in vector registers)
+  const int M = __builtin_amdgcn_readfirstlane(P->M);
   const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
-  const long unit = blockIdx.x;
-  const long b = unit / (M - 1);
-  const int pos = (int)(unit - b * (M - 1));
+  const int unit = blockIdx.x;
+  const int bi = unit / (M - 1);
+  const int pos = unit - bi * (M - 1);
+  const long b = bi;
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  if (parnmpcShape<L>(*nd).general) return;
-  const bool last = P->has_terminal && (pos == M - 2);
+  if (__builtin_amdgcn_readfirstlane((int)parnmpcShape<L>(*nd).general)) return;
+  const bool last = __builtin_amdgcn_readfirstlane(P->has_terminal) && (pos == M - 2);
   const double dt = nd->dt;
-  const long rec = b * P->NS + nd->slot;
-  const double* __restrict__ kk = B.kkt + rec * L::KKT;
-  const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
-  double* __restrict__ ki = B.kinv + rec * L::KINV;
+  const int NS = __builtin_amdgcn_readfirstlane(P->NS);
+  const long rec = b * NS + __builtin_amdgcn_readfirstlane(nd->slot);
+  auto uniformPtr = [](const double* p) -> const double* {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const double*>(((unsigned long long)hi << 32) | lo);
+  };
+  const double* __restrict__ kk = uniformPtr(B.kkt + rec * L::KKT);
+  const double* __restrict__ aux = uniformPtr(B.aux + (b * NS + __builtin_amdgcn_readfirstlane(nd->next)) * L::AUX);
+  double* __restrict__ ki = const_cast<double*>(uniformPtr(B.kinv + rec * L::KINV));
+  // six raw tiles of Q^-1 wait here for the end of the kernel (the lin record of the stage: written by K5a, read by K5b<BWD>, dead by now)
+  static_assert(L::LIN >= 6 * 256, "six tiles of scratch per stage");
+  double* __restrict__ scr = const_cast<double*>(uniformPtr(B.lin + rec * L::LIN));
 #ifdef IDOCP_K9_STAMPS      // (diagnostic build: per-phase clock stamps of one wavefront in the middle of the launch)
   const bool stamp = B.prof && blockIdx.x == gridDim.x / 2 + 7 && threadIdx.x == 0;
-#define KSTAMP(k) do { if (stamp) B.prof[k] = wall_clock64(); } while (0)
+#define KSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (stamp) B.prof[k] = wall_clock64(); } while (0)
 #else
-#define KSTAMP(k) do { } while (0)
+#define KSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); } while (0)      // (the phases are not to be interleaved: registers)
 #endif
   KSTAMP(0);
 
-  // ---- the record and aux_mat of the next stage -> LDS, 16 bytes per lane and load ----
-  {
-    constexpr int NR = S::RECN / 2, NA = NX * NX / 2, TR_ = (NR + 63) / 64, TA = (NA + 63) / 64;
-    double2 rv[TR_], av[TA];
+  // ---- everything the stage reads, requested at once, 16 bytes per lane and load: aux_mat of the next stage, the Q part and the F part
+  //      of the kkt record ----
+  constexpr int NA2 = NX * NX / 2, NQ2 = S::QPART / 2, NF2 = S::FPART / 2, TA = (NA2 + 63) / 64, TQ = (NQ2 + 63) / 64, TF = (NF2 + 63) / 64;
+  v2d rvA[TA], rvQ[TQ], rvF[TF];
 #pragma unroll
-    for (int t = 0; t < TR_; ++t) { const int e = lane + 64 * t; rv[t] = reinterpret_cast<const double2*>(kk)[e < NR ? e : NR - 1]; }
+  for (int t = 0; t < TA; ++t) { const int e = lane + 64 * t; rvA[t] = reinterpret_cast<const v2d*>(aux)[e < NA2 ? e : NA2 - 1]; }
 #pragma unroll
-    for (int t = 0; t < TA; ++t) { const int e = lane + 64 * t; av[t] = last ? double2{0.0, 0.0} : reinterpret_cast<const double2*>(aux)[e < NA ? e : NA - 1]; }
+  for (int t = 0; t < TQ; ++t) { const int e = lane + 64 * t; rvQ[t] = reinterpret_cast<const v2d*>(kk)[e < NQ2 ? e : NQ2 - 1]; }
 #pragma unroll
-    for (int t = 0; t < TR_; ++t) { const int e = lane + 64 * t; if (e < NR) reinterpret_cast<double2*>(&sm[S::REC])[e] = rv[t]; }
-#pragma unroll
-    for (int t = 0; t < TA; ++t) { const int e = lane + 64 * t; if (e < NA) reinterpret_cast<double2*>(&sm[S::AUXM])[e] = av[t]; }
-    if (lane == 0) { sm[S::CPAD] = 0.0; sm[S::CPAD + 1] = -1.0; sm[S::CPAD + 2] = dt; sm[S::CPAD + 3] = 1.0; }
-  }
-  waveLdsSync();
-  KSTAMP(1);
+  for (int t = 0; t < TF; ++t) { const int e = lane + 64 * t; rvF[t] = reinterpret_cast<const v2d*>(kk + S::QPART)[e < NF2 ? e : NF2 - 1]; }
+  if (lane == 0) { sm[S::CPAD] = 0.0; sm[S::CPAD + 1] = -1.0; sm[S::CPAD + 2] = dt; sm[S::CPAD + 3] = 1.0; }
 
-  // ---- tile helpers (LDS scratch TS) ----
+  // ---- tile helpers ----
   auto tileToLds = [&](const wtile& t) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) sm[S::TS + (4 * q + g) * LDT + li] = t[q];
@@ -158,161 +183,259 @@ __global__ __launch_bounds__(64, 1) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     waveLdsSync();
     return r;
   };
-  bool bad = false;
-  // A (six upper tiles of an SPD 48 x 48 matrix, destroyed) -> W = L^-1 (six lower tiles, W(i, k) at U3(k, i)) and G = W^T (upper, G(k, i) at U3(k, i))
-  auto cholInv3 = [&](wtile (&A)[6], wtile (&W)[6], wtile (&G)[6]) {
-    wtile R01, R02, R12;
-    // block 0
+  auto rowsOfTile = [&](const wtile& t, double (&a)[16]) {      // lane li of every row of 16 lanes <- row li of the (symmetric) tile
+    tileToLds(t);
+    waveLdsSync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = sm[S::TS + li * LDT + k];
+    waveLdsSync();
+  };
+  int bad = 0;
+  // A (six upper tiles of an SPD 48 x 48 matrix, destroyed) -> W = L^-1 (six lower tiles, W(i, k) at U3(k, i)); np2: pivots of the last block
+  auto cholInv3 = [&](wtile (&A)[6], wtile (&W)[6], auto np2) {
+    wtile R01, R02, R12, Gd;
     {
       double a[16];
-      tileToLds(A[U3(0, 0)]);
-      waveLdsSync();
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = sm[S::TS + li * LDT + k];
-      waveLdsSync();
+      rowsOfTile(A[U3(0, 0)], a);
       W[U3(0, 0)] = cholInvPass16(a, lane, bad);
-      G[U3(0, 0)] = transposeTile(W[U3(0, 0)]);
     }
-    R01 = wzero(); pAcc(R01, G[U3(0, 0)], A[U3(0, 1)]);          // R_0j = W_00 Q_0j  (= L_j0^T)
-    R02 = wzero(); pAcc(R02, G[U3(0, 0)], A[U3(0, 2)]);
+    Gd = transposeTile(W[U3(0, 0)]);
+    R01 = wzero(); pAcc(R01, Gd, A[U3(0, 1)]);          // R_0j = W_00 Q_0j  (= L_j0^T)
+    R02 = wzero(); pAcc(R02, Gd, A[U3(0, 2)]);
     pSub(A[U3(1, 1)], R01, R01);
     pSub(A[U3(1, 2)], R01, R02);
     pSub(A[U3(2, 2)], R02, R02);
-    // block 1
     {
       double a[16];
-      tileToLds(A[U3(1, 1)]);
-      waveLdsSync();
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = sm[S::TS + li * LDT + k];
-      waveLdsSync();
+      rowsOfTile(A[U3(1, 1)], a);
       W[U3(1, 1)] = cholInvPass16(a, lane, bad);
-      G[U3(1, 1)] = transposeTile(W[U3(1, 1)]);
     }
-    R12 = wzero(); pAcc(R12, G[U3(1, 1)], A[U3(1, 2)]);
+    Gd = transposeTile(W[U3(1, 1)]);
+    R12 = wzero(); pAcc(R12, Gd, A[U3(1, 2)]);
     pSub(A[U3(2, 2)], R12, R12);
-    // block 2
+    // W_10 = -W_11 L_10 W_00,  L_im = R_mi^T
+    {
+      wtile T = wzero();
+      pAcc(T, R01, W[U3(0, 0)]);
+      W[U3(0, 1)] = wzero(); pSub(W[U3(0, 1)], Gd, T);
+    }
     {
       double a[16];
-      tileToLds(A[U3(2, 2)]);
-      waveLdsSync();
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = sm[S::TS + li * LDT + k];
-      waveLdsSync();
-      W[U3(2, 2)] = cholInvPass16(a, lane, bad);
-      G[U3(2, 2)] = transposeTile(W[U3(2, 2)]);
+      rowsOfTile(A[U3(2, 2)], a);
+      W[U3(2, 2)] = cholInvPass16<decltype(np2)::value>(a, lane, bad);
     }
-    // off-diagonal blocks of W = L^-1:  W_ik = -W_ii sum_{k <= m < i} L_im W_mk,  L_im = R_mi^T
-    wtile T = wzero();
-    pAcc(T, R01, W[U3(0, 0)]);
-    W[U3(0, 1)] = wzero(); pSub(W[U3(0, 1)], G[U3(1, 1)], T);      // W_10
-    T = wzero();
-    pAcc(T, R12, W[U3(1, 1)]);
-    W[U3(1, 2)] = wzero(); pSub(W[U3(1, 2)], G[U3(2, 2)], T);      // W_21
-    T = wzero();
-    pAcc(T, R02, W[U3(0, 0)]);
-    pAcc(T, R12, W[U3(0, 1)]);
-    W[U3(0, 2)] = wzero(); pSub(W[U3(0, 2)], G[U3(2, 2)], T);      // W_20
-    G[U3(0, 1)] = transposeTile(W[U3(0, 1)]);
-    G[U3(1, 2)] = transposeTile(W[U3(1, 2)]);
-    G[U3(0, 2)] = transposeTile(W[U3(0, 2)]);
+    Gd = transposeTile(W[U3(2, 2)]);
+    {
+      wtile T = wzero();
+      pAcc(T, R12, W[U3(1, 1)]);
+      W[U3(1, 2)] = wzero(); pSub(W[U3(1, 2)], Gd, T);      // W_21
+      T = wzero();
+      pAcc(T, R02, W[U3(0, 0)]);
+      pAcc(T, R12, W[U3(0, 1)]);
+      W[U3(0, 2)] = wzero(); pSub(W[U3(0, 2)], Gd, T);      // W_20
+    }
+  };
+  // parking place of tiles: 4 doubles per lane and slot
+  auto parkTile = [&](int slot, const wtile& t) {
+    reinterpret_cast<v2d*>(&sm[S::BUF + 256 * slot + 4 * lane])[0] = v2d{t[0], t[1]};
+    reinterpret_cast<v2d*>(&sm[S::BUF + 256 * slot + 4 * lane])[1] = v2d{t[2], t[3]};
+  };
+  auto parkedTile = [&](int slot) -> wtile {
+    int o = 4 * lane;
+    asm volatile("" : "+v"(o));      // (every visit is a read of its own: merged into one early read the tiles would live in registers -- in scratch -- after all)
+    const v2d lo = reinterpret_cast<const v2d*>(&sm[S::BUF + 256 * slot + o])[0], hi = reinterpret_cast<const v2d*>(&sm[S::BUF + 256 * slot + o])[1];
+    return wtile{lo.x, lo.y, hi.x, hi.y};
   };
 
-  // ---- Q (order u, q, v; SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next): the six upper tiles ----
-  // entry (r, c) of Q, any order: LDS address in the staged record + the address of its aux_mat term (CPAD[0] = 0 where there is none)
-  auto qEntry = [&](int r, int c) -> double {
-    const int lo = r < c ? r : c, hi = r < c ? c : r;
-    int ad, ax = S::CPAD;
-    if (hi < NU) ad = S::REC + L::K_QUU + lo + NU * hi;
-    else if (lo < NU) ad = S::REC + L::K_QXU + (hi - NU) + NX * lo;
-    else {
-      const int rr = lo - NU, cc = hi - NU;
-      ad = S::REC + L::K_QXX + cc * (cc + 1) / 2 + rr;
-      ax = S::AUXM + rr + NX * cc;
-    }
-    return sm[ad] + sm[ax];
-  };
-  wtile Wq[6], Gq[6];
+  // ---- Q (order u, q, v; SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next): the six upper tiles, gathered from LDS -- first the
+  //      aux_mat terms, then the record's ----
+  wtile Wq[6];
   {
     wtile A[6];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) { const int e = lane + 64 * t; if (e < NA2) reinterpret_cast<v2d*>(&sm[S::BUF])[e] = last ? v2d{0.0, 0.0} : rvA[t]; }
+    waveLdsSync();
+    KSTAMP(1);
 #pragma unroll
     for (int it = 0; it < 3; ++it)
 #pragma unroll
       for (int jt = it; jt < 3; ++jt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) A[U3(it, jt)][q] = qEntry(16 * it + 4 * q + g, 16 * jt + li);
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * it + 4 * q + g, c = 16 * jt + li;
+          const bool xx = r >= NU && c >= NU;
+          const int lo = r < c ? r : c, hi = r < c ? c : r;
+          A[U3(it, jt)][q] = sm[xx ? S::BUF + (lo - NU) + NX * (hi - NU) : S::CPAD];
+        }
+    waveLdsSync();
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) { const int e = lane + 64 * t; if (e < NQ2) reinterpret_cast<v2d*>(&sm[S::BUF])[e] = rvQ[t]; }
+    waveLdsSync();
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int jt = it; jt < 3; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * it + 4 * q + g, c = 16 * jt + li;
+          const int lo = r < c ? r : c, hi = r < c ? c : r;
+          int ad;
+          if (hi < NU) ad = L::K_QUU + lo + NU * hi;
+          else if (lo < NU) ad = L::K_QXU + (hi - NU) + NX * lo;
+          else { const int rr = lo - NU, cc = hi - NU; ad = L::K_QXX + cc * (cc + 1) / 2 + rr; }
+          A[U3(it, jt)][q] += sm[S::BUF + ad];
+        }
+    waveLdsSync();
     KSTAMP(2);
-    cholInv3(A, Wq, Gq);
+    cholInv3(A, Wq, std::integral_constant<int, 16>{});
   }
+  // the F part of the record takes the place of the Q part; r1 = [Fq; Fv] is copied aside (BUF is reused before t1 is formed)
+#pragma unroll
+  for (int t = 0; t < TF; ++t) { const int e = lane + 64 * t; if (e < NF2) reinterpret_cast<v2d*>(&sm[S::BUF])[e] = rvF[t]; }
+  waveLdsSync();
+  if (lane < NX) sm[S::R1 + lane] = sm[S::BUF + (L::K_FX - S::QPART) + lane];
   KSTAMP(3);
 
-  // ---- F^T (48 x 48: columns 0 .. 35 the rows of F = [0 Fqq Fqv; Fvu Fvq Fvv], backward Euler: Fqq = -I, Fqv = dt I outside the base
-  //      blocks; column 36 = r2 = [lu; lx]; the rest zero) ----
-  auto ftEntry = [&](int z, int e) -> double {      // F^T(z, e) = F(e, z)
-    int ad = S::CPAD;                                // 0
-    if (e < NV) {
-      if (z >= NU && z < NU + NV) { const int cq = z - NU; ad = (e < 6 && cq < 6) ? S::REC + L::K_FQQ + e + 6 * cq : ((e >= 6 && e == cq) ? S::CPAD + 1 : S::CPAD); }
-      else if (z >= NU + NV) { const int cv = z - NU - NV; ad = (e < 6 && cv < 6) ? S::REC + L::K_FQV + e + 6 * cv : ((e >= 6 && e == cv) ? S::CPAD + 2 : S::CPAD); }
-    } else if (e < NX) {
-      const int rv = e - NV;
-      if (z < NU) ad = S::REC + L::K_FVU + rv + NV * z;
-      else if (z < NU + NV) ad = S::REC + L::K_FVQ + rv + NV * (z - NU);
-      else ad = S::REC + L::K_FVV + rv + NV * (z - NU - NV);
-    } else if (e == NX) {
-      ad = z < NU ? S::REC + L::K_LU + z : S::REC + L::K_LX + (z - NU);
-    }
-    return sm[ad];
-  };
-  // ---- Y = W F^T = P(G, F^T) and its transposed tiles ----
-  wtile Y[3][3], Yt[3][3];
-  {
-    wtile Ft[3][3];
+  // ---- the output: a column block of C0 / C1 (84 rows x up to 16 columns, ld NK) is put together in BUF and leaves with 16-byte stores,
+  //      64 lanes on 1 kB of consecutive memory.  A tile Z whose entry (row, col) belongs at kinv row r0 + col of the block's column
+  //      c0 + row: ----
+  auto stageTile = [&](const wtile& Z, int r0, int nrow, int c0, int ncol) {
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + 4 * q + g;
+      if (li < nrow && c >= 0 && c < ncol) sm[S::BUF + (r0 + li) + NK * c] = Z[q];
+    }
+  };
+  auto flushBlock = [&](int first_col, int ncol) {
+    waveLdsSync();
+    const int n2 = NK * ncol / 2;
+    v2d* __restrict__ dst = reinterpret_cast<v2d*>(ki + (long)NK * first_col);
+#pragma unroll
+    for (int t = 0; t < (NK * 16 / 2 + 63) / 64; ++t) {
+      const int e = lane + 64 * t;
+      if (e < n2) dst[e] = reinterpret_cast<const v2d*>(&sm[S::BUF])[e];
+    }
+    waveLdsSync();
+  };
+  double pt[3] = {0.0, 0.0, 0.0}, pb[3] = {0.0, 0.0, 0.0};       // top = -N^T z, bottom = W^T y2 + TR^T t1 (split_backward_correction.hxx:30-47)
+
+  // ---- Y = W F^T = P(G, F^T), G(kt, it) = W(it, kt)^T on the fly.  F^T (48 x 48: columns 0 .. 35 the rows of F = [0 Fqq Fqv; Fvu Fvq Fvv],
+  //      backward Euler: Fqq = -I, Fqv = dt I outside the base blocks; column 36 = r2 = [lu; lx]; the rest zero): one block row (three tiles)
+  //      at a time from the staged F part, structural entries from CPAD ----
+  auto ftRow = [&](int kt, wtile (&Fr)[3]) {
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int z = 16 * kt + 4 * q + g, e = 16 * jt + li;
+        int ad = S::CPAD;
+        if (e < NV) {
+          if (z >= NU && z < NU + NV) { const int cq = z - NU; ad = (e < 6 && cq < 6) ? S::BUF - S::QPART + L::K_FQQ + e + 6 * cq : ((e >= 6 && e == cq) ? S::CPAD + 1 : S::CPAD); }
+          else if (z >= NU + NV) { const int cv = z - NU - NV; ad = (e < 6 && cv < 6) ? S::BUF - S::QPART + L::K_FQV + e + 6 * cv : ((e >= 6 && e == cv) ? S::CPAD + 2 : S::CPAD); }
+        } else if (e < NX) {
+          const int rv_ = e - NV;
+          if (z < NU) ad = S::BUF - S::QPART + L::K_FVU + rv_ + NV * z;
+          else if (z < NU + NV) ad = S::BUF - S::QPART + L::K_FVQ + rv_ + NV * (z - NU);
+          else ad = S::BUF - S::QPART + L::K_FVV + rv_ + NV * (z - NU - NV);
+        } else if (e == NX) {
+          ad = z < NU ? S::BUF - S::QPART + L::K_LU + z : S::BUF - S::QPART + L::K_LX + (z - NU);
+        }
+        Fr[jt][q] = sm[ad];
+      }
+  };
+  wtile Sm[6];
+  {
+    wtile Y[3][3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) Y[it][jt] = wzero();
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      wtile Fr[3];
+      ftRow(kt, Fr);
+#pragma unroll
+      for (int it = kt; it < 3; ++it) {
+        const wtile Gt = transposeTile(Wq[U3(kt, it)]);
+#pragma unroll
+        for (int jt = 0; jt < 3; ++jt) pAcc(Y[it][jt], Gt, Fr[jt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    KSTAMP(4);
+    // y2 = W r2 = column 36 of Y
+    if (li == 4) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sm[S::Y2 + 16 * it + 4 * q + g] = Y[it][2][q];
+    }
+    // bottom of the coarse direction, first part: W^T y2 (per lane the terms of its rows; summed over the rows of lanes at the end)
+    waveLdsSync();
+    {
+      double y2v[3][4];
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y2v[it][q] = sm[S::Y2 + 16 * it + 4 * q + g];
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Ft[kt][jt][q] = ftEntry(16 * kt + 4 * q + g, 16 * jt + li);
+        for (int kt = jt; kt < 3; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pb[jt] += Wq[U3(jt, kt)][q] * y2v[kt][q];
+      // (evaluated HERE: the sums are needed at the very end, and the compiler would sink the whole computation -- with y2 and the six tiles of
+      //  W alive, in scratch -- down to there)
+      asm volatile("" : "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Q^-1 = W^T W: the six upper tiles wait in global scratch for the end of the kernel (BR = Q^-1 - Z1^T Z1); 32 bytes per lane, the
+    // wavefront on 2 kB of consecutive memory
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int jt = it; jt < 3; ++jt) {
+        wtile Z = wzero();
+#pragma unroll
+        for (int kt = jt; kt < 3; ++kt) pAcc(Z, Wq[U3(it, kt)], Wq[U3(jt, kt)]);
+        reinterpret_cast<v2d*>(scr + 256 * U3(it, jt))[2 * lane] = v2d{Z[0], Z[1]};
+        reinterpret_cast<v2d*>(scr + 256 * U3(it, jt))[2 * lane + 1] = v2d{Z[2], Z[3]};
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    // FQ = F Q^-1 = Y^T W = P(Y, W) (36 x 48), parked in LDS during the factorisation of S (of its rows 32 .. 47 only 32 .. 35 exist: one
+    // register per lane): slot 3 it + jt
+    waveLdsSync();
 #pragma unroll
     for (int it = 0; it < 3; ++it)
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) {
-        Y[it][jt] = wzero();
+        wtile Z = wzero();
 #pragma unroll
-        for (int kt = 0; kt <= it; ++kt) pAcc(Y[it][jt], Gq[U3(kt, it)], Ft[kt][jt]);
+        for (int kt = jt; kt < 3; ++kt) pAcc(Z, Y[kt][it], Wq[U3(jt, kt)]);
+        if (it < 2) parkTile(3 * it + jt, Z);
+        else sm[S::BUF + 6 * 256 + 64 * jt + lane] = Z[0];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    // S = P(Y, Y) (upper tiles); column 36 = F Q^-1 r2
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int jt = it; jt < 3; ++jt) {
+        Sm[U3(it, jt)] = wzero();
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) pAcc(Sm[U3(it, jt)], Y[kt][it], Y[kt][jt]);
       }
   }
-  KSTAMP(4);
-  // y2 = W r2 = column 36 of Y, as a vector over the rows (every lane of a row of 16 holds the entries of its rows 4 q + g)
-  double y2v[3][4];
+  // t1 = r1 - F Q^-1 r2 (zero beyond row 35), from the lanes that hold column 36 of S
+  if (li == 4) {
 #pragma unroll
-  for (int it = 0; it < 3; ++it)
+    for (int it = 0; it < 3; ++it)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) y2v[it][q] = rowBcast<4>(Y[it][2][q]);
-  // ---- S = P(Y, Y) (upper tiles); column 36 = F Q^-1 r2 ----
-  wtile Sm[6];
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int jt = it; jt < 3; ++jt) {
-      Sm[U3(it, jt)] = wzero();
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) pAcc(Sm[U3(it, jt)], Y[kt][it], Y[kt][jt]);
-    }
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int jt = 0; jt < 3; ++jt) Yt[jt][it] = transposeTile(Y[it][jt]);
-  // t1 = r1 - F Q^-1 r2 over the rows (zero beyond row 35)
-  double t1v[3][4];
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = 16 * it + 4 * q + g;
-      const double s36 = rowBcast<4>(Sm[U3(it, 2)][q]);
-      t1v[it][q] = row < NX ? sm[S::REC + L::K_FX + (row < NX ? row : 0)] - s36 : 0.0;
-    }
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * it + 4 * q + g;
+        sm[S::T1 + row] = row < NX ? sm[S::R1 + (row < NX ? row : 0)] - Sm[U3(it, 2)][q] : 0.0;
+      }
+  }
   // the padding of S: rows / columns 36 .. 47 = identity
 #pragma unroll
   for (int it = 0; it < 3; ++it)
@@ -321,77 +444,19 @@ __global__ __launch_bounds__(64, 1) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
       const int row = 16 * it + 4 * q + g, col = 32 + li;
       if (col >= NX || row >= NX) Sm[U3(it, 2)][q] = (row == col) ? 1.0 : 0.0;
     }
-  wtile Ns[6], Hs[6];
+  wtile Ns[6];
   KSTAMP(5);
-  cholInv3(Sm, Ns, Hs);
+  cholInv3(Sm, Ns, std::integral_constant<int, NX - 32>{});
   KSTAMP(6);
+  waveLdsSync();
+  double t1v[3][4];
+#pragma unroll
+  for (int it = 0; it < 3; ++it)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t1v[it][q] = sm[S::T1 + 16 * it + 4 * q + g];
 
-  // ---- V = Y N^T = P(Y^T, H) (48 x 36): contraction over the 36 rows of H (tile row 2: one k-step) ----
-  wtile V[3][3];
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int jt = 0; jt < 3; ++jt) {
-      V[it][jt] = wzero();
-#pragma unroll
-      for (int kt = 0; kt <= jt; ++kt) {
-        if (kt < 2) pAcc<4>(V[it][jt], Yt[kt][it], Hs[U3(kt, jt)]);
-        else pAcc<1>(V[it][jt], Yt[kt][it], Hs[U3(kt, jt)]);
-      }
-    }
-  // ---- U^T = P(V, W) (36 x 48): contraction over 48 ----
-  wtile Ut[3][3];
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int jt = 0; jt < 3; ++jt) {
-      Ut[it][jt] = wzero();
-#pragma unroll
-      for (int kt = jt; kt < 3; ++kt) pAcc(Ut[it][jt], V[kt][it], Wq[U3(jt, kt)]);
-    }
-  // ---- TR = S^-1 F Q^-1 = P(N, U^T) (36 x 48): contraction over 36 ----
-  wtile TRm[3][3];
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int jt = 0; jt < 3; ++jt) {
-      TRm[it][jt] = wzero();
-#pragma unroll
-      for (int kt = it; kt < 3; ++kt) {
-        if (kt < 2) pAcc<4>(TRm[it][jt], Ns[U3(it, kt)], Ut[kt][jt]);
-        else pAcc<1>(TRm[it][jt], Ns[U3(it, kt)], Ut[kt][jt]);
-      }
-    }
-
-  KSTAMP(7);
-  // ---- stores.  A tile Z whose entry (row, col) belongs at kinv row r0 + col, kinv column c0 + row of a column block (ld NK): 16 lanes of a
-  //      row of the wavefront write 128 consecutive bytes ----
-  auto storeTile = [&](const wtile& Z, double* __restrict__ blk, int r0, int nrow, int c0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = c0 + 4 * q + g;
-      if (li < nrow && c >= 0 && c < NX) blk[r0 + li + NK * c] = Z[q];
-    }
-  };
-  double* __restrict__ C0 = ki + L::I_C0;
-  double* __restrict__ C1 = ki + L::I_C1;
-  // C0 rows 36 .. 83: TR^T, i.e. entry (36 + rho, kappa) = TR(kappa, rho): tile (a, b) of TR as it is
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) storeTile(TRm[a][bb], C0, NX + 16 * bb, 16, 16 * a);
-  // C1 rows 0 .. 35: TR(:, NU:), entry (rho, kappa) = TR(rho, NU + kappa): the transposed tiles
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      const wtile Z = transposeTile(TRm[bb][a]);
-      storeTile(Z, C1, 16 * bb, NX - 16 * bb, 16 * a - NU);
-    }
-  KSTAMP(8);
-  // ---- the coarse direction (split_backward_correction.hxx:30-47): top = -S^-1 t1, bottom = W^T y2 + TR^T t1.  A product M^T x
-  //      contracts over the rows of accumulator-layout tiles: per lane the terms of its rows, then the four rows of 16 lanes are summed
-  //      through LDS ----
+  // ---- Z1 = N FQ = P(H, FQ) (36 x 48), H(kt, it) = N(it, kt)^T on the fly; z = N t1 = H^T t1 on the way (a product M^T x contracts over the
+  //      rows of accumulator-layout tiles: per lane the terms of its rows, then the four rows of 16 lanes are summed through LDS) ----
   auto reduceRows = [&](const double (&p)[3], double* out) {       // out[0 .. 47] = sum over the rows of lanes
 #pragma unroll
     for (int jt = 0; jt < 3; ++jt) sm[S::RED + 48 * g + 16 * jt + li] = p[jt];
@@ -399,104 +464,136 @@ __global__ __launch_bounds__(64, 1) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     if (lane < 48) out[lane] = (sm[S::RED + lane] + sm[S::RED + 48 + lane]) + (sm[S::RED + 96 + lane] + sm[S::RED + 144 + lane]);
     waveLdsSync();
   };
-  double* dir = &sm[S::DIR];                 // dlmd dgmm | du dq dv
+  wtile Z1[3][3];
   {
-    // z = N t1 = H^T t1
     double p[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int jt = 0; jt < 3; ++jt)
+    for (int it = 0; it < 3; ++it) {
 #pragma unroll
-      for (int kt = 0; kt <= jt; ++kt)
+      for (int jt = 0; jt < 3; ++jt) Z1[it][jt] = wzero();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p[jt] += Hs[U3(kt, jt)][q] * t1v[kt][q];
-    double* zz = &sm[S::DIR + NX];           // (scratch: the bottom of dir is written last)
-    reduceRows(p, zz);
-    double zv[3][4];
+      for (int kt = 0; kt <= it; ++kt) {
+        const wtile Ht = transposeTile(Ns[U3(kt, it)]);
 #pragma unroll
-    for (int it = 0; it < 3; ++it)
+        for (int q = 0; q < 4; ++q) p[it] += Ht[q] * t1v[kt][q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int row = 16 * it + 4 * q + g; zv[it][q] = row < NX ? zz[row] : 0.0; }
-    waveLdsSync();
-    // top = -N^T z
-    double pt[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int jt = 0; jt < 3; ++jt)
-#pragma unroll
-      for (int kt = jt; kt < 3; ++kt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pt[jt] -= Ns[U3(jt, kt)][q] * zv[kt][q];
-    double* tmp = &sm[S::DIR + NX];
-    reduceRows(pt, tmp);
-    if (lane < NX) dir[lane] = tmp[lane];
-    waveLdsSync();
-    // bottom = W^T y2 + TR^T t1
-    double pb[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int jt = 0; jt < 3; ++jt) {
-#pragma unroll
-      for (int kt = jt; kt < 3; ++kt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pb[jt] += Wq[U3(jt, kt)][q] * y2v[kt][q];
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pb[jt] += TRm[kt][jt][q] * t1v[kt][q];
-    }
-    reduceRows(pb, &sm[S::DIR + NX]);
-  }
-
-  KSTAMP(9);
-  // ---- TL = -S^-1 = -P(N, N) (36 x 36; C0 rows 0 .. 35, symmetric: lower tiles are the transposed upper ones) ----
-#pragma unroll
-  for (int it = 0; it < 3; ++it)
-#pragma unroll
-    for (int jt = it; jt < 3; ++jt) {
-      wtile Z = wzero();
-#pragma unroll
-      for (int kt = jt; kt < 3; ++kt) {
-        if (kt < 2) pSub<4>(Z, Ns[U3(it, kt)], Ns[U3(jt, kt)]);
-        else pSub<1>(Z, Ns[U3(it, kt)], Ns[U3(jt, kt)]);
+        for (int jt = 0; jt < 3; ++jt) {
+          if (kt < 2) pAcc<4>(Z1[it][jt], Ht, parkedTile(3 * kt + jt));
+          else pAcc<1>(Z1[it][jt], Ht, wtile{sm[S::BUF + 6 * 256 + 64 * jt + lane], 0.0, 0.0, 0.0});
+        }
       }
-      // entry (rho, kappa) = TL(rho, kappa) = TL(kappa, rho): the tile (a, b) = (it, jt) goes to rows 16 b + col, columns 16 a + row
-      storeTile(Z, C0, 16 * jt, NX - 16 * jt, 16 * it);
-      if (jt > it) { const wtile Zt = transposeTile(Z); storeTile(Zt, C0, 16 * it, 16, 16 * jt); }
+      __builtin_amdgcn_sched_barrier(0);
     }
-  // ---- BR(:, NU:) = (W^T W - U U^T)(:, NU:) (48 x 36; C1 rows 36 .. 83): entry (36 + rho, kappa) = BR(NU + kappa, rho) ----
+    reduceRows(p, &sm[S::ZZ]);
+  }
+  double zv[3][4];
 #pragma unroll
   for (int it = 0; it < 3; ++it)
 #pragma unroll
-    for (int jt = it; jt < 3; ++jt) {
+    for (int q = 0; q < 4; ++q) { const int row = 16 * it + 4 * q + g; zv[it][q] = row < NX ? sm[S::ZZ + row] : 0.0; }
+  // top of the coarse direction: -N^T z
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+    for (int kt = jt; kt < 3; ++kt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pt[jt] -= Ns[U3(jt, kt)][q] * zv[kt][q];
+  asm volatile("" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
+  KSTAMP(7);
+
+  // the iterate of the stage, requested before the output stores queue up in front of it
+  const double* __restrict__ s = B.sol + rec * L::SOL;
+  const int lv = lane < NV ? lane : 0;
+  const double s_lmd = s[L::S_LMD + lv], s_gmm = s[L::S_GMM + lv], s_v = s[L::S_V + lv], s_q = s[L::S_Q + lv + 1], s_u = s[L::S_U + (lane & 15)];
+  double s_qb[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) s_qb[k] = s[L::S_Q + k];
+  // ---- C0 = [TL; TR^T], TL = -S^-1 = -N^T N, TR = S^-1 F Q^-1 = N^T Z1, one block of columns a (rows a of S) at a time: kinv entry
+  //      (rho, kappa) = TL(kappa, rho) for rho < 36, TR(kappa, rho - 36) below -- the tiles (a, b) as they are ----
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    constexpr int dummy = 0; (void)dummy;
+    const int ncol = a < 2 ? 16 : NX - 32;
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
       wtile Z = wzero();
 #pragma unroll
-      for (int kt = jt; kt < 3; ++kt) pAcc(Z, Wq[U3(it, kt)], Wq[U3(jt, kt)]);
+      for (int kt = (a > bb ? a : bb); kt < 3; ++kt) {
+        if (kt < 2) pSub<4>(Z, Ns[U3(a, kt)], Ns[U3(bb, kt)]);
+        else pSub<1>(Z, Ns[U3(a, kt)], Ns[U3(bb, kt)]);
+      }
+      stageTile(Z, 16 * bb, NX - 16 * bb, 0, ncol);
+      wtile R = wzero();
+#pragma unroll
+      for (int kt = a; kt < 3; ++kt) {
+        if (kt < 2) pAcc<4>(R, Ns[U3(a, kt)], Z1[kt][bb]);
+        else pAcc<1>(R, Ns[U3(a, kt)], Z1[kt][bb]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pb[bb] += R[q] * t1v[a][q];
+      asm volatile("" : "+v"(pb[bb]));
+      stageTile(R, NX + 16 * bb, 16, 0, ncol);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    flushBlock(L::I_C0 / NK + 16 * a, ncol);
+  }
+  KSTAMP(8);
+  // ---- C1 = [TR(:, NU:); BR(:, NU:)], BR = Q^-1 - Z1^T Z1, one block of columns a (columns 16 a .. of (u, q, v), of which 12 .. exist) at a
+  //      time: kinv entry (rho, kappa) = TR(rho, NU + kappa) for rho < 36 -- the tile (a, b) of TR^T = Z1^T N --, BR(NU + kappa, rho - 36) below ----
+  static_assert(L::I_C0 % NK == 0 && L::I_C1 % NK == 0, "column blocks of the record");
+  // (the tiles of Q^-1 this wavefront stored earlier: same lanes, same addresses, never in this CU's L1 before -- the stores only have to be
+  //  complete, no cache maintenance: an agent-scope fence here writes the L2 back and cost 90 us under load)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int c0 = a == 0 ? -NU : 0;                         // the block's first column is max(0, 16 a - NU) of C1
+    const int first = a == 0 ? 0 : 16 * a - NU, ncol = a == 0 ? 16 - NU : 16;
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      wtile R = wzero();                                     // TR^T(a, b) = sum_kt Z1(kt, a)^T N(kt, b), kt >= b
+#pragma unroll
+      for (int kt = bb; kt < 3; ++kt) {
+        if (kt < 2) pAcc<4>(R, Z1[kt][a], Ns[U3(bb, kt)]);
+        else pAcc<1>(R, Z1[kt][a], Ns[U3(bb, kt)]);
+      }
+      stageTile(R, 16 * bb, NX - 16 * bb, c0, ncol);
+      // BR(a, b): Q^-1(a, b) from the scratch (the transposed tile below the diagonal)
+      const int tq = a <= bb ? U3(a, bb) : U3(bb, a);
+      const v2d lo = reinterpret_cast<const v2d*>(scr + 256 * tq)[2 * lane], hi = reinterpret_cast<const v2d*>(scr + 256 * tq)[2 * lane + 1];
+      wtile Z = wtile{lo.x, lo.y, hi.x, hi.y};
+      if (a > bb) Z = transposeTile(Z);
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt) {
-        if (kt < 2) pSub<4>(Z, Ut[kt][it], Ut[kt][jt]);
-        else pSub<1>(Z, Ut[kt][it], Ut[kt][jt]);
+        if (kt < 2) pSub<4>(Z, Z1[kt][a], Z1[kt][bb]);
+        else pSub<1>(Z, Z1[kt][a], Z1[kt][bb]);
       }
-      storeTile(Z, C1, NX + 16 * jt, 16, 16 * it - NU);
-      if (jt > it) { const wtile Zt = transposeTile(Z); storeTile(Zt, C1, NX + 16 * it, 16, 16 * jt - NU); }
+      stageTile(Z, NX + 16 * bb, 16, c0, ncol);
+      __builtin_amdgcn_sched_barrier(0);
     }
-
+    flushBlock(L::I_C1 / NK + first, ncol);
+  }
   KSTAMP(10);
-  // ---- s_new = s - direction (split_backward_correction.hxx:49-58) ----
-  const double* __restrict__ s = B.sol + rec * L::SOL;
+  // ---- the coarse direction and s_new = s - direction (split_backward_correction.hxx:30-58) ----
+  double* dir = &sm[S::DIR];                 // dlmd dgmm | du dq dv
+  reduceRows(pt, &sm[S::ZZ]);
+  if (lane < NX) dir[lane] = sm[S::ZZ + lane];
+  reduceRows(pb, dir + NX);
   double* __restrict__ sn = B.snew + rec * L::SNEW;
   if (lane < NV) {
-    sn[L::N_LMD + lane] = s[L::S_LMD + lane] - dir[lane];
-    sn[L::N_GMM + lane] = s[L::S_GMM + lane] - dir[NV + lane];
-    sn[L::N_V + lane] = s[L::S_V + lane] - dir[NX + NU + NV + lane];
-    if (lane >= 6) sn[L::N_Q + lane + 1] = s[L::S_Q + lane + 1] - dir[NX + NU + lane];
+    sn[L::N_LMD + lane] = s_lmd - dir[lane];
+    sn[L::N_GMM + lane] = s_gmm - dir[NV + lane];
+    sn[L::N_V + lane] = s_v - dir[NX + NU + NV + lane];
+    if (lane >= 6) sn[L::N_Q + lane + 1] = s_q - dir[NX + NU + lane];
   }
-  if (lane >= 32 && lane < 32 + NU) sn[L::N_U + lane - 32] = s[L::S_U + lane - 32] - dir[NX + lane - 32];
+  if (lane >= 32 && lane < 32 + NU) sn[L::N_U + lane - 32] = s_u - dir[NX + lane - 32];
   if (lane == 63) {
     double qn[7];
-    lieIntegrateBase(s + L::S_Q, dir + NX + NU, -1.0, qn);
+    lieIntegrateBase(s_qb, dir + NX + NU, -1.0, qn);
     for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
   }
   KSTAMP(11);
 #undef KSTAMP
-  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0 && B.status[b] == 0) B.status[b] = 1000 + pos;
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && lane == 0 && B.status[b] == 0) B.status[b] = 1000 + pos;
 }
 
 template <typename D>
