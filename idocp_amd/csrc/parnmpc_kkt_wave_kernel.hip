@@ -498,16 +498,45 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     for (int kt = jt; kt < 3; ++kt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) pt[jt] -= Ns[U3(jt, kt)][q] * zv[kt][q];
-  asm volatile("" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
+  // bottom, second part: TR^T t1 = Z1^T N t1 = Z1^T z
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pb[jt] += Z1[kt][jt][q] * zv[kt][q];
+  // ---- the coarse direction and s_new = s - direction (split_backward_correction.hxx:30-58), in front of the output: its loads and stores
+  //      do not queue behind 48 kB of stores ----
+  {
+    double* dir = &sm[S::DIR];                 // dlmd dgmm | du dq dv
+    reduceRows(pt, &sm[S::ZZ]);
+    if (lane < NX) dir[lane] = sm[S::ZZ + lane];
+    reduceRows(pb, dir + NX);
+    const double* __restrict__ s = B.sol + rec * L::SOL;
+    double* __restrict__ sn = B.snew + rec * L::SNEW;
+    if (lane < NV) {
+      sn[L::N_LMD + lane] = s[L::S_LMD + lane] - dir[lane];
+      sn[L::N_GMM + lane] = s[L::S_GMM + lane] - dir[NV + lane];
+      sn[L::N_V + lane] = s[L::S_V + lane] - dir[NX + NU + NV + lane];
+      if (lane >= 6) sn[L::N_Q + lane + 1] = s[L::S_Q + lane + 1] - dir[NX + NU + lane];
+    }
+    if (lane >= 32 && lane < 32 + NU) sn[L::N_U + lane - 32] = s[L::S_U + lane - 32] - dir[NX + lane - 32];
+    if (lane == 63) {
+      double qn[7];
+      lieIntegrateBase(s + L::S_Q, dir + NX + NU, -1.0, qn);
+      for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
+    }
+  }
+  // Q^-1: the six raw tiles come back from the scratch while C0 is put together
+  wtile Qi[6];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (stored by these very lanes, never in this CU's L1 before: the stores only have to be complete)
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const v2d lo = reinterpret_cast<const v2d*>(scr + 256 * t)[2 * lane], hi = reinterpret_cast<const v2d*>(scr + 256 * t)[2 * lane + 1];
+    Qi[t] = wtile{lo.x, lo.y, hi.x, hi.y};
+  }
   KSTAMP(7);
 
-  // the iterate of the stage, requested before the output stores queue up in front of it
-  const double* __restrict__ s = B.sol + rec * L::SOL;
-  const int lv = lane < NV ? lane : 0;
-  const double s_lmd = s[L::S_LMD + lv], s_gmm = s[L::S_GMM + lv], s_v = s[L::S_V + lv], s_q = s[L::S_Q + lv + 1], s_u = s[L::S_U + (lane & 15)];
-  double s_qb[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) s_qb[k] = s[L::S_Q + k];
   // ---- C0 = [TL; TR^T], TL = -S^-1 = -N^T N, TR = S^-1 F Q^-1 = N^T Z1, one block of columns a (rows a of S) at a time: kinv entry
   //      (rho, kappa) = TL(kappa, rho) for rho < 36, TR(kappa, rho - 36) below -- the tiles (a, b) as they are ----
 #pragma unroll
@@ -529,9 +558,6 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
         if (kt < 2) pAcc<4>(R, Ns[U3(a, kt)], Z1[kt][bb]);
         else pAcc<1>(R, Ns[U3(a, kt)], Z1[kt][bb]);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pb[bb] += R[q] * t1v[a][q];
-      asm volatile("" : "+v"(pb[bb]));
       stageTile(R, NX + 16 * bb, 16, 0, ncol);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -541,9 +567,6 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
   // ---- C1 = [TR(:, NU:); BR(:, NU:)], BR = Q^-1 - Z1^T Z1, one block of columns a (columns 16 a .. of (u, q, v), of which 12 .. exist) at a
   //      time: kinv entry (rho, kappa) = TR(rho, NU + kappa) for rho < 36 -- the tile (a, b) of TR^T = Z1^T N --, BR(NU + kappa, rho - 36) below ----
   static_assert(L::I_C0 % NK == 0 && L::I_C1 % NK == 0, "column blocks of the record");
-  // (the tiles of Q^-1 this wavefront stored earlier: same lanes, same addresses, never in this CU's L1 before -- the stores only have to be
-  //  complete, no cache maintenance: an agent-scope fence here writes the L2 back and cost 90 us under load)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int c0 = a == 0 ? -NU : 0;                         // the block's first column is max(0, 16 a - NU) of C1
@@ -558,9 +581,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
       }
       stageTile(R, 16 * bb, NX - 16 * bb, c0, ncol);
       // BR(a, b): Q^-1(a, b) from the scratch (the transposed tile below the diagonal)
-      const int tq = a <= bb ? U3(a, bb) : U3(bb, a);
-      const v2d lo = reinterpret_cast<const v2d*>(scr + 256 * tq)[2 * lane], hi = reinterpret_cast<const v2d*>(scr + 256 * tq)[2 * lane + 1];
-      wtile Z = wtile{lo.x, lo.y, hi.x, hi.y};
+      wtile Z = Qi[a <= bb ? U3(a, bb) : U3(bb, a)];
       if (a > bb) Z = transposeTile(Z);
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt) {
@@ -573,24 +594,6 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     flushBlock(L::I_C1 / NK + first, ncol);
   }
   KSTAMP(10);
-  // ---- the coarse direction and s_new = s - direction (split_backward_correction.hxx:30-58) ----
-  double* dir = &sm[S::DIR];                 // dlmd dgmm | du dq dv
-  reduceRows(pt, &sm[S::ZZ]);
-  if (lane < NX) dir[lane] = sm[S::ZZ + lane];
-  reduceRows(pb, dir + NX);
-  double* __restrict__ sn = B.snew + rec * L::SNEW;
-  if (lane < NV) {
-    sn[L::N_LMD + lane] = s_lmd - dir[lane];
-    sn[L::N_GMM + lane] = s_gmm - dir[NV + lane];
-    sn[L::N_V + lane] = s_v - dir[NX + NU + NV + lane];
-    if (lane >= 6) sn[L::N_Q + lane + 1] = s_q - dir[NX + NU + lane];
-  }
-  if (lane >= 32 && lane < 32 + NU) sn[L::N_U + lane - 32] = s_u - dir[NX + lane - 32];
-  if (lane == 63) {
-    double qn[7];
-    lieIntegrateBase(s_qb, dir + NX + NU, -1.0, qn);
-    for (int k = 0; k < 7; ++k) sn[L::N_Q + k] = qn[k];
-  }
   KSTAMP(11);
 #undef KSTAMP
   if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && lane == 0 && B.status[b] == 0) B.status[b] = 1000 + pos;
