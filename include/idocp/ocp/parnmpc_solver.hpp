@@ -30,9 +30,10 @@ class ParNMPCSolver {
  public:
   ParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
                 const double T, const int N, const int max_num_impulse = 0, const int nthreads = 1, const int device = 0)
-      : robot_(robot), N_(N), h_(nullptr), comm_(nullptr) {
+      : robot_(robot), N_(N), h_(nullptr), comm_(nullptr), cost_(cost) {
     (void)nthreads;
     const idocp_cost_t c = cost->native();
+    last_cost_ = c;
     const idocp_constraints_t k = constraints->native();
     if (max_num_impulse > 0) check(idocp_parnmpc_create_hybrid(&robot.model(), &c, &k, T, N, max_num_impulse, 1, device, &h_));
     else check(idocp_parnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
@@ -44,8 +45,9 @@ class ParNMPCSolver {
   // loops over one horizon, backward_correction_solver.cpp:255-366).  getSolution returns the local stages.
   ParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
                 const double T, const int N, idocp_comm_t* comm, const int max_num_impulse = 0, const int device = 0)
-      : robot_(robot), N_(N), h_(nullptr), comm_(comm) {
+      : robot_(robot), N_(N), h_(nullptr), comm_(comm), cost_(cost) {
     const idocp_cost_t c = cost->native();
+    last_cost_ = c;
     const idocp_constraints_t k = constraints->native();
     const int rank = idocp_comm_rank(comm), world = idocp_comm_world(comm);
     if (world < 1 || N % world != 0) { std::cerr << "invalid value: N must be divisible by the number of ranks!\n"; std::exit(EXIT_FAILURE); }
@@ -60,7 +62,7 @@ class ParNMPCSolver {
   ~ParNMPCSolver() { if (comm_) idocp_parnmpc_dist_detach(h_); idocp_ocp_destroy(h_); }
   // copyable and movable like the reference class (a copy is a deep copy of the device state; a sharded solver is bound to its
   // communicator and can only be moved)
-  ParNMPCSolver(const ParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), comm_(nullptr) {
+  ParNMPCSolver(const ParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), comm_(nullptr), cost_(other.cost_), last_cost_(other.last_cost_) {
     if (other.comm_) { std::cerr << "a sharded ParNMPCSolver cannot be copied\n"; std::exit(EXIT_FAILURE); }
     if (other.h_) check(idocp_ocp_clone(other.h_, &h_));
   }
@@ -68,14 +70,16 @@ class ParNMPCSolver {
     if (this != &other) {
       if (other.comm_ || comm_) { std::cerr << "a sharded ParNMPCSolver cannot be copied\n"; std::exit(EXIT_FAILURE); }
       idocp_ocp_t* n = nullptr; if (other.h_) check(idocp_ocp_clone(other.h_, &n)); idocp_ocp_destroy(h_); h_ = n; robot_ = other.robot_; N_ = other.N_;
+      cost_ = other.cost_; last_cost_ = other.last_cost_;
     }
     return *this;
   }
-  ParNMPCSolver(ParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), comm_(other.comm_), kkt_error_(other.kkt_error_) { other.h_ = nullptr; other.comm_ = nullptr; }
+  ParNMPCSolver(ParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), comm_(other.comm_), cost_(std::move(other.cost_)), last_cost_(other.last_cost_), kkt_error_(other.kkt_error_) { other.h_ = nullptr; other.comm_ = nullptr; }
   ParNMPCSolver& operator=(ParNMPCSolver&& other) noexcept {
     if (this != &other) {
       idocp_ocp_destroy(h_);                 // (drops this solver's own attachment, if any)
       h_ = other.h_; comm_ = other.comm_; robot_ = other.robot_; N_ = other.N_; kkt_error_ = other.kkt_error_;
+      cost_ = std::move(other.cost_); last_cost_ = other.last_cost_;
       other.h_ = nullptr; other.comm_ = nullptr;
     }
     return *this;
@@ -88,6 +92,7 @@ class ParNMPCSolver {
   }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    syncCost();
     if (comm_) {
       if (line_search) { std::cerr << "line_search=true is not supported on a sharded horizon\n"; std::exit(EXIT_FAILURE); }
       if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
@@ -167,6 +172,7 @@ class ParNMPCSolver {
     return e;
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    syncCost();
     if (comm_) {
       if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
       check(idocp_parnmpc_dist_kkt_error(h_, t, &kkt_error_));
@@ -181,7 +187,16 @@ class ParNMPCSolver {
   int N_;
   idocp_ocp_t* h_;
   idocp_comm_t* comm_ = nullptr;      // not owned
+  // the cost object is shared with the caller (as in the reference, whose solver keeps the shared_ptr): weights edited through it after
+  // construction reach the device with the next call (idocp_ocp_set_cost)
+  std::shared_ptr<CostFunction> cost_;
+  idocp_cost_t last_cost_{};
   double kkt_error_ = 0.0;
+  void syncCost() {
+    if (!cost_ || !h_) return;
+    const idocp_cost_t c = cost_->native();
+    if (std::memcmp(&c, &last_cost_, sizeof(c)) != 0) { check(idocp_ocp_set_cost(h_, &c)); last_cost_ = c; }
+  }
   mutable std::vector<SplitSolution> cache_;
   static void check(int rc) {
     if (rc != IDOCP_OK) {
