@@ -589,17 +589,20 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
             alg_bytes = A_STAGE["anymal_parnmpc"] * B * (Nl + (2 * (n_events - 1) + 1 if trot else 0))
             achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
             traffic = None
+            traffic_source = None
             import glob
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
                 try:
                     rec = json.load(open(pmc))
                     if rec.get("batch") == B and rec.get("horizon") == N:
-                        traffic = rec.get("hbm_bytes_per_launch", {}).get(dom)
+                        hb = rec.get("hbm_bytes_per_launch", {})
+                        traffic = hb.get(dom, hb.get(dom + "_wave"))
+                        traffic_source = "quoted from profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" % os.path.basename(pmc)
                         break
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_ms": ker[dom],
                                "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world}
         if not args.no_cpu_baseline and world == 1 and not trot:
@@ -848,6 +851,7 @@ def main():
     alg_bytes = a_stage * units[dom]
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
     traffic = None
+    traffic_source = None
     # HBM bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and
     # WRITE_SIZE in separate passes, gfx950 correction applied) by profiles/run_profiles.sh; only quoted
     # when the committed record was taken on this very workload / batch / horizon.
@@ -857,6 +861,7 @@ def main():
             rec = json.load(open(pmc))
             if rec.get("batch") == B and rec.get("horizon") == N and rec.get("workload", "iiwa14") == args.workload:
                 traffic = rec.get("hbm_bytes_per_launch", {}).get(KERNELS[dom])
+                traffic_source = "quoted from profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" % os.path.basename(pmc)
                 break
         except Exception:
             traffic = None
@@ -880,7 +885,7 @@ def main():
                        "kernel_ms": {KERNELS[i]: float(kms[i]) for i in range(len(KERNELS))},
                        "max_kkt_error_after": float(np.max(kkt)), "latency": latency},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kms[dom]),
                          # the whole iteration's compulsory bytes over the whole step: one unit per stage of the CHAIN (event stages
                          # included -- 120 for the default workload, not N + 1 = 101), i.e. the largest per-launch unit count
