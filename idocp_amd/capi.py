@@ -213,6 +213,10 @@ def _proto(lib):
     lib.idocp_ocp_pop_front_contact_status.restype = ci
     lib.idocp_ocp_get_chain.argtypes = [vp, cd, ci, P(ci), P(ci), P(ci), vp, P(ci), P(ci)]
     lib.idocp_ocp_get_chain.restype = ci
+    lib.idocp_ocp_get_chain_times.argtypes = [vp, cd, ci, vp]
+    lib.idocp_ocp_get_chain_times.restype = ci
+    lib.idocp_ocp_set_task_refs.argtypes = [vp, cd, ci, vp]
+    lib.idocp_ocp_set_task_refs.restype = ci
     lib.idocp_ocp_get_solution_chain.argtypes = [vp, cs, ci, vp]
     lib.idocp_ocp_get_solution_chain.restype = ci
     lib.idocp_ocp_get_direction_chain.argtypes = [vp, cs, ci, vp]

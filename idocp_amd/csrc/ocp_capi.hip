@@ -93,7 +93,11 @@ struct idocp_ocp {
   OcpProblem prob;
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;   // parallel to allocs (idocp_ocp_clone copies buffer by buffer)
-  double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr, *d_qref = nullptr;
+  double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr, *d_qref = nullptr, *d_taskref = nullptr;
+  std::vector<double> task_refs_host;      // idocp_ocp_set_task_refs: [M][12] for the chain discretised at task_refs_t
+  double task_refs_t = 0.0;
+  bool task_refs_lenient = false;          // creation, clone and the chain getters discretise without poses (constant pose in the table)
+  bool task_refs_stale = false;            // ... and leave the table to be redone by the next strict discretisation
   void* d_prob = nullptr;
   OcpNode* d_nodes = nullptr;
   bool contact_status_set = false;
@@ -206,8 +210,33 @@ void fillStatus(OcpNode& nd, const HostStatus& st) {
 // order.  Host-side index logic, re-run only when the initial time or the contact sequence changes.
 int discretizeParNMPC(idocp_ocp* h, double t);
 
+// Reference poses of the task-space cost for the M stages of the chain just built: the constant pose of the cost, or -- TimeVarying
+// variants -- the poses the caller evaluated at the stage times (idocp_ocp_get_chain_times -> idocp_ocp_set_task_refs).
+static int uploadTaskRefs(idocp_ocp* h, double t, int M) {
+  if (h->cost.task_dim == 0) return IDOCP_OK;
+  std::vector<double> tab((size_t)M * 12);
+  if (h->cost.task_time_varying) {
+    if (h->task_refs_host.size() != (size_t)M * 12 || h->task_refs_t != t) {
+      if (!h->task_refs_lenient) {
+        set_last_error("TimeVarying task-space cost: no reference poses for this chain (idocp_ocp_set_task_refs with the same t, M = the chain's length)");
+        return IDOCP_E_ARG;
+      }
+      for (int p = 0; p < M; ++p) for (int k = 0; k < 12; ++k) tab[(size_t)p * 12 + k] = h->cost.task_ref[k];
+      h->task_refs_stale = true;
+    } else {
+      tab = h->task_refs_host;
+      h->task_refs_stale = false;
+    }
+  } else {
+    for (int p = 0; p < M; ++p) for (int k = 0; k < 12; ++k) tab[(size_t)p * 12 + k] = h->cost.task_ref[k];
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_taskref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return IDOCP_OK;
+}
+
 int discretize(idocp_ocp* h, double t) {
-  if (!h->seq_dirty && h->disc_time == t) return IDOCP_OK;
+  if (!h->seq_dirty && h->disc_time == t && !(h->task_refs_stale && !h->task_refs_lenient)) return IDOCP_OK;
   if (h->parnmpc) return discretizeParNMPC(h, t);
   const int N_ideal = h->N;
   const double min_dt = std::sqrt(std::numeric_limits<double>::epsilon());       // ocp_discretizer.hpp:108-109
@@ -302,6 +331,7 @@ int discretize(idocp_ocp* h, double t) {
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  { const int rct = uploadTaskRefs(h, t, M); if (rct) return rct; }
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
   // The chain as the line search pairs it (line_search.cpp:80-113): the state-equation residual of a grid stage in front of an
   // impulse / lift is evaluated against the NEXT GRID STAGE (the value computed against the event stage is overwritten there).
@@ -478,6 +508,7 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  { const int rct = uploadTaskRefs(h, t, M); if (rct) return rct; }
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
   std::vector<int> ipos;
   for (int p = 0; p < M; ++p) if (h->chain[p].kind == 1) ipos.push_back(p);
@@ -523,6 +554,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  { const int rct = uploadTaskRefs(h, t, M); if (rct) return rct; }
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -620,7 +652,6 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   }
   if (cost->task_dim != 0) {
     if (cost->task_dim != 3 && cost->task_dim != 6) { set_last_error("invalid value: task_dim must be 0, 3 or 6"); return IDOCP_E_ARG; }
-    if (cost->task_time_varying) { set_last_error("unsupported cost: the TimeVarying task-space costs are carried by UnOCPSolver (fixed-base robots) only"); return IDOCP_E_UNSUPPORTED; }
     if (parnmpc && max_num_impulse > 0) { set_last_error("unsupported cost: task-space costs on a ParNMPC horizon with discrete events (the impulse-stage kernel has no such term)"); return IDOCP_E_UNSUPPORTED; }
     if (cost->task_joint < 0 || cost->task_joint > DQ::NU) { set_last_error("invalid value: the task frame must sit on the floating base or on a leg link"); return IDOCP_E_ARG; }
   }
@@ -682,6 +713,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if ((rc = allocBufO(h, &h->d_v0, (size_t)batch * DQ::NV))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_qref, (size_t)h->NS * DQ::NQ))) return fail(rc);
+  if ((rc = allocBufO(h, &h->d_taskref, (size_t)h->NS * 12))) return fail(rc);
   if ((rc = allocBufO(h, &tmp, ((size_t)batch * sizeof(int) + 7) / 8))) return fail(rc);
   B.status = reinterpret_cast<int*>(tmp);
   if ((rc = allocBufO(h, &tmp, 64))) return fail(rc);
@@ -704,6 +736,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   h->d_cond_pos = reinterpret_cast<int*>(tmp);
   B.cond_pos = h->d_cond_pos;
   B.q_ref = h->d_qref;
+  B.task_refs = h->d_taskref;
   B.leg_axes_xyy = 1;
   for (int leg = 0; leg < DQ::NL; ++leg)
     for (int j = 0; j < DQ::LJ; ++j) {
@@ -749,7 +782,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   B.model = static_cast<const DevModel*>(d_model);
   B.prob = static_cast<const OcpProblem*>(h->d_prob);
   h->phases.assign(1, HostStatus());                      // ContactSequence ctor: default (no contact) status
-  if ((rc = discretize(h, 0.0))) return fail(rc);
+  h->task_refs_lenient = true;
+  rc = discretize(h, 0.0);
+  h->task_refs_lenient = false;
+  if (rc) return fail(rc);
   // identity quaternion in every q so that an unset solution is a valid configuration
   {
     std::vector<double> q(DQ::NQ, 0.0); q[6] = 1.0;
@@ -881,7 +917,10 @@ int idocp_ocp_pop_front_contact_status(idocp_ocp_t* h) {             // contact_
 int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot, double* dt, int* dimf, int* sw_dimi) {
   if (!h) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
-  if ((rc = discretize(h, t))) return rc;
+  h->task_refs_lenient = true;
+  rc = discretize(h, t);
+  h->task_refs_lenient = false;
+  if (rc) return rc;
   const int M = h->M();
   if (capacity < M) { set_last_error("idocp_ocp_get_chain: capacity too small"); return IDOCP_E_ARG; }
   for (int p = 0; p < M; ++p) {
@@ -894,6 +933,29 @@ int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* 
     if (sw_dimi) sw_dimi[p] = nd.sw_dimi;
   }
   return M;
+}
+
+int idocp_ocp_get_chain_times(idocp_ocp_t* h, double t, int capacity, double* times) {
+  if (!h || !times) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  // (the chain's shape and times do not depend on the reference poses: a TimeVarying task cost without poses yet must not stop the
+  //  discretisation that tells the caller where to evaluate them)
+  h->task_refs_lenient = true;
+  rc = discretize(h, t);
+  h->task_refs_lenient = false;
+  if (rc) return rc;
+  const int M = h->M();
+  if (capacity < M) { set_last_error("idocp_ocp_get_chain_times: capacity too small"); return IDOCP_E_ARG; }
+  for (int p = 0; p < M; ++p) times[p] = h->chain_t[p];
+  return M;
+}
+int idocp_ocp_set_task_refs(idocp_ocp_t* h, double t, int M, const double* refs) {
+  if (!h || !refs || M <= 0) return IDOCP_E_ARG;
+  if (h->cost.task_dim == 0 || !h->cost.task_time_varying) { set_last_error("idocp_ocp_set_task_refs: the solver carries no TimeVarying task-space cost"); return IDOCP_E_ARG; }
+  h->task_refs_host.assign(refs, refs + (size_t)M * 12);
+  h->task_refs_t = t;
+  h->seq_dirty = true;                       // uploaded with the next discretisation at t
+  return IDOCP_OK;
 }
 
 static int setSolutionO(idocp_ocp_t* h, const char* name, const double* values, int per_instance) {
@@ -1731,13 +1793,19 @@ int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
     if (hipMemcpyAsync(h->allocs[i], src->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
+  h->task_refs_host = src->task_refs_host; h->task_refs_t = src->task_refs_t;
   h->contact_status_set = src->contact_status_set; h->stage_offset = src->stage_offset; h->has_terminal = src->has_terminal; h->has_prev = src->has_prev;
   h->phases = src->phases; h->event_time = src->event_time; h->is_impulse = src->is_impulse; h->impulse_status = src->impulse_status;
   h->slice_begin = src->slice_begin; h->slice_end = src->slice_end;
   h->filters = src->filters;                 // the line-search filter is part of the solver's state (LineSearch is a member of the reference's solvers)
   h->prob = src->prob;
   h->seq_dirty = true;                       // the chain is rebuilt (and uploaded) on first use
-  if (src->disc_time == src->disc_time) { if ((rc = discretize(h, src->disc_time))) return fail(rc); }
+  if (src->disc_time == src->disc_time) {
+    h->task_refs_lenient = true;
+    rc = discretize(h, src->disc_time);
+    h->task_refs_lenient = false;
+    if (rc) return fail(rc);
+  }
   *out = h;
   return IDOCP_OK;
 }

@@ -216,6 +216,8 @@ struct OcpBuffers {
                           // contact frames are not rotated against their joints (ANYmal):
                           // selects the instantiations of K5 whose rigid-body sweeps know the joint axes at compile time
   const double* q_ref;   // [M][NQ] reference configuration of every stage of the chain (time-varying cost)
+  const double* task_refs;   // [M][12] reference pose of the task-space cost at every stage of the chain (rotation row-major, position): the
+                             // constant cost.task_ref, or the poses of idocp_ocp_set_task_refs (TimeVaryingTaskSpace3DCost / 6DCost)
   // per-stage arrays, indexed [instance][slot] (NS slots per instance)
   double* sol;           // [batch][NS][SOL]
   double* dir;           // [batch][NS][DIR]

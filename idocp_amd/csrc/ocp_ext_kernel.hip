@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void ocp_ext_kernel(OcpBuffers B, int residual)
   if (P->task_dim != 0) {
     double pF[3], RF[9], w[3], v[3], diff[6], col[6];
     frameKinematics<D>(B.model, q, P->task_joint, P->task_R, P->task_p, dof, pF, RF, w, v);
-    const double* __restrict__ ref = P->task_ref;
+    const double* __restrict__ ref = B.task_refs + (long)pos * 12;      // (time_varying_task_space_{3d,6d}_cost.cpp: the reference at the stage's own time)
     const double ev[3] = {pF[0] - ref[9], pF[1] - ref[10], pF[2] - ref[11]};
     if (P->task_dim == 3) {
       // diff = p - p_ref ; J_3d = R_frame J_lin,LOCAL = the world-frame linear column

@@ -489,6 +489,19 @@ class HipOCP:
         assert M > 0, capi.lib().idocp_last_error()
         return [dict(kind=NODE_KINDS[kind[p]], index=index[p], slot=slot[p], dt=dt[p], dimf=dimf[p], sw_dimi=sw[p]) for p in range(M)]
 
+    def chain_times(self, t):
+        """Times of the stages of the chain discretised at t (idocp_ocp_get_chain_times): where a TimeVarying task-space reference is evaluated."""
+        cap = self.N + 1 + 3 * max(self.max_events, 1)
+        tt = np.zeros(cap)
+        M = self.lib.idocp_ocp_get_chain_times(self.h, t, cap, P(tt))
+        assert M > 0, capi.lib().idocp_last_error()
+        return tt[:M].copy()
+
+    def set_task_refs(self, t, refs):
+        """refs[M][12] (rotation row-major, position) for the chain discretised at t (idocp_ocp_set_task_refs)."""
+        refs = np.ascontiguousarray(refs, dtype=np.float64)
+        capi.check(self.lib.idocp_ocp_set_task_refs(self.h, t, refs.shape[0], P(refs)), "set_task_refs")
+
     def get_chain(self, name, M, instance=0):
         dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or OCP_CHAIN_EXTRA[name]
         out = np.zeros((M, dim))

@@ -34,6 +34,8 @@ class CostFunctionComponentBase {
   virtual bool exportTo(idocp_cost_t& cost) const = 0;
   // time-varying task-space costs: the reference poses at t + i dt, i = 0 .. N ([N + 1][12]); false = constant reference
   virtual bool stageRefs(const double /*t*/, const double /*dt*/, const int /*N*/, std::vector<double>& /*refs*/) const { return false; }
+  // the same at arbitrary times (the stages of a chain with discrete events, idocp_ocp_get_chain_times): refs[times.size()][12]
+  virtual bool refsAt(const std::vector<double>& /*times*/, std::vector<double>& /*refs*/) const { return false; }
 };
 
 // the task-space fields of the flat cost block (written by the components of task_space_cost.hpp)
@@ -103,6 +105,7 @@ class CostFunction {
   bool taskRefs(const double t, const double dt, const int N, std::vector<double>& refs) const {
     return task_ ? task_->stageRefs(t, dt, N, refs) : false;
   }
+  bool taskRefsAt(const std::vector<double>& times, std::vector<double>& refs) const { return task_ ? task_->refsAt(times, refs) : false; }
 
  private:
   bool have_[3];

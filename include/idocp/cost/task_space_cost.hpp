@@ -84,11 +84,16 @@ class TimeVaryingTaskSpace3DCost final : public CostFunctionComponentBase {
   void set_qi_3d_weight(const Eigen::Vector3d& w) { for (int k = 0; k < 3; ++k) c_.task_weighti[k] = w[k]; }
   bool exportTo(idocp_cost_t& cost) const override { keepTaskFields(c_, cost); return true; }
   bool stageRefs(const double t, const double dt, const int N, std::vector<double>& refs) const override {
-    refs.assign((size_t)(N + 1) * 12, 0.0);
+    std::vector<double> times((size_t)N + 1);
+    for (int i = 0; i <= N; ++i) times[i] = t + i * dt;
+    return refsAt(times, refs);
+  }
+  bool refsAt(const std::vector<double>& times, std::vector<double>& refs) const override {
+    refs.assign(times.size() * 12, 0.0);
     Eigen::VectorXd p(3);
-    for (int i = 0; i <= N; ++i) {
-      ref_->compute_q_3d_ref(t + i * dt, p);
-      double* r = &refs[(size_t)12 * i];
+    for (size_t i = 0; i < times.size(); ++i) {
+      ref_->compute_q_3d_ref(times[i], p);
+      double* r = &refs[12 * i];
       r[0] = r[4] = r[8] = 1.0;
       for (int k = 0; k < 3; ++k) r[9 + k] = p[k];
     }
@@ -119,11 +124,16 @@ class TimeVaryingTaskSpace6DCost final : public CostFunctionComponentBase {
   void set_qi_6d_weight(const Eigen::Vector3d& position_weight, const Eigen::Vector3d& rotation_weight) { taskcost::put6(c_.task_weighti, position_weight, rotation_weight); }
   bool exportTo(idocp_cost_t& cost) const override { keepTaskFields(c_, cost); return true; }
   bool stageRefs(const double t, const double dt, const int N, std::vector<double>& refs) const override {
-    refs.assign((size_t)(N + 1) * 12, 0.0);
+    std::vector<double> times((size_t)N + 1);
+    for (int i = 0; i <= N; ++i) times[i] = t + i * dt;
+    return refsAt(times, refs);
+  }
+  bool refsAt(const std::vector<double>& times, std::vector<double>& refs) const override {
+    refs.assign(times.size() * 12, 0.0);
     pinocchio::SE3 M;
-    for (int i = 0; i <= N; ++i) {
-      ref_->compute_q_6d_ref(t + i * dt, M);
-      taskcost::putPose(&refs[(size_t)12 * i], M);
+    for (size_t i = 0; i < times.size(); ++i) {
+      ref_->compute_q_6d_ref(times[i], M);
+      taskcost::putPose(&refs[12 * i], M);
     }
     return true;
   }

@@ -62,10 +62,11 @@ class OCPSolver {
     return *this;
   }
 
-  void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
+  void initConstraints(const double t) { syncTaskRefs(t); check(idocp_ocp_init_constraints(h_, t)); }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
     syncCost();
+    syncTaskRefs(t);
     check(idocp_ocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
 
@@ -138,6 +139,7 @@ class OCPSolver {
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
     syncCost();
+    syncTaskRefs(t);
     check(idocp_ocp_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
   idocp_ocp_t* handle() { return h_; }
@@ -151,6 +153,17 @@ class OCPSolver {
   // between two calls takes effect at the next one.  The device holds a copy; it is refreshed when the shared object has changed.
   std::shared_ptr<CostFunction> cost_;
   idocp_cost_t last_cost_{};
+  // TimeVaryingTaskSpace3DCost / 6DCost on the floating base: the reference object is asked for its pose at the time of every stage of the
+  // chain (time_varying_task_space_{3d,6d}_cost.cpp) -- up front, in front of every call that takes t
+  void syncTaskRefs(const double t) {
+    if (!cost_ || !h_ || !cost_->native().task_time_varying) return;
+    if (chain_times_.size() < 4096) chain_times_.resize(4096);
+    const int M = idocp_ocp_get_chain_times(h_, t, (int)chain_times_.size(), chain_times_.data());
+    if (M <= 0) check(M < 0 ? M : IDOCP_E_ARG);
+    const std::vector<double> times(chain_times_.begin(), chain_times_.begin() + M);
+    if (cost_->taskRefsAt(times, task_refs_)) check(idocp_ocp_set_task_refs(h_, t, M, task_refs_.data()));
+  }
+  std::vector<double> chain_times_, task_refs_;
   void syncCost() {
     if (!cost_) return;
     const idocp_cost_t c = cost_->native();

@@ -85,14 +85,16 @@ class ParNMPCSolver {
     return *this;
   }
 
-  void initConstraints(const double t) { check(idocp_ocp_init_constraints(h_, t)); }
+  void initConstraints(const double t) { syncTaskRefs(t); check(idocp_ocp_init_constraints(h_, t)); }
   void initBackwardCorrection(const double t) {
+    syncTaskRefs(t);
     if (comm_) check(idocp_parnmpc_dist_init_backward_correction(h_, t));
     else check(idocp_parnmpc_init_backward_correction(h_, t));
   }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
     syncCost();
+    syncTaskRefs(t);
     if (comm_) {
       if (line_search) { std::cerr << "line_search=true is not supported on a sharded horizon\n"; std::exit(EXIT_FAILURE); }
       if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
@@ -173,6 +175,7 @@ class ParNMPCSolver {
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
     syncCost();
+    syncTaskRefs(t);
     if (comm_) {
       if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
       check(idocp_parnmpc_dist_kkt_error(h_, t, &kkt_error_));
@@ -192,6 +195,17 @@ class ParNMPCSolver {
   std::shared_ptr<CostFunction> cost_;
   idocp_cost_t last_cost_{};
   double kkt_error_ = 0.0;
+  // TimeVaryingTaskSpace3DCost / 6DCost on the floating base: the reference object is asked for its pose at the time of every stage of the
+  // chain (time_varying_task_space_{3d,6d}_cost.cpp) -- up front, in front of every call that takes t
+  void syncTaskRefs(const double t) {
+    if (!cost_ || !h_ || !cost_->native().task_time_varying) return;
+    if (chain_times_.size() < 4096) chain_times_.resize(4096);
+    const int M = idocp_ocp_get_chain_times(h_, t, (int)chain_times_.size(), chain_times_.data());
+    if (M <= 0) check(M < 0 ? M : IDOCP_E_ARG);
+    const std::vector<double> times(chain_times_.begin(), chain_times_.begin() + M);
+    if (cost_->taskRefsAt(times, task_refs_)) check(idocp_ocp_set_task_refs(h_, t, M, task_refs_.data()));
+  }
+  std::vector<double> chain_times_, task_refs_;
   void syncCost() {
     if (!cost_ || !h_) return;
     const idocp_cost_t c = cost_->native();

@@ -407,6 +407,16 @@ int idocp_parnmpc_set_aux_mat_chain(idocp_ocp_t* h, int M, const double* values)
 int idocp_parnmpc_get_aux_mat_chain(idocp_ocp_t* h, int instance, double* out);
 int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot,
                         double* dt, int* dimf, int* sw_dimi);
+/* TimeVaryingTaskSpace3DCost / TimeVaryingTaskSpace6DCost on a floating-base robot (src/cost/time_varying_task_space_3d_cost.cpp,
+ * time_varying_task_space_6d_cost.cpp: the reference object is asked for its pose at the time of every stage).  The device cannot call the
+ * caller's reference object, so the poses are evaluated up front: idocp_ocp_get_chain_times lists the times of the M stages of the chain
+ * discretised at t (the order of idocp_ocp_get_chain: grid stages at t + i dt, impulse / aux / lift stages at their event times, the
+ * terminal stage at t + T; returns M), idocp_ocp_set_task_refs hands the M poses over, refs[M][12] = rotation (row-major, 9; identity for
+ * the 3D cost) then position (3).  They apply to every call with this t; a call with another t, or a chain of another length, fails with
+ * IDOCP_E_ARG until new poses are set.  cost.task_time_varying must be set at creation (OCPSolver on any chain, ParNMPCSolver on
+ * event-free horizons -- as for the constant-reference costs). */
+int idocp_ocp_get_chain_times(idocp_ocp_t* h, double t, int capacity, double* times);
+int idocp_ocp_set_task_refs(idocp_ocp_t* h, double t, int M, const double* refs);
 /* OCPSolver::setSolution (ocp_solver.cpp:95-165): name in {"q","v","a","f","u"};
  * "f" takes one 3-vector written to every contact.  Does not re-initialise the
  * constraints (like the reference). */

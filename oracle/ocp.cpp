@@ -55,16 +55,15 @@ int ContactSequenceC::eventOfLift(int k) const {
 static Robot makeTaskRobot(const RModel& model, const RCost& cost) {
   if (cost.task_dim == 0) return Robot(model);
   if (cost.task_dim != 3 && cost.task_dim != 6) throw std::invalid_argument("task_dim must be 0, 3 or 6");
-  if (cost.task_time_varying) throw std::logic_error("TimeVarying task-space costs are restated for UnOCPSolver only");
   RModel mt = model;
   mt.contact_frame_id[0] = -1; mt.contact_joint[0] = cost.task_joint;
   for (int k2 = 0; k2 < 9; ++k2) mt.contact_R[0][k2] = cost.task_frame_R[k2];
   for (int k2 = 0; k2 < 3; ++k2) mt.contact_p[0][k2] = cost.task_frame_p[k2];
   return Robot(mt);
 }
-static void taskTerms(const Robot& task_robot, const RCost& cost, const real* w, const Mat& q, real& c, Mat& g, Mat& H) {
+static void taskTerms(const Robot& task_robot, const RCost& cost, real t, const real* w, const Mat& q, real& c, Mat& g, Mat& H) {
   Robot rb = task_robot;
-  rb.taskSpaceTerms(cost.task_dim, cost.task_ref, w, q, c, g, H);
+  rb.taskSpaceTerms(cost.task_dim, cost.taskRefAt(t), w, q, c, g, H);      // (TimeVarying variants: the pose at the stage's own time)
 }
 
 OCPSolver::OCPSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
@@ -424,7 +423,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   }
   if (!impulse) for (int r = 0; r < nu; ++r) R.lu[r] += dt * cost.u_weight[r] * (si.u[r] - cost.u_ref[r]);
   Mat task_H;
-  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, impulse ? cost.task_weighti : cost.task_weight, si.q, c_, g_, task_H); R.lq += dt * g_; }      // (dt = 1 on impulse stages)
+  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, t, impulse ? cost.task_weighti : cost.task_weight, si.q, c_, g_, task_H); R.lq += dt * g_; }      // (dt = 1 on impulse stages)
   {
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) {
@@ -694,7 +693,7 @@ void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool r
   const real vs = vRefScale(cost, nd.t);      // TimeVaryingConfigurationSpaceCost::v_ref(t)
   for (int r = 0; r < nv; ++r) R.lv[r] += cost.vf_weight[r] * (sN.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
   Mat task_H;
-  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, cost.task_weightf, sN.q, c_, g_, task_H); R.lq += g_; }
+  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, nd.t, cost.task_weightf, sN.q, c_, g_, task_H); R.lq += g_; }
   // linearizeForwardEulerTerminal (state_equation.hxx:66-83)
   Mat Fqq_prev; robot.dSubtractdConfigurationMinus(q_prev, sN.q, Fqq_prev);
   M.Fqq_prev6 = Fqq_prev.block(0, 0, 6, 6);
@@ -1157,7 +1156,7 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
         l += cost.qf_weight[r] * qdiff[r] * qdiff[r] + cost.vf_weight[r] * dvr * dvr;
       }
       cost_sum += 0.5 * l;
-      if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, cost.task_weightf, x.q, c_, g_, H_); cost_sum += c_; }
+      if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, nd.t, cost.task_weightf, x.q, c_, g_, H_); cost_sum += c_; }
       continue;
     }
     const bool impulse = nd.kind == NodeC::Impulse;
@@ -1175,7 +1174,7 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
       l += wq[r] * qdiff[r] * qdiff[r] + wv[r] * dvr * dvr + wa[r] * x.a[r] * x.a[r];
     }
     if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
-    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, impulse ? cost.task_weighti : cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }
+    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, nd.t, impulse ? cost.task_weighti : cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) l += wf[c][k2] * (x.f[c][k2] - rf[c][k2]) * (x.f[c][k2] - rf[c][k2]);
     real barrier = 0, primal = 0;
     for (int c = 0; c < NCOMP; ++c) {
@@ -1567,8 +1566,8 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   Mat task_H, task_Hf;
   if (cost.task_dim) {
     real c_; Mat g_;
-    taskTerms(task_robot, cost, cost.task_weight, si.q, c_, g_, task_H); R.lq += dt * g_;
-    if (terminal) { taskTerms(task_robot, cost, cost.task_weightf, si.q, c_, g_, task_Hf); R.lq += g_; }
+    taskTerms(task_robot, cost, t, cost.task_weight, si.q, c_, g_, task_H); R.lq += dt * g_;
+    if (terminal) { taskTerms(task_robot, cost, t, cost.task_weightf, si.q, c_, g_, task_Hf); R.lq += g_; }
   }
   {
     int st = 0;
@@ -2330,7 +2329,7 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       else l += cost.q_weight[r] * qdiff[r] * qdiff[r] + cost.v_weight[r] * dvr * dvr + cost.a_weight[r] * x.a[r] * x.a[r];
     }
     if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
-    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }      // (stage part only: no terminal cost in the merit)
+    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, nd.t, cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }      // (stage part only: no terminal cost in the merit)
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) {
       const real w = impulse ? cost.fi_weight[c][k2] : cost.f_weight[c][k2], fr = impulse ? cost.fi_ref[c][k2] : cost.f_ref[c][k2];
       l += w * (x.f[c][k2] - fr) * (x.f[c][k2] - fr);

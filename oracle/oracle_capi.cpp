@@ -509,6 +509,13 @@ int oracle_ocp_set_contact_points(void* h, int phase, const double* points) {
   return 0;
 }
 // the chain produced by the last discretisation: returns its length M; arrays (may be NULL) of length M
+// TimeVarying task-space cost: the reference poses tabulated at M times (looked up by stage time, RCost::taskRefAt)
+static void fillTaskRefTable(RCost& cost, int M, const double* times, const double* refs) {
+  cost.task_tab_t.resize(M); cost.task_tab.resize(M);
+  for (int k = 0; k < M; ++k) { cost.task_tab_t[k] = times[k]; for (int j = 0; j < 12; ++j) cost.task_tab[k][j] = refs[12 * k + j]; }
+}
+int oracle_ocp_set_task_refs(void* h, int M, const double* times, const double* refs) { fillTaskRefTable(static_cast<OCPSolver*>(h)->cost, M, times, refs); return 0; }
+int oracle_parnmpc_set_task_refs(void* h, int M, const double* times, const double* refs) { fillTaskRefTable(static_cast<ParNMPCSolver*>(h)->cost, M, times, refs); return 0; }
 int oracle_ocp_chain(void* h, double t, int* kind, int* index, int* slot, double* tt, double* dt, int* sw_event, int* dimf) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   s->discretize(t);

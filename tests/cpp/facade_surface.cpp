@@ -8,6 +8,8 @@
 
 #include "../../examples/common.hpp"
 #include "idocp/cost/configuration_space_cost.hpp"
+#include "idocp/cost/task_space_3d_cost.hpp"
+#include "idocp/cost/time_varying_task_space_3d_cost.hpp"
 #include "idocp/ocp/ocp_solver.hpp"
 #include "idocp/ocp/parnmpc_solver.hpp"
 #include "idocp/unocp/unocp_solver.hpp"
@@ -104,6 +106,32 @@ int main(int argc, char** argv) {
     REQUIRE(maxDiff(s0.beta, cs.getSolution("beta")[0]) == 0.0 && maxDiff(s0.nu_passive, cs.getSolution("nu_passive")[0]) == 0.0);
     REQUIRE((int)s0.f.size() == robot.maxPointContacts() && s0.f[1][2] == s0.f_stack()[5]);
     REQUIRE(maxDiff(cs.getSolution(N).v, cs.getSolution("v")[N]) == 0.0);
+    {  // TimeVaryingTaskSpace3DCost on the floating base: a reference that does not move gives the constant-reference solver's step
+      struct Still : idocp::TimeVaryingTaskSpace3DRefBase {
+        ex::V3 p;
+        void compute_q_3d_ref(const double, Eigen::VectorXd& r) const override { r.resize(3); for (int k = 0; k < 3; ++k) r[k] = p[k]; }
+      };
+      auto still = std::make_shared<Still>();
+      still->p = ex::V3(0.35, 0.2, 0.05);
+      const int foot = ex::anymalFeet()[0];
+      auto tv = std::make_shared<idocp::TimeVaryingTaskSpace3DCost>(robot, foot, still);
+      tv->set_q_3d_weight(ex::V3(10, 10, 10));
+      auto fixed = std::make_shared<idocp::TaskSpace3DCost>(robot, foot);
+      fixed->set_q_3d_ref(still->p);
+      fixed->set_q_3d_weight(ex::V3(10, 10, 10));
+      auto c1 = std::make_shared<idocp::CostFunction>(), c2 = std::make_shared<idocp::CostFunction>();
+      c1->push_back(pose_cost); c1->push_back(tv);
+      c2->push_back(pose_cost); c2->push_back(fixed);
+      idocp::OCPSolver s1(robot, c1, ex::jointLimits(robot, 0.7, false, true), 0.25, N), s2(robot, c2, ex::jointLimits(robot, 0.7, false, true), 0.25, N);
+      for (idocp::OCPSolver* sp : {&s1, &s2}) {
+        standing.install(*sp, robot);
+        ex::restingGuess(*sp, robot, stand);
+        sp->initConstraints(0.1);
+        sp->updateSolution(0.1, stand, v);
+      }
+      REQUIRE(maxDiff(s1.getSolution(3).q, s2.getSolution(3).q) == 0.0 && maxDiff(s1.getSolution(3).u, s2.getSolution(3).u) == 0.0);
+      REQUIRE(maxDiff(s1.getSolution(3).q, solver.getSolution(3).q) > 1e-6);      // (and the task cost does act)
+    }
     std::cout << "floating-base solver: ok" << std::endl;
   }
   return 0;

@@ -364,6 +364,12 @@ class OracleOCP:
         return [dict(kind=NODE_KINDS[kind[p]], index=index[p], slot=slot[p], t=tt[p], dt=dt[p], sw_event=sw[p], dimf=dimf[p])
                 for p in range(M)]
 
+    def set_task_refs(self, times, refs):
+        """TimeVarying task-space cost: the reference poses refs[M][12] tabulated at the stage times (looked up by time)."""
+        times, refs = np.ascontiguousarray(times, dtype=np.float64), np.ascontiguousarray(refs, dtype=np.float64)
+        self.lib.oracle_ocp_set_task_refs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        assert self.lib.oracle_ocp_set_task_refs(self.h, len(times), P(times), P(refs)) == 0
+
     def get_chain(self, name, M):
         dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or OCP_CHAIN_EXTRA[name]
         out = np.zeros((M, dim))
@@ -511,6 +517,11 @@ class OracleParNMPC:
         M = self.lib.oracle_parnmpc_chain(self.h, t, cap, kind, index, slot, P(tt), P(dt), dimf, level)
         assert M >= 0, "the oracle rejected the discretisation"
         return [dict(kind=self.KINDS[kind[p]], index=index[p], slot=slot[p], t=tt[p], dt=dt[p], dimf=dimf[p], level=level[p]) for p in range(M)]
+
+    def set_task_refs(self, times, refs):
+        times, refs = np.ascontiguousarray(times, dtype=np.float64), np.ascontiguousarray(refs, dtype=np.float64)
+        self.lib.oracle_parnmpc_set_task_refs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        assert self.lib.oracle_parnmpc_set_task_refs(self.h, len(times), P(times), P(refs)) == 0
 
     def get_chain(self, name, M):
         dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or {"xi": 12, "dxi": 12}[name]

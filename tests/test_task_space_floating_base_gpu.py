@@ -151,9 +151,90 @@ def test_parnmpc_event_free_horizon_and_rejections():
     assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and hp.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
         parity(g.get(f), o.get(f), lambda f=f: hp.get(f), f, cap=5e-8)
-    # not carried: a horizon with discrete events under ParNMPC, the TimeVarying variants on a floating base
+    # not carried: a horizon with discrete events under ParNMPC
     h = C.c_void_p()
     lib = capi.lib()
     assert lib.idocp_parnmpc_create_hybrid(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 2, 1, 0, C.byref(h)) == -4
+
+
+def moving_reference(times, dim, p0=(0.1, 0.0, 0.47), vel=(0.25, -0.1, 0.05), t0=0.2, tf=1.2, yaw_rate=0.4):
+    """A reference object of the kind the reference's examples pass to TimeVaryingTaskSpace3DCost / 6DCost: a pose that moves with
+    constant velocity (and yaw rate) inside [t0, tf] and rests outside; tabulated at the given times as [M][12]."""
+    refs = np.zeros((len(times), 12))
+    for k, t in enumerate(times):
+        tau = min(max(t, t0), tf) - t0
+        yaw = yaw_rate * tau if dim == 6 else 0.0
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        refs[k, :9] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]).ravel()
+        refs[k, 9:] = np.array(p0) + np.array(vel) * tau
+    return refs
+
+
+@pytest.mark.parametrize("frame,dim", [("base", 6), ("LH_FOOT", 3)])
+def test_time_varying_reference_on_a_trotting_chain(frame, dim):
+    """TimeVaryingTaskSpace3DCost / TimeVaryingTaskSpace6DCost on the floating base (round 4; src/cost/time_varying_task_space_3d_cost.cpp,
+    time_varying_task_space_6d_cost.cpp): the reference pose is evaluated at the time of EVERY stage of the chain -- grid stages, the
+    impulse / aux / lift stages at their event times, the terminal stage -- through idocp_ocp_get_chain_times / idocp_ocp_set_task_refs."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    add_task(cost, frame, dim)
     cost.task_time_varying = 1
-    assert lib.idocp_ocp_create(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 1, 0, C.byref(h)) == -4
+    N, T, nimp = 31, 1.55, 2
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+    h = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=True)
+    g = HipOCP(m, cost, cons, T, N, batch=2, max_num_impulse=nimp + 1)
+    q, v = start((o, g, h), m, seq=nimp)
+    # without poses the solver refuses to run (the device cannot call the reference object)
+    assert g.lib.idocp_ocp_init_constraints(g.h, 0.0) != 0
+    times = g.chain_times(0.0)
+    chain_o = o.chain(0.0)
+    assert len(times) == len(chain_o) and np.allclose(times, [c["t"] for c in chain_o], rtol=0, atol=1e-12)
+    assert np.sum(np.diff(times) == 0.0) >= nimp           # an impulse stage and its aux stage share the event time
+    refs = moving_reference(times, dim)
+    assert np.abs(refs[0, 9:] - refs[-1, 9:]).max() > 0.1   # the reference does move along the horizon
+    g.set_task_refs(0.0, refs)
+    o.set_task_refs(times, refs); h.set_task_refs(times, refs)
+    for s_ in (o, g, h):
+        s_.init_constraints(0.0)
+    M = len(times)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)
+    assert abs(e_g[0] - e_o) < 1e-10 * max(1.0, e_o) and e_g[0] == e_g[1]
+    for it in range(3):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
+        for f in ("dq", "dv", "da", "df", "du", "dlmd", "dgmm", "dbeta", "dmu"):
+            parity(g.get_chain(f, M), o.get_chain(f, M), lambda f=f: h.get_chain(f, M), (it, f), cap=1e-8)
+    # the constant-reference solver of the same problem moves differently: the table is what the kernels read
+    cost.task_time_varying = 0
+    for k in range(12):
+        cost.task_ref[k] = refs[0, k]
+    gc = HipOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+    start((gc,), m, seq=nimp)
+    gc.init_constraints(0.0)
+    assert gc.update(0.0, q, v) == 0
+    assert np.abs(gc.get_chain("dq", M) - g.get_chain("dq", M)).max() > 1e-6
+    # a call at another time needs poses for that chain
+    assert g.update(0.05, q, v) != 0
+    t2 = g.chain_times(0.05)
+    g.set_task_refs(0.05, moving_reference(t2, dim))
+    assert g.update(0.05, q, v) == 0
+
+
+def test_time_varying_reference_parnmpc_event_free():
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    add_task(cost, "RH_THIGH", 3)
+    cost.task_time_varying = 1
+    o, g = OracleParNMPC(m, cost, cons, 0.5, 20), HipParNMPC(m, cost, cons, 0.5, 20)
+    hp = OracleParNMPC(m, cost, cons, 0.5, 20, hp=True)
+    q, v = start((o, g, hp), m)
+    times = g.chain_times(0.0)
+    assert np.allclose(times[:20], [c["t"] for c in o.chain(0.0)][:20], rtol=0, atol=1e-12)
+    refs = moving_reference(times, 3, p0=(-0.3, -0.1, 0.45), t0=0.1, tf=0.4)
+    g.set_task_refs(0.0, refs)
+    o.set_task_refs(times, refs); hp.set_task_refs(times, refs)
+    o.init(0.0); g.init(0.0); hp.init(0.0)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
+    assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and hp.update(0.0, q, v) == 0
+    for f in OCP_DIR_FIELDS:
+        parity(g.get(f), o.get(f), lambda f=f: hp.get(f), f, cap=5e-8)
