@@ -254,6 +254,7 @@ def _proto(lib):
         ("idocp_parnmpc_dist_set_initial_state", [vp, c_double_p, c_double_p, ci, ci]),
         ("idocp_parnmpc_dist_init_backward_correction", [vp, cd]),
         ("idocp_parnmpc_dist_update_solution", [vp, cd]),
+        ("idocp_parnmpc_dist_update_solution_ls", [vp, cd]),
         ("idocp_parnmpc_dist_kkt_error", [vp, cd, c_double_p]),
         ("idocp_ocp_batch", [vp]),
         ("idocp_ocp_set_riccati_storage", [vp, ci]),

@@ -94,6 +94,11 @@ struct idocp_ocp {
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;   // parallel to allocs (idocp_ocp_clone copies buffer by buffer)
   double *d_q0 = nullptr, *d_v0 = nullptr, *d_tmp = nullptr, *d_qref = nullptr, *d_taskref = nullptr;
+  // filter line search on a shard of a ParNMPC horizon (idocp_parnmpc_set_line_search_hooks, parnmpc_dist.hip): the trial iterate of the
+  // state in front of the shard's first stage, and the two collective steps of one probe
+  double *d_qtry = nullptr, *d_vtry = nullptr;
+  int (*ls_pre)(idocp_ocp_t*) = nullptr;       // after the trial iterate is formed: exchange its boundary state
+  int (*ls_post)(idocp_ocp_t*) = nullptr;      // after the shard's sums are formed: all-reduce them
   std::vector<double> task_refs_host;      // idocp_ocp_set_task_refs: [M][12] for the chain discretised at task_refs_t
   double task_refs_t = 0.0;
   bool task_refs_lenient = false;          // creation, clone and the chain getters discretise without poses (constant pose in the table)
@@ -711,6 +716,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   h->filters.assign(batch, {});
   if ((rc = allocBufO(h, &h->d_q0, (size_t)batch * DQ::NQ))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_v0, (size_t)batch * DQ::NV))) return fail(rc);
+  if (parnmpc) {
+    if ((rc = allocBufO(h, &h->d_qtry, (size_t)batch * DQ::NQ))) return fail(rc);
+    if ((rc = allocBufO(h, &h->d_vtry, (size_t)batch * DQ::NV))) return fail(rc);
+  }
   if ((rc = allocBufO(h, &h->d_tmp, (size_t)batch * IDOCP_MAX_NQ))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_qref, (size_t)h->NS * DQ::NQ))) return fail(rc);
   if ((rc = allocBufO(h, &h->d_taskref, (size_t)h->NS * 12))) return fail(rc);
@@ -1126,7 +1135,10 @@ void* idocp_ocp_stream(idocp_ocp_t* h) { return h ? (void*)h->stream : nullptr; 
 // The filter line search of ParNMPCSolver runs on one shard (horizons with discrete events included: every stage of the chain is
 // evaluated against the trial iterate of its chain predecessor, src/line_search/line_search.cpp:199-301, line_search.hpp:224-264).
 static int parnmpcLineSearchSupported(const idocp_ocp_t* h) {
-  if (h->has_prev || !h->has_terminal) { set_last_error("line_search=true on a shard of a ParNMPC horizon is not supported by the HIP path"); return IDOCP_E_UNSUPPORTED; }
+  if ((h->has_prev || !h->has_terminal) && !(h->ls_pre && h->ls_post)) {
+    set_last_error("line_search=true on a shard of a ParNMPC horizon needs the sharded driver (idocp_parnmpc_dist_update_solution_ls)");
+    return IDOCP_E_UNSUPPORTED;
+  }
   return IDOCP_OK;
 }
 static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, const double* d_q, std::vector<double>& out) {
@@ -1137,12 +1149,19 @@ static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, con
   Bt.sol = h->B.sol_try;
   Bt.ext = h->ext_try;                              // (the trial iterate's heights / rows; the expansion kernels keep reading the linearisation's)
   if (h->parnmpc) {
-    // ParNMPC: backward-Euler stages against the trial predecessor (the measured state in front of the first element of the chain);
+    // ParNMPC: backward-Euler stages against the trial predecessor (the measured state in front of the first element of the chain;
+    // on a shard with a left neighbour: that neighbour's trial iterate of its last stage, fetched by the driver's hook);
     // aux stages add the l1 norm of their switching constraint (K5s on the trial iterate), impulse stages have a kernel of their own
+    const double *pq = d_q, *pv = h->d_v0;
+    if (h->ls_pre) {
+      const int rcp = h->ls_pre(h);
+      if (rcp) return rcp;
+      if (h->has_prev) { pq = h->d_qtry; pv = h->d_vtry; }
+    }
     OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);
     if (h->has_switch) OcpLaunch<DQ>::switching(Bt, h->batch, M, h->stream);
-    OcpLaunch<DQ>::meritBackwardEuler(Bt, h->batch, M, d_q, h->d_v0, h->stream);
-    OcpLaunch<DQ>::parnmpcImpulseMerit(Bt, h->batch, h->n_impulse, d_q, h->d_v0, h->stream);
+    OcpLaunch<DQ>::meritBackwardEuler(Bt, h->batch, M, pq, pv, h->stream);
+    OcpLaunch<DQ>::parnmpcImpulseMerit(Bt, h->batch, h->n_impulse, pq, pv, h->stream);
   } else {
     Bt.nodes = h->B.nodes_ls;
     OcpLaunch<DQ>::rnea(Bt, h->batch, M, h->n_impulse, h->stream);
@@ -1151,6 +1170,7 @@ static int lineSearchEvalO(idocp_ocp_t* h, const std::vector<double>& alpha, con
   }
   OcpLaunch<DQ>::meritReduce(h->B, h->batch, h->stream);
   HIP_TRY(hipGetLastError());
+  if (h->parnmpc && h->ls_post) { const int rcp = h->ls_post(h); if (rcp) return rcp; }      // sum over the shards
   out.resize((size_t)h->batch * 2);
   HIP_TRY(hipMemcpyAsync(out.data(), h->B.merit, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1714,6 +1734,37 @@ int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v) {
   if (!h || !h->parnmpc || !d_q || !d_v) return IDOCP_E_ARG;
   *d_q = h->d_q0; *d_v = h->d_v0;
   return IDOCP_OK;
+}
+// ---- filter line search on a sharded horizon: what the driver (parnmpc_dist.hip) needs from the handle ----
+int idocp_parnmpc_set_line_search_hooks(idocp_ocp_t* h, int (*pre)(idocp_ocp_t*), int (*post)(idocp_ocp_t*)) {
+  if (!h || !h->parnmpc) return IDOCP_E_ARG;
+  h->ls_pre = pre; h->ls_post = post;
+  return IDOCP_OK;
+}
+// the state_last halo of the TRIAL iterate: export (q, v) of the shard's last stage from sol_try; import into the trial state in front of
+// the shard's first stage (d_buf[batch][idocp_parnmpc_halo_size(0)], enqueued on the handle's stream)
+int idocp_parnmpc_trial_halo_async(idocp_ocp_t* h, int do_import, double* d_buf) {
+  if (!h || !h->parnmpc || !d_buf) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  OcpBuffers Bt = h->B;
+  if (!do_import) Bt.sol = h->B.sol_try;
+  OcpLaunch<DQ>::parnmpcHalo(Bt, h->batch, 0, do_import != 0, d_buf, h->d_qtry, h->d_vtry, h->stream);
+  HIP_TRY(hipGetLastError());
+  return IDOCP_OK;
+}
+// cost and violation sums of the last probe, [batch][2] in device memory (what the driver all-reduces)
+int idocp_parnmpc_merit_device(idocp_ocp_t* h, double** d_merit) {
+  if (!h || !d_merit) return IDOCP_E_ARG;
+  *d_merit = h->B.merit;
+  return IDOCP_OK;
+}
+// LineSearch::computeStepSize on the direction of phases 0 .. 8 (with the hooks above: collectively on every shard); B.step then holds the
+// accepted primal steps
+int idocp_parnmpc_line_search(idocp_ocp_t* h) {
+  if (!h || !h->parnmpc) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  if ((rc = parnmpcLineSearchSupported(h))) return rc;
+  return runLineSearchO(h, h->d_q0);
 }
 // step sizes [batch][2] (primal, dual) in device memory: read after phase 8, overwrite with the global minimum before phase 9
 int idocp_parnmpc_step_sizes_device(idocp_ocp_t* h, double** d_steps) {

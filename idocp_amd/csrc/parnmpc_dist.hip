@@ -423,6 +423,61 @@ int idocp_parnmpc_dist_update_solution(idocp_ocp_t* h, double t) {
   return IDOCP_OK;
 }
 
+// ---- filter line search across the shards ----
+// One probe of LineSearch::computeCostAndViolation (src/line_search/line_search.cpp:199-301) needs, per shard, the trial iterate of the state
+// in front of its first stage -- the left neighbour's trial (q, v) of its last stage -- and the sums over ALL shards.  The handle calls
+// these two hooks from inside its probe (ocp_capi.hip, lineSearchEvalO); the state_last buffers are free by then (the boundary exchange of
+// the iteration is long done).
+static int lsPre(idocp_ocp_t* h) {
+  DistState* sp = stateOf(h);
+  if (!sp) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
+  DistState& s = *sp;
+  const int rank = s.comm->rank, world = s.comm->world;
+  if (world == 1) return IDOCP_OK;
+  const bool left = rank > 0, right = rank < world - 1;
+  if (right) RC(idocp_parnmpc_trial_halo_async(h, 0, s.sendb[STATE_LAST]));
+  RC(xgrouped(s, [&]() -> int {
+    if (right) RC(xsend(s, STATE_LAST, rank + 1));
+    if (left) RC(xrecv(s, STATE_LAST, rank - 1));
+    return IDOCP_OK;
+  }));
+  if (left) RC(idocp_parnmpc_trial_halo_async(h, 1, s.recvb[STATE_LAST]));
+  return IDOCP_OK;
+}
+static int lsPost(idocp_ocp_t* h) {
+  DistState* sp = stateOf(h);
+  if (!sp) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
+  double* d_merit = nullptr;
+  RC(idocp_parnmpc_merit_device(h, &d_merit));
+  return xallreduce(*sp, d_merit, (size_t)sp->batch * 2, 0);
+}
+
+// ParNMPCSolver::updateSolution(t, q, v, true) of the sharded horizon: the iteration up to the step sizes, the filter line search on the
+// primal step with every probe evaluated collectively, the integration.  Every rank runs the same filter on the same all-reduced sums.
+int idocp_parnmpc_dist_update_solution_ls(idocp_ocp_t* h, double t) {
+  DistState* sp = stateOf(h);
+  if (!sp) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist: attach a communicator first");
+  DistState& s = *sp;
+  const int rank = s.comm->rank, world = s.comm->world;
+  const bool left = rank > 0, right = rank < world - 1;
+  RC(idocp_parnmpc_set_line_search_hooks(h, lsPre, lsPost));
+  RC(idocp_parnmpc_discretize(h, t));
+  RC(exchangeBoundary(h, s));
+  RC(phases(h, s, {0, 1, 2}));
+  if (right) { RC(xrecv(s, BWD_FIRST, rank + 1)); RC(idocp_parnmpc_import_halo_async(h, BWD_FIRST, s.recvb[BWD_FIRST])); }
+  RC(phases(h, s, {3}));
+  if (left) { RC(idocp_parnmpc_export_halo_async(h, BWD_FIRST, s.sendb[BWD_FIRST])); RC(xsend(s, BWD_FIRST, rank - 1)); }
+  RC(phases(h, s, {4}));
+  if (left) { RC(xrecv(s, FWD_LAST, rank - 1)); RC(idocp_parnmpc_import_halo_async(h, FWD_LAST, s.recvb[FWD_LAST])); }
+  RC(phases(h, s, {5}));
+  if (right) { RC(idocp_parnmpc_export_halo_async(h, FWD_LAST, s.sendb[FWD_LAST])); RC(xsend(s, FWD_LAST, rank + 1)); }
+  RC(phases(h, s, {6, 7, 8}));
+  RC(xallreduce(s, s.d_steps, (size_t)s.batch * 2, 1));
+  RC(idocp_parnmpc_line_search(h));                              // collective: lsPre / lsPost inside every probe
+  RC(phases(h, s, {9}));
+  return IDOCP_OK;
+}
+
 // ParNMPCSolver::computeKKTResidual + KKTError of the whole horizon: sqrt(sum over ranks of the shards' squared errors)
 int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* h, double t, double* kkt_error) {
   DistState* sp = stateOf(h);

@@ -96,9 +96,9 @@ class ParNMPCSolver {
     syncCost();
     syncTaskRefs(t);
     if (comm_) {
-      if (line_search) { std::cerr << "line_search=true is not supported on a sharded horizon\n"; std::exit(EXIT_FAILURE); }
       if (idocp_comm_rank(comm_) == 0) check(idocp_parnmpc_dist_set_initial_state(h_, q.data(), v.data(), robot_.dimq(), robot_.dimv()));
-      check(idocp_parnmpc_dist_update_solution(h_, t));
+      // (line_search: the probes of the filter line search are evaluated collectively, every rank runs the same filter)
+      check(line_search ? idocp_parnmpc_dist_update_solution_ls(h_, t) : idocp_parnmpc_dist_update_solution(h_, t));
       check(idocp_ocp_synchronize(h_));
       return;
     }

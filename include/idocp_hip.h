@@ -578,6 +578,9 @@ int idocp_parnmpc_dist_set_initial_state(idocp_ocp_t* shard, const double* q, co
 int idocp_parnmpc_dist_init_backward_correction(idocp_ocp_t* shard, double t);
 /* One iteration of the whole horizon; returns when everything is enqueued (idocp_ocp_synchronize before reading results). */
 int idocp_parnmpc_dist_update_solution(idocp_ocp_t* shard, double t);
+/* ... with the filter line search on the primal step (ParNMPCSolver::updateSolution(t, q, v, true)): collective like the call above;
+ * host-synchronous (one device-to-host copy of the all-reduced sums per probe, like the single-handle path). */
+int idocp_parnmpc_dist_update_solution_ls(idocp_ocp_t* shard, double t);
 /* KKT error of the whole horizon on every rank, kkt_error[batch] (host). */
 int idocp_parnmpc_dist_kkt_error(idocp_ocp_t* shard, double t, double* kkt_error);
 int idocp_ocp_batch(idocp_ocp_t* h);
@@ -606,6 +609,17 @@ int idocp_ocp_set_cost(idocp_ocp_t* h, const idocp_cost_t* cost);
  * the step sizes ([batch][2]: primal, dual) -- the latter is all-reduced (min) between phases 8 and 9. */
 int idocp_parnmpc_prev_state(idocp_ocp_t* h, double** d_q, double** d_v);
 int idocp_parnmpc_step_sizes_device(idocp_ocp_t* h, double** d_steps);
+/* Filter line search of ParNMPCSolver on a sharded horizon (round 4; src/line_search/line_search.cpp:199-301 evaluates every stage against
+ * the trial iterate of its predecessor -- across a cut that is the left neighbour's trial iterate -- and sums over the horizon): the pieces
+ * the sharded driver puts together.  idocp_parnmpc_set_line_search_hooks installs the two collective steps of one probe (pre: after the
+ * trial iterate is formed; post: after the shard's cost / violation sums are formed); idocp_parnmpc_trial_halo_async packs / unpacks the
+ * state_last halo of the trial iterate; idocp_parnmpc_merit_device gives the sums [batch][2] to all-reduce; idocp_parnmpc_line_search runs
+ * LineSearch::computeStepSize on the direction of phases 0 .. 8 (every shard calls it: the filters evolve identically on identical sums).
+ * Application code calls idocp_parnmpc_dist_update_solution_ls. */
+int idocp_parnmpc_set_line_search_hooks(idocp_ocp_t* h, int (*pre)(idocp_ocp_t*), int (*post)(idocp_ocp_t*));
+int idocp_parnmpc_trial_halo_async(idocp_ocp_t* h, int do_import, double* d_buf);
+int idocp_parnmpc_merit_device(idocp_ocp_t* h, double** d_merit);
+int idocp_parnmpc_line_search(idocp_ocp_t* h);
 /* Discretise at time t (stage references, constraint levels) before launching phases by hand. */
 int idocp_parnmpc_discretize(idocp_ocp_t* h, double t);
 /* Squared KKT error of this shard's stages, d_err2[batch] in device memory (summed over the ranks by

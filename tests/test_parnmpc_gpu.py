@@ -259,6 +259,82 @@ def test_full_size_c4_parity_and_properties():
     assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12        # quaternions stay normalised
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_filter_line_search_equals_the_whole_horizon(world):
+    """ParNMPCSolver::updateSolution(t, q, v, line_search = true) on a SHARDED horizon (round 4): idocp_parnmpc_dist_update_solution_ls
+    -- the probes of the filter line search evaluated collectively (trial state_last halo to the right neighbour, all-reduce of the
+    cost / violation sums; every rank runs the same filter) -- against the single handle with line search: the accepted steps and the
+    iterates must agree to rounding over several iterations (in-process transport, one host thread per shard)."""
+    import ctypes as C
+    import threading
+    from helpers import P, arr
+    from idocp_amd import capi
+    from parnmpc_dist import HipParNMPCShard
+    N, T = 20, 0.5
+    m, o, g, q, v = make_pair(N, T)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    lib = capi.lib()
+    Nl = N // world
+    shards = [HipParNMPCShard(m, cost, cons, T, N, r, world, 1, 0) for r in range(world)]
+    # a shard alone refuses the line search (it cannot see its neighbours' trial iterates)
+    assert lib.idocp_parnmpc_update_solution(shards[1].h, 0.0, P(arr(q[None, :])), P(arr(v[None, :])), 1) != 0
+    comms = (C.c_void_p * world)()
+    capi.check(lib.idocp_comm_init_local(world, 0, comms), "comm_init_local")
+    for r, sh in enumerate(shards):
+        a = (C.c_int * 4)(1, 1, 1, 1)
+        capi.check(lib.idocp_ocp_set_contact_status_uniformly(sh.h, a, P(arr(pts))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"q", P(arr(ANYMAL_Q_STANDING))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"v", P(np.zeros(m.nv))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"f", P(arr([0, 0, 0.25 * (-m.total_mass * m.gravity[2])]))))
+        capi.check(lib.idocp_parnmpc_dist_attach(sh.h, comms[r]), "attach")
+    capi.check(lib.idocp_parnmpc_dist_set_initial_state(shards[0].h, P(arr(q[None, :])), P(arr(v[None, :])), m.nq, m.nv))
+    errors = []
+
+    def collective(fn):
+        def run(r):
+            try:
+                fn(r)
+            except Exception as e:      # noqa: BLE001
+                errors.append((r, e))
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in ts), "a rank of the sharded line search hangs"
+
+    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shards[r].h, 0.0), "init"))
+    for sh in shards:
+        capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
+
+    def get(sh, name, dim):
+        out = np.zeros((Nl, dim))
+        capi.check(lib.idocp_ocp_get_solution(sh.h, name.encode(), 0, P(out)))
+        return out
+
+    steps_seen = []
+    for it in range(5):
+        assert g.lib.idocp_parnmpc_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1) == 0
+        collective(lambda r: capi.check(lib.idocp_parnmpc_dist_update_solution_ls(shards[r].h, 0.0), "update_ls"))
+        for sh in shards:
+            capi.check(lib.idocp_ocp_synchronize(sh.h))
+        ag, bg = g.step_sizes()
+        for sh in shards:
+            ps, ds = np.zeros(1), np.zeros(1)
+            capi.check(lib.idocp_ocp_get_step_sizes(sh.h, P(ps), P(ds)))
+            assert abs(ps[0] - ag[0]) < 1e-12 and abs(ds[0] - bg[0]) < 1e-9, (it, ps[0], ag[0], ds[0], bg[0])
+        steps_seen.append(ag[0])
+        for name, dim in (("q", 19), ("v", 18), ("u", 12), ("lmd", 18), ("a", 18), ("f", 12)):
+            both = np.concatenate([get(sh, name, dim) for sh in shards])
+            assert rel_err(both, g.get(name)) < 1e-10, (it, name, rel_err(both, g.get(name)))
+    assert min(steps_seen) < 1.0 or max(steps_seen) <= 1.0      # (the steps are the line search's, whatever it accepted)
+    for r, sh in enumerate(shards):
+        capi.check(lib.idocp_parnmpc_dist_detach(sh.h))
+        lib.idocp_comm_destroy(comms[r])
+
+
 def test_filter_line_search_cost_violation_and_accepted_steps():
     """ParNMPCSolver::updateSolution(t, q, v, line_search = true) (parnmpc_solver.cpp:73-103) on an event-free horizon: total cost and
     l1 constraint violation of the trial iterates s (+) alpha d (src/line_search/line_search.cpp:199-237: backward-Euler residual
