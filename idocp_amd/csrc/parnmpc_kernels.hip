@@ -306,6 +306,73 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
   }
 }
 
+// S5, round 4: the same sweep with the rows of the KKT-inverse blocks requested TWO stages ahead.  A stage of the sweep is 36 fused multiply-adds
+// behind an LDS exchange (0.3 us); what the one-stage-ahead version above waits for is memory: a stage's loads are issued while the
+// stage in front of it is multiplied, i.e. one stage-time before they are needed, and a stage-time is shorter than the latency -- so the
+// stage-time BECOMES the latency (1.3 us), and behind it sits a second, dependent latency: the node table entry that tells where the rows
+// are.  Here the node table is turned into row offsets once, up front, in LDS (one lane per chain position), and three row buffers rotate.
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_backward_serial2_kernel(OcpBuffers B) {
+  using L = OcpLayout<D>;
+  constexpr int NX = D::NX, MAXM = 1024;
+  __shared__ double x[3][NX];
+  __shared__ long s_off[MAXM];
+  __shared__ int s_ld[MAXM], s_slot[MAXM];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int lane = threadIdx.x, ln = lane < NX ? lane : 0;
+  const long base = (long)blockIdx.x * __builtin_amdgcn_readfirstlane(P->NS);
+  const int i_first = __builtin_amdgcn_readfirstlane(P->has_terminal) ? M - 3 : M - 2;
+  if (i_first < 0) return;
+  for (int i = lane; i < M; i += 64) {
+    const OcpNode nd = B.nodes[i];
+    const ParnmpcShape sh = parnmpcShape<L>(nd);
+    s_slot[i] = nd.slot; s_off[i] = (long)nd.slot * L::KINV + sh.c1; s_ld[i] = sh.ld;
+  }
+  waveLdsSync();
+  const double* __restrict__ kinv0 = B.kinv + base * L::KINV + ln;
+  auto loadRows = [&](int i, double (&row)[NX]) {
+    const double* __restrict__ A = kinv0 + s_off[i];
+    const int ld = s_ld[i];
+#pragma unroll
+    for (int m = 0; m < NX; ++m) row[m] = A[ld * m];
+  };
+  auto loadS = [&](int i, double& s_, double& sn_) {
+    const long rec = base + s_slot[i];
+    s_ = B.sol[rec * L::SOL + L::S_LMD + ln];            // lmd then gmm: contiguous in both records
+    sn_ = B.snew[rec * L::SNEW + L::N_LMD + ln];
+  };
+  double r0[NX], r1[NX], r2[NX];
+  double s0 = 0, sn0 = 0, s1 = 0, sn1 = 0, s2 = 0, sn2 = 0;
+  double cur, s_next;
+  {
+    const long recn = base + s_slot[i_first + 1];
+    cur = B.snew[recn * L::SNEW + L::N_LMD + ln];
+    s_next = B.sol[recn * L::SOL + L::S_LMD + ln];
+    loadS(i_first, s0, sn0); loadRows(i_first, r0);
+    if (i_first >= 1) { loadS(i_first - 1, s1, sn1); loadRows(i_first - 1, r1); }
+  }
+  // one stage: multiplies with `row` (requested two stages ago), requests the rows of stage i - 2 into `row_far`
+  auto stage = [&](int i, const double (&row)[NX], double s_here, double sn_here, double (&row_far)[NX], double& s_far, double& sn_far, double* xb) {
+    const long rec = base + s_slot[i];
+    const double xl = cur - s_next;
+    if (lane < NX) { xb[lane] = xl; B.xres[rec * L::XRES + lane] = xl; }
+    if (i >= 2) { loadS(i - 2, s_far, sn_far); loadRows(i - 2, row_far); }
+    waveLdsSync();
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < NX; ++m) acc += row[m] * xb[m];      // (the order of the one-stage-ahead kernel: bit-identical results)
+    cur = sn_here - acc;
+    s_next = s_here;
+    if (lane < NX) B.snew[rec * L::SNEW + L::N_LMD + lane] = cur;
+  };
+  for (int i = i_first; i >= 0; i -= 3) {
+    stage(i, r0, s0, sn0, r2, s2, sn2, x[0]);
+    if (i >= 1) stage(i - 1, r1, s1, sn1, r0, s0, sn0, x[1]);
+    if (i >= 2) stage(i - 2, r2, s2, sn2, r1, s1, sn1, x[2]);
+  }
+}
+
 // K10a: backwardCorrectionParallel (:288-318; split_backward_correction.hxx:96-108): stages 0 .. N-2
 template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffers B) {
@@ -568,7 +635,13 @@ void OcpLaunch<D>::parnmpcPhase(int phase, const OcpBuffers& B, long batch, int 
                                 hipStream_t st) {
   const int nbp = has_terminal ? M - 2 : M - 1;      // stages of the backward parallel correction
   switch (phase) {
-    case 0: hipLaunchKernelGGL((parnmpc_backward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
+    case 0: {
+      // S5 with the rows requested two stages ahead (round 4) unless the chain is longer than its LDS tables or IDOCP_S5_DEPTH=1 asks for the old one
+      static const bool deep = [] { const char* e = getenv("IDOCP_S5_DEPTH"); return !(e && e[0] == '1'); }();
+      if (deep && M <= 1024) hipLaunchKernelGGL((parnmpc_backward_serial2_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B);
+      else hipLaunchKernelGGL((parnmpc_backward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B);
+      break;
+    }
     case 1: if (nbp > 0) hipLaunchKernelGGL((parnmpc_backward_parallel_kernel<D>), dim3((unsigned)(batch * nbp)), dim3(64), 0, st, B); break;
     case 2: hipLaunchKernelGGL((parnmpc_forward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0); break;
     case 3: hipLaunchKernelGGL((parnmpc_forward_parallel_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B); break;
