@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
@@ -306,11 +307,20 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
   }
 }
 
+#ifndef IDOCP_S5_BUFFERS
+#define IDOCP_S5_BUFFERS 3
+#endif
+template <int N, int K = 0, typename F>
+__device__ __forceinline__ void forEachConstS5(F f) {
+  if constexpr (K < N) { f(std::integral_constant<int, K>{}); forEachConstS5<N, K + 1>(f); }
+}
 // S5, round 4: the same sweep with the rows of the KKT-inverse blocks requested TWO stages ahead.  A stage of the sweep is 36 fused multiply-adds
 // behind an LDS exchange (0.3 us); what the one-stage-ahead version above waits for is memory: a stage's loads are issued while the
 // stage in front of it is multiplied, i.e. one stage-time before they are needed, and a stage-time is shorter than the latency -- so the
 // stage-time BECOMES the latency (1.3 us), and behind it sits a second, dependent latency: the node table entry that tells where the rows
-// are.  Here the node table is turned into row offsets once, up front, in LDS (one lane per chain position), and three row buffers rotate.
+// are.  Here the node table is turned into row offsets once, up front, in LDS (one lane per chain position), and three row buffers rotate
+// (IDOCP_S5_BUFFERS; four to six measured: 0.26 ms like three -- what is left, 1.0 us per stage, is the ~250 instructions of a stage on
+// the one wavefront a CU has of this kernel: 36 loads with their addresses, 36 LDS reads, 36 dependent multiply-adds).
 template <typename D>
 __global__ __launch_bounds__(64) void parnmpc_backward_serial2_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
@@ -342,34 +352,38 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial2_kernel(OcpBuffers
     s_ = B.sol[rec * L::SOL + L::S_LMD + ln];            // lmd then gmm: contiguous in both records
     sn_ = B.snew[rec * L::SNEW + L::N_LMD + ln];
   };
-  double r0[NX], r1[NX], r2[NX];
-  double s0 = 0, sn0 = 0, s1 = 0, sn1 = 0, s2 = 0, sn2 = 0;
+  constexpr int NB = IDOCP_S5_BUFFERS;                  // row buffers: a stage's rows are requested NB - 1 stages ahead
+  double r[NB][NX];
+  double sv[NB], snv[NB];
   double cur, s_next;
   {
     const long recn = base + s_slot[i_first + 1];
     cur = B.snew[recn * L::SNEW + L::N_LMD + ln];
     s_next = B.sol[recn * L::SOL + L::S_LMD + ln];
-    loadS(i_first, s0, sn0); loadRows(i_first, r0);
-    if (i_first >= 1) { loadS(i_first - 1, s1, sn1); loadRows(i_first - 1, r1); }
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) if (i_first - k >= 0) { loadS(i_first - k, sv[k], snv[k]); loadRows(i_first - k, r[k]); }
   }
-  // one stage: multiplies with `row` (requested two stages ago), requests the rows of stage i - 2 into `row_far`
-  auto stage = [&](int i, const double (&row)[NX], double s_here, double sn_here, double (&row_far)[NX], double& s_far, double& sn_far, double* xb) {
+  // one stage: multiplies with its rows (requested NB - 1 stages ago), requests the rows of stage i - (NB - 1) into the buffer that is free
+  auto stage = [&](int i, auto use_, auto far_) {
+    constexpr int use = decltype(use_)::value, far = decltype(far_)::value;
+    double* xb = x[use % 3];
     const long rec = base + s_slot[i];
     const double xl = cur - s_next;
     if (lane < NX) { xb[lane] = xl; B.xres[rec * L::XRES + lane] = xl; }
-    if (i >= 2) { loadS(i - 2, s_far, sn_far); loadRows(i - 2, row_far); }
+    if (i >= NB - 1) { loadS(i - (NB - 1), sv[far], snv[far]); loadRows(i - (NB - 1), r[far]); }
     waveLdsSync();
     double acc = 0.0;
 #pragma unroll
-    for (int m = 0; m < NX; ++m) acc += row[m] * xb[m];      // (the order of the one-stage-ahead kernel: bit-identical results)
-    cur = sn_here - acc;
-    s_next = s_here;
+    for (int m = 0; m < NX; ++m) acc += r[use][m] * xb[m];      // (the order of the one-stage-ahead kernel: bit-identical results)
+    cur = snv[use] - acc;
+    s_next = sv[use];
     if (lane < NX) B.snew[rec * L::SNEW + L::N_LMD + lane] = cur;
   };
-  for (int i = i_first; i >= 0; i -= 3) {
-    stage(i, r0, s0, sn0, r2, s2, sn2, x[0]);
-    if (i >= 1) stage(i - 1, r1, s1, sn1, r0, s0, sn0, x[1]);
-    if (i >= 2) stage(i - 2, r2, s2, sn2, r1, s1, sn1, x[2]);
+  for (int i = i_first; i >= 0; i -= NB) {
+    forEachConstS5<NB>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      if (i - k >= 0) stage(i - k, std::integral_constant<int, k>{}, std::integral_constant<int, (k + NB - 1) % NB>{});
+    });
   }
 }
 
