@@ -496,6 +496,100 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
   }
 }
 
+// S6, round 4: the same sweep with the stage's loads -- the 36 rows of its block of the KKT inverse, s of the stage before, the coarse s_new
+// of the stage -- requested TWO stages ahead (as in S5 above; the node table as offsets in LDS).  In the kernel above they are issued at the
+// top of the stage and hide behind the SE(3) log (1.1 us), but their latency is 2 us: the stage waits for them.  Same arithmetic, same order.
+template <typename D>
+__global__ __launch_bounds__(64) void parnmpc_forward_serial2_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
+  using L = OcpLayout<D>;
+  constexpr int NV = D::NV, NX = D::NX, MAXM = 1024;
+  constexpr int NQ = D::NQ, NS_ = NQ + NV;
+  __shared__ double x[NX], dx[NX], cur[NS_], spL[NS_], snL[NS_];
+  __shared__ long s_off[MAXM];
+  __shared__ int s_ld[MAXM], s_slot[MAXM];
+  const OcpProblem* __restrict__ P = B.prob;
+  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  const long base = b * __builtin_amdgcn_readfirstlane(P->NS);
+  const int i0 = __builtin_amdgcn_readfirstlane(P->has_prev) ? 0 : 1;
+  for (int i = lane; i < M; i += 64) {
+    const OcpNode nd = B.nodes[i];
+    const ParnmpcShape sh = parnmpcShape<L>(nd);
+    s_slot[i] = nd.slot; s_off[i] = (long)nd.slot * L::KINV + L::I_C0 + (sh.nk - NX); s_ld[i] = sh.ld;
+  }
+  {
+    const double *cq, *cv;
+    if (i0 == 0) { cq = B.fwd_prev + b * NS_; cv = cq + NQ; }
+    else { const long recp = base + B.nodes[0].slot; cq = B.snew + recp * L::SNEW + L::N_Q; cv = B.snew + recp * L::SNEW + L::N_V; }
+    if (lane < NQ) cur[lane] = cq[lane];
+    if (lane < NV) cur[NQ + lane] = cv[lane];
+  }
+  waveLdsSync();
+  const int lq = lane < NQ ? lane : 0, lvv = lane < NV ? lane : 0, lx = lane < NX ? lane : 0;
+  const double* __restrict__ kinv0 = B.kinv + base * L::KINV + lx;
+  // everything stage i reads from memory: s of the stage before (the measured state in front of stage 0), its own coarse s_new, its rows
+  auto fetch = [&](int i, double (&row)[NX], double& sp_q, double& sp_v, double& sn_q, double& sn_v) {
+    const long rec = base + s_slot[i];
+    const double *spq, *spv;
+    if (i == 0) { spq = q0 + b * NQ; spv = v0 + b * NV; }
+    else { const long recp = base + s_slot[i - 1]; spq = B.sol + recp * L::SOL + L::S_Q; spv = B.sol + recp * L::SOL + L::S_V; }
+    sp_q = spq[lq]; sp_v = spv[lvv];
+    sn_q = B.snew[rec * L::SNEW + L::N_Q + lq]; sn_v = B.snew[rec * L::SNEW + L::N_V + lvv];
+    const double* __restrict__ A = kinv0 + s_off[i];
+    const int ld = s_ld[i];
+#pragma unroll
+    for (int m = 0; m < NX; ++m) row[m] = A[ld * m];
+  };
+  constexpr int NB = 3;
+  double r[NB][NX], spq_[NB], spv_[NB], snq_[NB], snv_[NB];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) if (i0 + k <= M - 2) fetch(i0 + k, r[k], spq_[k], spv_[k], snq_[k], snv_[k]);
+  auto stage = [&](int i, auto use_, auto far_) {
+    constexpr int use = decltype(use_)::value, far = decltype(far_)::value;
+    const long rec = base + s_slot[i];
+    double* __restrict__ sn = B.snew + rec * L::SNEW;
+    if (i + NB - 1 <= M - 2) fetch(i + NB - 1, r[far], spq_[far], spv_[far], snq_[far], snv_[far]);
+    if (lane < NQ) { spL[lane] = spq_[use]; snL[lane] = snq_[use]; }
+    if (lane < NV) { spL[NQ + lane] = spv_[use]; snL[NQ + lane] = snv_[use]; }
+    waveLdsSync();
+    if (lane == 0) {
+      double R[9], p[3], d6[6];
+      lieRelative(spL, cur, R, p);          // s_new_prev.q (-) s_prev.q
+      lieLog6(R, p, d6);
+      for (int k = 0; k < 6; ++k) x[k] = d6[k];
+    }
+    if (lane >= 6 && lane < NV) x[lane] = cur[lane + 1] - spL[lane + 1];
+    if (lane < NV) x[NV + lane] = cur[NQ + lane] - spL[NQ + lane];
+    waveLdsSync();
+    if (lane < NX) {
+      B.xres[rec * L::XRES + lane] = x[lane];
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NX; ++m) acc += r[use][m] * x[m];
+      dx[lane] = acc;
+    }
+    waveLdsSync();
+    if (lane < NV) {
+      const double nv = snL[NQ + lane] - dx[NV + lane];
+      sn[L::N_V + lane] = nv; cur[NQ + lane] = nv;
+      if (lane >= 6) { const double nq = snL[lane + 1] - dx[lane]; sn[L::N_Q + lane + 1] = nq; cur[lane + 1] = nq; }
+    }
+    if (lane == 32) {
+      double qn[7];
+      lieIntegrateBase(snL, dx, -1.0, qn);
+      for (int k = 0; k < 7; ++k) { sn[L::N_Q + k] = qn[k]; cur[k] = qn[k]; }
+    }
+    waveLdsSync();
+  };
+  for (int i = i0; i <= M - 2; i += NB) {
+    forEachConstS5<NB>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      if (i + k <= M - 2) stage(i + k, std::integral_constant<int, k>{}, std::integral_constant<int, (k + NB - 1) % NB>{});
+    });
+  }
+}
+
 // K10b: forwardCorrectionParallel (:353-470; split_backward_correction.hxx:121-155): lmd / gmm / u corrections (stages > 0),
 // aux_mat = - KKT_inv.topLeftCorner(nx, nx), and the Newton direction d = s_new - s written into the dir record
 template <typename D>
@@ -657,7 +751,12 @@ void OcpLaunch<D>::parnmpcPhase(int phase, const OcpBuffers& B, long batch, int 
       break;
     }
     case 1: if (nbp > 0) hipLaunchKernelGGL((parnmpc_backward_parallel_kernel<D>), dim3((unsigned)(batch * nbp)), dim3(64), 0, st, B); break;
-    case 2: hipLaunchKernelGGL((parnmpc_forward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0); break;
+    case 2: {
+      static const bool deep = [] { const char* e = getenv("IDOCP_S6_DEPTH"); return !(e && e[0] == '1'); }();
+      if (deep && M <= 1024) hipLaunchKernelGGL((parnmpc_forward_serial2_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0);
+      else hipLaunchKernelGGL((parnmpc_forward_serial_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0);
+      break;
+    }
     case 3: hipLaunchKernelGGL((parnmpc_forward_parallel_kernel<D>), dim3((unsigned)(batch * (M - 1))), dim3(64), 0, st, B); break;
     default: hipLaunchKernelGGL((parnmpc_init_aux_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B); break;
   }
