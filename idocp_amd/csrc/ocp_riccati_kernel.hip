@@ -1415,15 +1415,27 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   constexpr int F2 = FL / 2, G2 = GL / 2, NF2 = (F2 + 63) / 64, NG2 = (G2 + 63) / 64;
   __shared__ __attribute__((aligned(16))) double fb[FL], gb[GL];
   __shared__ double dx[NX], du[NU], dxn[NX];
+  // the node table as the sweep needs it (slot, time step), in LDS up front: a stage's loads are requested two stages ahead, and an address
+  // that itself waits for a load from the node table shortens that distance by a memory latency (round 4; chains beyond the table read it
+  // from memory as before)
+  constexpr int MAXM = 1024;
+  __shared__ int s_slot[MAXM];
+  __shared__ double s_dtq[MAXM];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = __builtin_amdgcn_readfirstlane(P->M);
   const OcpNode* __restrict__ nodes = B.nodes;
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
-  const long base = b * P->NS;
+  const long base = b * __builtin_amdgcn_readfirstlane(P->NS);
+  const bool tab = M <= MAXM;
+  if (tab) {
+    for (int i = lane; i < M; i += 64) { s_slot[i] = nodes[i].slot; s_dtq[i] = nodes[i].dtq; }
+    waveLdsSync();
+  }
+  auto slotOf = [&](int i) -> int { return tab ? s_slot[i] : nodes[i].slot; };
   d2 frA[NF2], grA[NG2], frB[NF2], grB[NG2];        // two stages in flight
   auto fetch = [&](int i, d2 (&fr)[NF2], d2 (&gr)[NG2]) {
-    const long rec = base + nodes[i].slot;
+    const long rec = base + slotOf(i);
     const d2* __restrict__ fp = reinterpret_cast<const d2*>(B.kkt + rec * L::KKT + FO);
     const d2* __restrict__ gp = reinterpret_cast<const d2*>(B.gain + rec * L::GAIN);
 #pragma unroll
@@ -1433,13 +1445,13 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   };
   if (M > 1) fetch(0, frA, grA);
   if (M > 2) fetch(1, frB, grB);
-  const double* __restrict__ s0 = B.sol + (base + nodes[0].slot) * L::SOL;
+  const double* __restrict__ s0 = B.sol + (base + slotOf(0)) * L::SOL;
   // RiccatiRecursionSolver::computeInitialStateDirection (riccati_recursion_solver.cpp:110-126)
   if (lane == 0) {
     double R[9], p[3], d6[6];
     lieRelative(s0 + L::S_Q, q0 + b * NQ, R, p);         // q (-) s[0].q
     lieLog6(R, p, d6);
-    const double* __restrict__ Fi = B.exp + (base + nodes[0].slot) * L::EXP + L::E_FQQPI;
+    const double* __restrict__ Fi = B.exp + (base + slotOf(0)) * L::EXP + L::E_FQQPI;
     for (int r = 0; r < 6; ++r) { double acc = 0.0; for (int m = 0; m < 6; ++m) acc += Fi[r + 6 * m] * d6[m]; dx[r] = -acc; }
   }
   if (lane >= 6 && lane < NV) dx[lane] = q0[b * NQ + lane + 1] - s0[L::S_Q + lane + 1];
@@ -1451,8 +1463,8 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   const double* Fvu = fb + (L::K_FVU - FO);
   const double* Fx = fb + (L::K_FX - FO);
   auto step = [&](int i, d2 (&fr)[NF2], d2 (&gr)[NG2]) {       // forwardRiccatiRecursion along the chain (riccati_recursion_solver.cpp:129-162)
-    const long rec = base + nodes[i].slot;
-    const double dt = nodes[i].dtq;
+    const long rec = base + slotOf(i);
+    const double dt = tab ? s_dtq[i] : nodes[i].dtq;
     double* __restrict__ dd = B.dir + rec * L::DIR;
 #pragma unroll
     for (int t = 0; t < NF2; ++t) { const int e = lane + 64 * t; if (e < F2) reinterpret_cast<d2*>(fb)[e] = fr[t]; }
@@ -1508,7 +1520,7 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
     step(i, frA, grA);
     if (i + 1 < M - 1) step(i + 1, frB, grB);
   }
-  double* __restrict__ dd = B.dir + (base + nodes[M - 1].slot) * L::DIR;
+  double* __restrict__ dd = B.dir + (base + slotOf(M - 1)) * L::DIR;
   if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
 }
 
