@@ -12,15 +12,19 @@
 // W = L^-1 (lower triangular), S = M M^T, N = M^-1 every block of the inverse is a product of W, N, F -- and every product is taken in the
 // one form the matrix core offers without moving data: a 16 x 16 tile in the ACCUMULATOR layout of v_mfma_f64_16x16x4_f64 (lane = 16 g + li
 // holds rows 4 q + g, q = 0 .. 3, of column li) is, register by register, the A operand of X^T and the B operand of X, so that
-// P(X, Y) = X^T Y costs four instructions per tile and nothing else.  With Y = W F^T:
-//   S = P(Y, Y),  V = Y N^T = P(Y^T, N^T),  U^T = P(V, W),  TR = S^-1 F Q^-1 = P(N, U^T),  TL = -P(N, N),  BR = P(W, W) - P(U^T, U^T)
-// (transposed copies of tiles go through a 2 kB LDS scratch: four writes, four reads).  The factorisations are blocked by 16: a diagonal
+// P(X, Y) = X^T Y costs four instructions per tile and nothing else.  With Y = W F^T = P(W^T, F^T):
+//   S = P(Y, Y),  Q^-1 = P(W, W),  FQ = F Q^-1 = P(Y, W),  Z1 = N FQ = P(N^T, FQ),
+//   TR = S^-1 F Q^-1 = P(N, Z1),  TR^T = P(Z1, N),  TL = -S^-1 = -P(N, N),  BR = Q^-1 - P(Z1, Z1)
+// (transposed copies of tiles -- W^T, N^T -- go through a 2 kB LDS scratch: four writes, four reads).  The factorisations are blocked by 16: a diagonal
 // block is factorised AND inverted in one pass over its 16 pivots with one matrix row and one right-hand side (a unit vector) per lane and
 // the column entries travelling as DPP row broadcasts (the scheme of choleskySolveRows, dev_dense.hpp); panels, trailing updates and the
 // off-diagonal blocks of W are P-products again.  S has 36 rows: its third block is 4 x 4 padded with the identity, and column 36 of
 // the padding carries the vectors -- F^T gets r2 = [lu; lx] as a 37th column, so that W r2 and F Q^-1 r2 fall out of Y and S.
 // The coarse direction KKT^-1 [r1; r2] is four matrix-vector products that contract over the ROWS of accumulator-layout tiles.
-// One wavefront per stage, no workgroup barrier; against K9b's 256 threads with 84 barriers and ~10^4 vector instructions per thread.
+// One wavefront per stage, no workgroup barrier, TWO wavefronts per SIMD (<= 256 registers, 19.5 kB LDS: what does not fit waits in LDS --
+// FQ during the factorisation of S -- or in the stage's dead lin record -- Q^-1 until BR is formed); every global access is a 16-byte piece
+// of a 1 kB run (loads requested at once at the top, output staged in LDS by blocks of 16 columns).  Against K9b's 256 threads with 84
+// barriers and ~10^4 vector instructions per thread: 4.45 -> 2.2 ms (with the list of what the compiler had to be talked out of).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -541,7 +545,6 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
   //      (rho, kappa) = TL(kappa, rho) for rho < 36, TR(kappa, rho - 36) below -- the tiles (a, b) as they are ----
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    constexpr int dummy = 0; (void)dummy;
     const int ncol = a < 2 ? 16 : NX - 32;
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
