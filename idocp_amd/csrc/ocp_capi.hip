@@ -335,6 +335,7 @@ int discretize(idocp_ocp* h, double t) {
   std::vector<double> tab((size_t)M * DQ::NQ);
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
+  h->B.M = M; h->B.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   { const int rct = uploadTaskRefs(h, t, M); if (rct) return rct; }
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
@@ -512,6 +513,7 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   std::vector<double> tab((size_t)M * DQ::NQ);
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
+  h->B.M = M; h->B.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   { const int rct = uploadTaskRefs(h, t, M); if (rct) return rct; }
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));
@@ -558,6 +560,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   std::vector<double> tab((size_t)M * DQ::NQ);
   for (int p = 0; p < M; ++p) { qRefAt(h->cost, DQ::NQ, h->chain_t[p], &tab[(size_t)p * DQ::NQ]); h->chain[p].vref_on = vRefOnAt(h->cost, h->chain_t[p]); }
   h->prob.M = M; h->prob.NS = h->NS;
+  h->B.M = M; h->B.NS = h->NS;
   HIP_TRY(hipMemcpyAsync(h->d_qref, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   { const int rct = uploadTaskRefs(h, t, M); if (rct) return rct; }
   HIP_TRY(hipMemcpyAsync(h->d_nodes, h->chain.data(), sizeof(OcpNode) * M, hipMemcpyHostToDevice, h->stream));

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok, s_c1;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   int tid = threadIdx.x;
   constexpr int nt = 256;
   const int per = plist ? nlist : M;              // units: batch * M, one stage of the chain each (or batch * nlist: the chain positions of one
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
   if (BWD && terminal) {                            // placeholder stage (no cost, no constraint: the line search sums zeros)
-    if (MERIT && threadIdx.x < 2) B.merit_stage[(b * P->NS + nd->slot) * 4 + threadIdx.x] = 0.0;
+    if (MERIT && threadIdx.x < 2) B.merit_stage[(b * B.NS + nd->slot) * 4 + threadIdx.x] = 0.0;
     return;
   }
   const bool last = BWD && P->has_terminal && (pos == M - 2);   // ParNMPC: the stage that carries the terminal cost
@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // DIMF >= 0: the number of active contact rows is a compile-time constant (every loop bound and
   // index division below folds); DIMF < 0: read it from the stage's node.
   const int dimf = (DIMF >= 0) ? DIMF : nd->dimf, dimvf = NV + dimf;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ s_g = B.sol + rec * L::SOL;
-  const double* __restrict__ sn_g = B.sol + (b * P->NS + (terminal ? nd->slot : nd->next)) * L::SOL;
+  const double* __restrict__ sn_g = B.sol + (b * B.NS + (terminal ? nd->slot : nd->next)) * L::SOL;
   const double* s = &sm[S::SOLS];                   // LDS copies of this stage's and the next stage's solution records
   const double* sn = &sm[S::SOLN];                  // (only valid for non-terminal stages)
   const double* q = s + L::S_Q;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     const double lmd = s[L::S_LMD + r], gmm = s[L::S_GMM + r], lmdn = sn[L::S_LMD + r], gmmn = sn[L::S_GMM + r];
     double lq, lv, la, hq = 0.0, hv, ha;
     // backward Euler: the predecessor's state (the measured state in front of the first stage)
-    const double* __restrict__ sp_g = (BWD && nd->prev >= 0) ? B.sol + (b * P->NS + nd->prev) * L::SOL : nullptr;
+    const double* __restrict__ sp_g = (BWD && nd->prev >= 0) ? B.sol + (b * B.NS + nd->prev) * L::SOL : nullptr;
     const double qpr = !BWD ? 0.0 : (sp_g ? sp_g[L::S_Q + r + 1] : q0[b * NQ + r + 1]);
     const double vpr = !BWD ? 0.0 : (sp_g ? sp_g[L::S_V + r] : v0[b * NV + r]);
     double fq;
@@ -894,14 +894,14 @@ __global__ __launch_bounds__(64) void parnmpc_lie_kernel(OcpBuffers B, const dou
   using L = OcpLayout<D>;
   constexpr int NQ = D::NQ;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const long unit = (long)blockIdx.x * 64 + threadIdx.x;
   if (unit >= (long)P->batch * (M - 1)) return;
   const long b = unit / (M - 1);
   const int pos = (int)(unit - b * (M - 1));
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const int task = blockIdx.y;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
   double* __restrict__ zz = B.lie + rec * L::LIE;
@@ -913,11 +913,11 @@ __global__ __launch_bounds__(64) void parnmpc_lie_kernel(OcpBuffers B, const dou
     for (int k = 0; k < 36; ++k) zz[L::Z_JQ + k] = Ja[k];
     for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
   } else if (task == 1) {
-    lieRelative(B.sol + (b * P->NS + nd->next) * L::SOL + L::S_Q, q, R, p);      // q (-) q_next; ARG of q: Jlog6
+    lieRelative(B.sol + (b * B.NS + nd->next) * L::SOL + L::S_Q, q, R, p);      // q (-) q_next; ARG of q: Jlog6
     lieJlog6(R, p, Ja);
     for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
   } else {
-    const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * NQ) : (B.sol + (b * P->NS + nd->prev) * L::SOL + L::S_Q);
+    const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * NQ) : (B.sol + (b * B.NS + nd->prev) * L::SOL + L::S_Q);
     lieRelative(q, q_prev, R, p);                                                 // q_prev (-) q
     lieLog6(R, p, d6);
     for (int k = 0; k < 6; ++k) zz[L::Z_FQ6 + k] = d6[k];

@@ -206,6 +206,9 @@ struct OcpBuffers {
   const DevModel* model;
   const OcpProblem* prob;
   const OcpNode* nodes;  // [M] the chain
+  int M, NS;              // host-side copies of prob->M, prob->NS (set with every discretisation): kernel ARGUMENTS, i.e. scalar loads from the
+                          // kernarg segment -- every per-stage kernel needs them to find its stage, and P->M is a global load it would wait for
+                          // before it can even request its node (three dependent latencies to the first record byte instead of two)
   const int* impulse_pos; // chain positions of the impulse stages
   int n_impulse_fe;       // host-side: number of impulse stages of a FORWARD-EULER chain (OCPSolver): nominal records + tangent items; 0 under ParNMPC (K5a / K9i)
   const int* general_pos; // ParNMPC: chain positions of the stages with a general KKT shape (aux with switching rows, impulse)

@@ -133,14 +133,14 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   double* mjd = pm;
   __shared__ double dx[NX], du[NU], dfs[NF], das[NV];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
   const long b = unit / M;
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool terminal = (pos == M - 1);
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   double* __restrict__ dd = B.dir + rec * L::DIR;
   if (P->backward_euler && terminal) return;        // ParNMPC: placeholder stage
   const bool costate = !P->backward_euler;          // ParNMPC: dlmd, dgmm come from the backward correction (K10b)
@@ -257,11 +257,11 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
 
 __global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const long b = blockIdx.x;
   double ps = 1.0, ds = 1.0;
   for (int i = threadIdx.x; i < M - 1; i += 64) {
-    const long rec = b * P->NS + B.nodes[i].slot;
+    const long rec = b * B.NS + B.nodes[i].slot;
     ps = fmin(ps, B.step_stage[rec * 2]); ds = fmin(ds, B.step_stage[rec * 2 + 1]);
   }
 #pragma unroll
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
 
 __global__ __launch_bounds__(64) void ocp_kkt_error_kernel(OcpBuffers B, double* __restrict__ squared_out) {
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const long b = blockIdx.x;
   double e = 0.0;
-  for (int i = threadIdx.x; i < M; i += 64) e += B.err_stage[b * P->NS + B.nodes[i].slot];
+  for (int i = threadIdx.x; i < M; i += 64) e += B.err_stage[b * B.NS + B.nodes[i].slot];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
   if (threadIdx.x == 0) { if (squared_out) squared_out[b] = e; else B.err[b] = sqrt(e); }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   static_assert(L::NCON <= 128, "two IPM rows per lane");
   __shared__ double dgn[NV], laf[NVF + 2], dbm[NVF + 2], nup[6], dmu[NF];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
   const long b = unit / M;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   const bool bwd = P->backward_euler != 0;          // ParNMPC: own dgmm, + Fqq_inv^T in the costate correction
   if (bwd && !stage) return;
   const double dt = nd->dt;                         // 1 on impulse stages
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
   double* __restrict__ dd = B.dir + rec * L::DIR;
   double* __restrict__ s = B.sol + rec * L::SOL;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
 #pragma unroll
     for (int t = 0; t < 2; ++t) { const int row = lane + 64 * t; if (row < L::NCON) { sl_r[t] = slack[row]; dl_r[t] = dual[row]; } }
     // dgmm of the next stage of the chain (backward Euler: of this stage)
-    if (lane < NV) dgn_r = B.dir[(b * P->NS + (bwd ? nd->slot : nd->next)) * L::DIR + L::D_GMM + lane];
+    if (lane < NV) dgn_r = B.dir[(b * B.NS + (bwd ? nd->slot : nd->next)) * L::DIR + L::D_GMM + lane];
   }
   const bool bimp = bwd && nd->kind == 1;           // ParNMPC impulse stage (K9i filled the exp record): only the dv rows, dmu from K10b
   const int dimf = nd->dimf, dimvf = bimp ? NV : NV + dimf;
@@ -472,14 +472,14 @@ __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NF = D::NF;
   __shared__ double dx[NX], du[NU], dfs[NF];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
   const long b = unit / M;
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const bool stage = (pos < M - 1);
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double a = B.ls_alpha[b];
   const double* __restrict__ dd = B.dir + rec * L::DIR;
   const double* __restrict__ s = B.sol + rec * L::SOL;
@@ -523,11 +523,11 @@ __global__ __launch_bounds__(64) void ocp_trial_kernel(OcpBuffers B) {
 // totals of the chain: merit[b] = (sum of stage costs + barrier costs, sum of violations)
 __global__ __launch_bounds__(64) void ocp_merit_reduce_kernel(OcpBuffers B) {
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const long b = blockIdx.x;
   double c = 0.0, v = 0.0;
   for (int i = threadIdx.x; i < M; i += 64) {
-    const double* __restrict__ ms = B.merit_stage + (b * P->NS + B.nodes[i].slot) * 4;
+    const double* __restrict__ ms = B.merit_stage + (b * B.NS + B.nodes[i].slot) * 4;
     c += ms[0] + ms[2]; v += ms[1];
   }
 #pragma unroll
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64) void ocp_init_constraints_kernel(OcpBuffers B) 
   // ocp_linearizer.cpp:40-70, covers all N grid stages and the event stages): a later re-discretisation may bring a
   // slot into the chain.  Kind and gating level follow from the slot index alone.
   const OcpProblem* __restrict__ P = B.prob;
-  const int NS = P->NS, N = P->N, E = P->E;
+  const int NS = B.NS, N = P->N, E = P->E;
   const long su = blockIdx.x;                       // over batch * NS
   const int slot = (int)(su % NS);
   const bool impulse = (slot > N && slot <= N + E);

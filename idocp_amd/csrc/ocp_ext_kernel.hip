@@ -96,13 +96,13 @@ __global__ __launch_bounds__(64) void ocp_ext_kernel(OcpBuffers B, int residual)
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NC = D::NC;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
   const long b = unit / M;
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   double* __restrict__ xx = B.ext + rec * L::EXT;
   const bool bwd = P->backward_euler != 0;
   if (bwd && pos == M - 1) {                        // ParNMPC: placeholder behind the last stage
@@ -187,13 +187,13 @@ __global__ __launch_bounds__(64) void ocp_ext_hessian_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NX = D::NX, NC = D::NC;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const long unit = blockIdx.x;
   const long b = unit / M;
   const int pos = (int)(unit - b * M);
   const OcpNode* __restrict__ nd = B.nodes + pos;
   if (P->backward_euler && pos == M - 1) return;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ xx = B.ext + rec * L::EXT;
   double* __restrict__ kk = B.kkt + rec * L::KKT;
   double w[NC + 6];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void ocp_ext_init_kernel(OcpBuffers B, long nre
   const OcpProblem* __restrict__ P = B.prob;
   const long su = (long)blockIdx.x * 64 + threadIdx.x;
   if (su >= nrec) return;
-  const int NS = P->NS, N = P->N, E = P->E;
+  const int NS = B.NS, N = P->N, E = P->E;
   const int slot = (int)(su % NS);
   const bool impulse = (slot > N && slot <= N + E);
   const int level = (slot <= N) ? slot + (P->backward_euler ? 1 + P->stage_offset : 0) : (impulse ? -1 : 0);

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
   __shared__ long long recs[64];
   const OcpProblem* __restrict__ P = B.prob;
   const DevModel* __restrict__ m = B.model;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   // XCD-aware block order: workgroup n runs on XCD n % 8 and every XCD has an L2 of its own, so the 2 NL + 1 task blocks that read the
   // SAME 64 solution records are given ids that agree mod 8 and lie within 8 (2 NL + 1) of each other: n = (g_hi (2 NL + 1) + task) 8 + g_lo
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
   const OcpNode* __restrict__ nd = B.nodes + pos;
   // the terminal stage has no dynamics; impulse stages have a launch of their own (IMP)
   const bool valid = in_range && pos != M - 1 && (IMP || nd->kind != 1);
-  const long rec = (dbg & 2) ? 0 : b * P->NS + nd->slot;       // (lanes that are not valid compute on this record too and store nothing)
+  const long rec = (dbg & 2) ? 0 : b * B.NS + nd->slot;       // (lanes that are not valid compute on this record too and store nothing)
   const double* __restrict__ s = B.sol + rec * L::SOL;
   double* __restrict__ nom = B.nom + rec * L::NOM;
   const double gz = IMP ? 0.0 : m->gravity[2];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
       for (int k = 0; k < 6; ++k) zz[L::Z_QDIFF + k] = d6[k];
     } else if (lt == 1) {
       if (pos == M - 1) return;
-      lieRelative(B.sol + (b * P->NS + nd->next) * L::SOL + L::S_Q, sq, R, p);
+      lieRelative(B.sol + (b * B.NS + nd->next) * L::SOL + L::S_Q, sq, R, p);
       lieLog6(R, p, d6);
       lieJlog6(R, p, Ja);
       for (int k = 0; k < 36; ++k) zz[L::Z_FQQ + k] = Ja[k];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
       lieBlockInverse(Jb, Ja);
       for (int k = 0; k < 36; ++k) zz[L::Z_FQQI + k] = Ja[k];
     } else {
-      const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * D::NQ) : (B.sol + (b * P->NS + nd->prev) * L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
+      const double* __restrict__ q_prev = (nd->prev < 0) ? (q0 + b * D::NQ) : (B.sol + (b * B.NS + nd->prev) * L::SOL + L::S_Q);      // ocp_linearizer.hxx:231-248
       lieRelative(sq, q_prev, R, p);
       lieJlog6(R, p, Ja);
       lieDDiffArg0(R, p, Ja, Jb);

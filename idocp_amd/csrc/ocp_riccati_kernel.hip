@@ -332,13 +332,13 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_ker
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const OcpNode* __restrict__ nodes = B.nodes;
   const int tid = threadIdx.x;
   constexpr int nt = NT;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const long b = blockIdx.x;
-  const long base = b * P->NS;                    // first record of this instance
+  const long base = b * B.NS;                    // first record of this instance
   double* Pqq = &sm[S::PQQ];
   double* Pqv = &sm[S::PQV];
   double* Pvv = &sm[S::PVV];
@@ -773,14 +773,14 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int M = B.M;
   const OcpNode* __restrict__ nodes = B.nodes;
   const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
   const long b = blockIdx.x;
   // (values that are the same in every lane are made scalar by hand: the node table and the problem block are read with vector loads --
   // the kernel also stores to global memory, so the compiler will not use the scalar cache -- and everything derived from a vector
   // load, the record addresses first of all, would live in VGPR pairs)
-  const long base = b * __builtin_amdgcn_readfirstlane(P->NS);
+  const long base = b * B.NS;
   const bool p32 = __builtin_amdgcn_readfirstlane(P->ric_fp32) != 0;
   auto st32 = [&](double x) { return p32 ? (double)(float)x : x; };
   auto slotOf = [&](int pos) { return (long)__builtin_amdgcn_readfirstlane(nodes[pos].slot); };
@@ -1422,11 +1422,11 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
   __shared__ int s_slot[MAXM];
   __shared__ double s_dtq[MAXM];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int M = B.M;
   const OcpNode* __restrict__ nodes = B.nodes;
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
-  const long base = b * __builtin_amdgcn_readfirstlane(P->NS);
+  const long base = b * B.NS;
   const bool tab = M <= MAXM;
   if (tab) {
     for (int i = lane; i < M; i += 64) { s_slot[i] = nodes[i].slot; s_dtq[i] = nodes[i].dtq; }

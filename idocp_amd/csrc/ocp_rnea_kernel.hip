@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
   __shared__ double s_bn[NL + 1][6];      // nominal base force: own, then per leg
   const DevModel* __restrict__ m = B.model;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;                       // one non-terminal stage of the chain per wavefront
   const int per = IMPULSE ? nlist : (M - 1);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void ocp_rnea_kernel(OcpBuffers B, int nlist) {
   const OcpNode* __restrict__ nd = B.nodes + pos;
   constexpr bool impulse = IMPULSE;
   if (!IMPULSE && nd->kind == 1) return;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
   if (lane < D::NU) {

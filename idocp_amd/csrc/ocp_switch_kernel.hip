@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void ocp_switch_kernel(OcpBuffers B, int nsw) {
   __shared__ double s_dq[NV], s_q2[NQ], s_pq[NF][NV + 1], s_cs[NU][2], s_A0[36], s_Je[36], s_P[NF];
   const DevModel* __restrict__ m = B.model;
   const int lane = threadIdx.x;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ s = B.sol + rec * L::SOL;
   const double* __restrict__ q = s + L::S_Q;
   const double dt1 = nd->sw_dt1, dt2 = nd->sw_dt2;

@@ -51,10 +51,10 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
   const int pos = B.impulse_pos[blockIdx.y];
   const OcpNode* __restrict__ nd = B.nodes + pos;
   const int ni = nd->dimf;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ s = B.sol + rec * L::SOL;
-  const double* __restrict__ sn = B.sol + (b * P->NS + nd->next) * L::SOL;
-  const double* __restrict__ sp = nd->prev >= 0 ? B.sol + (b * P->NS + nd->prev) * L::SOL : nullptr;
+  const double* __restrict__ sn = B.sol + (b * B.NS + nd->next) * L::SOL;
+  const double* __restrict__ sp = nd->prev >= 0 ? B.sol + (b * B.NS + nd->prev) * L::SOL : nullptr;
   const double* __restrict__ lin = B.lin + rec * L::LIN;
   const double* __restrict__ zz = B.lie + rec * L::LIE;
   const double* __restrict__ qref = B.q_ref + (long)pos * NQ;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int tid = threadIdx.x, nt = 256;
   const long b = blockIdx.x;
   const int pos = B.general_pos[blockIdx.y];
@@ -322,10 +322,10 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_general_kernel(OcpBuf
   const bool impulse = sh.impulse;
   const bool last = P->has_terminal && (pos == M - 2);
   const double dt = nd->dt;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ kk = B.kkt + rec * L::KKT;
   const double* __restrict__ Wc = B.swc + rec * L::SWC;
-  const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
+  const double* __restrict__ aux = B.aux + (b * B.NS + nd->next) * L::AUX;
   double* __restrict__ ki = B.kinv + rec * L::KINV;
   if (tid == 0) s_ok = 1;
   // ---- Q over (w, q, v), padded, straight into the register tiles ----

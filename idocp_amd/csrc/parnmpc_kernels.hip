@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int tid = threadIdx.x, nt = 256;
   const long unit = blockIdx.x;
   const long b = unit / (M - 1);
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void parnmpc_kkt_inverse_kernel(OcpBuffers B) 
   if (parnmpcShape<L>(*nd).general) return;        // aux stages with switching rows and impulse stages: parnmpc_event_kernels.hip
   const bool last = P->has_terminal && (pos == M - 2);
   const double dt = nd->dt;
-  const long rec = b * P->NS + nd->slot;
+  const long rec = b * B.NS + nd->slot;
   const double* __restrict__ kk = B.kkt + rec * L::KKT;
-  const double* __restrict__ aux = B.aux + (b * P->NS + nd->next) * L::AUX;
+  const double* __restrict__ aux = B.aux + (b * B.NS + nd->next) * L::AUX;
   double* __restrict__ ki = B.kinv + rec * L::KINV;
   if (tid == 0) s_ok = 1;
   // ---- Qss in the order (u, q, v) (SplitBackwardCorrection::coarseUpdate: Qxx += aux_mat_next, Qvq = Qqv^T, Qux = Qxu^T):
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial_kernel(OcpBuffers 
   constexpr int NX = D::NX;
   __shared__ double x[2][NX];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x, ln = lane < NX ? lane : 0;
-  const long base = (long)blockIdx.x * P->NS;
+  const long base = (long)blockIdx.x * B.NS;
   // a shard that does not end the horizon also corrects its last stage, against the imported first stage of its
   // right neighbour (held in the placeholder records)
   const int i_first = P->has_terminal ? M - 3 : M - 2;
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(64) void parnmpc_backward_serial2_kernel(OcpBuffers
   __shared__ long s_off[MAXM];
   __shared__ int s_ld[MAXM], s_slot[MAXM];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int M = B.M;
   const int lane = threadIdx.x, ln = lane < NX ? lane : 0;
-  const long base = (long)blockIdx.x * __builtin_amdgcn_readfirstlane(P->NS);
+  const long base = (long)blockIdx.x * B.NS;
   const int i_first = __builtin_amdgcn_readfirstlane(P->has_terminal) ? M - 3 : M - 2;
   if (i_first < 0) return;
   for (int i = lane; i < M; i += 64) {
@@ -394,13 +394,13 @@ __global__ __launch_bounds__(64) void parnmpc_backward_parallel_kernel(OcpBuffer
   constexpr int NV = D::NV, NX = D::NX;
   __shared__ double x[NX], dz[L::NKG - NX];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
   const int per = P->has_terminal ? M - 2 : M - 1;
   const long b = unit / per;
   const int pos = (int)(unit - b * per);
-  const long rec = b * P->NS + B.nodes[pos].slot;
+  const long rec = b * B.NS + B.nodes[pos].slot;
   const ParnmpcShape sh = parnmpcShape<L>(B.nodes[pos]);
   const int ni = sh.ni, nw = sh.nw;
   if (lane < NX) x[lane] = B.xres[rec * L::XRES + lane];
@@ -430,9 +430,9 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial_kernel(OcpBuffers B
   // cur = the corrected (q, v) of the stage before; sp / sn = s and the coarse s_new (q, v) of the stages i - 1 / i
   __shared__ double x[NX], dx[NX], cur[NS_], spL[NS_], snL[NS_];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
-  const long base = (long)blockIdx.x * P->NS;
+  const long base = (long)blockIdx.x * B.NS;
   const long b = blockIdx.x;
   // a shard with a left neighbour also corrects its first stage: previous state = the imported (q, v) of the
   // neighbour's last stage (q0, v0), its corrected value = fwd_prev
@@ -508,10 +508,10 @@ __global__ __launch_bounds__(64) void parnmpc_forward_serial2_kernel(OcpBuffers 
   __shared__ long s_off[MAXM];
   __shared__ int s_ld[MAXM], s_slot[MAXM];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
-  const long base = b * __builtin_amdgcn_readfirstlane(P->NS);
+  const long base = b * B.NS;
   const int i0 = __builtin_amdgcn_readfirstlane(P->has_prev) ? 0 : 1;
   for (int i = lane; i < M; i += 64) {
     const OcpNode nd = B.nodes[i];
@@ -598,12 +598,12 @@ __global__ __launch_bounds__(64) void parnmpc_forward_parallel_kernel(OcpBuffers
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU;
   __shared__ double x[NX], dh[L::NKG - NX];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long unit = blockIdx.x;
   const long b = unit / (M - 1);
   const int pos = (int)(unit - b * (M - 1));
-  const long rec = b * P->NS + B.nodes[pos].slot;
+  const long rec = b * B.NS + B.nodes[pos].slot;
   const ParnmpcShape sh = parnmpcShape<L>(B.nodes[pos]);
   const int ni = sh.ni, nw = sh.nw, ld = sh.ld;
   const double* __restrict__ ki = B.kinv + rec * L::KINV;
@@ -658,10 +658,10 @@ __global__ __launch_bounds__(64) void parnmpc_init_aux_kernel(OcpBuffers B) {
   constexpr int NV = D::NV, NX = D::NX, NQ = D::NQ;
   __shared__ double Jq[36];
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
-  const long base = b * P->NS;
+  const long base = b * B.NS;
   if (lane == 0) {
     double R[9], p[3];
     lieRelative(B.q_ref + (long)(M - 2) * NQ, B.sol + (base + B.nodes[M - 2].slot) * L::SOL + L::S_Q, R, p);
@@ -693,9 +693,9 @@ __global__ void parnmpc_halo_kernel(OcpBuffers B, int kind, int do_import, doubl
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX;
   const OcpProblem* __restrict__ P = B.prob;
-  const int M = P->M;
+  const int M = B.M;
   const long b = blockIdx.x;
-  const long base = b * P->NS;
+  const long base = b * B.NS;
   const long first = base + B.nodes[0].slot, lastr = base + B.nodes[M - 2].slot, ph = base + B.nodes[M - 1].slot;
   const int size = (kind == 0 || kind == 4) ? NQ + NV : (kind == 1 ? 2 * NV + NQ : (kind == 3 ? 2 * NV : NX * NX));
   double* __restrict__ x = buf + b * size;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
   const OcpProblem* __restrict__ P = B.prob;
   // (uniform values are made scalar by hand: the kernel stores to global memory, so the problem block and the node table are read with
   //  vector loads, and addresses derived from them would live in vector registers)
-  const int M = __builtin_amdgcn_readfirstlane(P->M);
+  const int M = B.M;
   const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
   const int unit = blockIdx.x;
   const int bi = unit / (M - 1);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
   if (__builtin_amdgcn_readfirstlane((int)parnmpcShape<L>(*nd).general)) return;
   const bool last = __builtin_amdgcn_readfirstlane(P->has_terminal) && (pos == M - 2);
   const double dt = nd->dt;
-  const int NS = __builtin_amdgcn_readfirstlane(P->NS);
+  const int NS = B.NS;
   const long rec = b * NS + __builtin_amdgcn_readfirstlane(nd->slot);
   auto uniformPtr = [](const double* p) -> const double* {
     const unsigned long long u = reinterpret_cast<unsigned long long>(p);
