@@ -448,11 +448,9 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       s[L::S_BETA + r] = sr[L::S_BETA + r] + ap * dbm[r];
     }
   }
-  if (lane == 32) {
-    double qn[7];
-    lieIntegrateBase(sr + L::S_Q, dx, ap, qn);
-    for (int k = 0; k < 7; ++k) s[L::S_Q + k] = qn[k];
-  }
+  // (the base pose q (+) ap dq -- an SE(3) exponential -- is NOT done here: one lane walking its ~400 instructions while 63 wait is a tenth
+  //  of this kernel's time; ocp_integrate_base_kernel below does it with one LANE per stage.  It reads the base pose and dq, which this
+  //  kernel does not touch.)
   if (stage) {
     if (nd->has_u) {
       if (lane >= 40 && lane < 40 + NU) s[L::S_U + lane - 40] = sr[L::S_U + lane - 40] + ap * du[lane - 40];
@@ -464,6 +462,32 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       if (lane < nd->sw_dimi) s[L::S_XI + lane] = sr[L::S_XI + lane] + ap * dr[L::D_XI + lane];       // split_solution.hxx:235-238
     }
   }
+}
+
+// K7b: the base pose of SplitSolution::integrate (robot.integrateConfiguration, split_solution.hxx:212-239) for every stage of every instance,
+// one lane per stage: q_base <- q_base (+) ap dq_base.  Runs behind K7 on the same stream (either order would do: K7 leaves the base pose and
+// dq alone).  Round 4; until then lane 32 of every K7 wavefront did this while the other 63 lanes waited (0.06 of K7's 0.56 ms).
+template <typename D>
+__global__ __launch_bounds__(64) void ocp_integrate_base_kernel(OcpBuffers B, long total) {
+  using L = OcpLayout<D>;
+  const long unit = (long)blockIdx.x * 64 + threadIdx.x;
+  if (unit >= total) return;
+  const int M = B.M;
+  const long b = unit / M;
+  const int pos = (int)(unit - b * M);
+  if (B.prob->backward_euler != 0 && pos == M - 1) return;      // ParNMPC: the placeholder stage is not integrated (K7 returns there too)
+  const long rec = b * B.NS + B.nodes[pos].slot;
+  double* __restrict__ s = B.sol + rec * L::SOL;
+  const double* __restrict__ dd = B.dir + rec * L::DIR;
+  const double ap = B.step[b * 2];
+  double q[7], dq[6], qn[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) q[k] = s[L::S_Q + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dq[k] = dd[L::D_Q + k];
+  lieIntegrateBase(q, dq, ap, qn);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) s[L::S_Q + k] = qn[k];
 }
 
 template <typename D>
@@ -624,6 +648,8 @@ void OcpLaunch<D>::expandPrimal(const OcpBuffers& B, long batch, int M, hipStrea
 template <typename D>
 void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
   hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
+  const long total = batch * M;                      // K7b: the base poses, one lane per stage
+  hipLaunchKernelGGL((ocp_integrate_base_kernel<D>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, B, total);
 }
 template <typename D>
 void OcpLaunch<D>::trialIterate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
@@ -642,7 +668,7 @@ template <typename D>
 void OcpLaunch<D>::single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st) {
   if (kernel_id == 4) hipLaunchKernelGGL((ocp_expand_primal_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
   else if (kernel_id == 5) hipLaunchKernelGGL(ocp_reduce_steps_kernel, dim3((unsigned)batch), dim3(64), 0, st, B);
-  else hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
+  else expandDualIntegrate(B, batch, M, st);
 }
 
 // squared_out != nullptr: the SUM of the squared stage residuals goes there (horizon shards add theirs up before the root)
