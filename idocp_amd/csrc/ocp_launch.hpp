@@ -31,7 +31,8 @@ struct OcpLaunch {
   static void parnmpcImpulseMerit(const OcpBuffers& Btry, long batch, int n_impulse, const double* q0, const double* v0, hipStream_t st);      // line search on the impulse stages
   static void parnmpcImpulseCondense(const OcpBuffers& B, long batch, int n_impulse, bool residual, const double* q0, const double* v0,
                                      hipStream_t st);                                               // K9i: impulse stages of a ParNMPC chain
-  static void parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st); // K9g: aux (switching rows) and impulse stages
+  static void parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st); // aux (switching rows) and impulse stages: K9w's general instantiation, or K9g with IDOCP_K9_WAVE=0
+  static void parnmpcEventInverseWave(const OcpBuffers& B, long batch, int n_general, hipStream_t st);
   static void parnmpcPhase(int phase, const OcpBuffers& B, long batch, int M, bool has_terminal, const double* q0, const double* v0,
                            hipStream_t st);                                                       // 0 S5, 1 K10a, 2 S6, 3 K10b, 4 init aux_mat
   static void parnmpcHalo(const OcpBuffers& B, long batch, int kind, bool do_import, double* buf, double* q0, double* v0, hipStream_t st);

@@ -20,6 +20,8 @@
 // Q over (w, q, v) with w = u (aux) or f (impulse).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dev_dense.hpp"
 #include "dev_lie.hpp"
 #include "ocp_device.hpp"
@@ -519,6 +521,9 @@ void OcpLaunch<D>::parnmpcImpulseMerit(const OcpBuffers& Btry, long batch, int n
 template <typename D>
 void OcpLaunch<D>::parnmpcEventInverse(const OcpBuffers& B, long batch, int n_general, hipStream_t st) {
   if (n_general <= 0) return;
+  // K9w's general instantiation (one wavefront per stage, parnmpc_kkt_wave_kernel.hip) unless IDOCP_K9G_WAVE=0 / IDOCP_K9_WAVE=0 ask for K9g below
+  static const bool wave = [] { const char* e = getenv("IDOCP_K9G_WAVE"); const char* e2 = getenv("IDOCP_K9_WAVE"); return !((e && e[0] == '0') || (e2 && e2[0] == '0')); }();
+  if (wave) { parnmpcEventInverseWave(B, batch, n_general, st); return; }
   const size_t smem = KktInvEventSmem<D>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
