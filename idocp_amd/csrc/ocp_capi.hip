@@ -660,7 +660,6 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   }
   if (cost->task_dim != 0) {
     if (cost->task_dim != 3 && cost->task_dim != 6) { set_last_error("invalid value: task_dim must be 0, 3 or 6"); return IDOCP_E_ARG; }
-    if (parnmpc && max_num_impulse > 0) { set_last_error("unsupported cost: task-space costs on a ParNMPC horizon with discrete events (the impulse-stage kernel has no such term)"); return IDOCP_E_UNSUPPORTED; }
     if (cost->task_joint < 0 || cost->task_joint > DQ::NU) { set_last_error("invalid value: the task frame must sit on the floating base or on a leg link"); return IDOCP_E_ARG; }
   }
   if (!isQuadruped(*model)) {

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
     double dq = 0.0, dm = 0.0;
     for (int m = 0; m < NV; ++m) { dq += dIq[m + NV * r] * s[L::S_BETA + m]; dm += Mi[m + NV * r] * s[L::S_BETA + m]; }
     a_q += dq; a_dv += dm;
+    if (B.ext) a_q += B.ext[rec * L::EXT + L::X_LQ + r];      // task-space cost with its impulse weights (ocp_ext_kernel.hip)
     double vq = 0.0, vv = 0.0;
     for (int j = 0; j < ni; ++j) { vq += Vq[j + NF * r] * mu_p[j]; vv += Vv[j + NF * r] * mu_p[j]; }
     a_q += vq; a_v += vv;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
       m_viol += fabs(Fq[r]) + fabs(Fv[r]) + fabs(ImD[r]);
     }
     if (tid < ni) m_viol += fabs(Vr[tid]);
+    if (tid == 0 && B.ext) m_cost += B.ext[rec * L::EXT + L::X_COST];
     err[tid] = m_cost;
     blockLdsSync();
     if (tid == 0) { double acc = 0.0; for (int t = 0; t < 256; ++t) acc += err[t]; B.merit_stage[rec * 4] = acc; }
@@ -228,6 +230,10 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
       double acc = 0.0;
       for (int m = 0; m < NV; ++m) acc += Fvq[m + NV * r] * (P->dvi_weight[m] * Fvq[m + NV * c]);
       v += acc;
+      if (B.ext) {                                   // JJ^T diag(w_i) JJ of the task-space cost (the rows ocp_ext_kernel left)
+        const double* __restrict__ xx = B.ext + rec * L::EXT;
+        for (int k = 0; k < 6; ++k) v += xx[L::X_TW + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c];
+      }
     } else if (r == c) {
       v = P->vi_weight[r - NV];
     }

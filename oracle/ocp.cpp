@@ -1235,7 +1235,6 @@ ParNMPCSolver::ParNMPCSolver(const RModel& model, const RCost& cost_, const idoc
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (max_num_impulse < 0) throw std::out_of_range("invalid value: max_num_impulse must be non-negative!");
   if (!robot.hasFloatingBase()) throw std::logic_error("ParNMPCSolver oracle: floating-base robots only");
-  if (cost.task_dim != 0 && max_num_impulse > 0) throw std::logic_error("ParNMPC oracle: task-space costs on event-free horizons only");
   const int ns = nslots();
   s.assign(ns, SplitSolutionC(robot)); s_new = s;
   d.assign(ns, SplitDirectionC(robot));
@@ -1827,6 +1826,8 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
     R.lv[r] += cost.vi_weight[r] * (si.v[r] - vs * (r == 0 ? v_ref0 : cost.v_ref[r]));
     R.la[r] += cost.dvi_weight[r] * si.a[r];
   }
+  Mat task_Hi;      // TaskSpace3D / 6D cost on the impulse stage (computeImpulseCostDerivatives: its impulse weights, no dt)
+  if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, nd.t, cost.task_weighti, si.q, c_, g_, task_Hi); R.lq += g_; }
   {
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (is.active[c]) {
@@ -1900,6 +1901,7 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
   {
     Mat WJ = Jq; for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) WJ(r, c) *= cost.qi_weight[r];
     M.Qxx.addBlock(0, 0, Jq.t() * WJ);
+    if (cost.task_dim) M.Qxx.addBlock(0, 0, task_Hi);
     for (int r = 0; r < nv; ++r) { M.Qxx(nv + r, nv + r) += cost.vi_weight[r]; I.Qdvdv[r] += cost.dvi_weight[r]; }
     int st = 0;
     for (int c = 0; c < nc_; ++c) if (is.active[c]) { for (int r = 0; r < 3; ++r) M.Qff(st + r, st + r) += cost.fi_weight[c][r]; st += 3; }
@@ -2329,7 +2331,7 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
       else l += cost.q_weight[r] * qdiff[r] * qdiff[r] + cost.v_weight[r] * dvr * dvr + cost.a_weight[r] * x.a[r] * x.a[r];
     }
     if (!impulse) for (int r = 0; r < nu; ++r) l += cost.u_weight[r] * (x.u[r] - cost.u_ref[r]) * (x.u[r] - cost.u_ref[r]);
-    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, nd.t, cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }      // (stage part only: no terminal cost in the merit)
+    if (cost.task_dim) { real c_; Mat g_, H_; taskTerms(task_robot, cost, nd.t, impulse ? cost.task_weighti : cost.task_weight, x.q, c_, g_, H_); l += 2 * c_; }      // (stage part only: no terminal cost in the merit)
     for (int c = 0; c < nc_; ++c) if (cs.active[c]) for (int k2 = 0; k2 < 3; ++k2) {
       const real w = impulse ? cost.fi_weight[c][k2] : cost.f_weight[c][k2], fr = impulse ? cost.fi_ref[c][k2] : cost.f_ref[c][k2];
       l += w * (x.f[c][k2] - fr) * (x.f[c][k2] - fr);

@@ -366,3 +366,84 @@ def test_configs3_trotting_n256_chain_direction_and_iterates():
             break
         followed += 1
     assert followed >= 2, followed
+
+
+def test_sharded_filter_line_search_on_a_chain_with_events_equals_the_whole_chain():
+    """The sharded driver's line search (idocp_parnmpc_dist_update_solution_ls: trial halo to the right neighbour, all-reduce of the
+    cost / violation sums) on a horizon WITH discrete events -- the lift stage in the first shard, the aux / impulse pair in the second
+    -- against the single handle with line search: accepted steps and iterates along the chain over several iterations."""
+    import ctypes as C
+    import threading
+    from helpers import P, arr
+    from idocp_amd import capi
+    from parnmpc_dist import HipParNMPCShard
+    events = [([0, 1, 1, 0], 0.27), ([1, 1, 1, 1], 0.83)]
+    world = 2
+    m, o, g, q, v = make_pair(20, 1.0, events)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    lib = capi.lib()
+    shards = [HipParNMPCShard(m, cost, cons, 1.0, 20, r, world, 1, 0, max_num_impulse=3) for r in range(world)]
+    comms = (C.c_void_p * world)()
+    capi.check(lib.idocp_comm_init_local(world, 0, comms), "comm_init_local")
+    for r, sh in enumerate(shards):
+        capi.check(lib.idocp_ocp_set_contact_status_uniformly(sh.h, (C.c_int * 4)(1, 1, 1, 1), P(arr(pts))))
+        for status, t_ev in events:
+            capi.check(lib.idocp_ocp_push_back_contact_status(sh.h, (C.c_int * 4)(*status), P(arr(pts)), t_ev))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"q", P(arr(ANYMAL_Q_STANDING))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"v", P(np.zeros(m.nv))))
+        capi.check(lib.idocp_ocp_set_solution(sh.h, b"f", P(arr([0, 0, 0.25 * (-m.total_mass * m.gravity[2])]))))
+        capi.check(lib.idocp_parnmpc_dist_attach(sh.h, comms[r]), "attach")
+    capi.check(lib.idocp_parnmpc_dist_set_initial_state(shards[0].h, P(arr(q[None, :])), P(arr(v[None, :])), m.nq, m.nv))
+    errors = []
+
+    def collective(fn):
+        def run(r):
+            try:
+                fn(r)
+            except Exception as e:      # noqa: BLE001
+                errors.append((r, e))
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in ts), "a rank of the sharded line search hangs"
+
+    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shards[r].h, 0.0), "init"))
+    for sh in shards:
+        capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
+
+    def chain_len(sh):
+        cap = 64
+        kind = (C.c_int * cap)()
+        return lib.idocp_ocp_get_chain(sh.h, 0.0, cap, kind, None, None, None, None, None)
+
+    def get(sh, name, dim, n):
+        out = np.zeros((n, dim))
+        capi.check(lib.idocp_ocp_get_solution_chain(sh.h, name.encode(), 0, P(out)))
+        return out
+
+    lens = [chain_len(sh) for sh in shards]
+    M = chain_len(g)
+    assert sum(n - 1 for n in lens) == M - 1
+    steps_seen = []
+    for it in range(4):
+        assert g.lib.idocp_parnmpc_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1) == 0
+        collective(lambda r: capi.check(lib.idocp_parnmpc_dist_update_solution_ls(shards[r].h, 0.0), "update_ls"))
+        for sh in shards:
+            capi.check(lib.idocp_ocp_synchronize(sh.h))
+        ag, bg = g.step_sizes()
+        for sh in shards:
+            ps, ds = np.zeros(1), np.zeros(1)
+            capi.check(lib.idocp_ocp_get_step_sizes(sh.h, P(ps), P(ds)))
+            assert abs(ps[0] - ag[0]) < 1e-12 and abs(ds[0] - bg[0]) < 1e-9, (it, ps[0], ag[0], ds[0], bg[0])
+        steps_seen.append(ag[0])
+        for name, dim in (("q", 19), ("v", 18), ("lmd", 18), ("a", 18), ("f", 12)):
+            both = np.concatenate([get(sh, name, dim, n)[:-1] for sh, n in zip(shards, lens)])
+            whole = get(g, name, dim, M)[:-1]
+            assert rel_err(both, whole) < 1e-9, (it, name, rel_err(both, whole))
+    for r, sh in enumerate(shards):
+        capi.check(lib.idocp_parnmpc_dist_detach(sh.h))
+        lib.idocp_comm_destroy(comms[r])

@@ -137,7 +137,7 @@ def test_ocp_line_search_cost():
         assert abs(vi[0] - ref[1]) <= 1e-10 * max(1.0, abs(ref[1])), (alpha, vi[0], ref[1])
 
 
-def test_parnmpc_event_free_horizon_and_rejections():
+def test_parnmpc_event_free_horizon():
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=False)
     add_task(cost, "RH_THIGH", 6)
@@ -151,10 +151,6 @@ def test_parnmpc_event_free_horizon_and_rejections():
     assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and hp.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
         parity(g.get(f), o.get(f), lambda f=f: hp.get(f), f, cap=5e-8)
-    # not carried: a horizon with discrete events under ParNMPC
-    h = C.c_void_p()
-    lib = capi.lib()
-    assert lib.idocp_parnmpc_create_hybrid(C.byref(m), C.byref(cost), C.byref(cons), 1.0, 20, 2, 1, 0, C.byref(h)) == -4
 
 
 def moving_reference(times, dim, p0=(0.1, 0.0, 0.47), vel=(0.25, -0.1, 0.05), t0=0.2, tf=1.2, yaw_rate=0.4):
@@ -238,3 +234,63 @@ def test_time_varying_reference_parnmpc_event_free():
     assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and hp.update(0.0, q, v) == 0
     for f in OCP_DIR_FIELDS:
         parity(g.get(f), o.get(f), lambda f=f: hp.get(f), f, cap=5e-8)
+
+
+@pytest.mark.parametrize("frame,dim,time_varying", [("base", 6, False), ("LF_FOOT", 3, True)])
+def test_parnmpc_chain_with_events(frame, dim, time_varying):
+    """The task-space cost on a ParNMPC horizon WITH discrete events: the impulse stage takes the cost with its impulse weights
+    (ImpulseSplitParNMPC::linearizeOCP -> CostFunction::computeImpulseCostDerivatives / Hessian, impulse_split_parnmpc.hxx:60-112;
+    task_space_{3d,6d}_cost.cpp impulse members), the aux / lift stages the stage cost with their own dt; the reference may move with
+    the stage's time.  KKT error, first direction along the chain (the long double referee decides where an event pair sits), the
+    line search's cost and the accepted iterates."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    add_task(cost, frame, dim)
+    pos = np.array([0.0, 0.0, 0.48]) if frame == "base" else np.array([0.35, 0.2, 0.02])
+    set_reference(cost, m, pos, (0.03, -0.02, 0.04))
+    cost.task_time_varying = 1 if time_varying else 0
+    events = [([0, 1, 1, 0], 0.52), ([1, 1, 1, 1], 0.83)]
+    mk = lambda cls, **kw: cls(m, cost, cons, 1.0, 20, max_num_impulse=3, **kw)
+    o, g, hp = mk(OracleParNMPC), mk(HipParNMPC, batch=2), mk(OracleParNMPC, hp=True)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s_ in (o, g, hp):
+        pts = anymal_contact_points(m).copy()
+        s_.set_contact_status([1, 1, 1, 1], pts)
+        for status, t_ev in events:
+            s_.push_back_contact_status(status, pts, t_ev)
+        s_.set_solution("q", q)
+        s_.set_solution("v", v)
+        s_.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    co = o.chain(0.0)
+    M = len(co)
+    kinds = [c["kind"] for c in co]
+    assert "impulse" in kinds
+    if time_varying:
+        times = g.chain_times(0.0)
+        assert np.allclose(times[:M], [c["t"] for c in co], rtol=0, atol=1e-12)
+        refs = moving_reference(times, dim, p0=tuple(pos), t0=0.1, tf=0.9)
+        g.set_task_refs(0.0, refs)
+        o.set_task_refs(times, refs); hp.set_task_refs(times, refs)
+    o.init(0.0); g.init(0.0); hp.init(0.0)
+    e_o, e_g = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[0]
+    assert abs(e_g - e_o) < 1e-10 * max(1.0, e_o)
+    assert o.lib.oracle_parnmpc_compute_direction(o.h, 0.0, P(q), P(v)) == 0
+    assert g.lib.idocp_parnmpc_compute_direction(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv))) == 0
+    ap, _ = g.step_sizes()
+    for alpha in (0.0, 0.4 * ap[0], ap[0]):
+        ref = np.zeros(2)
+        assert o.lib.oracle_parnmpc_cost_and_violation(o.h, alpha, P(q), P(v), P(ref)) == 0
+        c, vi = np.zeros(g.batch), np.zeros(g.batch)
+        assert g.lib.idocp_ocp_line_search_eval(g.h, P(np.full(g.batch, alpha)), P(c), P(vi)) == 0
+        assert abs(c[0] - ref[0]) <= 1e-8 * max(1.0, abs(ref[0])), (alpha, c[0], ref[0])
+        assert abs(vi[0] - ref[1]) <= 1e-8 * max(1.0, abs(ref[1])), (alpha, vi[0], ref[1])
+        assert c[0] == c[-1]
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and hp.update(0.0, q, v) == 0
+    keep_reg = np.array([k != "impulse" for k in kinds])
+    for f in OCP_DIR_FIELDS:
+        keep = keep_reg if f in ("du", "dnu_passive") else np.ones(M, bool)
+        parity(g.get_chain(f, M + 1)[:M][keep], o.get_chain(f, M)[keep], lambda f=f, keep=keep: hp.get_chain(f, M)[keep], f, cap=1e-7)
+    for it in range(2):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    for f in ("q", "v", "a", "f"):
+        assert rel_err(g.get_chain(f, M + 1)[:M], o.get_chain(f, M)) < 1e-6, f
