@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const OcpProblem* __restrict__ P = B.prob;
   const int M = B.M;
   int tid = threadIdx.x;
+  // the roles of the wave-specialised front half (wave 1 carries the long M^-1 chain) rotate with the workgroup, so that the workgroups
+  // resident on a CU do not all put the same role on the same SIMD (2.745 against 2.77 ms; everything below derives from tid)
+  tid = (((tid >> 6) + (int)(blockIdx.x & 3)) & 3) * 64 + (tid & 63);
   constexpr int nt = 256;
   const int per = plist ? nlist : M;              // units: batch * M, one stage of the chain each (or batch * nlist: the chain positions of one
                                                   // stage class, launchCondenseMixed)
@@ -627,7 +630,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     }
     for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
   };
+  STAMPW(7);
   rneaAssembleQV<D>(bwp, tid, nt, sc, out);                           // reads the scratch behind the joint records
+  STAMPW(5);
   if (tid >= 160 && tid < 160 + NV) sm[S::LA + tid - 160] += dt * sm[S::TLA + tid - 160];      // C2, acceleration rows (t of wave 1, stage 1)
   if (tid >= 128 && tid < 128 + 6) {
     // condenseForwardEuler: Fq.head(6) <- -+ Fqq_inv Fq.head(6)
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     sm[S::FQ6 + r] = BWD ? acc : -acc;
   }
   if constexpr (EARLY_MJ) assembleTR();
+  STAMPW(6);
   blockLdsBarrier();
   if (tid < dimvf) {
     // ID - u on the actuated rows (contact_dynamics.hxx:88); [ID; C] also becomes column NX of dIDCdqv: MJtJinv [ID; C] then falls out
@@ -760,24 +766,41 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         X = &sm[S::MJ + SVF * 16 * ib]; xr = NV - 16 * ib; Y = &sm[S::QAFU + SVF * 6]; yc = NU; r0 = 16 * ib; c0 = 0;      // MJ symmetric
       }
     };
+    // The tiles leave branch-free: every LDS operand of the "base" terms is fetched from a clamped (always valid) address up front, the
+    // term is selected, and the only conditional is the store itself.  (Round 3 had `if (r < 6 && c < 6) base = sm[..]; else if (r == c) ..`
+    // per element: four separate blocks with an LDS wait each, 1.0 us for a pair of Qxx tiles against 0.7 us for their products.)
     auto finish = [&](int j, const mfma_d4& acc, int r0, int c0) {
+      const int r = r0 + (lane & 15), g4 = lane >> 4;                   // (mfmaTileStore's map: row = lane & 15, column = g + 4 q)
       if (j < 6) {
-        mfmaTileStore(acc, r0, c0, NX, NX, lane, [&](int r, int c, double v) {
-          double base = 0.0;
-          if (r < 6 && c < 6) base = sm[S::QB6 + r + 6 * c];
-          else if (r == c) base = (r < NV) ? sm[S::HQD + r] : sm[S::HVD + r - NV];
-          if (r <= c) kk[L::K_QXX + L::xsym(r, c)] = base - v;      // (the tiles on the diagonal carry both triangles)
-        });
+        double b6[4];
+        const double dg = sm[S::HQD + (r < NX ? r : NX - 1)];           // HQD | HVD are contiguous: entry r of the diagonal
+        static_assert(S::HVD == S::HQD + NV, "one diagonal vector");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = c0 + g4 + 4 * q; b6[q] = sm[S::QB6 + (r < 6 ? r : 5) + 6 * (c < 6 ? c : 5)]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + g4 + 4 * q;
+          const double base = (r < 6 && c < 6) ? b6[q] : (r == c ? dg : 0.0);
+          if (r <= c && c < NX) kk[L::K_QXX + L::xsym(r, c)] = base - acc[q];      // (the tiles on the diagonal carry both triangles)
+        }
       } else if (j < 12) {
-        mfmaTileStore(acc, r0, c0, NX, NV, lane, [&](int r, int c, double v) {
-          if (c < 6) ee[L::E_QXUP + r + NX * c] = -v;            // passive columns of Qxu_full
-          else kk[L::K_QXU + r + NX * (c - 6)] = -v;
-        });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + g4 + 4 * q;
+          double* dst = c < 6 ? ee + (L::E_QXUP + r + NX * c) : kk + (L::K_QXU + r + NX * (c - 6));      // passive columns of Qxu_full | Qxu
+          if (r < NX && c < NV) *dst = -acc[q];
+        }
       } else {
-        mfmaTileStore(acc, r0, c0, NV, NU, lane, [&](int r, int c, double v) {
-          if (r < 6) ee[L::E_QUUP + r + 6 * c] = v;              // Quu_passive_topRight
-          else kk[L::K_QUU + (r - 6) + NU * c] = v + ((r - 6 == c) ? sm[S::HUD + c] : 0.0);
-        });
+        double hd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = c0 + g4 + 4 * q; hd[q] = sm[S::HUD + (c < NU ? c : NU - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + g4 + 4 * q;
+          double* dst = r < 6 ? ee + (L::E_QUUP + r + 6 * c) : kk + (L::K_QUU + (r - 6) + NU * c);      // Quu_passive_topRight | Quu
+          const double v = acc[q] + ((r >= 6 && r - 6 == c) ? hd[q] : 0.0);
+          if (r < NV && c < NU) *dst = v;
+        }
       }
     };
     for (int j = 2 * wave; j < NJOB; j += 2 * (nt >> 6)) {
