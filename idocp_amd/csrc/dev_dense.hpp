@@ -329,8 +329,22 @@ __device__ __forceinline__ void blockLdsSync() {
 // -- NB + LJ = 9 dependent pivot steps instead of 18 and a quarter of the multiply-adds; pinocchio's sparse Cholesky
 // (Robot::computeMJtJinv, robot.hxx:576-615) exploits the same tree structure.  E is kept in the (redundant) lower-left block
 // while it is needed.  Every lane of the wavefront must call this.
+// progress / readers (LDS words, optional): other wavefronts of the workgroup may use the intermediate results -- *progress becomes 1 when
+// D^-1 (diagonal leg blocks) and E (transposed, lower-left block) are in place, 2 when S^-1 stands in the base block, 3 when the top-right
+// block -S^-1 E does; the function overwrites D^-1 and E only after *readers >= 1 (ldsFlagSet / ldsFlagWait below).
+__device__ __forceinline__ void ldsFlagSet(int* flag, int value, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ldsFlagWait(int* flag, int value, int lane) {
+  if (lane == 0) while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 template <int NB, int NL, int LJ>
-__device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, int* ok, long long* prof = nullptr) {
+__device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, int* ok, long long* prof = nullptr, int* progress = nullptr,
+                                                  int* readers = nullptr) {
 #define BA_STAMP(k) do { if (prof) prof[k] = wall_clock64(); } while (0)
   constexpr int NJ = NL * LJ;
   // (i) D_i^-1 in place (full symmetric blocks)
@@ -375,6 +389,7 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     M[(NB + c) + ld * r] = acc;
   }
   waveLdsSync();
+  if (progress) ldsFlagSet(progress, 1, lane);
   BA_STAMP(1);
   // (iii) S = A - E B^T: one entry per lane (NB NB lanes, NJ-term dots) written over the A block, then row r
   // into the registers of lane r; S^-1 by Gauss-Jordan, the pivot row as DPP row broadcasts.  (Round 2: lane r formed its whole row
@@ -396,6 +411,7 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     spdInverseRowsDpp<NB>(M, ld, NB, lane, ok);
   }
   waveLdsSync();
+  if (progress) ldsFlagSet(progress, 2, lane);
   BA_STAMP(3);
   // (iv) top-right = -S^-1 E (B is dead)
   for (int e = lane; e < NB * NJ; e += 64) {
@@ -406,6 +422,8 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     M[r + ld * (NB + c)] = -acc;
   }
   waveLdsSync();
+  if (progress) ldsFlagSet(progress, 3, lane);
+  if (readers) ldsFlagWait(readers, 1, lane);
   BA_STAMP(4);
   // (v) bottom-right = D^-1 - E^T (top-right)
   for (int e = lane; e < NJ * NJ; e += 64) {

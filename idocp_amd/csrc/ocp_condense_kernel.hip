@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
   constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = S::NVF, RVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>) and rows; NF / NVF: the HBM records'
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_ok, s_c1;
+  __shared__ int s_ok, s_c1, s_ba, s_gt;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = B.M;
   int tid = threadIdx.x;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
     }
     STAMP(3);
-    if (tid == 0) { s_ok = 1; s_c1 = 0; }
+    if (tid == 0) { s_ok = 1; s_c1 = 0; s_ba = 0; s_gt = 0; }
     if (!terminal) {
       for (int e = tid; e < S::IDC - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
       rneaSetup<D>(B.model, P, nd, tid, sc);
@@ -339,26 +339,17 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         }
         waveLdsSync();
         STAMPW(4);
-        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok);
+        // The contact Schur complement does not wait for M^-1: with M^-1 in its block-arrow form, J = [Jb Jl] and G = Jb - Jl E^T,
+        //   J M^-1 = [G S^-1 | G (-S^-1 E) + Jl D^-1],   J M^-1 J^T = (G S^-1) G^T + (Jl D^-1) Jl^T,
+        // so wave 2 forms G and Jl D^-1 as soon as E and D^-1 exist, the product and its inverse as soon as S^-1 does, and wave 3 the right part
+        // of BL once the top-right block does (below, behind C1) -- next to the rest of this inverse instead of behind it (round 4: 2.4 of
+        // the 9.1 us of this wavefront's chain)
+#ifdef IDOCP_K5_STAMPS
+        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok, stampw ? B.prof + 16 : nullptr, &s_ba, &s_gt);
+#else
+        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok, nullptr, &s_ba, &s_gt);
+#endif
         STAMPW(1);
-        // C1 done?  BL, SM reuse its input block.  (Its two wavefronts each add one; LDS operations of a wavefront complete in order.)
-        if (lane == 0) while (__hip_atomic_load(&s_c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) __builtin_amdgcn_s_sleep(4);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        STAMPW(2);
-        if (dimf > 0) {
-          for (int e = lane; e < dimf * NV; e += 64) {                 // BL = J Minv
-            const int c = e / dimf, r = e - c * dimf;
-            sm[S::BL + r + SF * c] = dotAny(&sm[S::JM + r], SF, &sm[S::MINV + NV * c], 1, NV);
-          }
-          waveLdsSync();
-          for (int e = lane; e < dimf * dimf; e += 64) {               // SM = BL J^T
-            const int c = e / dimf, r = e - c * dimf;
-            sm[S::SM + r + SF * c] = dotAny(&sm[S::BL + r], SF, &sm[S::JM + c], SF, NV);
-          }
-          waveLdsSync();
-          spdInverseRowsDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
-        }
         STAMPW(3);
       }
     }
@@ -546,6 +537,61 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_fetch_add(&s_c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // ---- the contact Schur complement next to wave 1's inverse (see there).  G and T = Jl D^-1 live behind BL and SM in the block C1 read. ----
+    constexpr int NJ = D::NL * D::LJ, LJ = D::LJ;
+    constexpr int GG = S::SM + SF * SF, TT = GG + SF * 6;
+    static_assert(TT + SF * NJ <= S::VEC, "G and Jl D^-1 fit behind BL, SM");
+    ldsFlagWait(&s_c1, 2, lane);                                   // both C1 wavefronts are done with that block
+    ldsFlagWait(&s_ba, 1, lane);                                   // D^-1 (leg blocks) and E (lower-left block, transposed) stand
+    if (wave == 2) {
+      for (int e = lane; e < dimf * 6; e += 64) {                  // G = Jb - Jl E^T
+        const int c = e / dimf, r = e - c * dimf;
+        double acc = sm[S::JM + r + SF * c];
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) acc -= sm[S::JM + r + SF * (6 + m)] * sm[S::MINV + (6 + m) + NV * c];
+        sm[GG + r + SF * c] = acc;
+      }
+      for (int e = lane; e < dimf * NJ; e += 64) {                 // T = Jl D^-1 (D^-1: full symmetric LJ x LJ blocks)
+        const int c = e / dimf, r = e - c * dimf, o = 6 + (c / LJ) * LJ;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < LJ; ++m) acc += sm[S::JM + r + SF * (o + m)] * sm[S::MINV + (o + m) + NV * (6 + c)];
+        sm[TT + r + SF * c] = acc;
+      }
+      waveLdsSync();
+      ldsFlagSet(&s_gt, 1, lane);                                  // wave 1 may overwrite D^-1 and E; wave 3 may read G, T
+      ldsFlagWait(&s_ba, 2, lane);                                 // S^-1 stands in the base block
+      for (int e = lane; e < dimf * 6; e += 64) {                  // BL[:, 0:6] = G S^-1
+        const int c = e / dimf, r = e - c * dimf;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc += sm[GG + r + SF * m] * sm[S::MINV + m + NV * c];
+        sm[S::BL + r + SF * c] = acc;
+      }
+      waveLdsSync();
+      for (int e = lane; e < dimf * dimf; e += 64) {               // SM = (G S^-1) G^T + T Jl^T
+        const int c = e / dimf, r = e - c * dimf;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc += sm[S::BL + r + SF * m] * sm[GG + c + SF * m];
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) acc += sm[TT + r + SF * m] * sm[S::JM + c + SF * (6 + m)];
+        sm[S::SM + r + SF * c] = acc;
+      }
+      waveLdsSync();
+      if (dimf > 0) spdInverseRowsDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
+    } else {
+      ldsFlagWait(&s_gt, 1, lane);
+      ldsFlagWait(&s_ba, 3, lane);                                 // the top-right block -S^-1 E stands
+      for (int e = lane; e < dimf * NJ; e += 64) {                 // BL[:, 6:] = G (-S^-1 E) + T
+        const int c = e / dimf, r = e - c * dimf;
+        double acc = sm[TT + r + SF * c];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc += sm[GG + r + SF * m] * sm[S::MINV + m + NV * (6 + c)];
+        sm[S::BL + r + SF * (6 + c)] = acc;
+      }
+    }
+    STAMPW(3);
   }
   blockLdsBarrier();
   STAMP(2);

@@ -46,7 +46,7 @@ def test_first_iteration_direction_parity(N, T):
     # by stage the GPU is at most 4x as far from it as the FP64 oracle is, + 1e-10 -- and a loose cap holds against the oracle.
     for f in OCP_DIR_FIELDS:
         referee_check(g.get(f), o.get(f), h.get(f), f)
-        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 5e-9), f
+        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 2e-8), f      # (the cap: two FP64 evaluations are 5e-9 apart on dlmd here)
     ao, bo = o.step_sizes()
     ag, bg = g.step_sizes()
     assert abs(ag[0] - ao) < 1e-10 and abs(bg[0] - bo) < 1e-10
@@ -54,7 +54,7 @@ def test_first_iteration_direction_parity(N, T):
     # here, two LLTs in the oracle) leave 1e-9 on lmd; the referee rule decides there as well
     for f in OCP_SOL_FIELDS:
         referee_check(g.get(f), o.get(f), h.get(f), f)
-        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 5e-9), f
+        assert rel_err(g.get(f), o.get(f)) < (TOL if N <= 20 else 2e-8), f
 
 
 def test_convergence_and_batch():
