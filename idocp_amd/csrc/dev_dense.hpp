@@ -310,6 +310,58 @@ __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// Inverse of an SPD n x n block (n <= N <= 8, in place in LDS, column-major, leading dimension ld) by ONE wavefront as A^-1 = W^T W with
+// W = L^-1, A = L L^T.  Lane l < n holds row l of A and the right-hand side e_l; the pivots walk the rows with DPP row broadcasts as in
+// choleskySolveRows, forward substitution only (x = column l of L^-1); the columns meet in the scratch Wb (N x N doubles: Wb[k + ldw l] =
+// W(k, l)) and n^2 lanes form the products.  What this buys over the Gauss-Jordan form (spdInverseRowsDpp) is instruction count -- a pivot
+// step broadcasts ONE column entry per remaining row instead of the whole pivot row: ~160 instead of ~270 instructions for n = 6, and on a
+// SIMD shared by four wavefronts the chain of such a phase costs what it issues (round 4: 1.44 us for six Gauss-Jordan pivots).
+template <int N>
+__device__ __forceinline__ void spdInverseCholDpp(double* A, int ld, int n, int lane, int* ok, double* Wb, int ldw) {
+  static_assert(N <= 8, "n^2 lanes form the product");
+  const int row = lane & 15;
+  double a[N], x[N];
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0); x[j] = (j == row) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {
+      const double p = rowBcastN(a[k], k);
+      bad |= !(p > 0.0);
+      asm volatile("" : "+v"(bad));
+      double is = __builtin_amdgcn_rsq(p);
+      double e = __builtin_fma(-p * is, is, 1.0);
+      is = __builtin_fma(0.5 * is, e, is);
+      e = __builtin_fma(-p * is, is, 1.0);
+      is = __builtin_fma(0.5 * is, e, is);
+      const double lrk = a[k] * is;                      // column k of L (row k: p / sqrt(p))
+      x[k] *= is;
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) {
+        const double lck = rowBcastN(lrk, c);
+        a[c] = __builtin_fma(-lrk, lck, a[c]);
+        x[c] = __builtin_fma(-lck, x[k], x[c]);
+      }
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) asm volatile("" : "+v"(x[c]), "+v"(a[c]));      // (pins the updates to their step, see choleskySolveRows)
+    }
+  }
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) Wb[k + ldw * lane] = x[k];
+  }
+  waveLdsSync();
+  if (lane < n * n) {
+    const int j = lane / n, i = lane - j * n;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc = __builtin_fma(Wb[k + ldw * i], Wb[k + ldw * j], acc);      // (W(k, l) = 0 for k < l and beyond n: the padding is the identity)
+    A[i + ld * j] = acc;
+  }
+  if (bad && lane == 0) *ok = 0;
+}
+
 // Barrier of a workgroup of several wavefronts for exchanges through LDS: the wavefront's LDS accesses are complete before and visible
 // after, but -- unlike __syncthreads() -- the global loads and stores in flight are not waited for (no s_waitcnt vmcnt(0)).  Only where no
 // data passes from one wavefront to another through global memory.
@@ -344,7 +396,10 @@ __device__ __forceinline__ void ldsFlagWait(int* flag, int value, int lane) {
 }
 template <int NB, int NL, int LJ>
 __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, int* ok, long long* prof = nullptr, int* progress = nullptr,
-                                                  int* readers = nullptr) {
+                                                  int* readers = nullptr, const double* Min = nullptr) {
+  // Min: where the matrix stands if not in M itself (same leading dimension): steps (i) - (iii) read it from there, everything is written to M,
+  // and Min is left untouched
+  if (!Min) Min = M;
 #define BA_STAMP(k) do { if (prof) prof[k] = wall_clock64(); } while (0)
   constexpr int NJ = NL * LJ;
   // (i) D_i^-1 in place (full symmetric blocks)
@@ -354,7 +409,7 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
 #pragma unroll
     for (int r = 0; r < LJ; ++r)
 #pragma unroll
-      for (int c = 0; c < LJ; ++c) d[r][c] = M[(o + (r < c ? r : c)) + ld * (o + (r < c ? c : r))];
+      for (int c = 0; c < LJ; ++c) d[r][c] = Min[(o + (r < c ? r : c)) + ld * (o + (r < c ? c : r))];
 #pragma unroll
     for (int k = 0; k < LJ; ++k) {
       const double p = d[k][k];
@@ -385,7 +440,7 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     const int c = e / NB, r = e - c * NB, o = NB + (c / LJ) * LJ;
     double acc = 0.0;
 #pragma unroll
-    for (int m = 0; m < LJ; ++m) acc += M[r + ld * (o + m)] * M[(o + m) + ld * (NB + c)];
+    for (int m = 0; m < LJ; ++m) acc += Min[r + ld * (o + m)] * M[(o + m) + ld * (NB + c)];
     M[(NB + c) + ld * r] = acc;
   }
   waveLdsSync();
@@ -399,16 +454,17 @@ __device__ __forceinline__ void blockArrowInverse(double* M, int ld, int lane, i
     double sval = 0.0;
     const int sc = lane / NB, sr = lane - sc * NB;
     if (lane < NB * NB) {
-      double acc = M[(sr < sc ? sr : sc) + ld * (sr < sc ? sc : sr)];
+      double acc = Min[(sr < sc ? sr : sc) + ld * (sr < sc ? sc : sr)];
 #pragma unroll
-      for (int m = 0; m < NJ; ++m) acc -= M[(NB + m) + ld * sr] * M[sc + ld * (NB + m)];      // (the operands are all fetched up front)
+      for (int m = 0; m < NJ; ++m) acc -= M[(NB + m) + ld * sr] * Min[sc + ld * (NB + m)];      // (the operands are all fetched up front)
       sval = acc;
     }
     waveLdsSync();                               // every lane has read A (and B) before A is overwritten
     if (lane < NB * NB) M[sr + ld * sc] = sval;
     waveLdsSync();
     BA_STAMP(2);
-    spdInverseRowsDpp<NB>(M, ld, NB, lane, ok);
+    if constexpr (NB <= 8 && NB <= NJ) spdInverseCholDpp<NB>(M, ld, NB, lane, ok, M + ld * NB, ld);      // (scratch: the B block, dead from here)
+    else spdInverseRowsDpp<NB>(M, ld, NB, lane, ok);
   }
   waveLdsSync();
   if (progress) ldsFlagSet(progress, 2, lane);

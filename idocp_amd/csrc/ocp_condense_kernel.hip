@@ -61,8 +61,9 @@ struct CondenseSmem {
   // that the 2 x 2 products read side by side (stride 2 NVF) on two bank groups only -- SQ_LDS_BANK_CONFLICT was 46 % of the LDS
   // cycles of that class against 25 % with NVF = 30 -- so it is padded by two rows.
   static constexpr int NV = D::NV, NX = D::NX, NF = SFP, NVF = D::NV + SFP + (((D::NV + SFP) % 8 == 0) ? 2 : 0), NU = D::NU;
+  static constexpr bool SEP_MINV = SFP <= 6;
   // matrices.  Aliases (lifetimes in the kernel body):
-  //   MINV  = MM            the mass matrix is inverted in place (scratch: MJ, not yet written)
+  //   MINV  = MM            the mass matrix is inverted in place (the wide layouts; the narrow ones: a block of its own, see below)
   //   QAFQV = DIDC          dIDCdqv is dead once MJD = MJtJinv * dIDCdqv is formed
   //   QAFU  = MM .. JM      M^-1 and J are dead once MJtJinv is assembled
   //   BL, SM  share the block that holds the solution / slack / dual copies during phase C
@@ -75,7 +76,7 @@ struct CondenseSmem {
                        MJD = MJ + NVF * NVF,
                        // MJ .. MJD also hold the scratch of the RNEA sweeps (dead before MJtJinv is assembled); the narrow layouts are padded for it
                        QFF = (MJD + NVF * (NX + 1) > MJ + RneaScratch<D>::TOTAL) ? MJD + NVF * (NX + 1) : MJ + RneaScratch<D>::TOTAL, TMP = QFF + NF * NF,
-                       MINV = MM, QAFQV = DIDC, QAFU = MM, ERR = MJ;
+                       QAFQV = DIDC, QAFU = MM, ERR = MJ;
   static constexpr int SOLS = TMP, SOLN = SOLS + L::SOL, SLK = SOLN + L::SOL, DUL = SLK + L::CON, TMP_EARLY = DUL + L::CON - TMP;
   static constexpr int BL = TMP, SM = BL + NF * NV, TMP_LATE = SM + NF * NF - TMP;
   static constexpr int VEC = TMP + (TMP_EARLY > TMP_LATE ? TMP_EARLY : TMP_LATE);
@@ -89,7 +90,10 @@ struct CondenseSmem {
                        LIEB = BM + 32, JQ = LIEB + L::Z_JQ, QDIFF = LIEB + L::Z_QDIFF, FQQ = LIEB + L::Z_FQQ, FQ6 = LIEB + L::Z_FQ6,
                        FQQI = LIEB + L::Z_FQQI, FQQP = LIEB + L::Z_FQQP, FQQPI = LIEB + L::Z_FQQPI,
                        HQD = LIEB + 196, HVD = HQD + NV, HUD = HVD + NV, QB6 = HUD + NU,       // diagonal / base-block Hessian terms before condensing
-                       TOTAL = QB6 + 36 + 2;
+                       // the narrow layouts have room for M^-1 in a block of its own: M then survives the inversion, and t = M^T beta + J^T mu
+                       // moves from the head of wave 1's chain to wave 3
+                       MINV = SEP_MINV ? QB6 + 36 + 2 : MM,
+                       TOTAL = QB6 + 36 + 2 + (SEP_MINV ? NV * NV : 0);
   static_assert(SOLS % 2 == 0 && LIEB % 2 == 0 && IDC % 2 == 0 && MJ % 2 == 0, "16-byte pieces");
 };
 
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
   constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = S::NVF, RVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>) and rows; NF / NVF: the HBM records'
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_ok, s_c1, s_ba, s_gt;
+  __shared__ int s_ok, s_c1, s_ba, s_gt, s_m;
   const OcpProblem* __restrict__ P = B.prob;
   const int M = B.M;
   int tid = threadIdx.x;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (tid >= 64 && tid < 70) { prez[5] = zz[L::Z_QDIFF + tid - 64]; prez[6] = zz[L::Z_FQ6 + tid - 64]; }
     }
     STAMP(3);
-    if (tid == 0) { s_ok = 1; s_c1 = 0; s_ba = 0; s_gt = 0; }
+    if (tid == 0) { s_ok = 1; s_c1 = 0; s_ba = 0; s_gt = 0; s_m = 0; }
     if (!terminal) {
       for (int e = tid; e < S::IDC - S::DIDC; e += nt) sm[S::DIDC + e] = 0.0;      // rows a seed does not reach, inactive contacts
       rneaSetup<D>(B.model, P, nd, tid, sc);
@@ -309,6 +313,20 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const double* dual = &sm[S::DUL];
   double err_local = 0.0, err_ipm = 0.0;     // RESIDUAL: plain squared residuals / IPM residuals (weighted by dt^2 below), per thread
   double merit_cost = 0.0, merit_viol = 0.0; // MERIT: this thread's share of the stage cost / l1 constraint violation
+  // C2 for the acceleration rows: t = M^T beta + J^T mu (beta, mu from the LDS copy of the solution record; la += dt t follows in stage 3).
+  // Needs M as the a-seed items left it: by wave 1 in front of the in-place inversion, or by wave 3 where M^-1 has a block of its own.
+  auto accelerationMultiplierTerm = [&](int lane_) {
+    if (lane_ < NV) {
+      double acc = dotAny(&sm[S::MM + NV * lane_], 1, s + L::S_BETA, 1, NV);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (!c_act[c]) continue;
+        const double* jc = &sm[S::JM + c_row[c] + SF * lane_];
+        acc += jc[0] * s[L::S_MU + 3 * c] + jc[1] * s[L::S_MU + 3 * c + 1] + jc[2] * s[L::S_MU + 3 * c + 2];
+      }
+      sm[S::TLA + lane_] = acc;
+    }
+  };
   if (wave == 0) {
     if (!MERIT && lane < RI::NQV) {
       if (!PLAIN && impulse) rneaTangentItem<D, XYY, true>(0.0, bwv, RI::qv(lane), sc, out);      // impulse stage: dynamics at zero velocity, contact velocity
@@ -327,17 +345,8 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       if (!RESIDUAL) {
         // C2 for the acceleration rows, while M is still M: t = M^T beta + J^T mu (beta, mu from the LDS copy of the solution record;
         // la += dt t follows in stage 3 -- nothing here waits for C1)
-        if (lane < NV) {
-          double acc = dotAny(&sm[S::MM + NV * lane], 1, s + L::S_BETA, 1, NV);
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            if (!c_act[c]) continue;
-            const double* jc = &sm[S::JM + c_row[c] + SF * lane];
-            acc += jc[0] * s[L::S_MU + 3 * c] + jc[1] * s[L::S_MU + 3 * c + 1] + jc[2] * s[L::S_MU + 3 * c + 2];
-          }
-          sm[S::TLA + lane] = acc;
-        }
-        waveLdsSync();
+        if constexpr (S::SEP_MINV) ldsFlagSet(&s_m, 1, lane);      // M and J stand (and stay): wave 3 forms t
+        else { accelerationMultiplierTerm(lane); waveLdsSync(); }
         STAMPW(4);
         // The contact Schur complement does not wait for M^-1: with M^-1 in its block-arrow form, J = [Jb Jl] and G = Jb - Jl E^T,
         //   J M^-1 = [G S^-1 | G (-S^-1 E) + Jl D^-1],   J M^-1 J^T = (G S^-1) G^T + (Jl D^-1) Jl^T,
@@ -345,9 +354,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         // of BL once the top-right block does (below, behind C1) -- next to the rest of this inverse instead of behind it (round 4: 2.4 of
         // the 9.1 us of this wavefront's chain)
 #ifdef IDOCP_K5_STAMPS
-        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok, stampw ? B.prof + 16 : nullptr, &s_ba, &s_gt);
+        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok, stampw ? B.prof + 16 : nullptr, &s_ba, &s_gt, &sm[S::MM]);
 #else
-        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok, nullptr, &s_ba, &s_gt);
+        blockArrowInverse<6, D::NL, D::LJ>(&sm[S::MINV], NV, lane, &s_ok, nullptr, &s_ba, &s_gt, &sm[S::MM]);
 #endif
         STAMPW(1);
         STAMPW(3);
@@ -533,6 +542,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   }
   if (wave >= 2) STAMPW(0);
   if (wave >= 2 && !MERIT && !RESIDUAL) {
+    if constexpr (S::SEP_MINV) {
+      if (wave == 3) { ldsFlagWait(&s_m, 1, lane); accelerationMultiplierTerm(lane); }      // (reads the solution copy: before this wavefront releases that block)
+    }
     // C1 of this wavefront is in LDS: tell wave 1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -579,7 +591,11 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         sm[S::SM + r + SF * c] = acc;
       }
       waveLdsSync();
-      if (dimf > 0) spdInverseRowsDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);      // SM = (J Minv J^T)^-1
+      if (dimf > 0) {                                                                 // SM = (J Minv J^T)^-1
+        constexpr int WW = TT + SF * NJ;
+        if constexpr (SF <= 8 && WW + SF * SF <= S::VEC) spdInverseCholDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok, &sm[WW], SF);
+        else spdInverseRowsDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);
+      }
     } else {
       ldsFlagWait(&s_gt, 1, lane);
       ldsFlagWait(&s_ba, 3, lane);                                 // the top-right block -S^-1 E stands
