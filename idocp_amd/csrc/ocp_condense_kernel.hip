@@ -865,7 +865,10 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         }
       }
     };
-    for (int j = 2 * wave; j < NJOB; j += 2 * (nt >> 6)) {
+    // The job numbers of a wavefront are made compile-time constants (a switch over the wavefront, the pair body instantiated per job): as
+    // run-time values they cost a chain of selects for the operand pointers and extents and a three-way branch in front of every store
+    auto pair = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
       const double *X0, *Y0, *X1, *Y1;
       int xr0, yc0, r00, c00, xr1, yc1, r01, c01;
       operands(j, X0, xr0, Y0, yc0, r00, c00);
@@ -874,6 +877,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       mfmaTilePairTN<RVF>(X0, xr0, Y0, yc0, X1, xr1, Y1, yc1, SVF, SVF, dimvf, lane, a0, a1);
       finish(j, a0, r00, c00);
       finish(j + 1, a1, r01, c01);
+    };
+    static_assert(nt == 256 && NJOB == 14, "four wavefronts: jobs 2 w, 2 w + 1 and 2 w + 8, 2 w + 9");
+    switch (__builtin_amdgcn_readfirstlane(wave)) {
+      case 0: pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 8>{}); break;
+      case 1: pair(std::integral_constant<int, 2>{}); pair(std::integral_constant<int, 10>{}); break;
+      case 2: pair(std::integral_constant<int, 4>{}); pair(std::integral_constant<int, 12>{}); break;
+      default: pair(std::integral_constant<int, 6>{}); break;
     }
   }
   STAMP(14);
