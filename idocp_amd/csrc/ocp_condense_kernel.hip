@@ -929,14 +929,14 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     kk[L::K_FX + tid] = sm[S::FQ + tid]; kk[L::K_FX + NV + tid] = sm[S::FV + tid];
   }
   if (tid < NU) kk[L::K_LU + tid] = sm[S::LU + tid];
-  // MJtJinv: the lower triangle, row by row (consecutive threads write consecutive addresses); element t of the triangle is (r, c) with
-  // r = the largest integer with r (r + 1) / 2 <= t
+  // MJtJinv: the lower triangle.  Rows p and RVF - 1 - p together have RVF + 1 entries: thread t takes entry t mod (RVF + 1) of pair
+  // t / (RVF + 1) -- a division by a constant and a select (round 3 took the row of element t from a square root: twice the instructions),
+  // consecutive threads on consecutive addresses within a row
   for (int t = tid; t < RVF * (RVF + 1) / 2; t += nt) {
-    int r = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);      // (single precision + the two corrections: exact here)
-    if ((r + 1) * (r + 2) / 2 <= t) ++r;
-    if (r * (r + 1) / 2 > t) --r;
-    const int c = t - r * (r + 1) / 2;
-    ee[L::E_MJ + t] = sm[S::MJ + r + SVF * c];
+    const int pr = t / (RVF + 1), idx = t - pr * (RVF + 1);
+    const bool lo = idx <= pr;
+    const int r = lo ? pr : RVF - 1 - pr, c = lo ? idx : idx - pr - 1;
+    ee[L::E_MJ + r * (r + 1) / 2 + c] = sm[S::MJ + r + SVF * c];
   }
   static_assert(RVF % 2 == 0 && NVF % 2 == 0 && L::E_MJD % 2 == 0 && L::EXP % 2 == 0, "16-byte stores of MJtJinv_dIDCdqv");
   for (int e = tid; e < (RVF / 2) * NX; e += nt) {
