@@ -118,7 +118,7 @@ __device__ __forceinline__ void blockLdsBarrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = false, bool XYY = false>
+template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = false, bool XYY = false, bool EVENTS = false>
 __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   const bool last = BWD && P->has_terminal && (pos == M - 2);   // ParNMPC: the stage that carries the terminal cost
   // DIMF >= 0 is only launched on stages without an impulse or a switching constraint (launchCondense: event-free chains;
   // launchCondenseMixed: those stages of a chain with events, grouped by their number of contact rows)
-  constexpr bool PLAIN = (DIMF >= 0);
+  // EVENTS: a compile-time contact count on stages that DO carry an impulse or a switching constraint (the event stages of a trot all have
+  // half of the feet: as members of the general class, with its run-time count, they cost 1.5 x a plain stage)
+  constexpr bool PLAIN = (DIMF >= 0) && !EVENTS;
   const bool impulse = PLAIN ? false : (nd->kind == 1);
   if (BWD && impulse) return;                       // ParNMPC: the backward-Euler impulse stage is K9i (parnmpc_event_kernels.hip)
   const int sw_dimi = PLAIN ? 0 : nd->sw_dimi;
@@ -1060,7 +1062,7 @@ void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, co
 // class 2: everything else (impulse stages, stages carrying a switching constraint, other contact counts, the terminal
 // stage) on the general instantiation.  B.cond_pos holds the chain positions class by class, n[c] their counts.
 template <typename D>
-void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[3], const double* q0, hipStream_t st, int part) {
+void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[4], const double* q0, hipStream_t st, int part) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double), smem_half = CondenseSmem<D, D::NF / 2>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
@@ -1070,6 +1072,8 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     configured = true;
   }
   const unsigned blocks = (unsigned)(batch * M);
@@ -1082,6 +1086,8 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
+  // class 3: event stages (impulse / switching constraint) with half of the feet
+  if (n[3] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); }
   if (n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
   OcpLaunch<D>::extHessian(B, batch, M, st);
 }
