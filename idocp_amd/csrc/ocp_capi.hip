@@ -126,7 +126,7 @@ struct idocp_ocp {
   int* d_switch_pos = nullptr;
   int* d_general_pos = nullptr;     // ParNMPC: chain positions of the aux (switching rows) / impulse stages
   int* d_cond_pos = nullptr;        // chain positions by stage class of K5b (all feet | half of them | the rest)
-  int cond_n[4] = {0, 0, 0, 0};      // all feet | half of them | the rest | event stages with half of the feet
+  int cond_n[5] = {0, 0, 0, 0, 0};      // all feet | half of them | the rest | event stages with half of the feet | flight stages
   int n_general = 0;
   int slice_begin = 0, slice_end = -1;   // ParNMPC with events: this handle keeps the grid stages [slice_begin, slice_end) of the chain (-1: all)
   int uniform_dimf = -1;              // dimf shared by all stages of an event-free chain, else -1
@@ -359,15 +359,16 @@ int discretize(idocp_ocp* h, double t) {
   h->B.n_switch = (int)spos.size();
   if (!spos.empty()) HIP_TRY(hipMemcpyAsync(h->d_switch_pos, spos.data(), sizeof(int) * spos.size(), hipMemcpyHostToDevice, h->stream));
   // stage classes of K5b (OcpLaunch::condenseMixed)
-  std::vector<int> cls[4];
+  std::vector<int> cls[5];
   for (int p = 0; p < M; ++p) {
     const OcpNode& nd = h->chain[p];
     const bool grid = (nd.kind == 0 || nd.kind == 2 || nd.kind == 3), plain = grid && nd.sw_dimi == 0;
     const bool event_half = !h->parnmpc && !plain && (grid || nd.kind == 1) && nd.dimf == DQ::NF / 2;      // an impulse / a switching constraint on half of the feet
-    cls[plain && nd.dimf == DQ::NF ? 0 : (plain && nd.dimf == DQ::NF / 2 ? 1 : (event_half ? 3 : 2))].push_back(p);
+    const bool flight = !h->parnmpc && plain && nd.dimf == 0;
+    cls[plain && nd.dimf == DQ::NF ? 0 : (plain && nd.dimf == DQ::NF / 2 ? 1 : (event_half ? 3 : (flight ? 4 : 2)))].push_back(p);
   }
   std::vector<int> cpos;
-  for (int c = 0; c < 4; ++c) { h->cond_n[c] = (int)cls[c].size(); cpos.insert(cpos.end(), cls[c].begin(), cls[c].end()); }
+  for (int c = 0; c < 5; ++c) { h->cond_n[c] = (int)cls[c].size(); cpos.insert(cpos.end(), cls[c].begin(), cls[c].end()); }
   HIP_TRY(hipMemcpyAsync(h->d_cond_pos, cpos.data(), sizeof(int) * cpos.size(), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_prob, &h->prob, sizeof(OcpProblem), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));     // tab is a stack temporary
@@ -1050,7 +1051,7 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
 
 // K5b: one launch on an event-free chain with all feet in contact, else one launch per stage class
 static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q, int part = 0) {
-  if (h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] + h->cond_n[3] == 0) OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream, part);
+  if (h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] + h->cond_n[3] + h->cond_n[4] == 0) OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream, part);
   else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, part);
 }
 

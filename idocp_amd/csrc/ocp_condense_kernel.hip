@@ -1062,7 +1062,7 @@ void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, co
 // class 2: everything else (impulse stages, stages carrying a switching constraint, other contact counts, the terminal
 // stage) on the general instantiation.  B.cond_pos holds the chain positions class by class, n[c] their counts.
 template <typename D>
-void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[4], const double* q0, hipStream_t st, int part) {
+void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[5], const double* q0, hipStream_t st, int part) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double), smem_half = CondenseSmem<D, D::NF / 2>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
@@ -1073,6 +1073,8 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     configured = true;
   }
@@ -1086,6 +1088,8 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
+  // class 4: flight stages (no contact rows at all; the wide LDS layout, every contact loop folded away)
+  if (n[4] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0, false, false, true>), dim3((unsigned)(batch * n[4])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0>), dim3((unsigned)(batch * n[4])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); }
   // class 3: event stages (impulse / switching constraint) with half of the feet
   if (n[3] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); }
   if (n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
