@@ -310,15 +310,15 @@ __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-// Inverse of an SPD n x n block (n <= N <= 8, in place in LDS, column-major, leading dimension ld) by ONE wavefront as A^-1 = W^T W with
+// Inverse of an SPD n x n block (n <= N <= 16, in place in LDS, column-major, leading dimension ld) by ONE wavefront as A^-1 = W^T W with
 // W = L^-1, A = L L^T.  Lane l < n holds row l of A and the right-hand side e_l; the pivots walk the rows with DPP row broadcasts as in
 // choleskySolveRows, forward substitution only (x = column l of L^-1); the columns meet in the scratch Wb (N x N doubles: Wb[k + ldw l] =
-// W(k, l)) and n^2 lanes form the products.  What this buys over the Gauss-Jordan form (spdInverseRowsDpp) is instruction count -- a pivot
+// W(k, l)) and the lanes form the n^2 products.  What this buys over the Gauss-Jordan form (spdInverseRowsDpp) is instruction count -- a pivot
 // step broadcasts ONE column entry per remaining row instead of the whole pivot row: ~160 instead of ~270 instructions for n = 6, and on a
 // SIMD shared by four wavefronts the chain of such a phase costs what it issues (round 4: 1.44 us for six Gauss-Jordan pivots).
 template <int N>
 __device__ __forceinline__ void spdInverseCholDpp(double* A, int ld, int n, int lane, int* ok, double* Wb, int ldw) {
-  static_assert(N <= 8, "n^2 lanes form the product");
+  static_assert(N <= 16, "one matrix row per lane of a DPP row");
   const int row = lane & 15;
   double a[N], x[N];
   int bad = 0;
@@ -352,8 +352,8 @@ __device__ __forceinline__ void spdInverseCholDpp(double* A, int ld, int n, int 
     for (int k = 0; k < N; ++k) Wb[k + ldw * lane] = x[k];
   }
   waveLdsSync();
-  if (lane < n * n) {
-    const int j = lane / n, i = lane - j * n;
+  for (int e = lane; e < n * n; e += 64) {
+    const int j = e / n, i = e - j * n;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) acc = __builtin_fma(Wb[k + ldw * i], Wb[k + ldw * j], acc);      // (W(k, l) = 0 for k < l and beyond n: the padding is the identity)

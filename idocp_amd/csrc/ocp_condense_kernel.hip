@@ -93,7 +93,9 @@ struct CondenseSmem {
                        // the narrow layouts have room for M^-1 in a block of its own: M then survives the inversion, and t = M^T beta + J^T mu
                        // moves from the head of wave 1's chain to wave 3
                        MINV = SEP_MINV ? QB6 + 36 + 2 : MM,
-                       TOTAL = QB6 + 36 + 2 + (SEP_MINV ? NV * NV : 0);
+                       // scratch of the contact Schur complement's inverse (W = L^-1): the wide layouts have no room for it behind G and Jl D^-1
+                       WSM = QB6 + 36 + 2 + (SEP_MINV ? NV * NV : 0),
+                       TOTAL = WSM + (SEP_MINV ? 0 : NF * NF);
   static_assert(SOLS % 2 == 0 && LIEB % 2 == 0 && IDC % 2 == 0 && MJ % 2 == 0, "16-byte pieces");
 };
 
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
   // DIMF >= 0: the number of active contact rows is a compile-time constant (every loop bound and
   // index division below folds); DIMF < 0: read it from the stage's node.
   const int dimf = (DIMF >= 0) ? DIMF : nd->dimf, dimvf = NV + dimf;
+  const int dimfd = (DIMF == 0) ? 1 : dimf;          // divisor of the index splits (the flight class, DIMF = 0, never runs those loops)
   const long rec = b * B.NS + nd->slot;
   const double* __restrict__ s_g = B.sol + rec * L::SOL;
   const double* __restrict__ sn_g = B.sol + (b * B.NS + (terminal ? nd->slot : nd->next)) * L::SOL;
@@ -559,14 +562,14 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     ldsFlagWait(&s_ba, 1, lane);                                   // D^-1 (leg blocks) and E (lower-left block, transposed) stand
     if (wave == 2) {
       for (int e = lane; e < dimf * 6; e += 64) {                  // G = Jb - Jl E^T
-        const int c = e / dimf, r = e - c * dimf;
+        const int c = e / dimfd, r = e - c * dimfd;
         double acc = sm[S::JM + r + SF * c];
 #pragma unroll
         for (int m = 0; m < NJ; ++m) acc -= sm[S::JM + r + SF * (6 + m)] * sm[S::MINV + (6 + m) + NV * c];
         sm[GG + r + SF * c] = acc;
       }
       for (int e = lane; e < dimf * NJ; e += 64) {                 // T = Jl D^-1 (D^-1: full symmetric LJ x LJ blocks)
-        const int c = e / dimf, r = e - c * dimf, o = 6 + (c / LJ) * LJ;
+        const int c = e / dimfd, r = e - c * dimfd, o = 6 + (c / LJ) * LJ;
         double acc = 0.0;
 #pragma unroll
         for (int m = 0; m < LJ; ++m) acc += sm[S::JM + r + SF * (o + m)] * sm[S::MINV + (o + m) + NV * (6 + c)];
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       ldsFlagSet(&s_gt, 1, lane);                                  // wave 1 may overwrite D^-1 and E; wave 3 may read G, T
       ldsFlagWait(&s_ba, 2, lane);                                 // S^-1 stands in the base block
       for (int e = lane; e < dimf * 6; e += 64) {                  // BL[:, 0:6] = G S^-1
-        const int c = e / dimf, r = e - c * dimf;
+        const int c = e / dimfd, r = e - c * dimfd;
         double acc = 0.0;
 #pragma unroll
         for (int m = 0; m < 6; ++m) acc += sm[GG + r + SF * m] * sm[S::MINV + m + NV * c];
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       }
       waveLdsSync();
       for (int e = lane; e < dimf * dimf; e += 64) {               // SM = (G S^-1) G^T + T Jl^T
-        const int c = e / dimf, r = e - c * dimf;
+        const int c = e / dimfd, r = e - c * dimfd;
         double acc = 0.0;
 #pragma unroll
         for (int m = 0; m < 6; ++m) acc += sm[S::BL + r + SF * m] * sm[GG + c + SF * m];
@@ -594,15 +597,15 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       }
       waveLdsSync();
       if (dimf > 0) {                                                                 // SM = (J Minv J^T)^-1
-        constexpr int WW = TT + SF * NJ;
-        if constexpr (SF <= 8 && WW + SF * SF <= S::VEC) spdInverseCholDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok, &sm[WW], SF);
-        else spdInverseRowsDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok);
+        constexpr int WW = (TT + SF * NJ + SF * SF <= S::VEC) ? TT + SF * NJ : S::WSM;
+        static_assert(WW != S::WSM || !S::SEP_MINV, "the narrow layouts keep W behind G and Jl D^-1");
+        spdInverseCholDpp<SF>(&sm[S::SM], SF, dimf, lane, &s_ok, &sm[WW], SF);
       }
     } else {
       ldsFlagWait(&s_gt, 1, lane);
       ldsFlagWait(&s_ba, 3, lane);                                 // the top-right block -S^-1 E stands
       for (int e = lane; e < dimf * NJ; e += 64) {                 // BL[:, 6:] = G (-S^-1 E) + T
-        const int c = e / dimf, r = e - c * dimf;
+        const int c = e / dimfd, r = e - c * dimfd;
         double acc = sm[TT + r + SF * c];
 #pragma unroll
         for (int m = 0; m < 6; ++m) acc += sm[GG + r + SF * m] * sm[S::MINV + m + NV * (6 + c)];
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       sm[S::MJ + r + SVF * (NV + c)] = tr;
       sm[S::MJ + (NV + c) + SVF * r] = tr;
     }
-    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimf, r = e - c * dimf; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
+    for (int e = tid; e < dimf * dimf; e += nt) { const int c = e / dimfd, r = e - c * dimfd; sm[S::MJ + (NV + r) + SVF * (NV + c)] = -sm[S::SM + r + SF * c]; }
   };
   STAMPW(7);
   rneaAssembleQV<D>(bwp, tid, nt, sc, out);                           // reads the scratch behind the joint records
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     if (e < NV * NV) { const int c = e / NV, r = e - c * NV; sm[S::QAFU + r + SVF * c] = hu * sm[S::QAA + r] * sm[S::MJ + r + SVF * c]; }
   }
   for (int e = tid; e < dimf * NV; e += nt) {
-    const int c = e / dimf, r = e - c * dimf;
+    const int c = e / dimfd, r = e - c * dimfd;
     sm[S::QAFU + NV + r + SVF * c] = hu * dotAny(&sm[S::QFF + r], SF, &sm[S::MJ + NV + SVF * c], 1, dimf);
   }
   STAMP(12);
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     if (e < NV * NX) { const int c = e / NV, r = e - c * NV; sm[S::QAFQV + r + SVF * c] = -sm[S::QAA + r] * sm[S::MJD + r + SVF * c]; }
   }
   for (int e = tid; e < dimf * NX; e += nt) {
-    const int c = e / dimf, r = e - c * dimf;
+    const int c = e / dimfd, r = e - c * dimfd;
     sm[S::QAFQV + NV + r + SVF * c] = -dotAny(&sm[S::QFF + r], SF, &sm[S::MJD + NV + SVF * c], 1, dimf);
   }
   if (tid < dimvf) {
