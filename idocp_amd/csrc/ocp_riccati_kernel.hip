@@ -1037,12 +1037,34 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int bb = 0; bb < 3; ++bb) Wt[a][bb] = tile_t{0.0, 0.0, 0.0, 0.0};
+    // The third row tile of Wt has FOUR rows (slots 32 .. 35 of x; the slots behind them are u, and P has no such columns): on the 16 x 16 x 4
+    // instruction that is 18 of the 54 products of the phase for a quarter of a tile each.  v_mfma_f64_4x4x4_4b_f64 takes its operands in the
+    // SAME lane map (A: lane 16 k + i16, B: lane 16 k + j16) but forms only the four diagonal 4 x 4 blocks, D[4 b + i][4 b + j] at lane
+    // 16 i + 4 b + j -- which is where register 0 of an accumulator-layout tile keeps rows 0 .. 3 -- at 8 instead of 59 ns.  So
+    // the operand's first four columns are copied into all four blocks (two DPP row shifts under a bank mask) and the product of block-row 0
+    // with the sixteen columns of a C tile drops straight into Wt[2][bb][0].  IDOCP_S3_MFMA4=0 at build time keeps the old form.
+#ifndef IDOCP_S3_MFMA4
+#define IDOCP_S3_MFMA4 1
+#endif
+    auto quadToRow = [&](double v) -> double {      // lanes 4 b + i of every row of 16  <-  lane i of that row
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xF, 0x2, false);      // row_shr:4 into bank 1
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xF, 0x2, false);
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xF, 0xC, false);      // row_shr:8 into banks 2, 3
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xF, 0xC, false);
+      return __hiloint2double(hi, lo);
+    };
     auto phase1 = [&](auto dtag) {
       constexpr int d = decltype(dtag)::value;
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+      for (int a = 0; a < (IDOCP_S3_MFMA4 ? 2 : 3); ++a)
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb) Wt[a][bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[DC[d]][a][DS[d]], Cd[d][bb], Wt[a][bb], 0, 0, 0);
+      if (IDOCP_S3_MFMA4) {
+        const double p4 = quadToRow(Pt[DC[d]][2][DS[d]]);
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) Wt[2][bb][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(p4, Cd[d][bb], Wt[2][bb][0], 0, 0, 0);
+      }
     };
     if (lane < 48) sm[S::VF + lane] = lane < NX ? fx : 0.0;
     waveLdsSync();
@@ -1181,10 +1203,17 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
         Pn[t] = Qh[t];
         if (TA[t] == 2) { Pn[t][1] = 0.0; Pn[t][2] = 0.0; Pn[t][3] = 0.0; }
       }
+      // (tiles 0 .. 2 are the row tile with the four rows 32 .. 35 of x: 4 x 4 x 4 products into register 0, as in phase 1)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < 3; ++s) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) Pn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Kr[TA[t]][s], Qh[TB[t]][s + 1], Pn[t], 0, 0, 0);
+        for (int t = (IDOCP_S3_MFMA4 ? 3 : 0); t < 6; ++t) Pn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Kr[TA[t]][s], Qh[TB[t]][s + 1], Pn[t], 0, 0, 0);
+        if (IDOCP_S3_MFMA4) {
+          const double k4 = quadToRow(Kr[2][s]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) Pn[t][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(k4, Qh[TB[t]][s + 1], Pn[t][0], 0, 0, 0);
+        }
+      }
     } else {
       // ---- stage with a switching constraint (split_riccati_factorizer.hxx:56-101): the Schur-complement step of the round-2 kernel
       //      on natural-layout copies in LDS ----
