@@ -70,6 +70,28 @@ __device__ __forceinline__ void pSub(wtile& acc, const wtile& X, const wtile& Y)
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[s], Y[s], acc, 0, 0, 0);
 }
+// The same products where X has FOUR columns (a column tile 32 .. 35 of a 36-wide matrix): the result has four rows, register 0 of the
+// accumulator tile.  v_mfma_f64_4x4x4_4b_f64 reads its operands in the lane map of the 16 x 16 x 4 form but only multiplies the four
+// diagonal 4 x 4 blocks, D[4 b + i][4 b + j] at lane 16 i + 4 b + j -- register 0's place for rows 0 .. 3 -- in 8 ns instead of 46 - 59
+// (DESIGN 4.0a).  X's first four columns are copied into all four blocks first (two DPP row shifts under a bank mask).
+__device__ __forceinline__ double quadToRow(double v) {      // lanes 4 b + i of every row of 16  <-  lane i of that row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xF, 0x2, false);      // row_shr:4 into bank 1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xF, 0x2, false);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xF, 0xC, false);      // row_shr:8 into banks 2, 3
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xF, 0xC, false);
+  return __hiloint2double(hi, lo);
+}
+template <int STEPS = 4>
+__device__ __forceinline__ void pAcc4(wtile& acc, const wtile& X, const wtile& Y) {
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(quadToRow(X[s]), Y[s], acc[0], 0, 0, 0);
+}
+template <int STEPS = 4>
+__device__ __forceinline__ void pSub4(wtile& acc, const wtile& X, const wtile& Y) {
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(-quadToRow(X[s]), Y[s], acc[0], 0, 0, 0);
+}
 __device__ __forceinline__ wtile wzero() { return wtile{0.0, 0.0, 0.0, 0.0}; }
 
 // register 4 q + g of sixteen per-lane values -> accumulator-layout register q (g = the lane's row of 16)
@@ -208,7 +230,8 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     R02 = wzero(); pAcc(R02, Gd, A[U3(0, 2)]);
     pSub(A[U3(1, 1)], R01, R01);
     pSub(A[U3(1, 2)], R01, R02);
-    pSub(A[U3(2, 2)], R02, R02);
+    constexpr bool QUAD = decltype(np2)::value <= 4;      // the last block has four rows / columns: its products as 4 x 4 x 4 blocks
+    if constexpr (QUAD) pSub4(A[U3(2, 2)], R02, R02); else pSub(A[U3(2, 2)], R02, R02);
     {
       double a[16];
       rowsOfTile(A[U3(1, 1)], a);
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     }
     Gd = transposeTile(W[U3(1, 1)]);
     R12 = wzero(); pAcc(R12, Gd, A[U3(1, 2)]);
-    pSub(A[U3(2, 2)], R12, R12);
+    if constexpr (QUAD) pSub4(A[U3(2, 2)], R12, R12); else pSub(A[U3(2, 2)], R12, R12);
     // W_10 = -W_11 L_10 W_00,  L_im = R_mi^T
     {
       wtile T = wzero();
@@ -231,12 +254,21 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
     Gd = transposeTile(W[U3(2, 2)]);
     {
       wtile T = wzero();
+      if constexpr (QUAD) {      // (T has four rows; of W_22^T only its 4 x 4 block meets them)
+        pAcc4(T, R12, W[U3(1, 1)]);
+        W[U3(1, 2)] = wzero(); pSub4<1>(W[U3(1, 2)], Gd, T);      // W_21
+        T = wzero();
+        pAcc4(T, R02, W[U3(0, 0)]);
+        pAcc4(T, R12, W[U3(0, 1)]);
+        W[U3(0, 2)] = wzero(); pSub4<1>(W[U3(0, 2)], Gd, T);      // W_20
+      } else {
       pAcc(T, R12, W[U3(1, 1)]);
       W[U3(1, 2)] = wzero(); pSub(W[U3(1, 2)], Gd, T);      // W_21
       T = wzero();
       pAcc(T, R02, W[U3(0, 0)]);
       pAcc(T, R12, W[U3(0, 1)]);
       W[U3(0, 2)] = wzero(); pSub(W[U3(0, 2)], Gd, T);      // W_20
+      }
     }
   };
   // parking place of tiles: 4 doubles per lane and slot
@@ -415,7 +447,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
       for (int jt = 0; jt < 3; ++jt) {
         wtile Z = wzero();
 #pragma unroll
-        for (int kt = jt; kt < 3; ++kt) pAcc(Z, Y[kt][it], Wq[U3(jt, kt)]);
+        for (int kt = jt; kt < 3; ++kt) { if (it == 2) pAcc4(Z, Y[kt][it], Wq[U3(jt, kt)]); else pAcc(Z, Y[kt][it], Wq[U3(jt, kt)]); }
         if (it < 2) parkTile(3 * it + jt, Z);
         else sm[S::BUF + 6 * 256 + 64 * jt + lane] = Z[0];
         __builtin_amdgcn_sched_barrier(0);
@@ -427,7 +459,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
       for (int jt = it; jt < 3; ++jt) {
         Sm[U3(it, jt)] = wzero();
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt) pAcc(Sm[U3(it, jt)], Y[kt][it], Y[kt][jt]);
+        for (int kt = 0; kt < 3; ++kt) { if (it == 2) pAcc4(Sm[U3(it, jt)], Y[kt][it], Y[kt][jt]); else pAcc(Sm[U3(it, jt)], Y[kt][it], Y[kt][jt]); }
       }
   }
   // t1 = r1 - F Q^-1 r2 (zero beyond row 35), from the lanes that hold column 36 of S
@@ -482,7 +514,10 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
         for (int q = 0; q < 4; ++q) p[it] += Ht[q] * t1v[kt][q];
 #pragma unroll
         for (int jt = 0; jt < 3; ++jt) {
-          if (kt < 2) pAcc<4>(Z1[it][jt], Ht, parkedTile(3 * kt + jt));
+          if (it == 2) {      // (four rows of Z1)
+            if (kt < 2) pAcc4<4>(Z1[it][jt], Ht, parkedTile(3 * kt + jt));
+            else pAcc4<1>(Z1[it][jt], Ht, wtile{sm[S::BUF + 6 * 256 + 64 * jt + lane], 0.0, 0.0, 0.0});
+          } else if (kt < 2) pAcc<4>(Z1[it][jt], Ht, parkedTile(3 * kt + jt));
           else pAcc<1>(Z1[it][jt], Ht, wtile{sm[S::BUF + 6 * 256 + 64 * jt + lane], 0.0, 0.0, 0.0});
         }
       }
