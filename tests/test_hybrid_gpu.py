@@ -155,6 +155,47 @@ def test_flight_phase_sequence_parity():
         assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-6, f
 
 
+def test_odd_contact_counts_take_the_general_class():
+    """Stages with THREE feet and with ONE foot in contact (dimf = 9, 3), reached by single-foot lifts and single-foot / two-feet impulses:
+    neither 12, 6 nor 0 contact rows, so every such stage -- plain, impulse, with a switching constraint -- runs the general instantiation of
+    the condensation kernel (run-time contact count in the wide LDS layout; its contact Schur complement next to the mass-matrix inverse,
+    DESIGN 4.0a).  First direction under the referee rule, then a few iterations."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    N, T, E = 28, 1.2, 6
+    mk = lambda cls, **kw: cls(m, cost, cons, T, N, max_num_impulse=E, **kw)
+    o, g, h = mk(OracleOCP), mk(HipOCP), mk(OracleOCP, hp=True)
+    from helpers import anymal_contact_points
+    pts = anymal_contact_points(m).copy()
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in (o, g, h):
+        s.set_contact_status([1, 1, 1, 1], pts)
+        s.push_back_contact_status([0, 1, 1, 1], pts, 0.17)          # one foot lifts: three feet, 9 rows
+        s.push_back_contact_status([0, 1, 0, 0], pts, 0.36)          # two more: one foot, 3 rows
+        p2 = pts.copy()
+        p2[:, 0] += 0.03
+        s.push_back_contact_status([1, 1, 0, 0], p2, 0.58)           # impulse of one foot (3 impulse rows), two feet after it
+        s.push_back_contact_status([1, 1, 1, 0], p2, 0.79)           # impulse of one foot, three feet after it
+        s.push_back_contact_status([1, 1, 1, 1], p2, 1.01)           # impulse of the last foot
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    co, cg = o.chain(0.0), g.chain(0.0)
+    assert [(a["kind"], a["slot"], a["dimf"]) for a in co] == [(b["kind"], b["slot"], b["dimf"]) for b in cg]
+    dims = {c["dimf"] for c in co if c["kind"] == "stage"}
+    assert {3, 9} <= dims and sum(1 for c in co if c["kind"] == "impulse") == 3
+    M = len(co)
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
+    for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+        referee_check(g.get_chain(f, M), o.get_chain(f, M), h.get_chain(f, M), f)
+        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-8, f
+    for it in range(3):
+        assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
+    for f in ("q", "v", "a", "u", "f"):
+        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-6, f
+
+
 def test_running_example_parity():
     """BASELINE.json configs[4]'s problem: examples/anymal/anymal_running.cpp (TimeVaryingConfigurationSpaceCost, 40 discrete
     events -- 26 touch-downs, 14 lift-offs --, flight phases, N = 240, T = 7) on the GPU against the oracle: same chain, the
