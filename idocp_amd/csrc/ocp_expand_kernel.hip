@@ -110,6 +110,36 @@ __device__ __forceinline__ void wideLoad(ex_d2 (&r)[(N2 + 63) / 64], const doubl
 #pragma unroll
   for (int t = 0; t < (N2 + 63) / 64; ++t) { const int e = lane + 64 * t; r[t] = p[e < N2 ? e : N2 - 1]; }
 }
+// The same for a record of which only the first n2 pieces carry data (lanes beyond re-read the last one: same cache line, no traffic)
+template <int N2>
+__device__ __forceinline__ void wideLoadN(ex_d2 (&r)[(N2 + 63) / 64], const double* __restrict__ src, int lane, int n2) {
+  const ex_d2* __restrict__ p = reinterpret_cast<const ex_d2*>(src);
+#pragma unroll
+  for (int t = 0; t < (N2 + 63) / 64; ++t) { const int e = lane + 64 * t; r[t] = p[e < n2 ? e : n2 - 1]; }
+}
+// A column-major block with leading dimension 2 LD2 of which only the first 2 h rows of a column carry data (h pieces per column, NC columns):
+// piece e of the compact numbering is row pair e mod h of column e / h.  inv = ceil(65536 / h) turns the division into a multiplication (exact
+// for e < 65536 / h).
+template <int N2, int LD2>
+__device__ __forceinline__ void wideLoadRows(ex_d2 (&r)[(N2 + 63) / 64], const double* __restrict__ src, int lane, int h, int inv, int n2) {
+  const ex_d2* __restrict__ p = reinterpret_cast<const ex_d2*>(src);
+#pragma unroll
+  for (int t = 0; t < (N2 + 63) / 64; ++t) {
+    int e = lane + 64 * t;
+    e = e < n2 ? e : n2 - 1;
+    const int c = (e * inv) >> 16;
+    r[t] = p[c * LD2 + (e - c * h)];
+  }
+}
+template <int N2, int LD2>
+__device__ __forceinline__ void wideStoreLdsRows(double* dst, const ex_d2 (&r)[(N2 + 63) / 64], int lane, int h, int inv, int n2) {
+#pragma unroll
+  for (int t = 0; t < (N2 + 63) / 64; ++t) {
+    const int e = lane + 64 * t;
+    const int c = (e * inv) >> 16;
+    if (e < n2) reinterpret_cast<ex_d2*>(dst)[c * LD2 + (e - c * h)] = r[t];
+  }
+}
 template <int N2>
 __device__ __forceinline__ void wideStoreLds(double* dst, const ex_d2 (&r)[(N2 + 63) / 64], int lane) {
 #pragma unroll
@@ -148,9 +178,13 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   const bool expand = !terminal && !bimp;
   ex_d2 pw[(RL / 2 + 63) / 64], mw[(MJDL / 2 + 63) / 64], uw[(MJUL / 2 + 63) / 64];
   if (costate) wideLoad<RL / 2>(pw, B.ric + rec * L::RIC, lane);
+  // only the rows the stage has are fetched: NV + dimf of the NVF rows of MJtJinv_dIDCdqv, the first (NV + dimf)(NV + dimf + 1) / 2 entries of
+  // the triangle of MJtJinv -- 3 kB less per stage with half of the feet in contact (round 4: the whole padded blocks)
+  const int rows_ld = NV + nd->dimf, h_ld = (rows_ld + 1) >> 1, inv_ld = 65535 / h_ld + 1, nmjd2 = h_ld * NX, ntri2 = (rows_ld * (rows_ld + 1) / 2 + 1) >> 1;
+  static_assert(NVF % 2 == 0 && (NVF / 2) * NX == MJDL / 2, "pieces per column of MJtJinv_dIDCdqv");
   if (expand) {
-    wideLoad<MJDL / 2>(mw, B.exp + rec * L::EXP + L::E_MJD, lane);
-    wideLoad<MJUL / 2>(uw, B.exp + rec * L::EXP + L::E_MJ, lane);
+    wideLoadRows<MJDL / 2, NVF / 2>(mw, B.exp + rec * L::EXP + L::E_MJD, lane, h_ld, inv_ld, nmjd2);
+    wideLoadN<MJUL / 2>(uw, B.exp + rec * L::EXP + L::E_MJ, lane, ntri2);
   }
   // the small operands of the second half (solution, slack / dual rows of this lane, MJtJinv_IDC) travel with the matrices
   static_assert(L::SOL % 2 == 0 && L::NCON <= 128, "two IPM rows per lane");
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
   }
   if (terminal) return;
   waveLdsSync();                                  // P has been read: the buffer takes MJtJinv_dIDCdqv
-  if (expand) wideStoreLds<MJDL / 2>(mjd, mw, lane);
+  if (expand) wideStoreLdsRows<MJDL / 2, NVF / 2>(mjd, mw, lane, h_ld, inv_ld, nmjd2);
   waveLdsSync();
   const long su = rec;
   const double* s = sr;
@@ -316,7 +350,8 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   double* __restrict__ dual = B.dual + rec * L::CON;
   ex_d2 mw[(MJL / 2 + 63) / 64], tw[(TL / 2 + 63) / 64], dw[(L::DIR / 2 + 63) / 64], sw[(L::SOL / 2 + 63) / 64];
   double sl_r[2] = {1.0, 1.0}, dl_r[2] = {1.0, 1.0};
-  if (stage) wideLoad<MJL / 2>(mw, B.exp + rec * L::EXP, lane);
+  const int rows_ld = (bwd && nd->kind == 1) ? NV : NV + nd->dimf;      // the rows of the triangle of MJtJinv this stage has (see dimvf below)
+  if (stage) wideLoadN<MJL / 2>(mw, B.exp + rec * L::EXP, lane, (rows_ld * (rows_ld + 1) / 2 + 1) >> 1);
   wideLoad<TL / 2>(tw, B.exp + rec * L::EXP + TO, lane);
   wideLoad<L::DIR / 2>(dw, dd, lane);
   wideLoad<L::SOL / 2>(sw, s, lane);
