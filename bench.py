@@ -717,7 +717,7 @@ def main():
         N = args.horizon if args.horizon != 100 else 200
         T = 7.0 * N / 240                           # the example's own time step (examples/anymal/anymal_running.cpp: T = 7, N = 240)
         nimp = 26
-        B = args.batch or 512
+        B = args.batch or 1024      # (512 until the end of round 4: the backward Riccati sweep runs one wavefront per instance, half of the SIMDs idle)
         model = anymal_model()
         cost, cons = running_problem(model, 10)
         nq, nv = model.nq, model.nv
