@@ -124,9 +124,9 @@ template <typename D, bool RESIDUAL, int DIMF, bool BWD = false, bool MERIT = fa
 __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0 = nullptr,
                                                               const int* __restrict__ plist = nullptr, int nlist = 0) {
   using L = OcpLayout<D>;
-  using S = CondenseSmem<D, (DIMF > 0) ? DIMF : D::NF>;
+  using S = CondenseSmem<D, (DIMF > 0) ? DIMF : (DIMF == 0 ? D::NF / 2 : D::NF)>;      // (flight stages, DIMF = 0: the narrow layout, nothing of it used by contacts)
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NVF = D::NVF, NU = D::NU, NC = D::NC;
-  constexpr int SF = (DIMF > 0) ? DIMF : NF, SVF = S::NVF, RVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>) and rows; NF / NVF: the HBM records'
+  constexpr int SF = (DIMF > 0) ? DIMF : (DIMF == 0 ? NF / 2 : NF), SVF = S::NVF, RVF = NV + SF;       // LDS leading dimensions (CondenseSmem<D, SF>) and rows; NF / NVF: the HBM records'
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ok, s_c1, s_ba, s_gt, s_m;
   const OcpProblem* __restrict__ P = B.prob;
@@ -1076,8 +1076,8 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
-    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
+    (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     (void)hipFuncSetAttribute((const void*)ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_half);
     configured = true;
   }
@@ -1091,8 +1091,8 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   // the largest class first; the launches are independent (every stage writes its own records)
   if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
   if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
-  // class 4: flight stages (no contact rows at all; the wide LDS layout, every contact loop folded away)
-  if (n[4] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0, false, false, true>), dim3((unsigned)(batch * n[4])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0>), dim3((unsigned)(batch * n[4])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); }
+  // class 4: flight stages (no contact rows at all; the narrow LDS layout, every contact loop folded away)
+  if (n[4] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0, false, false, true>), dim3((unsigned)(batch * n[4])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0>), dim3((unsigned)(batch * n[4])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); }
   // class 3: event stages (impulse / switching constraint) with half of the feet
   if (n[3] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); }
   if (n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
