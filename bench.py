@@ -33,6 +33,36 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_STAGE = {"iiwa14": 5544, "iiwa14_task_space": 5544, "iiwa14_unparnmpc": 5656, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
            "anymal_parnmpc_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
+
+
+def quoted_traffic(workload, batch, horizon, kernel):
+    """HBM bytes per launch of `kernel` from the NEWEST committed counter record of this workload (profiles/rNN_pmc_traffic_<workload>.json:
+    rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in passes of their own, gfx950 correction applied, profiles/run_profiles.sh) -- a QUOTATION,
+    labelled as one, and only when it describes what this run measures: same workload / batch / horizon, the record lists that very kernel
+    (keys are the kernels' own names: no fallback to a similarly named one), and no newer kernel-trace profile of the workload exists
+    whose round the record predates (a record of an earlier round describes earlier kernels).  Otherwise (None, reason)."""
+    import glob
+    import re
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)), reverse=True)
+    if not recs:
+        return None, "no committed counter record for this workload"
+    rnd = lambda path: int(re.match(r"r(\d+)_", os.path.basename(path)).group(1))
+    traces = glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_trace.txt" % workload))
+    newest_trace = max([rnd(t) for t in traces], default=0)
+    try:
+        rec = json.load(open(recs[0]))
+    except Exception as e:
+        return None, "unreadable record %s (%s)" % (os.path.basename(recs[0]), e)
+    name = os.path.basename(recs[0])
+    if rec.get("workload", workload) != workload or rec.get("batch") != batch or rec.get("horizon") != horizon:
+        return None, "profiles/%s was taken at batch %s / horizon %s, this run is %d / %d" % (name, rec.get("batch"), rec.get("horizon"), batch, horizon)
+    if rnd(recs[0]) < newest_trace:
+        return None, "profiles/%s predates the kernels of the round-%d kernel trace of this workload" % (name, newest_trace)
+    val = rec.get("hbm_bytes_per_launch", {}).get(kernel)
+    if val is None:
+        return None, "profiles/%s has no kernel named %s" % (name, kernel)
+    return val, ("quoted from profiles/%s (round %s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel %s; not measured in this run)"
+                 % (name, rec.get("round"), kernel))
 KERNELS_UN = ["un_linearize", "un_riccati_backward", "un_riccati_forward", "un_expand", "un_reduce_steps", "un_integrate"]
 KERNELS_UNP = ["un_linearize", "unparnmpc_coarse_update", "unparnmpc_backward_serial", "unparnmpc_backward_parallel",
                "unparnmpc_forward_serial", "unparnmpc_expand", "un_integrate"]
@@ -335,20 +365,52 @@ def latency_mode(lib, hip, build, q0, v0, iters=40):
     return out
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with
     torch.distributed.run and hand back their exit code.  Called BEFORE this process imports torch or makes any
     HIP call -- a process that has initialised the GPU must never be replaced or forked into ranks.  The ranks
-    inherit stdout, so rank 0's JSON line is this command's output."""
+    inherit stdout, so rank 0's JSON line is this command's output.
+    A first contact between ranks that never completes (an RCCL rendezvous, a halo whose peer is missing) must not eat the caller's
+    whole time budget: after `timeout_s` (--timeout / IDOCP_BENCH_TIMEOUT, default 1200 s) the launcher's process group is ended
+    -- these are exactly the processes started here, in a session of their own -- and the command exits with 124 and the tail
+    of what the ranks wrote to stderr."""
+    import signal
     import socket
     import subprocess
+    import tempfile
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("IDOCP_BENCH_TIMEOUT", "1200"))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.run(cmd).returncode
+    with tempfile.TemporaryFile(mode="w+") as err:
+        proc = subprocess.Popen(cmd, stderr=err, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=timeout_s)
+            timed_out = False
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+                try:
+                    os.killpg(proc.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            rc = 124
+        err.seek(0)
+        text = err.read()
+    if timed_out:
+        sys.stderr.write("bench.py: the %d ranks did not finish within %.0f s -- ended them.  Last stderr of the ranks:\n%s\n" % (n, timeout_s, text[-4000:]))
+    elif text:
+        sys.stderr.write(text)
+    return rc
 
 
 def run_stub(args, rank, world, dist):
@@ -409,6 +471,8 @@ class _StubDistLib:
     def idocp_parnmpc_dist_update_solution(self, h, t):
         self.updates += 1
         time.sleep(0.002)
+        if os.environ.get("IDOCP_BENCH_STUB_HANG") and self.updates == 2:
+            time.sleep(3600)                        # tests/test_bench_dist.py: a first contact that never completes
         return 0
 
 
@@ -434,6 +498,29 @@ def run_parnmpc_stub(args, rank, local_rank, world, dist):
                                      "parallelism": "horizon shards x%d" % world, "stages_per_rank": N // world}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+# what the horizon shards of configs[3] can buy.  The stage-parallel kernels divide by G; the two serial correction
+# sweeps are dependency chains over the N stages of an instance and cost N stage-times on any number of GPUs, plus 2 (G - 1) hops
+# (pack + ncclSend / ncclRecv + unpack of a 74 kB halo, ~15 us over xGMI), the boundary exchange and two all-reduces (~0.1 ms).
+# On one GPU the two parts are this run's own HIP-event times; with G > 1 ranks they are the one-GPU figures of the committed
+# round-5 profile (profiles/r05_anymal_parnmpc_kernel_trace.txt), labelled as such.
+PARNMPC_MODEL_1GPU = {"anymal_parnmpc": {"stage_parallel_ms": 5.3, "sweeps_ms": 0.94}, "anymal_parnmpc_trotting": {"stage_parallel_ms": 6.9, "sweeps_ms": 1.1}}
+
+
+def parnmpc_model_ms(workload, world, ker=None):
+    if ker:
+        serial = ker.get("parnmpc_backward_serial", 0.0) + ker.get("parnmpc_forward_serial", 0.0)
+        par, src = sum(ker.values()) - serial, "this run's kernel times"
+    else:
+        m = PARNMPC_MODEL_1GPU[workload]
+        par, serial, src = m["stage_parallel_ms"], m["sweeps_ms"], "one-GPU kernel times of the committed profile (bench.PARNMPC_MODEL_1GPU)"
+    model = {}
+    for g in (1, 2, 4, 8):
+        comm = 0.0 if g == 1 else 2 * (g - 1) * 0.015 + 0.1
+        model[str(g)] = par / g + serial + comm
+    return {"formula": "stage_parallel / G + sweeps + 2 (G - 1) * 0.015 ms + 0.1 ms (DESIGN.md section 5)", "stage_parallel_ms": par, "sweeps_ms": serial,
+            "source": src, "ms_per_step_by_gpus": model, "this_run": model[str(world)] if str(world) in model else None}
 
 
 def run_parnmpc_cxx(args, rank, local_rank, world, dist):
@@ -515,6 +602,26 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
     raw = exchange_unique_id(lib, dist, rank, world)
     capi.check(lib.idocp_comm_init_rank(raw, rank, world, local_rank, C.byref(comm)), "comm_init_rank")
     capi.check(lib.idocp_parnmpc_dist_attach(shard.h, comm), "dist_attach")
+    # what RCCL itself says it connected, and -- BEFORE anything is timed -- every halo kind across the REAL neighbours in the driver's own
+    # grouping, the all-reduces and the broadcast against known patterns (idocp_parnmpc_dist_transport_selftest; world 1: loop-back)
+    lib.idocp_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    lib.idocp_parnmpc_dist_transport_selftest.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    nr, ur, ver, tr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    capi.check(lib.idocp_comm_info(comm, C.byref(nr), C.byref(ur), C.byref(ver), C.byref(tr)), "comm_info")
+    if nr.value != world or ur.value != rank:
+        raise SystemExit("bench.py: RCCL reports rank %d of %d, the launcher started rank %d of %d" % (ur.value, nr.value, rank, world))
+    dev = C.c_double(-1.0)
+    rc_self = lib.idocp_parnmpc_dist_transport_selftest(shard.h, C.byref(dev))
+    worst = np.array([dev.value if rc_self == 0 else np.inf])
+    if dist is not None:
+        import torch
+        tw = torch.from_numpy(worst)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    if not (worst[0] <= 1e-9):
+        raise SystemExit("bench.py: transport self-test FAILED on rank %d of %d before the timed region: rc %d, largest deviation over the ranks %r (%s)"
+                         % (rank, world, rc_self, float(worst[0]), lib.idocp_last_error().decode() if rc_self else "halo / collective contents differ from the pattern"))
+    rccl_info = {"rccl_nranks": nr.value, "rccl_version": ver.value, "transport": "rccl" if tr.value else "in-process",
+                 "selftest_max_abs_diff": float(worst[0])}
     if rank == 0:
         capi.check(lib.idocp_parnmpc_dist_set_initial_state(shard.h, P(q0), P(v0), nq, nv))
     capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shard.h, 0.0), "dist_init_backward_correction")
@@ -581,26 +688,17 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
                                               "the converged ParNMPC solution of this problem (continuation in the step length)" % (n_events - 1, N + 2 * (n_events - 1) + 1))
                                        if trot else "4 point contacts on every stage, warm-started from the converged Riccati solution of the same OCP", B, N, world)),
                        "horizon": N, "batch_per_gpu": B, "parallelism": "horizon shards x%d" % world,
-                       "stages_per_rank": Nl, "setup": setup,
+                       "stages_per_rank": Nl, "setup": setup, "rccl": rccl_info,
+                       "model_ms": parnmpc_model_ms(args.workload, world, ker if world == 1 else None),
                        "kernel_ms": ker, "max_kkt_error_after": float(kkt.max())},
         }
         if ker:
             dom = max(ker, key=ker.get)
             alg_bytes = A_STAGE["anymal_parnmpc"] * B * (Nl + (2 * (n_events - 1) + 1 if trot else 0))
             achieved = alg_bytes / (ker[dom] * 1e-3) / 1e9
-            traffic = None
-            traffic_source = None
-            import glob
-            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
-                try:
-                    rec = json.load(open(pmc))
-                    if rec.get("batch") == B and rec.get("horizon") == N:
-                        hb = rec.get("hbm_bytes_per_launch", {})
-                        traffic = hb.get(dom, hb.get(dom + "_wave"))
-                        traffic_source = "quoted from profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" % os.path.basename(pmc)
-                        break
-                except Exception:
-                    traffic = None
+            # (the bench's phase "parnmpc_kkt_inverse" is the launch of parnmpc_kkt_inverse_wave_kernel unless IDOCP_K9_WAVE=0)
+            pmc_name = "parnmpc_kkt_inverse_wave" if dom == "parnmpc_kkt_inverse" and os.environ.get("IDOCP_K9_WAVE", "1") != "0" else dom
+            traffic, traffic_source = quoted_traffic(args.workload, B, N, pmc_name)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_ms": ker[dom],
@@ -642,13 +740,15 @@ def main():
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--friction-cone", choices=["linearized", "nonlinear"], default="linearized",
                     help="ANYmal workloads: LinearizedFrictionCone (the trotting / running examples) or FrictionCone (examples/anymal/ocp_benchmark.cpp:76)")
+    ap.add_argument("--timeout", type=float, default=None, help="--gpus N > 1 started without a launcher: seconds after which the ranks are ended "
+                                                              "and the command exits with 124 (default: IDOCP_BENCH_TIMEOUT or 1200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (config.latency)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N`: this process has not touched the GPU (numpy / ctypes only so far); it becomes the launcher
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.timeout))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -850,21 +950,8 @@ def main():
     a_stage = A_STAGE[args.workload]
     alg_bytes = a_stage * units[dom]
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
-    traffic = None
-    traffic_source = None
-    # HBM bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and
-    # WRITE_SIZE in separate passes, gfx950 correction applied) by profiles/run_profiles.sh; only quoted
-    # when the committed record was taken on this very workload / batch / horizon.
-    import glob
-    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)), reverse=True):
-        try:
-            rec = json.load(open(pmc))
-            if rec.get("batch") == B and rec.get("horizon") == N and rec.get("workload", "iiwa14") == args.workload:
-                traffic = rec.get("hbm_bytes_per_launch", {}).get(KERNELS[dom])
-                traffic_source = "quoted from profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" % os.path.basename(pmc)
-                break
-        except Exception:
-            traffic = None
+    # HBM bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (quoted_traffic above)
+    traffic, traffic_source = quoted_traffic(args.workload, B, N, KERNELS[dom])
 
     # parity guard inside the bench: the timed state must still be a valid solver state
     kkt = solver.kkt_error(0.0, q0, v0)

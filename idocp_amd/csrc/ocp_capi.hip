@@ -217,12 +217,45 @@ int discretizeParNMPC(idocp_ocp* h, double t);
 
 // Reference poses of the task-space cost for the M stages of the chain just built: the constant pose of the cost, or -- TimeVarying
 // variants -- the poses the caller evaluated at the stage times (idocp_ocp_get_chain_times -> idocp_ocp_set_task_refs).
+// The host half of a discretisation as it stood before a discretiser started to rewrite it.  The one recoverable error of a
+// discretiser that is only known once the new chain exists -- a TimeVarying task-space cost without reference poses for THIS chain --
+// restores it, so that the handle keeps describing the discretisation its device tables (d_nodes, class lists, d_prob) still hold.
+struct DiscSnapshot {
+  idocp_ocp* h;
+  std::vector<OcpNode> chain;
+  std::vector<int> chain_index;
+  std::vector<double> chain_t;
+  OcpProblem prob;
+  int Ngrid, uniform_dimf, n_impulse, n_general, BM, BNS, Bnimp, Bnsw;
+  bool has_switch, has_terminal, has_prev;
+  explicit DiscSnapshot(idocp_ocp* hh)
+      : h(hh), chain(hh->chain), chain_index(hh->chain_index), chain_t(hh->chain_t), prob(hh->prob), Ngrid(hh->Ngrid), uniform_dimf(hh->uniform_dimf),
+        n_impulse(hh->n_impulse), n_general(hh->n_general), BM(hh->B.M), BNS(hh->B.NS), Bnimp(hh->B.n_impulse_fe), Bnsw(hh->B.n_switch),
+        has_switch(hh->has_switch), has_terminal(hh->has_terminal), has_prev(hh->has_prev) {}
+  void restore() {
+    h->chain.swap(chain); h->chain_index.swap(chain_index); h->chain_t.swap(chain_t);
+    h->prob = prob; h->Ngrid = Ngrid; h->uniform_dimf = uniform_dimf; h->n_impulse = n_impulse; h->n_general = n_general;
+    h->B.M = BM; h->B.NS = BNS; h->B.n_impulse_fe = Bnimp; h->B.n_switch = Bnsw;
+    h->has_switch = has_switch; h->has_terminal = has_terminal; h->has_prev = has_prev;
+  }
+};
+
+// reference poses of a TimeVarying task-space cost must exist for the chain (t, M) unless the caller only asks for the chain's shape
+static int taskRefsAvailable(idocp_ocp* h, double t, int M) {
+  if (h->cost.task_dim == 0 || !h->cost.task_time_varying || h->task_refs_lenient) return IDOCP_OK;
+  if (h->task_refs_host.size() != (size_t)M * 12 || h->task_refs_t != t) {
+    set_last_error("TimeVarying task-space cost: no reference poses for this chain (idocp_ocp_set_task_refs with the same t, M = the chain's length)");
+    return IDOCP_E_ARG;
+  }
+  return IDOCP_OK;
+}
+
 static int uploadTaskRefs(idocp_ocp* h, double t, int M) {
   if (h->cost.task_dim == 0) return IDOCP_OK;
   std::vector<double> tab((size_t)M * 12);
   if (h->cost.task_time_varying) {
     if (h->task_refs_host.size() != (size_t)M * 12 || h->task_refs_t != t) {
-      if (!h->task_refs_lenient) {
+      if (!h->task_refs_lenient) {                       // (not reached: every discretiser asks taskRefsAvailable before it touches the device)
         set_last_error("TimeVarying task-space cost: no reference poses for this chain (idocp_ocp_set_task_refs with the same t, M = the chain's length)");
         return IDOCP_E_ARG;
       }
@@ -285,6 +318,7 @@ int discretize(idocp_ocp* h, double t) {
   }
   phase[Ng] = num_events;
   if (num_events > (int)h->phases.size() - 1) { set_last_error("OCPDiscretizer: inconsistent contact sequence"); return IDOCP_E_ARG; }
+  DiscSnapshot before(h);
   h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
   auto node = [&](int kind, int index, double tt, double dtt, const HostStatus& st, int level) {
     OcpNode nd;
@@ -324,6 +358,7 @@ int discretize(idocp_ocp* h, double t) {
   }
   node(4, Ng, ts[Ng], 0.0, h->phases[phase[Ng]], Ng);
   const int M = h->M();
+  if (taskRefsAvailable(h, t, M)) { before.restore(); return IDOCP_E_ARG; }
   for (int p = 0; p < M; ++p) {
     h->chain[p].prev = p > 0 ? h->chain[p - 1].slot : -1;
     h->chain[p].next = p + 1 < M ? h->chain[p + 1].slot : -1;
@@ -429,6 +464,7 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   // predecessor is the measured state (backward_correction_solver.cpp:201-217, 232-246).  The aux stage carries the switching
   // constraint like every other aux stage: the reference's call at :203-211 omits the impulse status and then sizes the KKT
   // inverse with it (split_backward_correction.hxx:46-52), which is not defined as written (oracle/ocp.cpp, same place)
+  DiscSnapshot before(h);
   h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
   auto node = [&](int kind, int index, double tt, double dtt, const HostStatus& st, int level) {
     OcpNode nd;
@@ -483,7 +519,7 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
       if (owner >= lo && owner < hi) { nodes.push_back(h->chain[p]); idx.push_back(h->chain_index[p]); tt.push_back(h->chain_t[p]); }
       else if (owner >= hi && next_slot < 0) next_slot = h->chain[p].slot;
     }
-    if (nodes.empty()) { set_last_error("ParNMPC: empty shard of the chain"); return IDOCP_E_ARG; }
+    if (nodes.empty()) { before.restore(); set_last_error("ParNMPC: empty shard of the chain"); return IDOCP_E_ARG; }
     h->chain.swap(nodes); h->chain_index.swap(idx); h->chain_t.swap(tt);
     is_first_shard = lo == 0; is_last_shard = hi >= Ng;
     if (!is_last_shard) {
@@ -505,6 +541,7 @@ int discretizeParNMPCHybrid(idocp_ocp* h, double t) {
   }
   h->has_terminal = is_last_shard; h->has_prev = !is_first_shard;
   const int M = h->M();
+  if (taskRefsAvailable(h, t, M)) { before.restore(); return IDOCP_E_ARG; }
   for (int p = 0; p < M; ++p) {
     h->chain[p].prev = p > 0 ? h->chain[p - 1].slot : -1;
     h->chain[p].next = p + 1 < M ? h->chain[p + 1].slot : -1;
@@ -545,6 +582,7 @@ int discretizeParNMPC(idocp_ocp* h, double t) {
   if (!h->event_time.empty()) return discretizeParNMPCHybrid(h, t);
   const int N = h->N;
   const double dt = h->T / N;
+  if (taskRefsAvailable(h, t, N + 1)) return IDOCP_E_ARG;          // before anything of the handle is rewritten
   h->chain.clear(); h->chain_index.clear(); h->chain_t.clear();
   for (int i = 0; i <= N; ++i) {
     OcpNode nd;
@@ -965,8 +1003,20 @@ int idocp_ocp_get_chain_times(idocp_ocp_t* h, double t, int capacity, double* ti
 int idocp_ocp_set_task_refs(idocp_ocp_t* h, double t, int M, const double* refs) {
   if (!h || !refs || M <= 0) return IDOCP_E_ARG;
   if (h->cost.task_dim == 0 || !h->cost.task_time_varying) { set_last_error("idocp_ocp_set_task_refs: the solver carries no TimeVarying task-space cost"); return IDOCP_E_ARG; }
+  const bool same = h->task_refs_t == t && h->task_refs_host.size() == (size_t)M * 12 &&
+                    std::memcmp(h->task_refs_host.data(), refs, sizeof(double) * (size_t)M * 12) == 0;
+  if (same && !h->task_refs_stale) return IDOCP_OK;          // the poses the device table already holds
   h->task_refs_host.assign(refs, refs + (size_t)M * 12);
   h->task_refs_t = t;
+  if (!h->seq_dirty && h->disc_time == t && M == h->M()) {
+    // the chain is the current one (idocp_ocp_get_chain_times has just discretised at t, the facade's order of calls): the table
+    // goes straight to the device -- no second discretisation with its host-synchronous uploads in the MPC loop
+    int rc = setDev(h); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_taskref, h->task_refs_host.data(), sizeof(double) * (size_t)M * 12, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->task_refs_stale = false;
+    return IDOCP_OK;
+  }
   h->seq_dirty = true;                       // uploaded with the next discretisation at t
   return IDOCP_OK;
 }
@@ -1332,12 +1382,44 @@ int idocp_ocp_get_split_solution(idocp_ocp_t* h, int instance, int stage, double
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
 }
+// The contact status the last discretisation linearises grid stage `stage` with (SplitSolution::setContactStatus,
+// split_solution.hxx:41-57: isContactActive(i), dimf): active[ncontacts] flags; returns dimf = 3 * (number of active contacts) or a
+// negative error code.  What sizes SplitSolution::f_stack() / mu_stack() of getSolution(stage) (split_solution.hpp:93-122).
+int idocp_ocp_get_stage_contact_status(idocp_ocp_t* h, int stage, int* active) {
+  if (!h || !active || stage < 0 || stage > (h->parnmpc ? h->N - 1 : h->Ngrid)) return IDOCP_E_ARG;
+  for (const OcpNode& nd : h->chain) {
+    if ((nd.kind == 0 || nd.kind == 4) && nd.slot == stage) {
+      for (int c = 0; c < DQ::NC; ++c) active[c] = nd.kind == 4 ? 0 : nd.active[c];
+      return nd.kind == 4 ? 0 : nd.dimf;
+    }
+  }
+  set_last_error("idocp_ocp_get_stage_contact_status: stage " + std::to_string(stage) + " is not a grid stage of the current discretisation");
+  return IDOCP_E_ARG;
+}
+// Direction components that exist only for the ACTIVE contacts of a stage (SplitDirection::df / dmu are daf().tail(dimf) /
+// dbetamu().tail(dimf), split_direction.hxx:150-229) or only on a stage that carries a switching constraint (dxi, dimi rows): the record
+// keeps whatever an earlier discretisation left in the other slots -- a stage whose contact status has changed since -- and the getters
+// report zeros there, like an absent entry (the integration never reads them: K7 steps the active contacts only).
+static void maskAbsentDirectionRows(const std::string& name, const OcpNode& nd, double* row) {
+  if (name == "df" || name == "dmu") {
+    for (int c = 0; c < DQ::NC; ++c) if (!nd.active[c]) for (int k = 0; k < 3; ++k) row[3 * c + k] = 0.0;
+  } else if (name == "dxi") {
+    for (int k = nd.sw_dimi; k < DQ::NF; ++k) row[k] = 0.0;
+  }
+}
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;
   if (!dirFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
   int rc = setDev(h); if (rc) return rc;
-  return copyField(h, h->B.dir + (size_t)instance * h->NS * LQ::DIR, LQ::DIR, h->parnmpc ? h->N : h->Ngrid + f.extra, f, out);
+  const size_t nrec = h->parnmpc ? h->N : h->Ngrid + f.extra;
+  rc = copyField(h, h->B.dir + (size_t)instance * h->NS * LQ::DIR, LQ::DIR, nrec, f, out);
+  if (rc) return rc;
+  const std::string n(name);
+  if (n == "df" || n == "dmu" || n == "dxi")
+    for (const OcpNode& nd : h->chain)
+      if ((nd.kind == 0 || nd.kind == 4) && nd.slot >= 0 && (size_t)nd.slot < nrec) maskAbsentDirectionRows(n, nd, out + (size_t)nd.slot * f.dim);
+  return IDOCP_OK;
 }
 
 // the same fields for every stage of the chain, in chain order: out[M][dim] (rows of stages that do not carry the
@@ -1369,7 +1451,12 @@ int idocp_ocp_get_direction_chain(idocp_ocp_t* h, const char* name, int instance
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;
   if (!dirFieldO(name, f)) { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
-  return getChainField(h, h->B.dir, LQ::DIR, f, instance, out);
+  int rc = getChainField(h, h->B.dir, LQ::DIR, f, instance, out);
+  if (rc) return rc;
+  const std::string n(name);
+  if (n == "df" || n == "dmu" || n == "dxi")
+    for (int p = 0; p < h->M(); ++p) maskAbsentDirectionRows(n, h->chain[p], out + (size_t)p * f.dim);
+  return IDOCP_OK;
 }
 
 int idocp_ocp_get_step_sizes(idocp_ocp_t* h, double* primal, double* dual) {

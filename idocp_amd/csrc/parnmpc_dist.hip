@@ -46,12 +46,16 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   bool load() {
     if (lib) return true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
     if (!lib) return false;
 #define SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(lib, "nccl" #f)); if (!f) return false;
     SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(Send) SYM(Recv) SYM(AllReduce) SYM(Broadcast) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+    SYM(GetVersion) SYM(CommCount) SYM(CommUserRank)
 #undef SYM
     return true;
   }
@@ -273,6 +277,22 @@ void idocp_comm_destroy(idocp_comm_t* c) {
   delete c;
 }
 
+// What the communicator itself reports (not what it was asked for): ncclCommCount, ncclCommUserRank, ncclGetVersion -- the bench prints
+// them so that a scaling line can be read against the ranks RCCL really connected.  transport: 1 RCCL, 0 the in-process test transport.
+int idocp_comm_info(const idocp_comm_t* c, int* nranks, int* user_rank, int* rccl_version, int* transport) {
+  if (!c) return IDOCP_E_ARG;
+  int n = c->world, r = c->rank, ver = 0;
+  if (c->nccl) {
+    NCCLC(g_rccl.CommCount(c->nccl, &n));
+    NCCLC(g_rccl.CommUserRank(c->nccl, &r));
+    NCCLC(g_rccl.GetVersion(&ver));
+  }
+  if (nranks) *nranks = n;
+  if (user_rank) *user_rank = r;
+  if (rccl_version) *rccl_version = ver;
+  if (transport) *transport = c->nccl ? 1 : 0;
+  return IDOCP_OK;
+}
 int idocp_comm_rank(const idocp_comm_t* c) { return c ? c->rank : -1; }
 int idocp_comm_world(const idocp_comm_t* c) { return c ? c->world : -1; }
 
@@ -323,12 +343,69 @@ int idocp_comm_set_force_collectives(idocp_comm_t* c, int on) {
 // Exercises every RCCL entry point the driver uses on THIS rank alone: grouped ncclSend / ncclRecv to itself for every halo kind
 // (buffers filled by a device pattern), all-reduce (sum, min) and broadcast, all on the shard's stream, and compares what came back.
 // With world == 1 the all-reduce / broadcast results must equal the inputs.  max_abs_diff: largest deviation seen (0 expected).
+// world > 1: the same calls across the REAL neighbours, in the grouping the driver uses (exchangeBoundary: everything for the right
+// neighbour and everything from the left one in one group, then the other way round), with a pattern that names kind, element and
+// SENDING rank, so that a halo that arrives from the wrong peer, in the wrong buffer or shifted is seen; then all-reduce (sum, min) and
+// the broadcast from the last rank against their closed forms.  A collective call: every rank of the communicator makes it.
+static double selftestPattern(int kind, size_t i, int rank) { return 1.0 + kind + 1e-3 * (double)(i % 9973) + 16.0 * rank; }
+static int neighbourSelftest(DistState& s, double* max_abs_diff) {
+  idocp_comm* c = s.comm;
+  const int rank = c->rank, world = c->world;
+  const bool left = rank > 0, right = rank < world - 1;
+  double worst = 0.0;
+  std::vector<double> buf;
+  auto fill = [&](int k) -> int {
+    buf.resize(s.count[k]);
+    for (size_t i = 0; i < s.count[k]; ++i) buf[i] = selftestPattern(k, i, rank);
+    HIPC(hipMemcpyAsync(s.sendb[k], buf.data(), s.count[k] * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPC(hipMemsetAsync(s.recvb[k], 0, s.count[k] * sizeof(double), s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    return IDOCP_OK;
+  };
+  auto check = [&](int k, int from) -> int {
+    buf.resize(s.count[k]);
+    HIPC(hipMemcpyAsync(buf.data(), s.recvb[k], s.count[k] * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    for (size_t i = 0; i < s.count[k]; ++i) worst = std::fmax(worst, std::fabs(buf[i] - selftestPattern(k, i, from)));
+    return IDOCP_OK;
+  };
+  for (int dir = 0; dir < 2; ++dir) {                  // 0: to the right neighbour, 1: to the left one
+    const bool snd = dir == 0 ? right : left, rcv = dir == 0 ? left : right;
+    const int to = dir == 0 ? rank + 1 : rank - 1, from = dir == 0 ? rank - 1 : rank + 1;
+    for (int k = 0; k < NKINDS; ++k) RC(fill(k));
+    RC(xgrouped(s, [&]() -> int {
+      if (snd) for (int k = 0; k < NKINDS; ++k) RC(xsend(s, k, to));
+      if (rcv) for (int k = 0; k < NKINDS; ++k) RC(xrecv(s, k, from));
+      return IDOCP_OK;
+    }));
+    if (rcv) for (int k = 0; k < NKINDS; ++k) RC(check(k, from));
+  }
+  for (int op = 0; op < 2; ++op) {
+    RC(fill(STATE_LAST));
+    RC(xallreduce(s, s.sendb[STATE_LAST], s.count[STATE_LAST], op));
+    buf.resize(s.count[STATE_LAST]);
+    HIPC(hipMemcpyAsync(buf.data(), s.sendb[STATE_LAST], buf.size() * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    for (size_t i = 0; i < buf.size(); ++i) {
+      const double base = selftestPattern(STATE_LAST, i, 0);
+      const double want = op == 0 ? world * base + 16.0 * (0.5 * world * (world - 1)) : base;
+      worst = std::fmax(worst, std::fabs(buf[i] - want) / (op == 0 ? world : 1));
+    }
+  }
+  RC(fill(AUX_ALL));
+  RC(xbroadcast(s, AUX_ALL, world - 1));
+  RC(check(AUX_ALL, world - 1));
+  *max_abs_diff = worst;
+  return IDOCP_OK;
+}
+
 int idocp_parnmpc_dist_transport_selftest(idocp_ocp_t* h, double* max_abs_diff) {
   DistState* sp = stateOf(h);
   if (!sp || !max_abs_diff) return fail(IDOCP_E_ARG, "idocp_parnmpc_dist_transport_selftest: attach a communicator first");
   DistState& s = *sp;
   idocp_comm* c = s.comm;
-  if (!c->nccl) return fail(IDOCP_E_UNSUPPORTED, "idocp_parnmpc_dist_transport_selftest: needs the RCCL transport (idocp_comm_init_rank)");
+  if (c->world > 1) return neighbourSelftest(s, max_abs_diff);
+  if (!c->nccl) return fail(IDOCP_E_UNSUPPORTED, "idocp_parnmpc_dist_transport_selftest: at world size 1 it needs the RCCL transport (idocp_comm_init_rank)");
   double worst = 0.0;
   std::vector<std::vector<double>> sent(NKINDS);
   for (int k = 0; k < NKINDS; ++k) {
@@ -460,6 +537,12 @@ int idocp_parnmpc_dist_update_solution_ls(idocp_ocp_t* h, double t) {
   DistState& s = *sp;
   const int rank = s.comm->rank, world = s.comm->world;
   const bool left = rank > 0, right = rank < world - 1;
+  // the hooks live on the handle for the duration of THIS call only: left installed, a later single-handle line search on the shard
+  // (idocp_parnmpc_update_solution(.., 1), idocp_ocp_line_search_eval) would issue RCCL calls the other ranks do not match
+  struct HookGuard {
+    idocp_ocp_t* h;
+    ~HookGuard() { idocp_parnmpc_set_line_search_hooks(h, nullptr, nullptr); }
+  } guard{h};
   RC(idocp_parnmpc_set_line_search_hooks(h, lsPre, lsPost));
   RC(idocp_parnmpc_discretize(h, t));
   RC(exchangeBoundary(h, s));

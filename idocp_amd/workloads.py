@@ -480,6 +480,12 @@ class HipOCP:
     def set_contact_points(self, phase, points):
         capi.check(self.lib.idocp_ocp_set_contact_points(self.h, phase, P(arr(points))), "set_contact_points")
 
+    def pop_back_contact_status(self):
+        capi.check(self.lib.idocp_ocp_pop_back_contact_status(self.h), "pop_back_contact_status")
+
+    def pop_front_contact_status(self):
+        capi.check(self.lib.idocp_ocp_pop_front_contact_status(self.h), "pop_front_contact_status")
+
     def chain(self, t):
         cap = self.N + 1 + 3 * max(self.max_events, 1)
         IA = lambda: (C.c_int * cap)()

@@ -88,7 +88,9 @@ class OCPSolver {
     const int nv = robot_.dimv(), nc = robot_.maxPointContacts();
     std::vector<double> rec((size_t)5 * nv + robot_.dimq() + robot_.dimu() + 6 * nc + 6);
     check(idocp_ocp_get_split_solution(h_, 0, stage, rec.data()));
-    s.assign(rec.data(), robot_.dimq(), nv, robot_.dimu(), nc, robot_.dim_passive());
+    std::vector<int> active(nc > 0 ? nc : 1, 0);
+    if (idocp_ocp_get_stage_contact_status(h_, stage, active.data()) < 0) check(IDOCP_E_ARG);
+    s.assign(rec.data(), robot_.dimq(), nv, robot_.dimu(), nc, robot_.dim_passive(), active.data());
     return s;
   }
 

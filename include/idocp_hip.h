@@ -115,8 +115,8 @@ typedef struct idocp_cost {
   double tv_t_begin, tv_t_end;
   /* TaskSpace3DCost / TaskSpace6DCost and their TimeVarying variants (src/cost/task_space_{3d,6d}_cost.cpp,
    * time_varying_task_space_{3d,6d}_cost.cpp) on one frame: of a fixed-base robot (UnOCPSolver, also the TimeVarying variants) or of a
-   * floating-base one (OCPSolver on any chain, ParNMPCSolver on event-free horizons; constant reference; the frame sits on the base
-   * or on a link of a leg).  SURVEY 8f row 3.
+   * floating-base one (OCPSolver and ParNMPCSolver on any chain, horizons with discrete events included; constant reference here, the
+   * TimeVarying variants through idocp_ocp_set_task_refs; the frame sits on the base or on a link of a leg).  SURVEY 8f row 3.
    * task_dim 0: none; 3: l = 1/2 dt |p_frame(q) - p_ref|^2_W; 6: l = 1/2 dt |log6(M_ref^-1 M_frame(q))|^2_W with the
    * Gauss-Newton Hessian of the reference.  The frame is given by its parent joint and its placement in that joint's
    * frame (idocp_model_frame_placement). */
@@ -413,8 +413,8 @@ int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* 
  * discretised at t (the order of idocp_ocp_get_chain: grid stages at t + i dt, impulse / aux / lift stages at their event times, the
  * terminal stage at t + T; returns M), idocp_ocp_set_task_refs hands the M poses over, refs[M][12] = rotation (row-major, 9; identity for
  * the 3D cost) then position (3).  They apply to every call with this t; a call with another t, or a chain of another length, fails with
- * IDOCP_E_ARG until new poses are set.  cost.task_time_varying must be set at creation (OCPSolver on any chain, ParNMPCSolver on
- * event-free horizons -- as for the constant-reference costs). */
+ * IDOCP_E_ARG until new poses are set.  cost.task_time_varying must be set at creation (OCPSolver and ParNMPCSolver on any chain,
+ * discrete events included -- as for the constant-reference costs). */
 int idocp_ocp_get_chain_times(idocp_ocp_t* h, double t, int capacity, double* times);
 int idocp_ocp_set_task_refs(idocp_ocp_t* h, double t, int M, const double* refs);
 /* OCPSolver::setSolution (ocp_solver.cpp:95-165): name in {"q","v","a","f","u"};
@@ -459,7 +459,14 @@ int idocp_ocp_get_solution(idocp_ocp_t* h, const char* name, int instance, doubl
  * out[3 nv + nq + nv + nu + nv + 2 * 3 ncontacts + 6] = lmd gmm q v a u beta f mu nu_passive
  * (split_solution.hxx:10-31); only lmd gmm q v are meaningful on the terminal stage. */
 int idocp_ocp_get_split_solution(idocp_ocp_t* h, int instance, int stage, double* out);
-/* Newton direction: dq dv da du df dlmd dgmm dbeta dmu dnu_passive. */
+/* The contact status grid stage `stage` of the current discretisation is linearised with
+ * (SplitSolution::setContactStatus / isContactActive / dimf, split_solution.hxx:41-57): active[ncontacts]
+ * flags; returns dimf (3 per active contact; 0 on the terminal stage) or a negative error code.  It sizes
+ * SplitSolution::f_stack() / mu_stack() (split_solution.hpp:93-122) in the facade's getSolution(stage). */
+int idocp_ocp_get_stage_contact_status(idocp_ocp_t* h, int stage, int* active);
+/* Newton direction: dq dv da du df dlmd dgmm dbeta dmu dnu_passive dxi.  df / dmu are [ncontacts][3] per stage with zeros for the
+ * contacts that are not active there, dxi has zeros behind the stage's switching-constraint rows (SplitDirection::df / dmu / dxi only
+ * have the active rows, split_direction.hxx:150-229). */
 int idocp_ocp_get_direction(idocp_ocp_t* h, const char* name, int instance, double* out);
 /* The same fields for every stage of the chain (incl. impulse / aux / lift stages), in
  * chain order: out[M][dim].  Extra names: "xi" / "dxi" (multiplier of the switching
@@ -516,8 +523,9 @@ int idocp_parnmpc_set_aux_mat(idocp_ocp_t* h, int nstages, const double* values)
 /* ParNMPCSolver::updateSolution (parnmpc_solver.cpp:73-103): coarseUpdate,
  * backwardCorrectionSerial / Parallel, forwardCorrectionSerial / Parallel, step sizes,
  * integrateSolution.  q[batch][nq], v[batch][nv]; line_search != 0: the filter line search on the primal step
- * (LineSearch::computeStepSize for ParNMPC, src/line_search/line_search.cpp:199-237) -- event-free horizons on one shard;
- * with discrete events or on a shard IDOCP_E_UNSUPPORTED.  idocp_ocp_line_search_eval / idocp_ocp_clear_line_search_filter
+ * (LineSearch::computeStepSize for ParNMPC, src/line_search/line_search.cpp:199-301) on a handle that holds the whole horizon,
+ * discrete events included; on a shard of a horizon IDOCP_E_UNSUPPORTED -- the sharded driver's
+ * idocp_parnmpc_dist_update_solution_ls evaluates every probe collectively (its hooks are installed for the duration of that call only).  idocp_ocp_line_search_eval / idocp_ocp_clear_line_search_filter
  * work on ParNMPC handles as well. */
 int idocp_parnmpc_update_solution(idocp_ocp_t* h, double t, const double* q, const double* v,
                                   int line_search);
@@ -592,10 +600,18 @@ int idocp_ocp_set_riccati_storage(idocp_ocp_t* h, int bits);
 int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv);
 /* Test switches of the transport (tests/test_rccl_gpu.py; the one-GPU box cannot run more than one rank):
  *  idocp_comm_set_force_collectives   world == 1: issue all-reduce / broadcast through RCCL anyway instead of skipping them
- *  idocp_parnmpc_dist_transport_selftest   grouped ncclSend / ncclRecv of every halo kind to this very rank, all-reduce (sum, min) and
- *                                          broadcast on the shard's stream; *max_abs_diff = deviation of what came back (0 expected) */
+ *  idocp_parnmpc_dist_transport_selftest   world 1: grouped ncclSend / ncclRecv of every halo kind to this very rank, all-reduce (sum, min)
+ *                                          and broadcast on the shard's stream.  world > 1 (COLLECTIVE: every rank calls it; bench.py does
+ *                                          before the timed region): every halo kind to the right neighbour and from the left one in one
+ *                                          group, then the other way round -- the grouping of the driver's boundary exchange
+ *                                          (backward_correction_solver.cpp:255-366 is what those halos feed) --, a pattern that names kind,
+ *                                          element and sending rank; all-reduce (sum, min) and broadcast against their closed forms.
+ *                                          *max_abs_diff = deviation of what came back (0 expected)
+ *  idocp_comm_info                         what the communicator reports about itself: ncclCommCount, ncclCommUserRank, ncclGetVersion
+ *                                          (any pointer may be NULL; transport: 1 RCCL, 0 the in-process test transport) */
 int idocp_comm_set_force_collectives(idocp_comm_t* c, int on);
 int idocp_parnmpc_dist_transport_selftest(idocp_ocp_t* shard, double* max_abs_diff);
+int idocp_comm_info(const idocp_comm_t* c, int* nranks, int* user_rank, int* rccl_version, int* transport);
 /* Deep copy of a solver handle (the reference's solver classes are copyable): same configuration, device records, contact
  * sequence and discretisation. */
 int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out);

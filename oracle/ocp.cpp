@@ -137,6 +137,31 @@ void OCPSolver::pushBackContactStatus(const std::vector<int>& active, const doub
   discretized_ = false;
 }
 
+// ContactSequence::pop_back / pop_front (contact_sequence.hxx:117-160) behind OCPSolver::popBackContactStatus /
+// popFrontContactStatus (ocp_solver.cpp:187-194): the last (first) discrete event leaves together with the contact phase
+// behind (in front of) it; a sequence without events falls back to the default status (no contact, points at the origin).
+// The stage records do NOT move: impulse / aux / lift index k after a pop_front holds what index k held before
+// (hybrid_container.hpp: the solver never shifts s.impulse / s.aux / s.lift).
+static void seqPopBack(ContactSequenceC& seq, int nc) {
+  if (seq.numEvents() > 0) {
+    seq.event_time.pop_back(); seq.is_impulse.pop_back(); seq.impulse_status.pop_back(); seq.phases.pop_back();
+  } else {
+    ContactStatus cs0; cs0.active.assign(nc, false); cs0.points.assign(nc, Mat(3));
+    seq.phases.assign(1, cs0);
+  }
+}
+static void seqPopFront(ContactSequenceC& seq, int nc) {
+  if (seq.numEvents() > 0) {
+    seq.event_time.erase(seq.event_time.begin()); seq.is_impulse.erase(seq.is_impulse.begin());
+    seq.impulse_status.erase(seq.impulse_status.begin()); seq.phases.erase(seq.phases.begin());
+  } else {
+    ContactStatus cs0; cs0.active.assign(nc, false); cs0.points.assign(nc, Mat(3));
+    seq.phases.assign(1, cs0);
+  }
+}
+void OCPSolver::popBackContactStatus() { seqPopBack(seq, nc_); discretized_ = false; }
+void OCPSolver::popFrontContactStatus() { seqPopFront(seq, nc_); discretized_ = false; }
+
 // ContactSequence::setContactPoints (contact_sequence.hxx:252-268)
 void OCPSolver::setContactPoints(int phase, const double* pts) {
   if (phase >= (int)seq.phases.size()) throw std::runtime_error("contact_phase must be smaller than numContactPhases()!");
@@ -1302,6 +1327,10 @@ void ParNMPCSolver::setContactStatusUniformly(const std::vector<int>& active, co
   seq.event_time.clear(); seq.is_impulse.clear(); seq.impulse_status.clear();
   discretized_ = false;
 }
+
+// ParNMPCSolver::popBackContactStatus / popFrontContactStatus (parnmpc_solver.cpp:202-209) -> ContactSequence::pop_back / pop_front
+void ParNMPCSolver::popBackContactStatus() { seqPopBack(seq, nc_); discretized_ = false; }
+void ParNMPCSolver::popFrontContactStatus() { seqPopFront(seq, nc_); discretized_ = false; }
 
 // ContactSequence::push_back (contact_sequence.hxx:63-117); capacities as in OCPSolver (see OCPSolver::pushBackContactStatus)
 void ParNMPCSolver::pushBackContactStatus(const std::vector<int>& active, const double* pts, real switching_time) {

@@ -130,6 +130,8 @@ class OCPSolver {
   void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points /*[nc][3]*/);   // ocp_solver.cpp:169-171
   void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, real switching_time);   // :174-177
   void setContactPoints(int contact_phase, const double* contact_points);                                     // :180-184
+  void popBackContactStatus();                                        // :187-189 -> ContactSequence::pop_back (contact_sequence.hxx:117-136)
+  void popFrontContactStatus();                                       // :192-194 -> ContactSequence::pop_front (contact_sequence.hxx:139-160)
   void setSolution(const std::string& name, const Mat& value);      // ocp_solver.cpp:95-165
   void initConstraints(real t);                                   // ocp_solver.cpp:60-64
   void updateSolution(real t, const Mat& q, const Mat& v, bool line_search = false);         // ocp_solver.cpp:67-92
@@ -221,6 +223,8 @@ class ParNMPCSolver {
                 int max_num_impulse = 0);
   void setContactStatusUniformly(const std::vector<int>& active, const double* contact_points);
   void pushBackContactStatus(const std::vector<int>& active, const double* contact_points, real switching_time);
+  void popBackContactStatus();                                        // parnmpc_solver.cpp:202-204
+  void popFrontContactStatus();                                       // parnmpc_solver.cpp:207-209
   void setSolution(const std::string& name, const Mat& value);
   void initBackwardCorrection(real t);                              // parnmpc_solver.cpp:66-70
   void initConstraints(real t);                                     // parnmpc_linearizer.cpp:43-75

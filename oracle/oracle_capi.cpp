@@ -504,6 +504,9 @@ int oracle_ocp_push_back_contact_status(void* h, const int* active, const double
   try { s->pushBackContactStatus(a, points, switching_time); } catch (...) { return -1; }
   return 0;
 }
+// OCPSolver::popBackContactStatus / popFrontContactStatus (ocp_solver.cpp:187-194)
+int oracle_ocp_pop_back_contact_status(void* h) { static_cast<OCPSolver*>(h)->popBackContactStatus(); return 0; }
+int oracle_ocp_pop_front_contact_status(void* h) { static_cast<OCPSolver*>(h)->popFrontContactStatus(); return 0; }
 int oracle_ocp_set_contact_points(void* h, int phase, const double* points) {
   try { static_cast<OCPSolver*>(h)->setContactPoints(phase, points); } catch (...) { return -1; }
   return 0;
@@ -803,6 +806,8 @@ void* oracle_parnmpc_create_hybrid(const idocp_model_t* m, const idocp_cost_t* c
                                    int max_num_impulse) {
   try { return new ParNMPCSolver(*m, *c, *k, T, N, max_num_impulse); } catch (...) { return nullptr; }
 }
+int oracle_parnmpc_pop_back_contact_status(void* h) { static_cast<ParNMPCSolver*>(h)->popBackContactStatus(); return 0; }
+int oracle_parnmpc_pop_front_contact_status(void* h) { static_cast<ParNMPCSolver*>(h)->popFrontContactStatus(); return 0; }
 int oracle_parnmpc_push_back_contact_status(void* h, const int* active, const double* points, double switching_time) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
   std::vector<int> a(active, active + s->robot.maxPointContacts());

@@ -102,6 +102,8 @@ int main(int argc, char** argv) {
     const idocp::OCPSolver& cs = solver;
     const idocp::SplitSolution& s0 = cs.getSolution(0);
     REQUIRE(maxDiff(s0.u, cs.getSolution("u")[0]) == 0.0 && maxDiff(s0.q, cs.getSolution("q")[0]) == 0.0);
+    // all four feet on the ground: f_stack() = the four contacts' forces, dimf() = 12 (split_solution.hpp:93-122)
+    REQUIRE(s0.dimf() == 12 && s0.isContactActive(2));
     REQUIRE(maxDiff(s0.f_stack(), cs.getSolution("f")[0]) == 0.0 && maxDiff(s0.mu_stack(), cs.getSolution("mu")[0]) == 0.0);
     REQUIRE(maxDiff(s0.beta, cs.getSolution("beta")[0]) == 0.0 && maxDiff(s0.nu_passive, cs.getSolution("nu_passive")[0]) == 0.0);
     REQUIRE((int)s0.f.size() == robot.maxPointContacts() && s0.f[1][2] == s0.f_stack()[5]);
@@ -131,6 +133,77 @@ int main(int argc, char** argv) {
       }
       REQUIRE(maxDiff(s1.getSolution(3).q, s2.getSolution(3).q) == 0.0 && maxDiff(s1.getSolution(3).u, s2.getSolution(3).u) == 0.0);
       REQUIRE(maxDiff(s1.getSolution(3).q, solver.getSolution(3).q) > 1e-6);      // (and the task cost does act)
+    }
+    {  // popFrontContactStatus / popBackContactStatus / pushBackContactStatus (ocp_solver.hpp:113-129): a receding horizon through the
+       // facade.  Solver A is given the gait [stand | lift LF+RH at 0.12 | touch-down at 0.27 | LH+RF swing at 0.27 ... ] and, once
+       // the first event has passed (t = 0.15), pops it and pushes the next phase; solver B is built with the shifted sequence
+       // directly.  From the same guess both must take the SAME step (bitwise: same chain, same records), and f_stack() of a trot
+       // stage holds the two stance feet only.
+      const int Nt = 16;
+      const double Tt = 0.8;
+      auto limits = ex::jointLimits(robot, 0.7, true);
+      idocp::OCPSolver A(robot, cost, limits, Tt, Nt, 3), B(robot, cost, limits, Tt, Nt, 3);
+      ex::Schedule gait(ex::footholds(robot, stand));
+      gait.add({0, 1, 2, 3}, 0.0);
+      gait.add({1, 2}, 0.12);
+      gait.advance({0, 3}, 0.05);
+      gait.add({0, 3}, 0.37);
+      gait.advance({1, 2}, 0.1);
+      gait.add({1, 2}, 0.62);
+      gait.install(A, robot);
+      ex::restingGuess(A, robot, stand);
+      A.initConstraints(0.0);
+      {
+        idocp::OCPSolver D(A);                                                // (A itself takes no step before the shift)
+        const idocp::OCPSolver& cA = D;
+        D.updateSolution(0.0, stand, v);
+        const idocp::SplitSolution& trot = cA.getSolution(5);                 // t = 0.25: LH, RF on the ground
+        REQUIRE(trot.dimf() == 6 && !trot.isContactActive(0) && trot.isContactActive(1) && trot.isContactActive(2) && !trot.isContactActive(3));
+        REQUIRE(trot.f_stack().size() == 6 && trot.f_stack()[2] == trot.f[1][2] && trot.f_stack()[5] == trot.f[2][2]);
+        REQUIRE((int)trot.f.size() == 4);                                     // the per-contact vectors cover every contact
+        REQUIRE(cA.getSolution(1).dimf() == 12);
+      }
+      // shift: the lift at 0.12 has passed at t = 0.15
+      ex::Schedule next = gait;
+      next.advance({0, 3}, 0.1);
+      auto status = robot.createContactStatus();
+      status.activateContacts({0, 3});
+      status.setContactPoints(next.feet);
+      A.popFrontContactStatus();
+      A.pushBackContactStatus(status, 0.87);
+      ex::Schedule shifted(gait.rows[1].points);
+      shifted.rows.push_back(gait.rows[1]);
+      shifted.rows.push_back(gait.rows[2]);
+      shifted.rows.push_back(gait.rows[3]);
+      shifted.rows.push_back({{0, 3}, next.feet, 0.87});
+      shifted.install(B, robot);
+      ex::restingGuess(B, robot, stand);
+      A.initConstraints(0.15);
+      B.initConstraints(0.15);
+      A.updateSolution(0.15, stand, v);
+      B.updateSolution(0.15, stand, v);
+      for (int i : {0, 3, 7, 12, Nt}) {
+        REQUIRE(maxDiff(A.getSolution(i).q, B.getSolution(i).q) == 0.0 && maxDiff(A.getSolution(i).lmd, B.getSolution(i).lmd) == 0.0);
+      }
+      REQUIRE(A.getSolution(0).dimf() == 6 && maxDiff(A.getSolution(0).f_stack(), B.getSolution(0).f_stack()) == 0.0);
+      // popBack: the phase pushed last leaves again; a solver built without it takes the same step
+      idocp::OCPSolver Cs(robot, cost, limits, Tt, Nt, 3);
+      shifted.rows.pop_back();
+      shifted.install(Cs, robot);
+      idocp::OCPSolver A2(robot, cost, limits, Tt, Nt, 3);                     // A has stepped: the same pops on a fresh solver
+      gait.install(A2, robot);
+      A2.popFrontContactStatus();
+      A2.pushBackContactStatus(status, 0.87);
+      A2.popBackContactStatus();
+      A = A2;
+      ex::restingGuess(A, robot, stand);
+      ex::restingGuess(Cs, robot, stand);
+      A.initConstraints(0.15);
+      Cs.initConstraints(0.15);
+      A.updateSolution(0.15, stand, v);
+      Cs.updateSolution(0.15, stand, v);
+      REQUIRE(maxDiff(A.getSolution(9).q, Cs.getSolution(9).q) == 0.0 && maxDiff(A.getSolution(9).u, Cs.getSolution(9).u) == 0.0);
+      std::cout << "receding horizon through the facade: ok" << std::endl;
     }
     std::cout << "floating-base solver: ok" << std::endl;
   }

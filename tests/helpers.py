@@ -354,6 +354,15 @@ class OracleOCP:
     def set_contact_points(self, phase, points):
         assert self.lib.oracle_ocp_set_contact_points(self.h, phase, P(arr(points))) == 0
 
+    # OCPSolver::popBackContactStatus / popFrontContactStatus (ocp_solver.cpp:187-194)
+    def pop_back_contact_status(self):
+        self.lib.oracle_ocp_pop_back_contact_status.argtypes = [C.c_void_p]
+        assert self.lib.oracle_ocp_pop_back_contact_status(self.h) == 0
+
+    def pop_front_contact_status(self):
+        self.lib.oracle_ocp_pop_front_contact_status.argtypes = [C.c_void_p]
+        assert self.lib.oracle_ocp_pop_front_contact_status(self.h) == 0
+
     def chain(self, t):
         """Stages in time order after OCPDiscretizer::discretizeOCP(t): list of dicts."""
         cap = self.N + 1 + 3 * max(self.max_events, 1)
@@ -508,6 +517,14 @@ class OracleParNMPC:
     def push_back_contact_status(self, active, points, switching_time):
         a = (C.c_int * 4)(*[int(x) for x in active])
         assert self.lib.oracle_parnmpc_push_back_contact_status(self.h, a, P(arr(points)), switching_time) == 0
+
+    def pop_back_contact_status(self):
+        self.lib.oracle_parnmpc_pop_back_contact_status.argtypes = [C.c_void_p]
+        assert self.lib.oracle_parnmpc_pop_back_contact_status(self.h) == 0
+
+    def pop_front_contact_status(self):
+        self.lib.oracle_parnmpc_pop_front_contact_status.argtypes = [C.c_void_p]
+        assert self.lib.oracle_parnmpc_pop_front_contact_status(self.h) == 0
 
     def chain(self, t=0.0):
         cap = self.N + 3 * self.max_num_impulse + 1

@@ -142,3 +142,31 @@ def test_unique_id_exchange_is_a_no_op_on_one_rank():
     lib = bench._StubDistLib()
     raw = bench.exchange_unique_id(lib, None, 0, 1)
     assert lib.idocp_comm_init_rank(raw, 0, 1, 0, None) == 0
+
+
+def test_bench_gpus2_first_contact_hang_is_ended_by_the_launcher_timeout():
+    """A multi-rank run whose ranks never finish (here: rank code that sleeps inside its second step, standing in for an RCCL first
+    contact that never completes) must not eat the driver's budget: `--timeout` ends the ranks the launcher started (its own process
+    group), the command exits 124, and stderr carries the notice.  No JSON line is printed."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IDOCP_BENCH_STUB="1", IDOCP_BENCH_STUB_HANG="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "anymal_parnmpc", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--timeout", "25"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 120
+    assert "did not finish within 25 s" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_parnmpc_scaling_model_of_the_bench_line():
+    """config.model_ms: DESIGN section 5's step-time model, from this run's kernel times on one GPU, from the committed figures on more."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ker = {"ocp_condense": 2.0, "parnmpc_kkt_inverse": 2.0, "parnmpc_backward_serial": 0.25, "parnmpc_forward_serial": 0.75, "ocp_expand_primal": 1.0}
+    m = bench.parnmpc_model_ms("anymal_parnmpc", 1, ker)
+    assert abs(m["stage_parallel_ms"] - 5.0) < 1e-12 and abs(m["sweeps_ms"] - 1.0) < 1e-12
+    assert abs(m["ms_per_step_by_gpus"]["1"] - 6.0) < 1e-12 and abs(m["ms_per_step_by_gpus"]["8"] - (5.0 / 8 + 1.0 + 14 * 0.015 + 0.1)) < 1e-12
+    m8 = bench.parnmpc_model_ms("anymal_parnmpc", 8)
+    assert m8["this_run"] == m8["ms_per_step_by_gpus"]["8"] and "committed" in m8["source"]

@@ -4,7 +4,7 @@ the chain (stage, [impulse, aux | lift], ..., terminal), on the reference's trot
 import numpy as np
 import pytest
 
-from helpers import (pairwise_check, ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, anymal_model, anymal_problem, referee_check,
+from helpers import (parity, pairwise_check, ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, anymal_model, anymal_problem, referee_check,
                      rel_err, trotting_sequence)
 
 pytestmark = pytest.mark.gpu
@@ -127,10 +127,11 @@ def test_flight_phase_sequence_parity():
     N, T, E = 24, 1.0, 5
     o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
     g = HipOCP(m, cost, cons, T, N, max_num_impulse=E)
+    h = OracleOCP(m, cost, cons, T, N, max_num_impulse=E, hp=True)
     from helpers import anymal_contact_points
     pts = anymal_contact_points(m).copy()
     q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
-    for s in (o, g):
+    for s in (o, g, h):
         s.set_contact_status([1, 1, 1, 1], pts)
         s.push_back_contact_status([0, 1, 0, 1], pts, 0.21)          # front feet lift
         s.push_back_contact_status([0, 0, 0, 0], pts, 0.33)          # flight
@@ -146,9 +147,9 @@ def test_flight_phase_sequence_parity():
     assert [(a["kind"], a["slot"], a["dimf"]) for a in co] == [(b["kind"], b["slot"], b["dimf"]) for b in cg]
     assert any(c["dimf"] == 0 and c["kind"] == "stage" for c in co) and sum(1 for c in co if c["kind"] == "impulse") == 2
     M = len(co)
-    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
-    for f in list(OCP_DIR_FIELDS) + ["dxi"]:
-        assert rel_err(g.get_chain(f, M), o.get_chain(f, M)) < 1e-9, f
+    assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0 and h.update(0.0, q, v) == 0
+    for f in list(OCP_DIR_FIELDS) + ["dxi"]:           # 1e-10 against the oracle, else the referee rule; never past 2e-8
+        parity(g.get_chain(f, M), o.get_chain(f, M), lambda: h.get_chain(f, M), f, cap=2e-8)
     for it in range(3):
         assert o.update(0.0, q, v) == 0 and g.update(0.0, q, v) == 0
     for f in ("q", "v", "a", "u", "f"):
@@ -389,3 +390,206 @@ def test_general_axes_instantiations_direction_parity(monkeypatch):
         _, n_exact = pairwise_check(g_general.get_chain(f, M), g_special.get_chain(f, M), o.get_chain(f, M), h.get_chain(f, M), f)
         exact_stages = min(exact_stages, n_exact)
     assert exact_stages >= M // 2, exact_stages
+
+
+class _SequenceRecorder:
+    """Collects what trotting_sequence pushes: [(active, points, time)], the phase list an MPC loop draws from."""
+    def __init__(self):
+        self.ev = []
+
+    def set_contact_status(self, a, p):
+        self.ev.append((list(a), np.array(p).copy(), None))
+
+    def push_back_contact_status(self, a, p, t):
+        self.ev.append((list(a), np.array(p).copy(), t))
+
+
+def test_receding_horizon_mpc_loop_with_pop_front_and_push_back():
+    """the receding-horizon use of OCPSolver -- popFrontContactStatus when the first discrete event has passed,
+    pushBackContactStatus of the gait's next phase when it enters the horizon (ocp_solver.cpp:174-194 -> ContactSequence::pop_front /
+    push_back, contact_sequence.hxx:63-160), the initial time advancing by two grid steps per MPC step, the measured state = the
+    plan's own state at the new time.  GPU, FP64 oracle and the long double referee walk the same loop; after EVERY shift the chain
+    (kind, index, slot, dt, contact dimension, switching rows) equals the oracle's discretiser and the Newton direction passes
+    parity() (1e-10 against the oracle, else the referee rule), cap 1e-7.
+    Two properties of the reference shape the loop: (i) initConstraints covers the event stages of the discretisation it is called
+    on only (ocp_linearizer.cpp:40-71) and ConstraintComponentData starts as slack = dual = 0 (constraint_component_data.hxx:11-17),
+    so an event index entering the horizon for the first time has no interior-point state: the loop calls initConstraints(t) after
+    every pushBack, as a driver of the reference has to; (ii) the stage records do not move when an event is popped (impulse index
+    k afterwards holds what index k held before: hybrid_container.hpp) -- stale warm starts, the same ones on both sides.
+    Event and stage times stay clear of the grid and of the gait reference's phase boundaries (t0 = 0.013, events at 0.52 + 0.5 k),
+    where floor() in the discretiser / the trotting reference would decide differently in FP64 and in long double."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    N, T, E = 31, 1.55, 4
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+    h = OracleOCP(m, cost, cons, T, N, max_num_impulse=E, hp=True)
+    g = HipOCP(m, cost, cons, T, N, batch=2, max_num_impulse=E)
+    solvers = (o, h, g)
+    rec = _SequenceRecorder()
+    trotting_sequence(rec, m, 12, t_start=0.52)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in solvers:
+        s.set_contact_status(rec.ev[0][0], rec.ev[0][1])
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    t0, dt_mpc = 0.013, 0.1
+    state = dict(k=1, times=[])
+
+    def feed(t):                       # push the phases whose switching time has entered the horizon
+        n = 0
+        while rec.ev[state["k"]][2] < t + T - 0.05:
+            for s in solvers:
+                s.push_back_contact_status(*rec.ev[state["k"]])
+            state["times"].append(rec.ev[state["k"]][2])
+            state["k"] += 1
+            n += 1
+        return n
+
+    def same_chain(t):
+        co, cg = o.chain(t), g.chain(t)
+        assert len(co) == len(cg)
+        for a, b in zip(co, cg):
+            assert a["kind"] == b["kind"] and a["index"] == b["index"] and a["slot"] == b["slot"] and a["dimf"] == b["dimf"], (t, a, b)
+            assert abs(a["dt"] - b["dt"]) < 1e-14 and (a["sw_event"] >= 0) == (b["sw_dimi"] > 0)
+        return co
+
+    t = t0
+    feed(t)
+    for s in solvers:
+        s.init_constraints(t)
+    for it in range(20):
+        for s in solvers:
+            assert s.update(t, q, v) == 0
+    assert o.kkt_error(t, q, v) < 1e-8 and g.kkt_error(t, q, v)[0] < 1e-8
+    pops, shapes, worst = 0, set(), 0.0
+    for step in range(22):
+        co = o.chain(t)
+        tn = t0 + dt_mpc * (step + 1)
+        at = [p for p, c in enumerate(co) if c["kind"] in ("stage", "terminal") and abs(c["t"] - tn) < 1e-9]
+        assert at
+        q, v = o.get_chain("q", len(co))[at[0]].copy(), o.get_chain("v", len(co))[at[0]].copy()       # the plan's state at the new time
+        t = tn
+        while state["times"] and state["times"][0] <= t + 1e-9:
+            for s in solvers:
+                s.pop_front_contact_status()
+            state["times"].pop(0)
+            pops += 1
+        if feed(t):
+            for s in solvers:
+                s.init_constraints(t)
+        co = same_chain(t)
+        M = len(co)
+        shapes.add("".join(c["kind"][0] for c in co))
+        for sweep in range(3):
+            for s in solvers:
+                assert s.update(t, q, v) == 0
+            for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+                worst = max(worst, parity(g.get_chain(f, M), o.get_chain(f, M), lambda: h.get_chain(f, M), (step, sweep, f), cap=1e-7))
+        for f in ("q", "v", "a", "u", "f", "lmd", "gmm"):
+            parity(g.get_chain(f, M), o.get_chain(f, M), lambda: h.get_chain(f, M), (step, "iterate", f), cap=1e-7)
+        e_o, e_g = o.kkt_error(t, q, v), g.kkt_error(t, q, v)
+        assert abs(e_g[0] - e_o) <= 1e-7 * max(1.0, e_o) and abs(e_g[1] - e_g[0]) <= 1e-9 * max(1.0, e_o)
+    assert pops >= 4 and len(shapes) >= 5          # a lift and three impulse events left through the front; the chain changed shape
+    print("MPC loop: %d pops, %d chain shapes, worst GPU-oracle direction distance %.2e" % (pops, len(shapes), worst))
+
+
+def perturbed_states(m, n, seed=20250, dq=0.02, dv=0.05, base=ANYMAL_Q_STANDING):
+    """Per-instance start states in the manner of SURVEY 8(d) C3 (base xy and joints +- 0.02 from std::mt19937_64(seed + b) there; numpy's
+    generator here), plus what C3 leaves at zero: a base yaw / pitch of a few degrees and a non-zero velocity of every degree of freedom."""
+    qs, vs = [], []
+    for b in range(n):
+        rng = np.random.default_rng(seed + b)
+        q = base.copy()
+        q[0:2] += dq * rng.uniform(-1, 1, 2)
+        quat = np.array([0.0, 0.0, 0.0, 1.0]) + 0.03 * rng.normal(size=4)
+        q[3:7] = quat / np.linalg.norm(quat)
+        q[7:] += dq * rng.uniform(-1, 1, 12)
+        qs.append(q)
+        vs.append(dv * rng.uniform(-1, 1, m.nv))
+    return np.array(qs), np.array(vs)
+
+
+def test_full_size_c3_from_three_perturbed_states():
+    """BASELINE configs[2] at its own size from per-instance states with a tilted base and v != 0 (the other full-size tests start every
+    instance from the standing pose at rest): one GPU handle with three different instances against three oracle / referee pairs, first
+    direction along the 120-stage chain under parity() with the 2e-8 cap of the standing-start test, then the iterates after four steps."""
+    nimp = 9
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    T, N, B = 0.5 + nimp * 0.5 + 0.05, 100, 3
+    qs, vs = perturbed_states(m, B)
+    g = HipOCP(m, cost, cons, T, N, batch=B, max_num_impulse=nimp + 1)
+    trotting_sequence(g, m, nimp)
+    g.set_solution_batch("q", qs)
+    g.set_solution_batch("v", vs)
+    g.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    g.init_constraints(0.0)
+    pairs = []
+    for b in range(B):
+        o = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1)
+        h = OracleOCP(m, cost, cons, T, N, max_num_impulse=nimp + 1, hp=True)
+        for s in (o, h):
+            trotting_sequence(s, m, nimp)
+            s.set_solution("q", qs[b])
+            s.set_solution("v", vs[b])
+            s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+            s.init_constraints(0.0)
+        pairs.append((o, h))
+    M = len(pairs[0][0].chain(0.0))
+    assert M == 120
+    e_g = g.kkt_error(0.0, qs, vs)
+    assert g.update(0.0, qs, vs) == 0
+    worst = 0.0
+    for b, (o, h) in enumerate(pairs):
+        e_o = o.kkt_error(0.0, qs[b], vs[b])
+        assert abs(e_g[b] - e_o) <= 1e-9 * max(1.0, e_o)
+        assert o.update(0.0, qs[b], vs[b]) == 0 and h.update(0.0, qs[b], vs[b]) == 0
+        for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+            worst = max(worst, parity(g.get_chain(f, M, b), o.get_chain(f, M), lambda: h.get_chain(f, M), (b, f), cap=2e-8))
+        ao, bo = o.step_sizes()
+        ag, bg = g.step_sizes()
+        assert abs(ag[b] - ao) < 1e-9 and abs(bg[b] - bo) < 1e-9
+    assert np.abs(g.get_chain("dq", M, 0) - g.get_chain("dq", M, 1)).max() > 1e-3          # the instances are different problems
+    for it in range(4):
+        assert g.update(0.0, qs, vs) == 0
+        for b, (o, h) in enumerate(pairs):
+            assert o.update(0.0, qs[b], vs[b]) == 0 and h.update(0.0, qs[b], vs[b]) == 0
+    for b, (o, h) in enumerate(pairs):
+        for f in ("q", "v", "a", "u", "f"):
+            parity(g.get_chain(f, M, b), o.get_chain(f, M), lambda: h.get_chain(f, M), (b, "iterate", f), cap=1e-7)
+    print("configs[2] from three perturbed states: worst GPU-oracle distance of the first direction %.2e" % worst)
+
+
+def test_configs4_grid_from_three_perturbed_states():
+    """BASELINE configs[4] on its own grid (running gait, N = 200, T = 7 * 200 / 240: 26 touch-downs, 14 lift-offs, flight phases) from
+    three per-instance states with a tilted base and v != 0: first direction along the chain under parity(), 1e-8 cap (the cap of the
+    standing-start test of this gait)."""
+    from helpers import ANYMAL_Q_RUNNING_START, running_problem, running_sequence
+    m = anymal_model()
+    steps = 10
+    cost, cons = running_problem(m, steps)
+    N, T, E, B = 200, 7.0 * 200 / 240, (steps + 3) * 2, 3
+    qs, vs = perturbed_states(m, B, seed=20260, base=ANYMAL_Q_RUNNING_START)
+    g = HipOCP(m, cost, cons, T, N, batch=B, max_num_impulse=E)
+    assert running_sequence(g, m, steps) == 40
+    g.set_solution_batch("q", qs)
+    g.set_solution_batch("v", vs)
+    g.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    g.init_constraints(0.0)
+    assert g.update(0.0, qs, vs) == 0
+    worst = 0.0
+    for b in range(B):
+        o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+        h = OracleOCP(m, cost, cons, T, N, max_num_impulse=E, hp=True)
+        for s in (o, h):
+            assert running_sequence(s, m, steps) == 40
+            s.set_solution("q", qs[b])
+            s.set_solution("v", vs[b])
+            s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+            s.init_constraints(0.0)
+            assert s.update(0.0, qs[b], vs[b]) == 0
+        M = len(o.chain(0.0))
+        for f in list(OCP_DIR_FIELDS) + ["dxi"]:
+            worst = max(worst, parity(g.get_chain(f, M, b), o.get_chain(f, M), lambda: h.get_chain(f, M), (b, f), cap=1e-8))
+    print("configs[4] grid from three perturbed states: worst GPU-oracle distance of the first direction %.2e" % worst)

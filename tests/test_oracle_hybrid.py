@@ -230,3 +230,63 @@ def test_long_double_referee_build_agrees_with_the_fp64_oracle():
         M = len(pair[0].chain(0.0))
         worst = max(rel_err(pair[0].get_chain(f, M), pair[1].get_chain(f, M)) for f in OCP_DIR_FIELDS)
         assert lo <= worst < hi, (N, worst)
+
+
+def _chain_key(chain):
+    return [(c["kind"], c["index"], c["slot"], c["dimf"], c["sw_event"], round(c["t"], 12), round(c["dt"], 12)) for c in chain]
+
+
+def test_pop_back_and_pop_front_follow_contact_sequence_semantics():
+    """ContactSequence::pop_back / pop_front (contact_sequence.hxx:117-160) restated in the oracle, held to the properties the
+    reference's own test asserts (test/hybrid/contact_sequence_test.cpp:75-92, 99-130, 178-252): a sequence from which the last
+    (first) k events were popped discretises like a sequence that was built without them (with the phase behind the first
+    popped-front event as its initial status); popping a sequence without events leaves the default status (no contact)."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    N, T, E = 31, 1.55, 5
+    pts0 = anymal_contact_points(m)
+
+    class Rec:                                   # the (status, points, time) list trotting_sequence pushes
+        def __init__(self):
+            self.ev = []
+        def set_contact_status(self, a, p):
+            self.ev.append((list(a), np.array(p).copy(), None))
+        def push_back_contact_status(self, a, p, t):
+            self.ev.append((list(a), np.array(p).copy(), t))
+    rec = Rec()
+    trotting_sequence(rec, m, 4, t_start=0.2, t_period=0.3)        # 5 events inside the horizon: lift, then four impulse events
+
+    def build(events):
+        s = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+        s.set_contact_status(events[0][0], events[0][1])
+        for a, p, t in events[1:]:
+            s.push_back_contact_status(a, p, t)
+        return s
+
+    full = build(rec.ev)
+    assert sum(1 for c in full.chain(0.0) if c["kind"] == "impulse") == 4 and sum(1 for c in full.chain(0.0) if c["kind"] == "lift") == 1
+    # pop_back: k events leave from the end
+    s = build(rec.ev)
+    for k in range(1, 6):
+        s.pop_back_contact_status()
+        assert _chain_key(s.chain(0.0)) == _chain_key(build(rec.ev[:len(rec.ev) - k]).chain(0.0)), k
+    s.pop_back_contact_status()                   # no event left: the default status, contact_sequence.hxx:131-135
+    assert all(c["dimf"] == 0 for c in s.chain(0.0)) and len(s.chain(0.0)) == N + 1
+    s.pop_back_contact_status()
+    s.pop_front_contact_status()                  # contact_sequence_test.cpp:85-92: popping the empty sequence is harmless
+    assert all(c["dimf"] == 0 for c in s.chain(0.0)) and len(s.chain(0.0)) == N + 1
+    # pop_front: k events leave from the front; what remains starts in the phase behind the k-th event
+    s = build(rec.ev)
+    for k in range(1, 6):
+        s.pop_front_contact_status()
+        assert _chain_key(s.chain(0.0)) == _chain_key(build(rec.ev[k:]).chain(0.0)), k
+    assert all(c["dimf"] == 6 for c in s.chain(0.0)[:-1])          # contact_sequence_test.cpp:252: the last post-event status stays
+    s.pop_front_contact_status()
+    assert all(c["dimf"] == 0 for c in s.chain(0.0))
+    # a popped-then-pushed sequence is the receding horizon of an MPC loop: same chain as the directly built one
+    s = build(rec.ev)
+    s.pop_front_contact_status()
+    a, p, t = rec.ev[-1]
+    nxt = [1 - x for x in a]
+    s.push_back_contact_status(nxt, p, t + 0.3)
+    assert _chain_key(s.chain(0.4)) == _chain_key(build(rec.ev[1:] + [(nxt, p, t + 0.3)]).chain(0.4))

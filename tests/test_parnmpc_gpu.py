@@ -183,6 +183,17 @@ def test_cxx_sharded_driver_equals_the_whole_horizon(N, T, world, iters):
         assert not errors, errors
         assert not any(t.is_alive() for t in ts), "a rank of the sharded driver hangs (pipeline order of the sweeps?)"
 
+    # the transport self-test across the REAL neighbours (what bench.py runs before the timed region of --gpus N > 1): every halo kind to
+    # the right and from the left in one group, then the other way round, all-reduce (sum, min), broadcast -- patterns that name kind,
+    # element and sending rank must come back exactly
+    lib.idocp_parnmpc_dist_transport_selftest.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.idocp_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    devs = [C.c_double(-1.0) for _ in range(world)]
+    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_transport_selftest(shards[r].h, C.byref(devs[r])), "selftest"))
+    assert all(0.0 <= d.value <= 1e-12 for d in devs), [d.value for d in devs]
+    nr, ur, tr = C.c_int(), C.c_int(), C.c_int(-1)
+    capi.check(lib.idocp_comm_info(comms[world - 1], C.byref(nr), C.byref(ur), None, C.byref(tr)))
+    assert (nr.value, ur.value, tr.value) == (world, world - 1, 0)
     collective(lambda r: capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shards[r].h, 0.0), "init"))
     for sh in shards:
         capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))
@@ -259,6 +270,52 @@ def test_full_size_c4_parity_and_properties():
     assert np.abs(np.linalg.norm(qs[:, 3:7], axis=1) - 1).max() < 1e-12        # quaternions stay normalised
 
 
+def test_full_size_c4_from_three_perturbed_measured_states():
+    """BASELINE configs[3] at its own size with three DIFFERENT instances: the warm start of test_full_size_c4 (the state an MPC loop is
+    in), then a measured state of its own per instance -- joints and base moved by +- 0.01, a tilted base, v != 0 -- as the initial state of
+    the backward-Euler chain.  First direction of every instance against an oracle / referee pair of its own: parity() with the 1e-9 cap
+    of the standing-start test."""
+    from helpers import OracleOCP, parity, warm_start_parnmpc
+    N, T, B = 256, 12.8, 3
+    m, o0, g, q, v, h0 = make_pair(N, T, batch=B, referee=True)
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    src = OracleOCP(m, cost, cons, T, N)
+    src.set_contact_status([1, 1, 1, 1], anymal_contact_points(m))
+    src.set_solution("q", ANYMAL_Q_STANDING)
+    src.set_solution("v", np.zeros(m.nv))
+    src.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    src.init_constraints(0.0)
+    for it in range(40):
+        assert src.update(0.0, q, v) == 0
+        if src.kkt_error(0.0, q, v) < 1e-9:
+            break
+    qs, vs = [], []
+    for b in range(B):
+        rng = np.random.default_rng(20270 + b)
+        qb = ANYMAL_Q_STANDING.copy()
+        qb[0:2] += 0.01 * rng.uniform(-1, 1, 2)
+        quat = np.array([0.0, 0.0, 0.0, 1.0]) + 0.01 * rng.normal(size=4)
+        qb[3:7] = quat / np.linalg.norm(quat)
+        qb[7:] += 0.01 * rng.uniform(-1, 1, 12)
+        qs.append(qb)
+        vs.append(0.02 * rng.uniform(-1, 1, m.nv))
+    qs, vs = np.array(qs), np.array(vs)
+    pairs = [(o0, h0)] + [make_pair(N, T, batch=1, referee=True)[1::4] for _ in range(B - 1)]
+    warm_start_parnmpc(src, (g,) + tuple(x for pr in pairs for x in pr), N)
+    g.init_constraints(0.0)
+    assert g.update(0.0, qs, vs) == 0
+    worst = 0.0
+    for b, (o, h) in enumerate(pairs):
+        for s in (o, h):
+            s.init_constraints(0.0)
+            assert s.update(0.0, qs[b], vs[b]) == 0
+        for f in OCP_DIR_FIELDS:
+            assert np.abs(o.get(f)).max() < 1e4, (f, np.abs(o.get(f)).max())
+            worst = max(worst, parity(g.get(f, b), o.get(f), lambda: h.get(f), (b, f), cap=1e-9))
+    assert np.abs(g.get("dq", 0) - g.get("dq", 1)).max() > 1e-4
+    print("configs[3] from three perturbed measured states: worst GPU-oracle distance of the first direction %.2e" % worst)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_filter_line_search_equals_the_whole_horizon(world):
     """ParNMPCSolver::updateSolution(t, q, v, line_search = true) on a SHARDED horizon (round 4): idocp_parnmpc_dist_update_solution_ls
@@ -305,6 +362,17 @@ def test_sharded_filter_line_search_equals_the_whole_horizon(world):
         assert not errors, errors
         assert not any(t.is_alive() for t in ts), "a rank of the sharded line search hangs"
 
+    # the transport self-test across the REAL neighbours (what bench.py runs before the timed region of --gpus N > 1): every halo kind to
+    # the right and from the left in one group, then the other way round, all-reduce (sum, min), broadcast -- patterns that name kind,
+    # element and sending rank must come back exactly
+    lib.idocp_parnmpc_dist_transport_selftest.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.idocp_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    devs = [C.c_double(-1.0) for _ in range(world)]
+    collective(lambda r: capi.check(lib.idocp_parnmpc_dist_transport_selftest(shards[r].h, C.byref(devs[r])), "selftest"))
+    assert all(0.0 <= d.value <= 1e-12 for d in devs), [d.value for d in devs]
+    nr, ur, tr = C.c_int(), C.c_int(), C.c_int(-1)
+    capi.check(lib.idocp_comm_info(comms[world - 1], C.byref(nr), C.byref(ur), None, C.byref(tr)))
+    assert (nr.value, ur.value, tr.value) == (world, world - 1, 0)
     collective(lambda r: capi.check(lib.idocp_parnmpc_dist_init_backward_correction(shards[r].h, 0.0), "init"))
     for sh in shards:
         capi.check(lib.idocp_ocp_init_constraints(sh.h, 0.0))

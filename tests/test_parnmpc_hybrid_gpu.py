@@ -345,6 +345,7 @@ def test_configs3_trotting_n256_chain_direction_and_iterates():
         assert np.isfinite(d_g).all() and np.abs(d_o).max() < 1e6, (f, np.abs(d_o).max())      # a direction one can step along
         referee_check(d_g, d_o, d_h, f)
         worst = max(worst, rel_err(d_g, d_o))
+    print("configs[3] trotting N = 256: worst GPU-oracle distance of the first direction %.2e" % worst)
     assert worst < 1e-6, worst                 # the cap against the FP64 oracle, stage by stage (the referee rule above is the bar)
     ao, bo = o.step_sizes()
     ag, bg = g.step_sizes()

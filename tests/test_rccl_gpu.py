@@ -27,6 +27,11 @@ def _shard_and_comm(m, cost, cons, T, N, batch=1):
     comm = C.c_void_p()
     capi.check(lib.idocp_comm_init_rank(raw, 0, 1, 0, C.byref(comm)), "comm_init_rank")
     assert lib.idocp_comm_rank(comm) == 0 and lib.idocp_comm_world(comm) == 1
+    # what RCCL itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion): the figures bench.py prints as config.rccl
+    lib.idocp_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    nr, ur, ver, tr = C.c_int(-1), C.c_int(-1), C.c_int(0), C.c_int(-1)
+    capi.check(lib.idocp_comm_info(comm, C.byref(nr), C.byref(ur), C.byref(ver), C.byref(tr)), "comm_info")
+    assert (nr.value, ur.value, tr.value) == (1, 0, 1) and ver.value > 20000, (nr.value, ur.value, ver.value, tr.value)
     return lib, sh, comm
 
 
