@@ -74,6 +74,19 @@ KERNELS_OCP = ["ocp_rnea", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_
 KERNELS_OCP_SPLIT = ["ocp_rnea", "ocp_nominal", "ocp_condense", "ocp_riccati_backward", "ocp_riccati_forward", "ocp_expand_primal",
                      "ocp_reduce_steps", "ocp_expand_dual_integrate"]
 KIDS_OCP_SPLIT = [0, 7, 8, 2, 3, 4, 5, 6]
+# round 5: the forward sweep expands as it walks (ocp_forward_expand_kernel = S4 + K6 + the step-size reduction behind kernel id 3;
+# idocp_ocp_fused_forward(h) == 1: batches of instances).  IDOCP_FUSED_FORWARD=0 brings the three kernels of the lists above back.
+KERNELS_OCP_FUSED = ["ocp_rnea", "ocp_nominal", "ocp_condense", "ocp_riccati_backward", "ocp_forward_expand", "ocp_expand_dual_integrate"]
+KIDS_OCP_FUSED = [0, 7, 8, 2, 3, 6]
+
+
+def ocp_kernel_lists(lib, h, B, Mc):
+    """(names, kernel ids, units per launch by position in the list, positions of the backward / forward sweep) of one OCPSolver iteration"""
+    lib.idocp_ocp_fused_forward.argtypes = [C.c_void_p]
+    if lib.idocp_ocp_fused_forward(h):
+        return KERNELS_OCP_FUSED, KIDS_OCP_FUSED, {0: B * (Mc - 1), 1: B * Mc, 2: B * Mc, 3: B * (Mc - 1), 4: B * Mc, 5: B * Mc}, (3, 4)
+    return (KERNELS_OCP_SPLIT, KIDS_OCP_SPLIT,
+            {0: B * (Mc - 1), 1: B * Mc, 2: B * Mc, 3: B * (Mc - 1), 4: B * (Mc - 1), 5: B * Mc, 6: B * (Mc - 1), 7: B * Mc}, (3, 4))
 
 
 class Hip:
@@ -348,7 +361,7 @@ def latency_mode(lib, hip, build, q0, v0, iters=40):
     ev = [hip.event() for _ in range(3)]
     acc = [0.0, 0.0]
     for _ in range(iters):
-        for kid in range(len(KERNELS_OCP)):
+        for kid in range(len(KERNELS_OCP)):              # (ids 4, 5 launch nothing when the forward sweep expands as it walks)
             if kid in (2, 3):
                 hip.record(ev[kid - 2], stream)
             capi.check(lib.idocp_ocp_launch_kernel(sv.h, kid, d_q, d_v), "kernel %d" % kid)
@@ -803,10 +816,8 @@ def main():
             return sv
         solver = build(B)
         Mc = len(solver.chain(0.0))
-        KERNELS, KIDS = KERNELS_OCP_SPLIT, KIDS_OCP_SPLIT
+        KERNELS, KIDS, units, riccati_ids = ocp_kernel_lists(lib, solver.h, B, Mc)
         launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
-        units = {0: B * (Mc - 1), 1: B * Mc, 2: B * Mc, 3: B * (Mc - 1), 4: B * (Mc - 1), 5: B * Mc, 6: B * (Mc - 1), 7: B * Mc}
-        riccati_ids = (3, 4)
         desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, trotting contact sequence (1 lift + %d impulse events, %d stages incl. impulse / "
                 "aux / lift stages, switching constraints; BASELINE.json configs[2]); " % (N, T, nimp, Mc))
         assert solver.update(0.0, q0, v0) == 0
@@ -833,10 +844,8 @@ def main():
             return sv
         solver = build(B)
         Mc = len(solver.chain(0.0))
-        KERNELS, KIDS = KERNELS_OCP_SPLIT, KIDS_OCP_SPLIT
+        KERNELS, KIDS, units, riccati_ids = ocp_kernel_lists(lib, solver.h, B, Mc)
         launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
-        units = {0: B * (Mc - 1), 1: B * Mc, 2: B * Mc, 3: B * (Mc - 1), 4: B * (Mc - 1), 5: B * Mc, 6: B * (Mc - 1), 7: B * Mc}
-        riccati_ids = (3, 4)
         desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, running contact sequence of examples/anymal/anymal_running.cpp (26 impulse + 14 lift "
                 "events, flight phases, %d stages in the chain; BASELINE.json configs[4] in FP64); " % (N, T, Mc))
         assert solver.update(0.0, q0, v0) == 0
@@ -862,10 +871,8 @@ def main():
             sv.init_constraints(0.0)
             return sv
         solver = build(B)
-        KERNELS, KIDS = KERNELS_OCP_SPLIT, KIDS_OCP_SPLIT
+        KERNELS, KIDS, units, riccati_ids = ocp_kernel_lists(lib, solver.h, B, N + 1)
         launch, sync_fn, stream = lib.idocp_ocp_launch_kernel, lib.idocp_ocp_synchronize, lib.idocp_ocp_stream(solver.h)
-        units = {0: B * N, 1: B * (N + 1), 2: B * (N + 1), 3: B * N, 4: B * N, 5: B * (N + 1), 6: B * N, 7: B * (N + 1)}
-        riccati_ids = (3, 4)
         desc = ("ANYmal OCPSolver N=%d T=%.2f FP64, 4 point contacts active on every stage (BASELINE.json configs[2], "
                 "uniform-contact variant), trotting cost + joint limits + linearized friction cone; " % (N, T))
         assert solver.update(0.0, q0, v0) == 0            # one full update through the host entry (uploads the stage references)

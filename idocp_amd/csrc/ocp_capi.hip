@@ -141,6 +141,7 @@ struct idocp_ocp {
   std::vector<std::vector<std::pair<double, double>>> filters;
   OcpNode* d_nodes_ls = nullptr;
   double* ext_try = nullptr;
+  int fused_forward_mode = -1;        // idocp_ocp_set_fused_forward: -1 by batch size, 0 S4 + K6, 1 the fused forward sweep
 };
 
 namespace {
@@ -1105,15 +1106,41 @@ static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q, int part =
   else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, part);
 }
 
-// one SQP iteration on the handle's stream: K5 (+ K5a on impulse stages, K5s), S3, S4, K6, K7
+// The forward sweep that expands as it walks (ocp_forward_expand_kernel) pays when the stage-parallel expansion it absorbs is bandwidth: a
+// batch of instances.  A few instances are the opposite case -- K6 spreads their stages over the whole chip while the fused walk strings the
+// expansion of all stages of an instance onto one wavefront's chain -- so small batches keep S4 + K6 (latency mode).  IDOCP_FUSED_FORWARD=0 / 1
+// forces one or the other; IDOCP_FUSED_FORWARD_MIN_BATCH moves the threshold.
+static bool fusedForward(const idocp_ocp_t* h) {
+  static const int forced = getenv("IDOCP_FUSED_FORWARD") ? atoi(getenv("IDOCP_FUSED_FORWARD")) : -1;
+  static const int min_batch = getenv("IDOCP_FUSED_FORWARD_MIN_BATCH") ? atoi(getenv("IDOCP_FUSED_FORWARD_MIN_BATCH")) : 384;
+  if (h->M() > OcpForwardExpandMaxChain) return false;             // the walk keeps the chain in LDS
+  if (h->fused_forward_mode >= 0) return h->fused_forward_mode != 0;
+  if (forced >= 0) return forced != 0;
+  return h->batch >= min_batch;
+}
+// per handle: mode -1 = by batch size (the default), 0 = S4 + K6 + reduction, 1 = the fused forward sweep
+int idocp_ocp_set_fused_forward(idocp_ocp_t* h, int mode) {
+  if (!h || h->parnmpc || mode < -1 || mode > 1) return IDOCP_E_ARG;
+  h->fused_forward_mode = mode;
+  ++h->disc_epoch;                      // a captured hipGraph holds the other kernels
+  return IDOCP_OK;
+}
+// 1 when the forward sweep and the primal expansion of this OCPSolver handle run as one kernel, 0 when they are S4, K6 and the reduction
+int idocp_ocp_fused_forward(idocp_ocp_t* h) { return (h && !h->parnmpc && fusedForward(h)) ? 1 : 0; }
+static void launchForwardO(idocp_ocp_t* h, int M, const double* d_q, const double* d_v) {
+  if (fusedForward(h)) { OcpLaunch<DQ>::forwardExpand(h->B, h->batch, M, d_q, d_v, h->stream); return; }
+  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream);
+  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+}
+
+// one SQP iteration on the handle's stream: K5 (+ K5a on impulse stages, K5s), S3, the forward sweep with the primal expansion (S4 + K6), K7
 static int launchUpdateO(idocp_ocp_t* h, int M, const double* d_q, const double* d_v) {
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
   OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   launchCondenseO(h, M, d_q);
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
-  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream);
-  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+  launchForwardO(h, M, d_q, d_v);
   OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
   HIP_TRY(hipGetLastError());
   return IDOCP_OK;
@@ -1133,7 +1160,10 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
     case 7: launchCondenseO(h, M, d_q, 1); break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
     case 8: launchCondenseO(h, M, d_q, 2); break;      // ... and the condensation launches proper
     case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream); break;
-    case 3: OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
+    // 3: the forward sweep.  Since round 5 it expands as it walks (S4 + K6 + the step-size reduction in one kernel, ocp_forward_expand_kernel);
+    // ids 4 and 5 are then empty.  IDOCP_FUSED_FORWARD=0 restores the three kernels behind ids 3, 4, 5.
+    case 3: if (fusedForward(h)) OcpLaunch<DQ>::forwardExpand(h->B, h->batch, M, d_q, d_v, h->stream); else OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
+    case 4: case 5: if (!fusedForward(h)) OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;
     default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;
   }
   HIP_TRY(hipGetLastError());
@@ -1287,8 +1317,7 @@ int idocp_ocp_compute_direction(idocp_ocp_t* h, double t, const double* q, const
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   launchCondenseO(h, M, h->d_q0);
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
-  OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, h->d_q0, h->d_v0, h->stream);
-  OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+  launchForwardO(h, M, h->d_q0, h->d_v0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
@@ -1324,8 +1353,7 @@ int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q, const d
     if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
     launchCondenseO(h, M, h->d_q0);
     OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
-    OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, h->d_q0, h->d_v0, h->stream);
-    OcpLaunch<DQ>::expandPrimal(h->B, h->batch, M, h->stream);
+    launchForwardO(h, M, h->d_q0, h->d_v0);
     HIP_TRY(hipGetLastError());
     if ((rc = runLineSearchO(h, h->d_q0))) return rc;
     OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
@@ -1939,6 +1967,7 @@ int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
   h->contact_status_set = src->contact_status_set; h->stage_offset = src->stage_offset; h->has_terminal = src->has_terminal; h->has_prev = src->has_prev;
   h->phases = src->phases; h->event_time = src->event_time; h->is_impulse = src->is_impulse; h->impulse_status = src->impulse_status;
   h->slice_begin = src->slice_begin; h->slice_end = src->slice_end;
+  h->fused_forward_mode = src->fused_forward_mode;
   h->filters = src->filters;                 // the line-search filter is part of the solver's state (LineSearch is a member of the reference's solvers)
   h->prob = src->prob;
   h->seq_dirty = true;                       // the chain is rebuilt (and uploaded) on first use

@@ -8,6 +8,9 @@
 
 namespace idocp_dev {
 
+// longest chain ocp_forward_expand_kernel keeps in LDS (slot, status word, two time steps per node); longer chains run S4 + K6
+constexpr int OcpForwardExpandMaxChain = 320;
+
 template <typename D>
 struct OcpLaunch {
   // M = length of the chain (stages in time order incl. event stages and the terminal stage)
@@ -42,6 +45,7 @@ struct OcpLaunch {
   static void meritBackwardEuler(const OcpBuffers& Btry, long batch, int M, const double* q0, const double* v0, hipStream_t st);      // the same for ParNMPC (event-free)
   static void meritReduce(const OcpBuffers& B, long batch, hipStream_t st);
   static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
+  static void forwardExpand(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);   // S4 + K6 + reduction fused (round 5)
   static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7
   static void initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st);     // every slot
   static void single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st);   // ids 4, 5, 6

@@ -471,6 +471,10 @@ class HipOCP:
             capi.check(self.lib.idocp_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
                        "idocp_ocp_create")
         self.h = h
+        # tests/test_forward_expand_gpu.py: every handle created under this switch runs the forward sweep in the given form (0 / 1)
+        if os.environ.get("IDOCP_TEST_FUSED_FORWARD") in ("0", "1"):
+            self.lib.idocp_ocp_set_fused_forward.argtypes = [C.c_void_p, C.c_int]
+            capi.check(self.lib.idocp_ocp_set_fused_forward(self.h, int(os.environ["IDOCP_TEST_FUSED_FORWARD"])), "set_fused_forward")
 
     # ---- contact sequences with discrete events
     def push_back_contact_status(self, active, points, switching_time):

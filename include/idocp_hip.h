@@ -648,9 +648,15 @@ int idocp_device_copy(void* d_dst, const void* d_src, unsigned long nbytes);
  * 3 = forward Riccati, 4 = expand primal, 5 = step-size reduction,
  * 6 = expand dual + integrate; 7 and 8 = the two halves of 1 (7: the nominal
  * rigid-body sweeps and the rows of the external terms, 8: the condensation
- * launches), so that a profiler of the caller can bracket them apart. */
+ * launches), so that a profiler of the caller can bracket them apart.
+ * Since round 5 the forward sweep of a BATCH of instances expands as it walks (riccati_recursion_solver.cpp:129-251 in one kernel): id 3
+ * is then the whole of 3 + 4 + 5 and ids 4, 5 launch nothing; idocp_ocp_fused_forward(h) says which form the handle runs (small batches
+ * keep the three kernels: latency mode; IDOCP_FUSED_FORWARD=0 / 1 forces one, IDOCP_FUSED_FORWARD_MIN_BATCH moves the threshold). */
 int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q,
                             const double* d_v);
+int idocp_ocp_fused_forward(idocp_ocp_t* h);
+/* mode -1: by batch size (default); 0: S4 + K6 + reduction; 1: the fused forward sweep -- per handle (tuning / the parity tests of both forms) */
+int idocp_ocp_set_fused_forward(idocp_ocp_t* h, int mode);
 
 const char* idocp_last_error(void);
 const char* idocp_version(void);
