@@ -1112,7 +1112,7 @@ static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q, int part =
 // forces one or the other; IDOCP_FUSED_FORWARD_MIN_BATCH moves the threshold.
 static bool fusedForward(const idocp_ocp_t* h) {
   static const int forced = getenv("IDOCP_FUSED_FORWARD") ? atoi(getenv("IDOCP_FUSED_FORWARD")) : -1;
-  static const int min_batch = getenv("IDOCP_FUSED_FORWARD_MIN_BATCH") ? atoi(getenv("IDOCP_FUSED_FORWARD_MIN_BATCH")) : 384;
+  static const int min_batch = getenv("IDOCP_FUSED_FORWARD_MIN_BATCH") ? atoi(getenv("IDOCP_FUSED_FORWARD_MIN_BATCH")) : 192;      // measured on configs[2]: S4 + K6 0.315 / 0.405 / 0.587 ms at batch 128 / 256 / 512, the fused walk 0.346 / 0.356 / 0.447
   if (h->M() > OcpForwardExpandMaxChain) return false;             // the walk keeps the chain in LDS
   if (h->fused_forward_mode >= 0) return h->fused_forward_mode != 0;
   if (forced >= 0) return forced != 0;

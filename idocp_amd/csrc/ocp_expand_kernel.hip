@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
 // RiccatiRecursionSolver::computeInitialStateDirection + forwardRiccatiRecursion (src/ocp/riccati_recursion_solver.cpp:110-162) and
 // computeDirection (:165-251) -- the costate P dx - s (split_riccati_factorizer.hxx:131-139), dxi = M dx + m (:139-145),
 // ContactDynamics::computeCondensedPrimalDirection (contact_dynamics.hxx:161-168), slack / dual directions and the fraction-to-boundary
-// candidates -- stage by stage along the chain of ONE instance, one wavefront per instance.  Rounds 1 - 4 ran S4 (a serial sweep that read
+// candidates -- stage by stage along the chain of ONE instance, one workgroup (two wavefronts, below) per instance.  Rounds 1 - 4 ran S4 (a serial sweep that read
 // the gain and the F blocks of the kkt record, 11.2 kB per stage) and then K6 (one wavefront per stage: P, MJtJinv [dIDC], MJtJinv, the
 // solution and IPM rows, 22 kB per stage) back to back over the same stages.  What S4 needs of a stage's dynamics is what K6 computes anyway:
 //     t = MJtJinv_dIDCdqv dx,   w = MJtJinv[:, u] du,   d[a; f] = w - t - MJtJinv_IDC            (contact_dynamics.hxx:161-168)
@@ -307,40 +307,41 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
 // of 33) and the 6.9 kB of Fvq / Fvv / Fvu are not read at all.  The records of stages i + 1 and i + 2 are in flight (16-byte loads into two
 // register sets, S4's scheme) while stage i is computed out of LDS; the step sizes of the instance are reduced on the way
 // (ocp_reduce_steps_kernel's job: the minimum over the chain's stages).
+// TWO wavefronts per instance.  One wavefront per instance (the first form of this kernel: 0.95 ms, then 0.86 with the row metadata decoded
+// up front and P unpacked to a full matrix; S4 + K6 took 0.97) is a chain of ~2 000 dependent instructions per stage with nothing to hide a
+// single latency behind -- one wavefront per SIMD at batch 1024 --: 7.2 us per stage.  Only a part of that is the recursion proper.  Wavefront 0
+// keeps  du = K dx + k,  t, w, d[a; f]  and  dx+  (gain, MJtJinv [dIDC], MJtJinv, Fqq6 / Fqv6 / Fx); wavefront 1 follows ONE STAGE BEHIND with
+// what only consumes the direction: the costate P dx - s, dxi, the slack / dual directions and the fraction-to-boundary candidates (P, s,
+// solution, slack / dual rows).  The direction of a stage travels through a ring of three LDS vectors (stage i in slot i mod 3: wavefront 0
+// fills dx of slot i + 1 while wavefront 1 still reads slot i - 1), one LDS barrier per stage: 0.69 ms, 4.7 TB/s.
+// Everything the walk needs besides the stage records lives in LDS or in registers BEFORE the first store of the kernel: the chain (slot, time
+// steps, contact status: two words and two doubles per node), the rows' limits, the problem's switches.  A load from global memory inside the
+// walk -- a node field, a limit indexed by the lane -- would make a wavefront wait for it with s_waitcnt vmcnt(0), i.e. for the records of the
+// NEXT two stages as well, which are in flight by then (vector memory returns in order): 12 us per stage (1.45 ms) in the very first form.
 template <typename D>
-__global__ __launch_bounds__(64, 1) void ocp_forward_expand_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
+__global__ __launch_bounds__(128, 1) void ocp_forward_expand_kernel(OcpBuffers B, const double* __restrict__ q0, const double* __restrict__ v0) {
   using L = OcpLayout<D>;
   constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NU = D::NU, NF = D::NF, NVF = D::NVF, NC = D::NC;
   constexpr int GL = L::GAIN, RL = L::R_SV + NV, MJDL = NVF * NX, MJUL = L::MJ_TRI;
   static_assert(GL % 2 == 0 && RL % 2 == 0 && MJDL % 2 == 0 && MJUL % 2 == 0 && L::SOL % 2 == 0 && L::GAIN % 2 == 0 && L::RIC % 2 == 0 && L::EXP % 2 == 0 &&
                 L::E_MJD % 2 == 0 && L::KKT % 2 == 0 && L::K_FQQ % 2 == 0 && L::K_FX % 2 == 0 && NVF % 2 == 0, "16-byte loads");
   static_assert(L::K_FQV == L::K_FQQ + 36 && L::NCON <= 128 && NX <= 36 && 36 + NX / 2 <= 64, "Fqq6 | Fqv6 and Fx on one load; two IPM rows per lane");
-  static_assert(NC <= 4 && NF <= 15 && NVF <= 30 && L::R_PQQ == 0 && L::R_SV == L::R_SQ + NV && L::C_FRIC <= 64 + 8, "node word: four contacts; lane maps");
+  static_assert(NC <= 4 && NF <= 15 && NVF + NV <= 64 && L::R_PQQ == 0 && L::R_SV == L::R_SQ + NV && L::C_FRIC <= 64 + 8, "node word: four contacts; lane maps");
   constexpr int NG2 = (GL / 2 + 63) / 64, NP2 = (RL / 2 + 63) / 64, NM2 = (MJDL / 2 + 63) / 64, NT2 = (MJUL / 2 + 63) / 64, NS2 = (L::SOL / 2 + 63) / 64;
   constexpr int MAXM = OcpForwardExpandMaxChain;
-  // P of the stage as the FULL symmetric nx x nx matrix (its record holds Pqq, Pvv as packed upper triangles and Pqv once: the mirror
-  // images are written when the record goes from the registers to LDS, at offsets every lane works out ONCE, below), followed by s and a
-  // slot for the record's padding entries
   constexpr int PF = NX * NX, PSV = PF, PPAD = PF + NX;
+  constexpr int DV = NX + NU + NV + NF + 2;             // one slot of the ring: dx | du | da | df (contact slots)
   __shared__ __attribute__((aligned(16))) double gb[GL], pfull[PF + NX + 2], mjd[MJDL], mju[MJUL], sr[L::SOL], fb[72 + NX];
-  __shared__ double dvec[NX + NU + NV], dxn[NX], dfs[NF];
-  double* const dx = dvec;            // the direction of the stage in one vector: the IPM rows index it (dx | du | da)
-  double* const du = dvec + NX;
-  double* const das = dvec + NX + NU;
-  // Everything the walk needs besides the stage records lives in LDS or in registers BEFORE the first store of the kernel: the chain (slot,
-  // time steps, contact status: two words and two doubles per node), the joint limits, the problem's switches.  A load from global memory
-  // inside the walk -- a node field, a limit indexed by the lane -- would make the wavefront wait for it with s_waitcnt vmcnt(0), i.e. for
-  // the records of the NEXT two stages as well, which are in flight by then (vector memory returns in order): 12 us per stage instead of 8.
+  __shared__ double ring[3][DV];
   __shared__ int n_slot[MAXM], n_word[MAXM];
   __shared__ double n_dt[MAXM], n_dtq[MAXM];
   const int M = B.M;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long b = blockIdx.x;
   const long base = b * B.NS;
   int use_cone, use_icone, use_cd, ck_stage, ck_imp;
   double cmu, barrier, frate;
-  // the two IPM rows of this lane (rows lane and lane + 64 of the slack / dual records), decoded once: a joint-limit / acceleration-limit row is
-  //   g = sgn (x - bound),  dg = sgn d   with x = sr[xoff], d = dvec[doff], present from constraint level `thr` on (4: never)
   int r_xoff[2], r_doff[2], r_thr[2];
   double r_sgn[2], r_bound[2];
   {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(64, 1) void ocp_forward_expand_kernel(OcpBuffers B,
       }
     }
     const OcpNode* __restrict__ nodes = B.nodes;
-    for (int i = lane; i < M; i += 64) {
+    for (int i = tid; i < M; i += 128) {
       const OcpNode* __restrict__ nd = nodes + i;
       int w = (nd->kind & 7) | ((nd->level < 3 ? (nd->level < 0 ? 0 : nd->level) : 3) << 3) | (nd->dimf << 5) | (nd->sw_dimi << 9) | ((nd->has_u ? 1 : 0) << 13);
 #pragma unroll
@@ -376,38 +377,9 @@ __global__ __launch_bounds__(64, 1) void ocp_forward_expand_kernel(OcpBuffers B,
       n_slot[i] = nd->slot; n_word[i] = w; n_dt[i] = nd->dt; n_dtq[i] = nd->dtq;
     }
   }
-  // where the two doubles of piece e = lane + 64 t of the ric record go in pfull: the entry itself and its mirror image
-  int p_a[NP2][2], p_b[NP2][2];
-#pragma unroll
-  for (int t = 0; t < NP2; ++t) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = 2 * (lane + 64 * t) + h;
-      int a = PPAD + h, bb = PPAD + h;                                 // padding entries of the record, pieces beyond it
-      if (k < L::R_PQV || (k >= L::R_PVV && k < L::R_SQ)) {
-        const bool vv = k >= L::R_PVV;
-        const int kk = vv ? k - L::R_PVV : k;
-        int c = 0;
-        while ((c + 1) * (c + 2) / 2 <= kk) ++c;                       // entry (r, c), r <= c, at c (c + 1) / 2 + r
-        const int r = kk - c * (c + 1) / 2;
-        if (c < NV) { const int o = vv ? NV : 0; a = (o + r) + NX * (o + c); bb = (o + c) + NX * (o + r); }
-      } else if (k >= L::R_PQV && k < L::R_PVV) {
-        const int kk = k - L::R_PQV, c = kk / NV, r = kk - c * NV;     // Pqv(r, c)
-        a = r + NX * (NV + c); bb = (NV + c) + NX * r;
-      } else if (k >= L::R_SQ && k < RL) {
-        a = bb = PSV + (k - L::R_SQ);
-      }
-      p_a[t][h] = a; p_b[t][h] = bb;
-    }
-  }
-  // the row of the (a, f) block this lane expands (lanes 36 ..: rows 0 .. 27; rows 28, 29 of a stage with all feet on the ground: lanes 0, 1)
-  // and where its twelve entries MJtJinv(row, 6 + j) lie in the packed lower triangle
-  const int af_row = lane >= 36 ? lane - 36 : 28 + lane;
-  int tri_off[NU];
-#pragma unroll
-  for (int j = 0; j < NU; ++j) { const int c = 6 + j; tri_off[j] = af_row >= c ? af_row * (af_row + 1) / 2 + c : c * (c + 1) / 2 + af_row; }
-  // RiccatiRecursionSolver::computeInitialStateDirection (riccati_recursion_solver.cpp:110-126)
-  {
+  // RiccatiRecursionSolver::computeInitialStateDirection (riccati_recursion_solver.cpp:110-126) -> slot 0 of the ring
+  if (wave == 0) {
+    double* dx = ring[0];
     const int slot0 = B.nodes[0].slot;
     const double* __restrict__ s0 = B.sol + (base + slot0) * L::SOL;
     if (lane == 0) {
@@ -420,194 +392,245 @@ __global__ __launch_bounds__(64, 1) void ocp_forward_expand_kernel(OcpBuffers B,
     if (lane >= 6 && lane < NV) dx[lane] = q0[b * NQ + lane + 1] - s0[L::S_Q + lane + 1];
     if (lane < NV) dx[NV + lane] = v0[b * NV + lane] - s0[L::S_V + lane];
   }
-  waveLdsSync();
-  struct Regs {
-    ex_d2 g[NG2], p[NP2], m[NM2], u[NT2], s[NS2], f;
-    double sl[2], dl[2], mjidc;
-  };
-  Regs RA, RB;
-  // everything a stage needs, requested at once (every address is a valid record of this instance: no branches between the loads)
-  auto fetch = [&](int i, Regs& R) {
-    const long rec = base + n_slot[i];
-    wideLoad<RL / 2>(R.p, B.ric + rec * L::RIC, lane);
-    if (i == M - 1) return;                                   // the terminal stage: costate only
-    wideLoad<GL / 2>(R.g, B.gain + rec * L::GAIN, lane);
-    const int rows_ld = NV + ((n_word[i] >> 5) & 15), h_ld = (rows_ld + 1) >> 1, inv_ld = 65535 / h_ld + 1;
-    wideLoadRows<MJDL / 2, NVF / 2>(R.m, B.exp + rec * L::EXP + L::E_MJD, lane, h_ld, inv_ld, h_ld * NX);
-    wideLoadN<MJUL / 2>(R.u, B.exp + rec * L::EXP + L::E_MJ, lane, (rows_ld * (rows_ld + 1) / 2 + 1) >> 1);
-    wideLoad<L::SOL / 2>(R.s, B.sol + rec * L::SOL, lane);
-    {
-      const ex_d2* __restrict__ kq = reinterpret_cast<const ex_d2*>(B.kkt + rec * L::KKT + L::K_FQQ);
-      const ex_d2* __restrict__ kx = reinterpret_cast<const ex_d2*>(B.kkt + rec * L::KKT + L::K_FX);
-      R.f = lane < 36 ? kq[lane] : kx[lane - 36 < NX / 2 ? lane - 36 : NX / 2 - 1];
-    }
+  blockLdsSync();
+  if (wave == 0) {
+    // =============== wavefront 0: the recursion ===============
+    struct Regs { ex_d2 g[NG2], m[NM2], u[NT2], f; double mjidc; };
+    Regs RA, RB;
+    // lanes 0 .. NVF - 1: row `lane` of the (a, f) block; lanes 32 + (0 .. NV - 1): row of dq+ (NVF <= 32 keeps them apart when all feet stand)
+    const int af_row = lane < NVF ? lane : NVF - 1;
+    int tri_off[NU];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = lane + 64 * t < L::NCON ? lane + 64 * t : L::NCON - 1;
-      R.sl[t] = B.slack[rec * L::CON + row]; R.dl[t] = B.dual[rec * L::CON + row];
-    }
-    R.mjidc = B.exp[rec * L::EXP + L::E_MJIDC + (af_row < NVF ? af_row : NVF - 1)];
-  };
-  fetch(0, RA);
-  if (M > 1) fetch(1, RB);
-  double ps_min = 1.0, ds_min = 1.0;
-  auto step = [&](int i, Regs& R) {
-    const int word = n_word[i];
-    const long rec = base + n_slot[i];
-    const int kind = word & 7, level = (word >> 3) & 3, dimf = (word >> 5) & 15, sw_dimi = (word >> 9) & 15, amask = (word >> 14) & 15, rows3 = (word >> 18) & 255;
-    const double sdt = n_dt[i], sdtq = n_dtq[i];
-    double* __restrict__ dd = B.dir + rec * L::DIR;
-    const bool terminal = (i == M - 1);
-    const int dimvf = NV + dimf;
-    const int h_ld = (dimvf + 1) >> 1, inv_ld = 65535 / h_ld + 1;
-#pragma unroll
-    for (int t = 0; t < NP2; ++t) {
-      pfull[p_a[t][0]] = R.p[t].x; pfull[p_b[t][0]] = R.p[t].x;
-      pfull[p_a[t][1]] = R.p[t].y; pfull[p_b[t][1]] = R.p[t].y;
-    }
-    if (!terminal) {
+    for (int j = 0; j < NU; ++j) { const int c = 6 + j; tri_off[j] = af_row >= c ? af_row * (af_row + 1) / 2 + c : c * (c + 1) / 2 + af_row; }
+    auto fetch = [&](int i, Regs& R) {
+      const long rec = base + n_slot[i];
+      wideLoad<GL / 2>(R.g, B.gain + rec * L::GAIN, lane);
+      const int rows_ld = NV + ((n_word[i] >> 5) & 15), h_ld = (rows_ld + 1) >> 1, inv_ld = 65535 / h_ld + 1;
+      wideLoadRows<MJDL / 2, NVF / 2>(R.m, B.exp + rec * L::EXP + L::E_MJD, lane, h_ld, inv_ld, h_ld * NX);
+      wideLoadN<MJUL / 2>(R.u, B.exp + rec * L::EXP + L::E_MJ, lane, (rows_ld * (rows_ld + 1) / 2 + 1) >> 1);
+      {
+        const ex_d2* __restrict__ kq = reinterpret_cast<const ex_d2*>(B.kkt + rec * L::KKT + L::K_FQQ);
+        const ex_d2* __restrict__ kx = reinterpret_cast<const ex_d2*>(B.kkt + rec * L::KKT + L::K_FX);
+        R.f = lane < 36 ? kq[lane] : kx[lane - 36 < NX / 2 ? lane - 36 : NX / 2 - 1];
+      }
+      R.mjidc = B.exp[rec * L::EXP + L::E_MJIDC + af_row];
+    };
+    if (M > 1) fetch(0, RA);
+    if (M > 2) fetch(1, RB);
+    auto step = [&](int i, Regs& R) {
+      double* const dv = ring[i % 3];
+      double* const dx = dv; double* const du = dv + NX; double* const das = dv + NX + NU; double* const dfs = dv + NX + NU + NV;
+      double* const dxn = ring[(i + 1) % 3];
+      const int word = n_word[i];
+      const long rec = base + n_slot[i];
+      const int dimf = (word >> 5) & 15, amask = (word >> 14) & 15, rows3 = (word >> 18) & 255;
+      const double sdt = n_dt[i], sdtq = n_dtq[i];
+      double* __restrict__ dd = B.dir + rec * L::DIR;
+      const int dimvf = NV + dimf;
+      const int h_ld = (dimvf + 1) >> 1, inv_ld = 65535 / h_ld + 1;
       wideStoreLds<GL / 2>(gb, R.g, lane);
       wideStoreLdsRows<MJDL / 2, NVF / 2>(mjd, R.m, lane, h_ld, inv_ld, h_ld * NX);
       wideStoreLds<MJUL / 2>(mju, R.u, lane);
-      wideStoreLds<L::SOL / 2>(sr, R.s, lane);
       if (lane < 36 + NX / 2) reinterpret_cast<ex_d2*>(fb)[lane] = R.f;
-    }
-    const double sl0 = R.sl[0], sl1 = R.sl[1], dl0 = R.dl[0], dl1 = R.dl[1], mjidc_r = R.mjidc;
-    waveLdsSync();
-    if (i + 2 < M) fetch(i + 2, R);
-    // ---- du = K dx + k: four lanes per row ----
-    if (!terminal) {
-      const int j = lane >> 2, part = lane & 3;
-      double acc = 0.0;
-      if (lane < 4 * NU) {
+      const double mjidc_r = R.mjidc;
+      waveLdsSync();
+      if (i + 2 < M - 1) fetch(i + 2, R);
+      // du = K dx + k: four lanes per row
+      {
+        const int j = lane >> 2, part = lane & 3;
+        double acc = 0.0;
+        if (lane < 4 * NU) {
 #pragma unroll
-        for (int t = 0; t < NX / 4; ++t) { const int c = (NX / 4) * part + t; acc += gb[L::G_K + j + NU * c] * dx[c]; }
+          for (int t = 0; t < NX / 4; ++t) { const int c = (NX / 4) * part + t; acc += gb[L::G_K + j + NU * c] * dx[c]; }
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (lane < 4 * NU && part == 0) { acc += gb[L::G_k + j]; du[j] = acc; dd[L::D_U + j] = acc; }
       }
-      acc += __shfl_xor(acc, 1);
-      acc += __shfl_xor(acc, 2);
-      if (lane < 4 * NU && part == 0) { acc += gb[L::G_k + j]; du[j] = acc; dd[L::D_U + j] = acc; }
+      // t = MJtJinv_dIDCdqv dx: one row per lane
+      double tt = 0.0;
+      if (lane < dimvf) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) tt += mjd[lane + NVF * c] * dx[c];
+      }
+      if (lane < NF) dfs[lane] = 0.0;
+      if (lane >= 40 && lane < 40 + NV) { const int r = lane - 40; dd[L::D_Q + r] = dx[r]; dd[L::D_V + r] = dx[NV + r]; }
+      waveLdsSync();                                             // du stands
+      // w = MJtJinv[:, u] du;  d[a; f] = w - t - MJtJinv_IDC (contact_dynamics.hxx:161-168; d.df() *= -1);  dv+ = dv + dt (w - t) + Fv
+      if (lane < dimvf) {
+        const int r = lane;
+        double ww = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) ww += mju[tri_off[j]] * du[j];      // MJtJinv(r, 6 + j)
+        const double acc_af = -mjidc_r + (ww - tt);
+        dd[L::D_T + r] = tt; dd[L::D_W + r] = ww;                // for the dual expansion (K7)
+        if (r < NV) {
+          dd[L::D_A + r] = acc_af; das[r] = acc_af;
+          dxn[NV + r] = dx[NV + r] + sdt * (ww - tt) + fb[72 + NV + r];
+        } else {
+          const int pr = r - NV;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int row_of = 3 * ((rows3 >> (2 * c)) & 3);
+            if (((amask >> c) & 1) && pr >= row_of && pr < row_of + 3) {
+              const int slot = 3 * c + (pr - row_of);
+              dfs[slot] = -acc_af; dd[L::D_F + slot] = -acc_af;
+            }
+          }
+        }
+      } else if (lane >= 32 && lane < 32 + NV) {
+        // dq+ = Fqq dq + Fqv dv + Fq: the base block from the kkt record, identity / dt I on the joints (state_equation.hxx:52-61)
+        const int r = lane - 32;
+        double dq = fb[72 + r];
+        if (r < 6) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) dq += fb[r + 6 * m] * dx[m] + fb[36 + r + 6 * m] * dx[NV + m];
+        } else {
+          dq += dx[r] + sdtq * dx[NV + r];
+        }
+        dxn[r] = dq;
+      }
+    };
+    static_assert(NVF <= 32, "the dq+ rows sit on the lanes behind the (a, f) rows");
+    for (int i = 0; i <= M; i += 2) {
+      if (i < M - 1) step(i, RA);
+      blockLdsSync();
+      if (i + 1 <= M) {
+        if (i + 1 < M - 1) step(i + 1, RB);
+        blockLdsSync();
+      }
     }
-    if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
-    // ---- ONE 36-term product for all lanes: lanes 0 .. 35 a row of the costate [dlmd; dgmm] = P dx - s (split_riccati_factorizer.hxx:131-139),
-    //      lanes 36 .. 63 a row of t = MJtJinv_dIDCdqv dx (contact_dynamics.hxx:161-168) ----
-    double acc36 = 0.0;
+    // the terminal stage's dq, dv
     {
-      const bool cs = lane < NX;
-      const double* mp = cs ? pfull + lane : mjd + (lane - 36);
-      const int st = cs ? NX : NVF;
-      if (cs || (!terminal && af_row < dimvf)) {
+      const double* dx = ring[(M - 1) % 3];
+      double* __restrict__ dd = B.dir + (base + n_slot[M - 1]) * L::DIR;
+      if (lane < NV) { dd[L::D_Q + lane] = dx[lane]; dd[L::D_V + lane] = dx[NV + lane]; }
+    }
+  } else {
+    // =============== wavefront 1: one stage behind -- costate, dxi, slack / dual directions, step sizes ===============
+    struct Regs { ex_d2 p[NP2], s[NS2]; double sl[2], dl[2]; };
+    Regs RA, RB;
+    int p_a[NP2][2], p_b[NP2][2];
 #pragma unroll
-        for (int c = 0; c < NX; ++c) acc36 += mp[st * c] * dx[c];
+    for (int t = 0; t < NP2; ++t) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * (lane + 64 * t) + h;
+        int a = PPAD + h, bb = PPAD + h;                                 // padding entries of the record, pieces beyond it
+        if (k < L::R_PQV || (k >= L::R_PVV && k < L::R_SQ)) {
+          const bool vv = k >= L::R_PVV;
+          const int kk = vv ? k - L::R_PVV : k;
+          int c = 0;
+          while ((c + 1) * (c + 2) / 2 <= kk) ++c;                       // entry (r, c), r <= c, at c (c + 1) / 2 + r
+          const int r = kk - c * (c + 1) / 2;
+          if (c < NV) { const int o = vv ? NV : 0; a = (o + r) + NX * (o + c); bb = (o + c) + NX * (o + r); }
+        } else if (k >= L::R_PQV && k < L::R_PVV) {
+          const int kk = k - L::R_PQV, c = kk / NV, r = kk - c * NV;     // Pqv(r, c)
+          a = r + NX * (NV + c); bb = (NV + c) + NX * r;
+        } else if (k >= L::R_SQ && k < RL) {
+          a = bb = PSV + (k - L::R_SQ);
+        }
+        p_a[t][h] = a; p_b[t][h] = bb;
       }
-      if (cs) dd[(lane < NV ? L::D_LMD : L::D_GMM - NV) + lane] = acc36 - pfull[PSV + lane];
     }
-    if (terminal) return;
-    double tt = acc36;
-    if (dimvf > 28 && lane < 2) {                                // a stage with all feet on the ground: rows 28, 29
-      tt = 0.0;
-      if (af_row < dimvf) {
+    auto fetch = [&](int i, Regs& R) {
+      const long rec = base + n_slot[i];
+      wideLoad<RL / 2>(R.p, B.ric + rec * L::RIC, lane);
+      wideLoad<L::SOL / 2>(R.s, B.sol + rec * L::SOL, lane);
 #pragma unroll
-        for (int c = 0; c < NX; ++c) tt += mjd[af_row + NVF * c] * dx[c];
+      for (int t = 0; t < 2; ++t) {
+        const int row = lane + 64 * t < L::NCON ? lane + 64 * t : L::NCON - 1;
+        R.sl[t] = B.slack[rec * L::CON + row]; R.dl[t] = B.dual[rec * L::CON + row];
       }
-    }
-    // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145): dxi = M dx + m
-    // (the nine stages of a trot that carry a switching constraint read their record here, behind the prefetch: a wait of a memory latency each)
-    if (sw_dimi > 0 && lane >= 16 && lane < 16 + sw_dimi) {
-      const int l = lane - 16;
-      const double* __restrict__ W = B.swc + rec * L::SWC;
-      double acc = W[L::W_m + l];
-      for (int c = 0; c < NX; ++c) acc += W[L::W_M + l + NF * c] * dx[c];
-      dd[L::D_XI + l] = acc;
-    }
-    if (lane < NF) dfs[lane] = 0.0;
-    waveLdsSync();                                             // du stands
-    // ---- w = MJtJinv[:, u] du;  d[a; f] = w - t - MJtJinv_IDC (contact_dynamics.hxx:161-168; d.df() *= -1);  dv+ = dv + dt (w - t) + Fv ----
-    if ((lane >= 36 || (dimvf > 28 && lane < 2)) && af_row < dimvf) {
-      const int r = af_row;
-      double ww = 0.0;
+    };
+    fetch(0, RA);
+    if (M > 1) fetch(1, RB);
+    double ps_min = 1.0, ds_min = 1.0;
+    auto step = [&](int i, Regs& R) {
+      const double* const dvec = ring[i % 3];
+      const double* const dx = dvec; const double* const dfs = dvec + NX + NU + NV;
+      const int word = n_word[i];
+      const long rec = base + n_slot[i];
+      const int kind = word & 7, level = (word >> 3) & 3, sw_dimi = (word >> 9) & 15, amask = (word >> 14) & 15;
+      double* __restrict__ dd = B.dir + rec * L::DIR;
+      const bool terminal = (i == M - 1);
 #pragma unroll
-      for (int j = 0; j < NU; ++j) ww += mju[tri_off[j]] * du[j];      // MJtJinv(r, 6 + j)
-      const double acc_af = -mjidc_r + (ww - tt);
-      dd[L::D_T + r] = tt; dd[L::D_W + r] = ww;                // for the dual expansion (K7)
-      if (r < NV) {
-        dd[L::D_A + r] = acc_af; das[r] = acc_af;
-        // (= Fvq dq + Fvv dv + Fvu du + Fv with the F blocks of contact_dynamics.hxx:150-156)
-        dxn[NV + r] = dx[NV + r] + sdt * (ww - tt) + fb[72 + NV + r];
-      } else {
-        const int pr = r - NV;
+      for (int t = 0; t < NP2; ++t) {
+        pfull[p_a[t][0]] = R.p[t].x; pfull[p_b[t][0]] = R.p[t].x;
+        pfull[p_a[t][1]] = R.p[t].y; pfull[p_b[t][1]] = R.p[t].y;
+      }
+      wideStoreLds<L::SOL / 2>(sr, R.s, lane);
+      const double sl0 = R.sl[0], sl1 = R.sl[1], dl0 = R.dl[0], dl1 = R.dl[1];
+      waveLdsSync();
+      if (i + 2 < M) fetch(i + 2, R);
+      // costate [dlmd; dgmm] = P dx - s (split_riccati_factorizer.hxx:131-139): one row per lane
+      if (lane < NX) {
+        double acc = 0.0;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int row_of = 3 * ((rows3 >> (2 * c)) & 3);
-          if (((amask >> c) & 1) && pr >= row_of && pr < row_of + 3) {
-            const int slot = 3 * c + (pr - row_of);
-            dfs[slot] = -acc_af; dd[L::D_F + slot] = -acc_af;
+        for (int c = 0; c < NX; ++c) acc += pfull[lane + NX * c] * dx[c];
+        dd[lane] = acc - pfull[PSV + lane];
+      }
+      static_assert(L::D_LMD == 0 && L::D_GMM == NV, "dlmd | dgmm lead the direction record");
+      if (terminal) return;
+      // SplitRiccatiFactorizer::computeLagrangeMultiplierDirection (split_riccati_factorizer.hxx:139-145): dxi = M dx + m
+      if (sw_dimi > 0 && lane >= 40 && lane < 40 + sw_dimi) {
+        const int l = lane - 40;
+        const double* __restrict__ W = B.swc + rec * L::SWC;
+        double acc = W[L::W_m + l];
+        for (int c = 0; c < NX; ++c) acc += W[L::W_M + l + NF * c] * dx[c];
+        dd[L::D_XI + l] = acc;
+      }
+      // slack / dual directions, fraction-to-boundary candidates (pdipm.hxx:52-81)
+      const bool impulse = kind == 1;
+      double ps = 1.0, ds = 1.0;
+      auto candidate = [&](double g, double dg, double sl, double dl) {
+        const double res = g + sl, duality = sl * dl - barrier;
+        const double dslack = -dg - res;
+        const double ddual = -(dl * dslack + duality) / sl;
+        ps = f2b(frate, sl, dslack, ps);
+        ds = f2b(frate, dl, ddual, ds);
+      };
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (!impulse && level >= r_thr[t]) candidate(r_sgn[t] * (sr[r_xoff[t]] - r_bound[t]), r_sgn[t] * dvec[r_doff[t]], t ? sl1 : sl0, t ? dl1 : dl0);
+      }
+      {
+        const int row = lane + 64;
+        if (row >= L::C_FRIC && row < L::C_ACC) {
+          const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
+          const int ck = impulse ? ck_imp : ck_stage;
+          if (r < coneRows(ck) && (impulse ? use_icone != 0 : use_cone != 0) && ((amask >> c) & 1)) {
+            double J[3];
+            const double f[3] = {sr[L::S_F + 3 * c], sr[L::S_F + 3 * c + 1], sr[L::S_F + 3 * c + 2]};
+            const double g = coneRow(ck, cmu, r, f, J);
+            candidate(g, J[0] * dfs[3 * c] + J[1] * dfs[3 * c + 1] + J[2] * dfs[3 * c + 2], sl1, dl1);
+          }
+        } else if (row >= L::C_CD && row < L::NCON) {
+          const int c = row - L::C_CD;
+          if (B.ext != nullptr && use_cd && !impulse && level >= 2 && !((amask >> c) & 1)) {
+            const double* __restrict__ xx = B.ext + rec * L::EXT;
+            double acc = 0.0;
+            for (int q = 0; q < NV; ++q) acc += xx[L::X_CDJ + c * NV + q] * dx[q];
+            candidate(-xx[L::X_Z + c], -acc, sl1, dl1);
           }
         }
       }
-    }
-    if (lane >= 8 && lane < 8 + NV) {
-      // dq+ = Fqq dq + Fqv dv + Fq: the base block from the kkt record, identity / dt I on the joints (state_equation.hxx:52-61)
-      const int r = lane - 8;
-      double dq = fb[72 + r];
-      if (r < 6) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) dq += fb[r + 6 * m] * dx[m] + fb[36 + r + 6 * m] * dx[NV + m];
-      } else {
-        dq += dx[r] + sdtq * dx[NV + r];
-      }
-      dxn[r] = dq;
-    }
-    waveLdsSync();
-    // ---- slack / dual directions, fraction-to-boundary candidates (pdipm.hxx:52-81) ----
-    const bool impulse = kind == 1;
-    double ps = 1.0, ds = 1.0;
-    auto candidate = [&](double g, double dg, double sl, double dl) {
-      const double res = g + sl, duality = sl * dl - barrier;
-      const double dslack = -dg - res;
-      const double ddual = -(dl * dslack + duality) / sl;
-      ps = f2b(frate, sl, dslack, ps);
-      ds = f2b(frate, dl, ddual, ds);
+      for (int off = 32; off >= 1; off >>= 1) { ps = fmin(ps, __shfl_xor(ps, off)); ds = fmin(ds, __shfl_xor(ds, off)); }
+      if (lane == 0) { B.step_stage[rec * 2] = ps; B.step_stage[rec * 2 + 1] = ds; }
+      ps_min = fmin(ps_min, ps); ds_min = fmin(ds_min, ds);
     };
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      // joint limits (rows 0 .. 71) and acceleration limits: decoded above
-      if (!impulse && level >= r_thr[t]) candidate(r_sgn[t] * (sr[r_xoff[t]] - r_bound[t]), r_sgn[t] * dvec[r_doff[t]], t ? sl1 : sl0, t ? dl1 : dl0);
-    }
-    {
-      // friction-cone rows (second row of lanes C_FRIC - 64 ..) and ContactDistance rows
-      const int row = lane + 64;
-      if (row >= L::C_FRIC && row < L::C_ACC) {
-        const int fr = row - L::C_FRIC, c = fr / 5, r = fr - 5 * c;
-        const int ck = impulse ? ck_imp : ck_stage;
-        if (r < coneRows(ck) && (impulse ? use_icone != 0 : use_cone != 0) && ((amask >> c) & 1)) {
-          double J[3];
-          const double f[3] = {sr[L::S_F + 3 * c], sr[L::S_F + 3 * c + 1], sr[L::S_F + 3 * c + 2]};
-          const double g = coneRow(ck, cmu, r, f, J);
-          candidate(g, J[0] * dfs[3 * c] + J[1] * dfs[3 * c + 1] + J[2] * dfs[3 * c + 2], sl1, dl1);
-        }
-      } else if (row >= L::C_CD && row < L::NCON) {
-        // ContactDistance of a contact that is not active (contact_distance.cpp:105-146): g = - z, dg = - J_c dq, both from the ext record
-        const int c = row - L::C_CD;
-        if (B.ext != nullptr && use_cd && !impulse && level >= 2 && !((amask >> c) & 1)) {
-          const double* __restrict__ xx = B.ext + rec * L::EXT;
-          double acc = 0.0;
-          for (int q = 0; q < NV; ++q) acc += xx[L::X_CDJ + c * NV + q] * dx[q];
-          candidate(-xx[L::X_Z + c], -acc, sl1, dl1);
-        }
+    // iteration i of wavefront 0 is stage i; this wavefront takes stage i - 1 next to it
+    for (int i = 0; i <= M; i += 2) {
+      if (i >= 1) step(i - 1, RB);
+      blockLdsSync();
+      if (i + 1 <= M) {
+        step(i, RA);
+        blockLdsSync();
       }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { ps = fmin(ps, __shfl_xor(ps, off)); ds = fmin(ds, __shfl_xor(ds, off)); }
-    if (lane == 0) { B.step_stage[rec * 2] = ps; B.step_stage[rec * 2 + 1] = ds; }
-    ps_min = fmin(ps_min, ps); ds_min = fmin(ds_min, ds);
-    if (lane < NX) dx[lane] = dxn[lane];                       // (every reader of dx is past the barrier above or in this very lane's past)
-    waveLdsSync();
-  };
-  for (int i = 0; i < M; i += 2) {
-    step(i, RA);
-    if (i + 1 < M) step(i + 1, RB);
+    if (lane == 0) { B.step[b * 2] = ps_min; B.step[b * 2 + 1] = ds_min; }
   }
-  if (lane == 0) { B.step[b * 2] = ps_min; B.step[b * 2 + 1] = ds_min; }
 }
 
 __global__ __launch_bounds__(64) void ocp_reduce_steps_kernel(OcpBuffers B) {
@@ -1005,7 +1028,7 @@ void OcpLaunch<D>::expandPrimal(const OcpBuffers& B, long batch, int M, hipStrea
 template <typename D>
 void OcpLaunch<D>::forwardExpand(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st) {
   (void)M;
-  hipLaunchKernelGGL((ocp_forward_expand_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0);
+  hipLaunchKernelGGL((ocp_forward_expand_kernel<D>), dim3((unsigned)batch), dim3(128), 0, st, B, q0, v0);
 }
 template <typename D>
 void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
