@@ -803,9 +803,14 @@ def main():
         model = anymal_model()
         cost, cons = anymal_problem(model, trotting_ref=True, cone=args.friction_cone)
         nq, nv = model.nq, model.nv
+        # the batch of SURVEY 8(d) C3: instance b of the node starts from q_standing with base-xy and joints moved by 0.02 U(-1, 1) drawn from a
+        # generator seeded 20250 + b (numpy's generator here, std::mt19937_64 there), v = 0; the quaternion stays the identity
         q0 = np.tile(ANYMAL_Q_STANDING, (B, 1))
-        q0[:, 7:] += 0.01 * rng.uniform(-1, 1, (B, 12))          # every instance of the batch starts from a state of its own
-        v0 = 0.01 * rng.uniform(-1, 1, (B, nv))
+        for bi in range(B):
+            r_b = np.random.default_rng(20250 + rank * B + bi)
+            q0[bi, 0:2] += 0.02 * r_b.uniform(-1, 1, 2)
+            q0[bi, 7:] += 0.02 * r_b.uniform(-1, 1, 12)
+        v0 = np.zeros((B, nv))
         def build(batch):
             sv = HipOCP(model, cost, cons, T, N, batch=batch, device=local_rank, max_num_impulse=nimp + 1)
             trotting_sequence(sv, model, nimp)

@@ -86,15 +86,21 @@ __device__ unsigned long long g_k1_prof[16];
 #else
 #define K1_T(i) do { } while (0)
 #endif
+#ifndef K1_ROUNDS
+#define K1_ROUNDS 3
+#endif
+#ifndef K1_WAVES
+#define K1_WAVES 2
+#endif
 template <int NV, int MODE, bool BWD = false, bool TASK = false, bool ZAX = false>
-__global__ __launch_bounds__(64, 2) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
+__global__ __launch_bounds__(64, K1_WAVES) void un_linearize_kernel(UnBuffers B, const double* __restrict__ q0 = nullptr,
                                                           const double* __restrict__ v0 = nullptr) {
   using L = UnLayout<NV>;
   constexpr int LPS = 3 * NV;        // lanes per stage (phase B and the rest of the kernel)
   constexpr int SPW = 64 / LPS;      // stages per round
-  constexpr int SPA = 64 / NV;       // stages per wavefront: phase A of the analytic recursion has a lane per (stage, joint)
-  constexpr int ROUNDS = SPA / SPW;
-  static_assert(SPA == SPW * ROUNDS, "whole rounds");
+  constexpr int ROUNDS = K1_ROUNDS;
+  constexpr int SPA = SPW * ROUNDS;  // stages per wavefront: phase A of the analytic recursion has a lane per (stage, joint)
+  static_assert(SPA * NV <= 64, "whole rounds");
   constexpr int BLK = RneaBlock::LEN;
   // s_dyn: the dyn records of the round's stages as they go to memory -- dID/d(q | v | a) [kind][c * NV + r], which the condensation reads
   // back, then ID, lu, diag(Quu).  s_po: the blocks of phase A, then (the rows are assembled by then) the kkt records of the round.
@@ -1624,7 +1630,7 @@ __global__ void un_square_kernel(double* __restrict__ out, const double* __restr
 // ------------------------------------------------------------ launchers ----
 template <int NV>
 void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t st) {
-    constexpr int SPA = 64 / NV;       // stages per wavefront of un_linearize_kernel
+    constexpr int SPA = (64 / (3 * NV)) * K1_ROUNDS;       // stages per wavefront of un_linearize_kernel
     const long units = batch * N;
     const dim3 grid((unsigned)((units + SPA - 1) / SPA));
     const double* none = nullptr;
@@ -1638,7 +1644,7 @@ void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t 
   }
 template <int NV>
 void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t st) {
-    constexpr int SPA = 64 / NV;       // stages per wavefront of un_linearize_kernel
+    constexpr int SPA = (64 / (3 * NV)) * K1_ROUNDS;       // stages per wavefront of un_linearize_kernel
     const long units = batch * N;
     const dim3 grid((unsigned)((units + SPA - 1) / SPA));
     const double* none = nullptr;
@@ -1709,8 +1715,8 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
   const unsigned inst_blocks = (unsigned)((batch + 3) / 4);
   switch (phase) {
     case 0:
-      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true, false, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
-      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
+      if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true, false, true>), dim3((unsigned)((batch * N + (64 / (3 * NV)) * K1_ROUNDS - 1) / ((64 / (3 * NV)) * K1_ROUNDS))), dim3(64), 0, st, B, q0, v0);
+      else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, true>), dim3((unsigned)((batch * N + (64 / (3 * NV)) * K1_ROUNDS - 1) / ((64 / (3 * NV)) * K1_ROUNDS))), dim3(64), 0, st, B, q0, v0);
       break;
     case 1: hipLaunchKernelGGL((unparnmpc_coarse_update_kernel<NV>), dim3((unsigned)((batch * N + K9U_SPB - 1) / K9U_SPB)), dim3(64 * K9U_SPB), 0, st, B); break;
     case 2: hipLaunchKernelGGL((unparnmpc_backward_serial_kernel<NV>), dim3(inst_blocks), dim3(64), 0, st, B); break;
@@ -1725,8 +1731,8 @@ void UnLaunch<NV>::parnmpcPhase(int phase, const UnBuffers& B, long batch, int N
 }
 template <int NV>
 void UnLaunch<NV>::parnmpcResidual(const UnBuffers& B, long batch, int N, const double* q0, const double* v0, hipStream_t st) {
-  if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true, false, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
-  else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + 64 / NV - 1) / (64 / NV))), dim3(64), 0, st, B, q0, v0);
+  if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true, false, true>), dim3((unsigned)((batch * N + (64 / (3 * NV)) * K1_ROUNDS - 1) / ((64 / (3 * NV)) * K1_ROUNDS))), dim3(64), 0, st, B, q0, v0);
+  else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, true>), dim3((unsigned)((batch * N + (64 / (3 * NV)) * K1_ROUNDS - 1) / ((64 / (3 * NV)) * K1_ROUNDS))), dim3(64), 0, st, B, q0, v0);
   hipLaunchKernelGGL((un_kkt_error_kernel<NV>), dim3((unsigned)batch), dim3(64), 0, st, B);
 }
 template <int NV>
