@@ -345,6 +345,13 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
         waveLdsSync();
         rneaAssembleA<D>(lane, sc, out);
         waveLdsSync();
+#ifdef IDOCP_K5_REP_AITEMS      // timing experiment: the a items a second time (idempotent) -- what they cost on wave 1's chain
+        asm volatile("" ::: "memory");
+        if (lane < RI::NA) rneaTangentItemA<D, XYY>(RI::a(lane), sc, out);
+        waveLdsSync();
+        rneaAssembleA<D>(lane, sc, out);
+        waveLdsSync();
+#endif
       }
       STAMPW(0);
       if (!RESIDUAL) {
