@@ -127,3 +127,31 @@ def test_default_choice_by_batch_size():
     assert lib.idocp_ocp_clone(small.h, C.byref(c)) == 0
     assert lib.idocp_ocp_fused_forward(c) == 1
     lib.idocp_ocp_destroy(c)
+
+
+def test_chains_longer_than_the_walk_keeps_in_lds_fall_back_to_s4_k6():
+    """The fused walk keeps the chain (slot, status word, two time steps per node) in LDS: OcpForwardExpandMaxChain = 320 nodes.  A longer chain
+    runs S4 + K6 whatever the handle was told, and is held to the oracle like any other."""
+    from helpers import OracleOCP, anymal_contact_points
+    m = anymal_model()
+    cost, cons = anymal_problem(m)
+    N, T = 330, 16.5
+    g = HipOCP(m, cost, cons, T, N, batch=2)
+    o = OracleOCP(m, cost, cons, T, N)
+    lib = capi.lib()
+    lib.idocp_ocp_fused_forward.argtypes = [C.c_void_p]
+    lib.idocp_ocp_set_fused_forward.argtypes = [C.c_void_p, C.c_int]
+    assert lib.idocp_ocp_set_fused_forward(g.h, 1) == 0
+    pts = anymal_contact_points(m)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in (g, o):
+        s.set_contact_status([1, 1, 1, 1], pts)
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    q[7:] += 0.02
+    assert g.update(0.0, q, v) == 0 and o.update(0.0, q, v) == 0
+    assert lib.idocp_ocp_fused_forward(g.h) == 0               # 331 nodes: the chain does not fit
+    for f in OCP_DIR_FIELDS:
+        assert rel_err(g.get(f, 1), o.get(f)) < 1e-9, f

@@ -346,7 +346,7 @@ def test_configs3_trotting_n256_chain_direction_and_iterates():
         referee_check(d_g, d_o, d_h, f)
         worst = max(worst, rel_err(d_g, d_o))
     print("configs[3] trotting N = 256: worst GPU-oracle distance of the first direction %.2e" % worst)
-    assert worst < 1e-6, worst                 # the cap against the FP64 oracle, stage by stage (the referee rule above is the bar)
+    assert worst < 1e-8, worst                 # the cap against the FP64 oracle, stage by stage (the referee rule above is the bar; observed 1.6e-9)
     ao, bo = o.step_sizes()
     ag, bg = g.step_sizes()
     assert abs(ag[0] - ao) < 1e-6 and abs(bg[0] - bo) < 1e-6
