@@ -578,6 +578,64 @@ __device__ __forceinline__ void mfmaTilePairTN(const double* X0, int xr0, const 
   }
 }
 
+// The same two tiles on v_mfma_f64_4x4x4_4b_f64 (round 5).  That form of the instruction reads its operands in the lane map above but only
+// multiplies the four diagonal 4 x 4 blocks -- D_b[i][j] = sum_k A[4 b + i][k] B[k][4 b + j] lands at lane 16 i + 4 b + j -- at 8 ns per
+// instruction instead of 59 (256 against 1024 multiply-adds: 1.85 x the rate, DESIGN_HISTORY 4.0a).  With B = sixteen rows of the tile as before
+// (X, lane li) and A = FOUR columns c0 + 4 q .. + 3 of it copied into all four blocks (Y column 4 q + (li & 3): an LDS broadcast read), one
+// instruction yields C[r0 + li][c0 + 4 q + g] at lane 16 g + li: register q of the accumulator layout of the tile.  A tile is thus up to four
+// independent one-register accumulations, and only the q's whose columns EXIST are computed: the stage blocks are 36, 18 and 12 wide, so of
+// the 14 tiles of phase H five are a quarter full or less (84 instructions of 59 ns become 216 of 8 ns).  Same operands per k-step as above.
+template <int KMAX>
+__device__ __forceinline__ void mfmaTilePairTN4(const double* X0, int xr0, const double* Y0, int yc0, const double* X1, int xr1, const double* Y1,
+                                                int yc1, int ldx, int ldy, int k, int lane, mfma_d4& acc0, mfma_d4& acc1) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int KS = (KMAX + 7) / 8;
+#ifdef IDOCP_K5_TILES_HYBRID
+  if (yc0 >= 16 && yc1 >= 16) { mfmaTilePairTN<KMAX>(X0, xr0, Y0, yc0, X1, xr1, Y1, yc1, ldx, ldy, k, lane, acc0, acc1); return; }
+#endif
+  const int li = lane & 15, g = lane >> 4, l4 = lane & 3;
+  const double* xp0 = X0 + ldx * (li < xr0 ? li : xr0 - 1) + 2 * g;
+  const double* xp1 = X1 + ldx * (li < xr1 ? li : xr1 - 1) + 2 * g;
+  d2 xa0[KS], xa1[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) { xa0[s] = *reinterpret_cast<const d2*>(xp0 + 8 * s); xa1[s] = *reinterpret_cast<const d2*>(xp1 + 8 * s); }
+  acc0 = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  acc1 = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  bool v0[KS], v1[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int kk = 8 * s + 2 * g;
+    v0[s] = kk < k; v1[s] = kk + 1 < k;
+    if (!v0[s]) xa0[s].x = 0.0;
+    if (!v1[s]) xa0[s].y = 0.0;
+    if (!v0[s]) xa1[s].x = 0.0;
+    if (!v1[s]) xa1[s].y = 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool on0 = 4 * q < yc0, on1 = 4 * q < yc1;      // (uniform: the tile has columns there)
+    if (!on0 && !on1) continue;
+    const int cq0 = 4 * q + l4 < yc0 ? 4 * q + l4 : (yc0 > 0 ? yc0 - 1 : 0), cq1 = 4 * q + l4 < yc1 ? 4 * q + l4 : (yc1 > 0 ? yc1 - 1 : 0);
+    const double* yp0 = Y0 + ldy * cq0 + 2 * g;
+    const double* yp1 = Y1 + ldy * cq1 + 2 * g;
+    d2 ya0[KS], ya1[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (on0) ya0[s] = *reinterpret_cast<const d2*>(yp0 + 8 * s);
+      if (on1) ya1[s] = *reinterpret_cast<const d2*>(yp1 + 8 * s);
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (on0) a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(v0[s] ? ya0[s].x : 0.0, xa0[s].x, a0, 0, 0, 0);
+      if (on1) a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(v0[s] ? ya1[s].x : 0.0, xa1[s].x, a1, 0, 0, 0);
+      if (on0) a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(v1[s] ? ya0[s].y : 0.0, xa0[s].y, a0, 0, 0, 0);
+      if (on1) a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(v1[s] ? ya1[s].y : 0.0, xa1[s].y, a1, 0, 0, 0);
+    }
+    acc0[q] = a0; acc1[q] = a1;
+  }
+}
+
 // store(r, c, value) for the elements of a tile at (r0, c0) that lie inside m x n
 template <typename Store>
 __device__ __forceinline__ void mfmaTileStore(const mfma_d4& acc, int r0, int c0, int m, int n, int lane, Store store) {

@@ -27,6 +27,14 @@
 
 namespace idocp_dev {
 
+// the tile products of K5 on the 4 x 4 x 4 form of the FP64 matrix instruction (dev_dense.hpp, mfmaTilePairTN4); -DIDOCP_K5_TILES16 brings
+// the 16 x 16 x 4 form of rounds 2 - 4 back
+#ifdef IDOCP_K5_TILES16
+#define K5_TILE_PAIR mfmaTilePairTN
+#else
+#define K5_TILE_PAIR mfmaTilePairTN4
+#endif
+
 __device__ __forceinline__ double ocpLimit(const OcpProblem* __restrict__ P, int comp, int r) {
   switch (comp) {
     case 0: return P->q_min[r];
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
     for (int jb = wave; jb < TX; jb += nt >> 6) {
       mfma_d4 a0, a1;
       const int r1 = dimvf > 16 ? dimvf - 16 : 1;
-      mfmaTilePairTN<RVF>(&sm[S::MJ], dimvf < 16 ? dimvf : 16, &sm[S::DIDC + SVF * 16 * jb], NX + 1 - 16 * jb, &sm[S::MJ + SVF * 16], r1,
+      K5_TILE_PAIR<RVF>(&sm[S::MJ], dimvf < 16 ? dimvf : 16, &sm[S::DIDC + SVF * 16 * jb], NX + 1 - 16 * jb, &sm[S::MJ + SVF * 16], r1,
                           &sm[S::DIDC + SVF * 16 * jb], NX + 1 - 16 * jb, SVF, SVF, dimvf, lane, a0, a1);
       auto put = [&](int r, int c, double v) { sm[S::MJD + r + SVF * c] = v; };
       mfmaTileStore(a0, 0, 16 * jb, dimvf, NX + 1, lane, put);
@@ -886,7 +894,7 @@ __global__ __launch_bounds__(256, 4) void ocp_condense_kernel(OcpBuffers B, cons
       operands(j, X0, xr0, Y0, yc0, r00, c00);
       operands(j + 1, X1, xr1, Y1, yc1, r01, c01);
       mfma_d4 a0, a1;
-      mfmaTilePairTN<RVF>(X0, xr0, Y0, yc0, X1, xr1, Y1, yc1, SVF, SVF, dimvf, lane, a0, a1);
+      K5_TILE_PAIR<RVF>(X0, xr0, Y0, yc0, X1, xr1, Y1, yc1, SVF, SVF, dimvf, lane, a0, a1);
       finish(j, a0, r00, c00);
       finish(j + 1, a1, r01, c01);
     };
