@@ -223,6 +223,77 @@ __device__ __forceinline__ double rowBcastN(double v, int n) {
     case 12: return rowBcast<12>(v); case 13: return rowBcast<13>(v); case 14: return rowBcast<14>(v); default: return rowBcast<15>(v);
   }
 }
+// Round 5: the same solve in the square-root-free form A = L D L^T (unit lower L) with the broadcast FUSED into the multiply-add.  One
+// wavefront per SIMD pays four cycles for every instruction it issues, so the phase costs what it issues: the round-4 form took
+// two v_mov_b32_dpp + two v_fma_f64 per (pivot, row) pair, a v_cndmask pair and a second Newton chain (sqrt next to 1 / sqrt) per pivot and
+// three instructions per pair of the backward substitution -- about 700 in all for N = 12.  gfx950 has the 64-bit DPP forms
+// `v_mov_b64_dpp` and `v_fmac_f64_dpp` (row_newbcast only), so `a -= bcast_c(u) * y` is ONE instruction; the pivot needs 1 / p only; the
+// diagonal needs no select (lane k's own entry is the pivot) and the backward substitution no scaling: 9 + 2 (N - 1 - k) instructions per
+// pivot and one per pair on the way back, about 310 for N = 12.  Same pivots, same update formulas up to the scaling by D (each product
+// u_r u_c / p is rounded once more or less than (u_r / sqrt p)(u_c / sqrt p)): as backward-stable as Eigen's LLT (tests/test_hybrid_gpu.py).
+// The instructions are inline assembly (the compiler does not fold a 64-bit DPP move into the multiply-add), which the hazard recogniser
+// does not look into: a DPP operand must not have been written by the two instructions before.  Every DPP operand below is either an entry
+// of `a` that the reciprocal chain of the pivot separates from its last update, or -- the pivot broadcast itself -- preceded by s_nop 1.
+template <int LANE>
+__device__ __forceinline__ void fmacNegRowBcast(double& acc, double u, double y) {       // acc -= u(lane LANE of the row of 16) * y
+  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(y), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ double rowBcastGuarded(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+  return r;
+}
+__device__ __forceinline__ void fmacNegRowBcastN(double& acc, double u, double y, int n) {      // (n is a constant after unrolling)
+  switch (n) {
+    case 0: fmacNegRowBcast<0>(acc, u, y); break;   case 1: fmacNegRowBcast<1>(acc, u, y); break;   case 2: fmacNegRowBcast<2>(acc, u, y); break;
+    case 3: fmacNegRowBcast<3>(acc, u, y); break;   case 4: fmacNegRowBcast<4>(acc, u, y); break;   case 5: fmacNegRowBcast<5>(acc, u, y); break;
+    case 6: fmacNegRowBcast<6>(acc, u, y); break;   case 7: fmacNegRowBcast<7>(acc, u, y); break;   case 8: fmacNegRowBcast<8>(acc, u, y); break;
+    case 9: fmacNegRowBcast<9>(acc, u, y); break;   case 10: fmacNegRowBcast<10>(acc, u, y); break; case 11: fmacNegRowBcast<11>(acc, u, y); break;
+    case 12: fmacNegRowBcast<12>(acc, u, y); break; case 13: fmacNegRowBcast<13>(acc, u, y); break; case 14: fmacNegRowBcast<14>(acc, u, y); break;
+    default: fmacNegRowBcast<15>(acc, u, y); break;
+  }
+}
+__device__ __forceinline__ double rowBcastGuardedN(double v, int n) {
+  switch (n) {
+    case 0: return rowBcastGuarded<0>(v);   case 1: return rowBcastGuarded<1>(v);   case 2: return rowBcastGuarded<2>(v);   case 3: return rowBcastGuarded<3>(v);
+    case 4: return rowBcastGuarded<4>(v);   case 5: return rowBcastGuarded<5>(v);   case 6: return rowBcastGuarded<6>(v);   case 7: return rowBcastGuarded<7>(v);
+    case 8: return rowBcastGuarded<8>(v);   case 9: return rowBcastGuarded<9>(v);   case 10: return rowBcastGuarded<10>(v); case 11: return rowBcastGuarded<11>(v);
+    case 12: return rowBcastGuarded<12>(v); case 13: return rowBcastGuarded<13>(v); case 14: return rowBcastGuarded<14>(v); default: return rowBcastGuarded<15>(v);
+  }
+}
+#ifndef IDOCP_CHOLESKY_LLT
+template <int N>
+__device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int lane, int* ok, double (&x)[N], int n = N) {
+  static_assert(N <= 16, "one matrix row per lane of a DPP row");
+  const int row = lane & 15;
+  double a[N];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double p = rowBcastGuardedN(a[k], k);      // d_k
+    bad = bad || !(p > 0.0);             // (one store at the end: a branch per step would split the steps into separate blocks)
+    const double ip = recipNewton(p);
+    const double lr = a[k] * ip;         // L(row, k)
+    const double z = x[k] * ip;          // entry k of D^-1 L^-1 b
+#pragma unroll
+    for (int c = k + 1; c < N; ++c) {
+      fmacNegRowBcastN(a[c], a[k], lr, c);      // A(row, c) -= A(c, k) L(row, k)
+      fmacNegRowBcastN(x[c], a[k], z, c);       // b_c -= A(c, k) z_k  ( = L(c, k) y_k )
+    }
+    a[k] = lr;
+    x[k] = z;
+  }
+#pragma unroll
+  for (int i = N - 1; i > 0; --i) {
+#pragma unroll
+    for (int r = 0; r < i; ++r) fmacNegRowBcastN(x[r], a[r], x[i], i);      // x_r -= L(i, r) x_i: row i of L lives in lane i
+  }
+  if (bad && lane == 0) *ok = 0;
+}
+#else
 template <int N>
 __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int lane, int* ok, double (&x)[N], int n = N) {
   static_assert(N <= 16, "one matrix row per lane of a DPP row");
@@ -265,6 +336,8 @@ __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int l
   if (bad && lane == 0) *ok = 0;
 }
 
+
+#endif
 
 // spdInverseRows for N <= 16 with the pivot row travelling as DPP row broadcasts (VGPR to VGPR, lane k of the row of 16 the matrix
 // lives in) instead of v_readlane: no scalar registers, no VALU-reads-SGPR wait states on the critical path of every pivot.

@@ -320,7 +320,7 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y,
 // the stores of this stage's would then complete at the first barrier after they were issued instead of under the stage's arithmetic.
 template <int NW> __device__ __forceinline__ void blockSync() {
   if constexpr (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-  else __syncthreads();
+  else blockLdsSync();      // (no s_waitcnt vmcnt(0): nothing passes between wavefronts through global memory)
 }
 
 template <typename D, int NT, bool HYBRID>
