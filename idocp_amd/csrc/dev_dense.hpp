@@ -11,6 +11,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace idocp_dev {
 
 // element (i, j) of a strided matrix view
@@ -236,12 +238,13 @@ __device__ __forceinline__ double rowBcastN(double v, int n) {
 // of `a` that the reciprocal chain of the pivot separates from its last update, or -- the pivot broadcast itself -- preceded by s_nop 1.
 template <int LANE>
 __device__ __forceinline__ void fmacNegRowBcast(double& acc, double u, double y) {       // acc -= u(lane LANE of the row of 16) * y
-  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(y), "n"(LANE));
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(y), "n"(LANE));
 }
-template <int LANE>
+template <int LANE, bool SPACED = false>      // SPACED: the caller has put two instructions between the last write of v and this read
 __device__ __forceinline__ double rowBcastGuarded(double v) {
   double r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+  if constexpr (SPACED) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
+  else asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(LANE));
   return r;
 }
 __device__ __forceinline__ void fmacNegRowBcastN(double& acc, double u, double y, int n) {      // (n is a constant after unrolling)
@@ -263,6 +266,16 @@ __device__ __forceinline__ double rowBcastGuardedN(double v, int n) {
   }
 }
 #ifndef IDOCP_CHOLESKY_LLT
+// The pivots are a dependent chain -- broadcast, reciprocal estimate, two Newton steps, scaling, the update of the next pivot: about eight
+// FP64 latencies per step, more than the step's 2 (N - 1 - k) independent updates take to issue.  The loop is therefore written one pivot
+// AHEAD: the update of the next pivot's own entry goes first, its broadcast and reciprocal chain start at once and the remaining updates of
+// step k are spread between the links of that chain.  The last Newton step is folded into the scaling (a x1 + (a x1) e1 instead of
+// a (x1 + x1 e1): one link less).
+// (compile-time loop: the pivot and column numbers are template arguments of the DPP instructions)
+template <int I, int E, typename F>
+__device__ __forceinline__ void staticFor(F&& f) {
+  if constexpr (I < E) { f(std::integral_constant<int, I>{}); staticFor<I + 1, E>(f); }
+}
 template <int N>
 __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int lane, int* ok, double (&x)[N], int n = N) {
   static_assert(N <= 16, "one matrix row per lane of a DPP row");
@@ -271,26 +284,53 @@ __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int l
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < N; ++j) a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0);
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const double p = rowBcastGuardedN(a[k], k);      // d_k
+  // reciprocal of the pivot as (x1, e1): 1 / p = x1 + x1 e1 up to the square of e1
+  double p = rowBcastGuarded<0>(a[0]);
+  double x1 = __builtin_amdgcn_rcp(p);
+  { const double e0 = __builtin_fma(-p, x1, 1.0); x1 = __builtin_fma(x1, e0, x1); }
+  double e1 = __builtin_fma(-p, x1, 1.0);
+  staticFor<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     bad = bad || !(p > 0.0);             // (one store at the end: a branch per step would split the steps into separate blocks)
-    const double ip = recipNewton(p);
-    const double lr = a[k] * ip;         // L(row, k)
-    const double z = x[k] * ip;          // entry k of D^-1 L^-1 b
-#pragma unroll
-    for (int c = k + 1; c < N; ++c) {
-      fmacNegRowBcastN(a[c], a[k], lr, c);      // A(row, c) -= A(c, k) L(row, k)
-      fmacNegRowBcastN(x[c], a[k], z, c);       // b_c -= A(c, k) z_k  ( = L(c, k) y_k )
-    }
+    const double t = a[k] * x1, tz = x[k] * x1;
+    const double lr = __builtin_fma(t, e1, t);         // L(row, k) = A(row, k) / d_k
+    const double z = __builtin_fma(tz, e1, tz);        // entry k of D^-1 L^-1 b
+    const double u = a[k];
     a[k] = lr;
     x[k] = z;
-  }
-#pragma unroll
-  for (int i = N - 1; i > 0; --i) {
-#pragma unroll
-    for (int r = 0; r < i; ++r) fmacNegRowBcastN(x[r], a[r], x[i], i);      // x_r -= L(i, r) x_i: row i of L lives in lane i
-  }
+    if constexpr (k + 1 < N) {
+      fmacNegRowBcast<k + 1>(a[k + 1], u, lr);         // the next pivot's entry first ...
+      fmacNegRowBcast<k + 1>(x[k + 1], u, z);
+      if constexpr (k + 2 < N) fmacNegRowBcast<k + 2>(a[k + 2], u, lr);
+      p = rowBcastGuarded<k + 1, (k + 2 < N)>(a[k + 1]);      // ... and its chain under the rest of this step's updates (two updates behind a[k + 1]'s: the DPP read is clear)
+      asm volatile("v_rcp_f64_e32 %0, %1" : "=v"(x1) : "v"(p));
+      // the updates left (column k + 2: x only) are dealt out in four parts between the links of the chain
+      constexpr int c0 = k + 2, left = N - c0 > 0 ? N - c0 : 0, q4 = (left + 3) / 4;
+      auto upd = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c > c0) fmacNegRowBcast<c>(a[c], u, lr);
+        fmacNegRowBcast<c>(x[c], u, z);
+      };
+      constexpr int c1 = c0 + q4 < N ? c0 + q4 : N, c2 = c0 + 2 * q4 < N ? c0 + 2 * q4 : N, c3 = c0 + 3 * q4 < N ? c0 + 3 * q4 : N;
+      // (the links are volatile assembly like the updates: the compiler knows no latency of inline assembly and pulls the chain together
+      // again otherwise.  s_nop 0: the reciprocal estimate is a transcendental, whose result the next instruction must not read.)
+      double e0;
+      staticFor<c0, c1>(upd);
+      asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(e0) : "v"(p), "v"(x1));
+      staticFor<c1, c2>(upd);
+      asm volatile("v_fmac_f64_e32 %0, %0, %1" : "+v"(x1) : "v"(e0));
+      staticFor<c2, c3>(upd);
+      asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e1) : "v"(p), "v"(x1));
+      staticFor<c3, N>(upd);
+    }
+  });
+  staticFor<0, N - 1>([&](auto ic) {
+    constexpr int i = N - 1 - decltype(ic)::value;
+    staticFor<0, i>([&](auto rc) {
+      constexpr int r = i - 1 - decltype(rc)::value;
+      fmacNegRowBcast<i>(x[r], a[r], x[i]);      // x_r -= L(i, r) x_i: row i of L lives in lane i; x_(i-1), the next multiplier, first
+    });
+  });
   if (bad && lane == 0) *ok = 0;
 }
 #else
@@ -383,6 +423,63 @@ __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// The forward half of choleskySolveRows in the L L^T form (the callers want W = L^-1 itself: A^-1 = W^T W), with the broadcast fused into the
+// multiply-add like there: pivot k costs a 64-bit DPP move, the reciprocal square root (estimate + two Newton steps), two scalings and
+// 2 (NP - 1 - k) v_fmac_f64_dpp -- the round-4 form took two 32-bit DPP moves and two v_fma_f64 per (pivot, row) pair, a second Newton chain for
+// sqrt(p) and a select pair per pivot (lane k's own entry is p / sqrt(p) like everybody's).  x: the lane's right-hand side (a unit vector for
+// the inverse).  The DPP operand L(row, k) is written by the first instruction of the scaling block; the second scaling and the s_nop are
+// the two wait states a DPP read of a fresh VALU result needs (inline assembly is invisible to the hazard recogniser).
+// Like the solve above the loop runs one pivot AHEAD: the next pivot's own entry is updated first, its broadcast and reciprocal-square-root
+// chain (estimate, two Newton steps: six links) start at once, and the other updates of the step are dealt out between the links.  Everything
+// is volatile assembly, i.e. in program order (the compiler knows no latency of inline assembly and pulls the chain together otherwise).
+// arrays of N; the pivot block is NP x NP (what lies beyond is identity padding that is never touched); n <= NP pivots are walked
+// (GUARD: n is a run-time number, the steps beyond it are skipped by a uniform branch).
+struct RsqrtChain {       // 1 / sqrt(p): x after link 5
+  double p, x, t, h, e;
+  template <int J> __device__ __forceinline__ void link() {
+    if constexpr (J == 0 || J == 3) asm volatile("s_nop 0\n\tv_mul_f64 %0, -%2, %3\n\tv_mul_f64 %1, 0.5, %3" : "=&v"(t), "=&v"(h) : "v"(p), "v"(x));
+    else if constexpr (J == 1 || J == 4) asm volatile("v_fma_f64 %0, %1, %2, 1.0" : "=v"(e) : "v"(t), "v"(x));
+    else if constexpr (J == 2 || J == 5) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(x) : "v"(h), "v"(e));
+  }
+};
+template <int N, int NP, bool GUARD>
+__device__ __forceinline__ void cholForwardFused(double (&a)[N], double (&x)[N], int& bad, int n) {
+  RsqrtChain ch;
+  ch.p = rowBcastGuarded<0>(a[0]);
+  asm volatile("v_rsq_f64_e32 %0, %1" : "=v"(ch.x) : "v"(ch.p));
+  staticFor<0, 6>([&](auto jc) { ch.template link<decltype(jc)::value>(); });
+  staticFor<0, NP>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (!GUARD || k < n) {
+      bad |= !(ch.p > 0.0);
+      asm volatile("" : "+v"(bad));      // (evaluated here: postponed to the end, the comparison keeps every pivot alive -- in scratch)
+      double lr;
+      // L(row, k) and y_k; the DPP reads of L(row, k) below need two wait states behind its write: the second scaling and the s_nop
+      asm volatile("v_mul_f64 %0, %2, %3\n\tv_mul_f64 %1, %1, %3\n\ts_nop 0" : "=&v"(lr), "+v"(x[k]) : "v"(a[k]), "v"(ch.x));
+      a[k] = lr;
+      auto upd = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        fmacNegRowBcast<c>(a[c], lr, lr);        // A(row, c) -= L(c, k) L(row, k)
+        fmacNegRowBcast<c>(x[c], lr, x[k]);      // b_c -= L(c, k) y_k
+      };
+      if constexpr (k + 1 < NP) {
+        upd(std::integral_constant<int, k + 1>{});
+        if constexpr (k + 2 < NP) fmacNegRowBcast<k + 2>(a[k + 2], lr, lr);
+        ch.p = rowBcastGuarded<k + 1, (k + 2 < NP)>(a[k + 1]);
+        asm volatile("v_rsq_f64_e32 %0, %1" : "=v"(ch.x) : "v"(ch.p));
+        constexpr int c0 = k + 2, cnt = NP - c0 > 0 ? NP - c0 : 0, q = cnt >= 6 ? (cnt + 5) / 6 : 1;      // a link behind every q columns
+        staticFor<c0, NP>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          if constexpr (c > c0) fmacNegRowBcast<c>(a[c], lr, lr);
+          fmacNegRowBcast<c>(x[c], lr, x[k]);
+          if constexpr ((c - c0 + 1) % q == 0 && (c - c0 + 1) / q <= 6) ch.template link<(c - c0 + 1) / q - 1>();
+        });
+        staticFor<(cnt / q < 6 ? cnt / q : 6), 6>([&](auto jc) { ch.template link<decltype(jc)::value>(); });
+      }
+    }
+  });
+}
+
 // Inverse of an SPD n x n block (n <= N <= 16, in place in LDS, column-major, leading dimension ld) by ONE wavefront as A^-1 = W^T W with
 // W = L^-1, A = L L^T.  Lane l < n holds row l of A and the right-hand side e_l; the pivots walk the rows with DPP row broadcasts as in
 // choleskySolveRows, forward substitution only (x = column l of L^-1); the columns meet in the scratch Wb (N x N doubles: Wb[k + ldw l] =
@@ -397,29 +494,7 @@ __device__ __forceinline__ void spdInverseCholDpp(double* A, int ld, int n, int 
   int bad = 0;
 #pragma unroll
   for (int j = 0; j < N; ++j) { a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0); x[j] = (j == row) ? 1.0 : 0.0; }
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < n) {
-      const double p = rowBcastN(a[k], k);
-      bad |= !(p > 0.0);
-      asm volatile("" : "+v"(bad));
-      double is = __builtin_amdgcn_rsq(p);
-      double e = __builtin_fma(-p * is, is, 1.0);
-      is = __builtin_fma(0.5 * is, e, is);
-      e = __builtin_fma(-p * is, is, 1.0);
-      is = __builtin_fma(0.5 * is, e, is);
-      const double lrk = a[k] * is;                      // column k of L (row k: p / sqrt(p))
-      x[k] *= is;
-#pragma unroll
-      for (int c = k + 1; c < N; ++c) {
-        const double lck = rowBcastN(lrk, c);
-        a[c] = __builtin_fma(-lrk, lck, a[c]);
-        x[c] = __builtin_fma(-lck, x[k], x[c]);
-      }
-#pragma unroll
-      for (int c = k + 1; c < N; ++c) asm volatile("" : "+v"(x[c]), "+v"(a[c]));      // (pins the updates to their step, see choleskySolveRows)
-    }
-  }
+  cholForwardFused<N, N, true>(a, x, bad, n);      // (pivots beyond n: the identity padding, nothing to do)
   if (lane < n) {
 #pragma unroll
     for (int k = 0; k < N; ++k) Wb[k + ldw * lane] = x[k];

@@ -119,24 +119,8 @@ __device__ __forceinline__ wtile cholInvPass16(double (&a)[16], int lane, int& b
   double x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = (k == li) ? 1.0 : 0.0;
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const double p = rowBcastN(a[k], k);
-    bad |= !(p > 0.0);
-    asm volatile("" : "+v"(bad));      // (evaluated here: postponed to the end, the comparison keeps all sixteen pivots alive -- in scratch)
-    double is, sq;
-    rsqrtNewton(p, is, sq);
-    const double lrk = (li == k) ? sq : a[k] * is;
-    x[k] *= is;
-#pragma unroll
-    for (int c = k + 1; c < NP; ++c) {
-      const double lck = rowBcastN(lrk, c);
-      a[c] -= lrk * lck;
-      x[c] -= lck * x[k];
-    }
-#pragma unroll
-    for (int c = k + 1; c < NP; ++c) asm volatile("" : "+v"(x[c]), "+v"(a[c]));      // (pins the updates to their step, see choleskySolveRows)
-  }
+  // (the rows / columns NP .. 15 of a padded block are the identity and never touched: the updates stop at NP)
+  cholForwardFused<16, NP, false>(a, x, bad, NP);
   return pickByGroup(x, g);
 }
 
