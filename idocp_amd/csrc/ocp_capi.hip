@@ -142,6 +142,7 @@ struct idocp_ocp {
   OcpNode* d_nodes_ls = nullptr;
   double* ext_try = nullptr;
   int fused_forward_mode = -1;        // idocp_ocp_set_fused_forward: -1 by batch size, 0 S4 + K6, 1 the fused forward sweep
+  int riccati_sweep_mode = -1;        // idocp_ocp_set_riccati_sweep: -1 by batch size, 0 one wavefront per instance (register-resident), 1 eight per instance
 };
 
 namespace {
@@ -1118,6 +1119,21 @@ static bool fusedForward(const idocp_ocp_t* h) {
   if (forced >= 0) return forced != 0;
   return h->batch >= min_batch;
 }
+// The backward sweep of a handful of instances (latency mode: one reference solver object is batch 1) runs eight wavefronts per instance --
+// measured on configs[2]: 0.79 / 0.83 against 0.855 / 0.858 ms at batch 1 / 16, 0.88 against 0.86 at 64.  IDOCP_RICCATI_WIDE_MAX_BATCH moves
+// the threshold, IDOCP_RICCATI_NT (ocp_riccati_kernel.hip) overrides everything.
+static bool wideSweep(const idocp_ocp_t* h) {
+  static const int max_batch = getenv("IDOCP_RICCATI_WIDE_MAX_BATCH") ? atoi(getenv("IDOCP_RICCATI_WIDE_MAX_BATCH")) : 16;
+  if (h->riccati_sweep_mode >= 0) return h->riccati_sweep_mode != 0;
+  return h->batch <= max_batch;
+}
+int idocp_ocp_set_riccati_sweep(idocp_ocp_t* h, int mode) {
+  if (!h || h->parnmpc || mode < -1 || mode > 1) return IDOCP_E_ARG;
+  h->riccati_sweep_mode = mode;
+  ++h->disc_epoch;                      // a captured hipGraph holds the other kernel
+  return IDOCP_OK;
+}
+int idocp_ocp_riccati_sweep(idocp_ocp_t* h) { return (h && !h->parnmpc && wideSweep(h)) ? 1 : 0; }
 // per handle: mode -1 = by batch size (the default), 0 = S4 + K6 + reduction, 1 = the fused forward sweep
 int idocp_ocp_set_fused_forward(idocp_ocp_t* h, int mode) {
   if (!h || h->parnmpc || mode < -1 || mode > 1) return IDOCP_E_ARG;
@@ -1139,7 +1155,7 @@ static int launchUpdateO(idocp_ocp_t* h, int M, const double* d_q, const double*
   OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   launchCondenseO(h, M, d_q);
-  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h));
   launchForwardO(h, M, d_q, d_v);
   OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
   HIP_TRY(hipGetLastError());
@@ -1159,7 +1175,7 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
     case 1: launchCondenseO(h, M, d_q); break;
     case 7: launchCondenseO(h, M, d_q, 1); break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
     case 8: launchCondenseO(h, M, d_q, 2); break;      // ... and the condensation launches proper
-    case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream); break;
+    case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h)); break;
     // 3: the forward sweep.  Since round 5 it expands as it walks (S4 + K6 + the step-size reduction in one kernel, ocp_forward_expand_kernel);
     // ids 4 and 5 are then empty.  IDOCP_FUSED_FORWARD=0 restores the three kernels behind ids 3, 4, 5.
     case 3: if (fusedForward(h)) OcpLaunch<DQ>::forwardExpand(h->B, h->batch, M, d_q, d_v, h->stream); else OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
@@ -1316,7 +1332,7 @@ int idocp_ocp_compute_direction(idocp_ocp_t* h, double t, const double* q, const
   OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
   if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
   launchCondenseO(h, M, h->d_q0);
-  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+  OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h));
   launchForwardO(h, M, h->d_q0, h->d_v0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1352,7 +1368,7 @@ int idocp_ocp_update_solution(idocp_ocp_t* h, double t, const double* q, const d
     OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
     if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
     launchCondenseO(h, M, h->d_q0);
-    OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream);
+    OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h));
     launchForwardO(h, M, h->d_q0, h->d_v0);
     HIP_TRY(hipGetLastError());
     if ((rc = runLineSearchO(h, h->d_q0))) return rc;
@@ -1968,6 +1984,7 @@ int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
   h->phases = src->phases; h->event_time = src->event_time; h->is_impulse = src->is_impulse; h->impulse_status = src->impulse_status;
   h->slice_begin = src->slice_begin; h->slice_end = src->slice_end;
   h->fused_forward_mode = src->fused_forward_mode;
+  h->riccati_sweep_mode = src->riccati_sweep_mode;
   h->filters = src->filters;                 // the line-search filter is part of the solver's state (LineSearch is a member of the reference's solvers)
   h->prob = src->prob;
   h->seq_dirty = true;                       // the chain is rebuilt (and uploaded) on first use

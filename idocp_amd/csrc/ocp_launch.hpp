@@ -23,7 +23,9 @@ struct OcpLaunch {
   static void residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st);   // K8
   static void condenseBackwardEuler(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, bool residual,
                                     hipStream_t st);                                          // K9a: ParNMPC stage (K5b with backward Euler)
-  static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st);  // S3
+  // S3.  wide: eight wavefronts per instance with P staged in LDS (latency mode, a handful of instances) instead of the register-resident
+  // sweep of one wavefront per instance
+  static void riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st, bool wide = false);
   static void riccatiForward(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);  // S4
   static void parnmpcInverse(const OcpBuffers& B, long batch, int M, hipStream_t st);            // K9w, or K9b with IDOCP_K9_WAVE=0
   static void parnmpcInverseWave(const OcpBuffers& B, long batch, int M, hipStream_t st);        // K9w (parnmpc_kkt_wave_kernel.hip)

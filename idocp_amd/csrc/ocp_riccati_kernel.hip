@@ -300,12 +300,22 @@ __device__ __forceinline__ void riccatiPhase5(const double* KM, const double* Y,
 }
 
 // the wavefront's share of a phase: FN<D, tile range of wave w>(args)
+#define RICCATI_TILES_CASE8(FN, NTILES, W, ...)                                                                                        \
+  case W: if constexpr (tileBegin(NTILES, W, 8) < tileBegin(NTILES, W + 1, 8)) FN<D, false, tileBegin(NTILES, W, 8), tileBegin(NTILES, W + 1, 8)>(__VA_ARGS__); break;
 #define RICCATI_TILES(FN, NTILES, ...)                                                                                                 \
   do {                                                                                                                                 \
     if constexpr (NW == 1) { FN<D, true, 0, NTILES>(__VA_ARGS__); }                                                                          \
     else if constexpr (NW == 2) {                                                                                                      \
       if (wave == 0) FN<D, false, tileBegin(NTILES, 0, 2), tileBegin(NTILES, 1, 2)>(__VA_ARGS__);                                            \
       else FN<D, false, tileBegin(NTILES, 1, 2), tileBegin(NTILES, 2, 2)>(__VA_ARGS__);                                                      \
+    } else if constexpr (NW == 8) {                                                                                                    \
+      switch (wave) {                                                                                                                  \
+        RICCATI_TILES_CASE8(FN, NTILES, 0, __VA_ARGS__) RICCATI_TILES_CASE8(FN, NTILES, 1, __VA_ARGS__)                                \
+        RICCATI_TILES_CASE8(FN, NTILES, 2, __VA_ARGS__) RICCATI_TILES_CASE8(FN, NTILES, 3, __VA_ARGS__)                                \
+        RICCATI_TILES_CASE8(FN, NTILES, 4, __VA_ARGS__) RICCATI_TILES_CASE8(FN, NTILES, 5, __VA_ARGS__)                                \
+        RICCATI_TILES_CASE8(FN, NTILES, 6, __VA_ARGS__) RICCATI_TILES_CASE8(FN, NTILES, 7, __VA_ARGS__)                                \
+        default: break;                                                                                                                \
+      }                                                                                                                                \
     } else {                                                                                                                           \
       if (wave == 0) FN<D, false, tileBegin(NTILES, 0, 4), tileBegin(NTILES, 1, 4)>(__VA_ARGS__);                                            \
       else if (wave == 1) FN<D, false, tileBegin(NTILES, 1, 4), tileBegin(NTILES, 2, 4)>(__VA_ARGS__);                                       \
@@ -324,7 +334,7 @@ template <int NW> __device__ __forceinline__ void blockSync() {
 }
 
 template <typename D, int NT, bool HYBRID>
-__global__ __launch_bounds__(NT, NT == 64 ? 1 : 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
+__global__ __launch_bounds__(NT, (NT == 64 || NT == 512) ? 1 : 2) void ocp_riccati_backward_kernel(OcpBuffers B) {
   using L = OcpLayout<D>;
   using S = RiccatiSmem<D>;
   constexpr int NV = D::NV, NX = D::NX, NU = D::NU, NN = NV * NV, NF = D::NF, LDW = S::LDW, NW = NT / 64;
@@ -1554,7 +1564,7 @@ __global__ __launch_bounds__(64) void ocp_riccati_forward_kernel(OcpBuffers B, c
 }
 
 template <typename D>
-void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st) {
+void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool hybrid, hipStream_t st, bool wide) {
   (void)M;
   const size_t smem = RiccatiSmem<D>::TOTAL * sizeof(double), smem_h = smem;      // the Schur blocks alias dead ones
   static bool configured = false;
@@ -1565,11 +1575,21 @@ void OcpLaunch<D>::riccatiBackward(const OcpBuffers& B, long batch, int M, bool 
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
     (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h);
+    (void)hipFuncSetAttribute((const void*)ocp_riccati_backward_kernel<D, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
   static const int nt_env = getenv("IDOCP_RICCATI_NT") ? atoi(getenv("IDOCP_RICCATI_NT")) : 0;
   // round 4: the register-resident sweep (one wavefront per instance at every batch size); IDOCP_RICCATI_REG=0 selects the round-2 kernels
   static const int reg_env = getenv("IDOCP_RICCATI_REG") ? atoi(getenv("IDOCP_RICCATI_REG")) : 1;
+  // Latency mode (a handful of instances, idocp_ocp_set_riccati_sweep): EIGHT wavefronts per instance on the LDS-staged kernel -- the tile
+  // products of a phase run side by side on the four matrix cores of a CU instead of one behind the other on one (batch 1: 0.79 against
+  // 0.855 ms per sweep; from 64 instances on the register-resident sweep wins: 0.884 against 0.859 ms)
+  if (nt_env == 512 || (nt_env == 0 && wide)) {
+    if (hybrid) hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 512, true>), dim3((unsigned)batch), dim3(512), smem_h, st, B);
+    else hipLaunchKernelGGL((ocp_riccati_backward_kernel<D, 512, false>), dim3((unsigned)batch), dim3(512), smem, st, B);
+    return;
+  }
   if (reg_env && nt_env == 0) {
     const size_t rs = RiccatiRegSmem<D>::BYTES;
     static bool reg_configured = false;
@@ -1607,7 +1627,7 @@ void OcpLaunch<D>::riccatiForward(const OcpBuffers& B, long batch, int M, const 
   hipLaunchKernelGGL((ocp_riccati_forward_kernel<D>), dim3((unsigned)batch), dim3(64), 0, st, B, q0, v0);
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::riccatiBackward(const OcpBuffers&, long, int, bool, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::riccatiBackward(const OcpBuffers&, long, int, bool, hipStream_t, bool);
 template void OcpLaunch<LeggedDims<4, 3>>::riccatiForward(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 
 }  // namespace idocp_dev

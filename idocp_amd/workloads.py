@@ -475,6 +475,10 @@ class HipOCP:
         if os.environ.get("IDOCP_TEST_FUSED_FORWARD") in ("0", "1"):
             self.lib.idocp_ocp_set_fused_forward.argtypes = [C.c_void_p, C.c_int]
             capi.check(self.lib.idocp_ocp_set_fused_forward(self.h, int(os.environ["IDOCP_TEST_FUSED_FORWARD"])), "set_fused_forward")
+        # tests/test_riccati_sweep_gpu.py: likewise the form of the backward sweep (0: one wavefront per instance, 1: eight)
+        if os.environ.get("IDOCP_TEST_RICCATI_SWEEP") in ("0", "1"):
+            self.lib.idocp_ocp_set_riccati_sweep.argtypes = [C.c_void_p, C.c_int]
+            capi.check(self.lib.idocp_ocp_set_riccati_sweep(self.h, int(os.environ["IDOCP_TEST_RICCATI_SWEEP"])), "set_riccati_sweep")
 
     # ---- contact sequences with discrete events
     def push_back_contact_status(self, active, points, switching_time):

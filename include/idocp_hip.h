@@ -658,6 +658,13 @@ int idocp_ocp_fused_forward(idocp_ocp_t* h);
 /* mode -1: by batch size (default); 0: S4 + K6 + reduction; 1: the fused forward sweep -- per handle (tuning / the parity tests of both forms) */
 int idocp_ocp_set_fused_forward(idocp_ocp_t* h, int mode);
 
+/* The backward Riccati sweep S3 (riccati_recursion_solver.cpp:48-107) has two forms: one wavefront per instance with P in registers (batches:
+ * the throughput form) and eight wavefronts per instance with P staged in LDS (a handful of instances: the latency form, 8 % faster at batch
+ * 1).  idocp_ocp_riccati_sweep(h): 1 when the handle runs the latency form.  set: mode -1 by batch size (default: batch <= 16 ->
+ * latency form; IDOCP_RICCATI_WIDE_MAX_BATCH moves the threshold), 0 throughput form, 1 latency form -- per handle, copied by clone. */
+int idocp_ocp_riccati_sweep(idocp_ocp_t* h);
+int idocp_ocp_set_riccati_sweep(idocp_ocp_t* h, int mode);
+
 const char* idocp_last_error(void);
 const char* idocp_version(void);
 
