@@ -372,8 +372,9 @@ __global__ __launch_bounds__(64, K1_WAVES) void un_linearize_kernel(UnBuffers B,
         const IpmRow row = ipmResidual(sgn, u, limitOf(P, c, r), sl, du, P->barrier);
         lu += sgn * dt * du;
         if (MODE == 0) {
-          lu += sgn * dt * (du * row.residual - row.duality) / sl;
-          h += dt * du / sl;
+          const double isl = recipNewton(sl);      // (slacks are positive: estimate + two Newton steps instead of two division sequences)
+          lu += sgn * dt * (du * row.residual - row.duality) * isl;
+          h += dt * du * isl;
         } else {
           e_con += row.residual * row.residual + row.duality * row.duality;
         }
@@ -437,8 +438,9 @@ __global__ __launch_bounds__(64, K1_WAVES) void un_linearize_kernel(UnBuffers B,
           const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, k), sl, du, P->barrier);
           l += sgn * dt * du;
           if (MODE == 0) {
-            l += sgn * dt * (du * row.residual - row.duality) / sl;
-            h += dt * du / sl;
+            const double isl = recipNewton(sl);
+            l += sgn * dt * (du * row.residual - row.duality) * isl;
+            h += dt * du * isl;
           } else {
             e_con += row.residual * row.residual + row.duality * row.duality;
           }
@@ -691,7 +693,9 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
 
     // SplitUnRiccatiFactorizer::backwardRiccatiRecursion (split_unriccati_factorizer.hxx:30-46):
     // Eigen::LLT(Qaa) done redundantly by every lane, then each lane solves its own columns.
-    double Lm[NV][NV];
+    // (sqrt and 1 / sqrt of a pivot from the hardware estimate + Newton steps, dev_dense.hpp: the library sqrt and the division sequence were
+    // 216 of the 1 580 instructions of a stage, all of them on the chain of the pivots)
+    double Lm[NV][NV], Linv[NV];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -699,9 +703,10 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
 #pragma unroll
       for (int m = 0; m < j; ++m) d -= Lm[j][m] * Lm[j][m];
       ok = ok && (d > 0.0);
-      const double ljj = sqrt(d);
-      const double inv = 1.0 / ljj;
+      double ljj, inv;
+      rsqrtNewton(d > 0.0 ? d : 1.0, inv, ljj);      // (a failed pivot is reported through `ok`; the lanes go on with finite numbers)
       Lm[j][j] = ljj;
+      Linv[j] = inv;
 #pragma unroll
       for (int r = j + 1; r < NV; ++r) {
         double t = sQaa[j * NV + r];
@@ -718,14 +723,14 @@ __global__ __launch_bounds__(64) void un_riccati_backward_kernel(UnBuffers B) {
     for (int r = 0; r < NV; ++r) {           // forward substitution  L y = b
 #pragma unroll
       for (int m = 0; m < r; ++m) { Kq[r] -= Lm[r][m] * Kq[m]; Kv[r] -= Lm[r][m] * Kv[m]; kv[r] -= Lm[r][m] * kv[m]; }
-      const double inv = 1.0 / Lm[r][r];
+      const double inv = Linv[r];
       Kq[r] *= inv; Kv[r] *= inv; kv[r] *= inv;
     }
 #pragma unroll
     for (int r = NV - 1; r >= 0; --r) {      // backward substitution  L^T x = y
 #pragma unroll
       for (int m = r + 1; m < NV; ++m) { Kq[r] -= Lm[m][r] * Kq[m]; Kv[r] -= Lm[m][r] * Kv[m]; kv[r] -= Lm[m][r] * kv[m]; }
-      const double inv = 1.0 / Lm[r][r];
+      const double inv = Linv[r];
       Kq[r] *= inv; Kv[r] *= inv; kv[r] *= inv;
     }
     // GK = Qaa K (backward_unriccati_recursion_factorizer.hxx:68)
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(64) void un_expand_kernel(UnBuffers B) {
     const double sl = c < 6 ? slack[c * NV + r] : B.slack_a[su * 2 * NV + (c - 6) * NV + r], dl = c < 6 ? dual[c * NV + r] : B.dual_a[su * 2 * NV + (c - 6) * NV + r];
     const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
     const double dslack = -sgn * dx - row.residual;
-    const double ddual = -(dl * dslack + row.duality) / sl;
+    const double ddual = -(dl * dslack + row.duality) * recipNewton(sl);
     ps = fractionToBoundary(P->fraction_rate, sl, dslack, ps);
     ds = fractionToBoundary(P->fraction_rate, dl, ddual, ds);
   }
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(64) void un_integrate_kernel(UnBuffers B) {
     const double sl = *slp, dl = *dlp;
     const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
     const double dslack = -sgn * dx - row.residual;
-    const double ddual = -(dl * dslack + row.duality) / sl;
+    const double ddual = -(dl * dslack + row.duality) * recipNewton(sl);
     if (active) { *slp = sl + ap * dslack; *dlp = dl + ad * ddual; }
   }
 }
@@ -1447,7 +1452,7 @@ __global__ __launch_bounds__(64) void unparnmpc_expand_kernel(UnBuffers B) {
     const double sl = c < 6 ? slack[c * NV + r] : B.slack_a[su * 2 * NV + (c - 6) * NV + r], dl = c < 6 ? dual[c * NV + r] : B.dual_a[su * 2 * NV + (c - 6) * NV + r];
     const IpmRow row = ipmResidual(sgn, x, limitOf(P, c, r), sl, dl, P->barrier);
     const double dslack = -sgn * dx - row.residual;
-    const double ddual = -(dl * dslack + row.duality) / sl;
+    const double ddual = -(dl * dslack + row.duality) * recipNewton(sl);
     ps = fractionToBoundary(P->fraction_rate, sl, dslack, ps);
     ds = fractionToBoundary(P->fraction_rate, dl, ddual, ds);
   }
