@@ -42,10 +42,7 @@ __device__ __forceinline__ bool ocpRowValid2(const OcpProblem* __restrict__ P, i
   return comp == 6 && P->use_friction_cone != 0;
 }
 __device__ __forceinline__ double f2b(double rate, double x, double dx, double cur) {
-  // x / dx through the reciprocal estimate + two Newton steps (a third of the instructions of the division sequence; three candidates per lane
-  // and stage).  Only dx < 0 can give a step in (0, 1) (x > 0); for dx >= 0 or a vanishing dx the product is negative, infinite or NaN
-  // and the comparisons keep `cur`, as x / dx does.
-  const double f = rate * x * recipNewton(-dx);
+  const double f = -rate * (x / dx);
   return (f > 0.0 && f < 1.0 && f < cur) ? f : cur;
 }
 
@@ -285,7 +282,7 @@ __global__ __launch_bounds__(64) void ocp_expand_primal_kernel(OcpBuffers B) {
     const double sl = sl_r[t], dl = dl_r[t];
     const double res = g + sl, duality = sl * dl - P->barrier;
     const double dslack = -dg - res;
-    const double ddual = -(dl * dslack + duality) * recipNewton(sl);
+    const double ddual = -(dl * dslack + duality) / sl;
     ps = f2b(P->fraction_rate, sl, dslack, ps);
     ds = f2b(P->fraction_rate, dl, ddual, ds);
   }
@@ -589,7 +586,7 @@ __global__ __launch_bounds__(128, 1) void ocp_forward_expand_kernel(OcpBuffers B
       auto candidate = [&](double g, double dg, double sl, double dl) {
         const double res = g + sl, duality = sl * dl - barrier;
         const double dslack = -dg - res;
-        const double ddual = -(dl * dslack + duality) * recipNewton(sl);
+        const double ddual = -(dl * dslack + duality) / sl;
         ps = f2b(frate, sl, dslack, ps);
         ds = f2b(frate, dl, ddual, ds);
       };
@@ -689,7 +686,6 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
   const bool bwd = P->backward_euler != 0;          // ParNMPC: own dgmm, + Fqq_inv^T in the costate correction
   if (bwd && !stage) return;
   const double dt = nd->dt;                         // 1 on impulse stages
-  const double idt = recipNewton(dt);               // (the two divisions by dt below: a multiply each)
   const long rec = b * B.NS + nd->slot;
   const double ap = B.step[b * 2], ad = B.step[b * 2 + 1];
   double* __restrict__ dd = B.dir + rec * L::DIR;
@@ -768,7 +764,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       acc += __shfl_xor(acc, 4);
       if (r < 6 && part == 0) {
         acc += tl[L::E_LUP - TO + r];
-        const double v = nd->has_u ? -acc * idt : 0.0;
+        const double v = nd->has_u ? -acc / dt : 0.0;
         nup[r] = v; dd[L::D_NUP + r] = v;
       }
     }
@@ -777,7 +773,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       const int r = lane;
       double acc = 0.0;
       for (int p = 0; p < dimvf; ++p) acc += mj(r, p) * laf[p];
-      const double v = -acc * idt;
+      const double v = -acc / dt;
       dbm[r] = v;
       if (r < NV) dd[L::D_BETA + r] = v;
       else {
@@ -808,7 +804,7 @@ __global__ __launch_bounds__(64) void ocp_expand_dual_integrate_kernel(OcpBuffer
       if (valid) {
         const double res = g + sl, duality = sl * dl - P->barrier;
         dslack = -dg - res;
-        ddual = -(dl * dslack + duality) * recipNewton(sl);
+        ddual = -(dl * dslack + duality) / sl;
       } else if (ipmIdleConeRow<D>(P, nd, row)) {
         dslack = 1.0; ddual = 1.0;       // rows of inactive contacts (linearized_friction_cone.cpp:162-163)
       } else {

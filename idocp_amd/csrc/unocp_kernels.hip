@@ -42,7 +42,7 @@ __device__ __forceinline__ IpmRow ipmResidual(double sgn, double x, double lim, 
 
 // pdipm::FractionToBoundary for one row (pdipm.hxx:52-73)
 __device__ __forceinline__ double fractionToBoundary(double rate, double x, double dx, double cur) {
-  const double f = rate * x * recipNewton(-dx);      // (x / dx through the reciprocal estimate: see f2b, ocp_expand_kernel.hip)
+  const double f = -rate * (x / dx);
   return (f > 0.0 && f < 1.0 && f < cur) ? f : cur;
 }
 
