@@ -518,7 +518,7 @@ def run_parnmpc_stub(args, rank, local_rank, world, dist):
 # (pack + ncclSend / ncclRecv + unpack of a 74 kB halo, ~15 us over xGMI), the boundary exchange and two all-reduces (~0.1 ms).
 # On one GPU the two parts are this run's own HIP-event times; with G > 1 ranks they are the one-GPU figures of the committed
 # round-5 profile (profiles/r05_anymal_parnmpc_kernel_trace.txt), labelled as such.
-PARNMPC_MODEL_1GPU = {"anymal_parnmpc": {"stage_parallel_ms": 5.39, "sweeps_ms": 0.97}, "anymal_parnmpc_trotting": {"stage_parallel_ms": 6.8, "sweeps_ms": 1.1}}
+PARNMPC_MODEL_1GPU = {"anymal_parnmpc": {"stage_parallel_ms": 5.25, "sweeps_ms": 0.95}, "anymal_parnmpc_trotting": {"stage_parallel_ms": 6.8, "sweeps_ms": 1.1}}
 
 
 def parnmpc_model_ms(workload, world, ker=None):
