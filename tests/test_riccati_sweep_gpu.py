@@ -122,3 +122,51 @@ def test_default_choice_by_batch_size():
     assert lib.idocp_ocp_clone(small.h, C.byref(c)) == 0
     assert lib.idocp_ocp_riccati_sweep(c) == 0
     lib.idocp_ocp_destroy(c)
+
+
+def test_a_captured_graph_follows_the_switch(monkeypatch):
+    """idocp_ocp_update_solution_graph replays captured launches: switching the form of the sweep must invalidate the capture.  A handle
+    captures its iteration in the eight-wavefront form; a clone of it (same iterate, same form) and the handle itself are then switched to
+    the register-resident form; the clone steps eagerly, the handle through the graph: bitwise the same iterate (the two forms differ in
+    the last digits, so a stale capture shows)."""
+    import copy
+    torch = pytest.importorskip("torch")
+    m, r = _trotting_handle(1, 31, 1.55, 2, 2, monkeypatch)
+    lib = capi.lib()
+    lib.idocp_ocp_set_riccati_sweep.argtypes = [C.c_void_p, C.c_int]
+    lib.idocp_ocp_riccati_sweep.argtypes = [C.c_void_p]
+    lib.idocp_ocp_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    q = np.tile(ANYMAL_Q_STANDING, (2, 1))
+    q[:, 7:] += 0.01
+    dq = torch.tensor(q, dtype=torch.float64, device="cuda")
+    dv = torch.zeros((2, m.nv), dtype=torch.float64, device="cuda")
+    args = (C.c_double(0.0), C.c_void_p(dq.data_ptr()), C.c_void_p(dv.data_ptr()))
+    for _ in range(3):      # the first call launches eagerly, the second captures, the third replays -- in the eight-wavefront form
+        capi.check(lib.idocp_ocp_update_solution_graph(r.h, *args), "graph")
+    capi.check(lib.idocp_ocp_synchronize(r.h))
+    h2 = C.c_void_p()
+    capi.check(lib.idocp_ocp_clone(r.h, C.byref(h2)), "clone")
+    e = copy.copy(r)
+    e.h = h2
+    assert lib.idocp_ocp_riccati_sweep(e.h) == 1
+    for s_ in (r, e):
+        assert lib.idocp_ocp_set_riccati_sweep(s_.h, 0) == 0 and lib.idocp_ocp_riccati_sweep(s_.h) == 0
+    for _ in range(2):
+        capi.check(lib.idocp_ocp_update_solution_graph(r.h, *args), "graph after the switch")
+        capi.check(lib.idocp_ocp_update_solution_device(e.h, *args), "eager")
+    capi.check(lib.idocp_ocp_synchronize(r.h))
+    capi.check(lib.idocp_ocp_synchronize(e.h))
+    M = len(r.chain(0.0))
+    for f in ("q", "v", "a", "u", "f", "lmd", "gmm"):
+        assert np.array_equal(e.get_chain(f, M), r.get_chain(f, M)), f
+    # and the eight-wavefront form does differ in the last digits on this problem: the comparison above can tell a stale capture
+    w = copy.copy(r)
+    h3 = C.c_void_p()
+    capi.check(lib.idocp_ocp_clone(r.h, C.byref(h3)), "clone")
+    w.h = h3
+    assert lib.idocp_ocp_set_riccati_sweep(w.h, 1) == 0
+    capi.check(lib.idocp_ocp_update_solution_device(w.h, *args), "eager, eight wavefronts")
+    capi.check(lib.idocp_ocp_update_solution_device(e.h, *args), "eager, one wavefront")
+    capi.check(lib.idocp_ocp_synchronize(w.h))
+    capi.check(lib.idocp_ocp_synchronize(e.h))
+    assert any(not np.array_equal(e.get_chain(f, M), w.get_chain(f, M)) for f in ("q", "v", "a", "u", "f", "lmd", "gmm"))
