@@ -991,10 +991,10 @@ def main():
                          "whole_step_frac": a_stage * max(units.values()) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if KERNELS[dom] == "ocp_condense":
-            # what the fraction above does NOT say: the condensation kernel does not wait for these bytes, it is bound by
+            # what the fraction above does NOT say (DESIGN_HISTORY.md 4.0a): the condensation kernel does not wait for these bytes, it is bound by
             # FP64 vector issue -- v_fma_f64 runs at half rate on gfx950 (55 TFLOP/s measured), ~70 % of that pipe is busy
             out["roofline"]["note"] = ("algorithmic bytes against the HBM peak; the kernel itself is bound by FP64 vector issue "
-                                       "(half-rate v_fma_f64, ~70 % of the vector pipe busy; DESIGN.md 4.0a)")
+                                       "(half-rate v_fma_f64, ~70 % of the vector pipe busy; DESIGN_HISTORY.md 4.0a, DESIGN.md 7-1)")
         if not args.no_cpu_baseline and world == 1:              # a reported baseline: rank 0 of the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts, nimp=nimp)
         print(json.dumps(out), flush=True)
