@@ -436,8 +436,10 @@ __device__ __forceinline__ void waveLdsSync() {
 // (GUARD: n is a run-time number, the steps beyond it are skipped by a uniform branch).
 struct RsqrtChain {       // 1 / sqrt(p): x after link 5
   double p, x, t, h, e;
-  template <int J> __device__ __forceinline__ void link() {
-    if constexpr (J == 0 || J == 3) asm volatile("s_nop 0\n\tv_mul_f64 %0, -%2, %3\n\tv_mul_f64 %1, 0.5, %3" : "=&v"(t), "=&v"(h) : "v"(p), "v"(x));
+  // GUARD: the estimate is a transcendental whose result the next instruction must not read -- link 0 right behind it needs a wait state
+  template <int J, bool GUARD = false> __device__ __forceinline__ void link() {
+    if constexpr ((J == 0 || J == 3) && GUARD) asm volatile("s_nop 0\n\tv_mul_f64 %0, -%2, %3\n\tv_mul_f64 %1, 0.5, %3" : "=&v"(t), "=&v"(h) : "v"(p), "v"(x));
+    else if constexpr (J == 0 || J == 3) asm volatile("v_mul_f64 %0, -%2, %3\n\tv_mul_f64 %1, 0.5, %3" : "=&v"(t), "=&v"(h) : "v"(p), "v"(x));
     else if constexpr (J == 1 || J == 4) asm volatile("v_fma_f64 %0, %1, %2, 1.0" : "=v"(e) : "v"(t), "v"(x));
     else if constexpr (J == 2 || J == 5) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(x) : "v"(h), "v"(e));
   }
@@ -447,7 +449,7 @@ __device__ __forceinline__ void cholForwardFused(double (&a)[N], double (&x)[N],
   RsqrtChain ch;
   ch.p = rowBcastGuarded<0>(a[0]);
   asm volatile("v_rsq_f64_e32 %0, %1" : "=v"(ch.x) : "v"(ch.p));
-  staticFor<0, 6>([&](auto jc) { ch.template link<decltype(jc)::value>(); });
+  staticFor<0, 6>([&](auto jc) { ch.template link<decltype(jc)::value, (decltype(jc)::value == 0)>(); });
   staticFor<0, NP>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if (!GUARD || k < n) {
@@ -474,7 +476,7 @@ __device__ __forceinline__ void cholForwardFused(double (&a)[N], double (&x)[N],
           fmacNegRowBcast<c>(x[c], lr, x[k]);
           if constexpr ((c - c0 + 1) % q == 0 && (c - c0 + 1) / q <= 6) ch.template link<(c - c0 + 1) / q - 1>();
         });
-        staticFor<(cnt / q < 6 ? cnt / q : 6), 6>([&](auto jc) { ch.template link<decltype(jc)::value>(); });
+        staticFor<(cnt / q < 6 ? cnt / q : 6), 6>([&](auto jc) { ch.template link<decltype(jc)::value, (decltype(jc)::value == 0)>(); });      // (link 0 here: nothing lay between it and the estimate)
       }
     }
   });

@@ -55,7 +55,8 @@ struct KktWaveSmem {
   static_assert(NX * NX <= NBUF && QPART <= NBUF && FPART <= NBUF && L::NK * 16 <= NBUF, "everything that passes through BUF");
   static constexpr int BUF = 0, CPAD = BUF + NBUF,      // CPAD: 0, -1, dt, 1 (structural entries of F^T read like data)
                        TS = CPAD + 4, RED = TS + 16 * LDT, Y2 = RED + 4 * 48, T1 = Y2 + 48, ZZ = T1 + 48, R1 = ZZ + 48, DIR = R1 + NX,
-                       TOTAL = DIR + NX + NQ_ + 4;
+                       DUMP = DIR + NX + NQ_ + 4,      // where the entries of an output tile that lie outside its block are written (no branch around the store)
+                       TOTAL = DUMP + 2;
   static_assert(TS % 2 == 0, "16-byte pieces");
 };
 
@@ -322,8 +323,9 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
   auto stageTile = [&](const wtile& Z, int r0, int nrow, int c0, int ncol) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      // (every lane stores: a branch around each of the 126 stores of a stage cost five instructions of mask bookkeeping apiece)
       const int c = c0 + 4 * q + g;
-      if (li < nrow && c >= 0 && c < ncol) sm[S::BUF + (r0 + li) + NK * c] = Z[q];
+      sm[(li < nrow && c >= 0 && c < ncol) ? S::BUF + (r0 + li) + NK * c : S::DUMP] = Z[q];
     }
   };
   auto flushBlock = [&](int first_col, int ncol) {
@@ -635,7 +637,7 @@ struct KktWaveSmemG {
   static_assert(L::K_QXX == 0 && L::K_QXU < L::K_QUU && L::K_FQQ == QPART && QPART % 2 == 0 && FPART % 2 == 0, "record order");
   static_assert(NX * NX <= NBUF && QPART <= NBUF && PHIX + NF * NX <= NBUF && L::NKG * 16 <= NBUF, "everything that passes through BUF");
   static constexpr int BUF = 0, CPAD = BUF + NBUF, TS = CPAD + 4, RED = TS + 16 * LDT, Y2 = RED + 4 * 48, T1 = Y2 + 48, ZZ = T1 + 48, R1 = ZZ + 48,
-                       DIR = R1 + 48, TOTAL = DIR + 48 + 48 + 4;
+                       DIR = R1 + 48, DUMP = DIR + 48 + 48 + 4, TOTAL = DUMP + 2;
   static_assert(TS % 2 == 0, "16-byte pieces");
 };
 
@@ -837,8 +839,9 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_general_kernel
   auto stageTile = [&](const wtile& Z, int r0, int nrow, int c0, int ncol) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      // (every lane stores: a branch around each of the 126 stores of a stage cost five instructions of mask bookkeeping apiece)
       const int c = c0 + 4 * q + g;
-      if (li < nrow && c >= 0 && c < ncol) sm[S::BUF + (r0 + li) + NK * c] = Z[q];
+      sm[(li < nrow && c >= 0 && c < ncol) ? S::BUF + (r0 + li) + NK * c : S::DUMP] = Z[q];
     }
   };
   // the same for a tile whose columns are VARIABLES 16 bz + li of the padded order (w padded to NU, q, v): kinv row nr + the true index
