@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
   tile_t Qc[6];
   auto stageIn = [&]() {
 #pragma unroll
-    for (int t = 0; t < PF; ++t) { const int e = lane + 64 * t; if (e < SL2) reinterpret_cast<rd2*>(&sm[S::PM])[e] = pre[t]; }
+    for (int t = 0; t < PF; ++t) { const int e = lane + 64 * t; if (64 * t + 63 < SL2 || e < SL2) reinterpret_cast<rd2*>(&sm[S::PM])[e] = pre[t]; }      // (only the last piece is partial: the others store without a mask)
     waveLdsSync();
     const double* kk = &sm[S::PM];
 #pragma unroll
