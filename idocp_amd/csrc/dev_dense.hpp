@@ -283,7 +283,7 @@ __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int l
   double a[N];
   bool bad = false;
 #pragma unroll
-  for (int j = 0; j < N; ++j) a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0);
+  for (int j = 0; j < N; ++j) { const double v = A[(row < n ? row : n - 1) + ld * j]; a[j] = (row < n && j < n) ? v : ((j == row) ? 1.0 : 0.0); }      // (every lane reads -- from a row that exists --, then selects: no mask around the N loads)
   // reciprocal of the pivot as (x1, e1): 1 / p = x1 + x1 e1 up to the square of e1
   double p = rowBcastGuarded<0>(a[0]);
   double x1 = __builtin_amdgcn_rcp(p);
@@ -341,7 +341,7 @@ __device__ __forceinline__ void choleskySolveRows(const double* A, int ld, int l
   double a[N], dinv = 1.0;      // dinv: 1 / L_kk, kept by the lanes of row k
   bool bad = false;
 #pragma unroll
-  for (int j = 0; j < N; ++j) a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0);
+  for (int j = 0; j < N; ++j) { const double v = A[(row < n ? row : n - 1) + ld * j]; a[j] = (row < n && j < n) ? v : ((j == row) ? 1.0 : 0.0); }      // (every lane reads -- from a row that exists --, then selects: no mask around the N loads)
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const double p = rowBcastN(a[k], k);
@@ -495,7 +495,7 @@ __device__ __forceinline__ void spdInverseCholDpp(double* A, int ld, int n, int 
   double a[N], x[N];
   int bad = 0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) { a[j] = (row < n && j < n) ? A[row + ld * j] : ((j == row) ? 1.0 : 0.0); x[j] = (j == row) ? 1.0 : 0.0; }
+  for (int j = 0; j < N; ++j) { const double v = A[(row < n ? row : n - 1) + ld * j]; a[j] = (row < n && j < n) ? v : ((j == row) ? 1.0 : 0.0); x[j] = (j == row) ? 1.0 : 0.0; }
   cholForwardFused<N, N, true>(a, x, bad, n);      // (pivots beyond n: the identity padding, nothing to do)
   if (lane < n) {
 #pragma unroll
