@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_kernel(OcpBuff
 #pragma unroll
     for (int t = 0; t < (NK * 16 / 2 + 63) / 64; ++t) {
       const int e = lane + 64 * t;
-      if (e < n2) dst[e] = reinterpret_cast<const v2d*>(&sm[S::BUF])[e];
+      if (64 * t + 63 < n2 || e < n2) dst[e] = reinterpret_cast<const v2d*>(&sm[S::BUF])[e];      // (only the last piece of a block is partial)
     }
     waveLdsSync();
   };
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64, 2) void parnmpc_kkt_inverse_wave_general_kernel
 #pragma unroll
     for (int t = 0; t < (NK * 16 / 2 + 63) / 64; ++t) {
       const int e = lane + 64 * t;
-      if (e < n2) dst[e] = reinterpret_cast<const v2d*>(&sm[S::BUF])[e];
+      if (64 * t + 63 < n2 || e < n2) dst[e] = reinterpret_cast<const v2d*>(&sm[S::BUF])[e];      // (only the last piece of a block is partial)
     }
     waveLdsSync();
   };
