@@ -1265,111 +1265,119 @@ __global__ __launch_bounds__(64, 1) void ocp_riccati_backward_reg_kernel(OcpBuff
       for (int t = 0; t < NWL; ++t) { const int e = lane + 64 * t; if (e < W2A + W2B) reinterpret_cast<rd2*>(&sm[S::WL])[e] = wl[t]; }
       waveLdsSync();
       CSTAMP(1);
-      const double* Phiu = &sm[S::WL_PHIU];
-      const double* Phix = &sm[S::WL_PHIX];
-      const double* Pv = &sm[S::WL_P];
-      for (int e = lane; e < dimi * NU; e += 64) {                // DGinv = Phiu Ginv
-        const int c = e / dimi, j = e - c * dimi;
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < NU; ++m) acc += Phiu[j + NF * m] * sm[S::GW + m + NU * c];
-        sm[S::DG + j + NF * c] = acc;
-      }
-      waveLdsSync();
-      for (int e = lane; e < dimi * dimi; e += 64) {              // S = DGinv Phiu^T
-        const int c = e / dimi, j = e - c * dimi;
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * Phiu[c + NF * m];
-        sm[S::SS + j + NF * c] = acc;
-      }
-      waveLdsSync();
-      CSTAMP(2);
-      // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves (llt_s_.solve, :64-66, 71-74), lane = column.  dimi is 3 per foot that
-      // touches down: the trotting and running gaits bring two feet down at a time, so the 6-row instantiation serves them
-      static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
-      auto sSolve = [&](auto ntag) {
-        constexpr int NR = decltype(ntag)::value;
-        double x[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          double val = 0.0;
-          if (j < dimi) val = lane < NU ? sm[S::DG + j + NF * lane] : (lane < NU + NX ? Phix[j + NF * (lane - NU)] : (lane == NU + NX ? Pv[j] : 0.0));
-          x[j] = val;
+      // The algebra of the switching rows loops over dimi, a run-time number: three per foot that touches down.  The gaits of the configs bring two
+      // feet down at a time, so the block exists a second time with dimi = 6 at compile time (the divisions by it become shifts, the
+      // six-term loops unroll and their LDS reads are in flight together): same operations in the same order, bitwise the same results.
+      auto switchingRows = [&](auto ditag) {
+        constexpr int DI = decltype(ditag)::value;
+        const int dimi_ = DI > 0 ? DI : dimi;
+        const double* Phiu = &sm[S::WL_PHIU];
+        const double* Phix = &sm[S::WL_PHIX];
+        const double* Pv = &sm[S::WL_P];
+        for (int e = lane; e < dimi_ * NU; e += 64) {                // DGinv = Phiu Ginv
+          const int c = e / dimi_, j = e - c * dimi_;
+          double acc = 0.0;
+  #pragma unroll
+          for (int m = 0; m < NU; ++m) acc += Phiu[j + NF * m] * sm[S::GW + m + NU * c];
+          sm[S::DG + j + NF * c] = acc;
         }
-        choleskySolveRows<NR>(&sm[S::SS], NF, lane, &s_ok, x, dimi);
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          if (j < dimi) {
-            if (lane < NU) sm[S::SDG + j + NF * lane] = x[j];
-            else if (lane < NU + NX) sm[S::MMX + j + NF * (lane - NU)] = x[j];
-            else if (lane == NU + NX) sm[S::MV + j] = x[j];
+        waveLdsSync();
+        for (int e = lane; e < dimi_ * dimi_; e += 64) {              // S = DGinv Phiu^T
+          const int c = e / dimi_, j = e - c * dimi_;
+          double acc = 0.0;
+  #pragma unroll
+          for (int m = 0; m < NU; ++m) acc += sm[S::DG + j + NF * m] * Phiu[c + NF * m];
+          sm[S::SS + j + NF * c] = acc;
+        }
+        waveLdsSync();
+        CSTAMP(2);
+        // S = L L^T and S^-1 [DGinv, Phix, P] by triangular solves (llt_s_.solve, :64-66, 71-74), lane = column.  dimi is 3 per foot that
+        // touches down: the trotting and running gaits bring two feet down at a time, so the 6-row instantiation serves them
+        static_assert(NU + NX + 1 <= 64, "one lane per right-hand side");
+        auto sSolve = [&](auto ntag) {
+          constexpr int NR = decltype(ntag)::value;
+          double x[NR];
+  #pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            double val = 0.0;
+            if (j < dimi_) val = lane < NU ? sm[S::DG + j + NF * lane] : (lane < NU + NX ? Phix[j + NF * (lane - NU)] : (lane == NU + NX ? Pv[j] : 0.0));
+            x[j] = val;
+          }
+          choleskySolveRows<NR>(&sm[S::SS], NF, lane, &s_ok, x, dimi_);
+  #pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            if (j < dimi_) {
+              if (lane < NU) sm[S::SDG + j + NF * lane] = x[j];
+              else if (lane < NU + NX) sm[S::MMX + j + NF * (lane - NU)] = x[j];
+              else if (lane == NU + NX) sm[S::MV + j] = x[j];
+            }
+          }
+        };
+        if (dimi_ <= 6) sSolve(std::integral_constant<int, 6>{}); else sSolve(std::integral_constant<int, NF>{});
+        waveLdsSync();
+        CSTAMP(3);
+        for (int e = lane; e < NU * NU; e += 64) {                  // Ginv -= SinvDGinv^T DGinv
+          const int c = e / NU, r = e - c * NU;
+          double acc = 0.0;
+          for (int l = 0; l < dimi_; ++l) acc += sm[S::SDG + l + NF * r] * sm[S::DG + l + NF * c];
+          sm[S::GW + e] -= acc;
+        }
+        waveLdsSync();
+        {
+          // K = -Ginv Qxu^T - SinvDGinv^T Phix, k = -Ginv lu - SinvDGinv^T P with the updated Ginv (:67-70)
+          for (int e = lane; e < NU * NX; e += 64) {
+            const int c = e / NU, j = e - c * NU;
+            double acc = 0.0;
+  #pragma unroll
+            for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
+            for (int l = 0; l < dimi_; ++l) acc += sm[S::SDG + l + NF * j] * Phix[l + NF * c];
+            sm[S::KM + e] = -acc;
+          }
+          if (lane >= 64 - NU) {
+            const int j = lane - (64 - NU);
+            double acc = 0.0;
+  #pragma unroll
+            for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
+            for (int l = 0; l < dimi_; ++l) acc += sm[S::SDG + l + NF * j] * Pv[l];
+            sm[S::KVN + j] = -acc;
           }
         }
+        CSTAMP(4);
+        {
+          // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu
+          double* __restrict__ Ww = B.swc + rec * L::SWC;
+          for (int e = lane; e < dimi_ * NX; e += 64) {
+            const int c = e / dimi_, l = e - c * dimi_;
+            double acc = sm[S::MMX + l + NF * c];
+  #pragma unroll
+            for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
+            sm[S::MMX + l + NF * c] = acc;
+            Ww[L::W_M + l + NF * c] = acc;
+          }
+          if (lane < dimi_) {
+            const int l = lane;
+            double acc = sm[S::MV + l];
+            for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * lu[m];
+            sm[S::MV + l] = acc;
+            Ww[L::W_m + l] = acc;
+          }
+        }
+        waveLdsSync();
+        CSTAMP(5);
+        for (int e = lane; e < NU * NX; e += 64) {                  // DtM = Phiu^T M (:88)
+          const int c = e / NU, m = e - c * NU;
+          double acc = 0.0;
+          for (int l = 0; l < dimi_; ++l) acc += Phiu[l + NF * m] * sm[S::MMX + l + NF * c];
+          sm[S::DTM + m + NU * c] = acc;
+        }
+        if (lane < NX) {                                            // Phix^T m (:98-99)
+          double acc = 0.0;
+          for (int l = 0; l < dimi_; ++l) acc += Phix[l + NF * lane] * sm[S::MV + l];
+          sm[S::SCORR + lane] = acc;
+        }
+        waveLdsSync();
       };
-      if (dimi <= 6) sSolve(std::integral_constant<int, 6>{}); else sSolve(std::integral_constant<int, NF>{});
-      waveLdsSync();
-      CSTAMP(3);
-      for (int e = lane; e < NU * NU; e += 64) {                  // Ginv -= SinvDGinv^T DGinv
-        const int c = e / NU, r = e - c * NU;
-        double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * r] * sm[S::DG + l + NF * c];
-        sm[S::GW + e] -= acc;
-      }
-      waveLdsSync();
-      {
-        // K = -Ginv Qxu^T - SinvDGinv^T Phix, k = -Ginv lu - SinvDGinv^T P with the updated Ginv (:67-70)
-        for (int e = lane; e < NU * NX; e += 64) {
-          const int c = e / NU, j = e - c * NU;
-          double acc = 0.0;
-#pragma unroll
-          for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * Qxu[c + NX * m];
-          for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Phix[l + NF * c];
-          sm[S::KM + e] = -acc;
-        }
-        if (lane >= 64 - NU) {
-          const int j = lane - (64 - NU);
-          double acc = 0.0;
-#pragma unroll
-          for (int m = 0; m < NU; ++m) acc += sm[S::GW + j + NU * m] * lu[m];
-          for (int l = 0; l < dimi; ++l) acc += sm[S::SDG + l + NF * j] * Pv[l];
-          sm[S::KVN + j] = -acc;
-        }
-      }
-      CSTAMP(4);
-      {
-        // multiplier policy dxi = M dx + m (:71-74): M = S^-1 Phix - SinvDGinv Qxu^T, m = S^-1 P - SinvDGinv lu
-        double* __restrict__ Ww = B.swc + rec * L::SWC;
-        for (int e = lane; e < dimi * NX; e += 64) {
-          const int c = e / dimi, l = e - c * dimi;
-          double acc = sm[S::MMX + l + NF * c];
-#pragma unroll
-          for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * Qxu[c + NX * m];
-          sm[S::MMX + l + NF * c] = acc;
-          Ww[L::W_M + l + NF * c] = acc;
-        }
-        if (lane < dimi) {
-          const int l = lane;
-          double acc = sm[S::MV + l];
-          for (int m = 0; m < NU; ++m) acc -= sm[S::SDG + l + NF * m] * lu[m];
-          sm[S::MV + l] = acc;
-          Ww[L::W_m + l] = acc;
-        }
-      }
-      waveLdsSync();
-      CSTAMP(5);
-      for (int e = lane; e < NU * NX; e += 64) {                  // DtM = Phiu^T M (:88)
-        const int c = e / NU, m = e - c * NU;
-        double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += Phiu[l + NF * m] * sm[S::MMX + l + NF * c];
-        sm[S::DTM + m + NU * c] = acc;
-      }
-      if (lane < NX) {                                            // Phix^T m (:98-99)
-        double acc = 0.0;
-        for (int l = 0; l < dimi; ++l) acc += Phix[l + NF * lane] * sm[S::MV + l];
-        sm[S::SCORR + lane] = acc;
-      }
-      waveLdsSync();
+      if (dimi == 6) switchingRows(std::integral_constant<int, 6>{}); else switchingRows(std::integral_constant<int, 0>{});
       CSTAMP(6);
       riccatiPhase4<D, true, 0, 3>(Quu, &sm[S::KM], &sm[S::GK], lane);     // GK = Quu K (backward_riccati_recursion_factorizer.hxx:128)
       waveLdsSync();
