@@ -31,8 +31,78 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector / matrix spec peak (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+# algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 4: A_stage = 8 [n_s + 2 n_c + n_d + 2 n_c + 2 (n_P + n_sP) + n_K] at the LARGEST stage
+# class of the workload (ANYmal: 12 contact rows); the per-class figures are a_stage_of() below
 A_STAGE = {"iiwa14": 5544, "iiwa14_task_space": 5544, "iiwa14_unparnmpc": 5656, "anymal": 25032, "anymal_trotting": 25032, "anymal_running": 25032, "anymal_parnmpc": 25032,
-           "anymal_parnmpc_trotting": 25032}    # algorithmic bytes per stage, SURVEY.md 8(d) / DESIGN.md 6
+           "anymal_parnmpc_trotting": 25032}
+
+
+def a_stage_of(kind, dimf, sw_dimi=0, nv=18, nu=12):
+    """SURVEY 8(d)'s formula evaluated for ONE stage of an ANYmal chain by its class (the survey quotes the nf = 12 stage, 25 032 B):
+    n_s solution doubles, n_c inequality rows, n_d direction doubles, P / s hand-off written and read once, gain written.
+      grid / aux / lift stage with nf contact rows: n_s = 127 + 2 nf (+ xi), n_c = 72 + 5 nf / 3, n_d = 126 + 2 nf (+ dxi), n_K = nu (2 nv + 1)
+      impulse stage (no u, no nu_passive, impulse friction cone only): n_s = 109 + 2 nf, n_c = 5 nf / 3, n_d = 108 + 2 nf, n_K = 0
+      terminal stage: n_s = 4 nv + 1, n_d = 4 nv, nothing else but P, s"""
+    n_P, n_sP = 3 * nv * nv, 2 * nv
+    if kind == "terminal":
+        n_s, n_c, n_d, n_K = 4 * nv + 1, 0, 4 * nv, 0
+    elif kind == "impulse":
+        n_s, n_c, n_d, n_K = 6 * nv + 1 + 2 * dimf, 5 * dimf // 3, 6 * nv + 2 * dimf, 0
+    else:
+        n_s, n_c, n_d, n_K = 6 * nv + 1 + nu + 6 + 2 * dimf + sw_dimi, 6 * nu + 5 * dimf // 3, 6 * nv + nu + 6 + 2 * dimf + sw_dimi, nu * (2 * nv + 1)
+    return 8 * (n_s + 2 * n_c + n_d + 2 * n_c + 2 * (n_P + n_sP) + n_K)
+
+
+def oracle_flops_record(workload, chain_stages):
+    """FLOPs of one SQP iteration of ONE instance by region, from tests/golden/oracle_flops.json -- DATA: the exact operation counts of the
+    CPU restatement taken by its counting build (oracle/flops.hpp, tests/golden/gen_oracle_flops.py; tests/test_oracle_flops.py holds the
+    file to a live recount).  None when the file has no entry for this workload at this chain length."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_flops.json")))
+    except (OSError, ValueError):
+        return None
+    w = rec.get("workloads", {}).get({"iiwa14_task_space": "iiwa14"}.get(workload, workload))
+    if not w or w.get("chain_stages") != chain_stages:
+        return None
+    return {"regions": {n: sum(r.values()) for n, r in w["regions"].items() if n != "other"}, "kernel_regions": rec["kernel_regions"],
+            "flop_per_iteration": w["flop_per_iteration"]}
+
+
+def kernel_flops(rec, kernel):
+    """FLOPs per instance and iteration of the regions a kernel of the product executes (kernel_regions of the record)"""
+    alias = {"ocp_nominal": "ocp_nominal+ocp_rnea(switch)", "ocp_rnea": None, "parnmpc_backward_serial": "parnmpc_corrections"}
+    key = alias.get(kernel, kernel)
+    regs = rec["kernel_regions"].get(key) if key else None
+    if not regs:
+        return None
+    return sum(rec["regions"].get(r, 0) for r in regs)
+
+
+def quoted_sq(workload, batch, horizon, kernel):
+    """Issue counters of `kernel` from the newest committed SQ record of this workload (profiles/rNN_pmc_sq_<workload>.json, written by
+    profiles/make_sq_json.py from the rocprofv3 --pmc SQ_* passes of profiles/run_profiles.sh ... sq) -- a QUOTATION under the same rule
+    as quoted_traffic: same workload / batch / horizon, the kernel's own name, not older than the newest kernel trace."""
+    import glob
+    import re
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_%s.json" % workload)), reverse=True)
+    if not recs:
+        return None, "no committed SQ counter record for this workload"
+    rnd = lambda path: int(re.match(r"r(\d+)_", os.path.basename(path)).group(1))
+    traces = glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_trace.txt" % workload))
+    try:
+        rec = json.load(open(recs[0]))
+    except Exception as e:
+        return None, "unreadable record %s (%s)" % (os.path.basename(recs[0]), e)
+    name = os.path.basename(recs[0])
+    if rec.get("batch") != batch or rec.get("horizon") != horizon:
+        return None, "profiles/%s was taken at batch %s / horizon %s, this run is %d / %d" % (name, rec.get("batch"), rec.get("horizon"), batch, horizon)
+    if rnd(recs[0]) < max([rnd(t) for t in traces], default=0):
+        return None, "profiles/%s predates the newest kernel trace of this workload" % name
+    val = rec.get("kernels", {}).get(kernel)
+    if val is None:
+        return None, "profiles/%s has no kernel named %s" % (name, kernel)
+    return val, "quoted from profiles/%s (round %s; rocprofv3 --pmc SQ_* passes of this command; not measured in this run)" % (name, rec.get("round"))
 
 
 def quoted_traffic(workload, batch, horizon, kernel):
@@ -399,26 +469,55 @@ def spawn_ranks(n, argv, timeout_s=None):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    def end_group(proc):
+        """SIGTERM, then SIGKILL, to the launcher's process group -- exactly the processes started here (a session of their own)"""
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(proc.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+
     with tempfile.TemporaryFile(mode="w+") as err:
         proc = subprocess.Popen(cmd, stderr=err, start_new_session=True)
+        # The ranks live in a session of their own, so a signal aimed at THIS process (a driver's SIGTERM, Ctrl-C) does not reach them:
+        # forward it -- SIGTERM / SIGINT / SIGHUP end the group before this process exits with 128 + signo -- and whatever else
+        # unwinds the wait (KeyboardInterrupt, an exception) ends the group in the `finally`.  No rank outlives its launcher.
+        interrupted = []
+
+        def forward(signo, _frame):
+            interrupted.append(signo)
+            raise KeyboardInterrupt
+
+        old = {}
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            try:
+                old[sg] = signal.signal(sg, forward)
+            except (ValueError, OSError):      # (not the main thread: the caller owns the signals)
+                pass
+        timed_out = False
         try:
-            rc = proc.wait(timeout=timeout_s)
-            timed_out = False
-        except subprocess.TimeoutExpired:
-            timed_out = True
-            for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
-                try:
-                    os.killpg(proc.pid, sig)
-                except ProcessLookupError:
-                    break
-                try:
-                    proc.wait(timeout=grace)
-                    break
-                except subprocess.TimeoutExpired:
-                    continue
-            rc = 124
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                timed_out = True
+                rc = 124
+        except KeyboardInterrupt:
+            rc = 128 + (interrupted[0] if interrupted else signal.SIGINT)
+        finally:
+            if proc.poll() is None:
+                end_group(proc)
+            for sg, h in old.items():
+                signal.signal(sg, h)
         err.seek(0)
         text = err.read()
+    if interrupted:
+        sys.stderr.write("bench.py: launcher received signal %d -- ended the %d ranks.\n" % (interrupted[0], n))
+        return rc
     if timed_out:
         sys.stderr.write("bench.py: the %d ranks did not finish within %.0f s -- ended them.  Last stderr of the ranks:\n%s\n" % (n, timeout_s, text[-4000:]))
     elif text:
@@ -952,11 +1051,14 @@ def main():
     ev = [[hip.event() for _ in range(len(KERNELS) + 1)] for _ in range(args.steps)]
     el = run_timed(step, sync, args.steps, args.warmup, dist, "cuda", ev)
 
-    # per-kernel average durations from the events of the timed region
+    # per-kernel average durations from the events of the timed region, and the per-step HIP-event time of every timed step (median and
+    # spread: a slow box moves all steps alike, a regression moves the median against the committed profile; boxes of this pool differ by ~5 %)
     kms = np.zeros(len(KERNELS))
+    step_ev = np.zeros(args.steps)
     for k in range(args.steps):
         for kid in range(len(KERNELS)):
             kms[kid] += hip.elapsed_ms(ev[k][kid], ev[k][kid + 1])
+        step_ev[k] = hip.elapsed_ms(ev[k][0], ev[k][len(KERNELS)])
     kms /= args.steps
     dom = int(np.argmax(kms))
     a_stage = A_STAGE[args.workload]
@@ -964,6 +1066,16 @@ def main():
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
     # HBM bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (quoted_traffic above)
     traffic, traffic_source = quoted_traffic(args.workload, B, N, KERNELS[dom])
+    # the same roofline priced class by class (ANYmal chains: a_stage_of() per stage of the chain) and with SURVEY's own unit count
+    # (N + 1 grid stages at the nf = 12 figure) -- `achieved` / `frac` above keep the chain-unit convention of rounds 1 - 5
+    by_class = None
+    if args.workload in ("anymal_trotting", "anymal_running", "anymal"):
+        ch = solver.chain(0.0)
+        per_chain = sum(a_stage_of(c["kind"], c["dimf"], c.get("sw_dimi", 0)) for c in ch)
+        by_class = {"bytes_per_iteration_by_stage_class": per_chain, "bytes_per_iteration_survey_N_plus_1": a_stage * (N + 1),
+                    "bytes_per_iteration_chain_units_at_nf12": a_stage * len(ch),
+                    "dominant_kernel_frac_by_stage_class": B * per_chain / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "dominant_kernel_frac_survey_N_plus_1": B * a_stage * (N + 1) / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     # parity guard inside the bench: the timed state must still be a valid solver state
     kkt = solver.kkt_error(0.0, q0, v0)
@@ -974,27 +1086,55 @@ def main():
         latency = latency_mode(lib, hip, build, q0, v0)
     if rank == 0:
         ms_step = 1e3 * el / args.steps
+        fused = KERNELS[riccati_ids[1]] == "ocp_forward_expand"
         out = {
             "metric": "SQP iterations/sec (whole node)", "value": whole_job_value(world, B, args.steps, el), "unit": "SQP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + "batch=%d independent OCP instances per GPU, replicas across GPUs" % B,
                        "horizon": N, "batch_per_gpu": B, "parallelism": "replicas x%d" % world,
-                       "ms_per_riccati_sweep": float(sum(kms[i] for i in riccati_ids)),
+                       # the sweeps under their own keys: with the fused forward sweep (batches of instances) the second kernel is S4 + K6 + the
+                       # step-size reduction in one walk, so the PAIR is not the "ms / Riccati sweep" of the metric -- that figure (S3 + S4 of one
+                       # instance, comparable with cpu_baseline.ms_per_riccati_sweep) is config.latency.ms_per_riccati_sweep
+                       "ms_backward_sweep": float(kms[riccati_ids[0]]),
+                       ("ms_forward_sweep_with_expansion" if fused else "ms_forward_sweep"): float(kms[riccati_ids[1]]),
+                       "ms_per_riccati_sweep": None if fused else float(sum(kms[i] for i in riccati_ids)),
                        "kernel_ms": {KERNELS[i]: float(kms[i]) for i in range(len(KERNELS))},
+                       "step_ms_hip_events": {"median": float(np.median(step_ev)), "min": float(step_ev.min()), "max": float(step_ev.max()),
+                                              "mean": float(step_ev.mean()), "note": "first to last event of each of the %d timed steps" % args.steps},
                        "max_kkt_error_after": float(np.max(kkt)), "latency": latency},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kms[dom]),
                          # the whole iteration's compulsory bytes over the whole step: one unit per stage of the CHAIN (event stages
                          # included -- 120 for the default workload, not N + 1 = 101), i.e. the largest per-launch unit count
-                         "whole_step_frac": a_stage * max(units.values()) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "whole_step_frac": a_stage * max(units.values()) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "by_stage_class": by_class},
         }
+        # the FP64 roofline of the same kernel: exact FLOPs of the reference's formulation (oracle counting build) over the launch time
+        frec = oracle_flops_record(args.workload, max(units.values()) // B)
+        if frec is not None:
+            kf = kernel_flops(frec, KERNELS[dom])
+            if kf:
+                tfl = B * kf / (kms[dom] * 1e-3) / 1e12
+                out["roofline"]["flops"] = {"per_launch": B * kf, "achieved_tflops": tfl, "peak": FP64_PEAK_TFLOPS, "frac": tfl / FP64_PEAK_TFLOPS,
+                                            "whole_step_tflops": B * frec["flop_per_iteration"] / (ms_step * 1e-3) / 1e12,
+                                            "whole_step_frac": B * frec["flop_per_iteration"] / (ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                            "source": "tests/golden/oracle_flops.json: exact add + mul + div + sqrt counts of the CPU restatement's formulation "
+                                                      "(dense blocks, FMA = 2), regions of this kernel: " + ", ".join(frec["kernel_regions"].get(KERNELS[dom], []))}
+                sq, sq_source = quoted_sq(args.workload, B, N, KERNELS[dom])
+                if sq is not None:
+                    # lane utilisation: useful FP64 lane-operations (FMA-equivalents = FLOP / 2) over the lane slots the kernel issued on the
+                    # vector and matrix pipes (SQ_INSTS_VALU x 64; an FP64 MFMA 4x4x4_4b does 256 multiply-adds)
+                    out["roofline"]["flops"]["lane_utilisation"] = (B * kf / 2) / max(1.0, sq["valu_lane_slots_per_launch"])
+                    out["roofline"]["mfma_util"] = sq.get("mfma_util")
+                    out["roofline"]["sq"] = sq
+                out["roofline"]["sq_source"] = sq_source
         if KERNELS[dom] == "ocp_condense":
-            # what the fraction above does NOT say (DESIGN_HISTORY.md 4.0a): the condensation kernel does not wait for these bytes, it is bound by
-            # FP64 vector issue -- v_fma_f64 runs at half rate on gfx950 (55 TFLOP/s measured), ~70 % of that pipe is busy
-            out["roofline"]["note"] = ("algorithmic bytes against the HBM peak; the kernel itself is bound by FP64 vector issue "
-                                       "(half-rate v_fma_f64, ~70 % of the vector pipe busy; DESIGN_HISTORY.md 4.0a, DESIGN.md 7-1)")
+            # what the HBM fraction above does NOT say: the condensation kernel does not wait for these bytes; it is a latency / issue-bound
+            # FP64 kernel -- read roofline.flops and roofline.sq next to it
+            out["roofline"]["note"] = ("algorithmic bytes against the HBM peak; the kernel itself is latency / issue bound at four resident workgroups per CU "
+                                       "(DESIGN.md 3.2, 7-1): roofline.flops is its FP64 roofline, roofline.sq its issue counters")
         if not args.no_cpu_baseline and world == 1:              # a reported baseline: rank 0 of the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.workload, model, cost, cons, T, N, q0[0], v0[0], pts, nimp=nimp)
         print(json.dumps(out), flush=True)

@@ -143,6 +143,12 @@ struct idocp_ocp {
   double* ext_try = nullptr;
   int fused_forward_mode = -1;        // idocp_ocp_set_fused_forward: -1 by batch size, 0 S4 + K6, 1 the fused forward sweep
   int riccati_sweep_mode = -1;        // idocp_ocp_set_riccati_sweep: -1 by batch size, 0 one wavefront per instance (register-resident), 1 eight per instance
+  // staging of the per-stage setters (idocp_ocp_set_solution_stages / _chain, the aux-matrix setters): an MPC loop warm-starts every tick, so
+  // the device scratch and its pinned host twin are kept (grown on demand) and the setter returns without a stream synchronisation -- the
+  // copy and the fill kernel are stream-ordered in front of whatever the caller launches next; fill_done guards the reuse of the host twin
+  double *d_fill = nullptr, *h_fill = nullptr;
+  size_t fill_cap = 0;
+  hipEvent_t fill_done = nullptr;
 };
 
 namespace {
@@ -868,6 +874,9 @@ void idocp_ocp_destroy(idocp_ocp_t* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->d_fill) (void)hipFree(h->d_fill);
+  if (h->h_fill) (void)hipHostFree(h->h_fill);
+  if (h->fill_done) (void)hipEventDestroy(h->fill_done);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1044,13 +1053,23 @@ int idocp_ocp_set_solution(idocp_ocp_t* h, const char* name, const double* value
 
 // Warm start of an MPC loop: a field of every grid stage (slots 0 .. nstages - 1), the same for all instances.
 static int fillStagesO(idocp_ocp_t* h, double* rec, int stride, int offset, int dim, int nstages, const double* values, bool chain = false) {
-  double* d_vals = nullptr;
   const size_t bytes = (size_t)nstages * dim * sizeof(double);
-  HIP_TRY(hipMalloc((void**)&d_vals, bytes));
-  hipError_t e = hipMemcpyAsync(d_vals, values, bytes, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) { ocpFillStages(rec, stride, offset, dim, h->NS, nstages, h->batch, d_vals, h->stream, chain ? h->d_nodes : nullptr); e = hipStreamSynchronize(h->stream); }
-  (void)hipFree(d_vals);
-  HIP_TRY(e);
+  if (h->fill_done) HIP_TRY(hipEventSynchronize(h->fill_done));      // the previous setter's copy has left the host twin (normally long ago)
+  else HIP_TRY(hipEventCreateWithFlags(&h->fill_done, hipEventDisableTiming));
+  if (bytes > h->fill_cap) {
+    if (h->d_fill) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_fill); h->d_fill = nullptr; }
+    if (h->h_fill) { (void)hipHostFree(h->h_fill); h->h_fill = nullptr; }
+    h->fill_cap = 0;
+    const size_t cap = bytes + bytes / 2;
+    HIP_TRY(hipMalloc((void**)&h->d_fill, cap));
+    HIP_TRY(hipHostMalloc((void**)&h->h_fill, cap, hipHostMallocDefault));
+    h->fill_cap = cap;
+  }
+  std::memcpy(h->h_fill, values, bytes);                              // the caller's buffer is free when the call returns
+  HIP_TRY(hipMemcpyAsync(h->d_fill, h->h_fill, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipEventRecord(h->fill_done, h->stream));
+  ocpFillStages(rec, stride, offset, dim, h->NS, nstages, h->batch, h->d_fill, h->stream, chain ? h->d_nodes : nullptr);
+  HIP_TRY(hipGetLastError());
   return IDOCP_OK;
 }
 int idocp_ocp_set_solution_stages(idocp_ocp_t* h, const char* name, int nstages, const double* values) {

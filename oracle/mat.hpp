@@ -12,9 +12,14 @@
 #include <cstring>
 #include <vector>
 
+#include "flops.hpp"      // FLOP_REGION(...); `make liboracle_flops.so`: the scalar below becomes a counting double
+
 // Scalar of the restatement.  The default build is FP64 like the reference; `make liboracle_hp.so` builds the SAME sources with
 // -DORACLE_REAL="long double" (x87 extended precision, 64-bit significand): the high-precision REFEREE the parity tests use to
 // decide, where GPU and FP64 oracle disagree by more than 1e-10 on an ill-conditioned stage, which of the two is nearer the truth.
+#ifdef ORACLE_COUNT_FLOPS
+#define ORACLE_REAL oracle::Counted
+#endif
 #ifndef ORACLE_REAL
 #define ORACLE_REAL double
 #endif

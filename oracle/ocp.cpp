@@ -377,7 +377,7 @@ void OCPSolver::qRef(real t, Mat& q_ref) const {
   q_ref = Mat(robot.dimq());
   for (int i = 0; i < robot.dimq(); ++i) q_ref[i] = cost.q_ref[i];
   if (cost.use_time_varying_ref) {      // set_q_ref (time_varying_configuration_space_cost.hpp:98-109)
-    const real tau = t <= cost.tv_t_begin ? 0.0 : ((t < cost.tv_t_end ? t : cost.tv_t_end) - cost.tv_t_begin);
+    const real tau = t <= cost.tv_t_begin ? real(0.0) : ((t < cost.tv_t_end ? t : cost.tv_t_end) - cost.tv_t_begin);
     if (tau > 0.0) {
       Mat qb = q_ref, v(robot.dimv());
       for (int i = 0; i < robot.dimv(); ++i) v[i] = cost.v_ref[i];
@@ -407,6 +407,7 @@ void OCPSolver::qRef(real t, Mat& q_ref) const {
 // The two are the same computation with (dt_dyn, dt_q) = (dt, dt) vs (1, 0), "a" playing the role of dv, no torque
 // variables on the impulse stage, and the contact VELOCITY constraint instead of the Baumgarte constraint.
 void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool residual_only) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   const NodeC& nd = chain[p];
   const bool impulse = nd.kind == NodeC::Impulse;
   const SplitSolutionC& si = s[nd.slot];
@@ -416,8 +417,8 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   ContactDynamicsDataC& D = cd[nd.slot];
   const ContactStatus& cs = nodeContacts(p);
   const int nv = nv_, nu = nu_, dimf = cs.dimf();
-  const real dt = impulse ? 1.0 : nd.dt;          // scaling of cost / constraints / dynamics multipliers
-  const real dtq = impulse ? 0.0 : nd.dt;         // q+ = q (+) dtq v
+  const real dt = impulse ? real(1.0) : nd.dt;          // scaling of cost / constraints / dynamics multipliers
+  const real dtq = impulse ? real(0.0) : nd.dt;         // q+ = q (+) dtq v
   const real t = nd.t;
   if (impulse) robot.updateKinematics(si.q, si.v + si.a, Mat(nv));     // impulse_split_ocp.hxx:47
   else robot.updateKinematics(si.q, si.v, si.a);
@@ -570,6 +571,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   }
   // ---- ForwardSwitchingConstraint::linearizeSwitchingConstraint (forward_switching_constraint.hxx:27-66)
   SwitchingC& W = sw[nd.slot];
+  FLOP_REGION_SET(R_SWITCH);
   if (nd.sw_event >= 0) {
     const ContactStatus& is = seq.impulse_status[nd.sw_event];
     const int dimi = is.dimf();
@@ -593,6 +595,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   } else {
     W = SwitchingC();
   }
+  FLOP_REGION_SET(R_COST_CONSTRAINTS);
   if (residual_only) return;
   // ---- cost Hessian (configuration_space_cost.cpp:351-365; contact_force_cost.cpp:182-211)
   {
@@ -662,6 +665,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   }
   // ---- ContactDynamics::condenseContactDynamics (contact_dynamics.hxx:105-158) /
   //      ImpulseDynamicsForwardEuler::condenseImpulseDynamics (impulse_dynamics_forward_euler.hxx:59-105)
+  FLOP_REGION_SET(R_CONDENSE);
   Robot::computeMJtJinv(D.dIDda, D.dCda, D.MJtJinv);
   D.MJtJinv_dIDCdqv = D.MJtJinv * D.dIDCdqv;
   D.MJtJinv_IDC = D.MJtJinv * D.IDC;
@@ -693,6 +697,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   M.Fvv = (-dt) * D.MJtJinv_dIDCdqv.block(0, nv, nv, nv) + Mat::Identity(nv);
   for (int r = 0; r < nv; ++r) R.Fv[r] -= dt * D.MJtJinv_IDC[r];
   // ---- ContactDynamics::condenseSwitchingConstraint (contact_dynamics.hxx:193-199)
+  FLOP_REGION_SET(R_SWITCH);
   if (nd.sw_event >= 0) {
     W.Phix -= W.Phia * D.MJtJinv_dIDCdqv.block(0, 0, nv, 2 * nv);
     W.Phiu = W.Phia * D.MJtJinv.block(0, kP, nv, nu);
@@ -702,6 +707,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
 
 // TerminalOCP::linearizeOCP / computeKKTResidual (terminal_ocp.hxx:50-66, 118-131)
 void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool residual_only) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   const NodeC& nd = chain[p];
   const SplitSolutionC& sN = s[nd.slot];
   SplitKKTMatrixC& M = kkt_matrix[nd.slot];
@@ -803,7 +809,7 @@ real OCPSolver::KKTError() {
   for (int p = 0; p < M() - 1; ++p) {
     const NodeC& nd = chain[p];
     const SplitKKTResidualC& R = kkt_residual[nd.slot];
-    const real dt = nd.kind == NodeC::Impulse ? 1.0 : nd.dt;
+    const real dt = nd.kind == NodeC::Impulse ? real(1.0) : nd.dt;
     real e = R.lq.squaredNorm() + R.lv.squaredNorm() + R.la.squaredNorm() + R.lf.squaredNorm() + R.lu_passive.squaredNorm() +
                R.lu.squaredNorm() + R.Fq.squaredNorm() + R.Fv.squaredNorm() + dt * dt * cd[nd.slot].IDC.squaredNorm();
     real c2 = 0;
@@ -822,6 +828,7 @@ real OCPSolver::KKTError() {
 // ImpulseSplitRiccatiFactorizer::backwardRiccatiRecursion (impulse_backward_riccati_recursion_factorizer.hxx:30-107) --
 // the same recursion with Fqv = 0 and no control.
 void OCPSolver::backwardRiccatiRecursion() {
+  FLOP_REGION(R_RICCATI_BWD);
   const int nv = nv_, nu = nu_, nj = nv - 6;
   {
     const int sl = chain.back().slot;
@@ -834,7 +841,7 @@ void OCPSolver::backwardRiccatiRecursion() {
   for (int p = M() - 2; p >= 0; --p) {
     const NodeC& nd = chain[p];
     const bool impulse = nd.kind == NodeC::Impulse;
-    const real dt = impulse ? 0.0 : nd.dt;
+    const real dt = impulse ? real(0.0) : nd.dt;
     const int sl = nd.slot;
     const RiccatiC& rn = riccati[chain[p + 1].slot];
     SplitKKTMatrixC& Mx = kkt_matrix[sl];
@@ -953,6 +960,7 @@ void OCPSolver::backwardRiccatiRecursion() {
 // computeInitialStateDirection + forwardRiccatiRecursion (riccati_recursion_solver.cpp:110-162;
 // split_riccati_factorizer.hxx:103-128; impulse_split_riccati_factorizer.hxx:27-44)
 void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
+  FLOP_REGION(R_RICCATI_FWD);
   const int nv = nv_, nj = nv - 6;
   {
     const int s0 = chain[0].slot;
@@ -964,7 +972,7 @@ void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
     const NodeC& nd = chain[p];
     const int sl = nd.slot, sn = chain[p + 1].slot;
     const bool impulse = nd.kind == NodeC::Impulse;
-    const real dt = impulse ? 0.0 : nd.dt;
+    const real dt = impulse ? real(0.0) : nd.dt;
     const SplitKKTMatrixC& Mx = kkt_matrix[sl];
     const SplitKKTResidualC& R = kkt_residual[sl];
     Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
@@ -993,6 +1001,7 @@ static real fractionToBoundary(real rate, const Mat& vec, const Mat& dvec) {    
 
 // RiccatiRecursionSolver::computeDirection (riccati_recursion_solver.cpp:165-251)
 void OCPSolver::computeDirection() {
+  FLOP_REGION(R_EXPAND);
   const int nv = nv_, nu = nu_;
   real pmin = 1, dmin = 1;
   const int Mc = M();
@@ -1060,6 +1069,7 @@ void OCPSolver::computeDirection() {
 
 // OCPLinearizer::integrateSolution (ocp_linearizer.cpp:140-221)
 void OCPSolver::integrateSolution() {
+  FLOP_REGION(R_INTEGRATE);
   const int nv = nv_, nu = nu_;
   const real ap = primal_step_size, ad = dual_step_size;
   const int Mc = M();
@@ -1073,7 +1083,7 @@ void OCPSolver::integrateSolution() {
     if (!terminal) {
       ContactDynamicsDataC& D = cd[sl];
       SplitKKTResidualC& R = kkt_residual[sl];
-      const real dt = impulse ? 1.0 : nd.dt;
+      const real dt = impulse ? real(1.0) : nd.dt;
       const int dimf = cs.dimf();
       Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
       const Mat& dgmm = d[chain[p + 1].slot].dgmm;
@@ -1129,7 +1139,7 @@ void OCPSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line
   auto t0 = std::chrono::steady_clock::now();
   backwardRiccatiRecursion();
   forwardRiccatiRecursion(q, v);
-  riccati_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
+  riccati_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   computeDirection();
   if (use_line_search)            // ocp_solver.cpp:84-90
     primal_step_size = line_search.computeStepSize([&](real a) { return costAndViolation(a); }, primal_step_size);
@@ -1186,7 +1196,7 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
     }
     const bool impulse = nd.kind == NodeC::Impulse;
     const ContactStatus& cs = nodeContacts(p);
-    const real dt = impulse ? 1.0 : nd.dt, dtq = impulse ? 0.0 : nd.dt;
+    const real dt = impulse ? real(1.0) : nd.dt, dtq = impulse ? real(0.0) : nd.dt;
     const real* wq = impulse ? cost.qi_weight : cost.q_weight;
     const real* wv = impulse ? cost.vi_weight : cost.v_weight;
     const real* wa = impulse ? cost.dvi_weight : cost.a_weight;
@@ -1559,6 +1569,7 @@ void ParNMPCSolver::initConstraints(real t) {
 // SplitParNMPC::linearizeOCP (split_parnmpc.hxx:50-84; with the switching constraint of an aux stage :86-124) /
 // TerminalParNMPC::linearizeOCP (terminal_parnmpc.hxx:50-82) and the computeKKTResidual twins.
 void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   const PNode& nd = chain[p];
   if (nd.kind == NodeC::Impulse) { linearizeImpulse(p, q_prev, v_prev, residual_only); return; }
   const int i = nd.slot;
@@ -1793,6 +1804,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     }
   }
   // ---- ContactDynamics::condenseContactDynamics(..., is_forward_euler = false) (contact_dynamics.hxx:105-158)
+  FLOP_REGION_SET(R_CONDENSE);
   Robot::computeMJtJinv(D.dIDda, D.dCda, D.MJtJinv);
   D.MJtJinv_dIDCdqv = D.MJtJinv * D.dIDCdqv;
   D.MJtJinv_IDC = D.MJtJinv * D.IDC;
@@ -1831,6 +1843,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
 // (impulse_dynamics_backward_euler.hxx:20-97).  Stored in the regular containers: a = dv, R.la = ldv, R.P = V,
 // M.Qff, M.Qxx; the impulse-only blocks in imp[slot].
 void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   const PNode& nd = chain[p];
   const int i = nd.slot;
   const SplitSolutionC& si = s[i];
@@ -1985,6 +1998,7 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
 //   [ 0  J ; J^T  Q ]  with  J = [F ; C] (C = Pq rows of an aux stage / V rows of an impulse stage) and Q over (w, q, v),
 // w = u (regular, aux, lift, terminal) or f (impulse).
 void ParNMPCSolver::coarseUpdate(real t, const Mat& q, const Mat& v) {
+  FLOP_REGION(R_KKT_INVERSE);
   discretize(t);
   const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
   for (int p = 0; p < Mc; ++p) {
@@ -2066,6 +2080,7 @@ void ParNMPCSolver::coarseUpdate(real t, const Mat& q, const Mat& v) {
 
 // backward_correction_solver.cpp:253-287; split_backward_correction.hxx:84-95
 void ParNMPCSolver::backwardCorrectionSerial() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = nv_, nx = 2 * nv, Mc = (int)chain.size();
   for (int p = has_terminal ? Mc - 2 : Mc - 1; p >= 0; --p) {
     const int i = chain[p].slot;
@@ -2081,6 +2096,7 @@ void ParNMPCSolver::backwardCorrectionSerial() {
 }
 // :288-318; split_backward_correction.hxx:96-108; impulse_split_backward_correction.hxx:70-79
 void ParNMPCSolver::backwardCorrectionParallel() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
   for (int p = 0; p < (has_terminal ? Mc - 1 : Mc); ++p) {
     const PNode& nd = chain[p];
@@ -2107,6 +2123,7 @@ void ParNMPCSolver::backwardCorrectionParallel() {
 }
 // :319-352; split_backward_correction.hxx:109-120
 void ParNMPCSolver::forwardCorrectionSerial() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = nv_, nx = 2 * nv, Mc = (int)chain.size();
   for (int p = has_prev ? 0 : 1; p < Mc; ++p) {
     const int i = chain[p].slot;
@@ -2124,6 +2141,7 @@ void ParNMPCSolver::forwardCorrectionSerial() {
 // :353-470; split_backward_correction.hxx:121-155; impulse_split_backward_correction.hxx:93-125;
 // SplitParNMPC / ImpulseSplitParNMPC::computeCondensed{Primal,Dual}Direction
 void ParNMPCSolver::forwardCorrectionParallel() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = nv_, nu = nu_, nx = 2 * nv, Mc = (int)chain.size();
   real pmin = 1, dmin = 1;
   for (int p = 0; p < Mc; ++p) {
@@ -2262,6 +2280,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
 
 // ParNMPCLinearizer::integrateSolution (parnmpc_linearizer.cpp:248-300); SplitSolution::integrate / ImpulseSplitSolution::integrate
 void ParNMPCSolver::integrateSolution() {
+  FLOP_REGION(R_INTEGRATE);
   const int nv = nv_;
   const real ap = primal_step_size, ad = dual_step_size;
   for (const PNode& nd : chain) {
@@ -2297,11 +2316,11 @@ void ParNMPCSolver::computeDirection(real t, const Mat& q, const Mat& v) {
   coarseUpdate(t, q, v);
   auto t0 = std::chrono::steady_clock::now();
   backwardCorrectionSerial();
-  serial_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
+  serial_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   backwardCorrectionParallel();
   t0 = std::chrono::steady_clock::now();
   forwardCorrectionSerial();
-  serial_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
+  serial_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   forwardCorrectionParallel();
 }
 void ParNMPCSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_line_search) {
@@ -2347,7 +2366,7 @@ std::pair<real, real> ParNMPCSolver::costAndViolation(real alpha, const Mat& q, 
     const bool impulse = nd.kind == NodeC::Impulse;
     const SplitSolutionC x = trial(p);
     const ContactStatus& cs = nodeContacts(nd);
-    const real dt = impulse ? 1.0 : nd.dt;
+    const real dt = impulse ? real(1.0) : nd.dt;
     Mat q_ref, qdiff;
     qRef(nd.t, q_ref);
     rb.subtractConfiguration(x.q, q_ref, qdiff);

@@ -270,6 +270,39 @@ int oracle_openmp_enabled(void) {
   return 0;
 #endif
 }
+// ---- exact FLOP counter (flops.hpp) -- only the liboracle_flops.so build counts --------------
+//   oracle_flops_enabled()            1 in the counting build
+//   oracle_flops_shape(&nregion, &nkind)
+//   oracle_flops_region_name(i) / oracle_flops_kind_name(k)
+//   oracle_flops_reset(); oracle_flops_get(out[nregion * nkind])      counts since the last reset, row-major [region][kind]
+int oracle_flops_enabled(void) {
+#ifdef ORACLE_COUNT_FLOPS
+  return 1;
+#else
+  return 0;
+#endif
+}
+static const char* const kFlopRegionNames[] = {"other", "kinematics", "rnea", "rnea_derivatives", "baumgarte_contact", "mjtjinv", "lie", "cost_constraints_multipliers",
+                                               "condense", "switching_constraint", "unconstrained_dynamics", "riccati_backward", "riccati_forward", "expand_direction",
+                                               "integrate", "parnmpc_kkt_inverse", "parnmpc_corrections"};
+static const char* const kFlopKindNames[] = {"add", "mul", "div", "sqrt", "transcendental"};
+void oracle_flops_shape(int* nregion, int* nkind) { *nregion = (int)(sizeof(kFlopRegionNames) / sizeof(kFlopRegionNames[0])); *nkind = 5; }
+const char* oracle_flops_region_name(int i) { return kFlopRegionNames[i]; }
+const char* oracle_flops_kind_name(int k) { return kFlopKindNames[k]; }
+#ifdef ORACLE_COUNT_FLOPS
+}      // extern "C"
+namespace oracle {
+thread_local int flop_region = R_OTHER;
+unsigned long long flop_count[R_NREGION][F_NKIND];
+}
+extern "C" {
+static_assert(sizeof(kFlopRegionNames) / sizeof(kFlopRegionNames[0]) == oracle::R_NREGION && oracle::F_NKIND == 5, "names of the FLOP regions / kinds");
+void oracle_flops_reset(void) { std::memset(oracle::flop_count, 0, sizeof(oracle::flop_count)); oracle::flop_region = oracle::R_OTHER; }
+void oracle_flops_get(unsigned long long* out) { std::memcpy(out, oracle::flop_count, sizeof(oracle::flop_count)); }
+#else
+void oracle_flops_reset(void) {}
+void oracle_flops_get(unsigned long long* out) { (void)out; }
+#endif
 // TaskSpace*Cost: references of stages 0 .. N, refs[N + 1][12] (rotation row-major, position)
 int oracle_unocp_set_task_refs(void* h, const double* refs) {
   UnOCPSolver* s = static_cast<UnOCPSolver*>(h);
@@ -424,8 +457,8 @@ int oracle_unparnmpc_get_constraint_data(void* h, double* slack, double* dual) {
       const int n = s->constraints.components[c].lim.size();
       const bool valid = s->constraints.valid(s->constraints.components[c], i + 1);
       for (int r = 0; r < n; ++r) {
-        if (slack) slack[(size_t)i * dimc + off + r] = valid ? data.slack[r] : 0.0;
-        if (dual) dual[(size_t)i * dimc + off + r] = valid ? data.dual[r] : 0.0;
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? (double)data.slack[r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? (double)data.dual[r] : 0.0;
       }
       off += n;
     }
@@ -445,8 +478,8 @@ int oracle_unocp_get_constraint_data(void* h, double* slack, double* dual) {
       const int n = s->constraints.components[c].lim.size();
       const bool valid = s->constraints.valid(s->constraints.components[c], i);
       for (int r = 0; r < n; ++r) {
-        if (slack) slack[(size_t)i * dimc + off + r] = valid ? data.slack[r] : 0.0;
-        if (dual) dual[(size_t)i * dimc + off + r] = valid ? data.dual[r] : 0.0;
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? (double)data.slack[r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? (double)data.dual[r] : 0.0;
       }
       off += n;
     }
@@ -749,8 +782,8 @@ int oracle_ocp_get_constraint_data(void* h, double* slack, double* dual) {
       const IpmData& data = s->ipm[i][comp];
       const bool valid = comp < 2 ? i >= 2 : (comp < 4 ? i >= 1 : true);
       for (int r = 0; r < data.slack.size(); ++r) {
-        if (slack) slack[(size_t)i * dimc + off + r] = valid ? data.slack[r] : 0.0;
-        if (dual) dual[(size_t)i * dimc + off + r] = valid ? data.dual[r] : 0.0;
+        if (slack) slack[(size_t)i * dimc + off + r] = valid ? (double)data.slack[r] : 0.0;
+        if (dual) dual[(size_t)i * dimc + off + r] = valid ? (double)data.dual[r] : 0.0;
       }
       off += data.slack.size();
     }
@@ -776,7 +809,7 @@ int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Q
   Mat Fqq = Mat::Identity(nv);
   Fqq.setBlock(0, 0, M.Fqq6);
   const int pos = s->posOfSlot(i);
-  const double dt_node = (pos >= 0 && s->chain[pos].kind != NodeC::Impulse) ? s->chain[pos].dt : 0.0;
+  const double dt_node = (pos >= 0 && s->chain[pos].kind != NodeC::Impulse) ? (double)s->chain[pos].dt : 0.0;
   Mat Fqv_full = dt_node * Mat::Identity(nv);
   Fqv_full.setBlock(0, 0, M.Fqv6);
   Am.setBlock(0, 0, Fqq); Am.setBlock(0, nv, Fqv_full); Am.setBlock(nv, 0, M.Fvq); Am.setBlock(nv, nv, M.Fvv);

@@ -87,6 +87,7 @@ Robot::Robot(const RModel& model) : m_(model) {
 }
 
 void Robot::setContactForces(const std::vector<bool>& active, const std::vector<Mat>& f) {
+  FLOP_REGION(R_RNEA);
   // PointContact::computeJointForceFromContactForce (point_contact.hxx:15-20):
   // fjoint[parent] = jXf.act(Force(f, 0))
   for (auto& fj : fjoint_) std::fill(fj.begin(), fj.end(), 0.0);
@@ -154,7 +155,7 @@ void Robot::forwardPass(const Mat& q, const Mat& v, const Mat& a, bool gravity) 
     }
     const real* ovp = pa >= 0 ? ov_[pa].d.data() : nullptr;
     const real* oap = pa >= 0 ? oa_[pa].d.data() : a0;
-    for (int k = 0; k < 6; ++k) ov_[i][k] = (ovp ? ovp[k] : 0.0) + vJ[k];
+    for (int k = 0; k < 6; ++k) ov_[i][k] = (ovp ? ovp[k] : real(0.0)) + vJ[k];
     real vxvJ[6]; crossMM(ov_[i].d.data(), vJ, vxvJ);
     for (int k = 0; k < 6; ++k) oa_[i][k] = oap[k] + aJ[k] + vxvJ[k];
     // oYcrb = oMi.act(inertia) as a 6x6 matrix about the world origin
@@ -210,6 +211,7 @@ void Robot::forwardPass(const Mat& q, const Mat& v, const Mat& a, bool gravity) 
 }
 
 void Robot::RNEA(const Mat& q, const Mat& v, const Mat& a, Mat& tau, bool gravity) {
+  FLOP_REGION(R_RNEA);
   forwardPass(q, v, a, gravity);
   const int n = m_.njoints;
   tau = Mat(m_.nv);
@@ -222,6 +224,7 @@ void Robot::RNEA(const Mat& q, const Mat& v, const Mat& a, Mat& tau, bool gravit
 
 void Robot::RNEADerivatives(const Mat& q, const Mat& v, const Mat& a, Mat& dq, Mat& dv, Mat& da,
                             bool gravity) {
+  FLOP_REGION(R_RNEA_DERIV);
   forwardPass(q, v, a, gravity);
   const int n = m_.njoints, nv = m_.nv;
   dq = Mat(nv, nv); dv = Mat(nv, nv); da = Mat(nv, nv);
@@ -287,6 +290,7 @@ static void actInvMotion(const real* R, const real* p, const real* m, real* out)
 }
 
 void Robot::updateKinematics(const Mat& q, const Mat& v, const Mat& a) {
+  FLOP_REGION(R_KINEMATICS);
   const int n = m_.njoints, nv = m_.nv;
   if ((int)kMi_.size() != n) { kMi_.resize(n); kS_ = Mat(6, nv); kv_.assign(n, Mat(6)); ka_.assign(n, Mat(6)); }
   for (int i = 0; i < n; ++i) {
@@ -319,9 +323,9 @@ void Robot::updateKinematics(const Mat& q, const Mat& v, const Mat& a) {
     for (int c = 0; c < ndof; ++c) for (int k = 0; k < 6; ++k) {
       vJ[k] += kS_(k, iv + c) * v[iv + c]; aJ[k] += kS_(k, iv + c) * a[iv + c];
     }
-    for (int k = 0; k < 6; ++k) kv_[i][k] = (pa >= 0 ? kv_[pa][k] : 0.0) + vJ[k];
+    for (int k = 0; k < 6; ++k) kv_[i][k] = (pa >= 0 ? kv_[pa][k] : real(0.0)) + vJ[k];
     real vxvJ[6]; crossMM(kv_[i].d.data(), vJ, vxvJ);
-    for (int k = 0; k < 6; ++k) ka_[i][k] = (pa >= 0 ? ka_[pa][k] : 0.0) + aJ[k] + vxvJ[k];
+    for (int k = 0; k < 6; ++k) ka_[i][k] = (pa >= 0 ? ka_[pa][k] : real(0.0)) + aJ[k] + vxvJ[k];
   }
 }
 
@@ -381,6 +385,7 @@ void Robot::frameDerivatives(int c, Mat& vdq, Mat& adq, Mat& adv, Mat& ada) cons
 
 void Robot::computeBaumgarteResidual(const std::vector<bool>& active, real time_step,
                                      const std::vector<Mat>& contact_points, Mat& C) const {
+  FLOP_REGION(R_BAUMGARTE);
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   C = Mat(3 * na);
   const real wv = 2 / time_step, wp = 1 / (time_step * time_step);
@@ -398,6 +403,7 @@ void Robot::computeBaumgarteResidual(const std::vector<bool>& active, real time_
 
 void Robot::computeBaumgarteDerivatives(const std::vector<bool>& active, real time_step, Mat& dCdq, Mat& dCdv,
                                         Mat& dCda) const {
+  FLOP_REGION(R_BAUMGARTE);
   const int nv = m_.nv;
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   dCdq = Mat(3 * na, nv); dCdv = Mat(3 * na, nv); dCda = Mat(3 * na, nv);
@@ -430,6 +436,7 @@ void Robot::computeBaumgarteDerivatives(const std::vector<bool>& active, real ti
 }
 
 void Robot::computeImpulseVelocityResidual(const std::vector<bool>& active, Mat& C) const {
+  FLOP_REGION(R_BAUMGARTE);
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   C = Mat(3 * na);
   int row = 0;
@@ -443,6 +450,7 @@ void Robot::computeImpulseVelocityResidual(const std::vector<bool>& active, Mat&
 }
 
 void Robot::computeImpulseVelocityDerivatives(const std::vector<bool>& active, Mat& dCdq, Mat& dCdv) const {
+  FLOP_REGION(R_BAUMGARTE);
   const int nv = m_.nv;
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   dCdq = Mat(3 * na, nv); dCdv = Mat(3 * na, nv);
@@ -457,6 +465,7 @@ void Robot::computeImpulseVelocityDerivatives(const std::vector<bool>& active, M
 }
 
 void Robot::computeContactResidual(const std::vector<bool>& active, const std::vector<Mat>& contact_points, Mat& P) const {
+  FLOP_REGION(R_BAUMGARTE);
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   P = Mat(3 * na);
   int row = 0;
@@ -470,6 +479,7 @@ void Robot::computeContactResidual(const std::vector<bool>& active, const std::v
 }
 
 void Robot::computeContactDerivative(const std::vector<bool>& active, Mat& Pq) const {
+  FLOP_REGION(R_BAUMGARTE);
   const int nv = m_.nv;
   int na = 0; for (int c = 0; c < m_.ncontacts; ++c) if (active[c]) ++na;
   Pq = Mat(3 * na, nv);
@@ -490,6 +500,7 @@ static void log3(const real* R, real* w, real* theta);
 static void VmatInv(const real* w, real* Vi);
 static void Jlog6(const real* R, const real* p, Mat& J);
 void Robot::taskSpaceTerms(int dim, const real* ref, const real* w, const Mat& q, real& cost, Mat& grad, Mat& hess) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   const int nv = m_.nv;
   const Mat zero(nv);
   updateKinematics(q, zero, zero);
@@ -528,6 +539,7 @@ void Robot::taskSpaceTerms(int dim, const real* ref, const real* w, const Mat& q
 }
 
 void Robot::computeMJtJinv(const Mat& M, const Mat& J, Mat& out) {
+  FLOP_REGION(R_MJTJINV);
   // robot.hxx:576-615.  pinocchio's sparse U D U^T factorisation of M is replaced
   // by a dense Cholesky (same solution); the block algebra follows the reference.
   const int nv = M.r, nf = J.r;
@@ -556,7 +568,7 @@ static void exp3(const real* w, real* R) {
   R[0] += 1; R[4] += 1; R[8] += 1;
 }
 static void log3(const real* R, real* w, real* theta) {
-  real c = (R[0] + R[4] + R[8] - 1) / 2; c = c > 1 ? 1 : (c < -1 ? -1 : c);
+  real c = (R[0] + R[4] + R[8] - 1) / 2; c = c > 1 ? real(1) : (c < -1 ? real(-1) : c);
   const real t = std::acos(c);
   const real ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
   const real s = t < 1e-8 ? 0.5 + t * t / 12 : t / (2 * std::sin(t));
@@ -591,6 +603,7 @@ static void RtoQuat(const real* R, real* q) {   // xyzw
 
 // pinocchio::integrate (SpecialEuclideanOperation<3>: q (+) v = q * exp6(v))
 void Robot::integrateConfiguration(const Mat& q, const Mat& v, real length, Mat& q_out) const {
+  FLOP_REGION(R_LIE);
   Mat out = q;
   for (int i = 0; i < m_.njoints; ++i) {
     const int iq = m_.idx_q[i], iv = m_.idx_v[i];
@@ -623,6 +636,7 @@ static void relativePlacement(const real* qm, const real* qp, real* R, real* p) 
 
 // pinocchio::difference(q_minus, q_plus) = log6(q_minus^-1 q_plus)
 void Robot::subtractConfiguration(const Mat& q_plus, const Mat& q_minus, Mat& diff) const {
+  FLOP_REGION(R_LIE);
   diff = Mat(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     const int iq = m_.idx_q[i], iv = m_.idx_v[i];
@@ -669,6 +683,7 @@ static void Jlog6(const real* R, const real* p, Mat& J) {
 
 // pinocchio::dDifference(q_minus, q_plus, ARG1)
 void Robot::dSubtractdConfigurationPlus(const Mat& q_plus, const Mat& q_minus, Mat& J) const {
+  FLOP_REGION(R_LIE);
   J = Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
@@ -681,6 +696,7 @@ void Robot::dSubtractdConfigurationPlus(const Mat& q_plus, const Mat& q_minus, M
 
 // pinocchio::dDifference(q_minus, q_plus, ARG0) = -Jlog6(M) Ad(M^-1),  M = q_minus^-1 q_plus
 void Robot::dSubtractdConfigurationMinus(const Mat& q_plus, const Mat& q_minus, Mat& J) const {
+  FLOP_REGION(R_LIE);
   J = -1.0 * Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
@@ -706,6 +722,7 @@ static void exp6(const real* v6, real* R, real* p) {
 
 // pinocchio::dIntegrate(q, v, ARG0): SpecialEuclideanOperation<3>::dIntegrate_dq_impl = exp6(v).toActionMatrixInverse()
 void Robot::dIntegratedConfiguration(const Mat& /*q*/, const Mat& v, Mat& J) const {
+  FLOP_REGION(R_LIE);
   J = Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
@@ -722,6 +739,7 @@ void Robot::dIntegratedConfiguration(const Mat& /*q*/, const Mat& v, Mat& J) con
 
 // pinocchio::dIntegrate(q, v, ARG1): dIntegrate_dv_impl = Jexp6(v) = Jlog6(exp6(v))^-1
 void Robot::dIntegratedVelocity(const Mat& /*q*/, const Mat& v, Mat& J) const {
+  FLOP_REGION(R_LIE);
   J = Mat::Identity(m_.nv);
   for (int i = 0; i < m_.njoints; ++i) {
     if (m_.jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
@@ -736,6 +754,7 @@ void Robot::dIntegratedVelocity(const Mat& /*q*/, const Mat& v, Mat& J) const {
 
 // Robot::dSubtractdConfigurationInverse (robot.hxx:151-163): block-triangular 6x6 inverse
 void Robot::dSubtractdConfigurationInverse(const Mat& J, Mat& Jinv) {
+  FLOP_REGION(R_LIE);
   auto inv3 = [](const Mat& A) {
     Mat I(3, 3);
     const real det = A(0, 0) * (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(1, 2) * A(2, 0)) +

@@ -202,6 +202,7 @@ void UnOCPSolver::computeStageResidual(Robot& robot, int i, real /*t*/) {
 
 // SplitUnOCP::linearizeOCP (split_unocp.hxx:69-99)
 void UnOCPSolver::linearizeStage(Robot& robot, int i, real t, const Mat& /*q_prev*/) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   SplitUnOCP& o = ocp[i];
   const SplitSolution& si = s[i];
   const int nv = o.nv;
@@ -250,6 +251,7 @@ void UnOCPSolver::linearizeStage(Robot& robot, int i, real t, const Mat& /*q_pre
   for (int r = 0; r < nv; ++r) o.Qqq(r, r) = Qqq_diag[r];
   if (cost.task_dim) o.Qqq += dt_ * task_H;                        // TaskSpace*Cost::computeStageCostHessian (Gauss-Newton)
   // UnconstrainedDynamics::condenseUnconstrainedDynamics (unconstrained_dynamics.hxx:68-94)
+  FLOP_REGION_SET(R_UNCONDENSE);
   SplitUnKKTMatrix& Q = unkkt_matrix[i];
   SplitUnKKTResidual& R = unkkt_residual[i];
   for (int r = 0; r < nv; ++r) o.lu_condensed[r] = o.lu[r] + o.Quu_diag[r] * o.ID[r];
@@ -276,6 +278,7 @@ void UnOCPSolver::linearizeStage(Robot& robot, int i, real t, const Mat& /*q_pre
 
 // TerminalOCP::linearizeOCP (terminal_ocp.hxx:50-66), fixed base
 void UnOCPSolver::linearizeTerminal(real /*t*/) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   const SplitSolution& sN = s[N_];
   const int nv = robot.dimv();
   terminal_lq.setZero(); terminal_lv.setZero();
@@ -304,6 +307,7 @@ void UnOCPSolver::linearizeOCP(real t, const Mat& q) {
 // UnRiccatiRecursion::backwardRiccatiRecursionTerminal + backwardRiccatiRecursion
 // (unriccati_recursion.cpp:39-58)
 void UnOCPSolver::backwardRiccatiRecursion() {
+  FLOP_REGION(R_RICCATI_BWD);
   const int nv = robot.dimv();
   riccati[N_].Pqq = terminal_Qqq;
   riccati[N_].Pvv = terminal_Qvv;
@@ -366,6 +370,7 @@ void UnOCPSolver::backwardRiccatiRecursion() {
 // d[0] initial state (unocp_solver.cpp:100-101) + UnRiccatiRecursion::forwardRiccatiRecursion
 // (unriccati_recursion.cpp:60-65; split_unriccati_factorizer.hxx:49-57)
 void UnOCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
+  FLOP_REGION(R_RICCATI_FWD);
   const int nv = robot.dimv();
   d[0].dq = q - s[0].q;
   d[0].dv = v - s[0].v;
@@ -406,7 +411,7 @@ static real trialStageCost(const RCost& c, const Constraints& cs, const Constrai
          c.a_weight[r] * x.a[r] * x.a[r] + c.u_weight[r] * (x.u[r] - c.u_ref[r]) * (x.u[r] - c.u_ref[r]);
     lf += c.qf_weight[r] * (x.q[r] - c.q_ref[r]) * (x.q[r] - c.q_ref[r]) + c.vf_weight[r] * (x.v[r] - c.v_ref[r]) * (x.v[r] - c.v_ref[r]);
   }
-  real cost = 0.5 * dt * l + (terminal_cost ? 0.5 * lf : 0.0);
+  real cost = 0.5 * dt * l + (terminal_cost ? 0.5 * lf : real(0.0));
   for (size_t j = 0; j < cs.components.size(); ++j) {
     if (!cs.valid(cs.components[j], level)) continue;
     const ConstraintComponentData& data = cd.data[j];
@@ -434,6 +439,7 @@ static real trialConstraintViolation(Robot& robot, const Constraints& cs, const 
 
 // second parallel loop of UnOCPSolver::updateSolution (unocp_solver.cpp:103-115)
 void UnOCPSolver::computeDirection() {
+  FLOP_REGION(R_EXPAND);
   real pmin = 1, dmin = 1;
   #pragma omp parallel for num_threads(nthreads) reduction(min : pmin, dmin)
   for (int i = 0; i <= N_; ++i) {
@@ -476,6 +482,7 @@ void UnOCPSolver::computeDirection() {
 
 // third parallel loop (unocp_solver.cpp:121-133): updatePrimal / updateDual
 void UnOCPSolver::integrate() {
+  FLOP_REGION(R_INTEGRATE);
   const real ap = primal_step_size, ad = dual_step_size;
   #pragma omp parallel for num_threads(nthreads)
   for (int i = 0; i <= N_; ++i) {
@@ -523,7 +530,7 @@ void UnOCPSolver::updateSolution(real t, const Mat& q, const Mat& v, bool use_li
   auto t0 = std::chrono::steady_clock::now();
   backwardRiccatiRecursion();
   forwardRiccatiRecursion(q, v);
-  riccati_seconds += std::chrono::duration<real>(std::chrono::steady_clock::now() - t0).count();
+  riccati_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   computeDirection();
   if (use_line_search)            // unocp_solver.cpp:116-120
     primal_step_size = line_search.computeStepSize([&](real a) { return costAndViolation(a); }, primal_step_size);
@@ -642,6 +649,7 @@ void UnParNMPCSolver::initBackwardCorrection(real /*t*/) {
 // (terminal_unparnmpc.hxx:69-102, 147-168): stage i < N - 1 couples to s[i + 1] through the costate, the last stage
 // carries the terminal cost instead.
 void UnParNMPCSolver::linearizeStage(int i, const Mat& q_prev, const Mat& v_prev, bool residual_only) {
+  FLOP_REGION(R_COST_CONSTRAINTS);
   SplitUnOCP& o = ocp[i];
   const SplitSolution& si = s[i];
   const bool terminal = (i == N_ - 1);
@@ -683,8 +691,8 @@ void UnParNMPCSolver::linearizeStage(int i, const Mat& q_prev, const Mat& v_prev
   // computeStageCostHessian [+ computeTerminalCostHessian] (configuration_space_cost.cpp:351-380)
   Mat Qqq_diag(nv);
   for (int r = 0; r < nv; ++r) {
-    Qqq_diag[r] += dt_ * cost.q_weight[r] + (terminal ? cost.qf_weight[r] : 0.0);
-    o.Qvv_diag[r] += dt_ * cost.v_weight[r] + (terminal ? cost.vf_weight[r] : 0.0);
+    Qqq_diag[r] += dt_ * cost.q_weight[r] + (terminal ? cost.qf_weight[r] : real(0.0));
+    o.Qvv_diag[r] += dt_ * cost.v_weight[r] + (terminal ? cost.vf_weight[r] : real(0.0));
     o.Qaa_diag[r] += dt_ * cost.a_weight[r];
     o.Quu_diag[r] += dt_ * cost.u_weight[r];
   }
@@ -726,6 +734,7 @@ void UnParNMPCSolver::linearizeStage(int i, const Mat& q_prev, const Mat& v_prev
 // UnBackwardCorrection::coarseUpdate (unbackward_correction.cpp:67-97) with SplitUnBackwardCorrection::coarseUpdate
 // (split_unbackward_correction.hxx:38-64) and SplitUnKKTMatrixInverter::invert (split_unkkt_matrix_inverter.hxx:37-80)
 void UnParNMPCSolver::coarseUpdate(real /*t*/, const Mat& q, const Mat& v) {
+  FLOP_REGION(R_KKT_INVERSE);
   const int nv = robot.dimv(), nx = 2 * nv, nq3 = 3 * nv, nk = 5 * nv;
   for (int i = lo_; i < hi_; ++i) {
     linearizeStage(i, i == 0 ? q : s[i - 1].q, i == 0 ? v : s[i - 1].v, false);
@@ -770,6 +779,7 @@ void UnParNMPCSolver::coarseUpdate(real /*t*/, const Mat& q, const Mat& v) {
 
 // split_unbackward_correction.hxx:72-81
 void UnParNMPCSolver::backwardCorrectionSerial() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
   for (int i = std::min(hi_ - 1, N_ - 2); i >= lo_; --i) {
     x_res[i].setSegment(0, s_new[i + 1].lmd - s[i + 1].lmd);
@@ -782,6 +792,7 @@ void UnParNMPCSolver::backwardCorrectionSerial() {
 
 // split_unbackward_correction.hxx:84-92
 void UnParNMPCSolver::backwardCorrectionParallel() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
   for (int i = std::min(hi_ - 1, N_ - 2); i >= lo_; --i) {
     const Mat dd = kkt_inv[i].block(nx, nk - nx, nk - nx, nx) * x_res[i];
@@ -793,6 +804,7 @@ void UnParNMPCSolver::backwardCorrectionParallel() {
 
 // split_unbackward_correction.hxx:95-104
 void UnParNMPCSolver::forwardCorrectionSerial() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
   for (int i = std::max(lo_, 1); i < hi_; ++i) {
     x_res[i].setSegment(0, s_new[i - 1].q - s[i - 1].q);
@@ -807,6 +819,7 @@ void UnParNMPCSolver::forwardCorrectionSerial() {
 // forwardCorrectionParallel + aux_mat, computeDirection (split_unbackward_correction.hxx:107-123), the condensed
 // direction (unconstrained_dynamics.hxx:97-106), slack / dual directions and the step sizes
 void UnParNMPCSolver::forwardCorrectionParallel() {
+  FLOP_REGION(R_CORRECTION);
   const int nv = robot.dimv(), nx = 2 * nv, nk = 5 * nv;
   real pmin = 1, dmin = 1;
   for (int i = lo_; i < hi_; ++i) {
@@ -849,6 +862,7 @@ void UnParNMPCSolver::forwardCorrectionParallel() {
 
 // updatePrimal / updateDual of every stage (unparnmpc_solver.cpp:88-102; split_solution.hxx:215-240)
 void UnParNMPCSolver::integrate() {
+  FLOP_REGION(R_INTEGRATE);
   const real ap = primal_step_size, ad = dual_step_size;
   for (int i = lo_; i < hi_; ++i) {
     s[i].lmd += ap * d[i].dlmd; s[i].gmm += ap * d[i].dgmm; s[i].q += ap * d[i].dq; s[i].v += ap * d[i].dv;

@@ -30,6 +30,7 @@ if [ "${3:-}" = "sq" ]; then
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA -d $out -o ${wl}_sq3 -- python3 $R/bench.py --workload $wl $extra --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $out/${wl}_sq3.log 2>&1
   cd $R
   python3 profiles/summarize_rocpd.py $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db $out/${wl}_sq3_results.db > $out/r${rnd}_${wl}_pmc_sq.txt
+  python3 profiles/make_sq_json.py $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db $out/${wl}_sq3_results.db $wl $batch $hor $rnd > $out/r${rnd}_pmc_sq_${wl}.json
   rm -f $out/${wl}_sq1_results.db $out/${wl}_sq2_results.db $out/${wl}_sq3_results.db
 fi
 python3 profiles/make_traffic_json.py $out/${wl}_fetch_results.db $out/${wl}_write_results.db $wl $batch $hor $rnd > $out/r${rnd}_pmc_traffic_${wl}.json

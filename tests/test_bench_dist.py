@@ -160,6 +160,57 @@ def test_bench_gpus2_first_contact_hang_is_ended_by_the_launcher_timeout():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_gpus2_sigterm_to_the_launcher_ends_the_ranks():
+    """The launcher puts its ranks in a session of their own (so that its timeout can end exactly them); a SIGTERM aimed at the LAUNCHER
+    -- a driver ending the command -- must therefore be forwarded: no rank may survive it (advisor, round 5).  The ranks hang inside their
+    second step; the launcher is told to terminate; afterwards no process of its group is left and the exit code is 128 + SIGTERM."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IDOCP_BENCH_STUB="1", IDOCP_BENCH_STUB_HANG="1")
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "anymal_parnmpc", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                             "--timeout", "600"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def descendants(pid):
+        """every process below `pid` in the parent tree (launcher -> torchrun -> ranks; torchrun gives its workers sessions of their own)"""
+        par = {}
+        for d in os.listdir("/proc"):
+            if not d.isdigit():
+                continue
+            try:
+                st = open("/proc/%s/stat" % d).read()
+                par[int(d)] = int(st[st.rindex(")") + 2:].split()[1])
+            except (OSError, ValueError):
+                continue
+        out, frontier = [], [pid]
+        while frontier:
+            nxt = [p for p, pp in par.items() if pp in frontier]
+            out += nxt
+            frontier = nxt
+        return out
+
+    # wait until the ranks exist (launcher -> torchrun -> 2 ranks)
+    deadline = time.time() + 120
+    members = []
+    while time.time() < deadline:
+        members = descendants(proc.pid)
+        if len(members) >= 3:
+            break
+        assert proc.poll() is None, proc.stderr.read()[-2000:]
+        time.sleep(0.5)
+    assert len(members) >= 3, members
+    time.sleep(3.0)                                  # (let the ranks reach the hanging step)
+    proc.send_signal(signal.SIGTERM)
+    try:
+        rc = proc.wait(timeout=60)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    assert rc == 128 + signal.SIGTERM, (rc, proc.stderr.read()[-2000:])
+    alive = [p for p in members if os.path.exists("/proc/%d" % p) and open("/proc/%d/stat" % p).read().split(")")[-1].split()[0] != "Z"]
+    assert not alive, "ranks outlived their launcher: %r" % alive
+
+
 def test_parnmpc_scaling_model_of_the_bench_line():
     """config.model_ms: DESIGN section 5's step-time model, from this run's kernel times on one GPU, from the committed figures on more."""
     sys.path.insert(0, ROOT)
