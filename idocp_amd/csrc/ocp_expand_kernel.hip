@@ -326,7 +326,10 @@ __global__ __launch_bounds__(128, 1) void ocp_forward_expand_kernel(OcpBuffers B
   static_assert(GL % 2 == 0 && RL % 2 == 0 && MJDL % 2 == 0 && MJUL % 2 == 0 && L::SOL % 2 == 0 && L::GAIN % 2 == 0 && L::RIC % 2 == 0 && L::EXP % 2 == 0 &&
                 L::E_MJD % 2 == 0 && L::KKT % 2 == 0 && L::K_FQQ % 2 == 0 && L::K_FX % 2 == 0 && NVF % 2 == 0, "16-byte loads");
   static_assert(L::K_FQV == L::K_FQQ + 36 && L::NCON <= 128 && NX <= 36 && 36 + NX / 2 <= 64, "Fqq6 | Fqv6 and Fx on one load; two IPM rows per lane");
-  static_assert(NC <= 4 && NF <= 15 && NVF + NV <= 64 && L::R_PQQ == 0 && L::R_SV == L::R_SQ + NV && L::C_FRIC <= 64 + 8, "node word: four contacts; lane maps");
+  static_assert(NC <= 4 && NF <= 15 && NVF + NV <= 64 && L::R_PQQ == 0 && L::R_SV == L::R_SQ + NV, "node word: four contacts; lane maps");
+  // wavefront 1 reaches the cone and contact-distance rows only as row = lane + 64 (the joint-limit / acceleration rows through both t): every
+  // such row must lie in [64, 128)
+  static_assert(L::C_FRIC >= 64 && L::C_CD >= 64 && L::NCON <= 128, "cone / contact-distance rows are mapped to lane + 64 only");
   constexpr int NG2 = (GL / 2 + 63) / 64, NP2 = (RL / 2 + 63) / 64, NM2 = (MJDL / 2 + 63) / 64, NT2 = (MJUL / 2 + 63) / 64, NS2 = (L::SOL / 2 + 63) / 64;
   constexpr int MAXM = OcpForwardExpandMaxChain;
   constexpr int PF = NX * NX, PSV = PF, PPAD = PF + NX;

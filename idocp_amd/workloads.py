@@ -458,6 +458,7 @@ def anymal_contact_points(model, q_at=None):
 
 class HipOCP:
     """Contact path through the C ABI (idocp_ocp_*)."""
+    _post_create = []      # callables applied to every new handle (a test seam: no environment variable changes what production runs)
 
     def __init__(self, model, cost, cons, T, N, batch=1, device=0, max_num_impulse=0):
         self.lib = capi.lib()
@@ -471,14 +472,8 @@ class HipOCP:
             capi.check(self.lib.idocp_ocp_create(C.byref(model), C.byref(cost), C.byref(cons), T, N, batch, device, C.byref(h)),
                        "idocp_ocp_create")
         self.h = h
-        # tests/test_forward_expand_gpu.py: every handle created under this switch runs the forward sweep in the given form (0 / 1)
-        if os.environ.get("IDOCP_TEST_FUSED_FORWARD") in ("0", "1"):
-            self.lib.idocp_ocp_set_fused_forward.argtypes = [C.c_void_p, C.c_int]
-            capi.check(self.lib.idocp_ocp_set_fused_forward(self.h, int(os.environ["IDOCP_TEST_FUSED_FORWARD"])), "set_fused_forward")
-        # tests/test_riccati_sweep_gpu.py: likewise the form of the backward sweep (0: one wavefront per instance, 1: eight)
-        if os.environ.get("IDOCP_TEST_RICCATI_SWEEP") in ("0", "1"):
-            self.lib.idocp_ocp_set_riccati_sweep.argtypes = [C.c_void_p, C.c_int]
-            capi.check(self.lib.idocp_ocp_set_riccati_sweep(self.h, int(os.environ["IDOCP_TEST_RICCATI_SWEEP"])), "set_riccati_sweep")
+        for hook in type(self)._post_create:      # (tests/helpers.force_forms: kernel forms forced per test; empty in production)
+            hook(self)
 
     # ---- contact sequences with discrete events
     def push_back_contact_status(self, active, points, switching_time):

@@ -14,6 +14,21 @@ from idocp_amd.workloads import P, arr, dp, ROOT, GOLDEN
 
 _oracles = {}
 
+
+def force_forms(monkeypatch, fused=None, sweep=None):
+    """Every OCPSolver handle created during this test runs the forward sweep (fused: 1 = ocp_forward_expand_kernel, 0 = S4 + K6) and / or the
+    backward sweep (sweep: 0 = one wavefront per instance, register-resident; 1 = eight per instance) in the given form instead of the one its
+    batch size would pick -- idocp_ocp_set_fused_forward / idocp_ocp_set_riccati_sweep on the new handle.  Scoped to the test by monkeypatch."""
+    def hook(solver):
+        lib = solver.lib
+        if fused is not None:
+            lib.idocp_ocp_set_fused_forward.argtypes = [C.c_void_p, C.c_int]
+            capi.check(lib.idocp_ocp_set_fused_forward(solver.h, int(fused)), "set_fused_forward")
+        if sweep is not None:
+            lib.idocp_ocp_set_riccati_sweep.argtypes = [C.c_void_p, C.c_int]
+            capi.check(lib.idocp_ocp_set_riccati_sweep(solver.h, int(sweep)), "set_riccati_sweep")
+    monkeypatch.setattr(HipOCP, "_post_create", list(HipOCP._post_create) + [hook])
+
 ORACLE_PATH_OVERRIDE = None       # bench.py's cpu_baseline leg points this at the natively built library
 
 def oracle(hp=False):

@@ -3,14 +3,14 @@ riccati_recursion_solver.cpp:110-251 in one kernel, one wavefront per instance) 
 oracle.  A handle picks the fused form by its batch size (idocp_ocp_fused_forward; the parity tests elsewhere run small batches, i.e.
 S4 + K6), so this file (i) compares the two forms with each other on one problem, stage by stage, and (ii) re-runs the oracle parity
 tests of the other files with every OCPSolver handle FORCED into the fused form (idocp_ocp_set_fused_forward through
-IDOCP_TEST_FUSED_FORWARD, read by workloads.HipOCP): event-free horizons, trotting / flight / odd-contact chains with impulse, aux and lift
+helpers.force_forms): event-free horizons, trotting / flight / odd-contact chains with impulse, aux and lift
 stages and switching constraints, the full-size configs, plug-ins whose IPM rows live in the ext record, the filter line search."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from helpers import ANYMAL_Q_STANDING, OCP_DIR_FIELDS, HipOCP, anymal_model, anymal_problem, rel_err, trotting_sequence
+from helpers import ANYMAL_Q_STANDING, force_forms, OCP_DIR_FIELDS, HipOCP, anymal_model, anymal_problem, rel_err, trotting_sequence
 from idocp_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -18,11 +18,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def fused(monkeypatch):
-    monkeypatch.setenv("IDOCP_TEST_FUSED_FORWARD", "1")
+    force_forms(monkeypatch, fused=1)
 
 
 def _trotting_handle(mode, N, T, nimp, batch, monkeypatch):
-    monkeypatch.setenv("IDOCP_TEST_FUSED_FORWARD", str(mode))
+    force_forms(monkeypatch, fused=mode)
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=True)
     g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1)

@@ -4,13 +4,13 @@ the kernel of the headline metric) and eight wavefronts per instance with P stag
 instances, the latency form).  A handle picks one by its batch size (idocp_ocp_riccati_sweep); the parity tests of the other files run small
 batches, i.e. the latency form, so this file (i) compares the two forms with each other, stage by stage, and (ii) re-runs the oracle parity
 tests of the other files with every OCPSolver handle FORCED into the register-resident form (idocp_ocp_set_riccati_sweep through
-IDOCP_TEST_RICCATI_SWEEP, read by workloads.HipOCP)."""
+helpers.force_forms)."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from helpers import ANYMAL_Q_STANDING, OCP_DIR_FIELDS, HipOCP, anymal_model, anymal_problem, rel_err, trotting_sequence
+from helpers import ANYMAL_Q_STANDING, force_forms, OCP_DIR_FIELDS, HipOCP, anymal_model, anymal_problem, rel_err, trotting_sequence
 from idocp_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -18,11 +18,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def narrow(monkeypatch):
-    monkeypatch.setenv("IDOCP_TEST_RICCATI_SWEEP", "0")
+    force_forms(monkeypatch, sweep=0)
 
 
 def _trotting_handle(mode, N, T, nimp, batch, monkeypatch):
-    monkeypatch.setenv("IDOCP_TEST_RICCATI_SWEEP", str(mode))
+    force_forms(monkeypatch, sweep=mode)
     m = anymal_model()
     cost, cons = anymal_problem(m, trotting_ref=True)
     g = HipOCP(m, cost, cons, T, N, batch=batch, max_num_impulse=nimp + 1)
