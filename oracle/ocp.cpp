@@ -665,6 +665,20 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   }
   // ---- ContactDynamics::condenseContactDynamics (contact_dynamics.hxx:105-158) /
   //      ImpulseDynamicsForwardEuler::condenseImpulseDynamics (impulse_dynamics_forward_euler.hxx:59-105)
+  if (keep_uncondensed) {      // test hook (ocp.hpp UncondensedC): everything the un-condensed Newton system of this stage consists of
+    UncondensedC& U = unc[nd.slot];
+    U.valid = true; U.kind = (int)nd.kind; U.dimf = dimf; U.dimi = (nd.sw_event >= 0) ? (int)R.P.size() : 0; U.has_u = impulse ? 0 : 1;
+    U.dt = dt; U.dtq = dtq;
+    U.active_mask = 0; for (int c = 0; c < nc_; ++c) if (cs.active[c]) U.active_mask |= 1 << c;
+    U.Qxx = M.Qxx; U.Qaa = M.Qaa_diag; U.Qff = M.Qff; U.Quu = M.Quu_full;
+    U.lq = R.lq; U.lv = R.lv; U.la = R.la; U.lf = R.lf; U.lu = R.lu; U.lu_passive = R.lu_passive;
+    U.Fq = R.Fq; U.Fq.setSegment(0, R.Fq_prev);                       // the residual before condenseForwardEuler premultiplied its base rows
+    U.Fv = R.Fv;
+    U.Fqq = M.Fqq_prev6;                                              // dSubtractdConfigurationPlus(q, q_next) (parked there by condenseForwardEuler)
+    U.Fqq_prev = Fqq_prev.block(0, 0, 6, 6);                          // dSubtractdConfigurationMinus(q_prev, q)
+    U.dIDCdqv = D.dIDCdqv; U.M = D.dIDda; U.J = D.dCda; U.IDC = D.IDC;
+    U.Phix = W.Phix; U.Phia = W.Phia; U.P = R.P;
+  }
   FLOP_REGION_SET(R_CONDENSE);
   Robot::computeMJtJinv(D.dIDda, D.dCda, D.MJtJinv);
   D.MJtJinv_dIDCdqv = D.MJtJinv * D.dIDCdqv;
@@ -739,6 +753,12 @@ void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool r
   M.Qxx.addBlock(0, 0, Jq.t() * WJ);
   for (int r = 0; r < nv; ++r) M.Qxx(nv + r, nv + r) += cost.vf_weight[r];
   if (cost.task_dim) M.Qxx.addBlock(0, 0, task_H);
+  if (keep_uncondensed) {
+    UncondensedC& U = unc[nd.slot];
+    U = UncondensedC();
+    U.valid = true; U.kind = (int)nd.kind;
+    U.Qxx = M.Qxx; U.lq = R.lq; U.lv = R.lv; U.Fqq_prev = M.Fqq_prev6;
+  }
 }
 
 // OCPLinearizer::runParallel (ocp_linearizer.hxx:113-228); q_prev (:231-248) is the chain predecessor's q
@@ -746,6 +766,7 @@ void OCPSolver::linearizeOCP(real t, const Mat& q) {
   discretize(t);
   if ((int)robots_.size() != nthreads) setNumThreads(nthreads);
   const int Mc = M();
+  if (keep_uncondensed) unc.assign(nslots(), UncondensedC());
   #pragma omp parallel for num_threads(nthreads)
   for (int p = 0; p < Mc; ++p) {
     Robot& rb = robots_[ORACLE_THREAD_NUM];

@@ -118,6 +118,17 @@ struct SwitchingC {
   Mat M, m;                      // dxi = M dx + m
 };
 
+// Test hook (tests/golden/gen_golden_kkt.py): the UN-CONDENSED Newton system of a stage, captured by linearizeNode / linearizeTerminal just
+// before condenseContactDynamics when OCPSolver::keep_uncondensed is set -- cost + IPM Hessians and gradients in all of (q, v, a, f, u), the raw
+// state-equation Jacobians, [dID; dC] / d(q, v, a), [ID; C], the switching-constraint rows.  A dense solve of the whole horizon's KKT system
+// assembled from these shares no formula with condensation, Riccati recursion and expansion.
+struct UncondensedC {
+  bool valid = false;
+  int kind = 0, dimf = 0, dimi = 0, has_u = 0, active_mask = 0;      // active_mask: bit c = contact c carries rows (impulse stages: the contacts of the impulse)
+  real dt = 0, dtq = 0;
+  Mat Qxx, Qaa, Qff, Quu, lq, lv, la, lf, lu, lu_passive, Fq, Fv, Fqq, Fqq_prev, dIDCdqv, M, J, IDC, Phix, Phia, P;
+};
+
 struct RiccatiC {
   Mat Pqq, Pqv, Pvv, sq, sv;
   explicit RiccatiC(int nv) : Pqq(nv, nv), Pqv(nv, nv), Pvv(nv, nv), sq(nv), sv(nv) {}
@@ -173,6 +184,8 @@ class OCPSolver {
   std::vector<SwitchingC> sw;
   std::vector<std::vector<IpmData>> ipm;    // [node][component]
   std::vector<Mat> cd_J;                    // ContactDistance: row 2 of the LOCAL frame Jacobians of the linearisation (nc x nv per slot)
+  bool keep_uncondensed = false;            // test hook: capture the un-condensed stage systems (UncondensedC) during linearizeOCP
+  std::vector<UncondensedC> unc;            // [slot]
   std::vector<RiccatiC> riccati;
   std::vector<Mat> K, k;
   real primal_step_size = 1, dual_step_size = 1;

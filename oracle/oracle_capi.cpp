@@ -820,6 +820,28 @@ int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Q
   xcpy(lu, R.lu.d.data(), sizeof(double) * nu);
   return 0;
 }
+// ---- test hook: the un-condensed Newton system of chain position `pos` (UncondensedC, ocp.hpp) --------------------------------
+//   oracle_ocp_keep_uncondensed(h, 1) before compute_direction / update_solution; then per position
+//   oracle_ocp_get_uncondensed(h, pos, "meta", out) -> [valid, kind, dimf, dimi, has_u, dt, dtq, active_mask]; any other name: the block, column-major;
+//   returns the number of doubles (out may be NULL to ask for it), -1 for an unknown name
+int oracle_ocp_keep_uncondensed(void* h, int on) { static_cast<OCPSolver*>(h)->keep_uncondensed = on != 0; return 0; }
+int oracle_ocp_get_uncondensed(void* h, int pos, const char* name, double* out) {
+  OCPSolver* s = static_cast<OCPSolver*>(h);
+  if (pos < 0 || pos >= s->M() || (int)s->unc.size() != s->nslots()) return -1;
+  const UncondensedC& U = s->unc[s->chain[pos].slot];
+  const std::string n(name);
+  if (n == "meta") {
+    if (out) { out[0] = U.valid; out[1] = U.kind; out[2] = U.dimf; out[3] = U.dimi; out[4] = U.has_u; out[5] = (double)U.dt; out[6] = (double)U.dtq; out[7] = U.active_mask; }
+    return 8;
+  }
+  const Mat* m = n == "Qxx" ? &U.Qxx : n == "Qaa" ? &U.Qaa : n == "Qff" ? &U.Qff : n == "Quu" ? &U.Quu : n == "lq" ? &U.lq : n == "lv" ? &U.lv : n == "la" ? &U.la
+               : n == "lf" ? &U.lf : n == "lu" ? &U.lu : n == "lu_passive" ? &U.lu_passive : n == "Fq" ? &U.Fq : n == "Fv" ? &U.Fv : n == "Fqq" ? &U.Fqq
+               : n == "Fqq_prev" ? &U.Fqq_prev : n == "dIDCdqv" ? &U.dIDCdqv : n == "M" ? &U.M : n == "J" ? &U.J : n == "IDC" ? &U.IDC : n == "Phix" ? &U.Phix
+               : n == "Phia" ? &U.Phia : n == "P" ? &U.P : nullptr;
+  if (!m) return -1;
+  if (out) for (int i = 0; i < m->size(); ++i) out[i] = (double)m->d[i];
+  return m->size();
+}
 double oracle_ocp_bench(void* h, double t, const double* q, const double* v, int iters, double* riccati_seconds) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   Mat Q = toVec(q, s->robot.dimq()), V = toVec(v, s->robot.dimv());

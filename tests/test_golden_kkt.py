@@ -1,0 +1,95 @@
+"""The condensation + expansion layer against an INDEPENDENT answer: tests/golden/kkt_anymal.json holds the Newton direction of a small hybrid
+ANYmal problem (2-contact stages with a switching constraint, an impulse stage, an aux stage, 4-contact stages, a lift stage, the terminal stage)
+obtained by tests/golden/gen_golden_kkt.py from ONE DENSE SOLVE of the un-condensed KKT system of the whole horizon in all variables
+(q v a f u | lmd gmm beta mu xi) -- no MJtJinv, no condensed Hessians, no Riccati recursion, no expansion formulas.
+
+* CPU: the oracle's condense -> Riccati -> expand direction (contact_dynamics.hxx:105-190, impulse_dynamics_forward_euler.hxx:59-142,
+  riccati_recursion_solver.cpp:48-251) equals it field by field and node by node to 1e-9;
+* CPU: the fixture is what the generator produces today from the oracle's un-condensed stage data (it cannot go stale silently);
+* GPU (-m gpu): the HIP direction through the C ABI equals it to 1e-9.
+
+One entry of the fixture is NOT the Newton step, on purpose: on a stage that carries a switching constraint the reference forms [dbeta; dmu]
+without the Phia^T dxi term (contact_dynamics.hxx:171-190); the generator follows the reference there, by a dense solve of the two stationarity
+rows concerned, and records how far that is from the Newton value (`dense_system.newton_minus_reference_dbeta_on_switching_stages`)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, HipOCP, OracleOCP
+
+sys.path.insert(0, GOLDEN)
+import gen_golden_kkt as G      # noqa: E402
+
+TOL = 1e-9
+
+
+def fixture():
+    with open(os.path.join(GOLDEN, "kkt_anymal.json")) as f:
+        return json.load(f)
+
+
+def second_iteration(Solver, spec, **kw):
+    o, qm, vm = G.build(spec, Solver, **kw)
+    M = len(o.chain(0.0))
+    assert o.update(0.0, qm, vm) == 0
+    assert o.update(0.0, qm, vm) == 0
+    return o, M
+
+
+def compare(got, ref, what):
+    table = []
+    for f in G.FIELDS:
+        want = np.array(ref["direction"][f])
+        have = got[f]
+        assert have.shape == want.shape, (f, have.shape, want.shape)
+        for p in range(want.shape[0]):
+            scale = max(1.0, np.max(np.abs(want[p])))
+            table.append((np.max(np.abs(have[p] - want[p])) / scale, f, p))
+    worst = max(table)
+    print("%s: worst field / node %s at chain position %d: %.2e" % (what, worst[1], worst[2], worst[0]))
+    assert worst[0] < TOL, "%s differs from the dense Newton direction: %s at chain position %d by %.3e" % (what, worst[1], worst[2], worst[0])
+
+
+def test_the_chain_has_every_node_kind():
+    ref = fixture()
+    kinds = [c["kind"] for c in ref["chain"]]
+    assert set(kinds) == {"stage", "impulse", "aux", "lift", "terminal"}
+    assert {c["dimf"] for c in ref["chain"] if c["kind"] == "stage"} == {6, 12}
+    assert any(c["sw_event"] >= 0 for c in ref["chain"])
+    assert ref["dense_system"]["max_abs_residual"] < 1e-12
+    # the reference's dual direction on the switching stage is far from the Newton value: the test below would see the difference
+    assert ref["dense_system"]["newton_minus_reference_dbeta_on_switching_stages"] > 1.0
+
+
+def test_oracle_direction_is_the_dense_newton_direction():
+    ref = fixture()
+    o, M = second_iteration(OracleOCP, ref["spec"])
+    assert [c["kind"] for c in o.chain(0.0)] == [c["kind"] for c in ref["chain"]]
+    compare({f: o.get_chain(f, M) for f in G.FIELDS}, ref, "oracle")
+
+
+def test_fixture_is_what_the_generator_produces():
+    import ctypes as C
+    ref = fixture()
+    assert ref["spec"] == G.problem_spec()
+    o, qm, vm = G.build(ref["spec"], OracleOCP)
+    M = len(o.chain(0.0))
+    assert o.update(0.0, qm, vm) == 0
+    o.lib.oracle_ocp_keep_uncondensed.argtypes = [C.c_void_p, C.c_int]
+    o.lib.oracle_ocp_keep_uncondensed(o.h, 1)
+    assert o.update(0.0, qm, vm) == 0
+    dense, _, info = G.dense_direction(o, M, o.get_chain("dq", M)[0], o.get_chain("dv", M)[0])
+    assert info["unknowns"] == ref["dense_system"]["unknowns"]
+    compare(dense, ref, "regenerated dense solve")
+
+
+@pytest.mark.gpu
+def test_hip_direction_is_the_dense_newton_direction():
+    ref = fixture()
+    g, M = second_iteration(HipOCP, ref["spec"], batch=2)
+    assert [c["kind"] for c in g.chain(0.0)] == [c["kind"] for c in ref["chain"]]
+    for inst in (0, 1):
+        compare({f: g.get_chain(f, M, inst) for f in G.FIELDS}, ref, "HIP (instance %d)" % inst)
