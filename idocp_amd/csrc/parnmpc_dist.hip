@@ -82,6 +82,13 @@ struct idocp_comm {
   ncclComm_t nccl = nullptr;
   LocalHub* hub = nullptr;
   bool force_collectives = false;     // world == 1: issue the collectives through RCCL anyway (idocp_comm_set_force_collectives)
+  // third transport (idocp_comm_init_callbacks): host-staged point-to-point / collectives through caller-supplied functions.  It follows the
+  // RCCL branch of the driver call by call -- same grouping, same order, same lifetime -- so that two PROCESSES can run the driver on a box
+  // where RCCL cannot connect them (one GPU: tests/test_parnmpc_gpu.py backs it with gloo)
+  bool has_cb = false;
+  idocp_comm_callbacks_t cb{};
+  bool in_group = false;
+  std::vector<int> pending_recv;      // halo kinds received inside the open group: copied to the device when the group ends
 };
 
 namespace {
@@ -95,6 +102,7 @@ struct DistState {
   double *sendb[NKINDS] = {}, *recvb[NKINDS] = {};
   size_t count[NKINDS] = {};
   double *d_q = nullptr, *d_v = nullptr, *d_steps = nullptr, *d_err2 = nullptr;
+  std::vector<double> hsend[NKINDS], hrecv[NKINDS], hred;      // host staging of the callback transport
 };
 std::map<idocp_ocp_t*, DistState> g_dist;
 std::mutex g_dist_mutex;
@@ -114,6 +122,13 @@ DistState* stateOf(idocp_ocp_t* h) {
 int xsend(DistState& s, int kind, int peer) {
   idocp_comm* c = s.comm;
   if (c->nccl) { NCCLC(g_rccl.Send(s.sendb[kind], s.count[kind], ncclDouble, peer, c->nccl, s.stream)); return IDOCP_OK; }
+  if (c->has_cb) {
+    s.hsend[kind].resize(s.count[kind]);
+    HIPC(hipMemcpyAsync(s.hsend[kind].data(), s.sendb[kind], s.count[kind] * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    if (c->cb.send(c->cb.ctx, s.hsend[kind].data(), (unsigned long)s.count[kind], peer, c->in_group ? 1 : 0)) return fail(IDOCP_E_DEVICE, "callback transport: send failed");
+    return IDOCP_OK;
+  }
   LocalHub* hub = c->hub;
   double* copy = nullptr;
   HIPC(hipMalloc((void**)&copy, s.count[kind] * sizeof(double)));
@@ -126,6 +141,14 @@ int xsend(DistState& s, int kind, int peer) {
 int xrecv(DistState& s, int kind, int peer) {
   idocp_comm* c = s.comm;
   if (c->nccl) { NCCLC(g_rccl.Recv(s.recvb[kind], s.count[kind], ncclDouble, peer, c->nccl, s.stream)); return IDOCP_OK; }
+  if (c->has_cb) {
+    s.hrecv[kind].resize(s.count[kind]);
+    if (c->cb.recv(c->cb.ctx, s.hrecv[kind].data(), (unsigned long)s.count[kind], peer, c->in_group ? 1 : 0)) return fail(IDOCP_E_DEVICE, "callback transport: recv failed");
+    if (c->in_group) { c->pending_recv.push_back(kind); return IDOCP_OK; }      // (posted: the data is there when the group ends)
+    HIPC(hipMemcpyAsync(s.recvb[kind], s.hrecv[kind].data(), s.count[kind] * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    return IDOCP_OK;
+  }
   LocalHub* hub = c->hub;
   std::pair<double*, size_t> msg;
   {
@@ -140,8 +163,28 @@ int xrecv(DistState& s, int kind, int peer) {
   HIPC(hipFree(msg.first));
   return IDOCP_OK;
 }
-int xgroupStart(DistState& s) { if (s.comm->nccl) NCCLC(g_rccl.GroupStart()); return IDOCP_OK; }
-int xgroupEnd(DistState& s) { if (s.comm->nccl) NCCLC(g_rccl.GroupEnd()); return IDOCP_OK; }
+int xgroupStart(DistState& s) {
+  if (s.comm->nccl) NCCLC(g_rccl.GroupStart());
+  if (s.comm->has_cb) {
+    s.comm->in_group = true; s.comm->pending_recv.clear();
+    if (s.comm->cb.group_start && s.comm->cb.group_start(s.comm->cb.ctx)) return fail(IDOCP_E_DEVICE, "callback transport: group_start failed");
+  }
+  return IDOCP_OK;
+}
+int xgroupEnd(DistState& s) {
+  if (s.comm->nccl) NCCLC(g_rccl.GroupEnd());
+  if (s.comm->has_cb) {
+    idocp_comm* c = s.comm;
+    c->in_group = false;
+    const int rc = c->cb.group_end ? c->cb.group_end(c->cb.ctx) : 0;      // completes every transfer posted since group_start
+    std::vector<int> kinds;
+    kinds.swap(c->pending_recv);
+    if (rc) return fail(IDOCP_E_DEVICE, "callback transport: group_end failed");
+    for (int kind : kinds) HIPC(hipMemcpyAsync(s.recvb[kind], s.hrecv[kind].data(), s.count[kind] * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    if (!kinds.empty()) HIPC(hipStreamSynchronize(s.stream));
+  }
+  return IDOCP_OK;
+}
 // Runs `body` between ncclGroupStart and ncclGroupEnd.  The group is ALWAYS closed: a failed send / recv inside an open group would
 // otherwise leave every later RCCL call of this thread queued in a group that never ends (and the peers hanging).  The first error wins.
 template <typename Body>
@@ -156,6 +199,15 @@ int xallreduce(DistState& s, double* d_buf, size_t n, int op) {
   idocp_comm* c = s.comm;
   if (c->world == 1 && !c->force_collectives) return IDOCP_OK;
   if (c->nccl) { NCCLC(g_rccl.AllReduce(d_buf, d_buf, n, ncclDouble, op == 0 ? ncclSum : ncclMin, c->nccl, s.stream)); return IDOCP_OK; }
+  if (c->has_cb) {
+    s.hred.resize(n);
+    HIPC(hipMemcpyAsync(s.hred.data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    if (c->cb.allreduce(c->cb.ctx, s.hred.data(), (unsigned long)n, op)) return fail(IDOCP_E_DEVICE, "callback transport: allreduce failed");
+    HIPC(hipMemcpyAsync(d_buf, s.hred.data(), n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    return IDOCP_OK;
+  }
   LocalHub* hub = c->hub;
   std::vector<double> mine(n);
   HIPC(hipMemcpyAsync(mine.data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, s.stream));
@@ -182,6 +234,17 @@ int xallreduce(DistState& s, double* d_buf, size_t n, int op) {
 int xbroadcast(DistState& s, int kind, int root) {      // sendb[kind] of `root` -> recvb[kind] of everybody
   idocp_comm* c = s.comm;
   if (c->nccl) { NCCLC(g_rccl.Broadcast(s.sendb[kind], s.recvb[kind], s.count[kind], ncclDouble, root, c->nccl, s.stream)); return IDOCP_OK; }
+  if (c->has_cb) {
+    s.hrecv[kind].resize(s.count[kind]);
+    if (c->rank == root) {
+      HIPC(hipMemcpyAsync(s.hrecv[kind].data(), s.sendb[kind], s.count[kind] * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+      HIPC(hipStreamSynchronize(s.stream));
+    }
+    if (c->cb.broadcast(c->cb.ctx, s.hrecv[kind].data(), (unsigned long)s.count[kind], root)) return fail(IDOCP_E_DEVICE, "callback transport: broadcast failed");
+    HIPC(hipMemcpyAsync(s.recvb[kind], s.hrecv[kind].data(), s.count[kind] * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIPC(hipStreamSynchronize(s.stream));
+    return IDOCP_OK;
+  }
   if (c->rank == root) {
     for (int p = 0; p < c->world; ++p) if (p != root) RC(xsend(s, kind, p));
     HIPC(hipMemcpyAsync(s.recvb[kind], s.sendb[kind], s.count[kind] * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
@@ -204,7 +267,7 @@ int exchangeBoundary(idocp_ocp_t* h, DistState& s) {
   if (right) RC(idocp_parnmpc_export_halo_async(h, STATE_LAST, s.sendb[STATE_LAST]));
   if (left) { RC(idocp_parnmpc_export_halo_async(h, COSTATE_FIRST, s.sendb[COSTATE_FIRST])); RC(idocp_parnmpc_export_halo_async(h, AUX_FIRST, s.sendb[AUX_FIRST])); }
   RC(xgrouped(s, [&]() -> int {
-    if (s.comm->nccl) {
+    if (s.comm->nccl || s.comm->has_cb) {
       if (right) RC(xsend(s, STATE_LAST, rank + 1));
       if (left) { RC(xrecv(s, STATE_LAST, rank - 1)); RC(xsend(s, COSTATE_FIRST, rank - 1)); RC(xsend(s, AUX_FIRST, rank - 1)); }
       if (right) { RC(xrecv(s, COSTATE_FIRST, rank + 1)); RC(xrecv(s, AUX_FIRST, rank + 1)); }
@@ -266,8 +329,18 @@ int idocp_comm_init_local(int world, int device, idocp_comm_t** out) {
   return IDOCP_OK;
 }
 
+int idocp_comm_init_callbacks(int rank, int world, int device, const idocp_comm_callbacks_t* cb, idocp_comm_t** out) {
+  if (!cb || !out || world < 1 || rank < 0 || rank >= world) return fail(IDOCP_E_ARG, "idocp_comm_init_callbacks: invalid argument");
+  if (!cb->send || !cb->recv || !cb->allreduce || !cb->broadcast) return fail(IDOCP_E_ARG, "idocp_comm_init_callbacks: send, recv, allreduce and broadcast are required");
+  idocp_comm* c = new idocp_comm();
+  c->rank = rank; c->world = world; c->device = device; c->has_cb = true; c->cb = *cb;
+  *out = c;
+  return IDOCP_OK;
+}
+
 void idocp_comm_destroy(idocp_comm_t* c) {
   if (!c) return;
+  if (c->has_cb && c->cb.destroy) c->cb.destroy(c->cb.ctx);
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   if (c->hub) {
     bool last;
@@ -278,7 +351,7 @@ void idocp_comm_destroy(idocp_comm_t* c) {
 }
 
 // What the communicator itself reports (not what it was asked for): ncclCommCount, ncclCommUserRank, ncclGetVersion -- the bench prints
-// them so that a scaling line can be read against the ranks RCCL really connected.  transport: 1 RCCL, 0 the in-process test transport.
+// them so that a scaling line can be read against the ranks RCCL really connected.  transport: 1 RCCL, 0 the in-process test transport, 2 caller-supplied callbacks.
 int idocp_comm_info(const idocp_comm_t* c, int* nranks, int* user_rank, int* rccl_version, int* transport) {
   if (!c) return IDOCP_E_ARG;
   int n = c->world, r = c->rank, ver = 0;
@@ -290,7 +363,7 @@ int idocp_comm_info(const idocp_comm_t* c, int* nranks, int* user_rank, int* rcc
   if (nranks) *nranks = n;
   if (user_rank) *user_rank = r;
   if (rccl_version) *rccl_version = ver;
-  if (transport) *transport = c->nccl ? 1 : 0;
+  if (transport) *transport = c->nccl ? 1 : (c->has_cb ? 2 : 0);
   return IDOCP_OK;
 }
 int idocp_comm_rank(const idocp_comm_t* c) { return c ? c->rank : -1; }

@@ -576,6 +576,27 @@ int idocp_comm_init_rank(const void* id, int rank, int world, int device, idocp_
 /* `world` endpoints on ONE GPU in one process (out[world]; one host thread per endpoint): the transport of the single-GPU test
  * of this driver, not a product path. */
 int idocp_comm_init_local(int world, int device, idocp_comm_t** out);
+/* Host-staged transport through caller-supplied functions (an MPI or gloo communicator the caller already owns; the cross-process test of
+ * the driver on a one-GPU box).  The driver makes the SAME calls in the same order and grouping as on RCCL
+ * (src/ocp/backward_correction_solver.cpp:255-366 is the computation being distributed):
+ *   send / recv   n doubles to / from rank `peer`.  in_group != 0: between group_start and group_end the call may only POST the transfer
+ *                 (buffers stay valid until group_end returns; ncclGroupStart / ncclGroupEnd semantics: a send and its matching receive of the
+ *                 same group never block each other); in_group == 0: complete before returning
+ *   group_start / group_end   optional (NULL: every send / recv must then be able to complete on its own)
+ *   allreduce     in place on n doubles, op 0 = sum, 1 = min;   broadcast   n doubles from rank `root`
+ *   destroy       optional, called by idocp_comm_destroy
+ * Every function returns 0 on success. */
+typedef struct idocp_comm_callbacks {
+  void* ctx;
+  int (*send)(void* ctx, const double* buf, unsigned long n, int peer, int in_group);
+  int (*recv)(void* ctx, double* buf, unsigned long n, int peer, int in_group);
+  int (*group_start)(void* ctx);
+  int (*group_end)(void* ctx);
+  int (*allreduce)(void* ctx, double* buf, unsigned long n, int op);
+  int (*broadcast)(void* ctx, double* buf, unsigned long n, int root);
+  void (*destroy)(void* ctx);
+} idocp_comm_callbacks_t;
+int idocp_comm_init_callbacks(int rank, int world, int device, const idocp_comm_callbacks_t* cb, idocp_comm_t** out);
 void idocp_comm_destroy(idocp_comm_t* c);
 int idocp_comm_rank(const idocp_comm_t* c);
 int idocp_comm_world(const idocp_comm_t* c);
