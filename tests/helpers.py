@@ -274,13 +274,46 @@ def parity(g, o, h, what, tol=1e-10, cap=None):
     + 1e-10) -- never a loosened tolerance on its own.  h: the referee's value, or a callable that produces it (only evaluated when
     needed).  cap: optional hard limit on the GPU-oracle distance even under the referee rule.  Returns the GPU-oracle distance."""
     e = rel_err(g, o)
+    hv = None
     if e >= tol:
         hv = h() if callable(h) else h
         assert hv is not None, (what, "%.2e against the oracle and no referee" % e)
+    _parity_table(g, o, hv, what, tol, cap)
+    if e >= tol:
         referee_check(g, o, hv, what, tol=tol)
     if cap is not None:
         assert e < cap, (what, e)
     return e
+
+
+def _parity_table(g, o, hv, what, tol, cap):
+    """IDOCP_PARITY_TABLE_DIR=<dir>: every parity() call appends its PER-STAGE error table to <dir>/parity_tables.txt -- the GPU-oracle distance
+    of every stage (relative to the stage's largest entry, like rel_err) and, where the referee was consulted, both distances from it -- so that a
+    regression INSIDE a cap or inside the referee rule's slack is visible in the committed copy (profiles/rNN_parity_tables.txt)."""
+    d = os.environ.get("IDOCP_PARITY_TABLE_DIR")
+    if not d:
+        return
+    ga, oa = np.asarray(g, dtype=np.float64), np.asarray(o, dtype=np.float64)
+    if ga.ndim < 2 or ga.shape != oa.shape:
+        return
+    n = ga.shape[0]
+    ga, oa = ga.reshape(n, -1), oa.reshape(n, -1)
+    scale = np.maximum(1.0, np.abs(oa).max(axis=1))
+    ego = np.abs(ga - oa).max(axis=1) / scale
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_tables.txt"), "a") as f:
+        f.write("## [%s] %s   tol %.0e  cap %s  worst %.2e at stage %d  (%d stages, %d above tol)\n" % (os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], what, tol, "%.0e" % cap if cap else "-", ego.max(), int(ego.argmax()), n, int((ego >= tol).sum())))
+        if hv is not None:
+            ha = np.asarray(hv, dtype=np.float64).reshape(n, -1)
+            sh = np.maximum(1.0, np.abs(ha).max(axis=1))
+            egh, eoh = np.abs(ga - ha).max(axis=1) / sh, np.abs(oa - ha).max(axis=1) / sh
+            f.write("# stage  gpu-oracle  gpu-referee  oracle-referee   (only stages above tol / 10)\n")
+            for i in range(n):
+                if ego[i] >= tol / 10:
+                    f.write("%6d  %.2e  %.2e  %.2e\n" % (i, ego[i], egh[i], eoh[i]))
+        else:
+            worst = np.argsort(ego)[::-1][:5]
+            f.write("# five worst stages (gpu-oracle): " + "  ".join("%d: %.2e" % (int(i), ego[i]) for i in worst) + "\n")
 
 def pairwise_check(a, b, o, h, what, tol=1e-10, factor=4.0, window=3):
     """Two GPU evaluations a, b of the same quantity (e.g. two instantiations of a kernel) against EACH OTHER, stage by stage, at the
