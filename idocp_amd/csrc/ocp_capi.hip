@@ -149,6 +149,13 @@ struct idocp_ocp {
   double *d_fill = nullptr, *h_fill = nullptr;
   size_t fill_cap = 0;
   hipEvent_t fill_done = nullptr;
+  // fork / join inside an iteration (round 6): the switching-constraint kernel K5s -- one latency-bound wavefront per stage that carries a
+  // switching constraint, 0.09 ms on configs[2] with most of the chip idle -- runs on a stream of its own NEXT TO the nominal sweeps K5n (both
+  // read the iterate only and write records of their own); the condensation launches wait for both.  IDOCP_SIDE_STREAM=0 keeps everything on
+  // the handle's stream.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_pending = false;          // a kernel is in flight on `side` that the next condensation launch has to wait for
 };
 
 namespace {
@@ -725,6 +732,13 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   h->NS = N + 1 + 3 * max_num_impulse;
   auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_last_error("hipStreamCreate failed"); return fail(IDOCP_E_DEVICE); }
+  {
+    static const bool use_side = !(getenv("IDOCP_SIDE_STREAM") && atoi(getenv("IDOCP_SIDE_STREAM")) == 0);
+    if (use_side && !parnmpc) {
+      if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { set_last_error("side stream: hipStreamCreate / hipEventCreate failed"); return fail(IDOCP_E_DEVICE); }
+    }
+  }
   const size_t ns = (size_t)batch * h->NS;
   OcpBuffers& B = h->B;
   int rc;
@@ -874,6 +888,9 @@ void idocp_ocp_destroy(idocp_ocp_t* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_fill) (void)hipFree(h->d_fill);
   if (h->h_fill) (void)hipHostFree(h->h_fill);
   if (h->fill_done) (void)hipEventDestroy(h->fill_done);
@@ -1169,11 +1186,48 @@ static void launchForwardO(idocp_ocp_t* h, int M, const double* d_q, const doubl
 }
 
 // one SQP iteration on the handle's stream: K5 (+ K5a on impulse stages, K5s), S3, the forward sweep with the primal expansion (S4 + K6), K7
+// K5s (and ParNMPC's impulse kernel K5a) in front of the condensation: on the side stream where the handle has one and the chain carries
+// switching constraints (fork here, join in joinSideO before the condensation launches), else on the handle's stream
+static int launchSwitchO(idocp_ocp_t* h, int M) {
+  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
+  if (!h->has_switch) return IDOCP_OK;
+  if (!h->side) { OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream); return IDOCP_OK; }
+  HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  OcpLaunch<DQ>::switching(h->B, h->batch, M, h->side);
+  HIP_TRY(hipEventRecord(h->ev_join, h->side));
+  h->side_pending = true;
+  return IDOCP_OK;
+}
+static int joinSideO(idocp_ocp_t* h) {
+  if (h->side_pending) { HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0)); h->side_pending = false; }
+  return IDOCP_OK;
+}
+// the condensation launches proper: on a chain with several stage classes the largest class on the handle's stream and the others beside it on
+// the side stream (their tails blend instead of adding up); joined before the external Hessian / the Riccati sweep
+static int launchCondenseClassesO(idocp_ocp_t* h, int M, const double* d_q) {
+  int rc;
+  if ((rc = joinSideO(h))) return rc;
+  const bool mixed = !(h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] + h->cond_n[3] + h->cond_n[4] == 0);
+  // OFF by default: measured (round 6, profiles/experiments/r06_side_stream.md) -- two different instantiations of the 57 kB condensation kernel
+  // resident together take 3.2 instead of 2.24 ms (configs[2]); IDOCP_SIDE_STREAM_K5=1 repeats the experiment
+  static const bool split = getenv("IDOCP_SIDE_STREAM_K5") && atoi(getenv("IDOCP_SIDE_STREAM_K5")) != 0;
+  if (!mixed || !h->side || !split || h->cond_n[1] == 0) { launchCondenseO(h, M, d_q, 2); return IDOCP_OK; }
+  HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, 3);
+  OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->side, 4);
+  HIP_TRY(hipEventRecord(h->ev_join, h->side));
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, 5);
+  return IDOCP_OK;
+}
 static int launchUpdateO(idocp_ocp_t* h, int M, const double* d_q, const double* d_v) {
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
-  OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
-  if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
-  launchCondenseO(h, M, d_q);
+  int rc;
+  if ((rc = launchSwitchO(h, M))) return rc;
+  launchCondenseO(h, M, d_q, 1);                          // nominal sweeps (+ Lie tasks, external rows): beside K5s
+  if ((rc = launchCondenseClassesO(h, M, d_q))) return rc;
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h));
   launchForwardO(h, M, d_q, d_v);
   OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
@@ -1187,13 +1241,10 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
   if (h->seq_dirty || h->disc_time != h->disc_time) { if ((rc = discretize(h, h->disc_time == h->disc_time ? h->disc_time : 0.0))) return rc; }
   const int M = h->M();
   switch (kernel_id) {
-    case 0:
-      OcpLaunch<DQ>::rnea(h->B, h->batch, M, h->n_impulse, h->stream);
-      if (h->has_switch) OcpLaunch<DQ>::switching(h->B, h->batch, M, h->stream);
-      break;
-    case 1: launchCondenseO(h, M, d_q); break;
+    case 0: if ((rc = launchSwitchO(h, M))) return rc; break;      // (with a side stream: K5s starts there and id 8 / 1 waits for it)
+    case 1: launchCondenseO(h, M, d_q, 1); if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;
     case 7: launchCondenseO(h, M, d_q, 1); break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
-    case 8: launchCondenseO(h, M, d_q, 2); break;      // ... and the condensation launches proper
+    case 8: if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;      // ... and the condensation launches proper
     case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h)); break;
     // 3: the forward sweep.  Since round 5 it expands as it walks (S4 + K6 + the step-size reduction in one kernel, ocp_forward_expand_kernel);
     // ids 4 and 5 are then empty.  IDOCP_FUSED_FORWARD=0 restores the three kernels behind ids 3, 4, 5.

@@ -1103,15 +1103,17 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
     OcpLaunch<D>::extRows(B, batch, M, false, st);
   }
   if (part == 1) return;
+  if (part == 5) { OcpLaunch<D>::extHessian(B, batch, M, st); return; }
   // the largest class first; the launches are independent (every stage writes its own records)
-  if (n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
-  if (n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
+  const bool big = part != 4, rest = part != 3;
+  if (big && n[1] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2>), dim3((unsigned)(batch * n[1])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0], n[1]); }
+  if (rest && n[0] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF, false, false, true>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF>), dim3((unsigned)(batch * n[0])), dim3(256), smem, st, B, q0, none, B.cond_pos, n[0]); }
   // class 4: flight stages (no contact rows at all; the narrow LDS layout, every contact loop folded away)
-  if (n[4] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0, false, false, true>), dim3((unsigned)(batch * n[4])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0>), dim3((unsigned)(batch * n[4])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); }
+  if (rest && n[4] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0, false, false, true>), dim3((unsigned)(batch * n[4])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, 0>), dim3((unsigned)(batch * n[4])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2] + n[3], n[4]); }
   // class 3: event stages (impulse / switching constraint) with half of the feet
-  if (n[3] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); }
-  if (n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
-  OcpLaunch<D>::extHessian(B, batch, M, st);
+  if (rest && n[3] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, true, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, D::NF / 2, false, false, false, true>), dim3((unsigned)(batch * n[3])), dim3(256), smem_half, st, B, q0, none, B.cond_pos + n[0] + n[1] + n[2], n[3]); }
+  if (rest && n[2] > 0) { if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1, false, false, true>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); else hipLaunchKernelGGL((ocp_condense_kernel<D, false, -1>), dim3((unsigned)(batch * n[2])), dim3(256), smem, st, B, q0, none, B.cond_pos + n[0] + n[1], n[2]); }
+  if (part == 0 || part == 2) OcpLaunch<D>::extHessian(B, batch, M, st);
 }
 // Line search: cost and l1 violation of every stage of the chain for the iterate Btry.sol points at (Btry.nodes: the chain with the
 // reference's pairing of the successors).  The caller has run the impulse RNEA and the switching kernel on Btry.

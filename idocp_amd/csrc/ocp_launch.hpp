@@ -19,6 +19,9 @@ struct OcpLaunch {
   // q0_lie != nullptr: with the Lie-group tasks of the forward-Euler stages (else the caller launches a lie kernel itself)
   static void nominal(const OcpBuffers& B, long batch, int M, hipStream_t st, const double* q0_lie = nullptr);      // K5n: nominal Newton-Euler sweeps -> nom record (every K5 / K8 / merit launch is preceded by it)
   static void condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st, int part = 0);   // K5b (+ terminal); dimf = -1: mixed chain
+  // part 0: everything; 1: the nominal sweeps + external rows; 2: the class launches + external Hessian; 3: the LARGEST class only; 4: the other
+  // classes only (parts 3 and 4 let the caller put them on two streams: the launches are independent, every stage writes its own records);
+  // 5: the external Hessian only
   static void condenseMixed(const OcpBuffers& B, long batch, int M, const int n[5], const double* q0, hipStream_t st, int part = 0);   // K5b on a chain with events, per stage class
   static void residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st);   // K8
   static void condenseBackwardEuler(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, bool residual,
