@@ -733,8 +733,10 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_last_error("hipStreamCreate failed"); return fail(IDOCP_E_DEVICE); }
   {
+    // (a batch of instances only: at batch 1 the two event hand-offs cost more than the 9 wavefronts of K5s -- 1.09 against 1.06 ms per iteration)
     static const bool use_side = !(getenv("IDOCP_SIDE_STREAM") && atoi(getenv("IDOCP_SIDE_STREAM")) == 0);
-    if (use_side && !parnmpc) {
+    static const int side_min_batch = getenv("IDOCP_SIDE_STREAM_MIN_BATCH") ? atoi(getenv("IDOCP_SIDE_STREAM_MIN_BATCH")) : 128;
+    if (use_side && !parnmpc && batch >= side_min_batch) {
       if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { set_last_error("side stream: hipStreamCreate / hipEventCreate failed"); return fail(IDOCP_E_DEVICE); }
     }
@@ -1138,9 +1140,9 @@ int idocp_ocp_init_constraints(idocp_ocp_t* h, double t) {
 }
 
 // K5b: one launch on an event-free chain with all feet in contact, else one launch per stage class
-static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q, int part = 0) {
+static void launchCondenseO(idocp_ocp_t* h, int M, const double* d_q, int part = 0, hipStream_t st_imp = nullptr) {
   if (h->uniform_dimf == DQ::NF || h->cond_n[0] + h->cond_n[1] + h->cond_n[3] + h->cond_n[4] == 0) OcpLaunch<DQ>::condense(h->B, h->batch, M, h->uniform_dimf, d_q, h->stream, part);
-  else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, part);
+  else OcpLaunch<DQ>::condenseMixed(h->B, h->batch, M, h->cond_n, d_q, h->stream, part, st_imp);
 }
 
 // The forward sweep that expands as it walks (ocp_forward_expand_kernel) pays when the stage-parallel expansion it absorbs is bandwidth: a
@@ -1195,12 +1197,28 @@ static int launchSwitchO(idocp_ocp_t* h, int M) {
   HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   OcpLaunch<DQ>::switching(h->B, h->batch, M, h->side);
-  HIP_TRY(hipEventRecord(h->ev_join, h->side));
-  h->side_pending = true;
+  h->side_pending = true;                              // (the join event is recorded by launchNominalO, behind the impulse stages' nominal launch)
+  return IDOCP_OK;
+}
+// the nominal sweeps K5n on the handle's stream; with a fork open (launchSwitchO) the small launch over the impulse stages goes beside them too
+static int launchNominalO(idocp_ocp_t* h, int M, const double* d_q) {
+  launchCondenseO(h, M, d_q, 1, h->side_pending ? h->side : nullptr);
+  if (h->side_pending) HIP_TRY(hipEventRecord(h->ev_join, h->side));
   return IDOCP_OK;
 }
 static int joinSideO(idocp_ocp_t* h) {
   if (h->side_pending) { HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0)); h->side_pending = false; }
+  return IDOCP_OK;
+}
+// K7 and, independent of it, the base poses K7b: beside each other where the handle has a side stream (joined at once: the next iteration
+// reads both)
+static int launchIntegrateO(idocp_ocp_t* h, int M) {
+  if (!h->side) { OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream); return IDOCP_OK; }
+  HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream, h->side);
+  HIP_TRY(hipEventRecord(h->ev_join, h->side));
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   return IDOCP_OK;
 }
 // the condensation launches proper: on a chain with several stage classes the largest class on the handle's stream and the others beside it on
@@ -1226,11 +1244,11 @@ static int launchUpdateO(idocp_ocp_t* h, int M, const double* d_q, const double*
   HIP_TRY(hipMemsetAsync(h->B.status, 0, sizeof(int) * h->batch, h->stream));
   int rc;
   if ((rc = launchSwitchO(h, M))) return rc;
-  launchCondenseO(h, M, d_q, 1);                          // nominal sweeps (+ Lie tasks, external rows): beside K5s
+  if ((rc = launchNominalO(h, M, d_q))) return rc;        // nominal sweeps (+ Lie tasks, external rows): beside K5s
   if ((rc = launchCondenseClassesO(h, M, d_q))) return rc;
   OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h));
   launchForwardO(h, M, d_q, d_v);
-  OcpLaunch<DQ>::expandDualIntegrate(h->B, h->batch, M, h->stream);
+  if ((rc = launchIntegrateO(h, M))) return rc;
   HIP_TRY(hipGetLastError());
   return IDOCP_OK;
 }
@@ -1242,14 +1260,15 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
   const int M = h->M();
   switch (kernel_id) {
     case 0: if ((rc = launchSwitchO(h, M))) return rc; break;      // (with a side stream: K5s starts there and id 8 / 1 waits for it)
-    case 1: launchCondenseO(h, M, d_q, 1); if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;
-    case 7: launchCondenseO(h, M, d_q, 1); break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
+    case 1: if ((rc = launchNominalO(h, M, d_q))) return rc; if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;
+    case 7: if ((rc = launchNominalO(h, M, d_q))) return rc; break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
     case 8: if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;      // ... and the condensation launches proper
     case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h)); break;
     // 3: the forward sweep.  Since round 5 it expands as it walks (S4 + K6 + the step-size reduction in one kernel, ocp_forward_expand_kernel);
     // ids 4 and 5 are then empty.  IDOCP_FUSED_FORWARD=0 restores the three kernels behind ids 3, 4, 5.
     case 3: if (fusedForward(h)) OcpLaunch<DQ>::forwardExpand(h->B, h->batch, M, d_q, d_v, h->stream); else OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
     case 4: case 5: if (!fusedForward(h)) OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;
+    case 6: if ((rc = launchIntegrateO(h, M))) return rc; break;
     default: OcpLaunch<DQ>::single(kernel_id, h->B, h->batch, M, h->stream); break;
   }
   HIP_TRY(hipGetLastError());

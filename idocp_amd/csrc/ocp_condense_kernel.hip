@@ -1080,7 +1080,7 @@ void OcpLaunch<D>::condense(const OcpBuffers& B, long batch, int M, int dimf, co
 // class 2: everything else (impulse stages, stages carrying a switching constraint, other contact counts, the terminal
 // stage) on the general instantiation.  B.cond_pos holds the chain positions class by class, n[c] their counts.
 template <typename D>
-void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[5], const double* q0, hipStream_t st, int part) {
+void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const int n[5], const double* q0, hipStream_t st, int part, hipStream_t st_imp) {
   const size_t smem = CondenseSmem<D>::TOTAL * sizeof(double), smem_half = CondenseSmem<D, D::NF / 2>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
@@ -1099,7 +1099,7 @@ void OcpLaunch<D>::condenseMixed(const OcpBuffers& B, long batch, int M, const i
   const unsigned blocks = (unsigned)(batch * M);
   const double* none = nullptr;
   if (part != 2) {
-    OcpLaunch<D>::nominal(B, batch, M, st, q0);      // (+ the Lie-group tasks)
+    OcpLaunch<D>::nominal(B, batch, M, st, q0, st_imp);      // (+ the Lie-group tasks)
     OcpLaunch<D>::extRows(B, batch, M, false, st);
   }
   if (part == 1) return;
@@ -1172,7 +1172,7 @@ void OcpLaunch<D>::condenseBackwardEuler(const OcpBuffers& B, long batch, int M,
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::condense(const OcpBuffers&, long, int, int, const double*, hipStream_t, int);
-template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t, int);
+template void OcpLaunch<LeggedDims<4, 3>>::condenseMixed(const OcpBuffers&, long, int, const int*, const double*, hipStream_t, int, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::merit(const OcpBuffers&, long, int, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::meritBackwardEuler(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::residual(const OcpBuffers&, long, int, const double*, hipStream_t);

@@ -1034,10 +1034,10 @@ void OcpLaunch<D>::forwardExpand(const OcpBuffers& B, long batch, int M, const d
   hipLaunchKernelGGL((ocp_forward_expand_kernel<D>), dim3((unsigned)batch), dim3(128), 0, st, B, q0, v0);
 }
 template <typename D>
-void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
+void OcpLaunch<D>::expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st, hipStream_t st_base) {
   hipLaunchKernelGGL((ocp_expand_dual_integrate_kernel<D>), dim3((unsigned)(batch * M)), dim3(64), 0, st, B);
   const long total = batch * M;                      // K7b: the base poses, one lane per stage
-  hipLaunchKernelGGL((ocp_integrate_base_kernel<D>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, B, total);
+  hipLaunchKernelGGL((ocp_integrate_base_kernel<D>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st_base ? st_base : st, B, total);
 }
 template <typename D>
 void OcpLaunch<D>::trialIterate(const OcpBuffers& B, long batch, int M, hipStream_t st) {
@@ -1072,7 +1072,7 @@ void ocpFillField(double* sol, int stride, int offset, int dim, long nrec_per_in
 }
 
 template void OcpLaunch<LeggedDims<4, 3>>::expandPrimal(const OcpBuffers&, long, int, hipStream_t);
-template void OcpLaunch<LeggedDims<4, 3>>::expandDualIntegrate(const OcpBuffers&, long, int, hipStream_t);
+template void OcpLaunch<LeggedDims<4, 3>>::expandDualIntegrate(const OcpBuffers&, long, int, hipStream_t, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::forwardExpand(const OcpBuffers&, long, int, const double*, const double*, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::trialIterate(const OcpBuffers&, long, int, hipStream_t);
 template void OcpLaunch<LeggedDims<4, 3>>::meritReduce(const OcpBuffers&, long, hipStream_t);

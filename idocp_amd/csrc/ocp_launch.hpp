@@ -17,12 +17,12 @@ struct OcpLaunch {
   static void rnea(const OcpBuffers& B, long batch, int M, int n_impulse, hipStream_t st);      // K5a (M - 1 stages; the n_impulse impulse stages in a launch of their own)
   static void switching(const OcpBuffers& B, long batch, int M, hipStream_t st);     // K5s: switching-constraint terms (all stages; no-op where absent)
   // q0_lie != nullptr: with the Lie-group tasks of the forward-Euler stages (else the caller launches a lie kernel itself)
-  static void nominal(const OcpBuffers& B, long batch, int M, hipStream_t st, const double* q0_lie = nullptr);      // K5n: nominal Newton-Euler sweeps -> nom record (every K5 / K8 / merit launch is preceded by it)
+  static void nominal(const OcpBuffers& B, long batch, int M, hipStream_t st, const double* q0_lie = nullptr, hipStream_t st_imp = nullptr);      // st_imp: the launch over the impulse stages of a forward-Euler chain on a stream of its own      // K5n: nominal Newton-Euler sweeps -> nom record (every K5 / K8 / merit launch is preceded by it)
   static void condense(const OcpBuffers& B, long batch, int M, int dimf, const double* q0, hipStream_t st, int part = 0);   // K5b (+ terminal); dimf = -1: mixed chain
   // part 0: everything; 1: the nominal sweeps + external rows; 2: the class launches + external Hessian; 3: the LARGEST class only; 4: the other
   // classes only (parts 3 and 4 let the caller put them on two streams: the launches are independent, every stage writes its own records);
   // 5: the external Hessian only
-  static void condenseMixed(const OcpBuffers& B, long batch, int M, const int n[5], const double* q0, hipStream_t st, int part = 0);   // K5b on a chain with events, per stage class
+  static void condenseMixed(const OcpBuffers& B, long batch, int M, const int n[5], const double* q0, hipStream_t st, int part = 0, hipStream_t st_imp = nullptr);   // K5b on a chain with events, per stage class
   static void residual(const OcpBuffers& B, long batch, int M, const double* q0, hipStream_t st);   // K8
   static void condenseBackwardEuler(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, bool residual,
                                     hipStream_t st);                                          // K9a: ParNMPC stage (K5b with backward Euler)
@@ -51,7 +51,7 @@ struct OcpLaunch {
   static void meritReduce(const OcpBuffers& B, long batch, hipStream_t st);
   static void expandPrimal(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K6 (+ step-size reduction)
   static void forwardExpand(const OcpBuffers& B, long batch, int M, const double* q0, const double* v0, hipStream_t st);   // S4 + K6 + reduction fused (round 5)
-  static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st);   // K7
+  static void expandDualIntegrate(const OcpBuffers& B, long batch, int M, hipStream_t st, hipStream_t st_base = nullptr);   // K7 (+ K7b, the base poses: independent of K7, on st_base if given)
   static void initConstraints(const OcpBuffers& B, long batch, int NS, hipStream_t st);     // every slot
   static void single(int kernel_id, const OcpBuffers& B, long batch, int M, hipStream_t st);   // ids 4, 5, 6
 };

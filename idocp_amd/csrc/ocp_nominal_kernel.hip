@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void ocp_nominal_kernel(OcpBuffers B, int dbg, 
 }
 
 template <typename D>
-void OcpLaunch<D>::nominal(const OcpBuffers& B, long batch, int M, hipStream_t st, const double* q0_lie) {
+void OcpLaunch<D>::nominal(const OcpBuffers& B, long batch, int M, hipStream_t st, const double* q0_lie, hipStream_t st_imp) {
   const unsigned ntask = 2 * D::NL + 1 + (q0_lie ? 3 : 0);
   const unsigned groups = (unsigned)((batch * M + 63) / 64), blocks = ((groups + 7) / 8) * 8 * ntask;
   static const int dbg = getenv("IDOCP_NOM_DBG") ? atoi(getenv("IDOCP_NOM_DBG")) : 0;
@@ -307,11 +307,12 @@ void OcpLaunch<D>::nominal(const OcpBuffers& B, long batch, int M, hipStream_t s
   if (B.n_impulse_fe > 0) {
     const unsigned gi = (unsigned)((batch * B.n_impulse_fe + 63) / 64), bi = ((gi + 7) / 8) * 8 * (2 * D::NL + 1);
     const double* none = nullptr;
-    if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe, none);
-    else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, true>), dim3(bi), dim3(64), 0, st, B, dbg, B.n_impulse_fe, none);
+    hipStream_t si = st_imp ? st_imp : st;      // (impulse stages have records of their own: independent of the launch above)
+    if (B.leg_axes_xyy) hipLaunchKernelGGL((ocp_nominal_kernel<D, true, true>), dim3(bi), dim3(64), 0, si, B, dbg, B.n_impulse_fe, none);
+    else hipLaunchKernelGGL((ocp_nominal_kernel<D, false, true>), dim3(bi), dim3(64), 0, si, B, dbg, B.n_impulse_fe, none);
   }
 }
 
-template void OcpLaunch<LeggedDims<4, 3>>::nominal(const OcpBuffers&, long, int, hipStream_t, const double*);
+template void OcpLaunch<LeggedDims<4, 3>>::nominal(const OcpBuffers&, long, int, hipStream_t, const double*, hipStream_t);
 
 }  // namespace idocp_dev
