@@ -38,6 +38,11 @@ class Model(C.Structure):
     ]
 
 
+class TaskComponent(C.Structure):
+    _fields_ = [("dim", C.c_int), ("joint", C.c_int), ("frame_R", C.c_double * 9), ("frame_p", C.c_double * 3),
+                ("weight", C.c_double * 6), ("weightf", C.c_double * 6), ("weighti", C.c_double * 6), ("ref", C.c_double * 12)]
+
+
 class Cost(C.Structure):
     _fields_ = [
         ("q_ref", C.c_double * MAX_NQ), ("v_ref", C.c_double * MAX_NV), ("u_ref", C.c_double * MAX_NV),
@@ -55,7 +60,21 @@ class Cost(C.Structure):
         ("task_dim", C.c_int), ("task_joint", C.c_int), ("task_frame_R", C.c_double * 9), ("task_frame_p", C.c_double * 3),
         ("task_weight", C.c_double * 6), ("task_weightf", C.c_double * 6), ("task_ref", C.c_double * 12), ("task_time_varying", C.c_int),
         ("task_weighti", C.c_double * 6),
+        ("task_extra_count", C.c_int), ("task_extra", TaskComponent * 3),
     ]
+
+    def add_task(self, dim, joint, frame_R, frame_p, weight, weightf, ref, weighti=None):
+        """one more TaskSpace3DCost / TaskSpace6DCost component (idocp_cost_t::task_extra; the first one lives in the task_* fields)"""
+        assert self.task_dim != 0 and self.task_extra_count < 3
+        t = self.task_extra[self.task_extra_count]
+        t.dim, t.joint = int(dim), int(joint)
+        for name, vals in (("frame_R", frame_R), ("frame_p", frame_p), ("weight", weight), ("weightf", weightf), ("weighti", weighti if weighti is not None else weight), ("ref", ref)):
+            arr = getattr(t, name)
+            vals = np.asarray(vals, dtype=np.float64).ravel()
+            for i in range(len(arr)):
+                arr[i] = float(vals[i]) if i < len(vals) else 0.0
+        self.task_extra_count += 1
+        return self
 
     def set(self, name, values):
         arr = getattr(self, name)

@@ -24,6 +24,7 @@ struct TaskCost {
   int joint;           // parent joint of the frame
   double R[9], p[3];   // placement of the frame in the joint frame (R row-major)
   double weight[6], weightf[6];
+  double ref[12];      // constant reference of a task_extra component (the first component's references live in UnBuffers::task_ref, per stage)
 };
 
 // diff[6] and, for joint k, col[6] = JJ[:, k].  cs = {cos q_i, sin q_i}; ref = rotation (row-major) + position.

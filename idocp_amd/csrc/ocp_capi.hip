@@ -687,6 +687,30 @@ static void fillCostFields(OcpProblem& p, const idocp_cost_t& cost) {
   for (int k = 0; k < 3; ++k) p.task_p[k] = cost.task_frame_p[k];
   for (int k = 0; k < 6; ++k) { p.task_weight[k] = cost.task_weight[k]; p.task_weightf[k] = cost.task_weightf[k]; p.task_weighti[k] = cost.task_weighti[k]; }
   for (int k = 0; k < 12; ++k) p.task_ref[k] = cost.task_ref[k];
+  const int nextra = cost.task_dim ? cost.task_extra_count : 0;
+  p.task_n = cost.task_dim ? 1 + nextra : 0;
+  for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) {
+    OcpProblem::TaskExtra& o = p.task_extra[e];
+    std::memset(&o, 0, sizeof(o));
+    if (e >= nextra) continue;
+    const idocp_task_component_t& t = cost.task_extra[e];
+    o.dim = t.dim; o.joint = t.joint;
+    for (int k = 0; k < 9; ++k) o.R[k] = t.frame_R[k];
+    for (int k = 0; k < 3; ++k) o.p[k] = t.frame_p[k];
+    for (int k = 0; k < 6; ++k) { o.weight[k] = t.weight[k]; o.weightf[k] = t.weightf[k]; o.weighti[k] = t.weighti[k]; }
+    for (int k = 0; k < 12; ++k) o.ref[k] = t.ref[k];
+  }
+}
+// the task_extra components of a cost block (idocp_cost_t): count, dimensions and frames
+static int checkTaskExtras(const idocp_cost_t* cost) {
+  if (cost->task_extra_count < 0 || cost->task_extra_count > IDOCP_MAX_EXTRA_TASKS) { set_last_error("invalid value: task_extra_count must be 0 .. " + std::to_string(IDOCP_MAX_EXTRA_TASKS)); return IDOCP_E_ARG; }
+  if (cost->task_extra_count > 0 && cost->task_dim == 0) { set_last_error("invalid value: task_extra components need the first task-space component (task_dim != 0)"); return IDOCP_E_ARG; }
+  for (int e = 0; e < cost->task_extra_count; ++e) {
+    const idocp_task_component_t& t = cost->task_extra[e];
+    if (t.dim != 3 && t.dim != 6) { set_last_error("invalid value: task_extra[" + std::to_string(e) + "].dim must be 3 or 6"); return IDOCP_E_ARG; }
+    if (t.joint < 0 || t.joint > DQ::NU) { set_last_error("invalid value: the frame of task_extra[" + std::to_string(e) + "] must sit on the floating base or on a leg link"); return IDOCP_E_ARG; }
+  }
+  return IDOCP_OK;
 }
 
 static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints, double T,
@@ -717,6 +741,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
     if (cost->task_dim != 3 && cost->task_dim != 6) { set_last_error("invalid value: task_dim must be 0, 3 or 6"); return IDOCP_E_ARG; }
     if (cost->task_joint < 0 || cost->task_joint > DQ::NU) { set_last_error("invalid value: the task frame must sit on the floating base or on a leg link"); return IDOCP_E_ARG; }
   }
+  { const int rc_t = checkTaskExtras(cost); if (rc_t) return rc_t; }
   if (!isQuadruped(*model)) {
     set_last_error("idocp_ocp_create: this build carries OCP kernels for a floating-base quadruped (4 legs x 3 joints, 4 point contacts) only");
     return IDOCP_E_UNSUPPORTED;
@@ -2050,6 +2075,7 @@ int idocp_ocp_set_cost(idocp_ocp_t* h, const idocp_cost_t* cost) {
     return IDOCP_E_UNSUPPORTED;
   }
   if (cost->task_dim != 0 && (cost->task_dim != 3 && cost->task_dim != 6)) { set_last_error("invalid value: task_dim must be 0, 3 or 6"); return IDOCP_E_ARG; }
+  { const int rc_t = checkTaskExtras(cost); if (rc_t) return rc_t; }
   h->cost = *cost;
   fillCostFields(h->prob, *cost);
   h->seq_dirty = true;              // the problem block and the per-stage reference table are uploaded with the next discretisation

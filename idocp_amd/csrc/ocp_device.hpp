@@ -83,7 +83,9 @@ struct OcpLayout {
   // heights z_c, the gradient term to be added to lq, the Hessian weights, the stage's share of the KKT error / line-search violation
   // then the task-space cost (TaskSpace3DCost / TaskSpace6DCost): the rows JJ (6 x NV, row-major), their weights (time step included), the cost
   static constexpr int X_CDJ = 0, X_Z = NC * NV, X_LQ = X_Z + NC, X_W = X_LQ + NV, X_ERR = X_W + NC, X_VIOL = X_ERR + 1;
-  static constexpr int X_TJ = X_VIOL + 1, X_TW = X_TJ + 6 * NV, X_COST = X_TW + 6;
+  // (NT component slots: idocp_cost_t's task_* block and its task_extra components; unused slots carry zero weights)
+  static constexpr int NT = 1 + IDOCP_MAX_EXTRA_TASKS;
+  static constexpr int X_TJ = X_VIOL + 1, X_TW = X_TJ + NT * 6 * NV, X_COST = X_TW + NT * 6;
   static constexpr int EXT = roundUp16(X_COST + 1);
   static constexpr int G_K = 0, G_k = NU * NX;
   static constexpr int GAIN = roundUp16(G_k + NU);
@@ -193,6 +195,8 @@ struct OcpProblem {
   // stages / the terminal stage / the impulse stages, constant reference (rotation row-major, position)
   int task_dim, task_joint;
   double task_R[9], task_p[3], task_weight[6], task_weightf[6], task_weighti[6], task_ref[12];
+  int task_n;                // number of task-space components: 0, or 1 + idocp_cost_t::task_extra_count
+  struct TaskExtra { int dim, joint; double R[9], p[3], weight[6], weightf[6], weighti[6], ref[12]; } task_extra[IDOCP_MAX_EXTRA_TASKS];
   int use_a_lower, use_a_upper;         // JointAccelerationLowerLimit / UpperLimit (acceleration level: every stage with torques)
   double a_min[IDOCP_MAX_NV], a_max[IDOCP_MAX_NV];
   int cone_kind, impulse_cone_kind;     // 0: Linearized(Impulse)FrictionCone (5 rows per contact), 1: (Impulse)FrictionCone (2 rows); coneRow below

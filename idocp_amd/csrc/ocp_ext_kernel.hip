@@ -139,12 +139,25 @@ __global__ __launch_bounds__(64) void ocp_ext_kernel(OcpBuffers B, int residual)
   }
   // ---- TaskSpace3DCost / TaskSpace6DCost (task_space_3d_cost.cpp:60-157, task_space_6d_cost.cpp:68-178) ----
   double cost = 0.0;
-  if (P->task_dim != 0) {
+  // one pass per component (CostFunction sums its components): the task_* block of the cost, then its task_extra components (constant references)
+  for (int tcomp = 0; tcomp < L::NT; ++tcomp) {
+    if (tcomp >= P->task_n) {
+      for (int e = lane; e < 6 * NV; e += 64) xx[L::X_TJ + tcomp * 6 * NV + e] = 0.0;
+      if (lane < 6) xx[L::X_TW + tcomp * 6 + lane] = 0.0;
+      continue;
+    }
+    const int t_dim = tcomp == 0 ? P->task_dim : P->task_extra[tcomp - 1].dim;
+    const int t_joint = tcomp == 0 ? P->task_joint : P->task_extra[tcomp - 1].joint;
+    const double* __restrict__ t_R = tcomp == 0 ? P->task_R : P->task_extra[tcomp - 1].R;
+    const double* __restrict__ t_p = tcomp == 0 ? P->task_p : P->task_extra[tcomp - 1].p;
+    const double* __restrict__ t_w = tcomp == 0 ? P->task_weight : P->task_extra[tcomp - 1].weight;
+    const double* __restrict__ t_wf = tcomp == 0 ? P->task_weightf : P->task_extra[tcomp - 1].weightf;
+    const double* __restrict__ t_wi = tcomp == 0 ? P->task_weighti : P->task_extra[tcomp - 1].weighti;
     double pF[3], RF[9], w[3], v[3], diff[6], col[6];
-    frameKinematics<D>(B.model, q, P->task_joint, P->task_R, P->task_p, dof, pF, RF, w, v);
-    const double* __restrict__ ref = B.task_refs + (long)pos * 12;      // (time_varying_task_space_{3d,6d}_cost.cpp: the reference at the stage's own time)
+    frameKinematics<D>(B.model, q, t_joint, t_R, t_p, dof, pF, RF, w, v);
+    const double* __restrict__ ref = tcomp == 0 ? B.task_refs + (long)pos * 12 : P->task_extra[tcomp - 1].ref;      // (time_varying_task_space_{3d,6d}_cost.cpp: the reference at the stage's own time)
     const double ev[3] = {pF[0] - ref[9], pF[1] - ref[10], pF[2] - ref[11]};
-    if (P->task_dim == 3) {
+    if (t_dim == 3) {
       // diff = p - p_ref ; J_3d = R_frame J_lin,LOCAL = the world-frame linear column
       for (int r = 0; r < 3; ++r) { diff[r] = ev[r]; col[r] = v[r]; diff[3 + r] = 0.0; col[3 + r] = 0.0; }
     } else {
@@ -167,15 +180,14 @@ __global__ __launch_bounds__(64) void ocp_ext_kernel(OcpBuffers B, int residual)
     // its terminal part is not in the line search's merit (line_search.cpp:228-237)
     const bool last = bwd && P->has_terminal && pos == M - 2;
     for (int k = 0; k < 6; ++k) {
-      const double wm = nd->kind == 1 ? P->task_weighti[k] : (nd->kind == 4 ? P->task_weightf[k] : dt * P->task_weight[k]);
-      const double wk = wm + (last ? P->task_weightf[k] : 0.0);
+      const double wraw = nd->kind == 1 ? t_wi[k] : (nd->kind == 4 ? t_wf[k] : dt * t_w[k]);
+      const double wm = (t_dim == 3 && k >= 3) ? 0.0 : wraw;
+      const double wk = wm + ((last && !(t_dim == 3 && k >= 3)) ? t_wf[k] : 0.0);
       lq += wk * diff[k] * col[k];
       cost += 0.5 * wm * diff[k] * diff[k];
-      if (lane < NV) xx[L::X_TJ + k * NV + lane] = col[k];
-      if (lane == 0) xx[L::X_TW + k] = residual ? 0.0 : wk;
+      if (lane < NV) xx[L::X_TJ + (tcomp * 6 + k) * NV + lane] = col[k];
+      if (lane == 0) xx[L::X_TW + tcomp * 6 + k] = residual ? 0.0 : wk;
     }
-  } else {
-    for (int e = lane; e < 6 * NV + 6; e += 64) xx[L::X_TJ + e] = 0.0;
   }
   if (lane < NV) xx[L::X_LQ + lane] = lq;
   if (lane == 0) { xx[L::X_ERR] = err; xx[L::X_VIOL] = viol; xx[L::X_COST] = cost; }
@@ -196,18 +208,19 @@ __global__ __launch_bounds__(64) void ocp_ext_hessian_kernel(OcpBuffers B) {
   const long rec = b * B.NS + nd->slot;
   const double* __restrict__ xx = B.ext + rec * L::EXT;
   double* __restrict__ kk = B.kkt + rec * L::KKT;
-  double w[NC + 6];
+  constexpr int NTW = 6 * L::NT;
+  double w[NC + NTW];
   bool any = false;
 #pragma unroll
-  for (int c = 0; c < NC + 6; ++c) { w[c] = c < NC ? xx[L::X_W + c] : xx[L::X_TW + c - NC]; any = any || w[c] != 0.0; }
+  for (int c = 0; c < NC + NTW; ++c) { w[c] = c < NC ? xx[L::X_W + c] : xx[L::X_TW + c - NC]; any = any || w[c] != 0.0; }
   if (!any) return;
+  const int ntw = 6 * P->task_n;
   for (int e = threadIdx.x; e < NV * NV; e += 64) {
     const int c2 = e / NV, r = e - c2 * NV;
     double acc = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc += w[c] * xx[L::X_CDJ + c * NV + r] * xx[L::X_CDJ + c * NV + c2];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc += w[NC + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c2];
+    for (int k = 0; k < ntw; ++k) acc += w[NC + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c2];
     if (r <= c2) kk[L::K_QXX + L::xsym(r, c2)] += acc;
   }
 }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void parnmpc_impulse_condense_kernel(OcpBuffer
       v += acc;
       if (B.ext) {                                   // JJ^T diag(w_i) JJ of the task-space cost (the rows ocp_ext_kernel left)
         const double* __restrict__ xx = B.ext + rec * L::EXT;
-        for (int k = 0; k < 6; ++k) v += xx[L::X_TW + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c];
+        for (int k = 0; k < 6 * L::NT; ++k) v += xx[L::X_TW + k] * xx[L::X_TJ + k * NV + r] * xx[L::X_TJ + k * NV + c];      // (unused component slots: zero weights)
       }
     } else if (r == c) {
       v = P->vi_weight[r - NV];

@@ -188,6 +188,13 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     if (cost->task_joint < 0 || cost->task_joint >= model->njoints) { set_last_error("invalid value: task_joint is not a joint of the model!"); return IDOCP_E_ARG; }
     if (bwd) { set_last_error("idocp_unparnmpc_create: the task-space costs are carried by UnOCPSolver only"); return IDOCP_E_UNSUPPORTED; }
   }
+  // further task-space components (idocp_cost_t::task_extra)
+  if (cost->task_extra_count < 0 || cost->task_extra_count > IDOCP_MAX_EXTRA_TASKS) { set_last_error("invalid value: task_extra_count must be 0 .. " + std::to_string(IDOCP_MAX_EXTRA_TASKS) + "!"); return IDOCP_E_ARG; }
+  if (cost->task_extra_count > 0 && cost->task_dim == 0) { set_last_error("invalid value: task_extra components need the first task-space component (task_dim != 0)!"); return IDOCP_E_ARG; }
+  for (int e = 0; e < cost->task_extra_count; ++e) {
+    if (cost->task_extra[e].dim != 3 && cost->task_extra[e].dim != 6) { set_last_error("invalid value: task_extra[" + std::to_string(e) + "].dim must be 3 or 6!"); return IDOCP_E_ARG; }
+    if (cost->task_extra[e].joint < 0 || cost->task_extra[e].joint >= model->njoints) { set_last_error("invalid value: task_extra[" + std::to_string(e) + "].joint is not a joint of the model!"); return IDOCP_E_ARG; }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_last_error("no HIP device available: the idocp HIP path has no CPU fallback");
@@ -245,6 +252,7 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
     if ((rc = allocBuf(h, &B.task_ref, (size_t)(N + 1) * 12))) return fail(rc);
     if ((rc = allocBuf(h, &B.task_term, (size_t)batch * L7::TASK))) return fail(rc);
     B.task = 1; B.task_stride = L7::TASK;
+    if (cost->task_extra_count > 0 && (rc = allocBuf(h, &B.task_xs, (size_t)batch * N * L7::TASK))) return fail(rc);      // stage terms of the further components
     std::vector<double> refs((size_t)(N + 1) * 12);
     for (int i = 0; i <= N; ++i) std::memcpy(&refs[12 * i], cost->task_ref, sizeof(double) * 12);
     if (hipMemcpyAsync(B.task_ref, refs.data(), refs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -274,6 +282,18 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   std::memcpy(up.task.R, cost->task_frame_R, sizeof(up.task.R)); std::memcpy(up.task.p, cost->task_frame_p, sizeof(up.task.p));
   std::memcpy(up.task.weight, cost->task_weight, sizeof(up.task.weight)); std::memcpy(up.task.weightf, cost->task_weightf, sizeof(up.task.weightf));
   if (cost->task_dim == 3) for (int k = 3; k < 6; ++k) up.task.weight[k] = up.task.weightf[k] = 0.0;
+  std::memcpy(up.task.ref, cost->task_ref, sizeof(up.task.ref));
+  up.task_n = cost->task_dim ? 1 + cost->task_extra_count : 0;
+  for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) {
+    TaskCost& tc = up.task_extra[e];
+    std::memset(&tc, 0, sizeof(tc));
+    if (cost->task_dim == 0 || e >= cost->task_extra_count) continue;
+    const idocp_task_component_t& t = cost->task_extra[e];
+    tc.dim = t.dim; tc.joint = t.joint;
+    std::memcpy(tc.R, t.frame_R, sizeof(tc.R)); std::memcpy(tc.p, t.frame_p, sizeof(tc.p));
+    std::memcpy(tc.weight, t.weight, sizeof(tc.weight)); std::memcpy(tc.weightf, t.weightf, sizeof(tc.weightf)); std::memcpy(tc.ref, t.ref, sizeof(tc.ref));
+    if (t.dim == 3) for (int k = 3; k < 6; ++k) tc.weight[k] = tc.weightf[k] = 0.0;
+  }
   void *d_model = nullptr, *d_prob = nullptr;
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&d_prob, sizeof(UnProblem)) != hipSuccess) {
     set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);

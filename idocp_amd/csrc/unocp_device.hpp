@@ -95,6 +95,8 @@ struct UnProblem {
   // aux, corrected lmd, gmm); has_prev: (q0, v0) is the left neighbour's last stage and B.xprev its corrected (q, v)
   int stage_offset, has_terminal, has_prev;
   TaskCost task;          // TaskSpace3DCost / TaskSpace6DCost (UnOCP only); task.dim = 0: none
+  int task_n;             // number of task-space components: 0, or 1 + idocp_cost_t::task_extra_count
+  TaskCost task_extra[IDOCP_MAX_EXTRA_TASKS];      // the further components (constant references)
 };
 
 // All device pointers of one handle.
@@ -131,7 +133,9 @@ struct UnBuffers {
   int task;              // host-side copy of prob->task.dim != 0: selects the kernel instantiations
   int task_stride;       // UnLayout<NV>::TASK for the kernels that are not templated on NV
   double* task_ref;      // [N+1][12]  reference pose of every stage: rotation (row-major) + position, shared by the batch
-  double* task_term;     // [batch][TASK]  terminal cost, gradient, Gauss-Newton Hessian (un_task_terminal_kernel)
+  double* task_term;     // [batch][TASK]  terminal cost, gradient, Gauss-Newton Hessian (un_task_terminal_kernel), all components
+  double* task_xs;       // [batch][N][TASK]  STAGE cost, gradient, Hessian of the task_extra components, time step included (un_task_terms_kernel;
+                         // null without such components): K1 / K4 add them to lq and Qqq, the line search to its cost
 };
 
 }  // namespace idocp_dev

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(64, K1_WAVES) void un_linearize_kernel(UnBuffers B,
     l += dt * w * (x - ref);
     h = dt * w;
     if (TASK && kind == 0) l += dt * task_g;     // TaskSpace*Cost::computeStageCostDerivatives
+    if (TASK && kind == 0 && B.task_xs) l += B.task_xs[((long)b * N + i) * L::TASK + L::T_G + k];      // ... of the task_extra components (un_task_terminal_kernel<.., STAGES>)
     if (term && kind < 2) {          // computeTerminalCostDerivatives / Hessian (configuration_space_cost.cpp:313-329, 368-380)
       const double wf = (kind == 0) ? P->qf_weight[k] : P->vf_weight[k];
       l += wf * (x - ref);
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(64, K1_WAVES) void un_linearize_kernel(UnBuffers B,
       if (TASK && k1kind == 0 && kind == 0) {     // TaskSpace*Cost::computeStageCostHessian: Qqq += dt JJ^T W JJ
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc += s_tJ[g][c][k1] * task_wc[c];
+        if (B.task_xs) acc += B.task_xs[((long)b * N + i) * L::TASK + L::T_H + k * NV + k1];      // the task_extra components
       }
       if (g0 < SPW && dst >= 0) {
         if (k1kind != kind) kk[dst + k * NV + k1] = acc;
@@ -537,7 +539,10 @@ __global__ __launch_bounds__(64, K1_WAVES) void un_linearize_kernel(UnBuffers B,
 // TaskSpace*Cost::computeTerminalCost / computeTerminalCostDerivatives / computeTerminalCostHessian at stage N of every
 // instance (task_space_6d_cost.cpp; terminal_ocp.hxx:50-66, 118-144) -> B.task_term.  8 lanes per instance, lane k = joint k.
 // TRIAL: at the line-search trial point q_N + alpha dq_N (cost only is read).
-template <int NV, bool TRIAL>
+// STAGES = false: the terminal stage N of every instance, ALL components with their terminal weights -> B.task_term (8 lanes per instance).
+// STAGES = true (round 6): the stages 0 .. N - 1 of every instance, the task_extra components only, stage weights times dt -> B.task_xs
+// (8 lanes per (instance, stage)); the first component's stage terms are formed inside K1.
+template <int NV, bool TRIAL, bool STAGES = false>
 __global__ __launch_bounds__(64) void un_task_terminal_kernel(UnBuffers B) {
   using L = UnLayout<NV>;
   static_assert(NV <= 8, "one joint per lane of an 8-lane group");
@@ -549,39 +554,50 @@ __global__ __launch_bounds__(64) void un_task_terminal_kernel(UnBuffers B) {
   const int g = lane >> 3;
   const int k0 = lane & 7;
   const int k = k0 < NV ? k0 : NV - 1;
-  long inst = (long)blockIdx.x * 8 + g;
-  const bool active = (inst < P->batch) && (k0 < NV);
-  if (inst >= P->batch) inst = P->batch - 1;
-  const double* __restrict__ sN = B.sol + (inst * (N + 1) + N) * L::SOL;
+  const long nunits = STAGES ? (long)P->batch * N : (long)P->batch;
+  long unit = (long)blockIdx.x * 8 + g;
+  const bool active = (unit < nunits) && (k0 < NV);
+  if (unit >= nunits) unit = nunits - 1;
+  const long inst = STAGES ? unit / N : unit;
+  const int stage = STAGES ? (int)(unit - inst * N) : N;
+  const double* __restrict__ sN = B.sol + (inst * (N + 1) + stage) * L::SOL;
   double qk = sN[L::S_Q + k];
-  if (TRIAL) qk += B.ls_alpha[inst] * (B.dir + (inst * (N + 1) + N) * L::SOL)[L::S_Q + k];
+  if (TRIAL) qk += B.ls_alpha[inst] * (B.dir + (inst * (N + 1) + stage) * L::SOL)[L::S_Q + k];
   double sj, cj;
   sincos(qk, &sj, &cj);
   s_cs[g][k][0] = cj; s_cs[g][k][1] = sj;
   WAVE_SYNC();
-  double diff[6], col[6], wc[6];
-  taskSpaceColumn<NV>(B.model, P->task, &s_cs[g][0][0], B.task_ref + 12 * N, k, diff, col);
-  double cost = 0.0, gk = 0.0;
+  double cost = 0.0, gk = 0.0, hk[NV];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    const double w = P->task.weightf[c];
-    cost += 0.5 * w * diff[c] * diff[c];
-    wc[c] = w * col[c];
-    gk += wc[c] * diff[c];
-    s_J[g][c][k] = col[c];
+  for (int r = 0; r < NV; ++r) hk[r] = 0.0;
+  const double scale = STAGES ? P->dt : 1.0;
+  for (int tcomp = STAGES ? 1 : 0; tcomp < P->task_n; ++tcomp) {
+    const TaskCost& tc = tcomp == 0 ? P->task : P->task_extra[tcomp - 1];
+    const double* __restrict__ ref = tcomp == 0 ? B.task_ref + 12 * stage : tc.ref;
+    double diff[6], col[6], wc[6];
+    taskSpaceColumn<NV>(B.model, tc, &s_cs[g][0][0], ref, k, diff, col);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double w = scale * (STAGES ? tc.weight[c] : tc.weightf[c]);
+      cost += 0.5 * w * diff[c] * diff[c];
+      wc[c] = w * col[c];
+      gk += wc[c] * diff[c];
+      s_J[g][c][k] = col[c];
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) hk[r] += s_J[g][c][r] * wc[c];
+    }
+    WAVE_SYNC();
   }
-  WAVE_SYNC();
   if (!active) return;
-  double* __restrict__ out = B.task_term + inst * L::TASK;
+  double* __restrict__ out = STAGES ? B.task_xs + unit * L::TASK : B.task_term + inst * L::TASK;
   if (k == 0) out[L::T_COST] = cost;
   out[L::T_G + k] = gk;
 #pragma unroll
-  for (int r = 0; r < NV; ++r) {
-    double h = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) h += s_J[g][c][r] * wc[c];
-    out[L::T_H + k * NV + r] = h;
-  }
+  for (int r = 0; r < NV; ++r) out[L::T_H + k * NV + r] = hk[r];
 }
 
 // --------------------------------------------------------------------- S1 ----
@@ -1542,6 +1558,7 @@ __global__ __launch_bounds__(64) void un_line_search_kernel(UnBuffers B, const d
     if (seed == 0) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) cost += 0.5 * dt * P->task.weight[c] * tdiff[c] * tdiff[c];
+      if (B.task_xs && k == 0) cost += B.task_xs[((long)b * N + i) * L::TASK + L::T_COST];      // task_extra components at the trial point (un_task_terminal_kernel<.., true, true> ran first)
     }
   }
   // the neighbour of the state equation at ITS trial point (the measured state is fixed)
@@ -1640,6 +1657,7 @@ void UnLaunch<NV>::linearize(const UnBuffers& B, long batch, int N, hipStream_t 
     const dim3 grid((unsigned)((units + SPA - 1) / SPA));
     const double* none = nullptr;
     if (B.task) {
+      if (B.task_xs) hipLaunchKernelGGL((un_task_terminal_kernel<NV, false, true>), dim3((unsigned)((units + 7) / 8)), dim3(64), 0, st, B);      // stage terms of the task_extra components
       if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true, true>), grid, dim3(64), 0, st, B, none, none);
       else hipLaunchKernelGGL((un_linearize_kernel<NV, 0, false, true>), grid, dim3(64), 0, st, B, none, none);
     } else {
@@ -1654,6 +1672,7 @@ void UnLaunch<NV>::residual(const UnBuffers& B, long batch, int N, hipStream_t s
     const dim3 grid((unsigned)((units + SPA - 1) / SPA));
     const double* none = nullptr;
     if (B.task) {
+      if (B.task_xs) hipLaunchKernelGGL((un_task_terminal_kernel<NV, false, true>), dim3((unsigned)((units + 7) / 8)), dim3(64), 0, st, B);
       if (B.zaxes) hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true, true>), grid, dim3(64), 0, st, B, none, none);
       else hipLaunchKernelGGL((un_linearize_kernel<NV, 1, false, true>), grid, dim3(64), 0, st, B, none, none);
       hipLaunchKernelGGL((un_task_terminal_kernel<NV, false>), dim3((unsigned)((batch + 7) / 8)), dim3(64), 0, st, B);
@@ -1750,6 +1769,7 @@ template <int NV>
 void UnLaunch<NV>::lineSearchEval(const UnBuffers& B, long batch, int N, bool bwd, const double* q0, const double* v0, hipStream_t st) {
   constexpr int SPW = 64 / (3 * NV);
   const unsigned blocks = (unsigned)((batch * N + SPW - 1) / SPW);
+  if (B.task_xs && !bwd) hipLaunchKernelGGL((un_task_terminal_kernel<NV, true, true>), dim3((unsigned)((batch * N + 7) / 8)), dim3(64), 0, st, B);      // task_extra stage costs at the trial point
   if (bwd) hipLaunchKernelGGL((un_line_search_kernel<NV, true>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
   else hipLaunchKernelGGL((un_line_search_kernel<NV, false>), dim3(blocks), dim3(64), 0, st, B, q0, v0);
   if (B.task && !bwd) hipLaunchKernelGGL((un_task_terminal_kernel<NV, true>), dim3((unsigned)((batch + 7) / 8)), dim3(64), 0, st, B);

@@ -6,10 +6,10 @@
 // natively can be pushed: one configuration-space cost (ConfigurationSpaceCost,
 // src/cost/configuration_space_cost.cpp:241-397, or TrottingConfigurationSpaceCost,
 // src/cost/trotting_configuration_space_cost.cpp), one ContactForceCost
-// (src/cost/contact_force_cost.cpp:153-194) and one task-space cost
-// (task_space_cost.hpp; UnOCPSolver only).  Anything else -- or a second
-// component of the same kind -- is rejected at push_back: there is no silent
-// CPU fallback.
+// (src/cost/contact_force_cost.cpp:153-194) and up to four task-space costs
+// (task_space_cost.hpp; one of them may be time-varying).  Anything else -- or a
+// second component of one of the first two kinds -- is rejected at push_back:
+// there is no silent CPU fallback.
 #ifndef IDOCP_COST_FUNCTION_HPP_
 #define IDOCP_COST_FUNCTION_HPP_
 
@@ -45,6 +45,18 @@ inline void keepTaskFields(const idocp_cost_t& from, idocp_cost_t& to) {
   for (int k = 0; k < 3; ++k) to.task_frame_p[k] = from.task_frame_p[k];
   for (int k = 0; k < 6; ++k) { to.task_weight[k] = from.task_weight[k]; to.task_weightf[k] = from.task_weightf[k]; to.task_weighti[k] = from.task_weighti[k]; }
   for (int k = 0; k < 12; ++k) to.task_ref[k] = from.task_ref[k];
+  to.task_extra_count = from.task_extra_count;
+  for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) to.task_extra[e] = from.task_extra[e];
+}
+// the task_* block of a cost as a task_extra component (a second, third ... task-space cost pushed into one CostFunction)
+inline idocp_task_component_t taskBlockAsComponent(const idocp_cost_t& c) {
+  idocp_task_component_t t;
+  t.dim = c.task_dim; t.joint = c.task_joint;
+  for (int k = 0; k < 9; ++k) t.frame_R[k] = c.task_frame_R[k];
+  for (int k = 0; k < 3; ++k) t.frame_p[k] = c.task_frame_p[k];
+  for (int k = 0; k < 6; ++k) { t.weight[k] = c.task_weight[k]; t.weightf[k] = c.task_weightf[k]; t.weighti[k] = c.task_weighti[k]; }
+  for (int k = 0; k < 12; ++k) t.ref[k] = c.task_ref[k];
+  return t;
 }
 
 class ConfigurationSpaceCost final : public CostFunctionComponentBase {
@@ -93,8 +105,10 @@ class CostFunction {
   CostFunction() : have_{false, false, false} { idocp_cost_init(&c_); }
   void push_back(const std::shared_ptr<CostFunctionComponentBase>& c) {
     const int k = (int)c->kind();
+    if (k == (int)CostFunctionComponentBase::TaskSpace && have_[k]) { pushFurtherTask(c); return; }
     if (have_[k] || !c->exportTo(c_)) {
-      std::cerr << "unsupported cost: the HIP path carries one configuration-space cost, one ContactForceCost and one task-space cost" << '\n';
+      std::cerr << "unsupported cost: the HIP path carries one configuration-space cost, one ContactForceCost and up to " << 1 + IDOCP_MAX_EXTRA_TASKS
+                << " task-space costs" << '\n';
       std::exit(EXIT_FAILURE);
     }
     have_[k] = true;
@@ -111,6 +125,27 @@ class CostFunction {
   bool have_[3];
   idocp_cost_t c_;
   std::shared_ptr<CostFunctionComponentBase> task_;
+  // A second, third ... task-space component (the reference's CostFunction takes any number of components, cost_function.hpp:67): it goes into
+  // the task_extra block of the flat cost.  Only the component in the task_* block can be time-varying (it is the one the solver asks for
+  // reference poses); a time-varying component pushed behind a constant one takes that place and the constant one moves to task_extra.
+  void pushFurtherTask(const std::shared_ptr<CostFunctionComponentBase>& c) {
+    idocp_cost_t blk;
+    idocp_cost_init(&blk);
+    if (!c->exportTo(blk) || c_.task_extra_count >= IDOCP_MAX_EXTRA_TASKS || (blk.task_time_varying && c_.task_time_varying)) {
+      std::cerr << "unsupported cost: the HIP path carries up to " << 1 + IDOCP_MAX_EXTRA_TASKS << " task-space costs, one of them time-varying" << '\n';
+      std::exit(EXIT_FAILURE);
+    }
+    if (blk.task_time_varying) {
+      c_.task_extra[c_.task_extra_count++] = taskBlockAsComponent(c_);
+      idocp_cost_t keep = c_;
+      keepTaskFields(blk, c_);
+      c_.task_extra_count = keep.task_extra_count;
+      for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) c_.task_extra[e] = keep.task_extra[e];
+      task_ = c;
+    } else {
+      c_.task_extra[c_.task_extra_count++] = taskBlockAsComponent(blk);
+    }
+  }
 };
 
 }  // namespace idocp

@@ -79,6 +79,17 @@ typedef struct idocp_model {
  * ConfigurationSpaceCost (src/cost/configuration_space_cost.cpp:241-397), the
  * cost of configs C1/C2.  Unset weights are zero like the reference's ctor.
  */
+/* One more task-space cost component of idocp_cost_t (task_extra): the fields of the task_* block of the cost, per component. */
+#define IDOCP_MAX_EXTRA_TASKS 3
+typedef struct idocp_task_component {
+  int dim;                     /* 3 or 6 */
+  int joint;                   /* parent joint of the frame */
+  double frame_R[9];           /* placement of the frame in the joint frame, row-major */
+  double frame_p[3];
+  double weight[6], weightf[6], weighti[6];      /* stage, terminal, impulse-stage weights (layout of task_weight) */
+  double ref[12];              /* constant reference: rotation (row-major, 9) then position (3) */
+} idocp_task_component_t;
+
 typedef struct idocp_cost {
   double q_ref[IDOCP_MAX_NQ];
   double v_ref[IDOCP_MAX_NV];
@@ -130,6 +141,11 @@ typedef struct idocp_cost {
   double task_ref[12];           /* constant reference: rotation (row-major, 9) then position (3); 3D uses the position only */
   int task_time_varying;         /* != 0: the references of the N + 1 stages come from idocp_unocp_set_task_refs */
   double task_weighti[6];        /* impulse-stage weights (qi_3d_weight / qi_6d_weight), same layout: OCPSolver on chains with impulse stages */
+  /* Further task-space components (CostFunction::push_back takes any number of components, include/idocp/cost/cost_function.hpp:67;
+   * round 6): up to IDOCP_MAX_EXTRA_TASKS more TaskSpace3DCost / TaskSpace6DCost terms, each on a frame of its own, summed with the one
+   * above.  Constant references (the TimeVarying variants: the first component only).  task_extra_count > 0 needs task_dim != 0. */
+  int task_extra_count;
+  idocp_task_component_t task_extra[IDOCP_MAX_EXTRA_TASKS];
 } idocp_cost_t;
 
 /*

@@ -64,6 +64,19 @@ static Robot makeTaskRobot(const RModel& model, const RCost& cost) {
 static void taskTerms(const Robot& task_robot, const RCost& cost, real t, const real* w, const Mat& q, real& c, Mat& g, Mat& H) {
   Robot rb = task_robot;
   rb.taskSpaceTerms(cost.task_dim, cost.taskRefAt(t), w, q, c, g, H);      // (TimeVarying variants: the pose at the stage's own time)
+  // further components (CostFunction sums its components, cost_function.hxx): the same term on their own frames, with the weights of the same
+  // kind (stage / impulse / terminal) as `w` is of the first component; constant references
+  const int kind = w == cost.task_weight ? 0 : (w == cost.task_weighti ? 1 : 2);
+  for (int e = 1; e < cost.taskCount(); ++e) {
+    RModel mt = task_robot.model();
+    mt.contact_frame_id[0] = -1; mt.contact_joint[0] = cost.taskJoint(e);
+    for (int k2 = 0; k2 < 9; ++k2) mt.contact_R[0][k2] = cost.taskFrameR(e)[k2];
+    for (int k2 = 0; k2 < 3; ++k2) mt.contact_p[0][k2] = cost.taskFrameP(e)[k2];
+    Robot re(mt);
+    real ce; Mat ge, He;
+    re.taskSpaceTerms(cost.taskDim(e), cost.taskConstRef(e), cost.taskWeight(e, kind), q, ce, ge, He);
+    c += ce; g += ge; H += He;
+  }
 }
 
 OCPSolver::OCPSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,

@@ -105,6 +105,16 @@ void UnOCPSolver::setTaskRefs(const double* refs) {
 void UnOCPSolver::taskTerms(int i, const Mat& q, real& c, Mat& g, Mat& H) const {
   Robot rb = task_robot_;
   rb.taskSpaceTerms(cost.task_dim, task_refs[i].data(), i == N_ ? cost.task_weightf : cost.task_weight, q, c, g, H);
+  for (int e = 1; e < cost.taskCount(); ++e) {      // further components on frames of their own (idocp_cost_t::task_extra), constant references
+    RModel mt = task_robot_.model();
+    mt.contact_frame_id[0] = -1; mt.contact_joint[0] = cost.taskJoint(e);
+    for (int k2 = 0; k2 < 9; ++k2) mt.contact_R[0][k2] = cost.taskFrameR(e)[k2];
+    for (int k2 = 0; k2 < 3; ++k2) mt.contact_p[0][k2] = cost.taskFrameP(e)[k2];
+    Robot re(mt);
+    real ce; Mat ge, He;
+    re.taskSpaceTerms(cost.taskDim(e), cost.taskConstRef(e), cost.taskWeight(e, i == N_ ? 2 : 0), q, ce, ge, He);
+    c += ce; g += ge; H += He;
+  }
 }
 
 void UnOCPSolver::setSolution(const std::string& name, const Mat& value) {
