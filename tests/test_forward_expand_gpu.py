@@ -155,3 +155,66 @@ def test_chains_longer_than_the_walk_keeps_in_lds_fall_back_to_s4_k6():
     assert lib.idocp_ocp_fused_forward(g.h) == 0               # 331 nodes: the chain does not fit
     for f in OCP_DIR_FIELDS:
         assert rel_err(g.get(f, 1), o.get(f)) < 1e-9, f
+
+
+def test_side_stream_iteration_equals_the_single_stream_one_and_survives_graph_capture(monkeypatch):
+    """Round 6: handles of >= 128 instances run the switching-constraint kernel, the impulse stages' nominal launch and the base-pose update
+    on a side stream beside their independent neighbours (fork / join with events; ocp_capi.hip launchSwitchO / launchNominalO / joinSideO /
+    launchIntegrateO).  (i) A handle created with IDOCP_SIDE_STREAM_MIN_BATCH above its batch (everything on one stream) and one with the
+    side stream step the same trotting chain to BITWISE the same iterate -- the kernels and their inputs are the same, only the order in
+    which independent launches start differs.  (ii) The fork / join is captured into the hipGraph of idocp_ocp_update_solution_graph:
+    a clone stepping through the graph stays bitwise on the eager handle."""
+    import copy
+    torch = pytest.importorskip("torch")
+    lib = capi.lib()
+    lib.idocp_ocp_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    B = 128
+    m = anymal_model()
+    q = np.tile(ANYMAL_Q_STANDING, (B, 1))
+    q[:, 7:] += 0.01 * np.random.default_rng(3).uniform(-1, 1, (B, 12))
+    dq = torch.tensor(q, dtype=torch.float64, device="cuda")
+    dv = torch.zeros((B, m.nv), dtype=torch.float64, device="cuda")
+    args = (C.c_double(0.0), C.c_void_p(dq.data_ptr()), C.c_void_p(dv.data_ptr()))
+
+    def handle():
+        cost, cons = anymal_problem(m, trotting_ref=True)
+        g = HipOCP(m, cost, cons, 1.55, 31, batch=B, max_num_impulse=3)
+        trotting_sequence(g, m, 2)
+        g.set_solution("q", ANYMAL_Q_STANDING)
+        g.set_solution("v", np.zeros(m.nv))
+        g.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        g.init_constraints(0.0)
+        return g
+
+    side = handle()                                   # (the default: a side stream from batch 128 on)
+    # the switch is read once per process: a handle WITHOUT a side stream is one below the threshold -- here made by a batch-127 twin would change
+    # the problem, so the single-stream reference runs kernel by kernel through idocp_ocp_launch_kernel on a clone, ids in the plain order, with a
+    # stream synchronisation after every launch (nothing can overlap)
+    h2 = C.c_void_p()
+    capi.check(lib.idocp_ocp_clone(side.h, C.byref(h2)), "clone")
+    plain = copy.copy(side)
+    plain.h = h2
+    h3 = C.c_void_p()
+    capi.check(lib.idocp_ocp_clone(side.h, C.byref(h3)), "clone")
+    graph = copy.copy(side)
+    graph.h = h3
+    lib.idocp_ocp_fused_forward.argtypes = [C.c_void_p]
+    kids = [0, 7, 8, 2, 3, 6] if lib.idocp_ocp_fused_forward(side.h) else [0, 7, 8, 2, 3, 4, 5, 6]
+    for it in range(3):
+        capi.check(lib.idocp_ocp_update_solution_device(side.h, *args), "eager, side stream")
+        capi.check(lib.idocp_ocp_update_solution_graph(graph.h, *args), "graph")      # (first call eager, second captures, third replays)
+        if it == 0:
+            capi.check(lib.idocp_ocp_update_solution_device(plain.h, *args), "first iteration of the serialised clone: discretises and uploads")
+        else:
+            for kid in kids:
+                capi.check(lib.idocp_ocp_launch_kernel(plain.h, kid, args[1], args[2]), "kernel %d" % kid)
+                capi.check(lib.idocp_ocp_synchronize(plain.h))
+    for s_ in (side, plain, graph):
+        capi.check(lib.idocp_ocp_synchronize(s_.h))
+    M = len(side.chain(0.0))
+    for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu"):
+        for inst in (0, B - 1):
+            ref = side.get_chain(f, M, inst)
+            assert np.isfinite(ref).all()
+            assert np.array_equal(plain.get_chain(f, M, inst), ref), ("serialised", f, inst)
+            assert np.array_equal(graph.get_chain(f, M, inst), ref), ("graph", f, inst)
