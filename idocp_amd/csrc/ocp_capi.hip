@@ -1222,7 +1222,8 @@ static int launchSwitchO(idocp_ocp_t* h, int M) {
   HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
   HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   OcpLaunch<DQ>::switching(h->B, h->batch, M, h->side);
-  h->side_pending = true;                              // (the join event is recorded by launchNominalO, behind the impulse stages' nominal launch)
+  HIP_TRY(hipEventRecord(h->ev_join, h->side));        // (recorded again by launchNominalO, behind the impulse stages' nominal launch)
+  h->side_pending = true;
   return IDOCP_OK;
 }
 // the nominal sweeps K5n on the handle's stream; with a fork open (launchSwitchO) the small launch over the impulse stages goes beside them too
@@ -1288,7 +1289,8 @@ int idocp_ocp_launch_kernel(idocp_ocp_t* h, int kernel_id, const double* d_q, co
     case 1: if ((rc = launchNominalO(h, M, d_q))) return rc; if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;
     case 7: if ((rc = launchNominalO(h, M, d_q))) return rc; break;      // the two halves of 1: the nominal rigid-body sweeps (+ external rows) ...
     case 8: if ((rc = launchCondenseClassesO(h, M, d_q))) return rc; break;      // ... and the condensation launches proper
-    case 2: OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h)); break;
+    case 2: if ((rc = joinSideO(h))) return rc;      // (a caller that skips the condensation ids still gets K5s in front of the sweep)
+            OcpLaunch<DQ>::riccatiBackward(h->B, h->batch, M, h->has_switch, h->stream, wideSweep(h)); break;
     // 3: the forward sweep.  Since round 5 it expands as it walks (S4 + K6 + the step-size reduction in one kernel, ocp_forward_expand_kernel);
     // ids 4 and 5 are then empty.  IDOCP_FUSED_FORWARD=0 restores the three kernels behind ids 3, 4, 5.
     case 3: if (fusedForward(h)) OcpLaunch<DQ>::forwardExpand(h->B, h->batch, M, d_q, d_v, h->stream); else OcpLaunch<DQ>::riccatiForward(h->B, h->batch, M, d_q, d_v, h->stream); break;
@@ -1339,6 +1341,7 @@ int idocp_ocp_synchronize(idocp_ocp_t* h) {
   if (!h) return IDOCP_E_ARG;
   int rc = setDev(h); if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->side) HIP_TRY(hipStreamSynchronize(h->side));      // (a fork left open by idocp_ocp_launch_kernel id 0 alone)
   return IDOCP_OK;
 }
 void* idocp_ocp_stream(idocp_ocp_t* h) { return h ? (void*)h->stream : nullptr; }
