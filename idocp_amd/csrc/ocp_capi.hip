@@ -759,8 +759,9 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_last_error("hipStreamCreate failed"); return fail(IDOCP_E_DEVICE); }
   {
     // (a batch of instances only: at batch 1 the two event hand-offs cost more than the 9 wavefronts of K5s -- 1.09 against 1.06 ms per iteration)
-    static const bool use_side = !(getenv("IDOCP_SIDE_STREAM") && atoi(getenv("IDOCP_SIDE_STREAM")) == 0);
-    static const int side_min_batch = getenv("IDOCP_SIDE_STREAM_MIN_BATCH") ? atoi(getenv("IDOCP_SIDE_STREAM_MIN_BATCH")) : 128;
+    // (read at every creation, not once per process: tests/test_forward_expand_gpu.py runs the oracle parity tests with the side stream forced on small batches)
+    const bool use_side = !(getenv("IDOCP_SIDE_STREAM") && atoi(getenv("IDOCP_SIDE_STREAM")) == 0);
+    const int side_min_batch = getenv("IDOCP_SIDE_STREAM_MIN_BATCH") ? atoi(getenv("IDOCP_SIDE_STREAM_MIN_BATCH")) : 128;
     if (use_side && !parnmpc && batch >= side_min_batch) {
       if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { set_last_error("side stream: hipStreamCreate / hipEventCreate failed"); return fail(IDOCP_E_DEVICE); }

@@ -218,3 +218,18 @@ def test_side_stream_iteration_equals_the_single_stream_one_and_survives_graph_c
             assert np.isfinite(ref).all()
             assert np.array_equal(plain.get_chain(f, M, inst), ref), ("serialised", f, inst)
             assert np.array_equal(graph.get_chain(f, M, inst), ref), ("graph", f, inst)
+
+
+def test_oracle_parity_with_the_side_stream_forced_on_small_batches(monkeypatch):
+    """The parity tests of the other files run small batches, i.e. handles WITHOUT a side stream (it starts at 128 instances); here the chains with
+    switching constraints, impulse stages and lift stages, the MPC loop and the full-size configs run with IDOCP_SIDE_STREAM_MIN_BATCH=1: every
+    handle forks K5s / the impulse stages' nominal launch / the base poses onto its side stream and joins them, under the same oracle bars."""
+    monkeypatch.setenv("IDOCP_SIDE_STREAM_MIN_BATCH", "1")
+    import test_hybrid_gpu as H
+    H.test_first_iteration_direction_parity_along_the_chain(False, 31, 1.55, 1e-10)
+    H.test_flight_phase_sequence_parity()
+    H.test_hybrid_convergence_and_kkt_error_parity()
+    H.test_receding_horizon_mpc_loop_with_pop_front_and_push_back()
+    H.test_full_size_c3_from_three_perturbed_states()
+    import test_golden_kkt as K
+    K.test_hip_direction_is_the_dense_newton_direction()
