@@ -469,8 +469,39 @@ def spawn_ranks(n, argv, timeout_s=None):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    def descendants(pid):
+        """every process below `pid` in the parent tree (/proc): torchrun gives its workers sessions of their own, so the ranks are NOT in the
+        launcher's process group -- they are found by parentage, before anything is signalled (an orphan is re-parented and lost)"""
+        par, born = {}, {}
+        try:
+            for d in os.listdir("/proc"):
+                if d.isdigit():
+                    try:
+                        st = open("/proc/%s/stat" % d).read()
+                        f = st[st.rindex(")") + 2:].split()
+                        par[int(d)], born[int(d)] = int(f[1]), f[19]          # parent pid, start time: (pid, start time) names a process for good
+                    except (OSError, ValueError, IndexError):
+                        pass
+        except OSError:
+            return []
+        out, frontier = [], [pid]
+        while frontier:
+            nxt = [p for p, pp in par.items() if pp in frontier]
+            out += [(p, born[p]) for p in nxt]
+            frontier = nxt
+        return out
+
+    def still(p, start):
+        try:
+            st = open("/proc/%d/stat" % p).read()
+            return st[st.rindex(")") + 2:].split()[19] == start
+        except (OSError, ValueError, IndexError):
+            return False
+
     def end_group(proc):
-        """SIGTERM, then SIGKILL, to the launcher's process group -- exactly the processes started here (a session of their own)"""
+        """SIGTERM to the launcher's process group (torchrun forwards it to its workers), then SIGKILL to the group AND to every process that
+        descended from it -- exactly the processes started here -- so that a rank stuck inside a driver call cannot outlive the command"""
+        tree = descendants(proc.pid)
         for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
             try:
                 os.killpg(proc.pid, sig)
@@ -481,6 +512,12 @@ def spawn_ranks(n, argv, timeout_s=None):
                 break
             except subprocess.TimeoutExpired:
                 continue
+        for p, start in tree:                            # survivors of the polite round (a rank that ignores SIGTERM); never a recycled pid
+            if still(p, start):
+                try:
+                    os.kill(p, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
 
     with tempfile.TemporaryFile(mode="w+") as err:
         proc = subprocess.Popen(cmd, stderr=err, start_new_session=True)
