@@ -852,6 +852,21 @@ def run_parnmpc_cxx(args, rank, local_rank, world, dist):
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                                "avg_launch_ms": ker[dom],
                                "whole_step_frac": A_STAGE["anymal_parnmpc"] * B * N / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world}
+            # FP64 roofline of the dominant kernel (exact FLOPs of the restatement's formulation, tests/golden/oracle_flops.json) and its issue counters
+            frec = None if trot else oracle_flops_record(args.workload, N)
+            if frec is not None:
+                kf = kernel_flops(frec, dom)
+                if kf:
+                    tfl = B * kf / (ker[dom] * 1e-3) / 1e12
+                    out["roofline"]["flops"] = {"per_launch": B * kf, "achieved_tflops": tfl, "peak": FP64_PEAK_TFLOPS, "frac": tfl / FP64_PEAK_TFLOPS,
+                                                "whole_step_tflops": B * frec["flop_per_iteration"] / (ms_step * 1e-3) / 1e12,
+                                                "whole_step_frac": B * frec["flop_per_iteration"] / (ms_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                                "source": "tests/golden/oracle_flops.json (exact operation counts of the CPU restatement, FMA = 2)"}
+                    sq, sq_source = quoted_sq(args.workload, B, N, pmc_name)
+                    if sq is not None:
+                        out["roofline"]["flops"]["lane_utilisation"] = (B * kf / 2) / max(1.0, sq["valu_lane_slots_per_launch"])
+                        out["roofline"]["mfma_util"] = sq.get("mfma_util")
+                    out["roofline"]["sq_source"] = sq_source
         if not args.no_cpu_baseline and world == 1 and not trot:
             from helpers import OracleParNMPC      # the CPU restatement: checker / baseline only
             o = OracleParNMPC(model, cost, cons, T, N)
