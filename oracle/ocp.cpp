@@ -15,10 +15,10 @@
 
 namespace oracle {
 
-static const int kP = 6;   // kDimFloatingBase
+// kP (a member of both solvers): the passive rows of a floating base, Robot::dim_passive -- 6, or 0 on a fixed-base robot
 
 SplitSolutionC::SplitSolutionC(const Robot& r)
-    : lmd(r.dimv()), gmm(r.dimv()), q(r.dimq()), v(r.dimv()), a(r.dimv()), u(r.dimu()), beta(r.dimv()), nu_passive(6),
+    : lmd(r.dimv()), gmm(r.dimv()), q(r.dimq()), v(r.dimv()), a(r.dimv()), u(r.dimu()), beta(r.dimv()), nu_passive(r.dimv() - r.dimu()),
       xi(3 * r.maxPointContacts()), f(r.maxPointContacts(), Mat(3)), mu(r.maxPointContacts(), Mat(3)) {
   if (r.hasFloatingBase()) q[6] = 1.0;
 }
@@ -33,13 +33,14 @@ Mat SplitSolutionC::mu_stack(const ContactStatus& cs) const {
   return o;
 }
 SplitDirectionC::SplitDirectionC(const Robot& r)
-    : dlmd(r.dimv()), dgmm(r.dimv()), du(r.dimu()), dq(r.dimv()), dv(r.dimv()), daf(r.dimv()), dbetamu(r.dimv()), dnu_passive(6),
+    : dlmd(r.dimv()), dgmm(r.dimv()), du(r.dimu()), dq(r.dimv()), dv(r.dimv()), daf(r.dimv()), dbetamu(r.dimv()), dnu_passive(r.dimv() - r.dimu()),
       dxi(0) {}
 SplitKKTMatrixC::SplitKKTMatrixC(int nv_, int nu_)
     : nv(nv_), nu(nu_), Qxx(2 * nv_, 2 * nv_), Qxu_full(2 * nv_, nv_), Quu_full(nv_, nv_), Qaa_diag(nv_), Qff(0, 0),
-      Fqq6(6, 6), Fqv6(6, 6), Fvq(nv_, nv_), Fvv(nv_, nv_), Fvu(nv_, nu_), Fqq_prev6(6, 6), Fqq_inv(6, 6), Fqq_prev_inv(6, 6) {}
+      Fqq6(nv_ - nu_, nv_ - nu_), Fqv6(nv_ - nu_, nv_ - nu_), Fvq(nv_, nv_), Fvv(nv_, nv_), Fvu(nv_, nu_), Fqq_prev6(nv_ - nu_, nv_ - nu_),
+      Fqq_inv(nv_ - nu_, nv_ - nu_), Fqq_prev_inv(nv_ - nu_, nv_ - nu_) {}
 SplitKKTResidualC::SplitKKTResidualC(int nv, int nu)
-    : Fq(nv), Fv(nv), lq(nv), lv(nv), la(nv), lf(0), lu(nu), lu_passive(6), Fq_prev(6), P(0) {}
+    : Fq(nv), Fv(nv), lq(nv), lv(nv), la(nv), lf(0), lu(nu), lu_passive(nv - nu), Fq_prev(nv - nu), P(0) {}
 
 int ContactSequenceC::eventOfImpulse(int k) const {
   for (int e = 0, n = 0; e < numEvents(); ++e) if (is_impulse[e]) { if (n == k) return e; ++n; }
@@ -82,11 +83,10 @@ static void taskTerms(const Robot& task_robot, const RCost& cost, real t, const 
 OCPSolver::OCPSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
                      int max_num_impulse)
     : robot(model), task_robot(makeTaskRobot(model, cost_)), cost(cost_), cons(constraints), N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts),
-      max_events_(max_num_impulse), T_(T), dt_(T / N) {
+      max_events_(max_num_impulse), kP(model.nv - model.nu), T_(T), dt_(T / N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (max_num_impulse < 0) throw std::out_of_range("invalid value: max_num_impulse must be non-negative!");
-  if (!robot.hasFloatingBase()) throw std::logic_error("OCPSolver oracle: floating-base robots only");
   const int ns = nslots();
   s.assign(ns, SplitSolutionC(robot));
   d.assign(ns, SplitDirectionC(robot));
@@ -525,22 +525,22 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   Mat Fqq, Fqq_prev;
   robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq);
   robot.dSubtractdConfigurationMinus(q_prev, si.q, Fqq_prev);
-  M.Fqq6 = Fqq.block(0, 0, 6, 6);
-  M.Fqq_prev6 = Fqq_prev.block(0, 0, 6, 6);
+  M.Fqq6 = Fqq.block(0, 0, kP, kP);
+  M.Fqq_prev6 = Fqq_prev.block(0, 0, kP, kP);
   {
-    Mat t1 = M.Fqq6.t() * sn.lmd.segment(0, 6) + M.Fqq_prev6.t() * si.lmd.segment(0, 6);
-    for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
-    for (int r = 6; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
+    Mat t1 = M.Fqq6.t() * sn.lmd.segment(0, kP) + M.Fqq_prev6.t() * si.lmd.segment(0, kP);
+    for (int r = 0; r < kP; ++r) R.lq[r] += t1[r];
+    for (int r = kP; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
     for (int r = 0; r < nv; ++r) { R.lv[r] += dtq * sn.lmd[r] + sn.gmm[r] - si.gmm[r]; R.la[r] += dt * sn.gmm[r]; }
   }
   if (!residual_only) {
     // condenseForwardEuler (state_equation.hxx:40-63) / condenseImpulseForwardEuler (impulse_state_equation.hxx:36-57)
     Robot::dSubtractdConfigurationInverse(M.Fqq_prev6, M.Fqq_prev_inv);
     Mat Fm; robot.dSubtractdConfigurationMinus(si.q, sn.q, Fm);
-    M.Fqq_prev6 = Fm.block(0, 0, 6, 6);
+    M.Fqq_prev6 = Fm.block(0, 0, kP, kP);
     Robot::dSubtractdConfigurationInverse(M.Fqq_prev6, M.Fqq_inv);
     M.Fqq_prev6 = M.Fqq6;
-    R.Fq_prev = R.Fq.segment(0, 6);
+    R.Fq_prev = R.Fq.segment(0, kP);
     M.Fqq6 = -1.0 * (M.Fqq_inv * M.Fqq_prev6);
     M.Fqv6 = (-dtq) * M.Fqq_inv;
     R.Fq.setSegment(0, -1.0 * (M.Fqq_inv * R.Fq_prev));
@@ -574,7 +574,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
   const Mat mu_stack = si.mu_stack(cs);
   if (dimf > 0) R.lf -= dt * (D.dCda * si.beta);
   if (!impulse) {
-    for (int r = 0; r < 6; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
+    for (int r = 0; r < kP; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
     for (int r = 0; r < nu; ++r) R.lu[r] -= dt * si.beta[kP + r];
   }
   if (dimf > 0) {
@@ -688,7 +688,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     U.Fq = R.Fq; U.Fq.setSegment(0, R.Fq_prev);                       // the residual before condenseForwardEuler premultiplied its base rows
     U.Fv = R.Fv;
     U.Fqq = M.Fqq_prev6;                                              // dSubtractdConfigurationPlus(q, q_next) (parked there by condenseForwardEuler)
-    U.Fqq_prev = Fqq_prev.block(0, 0, 6, 6);                          // dSubtractdConfigurationMinus(q_prev, q)
+    U.Fqq_prev = Fqq_prev.block(0, 0, kP, kP);                          // dSubtractdConfigurationMinus(q_prev, q)
     U.dIDCdqv = D.dIDCdqv; U.M = D.dIDda; U.J = D.dCda; U.IDC = D.IDC;
     U.Phix = W.Phix; U.Phia = W.Phia; U.P = R.P;
   }
@@ -716,7 +716,7 @@ void OCPSolver::linearizeNode(Robot& robot, int p, const Mat& q_prev, bool resid
     M.Qxu_full -= D.MJtJinv_dIDCdqv.t() * D.Qafu_full;
     M.Quu_full += D.MJtJinv.block(0, 0, nv, nv + dimf) * D.Qafu_full;
     Mat t1 = D.MJtJinv.block(0, 0, nv, nv + dimf) * D.laf;
-    for (int r = 0; r < 6; ++r) R.lu_passive[r] += t1[r];
+    for (int r = 0; r < kP; ++r) R.lu_passive[r] += t1[r];
     for (int r = 0; r < nu; ++r) R.lu[r] += t1[kP + r];
     M.Fvu = dt * D.MJtJinv.block(0, kP, nv, nu);
   }
@@ -754,10 +754,10 @@ void OCPSolver::linearizeTerminal(Robot& robot, int p, const Mat& q_prev, bool r
   if (cost.task_dim) { real c_; Mat g_; taskTerms(task_robot, cost, nd.t, cost.task_weightf, sN.q, c_, g_, task_H); R.lq += g_; }
   // linearizeForwardEulerTerminal (state_equation.hxx:66-83)
   Mat Fqq_prev; robot.dSubtractdConfigurationMinus(q_prev, sN.q, Fqq_prev);
-  M.Fqq_prev6 = Fqq_prev.block(0, 0, 6, 6);
-  Mat t1 = M.Fqq_prev6.t() * sN.lmd.segment(0, 6);
-  for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
-  for (int r = 6; r < nv; ++r) R.lq[r] -= sN.lmd[r];
+  M.Fqq_prev6 = Fqq_prev.block(0, 0, kP, kP);
+  Mat t1 = M.Fqq_prev6.t() * sN.lmd.segment(0, kP);
+  for (int r = 0; r < kP; ++r) R.lq[r] += t1[r];
+  for (int r = kP; r < nv; ++r) R.lq[r] -= sN.lmd[r];
   R.lv -= sN.gmm;
   if (residual_only) return;
   Robot::dSubtractdConfigurationInverse(M.Fqq_prev6, M.Fqq_prev_inv);     // condenseForwardEulerTerminal
@@ -863,7 +863,7 @@ real OCPSolver::KKTError() {
 // the same recursion with Fqv = 0 and no control.
 void OCPSolver::backwardRiccatiRecursion() {
   FLOP_REGION(R_RICCATI_BWD);
-  const int nv = nv_, nu = nu_, nj = nv - 6;
+  const int nv = nv_, nu = nu_, nj = nv - kP;
   {
     const int sl = chain.back().slot;
     riccati[sl].Pqq = kkt_matrix[sl].Qxx.block(0, 0, nv, nv);
@@ -882,21 +882,21 @@ void OCPSolver::backwardRiccatiRecursion() {
     SplitKKTResidualC& R = kkt_residual[sl];
     // BackwardRiccatiRecursionFactorizer::factorizeKKTMatrix (backward_riccati_recursion_factorizer.hxx:44-114)
     Mat AtPqq(nv, nv), AtPqv(nv, nv), AtPvq(nv, nv), AtPvv(nv, nv);
-    AtPqq.setBlock(0, 0, Mx.Fqq6.t() * rn.Pqq.block(0, 0, 6, nv)); AtPqq.setBlock(6, 0, rn.Pqq.block(6, 0, nj, nv));
-    AtPqv.setBlock(0, 0, Mx.Fqq6.t() * rn.Pqv.block(0, 0, 6, nv)); AtPqv.setBlock(6, 0, rn.Pqv.block(6, 0, nj, nv));
+    AtPqq.setBlock(0, 0, Mx.Fqq6.t() * rn.Pqq.block(0, 0, kP, nv)); AtPqq.setBlock(kP, 0, rn.Pqq.block(kP, 0, nj, nv));
+    AtPqv.setBlock(0, 0, Mx.Fqq6.t() * rn.Pqv.block(0, 0, kP, nv)); AtPqv.setBlock(kP, 0, rn.Pqv.block(kP, 0, nj, nv));
     if (!impulse) {
-      AtPvq.setBlock(0, 0, Mx.Fqv6.t() * rn.Pqq.block(0, 0, 6, nv)); AtPvq.setBlock(6, 0, dt * rn.Pqq.block(6, 0, nj, nv));
-      AtPvv.setBlock(0, 0, Mx.Fqv6.t() * rn.Pqv.block(0, 0, 6, nv)); AtPvv.setBlock(6, 0, dt * rn.Pqv.block(6, 0, nj, nv));
+      AtPvq.setBlock(0, 0, Mx.Fqv6.t() * rn.Pqq.block(0, 0, kP, nv)); AtPvq.setBlock(kP, 0, dt * rn.Pqq.block(kP, 0, nj, nv));
+      AtPvv.setBlock(0, 0, Mx.Fqv6.t() * rn.Pqv.block(0, 0, kP, nv)); AtPvv.setBlock(kP, 0, dt * rn.Pqv.block(kP, 0, nj, nv));
     }
     AtPqq += Mx.Fvq.t() * rn.Pqv.t();
     AtPqv += Mx.Fvq.t() * rn.Pvv;
     AtPvq += Mx.Fvv.t() * rn.Pqv.t();
     AtPvv += Mx.Fvv.t() * rn.Pvv;
     Mat Qqq = Mx.Qxx.block(0, 0, nv, nv), Qqv = Mx.Qxx.block(0, nv, nv, nv), Qvv = Mx.Qxx.block(nv, nv, nv, nv);
-    Qqq.addBlock(0, 0, AtPqq.block(0, 0, nv, 6) * Mx.Fqq6); Qqq.addBlock(0, 6, AtPqq.block(0, 6, nv, nj));
+    Qqq.addBlock(0, 0, AtPqq.block(0, 0, nv, kP) * Mx.Fqq6); Qqq.addBlock(0, kP, AtPqq.block(0, kP, nv, nj));
     if (!impulse) {
-      Qqv.addBlock(0, 0, AtPqq.block(0, 0, nv, 6) * Mx.Fqv6); Qqv.addBlock(0, 6, AtPqq.block(0, 6, nv, nj), dt);
-      Qvv.addBlock(0, 0, AtPvq.block(0, 0, nv, 6) * Mx.Fqv6); Qvv.addBlock(0, 6, AtPvq.block(0, 6, nv, nj), dt);
+      Qqv.addBlock(0, 0, AtPqq.block(0, 0, nv, kP) * Mx.Fqv6); Qqv.addBlock(0, kP, AtPqq.block(0, kP, nv, nj), dt);
+      Qvv.addBlock(0, 0, AtPvq.block(0, 0, nv, kP) * Mx.Fqv6); Qvv.addBlock(0, kP, AtPvq.block(0, kP, nv, nj), dt);
     }
     Qqq += AtPqv * Mx.Fvq;
     Qqv += AtPqv * Mx.Fvv;
@@ -960,8 +960,8 @@ void OCPSolver::backwardRiccatiRecursion() {
     r.Pqq = 0.5 * (r.Pqq + r.Pqq.t());
     r.Pvv = 0.5 * (r.Pvv + r.Pvv.t());
     r.sq = Mat(nv); r.sv = Mat(nv);
-    r.sq.setSegment(0, Mx.Fqq6.t() * rn.sq.segment(0, 6)); r.sq.setSegment(6, rn.sq.segment(6, nj));
-    if (!impulse) { r.sv.setSegment(0, Mx.Fqv6.t() * rn.sq.segment(0, 6)); r.sv.setSegment(6, dt * rn.sq.segment(6, nj)); }
+    r.sq.setSegment(0, Mx.Fqq6.t() * rn.sq.segment(0, kP)); r.sq.setSegment(kP, rn.sq.segment(kP, nj));
+    if (!impulse) { r.sv.setSegment(0, Mx.Fqv6.t() * rn.sq.segment(0, kP)); r.sv.setSegment(kP, dt * rn.sq.segment(kP, nj)); }
     r.sq += Mx.Fvq.t() * rn.sv;
     r.sv += Mx.Fvv.t() * rn.sv;
     r.sq -= AtPqq * R.Fq;
@@ -995,11 +995,11 @@ void OCPSolver::backwardRiccatiRecursion() {
 // split_riccati_factorizer.hxx:103-128; impulse_split_riccati_factorizer.hxx:27-44)
 void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
   FLOP_REGION(R_RICCATI_FWD);
-  const int nv = nv_, nj = nv - 6;
+  const int nv = nv_, nj = nv - kP;
   {
     const int s0 = chain[0].slot;
     robot.subtractConfiguration(q, s[s0].q, d[s0].dq);
-    d[s0].dq.setSegment(0, -1.0 * (kkt_matrix[s0].Fqq_prev_inv * d[s0].dq.segment(0, 6)));
+    d[s0].dq.setSegment(0, -1.0 * (kkt_matrix[s0].Fqq_prev_inv * d[s0].dq.segment(0, kP)));
     d[s0].dv = v - s[s0].v;
   }
   for (int p = 0; p < M() - 1; ++p) {
@@ -1012,10 +1012,10 @@ void OCPSolver::forwardRiccatiRecursion(const Mat& q, const Mat& v) {
     Mat dx(2 * nv); dx.setSegment(0, d[sl].dq); dx.setSegment(nv, d[sl].dv);
     if (impulse) d[sl].du.setZero(); else d[sl].du = K[sl] * dx + k[sl];
     Mat dqn = R.Fq, dvn = R.Fv;
-    Mat h = Mx.Fqq6 * d[sl].dq.segment(0, 6);
-    if (!impulse) h += Mx.Fqv6 * d[sl].dv.segment(0, 6);
-    for (int r = 0; r < 6; ++r) dqn[r] += h[r];
-    for (int r = 0; r < nj; ++r) dqn[6 + r] += d[sl].dq[6 + r] + dt * d[sl].dv[6 + r];
+    Mat h = Mx.Fqq6 * d[sl].dq.segment(0, kP);
+    if (!impulse) h += Mx.Fqv6 * d[sl].dv.segment(0, kP);
+    for (int r = 0; r < kP; ++r) dqn[r] += h[r];
+    for (int r = 0; r < nj; ++r) dqn[kP + r] += d[sl].dq[kP + r] + dt * d[sl].dv[kP + r];
     dvn += Mx.Fvq * d[sl].dq;
     dvn += Mx.Fvv * d[sl].dv;
     if (!impulse) dvn += Mx.Fvu * d[sl].du;
@@ -1125,9 +1125,9 @@ void OCPSolver::integrateSolution() {
       // ImpulseDynamicsForwardEuler::expansionDual (impulse_dynamics_forward_euler.hxx:127-137)
       if (!impulse) {
         d[sl].dnu_passive = R.lu_passive;
-        d[sl].dnu_passive += Mx.Quu_full.block(0, kP, 6, nu) * d[sl].du;
-        d[sl].dnu_passive += Mx.Qxu_full.block(0, 0, 2 * nv, 6).t() * dx;
-        d[sl].dnu_passive += dt * (D.MJtJinv.block(0, 0, 6, nv) * dgmm);
+        d[sl].dnu_passive += Mx.Quu_full.block(0, kP, kP, nu) * d[sl].du;
+        d[sl].dnu_passive += Mx.Qxu_full.block(0, 0, 2 * nv, kP).t() * dx;
+        d[sl].dnu_passive += dt * (D.MJtJinv.block(0, 0, kP, nv) * dgmm);
         d[sl].dnu_passive = (-1.0 / dt) * d[sl].dnu_passive;
       } else {
         d[sl].dnu_passive.setZero();
@@ -1138,7 +1138,7 @@ void OCPSolver::integrateSolution() {
       d[sl].dbetamu = (-1.0 / dt) * (D.MJtJinv * D.laf);
     }
     // stateequation::correctCostateDirectionForwardEuler (state_equation.hxx:96-108)
-    d[sl].dlmd.setSegment(0, -1.0 * (Mx.Fqq_prev_inv.t() * d[sl].dlmd.segment(0, 6)));
+    d[sl].dlmd.setSegment(0, -1.0 * (Mx.Fqq_prev_inv.t() * d[sl].dlmd.segment(0, kP)));
     // SplitOCP / ImpulseSplitOCP / TerminalOCP::updatePrimal -> (Impulse)SplitSolution::integrate
     // (split_solution.hxx:215-240, impulse_split_solution.hxx:188-203)
     SplitSolutionC& si = s[sl];
@@ -1299,11 +1299,10 @@ std::pair<real, real> OCPSolver::costAndViolation(real alpha) {
 ParNMPCSolver::ParNMPCSolver(const RModel& model, const RCost& cost_, const idocp_constraints_t& constraints, real T, int N,
                              int max_num_impulse)
     : robot(model), task_robot(makeTaskRobot(model, cost_)), cost(cost_), cons(constraints), next_s(robot), next_snew(robot), prev_s(robot), prev_snew(robot),
-      N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), max_events_(max_num_impulse), T_(T), dt_(T / N) {
+      N_ideal_(N), N_(N), nv_(model.nv), nu_(model.nu), nc_(model.ncontacts), max_events_(max_num_impulse), kP(model.nv - model.nu), T_(T), dt_(T / N) {
   if (T <= 0) throw std::out_of_range("invalid value: T must be positive!");
   if (N <= 0) throw std::out_of_range("invalid value: N must be positive!");
   if (max_num_impulse < 0) throw std::out_of_range("invalid value: max_num_impulse must be non-negative!");
-  if (!robot.hasFloatingBase()) throw std::logic_error("ParNMPCSolver oracle: floating-base robots only");
   const int ns = nslots();
   s.assign(ns, SplitSolutionC(robot)); s_new = s;
   d.assign(ns, SplitDirectionC(robot));
@@ -1706,29 +1705,29 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   Mat diff; robot.subtractConfiguration(q_prev, si.q, diff);
   for (int r = 0; r < nv; ++r) { R.Fq[r] = diff[r] + dt * si.v[r]; R.Fv[r] = v_prev[r] - si.v[r] + dt * si.a[r]; }
   Mat Fqq; robot.dSubtractdConfigurationMinus(q_prev, si.q, Fqq);
-  M.Fqq6 = Fqq.block(0, 0, 6, 6);
+  M.Fqq6 = Fqq.block(0, 0, kP, kP);
   {
-    Mat t1 = M.Fqq6.t() * si.lmd.segment(0, 6);
+    Mat t1 = M.Fqq6.t() * si.lmd.segment(0, kP);
     if (!terminal) {
       const SplitSolutionC& sn = *nextSolution(p);
       Mat Fqq_next; robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq_next);
-      M.Fqq_prev6 = Fqq_next.block(0, 0, 6, 6);
-      t1 += M.Fqq_prev6.t() * sn.lmd.segment(0, 6);
-      for (int r = 6; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
+      M.Fqq_prev6 = Fqq_next.block(0, 0, kP, kP);
+      t1 += M.Fqq_prev6.t() * sn.lmd.segment(0, kP);
+      for (int r = kP; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
       for (int r = 0; r < nv; ++r) R.lv[r] += dt * si.lmd[r] - si.gmm[r] + sn.gmm[r];
     } else {
-      for (int r = 6; r < nv; ++r) R.lq[r] -= si.lmd[r];
+      for (int r = kP; r < nv; ++r) R.lq[r] -= si.lmd[r];
       for (int r = 0; r < nv; ++r) R.lv[r] += dt * si.lmd[r] - si.gmm[r];
     }
-    for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
+    for (int r = 0; r < kP; ++r) R.lq[r] += t1[r];
     for (int r = 0; r < nv; ++r) R.la[r] += dt * si.gmm[r];
   }
   if (!residual_only) {
     // condenseBackwardEuler (state_equation.hxx:149-170)
     Mat Fp; robot.dSubtractdConfigurationPlus(q_prev, si.q, Fp);
-    Robot::dSubtractdConfigurationInverse(Fp.block(0, 0, 6, 6), M.Fqq_inv);
+    Robot::dSubtractdConfigurationInverse(Fp.block(0, 0, kP, kP), M.Fqq_inv);
     M.Fqq_prev6 = M.Fqq6;
-    R.Fq_prev = R.Fq.segment(0, 6);
+    R.Fq_prev = R.Fq.segment(0, kP);
     M.Fqq6 = M.Fqq_inv * M.Fqq_prev6;
     M.Fqv6 = dt * M.Fqq_inv;
     R.Fq.setSegment(0, M.Fqq_inv * R.Fq_prev);
@@ -1750,7 +1749,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   R.la += dt * (D.dIDda.t() * si.beta);
   const Mat mu_stack = si.mu_stack(cs);
   if (dimf > 0) R.lf -= dt * (D.dCda * si.beta);
-  for (int r = 0; r < 6; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
+  for (int r = 0; r < kP; ++r) R.lu_passive[r] = dt * si.nu_passive[r] - dt * si.beta[r];
   for (int r = 0; r < nu; ++r) R.lu[r] -= dt * si.beta[kP + r];
   if (dimf > 0) {
     R.lq += dt * (dCdq.t() * mu_stack);
@@ -1862,7 +1861,7 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
   M.Quu_full += D.MJtJinv.block(0, 0, nv, nv + dimf) * D.Qafu_full;
   {
     Mat t1 = D.MJtJinv.block(0, 0, nv, nv + dimf) * D.laf;
-    for (int r = 0; r < 6; ++r) R.lu_passive[r] += t1[r];
+    for (int r = 0; r < kP; ++r) R.lu_passive[r] += t1[r];
     for (int r = 0; r < nu; ++r) R.lu[r] += t1[kP + r];
   }
   M.Fvq = (-dt) * D.MJtJinv_dIDCdqv.block(0, 0, nv, nv);
@@ -1935,22 +1934,22 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
   Mat diff; robot.subtractConfiguration(q_prev, si.q, diff);
   for (int r = 0; r < nv; ++r) { R.Fq[r] = diff[r]; R.Fv[r] = v_prev[r] - si.v[r] + si.a[r]; }
   Mat Fqq; robot.dSubtractdConfigurationMinus(q_prev, si.q, Fqq);
-  M.Fqq6 = Fqq.block(0, 0, 6, 6);
+  M.Fqq6 = Fqq.block(0, 0, kP, kP);
   {
     Mat Fqq_next; robot.dSubtractdConfigurationPlus(si.q, sn.q, Fqq_next);
-    M.Fqq_prev6 = Fqq_next.block(0, 0, 6, 6);
-    Mat t1 = M.Fqq_prev6.t() * sn.lmd.segment(0, 6);
-    t1 += M.Fqq6.t() * si.lmd.segment(0, 6);
-    for (int r = 0; r < 6; ++r) R.lq[r] += t1[r];
-    for (int r = 6; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
+    M.Fqq_prev6 = Fqq_next.block(0, 0, kP, kP);
+    Mat t1 = M.Fqq_prev6.t() * sn.lmd.segment(0, kP);
+    t1 += M.Fqq6.t() * si.lmd.segment(0, kP);
+    for (int r = 0; r < kP; ++r) R.lq[r] += t1[r];
+    for (int r = kP; r < nv; ++r) R.lq[r] += sn.lmd[r] - si.lmd[r];
     for (int r = 0; r < nv; ++r) { R.lv[r] += -si.gmm[r] + sn.gmm[r]; R.la[r] += si.gmm[r]; }
   }
   if (!residual_only) {
     // condenseImpulseBackwardEuler (:86-111)
     Mat Fp; robot.dSubtractdConfigurationPlus(q_prev, si.q, Fp);
-    Robot::dSubtractdConfigurationInverse(Fp.block(0, 0, 6, 6), M.Fqq_inv);
+    Robot::dSubtractdConfigurationInverse(Fp.block(0, 0, kP, kP), M.Fqq_inv);
     M.Fqq_prev6 = M.Fqq6;
-    R.Fq_prev = R.Fq.segment(0, 6);
+    R.Fq_prev = R.Fq.segment(0, kP);
     M.Fqq6 = M.Fqq_inv * M.Fqq_prev6;
     R.Fq.setSegment(0, M.Fqq_inv * R.Fq_prev);
   }
@@ -2057,7 +2056,7 @@ void ParNMPCSolver::coarseUpdate(real t, const Mat& q, const Mat& v) {
       Q.setBlock(0, 0, M.Quu_full.block(kP, kP, nu, nu)); Q.setBlock(0, nu, Qxu.t()); Q.setBlock(nu, 0, Qxu); Q.setBlock(nu, nu, M.Qxx);
       Mat Fqq = -1.0 * Mat::Identity(nv), Fqv = nd.dt * Mat::Identity(nv);
       Fqq.setBlock(0, 0, M.Fqq6); Fqv.setBlock(0, 0, M.Fqv6);
-      for (int r = 0; r < 6; ++r) for (int c = 6; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; Fqv(r, c) = 0; Fqv(c, r) = 0; }
+      for (int r = 0; r < kP; ++r) for (int c = kP; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; Fqv(r, c) = 0; Fqv(c, r) = 0; }
       J.setBlock(0, nu, Fqq); J.setBlock(0, nu + nv, Fqv);
       J.setBlock(nv, 0, M.Fvu); J.setBlock(nv, nu, M.Fvq); J.setBlock(nv, nu + nv, M.Fvv);
       if (aux) J.setBlock(nx, nu, sw_Pq[i]);
@@ -2071,7 +2070,7 @@ void ParNMPCSolver::coarseUpdate(real t, const Mat& q, const Mat& v) {
       Q.setBlock(0, 0, M.Qff); Q.setBlock(0, ni, I.Qqf.t()); Q.setBlock(ni, 0, I.Qqf); Q.setBlock(ni, ni, M.Qxx);
       Mat Fqq = -1.0 * Mat::Identity(nv);
       Fqq.setBlock(0, 0, M.Fqq6);
-      for (int r = 0; r < 6; ++r) for (int c = 6; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; }
+      for (int r = 0; r < kP; ++r) for (int c = kP; c < nv; ++c) { Fqq(r, c) = 0; Fqq(c, r) = 0; }
       J.setBlock(0, ni, Fqq);
       J.setBlock(nv, 0, I.Fvf); J.setBlock(nv, ni, I.Fvq); J.setBlock(nv, ni + nv, -1.0 * Mat::Identity(nv));
       J.setBlock(nx, ni, I.Vq); J.setBlock(nx, ni + nv, I.Vv);
@@ -2248,7 +2247,7 @@ void ParNMPCSolver::forwardCorrectionParallel() {
       I.ldv += d[i].dgmm;
       Mat dbeta = -1.0 * (I.Minv * I.ldv);
       d[i].dbetamu = Mat(nv + dimf); d[i].dbetamu.setSegment(0, dbeta); d[i].dbetamu.setSegment(nv, dmu);
-      d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, 6));
+      d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, kP));
       continue;
     }
     d[i].du = s_new[i].u - s[i].u;
@@ -2299,15 +2298,15 @@ void ParNMPCSolver::forwardCorrectionParallel() {
     // (state_equation.hxx:172-181)
     ContactDynamicsDataC& Dm = cd[i];
     d[i].dnu_passive = R.lu_passive;
-    d[i].dnu_passive += M.Quu_full.block(0, kP, 6, nu) * d[i].du;
-    d[i].dnu_passive += M.Qxu_full.block(0, 0, nx, 6).t() * dx;
-    d[i].dnu_passive += dt * (Dm.MJtJinv.block(0, 0, 6, nv) * d[i].dgmm);
+    d[i].dnu_passive += M.Quu_full.block(0, kP, kP, nu) * d[i].du;
+    d[i].dnu_passive += M.Qxu_full.block(0, 0, nx, kP).t() * dx;
+    d[i].dnu_passive += dt * (Dm.MJtJinv.block(0, 0, kP, nv) * d[i].dgmm);
     d[i].dnu_passive = (-1.0 / dt) * d[i].dnu_passive;
     Dm.laf += Dm.Qafqv * dx;
     Dm.laf += Dm.Qafu_full.block(0, kP, nv + dimf, nu) * d[i].du;
     for (int r = 0; r < nv; ++r) Dm.laf[r] += dt * d[i].dgmm[r];
     d[i].dbetamu = (-1.0 / dt) * (Dm.MJtJinv * Dm.laf);
-    d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, 6));
+    d[i].dlmd.setSegment(0, M.Fqq_inv.t() * d[i].dlmd.segment(0, kP));
   }
   primal_step_size = pmin; dual_step_size = dmin;
 }

@@ -194,6 +194,7 @@ class OCPSolver {
 
  private:
   int N_ideal_, N_, nv_, nu_, nc_, max_events_;
+  int kP;                    // passive rows of the floating base (6), 0 on a fixed-base robot
   real T_, dt_;
   bool discretized_ = false;
   // components: 0..5 joint limits (q lo/up, v lo/up, u lo/up), 6 friction cone (impulse cone on impulse stages)
@@ -318,6 +319,7 @@ class ParNMPCSolver {
 
  private:
   int N_ideal_, N_, nv_, nu_, nc_, max_events_;
+  int kP;                    // passive rows of the floating base (6), 0 on a fixed-base robot
   real T_, dt_;
   real disc_t_ = 0;
   bool discretized_ = false;

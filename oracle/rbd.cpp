@@ -755,6 +755,7 @@ void Robot::dIntegratedVelocity(const Mat& /*q*/, const Mat& v, Mat& J) const {
 // Robot::dSubtractdConfigurationInverse (robot.hxx:151-163): block-triangular 6x6 inverse
 void Robot::dSubtractdConfigurationInverse(const Mat& J, Mat& Jinv) {
   FLOP_REGION(R_LIE);
+  if (J.r == 0) { Jinv = Mat(0, 0); return; }      // fixed base: no passive rows
   auto inv3 = [](const Mat& A) {
     Mat I(3, 3);
     const real det = A(0, 0) * (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(1, 2) * A(2, 0)) +

@@ -469,8 +469,14 @@ class OracleOCP:
         self.lib.oracle_ocp_compute_kkt_residual(self.h, t, P(arr(q)), P(arr(v)))
         return self.lib.oracle_ocp_kkt_error(self.h)
 
+    def _dim(self, name):
+        # ANYmal: the table; any other robot (the fixed-base arm of tests/test_oracle_fixed_base.py): from the model's dimensions
+        if self.nv == 18:
+            return OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS[name]
+        return {"q": self.nq, "u": self.nu, "du": self.nu}.get(name, self.nv)
+
     def get(self, name):
-        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS[name]
+        dim = self._dim(name)
         out = np.zeros((self.N + 1, dim))
         assert self.lib.oracle_ocp_get(self.h, name.encode(), dim, P(out)) == 0
         return out[:self.N] if name in OCP_STAGE_ONLY else out
@@ -544,6 +550,7 @@ class OracleParNMPC:
             lib.oracle_parnmpc_chain.argtypes = [vp, cd, ci, ip, ip, ip, dp, dp, ip, ip]
             lib.oracle_parnmpc_get_chain.argtypes = [vp, cs, ci, dp]
         self.N, self.nv, self.max_num_impulse = N, model.nv, max_num_impulse
+        self.nq, self.nu = model.nq, model.nu
         if max_num_impulse > 0:
             self.h = lib.oracle_parnmpc_create_hybrid(C.byref(model), C.byref(cost), C.byref(cons), T, N, max_num_impulse)
         else:
@@ -633,7 +640,7 @@ class OracleParNMPC:
         return self.lib.oracle_parnmpc_kkt_error(self.h, t, P(arr(q)), P(arr(v)))
 
     def get(self, name):
-        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS[name]
+        dim = (OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS[name]) if self.nv == 18 else {"q": self.nq, "u": self.nu, "du": self.nu}.get(name, self.nv)
         out = np.zeros((self.N, dim))
         assert self.lib.oracle_parnmpc_get(self.h, name.encode(), dim, P(out)) == 0
         return out
