@@ -137,6 +137,7 @@ def _proto(lib):
     for name, args in [
         ("idocp_unocp_set_solution", [vp, cs, c_double_p]),
         ("idocp_unocp_set_solution_batch", [vp, cs, c_double_p]),
+        ("idocp_unocp_set_solution_only", [vp, cs, c_double_p]),
         ("idocp_unocp_init_constraints", [vp]),
         ("idocp_unocp_set_task_refs", [vp, c_double_p]),
         ("idocp_unocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),
@@ -152,6 +153,7 @@ def _proto(lib):
         ("idocp_unocp_get_direction", [vp, cs, ci, c_double_p]),
         ("idocp_unocp_get_step_sizes", [vp, c_double_p, c_double_p]),
         ("idocp_unocp_get_riccati", [vp, ci, c_double_p, c_double_p, c_double_p, c_double_p]),
+        ("idocp_unocp_get_torque_feedback_gain", [vp, ci, ci, c_double_p, c_double_p]),
         ("idocp_unocp_get_constraint_data", [vp, ci, c_double_p, c_double_p]),
         ("idocp_unocp_dimc", [vp]),
         ("idocp_unocp_is_current_solution_feasible", [vp, c_int_p, c_int_p]),

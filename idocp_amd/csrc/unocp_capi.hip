@@ -433,7 +433,7 @@ void idocp_unocp_destroy(idocp_unocp_t* h) {
   delete h;
 }
 
-static int setSolutionImpl(idocp_unocp_t* h, const char* name, const double* values, int per_instance) {
+static int setSolutionImpl(idocp_unocp_t* h, const char* name, const double* values, int per_instance, bool init_constraints = true) {
   if (!h || !name || !values) return IDOCP_E_ARG;
   FieldRef f;
   const std::string n(name);
@@ -445,12 +445,16 @@ static int setSolutionImpl(idocp_unocp_t* h, const char* name, const double* val
   const size_t cnt = (size_t)(per_instance ? h->batch : 1) * f.dim;
   HIP_TRY(hipMemcpyAsync(h->d_tmp, values, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   fillField(h->B.sol, L7::SOL, f.offset, f.dim, h->N + 1, h->batch, h->d_tmp, per_instance, h->stream);
-  UnLaunch<7>::initConstraints(h->B, h->batch, h->N, h->stream);
+  if (init_constraints) UnLaunch<7>::initConstraints(h->B, h->batch, h->N, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return IDOCP_OK;
 }
 int idocp_unocp_set_solution(idocp_unocp_t* h, const char* name, const double* value) { return setSolutionImpl(h, name, value, 0); }
 int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name, const double* values) { return setSolutionImpl(h, name, values, 1); }
+// OCPSolver::setSolution / ParNMPCSolver::setSolution (ocp_solver.cpp:116-165, parnmpc_solver.cpp:128-180) leave the slack and dual variables alone
+// (the driver calls initConstraints(t) itself): the setter of the facade's OCPSolver / ParNMPCSolver on a fixed-base robot without contacts,
+// which are bound to these kernels (include/idocp/ocp/ocp_solver.hpp)
+int idocp_unocp_set_solution_only(idocp_unocp_t* h, const char* name, const double* value) { return setSolutionImpl(h, name, value, 0, false); }
 
 // TimeVaryingTaskSpace{3D,6D}Cost: the reference asks its TimeVaryingTaskSpace*RefBase for the pose at the time of every
 // stage (time_varying_task_space_6d_cost.cpp:65-67 with t = t0 + i dt from unocp_solver.cpp:78-94); here the caller evaluates
@@ -802,6 +806,29 @@ int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s
       if (K) std::memcpy(K + (size_t)i * nv * nx, g + L7::G_K, sizeof(double) * nv * nx);
       if (k) std::memcpy(k + (size_t)i * nv, g + L7::G_k, sizeof(double) * nv);
     }
+  }
+  return IDOCP_OK;
+}
+
+// OCPSolver::getStateFeedbackGain (ocp_solver.cpp:101-111) for the fixed-base robot without contacts: the torque policy du = Kq dq + Kv dv of the
+// contact-dynamics formulation is the acceleration policy da = Ka dx + ka of this one mapped through the linearised inverse dynamics,
+// du = ID + dID/dq dq + dID/dv dv + M da (unconstrained_dynamics.hxx:84-92):  Kq = dID/dq + M Ka_q,  Kv = dID/dv + M Ka_v, with the
+// derivatives of the SAME linearisation the gains belong to (the dyn record of the last updateSolution).  Kq, Kv: nv x nv col-major.
+int idocp_unocp_get_torque_feedback_gain(idocp_unocp_t* h, int instance, int stage, double* Kq, double* Kv) {
+  if (!h || !Kq || !Kv || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->N) { set_last_error("idocp_unocp_get_torque_feedback_gain: invalid argument"); return IDOCP_E_ARG; }
+  if (h->bwd || !h->B.gain) { set_last_error("idocp_unocp_get_torque_feedback_gain: the LQR policy belongs to UnOCPSolver (UnParNMPCSolver keeps none)"); return IDOCP_E_UNSUPPORTED; }
+  int rc = setDevice(h); if (rc) return rc;
+  const int nv = h->nv;
+  std::vector<double> dyn(L7::DYN), gain(L7::GAIN);
+  const size_t rec = (size_t)instance * h->N + stage;
+  HIP_TRY(hipMemcpyAsync(dyn.data(), h->B.dyn + rec * L7::DYN, dyn.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(gain.data(), h->B.gain + rec * L7::GAIN, gain.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const double *dq = &dyn[L7::D_DQ], *dv = &dyn[L7::D_DV], *M = &dyn[L7::D_DA], *Ka = &gain[L7::G_K];
+  for (int c = 0; c < nv; ++c) for (int r = 0; r < nv; ++r) {
+    double aq = dq[c * nv + r], av = dv[c * nv + r];
+    for (int m = 0; m < nv; ++m) { aq += M[m * nv + r] * Ka[c * nv + m]; av += M[m * nv + r] * Ka[(nv + c) * nv + m]; }
+    Kq[c * nv + r] = aq; Kv[c * nv + r] = av;
   }
   return IDOCP_OK;
 }

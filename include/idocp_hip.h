@@ -232,6 +232,12 @@ int idocp_unocp_set_solution(idocp_unocp_t* h, const char* name,
 /* Same, one value per instance: values[batch][dim]. */
 int idocp_unocp_set_solution_batch(idocp_unocp_t* h, const char* name,
                                    const double* values);
+/* OCPSolver::setSolution / ParNMPCSolver::setSolution (ocp_solver.cpp:116-165, parnmpc_solver.cpp:128-180) write the
+ * value and leave the slack / dual variables as they are (the driver calls initConstraints(t)): the setter behind the
+ * facade's idocp::OCPSolver / idocp::ParNMPCSolver on a fixed-base robot without contacts, which are bound to these
+ * kernels -- with no contact rows the two formulations condense one Newton system in two orders
+ * (tests/test_oracle_fixed_base.py). */
+int idocp_unocp_set_solution_only(idocp_unocp_t* h, const char* name, const double* value);
 /* Per-stage reference poses of a TimeVaryingTaskSpace3DCost / TimeVaryingTaskSpace6DCost (cost.task_dim != 0): the values of
  * TimeVaryingTaskSpace6DRefBase::compute_q_6d_ref (time_varying_task_space_6d_cost.hpp:21-42) at t + i dt, i = 0 .. N.
  * refs: host, [N + 1][12] = rotation (row-major) then position; a 3D cost reads the position only.  Without a call the
@@ -285,6 +291,11 @@ int idocp_unocp_get_step_sizes(idocp_unocp_t* h, double* primal, double* dual);
  * lqr_state_feedback_policy.hpp:11-28) */
 int idocp_unocp_get_riccati(idocp_unocp_t* h, int instance, double* P, double* s,
                             double* K, double* k);
+/* OCPSolver::getStateFeedbackGain (ocp_solver.cpp:101-111) on the fixed-base robot without contacts: the TORQUE policy
+ * du = Kq dq + Kv dv, i.e. the acceleration policy above mapped through the linearised inverse dynamics of the same
+ * linearisation (unconstrained_dynamics.hxx:84-92): Kq = dID/dq + M Ka_q, Kv = dID/dv + M Ka_v; nv x nv col-major. */
+int idocp_unocp_get_torque_feedback_gain(idocp_unocp_t* h, int instance, int stage,
+                                         double* Kq, double* Kv);
 /* Slack / dual variables of the IPM, [N][dimc] for one instance. */
 int idocp_unocp_get_constraint_data(idocp_unocp_t* h, int instance,
                                     double* slack, double* dual);
