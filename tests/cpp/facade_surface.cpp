@@ -78,6 +78,56 @@ int main(int argc, char** argv) {
     REQUIRE(maxDiff(cpn.getSolution(2).v, cpn.getSolution("v")[2]) == 0.0);
     idocp::UnParNMPCSolver pn2(pn);
     REQUIRE(maxDiff(pn2.getSolution(2).lmd, cpn.getSolution(2).lmd) == 0.0);
+    {  // OCPSolver / ParNMPCSolver on this robot (no contact frame): bound to the kernels above (ocp_solver.hpp, parnmpc_solver.hpp) -- the step of
+       // the unconstrained solver from the same start, bit for bit; setSolution without re-initialising the constraints; copies; the torque gain
+      idocp::UnOCPSolver un(robot, cost, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      idocp::OCPSolver oc(robot, cost, idocp::JointConstraintsFactory(robot).create(), 0.6, N, 0, 2);
+      REQUIRE(oc.unconstrainedSolver() != nullptr && oc.handle() == nullptr);
+      un.setSolution("q", q); un.setSolution("v", v);
+      oc.setSolution("q", q); oc.setSolution("v", v);
+      oc.setSolution("f", ex::V3(0, 0, 1));                                   // (every contact: there is none)
+      oc.setContactStatusUniformly(robot.createContactStatus());
+      oc.initConstraints(0.0);
+      oc.computeKKTResidual(0.0, q, v); un.computeKKTResidual(0.0, q, v);
+      REQUIRE(oc.KKTError() == un.KKTError());
+      oc.updateSolution(0.0, q, v); un.updateSolution(0.0, q, v);
+      const idocp::OCPSolver& coc = oc;
+      REQUIRE(maxDiff(coc.getSolution(4).u, un.getSolution(4).u) == 0.0 && maxDiff(coc.getSolution("lmd")[N], un.getSolution("lmd")[N]) == 0.0);
+      REQUIRE((int)coc.getSolution("f").size() == N && coc.getSolution("f")[0].size() == 0 && coc.getSolution(4).dimf() == 0);
+      Eigen::MatrixXd Kq, Kv, Aq, Av;
+      coc.getStateFeedbackGain(2, Kq, Kv);
+      un.getStateFeedbackGain(2, Aq, Av);                                       // (the acceleration gain: another matrix)
+      REQUIRE(Kq.rows() == n && Kq.cols() == n && Kv.rows() == n && std::isfinite(Kq(0, 0)) && std::fabs(Kq(0, 0) - Aq(0, 0)) > 1e-9);
+      idocp::OCPSolver oc2(oc), oc3;
+      oc3 = oc;
+      oc.updateSolution(0.0, q, v); oc2.updateSolution(0.0, q, v); oc3.updateSolution(0.0, q, v); un.updateSolution(0.0, q, v);
+      REQUIRE(maxDiff(oc2.getSolution(5).a, oc.getSolution(5).a) == 0.0 && maxDiff(oc3.getSolution(5).a, oc.getSolution(5).a) == 0.0);
+      REQUIRE(maxDiff(un.getSolution(5).a, oc.getSolution(5).a) == 0.0);
+      REQUIRE(oc.isCurrentSolutionFeasible());
+      idocp::OCPSolver moved(std::move(oc2));
+      REQUIRE(moved.unconstrainedSolver() != nullptr && maxDiff(moved.getSolution(5).a, oc.getSolution(5).a) == 0.0);
+      // setSolution after initConstraints keeps slack / dual (OCPSolver) -- UnOCPSolver's re-initialises them: the next steps differ
+      oc.setSolution("v", ex::filled(n, 0.05)); un.setSolution("v", ex::filled(n, 0.05));
+      oc.updateSolution(0.0, q, v); un.updateSolution(0.0, q, v);
+      REQUIRE(maxDiff(un.getSolution(5).a, oc.getSolution(5).a) > 0.0);
+
+      idocp::UnParNMPCSolver upn(robot, cost, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      idocp::ParNMPCSolver opn(robot, cost, idocp::JointConstraintsFactory(robot).create(), 0.6, N, 0, 2);
+      REQUIRE(opn.unconstrainedSolver() != nullptr);
+      upn.setSolution("q", q); upn.setSolution("v", v);
+      opn.setSolution("q", q); opn.setSolution("v", v);
+      upn.initConstraints(); opn.initConstraints(0.0);
+      upn.initBackwardCorrection(0.0); opn.initBackwardCorrection(0.0);
+      upn.updateSolution(0.0, q, v); opn.updateSolution(0.0, q, v);
+      const idocp::ParNMPCSolver& copn = opn;
+      REQUIRE(maxDiff(copn.getSolution(3).q, upn.getSolution(3).q) == 0.0 && maxDiff(copn.getSolution("gmm")[N - 1], upn.getSolution("gmm")[N - 1]) == 0.0);
+      opn.computeKKTResidual(0.0, q, v); upn.computeKKTResidual(0.0, q, v);
+      REQUIRE(opn.KKTError() == upn.KKTError());
+      idocp::ParNMPCSolver opn2(opn);
+      opn.updateSolution(0.0, q, v); opn2.updateSolution(0.0, q, v);
+      REQUIRE(maxDiff(opn2.getSolution(3).u, opn.getSolution(3).u) == 0.0);
+      std::cout << "contact-path solvers on the fixed-base robot: ok" << std::endl;
+    }
     std::cout << "fixed-base solvers: ok" << std::endl;
   }
   {  // ---- floating base
