@@ -300,9 +300,14 @@ def _parity_table(g, o, hv, what, tol, cap):
     ga, oa = ga.reshape(n, -1), oa.reshape(n, -1)
     scale = np.maximum(1.0, np.abs(oa).max(axis=1))
     ego = np.abs(ga - oa).max(axis=1) / scale
+    # the same distance ENTRY BY ENTRY (relative to the entry itself) over the entries that are at least 1e-3 of their stage's scale (the
+    # largest entry, never less than 1 -- the scale rel_err uses): rel_err holds the smaller entries of a large stage to an absolute bar, this
+    # column shows what that hides among the entries that carry the stage (a diagnostic, not a bar)
+    big = np.abs(oa) >= 1e-3 * scale[:, None]
+    cw = np.where(big, np.abs(ga - oa) / np.maximum(np.abs(oa), 1e-3), 0.0)
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "parity_tables.txt"), "a") as f:
-        f.write("## [%s] %s   tol %.0e  cap %s  worst %.2e at stage %d  (%d stages, %d above tol)\n" % (os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], what, tol, "%.0e" % cap if cap else "-", ego.max(), int(ego.argmax()), n, int((ego >= tol).sum())))
+        f.write("## [%s] %s   tol %.0e  cap %s  worst %.2e at stage %d  (%d stages, %d above tol)  entry-wise over the entries >= 1e-3 of the stage's scale: %.2e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], what, tol, "%.0e" % cap if cap else "-", ego.max(), int(ego.argmax()), n, int((ego >= tol).sum()), float(cw.max()) if cw.size else 0.0))
         if hv is not None:
             ha = np.asarray(hv, dtype=np.float64).reshape(n, -1)
             sh = np.maximum(1.0, np.abs(ha).max(axis=1))
