@@ -138,6 +138,7 @@ def _proto(lib):
         ("idocp_unocp_set_solution", [vp, cs, c_double_p]),
         ("idocp_unocp_set_solution_batch", [vp, cs, c_double_p]),
         ("idocp_unocp_set_solution_only", [vp, cs, c_double_p]),
+        ("idocp_unocp_set_cost", [vp, P(Cost)]),
         ("idocp_unocp_init_constraints", [vp]),
         ("idocp_unocp_set_task_refs", [vp, c_double_p]),
         ("idocp_unocp_update_solution", [vp, cd, c_double_p, c_double_p, ci]),

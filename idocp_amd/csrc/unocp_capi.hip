@@ -152,6 +152,44 @@ int idocp_device_upload(void* d_dst, const void* h_src, unsigned long long nbyte
   return IDOCP_OK;
 }
 
+// The problem block of a handle (cost, limits, IPM parameters, shard description) from the structs of the C ABI: at creation and when the cost is
+// replaced (idocp_unocp_set_cost).
+static void fillUnProblem(const idocp_model_t& model, const idocp_cost_t& cost, const idocp_constraints_t& constraints, double T, int N, int batch, int bwd,
+                          double dt, int stage_offset, int has_terminal, int has_prev, UnProblem& up) {
+  std::memset(&up, 0, sizeof(up));
+  up.N = N; up.batch = batch; up.T = T; up.dt = dt > 0.0 ? dt : T / N;
+  up.stage_offset = stage_offset; up.has_terminal = has_terminal; up.has_prev = has_prev;
+  for (int i = 0; i < model.nv; ++i) {
+    up.q_ref[i] = cost.q_ref[i]; up.v_ref[i] = cost.v_ref[i]; up.u_ref[i] = cost.u_ref[i];
+    up.q_weight[i] = cost.q_weight[i]; up.v_weight[i] = cost.v_weight[i]; up.a_weight[i] = cost.a_weight[i];
+    up.u_weight[i] = cost.u_weight[i]; up.qf_weight[i] = cost.qf_weight[i]; up.vf_weight[i] = cost.vf_weight[i];
+    up.q_min[i] = model.q_min[i]; up.q_max[i] = model.q_max[i]; up.v_max[i] = model.v_max[i]; up.u_max[i] = model.u_max[i];
+  }
+  up.use_q_limits = constraints.joint_position_limits; up.use_v_limits = constraints.joint_velocity_limits;
+  up.use_u_limits = constraints.joint_torque_limits;
+  up.use_a_lower = constraints.joint_acceleration_lower_limit ? 1 : 0;
+  up.use_a_upper = constraints.joint_acceleration_upper_limit ? 1 : 0;
+  for (int i = 0; i < IDOCP_MAX_NV; ++i) { up.a_min[i] = constraints.a_min[i]; up.a_max[i] = constraints.a_max[i]; }
+  up.barrier = constraints.barrier; up.fraction_rate = constraints.fraction_to_boundary_rate;
+  up.backward_euler = bwd;
+  up.task.dim = cost.task_dim; up.task.joint = cost.task_joint;
+  std::memcpy(up.task.R, cost.task_frame_R, sizeof(up.task.R)); std::memcpy(up.task.p, cost.task_frame_p, sizeof(up.task.p));
+  std::memcpy(up.task.weight, cost.task_weight, sizeof(up.task.weight)); std::memcpy(up.task.weightf, cost.task_weightf, sizeof(up.task.weightf));
+  if (cost.task_dim == 3) for (int k = 3; k < 6; ++k) up.task.weight[k] = up.task.weightf[k] = 0.0;
+  std::memcpy(up.task.ref, cost.task_ref, sizeof(up.task.ref));
+  up.task_n = cost.task_dim ? 1 + cost.task_extra_count : 0;
+  for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) {
+    TaskCost& tc = up.task_extra[e];
+    std::memset(&tc, 0, sizeof(tc));
+    if (cost.task_dim == 0 || e >= cost.task_extra_count) continue;
+    const idocp_task_component_t& t = cost.task_extra[e];
+    tc.dim = t.dim; tc.joint = t.joint;
+    std::memcpy(tc.R, t.frame_R, sizeof(tc.R)); std::memcpy(tc.p, t.frame_p, sizeof(tc.p));
+    std::memcpy(tc.weight, t.weight, sizeof(tc.weight)); std::memcpy(tc.weightf, t.weightf, sizeof(tc.weightf)); std::memcpy(tc.ref, t.ref, sizeof(tc.ref));
+    if (t.dim == 3) for (int k = 3; k < 6; ++k) tc.weight[k] = tc.weightf[k] = 0.0;
+  }
+}
+
 // bwd: 0 UnOCP, 1 UnParNMPC.  N, dt: the stages this handle holds and their time step; stage_offset / has_terminal / has_prev
 // describe a horizon shard of UnParNMPC (0 / 1 / 0 for a whole horizon).
 static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
@@ -262,38 +300,8 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   for (int i = 0; i < model->njoints; ++i) if (!(model->axis[i][0] == 0.0 && model->axis[i][1] == 0.0 && model->axis[i][2] == 1.0)) B.zaxes = 0;
   if (std::getenv("IDOCP_GENERAL_AXES")) B.zaxes = 0;      // tests: the general instantiation on a chain that qualifies for the special one
   DevModel dm; toDevModel(*model, dm);
-  UnProblem up; std::memset(&up, 0, sizeof(up));
-  up.N = N; up.batch = batch; up.T = T; up.dt = dt > 0.0 ? dt : T / N;
-  up.stage_offset = stage_offset; up.has_terminal = has_terminal; up.has_prev = has_prev;
-  for (int i = 0; i < model->nv; ++i) {
-    up.q_ref[i] = cost->q_ref[i]; up.v_ref[i] = cost->v_ref[i]; up.u_ref[i] = cost->u_ref[i];
-    up.q_weight[i] = cost->q_weight[i]; up.v_weight[i] = cost->v_weight[i]; up.a_weight[i] = cost->a_weight[i];
-    up.u_weight[i] = cost->u_weight[i]; up.qf_weight[i] = cost->qf_weight[i]; up.vf_weight[i] = cost->vf_weight[i];
-    up.q_min[i] = model->q_min[i]; up.q_max[i] = model->q_max[i]; up.v_max[i] = model->v_max[i]; up.u_max[i] = model->u_max[i];
-  }
-  up.use_q_limits = constraints->joint_position_limits; up.use_v_limits = constraints->joint_velocity_limits;
-  up.use_u_limits = constraints->joint_torque_limits;
-  up.use_a_lower = constraints->joint_acceleration_lower_limit ? 1 : 0;
-  up.use_a_upper = constraints->joint_acceleration_upper_limit ? 1 : 0;
-  for (int i = 0; i < IDOCP_MAX_NV; ++i) { up.a_min[i] = constraints->a_min[i]; up.a_max[i] = constraints->a_max[i]; }
-  up.barrier = constraints->barrier; up.fraction_rate = constraints->fraction_to_boundary_rate;
-  up.backward_euler = bwd;
-  up.task.dim = cost->task_dim; up.task.joint = cost->task_joint;
-  std::memcpy(up.task.R, cost->task_frame_R, sizeof(up.task.R)); std::memcpy(up.task.p, cost->task_frame_p, sizeof(up.task.p));
-  std::memcpy(up.task.weight, cost->task_weight, sizeof(up.task.weight)); std::memcpy(up.task.weightf, cost->task_weightf, sizeof(up.task.weightf));
-  if (cost->task_dim == 3) for (int k = 3; k < 6; ++k) up.task.weight[k] = up.task.weightf[k] = 0.0;
-  std::memcpy(up.task.ref, cost->task_ref, sizeof(up.task.ref));
-  up.task_n = cost->task_dim ? 1 + cost->task_extra_count : 0;
-  for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) {
-    TaskCost& tc = up.task_extra[e];
-    std::memset(&tc, 0, sizeof(tc));
-    if (cost->task_dim == 0 || e >= cost->task_extra_count) continue;
-    const idocp_task_component_t& t = cost->task_extra[e];
-    tc.dim = t.dim; tc.joint = t.joint;
-    std::memcpy(tc.R, t.frame_R, sizeof(tc.R)); std::memcpy(tc.p, t.frame_p, sizeof(tc.p));
-    std::memcpy(tc.weight, t.weight, sizeof(tc.weight)); std::memcpy(tc.weightf, t.weightf, sizeof(tc.weightf)); std::memcpy(tc.ref, t.ref, sizeof(tc.ref));
-    if (t.dim == 3) for (int k = 3; k < 6; ++k) tc.weight[k] = tc.weightf[k] = 0.0;
-  }
+  UnProblem up;
+  fillUnProblem(*model, *cost, *constraints, T, N, batch, bwd, dt, stage_offset, has_terminal, has_prev, up);
   void *d_model = nullptr, *d_prob = nullptr;
   if (hipMalloc(&d_model, sizeof(DevModel)) != hipSuccess || hipMalloc(&d_prob, sizeof(UnProblem)) != hipSuccess) {
     set_last_error("hipMalloc failed"); return fail(IDOCP_E_DEVICE);
@@ -323,6 +331,42 @@ int idocp_unocp_create(const idocp_model_t* model, const idocp_cost_t* cost, con
 int idocp_unparnmpc_create(const idocp_model_t* model, const idocp_cost_t* cost, const idocp_constraints_t* constraints,
                            double T, int N, int batch, int device, idocp_unocp_t** out) {
   return createImpl(model, cost, constraints, T, N, batch, device, 1, out);
+}
+
+// The reference's solvers SHARE the CostFunction with the driver (unocp_solver.hpp: shared_ptr members), so a reference or a weight changed
+// between two updateSolution calls takes effect at the next one; here the cost is copied at creation and this call is how an MPC loop moves
+// its goal (the counterpart of idocp_ocp_set_cost).  The KIND of cost must stay what it was: a task-space component cannot appear or disappear,
+// nor can the first task_extra component (their records are allocated at creation).  Stream-ordered: the next launch sees the new block.
+int idocp_unocp_set_cost(idocp_unocp_t* h, const idocp_cost_t* cost) {
+  if (!h || !cost) { set_last_error("idocp_unocp_set_cost: null argument"); return IDOCP_E_ARG; }
+  if ((cost->task_dim != 0) != (h->cost.task_dim != 0) || cost->task_time_varying != h->cost.task_time_varying ||
+      (cost->task_extra_count > 0) != (h->cost.task_extra_count > 0)) {
+    set_last_error("idocp_unocp_set_cost: a task-space cost cannot be added or removed after creation");
+    return IDOCP_E_UNSUPPORTED;
+  }
+  if (cost->task_dim != 0) {
+    if (cost->task_dim != 3 && cost->task_dim != 6) { set_last_error("invalid value: task_dim must be 0, 3 or 6!"); return IDOCP_E_ARG; }
+    if (cost->task_joint < 0 || cost->task_joint >= h->model.njoints) { set_last_error("invalid value: task_joint is not a joint of the model!"); return IDOCP_E_ARG; }
+  }
+  if (cost->task_extra_count < 0 || cost->task_extra_count > IDOCP_MAX_EXTRA_TASKS) { set_last_error("invalid value: task_extra_count must be 0 .. " + std::to_string(IDOCP_MAX_EXTRA_TASKS) + "!"); return IDOCP_E_ARG; }
+  for (int e = 0; e < cost->task_extra_count; ++e) {
+    if (cost->task_extra[e].dim != 3 && cost->task_extra[e].dim != 6) { set_last_error("invalid value: task_extra[" + std::to_string(e) + "].dim must be 3 or 6!"); return IDOCP_E_ARG; }
+    if (cost->task_extra[e].joint < 0 || cost->task_extra[e].joint >= h->model.njoints) { set_last_error("invalid value: task_extra[" + std::to_string(e) + "].joint is not a joint of the model!"); return IDOCP_E_ARG; }
+  }
+  int rc = setDevice(h); if (rc) return rc;
+  UnProblem up;
+  fillUnProblem(h->model, *cost, h->cons, h->T, h->N, h->batch, h->bwd, h->shard_dt, h->shard_offset, h->shard_terminal, h->shard_prev, up);
+  // (the block is read by kernels already queued on the stream: the copy is ordered behind them; `up` must outlive the asynchronous copy)
+  HIP_TRY(hipMemcpyAsync(const_cast<UnProblem*>(h->B.prob), &up, sizeof(up), hipMemcpyHostToDevice, h->stream));
+  if (cost->task_dim != 0 && !cost->task_time_varying) {      // the constant reference pose of every stage (time-varying: idocp_unocp_set_task_refs)
+    std::vector<double> refs((size_t)(h->N + 1) * 12);
+    for (int i = 0; i <= h->N; ++i) std::memcpy(&refs[12 * i], cost->task_ref, sizeof(double) * 12);
+    HIP_TRY(hipMemcpyAsync(h->B.task_ref, refs.data(), refs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->cost = *cost;
+  return IDOCP_OK;
 }
 
 static int wrongKind(const idocp_unocp_t* h, int want_bwd);

@@ -10,6 +10,7 @@
 #define IDOCP_UNOCP_SOLVER_HPP_
 
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -34,6 +35,7 @@ class UnOCPSolver {
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
     check(idocp_unocp_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    last_cost_ = c;
     cache_.resize(N + 1);
   }
   // unocp_solver.hpp:49: an empty solver, to be assigned a constructed one before use
@@ -41,7 +43,7 @@ class UnOCPSolver {
   ~UnOCPSolver() { idocp_unocp_destroy(h_); }
   // copyable and movable like the reference class (unocp_solver.hpp:59-74, `= default`): a copy is a DEEP copy of the solver state on
   // the device (idocp_unocp_clone)
-  UnOCPSolver(const UnOCPSolver& other) : robot_(other.robot_), cost_(other.cost_), N_(other.N_), dt_(other.dt_), h_(nullptr), cache_(other.cache_) {
+  UnOCPSolver(const UnOCPSolver& other) : robot_(other.robot_), cost_(other.cost_), N_(other.N_), dt_(other.dt_), h_(nullptr), cache_(other.cache_), last_cost_(other.last_cost_) {
     if (other.h_) check(idocp_unocp_clone(other.h_, &h_));
   }
   UnOCPSolver& operator=(const UnOCPSolver& other) {
@@ -49,16 +51,16 @@ class UnOCPSolver {
       idocp_unocp_t* n = nullptr;
       if (other.h_) check(idocp_unocp_clone(other.h_, &n));
       idocp_unocp_destroy(h_);
-      h_ = n; robot_ = other.robot_; cost_ = other.cost_; N_ = other.N_; dt_ = other.dt_; cache_ = other.cache_;
+      h_ = n; robot_ = other.robot_; cost_ = other.cost_; N_ = other.N_; dt_ = other.dt_; cache_ = other.cache_; last_cost_ = other.last_cost_;
     }
     return *this;
   }
   UnOCPSolver(UnOCPSolver&& other) noexcept
-      : robot_(other.robot_), cost_(std::move(other.cost_)), N_(other.N_), dt_(other.dt_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
+      : robot_(other.robot_), cost_(std::move(other.cost_)), N_(other.N_), dt_(other.dt_), h_(other.h_), cache_(std::move(other.cache_)), last_cost_(other.last_cost_) { other.h_ = nullptr; }
   UnOCPSolver& operator=(UnOCPSolver&& other) noexcept {
     if (this != &other) {
       idocp_unocp_destroy(h_);
-      h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; cost_ = std::move(other.cost_); N_ = other.N_; dt_ = other.dt_; cache_ = std::move(other.cache_);
+      h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; cost_ = std::move(other.cost_); N_ = other.N_; dt_ = other.dt_; cache_ = std::move(other.cache_); last_cost_ = other.last_cost_;
     }
     return *this;
   }
@@ -66,6 +68,7 @@ class UnOCPSolver {
   void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    syncCost();
     uploadTaskRefs(t);
     check(idocp_unocp_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
@@ -151,6 +154,7 @@ class UnOCPSolver {
     return e;
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    syncCost();
     uploadTaskRefs(t);
     check(idocp_unocp_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
@@ -164,6 +168,14 @@ class UnOCPSolver {
   idocp_unocp_t* h_;
   mutable std::vector<SplitSolution> cache_;
   std::vector<double> task_refs_;
+  // The reference's solver SHARES the cost function with the driver (unocp_solver.hpp: shared_ptr members): a reference or weight the driver
+  // changes between two calls takes effect at the next one.  The device holds a copy; it is refreshed when the shared object has changed.
+  idocp_cost_t last_cost_{};
+  void syncCost() {
+    if (!cost_ || !h_) return;
+    const idocp_cost_t c = cost_->native();
+    if (std::memcmp(&c, &last_cost_, sizeof(c)) != 0) { check(idocp_unocp_set_cost(h_, &c)); last_cost_ = c; }
+  }
   // TimeVaryingTaskSpace*Cost: the reference asks the user's ref object at the time of every stage inside linearizeOCP
   // (unocp_solver.cpp:78-94 -> time_varying_task_space_6d_cost.cpp:65-67); here the poses are evaluated up front and uploaded
   void uploadTaskRefs(const double t) {

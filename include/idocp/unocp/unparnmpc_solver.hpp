@@ -10,6 +10,7 @@
 #define IDOCP_UNPARNMPC_SOLVER_HPP_
 
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -30,18 +31,19 @@ class UnParNMPCSolver {
  public:
   UnParNMPCSolver(const Robot& robot, const std::shared_ptr<CostFunction>& cost, const std::shared_ptr<Constraints>& constraints,
                   const double T, const int N, const int nthreads = 1, const int device = 0)
-      : robot_(robot), N_(N), h_(nullptr) {
+      : robot_(robot), N_(N), h_(nullptr), cost_(cost) {
     (void)nthreads;
     const idocp_cost_t c = cost->native();
     const idocp_constraints_t k = constraints->native();
     check(idocp_unparnmpc_create(&robot.model(), &c, &k, T, N, 1, device, &h_));
+    last_cost_ = c;
     cache_.resize(N);
   }
   // unparnmpc_solver.hpp:48: an empty solver, to be assigned a constructed one before use
   UnParNMPCSolver() : robot_(), N_(0), h_(nullptr) {}
   ~UnParNMPCSolver() { idocp_unocp_destroy(h_); }
   // copyable and movable like the reference class (`= default` there): a copy is a DEEP copy of the device state (idocp_unocp_clone)
-  UnParNMPCSolver(const UnParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_) {
+  UnParNMPCSolver(const UnParNMPCSolver& other) : robot_(other.robot_), N_(other.N_), h_(nullptr), cache_(other.cache_), cost_(other.cost_), last_cost_(other.last_cost_) {
     if (other.h_) check(idocp_unocp_clone(other.h_, &h_));
   }
   UnParNMPCSolver& operator=(const UnParNMPCSolver& other) {
@@ -49,20 +51,21 @@ class UnParNMPCSolver {
       idocp_unocp_t* n = nullptr;
       if (other.h_) check(idocp_unocp_clone(other.h_, &n));
       idocp_unocp_destroy(h_);
-      h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_;
+      h_ = n; robot_ = other.robot_; N_ = other.N_; cache_ = other.cache_; cost_ = other.cost_; last_cost_ = other.last_cost_;
     }
     return *this;
   }
-  UnParNMPCSolver(UnParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cache_(std::move(other.cache_)) { other.h_ = nullptr; }
+  UnParNMPCSolver(UnParNMPCSolver&& other) noexcept : robot_(other.robot_), N_(other.N_), h_(other.h_), cache_(std::move(other.cache_)), cost_(std::move(other.cost_)), last_cost_(other.last_cost_) { other.h_ = nullptr; }
   UnParNMPCSolver& operator=(UnParNMPCSolver&& other) noexcept {
-    if (this != &other) { idocp_unocp_destroy(h_); h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; N_ = other.N_; cache_ = std::move(other.cache_); }
+    if (this != &other) { idocp_unocp_destroy(h_); h_ = other.h_; other.h_ = nullptr; robot_ = other.robot_; N_ = other.N_; cache_ = std::move(other.cache_); cost_ = std::move(other.cost_); last_cost_ = other.last_cost_; }
     return *this;
   }
 
   void initConstraints() { check(idocp_unocp_init_constraints(h_)); }
-  void initBackwardCorrection(const double t) { check(idocp_unparnmpc_init_backward_correction(h_, t)); }
+  void initBackwardCorrection(const double t) { syncCost(); check(idocp_unparnmpc_init_backward_correction(h_, t)); }
 
   void updateSolution(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v, const bool line_search = false) {
+    syncCost();
     check(idocp_unparnmpc_update_solution(h_, t, q.data(), v.data(), line_search ? 1 : 0));
   }
 
@@ -136,6 +139,7 @@ class UnParNMPCSolver {
     return e;
   }
   void computeKKTResidual(const double t, const Eigen::VectorXd& q, const Eigen::VectorXd& v) {
+    syncCost();
     check(idocp_unparnmpc_compute_kkt_residual(h_, t, q.data(), v.data()));
   }
   idocp_unocp_t* handle() { return h_; }
@@ -145,6 +149,15 @@ class UnParNMPCSolver {
   int N_;
   idocp_unocp_t* h_;
   mutable std::vector<SplitSolution> cache_;
+  // the cost object is shared with the caller (as in the reference, whose solver keeps the shared_ptr): weights and references edited through it
+  // after construction reach the device with the next call (idocp_unocp_set_cost)
+  std::shared_ptr<CostFunction> cost_;
+  idocp_cost_t last_cost_{};
+  void syncCost() {
+    if (!cost_ || !h_) return;
+    const idocp_cost_t c = cost_->native();
+    if (std::memcmp(&c, &last_cost_, sizeof(c)) != 0) { check(idocp_unocp_set_cost(h_, &c)); last_cost_ = c; }
+  }
   static void check(int rc) {
     if (rc != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';

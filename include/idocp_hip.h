@@ -223,6 +223,11 @@ void idocp_unocp_destroy(idocp_unocp_t* h);
  * unocp_solver.hpp:59-62): same problem, same device, every device buffer and the line-search
  * filter copied. */
 int idocp_unocp_clone(idocp_unocp_t* src, idocp_unocp_t** out);
+/* Replace the cost of a UnOCPSolver / UnParNMPCSolver handle: the counterpart of idocp_ocp_set_cost.  The reference's
+ * solvers share the CostFunction with the driver (unocp_solver.hpp: shared_ptr members), so references and weights changed
+ * between two updateSolution calls take effect at the next one; here the cost is copied at creation and this call is how
+ * an MPC loop moves its goal.  A task-space component cannot be added or removed (IDOCP_E_UNSUPPORTED). */
+int idocp_unocp_set_cost(idocp_unocp_t* h, const idocp_cost_t* cost);
 
 /* UnOCPSolver::setSolution(name, value) (unocp_solver.cpp:157-181): name in
  * {"q","v","a","u"}; value[dim] is written to every stage of every instance,

@@ -128,6 +128,26 @@ int main(int argc, char** argv) {
       REQUIRE(maxDiff(opn2.getSolution(3).u, opn.getSolution(3).u) == 0.0);
       std::cout << "contact-path solvers on the fixed-base robot: ok" << std::endl;
     }
+    {  // the cost function is SHARED with the driver (unocp_solver.hpp: shared_ptr members): a reference moved after construction takes effect
+       // at the next call -- equal, bit for bit, to a solver constructed after the move
+      auto reach2 = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
+      reach2->set_q_ref(ex::filled(n, -1));
+      ex::attachWeights(*reach2, ex::filled(n, 10), ex::filled(n, 0.1), ex::filled(n, 0.01), false);
+      auto cost2 = std::make_shared<idocp::CostFunction>();
+      cost2->push_back(reach2);
+      idocp::UnOCPSolver early(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      idocp::UnParNMPCSolver early_pn(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      reach2->set_q_ref(ex::filled(n, 0.3));                                    // the driver moves the goal
+      reach2->set_qf_weight(ex::filled(n, 25));
+      idocp::UnOCPSolver late(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      idocp::UnParNMPCSolver late_pn(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      for (idocp::UnOCPSolver* sp : {&early, &late}) { sp->setSolution("q", q); sp->setSolution("v", v); sp->updateSolution(0.0, q, v); }
+      REQUIRE(maxDiff(early.getSolution(4).a, late.getSolution(4).a) == 0.0 && maxDiff(early.getSolution(N).lmd, late.getSolution(N).lmd) == 0.0);
+      REQUIRE(maxDiff(early.getSolution(4).a, solver.getSolution(4).a) > 1e-9);      // (and it is another problem than the one above)
+      for (idocp::UnParNMPCSolver* sp : {&early_pn, &late_pn}) { sp->setSolution("q", q); sp->setSolution("v", v); sp->initBackwardCorrection(0.0); sp->updateSolution(0.0, q, v); }
+      REQUIRE(maxDiff(early_pn.getSolution(4).a, late_pn.getSolution(4).a) == 0.0);
+      std::cout << "shared cost function: ok" << std::endl;
+    }
     std::cout << "fixed-base solvers: ok" << std::endl;
   }
   {  // ---- floating base

@@ -275,4 +275,4 @@ def test_facade_surface_const_getters_copies_and_default_constructors(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, IIWA_URDF, ANYMAL_URDF], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    assert "fixed-base solvers: ok" in r.stdout and "contact-path solvers on the fixed-base robot: ok" in r.stdout and "floating-base solver: ok" in r.stdout and "receding horizon through the facade: ok" in r.stdout
+    assert "fixed-base solvers: ok" in r.stdout and "shared cost function: ok" in r.stdout and "contact-path solvers on the fixed-base robot: ok" in r.stdout and "floating-base solver: ok" in r.stdout and "receding horizon through the facade: ok" in r.stdout

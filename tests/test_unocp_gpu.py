@@ -226,3 +226,42 @@ def test_general_axes_instantiation_direction_parity(monkeypatch):
         assert rel_err(g_general.direction(f), o.direction(f)) < TOL, f
         assert rel_err(g_special.direction(f), o.direction(f)) < TOL, f
         assert rel_err(g_general.direction(f), g_special.direction(f)) < TOL, f
+
+
+
+def test_set_cost_moves_the_goal_like_the_shared_cost_function_of_the_reference():
+    """The reference's UnOCPSolver / UnParNMPCSolver share the CostFunction with the driver (shared_ptr members, unocp_solver.hpp): an MPC loop that
+    moves q_ref or re-weights between two updates sees it at the next one.  idocp_unocp_set_cost is that on a handle: from the same iterate the
+    step equals, bit for bit, the step of a solver CREATED with the new cost, and the oracle's for that cost to 1e-10."""
+    from helpers import HipUnParNMPC, OracleUnParNMPC
+    m = iiwa14_model()
+    cost_a, cons = unocp_problem(m)
+    cost_b, _ = unocp_problem(m)
+    cost_b.set("q_ref", np.linspace(-1.0, 1.0, m.nv)).set("v_ref", np.zeros(m.nv))
+    cost_b.set("q_weight", np.full(m.nv, 3.0)).set("qf_weight", np.full(m.nv, 7.0)).set("u_weight", np.full(m.nv, 1e-3))
+    T, N = 1.0, 20
+    q, v = np.full(m.nv, 0.4), np.zeros(m.nv)
+    lib = capi.lib()
+    for Hip, Orc in ((HipUnOCP, OracleUnOCP), (HipUnParNMPC, OracleUnParNMPC)):
+        un = Hip is HipUnOCP
+        moved, fresh, o = Hip(m, cost_a, cons, T, N), Hip(m, cost_b, cons, T, N), Orc(m, cost_b, cons, T, N)
+        capi.check(lib.idocp_unocp_set_cost(moved.h, C.byref(cost_b)), "set_cost")
+        for s in (moved, fresh, o):
+            s.set_solution("q", q)
+            s.set_solution("v", v)
+            if not un:
+                s.init(0.0)                  # (the aux matrices of initBackwardCorrection carry the terminal weights)
+        e_m, e_f = moved.kkt_error(0.0, q, v)[0], fresh.kkt_error(0.0, q, v)[0]
+        assert e_m == e_f and abs(e_m - o.kkt_error(0.0, q, v)) <= 1e-10 * e_f
+        for it in range(2):
+            assert moved.update(0.0, q, v) == 0 and fresh.update(0.0, q, v) == 0 and o.update(0.0, q, v) == 0
+            for name in DIR_FIELDS:
+                a, b, r = (moved.direction(name), fresh.direction(name), o.direction(name)) if un else (moved.get(name), fresh.get(name), o.get(name))
+                assert np.array_equal(a, b), (it, name)
+                assert rel_err(a, r) <= (TOL if it == 0 else 1e-8), (it, name, rel_err(a, r))
+    # the kind of cost is fixed at creation
+    cost_t, _ = unocp_problem(m)
+    cost_t.task_dim = 3
+    g = HipUnOCP(m, cost_a, cons, T, N)
+    assert lib.idocp_unocp_set_cost(g.h, C.byref(cost_t)) != 0
+    assert b"cannot be added or removed" in lib.idocp_last_error()
