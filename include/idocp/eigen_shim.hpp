@@ -8,7 +8,7 @@
 #ifndef IDOCP_EIGEN_SHIM_HPP_
 #define IDOCP_EIGEN_SHIM_HPP_
 
-#if defined(__has_include)
+#if defined(__has_include) && !defined(IDOCP_EIGEN_IS_THE_SHIM)      // (idocp/compat/Eigen/Core: a forwarder to this file, for drivers that include "Eigen/Core")
 #if __has_include(<Eigen/Core>)
 #include <Eigen/Core>
 #define IDOCP_HAVE_EIGEN 1
