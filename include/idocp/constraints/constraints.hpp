@@ -155,6 +155,19 @@ class Constraints {
     }
     (c->upper ? hi_ : lo_)[c->family] = 1;
   }
+  // Constraints::setBarrier / setFractionToBoundaryRate (constraints.hxx:474-492): one value for every component pushed so far -- which is all the
+  // kernels take anyway (the reference asserts positivity, constraint_component_base.hxx:10-20; here a message, the solver would refuse the value
+  // too).  Call them before the solver is constructed: the solver copies the parameters.
+  void setBarrier(const double barrier) {
+    if (!(barrier > 0)) { std::cerr << "invalid value: barrier must be positive!" << '\n'; std::exit(EXIT_FAILURE); }
+    c_.barrier = barrier;
+  }
+  void setFractionToBoundaryRate(const double fraction_to_boundary_rate) {
+    if (!(fraction_to_boundary_rate > 0)) { std::cerr << "invalid value: fraction_to_boundary_rate must be positive!" << '\n'; std::exit(EXIT_FAILURE); }
+    c_.fraction_to_boundary_rate = fraction_to_boundary_rate;
+  }
+  // Constraints::clear (constraints.hxx:43-48): no component left
+  void clear() { *this = Constraints(); }
   // The kernels treat a limit family as a lower+upper pair (what
   // JointConstraintsFactory::create() builds); a lone lower or upper limit is rejected.
   idocp_constraints_t native() const {

@@ -103,18 +103,26 @@ class ConfigurationSpaceCost final : public CostFunctionComponentBase {
 class CostFunction {
  public:
   CostFunction() : have_{false, false, false} { idocp_cost_init(&c_); }
+  // CostFunction::push_back (cost_function.hxx:19-22).  The component is KEPT (shared with the driver, as in the reference): native() exports
+  // it again on every call, so a weight or reference the driver changes through the component afterwards reaches the solver at its next call.
   void push_back(const std::shared_ptr<CostFunctionComponentBase>& c) {
-    const int k = (int)c->kind();
-    if (k == (int)CostFunctionComponentBase::TaskSpace && have_[k]) { pushFurtherTask(c); return; }
-    if (have_[k] || !c->exportTo(c_)) {
+    if (!place(c, c_, have_, task_)) {
       std::cerr << "unsupported cost: the HIP path carries one configuration-space cost, one ContactForceCost and up to " << 1 + IDOCP_MAX_EXTRA_TASKS
-                << " task-space costs" << '\n';
+                << " task-space costs, one of them time-varying" << '\n';
       std::exit(EXIT_FAILURE);
     }
-    have_[k] = true;
-    if (k == (int)CostFunctionComponentBase::TaskSpace) task_ = c;
+    comps_.push_back(c);
   }
-  const idocp_cost_t& native() const { return c_; }
+  // CostFunction::clear (cost_function.hxx:25-27)
+  void clear() { comps_.clear(); task_.reset(); have_[0] = have_[1] = have_[2] = false; idocp_cost_init(&c_); }
+  // the flat cost block of the C ABI, exported afresh from the components in the order they were pushed
+  const idocp_cost_t& native() const {
+    idocp_cost_init(&c_);
+    bool have[3] = {false, false, false};
+    std::shared_ptr<CostFunctionComponentBase> task;
+    for (const auto& c : comps_) place(c, c_, have, task);      // (accepted by push_back: the kind of a component does not change)
+    return c_;
+  }
   // reference poses of a time-varying task-space cost at the stage times; false: none pushed / constant reference
   bool taskRefs(const double t, const double dt, const int N, std::vector<double>& refs) const {
     return task_ ? task_->stageRefs(t, dt, N, refs) : false;
@@ -123,28 +131,35 @@ class CostFunction {
 
  private:
   bool have_[3];
-  idocp_cost_t c_;
-  std::shared_ptr<CostFunctionComponentBase> task_;
-  // A second, third ... task-space component (the reference's CostFunction takes any number of components, cost_function.hpp:67): it goes into
-  // the task_extra block of the flat cost.  Only the component in the task_* block can be time-varying (it is the one the solver asks for
-  // reference poses); a time-varying component pushed behind a constant one takes that place and the constant one moves to task_extra.
-  void pushFurtherTask(const std::shared_ptr<CostFunctionComponentBase>& c) {
-    idocp_cost_t blk;
-    idocp_cost_init(&blk);
-    if (!c->exportTo(blk) || c_.task_extra_count >= IDOCP_MAX_EXTRA_TASKS || (blk.task_time_varying && c_.task_time_varying)) {
-      std::cerr << "unsupported cost: the HIP path carries up to " << 1 + IDOCP_MAX_EXTRA_TASKS << " task-space costs, one of them time-varying" << '\n';
-      std::exit(EXIT_FAILURE);
+  mutable idocp_cost_t c_;
+  std::shared_ptr<CostFunctionComponentBase> task_;      // the task-space component in the task_* block (the one asked for reference poses)
+  std::vector<std::shared_ptr<CostFunctionComponentBase>> comps_;
+  // One component into the flat block: the first of its kind through exportTo; a second, third ... task-space component (the reference's
+  // CostFunction takes any number of components, cost_function.hpp:67) into the task_extra block.  Only the component in the task_* block can be
+  // time-varying (it is the one the solver asks for reference poses); a time-varying component pushed behind a constant one takes that place and
+  // the constant one moves to task_extra.  false: cannot be represented.
+  static bool place(const std::shared_ptr<CostFunctionComponentBase>& c, idocp_cost_t& blk, bool (&have)[3], std::shared_ptr<CostFunctionComponentBase>& task) {
+    const int k = (int)c->kind();
+    if (!(k == (int)CostFunctionComponentBase::TaskSpace && have[k])) {
+      if (have[k] || !c->exportTo(blk)) return false;
+      have[k] = true;
+      if (k == (int)CostFunctionComponentBase::TaskSpace) task = c;
+      return true;
     }
-    if (blk.task_time_varying) {
-      c_.task_extra[c_.task_extra_count++] = taskBlockAsComponent(c_);
-      idocp_cost_t keep = c_;
-      keepTaskFields(blk, c_);
-      c_.task_extra_count = keep.task_extra_count;
-      for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) c_.task_extra[e] = keep.task_extra[e];
-      task_ = c;
+    idocp_cost_t one;
+    idocp_cost_init(&one);
+    if (!c->exportTo(one) || blk.task_extra_count >= IDOCP_MAX_EXTRA_TASKS || (one.task_time_varying && blk.task_time_varying)) return false;
+    if (one.task_time_varying) {
+      blk.task_extra[blk.task_extra_count++] = taskBlockAsComponent(blk);
+      idocp_cost_t keep = blk;
+      keepTaskFields(one, blk);
+      blk.task_extra_count = keep.task_extra_count;
+      for (int e = 0; e < IDOCP_MAX_EXTRA_TASKS; ++e) blk.task_extra[e] = keep.task_extra[e];
+      task = c;
     } else {
-      c_.task_extra[c_.task_extra_count++] = taskBlockAsComponent(blk);
+      blk.task_extra[blk.task_extra_count++] = taskBlockAsComponent(one);
     }
+    return true;
   }
 };
 

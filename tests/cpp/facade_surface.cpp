@@ -139,11 +139,26 @@ int main(int argc, char** argv) {
       idocp::UnParNMPCSolver early_pn(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
       reach2->set_q_ref(ex::filled(n, 0.3));                                    // the driver moves the goal
       reach2->set_qf_weight(ex::filled(n, 25));
-      idocp::UnOCPSolver late(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
-      idocp::UnParNMPCSolver late_pn(robot, cost2, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      auto reach3 = std::make_shared<idocp::ConfigurationSpaceCost>(robot);       // the moved problem, stated afresh
+      reach3->set_q_ref(ex::filled(n, 0.3));
+      ex::attachWeights(*reach3, ex::filled(n, 10), ex::filled(n, 0.1), ex::filled(n, 0.01), false);
+      reach3->set_qf_weight(ex::filled(n, 25));
+      auto cost3 = std::make_shared<idocp::CostFunction>();
+      cost3->push_back(reach3);
+      idocp::UnOCPSolver late(robot, cost3, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+      idocp::UnParNMPCSolver late_pn(robot, cost3, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
       for (idocp::UnOCPSolver* sp : {&early, &late}) { sp->setSolution("q", q); sp->setSolution("v", v); sp->updateSolution(0.0, q, v); }
       REQUIRE(maxDiff(early.getSolution(4).a, late.getSolution(4).a) == 0.0 && maxDiff(early.getSolution(N).lmd, late.getSolution(N).lmd) == 0.0);
-      REQUIRE(maxDiff(early.getSolution(4).a, solver.getSolution(4).a) > 1e-9);      // (and it is another problem than the one above)
+      {                                                                         // (and the move matters: a solver of the problem as it was)
+        auto reach0 = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
+        reach0->set_q_ref(ex::filled(n, -1));
+        ex::attachWeights(*reach0, ex::filled(n, 10), ex::filled(n, 0.1), ex::filled(n, 0.01), false);
+        auto cost0 = std::make_shared<idocp::CostFunction>();
+        cost0->push_back(reach0);
+        idocp::UnOCPSolver before(robot, cost0, idocp::JointConstraintsFactory(robot).create(), 0.6, N);
+        before.setSolution("q", q); before.setSolution("v", v); before.updateSolution(0.0, q, v);
+        REQUIRE(maxDiff(early.getSolution(4).a, before.getSolution(4).a) > 1e-6);
+      }
       for (idocp::UnParNMPCSolver* sp : {&early_pn, &late_pn}) { sp->setSolution("q", q); sp->setSolution("v", v); sp->initBackwardCorrection(0.0); sp->updateSolution(0.0, q, v); }
       REQUIRE(maxDiff(early_pn.getSolution(4).a, late_pn.getSolution(4).a) == 0.0);
       std::cout << "shared cost function: ok" << std::endl;
@@ -178,6 +193,25 @@ int main(int argc, char** argv) {
     REQUIRE(maxDiff(s0.beta, cs.getSolution("beta")[0]) == 0.0 && maxDiff(s0.nu_passive, cs.getSolution("nu_passive")[0]) == 0.0);
     REQUIRE((int)s0.f.size() == robot.maxPointContacts() && s0.f[1][2] == s0.f_stack()[5]);
     REQUIRE(maxDiff(cs.getSolution(N).v, cs.getSolution("v")[N]) == 0.0);
+    {  // the shared cost function on the floating base (ocp_solver.hpp:37-39): weights changed through the component after construction
+       // reach the solver at its next call -- the step of a solver constructed with those weights
+      auto pc1 = std::make_shared<idocp::ConfigurationSpaceCost>(robot), pc2 = std::make_shared<idocp::ConfigurationSpaceCost>(robot);
+      for (auto& pc : {pc1, pc2}) { pc->set_q_ref(stand); ex::attachWeights(*pc, ex::filled(18, 10), ex::filled(18, 1), ex::filled(18, 0.01), false); }
+      ex::attachWeights(*pc2, ex::filled(18, 4), ex::filled(18, 2), ex::filled(18, 0.05), false);
+      auto c1 = std::make_shared<idocp::CostFunction>(), c2 = std::make_shared<idocp::CostFunction>();
+      c1->push_back(pc1); c1->push_back(ex::forceCost(robot, ex::V3(0.001, 0.001, 0.001), false, &share));
+      c2->push_back(pc2); c2->push_back(ex::forceCost(robot, ex::V3(0.001, 0.001, 0.001), false, &share));
+      idocp::OCPSolver s1(robot, c1, ex::jointLimits(robot, 0.7, false, true), 0.25, N), s2(robot, c2, ex::jointLimits(robot, 0.7, false, true), 0.25, N);
+      ex::attachWeights(*pc1, ex::filled(18, 4), ex::filled(18, 2), ex::filled(18, 0.05), false);       // ... after s1 was constructed
+      for (idocp::OCPSolver* sp : {&s1, &s2}) {
+        standing.install(*sp, robot);
+        ex::restingGuess(*sp, robot, stand);
+        sp->initConstraints(0.0);
+        sp->updateSolution(0.0, stand, v);
+      }
+      REQUIRE(maxDiff(s1.getSolution(3).u, s2.getSolution(3).u) == 0.0 && maxDiff(s1.getSolution(N).lmd, s2.getSolution(N).lmd) == 0.0);
+      REQUIRE(maxDiff(s1.getSolution(3).u, solver.getSolution(3).u) > 1e-9);
+    }
     {  // TimeVaryingTaskSpace3DCost on the floating base: a reference that does not move gives the constant-reference solver's step
       struct Still : idocp::TimeVaryingTaskSpace3DRefBase {
         ex::V3 p;
