@@ -120,6 +120,12 @@ def _proto(lib):
         raise LibraryMissing("idocp_amd/capi.py structs do not match libidocp_hip.so (rebuild: python idocp_amd/build.py)")
     lib.idocp_model_contact_positions.argtypes = [P(Model), vp, vp]
     lib.idocp_model_contact_positions.restype = ci
+    lib.idocp_model_integrate_configuration.argtypes = [P(Model), vp, vp, cd, vp]
+    lib.idocp_model_integrate_configuration.restype = ci
+    lib.idocp_model_subtract_configuration.argtypes = [P(Model), vp, vp, vp]
+    lib.idocp_model_subtract_configuration.restype = ci
+    lib.idocp_model_normalize_configuration.argtypes = [P(Model), vp]
+    lib.idocp_model_normalize_configuration.restype = ci
     lib.idocp_cost_init.argtypes = [P(Cost)]
     lib.idocp_cost_init.restype = None
     lib.idocp_constraints_init.argtypes = [P(Constraints)]

@@ -2066,6 +2066,45 @@ int idocp_ocp_state_dims(idocp_ocp_t* h, int* nq, int* nv) {
   return IDOCP_OK;
 }
 
+// Robot::integrateConfiguration / subtractConfiguration / normalizeConfiguration (include/idocp/robot/robot.hxx:96-147) on the HOST, joint by joint:
+// what an MPC loop does between two solver calls -- advance the plant by one sampling period, measure the distance to a goal, keep the base
+// quaternion on the unit sphere.  Either side of the hot path, not on it (the kernels carry their own copies: dev_lie.hpp, the same functions).
+int idocp_model_integrate_configuration(const idocp_model_t* m, const double* q, const double* v, double length, double* q_out) {
+  if (!m || !q || !v || !q_out) { set_last_error("idocp_model_integrate_configuration: null argument"); return IDOCP_E_ARG; }
+  for (int i = 0; i < m->njoints; ++i) {
+    const int iq = m->idx_q[i], iv = m->idx_v[i];
+    if (m->jtype[i] == IDOCP_JOINT_FREEFLYER) idocp_dev::lieIntegrateBase(q + iq, v + iv, length, q_out + iq);      // pinocchio::integrate on SE(3)
+    else q_out[iq] = q[iq] + length * v[iv];
+  }
+  return IDOCP_OK;
+}
+// diff[nv] = q_plus (-) q_minus: log6(M_minus^-1 M_plus) on the free-flyer (pinocchio::difference(q_minus, q_plus)), q_plus - q_minus on a revolute joint
+int idocp_model_subtract_configuration(const idocp_model_t* m, const double* q_plus, const double* q_minus, double* diff) {
+  if (!m || !q_plus || !q_minus || !diff) { set_last_error("idocp_model_subtract_configuration: null argument"); return IDOCP_E_ARG; }
+  for (int i = 0; i < m->njoints; ++i) {
+    const int iq = m->idx_q[i], iv = m->idx_v[i];
+    if (m->jtype[i] == IDOCP_JOINT_FREEFLYER) {
+      double R[9], p[3];
+      idocp_dev::lieRelative(q_minus + iq, q_plus + iq, R, p);
+      idocp_dev::lieLog6(R, p, diff + iv);
+    } else {
+      diff[iv] = q_plus[iq] - q_minus[iq];
+    }
+  }
+  return IDOCP_OK;
+}
+int idocp_model_normalize_configuration(const idocp_model_t* m, double* q) {
+  if (!m || !q) { set_last_error("idocp_model_normalize_configuration: null argument"); return IDOCP_E_ARG; }
+  for (int i = 0; i < m->njoints; ++i) {
+    if (m->jtype[i] != IDOCP_JOINT_FREEFLYER) continue;
+    double* qu = q + m->idx_q[i] + 3;
+    const double n = std::sqrt(qu[0] * qu[0] + qu[1] * qu[1] + qu[2] * qu[2] + qu[3] * qu[3]);
+    if (!(n > 0)) { set_last_error("idocp_model_normalize_configuration: zero quaternion"); return IDOCP_E_ARG; }
+    for (int c = 0; c < 4; ++c) qu[c] /= n;
+  }
+  return IDOCP_OK;
+}
+
 // Deep copy (the reference's solver classes are copyable, `= default`: ocp_solver.hpp:171-186): a new handle of the same
 // configuration whose device records, contact sequence and discretisation state equal the source's.
 // The reference's solvers hold a shared_ptr to the CostFunction (ocp_solver.hpp:37-39): weights and references a driver changes

@@ -22,6 +22,13 @@ class ContactStatus {
   int dimf() const { return dimf_; }
   int maxPointContacts() const { return max_point_contacts_; }
 
+  // ContactStatus::setActivity (contact_status.hxx:81-92): all flags at once
+  void setActivity(const std::vector<bool>& is_contact_active) {
+    assert((int)is_contact_active.size() == max_point_contacts_);
+    is_contact_active_ = is_contact_active;
+    dimf_ = 0;
+    for (const bool on : is_contact_active_) if (on) dimf_ += 3;
+  }
   void activateContact(const int contact_index) {
     if (!is_contact_active_.at(contact_index)) { is_contact_active_[contact_index] = true; dimf_ += 3; }
   }

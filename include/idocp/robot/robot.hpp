@@ -77,6 +77,31 @@ class Robot {
     contact_status.setContactPoints(pts);
   }
 
+  // Robot::integrateConfiguration / subtractConfiguration / normalizeConfiguration (robot.hxx:96-147; robot.hpp:105-160): what a driver does
+  // between two solver calls (advance the plant, measure a distance on the configuration manifold).  Host arithmetic behind the C ABI
+  // (idocp_model_integrate_configuration ...).
+  void integrateConfiguration(const Eigen::VectorXd& v, const double integration_length, Eigen::VectorXd& q) const {      // in place (robot.hpp:82-86)
+    Eigen::VectorXd out(model_.nq);
+    integrateConfiguration(q, v, integration_length, out);
+    q = out;
+  }
+  void integrateConfiguration(const Eigen::VectorXd& q, const Eigen::VectorXd& v, const double integration_length, Eigen::VectorXd& q_integrated) const {
+    sized(q, model_.nq, "q"); sized(v, model_.nv, "v");
+    if (q_integrated.size() != model_.nq) q_integrated.resize(model_.nq);
+    ok(idocp_model_integrate_configuration(&model_, q.data(), v.data(), integration_length, q_integrated.data()));
+  }
+  void subtractConfiguration(const Eigen::VectorXd& q_plus, const Eigen::VectorXd& q_minus, Eigen::VectorXd& difference) const {
+    sized(q_plus, model_.nq, "q_plus"); sized(q_minus, model_.nq, "q_minus");
+    if (difference.size() != model_.nv) difference.resize(model_.nv);
+    ok(idocp_model_subtract_configuration(&model_, q_plus.data(), q_minus.data(), difference.data()));
+  }
+  void normalizeConfiguration(Eigen::VectorXd& q) const {
+    sized(q, model_.nq, "q");
+    ok(idocp_model_normalize_configuration(&model_, q.data()));
+  }
+  // Robot::createImpulseStatus (robot.hxx:672-675): in this library an impulse status is a ContactStatus (the feet that touch down)
+  ContactStatus createImpulseStatus() const { return ContactStatus(model_.ncontacts); }
+
   const idocp_model_t& model() const { return model_; }
   // the URDF this robot was built from (frame lookups of the task-space costs)
   const std::string& pathToUrdf() const { return path_; }
@@ -85,6 +110,10 @@ class Robot {
   idocp_model_t model_;
   std::string path_;
   std::vector<double> points_;     // contact-frame positions of the last updateFrameKinematics(q)
+  static void ok(int rc) { if (rc != IDOCP_OK) { std::cerr << idocp_last_error() << '\n'; std::exit(EXIT_FAILURE); } }
+  static void sized(const Eigen::VectorXd& x, int n, const char* name) {
+    if (x.size() != n) { std::cerr << "invalid size: " << name << ".size() must be " << n << "!" << '\n'; std::exit(EXIT_FAILURE); }
+  }
   Eigen::VectorXd get(const double* p) const {
     Eigen::VectorXd v(model_.nu);
     for (int i = 0; i < model_.nu; ++i) v[i] = p[i];

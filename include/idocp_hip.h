@@ -199,6 +199,15 @@ int idocp_model_frame_id(const char* path_to_urdf, const char* frame_name);
  * set-up before the contact sequence is built, examples/anymal/ocp_benchmark.cpp:
  * 104-106), not part of the hot path. */
 int idocp_model_contact_positions(const idocp_model_t* model, const double* q, double* points);
+/* Robot::integrateConfiguration / subtractConfiguration / normalizeConfiguration (include/idocp/robot/robot.hxx:96-147), host
+ * arithmetic: q_out[nq] = q (+) length v (SE(3) exponential on a floating base); diff[nv] = q_plus (-) q_minus
+ * (pinocchio::difference(q_minus, q_plus)); the base quaternion of q scaled to unit length.  What an MPC loop does between
+ * two solver calls; the stage kernels carry their own copies of the same functions. */
+int idocp_model_integrate_configuration(const idocp_model_t* model, const double* q, const double* v, double length,
+                                        double* q_out);
+int idocp_model_subtract_configuration(const idocp_model_t* model, const double* q_plus, const double* q_minus,
+                                       double* diff);
+int idocp_model_normalize_configuration(const idocp_model_t* model, double* q);
 
 /* Guards against a driver compiled against an older header than the loaded library:
  * pass sizeof(idocp_model_t), sizeof(idocp_cost_t), sizeof(idocp_constraints_t);

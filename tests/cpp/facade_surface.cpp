@@ -164,6 +164,17 @@ int main(int argc, char** argv) {
       std::cout << "shared cost function: ok" << std::endl;
     }
     std::cout << "fixed-base solvers: ok" << std::endl;
+    {  // Robot::integrateConfiguration (both overloads) / subtractConfiguration / normalizeConfiguration on the fixed-base arm (robot.hpp:82-147)
+      ex::Vec qa = ex::filled(n, 0.25), va = ex::filled(n, -2.0), qb, d;
+      robot.integrateConfiguration(qa, va, 0.1, qb);
+      REQUIRE(qb.size() == n && std::fabs(qb[3] - 0.05) < 1e-15);
+      robot.subtractConfiguration(qb, qa, d);
+      REQUIRE(d.size() == n && std::fabs(d[2] + 0.2) < 1e-15);
+      robot.integrateConfiguration(va, 0.1, qa);
+      REQUIRE(maxDiff(qa, qb) == 0.0);
+      robot.normalizeConfiguration(qa);
+      REQUIRE(maxDiff(qa, qb) == 0.0);
+    }
   }
   {  // ---- floating base
     idocp::Robot robot(argv[2], ex::anymalFeet());
@@ -184,6 +195,20 @@ int main(int argc, char** argv) {
     solver.initConstraints(0.0);
     const ex::Vec v = ex::Vec::Zero(robot.dimv());
     solver.updateSolution(0.0, stand, v);
+    {  // ... and on the floating base: one sampling period of a twist forwards, the way back through subtractConfiguration, a unit quaternion throughout
+      ex::Vec tw = ex::runs({{3, 0.3}, {3, -0.8}, {12, 0.5}}), q1, back;
+      robot.integrateConfiguration(stand, tw, 0.2, q1);
+      robot.subtractConfiguration(q1, stand, back);
+      double worst = 0.0, nq2 = 0.0;
+      for (int k = 0; k < 18; ++k) worst = std::fmax(worst, std::fabs(back[k] - 0.2 * tw[k]));
+      for (int k = 3; k < 7; ++k) nq2 += q1[k] * q1[k];
+      REQUIRE(worst < 1e-13 && std::fabs(nq2 - 1.0) < 1e-14);
+      ex::Vec q2 = q1;
+      for (int k = 3; k < 7; ++k) q2[k] *= 3.0;
+      robot.normalizeConfiguration(q2);
+      REQUIRE(maxDiff(q2, q1) < 1e-15);
+      REQUIRE(robot.createImpulseStatus().maxPointContacts() == robot.maxPointContacts());
+    }
     const idocp::OCPSolver& cs = solver;
     const idocp::SplitSolution& s0 = cs.getSolution(0);
     REQUIRE(maxDiff(s0.u, cs.getSolution("u")[0]) == 0.0 && maxDiff(s0.q, cs.getSolution("q")[0]) == 0.0);
