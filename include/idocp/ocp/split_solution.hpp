@@ -24,6 +24,7 @@ class SplitSolution {
   int dimf() const { return static_cast<int>(f_stack_.size()); }
   bool isContactActive(const int contact_index) const { return is_contact_active_.at(contact_index); }
   const std::vector<bool>& isContactActive() const { return is_contact_active_; }
+  bool hasActiveContacts() const { return f_stack_.size() > 0; }      // split_solution.hxx:52-54
 
   // fill from one record of the C ABI (idocp_ocp_get_split_solution / idocp_unocp_get_split_solution):
   // lmd gmm q v a u beta [f mu nu_passive]
