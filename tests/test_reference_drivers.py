@@ -54,6 +54,26 @@ def test_the_reference_example_drivers_compile_and_link_unmodified():
     assert subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "examples/_ref"], capture_output=True, text=True).stdout == ""
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "examples", "iiwa14")) or shutil.which("cmake") is None, reason="needs the reference tree and cmake")
+def test_the_reference_cmake_projects_configure_and_build_against_the_package_config(tmp_path):
+    """README "Usage" of the reference: find_package(idocp REQUIRED) + idocp::idocp + ${IDOCP_INCLUDE_DIR}.  cmake/idocpConfig.cmake provides that package
+    for this tree; the reference's examples/iiwa14 and examples/anymal PROJECTS -- their own CMakeLists.txt, C++11 requested -- configure and build with
+    it, nothing edited (out-of-source: nothing is written under the reference tree)."""
+    for robot, n in (("iiwa14", 6), ("anymal", 6)):
+        build = tmp_path / robot
+        r = subprocess.run(["cmake", "-S", os.path.join(REF, "examples", robot), "-B", str(build), "-Didocp_DIR=" + os.path.join(ROOT, "cmake"),
+                            "-DCMAKE_BUILD_TYPE=Release", "-DCMAKE_POLICY_VERSION_MINIMUM=3.5"],      # (the projects ask for CMake 3.1, which current CMake only accepts with this)
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        r = subprocess.run(["cmake", "--build", str(build), "-j", "4"], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        exes = [f for f in os.listdir(build) if os.path.isfile(build / f) and os.access(build / f, os.X_OK) and open(build / f, "rb").read(4) == b"\x7fELF"]
+        assert len(exes) == n, exes
+        # linked against THIS library
+        ldd = subprocess.run(["ldd", str(build / exes[0])], capture_output=True, text=True).stdout
+        assert os.path.join(ROOT, "idocp_amd", "lib", "libidocp_hip.so") in ldd, ldd
+
+
 @pytest.mark.gpu
 def test_the_reference_example_drivers_run_on_the_gpu_and_print_what_our_drivers_print(tmp_path):
     if not os.path.isdir(REF_BIN) or sorted(os.listdir(REF_BIN)) != sorted(TWINS):
