@@ -77,20 +77,28 @@ class XmlReader {
     while (i_ < s_.size() && (std::isalnum((unsigned char)s_[i_]) || s_[i_] == '_' || s_[i_] == ':' || s_[i_] == '-' || s_[i_] == '.')) ++i_;
     return s_.substr(b, i_ - b);
   }
-  std::unique_ptr<XmlNode> parseElement() {
-    if (i_ >= s_.size() || s_[i_] != '<') { ok_ = false; return nullptr; }
+  // (Every exit on damaged input sets ok_ and returns null: a truncated closing tag used to send the position back to 0 -- `npos + 1` -- and the
+  //  reader into unbounded recursion; tests/test_urdf_reader_robustness.py feeds it truncated and corrupted files.)
+  std::unique_ptr<XmlNode> parseElement(int depth = 0) {
+    if (depth > 64 || i_ >= s_.size() || s_[i_] != '<') { ok_ = false; return nullptr; }      // (a URDF nests five deep)
     ++i_;
     auto node = std::make_unique<XmlNode>();
     node->name = parseName();
     for (;;) {
       skipWs();
       if (i_ >= s_.size()) { ok_ = false; return nullptr; }
-      if (s_[i_] == '/') { i_ += 2; return node; }          // "/>"
+      if (s_[i_] == '/') {                                   // "/>"
+        if (i_ + 1 >= s_.size() || s_[i_ + 1] != '>') { ok_ = false; return nullptr; }
+        i_ += 2;
+        return node;
+      }
       if (s_[i_] == '>') { ++i_; break; }
       std::string key = parseName();
+      if (key.empty()) { ok_ = false; return nullptr; }      // (neither an attribute nor the end of the tag: the loop would not advance)
       skipWs();
       if (i_ >= s_.size() || s_[i_] != '=') { ok_ = false; return nullptr; }
       ++i_; skipWs();
+      if (i_ >= s_.size() || (s_[i_] != '"' && s_[i_] != '\'')) { ok_ = false; return nullptr; }
       char quote = s_[i_++];
       size_t e = s_.find(quote, i_);
       if (e == std::string::npos) { ok_ = false; return nullptr; }
@@ -102,8 +110,13 @@ class XmlReader {
       if (lt == std::string::npos) { ok_ = false; return nullptr; }
       i_ = lt;
       if (starts("<!--") || starts("<?") || starts("<!")) { skipMisc(); continue; }
-      if (starts("</")) { size_t e = s_.find('>', i_); i_ = e + 1; return node; }
-      auto c = parseElement();
+      if (starts("</")) {
+        size_t e = s_.find('>', i_);
+        if (e == std::string::npos) { ok_ = false; return nullptr; }
+        i_ = e + 1;
+        return node;
+      }
+      auto c = parseElement(depth + 1);
       if (!c) return nullptr;
       node->children.push_back(std::move(c));
     }
@@ -324,6 +337,15 @@ static bool buildFrames(const std::string& path, idocp_model_t& m, std::vector<F
     m.u_max[k] = b.lim_e[np + k];  m.v_max[k] = b.lim_v[np + k];
   }
   m.gravity[0] = 0; m.gravity[1] = 0; m.gravity[2] = -9.81;
+  // every number the kernels will compute with is one (a "nan" or an overflowing literal in the file parses to a non-finite double and would
+  // surface as NaN directions a thousand lines from here); joint limits may be infinite -- an unlimited joint -- but not NaN
+  auto finite = [](const double* p, int n) { for (int k = 0; k < n; ++k) if (!std::isfinite(p[k])) return false; return true; };
+  bool good = std::isfinite(m.total_mass);
+  for (int i = 0; i < m.njoints && good; ++i)
+    good = std::isfinite(m.mass[i]) && finite(m.com[i], 3) && finite(m.inertia[i], 9) && finite(m.axis[i], 3) && finite(m.plc_R[i], 9) && finite(m.plc_p[i], 3);
+  for (int k = 0; k < m.nu && good; ++k) good = !(std::isnan(m.q_min[k]) || std::isnan(m.q_max[k]) || std::isnan(m.u_max[k]) || std::isnan(m.v_max[k]));
+  for (const FrameEntry& f : b.frames) if (good) good = finite(f.placement.R, 9) && finite(f.placement.p, 3);
+  if (!good) { err = "malformed URDF: a value that is not a finite number: " + path; return false; }
   frames = b.frames;
   return true;
 }
