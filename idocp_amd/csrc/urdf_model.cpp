@@ -291,6 +291,7 @@ struct Builder {
         m.nq += ff ? 7 : 1; m.nv += ff ? 6 : 1;
         if (m.nv > IDOCP_MAX_NV || m.nq > IDOCP_MAX_NQ) { err = "too many degrees of freedom"; return; }
         double n = std::sqrt(j.axis[0]*j.axis[0] + j.axis[1]*j.axis[1] + j.axis[2]*j.axis[2]);
+        if (!ff && !(n > 0)) { err = "joint '" + j.name + "' has no axis direction (axis xyz = 0 0 0)"; return; }
         for (int k = 0; k < 3; ++k) m.axis[id][k] = ff ? 0.0 : j.axis[k] / (n > 0 ? n : 1.0);
         std::memcpy(m.plc_R[id], Mj.R, sizeof(Mj.R));
         std::memcpy(m.plc_p[id], Mj.p, sizeof(Mj.p));

@@ -61,3 +61,57 @@ def test_damaged_urdf_files_are_refused_or_read_never_crashed_on(tmp_path):
     assert rc != 0
     rc, _ = try_model(IIWA_URDF, [9999])
     assert rc != 0 and len(lib.idocp_last_error()) > 0
+
+
+def chain_urdf(n, extra=""):
+    """A serial chain of n revolute joints about z, link masses 1 kg."""
+    out = ['<robot name="chain">']
+    for i in range(n + 1):
+        out.append('<link name="l%d"><inertial><origin xyz="0 0 0.1" rpy="0 0 0"/><mass value="1.0"/>'
+                   '<inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial></link>' % i)
+    for i in range(n):
+        out.append('<joint name="j%d" type="revolute"><parent link="l%d"/><child link="l%d"/><origin xyz="0 0 0.2" rpy="0 0 0"/>'
+                   '<axis xyz="0 0 1"/><limit lower="-2" upper="2" effort="100" velocity="3"/></joint>' % (i, i, i + 1))
+    out.append(extra)
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+def test_structurally_hostile_urdf_files(tmp_path):
+    """More joints than the model struct holds, a kinematic loop, two roots, a joint whose links do not exist, a self-parenting joint, a
+    mile-deep nesting: an error code each (or a model where the file is legal), no overflow of the fixed-size arrays, no hang."""
+    lib = capi.lib()
+    lib.idocp_model_from_urdf.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(capi.Model)]
+
+    def load(text, name):
+        p = tmp_path / name
+        p.write_text(text)
+        return try_model(str(p), [])
+
+    for n in (1, 7, capi.MAX_JOINTS):
+        rc, m = load(chain_urdf(n), "chain%d.urdf" % n)
+        assert rc == 0 and m.njoints == n and m.nv == n and abs(m.total_mass - n) < 1e-12, (n, rc, lib.idocp_last_error())      # (the fixed root link carries no joint)
+    for n in (capi.MAX_JOINTS + 1, 40, 400):
+        rc, _ = load(chain_urdf(n), "long%d.urdf" % n)
+        assert rc != 0 and len(lib.idocp_last_error()) > 0, n
+    loop = '<joint name="back" type="revolute"><parent link="l3"/><child link="l1"/><axis xyz="0 0 1"/></joint>'
+    rc, _ = load(chain_urdf(3, loop), "loop.urdf")
+    assert rc != 0
+    self_parent = '<joint name="self" type="revolute"><parent link="l2"/><child link="l2"/><axis xyz="0 0 1"/></joint>'
+    rc, _ = load(chain_urdf(3, self_parent), "self.urdf")
+    assert rc != 0
+    ghost = '<joint name="ghost" type="revolute"><parent link="nowhere"/><child link="neither"/><axis xyz="0 0 1"/></joint>'
+    rc, _ = load(chain_urdf(3, ghost), "ghost.urdf")
+    assert rc != 0 or True                                   # (links that are never declared: refused or ignored, never followed)
+    two_roots = '<link name="island"/>'
+    rc, _ = load(chain_urdf(3, two_roots), "two_roots.urdf")
+    assert rc != 0 or True
+    deep = "<robot>" + "<a>" * 5000 + "</a>" * 5000 + "</robot>"
+    rc, _ = load(deep, "deep.urdf")
+    assert rc != 0
+    zero_axis = chain_urdf(2).replace('<axis xyz="0 0 1"/>', '<axis xyz="0 0 0"/>', 1)
+    rc, _ = load(zero_axis, "zero_axis.urdf")
+    assert rc != 0, "a joint without an axis direction cannot be normalised"
+    prismatic = chain_urdf(2).replace('type="revolute"', 'type="prismatic"', 1)
+    rc, _ = load(prismatic, "prismatic.urdf")
+    assert rc != 0 and len(lib.idocp_last_error()) > 0      # (the kernels carry revolute joints and a free-flyer)
