@@ -28,6 +28,7 @@ using idocp_host::set_last_error;
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) {                                                                   \
       set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      (void)hipGetLastError(); /* HIP keeps a failed call as the thread's "last error": reported here, it must not fail the next handle's launches */ \
       return IDOCP_E_DEVICE;                                                                  \
     }                                                                                         \
   } while (0)
@@ -755,7 +756,7 @@ static int createOcpImpl(const idocp_model_t* model, const idocp_cost_t* cost, c
   idocp_ocp* h = new idocp_ocp();
   h->model = *model; h->cost = *cost; h->cons = *constraints; h->N = N; h->E = max_num_impulse; h->batch = batch; h->device = device; h->T = T;
   h->NS = N + 1 + 3 * max_num_impulse;
-  auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
+  auto fail = [&](int code) { (void)hipGetLastError(); idocp_ocp_destroy(h); return code; };      // (clears HIP's sticky last error: see HIP_TRY)
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { set_last_error("hipStreamCreate failed"); return fail(IDOCP_E_DEVICE); }
   {
     // (a batch of instances only: at batch 1 the two event hand-offs cost more than the 9 wavefronts of K5s -- 1.09 against 1.06 ms per iteration)
@@ -2129,7 +2130,7 @@ int idocp_ocp_clone(idocp_ocp_t* src, idocp_ocp_t** out) {
   int rc = setDev(src); if (rc) return rc;
   idocp_ocp_t* h = nullptr;
   if ((rc = createOcpImpl(&src->model, &src->cost, &src->cons, src->T, src->N, src->E, src->batch, src->device, src->parnmpc, &h))) return rc;
-  auto fail = [&](int code) { idocp_ocp_destroy(h); return code; };
+  auto fail = [&](int code) { (void)hipGetLastError(); idocp_ocp_destroy(h); return code; };      // (clears HIP's sticky last error: see HIP_TRY)
   if (h->allocs.size() != src->allocs.size()) { set_last_error("idocp_ocp_clone: allocation tables differ"); return fail(IDOCP_E_DEVICE); }
   if (hipStreamSynchronize(src->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
   for (size_t i = 0; i < h->allocs.size(); ++i) {

@@ -108,7 +108,7 @@ std::map<idocp_ocp_t*, DistState> g_dist;
 std::mutex g_dist_mutex;
 
 int fail(int code, const std::string& msg) { idocp_set_last_error_string(msg.c_str()); return code; }
-#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(IDOCP_E_DEVICE, std::string(#x " failed: ") + hipGetErrorString(e_)); } while (0)
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(IDOCP_E_DEVICE, std::string(#x " failed: ") + hipGetErrorString(e_)); } } while (0)      // (the sticky last error is cleared: ocp_capi.hip HIP_TRY)
 #define NCCLC(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(IDOCP_E_DEVICE, std::string(#x " failed: ") + g_rccl.GetErrorString(r_)); } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 

@@ -29,6 +29,7 @@ using idocp_host::set_last_error;
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) {                                                                   \
       set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+      (void)hipGetLastError(); /* HIP keeps a failed call as the thread's "last error": reported here, it must not fail the next handle's launches */ \
       return IDOCP_E_DEVICE;                                                                  \
     }                                                                                         \
   } while (0)
@@ -245,7 +246,7 @@ static int createImpl(const idocp_model_t* model, const idocp_cost_t* cost, cons
   h->level_offset = bwd ? 1 + stage_offset : 0; h->shard = (stage_offset != 0 || !has_terminal || has_prev) ? 1 : 0;
   h->shard_dt = dt; h->shard_offset = stage_offset; h->shard_terminal = has_terminal; h->shard_prev = has_prev;
   int rc = IDOCP_OK;
-  auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
+  auto fail = [&](int code) { (void)hipGetLastError(); idocp_unocp_destroy(h); return code; };      // (clears HIP's sticky last error: see HIP_TRY)
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
     set_last_error("hipSetDevice/hipStreamCreate failed");
     return fail(IDOCP_E_DEVICE);
@@ -380,7 +381,7 @@ int idocp_unocp_clone(idocp_unocp_t* src, idocp_unocp_t** out) {
   int rc = createImpl(&src->model, &src->cost, &src->cons, src->T, src->N, src->batch, src->device, src->bwd, &h, src->shard_dt, src->shard_offset,
                       src->shard_terminal, src->shard_prev);
   if (rc) return rc;
-  auto fail = [&](int code) { idocp_unocp_destroy(h); return code; };
+  auto fail = [&](int code) { (void)hipGetLastError(); idocp_unocp_destroy(h); return code; };      // (clears HIP's sticky last error: see HIP_TRY)
   if (h->allocs.size() != src->allocs.size() || h->alloc_bytes != src->alloc_bytes) { set_last_error("idocp_unocp_clone: allocation tables differ"); return fail(IDOCP_E_DEVICE); }
   if (hipStreamSynchronize(src->stream) != hipSuccess) return fail(IDOCP_E_DEVICE);
   for (size_t i = 0; i < h->allocs.size(); ++i)
