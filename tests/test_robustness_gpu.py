@@ -122,3 +122,42 @@ def test_sizes_no_device_holds_are_refused_with_a_message():
     # ... and the device is still there for the next one
     g = HipUnOCP(m, cost, cons, 1.0, 20)
     assert g.update(0.0, np.full(m.nv, 0.3), np.zeros(m.nv)) == 0
+
+
+def test_create_destroy_cycles_do_not_leak_device_memory():
+    """A service that builds a solver per request: two hundred create / use / destroy cycles of each handle type (and of clones) leave the device's
+    free memory where it was."""
+    import torch
+    lib = capi.lib()
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    ma = anymal_model()
+    cost_a, cons_a = anymal_problem(ma, trotting_ref=False)
+    pts = anymal_contact_points(ma)
+
+    def cycle():
+        g = HipUnOCP(m, cost, cons, 1.0, 20, batch=8)
+        assert g.update(0.0, np.full(m.nv, 0.3), np.zeros(m.nv)) == 0
+        c = C.c_void_p()
+        capi.check(lib.idocp_unocp_clone(g.h, C.byref(c)), "clone")
+        lib.idocp_unocp_destroy(c)
+        p = HipUnParNMPC(m, cost, cons, 1.0, 20, batch=4)
+        p.init(0.0)
+        h = HipOCP(ma, cost_a, cons_a, 0.2, 8, batch=4, max_num_impulse=2)
+        h.set_contact_status([1, 1, 1, 1], pts)
+        h.init_constraints(0.0)
+        assert h.update(0.0, ANYMAL_Q_STANDING, np.zeros(ma.nv)) == 0
+        n = HipParNMPC(ma, cost_a, cons_a, 0.2, 8, batch=2)
+        n.set_contact_status([1, 1, 1, 1], pts)
+        n.init(0.0)
+        del g, p, h, n
+
+    for _ in range(5):
+        cycle()                                   # (allocator pools, code objects, the side streams' first use)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(200):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MB over 200 cycles" % ((free0 - free1) / 2 ** 20)
