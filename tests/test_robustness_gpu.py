@@ -161,3 +161,45 @@ def test_create_destroy_cycles_do_not_leak_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MB over 200 cycles" % ((free0 - free1) / 2 ** 20)
+
+
+def test_handles_driven_from_concurrent_host_threads_give_the_single_threaded_results():
+    """A service with a worker thread per request: four host threads, each with handles of its own (ctypes releases the interpreter lock inside
+    every C-ABI call, so the calls really overlap), iterate different problems side by side.  Each must end exactly where it ends when it runs alone:
+    the library keeps no state between handles (idocp_last_error is thread-local, every handle has its stream)."""
+    import threading
+    m = iiwa14_model()
+    cost, cons = unocp_problem(m)
+    ma = anymal_model()
+    cost_a, cons_a = anymal_problem(ma, trotting_ref=False)
+    pts = anymal_contact_points(ma)
+    fz = [0, 0, 0.25 * (-ma.total_mass * ma.gravity[2])]
+
+    def work(k, out):
+        q = np.full(m.nv, 0.2 + 0.1 * k)
+        g = HipUnOCP(m, cost, cons, 1.0, 20 + k, batch=1 + k)
+        g.set_solution("q", q)
+        qa = ANYMAL_Q_STANDING.copy()
+        qa[7:] += 0.01 * (k + 1) * np.cos(np.arange(12))
+        h = HipOCP(ma, cost_a, cons_a, 0.3, 10 + k, batch=1 + k)
+        h.set_contact_status([1, 1, 1, 1], pts)
+        h.set_solution("q", ANYMAL_Q_STANDING)
+        h.set_solution("f", fz)
+        h.init_constraints(0.0)
+        for _ in range(15):
+            assert g.update(0.0, q, np.zeros(m.nv)) == 0
+            assert h.update(0.0, qa, np.zeros(ma.nv)) == 0
+        out[k] = (g.solution("q", k).copy(), g.solution("lmd", k).copy(), h.get("q", k).copy(), h.get("u", k).copy(), g.kkt_error(0.0, q, np.zeros(m.nv))[k])
+
+    alone, together = {}, {}
+    for k in range(4):
+        work(k, alone)
+    threads = [threading.Thread(target=work, args=(k, together)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(together) == [0, 1, 2, 3]
+    for k in range(4):
+        for a, b in zip(alone[k], together[k]):
+            assert np.array_equal(a, b), k
