@@ -554,7 +554,7 @@ int oracle_ocp_set_task_refs(void* h, int M, const double* times, const double* 
 int oracle_parnmpc_set_task_refs(void* h, int M, const double* times, const double* refs) { fillTaskRefTable(static_cast<ParNMPCSolver*>(h)->cost, M, times, refs); return 0; }
 int oracle_ocp_chain(void* h, double t, int* kind, int* index, int* slot, double* tt, double* dt, int* sw_event, int* dimf) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
-  s->discretize(t);
+  try { s->discretize(t); } catch (const std::exception& e) { g_oracle_error = e.what(); return -1; }      // (a sequence the discretiser refuses)
   for (int p = 0; p < s->M(); ++p) {
     const NodeC& nd = s->chain[p];
     if (kind) kind[p] = nd.kind;
