@@ -67,3 +67,68 @@ def test_first_direction_on_random_problems(seed):
     for name in OCP_DIR_FIELDS:
         worst = max(worst, parity(g.get(name, 1), o.get(name), lambda name=name: referee(name), (seed, active, N, name), tol=TOL, cap=1e-7))
     print("seed %d  contacts %s  N %d  %s  worst %.2e%s" % (seed, active, N, "ParNMPC" if par else "OCP", worst, "  (referee consulted)" if ran_referee else ""))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_first_direction_along_random_event_chains(seed):
+    """Random gaits: up to three events at random times, a random set of feet lifting off or touching down at each -- one, two, three or four feet at
+    once, so the switching constraint has 3, 6, 9 or 12 rows (the trot of the other tests: always 6) and the impulse stages every row count.  First
+    Newton direction along the whole chain (grid, impulse, aux and lift stages), every field, under helpers.parity."""
+    from helpers import OCP_SOL_FIELDS
+    rng = np.random.default_rng(500 + seed)
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    N = int(rng.integers(12, 30))
+    dt = float(rng.uniform(0.02, 0.04))
+    T = N * dt
+    E = 3
+    solvers = [HipOCP(m, cost, cons, T, N, batch=2, max_num_impulse=E), OracleOCP(m, cost, cons, T, N, max_num_impulse=E),
+               OracleOCP(m, cost, cons, T, N, max_num_impulse=E, hp=True)]
+    active = np.array([1, 1, 1, 1]) if seed % 2 == 0 else rng.integers(0, 2, size=4)
+    landing = seed == 0                                      # one case by hand: all four feet touch down at once out of a flight phase (12 rows)
+    if landing:
+        active = np.array([0, 0, 0, 0])
+    for s in solvers:
+        s.set_contact_status(active, pts)
+    n_ev = int(rng.integers(1, E + 1))
+    # events at least two grid intervals apart and off the grid points (the near-grid cases have tests of their own; here the rows are the subject)
+    times = np.sort(rng.choice(np.arange(2, N - 2), size=n_ev, replace=False)) * dt + rng.uniform(0.2, 0.8, n_ev) * dt
+    times = times[np.concatenate([[True], np.diff(times) > 2 * dt])]
+    rows = []
+    for t_ev in times:
+        flip = np.zeros(4, dtype=int)
+        flip[rng.choice(4, size=int(rng.integers(1, 5)), replace=False)] = 1
+        if landing:
+            flip[:] = 1
+        nxt = np.where(flip == 1, 1 - active, active)
+        rows.append(3 * int(((nxt == 1) & (active == 0)).sum()))
+        for s in solvers:
+            s.push_back_contact_status(nxt, pts, float(t_ev))
+        active = nxt
+    q = ANYMAL_Q_STANDING.copy()
+    q[7:] += rng.uniform(-0.05, 0.05, 12)
+    v = rng.uniform(-0.1, 0.1, m.nv)
+    for s in solvers:
+        s.set_solution("q", ANYMAL_Q_STANDING)
+        s.set_solution("v", np.zeros(m.nv))
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    g, o, h = solvers
+    assert g.update(0.0, q, v) == 0 and o.update(0.0, q, v) == 0
+    M = len(o.chain(0.0))
+    assert len(g.chain(0.0)) == M
+    ran = []
+
+    def referee(name):
+        if not ran:
+            assert h.update(0.0, q, v) == 0
+            ran.append(1)
+        return h.get_chain(name, M)
+
+    worst = 0.0
+    for name in list(OCP_DIR_FIELDS) + ["dxi"]:
+        worst = max(worst, parity(g.get_chain(name, M), o.get_chain(name, M), lambda name=name: referee(name), (seed, rows, name), tol=TOL, cap=1e-6))
+    kinds = [c["kind"] for c in o.chain(0.0)]
+    print("seed %d  N %d  touch-down rows per event %s  chain %d (%d impulse, %d lift)  worst %.2e%s" %
+          (seed, N, rows, M, kinds.count("impulse"), kinds.count("lift"), worst, "  (referee consulted)" if ran else ""))
