@@ -132,3 +132,67 @@ def test_first_direction_along_random_event_chains(seed):
     kinds = [c["kind"] for c in o.chain(0.0)]
     print("seed %d  N %d  touch-down rows per event %s  chain %d (%d impulse, %d lift)  worst %.2e%s" %
           (seed, N, rows, M, kinds.count("impulse"), kinds.count("lift"), worst, "  (referee consulted)" if ran else ""))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_first_direction_along_random_event_chains_parnmpc(seed):
+    """The same gaits through ParNMPCSolver (backward-Euler stages, the KKT inverses of the aux / impulse pair with 3, 6, 9 or 12 extra rows: the general
+    instantiation of the event kernels).  The coarse update from a cold start is ill-conditioned around an event (tests/test_parnmpc_hybrid_gpu.py), so the
+    long double referee decides stage by stage; the cap is on the distance from the FP64 oracle."""
+    from helpers import HipParNMPC, OracleParNMPC
+    rng = np.random.default_rng(900 + seed)
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    N = int(rng.integers(12, 26))
+    dt = float(rng.uniform(0.02, 0.04))
+    T = N * dt
+    E = 2
+    solvers = [HipParNMPC(m, cost, cons, T, N, batch=2, max_num_impulse=E), OracleParNMPC(m, cost, cons, T, N, max_num_impulse=E),
+               OracleParNMPC(m, cost, cons, T, N, max_num_impulse=E, hp=True)]
+    active = np.array([0, 0, 0, 0]) if seed == 0 else (np.array([1, 1, 1, 1]) if seed % 2 == 0 else rng.integers(0, 2, size=4))
+    for s in solvers:
+        s.set_contact_status(active, pts)
+    n_ev = int(rng.integers(1, E + 1))
+    times = np.sort(rng.choice(np.arange(2, N - 3), size=n_ev, replace=False)) * dt + rng.uniform(0.2, 0.8, n_ev) * dt
+    times = times[np.concatenate([[True], np.diff(times) > 2 * dt])]
+    rows = []
+    for t_ev in times:
+        flip = np.zeros(4, dtype=int)
+        flip[rng.choice(4, size=int(rng.integers(1, 5)), replace=False)] = 1
+        if seed == 0:
+            flip[:] = 1
+        nxt = np.where(flip == 1, 1 - active, active)
+        rows.append(3 * int(((nxt == 1) & (active == 0)).sum()))
+        for s in solvers:
+            s.push_back_contact_status(nxt, pts, float(t_ev))
+        active = nxt
+    q = ANYMAL_Q_STANDING.copy()
+    q[7:] += rng.uniform(-0.03, 0.03, 12)
+    v = rng.uniform(-0.05, 0.05, m.nv)
+    for s in solvers:
+        s.set_solution("q", ANYMAL_Q_STANDING)
+        s.set_solution("v", np.zeros(m.nv))
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init(0.0)
+    g, o, h = solvers
+    assert g.update(0.0, q, v) == 0 and o.update(0.0, q, v) == 0
+    kinds = [c["kind"] for c in o.chain(0.0)]
+    M = len(kinds)
+    assert len(g.chain(0.0)) == M + 1
+    ran = []
+
+    def referee(name, keep):
+        if not ran:
+            assert h.update(0.0, q, v) == 0
+            ran.append(1)
+        return h.get_chain(name, M)[keep]
+
+    keep_reg = np.array([k != "impulse" for k in kinds])
+    worst = 0.0
+    for name in OCP_DIR_FIELDS:
+        keep = keep_reg if name in ("du", "dnu_passive") else np.ones(M, bool)
+        worst = max(worst, parity(g.get_chain(name, M + 1)[:M][keep], o.get_chain(name, M)[keep], lambda name=name, keep=keep: referee(name, keep),
+                                  (seed, rows, name), tol=TOL, cap=1e-5))
+    print("seed %d  N %d  touch-down rows per event %s  chain %d (%d impulse, %d lift)  worst %.2e%s" %
+          (seed, N, rows, M, kinds.count("impulse"), kinds.count("lift"), worst, "  (referee consulted)" if ran else ""))
