@@ -196,3 +196,53 @@ def test_first_direction_along_random_event_chains_parnmpc(seed):
                                   (seed, rows, name), tol=TOL, cap=1e-5))
     print("seed %d  N %d  touch-down rows per event %s  chain %d (%d impulse, %d lift)  worst %.2e%s" %
           (seed, N, rows, M, kinds.count("impulse"), kinds.count("lift"), worst, "  (referee consulted)" if ran else ""))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_filter_line_search_on_random_problems_follows_the_oracle(seed):
+    """updateSolution(..., line_search = true) on random problems (OCPSolver: uniform contacts or a random event; the filter logic runs on the host,
+    the trial iterates' cost and violation on the device): the accepted steps are the oracle's, iteration after iteration -- a different accept /
+    reject decision anywhere would show as a different step size at once."""
+    import ctypes as C
+    from helpers import P, arr, rel_err
+    from idocp_amd import capi
+    rng = np.random.default_rng(4242 + seed)
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False) if seed < 4 else random_problem(rng, m)      # (the last two: weights over four decades; an iterate
+    pts = anymal_contact_points(m)                                                                  #  may then lose convexity -- both must say so together)
+    N = int(rng.integers(8, 22))
+    T = N * float(rng.uniform(0.02, 0.04))
+    E = 1 if seed % 2 else 0
+    g = HipOCP(m, cost, cons, T, N, batch=2, max_num_impulse=E)
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+    o.lib.oracle_ocp_update_solution_ls.argtypes = [C.c_void_p, C.c_double, capi.c_double_p, capi.c_double_p]
+    active = np.array([1, 1, 1, 1])
+    for s in (g, o):
+        s.set_contact_status(active, pts)
+    if E:
+        nxt = np.array([0, 1, 1, 0]) if seed % 4 == 1 else np.array([1, 0, 1, 1])
+        t_ev = (int(rng.integers(2, N - 2)) + float(rng.uniform(0.2, 0.8))) * T / N
+        for s in (g, o):
+            s.push_back_contact_status(nxt, pts, t_ev)
+    q = ANYMAL_Q_STANDING.copy()
+    q[7:] += rng.uniform(-0.1, 0.1, 12)
+    v = rng.uniform(-0.2, 0.2, m.nv)
+    for s in (g, o):
+        s.set_solution("q", ANYMAL_Q_STANDING)
+        s.set_solution("v", np.zeros(m.nv))
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+        s.init_constraints(0.0)
+    steps = []
+    for it in range(5):
+        ro = o.lib.oracle_ocp_update_solution_ls(o.h, 0.0, P(arr(q)), P(arr(v)))
+        rg = g.lib.idocp_ocp_update_solution(g.h, 0.0, P(g._bc(q, g.nq)), P(g._bc(v, g.nv)), 1)
+        assert (ro == 0) == (rg == 0), (seed, it, "one of the two lost positive definiteness, the other did not", ro, rg, capi.lib().idocp_last_error())
+        if ro != 0:
+            steps.append(float("nan"))
+            break
+        (ao, bo), (ag, bg) = o.step_sizes(), g.step_sizes()
+        assert abs(ag[1] - ao) <= 1e-9 * max(ao, 1e-3) and abs(bg[1] - bo) <= 1e-7 * max(bo, 1e-3), (seed, it, ag[1], ao, bg[1], bo)
+        steps.append(ao)
+        for f in ("q", "v", "a", "u", "f"):
+            assert rel_err(g.get(f, 1), o.get(f)) < 1e-7, (seed, it, f)
+    print("seed %d  N %d  event %d  accepted primal steps %s" % (seed, N, E, " ".join("%.3g" % a for a in steps)))
