@@ -246,3 +246,70 @@ def test_filter_line_search_on_random_problems_follows_the_oracle(seed):
         for f in ("q", "v", "a", "u", "f"):
             assert rel_err(g.get(f, 1), o.get(f)) < 1e-7, (seed, it, f)
     print("seed %d  N %d  event %d  accepted primal steps %s" % (seed, N, E, " ".join("%.3g" % a for a in steps)))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_first_direction_on_random_fixed_base_problems(seed):
+    """The fixed-base solvers on random problems: horizon, weights over four decades, tighter or looser joint limits, acceleration limits on or off, a
+    task-space cost (3D / 6D, a random frame of the chain, a random reference pose, per-stage references or a constant one) on every other UnOCP
+    problem; UnOCPSolver and UnParNMPCSolver alternate.  1e-10 on the first direction, the Riccati factors and the KKT error."""
+    import ctypes as C
+    from helpers import (DIR_FIELDS, HipUnOCP, HipUnParNMPC, OracleUnOCP, OracleUnParNMPC, iiwa14_model, rel_err)
+    from idocp_amd import capi
+    from idocp_amd.workloads import task_space_problem
+    rng = np.random.default_rng(31337 + seed)
+    m = iiwa14_model()
+    nv = m.nv
+    par = seed % 2 == 1
+    task = (not par) and seed % 4 == 0
+    lw = lambda lo, hi: 10.0 ** rng.uniform(lo, hi, size=nv)
+    if task:
+        dim = 3 if seed % 8 == 0 else 6
+        cost, cons = task_space_problem(m, dim=dim, frame_id=int(rng.choice([10, 14, 18, 22])), weight=float(10.0 ** rng.uniform(1, 3)), time_varying=bool(seed % 8 == 4))
+        ang = rng.uniform(-1, 1, 3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        Rm = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        ref = np.concatenate([Rm.ravel(), rng.uniform(-0.5, 0.8, 3)])
+        for k in range(12):
+            cost.task_ref[k] = float(ref[k])
+    else:
+        cost = capi.Cost()
+        cons = capi.Constraints()
+        capi.lib().idocp_constraints_init(C.byref(cons))
+        cost.set("q_ref", rng.uniform(-1, 1, nv)).set("v_ref", rng.uniform(-1, 1, nv)).set("u_ref", rng.uniform(-5, 5, nv))
+        cost.set("q_weight", lw(-1, 2)).set("qf_weight", lw(-1, 2))
+    cost.set("v_weight", lw(-2, 1)).set("vf_weight", lw(-2, 1)).set("a_weight", lw(-3, -1)).set("u_weight", lw(-5, -2))
+    for i in range(nv):
+        m.u_max[i] = float(rng.uniform(40, 300))
+        m.v_max[i] = float(rng.uniform(1.0, 3.0))
+    if seed % 3 == 0:
+        cons.joint_acceleration_lower_limit = cons.joint_acceleration_upper_limit = 1
+        for i in range(nv):
+            cons.a_min[i], cons.a_max[i] = float(-rng.uniform(5, 50)), float(rng.uniform(5, 50))
+    N = int(rng.integers(2, 40))
+    T = N * float(rng.uniform(0.01, 0.06))
+    q, v = rng.uniform(-1.2, 1.2, nv), rng.uniform(-0.5, 0.5, nv)
+    Hip, Orc = (HipUnParNMPC, OracleUnParNMPC) if par else (HipUnOCP, OracleUnOCP)
+    g, o = Hip(m, cost, cons, T, N, batch=3), Orc(m, cost, cons, T, N)
+    for s in (g, o):
+        s.set_solution("q", 0.5 * q)
+        s.set_solution("v", np.zeros(nv))
+        if task and cost.task_time_varying:
+            refs = np.tile(ref, (N + 1, 1))
+            refs[:, 9:] += 0.05 * np.sin(np.arange(N + 1))[:, None]
+            s.set_task_refs(refs)
+        if par:
+            s.init(0.0)
+    eo, eg = o.kkt_error(0.0, q, v), g.kkt_error(0.0, q, v)[2]
+    assert abs(eg - eo) <= 1e-10 * max(1.0, eo)
+    assert g.update(0.0, q, v) == 0 and o.update(0.0, q, v) == 0
+    worst = 0.0
+    for f in DIR_FIELDS:
+        a, b = (g.get(f, 2), o.get(f)) if par else (g.direction(f, 2), o.direction(f))
+        e = rel_err(a, b)
+        worst = max(worst, e)
+        assert e <= TOL, (seed, f, e)
+    if not par:
+        for x, y in zip(g.riccati(2), o.riccati()):
+            assert rel_err(x, y) <= TOL
+    print("seed %d  %s  N %d  task %s  acceleration limits %s  worst %.2e" % (seed, "UnParNMPC" if par else "UnOCP", N, (dim if task else "-"), bool(seed % 3 == 0), worst))
