@@ -593,3 +593,80 @@ def test_configs4_grid_from_three_perturbed_states():
         for f in list(OCP_DIR_FIELDS) + ["dxi"]:
             worst = max(worst, parity(g.get_chain(f, M, b), o.get_chain(f, M), lambda: h.get_chain(f, M), (b, f), cap=1e-8))
     print("configs[4] grid from three perturbed states: worst GPU-oracle distance of the first direction %.2e" % worst)
+
+
+def test_long_receding_horizon_run_recycles_the_event_slots():
+    """The loop above for NINE seconds of gait instead of two: 90 shifts, every impulse / aux / lift slot of the containers (max_num_impulse = 4) reused
+    several times over as events enter at the back and leave through the front.  GPU against the FP64 oracle at every tick: the same chain, the same
+    first direction of the tick (cap 1e-6: the loop feeds both with the ORACLE's plan, so rounding differences of the iterates accumulate in the GPU's
+    warm start only through its own multipliers), a KKT error that stays where the oracle's stays, no error code on the way."""
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=True)
+    N, T, E = 31, 1.55, 4
+    o = OracleOCP(m, cost, cons, T, N, max_num_impulse=E)
+    g = HipOCP(m, cost, cons, T, N, batch=1, max_num_impulse=E)
+    solvers = (o, g)
+    rec = _SequenceRecorder()
+    trotting_sequence(rec, m, 44, t_start=0.52)
+    q, v = ANYMAL_Q_STANDING.copy(), np.zeros(m.nv)
+    for s in solvers:
+        s.set_contact_status(rec.ev[0][0], rec.ev[0][1])
+        s.set_solution("q", q)
+        s.set_solution("v", v)
+        s.set_solution("f", [0, 0, 0.25 * (-m.total_mass * m.gravity[2])])
+    t0, dt_mpc = 0.013, 0.1
+    k, times = 1, []
+
+    def feed(t):
+        nonlocal k
+        n = 0
+        while k < len(rec.ev) and rec.ev[k][2] < t + T - 0.05:
+            for s in solvers:
+                s.push_back_contact_status(*rec.ev[k])
+            times.append(rec.ev[k][2])
+            k += 1
+            n += 1
+        return n
+
+    t = t0
+    feed(t)
+    for s in solvers:
+        s.init_constraints(t)
+    for it in range(20):
+        for s in solvers:
+            assert s.update(t, q, v) == 0
+    pops, slots_used, worst, worst_kkt = 0, {}, 0.0, 0.0
+    for step in range(90):
+        co = o.chain(t)
+        tn = t0 + dt_mpc * (step + 1)
+        at = [p for p, c in enumerate(co) if c["kind"] in ("stage", "terminal") and abs(c["t"] - tn) < 1e-9]
+        assert at, step
+        q, v = o.get_chain("q", len(co))[at[0]].copy(), o.get_chain("v", len(co))[at[0]].copy()
+        t = tn
+        while times and times[0] <= t + 1e-9:
+            for s in solvers:
+                s.pop_front_contact_status()
+            times.pop(0)
+            pops += 1
+        if feed(t):
+            for s in solvers:
+                s.init_constraints(t)
+        co, cg = o.chain(t), g.chain(t)
+        assert len(co) == len(cg), step
+        for a, b in zip(co, cg):
+            assert a["kind"] == b["kind"] and a["index"] == b["index"] and a["slot"] == b["slot"] and a["dimf"] == b["dimf"] and abs(a["dt"] - b["dt"]) < 1e-14, (step, a, b)
+            if a["kind"] in ("impulse", "aux", "lift"):
+                slots_used[(a["kind"], a["index"])] = slots_used.get((a["kind"], a["index"]), 0) + 1
+        M = len(co)
+        for sweep in range(2):
+            assert o.update(t, q, v) == 0 and g.update(t, q, v) == 0, (step, sweep, capi.lib().idocp_last_error())
+            if sweep == 0:
+                for f in ("dq", "dv", "du", "df", "dlmd", "dgmm"):
+                    e = rel_err(g.get_chain(f, M), o.get_chain(f, M))
+                    worst = max(worst, e)
+                    assert e < 1e-6, (step, f, e)
+        e_o, e_g = o.kkt_error(t, q, v), g.kkt_error(t, q, v)[0]
+        worst_kkt = max(worst_kkt, e_g)
+        assert np.isfinite(e_g) and abs(e_g - e_o) <= 1e-5 * max(1.0, e_o), (step, e_g, e_o)
+    assert pops >= 16 and max(slots_used.values()) >= 20 and len(slots_used) >= 6, (pops, slots_used)
+    print("long MPC run: %d shifts, %d pops, slot use %s, worst direction distance %.2e, largest KKT error %.2e" % (90, pops, dict(sorted(slots_used.items())), worst, worst_kkt))
