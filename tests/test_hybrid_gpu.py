@@ -4,6 +4,8 @@ the chain (stage, [impulse, aux | lift], ..., terminal), on the reference's trot
 import numpy as np
 import pytest
 
+from idocp_amd import capi
+
 from helpers import (parity, pairwise_check, ANYMAL_Q_STANDING, OCP_DIR_FIELDS, OCP_SOL_FIELDS, HipOCP, OracleOCP, anymal_model, anymal_problem, referee_check,
                      rel_err, trotting_sequence)
 
