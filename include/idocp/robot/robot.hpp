@@ -99,6 +99,25 @@ class Robot {
     sized(q, model_.nq, "q");
     ok(idocp_model_normalize_configuration(&model_, q.data()));
   }
+  // Robot::setFrictionCoefficient / frictionCoefficient / setRestitutionCoefficient / restitutionCoefficient (robot.hxx:358-406): per-contact properties
+  // the reference stores (defaults 0.8 and 0, point_contact.hpp) and nothing on the solver path reads -- the friction cones take their mu as a
+  // constructor argument (friction_cone.hpp).  Kept so that a driver that sets them compiles and reads back what it set.
+  void setFrictionCoefficient(const std::vector<double>& friction_coefficient) {
+    for (int i = 0; i < model_.ncontacts && i < (int)friction_coefficient.size(); ++i) {
+      if (friction_coefficient[i] <= 0) { std::cerr << "invalid argument: friction coefficient must be positive" << '\n'; std::exit(EXIT_FAILURE); }
+      friction_[i] = friction_coefficient[i];
+    }
+  }
+  double frictionCoefficient(const int contact_index) const { noContacts(); return friction_[contact_index]; }
+  void setRestitutionCoefficient(const std::vector<double>& restitution_coefficient) {
+    for (int i = 0; i < model_.ncontacts && i < (int)restitution_coefficient.size(); ++i) {
+      if (restitution_coefficient[i] < 0 || restitution_coefficient[i] > 1) { std::cerr << "invalid argument: restitution coefficient must be in [0, 1]" << '\n'; std::exit(EXIT_FAILURE); }
+      restitution_[i] = restitution_coefficient[i];
+    }
+  }
+  double restitutionCoefficient(const int contact_index) const { noContacts(); return restitution_[contact_index]; }
+  // Robot::contactFramesIndices (robot.hxx:655-661)
+  std::vector<int> contactFramesIndices() const { return std::vector<int>(model_.contact_frame_id, model_.contact_frame_id + model_.ncontacts); }
   // Robot::createImpulseStatus (robot.hxx:672-675): in this library an impulse status is a ContactStatus (the feet that touch down)
   ContactStatus createImpulseStatus() const { return ContactStatus(model_.ncontacts); }
 
@@ -110,6 +129,10 @@ class Robot {
   idocp_model_t model_;
   std::string path_;
   std::vector<double> points_;     // contact-frame positions of the last updateFrameKinematics(q)
+  double friction_[IDOCP_MAX_CONTACTS] = {0.8, 0.8, 0.8, 0.8}, restitution_[IDOCP_MAX_CONTACTS] = {0.0, 0.0, 0.0, 0.0};
+  void noContacts() const {
+    if (model_.ncontacts == 0) { std::cerr << "invalid function call: robot has no point contacts!" << '\n'; std::exit(EXIT_FAILURE); }
+  }
   static void ok(int rc) { if (rc != IDOCP_OK) { std::cerr << idocp_last_error() << '\n'; std::exit(EXIT_FAILURE); } }
   static void sized(const Eigen::VectorXd& x, int n, const char* name) {
     if (x.size() != n) { std::cerr << "invalid size: " << name << ".size() must be " << n << "!" << '\n'; std::exit(EXIT_FAILURE); }

@@ -208,6 +208,10 @@ int main(int argc, char** argv) {
       robot.normalizeConfiguration(q2);
       REQUIRE(maxDiff(q2, q1) < 1e-15);
       REQUIRE(robot.createImpulseStatus().maxPointContacts() == robot.maxPointContacts());
+      // per-contact properties the reference stores (robot_test.cpp:106: the default friction coefficient is 0.8) and the frame indices
+      REQUIRE(robot.frictionCoefficient(2) == 0.8 && robot.restitutionCoefficient(0) == 0.0);
+      robot.setFrictionCoefficient({0.5, 0.6, 0.7, 0.9});
+      REQUIRE(robot.frictionCoefficient(2) == 0.7 && robot.contactFramesIndices() == ex::anymalFeet());
     }
     const idocp::OCPSolver& cs = solver;
     const idocp::SplitSolution& s0 = cs.getSolution(0);
