@@ -19,8 +19,8 @@ namespace idocp {
 class ConstraintComponentBase {
  public:
   enum Family { Position, Velocity, Torque, LinearFrictionCone, QuadraticFrictionCone, Acceleration, Distance };
-  ConstraintComponentBase(Family f, bool upper, double barrier, double rate)
-      : family(f), upper(upper), barrier(barrier), fraction_to_boundary_rate(rate) {}
+  ConstraintComponentBase(Family f, bool upper_in, double barrier_in, double rate_in)
+      : family(f), upper(upper_in), barrier(barrier_in), fraction_to_boundary_rate(rate_in) {}
   virtual ~ConstraintComponentBase() {}
   Family family;
   bool upper;
@@ -44,8 +44,8 @@ class ConstraintComponentBase {
 #define IDOCP_LIMIT_CLASS(NAME, FAMILY, UPPER)                                                        \
   class NAME final : public ConstraintComponentBase {                                                 \
    public:                                                                                            \
-    explicit NAME(const Robot&, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)   \
-        : ConstraintComponentBase(FAMILY, UPPER, barrier, fraction_to_boundary_rate) {}               \
+    explicit NAME(const Robot&, double barrier_in = 1.0e-04, double rate_in = 0.995)   \
+        : ConstraintComponentBase(FAMILY, UPPER, barrier_in, rate_in) {}               \
   }
 IDOCP_LIMIT_CLASS(JointPositionLowerLimit, Position, false);
 IDOCP_LIMIT_CLASS(JointPositionUpperLimit, Position, true);
@@ -59,29 +59,29 @@ IDOCP_LIMIT_CLASS(JointTorquesUpperLimit, Torque, true);
 // <= amax with the bounds passed to the constructor (the robot model has none); each may be used on its own.
 class JointAccelerationLowerLimit final : public ConstraintComponentBase {
  public:
-  JointAccelerationLowerLimit(const Robot& robot, const Eigen::VectorXd& amin, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(Acceleration, false, barrier, fraction_to_boundary_rate) { bound = checkedBound(robot, amin, "amin"); }
+  JointAccelerationLowerLimit(const Robot& robot, const Eigen::VectorXd& amin, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(Acceleration, false, barrier_in, rate_in) { bound = checkedBound(robot, amin, "amin"); }
 };
 class JointAccelerationUpperLimit final : public ConstraintComponentBase {
  public:
-  JointAccelerationUpperLimit(const Robot& robot, const Eigen::VectorXd& amax, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(Acceleration, true, barrier, fraction_to_boundary_rate) { bound = checkedBound(robot, amax, "amax"); }
+  JointAccelerationUpperLimit(const Robot& robot, const Eigen::VectorXd& amax, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(Acceleration, true, barrier_in, rate_in) { bound = checkedBound(robot, amax, "amax"); }
 };
 
 // ContactDistance (src/constraints/contact_distance.cpp): the frames of the contacts that are not active on a stage stay above z = 0
 // (floating-base solvers).
 class ContactDistance final : public ConstraintComponentBase {
  public:
-  explicit ContactDistance(const Robot&, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(Distance, false, barrier, fraction_to_boundary_rate) {}
+  explicit ContactDistance(const Robot&, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(Distance, false, barrier_in, rate_in) {}
 };
 
 // LinearizedFrictionCone (include/idocp/constraints/linearized_friction_cone.hpp:17-120,
 // src/constraints/linearized_friction_cone.cpp): five rows per active contact, evaluated in K5b.
 class LinearizedFrictionCone final : public ConstraintComponentBase {
  public:
-  LinearizedFrictionCone(const Robot&, const double mu, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(LinearFrictionCone, false, barrier, fraction_to_boundary_rate) { setFrictionCoefficient(mu); }
+  LinearizedFrictionCone(const Robot&, const double mu_in, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(LinearFrictionCone, false, barrier_in, rate_in) { setFrictionCoefficient(mu_in); }
   void setFrictionCoefficient(const double mu_in) {
     if (mu_in <= 0) {      // linearized_friction_cone.cpp:20-31
       std::cerr << "invalid argment: mu must be positive" << '\n';
@@ -94,16 +94,16 @@ class LinearizedFrictionCone final : public ConstraintComponentBase {
 // impulse stage (no time-step scaling).
 class LinearizedImpulseFrictionCone final : public ConstraintComponentBase {
  public:
-  LinearizedImpulseFrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(LinearFrictionCone, true, barrier, fraction_to_boundary_rate) { mu = mu_in; }
+  LinearizedImpulseFrictionCone(const Robot&, const double mu_in, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(LinearFrictionCone, true, barrier_in, rate_in) { mu = mu_in; }
 };
 
 // FrictionCone (include/idocp/constraints/friction_cone.hpp, src/constraints/friction_cone.cpp; the cone of
 // examples/anymal/ocp_benchmark.cpp:76): two rows per active contact, -fz <= 0 and fx^2 + fy^2 - mu^2 fz^2 <= 0.
 class FrictionCone final : public ConstraintComponentBase {
  public:
-  FrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(QuadraticFrictionCone, false, barrier, fraction_to_boundary_rate) { setFrictionCoefficient(mu_in); }
+  FrictionCone(const Robot&, const double mu_in, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(QuadraticFrictionCone, false, barrier_in, rate_in) { setFrictionCoefficient(mu_in); }
   void setFrictionCoefficient(const double mu_in) {
     if (mu_in <= 0) {      // friction_cone.cpp:13-22
       std::cerr << "invalid value: mu must be positive!" << '\n';
@@ -115,8 +115,8 @@ class FrictionCone final : public ConstraintComponentBase {
 // Impulse twin (src/constraints/impulse_friction_cone.cpp)
 class ImpulseFrictionCone final : public ConstraintComponentBase {
  public:
-  ImpulseFrictionCone(const Robot&, const double mu_in, double barrier = 1.0e-04, double fraction_to_boundary_rate = 0.995)
-      : ConstraintComponentBase(QuadraticFrictionCone, true, barrier, fraction_to_boundary_rate) { mu = mu_in; }
+  ImpulseFrictionCone(const Robot&, const double mu_in, double barrier_in = 1.0e-04, double rate_in = 0.995)
+      : ConstraintComponentBase(QuadraticFrictionCone, true, barrier_in, rate_in) { mu = mu_in; }
 };
 
 class Constraints {
