@@ -38,7 +38,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-NV, NU, NX = 18, 12, 36
+NV, NU, NX = 18, 12, 36      # (gen_golden_kkt_iiwa14.py sets them to the arm's 7, 7, 14 and runs the same assembly)
+NC3 = 12                      # width of the per-contact fields f / mu / xi
 FIELDS = ("dq", "dv", "da", "df", "du", "dlmd", "dgmm", "dbeta", "dmu", "dnu_passive", "dxi")
 
 
@@ -96,14 +97,15 @@ def stage_data(o, pos):
     nf, ni = d["dimf"], d["dimi"]
     d["Qxx"] = fetch(o, pos, "Qxx", (NX, NX))
     d["lq"], d["lv"] = fetch(o, pos, "lq"), fetch(o, pos, "lv")
-    d["Fqq_prev"] = fetch(o, pos, "Fqq_prev", (6, 6))
+    NP = NV - NU                  # passive rows of a floating base: the blocks of the configuration-difference Jacobians
+    d["Fqq_prev"] = fetch(o, pos, "Fqq_prev", (NP, NP))
     if d["kind"] == 4:      # terminal
         return d
     d["Qaa"], d["Qff"] = fetch(o, pos, "Qaa"), fetch(o, pos, "Qff", (nf, nf))
     d["Quu"] = fetch(o, pos, "Quu", (NV, NV))
     for n in ("la", "lf", "lu", "lu_passive", "Fq", "Fv", "IDC"):
         d[n] = fetch(o, pos, n)
-    d["Fqq"] = fetch(o, pos, "Fqq", (6, 6))
+    d["Fqq"] = fetch(o, pos, "Fqq", (NP, NP))
     d["dIDCdqv"] = fetch(o, pos, "dIDCdqv", (NV + nf, NX))
     d["M"], d["J"] = fetch(o, pos, "M", (NV, NV)), fetch(o, pos, "J", (nf, NV))
     if ni:
@@ -114,7 +116,8 @@ def stage_data(o, pos):
 def full(block6, tail):
     """nv x nv Jacobian of the floating base's configuration difference: the 6 x 6 base block, `tail` * I on the joints"""
     A = tail * np.eye(NV)
-    A[:6, :6] = block6
+    NP = NV - NU
+    A[:NP, :NP] = block6
     return A
 
 
@@ -173,8 +176,9 @@ def assemble(nodes, dq0, dv0):
         r[f] = -d["lf"]
         if d["has_u"]:
             u = idx[("u", p)]
-            S = np.zeros((NU, NV)); S[:, 6:] = np.eye(NU)                  # u enters the actuated rows of ID
-            K[u, u] += d["Quu"][6:, 6:]; K[u, be] += -dt * S
+            NP = NV - NU
+            S = np.zeros((NU, NV)); S[:, NP:] = np.eye(NU)                 # u enters the actuated rows of ID
+            K[u, u] += d["Quu"][NP:, NP:]; K[u, be] += -dt * S
             r[u] = -d["lu"]
             K[be, u] += -dt * S.T
         # state equation p -> p + 1 (multipliers lmd_{p+1}, gmm_{p+1})
@@ -214,8 +218,9 @@ def dense_direction(o, M, dq0, dv0):
     K, r, idx = assemble(nodes, dq0, dv0)
     assert np.max(np.abs(K - K.T)) < 1e-9 * np.max(np.abs(K)), "the Newton system of an equality-constrained problem is symmetric"
     z, res = solve_refined(K, r)
-    out = {f: np.zeros((M, dim)) for f, dim in (("dq", NV), ("dv", NV), ("da", NV), ("df", 12), ("du", NU), ("dlmd", NV), ("dgmm", NV),
-                                                  ("dbeta", NV), ("dmu", 12), ("dnu_passive", 6), ("dxi", 12))}
+    NP = NV - NU
+    out = {f: np.zeros((M, dim)) for f, dim in (("dq", NV), ("dv", NV), ("da", NV), ("df", NC3), ("du", NU), ("dlmd", NV), ("dgmm", NV),
+                                                  ("dbeta", NV), ("dmu", NC3), ("dnu_passive", NP), ("dxi", NC3))}
     newton = {"dbeta": np.zeros((M, NV))}      # the exact Newton dbeta, for the record (differs from the reference's on switching stages)
     for p, d in enumerate(nodes):
         out["dq"][p], out["dv"][p] = z[idx[("q", p)]], z[idx[("v", p)]]
@@ -245,7 +250,7 @@ def dense_direction(o, M, dq0, dv0):
             out["du"][p] = z[idx[("u", p)]]
             # passive torques are fixed at zero; nu_passive is the multiplier of that: row u_passive of the stationarity conditions reads
             # - dt dbeta[:6] + dt dnu = - lu_passive
-            out["dnu_passive"][p] = out["dbeta"][p, :6] - d["lu_passive"] / d["dt"]
+            out["dnu_passive"][p] = out["dbeta"][p, :NP] - d["lu_passive"] / d["dt"]
         if d["dimi"]:
             out["dxi"][p, :d["dimi"]] = z[idx[("xi", p)]]
     return out, nodes, {"unknowns": int(K.shape[0]), "max_abs_residual": res, "cond_estimate": float(np.linalg.cond(K)),

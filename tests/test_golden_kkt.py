@@ -18,10 +18,11 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, HipOCP, OracleOCP
+from helpers import GOLDEN, HipOCP, HipUnOCP, OracleOCP, OracleUnOCP
 
 sys.path.insert(0, GOLDEN)
 import gen_golden_kkt as G      # noqa: E402
+import gen_golden_kkt_iiwa14 as GI      # noqa: E402
 
 TOL = 1e-9
 
@@ -93,3 +94,64 @@ def test_hip_direction_is_the_dense_newton_direction():
     assert [c["kind"] for c in g.chain(0.0)] == [c["kind"] for c in ref["chain"]]
     for inst in (0, 1):
         compare({f: g.get_chain(f, M, inst) for f in G.FIELDS}, ref, "HIP (instance %d)" % inst)
+
+
+# ---- the fixed-base path: tests/golden/kkt_iiwa14.json (gen_golden_kkt_iiwa14.py) ----
+# One dense un-condensed solve, three condensations held to it: the oracle's OCPSolver on the arm (a eliminated through M^-1, Riccati on u), the oracle's
+# UnOCPSolver (u eliminated through u = ID(q, v, a), Riccati on a: unconstrained_dynamics.hxx:55-106, split_unriccati_factorizer.hxx) and the HIP kernels.
+
+def fixture_arm():
+    with open(os.path.join(GOLDEN, "kkt_iiwa14.json")) as f:
+        return json.load(f)
+
+
+def compare_arm(got, ref, what):
+    worst = (-1.0, "", -1)
+    for f in GI.FIELDS:
+        want = np.array(ref["direction"][f])
+        have = got[f]
+        n = have.shape[0]                                  # (the stage-only fields stop in front of the terminal stage)
+        assert n in (want.shape[0], want.shape[0] - 1) and have.shape[1] == want.shape[1], (f, have.shape, want.shape)
+        for p in range(n):
+            e = np.max(np.abs(have[p] - want[p])) / max(1.0, np.max(np.abs(want[p])))
+            worst = max(worst, (e, f, p))
+    print("%s: worst field / stage %s at stage %s: %.2e" % (what, worst[1], worst[2], worst[0]))
+    assert worst[0] < TOL, "%s differs from the dense Newton direction: %s at stage %s by %.3e" % (what, worst[1], worst[2], worst[0])
+
+
+def second_iteration_arm(Solver, spec, **kw):
+    o, qm, vm = GI.build(spec, Solver, **kw)
+    assert o.update(0.0, qm, vm) == 0
+    assert o.update(0.0, qm, vm) == 0
+    return o
+
+
+def test_arm_fixture_is_what_the_generator_produces():
+    import ctypes as C
+    ref = fixture_arm()
+    assert ref["spec"] == GI.problem_spec()
+    o, qm, vm = GI.build(ref["spec"], OracleOCP)
+    assert o.update(0.0, qm, vm) == 0
+    o.lib.oracle_ocp_keep_uncondensed.argtypes = [C.c_void_p, C.c_int]
+    o.lib.oracle_ocp_keep_uncondensed(o.h, 1)
+    assert o.update(0.0, qm, vm) == 0
+    dense, _, info = GI.dense_direction(o, ref["spec"]["N"] + 1, o.get("dq")[0], o.get("dv")[0])
+    assert info["unknowns"] == ref["dense_system"]["unknowns"] and ref["dense_system"]["max_abs_residual"] < 1e-13
+    compare_arm(dense, ref, "regenerated dense solve")
+    assert (G.NV, G.NU, G.NX) == (18, 12, 36)               # (the arm's dimensions did not leak into the ANYmal generator)
+
+
+def test_both_oracle_condensations_of_the_arm_are_the_dense_newton_direction():
+    ref = fixture_arm()
+    o = second_iteration_arm(OracleOCP, ref["spec"])
+    compare_arm({f: o.get(f) for f in GI.FIELDS}, ref, "oracle OCPSolver on the arm")
+    u = second_iteration_arm(OracleUnOCP, ref["spec"])
+    compare_arm({f: u.direction(f) for f in GI.FIELDS}, ref, "oracle UnOCPSolver")
+
+
+@pytest.mark.gpu
+def test_hip_fixed_base_direction_is_the_dense_newton_direction():
+    ref = fixture_arm()
+    g = second_iteration_arm(HipUnOCP, ref["spec"], batch=2)
+    for inst in (0, 1):
+        compare_arm({f: g.direction(f, inst) for f in GI.FIELDS}, ref, "HIP UnOCP kernels (instance %d)" % inst)
