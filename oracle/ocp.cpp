@@ -1837,6 +1837,20 @@ void ParNMPCSolver::linearizeNode(int p, const Mat& q_prev, const Mat& v_prev, b
     }
   }
   // ---- ContactDynamics::condenseContactDynamics(..., is_forward_euler = false) (contact_dynamics.hxx:105-158)
+  if (keep_uncondensed) {      // test hook (ocp.hpp UncondensedC; tests/golden/gen_golden_kkt_parnmpc.py): the un-condensed Newton system of this backward-Euler stage
+    if ((int)unc.size() != nslots()) unc.assign(nslots(), UncondensedC());
+    UncondensedC& U = unc[i];
+    U = UncondensedC();
+    U.valid = true; U.kind = (int)nd.kind; U.dimf = dimf; U.dimi = (int)R.P.size(); U.has_u = 1; U.dt = dt; U.dtq = dt;
+    U.active_mask = 0; for (int c = 0; c < nc_; ++c) if (cs.active[c]) U.active_mask |= 1 << c;
+    U.Qxx = M.Qxx; U.Qaa = M.Qaa_diag; U.Qff = M.Qff; U.Quu = M.Quu_full;
+    U.lq = R.lq; U.lv = R.lv; U.la = R.la; U.lf = R.lf; U.lu = R.lu; U.lu_passive = R.lu_passive;
+    U.Fq = R.Fq; U.Fq.setSegment(0, R.Fq_prev);          // the residual before condenseBackwardEuler premultiplied its base rows
+    U.Fv = R.Fv;
+    U.Fqq = M.Fqq_prev6;                                 // dSubtractdConfigurationMinus(q_prev, q): d Fq / d q of THIS stage (parked there by condenseBackwardEuler)
+    U.dIDCdqv = D.dIDCdqv; U.M = D.dIDda; U.J = D.dCda; U.IDC = D.IDC;
+    if (nd.kind == NodeC::Aux) { U.Phix = sw_Pq[i]; U.P = R.P; }
+  }
   FLOP_REGION_SET(R_CONDENSE);
   Robot::computeMJtJinv(D.dIDda, D.dCda, D.MJtJinv);
   D.MJtJinv_dIDCdqv = D.MJtJinv * D.dIDCdqv;

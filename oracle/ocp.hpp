@@ -269,6 +269,8 @@ class ParNMPCSolver {
     int event = -1;            // Aux / Impulse: event index of the impulse
   };
   void discretize(real t);                                           // ParNMPCDiscretizer::discretizeOCP
+  bool keep_uncondensed = false;            // test hook: capture the un-condensed stage systems (UncondensedC) in linearizeNode
+  std::vector<UncondensedC> unc;            // [slot]
   std::vector<PNode> chain;
   ContactSequenceC seq;
   const ContactStatus& nodeContacts(const PNode& nd) const { return nd.kind == NodeC::Impulse ? seq.impulse_status[nd.event] : seq.phases[nd.phase]; }

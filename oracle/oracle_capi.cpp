@@ -825,10 +825,20 @@ int oracle_ocp_get_lqr_stage(void* h, int i, double* Qxx, double* Qxu, double* Q
 //   oracle_ocp_get_uncondensed(h, pos, "meta", out) -> [valid, kind, dimf, dimi, has_u, dt, dtq, active_mask]; any other name: the block, column-major;
 //   returns the number of doubles (out may be NULL to ask for it), -1 for an unknown name
 int oracle_ocp_keep_uncondensed(void* h, int on) { static_cast<OCPSolver*>(h)->keep_uncondensed = on != 0; return 0; }
+static int uncondensedField(const UncondensedC& U, const char* name, double* out);
 int oracle_ocp_get_uncondensed(void* h, int pos, const char* name, double* out) {
   OCPSolver* s = static_cast<OCPSolver*>(h);
   if (pos < 0 || pos >= s->M() || (int)s->unc.size() != s->nslots()) return -1;
-  const UncondensedC& U = s->unc[s->chain[pos].slot];
+  return uncondensedField(s->unc[s->chain[pos].slot], name, out);
+}
+// the same for a ParNMPCSolver (backward-Euler stages; Fqq = d Fq / d q of the stage itself, no Fqq_prev)
+int oracle_parnmpc_keep_uncondensed(void* h, int on) { static_cast<ParNMPCSolver*>(h)->keep_uncondensed = on != 0; return 0; }
+int oracle_parnmpc_get_uncondensed(void* h, int pos, const char* name, double* out) {
+  ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
+  if (pos < 0 || pos >= s->M() || (int)s->unc.size() != s->nslots()) return -1;
+  return uncondensedField(s->unc[s->chain[pos].slot], name, out);
+}
+static int uncondensedField(const UncondensedC& U, const char* name, double* out) {
   const std::string n(name);
   if (n == "meta") {
     if (out) { out[0] = U.valid; out[1] = U.kind; out[2] = U.dimf; out[3] = U.dimi; out[4] = U.has_u; out[5] = (double)U.dt; out[6] = (double)U.dtq; out[7] = U.active_mask; }

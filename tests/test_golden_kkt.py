@@ -18,11 +18,12 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, HipOCP, HipUnOCP, OracleOCP, OracleUnOCP
+from helpers import GOLDEN, HipOCP, HipParNMPC, HipUnOCP, OracleOCP, OracleParNMPC, OracleUnOCP
 
 sys.path.insert(0, GOLDEN)
 import gen_golden_kkt as G      # noqa: E402
 import gen_golden_kkt_iiwa14 as GI      # noqa: E402
+import gen_golden_kkt_parnmpc as GP      # noqa: E402
 
 TOL = 1e-9
 
@@ -155,3 +156,49 @@ def test_hip_fixed_base_direction_is_the_dense_newton_direction():
     g = second_iteration_arm(HipUnOCP, ref["spec"], batch=2)
     for inst in (0, 1):
         compare_arm({f: g.direction(f, inst) for f in GI.FIELDS}, ref, "HIP UnOCP kernels (instance %d)" % inst)
+
+
+# ---- the ParNMPC stage: tests/golden/kkt_parnmpc.json (gen_golden_kkt_parnmpc.py) ----
+# The coarse update of ParNMPCSolver is the Newton step of ONE backward-Euler stage; on a horizon of one stage it is the whole iteration.  The dense solve of that
+# stage's un-condensed system against the condensed route: backward-Euler contact-dynamics condensation + the block-wise KKT inverse
+# (split_parnmpc.hxx, split_kkt_matrix_inverter.hxx:56-197) -- four feet, two feet, none.
+
+def fixture_parnmpc():
+    with open(os.path.join(GOLDEN, "kkt_parnmpc.json")) as f:
+        return json.load(f)
+
+
+def compare_stage(have, ref_case, what):
+    worst = (-1.0, "")
+    for f in GP.FIELDS:
+        want = np.array(ref_case["direction"][f])
+        assert have[f].shape == want.shape, (f, have[f].shape, want.shape)
+        worst = max(worst, (np.max(np.abs(have[f] - want)) / max(1.0, np.max(np.abs(want))), f))
+    print("%s: worst field %s: %.2e" % (what, worst[1], worst[0]))
+    assert worst[0] < TOL, "%s differs from the dense stage-wise Newton step: %s by %.3e" % (what, worst[1], worst[0])
+
+
+def test_parnmpc_stage_fixture_is_what_the_generator_produces_and_the_oracle_condensation_equals_it():
+    import ctypes as C
+    ref = fixture_parnmpc()
+    assert ref["spec"] == GP.problem_spec() and {k: v["active"] for k, v in ref["cases"].items()} == GP.CASES
+    assert {v["dense_system"]["dimf"] for v in ref["cases"].values()} == {0, 6, 12}
+    for name, case in ref["cases"].items():
+        o, qm, vm = GP.run(ref["spec"], case["active"], OracleParNMPC)
+        o.lib.oracle_parnmpc_keep_uncondensed.argtypes = [C.c_void_p, C.c_int]
+        o.lib.oracle_parnmpc_keep_uncondensed(o.h, 1)
+        assert o.update(0.0, qm, vm) == 0
+        dense, info = GP.dense_stage_step(o)
+        assert info["unknowns"] == case["dense_system"]["unknowns"]
+        compare_stage(dense, case, "regenerated dense solve (%s)" % name)
+        compare_stage({f: o.get(f)[0] for f in GP.FIELDS}, case, "oracle ParNMPCSolver (%s)" % name)
+
+
+@pytest.mark.gpu
+def test_hip_parnmpc_stage_is_the_dense_stage_wise_newton_step():
+    ref = fixture_parnmpc()
+    for name, case in ref["cases"].items():
+        g, qm, vm = GP.run(ref["spec"], case["active"], HipParNMPC, batch=2)
+        assert g.update(0.0, qm, vm) == 0
+        for inst in (0, 1):
+            compare_stage({f: g.get(f, inst)[0] for f in GP.FIELDS}, case, "HIP ParNMPC kernels (%s, instance %d)" % (name, inst))
