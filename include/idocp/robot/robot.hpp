@@ -12,6 +12,7 @@
 
 #include "idocp/eigen_shim.hpp"
 #include "idocp/robot/contact_status.hpp"
+#include "idocp/robot/impulse_status.hpp"
 #include "idocp_hip.h"
 
 namespace idocp {
@@ -118,8 +119,8 @@ class Robot {
   double restitutionCoefficient(const int contact_index) const { noContacts(); return restitution_[contact_index]; }
   // Robot::contactFramesIndices (robot.hxx:655-661)
   std::vector<int> contactFramesIndices() const { return std::vector<int>(model_.contact_frame_id, model_.contact_frame_id + model_.ncontacts); }
-  // Robot::createImpulseStatus (robot.hxx:672-675): in this library an impulse status is a ContactStatus (the feet that touch down)
-  ContactStatus createImpulseStatus() const { return ContactStatus(model_.ncontacts); }
+  // Robot::createImpulseStatus (robot.hxx:672-675)
+  ImpulseStatus createImpulseStatus() const { return ImpulseStatus(model_.ncontacts); }
 
   const idocp_model_t& model() const { return model_; }
   // the URDF this robot was built from (frame lookups of the task-space costs)

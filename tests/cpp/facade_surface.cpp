@@ -207,7 +207,16 @@ int main(int argc, char** argv) {
       for (int k = 3; k < 7; ++k) q2[k] *= 3.0;
       robot.normalizeConfiguration(q2);
       REQUIRE(maxDiff(q2, q1) < 1e-15);
-      REQUIRE(robot.createImpulseStatus().maxPointContacts() == robot.maxPointContacts());
+      {  // ImpulseStatus (impulse_status.hpp): the contacts that BECOME active between two statuses
+        idocp::ImpulseStatus imp = robot.createImpulseStatus();
+        idocp::ContactStatus pre = robot.createContactStatus(), post = robot.createContactStatus();
+        pre.activateContacts({1, 2});
+        post.activateContacts({0, 1, 2, 3});
+        imp.setActivity(pre, post);
+        REQUIRE(imp.maxPointContacts() == robot.maxPointContacts() && imp.dimf() == 6 && imp.isImpulseActive(0) && !imp.isImpulseActive(1) && imp.isImpulseActive(3));
+        imp.deactivateImpulse();
+        REQUIRE(!imp.hasActiveImpulse());
+      }
       // per-contact properties the reference stores (robot_test.cpp:106: the default friction coefficient is 0.8) and the frame indices
       REQUIRE(robot.frictionCoefficient(2) == 0.8 && robot.restitutionCoefficient(0) == 0.0);
       robot.setFrictionCoefficient({0.5, 0.6, 0.7, 0.9});
