@@ -75,6 +75,13 @@ class Vector3d {
   double& coeffRef(int i) { return (*this)[i]; }
   double coeff(int i) const { return (*this)[i]; }
   CommaInit<Vector3d> operator<<(double first) { return CommaInit<Vector3d>(*this, first); }
+  double squaredNorm() const { return d_[0] * d_[0] + d_[1] * d_[1] + d_[2] * d_[2]; }
+  // DenseBase::isApprox with the default precision of double: |a - b|^2 <= 1e-24 min(|a|^2, |b|^2)
+  bool isApprox(const Vector3d& o, const double prec = 1e-12) const {
+    const Vector3d e(d_[0] - o.d_[0], d_[1] - o.d_[1], d_[2] - o.d_[2]);
+    const double na = squaredNorm(), nb = o.squaredNorm();
+    return e.squaredNorm() <= prec * prec * (na < nb ? na : nb);
+  }
  private:
   double d_[3];
 };

@@ -16,6 +16,17 @@ class ContactStatus {
       : is_contact_active_(max_point_contacts, false), contact_points_(max_point_contacts), dimf_(0),
         max_point_contacts_(max_point_contacts) {}
 
+  // contact_status.hxx:34-50: equal = the same contacts active AND the same contact points (isApprox)
+  bool operator==(const ContactStatus& other) const {
+    assert(other.maxPointContacts() == max_point_contacts_);
+    for (int i = 0; i < max_point_contacts_; ++i) {
+      if (other.isContactActive(i) != isContactActive(i)) return false;
+      if (!other.contactPoints()[i].isApprox(contactPoints()[i])) return false;
+    }
+    return true;
+  }
+  bool operator!=(const ContactStatus& other) const { return !(*this == other); }
+
   bool isContactActive(const int contact_index) const { return is_contact_active_.at(contact_index); }
   const std::vector<bool>& isContactActive() const { return is_contact_active_; }
   bool hasActiveContacts() const { return dimf_ > 0; }

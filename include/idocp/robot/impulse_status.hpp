@@ -16,6 +16,9 @@ class ImpulseStatus {
  public:
   explicit ImpulseStatus(const int max_point_contacts = 0) : status_(max_point_contacts) {}
 
+  bool operator==(const ImpulseStatus& other) const { return status_ == other.status_; }      // impulse_status.hxx:36-56
+  bool operator!=(const ImpulseStatus& other) const { return !(*this == other); }
+
   bool isImpulseActive(const int contact_index) const { return status_.isContactActive(contact_index); }
   const std::vector<bool>& isImpulseActive() const { return status_.isContactActive(); }
   bool hasActiveImpulse() const { return status_.hasActiveContacts(); }
