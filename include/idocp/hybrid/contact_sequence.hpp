@@ -5,6 +5,9 @@
 // solvers keep a sequence of their own behind the C ABI (idocp_ocp_push_back_contact_status / pop_back / pop_front, ocp_capi.hip: same rules, checked
 // against the oracle on random sequences, tests/test_discretiser_fuzz_gpu.py); this class is for drivers that plan a gait before handing it over:
 //   for (int i = 0; i < seq.numDiscreteEvents(); ++i) solver.pushBackContactStatus(seq.contactStatus(i + 1), seq.eventTime(i));
+// Two places where this class does what the reference's text says rather than what its code does on inputs that break the sequence anyway:
+// updateImpulseTime / updateLiftTime check BOTH neighbours of the event (contact_sequence.hxx:183-197 checks the later one only for the first event), and
+// setContactPoints moves the impulse that opens the phase (contact_sequence.hxx:262-264 indexes the impulses by phase, right only while no lift precedes).
 #ifndef IDOCP_CONTACT_SEQUENCE_HPP_
 #define IDOCP_CONTACT_SEQUENCE_HPP_
 
