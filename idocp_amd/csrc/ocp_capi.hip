@@ -1604,6 +1604,22 @@ int idocp_parnmpc_get_aux_mat_chain(idocp_ocp_t* h, int instance, double* out) {
   Field f{0, DQ::NX * DQ::NX, 0};
   return getChainField(h, h->B.aux, LQ::AUX, f, instance, out);
 }
+// the coarse / corrected iterate s_new of the backward correction along the chain (SplitBackwardCorrection's s_new: lmd gmm u q v; "xi": the switching
+// multiplier of an aux stage).  On an impulse stage "u" holds the impulse forces f and "xi" the multipliers mu of the velocity constraint, both packed
+// (active contacts first).  out[M][dim], dim = nv (lmd gmm v), nq (q), nu (u), 3 nc (xi).
+int idocp_parnmpc_get_new_solution_chain(idocp_ocp_t* h, const char* name, int instance, double* out) {
+  if (!h || !name || !out || !h->parnmpc || instance < 0 || instance >= h->batch) { set_last_error("idocp_parnmpc_get_new_solution_chain: not a ParNMPC handle, or a null argument"); return IDOCP_E_ARG; }
+  const std::string n(name);
+  Field f;
+  if (n == "lmd") f = {LQ::N_LMD, DQ::NV, 0};
+  else if (n == "gmm") f = {LQ::N_GMM, DQ::NV, 0};
+  else if (n == "u") f = {LQ::N_U, DQ::NU, 0};
+  else if (n == "q") f = {LQ::N_Q, DQ::NQ, 0};
+  else if (n == "v") f = {LQ::N_V, DQ::NV, 0};
+  else if (n == "xi") f = {LQ::N_XI, DQ::NF, 0};
+  else { set_last_error(std::string("unknown field name: ") + name); return IDOCP_E_ARG; }
+  return getChainField(h, h->B.snew, LQ::SNEW, f, instance, out);
+}
 int idocp_ocp_get_solution_chain(idocp_ocp_t* h, const char* name, int instance, double* out) {
   if (!h || !name || !out || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   Field f;

@@ -446,6 +446,12 @@ int idocp_parnmpc_set_aux_mat_chain(idocp_ocp_t* h, int M, const double* values)
 /* ... and its counterpart: aux_mat of every stage of the chain of one instance, out[M][nx * nx] (column-major per stage).  With
  * idocp_ocp_get_solution_chain this carries a converged ParNMPC solver over into another handle (another batch size, a shard). */
 int idocp_parnmpc_get_aux_mat_chain(idocp_ocp_t* h, int instance, double* out);
+/* The coarse / corrected iterate s_new of the backward correction along the chain (SplitBackwardCorrection::s_new_,
+ * split_backward_correction.hxx:50-82; after idocp_parnmpc_launch_phase 0 - 2 the coarse update, after the correction phases the corrected
+ * iterate).  name: lmd gmm u q v xi; on an impulse stage "u" holds the impulse forces f and "xi" the multipliers mu of the velocity
+ * constraint, both packed (active contacts first); "xi" of an aux stage is its switching multiplier.  out[M][dim], dim = nv, nv, nu, nq,
+ * nv, 3 * max_point_contacts. */
+int idocp_parnmpc_get_new_solution_chain(idocp_ocp_t* h, const char* name, int instance, double* out);
 int idocp_ocp_get_chain(idocp_ocp_t* h, double t, int capacity, int* kind, int* index, int* slot,
                         double* dt, int* dimf, int* sw_dimi);
 /* TimeVaryingTaskSpace3DCost / TimeVaryingTaskSpace6DCost on a floating-base robot (src/cost/time_varying_task_space_3d_cost.cpp,

@@ -2017,6 +2017,23 @@ void ParNMPCSolver::linearizeImpulse(int p, const Mat& q_prev, const Mat& v_prev
       st += 3;
     }
   }
+  if (keep_uncondensed) {      // test hook (tests/golden/gen_golden_kkt_parnmpc_events.py): the un-condensed Newton system of this impulse stage
+    if ((int)unc.size() != nslots()) unc.assign(nslots(), UncondensedC());
+    UncondensedC& U = unc[i];
+    U = UncondensedC();
+    U.valid = true; U.kind = (int)nd.kind; U.dimf = dimf; U.dimi = dimf; U.has_u = 0; U.dt = 1; U.dtq = 0;
+    U.active_mask = 0; for (int c = 0; c < nc_; ++c) if (is.active[c]) U.active_mask |= 1 << c;
+    U.Qxx = M.Qxx; U.Qaa = I.Qdvdv; U.Qff = M.Qff;
+    U.lq = R.lq; U.lv = R.lv; U.la = R.la; U.lf = R.lf;
+    U.Fq = R.Fq; U.Fq.setSegment(0, R.Fq_prev);          // q_prev (-) q before condenseImpulseBackwardEuler premultiplied its base rows
+    U.Fv = R.Fv;                                         // v_prev - v + dv
+    U.Fqq = M.Fqq_prev6;                                 // dSubtractdConfigurationMinus(q_prev, q)
+    U.dIDCdqv = Mat(nv + dimf, 2 * nv);                  // [d ImD / dq, 0; Vq, Vv]
+    U.dIDCdqv.setBlock(0, 0, I.dImDdq);
+    if (dimf > 0) { U.dIDCdqv.setBlock(nv, 0, I.Vq); U.dIDCdqv.setBlock(nv, nv, I.Vv); }
+    U.M = I.dImDddv; U.J = I.Vv;
+    U.IDC = Mat(nv + dimf); U.IDC.setSegment(0, I.ImD); if (dimf > 0) U.IDC.setSegment(nv, R.P);
+  }
   // ---- condenseImpulseDynamics (:59-97)
   {
     LLT lltM;
@@ -2058,6 +2075,7 @@ void ParNMPCSolver::coarseUpdate(real t, const Mat& q, const Mat& v) {
     const SplitKKTResidualC& R = kkt_residual[i];
     if (p + 1 < Mc) M.Qxx += aux_mat[chain[p + 1].slot];
     else if (!has_terminal) M.Qxx += next_aux;
+    if (keep_uncondensed && (int)unc.size() == nslots()) unc[i].aux_next = p + 1 < Mc ? aux_mat[chain[p + 1].slot] : (!has_terminal ? next_aux : Mat(nx, nx));
     const bool impulse = nd.kind == NodeC::Impulse, aux = nd.kind == NodeC::Aux;
     const int ni = (impulse || aux) ? seq.impulse_status[nd.event].dimf() : 0;
     const int nw = impulse ? ni : nu, nQ = nw + nx, nr = nx + ni, nK = nr + nQ;

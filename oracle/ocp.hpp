@@ -127,6 +127,7 @@ struct UncondensedC {
   int kind = 0, dimf = 0, dimi = 0, has_u = 0, active_mask = 0;      // active_mask: bit c = contact c carries rows (impulse stages: the contacts of the impulse)
   real dt = 0, dtq = 0;
   Mat Qxx, Qaa, Qff, Quu, lq, lv, la, lf, lu, lu_passive, Fq, Fv, Fqq, Fqq_prev, dIDCdqv, M, J, IDC, Phix, Phia, P;
+  Mat aux_next;      // ParNMPC: what the coarse update adds to Qxx for the stage behind this one (BackwardCorrectionSolver::aux_mat_ of the next stage)
 };
 
 struct RiccatiC {

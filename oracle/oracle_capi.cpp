@@ -847,7 +847,7 @@ static int uncondensedField(const UncondensedC& U, const char* name, double* out
   const Mat* m = n == "Qxx" ? &U.Qxx : n == "Qaa" ? &U.Qaa : n == "Qff" ? &U.Qff : n == "Quu" ? &U.Quu : n == "lq" ? &U.lq : n == "lv" ? &U.lv : n == "la" ? &U.la
                : n == "lf" ? &U.lf : n == "lu" ? &U.lu : n == "lu_passive" ? &U.lu_passive : n == "Fq" ? &U.Fq : n == "Fv" ? &U.Fv : n == "Fqq" ? &U.Fqq
                : n == "Fqq_prev" ? &U.Fqq_prev : n == "dIDCdqv" ? &U.dIDCdqv : n == "M" ? &U.M : n == "J" ? &U.J : n == "IDC" ? &U.IDC : n == "Phix" ? &U.Phix
-               : n == "Phia" ? &U.Phia : n == "P" ? &U.P : nullptr;
+               : n == "Phia" ? &U.Phia : n == "P" ? &U.P : n == "aux_next" ? &U.aux_next : nullptr;
   if (!m) return -1;
   if (out) for (int i = 0; i < m->size(); ++i) out[i] = (double)m->d[i];
   return m->size();
@@ -893,16 +893,19 @@ int oracle_parnmpc_chain(void* h, double t, int capacity, int* kind, int* index,
 // solution / direction field along the chain: out[M][stride]  (a = dv, da = ddv on impulse stages)
 int oracle_parnmpc_get_chain(void* h, const char* name, int stride, double* out) {
   ParNMPCSolver* s = static_cast<ParNMPCSolver*>(h);
-  const std::string n(name);
+  const std::string name_in(name);
   const int nv = s->robot.dimv(), nc = s->robot.maxPointContacts();
   for (int p = 0; p < s->M(); ++p) {
     const ParNMPCSolver::PNode& nd = s->chain[p];
     double* o = out + (size_t)p * stride;
     for (int k = 0; k < stride; ++k) o[k] = 0.0;
-    const SplitSolutionC& x = s->s[nd.slot];
+    std::string n = name_in;
+    const bool coarse = n.rfind("new_", 0) == 0;      // "new_" + field: the coarse / corrected iterate s_new of the backward correction
+    const SplitSolutionC& x = coarse ? s->s_new[nd.slot] : s->s[nd.slot];
     const SplitDirectionC& d = s->d[nd.slot];
     const ContactStatus& cs = s->nodeContacts(nd);
     auto put = [&](const Mat& m) { for (int k = 0; k < m.size() && k < stride; ++k) o[k] = m[k]; };
+    if (coarse) n = n.substr(4);
     if (n == "q") put(x.q); else if (n == "v") put(x.v); else if (n == "a") put(x.a);
     else if (n == "u") { if (nd.kind != NodeC::Impulse) put(x.u); }
     else if (n == "lmd") put(x.lmd); else if (n == "gmm") put(x.gmm); else if (n == "beta") put(x.beta);

@@ -601,7 +601,8 @@ class OracleParNMPC:
         assert self.lib.oracle_parnmpc_set_task_refs(self.h, len(times), P(times), P(refs)) == 0
 
     def get_chain(self, name, M):
-        dim = OCP_SOL_FIELDS.get(name) or OCP_DIR_FIELDS.get(name) or {"xi": 12, "dxi": 12}[name]
+        base = name[4:] if name.startswith("new_") else name      # "new_" + field: the coarse / corrected iterate of the backward correction
+        dim = OCP_SOL_FIELDS.get(base) or OCP_DIR_FIELDS.get(base) or {"xi": 12, "dxi": 12}[base]
         out = np.zeros((M, dim))
         assert self.lib.oracle_parnmpc_get_chain(self.h, name.encode(), dim, P(out)) == 0
         return out

@@ -24,6 +24,7 @@ sys.path.insert(0, GOLDEN)
 import gen_golden_kkt as G      # noqa: E402
 import gen_golden_kkt_iiwa14 as GI      # noqa: E402
 import gen_golden_kkt_parnmpc as GP      # noqa: E402
+import gen_golden_kkt_parnmpc_events as GE      # noqa: E402
 
 TOL = 1e-9
 
@@ -202,3 +203,84 @@ def test_hip_parnmpc_stage_is_the_dense_stage_wise_newton_step():
         assert g.update(0.0, qm, vm) == 0
         for inst in (0, 1):
             compare_stage({f: g.get(f, inst)[0] for f in GP.FIELDS}, case, "HIP ParNMPC kernels (%s, instance %d)" % (name, inst))
+
+
+# ---- the ParNMPC stages of a horizon with events: tests/golden/kkt_parnmpc_events.json (gen_golden_kkt_parnmpc_events.py) ----
+# The coarse iterate of EVERY chain position (regular, aux with 3 / 6 / 12 switching rows, impulse with as many, lift, terminal; aux_mat of the stage behind,
+# the state of the stage in front) from dense solves of the stages' un-condensed systems, against the condensed route: backward-Euler condensation of the
+# contact / impulse dynamics, the premultiplied base rows, the block-wise KKT inverses (split_kkt_matrix_inverter.hxx:44-166,
+# impulse_split_kkt_matrix_inverter.hxx:34-80).
+
+def fixture_parnmpc_events():
+    with open(os.path.join(GOLDEN, "kkt_parnmpc_events.json")) as f:
+        return json.load(f)
+
+
+def compare_chain(have, case, what, tol=TOL):
+    worst = (-1.0, "", -1)
+    for f in GE.FIELDS:
+        want = np.array(case["iterate"][f])
+        assert have[f].shape == want.shape, (f, have[f].shape, want.shape)
+        for p in range(want.shape[0]):
+            worst = max(worst, (np.max(np.abs(have[f][p] - want[p])) / max(1.0, np.max(np.abs(want[p]))), f, p))
+    print("%s: worst field %s at chain position %d (%s): %.2e" % (what, worst[1], worst[2], case["stages"][worst[2]]["chain_kind"], worst[0]))
+    assert worst[0] < tol, "%s differs from the dense stage-wise Newton steps: %s at chain position %d by %.3e" % (what, worst[1], worst[2], worst[0])
+
+
+def test_parnmpc_event_chain_fixture_is_what_the_generator_produces_and_the_oracle_condensation_equals_it():
+    ref = fixture_parnmpc_events()
+    assert ref["spec"] == GE.problem_spec() and set(ref["cases"]) == set(GE.CASES)
+    kinds, rows = set(), set()
+    md = GE.model_dict()
+    for name, case in ref["cases"].items():
+        o, qm, vm = GE.build(ref["spec"], name, OracleParNMPC)
+        GE.prepare(o, qm, vm)
+        dense, infos = GE.coarse_iterates(o, md, qm)
+        assert [i["chain_kind"] for i in infos] == [i["chain_kind"] for i in case["stages"]]
+        compare_chain(dense, case, "regenerated dense solves (%s)" % name)
+        compare_chain({f: o.get_chain(f, len(infos)) for f in GE.FIELDS}, case, "oracle ParNMPCSolver, coarse update (%s)" % name)
+        kinds |= {i["chain_kind"] for i in infos}
+        rows |= {i["switching_rows"] for i in infos if i["switching_rows"]}
+    assert kinds == {"stage", "aux", "impulse", "lift", "terminal"} and rows == {3, 6, 12}
+
+
+@pytest.mark.gpu
+def test_hip_parnmpc_coarse_update_along_an_event_chain_is_the_dense_stage_wise_newton_step():
+    import ctypes as C
+    from idocp_amd import capi
+    from helpers import P, arr
+    ref = fixture_parnmpc_events()
+    for name, case in ref["cases"].items():
+        g, qm, vm = GE.build(ref["spec"], name, HipParNMPC, batch=2)
+        assert g.update(0.0, qm, vm) == 0
+        dq, dv = C.c_void_p(), C.c_void_p()
+        capi.check(g.lib.idocp_parnmpc_prev_state(g.h, C.byref(dq), C.byref(dv)), "prev_state")
+        qb, vb = arr(np.tile(qm, (2, 1))), arr(np.tile(vm, (2, 1)))
+        capi.check(g.lib.idocp_device_upload(dq, qb.ctypes.data, qb.nbytes), "upload q")
+        capi.check(g.lib.idocp_device_upload(dv, vb.ctypes.data, vb.nbytes), "upload v")
+        capi.check(g.lib.idocp_parnmpc_discretize(g.h, 0.0), "discretize")
+        for ph in (0, 1, 2):                                  # tangent RNEA, backward-Euler condensation, KKT inverse + coarse update
+            capi.check(g.lib.idocp_parnmpc_launch_phase(g.h, ph, dq, dv), "phase %d" % ph)
+        capi.check(g.lib.idocp_ocp_synchronize(g.h), "synchronize")
+        M = len(case["stages"])
+        for inst in (0, 1):
+            raw = {}
+            for f, dim in (("lmd", 18), ("gmm", 18), ("u", 12), ("q", 19), ("v", 18), ("xi", 12)):
+                out = np.zeros((M + 1, dim))
+                capi.check(g.lib.idocp_parnmpc_get_new_solution_chain(g.h, f.encode(), inst, P(out)), "get_new_solution_chain " + f)
+                raw[f] = out[:M]
+            # the fixture's layout: f / mu of an impulse stage in the slots of their contacts, the untouched ones as the iterate has them
+            cur_f, cur_mu = g.get_chain("f", M + 1, inst)[:M], g.get_chain("mu", M + 1, inst)[:M]
+            have = {"new_lmd": raw["lmd"], "new_gmm": raw["gmm"], "new_q": raw["q"], "new_v": raw["v"], "new_u": raw["u"].copy(),
+                    "new_xi": np.zeros((M, 12)), "new_f": cur_f.copy(), "new_mu": cur_mu.copy()}
+            for p, st in enumerate(case["stages"]):
+                if st["impulse"]:
+                    n = st["dimf"]
+                    landing = [c for c in range(4) if np.any(np.array(case["iterate"]["new_f"][p]).reshape(4, 3)[c] != cur_f[p].reshape(4, 3)[c])]
+                    assert 3 * len(landing) == n, (name, p, landing, n)
+                    rows = [3 * c + k for c in landing for k in range(3)]
+                    have["new_f"][p][rows], have["new_mu"][p][rows] = raw["u"][p][:n], raw["xi"][p][:n]
+                    have["new_u"][p] = 0.0
+                elif st["switching_rows"]:
+                    have["new_xi"][p][:st["switching_rows"]] = raw["xi"][p][:st["switching_rows"]]
+            compare_chain(have, case, "HIP ParNMPC kernels, coarse update (%s, instance %d)" % (name, inst))
