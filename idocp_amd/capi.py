@@ -119,6 +119,8 @@ def _proto(lib):
     if lib.idocp_abi_check(C.sizeof(Model), C.sizeof(Cost), C.sizeof(Constraints)) != 0:
         raise LibraryMissing("idocp_amd/capi.py structs do not match libidocp_hip.so (rebuild: python idocp_amd/build.py)")
     lib.idocp_model_contact_positions.argtypes = [P(Model), vp, vp]
+    lib.idocp_model_frame_world_placement.argtypes = [P(Model), vp, ci, vp, vp, vp, vp]
+    lib.idocp_model_frame_world_placement.restype = ci
     lib.idocp_model_contact_positions.restype = ci
     lib.idocp_model_integrate_configuration.argtypes = [P(Model), vp, vp, cd, vp]
     lib.idocp_model_integrate_configuration.restype = ci

@@ -43,12 +43,9 @@ void quatToRot(const double* qq, double* R) {     // xyzw
 
 }  // namespace
 
-extern "C" int idocp_model_contact_positions(const idocp_model_t* m, const double* q, double* points) {
-  if (m == nullptr || q == nullptr || points == nullptr) {
-    idocp_host::set_last_error("invalid argument: model, q and points must not be null!");
-    return IDOCP_E_ARG;
-  }
-  Xf world[IDOCP_MAX_JOINTS];
+namespace {
+// world placement of every joint frame at q
+void jointPlacements(const idocp_model_t* m, const double* q, Xf* world) {
   for (int i = 0; i < m->njoints; ++i) {
     Xf base;
     if (m->parent[i] < 0) {
@@ -69,10 +66,42 @@ extern "C" int idocp_model_contact_positions(const idocp_model_t* m, const doubl
     }
     compose(placed, Rj, pj, &world[i]);
   }
+}
+}  // namespace
+
+extern "C" int idocp_model_contact_positions(const idocp_model_t* m, const double* q, double* points) {
+  if (m == nullptr || q == nullptr || points == nullptr) {
+    idocp_host::set_last_error("invalid argument: model, q and points must not be null!");
+    return IDOCP_E_ARG;
+  }
+  Xf world[IDOCP_MAX_JOINTS];
+  jointPlacements(m, q, world);
   for (int c = 0; c < m->ncontacts; ++c) {
     Xf f;
     compose(world[m->contact_joint[c]], m->contact_R[c], m->contact_p[c], &f);
     for (int k = 0; k < 3; ++k) points[3 * c + k] = f.p[k];
   }
+  return IDOCP_OK;
+}
+
+// Robot::framePosition / frameRotation / framePlacement (robot.hxx:206-233) of a frame that sits on `joint` with the local placement (R_local, p_local)
+// -- what idocp_model_frame_placement returns for a frame id of the URDF.  R_world row-major [9], p_world [3].
+extern "C" int idocp_model_frame_world_placement(const idocp_model_t* m, const double* q, int joint, const double* R_local, const double* p_local,
+                                                 double* R_world, double* p_world) {
+  if (m == nullptr || q == nullptr || R_local == nullptr || p_local == nullptr || R_world == nullptr || p_world == nullptr) {
+    idocp_host::set_last_error("invalid argument: null pointer!");
+    return IDOCP_E_ARG;
+  }
+  if (joint < -1 || joint >= m->njoints) {
+    idocp_host::set_last_error("invalid argument: the frame's joint does not exist in this model!");
+    return IDOCP_E_ARG;
+  }
+  Xf world[IDOCP_MAX_JOINTS], f, root;
+  jointPlacements(m, q, world);
+  for (int k = 0; k < 9; ++k) root.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+  root.p[0] = root.p[1] = root.p[2] = 0.0;
+  compose(joint < 0 ? root : world[joint], R_local, p_local, &f);      // (joint -1: a frame fixed to the world)
+  for (int k = 0; k < 9; ++k) R_world[k] = f.R[k];
+  for (int k = 0; k < 3; ++k) p_world[k] = f.p[k];
   return IDOCP_OK;
 }

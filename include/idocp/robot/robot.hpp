@@ -13,6 +13,7 @@
 #include "idocp/eigen_shim.hpp"
 #include "idocp/robot/contact_status.hpp"
 #include "idocp/robot/impulse_status.hpp"
+#include "idocp/pinocchio_shim.hpp"
 #include "idocp_hip.h"
 
 namespace idocp {
@@ -62,11 +63,43 @@ class Robot {
       std::cerr << "invalid size: q.size() must be " << model_.nq << "!" << '\n';
       std::exit(EXIT_FAILURE);
     }
+    q_kin_.assign(q.data(), q.data() + model_.nq);
     points_.assign(3 * (size_t)model_.ncontacts, 0.0);
+    if (model_.ncontacts == 0) return;
     if (idocp_model_contact_positions(&model_, q.data(), points_.data()) != IDOCP_OK) {
       std::cerr << idocp_last_error() << '\n';
       std::exit(EXIT_FAILURE);
     }
+  }
+  // Robot::updateKinematics(q[, v[, a]]) (robot.hxx:166-203): the facade keeps the configuration for the frame queries below; velocities and accelerations of
+  // frames are evaluated inside the stage kernels and have no host-side query.
+  void updateKinematics(const Eigen::VectorXd& q) { updateFrameKinematics(q); }
+  void updateKinematics(const Eigen::VectorXd& q, const Eigen::VectorXd&) { updateFrameKinematics(q); }
+  void updateKinematics(const Eigen::VectorXd& q, const Eigen::VectorXd&, const Eigen::VectorXd&) { updateFrameKinematics(q); }
+  // Robot::framePosition / frameRotation / framePlacement (robot.hxx:206-233): of any frame of the URDF (pinocchio's frame numbering, as the
+  // contact frames and the task-space costs use it), at the configuration of the last updateFrameKinematics / updateKinematics
+  Eigen::Vector3d framePosition(const int frame_id) const { return framePlacement(frame_id).translation(); }
+  Eigen::Matrix3d frameRotation(const int frame_id) const { return framePlacement(frame_id).rotation(); }
+  pinocchio::SE3 framePlacement(const int frame_id) const {
+    if (q_kin_.empty()) { std::cerr << "invalid function call: call updateFrameKinematics(q) first!" << '\n'; std::exit(EXIT_FAILURE); }
+    int joint = 0;
+    double Rl[9], pl[3], Rw[9], pw[3];
+    ok(idocp_model_frame_placement(path_.c_str(), frame_id, &joint, Rl, pl));
+    ok(idocp_model_frame_world_placement(&model_, q_kin_.data(), joint, Rl, pl, Rw, pw));
+    Eigen::Matrix3d R;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R(r, c) = Rw[3 * r + c];
+    return pinocchio::SE3(R, Eigen::Vector3d(pw[0], pw[1], pw[2]));
+  }
+  // Robot::generateFeasibleConfiguration (robot.hxx:618-626): uniform between the joint position limits; the base, if any, uniform in [-1, 1]^3 with a
+  // uniformly random orientation
+  Eigen::VectorXd generateFeasibleConfiguration() const {
+    Eigen::VectorXd q(model_.nq);
+    auto uni = [](const double lo, const double hi) { return lo + (hi - lo) * (std::rand() / (double)RAND_MAX); };
+    const int nb = model_.has_floating_base ? 7 : 0;
+    for (int k = 0; k < nb; ++k) q[k] = uni(-1.0, 1.0);
+    for (int k = 0; k < model_.nu; ++k) q[nb + k] = uni(model_.q_min[k], model_.q_max[k]);      // (the model's limit arrays run over the actuated joints)
+    if (nb) ok(idocp_model_normalize_configuration(&model_, q.data()));
+    return q;
   }
   void getContactPoints(std::vector<Eigen::Vector3d>& contact_points) const {
     contact_points.resize(model_.ncontacts);
@@ -130,6 +163,7 @@ class Robot {
   idocp_model_t model_;
   std::string path_;
   std::vector<double> points_;     // contact-frame positions of the last updateFrameKinematics(q)
+  std::vector<double> q_kin_;      // that configuration (frame queries)
   double friction_[IDOCP_MAX_CONTACTS] = {0.8, 0.8, 0.8, 0.8}, restitution_[IDOCP_MAX_CONTACTS] = {0.0, 0.0, 0.0, 0.0};
   void noContacts() const {
     if (model_.ncontacts == 0) { std::cerr << "invalid function call: robot has no point contacts!" << '\n'; std::exit(EXIT_FAILURE); }

@@ -199,6 +199,11 @@ int idocp_model_frame_id(const char* path_to_urdf, const char* frame_name);
  * set-up before the contact sequence is built, examples/anymal/ocp_benchmark.cpp:
  * 104-106), not part of the hot path. */
 int idocp_model_contact_positions(const idocp_model_t* model, const double* q, double* points);
+/* Robot::framePosition / frameRotation / framePlacement (include/idocp/robot/robot.hxx:206-233) after updateFrameKinematics(q): world
+ * placement of a frame that sits on `joint` with the local placement (R_local row-major [9], p_local [3]) -- the pair
+ * idocp_model_frame_placement returns for a frame id of the URDF; joint -1 = fixed to the world.  Host arithmetic. */
+int idocp_model_frame_world_placement(const idocp_model_t* model, const double* q, int joint, const double* R_local,
+                                      const double* p_local, double* R_world, double* p_world);
 /* Robot::integrateConfiguration / subtractConfiguration / normalizeConfiguration (include/idocp/robot/robot.hxx:96-147), host
  * arithmetic: q_out[nq] = q (+) length v (SE(3) exponential on a floating base); diff[nv] = q_plus (-) q_minus
  * (pinocchio::difference(q_minus, q_plus)); the base quaternion of q scaled to unit length.  What an MPC loop does between

@@ -207,6 +207,30 @@ int main(int argc, char** argv) {
       for (int k = 3; k < 7; ++k) q2[k] *= 3.0;
       robot.normalizeConfiguration(q2);
       REQUIRE(maxDiff(q2, q1) < 1e-15);
+      {  // frame queries (robot.hxx:206-233): a contact frame's position is its contact point; a rotation is orthonormal; random configurations stay inside the limits
+        robot.updateKinematics(q1, v);
+        std::vector<Eigen::Vector3d> feet;
+        robot.getContactPoints(feet);
+        const std::vector<int> ids = robot.contactFramesIndices();
+        double off = 0.0, ortho = 0.0;
+        for (int c = 0; c < 4; ++c) {
+          const Eigen::Vector3d p = robot.framePosition(ids[c]);
+          for (int k = 0; k < 3; ++k) off = std::fmax(off, std::fabs(p[k] - feet[c][k]));
+        }
+        const pinocchio::SE3 X = robot.framePlacement(ids[2]);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+          double acc = 0.0;
+          for (int k = 0; k < 3; ++k) acc += X.rotation()(k, i) * X.rotation()(k, j);
+          ortho = std::fmax(ortho, std::fabs(acc - (i == j ? 1.0 : 0.0)));
+        }
+        REQUIRE(off < 1e-15 && ortho < 1e-14 && std::fabs(robot.frameRotation(ids[2])(1, 2) - X.rotation()(1, 2)) == 0.0);
+        const ex::Vec qr = robot.generateFeasibleConfiguration(), lo = robot.lowerJointPositionLimit(), hi = robot.upperJointPositionLimit();
+        bool inside = qr.size() == 19;
+        double nq = 0.0;
+        for (int k = 3; k < 7; ++k) nq += qr[k] * qr[k];
+        for (int k = 0; k < 12; ++k) inside = inside && qr[7 + k] >= lo[k] && qr[7 + k] <= hi[k];
+        REQUIRE(inside && std::fabs(nq - 1.0) < 1e-14);
+      }
       {  // ImpulseStatus (impulse_status.hpp): the contacts that BECOME active between two statuses
         idocp::ImpulseStatus imp = robot.createImpulseStatus();
         idocp::ContactStatus pre = robot.createContactStatus(), post = robot.createContactStatus();

@@ -65,3 +65,34 @@ def test_normalize_configuration():
     capi.check(lib.idocp_model_normalize_configuration(C.byref(mi), P(qi)), "normalize")
     assert np.array_equal(qi, keep)
     assert lib.idocp_model_integrate_configuration(C.byref(mi), None, P(qi), 1.0, P(qi)) != 0
+
+
+def test_frame_world_placement_matches_the_independent_frame_kinematics():
+    """Robot::framePosition / frameRotation / framePlacement of the facade: idocp_model_frame_placement (frame id -> joint + local placement) followed by
+    idocp_model_frame_world_placement, against the forward kinematics of tests/golden/gen_golden_rbd.py (its own URDF walk and frame numbering) -- EVERY
+    frame of both URDFs that sits on a joint; the ones fixed to the world have no joint to report and are refused."""
+    import sys
+    from helpers import ANYMAL_CONTACT_FRAMES, ANYMAL_URDF, GOLDEN, IIWA_URDF
+    sys.path.insert(0, GOLDEN)
+    import gen_golden_rbd as RBD
+    lib = capi.lib()
+    rng = np.random.default_rng(77)
+    for urdf, contact_frames in ((ANYMAL_URDF, ANYMAL_CONTACT_FRAMES), (IIWA_URDF, ())):
+        m = capi.model_from_urdf(urdf, contact_frames)
+        every = RBD.load_model(urdf)["frames"]
+        frames = [fid for fid, fr in enumerate(every) if fr[1] >= 0]
+        assert len(frames) >= 15 and set(contact_frames) <= set(frames)
+        M = RBD.load_model(urdf, frames)                   # (the generator treats the frames asked for as its "contacts")
+        joint = C.c_int()
+        Rl, pl, Rw, pw = np.zeros(9), np.zeros(3), np.zeros(9), np.zeros(3)
+        for fid, fr in enumerate(every):
+            if fr[1] < 0:
+                assert lib.idocp_model_frame_placement(urdf.encode(), fid, C.byref(joint), P(Rl), P(pl)) != 0
+        for _ in range(2):
+            q = RBD.random_q(M, rng)
+            want = RBD.frame_kinematics(M, q, np.zeros(M["nv"]), np.zeros(M["nv"]))
+            for fid, w in zip(frames, want):
+                assert lib.idocp_model_frame_placement(urdf.encode(), fid, C.byref(joint), P(Rl), P(pl)) == 0
+                assert lib.idocp_model_frame_world_placement(C.byref(m), P(arr(q)), joint.value, P(Rl), P(pl), P(Rw), P(pw)) == 0
+                assert np.abs(pw - w["p"]).max() < 1e-13 and np.abs(Rw.reshape(3, 3) - w["R"]).max() < 1e-13, (urdf, fid)
+    assert lib.idocp_model_frame_world_placement(C.byref(m), P(arr(q)), 99, P(Rl), P(pl), P(Rw), P(pw)) != 0

@@ -56,7 +56,7 @@ def other_quadruped(seed):
             m.contact_R[c][k] = float(R.reshape(-1)[k])
         for k in range(3):
             m.contact_p[c][k] = float(m.contact_p[c][k] * rng.uniform(0.8, 1.2) + rng.uniform(-0.01, 0.01))
-    for k in range(6, m.nv):
+    for k in range(m.nu):                                     # (the limit arrays run over the actuated joints)
         m.q_min[k], m.q_max[k] = float(m.q_min[k] * rng.uniform(0.8, 1.2)), float(m.q_max[k] * rng.uniform(0.8, 1.2))
         m.v_max[k], m.u_max[k] = float(m.v_max[k] * rng.uniform(0.7, 1.3)), float(m.u_max[k] * rng.uniform(0.7, 1.3))
     return m, rng
