@@ -957,12 +957,13 @@ int idocp_rnea_derivatives(const idocp_model_t* model, int n, const double* q, c
   HIP_TRY(hipSetDevice(device));
   const int nv = model->nv;
   DevModel dm; toDevModel(*model, dm);
-  DevModel* d_m; double *d_q, *d_v, *d_a, *d_tau, *d_dq, *d_dv, *d_da;
-  HIP_TRY(hipMalloc((void**)&d_m, sizeof(dm)));
-  HIP_TRY(hipMalloc((void**)&d_q, sizeof(double) * n * nv)); HIP_TRY(hipMalloc((void**)&d_v, sizeof(double) * n * nv));
-  HIP_TRY(hipMalloc((void**)&d_a, sizeof(double) * n * nv)); HIP_TRY(hipMalloc((void**)&d_tau, sizeof(double) * n * nv));
-  HIP_TRY(hipMalloc((void**)&d_dq, sizeof(double) * n * nv * nv)); HIP_TRY(hipMalloc((void**)&d_dv, sizeof(double) * n * nv * nv));
-  HIP_TRY(hipMalloc((void**)&d_da, sizeof(double) * n * nv * nv));
+  // one allocation, released on every way out of this function
+  struct Scratch { void* p = nullptr; ~Scratch() { if (p) (void)hipFree(p); } } scratch;
+  const size_t nvec = (size_t)n * nv, nmat = nvec * nv, model_doubles = (sizeof(dm) + sizeof(double) - 1) / sizeof(double);
+  HIP_TRY(hipMalloc(&scratch.p, sizeof(double) * (model_doubles + 4 * nvec + 3 * nmat)));
+  double* base = static_cast<double*>(scratch.p);
+  DevModel* d_m = reinterpret_cast<DevModel*>(base);
+  double *d_q = base + model_doubles, *d_v = d_q + nvec, *d_a = d_v + nvec, *d_tau = d_a + nvec, *d_dq = d_tau + nvec, *d_dv = d_dq + nmat, *d_da = d_dv + nmat;
   HIP_TRY(hipMemcpy(d_m, &dm, sizeof(dm), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * n * nv, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_v, v, sizeof(double) * n * nv, hipMemcpyHostToDevice));
@@ -976,8 +977,6 @@ int idocp_rnea_derivatives(const idocp_model_t* model, int n, const double* q, c
   HIP_TRY(hipMemcpy(dtau_dq, d_dq, sizeof(double) * n * nv * nv, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(dtau_dv, d_dv, sizeof(double) * n * nv * nv, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(dtau_da, d_da, sizeof(double) * n * nv * nv, hipMemcpyDeviceToHost));
-  (void)hipFree(d_m); (void)hipFree(d_q); (void)hipFree(d_v); (void)hipFree(d_a); (void)hipFree(d_tau);
-  (void)hipFree(d_dq); (void)hipFree(d_dv); (void)hipFree(d_da);
   return IDOCP_OK;
 }
 
