@@ -1797,6 +1797,25 @@ int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n) {
   return IDOCP_OK;
 }
 
+// ContactDynamicsData of a grid stage as the condensation kernel left it (contact_dynamics_data.hxx:8-29: MJtJinv, MJtJinv_dIDCdqv, MJtJinv_IDC), dense and
+// column-major with n = nv + dimf rows (the active contacts packed): what the parity tests hold to the INDEPENDENT rigid-body vectors of tests/golden
+// (M, J and the derivatives of [ID; C] follow from these three by one inverse).  Returns dimf, or a negative error code.
+int idocp_ocp_get_contact_dynamics(idocp_ocp_t* h, int instance, int stage, double* MJtJinv, double* MJtJinv_dIDCdqv, double* MJtJinv_IDC) {
+  if (!h || !MJtJinv || !MJtJinv_dIDCdqv || !MJtJinv_IDC || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
+  int dimf = -1;
+  for (const OcpNode& nd : h->chain) if (nd.kind == 0 && nd.slot == stage) dimf = nd.dimf;
+  if (dimf < 0) { set_last_error("idocp_ocp_get_contact_dynamics: stage " + std::to_string(stage) + " is not a grid stage of the current discretisation"); return IDOCP_E_ARG; }
+  int rc = setDev(h); if (rc) return rc;
+  std::vector<double> e(LQ::EXP);
+  HIP_TRY(hipMemcpyAsync(e.data(), h->B.exp + ((size_t)instance * h->NS + stage) * LQ::EXP, e.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int n = DQ::NV + dimf;
+  for (int c = 0; c < n; ++c) for (int r = 0; r < n; ++r) MJtJinv[r + n * c] = r >= c ? e[LQ::E_MJ + r * (r + 1) / 2 + c] : e[LQ::E_MJ + c * (c + 1) / 2 + r];      // (packed lower triangle)
+  for (int c = 0; c < DQ::NX; ++c) for (int r = 0; r < n; ++r) MJtJinv_dIDCdqv[r + n * c] = e[LQ::E_MJD + r + DQ::NVF * c];
+  for (int r = 0; r < n; ++r) MJtJinv_IDC[r] = e[LQ::E_MJIDC + r];
+  return dimf;
+}
+
 int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu, double* Quu, double* A, double* Bm,
                             double* lx, double* lu, double* Fx) {
   if (!h || instance < 0 || instance >= h->batch || stage < 0 || stage >= h->Ngrid) return IDOCP_E_ARG;

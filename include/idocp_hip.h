@@ -545,6 +545,11 @@ int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* w
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual);
 /* Condensed LQR data of one stage after the linearisation kernels (parity tests):
  * Qxx[2nv*2nv], Qxu[2nv*nu], Quu[nu*nu], A[2nv*2nv], B[2nv*nu], lx[2nv], lu[nu], Fx[2nv]. */
+/* ContactDynamicsData of a grid stage after the condensation (include/idocp/ocp/contact_dynamics_data.hxx:8-29): MJtJinv [n * n], MJtJinv_dIDCdqv
+ * [n * 2 nv], MJtJinv_IDC [n], dense column-major with n = nv + dimf rows (the rows of the active contacts packed).  Returns dimf (>= 0) or an
+ * error code (< 0).  For tests: M, J and the derivatives of [ID; C] follow from the three by one inverse. */
+int idocp_ocp_get_contact_dynamics(idocp_ocp_t* h, int instance, int stage, double* MJtJinv, double* MJtJinv_dIDCdqv,
+                                   double* MJtJinv_IDC);
 int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu,
                             double* Quu, double* A, double* B, double* lx, double* lu,
                             double* Fx);
