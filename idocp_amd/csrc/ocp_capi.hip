@@ -1797,6 +1797,36 @@ int idocp_ocp_get_profile(idocp_ocp_t* h, long long* out, int n) {
   return IDOCP_OK;
 }
 
+// The inverse of idocp_ocp_get_lqr_stage, for every instance: the condensed LQR stage the backward sweep reads (its kkt record), so that a test can run
+// the sweep alone on a problem whose answer it knows (tests/test_golden_riccati.py: the dense KKT solution of a random LQR problem in the reference's
+// block structure).  Column-major blocks; terminal != 0: Qxx and lx only.
+int idocp_ocp_set_lqr_stage(idocp_ocp_t* h, int stage, int terminal, const double* Qxx, const double* Qxu, const double* Quu, const double* Fqq6,
+                            const double* Fqv6, const double* Fvq, const double* Fvv, const double* Fvu, const double* lx, const double* lu,
+                            const double* Fx) {
+  if (!h || !Qxx || !lx || stage < 0 || stage > h->Ngrid) return IDOCP_E_ARG;
+  if (!terminal && (!Qxu || !Quu || !Fqq6 || !Fqv6 || !Fvq || !Fvv || !Fvu || !lu || !Fx)) return IDOCP_E_ARG;
+  int rc = setDev(h); if (rc) return rc;
+  const int nv = DQ::NV, nx = DQ::NX, nu = DQ::NU;
+  std::vector<double> k(LQ::KKT, 0.0);
+  for (int c = 0; c < nx; ++c) for (int r = 0; r <= c; ++r) k[LQ::K_QXX + LQ::xsym(r, c)] = Qxx[c * nx + r];
+  std::memcpy(&k[LQ::K_LX], lx, sizeof(double) * nx);
+  if (!terminal) {
+    std::memcpy(&k[LQ::K_QXU], Qxu, sizeof(double) * nx * nu);
+    std::memcpy(&k[LQ::K_QUU], Quu, sizeof(double) * nu * nu);
+    std::memcpy(&k[LQ::K_FQQ], Fqq6, sizeof(double) * 36);
+    std::memcpy(&k[LQ::K_FQV], Fqv6, sizeof(double) * 36);
+    std::memcpy(&k[LQ::K_FVQ], Fvq, sizeof(double) * nv * nv);
+    std::memcpy(&k[LQ::K_FVV], Fvv, sizeof(double) * nv * nv);
+    std::memcpy(&k[LQ::K_FVU], Fvu, sizeof(double) * nv * nu);
+    std::memcpy(&k[LQ::K_LU], lu, sizeof(double) * nu);
+    std::memcpy(&k[LQ::K_FX], Fx, sizeof(double) * nx);
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (long b = 0; b < h->batch; ++b)
+    HIP_TRY(hipMemcpy(h->B.kkt + ((size_t)b * h->NS + stage) * LQ::KKT, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+  return IDOCP_OK;
+}
+
 // ContactDynamicsData of a grid stage as the condensation kernel left it (contact_dynamics_data.hxx:8-29: MJtJinv, MJtJinv_dIDCdqv, MJtJinv_IDC), dense and
 // column-major with n = nv + dimf rows (the active contacts packed): what the parity tests hold to the INDEPENDENT rigid-body vectors of tests/golden
 // (M, J and the derivatives of [ID; C] follow from these three by one inverse).  Returns dimf, or a negative error code.

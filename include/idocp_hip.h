@@ -545,6 +545,13 @@ int idocp_ocp_is_current_solution_feasible(idocp_ocp_t* h, int* feasible, int* w
 int idocp_ocp_get_constraint_data(idocp_ocp_t* h, int instance, double* slack, double* dual);
 /* Condensed LQR data of one stage after the linearisation kernels (parity tests):
  * Qxx[2nv*2nv], Qxu[2nv*nu], Quu[nu*nu], A[2nv*2nv], B[2nv*nu], lx[2nv], lu[nu], Fx[2nv]. */
+/* The inverse of idocp_ocp_get_lqr_stage, for every instance of the handle: writes the condensed LQR stage the backward Riccati sweep reads
+ * (SplitKKTMatrix / SplitKKTResidual after condensation, split_kkt_matrix.hxx, split_kkt_residual.hxx).  Blocks column-major: Qxx [2nv x 2nv], Qxu
+ * [2nv x nu], Quu [nu x nu], Fqq6 / Fqv6 [6 x 6] (the base blocks of Fqq, Fqv), Fvq, Fvv [nv x nv], Fvu [nv x nu], lx [2nv], lu [nu], Fx [2nv];
+ * terminal != 0: Qxx and lx only.  For tests that run the sweep alone (idocp_ocp_launch_kernel id 2) on a problem with a known answer. */
+int idocp_ocp_set_lqr_stage(idocp_ocp_t* h, int stage, int terminal, const double* Qxx, const double* Qxu, const double* Quu,
+                            const double* Fqq6, const double* Fqv6, const double* Fvq, const double* Fvv, const double* Fvu,
+                            const double* lx, const double* lu, const double* Fx);
 /* ContactDynamicsData of a grid stage after the condensation (include/idocp/ocp/contact_dynamics_data.hxx:8-29): MJtJinv [n * n], MJtJinv_dIDCdqv
  * [n * 2 nv], MJtJinv_IDC [n], dense column-major with n = nv + dimf rows (the rows of the active contacts packed).  Returns dimf (>= 0) or an
  * error code (< 0).  For tests: M, J and the derivatives of [ID; C] follow from the three by one inverse. */
