@@ -272,6 +272,7 @@ def _proto(lib):
         ("idocp_ocp_set_solution_chain", [vp, C.c_char_p, ci, c_double_p]),
         ("idocp_parnmpc_set_aux_mat_chain", [vp, ci, c_double_p]),
         ("idocp_ocp_get_contact_dynamics", [vp, ci, ci, c_double_p, c_double_p, c_double_p]),
+        ("idocp_ocp_get_contact_dynamics_chain", [vp, ci, ci, c_double_p, c_double_p, c_double_p]),
         ("idocp_ocp_set_lqr_stage", [vp, ci, ci] + [c_double_p] * 11),
         ("idocp_parnmpc_get_new_solution_chain", [vp, C.c_char_p, ci, c_double_p]),
         ("idocp_parnmpc_get_aux_mat_chain", [vp, ci, c_double_p]),

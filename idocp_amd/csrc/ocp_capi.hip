@@ -1830,11 +1830,23 @@ int idocp_ocp_set_lqr_stage(idocp_ocp_t* h, int stage, int terminal, const doubl
 // ContactDynamicsData of a grid stage as the condensation kernel left it (contact_dynamics_data.hxx:8-29: MJtJinv, MJtJinv_dIDCdqv, MJtJinv_IDC), dense and
 // column-major with n = nv + dimf rows (the active contacts packed): what the parity tests hold to the INDEPENDENT rigid-body vectors of tests/golden
 // (M, J and the derivatives of [ID; C] follow from these three by one inverse).  Returns dimf, or a negative error code.
+static int getContactDynamics(idocp_ocp_t* h, int instance, int stage, int dimf, double* MJtJinv, double* MJtJinv_dIDCdqv, double* MJtJinv_IDC);
 int idocp_ocp_get_contact_dynamics(idocp_ocp_t* h, int instance, int stage, double* MJtJinv, double* MJtJinv_dIDCdqv, double* MJtJinv_IDC) {
   if (!h || !MJtJinv || !MJtJinv_dIDCdqv || !MJtJinv_IDC || instance < 0 || instance >= h->batch) return IDOCP_E_ARG;
   int dimf = -1;
   for (const OcpNode& nd : h->chain) if (nd.kind == 0 && nd.slot == stage) dimf = nd.dimf;
   if (dimf < 0) { set_last_error("idocp_ocp_get_contact_dynamics: stage " + std::to_string(stage) + " is not a grid stage of the current discretisation"); return IDOCP_E_ARG; }
+  return getContactDynamics(h, instance, stage, dimf, MJtJinv, MJtJinv_dIDCdqv, MJtJinv_IDC);
+}
+// the same by chain position: any stage that has dynamics -- grid, aux, lift, and IMPULSE stages (ImpulseDynamicsForwardEulerData,
+// impulse_dynamics_forward_euler_data.hxx: MJtJinv of the impulse's contacts, the blocks of [ImD; V] in place of [ID; C])
+int idocp_ocp_get_contact_dynamics_chain(idocp_ocp_t* h, int instance, int position, double* MJtJinv, double* MJtJinv_dIDCdqv, double* MJtJinv_IDC) {
+  if (!h || !MJtJinv || !MJtJinv_dIDCdqv || !MJtJinv_IDC || instance < 0 || instance >= h->batch || position < 0 || position >= h->M()) return IDOCP_E_ARG;
+  const OcpNode& nd = h->chain[position];
+  if (nd.kind == 4) { set_last_error("idocp_ocp_get_contact_dynamics_chain: the terminal stage has no dynamics"); return IDOCP_E_ARG; }
+  return getContactDynamics(h, instance, nd.slot, nd.dimf, MJtJinv, MJtJinv_dIDCdqv, MJtJinv_IDC);
+}
+static int getContactDynamics(idocp_ocp_t* h, int instance, int stage, int dimf, double* MJtJinv, double* MJtJinv_dIDCdqv, double* MJtJinv_IDC) {
   int rc = setDev(h); if (rc) return rc;
   std::vector<double> e(LQ::EXP);
   HIP_TRY(hipMemcpyAsync(e.data(), h->B.exp + ((size_t)instance * h->NS + stage) * LQ::EXP, e.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -557,6 +557,10 @@ int idocp_ocp_set_lqr_stage(idocp_ocp_t* h, int stage, int terminal, const doubl
  * error code (< 0).  For tests: M, J and the derivatives of [ID; C] follow from the three by one inverse. */
 int idocp_ocp_get_contact_dynamics(idocp_ocp_t* h, int instance, int stage, double* MJtJinv, double* MJtJinv_dIDCdqv,
                                    double* MJtJinv_IDC);
+/* The same by position in the chain of the current discretisation: grid, aux, lift and IMPULSE stages (there: ImpulseDynamicsForwardEulerData,
+ * include/idocp/impulse/impulse_dynamics_forward_euler_data.hxx -- MJtJinv over the impulse's contacts, the blocks of [ImD; V] in place of [ID; C]). */
+int idocp_ocp_get_contact_dynamics_chain(idocp_ocp_t* h, int instance, int position, double* MJtJinv, double* MJtJinv_dIDCdqv,
+                                         double* MJtJinv_IDC);
 int idocp_ocp_get_lqr_stage(idocp_ocp_t* h, int instance, int stage, double* Qxx, double* Qxu,
                             double* Quu, double* A, double* B, double* lx, double* lu,
                             double* Fx);

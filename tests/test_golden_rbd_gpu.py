@@ -75,3 +75,42 @@ def test_baumgarte_terms_and_mjtjinv_against_the_independent_vectors():
             worst = max(worst, *errs)
             assert max(errs) < 1e-11, errs
     print("MJtJinv, C, dC/dq, dC/dv, J against the independent vectors: worst %.2e" % worst)
+
+
+def test_impulse_dynamics_against_the_independent_vectors():
+    """rbd_anymal.json `tau_impulse`, `dimp_dq`, `dimp_ddv`: Robot::RNEAImpulse(+Derivatives) (robot.hxx:505-540) -- zero gravity, v = 0, a = dv, the impulse
+    forces on all four feet -- as the impulse instantiation of the condensation kernel computes them on the impulse stage of a landing out of a flight phase."""
+    with open(os.path.join(GOLDEN, "rbd_anymal.json")) as fh:
+        gold = json.load(fh)
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    worst = 0.0
+    for s in gold["samples"]:
+        g = HipOCP(m, cost, cons, 0.2, 4, batch=2, max_num_impulse=1)
+        q, v, a = arr(s["q"]), arr(s["v"]), arr(s["a"])
+        pts = np.zeros((4, 3))
+        g.set_contact_status([0, 0, 0, 0], pts)
+        g.push_back_contact_status([1, 1, 1, 1], pts, 0.12)
+        g.set_solution("q", q)
+        g.set_solution("v", v)
+        g.set_solution("a", a)                                # (dv of the impulse stage: ocp_solver.cpp:116-123)
+        g.set_solution("u", np.zeros(12))
+        g.init_constraints(0.0)
+        chain = g.chain(0.0)
+        pos = [c["kind"] for c in chain].index("impulse")
+        M = len(chain)
+        f = np.zeros((M, 12))
+        f[:] = arr(s["f"]).reshape(-1)
+        capi.check(g.lib.idocp_ocp_set_solution_chain(g.h, b"f", M, P(arr(f))), "set f along the chain")
+        assert g.update(0.0, q, v) == 0, capi.lib().idocp_last_error()
+        n = NV + NF
+        for inst in (0, 1):
+            MJ, MJD, MJIDC = np.zeros(n * n), np.zeros(n * 2 * NV), np.zeros(n)
+            assert g.lib.idocp_ocp_get_contact_dynamics_chain(g.h, inst, pos, P(MJ), P(MJD), P(MJIDC)) == NF
+            K = np.linalg.inv(MJ.reshape(n, n).T)
+            dImD, ImD = K @ MJD.reshape(2 * NV, n).T, K @ MJIDC
+            errs = (rel_err(ImD[:NV], s["tau_impulse"]), rel_err(dImD[:NV, :NV], s["dimp_dq"]), rel_err(K[:NV, :NV], s["dimp_ddv"]),
+                    float(np.abs(dImD[:NV, NV:]).max()))      # (no velocity in the impulse dynamics)
+            worst = max(worst, *errs)
+            assert max(errs) < 1e-11, errs
+    print("ImD, dImD/dq, M on the impulse stage against the independent vectors: worst %.2e" % worst)
