@@ -96,3 +96,24 @@ def test_frame_world_placement_matches_the_independent_frame_kinematics():
                 assert lib.idocp_model_frame_world_placement(C.byref(m), P(arr(q)), joint.value, P(Rl), P(pl), P(Rw), P(pw)) == 0
                 assert np.abs(pw - w["p"]).max() < 1e-13 and np.abs(Rw.reshape(3, 3) - w["R"]).max() < 1e-13, (urdf, fid)
     assert lib.idocp_model_frame_world_placement(C.byref(m), P(arr(q)), 99, P(Rl), P(pl), P(Rw), P(pw)) != 0
+
+
+def test_host_lie_operations_match_the_independent_vectors():
+    """The product's host integrate / subtract against tests/golden/contact_anymal.json (gen_golden_rbd.py: SE(3) exponential and logarithm written out on
+    their own) -- no restatement in between."""
+    import json
+    import os
+    from helpers import GOLDEN
+    with open(os.path.join(GOLDEN, "contact_anymal.json")) as fh:
+        gold = json.load(fh)
+    m = anymal_model()
+    lib = capi.lib()
+    for s in gold["samples"]:
+        q, q1, dv = arr(s["q"]), arr(s["q1"]), arr(s["dv"])
+        qi, diff = np.zeros(m.nq), np.zeros(m.nv)
+        assert lib.idocp_model_integrate_configuration(C.byref(m), P(q), P(dv), 1.0, P(qi)) == 0
+        assert lib.idocp_model_subtract_configuration(C.byref(m), P(q1), P(q), P(diff)) == 0
+        want = arr(s["q_plus_dv"])
+        if np.dot(want[3:7], qi[3:7]) < 0:
+            want[3:7] *= -1                    # quaternion double cover
+        assert np.abs(qi - want).max() < 1e-13 and np.abs(diff - arr(s["q1_minus_q"])).max() < 1e-12
