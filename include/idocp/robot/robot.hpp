@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <iostream>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -82,10 +83,14 @@ class Robot {
   Eigen::Matrix3d frameRotation(const int frame_id) const { return framePlacement(frame_id).rotation(); }
   pinocchio::SE3 framePlacement(const int frame_id) const {
     if (q_kin_.empty()) { std::cerr << "invalid function call: call updateFrameKinematics(q) first!" << '\n'; std::exit(EXIT_FAILURE); }
-    int joint = 0;
-    double Rl[9], pl[3], Rw[9], pw[3];
-    ok(idocp_model_frame_placement(path_.c_str(), frame_id, &joint, Rl, pl));
-    ok(idocp_model_frame_world_placement(&model_, q_kin_.data(), joint, Rl, pl, Rw, pw));
+    auto it = frames_.find(frame_id);                      // (where the frame sits is read from the URDF once per frame)
+    if (it == frames_.end()) {
+      FrameLocation loc;
+      ok(idocp_model_frame_placement(path_.c_str(), frame_id, &loc.joint, loc.R, loc.p));
+      it = frames_.emplace(frame_id, loc).first;
+    }
+    double Rw[9], pw[3];
+    ok(idocp_model_frame_world_placement(&model_, q_kin_.data(), it->second.joint, it->second.R, it->second.p, Rw, pw));
     Eigen::Matrix3d R;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R(r, c) = Rw[3 * r + c];
     return pinocchio::SE3(R, Eigen::Vector3d(pw[0], pw[1], pw[2]));
@@ -164,6 +169,8 @@ class Robot {
   std::string path_;
   std::vector<double> points_;     // contact-frame positions of the last updateFrameKinematics(q)
   std::vector<double> q_kin_;      // that configuration (frame queries)
+  struct FrameLocation { int joint; double R[9], p[3]; };
+  mutable std::map<int, FrameLocation> frames_;
   double friction_[IDOCP_MAX_CONTACTS] = {0.8, 0.8, 0.8, 0.8}, restitution_[IDOCP_MAX_CONTACTS] = {0.0, 0.0, 0.0, 0.0};
   void noContacts() const {
     if (model_.ncontacts == 0) { std::cerr << "invalid function call: robot has no point contacts!" << '\n'; std::exit(EXIT_FAILURE); }
