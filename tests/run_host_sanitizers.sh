@@ -2,7 +2,7 @@
 # The HOST side of the library (URDF reader, model helpers, discretiser, argument checks, error paths, the C ABI's bookkeeping) under AddressSanitizer +
 # UBSan: every source compiled with host instrumentation (`-fsanitize=address,undefined -fno-gpu-sanitize`: the device code is NOT instrumented -- GPU ASan is
 # not available on this pool), linked into build/asan/libidocp_hip_asan.so, and the whole `-m "not gpu"` suite run against it (IDOCP_HIP_LIB).  CPU only.
-# Round 6: 92 passed, no report (the URDF reader after its two fixes: unbounded recursion on a truncated closing tag, non-finite numbers accepted).
+# Round 6: 114 passed, no report (the URDF reader after its two fixes: unbounded recursion on a truncated closing tag, non-finite numbers accepted).
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/asan
