@@ -313,3 +313,63 @@ def test_first_direction_on_random_fixed_base_problems(seed):
         for x, y in zip(g.riccati(2), o.riccati()):
             assert rel_err(x, y) <= TOL
     print("seed %d  %s  N %d  task %s  acceleration limits %s  worst %.2e" % (seed, "UnParNMPC" if par else "UnOCP", N, (dim if task else "-"), bool(seed % 3 == 0), worst))
+
+
+@pytest.mark.parametrize("solver", ["ocp", "parnmpc"])
+def test_a_ragged_batch_of_different_instances(solver, monkeypatch):
+    """70 instances with states of their own along an event chain: 70 x 17 chain stages are neither a multiple of a wavefront's 64 lanes (the nominal sweeps carry
+    one stage per lane) nor of anything else; both sweeps run in their throughput forms (one wavefront per instance, fused forward sweep -- the latter would start at
+    batch 192 by itself and is switched on here).  Instances at the seams -- 0, 31, 63, 64, 69 -- against an oracle each, first direction along the whole chain."""
+    from helpers import force_forms
+    force_forms(monkeypatch, fused=1, sweep=0)
+    rng = np.random.default_rng(7070)
+    m = anymal_model()
+    cost, cons = anymal_problem(m, trotting_ref=False)
+    pts = anymal_contact_points(m)
+    N, dt, B = 13, 0.03, 70
+    par = solver == "parnmpc"
+    Hip, Orc = (HipParNMPC, OracleParNMPC) if par else (HipOCP, OracleOCP)
+    g = Hip(m, cost, cons, N * dt, N, batch=B, max_num_impulse=2)
+    events = [([1, 0, 1, 1], 3.4 * dt), ([1, 1, 1, 1], 8.7 * dt)]
+    qs = np.tile(ANYMAL_Q_STANDING, (B, 1))
+    qs[:, 7:] += rng.uniform(-0.08, 0.08, (B, 12))
+    qs[:, 0:3] += rng.uniform(-0.03, 0.03, (B, 3))
+    quat = qs[:, 3:7] + rng.uniform(-0.03, 0.03, (B, 4))
+    qs[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    vs = rng.uniform(-0.15, 0.15, (B, m.nv))
+    fz = [0, 0, 0.25 * (-m.total_mass * m.gravity[2])]
+
+    def prepare(s):
+        s.set_contact_status([1, 1, 1, 1], pts)
+        for status, when in events:
+            s.push_back_contact_status(status, pts, when)
+        s.set_solution("q", ANYMAL_Q_STANDING)
+        s.set_solution("v", np.zeros(m.nv))
+        s.set_solution("f", fz)
+        s.init(0.0) if par else s.init_constraints(0.0)
+
+    prepare(g)
+    if not par:
+        assert g.lib.idocp_ocp_riccati_sweep(g.h) == 0 and g.lib.idocp_ocp_fused_forward(g.h) == 1      # the throughput forms
+    assert g.update(0.0, qs, vs) == 0
+    worst = 0.0
+    for b in (0, 31, 63, 64, 69):
+        o, h = Orc(m, cost, cons, N * dt, N, max_num_impulse=2), Orc(m, cost, cons, N * dt, N, max_num_impulse=2, hp=True)
+        prepare(o)
+        prepare(h)
+        assert o.update(0.0, qs[b], vs[b]) == 0
+        M = len(o.chain(0.0))
+        ran = []
+
+        def referee(name, h=h, b=b, M=M, ran=ran):
+            if not ran:
+                assert h.update(0.0, qs[b], vs[b]) == 0
+                ran.append(1)
+            return h.get_chain(name, M)
+
+        keep = np.array([c["kind"] != "impulse" for c in o.chain(0.0)])
+        for name in OCP_DIR_FIELDS:
+            k = keep if (par and name in ("du", "dnu_passive")) else np.ones(M, bool)
+            have = g.get_chain(name, M + (1 if par else 0), b)[:M][k]
+            worst = max(worst, parity(have, o.get_chain(name, M)[k], lambda name=name, k=k: referee(name)[k], (solver, b, name), tol=TOL, cap=1e-6))
+    print("%s, 70 different instances: worst of five %.2e" % (solver, worst))
