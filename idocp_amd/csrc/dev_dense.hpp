@@ -672,13 +672,16 @@ __device__ __forceinline__ void spdInverseRowsGrouped(double* A, int gstride, in
     const double p = prow[k];
     if (on && r == k && !(p > 0.0)) ok[g] = 0;
     const double ip = recipNewton(p);
-    const double aik = a[k];
     const bool isk = r == k;
+    // a[j] = isk ? akj ip : a[j] - (aik akj) ip  without a select per entry: the row factor x and what is kept of the old entry are chosen once per step, and
+    // fma(-(x akj), ip, keep a[j]) is, lane by lane, the value of either branch with the SAME roundings (x akj and keep a[j] are exact on the pivot lane): two
+    // v_cndmask_b32 and a multiply fewer per entry on a chain that is issue-bound with one wavefront per SIMD, bit for bit the results of spdInverseRows
+    const double aik = a[k];
+    const double x = isk ? -1.0 : aik, keep = isk ? 0.0 : 1.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       if (j == k) continue;
-      const double akj = prow[j];
-      a[j] = isk ? akj * ip : a[j] - aik * akj * ip;
+      a[j] = __builtin_fma(-(x * prow[j]), ip, keep * a[j]);
     }
     a[k] = isk ? ip : -aik * ip;
   }
