@@ -1173,7 +1173,7 @@ template <int NV>
 __global__ __launch_bounds__(64 * K9U_SPB) void unparnmpc_coarse_update_kernel(UnBuffers B) {
   using L = UnLayout<NV>;
   constexpr int NX = L::NX, NQ = L::NQ3, NK = 5 * NV, SPB = K9U_SPB;
-  __shared__ double sQa[SPB][NQ * NQ], sFQa[SPB][NX * NQ], sSa[SPB][NX * NX], sTRa[SPB][NX * NQ], sresa[SPB][NK], st1a[SPB][NX], sda[SPB][NK];
+  __shared__ __attribute__((aligned(16))) double sQa[SPB][NQ * NQ], sFQa[SPB][NX * NQ], sSa[SPB][NX * NX], sTRa[SPB][NX * NQ], sresa[SPB][NK], st1a[SPB][NX], sda[SPB][NK];
   __shared__ int s_ok[SPB];
   const UnProblem* __restrict__ P = B.prob;
   const int N = P->N;
@@ -1228,12 +1228,24 @@ __global__ __launch_bounds__(64 * K9U_SPB) void unparnmpc_coarse_update_kernel(U
   if (w == 0) spdInverseRowsGrouped<NX, SPB>(&sSa[0][0], NX * NX, lane, s_ok);
   __syncthreads();
   K9_T(3);
-  for (int e = lane; e < NX * NQ; e += 64) {                          // TR = S^-1 FQ
-    const int c = e / NX, r = e - c * NX;
-    double acc = 0.0;
+  // TR = S^-1 FQ (NX x NQ).  A lane forms a 2 x 3 tile of it: per step of the contraction one 16-byte read of S^-1 (two rows of a column) and three
+  // reads of FQ feed six multiply-adds -- 4 LDS instructions where one output per lane takes 12; every entry still sums k = 0 .. NX - 1 in that order.
+  // (The LDS pipe of a CU is active 68 % of this kernel's time: profiles/experiments/r06_k1_occupancy.md.)
+  static_assert(NX % 2 == 0 && NQ % 3 == 0 && (NX / 2) * (NQ / 3) <= 64 && (NX * NQ) % 2 == 0 && (NX * NX) % 2 == 0, "2 x 3 tiles of TR, 3 x 2 tiles of BR on one wavefront");
+  typedef double kd2 __attribute__((ext_vector_type(2)));
+  if (lane < (NX / 2) * (NQ / 3)) {
+    const int tc = lane / (NX / 2), tr = lane - tc * (NX / 2), r0 = 2 * tr, c0 = 3 * tc;
+    double a00 = 0.0, a01 = 0.0, a02 = 0.0, a10 = 0.0, a11 = 0.0, a12 = 0.0;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) acc += sS[r + NX * k] * sFQ[k + NX * c];
-    sTR[e] = acc;
+    for (int k = 0; k < NX; ++k) {
+      const kd2 sv = *reinterpret_cast<const kd2*>(&sS[r0 + NX * k]);
+      const double b0 = sFQ[k + NX * c0], b1 = sFQ[k + NX * (c0 + 1)], b2 = sFQ[k + NX * (c0 + 2)];
+      a00 += sv.x * b0; a01 += sv.x * b1; a02 += sv.x * b2;
+      a10 += sv.y * b0; a11 += sv.y * b1; a12 += sv.y * b2;
+    }
+    *reinterpret_cast<kd2*>(&sTR[r0 + NX * c0]) = kd2{a00, a10};
+    *reinterpret_cast<kd2*>(&sTR[r0 + NX * (c0 + 1)]) = kd2{a01, a11};
+    *reinterpret_cast<kd2*>(&sTR[r0 + NX * (c0 + 2)]) = kd2{a02, a12};
   }
   __syncthreads();
   K9_T(4);
@@ -1242,12 +1254,32 @@ __global__ __launch_bounds__(64 * K9U_SPB) void unparnmpc_coarse_update_kernel(U
     for (int e = lane; e < NX * NX; e += 64) ki[L::I_TL + e] = -sS[e];
     for (int e = lane; e < NX * NQ; e += 64) ki[L::I_TR + e] = sTR[e];
   }
-  for (int e = lane; e < NQ * NX; e += 64) {                          // the (q, v) columns of BR = Q^-1 - FQ^T TR
-    const int c = e / NQ, r = e - c * NQ;
-    double acc = sQ[r + NQ * (NV + c)];
+  // the (q, v) columns of BR = Q^-1 - FQ^T TR (NQ x NX): 3 x 2 tiles, both operands contiguous along the contraction -- two steps per 16-byte read, five
+  // reads for twelve multiply-adds
+  if (lane < (NQ / 3) * (NX / 2)) {
+    const int tc = lane / (NQ / 3), tr = lane - tc * (NQ / 3), r0 = 3 * tr, c0 = 2 * tc;
+    double acc[3][2];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) acc -= sFQ[k + NX * r] * sTR[k + NX * (NV + c)];
-    if (valid) ki[L::I_BRC + e] = acc;
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = sQ[(r0 + i) + NQ * (NV + c0 + j)];
+#pragma unroll
+    for (int k = 0; k < NX; k += 2) {
+      kd2 fa[3], tb[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fa[i] = *reinterpret_cast<const kd2*>(&sFQ[k + NX * (r0 + i)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tb[j] = *reinterpret_cast<const kd2*>(&sTR[k + NX * (NV + c0 + j)]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j] -= fa[i].x * tb[j].x; acc[i][j] -= fa[i].y * tb[j].y; }
+    }
+    if (valid)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ki[L::I_BRC + (r0 + i) + NQ * (c0 + j)] = acc[i][j];
   }
   K9_T(5);
   // d = K^-1 res:  t1 = TR l,  d_top = -S^-1 Fx + t1,  d_bot = TR^T Fx + Q^-1 l - FQ^T t1
